@@ -1,0 +1,157 @@
+/*
+ * oracle/aomref.h -- CPU restatement of the aom_dsp / av1 encoder hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity oracle and the CPU baseline
+ * ("port") for bench.py.  Nothing under aom-av1-psy_amd/ (the product) may
+ * include, link or call it; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do.
+ *
+ * Every function is a from-scratch plain-C restatement of the reference function
+ * named in its comment (file:line relative to /root/reference, libaom v3.5.0
+ * "psy" fork).  Block sizes are run-time (w, h) parameters instead of the
+ * reference's 22 macro-stamped symbols per family.
+ *
+ * Pinning status (see DESIGN.md "Oracle"): the reference cannot be compiled here
+ * under the project rules (all sources include the cmake-generated
+ * config/aom_config.h), so there is no oracle/_ref build.  The oracle is pinned
+ * by (a) the known-answer tests the reference's own gtests hold (SAD max,
+ * variance Zero/OneQuarter, ...), (b) golden vectors produced by mechanically
+ * evaluating the reference's straight-line 1-D transform statements
+ * (tests/golden/ref_txfm1d_eval.py), (c) the reference tests' double-precision
+ * transform tolerance bounds, and (d) every constant table compared with the
+ * initialisers parsed out of the reference sources.  Families with no such pin
+ * (quantize_b, loop filter, CDEF, mcomp) are marked "parity unpinned" in
+ * DESIGN.md.
+ */
+#ifndef AOMREF_ORACLE_H_
+#define AOMREF_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- SAD (aom_dsp/sad.c) ------------------------------------------------ */
+/* sad.c:22-36 sad(); SADMXN :41-45 */
+unsigned orc_sad(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int w, int h);
+/* sad.c:65-69 aom_sad_skip_MxN_c: even rows only, doubled */
+unsigned orc_sad_skip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int w, int h);
+/* sad.c:94-103 aom_sadMxNx4d_c; x3d (:124-129) forwards to x4d and so reads ref[3] */
+void orc_sad_x4d(const uint8_t *src, int src_stride, const uint8_t *const ref[4], int ref_stride, int w, int h,
+                 uint32_t out[4]);
+void orc_sad_skip_x4d(const uint8_t *src, int src_stride, const uint8_t *const ref[4], int ref_stride, int w, int h,
+                      uint32_t out[4]);
+/* sad.c:46-53 aom_sadMxN_avg_c with variance.c:306-320 aom_comp_avg_pred_c */
+unsigned orc_sad_avg(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride,
+                     const uint8_t *second_pred, int w, int h);
+
+/* highbd: sad.c:240-256,276-332.  Planes are plain uint16_t* here (the
+ * CONVERT_TO_SHORTPTR byte-pointer convention, aom_ports/mem.h:79-80, is a host
+ * pointer encoding, applied by the caller).  `bd` selects the encoder's vtable
+ * wrapper (av1/encoder/encoder_utils.h:155-208): 8 -> raw, 10 -> >>2, 12 -> >>4;
+ * bd == 0 returns the raw kernel value. */
+unsigned orc_highbd_sad(const uint16_t *src, int src_stride, const uint16_t *ref, int ref_stride, int w, int h,
+                        int bd);
+unsigned orc_highbd_sad_skip(const uint16_t *src, int src_stride, const uint16_t *ref, int ref_stride, int w, int h,
+                             int bd);
+void orc_highbd_sad_x4d(const uint16_t *src, int src_stride, const uint16_t *const ref[4], int ref_stride, int w,
+                        int h, int bd, uint32_t out[4]);
+
+/* ---- variance (aom_dsp/variance.c) ---------------------------------------- */
+/* variance.c:56-73 variance(); VAR :141-148.  returns var, writes *sse (and *sum if non-NULL) */
+uint32_t orc_variance(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int w, int h, uint32_t *sse,
+                      int *sum);
+/* variance.c:91-139,150-163 aom_sub_pixel_varianceMxN_c; a = interpolated block, b = source */
+uint32_t orc_sub_pixel_variance(const uint8_t *a, int a_stride, int xoff, int yoff, const uint8_t *b, int b_stride,
+                                int w, int h, uint32_t *sse);
+/* variance.c:342-429 highbd_{8,10,12}_variance */
+uint32_t orc_highbd_variance(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h,
+                             int bd, uint32_t *sse, int *sum);
+/* variance.c:475-561 aom_highbd_{8,10,12}_sub_pixel_varianceMxN_c */
+uint32_t orc_highbd_sub_pixel_variance(const uint16_t *a, int a_stride, int xoff, int yoff, const uint16_t *b,
+                                       int b_stride, int w, int h, int bd, uint32_t *sse);
+
+/* ---- subtract (aom_dsp/subtract.c:20-53) ---------------------------------- */
+void orc_subtract_block(int rows, int cols, int16_t *diff, ptrdiff_t diff_stride, const uint8_t *src,
+                        ptrdiff_t src_stride, const uint8_t *pred, ptrdiff_t pred_stride);
+void orc_highbd_subtract_block(int rows, int cols, int16_t *diff, ptrdiff_t diff_stride, const uint16_t *src,
+                               ptrdiff_t src_stride, const uint16_t *pred, ptrdiff_t pred_stride);
+
+/* ---- transforms (av1/common/av1_txfm.[ch], av1/encoder/av1_fwd_txfm{1d,2d}.c,
+ *                  av1/common/av1_inv_txfm{1d,2d}.c) ---------------------------- */
+/* TX_SIZE / TX_TYPE numbering follows av1/common/enums.h:169-193 and
+ * aom_dsp/txfm_common.h:52-68 (values are part of the interface). */
+enum {
+  ORC_TX_4X4, ORC_TX_8X8, ORC_TX_16X16, ORC_TX_32X32, ORC_TX_64X64, ORC_TX_4X8, ORC_TX_8X4, ORC_TX_8X16,
+  ORC_TX_16X8, ORC_TX_16X32, ORC_TX_32X16, ORC_TX_32X64, ORC_TX_64X32, ORC_TX_4X16, ORC_TX_16X4, ORC_TX_8X32,
+  ORC_TX_32X8, ORC_TX_16X64, ORC_TX_64X16, ORC_TX_SIZES_ALL
+};
+enum {
+  ORC_DCT_DCT, ORC_ADST_DCT, ORC_DCT_ADST, ORC_ADST_ADST, ORC_FLIPADST_DCT, ORC_DCT_FLIPADST,
+  ORC_FLIPADST_FLIPADST, ORC_ADST_FLIPADST, ORC_FLIPADST_ADST, ORC_IDTX, ORC_V_DCT, ORC_H_DCT, ORC_V_ADST,
+  ORC_H_ADST, ORC_V_FLIPADST, ORC_H_FLIPADST, ORC_TX_TYPES
+};
+/* 1-D kinds */
+enum { ORC_1D_DCT, ORC_1D_ADST, ORC_1D_IDTX };
+
+extern const int32_t orc_cospi[7][64]; /* av1_txfm.c:18-58 av1_cospi_arr_data */
+extern const int32_t orc_sinpi[7][5];  /* av1_txfm.c:62-69 av1_sinpi_arr_data */
+extern const int orc_tx_wide[ORC_TX_SIZES_ALL], orc_tx_high[ORC_TX_SIZES_ALL];
+
+/* av1_fwd_txfm1d.c: av1_fdct{4..64}, av1_fadst{4,8,16}, av1_fidentity{4..32}_c.  in/out must not alias. */
+void orc_fwd_txfm1d(int kind, int n, const int32_t *in, int32_t *out, int cos_bit);
+/* av1_inv_txfm1d.c: av1_idct*, av1_iadst*, av1_iidentity*.  clamp_bit = stage_range value (<=0: none) */
+void orc_inv_txfm1d(int kind, int n, const int32_t *in, int32_t *out, int cos_bit, int clamp_bit);
+/* 1 if (tx_size, tx_type) is a combination av1_get_fwd_txfm_cfg can serve (no INVALID 1-D type) */
+int orc_txfm_valid(int tx_size, int tx_type);
+/* av1_fwd_txfm2d.c:56-127 fwd_txfm2d_c + the 19 av1_fwd_txfm2d_WxH_c wrappers (:129-312),
+ * including the 64-point zero-out / re-pack.  Output length = min(w,32)*min(h,32) packed
+ * for 64-wide sizes exactly as the reference leaves it (full w*h array is written). */
+void orc_fwd_txfm2d(const int16_t *input, int32_t *output, int stride, int tx_size, int tx_type, int bd);
+/* av1_inv_txfm2d.c:234-309 inv_txfm2d_add_c via av1_inv_txfm2d_add_WxH_c; dst is uint16 (highbd) */
+void orc_inv_txfm2d_add(const int32_t *input, uint16_t *dst, int stride, int tx_size, int tx_type, int bd);
+
+/* ---- quantize (aom_dsp/quantize.c, av1/encoder/av1_quantize.c) -------------------- */
+/* quantize.c:108-169 aom_quantize_b_helper_c with qm_ptr == iqm_ptr == NULL */
+void orc_quantize_b(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
+                    const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
+                    const int16_t *dequant, uint16_t *eob, const int16_t *scan, const int16_t *iscan,
+                    int log_scale);
+/* quantize.c:261-316 aom_highbd_quantize_b_helper_c, qm NULL */
+void orc_highbd_quantize_b(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
+                           const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff,
+                           int32_t *dqcoeff, const int16_t *dequant, uint16_t *eob, const int16_t *scan,
+                           const int16_t *iscan, int log_scale);
+/* av1_quantize.c:580-674 av1_build_quantizer (Y plane, no delta-q, sharpness 0): fills the
+ * two (DC, AC) lanes of each table for one qindex.  tables laid out [5][2]:
+ * zbin, round, quant, quant_shift, dequant. */
+void orc_build_quantizer_y(int bit_depth, int qindex, int16_t tables[5][2]);
+int16_t orc_dc_q(int qindex, int delta, int bit_depth); /* av1/common/quant_common.c av1_dc_quant_QTX */
+int16_t orc_ac_q(int qindex, int delta, int bit_depth); /* av1_ac_quant_QTX */
+/* av1/common/scan.c default (zig-zag) / row / col scans, get_scan (scan.h:41-48).
+ * Writes n = w*h (clamped to 32x32 for 64-point sizes) entries; returns n. */
+int orc_get_scan(int tx_size, int tx_type, int16_t *scan, int16_t *iscan);
+
+/* ---- loop filter (aom_dsp/loopfilter.c) ------------------------------------------- */
+/* aom_lpf_{horizontal,vertical}_{4,6,8,14}_c (:136-511): one 4-px edge unit, in place.
+ * vertical != 0 filters a vertical edge (pixels left/right of s). */
+void orc_lpf(uint8_t *s, int pitch, int vertical, int len, uint8_t blimit, uint8_t limit, uint8_t thresh);
+/* aom_highbd_lpf_* (:602-997) */
+void orc_highbd_lpf(uint16_t *s, int pitch, int vertical, int len, uint8_t blimit, uint8_t limit, uint8_t thresh,
+                    int bd);
+/* av1_loopfilter.c:47-66,118-120: thresholds from (level, sharpness) */
+void orc_lpf_thresholds(int level, int sharpness, uint8_t *mblim, uint8_t *lim, uint8_t *hev_thr);
+
+/* ---- CDEF (av1/common/cdef_block.c) ------------------------------------------------ */
+int orc_cdef_find_dir(const uint16_t *img, int stride, int32_t *var, int coeff_shift);
+/* cdef_filter_block_internal (:139-201): dst8 or dst16 non-NULL selects output type */
+void orc_cdef_filter_block(uint8_t *dst8, uint16_t *dst16, int dstride, const uint16_t *in, int pri_strength,
+                           int sec_strength, int dir, int pri_damping, int sec_damping, int coeff_shift,
+                           int block_w, int block_h, int enable_primary, int enable_secondary);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AOMREF_ORACLE_H_ */
