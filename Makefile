@@ -1,0 +1,27 @@
+# Builds libaomhip.so (the product: HIP kernels + C ABI, gfx950 only) and the CPU oracle
+# (test infrastructure).  `make -j4` here cross-compiles without a GPU.
+HIPCC ?= /opt/rocm/bin/hipcc
+PKG := aom-av1-psy_amd
+CSRC := $(PKG)/csrc
+LIBDIR := $(PKG)/lib
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+SRCS := $(wildcard $(CSRC)/*.hip)
+OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
+
+all: lib oracle
+lib: $(LIBDIR)/libaomhip.so
+oracle:
+	$(MAKE) -C oracle
+
+build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/aomhip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libaomhip.so: $(OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -rf build $(LIBDIR)/libaomhip.so
+	$(MAKE) -C oracle clean
+.PHONY: all lib oracle clean

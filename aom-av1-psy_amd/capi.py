@@ -1,0 +1,155 @@
+"""ctypes binding of include/aomhip.h.  Fails loudly if libaomhip.so is missing."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaomhip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libaomhip.so not built (%s): run `make lib` / __graft_entry__.build(). "
+        "There is no CPU fallback for the HIP path." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+OK = 0
+SAD_SKIP_ROWS = 1
+
+
+class Planes(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("frame_stride", C.c_int64), ("width", C.c_int32), ("height", C.c_int32),
+                ("stride", C.c_int32), ("border", C.c_int32), ("bit_depth", C.c_int32), ("n_frames", C.c_int32)]
+
+
+sad_cand_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2"), ("ry", "<i2")])
+sad_x4d_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2", (4,)), ("ry", "<i2", (4,))])
+
+_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+_PP = C.POINTER(Planes)
+
+_protos = {
+    "aomhip_abi_version": (C.c_int, []),
+    "aomhip_device_count": (C.c_int, []),
+    "aomhip_last_error": (C.c_char_p, []),
+    "aomhip_ctx_create": (C.c_int, [_i, _vp, C.POINTER(_vp)]),
+    "aomhip_ctx_destroy": (None, [_vp]),
+    "aomhip_ctx_sync": (C.c_int, [_vp]),
+    "aomhip_ctx_stream": (_vp, [_vp]),
+    "aomhip_timer_begin": (C.c_int, [_vp]),
+    "aomhip_timer_end": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "aomhip_malloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    "aomhip_free": (C.c_int, [_vp, _vp]),
+    "aomhip_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "aomhip_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "aomhip_memset": (C.c_int, [_vp, _vp, _i, _sz]),
+    "aomhip_calc_stride": (C.c_int, [_i, _i]),
+    "aomhip_planes_alloc": (C.c_int, [_vp, _i, _i, _i, _i, _i, _PP]),
+    "aomhip_planes_free": (C.c_int, [_vp, _PP]),
+    "aomhip_planes_upload": (C.c_int, [_vp, _PP, _i, _vp, _i]),
+    "aomhip_planes_extend_borders": (C.c_int, [_vp, _PP, _i, _i]),
+    "aomhip_planes_download": (C.c_int, [_vp, _PP, _i, _vp]),
+    "aomhip_sad_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
+    "aomhip_sad_x4d_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
+    "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
+    "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
+    "aomhip_sad_x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp, _i, _i]),
+    "aomhip_sad_skip_x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp, _i, _i]),
+    "aomhip_sad16x16": (C.c_uint, [_vp, _i, _vp, _i]),
+    "aomhip_sad16x16x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp]),
+    "aomhip_highbd_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, _i]),
+}
+for _name, (_res, _args) in _protos.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header/library mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED = sorted(_protos)
+
+
+class AomHipError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != OK:
+        raise AomHipError("%s failed (status %d): %s" % (what, rc, lib.aomhip_last_error().decode()))
+
+
+class Context:
+    """aomhip_ctx wrapper: one HIP stream on one device."""
+
+    def __init__(self, device=0, stream=None):
+        h = _vp()
+        check(lib.aomhip_ctx_create(device, stream, C.byref(h)), "aomhip_ctx_create")
+        self.h = h
+        self.device = device
+        self._allocs = []
+
+    def close(self):
+        if self.h:
+            lib.aomhip_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        check(lib.aomhip_ctx_sync(self.h), "sync")
+
+    # ---- raw device memory
+    def malloc(self, nbytes):
+        p = _vp()
+        check(lib.aomhip_malloc(self.h, nbytes, C.byref(p)), "malloc")
+        return p.value
+
+    def free(self, ptr):
+        check(lib.aomhip_free(self.h, ptr), "free")
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(max(arr.nbytes, 16))
+        check(lib.aomhip_memcpy_h2d(self.h, p, arr.ctypes.data, arr.nbytes), "h2d")
+        return p
+
+    def from_device(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype)
+        check(lib.aomhip_memcpy_d2h(self.h, out.ctypes.data, ptr, out.nbytes), "d2h")
+        return out
+
+    def timer_begin(self):
+        check(lib.aomhip_timer_begin(self.h), "timer_begin")
+
+    def timer_end(self):
+        ms = C.c_float()
+        check(lib.aomhip_timer_end(self.h, C.byref(ms)), "timer_end")
+        return ms.value
+
+    # ---- planes
+    def planes_alloc(self, width, height, border, bit_depth, n_frames):
+        p = Planes()
+        check(lib.aomhip_planes_alloc(self.h, width, height, border, bit_depth, n_frames, C.byref(p)), "planes_alloc")
+        return p
+
+    def planes_free(self, p):
+        check(lib.aomhip_planes_free(self.h, C.byref(p)), "planes_free")
+
+    def planes_upload(self, p, frame, pixels):
+        dt = np.uint8 if p.bit_depth == 8 else np.uint16
+        pixels = np.ascontiguousarray(pixels, dtype=dt)
+        assert pixels.shape == (p.height, p.width)
+        check(lib.aomhip_planes_upload(self.h, C.byref(p), frame, pixels.ctypes.data, pixels.shape[1]), "upload")
+
+    def planes_download(self, p, frame):
+        dt = np.uint8 if p.bit_depth == 8 else np.uint16
+        out = np.empty((p.height + 2 * p.border, p.stride), dt)
+        check(lib.aomhip_planes_download(self.h, C.byref(p), frame, out.ctypes.data), "download")
+        return out
+
+    # ---- SAD
+    def sad_batch(self, src, ref, first_frame, n_frames, bw, bh, flags, d_cands, n_cands, cand_frame_stride, d_out):
+        check(lib.aomhip_sad_batch(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, bw, bh, flags, d_cands,
+                                   n_cands, cand_frame_stride, d_out), "aomhip_sad_batch")
+
+    def sad_x4d_batch(self, src, ref, first_frame, n_frames, bw, bh, flags, d_groups, n_groups, group_frame_stride,
+                      d_out):
+        check(lib.aomhip_sad_x4d_batch(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, bw, bh, flags,
+                                       d_groups, n_groups, group_frame_stride, d_out), "aomhip_sad_x4d_batch")

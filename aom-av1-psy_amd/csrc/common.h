@@ -1,0 +1,89 @@
+// Internal helpers shared by the libaomhip translation units (not part of the ABI).
+#ifndef AOMHIP_CSRC_COMMON_H_
+#define AOMHIP_CSRC_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "aomhip.h"
+
+struct aomhip_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  hipEvent_t ev0, ev1;
+  // scratch for the rtcd-signature conformance entry points (host pointers in/out)
+  void *d_scratch;
+  size_t d_scratch_bytes;
+  void *h_pinned;
+  size_t h_pinned_bytes;
+};
+
+namespace aomhip {
+
+void set_error(const char *fmt, ...);
+[[noreturn]] void fatal(const char *what);  // rtcd-signature paths: report and abort (no fallback)
+aomhip_ctx *default_ctx();                  // lazily created per-thread context for the rtcd-signature paths
+void *scratch(aomhip_ctx *ctx, size_t bytes);
+void *pinned(aomhip_ctx *ctx, size_t bytes);
+
+#define AOMHIP_TRY(expr)                                                                       \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      aomhip::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return AOMHIP_ERR_HIP;                                                                   \
+    }                                                                                          \
+  } while (0)
+
+#define AOMHIP_LAUNCH_CHECK()                                                                  \
+  do {                                                                                         \
+    hipError_t e_ = hipGetLastError();                                                         \
+    if (e_ != hipSuccess) {                                                                    \
+      aomhip::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return AOMHIP_ERR_HIP;                                                                   \
+    }                                                                                          \
+  } while (0)
+
+// MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8 (speed only, never correctness).
+// Remap a linear workgroup index so that each XCD walks one contiguous 1/8 of the
+// work list: neighbouring blocks of a frame then share that XCD's private L2.
+__device__ __forceinline__ unsigned xcd_chunked_index(unsigned b, unsigned n) {
+  constexpr unsigned kXcd = 8;
+  const unsigned q = n / kXcd, r = n % kXcd;
+  const unsigned xcd = b % kXcd, idx = b / kXcd;
+  return xcd < r ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+}
+
+// Device view of aomhip_planes for one element type.
+template <typename T>
+struct PlaneView {
+  const T *origin;  // pixel (0,0) of frame 0
+  int64_t frame_stride;
+  int stride;
+};
+template <typename T>
+inline PlaneView<T> view_of(const aomhip_planes &p) {
+  PlaneView<T> v;
+  v.origin = static_cast<const T *>(p.base) + (int64_t)p.border * p.stride + p.border;
+  v.frame_stride = p.frame_stride;
+  v.stride = p.stride;
+  return v;
+}
+
+// The reference's 22 block sizes (av1/common/enums.h:99-124).
+inline bool valid_block(int w, int h) {
+  auto p2 = [](int v) { return v >= 4 && v <= 128 && (v & (v - 1)) == 0; };
+  if (!p2(w) || !p2(h)) return false;
+  const int r = w > h ? w / h : h / w;
+  if (r > 4) return false;
+  if (r == 4 && (w == 128 || h == 128)) return false;  // no 128x32 / 32x128
+  return true;
+}
+
+}  // namespace aomhip
+#endif  // AOMHIP_CSRC_COMMON_H_

@@ -1,0 +1,292 @@
+// libaomhip runtime: contexts, streams, device memory, HBM-resident YV12 plane rings.
+// Host side of include/aomhip.h "context" and "planes in HBM".
+#include <cstdarg>
+
+#include "common.h"
+
+namespace aomhip {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+void fatal(const char *what) {
+  fprintf(stderr, "libaomhip: fatal in %s: %s\n", what, g_err);
+  fflush(stderr);
+  abort();
+}
+
+static thread_local aomhip_ctx *g_default_ctx = nullptr;
+
+aomhip_ctx *default_ctx() {
+  if (!g_default_ctx) {
+    const char *dev = getenv("AOMHIP_DEVICE");
+    if (aomhip_ctx_create(dev ? atoi(dev) : 0, nullptr, &g_default_ctx) != AOMHIP_OK) fatal("default context");
+  }
+  return g_default_ctx;
+}
+
+void *scratch(aomhip_ctx *ctx, size_t bytes) {
+  if (ctx->d_scratch_bytes < bytes) {
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
+    if (hipMalloc(&ctx->d_scratch, cap) != hipSuccess) {
+      ctx->d_scratch = nullptr;
+      ctx->d_scratch_bytes = 0;
+      set_error("hipMalloc(%zu) for scratch failed", cap);
+      return nullptr;
+    }
+    ctx->d_scratch_bytes = cap;
+  }
+  return ctx->d_scratch;
+}
+
+void *pinned(aomhip_ctx *ctx, size_t bytes) {
+  if (ctx->h_pinned_bytes < bytes) {
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
+    if (hipHostMalloc(&ctx->h_pinned, cap, hipHostMallocDefault) != hipSuccess) {
+      ctx->h_pinned = nullptr;
+      ctx->h_pinned_bytes = 0;
+      set_error("hipHostMalloc(%zu) failed", cap);
+      return nullptr;
+    }
+    ctx->h_pinned_bytes = cap;
+  }
+  return ctx->h_pinned;
+}
+
+// Replicate the visible edge pixels of each frame into its border: every element
+// outside the visible rectangle takes visible[clamp(y)][clamp(x)], which is what
+// aom_extend_frame_borders_c produces (aom_scale/generic/yv12extend.c:22-221).
+template <typename T>
+__global__ void extend_borders_kernel(T *base, int64_t frame_stride, int first_frame, int width, int height,
+                                      int stride, int border) {
+  const int rows = ((height + 7) & ~7) + 2 * border;
+  T *frame = base + (int64_t)(first_frame + blockIdx.z) * frame_stride;
+  const int y = blockIdx.y - border;  // one row per blockIdx.y
+  if ((int)blockIdx.y >= rows) return;
+  const int cy = y < 0 ? 0 : (y >= height ? height - 1 : y);
+  const T *src_row = frame + (int64_t)(cy + border) * stride + border;
+  T *dst_row = frame + (int64_t)(y + border) * stride + border;
+  const bool interior_row = (y == cy);
+  for (int xi = blockIdx.x * blockDim.x + threadIdx.x; xi < stride; xi += gridDim.x * blockDim.x) {
+    const int x = xi - border;
+    if (interior_row && x >= 0 && x < width) continue;
+    const int cx = x < 0 ? 0 : (x >= width ? width - 1 : x);
+    dst_row[x] = src_row[cx];
+  }
+}
+
+}  // namespace aomhip
+
+using namespace aomhip;
+
+extern "C" {
+
+int aomhip_abi_version(void) { return AOMHIP_ABI_VERSION; }
+
+const char *aomhip_last_error(void) { return g_err; }
+
+int aomhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int aomhip_ctx_create(int device, void *stream, aomhip_ctx **out) {
+  if (!out) return AOMHIP_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_error("no HIP device visible (libaomhip has no CPU fallback)");
+    return AOMHIP_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    set_error("device %d out of range [0,%d)", device, n);
+    return AOMHIP_ERR_INVALID;
+  }
+  AOMHIP_TRY(hipSetDevice(device));
+  aomhip_ctx *c = static_cast<aomhip_ctx *>(calloc(1, sizeof(aomhip_ctx)));
+  if (!c) return AOMHIP_ERR_NOMEM;
+  c->device = device;
+  if (stream) {
+    c->stream = static_cast<hipStream_t>(stream);
+    c->own_stream = false;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+      free(c);
+      return AOMHIP_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    set_error("hipEventCreate failed");
+    free(c);
+    return AOMHIP_ERR_HIP;
+  }
+  *out = c;
+  return AOMHIP_OK;
+}
+
+void aomhip_ctx_destroy(aomhip_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  (void)hipEventDestroy(ctx->ev0);
+  (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  if (g_default_ctx == ctx) g_default_ctx = nullptr;
+  free(ctx);
+}
+
+int aomhip_ctx_sync(aomhip_ctx *ctx) {
+  if (!ctx) return AOMHIP_ERR_INVALID;
+  AOMHIP_TRY(hipStreamSynchronize(ctx->stream));
+  return AOMHIP_OK;
+}
+
+void *aomhip_ctx_stream(aomhip_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
+
+int aomhip_timer_begin(aomhip_ctx *ctx) {
+  if (!ctx) return AOMHIP_ERR_INVALID;
+  AOMHIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  return AOMHIP_OK;
+}
+
+int aomhip_timer_end(aomhip_ctx *ctx, float *elapsed_ms) {
+  if (!ctx || !elapsed_ms) return AOMHIP_ERR_INVALID;
+  AOMHIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  AOMHIP_TRY(hipEventSynchronize(ctx->ev1));
+  AOMHIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+  return AOMHIP_OK;
+}
+
+int aomhip_malloc(aomhip_ctx *ctx, size_t bytes, void **dptr) {
+  if (!ctx || !dptr) return AOMHIP_ERR_INVALID;
+  AOMHIP_TRY(hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? AOMHIP_ERR_NOMEM : AOMHIP_ERR_HIP;
+  }
+  return AOMHIP_OK;
+}
+
+int aomhip_free(aomhip_ctx *ctx, void *dptr) {
+  if (!ctx) return AOMHIP_ERR_INVALID;
+  AOMHIP_TRY(hipStreamSynchronize(ctx->stream));
+  AOMHIP_TRY(hipFree(dptr));
+  return AOMHIP_OK;
+}
+
+int aomhip_memcpy_h2d(aomhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx) return AOMHIP_ERR_INVALID;
+  AOMHIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  AOMHIP_TRY(hipStreamSynchronize(ctx->stream));  // src may be pageable and reused by the caller
+  return AOMHIP_OK;
+}
+
+int aomhip_memcpy_d2h(aomhip_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx) return AOMHIP_ERR_INVALID;
+  AOMHIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  AOMHIP_TRY(hipStreamSynchronize(ctx->stream));
+  return AOMHIP_OK;
+}
+
+int aomhip_memset(aomhip_ctx *ctx, void *dst, int value, size_t bytes) {
+  if (!ctx) return AOMHIP_ERR_INVALID;
+  AOMHIP_TRY(hipMemsetAsync(dst, value, bytes, ctx->stream));
+  return AOMHIP_OK;
+}
+
+int aomhip_calc_stride(int width, int border) {
+  const int aligned_width = (width + 7) & ~7;
+  return ((aligned_width + 2 * border) + 31) & ~31;
+}
+
+int aomhip_planes_alloc(aomhip_ctx *ctx, int width, int height, int border, int bit_depth, int n_frames,
+                        aomhip_planes *out) {
+  if (!ctx || !out || width <= 0 || height <= 0 || border < 0 || n_frames <= 0 ||
+      (bit_depth != 8 && bit_depth != 10 && bit_depth != 12)) {
+    set_error("aomhip_planes_alloc: bad geometry");
+    return AOMHIP_ERR_INVALID;
+  }
+  memset(out, 0, sizeof(*out));
+  const int stride = aomhip_calc_stride(width, border);
+  const int aligned_height = (height + 7) & ~7;
+  const int64_t rows = (int64_t)aligned_height + 2 * border;
+  // Round the per-frame size up to 256 elements so every frame starts 256-byte aligned.
+  const int64_t frame_elems = (rows * stride + 255) & ~(int64_t)255;
+  const size_t esz = bit_depth == 8 ? 1 : 2;
+  void *base = nullptr;
+  // + one extra row of slack: the sub-pixel kernels read (W+1) x (H+1) like the reference does.
+  int rc = aomhip_malloc(ctx, (size_t)(frame_elems * n_frames + stride + 64) * esz, &base);
+  if (rc != AOMHIP_OK) return rc;
+  out->base = base;
+  out->frame_stride = frame_elems;
+  out->width = width;
+  out->height = height;
+  out->stride = stride;
+  out->border = border;
+  out->bit_depth = bit_depth;
+  out->n_frames = n_frames;
+  return AOMHIP_OK;
+}
+
+int aomhip_planes_free(aomhip_ctx *ctx, aomhip_planes *p) {
+  if (!ctx || !p) return AOMHIP_ERR_INVALID;
+  int rc = AOMHIP_OK;
+  if (p->base) rc = aomhip_free(ctx, p->base);
+  memset(p, 0, sizeof(*p));
+  return rc;
+}
+
+int aomhip_planes_extend_borders(aomhip_ctx *ctx, const aomhip_planes *p, int first_frame, int n_frames) {
+  if (!ctx || !p || !p->base || first_frame < 0 || n_frames <= 0 || first_frame + n_frames > p->n_frames)
+    return AOMHIP_ERR_INVALID;
+  if (p->border == 0) return AOMHIP_OK;
+  const int rows = ((p->height + 7) & ~7) + 2 * p->border;  // aligned_height + borders, yv12config.c:138-170
+  dim3 grid((p->stride + 255) / 256, rows, n_frames), block(256);
+  if (p->bit_depth == 8)
+    hipLaunchKernelGGL(extend_borders_kernel<uint8_t>, grid, block, 0, ctx->stream, static_cast<uint8_t *>(p->base),
+                       p->frame_stride, first_frame, p->width, p->height, p->stride, p->border);
+  else
+    hipLaunchKernelGGL(extend_borders_kernel<uint16_t>, grid, block, 0, ctx->stream,
+                       static_cast<uint16_t *>(p->base), p->frame_stride, first_frame, p->width, p->height,
+                       p->stride, p->border);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+int aomhip_planes_upload(aomhip_ctx *ctx, const aomhip_planes *p, int frame, const void *host_pixels,
+                         int host_stride) {
+  if (!ctx || !p || !p->base || !host_pixels || frame < 0 || frame >= p->n_frames || host_stride < p->width)
+    return AOMHIP_ERR_INVALID;
+  const size_t esz = p->bit_depth == 8 ? 1 : 2;
+  char *dst = static_cast<char *>(p->base) +
+              ((size_t)frame * p->frame_stride + (size_t)p->border * p->stride + p->border) * esz;
+  AOMHIP_TRY(hipMemcpy2DAsync(dst, (size_t)p->stride * esz, host_pixels, (size_t)host_stride * esz,
+                              (size_t)p->width * esz, p->height, hipMemcpyHostToDevice, ctx->stream));
+  AOMHIP_TRY(hipStreamSynchronize(ctx->stream));
+  return aomhip_planes_extend_borders(ctx, p, frame, 1);
+}
+
+int aomhip_planes_download(aomhip_ctx *ctx, const aomhip_planes *p, int frame, void *host_bordered) {
+  if (!ctx || !p || !p->base || !host_bordered || frame < 0 || frame >= p->n_frames) return AOMHIP_ERR_INVALID;
+  const size_t esz = p->bit_depth == 8 ? 1 : 2;
+  const size_t n = (size_t)p->stride * (p->height + 2 * p->border) * esz;
+  return aomhip_memcpy_d2h(ctx, host_bordered, static_cast<char *>(p->base) + (size_t)frame * p->frame_stride * esz,
+                           n);
+}
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the aom_dsp hot path on MI355X (contract: see the task prompt).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU).  The frame is
+cut into N uniform tile columns (av1/common/tile_common.c:76-97); rank r owns column r and
+processes only that column's blocks.  The ring of frame pairs grows with N (F frames per
+rank), so per-GPU work is fixed: "scaling": "weak".  There is no data-path collective in the
+SAD search itself (the reference planes are inputs); the only torch.distributed traffic is
+the barrier / max-reduce of the timing.
+
+A "step" is one pass of the hot path over the whole ring: one `aomhip_sad_batch` launch (the
+mv (0,0) candidate of every 16x16 block) plus one `aomhip_sad_x4d_batch` launch (one group of
+four uniformly random positions in [-64,64]^2 per block) -- SURVEY.md 8(d) "Mode A", 5
+candidates per block.  Inputs are resident in HBM before the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+SAD16_BYTES_8BIT = 516  # src block + ref block + 4 B result
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "sad16x16_modeA_1080p_8bit": dict(width=1920, height=1080, bit_depth=8, frames=64),
+    # the north-star target size
+    "sad16x16_modeA_4k_8bit": dict(width=3840, height=2160, bit_depth=8, frames=64),
+    "sad16x16_modeA_4k_10bit": dict(width=3840, height=2160, bit_depth=10, frames=32),
+}
+
+
+def dist_setup(n_gpus):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None, 0, 1
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return dist, rank, world
+
+
+def barrier(dist, dev):
+    if dist is not None:
+        import torch
+        dist.barrier(device_ids=[dev])
+        torch.cuda.synchronize()
+
+
+class SadModeA:
+    """HBM-resident ring of frame pairs + the Mode-A work list of one tile column."""
+
+    def __init__(self, pkg, ctx, name, rank, world, frames_per_rank=None, seed=1):
+        cfg = WORKLOADS[name]
+        self.name, self.cfg, self.ctx, self.pkg = name, cfg, ctx, pkg
+        W, H, bd = cfg["width"], cfg["height"], cfg["bit_depth"]
+        self.F = (frames_per_rank or cfg["frames"])
+        self.ring = self.F * world
+        self.border = 160
+        synth, capi = pkg.synth, pkg.capi
+        self.src = ctx.planes_alloc(W, H, self.border, bd, self.ring)
+        self.ref = ctx.planes_alloc(W, H, self.border, bd, self.ring)
+        self.host_pair0 = None
+        for f in range(self.F):  # ring slots beyond F re-use the F base frames' pixels
+            s = synth.lcg_frame(W, H, 2 * f, 0, bd)
+            r = synth.lcg_frame(W, H, 2 * f + 1, 0, bd)
+            if f == 0:
+                self.host_pair0 = (s, r)
+            for k in range(world):
+                ctx.planes_upload(self.src, f + k * self.F, s)
+                ctx.planes_upload(self.ref, f + k * self.F, r)
+        cols = synth.tile_column_bounds(W, world)
+        x0, x1 = cols[rank] if rank < len(cols) else (0, 0)
+        cands, groups = synth.mode_a_worklist(W, H, 16, seed=seed)
+        keep = (cands["sx"] >= x0) & (cands["sx"] < x1)
+        self.blocks_per_frame = int(keep.sum())
+        base_c, base_g = cands[keep], groups[keep]
+        n = self.blocks_per_frame
+        # distinct random positions per frame (same block grid)
+        rng = np.random.default_rng(seed + 977 * rank)
+        allg = np.tile(base_g, (self.ring, 1))
+        allg["rx"] = allg["sx"][..., None] + rng.integers(-64, 65, (self.ring, n, 4), dtype=np.int16)
+        allg["ry"] = allg["sy"][..., None] + rng.integers(-64, 65, (self.ring, n, 4), dtype=np.int16)
+        self.h_cands, self.h_groups0 = base_c, allg[0].copy()
+        self.d_cands = ctx.to_device(base_c) if n else None
+        self.d_groups = ctx.to_device(allg) if n else None
+        self.d_out1 = ctx.malloc(max(16, self.ring * n * 4))
+        self.d_out4 = ctx.malloc(max(16, self.ring * n * 16))
+        self.cands_per_step = 5 * n * self.ring
+        self.tile = (x0, x1)
+
+    def launch_single(self):
+        if self.blocks_per_frame:
+            self.ctx.sad_batch(self.src, self.ref, 0, self.ring, 16, 16, 0, self.d_cands, self.blocks_per_frame, 0,
+                               self.d_out1)
+
+    def launch_x4d(self):
+        if self.blocks_per_frame:
+            self.ctx.sad_x4d_batch(self.src, self.ref, 0, self.ring, 16, 16, 0, self.d_groups, self.blocks_per_frame,
+                                   self.blocks_per_frame, self.d_out4)
+
+    def step(self):
+        self.launch_single()
+        self.launch_x4d()
+
+    def bytes_per_cand(self):
+        return SAD16_BYTES_8BIT if self.cfg["bit_depth"] == 8 else 1028
+
+    def check_frame0(self, orc):
+        """Exact check of ring slot 0 against the oracle (not timed)."""
+        n = self.blocks_per_frame
+        if not n:
+            return True
+        s, r = self.host_pair0
+        sb = orc.extend_plane(s, self.border, self.src.stride)
+        rb = orc.extend_plane(r, self.border, self.ref.stride)
+        bd = self.cfg["bit_depth"]
+        got1 = self.ctx.from_device(self.d_out1, (n,), np.uint32)
+        got4 = self.ctx.from_device(self.d_out4, (n, 4), np.uint32)
+        ok = np.array_equal(got1, orc.sad_batch(sb, rb, self.border, 16, 16, self.h_cands, bd=bd, threads=4))
+        ok &= np.array_equal(got4, orc.sad_x4d_batch(sb, rb, self.border, 16, 16, self.h_groups0, bd=bd, threads=4))
+        return bool(ok)
+
+    def cpu_baseline(self, orc, target_s=12.0):
+        """Oracle ("port") on the host cores over a bounded sample of the same work list."""
+        s, r = self.host_pair0
+        sb = orc.extend_plane(s, self.border, self.src.stride)
+        rb = orc.extend_plane(r, self.border, self.ref.stride)
+        bd = self.cfg["bit_depth"]
+        threads = orc.lib.orc_max_threads()
+        full_c, full_g = self.pkg.synth.mode_a_worklist(self.cfg["width"], self.cfg["height"], 16, seed=1)
+
+        def one_pass():
+            orc.sad_batch(sb, rb, self.border, 16, 16, full_c, bd=bd, threads=threads)
+            orc.sad_x4d_batch(sb, rb, self.border, 16, 16, full_g, bd=bd, threads=threads)
+        one_pass()
+        t0 = time.perf_counter()
+        one_pass()
+        dt = max(time.perf_counter() - t0, 1e-6)
+        reps = int(min(max(target_s / dt, 3), 20000))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one_pass()
+        dt = time.perf_counter() - t0
+        n = 5 * len(full_c) * reps
+        return {"value": n / dt, "unit": "candidates/s", "cores": threads, "kind": "port",
+                "sample": "%d passes of the full-frame Mode-A list of frame pair 0 (%d candidates each), "
+                          "oracle C -O3 -mavx2, OpenMP static over candidates" % (reps, 5 * len(full_c))}
+
+    def free(self):
+        c = self.ctx
+        for p in (self.src, self.ref):
+            c.planes_free(p)
+        for d in (self.d_cands, self.d_groups, self.d_out1, self.d_out4):
+            if d:
+                c.free(d)
+
+
+def time_steps(wl, ctx, dist, dev, steps, warmup):
+    for _ in range(warmup):
+        wl.step()
+    ctx.sync()
+    barrier(dist, dev)
+    ctx.timer_begin()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    ev_ms = ctx.timer_end()  # HIP events on the launch stream, syncs
+    ctx.sync()
+    barrier(dist, dev)
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    return wall, ev_ms
+
+
+def kernel_avg_ms(ctx, fn, reps):
+    fn()
+    ctx.sync()
+    ctx.timer_begin()
+    for _ in range(reps):
+        fn()
+    return ctx.timer_end() / reps
+
+
+def load_traffic(name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json,
+    produced by tools/pmc_traffic.py from separate rocprofv3 --pmc runs); None when not measured."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get(name)
+        except Exception:
+            return None
+    return None
+
+
+def run_workload(pkg, ctx, dist, dev, rank, world, name, steps, warmup, want_cpu, orc):
+    wl = SadModeA(pkg, ctx, name, rank, world)
+    wl.step()
+    ctx.sync()
+    ok = wl.check_frame0(orc) if orc is not None else None
+    wall, ev_ms = time_steps(wl, ctx, dist, dev, steps, warmup)
+    total = wl.cands_per_step
+    if dist is not None:
+        import torch
+        t = torch.tensor([total], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        total = int(t.item())
+    k_ms = kernel_avg_ms(ctx, wl.launch_x4d, max(steps, 10))
+    k1_ms = kernel_avg_ms(ctx, wl.launch_single, max(steps, 10))
+    x4d_bytes = 4 * wl.blocks_per_frame * wl.ring * wl.bytes_per_cand()
+    ach = x4d_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic = load_traffic(name)
+    res = {
+        "workload": name, "value": total * steps / wall, "unit": "candidates/s", "ms_per_step": wall / steps * 1e3,
+        "event_ms_per_step": ev_ms / steps, "candidates_per_step": total, "parity_frame0": ok,
+        "roofline": {"bound": "hbm", "kernel": "sad_x4d_kernel<16x16>", "achieved": ach, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                     "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": x4d_bytes,
+                     "note": "achieved = ALGORITHMIC bytes (516 B per 8-bit 16x16 candidate, 1028 B 10-bit) / launch time; "
+                             "overlapping candidates are served by L2/Infinity Cache, so compare with `traffic`"},
+        "kernels": {"sad_x4d_kernel_avg_ms": k_ms, "sad_cand_kernel_avg_ms": k1_ms},
+        "ring_frames": wl.ring, "blocks_per_frame_this_rank": wl.blocks_per_frame, "tile_column_px": list(wl.tile),
+    }
+    if want_cpu and rank == 0 and orc is not None:
+        res["cpu_baseline"] = wl.cpu_baseline(orc)
+    wl.free()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sad16x16_modeA_1080p_8bit", choices=sorted(WORKLOADS))
+    ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    dist, rank, world = dist_setup(args.gpus)
+    dev = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    import aom_av1_psy_amd as pkg  # raises if libaomhip.so is missing: no fallback
+    stream = None
+    if world > 1:
+        import torch
+        stream = torch.cuda.current_stream().cuda_stream or None
+    ctx = pkg.capi.Context(dev, stream)
+    orc = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as orc  # checker + cpu_baseline only
+    except Exception as e:  # pragma: no cover
+        print("warning: oracle unavailable (%s): no parity spot check / cpu_baseline" % e, file=sys.stderr)
+
+    main_res = run_workload(pkg, ctx, dist, dev, rank, world, args.workload, args.steps, args.warmup,
+                            not args.no_cpu_baseline and world == 1, orc)
+    others = []
+    if world == 1:
+        names = ([n for n in ("sad16x16_modeA_4k_8bit", "sad16x16_modeA_4k_10bit") if n != args.workload]
+                 if args.others == "auto" else [n for n in args.others.split(",") if n])
+        for n in names:
+            others.append(run_workload(pkg, ctx, dist, dev, rank, world, n, args.steps, args.warmup, False, orc))
+    ctx.close()
+
+    if rank == 0:
+        cfg = WORKLOADS[args.workload]
+        line = {
+            "metric": "SAD-candidates/s", "value": main_res["value"], "unit": "candidates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8" if cfg["bit_depth"] == 8 else "u16", "data": "synthetic",
+            "config": {"workload": args.workload, "frame": "%dx%d" % (cfg["width"], cfg["height"]),
+                       "bit_depth": cfg["bit_depth"], "block": "16x16",
+                       "mode": "A: 1 sad16x16 @mv(0,0) + 1 sad16x16x4d (uniform in [-64,64]^2) per block",
+                       "ring_frame_pairs_per_gpu": cfg["frames"], "candidates_per_step": main_res["candidates_per_step"],
+                       "partition": "tile columns (tile_common.c:76-97), one per GPU; no data-path collective"},
+            "roofline": main_res["roofline"],
+            "cpu_baseline": main_res.get("cpu_baseline"),
+            "parity_frame0": main_res["parity_frame0"],
+            "kernels": main_res["kernels"],
+            "others": others,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

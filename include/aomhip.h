@@ -1,0 +1,172 @@
+/*
+ * aomhip.h -- C ABI of libaomhip: the MI355X (gfx950) back end for the aom_dsp
+ * encoder hot path of libaom v3.5.0 / aom-av1-psy.
+ *
+ * Plain C, plain pointers and sizes: this is exactly what a `hip` pseudo-ISA added
+ * to the reference's rtcd generator (build/cmake/rtcd.pl:384-388) and the batching
+ * layer at its call sites (av1/encoder/mcomp.c, av1/encoder/encodemb.c) would bind.
+ * INTEGRATION.md shows the reference-side stubs.
+ *
+ * Two groups of entry points:
+ *
+ *  1. Batched entry points (the fast path).  Frame planes live in HBM with the
+ *     reference's YV12 layout (aom_scale/yv12config.h:41-126, stride rule :204-206,
+ *     replicated borders aom_scale/generic/yv12extend.c:22-221).  Work arrives as
+ *     device-resident lists (candidates, transform blocks, ...) and results stay on
+ *     the device until the caller copies them.  All calls are asynchronous on the
+ *     context's HIP stream.
+ *
+ *  2. Conformance entry points with the reference's rtcd signatures
+ *     (aom_dsp/aom_dsp_rtcd_defs.pl, av1/common/av1_rtcd_defs.pl).  Host pointers
+ *     in, results out, one kernel launch per call: for parity tests and plumbing,
+ *     not for speed.  They run the same device code as group 1.
+ *
+ * Error model: the reference's DSP functions have no error return
+ * (aom_dsp_rtcd_defs.pl protos are value/void).  Batched calls return an
+ * aomhip_status_t; rtcd-signature calls cannot, so any HIP failure there is
+ * reported on stderr and the process aborts (there is NO CPU fallback anywhere in
+ * this library: a result is either computed on the GPU or not at all).
+ */
+#ifndef AOMHIP_H_
+#define AOMHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AOMHIP_ABI_VERSION 1
+
+typedef enum {
+  AOMHIP_OK = 0,
+  AOMHIP_ERR_NO_DEVICE = 1,   /* no HIP device / runtime failure at init */
+  AOMHIP_ERR_INVALID = 2,     /* bad argument (unsupported block size, null pointer, ...) */
+  AOMHIP_ERR_HIP = 3,         /* a HIP call failed; aomhip_last_error() has the text */
+  AOMHIP_ERR_NOMEM = 4
+} aomhip_status_t;
+
+/* ------------------------------------------------------------------ context */
+
+/* One context per host thread that issues work (the reference calls its kernels
+ * concurrently from tile / row-MT workers, av1/encoder/ethread.c:488-593). */
+typedef struct aomhip_ctx aomhip_ctx;
+
+/* device: HIP ordinal.  stream: an existing hipStream_t to launch on (e.g. the
+ * caller framework's stream) or NULL to create a private non-blocking stream. */
+int aomhip_ctx_create(int device, void *stream, aomhip_ctx **out);
+void aomhip_ctx_destroy(aomhip_ctx *ctx);
+int aomhip_ctx_sync(aomhip_ctx *ctx);            /* hipStreamSynchronize */
+void *aomhip_ctx_stream(aomhip_ctx *ctx);        /* the hipStream_t in use */
+int aomhip_device_count(void);                   /* 0 when no GPU is visible */
+const char *aomhip_last_error(void);             /* thread-local text of the last failure */
+int aomhip_abi_version(void);
+
+/* HIP-event timing on the context's stream (bench.py's per-launch durations). */
+int aomhip_timer_begin(aomhip_ctx *ctx);
+int aomhip_timer_end(aomhip_ctx *ctx, float *elapsed_ms); /* records, syncs, returns ms */
+
+/* Device memory helpers so a non-HIP host (C encoder, ctypes) needs no runtime of its own. */
+int aomhip_malloc(aomhip_ctx *ctx, size_t bytes, void **dptr);
+int aomhip_free(aomhip_ctx *ctx, void *dptr);
+int aomhip_memcpy_h2d(aomhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int aomhip_memcpy_d2h(aomhip_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronises */
+int aomhip_memset(aomhip_ctx *ctx, void *dst, int value, size_t bytes);
+
+/* ------------------------------------------------------------------ planes in HBM */
+
+/* A ring of n_frames identical planes.  Mirrors struct buf_2d
+ * (av1/common/blockd.h:444-450) + the YV12 border convention: element (x, y) of
+ * frame f, x in [-border, width+border), y likewise, is at
+ *   base[f * frame_stride + (y + border) * stride + (x + border)].
+ * Elements are uint8_t for bit_depth 8 and uint16_t for 10/12 (the reference's
+ * CONVERT_TO_SHORTPTR byte-pointer encoding, aom_ports/mem.h:79-80, is a host
+ * pointer trick and does not exist on the device side). */
+typedef struct {
+  void *base;            /* device pointer */
+  int64_t frame_stride;  /* elements between frames */
+  int32_t width, height; /* visible size in pixels */
+  int32_t stride;        /* elements per row; aom_calc_y_stride(aligned_width, border) */
+  int32_t border;        /* replicated border in pixels on every side */
+  int32_t bit_depth;     /* 8, 10 or 12 */
+  int32_t n_frames;
+} aomhip_planes;
+
+/* aom_calc_y_stride (aom_scale/yv12config.h:204-206) with aligned_width = (w+7)&~7 */
+int aomhip_calc_stride(int width, int border);
+/* Allocate a ring with the reference's geometry (yv12config.c:138-170). */
+int aomhip_planes_alloc(aomhip_ctx *ctx, int width, int height, int border, int bit_depth, int n_frames,
+                        aomhip_planes *out);
+int aomhip_planes_free(aomhip_ctx *ctx, aomhip_planes *p);
+/* Copy the visible area of one frame from host memory (host_stride in elements)
+ * and replicate its edges into the border on the device
+ * (aom_extend_frame_borders_c, aom_scale/generic/yv12extend.c:22-221). */
+int aomhip_planes_upload(aomhip_ctx *ctx, const aomhip_planes *p, int frame, const void *host_pixels,
+                         int host_stride);
+/* Re-extend borders of frames [first, first+n) after device-side writes. */
+int aomhip_planes_extend_borders(aomhip_ctx *ctx, const aomhip_planes *p, int first_frame, int n_frames);
+/* Whole bordered frame back to the host (tests). host buffer = stride*(height+2*border) elements */
+int aomhip_planes_download(aomhip_ctx *ctx, const aomhip_planes *p, int frame, void *host_bordered);
+
+/* ------------------------------------------------------------------ batched SAD */
+
+/* One SAD candidate: top-left of the source block and of the reference block, in
+ * pixels relative to the visible origin of their planes (may be negative / reach
+ * into the border, as full-pel MVs do: av1/encoder/mcomp.h:216-247). */
+typedef struct {
+  int16_t sx, sy, rx, ry;
+} aomhip_sad_cand;
+
+/* One x4d group: a source block and four reference positions
+ * (aom_sadMxNx4d, aom_dsp/sad.c:94-103; x3d callers pass 4 pointers too, :124-129). */
+typedef struct {
+  int16_t sx, sy;
+  int16_t rx[4], ry[4];
+} aomhip_sad_x4d_cand;
+
+#define AOMHIP_SAD_SKIP_ROWS 1 /* aom_sad_skip_MxN: even rows, result doubled (sad.c:65-69) */
+
+/* Batched aom_sadWxH / aom_sad_skip_WxH / aom_highbd_sadWxH (+ the encoder's
+ * _bits10/_bits12 >>2 / >>4 vtable wrappers, av1/encoder/encoder_utils.h:155-208,
+ * applied when the planes are 10/12-bit).
+ *   frames [first_frame, first_frame + n_frames) of src are compared with the same
+ *   frame index of ref.  d_cands holds n_cands candidates per frame; frame f uses
+ *   d_cands + f_rel * cand_frame_stride (0 = one list shared by all frames).
+ *   d_out[f_rel * n_cands + i] receives the SAD.  bw x bh is one of the reference's
+ *   22 block sizes (av1/common/enums.h:99-124). */
+int aomhip_sad_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame,
+                     int n_frames, int bw, int bh, int flags, const aomhip_sad_cand *d_cands, int n_cands,
+                     int64_t cand_frame_stride, uint32_t *d_out);
+/* Batched aom_sadWxHx4d / aom_sad_skip_WxHx4d: d_out[(f_rel * n_groups + i) * 4 + k]. */
+int aomhip_sad_x4d_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame,
+                         int n_frames, int bw, int bh, int flags, const aomhip_sad_x4d_cand *d_groups,
+                         int n_groups, int64_t group_frame_stride, uint32_t *d_out);
+
+/* ------------------------------------------------------------------ rtcd-signature conformance entry points */
+
+/* aom_dsp_rtcd_defs.pl:762-763 aom_sad{W}x{H} / aom_sad_skip_{W}x{H}; host pointers. */
+unsigned int aomhip_sad(const uint8_t *src_ptr, int src_stride, const uint8_t *ref_ptr, int ref_stride, int bw,
+                        int bh);
+unsigned int aomhip_sad_skip(const uint8_t *src_ptr, int src_stride, const uint8_t *ref_ptr, int ref_stride, int bw,
+                             int bh);
+/* aom_dsp_rtcd_defs.pl:1001-1004 aom_sad{W}x{H}x4d / x3d / skip x4d */
+void aomhip_sad_x4d(const uint8_t *src_ptr, int src_stride, const uint8_t *const ref_ptr[4], int ref_stride,
+                    uint32_t sad_array[4], int bw, int bh);
+void aomhip_sad_skip_x4d(const uint8_t *src_ptr, int src_stride, const uint8_t *const ref_ptr[4], int ref_stride,
+                         uint32_t sad_array[4], int bw, int bh);
+/* The fixed-size symbols the reference's macro-stamped names map to (config 1/2 of
+ * BASELINE.json name these two). */
+unsigned int aomhip_sad16x16(const uint8_t *src_ptr, int src_stride, const uint8_t *ref_ptr, int ref_stride);
+void aomhip_sad16x16x4d(const uint8_t *src_ptr, int src_stride, const uint8_t *const ref_ptr[4], int ref_stride,
+                        uint32_t sad_array[4]);
+/* aom_dsp_rtcd_defs.pl:880-887 aom_highbd_sad{W}x{H}: `src8`/`ref8` are
+ * CONVERT_TO_BYTEPTR-encoded uint16_t pointers exactly as the reference passes them.
+ * bd = 8/10/12 applies the encoder's vtable wrapper; 0 = raw kernel value. */
+unsigned int aomhip_highbd_sad(const uint8_t *src8, int src_stride, const uint8_t *ref8, int ref_stride, int bw,
+                               int bh, int bd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AOMHIP_H_ */
