@@ -40,35 +40,70 @@ template <> __device__ __forceinline__ uint32_t sad_dword<uint16_t>(uint32_t a, 
 
 // Sum over the TPC lanes that share a candidate (TPC a power of two, groups aligned).
 template <int TPC> __device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+  // DPP butterflies that never leave the TPC-lane group: xor 1, xor 2 inside a quad, then
+  // mirror inside 8 lanes, then mirror inside the 16-lane row.
   if constexpr (TPC >= 2) v += __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
   if constexpr (TPC >= 4) v += __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-  if constexpr (TPC >= 8) v += __builtin_amdgcn_update_dpp(0u, v, 0x124, 0xf, 0xf, false);  // row_ror:4
-  if constexpr (TPC >= 16) v += __builtin_amdgcn_update_dpp(0u, v, 0x128, 0xf, 0xf, false); // row_ror:8
+  if constexpr (TPC >= 8) v += __builtin_amdgcn_update_dpp(0u, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  if constexpr (TPC >= 16) v += __builtin_amdgcn_update_dpp(0u, v, 0x140, 0xf, 0xf, false); // row_mirror
   if constexpr (TPC >= 32) v += __shfl_xor(v, 16, 64);
   if constexpr (TPC >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 
 // Geometry of one block size for element type T.
-template <typename T, int W, int H, bool SKIP> struct SadGeom {
+template <typename T, int W, int H, bool SKIP, int UPL = 2> struct SadGeom {
   static constexpr int kRowBytes = W * (int)sizeof(T);
   static constexpr int kUnitBytes = kRowBytes < 16 ? kRowBytes : 16;
   static constexpr int kUnitElems = kUnitBytes / (int)sizeof(T);
   static constexpr int kUnitsPerRow = kRowBytes / kUnitBytes;
   static constexpr int kRows = SKIP ? H / 2 : H;
   static constexpr int kUnits = kUnitsPerRow * kRows;
-  // two units per lane where the block is big enough; never more than a wavefront
-  static constexpr int kTpcRaw = kUnits >= 2 ? kUnits / 2 : 1;
+  // UPL units per lane where the block is big enough; never more than a wavefront
+  static constexpr int kTpcRaw = kUnits >= UPL ? kUnits / UPL : 1;
   static constexpr int kTpc = kTpcRaw > 64 ? 64 : kTpcRaw;
   static constexpr int kUnitsPerLane = kUnits / kTpc;
   static constexpr int kRowStep = SKIP ? 2 : 1;
 };
 
-template <typename T, int BYTES>
-__device__ __forceinline__ uint32_t unit_sad(const T *s, const T *r, uint32_t acc) {
+// Fetch BYTES (4/8/16) from an arbitrarily aligned address.
+//  VARIANT 0: one unaligned global_load (the TCP splits a misaligned dwordx4 into ~3.4 cache
+//             accesses per lane -- measured, profiles/r01_pmc_*).
+//  VARIANT 1: one or two 16-byte ALIGNED loads covering the bytes, realigned in registers with
+//             v_cndmask / v_alignbyte (at most 2 cache accesses per lane, 1 when aligned).
+template <int BYTES, int VARIANT>
+__device__ __forceinline__ typename UnitLoad<BYTES>::type load_unit(const void *p) {
   using L = typename UnitLoad<BYTES>::type;
-  const L a = *reinterpret_cast<const L *>(s);
-  const L b = *reinterpret_cast<const L *>(r);
+  if constexpr (VARIANT == 0) {
+    return *reinterpret_cast<const L *>(p);
+  } else {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint4 *base = reinterpret_cast<const uint4 *>(a & ~(uintptr_t)15);
+    const unsigned sh = (unsigned)(a & 15);
+    const uint4 lo = base[0];
+    uint4 hi = make_uint4(0, 0, 0, 0);
+    if (sh + BYTES > 16) hi = base[1];
+    uint32_t d[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+    constexpr int kN = BYTES / 4 + 1;  // dwords needed after the dword-granular shift
+    if (sh & 8) {
+#pragma unroll
+      for (int i = 0; i < kN + 1 && i + 2 < 8; ++i) d[i] = d[i + 2];
+    }
+    if (sh & 4) {
+#pragma unroll
+      for (int i = 0; i < kN && i + 1 < 8; ++i) d[i] = d[i + 1];
+    }
+    L out;
+#pragma unroll
+    for (int i = 0; i < BYTES / 4; ++i) out.v[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh & 3);
+    return out;
+  }
+}
+
+template <typename T, int BYTES, int VARIANT>
+__device__ __forceinline__ uint32_t unit_sad(const T *s, const T *r, uint32_t acc) {
+  const auto a = load_unit<BYTES, VARIANT>(s);
+  const auto b = load_unit<BYTES, VARIANT>(r);
 #pragma unroll
   for (int i = 0; i < BYTES / 4; ++i) acc = sad_dword<T>(a.v[i], b.v[i], acc);
   return acc;
@@ -77,13 +112,13 @@ __device__ __forceinline__ uint32_t unit_sad(const T *s, const T *r, uint32_t ac
 constexpr int kBlockThreads = 256;
 
 // One candidate list entry per TPC lanes.
-template <typename T, int W, int H, bool SKIP>
+template <typename T, int W, int H, bool SKIP, int VARIANT>
 __global__ __launch_bounds__(kBlockThreads) void sad_cand_kernel(PlaneView<T> src, PlaneView<T> ref, int first_frame,
                                                                   const aomhip_sad_cand *__restrict__ cands,
                                                                   int n_cands, int64_t cand_frame_stride,
                                                                   uint32_t *__restrict__ out, int blocks_per_frame8,
                                                                   int shift) {
-  using G = SadGeom<T, W, H, SKIP>;
+  using G = SadGeom<T, W, H, SKIP, (VARIANT & 2) ? 1 : 2>;
   constexpr int kCpb = kBlockThreads / G::kTpc;  // candidates per workgroup
   const unsigned b = blockIdx.x;
   const unsigned f_rel = b / blocks_per_frame8;
@@ -101,20 +136,20 @@ __global__ __launch_bounds__(kBlockThreads) void sad_cand_kernel(PlaneView<T> sr
     const int u = lane_in_cand + k * G::kTpc;
     const int row = (u / G::kUnitsPerRow) * G::kRowStep;
     const int col = (u % G::kUnitsPerRow) * G::kUnitElems;
-    acc = unit_sad<T, G::kUnitBytes>(sp + (int64_t)row * src.stride + col, rp + (int64_t)row * ref.stride + col, acc);
+    acc = unit_sad<T, G::kUnitBytes, (VARIANT & 1)>(sp + (int64_t)row * src.stride + col, rp + (int64_t)row * ref.stride + col, acc);
   }
   acc = group_sum<G::kTpc>(acc);
   if (lane_in_cand == 0) out[(int64_t)f_rel * n_cands + ci] = (SKIP ? 2u * acc : acc) >> shift;
 }
 
 // One x4d group (shared source block, four reference positions) per TPC lanes.
-template <typename T, int W, int H, bool SKIP>
+template <typename T, int W, int H, bool SKIP, int VARIANT>
 __global__ __launch_bounds__(kBlockThreads) void sad_x4d_kernel(PlaneView<T> src, PlaneView<T> ref, int first_frame,
                                                                  const aomhip_sad_x4d_cand *__restrict__ groups,
                                                                  int n_groups, int64_t group_frame_stride,
                                                                  uint32_t *__restrict__ out, int blocks_per_frame8,
                                                                  int shift) {
-  using G = SadGeom<T, W, H, SKIP>;
+  using G = SadGeom<T, W, H, SKIP, (VARIANT & 2) ? 1 : 2>;
   using L = typename UnitLoad<G::kUnitBytes>::type;
   constexpr int kGpb = kBlockThreads / G::kTpc;
   const unsigned b = blockIdx.x;
@@ -133,10 +168,10 @@ __global__ __launch_bounds__(kBlockThreads) void sad_x4d_kernel(PlaneView<T> src
     const int u = lane_in_cand + k * G::kTpc;
     const int row = (u / G::kUnitsPerRow) * G::kRowStep;
     const int col = (u % G::kUnitsPerRow) * G::kUnitElems;
-    const L a = *reinterpret_cast<const L *>(sp + (int64_t)row * src.stride + col);
+    const L a = load_unit<G::kUnitBytes, (VARIANT & 1)>(sp + (int64_t)row * src.stride + col);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const L r = *reinterpret_cast<const L *>(rbase + (int64_t)(c.ry[j] + row) * ref.stride + c.rx[j] + col);
+      const L r = load_unit<G::kUnitBytes, (VARIANT & 1)>(rbase + (int64_t)(c.ry[j] + row) * ref.stride + c.rx[j] + col);
 #pragma unroll
       for (int i = 0; i < G::kUnitBytes / 4; ++i) acc[j] = sad_dword<T>(a.v[i], r.v[i], acc[j]);
     }
@@ -160,29 +195,42 @@ struct SadLaunch {
   int shift;  // vtable wrapper: 0 / 2 (10-bit) / 4 (12-bit)
 };
 
-template <typename T, int W, int H, bool SKIP>
-static int launch_cand(const SadLaunch &l, const PlaneView<T> &s, const PlaneView<T> &r, const aomhip_sad_cand *c, int n,
-                       int64_t cfs, uint32_t *out) {
-  using G = SadGeom<T, W, H, SKIP>;
+template <typename T, int W, int H, bool SKIP, int VARIANT>
+static int launch_cand_v(const SadLaunch &l, const PlaneView<T> &s, const PlaneView<T> &r, const aomhip_sad_cand *c,
+                         int n, int64_t cfs, uint32_t *out) {
+  using G = SadGeom<T, W, H, SKIP, (VARIANT & 2) ? 1 : 2>;
   constexpr int kCpb = kBlockThreads / G::kTpc;
   const int bpf = (n + kCpb - 1) / kCpb;
   const int bpf8 = (bpf + 7) & ~7;
-  hipLaunchKernelGGL((sad_cand_kernel<T, W, H, SKIP>), dim3((unsigned)bpf8 * l.n_frames), dim3(kBlockThreads), 0,
-                     l.stream, s, r, l.first_frame, c, n, cfs, out, bpf8, l.shift);
+  hipLaunchKernelGGL((sad_cand_kernel<T, W, H, SKIP, VARIANT>), dim3((unsigned)bpf8 * l.n_frames), dim3(kBlockThreads),
+                     0, l.stream, s, r, l.first_frame, c, n, cfs, out, bpf8, l.shift);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
+}
+template <typename T, int W, int H, bool SKIP, int VARIANT>
+static int launch_x4d_v(const SadLaunch &l, const PlaneView<T> &s, const PlaneView<T> &r,
+                        const aomhip_sad_x4d_cand *g, int n, int64_t gfs, uint32_t *out) {
+  using G = SadGeom<T, W, H, SKIP, (VARIANT & 2) ? 1 : 2>;
+  constexpr int kGpb = kBlockThreads / G::kTpc;
+  const int bpf = (n + kGpb - 1) / kGpb;
+  const int bpf8 = (bpf + 7) & ~7;
+  hipLaunchKernelGGL((sad_x4d_kernel<T, W, H, SKIP, VARIANT>), dim3((unsigned)bpf8 * l.n_frames), dim3(kBlockThreads),
+                     0, l.stream, s, r, l.first_frame, g, n, gfs, out, bpf8, l.shift);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+// Only variant 0 is instantiated.  Measured on MI355X at 4K Mode A (profiles/r01_sad_variants.md):
+// aligned-window loads cut TCP cache accesses by 39 % but raise L2 requests by 37 % and run 25-30 %
+// slower at either occupancy; one unit per lane is neutral for x4d and 13 % slower for single SADs.
+template <typename T, int W, int H, bool SKIP>
+static int launch_cand(const SadLaunch &l, const PlaneView<T> &s, const PlaneView<T> &r, const aomhip_sad_cand *c, int n,
+                       int64_t cfs, uint32_t *out) {
+  return launch_cand_v<T, W, H, SKIP, 0>(l, s, r, c, n, cfs, out);
 }
 template <typename T, int W, int H, bool SKIP>
 static int launch_x4d(const SadLaunch &l, const PlaneView<T> &s, const PlaneView<T> &r, const aomhip_sad_x4d_cand *g,
                       int n, int64_t gfs, uint32_t *out) {
-  using G = SadGeom<T, W, H, SKIP>;
-  constexpr int kGpb = kBlockThreads / G::kTpc;
-  const int bpf = (n + kGpb - 1) / kGpb;
-  const int bpf8 = (bpf + 7) & ~7;
-  hipLaunchKernelGGL((sad_x4d_kernel<T, W, H, SKIP>), dim3((unsigned)bpf8 * l.n_frames), dim3(kBlockThreads), 0,
-                     l.stream, s, r, l.first_frame, g, n, gfs, out, bpf8, l.shift);
-  AOMHIP_LAUNCH_CHECK();
-  return AOMHIP_OK;
+  return launch_x4d_v<T, W, H, SKIP, 0>(l, s, r, g, n, gfs, out);
 }
 
 // Dispatch over the reference's 22 block sizes (av1/common/enums.h:99-124).

@@ -15,10 +15,13 @@ int orc_max_threads(void) { return omp_get_max_threads(); }
 
 /* origin pointers address pixel (0,0) of a bordered plane; elem16 selects uint16 planes. */
 void orc_sad_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16,
-                   int bd, int w, int h, int skip, const orc_cand *c, int n, uint32_t *out, int threads) {
+                   int bd, int w, int h, int skip, const orc_cand *c, int n, uint32_t *out, int threads, int reps) {
   if (threads < 1) threads = 1;
+  if (reps < 1) reps = 1;
+  /* reps > 1: the CPU-baseline leg walks the same list `reps` times inside one parallel loop */
 #pragma omp parallel for num_threads(threads) schedule(static)
-  for (int i = 0; i < n; ++i) {
+  for (long long it = 0; it < (long long)n * reps; ++it) {
+    const int i = (int)(it % n);
     if (!elem16) {
       const uint8_t *s = (const uint8_t *)src_origin + (ptrdiff_t)c[i].sy * src_stride + c[i].sx;
       const uint8_t *r = (const uint8_t *)ref_origin + (ptrdiff_t)c[i].ry * ref_stride + c[i].rx;
@@ -33,10 +36,12 @@ void orc_sad_batch(const void *src_origin, int src_stride, const void *ref_origi
 }
 
 void orc_sad_x4d_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16,
-                       int bd, int w, int h, int skip, const orc_x4d_group *g, int n, uint32_t *out, int threads) {
+                       int bd, int w, int h, int skip, const orc_x4d_group *g, int n, uint32_t *out, int threads, int reps) {
   if (threads < 1) threads = 1;
+  if (reps < 1) reps = 1;
 #pragma omp parallel for num_threads(threads) schedule(static)
-  for (int i = 0; i < n; ++i) {
+  for (long long it = 0; it < (long long)n * reps; ++it) {
+    const int i = (int)(it % n);
     for (int k = 0; k < 4; ++k) {
       if (!elem16) {
         const uint8_t *s = (const uint8_t *)src_origin + (ptrdiff_t)g[i].sy * src_stride + g[i].sx;

@@ -79,9 +79,9 @@ def sub_pixel_variance(a, ay, ax, xoff, yoff, b, by, bx, w, h, bd=None):
 # ---- work-list drivers (aomref_batch.c)
 lib.orc_max_threads.restype = C.c_int
 lib.orc_sad_batch.restype = None
-lib.orc_sad_batch.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i]
+lib.orc_sad_batch.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i]
 lib.orc_sad_x4d_batch.restype = None
-lib.orc_sad_x4d_batch.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i]
+lib.orc_sad_x4d_batch.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i]
 
 
 def extend_plane(pixels, border, stride=None):
@@ -97,20 +97,20 @@ def extend_plane(pixels, border, stride=None):
     return out
 
 
-def sad_batch(src_b, ref_b, border, w, h, cands, skip=False, bd=8, threads=1):
+def sad_batch(src_b, ref_b, border, w, h, cands, skip=False, bd=8, threads=1, reps=1):
     """src_b/ref_b: bordered planes from extend_plane(); cands: structured array (sx,sy,rx,ry)."""
     cands = np.ascontiguousarray(cands)
     out = np.empty(len(cands), np.uint32)
     lib.orc_sad_batch(_addr(src_b, border, border), src_b.shape[1], _addr(ref_b, border, border), ref_b.shape[1],
                       int(src_b.dtype != np.uint8), bd, w, h, int(skip), cands.ctypes.data, len(cands),
-                      out.ctypes.data, threads)
+                      out.ctypes.data, threads, reps)
     return out
 
 
-def sad_x4d_batch(src_b, ref_b, border, w, h, groups, skip=False, bd=8, threads=1):
+def sad_x4d_batch(src_b, ref_b, border, w, h, groups, skip=False, bd=8, threads=1, reps=1):
     groups = np.ascontiguousarray(groups)
     out = np.empty((len(groups), 4), np.uint32)
     lib.orc_sad_x4d_batch(_addr(src_b, border, border), src_b.shape[1], _addr(ref_b, border, border), ref_b.shape[1],
                           int(src_b.dtype != np.uint8), bd, w, h, int(skip), groups.ctypes.data, len(groups),
-                          out.ctypes.data, threads)
+                          out.ctypes.data, threads, reps)
     return out

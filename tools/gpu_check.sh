@@ -15,5 +15,5 @@ echo "== bench"
 timeout 900 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 6000 $OUT/bench.json; tail -5 $OUT/bench.err
 echo "== rocprof kernel stats"
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o sad -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/prof.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o sad -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/prof.err
 find $OUT/prof -name '*kernel_stats*' | head; f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -12 "$f"
