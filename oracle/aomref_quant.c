@@ -1,0 +1,148 @@
+/*
+ * oracle/aomref_quant.c -- dead-zone quantisers, quantiser tables, scan orders.
+ * TEST INFRASTRUCTURE ONLY (see aomref.h).  Restates aom_dsp/quantize.c:108-169,261-316,
+ * av1/encoder/av1_quantize.c:580-674, av1/common/quant_common.c:193-215 and the scan tables
+ * of av1/common/scan.c (generated from their zig-zag / row / column rule instead of 7 900
+ * literal entries; tests compare every generated table with the reference initialiser).
+ *
+ * PARITY UNPINNED for the two quantise functions: the reference's only tests for them are
+ * SIMD-vs-C (test/quantize_func_test.cc), so there is no independent known answer; they are
+ * short and were restated statement by statement.
+ */
+#include "aomref.h"
+
+#include <string.h>
+
+#define QM_BITS 5 /* aom_dsp/quantize.h AOM_QM_BITS; qmatrix pointers are NULL on this path => wt = iwt = 32 */
+
+static int rpot(int v, int n) { return (v + ((1 << n) >> 1)) >> n; } /* ROUND_POWER_OF_TWO */
+
+void orc_quantize_b(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
+                    const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
+                    const int16_t *dequant, uint16_t *eob, const int16_t *scan, const int16_t *iscan,
+                    int log_scale) {
+  (void)iscan;
+  const int zb[2] = { rpot(zbin[0], log_scale), rpot(zbin[1], log_scale) };
+  const int wt = 1 << QM_BITS;
+  int last = -1;
+  memset(qcoeff, 0, (size_t)n * sizeof(*qcoeff));
+  memset(dqcoeff, 0, (size_t)n * sizeof(*dqcoeff));
+  /* The reference first walks the scan backwards to drop the all-inside-dead-zone tail
+   * (quantize.c:127-137); coefficients it drops fail the test below anyway, so a single
+   * forward pass over every position is equivalent. */
+  for (int i = 0; i < (int)n; ++i) {
+    const int rc = scan[i], ac = (rc != 0);
+    const int c = coeff[rc];
+    const int sign = c >> 31; /* AOMSIGN */
+    const int a = (c ^ sign) - sign;
+    if (a * wt < (zb[ac] << QM_BITS)) continue;
+    int64_t t = a + rpot(round[ac], log_scale);
+    if (t > INT16_MAX) t = INT16_MAX; /* clamp(..., INT16_MIN, INT16_MAX): low-bd only */
+    if (t < INT16_MIN) t = INT16_MIN;
+    t *= wt;
+    const int q = (int)(((((t * quant[ac]) >> 16) + t) * quant_shift[ac]) >> (16 - log_scale + QM_BITS));
+    qcoeff[rc] = (q ^ sign) - sign;
+    const int dq = (dequant[ac] * wt + (1 << (QM_BITS - 1))) >> QM_BITS;
+    const int adq = (q * dq) >> log_scale;
+    dqcoeff[rc] = (adq ^ sign) - sign;
+    if (q) last = i;
+  }
+  *eob = (uint16_t)(last + 1);
+}
+
+void orc_highbd_quantize_b(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
+                           const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff,
+                           int32_t *dqcoeff, const int16_t *dequant, uint16_t *eob, const int16_t *scan,
+                           const int16_t *iscan, int log_scale) {
+  (void)iscan;
+  const int zb[2] = { rpot(zbin[0], log_scale), rpot(zbin[1], log_scale) };
+  const int wt = 1 << QM_BITS;
+  int last = -1;
+  memset(qcoeff, 0, (size_t)n * sizeof(*qcoeff));
+  memset(dqcoeff, 0, (size_t)n * sizeof(*dqcoeff));
+  for (int i = 0; i < (int)n; ++i) {
+    const int rc = scan[i], ac = (rc != 0);
+    const int c = coeff[rc];
+    /* pre-scan test (quantize.c:281-291): keep when coeff*wt is outside (-zbin*32, zbin*32) */
+    const int cw = (int)((uint32_t)c * (uint32_t)wt);
+    if (!(cw >= zb[ac] * (1 << QM_BITS) || cw <= -zb[ac] * (1 << QM_BITS))) continue;
+    const int sign = c >> 31;
+    const int a = (c ^ sign) - sign;
+    const int64_t t1 = a + rpot(round[ac], log_scale);
+    const int64_t tw = t1 * wt;
+    const int64_t t2 = ((tw * quant[ac]) >> 16) + tw;
+    const int q = (int)((t2 * quant_shift[ac]) >> (16 - log_scale + QM_BITS));
+    qcoeff[rc] = (q ^ sign) - sign;
+    const int dq = (dequant[ac] * wt + (1 << (QM_BITS - 1))) >> QM_BITS;
+    const int adq = (int)((uint32_t)q * (uint32_t)dq) >> log_scale;
+    dqcoeff[rc] = (adq ^ sign) - sign;
+    if (q) last = i;
+  }
+  *eob = (uint16_t)(last + 1);
+}
+
+/* ------------------------------------------------------------------ tables */
+
+static const int16_t k_qlookup[6][256] = {
+#include "aomref_qlookup.inc"
+};
+
+static int clampq(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+static int bd_row(int bit_depth) { return bit_depth == 10 ? 1 : bit_depth == 12 ? 2 : 0; }
+
+int16_t orc_dc_q(int qindex, int delta, int bit_depth) { return k_qlookup[bd_row(bit_depth)][clampq(qindex + delta)]; }
+int16_t orc_ac_q(int qindex, int delta, int bit_depth) {
+  return k_qlookup[3 + bd_row(bit_depth)][clampq(qindex + delta)];
+}
+
+void orc_build_quantizer_y(int bit_depth, int qindex, int16_t tables[5][2]) {
+  /* get_qzbin_factor (av1_quantize.c:590-602) */
+  const int dcq = orc_dc_q(qindex, 0, bit_depth);
+  const int thr = bit_depth == 8 ? 148 : bit_depth == 10 ? 592 : 2368;
+  const int zbin_factor = qindex == 0 ? 64 : (dcq < thr ? 84 : 80);
+  const int round_factor = qindex == 0 ? 64 : 48;
+  for (int i = 0; i < 2; ++i) {
+    const int d = i == 0 ? dcq : orc_ac_q(qindex, 0, bit_depth);
+    /* invert_quant (:580-588) */
+    int l = 0;
+    for (uint32_t t = (uint32_t)d; t > 1; t >>= 1) ++l;
+    const int m = 1 + (1 << (16 + l)) / d;
+    tables[0][i] = (int16_t)rpot(zbin_factor * d, 7); /* y_zbin  */
+    tables[1][i] = (int16_t)((round_factor * d) >> 7); /* y_round */
+    tables[2][i] = (int16_t)(m - (1 << 16));           /* y_quant */
+    tables[3][i] = (int16_t)(1 << (16 - l));           /* y_quant_shift */
+    tables[4][i] = (int16_t)d;                         /* y_dequant_QTX */
+  }
+}
+
+/* ------------------------------------------------------------------ scans */
+
+int orc_get_scan(int tx_size, int tx_type, int16_t *scan, int16_t *iscan) {
+  /* av1_scan_orders (scan.c:1666-): 2-D types use the zig-zag, V_* the row scan, H_* the column
+   * scan; 64-point dimensions use the 32-point table.  Index = c*h + r (transposed layout). */
+  int w = orc_tx_wide[tx_size], h = orc_tx_high[tx_size];
+  if (w > 32) w = 32;
+  if (h > 32) h = 32;
+  const int n = w * h;
+  int k = 0;
+  if (tx_type >= ORC_V_DCT && (tx_type & 1)) { /* H_DCT, H_ADST, H_FLIPADST: "mcol" = identity */
+    for (int i = 0; i < n; ++i) scan[k++] = (int16_t)i;
+  } else if (tx_type >= ORC_V_DCT) { /* V_*: "mrow" */
+    for (int r = 0; r < h; ++r)
+      for (int c = 0; c < w; ++c) scan[k++] = (int16_t)(c * h + r);
+  } else {
+    for (int d = 0; d < w + h - 1; ++d) {
+      /* walk the anti-diagonal r + c = d; wide blocks always upwards, tall always downwards,
+       * square blocks alternate starting upwards on even d */
+      const int up = (w > h) || (w == h && (d & 1) == 0);
+      for (int t = 0; t < h; ++t) {
+        const int r = up ? h - 1 - t : t, c = d - r;
+        if (c < 0 || c >= w) continue;
+        scan[k++] = (int16_t)(c * h + r);
+      }
+    }
+  }
+  if (iscan)
+    for (int i = 0; i < n; ++i) iscan[scan[i]] = (int16_t)i;
+  return n;
+}

@@ -114,3 +114,102 @@ def sad_x4d_batch(src_b, ref_b, border, w, h, groups, skip=False, bd=8, threads=
                           int(src_b.dtype != np.uint8), bd, w, h, int(skip), groups.ctypes.data, len(groups),
                           out.ctypes.data, threads, reps)
     return out
+
+
+# ---- transforms / quantize / tables (aomref_txfm.c, aomref_quant.c)
+_i32 = np.ctypeslib.ndpointer(np.int32, flags="C")
+_i16 = np.ctypeslib.ndpointer(np.int16, flags="C")
+lib.orc_fwd_txfm1d.argtypes = [_i, _i, _i32, _i32, _i]
+lib.orc_inv_txfm1d.argtypes = [_i, _i, _i32, _i32, _i, _i]
+lib.orc_txfm_valid.restype = _i
+lib.orc_txfm_valid.argtypes = [_i, _i]
+lib.orc_fwd_txfm2d.argtypes = [_vp, _i32, _i, _i, _i, _i]
+lib.orc_inv_txfm2d_add.argtypes = [_i32, _vp, _i, _i, _i, _i]
+lib.orc_get_scan.restype = _i
+lib.orc_get_scan.argtypes = [_i, _i, _i16, _i16]
+lib.orc_dc_q.restype = C.c_int16
+lib.orc_dc_q.argtypes = [_i, _i, _i]
+lib.orc_ac_q.restype = C.c_int16
+lib.orc_ac_q.argtypes = [_i, _i, _i]
+lib.orc_build_quantizer_y.argtypes = [_i, _i, _i16]
+for _f in (lib.orc_quantize_b, lib.orc_highbd_quantize_b):
+    _f.restype = None
+    _f.argtypes = [_i32, C.c_ssize_t, _i16, _i16, _i16, _i16, _i32, _i32, _i16, C.POINTER(C.c_uint16), _i16, _i16, _i]
+
+TX_W = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
+TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
+V_KIND = [0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3]  # per TX_TYPE: 0 DCT 1 ADST 2 FLIPADST 3 IDTX
+H_KIND = [0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2]
+
+
+def av1_tx_valid(tx_size, tx_type):
+    """test/av1_txfm_test.h:89-100 IsTxSizeTypeValid: the (size, type) pairs AV1 actually uses."""
+    m = max(TX_W[tx_size], TX_H[tx_size])
+    if m > 32:
+        return tx_type == 0
+    if m == 32:
+        return tx_type in (0, 9)
+    return True
+
+
+def cospi_table():
+    return np.ctypeslib.as_array((C.c_int32 * (7 * 64)).in_dll(lib, "orc_cospi")).reshape(7, 64).copy()
+
+
+def sinpi_table():
+    return np.ctypeslib.as_array((C.c_int32 * (7 * 5)).in_dll(lib, "orc_sinpi")).reshape(7, 5).copy()
+
+
+def fwd_txfm1d(kind, x, cos_bit):
+    x = np.ascontiguousarray(x, np.int32)
+    o = np.zeros_like(x)
+    lib.orc_fwd_txfm1d(kind, x.size, x, o, cos_bit)
+    return o
+
+
+def inv_txfm1d(kind, x, cos_bit, clamp_bit):
+    x = np.ascontiguousarray(x, np.int32)
+    o = np.zeros_like(x)
+    lib.orc_inv_txfm1d(kind, x.size, x, o, cos_bit, clamp_bit)
+    return o
+
+
+def fwd_txfm2d(block, tx_size, tx_type, bd=8):
+    """block: int16 [h, w] residual -> int32 [w*h] coefficients in the reference's transposed layout."""
+    block = np.ascontiguousarray(block, np.int16)
+    h, w = block.shape
+    assert (w, h) == (TX_W[tx_size], TX_H[tx_size])
+    out = np.zeros(w * h, np.int32)
+    lib.orc_fwd_txfm2d(block.ctypes.data, out, w, tx_size, tx_type, bd)
+    return out
+
+
+def inv_txfm2d_add(coeff, dst, tx_size, tx_type, bd):
+    coeff = np.ascontiguousarray(coeff, np.int32)
+    dst = np.ascontiguousarray(dst, np.uint16).copy()
+    lib.orc_inv_txfm2d_add(coeff, dst.ctypes.data, dst.shape[1], tx_size, tx_type, bd)
+    return dst
+
+
+def get_scan(tx_size, tx_type):
+    n = min(TX_W[tx_size], 32) * min(TX_H[tx_size], 32)
+    s, i = np.zeros(n, np.int16), np.zeros(n, np.int16)
+    assert lib.orc_get_scan(tx_size, tx_type, s, i) == n
+    return s, i
+
+
+def build_quantizer_y(bit_depth, qindex):
+    """-> dict of int16[2] (DC, AC): zbin, round, quant, quant_shift, dequant."""
+    t = np.zeros((5, 2), np.int16)
+    lib.orc_build_quantizer_y(bit_depth, qindex, t)
+    return dict(zip(("zbin", "round", "quant", "quant_shift", "dequant"), t))
+
+
+def quantize_b(coeff, q, scan, iscan, log_scale, highbd=False):
+    coeff = np.ascontiguousarray(coeff, np.int32)
+    qc, dq = np.zeros_like(coeff), np.zeros_like(coeff)
+    eob = C.c_uint16()
+    f = lib.orc_highbd_quantize_b if highbd else lib.orc_quantize_b
+    f(coeff, coeff.size, q["zbin"], q["round"], q["quant"], q["quant_shift"], qc, dq, q["dequant"], C.byref(eob),
+      np.ascontiguousarray(scan, np.int16), np.ascontiguousarray(iscan, np.int16), log_scale)
+    return qc, dq, eob.value

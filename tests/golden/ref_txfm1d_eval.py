@@ -97,7 +97,7 @@ def parse_int_table(path, name):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
-    m = re.search(re.escape(name) + r"\s*(?:\[[^\]]*\])+\s*=\s*\{", src)
+    m = re.search(re.escape(name) + r"\s*(?:\[[^\]]*\])+\s*\)?\s*=\s*\{", src)
     if not m:
         raise KeyError(name)
     depth, i = 1, m.end()

@@ -1,0 +1,239 @@
+"""Pins the oracle's transforms, tables and scans:
+  * every 1-D butterfly network == the committed golden vectors that were produced by evaluating
+    the reference's own statements (tests/golden/make_golden.py), and == a live re-evaluation when
+    /root/reference is present;
+  * every constant table == the reference initialiser (live) / its committed sha256;
+  * forward 2-D transform within the reference gtest's double-precision error bounds
+    (test/av1_fwd_txfm2d_test.cc:145-187), inverse(forward(x)) within test/av1_inv_txfm2d_test.cc's;
+  * quantize_b: "parity unpinned" in the reference (SIMD-vs-C tests only) -> definitional properties."""
+import hashlib
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REFERENCE, ROOT, have_reference
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(vals):
+    return hashlib.sha256(np.asarray(vals, dtype=np.int64).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def sums():
+    return json.load(open(os.path.join(GOLD, "table_checksums.json")))
+
+
+def test_txfm1d_networks_match_reference_goldens(oracle):
+    g = np.load(os.path.join(GOLD, "txfm1d_golden.npz"))
+    names = sorted({k.split("/")[0] for k in g.files})
+    assert len(names) == 14
+    for name in names:
+        x = g[name + "/in"]
+        inv = name.startswith("av1_i")
+        kind = 1 if "adst" in name else 0
+        for key in [k for k in g.files if k.startswith(name + "/cb")]:
+            cb = int(key.split("/")[1][2:]); clamp = int(key.split("/")[2][5:])
+            want = g[key]
+            for row in range(x.shape[0]):
+                got = oracle.inv_txfm1d(kind, x[row], cb, clamp) if inv else oracle.fwd_txfm1d(kind, x[row], cb)
+                assert np.array_equal(got, want[row]), (name, cb, clamp, row)
+
+
+@pytest.mark.skipif(not have_reference(), reason="live re-evaluation needs /root/reference")
+def test_txfm1d_networks_live_reference(oracle):
+    sys.path.insert(0, GOLD)
+    import ref_txfm1d_eval as rt
+    fns, cospi, _ = rt.load_reference_networks()
+    rng = np.random.default_rng(7)
+    for name, fn in fns.items():
+        inv, kind, size = name.startswith("av1_i"), (1 if "adst" in name else 0), fn[0]
+        x = rng.integers(-(1 << 17), 1 << 17, size=(20, size), dtype=np.int64)
+        for cb in (10, 13) if not inv else (12,):
+            clamp = 18 if inv else 0
+            want = rt.evaluate(fn, x, cb, cospi[cb - 10], clamp)
+            for r in range(20):
+                got = oracle.inv_txfm1d(kind, x[r], cb, clamp) if inv else oracle.fwd_txfm1d(kind, x[r], cb)
+                assert np.array_equal(got, want[r])
+
+
+def test_constant_tables(oracle, sums):
+    cos = oracle.cospi_table()
+    formula = [[int(round(math.cos(math.pi * j / 128) * (1 << (10 + i)))) for j in range(64)] for i in range(7)]
+    assert cos.tolist() == formula  # av1_txfm.c:17 comment gives this formula
+    assert sha(cos) == sums["cospi"] and sha(oracle.sinpi_table()) == sums["sinpi"]
+    sp = oracle.sinpi_table()
+    assert all(r[1] + r[2] == r[4] for r in sp)  # av1_inv_txfm1d.c:672 assert
+    for row, bd in enumerate((8, 10, 12)):
+        dc = [oracle.lib.orc_dc_q(q, 0, bd) for q in range(256)]
+        ac = [oracle.lib.orc_ac_q(q, 0, bd) for q in range(256)]
+        sfx = {8: "", 10: "_10", 12: "_12"}[bd]
+        assert sha(dc) == sums["dc_qlookup%s_QTX" % sfx] and sha(ac) == sums["ac_qlookup%s_QTX" % sfx]
+    assert oracle.lib.orc_dc_q(0, 0, 8) == 4 and oracle.lib.orc_ac_q(255, 0, 8) == 1828
+    assert oracle.lib.orc_dc_q(300, 0, 8) == oracle.lib.orc_dc_q(255, 0, 8)  # clamp to MAXQ
+
+
+def test_scan_tables(oracle, sums):
+    ents = sums["av1_scan_orders"]
+    for ts in range(19):
+        for tt in range(16):
+            scan, iscan = oracle.get_scan(ts, tt)
+            sname, iname = ents[ts * 16 + tt]
+            assert sha(scan) == sums[sname], (ts, tt, sname)
+            assert sha(iscan) == sums[iname], (ts, tt, iname)
+            assert sorted(scan.tolist()) == list(range(scan.size))
+
+
+@pytest.mark.skipif(not have_reference(), reason="needs /root/reference")
+def test_tables_live_reference(oracle):
+    sys.path.insert(0, GOLD)
+    import ref_txfm1d_eval as rt
+    assert oracle.cospi_table().ravel().tolist() == rt.parse_int_table(REFERENCE + "/av1/common/av1_txfm.c", "av1_cospi_arr_data")
+    assert oracle.sinpi_table().ravel().tolist() == rt.parse_int_table(REFERENCE + "/av1/common/av1_txfm.c", "av1_sinpi_arr_data")
+    want = rt.parse_int_table(REFERENCE + "/av1/common/scan.c", "default_scan_16x16")
+    assert oracle.get_scan(2, 0)[0].tolist() == want
+
+
+# ---------------------------------------------------------------- 2-D forward: reference gtest tolerance
+
+AVG_ERR = [0.5, 0.5, 1.2, 6.1, 3.4, 0.57, 0.68, 0.92, 1.1, 4.1, 6, 3.5, 5.7, 0.6, 0.9, 1.2, 1.7, 2.0, 4.7]
+MAX_ERR = [3, 5, 11, 70, 64, 3.9, 4.3, 12, 12, 32, 46, 136, 136, 5, 6, 21, 13, 30, 36]
+FWD_SHIFT_SUM = [2, 1, 0, -2, -4, 1, 1, 0, 0, -2, -2, -4, -4, 1, 1, 0, 0, -2, -2]  # sum of av1_fwd_txfm2d.c:314-332
+
+
+def ref_1d(x, kind):  # test/av1_txfm_test.cc:104-217 reference_{dct,adst,idtx}_1d, columns of x
+    n = x.shape[0]
+    if kind == 3:
+        return x * {4: math.sqrt(2), 8: 2, 16: 2 * math.sqrt(2), 32: 4, 64: 4 * math.sqrt(2)}[n]
+    k = np.arange(n)[:, None]; m = np.arange(n)[None, :]
+    if kind == 0:
+        mat = np.cos(math.pi * (2 * m + 1) * k / (2 * n))
+        mat[0] *= 1 / math.sqrt(2)
+        return mat @ x
+    if n == 4:  # integer fadst4 with the 14-bit sinpi constants (av1_txfm_test.cc:125-171)
+        s1, s2, s3, s4 = 5283, 9929, 13377, 15212
+        xi = np.rint(x).astype(np.int64)
+        x0, x1, x2, x3 = xi
+        a, b = s1 * x0 + s2 * x1 + s4 * x3, s3 * (x0 + x1 - x3)
+        c, d = s4 * x0 - s1 * x1 + s2 * x3, s3 * x2
+        o = np.stack([a + d, b, c - d, c - a + d])
+        o = (o + (1 << 13)) >> 14
+        o[:, (xi == 0).all(axis=0)] = 0
+        return o.astype(np.float64)
+    return np.sin(math.pi * (2 * m + 1) * (2 * k + 1) / (4 * n)) @ x
+
+
+def reference_hybrid_2d(x, tx_size, tx_type, oracle):
+    vt, ht = oracle.V_KIND[tx_type], oracle.H_KIND[tx_type]
+    if vt == 2: x = x[::-1]
+    if ht == 2: x = x[:, ::-1]
+    t = ref_1d(x.astype(np.float64), 1 if vt == 2 else vt)          # columns
+    t = ref_1d(t.T, 1 if ht == 2 else ht).T                          # rows
+    return t  # [r, c]
+
+
+@pytest.mark.parametrize("tx_size", range(19))
+def test_fwd_txfm2d_accuracy_vs_double_reference(oracle, tx_size):
+    w, h = oracle.TX_W[tx_size], oracle.TX_H[tx_size]
+    amp = 2.0 ** FWD_SHIFT_SUM[tx_size] * (math.sqrt(2) if max(w, h) == 2 * min(w, h) else 1.0)
+    rng = np.random.default_rng(tx_size)
+    for tx_type in range(16):
+        if not oracle.av1_tx_valid(tx_size, tx_type):
+            continue
+        tot = 0.0
+        count = 12
+        for _ in range(count):
+            x = rng.integers(0, 1024, (h, w)).astype(np.int16)  # Rand16() % (1 << 10), av1_txfm_test.h:86-87
+            got = oracle.fwd_txfm2d(x, tx_size, tx_type, 10).reshape(w, h).T.astype(np.float64)  # -> [r, c]
+            want = np.rint(reference_hybrid_2d(x, tx_size, tx_type, oracle) * amp)  # av1_txfm_test.cc:336-342
+            kw, kh = min(w, 32), min(h, 32)
+            if w == 64 or h == 64:  # packed: only the low 32 frequencies survive
+                got = oracle.fwd_txfm2d(x, tx_size, tx_type, 10)[:kw * kh].reshape(kw, kh).T.astype(np.float64)
+                want = want[:kh, :kw]
+            err = np.abs(got - want) / amp
+            assert err.max() <= MAX_ERR[tx_size], (tx_size, tx_type, err.max())
+            tot += err.mean() * (kw * kh) / (w * h)
+        # the reference instantiates this check for the 5 square sizes only (`s < TX_SIZES`, :190); the rectangular
+        # rows of its threshold tables are applied here with 10 % slack on the 12-sample average
+        slack = 1.0 if tx_size < 5 else 1.1
+        assert tot / count <= AVG_ERR[tx_size] * slack, (tx_size, tx_type, tot / count)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_inv_of_fwd_roundtrip(oracle, bd):
+    """test/av1_inv_txfm2d_test.cc:153-217: inverse(forward(residual)) + prediction reproduces the
+    pixels within a small per-size error (those tests allow <= 2..7; identity-free sizes give <= 1..3)."""
+    rng = np.random.default_rng(bd)
+    mx = (1 << bd) - 1
+    for tx_size in range(19):
+        w, h = oracle.TX_W[tx_size], oracle.TX_H[tx_size]
+        for tx_type in range(16):
+            if not oracle.av1_tx_valid(tx_size, tx_type):
+                continue
+            pred = rng.integers(0, mx + 1, (h, w)).astype(np.uint16)
+            src = rng.integers(0, mx + 1, (h, w)).astype(np.uint16)
+            if w == 64 or h == 64:  # 64-point keeps only low frequencies: use a smooth residual
+                src = np.clip(pred.astype(np.int64) + rng.integers(-3, 4), 0, mx).astype(np.uint16)
+            res = (src.astype(np.int32) - pred.astype(np.int32)).astype(np.int16)
+            coeff = oracle.fwd_txfm2d(res, tx_size, tx_type, bd)
+            rec = oracle.inv_txfm2d_add(coeff, pred, tx_size, tx_type, bd)
+            lim = 2 if max(w, h) <= 16 else 4 if max(w, h) == 32 else 8
+            assert np.abs(rec.astype(np.int64) - src.astype(np.int64)).max() <= lim, (tx_size, tx_type)
+
+
+# ---------------------------------------------------------------- quantize_b
+
+@pytest.mark.parametrize("highbd", [False, True])
+@pytest.mark.parametrize("tx_size,log_scale", [(0, 0), (1, 0), (2, 0), (3, 1), (4, 2), (7, 0), (9, 1)])
+def test_quantize_b_definition(oracle, tx_size, log_scale, highbd):
+    """Input classes of test/quantize_func_test.cc:202-259 (zero, DC only, large negative, random);
+    checks the per-coefficient definition of quantize.c:139-166 in exact integer arithmetic."""
+    scan, iscan = oracle.get_scan(tx_size, 0)
+    n = scan.size
+    rng = np.random.default_rng(tx_size * 10 + log_scale)
+    bd = 10 if highbd else 8
+    for qindex in (0, 1, 20, 100, 200, 255):
+        q = oracle.build_quantizer_y(bd, qindex)
+        span = 8191 if not highbd else 65535
+        cases = [np.zeros(n, np.int32), np.full(n, 16, np.int32), rng.integers(-span, span + 1, n).astype(np.int32),
+                 rng.integers(-64, 65, n).astype(np.int32)]
+        dc = np.zeros(n, np.int32); dc[0] = -8191; cases.append(dc)
+        for c in cases:
+            qc, dq, eob = oracle.quantize_b(c, q, scan, iscan, log_scale, highbd)
+            want_q = np.zeros(n, np.int64); want_dq = np.zeros(n, np.int64)
+            for rc in range(n):
+                ac = int(rc != 0)
+                zb = (int(q["zbin"][ac]) + ((1 << log_scale) >> 1)) >> log_scale
+                rd = (int(q["round"][ac]) + ((1 << log_scale) >> 1)) >> log_scale
+                a = abs(int(c[rc]))
+                if a * 32 < zb * 32:
+                    continue
+                t = a + rd
+                if not highbd:
+                    t = min(t, 32767)
+                t *= 32
+                qq = ((((t * int(q["quant"][ac])) >> 16) + t) * int(q["quant_shift"][ac])) >> (16 - log_scale + 5)
+                sgn = -1 if c[rc] < 0 else 1
+                want_q[rc] = sgn * qq
+                want_dq[rc] = sgn * ((qq * int(q["dequant"][ac])) >> log_scale)
+            assert np.array_equal(qc, want_q) and np.array_equal(dq, want_dq)
+            nz = np.nonzero(want_q[scan])[0]
+            assert eob == (nz.max() + 1 if nz.size else 0)
+
+
+def test_build_quantizer_properties(oracle):
+    """av1_quantize.c:580-588 invert_quant: ((x*quant >> 16) + x) * shift >> 16 == x / d up to 1."""
+    for bd in (8, 10, 12):
+        for qindex in range(0, 256, 5):
+            q = oracle.build_quantizer_y(bd, qindex)
+            for i in (0, 1):
+                d = int(q["dequant"][i])
+                assert d == (oracle.lib.orc_dc_q if i == 0 else oracle.lib.orc_ac_q)(qindex, 0, bd)
+                for x in (d, 7 * d + 3, 1000 * d // 7):
+                    y = ((((x * int(q["quant"][i])) >> 16) + x) * int(q["quant_shift"][i])) >> 16
+                    assert abs(y - x // d) <= 1
