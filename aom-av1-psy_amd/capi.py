@@ -23,6 +23,19 @@ class Planes(C.Structure):
                 ("stride", C.c_int32), ("border", C.c_int32), ("bit_depth", C.c_int32), ("n_frames", C.c_int32)]
 
 
+class QuantParams(C.Structure):
+    _fields_ = [(n, C.c_int16 * 2) for n in ("zbin", "round", "quant", "quant_shift", "dequant")]
+
+    @classmethod
+    def from_tables(cls, t):
+        """t: mapping name -> 2 int16 (DC, AC), e.g. rows of av1_build_quantizer output."""
+        q = cls()
+        for n in ("zbin", "round", "quant", "quant_shift", "dequant"):
+            getattr(q, n)[0], getattr(q, n)[1] = int(t[n][0]), int(t[n][1])
+        return q
+
+
+txb_dtype = np.dtype([("x", "<i4"), ("y", "<i4"), ("out_offset", "<u4"), ("tx_type", "u1"), ("reserved", "u1", (3,))])
 sad_cand_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2"), ("ry", "<i2")])
 sad_x4d_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2", (4,)), ("ry", "<i2", (4,))])
 
@@ -52,6 +65,13 @@ _protos = {
     "aomhip_planes_download": (C.c_int, [_vp, _PP, _i, _vp]),
     "aomhip_sad_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
     "aomhip_sad_x4d_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
+    "aomhip_tx_size_wide": (C.c_int, [_i]),
+    "aomhip_tx_size_high": (C.c_int, [_i]),
+    "aomhip_tx_max_eob": (C.c_int, [_i]),
+    "aomhip_xform_quant_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _i, C.POINTER(QuantParams), _i, _vp, _vp,
+                                           _vp, _vp]),
+    "aomhip_subtract_xform_quant_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _vp, _i, _i, _i, C.POINTER(QuantParams),
+                                                    _vp, _vp, _vp, _vp]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp, _i, _i]),
@@ -153,3 +173,16 @@ class Context:
                       d_out):
         check(lib.aomhip_sad_x4d_batch(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, bw, bh, flags,
                                        d_groups, n_groups, group_frame_stride, d_out), "aomhip_sad_x4d_batch")
+
+    # ---- forward transform + quantise
+    def xform_quant_batch(self, d_residual, stride, tx_size, d_blocks, n_blocks, grid_cols, tx_type, qp, is_hbd,
+                          d_coeff, d_qcoeff, d_dqcoeff, d_eob):
+        check(lib.aomhip_xform_quant_batch(self.h, d_residual, stride, tx_size, d_blocks, n_blocks, grid_cols, tx_type,
+                                           C.byref(qp), int(is_hbd), d_coeff, d_qcoeff, d_dqcoeff, d_eob),
+              "aomhip_xform_quant_batch")
+
+    def subtract_xform_quant_batch(self, src, pred, frame, tx_size, d_blocks, n_blocks, grid_cols, tx_type, qp,
+                                   d_coeff, d_qcoeff, d_dqcoeff, d_eob):
+        check(lib.aomhip_subtract_xform_quant_batch(self.h, C.byref(src), C.byref(pred), frame, tx_size, d_blocks,
+                                                    n_blocks, grid_cols, tx_type, C.byref(qp), d_coeff, d_qcoeff,
+                                                    d_dqcoeff, d_eob), "aomhip_subtract_xform_quant_batch")

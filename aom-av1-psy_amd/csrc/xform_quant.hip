@@ -1,0 +1,303 @@
+// Fused forward 2-D transform + aom_quantize_b on gfx950.
+//
+// Reference path: av1/encoder/encodemb.c:288-341 av1_xform_quant = av1_xform (hybrid_fwd_txfm.c:233
+// -> av1_fwd_txfm2d_WxH_c, av1_fwd_txfm2d.c:56-312) followed by av1_quant ->
+// av1_quantize_b_facade (av1_quantize.c:302-372) -> aom_quantize_b{,_32x32,_64x64}_c /
+// aom_highbd_quantize_b* (aom_dsp/quantize.c:108-169,261-316,399-470).
+//
+// Mapping.  A W x H transform block is owned by max(W, H) adjacent lanes of one wavefront.
+//   column pass: lane c holds column c (H values in VGPRs), runs the H-point network
+//   transpose  : through a padded LDS tile (stride W + 1 words: conflict-free both ways)
+//   row pass   : lane r holds row r (W values), runs the W-point network, then quantises its W
+//                coefficients in registers and stores coeff / qcoeff / dqcoeff in the reference's
+//                transposed layout (index c*H + r): for each c the block's lanes write one
+//                contiguous 4*H-byte run.
+// eob is a max-reduction of (inverse-scan position + 1) over non-zero levels; the inverse scan
+// position is computed arithmetically (zig-zag / row / column rule of av1/common/scan.c) instead
+// of being looked up.  The kernel moves 2 B in and 8 (+4 with coeff) B out per sample and does
+// O(log N) butterflies per sample: HBM-bound for small sizes, VALU-bound towards 32 / 64 points.
+// 64-point sizes only compute the 32 low-frequency outputs per dimension (the reference computes
+// and then discards the rest, av1_fwd_txfm2d.c:241-312).
+#include "common.h"
+#include "txfm_device.h"
+
+namespace aomhip {
+
+using namespace txfm;
+
+struct QuantArgs {
+  int16_t zbin[2], round[2], quant[2], quant_shift[2], dequant[2];
+};
+
+// av1_scan_orders (scan.c:1666-): class 0 = zig-zag (all 2-D types), 1 = "mrow" (V_* types),
+// 2 = "mcol" (H_* types).  Position of coefficient (r, c) in a KW x KH scan.
+template <int KW, int KH> __device__ __forceinline__ int iscan_pos(int r, int c, int scan_class) {
+  if (scan_class == 2) return c * KH + r;
+  if (scan_class == 1) return r * KW + c;
+  constexpr int m = KW < KH ? KW : KH, M = KW < KH ? KH : KW;
+  const int d = r + c;
+  int before;  // coefficients on earlier anti-diagonals
+  if (d <= m)
+    before = d * (d + 1) / 2;
+  else if (d <= M)
+    before = m * (m + 1) / 2 + (d - m) * m;
+  else
+    before = KW * KH - (KW + KH - 1 - d) * (KW + KH - d) / 2;
+  const bool up = (KW > KH) || (KW == KH && (d & 1) == 0);
+  const int cmin = d - (KH - 1) > 0 ? d - (KH - 1) : 0;
+  const int rmin = d - (KW - 1) > 0 ? d - (KW - 1) : 0;
+  return before + (up ? c - cmin : r - rmin);
+}
+
+// per-TX_TYPE vertical / horizontal 1-D kinds (common_data.h:149-159): 0 DCT 1 ADST 2 FLIPADST 3 IDTX
+__device__ constexpr uint8_t kVKind[16] = { 0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3 };
+__device__ constexpr uint8_t kHKind[16] = { 0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2 };
+
+template <int LPB> __device__ __forceinline__ int group_max(int v) {
+  if constexpr (LPB >= 2) v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
+  if constexpr (LPB >= 4) v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
+  if constexpr (LPB >= 8) v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
+  if constexpr (LPB >= 16) v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false));
+  if constexpr (LPB >= 32) v = max(v, __shfl_xor(v, 16, 64));
+  if constexpr (LPB >= 64) v = max(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+constexpr int kXqThreads = 256;
+
+// SRC: 0 = int16 residual plane; 1 = uint8 src - pred planes; 2 = uint16 src - pred planes
+template <int W, int H, bool HBD, int SRC>
+__global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
+    const void *__restrict__ in0, const void *__restrict__ in1, int stride0, int stride1,
+    const aomhip_txb *__restrict__ blocks, int n_blocks, int grid_cols, int uniform_type, QuantArgs qa,
+    int32_t *__restrict__ coeff, int32_t *__restrict__ qcoeff, int32_t *__restrict__ dqcoeff,
+    uint16_t *__restrict__ eob, int nblk8) {
+  using C = Cfg2D<W, H>;
+  constexpr int LPB = W > H ? W : H;
+  constexpr int BPW = kXqThreads / LPB;  // blocks per workgroup
+  constexpr int KW = W < 32 ? W : 32, KH = H < 32 ? H : 32;
+  constexpr int NC = KW * KH;                       // av1_get_max_eob
+  constexpr int LS = (W * H > 256) + (W * H > 1024);  // av1_get_tx_scale (av1/common/idct.c:24-28)
+  constexpr int LSTRIDE = W + 1;
+  __shared__ int32_t tile[BPW][KH * LSTRIDE];
+
+  const int slot = threadIdx.x / LPB, lane = threadIdx.x % LPB;
+  const unsigned wg = xcd_chunked_index(blockIdx.x, nblk8);
+  const int bi = wg * BPW + slot;
+  const bool live = bi < n_blocks;
+  int bx = 0, by = 0, tx_type = uniform_type;
+  int64_t out_off = (int64_t)bi * NC;
+  if (live) {
+    if (blocks) {
+      const aomhip_txb b = blocks[bi];
+      bx = b.x;
+      by = b.y;
+      tx_type = b.tx_type;
+      out_off = b.out_offset;
+    } else {  // regular grid: block bi of a plane that is grid_cols blocks wide
+      bx = (bi % grid_cols) * W;
+      by = (bi / grid_cols) * H;
+    }
+  }
+  const int vk = kVKind[tx_type & 15], hk = kHKind[tx_type & 15];
+  int32_t(&t)[KH * LSTRIDE] = tile[slot];
+
+  // ---- columns
+  if (live && lane < W) {
+    int32_t x[H];
+    const bool ud = (vk == 2);
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+      const int rr = ud ? H - 1 - r : r;
+      int v;
+      if constexpr (SRC == 0) {
+        v = static_cast<const int16_t *>(in0)[(int64_t)(by + rr) * stride0 + bx + lane];
+      } else if constexpr (SRC == 1) {
+        v = (int)static_cast<const uint8_t *>(in0)[(int64_t)(by + rr) * stride0 + bx + lane] -
+            (int)static_cast<const uint8_t *>(in1)[(int64_t)(by + rr) * stride1 + bx + lane];
+      } else {
+        v = (int)static_cast<const uint16_t *>(in0)[(int64_t)(by + rr) * stride0 + bx + lane] -
+            (int)static_cast<const uint16_t *>(in1)[(int64_t)(by + rr) * stride1 + bx + lane];
+      }
+      x[r] = v * (1 << C::fs0);  // round_shift_array with a negative bit = exact left shift of an int16
+    }
+    fwd_1d<H, C::cos_bit_col>(x, vk == 2 ? 1 : vk);
+    const int dc = (hk == 2) ? W - 1 - lane : lane;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) {
+      int32_t v = x[r];
+      if constexpr (C::fs1 < 0) v = rshift(v, -C::fs1);
+      t[r * LSTRIDE + dc] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- rows + quantise
+  int my_eob = 0;
+  if (live && lane < KH) {
+    const int r = lane;
+    int32_t y[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) y[c] = t[r * LSTRIDE + c];
+    fwd_1d<W, C::cos_bit_row>(y, hk == 2 ? 1 : hk);
+    const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
+    const int zb[2] = { (qa.zbin[0] + ((1 << LS) >> 1)) >> LS, (qa.zbin[1] + ((1 << LS) >> 1)) >> LS };
+    const int rd[2] = { (qa.round[0] + ((1 << LS) >> 1)) >> LS, (qa.round[1] + ((1 << LS) >> 1)) >> LS };
+#pragma unroll
+    for (int c = 0; c < KW; ++c) {
+      int32_t v = y[c];
+      if constexpr (C::fs2 < 0) v = rshift(v, -C::fs2);
+      if constexpr (C::rect2) v = rshift64((int64_t)v * kSqrt2, kSqrt2Bits);
+      const int rc = c * KH + r;
+      if (coeff) coeff[out_off + rc] = v;
+      const int ac = (rc != 0);
+      const int sign = v >> 31;
+      const int a = (v ^ sign) - sign;
+      int q = 0, dq = 0;
+      if (a >= zb[ac]) {
+        int64_t tmp = (int64_t)a + rd[ac];
+        if constexpr (!HBD) tmp = tmp > 32767 ? 32767 : tmp;  // clamp(.., INT16_MIN, INT16_MAX): low-bd only
+        tmp *= 32;                                           // wt = 1 << AOM_QM_BITS, no quant matrix on this path
+        const int64_t t2 = ((tmp * qa.quant[ac]) >> 16) + tmp;
+        q = (int)((t2 * qa.quant_shift[ac]) >> (16 - LS + 5));
+        dq = (int)((uint32_t)q * (uint32_t)qa.dequant[ac]) >> LS;
+        if (q) {
+          const int p = iscan_pos<KW, KH>(r, c, scan_class) + 1;
+          my_eob = p > my_eob ? p : my_eob;
+        }
+      }
+      qcoeff[out_off + rc] = (q ^ sign) - sign;
+      dqcoeff[out_off + rc] = (dq ^ sign) - sign;
+    }
+  }
+  my_eob = group_max<LPB>(my_eob);
+  if (live && lane == 0) eob[bi] = (uint16_t)my_eob;
+}
+
+struct XqLaunch {
+  hipStream_t stream;
+  const void *in0, *in1;
+  int stride0, stride1;
+  const aomhip_txb *blocks;
+  int n_blocks, grid_cols, uniform_type;
+  QuantArgs qa;
+  int32_t *coeff, *qcoeff, *dqcoeff;
+  uint16_t *eob;
+};
+
+template <int W, int H, bool HBD, int SRC> static int launch_xq(const XqLaunch &l) {
+  constexpr int LPB = W > H ? W : H;
+  constexpr int BPW = kXqThreads / LPB;
+  const int nwg = (l.n_blocks + BPW - 1) / BPW;
+  const int nwg8 = (nwg + 7) & ~7;
+  hipLaunchKernelGGL((xform_quant_kernel<W, H, HBD, SRC>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0, l.in1,
+                     l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff, l.qcoeff,
+                     l.dqcoeff, l.eob, nwg8);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+template <bool HBD, int SRC> static int dispatch_xq(int tx_size, const XqLaunch &l) {
+  switch (tx_size) {  // TX_SIZE order of av1/common/enums.h:169-193
+    case 0: return launch_xq<4, 4, HBD, SRC>(l);
+    case 1: return launch_xq<8, 8, HBD, SRC>(l);
+    case 2: return launch_xq<16, 16, HBD, SRC>(l);
+    case 3: return launch_xq<32, 32, HBD, SRC>(l);
+    case 4: return launch_xq<64, 64, HBD, SRC>(l);
+    case 5: return launch_xq<4, 8, HBD, SRC>(l);
+    case 6: return launch_xq<8, 4, HBD, SRC>(l);
+    case 7: return launch_xq<8, 16, HBD, SRC>(l);
+    case 8: return launch_xq<16, 8, HBD, SRC>(l);
+    case 9: return launch_xq<16, 32, HBD, SRC>(l);
+    case 10: return launch_xq<32, 16, HBD, SRC>(l);
+    case 11: return launch_xq<32, 64, HBD, SRC>(l);
+    case 12: return launch_xq<64, 32, HBD, SRC>(l);
+    case 13: return launch_xq<4, 16, HBD, SRC>(l);
+    case 14: return launch_xq<16, 4, HBD, SRC>(l);
+    case 15: return launch_xq<8, 32, HBD, SRC>(l);
+    case 16: return launch_xq<32, 8, HBD, SRC>(l);
+    case 17: return launch_xq<16, 64, HBD, SRC>(l);
+    case 18: return launch_xq<64, 16, HBD, SRC>(l);
+  }
+  set_error("bad tx_size %d", tx_size);
+  return AOMHIP_ERR_INVALID;
+}
+
+static const int kTxW[19] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64 };
+static const int kTxH[19] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16 };
+
+static bool type_ok(int tx_size, int tx_type) {
+  // what av1_get_fwd_txfm_cfg can serve (av1_txfm.c:89-96): ADST <= 16 points, identity <= 32, 64 DCT only
+  static const uint8_t vk[16] = { 0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3 };
+  static const uint8_t hk[16] = { 0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2 };
+  if (tx_type < 0 || tx_type > 15) return false;
+  const int vmax = vk[tx_type] == 0 ? 64 : vk[tx_type] == 3 ? 32 : 16;
+  const int hmax = hk[tx_type] == 0 ? 64 : hk[tx_type] == 3 ? 32 : 16;
+  return kTxH[tx_size] <= vmax && kTxW[tx_size] <= hmax;
+}
+
+static QuantArgs to_args(const aomhip_quant_params *q) {
+  QuantArgs a;
+  for (int i = 0; i < 2; ++i) {
+    a.zbin[i] = q->zbin[i];
+    a.round[i] = q->round[i];
+    a.quant[i] = q->quant[i];
+    a.quant_shift[i] = q->quant_shift[i];
+    a.dequant[i] = q->dequant[i];
+  }
+  return a;
+}
+
+}  // namespace aomhip
+
+using namespace aomhip;
+
+extern "C" {
+
+int aomhip_tx_size_wide(int tx_size) { return tx_size >= 0 && tx_size < 19 ? kTxW[tx_size] : 0; }
+int aomhip_tx_size_high(int tx_size) { return tx_size >= 0 && tx_size < 19 ? kTxH[tx_size] : 0; }
+int aomhip_tx_max_eob(int tx_size) {
+  if (tx_size < 0 || tx_size >= 19) return 0;
+  const int w = kTxW[tx_size] < 32 ? kTxW[tx_size] : 32, h = kTxH[tx_size] < 32 ? kTxH[tx_size] : 32;
+  return w * h;
+}
+
+int aomhip_xform_quant_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int tx_size,
+                             const aomhip_txb *d_blocks, int n_blocks, int grid_cols, int uniform_tx_type,
+                             const aomhip_quant_params *qparams, int is_hbd, int32_t *d_coeff, int32_t *d_qcoeff,
+                             int32_t *d_dqcoeff, uint16_t *d_eob) {
+  if (!ctx || !d_residual || !qparams || !d_qcoeff || !d_dqcoeff || !d_eob || tx_size < 0 || tx_size >= 19 ||
+      n_blocks < 0 || (!d_blocks && (grid_cols <= 0 || !type_ok(tx_size, uniform_tx_type)))) {
+    set_error("aomhip_xform_quant_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  XqLaunch l{ ctx->stream, d_residual, nullptr, residual_stride, 0, d_blocks, n_blocks, grid_cols, uniform_tx_type,
+              to_args(qparams), d_coeff, d_qcoeff, d_dqcoeff, d_eob };
+  return is_hbd ? dispatch_xq<true, 0>(tx_size, l) : dispatch_xq<false, 0>(tx_size, l);
+}
+
+int aomhip_subtract_xform_quant_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *pred, int frame,
+                                      int tx_size, const aomhip_txb *d_blocks, int n_blocks, int grid_cols,
+                                      int uniform_tx_type, const aomhip_quant_params *qparams, int32_t *d_coeff,
+                                      int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
+  if (!ctx || !src || !pred || !src->base || !pred->base || !qparams || !d_qcoeff || !d_dqcoeff || !d_eob ||
+      tx_size < 0 || tx_size >= 19 || n_blocks < 0 || frame < 0 || frame >= src->n_frames ||
+      frame >= pred->n_frames || (src->bit_depth == 8) != (pred->bit_depth == 8) ||
+      (!d_blocks && (grid_cols <= 0 || !type_ok(tx_size, uniform_tx_type)))) {
+    set_error("aomhip_subtract_xform_quant_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  const size_t esz = src->bit_depth == 8 ? 1 : 2;
+  const char *s = static_cast<const char *>(src->base) +
+                  ((size_t)frame * src->frame_stride + (size_t)src->border * src->stride + src->border) * esz;
+  const char *p = static_cast<const char *>(pred->base) +
+                  ((size_t)frame * pred->frame_stride + (size_t)pred->border * pred->stride + pred->border) * esz;
+  XqLaunch l{ ctx->stream, s, p, src->stride, pred->stride, d_blocks, n_blocks, grid_cols, uniform_tx_type,
+              to_args(qparams), d_coeff, d_qcoeff, d_dqcoeff, d_eob };
+  // encodemb.c:323: the quantiser flavour follows the bit depth of the planes
+  return src->bit_depth == 8 ? dispatch_xq<false, 1>(tx_size, l) : dispatch_xq<true, 2>(tx_size, l);
+}
+
+}  // extern "C"

@@ -143,6 +143,51 @@ int aomhip_sad_x4d_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip
                          int n_frames, int bw, int bh, int flags, const aomhip_sad_x4d_cand *d_groups,
                          int n_groups, int64_t group_frame_stride, uint32_t *d_out);
 
+/* ------------------------------------------------------------------ batched forward transform + quantise */
+
+/* One transform block of a batch (all blocks of a call share one TX_SIZE). */
+typedef struct {
+  int32_t x, y;        /* top-left sample of the block in the residual (or src/pred) plane */
+  uint32_t out_offset; /* first coefficient of this block in d_coeff/d_qcoeff/d_dqcoeff (the reference's
+                          BLOCK_OFFSET(block) * 16 convention, av1/encoder/encodemb.c:297-299) */
+  uint8_t tx_type;     /* TX_TYPE, aom_dsp/txfm_common.h:52-68 */
+  uint8_t reserved[3];
+} aomhip_txb;
+
+/* Per-plane quantiser rows for one qindex: element 0 = DC, 1 = AC.  Same meaning as the
+ * zbin/round/quant/quant_shift/dequant pointers of aom_quantize_b (aom_dsp_rtcd_defs.pl:653-691);
+ * av1_build_quantizer (av1/encoder/av1_quantize.c:605-674) fills them on the host. */
+typedef struct {
+  int16_t zbin[2], round[2], quant[2], quant_shift[2], dequant[2];
+} aomhip_quant_params;
+
+int aomhip_tx_size_wide(int tx_size); /* tx_size_wide / tx_size_high (av1/common/common_data.h) */
+int aomhip_tx_size_high(int tx_size);
+int aomhip_tx_max_eob(int tx_size);   /* av1_get_max_eob (av1/common/blockd.h:1600-1608): coefficients per block */
+
+/* av1_xform_quant (av1/encoder/encodemb.c:288-341) over a list of transform blocks of one TX_SIZE:
+ * av1_fwd_txfm2d_WxH (av1_rtcd_defs.pl:355-399) on the int16 residual, then aom_quantize_b /
+ * _32x32 / _64x64 (or aom_highbd_quantize_b* when is_hbd) chosen by av1_get_tx_scale exactly like
+ * av1_quantize_b_facade (av1_quantize.c:302-372), quant matrices off (NULL qm pointers).
+ *   d_residual     device int16 samples, residual_stride elements per row
+ *   d_blocks       device list, or NULL for "grid mode": block i is at
+ *                  ((i % grid_cols) * W, (i / grid_cols) * H), all of type uniform_tx_type,
+ *                  coefficients at i * aomhip_tx_max_eob(tx_size)
+ *   d_coeff        transform coefficients (reference layout: transposed, 64-point sizes packed to
+ *                  32); may be NULL when only the quantised levels are wanted
+ *   d_qcoeff / d_dqcoeff / d_eob[n_blocks]   as aom_quantize_b writes them */
+int aomhip_xform_quant_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int tx_size,
+                             const aomhip_txb *d_blocks, int n_blocks, int grid_cols, int uniform_tx_type,
+                             const aomhip_quant_params *qparams, int is_hbd, int32_t *d_coeff, int32_t *d_qcoeff,
+                             int32_t *d_dqcoeff, uint16_t *d_eob);
+/* Same with aom_subtract_block / aom_highbd_subtract_block (aom_dsp/subtract.c:20-53) fused in
+ * front: residual = src - pred of frame `frame`, block positions relative to the visible origin.
+ * 8-bit planes use aom_quantize_b*, 10/12-bit planes aom_highbd_quantize_b* (encodemb.c:323). */
+int aomhip_subtract_xform_quant_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *pred, int frame,
+                                      int tx_size, const aomhip_txb *d_blocks, int n_blocks, int grid_cols,
+                                      int uniform_tx_type, const aomhip_quant_params *qparams, int32_t *d_coeff,
+                                      int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);
+
 /* ------------------------------------------------------------------ rtcd-signature conformance entry points */
 
 /* aom_dsp_rtcd_defs.pl:762-763 aom_sad{W}x{H} / aom_sad_skip_{W}x{H}; host pointers. */

@@ -57,3 +57,38 @@ void orc_sad_x4d_batch(const void *src_origin, int src_stride, const void *ref_o
     }
   }
 }
+
+/* ---- av1_xform_quant over a block list (aomhip_xform_quant_batch's checker / CPU baseline) ---- */
+typedef struct { int32_t x, y; uint32_t out_offset; uint8_t tx_type; uint8_t reserved[3]; } orc_txb; /* == aomhip_txb */
+
+void orc_xform_quant_batch(const int16_t *residual, int stride, int tx_size, const orc_txb *blocks, int n,
+                           int grid_cols, int uniform_type, const int16_t q[5][2], int is_hbd, int32_t *coeff,
+                           int32_t *qcoeff, int32_t *dqcoeff, uint16_t *eob, int threads, int reps) {
+  const int w = orc_tx_wide[tx_size], h = orc_tx_high[tx_size];
+  const int kw = w < 32 ? w : 32, kh = h < 32 ? h : 32, nc = kw * kh;
+  const int log_scale = (w * h > 256) + (w * h > 1024); /* av1_get_tx_scale, av1/common/idct.c:24-28 */
+  int16_t scans[16][1024], iscans[16][1024];
+  uint8_t have[16] = { 0 };
+  for (int i = 0; i < n; ++i) {
+    const int tt = blocks ? blocks[i].tx_type : uniform_type;
+    if (!have[tt]) { orc_get_scan(tx_size, tt, scans[tt], iscans[tt]); have[tt] = 1; }
+  }
+  if (threads < 1) threads = 1;
+  if (reps < 1) reps = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (long long it = 0; it < (long long)n * reps; ++it) {
+    const int i = (int)(it % n);
+    int32_t full[64 * 64];
+    const int bx = blocks ? blocks[i].x : (i % grid_cols) * w, by = blocks ? blocks[i].y : (i / grid_cols) * h;
+    const int tt = blocks ? blocks[i].tx_type : uniform_type;
+    const size_t off = blocks ? blocks[i].out_offset : (size_t)i * nc;
+    orc_fwd_txfm2d(residual + (ptrdiff_t)by * stride + bx, full, stride, tx_size, tt, is_hbd ? 10 : 8);
+    if (coeff) for (int k = 0; k < nc; ++k) coeff[off + k] = full[k];
+    if (is_hbd)
+      orc_highbd_quantize_b(full, nc, q[0], q[1], q[2], q[3], qcoeff + off, dqcoeff + off, q[4], &eob[i], scans[tt],
+                            iscans[tt], log_scale);
+    else
+      orc_quantize_b(full, nc, q[0], q[1], q[2], q[3], qcoeff + off, dqcoeff + off, q[4], &eob[i], scans[tt],
+                     iscans[tt], log_scale);
+  }
+}

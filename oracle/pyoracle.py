@@ -213,3 +213,23 @@ def quantize_b(coeff, q, scan, iscan, log_scale, highbd=False):
     f(coeff, coeff.size, q["zbin"], q["round"], q["quant"], q["quant_shift"], qc, dq, q["dequant"], C.byref(eob),
       np.ascontiguousarray(scan, np.int16), np.ascontiguousarray(iscan, np.int16), log_scale)
     return qc, dq, eob.value
+
+
+lib.orc_xform_quant_batch.restype = None
+lib.orc_xform_quant_batch.argtypes = [_vp, _i, _i, _vp, _i, _i, _i, _i16, _i, _vp, _vp, _vp, _vp, _i, _i]
+
+
+def xform_quant_batch(residual, tx_size, blocks, n, grid_cols, tx_type, q, is_hbd, total_coeffs, want_coeff=True,
+                      threads=1, reps=1):
+    """residual: int16 2-D array; blocks: structured array (x,y,out_offset,tx_type) or None (grid mode);
+    q: dict from build_quantizer_y.  -> (coeff|None, qcoeff, dqcoeff, eob)"""
+    residual = np.ascontiguousarray(residual, np.int16)
+    qt = np.ascontiguousarray(np.stack([q[k] for k in ("zbin", "round", "quant", "quant_shift", "dequant")]), np.int16)
+    coeff = np.zeros(total_coeffs, np.int32) if want_coeff else None
+    qc, dq = np.zeros(total_coeffs, np.int32), np.zeros(total_coeffs, np.int32)
+    eob = np.zeros(n, np.uint16)
+    bl = np.ascontiguousarray(blocks) if blocks is not None else None
+    lib.orc_xform_quant_batch(residual.ctypes.data, residual.shape[1], tx_size, bl.ctypes.data if bl is not None else None,
+                              n, grid_cols, tx_type, qt, int(is_hbd), coeff.ctypes.data if want_coeff else None,
+                              qc.ctypes.data, dq.ctypes.data, eob.ctypes.data, threads, reps)
+    return coeff, qc, dq, eob

@@ -1,0 +1,175 @@
+"""Parity of the fused forward-transform + quantise HIP kernel with the oracle (bit-exact), through
+the C ABI: all 19 transform sizes x every servable TX_TYPE, low-bd and high-bd quantisers, list
+mode / grid mode / fused-subtract mode, qindex sweep, extreme inputs (mirrors
+test/av1_fwd_txfm2d_test.cc:243-297 input classes and test/quantize_func_test.cc:202-259)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_list(hip, oracle, ctx, residual, tx_size, blocks, q, is_hbd, want_coeff=True):
+    n = len(blocks)
+    nc = hip.capi.lib.aomhip_tx_max_eob(tx_size)
+    total = int(blocks["out_offset"].max()) + nc if n else 0
+    d_res = ctx.to_device(residual)
+    d_blk = ctx.to_device(blocks)
+    d_c = ctx.malloc(total * 4) if want_coeff else None
+    d_q, d_dq, d_e = ctx.malloc(total * 4), ctx.malloc(total * 4), ctx.malloc(max(2 * n, 16))
+    for d in (d_q, d_dq):
+        hip.capi.check(hip.capi.lib.aomhip_memset(ctx.h, d, 0x5A, total * 4))
+    qp = hip.capi.QuantParams.from_tables(q)
+    ctx.xform_quant_batch(d_res, residual.shape[1], tx_size, d_blk, n, 0, 0, qp, is_hbd, d_c, d_q, d_dq, d_e)
+    got = (ctx.from_device(d_c, (total,), np.int32) if want_coeff else None, ctx.from_device(d_q, (total,), np.int32),
+           ctx.from_device(d_dq, (total,), np.int32), ctx.from_device(d_e, (n,), np.uint16))
+    for d in (d_res, d_blk, d_c, d_q, d_dq, d_e):
+        if d:
+            ctx.free(d)
+    want = oracle.xform_quant_batch(residual, tx_size, blocks, n, 0, 0, q, is_hbd, total, want_coeff, threads=4)
+    return got, want
+
+
+def _blocks(hip, rng, W, H, w, h, n, types, nc, shuffle=True):
+    b = np.zeros(n, hip.capi.txb_dtype)
+    b["x"] = rng.integers(0, W - w + 1, n)
+    b["y"] = rng.integers(0, H - h + 1, n)
+    b["tx_type"] = rng.choice(types, n)
+    order = rng.permutation(n) if shuffle else np.arange(n)
+    b["out_offset"] = order * nc  # the reference's BLOCK_OFFSET is arbitrary per block
+    return b
+
+
+@pytest.mark.parametrize("is_hbd", [False, True])
+@pytest.mark.parametrize("tx_size", range(19))
+def test_all_sizes_all_types_random(hip, oracle, ctx, tx_size, is_hbd):
+    w, h = oracle.TX_W[tx_size], oracle.TX_H[tx_size]
+    types = [t for t in range(16) if oracle.lib.orc_txfm_valid(tx_size, t)]
+    rng = np.random.default_rng(tx_size * 2 + is_hbd)
+    W, H = 192, 160
+    nc = hip.capi.lib.aomhip_tx_max_eob(tx_size)
+    bits = 11 if is_hbd else 9  # residual of 10-bit / 8-bit video
+    residual = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), (H, W)).astype(np.int16)
+    n = 301 if w * h <= 256 else 67  # ragged
+    blocks = _blocks(hip, rng, W, H, w, h, n, types, nc)
+    for qindex in (0, 60, 255):
+        q = oracle.build_quantizer_y(10 if is_hbd else 8, qindex)
+        got, want = _run_list(hip, oracle, ctx, residual, tx_size, blocks, q, is_hbd)
+        for g, wv, name in zip(got, want, ("coeff", "qcoeff", "dqcoeff", "eob")):
+            assert np.array_equal(g, wv), (tx_size, is_hbd, qindex, name)
+
+
+@pytest.mark.parametrize("tx_size", [0, 1, 2, 3, 4, 9, 12, 17])
+def test_extreme_inputs(hip, oracle, ctx, tx_size):
+    """all-max / all-min / alternating residuals (av1_fwd_txfm2d_test.cc:264-269 uses +-(1<<bd)-1),
+    DC-only and zero blocks (quantize_func_test.cc ZeroInput / DcOnly / LargeNegativeInput)."""
+    w, h = oracle.TX_W[tx_size], oracle.TX_H[tx_size]
+    types = [t for t in range(16) if oracle.lib.orc_txfm_valid(tx_size, t)]
+    nc = hip.capi.lib.aomhip_tx_max_eob(tx_size)
+    pats = []
+    for v in (1023, -1023, 255, -256, 0, 4095, -4096):
+        pats.append(np.full((h, w), v, np.int16))
+    chk = np.indices((h, w)).sum(0) % 2
+    pats.append(np.where(chk, 1023, -1023).astype(np.int16))
+    one = np.zeros((h, w), np.int16); one[0, 0] = -8191; pats.append(one)
+    residual = np.concatenate(pats, axis=1)
+    n = len(pats) * len(types)
+    blocks = np.zeros(n, hip.capi.txb_dtype)
+    k = 0
+    for pi in range(len(pats)):
+        for t in types:
+            blocks[k] = (pi * w, 0, k * nc, t, (0, 0, 0)); k += 1
+    for is_hbd in (False, True):
+        for qindex in (1, 100):
+            q = oracle.build_quantizer_y(12 if is_hbd else 8, qindex)
+            got, want = _run_list(hip, oracle, ctx, residual, tx_size, blocks, q, is_hbd)
+            for g, wv, name in zip(got, want, ("coeff", "qcoeff", "dqcoeff", "eob")):
+                assert np.array_equal(g, wv), (tx_size, is_hbd, qindex, name)
+
+
+def test_grid_mode_and_null_coeff(hip, oracle, ctx):
+    rng = np.random.default_rng(11)
+    W, H = 256, 128
+    residual = rng.integers(-256, 256, (H, W)).astype(np.int16)
+    for tx_size, tx_type in [(0, 0), (1, 3), (2, 0), (3, 0), (2, 9), (8, 5)]:
+        w, h = oracle.TX_W[tx_size], oracle.TX_H[tx_size]
+        gc, n = W // w, (W // w) * (H // h)
+        nc = hip.capi.lib.aomhip_tx_max_eob(tx_size)
+        q = oracle.build_quantizer_y(8, 100)
+        d_res = ctx.to_device(residual)
+        d_q, d_dq, d_e = ctx.malloc(n * nc * 4), ctx.malloc(n * nc * 4), ctx.malloc(2 * n)
+        ctx.xform_quant_batch(d_res, W, tx_size, None, n, gc, tx_type, hip.capi.QuantParams.from_tables(q), False, None,
+                              d_q, d_dq, d_e)
+        _, wq, wdq, we = oracle.xform_quant_batch(residual, tx_size, None, n, gc, tx_type, q, False, n * nc, False, 4)
+        assert np.array_equal(ctx.from_device(d_q, (n * nc,), np.int32), wq)
+        assert np.array_equal(ctx.from_device(d_dq, (n * nc,), np.int32), wdq)
+        assert np.array_equal(ctx.from_device(d_e, (n,), np.uint16), we)
+        for d in (d_res, d_q, d_dq, d_e):
+            ctx.free(d)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_fused_subtract(hip, oracle, ctx, bd):
+    """aom_subtract_block + transform + quantise in one launch == oracle subtract then xform_quant."""
+    rng = np.random.default_rng(bd)
+    W, H, border = 128, 96, 32
+    src = hip.synth.lcg_frame(W, H, 5, 0, bd)
+    pred = np.clip(src.astype(np.int32) + rng.integers(-40, 41, (H, W)), 0, (1 << bd) - 1).astype(src.dtype)
+    ps, pp = ctx.planes_alloc(W, H, border, bd, 2), ctx.planes_alloc(W, H, border, bd, 2)
+    ctx.planes_upload(ps, 1, src)
+    ctx.planes_upload(pp, 1, pred)
+    residual = (src.astype(np.int32) - pred.astype(np.int32)).astype(np.int16)  # subtract.c:20-53
+    for tx_size in (0, 2, 3, 7):
+        w, h = oracle.TX_W[tx_size], oracle.TX_H[tx_size]
+        types = [t for t in range(16) if oracle.lib.orc_txfm_valid(tx_size, t)]
+        nc = hip.capi.lib.aomhip_tx_max_eob(tx_size)
+        n = 97
+        blocks = _blocks(hip, rng, W, H, w, h, n, types, nc)
+        q = oracle.build_quantizer_y(bd, 80)
+        d_blk = ctx.to_device(blocks)
+        d_c, d_q, d_dq, d_e = ctx.malloc(n * nc * 4), ctx.malloc(n * nc * 4), ctx.malloc(n * nc * 4), ctx.malloc(2 * n)
+        ctx.subtract_xform_quant_batch(ps, pp, 1, tx_size, d_blk, n, 0, 0, hip.capi.QuantParams.from_tables(q), d_c,
+                                       d_q, d_dq, d_e)
+        wc, wq, wdq, we = oracle.xform_quant_batch(residual, tx_size, blocks, n, 0, 0, q, bd > 8, n * nc, True, 4)
+        assert np.array_equal(ctx.from_device(d_c, (n * nc,), np.int32), wc)
+        assert np.array_equal(ctx.from_device(d_q, (n * nc,), np.int32), wq)
+        assert np.array_equal(ctx.from_device(d_dq, (n * nc,), np.int32), wdq)
+        assert np.array_equal(ctx.from_device(d_e, (n,), np.uint16), we)
+        for d in (d_blk, d_c, d_q, d_dq, d_e):
+            ctx.free(d)
+    ctx.planes_free(ps); ctx.planes_free(pp)
+
+
+def test_full_size_1080p_properties(hip, oracle, ctx):
+    """BASELINE configs[2] at full size (all 16x16 blocks of a 1920x1088 residual plane): exact vs the
+    oracle, plus size-independent properties: dqcoeff == qcoeff*dequant>>log_scale, eob consistent with
+    the scan, zero residual -> all zero."""
+    rng = np.random.default_rng(3)
+    W, H = 1920, 1088
+    residual = ((rng.integers(0, 1 << 16, (H, W)) & 511) - 256).astype(np.int16)
+    tx_size, w = 2, 16
+    gc, n, nc = W // w, (W // w) * (H // w), 256
+    assert n == 8160
+    q = oracle.build_quantizer_y(8, 100)
+    d_res = ctx.to_device(residual)
+    d_c, d_q, d_dq, d_e = ctx.malloc(n * nc * 4), ctx.malloc(n * nc * 4), ctx.malloc(n * nc * 4), ctx.malloc(2 * n)
+    ctx.xform_quant_batch(d_res, W, tx_size, None, n, gc, 0, hip.capi.QuantParams.from_tables(q), False, d_c, d_q, d_dq,
+                          d_e)
+    gq = ctx.from_device(d_q, (n, nc), np.int32)
+    gdq = ctx.from_device(d_dq, (n, nc), np.int32)
+    ge = ctx.from_device(d_e, (n,), np.uint16)
+    gcf = ctx.from_device(d_c, (n * nc,), np.int32)
+    wc, wq, wdq, we = oracle.xform_quant_batch(residual, tx_size, None, n, gc, 0, q, False, n * nc, True, threads=8)
+    assert np.array_equal(gcf, wc) and np.array_equal(gq.ravel(), wq) and np.array_equal(gdq.ravel(), wdq)
+    assert np.array_equal(ge, we)
+    deq = np.where(np.arange(nc) == 0, int(q["dequant"][0]), int(q["dequant"][1]))
+    assert np.array_equal(np.abs(gdq), np.abs(gq) * deq)
+    scan, _ = oracle.get_scan(tx_size, 0)
+    nz = gq[:, scan] != 0
+    last = np.where(nz.any(1), nc - np.argmax(nz[:, ::-1], axis=1), 0)
+    assert np.array_equal(ge, last)
+    hip.capi.check(hip.capi.lib.aomhip_memset(ctx.h, d_res, 0, residual.nbytes))
+    ctx.xform_quant_batch(d_res, W, tx_size, None, n, gc, 0, hip.capi.QuantParams.from_tables(q), False, d_c, d_q, d_dq,
+                          d_e)
+    assert not ctx.from_device(d_q, (n * nc,), np.int32).any() and not ctx.from_device(d_e, (n,), np.uint16).any()
+    for d in (d_res, d_c, d_q, d_dq, d_e):
+        ctx.free(d)
