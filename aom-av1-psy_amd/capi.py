@@ -37,6 +37,8 @@ class QuantParams(C.Structure):
 
 txb_dtype = np.dtype([("x", "<i4"), ("y", "<i4"), ("out_offset", "<u4"), ("tx_type", "u1"), ("reserved", "u1", (3,))])
 sad_cand_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2"), ("ry", "<i2")])
+var_cand_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2"), ("ry", "<i2"), ("xoff", "u1"), ("yoff", "u1"),
+                           ("reserved", "u1", (2,))])
 sad_x4d_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2", (4,)), ("ry", "<i2", (4,))])
 
 _vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
@@ -65,6 +67,13 @@ _protos = {
     "aomhip_planes_download": (C.c_int, [_vp, _PP, _i, _vp]),
     "aomhip_sad_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
     "aomhip_sad_x4d_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
+    "aomhip_variance_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp]),
+    "aomhip_sub_pixel_variance_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp]),
+    "aomhip_variance": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint)]),
+    "aomhip_sub_pixel_variance": (C.c_uint, [_vp, _i, _i, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint)]),
+    "aomhip_variance16x16": (C.c_uint, [_vp, _i, _vp, _i, C.POINTER(C.c_uint)]),
+    "aomhip_highbd_variance": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, _i, C.POINTER(C.c_uint)]),
+    "aomhip_highbd_sub_pixel_variance": (C.c_uint, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, C.POINTER(C.c_uint)]),
     "aomhip_tx_size_wide": (C.c_int, [_i]),
     "aomhip_tx_size_high": (C.c_int, [_i]),
     "aomhip_tx_max_eob": (C.c_int, [_i]),
@@ -186,3 +195,9 @@ class Context:
         check(lib.aomhip_subtract_xform_quant_batch(self.h, C.byref(src), C.byref(pred), frame, tx_size, d_blocks,
                                                     n_blocks, grid_cols, tx_type, C.byref(qp), d_coeff, d_qcoeff,
                                                     d_dqcoeff, d_eob), "aomhip_subtract_xform_quant_batch")
+
+    # ---- variance
+    def variance_batch(self, src, ref, first_frame, n_frames, bw, bh, d_cands, n, stride, d_var, d_sse, subpel=False):
+        f = lib.aomhip_sub_pixel_variance_batch if subpel else lib.aomhip_variance_batch
+        check(f(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, bw, bh, d_cands, n, stride, d_var, d_sse),
+              "aomhip_variance_batch")

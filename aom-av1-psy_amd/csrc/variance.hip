@@ -1,0 +1,324 @@
+// Batched variance / sub-pixel (bilinear) variance on gfx950.
+// Reference: aom_dsp/variance.c:56-73,141-163 (8-bit), :342-429,475-561 (highbd);
+// bilinear taps aom_dsp/aom_filter.h:43-50 (FILTER_BITS 7).
+//
+// Same lane mapping as the SAD kernels (sad.hip): a W x H block is cut into row units of up to
+// 16 bytes spread over TPC adjacent lanes; each lane accumulates sum(d) and sum(d*d) for its
+// units, TPC partials are folded with DPP / lane permutes, one lane applies the reference's
+// final formula (including the 10/12-bit rounding and the max(0, .) clamp).
+// Differences are formed element-wise in 32 bits; 8-bit block totals fit 32 bits (variance.c:56-73),
+// highbd totals are 64-bit (variance.c:342-362).
+// The sub-pixel form filters (W+1) x (H+1) reference pixels in registers (horizontal 2-tap to
+// 16 bits, vertical 2-tap to pixel range, +64 >> 7 each) and never materialises the reference's
+// fdata3 / temp2 scratch blocks.
+#include <type_traits>
+
+#include "common.h"
+
+namespace aomhip {
+
+struct __attribute__((packed, aligned(1))) VU128 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) VU64 { uint32_t v[2]; };
+struct __attribute__((packed, aligned(1))) VU32 { uint32_t v[1]; };
+template <int BYTES> struct VLoad;
+template <> struct VLoad<16> { using type = VU128; };
+template <> struct VLoad<8> { using type = VU64; };
+template <> struct VLoad<4> { using type = VU32; };
+
+__device__ constexpr uint8_t kBilinear[8][2] = { { 128, 0 }, { 112, 16 }, { 96, 32 }, { 80, 48 },
+                                                 { 64, 64 }, { 48, 80 },  { 32, 96 }, { 16, 112 } };
+
+template <int TPC> __device__ __forceinline__ int32_t gsum32(int32_t v) {
+  if constexpr (TPC >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+  if constexpr (TPC >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+  if constexpr (TPC >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+  if constexpr (TPC >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+  if constexpr (TPC >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (TPC >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+template <int TPC> __device__ __forceinline__ uint64_t gsum64(uint64_t v) {
+#pragma unroll
+  for (int m = 1; m < TPC; m <<= 1) v += __shfl_xor((unsigned long long)v, m, 64);
+  return v;
+}
+
+template <typename T, int W, int H> struct VarGeom {
+  static constexpr int kRowBytes = W * (int)sizeof(T);
+  static constexpr int kUnitBytes = kRowBytes < 16 ? kRowBytes : 16;
+  static constexpr int kUnitElems = kUnitBytes / (int)sizeof(T);
+  static constexpr int kUnitsPerRow = kRowBytes / kUnitBytes;
+  static constexpr int kUnits = kUnitsPerRow * H;
+  static constexpr int kTpcRaw = kUnits >= 2 ? kUnits / 2 : 1;
+  static constexpr int kTpc = kTpcRaw > 64 ? 64 : kTpcRaw;
+  static constexpr int kUnitsPerLane = kUnits / kTpc;
+};
+
+template <typename T, int N> __device__ __forceinline__ void load_elems(const T *p, int (&out)[N]) {
+  // N elements from an arbitrarily aligned address with one wide load
+  using L = typename VLoad<N * (int)sizeof(T)>::type;
+  const L raw = *reinterpret_cast<const L *>(p);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if constexpr (sizeof(T) == 1)
+      out[i] = (raw.v[i / 4] >> (8 * (i % 4))) & 0xFF;
+    else
+      out[i] = (raw.v[i / 2] >> (16 * (i % 2))) & 0xFFFF;
+  }
+}
+
+// variance.c:141-148 VAR / :383-420 HIGHBD_VAR final formulas
+template <int BD_CLASS /*0: 8-bit planes*/, int LOG2N>
+__device__ __forceinline__ void finish(int64_t sum64, uint64_t sse64, int bit_depth, uint32_t *var, uint32_t *sse) {
+  int32_t s;
+  uint32_t q;
+  if (bit_depth == 10) {
+    q = (uint32_t)((sse64 + 8) >> 4);
+    s = (int32_t)((sum64 + 2) >> 2);  // arithmetic shift of a possibly negative sum (aom_ports/mem.h:45)
+  } else if (bit_depth == 12) {
+    q = (uint32_t)((sse64 + 128) >> 8);
+    s = (int32_t)((sum64 + 8) >> 4);
+  } else {
+    q = (uint32_t)sse64;
+    s = (int32_t)sum64;
+  }
+  *sse = q;
+  const int64_t sq = ((int64_t)s * s) >> LOG2N;  // sum^2 >= 0: shift == division by W*H
+  if (bit_depth == 8) {
+    *var = q - (uint32_t)sq;
+  } else {
+    const int64_t v = (int64_t)q - sq;
+    *var = v >= 0 ? (uint32_t)v : 0;
+  }
+}
+
+constexpr int ilog2v(int n) { return n <= 1 ? 0 : 1 + ilog2v(n >> 1); }
+constexpr int kVarThreads = 256;
+
+// SUBPEL = false: variance(src block at (sx,sy), ref block at (rx,ry)), diff = src - ref.
+// SUBPEL = true : the ref block is interpolated at (rx + xoff/8, ry + yoff/8) first and diff = ref' - src
+//                 (variance.c:150-163; `a` is the reference, `b` the source, av1/encoder/mcomp.c:2327).
+template <typename T, int W, int H, bool SUBPEL>
+__global__ __launch_bounds__(kVarThreads) void variance_kernel(PlaneView<T> src, PlaneView<T> ref, int first_frame,
+                                                               const aomhip_var_cand *__restrict__ cands, int n_cands,
+                                                               int64_t cand_frame_stride, uint32_t *__restrict__ out_var,
+                                                               uint32_t *__restrict__ out_sse, int bpf8, int bit_depth) {
+  using G = VarGeom<T, W, H>;
+  constexpr int kCpb = kVarThreads / G::kTpc;
+  constexpr int E = G::kUnitElems;
+  const unsigned b = blockIdx.x;
+  const unsigned f_rel = b / bpf8;
+  const unsigned x = xcd_chunked_index(b % bpf8, bpf8);
+  const int lane_in_cand = threadIdx.x % G::kTpc;
+  const int ci = x * kCpb + threadIdx.x / G::kTpc;
+  if (ci >= n_cands) return;
+  const aomhip_var_cand c = cands[(int64_t)f_rel * cand_frame_stride + ci];
+  const int64_t fo = (int64_t)(first_frame + f_rel);
+  const T *sp = src.origin + fo * src.frame_stride + (int64_t)c.sy * src.stride + c.sx;
+  const T *rp = ref.origin + fo * ref.frame_stride + (int64_t)c.ry * ref.stride + c.rx;
+  const int fx0 = kBilinear[c.xoff & 7][0], fx1 = kBilinear[c.xoff & 7][1];
+  const int fy0 = kBilinear[c.yoff & 7][0], fy1 = kBilinear[c.yoff & 7][1];
+  int64_t sum = 0;
+  uint64_t sse = 0;
+#pragma unroll
+  for (int k = 0; k < G::kUnitsPerLane; ++k) {
+    const int u = lane_in_cand + k * G::kTpc;
+    const int row = u / G::kUnitsPerRow;
+    const int col = (u % G::kUnitsPerRow) * E;
+    int bpx[E], apx[E];
+    load_elems<T, E>(sp + (int64_t)row * src.stride + col, bpx);
+    if constexpr (!SUBPEL) {
+      load_elems<T, E>(rp + (int64_t)row * ref.stride + col, apx);
+    } else {
+      int r0[E], r0n[E], r1[E], r1n[E];
+      const T *a0 = rp + (int64_t)row * ref.stride + col;
+      const T *a1 = a0 + ref.stride;
+      load_elems<T, E>(a0, r0);
+      load_elems<T, E>(a0 + 1, r0n);
+      load_elems<T, E>(a1, r1);
+      load_elems<T, E>(a1 + 1, r1n);
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const int h0 = (r0[i] * fx0 + r0n[i] * fx1 + 64) >> 7;  // first pass, uint16 range
+        const int h1 = (r1[i] * fx0 + r1n[i] * fx1 + 64) >> 7;
+        apx[i] = (h0 * fy0 + h1 * fy1 + 64) >> 7;               // second pass
+        if constexpr (sizeof(T) == 1) apx[i] &= 0xFF;           // stored to uint8_t temp2 (variance.c:155)
+        else apx[i] &= 0xFFFF;
+      }
+    }
+    int32_t us = 0;
+    uint32_t uq = 0;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      // plain variance is called as vf(src, ref): d = src - ref (av1/encoder/mcomp.c get_mvpred_var_cost);
+      // the sub-pixel form as svf(ref, xoff, yoff, src): d = interpolated ref - src (mcomp.c:2327).  The sign
+      // matters for the 10/12-bit rounding of the (possibly negative) sum.
+      const int d = SUBPEL ? apx[i] - bpx[i] : bpx[i] - apx[i];
+      us += d;
+      uq += (uint32_t)(d * d);
+    }
+    sum += us;
+    sse += uq;  // <= 8 * 4095^2 per unit: no 32-bit overflow inside a unit
+  }
+  if constexpr (sizeof(T) == 1) {
+    sum = gsum32<G::kTpc>((int32_t)sum);
+    sse = (uint32_t)gsum32<G::kTpc>((int32_t)(uint32_t)sse);  // 8-bit: totals fit 32 bits (variance.c:56-73)
+  } else {
+    sum = (int64_t)gsum64<G::kTpc>((uint64_t)sum);
+    sse = gsum64<G::kTpc>(sse);
+  }
+  if (lane_in_cand == 0) {
+    uint32_t v, q;
+    finish<0, ilog2v(W * H)>(sum, sse, bit_depth, &v, &q);
+    out_var[(int64_t)f_rel * n_cands + ci] = v;
+    out_sse[(int64_t)f_rel * n_cands + ci] = q;
+  }
+}
+
+struct VarLaunch {
+  hipStream_t stream;
+  int first_frame, n_frames, bit_depth;
+};
+
+template <typename T, int W, int H, bool SUBPEL>
+static int launch_var(const VarLaunch &l, const PlaneView<T> &s, const PlaneView<T> &r, const aomhip_var_cand *c, int n,
+                      int64_t cfs, uint32_t *var, uint32_t *sse) {
+  using G = VarGeom<T, W, H>;
+  constexpr int kCpb = kVarThreads / G::kTpc;
+  const int bpf = (n + kCpb - 1) / kCpb;
+  const int bpf8 = (bpf + 7) & ~7;
+  hipLaunchKernelGGL((variance_kernel<T, W, H, SUBPEL>), dim3((unsigned)bpf8 * l.n_frames), dim3(kVarThreads), 0,
+                     l.stream, s, r, l.first_frame, c, n, cfs, var, sse, bpf8, l.bit_depth);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+#define AOMHIP_FOR_BLOCK_SIZES(X)                                                                                \
+  X(4, 4) X(4, 8) X(8, 4) X(8, 8) X(8, 16) X(16, 8) X(16, 16) X(16, 32) X(32, 16) X(32, 32) X(32, 64) X(64, 32) \
+  X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(4, 16) X(16, 4) X(8, 32) X(32, 8) X(16, 64) X(64, 16)
+
+template <typename T>
+static int dispatch_var(bool subpel, const VarLaunch &l, const PlaneView<T> &s, const PlaneView<T> &r, int bw, int bh,
+                        const aomhip_var_cand *c, int n, int64_t cfs, uint32_t *var, uint32_t *sse) {
+#define X(W, H)                                                                                  \
+  if (bw == W && bh == H)                                                                        \
+    return subpel ? launch_var<T, W, H, true>(l, s, r, c, n, cfs, var, sse)                      \
+                  : launch_var<T, W, H, false>(l, s, r, c, n, cfs, var, sse);
+  AOMHIP_FOR_BLOCK_SIZES(X)
+#undef X
+  set_error("unsupported block size %dx%d", bw, bh);
+  return AOMHIP_ERR_INVALID;
+}
+
+static int var_batch(bool subpel, aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame,
+                     int n_frames, int bw, int bh, const aomhip_var_cand *d_cands, int n_cands,
+                     int64_t cand_frame_stride, uint32_t *d_var, uint32_t *d_sse) {
+  if (!ctx || !src || !ref || !src->base || !ref->base || !d_var || !d_sse || (n_cands > 0 && !d_cands) ||
+      !valid_block(bw, bh) || (src->bit_depth == 8) != (ref->bit_depth == 8) || n_cands < 0 || n_frames < 0 ||
+      first_frame < 0 || first_frame + n_frames > src->n_frames || first_frame + n_frames > ref->n_frames) {
+    set_error("variance batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_cands == 0 || n_frames == 0) return AOMHIP_OK;
+  VarLaunch l{ ctx->stream, first_frame, n_frames, src->bit_depth };
+  if (src->bit_depth == 8)
+    return dispatch_var<uint8_t>(subpel, l, view_of<uint8_t>(*src), view_of<uint8_t>(*ref), bw, bh, d_cands, n_cands,
+                                 cand_frame_stride, d_var, d_sse);
+  return dispatch_var<uint16_t>(subpel, l, view_of<uint16_t>(*src), view_of<uint16_t>(*ref), bw, bh, d_cands, n_cands,
+                                cand_frame_stride, d_var, d_sse);
+}
+
+// rtcd-signature path: a = (bw+1) x (bh+1) pixels at a_ptr, b = bw x bh at b_ptr, host memory.
+template <typename T>
+static uint32_t host_variance(bool subpel, const T *a, int a_stride, int xoff, int yoff, const T *b, int b_stride, int bw,
+                              int bh, int bit_depth, uint32_t *sse_out) {
+  aomhip_ctx *ctx = default_ctx();
+  if (!valid_block(bw, bh)) {
+    set_error("unsupported block size %dx%d", bw, bh);
+    fatal("aomhip_variance");
+  }
+  const int aw = bw + (subpel ? 1 : 0), ah = bh + (subpel ? 1 : 0);
+  const int astr = (aw + 15) & ~15;  // padded so the kernel's trailing wide load stays inside the staging area
+  const size_t a_bytes = (size_t)astr * (ah + 1) * sizeof(T) + 64, b_bytes = (size_t)bw * bh * sizeof(T);
+  const size_t b_off = (a_bytes + 15) & ~(size_t)15, c_off = (b_off + b_bytes + 15) & ~(size_t)15;
+  const size_t o_off = c_off + 16, total = o_off + 16;
+  char *h = static_cast<char *>(pinned(ctx, total));
+  char *d = static_cast<char *>(scratch(ctx, total));
+  if (!h || !d) fatal("aomhip_variance scratch");
+  memset(h, 0, total);
+  for (int r = 0; r < ah; ++r)
+    memcpy(reinterpret_cast<T *>(h) + (size_t)r * astr, a + (size_t)r * a_stride, (size_t)aw * sizeof(T));
+  for (int r = 0; r < bh; ++r)
+    memcpy(reinterpret_cast<T *>(h + b_off) + (size_t)r * bw, b + (size_t)r * b_stride, (size_t)bw * sizeof(T));
+  aomhip_var_cand *hc = reinterpret_cast<aomhip_var_cand *>(h + c_off);
+  *hc = aomhip_var_cand{ 0, 0, 0, 0, (uint8_t)xoff, (uint8_t)yoff, { 0, 0 } };
+  if (hipMemcpyAsync(d, h, o_off, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) fatal("aomhip_variance H2D");
+  // sub-pixel: a is the (interpolated) "ref" operand, b the "src" operand; plain: variance(a, b) = a - b, so a
+  // takes the src slot.
+  PlaneView<T> pa{ reinterpret_cast<const T *>(d), 0, astr };
+  PlaneView<T> pb{ reinterpret_cast<const T *>(d + b_off), 0, bw };
+  const PlaneView<T> &sv = subpel ? pb : pa;
+  const PlaneView<T> &rv = subpel ? pa : pb;
+  VarLaunch l{ ctx->stream, 0, 1, bit_depth };
+  uint32_t *dv = reinterpret_cast<uint32_t *>(d + o_off);
+  if (dispatch_var<T>(subpel, l, sv, rv, bw, bh, reinterpret_cast<const aomhip_var_cand *>(d + c_off), 1, 0, dv,
+                      dv + 1) != AOMHIP_OK)
+    fatal("aomhip_variance launch");
+  if (hipMemcpyAsync(h + o_off, d + o_off, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess)
+    fatal("aomhip_variance D2H");
+  const uint32_t *res = reinterpret_cast<const uint32_t *>(h + o_off);
+  if (sse_out) *sse_out = res[1];
+  return res[0];
+}
+
+}  // namespace aomhip
+
+using namespace aomhip;
+
+extern "C" {
+
+int aomhip_variance_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame,
+                          int n_frames, int bw, int bh, const aomhip_var_cand *d_cands, int n_cands,
+                          int64_t cand_frame_stride, uint32_t *d_var, uint32_t *d_sse) {
+  return var_batch(false, ctx, src, ref, first_frame, n_frames, bw, bh, d_cands, n_cands, cand_frame_stride, d_var,
+                   d_sse);
+}
+
+int aomhip_sub_pixel_variance_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref,
+                                    int first_frame, int n_frames, int bw, int bh, const aomhip_var_cand *d_cands,
+                                    int n_cands, int64_t cand_frame_stride, uint32_t *d_var, uint32_t *d_sse) {
+  return var_batch(true, ctx, src, ref, first_frame, n_frames, bw, bh, d_cands, n_cands, cand_frame_stride, d_var,
+                   d_sse);
+}
+
+unsigned int aomhip_variance(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int bw, int bh,
+                             unsigned int *sse) {
+  return host_variance<uint8_t>(false, a, a_stride, 0, 0, b, b_stride, bw, bh, 8, sse);
+}
+
+unsigned int aomhip_sub_pixel_variance(const uint8_t *a, int a_stride, int xoffset, int yoffset, const uint8_t *b,
+                                       int b_stride, int bw, int bh, unsigned int *sse) {
+  return host_variance<uint8_t>(true, a, a_stride, xoffset, yoffset, b, b_stride, bw, bh, 8, sse);
+}
+
+unsigned int aomhip_variance16x16(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, unsigned int *sse) {
+  return aomhip_variance(a, a_stride, b, b_stride, 16, 16, sse);
+}
+
+unsigned int aomhip_highbd_variance(const uint8_t *a8, int a_stride, const uint8_t *b8, int b_stride, int bw, int bh,
+                                    int bd, unsigned int *sse) {
+  const uint16_t *a = reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(a8) << 1);
+  const uint16_t *b = reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(b8) << 1);
+  return host_variance<uint16_t>(false, a, a_stride, 0, 0, b, b_stride, bw, bh, bd, sse);
+}
+
+unsigned int aomhip_highbd_sub_pixel_variance(const uint8_t *a8, int a_stride, int xoffset, int yoffset,
+                                              const uint8_t *b8, int b_stride, int bw, int bh, int bd,
+                                              unsigned int *sse) {
+  const uint16_t *a = reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(a8) << 1);
+  const uint16_t *b = reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(b8) << 1);
+  return host_variance<uint16_t>(true, a, a_stride, xoffset, yoffset, b, b_stride, bw, bh, bd, sse);
+}
+
+}  // extern "C"

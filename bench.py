@@ -166,6 +166,108 @@ class SadModeA:
                 c.free(d)
 
 
+TXQ_SIZES = [(0, 4), (1, 8), (2, 16), (3, 32)]  # (TX_SIZE, n) : TX_4X4, TX_8X8, TX_16X16, TX_32X32
+
+
+class TxqGrid:
+    """BASELINE.json configs[2]: av1_fwd_txfm2d_{4x4..32x32} + aom_quantize_b over every transform block of
+    F residual planes (1920x1088 int16, 9-bit signed samples as for 8-bit video), DCT_DCT, qindex 100.
+    One launch per transform size over the whole ring (grid mode: the ring is one tall plane)."""
+
+    W, H = 1920, 1088
+
+    def __init__(self, pkg, ctx, orc, frames=32, qindex=100, seed=5):
+        self.ctx, self.pkg, self.orc, self.F = ctx, pkg, orc, frames
+        rng = np.random.default_rng(seed)
+        self.h_res0 = ((rng.integers(0, 1 << 16, (self.H, self.W)) & 511) - 256).astype(np.int16)
+        self.d_res = ctx.malloc(frames * self.H * self.W * 2)
+        for f in range(frames):
+            plane = self.h_res0 if f == 0 else ((rng.integers(0, 1 << 16, (self.H, self.W)) & 511) - 256).astype(np.int16)
+            pkg.capi.check(pkg.capi.lib.aomhip_memcpy_h2d(ctx.h, self.d_res + f * self.H * self.W * 2,
+                                                          plane.ctypes.data, plane.nbytes), "h2d")
+        self.samples = frames * self.H * self.W
+        self.d_q, self.d_dq = ctx.malloc(self.samples * 4), ctx.malloc(self.samples * 4)
+        self.d_eob = ctx.malloc(2 * self.samples // 16)
+        self.qt = orc.build_quantizer_y(8, qindex) if orc is not None else None
+        self.qp = pkg.capi.QuantParams.from_tables(self.qt) if self.qt else None
+        self.blocks = {n: (self.W // n) * (self.H // n) * frames for _, n in TXQ_SIZES}
+        self.blocks_per_step = sum(self.blocks.values())
+
+    def launch(self, tx_size, n):
+        self.ctx.xform_quant_batch(self.d_res, self.W, tx_size, None, self.blocks[n], self.W // n, 0, self.qp, False, None,
+                                   self.d_q, self.d_dq, self.d_eob)
+
+    def step(self):
+        for ts, n in TXQ_SIZES:
+            self.launch(ts, n)
+
+    def check(self):
+        """Exact check of frame 0, 16x16, against the oracle (not timed)."""
+        n = (self.W // 16) * (self.H // 16)
+        self.launch(2, 16)
+        gq = self.ctx.from_device(self.d_q, (n * 256,), np.int32)
+        ge = self.ctx.from_device(self.d_eob, (n,), np.uint16)
+        _, wq, _, we = self.orc.xform_quant_batch(self.h_res0, 2, None, n, self.W // 16, 0, self.qt, False, n * 256,
+                                                  False, threads=8)
+        return bool(np.array_equal(gq, wq) and np.array_equal(ge, we))
+
+    def cpu_baseline(self, target_s=8.0):
+        threads = min(self.orc.lib.orc_max_threads(), os.cpu_count() or 1)
+
+        def passes(reps):
+            for ts, n in TXQ_SIZES:
+                nb = (self.W // n) * (self.H // n)
+                self.orc.xform_quant_batch(self.h_res0, ts, None, nb, self.W // n, 0, self.qt, False, nb * n * n, False,
+                                           threads=threads, reps=reps)
+        passes(1)
+        t0 = time.perf_counter(); passes(2); dt = max(time.perf_counter() - t0, 1e-6) / 2
+        reps = int(min(max(target_s / dt, 2), 5000))
+        t0 = time.perf_counter(); passes(reps); dt = time.perf_counter() - t0
+        per_pass = sum((self.W // n) * (self.H // n) for _, n in TXQ_SIZES)
+        return {"value": per_pass * reps / dt, "unit": "blocks/s", "cores": threads, "kind": "port",
+                "sample": "%d passes over all 4x4/8x8/16x16/32x32 blocks of residual plane 0 (%d blocks per pass), "
+                          "oracle C (gcc -O3 -mavx2), OpenMP static over blocks" % (reps, per_pass)}
+
+    def free(self):
+        for d in (self.d_res, self.d_q, self.d_dq, self.d_eob):
+            self.ctx.free(d)
+
+
+def run_txq(pkg, ctx, orc, steps, warmup, want_cpu):
+    wl = TxqGrid(pkg, ctx, orc)
+    ok = wl.check()
+    for _ in range(warmup):
+        wl.step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.timer_begin()
+    for _ in range(steps):
+        wl.step()
+    ev_ms = ctx.timer_end()
+    wall = time.perf_counter() - t0
+    per = {}
+    for ts, n in TXQ_SIZES:
+        ms = kernel_avg_ms(ctx, lambda: wl.launch(ts, n), max(steps, 10))
+        nbytes = wl.blocks[n] * (10 * n * n + 2)  # SURVEY 8(d): 2 B in + 4 + 4 B out per sample + eob
+        per["%dx%d" % (n, n)] = {"avg_launch_ms": ms, "blocks_per_launch": wl.blocks[n],
+                                 "blocks_per_s": wl.blocks[n] / (ms * 1e-3),
+                                 "achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    dom = max(per, key=lambda k: per[k]["avg_launch_ms"])
+    res = {"workload": "fwd_txfm2d+quantize_b_1080p_8bit", "value": wl.blocks_per_step * steps / wall, "unit": "blocks/s",
+           "ms_per_step": wall / steps * 1e3, "event_ms_per_step": ev_ms / steps, "blocks_per_step": wl.blocks_per_step,
+           "parity_frame0_16x16": ok, "config": {"plane": "1920x1088 int16 residual, 9-bit signed", "ring_planes": wl.F,
+                                                 "tx_type": "DCT_DCT", "qindex": 100, "sizes": "4x4,8x8,16x16,32x32 (all blocks of each)"},
+           "roofline": {"bound": "hbm", "kernel": "xform_quant_kernel<%s>" % dom, "achieved": per[dom]["achieved_GBs"],
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom]["frac"], "traffic": load_traffic("txq_" + dom),
+                        "avg_launch_ms": per[dom]["avg_launch_ms"],
+                        "note": "algorithmic bytes = (10*N + 2) per block of N samples (int16 in, qcoeff + dqcoeff out, eob)"},
+           "per_size": per}
+    if want_cpu and orc is not None:
+        res["cpu_baseline"] = wl.cpu_baseline()
+    wl.free()
+    return res
+
+
 def time_steps(wl, ctx, dist, dev, steps, warmup):
     for _ in range(warmup):
         wl.step()
@@ -275,6 +377,8 @@ def main():
                  if args.others == "auto" else [n for n in args.others.split(",") if n])
         for n in names:
             others.append(run_workload(pkg, ctx, dist, dev, rank, world, n, args.steps, args.warmup, False, orc))
+        if args.others == "auto" and orc is not None:
+            others.append(run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline))
     ctx.close()
 
     if rank == 0:

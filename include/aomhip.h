@@ -143,6 +143,28 @@ int aomhip_sad_x4d_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip
                          int n_frames, int bw, int bh, int flags, const aomhip_sad_x4d_cand *d_groups,
                          int n_groups, int64_t group_frame_stride, uint32_t *d_out);
 
+/* ------------------------------------------------------------------ batched variance / sub-pixel variance */
+
+/* One evaluation: source block at (sx, sy), reference block at (rx, ry) [+ (xoff, yoff)/8 pel for the
+ * sub-pixel form, offsets 0..7 as in aom_sub_pixel_varianceWxH]. */
+typedef struct {
+  int16_t sx, sy, rx, ry;
+  uint8_t xoff, yoff;
+  uint8_t reserved[2];
+} aomhip_var_cand;
+
+/* Batched aom_varianceWxH(src, ref) (aom_dsp_rtcd_defs.pl:1367) / aom_highbd_{10,12}_varianceWxH for
+ * 10/12-bit planes: d_var[f_rel * n + i] = variance, d_sse[...] = *sse.  diff = src - ref. */
+int aomhip_variance_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame,
+                          int n_frames, int bw, int bh, const aomhip_var_cand *d_cands, int n_cands,
+                          int64_t cand_frame_stride, uint32_t *d_var, uint32_t *d_sse);
+/* Batched aom_sub_pixel_varianceWxH(ref, xoff, yoff, src) (aom_dsp_rtcd_defs.pl:1368; the call shape of
+ * av1/encoder/mcomp.c:2327): 2-tap bilinear interpolation of the reference block, then variance against
+ * the source block.  Reads (W+1) x (H+1) reference pixels like the reference does. */
+int aomhip_sub_pixel_variance_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref,
+                                    int first_frame, int n_frames, int bw, int bh, const aomhip_var_cand *d_cands,
+                                    int n_cands, int64_t cand_frame_stride, uint32_t *d_var, uint32_t *d_sse);
+
 /* ------------------------------------------------------------------ batched forward transform + quantise */
 
 /* One transform block of a batch (all blocks of a call share one TX_SIZE). */
@@ -210,6 +232,21 @@ void aomhip_sad16x16x4d(const uint8_t *src_ptr, int src_stride, const uint8_t *c
  * bd = 8/10/12 applies the encoder's vtable wrapper; 0 = raw kernel value. */
 unsigned int aomhip_highbd_sad(const uint8_t *src8, int src_stride, const uint8_t *ref8, int ref_stride, int bw,
                                int bh, int bd);
+
+/* aom_dsp_rtcd_defs.pl:1367-1370 aom_variance{W}x{H}(a, a_stride, b, b_stride, sse) and
+ * aom_sub_pixel_variance{W}x{H}(a, a_stride, xoffset, yoffset, b, b_stride, sse); host pointers. */
+unsigned int aomhip_variance(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int bw, int bh,
+                             unsigned int *sse);
+unsigned int aomhip_sub_pixel_variance(const uint8_t *a, int a_stride, int xoffset, int yoffset, const uint8_t *b,
+                                       int b_stride, int bw, int bh, unsigned int *sse);
+unsigned int aomhip_variance16x16(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, unsigned int *sse);
+/* aom_dsp_rtcd_defs.pl:1480-1482 aom_highbd_{8,10,12}_variance / _sub_pixel_variance: CONVERT_TO_BYTEPTR
+ * pointers, bd = 8 / 10 / 12 selects the flavour. */
+unsigned int aomhip_highbd_variance(const uint8_t *a8, int a_stride, const uint8_t *b8, int b_stride, int bw, int bh,
+                                    int bd, unsigned int *sse);
+unsigned int aomhip_highbd_sub_pixel_variance(const uint8_t *a8, int a_stride, int xoffset, int yoffset,
+                                              const uint8_t *b8, int b_stride, int bw, int bh, int bd,
+                                              unsigned int *sse);
 
 #ifdef __cplusplus
 }

@@ -233,3 +233,17 @@ def xform_quant_batch(residual, tx_size, blocks, n, grid_cols, tx_type, q, is_hb
                               n, grid_cols, tx_type, qt, int(is_hbd), coeff.ctypes.data if want_coeff else None,
                               qc.ctypes.data, dq.ctypes.data, eob.ctypes.data, threads, reps)
     return coeff, qc, dq, eob
+
+
+def variance_cands(src_b, ref_b, border, w, h, cands, subpel=False, bd=8):
+    """Per-candidate (var, sse) for a structured candidate array (sx,sy,rx,ry,xoff,yoff).
+    plain: variance(src, ref); sub-pixel: sub_pixel_variance(ref, xoff, yoff, src) -- the reference's call shapes."""
+    out = np.zeros((len(cands), 2), np.uint32)
+    for i, c in enumerate(cands):
+        sy, sx, ry, rx = int(c["sy"]) + border, int(c["sx"]) + border, int(c["ry"]) + border, int(c["rx"]) + border
+        if subpel:
+            out[i] = sub_pixel_variance(ref_b, ry, rx, int(c["xoff"]), int(c["yoff"]), src_b, sy, sx, w, h, bd)
+        else:
+            v, sse, _ = variance(src_b, sy, sx, ref_b, ry, rx, w, h, bd)
+            out[i] = (v, sse)
+    return out
