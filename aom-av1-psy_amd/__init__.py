@@ -6,6 +6,6 @@ is only the thin ctypes binding used by tests and bench.py, plus the synthetic
 frame / work-list generators of SURVEY.md section 8(d).  It has no CPU fallback:
 importing `capi` without the built library raises.
 """
-from . import capi, synth  # noqa: F401
+from . import capi, partition, synth  # noqa: F401
 
-__all__ = ["capi", "synth"]
+__all__ = ["capi", "partition", "synth"]

@@ -80,8 +80,7 @@ class SadModeA:
             for k in range(world):
                 ctx.planes_upload(self.src, f + k * self.F, s)
                 ctx.planes_upload(self.ref, f + k * self.F, r)
-        cols = synth.tile_column_bounds(W, world)
-        x0, x1 = cols[rank] if rank < len(cols) else (0, 0)
+        x0, x1 = pkg.partition.column_of_rank(W, world, rank)
         cands, groups = synth.mode_a_worklist(W, H, 16, seed=seed)
         keep = (cands["sx"] >= x0) & (cands["sx"] < x1)
         self.blocks_per_frame = int(keep.sum())
