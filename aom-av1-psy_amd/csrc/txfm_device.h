@@ -45,11 +45,19 @@ __device__ __forceinline__ int32_t rshift(int32_t x, int bit) { return (x >> bit
 __device__ __forceinline__ int32_t rshift64(int64_t v, int bit) { return (int32_t)((v + ((int64_t)1 << (bit - 1))) >> bit); }
 
 // half_btf (av1_txfm.h:80-102): 32-bit wrapping products, 64-bit sum + rounding, shift.
+#ifndef AOMHIP_EXPERIMENT_FAST_BTF
+#define AOMHIP_EXPERIMENT_FAST_BTF 0
+#endif
 template <int BIT> __device__ __forceinline__ int32_t hbtf(int32_t w0, int32_t a, int32_t w1, int32_t b) {
+#if AOMHIP_EXPERIMENT_FAST_BTF
+  // 24-bit multiply-adds, 32-bit wrapping sum (valid when |a|,|b| < 2^23 and the rounded sum fits 32 bits)
+  return (int32_t)((uint32_t)__mul24(w0, a) + (uint32_t)__mul24(w1, b) + (1u << (BIT - 1))) >> BIT;
+#else
   const int32_t p0 = (int32_t)((uint32_t)w0 * (uint32_t)a);
   const int32_t p1 = (int32_t)((uint32_t)w1 * (uint32_t)b);
   const int64_t s = (int64_t)p0 + (int64_t)p1 + ((int64_t)1 << (BIT - 1));
   return (int32_t)(s >> BIT);
+#endif
 }
 __device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }

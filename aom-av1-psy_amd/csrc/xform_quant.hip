@@ -27,7 +27,38 @@ using namespace txfm;
 
 struct QuantArgs {
   int16_t zbin[2], round[2], quant[2], quant_shift[2], dequant[2];
+  int8_t qs_log2[2];  // log2(quant_shift) when it is a power of two (it always is out of invert_quant,
+                      // av1_quantize.c:580-588), else -1 -> generic 64-bit path
 };
+
+// aom_quantize_b_helper_c / aom_highbd_quantize_b_helper_c (aom_dsp/quantize.c:139-166,293-313) for one
+// coefficient, qm == NULL (wt = iwt = 32), branch-free.  Exact re-associations used for the low-bd form:
+//   ((32t * quant) >> 16)            == (t * quant) >> 11         (same rational, same floor; fits int32)
+//   (t2 * 2^k) >> m                  == t2 >> (m - k)             (quant_shift is a power of two)
+template <bool HBD, int LS>
+__device__ __forceinline__ void quantize_one(int32_t v, int zb, int rd, int quant, int qshift, int qs_log2, int dequant,
+                                             int32_t *qout, int32_t *dqout) {
+  const int sign = v >> 31;
+  const int a = (v ^ sign) - sign;
+  int q;
+  if constexpr (!HBD) {
+    int t = a + rd;
+    t = t > 32767 ? 32767 : t;  // clamp(.., INT16_MIN, INT16_MAX); a + rd >= 0
+    const int t2 = ((t * quant) >> 11) + (t << 5);
+    if (qs_log2 >= 0)
+      q = t2 >> (21 - LS - qs_log2);
+    else
+      q = (int)(((int64_t)t2 * qshift) >> (21 - LS));
+  } else {
+    const int64_t tw = ((int64_t)a + rd) * 32;
+    const int64_t t2 = ((tw * quant) >> 16) + tw;
+    q = (int)((t2 * qshift) >> (21 - LS));
+  }
+  q = (a >= zb) ? q : 0;
+  const int dq = (int)((uint32_t)q * (uint32_t)dequant) >> LS;
+  *qout = (q ^ sign) - sign;
+  *dqout = (dq ^ sign) - sign;
+}
 
 // av1_scan_orders (scan.c:1666-): class 0 = zig-zag (all 2-D types), 1 = "mrow" (V_* types),
 // 2 = "mcol" (H_* types).  Position of coefficient (r, c) in a KW x KH scan.
@@ -64,6 +95,10 @@ template <int LPB> __device__ __forceinline__ int group_max(int v) {
 }
 
 constexpr int kXqThreads = 256;
+
+struct __attribute__((packed, aligned(1))) VecU128 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) VecU64 { uint32_t v[2]; };
+struct __attribute__((packed, aligned(1))) VecU32 { uint32_t v[1]; };
 
 // SRC: 0 = int16 residual plane; 1 = uint8 src - pred planes; 2 = uint16 src - pred planes
 template <int W, int H, bool HBD, int SRC>
@@ -143,6 +178,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
     const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
     const int zb[2] = { (qa.zbin[0] + ((1 << LS) >> 1)) >> LS, (qa.zbin[1] + ((1 << LS) >> 1)) >> LS };
     const int rd[2] = { (qa.round[0] + ((1 << LS) >> 1)) >> LS, (qa.round[1] + ((1 << LS) >> 1)) >> LS };
+    int last_c = -1;  // the inverse scan position grows with c along a row: only the last non-zero c matters
 #pragma unroll
     for (int c = 0; c < KW; ++c) {
       int32_t v = y[c];
@@ -150,28 +186,192 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
       if constexpr (C::rect2) v = rshift64((int64_t)v * kSqrt2, kSqrt2Bits);
       const int rc = c * KH + r;
       if (coeff) coeff[out_off + rc] = v;
-      const int ac = (rc != 0);
-      const int sign = v >> 31;
-      const int a = (v ^ sign) - sign;
-      int q = 0, dq = 0;
-      if (a >= zb[ac]) {
-        int64_t tmp = (int64_t)a + rd[ac];
-        if constexpr (!HBD) tmp = tmp > 32767 ? 32767 : tmp;  // clamp(.., INT16_MIN, INT16_MAX): low-bd only
-        tmp *= 32;                                           // wt = 1 << AOM_QM_BITS, no quant matrix on this path
-        const int64_t t2 = ((tmp * qa.quant[ac]) >> 16) + tmp;
-        q = (int)((t2 * qa.quant_shift[ac]) >> (16 - LS + 5));
-        dq = (int)((uint32_t)q * (uint32_t)qa.dequant[ac]) >> LS;
-        if (q) {
-          const int p = iscan_pos<KW, KH>(r, c, scan_class) + 1;
-          my_eob = p > my_eob ? p : my_eob;
-        }
-      }
-      qcoeff[out_off + rc] = (q ^ sign) - sign;
-      dqcoeff[out_off + rc] = (dq ^ sign) - sign;
+      const int ac = (c == 0) ? (r != 0) : 1;  // DC is (r, c) == (0, 0)
+      int32_t qv, dqv;
+      quantize_one<HBD, LS>(v, zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.qs_log2[ac], qa.dequant[ac], &qv,
+                            &dqv);
+      last_c = qv ? c : last_c;
+      qcoeff[out_off + rc] = qv;
+      dqcoeff[out_off + rc] = dqv;
     }
+    if (last_c >= 0) my_eob = iscan_pos<KW, KH>(r, last_c, scan_class) + 1;
   }
   my_eob = group_max<LPB>(my_eob);
   if (live && lane == 0) eob[bi] = (uint16_t)my_eob;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Staged variant: identical arithmetic, but every global access is 16 bytes wide.
+//   1. the block's residual rows are fetched with one 16-byte load per 8 samples into LDS region A
+//   2. column pass reads its column from A, writes the transpose tile (region B)
+//   3. row pass reads its row from B; the quantised levels go back to LDS in the reference's
+//      coefficient order (qcoeff -> A, dqcoeff -> B), and are copied out with dwordx4 stores.
+// For 16x16 this is 2 loads + 8 stores per lane instead of 16 + 32.
+template <int W, int H, bool HBD, int SRC>
+__global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
+    const void *__restrict__ in0, const void *__restrict__ in1, int stride0, int stride1,
+    const aomhip_txb *__restrict__ blocks, int n_blocks, int grid_cols, int uniform_type, QuantArgs qa,
+    int32_t *__restrict__ coeff, int32_t *__restrict__ qcoeff, int32_t *__restrict__ dqcoeff,
+    uint16_t *__restrict__ eob, int nblk8) {
+  using C = Cfg2D<W, H>;
+  constexpr int LPB = W > H ? W : H;
+  constexpr int BPW = kXqThreads / LPB;
+  constexpr int KW = W < 32 ? W : 32, KH = H < 32 ? H : 32;
+  constexpr int NC = KW * KH;
+  constexpr int LS = (W * H > 256) + (W * H > 1024);
+  constexpr int LSTRIDE = W + 1;
+  constexpr int A_WORDS = (W * H / 2 > NC ? W * H / 2 : NC);  // int16 input tile, later qcoeff staging
+  constexpr int B_WORDS = (KH * LSTRIDE + 3) & ~3;            // transpose tile, later dqcoeff staging
+  __shared__ __attribute__((aligned(16))) int32_t lds[BPW][A_WORDS + B_WORDS];
+
+  const int slot = threadIdx.x / LPB, lane = threadIdx.x % LPB;
+  const unsigned wg = xcd_chunked_index(blockIdx.x, nblk8);
+  const int bi = wg * BPW + slot;
+  const bool live = bi < n_blocks;
+  int bx = 0, by = 0, tx_type = uniform_type;
+  int64_t out_off = (int64_t)bi * NC;
+  if (live) {
+    if (blocks) {
+      const aomhip_txb b = blocks[bi];
+      bx = b.x;
+      by = b.y;
+      tx_type = b.tx_type;
+      out_off = b.out_offset;
+    } else {
+      bx = (bi % grid_cols) * W;
+      by = (bi / grid_cols) * H;
+    }
+  }
+  const int vk = kVKind[tx_type & 15], hk = kHKind[tx_type & 15];
+  int32_t *A = lds[slot];
+  int32_t *B = lds[slot] + A_WORDS;
+  int16_t *A16 = reinterpret_cast<int16_t *>(A);
+
+  // ---- 1. residual rows -> LDS (8 samples per access; 4 for 4-wide blocks)
+  constexpr int CS = W < 8 ? W : 8;             // samples per chunk
+  constexpr int CPR = W / CS;                   // chunks per row
+  constexpr int CHUNKS = H * CPR;
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < (CHUNKS + LPB - 1) / LPB; ++k) {
+      const int i = lane + k * LPB;
+      if (i < CHUNKS) {
+        const int row = i / CPR, col = (i % CPR) * CS;
+        int16_t v[CS];
+        if constexpr (SRC == 0) {
+          const int16_t *p = static_cast<const int16_t *>(in0) + (int64_t)(by + row) * stride0 + bx + col;
+          if constexpr (CS == 8) {
+            const VecU128 raw = *reinterpret_cast<const VecU128 *>(p);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (int16_t)(raw.v[j / 2] >> (16 * (j % 2)));
+          } else {
+            const VecU64 raw = *reinterpret_cast<const VecU64 *>(p);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (int16_t)(raw.v[j / 2] >> (16 * (j % 2)));
+          }
+        } else if constexpr (SRC == 1) {
+          const uint8_t *ps = static_cast<const uint8_t *>(in0) + (int64_t)(by + row) * stride0 + bx + col;
+          const uint8_t *pp = static_cast<const uint8_t *>(in1) + (int64_t)(by + row) * stride1 + bx + col;
+          uint32_t a[CS / 4], b[CS / 4];
+          if constexpr (CS == 8) {
+            const VecU64 ra = *reinterpret_cast<const VecU64 *>(ps), rb = *reinterpret_cast<const VecU64 *>(pp);
+            a[0] = ra.v[0]; a[1] = ra.v[1]; b[0] = rb.v[0]; b[1] = rb.v[1];
+          } else {
+            a[0] = reinterpret_cast<const VecU32 *>(ps)->v[0];
+            b[0] = reinterpret_cast<const VecU32 *>(pp)->v[0];
+          }
+#pragma unroll
+          for (int j = 0; j < CS; ++j)
+            v[j] = (int16_t)((int)((a[j / 4] >> (8 * (j % 4))) & 0xFF) - (int)((b[j / 4] >> (8 * (j % 4))) & 0xFF));
+        } else {
+          const uint16_t *ps = static_cast<const uint16_t *>(in0) + (int64_t)(by + row) * stride0 + bx + col;
+          const uint16_t *pp = static_cast<const uint16_t *>(in1) + (int64_t)(by + row) * stride1 + bx + col;
+          uint32_t a[CS / 2], b[CS / 2];
+          if constexpr (CS == 8) {
+            const VecU128 ra = *reinterpret_cast<const VecU128 *>(ps), rb = *reinterpret_cast<const VecU128 *>(pp);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] = ra.v[j]; b[j] = rb.v[j]; }
+          } else {
+            const VecU64 ra = *reinterpret_cast<const VecU64 *>(ps), rb = *reinterpret_cast<const VecU64 *>(pp);
+            a[0] = ra.v[0]; a[1] = ra.v[1]; b[0] = rb.v[0]; b[1] = rb.v[1];
+          }
+#pragma unroll
+          for (int j = 0; j < CS; ++j)
+            v[j] = (int16_t)((int)((a[j / 2] >> (16 * (j % 2))) & 0xFFFF) - (int)((b[j / 2] >> (16 * (j % 2))) & 0xFFFF));
+        }
+#pragma unroll
+        for (int j = 0; j < CS; j += 2)
+          *reinterpret_cast<uint32_t *>(&A16[row * W + col + j]) = (uint16_t)v[j] | ((uint32_t)(uint16_t)v[j + 1] << 16);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. columns
+  if (live && lane < W) {
+    int32_t x[H];
+    const bool ud = (vk == 2);
+#pragma unroll
+    for (int r = 0; r < H; ++r) x[r] = (int)A16[(ud ? H - 1 - r : r) * W + lane] * (1 << C::fs0);
+    fwd_1d<H, C::cos_bit_col>(x, vk == 2 ? 1 : vk);
+    const int dc = (hk == 2) ? W - 1 - lane : lane;
+#pragma unroll
+    for (int r = 0; r < KH; ++r) {
+      int32_t v = x[r];
+      if constexpr (C::fs1 < 0) v = rshift(v, -C::fs1);
+      B[r * LSTRIDE + dc] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. rows + quantise
+  int my_eob = 0;
+  int32_t y[W];
+  const int r = lane;
+  if (live && lane < KH) {
+#pragma unroll
+    for (int c = 0; c < W; ++c) y[c] = B[r * LSTRIDE + c];
+  }
+  __syncthreads();  // A (input) and B (tile) are dead from here: they become the output staging areas
+  if (live && lane < KH) {
+    fwd_1d<W, C::cos_bit_row>(y, hk == 2 ? 1 : hk);
+    const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
+    const int zb[2] = { (qa.zbin[0] + ((1 << LS) >> 1)) >> LS, (qa.zbin[1] + ((1 << LS) >> 1)) >> LS };
+    const int rd[2] = { (qa.round[0] + ((1 << LS) >> 1)) >> LS, (qa.round[1] + ((1 << LS) >> 1)) >> LS };
+    int last_c = -1;
+#pragma unroll
+    for (int c = 0; c < KW; ++c) {
+      int32_t v = y[c];
+      if constexpr (C::fs2 < 0) v = rshift(v, -C::fs2);
+      if constexpr (C::rect2) v = rshift64((int64_t)v * kSqrt2, kSqrt2Bits);
+      const int rc = c * KH + r;
+      if (coeff) coeff[out_off + rc] = v;
+      const int ac = (c == 0) ? (r != 0) : 1;
+      int32_t qv, dqv;
+      quantize_one<HBD, LS>(v, zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.qs_log2[ac], qa.dequant[ac], &qv,
+                            &dqv);
+      last_c = qv ? c : last_c;
+      A[rc] = qv;
+      B[rc] = dqv;
+    }
+    if (last_c >= 0) my_eob = iscan_pos<KW, KH>(r, last_c, scan_class) + 1;
+  }
+  my_eob = group_max<LPB>(my_eob);
+  if (live && lane == 0) eob[bi] = (uint16_t)my_eob;
+  __syncthreads();
+
+  // ---- 4. copy out, 16 bytes per lane per store
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < (NC / 4 + LPB - 1) / LPB; ++k) {
+      const int i = lane + k * LPB;
+      if (i < NC / 4) {
+        *reinterpret_cast<uint4 *>(qcoeff + out_off + 4 * i) = *reinterpret_cast<const uint4 *>(A + 4 * i);
+        *reinterpret_cast<uint4 *>(dqcoeff + out_off + 4 * i) = *reinterpret_cast<const uint4 *>(B + 4 * i);
+      }
+    }
+  }
 }
 
 struct XqLaunch {
@@ -190,9 +390,18 @@ template <int W, int H, bool HBD, int SRC> static int launch_xq(const XqLaunch &
   constexpr int BPW = kXqThreads / LPB;
   const int nwg = (l.n_blocks + BPW - 1) / BPW;
   const int nwg8 = (nwg + 7) & ~7;
-  hipLaunchKernelGGL((xform_quant_kernel<W, H, HBD, SRC>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0, l.in1,
-                     l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff, l.qcoeff,
-                     l.dqcoeff, l.eob, nwg8);
+  // Blocks up to 16x16 gain from the 16-byte staged accesses; above that the extra LDS footprint costs more
+  // occupancy than it saves (measured, profiles/r01_txq_variants.md).  AOMHIP_XQ_VARIANT forces one.
+  static const int forced = [] { const char *e = getenv("AOMHIP_XQ_VARIANT"); return e ? atoi(e) : -1; }();
+  const int variant = forced >= 0 ? forced : (W * H <= 256 ? 1 : 0);
+  if (variant == 0)
+    hipLaunchKernelGGL((xform_quant_kernel<W, H, HBD, SRC>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0, l.in1,
+                       l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff,
+                       l.qcoeff, l.dqcoeff, l.eob, nwg8);
+  else
+    hipLaunchKernelGGL((xform_quant_staged_kernel<W, H, HBD, SRC>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0,
+                       l.in1, l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff,
+                       l.qcoeff, l.dqcoeff, l.eob, nwg8);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
@@ -244,6 +453,13 @@ static QuantArgs to_args(const aomhip_quant_params *q) {
     a.quant[i] = q->quant[i];
     a.quant_shift[i] = q->quant_shift[i];
     a.dequant[i] = q->dequant[i];
+    const int qs = q->quant_shift[i];
+    a.qs_log2[i] = -1;
+    if (qs > 0 && (qs & (qs - 1)) == 0) {
+      int l = 0;
+      while ((1 << l) < qs) ++l;
+      a.qs_log2[i] = (int8_t)l;
+    }
   }
   return a;
 }

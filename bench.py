@@ -348,7 +348,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="sad16x16_modeA_1080p_8bit", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="sad16x16_modeA_1080p_8bit", choices=sorted(WORKLOADS) + ["txq_1080p_8bit"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -368,6 +368,15 @@ def main():
     except Exception as e:  # pragma: no cover
         print("warning: oracle unavailable (%s): no parity spot check / cpu_baseline" % e, file=sys.stderr)
 
+    if args.workload == "txq_1080p_8bit":  # profiling convenience: transform+quantise only (single GPU)
+        r = run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline)
+        ctx.close()
+        print(json.dumps({"metric": "fwd_txfm+quant blocks/s", "value": r["value"], "unit": "blocks/s", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+                          "data": "synthetic", "config": dict(r["config"], workload=r["workload"]),
+                          "roofline": r["roofline"], "cpu_baseline": r.get("cpu_baseline"), "per_size": r["per_size"]}))
+        return
     main_res = run_workload(pkg, ctx, dist, dev, rank, world, args.workload, args.steps, args.warmup,
                             not args.no_cpu_baseline and world == 1, orc)
     others = []

@@ -20,6 +20,8 @@ TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA
 TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum
 TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 TCC_REQ_sum TCC_BUSY_avr TCC_TAG_STALL_sum TCC_EA0_RDREQ_sum
+SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_IFETCH SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR
+TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_WRITE_sum TCC_NORMAL_WRITEBACK_sum
 LIST
 python - "$OUT" <<'PY'
 import csv,glob,sys,collections
@@ -27,8 +29,10 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1]+"/g*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
-        if "sad_" not in k: continue
-        short="x4d" if "x4d" in k else "cand"
+        if "sad_" not in k and "xform_quant" not in k: continue
+        import re
+        m=re.search(r"xform_quant\w*<(\d+), (\d+)", k)
+        short=("xq%sx%s"%m.groups()) if m else ("x4d" if "x4d" in k else "cand")
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,d in acc.items():
     print("==",k)
