@@ -81,6 +81,7 @@ _protos = {
                                            _vp, _vp]),
     "aomhip_subtract_xform_quant_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _vp, _i, _i, _i, C.POINTER(QuantParams),
                                                     _vp, _vp, _vp, _vp]),
+    "aomhip_inv_txfm_add_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _PP, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp, _i, _i]),
@@ -201,3 +202,7 @@ class Context:
         f = lib.aomhip_sub_pixel_variance_batch if subpel else lib.aomhip_variance_batch
         check(f(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, bw, bh, d_cands, n, stride, d_var, d_sse),
               "aomhip_variance_batch")
+
+    def inv_txfm_add_batch(self, d_dqcoeff, tx_size, d_blocks, n_blocks, grid_cols, tx_type, d_eob, dst, frame):
+        check(lib.aomhip_inv_txfm_add_batch(self.h, d_dqcoeff, tx_size, d_blocks, n_blocks, grid_cols, tx_type, d_eob,
+                                            C.byref(dst), frame), "aomhip_inv_txfm_add_batch")

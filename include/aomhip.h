@@ -210,6 +210,19 @@ int aomhip_subtract_xform_quant_batch(aomhip_ctx *ctx, const aomhip_planes *src,
                                       int uniform_tx_type, const aomhip_quant_params *qparams, int32_t *d_coeff,
                                       int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);
 
+/* ------------------------------------------------------------------ batched inverse transform + reconstruction */
+
+/* av1_inverse_transform_block (av1/common/idct.c:304) -> av1_inv_txfm2d_add_WxH (av1_rtcd_defs.pl:137-243,
+ * av1/common/av1_inv_txfm2d.c:234-450) over a list of blocks of one TX_SIZE: the dequantised coefficients
+ * at d_dqcoeff + out_offset (reference layout: transposed, 64-point sizes packed to 32) are inverse
+ * transformed and ADDED to the prediction already in `dst` (frame `frame`), clipped to the plane's bit depth.
+ * 8-bit planes follow av1_inv_txfm_add_c (the same arithmetic with bd = 8).  Blocks must not overlap.
+ * d_eob (optional): blocks with eob == 0 are skipped like the reference does.  Grid mode as in
+ * aomhip_xform_quant_batch when d_blocks == NULL. */
+int aomhip_inv_txfm_add_batch(aomhip_ctx *ctx, const int32_t *d_dqcoeff, int tx_size, const aomhip_txb *d_blocks,
+                              int n_blocks, int grid_cols, int uniform_tx_type, const uint16_t *d_eob,
+                              const aomhip_planes *dst, int frame);
+
 /* ------------------------------------------------------------------ rtcd-signature conformance entry points */
 
 /* aom_dsp_rtcd_defs.pl:762-763 aom_sad{W}x{H} / aom_sad_skip_{W}x{H}; host pointers. */

@@ -92,3 +92,17 @@ void orc_xform_quant_batch(const int16_t *residual, int stride, int tx_size, con
                      iscans[tt], log_scale);
   }
 }
+
+/* ---- av1_inverse_transform_block over a block list: adds into a uint16 working copy of the plane ---- */
+void orc_inv_txfm_add_batch(const int32_t *dqcoeff, int tx_size, const orc_txb *blocks, int n, int grid_cols,
+                            int uniform_type, const uint16_t *eob, uint16_t *dst, int dst_stride, int bd) {
+  const int w = orc_tx_wide[tx_size], h = orc_tx_high[tx_size];
+  const int kw = w < 32 ? w : 32, kh = h < 32 ? h : 32, nc = kw * kh;
+  for (int i = 0; i < n; ++i) {
+    if (eob && eob[i] == 0) continue;
+    const int bx = blocks ? blocks[i].x : (i % grid_cols) * w, by = blocks ? blocks[i].y : (i / grid_cols) * h;
+    const int tt = blocks ? blocks[i].tx_type : uniform_type;
+    const size_t off = blocks ? blocks[i].out_offset : (size_t)i * nc;
+    orc_inv_txfm2d_add(dqcoeff + off, dst + (ptrdiff_t)by * dst_stride + bx, dst_stride, tx_size, tt, bd);
+  }
+}

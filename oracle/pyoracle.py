@@ -247,3 +247,18 @@ def variance_cands(src_b, ref_b, border, w, h, cands, subpel=False, bd=8):
             v, sse, _ = variance(src_b, sy, sx, ref_b, ry, rx, w, h, bd)
             out[i] = (v, sse)
     return out
+
+
+lib.orc_inv_txfm_add_batch.restype = None
+lib.orc_inv_txfm_add_batch.argtypes = [_i32, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i]
+
+
+def inv_txfm_add_batch(dqcoeff, tx_size, blocks, n, grid_cols, tx_type, eob, dst, bd):
+    """dst: 2-D pixel array (uint8 or uint16); returns the reconstructed copy (same dtype)."""
+    work = np.ascontiguousarray(dst, np.uint16).copy()
+    bl = np.ascontiguousarray(blocks) if blocks is not None else None
+    e = np.ascontiguousarray(eob, np.uint16) if eob is not None else None
+    lib.orc_inv_txfm_add_batch(np.ascontiguousarray(dqcoeff, np.int32), tx_size, bl.ctypes.data if bl is not None else None,
+                               n, grid_cols, tx_type, e.ctypes.data if e is not None else None, work.ctypes.data,
+                               work.shape[1], bd)
+    return work.astype(dst.dtype)
