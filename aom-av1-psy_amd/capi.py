@@ -82,6 +82,7 @@ _protos = {
     "aomhip_subtract_xform_quant_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _vp, _i, _i, _i, C.POINTER(QuantParams),
                                                     _vp, _vp, _vp, _vp]),
     "aomhip_inv_txfm_add_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _PP, _i]),
+    "aomhip_deblock_plane": (C.c_int, [_vp, _PP, _i, _vp, _i, _i, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp, _i, _i]),
@@ -206,3 +207,7 @@ class Context:
     def inv_txfm_add_batch(self, d_dqcoeff, tx_size, d_blocks, n_blocks, grid_cols, tx_type, d_eob, dst, frame):
         check(lib.aomhip_inv_txfm_add_batch(self.h, d_dqcoeff, tx_size, d_blocks, n_blocks, grid_cols, tx_type, d_eob,
                                             C.byref(dst), frame), "aomhip_inv_txfm_add_batch")
+
+    def deblock_plane(self, p, frame, d_params, units_stride, sharpness=0, passes=3):
+        check(lib.aomhip_deblock_plane(self.h, C.byref(p), frame, d_params, units_stride, sharpness, passes),
+              "aomhip_deblock_plane")

@@ -1,0 +1,236 @@
+// AV1 deblocking filter over a whole plane on gfx950.
+// Reference: taps aom_dsp/loopfilter.c (8-bit :20-511, highbd :515-997); thresholds
+// av1/common/av1_loopfilter.c:47-66,118-120; edge driver av1_loopfilter.c:223-328,1304-1352,1905-
+// and its order thread_common.c:251-322,375-395 (per superblock row: vertical edges, then horizontal).
+//
+// The host (or an upstream kernel) reduces the reference's mode-info walk (set_lpf_parameters) to one
+// 4-byte record per 4x4 unit of the plane: {len_v, lvl_v, len_h, lvl_h} = filter length (0/4/6/8/14) and
+// filter level of the vertical edge on the unit's left side and of the horizontal edge on its top side.
+// Because the length is derived from the smaller of the two adjacent transform sizes, the pixels an edge
+// reads and writes lie strictly inside its own half-transform zone: all vertical edges of a plane are
+// mutually independent, and so are all horizontal edges.  The plane is therefore filtered by exactly two
+// launches -- every vertical edge, then every horizontal edge -- which tests/ prove equal to the
+// reference's superblock-row order on random transform partitions.
+//
+//   vertical pass  : one lane per (edge unit, pixel row): one 16-byte window load (2 for 16-bit pixels),
+//                    taps in registers, stores restricted to the edge's own zone (2 / 8 / 16 bytes)
+//   horizontal pass: one lane per (pixel column, edge unit): lanes of a wavefront cover 64 adjacent
+//                    columns, so each of the up-to-14 row accesses is one coalesced 64-pixel segment
+// Algorithmic bytes: each pixel is read and written once per pass.
+#include "common.h"
+
+namespace aomhip {
+
+struct __attribute__((packed, aligned(1))) DU128 { uint32_t v[4]; };
+
+__device__ __forceinline__ int iabsd(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int clampd(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// x[7 + i] holds tap i (i = -7 .. 6: p6 .. p0, q0 .. q6); filters in place.
+__device__ __forceinline__ void lpf_window(int (&x)[14], int len, int level, int sharpness, int bd) {
+  // update_sharpness / av1_loop_filter_frame_init (av1_loopfilter.c:47-66,118-120)
+  int inside = level >> ((sharpness > 0) + (sharpness > 4));
+  if (sharpness > 0 && inside > 9 - sharpness) inside = 9 - sharpness;
+  if (inside < 1) inside = 1;
+  const int sh = bd - 8;
+  const int lim = inside << sh, blim = (2 * (level + 2) + inside) << sh, thr = (level >> 4) << sh, one = 1 << sh;
+  const int p3 = x[3], p2 = x[4], p1 = x[5], p0 = x[6], q0 = x[7], q1 = x[8], q2 = x[9], q3 = x[10];
+
+  bool mask = !(iabsd(p1 - p0) > lim || iabsd(q1 - q0) > lim || iabsd(p0 - q0) * 2 + iabsd(p1 - q1) / 2 > blim);
+  bool flat = false, flat2 = false;
+  if (len >= 6) {
+    mask = mask && !(iabsd(p2 - p1) > lim || iabsd(q2 - q1) > lim);
+    flat = !(iabsd(p1 - p0) > one || iabsd(q1 - q0) > one || iabsd(p2 - p0) > one || iabsd(q2 - q0) > one);
+  }
+  if (len >= 8) {
+    mask = mask && !(iabsd(p3 - p2) > lim || iabsd(q3 - q2) > lim);
+    flat = flat && !(iabsd(p3 - p0) > one || iabsd(q3 - q0) > one);
+  }
+  if (len == 14) {
+    flat2 = !(iabsd(x[2] - p0) > one || iabsd(x[11] - q0) > one || iabsd(x[1] - p0) > one ||
+              iabsd(x[12] - q0) > one || iabsd(x[0] - p0) > one || iabsd(x[13] - q0) > one);
+  }
+
+  if (len == 14 && flat2 && flat && mask) {
+    // 13 taps [1 1 1 1 1 2 2 2 1 1 1 1 1] over the edge-replicated window p6..q6, >> 4 (loopfilter.c:378-424)
+    int o[12];
+#pragma unroll
+    for (int i = 1; i <= 12; ++i) {  // output index in x[]: p5 .. q5
+      int s = 8;
+#pragma unroll
+      for (int k = -6; k <= 6; ++k) {
+        int j = i + k;
+        j = j < 0 ? 0 : (j > 13 ? 13 : j);
+        s += ((k >= -1 && k <= 1) ? 2 : 1) * x[j];
+      }
+      o[i - 1] = s >> 4;
+    }
+#pragma unroll
+    for (int i = 1; i <= 12; ++i) x[i] = o[i - 1];
+  } else if (len >= 8 && flat && mask) {
+    // 7 taps [1 1 1 2 1 1 1] over p3..q3, >> 3 (loopfilter.c:216-237)
+    int o[6];
+#pragma unroll
+    for (int i = 4; i <= 9; ++i) {  // p2 .. q2
+      int s = 4 + x[i];
+#pragma unroll
+      for (int k = -3; k <= 3; ++k) {
+        int j = i + k;
+        j = j < 3 ? 3 : (j > 10 ? 10 : j);
+        s += x[j];
+      }
+      o[i - 4] = s >> 3;
+    }
+#pragma unroll
+    for (int i = 4; i <= 9; ++i) x[i] = o[i - 4];
+  } else if (len == 6 && flat && mask) {
+    // 5 taps [1 2 2 2 1] over p2..q2, >> 3 (loopfilter.c:202-214)
+    int o[4];
+#pragma unroll
+    for (int i = 5; i <= 8; ++i) {  // p1 .. q1
+      int s = 4;
+#pragma unroll
+      for (int k = -2; k <= 2; ++k) {
+        int j = i + k;
+        j = j < 4 ? 4 : (j > 9 ? 9 : j);
+        s += ((k >= -1 && k <= 1) ? 2 : 1) * x[j];
+      }
+      o[i - 5] = s >> 3;
+    }
+#pragma unroll
+    for (int i = 5; i <= 8; ++i) x[i] = o[i - 5];
+  } else {
+    // filter4 / highbd_filter4 (loopfilter.c:104-134,602-638) in the signed offset domain
+    const int off = 0x80 << sh, lo = -(128 << sh), hi = (128 << sh) - 1;
+    const int ps1 = p1 - off, ps0 = p0 - off, qs0 = q0 - off, qs1 = q1 - off;
+    const bool hev = iabsd(p1 - p0) > thr || iabsd(q1 - q0) > thr;
+    int f = hev ? clampd(ps1 - qs1, lo, hi) : 0;
+    f = mask ? clampd(f + 3 * (qs0 - ps0), lo, hi) : 0;
+    const int f1 = clampd(f + 4, lo, hi) >> 3;
+    const int f2 = clampd(f + 3, lo, hi) >> 3;
+    const int f3 = hev ? 0 : ((f1 + 1) >> 1);
+    x[7] = clampd(qs0 - f1, lo, hi) + off;
+    x[6] = clampd(ps0 + f2, lo, hi) + off;
+    x[8] = clampd(qs1 - f3, lo, hi) + off;
+    x[5] = clampd(ps1 + f3, lo, hi) + off;
+  }
+}
+
+constexpr int kDbThreads = 256;
+
+// Vertical edges: lane = (unit column ux, pixel row y).
+template <typename PIX>
+__global__ __launch_bounds__(kDbThreads) void deblock_vert_kernel(PIX *origin, int stride, int width, int height,
+                                                                  const uint8_t *__restrict__ params, int units_stride,
+                                                                  int sharpness, int bd) {
+  const int ux = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * (kDbThreads / 64) + (threadIdx.x >> 6);
+  const int ucols = (width + 3) >> 2;
+  if (ux <= 0 || ux >= ucols || y >= height) return;
+  const uint8_t *e = params + ((size_t)(y >> 2) * units_stride + ux) * 4;
+  const int len = e[0], level = e[1];
+  if (len == 0 || level == 0) return;
+  PIX *s = origin + (int64_t)y * stride + 4 * ux;  // q0
+  int x[14];
+  if constexpr (sizeof(PIX) == 1) {
+    const DU128 w = *reinterpret_cast<const DU128 *>(s - 8);  // pixels x-8 .. x+7
+#pragma unroll
+    for (int i = 0; i < 14; ++i) x[i] = (w.v[(i + 1) / 4] >> (8 * ((i + 1) % 4))) & 0xFF;
+  } else {
+    const DU128 w0 = *reinterpret_cast<const DU128 *>(s - 8), w1 = *reinterpret_cast<const DU128 *>(s);
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      const int px = i + 1;  // index within the 16-pixel window
+      const uint32_t d = px < 8 ? w0.v[px / 2] : w1.v[(px - 8) / 2];
+      x[i] = (d >> (16 * (px % 2))) & 0xFFFF;
+    }
+  }
+  lpf_window(x, len, level, sharpness, bd);
+  // write back only this edge's own zone
+  if (len == 14) {
+#pragma unroll
+    for (int i = 1; i <= 12; ++i) s[i - 7] = (PIX)x[i];
+  } else if (len == 8) {
+#pragma unroll
+    for (int i = 4; i <= 9; ++i) s[i - 7] = (PIX)x[i];
+  } else {
+#pragma unroll
+    for (int i = 5; i <= 8; ++i) s[i - 7] = (PIX)x[i];
+  }
+}
+
+// Horizontal edges: lane = (pixel column xcol, unit row uy).
+template <typename PIX>
+__global__ __launch_bounds__(kDbThreads) void deblock_horz_kernel(PIX *origin, int stride, int width, int height,
+                                                                  const uint8_t *__restrict__ params, int units_stride,
+                                                                  int sharpness, int bd) {
+  const int xcol = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int uy = blockIdx.y * (kDbThreads / 64) + (threadIdx.x >> 6);
+  const int urows = (height + 3) >> 2;
+  if (xcol >= width || uy <= 0 || uy >= urows) return;
+  const uint8_t *e = params + ((size_t)uy * units_stride + (xcol >> 2)) * 4;
+  const int len = e[2], level = e[3];
+  if (len == 0 || level == 0) return;
+  PIX *s = origin + (int64_t)(4 * uy) * stride + xcol;  // q0
+  const int reach = len == 14 ? 7 : (len == 8 ? 4 : (len == 6 ? 3 : 2));
+  int x[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    const int k = i - 7;
+    x[i] = (k >= -reach && k < reach) ? (int)s[(int64_t)k * stride] : 0;
+  }
+  lpf_window(x, len, level, sharpness, bd);
+  const int wr = len == 14 ? 6 : (len == 8 ? 3 : 2);
+#pragma unroll
+  for (int i = 1; i <= 12; ++i) {
+    const int k = i - 7;
+    if (k >= -wr && k < wr) s[(int64_t)k * stride] = (PIX)x[i];
+  }
+}
+
+}  // namespace aomhip
+
+using namespace aomhip;
+
+extern "C" {
+
+int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, const uint8_t *d_edge_params,
+                         int units_stride, int sharpness, int passes) {
+  if (!ctx || !p || !p->base || !d_edge_params || frame < 0 || frame >= p->n_frames || sharpness < 0 ||
+      sharpness > 7 || units_stride < (p->width + 3) / 4) {
+    set_error("aomhip_deblock_plane: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  const size_t esz = p->bit_depth == 8 ? 1 : 2;
+  char *origin = static_cast<char *>(p->base) +
+                 ((size_t)frame * p->frame_stride + (size_t)p->border * p->stride + p->border) * esz;
+  const int ucols = (p->width + 3) / 4, urows = (p->height + 3) / 4;
+  const int rows_per_wg = kDbThreads / 64;
+  const dim3 gv((ucols + 63) / 64, (p->height + rows_per_wg - 1) / rows_per_wg);
+  const dim3 gh((p->width + 63) / 64, (urows + rows_per_wg - 1) / rows_per_wg);
+  if (passes & 1) {
+    if (esz == 1)
+      hipLaunchKernelGGL(deblock_vert_kernel<uint8_t>, gv, dim3(kDbThreads), 0, ctx->stream,
+                         reinterpret_cast<uint8_t *>(origin), p->stride, p->width, p->height, d_edge_params,
+                         units_stride, sharpness, p->bit_depth);
+    else
+      hipLaunchKernelGGL(deblock_vert_kernel<uint16_t>, gv, dim3(kDbThreads), 0, ctx->stream,
+                         reinterpret_cast<uint16_t *>(origin), p->stride, p->width, p->height, d_edge_params,
+                         units_stride, sharpness, p->bit_depth);
+    AOMHIP_LAUNCH_CHECK();
+  }
+  if (passes & 2) {
+    if (esz == 1)
+      hipLaunchKernelGGL(deblock_horz_kernel<uint8_t>, gh, dim3(kDbThreads), 0, ctx->stream,
+                         reinterpret_cast<uint8_t *>(origin), p->stride, p->width, p->height, d_edge_params,
+                         units_stride, sharpness, p->bit_depth);
+    else
+      hipLaunchKernelGGL(deblock_horz_kernel<uint16_t>, gh, dim3(kDbThreads), 0, ctx->stream,
+                         reinterpret_cast<uint16_t *>(origin), p->stride, p->width, p->height, d_edge_params,
+                         units_stride, sharpness, p->bit_depth);
+    AOMHIP_LAUNCH_CHECK();
+  }
+  return AOMHIP_OK;
+}
+
+}  // extern "C"

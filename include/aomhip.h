@@ -223,6 +223,20 @@ int aomhip_inv_txfm_add_batch(aomhip_ctx *ctx, const int32_t *d_dqcoeff, int tx_
                               int n_blocks, int grid_cols, int uniform_tx_type, const uint16_t *d_eob,
                               const aomhip_planes *dst, int frame);
 
+/* ------------------------------------------------------------------ deblocking filter */
+
+/* Whole-plane AV1 deblocking, in place on frame `frame` of `p`.
+ * d_edge_params: one 4-byte record per 4x4 unit of the plane, row-major with `units_stride` records per
+ * row: { len_v, lvl_v, len_h, lvl_h } = filter length (0 = none, 4, 6, 8, 14; tx_dim_to_filter_length,
+ * av1/common/av1_loopfilter.c:219,299-310) and filter level (av1_get_filter_level, :68) of the vertical
+ * edge on the unit's left side and of the horizontal edge on its top side -- i.e. the output of
+ * set_lpf_parameters (:223-328) for that position.  Limits follow update_sharpness (:47-66) with
+ * `sharpness` (0..7).  The taps are aom_lpf_{vertical,horizontal}_{4,6,8,14} / aom_highbd_lpf_*
+ * (aom_dsp_rtcd_defs.pl:474-594; aom_dsp/loopfilter.c).  passes: bit 0 = vertical edges, bit 1 =
+ * horizontal edges; 3 runs both in the reference's order (all vertical, then all horizontal). */
+int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, const uint8_t *d_edge_params,
+                         int units_stride, int sharpness, int passes);
+
 /* ------------------------------------------------------------------ rtcd-signature conformance entry points */
 
 /* aom_dsp_rtcd_defs.pl:762-763 aom_sad{W}x{H} / aom_sad_skip_{W}x{H}; host pointers. */

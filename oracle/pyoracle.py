@@ -262,3 +262,73 @@ def inv_txfm_add_batch(dqcoeff, tx_size, blocks, n, grid_cols, tx_type, eob, dst
                                n, grid_cols, tx_type, e.ctypes.data if e is not None else None, work.ctypes.data,
                                work.shape[1], bd)
     return work.astype(dst.dtype)
+
+
+# ---- deblocking (aomref_lpf.c)
+lib.orc_lpf.restype = None
+lib.orc_lpf.argtypes = [_vp, _i, _i, _i, C.c_uint8, C.c_uint8, C.c_uint8]
+lib.orc_highbd_lpf.restype = None
+lib.orc_highbd_lpf.argtypes = [_vp, _i, _i, _i, C.c_uint8, C.c_uint8, C.c_uint8, _i]
+lib.orc_lpf_thresholds.restype = None
+lib.orc_lpf_thresholds.argtypes = [_i, _i, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
+lib.orc_deblock_plane.restype = None
+lib.orc_deblock_plane.argtypes = [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i]
+
+
+def lpf_edge(pixels, y, x, vertical, length, blimit, limit, thresh, bd=8):
+    """Filter one 4-px edge unit in place; (y, x) is q0 of the first pixel line."""
+    if pixels.dtype == np.uint8:
+        lib.orc_lpf(_addr(pixels, y, x), pixels.shape[1], int(vertical), length, blimit, limit, thresh)
+    else:
+        lib.orc_highbd_lpf(_addr(pixels, y, x), pixels.shape[1], int(vertical), length, blimit, limit, thresh, bd)
+
+
+def deblock_plane(pixels, params, sharpness=0, bd=8, order=0):
+    """pixels: 2-D visible plane; params: uint8 [urows, ucols, 4] -> filtered copy."""
+    out = np.ascontiguousarray(pixels).copy()
+    params = np.ascontiguousarray(params, np.uint8)
+    h, w = out.shape
+    lib.orc_deblock_plane(out.ctypes.data, out.shape[1], w, h, int(out.dtype != np.uint8), bd, params.ctypes.data,
+                          params.shape[1], sharpness, order)
+    return out
+
+
+def random_edge_params(rng, width, height, max_log2=6, level_range=(1, 64), chroma=False):
+    """Edge records consistent with a random transform partition (so that footprints never overlap, as in the
+    reference): each 64x64 superblock is split quad-tree style into square transforms of 4..64 px; every
+    transform carries a random level; len = tx_dim_to_filter_length[min(tx on both sides)]."""
+    ucols, urows = (width + 3) // 4, (height + 3) // 4
+    txs = np.zeros((urows, ucols), np.uint8)   # transform size (px) covering each 4x4 unit
+    lvl = np.zeros((urows, ucols), np.uint8)
+    org = np.zeros((urows, ucols, 2), np.int32)  # top-left unit of the covering transform
+
+    def split(y0, x0, size):
+        if size > 4 and (size > (1 << max_log2) or rng.random() < 0.55):
+            h = size // 2
+            for dy in (0, h):
+                for dx in (0, h):
+                    split(y0 + dy, x0 + dx, h)
+            return
+        u = size // 4
+        uy, ux = y0 // 4, x0 // 4
+        if uy >= urows or ux >= ucols:
+            return
+        txs[uy:uy + u, ux:ux + u] = size
+        lvl[uy:uy + u, ux:ux + u] = rng.integers(level_range[0], level_range[1])
+        org[uy:uy + u, ux:ux + u] = (uy, ux)
+    for y0 in range(0, height, 64):
+        for x0 in range(0, width, 64):
+            split(y0, x0, 64)
+    flen = (lambda t: 4 if t == 4 else 6) if chroma else (lambda t: 4 if t == 4 else 8 if t == 8 else 14)
+    p = np.zeros((urows, ucols, 4), np.uint8)
+    for uy in range(urows):
+        for ux in range(ucols):
+            if ux > 0 and org[uy, ux, 1] == ux:      # a transform starts here: vertical edge on its left
+                t = min(txs[uy, ux], txs[uy, ux - 1])
+                l = lvl[uy, ux] if lvl[uy, ux] else lvl[uy, ux - 1]  # av1_loopfilter.c:285-297: current level, else previous
+                p[uy, ux, 0], p[uy, ux, 1] = flen(t), l
+            if uy > 0 and org[uy, ux, 0] == uy:
+                t = min(txs[uy, ux], txs[uy - 1, ux])
+                l = lvl[uy, ux] if lvl[uy, ux] else lvl[uy - 1, ux]
+                p[uy, ux, 2], p[uy, ux, 3] = flen(t), l
+    return p
