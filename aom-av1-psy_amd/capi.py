@@ -83,6 +83,7 @@ _protos = {
                                                     _vp, _vp, _vp, _vp]),
     "aomhip_inv_txfm_add_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _PP, _i]),
     "aomhip_deblock_plane": (C.c_int, [_vp, _PP, _i, _vp, _i, _i, _i]),
+    "aomhip_cdef_luma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp, _i, _i]),
@@ -211,3 +212,8 @@ class Context:
     def deblock_plane(self, p, frame, d_params, units_stride, sharpness=0, passes=3):
         check(lib.aomhip_deblock_plane(self.h, C.byref(p), frame, d_params, units_stride, sharpness, passes),
               "aomhip_deblock_plane")
+
+    def cdef_luma_plane(self, src, src_frame, dst, dst_frame, d_pri, d_sec, fb_stride, d_skip, damping, d_dir=None,
+                        d_var=None):
+        check(lib.aomhip_cdef_luma_plane(self.h, C.byref(src), src_frame, C.byref(dst), dst_frame, d_pri, d_sec,
+                                         fb_stride, d_skip, damping, d_dir, d_var), "aomhip_cdef_luma_plane")

@@ -1,0 +1,250 @@
+// CDEF (constrained directional enhancement filter), luma plane, on gfx950.
+// Reference: av1/common/cdef_block.c:57-133 (cdef_find_dir), :139-201 (cdef_filter_block_internal),
+// :289-293 (adjust_strength), :323-426 (av1_cdef_filter_fb); av1/common/cdef.h:59-67 (constrain);
+// per-64x64 driver av1/common/cdef.c:138-345 (cdef_prepare_fb / cdef_fb_col).
+//
+// The reference filters in place and keeps line / column buffers so that every tap reads PRE-CDEF
+// (deblocked) pixels, with CDEF_VERY_LARGE outside the frame.  An out-of-place kernel (read the deblocked
+// plane, write the CDEF plane) has exactly those semantics with no buffers.
+//
+// One workgroup per 64x64 filter block:
+//   1. the 68 x 68 footprint (2-pixel halo) is staged in LDS as uint16, 0x4000 outside the frame
+//   2. 64 lanes find the direction + variance of the 64 8x8 blocks (pixels in VGPRs, the 8 directional
+//      partial-sum sets evaluated one after the other with compile-time line indices)
+//   3. all 256 lanes filter: 4 lanes per 8x8 block, 2 rows each, taps read from LDS
+// Skipped 8x8 blocks (all four 4x4 skip_txfm) and blocks of a zero-strength filter block are copied.
+// Algorithmic bytes: one read and one write per pixel.
+#include "common.h"
+
+namespace aomhip {
+
+constexpr int kVeryLarge = 0x4000;  // CDEF_VERY_LARGE (cdef_block.h:31)
+constexpr int kTW = 72, kTH = 68;   // LDS tile: rows -2..65, cols -4..67
+
+__device__ __forceinline__ int msb_u(unsigned v) { return 31 - __clz((int)v); }  // get_msb, v != 0
+
+__device__ __forceinline__ int constrain_d(int diff, int threshold, int damping) {
+  if (!threshold) return 0;
+  int shift = damping - msb_u((unsigned)threshold);
+  shift = shift < 0 ? 0 : shift;
+  const int a = diff < 0 ? -diff : diff;
+  int m = threshold - (a >> shift);
+  m = m < 0 ? 0 : m;
+  m = m > a ? a : m;
+  return diff < 0 ? -m : m;
+}
+
+// line index of pixel (i, j) for direction D (cdef_block.c:71-87)
+template <int D> __device__ __forceinline__ constexpr int dir_line(int i, int j) {
+  return D == 0 ? i + j
+       : D == 1 ? i + j / 2
+       : D == 2 ? i
+       : D == 3 ? 3 + i - j / 2
+       : D == 4 ? 7 + i - j
+       : D == 5 ? 3 - i / 2 + j
+       : D == 6 ? j
+                : i / 2 + j;
+}
+
+template <int D> __device__ __forceinline__ int dir_cost(const int (&x)[64]) {
+  int partial[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) partial[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) partial[dir_line<D>(i, j)] += x[i * 8 + j];
+  // weights 840 / (pixels on the line): div_table (cdef_block.c:67)
+  constexpr int div_table[9] = { 0, 840, 420, 280, 210, 168, 140, 120, 105 };
+  int cost = 0;
+  if constexpr (D == 2 || D == 6) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cost += partial[k] * partial[k];
+    cost *= div_table[8];
+  } else if constexpr (D == 0 || D == 4) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) cost += (partial[k] * partial[k] + partial[14 - k] * partial[14 - k]) * div_table[k + 1];
+    cost += partial[7] * partial[7] * div_table[8];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) cost += partial[3 + k] * partial[3 + k];
+    cost *= div_table[8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      cost += (partial[k] * partial[k] + partial[10 - k] * partial[10 - k]) * div_table[2 * k + 2];
+  }
+  return cost;
+}
+
+// Cdef_Directions (AV1 spec 7.15.3; cdef_block.c:25-48) as LDS offsets dy * kTW + dx for taps k = 0, 1
+__device__ constexpr int kDirOff[8][2] = {
+  { -1 * kTW + 1, -2 * kTW + 2 }, { 0 * kTW + 1, -1 * kTW + 2 }, { 0 * kTW + 1, 0 * kTW + 2 }, { 0 * kTW + 1, 1 * kTW + 2 },
+  { 1 * kTW + 1, 2 * kTW + 2 },   { 1 * kTW + 0, 2 * kTW + 1 },  { 1 * kTW + 0, 2 * kTW + 0 }, { 1 * kTW + 0, 2 * kTW - 1 }
+};
+
+template <typename PIX>
+__global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ src, PIX *__restrict__ dst, int stride,
+                                                        int width, int height, const uint8_t *__restrict__ fb_pri,
+                                                        const uint8_t *__restrict__ fb_sec, int fb_stride,
+                                                        const uint8_t *__restrict__ skip, int damping, int coeff_shift,
+                                                        uint8_t *__restrict__ dir_out, int32_t *__restrict__ var_out) {
+  __shared__ uint16_t tile[kTH * kTW];
+  __shared__ int8_t sdir[64];
+  __shared__ int32_t svar[64];
+  const int fbx = blockIdx.x, fby = blockIdx.y;
+  const int x0 = fbx * 64, y0 = fby * 64;
+  const int tid = threadIdx.x;
+  const int b8w = width >> 3;
+
+  // 1. stage the footprint
+  for (int i = tid; i < kTH * kTW; i += 256) {
+    const int r = i / kTW - 2, c = i % kTW - 4;
+    const int y = y0 + r, x = x0 + c;
+    int v = kVeryLarge;
+    if (y >= 0 && y < height && x >= 0 && x < width) v = src[(int64_t)y * stride + x];
+    tile[i] = (uint16_t)v;
+  }
+  const int level = fb_pri[fby * fb_stride + fbx], sec = fb_sec[fby * fb_stride + fbx];
+  __syncthreads();
+
+  // 2. direction search, one lane per 8x8 block
+  if (tid < 64) {
+    const int by = tid >> 3, bx = tid & 7;
+    const int gy = y0 + by * 8, gx = x0 + bx * 8;
+    int d = -1, var = 0;
+    if (gy < height && gx < width && (level | sec) != 0 && !skip[(gy >> 3) * b8w + (gx >> 3)]) {
+      int x[64];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          x[i * 8 + j] = ((int)tile[(by * 8 + i + 2) * kTW + bx * 8 + j + 4] >> coeff_shift) - 128;
+      int cost[8];
+      cost[0] = dir_cost<0>(x); cost[1] = dir_cost<1>(x); cost[2] = dir_cost<2>(x); cost[3] = dir_cost<3>(x);
+      cost[4] = dir_cost<4>(x); cost[5] = dir_cost<5>(x); cost[6] = dir_cost<6>(x); cost[7] = dir_cost<7>(x);
+      int best = 0, best_cost = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (cost[k] > best_cost) {
+          best_cost = cost[k];
+          best = k;
+        }
+      int orth = cost[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) orth = (((best + 4) & 7) == k) ? cost[k] : orth;
+      var = (best_cost - orth) >> 10;
+      d = best;
+    }
+    sdir[tid] = (int8_t)d;
+    svar[tid] = var;
+    if (gy < height && gx < width) {
+      if (dir_out) dir_out[(gy >> 3) * b8w + (gx >> 3)] = d < 0 ? 0 : (uint8_t)d;
+      if (var_out) var_out[(gy >> 3) * b8w + (gx >> 3)] = var;
+    }
+  }
+  __syncthreads();
+
+  // 3. filter: 4 lanes per 8x8 block, rows 2q and 2q + 1
+  const int blk = tid >> 2, q = tid & 3;
+  const int by = blk >> 3, bx = blk & 7;
+  const int gy0 = y0 + by * 8 + 2 * q, gx0 = x0 + bx * 8;
+  if (gy0 >= height || gx0 >= width) return;
+  const int d = sdir[blk];
+  const int pri_strength = level << coeff_shift, sec_strength = sec << coeff_shift;
+  int t = 0;
+  if (d >= 0) {  // adjust_strength (cdef_block.c:289-293)
+    const int var = svar[blk];
+    const int i = (var >> 6) ? min(msb_u((unsigned)(var >> 6)), 12) : 0;
+    t = var ? (pri_strength * (4 + i) + 8) >> 4 : 0;
+  }
+  const int dmp = damping + coeff_shift;
+  const int dir = pri_strength ? (d < 0 ? 0 : d) : 0;
+  const bool en_pri = (t != 0), en_sec = (sec_strength != 0), clip = en_pri && en_sec;
+  const int pt0 = ((t >> coeff_shift) & 1) ? 3 : 4, pt1 = ((t >> coeff_shift) & 1) ? 3 : 2;  // cdef_pri_taps
+  const int po0 = kDirOff[dir][0], po1 = kDirOff[dir][1];
+  const int s1o0 = kDirOff[(dir + 2) & 7][0], s1o1 = kDirOff[(dir + 2) & 7][1];
+  const int s2o0 = kDirOff[(dir + 6) & 7][0], s2o1 = kDirOff[(dir + 6) & 7][1];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int ly = by * 8 + 2 * q + rr;
+    PIX outv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pos = (ly + 2) * kTW + bx * 8 + j + 4;
+      const int x = tile[pos];
+      int y = x;
+      if (d >= 0) {
+        int sum = 0, mx = x, mn = x;
+        if (en_pri) {
+          const int p0 = tile[pos + po0], p1 = tile[pos - po0], p2 = tile[pos + po1], p3 = tile[pos - po1];
+          sum += pt0 * (constrain_d(p0 - x, t, dmp) + constrain_d(p1 - x, t, dmp));
+          sum += pt1 * (constrain_d(p2 - x, t, dmp) + constrain_d(p3 - x, t, dmp));
+          if (clip) {
+            mx = max(mx, p0 == kVeryLarge ? x : p0); mx = max(mx, p1 == kVeryLarge ? x : p1);
+            mx = max(mx, p2 == kVeryLarge ? x : p2); mx = max(mx, p3 == kVeryLarge ? x : p3);
+            mn = min(min(mn, p0), min(p1, min(p2, p3)));
+          }
+        }
+        if (en_sec) {
+          const int a0 = tile[pos + s1o0], a1 = tile[pos - s1o0], a2 = tile[pos + s2o0], a3 = tile[pos - s2o0];
+          const int c0 = tile[pos + s1o1], c1 = tile[pos - s1o1], c2 = tile[pos + s2o1], c3 = tile[pos - s2o1];
+          sum += 2 * (constrain_d(a0 - x, sec_strength, dmp) + constrain_d(a1 - x, sec_strength, dmp) +
+                      constrain_d(a2 - x, sec_strength, dmp) + constrain_d(a3 - x, sec_strength, dmp));
+          sum += 1 * (constrain_d(c0 - x, sec_strength, dmp) + constrain_d(c1 - x, sec_strength, dmp) +
+                      constrain_d(c2 - x, sec_strength, dmp) + constrain_d(c3 - x, sec_strength, dmp));
+          if (clip) {
+            mx = max(mx, a0 == kVeryLarge ? x : a0); mx = max(mx, a1 == kVeryLarge ? x : a1);
+            mx = max(mx, a2 == kVeryLarge ? x : a2); mx = max(mx, a3 == kVeryLarge ? x : a3);
+            mx = max(mx, c0 == kVeryLarge ? x : c0); mx = max(mx, c1 == kVeryLarge ? x : c1);
+            mx = max(mx, c2 == kVeryLarge ? x : c2); mx = max(mx, c3 == kVeryLarge ? x : c3);
+            mn = min(min(min(mn, a0), min(a1, a2)), min(min(a3, c0), min(c1, min(c2, c3))));
+          }
+        }
+        y = x + ((8 + sum - (sum < 0)) >> 4);
+        if (clip) y = y < mn ? mn : (y > mx ? mx : y);
+      }
+      outv[j] = (PIX)y;
+    }
+    PIX *o = dst + (int64_t)(gy0 + rr) * stride + gx0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = outv[j];
+  }
+}
+
+}  // namespace aomhip
+
+using namespace aomhip;
+
+extern "C" {
+
+int aomhip_cdef_luma_plane(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dst,
+                           int dst_frame, const uint8_t *d_fb_pri, const uint8_t *d_fb_sec, int fb_stride,
+                           const uint8_t *d_skip8x8, int damping, uint8_t *d_dir_out, int32_t *d_var_out) {
+  if (!ctx || !src || !dst || !src->base || !dst->base || !d_fb_pri || !d_fb_sec || !d_skip8x8 || src_frame < 0 ||
+      src_frame >= src->n_frames || dst_frame < 0 || dst_frame >= dst->n_frames || src->width != dst->width ||
+      src->height != dst->height || src->stride != dst->stride || src->bit_depth != dst->bit_depth ||
+      (src->width & 7) || (src->height & 7) || damping < 3 || damping > 6 || fb_stride < (src->width + 63) / 64 ||
+      (src->base == dst->base && src_frame == dst_frame)) {
+    set_error("aomhip_cdef_luma_plane: invalid argument (dimensions must be multiples of 8, out of place)");
+    return AOMHIP_ERR_INVALID;
+  }
+  const size_t esz = src->bit_depth == 8 ? 1 : 2;
+  const char *s = static_cast<const char *>(src->base) +
+                  ((size_t)src_frame * src->frame_stride + (size_t)src->border * src->stride + src->border) * esz;
+  char *d = static_cast<char *>(dst->base) +
+            ((size_t)dst_frame * dst->frame_stride + (size_t)dst->border * dst->stride + dst->border) * esz;
+  const dim3 grid((src->width + 63) / 64, (src->height + 63) / 64);
+  if (esz == 1)
+    hipLaunchKernelGGL(cdef_luma_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, reinterpret_cast<const uint8_t *>(s),
+                       reinterpret_cast<uint8_t *>(d), src->stride, src->width, src->height, d_fb_pri, d_fb_sec,
+                       fb_stride, d_skip8x8, damping, 0, d_dir_out, d_var_out);
+  else
+    hipLaunchKernelGGL(cdef_luma_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const uint16_t *>(s), reinterpret_cast<uint16_t *>(d), src->stride, src->width,
+                       src->height, d_fb_pri, d_fb_sec, fb_stride, d_skip8x8, damping, src->bit_depth - 8, d_dir_out,
+                       d_var_out);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+}  // extern "C"

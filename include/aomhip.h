@@ -237,6 +237,25 @@ int aomhip_inv_txfm_add_batch(aomhip_ctx *ctx, const int32_t *d_dqcoeff, int tx_
 int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, const uint8_t *d_edge_params,
                          int units_stride, int sharpness, int passes);
 
+/* ------------------------------------------------------------------ CDEF */
+
+/* av1_cdef_frame (av1/common/cdef.c:440) for the LUMA plane, out of place: frame `src_frame` of `src` is the
+ * deblocked input, frame `dst_frame` of `dst` receives the filtered plane (same geometry; width and height
+ * multiples of 8).  Semantics of av1_cdef_filter_fb (av1/common/cdef_block.c:323-426) with pli == 0:
+ * cdef_find_dir (:57-126) per non-skipped 8x8 block, adjust_strength (:289-293), cdef_filter_{8,16}_{0..3}
+ * (:139-281; av1_rtcd_defs.pl:504-519); taps read pre-CDEF pixels, CDEF_VERY_LARGE outside the frame
+ * (cdef.c:138-245).
+ *   d_fb_pri / d_fb_sec  one byte per 64x64 filter block (fb_stride per row): primary level and secondary
+ *                        strength (after the 3 -> 4 rule, cdef.c:309-313) = cdef_strengths[idx] / 4, % 4
+ *   d_skip8x8            one byte per 8x8 block, row-major (width/8 per row): non-zero = all four 4x4 mode
+ *                        infos are skip_txfm (is_8x8_block_skip, cdef.c:24-35) -> block is copied
+ *   damping              cdef_damping, 3..6
+ *   d_dir_out/d_var_out  optional per-8x8 direction / variance (the chroma planes reuse the luma
+ *                        directions, cdef_block.c:355-369) */
+int aomhip_cdef_luma_plane(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dst,
+                           int dst_frame, const uint8_t *d_fb_pri, const uint8_t *d_fb_sec, int fb_stride,
+                           const uint8_t *d_skip8x8, int damping, uint8_t *d_dir_out, int32_t *d_var_out);
+
 /* ------------------------------------------------------------------ rtcd-signature conformance entry points */
 
 /* aom_dsp_rtcd_defs.pl:762-763 aom_sad{W}x{H} / aom_sad_skip_{W}x{H}; host pointers. */

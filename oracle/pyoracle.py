@@ -332,3 +332,32 @@ def random_edge_params(rng, width, height, max_log2=6, level_range=(1, 64), chro
                 l = lvl[uy, ux] if lvl[uy, ux] else lvl[uy - 1, ux]
                 p[uy, ux, 2], p[uy, ux, 3] = flen(t), l
     return p
+
+
+# ---- CDEF (aomref_cdef.c)
+lib.orc_cdef_find_dir.restype = _i
+lib.orc_cdef_find_dir.argtypes = [_vp, _i, C.POINTER(C.c_int32), _i]
+lib.orc_cdef_plane_luma.restype = None
+lib.orc_cdef_plane_luma.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]
+
+
+def cdef_find_dir(block16, coeff_shift=0):
+    b = np.ascontiguousarray(block16, np.uint16)
+    var = C.c_int32()
+    d = lib.orc_cdef_find_dir(b.ctypes.data, b.shape[1], C.byref(var), coeff_shift)
+    return d, var.value
+
+
+def cdef_plane_luma(pixels, fb_pri, fb_sec, skip, damping, bd=8):
+    """pixels: 2-D plane (uint8/uint16); fb_pri/fb_sec: [fb_rows, fb_cols] uint8; skip: [h/8, w/8] uint8.
+    -> (filtered plane, dir [h/8, w/8] uint8, var int32)"""
+    src = np.ascontiguousarray(pixels)
+    dst = np.zeros_like(src)
+    h, w = src.shape
+    fb_pri = np.ascontiguousarray(fb_pri, np.uint8); fb_sec = np.ascontiguousarray(fb_sec, np.uint8)
+    skip = np.ascontiguousarray(skip, np.uint8)
+    d = np.zeros((h // 8, w // 8), np.uint8); v = np.zeros((h // 8, w // 8), np.int32)
+    lib.orc_cdef_plane_luma(src.ctypes.data, dst.ctypes.data, src.shape[1], w, h, int(src.dtype != np.uint8), bd,
+                            fb_pri.ctypes.data, fb_sec.ctypes.data, fb_pri.shape[1], skip.ctypes.data, damping,
+                            d.ctypes.data, v.ctypes.data)
+    return dst, d, v

@@ -1,0 +1,81 @@
+"""Parity of the HIP CDEF luma kernel with the oracle (bit-exact): random strengths per 64x64 filter block,
+random skip maps, all dampings, 8/10/12-bit, partial filter blocks at the right / bottom frame edge,
+direction / variance side outputs; plus the 4K 10-bit plane of BASELINE configs[4] (pri 4 / sec 2, damping 6)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _content(rng, W, H, bd):
+    mx = (1 << bd) - 1
+    base = rng.integers(mx // 8, mx - mx // 8, (H // 8 + 1, W // 8 + 1))
+    i, j = np.indices((H, W))
+    pix = np.kron(base, np.ones((8, 8), np.int64))[:H, :W] + ((i * 3 + j * 5) % 17) * (mx // 255 + 1) + rng.integers(-8, 9, (H, W))
+    return np.clip(pix, 0, mx).astype(np.uint8 if bd == 8 else np.uint16)
+
+
+def _run(hip, ctx, pix, pri, sec, skip, damping, bd):
+    H, W = pix.shape
+    ps, pd = ctx.planes_alloc(W, H, 32, bd, 1), ctx.planes_alloc(W, H, 32, bd, 2)
+    ctx.planes_upload(ps, 0, pix)
+    d_pri, d_sec, d_skip = ctx.to_device(pri), ctx.to_device(sec), ctx.to_device(skip)
+    nb = (H // 8) * (W // 8)
+    d_dir, d_var = ctx.malloc(max(nb, 16)), ctx.malloc(nb * 4)
+    ctx.cdef_luma_plane(ps, 0, pd, 1, d_pri, d_sec, pri.shape[1], d_skip, damping, d_dir, d_var)
+    out = ctx.planes_download(pd, 1)[32:32 + H, 32:32 + W]
+    gdir = ctx.from_device(d_dir, (H // 8, W // 8), np.uint8)
+    gvar = ctx.from_device(d_var, (H // 8, W // 8), np.int32)
+    ctx.planes_free(ps); ctx.planes_free(pd)
+    for d in (d_pri, d_sec, d_skip, d_dir, d_var):
+        ctx.free(d)
+    return out, gdir, gvar
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_random_strength_maps(hip, oracle, ctx, bd):
+    rng = np.random.default_rng(bd)
+    for trial in range(5):
+        W, H = int(rng.choice([64, 136, 200, 320])), int(rng.choice([64, 72, 200]))
+        pix = _content(rng, W, H, bd)
+        fbh, fbw = (H + 63) // 64, (W + 63) // 64
+        pri = rng.integers(0, 16, (fbh, fbw)).astype(np.uint8)
+        sec = rng.choice([0, 1, 2, 4], (fbh, fbw)).astype(np.uint8)
+        if trial == 0:
+            pri[0, 0], sec[0, 0] = 0, 0
+        skip = (rng.random((H // 8, W // 8)) < 0.25).astype(np.uint8)
+        damping = int(rng.integers(3, 7))
+        got, gdir, gvar = _run(hip, ctx, pix, pri, sec, skip, damping, bd)
+        want, wdir, wvar = oracle.cdef_plane_luma(pix, pri, sec, skip, damping, bd)
+        assert np.array_equal(got, want), (bd, trial)
+        assert np.array_equal(gdir, wdir) and np.array_equal(gvar, wvar)
+        assert not np.array_equal(got, pix)
+
+
+def test_each_enable_combination(hip, oracle, ctx):
+    """strength_index 0..3 of av1_cdef_filter_fb: {pri, sec} x {on, off}, odd / even primary strengths
+    (the two cdef_pri_taps rows) and every damping."""
+    rng = np.random.default_rng(3)
+    pix = _content(rng, 128, 64, 8)
+    noskip = np.zeros((8, 16), np.uint8)
+    for pri_v in (0, 1, 2, 7, 15):
+        for sec_v in (0, 1, 2, 4):
+            for damping in (3, 6):
+                pri = np.full((1, 2), pri_v, np.uint8); sec = np.full((1, 2), sec_v, np.uint8)
+                got, _, _ = _run(hip, ctx, pix, pri, sec, noskip, damping, 8)
+                want, _, _ = oracle.cdef_plane_luma(pix, pri, sec, noskip, damping, 8)
+                assert np.array_equal(got, want), (pri_v, sec_v, damping)
+
+
+def test_full_size_4k_10bit(hip, oracle, ctx):
+    W, H, bd = 3840, 2160, 10
+    src, _ = hip.synth.shifted_smooth_pair(W, H, 2, bd)
+    rng = np.random.default_rng(6)
+    pix = np.clip(src.astype(np.int32) + rng.integers(-20, 21, (H, W)), 0, 1023).astype(np.uint16)
+    fbh, fbw = (H + 63) // 64, (W + 63) // 64
+    pri = np.full((fbh, fbw), 4, np.uint8); sec = np.full((fbh, fbw), 2, np.uint8)
+    skip = np.zeros((H // 8, W // 8), np.uint8)
+    got, gdir, gvar = _run(hip, ctx, pix, pri, sec, skip, 6, bd)
+    want, wdir, wvar = oracle.cdef_plane_luma(pix, pri, sec, skip, 6, bd)
+    assert np.array_equal(got, want) and np.array_equal(gdir, wdir) and np.array_equal(gvar, wvar)
+    assert got.max() <= pix.max() and got.min() >= pix.min()
