@@ -37,6 +37,9 @@ class QuantParams(C.Structure):
 
 txb_dtype = np.dtype([("x", "<i4"), ("y", "<i4"), ("out_offset", "<u4"), ("tx_type", "u1"), ("reserved", "u1", (3,))])
 sad_cand_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2"), ("ry", "<i2")])
+search_block_dtype = np.dtype([(n, "<i2") for n in ("bx", "by", "start_row", "start_col", "ref_row", "ref_col", "row_min",
+                                                    "row_max", "col_min", "col_max")])
+MV_COST_L1_LOWRES, MV_COST_L1_MIDRES, MV_COST_L1_HDRES, MV_COST_NONE = 1, 2, 3, 4
 var_cand_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2"), ("ry", "<i2"), ("xoff", "u1"), ("yoff", "u1"),
                            ("reserved", "u1", (2,))])
 sad_x4d_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2", (4,)), ("ry", "<i2", (4,))])
@@ -84,6 +87,8 @@ _protos = {
     "aomhip_inv_txfm_add_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _PP, _i]),
     "aomhip_deblock_plane": (C.c_int, [_vp, _PP, _i, _vp, _i, _i, _i]),
     "aomhip_cdef_luma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "aomhip_fullpel_diamond_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "aomhip_subpel_bilinear_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp, _i, _i]),
@@ -217,3 +222,14 @@ class Context:
                         d_var=None):
         check(lib.aomhip_cdef_luma_plane(self.h, C.byref(src), src_frame, C.byref(dst), dst_frame, d_pri, d_sec,
                                          fb_stride, d_skip, damping, d_dir, d_var), "aomhip_cdef_luma_plane")
+
+    # ---- motion search
+    def fullpel_diamond_batch(self, src, ref, frame, bw, bh, clamped, step_param, cost_type, d_blocks, n, d_mv, d_cost):
+        check(lib.aomhip_fullpel_diamond_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, clamped, step_param,
+                                               cost_type, d_blocks, n, d_mv, d_cost), "aomhip_fullpel_diamond_batch")
+
+    def subpel_bilinear_batch(self, src, ref, frame, bw, bh, cost_type, iters, allow_hp, forced_stop, d_blocks, n, d_mv,
+                              d_err, d_dist, d_sse):
+        check(lib.aomhip_subpel_bilinear_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, cost_type, iters,
+                                               allow_hp, forced_stop, d_blocks, n, d_mv, d_err, d_dist, d_sse),
+              "aomhip_subpel_bilinear_batch")

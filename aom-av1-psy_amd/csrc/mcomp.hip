@@ -1,0 +1,422 @@
+// Device-side motion search on gfx950: full-pel diamond search + bilinear sub-pel refinement over a batch
+// of blocks (av1/encoder/mcomp.c).  One wavefront owns one block for the whole (sequential, greedy) search;
+// the data parallelism is across blocks and across the 8 sites of a diamond step.
+//
+//   fullpel_diamond_kernel : full_pixel_diamond (mcomp.c:1421-1470) = diamond_search_sad (:1299-1416) with the
+//       restart loop and the final get_mvpred_var_cost (:645-664).  The 64 lanes form 8 groups of 8; each
+//       group evaluates one site of the step (aom_sadWxH through the vtable's sdf / sdx4df, with the 10/12-bit
+//       >>2 / >>4 wrappers of encoder_utils.h:155-208), the 8 results are broadcast and every lane replays the
+//       reference's two-stage comparison `if (sad < best) { sad += cost; if (sad < best) ... }` in site order,
+//       so ties and cost effects resolve exactly as in the scalar loop.
+//   subpel_bilinear_kernel : av1_find_best_sub_pixel_tree_pruned_more (:2844-2929) with cost_list == NULL on an
+//       unscaled reference: setup_center_error (:2718-2778), two_level_checks_fast (:2503-2624) at 1/2, 1/4,
+//       1/8 pel, each candidate = one aom_sub_pixel_varianceWxH evaluated by all 64 lanes.
+// MV cost: MV_COST_NONE and the three L1 types (mcomp.c:236-244,271-339); the entropy-table type is refused.
+#include <climits>
+
+#include "common.h"
+
+namespace aomhip {
+
+struct __attribute__((packed, aligned(1))) MU128 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) MU64 { uint32_t v[2]; };
+struct __attribute__((packed, aligned(1))) MU32 { uint32_t v[1]; };
+template <int BYTES> struct MLoad;
+template <> struct MLoad<16> { using type = MU128; };
+template <> struct MLoad<8> { using type = MU64; };
+template <> struct MLoad<4> { using type = MU32; };
+
+enum { kCostEntropy = 0, kCostL1Low = 1, kCostL1Mid = 2, kCostL1Hd = 3, kCostNone = 4 };  // MV_COST_TYPE (mcomp.h:40-50)
+
+__device__ __forceinline__ int iabsm(int v) { return v < 0 ? -v : v; }
+
+struct CostCtx {
+  int cost_type, ref_row, ref_col;  // ref_mv in 1/8 pel
+  __device__ __forceinline__ int sad_cost(int row, int col) const {  // mvsad_err_cost_ (mcomp.c:310-339)
+    const int frr = (ref_row + 3 + (ref_row >= 0)) >> 3, frc = (ref_col + 3 + (ref_col >= 0)) >> 3;  // GET_MV_RAWPEL
+    const int d = iabsm((row - frr) * 8) + iabsm((col - frc) * 8);
+    const int lambda = cost_type == kCostL1Low ? 32 : cost_type == kCostL1Mid ? 15 : cost_type == kCostL1Hd ? 8 : 0;
+    return (lambda * d) >> 3;
+  }
+  __device__ __forceinline__ int var_cost(int mrow, int mcol) const {  // mv_err_cost_ (mcomp.c:271-308)
+    const int d = iabsm(mrow - ref_row) + iabsm(mcol - ref_col);
+    const int lambda = cost_type == kCostL1Low ? 2 : cost_type == kCostL1Mid ? 0 : cost_type == kCostL1Hd ? 1 : 0;
+    return (lambda * d) >> 3;
+  }
+};
+
+template <typename T> __device__ __forceinline__ uint32_t sadw(uint32_t a, uint32_t b, uint32_t acc) {
+  if constexpr (sizeof(T) == 1) return __builtin_amdgcn_sad_u8(a, b, acc);
+  else return __builtin_amdgcn_sad_u16(a, b, acc);
+}
+
+// SAD of the W x H block at sp vs rp, computed by the 8 lanes of a group (l = lane & 7); all 8 get the sum.
+template <typename T, int W, int H>
+__device__ __forceinline__ uint32_t group8_sad(const T *sp, int sstride, const T *rp, int rstride, int l, bool active) {
+  constexpr int RB = W * (int)sizeof(T);
+  constexpr int UB = RB < 16 ? RB : 16;
+  constexpr int UE = UB / (int)sizeof(T);
+  constexpr int UPR = RB / UB;
+  constexpr int U = UPR * H;
+  using L = typename MLoad<UB>::type;
+  uint32_t acc = 0;
+  if (active) {
+    for (int u = l; u < U; u += 8) {
+      const int row = u / UPR, col = (u % UPR) * UE;
+      const L a = *reinterpret_cast<const L *>(sp + (int64_t)row * sstride + col);
+      const L b = *reinterpret_cast<const L *>(rp + (int64_t)row * rstride + col);
+#pragma unroll
+      for (int i = 0; i < UB / 4; ++i) acc = sadw<T>(a.v[i], b.v[i], acc);
+    }
+  }
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0xB1, 0xf, 0xf, false);
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0x4E, 0xf, 0xf, false);
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0x141, 0xf, 0xf, false);
+  return acc;
+}
+
+__device__ __forceinline__ int64_t wave_sum64(int64_t v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor((long long)v, m, 64);
+  return v;
+}
+
+// Variance (SUBPEL = false) or bilinear sub-pixel variance of a W x H block by all 64 lanes.  a = "ref" operand
+// (interpolated when SUBPEL), b = "src" operand; diff = A_MINUS_B ? a - b : b - a.  Returns var, *sse.
+template <typename T, int W, int H, bool SUBPEL>
+__device__ __forceinline__ uint32_t wave_variance(const T *ap, int astride, int xoff, int yoff, const T *bp, int bstride,
+                                                  bool a_minus_b, int bit_depth, int lane, uint32_t *sse_out) {
+  constexpr int UE = 4;  // pixels per unit
+  constexpr int UPR = W / UE;
+  constexpr int U = UPR * H;
+  constexpr uint8_t kBil[8][2] = { { 128, 0 }, { 112, 16 }, { 96, 32 }, { 80, 48 },
+                                   { 64, 64 }, { 48, 80 },  { 32, 96 }, { 16, 112 } };  // aom_filter.h:43-50
+  const int fx0 = kBil[xoff & 7][0], fx1 = kBil[xoff & 7][1], fy0 = kBil[yoff & 7][0], fy1 = kBil[yoff & 7][1];
+  int64_t sum = 0, sse = 0;
+  for (int u = lane; u < U; u += 64) {
+    const int row = u / UPR, col = (u % UPR) * UE;
+    const T *a0 = ap + (int64_t)row * astride + col;
+    const T *b0 = bp + (int64_t)row * bstride + col;
+    int us = 0;
+    uint32_t uq = 0;
+#pragma unroll
+    for (int i = 0; i < UE; ++i) {
+      int av;
+      if constexpr (SUBPEL) {
+        const int h0 = ((int)a0[i] * fx0 + (int)a0[i + 1] * fx1 + 64) >> 7;
+        const int h1 = ((int)a0[astride + i] * fx0 + (int)a0[astride + i + 1] * fx1 + 64) >> 7;
+        av = (h0 * fy0 + h1 * fy1 + 64) >> 7;
+        av &= (sizeof(T) == 1) ? 0xFF : 0xFFFF;
+      } else {
+        av = a0[i];
+      }
+      const int d = a_minus_b ? av - (int)b0[i] : (int)b0[i] - av;
+      us += d;
+      uq += (uint32_t)(d * d);
+    }
+    sum += us;
+    sse += uq;
+  }
+  sum = wave_sum64(sum);
+  sse = wave_sum64(sse);
+  // variance.c:141-148 / :383-420
+  int32_t s;
+  uint32_t q;
+  if (bit_depth == 10) {
+    q = (uint32_t)(((uint64_t)sse + 8) >> 4);
+    s = (int32_t)((sum + 2) >> 2);
+  } else if (bit_depth == 12) {
+    q = (uint32_t)(((uint64_t)sse + 128) >> 8);
+    s = (int32_t)((sum + 8) >> 4);
+  } else {
+    q = (uint32_t)sse;
+    s = (int32_t)sum;
+  }
+  *sse_out = q;
+  constexpr int LOG2N = __builtin_ctz(W * H);
+  const int64_t sq = ((int64_t)s * s) >> LOG2N;
+  if (bit_depth == 8) return q - (uint32_t)sq;
+  const int64_t v = (int64_t)q - sq;
+  return v >= 0 ? (uint32_t)v : 0;
+}
+
+constexpr int kSearchThreads = 256;  // 4 blocks (wavefronts) per workgroup
+
+template <typename T, int W, int H>
+__global__ __launch_bounds__(kSearchThreads) void fullpel_diamond_kernel(
+    PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
+    int level, int step_param, int cost_type, int bit_depth, int16_t *__restrict__ out_mv,
+    int32_t *__restrict__ out_cost) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * (kSearchThreads / 64) + wave;
+  if (bi >= n_blocks) return;
+  const aomhip_search_block b = blocks[bi];
+  const T *sp = src.origin + (int64_t)frame * src.frame_stride + (int64_t)b.by * src.stride + b.bx;
+  const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)b.by * ref.stride + b.bx;
+  const CostCtx cc{ cost_type, b.ref_row, b.ref_col };
+  const int shift = bit_depth == 10 ? 2 : bit_depth == 12 ? 4 : 0;  // vtable wrappers for highbd SAD
+  const int g = lane >> 3, l = lane & 7;
+  const int dr = (g == 0 || g == 4 || g == 6) ? -1 : (g == 1 || g == 5 || g == 7) ? 1 : 0;   // site order of
+  const int dc = (g == 2 || g == 4 || g == 7) ? -1 : (g == 3 || g == 5 || g == 6) ? 1 : 0;   // mcomp.c:366-370
+
+  // radius of stage k (av1_init_dsmotion_compensation): DIAMOND 2^k, CLAMPED_DIAMOND min(2^k, 256); 11 stages
+  auto radius = [level](int k) { const int r = 1 << k; return (level > 0 && r > 256) ? 256 : r; };
+
+  auto run_diamond = [&](int search_step, int *num00, int *orow, int *ocol) -> int {
+    int row = min(max((int)b.start_row, (int)b.row_min), (int)b.row_max);  // clamp_fullmv
+    int col = min(max((int)b.start_col, (int)b.col_min), (int)b.col_max);
+    const int tot_steps = 11 - search_step;
+    *num00 = 0;
+    uint32_t s0 = group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)row * ref.stride + col, ref.stride, l, true) >> shift;
+    s0 = __shfl(s0, 0, 64);
+    uint32_t bestsad = s0 + (uint32_t)cc.sad_cost(row, col);
+    int is_off_center = 0;
+    int next_step_size = tot_steps > 2 ? radius(tot_steps - 2) : 1;
+    for (int step = tot_steps - 1; step >= 0; --step) {
+      const int r = radius(step);
+      if (step > 0) next_step_size = radius(step - 1);
+      const int srow = row + dr * r, scol = col + dc * r;
+      const bool inr = scol >= b.col_min && scol <= b.col_max && srow >= b.row_min && srow <= b.row_max;
+      const uint32_t mine =
+          group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)srow * ref.stride + scol, ref.stride, l, inr) >> shift;
+      int best_site = 0;
+#pragma unroll
+      for (int idx = 1; idx <= 8; ++idx) {
+        const uint32_t sad = __shfl(mine, (idx - 1) * 8, 64);
+        const int ok = __shfl((int)inr, (idx - 1) * 8, 64);
+        const int ddr = (idx == 1 || idx == 5 || idx == 7) ? -1 : (idx == 2 || idx == 6 || idx == 8) ? 1 : 0;
+        const int ddc = (idx == 3 || idx == 5 || idx == 8) ? -1 : (idx == 4 || idx == 6 || idx == 7) ? 1 : 0;
+        if (ok && sad < bestsad) {
+          const uint32_t thissad = sad + (uint32_t)cc.sad_cost(row + ddr * r, col + ddc * r);
+          if (thissad < bestsad) {
+            bestsad = thissad;
+            best_site = idx;
+          }
+        }
+      }
+      if (best_site != 0) {
+        const int ddr = (best_site == 1 || best_site == 5 || best_site == 7) ? -1
+                        : (best_site == 2 || best_site == 6 || best_site == 8) ? 1 : 0;
+        const int ddc = (best_site == 3 || best_site == 5 || best_site == 8) ? -1
+                        : (best_site == 4 || best_site == 6 || best_site == 7) ? 1 : 0;
+        row += ddr * r;
+        col += ddc * r;
+        is_off_center = 1;
+      }
+      if (is_off_center == 0) (*num00)++;
+      if (best_site == 0) {
+        while (next_step_size == radius(step) && step > 2) {
+          ++(*num00);
+          --step;
+          next_step_size = radius(step - 1);
+        }
+      }
+    }
+    *orow = row;
+    *ocol = col;
+    return (int)bestsad;
+  };
+
+  auto var_cost_at = [&](int row, int col) -> int {  // get_mvpred_var_cost: vf(src, ref) + mv_err_cost_
+    uint32_t sse;
+    const uint32_t v = wave_variance<T, W, H, false>(rbase + (int64_t)row * ref.stride + col, ref.stride, 0, 0, sp,
+                                                     src.stride, /*a_minus_b=*/false, bit_depth, lane, &sse);
+    return (int)v + cc.var_cost(row * 8, col * 8);
+  };
+
+  // full_pixel_diamond (mcomp.c:1421-1470)
+  int n00, num00 = 0, br, bc;
+  int bestsme = run_diamond(step_param, &n00, &br, &bc);
+  if (bestsme < INT_MAX) bestsme = var_cost_at(br, bc);
+  const int further_steps = 11 - 1 - step_param;
+  int nn = n00;
+  while (nn < further_steps) {
+    ++nn;
+    if (num00) {
+      num00--;
+    } else {
+      int tr, tc;
+      int thissme = run_diamond(step_param + nn, &num00, &tr, &tc);
+      if (thissme < INT_MAX) thissme = var_cost_at(tr, tc);
+      if (thissme < bestsme) {
+        bestsme = thissme;
+        br = tr;
+        bc = tc;
+      }
+    }
+  }
+  if (lane == 0) {
+    out_mv[2 * bi] = (int16_t)br;
+    out_mv[2 * bi + 1] = (int16_t)bc;
+    out_cost[bi] = bestsme;
+  }
+}
+
+template <typename T, int W, int H>
+__global__ __launch_bounds__(kSearchThreads) void subpel_bilinear_kernel(
+    PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
+    int cost_type, int iters_per_step, int allow_hp, int forced_stop, int bit_depth, int16_t *__restrict__ out_mv,
+    uint32_t *__restrict__ out_err, int32_t *__restrict__ out_dist, uint32_t *__restrict__ out_sse) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * (kSearchThreads / 64) + wave;
+  if (bi >= n_blocks) return;
+  const aomhip_search_block b = blocks[bi];  // start_* in 1/8 pel, limits = SubpelMvLimits
+  const T *sp = src.origin + (int64_t)frame * src.frame_stride + (int64_t)b.by * src.stride + b.bx;
+  const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)b.by * ref.stride + b.bx;
+  const CostCtx cc{ cost_type, b.ref_row, b.ref_col };
+
+  uint32_t besterr, sse1;
+  int distortion, best_row = b.start_row, best_col = b.start_col;
+  {  // setup_center_error: vf(ref at the full-pel part, src): diff = ref - src
+    const int fr = b.start_row >> 3, fc = b.start_col >> 3;
+    const uint32_t v = wave_variance<T, W, H, false>(rbase + (int64_t)fr * ref.stride + fc, ref.stride, 0, 0, sp,
+                                                     src.stride, /*a_minus_b=*/true, bit_depth, lane, &sse1);
+    distortion = (int)v;
+    besterr = v + (uint32_t)cc.var_cost(b.start_row, b.start_col);
+  }
+  auto check = [&](int mrow, int mcol) -> uint32_t {  // check_better_fast (mcomp.c:2433-2461)
+    if (mcol < b.col_min || mcol > b.col_max || mrow < b.row_min || mrow > b.row_max) return (uint32_t)INT_MAX;
+    uint32_t sse;
+    const int thismse = (int)wave_variance<T, W, H, true>(rbase + (int64_t)(mrow >> 3) * ref.stride + (mcol >> 3),
+                                                          ref.stride, mcol & 7, mrow & 7, sp, src.stride, true,
+                                                          bit_depth, lane, &sse);
+    const uint32_t cost = (uint32_t)cc.var_cost(mrow, mcol) + (uint32_t)thismse;
+    if (cost < besterr) {
+      besterr = cost;
+      best_row = mrow;
+      best_col = mcol;
+      distortion = thismse;
+      sse1 = sse;
+    }
+    return cost;
+  };
+  auto two_level = [&](int trow, int tcol, int hstep) {  // two_level_checks_fast (mcomp.c:2503-2624)
+    const uint32_t left = check(trow, tcol - hstep);
+    const uint32_t right = check(trow, tcol + hstep);
+    const uint32_t up = check(trow - hstep, tcol);
+    const uint32_t down = check(trow + hstep, tcol);
+    const int drow = up <= down ? -hstep : hstep, dcol = left <= right ? -hstep : hstep;
+    check(trow + drow, tcol + dcol);
+    if (iters_per_step <= 1) return;
+    const int br = best_row, bc = best_col;
+    if (trow != br && tcol != bc) {
+      check(br, bc + dcol);
+      check(br + drow, bc);
+    } else if (trow == br && tcol != bc) {
+      check(br + hstep, bc + dcol);
+      check(br - hstep, bc + dcol);
+      check(br - drow, bc);
+    } else if (trow != br && tcol == bc) {
+      check(br + drow, bc + hstep);
+      check(br + drow, bc - hstep);
+      check(br, bc - dcol);
+    }
+  };
+  int hstep = 4;          // INIT_SUBPEL_STEP_SIZE
+  if (forced_stop != 3) {  // FULL_PEL
+    two_level(b.start_row, b.start_col, hstep);
+    if (forced_stop < 2) {  // < HALF_PEL
+      hstep >>= 1;
+      two_level(best_row, best_col, hstep);
+    }
+    if (allow_hp && forced_stop == 0) {  // EIGHTH_PEL
+      hstep >>= 1;
+      two_level(best_row, best_col, hstep);
+    }
+  }
+  if (lane == 0) {
+    out_mv[2 * bi] = (int16_t)best_row;
+    out_mv[2 * bi + 1] = (int16_t)best_col;
+    out_err[bi] = besterr;
+    out_dist[bi] = distortion;
+    out_sse[bi] = sse1;
+  }
+}
+
+#define AOMHIP_FOR_BLOCK_SIZES(X)                                                                                \
+  X(4, 4) X(4, 8) X(8, 4) X(8, 8) X(8, 16) X(16, 8) X(16, 16) X(16, 32) X(32, 16) X(32, 32) X(32, 64) X(64, 32) \
+  X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(4, 16) X(16, 4) X(8, 32) X(32, 8) X(16, 64) X(64, 16)
+
+static int check_common(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                        const void *blocks, int n, int cost_type) {
+  if (!ctx || !src || !ref || !src->base || !ref->base || (n > 0 && !blocks) || n < 0 || frame < 0 ||
+      frame >= src->n_frames || frame >= ref->n_frames || !valid_block(bw, bh) ||
+      (src->bit_depth == 8) != (ref->bit_depth == 8)) {
+    set_error("motion search: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (cost_type == kCostEntropy || cost_type < 0 || cost_type > kCostNone) {
+    set_error("motion search: MV_COST_ENTROPY (cost tables) is not supported on the device path yet");
+    return AOMHIP_ERR_INVALID;
+  }
+  return AOMHIP_OK;
+}
+
+}  // namespace aomhip
+
+using namespace aomhip;
+
+extern "C" {
+
+int aomhip_fullpel_diamond_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw,
+                                 int bh, int clamped, int step_param, int mv_cost_type,
+                                 const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
+                                 int32_t *d_best_cost) {
+  int rc = check_common(ctx, src, ref, frame, bw, bh, d_blocks, n_blocks, mv_cost_type);
+  if (rc != AOMHIP_OK) return rc;
+  if (!d_best_mv || !d_best_cost || step_param < 0 || step_param > 10) {
+    set_error("aomhip_fullpel_diamond_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  const dim3 grid((n_blocks + 3) / 4), block(kSearchThreads);
+#define X(W, H)                                                                                                      \
+  if (bw == W && bh == H) {                                                                                          \
+    if (src->bit_depth == 8)                                                                                         \
+      hipLaunchKernelGGL((fullpel_diamond_kernel<uint8_t, W, H>), grid, block, 0, ctx->stream, view_of<uint8_t>(*src), \
+                         view_of<uint8_t>(*ref), frame, d_blocks, n_blocks, clamped, step_param, mv_cost_type, 8,    \
+                         d_best_mv, d_best_cost);                                                                    \
+    else                                                                                                             \
+      hipLaunchKernelGGL((fullpel_diamond_kernel<uint16_t, W, H>), grid, block, 0, ctx->stream,                       \
+                         view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame, d_blocks, n_blocks, clamped,       \
+                         step_param, mv_cost_type, src->bit_depth, d_best_mv, d_best_cost);                          \
+    AOMHIP_LAUNCH_CHECK();                                                                                           \
+    return AOMHIP_OK;                                                                                                \
+  }
+  AOMHIP_FOR_BLOCK_SIZES(X)
+#undef X
+  return AOMHIP_ERR_INVALID;
+}
+
+int aomhip_subpel_bilinear_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw,
+                                 int bh, int mv_cost_type, int iters_per_step, int allow_hp, int forced_stop,
+                                 const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
+                                 uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse) {
+  int rc = check_common(ctx, src, ref, frame, bw, bh, d_blocks, n_blocks, mv_cost_type);
+  if (rc != AOMHIP_OK) return rc;
+  if (!d_best_mv || !d_best_err || !d_distortion || !d_sse || forced_stop < 0 || forced_stop > 3) {
+    set_error("aomhip_subpel_bilinear_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  const dim3 grid((n_blocks + 3) / 4), block(kSearchThreads);
+#define X(W, H)                                                                                                      \
+  if (bw == W && bh == H) {                                                                                          \
+    if (src->bit_depth == 8)                                                                                         \
+      hipLaunchKernelGGL((subpel_bilinear_kernel<uint8_t, W, H>), grid, block, 0, ctx->stream, view_of<uint8_t>(*src), \
+                         view_of<uint8_t>(*ref), frame, d_blocks, n_blocks, mv_cost_type, iters_per_step, allow_hp,  \
+                         forced_stop, 8, d_best_mv, d_best_err, d_distortion, d_sse);                                \
+    else                                                                                                             \
+      hipLaunchKernelGGL((subpel_bilinear_kernel<uint16_t, W, H>), grid, block, 0, ctx->stream,                       \
+                         view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame, d_blocks, n_blocks, mv_cost_type,  \
+                         iters_per_step, allow_hp, forced_stop, src->bit_depth, d_best_mv, d_best_err, d_distortion, \
+                         d_sse);                                                                                     \
+    AOMHIP_LAUNCH_CHECK();                                                                                           \
+    return AOMHIP_OK;                                                                                                \
+  }
+  AOMHIP_FOR_BLOCK_SIZES(X)
+#undef X
+  return AOMHIP_ERR_INVALID;
+}
+
+}  // extern "C"

@@ -42,8 +42,8 @@ def lcg_frame(width, height, frame_idx, plane=0, bit_depth=8):
     return out
 
 
-def shifted_smooth_pair(width, height, frame_idx, bit_depth=8, shift=(3, -2)):
-    """Natural-like content: low-pass filtered noise; ref = src shifted by (dx, dy) plus a
+def shifted_smooth_pair(width, height, frame_idx, bit_depth=8, shift=(3, -2), frac8=(0, 0)):
+    """Natural-like content: low-pass filtered noise; ref = src shifted by (dx, dy) [+ frac8/8 pel, bilinear] plus a
     little noise, so motion searches converge (configs 4/5)."""
     rng = np.random.default_rng(0xBABA + frame_idx)
     pad = 16
@@ -61,7 +61,12 @@ def shifted_smooth_pair(width, height, frame_idx, bit_depth=8, shift=(3, -2)):
     img = np.clip(n * (mx / 6.0) + mx / 2.0, 0, mx)
     dx, dy = shift
     src = img[pad:pad + height, pad:pad + width]
-    ref = img[pad - dy:pad - dy + height, pad - dx:pad - dx + width] + rng.normal(0, mx / 256.0, (height, width))
+    fx, fy = frac8[0] / 8.0, frac8[1] / 8.0
+
+    def win(oy, ox):
+        return img[pad - dy - oy:pad - dy - oy + height, pad - dx - ox:pad - dx - ox + width]
+    ref = ((1 - fy) * ((1 - fx) * win(0, 0) + fx * win(0, 1)) + fy * ((1 - fx) * win(1, 0) + fx * win(1, 1))
+           + rng.normal(0, mx / 256.0, (height, width)))
     dt = np.uint16 if bit_depth > 8 else np.uint8
     return np.clip(np.rint(src), 0, mx).astype(dt), np.clip(np.rint(ref), 0, mx).astype(dt)
 

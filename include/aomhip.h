@@ -256,6 +256,43 @@ int aomhip_cdef_luma_plane(aomhip_ctx *ctx, const aomhip_planes *src, int src_fr
                            int dst_frame, const uint8_t *d_fb_pri, const uint8_t *d_fb_sec, int fb_stride,
                            const uint8_t *d_skip8x8, int damping, uint8_t *d_dir_out, int32_t *d_var_out);
 
+/* ------------------------------------------------------------------ device-side motion search */
+
+/* One block of a search batch.  Full-pel search: start_* / limits are FULLPEL_MV units (pixels), limits =
+ * FullMvLimits after av1_set_mv_search_range (av1/encoder/mcomp.c:196-215).  Sub-pel search: start_* is the
+ * MV to refine in 1/8 pel, limits = SubpelMvLimits (av1_set_subpel_mv_search_range, mcomp.h:344-361).
+ * ref_row / ref_col is ref_mv (1/8 pel) for the MV cost (MV_COST_PARAMS, mcomp.h:70-84). */
+typedef struct {
+  int16_t bx, by;               /* block origin in the source plane (pixels) */
+  int16_t start_row, start_col;
+  int16_t ref_row, ref_col;
+  int16_t row_min, row_max, col_min, col_max;
+} aomhip_search_block;
+
+/* MV_COST_TYPE (av1/encoder/mcomp.h:40-50).  The entropy-table type is not implemented on the device. */
+#define AOMHIP_MV_COST_ENTROPY 0
+#define AOMHIP_MV_COST_L1_LOWRES 1
+#define AOMHIP_MV_COST_L1_MIDRES 2
+#define AOMHIP_MV_COST_L1_HDRES 3
+#define AOMHIP_MV_COST_NONE 4
+
+/* full_pixel_diamond (av1/encoder/mcomp.c:1421-1470) for every block: diamond_search_sad (:1299-1416) on the
+ * DIAMOND (clamped = 0) or CLAMPED_DIAMOND (1) site table (av1_init_dsmotion_compensation, :350-389) from
+ * step_param, its restart loop, and the final variance + MV cost (get_mvpred_var_cost, :645-664).
+ * d_best_mv[2*i] = row, [2*i+1] = col (full-pel); d_best_cost[i] = the value full_pixel_diamond returns. */
+int aomhip_fullpel_diamond_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw,
+                                 int bh, int clamped, int step_param, int mv_cost_type,
+                                 const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
+                                 int32_t *d_best_cost);
+/* av1_find_best_sub_pixel_tree_pruned_more (mcomp.c:2844-2929) with the bilinear estimator
+ * (subpel_search_type USE_2_TAPS_ORIG -> vfp->svf), cost_list == NULL, unscaled reference.
+ * forced_stop: 0 EIGHTH_PEL, 1 QUARTER_PEL, 2 HALF_PEL, 3 FULL_PEL (SUBPEL_FORCE_STOP, speed_features.h).
+ * Outputs per block: best MV (1/8 pel), besterr (return value), *distortion, *sse1. */
+int aomhip_subpel_bilinear_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw,
+                                 int bh, int mv_cost_type, int iters_per_step, int allow_hp, int forced_stop,
+                                 const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
+                                 uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse);
+
 /* ------------------------------------------------------------------ rtcd-signature conformance entry points */
 
 /* aom_dsp_rtcd_defs.pl:762-763 aom_sad{W}x{H} / aom_sad_skip_{W}x{H}; host pointers. */

@@ -361,3 +361,44 @@ def cdef_plane_luma(pixels, fb_pri, fb_sec, skip, damping, bd=8):
                             fb_pri.ctypes.data, fb_sec.ctypes.data, fb_pri.shape[1], skip.ctypes.data, damping,
                             d.ctypes.data, v.ctypes.data)
     return dst, d, v
+
+
+# ---- motion search (aomref_mcomp.c)
+lib.orc_fullpel_diamond_batch.restype = None
+lib.orc_fullpel_diamond_batch.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i]
+lib.orc_subpel_bilinear_batch.restype = None
+lib.orc_subpel_bilinear_batch.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i]
+
+
+def fullpel_diamond_batch(src_b, ref_b, border, w, h, blocks, clamped=0, step_param=4, cost_type=3, bd=8, threads=4):
+    blocks = np.ascontiguousarray(blocks)
+    mv = np.zeros((len(blocks), 2), np.int16); cost = np.zeros(len(blocks), np.int32)
+    lib.orc_fullpel_diamond_batch(_addr(src_b, border, border), src_b.shape[1], _addr(ref_b, border, border),
+                                  ref_b.shape[1], int(src_b.dtype != np.uint8), bd, w, h, clamped, step_param, cost_type,
+                                  blocks.ctypes.data, len(blocks), mv.ctypes.data, cost.ctypes.data, threads)
+    return mv, cost
+
+
+def subpel_bilinear_batch(src_b, ref_b, border, w, h, blocks, cost_type=3, iters=2, allow_hp=1, forced_stop=0, bd=8,
+                          threads=4):
+    blocks = np.ascontiguousarray(blocks)
+    n = len(blocks)
+    mv = np.zeros((n, 2), np.int16); err = np.zeros(n, np.uint32); dist = np.zeros(n, np.int32); sse = np.zeros(n, np.uint32)
+    lib.orc_subpel_bilinear_batch(_addr(src_b, border, border), src_b.shape[1], _addr(ref_b, border, border),
+                                  ref_b.shape[1], int(src_b.dtype != np.uint8), bd, w, h, cost_type, iters, allow_hp,
+                                  forced_stop, blocks.ctypes.data, n, mv.ctypes.data, err.ctypes.data, dist.ctypes.data,
+                                  sse.ctypes.data, threads)
+    return mv, err, dist, sse
+
+
+def mv_limits_for_block(bx, by, w, h, width, height, border, ref_row=0, ref_col=0):
+    """av1_set_mv_limits (mcomp.h:216-247; frame-relative, may reach border - 2*AOM_INTERP_EXTEND(4) outside the
+    frame... here: block + interp extend stays inside the replicated border) intersected with
+    av1_set_mv_search_range around ref_mv (mcomp.c:196-215, MAX_FULL_PEL_VAL 1023)."""
+    ext = border - 8
+    col_min, col_max = -(bx + ext), (width - bx - w) + ext
+    row_min, row_max = -(by + ext), (height - by - h) + ext
+    fr, fc = ref_row >> 3, ref_col >> 3
+    col_min, col_max = max(col_min, fc - 1023), min(col_max, fc + 1023)
+    row_min, row_max = max(row_min, fr - 1023), min(row_max, fr + 1023)
+    return row_min, row_max, col_min, col_max
