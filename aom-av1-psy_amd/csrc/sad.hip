@@ -219,7 +219,9 @@ static int launch_x4d_v(const SadLaunch &l, const PlaneView<T> &s, const PlaneVi
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
-// Only variant 0 is instantiated.  Measured on MI355X at 4K Mode A (profiles/r01_sad_variants.md):
+
+// Only variant 0 is instantiated.  Measured on MI355X at 4K Mode A (profiles/r01_sad_variants.md; that file
+// also records the LDS-staged reference-window kernel that was tried and removed -- 2x slower):
 // aligned-window loads cut TCP cache accesses by 39 % but raise L2 requests by 37 % and run 25-30 %
 // slower at either occupancy; one unit per lane is neutral for x4d and 13 % slower for single SADs.
 template <typename T, int W, int H, bool SKIP>

@@ -71,15 +71,22 @@ def shifted_smooth_pair(width, height, frame_idx, bit_depth=8, shift=(3, -2), fr
     return np.clip(np.rint(src), 0, mx).astype(dt), np.clip(np.rint(ref), 0, mx).astype(dt)
 
 
-def mode_a_worklist(width, height, bsize=16, seed=1, search=64):
+def mode_a_worklist(width, height, bsize=16, seed=1, search=64, order="raster"):
     """SURVEY 8(d) Mode A: per full bsize x bsize block one candidate at mv (0,0) and one x4d
     group whose four reference positions are uniform in [-search, search]^2.
-    Returns (cands[n_blocks], groups[n_blocks]) as structured arrays in raster order."""
+    Returns (cands[n_blocks], groups[n_blocks]) as structured arrays.  order = "sb64": superblock by
+    superblock (64x64, raster), blocks in raster order inside each -- the order in which the encoder's
+    per-superblock call sites (av1/encoder/encodeframe.c:1069 encode_sb_row) visit them; "raster": plain raster."""
     from .capi import sad_cand_dtype, sad_x4d_dtype
     bx = np.arange(0, width - bsize + 1, bsize, dtype=np.int16)
     by = np.arange(0, height - bsize + 1, bsize, dtype=np.int16)
     gx, gy = np.meshgrid(bx, by)
     gx, gy = gx.ravel(), gy.ravel()
+    if order == "sb64":
+        sbs_per_row = (width + 63) // 64
+        key = ((gy // 64).astype(np.int64) * sbs_per_row + gx // 64) * 4096 + (gy % 64) * 64 + (gx % 64)
+        perm = np.argsort(key, kind="stable")
+        gx, gy = gx[perm], gy[perm]
     n = gx.size
     rng = np.random.default_rng(seed)
     cands = np.zeros(n, sad_cand_dtype)
