@@ -26,6 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FRAMES_OVERRIDE = 0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SAD16_BYTES_8BIT = 516  # src block + ref block + 4 B result
 
@@ -38,23 +39,38 @@ WORKLOADS = {
 }
 
 
-def dist_setup(n_gpus):
+_BACKEND = "nccl"  # RCCL; "gloo" only for the single-GPU dry run of the N > 1 code path (tools/gpu_dist_dryrun.sh)
+
+
+def dist_setup(n_gpus, backend):
+    global _BACKEND
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return None, 0, 1
     import torch
     import torch.distributed as dist
+    _BACKEND = backend
     rank = int(os.environ["RANK"])
-    local = int(os.environ.get("LOCAL_RANK", rank))
+    local = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
     return dist, rank, world
+
+
+def _red_device():
+    return "cuda" if _BACKEND == "nccl" else "cpu"
 
 
 def barrier(dist, dev):
     if dist is not None:
         import torch
-        dist.barrier(device_ids=[dev])
+        if _BACKEND == "nccl":
+            dist.barrier(device_ids=[dev])
+        else:
+            dist.barrier()
         torch.cuda.synchronize()
 
 
@@ -282,7 +298,7 @@ def time_steps(wl, ctx, dist, dev, steps, warmup):
     wall = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device=_red_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     return wall, ev_ms
@@ -310,7 +326,7 @@ def load_traffic(name):
 
 
 def run_workload(pkg, ctx, dist, dev, rank, world, name, steps, warmup, want_cpu, orc):
-    wl = SadModeA(pkg, ctx, name, rank, world)
+    wl = SadModeA(pkg, ctx, name, rank, world, frames_per_rank=FRAMES_OVERRIDE or None)
     wl.step()
     ctx.sync()
     ok = wl.check_frame0(orc) if orc is not None else None
@@ -318,7 +334,7 @@ def run_workload(pkg, ctx, dist, dev, rank, world, name, steps, warmup, want_cpu
     total = wl.cands_per_step
     if dist is not None:
         import torch
-        t = torch.tensor([total], dtype=torch.float64, device="cuda")
+        t = torch.tensor([total], dtype=torch.float64, device=_red_device())
         dist.all_reduce(t)
         total = int(t.item())
     k_ms = kernel_avg_ms(ctx, wl.launch_x4d, max(steps, 10))
@@ -337,6 +353,11 @@ def run_workload(pkg, ctx, dist, dev, rank, world, name, steps, warmup, want_cpu
         "kernels": {"sad_x4d_kernel_avg_ms": k_ms, "sad_cand_kernel_avg_ms": k1_ms},
         "ring_frames": wl.ring, "blocks_per_frame_this_rank": wl.blocks_per_frame, "tile_column_px": list(wl.tile),
     }
+    if traffic and k_ms > 0:  # the mandatory companion figure and the cache-bound rule
+        res["roofline"]["traffic_GBs"] = traffic / (k_ms * 1e-3) / 1e9
+        res["roofline"]["traffic_frac_of_peak"] = res["roofline"]["traffic_GBs"] / HBM_PEAK_GBS
+        res["roofline"]["regime"] = ("cache-bound: algorithmic bytes exceed measured fabric traffic by %.2fx"
+                                     % (x4d_bytes / traffic)) if x4d_bytes > 1.5 * traffic else "hbm-bound"
     if want_cpu and rank == 0 and orc is not None:
         res["cpu_baseline"] = wl.cpu_baseline(orc)
     wl.free()
@@ -351,10 +372,18 @@ def main():
     ap.add_argument("--workload", default="sad16x16_modeA_1080p_8bit", choices=sorted(WORKLOADS) + ["txq_1080p_8bit"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the real multi-GPU path); gloo only to dry-run the N > 1 code on one GPU")
+    ap.add_argument("--frames-per-gpu", type=int, default=0, help="override the ring size per GPU (0 = workload default)")
     args = ap.parse_args()
 
-    dist, rank, world = dist_setup(args.gpus)
-    dev = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    global FRAMES_OVERRIDE
+    FRAMES_OVERRIDE = args.frames_per_gpu
+    dist, rank, world = dist_setup(args.gpus, args.dist_backend)
+    dev = 0
+    if world > 1:
+        import torch
+        dev = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     import aom_av1_psy_amd as pkg  # raises if libaomhip.so is missing: no fallback
     stream = None
     if world > 1:
@@ -399,7 +428,7 @@ def main():
             "config": {"workload": args.workload, "frame": "%dx%d" % (cfg["width"], cfg["height"]),
                        "bit_depth": cfg["bit_depth"], "block": "16x16",
                        "mode": "A: 1 sad16x16 @mv(0,0) + 1 sad16x16x4d (uniform in [-64,64]^2) per block",
-                       "ring_frame_pairs_per_gpu": cfg["frames"], "candidates_per_step": main_res["candidates_per_step"],
+                       "ring_frame_pairs_per_gpu": FRAMES_OVERRIDE or cfg["frames"], "candidates_per_step": main_res["candidates_per_step"],
                        "partition": "tile columns (tile_common.c:76-97), one per GPU; no data-path collective"},
             "roofline": main_res["roofline"],
             "cpu_baseline": main_res.get("cpu_baseline"),
