@@ -6,7 +6,8 @@ CSRC := $(PKG)/csrc
 LIBDIR := $(PKG)/lib
 HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 SRCS := $(wildcard $(CSRC)/*.hip)
-OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
+CPPS := $(wildcard $(CSRC)/*.cpp)
+OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS)) $(patsubst $(CSRC)/%.cpp,build/%.o,$(CPPS))
 
 all: lib oracle
 lib: $(LIBDIR)/libaomhip.so
@@ -14,6 +15,10 @@ oracle:
 	$(MAKE) -C oracle
 
 build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/aomhip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+build/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/aomhip.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

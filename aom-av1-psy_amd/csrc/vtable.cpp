@@ -1,0 +1,71 @@
+// Binder for the encoder's per-block-size kernel table (aom_variance_fn_ptr_t, aom_dsp/variance.h:84-103;
+// filled by BFP / HIGHBD_BFP at av1/encoder/encoder.c:986-1226 and encoder_utils.h:130-139,572-).  Motion
+// search reaches its kernels only through this table (mcomp.c:105,125-132), so overwriting its entries after
+// av1_create_primary_compressor is the least invasive way to route sdf / sdsf / vf / svf / sdx4df / sdx3df /
+// sdsx4df to the GPU.  Each entry is a fixed-size function with the reference's exact signature that forwards
+// to the generic rtcd-signature entry points of libaomhip (sad.hip, variance.hip).
+#include "aomhip.h"
+
+namespace {
+
+#define AOMHIP_SIZES(X)                                                                                          \
+  X(4, 4) X(4, 8) X(8, 4) X(8, 8) X(8, 16) X(16, 8) X(16, 16) X(16, 32) X(32, 16) X(32, 32) X(32, 64) X(64, 32) \
+  X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(4, 16) X(16, 4) X(8, 32) X(32, 8) X(16, 64) X(64, 16)
+
+template <int W, int H> struct Fixed {
+  static unsigned int sdf(const uint8_t *a, int as, const uint8_t *b, int bs) { return aomhip_sad(a, as, b, bs, W, H); }
+  static unsigned int sdsf(const uint8_t *a, int as, const uint8_t *b, int bs) { return aomhip_sad_skip(a, as, b, bs, W, H); }
+  static unsigned int vf(const uint8_t *a, int as, const uint8_t *b, int bs, unsigned int *sse) {
+    return aomhip_variance(a, as, b, bs, W, H, sse);
+  }
+  static unsigned int svf(const uint8_t *a, int as, int xo, int yo, const uint8_t *b, int bs, unsigned int *sse) {
+    return aomhip_sub_pixel_variance(a, as, xo, yo, b, bs, W, H, sse);
+  }
+  static void sdx4df(const uint8_t *a, int as, const uint8_t *const b[], int bs, unsigned int *out) {
+    aomhip_sad_x4d(a, as, b, bs, out, W, H);
+  }
+  static void sdsx4df(const uint8_t *a, int as, const uint8_t *const b[], int bs, unsigned int *out) {
+    aomhip_sad_skip_x4d(a, as, b, bs, out, W, H);
+  }
+  // highbd flavours: CONVERT_TO_BYTEPTR pointers in, the _bits{8,10,12} wrappers folded in via BD
+  template <int BD> static unsigned int hsdf(const uint8_t *a, int as, const uint8_t *b, int bs) {
+    return aomhip_highbd_sad(a, as, b, bs, W, H, BD);
+  }
+  template <int BD> static unsigned int hvf(const uint8_t *a, int as, const uint8_t *b, int bs, unsigned int *sse) {
+    return aomhip_highbd_variance(a, as, b, bs, W, H, BD, sse);
+  }
+  template <int BD>
+  static unsigned int hsvf(const uint8_t *a, int as, int xo, int yo, const uint8_t *b, int bs, unsigned int *sse) {
+    return aomhip_highbd_sub_pixel_variance(a, as, xo, yo, b, bs, W, H, BD, sse);
+  }
+  template <int BD> static void hsdx4df(const uint8_t *a, int as, const uint8_t *const b[], int bs, unsigned int *out) {
+    for (int k = 0; k < 4; ++k) out[k] = aomhip_highbd_sad(a, as, b[k], bs, W, H, BD);
+  }
+};
+
+template <int W, int H> void fill(aomhip_variance_vtable *t, int bd) {
+  using F = Fixed<W, H>;
+  if (bd == 8) {
+    t->sdf = F::sdf; t->sdsf = F::sdsf; t->vf = F::vf; t->svf = F::svf;
+    t->sdx4df = F::sdx4df; t->sdx3df = F::sdx4df;  // aom_sadWxHx3d_c forwards to x4d (aom_dsp/sad.c:124-129)
+    t->sdsx4df = F::sdsx4df;
+  } else if (bd == 10) {
+    t->sdf = F::template hsdf<10>; t->vf = F::template hvf<10>; t->svf = F::template hsvf<10>;
+    t->sdx4df = F::template hsdx4df<10>; t->sdx3df = F::template hsdx4df<10>;
+  } else {
+    t->sdf = F::template hsdf<12>; t->vf = F::template hvf<12>; t->svf = F::template hsvf<12>;
+    t->sdx4df = F::template hsdx4df<12>; t->sdx3df = F::template hsdx4df<12>;
+  }
+}
+
+}  // namespace
+
+extern "C" int aomhip_bind_variance_vtable(aomhip_variance_vtable *table, int bit_depth) {
+  if (!table || (bit_depth != 8 && bit_depth != 10 && bit_depth != 12)) return AOMHIP_ERR_INVALID;
+  // BLOCK_SIZE order of av1/common/enums.h:99-124
+  int i = 0;
+#define X(W, H) fill<W, H>(&table[i++], bit_depth);
+  AOMHIP_SIZES(X)
+#undef X
+  return AOMHIP_OK;
+}

@@ -293,6 +293,32 @@ int aomhip_subpel_bilinear_batch(aomhip_ctx *ctx, const aomhip_planes *src, cons
                                  const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
                                  uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse);
 
+/* ------------------------------------------------------------------ the encoder's kernel vtable */
+
+/* Mirror of aom_variance_fn_ptr_t (aom_dsp/variance.h:84-103): same field order, same pointer types
+ * (typedefs :26-82), so a `aom_variance_fn_ptr_t[BLOCK_SIZES_ALL]` can be passed by cast. */
+typedef struct aomhip_variance_vtable {
+  unsigned int (*sdf)(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride);
+  unsigned int (*sdsf)(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride);
+  unsigned int (*sdaf)(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, const uint8_t *second_pred);
+  unsigned int (*vf)(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, unsigned int *sse);
+  unsigned int (*svf)(const uint8_t *a, int a_stride, int xoffset, int yoffset, const uint8_t *b, int b_stride,
+                      unsigned int *sse);
+  void *svaf;
+  void (*sdx4df)(const uint8_t *a, int a_stride, const uint8_t *const b_array[], int b_stride, unsigned int *sad_array);
+  void (*sdx3df)(const uint8_t *a, int a_stride, const uint8_t *const b_array[], int b_stride, unsigned int *sad_array);
+  void (*sdsx4df)(const uint8_t *a, int a_stride, const uint8_t *const b_array[], int b_stride,
+                  unsigned int *sad_array);
+  void *msdf, *msvf, *osdf, *ovf, *osvf, *jsdaf, *jsvaf; /* compound / masked / OBMC entries: left untouched */
+} aomhip_variance_vtable;
+
+/* Overwrites sdf, sdsf (8-bit), vf, svf, sdx4df, sdx3df, sdsx4df (8-bit) of the 22 entries (BLOCK_SIZE order,
+ * av1/common/enums.h:99-124) with GPU-backed functions of the reference's exact signatures -- what a
+ * maintainer calls right after av1_create_primary_compressor fills ppi->fn_ptr (av1/encoder/encoder.c:986-1226;
+ * highbd: encoder_utils.h:130-139,572-, the _bits10 / _bits12 SAD wrappers are folded in).  Every other
+ * entry keeps the reference's value.  These are the one-launch-per-call conformance functions. */
+int aomhip_bind_variance_vtable(aomhip_variance_vtable *table, int bit_depth);
+
 /* ------------------------------------------------------------------ rtcd-signature conformance entry points */
 
 /* aom_dsp_rtcd_defs.pl:762-763 aom_sad{W}x{H} / aom_sad_skip_{W}x{H}; host pointers. */
