@@ -234,3 +234,17 @@ class Context:
         check(lib.aomhip_subpel_bilinear_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, cost_type, iters,
                                                allow_hp, forced_stop, d_blocks, n, d_mv, d_err, d_dist, d_sse),
               "aomhip_subpel_bilinear_batch")
+
+
+def planes_from_tensor(t, width, height, border, bit_depth, n_frames=1):
+    """Wrap caller-owned device memory (e.g. a torch tensor that RCCL collectives operate on) as an aomhip_planes
+    ring: t must hold n_frames * frame_stride elements laid out like aomhip_planes_alloc does.  Returns
+    (Planes, frame_stride_elements, rows)."""
+    stride = lib.aomhip_calc_stride(width, border)
+    rows = ((height + 7) & ~7) + 2 * border
+    frame_elems = (rows * stride + 255) & ~255
+    assert t.numel() >= frame_elems * n_frames
+    p = Planes()
+    p.base, p.frame_stride, p.width, p.height = t.data_ptr(), frame_elems, width, height
+    p.stride, p.border, p.bit_depth, p.n_frames = stride, border, bit_depth, n_frames
+    return p, frame_elems, rows

@@ -58,3 +58,28 @@ def gather_results(dist, local, index, total, device):
         ok = i >= 0
         out[i[ok]] = v.cpu().numpy()[ok].astype(np.uint32)
     return out.reshape((total,) + local.shape[1:])
+
+
+def exchange_strips(dist, plane2d, bounds, rank):
+    """The one real exchange step of the tile-column encoder: after frame t is reconstructed, GPU r
+    holds valid pixels only in its own tile column [x0_r, x1_r) of the reconstructed plane; every GPU needs the
+    whole plane as the reference of frame t+1 (MV limits are frame-relative, av1/encoder/mcomp.h:216-247).
+    Realised as one broadcast per strip (north_star: "RCCL broadcast of reconstructed reference planes"); on the
+    fully connected xGMI mesh each goes directly to the 7 peers.  plane2d: torch tensor [rows, stride] on this
+    rank's device (nccl) or CPU (gloo); bounds: [(x0, x1)] in elements of that tensor, one per rank.  Use a uint8
+    (byte) view for 10/12-bit planes: RCCL has no 16-bit integer type."""
+    if dist is None:
+        return plane2d
+    for r, (x0, x1) in enumerate(bounds):
+        if x1 <= x0:
+            continue
+        buf = plane2d[:, x0:x1].contiguous()
+        if buf.is_cuda and dist.get_backend() == "gloo":  # single-GPU dry run only: gloo moves host memory
+            host = buf.cpu()
+            dist.broadcast(host, src=r)
+            buf = host.to(buf.device)
+        else:
+            dist.broadcast(buf, src=r)
+        if r != rank:
+            plane2d[:, x0:x1] = buf
+    return plane2d

@@ -283,6 +283,123 @@ def run_txq(pkg, ctx, orc, steps, warmup, want_cpu):
     return res
 
 
+class SearchPipeline:
+    """BASELINE.json configs[3]: full-pel diamond search (DIAMOND, step_param 4, MV_COST_L1_HDRES) + bilinear sub-pel
+    tree (1/2, 1/4, 1/8) for every 16x16 block of 3840x2160 10-bit frame pairs, tile columns across the GPUs.
+    With N > 1 the reference plane lives in a torch tensor and each step first exchanges the tile-column strips
+    (partition.exchange_strips: one RCCL broadcast per strip) -- the per-frame exchange of the real encoder."""
+
+    W, H, BD, BORDER, BS = 3840, 2160, 10, 160, 16
+
+    def __init__(self, pkg, ctx, dist, rank, world, frames=4):
+        import ctypes as C
+        self.pkg, self.ctx, self.dist, self.rank, self.world, self.F = pkg, ctx, dist, rank, world, frames
+        capi, synth, part = pkg.capi, pkg.synth, pkg.partition
+        W, H, bd, border = self.W, self.H, self.BD, self.BORDER
+        self.src = ctx.planes_alloc(W, H, border, bd, frames)
+        self.ref_t = None
+        if world > 1:
+            import torch
+            stride = capi.lib.aomhip_calc_stride(W, border)
+            rows = ((H + 7) & ~7) + 2 * border
+            fe = (rows * stride + 255) & ~255
+            # raw bytes: RCCL has no 16-bit integer type, the strips are exchanged as uint8
+            self.ref_t = torch.zeros((fe * frames + stride + 64) * 2, dtype=torch.uint8, device="cuda")
+            self.ref, self.fe, self.rows = capi.planes_from_tensor(self.ref_t.view(torch.int16), W, H, border, bd, frames)
+        else:
+            self.ref = ctx.planes_alloc(W, H, border, bd, frames)
+        for f in range(frames):
+            s_, r_ = synth.shifted_smooth_pair(W, H, f, bd, shift=(3 + f % 3, -2 + f % 2), frac8=(f % 8, (3 * f) % 8))
+            ctx.planes_upload(self.src, f, s_)
+            ctx.planes_upload(self.ref, f, r_)
+        x0, x1 = part.column_of_rank(W, world, rank)
+        self.bounds = []
+        for r in range(world):
+            a, b = part.column_of_rank(W, world, r)
+            self.bounds.append((0 if r == 0 else 2 * (a + border), 2 * (self.ref.stride if r == world - 1 else b + border)))
+        xs, ys = np.meshgrid(np.arange(x0, x1 - self.BS + 1, self.BS), np.arange(0, H - self.BS + 1, self.BS))
+        n = xs.size
+        b = np.zeros(n, capi.search_block_dtype)
+        b["bx"], b["by"] = xs.ravel(), ys.ravel()
+        ext = border - 8
+        b["col_min"] = np.maximum(-(b["bx"] + ext), -1023); b["col_max"] = np.minimum(W - b["bx"] - self.BS + ext, 1023)
+        b["row_min"] = np.maximum(-(b["by"] + ext), -1023); b["row_max"] = np.minimum(H - b["by"] - self.BS + ext, 1023)
+        self.n = n
+        self.h_blocks = b
+        self.d_blocks = ctx.to_device(b) if n else None
+        self.d_sub = ctx.malloc(max(16, n * 20))
+        self.d_mv, self.d_cost = ctx.malloc(max(16, n * 4)), ctx.malloc(max(16, n * 4))
+        self.d_smv, self.d_err, self.d_dist, self.d_sse = (ctx.malloc(max(16, n * 4)) for _ in range(4))
+        self.frame = 0
+
+    def step(self):
+        """one frame pair: [exchange] -> full-pel -> sub-pel (sub-pel start MVs are built on the host from the
+        full-pel result of the PREVIOUS visit of this ring slot; the kernels' work is what is timed)."""
+        f = self.frame % self.F
+        self.frame += 1
+        if self.world > 1:
+            import torch
+            rb = 2 * self.ref.stride  # bytes per row
+            plane = self.ref_t[2 * f * self.fe: 2 * f * self.fe + self.rows * rb].view(self.rows, rb)
+            self.pkg.partition.exchange_strips(self.dist, plane, self.bounds, self.rank)
+            torch.cuda.current_stream().synchronize()
+        if not self.n:
+            return
+        c, capi = self.ctx, self.pkg.capi
+        c.fullpel_diamond_batch(self.src, self.ref, f, self.BS, self.BS, 0, 4, capi.MV_COST_L1_HDRES, self.d_blocks, self.n,
+                                self.d_mv, self.d_cost)
+        c.subpel_bilinear_batch(self.src, self.ref, f, self.BS, self.BS, capi.MV_COST_L1_HDRES, 2, 1, 0, self.d_sub_blocks(f),
+                                self.n, self.d_smv, self.d_err, self.d_dist, self.d_sse)
+
+    def d_sub_blocks(self, f):
+        if not hasattr(self, "_sub"):
+            self._sub = {}
+        if f not in self._sub:  # built once per ring slot from a (synchronous) full-pel pass
+            c, capi = self.ctx, self.pkg.capi
+            c.fullpel_diamond_batch(self.src, self.ref, f, self.BS, self.BS, 0, 4, capi.MV_COST_L1_HDRES, self.d_blocks,
+                                    self.n, self.d_mv, self.d_cost)
+            mv = c.from_device(self.d_mv, (self.n, 2), np.int16)
+            sp = self.h_blocks.copy()
+            sp["start_row"], sp["start_col"] = mv[:, 0] * 8, mv[:, 1] * 8
+            for k in ("row_min", "row_max", "col_min", "col_max"):
+                sp[k] = np.clip(self.h_blocks[k].astype(np.int32) * 8, -16383, 16383)
+            self._sub[f] = (c.to_device(sp), mv)
+        return self._sub[f][0]
+
+    def check(self, orc):
+        """slot 0 against the oracle on a sample of blocks (not timed)."""
+        if not self.n:
+            return True
+        self.d_sub_blocks(0)
+        mv = self._sub[0][1]
+        s_, r_ = self.pkg.synth.shifted_smooth_pair(self.W, self.H, 0, self.BD, shift=(3, -2), frac8=(0, 0))
+        sb = orc.extend_plane(s_, self.BORDER, self.src.stride); rb = orc.extend_plane(r_, self.BORDER, self.ref.stride)
+        idx = np.arange(0, self.n, max(1, self.n // 500))
+        wmv, _ = orc.fullpel_diamond_batch(sb, rb, self.BORDER, self.BS, self.BS, self.h_blocks[idx], 0, 4, 3, self.BD, threads=8)
+        return bool(np.array_equal(mv[idx], wmv))
+
+
+def run_search(pkg, ctx, dist, dev, rank, world, orc, steps, warmup):
+    wl = SearchPipeline(pkg, ctx, dist, rank, world)
+    ok = wl.check(orc) if orc is not None else None
+    for f in range(wl.F):
+        if wl.n:
+            wl.d_sub_blocks(f)
+    wall, ev_ms = time_steps(wl, ctx, dist, dev, steps, warmup)
+    total = wl.n
+    if dist is not None:
+        import torch
+        t = torch.tensor([float(total)], dtype=torch.float64, device=_red_device())
+        dist.all_reduce(t)
+        total = int(t.item())
+    return {"workload": "fullpel_diamond+subpel_bilinear_4k_10bit", "value": total * steps / wall, "unit": "blocks/s",
+            "frames_per_s": steps / wall, "ms_per_step": wall / steps * 1e3, "blocks_per_step": total,
+            "parity_sample_slot0": ok,
+            "config": {"frame": "3840x2160 10-bit", "block": "16x16", "search": "DIAMOND step_param 4, MV_COST_L1_HDRES; "
+                       "sub-pel tree pruned_more, bilinear, 1/8 pel, iters 2", "exchange": "one RCCL broadcast per "
+                       "tile-column strip per frame" if world > 1 else "none (1 GPU)"}}
+
+
 def time_steps(wl, ctx, dist, dev, steps, warmup):
     for _ in range(warmup):
         wl.step()
@@ -369,7 +486,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="sad16x16_modeA_1080p_8bit", choices=sorted(WORKLOADS) + ["txq_1080p_8bit"])
+    ap.add_argument("--workload", default="sad16x16_modeA_1080p_8bit",
+                    choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "search_4k_10bit"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -397,6 +515,18 @@ def main():
     except Exception as e:  # pragma: no cover
         print("warning: oracle unavailable (%s): no parity spot check / cpu_baseline" % e, file=sys.stderr)
 
+    if args.workload == "search_4k_10bit":  # configs[3]: search pipeline with the per-frame strip exchange (any N)
+        r = run_search(pkg, ctx, dist, dev, rank, world, orc, args.steps, args.warmup)
+        ctx.close()
+        if rank == 0:
+            print(json.dumps({"metric": "search blocks/s", "value": r["value"], "unit": "blocks/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16",
+                              "data": "synthetic", "config": dict(r["config"], workload=r["workload"]),
+                              "frames_per_s": r["frames_per_s"], "parity_sample_slot0": r["parity_sample_slot0"]}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.workload == "txq_1080p_8bit":  # profiling convenience: transform+quantise only (single GPU)
         r = run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline)
         ctx.close()
@@ -416,6 +546,7 @@ def main():
             others.append(run_workload(pkg, ctx, dist, dev, rank, world, n, args.steps, args.warmup, False, orc))
         if args.others == "auto" and orc is not None:
             others.append(run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline))
+            others.append(run_search(pkg, ctx, None, dev, 0, 1, orc, max(4, args.steps // 2), 1))
     ctx.close()
 
     if rank == 0:

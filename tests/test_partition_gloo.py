@@ -44,7 +44,20 @@ def _worker(rank, world, port, q):
         t = pkg.partition.reduce_scalar(dist, float(rank + 1), "MAX", "cpu")
         n = pkg.partition.reduce_scalar(dist, float(len(mine)), "SUM", "cpu")
         want = orc.sad_x4d_batch(sb, rb, border, 16, 16, groups)
-        q.put((rank, bool(np.array_equal(full, want)), t, n, len(groups)))
+        # the exchange step: every rank owns only its tile-column strip of the "reconstructed" plane
+        import torch
+        stride = rb.shape[1]
+        mine_only = torch.zeros(rb.shape, dtype=torch.uint8)
+        bounds = []
+        for r in range(world):
+            a, b = pkg.partition.column_of_rank(W, world, r)
+            # strips in bordered coordinates; the outer strips carry the frame border with them
+            bounds.append((0 if r == 0 else a + border, stride if r == world - 1 else b + border))
+        a, b = bounds[rank]
+        mine_only[:, a:b] = torch.from_numpy(rb[:, a:b].copy())
+        pkg.partition.exchange_strips(dist, mine_only, bounds, rank)
+        ok_x = bool(np.array_equal(mine_only.numpy(), rb))
+        q.put((rank, bool(np.array_equal(full, want)) and ok_x, t, n, len(groups)))
         dist.destroy_process_group()
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e), 0, 0, 0))
