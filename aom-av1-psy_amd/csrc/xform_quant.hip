@@ -374,6 +374,119 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Whole-block-per-lane variant for the smallest transforms (W, H <= 8): a lane keeps the entire block in
+// VGPRs, runs the column and row networks back to back (the transpose is register renaming), quantises and
+// writes its coefficients as contiguous dwordx4 runs.  No LDS, no barriers, inverse-scan positions are
+// compile-time constants.  For 4x4 this does ~3x fewer VALU instructions per block than 4 lanes per block.
+template <int W, int H, bool HBD, int SRC>
+__global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
+    const void *__restrict__ in0, const void *__restrict__ in1, int stride0, int stride1,
+    const aomhip_txb *__restrict__ blocks, int n_blocks, int grid_cols, int uniform_type, QuantArgs qa,
+    int32_t *__restrict__ coeff, int32_t *__restrict__ qcoeff, int32_t *__restrict__ dqcoeff,
+    uint16_t *__restrict__ eob, int nblk8) {
+  using C = Cfg2D<W, H>;
+  constexpr int NC = W * H;
+  constexpr int LS = 0;  // <= 64 samples: av1_get_tx_scale == 0
+  const unsigned wg = xcd_chunked_index(blockIdx.x, nblk8);
+  const int bi = wg * kXqThreads + threadIdx.x;
+  if (bi >= n_blocks) return;
+  int bx, by, tx_type = uniform_type;
+  int64_t out_off = (int64_t)bi * NC;
+  if (blocks) {
+    const aomhip_txb b = blocks[bi];
+    bx = b.x; by = b.y; tx_type = b.tx_type; out_off = b.out_offset;
+  } else {
+    bx = (bi % grid_cols) * W;
+    by = (bi / grid_cols) * H;
+  }
+  const int vk = kVKind[tx_type & 15], hk = kHKind[tx_type & 15];
+  const bool ud = (vk == 2), lr = (hk == 2);
+
+  // ---- load rows (one wide access per row), apply the up/down flip while loading
+  int32_t x[H][W];
+#pragma unroll
+  for (int r = 0; r < H; ++r) {
+    const int rr = ud ? H - 1 - r : r;
+    int v[W];
+    if constexpr (SRC == 0) {
+      const int16_t *p = static_cast<const int16_t *>(in0) + (int64_t)(by + rr) * stride0 + bx;
+      if constexpr (W == 8) {
+        const VecU128 raw = *reinterpret_cast<const VecU128 *>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (int16_t)(raw.v[j / 2] >> (16 * (j % 2)));
+      } else {
+        const VecU64 raw = *reinterpret_cast<const VecU64 *>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (int16_t)(raw.v[j / 2] >> (16 * (j % 2)));
+      }
+    } else if constexpr (SRC == 1) {
+      const uint8_t *ps = static_cast<const uint8_t *>(in0) + (int64_t)(by + rr) * stride0 + bx;
+      const uint8_t *pp = static_cast<const uint8_t *>(in1) + (int64_t)(by + rr) * stride1 + bx;
+#pragma unroll
+      for (int j = 0; j < W; ++j) v[j] = (int)ps[j] - (int)pp[j];
+    } else {
+      const uint16_t *ps = static_cast<const uint16_t *>(in0) + (int64_t)(by + rr) * stride0 + bx;
+      const uint16_t *pp = static_cast<const uint16_t *>(in1) + (int64_t)(by + rr) * stride1 + bx;
+#pragma unroll
+      for (int j = 0; j < W; ++j) v[j] = (int)ps[j] - (int)pp[j];
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) x[r][j] = v[j] * (1 << C::fs0);
+  }
+
+  // ---- columns
+#pragma unroll
+  for (int c = 0; c < W; ++c) {
+    int32_t col[H];
+#pragma unroll
+    for (int r = 0; r < H; ++r) col[r] = x[r][c];
+    fwd_1d<H, C::cos_bit_col>(col, vk == 2 ? 1 : vk);
+#pragma unroll
+    for (int r = 0; r < H; ++r) x[r][c] = (C::fs1 < 0) ? rshift(col[r], C::fs1 < 0 ? -C::fs1 : 1) : col[r];
+  }
+
+  // ---- rows + quantise
+  const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
+  const int zb[2] = { qa.zbin[0], qa.zbin[1] }, rd[2] = { qa.round[0], qa.round[1] };
+  int my_eob = 0;
+  int32_t qv[H][W], dv[H][W];
+#pragma unroll
+  for (int r = 0; r < H; ++r) {
+    int32_t y[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) y[c] = x[r][lr ? W - 1 - c : c];  // left/right flip of the column-pass output
+    fwd_1d<W, C::cos_bit_row>(y, hk == 2 ? 1 : hk);
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      int32_t v = y[c];
+      if constexpr (C::fs2 < 0) v = rshift(v, C::fs2 < 0 ? -C::fs2 : 1);
+      if constexpr (C::rect2) v = rshift64((int64_t)v * kSqrt2, kSqrt2Bits);
+      if (coeff) coeff[out_off + c * H + r] = v;
+      const int ac = (r | c) != 0;
+      quantize_one<HBD, LS>(v, zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.qs_log2[ac], qa.dequant[ac],
+                            &qv[r][c], &dv[r][c]);
+      // inverse-scan positions are constants here (r, c are unrolled)
+      const int p0 = iscan_pos<W, H>(r, c, 0) + 1, p1 = iscan_pos<W, H>(r, c, 1) + 1, p2 = iscan_pos<W, H>(r, c, 2) + 1;
+      const int p = scan_class == 0 ? p0 : (scan_class == 1 ? p1 : p2);
+      my_eob = (qv[r][c] != 0 && p > my_eob) ? p : my_eob;
+    }
+  }
+  eob[bi] = (uint16_t)my_eob;
+  // ---- store in the reference's transposed order (index c*H + r): column c is H contiguous values
+#pragma unroll
+  for (int c = 0; c < W; ++c) {
+#pragma unroll
+    for (int r4 = 0; r4 < H; r4 += 4) {
+      *reinterpret_cast<uint4 *>(qcoeff + out_off + c * H + r4) =
+          make_uint4((uint32_t)qv[r4][c], (uint32_t)qv[r4 + 1][c], (uint32_t)qv[r4 + 2][c], (uint32_t)qv[r4 + 3][c]);
+      *reinterpret_cast<uint4 *>(dqcoeff + out_off + c * H + r4) =
+          make_uint4((uint32_t)dv[r4][c], (uint32_t)dv[r4 + 1][c], (uint32_t)dv[r4 + 2][c], (uint32_t)dv[r4 + 3][c]);
+    }
+  }
+}
+
 struct XqLaunch {
   hipStream_t stream;
   const void *in0, *in1;
@@ -388,12 +501,28 @@ struct XqLaunch {
 template <int W, int H, bool HBD, int SRC> static int launch_xq(const XqLaunch &l) {
   constexpr int LPB = W > H ? W : H;
   constexpr int BPW = kXqThreads / LPB;
+  // Variants (measured, profiles/r01_txq_variants.md):
+  //   2  whole block per lane, registers only           -> 4x4
+  //   1  16-byte accesses staged through LDS             -> up to 16x16
+  //   0  lanes load / store their own column / row       -> larger blocks (LDS footprint would cost occupancy)
+  // AOMHIP_XQ_VARIANT forces one (falls back to 1 where 2 is not instantiated).
+  static const int forced = [] { const char *e = getenv("AOMHIP_XQ_VARIANT"); return e ? atoi(e) : -1; }();
+  constexpr bool kLane = (W == 4 && H == 4);  // 8x8 per lane measured 60 % slower than the staged kernel
+  int variant = forced >= 0 ? forced : (kLane ? 2 : (W * H <= 256 ? 1 : 0));
+  if (variant == 2 && !kLane) variant = 1;
+  if constexpr (kLane) {
+    if (variant == 2) {
+      const int nwg = (l.n_blocks + kXqThreads - 1) / kXqThreads;
+      const int nwg8 = (nwg + 7) & ~7;
+      hipLaunchKernelGGL((xform_quant_lane_kernel<W, H, HBD, SRC>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0,
+                         l.in1, l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff,
+                         l.qcoeff, l.dqcoeff, l.eob, nwg8);
+      AOMHIP_LAUNCH_CHECK();
+      return AOMHIP_OK;
+    }
+  }
   const int nwg = (l.n_blocks + BPW - 1) / BPW;
   const int nwg8 = (nwg + 7) & ~7;
-  // Blocks up to 16x16 gain from the 16-byte staged accesses; above that the extra LDS footprint costs more
-  // occupancy than it saves (measured, profiles/r01_txq_variants.md).  AOMHIP_XQ_VARIANT forces one.
-  static const int forced = [] { const char *e = getenv("AOMHIP_XQ_VARIANT"); return e ? atoi(e) : -1; }();
-  const int variant = forced >= 0 ? forced : (W * H <= 256 ? 1 : 0);
   if (variant == 0)
     hipLaunchKernelGGL((xform_quant_kernel<W, H, HBD, SRC>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0, l.in1,
                        l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff,
