@@ -90,6 +90,7 @@ _protos = {
     "aomhip_fullpel_diamond_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_subpel_bilinear_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_bind_variance_vtable": (C.c_int, [_vp, _i]),
+    "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp, _i, _i]),
@@ -234,6 +235,10 @@ class Context:
         check(lib.aomhip_subpel_bilinear_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, cost_type, iters,
                                                allow_hp, forced_stop, d_blocks, n, d_mv, d_err, d_dist, d_sse),
               "aomhip_subpel_bilinear_batch")
+
+    def build_pred_fullpel(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n):
+        check(lib.aomhip_build_pred_fullpel(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks,
+                                            d_mv, n), "aomhip_build_pred_fullpel")
 
 
 def planes_from_tensor(t, width, height, border, bit_depth, n_frames=1):

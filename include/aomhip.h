@@ -319,6 +319,14 @@ typedef struct aomhip_variance_vtable {
  * entry keeps the reference's value.  These are the one-launch-per-call conformance functions. */
 int aomhip_bind_variance_vtable(aomhip_variance_vtable *table, int bit_depth);
 
+/* Full-pel motion-compensated prediction for the frame-level pipeline: pred block i = reference block at
+ * (bx + mv.col, by + mv.row) with mv = d_fullpel_mv[2i], [2i+1] (row, col), i.e. av1_build_inter_predictor
+ * (av1/common/reconinter.c) for an integer MV, where the convolve is aom_convolve_copy.  Sub-pel interpolation
+ * (the 8-tap filters) is outside this library's path. */
+int aomhip_build_pred_fullpel(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred,
+                              int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks,
+                              const int16_t *d_fullpel_mv, int n_blocks);
+
 /* ------------------------------------------------------------------ rtcd-signature conformance entry points */
 
 /* aom_dsp_rtcd_defs.pl:762-763 aom_sad{W}x{H} / aom_sad_skip_{W}x{H}; host pointers. */
