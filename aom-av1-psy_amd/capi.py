@@ -70,6 +70,8 @@ _protos = {
     "aomhip_planes_download": (C.c_int, [_vp, _PP, _i, _vp]),
     "aomhip_sad_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
     "aomhip_sad_x4d_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
+    "aomhip_sad_sb_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp,
+                                      _i, _i64, _vp]),
     "aomhip_variance_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp]),
     "aomhip_sub_pixel_variance_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp]),
     "aomhip_variance": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint)]),
@@ -154,6 +156,9 @@ class Context:
         check(lib.aomhip_memcpy_d2h(self.h, out.ctypes.data, ptr, out.nbytes), "d2h")
         return out
 
+    def memset(self, ptr, value, nbytes):
+        check(lib.aomhip_memset(self.h, ptr, value, nbytes), "memset")
+
     def timer_begin(self):
         check(lib.aomhip_timer_begin(self.h), "timer_begin")
 
@@ -205,6 +210,13 @@ class Context:
         check(lib.aomhip_subtract_xform_quant_batch(self.h, C.byref(src), C.byref(pred), frame, tx_size, d_blocks,
                                                     n_blocks, grid_cols, tx_type, C.byref(qp), d_coeff, d_qcoeff,
                                                     d_dqcoeff, d_eob), "aomhip_subtract_xform_quant_batch")
+
+    def sad_sb_batch(self, src, ref, first_frame, n_frames, bw, bh, flags, sb_w, sb_h, rng, n_buckets, d_groups=None,
+                     d_group_off=None, n_groups=0, group_frame_stride=0, d_out_groups=None, d_cands=None, d_cand_off=None,
+                     n_cands=0, cand_frame_stride=0, d_out_cands=None):
+        check(lib.aomhip_sad_sb_batch(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, bw, bh, flags, sb_w, sb_h,
+                                      rng, n_buckets, d_groups, d_group_off, n_groups, group_frame_stride, d_out_groups,
+                                      d_cands, d_cand_off, n_cands, cand_frame_stride, d_out_cands), "aomhip_sad_sb_batch")
 
     # ---- variance
     def variance_batch(self, src, ref, first_frame, n_frames, bw, bh, d_cands, n, stride, d_var, d_sse, subpel=False):

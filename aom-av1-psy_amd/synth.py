@@ -98,6 +98,20 @@ def mode_a_worklist(width, height, bsize=16, seed=1, search=64, order="raster"):
     return cands, groups
 
 
+def bucket_order(sx, sy, width, height, sb_w, sb_h):
+    """Host batching for aomhip_sad_sb_batch: -> (perm, offsets) such that list[perm] is sorted by the sb_w x sb_h
+    cell (raster over cells) its source block starts in, stable inside a cell, and offsets[b]..offsets[b+1]
+    delimit cell b (int32, n_cells + 1)."""
+    cpr = (width + sb_w - 1) // sb_w
+    rows = (height + sb_h - 1) // sb_h
+    cell = (np.asarray(sy, np.int64) // sb_h) * cpr + np.asarray(sx, np.int64) // sb_w
+    perm = np.argsort(cell, kind="stable")
+    counts = np.bincount(cell, minlength=cpr * rows)
+    offsets = np.zeros(cpr * rows + 1, np.int32)
+    offsets[1:] = np.cumsum(counts)
+    return perm, offsets
+
+
 def tile_column_bounds(width, n_cols, sb=64):
     """Uniform tile columns in superblock units (av1/common/tile_common.c:76-97):
     size_sb = ceil(sb_cols / n_cols); returns [(x0, x1), ...] in pixels (may be fewer than n_cols)."""

@@ -10,10 +10,12 @@ rank), so per-GPU work is fixed: "scaling": "weak".  There is no data-path colle
 SAD search itself (the reference planes are inputs); the only torch.distributed traffic is
 the barrier / max-reduce of the timing.
 
-A "step" is one pass of the hot path over the whole ring: one `aomhip_sad_batch` launch (the
-mv (0,0) candidate of every 16x16 block) plus one `aomhip_sad_x4d_batch` launch (one group of
-four uniformly random positions in [-64,64]^2 per block) -- SURVEY.md 8(d) "Mode A", 5
-candidates per block.  Inputs are resident in HBM before the timed region starts.
+A "step" is one pass of the hot path over the whole ring -- SURVEY.md 8(d) "Mode A", 5 candidates per 16x16
+block: the mv (0,0) candidate plus one x4d group of four uniformly random positions in [-64,64]^2.  8-bit planes
+go through ONE `aomhip_sad_sb_batch` launch (superblock-bucketed lists, reference window staged in LDS);
+10-bit planes through one `aomhip_sad_batch` + one `aomhip_sad_x4d_batch` launch (the direct kernels, which
+are the faster ones there).  Both are timed and reported under "kernels".  Inputs are resident in HBM before
+the timed region starts.
 """
 import argparse
 import json
@@ -110,6 +112,17 @@ class SadModeA:
         self.h_cands, self.h_groups0 = base_c, allg[0].copy()
         self.d_cands = ctx.to_device(base_c) if n else None
         self.d_groups = ctx.to_device(allg) if n else None
+        # Superblock-bucketed copy of the same lists (aomhip_sad_sb_batch): 128x128 cells, range 64 -- the path the
+        # step uses for 8-bit planes (2x the direct kernels); AOMHIP_SAD_PATH=direct|sb overrides.
+        self.path = os.environ.get("AOMHIP_SAD_PATH", "sb" if bd == 8 else "direct")
+        self.cell = (128, 128) if bd == 8 else (128, 64)
+        self.d_sb = None
+        if n and self.path == "sb":
+            perm, off = synth.bucket_order(base_c["sx"], base_c["sy"], W, H, *self.cell)
+            self.perm, self.n_buckets = perm, len(off) - 1
+            self.d_sb = (ctx.to_device(np.ascontiguousarray(allg[:, perm])), ctx.to_device(base_c[perm]), ctx.to_device(off))
+            self.d_sb_out4 = ctx.malloc(max(16, self.ring * n * 16))
+            self.d_sb_out1 = ctx.malloc(max(16, self.ring * n * 4))
         self.d_out1 = ctx.malloc(max(16, self.ring * n * 4))
         self.d_out4 = ctx.malloc(max(16, self.ring * n * 16))
         self.cands_per_step = 5 * n * self.ring
@@ -125,9 +138,19 @@ class SadModeA:
             self.ctx.sad_x4d_batch(self.src, self.ref, 0, self.ring, 16, 16, 0, self.d_groups, self.blocks_per_frame,
                                    self.blocks_per_frame, self.d_out4)
 
+    def launch_sb(self):
+        if self.d_sb:
+            n = self.blocks_per_frame
+            self.ctx.sad_sb_batch(self.src, self.ref, 0, self.ring, 16, 16, 0, self.cell[0], self.cell[1], 64, self.n_buckets,
+                                  self.d_sb[0], self.d_sb[2], n, n, self.d_sb_out4, self.d_sb[1], self.d_sb[2], n, 0,
+                                  self.d_sb_out1)
+
     def step(self):
-        self.launch_single()
-        self.launch_x4d()
+        if self.path == "sb":
+            self.launch_sb()
+        else:
+            self.launch_single()
+            self.launch_x4d()
 
     def bytes_per_cand(self):
         return SAD16_BYTES_8BIT if self.cfg["bit_depth"] == 8 else 1028
@@ -141,8 +164,13 @@ class SadModeA:
         sb = orc.extend_plane(s, self.border, self.src.stride)
         rb = orc.extend_plane(r, self.border, self.ref.stride)
         bd = self.cfg["bit_depth"]
-        got1 = self.ctx.from_device(self.d_out1, (n,), np.uint32)
-        got4 = self.ctx.from_device(self.d_out4, (n, 4), np.uint32)
+        if self.path == "sb":  # un-permute the bucket order
+            got1, got4 = np.empty((n,), np.uint32), np.empty((n, 4), np.uint32)
+            got1[self.perm] = self.ctx.from_device(self.d_sb_out1, (n,), np.uint32)
+            got4[self.perm] = self.ctx.from_device(self.d_sb_out4, (n, 4), np.uint32)
+        else:
+            got1 = self.ctx.from_device(self.d_out1, (n,), np.uint32)
+            got4 = self.ctx.from_device(self.d_out4, (n, 4), np.uint32)
         ok = np.array_equal(got1, orc.sad_batch(sb, rb, self.border, 16, 16, self.h_cands, bd=bd, threads=4))
         ok &= np.array_equal(got4, orc.sad_x4d_batch(sb, rb, self.border, 16, 16, self.h_groups0, bd=bd, threads=4))
         return bool(ok)
@@ -176,7 +204,8 @@ class SadModeA:
         c = self.ctx
         for p in (self.src, self.ref):
             c.planes_free(p)
-        for d in (self.d_cands, self.d_groups, self.d_out1, self.d_out4):
+        for d in (self.d_cands, self.d_groups, self.d_out1, self.d_out4) + (tuple(self.d_sb) + (self.d_sb_out4, self.d_sb_out1)
+                                                                          if self.d_sb else ()):
             if d:
                 c.free(d)
 
@@ -513,20 +542,27 @@ def run_workload(pkg, ctx, dist, dev, rank, world, name, steps, warmup, want_cpu
         t = torch.tensor([total], dtype=torch.float64, device=_red_device())
         dist.all_reduce(t)
         total = int(t.item())
-    k_ms = kernel_avg_ms(ctx, wl.launch_x4d, max(steps, 10))
+    kx_ms = kernel_avg_ms(ctx, wl.launch_x4d, max(steps, 10))
     k1_ms = kernel_avg_ms(ctx, wl.launch_single, max(steps, 10))
-    x4d_bytes = 4 * wl.blocks_per_frame * wl.ring * wl.bytes_per_cand()
+    if wl.path == "sb":  # dominant (only) kernel of the step: all five candidates of every block in one launch
+        k_ms = kernel_avg_ms(ctx, wl.launch_sb, max(steps, 10))
+        x4d_bytes = 5 * wl.blocks_per_frame * wl.ring * wl.bytes_per_cand()
+        kname, traffic = "sad_sb_kernel<16x16>", load_traffic(name + ":sb")
+    else:
+        k_ms = kx_ms
+        x4d_bytes = 4 * wl.blocks_per_frame * wl.ring * wl.bytes_per_cand()
+        kname, traffic = "sad_x4d_kernel<16x16>", load_traffic(name)
     ach = x4d_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    traffic = load_traffic(name)
     res = {
         "workload": name, "value": total * steps / wall, "unit": "candidates/s", "ms_per_step": wall / steps * 1e3,
         "event_ms_per_step": ev_ms / steps, "candidates_per_step": total, "parity_frame0": ok,
-        "roofline": {"bound": "hbm", "kernel": "sad_x4d_kernel<16x16>", "achieved": ach, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": x4d_bytes,
                      "note": "achieved = ALGORITHMIC bytes (516 B per 8-bit 16x16 candidate, 1028 B 10-bit) / launch time; "
                              "overlapping candidates are served by L2/Infinity Cache, so compare with `traffic`"},
-        "kernels": {"sad_x4d_kernel_avg_ms": k_ms, "sad_cand_kernel_avg_ms": k1_ms},
+        "kernels": {"path": wl.path, "sad_sb_kernel_avg_ms": k_ms if wl.path == "sb" else None,
+                    "sad_x4d_kernel_avg_ms": kx_ms, "sad_cand_kernel_avg_ms": k1_ms},
         "ring_frames": wl.ring, "blocks_per_frame_this_rank": wl.blocks_per_frame, "tile_column_px": list(wl.tile),
     }
     if traffic and k_ms > 0:  # the mandatory companion figure and the cache-bound rule

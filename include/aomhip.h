@@ -143,6 +143,28 @@ int aomhip_sad_x4d_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip
                          int n_frames, int bw, int bh, int flags, const aomhip_sad_x4d_cand *d_groups,
                          int n_groups, int64_t group_frame_stride, uint32_t *d_out);
 
+/* Superblock-bucketed SAD batch: the same results as aomhip_sad_x4d_batch / aomhip_sad_batch, for work lists
+ * laid out the way the encoder's per-superblock call sites issue them (av1/encoder/encodeframe.c:1069
+ * encode_sb_row; motion vectors confined by av1_set_mv_search_range, av1/encoder/mcomp.c:101).
+ *   The visible plane is cut into cells of sb_w x sb_h pixels, raster order, cells_per_row =
+ *   ceil(width / sb_w); n_buckets must equal the number of cells.  Bucket b holds the entries whose SOURCE
+ *   block starts inside cell b: entries [d_*_bucket_offsets[b], d_*_bucket_offsets[b + 1]) of the list.  The
+ *   offsets are shared by all frames (frame f uses list + f_rel * *_frame_stride, 0 = one shared list).
+ *   Every reference block is expected to lie within `range` pixels of its cell
+ *   ([cell_x0 - range, cell_x0 + sb_w + range) x likewise in y); one workgroup stages that window in LDS
+ *   once and serves all the bucket's candidates from it.  An entry outside the window is still evaluated
+ *   exactly, from global memory -- the contract is about speed, not validity.
+ *   Either list may be NULL (then its offsets / output are ignored).  The window
+ *   (sb_w + 2 range) x (sb_h + 2 range) x bytes-per-pixel (+ 16 B per row) must fit 160 KB; 128 x 128 cells with
+ *   range 64 (8-bit) use 68 KB so that two workgroups share a CU.
+ *   Outputs: d_out_groups[(f_rel * n_groups + i) * 4 + k], d_out_cands[f_rel * n_cands + i]. */
+int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame,
+                        int n_frames, int bw, int bh, int flags, int sb_w, int sb_h, int range, int n_buckets,
+                        const aomhip_sad_x4d_cand *d_groups, const int32_t *d_group_bucket_offsets, int n_groups,
+                        int64_t group_frame_stride, uint32_t *d_out_groups, const aomhip_sad_cand *d_cands,
+                        const int32_t *d_cand_bucket_offsets, int n_cands, int64_t cand_frame_stride,
+                        uint32_t *d_out_cands);
+
 /* ------------------------------------------------------------------ batched variance / sub-pixel variance */
 
 /* One evaluation: source block at (sx, sy), reference block at (rx, ry) [+ (xoff, yoff)/8 pel for the
