@@ -11,11 +11,10 @@ SAD search itself (the reference planes are inputs); the only torch.distributed 
 the barrier / max-reduce of the timing.
 
 A "step" is one pass of the hot path over the whole ring -- SURVEY.md 8(d) "Mode A", 5 candidates per 16x16
-block: the mv (0,0) candidate plus one x4d group of four uniformly random positions in [-64,64]^2.  8-bit planes
-go through ONE `aomhip_sad_sb_batch` launch (superblock-bucketed lists, reference window staged in LDS);
-10-bit planes through one `aomhip_sad_batch` + one `aomhip_sad_x4d_batch` launch (the direct kernels, which
-are the faster ones there).  Both are timed and reported under "kernels".  Inputs are resident in HBM before
-the timed region starts.
+block: the mv (0,0) candidate plus one x4d group of four uniformly random positions in [-64,64]^2.  The step is
+ONE `aomhip_sad_sb_batch` launch (superblock-bucketed lists, reference window staged in LDS by persistent
+workgroups); the direct kernels (`aomhip_sad_batch` + `aomhip_sad_x4d_batch`, arbitrary lists) are timed beside it
+and reported under "kernels".  Inputs are resident in HBM before the timed region starts.
 """
 import argparse
 import json
@@ -112,10 +111,11 @@ class SadModeA:
         self.h_cands, self.h_groups0 = base_c, allg[0].copy()
         self.d_cands = ctx.to_device(base_c) if n else None
         self.d_groups = ctx.to_device(allg) if n else None
-        # Superblock-bucketed copy of the same lists (aomhip_sad_sb_batch): 128x128 cells, range 64 -- the path the
-        # step uses for 8-bit planes (2x the direct kernels); AOMHIP_SAD_PATH=direct|sb overrides.
-        self.path = os.environ.get("AOMHIP_SAD_PATH", "sb" if bd == 8 else "direct")
-        self.cell = (128, 128) if bd == 8 else (128, 64)
+        # Superblock-bucketed copy of the same lists (aomhip_sad_sb_batch), range 64: cells of 384x128 pixels for
+        # 8-bit planes (512 x 256-byte window + row padding = 136 KB of LDS), 128x128 for 10/12-bit (256 x 512 bytes).
+        # It is the path the step uses (2.1x / 1.6x the direct kernels); AOMHIP_SAD_PATH=direct|sb overrides.
+        self.path = os.environ.get("AOMHIP_SAD_PATH", "sb")
+        self.cell = (384, 128) if bd == 8 else (128, 128)
         self.d_sb = None
         if n and self.path == "sb":
             perm, off = synth.bucket_order(base_c["sx"], base_c["sy"], W, H, *self.cell)

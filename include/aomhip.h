@@ -151,12 +151,13 @@ int aomhip_sad_x4d_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip
  *   block starts inside cell b: entries [d_*_bucket_offsets[b], d_*_bucket_offsets[b + 1]) of the list.  The
  *   offsets are shared by all frames (frame f uses list + f_rel * *_frame_stride, 0 = one shared list).
  *   Every reference block is expected to lie within `range` pixels of its cell
- *   ([cell_x0 - range, cell_x0 + sb_w + range) x likewise in y); one workgroup stages that window in LDS
- *   once and serves all the bucket's candidates from it.  An entry outside the window is still evaluated
- *   exactly, from global memory -- the contract is about speed, not validity.
+ *   ([cell_x0 - range, cell_x0 + sb_w + range) x likewise in y): persistent workgroups stage that window in LDS
+ *   (the next cell's window is in flight while the current one is evaluated) and serve all the bucket's
+ *   candidates from it.  An entry outside the window is still evaluated exactly, from global memory -- the
+ *   contract is about speed, not validity.
  *   Either list may be NULL (then its offsets / output are ignored).  The window
- *   (sb_w + 2 range) x (sb_h + 2 range) x bytes-per-pixel (+ 16 B per row) must fit 160 KB; 128 x 128 cells with
- *   range 64 (8-bit) use 68 KB so that two workgroups share a CU.
+ *   (sb_w + 2 range) x (sb_h + 2 range) x bytes-per-pixel (+ 16 B per row) must fit the 160 KB LDS of a CU.
+ *   Measured best on MI355X at range 64: 384 x 128 cells for 8-bit planes, 128 x 128 for 10/12-bit.
  *   Outputs: d_out_groups[(f_rel * n_groups + i) * 4 + k], d_out_cands[f_rel * n_cands + i]. */
 int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame,
                         int n_frames, int bw, int bh, int flags, int sb_w, int sb_h, int range, int n_buckets,
