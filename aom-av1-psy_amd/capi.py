@@ -89,6 +89,7 @@ _protos = {
     "aomhip_inv_txfm_add_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _PP, _i]),
     "aomhip_deblock_plane": (C.c_int, [_vp, _PP, _i, _vp, _i, _i, _i]),
     "aomhip_cdef_luma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "aomhip_cdef_chroma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i]),
     "aomhip_fullpel_diamond_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_subpel_bilinear_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_bind_variance_vtable": (C.c_int, [_vp, _i]),
@@ -227,6 +228,11 @@ class Context:
     def inv_txfm_add_batch(self, d_dqcoeff, tx_size, d_blocks, n_blocks, grid_cols, tx_type, d_eob, dst, frame):
         check(lib.aomhip_inv_txfm_add_batch(self.h, d_dqcoeff, tx_size, d_blocks, n_blocks, grid_cols, tx_type, d_eob,
                                             C.byref(dst), frame), "aomhip_inv_txfm_add_batch")
+
+    def cdef_chroma_plane(self, src, src_frame, dst, dst_frame, xdec, ydec, d_luma_dir, d_pri, d_sec, fb_stride, d_skip,
+                          damping):
+        check(lib.aomhip_cdef_chroma_plane(self.h, C.byref(src), src_frame, C.byref(dst), dst_frame, xdec, ydec, d_luma_dir,
+                                           d_pri, d_sec, fb_stride, d_skip, damping), "aomhip_cdef_chroma_plane")
 
     def deblock_plane(self, p, frame, d_params, units_stride, sharpness=0, passes=3):
         check(lib.aomhip_deblock_plane(self.h, C.byref(p), frame, d_params, units_stride, sharpness, passes),

@@ -112,7 +112,9 @@ __global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ 
     const int by = tid >> 3, bx = tid & 7;
     const int gy = y0 + by * 8, gx = x0 + bx * 8;
     int d = -1, var = 0;
-    if (gy < height && gx < width && (level | sec) != 0 && !skip[(gy >> 3) * b8w + (gx >> 3)]) {
+    // (a zero-strength filter block is still searched when the caller wants the directions: its chroma strengths
+    //  may be non-zero, cdef.c:334-345; filtering with zero strengths below is the identity)
+    if (gy < height && gx < width && ((level | sec) != 0 || dir_out || var_out) && !skip[(gy >> 3) * b8w + (gx >> 3)]) {
       int x[64];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -211,9 +213,129 @@ __global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ 
   }
 }
 
+// Chroma planes: av1_cdef_filter_fb with pli > 0 (cdef_block.c:323-426).  A luma 8x8 block maps to a
+// (8 >> XDEC) x (8 >> YDEC) chroma block; the direction comes from luma (converted for 4:2:2 / 4:4:0, :362-371),
+// the primary strength is not variance-adjusted and the damping is one less (:333).  Same structure as the luma
+// kernel without the direction search: one workgroup per filter block, footprint in LDS, 4 lanes per block.
+__device__ constexpr int8_t kDirDyDx[8][2][2] = { { { -1, 1 }, { -2, 2 } }, { { 0, 1 }, { -1, 2 } }, { { 0, 1 }, { 0, 2 } },
+                                                  { { 0, 1 }, { 1, 2 } },   { { 1, 1 }, { 2, 2 } },  { { 1, 0 }, { 2, 1 } },
+                                                  { { 1, 0 }, { 2, 0 } },   { { 1, 0 }, { 2, -1 } } };
+
+template <typename PIX, int XDEC, int YDEC>
+__global__ __launch_bounds__(256) void cdef_chroma_kernel(const PIX *__restrict__ src, PIX *__restrict__ dst, int stride,
+                                                          int width, int height, const uint8_t *__restrict__ luma_dir,
+                                                          const uint8_t *__restrict__ fb_pri,
+                                                          const uint8_t *__restrict__ fb_sec, int fb_stride,
+                                                          const uint8_t *__restrict__ skip, int damping,
+                                                          int coeff_shift) {
+  constexpr int BW = 8 >> XDEC, BH = 8 >> YDEC;    // chroma block of one luma 8x8
+  constexpr int FW = 64 >> XDEC, FH = 64 >> YDEC;  // chroma filter block
+  constexpr int TW = FW + 8, TH = FH + 4;          // LDS tile: rows -2..FH+1, cols -4..FW+3
+  __shared__ uint16_t tile[TH * TW];
+  const int fbx = blockIdx.x, fby = blockIdx.y;
+  const int x0 = fbx * FW, y0 = fby * FH;
+  const int tid = threadIdx.x;
+  const int nbx = width / BW;
+  for (int i = tid; i < TH * TW; i += 256) {
+    const int r = i / TW - 2, c = i % TW - 4;
+    const int y = y0 + r, x = x0 + c;
+    int v = kVeryLarge;
+    if (y >= 0 && y < height && x >= 0 && x < width) v = src[(int64_t)y * stride + x];
+    tile[i] = (uint16_t)v;
+  }
+  const int level = fb_pri[fby * fb_stride + fbx], sec = fb_sec[fby * fb_stride + fbx];
+  __syncthreads();
+
+  constexpr int kRows = BH / 4 > 0 ? BH / 4 : 1;  // rows per lane (4 lanes per block)
+  const int blk = tid >> 2, q = tid & 3;
+  const int by = blk >> 3, bx = blk & 7;
+  const int gx0 = x0 + bx * BW, gyb = y0 + by * BH;
+  if (gyb >= height || gx0 >= width) return;
+  const int bidx = (gyb / BH) * nbx + gx0 / BW;
+  const bool filt = (level | sec) != 0 && !skip[bidx];
+  const int pri_strength = level << coeff_shift, sec_strength = sec << coeff_shift;
+  int dir = luma_dir[bidx] & 7;
+  if constexpr (XDEC != YDEC) {
+    constexpr int conv422[8] = { 7, 0, 2, 4, 5, 6, 6, 6 }, conv440[8] = { 1, 2, 2, 2, 3, 4, 6, 0 };
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c = dir == k ? (XDEC ? conv422[k] : conv440[k]) : c;
+    dir = c;
+  }
+  dir = pri_strength ? dir : 0;
+  const int t = pri_strength;
+  const int dmp = damping + coeff_shift - 1;
+  const bool en_pri = t != 0, en_sec = sec_strength != 0, clip = en_pri && en_sec;
+  const int pt0 = ((t >> coeff_shift) & 1) ? 3 : 4, pt1 = ((t >> coeff_shift) & 1) ? 3 : 2;
+  auto off = [&](int d, int k) { return kDirDyDx[d][k][0] * TW + kDirDyDx[d][k][1]; };
+  const int po0 = off(dir, 0), po1 = off(dir, 1);
+  const int s1o0 = off((dir + 2) & 7, 0), s1o1 = off((dir + 2) & 7, 1);
+  const int s2o0 = off((dir + 6) & 7, 0), s2o1 = off((dir + 6) & 7, 1);
+#pragma unroll
+  for (int rr = 0; rr < kRows; ++rr) {
+    const int ly = by * BH + q * kRows + rr;
+    if (q * kRows + rr >= BH) break;
+    PIX outv[BW];
+#pragma unroll
+    for (int j = 0; j < BW; ++j) {
+      const int pos = (ly + 2) * TW + bx * BW + j + 4;
+      const int x = tile[pos];
+      int y = x;
+      if (filt) {
+        int sum = 0, mx = x, mn = x;
+        if (en_pri) {
+          const int p0 = tile[pos + po0], p1 = tile[pos - po0], p2 = tile[pos + po1], p3 = tile[pos - po1];
+          sum += pt0 * (constrain_d(p0 - x, t, dmp) + constrain_d(p1 - x, t, dmp));
+          sum += pt1 * (constrain_d(p2 - x, t, dmp) + constrain_d(p3 - x, t, dmp));
+          if (clip) {
+            mx = max(mx, p0 == kVeryLarge ? x : p0); mx = max(mx, p1 == kVeryLarge ? x : p1);
+            mx = max(mx, p2 == kVeryLarge ? x : p2); mx = max(mx, p3 == kVeryLarge ? x : p3);
+            mn = min(min(mn, p0), min(p1, min(p2, p3)));
+          }
+        }
+        if (en_sec) {
+          const int a0 = tile[pos + s1o0], a1 = tile[pos - s1o0], a2 = tile[pos + s2o0], a3 = tile[pos - s2o0];
+          const int c0 = tile[pos + s1o1], c1 = tile[pos - s1o1], c2 = tile[pos + s2o1], c3 = tile[pos - s2o1];
+          sum += 2 * (constrain_d(a0 - x, sec_strength, dmp) + constrain_d(a1 - x, sec_strength, dmp) +
+                      constrain_d(a2 - x, sec_strength, dmp) + constrain_d(a3 - x, sec_strength, dmp));
+          sum += 1 * (constrain_d(c0 - x, sec_strength, dmp) + constrain_d(c1 - x, sec_strength, dmp) +
+                      constrain_d(c2 - x, sec_strength, dmp) + constrain_d(c3 - x, sec_strength, dmp));
+          if (clip) {
+            mx = max(mx, a0 == kVeryLarge ? x : a0); mx = max(mx, a1 == kVeryLarge ? x : a1);
+            mx = max(mx, a2 == kVeryLarge ? x : a2); mx = max(mx, a3 == kVeryLarge ? x : a3);
+            mx = max(mx, c0 == kVeryLarge ? x : c0); mx = max(mx, c1 == kVeryLarge ? x : c1);
+            mx = max(mx, c2 == kVeryLarge ? x : c2); mx = max(mx, c3 == kVeryLarge ? x : c3);
+            mn = min(min(min(mn, a0), min(a1, a2)), min(min(a3, c0), min(c1, min(c2, c3))));
+          }
+        }
+        y = x + ((8 + sum - (sum < 0)) >> 4);
+        if (clip) y = y < mn ? mn : (y > mx ? mx : y);
+      }
+      outv[j] = (PIX)y;
+    }
+    PIX *o = dst + (int64_t)(y0 + ly) * stride + gx0;
+#pragma unroll
+    for (int j = 0; j < BW; ++j) o[j] = outv[j];
+  }
+}
+
 }  // namespace aomhip
 
 using namespace aomhip;
+
+template <typename PIX>
+static void launch_chroma(hipStream_t st, dim3 grid, int xdec, int ydec, const void *s, void *d, int stride, int w, int h,
+                          const uint8_t *dir, const uint8_t *pri, const uint8_t *sec, int fbs, const uint8_t *skip,
+                          int damping, int cs) {
+#define AOMHIP_CDEF_C(X, Y)                                                                                          \
+  hipLaunchKernelGGL((cdef_chroma_kernel<PIX, X, Y>), grid, dim3(256), 0, st, static_cast<const PIX *>(s),           \
+                     static_cast<PIX *>(d), stride, w, h, dir, pri, sec, fbs, skip, damping, cs)
+  if (xdec == 1 && ydec == 1) AOMHIP_CDEF_C(1, 1);
+  else if (xdec == 0 && ydec == 0) AOMHIP_CDEF_C(0, 0);
+  else if (xdec == 1 && ydec == 0) AOMHIP_CDEF_C(1, 0);
+  else AOMHIP_CDEF_C(0, 1);
+#undef AOMHIP_CDEF_C
+}
 
 extern "C" {
 
@@ -243,6 +365,34 @@ int aomhip_cdef_luma_plane(aomhip_ctx *ctx, const aomhip_planes *src, int src_fr
                        reinterpret_cast<const uint16_t *>(s), reinterpret_cast<uint16_t *>(d), src->stride, src->width,
                        src->height, d_fb_pri, d_fb_sec, fb_stride, d_skip8x8, damping, src->bit_depth - 8, d_dir_out,
                        d_var_out);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+int aomhip_cdef_chroma_plane(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dst,
+                             int dst_frame, int xdec, int ydec, const uint8_t *d_luma_dir, const uint8_t *d_fb_uv_pri,
+                             const uint8_t *d_fb_uv_sec, int fb_stride, const uint8_t *d_skip8x8, int damping) {
+  if (!ctx || !src || !dst || !src->base || !dst->base || !d_luma_dir || !d_fb_uv_pri || !d_fb_uv_sec || !d_skip8x8 ||
+      src_frame < 0 || src_frame >= src->n_frames || dst_frame < 0 || dst_frame >= dst->n_frames ||
+      src->width != dst->width || src->height != dst->height || src->stride != dst->stride ||
+      src->bit_depth != dst->bit_depth || xdec < 0 || xdec > 1 || ydec < 0 || ydec > 1 ||
+      (src->width % (8 >> xdec)) || (src->height % (8 >> ydec)) || damping < 3 || damping > 6 ||
+      fb_stride < (src->width + (64 >> xdec) - 1) / (64 >> xdec) || (src->base == dst->base && src_frame == dst_frame)) {
+    set_error("aomhip_cdef_chroma_plane: invalid argument (chroma size must be whole blocks, out of place)");
+    return AOMHIP_ERR_INVALID;
+  }
+  const size_t esz = src->bit_depth == 8 ? 1 : 2;
+  const char *s = static_cast<const char *>(src->base) +
+                  ((size_t)src_frame * src->frame_stride + (size_t)src->border * src->stride + src->border) * esz;
+  char *d = static_cast<char *>(dst->base) +
+            ((size_t)dst_frame * dst->frame_stride + (size_t)dst->border * dst->stride + dst->border) * esz;
+  const dim3 grid((src->width + (64 >> xdec) - 1) / (64 >> xdec), (src->height + (64 >> ydec) - 1) / (64 >> ydec));
+  if (esz == 1)
+    launch_chroma<uint8_t>(ctx->stream, grid, xdec, ydec, s, d, src->stride, src->width, src->height, d_luma_dir,
+                           d_fb_uv_pri, d_fb_uv_sec, fb_stride, d_skip8x8, damping, 0);
+  else
+    launch_chroma<uint16_t>(ctx->stream, grid, xdec, ydec, s, d, src->stride, src->width, src->height, d_luma_dir,
+                            d_fb_uv_pri, d_fb_uv_sec, fb_stride, d_skip8x8, damping, src->bit_depth - 8);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

@@ -273,11 +273,23 @@ int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, con
  *   d_skip8x8            one byte per 8x8 block, row-major (width/8 per row): non-zero = all four 4x4 mode
  *                        infos are skip_txfm (is_8x8_block_skip, cdef.c:24-35) -> block is copied
  *   damping              cdef_damping, 3..6
- *   d_dir_out/d_var_out  optional per-8x8 direction / variance (the chroma planes reuse the luma
- *                        directions, cdef_block.c:355-369) */
+ *   d_dir_out/d_var_out  optional per-8x8 direction / variance of every non-skipped block (the chroma planes
+ *                        reuse the luma directions, cdef_block.c:355-369); 0 for skipped blocks */
 int aomhip_cdef_luma_plane(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dst,
                            int dst_frame, const uint8_t *d_fb_pri, const uint8_t *d_fb_sec, int fb_stride,
                            const uint8_t *d_skip8x8, int damping, uint8_t *d_dir_out, int32_t *d_var_out);
+
+/* The same for a CHROMA plane (pli > 0 in av1_cdef_filter_fb, cdef_block.c:323-426): `src` / `dst` are rings of that
+ * chroma plane, xdec / ydec its subsampling (4:2:0 = 1,1; 4:4:4 = 0,0; 4:2:2 = 1,0; 4:4:0 = 0,1), so one luma 8x8
+ * block is a (8 >> xdec) x (8 >> ydec) chroma block and a filter block is (64 >> xdec) x (64 >> ydec).
+ *   d_luma_dir            the d_dir_out of aomhip_cdef_luma_plane on the frame's luma plane (converted here for
+ *                         4:2:2 / 4:4:0, :362-371); requesting it there makes that launch search every
+ *                         non-skipped block, also in filter blocks whose luma strengths are zero (cdef.c:334-345)
+ *   d_fb_uv_pri / _sec    cdef_uv_strengths[idx] / 4, % 4 (3 -> 4) per filter block (cdef.c:318-322)
+ *   d_skip8x8, damping    as for luma; the primary strength is not variance-adjusted, damping - 1 (:333,:395) */
+int aomhip_cdef_chroma_plane(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dst,
+                             int dst_frame, int xdec, int ydec, const uint8_t *d_luma_dir, const uint8_t *d_fb_uv_pri,
+                             const uint8_t *d_fb_uv_sec, int fb_stride, const uint8_t *d_skip8x8, int damping);
 
 /* ------------------------------------------------------------------ device-side motion search */
 

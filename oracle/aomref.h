@@ -150,6 +150,13 @@ int orc_cdef_find_dir(const uint16_t *img, int stride, int32_t *var, int coeff_s
 void orc_cdef_filter_block(uint8_t *dst8, uint16_t *dst16, int dstride, const uint16_t *in, int pri_strength,
                            int sec_strength, int dir, int pri_damping, int sec_damping, int coeff_shift,
                            int block_w, int block_h, int enable_primary, int enable_secondary);
+/* plane drivers: av1_cdef_frame for one plane, out of place (cdef.c:138-345 + cdef_block.c:323-426) */
+void orc_cdef_plane_luma(const void *src, void *dst, int stride, int width, int height, int elem16, int bd,
+                         const uint8_t *fb_pri, const uint8_t *fb_sec, int fb_stride, const uint8_t *skip, int damping,
+                         uint8_t *dir_out, int32_t *var_out);
+void orc_cdef_plane_chroma(const void *src, void *dst, int stride, int width, int height, int elem16, int bd, int xdec,
+                           int ydec, const uint8_t *dir, const uint8_t *fb_pri, const uint8_t *fb_sec, int fb_stride,
+                           const uint8_t *skip, int damping);
 
 #ifdef __cplusplus
 }

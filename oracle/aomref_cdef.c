@@ -134,7 +134,7 @@ static int adjust_strength(int strength, int32_t var) { /* cdef_block.c:289-293 
  * fb_pri / fb_sec: per 64x64 filter block the primary level and the secondary strength AFTER the
  * "3 -> 4" rule (cdef.c:309-313); a block with pri == sec == 0 and every skipped 8x8 is copied.
  * skip: one byte per 8x8 block (row-major, (width/8) per row), non-zero = all four 4x4 are skip_txfm.
- * dir_out / var_out (optional): per-8x8 direction and variance for the chroma planes. */
+ * dir_out / var_out (optional): per-8x8 direction and variance of every non-skipped block, for the chroma planes. */
 void orc_cdef_plane_luma(const void *src, void *dst, int stride, int width, int height, int elem16, int bd,
                          const uint8_t *fb_pri, const uint8_t *fb_sec, int fb_stride, const uint8_t *skip, int damping,
                          uint8_t *dir_out, int32_t *var_out) {
@@ -162,7 +162,11 @@ void orc_cdef_plane_luma(const void *src, void *dst, int stride, int width, int 
       const int level = fb_pri[fb], sec = fb_sec[fb];
       if (dir_out) dir_out[by * b8w + bx] = 0;
       if (var_out) var_out[by * b8w + bx] = 0;
-      if ((level == 0 && sec == 0) || skip[by * b8w + bx]) continue;
+      if (skip[by * b8w + bx]) continue;
+      /* A filter block whose luma strengths are zero is still searched for directions when the chroma
+       * strengths are not (cdef.c:334-345 "do not skip ... luma ... direction is computed based on luma"); the
+       * side outputs therefore cover every non-skipped block whenever they are requested. */
+      if (level == 0 && sec == 0 && !dir_out && !var_out) continue;
       /* local CDEF_BSTRIDE buffer: rows -2..9, cols -8..(8+8) around the block */
       for (int r = -2; r < 10; ++r)
         for (int c = -8; c < 16; ++c) in[(r + 2) * 144 + c + 8] = pad[(by * 8 + r + 2) * pw + bx * 8 + c + 8];
@@ -180,6 +184,57 @@ void orc_cdef_plane_luma(const void *src, void *dst, int stride, int width, int 
       else
         orc_cdef_filter_block((uint8_t *)dst + (size_t)by * 8 * stride + bx * 8, NULL, stride, blk, t, sec_strength,
                               pri_strength ? dir : 0, dmp, dmp, coeff_shift, 8, 8, t != 0, sec_strength != 0);
+    }
+  }
+  free(pad);
+}
+
+/* Chroma plane driver: av1_cdef_filter_fb for pli > 0 (cdef_block.c:323-426): block (8 >> xdec) x (8 >> ydec) per
+ * luma 8x8, direction taken from luma (converted by conv422 / conv440 when xdec != ydec, :362-371), no
+ * adjust_strength, damping - 1 (:333), CDEF_VERY_LARGE outside the chroma plane (cdef.c:138-245).
+ * width / height: chroma plane size; dir: luma directions [height_blocks][width_blocks]; fb_pri / fb_sec: the uv
+ * level and secondary strength per 64x64 luma filter block (after the "3 -> 4" rule, cdef.c:318-322). */
+void orc_cdef_plane_chroma(const void *src, void *dst, int stride, int width, int height, int elem16, int bd, int xdec,
+                           int ydec, const uint8_t *dir, const uint8_t *fb_pri, const uint8_t *fb_sec, int fb_stride,
+                           const uint8_t *skip, int damping) {
+  static const int conv422[8] = { 7, 0, 2, 4, 5, 6, 6, 6 };
+  static const int conv440[8] = { 1, 2, 2, 2, 3, 4, 6, 0 };
+  const int coeff_shift = bd - 8;
+  const int bw = 8 >> xdec, bh = 8 >> ydec;
+  const int nbx = width / bw, nby = height / bh;
+  const int pw = width + 16, ph = height + 4;
+  uint16_t *pad = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)pw * ph);
+  for (int i = 0; i < pw * ph; ++i) pad[i] = VERY_LARGE;
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) {
+      const int v = elem16 ? ((const uint16_t *)src)[(size_t)y * stride + x] : ((const uint8_t *)src)[(size_t)y * stride + x];
+      pad[(y + 2) * pw + x + 8] = (uint16_t)v;
+      if (elem16)
+        ((uint16_t *)dst)[(size_t)y * stride + x] = (uint16_t)v;
+      else
+        ((uint8_t *)dst)[(size_t)y * stride + x] = (uint8_t)v;
+    }
+  uint16_t in[144 * (8 + 4)];
+  for (int by = 0; by < nby; ++by) {
+    for (int bx = 0; bx < nbx; ++bx) {
+      const int fb = (by / 8) * fb_stride + bx / 8;
+      const int level = fb_pri[fb], sec = fb_sec[fb];
+      if ((level == 0 && sec == 0) || skip[by * nbx + bx]) continue;
+      for (int r = -2; r < bh + 2; ++r)
+        for (int c = -8; c < bw + 8; ++c) in[(r + 2) * 144 + c + 8] = pad[(by * bh + r + 2) * pw + bx * bw + c + 8];
+      const uint16_t *blk = in + 2 * 144 + 8;
+      int d = dir[by * nbx + bx];
+      if (xdec != ydec) d = (xdec ? conv422 : conv440)[d];
+      const int pri_strength = level << coeff_shift, sec_strength = sec << coeff_shift;
+      const int dmp = damping + coeff_shift - 1;
+      if (elem16)
+        orc_cdef_filter_block(NULL, (uint16_t *)dst + (size_t)by * bh * stride + bx * bw, stride, blk, pri_strength,
+                              sec_strength, pri_strength ? d : 0, dmp, dmp, coeff_shift, bw, bh, pri_strength != 0,
+                              sec_strength != 0);
+      else
+        orc_cdef_filter_block((uint8_t *)dst + (size_t)by * bh * stride + bx * bw, NULL, stride, blk, pri_strength,
+                              sec_strength, pri_strength ? d : 0, dmp, dmp, coeff_shift, bw, bh, pri_strength != 0,
+                              sec_strength != 0);
     }
   }
   free(pad);

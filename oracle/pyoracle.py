@@ -363,6 +363,22 @@ def cdef_plane_luma(pixels, fb_pri, fb_sec, skip, damping, bd=8):
     return dst, d, v
 
 
+def cdef_plane_chroma(pixels, xdec, ydec, luma_dir, fb_pri, fb_sec, skip, damping, bd=8):
+    """pixels: chroma plane; luma_dir: [h_blocks, w_blocks] uint8 from cdef_plane_luma; fb_pri / fb_sec: uv strengths."""
+    src = np.ascontiguousarray(pixels)
+    dst = np.zeros_like(src)
+    h, w = src.shape
+    d = np.ascontiguousarray(luma_dir, np.uint8)
+    fb_pri = np.ascontiguousarray(fb_pri, np.uint8); fb_sec = np.ascontiguousarray(fb_sec, np.uint8)
+    skip = np.ascontiguousarray(skip, np.uint8)
+    lib.orc_cdef_plane_chroma.restype = None
+    lib.orc_cdef_plane_chroma(C.c_void_p(src.ctypes.data), C.c_void_p(dst.ctypes.data), src.shape[1], w, h,
+                              int(src.dtype != np.uint8), bd, xdec, ydec, C.c_void_p(d.ctypes.data),
+                              C.c_void_p(fb_pri.ctypes.data), C.c_void_p(fb_sec.ctypes.data), fb_pri.shape[1],
+                              C.c_void_p(skip.ctypes.data), damping)
+    return dst
+
+
 # ---- motion search (aomref_mcomp.c)
 lib.orc_fullpel_diamond_batch.restype = None
 lib.orc_fullpel_diamond_batch.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i]

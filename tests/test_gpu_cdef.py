@@ -79,3 +79,60 @@ def test_full_size_4k_10bit(hip, oracle, ctx):
     want, wdir, wvar = oracle.cdef_plane_luma(pix, pri, sec, skip, 6, bd)
     assert np.array_equal(got, want) and np.array_equal(gdir, wdir) and np.array_equal(gvar, wvar)
     assert got.max() <= pix.max() and got.min() >= pix.min()
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("xdec,ydec", [(1, 1), (0, 0), (1, 0), (0, 1)])
+def test_chroma_planes(hip, oracle, ctx, bd, xdec, ydec):
+    """pli > 0: directions from the luma launch (also in filter blocks whose LUMA strengths are zero), uv strengths,
+    no variance adjustment, damping - 1; 4:2:0 / 4:4:4 / 4:2:2 / 4:4:0."""
+    rng = np.random.default_rng(bd * 4 + xdec * 2 + ydec)
+    for trial in range(3):
+        W, H = int(rng.choice([64, 136, 320])), int(rng.choice([64, 72, 200]))
+        cw, ch = W >> xdec, H >> ydec
+        luma, chroma = _content(rng, W, H, bd), _content(rng, cw, ch, bd)
+        fbh, fbw = (H + 63) // 64, (W + 63) // 64
+        pri_y = rng.integers(0, 16, (fbh, fbw)).astype(np.uint8); sec_y = rng.choice([0, 1, 2, 4], (fbh, fbw)).astype(np.uint8)
+        pri_uv = rng.integers(0, 16, (fbh, fbw)).astype(np.uint8); sec_uv = rng.choice([0, 1, 2, 4], (fbh, fbw)).astype(np.uint8)
+        pri_y[0, 0] = sec_y[0, 0] = 0  # luma off, chroma on: directions must still be there
+        pri_uv[0, 0], sec_uv[0, 0] = 5, 2
+        if fbw > 1:
+            pri_uv[0, 1] = sec_uv[0, 1] = 0  # chroma off
+        skip = (rng.random((H // 8, W // 8)) < 0.2).astype(np.uint8)
+        damping = int(rng.integers(3, 7))
+        _, gdir, _ = _run(hip, ctx, luma, pri_y, sec_y, skip, damping, bd)
+        _, wdir, _ = oracle.cdef_plane_luma(luma, pri_y, sec_y, skip, damping, bd)
+        assert np.array_equal(gdir, wdir)
+        assert wdir[:8, :8][skip[:8, :8] == 0].any()  # directions exist in the zero-luma-strength filter block
+        ps, pd = ctx.planes_alloc(cw, ch, 32, bd, 1), ctx.planes_alloc(cw, ch, 32, bd, 2)
+        ctx.planes_upload(ps, 0, chroma)
+        d_dir, d_pri, d_sec, d_skip = ctx.to_device(gdir), ctx.to_device(pri_uv), ctx.to_device(sec_uv), ctx.to_device(skip)
+        ctx.cdef_chroma_plane(ps, 0, pd, 1, xdec, ydec, d_dir, d_pri, d_sec, fbw, d_skip, damping)
+        got = ctx.planes_download(pd, 1)[32:32 + ch, 32:32 + cw]
+        want = oracle.cdef_plane_chroma(chroma, xdec, ydec, wdir, pri_uv, sec_uv, skip, damping, bd)
+        assert np.array_equal(got, want), (bd, xdec, ydec, trial)
+        assert not np.array_equal(got, chroma)
+        ctx.planes_free(ps); ctx.planes_free(pd)
+        for d in (d_dir, d_pri, d_sec, d_skip):
+            ctx.free(d)
+
+
+def test_chroma_full_size_4k_10bit_420(hip, oracle, ctx):
+    W, H, bd = 3840, 2160, 10
+    rng = np.random.default_rng(8)
+    src, _ = hip.synth.shifted_smooth_pair(W, H, 2, bd)
+    luma = np.clip(src.astype(np.int32) + rng.integers(-20, 21, (H, W)), 0, 1023).astype(np.uint16)
+    chroma = np.clip(src[::2, ::2].astype(np.int32) + rng.integers(-20, 21, (H // 2, W // 2)), 0, 1023).astype(np.uint16)
+    fbh, fbw = (H + 63) // 64, (W + 63) // 64
+    pri = np.full((fbh, fbw), 4, np.uint8); sec = np.full((fbh, fbw), 2, np.uint8)
+    skip = np.zeros((H // 8, W // 8), np.uint8)
+    _, gdir, _ = _run(hip, ctx, luma, pri, sec, skip, 6, bd)
+    ps, pd = ctx.planes_alloc(W // 2, H // 2, 32, bd, 1), ctx.planes_alloc(W // 2, H // 2, 32, bd, 1)
+    ctx.planes_upload(ps, 0, chroma)
+    d_dir, d_pri, d_sec, d_skip = ctx.to_device(gdir), ctx.to_device(pri), ctx.to_device(sec), ctx.to_device(skip)
+    ctx.cdef_chroma_plane(ps, 0, pd, 0, 1, 1, d_dir, d_pri, d_sec, fbw, d_skip, 6)
+    got = ctx.planes_download(pd, 0)[32:32 + H // 2, 32:32 + W // 2]
+    assert np.array_equal(got, oracle.cdef_plane_chroma(chroma, 1, 1, gdir, pri, sec, skip, 6, bd))
+    ctx.planes_free(ps); ctx.planes_free(pd)
+    for d in (d_dir, d_pri, d_sec, d_skip):
+        ctx.free(d)

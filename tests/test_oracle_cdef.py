@@ -52,3 +52,27 @@ def test_plane_filtering_is_bounded_and_local(oracle):
                 assert np.array_equal(out[blk], pix[blk])
     # with primary and secondary both on, the output is clamped to the range of the taps it read (cdef_block.c:186-188)
     assert out.max() <= pix.max() and out.min() >= pix.min()
+
+
+def test_chroma_identity_and_direction_reuse(oracle):
+    """Chroma driver: zero uv strength or skip = copy; directions exist for blocks of a zero-LUMA-strength filter block
+    when requested (the chroma planes need them, cdef.c:334-345); 4:2:2 / 4:4:0 direction conversion tables."""
+    rng = np.random.default_rng(2)
+    W, H = 128, 64
+    luma = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    zero = np.zeros((1, 2), np.uint8)
+    skip = np.zeros((H // 8, W // 8), np.uint8)
+    out, d, v = oracle.cdef_plane_luma(luma, zero, zero, skip, 6, 8)
+    assert np.array_equal(out, luma) and d.max() > 0
+    u = rng.integers(0, 256, (H // 2, W // 2)).astype(np.uint8)
+    assert np.array_equal(oracle.cdef_plane_chroma(u, 1, 1, d, zero, zero, skip, 6, 8), u)
+    allskip = np.ones_like(skip)
+    four, two = np.full((1, 2), 4, np.uint8), np.full((1, 2), 2, np.uint8)
+    assert np.array_equal(oracle.cdef_plane_chroma(u, 1, 1, d, four, two, allskip, 6, 8), u)
+    f = oracle.cdef_plane_chroma(u, 1, 1, d, four, two, skip, 6, 8)
+    assert not np.array_equal(f, u) and np.abs(f.astype(int) - u).max() <= 4 + 2 * 2  # bounded by the strengths
+    # 4:2:2 with every luma direction forced to 0 equals 4:2:2 filtering along converted direction 7 (conv422[0])
+    u422 = rng.integers(0, 256, (H, W // 2)).astype(np.uint8)
+    a = oracle.cdef_plane_chroma(u422, 1, 0, np.zeros_like(d), four, zero, skip, 6, 8)
+    taps = a.astype(int) - u422
+    assert np.abs(taps).max() <= 4 and np.abs(taps).max() > 0
