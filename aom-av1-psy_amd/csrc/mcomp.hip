@@ -50,23 +50,59 @@ template <typename T> __device__ __forceinline__ uint32_t sadw(uint32_t a, uint3
   else return __builtin_amdgcn_sad_u16(a, b, acc);
 }
 
+// Geometry of the 8-lanes-per-site SAD: row units of <= 16 bytes, lane l of a group owns units l, l + 8, ...
+template <typename T, int W, int H> struct G8 {
+  static constexpr int RB = W * (int)sizeof(T);
+  static constexpr int UB = RB < 16 ? RB : 16;
+  static constexpr int UE = UB / (int)sizeof(T);
+  static constexpr int UPR = RB / UB;
+  static constexpr int U = UPR * H;
+  static constexpr int PER_LANE = (U + 7) / 8;
+  // the lane's source units stay in registers across all the sites of a search when they fit (<= 32 VGPRs)
+  static constexpr bool KEEP = PER_LANE <= 8;
+  using L = typename MLoad<UB>::type;
+};
+
+template <typename T, int W, int H>
+__device__ __forceinline__ void group8_load_src(const T *sp, int sstride, int l, typename G8<T, W, H>::L (&s)[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1]) {
+  using G = G8<T, W, H>;
+  if constexpr (G::KEEP) {
+#pragma unroll
+    for (int k = 0; k < G::PER_LANE; ++k) {
+      const int u = min(l + 8 * k, G::U - 1);
+      const int row = u / G::UPR, col = (u % G::UPR) * G::UE;
+      s[k] = *reinterpret_cast<const typename G::L *>(sp + (int64_t)row * sstride + col);
+    }
+  }
+}
+
 // SAD of the W x H block at sp vs rp, computed by the 8 lanes of a group (l = lane & 7); all 8 get the sum.
 template <typename T, int W, int H>
-__device__ __forceinline__ uint32_t group8_sad(const T *sp, int sstride, const T *rp, int rstride, int l, bool active) {
-  constexpr int RB = W * (int)sizeof(T);
-  constexpr int UB = RB < 16 ? RB : 16;
-  constexpr int UE = UB / (int)sizeof(T);
-  constexpr int UPR = RB / UB;
-  constexpr int U = UPR * H;
-  using L = typename MLoad<UB>::type;
+__device__ __forceinline__ uint32_t group8_sad(const T *sp, int sstride, const T *rp, int rstride, int l, bool active,
+                                               const typename G8<T, W, H>::L (&s)[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1]) {
+  using G = G8<T, W, H>;
+  using L = typename G::L;
   uint32_t acc = 0;
   if (active) {
-    for (int u = l; u < U; u += 8) {
-      const int row = u / UPR, col = (u % UPR) * UE;
-      const L a = *reinterpret_cast<const L *>(sp + (int64_t)row * sstride + col);
-      const L b = *reinterpret_cast<const L *>(rp + (int64_t)row * rstride + col);
+    if constexpr (G::KEEP) {
 #pragma unroll
-      for (int i = 0; i < UB / 4; ++i) acc = sadw<T>(a.v[i], b.v[i], acc);
+      for (int k = 0; k < G::PER_LANE; ++k) {
+        const int u = l + 8 * k;
+        if (u < G::U) {
+          const int row = u / G::UPR, col = (u % G::UPR) * G::UE;
+          const L b = *reinterpret_cast<const L *>(rp + (int64_t)row * rstride + col);
+#pragma unroll
+          for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(s[k].v[i], b.v[i], acc);
+        }
+      }
+    } else {
+      for (int u = l; u < G::U; u += 8) {
+        const int row = u / G::UPR, col = (u % G::UPR) * G::UE;
+        const L a = *reinterpret_cast<const L *>(sp + (int64_t)row * sstride + col);
+        const L b = *reinterpret_cast<const L *>(rp + (int64_t)row * rstride + col);
+#pragma unroll
+        for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(a.v[i], b.v[i], acc);
+      }
     }
   }
   acc += __builtin_amdgcn_update_dpp(0u, acc, 0xB1, 0xf, 0xf, false);
@@ -140,6 +176,107 @@ __device__ __forceinline__ uint32_t wave_variance(const T *ap, int astride, int 
   return v >= 0 ? (uint32_t)v : 0;
 }
 
+// ---- 16 lanes per candidate: up to four independent candidates of one block are evaluated side by side -------------
+// Variance (SUBPEL = false) or bilinear sub-pixel variance of the W x H block at ap (per-GROUP pointer and phase) vs
+// the source block bp, by the 16 lanes of a group (j = lane & 15); every lane of the group returns the result.
+// Pixel units of 8 (4 for W = 4) per lane; the two Σ are reduced inside the DPP row (= the group) -- no LDS, no
+// cross-row traffic.  Semantics identical to wave_variance (aom_dsp/variance.c:56-73,91-163,342-561).
+template <typename T> __device__ __forceinline__ int px_of(const uint32_t *v, int i) {
+  if constexpr (sizeof(T) == 2) return (int)((v[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+  else return (int)((v[i >> 2] >> (8 * (i & 3))) & 0xffu);
+}
+__device__ __forceinline__ uint32_t row16_sum_u32(uint32_t v) {
+  v += __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x141, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x140, 0xf, 0xf, false);
+  return v;
+}
+__device__ __forceinline__ uint64_t row16_sum_u64(uint64_t v) {
+#define AOMHIP_STEP64(CTRL)                                                                      \
+  {                                                                                              \
+    const uint32_t lo = __builtin_amdgcn_update_dpp(0u, (uint32_t)v, CTRL, 0xf, 0xf, false);     \
+    const uint32_t hi = __builtin_amdgcn_update_dpp(0u, (uint32_t)(v >> 32), CTRL, 0xf, 0xf, false); \
+    v += ((uint64_t)hi << 32) | lo;                                                              \
+  }
+  AOMHIP_STEP64(0xB1) AOMHIP_STEP64(0x4E) AOMHIP_STEP64(0x141) AOMHIP_STEP64(0x140)
+#undef AOMHIP_STEP64
+  return v;
+}
+
+template <typename T, int W, int H, bool SUBPEL>
+__device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, int xoff, int yoff, const T *bp, int bstride,
+                                                     bool a_minus_b, int bit_depth, int j, bool active,
+                                                     uint32_t *sse_out) {
+  constexpr int UE = W >= 8 ? 8 : 4;
+  constexpr int UPR = W / UE;
+  constexpr int U = UPR * H;
+  constexpr int UB = UE * (int)sizeof(T);
+  using L = typename MLoad<UB>::type;
+  constexpr uint8_t kBil[8][2] = { { 128, 0 }, { 112, 16 }, { 96, 32 }, { 80, 48 },
+                                   { 64, 64 }, { 48, 80 },  { 32, 96 }, { 16, 112 } };  // aom_filter.h:43-50
+  const int fx0 = kBil[xoff & 7][0], fx1 = kBil[xoff & 7][1], fy0 = kBil[yoff & 7][0], fy1 = kBil[yoff & 7][1];
+  int32_t sum = 0;   // |Σd| <= 4095 * W * H < 2^31 for every block size
+  uint64_t sse = 0;
+  if (active) {
+    for (int u = j; u < U; u += 16) {
+      const int row = u / UPR, col = (u % UPR) * UE;
+      const T *a0 = ap + (int64_t)row * astride + col;
+      const L bv = *reinterpret_cast<const L *>(bp + (int64_t)row * bstride + col);
+      const L r0 = *reinterpret_cast<const L *>(a0);
+      int us = 0;
+      uint32_t uq = 0;  // 8 * 4095^2 < 2^32
+      if constexpr (SUBPEL) {
+        const L r1 = *reinterpret_cast<const L *>(a0 + astride);
+        const int e0 = a0[UE], e1 = a0[astride + UE];
+#pragma unroll
+        for (int i = 0; i < UE; ++i) {
+          const int p00 = px_of<T>(r0.v, i), p01 = i + 1 < UE ? px_of<T>(r0.v, i + 1 < UE ? i + 1 : i) : e0;
+          const int p10 = px_of<T>(r1.v, i), p11 = i + 1 < UE ? px_of<T>(r1.v, i + 1 < UE ? i + 1 : i) : e1;
+          const int h0 = (p00 * fx0 + p01 * fx1 + 64) >> 7;
+          const int h1 = (p10 * fx0 + p11 * fx1 + 64) >> 7;
+          int av = (h0 * fy0 + h1 * fy1 + 64) >> 7;
+          av &= (sizeof(T) == 1) ? 0xFF : 0xFFFF;
+          const int bvp = px_of<T>(bv.v, i);
+          const int d = a_minus_b ? av - bvp : bvp - av;
+          us += d;
+          uq += (uint32_t)(d * d);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < UE; ++i) {
+          const int av = px_of<T>(r0.v, i), bvp = px_of<T>(bv.v, i);
+          const int d = a_minus_b ? av - bvp : bvp - av;
+          us += d;
+          uq += (uint32_t)(d * d);
+        }
+      }
+      sum += us;
+      sse += uq;
+    }
+  }
+  const int64_t tsum = (int64_t)(int32_t)row16_sum_u32((uint32_t)sum);
+  const uint64_t tsse = row16_sum_u64(sse);
+  int32_t sfin;
+  uint32_t q;
+  if (bit_depth == 10) {
+    q = (uint32_t)((tsse + 8) >> 4);
+    sfin = (int32_t)((tsum + 2) >> 2);
+  } else if (bit_depth == 12) {
+    q = (uint32_t)((tsse + 128) >> 8);
+    sfin = (int32_t)((tsum + 8) >> 4);
+  } else {
+    q = (uint32_t)tsse;
+    sfin = (int32_t)tsum;
+  }
+  *sse_out = q;
+  constexpr int LOG2N = __builtin_ctz(W * H);
+  const int64_t sq = ((int64_t)sfin * sfin) >> LOG2N;
+  if (bit_depth == 8) return q - (uint32_t)sq;
+  const int64_t v = (int64_t)q - sq;
+  return v >= 0 ? (uint32_t)v : 0;
+}
+
 constexpr int kSearchThreads = 256;  // 4 blocks (wavefronts) per workgroup
 
 template <typename T, int W, int H>
@@ -159,6 +296,9 @@ __global__ __launch_bounds__(kSearchThreads) void fullpel_diamond_kernel(
   const int dr = (g == 0 || g == 4 || g == 6) ? -1 : (g == 1 || g == 5 || g == 7) ? 1 : 0;   // site order of
   const int dc = (g == 2 || g == 4 || g == 7) ? -1 : (g == 3 || g == 5 || g == 6) ? 1 : 0;   // mcomp.c:366-370
 
+  typename G8<T, W, H>::L srcu[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1];
+  group8_load_src<T, W, H>(sp, src.stride, l, srcu);
+
   // radius of stage k (av1_init_dsmotion_compensation): DIAMOND 2^k, CLAMPED_DIAMOND min(2^k, 256); 11 stages
   auto radius = [level](int k) { const int r = 1 << k; return (level > 0 && r > 256) ? 256 : r; };
 
@@ -167,7 +307,8 @@ __global__ __launch_bounds__(kSearchThreads) void fullpel_diamond_kernel(
     int col = min(max((int)b.start_col, (int)b.col_min), (int)b.col_max);
     const int tot_steps = 11 - search_step;
     *num00 = 0;
-    uint32_t s0 = group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)row * ref.stride + col, ref.stride, l, true) >> shift;
+    // (the centre is one position: group 0 evaluates it, the other seven groups would only repeat its loads)
+    uint32_t s0 = group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)row * ref.stride + col, ref.stride, l, g == 0, srcu) >> shift;
     s0 = __shfl(s0, 0, 64);
     uint32_t bestsad = s0 + (uint32_t)cc.sad_cost(row, col);
     int is_off_center = 0;
@@ -178,7 +319,7 @@ __global__ __launch_bounds__(kSearchThreads) void fullpel_diamond_kernel(
       const int srow = row + dr * r, scol = col + dc * r;
       const bool inr = scol >= b.col_min && scol <= b.col_max && srow >= b.row_min && srow <= b.row_max;
       const uint32_t mine =
-          group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)srow * ref.stride + scol, ref.stride, l, inr) >> shift;
+          group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)srow * ref.stride + scol, ref.stride, l, inr, srcu) >> shift;
       int best_site = 0;
 #pragma unroll
       for (int idx = 1; idx <= 8; ++idx) {
@@ -265,51 +406,77 @@ __global__ __launch_bounds__(kSearchThreads) void subpel_bilinear_kernel(
   const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)b.by * ref.stride + b.bx;
   const CostCtx cc{ cost_type, b.ref_row, b.ref_col };
 
+  const int grp = lane >> 4, j = lane & 15;
   uint32_t besterr, sse1;
   int distortion, best_row = b.start_row, best_col = b.start_col;
   {  // setup_center_error: vf(ref at the full-pel part, src): diff = ref - src
     const int fr = b.start_row >> 3, fc = b.start_col >> 3;
-    const uint32_t v = wave_variance<T, W, H, false>(rbase + (int64_t)fr * ref.stride + fc, ref.stride, 0, 0, sp,
-                                                     src.stride, /*a_minus_b=*/true, bit_depth, lane, &sse1);
+    uint32_t q;
+    uint32_t v = group16_variance<T, W, H, false>(rbase + (int64_t)fr * ref.stride + fc, ref.stride, 0, 0, sp, src.stride,
+                                                  /*a_minus_b=*/true, bit_depth, j, grp == 0, &q);
+    v = __shfl(v, 0, 64);
+    sse1 = __shfl(q, 0, 64);
     distortion = (int)v;
     besterr = v + (uint32_t)cc.var_cost(b.start_row, b.start_col);
   }
-  auto check = [&](int mrow, int mcol) -> uint32_t {  // check_better_fast (mcomp.c:2433-2461)
-    if (mcol < b.col_min || mcol > b.col_max || mrow < b.row_min || mrow > b.row_max) return (uint32_t)INT_MAX;
-    uint32_t sse;
-    const int thismse = (int)wave_variance<T, W, H, true>(rbase + (int64_t)(mrow >> 3) * ref.stride + (mcol >> 3),
-                                                          ref.stride, mcol & 7, mrow & 7, sp, src.stride, true,
-                                                          bit_depth, lane, &sse);
-    const uint32_t cost = (uint32_t)cc.var_cost(mrow, mcol) + (uint32_t)thismse;
-    if (cost < besterr) {
-      besterr = cost;
-      best_row = mrow;
-      best_col = mcol;
-      distortion = thismse;
-      sse1 = sse;
+  // check_better_fast (mcomp.c:2433-2461) for up to four candidates whose POSITIONS do not depend on each other:
+  // group g evaluates candidate g (one aom_sub_pixel_varianceWxH each), then every lane replays the reference's
+  // sequential `if (cost < besterr)` updates in candidate order, so the outcome is that of the scalar sequence.
+  auto check_n = [&](int n, const int (&mrow)[4], const int (&mcol)[4], uint32_t (&cost)[4]) {
+    int my_row = mrow[0], my_col = mcol[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      my_row = grp == k ? mrow[k] : my_row;
+      my_col = grp == k ? mcol[k] : my_col;
     }
-    return cost;
+    const bool inb = my_col >= b.col_min && my_col <= b.col_max && my_row >= b.row_min && my_row <= b.row_max;
+    uint32_t q;
+    const uint32_t v = group16_variance<T, W, H, true>(rbase + (int64_t)(my_row >> 3) * ref.stride + (my_col >> 3),
+                                                       ref.stride, my_col & 7, my_row & 7, sp, src.stride, true, bit_depth,
+                                                       j, inb && grp < n, &q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      cost[k] = (uint32_t)INT_MAX;
+      if (k < n) {
+        const uint32_t vk = __shfl(v, 16 * k, 64), qk = __shfl(q, 16 * k, 64);
+        const bool in_k = mcol[k] >= b.col_min && mcol[k] <= b.col_max && mrow[k] >= b.row_min && mrow[k] <= b.row_max;
+        if (in_k) {
+          const int thismse = (int)vk;
+          cost[k] = (uint32_t)cc.var_cost(mrow[k], mcol[k]) + (uint32_t)thismse;
+          if (cost[k] < besterr) {
+            besterr = cost[k];
+            best_row = mrow[k];
+            best_col = mcol[k];
+            distortion = thismse;
+            sse1 = qk;
+          }
+        }
+      }
+    }
   };
   auto two_level = [&](int trow, int tcol, int hstep) {  // two_level_checks_fast (mcomp.c:2503-2624)
-    const uint32_t left = check(trow, tcol - hstep);
-    const uint32_t right = check(trow, tcol + hstep);
-    const uint32_t up = check(trow - hstep, tcol);
-    const uint32_t down = check(trow + hstep, tcol);
+    uint32_t c[4];
+    {
+      const int r4[4] = { trow, trow, trow - hstep, trow + hstep }, c4[4] = { tcol - hstep, tcol + hstep, tcol, tcol };
+      check_n(4, r4, c4, c);  // left, right, up, down
+    }
+    const uint32_t left = c[0], right = c[1], up = c[2], down = c[3];
     const int drow = up <= down ? -hstep : hstep, dcol = left <= right ? -hstep : hstep;
-    check(trow + drow, tcol + dcol);
+    {
+      const int r1[4] = { trow + drow, 0, 0, 0 }, c1[4] = { tcol + dcol, 0, 0, 0 };
+      check_n(1, r1, c1, c);
+    }
     if (iters_per_step <= 1) return;
     const int br = best_row, bc = best_col;
     if (trow != br && tcol != bc) {
-      check(br, bc + dcol);
-      check(br + drow, bc);
+      const int r2[4] = { br, br + drow, 0, 0 }, c2[4] = { bc + dcol, bc, 0, 0 };
+      check_n(2, r2, c2, c);
     } else if (trow == br && tcol != bc) {
-      check(br + hstep, bc + dcol);
-      check(br - hstep, bc + dcol);
-      check(br - drow, bc);
+      const int r3[4] = { br + hstep, br - hstep, br - drow, 0 }, c3[4] = { bc + dcol, bc + dcol, bc, 0 };
+      check_n(3, r3, c3, c);
     } else if (trow != br && tcol == bc) {
-      check(br + drow, bc + hstep);
-      check(br + drow, bc - hstep);
-      check(br, bc - dcol);
+      const int r3[4] = { br + drow, br + drow, br, 0 }, c3[4] = { bc + hstep, bc - hstep, bc - dcol, 0 };
+      check_n(3, r3, c3, c);
     }
   };
   int hstep = 4;          // INIT_SUBPEL_STEP_SIZE
