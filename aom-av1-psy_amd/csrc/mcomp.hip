@@ -280,7 +280,7 @@ __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, i
 constexpr int kSearchThreads = 256;  // 4 blocks (wavefronts) per workgroup
 
 template <typename T, int W, int H>
-__global__ __launch_bounds__(kSearchThreads) void fullpel_diamond_kernel(
+__global__ __launch_bounds__(kSearchThreads, 5) void fullpel_diamond_kernel(
     PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
     int level, int step_param, int cost_type, int bit_depth, int16_t *__restrict__ out_mv,
     int32_t *__restrict__ out_cost) {
@@ -365,26 +365,44 @@ __global__ __launch_bounds__(kSearchThreads) void fullpel_diamond_kernel(
     return (int)v + cc.var_cost(row * 8, col * 8);
   };
 
-  // full_pixel_diamond (mcomp.c:1421-1470)
-  int n00, num00 = 0, br, bc;
-  int bestsme = run_diamond(step_param, &n00, &br, &bc);
-  if (bestsme < INT_MAX) bestsme = var_cost_at(br, bc);
+  // full_pixel_diamond (mcomp.c:1421-1470): the first search at step_param, then restarts at step_param + n that are
+  // skipped while the previous search reported it would have stayed on the centre (num00).  One loop, one inlined
+  // copy of the search body (two copies cost 30 VGPRs = one wave per SIMD of occupancy).
+  int n = 0, num00 = 0, br = 0, bc = 0, bestsme = INT_MAX;
   const int further_steps = 11 - 1 - step_param;
-  int nn = n00;
-  while (nn < further_steps) {
-    ++nn;
-    if (num00) {
-      num00--;
-    } else {
-      int tr, tc;
-      int thissme = run_diamond(step_param + nn, &num00, &tr, &tc);
-      if (thissme < INT_MAX) thissme = var_cost_at(tr, tc);
-      if (thissme < bestsme) {
-        bestsme = thissme;
-        br = tr;
-        bc = tc;
+  bool first = true;
+  for (;;) {
+    bool run_it = true;
+    int sstep = step_param;
+    if (!first) {
+      if (n >= further_steps) break;
+      ++n;
+      if (num00) {
+        --num00;
+        run_it = false;
+      } else {
+        sstep = step_param + n;
       }
     }
+    if (run_it) {
+      int t00, tr, tc;
+      int sme = run_diamond(sstep, &t00, &tr, &tc);
+      if (sme < INT_MAX) sme = var_cost_at(tr, tc);
+      if (first) {
+        bestsme = sme;
+        br = tr;
+        bc = tc;
+        n = t00;
+      } else {
+        num00 = t00;
+        if (sme < bestsme) {
+          bestsme = sme;
+          br = tr;
+          bc = tc;
+        }
+      }
+    }
+    first = false;
   }
   if (lane == 0) {
     out_mv[2 * bi] = (int16_t)br;

@@ -115,7 +115,13 @@ class SadModeA:
         # 8-bit planes (512 x 256-byte window + row padding = 136 KB of LDS), 128x128 for 10/12-bit (256 x 512 bytes).
         # It is the path the step uses (2.1x / 1.6x the direct kernels); AOMHIP_SAD_PATH=direct|sb overrides.
         self.path = os.environ.get("AOMHIP_SAD_PATH", "sb")
-        self.cell = (384, 128) if bd == 8 else (128, 128)
+        # Cells are anchored at x = 0, tile columns start at multiples of their width: a cell width that divides the
+        # column width keeps every cell inside one rank's column (a straddling cell would stage its whole window for
+        # a fraction of its blocks).  Tuned width when it divides, else the largest divisor that fits LDS.
+        tuned, widest = (384, 384) if bd == 8 else (128, 176)
+        col_w = pkg.partition.column_of_rank(W, world, 0)[1] - pkg.partition.column_of_rank(W, world, 0)[0]
+        cw = tuned if col_w % tuned == 0 else max([d for d in range(16, widest + 1, 16) if col_w % d == 0] or [tuned])
+        self.cell = (cw, 128)
         self.d_sb = None
         if n and self.path == "sb":
             perm, off = synth.bucket_order(base_c["sx"], base_c["sy"], W, H, *self.cell)
