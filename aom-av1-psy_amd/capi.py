@@ -92,6 +92,7 @@ _protos = {
     "aomhip_cdef_chroma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i]),
     "aomhip_fullpel_diamond_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_subpel_bilinear_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "aomhip_mesh_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, C.POINTER(C.c_int), _i, _vp, _i, _vp, _vp]),
     "aomhip_bind_variance_vtable": (C.c_int, [_vp, _i]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
@@ -228,6 +229,11 @@ class Context:
     def inv_txfm_add_batch(self, d_dqcoeff, tx_size, d_blocks, n_blocks, grid_cols, tx_type, d_eob, dst, frame):
         check(lib.aomhip_inv_txfm_add_batch(self.h, d_dqcoeff, tx_size, d_blocks, n_blocks, grid_cols, tx_type, d_eob,
                                             C.byref(dst), frame), "aomhip_inv_txfm_add_batch")
+
+    def mesh_search_batch(self, src, ref, frame, bw, bh, cost_type, patterns, fine, d_blocks, n_blocks, d_mv, d_cost):
+        pat = (C.c_int * 8)(*[int(v) for pair in patterns for v in pair])
+        check(lib.aomhip_mesh_search_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, cost_type, pat, fine, d_blocks,
+                                           n_blocks, d_mv, d_cost), "aomhip_mesh_search_batch")
 
     def cdef_chroma_plane(self, src, src_frame, dst, dst_frame, xdec, ydec, d_luma_dir, d_pri, d_sec, fb_stride, d_skip,
                           damping):

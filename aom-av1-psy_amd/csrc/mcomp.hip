@@ -518,6 +518,201 @@ __global__ __launch_bounds__(kSearchThreads) void subpel_bilinear_kernel(
   }
 }
 
+// ---- exhaustive mesh search: full_pixel_exhaustive (mcomp.c:1547-1617) over exhaustive_mesh_search (:1474-1543) ----
+// One 256-lane workgroup per block.  A pass visits a (2*range/step + 1)^2 mesh around the current best MV; every
+// candidate's SAD + MV cost is independent of the others, and the reference's running update (update_mvs_and_sad,
+// :839-858: skip on this_sad >= best, else add the cost and take it on strict <) is, because the cost is never
+// negative, exactly "arg-min of sad + cost, first in raster order wins ties, the start position wins ties against
+// everything".  So: the pass's reference window (all rows and columns any candidate touches) and the source block
+// are staged in LDS, lane t evaluates candidates t, t + 256, ... entirely out of LDS (source rows are broadcast
+// reads, neighbouring lanes read neighbouring columns of the same window rows: conflict-free), and the workgroup
+// reduces the 64-bit keys (total << 32 | raster index + 1).  The step-1 column rule of the reference is kept: columns
+// are taken four at a time and the tail group `for (i = 0; i < end_col - c; ++i)` never visits column end_col.
+// A pass whose window does not fit the LDS budget (range grown to 5/4 |start mv|) reads the reference from global
+// memory instead -- same arithmetic.
+// LDS reads: a ds_read_b128 whose address is not 16-byte aligned runs at 1/12 of the aligned rate on gfx950
+// (tools/lds_unaligned_probe.hip: 0.61 vs 7.4 T lane-reads/s), so window rows are read as aligned dwords and
+// realigned with v_alignbyte; the packed source rows are 16-byte aligned.
+constexpr int kMeshThreads = 256;
+
+template <typename T, int W, int H, bool FROM_LDS>
+__device__ __forceinline__ uint32_t mesh_sad(const uint32_t *lds_src, const char *win, int64_t pitch) {
+  constexpr int RB = W * (int)sizeof(T);
+  constexpr int UB = RB < 16 ? RB : 16;
+  constexpr int UPR = RB / UB;
+  using L = typename MLoad<UB>::type;
+  uint32_t acc = 0;
+#pragma unroll(H <= 16 ? H : 4)
+  for (int r = 0; r < H; ++r) {
+#pragma unroll
+    for (int u = 0; u < UPR; ++u) {
+      L a, b;
+      if constexpr (UB == 16) {  // packed source rows are 16-byte aligned in LDS: one ds_read_b128
+        const uint4 t = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(lds_src) + r * RB + u * UB);
+        a.v[0] = t.x; a.v[1] = t.y; a.v[2] = t.z; a.v[3] = t.w;
+      } else {
+        a = *reinterpret_cast<const L *>(reinterpret_cast<const char *>(lds_src) + r * RB + u * UB);
+      }
+      if constexpr (FROM_LDS) {
+        const char *p = win + r * pitch + u * UB;
+        const unsigned sh = (unsigned)(uintptr_t)p & 3u;
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh);
+        uint32_t d[UB / 4 + 1];
+#pragma unroll
+        for (int i = 0; i <= UB / 4; ++i) d[i] = q[i];
+#pragma unroll
+        for (int i = 0; i < UB / 4; ++i) b.v[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+      } else {
+        b = *reinterpret_cast<const L *>(win + r * pitch + u * UB);
+      }
+#pragma unroll
+      for (int i = 0; i < UB / 4; ++i) acc = sadw<T>(a.v[i], b.v[i], acc);
+    }
+  }
+  return acc;
+}
+
+template <typename T, int W, int H>
+__global__ __launch_bounds__(kMeshThreads) void mesh_search_kernel(
+    PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
+    int cost_type, int bit_depth, int4 pat_range, int4 pat_interval, int fine, int lds_window_bytes,
+    int16_t *__restrict__ out_mv, int32_t *__restrict__ out_cost) {
+  extern __shared__ uint32_t mesh_lds[];
+  constexpr int ES = (int)sizeof(T);
+  constexpr int kSrcBytes = W * H * ES;
+  __shared__ unsigned long long wg_key[kMeshThreads / 64];
+  uint32_t *lds_src = mesh_lds;
+  char *lds_win = reinterpret_cast<char *>(mesh_lds) + ((kSrcBytes + 15) & ~15);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bi = blockIdx.x;
+  if (bi >= n_blocks) return;
+  const aomhip_search_block b = blocks[bi];
+  const T *sp = src.origin + (int64_t)frame * src.frame_stride + (int64_t)b.by * src.stride + b.bx;
+  const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)b.by * ref.stride + b.bx;
+  const CostCtx cc{ cost_type, b.ref_row, b.ref_col };
+  const int shift = bit_depth == 10 ? 2 : bit_depth == 12 ? 4 : 0;
+
+  // source block -> LDS, packed rows
+  for (int q = tid; q < kSrcBytes / 4; q += kMeshThreads) {
+    const int byte = q * 4, r = byte / (W * ES), c = byte % (W * ES);
+    lds_src[q] = reinterpret_cast<const MU32 *>(reinterpret_cast<const char *>(sp + (int64_t)r * src.stride) + c)->v[0];
+  }
+
+  int br = b.start_row, bc = b.start_col;
+  int bestsme = INT_MAX;
+  const int ranges[4] = { pat_range.x, pat_range.y, pat_range.z, pat_range.w };
+  const int intervals[4] = { pat_interval.x, pat_interval.y, pat_interval.z, pat_interval.w };
+  int range = ranges[0], interval = intervals[0];
+  const bool legal = !(range < 7 || range > 256 || interval < 1 || interval > range);
+  if (legal) {
+    const int div = range / interval;
+    const int m = max(iabsm(br), iabsm(bc));
+    range = min(max(range, (5 * m) / 4), 256);
+    interval = max(interval, range / div);
+    if (fine) interval = min(interval, 4);
+    const bool progressive = interval > 1 && range > 7;
+    for (int pass = 0; pass < 4; ++pass) {
+      if (pass > 0) {
+        if (!progressive) break;
+        range = ranges[pass];
+        interval = intervals[pass];
+      }
+      // ---- one exhaustive_mesh_search(start = (br, bc), range, interval)
+      const int srow = min(max(br, (int)b.row_min), (int)b.row_max), scol = min(max(bc, (int)b.col_min), (int)b.col_max);
+      const int start_row = max(-range, b.row_min - srow), start_col = max(-range, b.col_min - scol);
+      const int end_row = min(range, b.row_max - srow), end_col = min(range, b.col_max - scol);
+      const int step = interval;
+      const int nr = end_row >= start_row ? (end_row - start_row) / step + 1 : 0;
+      int nc;
+      if (step > 1) {
+        nc = end_col >= start_col ? (end_col - start_col) / step + 1 : 0;
+      } else {
+        const int span = end_col - start_col + 1;  // may be <= 0
+        const int g4 = span > 0 ? span / 4 : 0, rem = span > 0 ? span - 4 * g4 : 0;
+        nc = 4 * g4 + (rem > 0 ? rem - 1 : 0);
+      }
+      const int n_cand = nr * nc;
+      // window: rows srow + start_row .. srow + end_row + H - 1, cols scol + start_col .. scol + end_col + W - 1
+      const int wrows = (end_row - start_row) + H, wcols = (end_col - start_col) + W;
+      const int wpitch = ((wcols * ES + 15) & ~15) + 16;
+      const bool fits = n_cand > 0 && wrows > 0 && (int64_t)wrows * wpitch + 16 <= lds_window_bytes;
+      const T *worg = rbase + (int64_t)(srow + start_row) * ref.stride + (scol + start_col);
+      __syncthreads();  // previous pass done with the window (and the source block is in place)
+      if (fits) {
+        const int cpr = wpitch / 16 - 1;  // chunks that carry pixels (the tail chunk may over-read <= 15 bytes: in-row)
+        const int total = wrows * cpr;
+        for (int q = tid; q < total; q += kMeshThreads) {
+          const int r = q / cpr, c = q - r * cpr;
+          const MU128 v = *reinterpret_cast<const MU128 *>(reinterpret_cast<const char *>(worg + (int64_t)r * ref.stride) + c * 16);
+          *reinterpret_cast<uint4 *>(lds_win + r * wpitch + c * 16) = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+        }
+      }
+      __syncthreads();
+      // start position (clamped start): best so far
+      unsigned long long key;
+      {
+        uint32_t s0;
+        if (fits)
+          s0 = mesh_sad<T, W, H, true>(lds_src, lds_win + (-start_row) * wpitch + (-start_col) * ES, wpitch);
+        else
+          s0 = mesh_sad<T, W, H, false>(lds_src, reinterpret_cast<const char *>(rbase + (int64_t)srow * ref.stride + scol),
+                                        (int64_t)ref.stride * ES);
+        const uint32_t t0 = (s0 >> shift) + (uint32_t)cc.sad_cost(srow, scol);
+        key = (unsigned long long)t0 << 32;
+      }
+      for (int idx = tid; idx < n_cand; idx += kMeshThreads) {
+        const int ir = idx / nc, ic = idx - ir * nc;
+        const int r = start_row + ir * step, c = start_col + (step > 1 ? ic * step : ic);
+        uint32_t sad;
+        if (fits)
+          sad = mesh_sad<T, W, H, true>(lds_src, lds_win + (r - start_row) * wpitch + (c - start_col) * ES, wpitch);
+        else
+          sad = mesh_sad<T, W, H, false>(lds_src,
+                                         reinterpret_cast<const char *>(rbase + (int64_t)(srow + r) * ref.stride + scol + c),
+                                         (int64_t)ref.stride * ES);
+        const uint32_t tot = (sad >> shift) + (uint32_t)cc.sad_cost(srow + r, scol + c);
+        const unsigned long long k = ((unsigned long long)tot << 32) | (uint32_t)(idx + 1);
+        key = k < key ? k : key;
+      }
+      // workgroup arg-min
+#pragma unroll
+      for (int msk = 1; msk < 64; msk <<= 1) {
+        const unsigned long long o = __shfl_xor(key, msk, 64);
+        key = o < key ? o : key;
+      }
+      if (lane == 0) wg_key[wave] = key;
+      __syncthreads();
+      key = wg_key[0];
+#pragma unroll
+      for (int w2 = 1; w2 < kMeshThreads / 64; ++w2) key = wg_key[w2] < key ? wg_key[w2] : key;
+      const uint32_t widx = (uint32_t)key;
+      bestsme = (int)(uint32_t)(key >> 32);
+      if (widx == 0) {
+        br = srow;
+        bc = scol;
+      } else {
+        const int ir = (int)(widx - 1) / nc, ic = (int)(widx - 1) - ir * nc;
+        br = srow + start_row + ir * step;
+        bc = scol + start_col + (step > 1 ? ic * step : ic);
+      }
+      if (pass > 0 && interval == 1) break;
+      if (pass == 0 && !progressive) break;
+    }
+    // get_mvpred_var_cost at the winner (wave 0; the others are done)
+    if (wave == 0 && bestsme < INT_MAX) {
+      uint32_t sse;
+      const uint32_t v = wave_variance<T, W, H, false>(rbase + (int64_t)br * ref.stride + bc, ref.stride, 0, 0, sp, src.stride,
+                                                       /*a_minus_b=*/false, bit_depth, lane, &sse);
+      bestsme = (int)v + cc.var_cost(br * 8, bc * 8);
+    }
+  }
+  if (tid == 0) {
+    out_mv[2 * bi] = (int16_t)br;
+    out_mv[2 * bi + 1] = (int16_t)bc;
+    out_cost[bi] = bestsme;
+  }
+}
+
 #define AOMHIP_FOR_BLOCK_SIZES(X)                                                                                \
   X(4, 4) X(4, 8) X(8, 4) X(8, 8) X(8, 16) X(16, 8) X(16, 16) X(16, 32) X(32, 16) X(32, 32) X(32, 64) X(64, 32) \
   X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(4, 16) X(16, 4) X(8, 32) X(32, 8) X(16, 64) X(64, 16)
@@ -601,6 +796,53 @@ int aomhip_subpel_bilinear_batch(aomhip_ctx *ctx, const aomhip_planes *src, cons
   }
   AOMHIP_FOR_BLOCK_SIZES(X)
 #undef X
+  return AOMHIP_ERR_INVALID;
+}
+
+int aomhip_mesh_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                             int mv_cost_type, const int mesh_patterns[8], int fine_search_interval,
+                             const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
+                             int32_t *d_best_cost) {
+  int rc = check_common(ctx, src, ref, frame, bw, bh, d_blocks, n_blocks, mv_cost_type);
+  if (rc != AOMHIP_OK) return rc;
+  if (!d_best_mv || !d_best_cost || !mesh_patterns) {
+    set_error("aomhip_mesh_search_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  const int es = src->bit_depth == 8 ? 1 : 2;
+  // LDS: the source block + the first pass's nominal window, capped at what one CU has
+  const int r0 = mesh_patterns[0] < 7 ? 7 : mesh_patterns[0] > 256 ? 256 : mesh_patterns[0];
+  const int64_t pitch = (((2 * r0 + bw) * es + 15) & ~15) + 16;
+  int64_t want = pitch * (2 * r0 + bh) + 16;
+  const int64_t src_bytes = ((int64_t)bw * bh * es + 15) & ~15;
+  const int64_t cap = 150 * 1024 - src_bytes;
+  if (want > cap) want = cap;
+  if (want < 4096) want = 4096;
+  const size_t lds = (size_t)(src_bytes + want);
+  const int4 pr = make_int4(mesh_patterns[0], mesh_patterns[2], mesh_patterns[4], mesh_patterns[6]);
+  const int4 pi = make_int4(mesh_patterns[1], mesh_patterns[3], mesh_patterns[5], mesh_patterns[7]);
+  const dim3 grid(n_blocks), block(kMeshThreads);
+#define X(W, H)                                                                                                       \
+  if (bw == W && bh == H) {                                                                                           \
+    if (src->bit_depth == 8) {                                                                                        \
+      auto k = mesh_search_kernel<uint8_t, W, H>;                                                                     \
+      if (lds > 64 * 1024) AOMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL(k, grid, block, lds, ctx->stream, view_of<uint8_t>(*src), view_of<uint8_t>(*ref), frame, d_blocks, \
+                         n_blocks, mv_cost_type, 8, pr, pi, fine_search_interval, (int)want, d_best_mv, d_best_cost);  \
+    } else {                                                                                                          \
+      auto k = mesh_search_kernel<uint16_t, W, H>;                                                                    \
+      if (lds > 64 * 1024) AOMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL(k, grid, block, lds, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame,    \
+                         d_blocks, n_blocks, mv_cost_type, src->bit_depth, pr, pi, fine_search_interval, (int)want,   \
+                         d_best_mv, d_best_cost);                                                                     \
+    }                                                                                                                 \
+    AOMHIP_LAUNCH_CHECK();                                                                                            \
+    return AOMHIP_OK;                                                                                                 \
+  }
+  AOMHIP_FOR_BLOCK_SIZES(X)
+#undef X
+  set_error("unsupported block size %dx%d", bw, bh);
   return AOMHIP_ERR_INVALID;
 }
 

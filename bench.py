@@ -367,6 +367,15 @@ class SearchPipeline:
         self.d_smv, self.d_err, self.d_dist, self.d_sse = (ctx.malloc(max(16, n * 4)) for _ in range(4))
         self.frame = 0
 
+    def free(self):
+        c = self.ctx
+        c.planes_free(self.src)
+        if self.ref_t is None:
+            c.planes_free(self.ref)
+        for d in (self.d_blocks, self.d_sub, self.d_mv, self.d_cost, self.d_smv, self.d_err, self.d_dist, self.d_sse):
+            if d:
+                c.free(d)
+
     def step(self):
         """one frame pair: [exchange] -> full-pel -> sub-pel (sub-pel start MVs are built on the host from the
         full-pel result of the PREVIOUS visit of this ring slot; the kernels' work is what is timed)."""
@@ -492,6 +501,40 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
             "config": {"frame": "3840x2160 10-bit luma", "stages": "fullpel diamond + subpel bilinear (16x16) -> fullpel pred "
                        "-> subtract+fwd_txfm2d_16x16+quantize_b q100 -> inv_txfm_add -> deblock (8x8 edges, level 32) -> "
                        "CDEF (pri 4, sec 2, damping 6)", "gpus": 1}}
+
+
+def run_mesh(pkg, ctx, orc, steps, warmup):
+    """SURVEY 8(d) Mode B (informational) through the reference's own exhaustive search: full_pixel_exhaustive
+    (mcomp.c:1547-1617) for every 16x16 block of a 4K 10-bit frame pair, (a) one dense pass range 16 / interval 1
+    (33 rows x 32 columns + the start position = 1057 SADs per block: the reference's four-at-a-time column rule
+    leaves column +16 out) and (b) the speed-0 good-quality pattern {64,8},{28,4},{15,1},{7,1}."""
+    sp = SearchPipeline(pkg, ctx, None, 0, 1, frames=2)
+    n = sp.n
+    out = {"workload": "mesh_search_4k_10bit", "blocks_per_frame": n}
+    for name, pat, cands in (("dense_range16", [(16, 1), (16, 1), (0, 0), (0, 0)], 1057),
+                             ("good_quality_speed0", [(64, 8), (28, 4), (15, 1), (7, 1)], 17 * 17 + 15 * 15 + 31 * 28 + 15 * 12 + 4)):
+        def frame(f=0):
+            ctx.mesh_search_batch(sp.src, sp.ref, f, 16, 16, pkg.capi.MV_COST_L1_HDRES, pat, 0, sp.d_blocks, n, sp.d_mv, sp.d_cost)
+        for _ in range(warmup):
+            frame()
+        ctx.sync()
+        ctx.timer_begin()
+        for k in range(steps):
+            frame(k % sp.F)
+        ms = ctx.timer_end() / steps
+        out[name] = {"ms_per_frame": ms, "frames_per_s": 1e3 / ms, "sad_candidates_per_s": n * cands / ms * 1e3,
+                     "candidates_per_block": cands}
+    # exact check of a sample of the last launch against the oracle
+    f = (steps - 1) % sp.F
+    idx = np.arange(0, n, max(1, n // 200))
+    mv = ctx.from_device(sp.d_mv, (n, 2), np.int16)[idx]
+    s_, r_ = pkg.synth.shifted_smooth_pair(sp.W, sp.H, f, sp.BD, shift=(3 + f % 3, -2 + f % 2), frac8=(f % 8, (3 * f) % 8))
+    sb, rb = orc.extend_plane(s_, sp.BORDER, sp.src.stride), orc.extend_plane(r_, sp.BORDER, sp.ref.stride)
+    wmv, _ = orc.mesh_search_batch(sb, rb, sp.BORDER, 16, 16, sp.h_blocks[idx], [(64, 8), (28, 4), (15, 1), (7, 1)], 0, 3, sp.BD, threads=8)
+    out["parity_sample"] = bool(np.array_equal(mv, wmv))
+    out["value"], out["unit"] = out["dense_range16"]["sad_candidates_per_s"], "candidates/s"
+    sp.free()
+    return out
 
 
 def time_steps(wl, ctx, dist, dev, steps, warmup):
@@ -649,6 +692,7 @@ def main():
             others.append(run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline))
             others.append(run_search(pkg, ctx, None, dev, 0, 1, orc, max(4, args.steps // 2), 1))
             others.append(run_inner_loop(pkg, ctx, orc, max(4, args.steps // 2), 1))
+            others.append(run_mesh(pkg, ctx, orc, max(4, args.steps // 4), 1))
     ctx.close()
 
     if rank == 0:

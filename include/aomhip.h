@@ -328,6 +328,18 @@ int aomhip_subpel_bilinear_batch(aomhip_ctx *ctx, const aomhip_planes *src, cons
                                  const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
                                  uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse);
 
+/* full_pixel_exhaustive (av1/encoder/mcomp.c:1547-1617): the mesh search av1_full_pixel_search (:1693-1832) runs as a
+ * follow-up / for intra block copy.  mesh_patterns = MAX_MESH_STEP (4) pairs {range, interval} on the HOST (a row of
+ * good_quality_mesh_patterns / intrabc_mesh_patterns, av1/encoder/speed_features.c:25-43); the first pair is grown
+ * with the start MV (range = max(range, 5/4 |mv|) <= 256) and the passes narrow until interval 1, each pass =
+ * exhaustive_mesh_search (:1474-1543, including its four-columns-at-a-time rule at interval 1), then the winner's
+ * variance + MV cost (get_mvpred_var_cost).  start_* of each block is the start MV (full-pel), limits = FullMvLimits.
+ * cost_list is not produced.  Outputs as aomhip_fullpel_diamond_batch. */
+int aomhip_mesh_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                             int mv_cost_type, const int mesh_patterns[8], int fine_search_interval,
+                             const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
+                             int32_t *d_best_cost);
+
 /* ------------------------------------------------------------------ the encoder's kernel vtable */
 
 /* Mirror of aom_variance_fn_ptr_t (aom_dsp/variance.h:84-103): same field order, same pointer types

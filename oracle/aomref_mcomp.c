@@ -178,6 +178,77 @@ void orc_fullpel_diamond_batch(const void *src_origin, int src_stride, const voi
   }
 }
 
+/* ---- exhaustive mesh search: exhaustive_mesh_search (mcomp.c:1474-1543) + full_pixel_exhaustive (:1547-1617) ----
+ * Literal restatement including the reference's column handling at step 1: positions are taken four at a time
+ * (sdx4df), and the tail group `for (i = 0; i < end_col - c; ++i)` does NOT visit column end_col itself.
+ * update_mvs_and_sad (:839-858): skip when this_sad >= best_sad, else add the MV cost and take it on strict <. */
+static int mesh_pass(const search_ctx *c, const orc_search_block *b, int *row0, int *col0, int range, int step) {
+  int srow = *row0, scol = *col0;
+  srow = srow < b->row_min ? b->row_min : srow > b->row_max ? b->row_max : srow; /* clamp_fullmv */
+  scol = scol < b->col_min ? b->col_min : scol > b->col_max ? b->col_max : scol;
+  int best_row = srow, best_col = scol;
+  unsigned best_sad = sad_at(c, srow, scol) + (unsigned)mvsad_cost(c, srow, scol);
+  const int col_step = step > 1 ? step : 4;
+  const int start_row = -range > b->row_min - srow ? -range : b->row_min - srow;
+  const int start_col = -range > b->col_min - scol ? -range : b->col_min - scol;
+  const int end_row = range < b->row_max - srow ? range : b->row_max - srow;
+  const int end_col = range < b->col_max - scol ? range : b->col_max - scol;
+  for (int r = start_row; r <= end_row; r += step) {
+    for (int cc = start_col; cc <= end_col; cc += col_step) {
+      const int n = step > 1 ? 1 : (cc + 3 <= end_col ? 4 : end_col - cc);
+      for (int i = 0; i < n; ++i) {
+        const int row = srow + r, col = scol + cc + i;
+        const unsigned this_sad = sad_at(c, row, col);
+        if (this_sad >= best_sad) continue;
+        const unsigned sad = this_sad + (unsigned)mvsad_cost(c, row, col);
+        if (sad < best_sad) {
+          best_sad = sad;
+          best_row = row;
+          best_col = col;
+        }
+      }
+    }
+  }
+  *row0 = best_row;
+  *col0 = best_col;
+  return (int)best_sad;
+}
+
+/* patterns: MAX_MESH_STEP = 4 pairs {range, interval} (av1/encoder/speed_features.c:25-33) */
+void orc_mesh_search_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16,
+                           int bd, int w, int h, int cost_type, const int *patterns, int fine_search_interval,
+                           const orc_search_block *blocks, int n, int16_t *out_mv, int32_t *out_cost, int threads) {
+  if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
+  for (int i = 0; i < n; ++i) {
+    const orc_search_block *b = &blocks[i];
+    search_ctx c;
+    make_ctx(&c, src_origin, src_stride, ref_origin, ref_stride, elem16, bd, w, h, cost_type, b->bx, b->by, b->ref_row,
+             b->ref_col);
+    int interval = patterns[1], range = patterns[0];
+    int br = b->start_row, bc = b->start_col, bestsme = INT_MAX;
+    if (!(range < 7 || range > 256 || interval < 1 || interval > range)) {
+      const int div = range / interval;
+      const int m = abs(br) > abs(bc) ? abs(br) : abs(bc);
+      range = range > (5 * m) / 4 ? range : (5 * m) / 4;
+      range = range < 256 ? range : 256;
+      interval = interval > range / div ? interval : range / div;
+      if (fine_search_interval) interval = interval < 4 ? interval : 4;
+      bestsme = mesh_pass(&c, b, &br, &bc, range, interval);
+      if (interval > 1 && range > 7) {
+        for (int k = 1; k < 4; ++k) {
+          bestsme = mesh_pass(&c, b, &br, &bc, patterns[2 * k], patterns[2 * k + 1]);
+          if (patterns[2 * k + 1] == 1) break;
+        }
+      }
+      if (bestsme < INT_MAX) bestsme = var_cost_at(&c, br, bc);
+    }
+    out_mv[2 * i] = (int16_t)br;
+    out_mv[2 * i + 1] = (int16_t)bc;
+    out_cost[i] = bestsme;
+  }
+}
+
 /* ---- bilinear sub-pel: av1_find_best_sub_pixel_tree_pruned_more, cost_list NULL ---- */
 
 typedef struct {

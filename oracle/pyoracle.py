@@ -395,6 +395,24 @@ def fullpel_diamond_batch(src_b, ref_b, border, w, h, blocks, clamped=0, step_pa
     return mv, cost
 
 
+GOOD_QUALITY_MESH_PATTERNS = [  # av1/encoder/speed_features.c:25-33, indexed by mesh speed
+    [(64, 8), (28, 4), (15, 1), (7, 1)], [(64, 8), (28, 4), (15, 1), (7, 1)], [(64, 8), (14, 2), (7, 1), (7, 1)],
+    [(64, 16), (24, 8), (12, 4), (7, 1)], [(64, 16), (24, 8), (12, 4), (7, 1)], [(64, 16), (24, 8), (12, 4), (7, 1)]]
+
+
+def mesh_search_batch(src_b, ref_b, border, w, h, blocks, patterns, fine_search_interval=0, cost_type=3, bd=8, threads=4):
+    blocks = np.ascontiguousarray(blocks)
+    pat = np.ascontiguousarray(np.asarray(patterns, np.int32).reshape(-1))
+    assert pat.size == 8
+    mv = np.zeros((len(blocks), 2), np.int16); cost = np.zeros(len(blocks), np.int32)
+    lib.orc_mesh_search_batch.restype = None
+    lib.orc_mesh_search_batch(C.c_void_p(_addr(src_b, border, border)), src_b.shape[1], C.c_void_p(_addr(ref_b, border, border)),
+                              ref_b.shape[1], int(src_b.dtype != np.uint8), bd, w, h, cost_type, C.c_void_p(pat.ctypes.data),
+                              fine_search_interval, C.c_void_p(blocks.ctypes.data), len(blocks), C.c_void_p(mv.ctypes.data),
+                              C.c_void_p(cost.ctypes.data), threads)
+    return mv, cost
+
+
 def subpel_bilinear_batch(src_b, ref_b, border, w, h, blocks, cost_type=3, iters=2, allow_hp=1, forced_stop=0, bd=8,
                           threads=4):
     blocks = np.ascontiguousarray(blocks)

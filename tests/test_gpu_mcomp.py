@@ -100,3 +100,65 @@ def test_subpel_bilinear_matches_oracle(hip, oracle, ctx, bw, bh, bd):
     for d in (d_b, d_mv, d_e, d_d, d_s):
         ctx.free(d)
     ctx.planes_free(ps); ctx.planes_free(pr)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bw,bh", [(16, 16), (8, 8), (32, 32), (64, 64), (4, 4), (16, 8), (8, 32), (128, 128)])
+def test_mesh_search_matches_oracle(hip, oracle, ctx, bw, bh, bd):
+    """full_pixel_exhaustive: every row of good_quality_mesh_patterns + an intrabc-style dense pattern, tight limits
+    (column spans of every length mod 4 exercise the reference's four-at-a-time column rule), start MVs that grow the
+    first range, fine_search_interval, all cost types."""
+    rng = np.random.default_rng(bw * 5 + bh + bd)
+    W, H, border = 320, 256, 160
+    src, ref = hip.synth.shifted_smooth_pair(W, H, bw + bd, bd, shift=(int(rng.integers(-12, 13)), int(rng.integers(-12, 13))))
+    ref = np.clip(ref.astype(np.int32) + rng.integers(-3, 4, ref.shape), 0, (1 << bd) - 1).astype(ref.dtype)
+    ps, pr = _upload(hip, ctx, src, ref, border, bd)
+    sb, rb = oracle.extend_plane(src, border, ps.stride), oracle.extend_plane(ref, border, pr.stride)
+    n = 40 if bw * bh <= 1024 else 12
+    blocks = _mk_blocks(hip, oracle, rng, W, H, bw, bh, border, n, start_range=20, ref_range=40)
+    k = np.arange(n)
+    blocks["col_max"][::3] = np.minimum(blocks["col_max"][::3], blocks["start_col"][::3] + (k[::3] % 7))  # spans mod 4
+    blocks["col_min"][1::4] = np.maximum(blocks["col_min"][1::4], blocks["start_col"][1::4] - (k[1::4] % 5))
+    blocks["row_min"][::5] = np.maximum(blocks["row_min"][::5], -3)
+    blocks["start_row"][2::6] = np.clip(blocks["start_row"][2::6] * 4, blocks["row_min"][2::6], blocks["row_max"][2::6])  # larger |mv|
+    pats = list(oracle.GOOD_QUALITY_MESH_PATTERNS[::2]) + [[(16, 1), (16, 1), (0, 0), (0, 0)], [(64, 4), (16, 1), (0, 0), (0, 0)]]
+    d_b, d_mv, d_c = ctx.to_device(blocks), ctx.malloc(n * 4), ctx.malloc(n * 4)
+    for pi, pat in enumerate(pats):
+        for fine, cost_type in ((0, 3), (1, 1), (0, 4)) if pi == 0 else ((0, 3),):
+            ctx.mesh_search_batch(ps, pr, 1, bw, bh, cost_type, pat, fine, d_b, n, d_mv, d_c)
+            mv, cost = ctx.from_device(d_mv, (n, 2), np.int16), ctx.from_device(d_c, (n,), np.int32)
+            wmv, wcost = oracle.mesh_search_batch(sb, rb, border, bw, bh, blocks, pat, fine, cost_type, bd)
+            assert np.array_equal(mv, wmv), (bw, bh, bd, pi, fine, cost_type, np.nonzero((mv != wmv).any(1))[0][:5])
+            assert np.array_equal(cost, wcost)
+    # illegal pattern -> INT_MAX, MV = start (mcomp.c:1567-1570)
+    ctx.mesh_search_batch(ps, pr, 1, bw, bh, 3, [(4, 1), (0, 0), (0, 0), (0, 0)], 0, d_b, n, d_mv, d_c)
+    assert (ctx.from_device(d_c, (n,), np.int32) == np.iinfo(np.int32).max).all()
+    assert np.array_equal(ctx.from_device(d_mv, (n, 2), np.int16), np.stack([blocks["start_row"], blocks["start_col"]], 1))
+    for d in (d_b, d_mv, d_c):
+        ctx.free(d)
+    ctx.planes_free(ps); ctx.planes_free(pr)
+
+
+def test_mesh_search_4k_10bit_tile(hip, oracle, ctx):
+    """One 4K 10-bit superblock row of 16x16 blocks, speed-0 pattern: device == oracle; the mesh finds the global shift."""
+    rng = np.random.default_rng(21)
+    W, H, border, bd = 3840, 128, 160, 10
+    src, ref = hip.synth.shifted_smooth_pair(W, H, 4, bd, shift=(-6, 11))
+    ps, pr = _upload(hip, ctx, src, ref, border, bd)
+    sb, rb = oracle.extend_plane(src, border, ps.stride), oracle.extend_plane(ref, border, pr.stride)
+    bx, by = np.meshgrid(np.arange(0, W, 16), np.arange(0, H, 16))
+    n = bx.size
+    blocks = np.zeros(n, hip.capi.search_block_dtype)
+    blocks["bx"], blocks["by"] = bx.ravel(), by.ravel()
+    for i in range(n):
+        lim = oracle.mv_limits_for_block(int(blocks["bx"][i]), int(blocks["by"][i]), 16, 16, W, H, border)
+        blocks["row_min"][i], blocks["row_max"][i], blocks["col_min"][i], blocks["col_max"][i] = lim
+    d_b, d_mv, d_c = ctx.to_device(blocks), ctx.malloc(n * 4), ctx.malloc(n * 4)
+    ctx.mesh_search_batch(ps, pr, 1, 16, 16, 3, oracle.GOOD_QUALITY_MESH_PATTERNS[0], 0, d_b, n, d_mv, d_c)
+    mv, cost = ctx.from_device(d_mv, (n, 2), np.int16), ctx.from_device(d_c, (n,), np.int32)
+    wmv, wcost = oracle.mesh_search_batch(sb, rb, border, 16, 16, blocks, oracle.GOOD_QUALITY_MESH_PATTERNS[0], 0, 3, bd, threads=8)
+    assert np.array_equal(mv, wmv) and np.array_equal(cost, wcost)
+    assert ((mv == np.array([11, -6])).all(1)).mean() > 0.3  # (coarse first pass: not every block lands on it)
+    for d in (d_b, d_mv, d_c):
+        ctx.free(d)
+    ctx.planes_free(ps); ctx.planes_free(pr)

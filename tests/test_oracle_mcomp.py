@@ -54,3 +54,37 @@ def test_subpel_refinement_monotone(hip, oracle):
     assert np.array_equal(m0, np.stack([sp["start_row"], sp["start_col"]], 1))
     assert (e1 <= e0).all() and (e1 < e0).any()
     assert (np.abs(m1 - m0) <= 7).all()  # 4 + 2 + 1 eighth-pel at most per axis
+
+
+def test_mesh_search_is_argmin_with_reference_column_rule(hip, oracle):
+    """exhaustive_mesh_search against an independent numpy restatement: arg-min of sad + cost over exactly the
+    positions the reference visits (four columns at a time at interval 1, the tail group skipping column end_col,
+    mcomp.c:1512-1537), first in raster order on ties, the start position winning ties."""
+    rng = np.random.default_rng(5)
+    W, H, border, bd, bw = 160, 128, 64, 8, 16
+    src = rng.integers(0, 256, (H, W)).astype(np.uint8); ref = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    sb, rb = oracle.extend_plane(src, border), oracle.extend_plane(ref, border)
+    n = 24
+    b = np.zeros(n, hip.capi.search_block_dtype)
+    b["bx"], b["by"] = rng.integers(0, W - bw, n), rng.integers(0, H - bw, n)
+    for i in range(n):
+        lim = oracle.mv_limits_for_block(int(b["bx"][i]), int(b["by"][i]), bw, bw, W, H, border)
+        b["row_min"][i], b["row_max"][i], b["col_min"][i], b["col_max"][i] = lim
+    b["col_max"] = np.minimum(b["col_max"], b["start_col"] + np.arange(n) % 9)  # spans of every length mod 4
+    pat = [(7, 1), (0, 0), (0, 0), (0, 0)]  # single dense pass (interval 1: no progressive passes)
+    mv, cost = oracle.mesh_search_batch(sb, rb, border, bw, bw, b, pat, 0, 4, bd)  # MV_COST_NONE
+    for i in range(n):
+        x, y = int(b["bx"][i]) + border, int(b["by"][i]) + border
+        blk = sb[y:y + bw, x:x + bw].astype(np.int32)
+        sr = min(max(0, b["row_min"][i]), b["row_max"][i]); sc = min(max(0, b["col_min"][i]), b["col_max"][i])
+        r0, r1 = max(-7, b["row_min"][i] - sr), min(7, b["row_max"][i] - sr)
+        c0, c1 = max(-7, b["col_min"][i] - sc), min(7, b["col_max"][i] - sc)
+        span = c1 - c0 + 1
+        ncols = 4 * (span // 4) + max(span % 4 - 1, 0) if span > 0 else 0
+        best, best_mv = int(np.abs(blk - rb[y + sr:y + sr + bw, x + sc:x + sc + bw]).sum()), (sr, sc)
+        for r in range(r0, r1 + 1):
+            for c in range(c0, c0 + ncols):
+                s = int(np.abs(blk - rb[y + sr + r:y + sr + r + bw, x + sc + c:x + sc + c + bw]).sum())
+                if s < best:
+                    best, best_mv = s, (sr + r, sc + c)
+        assert tuple(mv[i]) == best_mv, i
