@@ -8,7 +8,7 @@
 // the measured bound is that fill path, not HBM (profiles/r01_sad_variants.md).  Here a workgroup takes one
 // bucket (an sb_w x sb_h cell of source blocks) at a time, pulls the (sb_w + 2*range) x (sb_h + 2*range) reference
 // window into LDS once with full-line coalesced loads (each byte crosses L2->L1 once per bucket), and evaluates
-// every candidate of the bucket from LDS: one unaligned ds_read_b128 per 16 reference bytes, v_sad_u8 / v_sad_u16,
+// every candidate of the bucket from LDS: aligned dword reads + v_alignbyte per 16 reference bytes, v_sad_u8 / v_sad_u16,
 // DPP group reduction.  A candidate whose reference block is not wholly inside the window (the caller exceeded
 // `range`) is still evaluated, straight from global memory -- slower, never wrong.
 // Measured on one MI355X, Mode A 16x16, ring of 64 4K frame pairs (profiles/r01_sad_sb.md): 2.29e10 candidates/s
@@ -61,11 +61,20 @@ template <typename T, int W, int H, bool SKIP> struct Geom {
 
 constexpr int kLdsPadBytes = 16;  // row pitch = window bytes + 16: 16 consecutive rows start in 16 distinct bank quads
 
-// BYTES at an arbitrary byte offset of the LDS window.  gfx950 runs LDS in unaligned-access mode: one ds_read_b128 /
-// b64 / b32 at any byte address (the compiler emits exactly that for an align-1 type), no realignment in registers.
+// BYTES at an arbitrary byte offset of the LDS window: BYTES/4 + 1 aligned dword reads, realigned in registers with
+// v_alignbyte.  (gfx950 does execute a ds_read_b128 at any byte address, but a misaligned one runs at 1/12 of the
+// aligned rate -- tools/lds_unaligned_probe.hip: 0.61 vs 7.4 T lane-reads/s -- which made the LDS the bottleneck.)
 template <int BYTES>
 __device__ __forceinline__ typename UnitLoad<BYTES>::type lds_unit(const uint32_t *lds, unsigned byte_off) {
-  return *reinterpret_cast<const typename UnitLoad<BYTES>::type *>(reinterpret_cast<const char *>(lds) + byte_off);
+  const uint32_t *p = lds + (byte_off >> 2);
+  const unsigned sh = byte_off & 3;
+  uint32_t d[BYTES / 4 + 1];
+#pragma unroll
+  for (int i = 0; i <= BYTES / 4; ++i) d[i] = p[i];
+  typename UnitLoad<BYTES>::type out;
+#pragma unroll
+  for (int i = 0; i < BYTES / 4; ++i) out.v[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+  return out;
 }
 
 struct SbArgs {
