@@ -70,6 +70,7 @@ _protos = {
     "aomhip_planes_download": (C.c_int, [_vp, _PP, _i, _vp]),
     "aomhip_sad_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
     "aomhip_sad_x4d_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
+    "aomhip_sad_avg_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp, _i, _i, _vp]),
     "aomhip_sad_sb_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp,
                                       _i, _i64, _vp]),
     "aomhip_variance_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp]),
@@ -212,6 +213,12 @@ class Context:
         check(lib.aomhip_subtract_xform_quant_batch(self.h, C.byref(src), C.byref(pred), frame, tx_size, d_blocks,
                                                     n_blocks, grid_cols, tx_type, C.byref(qp), d_coeff, d_qcoeff,
                                                     d_dqcoeff, d_eob), "aomhip_subtract_xform_quant_batch")
+
+    def sad_avg_batch(self, src, ref, first_frame, n_frames, bw, bh, d_cands, n_cands, cand_frame_stride, d_second_pred,
+                      d_pred_index, fwd_offset, bck_offset, d_out):
+        check(lib.aomhip_sad_avg_batch(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, bw, bh, d_cands, n_cands,
+                                       cand_frame_stride, d_second_pred, d_pred_index, fwd_offset, bck_offset, d_out),
+              "aomhip_sad_avg_batch")
 
     def sad_sb_batch(self, src, ref, first_frame, n_frames, bw, bh, flags, sb_w, sb_h, rng, n_buckets, d_groups=None,
                      d_group_off=None, n_groups=0, group_frame_stride=0, d_out_groups=None, d_cands=None, d_cand_off=None,

@@ -188,6 +188,56 @@ __global__ __launch_bounds__(kBlockThreads) void sad_x4d_kernel(PlaneView<T> src
   }
 }
 
+// Compound-average SAD (the vtable's sdaf / jsdaf: aom_sadWxH_avg, aom_dist_wtd_sadWxH_avg and their highbd forms,
+// aom_dsp/sad.c:50-64,282-297): the candidate is compared with comp = round((second_pred + ref) / 2), or with the
+// distance-weighted blend (pred * bck + ref * fwd + 8) >> 4 (aom_dsp/variance.c:306-339,731-766).  second_pred is a
+// W-contiguous block; one block per candidate, picked by pred_index (NULL: block 0).  Same lane mapping as
+// sad_cand_kernel; the blend is done per element after unpacking.
+template <typename T, int W, int H>
+__global__ __launch_bounds__(kBlockThreads) void sad_avg_kernel(PlaneView<T> src, PlaneView<T> ref, int first_frame,
+                                                                 const aomhip_sad_cand *__restrict__ cands, int n_cands,
+                                                                 int64_t cand_frame_stride, const T *__restrict__ preds,
+                                                                 const uint32_t *__restrict__ pred_index, int fwd,
+                                                                 int bck, uint32_t *__restrict__ out, int shift) {
+  using G = SadGeom<T, W, H, false, 2>;
+  using L = typename UnitLoad<G::kUnitBytes>::type;
+  constexpr int kCpb = kBlockThreads / G::kTpc;
+  constexpr int kEPD = 4 / (int)sizeof(T);  // elements per dword
+  constexpr uint32_t kMask = sizeof(T) == 1 ? 0xffu : 0xffffu;
+  const unsigned f_rel = blockIdx.y;
+  const int lane_in_cand = threadIdx.x % G::kTpc;
+  const int ci = blockIdx.x * kCpb + threadIdx.x / G::kTpc;
+  if (ci >= n_cands) return;
+  const aomhip_sad_cand c = cands[(int64_t)f_rel * cand_frame_stride + ci];
+  const int64_t fo = (int64_t)(first_frame + f_rel);
+  const T *sp = src.origin + fo * src.frame_stride + (int64_t)c.sy * src.stride + c.sx;
+  const T *rp = ref.origin + fo * ref.frame_stride + (int64_t)c.ry * ref.stride + c.rx;
+  const T *pp = preds + (int64_t)(pred_index ? pred_index[(int64_t)f_rel * n_cands + ci] : 0u) * (W * H);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < G::kUnitsPerLane; ++k) {
+    const int u = lane_in_cand + k * G::kTpc;
+    const int row = u / G::kUnitsPerRow, col = (u % G::kUnitsPerRow) * G::kUnitElems;
+    const L a = *reinterpret_cast<const L *>(sp + (int64_t)row * src.stride + col);
+    const L b = *reinterpret_cast<const L *>(rp + (int64_t)row * ref.stride + col);
+    const L p = *reinterpret_cast<const L *>(pp + row * W + col);
+#pragma unroll
+    for (int i = 0; i < G::kUnitBytes / 4; ++i) {
+      uint32_t comp = 0;
+#pragma unroll
+      for (int e = 0; e < kEPD; ++e) {
+        const int sh = e * 8 * (int)sizeof(T);
+        const int rv = (int)((b.v[i] >> sh) & kMask), pv = (int)((p.v[i] >> sh) & kMask);
+        const int cv = (fwd | bck) ? (pv * bck + rv * fwd + 8) >> 4 : (pv + rv + 1) >> 1;
+        comp |= ((uint32_t)cv & kMask) << sh;
+      }
+      acc = sad_dword<T>(a.v[i], comp, acc);
+    }
+  }
+  acc = group_sum<G::kTpc>(acc);
+  if (lane_in_cand == 0) out[(int64_t)f_rel * n_cands + ci] = acc >> shift;
+}
+
 struct SadLaunch {
   hipStream_t stream;
   int first_frame, n_frames;
@@ -362,6 +412,45 @@ int aomhip_sad_x4d_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip
                                                   d_groups, n_groups, group_frame_stride, d_out);
   return dispatch<uint16_t, aomhip_sad_x4d_cand>(true, l, view_of<uint16_t>(*src), view_of<uint16_t>(*ref), bw, bh,
                                                  d_groups, n_groups, group_frame_stride, d_out);
+}
+
+int aomhip_sad_avg_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame, int n_frames,
+                         int bw, int bh, const aomhip_sad_cand *d_cands, int n_cands, int64_t cand_frame_stride,
+                         const void *d_second_pred, const uint32_t *d_pred_index, int fwd_offset, int bck_offset,
+                         uint32_t *d_out) {
+  int rc = check_args(ctx, src, ref, first_frame, n_frames, bw, bh, d_cands, n_cands, d_out);
+  if (rc != AOMHIP_OK) return rc;
+  if (!d_second_pred || fwd_offset < 0 || bck_offset < 0 || fwd_offset > 16 || bck_offset > 16 ||
+      ((fwd_offset | bck_offset) && fwd_offset + bck_offset != 16)) {
+    set_error("aomhip_sad_avg_batch: second_pred missing or weights not 0/0 (plain average) or summing to 16");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_cands == 0 || n_frames == 0) return AOMHIP_OK;
+  const int shift = wrapper_shift(src->bit_depth);
+#define X(W, H)                                                                                                          \
+  if (bw == W && bh == H) {                                                                                              \
+    if (src->bit_depth == 8) {                                                                                           \
+      using G = SadGeom<uint8_t, W, H, false, 2>;                                                                        \
+      constexpr int kCpb = kBlockThreads / G::kTpc;                                                                      \
+      hipLaunchKernelGGL((sad_avg_kernel<uint8_t, W, H>), dim3((n_cands + kCpb - 1) / kCpb, n_frames), dim3(kBlockThreads), \
+                         0, ctx->stream, view_of<uint8_t>(*src), view_of<uint8_t>(*ref), first_frame, d_cands, n_cands,  \
+                         cand_frame_stride, static_cast<const uint8_t *>(d_second_pred), d_pred_index, fwd_offset,       \
+                         bck_offset, d_out, shift);                                                                      \
+    } else {                                                                                                             \
+      using G = SadGeom<uint16_t, W, H, false, 2>;                                                                       \
+      constexpr int kCpb = kBlockThreads / G::kTpc;                                                                      \
+      hipLaunchKernelGGL((sad_avg_kernel<uint16_t, W, H>), dim3((n_cands + kCpb - 1) / kCpb, n_frames),                   \
+                         dim3(kBlockThreads), 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref),          \
+                         first_frame, d_cands, n_cands, cand_frame_stride, static_cast<const uint16_t *>(d_second_pred), \
+                         d_pred_index, fwd_offset, bck_offset, d_out, shift);                                            \
+    }                                                                                                                    \
+    AOMHIP_LAUNCH_CHECK();                                                                                               \
+    return AOMHIP_OK;                                                                                                    \
+  }
+  AOMHIP_FOR_BLOCK_SIZES(X)
+#undef X
+  set_error("unsupported block size %dx%d", bw, bh);
+  return AOMHIP_ERR_INVALID;
 }
 
 unsigned int aomhip_sad(const uint8_t *src_ptr, int src_stride, const uint8_t *ref_ptr, int ref_stride, int bw, int bh) {

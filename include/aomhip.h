@@ -143,6 +143,18 @@ int aomhip_sad_x4d_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip
                          int n_frames, int bw, int bh, int flags, const aomhip_sad_x4d_cand *d_groups,
                          int n_groups, int64_t group_frame_stride, uint32_t *d_out);
 
+/* Batched compound-average SAD: the vtable's sdaf / jsdaf entries (aom_sadWxH_avg, aom_dist_wtd_sadWxH_avg,
+ * aom_highbd_* forms; aom_dsp/sad.c:50-64,282-297; blends aom_dsp/variance.c:306-339,731-766; the 10/12-bit
+ * >>2 / >>4 wrappers av1/encoder/encoder_utils.h:210-262 applied as for aomhip_sad_batch).
+ *   d_second_pred   bw*bh-contiguous prediction blocks (pixel type of the planes), block k at k * bw * bh
+ *   d_pred_index    per candidate (and frame: [f_rel * n_cands + i]) the block it is blended with; NULL = block 0
+ *   fwd_offset / bck_offset   0 / 0: comp = (pred + ref + 1) >> 1 (aom_comp_avg_pred); otherwise the
+ *                   DIST_WTD_COMP_PARAMS weights (sum 16): comp = (pred * bck + ref * fwd + 8) >> 4 */
+int aomhip_sad_avg_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame, int n_frames,
+                         int bw, int bh, const aomhip_sad_cand *d_cands, int n_cands, int64_t cand_frame_stride,
+                         const void *d_second_pred, const uint32_t *d_pred_index, int fwd_offset, int bck_offset,
+                         uint32_t *d_out);
+
 /* Superblock-bucketed SAD batch: the same results as aomhip_sad_x4d_batch / aomhip_sad_batch, for work lists
  * laid out the way the encoder's per-superblock call sites issue them (av1/encoder/encodeframe.c:1069
  * encode_sb_row; motion vectors confined by av1_set_mv_search_range, av1/encoder/mcomp.c:101).

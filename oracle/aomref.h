@@ -46,6 +46,9 @@ void orc_sad_skip_x4d(const uint8_t *src, int src_stride, const uint8_t *const r
 /* sad.c:46-53 aom_sadMxN_avg_c with variance.c:306-320 aom_comp_avg_pred_c */
 unsigned orc_sad_avg(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride,
                      const uint8_t *second_pred, int w, int h);
+/* all flavours: plain / dist_wtd (sad.c:57-64, variance.c:322-339), highbd (sad.c:282-297, variance.c:731-766) */
+unsigned orc_sad_avg_any(const void *src, int src_stride, const void *ref, int ref_stride, const void *second_pred,
+                         int w, int h, int elem16, int bd, int fwd_offset, int bck_offset);
 
 /* highbd: sad.c:240-256,276-332.  Planes are plain uint16_t* here (the
  * CONVERT_TO_SHORTPTR byte-pointer convention, aom_ports/mem.h:79-80, is a host

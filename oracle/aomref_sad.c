@@ -51,6 +51,32 @@ unsigned orc_sad_avg(const uint8_t *src, int src_stride, const uint8_t *ref, int
   return acc;
 }
 
+/* Compound-average SAD, all flavours (sad.c:50-64 SADMXN avg / dist_wtd avg; highbd :282-297 with
+ * aom_highbd_comp_avg_pred_c / aom_highbd_dist_wtd_comp_avg_pred_c, variance.c:731-766; 8-bit preds :306-339):
+ * fwd_offset == bck_offset == 0 selects the plain rounded average, otherwise
+ * comp = ROUND_POWER_OF_TWO(pred * bck_offset + ref * fwd_offset, DIST_PRECISION_BITS = 4).
+ * `bd` applies the encoder's _bits10 / _bits12 wrappers (encoder_utils.h:210-262) as for orc_highbd_sad. */
+unsigned orc_sad_avg_any(const void *src, int src_stride, const void *ref, int ref_stride, const void *second_pred,
+                         int w, int h, int elem16, int bd, int fwd_offset, int bck_offset) {
+  unsigned acc = 0;
+  for (int r = 0; r < h; ++r) {
+    for (int c = 0; c < w; ++c) {
+      const int s = elem16 ? ((const uint16_t *)src)[r * src_stride + c] : ((const uint8_t *)src)[r * src_stride + c];
+      const int f = elem16 ? ((const uint16_t *)ref)[r * ref_stride + c] : ((const uint8_t *)ref)[r * ref_stride + c];
+      const int p = elem16 ? ((const uint16_t *)second_pred)[r * w + c] : ((const uint8_t *)second_pred)[r * w + c];
+      int comp;
+      if (fwd_offset == 0 && bck_offset == 0)
+        comp = RPOT(p + f, 1);
+      else
+        comp = RPOT(p * bck_offset + f * fwd_offset, 4);
+      if (!elem16) comp = (uint8_t)comp;
+      acc += (unsigned)abs(s - comp);
+    }
+  }
+  if (elem16) return bd == 10 ? acc >> 2 : bd == 12 ? acc >> 4 : acc;
+  return acc;
+}
+
 /* ------------------------------------------------------------------ SAD, highbd */
 
 static unsigned hbd_sad_raw(const uint16_t *src, int src_stride, const uint16_t *ref, int ref_stride, int w,

@@ -84,6 +84,19 @@ lib.orc_sad_x4d_batch.restype = None
 lib.orc_sad_x4d_batch.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i]
 
 
+def sad_avg_batch(src_b, ref_b, border, w, h, cands, preds, pred_index, fwd_offset=0, bck_offset=0, bd=8):
+    """cands: structured (sx, sy, rx, ry); preds: [n_preds, h, w] contiguous blocks; pred_index: per candidate."""
+    lib.orc_sad_avg_any.restype = C.c_uint
+    preds = np.ascontiguousarray(preds, src_b.dtype)
+    e16 = int(src_b.dtype != np.uint8)
+    out = np.zeros(len(cands), np.uint32)
+    for i, c in enumerate(cands):
+        out[i] = lib.orc_sad_avg_any(C.c_void_p(_addr(src_b, border + int(c["sy"]), border + int(c["sx"]))), src_b.shape[1],
+                                     C.c_void_p(_addr(ref_b, border + int(c["ry"]), border + int(c["rx"]))), ref_b.shape[1],
+                                     C.c_void_p(preds[int(pred_index[i])].ctypes.data), w, h, e16, bd, fwd_offset, bck_offset)
+    return out
+
+
 def extend_plane(pixels, border, stride=None):
     """Host model of an HBM plane: replicate edges into `border` px on every side
     (aom_scale/generic/yv12extend.c:22-221); returns (bordered array, origin (y, x))."""

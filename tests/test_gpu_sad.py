@@ -216,3 +216,37 @@ def test_full_size_1080p_mode_a_properties(hip, oracle, ctx):
         ctx.planes_free(p)
     for d in (d_c, d_g, d_o1, d_o4, d_f, d_of):
         ctx.free(d)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_compound_average_sad(hip, oracle, ctx, bd):
+    """sdaf / jsdaf: aom_sadWxH_avg and aom_dist_wtd_sadWxH_avg (+ highbd, + bits10/12 wrappers), all 22 sizes, the
+    four quant_dist_lookup_table weight pairs (av1/common/reconinter.c) and the plain average."""
+    rng = np.random.default_rng(bd)
+    W, H, border = 256, 192, 64
+    src, ref = hip.synth.lcg_frame(W, H, 1, 0, bd), hip.synth.lcg_frame(W, H, 2, 1, bd)
+    ps, pr = ctx.planes_alloc(W, H, border, bd, 2), ctx.planes_alloc(W, H, border, bd, 2)
+    ctx.planes_upload(ps, 1, src); ctx.planes_upload(pr, 1, ref)
+    sb, rb = oracle.extend_plane(src, border, ps.stride), oracle.extend_plane(ref, border, pr.stride)
+    dt = np.uint8 if bd == 8 else np.uint16
+    for (w, h) in BLOCK_SIZES:
+        n, npred = 150, 7
+        cands = np.zeros(n, hip.capi.sad_cand_dtype)
+        cands["sx"], cands["sy"] = rng.integers(0, W - w + 1, n), rng.integers(0, H - h + 1, n)
+        cands["rx"], cands["ry"] = rng.integers(-border, W + border - w + 1, n), rng.integers(-border, H + border - h + 1, n)
+        preds = rng.integers(0, 1 << bd, (npred, h, w)).astype(dt)
+        preds[0] = (1 << bd) - 1  # saturated block: the weighted blend must not wrap
+        pidx = rng.integers(0, npred, n).astype(np.uint32)
+        d_c, d_p, d_i, d_o = ctx.to_device(cands), ctx.to_device(preds), ctx.to_device(pidx), ctx.malloc(n * 4)
+        for fwd, bck in ((0, 0), (9, 7), (11, 5), (12, 4), (13, 3), (4, 12)):
+            ctx.sad_avg_batch(ps, pr, 1, 1, w, h, d_c, n, 0, d_p, d_i, fwd, bck, d_o)
+            want = oracle.sad_avg_batch(sb, rb, border, w, h, cands, preds, pidx, fwd, bck, bd)
+            assert np.array_equal(ctx.from_device(d_o, (n,), np.uint32), want), (w, h, bd, fwd, bck)
+        ctx.sad_avg_batch(ps, pr, 1, 1, w, h, d_c, n, 0, d_p, None, 0, 0, d_o)  # NULL index: block 0 for everyone
+        assert np.array_equal(ctx.from_device(d_o, (n,), np.uint32),
+                              oracle.sad_avg_batch(sb, rb, border, w, h, cands, preds, np.zeros(n, np.uint32), 0, 0, bd))
+        for d in (d_c, d_p, d_i, d_o):
+            ctx.free(d)
+    with pytest.raises(hip.capi.AomHipError):
+        ctx.sad_avg_batch(ps, pr, 1, 1, 16, 16, 0, 0, 0, None, None, 0, 0, 1)
+    ctx.planes_free(ps); ctx.planes_free(pr)

@@ -170,3 +170,27 @@ def test_config0_cpu_rtcd_path_640x360(oracle):
     # border replication: a candidate hanging off the top-left corner reads replicated edge pixels
     edge = np.zeros(1, cands.dtype); edge["rx"], edge["ry"] = -20, -20
     assert oracle.sad_batch(sb, rb, border, 16, 16, edge)[0] == ref_sad_np(src[:16, :16], np.full((16, 16), ref[0, 0]))
+
+
+def test_compound_average_sad_flavours(oracle):
+    """orc_sad_avg_any: plain average == orc_sad_avg (sad.c:50-56) == sad against an explicitly blended block; the
+    distance-weighted blend follows variance.c:322-339; highbd applies the bits10 / bits12 wrapper shift."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    lib = oracle.lib
+    lib.orc_sad_avg_any.restype = C.c_uint
+    for (w, h) in [(4, 4), (16, 16), (64, 32), (128, 128)]:
+        s = rng.integers(0, 256, (h, w + 3), dtype=np.uint8); r = rng.integers(0, 256, (h, w + 5), dtype=np.uint8)
+        p = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        plain = lib.orc_sad_avg_any(C.c_void_p(s.ctypes.data), s.shape[1], C.c_void_p(r.ctypes.data), r.shape[1], C.c_void_p(p.ctypes.data), w, h, 0, 8, 0, 0)
+        lib.orc_sad_avg.restype = C.c_uint
+        assert plain == lib.orc_sad_avg(C.c_void_p(s.ctypes.data), s.shape[1], C.c_void_p(r.ctypes.data), r.shape[1], C.c_void_p(p.ctypes.data), w, h)
+        blend = ((p.astype(int) + r[:, :w] + 1) >> 1)
+        assert plain == int(np.abs(s[:, :w].astype(int) - blend).sum())
+        wt = lib.orc_sad_avg_any(C.c_void_p(s.ctypes.data), s.shape[1], C.c_void_p(r.ctypes.data), r.shape[1], C.c_void_p(p.ctypes.data), w, h, 0, 8, 11, 5)
+        assert wt == int(np.abs(s[:, :w].astype(int) - ((p.astype(int) * 5 + r[:, :w].astype(int) * 11 + 8) >> 4)).sum())
+        s16 = (s.astype(np.uint16) << 2) | 3; r16 = (r.astype(np.uint16) << 2) | 1; p16 = (p.astype(np.uint16) << 2) | 2
+        raw = int(np.abs(s16[:, :w].astype(int) - ((p16.astype(int) + r16[:, :w] + 1) >> 1)).sum())
+        for bd, sh in ((10, 2), (12, 4)):
+            got = lib.orc_sad_avg_any(C.c_void_p(s16.ctypes.data), s16.shape[1], C.c_void_p(r16.ctypes.data), r16.shape[1], C.c_void_p(p16.ctypes.data), w, h, 1, bd, 0, 0)
+            assert got == raw >> sh
