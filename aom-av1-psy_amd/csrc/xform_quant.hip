@@ -487,6 +487,96 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Adaptive quantiser: aom_quantize_b_adaptive_helper_c / aom_highbd_quantize_b_adaptive_helper_c
+// (aom_dsp/quantize.c:16-105,173-258; selected by qparam->use_quant_b_adapt, av1_quantize.c:309-341,453-) on
+// already materialised transform coefficients.  The three sequential passes of the reference are reductions:
+//   non_zero_count = 1 + last scan position whose coefficient lies outside the dead zone widened by
+//                    ROUND_POWER_OF_TWO(dequant * EOB_FACTOR(325), 7)          (backward pre-scan, :36-46)
+//   eob / first    = last / first scan position below non_zero_count with a non-zero level
+//   if first == eob and that level is +-1 and the coefficient lies inside the zone widened by
+//                    dequant * (325 + SKIP_EOB_FACTOR_ADJUST(200)) / 128: drop it, eob = 0   (:84-102)
+// One wavefront per block; lane l owns coefficients l, l + 64, ... of the (transposed) coefficient array.
+template <int KW, int KH, bool HBD, int LS>
+__global__ __launch_bounds__(256) void quant_adaptive_kernel(const int32_t *__restrict__ coeff,
+                                                             const aomhip_txb *__restrict__ blocks, int n_blocks,
+                                                             int uniform_type, QuantArgs qa, int32_t *__restrict__ qcoeff,
+                                                             int32_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob) {
+  constexpr int NC = KW * KH;
+  constexpr int PER = (NC + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bi >= n_blocks) return;
+  const int tx_type = blocks ? blocks[bi].tx_type : uniform_type;
+  const int64_t off = blocks ? (int64_t)blocks[bi].out_offset : (int64_t)bi * NC;
+  const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
+  const int zb[2] = { (qa.zbin[0] + ((1 << LS) >> 1)) >> LS, (qa.zbin[1] + ((1 << LS) >> 1)) >> LS };
+  const int rd[2] = { (qa.round[0] + ((1 << LS) >> 1)) >> LS, (qa.round[1] + ((1 << LS) >> 1)) >> LS };
+  const int add1[2] = { (qa.dequant[0] * 325 + 64) >> 7, (qa.dequant[1] * 325 + 64) >> 7 };
+  const int add2[2] = { (qa.dequant[0] * 525 + 64) >> 7, (qa.dequant[1] * 525 + 64) >> 7 };
+  int32_t v[PER];
+  int pos[PER];
+  int nzc = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int rc = lane + 64 * k;
+    v[k] = 0;
+    pos[k] = -1;
+    if (rc < NC) {
+      v[k] = coeff[off + rc];
+      const int c = rc / KH, r = rc % KH;  // transposed layout: rc = c * KH + r
+      pos[k] = iscan_pos<KW, KH>(r, c, scan_class);
+      const int ac = rc != 0;
+      const int64_t cw = (int64_t)v[k] * 32;  // coeff * wt (the reference forms it in int; |coeff| < 2^26 here)
+      const bool inside = cw < (int64_t)zb[ac] * 32 + add1[ac] && cw > -(int64_t)zb[ac] * 32 - add1[ac];
+      if (!inside) nzc = max(nzc, pos[k] + 1);
+    }
+  }
+  nzc = group_max<64>(nzc);
+  int32_t qv[PER], dv[PER];
+  int last = 0, first = NC;  // last = eob (position + 1), first = position
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    qv[k] = dv[k] = 0;
+    if (pos[k] >= 0 && pos[k] < nzc) {
+      const int ac = (lane + 64 * k) != 0;
+      quantize_one<HBD, LS>(v[k], zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.qs_log2[ac], qa.dequant[ac], &qv[k],
+                            &dv[k]);
+      if (qv[k]) {
+        last = max(last, pos[k] + 1);
+        first = min(first, pos[k]);
+      }
+    }
+  }
+  last = group_max<64>(last);
+  first = -group_max<64>(-first);
+  if (last > 0 && first == last - 1) {  // exactly one non-zero level
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (pos[k] == first && (qv[k] == 1 || qv[k] == -1)) {
+        const int ac = (lane + 64 * k) != 0;
+        const int64_t cw = (int64_t)v[k] * 32;
+        if (cw < (int64_t)zb[ac] * 32 + add2[ac] && cw > -(int64_t)zb[ac] * 32 - add2[ac]) qv[k] = dv[k] = 0;
+      }
+    }
+    // did the owner drop it?  (one more vote: the eob must follow)
+    int still = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) still |= (qv[k] != 0);
+    still = group_max<64>(still);
+    if (!still) last = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int rc = lane + 64 * k;
+    if (rc < NC) {
+      qcoeff[off + rc] = qv[k];
+      dqcoeff[off + rc] = dv[k];
+    }
+  }
+  if (lane == 0) eob[bi] = (uint16_t)last;
+}
+
 struct XqLaunch {
   hipStream_t stream;
   const void *in0, *in1;
@@ -643,6 +733,39 @@ int aomhip_subtract_xform_quant_batch(aomhip_ctx *ctx, const aomhip_planes *src,
               to_args(qparams), d_coeff, d_qcoeff, d_dqcoeff, d_eob };
   // encodemb.c:323: the quantiser flavour follows the bit depth of the planes
   return src->bit_depth == 8 ? dispatch_xq<false, 1>(tx_size, l) : dispatch_xq<true, 2>(tx_size, l);
+}
+
+int aomhip_quantize_b_adaptive_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks,
+                                     int n_blocks, int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd,
+                                     int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
+  if (!ctx || !d_coeff || !qparams || !d_qcoeff || !d_dqcoeff || !d_eob || tx_size < 0 || tx_size >= 19 || n_blocks < 0 ||
+      (!d_blocks && (uniform_tx_type < 0 || uniform_tx_type > 15))) {
+    set_error("aomhip_quantize_b_adaptive_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  const QuantArgs qa = to_args(qparams);
+  const int w = kTxW[tx_size], h = kTxH[tx_size];
+  const int kw = w > 32 ? 32 : w, kh = h > 32 ? 32 : h;
+  const int ls = (w * h > 256) + (w * h > 1024);  // av1_get_tx_scale (av1/common/idct.c:24-28)
+  const dim3 grid((n_blocks + 3) / 4), block(256);
+#define AOMHIP_QA(KW_, KH_, LS_)                                                                                       \
+  if (kw == KW_ && kh == KH_ && ls == LS_) {                                                                           \
+    if (is_hbd)                                                                                                        \
+      hipLaunchKernelGGL((quant_adaptive_kernel<KW_, KH_, true, LS_>), grid, block, 0, ctx->stream, d_coeff, d_blocks,  \
+                         n_blocks, uniform_tx_type, qa, d_qcoeff, d_dqcoeff, d_eob);                                   \
+    else                                                                                                               \
+      hipLaunchKernelGGL((quant_adaptive_kernel<KW_, KH_, false, LS_>), grid, block, 0, ctx->stream, d_coeff, d_blocks, \
+                         n_blocks, uniform_tx_type, qa, d_qcoeff, d_dqcoeff, d_eob);                                   \
+    AOMHIP_LAUNCH_CHECK();                                                                                             \
+    return AOMHIP_OK;                                                                                                  \
+  }
+  AOMHIP_QA(4, 4, 0) AOMHIP_QA(8, 8, 0) AOMHIP_QA(16, 16, 0) AOMHIP_QA(32, 32, 1) AOMHIP_QA(32, 32, 2)
+  AOMHIP_QA(4, 8, 0) AOMHIP_QA(8, 4, 0) AOMHIP_QA(8, 16, 0) AOMHIP_QA(16, 8, 0) AOMHIP_QA(16, 32, 1) AOMHIP_QA(32, 16, 1)
+  AOMHIP_QA(4, 16, 0) AOMHIP_QA(16, 4, 0) AOMHIP_QA(8, 32, 0) AOMHIP_QA(32, 8, 0)
+#undef AOMHIP_QA
+  set_error("aomhip_quantize_b_adaptive_batch: no kernel for tx_size %d", tx_size);
+  return AOMHIP_ERR_INVALID;
 }
 
 }  // extern "C"

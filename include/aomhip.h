@@ -245,6 +245,16 @@ int aomhip_subtract_xform_quant_batch(aomhip_ctx *ctx, const aomhip_planes *src,
                                       int uniform_tx_type, const aomhip_quant_params *qparams, int32_t *d_coeff,
                                       int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);
 
+/* The adaptive quantiser (qparam->use_quant_b_adapt, av1/encoder/av1_quantize.c:309-341,453-):
+ * aom_quantize_b_adaptive_helper_c / aom_highbd_quantize_b_adaptive_helper_c (aom_dsp/quantize.c:16-105,173-258;
+ * EOB_FACTOR 325, SKIP_EOB_FACTOR_ADJUST 200, aom_dsp/quantize.h:23-24) on transform coefficients that are already
+ * in device memory in the reference layout (the d_coeff output of aomhip_xform_quant_batch).  Blocks, offsets and
+ * scan selection as in aomhip_xform_quant_batch (list or grid mode); 64-point sizes quantise their packed 32 x 32
+ * (or 32 x 16 ...) coefficients with log_scale from av1_get_tx_scale. */
+int aomhip_quantize_b_adaptive_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks,
+                                     int n_blocks, int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd,
+                                     int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);
+
 /* ------------------------------------------------------------------ batched inverse transform + reconstruction */
 
 /* av1_inverse_transform_block (av1/common/idct.c:304) -> av1_inv_txfm2d_add_WxH (av1_rtcd_defs.pl:137-243,

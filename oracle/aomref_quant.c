@@ -146,3 +146,69 @@ int orc_get_scan(int tx_size, int tx_type, int16_t *scan, int16_t *iscan) {
     for (int i = 0; i < n; ++i) iscan[scan[i]] = (int16_t)i;
   return n;
 }
+
+/* aom_quantize_b_adaptive_helper_c / aom_highbd_quantize_b_adaptive_helper_c (aom_dsp/quantize.c:16-105,173-258),
+ * qm_ptr == iqm_ptr == NULL; EOB_FACTOR 325, SKIP_EOB_FACTOR_ADJUST 200 (aom_dsp/quantize.h:23-24).  Literal:
+ * backward pre-scan over a dead zone widened by dequant * 325 / 128, forward quantisation of what is left, and the
+ * "single +-1 coefficient" kill with the zone widened by dequant * 525 / 128.  PARITY UNPINNED like quantize_b. */
+void orc_quantize_b_adaptive(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
+                             const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
+                             const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale, int highbd) {
+  const int zb[2] = { rpot(zbin[0], log_scale), rpot(zbin[1], log_scale) };
+  const int nzb[2] = { -zb[0], -zb[1] };
+  const int wt = 1 << QM_BITS;
+  int non_zero_count = (int)n, eob = -1, first = -1;
+  memset(qcoeff, 0, (size_t)n * sizeof(*qcoeff));
+  memset(dqcoeff, 0, (size_t)n * sizeof(*dqcoeff));
+  int prescan_add[2];
+  for (int i = 0; i < 2; ++i) prescan_add[i] = rpot(dequant[i] * 325, 7);
+  for (int i = (int)n - 1; i >= 0; --i) {
+    const int rc = scan[i], ac = (rc != 0);
+    const int c = coeff[rc] * wt;
+    if (c < (zb[ac] * (1 << QM_BITS) + prescan_add[ac]) && c > (nzb[ac] * (1 << QM_BITS) - prescan_add[ac]))
+      non_zero_count--;
+    else
+      break;
+  }
+  for (int i = 0; i < non_zero_count; ++i) {
+    const int rc = scan[i], ac = (rc != 0);
+    const int c = coeff[rc];
+    const int sign = c >> 31;
+    const int a = (c ^ sign) - sign;
+    if (a * wt < (zb[ac] << QM_BITS)) continue;
+    int q;
+    if (!highbd) {
+      int64_t t = a + rpot(round[ac], log_scale);
+      if (t > INT16_MAX) t = INT16_MAX;
+      if (t < INT16_MIN) t = INT16_MIN;
+      t *= wt;
+      q = (int)(((((t * quant[ac]) >> 16) + t) * quant_shift[ac]) >> (16 - log_scale + QM_BITS));
+    } else {
+      const int64_t t1 = a + rpot(round[ac], log_scale);
+      const int64_t tw = t1 * wt;
+      const int64_t t2 = ((tw * quant[ac]) >> 16) + tw;
+      q = (int)((t2 * quant_shift[ac]) >> (16 - log_scale + QM_BITS));
+    }
+    qcoeff[rc] = (q ^ sign) - sign;
+    const int dq = (dequant[ac] * wt + (1 << (QM_BITS - 1))) >> QM_BITS;
+    const int adq = (q * dq) >> log_scale;
+    dqcoeff[rc] = (adq ^ sign) - sign;
+    if (q) {
+      eob = i;
+      if (first == -1) first = i;
+    }
+  }
+  if (eob >= 0 && first == eob) {
+    const int rc = scan[eob], ac = (rc != 0);
+    if (qcoeff[rc] == 1 || qcoeff[rc] == -1) {
+      const int c = coeff[rc] * wt;
+      const int add = rpot(dequant[ac] * (325 + 200), 7);
+      if (c < (zb[ac] * (1 << QM_BITS) + add) && c > (nzb[ac] * (1 << QM_BITS) - add)) {
+        qcoeff[rc] = 0;
+        dqcoeff[rc] = 0;
+        eob = -1;
+      }
+    }
+  }
+  *eob_out = (uint16_t)(eob + 1);
+}

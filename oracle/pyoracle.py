@@ -228,6 +228,20 @@ def quantize_b(coeff, q, scan, iscan, log_scale, highbd=False):
     return qc, dq, eob.value
 
 
+def quantize_b_adaptive(coeff, q, scan, log_scale, highbd=False):
+    coeff = np.ascontiguousarray(coeff, np.int32)
+    qc, dq = np.zeros_like(coeff), np.zeros_like(coeff)
+    eob = C.c_uint16()
+    sc = np.ascontiguousarray(scan, np.int16)
+    tabs = [np.ascontiguousarray(q[k], np.int16) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
+    lib.orc_quantize_b_adaptive.restype = None
+    lib.orc_quantize_b_adaptive(C.c_void_p(coeff.ctypes.data), C.c_ssize_t(coeff.size), C.c_void_p(tabs[0].ctypes.data),
+                                C.c_void_p(tabs[1].ctypes.data), C.c_void_p(tabs[2].ctypes.data), C.c_void_p(tabs[3].ctypes.data),
+                                C.c_void_p(qc.ctypes.data), C.c_void_p(dq.ctypes.data), C.c_void_p(tabs[4].ctypes.data),
+                                C.byref(eob), C.c_void_p(sc.ctypes.data), log_scale, int(highbd))
+    return qc, dq, eob.value
+
+
 lib.orc_xform_quant_batch.restype = None
 lib.orc_xform_quant_batch.argtypes = [_vp, _i, _i, _vp, _i, _i, _i, _i16, _i, _vp, _vp, _vp, _vp, _i, _i]
 

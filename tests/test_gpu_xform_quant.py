@@ -173,3 +173,54 @@ def test_full_size_1080p_properties(hip, oracle, ctx):
     assert not ctx.from_device(d_q, (n * nc,), np.int32).any() and not ctx.from_device(d_e, (n,), np.uint16).any()
     for d in (d_res, d_c, d_q, d_dq, d_e):
         ctx.free(d)
+
+
+@pytest.mark.parametrize("hbd", [False, True])
+def test_adaptive_quantiser(hip, oracle, ctx, hbd):
+    """aom_[highbd_]quantize_b_adaptive on device-resident coefficients == oracle, every transform size, scan class and
+    log_scale; coefficient populations that exercise each rule: dense, sparse tails inside the widened dead zone, a
+    single +-1 survivor (dropped or kept), all-zero."""
+    rng = np.random.default_rng(11 + hbd)
+    bd = 10 if hbd else 8
+    for tx_size in range(19):
+        w, h = oracle.TX_W[tx_size], oracle.TX_H[tx_size]
+        nc = hip.capi.lib.aomhip_tx_max_eob(tx_size)
+        ls = int(w * h > 256) + int(w * h > 1024)
+        types = [t for t in (0, 10, 11, 9, 3) if oracle.lib.orc_txfm_valid(tx_size, t)]
+        n = 96
+        for qindex in (20, 120, 220):
+            q = oracle.build_quantizer_y(bd, qindex)
+            dqs = int(q["dequant"][1])
+            coeff = np.zeros((n, nc), np.int32)
+            for i in range(n):
+                kind = i % 6
+                if kind == 0:
+                    coeff[i] = rng.normal(0, dqs * 2, nc)
+                elif kind == 1:  # energy only at the start of the scan, small tail
+                    coeff[i] = rng.normal(0, dqs * 0.6, nc)
+                elif kind == 2:  # one coefficient near the +-1 level, position random
+                    coeff[i, rng.integers(0, nc)] = int(rng.choice([-1, 1])) * int(dqs * rng.uniform(0.4, 2.2))
+                elif kind == 3:
+                    coeff[i] = rng.integers(-dqs, dqs + 1, nc) * (rng.random(nc) < 0.05)
+                elif kind == 4:
+                    coeff[i, 0] = int(rng.integers(-4 * dqs, 4 * dqs))  # DC only
+                # kind 5: all zero
+            tt = rng.choice(types, n).astype(np.uint8)
+            blocks = np.zeros(n, hip.capi.txb_dtype)
+            blocks["out_offset"] = np.arange(n) * nc
+            blocks["tx_type"] = tt
+            d_c, d_b = ctx.to_device(coeff), ctx.to_device(blocks)
+            d_q, d_dq, d_e = ctx.malloc(n * nc * 4), ctx.malloc(n * nc * 4), ctx.malloc(2 * n)
+            ctx.quantize_b_adaptive_batch(d_c, tx_size, d_b, n, 0, hip.capi.QuantParams.from_tables(q), hbd, d_q, d_dq, d_e)
+            gq, gdq = ctx.from_device(d_q, (n, nc), np.int32), ctx.from_device(d_dq, (n, nc), np.int32)
+            ge = ctx.from_device(d_e, (n,), np.uint16)
+            differs = 0
+            for i in range(n):
+                scan, iscan = oracle.get_scan(tx_size, int(tt[i]))
+                wq, wdq, we = oracle.quantize_b_adaptive(coeff[i], q, scan, ls, hbd)
+                assert np.array_equal(gq[i], wq) and np.array_equal(gdq[i], wdq) and ge[i] == we, (tx_size, qindex, i, int(tt[i]))
+                pq, _, pe = oracle.quantize_b(coeff[i], q, scan, iscan, ls, hbd)
+                differs += int(pe != we or not np.array_equal(pq, wq))
+            assert differs > 0, (tx_size, qindex)  # the adaptive rules actually fired somewhere
+            for d in (d_c, d_b, d_q, d_dq, d_e):
+                ctx.free(d)

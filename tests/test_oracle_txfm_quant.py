@@ -237,3 +237,35 @@ def test_build_quantizer_properties(oracle):
                 for x in (d, 7 * d + 3, 1000 * d // 7):
                     y = ((((x * int(q["quant"][i])) >> 16) + x) * int(q["quant_shift"][i])) >> 16
                     assert abs(y - x // d) <= 1
+
+
+def test_adaptive_quantiser_rules(oracle):
+    """orc_quantize_b_adaptive (quantize.c:16-105): equals plain quantize_b when nothing lies in the widened zone;
+    a trailing run inside zbin + dequant*325/128 is dropped wholesale; a lone +-1 inside zbin + dequant*525/128 is
+    dropped with eob 0; results never have more non-zeros than quantize_b."""
+    rng = np.random.default_rng(4)
+    q = oracle.build_quantizer_y(8, 100)
+    scan, iscan = oracle.get_scan(2, 0)
+    zb, dqv = int(q["zbin"][1]), int(q["dequant"][1])
+    big = (rng.integers(4 * dqv, 9 * dqv, 256) * rng.choice([-1, 1], 256)).astype(np.int32)
+    a, b = oracle.quantize_b(big, q, scan, iscan, 0), oracle.quantize_b_adaptive(big, q, scan, 0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] == 256
+    # head of strong coefficients, tail just above zbin (plain keeps it as level 1, adaptive pre-scan drops it)
+    c = np.zeros(256, np.int32)
+    c[scan[:10]] = 6 * dqv
+    # inside the widened zone  <=>  coeff * 32 < zbin * 32 + add  (the add is NOT scaled by the qm weight, :41-44)
+    tail_val = zb + ((dqv * 325 + 64 >> 7) - 1) // 32
+    c[scan[10:40]] = tail_val
+    pq, _, pe = oracle.quantize_b(c, q, scan, iscan, 0)
+    aq, _, ae = oracle.quantize_b_adaptive(c, q, scan, 0)
+    assert pe == 40 and ae == 10 and np.count_nonzero(aq) == 10 and np.count_nonzero(pq) == 40
+    # lone coefficient that quantises to +-1
+    for v, dropped in ((zb + ((dqv * 525 + 64 >> 7) - 1) // 32, True), (zb + (dqv * 525 + 64 >> 7) // 32 + 1, False)):
+        c = np.zeros(256, np.int32); c[scan[7]] = -v
+        pq, _, pe = oracle.quantize_b(c, q, scan, iscan, 0)
+        aq, _, ae = oracle.quantize_b_adaptive(c, q, scan, 0)
+        if abs(pq[scan[7]]) == 1:
+            assert (ae == 0 and not aq.any()) == dropped
+    for _ in range(50):
+        c = (rng.normal(0, dqv, 256)).astype(np.int32)
+        assert np.count_nonzero(oracle.quantize_b_adaptive(c, q, scan, 0)[0]) <= np.count_nonzero(oracle.quantize_b(c, q, scan, iscan, 0)[0])
