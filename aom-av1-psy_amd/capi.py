@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaomhip.so")
+LIB_PATH = os.environ.get("AOMHIP_LIB") or os.path.join(_HERE, "lib", "libaomhip.so")  # (override: kernel A/B tools)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

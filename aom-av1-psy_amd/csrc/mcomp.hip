@@ -16,6 +16,12 @@
 
 #include "common.h"
 
+// LDS window for the fine diamond steps: bit-exact, but measured 5 % SLOWER than the L1/L2 path on 4K 10-bit 16x16
+// (0.59 vs 0.56 ms per frame, tools/gpu_ab_search.sh) -- the staging costs more than the few r <= 8 steps save.  Off.
+#ifndef AOMHIP_DIAMOND_LDS_WINDOW
+#define AOMHIP_DIAMOND_LDS_WINDOW 0
+#endif
+
 namespace aomhip {
 
 struct __attribute__((packed, aligned(1))) MU128 { uint32_t v[4]; };
@@ -102,6 +108,38 @@ __device__ __forceinline__ uint32_t group8_sad(const T *sp, int sstride, const T
         const L b = *reinterpret_cast<const L *>(rp + (int64_t)row * rstride + col);
 #pragma unroll
         for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(a.v[i], b.v[i], acc);
+      }
+    }
+  }
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0xB1, 0xf, 0xf, false);
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0x4E, 0xf, 0xf, false);
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0x141, 0xf, 0xf, false);
+  return acc;
+}
+
+// The same SAD with the reference block taken from an LDS window (byte offset `off` of the block's top-left pixel,
+// row pitch `pitch` bytes, both multiples of sizeof(T)): aligned dword reads + v_alignbyte, because a misaligned
+// ds_read_b128 runs at 1/12 of the aligned rate (tools/lds_unaligned_probe.hip).  Source units from registers.
+template <typename T, int W, int H>
+__device__ __forceinline__ uint32_t group8_sad_lds(const uint32_t *win, unsigned off, int pitch, int l, bool active,
+                                                   const typename G8<T, W, H>::L (&s)[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1]) {
+  using G = G8<T, W, H>;
+  static_assert(G::KEEP, "LDS path is only instantiated for blocks whose source units stay in registers");
+  uint32_t acc = 0;
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < G::PER_LANE; ++k) {
+      const int u = l + 8 * k;
+      if (u < G::U) {
+        const int row = u / G::UPR, colb = (u % G::UPR) * G::UB;
+        const unsigned o = off + (unsigned)(row * pitch + colb);
+        const uint32_t *p = win + (o >> 2);
+        const unsigned sh = o & 3;
+        uint32_t d[G::UB / 4 + 1];
+#pragma unroll
+        for (int i = 0; i <= G::UB / 4; ++i) d[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(s[k].v[i], __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh), acc);
       }
     }
   }
@@ -299,6 +337,37 @@ __global__ __launch_bounds__(kSearchThreads, 5) void fullpel_diamond_kernel(
   typename G8<T, W, H>::L srcu[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1];
   group8_load_src<T, W, H>(sp, src.stride, l, srcu);
 
+  // LDS window for the fine steps of a search (radius <= 8): the (2*15 + H) x (2*15 + W) pixels around the current
+  // centre are staged once (about the traffic of ONE diamond step) and the remaining steps of the run -- whose
+  // sites stay within 8 + 4 + 2 + 1 = 15 pixels of that centre -- read LDS instead of the L1/L2 path.  Only for
+  // blocks up to 32 x 32 (LDS per wavefront: 4.4 KB for 16x16 16-bit, 15 KB for 32x32); a window is only ever
+  // placed over legal MV positions, so it never reaches outside the bordered plane.
+  constexpr bool kUseLds = AOMHIP_DIAMOND_LDS_WINDOW && G8<T, W, H>::KEEP && W * H <= 1024 && W >= 8;
+  constexpr int kRW = 15;
+  constexpr int kWinRows = 2 * kRW + H, kWinPitch = ((2 * kRW + W) * (int)sizeof(T) + 15) & ~15;
+  __shared__ uint32_t win_all[kUseLds ? (kSearchThreads / 64) * (kWinRows * kWinPitch / 4 + 8) : 1];
+  uint32_t *win = win_all + (kUseLds ? wave * (kWinRows * kWinPitch / 4 + 8) : 0);
+  int wr0 = INT_MIN / 2, wc0 = INT_MIN / 2;  // window origin in MV space; far away = nothing staged
+  auto stage_window = [&](int row, int col) {
+    if constexpr (kUseLds) {
+      if (b.row_max - b.row_min < 2 * kRW || b.col_max - b.col_min < 2 * kRW) return;
+      wr0 = min(max(row - kRW, (int)b.row_min), (int)b.row_max - 2 * kRW);
+      wc0 = min(max(col - kRW, (int)b.col_min), (int)b.col_max - 2 * kRW);
+      const char *g0 = reinterpret_cast<const char *>(rbase + (int64_t)wr0 * ref.stride + wc0);
+      constexpr int kCpr = kWinPitch / 16;
+      for (int q = lane; q < kWinRows * kCpr; q += 64) {
+        const int r = q / kCpr, c = q - r * kCpr;
+        const MU128 v = *reinterpret_cast<const MU128 *>(g0 + (int64_t)r * ref.stride * (int)sizeof(T) + c * 16);
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(win) + r * kWinPitch + c * 16) = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+      }
+      // one wavefront owns the window: its own LDS writes are visible to its later reads once they have retired
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    }
+  };
+  auto covered = [&](int row, int col, int r) {
+    return row - r >= wr0 && row + r <= wr0 + 2 * kRW && col - r >= wc0 && col + r <= wc0 + 2 * kRW;
+  };
+
   // radius of stage k (av1_init_dsmotion_compensation): DIAMOND 2^k, CLAMPED_DIAMOND min(2^k, 256); 11 stages
   auto radius = [level](int k) { const int r = 1 << k; return (level > 0 && r > 256) ? 256 : r; };
 
@@ -309,7 +378,7 @@ __global__ __launch_bounds__(kSearchThreads, 5) void fullpel_diamond_kernel(
     *num00 = 0;
     // (the centre is one position: group 0 evaluates it, the other seven groups would only repeat its loads)
     uint32_t s0 = group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)row * ref.stride + col, ref.stride, l, g == 0, srcu) >> shift;
-    s0 = __shfl(s0, 0, 64);
+    s0 = (uint32_t)__builtin_amdgcn_readlane((int)s0, 0);
     uint32_t bestsad = s0 + (uint32_t)cc.sad_cost(row, col);
     int is_off_center = 0;
     int next_step_size = tot_steps > 2 ? radius(tot_steps - 2) : 1;
@@ -318,13 +387,29 @@ __global__ __launch_bounds__(kSearchThreads, 5) void fullpel_diamond_kernel(
       if (step > 0) next_step_size = radius(step - 1);
       const int srow = row + dr * r, scol = col + dc * r;
       const bool inr = scol >= b.col_min && scol <= b.col_max && srow >= b.row_min && srow <= b.row_max;
-      const uint32_t mine =
-          group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)srow * ref.stride + scol, ref.stride, l, inr, srcu) >> shift;
+      uint32_t mine;
+      bool from_lds = false;
+      if constexpr (kUseLds) {
+        if (r <= 8) {
+          if (!covered(row, col, r) && step >= 2) stage_window(row, col);
+          from_lds = covered(row, col, r);
+        }
+      }
+      if constexpr (kUseLds) {
+        if (from_lds)
+          mine = group8_sad_lds<T, W, H>(win, (unsigned)((srow - wr0) * kWinPitch + (scol - wc0) * (int)sizeof(T)), kWinPitch, l,
+                                         inr, srcu) >> shift;
+        else
+          mine = group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)srow * ref.stride + scol, ref.stride, l, inr, srcu) >> shift;
+      } else {
+        mine = group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)srow * ref.stride + scol, ref.stride, l, inr, srcu) >> shift;
+      }
       int best_site = 0;
 #pragma unroll
       for (int idx = 1; idx <= 8; ++idx) {
-        const uint32_t sad = __shfl(mine, (idx - 1) * 8, 64);
-        const int ok = __shfl((int)inr, (idx - 1) * 8, 64);
+        // (v_readlane to an SGPR: every lane needs the same value; a ds_bpermute-based __shfl costs an LDS round trip)
+        const uint32_t sad = (uint32_t)__builtin_amdgcn_readlane((int)mine, (idx - 1) * 8);
+        const int ok = __builtin_amdgcn_readlane((int)inr, (idx - 1) * 8);
         const int ddr = (idx == 1 || idx == 5 || idx == 7) ? -1 : (idx == 2 || idx == 6 || idx == 8) ? 1 : 0;
         const int ddc = (idx == 3 || idx == 5 || idx == 8) ? -1 : (idx == 4 || idx == 6 || idx == 7) ? 1 : 0;
         if (ok && sad < bestsad) {
@@ -359,9 +444,12 @@ __global__ __launch_bounds__(kSearchThreads, 5) void fullpel_diamond_kernel(
   };
 
   auto var_cost_at = [&](int row, int col) -> int {  // get_mvpred_var_cost: vf(src, ref) + mv_err_cost_
+    // lanes 0..15 (one DPP row) evaluate it: the sums reduce with four DPP steps instead of twelve 64-bit shuffles,
+    // which made one variance as expensive as five diamond steps
     uint32_t sse;
-    const uint32_t v = wave_variance<T, W, H, false>(rbase + (int64_t)row * ref.stride + col, ref.stride, 0, 0, sp,
-                                                     src.stride, /*a_minus_b=*/false, bit_depth, lane, &sse);
+    uint32_t v = group16_variance<T, W, H, false>(rbase + (int64_t)row * ref.stride + col, ref.stride, 0, 0, sp, src.stride,
+                                                  /*a_minus_b=*/false, bit_depth, lane & 15, lane < 16, &sse);
+    v = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
     return (int)v + cc.var_cost(row * 8, col * 8);
   };
 

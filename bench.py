@@ -495,9 +495,31 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
     rec = ctx.planes_download(out, 0)[border:border + H, border:border + W].astype(np.int32)
     srcf = ctx.planes_download(sp.src, f_last)[border:border + H, border:border + W].astype(np.int32)
     psnr = 10 * np.log10(1023.0 ** 2 / max(np.mean((rec - srcf) ** 2), 1e-9))
+    # per-stage launch times (each stage alone, same inputs) and the algorithmic rate of the memory-bound ones
+    # (deblock / CDEF read + write each pixel once per pass; transform stages as the txq workload)
+    f0 = 0
+    px_bytes = W * H * 2
+    stage_fns = {
+        "fullpel_diamond": lambda: ctx.fullpel_diamond_batch(sp.src, sp.ref, f0, 16, 16, 0, 4, capi.MV_COST_L1_HDRES, sp.d_blocks, n, sp.d_mv, sp.d_cost),
+        "subpel_bilinear": lambda: ctx.subpel_bilinear_batch(sp.src, sp.ref, f0, 16, 16, capi.MV_COST_L1_HDRES, 2, 1, 0, sp.d_sub_blocks(f0), n, sp.d_smv, sp.d_err, sp.d_dist, sp.d_sse),
+        "pred_fullpel": lambda: ctx.build_pred_fullpel(sp.ref, f0, pred, f0, 16, 16, sp.d_blocks, sp.d_mv, n),
+        "subtract_xform_quant_16x16": lambda: ctx.subtract_xform_quant_batch(sp.src, pred, f0, 2, None, n, W // 16, 0, qp, None, d_q, d_dq, d_e),
+        "inv_txfm_add_16x16": lambda: ctx.inv_txfm_add_batch(d_dq, 2, None, n, W // 16, 0, d_e, pred, f0),
+        "deblock_vert+horz": lambda: ctx.deblock_plane(pred, f0, d_params, W // 4, 0, 3),
+        "cdef_luma": lambda: ctx.cdef_luma_plane(pred, f0, out, 0, d_pri, d_sec, fbw, d_skip, 6),
+    }
+    stage_bytes = {"pred_fullpel": 2 * px_bytes, "subtract_xform_quant_16x16": 2 * px_bytes + n * (256 * 8 + 2),
+                   "inv_txfm_add_16x16": n * 256 * 4 + 2 * px_bytes, "deblock_vert+horz": 2 * 2 * px_bytes, "cdef_luma": 2 * px_bytes}
+    stages = {}
+    for name, fn in stage_fns.items():
+        ms = kernel_avg_ms(ctx, fn, max(steps, 8))
+        stages[name] = {"ms": ms}
+        if name in stage_bytes:
+            stages[name]["algorithmic_GBs"] = stage_bytes[name] / (ms * 1e-3) / 1e9
+            stages[name]["frac_of_8TBs"] = stages[name]["algorithmic_GBs"] / HBM_PEAK_GBS
     return {"workload": "encode_inner_loop_4k_10bit", "value": steps / wall, "unit": "frames/s",
             "ms_per_frame": wall / steps * 1e3, "event_ms_per_frame": ev_ms / steps, "blocks_per_frame": n,
-            "recon_psnr_db_last_frame": float(psnr),
+            "recon_psnr_db_last_frame": float(psnr), "stages": stages,
             "config": {"frame": "3840x2160 10-bit luma", "stages": "fullpel diamond + subpel bilinear (16x16) -> fullpel pred "
                        "-> subtract+fwd_txfm2d_16x16+quantize_b q100 -> inv_txfm_add -> deblock (8x8 edges, level 32) -> "
                        "CDEF (pri 4, sec 2, damping 6)", "gpus": 1}}
