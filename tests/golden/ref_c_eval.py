@@ -40,6 +40,8 @@ I8, U8 = T(8, True, "int8_t"), T(8, False, "uint8_t")
 I16, U16 = T(16, True, "int16_t"), T(16, False, "uint16_t")
 I32, U32 = T(32, True, "int"), T(32, False, "unsigned int")
 I64, U64 = T(64, True, "int64_t"), T(64, False, "uint64_t")
+F64 = T(64, True, "double")      # the only floating type: used by the site builders ((int)(0.41 * radius) ...)
+F64.mask = None
 PTR = "ptr"      # type tag of pointer-valued expressions
 VOID = "void"
 
@@ -48,12 +50,16 @@ BASE_TYPEDEFS = {
     "int64_t": I64, "uint64_t": U64, "intptr_t": I64, "uintptr_t": U64, "size_t": U64, "ptrdiff_t": I64,
     "ssize_t": I64,
 }
-TYPE_WORDS = {"void", "char", "short", "int", "long", "signed", "unsigned", "_Bool"}
+TYPE_WORDS = {"void", "char", "short", "int", "long", "signed", "unsigned", "_Bool", "double", "float"}
 QUALIFIERS = {"const", "static", "inline", "__inline", "__inline__", "volatile", "register", "extern", "restrict",
               "__restrict", "INLINE", "AOM_INLINE", "AOM_FORCE_INLINE"}
 
 
 def wrap(v, t):
+    if t is F64:
+        return float(v)
+    if v.__class__ is float:
+        v = int(v)                 # C conversion: truncation towards zero
     v &= t.mask
     if t.signed and v >> (t.bits - 1):
         v -= 1 << t.bits
@@ -61,10 +67,12 @@ def wrap(v, t):
 
 
 def promote(t):
-    return I32 if t.bits < 32 else t
+    return I32 if t.bits < 32 else t      # (F64 has 64 bits: unchanged)
 
 
 def common(a, b):
+    if a is F64 or b is F64:
+        return F64
     a, b = promote(a), promote(b)
     if a is b:
         return a
@@ -107,6 +115,11 @@ class Ptr:
         if t.__class__ is T:
             if v is None:
                 raise CError("read of uninitialised element %d" % self.off)
+            if v < 0:
+                if not t.signed:
+                    v += t.mask + 1          # element written through a signed view of the same width
+            elif t.signed and t.mask is not None and v > (t.mask >> 1):
+                v -= t.mask + 1
             return v, t
         if t.__class__ is StructType:
             return v, t
@@ -475,6 +488,8 @@ class Parser:
         w = set(words)
         if "void" in w:
             return VOID
+        if "double" in w or "float" in w:
+            return F64
         uns = "unsigned" in w
         if "char" in w:
             return U8 if uns else I8
@@ -792,7 +807,7 @@ class Parser:
 def parse_int_literal(s):
     m = re.match(r"^(0[xX][0-9a-fA-F]+|\d+)([uUlL]*)$", s)
     if not m:
-        raise CError("floating-point literal %r not supported" % s)
+        return float(s.rstrip("fFlL")), F64
     txt, suf = m.group(1), m.group(2).lower()
     hexa = txt[:2].lower() == "0x"
     v = int(txt, 16) if hexa else (int(txt, 8) if len(txt) > 1 and txt[0] == "0" else int(txt))
@@ -1052,6 +1067,19 @@ class Interp:
                 raise CError("shift count %d out of range" % b)
             return (wrap(a << b, t) if op == "<<" else a >> b), t
         t = common(at, bt)
+        if t is F64:
+            a, b = float(a), float(b)
+            if op == "+":
+                return a + b, t
+            if op == "-":
+                return a - b, t
+            if op == "*":
+                return a * b, t
+            if op == "/":
+                return a / b, t
+            if op in ("<", ">", "<=", ">=", "==", "!="):
+                return int({"<": a < b, ">": a > b, "<=": a <= b, ">=": a >= b, "==": a == b, "!=": a != b}[op]), I32
+            raise CError("operator %s on double" % op)
         a, b = wrap(a, t), wrap(b, t)
         if op == "+":
             return wrap(a + b, t), t
@@ -1211,7 +1239,13 @@ class Interp:
                     raise CError("cast to struct")
                 return v, t
             if t is PTR:
-                return v, PTR          # pointer casts keep the buffer (element sizes never change in the evaluated code)
+                # pointer casts keep the buffer; a cast between integer types of one size gives a re-typed view
+                if (v.__class__ is Ptr and ty[0] == "ptr" and ty[1].__class__ is T and v.t.__class__ is T and ty[1] is not v.t
+                        and not v.dims):
+                    if ty[1].size != v.t.size:
+                        raise CError("pointer cast changes the element size (%s -> %s)" % (v.t, ty[1]))
+                    return Ptr(v.buf, v.off, ty[1]), PTR
+                return v, PTR
             if t.__class__ is T and v == 0:
                 return None, PTR
             raise CError("integer to pointer cast")
@@ -1702,7 +1736,11 @@ class CEval:
 
     # -- Python-side helpers
     def ctype(self, name):
-        return self.typedefs[name] if isinstance(name, str) else name
+        if not isinstance(name, str):
+            return name
+        basic = {"int": I32, "unsigned int": U32, "unsigned": U32, "char": I8, "unsigned char": U8, "short": I16,
+                 "unsigned short": U16, "long": I64, "unsigned long": U64}
+        return basic[name] if name in basic else self.typedefs[name]
 
     def array(self, values, ctype, dims=()):
         t = self.ctype(ctype)

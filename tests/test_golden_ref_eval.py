@@ -105,3 +105,63 @@ def test_sad_variance_match_reference_evaluation(oracle):
             cand["sx"], cand["sy"], cand["rx"], cand["ry"] = r["ox"], r["oy"], r["rx"], r["ry"]
             got = oracle.sad_avg_batch(a, b, 0, w, h, cand, sp, [0], bd=8)
             assert int(got[0]) == r["sad_avg"], r
+
+
+# ---- motion search: av1/encoder/mcomp.c interpreted (tests/golden/gen_ref_eval_mcomp.py)
+
+def load_mcomp():
+    z = np.load(os.path.join(GOLD, "ref_eval_mcomp.npz"))
+    meta = json.loads(bytes(z["cases"]).decode())
+    return z, meta
+
+
+def blocks_of(oracle_or_dtype, blk):
+    dt = np.dtype([(n, "<i2") for n in ("bx", "by", "start_row", "start_col", "ref_row", "ref_col", "row_min", "row_max", "col_min", "col_max")])
+    b = np.zeros(1, dt)
+    for n, v in zip(dt.names, blk):
+        b[n] = v
+    return b
+
+
+def test_fullpel_diamond_matches_reference_evaluation(oracle):
+    z, meta = load_mcomp()
+    n = 0
+    for c in meta["cases"]:
+        if c["kind"] != "diamond":
+            continue
+        mv, cost = oracle.fullpel_diamond_batch(z["src%d" % c["bd"]], z["ref%d" % c["bd"]], meta["border"], c["w"], c["h"], blocks_of(oracle, c["block"]),
+                                                clamped=int(c["method"] == "CLAMPED_DIAMOND"), step_param=c["step_param"], cost_type=c["cost_type"],
+                                                bd=c["bd"], threads=1)
+        assert (list(map(int, mv[0])), int(cost[0])) == (c["mv"], c["cost"]), c
+        n += 1
+    assert n >= 70
+
+
+def test_mesh_search_matches_reference_evaluation(oracle):
+    z, meta = load_mcomp()
+    n = 0
+    for c in meta["cases"]:
+        if c["kind"] != "mesh":
+            continue
+        mv, cost = oracle.mesh_search_batch(z["src%d" % c["bd"]], z["ref%d" % c["bd"]], meta["border"], c["w"], c["h"], blocks_of(oracle, c["block"]),
+                                            c["mesh"], fine_search_interval=c["fine_interval"], cost_type=c["cost_type"], bd=c["bd"], threads=1)
+        assert (list(map(int, mv[0])), int(cost[0])) == (c["mv"], c["cost"]), c
+        n += 1
+    assert n >= 12
+
+
+def test_subpel_tree_matches_reference_evaluation(oracle):
+    z, meta = load_mcomp()
+    n = 0
+    for c in meta["cases"]:
+        if c["kind"] != "subpel" or not c["fn"].endswith("pruned_more") or c["cost_type"] == 0:
+            continue
+        blk = list(c["block"])
+        blk[2], blk[3] = c["fullpel_mv"][0] * 8, c["fullpel_mv"][1] * 8      # starts from the full-pel optimum (1/8 pel units)
+        blk[6:10] = c["subpel_limits"]                                        # SubpelMvLimits from av1_set_subpel_mv_search_range
+        mv, err, dist, sse = oracle.subpel_bilinear_batch(z["src%d" % c["bd"]], z["ref%d" % c["bd"]], meta["border"], c["w"], c["h"], blocks_of(oracle, blk),
+                                                          cost_type=c["cost_type"], iters=c["iters"], allow_hp=c["allow_hp"], forced_stop=c["forced_stop"],
+                                                          bd=c["bd"], threads=1)
+        assert (list(map(int, mv[0])), int(err[0]), int(dist[0]), int(sse[0])) == (c["mv"], c["err"], c["distortion"], c["sse"]), c
+        n += 1
+    assert n >= 6
