@@ -16,6 +16,7 @@
 
 #include <limits.h>
 #include <stdlib.h>
+#include <string.h>
 
 typedef struct { int16_t bx, by, start_row, start_col, ref_row, ref_col, row_min, row_max, col_min, col_max; } orc_search_block;
 typedef struct { int16_t bx, by, start_row, start_col, ref_row, ref_col, row_min, row_max, col_min, col_max; } orc_subpel_block;
@@ -26,9 +27,21 @@ typedef struct {
   const void *src, *ref; /* pixel (0,0) of the block in src; pixel (0,0)+block origin of the ref plane */
   int src_stride, ref_stride, elem16, bd, w, h, cost_type;
   int ref_row, ref_col; /* ref_mv in 1/8 pel */
+  /* MV_COST_ENTROPY inputs (MV_COST_PARAMS, mcomp.h:70-84): joint[4], two tables addressed from their CENTRE */
+  const int *mvjcost, *mvcost[2];
+  int sad_per_bit, error_per_bit;
+  int skip_sad; /* ms_params->sdf is the vtable's sdsf (rows skipped): av1_make_default_fullpel_ms_params, mcomp.c:122-133 */
 } search_ctx;
 
 static unsigned sad_at(const search_ctx *c, int row, int col) { /* ms_params->sdf */
+  if (c->skip_sad) {
+    if (c->elem16)
+      return orc_highbd_sad_skip((const uint16_t *)c->src, c->src_stride,
+                                 (const uint16_t *)c->ref + (ptrdiff_t)row * c->ref_stride + col, c->ref_stride, c->w,
+                                 c->h, c->bd);
+    return orc_sad_skip((const uint8_t *)c->src, c->src_stride,
+                        (const uint8_t *)c->ref + (ptrdiff_t)row * c->ref_stride + col, c->ref_stride, c->w, c->h);
+  }
   if (c->elem16)
     return orc_highbd_sad((const uint16_t *)c->src, c->src_stride,
                           (const uint16_t *)c->ref + (ptrdiff_t)row * c->ref_stride + col, c->ref_stride, c->w, c->h,
@@ -41,6 +54,11 @@ static int mvsad_cost(const search_ctx *c, int row, int col) { /* mvsad_err_cost
   const int frr = (c->ref_row + 3 + (c->ref_row >= 0)) >> 3, frc = (c->ref_col + 3 + (c->ref_col >= 0)) >> 3;
   const int d = abs((row - frr) * 8) + abs((col - frc) * 8);
   switch (c->cost_type) {
+    case ORC_MV_COST_ENTROPY: { /* ROUND_POWER_OF_TWO((unsigned)mv_cost(diff) * sad_per_bit, AV1_PROB_COST_SHIFT = 9) */
+      const int dr = (row - frr) * 8, dc = (col - frc) * 8;
+      const unsigned bits = (unsigned)(c->mvjcost[(dc != 0) | ((dr != 0) << 1)] + c->mvcost[0][dr] + c->mvcost[1][dc]);
+      return (int)((bits * (unsigned)c->sad_per_bit + 256u) >> 9);
+    }
     case ORC_MV_COST_L1_LOWRES: return (32 * d) >> 3;
     case ORC_MV_COST_L1_MIDRES: return (15 * d) >> 3;
     case ORC_MV_COST_L1_HDRES: return (8 * d) >> 3;
@@ -50,6 +68,12 @@ static int mvsad_cost(const search_ctx *c, int row, int col) { /* mvsad_err_cost
 static int mv_cost_var(const search_ctx *c, int mrow, int mcol) { /* mv_err_cost_, mv in 1/8 pel */
   const int d = abs(mrow - c->ref_row) + abs(mcol - c->ref_col);
   switch (c->cost_type) {
+    case ORC_MV_COST_ENTROPY: { /* ROUND_POWER_OF_TWO_64((int64)mv_cost(diff) * error_per_bit, 7 + 9 - 6 + 4) */
+      if (!c->mvcost[0]) return 0;
+      const int dr = mrow - c->ref_row, dc = mcol - c->ref_col;
+      const int64_t bits = c->mvjcost[(dc != 0) | ((dr != 0) << 1)] + c->mvcost[0][dr] + c->mvcost[1][dc];
+      return (int)((bits * c->error_per_bit + (1 << 13)) >> 14);
+    }
     case ORC_MV_COST_L1_LOWRES: return (2 * d) >> 3;
     case ORC_MV_COST_L1_MIDRES: return (0 * d) >> 3;
     case ORC_MV_COST_L1_HDRES: return (1 * d) >> 3;
@@ -138,6 +162,7 @@ static void make_ctx(search_ctx *c, const void *src_origin, int src_stride, cons
   c->ref = (const char *)ref_origin + ((ptrdiff_t)by * ref_stride + bx) * e;
   c->src_stride = src_stride; c->ref_stride = ref_stride; c->elem16 = elem16; c->bd = bd; c->w = w; c->h = h;
   c->cost_type = cost_type; c->ref_row = ref_row; c->ref_col = ref_col;
+  c->mvjcost = NULL; c->mvcost[0] = c->mvcost[1] = NULL; c->sad_per_bit = c->error_per_bit = 0; c->skip_sad = 0;
 }
 
 void orc_fullpel_diamond_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride,
@@ -182,7 +207,7 @@ void orc_fullpel_diamond_batch(const void *src_origin, int src_stride, const voi
  * Literal restatement including the reference's column handling at step 1: positions are taken four at a time
  * (sdx4df), and the tail group `for (i = 0; i < end_col - c; ++i)` does NOT visit column end_col itself.
  * update_mvs_and_sad (:839-858): skip when this_sad >= best_sad, else add the MV cost and take it on strict <. */
-static int mesh_pass(const search_ctx *c, const orc_search_block *b, int *row0, int *col0, int range, int step) {
+static int mesh_pass2(const search_ctx *c, const orc_search_block *b, int *row0, int *col0, int range, int step, int *second) {
   int srow = *row0, scol = *col0;
   srow = srow < b->row_min ? b->row_min : srow > b->row_max ? b->row_max : srow; /* clamp_fullmv */
   scol = scol < b->col_min ? b->col_min : scol > b->col_max ? b->col_max : scol;
@@ -203,6 +228,10 @@ static int mesh_pass(const search_ctx *c, const orc_search_block *b, int *row0, 
         const unsigned sad = this_sad + (unsigned)mvsad_cost(c, row, col);
         if (sad < best_sad) {
           best_sad = sad;
+          if (second) { /* update_mvs_and_sad: *second_best_mv = *best_mv */
+            second[0] = best_row;
+            second[1] = best_col;
+          }
           best_row = row;
           best_col = col;
         }
@@ -212,6 +241,9 @@ static int mesh_pass(const search_ctx *c, const orc_search_block *b, int *row0, 
   *row0 = best_row;
   *col0 = best_col;
   return (int)best_sad;
+}
+static int mesh_pass(const search_ctx *c, const orc_search_block *b, int *row0, int *col0, int range, int step) {
+  return mesh_pass2(c, b, row0, col0, range, step, NULL);
 }
 
 /* patterns: MAX_MESH_STEP = 4 pairs {range, interval} (av1/encoder/speed_features.c:25-33) */
@@ -247,6 +279,473 @@ void orc_mesh_search_batch(const void *src_origin, int src_stride, const void *r
     out_mv[2 * i + 1] = (int16_t)bc;
     out_cost[i] = bestsme;
   }
+}
+
+/* =====================================================================================================
+ * av1_full_pixel_search (mcomp.c:1693-1832) for every SEARCH_METHODS value: site tables of all five builders,
+ * diamond_search_sad on tables (NSTEP has 12 sites per stage), pattern_search (:998-1226) with its 3-point
+ * refinement and cost_list bookkeeping, calc_int_sad_list (:768-821), the mesh follow-up rules and the
+ * downsampled-SAD quality re-check.  Pinned against the interpreted reference (tests/golden/ref_eval_mcomp.npz).
+ * ===================================================================================================== */
+
+enum { SM_DIAMOND, SM_NSTEP, SM_NSTEP_8PT, SM_CLAMPED_DIAMOND, SM_HEX, SM_BIGDIA, SM_SQUARE, SM_FAST_HEX, SM_FAST_DIAMOND,
+       SM_FAST_BIGDIA, SM_VFAST_DIAMOND, SM_COUNT }; /* SEARCH_METHODS, mcomp_structs.h:50-83 */
+
+/* search_site_config (mcomp_structs.h:36-48) without the stride-dependent offsets */
+typedef struct {
+  int num_search_steps;
+  int searches_per_step[22];
+  int radius[22];
+  int16_t mv[22][17][2]; /* row, col */
+} orc_sites;
+
+static void site_set(orc_sites *s, int stage, int idx, int row, int col) {
+  s->mv[stage][idx][0] = (int16_t)row;
+  s->mv[stage][idx][1] = (int16_t)col;
+}
+
+/* The 13-entry site list shared by the diamond / n-step builders (mcomp.c:366-370,405-419,452-466): centre, the four
+ * axis points, then pairs at (+-radius, +-t) and (+-t, +-radius); with t == radius the first eight are the diamond's. */
+static void step_sites(orc_sites *s, int stage, int radius, int t, int npts) {
+  const int m[13][2] = { { 0, 0 },        { -radius, 0 }, { radius, 0 },  { 0, -radius }, { 0, radius },
+                         { -radius, -t }, { radius, t },  { -t, radius }, { t, -radius }, { -radius, t },
+                         { radius, -t },  { t, radius },  { -t, -radius } };
+  for (int i = 0; i <= npts; ++i) site_set(s, stage, i, m[i][0], m[i][1]);
+  s->searches_per_step[stage] = npts;
+  s->radius[stage] = radius;
+}
+
+void orc_init_search_sites(int method, orc_sites *s) {
+  static const uint8_t lookup[SM_COUNT] = { SM_DIAMOND, SM_NSTEP,  SM_NSTEP_8PT, SM_CLAMPED_DIAMOND, SM_HEX,   SM_BIGDIA,
+                                            SM_SQUARE,  SM_HEX,    SM_BIGDIA,    SM_BIGDIA,          SM_BIGDIA }; /* mcomp.h:199-211 */
+  memset(s, 0, sizeof(*s));
+  switch (lookup[method]) {
+    case SM_DIAMOND:
+    case SM_CLAMPED_DIAMOND: { /* av1_init_dsmotion_compensation, level = CLAMPED */
+      const int level = lookup[method] == SM_CLAMPED_DIAMOND;
+      int stage = 10, n = 0;
+      for (int radius = level ? 1024 / 4 : 1024; radius > 0;) {
+        /* the diamond's diagonal sites are (-r,-r), (r,r), (-r,r), (r,-r): the n-step list with t = radius */
+        step_sites(s, stage, radius, radius, 8);
+        if (!level || (stage < 9 && level)) radius /= 2;
+        --stage;
+        ++n;
+      }
+      s->num_search_steps = n;
+      break;
+    }
+    case SM_NSTEP:
+    case SM_NSTEP_8PT: { /* av1_init_motion_compensation_nstep, level = NSTEP_8PT */
+      const int level = lookup[method] == SM_NSTEP_8PT;
+      const int num_stages = level ? 16 : 15;
+      int radius = 1;
+      for (int stage = 0; stage < num_stages; ++stage) {
+        int t = (int)(0.41 * radius), npts = 12;
+        if (t < 1) t = 1;
+        if (radius <= 5 || level) {
+          t = radius;
+          npts = 8;
+        }
+        step_sites(s, stage, radius, t, npts);
+        if (stage < 12) {
+          const double grown = radius * 1.5 + 0.5;
+          radius = (int)(grown > radius + 1 ? grown : radius + 1);
+        }
+      }
+      s->num_search_steps = num_stages;
+      break;
+    }
+    default: { /* the three pattern shapes; the largest step of scale i is 2^i (mcomp.c:476-633) */
+      const int shape = lookup[method];
+      int radius = 1;
+      for (int i = 0; i < 11; ++i, radius *= 2) {
+        const int r = radius, hf = radius / 2;
+        int n;
+        if (shape == SM_SQUARE || (shape == SM_HEX && i == 0)) {
+          const int m[8][2] = { { -r, -r }, { 0, -r }, { r, -r }, { r, 0 }, { r, r }, { 0, r }, { -r, r }, { -r, 0 } };
+          for (int j = 0; j < 8; ++j) site_set(s, i, j, m[j][0], m[j][1]);
+          n = 8;
+        } else if (shape == SM_HEX) {
+          const int m[6][2] = { { -hf, -r }, { hf, -r }, { r, 0 }, { hf, r }, { -hf, r }, { -r, 0 } };
+          for (int j = 0; j < 6; ++j) site_set(s, i, j, m[j][0], m[j][1]);
+          n = 6;
+        } else if (i == 0) { /* BIGDIA: the four closest points */
+          const int m[4][2] = { { 0, -1 }, { 1, 0 }, { 0, 1 }, { -1, 0 } };
+          for (int j = 0; j < 4; ++j) site_set(s, i, j, m[j][0], m[j][1]);
+          n = 4;
+        } else {
+          const int m[8][2] = { { -hf, -hf }, { 0, -r }, { hf, -hf }, { r, 0 }, { hf, hf }, { 0, r }, { -hf, hf }, { -r, 0 } };
+          for (int j = 0; j < 8; ++j) site_set(s, i, j, m[j][0], m[j][1]);
+          n = 8;
+        }
+        s->searches_per_step[i] = n;
+        s->radius[i] = radius;
+      }
+      s->num_search_steps = 11;
+    }
+  }
+}
+
+static int mv_in_range(const orc_search_block *b, int row, int col) { /* av1_is_fullmv_in_range */
+  return col >= b->col_min && col <= b->col_max && row >= b->row_min && row <= b->row_max;
+}
+static int check_bounds(const orc_search_block *b, int row, int col, int range) { /* mcomp.c:637-643 */
+  return (row - range) >= b->row_min && (row + range) <= b->row_max && (col - range) >= b->col_min && (col + range) <= b->col_max;
+}
+/* Number of candidates a full scan of scale `stage` really visits (mcomp.c:1046-1066,1095-1113).  Inside the limits
+ * the reference takes groups of four through sdx4df and then calls calc_sad_update_bestmv(num_candidates = n % 4,
+ * cand_start = 4 * (n / 4)), whose loop `for (i = cand_start; i < num_candidates; i++)` is EMPTY for n = 6: the last
+ * two HEX candidates are only visited by the per-candidate path taken near the limits.  Reproduced as is. */
+static int scan_count(const orc_search_block *b, int br, int bc, int stage, int n) {
+  if (!check_bounds(b, br, bc, 1 << stage)) return n;
+  const int groups = 4 * (n >> 2);
+  return (n % 4) > groups ? (n % 4) : groups;
+}
+
+/* diamond_search_sad (mcomp.c:1299-1416) on a site table; second[2] (may be NULL) follows *second_best_mv */
+static int diamond_search_sites(const search_ctx *c, const orc_search_block *b, const orc_sites *s, int search_step, int *num00,
+                                int *best_row, int *best_col, int *second) {
+  int row = b->start_row, col = b->start_col;
+  row = row < b->row_min ? b->row_min : row > b->row_max ? b->row_max : row; /* clamp_fullmv */
+  col = col < b->col_min ? b->col_min : col > b->col_max ? b->col_max : col;
+  const int tot_steps = s->num_search_steps - search_step;
+  *num00 = 0;
+  unsigned bestsad = sad_at(c, row, col) + (unsigned)mvsad_cost(c, row, col);
+  int is_off_center = 0;
+  int next_step_size = tot_steps > 2 ? s->radius[tot_steps - 2] : 1;
+  for (int step = tot_steps - 1; step >= 0; --step) {
+    int best_site = 0;
+    if (step > 0) next_step_size = s->radius[step - 1];
+    /* (the all_in / sdx4df branch and the per-site branch apply the same two-stage comparison in the same order) */
+    for (int idx = 1; idx <= s->searches_per_step[step]; ++idx) {
+      const int r = row + s->mv[step][idx][0], cc = col + s->mv[step][idx][1];
+      if (!mv_in_range(b, r, cc)) continue;
+      unsigned thissad = sad_at(c, r, cc);
+      if (thissad < bestsad) {
+        thissad += (unsigned)mvsad_cost(c, r, cc);
+        if (thissad < bestsad) {
+          bestsad = thissad;
+          best_site = idx;
+        }
+      }
+    }
+    if (best_site != 0) {
+      if (second) {
+        second[0] = row;
+        second[1] = col;
+      }
+      row += s->mv[step][best_site][0];
+      col += s->mv[step][best_site][1];
+      is_off_center = 1;
+    }
+    if (is_off_center == 0) (*num00)++;
+    if (best_site == 0) {
+      while (next_step_size == s->radius[step] && step > 2) {
+        ++(*num00);
+        --step;
+        next_step_size = s->radius[step - 1];
+      }
+    }
+  }
+  *best_row = row;
+  *best_col = col;
+  return (int)bestsad;
+}
+
+/* calc_int_sad_list (mcomp.c:768-821): cost_list[0] centre, then left, bottom, right, top */
+static void sad_cost_list(const search_ctx *c, const orc_search_block *b, int br, int bc, int *cost_list, int has_sad) {
+  static const int8_t nb[4][2] = { { 0, -1 }, { 1, 0 }, { 0, 1 }, { -1, 0 } };
+  if (!has_sad) {
+    cost_list[0] = (int)sad_at(c, br, bc);
+    for (int i = 0; i < 4; ++i) {
+      const int r = br + nb[i][0], cc = bc + nb[i][1];
+      cost_list[i + 1] = mv_in_range(b, r, cc) ? (int)sad_at(c, r, cc) : INT_MAX;
+    }
+  }
+  cost_list[0] += mvsad_cost(c, br, bc);
+  for (int i = 0; i < 4; ++i)
+    if (cost_list[i + 1] != INT_MAX) cost_list[i + 1] += mvsad_cost(c, br + nb[i][0], bc + nb[i][1]);
+}
+
+/* full_pixel_diamond (mcomp.c:1421-1470) */
+static int full_pixel_diamond_sites(const search_ctx *c, const orc_search_block *b, const orc_sites *s, int step_param,
+                                    int *cost_list, int *best_row, int *best_col, int *second) {
+  int n, num00 = 0, br, bc;
+  int bestsme = diamond_search_sites(c, b, s, step_param, &n, &br, &bc, second);
+  if (bestsme < INT_MAX) bestsme = var_cost_at(c, br, bc);
+  const int further_steps = s->num_search_steps - 1 - step_param;
+  while (n < further_steps) {
+    ++n;
+    if (num00) {
+      num00--;
+    } else {
+      int tr, tc;
+      int thissme = diamond_search_sites(c, b, s, step_param + n, &num00, &tr, &tc, second);
+      if (thissme < INT_MAX) thissme = var_cost_at(c, tr, tc);
+      if (thissme < bestsme) {
+        bestsme = thissme;
+        br = tr;
+        bc = tc;
+      }
+    }
+  }
+  if (cost_list) sad_cost_list(c, b, br, bc, cost_list, 0);
+  *best_row = br;
+  *best_col = bc;
+  return bestsme;
+}
+
+typedef struct {
+  const search_ctx *c;
+  const orc_search_block *b;
+  const orc_sites *s;
+  unsigned bestsad, raw_bestsad;
+} pat_state;
+
+/* calc_sad4 / calc_sad / calc_sad3 / calc_sad_..._with_indices (mcomp.c:862-992) in one routine: candidates idx[0..n)
+ * of scale `stage` around (br, bc) are tried in order with update_mvs_and_sad (:839-858).  Returns the winner as a
+ * POSITION in idx[] (report_pos, the 3-point forms) or as the candidate index itself; -1 = none.  A candidate
+ * outside the limits is skipped; where a cost_list is kept its entry is INT_MAX (written by the indexed form,
+ * left at its initial INT_MAX by the range form). */
+static int pat_eval(pat_state *p, int br, int bc, int stage, const int *idx, int n, int report_pos, int *cost_list) {
+  int best = -1;
+  for (int i = 0; i < n; ++i) {
+    const int index = idx[i];
+    const int r = br + p->s->mv[stage][index][0], cc = bc + p->s->mv[stage][index][1];
+    if (!mv_in_range(p->b, r, cc)) {
+      if (cost_list) cost_list[index + 1] = INT_MAX;
+      continue;
+    }
+    const unsigned this_sad = sad_at(p->c, r, cc);
+    if (cost_list) cost_list[index + 1] = (int)this_sad;
+    if (this_sad >= p->bestsad) continue;
+    const unsigned sad = this_sad + (unsigned)mvsad_cost(p->c, r, cc);
+    if (sad < p->bestsad) {
+      p->raw_bestsad = this_sad;
+      p->bestsad = sad;
+      best = report_pos ? i : index;
+    }
+  }
+  return best;
+}
+
+static int pattern_search(const search_ctx *c, const orc_search_block *b, const orc_sites *s, int search_step, int do_init_search,
+                          int *cost_list, int *best_row, int *best_col) {
+  static const int all[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
+  const int *num_candidates = s->searches_per_step;
+  const int last_is_4 = num_candidates[0] == 4;
+  pat_state p = { c, b, s, UINT_MAX, UINT_MAX };
+  int k = -1, st;
+  if (search_step > 10) search_step = 10;
+  int best_init_s = 10 - search_step; /* search_steps[] */
+  int br = b->start_row, bc = b->start_col;
+  br = br < b->row_min ? b->row_min : br > b->row_max ? b->row_max : br;
+  bc = bc < b->col_min ? b->col_min : bc > b->col_max ? b->col_max : bc;
+  if (cost_list) cost_list[0] = cost_list[1] = cost_list[2] = cost_list[3] = cost_list[4] = INT_MAX;
+  int costlist_has_sad = 0;
+  p.raw_bestsad = sad_at(c, br, bc);
+  p.bestsad = p.raw_bestsad + (unsigned)mvsad_cost(c, br, bc);
+
+  if (do_init_search) {
+    st = best_init_s;
+    best_init_s = -1;
+    for (int t = 0; t <= st; ++t) {
+      const int best_site = pat_eval(&p, br, bc, t, all, scan_count(b, br, bc, t, num_candidates[t]), 0, NULL);
+      if (best_site == -1) continue;
+      best_init_s = t;
+      k = best_site;
+    }
+    if (best_init_s != -1) {
+      br += s->mv[best_init_s][k][0];
+      bc += s->mv[best_init_s][k][1];
+    }
+  }
+
+  if (best_init_s != -1) {
+    const int last_s = (last_is_4 && cost_list != NULL);
+    int best_site = -1;
+    st = best_init_s;
+    for (; st >= last_s; st--) {
+      if (!do_init_search || st != best_init_s) {
+        best_site = pat_eval(&p, br, bc, st, all, scan_count(b, br, bc, st, num_candidates[st]), 0, NULL);
+        if (best_site == -1) continue;
+        br += s->mv[st][best_site][0];
+        bc += s->mv[st][best_site][1];
+        k = best_site;
+      }
+      do {
+        int chk[3];
+        chk[0] = (k == 0) ? num_candidates[st] - 1 : k - 1;
+        chk[1] = k;
+        chk[2] = (k == num_candidates[st] - 1) ? 0 : k + 1;
+        best_site = pat_eval(&p, br, bc, st, chk, 3, 1, NULL);
+        if (best_site != -1) {
+          k = chk[best_site];
+          br += s->mv[st][k][0];
+          bc += s->mv[st][k][1];
+        }
+      } while (best_site != -1);
+    }
+    if (st == 0) { /* only reached with a cost_list (last_s == 1) */
+      cost_list[0] = (int)p.raw_bestsad;
+      costlist_has_sad = 1;
+      if (!do_init_search || st != best_init_s) {
+        best_site = pat_eval(&p, br, bc, 0, all, 4, 0, cost_list);
+        if (best_site != -1) {
+          br += s->mv[0][best_site][0];
+          bc += s->mv[0][best_site][1];
+          k = best_site;
+        }
+      }
+      while (best_site != -1) {
+        int chk[3];
+        chk[0] = (k == 0) ? num_candidates[0] - 1 : k - 1;
+        chk[1] = k;
+        chk[2] = (k == num_candidates[0] - 1) ? 0 : k + 1;
+        cost_list[1] = cost_list[2] = cost_list[3] = cost_list[4] = INT_MAX;
+        cost_list[((k + 2) % 4) + 1] = cost_list[0];
+        cost_list[0] = (int)p.raw_bestsad;
+        best_site = pat_eval(&p, br, bc, 0, chk, 3, 1, cost_list);
+        if (best_site != -1) {
+          k = chk[best_site];
+          br += s->mv[0][k][0];
+          bc += s->mv[0][k][1];
+        }
+      }
+    }
+  }
+  *best_row = br;
+  *best_col = bc;
+  if (cost_list) sad_cost_list(c, b, br, bc, cost_list, costlist_has_sad);
+  return var_cost_at(c, br, bc);
+}
+
+typedef struct {
+  int32_t search_method, step_param, cost_type, sad_per_bit, error_per_bit;
+  int32_t skip_sad;               /* ms_params->sdf / sdx4df / sdx3df are the row-skipping forms */
+  int32_t run_mesh_search, prune_mesh_search, mesh_search_mv_diff_threshold, force_mesh_thresh;
+  int32_t fine_search_interval;
+  int32_t mesh_patterns[8];       /* {range, interval} x MAX_MESH_STEP */
+} orc_search_params;
+
+static int mesh_pass2(const search_ctx *c, const orc_search_block *b, int *row0, int *col0, int range, int step, int *second);
+
+static int full_pixel_exhaustive(const search_ctx *c, const orc_search_block *b, const orc_search_params *q, int srow, int scol,
+                                 int *cost_list, int *best_row, int *best_col, int *second) {
+  int interval = q->mesh_patterns[1], range = q->mesh_patterns[0];
+  int br = srow, bc = scol, bestsme;
+  *best_row = br;
+  *best_col = bc;
+  if (range < 7 || range > 256 || interval < 1 || interval > range) return INT_MAX;
+  const int div = range / interval;
+  const int m = abs(br) > abs(bc) ? abs(br) : abs(bc);
+  range = range > (5 * m) / 4 ? range : (5 * m) / 4;
+  range = range < 256 ? range : 256;
+  interval = interval > range / div ? interval : range / div;
+  if (q->fine_search_interval) interval = interval < 4 ? interval : 4;
+  bestsme = mesh_pass2(c, b, &br, &bc, range, interval, second);
+  if (interval > 1 && range > 7) {
+    for (int k = 1; k < 4; ++k) {
+      bestsme = mesh_pass2(c, b, &br, &bc, q->mesh_patterns[2 * k], q->mesh_patterns[2 * k + 1], second);
+      if (q->mesh_patterns[2 * k + 1] == 1) break;
+    }
+  }
+  if (bestsme < INT_MAX) bestsme = var_cost_at(c, br, bc);
+  if (cost_list) sad_cost_list(c, b, br, bc, cost_list, 0);
+  *best_row = br;
+  *best_col = bc;
+  return bestsme;
+}
+
+static int log2_area_mi(int w, int h) { /* mi_size_wide_log2 + mi_size_high_log2 (4-pixel units) */
+  int l = 0;
+  for (int v = w / 4; v > 1; v >>= 1) ++l;
+  for (int v = h / 4; v > 1; v >>= 1) ++l;
+  return l;
+}
+
+static int full_pixel_search(search_ctx *c, const orc_search_block *b, const orc_search_params *q, const orc_sites *s,
+                             int *cost_list, int *best_row, int *best_col, int *second) {
+  int var = 0, br = -32768, bc = -32768; /* MARK_MV_INVALID */
+  second[0] = second[1] = -32768;
+  for (int i = 0; i < 5; ++i) cost_list[i] = INT_MAX;
+  const int m = q->search_method, sp = q->step_param;
+  switch (m) {
+    case SM_FAST_BIGDIA: var = pattern_search(c, b, s, sp > 8 ? sp : 8, 0, cost_list, &br, &bc); break;
+    case SM_VFAST_DIAMOND: var = pattern_search(c, b, s, sp > 10 ? sp : 10, 0, cost_list, &br, &bc); break;
+    case SM_FAST_DIAMOND: var = pattern_search(c, b, s, sp > 9 ? sp : 9, 0, cost_list, &br, &bc); break;
+    case SM_FAST_HEX: var = pattern_search(c, b, s, sp > 9 ? sp : 9, 0, cost_list, &br, &bc); break;
+    case SM_HEX:
+    case SM_SQUARE:
+    case SM_BIGDIA: var = pattern_search(c, b, s, sp, 1, cost_list, &br, &bc); break;
+    default: var = full_pixel_diamond_sites(c, b, s, sp, cost_list, &br, &bc, second); break;
+  }
+  int run_mesh_search = q->run_mesh_search;
+  if (!run_mesh_search && (m == SM_NSTEP || m == SM_NSTEP_8PT)) {
+    int thr = q->force_mesh_thresh;
+    thr >>= 10 - log2_area_mi(c->w, c->h);
+    if (var > thr) run_mesh_search = 1;
+  }
+  if (q->prune_mesh_search) { /* (is_intra_mode == 0 here) */
+    const int dr = abs(b->start_row - br), dc = abs(b->start_col - bc);
+    if ((dr > dc ? dr : dc) <= q->mesh_search_mv_diff_threshold) run_mesh_search = 0;
+  }
+  if (c->skip_sad) { /* ms_params->sdf != ms_params->vfp->sdf */
+    search_ctx full = *c;
+    full.skip_sad = 0;
+    const int sad = (int)sad_at(&full, br, bc), skip_sad = (int)sad_at(c, br, bc);
+    const int thresh = 1 << log2_area_mi(c->w, c->h);
+    if (sad > thresh && abs(skip_sad - sad) * 10 >= (sad > 1 ? sad : 1) * 9)
+      return full_pixel_search(&full, b, q, s, cost_list, best_row, best_col, second);
+  }
+  if (run_mesh_search) {
+    int er, ec;
+    const int var_ex = full_pixel_exhaustive(c, b, q, br, bc, cost_list, &er, &ec, second);
+    if (var_ex < var) {
+      var = var_ex;
+      br = er;
+      bc = ec;
+    }
+  }
+  *best_row = br;
+  *best_col = bc;
+  return var;
+}
+
+/* outputs per block: mv[2], cost, cost_list[5], second_best[2] */
+void orc_full_pixel_search_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16,
+                                 int bd, int w, int h, const orc_search_params *q, const int *mvjcost, const int *mvcost0,
+                                 const int *mvcost1, const orc_search_block *blocks, int n, int16_t *out_mv, int32_t *out_cost,
+                                 int32_t *out_cost_list, int16_t *out_second, int threads) {
+  orc_sites sites;
+  orc_init_search_sites(q->search_method, &sites);
+  if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 8)
+  for (int i = 0; i < n; ++i) {
+    const orc_search_block *b = &blocks[i];
+    search_ctx c;
+    make_ctx(&c, src_origin, src_stride, ref_origin, ref_stride, elem16, bd, w, h, q->cost_type, b->bx, b->by, b->ref_row,
+             b->ref_col);
+    c.mvjcost = mvjcost; c.mvcost[0] = mvcost0; c.mvcost[1] = mvcost1; /* table centres */
+    c.sad_per_bit = q->sad_per_bit; c.error_per_bit = q->error_per_bit; c.skip_sad = q->skip_sad;
+    int br, bc, second[2], cl[5];
+    const int var = full_pixel_search(&c, b, q, &sites, cl, &br, &bc, second);
+    out_mv[2 * i] = (int16_t)br; out_mv[2 * i + 1] = (int16_t)bc;
+    out_cost[i] = var;
+    for (int k = 0; k < 5; ++k) out_cost_list[5 * i + k] = cl[k];
+    out_second[2 * i] = (int16_t)second[0]; out_second[2 * i + 1] = (int16_t)second[1];
+  }
+}
+
+/* site tables for the tests: flat (row, col) pairs of the USED sites per stage */
+int orc_search_sites_dump(int method, int *num_steps, int *per_step, int *radius, int16_t *mv /* [22][17][2] */) {
+  orc_sites s;
+  orc_init_search_sites(method, &s);
+  *num_steps = s.num_search_steps;
+  memcpy(per_step, s.searches_per_step, sizeof(s.searches_per_step));
+  memcpy(radius, s.radius, sizeof(s.radius));
+  memcpy(mv, s.mv, sizeof(s.mv));
+  return 0;
 }
 
 /* ---- bilinear sub-pel: av1_find_best_sub_pixel_tree_pruned_more, cost_list NULL ---- */

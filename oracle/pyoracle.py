@@ -452,6 +452,57 @@ def subpel_bilinear_batch(src_b, ref_b, border, w, h, blocks, cost_type=3, iters
     return mv, err, dist, sse
 
 
+SEARCH_METHODS = ["DIAMOND", "NSTEP", "NSTEP_8PT", "CLAMPED_DIAMOND", "HEX", "BIGDIA", "SQUARE", "FAST_HEX", "FAST_DIAMOND",
+                  "FAST_BIGDIA", "VFAST_DIAMOND"]      # SEARCH_METHODS values, mcomp_structs.h:50-83
+
+
+class SearchParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("search_method", "step_param", "cost_type", "sad_per_bit", "error_per_bit", "skip_sad",
+                                         "run_mesh_search", "prune_mesh_search", "mesh_search_mv_diff_threshold",
+                                         "force_mesh_thresh", "fine_search_interval")] + [("mesh_patterns", C.c_int32 * 8)]
+
+
+def search_params(method, step_param, cost_type, sad_per_bit=0, error_per_bit=0, skip_sad=0, run_mesh=0, prune_mesh=0,
+                  mesh_diff_thr=0, force_mesh_thresh=2147483647, fine_interval=0, mesh=None):
+    q = SearchParams(method if isinstance(method, int) else SEARCH_METHODS.index(method), step_param, cost_type, sad_per_bit,
+                     error_per_bit, int(skip_sad), run_mesh, prune_mesh, mesh_diff_thr, force_mesh_thresh, fine_interval)
+    for i, v in enumerate(np.asarray(mesh if mesh is not None else [[0, 0]] * 4).reshape(-1)):
+        q.mesh_patterns[i] = int(v)
+    return q
+
+
+def full_pixel_search_batch(src_b, ref_b, border, w, h, blocks, q, mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4):
+    """av1_full_pixel_search per block.  mvcost0/1: full tables (odd length); their centres are passed on.
+    -> mv [n,2], cost [n], cost_list [n,5], second_best [n,2]"""
+    blocks = np.ascontiguousarray(blocks)
+    n = len(blocks)
+    mv = np.zeros((n, 2), np.int16); cost = np.zeros(n, np.int32); cl = np.zeros((n, 5), np.int32); sec = np.zeros((n, 2), np.int16)
+    keep = []
+    def centre(t):
+        if t is None:
+            return None
+        t = np.ascontiguousarray(t, np.int32); keep.append(t)
+        return C.c_void_p(t.ctypes.data + (t.size // 2) * 4)
+    j = None
+    if mvjcost is not None:
+        jj = np.ascontiguousarray(mvjcost, np.int32); keep.append(jj); j = C.c_void_p(jj.ctypes.data)
+    lib.orc_full_pixel_search_batch.restype = None
+    lib.orc_full_pixel_search_batch(C.c_void_p(_addr(src_b, border, border)), src_b.shape[1], C.c_void_p(_addr(ref_b, border, border)),
+                                    ref_b.shape[1], int(src_b.dtype != np.uint8), bd, w, h, C.byref(q), j, centre(mvcost0), centre(mvcost1),
+                                    C.c_void_p(blocks.ctypes.data), n, C.c_void_p(mv.ctypes.data), C.c_void_p(cost.ctypes.data),
+                                    C.c_void_p(cl.ctypes.data), C.c_void_p(sec.ctypes.data), threads)
+    return mv, cost, cl, sec
+
+
+def search_sites(method):
+    """-> (num_search_steps, searches_per_step[22], radius[22], mv[22,17,2]) of the method's site table."""
+    ns = C.c_int()
+    per, rad, mv = np.zeros(22, np.int32), np.zeros(22, np.int32), np.zeros((22, 17, 2), np.int16)
+    lib.orc_search_sites_dump(method if isinstance(method, int) else SEARCH_METHODS.index(method), C.byref(ns),
+                              C.c_void_p(per.ctypes.data), C.c_void_p(rad.ctypes.data), C.c_void_p(mv.ctypes.data))
+    return ns.value, per, rad, mv
+
+
 def mv_limits_for_block(bx, by, w, h, width, height, border, ref_row=0, ref_col=0):
     """av1_set_mv_limits (mcomp.h:216-247; frame-relative, may reach border - 2*AOM_INTERP_EXTEND(4) outside the
     frame... here: block + interp extend stays inside the replicated border) intersected with

@@ -165,3 +165,38 @@ def test_subpel_tree_matches_reference_evaluation(oracle):
         assert (list(map(int, mv[0])), int(err[0]), int(dist[0]), int(sse[0])) == (c["mv"], c["err"], c["distortion"], c["sse"]), c
         n += 1
     assert n >= 6
+
+
+def test_search_site_tables_match_reference_evaluation(oracle):
+    _, meta = load_mcomp()
+    for method, ref in meta["sites"].items():
+        ns, per, rad, mv = oracle.search_sites(method)
+        assert ns == ref["num_search_steps"], method
+        first = ref["first_stage"]
+        lo = 1 if method in ("DIAMOND", "CLAMPED_DIAMOND", "NSTEP", "NSTEP_8PT") else 0
+        for i in range(ns):
+            st = i + first
+            assert per[st] == ref["searches_per_step"][i] and rad[st] == ref["radius"][i], (method, st)
+            assert mv[st, lo:lo + per[st]].tolist() == ref["mv"][i], (method, st)
+
+
+def test_full_pixel_search_matches_reference_evaluation(oracle):
+    """av1_full_pixel_search: all 11 methods x {entropy, L1, none} costs, cost lists, second-best MVs, mesh follow-ups
+    (forced / pruned), the downsampled-SAD re-check -- and full_pixel_diamond's cost list."""
+    z, meta = load_mcomp()
+    n = 0
+    for c in meta["cases"]:
+        if c["kind"] not in ("search", "diamond"):
+            continue
+        q = oracle.search_params(c["method"], c["step_param"], c["cost_type"], c.get("sad_per_bit", 20), c.get("error_per_bit", 60),
+                                 c.get("skip_sad", False), c.get("run_mesh", 0), c.get("prune_mesh", 0), c.get("mesh_diff_thr", 0),
+                                 c.get("force_mesh_thresh", 2147483647), c.get("fine_interval", 0), c.get("mesh"))
+        mv, cost, cl, sec = oracle.full_pixel_search_batch(z["src%d" % c["bd"]], z["ref%d" % c["bd"]], meta["border"], c["w"], c["h"],
+                                                           blocks_of(oracle, c["block"]), q, z["mvjcost"], z["mvcost0"], z["mvcost1"],
+                                                           bd=c["bd"], threads=1)
+        got = (mv[0].tolist(), int(cost[0]), cl[0].tolist())
+        assert got == (c["mv"], c["cost"], c["cost_list"]), (c, got)
+        if c.get("second_best") is not None and c["kind"] == "search":
+            assert sec[0].tolist() == c["second_best"], (c, sec[0].tolist())
+        n += 1
+    assert n >= 180
