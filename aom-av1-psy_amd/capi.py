@@ -23,6 +23,36 @@ class Planes(C.Structure):
                 ("stride", C.c_int32), ("border", C.c_int32), ("bit_depth", C.c_int32), ("n_frames", C.c_int32)]
 
 
+SEARCH_METHODS = ["DIAMOND", "NSTEP", "NSTEP_8PT", "CLAMPED_DIAMOND", "HEX", "BIGDIA", "SQUARE", "FAST_HEX", "FAST_DIAMOND",
+                  "FAST_BIGDIA", "VFAST_DIAMOND"]   # AOMHIP_SEARCH_* values
+
+
+class SearchParams(C.Structure):
+    """aomhip_search_params."""
+    _fields_ = [(n, C.c_int32) for n in ("search_method", "step_param", "mv_cost_type", "sad_per_bit", "error_per_bit",
+                                         "use_downsampled_sad", "run_mesh_search", "prune_mesh_search",
+                                         "mesh_search_mv_diff_threshold", "force_mesh_thresh", "fine_search_interval")] + \
+               [("mesh_patterns", C.c_int32 * 8)]
+
+    @classmethod
+    def make(cls, method, step_param, cost_type, sad_per_bit=0, error_per_bit=0, skip_sad=0, run_mesh=0, prune_mesh=0,
+             mesh_diff_thr=0, force_mesh_thresh=2147483647, fine_interval=0, mesh=None):
+        q = cls(method if isinstance(method, int) else SEARCH_METHODS.index(method), step_param, cost_type, sad_per_bit,
+                error_per_bit, int(skip_sad), run_mesh, prune_mesh, mesh_diff_thr, force_mesh_thresh, fine_interval)
+        for i, v in enumerate(np.asarray(mesh if mesh is not None else [[0, 0]] * 4).reshape(-1)):
+            q.mesh_patterns[i] = int(v)
+        return q
+
+
+def search_sites(method):
+    """aomhip_search_sites -> (num_search_steps, searches_per_step[22], radius[22], mv[22, 17, 2])."""
+    ns = C.c_int()
+    per, rad, mv = np.zeros(22, np.int32), np.zeros(22, np.int32), np.zeros((22, 17, 2), np.int16)
+    check(lib.aomhip_search_sites(method if isinstance(method, int) else SEARCH_METHODS.index(method), C.byref(ns), per.ctypes.data,
+                                  rad.ctypes.data, mv.ctypes.data), "aomhip_search_sites")
+    return ns.value, per, rad, mv
+
+
 class QuantParams(C.Structure):
     _fields_ = [(n, C.c_int16 * 2) for n in ("zbin", "round", "quant", "quant_shift", "dequant")]
 
@@ -95,6 +125,8 @@ _protos = {
     "aomhip_fullpel_diamond_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_subpel_bilinear_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_mesh_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, C.POINTER(C.c_int), _i, _vp, _i, _vp, _vp]),
+    "aomhip_full_pixel_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "aomhip_search_sites": (C.c_int, [_i, C.POINTER(C.c_int), _vp, _vp, _vp]),
     "aomhip_bind_variance_vtable": (C.c_int, [_vp, _i]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
@@ -271,6 +303,13 @@ class Context:
         check(lib.aomhip_subpel_bilinear_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, cost_type, iters,
                                                allow_hp, forced_stop, d_blocks, n, d_mv, d_err, d_dist, d_sse),
               "aomhip_subpel_bilinear_batch")
+
+    def full_pixel_search_batch(self, src, ref, frame, bw, bh, params, d_blocks, n, d_mv, d_cost, d_cost_list=None, d_second=None,
+                                d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):
+        """av1_full_pixel_search per block; params: SearchParams; d_mvcost_row/col point at the CENTRE of their tables."""
+        check(lib.aomhip_full_pixel_search_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(params), d_mvjcost,
+                                                 d_mvcost_row, d_mvcost_col, d_blocks, n, d_mv, d_cost, d_cost_list, d_second),
+              "aomhip_full_pixel_search_batch")
 
     def build_pred_fullpel(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n):
         check(lib.aomhip_build_pred_fullpel(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks,

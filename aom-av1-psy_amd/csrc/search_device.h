@@ -1,0 +1,309 @@
+// Device helpers shared by the motion-search kernels (mcomp.hip, fullpel_search.hip): 8-lanes-per-candidate SAD,
+// 16-lanes-per-candidate (sub-pel) variance, the L1 / NONE MV cost forms.  Not part of the ABI.
+#ifndef AOMHIP_CSRC_SEARCH_DEVICE_H_
+#define AOMHIP_CSRC_SEARCH_DEVICE_H_
+
+#include <climits>
+
+#include "common.h"
+
+namespace aomhip {
+
+struct __attribute__((packed, aligned(1))) MU128 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) MU64 { uint32_t v[2]; };
+struct __attribute__((packed, aligned(1))) MU32 { uint32_t v[1]; };
+template <int BYTES> struct MLoad;
+template <> struct MLoad<16> { using type = MU128; };
+template <> struct MLoad<8> { using type = MU64; };
+template <> struct MLoad<4> { using type = MU32; };
+
+enum { kCostEntropy = 0, kCostL1Low = 1, kCostL1Mid = 2, kCostL1Hd = 3, kCostNone = 4 };  // MV_COST_TYPE (mcomp.h:40-50)
+
+__device__ __forceinline__ int iabsm(int v) { return v < 0 ? -v : v; }
+
+struct CostCtx {
+  int cost_type, ref_row, ref_col;  // ref_mv in 1/8 pel
+  __device__ __forceinline__ int sad_cost(int row, int col) const {  // mvsad_err_cost_ (mcomp.c:310-339)
+    const int frr = (ref_row + 3 + (ref_row >= 0)) >> 3, frc = (ref_col + 3 + (ref_col >= 0)) >> 3;  // GET_MV_RAWPEL
+    const int d = iabsm((row - frr) * 8) + iabsm((col - frc) * 8);
+    const int lambda = cost_type == kCostL1Low ? 32 : cost_type == kCostL1Mid ? 15 : cost_type == kCostL1Hd ? 8 : 0;
+    return (lambda * d) >> 3;
+  }
+  __device__ __forceinline__ int var_cost(int mrow, int mcol) const {  // mv_err_cost_ (mcomp.c:271-308)
+    const int d = iabsm(mrow - ref_row) + iabsm(mcol - ref_col);
+    const int lambda = cost_type == kCostL1Low ? 2 : cost_type == kCostL1Mid ? 0 : cost_type == kCostL1Hd ? 1 : 0;
+    return (lambda * d) >> 3;
+  }
+};
+
+template <typename T> __device__ __forceinline__ uint32_t sadw(uint32_t a, uint32_t b, uint32_t acc) {
+  if constexpr (sizeof(T) == 1) return __builtin_amdgcn_sad_u8(a, b, acc);
+  else return __builtin_amdgcn_sad_u16(a, b, acc);
+}
+
+// Geometry of the 8-lanes-per-site SAD: row units of <= 16 bytes, lane l of a group owns units l, l + 8, ...
+template <typename T, int W, int H> struct G8 {
+  static constexpr int RB = W * (int)sizeof(T);
+  static constexpr int UB = RB < 16 ? RB : 16;
+  static constexpr int UE = UB / (int)sizeof(T);
+  static constexpr int UPR = RB / UB;
+  static constexpr int U = UPR * H;
+  static constexpr int PER_LANE = (U + 7) / 8;
+  // the lane's source units stay in registers across all the sites of a search when they fit (<= 32 VGPRs)
+  static constexpr bool KEEP = PER_LANE <= 8;
+  using L = typename MLoad<UB>::type;
+};
+
+template <typename T, int W, int H>
+__device__ __forceinline__ void group8_load_src(const T *sp, int sstride, int l, typename G8<T, W, H>::L (&s)[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1]) {
+  using G = G8<T, W, H>;
+  if constexpr (G::KEEP) {
+#pragma unroll
+    for (int k = 0; k < G::PER_LANE; ++k) {
+      const int u = min(l + 8 * k, G::U - 1);
+      const int row = u / G::UPR, col = (u % G::UPR) * G::UE;
+      s[k] = *reinterpret_cast<const typename G::L *>(sp + (int64_t)row * sstride + col);
+    }
+  }
+}
+
+// SAD of the W x H block at sp vs rp, computed by the 8 lanes of a group (l = lane & 7); all 8 get the sum.
+template <typename T, int W, int H>
+__device__ __forceinline__ uint32_t group8_sad(const T *sp, int sstride, const T *rp, int rstride, int l, bool active,
+                                               const typename G8<T, W, H>::L (&s)[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1]) {
+  using G = G8<T, W, H>;
+  using L = typename G::L;
+  uint32_t acc = 0;
+  if (active) {
+    if constexpr (G::KEEP) {
+#pragma unroll
+      for (int k = 0; k < G::PER_LANE; ++k) {
+        const int u = l + 8 * k;
+        if (u < G::U) {
+          const int row = u / G::UPR, col = (u % G::UPR) * G::UE;
+          const L b = *reinterpret_cast<const L *>(rp + (int64_t)row * rstride + col);
+#pragma unroll
+          for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(s[k].v[i], b.v[i], acc);
+        }
+      }
+    } else {
+      for (int u = l; u < G::U; u += 8) {
+        const int row = u / G::UPR, col = (u % G::UPR) * G::UE;
+        const L a = *reinterpret_cast<const L *>(sp + (int64_t)row * sstride + col);
+        const L b = *reinterpret_cast<const L *>(rp + (int64_t)row * rstride + col);
+#pragma unroll
+        for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(a.v[i], b.v[i], acc);
+      }
+    }
+  }
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0xB1, 0xf, 0xf, false);
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0x4E, 0xf, 0xf, false);
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0x141, 0xf, 0xf, false);
+  return acc;
+}
+
+// The same SAD with the reference block taken from an LDS window (byte offset `off` of the block's top-left pixel,
+// row pitch `pitch` bytes, both multiples of sizeof(T)): aligned dword reads + v_alignbyte, because a misaligned
+// ds_read_b128 runs at 1/12 of the aligned rate (tools/lds_unaligned_probe.hip).  Source units from registers.
+template <typename T, int W, int H>
+__device__ __forceinline__ uint32_t group8_sad_lds(const uint32_t *win, unsigned off, int pitch, int l, bool active,
+                                                   const typename G8<T, W, H>::L (&s)[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1]) {
+  using G = G8<T, W, H>;
+  static_assert(G::KEEP, "LDS path is only instantiated for blocks whose source units stay in registers");
+  uint32_t acc = 0;
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < G::PER_LANE; ++k) {
+      const int u = l + 8 * k;
+      if (u < G::U) {
+        const int row = u / G::UPR, colb = (u % G::UPR) * G::UB;
+        const unsigned o = off + (unsigned)(row * pitch + colb);
+        const uint32_t *p = win + (o >> 2);
+        const unsigned sh = o & 3;
+        uint32_t d[G::UB / 4 + 1];
+#pragma unroll
+        for (int i = 0; i <= G::UB / 4; ++i) d[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(s[k].v[i], __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh), acc);
+      }
+    }
+  }
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0xB1, 0xf, 0xf, false);
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0x4E, 0xf, 0xf, false);
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0x141, 0xf, 0xf, false);
+  return acc;
+}
+
+__device__ __forceinline__ int64_t wave_sum64(int64_t v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor((long long)v, m, 64);
+  return v;
+}
+
+// Variance (SUBPEL = false) or bilinear sub-pixel variance of a W x H block by all 64 lanes.  a = "ref" operand
+// (interpolated when SUBPEL), b = "src" operand; diff = A_MINUS_B ? a - b : b - a.  Returns var, *sse.
+template <typename T, int W, int H, bool SUBPEL>
+__device__ __forceinline__ uint32_t wave_variance(const T *ap, int astride, int xoff, int yoff, const T *bp, int bstride,
+                                                  bool a_minus_b, int bit_depth, int lane, uint32_t *sse_out) {
+  constexpr int UE = 4;  // pixels per unit
+  constexpr int UPR = W / UE;
+  constexpr int U = UPR * H;
+  constexpr uint8_t kBil[8][2] = { { 128, 0 }, { 112, 16 }, { 96, 32 }, { 80, 48 },
+                                   { 64, 64 }, { 48, 80 },  { 32, 96 }, { 16, 112 } };  // aom_filter.h:43-50
+  const int fx0 = kBil[xoff & 7][0], fx1 = kBil[xoff & 7][1], fy0 = kBil[yoff & 7][0], fy1 = kBil[yoff & 7][1];
+  int64_t sum = 0, sse = 0;
+  for (int u = lane; u < U; u += 64) {
+    const int row = u / UPR, col = (u % UPR) * UE;
+    const T *a0 = ap + (int64_t)row * astride + col;
+    const T *b0 = bp + (int64_t)row * bstride + col;
+    int us = 0;
+    uint32_t uq = 0;
+#pragma unroll
+    for (int i = 0; i < UE; ++i) {
+      int av;
+      if constexpr (SUBPEL) {
+        const int h0 = ((int)a0[i] * fx0 + (int)a0[i + 1] * fx1 + 64) >> 7;
+        const int h1 = ((int)a0[astride + i] * fx0 + (int)a0[astride + i + 1] * fx1 + 64) >> 7;
+        av = (h0 * fy0 + h1 * fy1 + 64) >> 7;
+        av &= (sizeof(T) == 1) ? 0xFF : 0xFFFF;
+      } else {
+        av = a0[i];
+      }
+      const int d = a_minus_b ? av - (int)b0[i] : (int)b0[i] - av;
+      us += d;
+      uq += (uint32_t)(d * d);
+    }
+    sum += us;
+    sse += uq;
+  }
+  sum = wave_sum64(sum);
+  sse = wave_sum64(sse);
+  // variance.c:141-148 / :383-420
+  int32_t s;
+  uint32_t q;
+  if (bit_depth == 10) {
+    q = (uint32_t)(((uint64_t)sse + 8) >> 4);
+    s = (int32_t)((sum + 2) >> 2);
+  } else if (bit_depth == 12) {
+    q = (uint32_t)(((uint64_t)sse + 128) >> 8);
+    s = (int32_t)((sum + 8) >> 4);
+  } else {
+    q = (uint32_t)sse;
+    s = (int32_t)sum;
+  }
+  *sse_out = q;
+  constexpr int LOG2N = __builtin_ctz(W * H);
+  const int64_t sq = ((int64_t)s * s) >> LOG2N;
+  if (bit_depth == 8) return q - (uint32_t)sq;
+  const int64_t v = (int64_t)q - sq;
+  return v >= 0 ? (uint32_t)v : 0;
+}
+
+// ---- 16 lanes per candidate: up to four independent candidates of one block are evaluated side by side -------------
+// Variance (SUBPEL = false) or bilinear sub-pixel variance of the W x H block at ap (per-GROUP pointer and phase) vs
+// the source block bp, by the 16 lanes of a group (j = lane & 15); every lane of the group returns the result.
+// Pixel units of 8 (4 for W = 4) per lane; the two Σ are reduced inside the DPP row (= the group) -- no LDS, no
+// cross-row traffic.  Semantics identical to wave_variance (aom_dsp/variance.c:56-73,91-163,342-561).
+template <typename T> __device__ __forceinline__ int px_of(const uint32_t *v, int i) {
+  if constexpr (sizeof(T) == 2) return (int)((v[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+  else return (int)((v[i >> 2] >> (8 * (i & 3))) & 0xffu);
+}
+__device__ __forceinline__ uint32_t row16_sum_u32(uint32_t v) {
+  v += __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x141, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x140, 0xf, 0xf, false);
+  return v;
+}
+__device__ __forceinline__ uint64_t row16_sum_u64(uint64_t v) {
+#define AOMHIP_STEP64(CTRL)                                                                      \
+  {                                                                                              \
+    const uint32_t lo = __builtin_amdgcn_update_dpp(0u, (uint32_t)v, CTRL, 0xf, 0xf, false);     \
+    const uint32_t hi = __builtin_amdgcn_update_dpp(0u, (uint32_t)(v >> 32), CTRL, 0xf, 0xf, false); \
+    v += ((uint64_t)hi << 32) | lo;                                                              \
+  }
+  AOMHIP_STEP64(0xB1) AOMHIP_STEP64(0x4E) AOMHIP_STEP64(0x141) AOMHIP_STEP64(0x140)
+#undef AOMHIP_STEP64
+  return v;
+}
+
+template <typename T, int W, int H, bool SUBPEL>
+__device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, int xoff, int yoff, const T *bp, int bstride,
+                                                     bool a_minus_b, int bit_depth, int j, bool active,
+                                                     uint32_t *sse_out) {
+  constexpr int UE = W >= 8 ? 8 : 4;
+  constexpr int UPR = W / UE;
+  constexpr int U = UPR * H;
+  constexpr int UB = UE * (int)sizeof(T);
+  using L = typename MLoad<UB>::type;
+  constexpr uint8_t kBil[8][2] = { { 128, 0 }, { 112, 16 }, { 96, 32 }, { 80, 48 },
+                                   { 64, 64 }, { 48, 80 },  { 32, 96 }, { 16, 112 } };  // aom_filter.h:43-50
+  const int fx0 = kBil[xoff & 7][0], fx1 = kBil[xoff & 7][1], fy0 = kBil[yoff & 7][0], fy1 = kBil[yoff & 7][1];
+  int32_t sum = 0;   // |Σd| <= 4095 * W * H < 2^31 for every block size
+  uint64_t sse = 0;
+  if (active) {
+    for (int u = j; u < U; u += 16) {
+      const int row = u / UPR, col = (u % UPR) * UE;
+      const T *a0 = ap + (int64_t)row * astride + col;
+      const L bv = *reinterpret_cast<const L *>(bp + (int64_t)row * bstride + col);
+      const L r0 = *reinterpret_cast<const L *>(a0);
+      int us = 0;
+      uint32_t uq = 0;  // 8 * 4095^2 < 2^32
+      if constexpr (SUBPEL) {
+        const L r1 = *reinterpret_cast<const L *>(a0 + astride);
+        const int e0 = a0[UE], e1 = a0[astride + UE];
+#pragma unroll
+        for (int i = 0; i < UE; ++i) {
+          const int p00 = px_of<T>(r0.v, i), p01 = i + 1 < UE ? px_of<T>(r0.v, i + 1 < UE ? i + 1 : i) : e0;
+          const int p10 = px_of<T>(r1.v, i), p11 = i + 1 < UE ? px_of<T>(r1.v, i + 1 < UE ? i + 1 : i) : e1;
+          const int h0 = (p00 * fx0 + p01 * fx1 + 64) >> 7;
+          const int h1 = (p10 * fx0 + p11 * fx1 + 64) >> 7;
+          int av = (h0 * fy0 + h1 * fy1 + 64) >> 7;
+          av &= (sizeof(T) == 1) ? 0xFF : 0xFFFF;
+          const int bvp = px_of<T>(bv.v, i);
+          const int d = a_minus_b ? av - bvp : bvp - av;
+          us += d;
+          uq += (uint32_t)(d * d);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < UE; ++i) {
+          const int av = px_of<T>(r0.v, i), bvp = px_of<T>(bv.v, i);
+          const int d = a_minus_b ? av - bvp : bvp - av;
+          us += d;
+          uq += (uint32_t)(d * d);
+        }
+      }
+      sum += us;
+      sse += uq;
+    }
+  }
+  const int64_t tsum = (int64_t)(int32_t)row16_sum_u32((uint32_t)sum);
+  const uint64_t tsse = row16_sum_u64(sse);
+  int32_t sfin;
+  uint32_t q;
+  if (bit_depth == 10) {
+    q = (uint32_t)((tsse + 8) >> 4);
+    sfin = (int32_t)((tsum + 2) >> 2);
+  } else if (bit_depth == 12) {
+    q = (uint32_t)((tsse + 128) >> 8);
+    sfin = (int32_t)((tsum + 8) >> 4);
+  } else {
+    q = (uint32_t)tsse;
+    sfin = (int32_t)tsum;
+  }
+  *sse_out = q;
+  constexpr int LOG2N = __builtin_ctz(W * H);
+  const int64_t sq = ((int64_t)sfin * sfin) >> LOG2N;
+  if (bit_depth == 8) return q - (uint32_t)sq;
+  const int64_t v = (int64_t)q - sq;
+  return v >= 0 ? (uint32_t)v : 0;
+}
+
+#define AOMHIP_FOR_BLOCK_SIZES(X)                                                                                \
+  X(4, 4) X(4, 8) X(8, 4) X(8, 8) X(8, 16) X(16, 8) X(16, 16) X(16, 32) X(32, 16) X(32, 32) X(32, 64) X(64, 32) \
+  X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(4, 16) X(16, 4) X(8, 32) X(32, 8) X(16, 64) X(64, 16)
+
+}  // namespace aomhip
+
+#endif  // AOMHIP_CSRC_SEARCH_DEVICE_H_

@@ -326,7 +326,7 @@ typedef struct {
   int16_t row_min, row_max, col_min, col_max;
 } aomhip_search_block;
 
-/* MV_COST_TYPE (av1/encoder/mcomp.h:40-50).  The entropy-table type is not implemented on the device. */
+/* MV_COST_TYPE (av1/encoder/mcomp.h:40-50).  The entropy-table type is taken by aomhip_full_pixel_search_batch only. */
 #define AOMHIP_MV_COST_ENTROPY 0
 #define AOMHIP_MV_COST_L1_LOWRES 1
 #define AOMHIP_MV_COST_L1_MIDRES 2
@@ -361,6 +361,55 @@ int aomhip_mesh_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const ao
                              int mv_cost_type, const int mesh_patterns[8], int fine_search_interval,
                              const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
                              int32_t *d_best_cost);
+
+/* SEARCH_METHODS (av1/encoder/mcomp_structs.h:50-83) */
+#define AOMHIP_SEARCH_DIAMOND 0
+#define AOMHIP_SEARCH_NSTEP 1
+#define AOMHIP_SEARCH_NSTEP_8PT 2
+#define AOMHIP_SEARCH_CLAMPED_DIAMOND 3
+#define AOMHIP_SEARCH_HEX 4
+#define AOMHIP_SEARCH_BIGDIA 5
+#define AOMHIP_SEARCH_SQUARE 6
+#define AOMHIP_SEARCH_FAST_HEX 7
+#define AOMHIP_SEARCH_FAST_DIAMOND 8
+#define AOMHIP_SEARCH_FAST_BIGDIA 9
+#define AOMHIP_SEARCH_VFAST_DIAMOND 10
+
+/* The per-call part of FULLPEL_MOTION_SEARCH_PARAMS (av1/encoder/mcomp.h:101-141) and of its MV_COST_PARAMS
+ * (:70-84); the per-block part (buffers, start MV, ref_mv, mv_limits) is aomhip_search_block. */
+typedef struct {
+  int32_t search_method;                 /* AOMHIP_SEARCH_*; selects the site table (av1_init_motion_compensation[]) */
+  int32_t step_param;
+  int32_t mv_cost_type;                  /* AOMHIP_MV_COST_* */
+  int32_t sad_per_bit, error_per_bit;    /* used by MV_COST_ENTROPY only */
+  int32_t use_downsampled_sad;           /* ms_params->sdf/sdx4df/sdx3df = the vtable's sdsf/sdsx4df (mcomp.c:122-133) */
+  int32_t run_mesh_search, prune_mesh_search, mesh_search_mv_diff_threshold, force_mesh_thresh;
+  int32_t fine_search_interval;
+  int32_t mesh_patterns[8];              /* mesh_patterns[is_intra_mode = 0]: {range, interval} x MAX_MESH_STEP */
+} aomhip_search_params;
+
+/* av1_full_pixel_search (av1/encoder/mcomp.c:1693-1832) for every block, single reference, no mask / second_pred:
+ * the dispatch on search_method -- pattern_search (:998-1226) for HEX / BIGDIA / SQUARE and their FAST_ forms,
+ * full_pixel_diamond (:1421-1470) on the DIAMOND / CLAMPED_DIAMOND / NSTEP / NSTEP_8PT tables -- then the follow-up
+ * mesh rules (run_mesh_search, force_mesh_thresh for NSTEP, prune_mesh_search), the downsampled-SAD quality re-check
+ * (:1777-1810) and full_pixel_exhaustive.
+ *   d_mvjcost (4 ints), d_mvcost_row / d_mvcost_col   MV_COST_ENTROPY tables in device memory; the two component
+ *                         pointers address the CENTRE of their tables like mv_cost_params.mvcost[] does
+ *                         (index = mv difference in 1/8 pel).  Ignored (may be NULL) for the other cost types.
+ * Outputs per block: d_best_mv (row, col), d_best_cost (the returned variance + MV cost),
+ * d_cost_list (5 ints: centre, left, bottom, right, top -- calc_int_sad_list, :768-821; may be NULL),
+ * d_second_best_mv (row, col; INVALID_MV_ROW_COL -32768 where the reference leaves it invalid; may be NULL). */
+int aomhip_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw,
+                                   int bh, const aomhip_search_params *params, const int32_t *d_mvjcost,
+                                   const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                   const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
+                                   int32_t *d_best_cost, int32_t *d_cost_list, int16_t *d_second_best_mv);
+
+/* The site table av1_init_motion_compensation[search_method_lookup[method]] builds (mcomp.c:350-634), without the
+ * stride-dependent offsets: sites[stage][index] = {row, col}; index 0 is the centre for the diamond / n-step tables,
+ * a candidate for the pattern tables.  Host only (for tests and for callers that want the table). */
+int aomhip_search_sites(int search_method, int *num_search_steps, int searches_per_step[22], int radius[22],
+                        int16_t sites[22][17][2]);
 
 /* ------------------------------------------------------------------ the encoder's kernel vtable */
 

@@ -626,6 +626,7 @@ typedef struct {
   int32_t run_mesh_search, prune_mesh_search, mesh_search_mv_diff_threshold, force_mesh_thresh;
   int32_t fine_search_interval;
   int32_t mesh_patterns[8];       /* {range, interval} x MAX_MESH_STEP */
+  int32_t no_cost_list;           /* the caller passes cost_list == NULL (changes pattern_search's last scale, :1077) */
 } orc_search_params;
 
 static int mesh_pass2(const search_ctx *c, const orc_search_block *b, int *row0, int *col0, int range, int step, int *second);
@@ -668,7 +669,8 @@ static int full_pixel_search(search_ctx *c, const orc_search_block *b, const orc
                              int *cost_list, int *best_row, int *best_col, int *second) {
   int var = 0, br = -32768, bc = -32768; /* MARK_MV_INVALID */
   second[0] = second[1] = -32768;
-  for (int i = 0; i < 5; ++i) cost_list[i] = INT_MAX;
+  if (cost_list)
+    for (int i = 0; i < 5; ++i) cost_list[i] = INT_MAX;
   const int m = q->search_method, sp = q->step_param;
   switch (m) {
     case SM_FAST_BIGDIA: var = pattern_search(c, b, s, sp > 8 ? sp : 8, 0, cost_list, &br, &bc); break;
@@ -729,7 +731,8 @@ void orc_full_pixel_search_batch(const void *src_origin, int src_stride, const v
     c.mvjcost = mvjcost; c.mvcost[0] = mvcost0; c.mvcost[1] = mvcost1; /* table centres */
     c.sad_per_bit = q->sad_per_bit; c.error_per_bit = q->error_per_bit; c.skip_sad = q->skip_sad;
     int br, bc, second[2], cl[5];
-    const int var = full_pixel_search(&c, b, q, &sites, cl, &br, &bc, second);
+    for (int k = 0; k < 5; ++k) cl[k] = INT_MAX;
+    const int var = full_pixel_search(&c, b, q, &sites, q->no_cost_list ? NULL : cl, &br, &bc, second);
     out_mv[2 * i] = (int16_t)br; out_mv[2 * i + 1] = (int16_t)bc;
     out_cost[i] = var;
     for (int k = 0; k < 5; ++k) out_cost_list[5 * i + k] = cl[k];

@@ -459,15 +459,16 @@ SEARCH_METHODS = ["DIAMOND", "NSTEP", "NSTEP_8PT", "CLAMPED_DIAMOND", "HEX", "BI
 class SearchParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("search_method", "step_param", "cost_type", "sad_per_bit", "error_per_bit", "skip_sad",
                                          "run_mesh_search", "prune_mesh_search", "mesh_search_mv_diff_threshold",
-                                         "force_mesh_thresh", "fine_search_interval")] + [("mesh_patterns", C.c_int32 * 8)]
+                                         "force_mesh_thresh", "fine_search_interval")] + [("mesh_patterns", C.c_int32 * 8), ("no_cost_list", C.c_int32)]
 
 
 def search_params(method, step_param, cost_type, sad_per_bit=0, error_per_bit=0, skip_sad=0, run_mesh=0, prune_mesh=0,
-                  mesh_diff_thr=0, force_mesh_thresh=2147483647, fine_interval=0, mesh=None):
+                  mesh_diff_thr=0, force_mesh_thresh=2147483647, fine_interval=0, mesh=None, no_cost_list=0):
     q = SearchParams(method if isinstance(method, int) else SEARCH_METHODS.index(method), step_param, cost_type, sad_per_bit,
                      error_per_bit, int(skip_sad), run_mesh, prune_mesh, mesh_diff_thr, force_mesh_thresh, fine_interval)
     for i, v in enumerate(np.asarray(mesh if mesh is not None else [[0, 0]] * 4).reshape(-1)):
         q.mesh_patterns[i] = int(v)
+    q.no_cost_list = int(no_cost_list)
     return q
 
 
