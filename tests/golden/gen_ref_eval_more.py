@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""More golden vectors from the interpreted reference (build container only; see ref_c_eval.py):
+
+  ref_eval_txfm2d.npz   av1_fwd_txfm2d_{W}x{H}_c (all 19 sizes, valid tx types) and av1_inv_txfm2d_add_{W}x{H}_c
+                        (8/10/12-bit) -- av1/encoder/av1_fwd_txfm2d.c, av1/common/av1_inv_txfm2d.c and the 1-D networks
+  ref_eval_tables.npz   update_sharpness + the hev rule of av1_loop_filter_init (av1/common/av1_loopfilter.c:47-66,
+                        118-120) for every level x sharpness; av1_build_quantizer (av1/encoder/av1_quantize.c:580-674)
+                        for 8/10/12-bit, all 256 qindex, Y / U / V with delta_q
+  ref_eval_cdef_fb.npz  av1_cdef_filter_fb (av1/common/cdef_block.c:323-426) on whole 64x64 filter blocks: luma
+                        (direction search, variance-adjusted strength) and chroma for 4:2:0 / 4:2:2 / 4:4:0 / 4:4:4
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref_c_eval as R  # noqa: E402
+from gen_ref_eval_golden import evaluator, save  # noqa: E402
+
+TX_W = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
+TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
+
+
+def gen_txfm2d():
+    import pyoracle as orc      # only av1_tx_valid (which (size, type) pairs exist) is taken from the oracle
+    ev = evaluator(["aom_dsp/txfm_common.h", "av1/common/common.h", "av1/common/common_data.h", "av1/common/av1_txfm.h", "av1/common/av1_txfm.c",
+                    "av1/encoder/av1_fwd_txfm1d.h", "av1/encoder/av1_fwd_txfm1d_cfg.h", "av1/encoder/av1_fwd_txfm1d.c", "av1/encoder/av1_fwd_txfm2d.c",
+                    "av1/common/av1_inv_txfm1d.h", "av1/common/av1_inv_txfm1d_cfg.h", "av1/common/av1_inv_txfm1d.c", "av1/common/av1_inv_txfm2d.c"])
+    rng = np.random.default_rng(20261007)
+    arrays, cases = {}, []
+    k = 0
+    for tx_size in range(19):
+        w, h = TX_W[tx_size], TX_H[tx_size]
+        n = w * h
+        types = [t for t in range(16) if orc.av1_tx_valid(tx_size, t)]
+        if n >= 1024:
+            types = types[:1] if n >= 2048 else types[:2]
+        elif n >= 256:
+            types = types[::3]
+        for tx_type in types:
+            kinds = ("max", "min", "rand9", "rand11") if tx_type == types[0] else ("rand9", "rand11")
+            if n >= 2048:
+                kinds = ("max", "rand9")
+            for kind in kinds:
+                bd = 10 if kind == "rand11" else 8
+                lim = (1 << (bd + 1)) - 1 if kind != "rand11" else 2047
+                if kind == "max":
+                    x = np.full(n, 255)
+                elif kind == "min":
+                    x = np.full(n, -255)
+                else:
+                    x = rng.integers(-(lim >> 1), (lim >> 1) + 1, n)
+                S = w + 3                                        # a stride that is not the width
+                buf = np.zeros(h * S, np.int64)
+                buf.reshape(h, S)[:, :w] = x.reshape(h, w)
+                out = ev.array([0] * n, "int32_t")
+                ev.call("av1_fwd_txfm2d_%dx%d_c" % (w, h), ev.array(buf, "int16_t"), out, S, tx_type, bd)
+                coeff = np.asarray(out.buf, np.int32)
+                arrays["x%d" % k], arrays["c%d" % k] = x.astype(np.int16), coeff
+                rec = {"tx_size": tx_size, "tx_type": tx_type, "w": w, "h": h, "bd": bd, "kind": kind}
+                # inverse: a sparsified / quantised version of the coefficients added to a random prediction
+                if kind.startswith("rand"):
+                    dq = (coeff // 8) * 8
+                    dq[np.abs(coeff) < 24] = 0
+                    if n > 1024:                                  # 64-point sizes keep only the 32 low frequencies
+                        dq = dq.reshape(-1)
+                    ibd = bd if kind == "rand11" else int(rng.choice([8, 12]))
+                    scale = 1 << (ibd - bd) if ibd >= bd else 1
+                    dst = rng.integers(0, 1 << ibd, n)
+                    dbuf = np.zeros(h * S, np.int64)
+                    dbuf.reshape(h, S)[:, :w] = dst.reshape(h, w)
+                    dp = ev.array(dbuf, "uint16_t")
+                    ev.call("av1_inv_txfm2d_add_%dx%d_c" % (w, h), ev.array(dq * scale, "int32_t"), dp, S, tx_type, ibd)
+                    arrays["dq%d" % k] = (dq * scale).astype(np.int32)
+                    arrays["p%d" % k] = dst.astype(np.uint16)
+                    arrays["r%d" % k] = np.asarray(dp.buf, np.uint16).reshape(h, S)[:, :w].copy()
+                    rec["inv_bd"] = ibd
+                cases.append(rec)
+                k += 1
+    save("ref_eval_txfm2d.npz", arrays, cases)
+
+
+def gen_tables():
+    ev = evaluator(["aom/aom_codec.h", "av1/common/seg_common.h", "av1/common/blockd.h", "av1/common/av1_loopfilter.h", "av1/common/av1_loopfilter.c", "av1/common/quant_common.h", "av1/common/quant_common.c",
+                    "av1/encoder/av1_quantize.h", "av1/encoder/av1_quantize.c"])
+    arrays = {}
+    # loop-filter thresholds: lfthr[lvl].{mblim, lim} from update_sharpness, hev_thr = lvl >> 4 (av1_loop_filter_init)
+    th = np.zeros((8, 64, 3), np.int32)
+    for sharp in range(8):
+        lfi = ev.new("loop_filter_info_n")
+        ev.interp.call("update_sharpness", [(lfi, R.PTR), (sharp, R.I32)])
+        for lvl in range(64):
+            th[sharp, lvl] = (ev.get(lfi, "lfthr[%d].mblim[0]" % lvl), ev.get(lfi, "lfthr[%d].lim[0]" % lvl), lvl >> 4)
+            assert ev.get(lfi, "lfthr[%d].lim[15]" % lvl) == th[sharp, lvl, 1]
+    arrays["lpf_thresholds"] = th
+    # quantiser tables
+    bits = {8: "AOM_BITS_8", 10: "AOM_BITS_10", 12: "AOM_BITS_12"}
+    for bd in (8, 10, 12):
+        for (ydc, udc, uac, vdc, vac) in ((0, 0, 0, 0, 0), (-7, 5, -3, 9, 12)):
+            if bd != 8 and ydc:
+                continue
+            qs, dq = ev.new("QUANTS"), ev.new("Dequants")
+            t0 = time.time()
+            ev.call("av1_build_quantizer", ev.globs[bits[bd]].buf[0], ydc, udc, uac, vdc, vac, qs, dq)
+            for plane in "yuv":
+                tab = np.zeros((256, 5, 8), np.int32)
+                for f, name in enumerate(("%s_zbin", "%s_round", "%s_quant", "%s_quant_shift")):
+                    tab[:, f, :] = np.asarray(ev.field(qs, name % plane).buf, np.int64).reshape(256, 8)
+                tab[:, 4, :] = np.asarray(ev.field(dq, "%s_dequant_QTX" % plane).buf, np.int64).reshape(256, 8)
+                arrays["quant_%s_bd%d_%s" % (plane, bd, "d" if ydc else "0")] = tab.astype(np.int16)
+            print("  build_quantizer bd %d: %.1f s" % (bd, time.time() - t0))
+    save("ref_eval_tables.npz", arrays, [{"deltas": [-7, 5, -3, 9, 12]}])
+
+
+def gen_cdef_fb():
+    ev = evaluator(["aom/aom_image.h", "av1/common/cdef_block.h", "av1/common/cdef.h", "av1/common/cdef_block.c"])
+    bstride = ev.interp.ev(R.Parser(ev.pp.expand(R.tokenize("CDEF_BSTRIDE")), ev.typedefs).expr())[0]
+    VL = 0x4000
+    rng = np.random.default_rng(20261008)
+    arrays, cases = {}, []
+    k = 0
+    P = 192                                          # luma plane; the filter block under test is the centre 64x64
+    for bd in (8, 10):
+        mx = (1 << bd) - 1
+        yy, xx = np.mgrid[0:P, 0:P]
+        luma = np.clip(mx // 2 + (mx // 5) * np.sin(xx / 9.0 + yy / 17.0) + (mx // 7) * ((xx // 23 + yy // 29) % 2)
+                       + rng.integers(-(6 << (bd - 8)), (6 << (bd - 8)) + 1, (P, P)), 0, mx).astype(np.int64)
+        arrays["luma%d" % bd] = luma.astype(np.uint16)
+        for (xdec, ydec, pli) in ((0, 0, 0), (1, 1, 1), (1, 0, 1), (0, 1, 1), (0, 0, 1)):
+            for (level, sec, damping, at_edge) in ((4, 2, 6, 0), (9, 0, 5, 0), (0, 4, 3, 0), (15, 1, 4, 1), (1, 2, 6, 1)):
+                if pli and (level, sec) == (9, 0) and bd == 10:
+                    continue
+                plane = luma if not pli else np.ascontiguousarray(luma[::(1 << ydec), ::(1 << xdec)])
+                pw, ph = 64 >> xdec, 64 >> ydec             # the filter block in this plane
+                y0, x0 = (0, 0) if at_edge else (ph, pw)     # at_edge: the top-left filter block (frame edges above / left)
+                tile = np.full((ph + 4 + 2, bstride), VL, np.int64)      # 2 border rows above and below (+ spare)
+                # cdef_prepare_fb semantics: available neighbours are copied, frame edges are CDEF_VERY_LARGE
+                for r in range(-2, ph + 2):
+                    for c0, c1 in ((-8, pw + 8),):
+                        ys = y0 + r
+                        if ys < 0 or ys >= plane.shape[0]:
+                            continue
+                        xs0, xs1 = max(x0 + c0, 0), min(x0 + c1, plane.shape[1])
+                        tile[r + 2, 8 + (xs0 - x0):8 + (xs1 - x0)] = plane[ys, xs0:xs1]
+                skip = rng.random((8, 8)) < 0.2
+                dl = [(by, bx) for by in range(8) for bx in range(8) if not skip[by, bx]]
+                dlist = ev.interp.alloc(("arr", ev.typedefs["cdef_list"], 64), True)
+                for i, (by, bx) in enumerate(dl):
+                    ev.set(dlist, "[%d].by" % i, by); ev.set(dlist, "[%d].bx" % i, bx)
+                dirs = ev.interp.alloc(("arr", ("arr", R.I32, 16), 16), True)
+                var = ev.interp.alloc(("arr", ("arr", R.I32, 16), 16), True)
+                if pli:                                     # chroma reuses the luma directions: give it a full table
+                    ldir = rng.integers(0, 8, (16, 16))
+                    for i, v in enumerate(ldir.ravel()):
+                        dirs.buf[i] = int(v)
+                    arrays["ld%d" % k] = ldir[:8, :8].astype(np.uint8)
+                inp = ev.array(tile.ravel(), "uint16_t")
+                use8 = bd == 8
+                dst = ev.array(plane[y0:y0 + ph, x0:x0 + pw].ravel(), "uint8_t" if use8 else "uint16_t")
+                ev.call("av1_cdef_filter_fb", dst if use8 else None, None if use8 else dst, pw, inp.add(2 * bstride + 8), xdec, ydec,
+                        dirs.deref()[0], None, var.deref()[0], pli, dlist.deref()[0], len(dl), level, sec, damping, bd - 8)
+                arrays["o%d" % k] = np.asarray(dst.buf, np.uint16).reshape(ph, pw)
+                arrays["s%d" % k] = skip.astype(np.uint8)
+                if not pli:
+                    arrays["d%d" % k] = np.asarray(dirs.buf, np.int32).reshape(16, 16)[:8, :8]
+                    arrays["v%d" % k] = np.asarray(var.buf, np.int32).reshape(16, 16)[:8, :8]
+                cases.append({"bd": bd, "xdec": xdec, "ydec": ydec, "pli": pli, "level": level, "sec": sec, "damping": damping, "at_edge": at_edge,
+                              "y0": y0, "x0": x0, "pw": pw, "ph": ph})
+                k += 1
+    save("ref_eval_cdef_fb.npz", arrays, cases)
+
+
+if __name__ == "__main__":
+    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb"]:
+        t = time.time()
+        globals()["gen_" + w]()
+        print("  (%s: %.1f s)" % (w, time.time() - t))

@@ -1165,6 +1165,8 @@ class Interp:
                 return st.deref()
             if name in self.funcs or name in self.pycalls or name in self.protos:
                 return FuncRef(name), PTR
+            if name + "_c" in self.funcs:       # rtcd name used as a function-pointer value (generic target: the _c symbol)
+                return FuncRef(name + "_c"), PTR
             raise CError("unknown identifier %s" % name)
         if k == "bin":
             op = node[1]
@@ -1292,12 +1294,17 @@ class Interp:
             return self.sizeof(node[1]), U64
         if k == "sizeof_e":
             inner = node[1]
-            if inner[0] == "var":
-                st = self.lookup(inner[1])
+            if inner[0] == "var" or inner[0] == "member":     # sizeof an object (arrays do not decay here)
+                st = self.lookup(inner[1]) if inner[0] == "var" else self.member_storage(inner)
                 n = 1
                 for d in st.dims:
                     n *= d
                 return n * self.sizeof(st.t), U64
+            if inner[0] == "deref" or inner[0] == "index":    # sizeof(*p), sizeof(p[i]): the operand is not evaluated
+                pv = self.ev(inner[1])[0] if inner[0] == "deref" else self.ev(("bin", "+", inner[1], inner[2]))[0]
+                if pv.__class__ is not Ptr:
+                    raise CError("sizeof through a non-pointer")
+                return self.sizeof(pv.t) * (pv.stride if pv.dims else 1), U64
             v, t = self.ev(inner)
             if t is PTR:
                 return (self.sizeof(v.t) * v.stride if v.__class__ is Ptr and v.dims else 8), U64

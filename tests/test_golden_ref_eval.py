@@ -200,3 +200,69 @@ def test_full_pixel_search_matches_reference_evaluation(oracle):
             assert sec[0].tolist() == c["second_best"], (c, sec[0].tolist())
         n += 1
     assert n >= 180
+
+
+# ---- 2-D transforms, threshold / quantiser tables, whole CDEF filter blocks (tests/golden/gen_ref_eval_more.py)
+
+def test_txfm2d_matches_reference_evaluation(oracle):
+    z, cases = load("ref_eval_txfm2d.npz")
+    assert len(cases) >= 300 and len({c["tx_size"] for c in cases}) == 19
+    n_inv = 0
+    for k, c in enumerate(cases):
+        w, h = c["w"], c["h"]
+        got = oracle.fwd_txfm2d(z["x%d" % k].reshape(h, w), c["tx_size"], c["tx_type"], c["bd"])
+        nn = min(w, 32) * min(h, 32)      # 64-point sizes: only the re-packed 32 low frequencies are defined (av1_fwd_txfm2d.c:241-312)
+        assert np.array_equal(got[:nn], z["c%d" % k][:nn]), c
+        if "inv_bd" in c:
+            rec = oracle.inv_txfm2d_add(z["dq%d" % k][:nn], z["p%d" % k].reshape(h, w), c["tx_size"], c["tx_type"], c["inv_bd"])
+            assert np.array_equal(rec, z["r%d" % k]), c
+            n_inv += 1
+    assert n_inv >= 200
+
+
+def test_lpf_thresholds_and_quantizer_tables_match_reference_evaluation(oracle):
+    z, _ = load("ref_eval_tables.npz")
+    th = z["lpf_thresholds"]
+    for sharp in range(8):
+        for lvl in range(64):
+            a, b, c = C.c_uint8(), C.c_uint8(), C.c_uint8()
+            oracle.lib.orc_lpf_thresholds(lvl, sharp, C.byref(a), C.byref(b), C.byref(c))
+            assert [a.value, b.value, c.value] == th[sharp, lvl].tolist(), (sharp, lvl)
+    for bd in (8, 10, 12):
+        tab = z["quant_y_bd%d_0" % bd]          # [qindex, {zbin, round, quant, quant_shift, dequant}, 8 lanes]
+        for qindex in range(256):
+            q = oracle.build_quantizer_y(bd, qindex)
+            for f, name in enumerate(("zbin", "round", "quant", "quant_shift", "dequant")):
+                assert q[name].tolist() == tab[qindex, f, :2].tolist(), (bd, qindex, name)
+                assert (tab[qindex, f, 2:] == tab[qindex, f, 1]).all()     # lanes 2..7 replicate the AC entry
+    # the delta_q planes: dc/ac lookups at shifted indices (orc_dc_q / orc_ac_q are what a caller builds U/V tables from)
+    oracle.lib.orc_dc_q.restype = oracle.lib.orc_ac_q.restype = C.c_int16
+    ydc, udc, uac, vdc, vac = -7, 5, -3, 9, 12
+    for plane, (ddc, dac) in (("y", (ydc, 0)), ("u", (udc, uac)), ("v", (vdc, vac))):
+        tab = z["quant_%s_bd8_d" % plane]
+        for qindex in (0, 1, 17, 128, 250, 255):
+            assert tab[qindex, 4, 0] == oracle.lib.orc_dc_q(qindex, ddc, 8) and tab[qindex, 4, 1] == oracle.lib.orc_ac_q(qindex, dac, 8)
+
+
+def test_cdef_filter_block_64x64_matches_reference_evaluation(oracle):
+    z, cases = load("ref_eval_cdef_fb.npz")
+    assert len(cases) >= 40
+    for k, c in enumerate(cases):
+        bd, xdec, ydec = c["bd"], c["xdec"], c["ydec"]
+        luma = z["luma%d" % bd]
+        plane = np.ascontiguousarray((luma if not c["pli"] else luma[::(1 << ydec), ::(1 << xdec)]).astype(np.uint8 if bd == 8 else np.uint16))
+        fby, fbx = (0, 0) if c["at_edge"] else (1, 1)
+        skip = np.ones((24, 24), np.uint8)                                  # only the filter block under test is processed
+        skip[fby * 8:fby * 8 + 8, fbx * 8:fbx * 8 + 8] = z["s%d" % k]
+        pri, sec = np.full((3, 3), c["level"], np.uint8), np.full((3, 3), c["sec"], np.uint8)
+        ys, xs = slice(c["y0"], c["y0"] + c["ph"]), slice(c["x0"], c["x0"] + c["pw"])
+        if not c["pli"]:
+            out, d, v = oracle.cdef_plane_luma(plane, pri, sec, skip, c["damping"], bd)
+            keep = z["s%d" % k] == 0
+            assert np.array_equal(d[fby * 8:fby * 8 + 8, fbx * 8:fbx * 8 + 8][keep], z["d%d" % k][keep].astype(np.uint8)), c
+            assert np.array_equal(v[fby * 8:fby * 8 + 8, fbx * 8:fbx * 8 + 8][keep], z["v%d" % k][keep]), c
+        else:
+            ld = np.zeros((24, 24), np.uint8)
+            ld[fby * 8:fby * 8 + 8, fbx * 8:fbx * 8 + 8] = z["ld%d" % k]
+            out = oracle.cdef_plane_chroma(plane, xdec, ydec, ld, pri, sec, skip, c["damping"], bd)
+        assert np.array_equal(out[ys, xs].astype(np.uint16), z["o%d" % k]), c
