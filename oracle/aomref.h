@@ -19,9 +19,13 @@
  * evaluating the reference's straight-line 1-D transform statements
  * (tests/golden/ref_txfm1d_eval.py), (c) the reference tests' double-precision
  * transform tolerance bounds, and (d) every constant table compared with the
- * initialisers parsed out of the reference sources.  Families with no such pin
- * (quantize_b, loop filter, CDEF, mcomp) are marked "parity unpinned" in
- * DESIGN.md.
+ * initialisers parsed out of the reference sources, and (e) for EVERY family --
+ * SAD, variance, subtract, the 2-D transforms, the quantisers and their tables,
+ * the loop filters and their thresholds, CDEF (block and filter-block level) and
+ * the whole of the motion search -- golden vectors obtained by interpreting the
+ * reference's own C functions where they lie (tests/golden/ref_c_eval.py, a
+ * C-subset interpreter; fixtures tests/golden/ref_eval_*.npz, checked by
+ * tests/test_golden_ref_eval.py).  No family is left "parity unpinned".
  */
 #ifndef AOMREF_ORACLE_H_
 #define AOMREF_ORACLE_H_

@@ -3,9 +3,10 @@
  * TEST INFRASTRUCTURE ONLY (see aomref.h).  Restates av1/common/cdef_block.c:57-426, the constrain()
  * of av1/common/cdef.h:59-67 and the per-64x64 logic of av1/common/cdef.c:138-345.
  *
- * PARITY UNPINNED: the reference's CDEF gtests are SIMD-vs-C only (test/cdef_test.cc:408-436).
- * tests/test_oracle_cdef.py checks definitional properties (direction of synthetic ramps, zero
- * strength = identity, flat areas untouched, clamp to the tap range).
+ * PINNED by interpreting the reference's cdef_find_dir_c, cdef_filter_{8,16}_{0..3}_c and av1_cdef_filter_fb
+ * (luma + the four chroma subsamplings, whole 64x64 filter blocks) on seeded inputs: tests/golden/ref_eval_cdef.npz,
+ * ref_eval_cdef_fb.npz, checked bit for bit in tests/test_golden_ref_eval.py.  (The reference's own CDEF gtests are
+ * SIMD-vs-C only, test/cdef_test.cc:408-436.)  tests/test_oracle_cdef.py adds definitional properties.
  */
 #include "aomref.h"
 

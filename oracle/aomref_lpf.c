@@ -12,7 +12,9 @@
  * tests/test_oracle_lpf_cdef.py checks these against the reference's literal tap listings by
  * evaluating the reference's own statements.
  *
- * PARITY UNPINNED beyond that: the reference's lpf gtests are SIMD-vs-C only (test/lpf_test.cc).
+ * PINNED by interpreting the reference's aom_[highbd_]lpf_{horizontal,vertical}_{4,6,8,14}_c (720 cases, 8/10/12-bit)
+ * and update_sharpness (every level x sharpness): tests/golden/ref_eval_lpf.npz, ref_eval_tables.npz, checked bit for
+ * bit in tests/test_golden_ref_eval.py.  (The reference's own lpf gtests are SIMD-vs-C only, test/lpf_test.cc.)
  */
 #include "aomref.h"
 

@@ -9,8 +9,10 @@
  * The kernels are reached through the per-block-size vtable (aom_dsp/variance.h:84-103): sdf / vf / svf
  * with the 10/12-bit wrappers of av1/encoder/encoder_utils.h.
  *
- * PARITY UNPINNED: no reference unit test drives mcomp.c; tests check convergence on
- * content with a known shift and definitional properties only.
+ * PINNED by interpreting the reference's mcomp.c itself (full_pixel_diamond, av1_full_pixel_search for all 11 search
+ * methods, full_pixel_exhaustive, the sub-pel trees; 8/10-bit; every MV cost type; cost lists; second-best MVs) with
+ * its own site builders and its own SAD / variance functions in the vtable: tests/golden/ref_eval_mcomp.npz
+ * (generator tests/golden/gen_ref_eval_mcomp.py), checked bit for bit in tests/test_golden_ref_eval.py.
  */
 #include "aomref.h"
 

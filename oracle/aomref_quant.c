@@ -5,9 +5,10 @@
  * of av1/common/scan.c (generated from their zig-zag / row / column rule instead of 7 900
  * literal entries; tests compare every generated table with the reference initialiser).
  *
- * PARITY UNPINNED for the two quantise functions: the reference's only tests for them are
- * SIMD-vs-C (test/quantize_func_test.cc), so there is no independent known answer; they are
- * short and were restated statement by statement.
+ * PINNED by interpreting the reference's aom_[highbd_]quantize_b{,_32x32,_64x64}[_adaptive]_c (688 cases) and
+ * av1_build_quantizer (8/10/12-bit, all 256 qindex, Y/U/V with delta_q): tests/golden/ref_eval_quant.npz,
+ * ref_eval_tables.npz, checked bit for bit in tests/test_golden_ref_eval.py.  (The reference's own tests for the
+ * quantisers are SIMD-vs-C only, test/quantize_func_test.cc.)
  */
 #include "aomref.h"
 
@@ -150,7 +151,7 @@ int orc_get_scan(int tx_size, int tx_type, int16_t *scan, int16_t *iscan) {
 /* aom_quantize_b_adaptive_helper_c / aom_highbd_quantize_b_adaptive_helper_c (aom_dsp/quantize.c:16-105,173-258),
  * qm_ptr == iqm_ptr == NULL; EOB_FACTOR 325, SKIP_EOB_FACTOR_ADJUST 200 (aom_dsp/quantize.h:23-24).  Literal:
  * backward pre-scan over a dead zone widened by dequant * 325 / 128, forward quantisation of what is left, and the
- * "single +-1 coefficient" kill with the zone widened by dequant * 525 / 128.  PARITY UNPINNED like quantize_b. */
+ * "single +-1 coefficient" kill with the zone widened by dequant * 525 / 128.  Pinned like quantize_b (file header). */
 void orc_quantize_b_adaptive(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
                              const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
                              const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale, int highbd) {

@@ -5,7 +5,7 @@
   * every constant table == the reference initialiser (live) / its committed sha256;
   * forward 2-D transform within the reference gtest's double-precision error bounds
     (test/av1_fwd_txfm2d_test.cc:145-187), inverse(forward(x)) within test/av1_inv_txfm2d_test.cc's;
-  * quantize_b: "parity unpinned" in the reference (SIMD-vs-C tests only) -> definitional properties."""
+  * quantize_b: definitional properties here; pinned against the interpreted reference in test_golden_ref_eval.py."""
 import hashlib
 import json
 import math
