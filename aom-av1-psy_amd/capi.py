@@ -44,6 +44,14 @@ class SearchParams(C.Structure):
         return q
 
 
+SUBPEL_TREES = {"pruned_more": 0, "pruned": 1, "tree": 2}
+
+
+class SubpelParams(C.Structure):
+    """aomhip_subpel_params."""
+    _fields_ = [(n, C.c_int32) for n in ("tree", "mv_cost_type", "error_per_bit", "iters_per_step", "allow_hp", "forced_stop")]
+
+
 def search_sites(method):
     """aomhip_search_sites -> (num_search_steps, searches_per_step[22], radius[22], mv[22, 17, 2])."""
     ns = C.c_int()
@@ -127,6 +135,7 @@ _protos = {
     "aomhip_mesh_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, C.POINTER(C.c_int), _i, _vp, _i, _vp, _vp]),
     "aomhip_full_pixel_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_search_sites": (C.c_int, [_i, C.POINTER(C.c_int), _vp, _vp, _vp]),
+    "aomhip_subpel_tree_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_bind_variance_vtable": (C.c_int, [_vp, _i]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
@@ -310,6 +319,12 @@ class Context:
         check(lib.aomhip_full_pixel_search_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(params), d_mvjcost,
                                                  d_mvcost_row, d_mvcost_col, d_blocks, n, d_mv, d_cost, d_cost_list, d_second),
               "aomhip_full_pixel_search_batch")
+
+    def subpel_tree_batch(self, src, ref, frame, bw, bh, params, d_blocks, n, d_mv, d_err, d_dist, d_sse, d_cost_list=None,
+                          d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):
+        check(lib.aomhip_subpel_tree_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(params), d_mvjcost,
+                                           d_mvcost_row, d_mvcost_col, d_blocks, d_cost_list, n, d_mv, d_err, d_dist, d_sse),
+              "aomhip_subpel_tree_batch")
 
     def build_pred_fullpel(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n):
         check(lib.aomhip_build_pred_fullpel(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks,

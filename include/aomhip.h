@@ -350,6 +350,27 @@ int aomhip_subpel_bilinear_batch(aomhip_ctx *ctx, const aomhip_planes *src, cons
                                  const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
                                  uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse);
 
+/* The three bilinear sub-pel searches with everything the scalar calls take: `tree` 0 =
+ * av1_find_best_sub_pixel_tree_pruned_more (mcomp.c:2844-2929), 1 = _pruned (:2931-3067), 2 = av1_find_best_sub_pixel_tree
+ * (:3069-3133: first_level_check_fast + second_level_check_v2 per precision); subpel_search_type USE_2_TAPS_ORIG,
+ * unscaled reference, last_mv_search_list == NULL.
+ *   d_cost_list    5 ints per block as aomhip_full_pixel_search_batch wrote them (ms_params->cost_list), or NULL: a
+ *                  usable list replaces the first two-level check (pruned_more: minimum of the fitted cost surface,
+ *                  get_cost_surf_min; pruned: the three candidates of the cheaper quadrant)
+ *   d_mvjcost ...  MV_COST_ENTROPY tables (component pointers at the table CENTRES, index = 1/8-pel difference) with
+ *                  error_per_bit; ignored for the other cost types
+ * Blocks and outputs as aomhip_subpel_bilinear_batch. */
+typedef struct {
+  int32_t tree;                 /* 0 pruned_more, 1 pruned, 2 tree */
+  int32_t mv_cost_type;         /* AOMHIP_MV_COST_* */
+  int32_t error_per_bit;
+  int32_t iters_per_step, allow_hp, forced_stop;
+} aomhip_subpel_params;
+int aomhip_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                             const aomhip_subpel_params *params, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                             const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, const int32_t *d_cost_list,
+                             int n_blocks, int16_t *d_best_mv, uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse);
+
 /* full_pixel_exhaustive (av1/encoder/mcomp.c:1547-1617): the mesh search av1_full_pixel_search (:1693-1832) runs as a
  * follow-up / for intra block copy.  mesh_patterns = MAX_MESH_STEP (4) pairs {range, interval} on the HOST (a row of
  * good_quality_mesh_patterns / intrabc_mesh_patterns, av1/encoder/speed_features.c:25-43); the first pair is grown

@@ -772,7 +772,7 @@ static unsigned svf_at(const search_ctx *c, int mrow, int mcol, uint32_t *sse) {
                                 mrow & 7, (const uint8_t *)c->src, c->src_stride, c->w, c->h, sse);
 }
 
-static unsigned check_better_fast(subpel_state *s, int mrow, int mcol) {
+static unsigned check_better_fast2(subpel_state *s, int mrow, int mcol, int *is_better) {
   if (mcol < s->col_min || mcol > s->col_max || mrow < s->row_min || mrow > s->row_max) return INT_MAX;
   uint32_t sse;
   const int thismse = (int)svf_at(s->c, mrow, mcol, &sse);
@@ -783,18 +783,42 @@ static unsigned check_better_fast(subpel_state *s, int mrow, int mcol) {
     s->best_col = mcol;
     s->distortion = thismse;
     s->sse1 = sse;
+    *is_better |= 1;
   }
   return cost;
 }
+static unsigned check_better_fast(subpel_state *s, int mrow, int mcol) {
+  int dummy = 0;
+  return check_better_fast2(s, mrow, mcol, &dummy);
+}
 
-static void two_level_checks_fast(subpel_state *s, int trow, int tcol, int hstep, int iters) {
-  /* first_level_check_fast */
+/* first_level_check_fast (mcomp.c:2503-2543): four cardinal candidates, then the diagonal they point at */
+static void first_level_check_fast(subpel_state *s, int trow, int tcol, int hstep, int *drow_out, int *dcol_out) {
   const unsigned left = check_better_fast(s, trow, tcol - hstep);
   const unsigned right = check_better_fast(s, trow, tcol + hstep);
   const unsigned up = check_better_fast(s, trow - hstep, tcol);
   const unsigned down = check_better_fast(s, trow + hstep, tcol);
   const int drow = up <= down ? -hstep : hstep, dcol = left <= right ? -hstep : hstep; /* get_best_diag_step */
   check_better_fast(s, trow + drow, tcol + dcol);
+  *drow_out = drow;
+  *dcol_out = dcol;
+}
+
+/* second_level_check_v2 (mcomp.c:2665-2716), bilinear branch */
+static void second_level_check_v2(subpel_state *s, int trow, int tcol, int drow, int dcol) {
+  if (trow == s->best_row && tcol == s->best_col) return;
+  if (trow == s->best_row) drow = -drow;
+  else if (tcol == s->best_col) dcol = -dcol;
+  const int br = s->best_row, bc = s->best_col;
+  int has_better = 0;
+  check_better_fast2(s, br + drow, bc, &has_better);
+  check_better_fast2(s, br, bc + dcol, &has_better);
+  if (has_better) check_better_fast2(s, br + drow, bc + dcol, &has_better);
+}
+
+static void two_level_checks_fast(subpel_state *s, int trow, int tcol, int hstep, int iters) {
+  int drow, dcol;
+  first_level_check_fast(s, trow, tcol, hstep, &drow, &dcol);
   if (iters <= 1) return;
   /* second_level_check_fast */
   const int br = s->best_row, bc = s->best_col;
@@ -843,6 +867,86 @@ void orc_subpel_bilinear_batch(const void *src_origin, int src_stride, const voi
     int hstep = 4; /* INIT_SUBPEL_STEP_SIZE */
     if (forced_stop != 3) {
       two_level_checks_fast(&s, b->start_row, b->start_col, hstep, iters_per_step);
+      if (forced_stop < 2) {
+        hstep >>= 1;
+        two_level_checks_fast(&s, s.best_row, s.best_col, hstep, iters_per_step);
+      }
+      if (allow_hp && forced_stop == 0) {
+        hstep >>= 1;
+        two_level_checks_fast(&s, s.best_row, s.best_col, hstep, iters_per_step);
+      }
+    }
+    out_mv[2 * i] = (int16_t)s.best_row;
+    out_mv[2 * i + 1] = (int16_t)s.best_col;
+    out_err[i] = s.besterr;
+    out_distortion[i] = s.distortion;
+    out_sse[i] = s.sse1;
+  }
+}
+
+/* ---- the three bilinear sub-pel trees with an optional cost list and every MV cost type ----
+ * tree: 0 av1_find_best_sub_pixel_tree_pruned_more (mcomp.c:2844-2929), 1 _pruned (:2931-3067), 2 _tree (:3069-3133),
+ * subpel_search_type USE_2_TAPS_ORIG, unscaled reference, last_mv_search_list == NULL.
+ * cost_lists: 5 ints per block (what av1_full_pixel_search returned) or NULL. */
+static int divide_and_round(int n, int d) { return ((n < 0) ^ (d < 0)) ? ((n - d / 2) / d) : ((n + d / 2) / d); }
+
+void orc_subpel_tree_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16, int bd,
+                           int w, int h, int tree, int cost_type, int error_per_bit, const int *mvjcost, const int *mvcost0,
+                           const int *mvcost1, int iters_per_step, int allow_hp, int forced_stop,
+                           const orc_subpel_block *blocks, const int32_t *cost_lists, int n, int16_t *out_mv, uint32_t *out_err,
+                           int32_t *out_distortion, uint32_t *out_sse, int threads) {
+  if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 16)
+  for (int i = 0; i < n; ++i) {
+    const orc_subpel_block *b = &blocks[i];
+    search_ctx c;
+    make_ctx(&c, src_origin, src_stride, ref_origin, ref_stride, elem16, bd, w, h, cost_type, b->bx, b->by, b->ref_row,
+             b->ref_col);
+    c.mvjcost = mvjcost; c.mvcost[0] = mvcost0; c.mvcost[1] = mvcost1; c.error_per_bit = error_per_bit;
+    subpel_state s = { &c, b->row_min, b->row_max, b->col_min, b->col_max, INT_MAX, 0, 0, b->start_row, b->start_col };
+    { /* setup_center_error (:2718-2778): vf(ref at the full-pel part, src) */
+      uint32_t sse;
+      unsigned v;
+      const int fr = b->start_row >> 3, fc = b->start_col >> 3;
+      if (elem16)
+        v = orc_highbd_variance((const uint16_t *)c.ref + (ptrdiff_t)fr * ref_stride + fc, ref_stride,
+                                (const uint16_t *)c.src, src_stride, w, h, bd, &sse, NULL);
+      else
+        v = orc_variance((const uint8_t *)c.ref + (ptrdiff_t)fr * ref_stride + fc, ref_stride, (const uint8_t *)c.src,
+                         src_stride, w, h, &sse, NULL);
+      s.distortion = (int)v;
+      s.sse1 = sse;
+      s.besterr = v + (unsigned)mv_cost_var(&c, b->start_row, b->start_col);
+    }
+    int hstep = 4; /* INIT_SUBPEL_STEP_SIZE */
+    const int sr = b->start_row, sc = b->start_col;
+    if (tree == 2) {
+      int round = 3 - forced_stop; /* FULL_PEL - forced_stop */
+      if (round > 3 - !allow_hp) round = 3 - !allow_hp;
+      for (int iter = 0; iter < round; ++iter) {
+        const int cr = s.best_row, cc = s.best_col;
+        int drow, dcol;
+        first_level_check_fast(&s, cr, cc, hstep, &drow, &dcol);
+        if (!(cr == s.best_row && cc == s.best_col) && iters_per_step > 1) second_level_check_v2(&s, cr, cc, drow, dcol);
+        hstep >>= 1;
+      }
+    } else if (forced_stop != 3) {
+      const int32_t *cl = cost_lists ? cost_lists + 5 * i : NULL;
+      const int usable = cl && cl[0] != INT_MAX && cl[1] != INT_MAX && cl[2] != INT_MAX && cl[3] != INT_MAX && cl[4] != INT_MAX;
+      if (tree == 0 && usable && cl[0] < cl[1] && cl[0] < cl[2] && cl[0] < cl[3] && cl[0] < cl[4]) {
+        /* get_cost_surf_min(bits = 1): minimum of the fitted paraboloid in half-pel units */
+        const int ic = divide_and_round((cl[1] - cl[3]) * 1, cl[1] - 2 * cl[0] + cl[3]);
+        const int ir = divide_and_round((cl[4] - cl[2]) * 1, cl[4] - 2 * cl[0] + cl[2]);
+        if (ir != 0 || ic != 0) check_better_fast(&s, sr + ir * hstep, sc + ic * hstep);
+      } else if (tree == 1 && usable) {
+        const unsigned whichdir = (cl[1] < cl[3] ? 0 : 1) + (cl[2] < cl[4] ? 0 : 2);
+        const int dc = (whichdir & 1) ? hstep : -hstep, dr = (whichdir & 2) ? -hstep : hstep; /* right : left, top : bottom */
+        check_better_fast(&s, sr, sc + dc);
+        check_better_fast(&s, sr + dr, sc);
+        check_better_fast(&s, sr + dr, sc + dc);
+      } else {
+        two_level_checks_fast(&s, sr, sc, hstep, iters_per_step);
+      }
       if (forced_stop < 2) {
         hstep >>= 1;
         two_level_checks_fast(&s, s.best_row, s.best_col, hstep, iters_per_step);

@@ -452,6 +452,36 @@ def subpel_bilinear_batch(src_b, ref_b, border, w, h, blocks, cost_type=3, iters
     return mv, err, dist, sse
 
 
+SUBPEL_TREES = {"pruned_more": 0, "pruned": 1, "tree": 2}
+
+
+def subpel_tree_batch(src_b, ref_b, border, w, h, blocks, tree="pruned_more", cost_type=3, error_per_bit=0, mvjcost=None,
+                      mvcost0=None, mvcost1=None, iters=2, allow_hp=1, forced_stop=0, cost_lists=None, bd=8, threads=4):
+    """The three bilinear sub-pel trees (tree: pruned_more / pruned / tree) with an optional per-block cost list."""
+    blocks = np.ascontiguousarray(blocks)
+    n = len(blocks)
+    mv = np.zeros((n, 2), np.int16); err = np.zeros(n, np.uint32); dist = np.zeros(n, np.int32); sse = np.zeros(n, np.uint32)
+    keep = []
+    def centre(t):
+        if t is None:
+            return None
+        t = np.ascontiguousarray(t, np.int32); keep.append(t)
+        return C.c_void_p(t.ctypes.data + (t.size // 2) * 4)
+    j = None
+    if mvjcost is not None:
+        jj = np.ascontiguousarray(mvjcost, np.int32); keep.append(jj); j = C.c_void_p(jj.ctypes.data)
+    cl = None
+    if cost_lists is not None:
+        cla = np.ascontiguousarray(cost_lists, np.int32).reshape(n, 5); keep.append(cla); cl = C.c_void_p(cla.ctypes.data)
+    lib.orc_subpel_tree_batch.restype = None
+    lib.orc_subpel_tree_batch(C.c_void_p(_addr(src_b, border, border)), src_b.shape[1], C.c_void_p(_addr(ref_b, border, border)),
+                              ref_b.shape[1], int(src_b.dtype != np.uint8), bd, w, h, SUBPEL_TREES.get(tree, tree), cost_type,
+                              error_per_bit, j, centre(mvcost0), centre(mvcost1), iters, allow_hp, forced_stop,
+                              C.c_void_p(blocks.ctypes.data), cl, n, C.c_void_p(mv.ctypes.data), C.c_void_p(err.ctypes.data),
+                              C.c_void_p(dist.ctypes.data), C.c_void_p(sse.ctypes.data), threads)
+    return mv, err, dist, sse
+
+
 SEARCH_METHODS = ["DIAMOND", "NSTEP", "NSTEP_8PT", "CLAMPED_DIAMOND", "HEX", "BIGDIA", "SQUARE", "FAST_HEX", "FAST_DIAMOND",
                   "FAST_BIGDIA", "VFAST_DIAMOND"]      # SEARCH_METHODS values, mcomp_structs.h:50-83
 

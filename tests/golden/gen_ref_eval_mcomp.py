@@ -348,10 +348,49 @@ def main():
                     err = ev.call(fn, make_xd(ev), None, sp, start.buf[0], best, dist, sse, None)
                     lim = [ev.get(sp, "mv_limits." + k) for k in ("row_min", "row_max", "col_min", "col_max")]
                     cases.append(dict(kind="subpel", fn=fn, bd=bd, w=w, h=h, block=list(blk), fullpel_mv=fp["mv"], cost_type=COST_TYPES[cost_type],
-                                      allow_hp=allow_hp, forced_stop=forced_stop, iters=iters, subpel_limits=lim,
+                                      allow_hp=allow_hp, forced_stop=forced_stop, iters=iters, subpel_limits=lim, error_per_bit=60,
                                       mv=[ev.get(best, "row"), ev.get(best, "col")], err=err, distortion=dist.buf[0], sse=sse.buf[0],
                                       sec_s=round(time.time() - t1, 2)))
     print("subpel: %d cases, %.0f s" % (len(cases) - n0, time.time() - t0))
+    # 5. the sub-pel trees driven by a cost list, as the encoder does: cost_list = what av1_full_pixel_search returned
+    #    (appended after the sections above with its own generator so that the earlier cases keep their values)
+    n0 = len(cases)
+    rng2 = np.random.default_rng(20261009)
+    for bd in (8, 10):
+        hs = harness[bd]
+        for fn in ("av1_find_best_sub_pixel_tree_pruned_more", "av1_find_best_sub_pixel_tree_pruned"):
+            for cost_type in ("L1_HDRES", "ENTROPY", "NONE"):
+                for trial in range(3 if bd == 8 else 1):
+                    w, h = (16, 16) if trial != 1 else (8, 8)
+                    bx, by = int(rng2.integers(0, (W - w) // 4 + 1)) * 4, int(rng2.integers(0, (H - h) // 4 + 1)) * 4
+                    blk = (bx, by, 0, 0, int(rng2.integers(-30, 31)), int(rng2.integers(-30, 31))) + limits(bx, by, w, h, 24)
+                    method = ("NSTEP", "BIGDIA", "HEX")[trial]
+                    fp = run_fullpel("search", bd, w, h, blk, method, 2, cost_type, sad_per_bit=25, error_per_bit=70)
+                    cases.pop()
+                    allow_hp, forced_stop, iters = int(rng2.integers(0, 2)), int(rng2.integers(0, 2)), int(rng2.integers(1, 3))
+                    sp = ev.new("SUBPEL_MOTION_SEARCH_PARAMS")
+                    ev.set(sp, "allow_hp", allow_hp); ev.set(sp, "forced_stop", forced_stop); ev.set(sp, "iters_per_step", iters)
+                    ev.set(sp, "cost_list", ev.array(fp["cost_list"], "int"))
+                    fl = ev.new("FullMvLimits")
+                    for k, v in zip(("row_min", "row_max", "col_min", "col_max"), blk[6:]):
+                        ev.set(fl, k, v)
+                    refmv = hs.mv_struct("MV", blk[4], blk[5])
+                    ev.interp.call("av1_set_subpel_mv_search_range", [(ev.field(sp, "mv_limits"), R.PTR), (fl, R.PTR), (refmv, R.PTR)])
+                    hs.cost_params(sp, "mv_cost_params.", cost_type, blk[4], blk[5], 25, 70)
+                    ev.set(sp, "var_params.vfp", hs.vtable(w, h))
+                    ev.set(sp, "var_params.subpel_search_type", hs.const("USE_2_TAPS_ORIG"))
+                    ev.set(sp, "var_params.ms_buffers.ref", hs.buf2d(hs.refp, by, bx)); ev.set(sp, "var_params.ms_buffers.src", hs.buf2d(hs.srcp, by, bx))
+                    ev.set(sp, "var_params.w", w); ev.set(sp, "var_params.h", h)
+                    start = hs.mv_struct("MV", fp["mv"][0] * 8, fp["mv"][1] * 8)
+                    best = ev.new("MV")
+                    dist, sse = ev.array([0], "int"), ev.array([0], "unsigned int")
+                    err = ev.call(fn, make_xd(ev), None, sp, start.buf[0], best, dist, sse, None)
+                    lim = [ev.get(sp, "mv_limits." + k) for k in ("row_min", "row_max", "col_min", "col_max")]
+                    cases.append(dict(kind="subpel", fn=fn, bd=bd, w=w, h=h, block=list(blk), fullpel_mv=fp["mv"], cost_type=COST_TYPES[cost_type],
+                                      allow_hp=allow_hp, forced_stop=forced_stop, iters=iters, subpel_limits=lim, cost_list=fp["cost_list"],
+                                      error_per_bit=70, mv=[ev.get(best, "row"), ev.get(best, "col")], err=err, distortion=dist.buf[0],
+                                      sse=sse.buf[0]))
+    print("subpel with cost list: %d cases, %.0f s" % (len(cases) - n0, time.time() - t0))
     # the site tables themselves (G1): every builder, as (stage, index) -> (row, col), searches_per_step, radius
     sites = {}
     for m in METHODS:

@@ -151,20 +151,30 @@ def test_mesh_search_matches_reference_evaluation(oracle):
 
 
 def test_subpel_tree_matches_reference_evaluation(oracle):
+    """av1_find_best_sub_pixel_tree{_pruned_more,_pruned,} (bilinear): with and without a cost list, every MV cost type."""
     z, meta = load_mcomp()
-    n = 0
+    n, with_cl = 0, 0
     for c in meta["cases"]:
-        if c["kind"] != "subpel" or not c["fn"].endswith("pruned_more") or c["cost_type"] == 0:
+        if c["kind"] != "subpel":
             continue
         blk = list(c["block"])
         blk[2], blk[3] = c["fullpel_mv"][0] * 8, c["fullpel_mv"][1] * 8      # starts from the full-pel optimum (1/8 pel units)
         blk[6:10] = c["subpel_limits"]                                        # SubpelMvLimits from av1_set_subpel_mv_search_range
-        mv, err, dist, sse = oracle.subpel_bilinear_batch(z["src%d" % c["bd"]], z["ref%d" % c["bd"]], meta["border"], c["w"], c["h"], blocks_of(oracle, blk),
-                                                          cost_type=c["cost_type"], iters=c["iters"], allow_hp=c["allow_hp"], forced_stop=c["forced_stop"],
-                                                          bd=c["bd"], threads=1)
+        tree = {"av1_find_best_sub_pixel_tree_pruned_more": "pruned_more", "av1_find_best_sub_pixel_tree_pruned": "pruned",
+                "av1_find_best_sub_pixel_tree": "tree"}[c["fn"]]
+        args = (z["src%d" % c["bd"]], z["ref%d" % c["bd"]], meta["border"], c["w"], c["h"], blocks_of(oracle, blk))
+        mv, err, dist, sse = oracle.subpel_tree_batch(*args, tree=tree, cost_type=c["cost_type"], error_per_bit=c["error_per_bit"],
+                                                      mvjcost=z["mvjcost"], mvcost0=z["mvcost0"], mvcost1=z["mvcost1"], iters=c["iters"],
+                                                      allow_hp=c["allow_hp"], forced_stop=c["forced_stop"],
+                                                      cost_lists=[c["cost_list"]] if "cost_list" in c else None, bd=c["bd"], threads=1)
         assert (list(map(int, mv[0])), int(err[0]), int(dist[0]), int(sse[0])) == (c["mv"], c["err"], c["distortion"], c["sse"]), c
+        if tree == "pruned_more" and "cost_list" not in c and c["cost_type"] != 0:     # the older entry point agrees
+            got = oracle.subpel_bilinear_batch(*args, cost_type=c["cost_type"], iters=c["iters"], allow_hp=c["allow_hp"],
+                                               forced_stop=c["forced_stop"], bd=c["bd"], threads=1)
+            assert np.array_equal(got[0], mv) and int(got[1][0]) == c["err"]
         n += 1
-    assert n >= 6
+        with_cl += "cost_list" in c
+    assert n >= 48 and with_cl >= 24
 
 
 def test_search_site_tables_match_reference_evaluation(oracle):

@@ -166,3 +166,98 @@ def test_full_pixel_search_rejects_bad_arguments(hip, ctx):
     for d in (d_b, d_mv, d_c):
         ctx.free(d)
     ctx.planes_free(ps); ctx.planes_free(pr)
+
+
+# ---- the bilinear sub-pel trees (aomhip_subpel_tree_batch)
+
+def _run_subpel(hip, ctx, ps, pr, bw, bh, blocks, tree, cost_type, error_per_bit, iters, allow_hp, forced_stop, cost_lists=None,
+                tables=None):
+    n = len(blocks)
+    d_b = ctx.to_device(blocks)
+    d_mv, d_e, d_d, d_s = (ctx.malloc(max(16, n * 4)) for _ in range(4))
+    keep, extra = [], {}
+    if cost_lists is not None:
+        d_cl = ctx.to_device(np.ascontiguousarray(cost_lists, np.int32)); keep.append(d_cl); extra["d_cost_list"] = d_cl
+    if tables is not None:
+        j, c0, c1 = (np.ascontiguousarray(t, np.int32) for t in tables)
+        dj, d0, d1 = ctx.to_device(j), ctx.to_device(c0), ctx.to_device(c1)
+        keep += [dj, d0, d1]
+        extra.update(d_mvjcost=dj, d_mvcost_row=d0 + 4 * (c0.size // 2), d_mvcost_col=d1 + 4 * (c1.size // 2))
+    p = hip.capi.SubpelParams(hip.capi.SUBPEL_TREES.get(tree, tree), cost_type, error_per_bit, iters, allow_hp, forced_stop)
+    ctx.subpel_tree_batch(ps, pr, 0, bw, bh, p, d_b, n, d_mv, d_e, d_d, d_s, **extra)
+    out = (ctx.from_device(d_mv, (n, 2), np.int16), ctx.from_device(d_e, (n,), np.uint32), ctx.from_device(d_d, (n,), np.int32),
+           ctx.from_device(d_s, (n,), np.uint32))
+    for d in [d_b, d_mv, d_e, d_d, d_s] + keep:
+        ctx.free(d)
+    return out
+
+
+def test_subpel_trees_match_reference_goldens(hip, ctx):
+    z = np.load(os.path.join(GOLD, "ref_eval_mcomp.npz"))
+    meta = json.loads(bytes(z["cases"]).decode())
+    W, H, border = meta["W"], meta["H"], meta["border"]
+    planes = {}
+    for bd in (8, 10):
+        ps, pr = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+        ctx.planes_upload(ps, 0, np.ascontiguousarray(z["src%d" % bd][border:border + H, border:border + W]))
+        ctx.planes_upload(pr, 0, np.ascontiguousarray(z["ref%d" % bd][border:border + H, border:border + W]))
+        planes[bd] = (ps, pr)
+    tables = (z["mvjcost"], z["mvcost0"], z["mvcost1"])
+    n = 0
+    for c in meta["cases"]:
+        if c["kind"] != "subpel":
+            continue
+        blk = np.zeros(1, hip.capi.search_block_dtype)
+        vals = list(c["block"])
+        vals[2], vals[3] = c["fullpel_mv"][0] * 8, c["fullpel_mv"][1] * 8
+        vals[6:10] = c["subpel_limits"]
+        for name, v in zip(blk.dtype.names, vals):
+            blk[name] = v
+        tree = {"av1_find_best_sub_pixel_tree_pruned_more": "pruned_more", "av1_find_best_sub_pixel_tree_pruned": "pruned",
+                "av1_find_best_sub_pixel_tree": "tree"}[c["fn"]]
+        ps, pr = planes[c["bd"]]
+        mv, err, dist, sse = _run_subpel(hip, ctx, ps, pr, c["w"], c["h"], blk, tree, c["cost_type"], c["error_per_bit"], c["iters"],
+                                         c["allow_hp"], c["forced_stop"], [c["cost_list"]] if "cost_list" in c else None, tables)
+        assert (mv[0].tolist(), int(err[0]), int(dist[0]), int(sse[0])) == (c["mv"], c["err"], c["distortion"], c["sse"]), c
+        n += 1
+    assert n >= 48
+    for ps, pr in planes.values():
+        ctx.planes_free(ps); ctx.planes_free(pr)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bw,bh", [(16, 16), (8, 8), (32, 16), (4, 8), (64, 64)])
+def test_subpel_trees_match_oracle(hip, oracle, ctx, bw, bh, bd):
+    rng = np.random.default_rng(bw * 7 + bh + bd)
+    W, H, border = 320, 192, 96
+    src, ref = hip.synth.shifted_smooth_pair(W, H, bw + bd, bd, shift=(int(rng.integers(-5, 6)), int(rng.integers(-5, 6))))
+    ref = np.clip(ref.astype(np.int32) + rng.integers(-2 << (bd - 8), (2 << (bd - 8)) + 1, ref.shape), 0, (1 << bd) - 1).astype(ref.dtype)
+    ps, pr = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(ps, 0, src); ctx.planes_upload(pr, 0, ref)
+    sb, rb = oracle.extend_plane(src, border, ps.stride), oracle.extend_plane(ref, border, pr.stride)
+    n = 151
+    fb = _mk_blocks(hip, oracle, rng, W, H, bw, bh, border, n, start_range=4, ref_range=30)
+    tables = _cost_tables(rng)
+    # full-pel stage (NSTEP) gives the start MVs and the cost lists, as in the encoder
+    q = oracle.search_params("NSTEP", 3, 3, 20, 60)
+    fmv, _, cl, _ = oracle.full_pixel_search_batch(sb, rb, border, bw, bh, fb, q, *tables, bd=bd)
+    blocks = fb.copy()
+    blocks["start_row"], blocks["start_col"] = fmv[:, 0] * 8, fmv[:, 1] * 8
+    # av1_set_subpel_mv_search_range (mcomp.h:345-368)
+    for i in range(n):
+        rr, rc = int(blocks["ref_row"][i]), int(blocks["ref_col"][i])
+        blocks["col_min"][i] = max(int(fb["col_min"][i]) * 8, rc - 8184, -16383 + 0)
+        blocks["col_max"][i] = min(int(fb["col_max"][i]) * 8, rc + 8184, 16383)
+        blocks["row_min"][i] = max(int(fb["row_min"][i]) * 8, rr - 8184, -16383)
+        blocks["row_max"][i] = min(int(fb["row_max"][i]) * 8, rr + 8184, 16383)
+    cl[::9, 2] = 2147483647          # some unusable lists
+    for tree in ("pruned_more", "pruned", "tree"):
+        for cost_type, use_cl, iters, allow_hp, forced_stop in ((3, True, 2, 1, 0), (0, True, 1, 0, 1), (4, False, 2, 1, 0), (1, True, 2, 1, 2),
+                                                                (0, False, 2, 0, 0), (3, False, 1, 1, 3)):
+            got = _run_subpel(hip, ctx, ps, pr, bw, bh, blocks, tree, cost_type, 77, iters, allow_hp, forced_stop, cl if use_cl else None, tables)
+            want = oracle.subpel_tree_batch(sb, rb, border, bw, bh, blocks, tree=tree, cost_type=cost_type, error_per_bit=77, mvjcost=tables[0],
+                                            mvcost0=tables[1], mvcost1=tables[2], iters=iters, allow_hp=allow_hp, forced_stop=forced_stop,
+                                            cost_lists=cl if use_cl else None, bd=bd)
+            for name, a, w_ in zip(("mv", "err", "dist", "sse"), got, want):
+                assert np.array_equal(a, w_), (tree, cost_type, use_cl, iters, allow_hp, forced_stop, name)
+    ctx.planes_free(ps); ctx.planes_free(pr)

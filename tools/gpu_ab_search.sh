@@ -1,9 +1,11 @@
-mkdir -p gpurun_out/r01u
-python -m pytest tests/test_gpu_mcomp.py -x -q -m gpu 2>&1 | tail -3
+#!/bin/bash
+# A/B of motion-search kernel builds: gpurun -- 'bash tools/gpu_ab_search.sh "lib1.so lib2.so"'  ("" = the shipped library)
+LIBS=${1:-""}
+python -m pytest tests/test_gpu_mcomp.py -x -q -m gpu 2>&1 | tail -2
 for r in 1 2; do
-for v in "" aom-av1-psy_amd/lib/libaomhip_nolds.so; do
-echo "== lib=$v"
-AOMHIP_LIB=$v python bench.py --workload search_4k_10bit --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
+for v in "" $LIBS; do
+echo "== lib=${v:-shipped}"
+AOMHIP_LIB=$v python bench.py --workload search_4k_10bit --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('ms/frame %.4f  blocks/s %.4g parity %s' % (d['ms_per_step'], d['value'], d.get('parity_sample_slot0')))"
 done; done
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01u/search -o k -- python bench.py --workload search_4k_10bit --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/r01u/search.json 2>gpurun_out/r01u/search.err
-cut -c1-150 gpurun_out/r01u/search/*kernel_stats.csv | head -5
