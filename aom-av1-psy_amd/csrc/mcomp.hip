@@ -222,12 +222,16 @@ struct SubpelCostTables {
   int error_per_bit;
 };
 
-template <typename T, int W, int H>
+// GENERAL = false is the lean instantiation behind aomhip_subpel_bilinear_batch (pruned_more, no cost list, L1 / no MV
+// cost): the extra arguments and branches of the general form cost it 2 % on the 4K search benchmark.
+template <typename T, int W, int H, bool GENERAL>
 __global__ __launch_bounds__(kSearchThreads, AOMHIP_SUBPEL_WAVES) void subpel_bilinear_kernel(
     PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
-    int cost_type, int iters_per_step, int allow_hp, int forced_stop, int bit_depth, int tree,
-    const int32_t *__restrict__ cost_lists, SubpelCostTables ct, int16_t *__restrict__ out_mv,
+    int cost_type, int iters_per_step, int allow_hp, int forced_stop, int bit_depth, int tree_arg,
+    const int32_t *__restrict__ cost_lists_arg, SubpelCostTables ct, int16_t *__restrict__ out_mv,
     uint32_t *__restrict__ out_err, int32_t *__restrict__ out_dist, uint32_t *__restrict__ out_sse) {
+  const int tree = GENERAL ? tree_arg : 0;
+  const int32_t *cost_lists = GENERAL ? cost_lists_arg : nullptr;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bi = blockIdx.x * (kSearchThreads / 64) + wave;
   if (bi >= n_blocks) return;
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(kSearchThreads, AOMHIP_SUBPEL_WAVES) void subpel_bi
   const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)b.by * ref.stride + b.bx;
   const CostCtx cc{ cost_type, b.ref_row, b.ref_col };
   auto var_cost = [&](int mrow, int mcol) -> int {  // mv_err_cost_ (mcomp.c:271-308)
-    if (cost_type == kCostEntropy) {
+    if (GENERAL && cost_type == kCostEntropy) {
       const int dr = mrow - b.ref_row, dc = mcol - b.ref_col;
       const int64_t bits = ct.mvjcost[(dc != 0) | ((dr != 0) << 1)] + ct.mvcost0[dr] + ct.mvcost1[dc];
       return (int)((bits * ct.error_per_bit + (1 << 13)) >> 14);
@@ -646,14 +650,15 @@ static int launch_subpel(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip
                          int16_t *d_best_mv, uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse) {
   if (n_blocks == 0) return AOMHIP_OK;
   const dim3 grid((n_blocks + 3) / 4), block(kSearchThreads);
+  const bool general = tree != 0 || d_cost_lists != nullptr || mv_cost_type == kCostEntropy;
 #define X(W, H)                                                                                                      \
   if (bw == W && bh == H) {                                                                                          \
     if (src->bit_depth == 8)                                                                                         \
-      hipLaunchKernelGGL((subpel_bilinear_kernel<uint8_t, W, H>), grid, block, 0, ctx->stream, view_of<uint8_t>(*src), \
+      hipLaunchKernelGGL((general ? subpel_bilinear_kernel<uint8_t, W, H, true> : subpel_bilinear_kernel<uint8_t, W, H, false>), grid, block, 0, ctx->stream, view_of<uint8_t>(*src), \
                          view_of<uint8_t>(*ref), frame, d_blocks, n_blocks, mv_cost_type, iters_per_step, allow_hp,  \
                          forced_stop, 8, tree, d_cost_lists, ct, d_best_mv, d_best_err, d_distortion, d_sse);        \
     else                                                                                                             \
-      hipLaunchKernelGGL((subpel_bilinear_kernel<uint16_t, W, H>), grid, block, 0, ctx->stream,                       \
+      hipLaunchKernelGGL((general ? subpel_bilinear_kernel<uint16_t, W, H, true> : subpel_bilinear_kernel<uint16_t, W, H, false>), grid, block, 0, ctx->stream, \
                          view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame, d_blocks, n_blocks, mv_cost_type,  \
                          iters_per_step, allow_hp, forced_stop, src->bit_depth, tree, d_cost_lists, ct, d_best_mv,   \
                          d_best_err, d_distortion, d_sse);                                                           \
