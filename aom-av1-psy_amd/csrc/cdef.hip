@@ -8,10 +8,12 @@
 // plane, write the CDEF plane) has exactly those semantics with no buffers.
 //
 // One workgroup per 64x64 filter block:
-//   1. the 68 x 68 footprint (2-pixel halo) is staged in LDS as uint16, 0x4000 outside the frame
-//   2. 64 lanes find the direction + variance of the 64 8x8 blocks (pixels in VGPRs, the 8 directional
-//      partial-sum sets evaluated one after the other with compile-time line indices)
-//   3. all 256 lanes filter: 4 lanes per 8x8 block, 2 rows each, taps read from LDS
+//   1. the 68 x 72 footprint (2-row / 4-column halo) is staged in LDS as uint16 with 8-byte loads, 0x4000 outside
+//      the frame
+//   2. direction search: lane = 8x8 block, each of the four waves evaluates two of the eight directional
+//      partial-sum sets for all 64 blocks (pixels in VGPRs, compile-time line indices); 64 lanes then pick the best
+//   3. filter: lane = pixel column, each wave owns 16 rows: conflict-free LDS tap reads, one contiguous 64-pixel
+//      store per row, no divergent tap code (a disabled strength makes its taps contribute 0)
 // Skipped 8x8 blocks (all four 4x4 skip_txfm) and blocks of a zero-strength filter block are copied.
 // Algorithmic bytes: one read and one write per pixel.
 #include "common.h"
@@ -82,32 +84,104 @@ __device__ constexpr int kDirOff[8][2] = {
   { 1 * kTW + 1, 2 * kTW + 2 },   { 1 * kTW + 0, 2 * kTW + 1 },  { 1 * kTW + 0, 2 * kTW + 0 }, { 1 * kTW + 0, 2 * kTW - 1 }
 };
 
+// Packed int16 pairs (two pixels per VGPR; clang lowers the element-wise operators to v_pk_* on gfx950)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 splat2(int v) { return s16x2{ (short)v, (short)v }; }
+__device__ __forceinline__ s16x2 pack2(int lo, int hi) { return s16x2{ (short)lo, (short)hi }; }
+__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+// constrain() (av1/common/cdef.h:59-67) on a pair, with shift = max(0, damping - msb(threshold)) hoisted out of it;
+// threshold 0 yields 0 by itself (m = -(a >> shift) <= 0)
+__device__ __forceinline__ s16x2 constrain_pk(s16x2 diff, s16x2 thr, s16x2 shift) {
+  const s16x2 a = pmax(diff, -diff);
+  s16x2 m = thr - (a >> shift);
+  m = pmin(pmax(m, splat2(0)), a);
+  const s16x2 sg = diff >> splat2(15);
+  return (m ^ sg) - sg;
+}
+
+// constrain() with the shift (damping - msb(threshold), floored at 0) hoisted out; threshold 0 gives 0 by itself
+__device__ __forceinline__ int constrain_s(int diff, int threshold, int shift) {
+  const int a = diff < 0 ? -diff : diff;
+  int m = threshold - (a >> shift);
+  m = m < 0 ? 0 : m;
+  m = m > a ? a : m;
+  return diff < 0 ? -m : m;
+}
+
 template <typename PIX>
 __global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ src, PIX *__restrict__ dst, int stride,
                                                         int width, int height, const uint8_t *__restrict__ fb_pri,
                                                         const uint8_t *__restrict__ fb_sec, int fb_stride,
                                                         const uint8_t *__restrict__ skip, int damping, int coeff_shift,
                                                         uint8_t *__restrict__ dir_out, int32_t *__restrict__ var_out) {
-  __shared__ uint16_t tile[kTH * kTW];
+  __shared__ __attribute__((aligned(16))) uint16_t tile[kTH * kTW];
+  __shared__ int32_t scost[8][64];
   __shared__ int8_t sdir[64];
   __shared__ int32_t svar[64];
   const int fbx = blockIdx.x, fby = blockIdx.y;
   const int x0 = fbx * 64, y0 = fby * 64;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int b8w = width >> 3;
 
-  // 1. stage the footprint
-  for (int i = tid; i < kTH * kTW; i += 256) {
-    const int r = i / kTW - 2, c = i % kTW - 4;
-    const int y = y0 + r, x = x0 + c;
-    int v = kVeryLarge;
-    if (y >= 0 && y < height && x >= 0 && x < width) v = src[(int64_t)y * stride + x];
-    tile[i] = (uint16_t)v;
+  // 1. stage the 68 x 72 footprint, four pixels per lane and step.  The frame width is a multiple of 8 and a group
+  //    starts at a multiple of 4, so a group is entirely inside or entirely outside the frame.
+  {
+    constexpr int kGroups = kTW / 4;  // 18 per row
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)((size_t)stride * sizeof(PIX))) & (4 * sizeof(PIX) - 1)) == 0;
+    for (int gi = tid; gi < kTH * kGroups; gi += 256) {
+      const int r = gi / kGroups - 2, c = (gi % kGroups) * 4 - 4;
+      const int y = y0 + r, x = x0 + c;
+      uint32_t lo = kVeryLarge | (kVeryLarge << 16), hi = lo;
+      if (y >= 0 && y < height && x >= 0 && x < width) {
+        const PIX *p = src + (int64_t)y * stride + x;
+        if constexpr (sizeof(PIX) == 2) {
+          if (vec_ok) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(p);
+            lo = v.x;
+            hi = v.y;
+          } else {
+            lo = (uint32_t)p[0] | ((uint32_t)p[1] << 16);
+            hi = (uint32_t)p[2] | ((uint32_t)p[3] << 16);
+          }
+        } else {
+          uint32_t v;
+          if (vec_ok) v = *reinterpret_cast<const uint32_t *>(p);
+          else v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+          lo = (v & 0xffu) | ((v & 0xff00u) << 8);
+          hi = ((v >> 16) & 0xffu) | ((v >> 8) & 0xff0000u);
+        }
+      }
+      *reinterpret_cast<uint2 *>(&tile[gi * 4]) = make_uint2(lo, hi);
+    }
   }
   const int level = fb_pri[fby * fb_stride + fbx], sec = fb_sec[fby * fb_stride + fbx];
   __syncthreads();
 
-  // 2. direction search, one lane per 8x8 block
+  // 2. direction search: lane = 8x8 block, wave w evaluates directions 2w and 2w + 1 of all 64 blocks
+  {
+    const int by = lane >> 3, bx = lane & 7;
+    int x[64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint2 v0 = *reinterpret_cast<const uint2 *>(&tile[(by * 8 + i + 2) * kTW + bx * 8 + 4]);
+      const uint2 v1 = *reinterpret_cast<const uint2 *>(&tile[(by * 8 + i + 2) * kTW + bx * 8 + 8]);
+      const uint32_t w4[4] = { v0.x, v0.y, v1.x, v1.y };
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        x[i * 8 + 2 * k] = ((int)(w4[k] & 0xffffu) >> coeff_shift) - 128;
+        x[i * 8 + 2 * k + 1] = ((int)(w4[k] >> 16) >> coeff_shift) - 128;
+      }
+    }
+    int ca, cb;
+    if (wave == 0) { ca = dir_cost<0>(x); cb = dir_cost<1>(x); }
+    else if (wave == 1) { ca = dir_cost<2>(x); cb = dir_cost<3>(x); }
+    else if (wave == 2) { ca = dir_cost<4>(x); cb = dir_cost<5>(x); }
+    else { ca = dir_cost<6>(x); cb = dir_cost<7>(x); }
+    scost[2 * wave][lane] = ca;
+    scost[2 * wave + 1][lane] = cb;
+  }
+  __syncthreads();
   if (tid < 64) {
     const int by = tid >> 3, bx = tid & 7;
     const int gy = y0 + by * 8, gx = x0 + bx * 8;
@@ -115,15 +189,9 @@ __global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ 
     // (a zero-strength filter block is still searched when the caller wants the directions: its chroma strengths
     //  may be non-zero, cdef.c:334-345; filtering with zero strengths below is the identity)
     if (gy < height && gx < width && ((level | sec) != 0 || dir_out || var_out) && !skip[(gy >> 3) * b8w + (gx >> 3)]) {
-      int x[64];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          x[i * 8 + j] = ((int)tile[(by * 8 + i + 2) * kTW + bx * 8 + j + 4] >> coeff_shift) - 128;
       int cost[8];
-      cost[0] = dir_cost<0>(x); cost[1] = dir_cost<1>(x); cost[2] = dir_cost<2>(x); cost[3] = dir_cost<3>(x);
-      cost[4] = dir_cost<4>(x); cost[5] = dir_cost<5>(x); cost[6] = dir_cost<6>(x); cost[7] = dir_cost<7>(x);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cost[k] = scost[k][tid];
       int best = 0, best_cost = 0;
 #pragma unroll
       for (int k = 0; k < 8; ++k)
@@ -146,70 +214,71 @@ __global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ 
   }
   __syncthreads();
 
-  // 3. filter: 4 lanes per 8x8 block, rows 2q and 2q + 1
-  const int blk = tid >> 2, q = tid & 3;
-  const int by = blk >> 3, bx = blk & 7;
-  const int gy0 = y0 + by * 8 + 2 * q, gx0 = x0 + bx * 8;
-  if (gy0 >= height || gx0 >= width) return;
-  const int d = sdir[blk];
+  // 3. filter: lane = pixel column, wave w owns rows 16w .. 16w + 15 (two rows of 8x8 blocks).  Adjacent lanes read
+  //    adjacent LDS elements and write one contiguous 64-pixel row segment per step.  Two vertically adjacent pixels
+  //    are processed together as packed int16 pairs (v_pk_* ops: the kernel is VALU-bound, PMC in
+  //    profiles/r01_cdef.md) -- every intermediate of cdef_filter_block_internal fits int16, which is also what the
+  //    reference computes in.  Disabled taps contribute nothing by themselves (constrain with strength 0 is 0), so the
+  //    per-block enables only select whether the final clamp applies: no divergent tap code.
+  const int gx = x0 + lane;
+  if (gx >= width) return;
   const int pri_strength = level << coeff_shift, sec_strength = sec << coeff_shift;
-  int t = 0;
-  if (d >= 0) {  // adjust_strength (cdef_block.c:289-293)
-    const int var = svar[blk];
-    const int i = (var >> 6) ? min(msb_u((unsigned)(var >> 6)), 12) : 0;
-    t = var ? (pri_strength * (4 + i) + 8) >> 4 : 0;
-  }
   const int dmp = damping + coeff_shift;
-  const int dir = pri_strength ? (d < 0 ? 0 : d) : 0;
-  const bool en_pri = (t != 0), en_sec = (sec_strength != 0), clip = en_pri && en_sec;
-  const int pt0 = ((t >> coeff_shift) & 1) ? 3 : 4, pt1 = ((t >> coeff_shift) & 1) ? 3 : 2;  // cdef_pri_taps
-  const int po0 = kDirOff[dir][0], po1 = kDirOff[dir][1];
-  const int s1o0 = kDirOff[(dir + 2) & 7][0], s1o1 = kDirOff[(dir + 2) & 7][1];
-  const int s2o0 = kDirOff[(dir + 6) & 7][0], s2o1 = kDirOff[(dir + 6) & 7][1];
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int ly = by * 8 + 2 * q + rr;
-    PIX outv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int pos = (ly + 2) * kTW + bx * 8 + j + 4;
-      const int x = tile[pos];
-      int y = x;
-      if (d >= 0) {
-        int sum = 0, mx = x, mn = x;
-        if (en_pri) {
-          const int p0 = tile[pos + po0], p1 = tile[pos - po0], p2 = tile[pos + po1], p3 = tile[pos - po1];
-          sum += pt0 * (constrain_d(p0 - x, t, dmp) + constrain_d(p1 - x, t, dmp));
-          sum += pt1 * (constrain_d(p2 - x, t, dmp) + constrain_d(p3 - x, t, dmp));
-          if (clip) {
-            mx = max(mx, p0 == kVeryLarge ? x : p0); mx = max(mx, p1 == kVeryLarge ? x : p1);
-            mx = max(mx, p2 == kVeryLarge ? x : p2); mx = max(mx, p3 == kVeryLarge ? x : p3);
-            mn = min(min(mn, p0), min(p1, min(p2, p3)));
-          }
-        }
-        if (en_sec) {
-          const int a0 = tile[pos + s1o0], a1 = tile[pos - s1o0], a2 = tile[pos + s2o0], a3 = tile[pos - s2o0];
-          const int c0 = tile[pos + s1o1], c1 = tile[pos - s1o1], c2 = tile[pos + s2o1], c3 = tile[pos - s2o1];
-          sum += 2 * (constrain_d(a0 - x, sec_strength, dmp) + constrain_d(a1 - x, sec_strength, dmp) +
-                      constrain_d(a2 - x, sec_strength, dmp) + constrain_d(a3 - x, sec_strength, dmp));
-          sum += 1 * (constrain_d(c0 - x, sec_strength, dmp) + constrain_d(c1 - x, sec_strength, dmp) +
-                      constrain_d(c2 - x, sec_strength, dmp) + constrain_d(c3 - x, sec_strength, dmp));
-          if (clip) {
-            mx = max(mx, a0 == kVeryLarge ? x : a0); mx = max(mx, a1 == kVeryLarge ? x : a1);
-            mx = max(mx, a2 == kVeryLarge ? x : a2); mx = max(mx, a3 == kVeryLarge ? x : a3);
-            mx = max(mx, c0 == kVeryLarge ? x : c0); mx = max(mx, c1 == kVeryLarge ? x : c1);
-            mx = max(mx, c2 == kVeryLarge ? x : c2); mx = max(mx, c3 == kVeryLarge ? x : c3);
-            mn = min(min(min(mn, a0), min(a1, a2)), min(min(a3, c0), min(c1, min(c2, c3))));
-          }
-        }
-        y = x + ((8 + sum - (sum < 0)) >> 4);
-        if (clip) y = y < mn ? mn : (y > mx ? mx : y);
-      }
-      outv[j] = (PIX)y;
+  const int sec_shift = sec_strength ? max(0, dmp - msb_u((unsigned)sec_strength)) : 0;
+  const s16x2 sec_thr = splat2(sec_strength), sec_sh = splat2(sec_shift);
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    const int by = wave * 2 + half, bx = lane >> 3, blk = by * 8 + bx;
+    if (y0 + by * 8 >= height) break;
+    const int d = sdir[blk];
+    int t = 0;
+    if (d >= 0) {  // adjust_strength (cdef_block.c:289-293)
+      const int var = svar[blk];
+      const int i = (var >> 6) ? min(msb_u((unsigned)(var >> 6)), 12) : 0;
+      t = var ? (pri_strength * (4 + i) + 8) >> 4 : 0;
     }
-    PIX *o = dst + (int64_t)(gy0 + rr) * stride + gx0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = outv[j];
+    const int pri_shift = t ? max(0, dmp - msb_u((unsigned)t)) : 0;
+    const int dir = pri_strength ? (d < 0 ? 0 : d) : 0;
+    const bool clip = (t != 0) && (sec_strength != 0);
+    const s16x2 pt0 = splat2(((t >> coeff_shift) & 1) ? 3 : 4), pt1 = splat2(((t >> coeff_shift) & 1) ? 3 : 2);  // cdef_pri_taps
+    const s16x2 pri_thr = splat2(t), pri_sh = splat2(pri_shift);
+    const int po0 = kDirOff[dir][0], po1 = kDirOff[dir][1];
+    const int s1o0 = kDirOff[(dir + 2) & 7][0], s1o1 = kDirOff[(dir + 2) & 7][1];
+    const int s2o0 = kDirOff[(dir + 6) & 7][0], s2o1 = kDirOff[(dir + 6) & 7][1];
+#pragma unroll 2
+    for (int rr = 0; rr < 8; rr += 2) {
+      const int ly = by * 8 + rr;
+      const int pos = (ly + 2) * kTW + lane + 4;
+      auto ld2 = [&](int off) { return pack2(tile[pos + off], tile[pos + kTW + off]); };  // rows ly and ly + 1
+      const s16x2 x = ld2(0);
+      s16x2 y = x;
+      if (d >= 0) {
+        const s16x2 p0 = ld2(po0), p1 = ld2(-po0), p2 = ld2(po1), p3 = ld2(-po1);
+        const s16x2 a0 = ld2(s1o0), a1 = ld2(-s1o0), a2 = ld2(s2o0), a3 = ld2(-s2o0);
+        const s16x2 c0 = ld2(s1o1), c1 = ld2(-s1o1), c2 = ld2(s2o1), c3 = ld2(-s2o1);
+        s16x2 sum = pt0 * (constrain_pk(p0 - x, pri_thr, pri_sh) + constrain_pk(p1 - x, pri_thr, pri_sh)) +
+                    pt1 * (constrain_pk(p2 - x, pri_thr, pri_sh) + constrain_pk(p3 - x, pri_thr, pri_sh));
+        const s16x2 sa = constrain_pk(a0 - x, sec_thr, sec_sh) + constrain_pk(a1 - x, sec_thr, sec_sh) +
+                         constrain_pk(a2 - x, sec_thr, sec_sh) + constrain_pk(a3 - x, sec_thr, sec_sh);
+        const s16x2 sc = constrain_pk(c0 - x, sec_thr, sec_sh) + constrain_pk(c1 - x, sec_thr, sec_sh) +
+                         constrain_pk(c2 - x, sec_thr, sec_sh) + constrain_pk(c3 - x, sec_thr, sec_sh);
+        sum += sa + sa + sc;
+        // y = x + ((8 + sum - (sum < 0)) >> 4): (sum < 0) is -(sum >> 15)
+        y = x + ((splat2(8) + sum + (sum >> splat2(15))) >> splat2(4));
+        if (clip) {
+          // CDEF_VERY_LARGE (0x4000) must not enter the maximum: & 0x3fff turns it into 0 and leaves pixels alone
+          const s16x2 k = splat2(0x3fff);
+          s16x2 mx = pmax(pmax(pmax(x, p0 & k), pmax(p1 & k, p2 & k)), pmax(pmax(p3 & k, a0 & k), pmax(a1 & k, a2 & k)));
+          mx = pmax(pmax(pmax(mx, a3 & k), pmax(c0 & k, c1 & k)), pmax(c2 & k, c3 & k));
+          s16x2 mn = pmin(pmin(pmin(x, p0), pmin(p1, p2)), pmin(pmin(p3, a0), pmin(a1, a2)));
+          mn = pmin(pmin(pmin(mn, a3), pmin(c0, c1)), pmin(c2, c3));
+          y = pmin(pmax(y, mn), mx);
+        }
+      }
+      PIX *o = dst + (int64_t)(y0 + ly) * stride + gx;
+      o[0] = (PIX)(uint16_t)y.x;
+      o[stride] = (PIX)(uint16_t)y.y;
+    }
   }
 }
 

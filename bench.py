@@ -653,7 +653,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sad16x16_modeA_1080p_8bit",
-                    choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "search_4k_10bit"])
+                    choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "search_4k_10bit", "inner_loop_4k_10bit"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -692,6 +692,15 @@ def main():
                               "frames_per_s": r["frames_per_s"], "parity_sample_slot0": r["parity_sample_slot0"]}))
         if dist is not None:
             dist.destroy_process_group()
+        return
+    if args.workload == "inner_loop_4k_10bit":  # profiling convenience: the configs[4] chain with per-stage timings (single GPU)
+        r = run_inner_loop(pkg, ctx, orc, args.steps, args.warmup)
+        ctx.close()
+        print(json.dumps({"metric": "encode inner loop frames/s", "value": r["value"], "unit": "frames/s", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_frame"], "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+                          "config": dict(r["config"], workload=r["workload"]), "stages": r["stages"],
+                          "recon_psnr_db_last_frame": r["recon_psnr_db_last_frame"]}))
         return
     if args.workload == "txq_1080p_8bit":  # profiling convenience: transform+quantise only (single GPU)
         r = run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline)
