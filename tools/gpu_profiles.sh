@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/$TAG/stats
 mkdir -p $OUT
 export TMPDIR=/tmp
-for WL in sad16x16_modeA_1080p_8bit sad16x16_modeA_4k_8bit sad16x16_modeA_4k_10bit txq_1080p_8bit; do
+for WL in sad16x16_modeA_1080p_8bit sad16x16_modeA_4k_8bit sad16x16_modeA_4k_10bit txq_1080p_8bit search_4k_10bit inner_loop_4k_10bit; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$WL -o k -- \
       python bench.py --steps 20 --warmup 3 --workload $WL --others "" --no-cpu-baseline > $OUT/$WL.json 2> $OUT/$WL.err
   f=$(find $OUT/$WL -name '*kernel_stats.csv' | head -1)
@@ -14,6 +14,7 @@ for WL in sad16x16_modeA_1080p_8bit sad16x16_modeA_4k_8bit sad16x16_modeA_4k_10b
   python - "$OUT/$WL.json" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read())
-print("   bench: value %.4g %s; dominant %s avg_launch_ms %.4f" % (d["value"], d["unit"], d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"]))
+r=d.get("roofline")
+print("   bench: value %.4g %s" % (d["value"], d["unit"]) + (("; dominant %s avg_launch_ms %.4f" % (r["kernel"], r["avg_launch_ms"])) if r and "kernel" in r else ""))
 PY
 done
