@@ -760,6 +760,7 @@ typedef struct {
   int row_min, row_max, col_min, col_max; /* SubpelMvLimits */
   unsigned besterr, sse1;
   int distortion, best_row, best_col;
+  int upsampled; /* 0: estimated_pref_error (bilinear svf); 1: upsampled_pref_error with the 8-tap regular filter */
 } subpel_state;
 
 static unsigned svf_at(const search_ctx *c, int mrow, int mcol, uint32_t *sse) { /* estimated_pref_error */
@@ -772,10 +773,85 @@ static unsigned svf_at(const search_ctx *c, int mrow, int mcol, uint32_t *sse) {
                                 mrow & 7, (const uint8_t *)c->src, c->src_stride, c->w, c->h, sse);
 }
 
+/* EIGHTTAP_REGULAR sub-pel kernels (AV1 spec, av1/common/filter.h:124-141); a 1/8-pel offset s uses row 2 * s */
+static const int8_t k_sub_pel_8[16][8] = {
+  { 0, 0, 0, 128, 0, 0, 0, 0 },      { 0, 2, -6, 126, 8, -2, 0, 0 },    { 0, 2, -10, 122, 18, -4, 0, 0 },
+  { 0, 2, -12, 116, 28, -8, 2, 0 },  { 0, 2, -14, 110, 38, -10, 2, 0 }, { 0, 2, -14, 102, 48, -12, 2, 0 },
+  { 0, 2, -16, 94, 58, -12, 2, 0 },  { 0, 2, -14, 84, 66, -12, 2, 0 },  { 0, 2, -14, 76, 76, -14, 2, 0 },
+  { 0, 2, -12, 66, 84, -14, 2, 0 },  { 0, 2, -12, 58, 94, -16, 2, 0 },  { 0, 2, -12, 48, 102, -14, 2, 0 },
+  { 0, 2, -10, 38, 110, -14, 2, 0 }, { 0, 2, -8, 28, 116, -12, 2, 0 },  { 0, 0, -4, 18, 122, -10, 2, 0 },
+  { 0, 0, -2, 8, 126, -6, 2, 0 }
+};
+const int8_t *orc_sub_pel_filters_8(void) { return &k_sub_pel_8[0][0]; }
+
+static int ref_px(const search_ctx *c, int row, int col) {
+  return c->elem16 ? ((const uint16_t *)c->ref)[(ptrdiff_t)row * c->ref_stride + col]
+                   : ((const uint8_t *)c->ref)[(ptrdiff_t)row * c->ref_stride + col];
+}
+
+/* aom_[highbd_]upsampled_pred_c (av1/encoder/reconinter_enc.c:424-505,562-640), unscaled reference, USE_8_TAPS:
+ * aom_convolve8_horiz then _vert (aom_dsp/aom_convolve.c:36-108,181-253), each pass rounded by FILTER_BITS = 7 and
+ * clipped to the pixel range; a zero offset in one direction skips that pass.  pred: w * h, row pitch w. */
+static void upsampled_pred8(const search_ctx *c, int mrow, int mcol, uint16_t *pred) {
+  const int fr = mrow >> 3, fc = mcol >> 3, sx = mcol & 7, sy = mrow & 7;
+  const int8_t *kx = k_sub_pel_8[2 * sx], *ky = k_sub_pel_8[2 * sy];
+  const int mx = c->elem16 ? (1 << c->bd) - 1 : 255;
+  const int w = c->w, h = c->h;
+  if (!sx && !sy) {
+    for (int r = 0; r < h; ++r)
+      for (int x = 0; x < w; ++x) pred[r * w + x] = (uint16_t)ref_px(c, fr + r, fc + x);
+    return;
+  }
+  uint16_t *tmp = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(h + 7) * w); /* rows -3 .. h + 3 */
+  for (int r = -3; r < h + 4; ++r)
+    for (int x = 0; x < w; ++x) {
+      int v;
+      if (sx) {
+        int sum = 0;
+        for (int k = 0; k < 8; ++k) sum += ref_px(c, fr + r, fc + x - 3 + k) * kx[k];
+        v = (sum + 64) >> 7;
+        v = v < 0 ? 0 : v > mx ? mx : v;
+      } else {
+        v = ref_px(c, fr + r, fc + x);
+      }
+      tmp[(r + 3) * w + x] = (uint16_t)v;
+    }
+  for (int r = 0; r < h; ++r)
+    for (int x = 0; x < w; ++x) {
+      int v;
+      if (sy) {
+        int sum = 0;
+        for (int k = 0; k < 8; ++k) sum += tmp[(r + k) * w + x] * ky[k];
+        v = (sum + 64) >> 7;
+        v = v < 0 ? 0 : v > mx ? mx : v;
+      } else {
+        v = tmp[(r + 3) * w + x];
+      }
+      pred[r * w + x] = (uint16_t)v;
+    }
+  free(tmp);
+}
+
+static unsigned upsampled_err(const search_ctx *c, int mrow, int mcol, uint32_t *sse) { /* upsampled_pref_error */
+  uint16_t *pred = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)c->w * c->h);
+  upsampled_pred8(c, mrow, mcol, pred);
+  unsigned v;
+  if (c->elem16) {
+    v = orc_highbd_variance(pred, c->w, (const uint16_t *)c->src, c->src_stride, c->w, c->h, c->bd, sse, NULL);
+  } else {
+    uint8_t *p8 = (uint8_t *)malloc((size_t)c->w * c->h);
+    for (int i = 0; i < c->w * c->h; ++i) p8[i] = (uint8_t)pred[i];
+    v = orc_variance(p8, c->w, (const uint8_t *)c->src, c->src_stride, c->w, c->h, sse, NULL);
+    free(p8);
+  }
+  free(pred);
+  return v;
+}
+
 static unsigned check_better_fast2(subpel_state *s, int mrow, int mcol, int *is_better) {
   if (mcol < s->col_min || mcol > s->col_max || mrow < s->row_min || mrow > s->row_max) return INT_MAX;
   uint32_t sse;
-  const int thismse = (int)svf_at(s->c, mrow, mcol, &sse);
+  const int thismse = s->upsampled ? (int)upsampled_err(s->c, mrow, mcol, &sse) : (int)svf_at(s->c, mrow, mcol, &sse);
   const unsigned cost = (unsigned)mv_cost_var(s->c, mrow, mcol) + (unsigned)thismse;
   if (cost < s->besterr) {
     s->besterr = cost;
@@ -848,7 +924,7 @@ void orc_subpel_bilinear_batch(const void *src_origin, int src_stride, const voi
     search_ctx c;
     make_ctx(&c, src_origin, src_stride, ref_origin, ref_stride, elem16, bd, w, h, cost_type, b->bx, b->by, b->ref_row,
              b->ref_col);
-    subpel_state s = { &c, b->row_min, b->row_max, b->col_min, b->col_max, INT_MAX, 0, 0, b->start_row, b->start_col };
+    subpel_state s = { &c, b->row_min, b->row_max, b->col_min, b->col_max, INT_MAX, 0, 0, b->start_row, b->start_col, 0 };
     /* setup_center_error: vf(ref at the full-pel part, src) -- note the operand order */
     {
       uint32_t sse;
@@ -886,12 +962,13 @@ void orc_subpel_bilinear_batch(const void *src_origin, int src_stride, const voi
 
 /* ---- the three bilinear sub-pel trees with an optional cost list and every MV cost type ----
  * tree: 0 av1_find_best_sub_pixel_tree_pruned_more (mcomp.c:2844-2929), 1 _pruned (:2931-3067), 2 _tree (:3069-3133),
- * subpel_search_type USE_2_TAPS_ORIG, unscaled reference, last_mv_search_list == NULL.
+ * subpel_search_type USE_2_TAPS_ORIG (0) or, for the tree, USE_8_TAPS (3: up-sampled prediction error); unscaled
+ * reference, last_mv_search_list == NULL.
  * cost_lists: 5 ints per block (what av1_full_pixel_search returned) or NULL. */
 static int divide_and_round(int n, int d) { return ((n < 0) ^ (d < 0)) ? ((n - d / 2) / d) : ((n + d / 2) / d); }
 
 void orc_subpel_tree_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16, int bd,
-                           int w, int h, int tree, int cost_type, int error_per_bit, const int *mvjcost, const int *mvcost0,
+                           int w, int h, int tree, int subpel_search_type, int cost_type, int error_per_bit, const int *mvjcost, const int *mvcost0,
                            const int *mvcost1, int iters_per_step, int allow_hp, int forced_stop,
                            const orc_subpel_block *blocks, const int32_t *cost_lists, int n, int16_t *out_mv, uint32_t *out_err,
                            int32_t *out_distortion, uint32_t *out_sse, int threads) {
@@ -903,8 +980,11 @@ void orc_subpel_tree_batch(const void *src_origin, int src_stride, const void *r
     make_ctx(&c, src_origin, src_stride, ref_origin, ref_stride, elem16, bd, w, h, cost_type, b->bx, b->by, b->ref_row,
              b->ref_col);
     c.mvjcost = mvjcost; c.mvcost[0] = mvcost0; c.mvcost[1] = mvcost1; c.error_per_bit = error_per_bit;
-    subpel_state s = { &c, b->row_min, b->row_max, b->col_min, b->col_max, INT_MAX, 0, 0, b->start_row, b->start_col };
-    { /* setup_center_error (:2718-2778): vf(ref at the full-pel part, src) */
+    /* only av1_find_best_sub_pixel_tree measures with the up-sampled prediction (check_better / first_level_check,
+     * :2465-2663); the pruned trees always use the bilinear estimate on an unscaled reference (check_better_fast) */
+    const int upsampled = tree == 2 && subpel_search_type == 3; /* USE_8_TAPS */
+    subpel_state s = { &c, b->row_min, b->row_max, b->col_min, b->col_max, INT_MAX, 0, 0, b->start_row, b->start_col, upsampled };
+    { /* setup_center_error (:2718-2778) / upsampled_setup_center_error: vf(ref at the full-pel part, src) */
       uint32_t sse;
       unsigned v;
       const int fr = b->start_row >> 3, fc = b->start_col >> 3;

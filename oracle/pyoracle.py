@@ -456,7 +456,8 @@ SUBPEL_TREES = {"pruned_more": 0, "pruned": 1, "tree": 2}
 
 
 def subpel_tree_batch(src_b, ref_b, border, w, h, blocks, tree="pruned_more", cost_type=3, error_per_bit=0, mvjcost=None,
-                      mvcost0=None, mvcost1=None, iters=2, allow_hp=1, forced_stop=0, cost_lists=None, bd=8, threads=4):
+                      mvcost0=None, mvcost1=None, iters=2, allow_hp=1, forced_stop=0, cost_lists=None, bd=8, threads=4,
+                      subpel_search_type=0):
     """The three bilinear sub-pel trees (tree: pruned_more / pruned / tree) with an optional per-block cost list."""
     blocks = np.ascontiguousarray(blocks)
     n = len(blocks)
@@ -475,8 +476,8 @@ def subpel_tree_batch(src_b, ref_b, border, w, h, blocks, tree="pruned_more", co
         cla = np.ascontiguousarray(cost_lists, np.int32).reshape(n, 5); keep.append(cla); cl = C.c_void_p(cla.ctypes.data)
     lib.orc_subpel_tree_batch.restype = None
     lib.orc_subpel_tree_batch(C.c_void_p(_addr(src_b, border, border)), src_b.shape[1], C.c_void_p(_addr(ref_b, border, border)),
-                              ref_b.shape[1], int(src_b.dtype != np.uint8), bd, w, h, SUBPEL_TREES.get(tree, tree), cost_type,
-                              error_per_bit, j, centre(mvcost0), centre(mvcost1), iters, allow_hp, forced_stop,
+                              ref_b.shape[1], int(src_b.dtype != np.uint8), bd, w, h, SUBPEL_TREES.get(tree, tree), subpel_search_type,
+                              cost_type, error_per_bit, j, centre(mvcost0), centre(mvcost1), iters, allow_hp, forced_stop,
                               C.c_void_p(blocks.ctypes.data), cl, n, C.c_void_p(mv.ctypes.data), C.c_void_p(err.ctypes.data),
                               C.c_void_p(dist.ctypes.data), C.c_void_p(sse.ctypes.data), threads)
     return mv, err, dist, sse

@@ -47,9 +47,17 @@ def make_evaluator():
     for f in ["av1/common/mv.h"]:
         ev.load(REF + f)
     ev.define("MARK_MV_INVALID", "do { (mv)->row = INVALID_MV_ROW_COL; (mv)->col = INVALID_MV_ROW_COL; } while (0)", ["mv"])
-    for f in ["av1/common/entropymv.h", "av1/common/blockd.h", "av1/encoder/speed_features.h", "av1/encoder/cost.h", "av1/encoder/rd.h", "av1/encoder/encodemv.h", "av1/encoder/mcomp_structs.h", "av1/encoder/mcomp.h",
-              "av1/common/scale.h", "aom_dsp/sad.c", "aom_dsp/variance.c", "av1/encoder/encoder_utils.h", "av1/encoder/mcomp.c"]:
+    for f in ["av1/common/entropymv.h", "aom_scale/yv12config.h", "av1/common/blockd.h", "av1/encoder/speed_features.h", "av1/encoder/cost.h", "av1/encoder/rd.h", "av1/encoder/encodemv.h", "av1/encoder/mcomp_structs.h", "av1/encoder/mcomp.h",
+              "av1/common/scale.h", "aom_dsp/sad.c", "aom_dsp/variance.c", "av1/encoder/encoder_utils.h", "aom_dsp/aom_convolve.c",
+              "av1/encoder/reconinter_enc.c", "av1/encoder/mcomp.c"]:
         ev.load(REF + f)
+    # aom_convolve8_* recover the kernel table and the phase from the kernel POINTER (get_filter_base masks the address
+    # with ~0xFF, relying on the table's 256-byte alignment; get_filter_offset is a pointer difference in kernels).  In
+    # the evaluator's (buffer, element) pointer model the same two values are the buffer start and element / 8.
+    for fn in ("get_filter_base", "get_filter_offset"):
+        ev.funcs.pop(fn)
+    ev.interp.pycalls["get_filter_base"] = lambda it, a: (R.Ptr(a[0][0].buf, 0, a[0][0].t, (8,)), R.PTR)
+    ev.interp.pycalls["get_filter_offset"] = lambda it, a: (a[0][0].off // 8, R.I32)
     # MACROBLOCKD / MB_MODE_INFO contain unions and dozens of unrelated members, so the evaluator knows them only as
     # opaque parameter types.  The sub-pel entry points read exactly three things through `xd` (mcomp.c:2864-2867):
     # xd->mi[0]->use_intrabc and xd->block_ref_scale_factors[0] (a real `struct scale_factors`, av1/common/scale.h).
@@ -58,12 +66,20 @@ def make_evaluator():
     mbmi = ev.structs["<opaque>MB_MODE_INFO"]
     mbmi.fields = [("use_intrabc", R.U8)]
     xd = ev.structs["<opaque>MACROBLOCKD"]
-    xd.fields = [("mi", ("ptr", ("ptr", mbmi))), ("block_ref_scale_factors", ("arr", ("ptr", ev.structs["scale_factors"]), 2))]
+    # upsampled_pref_error additionally reads xd->mi_row / mi_col (passed on, unused for an unscaled reference), xd->bd and
+    # xd->cur_buf->flags (is_cur_buf_hbd, blockd.h:936-943)
+    yv12 = ev.structs.setdefault("<opaque>YV12_BUFFER_CONFIG", R.StructType("YV12_BUFFER_CONFIG"))
+    yv12.fields = [("flags", R.U32)]
+    xd.fields = [("mi", ("ptr", ("ptr", mbmi))), ("block_ref_scale_factors", ("arr", ("ptr", ev.structs["scale_factors"]), 2)),
+                 ("mi_row", R.I32), ("mi_col", R.I32), ("bd", R.I32), ("cur_buf", ("ptr", yv12))]
     return ev
 
 
-def make_xd(ev):
+def make_xd(ev, bd=8):
     xd = ev.interp.alloc(ev.structs["<opaque>MACROBLOCKD"], True)
+    cur = ev.interp.alloc(ev.structs["<opaque>YV12_BUFFER_CONFIG"], True)
+    ev.set(cur, "flags", 8 if bd > 8 else 0)              # YV12_FLAG_HIGHBITDEPTH (aom_scale/yv12config.h:127)
+    ev.set(xd, "cur_buf", cur); ev.set(xd, "bd", bd)
     mi = ev.interp.alloc(ev.structs["<opaque>MB_MODE_INFO"], True)
     mip = ev.interp.alloc(("ptr", ev.structs["<opaque>MB_MODE_INFO"]), True)
     mip.store(mi, R.PTR)
@@ -391,6 +407,44 @@ def main():
                                       error_per_bit=70, mv=[ev.get(best, "row"), ev.get(best, "col")], err=err, distortion=dist.buf[0],
                                       sse=sse.buf[0]))
     print("subpel with cost list: %d cases, %.0f s" % (len(cases) - n0, time.time() - t0))
+    # 6. av1_find_best_sub_pixel_tree with the up-sampled prediction error (subpel_search_type USE_8_TAPS, the encoder's
+    #    default): aom_[highbd_]upsampled_pred_c -> aom_[highbd_]convolve8_{horiz,vert}_c -> vfp->vf
+    n0 = len(cases)
+    rng3 = np.random.default_rng(20261010)
+    for bd in (8, 10):
+        hs = harness[bd]
+        for (w, h, cost_type) in ((8, 8, "L1_HDRES"), (16, 16, "NONE"), (16, 8, "ENTROPY"), (8, 16, "L1_LOWRES")):
+            if bd == 10 and (w, h) != (8, 8):
+                continue
+            for trial in range(2):
+                bx, by = int(rng3.integers(0, (W - w) // 4 + 1)) * 4, int(rng3.integers(0, (H - h) // 4 + 1)) * 4
+                blk = (bx, by, 0, 0, int(rng3.integers(-30, 31)), int(rng3.integers(-30, 31))) + limits(bx, by, w, h, 24)
+                fp = run_fullpel("diamond", bd, w, h, blk, "DIAMOND", 4, cost_type)
+                cases.pop()
+                allow_hp, forced_stop, iters = int(rng3.integers(0, 2)), int(rng3.integers(0, 2)), 2 - (trial & 1)
+                sp = ev.new("SUBPEL_MOTION_SEARCH_PARAMS")
+                ev.set(sp, "allow_hp", allow_hp); ev.set(sp, "forced_stop", forced_stop); ev.set(sp, "iters_per_step", iters)
+                fl = ev.new("FullMvLimits")
+                for k, v in zip(("row_min", "row_max", "col_min", "col_max"), blk[6:]):
+                    ev.set(fl, k, v)
+                refmv = hs.mv_struct("MV", blk[4], blk[5])
+                ev.interp.call("av1_set_subpel_mv_search_range", [(ev.field(sp, "mv_limits"), R.PTR), (fl, R.PTR), (refmv, R.PTR)])
+                hs.cost_params(sp, "mv_cost_params.", cost_type, blk[4], blk[5], 25, 70)
+                ev.set(sp, "var_params.vfp", hs.vtable(w, h))
+                ev.set(sp, "var_params.subpel_search_type", hs.const("USE_8_TAPS"))
+                ev.set(sp, "var_params.ms_buffers.ref", hs.buf2d(hs.refp, by, bx)); ev.set(sp, "var_params.ms_buffers.src", hs.buf2d(hs.srcp, by, bx))
+                ev.set(sp, "var_params.w", w); ev.set(sp, "var_params.h", h)
+                start = hs.mv_struct("MV", fp["mv"][0] * 8, fp["mv"][1] * 8)
+                best = ev.new("MV")
+                dist, sse = ev.array([0], "int"), ev.array([0], "unsigned int")
+                t1 = time.time()
+                err = ev.call("av1_find_best_sub_pixel_tree", make_xd(ev, bd), None, sp, start.buf[0], best, dist, sse, None)
+                lim = [ev.get(sp, "mv_limits." + k) for k in ("row_min", "row_max", "col_min", "col_max")]
+                cases.append(dict(kind="subpel", fn="av1_find_best_sub_pixel_tree", subpel_search_type=3, bd=bd, w=w, h=h, block=list(blk),
+                                  fullpel_mv=fp["mv"], cost_type=COST_TYPES[cost_type], allow_hp=allow_hp, forced_stop=forced_stop, iters=iters,
+                                  subpel_limits=lim, error_per_bit=70, mv=[ev.get(best, "row"), ev.get(best, "col")], err=err,
+                                  distortion=dist.buf[0], sse=sse.buf[0], sec_s=round(time.time() - t1, 1)))
+    print("subpel tree, 8-tap up-sampled error: %d cases, %.0f s" % (len(cases) - n0, time.time() - t0))
     # the site tables themselves (G1): every builder, as (stage, index) -> (row, col), searches_per_step, radius
     sites = {}
     for m in METHODS:

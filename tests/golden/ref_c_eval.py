@@ -411,7 +411,8 @@ class Parser:
 
     def is_type_start(self, k=0):
         s = self.peek(k)
-        return self.kind(k) == "id" and (s in TYPE_WORDS or s in QUALIFIERS or s in self.typedefs or s in ("struct", "union", "enum"))
+        return self.kind(k) == "id" and (s in TYPE_WORDS or s in QUALIFIERS or s in self.typedefs or s in ("struct", "union", "enum")
+                                         or ("<opaque>" + s) in self.structs)
 
     # -- declarations
     def specifiers(self):
@@ -473,7 +474,7 @@ class Parser:
                 raise CError("union not supported")
             elif s == "__attribute__":
                 self.i += 1; self.skip_parens()
-            elif (self.lenient and base is None and not words and s not in self.typedefs
+            elif ((self.lenient or ("<opaque>" + s) in self.structs) and base is None and not words and s not in self.typedefs
                   and (self.peek(1) in ("*", ")", ",") or self.kind(1) == "id")):
                 self.i += 1
                 base = self.structs.get("<opaque>" + s)
@@ -1242,6 +1243,11 @@ class Interp:
                 return v, t
             if t is PTR:
                 # pointer casts keep the buffer; a cast between integer types of one size gives a re-typed view
+                if v.__class__ is Ptr and ty[0] == "ptr" and ty[1].__class__ is T and v.t.__class__ is T and v.dims:
+                    # (int16_t *)table2d: a pointer to rows becomes a pointer to the first scalar of that row
+                    if ty[1].size != v.t.size:
+                        raise CError("pointer cast changes the element size (%s -> %s)" % (v.t, ty[1]))
+                    return Ptr(v.buf, v.off, ty[1] if ty[1] is not v.t else v.t), PTR
                 if (v.__class__ is Ptr and ty[0] == "ptr" and ty[1].__class__ is T and v.t.__class__ is T and ty[1] is not v.t
                         and not v.dims):
                     if ty[1].size != v.t.size:

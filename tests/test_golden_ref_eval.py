@@ -166,7 +166,8 @@ def test_subpel_tree_matches_reference_evaluation(oracle):
         mv, err, dist, sse = oracle.subpel_tree_batch(*args, tree=tree, cost_type=c["cost_type"], error_per_bit=c["error_per_bit"],
                                                       mvjcost=z["mvjcost"], mvcost0=z["mvcost0"], mvcost1=z["mvcost1"], iters=c["iters"],
                                                       allow_hp=c["allow_hp"], forced_stop=c["forced_stop"],
-                                                      cost_lists=[c["cost_list"]] if "cost_list" in c else None, bd=c["bd"], threads=1)
+                                                      cost_lists=[c["cost_list"]] if "cost_list" in c else None, bd=c["bd"], threads=1,
+                                                      subpel_search_type=c.get("subpel_search_type", 0))
         assert (list(map(int, mv[0])), int(err[0]), int(dist[0]), int(sse[0])) == (c["mv"], c["err"], c["distortion"], c["sse"]), c
         if tree == "pruned_more" and "cost_list" not in c and c["cost_type"] != 0:     # the older entry point agrees
             got = oracle.subpel_bilinear_batch(*args, cost_type=c["cost_type"], iters=c["iters"], allow_hp=c["allow_hp"],
@@ -174,7 +175,8 @@ def test_subpel_tree_matches_reference_evaluation(oracle):
             assert np.array_equal(got[0], mv) and int(got[1][0]) == c["err"]
         n += 1
         with_cl += "cost_list" in c
-    assert n >= 48 and with_cl >= 24
+    assert n >= 58 and with_cl >= 24
+    assert sum(c.get("subpel_search_type", 0) == 3 for c in meta["cases"]) >= 10      # the 8-tap (up-sampled prediction) tree
 
 
 def test_search_site_tables_match_reference_evaluation(oracle):
