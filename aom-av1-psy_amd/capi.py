@@ -49,7 +49,8 @@ SUBPEL_TREES = {"pruned_more": 0, "pruned": 1, "tree": 2}
 
 class SubpelParams(C.Structure):
     """aomhip_subpel_params."""
-    _fields_ = [(n, C.c_int32) for n in ("tree", "mv_cost_type", "error_per_bit", "iters_per_step", "allow_hp", "forced_stop")]
+    _fields_ = [(n, C.c_int32) for n in ("tree", "mv_cost_type", "error_per_bit", "iters_per_step", "allow_hp", "forced_stop",
+                                         "subpel_search_type")]
 
 
 def search_sites(method):

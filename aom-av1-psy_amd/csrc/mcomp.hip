@@ -25,12 +25,8 @@
 
 namespace aomhip {
 
-constexpr int kSearchThreads = 256;  // 4 blocks (wavefronts) per workgroup
 #ifndef AOMHIP_DIAMOND_WAVES
 #define AOMHIP_DIAMOND_WAVES 5   // waves per SIMD the register allocation aims at (A/B: profiles/r01_search_variants.md)
-#endif
-#ifndef AOMHIP_SUBPEL_WAVES
-#define AOMHIP_SUBPEL_WAVES 5
 #endif
 
 template <typename T, int W, int H>
@@ -212,189 +208,6 @@ __global__ __launch_bounds__(kSearchThreads, AOMHIP_DIAMOND_WAVES) void fullpel_
     out_mv[2 * bi] = (int16_t)br;
     out_mv[2 * bi + 1] = (int16_t)bc;
     out_cost[bi] = bestsme;
-  }
-}
-
-// MV_COST_ENTROPY inputs of the sub-pel search (mv_err_cost, mcomp.c:271-295): joint[4] and the two component tables
-// addressed from their centres, error_per_bit
-struct SubpelCostTables {
-  const int *mvjcost, *mvcost0, *mvcost1;
-  int error_per_bit;
-};
-
-// GENERAL = false is the lean instantiation behind aomhip_subpel_bilinear_batch (pruned_more, no cost list, L1 / no MV
-// cost): the extra arguments and branches of the general form cost it 2 % on the 4K search benchmark.
-template <typename T, int W, int H, bool GENERAL>
-__global__ __launch_bounds__(kSearchThreads, AOMHIP_SUBPEL_WAVES) void subpel_bilinear_kernel(
-    PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
-    int cost_type, int iters_per_step, int allow_hp, int forced_stop, int bit_depth, int tree_arg,
-    const int32_t *__restrict__ cost_lists_arg, SubpelCostTables ct, int16_t *__restrict__ out_mv,
-    uint32_t *__restrict__ out_err, int32_t *__restrict__ out_dist, uint32_t *__restrict__ out_sse) {
-  const int tree = GENERAL ? tree_arg : 0;
-  const int32_t *cost_lists = GENERAL ? cost_lists_arg : nullptr;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int bi = blockIdx.x * (kSearchThreads / 64) + wave;
-  if (bi >= n_blocks) return;
-  const aomhip_search_block b = blocks[bi];  // start_* in 1/8 pel, limits = SubpelMvLimits
-  const T *sp = src.origin + (int64_t)frame * src.frame_stride + (int64_t)b.by * src.stride + b.bx;
-  const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)b.by * ref.stride + b.bx;
-  const CostCtx cc{ cost_type, b.ref_row, b.ref_col };
-  auto var_cost = [&](int mrow, int mcol) -> int {  // mv_err_cost_ (mcomp.c:271-308)
-    if (GENERAL && cost_type == kCostEntropy) {
-      const int dr = mrow - b.ref_row, dc = mcol - b.ref_col;
-      const int64_t bits = ct.mvjcost[(dc != 0) | ((dr != 0) << 1)] + ct.mvcost0[dr] + ct.mvcost1[dc];
-      return (int)((bits * ct.error_per_bit + (1 << 13)) >> 14);
-    }
-    return cc.var_cost(mrow, mcol);
-  };
-
-  const int grp = lane >> 4, j = lane & 15;
-  uint32_t besterr, sse1;
-  int distortion, best_row = b.start_row, best_col = b.start_col;
-  {  // setup_center_error: vf(ref at the full-pel part, src): diff = ref - src
-    const int fr = b.start_row >> 3, fc = b.start_col >> 3;
-    uint32_t q;
-    uint32_t v = group16_variance<T, W, H, false>(rbase + (int64_t)fr * ref.stride + fc, ref.stride, 0, 0, sp, src.stride,
-                                                  /*a_minus_b=*/true, bit_depth, j, grp == 0, &q);
-    v = __shfl(v, 0, 64);
-    sse1 = __shfl(q, 0, 64);
-    distortion = (int)v;
-    besterr = v + (uint32_t)var_cost(b.start_row, b.start_col);
-  }
-  // check_better_fast (mcomp.c:2433-2461) for up to four candidates whose POSITIONS do not depend on each other:
-  // group g evaluates candidate g (one aom_sub_pixel_varianceWxH each), then every lane replays the reference's
-  // sequential `if (cost < besterr)` updates in candidate order, so the outcome is that of the scalar sequence.
-  int is_better = 0;  // check_better_fast's *is_better (only second_level_check_v2 looks at it)
-  auto check_n = [&](int n, const int (&mrow)[4], const int (&mcol)[4], uint32_t (&cost)[4]) {
-    int my_row = mrow[0], my_col = mcol[0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) {
-      my_row = grp == k ? mrow[k] : my_row;
-      my_col = grp == k ? mcol[k] : my_col;
-    }
-    const bool inb = my_col >= b.col_min && my_col <= b.col_max && my_row >= b.row_min && my_row <= b.row_max;
-    uint32_t q;
-    const uint32_t v = group16_variance<T, W, H, true>(rbase + (int64_t)(my_row >> 3) * ref.stride + (my_col >> 3),
-                                                       ref.stride, my_col & 7, my_row & 7, sp, src.stride, true, bit_depth,
-                                                       j, inb && grp < n, &q);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      cost[k] = (uint32_t)INT_MAX;
-      if (k < n) {
-        const uint32_t vk = __shfl(v, 16 * k, 64), qk = __shfl(q, 16 * k, 64);
-        const bool in_k = mcol[k] >= b.col_min && mcol[k] <= b.col_max && mrow[k] >= b.row_min && mrow[k] <= b.row_max;
-        if (in_k) {
-          const int thismse = (int)vk;
-          cost[k] = (uint32_t)var_cost(mrow[k], mcol[k]) + (uint32_t)thismse;
-          if (cost[k] < besterr) {
-            besterr = cost[k];
-            best_row = mrow[k];
-            best_col = mcol[k];
-            distortion = thismse;
-            sse1 = qk;
-            is_better = 1;
-          }
-        }
-      }
-    }
-  };
-  auto first_level = [&](int trow, int tcol, int hstep, int *odrow, int *odcol) {  // first_level_check_fast (:2503-2543)
-    uint32_t c[4];
-    {
-      const int r4[4] = { trow, trow, trow - hstep, trow + hstep }, c4[4] = { tcol - hstep, tcol + hstep, tcol, tcol };
-      check_n(4, r4, c4, c);  // left, right, up, down
-    }
-    const uint32_t left = c[0], right = c[1], up = c[2], down = c[3];
-    const int drow = up <= down ? -hstep : hstep, dcol = left <= right ? -hstep : hstep;
-    {
-      const int r1[4] = { trow + drow, 0, 0, 0 }, c1[4] = { tcol + dcol, 0, 0, 0 };
-      check_n(1, r1, c1, c);
-    }
-    *odrow = drow;
-    *odcol = dcol;
-  };
-  auto second_level_v2 = [&](int trow, int tcol, int drow, int dcol) {  // second_level_check_v2 (:2665-2716), bilinear branch
-    if (trow == best_row && tcol == best_col) return;
-    if (trow == best_row) drow = -drow;
-    else if (tcol == best_col) dcol = -dcol;
-    const int br = best_row, bc = best_col;
-    uint32_t c[4];
-    is_better = 0;
-    // row_bias then col_bias: the second position does not depend on the first outcome
-    const int r2[4] = { br + drow, br, 0, 0 }, c2[4] = { bc, bc + dcol, 0, 0 };
-    check_n(2, r2, c2, c);
-    if (is_better) {
-      const int r1[4] = { br + drow, 0, 0, 0 }, c1[4] = { bc + dcol, 0, 0, 0 };
-      check_n(1, r1, c1, c);
-    }
-  };
-  auto two_level = [&](int trow, int tcol, int hstep) {  // two_level_checks_fast (mcomp.c:2503-2624)
-    uint32_t c[4];
-    int drow, dcol;
-    first_level(trow, tcol, hstep, &drow, &dcol);
-    if (iters_per_step <= 1) return;
-    const int br = best_row, bc = best_col;
-    if (trow != br && tcol != bc) {
-      const int r2[4] = { br, br + drow, 0, 0 }, c2[4] = { bc + dcol, bc, 0, 0 };
-      check_n(2, r2, c2, c);
-    } else if (trow == br && tcol != bc) {
-      const int r3[4] = { br + hstep, br - hstep, br - drow, 0 }, c3[4] = { bc + dcol, bc + dcol, bc, 0 };
-      check_n(3, r3, c3, c);
-    } else if (trow != br && tcol == bc) {
-      const int r3[4] = { br + drow, br + drow, br, 0 }, c3[4] = { bc + hstep, bc - hstep, bc - dcol, 0 };
-      check_n(3, r3, c3, c);
-    }
-  };
-  int hstep = 4;          // INIT_SUBPEL_STEP_SIZE
-  if (tree == 2) {         // av1_find_best_sub_pixel_tree (:3069-3133)
-    const int round = min(3 - forced_stop, 3 - (allow_hp ? 0 : 1));
-    for (int iter = 0; iter < round; ++iter) {
-      const int cr = best_row, ccol = best_col;
-      int drow, dcol;
-      first_level(cr, ccol, hstep, &drow, &dcol);
-      if (!(cr == best_row && ccol == best_col) && iters_per_step > 1) second_level_v2(cr, ccol, drow, dcol);
-      hstep >>= 1;
-    }
-  } else if (forced_stop != 3) {  // FULL_PEL
-    // first iteration: a usable cost list replaces the two-level check (pruned_more: the minimum of the fitted cost
-    // surface, :2879-2893; pruned: the quadrant the cheaper neighbours point at, :2968-3043)
-    int c0 = INT_MAX, c1 = INT_MAX, c2 = INT_MAX, c3 = INT_MAX, c4 = INT_MAX;
-    if (cost_lists) {
-      c0 = cost_lists[5 * bi]; c1 = cost_lists[5 * bi + 1]; c2 = cost_lists[5 * bi + 2];
-      c3 = cost_lists[5 * bi + 3]; c4 = cost_lists[5 * bi + 4];
-    }
-    const bool usable = c0 != INT_MAX && c1 != INT_MAX && c2 != INT_MAX && c3 != INT_MAX && c4 != INT_MAX;
-    uint32_t cst[4];
-    if (tree == 0 && usable && c0 < c1 && c0 < c2 && c0 < c3 && c0 < c4) {
-      auto div_round = [](int n, int d) { return ((n < 0) ^ (d < 0)) ? ((n - d / 2) / d) : ((n + d / 2) / d); };
-      const int ic = div_round(c1 - c3, c1 - 2 * c0 + c3), ir = div_round(c4 - c2, c4 - 2 * c0 + c2);  // get_cost_surf_min, bits = 1
-      if (ir != 0 || ic != 0) {
-        const int r1[4] = { b.start_row + ir * hstep, 0, 0, 0 }, q1[4] = { b.start_col + ic * hstep, 0, 0, 0 };
-        check_n(1, r1, q1, cst);
-      }
-    } else if (tree == 1 && usable) {
-      const int dc = (c1 < c3) ? -hstep : hstep, dr = (c2 < c4) ? hstep : -hstep;  // left : right, bottom : top
-      const int r3[4] = { b.start_row, b.start_row + dr, b.start_row + dr, 0 };
-      const int q3[4] = { b.start_col + dc, b.start_col, b.start_col + dc, 0 };
-      check_n(3, r3, q3, cst);
-    } else {
-      two_level(b.start_row, b.start_col, hstep);
-    }
-    if (forced_stop < 2) {  // < HALF_PEL
-      hstep >>= 1;
-      two_level(best_row, best_col, hstep);
-    }
-    if (allow_hp && forced_stop == 0) {  // EIGHTH_PEL
-      hstep >>= 1;
-      two_level(best_row, best_col, hstep);
-    }
-  }
-  if (lane == 0) {
-    out_mv[2 * bi] = (int16_t)best_row;
-    out_mv[2 * bi + 1] = (int16_t)best_col;
-    out_err[bi] = besterr;
-    out_dist[bi] = distortion;
-    out_sse[bi] = sse1;
   }
 }
 
@@ -593,20 +406,6 @@ __global__ __launch_bounds__(kMeshThreads) void mesh_search_kernel(
   }
 }
 
-static int check_common(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
-                        const void *blocks, int n, int cost_type) {
-  if (!ctx || !src || !ref || !src->base || !ref->base || (n > 0 && !blocks) || n < 0 || frame < 0 ||
-      frame >= src->n_frames || frame >= ref->n_frames || !valid_block(bw, bh) ||
-      (src->bit_depth == 8) != (ref->bit_depth == 8)) {
-    set_error("motion search: invalid argument");
-    return AOMHIP_ERR_INVALID;
-  }
-  if (cost_type == kCostEntropy || cost_type < 0 || cost_type > kCostNone) {
-    set_error("motion search: MV_COST_ENTROPY (cost tables) is not supported on the device path yet");
-    return AOMHIP_ERR_INVALID;
-  }
-  return AOMHIP_OK;
-}
 
 }  // namespace aomhip
 
@@ -642,68 +441,6 @@ int aomhip_fullpel_diamond_batch(aomhip_ctx *ctx, const aomhip_planes *src, cons
   AOMHIP_FOR_BLOCK_SIZES(X)
 #undef X
   return AOMHIP_ERR_INVALID;
-}
-
-static int launch_subpel(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
-                         int mv_cost_type, int iters_per_step, int allow_hp, int forced_stop, int tree,
-                         const int32_t *d_cost_lists, SubpelCostTables ct, const aomhip_search_block *d_blocks, int n_blocks,
-                         int16_t *d_best_mv, uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse) {
-  if (n_blocks == 0) return AOMHIP_OK;
-  const dim3 grid((n_blocks + 3) / 4), block(kSearchThreads);
-  const bool general = tree != 0 || d_cost_lists != nullptr || mv_cost_type == kCostEntropy;
-#define X(W, H)                                                                                                      \
-  if (bw == W && bh == H) {                                                                                          \
-    if (src->bit_depth == 8)                                                                                         \
-      hipLaunchKernelGGL((general ? subpel_bilinear_kernel<uint8_t, W, H, true> : subpel_bilinear_kernel<uint8_t, W, H, false>), grid, block, 0, ctx->stream, view_of<uint8_t>(*src), \
-                         view_of<uint8_t>(*ref), frame, d_blocks, n_blocks, mv_cost_type, iters_per_step, allow_hp,  \
-                         forced_stop, 8, tree, d_cost_lists, ct, d_best_mv, d_best_err, d_distortion, d_sse);        \
-    else                                                                                                             \
-      hipLaunchKernelGGL((general ? subpel_bilinear_kernel<uint16_t, W, H, true> : subpel_bilinear_kernel<uint16_t, W, H, false>), grid, block, 0, ctx->stream, \
-                         view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame, d_blocks, n_blocks, mv_cost_type,  \
-                         iters_per_step, allow_hp, forced_stop, src->bit_depth, tree, d_cost_lists, ct, d_best_mv,   \
-                         d_best_err, d_distortion, d_sse);                                                           \
-    AOMHIP_LAUNCH_CHECK();                                                                                           \
-    return AOMHIP_OK;                                                                                                \
-  }
-  AOMHIP_FOR_BLOCK_SIZES(X)
-#undef X
-  return AOMHIP_ERR_INVALID;
-}
-
-int aomhip_subpel_bilinear_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw,
-                                 int bh, int mv_cost_type, int iters_per_step, int allow_hp, int forced_stop,
-                                 const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
-                                 uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse) {
-  int rc = check_common(ctx, src, ref, frame, bw, bh, d_blocks, n_blocks, mv_cost_type);
-  if (rc != AOMHIP_OK) return rc;
-  if (!d_best_mv || !d_best_err || !d_distortion || !d_sse || forced_stop < 0 || forced_stop > 3) {
-    set_error("aomhip_subpel_bilinear_batch: invalid argument");
-    return AOMHIP_ERR_INVALID;
-  }
-  return launch_subpel(ctx, src, ref, frame, bw, bh, mv_cost_type, iters_per_step, allow_hp, forced_stop, /*tree=*/0, nullptr,
-                       SubpelCostTables{ nullptr, nullptr, nullptr, 0 }, d_blocks, n_blocks, d_best_mv, d_best_err,
-                       d_distortion, d_sse);
-}
-
-int aomhip_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
-                             const aomhip_subpel_params *p, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
-                             const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, const int32_t *d_cost_list,
-                             int n_blocks, int16_t *d_best_mv, uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse) {
-  if (!p) {
-    set_error("aomhip_subpel_tree_batch: invalid argument");
-    return AOMHIP_ERR_INVALID;
-  }
-  const bool entropy = p->mv_cost_type == kCostEntropy;
-  int rc = check_common(ctx, src, ref, frame, bw, bh, d_blocks, n_blocks, entropy ? kCostNone : p->mv_cost_type);
-  if (rc != AOMHIP_OK) return rc;
-  if (!d_best_mv || !d_best_err || !d_distortion || !d_sse || p->forced_stop < 0 || p->forced_stop > 3 || p->tree < 0 ||
-      p->tree > 2 || (entropy && (!d_mvjcost || !d_mvcost_row || !d_mvcost_col))) {
-    set_error("aomhip_subpel_tree_batch: invalid argument (tree 0..2, forced_stop 0..3, MV_COST_ENTROPY needs its tables)");
-    return AOMHIP_ERR_INVALID;
-  }
-  return launch_subpel(ctx, src, ref, frame, bw, bh, p->mv_cost_type, p->iters_per_step, p->allow_hp, p->forced_stop, p->tree,
-                       d_cost_list, SubpelCostTables{ d_mvjcost, d_mvcost_row, d_mvcost_col, p->error_per_bit }, d_blocks,
-                       n_blocks, d_best_mv, d_best_err, d_distortion, d_sse);
 }
 
 int aomhip_mesh_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,

@@ -304,6 +304,23 @@ __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, i
   X(4, 4) X(4, 8) X(8, 4) X(8, 8) X(8, 16) X(16, 8) X(16, 16) X(16, 32) X(32, 16) X(32, 32) X(32, 64) X(64, 32) \
   X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(4, 16) X(16, 4) X(8, 32) X(32, 8) X(16, 64) X(64, 16)
 
+inline int check_common(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                        const void *blocks, int n, int cost_type) {
+  if (!ctx || !src || !ref || !src->base || !ref->base || (n > 0 && !blocks) || n < 0 || frame < 0 ||
+      frame >= src->n_frames || frame >= ref->n_frames || !valid_block(bw, bh) ||
+      (src->bit_depth == 8) != (ref->bit_depth == 8)) {
+    set_error("motion search: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (cost_type == kCostEntropy || cost_type < 0 || cost_type > kCostNone) {
+    set_error("motion search: MV_COST_ENTROPY (cost tables) is not supported on the device path yet");
+    return AOMHIP_ERR_INVALID;
+  }
+  return AOMHIP_OK;
+}
+
+constexpr int kSearchThreads = 256;  // 4 blocks (wavefronts) per workgroup
+
 }  // namespace aomhip
 
 #endif  // AOMHIP_CSRC_SEARCH_DEVICE_H_

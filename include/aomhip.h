@@ -352,8 +352,8 @@ int aomhip_subpel_bilinear_batch(aomhip_ctx *ctx, const aomhip_planes *src, cons
 
 /* The three bilinear sub-pel searches with everything the scalar calls take: `tree` 0 =
  * av1_find_best_sub_pixel_tree_pruned_more (mcomp.c:2844-2929), 1 = _pruned (:2931-3067), 2 = av1_find_best_sub_pixel_tree
- * (:3069-3133: first_level_check_fast + second_level_check_v2 per precision); subpel_search_type USE_2_TAPS_ORIG,
- * unscaled reference, last_mv_search_list == NULL.
+ * (:3069-3133: first_level_check[_fast] + second_level_check_v2 per precision); subpel_search_type USE_2_TAPS_ORIG or
+ * USE_8_TAPS, unscaled reference, last_mv_search_list == NULL.
  *   d_cost_list    5 ints per block as aomhip_full_pixel_search_batch wrote them (ms_params->cost_list), or NULL: a
  *                  usable list replaces the first two-level check (pruned_more: minimum of the fitted cost surface,
  *                  get_cost_surf_min; pruned: the three candidates of the cheaper quadrant)
@@ -365,6 +365,11 @@ typedef struct {
   int32_t mv_cost_type;         /* AOMHIP_MV_COST_* */
   int32_t error_per_bit;
   int32_t iters_per_step, allow_hp, forced_stop;
+  int32_t subpel_search_type;   /* SUBPEL_SEARCH_TYPE (av1/common/filter.h:45-50): 0 USE_2_TAPS_ORIG, or 3 USE_8_TAPS -- the
+                                 * tree then measures every candidate with the up-sampled prediction (aom_upsampled_pred:
+                                 * 8-tap regular filter, two rounded passes) as upsampled_pref_error does; the pruned
+                                 * trees use the bilinear estimate for every value (check_better_fast, unscaled ref).
+                                 * The block + MV + 3 pixels must stay inside the bordered plane. */
 } aomhip_subpel_params;
 int aomhip_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
                              const aomhip_subpel_params *params, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,

@@ -774,7 +774,7 @@ static unsigned svf_at(const search_ctx *c, int mrow, int mcol, uint32_t *sse) {
 }
 
 /* EIGHTTAP_REGULAR sub-pel kernels (AV1 spec, av1/common/filter.h:124-141); a 1/8-pel offset s uses row 2 * s */
-static const int8_t k_sub_pel_8[16][8] = {
+static const int16_t k_sub_pel_8[16][8] = {
   { 0, 0, 0, 128, 0, 0, 0, 0 },      { 0, 2, -6, 126, 8, -2, 0, 0 },    { 0, 2, -10, 122, 18, -4, 0, 0 },
   { 0, 2, -12, 116, 28, -8, 2, 0 },  { 0, 2, -14, 110, 38, -10, 2, 0 }, { 0, 2, -14, 102, 48, -12, 2, 0 },
   { 0, 2, -16, 94, 58, -12, 2, 0 },  { 0, 2, -14, 84, 66, -12, 2, 0 },  { 0, 2, -14, 76, 76, -14, 2, 0 },
@@ -782,7 +782,7 @@ static const int8_t k_sub_pel_8[16][8] = {
   { 0, 2, -10, 38, 110, -14, 2, 0 }, { 0, 2, -8, 28, 116, -12, 2, 0 },  { 0, 0, -4, 18, 122, -10, 2, 0 },
   { 0, 0, -2, 8, 126, -6, 2, 0 }
 };
-const int8_t *orc_sub_pel_filters_8(void) { return &k_sub_pel_8[0][0]; }
+const int16_t *orc_sub_pel_filters_8(void) { return &k_sub_pel_8[0][0]; }
 
 static int ref_px(const search_ctx *c, int row, int col) {
   return c->elem16 ? ((const uint16_t *)c->ref)[(ptrdiff_t)row * c->ref_stride + col]
@@ -794,7 +794,7 @@ static int ref_px(const search_ctx *c, int row, int col) {
  * clipped to the pixel range; a zero offset in one direction skips that pass.  pred: w * h, row pitch w. */
 static void upsampled_pred8(const search_ctx *c, int mrow, int mcol, uint16_t *pred) {
   const int fr = mrow >> 3, fc = mcol >> 3, sx = mcol & 7, sy = mrow & 7;
-  const int8_t *kx = k_sub_pel_8[2 * sx], *ky = k_sub_pel_8[2 * sy];
+  const int16_t *kx = k_sub_pel_8[2 * sx], *ky = k_sub_pel_8[2 * sy];
   const int mx = c->elem16 ? (1 << c->bd) - 1 : 255;
   const int w = c->w, h = c->h;
   if (!sx && !sy) {

@@ -171,7 +171,7 @@ def test_full_pixel_search_rejects_bad_arguments(hip, ctx):
 # ---- the bilinear sub-pel trees (aomhip_subpel_tree_batch)
 
 def _run_subpel(hip, ctx, ps, pr, bw, bh, blocks, tree, cost_type, error_per_bit, iters, allow_hp, forced_stop, cost_lists=None,
-                tables=None):
+                tables=None, sst=0):
     n = len(blocks)
     d_b = ctx.to_device(blocks)
     d_mv, d_e, d_d, d_s = (ctx.malloc(max(16, n * 4)) for _ in range(4))
@@ -183,7 +183,7 @@ def _run_subpel(hip, ctx, ps, pr, bw, bh, blocks, tree, cost_type, error_per_bit
         dj, d0, d1 = ctx.to_device(j), ctx.to_device(c0), ctx.to_device(c1)
         keep += [dj, d0, d1]
         extra.update(d_mvjcost=dj, d_mvcost_row=d0 + 4 * (c0.size // 2), d_mvcost_col=d1 + 4 * (c1.size // 2))
-    p = hip.capi.SubpelParams(hip.capi.SUBPEL_TREES.get(tree, tree), cost_type, error_per_bit, iters, allow_hp, forced_stop)
+    p = hip.capi.SubpelParams(hip.capi.SUBPEL_TREES.get(tree, tree), cost_type, error_per_bit, iters, allow_hp, forced_stop, sst)
     ctx.subpel_tree_batch(ps, pr, 0, bw, bh, p, d_b, n, d_mv, d_e, d_d, d_s, **extra)
     out = (ctx.from_device(d_mv, (n, 2), np.int16), ctx.from_device(d_e, (n,), np.uint32), ctx.from_device(d_d, (n,), np.int32),
            ctx.from_device(d_s, (n,), np.uint32))
@@ -217,16 +217,17 @@ def test_subpel_trees_match_reference_goldens(hip, ctx):
                 "av1_find_best_sub_pixel_tree": "tree"}[c["fn"]]
         ps, pr = planes[c["bd"]]
         mv, err, dist, sse = _run_subpel(hip, ctx, ps, pr, c["w"], c["h"], blk, tree, c["cost_type"], c["error_per_bit"], c["iters"],
-                                         c["allow_hp"], c["forced_stop"], [c["cost_list"]] if "cost_list" in c else None, tables)
+                                         c["allow_hp"], c["forced_stop"], [c["cost_list"]] if "cost_list" in c else None, tables,
+                                         c.get("subpel_search_type", 0))
         assert (mv[0].tolist(), int(err[0]), int(dist[0]), int(sse[0])) == (c["mv"], c["err"], c["distortion"], c["sse"]), c
         n += 1
-    assert n >= 48
+    assert n >= 58
     for ps, pr in planes.values():
         ctx.planes_free(ps); ctx.planes_free(pr)
 
 
 @pytest.mark.parametrize("bd", [8, 10, 12])
-@pytest.mark.parametrize("bw,bh", [(16, 16), (8, 8), (32, 16), (4, 8), (64, 64)])
+@pytest.mark.parametrize("bw,bh", [(16, 16), (8, 8), (32, 16), (4, 8), (64, 64), (128, 128), (4, 4)])
 def test_subpel_trees_match_oracle(hip, oracle, ctx, bw, bh, bd):
     rng = np.random.default_rng(bw * 7 + bh + bd)
     W, H, border = 320, 192, 96
@@ -260,4 +261,12 @@ def test_subpel_trees_match_oracle(hip, oracle, ctx, bw, bh, bd):
                                             cost_lists=cl if use_cl else None, bd=bd)
             for name, a, w_ in zip(("mv", "err", "dist", "sse"), got, want):
                 assert np.array_equal(a, w_), (tree, cost_type, use_cl, iters, allow_hp, forced_stop, name)
+    # the tree with the up-sampled (8-tap) prediction error
+    for cost_type, iters, allow_hp, forced_stop in ((3, 2, 1, 0), (0, 1, 0, 1), (4, 2, 0, 0)):
+        got = _run_subpel(hip, ctx, ps, pr, bw, bh, blocks, "tree", cost_type, 77, iters, allow_hp, forced_stop, None, tables, sst=3)
+        want = oracle.subpel_tree_batch(sb, rb, border, bw, bh, blocks, tree="tree", cost_type=cost_type, error_per_bit=77, mvjcost=tables[0],
+                                        mvcost0=tables[1], mvcost1=tables[2], iters=iters, allow_hp=allow_hp, forced_stop=forced_stop, bd=bd,
+                                        subpel_search_type=3)
+        for name, a, w_ in zip(("mv", "err", "dist", "sse"), got, want):
+            assert np.array_equal(a, w_), ("8tap", cost_type, iters, allow_hp, forced_stop, name)
     ctx.planes_free(ps); ctx.planes_free(pr)
