@@ -115,6 +115,10 @@ _protos = {
     "aomhip_variance_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp]),
     "aomhip_sub_pixel_variance_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp]),
     "aomhip_variance": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint)]),
+    "aomhip_mse": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint)]),
+    "aomhip_get_var": (None, [_vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint), C.POINTER(C.c_int)]),
+    "aomhip_get_var_sse_sum_8x8_quad": (None, [_vp, _i, _vp, _i, _vp, _vp, C.POINTER(C.c_uint), C.POINTER(C.c_int), _vp]),
+    "aomhip_get_var_sse_sum_16x16_dual": (None, [_vp, _i, _vp, _i, _vp, C.POINTER(C.c_uint), C.POINTER(C.c_int), _vp]),
     "aomhip_sub_pixel_variance": (C.c_uint, [_vp, _i, _i, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint)]),
     "aomhip_variance16x16": (C.c_uint, [_vp, _i, _vp, _i, C.POINTER(C.c_uint)]),
     "aomhip_highbd_variance": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, _i, C.POINTER(C.c_uint)]),

@@ -102,7 +102,8 @@ template <typename T, int W, int H, bool SUBPEL>
 __global__ __launch_bounds__(kVarThreads) void variance_kernel(PlaneView<T> src, PlaneView<T> ref, int first_frame,
                                                                const aomhip_var_cand *__restrict__ cands, int n_cands,
                                                                int64_t cand_frame_stride, uint32_t *__restrict__ out_var,
-                                                               uint32_t *__restrict__ out_sse, int bpf8, int bit_depth) {
+                                                               uint32_t *__restrict__ out_sse, int bpf8, int bit_depth,
+                                                               int32_t *__restrict__ out_sum) {
   using G = VarGeom<T, W, H>;
   constexpr int kCpb = kVarThreads / G::kTpc;
   constexpr int E = G::kUnitElems;
@@ -172,12 +173,14 @@ __global__ __launch_bounds__(kVarThreads) void variance_kernel(PlaneView<T> src,
     finish<0, ilog2v(W * H)>(sum, sse, bit_depth, &v, &q);
     out_var[(int64_t)f_rel * n_cands + ci] = v;
     out_sse[(int64_t)f_rel * n_cands + ci] = q;
+    if (out_sum) out_sum[(int64_t)f_rel * n_cands + ci] = (int32_t)sum;  // the raw sum of differences (aom_get*var, 8-bit)
   }
 }
 
 struct VarLaunch {
   hipStream_t stream;
   int first_frame, n_frames, bit_depth;
+  int32_t *out_sum = nullptr;
 };
 
 template <typename T, int W, int H, bool SUBPEL>
@@ -188,7 +191,7 @@ static int launch_var(const VarLaunch &l, const PlaneView<T> &s, const PlaneView
   const int bpf = (n + kCpb - 1) / kCpb;
   const int bpf8 = (bpf + 7) & ~7;
   hipLaunchKernelGGL((variance_kernel<T, W, H, SUBPEL>), dim3((unsigned)bpf8 * l.n_frames), dim3(kVarThreads), 0,
-                     l.stream, s, r, l.first_frame, c, n, cfs, var, sse, bpf8, l.bit_depth);
+                     l.stream, s, r, l.first_frame, c, n, cfs, var, sse, bpf8, l.bit_depth, l.out_sum);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
@@ -231,7 +234,7 @@ static int var_batch(bool subpel, aomhip_ctx *ctx, const aomhip_planes *src, con
 // rtcd-signature path: a = (bw+1) x (bh+1) pixels at a_ptr, b = bw x bh at b_ptr, host memory.
 template <typename T>
 static uint32_t host_variance(bool subpel, const T *a, int a_stride, int xoff, int yoff, const T *b, int b_stride, int bw,
-                              int bh, int bit_depth, uint32_t *sse_out) {
+                              int bh, int bit_depth, uint32_t *sse_out, int *sum_out = nullptr) {
   aomhip_ctx *ctx = default_ctx();
   if (!valid_block(bw, bh)) {
     set_error("unsupported block size %dx%d", bw, bh);
@@ -261,14 +264,16 @@ static uint32_t host_variance(bool subpel, const T *a, int a_stride, int xoff, i
   const PlaneView<T> &rv = subpel ? pa : pb;
   VarLaunch l{ ctx->stream, 0, 1, bit_depth };
   uint32_t *dv = reinterpret_cast<uint32_t *>(d + o_off);
+  l.out_sum = reinterpret_cast<int32_t *>(dv + 2);
   if (dispatch_var<T>(subpel, l, sv, rv, bw, bh, reinterpret_cast<const aomhip_var_cand *>(d + c_off), 1, 0, dv,
                       dv + 1) != AOMHIP_OK)
     fatal("aomhip_variance launch");
-  if (hipMemcpyAsync(h + o_off, d + o_off, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+  if (hipMemcpyAsync(h + o_off, d + o_off, 12, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess)
     fatal("aomhip_variance D2H");
   const uint32_t *res = reinterpret_cast<const uint32_t *>(h + o_off);
   if (sse_out) *sse_out = res[1];
+  if (sum_out) *sum_out = (int)(int32_t)res[2];
   return res[0];
 }
 
@@ -300,6 +305,43 @@ unsigned int aomhip_variance(const uint8_t *a, int a_stride, const uint8_t *b, i
 unsigned int aomhip_sub_pixel_variance(const uint8_t *a, int a_stride, int xoffset, int yoffset, const uint8_t *b,
                                        int b_stride, int bw, int bh, unsigned int *sse) {
   return host_variance<uint8_t>(true, a, a_stride, xoffset, yoffset, b, b_stride, bw, bh, 8, sse);
+}
+
+unsigned int aomhip_mse(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int bw, int bh, unsigned int *sse) {
+  uint32_t q = 0;
+  host_variance<uint8_t>(false, a, a_stride, 0, 0, b, b_stride, bw, bh, 8, &q);
+  if (sse) *sse = q;
+  return q;
+}
+
+void aomhip_get_var(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int bw, int bh, unsigned int *sse,
+                    int *sum) {
+  uint32_t q = 0;
+  host_variance<uint8_t>(false, a, a_stride, 0, 0, b, b_stride, bw, bh, 8, &q, sum);
+  if (sse) *sse = q;
+}
+
+void aomhip_get_var_sse_sum_8x8_quad(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, uint32_t *sse8x8,
+                                     int *sum8x8, unsigned int *tot_sse, int *tot_sum, uint32_t *var8x8) {
+  for (int k = 0; k < 4; ++k) {
+    uint32_t q = 0;
+    var8x8[k] = host_variance<uint8_t>(false, a + 8 * k, a_stride, 0, 0, b + 8 * k, b_stride, 8, 8, 8, &q, &sum8x8[k]);
+    sse8x8[k] = q;
+    *tot_sse += q;
+    *tot_sum += sum8x8[k];
+  }
+}
+
+void aomhip_get_var_sse_sum_16x16_dual(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, uint32_t *sse16x16,
+                                       unsigned int *tot_sse, int *tot_sum, uint32_t *var16x16) {
+  for (int k = 0; k < 2; ++k) {
+    uint32_t q = 0;
+    int sum = 0;
+    var16x16[k] = host_variance<uint8_t>(false, a + 16 * k, a_stride, 0, 0, b + 16 * k, b_stride, 16, 16, 8, &q, &sum);
+    sse16x16[k] = q;
+    *tot_sse += q;
+    *tot_sum += sum;
+  }
 }
 
 unsigned int aomhip_variance16x16(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, unsigned int *sse) {

@@ -501,6 +501,17 @@ unsigned int aomhip_variance(const uint8_t *a, int a_stride, const uint8_t *b, i
 unsigned int aomhip_sub_pixel_variance(const uint8_t *a, int a_stride, int xoffset, int yoffset, const uint8_t *b,
                                        int b_stride, int bw, int bh, unsigned int *sse);
 unsigned int aomhip_variance16x16(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, unsigned int *sse);
+/* The other forms of `variance()` (aom_dsp/variance.c:200-262; aom_dsp_rtcd_defs.pl:1304-1321), 8-bit:
+ * aom_mse{W}x{H} (returns and stores the sse), aom_get{W}x{H}var (sse and the signed sum of differences),
+ * aom_get_var_sse_sum_8x8_quad (four 8x8 blocks of an 8x32 row: per-block sse / sum / variance, totals ACCUMULATED
+ * into *tot_sse / *tot_sum as the reference does) and aom_get_var_sse_sum_16x16_dual (two 16x16 blocks). */
+unsigned int aomhip_mse(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int bw, int bh, unsigned int *sse);
+void aomhip_get_var(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int bw, int bh, unsigned int *sse,
+                    int *sum);
+void aomhip_get_var_sse_sum_8x8_quad(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, uint32_t *sse8x8,
+                                     int *sum8x8, unsigned int *tot_sse, int *tot_sum, uint32_t *var8x8);
+void aomhip_get_var_sse_sum_16x16_dual(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, uint32_t *sse16x16,
+                                       unsigned int *tot_sse, int *tot_sum, uint32_t *var16x16);
 /* aom_dsp_rtcd_defs.pl:1480-1482 aom_highbd_{8,10,12}_variance / _sub_pixel_variance: CONVERT_TO_BYTEPTR
  * pointers, bd = 8 / 10 / 12 selects the flavour. */
 unsigned int aomhip_highbd_variance(const uint8_t *a8, int a_stride, const uint8_t *b8, int b_stride, int bw, int bh,

@@ -282,7 +282,32 @@ def gen_sadvar():
                 sp = np.random.default_rng(rec["second_pred_seed"]).integers(0, mx + 1, w * h)
                 rec["sad_avg"] = ev.call("aom_%ssad%dx%d_avg_c" % (hb, w, h), A, S, Bp, S, ev.array(sp, ct))
             rows.append(rec)
-    save("ref_eval_sadvar.npz", planes, rows)
+    # the other forms of variance() (variance.c:200-262), 8-bit: own generator so that the rows above keep their values
+    rng2 = np.random.default_rng(20261011)
+    a, b = planes["a8"].astype(np.int64), planes["b8"].astype(np.int64)
+    S = a.shape[1]
+    pa, pb = ev.array(a.ravel(), "uint8_t"), ev.array(b.ravel(), "uint8_t")
+    extras = []
+    for trial in range(6):
+        ox, oy, rx, ry = (int(rng2.integers(0, 100)) for _ in range(4))
+        A, Bp = pa.add(oy * S + ox), pb.add(ry * S + rx)
+        rec = {"extra": 1, "ox": ox, "oy": oy, "rx": rx, "ry": ry}
+        sse, sm = ev.array([0], "unsigned int"), ev.array([0], "int")
+        for (w, h) in ((16, 16), (16, 8), (8, 16), (8, 8)):
+            rec["mse%dx%d" % (w, h)] = [ev.call("aom_mse%dx%d_c" % (w, h), A, S, Bp, S, sse), sse.buf[0]]
+        for n in (8, 16):
+            ev.call("aom_get%dx%dvar_c" % (n, n), A, S, Bp, S, sse, sm)
+            rec["get%dvar" % n] = [sse.buf[0], sm.buf[0]]
+        s8, m8, v8 = ev.array([0] * 4, "uint32_t"), ev.array([0] * 4, "int"), ev.array([0] * 4, "uint32_t")
+        ts, tm = ev.array([1000 + trial], "unsigned int"), ev.array([-50 * trial], "int")       # the totals accumulate
+        ev.call("aom_get_var_sse_sum_8x8_quad_c", A, S, Bp, S, s8, m8, ts, tm, v8)
+        rec["quad"] = [list(s8.buf), list(m8.buf), ts.buf[0], tm.buf[0], list(v8.buf), 1000 + trial, -50 * trial]
+        s16, v16 = ev.array([0] * 2, "uint32_t"), ev.array([0] * 2, "uint32_t")
+        ts, tm = ev.array([7], "unsigned int"), ev.array([3], "int")
+        ev.call("aom_get_var_sse_sum_16x16_dual_c", A, S, Bp, S, s16, ts, tm, v16)
+        rec["dual"] = [list(s16.buf), ts.buf[0], tm.buf[0], list(v16.buf), 7, 3]
+        extras.append(rec)
+    save("ref_eval_sadvar.npz", planes, rows + extras)
 
 
 if __name__ == "__main__":

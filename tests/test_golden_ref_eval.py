@@ -80,6 +80,22 @@ def test_sad_variance_match_reference_evaluation(oracle):
     z, rows = load("ref_eval_sadvar.npz")
     assert len(rows) >= 60
     for r in rows:
+        if r.get("extra"):      # aom_mse / aom_get*var / 8x8 quad / 16x16 dual: all `variance()` with the sum kept
+            a, b = np.ascontiguousarray(z["a8"].astype(np.uint8)), np.ascontiguousarray(z["b8"].astype(np.uint8))
+            var_at = lambda dx, w, h: oracle.variance(a, r["oy"], r["ox"] + dx, b, r["ry"], r["rx"] + dx, w, h, bd=8)
+            for (w, h) in ((16, 16), (16, 8), (8, 16), (8, 8)):
+                assert r["mse%dx%d" % (w, h)] == [var_at(0, w, h)[1]] * 2
+            for n in (8, 16):
+                v, sse, sm = var_at(0, n, n)
+                assert r["get%dvar" % n] == [sse, sm]
+            s8, m8, ts, tm, v8, ts0, tm0 = r["quad"]
+            got = [var_at(8 * k, 8, 8) for k in range(4)]
+            assert ([g[1] for g in got], [g[2] for g in got], [g[0] for g in got]) == (s8, m8, v8)
+            assert (ts, tm) == (ts0 + sum(s8), tm0 + sum(m8))
+            s16, ts, tm, v16, ts0, tm0 = r["dual"]
+            got = [var_at(16 * k, 16, 16) for k in range(2)]
+            assert ([g[1] for g in got], [g[0] for g in got]) == (s16, v16) and (ts, tm) == (ts0 + sum(s16), tm0 + sum(g[2] for g in got))
+            continue
         bd, w, h = r["bd"], r["w"], r["h"]
         a = np.ascontiguousarray(z["a%d" % bd].astype(np.uint8 if bd == 8 else np.uint16))
         b = np.ascontiguousarray(z["b%d" % bd].astype(np.uint8 if bd == 8 else np.uint16))

@@ -27,6 +27,27 @@ def test_sad_variance_entry_points_match_reference_goldens(hip):
     lib = hip.capi.lib
     z, rows = load("ref_eval_sadvar.npz")
     for r in rows:
+        if r.get("extra"):
+            a, b = np.ascontiguousarray(z["a8"].astype(np.uint8)), np.ascontiguousarray(z["b8"].astype(np.uint8))
+            S = a.shape[1]
+            pa, pb = a.ctypes.data + r["oy"] * S + r["ox"], b.ctypes.data + r["ry"] * S + r["rx"]
+            sse, sm = C.c_uint(), C.c_int()
+            for (w, h) in ((16, 16), (16, 8), (8, 16), (8, 8)):
+                assert [lib.aomhip_mse(pa, S, pb, S, w, h, C.byref(sse)), sse.value] == r["mse%dx%d" % (w, h)]
+            for n in (8, 16):
+                lib.aomhip_get_var(pa, S, pb, S, n, n, C.byref(sse), C.byref(sm))
+                assert [sse.value, sm.value] == r["get%dvar" % n]
+            s8, m8, ts, tm, v8, ts0, tm0 = r["quad"]
+            o_s, o_m, o_v = (C.c_uint32 * 4)(), (C.c_int * 4)(), (C.c_uint32 * 4)()
+            t_s, t_m = C.c_uint(ts0), C.c_int(tm0)
+            lib.aomhip_get_var_sse_sum_8x8_quad(pa, S, pb, S, o_s, o_m, C.byref(t_s), C.byref(t_m), o_v)
+            assert (list(o_s), list(o_m), t_s.value, t_m.value, list(o_v)) == (s8, m8, ts, tm, v8)
+            s16, ts, tm, v16, ts0, tm0 = r["dual"]
+            o_s2, o_v2 = (C.c_uint32 * 2)(), (C.c_uint32 * 2)()
+            t_s, t_m = C.c_uint(ts0), C.c_int(tm0)
+            lib.aomhip_get_var_sse_sum_16x16_dual(pa, S, pb, S, o_s2, C.byref(t_s), C.byref(t_m), o_v2)
+            assert (list(o_s2), t_s.value, t_m.value, list(o_v2)) == (s16, ts, tm, v16)
+            continue
         bd, w, h = r["bd"], r["w"], r["h"]
         a = np.ascontiguousarray(z["a%d" % bd].astype(np.uint8 if bd == 8 else np.uint16))
         b = np.ascontiguousarray(z["b%d" % bd].astype(np.uint8 if bd == 8 else np.uint16))
