@@ -59,6 +59,54 @@ __global__ __launch_bounds__(kInvThreads) void inv_txfm_add_kernel(const int32_t
     }
     if (eob && eob[bi] == 0) live = false;  // av1_inverse_transform_block: nothing to add when eob == 0
   }
+  if constexpr (W == 4 && H == 4) {
+    // lossless: av1_highbd_iwht4x4_add (idct.c:34-41) -> _16_add (eob > 1) or _1_add (av1_inv_txfm2d.c:20-114); one lane
+    // does the 16 pixels (lossless blocks are rare and tiny)
+    if (live && tx_type == kTxWht) {
+      if (lane == 0) {
+        constexpr int kMaxW = (1 << BD) - 1;
+        auto put = [&](int r, int c, int v) {
+          PIX *p = dst_origin + (int64_t)(by + r) * dst_stride + bx + c;
+          int o = (int)*p + v;
+          *p = (PIX)(o < 0 ? 0 : (o > kMaxW ? kMaxW : o));
+        };
+        auto bf = [](int &a, int &b, int &c, int &d) {
+          int a1 = a + c, d1 = d - b;
+          const int e1 = (a1 - d1) >> 1;
+          const int b1 = e1 - b, c1 = e1 - c;
+          a1 -= b1;
+          d1 += c1;
+          a = a1; b = b1; c = c1; d = d1;
+        };
+        const int32_t *in = dqcoeff + in_off;
+        if (!eob || eob[bi] > 1) {
+          int o[16];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int a = in[i] >> 2, c = in[4 + i] >> 2, d = in[8 + i] >> 2, b = in[12 + i] >> 2;
+            bf(a, b, c, d);
+            o[i] = a; o[4 + i] = b; o[8 + i] = c; o[12 + i] = d;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int a = o[4 * i], c = o[4 * i + 1], d = o[4 * i + 2], b = o[4 * i + 3];
+            bf(a, b, c, d);
+            put(0, i, a); put(1, i, b); put(2, i, c); put(3, i, d);
+          }
+        } else {
+          int a1 = in[0] >> 2, e1 = a1 >> 1;
+          a1 -= e1;
+          const int tmp[4] = { a1, e1, e1, e1 };
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int e = tmp[i] >> 1, a = tmp[i] - e;
+            put(0, i, a); put(1, i, e); put(2, i, e); put(3, i, e);
+          }
+        }
+      }
+      live = false;
+    }
+  }
   const int vk = kIVKind[tx_type & 15], hk = kIHKind[tx_type & 15];
   int32_t(&t)[KH * LSTRIDE] = tile[slot];
 

@@ -19,6 +19,10 @@
 #include <cstdint>
 
 namespace aomhip {
+
+// tx_type value (in aomhip_txb / uniform_tx_type) that selects the lossless 4x4 Walsh-Hadamard pair (AOMHIP_TX_WHT)
+constexpr int kTxWht = 16;
+
 namespace txfm {
 
 __device__ constexpr int32_t kCospi[7][64] = {

@@ -406,6 +406,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
 
   // ---- load rows (one wide access per row), apply the up/down flip while loading
   int32_t x[H][W];
+  int32_t x0[H][W];  // the raw residual (the lossless WHT takes it unshifted)
 #pragma unroll
   for (int r = 0; r < H; ++r) {
     const int rr = ud ? H - 1 - r : r;
@@ -433,7 +434,10 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
       for (int j = 0; j < W; ++j) v[j] = (int)ps[j] - (int)pp[j];
     }
 #pragma unroll
-    for (int j = 0; j < W; ++j) x[r][j] = v[j] * (1 << C::fs0);
+    for (int j = 0; j < W; ++j) {
+      x0[r][j] = v[j];
+      x[r][j] = v[j] * (1 << C::fs0);
+    }
   }
 
   // ---- columns
@@ -448,29 +452,65 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
   }
 
   // ---- rows + quantise
-  const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
+  const bool wht = (W == 4 && H == 4) && tx_type == kTxWht;  // lossless: DCT_DCT scan (the flag, not the type, selects WHT)
+  const int scan_class = (wht || tx_type < 10) ? 0 : ((tx_type & 1) ? 2 : 1);
   const int zb[2] = { qa.zbin[0], qa.zbin[1] }, rd[2] = { qa.round[0], qa.round[1] };
   int my_eob = 0;
   int32_t qv[H][W], dv[H][W];
+  auto emit = [&](int r, int c, int32_t v) {  // coefficient (r, c) = index c * H + r of the reference's output
+    if (coeff) coeff[out_off + c * H + r] = v;
+    const int ac = (r | c) != 0;
+    quantize_one<HBD, LS>(v, zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.qs_log2[ac], qa.dequant[ac], &qv[r][c],
+                          &dv[r][c]);
+    // inverse-scan positions are constants here (r, c are unrolled)
+    const int p0 = iscan_pos<W, H>(r, c, 0) + 1, p1 = iscan_pos<W, H>(r, c, 1) + 1, p2 = iscan_pos<W, H>(r, c, 2) + 1;
+    const int p = scan_class == 0 ? p0 : (scan_class == 1 ? p1 : p2);
+    my_eob = (qv[r][c] != 0 && p > my_eob) ? p : my_eob;
+  };
+  if constexpr (W == 4 && H == 4) {
+    if (wht) {  // av1_fwht4x4_c (hybrid_fwd_txfm.c:24-76) on the raw residual, UNIT_QUANT_FACTOR = 4
+      auto bf = [](int &a, int &b, int &c, int &d) {
+        int a1 = a + b, d1 = d - c;
+        const int e1 = (a1 - d1) >> 1;
+        const int b1 = e1 - b, c1 = e1 - c;
+        a1 -= c1;
+        d1 += b1;
+        a = a1; b = b1; c = c1; d = d1;
+      };
+      int t[16], raw[4][4];
 #pragma unroll
-  for (int r = 0; r < H; ++r) {
-    int32_t y[W];
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c = 0; c < W; ++c) y[c] = x[r][lr ? W - 1 - c : c];  // left/right flip of the column-pass output
-    fwd_1d<W, C::cos_bit_row>(y, hk == 2 ? 1 : hk);
+        for (int c = 0; c < 4; ++c) raw[r][c] = x0[r][c];
 #pragma unroll
-    for (int c = 0; c < W; ++c) {
-      int32_t v = y[c];
-      if constexpr (C::fs2 < 0) v = rshift(v, C::fs2 < 0 ? -C::fs2 : 1);
-      if constexpr (C::rect2) v = rshift64((int64_t)v * kSqrt2, kSqrt2Bits);
-      if (coeff) coeff[out_off + c * H + r] = v;
-      const int ac = (r | c) != 0;
-      quantize_one<HBD, LS>(v, zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.qs_log2[ac], qa.dequant[ac],
-                            &qv[r][c], &dv[r][c]);
-      // inverse-scan positions are constants here (r, c are unrolled)
-      const int p0 = iscan_pos<W, H>(r, c, 0) + 1, p1 = iscan_pos<W, H>(r, c, 1) + 1, p2 = iscan_pos<W, H>(r, c, 2) + 1;
-      const int p = scan_class == 0 ? p0 : (scan_class == 1 ? p1 : p2);
-      my_eob = (qv[r][c] != 0 && p > my_eob) ? p : my_eob;
+      for (int i = 0; i < 4; ++i) {
+        int a = raw[0][i], b = raw[1][i], c = raw[2][i], d = raw[3][i];
+        bf(a, b, c, d);
+        t[4 * i + 0] = a; t[4 * i + 1] = c; t[4 * i + 2] = d; t[4 * i + 3] = b;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int a = t[i], b = t[4 + i], c = t[8 + i], d = t[12 + i];
+        bf(a, b, c, d);
+        // output index 4 * k + i = c * H + r with c = k, r = i
+        emit(i, 0, a * 4); emit(i, 1, c * 4); emit(i, 2, d * 4); emit(i, 3, b * 4);
+      }
+    }
+  }
+  if (!wht) {
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+      int32_t y[W];
+#pragma unroll
+      for (int c = 0; c < W; ++c) y[c] = x[r][lr ? W - 1 - c : c];  // left/right flip of the column-pass output
+      fwd_1d<W, C::cos_bit_row>(y, hk == 2 ? 1 : hk);
+#pragma unroll
+      for (int c = 0; c < W; ++c) {
+        int32_t v = y[c];
+        if constexpr (C::fs2 < 0) v = rshift(v, C::fs2 < 0 ? -C::fs2 : 1);
+        if constexpr (C::rect2) v = rshift64((int64_t)v * kSqrt2, kSqrt2Bits);
+        emit(r, c, v);
+      }
     }
   }
   eob[bi] = (uint16_t)my_eob;
@@ -655,6 +695,7 @@ static const int kTxW[19] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 
 static const int kTxH[19] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16 };
 
 static bool type_ok(int tx_size, int tx_type) {
+  if (tx_type == kTxWht) return tx_size == 0;  // lossless WHT: TX_4X4 only
   // what av1_get_fwd_txfm_cfg can serve (av1_txfm.c:89-96): ADST <= 16 points, identity <= 32, 64 DCT only
   static const uint8_t vk[16] = { 0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3 };
   static const uint8_t hk[16] = { 0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2 };

@@ -218,6 +218,11 @@ typedef struct {
   int16_t zbin[2], round[2], quant[2], quant_shift[2], dequant[2];
 } aomhip_quant_params;
 
+/* tx_type value (aomhip_txb::tx_type / uniform_tx_type) selecting the LOSSLESS 4x4 pair instead of a TX_TYPE: av1_fwht4x4
+ * (av1/encoder/hybrid_fwd_txfm.c:24-76, chosen by txfm_param->lossless, :233-313) in the forward entry points and
+ * av1_highbd_iwht4x4_add (av1/common/idct.c:34-41: _16_add when eob > 1, else _1_add) in aomhip_inv_txfm_add_batch;
+ * TX_4X4 only; the coefficients are scanned with the DCT_DCT order. */
+#define AOMHIP_TX_WHT 16
 int aomhip_tx_size_wide(int tx_size); /* tx_size_wide / tx_size_high (av1/common/common_data.h) */
 int aomhip_tx_size_high(int tx_size);
 int aomhip_tx_max_eob(int tx_size);   /* av1_get_max_eob (av1/common/blockd.h:1600-1608): coefficients per block */

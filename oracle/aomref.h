@@ -119,6 +119,9 @@ int orc_txfm_valid(int tx_size, int tx_type);
 void orc_fwd_txfm2d(const int16_t *input, int32_t *output, int stride, int tx_size, int tx_type, int bd);
 /* av1_inv_txfm2d.c:234-309 inv_txfm2d_add_c via av1_inv_txfm2d_add_WxH_c; dst is uint16 (highbd) */
 void orc_inv_txfm2d_add(const int32_t *input, uint16_t *dst, int stride, int tx_size, int tx_type, int bd);
+#define ORC_TX_WHT 16 /* lossless 4x4 Walsh-Hadamard in the batch drivers' tx_type field */
+void orc_fwht4x4(const int16_t *input, int32_t *output, int stride);
+void orc_iwht4x4_add(const int32_t *input, uint16_t *dst, int stride, int eob, int bd);
 
 /* ---- quantize (aom_dsp/quantize.c, av1/encoder/av1_quantize.c) -------------------- */
 /* quantize.c:108-169 aom_quantize_b_helper_c with qm_ptr == iqm_ptr == NULL */

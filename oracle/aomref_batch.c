@@ -67,11 +67,11 @@ void orc_xform_quant_batch(const int16_t *residual, int stride, int tx_size, con
   const int w = orc_tx_wide[tx_size], h = orc_tx_high[tx_size];
   const int kw = w < 32 ? w : 32, kh = h < 32 ? h : 32, nc = kw * kh;
   const int log_scale = (w * h > 256) + (w * h > 1024); /* av1_get_tx_scale, av1/common/idct.c:24-28 */
-  int16_t scans[16][1024], iscans[16][1024];
-  uint8_t have[16] = { 0 };
+  int16_t scans[17][1024], iscans[17][1024];
+  uint8_t have[17] = { 0 };
   for (int i = 0; i < n; ++i) {
     const int tt = blocks ? blocks[i].tx_type : uniform_type;
-    if (!have[tt]) { orc_get_scan(tx_size, tt, scans[tt], iscans[tt]); have[tt] = 1; }
+    if (!have[tt]) { orc_get_scan(tx_size, tt == ORC_TX_WHT ? 0 : tt, scans[tt], iscans[tt]); have[tt] = 1; } /* lossless: DCT_DCT scan */
   }
   if (threads < 1) threads = 1;
   if (reps < 1) reps = 1;
@@ -82,7 +82,8 @@ void orc_xform_quant_batch(const int16_t *residual, int stride, int tx_size, con
     const int bx = blocks ? blocks[i].x : (i % grid_cols) * w, by = blocks ? blocks[i].y : (i / grid_cols) * h;
     const int tt = blocks ? blocks[i].tx_type : uniform_type;
     const size_t off = blocks ? blocks[i].out_offset : (size_t)i * nc;
-    orc_fwd_txfm2d(residual + (ptrdiff_t)by * stride + bx, full, stride, tx_size, tt, is_hbd ? 10 : 8);
+    if (tt == ORC_TX_WHT) orc_fwht4x4(residual + (ptrdiff_t)by * stride + bx, full, stride);
+    else orc_fwd_txfm2d(residual + (ptrdiff_t)by * stride + bx, full, stride, tx_size, tt, is_hbd ? 10 : 8);
     if (coeff) for (int k = 0; k < nc; ++k) coeff[off + k] = full[k];
     if (is_hbd)
       orc_highbd_quantize_b(full, nc, q[0], q[1], q[2], q[3], qcoeff + off, dqcoeff + off, q[4], &eob[i], scans[tt],
@@ -103,6 +104,7 @@ void orc_inv_txfm_add_batch(const int32_t *dqcoeff, int tx_size, const orc_txb *
     const int bx = blocks ? blocks[i].x : (i % grid_cols) * w, by = blocks ? blocks[i].y : (i / grid_cols) * h;
     const int tt = blocks ? blocks[i].tx_type : uniform_type;
     const size_t off = blocks ? blocks[i].out_offset : (size_t)i * nc;
-    orc_inv_txfm2d_add(dqcoeff + off, dst + (ptrdiff_t)by * dst_stride + bx, dst_stride, tx_size, tt, bd);
+    if (tt == ORC_TX_WHT) orc_iwht4x4_add(dqcoeff + off, dst + (ptrdiff_t)by * dst_stride + bx, dst_stride, eob ? eob[i] : 16, bd);
+    else orc_inv_txfm2d_add(dqcoeff + off, dst + (ptrdiff_t)by * dst_stride + bx, dst_stride, tx_size, tt, bd);
   }
 }

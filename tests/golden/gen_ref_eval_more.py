@@ -31,7 +31,8 @@ def gen_txfm2d():
     import pyoracle as orc      # only av1_tx_valid (which (size, type) pairs exist) is taken from the oracle
     ev = evaluator(["aom_dsp/txfm_common.h", "av1/common/common.h", "av1/common/common_data.h", "av1/common/av1_txfm.h", "av1/common/av1_txfm.c",
                     "av1/encoder/av1_fwd_txfm1d.h", "av1/encoder/av1_fwd_txfm1d_cfg.h", "av1/encoder/av1_fwd_txfm1d.c", "av1/encoder/av1_fwd_txfm2d.c",
-                    "av1/common/av1_inv_txfm1d.h", "av1/common/av1_inv_txfm1d_cfg.h", "av1/common/av1_inv_txfm1d.c", "av1/common/av1_inv_txfm2d.c"])
+                    "av1/common/av1_inv_txfm1d.h", "av1/common/av1_inv_txfm1d_cfg.h", "av1/common/av1_inv_txfm1d.c", "av1/common/av1_inv_txfm2d.c",
+                    "av1/encoder/hybrid_fwd_txfm.c"])
     rng = np.random.default_rng(20261007)
     arrays, cases = {}, []
     k = 0
@@ -83,6 +84,32 @@ def gen_txfm2d():
                     rec["inv_bd"] = ibd
                 cases.append(rec)
                 k += 1
+    # lossless 4x4: av1_fwht4x4_c and av1_highbd_iwht4x4_{16,1}_add_c (own generator: the cases above keep their values)
+    rng2 = np.random.default_rng(20261012)
+    for trial in range(24):
+        bd = (8, 10, 12)[trial % 3]
+        lim = (1 << bd) - 1
+        x = rng2.integers(-lim, lim + 1, 16) if trial >= 3 else np.full(16, (lim, -lim, 0)[trial])
+        S = 7
+        buf = np.zeros(4 * S, np.int64)
+        buf.reshape(4, S)[:, :4] = x.reshape(4, 4)
+        out = ev.array([0] * 16, "int32_t")
+        ev.call("av1_fwht4x4_c", ev.array(buf, "int16_t"), out, S)
+        coeff = np.asarray(out.buf, np.int32)
+        dq = coeff.copy()
+        if trial % 4 == 1:
+            dq[1:] = 0                                   # DC only: the _1_add form
+        dst = rng2.integers(0, 1 << bd, 16)
+        dbuf = np.zeros(4 * S, np.int64)
+        dbuf.reshape(4, S)[:, :4] = dst.reshape(4, 4)
+        dp = ev.array(dbuf, "uint16_t")
+        eob = 1 if trial % 4 == 1 else 16
+        ev.call("av1_highbd_iwht4x4_16_add_c" if eob > 1 else "av1_highbd_iwht4x4_1_add_c", ev.array(dq, "int32_t"), dp, S, bd)
+        arrays["x%d" % k], arrays["c%d" % k] = x.astype(np.int16), coeff
+        arrays["dq%d" % k], arrays["p%d" % k] = dq.astype(np.int32), dst.astype(np.uint16)
+        arrays["r%d" % k] = np.asarray(dp.buf, np.uint16).reshape(4, S)[:, :4].copy()
+        cases.append({"wht": 1, "tx_size": 0, "tx_type": 16, "w": 4, "h": 4, "bd": bd, "inv_bd": bd, "eob": eob})
+        k += 1
     save("ref_eval_txfm2d.npz", arrays, cases)
 
 

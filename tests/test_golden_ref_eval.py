@@ -234,10 +234,21 @@ def test_full_pixel_search_matches_reference_evaluation(oracle):
 
 def test_txfm2d_matches_reference_evaluation(oracle):
     z, cases = load("ref_eval_txfm2d.npz")
-    assert len(cases) >= 300 and len({c["tx_size"] for c in cases}) == 19
+    assert len(cases) >= 340 and len({c["tx_size"] for c in cases}) == 19 and sum(c.get("wht", 0) for c in cases) == 24
     n_inv = 0
     for k, c in enumerate(cases):
         w, h = c["w"], c["h"]
+        if c.get("wht"):            # lossless Walsh-Hadamard pair
+            out = np.zeros(16, np.int32)
+            xin = np.ascontiguousarray(z["x%d" % k].reshape(4, 4))
+            oracle.lib.orc_fwht4x4(C.c_void_p(xin.ctypes.data), C.c_void_p(out.ctypes.data), 4)
+            assert np.array_equal(out, z["c%d" % k]), c
+            dst = np.ascontiguousarray(z["p%d" % k].reshape(4, 4).astype(np.uint16))
+            dq = np.ascontiguousarray(z["dq%d" % k])
+            oracle.lib.orc_iwht4x4_add(C.c_void_p(dq.ctypes.data), C.c_void_p(dst.ctypes.data), 4, c["eob"], c["inv_bd"])
+            assert np.array_equal(dst, z["r%d" % k]), c
+            n_inv += 1
+            continue
         got = oracle.fwd_txfm2d(z["x%d" % k].reshape(h, w), c["tx_size"], c["tx_type"], c["bd"])
         nn = min(w, 32) * min(h, 32)      # 64-point sizes: only the re-packed 32 low frequencies are defined (av1_fwd_txfm2d.c:241-312)
         assert np.array_equal(got[:nn], z["c%d" % k][:nn]), c

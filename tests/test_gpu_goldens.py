@@ -99,7 +99,7 @@ def test_fwd_and_inv_txfm2d_match_reference_goldens(hip, oracle, ctx):
             pred[:h, :w] = z["p%d" % k].reshape(h, w)
             p = ctx.planes_alloc(P, P, border, bd, 1)
             ctx.planes_upload(p, 0, pred)
-            d_dq, d_e = ctx.to_device(np.ascontiguousarray(z["dq%d" % k][:nc])), ctx.to_device(np.asarray([nc], np.uint16))
+            d_dq, d_e = ctx.to_device(np.ascontiguousarray(z["dq%d" % k][:nc])), ctx.to_device(np.asarray([c.get("eob", nc)], np.uint16))
             ctx.inv_txfm_add_batch(d_dq, ts, d_b, 1, 0, 0, d_e, p, 0)
             rec = ctx.planes_download(p, 0)[border:border + h, border:border + w]
             assert np.array_equal(rec.astype(np.uint16), z["r%d" % k]), c
