@@ -380,7 +380,9 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
 // VGPRs, runs the column and row networks back to back (the transpose is register renaming), quantises and
 // writes its coefficients as contiguous dwordx4 runs.  No LDS, no barriers, inverse-scan positions are
 // compile-time constants.  For 4x4 this does ~3x fewer VALU instructions per block than 4 lanes per block.
-template <int W, int H, bool HBD, int SRC>
+// WHT = true: the lossless instantiation (av1_fwht4x4), chosen per launch by uniform_tx_type == AOMHIP_TX_WHT -- a
+// per-block test costs the hot 4x4 path 7 % (it keeps the unshifted residual alive).
+template <int W, int H, bool HBD, int SRC, bool WHT = false>
 __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
     const void *__restrict__ in0, const void *__restrict__ in1, int stride0, int stride1,
     const aomhip_txb *__restrict__ blocks, int n_blocks, int grid_cols, int uniform_type, QuantArgs qa,
@@ -452,7 +454,8 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
   }
 
   // ---- rows + quantise
-  const bool wht = (W == 4 && H == 4) && tx_type == kTxWht;  // lossless: DCT_DCT scan (the flag, not the type, selects WHT)
+  constexpr bool wht = WHT && W == 4 && H == 4;  // lossless: DCT_DCT scan (the flag, not the type, selects WHT)
+  if (wht) tx_type = 0;
   const int scan_class = (wht || tx_type < 10) ? 0 : ((tx_type & 1) ? 2 : 1);
   const int zb[2] = { qa.zbin[0], qa.zbin[1] }, rd[2] = { qa.round[0], qa.round[1] };
   int my_eob = 0;
@@ -467,8 +470,8 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
     const int p = scan_class == 0 ? p0 : (scan_class == 1 ? p1 : p2);
     my_eob = (qv[r][c] != 0 && p > my_eob) ? p : my_eob;
   };
-  if constexpr (W == 4 && H == 4) {
-    if (wht) {  // av1_fwht4x4_c (hybrid_fwd_txfm.c:24-76) on the raw residual, UNIT_QUANT_FACTOR = 4
+  if constexpr (wht) {
+    {  // av1_fwht4x4_c (hybrid_fwd_txfm.c:24-76) on the raw residual, UNIT_QUANT_FACTOR = 4
       auto bf = [](int &a, int &b, int &c, int &d) {
         int a1 = a + b, d1 = d - c;
         const int e1 = (a1 - d1) >> 1;
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
       }
     }
   }
-  if (!wht) {
+  if constexpr (!wht) {
 #pragma unroll
     for (int r = 0; r < H; ++r) {
       int32_t y[W];
@@ -644,9 +647,14 @@ template <int W, int H, bool HBD, int SRC> static int launch_xq(const XqLaunch &
     if (variant == 2) {
       const int nwg = (l.n_blocks + kXqThreads - 1) / kXqThreads;
       const int nwg8 = (nwg + 7) & ~7;
-      hipLaunchKernelGGL((xform_quant_lane_kernel<W, H, HBD, SRC>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0,
-                         l.in1, l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff,
-                         l.qcoeff, l.dqcoeff, l.eob, nwg8);
+      if (l.uniform_type == kTxWht)
+        hipLaunchKernelGGL((xform_quant_lane_kernel<W, H, HBD, SRC, true>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0,
+                           l.in1, l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff,
+                           l.qcoeff, l.dqcoeff, l.eob, nwg8);
+      else
+        hipLaunchKernelGGL((xform_quant_lane_kernel<W, H, HBD, SRC>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0,
+                           l.in1, l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff,
+                           l.qcoeff, l.dqcoeff, l.eob, nwg8);
       AOMHIP_LAUNCH_CHECK();
       return AOMHIP_OK;
     }
@@ -743,7 +751,8 @@ int aomhip_xform_quant_batch(aomhip_ctx *ctx, const int16_t *d_residual, int res
                              const aomhip_quant_params *qparams, int is_hbd, int32_t *d_coeff, int32_t *d_qcoeff,
                              int32_t *d_dqcoeff, uint16_t *d_eob) {
   if (!ctx || !d_residual || !qparams || !d_qcoeff || !d_dqcoeff || !d_eob || tx_size < 0 || tx_size >= 19 ||
-      n_blocks < 0 || (!d_blocks && (grid_cols <= 0 || !type_ok(tx_size, uniform_tx_type)))) {
+      n_blocks < 0 || (!d_blocks && (grid_cols <= 0 || !type_ok(tx_size, uniform_tx_type))) ||
+      (uniform_tx_type == kTxWht && tx_size != 0)) {
     set_error("aomhip_xform_quant_batch: invalid argument");
     return AOMHIP_ERR_INVALID;
   }

@@ -221,7 +221,9 @@ typedef struct {
 /* tx_type value (aomhip_txb::tx_type / uniform_tx_type) selecting the LOSSLESS 4x4 pair instead of a TX_TYPE: av1_fwht4x4
  * (av1/encoder/hybrid_fwd_txfm.c:24-76, chosen by txfm_param->lossless, :233-313) in the forward entry points and
  * av1_highbd_iwht4x4_add (av1/common/idct.c:34-41: _16_add when eob > 1, else _1_add) in aomhip_inv_txfm_add_batch;
- * TX_4X4 only; the coefficients are scanned with the DCT_DCT order. */
+ * TX_4X4 only; the coefficients are scanned with the DCT_DCT order.  The forward entry points take it PER LAUNCH: pass
+ * uniform_tx_type = AOMHIP_TX_WHT (also with a block list, whose tx_type fields are then ignored) -- the batching layer
+ * buckets the lossless segments' blocks like it buckets transform sizes.  The inverse accepts it per block or per launch. */
 #define AOMHIP_TX_WHT 16
 int aomhip_tx_size_wide(int tx_size); /* tx_size_wide / tx_size_high (av1/common/common_data.h) */
 int aomhip_tx_size_high(int tx_size);

@@ -88,7 +88,7 @@ def test_fwd_and_inv_txfm2d_match_reference_goldens(hip, oracle, ctx):
         res = np.ascontiguousarray(z["x%d" % k].reshape(h, w))
         d_res, d_b = ctx.to_device(res), ctx.to_device(blk)
         d_c, d_q, d_dq, d_e = ctx.malloc(nc * 4), ctx.malloc(nc * 4), ctx.malloc(nc * 4), ctx.malloc(16)
-        ctx.xform_quant_batch(d_res, w, ts, d_b, 1, 0, 0, qp, c["bd"] > 8, d_c, d_q, d_dq, d_e)
+        ctx.xform_quant_batch(d_res, w, ts, d_b, 1, 0, 16 if c.get("wht") else 0, qp, c["bd"] > 8, d_c, d_q, d_dq, d_e)
         assert np.array_equal(ctx.from_device(d_c, (nc,), np.int32), z["c%d" % k][:nc]), c
         for d in (d_res, d_c, d_q, d_dq, d_e):
             ctx.free(d)
