@@ -134,11 +134,23 @@ __device__ __forceinline__ uint32_t group8_sad_mem(const T *sp, int sstride, con
 constexpr int kFpsThreads = 256;  // 4 blocks (wavefronts) per workgroup
 constexpr int kInvalidMv = -32768;  // INVALID_MV_ROW_COL (av1/common/mv.h:27)
 
+#ifndef AOMHIP_FPS_WAVES
+#define AOMHIP_FPS_WAVES 3   // waves per SIMD the register allocation aims at (profiles/r01_search_variants.md)
+#endif
+
 template <typename T, int W, int H>
-__global__ __launch_bounds__(kFpsThreads) void full_pixel_search_kernel(
+__global__ __launch_bounds__(kFpsThreads, AOMHIP_FPS_WAVES) void full_pixel_search_kernel(
     PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
     const SiteTable *__restrict__ sites, SearchArgs q, int16_t *__restrict__ out_mv, int32_t *__restrict__ out_cost,
     int32_t *__restrict__ out_cost_list, int16_t *__restrict__ out_second) {
+  // the site table is read on the dependent chain of every step: keep it in LDS (1.7 KB), not behind a global load
+  __shared__ SiteTable sS;
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(sites);
+    uint32_t *d = reinterpret_cast<uint32_t *>(&sS);
+    for (int i = threadIdx.x; i < (int)(sizeof(SiteTable) / 4); i += kFpsThreads) d[i] = g[i];
+  }
+  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bi = blockIdx.x * (kFpsThreads / 64) + wave;
   if (bi >= n_blocks) return;
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(kFpsThreads) void full_pixel_search_kernel(
   const int row_min = b.row_min, row_max = b.row_max, col_min = b.col_min, col_max = b.col_max;
   const int ref_row = b.ref_row, ref_col = b.ref_col;
   const int frr = (ref_row + 3 + (ref_row >= 0)) >> 3, frc = (ref_col + 3 + (ref_col >= 0)) >> 3;  // get_fullmv_from_mv
-  const SiteTable &S = *sites;
+  const SiteTable &S = sS;
   bool skip = q.skip_sad != 0;
 
   typename G8<T, W, H>::L srcu[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1];
@@ -279,26 +291,45 @@ __global__ __launch_bounds__(kFpsThreads) void full_pixel_search_kernel(
     if (cl[4] != INT_MAX) cl[4] += sad_cost(br - 1, bc);
   };
 
-  // ---- full_pixel_diamond (:1421-1470)
+  // ---- full_pixel_diamond (:1421-1470): the first search at step_param, then restarts at step_param + n that are skipped
+  //      while the previous one reported it would have stayed on the centre (num00).  One loop = one inlined copy of
+  //      the search body.
   auto full_pixel_diamond = [&](int step_param, int *obr, int *obc) -> int {
-    int n, num00 = 0, br, bc;
-    int bestsme = diamond(step_param, &n, &br, &bc);
-    if (bestsme < INT_MAX) bestsme = var_cost_at(br, bc);
+    int n = 0, num00 = 0, br = 0, bc = 0, bestsme = INT_MAX;
     const int further_steps = S.num_search_steps - 1 - step_param;
-    while (n < further_steps) {
-      ++n;
-      if (num00) {
-        num00--;
-      } else {
-        int tr, tc;
-        int thissme = diamond(step_param + n, &num00, &tr, &tc);
-        if (thissme < INT_MAX) thissme = var_cost_at(tr, tc);
-        if (thissme < bestsme) {
-          bestsme = thissme;
-          br = tr;
-          bc = tc;
+    bool first = true;
+    for (;;) {
+      bool run_it = true;
+      int sstep = step_param;
+      if (!first) {
+        if (n >= further_steps) break;
+        ++n;
+        if (num00) {
+          --num00;
+          run_it = false;
+        } else {
+          sstep = step_param + n;
         }
       }
+      if (run_it) {
+        int t00, tr, tc;
+        int sme = diamond(sstep, &t00, &tr, &tc);
+        if (sme < INT_MAX) sme = var_cost_at(tr, tc);
+        if (first) {
+          bestsme = sme;
+          br = tr;
+          bc = tc;
+          n = t00;
+        } else {
+          num00 = t00;
+          if (sme < bestsme) {
+            bestsme = sme;
+            br = tr;
+            bc = tc;
+          }
+        }
+      }
+      first = false;
     }
     sad_cost_list(br, bc, false);
     *obr = br;
@@ -485,13 +516,16 @@ __global__ __launch_bounds__(kFpsThreads) void full_pixel_search_kernel(
     range = min(range, 256);
     interval = max(interval, range / div);
     if (q.fine_interval) interval = min(interval, 4);
-    int bestsme = mesh_pass(&br, &bc, range, interval);
-    if (interval > 1 && range > 7) {
+    int bestsme = INT_MAX;
+    const bool more = interval > 1 && range > 7;
 #pragma unroll 1
-      for (int k = 1; k < 4; ++k) {
-        bestsme = mesh_pass(&br, &bc, q.mesh[2 * k], q.mesh[2 * k + 1]);
-        if (q.mesh[2 * k + 1] == 1) break;
+    for (int k = 0; k < 4; ++k) {  // pass 0 with the grown first pattern, then (if it was coarse) the narrowing passes
+      if (k > 0) {
+        range = q.mesh[2 * k];
+        interval = q.mesh[2 * k + 1];
       }
+      bestsme = mesh_pass(&br, &bc, range, interval);
+      if (!more || (k > 0 && interval == 1)) break;
     }
     if (bestsme < INT_MAX) bestsme = var_cost_at(br, bc);
     sad_cost_list(br, bc, false);
@@ -507,11 +541,13 @@ __global__ __launch_bounds__(kFpsThreads) void full_pixel_search_kernel(
   for (int attempt = 0; attempt < 2; ++attempt) {
     second_row = second_col = kInvalidMv;
     const int m = q.method, sp_ = q.step_param;
-    if (m == kFastBigdia) var = pattern_search(max(8, sp_), false, &br, &bc);
-    else if (m == kVfastDiamond) var = pattern_search(max(10, sp_), false, &br, &bc);
-    else if (m == kFastDiamond || m == kFastHex) var = pattern_search(max(9, sp_), false, &br, &bc);
-    else if (m == kHex || m == kSquare || m == kBigdia) var = pattern_search(sp_, true, &br, &bc);
-    else var = full_pixel_diamond(sp_, &br, &bc);
+    const bool is_pattern = m >= kHex;  // HEX, BIGDIA, SQUARE and the four FAST_ forms
+    if (is_pattern) {
+      const int floor_step = m == kFastBigdia ? 8 : m == kVfastDiamond ? 10 : (m == kFastDiamond || m == kFastHex) ? 9 : 0;
+      var = pattern_search(max(floor_step, sp_), /*do_init_search=*/m == kHex || m == kSquare || m == kBigdia, &br, &bc);
+    } else {
+      var = full_pixel_diamond(sp_, &br, &bc);
+    }
 
     int run_mesh = q.run_mesh;
     if (!run_mesh && (m == kNstep || m == kNstep8)) {

@@ -423,6 +423,43 @@ class SearchPipeline:
         return bool(np.array_equal(mv[idx], wmv))
 
 
+def run_search_default(pkg, ctx, orc, steps, warmup):
+    """Informational: libaom's DEFAULT search flavour on the same 4K 10-bit pair -- av1_full_pixel_search with NSTEP
+    (general kernel: cost list, second-best MV) and av1_find_best_sub_pixel_tree with the 8-tap up-sampled error."""
+    capi = pkg.capi
+    wl = SearchPipeline(pkg, ctx, None, 0, 1)
+    n = wl.n
+    d_cl, d_sec = ctx.malloc(n * 20), ctx.malloc(n * 4)
+    q = capi.SearchParams.make("NSTEP", 3, capi.MV_COST_L1_HDRES)
+    sp = capi.SubpelParams(2, capi.MV_COST_NONE, 0, 2, 1, 0, 3)      # tree, USE_8_TAPS, no MV cost (as tf_motion_search)
+    out = {}
+    full = lambda f: ctx.full_pixel_search_batch(wl.src, wl.ref, f, 16, 16, q, wl.d_blocks, n, wl.d_mv, wl.d_cost, d_cl, d_sec)
+    sub = lambda f: ctx.subpel_tree_batch(wl.src, wl.ref, f, 16, 16, sp, wl.d_sub_blocks(f), n, wl.d_smv, wl.d_err, wl.d_dist, wl.d_sse)
+    for f in range(wl.F):
+        wl.d_sub_blocks(f)
+    for name, fn in (("full_pixel_search_NSTEP", full), ("subpel_tree_8tap", sub)):
+        k = [0]
+        def once():
+            fn(k[0] % wl.F); k[0] += 1
+        out[name + "_ms_per_frame"] = kernel_avg_ms(ctx, once, max(steps, 8))
+    ok = None
+    if orc is not None:
+        full(0)
+        mv = ctx.from_device(wl.d_mv, (n, 2), np.int16)
+        s_, r_ = pkg.synth.shifted_smooth_pair(wl.W, wl.H, 0, wl.BD, shift=(3, -2), frac8=(0, 0))
+        sb = orc.extend_plane(s_, wl.BORDER, wl.src.stride); rb = orc.extend_plane(r_, wl.BORDER, wl.ref.stride)
+        idx = np.arange(0, n, max(1, n // 300))
+        wmv = orc.full_pixel_search_batch(sb, rb, wl.BORDER, 16, 16, wl.h_blocks[idx], orc.search_params("NSTEP", 3, 3), bd=wl.BD, threads=8)[0]
+        ok = bool(np.array_equal(mv[idx], wmv))
+    tot = out["full_pixel_search_NSTEP_ms_per_frame"] + out["subpel_tree_8tap_ms_per_frame"]
+    ctx.free(d_cl); ctx.free(d_sec)
+    wl.free()
+    out.update({"workload": "default_search_NSTEP+8tap_tree_4k_10bit", "value": n / (tot * 1e-3), "unit": "blocks/s", "blocks_per_frame": n,
+                "parity_sample_slot0": ok, "config": {"frame": "3840x2160 10-bit", "block": "16x16", "full_pel": "av1_full_pixel_search, NSTEP, "
+                "step_param 3, MV_COST_L1_HDRES, cost list + second-best MV", "sub_pel": "av1_find_best_sub_pixel_tree, USE_8_TAPS, 1/8 pel, iters 2"}})
+    return out
+
+
 def run_search(pkg, ctx, dist, dev, rank, world, orc, steps, warmup):
     wl = SearchPipeline(pkg, ctx, dist, rank, world)
     ok = wl.check(orc) if orc is not None else None
@@ -653,7 +690,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sad16x16_modeA_1080p_8bit",
-                    choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "search_4k_10bit", "inner_loop_4k_10bit"])
+                    choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "search_4k_10bit", "inner_loop_4k_10bit", "default_search_4k_10bit"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -702,6 +739,13 @@ def main():
                           "config": dict(r["config"], workload=r["workload"]), "stages": r["stages"],
                           "recon_psnr_db_last_frame": r["recon_psnr_db_last_frame"]}))
         return
+    if args.workload == "default_search_4k_10bit":  # informational: NSTEP full-pel + 8-tap sub-pel tree (single GPU)
+        r = run_search_default(pkg, ctx, orc, args.steps, args.warmup)
+        ctx.close()
+        print(json.dumps(dict(r, metric="search blocks/s", n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True,
+                              scaling="weak", vs_baseline=None, dtype="u16", data="synthetic",
+                              ms_per_step=r["full_pixel_search_NSTEP_ms_per_frame"] + r["subpel_tree_8tap_ms_per_frame"])))
+        return
     if args.workload == "txq_1080p_8bit":  # profiling convenience: transform+quantise only (single GPU)
         r = run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline)
         ctx.close()
@@ -724,6 +768,7 @@ def main():
             others.append(run_search(pkg, ctx, None, dev, 0, 1, orc, max(4, args.steps // 2), 1))
             others.append(run_inner_loop(pkg, ctx, orc, max(4, args.steps // 2), 1))
             others.append(run_mesh(pkg, ctx, orc, max(4, args.steps // 4), 1))
+            others.append(run_search_default(pkg, ctx, orc, max(4, args.steps // 2), 1))
     ctx.close()
 
     if rank == 0:
