@@ -37,6 +37,9 @@ template <int W, int H> struct UpTile {
 // Variance of (up-sampled prediction at `ap` + (xoff, yoff)/8) against the source block, by the 16 lanes of a group
 // (j = lane & 15).  `tile`: this group's UpTile<W,H>::ELEMS uint16 of LDS.  The block is processed in strips of SH rows:
 // horizontal pass into LDS, then vertical pass + difference accumulation.  diff = pred - src (vf(pred, w, src, stride)).
+// A lane computes 8 (4 for W = 4) adjacent pixels from one 16-pixel window load; the window starts 2 pixels left of
+// the unit and is read in full, i.e. up to 5 pixels beyond the filter's right-most tap -- inside the replicated border
+// for any MV the limits admit (they keep 8 pixels of margin) and inside the plane allocation in any case.
 template <typename T, int W, int H>
 __device__ __forceinline__ uint32_t group16_upsampled_variance(const T *ap, int astride, int xoff, int yoff, const T *bp,
                                                                int bstride, int bit_depth, int j, bool active,
@@ -51,16 +54,39 @@ __device__ __forceinline__ uint32_t group16_upsampled_variance(const T *ap, int 
   }
   int32_t sum = 0;
   uint64_t sse = 0;
+  constexpr int UW = W < 8 ? W : 8;                   // pixels per unit: one lane computes UW adjacent outputs
+  constexpr int UPR = W / UW;                          // units per row
+  constexpr int LW = sizeof(T) == 2 ? 8 : 4;           // dwords of the horizontal window load (16 pixels from column c - 2)
   for (int r0 = 0; r0 < H; r0 += U::SH) {
     if (active) {
-      for (int e = j; e < U::ELEMS; e += 16) {     // horizontal pass: rows r0 - 2 .. r0 + SH + 2
-        const int tr = e / W, c = e - tr * W;
+      for (int u = j; u < U::ROWS * UPR; u += 16) {    // horizontal pass: rows r0 - 2 .. r0 + SH + 2
+        const int tr = u / UPR, c = (u - tr * UPR) * UW;
         const T *p = ap + (int64_t)(r0 + tr - 2) * astride + c - 2;
-        int acc = 64;
+        uint32_t wv[LW];
+        {
+          const MU128 lo = *reinterpret_cast<const MU128 *>(p);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc += (int)p[k] * kx[k];
-        acc >>= 7;
-        tile[e] = (uint16_t)(acc < 0 ? 0 : (acc > pmax ? pmax : acc));
+          for (int k = 0; k < 4; ++k) wv[k] = lo.v[k];
+          if constexpr (sizeof(T) == 2) {
+            const MU128 hi = *reinterpret_cast<const MU128 *>(p + 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wv[4 + k] = hi.v[k];
+          }
+        }
+        uint32_t outw[UW / 2];
+#pragma unroll
+        for (int i = 0; i < UW; ++i) {
+          int acc = 64;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc += px_of<T>(wv, i + k) * kx[k];
+          acc >>= 7;
+          acc = acc < 0 ? 0 : (acc > pmax ? pmax : acc);
+          if (i & 1) outw[i >> 1] |= (uint32_t)acc << 16;
+          else outw[i >> 1] = (uint32_t)acc;
+        }
+        uint32_t *dstw = reinterpret_cast<uint32_t *>(tile + tr * W + c);
+#pragma unroll
+        for (int k = 0; k < UW / 2; ++k) dstw[k] = outw[k];
       }
     }
     // the group's own LDS writes must be visible to its reads below: one wavefront, so a wave-level fence suffices
@@ -68,21 +94,33 @@ __device__ __forceinline__ uint32_t group16_upsampled_variance(const T *ap, int 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (active) {
-      uint32_t uq = 0;
-      int32_t us = 0;
-      for (int e = j; e < U::SH * W; e += 16) {    // vertical pass + difference
-        const int orow = e / W, c = e - orow * W;
-        int acc = 64;
+      for (int u = j; u < U::SH * UPR; u += 16) {     // vertical pass + difference
+        const int orow = u / UPR, c = (u - orow * UPR) * UW;
+        uint32_t rows6[6][UW / 2];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc += (int)tile[(orow + k) * W + c] * ky[k];
-        acc >>= 7;
-        const int pv = acc < 0 ? 0 : (acc > pmax ? pmax : acc);
-        const int d = pv - (int)bp[(int64_t)(r0 + orow) * bstride + c];
-        us += d;
-        uq += (uint32_t)(d * d);
+        for (int k = 0; k < 6; ++k) {
+          const uint32_t *srcw = reinterpret_cast<const uint32_t *>(tile + (orow + k) * W + c);
+#pragma unroll
+          for (int q = 0; q < UW / 2; ++q) rows6[k][q] = srcw[q];
+        }
+        using BL = typename MLoad<UW * (int)sizeof(T)>::type;
+        const BL bv = *reinterpret_cast<const BL *>(bp + (int64_t)(r0 + orow) * bstride + c);
+        uint32_t uq = 0;
+        int32_t us = 0;
+#pragma unroll
+        for (int i = 0; i < UW; ++i) {
+          int acc = 64;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc += (int)((rows6[k][i >> 1] >> (16 * (i & 1))) & 0xffffu) * ky[k];
+          acc >>= 7;
+          const int pv = acc < 0 ? 0 : (acc > pmax ? pmax : acc);
+          const int d = pv - px_of<T>(bv.v, i);
+          us += d;
+          uq += (uint32_t)(d * d);
+        }
+        sum += us;
+        sse += uq;
       }
-      sum += us;
-      sse += uq;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
