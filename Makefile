@@ -14,7 +14,7 @@ lib: $(LIBDIR)/libaomhip.so
 oracle:
 	$(MAKE) -C oracle
 
-build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/aomhip.h
+build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) include/aomhip.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
