@@ -270,3 +270,30 @@ def test_subpel_trees_match_oracle(hip, oracle, ctx, bw, bh, bd):
         for name, a, w_ in zip(("mv", "err", "dist", "sse"), got, want):
             assert np.array_equal(a, w_), ("8tap", cost_type, iters, allow_hp, forced_stop, name)
     ctx.planes_free(ps); ctx.planes_free(pr)
+
+
+def test_edge_cases_empty_ragged_degenerate_limits(hip, oracle, ctx):
+    """n = 0, n not a multiple of the 4 blocks per workgroup, a single legal MV, start MVs outside the limits (clamped)."""
+    rng = np.random.default_rng(11)
+    W, H, border, bw, bh = 128, 96, 64, 8, 8
+    src = rng.integers(0, 256, (H, W)).astype(np.uint8); ref = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    ps, pr = ctx.planes_alloc(W, H, border, 8, 1), ctx.planes_alloc(W, H, border, 8, 1)
+    ctx.planes_upload(ps, 0, src); ctx.planes_upload(pr, 0, ref)
+    sb, rb = oracle.extend_plane(src, border, ps.stride), oracle.extend_plane(ref, border, pr.stride)
+    q = hip.capi.SearchParams.make("NSTEP", 0, 3)
+    d_mv, d_c = ctx.malloc(64), ctx.malloc(64)
+    ctx.full_pixel_search_batch(ps, pr, 0, bw, bh, q, None, 0, d_mv, d_c)          # empty batch: a no-op
+    ctx.free(d_mv); ctx.free(d_c)
+    for n in (1, 2, 3, 5, 7):
+        blocks = _mk_blocks(hip, oracle, rng, W, H, bw, bh, border, n, start_range=40, ref_range=10)   # starts beyond the limits
+        blocks["row_min"][0] = blocks["row_max"][0] = 2; blocks["col_min"][0] = blocks["col_max"][0] = -3   # one legal position
+        if n > 2:
+            blocks["row_min"][2], blocks["row_max"][2] = -1, 0                                            # a 2 x N strip
+        for method in ("NSTEP", "HEX", "BIGDIA", "DIAMOND"):
+            got = _run(hip, ctx, ps, pr, 0, bw, bh, hip.capi.SearchParams.make(method, 1, 3, run_mesh=1, mesh=[(8, 2), (4, 1), (2, 1), (1, 1)]), blocks)
+            want = oracle.full_pixel_search_batch(sb, rb, border, bw, bh, blocks,
+                                                  oracle.search_params(method, 1, 3, run_mesh=1, mesh=[(8, 2), (4, 1), (2, 1), (1, 1)]))
+            for name, a, w_ in zip(("mv", "cost", "cost_list", "second"), got, want):
+                assert np.array_equal(a, w_), (n, method, name)
+            assert got[0][0].tolist() == [2, -3]
+    ctx.planes_free(ps); ctx.planes_free(pr)
