@@ -24,7 +24,7 @@ class Planes(C.Structure):
 
 
 SEARCH_METHODS = ["DIAMOND", "NSTEP", "NSTEP_8PT", "CLAMPED_DIAMOND", "HEX", "BIGDIA", "SQUARE", "FAST_HEX", "FAST_DIAMOND",
-                  "FAST_BIGDIA", "VFAST_DIAMOND"]   # AOMHIP_SEARCH_* values
+                  "FAST_BIGDIA", "VFAST_DIAMOND", "NSTEP_FPF"]   # AOMHIP_SEARCH_* values
 
 
 class SearchParams(C.Structure):

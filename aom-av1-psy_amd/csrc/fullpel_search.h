@@ -15,7 +15,7 @@ struct SiteTable {
   int16_t mv[22][17][2];
 };
 
-enum { kDiamond, kNstep, kNstep8, kClamped, kHex, kBigdia, kSquare, kFastHex, kFastDiamond, kFastBigdia, kVfastDiamond, kMethods };
+enum { kDiamond, kNstep, kNstep8, kClamped, kHex, kBigdia, kSquare, kFastHex, kFastDiamond, kFastBigdia, kVfastDiamond, kNstepFpf, kMethods };
 
 struct SearchArgs {
   int method, step_param, cost_type, sad_per_bit, error_per_bit, skip_sad;

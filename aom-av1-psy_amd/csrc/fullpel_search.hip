@@ -35,7 +35,7 @@ static void ring(SiteTable *s, int stage, int radius, int t, int npts) {
 }
 
 static void build_sites(int method, SiteTable *s) {
-  static const int lookup[kMethods] = { kDiamond, kNstep, kNstep8, kClamped, kHex, kBigdia, kSquare, kHex, kBigdia, kBigdia, kBigdia };
+  static const int lookup[kMethods] = { kDiamond, kNstep, kNstep8, kClamped, kHex, kBigdia, kSquare, kHex, kBigdia, kBigdia, kBigdia, kNstepFpf };
   memset(s, 0, sizeof(*s));
   const int shape = lookup[method];
   if (shape == kDiamond || shape == kClamped) {  // av1_init_dsmotion_compensation (:350-389)
@@ -44,6 +44,14 @@ static void build_sites(int method, SiteTable *s) {
     for (int radius = level ? 256 : 1024; radius > 0; --stage, ++n) {
       ring(s, stage, radius, radius, 8);
       if (!level || stage < 9) radius /= 2;
+    }
+    s->num_search_steps = n;
+  } else if (shape == kNstepFpf) {  // av1_init_motion_fpf (:391-431): the first-pass table
+    int stage = 10, n = 0;
+    for (int radius = 1024; radius > 0; radius /= 2, --stage, ++n) {
+      int t = (int)(0.41 * radius);
+      if (t < 1) t = 1;
+      ring(s, stage, radius, t, radius == 1 ? 8 : 12);
     }
     s->num_search_steps = n;
   } else if (shape == kNstep || shape == kNstep8) {  // av1_init_motion_compensation_nstep (:436-474)

@@ -407,6 +407,9 @@ int aomhip_mesh_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const ao
 #define AOMHIP_SEARCH_FAST_DIAMOND 8
 #define AOMHIP_SEARCH_FAST_BIGDIA 9
 #define AOMHIP_SEARCH_VFAST_DIAMOND 10
+/* not a SEARCH_METHODS value: NSTEP (full_pixel_diamond + the NSTEP mesh rule) on the FIRST-PASS site table
+ * av1_init_motion_fpf (mcomp.c:391-431), as first_pass_motion_search sets it up (firstpass.c:261-299) */
+#define AOMHIP_SEARCH_NSTEP_FPF 11
 
 /* The per-call part of FULLPEL_MOTION_SEARCH_PARAMS (av1/encoder/mcomp.h:101-141) and of its MV_COST_PARAMS
  * (:70-84); the per-block part (buffers, start MV, ref_mv, mv_limits) is aomhip_search_block. */

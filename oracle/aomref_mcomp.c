@@ -291,7 +291,9 @@ void orc_mesh_search_batch(const void *src_origin, int src_stride, const void *r
  * ===================================================================================================== */
 
 enum { SM_DIAMOND, SM_NSTEP, SM_NSTEP_8PT, SM_CLAMPED_DIAMOND, SM_HEX, SM_BIGDIA, SM_SQUARE, SM_FAST_HEX, SM_FAST_DIAMOND,
-       SM_FAST_BIGDIA, SM_VFAST_DIAMOND, SM_COUNT }; /* SEARCH_METHODS, mcomp_structs.h:50-83 */
+       SM_FAST_BIGDIA, SM_VFAST_DIAMOND, SM_COUNT, /* SEARCH_METHODS, mcomp_structs.h:50-83 */
+       SM_NSTEP_FPF = SM_COUNT, /* NSTEP on the first-pass site table (av1_init_motion_fpf, mcomp.c:391-431; firstpass.c:261-299) */
+       SM_ALL };
 
 /* search_site_config (mcomp_structs.h:36-48) without the stride-dependent offsets */
 typedef struct {
@@ -318,8 +320,8 @@ static void step_sites(orc_sites *s, int stage, int radius, int t, int npts) {
 }
 
 void orc_init_search_sites(int method, orc_sites *s) {
-  static const uint8_t lookup[SM_COUNT] = { SM_DIAMOND, SM_NSTEP,  SM_NSTEP_8PT, SM_CLAMPED_DIAMOND, SM_HEX,   SM_BIGDIA,
-                                            SM_SQUARE,  SM_HEX,    SM_BIGDIA,    SM_BIGDIA,          SM_BIGDIA }; /* mcomp.h:199-211 */
+  static const uint8_t lookup[SM_ALL] = { SM_DIAMOND, SM_NSTEP,  SM_NSTEP_8PT, SM_CLAMPED_DIAMOND, SM_HEX,   SM_BIGDIA,
+                                            SM_SQUARE,  SM_HEX,    SM_BIGDIA,    SM_BIGDIA,          SM_BIGDIA, SM_NSTEP_FPF }; /* mcomp.h:199-211 */
   memset(s, 0, sizeof(*s));
   switch (lookup[method]) {
     case SM_DIAMOND:
@@ -332,6 +334,16 @@ void orc_init_search_sites(int method, orc_sites *s) {
         if (!level || (stage < 9 && level)) radius /= 2;
         --stage;
         ++n;
+      }
+      s->num_search_steps = n;
+      break;
+    }
+    case SM_NSTEP_FPF: { /* av1_init_motion_fpf: radius 1024 .. 1 from stage 10 down, 12 sites (8 at radius 1) */
+      int stage = 10, n = 0;
+      for (int radius = 1024; radius > 0; radius /= 2, --stage, ++n) {
+        int t = (int)(0.41 * radius);
+        if (t < 1) t = 1;
+        step_sites(s, stage, radius, t, radius == 1 ? 8 : 12);
       }
       s->num_search_steps = n;
       break;
@@ -685,7 +697,7 @@ static int full_pixel_search(search_ctx *c, const orc_search_block *b, const orc
     default: var = full_pixel_diamond_sites(c, b, s, sp, cost_list, &br, &bc, second); break;
   }
   int run_mesh_search = q->run_mesh_search;
-  if (!run_mesh_search && (m == SM_NSTEP || m == SM_NSTEP_8PT)) {
+  if (!run_mesh_search && (m == SM_NSTEP || m == SM_NSTEP_8PT || m == SM_NSTEP_FPF)) {
     int thr = q->force_mesh_thresh;
     thr >>= 10 - log2_area_mi(c->w, c->h);
     if (var > thr) run_mesh_search = 1;

@@ -484,7 +484,8 @@ def subpel_tree_batch(src_b, ref_b, border, w, h, blocks, tree="pruned_more", co
 
 
 SEARCH_METHODS = ["DIAMOND", "NSTEP", "NSTEP_8PT", "CLAMPED_DIAMOND", "HEX", "BIGDIA", "SQUARE", "FAST_HEX", "FAST_DIAMOND",
-                  "FAST_BIGDIA", "VFAST_DIAMOND"]      # SEARCH_METHODS values, mcomp_structs.h:50-83
+                  "FAST_BIGDIA", "VFAST_DIAMOND",      # SEARCH_METHODS values, mcomp_structs.h:50-83
+                  "NSTEP_FPF"]                         # + NSTEP on the first-pass site table (av1_init_motion_fpf)
 
 
 class SearchParams(C.Structure):

@@ -156,11 +156,14 @@ class Harness:
             cfg = ev.new("search_site_config")
             # av1_init_motion_compensation[] (mcomp.h:186-195) and the level rule of its callers (e.g. encoder.c:
             # level = search method is NSTEP_8PT or CLAMPED_DIAMOND)
-            lookup = ev.global_values("search_method_lookup")
-            table = ev.globs["av1_init_motion_compensation"]
-            fn = table.buf[lookup[self.const(method)]]
-            level = int(method in ("NSTEP_8PT", "CLAMPED_DIAMOND"))
-            ev.interp.call(fn.name, [(cfg, R.PTR), (self.S, R.I32), (level, R.I32)])
+            if method == "NSTEP_FPF":        # the first-pass table (firstpass.c:261-299 uses it with search_method NSTEP)
+                ev.interp.call("av1_init_motion_fpf", [(cfg, R.PTR), (self.S, R.I32)])
+            else:
+                lookup = ev.global_values("search_method_lookup")
+                table = ev.globs["av1_init_motion_compensation"]
+                fn = table.buf[lookup[self.const(method)]]
+                level = int(method in ("NSTEP_8PT", "CLAMPED_DIAMOND"))
+                ev.interp.call(fn.name, [(cfg, R.PTR), (self.S, R.I32), (level, R.I32)])
             self.site_cfgs[method] = cfg
         return self.site_cfgs[method]
 
@@ -204,7 +207,7 @@ class Harness:
         vfp = self.vtable(w, h)
         ev.set(ms, "bsize", self.const(BSIZE[(w, h)])); ev.set(ms, "vfp", vfp)
         ev.set(ms, "ms_buffers.ref", self.buf2d(self.refp, by, bx)); ev.set(ms, "ms_buffers.src", self.buf2d(self.srcp, by, bx))
-        ev.set(ms, "search_method", self.const(method)); ev.set(ms, "search_sites", self.sites(method))
+        ev.set(ms, "search_method", self.const("NSTEP" if method == "NSTEP_FPF" else method)); ev.set(ms, "search_sites", self.sites(method))
         for k, v in dict(row_min=rmin, row_max=rmax, col_min=cmin, col_max=cmax).items():
             ev.set(ms, "mv_limits." + k, v)
         self.cost_params(ms, "mv_cost_params.", cost_type, rrow, rcol, sad_per_bit, error_per_bit)
@@ -445,18 +448,28 @@ def main():
                                   subpel_limits=lim, error_per_bit=70, mv=[ev.get(best, "row"), ev.get(best, "col")], err=err,
                                   distortion=dist.buf[0], sse=sse.buf[0], sec_s=round(time.time() - t1, 1)))
     print("subpel tree, 8-tap up-sampled error: %d cases, %.0f s" % (len(cases) - n0, time.time() - t0))
+    # 7. NSTEP on the first-pass site table av1_init_motion_fpf (own generator)
+    n0 = len(cases)
+    rng4 = np.random.default_rng(20261013)
+    for trial in range(6):
+        w, h = ((16, 16), (8, 8), (16, 8))[trial % 3]
+        bx, by = int(rng4.integers(0, (W - w) // 4 + 1)) * 4, int(rng4.integers(0, (H - h) // 4 + 1)) * 4
+        blk = (bx, by, int(rng4.integers(-3, 4)), int(rng4.integers(-3, 4)), int(rng4.integers(-20, 21)), int(rng4.integers(-20, 21))) + limits(bx, by, w, h, 28)
+        run_fullpel("search", 8 if trial < 4 else 10, w, h, blk, "NSTEP_FPF", int(rng4.integers(0, 5)), ("L1_HDRES", "NONE", "ENTROPY")[trial % 3],
+                    sad_per_bit=22, error_per_bit=66)
+    print("first-pass table: %d cases, %.0f s" % (len(cases) - n0, time.time() - t0))
     # the site tables themselves (G1): every builder, as (stage, index) -> (row, col), searches_per_step, radius
     sites = {}
-    for m in METHODS:
+    for m in METHODS + ["NSTEP_FPF"]:
         cfg = harness[8].sites(m)
         n = ev.get(cfg, "num_search_steps")
         sp = [ev.get(cfg, "searches_per_step[%d]" % i) for i in range(n)]
         rad = [ev.get(cfg, "radius[%d]" % i) for i in range(n)]
-        first = 0 if m not in ("DIAMOND", "CLAMPED_DIAMOND") else 11 - n
+        first = 0 if m not in ("DIAMOND", "CLAMPED_DIAMOND", "NSTEP_FPF") else 11 - n
         mv = []
         for i in range(n):
             st = i + first
-            lo = 1 if m in ("DIAMOND", "CLAMPED_DIAMOND", "NSTEP", "NSTEP_8PT") else 0
+            lo = 1 if m in ("DIAMOND", "CLAMPED_DIAMOND", "NSTEP", "NSTEP_8PT", "NSTEP_FPF") else 0
             cnt = sp[i + first] if first else sp[i]
             mv.append([[ev.get(cfg, "site[%d][%d].mv.row" % (st, j)), ev.get(cfg, "site[%d][%d].mv.col" % (st, j))] for j in range(lo, lo + cnt)])
         sites[m] = dict(num_search_steps=n, searches_per_step=sp if not first else [ev.get(cfg, "searches_per_step[%d]" % (i + first)) for i in range(n)],

@@ -201,7 +201,7 @@ def test_search_site_tables_match_reference_evaluation(oracle):
         ns, per, rad, mv = oracle.search_sites(method)
         assert ns == ref["num_search_steps"], method
         first = ref["first_stage"]
-        lo = 1 if method in ("DIAMOND", "CLAMPED_DIAMOND", "NSTEP", "NSTEP_8PT") else 0
+        lo = 1 if method in ("DIAMOND", "CLAMPED_DIAMOND", "NSTEP", "NSTEP_8PT", "NSTEP_FPF") else 0
         for i in range(ns):
             st = i + first
             assert per[st] == ref["searches_per_step"][i] and rad[st] == ref["radius"][i], (method, st)

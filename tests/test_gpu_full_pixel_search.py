@@ -38,7 +38,7 @@ def test_site_tables_match_reference_evaluation(hip):
         ns, per, rad, mv = hip.capi.search_sites(method)
         assert ns == ref["num_search_steps"]
         first = ref["first_stage"]
-        lo = 1 if method in ("DIAMOND", "CLAMPED_DIAMOND", "NSTEP", "NSTEP_8PT") else 0
+        lo = 1 if method in ("DIAMOND", "CLAMPED_DIAMOND", "NSTEP", "NSTEP_8PT", "NSTEP_FPF") else 0
         for i in range(ns):
             st = i + first
             assert per[st] == ref["searches_per_step"][i] and rad[st] == ref["radius"][i]
@@ -162,7 +162,7 @@ def test_full_pixel_search_rejects_bad_arguments(hip, ctx):
     with pytest.raises(Exception):      # step_param beyond the table
         ctx.full_pixel_search_batch(ps, pr, 0, 16, 16, hip.capi.SearchParams.make("DIAMOND", 11, 3), d_b, 1, d_mv, d_c)
     with pytest.raises(Exception):      # unknown method
-        ctx.full_pixel_search_batch(ps, pr, 0, 16, 16, hip.capi.SearchParams.make(11, 0, 3), d_b, 1, d_mv, d_c)
+        ctx.full_pixel_search_batch(ps, pr, 0, 16, 16, hip.capi.SearchParams.make(12, 0, 3), d_b, 1, d_mv, d_c)
     for d in (d_b, d_mv, d_c):
         ctx.free(d)
     ctx.planes_free(ps); ctx.planes_free(pr)
