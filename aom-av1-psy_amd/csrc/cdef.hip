@@ -315,76 +315,71 @@ __global__ __launch_bounds__(256) void cdef_chroma_kernel(const PIX *__restrict_
   const int level = fb_pri[fby * fb_stride + fbx], sec = fb_sec[fby * fb_stride + fbx];
   __syncthreads();
 
-  constexpr int kRows = BH / 4 > 0 ? BH / 4 : 1;  // rows per lane (4 lanes per block)
-  const int blk = tid >> 2, q = tid & 3;
-  const int by = blk >> 3, bx = blk & 7;
-  const int gx0 = x0 + bx * BW, gyb = y0 + by * BH;
-  if (gyb >= height || gx0 >= width) return;
-  const int bidx = (gyb / BH) * nbx + gx0 / BW;
-  const bool filt = (level | sec) != 0 && !skip[bidx];
+  // filter: lane = pixel column (two rows of lanes per wavefront when the filter block is 32 wide), two vertically
+  // adjacent pixels per lane as packed int16 -- the luma kernel's scheme (profiles/r01_cdef.md)
+  constexpr int kLanesPerRow = FW;                       // 64 or 32
+  constexpr int kSub = 64 / kLanesPerRow;                // row pairs a wavefront handles per step
+  constexpr int kRowsPerWave = FH / 4;                   // 16 or 8
+  const int wave = tid >> 6, lane = tid & 63;
+  const int col = lane % kLanesPerRow, rsub = lane / kLanesPerRow;
+  const int gx = x0 + col;
+  if (gx >= width) return;
   const int pri_strength = level << coeff_shift, sec_strength = sec << coeff_shift;
-  int dir = luma_dir[bidx] & 7;
-  if constexpr (XDEC != YDEC) {
-    constexpr int conv422[8] = { 7, 0, 2, 4, 5, 6, 6, 6 }, conv440[8] = { 1, 2, 2, 2, 3, 4, 6, 0 };
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) c = dir == k ? (XDEC ? conv422[k] : conv440[k]) : c;
-    dir = c;
-  }
-  dir = pri_strength ? dir : 0;
-  const int t = pri_strength;
   const int dmp = damping + coeff_shift - 1;
-  const bool en_pri = t != 0, en_sec = sec_strength != 0, clip = en_pri && en_sec;
-  const int pt0 = ((t >> coeff_shift) & 1) ? 3 : 4, pt1 = ((t >> coeff_shift) & 1) ? 3 : 2;
+  const int t = pri_strength;
+  const int pri_shift = t ? max(0, dmp - msb_u((unsigned)t)) : 0;
+  const int sec_shift = sec_strength ? max(0, dmp - msb_u((unsigned)sec_strength)) : 0;
+  const bool clip = (t != 0) && (sec_strength != 0);
+  const s16x2 pri_thr = splat2(t), pri_sh = splat2(pri_shift), sec_thr = splat2(sec_strength), sec_sh = splat2(sec_shift);
+  const s16x2 pt0 = splat2(((t >> coeff_shift) & 1) ? 3 : 4), pt1 = splat2(((t >> coeff_shift) & 1) ? 3 : 2);
   auto off = [&](int d, int k) { return kDirDyDx[d][k][0] * TW + kDirDyDx[d][k][1]; };
-  const int po0 = off(dir, 0), po1 = off(dir, 1);
-  const int s1o0 = off((dir + 2) & 7, 0), s1o1 = off((dir + 2) & 7, 1);
-  const int s2o0 = off((dir + 6) & 7, 0), s2o1 = off((dir + 6) & 7, 1);
+#pragma unroll 1
+  for (int step = 0; step < kRowsPerWave / (2 * kSub); ++step) {
+    const int ly = wave * kRowsPerWave + (step * kSub + rsub) * 2;   // rows ly, ly + 1 (same chroma block: BH is 4 or 8)
+    const int gy = y0 + ly;
+    if (gy >= height) continue;
+    const int bidx = (gy / BH) * nbx + gx / BW;
+    const bool filt = (level | sec) != 0 && !skip[bidx];
+    int dir = luma_dir[bidx] & 7;
+    if constexpr (XDEC != YDEC) {
+      constexpr int conv422[8] = { 7, 0, 2, 4, 5, 6, 6, 6 }, conv440[8] = { 1, 2, 2, 2, 3, 4, 6, 0 };
+      int c = 0;
 #pragma unroll
-  for (int rr = 0; rr < kRows; ++rr) {
-    const int ly = by * BH + q * kRows + rr;
-    if (q * kRows + rr >= BH) break;
-    PIX outv[BW];
-#pragma unroll
-    for (int j = 0; j < BW; ++j) {
-      const int pos = (ly + 2) * TW + bx * BW + j + 4;
-      const int x = tile[pos];
-      int y = x;
-      if (filt) {
-        int sum = 0, mx = x, mn = x;
-        if (en_pri) {
-          const int p0 = tile[pos + po0], p1 = tile[pos - po0], p2 = tile[pos + po1], p3 = tile[pos - po1];
-          sum += pt0 * (constrain_d(p0 - x, t, dmp) + constrain_d(p1 - x, t, dmp));
-          sum += pt1 * (constrain_d(p2 - x, t, dmp) + constrain_d(p3 - x, t, dmp));
-          if (clip) {
-            mx = max(mx, p0 == kVeryLarge ? x : p0); mx = max(mx, p1 == kVeryLarge ? x : p1);
-            mx = max(mx, p2 == kVeryLarge ? x : p2); mx = max(mx, p3 == kVeryLarge ? x : p3);
-            mn = min(min(mn, p0), min(p1, min(p2, p3)));
-          }
-        }
-        if (en_sec) {
-          const int a0 = tile[pos + s1o0], a1 = tile[pos - s1o0], a2 = tile[pos + s2o0], a3 = tile[pos - s2o0];
-          const int c0 = tile[pos + s1o1], c1 = tile[pos - s1o1], c2 = tile[pos + s2o1], c3 = tile[pos - s2o1];
-          sum += 2 * (constrain_d(a0 - x, sec_strength, dmp) + constrain_d(a1 - x, sec_strength, dmp) +
-                      constrain_d(a2 - x, sec_strength, dmp) + constrain_d(a3 - x, sec_strength, dmp));
-          sum += 1 * (constrain_d(c0 - x, sec_strength, dmp) + constrain_d(c1 - x, sec_strength, dmp) +
-                      constrain_d(c2 - x, sec_strength, dmp) + constrain_d(c3 - x, sec_strength, dmp));
-          if (clip) {
-            mx = max(mx, a0 == kVeryLarge ? x : a0); mx = max(mx, a1 == kVeryLarge ? x : a1);
-            mx = max(mx, a2 == kVeryLarge ? x : a2); mx = max(mx, a3 == kVeryLarge ? x : a3);
-            mx = max(mx, c0 == kVeryLarge ? x : c0); mx = max(mx, c1 == kVeryLarge ? x : c1);
-            mx = max(mx, c2 == kVeryLarge ? x : c2); mx = max(mx, c3 == kVeryLarge ? x : c3);
-            mn = min(min(min(mn, a0), min(a1, a2)), min(min(a3, c0), min(c1, min(c2, c3))));
-          }
-        }
-        y = x + ((8 + sum - (sum < 0)) >> 4);
-        if (clip) y = y < mn ? mn : (y > mx ? mx : y);
-      }
-      outv[j] = (PIX)y;
+      for (int k = 0; k < 8; ++k) c = dir == k ? (XDEC ? conv422[k] : conv440[k]) : c;
+      dir = c;
     }
-    PIX *o = dst + (int64_t)(y0 + ly) * stride + gx0;
-#pragma unroll
-    for (int j = 0; j < BW; ++j) o[j] = outv[j];
+    dir = pri_strength ? dir : 0;
+    const int po0 = off(dir, 0), po1 = off(dir, 1);
+    const int s1o0 = off((dir + 2) & 7, 0), s1o1 = off((dir + 2) & 7, 1);
+    const int s2o0 = off((dir + 6) & 7, 0), s2o1 = off((dir + 6) & 7, 1);
+    const int pos = (ly + 2) * TW + col + 4;
+    auto ld2 = [&](int o) { return pack2(tile[pos + o], tile[pos + TW + o]); };
+    const s16x2 x = ld2(0);
+    s16x2 y = x;
+    if (filt) {
+      const s16x2 p0 = ld2(po0), p1 = ld2(-po0), p2 = ld2(po1), p3 = ld2(-po1);
+      const s16x2 a0 = ld2(s1o0), a1 = ld2(-s1o0), a2 = ld2(s2o0), a3 = ld2(-s2o0);
+      const s16x2 c0 = ld2(s1o1), c1 = ld2(-s1o1), c2 = ld2(s2o1), c3 = ld2(-s2o1);
+      s16x2 sum = pt0 * (constrain_pk(p0 - x, pri_thr, pri_sh) + constrain_pk(p1 - x, pri_thr, pri_sh)) +
+                  pt1 * (constrain_pk(p2 - x, pri_thr, pri_sh) + constrain_pk(p3 - x, pri_thr, pri_sh));
+      const s16x2 sa = constrain_pk(a0 - x, sec_thr, sec_sh) + constrain_pk(a1 - x, sec_thr, sec_sh) +
+                       constrain_pk(a2 - x, sec_thr, sec_sh) + constrain_pk(a3 - x, sec_thr, sec_sh);
+      const s16x2 sc = constrain_pk(c0 - x, sec_thr, sec_sh) + constrain_pk(c1 - x, sec_thr, sec_sh) +
+                       constrain_pk(c2 - x, sec_thr, sec_sh) + constrain_pk(c3 - x, sec_thr, sec_sh);
+      sum += sa + sa + sc;
+      y = x + ((splat2(8) + sum + (sum >> splat2(15))) >> splat2(4));
+      if (clip) {
+        const s16x2 k = splat2(0x3fff);
+        s16x2 mx = pmax(pmax(pmax(x, p0 & k), pmax(p1 & k, p2 & k)), pmax(pmax(p3 & k, a0 & k), pmax(a1 & k, a2 & k)));
+        mx = pmax(pmax(pmax(mx, a3 & k), pmax(c0 & k, c1 & k)), pmax(c2 & k, c3 & k));
+        s16x2 mn = pmin(pmin(pmin(x, p0), pmin(p1, p2)), pmin(pmin(p3, a0), pmin(a1, a2)));
+        mn = pmin(pmin(pmin(mn, a3), pmin(c0, c1)), pmin(c2, c3));
+        y = pmin(pmax(y, mn), mx);
+      }
+    }
+    PIX *o = dst + (int64_t)gy * stride + gx;
+    o[0] = (PIX)(uint16_t)y.x;
+    o[stride] = (PIX)(uint16_t)y.y;
   }
 }
 
