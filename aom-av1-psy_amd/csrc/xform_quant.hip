@@ -94,6 +94,33 @@ template <int LPB> __device__ __forceinline__ int group_max(int v) {
   return v;
 }
 
+template <int LPB> __device__ __forceinline__ int64_t group_sum64(int64_t v) {
+#pragma unroll
+  for (int m = 1; m < LPB; m <<= 1) v += __shfl_xor((long long)v, m, 64);
+  return v;
+}
+// one term pair of av1_block_error_c / av1_highbd_block_error_c (av1/encoder/rdopt.c:635-682): err_shift < 0 selects the
+// low-bd form, whose products are 32-bit (`diff * diff` on int operands wraps exactly as the compiled reference does)
+__device__ __forceinline__ void block_err_acc(int32_t c, int32_t dq, int err_shift, int64_t &e, int64_t &z) {
+  const int32_t diff = c - dq;
+  if (err_shift < 0) {
+    e += (int64_t)(int32_t)((uint32_t)diff * (uint32_t)diff);
+    z += (int64_t)(int32_t)((uint32_t)c * (uint32_t)c);
+  } else {
+    e += (int64_t)diff * diff;
+    z += (int64_t)c * c;
+  }
+}
+__device__ __forceinline__ void block_err_store(int64_t *out, int bi, int64_t e, int64_t z, int err_shift) {
+  if (err_shift > 0) {
+    const int64_t r = (int64_t)1 << (err_shift - 1);
+    e = (e + r) >> err_shift;
+    z = (z + r) >> err_shift;
+  }
+  out[2 * (int64_t)bi] = e;
+  out[2 * (int64_t)bi + 1] = z;
+}
+
 constexpr int kXqThreads = 256;
 
 struct __attribute__((packed, aligned(1))) VecU128 { uint32_t v[4]; };
@@ -106,7 +133,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
     const void *__restrict__ in0, const void *__restrict__ in1, int stride0, int stride1,
     const aomhip_txb *__restrict__ blocks, int n_blocks, int grid_cols, int uniform_type, QuantArgs qa,
     int32_t *__restrict__ coeff, int32_t *__restrict__ qcoeff, int32_t *__restrict__ dqcoeff,
-    uint16_t *__restrict__ eob, int nblk8) {
+    uint16_t *__restrict__ eob, int nblk8, int64_t *__restrict__ err_out, int err_shift) {
   using C = Cfg2D<W, H>;
   constexpr int LPB = W > H ? W : H;
   constexpr int BPW = kXqThreads / LPB;  // blocks per workgroup
@@ -169,6 +196,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
 
   // ---- rows + quantise
   int my_eob = 0;
+  int64_t berr = 0, bssz = 0;
   if (live && lane < KH) {
     const int r = lane;
     int32_t y[W];
@@ -193,11 +221,17 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
       last_c = qv ? c : last_c;
       qcoeff[out_off + rc] = qv;
       dqcoeff[out_off + rc] = dqv;
+      if (err_out) block_err_acc(v, dqv, err_shift, berr, bssz);
     }
     if (last_c >= 0) my_eob = iscan_pos<KW, KH>(r, last_c, scan_class) + 1;
   }
   my_eob = group_max<LPB>(my_eob);
   if (live && lane == 0) eob[bi] = (uint16_t)my_eob;
+  if (err_out) {
+    berr = group_sum64<LPB>(berr);
+    bssz = group_sum64<LPB>(bssz);
+    if (live && lane == 0) block_err_store(err_out, bi, berr, bssz, err_shift);
+  }
 }
 
 
@@ -213,7 +247,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
     const void *__restrict__ in0, const void *__restrict__ in1, int stride0, int stride1,
     const aomhip_txb *__restrict__ blocks, int n_blocks, int grid_cols, int uniform_type, QuantArgs qa,
     int32_t *__restrict__ coeff, int32_t *__restrict__ qcoeff, int32_t *__restrict__ dqcoeff,
-    uint16_t *__restrict__ eob, int nblk8) {
+    uint16_t *__restrict__ eob, int nblk8, int64_t *__restrict__ err_out, int err_shift) {
   using C = Cfg2D<W, H>;
   constexpr int LPB = W > H ? W : H;
   constexpr int BPW = kXqThreads / LPB;
@@ -329,6 +363,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
   int my_eob = 0;
   int32_t y[W];
   const int r = lane;
+  int64_t berr = 0, bssz = 0;
   if (live && lane < KH) {
 #pragma unroll
     for (int c = 0; c < W; ++c) y[c] = B[r * LSTRIDE + c];
@@ -354,11 +389,17 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
       last_c = qv ? c : last_c;
       A[rc] = qv;
       B[rc] = dqv;
+      if (err_out) block_err_acc(v, dqv, err_shift, berr, bssz);
     }
     if (last_c >= 0) my_eob = iscan_pos<KW, KH>(r, last_c, scan_class) + 1;
   }
   my_eob = group_max<LPB>(my_eob);
   if (live && lane == 0) eob[bi] = (uint16_t)my_eob;
+  if (err_out) {
+    berr = group_sum64<LPB>(berr);
+    bssz = group_sum64<LPB>(bssz);
+    if (live && lane == 0) block_err_store(err_out, bi, berr, bssz, err_shift);
+  }
   __syncthreads();
 
   // ---- 4. copy out, 16 bytes per lane per store
@@ -387,7 +428,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
     const void *__restrict__ in0, const void *__restrict__ in1, int stride0, int stride1,
     const aomhip_txb *__restrict__ blocks, int n_blocks, int grid_cols, int uniform_type, QuantArgs qa,
     int32_t *__restrict__ coeff, int32_t *__restrict__ qcoeff, int32_t *__restrict__ dqcoeff,
-    uint16_t *__restrict__ eob, int nblk8) {
+    uint16_t *__restrict__ eob, int nblk8, int64_t *__restrict__ err_out, int err_shift) {
   using C = Cfg2D<W, H>;
   constexpr int NC = W * H;
   constexpr int LS = 0;  // <= 64 samples: av1_get_tx_scale == 0
@@ -459,6 +500,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
   const int scan_class = (wht || tx_type < 10) ? 0 : ((tx_type & 1) ? 2 : 1);
   const int zb[2] = { qa.zbin[0], qa.zbin[1] }, rd[2] = { qa.round[0], qa.round[1] };
   int my_eob = 0;
+  int64_t berr = 0, bssz = 0;
   int32_t qv[H][W], dv[H][W];
   auto emit = [&](int r, int c, int32_t v) {  // coefficient (r, c) = index c * H + r of the reference's output
     if (coeff) coeff[out_off + c * H + r] = v;
@@ -469,6 +511,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
     const int p0 = iscan_pos<W, H>(r, c, 0) + 1, p1 = iscan_pos<W, H>(r, c, 1) + 1, p2 = iscan_pos<W, H>(r, c, 2) + 1;
     const int p = scan_class == 0 ? p0 : (scan_class == 1 ? p1 : p2);
     my_eob = (qv[r][c] != 0 && p > my_eob) ? p : my_eob;
+    if (err_out) block_err_acc(v, dv[r][c], err_shift, berr, bssz);
   };
   if constexpr (wht) {
     {  // av1_fwht4x4_c (hybrid_fwd_txfm.c:24-76) on the raw residual, UNIT_QUANT_FACTOR = 4
@@ -517,6 +560,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
     }
   }
   eob[bi] = (uint16_t)my_eob;
+  if (err_out) block_err_store(err_out, bi, berr, bssz, err_shift);
   // ---- store in the reference's transposed order (index c*H + r): column c is H contiguous values
 #pragma unroll
   for (int c = 0; c < W; ++c) {
@@ -629,6 +673,9 @@ struct XqLaunch {
   QuantArgs qa;
   int32_t *coeff, *qcoeff, *dqcoeff;
   uint16_t *eob;
+  int64_t *err_out = nullptr;  // optional av1_block_error outputs: {error, ssz} per block
+  int err_shift = 0;           // 0: av1_block_error_c (32-bit products); 2 * (bd - 8) >= 0 with err_hbd: the highbd form
+
 };
 
 template <int W, int H, bool HBD, int SRC> static int launch_xq(const XqLaunch &l) {
@@ -650,11 +697,11 @@ template <int W, int H, bool HBD, int SRC> static int launch_xq(const XqLaunch &
       if (l.uniform_type == kTxWht)
         hipLaunchKernelGGL((xform_quant_lane_kernel<W, H, HBD, SRC, true>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0,
                            l.in1, l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff,
-                           l.qcoeff, l.dqcoeff, l.eob, nwg8);
+                           l.qcoeff, l.dqcoeff, l.eob, nwg8, l.err_out, l.err_shift);
       else
         hipLaunchKernelGGL((xform_quant_lane_kernel<W, H, HBD, SRC>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0,
                            l.in1, l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff,
-                           l.qcoeff, l.dqcoeff, l.eob, nwg8);
+                           l.qcoeff, l.dqcoeff, l.eob, nwg8, l.err_out, l.err_shift);
       AOMHIP_LAUNCH_CHECK();
       return AOMHIP_OK;
     }
@@ -664,11 +711,11 @@ template <int W, int H, bool HBD, int SRC> static int launch_xq(const XqLaunch &
   if (variant == 0)
     hipLaunchKernelGGL((xform_quant_kernel<W, H, HBD, SRC>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0, l.in1,
                        l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff,
-                       l.qcoeff, l.dqcoeff, l.eob, nwg8);
+                       l.qcoeff, l.dqcoeff, l.eob, nwg8, l.err_out, l.err_shift);
   else
     hipLaunchKernelGGL((xform_quant_staged_kernel<W, H, HBD, SRC>), dim3(nwg8), dim3(kXqThreads), 0, l.stream, l.in0,
                        l.in1, l.stride0, l.stride1, l.blocks, l.n_blocks, l.grid_cols, l.uniform_type, l.qa, l.coeff,
-                       l.qcoeff, l.dqcoeff, l.eob, nwg8);
+                       l.qcoeff, l.dqcoeff, l.eob, nwg8, l.err_out, l.err_shift);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
@@ -759,6 +806,24 @@ int aomhip_xform_quant_batch(aomhip_ctx *ctx, const int16_t *d_residual, int res
   if (n_blocks == 0) return AOMHIP_OK;
   XqLaunch l{ ctx->stream, d_residual, nullptr, residual_stride, 0, d_blocks, n_blocks, grid_cols, uniform_tx_type,
               to_args(qparams), d_coeff, d_qcoeff, d_dqcoeff, d_eob };
+  return is_hbd ? dispatch_xq<true, 0>(tx_size, l) : dispatch_xq<false, 0>(tx_size, l);
+}
+
+int aomhip_xform_quant_dist_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int tx_size,
+                                  const aomhip_txb *d_blocks, int n_blocks, int grid_cols, int uniform_tx_type,
+                                  const aomhip_quant_params *qparams, int is_hbd, int bit_depth, int32_t *d_coeff,
+                                  int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob, int64_t *d_block_error) {
+  if (!ctx || !d_residual || !qparams || !d_qcoeff || !d_dqcoeff || !d_eob || !d_block_error || tx_size < 0 || tx_size >= 19 ||
+      n_blocks < 0 || (!d_blocks && (grid_cols <= 0 || !type_ok(tx_size, uniform_tx_type))) ||
+      (uniform_tx_type == kTxWht && tx_size != 0) || (bit_depth != 8 && bit_depth != 10 && bit_depth != 12)) {
+    set_error("aomhip_xform_quant_dist_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  XqLaunch l{ ctx->stream, d_residual, nullptr, residual_stride, 0, d_blocks, n_blocks, grid_cols, uniform_tx_type,
+              to_args(qparams), d_coeff, d_qcoeff, d_dqcoeff, d_eob };
+  l.err_out = d_block_error;
+  l.err_shift = is_hbd ? 2 * (bit_depth - 8) : -1;   // the highbd form when the buffers are high bit depth (tx_search.c)
   return is_hbd ? dispatch_xq<true, 0>(tx_size, l) : dispatch_xq<false, 0>(tx_size, l);
 }
 

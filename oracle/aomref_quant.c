@@ -213,3 +213,28 @@ void orc_quantize_b_adaptive(const int32_t *coeff, intptr_t n, const int16_t *zb
   }
   *eob_out = (uint16_t)(eob + 1);
 }
+
+/* av1_block_error_c / av1_highbd_block_error_c (av1/encoder/rdopt.c:635-682): transform-domain distortion and the energy
+ * of the unquantised coefficients.  The low-bd form multiplies `int` operands (diff * diff, coeff * coeff): 32-bit
+ * products, reproduced with unsigned wrap-around + sign extension (what the compiled reference does on this target).
+ * bd = 0 selects the low-bd form; 8 / 10 / 12 the highbd form with its 2 * (bd - 8)-bit rounding. */
+int64_t orc_block_error(const int32_t *coeff, const int32_t *dqcoeff, intptr_t n, int64_t *ssz, int bd) {
+  int64_t error = 0, sq = 0;
+  for (intptr_t i = 0; i < n; ++i) {
+    const int32_t diff = (int32_t)((uint32_t)coeff[i] - (uint32_t)dqcoeff[i]);
+    if (bd == 0) {
+      error += (int32_t)((uint32_t)diff * (uint32_t)diff);
+      sq += (int32_t)((uint32_t)coeff[i] * (uint32_t)coeff[i]);
+    } else {
+      error += (int64_t)diff * diff;
+      sq += (int64_t)coeff[i] * coeff[i];
+    }
+  }
+  if (bd > 8) {
+    const int shift = 2 * (bd - 8);
+    error = (error + ((int64_t)1 << (shift - 1))) >> shift;
+    sq = (sq + ((int64_t)1 << (shift - 1))) >> shift;
+  }
+  *ssz = sq;
+  return error;
+}

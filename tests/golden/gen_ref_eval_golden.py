@@ -105,6 +105,20 @@ def gen_quant():
                                           "log_scale": {"": 0, "_32x32": 1, "_64x64": 2}[suf],
                                           "tables": {m: [int(q[m][0]), int(q[m][1])] for m in q}})
                             k += 1
+    # av1_block_error_c / av1_highbd_block_error_c (av1/encoder/rdopt.c:635-682) on (coeff, dqcoeff) pairs of the cases above:
+    # the transform-domain distortion the fused transform + quantise + distortion entry point returns
+    ev2 = evaluator(["aom_dsp/quantize.h", "av1/encoder/rdopt.c"])
+    berr = []
+    for kk in range(0, k, 7):
+        c, dq = arrays["c%d" % kk], arrays["d%d" % kk]
+        ssz = ev2.array([0], "int64_t")
+        e8 = ev2.call("av1_block_error_c", ev2.array(c, "int32_t"), ev2.array(dq, "int32_t"), c.size, ssz)
+        row = [kk, e8, ssz.buf[0]]
+        for bd in (8, 10, 12):
+            e = ev2.call("av1_highbd_block_error_c", ev2.array(c, "int32_t"), ev2.array(dq, "int32_t"), c.size, ssz, bd)
+            row += [e, ssz.buf[0]]
+        berr.append(row)
+    arrays["block_error"] = np.asarray(berr, np.int64)
     save("ref_eval_quant.npz", arrays, cases)
 
 

@@ -36,6 +36,21 @@ def test_quantize_b_matches_reference_evaluation(oracle):
         assert np.array_equal(dq, z["d%d" % k]), (k, c["fn"], c["kind"], c["qindex"])
 
 
+def test_block_error_matches_reference_evaluation(oracle):
+    z, _ = load("ref_eval_quant.npz")
+    f = oracle.lib.orc_block_error
+    f.restype = C.c_int64
+    rows = z["block_error"]
+    assert len(rows) >= 90
+    for row in rows:
+        kk = int(row[0])
+        c, dq = np.ascontiguousarray(z["c%d" % kk], np.int32), np.ascontiguousarray(z["d%d" % kk], np.int32)
+        ssz = C.c_int64()
+        for j, bd in enumerate((0, 8, 10, 12)):
+            e = f(C.c_void_p(c.ctypes.data), C.c_void_p(dq.ctypes.data), C.c_ssize_t(c.size), C.byref(ssz), bd)
+            assert (e, ssz.value) == (int(row[1 + 2 * j]), int(row[2 + 2 * j])), (kk, bd)
+
+
 def test_lpf_matches_reference_evaluation(oracle):
     z, cases = load("ref_eval_lpf.npz")
     assert len(cases) >= 700

@@ -224,3 +224,41 @@ def test_adaptive_quantiser(hip, oracle, ctx, hbd):
             assert differs > 0, (tx_size, qindex)  # the adaptive rules actually fired somewhere
             for d in (d_c, d_b, d_q, d_dq, d_e):
                 ctx.free(d)
+
+
+@pytest.mark.parametrize("is_hbd,bit_depth", [(False, 8), (True, 8), (True, 10), (True, 12)])
+@pytest.mark.parametrize("tx_size", [0, 1, 2, 3, 4, 6, 9, 13, 18])
+def test_fused_block_error(hip, oracle, ctx, tx_size, is_hbd, bit_depth):
+    """aomhip_xform_quant_dist_batch: the same coefficients / levels as aomhip_xform_quant_batch plus av1_block_error /
+    av1_highbd_block_error (rdopt.c:635-682) of every block, against the oracle's restatement (itself pinned against the
+    interpreted reference, tests/test_golden_ref_eval.py)."""
+    import ctypes as C
+    w, h = oracle.TX_W[tx_size], oracle.TX_H[tx_size]
+    types = [t for t in range(16) if oracle.lib.orc_txfm_valid(tx_size, t)]
+    rng = np.random.default_rng(tx_size * 5 + bit_depth + is_hbd)
+    W, H = 192, 160
+    nc = hip.capi.lib.aomhip_tx_max_eob(tx_size)
+    bits = bit_depth + 1
+    residual = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), (H, W)).astype(np.int16)
+    n = 203 if w * h <= 256 else 41
+    blocks = _blocks(hip, rng, W, H, w, h, n, types, nc)
+    q = oracle.build_quantizer_y(bit_depth if is_hbd else 8, 120)
+    total = int(blocks["out_offset"].max()) + nc
+    d_res, d_blk = ctx.to_device(residual), ctx.to_device(blocks)
+    d_c, d_q, d_dq, d_e, d_err = ctx.malloc(total * 4), ctx.malloc(total * 4), ctx.malloc(total * 4), ctx.malloc(max(2 * n, 16)), ctx.malloc(16 * n)
+    qp = hip.capi.QuantParams.from_tables(q)
+    ctx.xform_quant_dist_batch(d_res, W, tx_size, d_blk, n, 0, 0, qp, is_hbd, bit_depth, d_c, d_q, d_dq, d_e, d_err)
+    coeff, dq = ctx.from_device(d_c, (total,), np.int32), ctx.from_device(d_dq, (total,), np.int32)
+    err = ctx.from_device(d_err, (n, 2), np.int64)
+    want = oracle.xform_quant_batch(residual, tx_size, blocks, n, 0, 0, q, is_hbd, total, True, threads=4)
+    assert np.array_equal(coeff, want[0]) and np.array_equal(dq, want[2])
+    f = oracle.lib.orc_block_error
+    f.restype = C.c_int64
+    for i in range(n):
+        off = int(blocks["out_offset"][i])
+        c, d = np.ascontiguousarray(coeff[off:off + nc]), np.ascontiguousarray(dq[off:off + nc])
+        ssz = C.c_int64()
+        e = f(C.c_void_p(c.ctypes.data), C.c_void_p(d.ctypes.data), C.c_ssize_t(nc), C.byref(ssz), bit_depth if is_hbd else 0)
+        assert (int(err[i, 0]), int(err[i, 1])) == (e, ssz.value), (tx_size, i)
+    for d in (d_res, d_blk, d_c, d_q, d_dq, d_e, d_err):
+        ctx.free(d)
