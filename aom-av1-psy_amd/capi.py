@@ -128,7 +128,7 @@ _protos = {
     "aomhip_tx_max_eob": (C.c_int, [_i]),
     "aomhip_xform_quant_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _i, C.POINTER(QuantParams), _i, _vp, _vp,
                                            _vp, _vp]),
-    "aomhip_xform_quant_dist_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "aomhip_xform_quant_ex_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_subtract_xform_quant_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _vp, _i, _i, _i, C.POINTER(QuantParams),
                                                     _vp, _vp, _vp, _vp]),
     "aomhip_quantize_b_adaptive_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, C.POINTER(QuantParams), _i, _vp, _vp, _vp]),
@@ -275,10 +275,10 @@ class Context:
                                       rng, n_buckets, d_groups, d_group_off, n_groups, group_frame_stride, d_out_groups,
                                       d_cands, d_cand_off, n_cands, cand_frame_stride, d_out_cands), "aomhip_sad_sb_batch")
 
-    def xform_quant_dist_batch(self, d_res, stride, tx_size, d_blocks, n, grid_cols, tx_type, qp, is_hbd, bit_depth, d_coeff, d_q, d_dq,
-                               d_eob, d_err):
-        check(lib.aomhip_xform_quant_dist_batch(self.h, d_res, stride, tx_size, d_blocks, n, grid_cols, tx_type, C.byref(qp), int(is_hbd),
-                                                bit_depth, d_coeff, d_q, d_dq, d_eob, d_err), "aomhip_xform_quant_dist_batch")
+    def xform_quant_ex_batch(self, d_res, stride, tx_size, d_blocks, n, grid_cols, tx_type, qp, is_hbd, bit_depth, quant_kind, d_coeff,
+                             d_q, d_dq, d_eob, d_err=None):
+        check(lib.aomhip_xform_quant_ex_batch(self.h, d_res, stride, tx_size, d_blocks, n, grid_cols, tx_type, C.byref(qp), int(is_hbd),
+                                              bit_depth, quant_kind, d_coeff, d_q, d_dq, d_eob, d_err), "aomhip_xform_quant_ex_batch")
 
     def quantize_b_adaptive_batch(self, d_coeff, tx_size, d_blocks, n_blocks, tx_type, qp, is_hbd, d_qcoeff, d_dqcoeff, d_eob):
         check(lib.aomhip_quantize_b_adaptive_batch(self.h, d_coeff, tx_size, d_blocks, n_blocks, tx_type, C.byref(qp),

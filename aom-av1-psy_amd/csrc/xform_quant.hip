@@ -25,6 +25,11 @@ namespace aomhip {
 
 using namespace txfm;
 
+#ifndef AOMHIP_XQ_EXTRAS
+#define AOMHIP_XQ_EXTRAS 1   // 0 compiles the fp quantiser and the fused block error out (A/B of their cost on the plain path)
+#endif
+constexpr int kQuantFp = -2;  // QuantArgs::qs_log2 value that selects the av1_quantize_fp family
+
 struct QuantArgs {
   int16_t zbin[2], round[2], quant[2], quant_shift[2], dequant[2];
   int8_t qs_log2[2];  // log2(quant_shift) when it is a power of two (it always is out of invert_quant,
@@ -41,6 +46,19 @@ __device__ __forceinline__ void quantize_one(int32_t v, int zb, int rd, int quan
   const int sign = v >> 31;
   const int a = (v ^ sign) - sign;
   int q;
+  if (AOMHIP_XQ_EXTRAS && qs_log2 == kQuantFp) {
+    // av1_quantize_fp_no_qmatrix / highbd_quantize_fp_helper_c (av1/encoder/av1_quantize.c:36-69,181-207): no dead zone
+    // table, threshold (|c| << (1 + log_scale)) >= dequant, level = ((|c| + round_fp) * quant_fp) >> (16 - log_scale);
+    // the low-bd form saturates |c| + round at INT16_MAX first.  `rd` arrives log-scaled, `quant` is quant_fp.
+    int64_t t = (int64_t)a + rd;
+    if constexpr (!HBD) t = t > 32767 ? 32767 : t;
+    q = (int)((t * quant) >> (16 - LS));
+    q = (((int64_t)a << (1 + LS)) >= dequant) ? q : 0;
+    const int dqf = (int)((uint32_t)q * (uint32_t)dequant) >> LS;
+    *qout = (q ^ sign) - sign;
+    *dqout = (dqf ^ sign) - sign;
+    return;
+  }
   if constexpr (!HBD) {
     int t = a + rd;
     t = t > 32767 ? 32767 : t;  // clamp(.., INT16_MIN, INT16_MAX); a + rd >= 0
@@ -221,13 +239,13 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
       last_c = qv ? c : last_c;
       qcoeff[out_off + rc] = qv;
       dqcoeff[out_off + rc] = dqv;
-      if (err_out) block_err_acc(v, dqv, err_shift, berr, bssz);
+      if (AOMHIP_XQ_EXTRAS && err_out) block_err_acc(v, dqv, err_shift, berr, bssz);
     }
     if (last_c >= 0) my_eob = iscan_pos<KW, KH>(r, last_c, scan_class) + 1;
   }
   my_eob = group_max<LPB>(my_eob);
   if (live && lane == 0) eob[bi] = (uint16_t)my_eob;
-  if (err_out) {
+  if (AOMHIP_XQ_EXTRAS && err_out) {
     berr = group_sum64<LPB>(berr);
     bssz = group_sum64<LPB>(bssz);
     if (live && lane == 0) block_err_store(err_out, bi, berr, bssz, err_shift);
@@ -389,13 +407,13 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
       last_c = qv ? c : last_c;
       A[rc] = qv;
       B[rc] = dqv;
-      if (err_out) block_err_acc(v, dqv, err_shift, berr, bssz);
+      if (AOMHIP_XQ_EXTRAS && err_out) block_err_acc(v, dqv, err_shift, berr, bssz);
     }
     if (last_c >= 0) my_eob = iscan_pos<KW, KH>(r, last_c, scan_class) + 1;
   }
   my_eob = group_max<LPB>(my_eob);
   if (live && lane == 0) eob[bi] = (uint16_t)my_eob;
-  if (err_out) {
+  if (AOMHIP_XQ_EXTRAS && err_out) {
     berr = group_sum64<LPB>(berr);
     bssz = group_sum64<LPB>(bssz);
     if (live && lane == 0) block_err_store(err_out, bi, berr, bssz, err_shift);
@@ -511,7 +529,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
     const int p0 = iscan_pos<W, H>(r, c, 0) + 1, p1 = iscan_pos<W, H>(r, c, 1) + 1, p2 = iscan_pos<W, H>(r, c, 2) + 1;
     const int p = scan_class == 0 ? p0 : (scan_class == 1 ? p1 : p2);
     my_eob = (qv[r][c] != 0 && p > my_eob) ? p : my_eob;
-    if (err_out) block_err_acc(v, dv[r][c], err_shift, berr, bssz);
+    if (AOMHIP_XQ_EXTRAS && err_out) block_err_acc(v, dv[r][c], err_shift, berr, bssz);
   };
   if constexpr (wht) {
     {  // av1_fwht4x4_c (hybrid_fwd_txfm.c:24-76) on the raw residual, UNIT_QUANT_FACTOR = 4
@@ -560,7 +578,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
     }
   }
   eob[bi] = (uint16_t)my_eob;
-  if (err_out) block_err_store(err_out, bi, berr, bssz, err_shift);
+  if (AOMHIP_XQ_EXTRAS && err_out) block_err_store(err_out, bi, berr, bssz, err_shift);
   // ---- store in the reference's transposed order (index c*H + r): column c is H contiguous values
 #pragma unroll
   for (int c = 0; c < W; ++c) {
@@ -760,7 +778,7 @@ static bool type_ok(int tx_size, int tx_type) {
   return kTxH[tx_size] <= vmax && kTxW[tx_size] <= hmax;
 }
 
-static QuantArgs to_args(const aomhip_quant_params *q) {
+static QuantArgs to_args(const aomhip_quant_params *q, int quant_kind = 0) {
   QuantArgs a;
   for (int i = 0; i < 2; ++i) {
     a.zbin[i] = q->zbin[i];
@@ -776,6 +794,7 @@ static QuantArgs to_args(const aomhip_quant_params *q) {
       a.qs_log2[i] = (int8_t)l;
     }
   }
+  if (quant_kind == 1) a.qs_log2[0] = a.qs_log2[1] = (int8_t)kQuantFp;
   return a;
 }
 
@@ -809,19 +828,20 @@ int aomhip_xform_quant_batch(aomhip_ctx *ctx, const int16_t *d_residual, int res
   return is_hbd ? dispatch_xq<true, 0>(tx_size, l) : dispatch_xq<false, 0>(tx_size, l);
 }
 
-int aomhip_xform_quant_dist_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int tx_size,
-                                  const aomhip_txb *d_blocks, int n_blocks, int grid_cols, int uniform_tx_type,
-                                  const aomhip_quant_params *qparams, int is_hbd, int bit_depth, int32_t *d_coeff,
-                                  int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob, int64_t *d_block_error) {
-  if (!ctx || !d_residual || !qparams || !d_qcoeff || !d_dqcoeff || !d_eob || !d_block_error || tx_size < 0 || tx_size >= 19 ||
+int aomhip_xform_quant_ex_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int tx_size,
+                                const aomhip_txb *d_blocks, int n_blocks, int grid_cols, int uniform_tx_type,
+                                const aomhip_quant_params *qparams, int is_hbd, int bit_depth, int quant_kind, int32_t *d_coeff,
+                                int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob, int64_t *d_block_error) {
+  if (!ctx || !d_residual || !qparams || !d_qcoeff || !d_dqcoeff || !d_eob || tx_size < 0 || tx_size >= 19 ||
       n_blocks < 0 || (!d_blocks && (grid_cols <= 0 || !type_ok(tx_size, uniform_tx_type))) ||
-      (uniform_tx_type == kTxWht && tx_size != 0) || (bit_depth != 8 && bit_depth != 10 && bit_depth != 12)) {
-    set_error("aomhip_xform_quant_dist_batch: invalid argument");
+      (uniform_tx_type == kTxWht && tx_size != 0) || (bit_depth != 8 && bit_depth != 10 && bit_depth != 12) ||
+      quant_kind < 0 || quant_kind > 1) {
+    set_error("aomhip_xform_quant_ex_batch: invalid argument");
     return AOMHIP_ERR_INVALID;
   }
   if (n_blocks == 0) return AOMHIP_OK;
   XqLaunch l{ ctx->stream, d_residual, nullptr, residual_stride, 0, d_blocks, n_blocks, grid_cols, uniform_tx_type,
-              to_args(qparams), d_coeff, d_qcoeff, d_dqcoeff, d_eob };
+              to_args(qparams, quant_kind), d_coeff, d_qcoeff, d_dqcoeff, d_eob };
   l.err_out = d_block_error;
   l.err_shift = is_hbd ? 2 * (bit_depth - 8) : -1;   // the highbd form when the buffers are high bit depth (tx_search.c)
   return is_hbd ? dispatch_xq<true, 0>(tx_size, l) : dispatch_xq<false, 0>(tx_size, l);

@@ -247,16 +247,23 @@ int aomhip_xform_quant_batch(aomhip_ctx *ctx, const int16_t *d_residual, int res
 /* Same with aom_subtract_block / aom_highbd_subtract_block (aom_dsp/subtract.c:20-53) fused in
  * front: residual = src - pred of frame `frame`, block positions relative to the visible origin.
  * 8-bit planes use aom_quantize_b*, 10/12-bit planes aom_highbd_quantize_b* (encodemb.c:323). */
-/* aomhip_xform_quant_batch fused with the transform-domain distortion the RD search takes right after it
- * (dist_block_tx_domain, av1/encoder/tx_search.c: av1_block_error / av1_highbd_block_error over av1_get_max_eob
- * coefficients, av1/encoder/rdopt.c:635-682): d_block_error[2 * i] = sum (coeff - dqcoeff)^2, [2 * i + 1] = ssz = sum
- * coeff^2 of block i -- the low-bd form when !is_hbd (32-bit products, as the compiled reference), else the highbd form
- * rounded by 2 * (bit_depth - 8) bits.  The caller applies its own tx-scale shift.  The coefficients never travel back
- * through HBM for the distortion pass. */
-int aomhip_xform_quant_dist_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int tx_size,
-                                  const aomhip_txb *d_blocks, int n_blocks, int grid_cols, int uniform_tx_type,
-                                  const aomhip_quant_params *qparams, int is_hbd, int bit_depth, int32_t *d_coeff,
-                                  int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob, int64_t *d_block_error);
+/* aomhip_xform_quant_batch with the two things av1_xform_quant's callers choose per call (av1/encoder/encodemb.c:288-341):
+ *   quant_kind     AOMHIP_QUANT_B = aom_[highbd_]quantize_b (xform_quant_idx AV1_XFORM_QUANT_B); AOMHIP_QUANT_FP =
+ *                  av1_[highbd_]quantize_fp{,_32x32,_64x64} (AV1_XFORM_QUANT_FP, the flavour used ahead of trellis
+ *                  optimisation; av1/encoder/av1_quantize.c:36-69,181-300): qparams then carries round_fp / quant_fp in
+ *                  its round / quant fields (zbin and quant_shift are not read)
+ *   d_block_error  NULL, or 2 int64 per block: the transform-domain distortion the RD search takes right after the
+ *                  transform (dist_block_tx_domain, tx_search.c -> av1_block_error / av1_highbd_block_error over
+ *                  av1_get_max_eob coefficients, av1/encoder/rdopt.c:635-682): [2 i] = sum (coeff - dqcoeff)^2,
+ *                  [2 i + 1] = ssz = sum coeff^2 -- the low-bd form when !is_hbd (32-bit products, as the compiled
+ *                  reference), else the highbd form rounded by 2 * (bit_depth - 8) bits.  The caller applies its own
+ *                  tx-scale shift.  The coefficients never travel back through HBM for the distortion pass. */
+#define AOMHIP_QUANT_B 0
+#define AOMHIP_QUANT_FP 1
+int aomhip_xform_quant_ex_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int tx_size,
+                                const aomhip_txb *d_blocks, int n_blocks, int grid_cols, int uniform_tx_type,
+                                const aomhip_quant_params *qparams, int is_hbd, int bit_depth, int quant_kind, int32_t *d_coeff,
+                                int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob, int64_t *d_block_error);
 int aomhip_subtract_xform_quant_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *pred, int frame,
                                       int tx_size, const aomhip_txb *d_blocks, int n_blocks, int grid_cols,
                                       int uniform_tx_type, const aomhip_quant_params *qparams, int32_t *d_coeff,

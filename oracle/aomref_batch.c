@@ -61,6 +61,12 @@ void orc_sad_x4d_batch(const void *src_origin, int src_stride, const void *ref_o
 /* ---- av1_xform_quant over a block list (aomhip_xform_quant_batch's checker / CPU baseline) ---- */
 typedef struct { int32_t x, y; uint32_t out_offset; uint8_t tx_type; uint8_t reserved[3]; } orc_txb; /* == aomhip_txb */
 
+void orc_quantize_fp(const int32_t *coeff, intptr_t n, const int16_t *round_fp, const int16_t *quant_fp, int32_t *qcoeff,
+                     int32_t *dqcoeff, const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale,
+                     int highbd);
+static int g_quant_kind = 0; /* 0 quantize_b, 1 quantize_fp: set by orc_xform_quant_set_kind (tests only, single-threaded setup) */
+void orc_xform_quant_set_kind(int kind) { g_quant_kind = kind; }
+
 void orc_xform_quant_batch(const int16_t *residual, int stride, int tx_size, const orc_txb *blocks, int n,
                            int grid_cols, int uniform_type, const int16_t q[5][2], int is_hbd, int32_t *coeff,
                            int32_t *qcoeff, int32_t *dqcoeff, uint16_t *eob, int threads, int reps) {
@@ -85,7 +91,9 @@ void orc_xform_quant_batch(const int16_t *residual, int stride, int tx_size, con
     if (tt == ORC_TX_WHT) orc_fwht4x4(residual + (ptrdiff_t)by * stride + bx, full, stride);
     else orc_fwd_txfm2d(residual + (ptrdiff_t)by * stride + bx, full, stride, tx_size, tt, is_hbd ? 10 : 8);
     if (coeff) for (int k = 0; k < nc; ++k) coeff[off + k] = full[k];
-    if (is_hbd)
+    if (g_quant_kind == 1)
+      orc_quantize_fp(full, nc, q[1], q[2], qcoeff + off, dqcoeff + off, q[4], &eob[i], scans[tt], log_scale, is_hbd);
+    else if (is_hbd)
       orc_highbd_quantize_b(full, nc, q[0], q[1], q[2], q[3], qcoeff + off, dqcoeff + off, q[4], &eob[i], scans[tt],
                             iscans[tt], log_scale);
     else

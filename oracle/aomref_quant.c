@@ -238,3 +238,33 @@ int64_t orc_block_error(const int32_t *coeff, const int32_t *dqcoeff, intptr_t n
   *ssz = sq;
   return error;
 }
+
+/* av1_quantize_fp_no_qmatrix (av1/encoder/av1_quantize.c:36-69, behind av1_quantize_fp{,_32x32,_64x64}_c) and
+ * highbd_quantize_fp_helper_c without matrices (:181-207, behind av1_highbd_quantize_fp_c).  round / quant are the
+ * caller's round_fp / quant_fp tables. */
+void orc_quantize_fp(const int32_t *coeff, intptr_t n, const int16_t *round_fp, const int16_t *quant_fp, int32_t *qcoeff,
+                     int32_t *dqcoeff, const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale,
+                     int highbd) {
+  const int rounding[2] = { (round_fp[0] + ((1 << log_scale) >> 1)) >> log_scale, (round_fp[1] + ((1 << log_scale) >> 1)) >> log_scale };
+  int eob = 0;
+  memset(qcoeff, 0, (size_t)n * sizeof(*qcoeff));
+  memset(dqcoeff, 0, (size_t)n * sizeof(*dqcoeff));
+  for (intptr_t i = 0; i < n; ++i) {
+    const int rc = scan[i], ac = rc != 0;
+    const int c = coeff[rc], sign = c < 0 ? -1 : 0;
+    int64_t a = (int64_t)((c ^ sign) - sign);
+    int q = 0;
+    if ((a << (1 + log_scale)) >= dequant[ac]) {
+      a += rounding[ac];
+      if (!highbd && a > INT16_MAX) a = INT16_MAX;
+      q = (int)((a * quant_fp[ac]) >> (16 - log_scale));
+      if (q) {
+        qcoeff[rc] = (q ^ sign) - sign;
+        const int32_t adq = (int32_t)((uint32_t)q * (uint32_t)dequant[ac]) >> log_scale;
+        dqcoeff[rc] = (adq ^ sign) - sign;
+      }
+    }
+    if (q) eob = (int)i + 1;
+  }
+  *eob_out = (uint16_t)eob;
+}

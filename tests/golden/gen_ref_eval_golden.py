@@ -119,6 +119,28 @@ def gen_quant():
             row += [e, ssz.buf[0]]
         berr.append(row)
     arrays["block_error"] = np.asarray(berr, np.int64)
+    # av1_quantize_fp{,_32x32,_64x64}_c and av1_highbd_quantize_fp_c (av1/encoder/av1_quantize.c) on the coefficient vectors of
+    # every 5th case above; round_fp / quant_fp as av1_build_quantizer derives them from the dequantiser
+    ev3 = evaluator(["aom_dsp/quantize.h", "av1/common/quant_common.h", "av1/encoder/av1_quantize.h", "av1/encoder/av1_quantize.c"])
+    fp_rows = []
+    for kk in range(0, k, 5):
+        c0 = cases[kk]
+        n, ls, hbd = c0["n"], c0["log_scale"], c0["hbd"]
+        scan, iscan = orc.get_scan(c0["tx_size"], c0["tx_type"])
+        dq2 = c0["tables"]["dequant"]
+        rfp, qfp = [(64 * d) >> 7 for d in dq2], [(1 << 16) // d for d in dq2]
+        c = arrays["c%d" % kk]
+        qc, dqc, eob = ev3.array([0x55] * n, "int32_t"), ev3.array([0x55] * n, "int32_t"), ev3.array([77], "uint16_t")
+        t = {m: ev3.array(c0["tables"][m], "int16_t") for m in c0["tables"]}
+        args = [ev3.array(c, "int32_t"), n, t["zbin"], ev3.array(rfp, "int16_t"), ev3.array(qfp, "int16_t"), t["quant_shift"], qc, dqc,
+                t["dequant"], eob, ev3.array(scan, "int16_t"), ev3.array(iscan, "int16_t")]
+        if hbd:
+            ev3.call("av1_highbd_quantize_fp_c", *args, ls)
+        else:
+            ev3.call("av1_quantize_fp%s_c" % {0: "", 1: "_32x32", 2: "_64x64"}[ls], *args)
+        arrays["fq%d" % kk], arrays["fd%d" % kk] = np.asarray(qc.buf, np.int32), np.asarray(dqc.buf, np.int32)
+        fp_rows.append([kk, int(eob.buf[0]), rfp[0], rfp[1], qfp[0], qfp[1]])
+    arrays["quantize_fp"] = np.asarray(fp_rows, np.int64)
     save("ref_eval_quant.npz", arrays, cases)
 
 

@@ -51,6 +51,26 @@ def test_block_error_matches_reference_evaluation(oracle):
             assert (e, ssz.value) == (int(row[1 + 2 * j]), int(row[2 + 2 * j])), (kk, bd)
 
 
+def test_quantize_fp_matches_reference_evaluation(oracle):
+    z, cases = load("ref_eval_quant.npz")
+    f = oracle.lib.orc_quantize_fp
+    f.restype = None
+    rows = z["quantize_fp"]
+    assert len(rows) >= 130
+    for kk, eob, r0, r1, q0, q1 in rows.tolist():
+        c = cases[kk]
+        coeff = np.ascontiguousarray(z["c%d" % kk], np.int32)
+        scan, _ = oracle.get_scan(c["tx_size"], c["tx_type"])
+        scan = np.ascontiguousarray(scan, np.int16)
+        rfp, qfp, deq = np.asarray([r0, r1], np.int16), np.asarray([q0, q1], np.int16), np.asarray(c["tables"]["dequant"], np.int16)
+        qc, dq = np.zeros_like(coeff), np.zeros_like(coeff)
+        e = C.c_uint16()
+        f(C.c_void_p(coeff.ctypes.data), C.c_ssize_t(coeff.size), C.c_void_p(rfp.ctypes.data), C.c_void_p(qfp.ctypes.data),
+          C.c_void_p(qc.ctypes.data), C.c_void_p(dq.ctypes.data), C.c_void_p(deq.ctypes.data), C.byref(e), C.c_void_p(scan.ctypes.data),
+          c["log_scale"], c["hbd"])
+        assert e.value == eob and np.array_equal(qc, z["fq%d" % kk]) and np.array_equal(dq, z["fd%d" % kk]), (kk, c["fn"])
+
+
 def test_lpf_matches_reference_evaluation(oracle):
     z, cases = load("ref_eval_lpf.npz")
     assert len(cases) >= 700

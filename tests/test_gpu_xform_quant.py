@@ -229,7 +229,7 @@ def test_adaptive_quantiser(hip, oracle, ctx, hbd):
 @pytest.mark.parametrize("is_hbd,bit_depth", [(False, 8), (True, 8), (True, 10), (True, 12)])
 @pytest.mark.parametrize("tx_size", [0, 1, 2, 3, 4, 6, 9, 13, 18])
 def test_fused_block_error(hip, oracle, ctx, tx_size, is_hbd, bit_depth):
-    """aomhip_xform_quant_dist_batch: the same coefficients / levels as aomhip_xform_quant_batch plus av1_block_error /
+    """aomhip_xform_quant_ex_batch with d_block_error: the same coefficients / levels as aomhip_xform_quant_batch plus av1_block_error /
     av1_highbd_block_error (rdopt.c:635-682) of every block, against the oracle's restatement (itself pinned against the
     interpreted reference, tests/test_golden_ref_eval.py)."""
     import ctypes as C
@@ -247,7 +247,7 @@ def test_fused_block_error(hip, oracle, ctx, tx_size, is_hbd, bit_depth):
     d_res, d_blk = ctx.to_device(residual), ctx.to_device(blocks)
     d_c, d_q, d_dq, d_e, d_err = ctx.malloc(total * 4), ctx.malloc(total * 4), ctx.malloc(total * 4), ctx.malloc(max(2 * n, 16)), ctx.malloc(16 * n)
     qp = hip.capi.QuantParams.from_tables(q)
-    ctx.xform_quant_dist_batch(d_res, W, tx_size, d_blk, n, 0, 0, qp, is_hbd, bit_depth, d_c, d_q, d_dq, d_e, d_err)
+    ctx.xform_quant_ex_batch(d_res, W, tx_size, d_blk, n, 0, 0, qp, is_hbd, bit_depth, 0, d_c, d_q, d_dq, d_e, d_err)
     coeff, dq = ctx.from_device(d_c, (total,), np.int32), ctx.from_device(d_dq, (total,), np.int32)
     err = ctx.from_device(d_err, (n, 2), np.int64)
     want = oracle.xform_quant_batch(residual, tx_size, blocks, n, 0, 0, q, is_hbd, total, True, threads=4)
@@ -262,3 +262,46 @@ def test_fused_block_error(hip, oracle, ctx, tx_size, is_hbd, bit_depth):
         assert (int(err[i, 0]), int(err[i, 1])) == (e, ssz.value), (tx_size, i)
     for d in (d_res, d_blk, d_c, d_q, d_dq, d_e, d_err):
         ctx.free(d)
+
+
+@pytest.mark.parametrize("is_hbd", [False, True])
+@pytest.mark.parametrize("tx_size", [0, 1, 2, 3, 4, 5, 10, 14, 17])
+def test_quantize_fp_flavour(hip, oracle, ctx, tx_size, is_hbd):
+    """AOMHIP_QUANT_FP: av1_[highbd_]quantize_fp{,_32x32,_64x64} fused behind the transform, with the block error."""
+    w, h = oracle.TX_W[tx_size], oracle.TX_H[tx_size]
+    types = [t for t in range(16) if oracle.lib.orc_txfm_valid(tx_size, t)]
+    rng = np.random.default_rng(tx_size * 11 + is_hbd)
+    W, H = 192, 160
+    nc = hip.capi.lib.aomhip_tx_max_eob(tx_size)
+    bits = 11 if is_hbd else 9
+    residual = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), (H, W)).astype(np.int16)
+    n = 157 if w * h <= 256 else 37
+    blocks = _blocks(hip, rng, W, H, w, h, n, types, nc)
+    total = int(blocks["out_offset"].max()) + nc
+    for qindex in (0, 40, 130, 255):
+        q = oracle.build_quantizer_y(10 if is_hbd else 8, qindex)
+        dq = q["dequant"].astype(np.int64)
+        qfp = dict(q, round=((64 * dq) >> 7).astype(np.int16), quant=((1 << 16) // dq).astype(np.int16))   # y_round_fp / y_quant_fp
+        d_res, d_blk = ctx.to_device(residual), ctx.to_device(blocks)
+        d_c, d_q, d_dq, d_e = ctx.malloc(total * 4), ctx.malloc(total * 4), ctx.malloc(total * 4), ctx.malloc(max(2 * n, 16))
+        for d in (d_q, d_dq):
+            hip.capi.check(hip.capi.lib.aomhip_memset(ctx.h, d, 0x5A, total * 4))
+        ctx.xform_quant_ex_batch(d_res, W, tx_size, d_blk, n, 0, 0, hip.capi.QuantParams.from_tables(qfp), is_hbd, 10 if is_hbd else 8, 1,
+                                 d_c, d_q, d_dq, d_e, None)
+        got = (ctx.from_device(d_c, (total,), np.int32), ctx.from_device(d_q, (total,), np.int32), ctx.from_device(d_dq, (total,), np.int32),
+               ctx.from_device(d_e, (n,), np.uint16))
+        oracle.lib.orc_xform_quant_set_kind(1)
+        try:
+            want = oracle.xform_quant_batch(residual, tx_size, blocks, n, 0, 0, qfp, is_hbd, total, True, threads=1)
+        finally:
+            oracle.lib.orc_xform_quant_set_kind(0)
+        used = np.zeros(total, bool)
+        for off in blocks["out_offset"]:
+            used[int(off):int(off) + nc] = True
+        for g, wv, name in zip(got, want, ("coeff", "qcoeff", "dqcoeff", "eob")):
+            if name == "eob":
+                assert np.array_equal(g, wv), (tx_size, is_hbd, qindex, name)
+            else:
+                assert np.array_equal(g[used], wv[used]), (tx_size, is_hbd, qindex, name)
+        for d in (d_res, d_blk, d_c, d_q, d_dq, d_e):
+            ctx.free(d)
