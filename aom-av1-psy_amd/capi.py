@@ -128,6 +128,7 @@ _protos = {
     "aomhip_tx_max_eob": (C.c_int, [_i]),
     "aomhip_xform_quant_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _i, C.POINTER(QuantParams), _i, _vp, _vp,
                                            _vp, _vp]),
+    "aomhip_subtract_xform_quant_ex_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_xform_quant_ex_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_subtract_xform_quant_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _vp, _i, _i, _i, C.POINTER(QuantParams),
                                                     _vp, _vp, _vp, _vp]),
@@ -279,6 +280,12 @@ class Context:
                              d_q, d_dq, d_eob, d_err=None):
         check(lib.aomhip_xform_quant_ex_batch(self.h, d_res, stride, tx_size, d_blocks, n, grid_cols, tx_type, C.byref(qp), int(is_hbd),
                                               bit_depth, quant_kind, d_coeff, d_q, d_dq, d_eob, d_err), "aomhip_xform_quant_ex_batch")
+
+    def subtract_xform_quant_ex_batch(self, src, pred, frame, tx_size, d_blocks, n, grid_cols, tx_type, qp, quant_kind, d_coeff, d_q, d_dq,
+                                      d_eob, d_err=None):
+        check(lib.aomhip_subtract_xform_quant_ex_batch(self.h, C.byref(src), C.byref(pred), frame, tx_size, d_blocks, n, grid_cols, tx_type,
+                                                       C.byref(qp), quant_kind, d_coeff, d_q, d_dq, d_eob, d_err),
+              "aomhip_subtract_xform_quant_ex_batch")
 
     def quantize_b_adaptive_batch(self, d_coeff, tx_size, d_blocks, n_blocks, tx_type, qp, is_hbd, d_qcoeff, d_dqcoeff, d_eob):
         check(lib.aomhip_quantize_b_adaptive_batch(self.h, d_coeff, tx_size, d_blocks, n_blocks, tx_type, C.byref(qp),

@@ -847,15 +847,17 @@ int aomhip_xform_quant_ex_batch(aomhip_ctx *ctx, const int16_t *d_residual, int 
   return is_hbd ? dispatch_xq<true, 0>(tx_size, l) : dispatch_xq<false, 0>(tx_size, l);
 }
 
-int aomhip_subtract_xform_quant_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *pred, int frame,
-                                      int tx_size, const aomhip_txb *d_blocks, int n_blocks, int grid_cols,
-                                      int uniform_tx_type, const aomhip_quant_params *qparams, int32_t *d_coeff,
-                                      int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
+int aomhip_subtract_xform_quant_ex_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *pred, int frame,
+                                         int tx_size, const aomhip_txb *d_blocks, int n_blocks, int grid_cols,
+                                         int uniform_tx_type, const aomhip_quant_params *qparams, int quant_kind,
+                                         int32_t *d_coeff, int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob,
+                                         int64_t *d_block_error) {
   if (!ctx || !src || !pred || !src->base || !pred->base || !qparams || !d_qcoeff || !d_dqcoeff || !d_eob ||
       tx_size < 0 || tx_size >= 19 || n_blocks < 0 || frame < 0 || frame >= src->n_frames ||
       frame >= pred->n_frames || (src->bit_depth == 8) != (pred->bit_depth == 8) ||
-      (!d_blocks && (grid_cols <= 0 || !type_ok(tx_size, uniform_tx_type)))) {
-    set_error("aomhip_subtract_xform_quant_batch: invalid argument");
+      (!d_blocks && (grid_cols <= 0 || !type_ok(tx_size, uniform_tx_type))) || quant_kind < 0 || quant_kind > 1 ||
+      (uniform_tx_type == kTxWht && tx_size != 0)) {
+    set_error("aomhip_subtract_xform_quant_ex_batch: invalid argument");
     return AOMHIP_ERR_INVALID;
   }
   if (n_blocks == 0) return AOMHIP_OK;
@@ -865,9 +867,19 @@ int aomhip_subtract_xform_quant_batch(aomhip_ctx *ctx, const aomhip_planes *src,
   const char *p = static_cast<const char *>(pred->base) +
                   ((size_t)frame * pred->frame_stride + (size_t)pred->border * pred->stride + pred->border) * esz;
   XqLaunch l{ ctx->stream, s, p, src->stride, pred->stride, d_blocks, n_blocks, grid_cols, uniform_tx_type,
-              to_args(qparams), d_coeff, d_qcoeff, d_dqcoeff, d_eob };
+              to_args(qparams, quant_kind), d_coeff, d_qcoeff, d_dqcoeff, d_eob };
+  l.err_out = d_block_error;
+  l.err_shift = src->bit_depth == 8 ? -1 : 2 * (src->bit_depth - 8);
   // encodemb.c:323: the quantiser flavour follows the bit depth of the planes
   return src->bit_depth == 8 ? dispatch_xq<false, 1>(tx_size, l) : dispatch_xq<true, 2>(tx_size, l);
+}
+
+int aomhip_subtract_xform_quant_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *pred, int frame,
+                                      int tx_size, const aomhip_txb *d_blocks, int n_blocks, int grid_cols,
+                                      int uniform_tx_type, const aomhip_quant_params *qparams, int32_t *d_coeff,
+                                      int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
+  return aomhip_subtract_xform_quant_ex_batch(ctx, src, pred, frame, tx_size, d_blocks, n_blocks, grid_cols, uniform_tx_type,
+                                              qparams, 0, d_coeff, d_qcoeff, d_dqcoeff, d_eob, nullptr);
 }
 
 int aomhip_quantize_b_adaptive_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks,

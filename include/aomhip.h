@@ -268,6 +268,13 @@ int aomhip_subtract_xform_quant_batch(aomhip_ctx *ctx, const aomhip_planes *src,
                                       int tx_size, const aomhip_txb *d_blocks, int n_blocks, int grid_cols,
                                       int uniform_tx_type, const aomhip_quant_params *qparams, int32_t *d_coeff,
                                       int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);
+/* the same with quant_kind and the optional block error of aomhip_xform_quant_ex_batch (the error form follows the planes'
+ * bit depth) */
+int aomhip_subtract_xform_quant_ex_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *pred, int frame,
+                                         int tx_size, const aomhip_txb *d_blocks, int n_blocks, int grid_cols,
+                                         int uniform_tx_type, const aomhip_quant_params *qparams, int quant_kind,
+                                         int32_t *d_coeff, int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob,
+                                         int64_t *d_block_error);
 
 /* The adaptive quantiser (qparam->use_quant_b_adapt, av1/encoder/av1_quantize.c:309-341,453-):
  * aom_quantize_b_adaptive_helper_c / aom_highbd_quantize_b_adaptive_helper_c (aom_dsp/quantize.c:16-105,173-258;

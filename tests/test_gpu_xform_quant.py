@@ -2,6 +2,8 @@
 the C ABI: all 19 transform sizes x every servable TX_TYPE, low-bd and high-bd quantisers, list
 mode / grid mode / fused-subtract mode, qindex sweep, extreme inputs (mirrors
 test/av1_fwd_txfm2d_test.cc:243-297 input classes and test/quantize_func_test.cc:202-259)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -134,7 +136,21 @@ def test_fused_subtract(hip, oracle, ctx, bd):
         assert np.array_equal(ctx.from_device(d_q, (n * nc,), np.int32), wq)
         assert np.array_equal(ctx.from_device(d_dq, (n * nc,), np.int32), wdq)
         assert np.array_equal(ctx.from_device(d_e, (n,), np.uint16), we)
-        for d in (d_blk, d_c, d_q, d_dq, d_e):
+        # the _ex form: same levels plus av1_block_error / av1_highbd_block_error per block (rdopt.c:635-682)
+        d_err = ctx.malloc(16 * n)
+        ctx.subtract_xform_quant_ex_batch(ps, pp, 1, tx_size, d_blk, n, 0, 0, hip.capi.QuantParams.from_tables(q), 0, d_c, d_q, d_dq,
+                                          d_e, d_err)
+        assert np.array_equal(ctx.from_device(d_q, (n * nc,), np.int32), wq)
+        err = ctx.from_device(d_err, (n, 2), np.int64)
+        f = oracle.lib.orc_block_error
+        f.restype = C.c_int64
+        for i in range(n):
+            off = int(blocks["out_offset"][i])
+            c, d = np.ascontiguousarray(wc[off:off + nc]), np.ascontiguousarray(wdq[off:off + nc])
+            ssz = C.c_int64()
+            e = f(C.c_void_p(c.ctypes.data), C.c_void_p(d.ctypes.data), C.c_ssize_t(nc), C.byref(ssz), bd if bd > 8 else 0)
+            assert (int(err[i, 0]), int(err[i, 1])) == (e, ssz.value), (tx_size, i)
+        for d in (d_blk, d_c, d_q, d_dq, d_e, d_err):
             ctx.free(d)
     ctx.planes_free(ps); ctx.planes_free(pp)
 
