@@ -79,6 +79,15 @@ sad_cand_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2"), ("ry", "
 search_block_dtype = np.dtype([(n, "<i2") for n in ("bx", "by", "start_row", "start_col", "ref_row", "ref_col", "row_min",
                                                     "row_max", "col_min", "col_max")])
 MV_COST_L1_LOWRES, MV_COST_L1_MIDRES, MV_COST_L1_HDRES, MV_COST_NONE = 1, 2, 3, 4
+COMP_AVG, COMP_DIST_WTD, COMP_MASK, COMP_OBMC = 0, 1, 2, 3
+
+
+class CompoundParams(C.Structure):
+    """aomhip_compound_params (include/aomhip.h)."""
+    _fields_ = [("kind", C.c_int32), ("subpel", C.c_int32), ("fwd_offset", C.c_int32), ("bck_offset", C.c_int32),
+                ("mask_stride", C.c_int32), ("invert_mask", C.c_int32)]
+
+
 var_cand_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2"), ("ry", "<i2"), ("xoff", "u1"), ("yoff", "u1"),
                            ("reserved", "u1", (2,))])
 sad_x4d_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2", (4,)), ("ry", "<i2", (4,))])
@@ -110,6 +119,8 @@ _protos = {
     "aomhip_sad_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
     "aomhip_sad_x4d_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
     "aomhip_sad_avg_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp, _i, _i, _vp]),
+    "aomhip_compound_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aomhip_compound": (C.c_uint, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(C.c_uint)]),
     "aomhip_sad_sb_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp,
                                       _i, _i64, _vp]),
     "aomhip_variance_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp]),
@@ -268,6 +279,13 @@ class Context:
         check(lib.aomhip_sad_avg_batch(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, bw, bh, d_cands, n_cands,
                                        cand_frame_stride, d_second_pred, d_pred_index, fwd_offset, bck_offset, d_out),
               "aomhip_sad_avg_batch")
+
+    def compound_batch(self, src, ref, first_frame, n_frames, bw, bh, d_cands, n_cands, cand_frame_stride, params, d_second_pred=None,
+                       d_mask=None, d_obmc_wsrc=None, d_obmc_mask=None, d_pred_index=None, d_mask_offset=None, d_var=None, d_sse=None,
+                       d_sad=None):
+        check(lib.aomhip_compound_batch(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, bw, bh, d_cands, n_cands,
+                                        cand_frame_stride, C.byref(params), d_second_pred, d_mask, d_obmc_wsrc, d_obmc_mask, d_pred_index,
+                                        d_mask_offset, d_var, d_sse, d_sad), "aomhip_compound_batch")
 
     def sad_sb_batch(self, src, ref, first_frame, n_frames, bw, bh, flags, sb_w, sb_h, rng, n_buckets, d_groups=None,
                      d_group_off=None, n_groups=0, group_frame_stride=0, d_out_groups=None, d_cands=None, d_cand_off=None,

@@ -200,6 +200,49 @@ int aomhip_sub_pixel_variance_batch(aomhip_ctx *ctx, const aomhip_planes *src, c
                                     int first_frame, int n_frames, int bw, int bh, const aomhip_var_cand *d_cands,
                                     int n_cands, int64_t cand_frame_stride, uint32_t *d_var, uint32_t *d_sse);
 
+/* ------------------------------------------------------------------ compound / masked / OBMC table members
+ * The remaining members of aom_variance_fn_ptr_t (aom_dsp/variance.h:84-103) as ONE batched call: per candidate the
+ * reference block at (rx, ry) is [subpel: bilinearly interpolated at (xoff, yoff) / 8 first, variance.c:91-139]
+ * blended with a second predictor and compared with the source block at (sx, sy):
+ *   AOMHIP_COMP_AVG       (pred + ref + 1) >> 1                  svaf: aom_[highbd_N_]sub_pixel_avg_varianceWxH  (variance.c:165-182,563-622)
+ *                                                                sdaf: aom_[highbd_]sadWxH_avg                    (sad.c:50-56)
+ *   AOMHIP_COMP_DIST_WTD  (pred * bck + ref * fwd + 8) >> 4      jsvaf / jsdaf: the dist_wtd forms               (variance.c:183-200,321-339,624-690)
+ *   AOMHIP_COMP_MASK      AOM_BLEND_A64(mask, ref, pred)         msvf: aom_[highbd_N_]masked_sub_pixel_variance  (variance.c:773-811,840-928)
+ *                         (invert_mask swaps ref and pred)       msdf: aom_[highbd_]masked_sad                   (sad_av1.c:20-52)
+ *   AOMHIP_COMP_OBMC      ROUND_POWER_OF_TWO_SIGNED(wsrc - ref * mask, 12) against nothing else: ovf / osvf
+ *                         aom_[highbd_N_]obmc_[sub_pixel_]variance (variance.c:957-1000,1064-1192), osdf aom_[highbd_]obmc_sad
+ *                         (sad_av1.c:163-186,215-239); the source plane and (sx, sy) are not read.
+ * Outputs (any may be NULL, not all): d_var / d_sse with the final formulas of the planes' bit depth (8-bit, or the
+ * highbd 8 / 10 / 12 families), d_sad with the encoder's _bits10 / _bits12 shifts (encoder_utils.h:210-262,363-387,
+ * 527-542) -- all indexed [f_rel * n_cands + i].
+ *   d_second_pred   bw*bh-contiguous blocks of the planes' pixel type; d_obmc_wsrc / d_obmc_mask: bw*bh-contiguous int32 blocks
+ *   d_pred_index    [f_rel * n_cands + i] -> block number in d_second_pred (or in the two OBMC buffers); NULL = block 0
+ *   d_mask          0..64 weights, row stride mask_stride; d_mask_offset[f_rel * n_cands + i] = byte offset of the candidate's
+ *                   mask (e.g. into a wedge master table, av1/common/reconinter.c); NULL = 0 */
+#define AOMHIP_COMP_AVG 0
+#define AOMHIP_COMP_DIST_WTD 1
+#define AOMHIP_COMP_MASK 2
+#define AOMHIP_COMP_OBMC 3
+typedef struct aomhip_compound_params {
+  int32_t kind;                    /* AOMHIP_COMP_* */
+  int32_t subpel;                  /* 1: run the two bilinear passes with the candidate's xoff / yoff (also for offset 0, like the reference) */
+  int32_t fwd_offset, bck_offset;  /* DIST_WTD_COMP_PARAMS (av1/common/blockd.h:558-562); sum 16 */
+  int32_t mask_stride, invert_mask;
+} aomhip_compound_params;
+int aomhip_compound_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame, int n_frames, int bw,
+                          int bh, const aomhip_var_cand *d_cands, int n_cands, int64_t cand_frame_stride,
+                          const aomhip_compound_params *p, const void *d_second_pred, const uint8_t *d_mask, const int32_t *d_obmc_wsrc,
+                          const int32_t *d_obmc_mask, const uint32_t *d_pred_index, const uint32_t *d_mask_offset, uint32_t *d_var,
+                          uint32_t *d_sse, uint32_t *d_sad);
+/* The same on host pointers with the operand roles of the reference's signatures (one launch per call; what the
+ * vtable entries forward to): `a` is interpolated / blended, `b` is the block it is compared with (NULL for OBMC);
+ * is_hbd: a, b, second_pred are CONVERT_TO_BYTEPTR-encoded uint16_t pointers and bd selects the 8 / 10 / 12 family.
+ * Returns the variance (want_sad 0, *sse filled when non-NULL) or the SAD (want_sad 1). */
+unsigned int aomhip_compound(const aomhip_compound_params *p, const uint8_t *a, int a_stride, int xoffset, int yoffset, const uint8_t *b,
+                             int b_stride, const uint8_t *second_pred, const uint8_t *mask, const int32_t *obmc_wsrc,
+                             const int32_t *obmc_mask, int bw, int bh, int bd, int is_hbd, int want_sad, unsigned int *sse);
+
+
 /* ------------------------------------------------------------------ batched forward transform + quantise */
 
 /* One transform block of a batch (all blocks of a call share one TX_SIZE). */
@@ -482,15 +525,28 @@ typedef struct aomhip_variance_vtable {
   unsigned int (*vf)(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, unsigned int *sse);
   unsigned int (*svf)(const uint8_t *a, int a_stride, int xoffset, int yoffset, const uint8_t *b, int b_stride,
                       unsigned int *sse);
-  void *svaf;
+  unsigned int (*svaf)(const uint8_t *a, int a_stride, int xoffset, int yoffset, const uint8_t *b, int b_stride, unsigned int *sse,
+                       const uint8_t *second_pred);
   void (*sdx4df)(const uint8_t *a, int a_stride, const uint8_t *const b_array[], int b_stride, unsigned int *sad_array);
   void (*sdx3df)(const uint8_t *a, int a_stride, const uint8_t *const b_array[], int b_stride, unsigned int *sad_array);
   void (*sdsx4df)(const uint8_t *a, int a_stride, const uint8_t *const b_array[], int b_stride,
                   unsigned int *sad_array);
-  void *msdf, *msvf, *osdf, *ovf, *osvf, *jsdaf, *jsvaf; /* compound / masked / OBMC entries: left untouched */
+  unsigned int (*msdf)(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, const uint8_t *second_pred,
+                       const uint8_t *msk, int msk_stride, int invert_mask);
+  unsigned int (*msvf)(const uint8_t *src, int src_stride, int xoffset, int yoffset, const uint8_t *ref, int ref_stride,
+                       const uint8_t *second_pred, const uint8_t *msk, int msk_stride, int invert_mask, unsigned int *sse);
+  unsigned int (*osdf)(const uint8_t *pred, int pred_stride, const int32_t *wsrc, const int32_t *msk);
+  unsigned int (*ovf)(const uint8_t *pred, int pred_stride, const int32_t *wsrc, const int32_t *msk, unsigned int *sse);
+  unsigned int (*osvf)(const uint8_t *pred, int pred_stride, int xoffset, int yoffset, const int32_t *wsrc, const int32_t *msk,
+                       unsigned int *sse);
+  /* jcp_param: the reference's DIST_WTD_COMP_PARAMS { int use_dist_wtd_comp_avg, fwd_offset, bck_offset } (blockd.h:558-562) */
+  unsigned int (*jsdaf)(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, const uint8_t *second_pred,
+                        const void *jcp_param);
+  unsigned int (*jsvaf)(const uint8_t *a, int a_stride, int xoffset, int yoffset, const uint8_t *b, int b_stride, unsigned int *sse,
+                        const uint8_t *second_pred, const void *jcp_param);
 } aomhip_variance_vtable;
 
-/* Overwrites sdf, sdsf (8-bit), vf, svf, sdx4df, sdx3df, sdsx4df (8-bit) of the 22 entries (BLOCK_SIZE order,
+/* Overwrites all 16 members (sdsf / sdsx4df: 8-bit tables only) of the 22 entries (BLOCK_SIZE order,
  * av1/common/enums.h:99-124) with GPU-backed functions of the reference's exact signatures -- what a
  * maintainer calls right after av1_create_primary_compressor fills ppi->fn_ptr (av1/encoder/encoder.c:986-1226;
  * highbd: encoder_utils.h:130-139,572-, the _bits10 / _bits12 SAD wrappers are folded in).  Every other

@@ -97,6 +97,51 @@ def sad_avg_batch(src_b, ref_b, border, w, h, cands, preds, pred_index, fwd_offs
     return out
 
 
+def compound_batch(src_b, ref_b, border, w, h, cands, kind, subpel, bd=8, preds=None, pred_index=None, fwd_offset=0, bck_offset=0,
+                   masks=None, mask_stride=0, mask_offset=None, invert_mask=0, wsrc=None, omask=None):
+    """The compound / masked / OBMC table members (oracle/aomref_compound.c) over a candidate list, mirroring
+    aomhip_compound_batch: returns (var, sse, sad) arrays.  cands: structured (sx, sy, rx, ry, xoff, yoff)."""
+    e16 = int(src_b.dtype != np.uint8)
+    n = len(cands)
+    var, sse, sad = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    lib.orc_compound_sub_pixel_variance.restype = C.c_uint32
+    lib.orc_masked_sad.restype = lib.orc_obmc_sad.restype = C.c_uint
+    lib.orc_obmc_variance.restype = C.c_uint32
+    lib.orc_sad_avg_any.restype = C.c_uint
+    q = C.c_uint32()
+    if preds is not None:
+        preds = np.ascontiguousarray(preds, src_b.dtype)
+    if masks is not None:
+        masks = np.ascontiguousarray(masks, np.uint8)
+    for i, c in enumerate(cands):
+        a = C.c_void_p(_addr(ref_b, border + int(c["ry"]), border + int(c["rx"])))
+        b = C.c_void_p(_addr(src_b, border + int(c["sy"]), border + int(c["sx"])))
+        xo, yo = (int(c["xoff"]), int(c["yoff"])) if subpel else (0, 0)
+        k = int(pred_index[i]) if pred_index is not None else 0
+        if kind == 3:
+            ws, om = np.ascontiguousarray(wsrc[k], np.int32), np.ascontiguousarray(omask[k], np.int32)
+            var[i] = lib.orc_obmc_variance(a, ref_b.shape[1], int(subpel), xo, yo, C.c_void_p(ws.ctypes.data), C.c_void_p(om.ctypes.data), w, h,
+                                           e16, bd, C.byref(q))
+            sse[i] = q.value
+            if not subpel:
+                sad[i] = lib.orc_obmc_sad(a, ref_b.shape[1], C.c_void_p(ws.ctypes.data), C.c_void_p(om.ctypes.data), w, h, e16, bd)
+            continue
+        sp = C.c_void_p(preds[k].ctypes.data)
+        mp = C.c_void_p(masks.ctypes.data + (int(mask_offset[i]) if mask_offset is not None else 0)) if kind == 2 else None
+        # the reference runs both bilinear passes in the sub-pixel forms only; offset (0, 0) is the identity, which is what
+        # lets one restatement serve the full-pel SAD forms' variance outputs too
+        var[i] = lib.orc_compound_sub_pixel_variance(a, ref_b.shape[1], xo, yo, b, src_b.shape[1], w, h, e16, bd, kind, sp, fwd_offset,
+                                                     bck_offset, mp, mask_stride, invert_mask, C.byref(q))
+        sse[i] = q.value
+        if not subpel:
+            if kind == 2:
+                sad[i] = lib.orc_masked_sad(b, src_b.shape[1], a, ref_b.shape[1], sp, mp, mask_stride, invert_mask, w, h, e16, bd)
+            else:
+                sad[i] = lib.orc_sad_avg_any(b, src_b.shape[1], a, ref_b.shape[1], sp, w, h, e16, bd, fwd_offset if kind == 1 else 0,
+                                             bck_offset if kind == 1 else 0)
+    return var, sse, sad
+
+
 def extend_plane(pixels, border, stride=None):
     """Host model of an HBM plane: replicate edges into `border` px on every side
     (aom_scale/generic/yv12extend.c:22-221); returns (bordered array, origin (y, x))."""

@@ -203,8 +203,100 @@ def gen_cdef_fb():
     save("ref_eval_cdef_fb.npz", arrays, cases)
 
 
+
+def gen_compound():
+    """The compound / masked / OBMC members of aom_variance_fn_ptr_t (svaf, jsvaf, msdf, msvf, osdf, ovf, osvf), 8/10/12-bit."""
+    ev = evaluator(["aom_dsp/variance.h", "aom_dsp/blend.h", "av1/common/mv.h", "aom_scale/yv12config.h", "av1/common/blockd.h", "aom_dsp/sad.c",
+                    "aom_dsp/variance.c", "aom_dsp/sad_av1.c"])
+    rng = np.random.default_rng(20261013)
+    arrays, cases = {}, []
+    S, ROWS = 160, 150
+    k = 0
+    for bd in (8, 10, 12):
+        mx = (1 << bd) - 1
+        a = rng.integers(0, mx + 1, (ROWS, S))
+        b = np.clip(a + rng.integers(-(24 << (bd - 8)), (24 << (bd - 8)) + 1, a.shape), 0, mx)
+        arrays["a%d" % bd], arrays["b%d" % bd] = a.astype(np.uint16), b.astype(np.uint16)
+        ct = "uint8_t" if bd == 8 else "uint16_t"
+        pa, pb = ev.array(a.ravel(), ct), ev.array(b.ravel(), ct)
+        hb = "" if bd == 8 else "highbd_"
+        hbn = "" if bd == 8 else "highbd_%d_" % bd
+        hbo = "" if bd == 8 else ("highbd_" if bd == 8 else "highbd_%d_" % bd)
+        sizes = {8: [(4, 4), (8, 8), (16, 16), (16, 8), (8, 16), (4, 16), (16, 4), (32, 16), (32, 32), (64, 32), (128, 128)],
+                 10: [(4, 4), (8, 8), (16, 16), (8, 4), (16, 32), (32, 8), (64, 16), (64, 64)],
+                 12: [(4, 8), (8, 8), (16, 16), (8, 32), (16, 64), (32, 64)]}[bd]
+        for (w, h) in sizes:
+            ax, ay = int(rng.integers(0, S - w - 1)), int(rng.integers(0, ROWS - h - 1))
+            bx, by = int(rng.integers(0, S - w - 1)), int(rng.integers(0, ROWS - h - 1))
+            A, B = pa.add(ay * S + ax), pb.add(by * S + bx)
+            sp = rng.integers(0, mx + 1, w * h)
+            ms = w + 3                                                            # a mask with a stride of its own
+            mask = rng.integers(0, 65, (h, ms))
+            mask[0, 0], mask[h - 1, w - 1] = 0, 64
+            om = rng.integers(0, 4097, w * h)                                      # OBMC weights (scaled by 4096)
+            ws = rng.integers(0, mx + 1, w * h) * 4096 - rng.integers(0, mx + 1, w * h) * (4096 - om)
+            arrays["sp%d" % k], arrays["mask%d" % k] = sp.astype(np.uint16), mask.astype(np.uint8)
+            arrays["om%d" % k], arrays["ws%d" % k] = om.astype(np.int32), ws.astype(np.int32)
+            SP, M, OM, WS = ev.array(sp, ct), ev.array(mask.ravel(), "uint8_t"), ev.array(om, "int32_t"), ev.array(ws, "int32_t")
+            sse = ev.array([0], "uint32_t")
+            rec = {"k": k, "bd": bd, "w": w, "h": h, "ax": ax, "ay": ay, "bx": bx, "by": by, "mask_stride": ms}
+            rec["svaf"] = []
+            for (xo, yo) in ((3, 5), (0, 4), (0, 0)):
+                v = ev.call("aom_%ssub_pixel_avg_variance%dx%d_c" % (hbn if bd > 8 else "", w, h), A, S, xo, yo, B, S, sse, SP)
+                rec["svaf"].append([xo, yo, v, sse.buf[0]])
+            rec["jsvaf"] = []
+            for (xo, yo, fwd, bck) in ((5, 2, 9, 7), (1, 0, 13, 3), (6, 7, 4, 12)):
+                jcp = ev.new("DIST_WTD_COMP_PARAMS")
+                ev.set(jcp, "use_dist_wtd_comp_avg", 1); ev.set(jcp, "fwd_offset", fwd); ev.set(jcp, "bck_offset", bck)
+                v = ev.call("aom_%sdist_wtd_sub_pixel_avg_variance%dx%d_c" % (hbn if bd > 8 else "", w, h), A, S, xo, yo, B, S, sse, SP, jcp)
+                rec["jsvaf"].append([xo, yo, fwd, bck, v, sse.buf[0]])
+            rec["msvf"] = []
+            for (xo, yo, inv) in ((7, 1, 0), (2, 3, 1), (0, 0, 0)):
+                fn = "aom_masked_sub_pixel_variance%dx%d_c" % (w, h) if bd == 8 else "aom_highbd_%d_masked_sub_pixel_variance%dx%d_c" % (bd, w, h)
+                v = ev.call(fn, A, S, xo, yo, B, S, SP, M, ms, inv, sse)
+                rec["msvf"].append([xo, yo, inv, v, sse.buf[0]])
+            # msdf(src, ref, second_pred, ...): the source block is b, the reference a (the raw kernel value; the
+            # _bits10 / _bits12 wrappers of encoder_utils.h:363-387 shift it by 2 / 4)
+            rec["msdf"] = [[inv, ev.call("aom_%smasked_sad%dx%d_c" % (hb, w, h), B, S, A, S, SP, M, ms, inv)] for inv in (0, 1)]
+            rec["osdf"] = ev.call("aom_%sobmc_sad%dx%d_c" % (hb, w, h), A, S, WS, OM)
+            on = "aom_obmc_" if bd == 8 else ("aom_highbd_obmc_" if bd == 8 else "aom_highbd_%d_obmc_" % bd)
+            v = ev.call(on + "variance%dx%d_c" % (w, h), A, S, WS, OM, sse)
+            rec["ovf"] = [v, sse.buf[0]]
+            rec["osvf"] = []
+            for (xo, yo) in ((2, 6), (0, 0)):
+                v = ev.call(on + "sub_pixel_variance%dx%d_c" % (w, h), A, S, xo, yo, WS, OM, sse)
+                rec["osvf"].append([xo, yo, v, sse.buf[0]])
+            cases.append(rec)
+            k += 1
+    # 8-bit content through the highbd_8 / un-numbered highbd symbols (what a high-bit-depth build uses for 8-bit video)
+    a, b = arrays["a8"].astype(np.int64), arrays["b8"].astype(np.int64)
+    pa, pb = ev.array(a.ravel(), "uint16_t"), ev.array(b.ravel(), "uint16_t")
+    for (w, h) in ((8, 8), (16, 16)):
+        ax, ay, bx, by = 5, 7, 11, 3
+        A, B = pa.add(ay * S + ax), pb.add(by * S + bx)
+        sp = rng.integers(0, 256, w * h)
+        om = rng.integers(0, 4097, w * h)
+        ws = rng.integers(0, 256, w * h) * 4096 - rng.integers(0, 256, w * h) * (4096 - om)
+        mask = rng.integers(0, 65, (h, w))
+        arrays["sp%d" % k], arrays["mask%d" % k] = sp.astype(np.uint16), mask.astype(np.uint8)
+        arrays["om%d" % k], arrays["ws%d" % k] = om.astype(np.int32), ws.astype(np.int32)
+        SP, M, OM, WS = ev.array(sp, "uint16_t"), ev.array(mask.ravel(), "uint8_t"), ev.array(om, "int32_t"), ev.array(ws, "int32_t")
+        sse = ev.array([0], "uint32_t")
+        rec = {"k": k, "bd": 8, "hbd8": 1, "w": w, "h": h, "ax": ax, "ay": ay, "bx": bx, "by": by, "mask_stride": w}
+        v = ev.call("aom_highbd_8_sub_pixel_avg_variance%dx%d_c" % (w, h), A, S, 3, 5, B, S, sse, SP)
+        rec["svaf"] = [[3, 5, v, sse.buf[0]]]
+        v = ev.call("aom_highbd_8_masked_sub_pixel_variance%dx%d_c" % (w, h), A, S, 7, 1, B, S, SP, M, w, 1, sse)
+        rec["msvf"] = [[7, 1, 1, v, sse.buf[0]]]
+        v = ev.call("aom_highbd_obmc_variance%dx%d_c" % (w, h), A, S, WS, OM, sse)
+        rec["ovf"] = [v, sse.buf[0]]
+        v = ev.call("aom_highbd_obmc_sub_pixel_variance%dx%d_c" % (w, h), A, S, 2, 6, WS, OM, sse)
+        rec["osvf"] = [[2, 6, v, sse.buf[0]]]
+        cases.append(rec)
+        k += 1
+    save("ref_eval_compound.npz", arrays, cases)
+
 if __name__ == "__main__":
-    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb"]:
+    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound"]:
         t = time.time()
         globals()["gen_" + w]()
         print("  (%s: %.1f s)" % (w, time.time() - t))

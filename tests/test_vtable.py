@@ -1,6 +1,7 @@
 """aomhip_bind_variance_vtable: the table layout mirrors aom_variance_fn_ptr_t (16 pointers, aom_dsp/variance.h
-:84-103), the binder fills exactly the motion-search entries and leaves the compound / masked / OBMC ones
-alone (no GPU needed); on the GPU box, calls THROUGH the bound pointers match the oracle."""
+:84-103), the binder fills every member (the down-sampled SAD pair only in the 8-bit table) with one function
+per block size (no GPU needed); on the GPU box, calls THROUGH the bound pointers match the oracle (the compound /
+masked / OBMC members: tests/test_gpu_compound.py)."""
 import ctypes as C
 
 import numpy as np
@@ -27,14 +28,14 @@ def _bound(hip, bd):
 
 def test_layout_and_which_entries_are_bound(hip):
     assert C.sizeof(VTable) == 16 * C.sizeof(C.c_void_p)
-    for bd, filled in ((8, {"sdf", "sdsf", "vf", "svf", "sdx4df", "sdx3df", "sdsx4df"}),
-                       (10, {"sdf", "vf", "svf", "sdx4df", "sdx3df"})):
+    for bd, filled in ((8, set(FIELDS)), (10, set(FIELDS) - {"sdsf", "sdsx4df"}), (12, set(FIELDS) - {"sdsf", "sdsx4df"})):
         tbl = _bound(hip, bd)
         for t in tbl:
             for n in FIELDS:
                 v = getattr(t, n)
                 assert (v != 0xDEAD0000) == (n in filled), (bd, n)
-        assert len({tbl[i].sdf for i in range(22)}) == 22  # one function per block size
+        for n in filled - {"sdx3df"}:
+            assert len({getattr(tbl[i], n) for i in range(22)}) == 22, n  # one function per block size
         assert all(tbl[i].sdx3df == tbl[i].sdx4df for i in range(22))  # x3d forwards to x4d (sad.c:124-129)
     assert hip.capi.lib.aomhip_bind_variance_vtable(None, 8) != 0
     assert hip.capi.lib.aomhip_bind_variance_vtable(C.byref((VTable * 22)()), 9) != 0
