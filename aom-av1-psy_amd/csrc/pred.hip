@@ -1,10 +1,114 @@
 // Integer-MV motion-compensated prediction: for a full-pel motion vector the reference's inter predictor
 // (av1_build_inter_predictor -> the convolve with zero sub-pel phase, av1/common/reconinter.c) degenerates to
 // aom_convolve_copy, i.e. pred block = reference block at (bx + mv.col, by + mv.row).  This is only the
-// glue the frame-level pipeline (search -> residual -> transform) needs; sub-pel interpolation is out of scope.
+// glue the frame-level pipeline (search -> residual -> transform) needs.
+//
+// Sub-pel MVs: inter_pred_kernel below is the single-reference, unscaled luma predictor behind
+// av1_enc_build_inter_predictor (av1/encoder/reconinter_enc.c:47-51 -> av1_make_inter_predictor ->
+// [highbd_]inter_predictor, av1/common/reconinter.h:252-296 -> av1_[highbd_]convolve_2d_facade,
+// av1/common/convolve.c:495-567,982-1058): 8-tap separable interpolation at 1/16-pel phases.
 #include "common.h"
 
 namespace aomhip {
+
+// AV1 Subpel_Filters [set][phase][tap] (av1/common/filter.h:110-236): regular, smooth, sharp, bilinear, 4-tap regular, 4-tap smooth
+__device__ const int16_t kInterp[6][16][8] __attribute__((aligned(16))) = {
+#include "interp_table.inc"
+};
+
+struct __attribute__((packed, aligned(1))) PU128 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) PU64 { uint32_t v[2]; };
+
+// 8 consecutive pixels from an arbitrarily aligned address with one wide load
+template <typename T> __device__ __forceinline__ void load8(const T *p, int (&out)[8]) {
+  if constexpr (sizeof(T) == 1) {
+    const PU64 raw = *reinterpret_cast<const PU64 *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (raw.v[i / 4] >> (8 * (i % 4))) & 0xFF;
+  } else {
+    const PU128 raw = *reinterpret_cast<const PU128 *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (raw.v[i / 2] >> (16 * (i % 2))) & 0xFFFF;
+  }
+}
+
+// One LANE owns one column of one block and walks down its H + 7 input rows: per row one unaligned 8-pixel load and
+// the horizontal 8-tap (av1_convolve_2d_sr_c's first loop, convolve.c:92-106), the last 8 intermediates stay in
+// registers, and from row 7 on the vertical 8-tap + the two rounding stages + clip produce one output pixel per row
+// (:108-125).  A wavefront therefore holds 64 / W blocks side by side (W <= 64; two column passes for W = 128), every
+// global access is a run of W adjacent pixels, and nothing goes through LDS or scratch.
+// The facade's other three cases need no code of their own: with round_0 + round_1 == 14 (non-compound,
+// convolve.h:72-81) the 2-D pipeline with an identity kernel (phase 0 = {0,0,0,128,0,0,0,0}) in one direction is
+// bit-identical to av1_convolve_x_sr / _y_sr / aom_convolve_copy -- the offsets cancel exactly and
+// (128 a + 2^(13 - r0)) >> (14 - r0) == (a + 2^(6 - r0)) >> (7 - r0).  tests/test_gpu_inter_pred.py checks all four
+// cases against the oracle, which restates them separately, and against the interpreted reference.
+template <typename T, int W, int H>
+__global__ __launch_bounds__(256) void inter_pred_kernel(PlaneView<T> ref, int ref_frame, T *dst_origin, int dst_stride,
+                                                         const aomhip_search_block *__restrict__ blocks,
+                                                         const int16_t *__restrict__ mv, int n_blocks, int set_x, int set_y, int bit_depth,
+                                                         int x_lo, int x_hi, int y_lo, int y_hi) {
+  constexpr int LPB = W < 64 ? W : 64;  // lanes per block
+  constexpr int BPW = 64 / LPB;         // blocks per wavefront
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bi = (blockIdx.x * 4 + wave) * BPW + lane / LPB;
+  if (bi >= n_blocks) return;
+  const int col0 = lane % LPB;
+  const int bx = blocks[bi].bx, by = blocks[bi].by;
+  // init_subpel_params (reconinter.h:130-165), unscaled luma: position in 1/16 pel
+  int pos_x = (bx << 4) + mv[2 * bi + 1] * 2, pos_y = (by << 4) + mv[2 * bi] * 2;
+  // keeps every access inside the allocation; the identity for MVs within av1_set_mv_limits (mcomp.h:216-247)
+  pos_x = min(max(pos_x, x_lo), x_hi);
+  pos_y = min(max(pos_y, y_lo), y_hi);
+  const int tbd = sizeof(T) == 1 ? 8 : bit_depth;
+  const int r0 = tbd == 12 ? 5 : 3, r1 = 14 - r0;  // get_conv_params_no_round (convolve.h:72-81)
+  const int ob = tbd + 14 - r0;
+  const int hoff = (1 << (tbd + 6)) + ((1 << r0) >> 1);
+  const int voff = (1 << ob) + ((1 << r1) >> 1);
+  const int vsub = (1 << (ob - r1)) + (1 << (ob - r1 - 1));
+  const int pmax = (1 << tbd) - 1;
+  int fx[8], fy[8];
+  {
+    const PU128 a = *reinterpret_cast<const PU128 *>(&kInterp[set_x][pos_x & 15][0]);
+    const PU128 b = *reinterpret_cast<const PU128 *>(&kInterp[set_y][pos_y & 15][0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      fx[i] = (int16_t)(a.v[i / 2] >> (16 * (i % 2)));
+      fy[i] = (int16_t)(b.v[i / 2] >> (16 * (i % 2)));
+    }
+  }
+  const T *base = ref.origin + (int64_t)ref_frame * ref.frame_stride + (int64_t)((pos_y >> 4) - 3) * ref.stride + (pos_x >> 4) - 3;
+  T *dbase = dst_origin + (int64_t)by * dst_stride + bx;
+#pragma unroll 1
+  for (int col = col0; col < W; col += 64) {
+    const T *p = base + col;
+    T *d = dbase + col;
+    int win[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) win[i] = 0;
+#pragma unroll 8
+    for (int r = 0; r < H + 7; ++r) {
+      int px[8];
+      load8<T>(p, px);
+      p += ref.stride;
+      int hs = hoff;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) hs += fx[k] * px[k];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) win[k] = win[k + 1];
+      win[7] = hs >> r0;
+      if (r >= 7) {
+        int vs = voff;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vs += fy[k] * win[k];
+        int res = (vs >> r1) - vsub;
+        if constexpr (sizeof(T) == 1) res = (int16_t)res;  // convolve.c:119 keeps it in an int16_t
+        // bits = 14 - round_0 - round_1 == 0: ROUND_POWER_OF_TWO(res, 0) is res
+        *d = (T)min(max(res, 0), pmax);
+        d += dst_stride;
+      }
+    }
+  }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void pred_copy_kernel(PlaneView<T> ref, int ref_frame, T *dst_origin, int dst_stride,
@@ -25,9 +129,57 @@ __global__ __launch_bounds__(256) void pred_copy_kernel(PlaneView<T> ref, int re
   }
 }
 
+
+#define AOMHIP_PRED_SIZES(X)                                                                                     \
+  X(4, 4) X(4, 8) X(8, 4) X(8, 8) X(8, 16) X(16, 8) X(16, 16) X(16, 32) X(32, 16) X(32, 32) X(32, 64) X(64, 32) \
+  X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(4, 16) X(16, 4) X(8, 32) X(32, 8) X(16, 64) X(64, 16)
+
+template <typename T>
+static int launch_inter_pred(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred, int pred_frame, int bw,
+                             int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv, int n_blocks, int fx, int fy) {
+  // av1_get_interp_filter_params_with_block_size (filter.h:247-253): a dimension <= 4 takes the 4-tap sets
+  auto set_of = [](int f, int dim) { return dim <= 4 ? (f == 1 ? 5 : f == 3 ? 3 : 4) : f; };
+  T *d = reinterpret_cast<T *>(pred->base) + (size_t)pred_frame * pred->frame_stride + (size_t)pred->border * pred->stride + pred->border;
+  // the 8-pixel row load starts 3 left of the integer position and the walk covers rows -3 .. bh + 3
+  const int x_lo = (-ref->border + 3) << 4, x_hi = ((ref->width + ref->border - bw - 5) << 4) | 15;
+  const int y_lo = (-ref->border + 3) << 4, y_hi = ((ref->height + ref->border - bh - 5) << 4) | 15;
+  const int lpb = bw < 64 ? bw : 64, bpw = 64 / lpb;
+  const dim3 grid((n_blocks + 4 * bpw - 1) / (4 * bpw)), block(256);
+#define X(W, H)                                                                                                                    \
+  if (bw == W && bh == H) {                                                                                                        \
+    hipLaunchKernelGGL((inter_pred_kernel<T, W, H>), grid, block, 0, ctx->stream, view_of<T>(*ref), ref_frame, d, pred->stride,   \
+                       d_blocks, d_mv, n_blocks, set_of(fx, W), set_of(fy, H), ref->bit_depth, x_lo, x_hi, y_lo, y_hi);            \
+    AOMHIP_LAUNCH_CHECK();                                                                                                         \
+    return AOMHIP_OK;                                                                                                              \
+  }
+  AOMHIP_PRED_SIZES(X)
+#undef X
+  set_error("unsupported block size %dx%d", bw, bh);
+  return AOMHIP_ERR_INVALID;
+}
+
 }  // namespace aomhip
 
 using namespace aomhip;
+
+extern "C" int aomhip_build_inter_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred,
+                                             int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv,
+                                             int n_blocks, int interp_filter_x, int interp_filter_y) {
+  if (!ctx || !ref || !pred || !ref->base || !pred->base || (n_blocks > 0 && (!d_blocks || !d_mv)) || n_blocks < 0 || ref_frame < 0 ||
+      ref_frame >= ref->n_frames || pred_frame < 0 || pred_frame >= pred->n_frames || !valid_block(bw, bh) ||
+      ref->bit_depth != pred->bit_depth || interp_filter_x < 0 || interp_filter_x > 3 || interp_filter_y < 0 || interp_filter_y > 3) {
+    set_error("aomhip_build_inter_pred_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (ref->border < 8) {
+    set_error("aomhip_build_inter_pred_batch: the reference planes need a border of at least 8 pixels for the 8-tap kernels");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  if (ref->bit_depth == 8)
+    return launch_inter_pred<uint8_t>(ctx, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, interp_filter_x, interp_filter_y);
+  return launch_inter_pred<uint16_t>(ctx, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, interp_filter_x, interp_filter_y);
+}
 
 extern "C" int aomhip_build_pred_fullpel(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame,
                                          const aomhip_planes *pred, int pred_frame, int bw, int bh,

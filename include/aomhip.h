@@ -555,11 +555,31 @@ int aomhip_bind_variance_vtable(aomhip_variance_vtable *table, int bit_depth);
 
 /* Full-pel motion-compensated prediction for the frame-level pipeline: pred block i = reference block at
  * (bx + mv.col, by + mv.row) with mv = d_fullpel_mv[2i], [2i+1] (row, col), i.e. av1_build_inter_predictor
- * (av1/common/reconinter.c) for an integer MV, where the convolve is aom_convolve_copy.  Sub-pel interpolation
- * (the 8-tap filters) is outside this library's path. */
+ * (av1/common/reconinter.c) for an integer MV, where the convolve is aom_convolve_copy. */
 int aomhip_build_pred_fullpel(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred,
                               int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks,
                               const int16_t *d_fullpel_mv, int n_blocks);
+
+/* Sub-pel motion-compensated prediction, single reference, unscaled, luma: av1_enc_build_inter_predictor
+ * (av1/encoder/reconinter_enc.c:47-51) -> av1_make_inter_predictor -> [highbd_]inter_predictor
+ * (av1/common/reconinter.h:252-296) -> av1_[highbd_]convolve_2d_facade (av1/common/convolve.c:495-567,982-1058):
+ * aom_convolve_copy / av1_convolve_x_sr / _y_sr / _2d_sr chosen by the MV's fraction, with get_conv_params'
+ * rounding (convolve.h:63-100; 12-bit: round_0 = 5) and av1_get_interp_filter_params_with_block_size's kernel sets
+ * (filter.h:247-253: a dimension <= 4 takes the 4-tap kernels).
+ *   d_mv            (row, col) per block in 1/8 pel, as produced by aomhip_subpel_tree_batch; must satisfy
+ *                   av1_set_mv_limits for the planes' border (then init_subpel_params' position clamp,
+ *                   reconinter.h:153-156, is the identity; out-of-range MVs are clamped to the allocation instead)
+ *   interp_filter_* InterpFilter (filter.h:30-36): 0 EIGHTTAP_REGULAR, 1 EIGHTTAP_SMOOTH, 2 MULTITAP_SHARP, 3 BILINEAR;
+ *                   x = InterpFilters::x_filter applies horizontally.  MULTITAP_SHARP2 (12 taps, temporal filter only),
+ *                   scaled references, compound, warped and OBMC prediction are outside this call.
+ * Writes block i of frame pred_frame of `pred` at (bx, by).  The reference planes need a border >= 8. */
+#define AOMHIP_INTERP_REGULAR 0
+#define AOMHIP_INTERP_SMOOTH 1
+#define AOMHIP_INTERP_SHARP 2
+#define AOMHIP_INTERP_BILINEAR 3
+int aomhip_build_inter_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred,
+                                  int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv,
+                                  int n_blocks, int interp_filter_x, int interp_filter_y);
 
 /* ------------------------------------------------------------------ rtcd-signature conformance entry points */
 

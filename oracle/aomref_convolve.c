@@ -1,0 +1,97 @@
+/*
+ * oracle/aomref_convolve.c -- single-reference, unscaled inter prediction of one block: the sub-pel interpolation
+ * behind av1_enc_build_inter_predictor (av1/encoder/reconinter_enc.c:47-51 -> build_one_inter_predictor ->
+ * av1_make_inter_predictor -> [highbd_]inter_predictor, av1/common/reconinter.h:252-296 ->
+ * av1_[highbd_]convolve_2d_facade, av1/common/convolve.c:495-567,982-1058).
+ *
+ * TEST INFRASTRUCTURE ONLY (see aomref.h).  Pinned by tests/golden/ref_eval_convolve.npz (the reference's own
+ * av1_[highbd_]convolve_{2d,x,y}_sr_c and the facade, interpreted where they lie).
+ */
+#include <stdlib.h>
+
+#include "aomref.h"
+
+#define RPOT(v, n) (((v) + ((1 << (n)) >> 1)) >> (n))
+
+static const int16_t k_interp[6][16][8] = {
+#include "aomref_interp.inc"
+};
+
+/* av1_get_interp_filter_params_with_block_size (av1/common/filter.h:247-253): interp_filter 0 EIGHTTAP_REGULAR,
+ * 1 EIGHTTAP_SMOOTH, 2 MULTITAP_SHARP, 3 BILINEAR; a dimension <= 4 switches to the 4-tap sets (sharp -> regular). */
+static const int16_t *kernel_of(int interp_filter, int dim, int subpel_qn) {
+  int set = interp_filter;
+  if (dim <= 4) set = interp_filter == 1 ? 5 : interp_filter == 3 ? 3 : 4;
+  return k_interp[set][subpel_qn & 15];
+}
+
+static int px(const void *p, int elem16, ptrdiff_t i) { return elem16 ? ((const uint16_t *)p)[i] : ((const uint8_t *)p)[i]; }
+static void put(void *p, int elem16, ptrdiff_t i, int v, int bd) {
+  const int mx = (1 << (elem16 ? bd : 8)) - 1;
+  v = v < 0 ? 0 : v > mx ? mx : v; /* clip_pixel / clip_pixel_highbd */
+  if (elem16) ((uint16_t *)p)[i] = (uint16_t)v; else ((uint8_t *)p)[i] = (uint8_t)v;
+}
+
+/* convolve_2d_facade_single / highbd_convolve_2d_facade_single with get_conv_params(0, plane, bd)
+ * (av1/common/convolve.h:63-100): round_0 = 3 (5 for 12-bit), round_1 = 14 - round_0.
+ * src points at the block's integer position; dst stride in elements. */
+void orc_convolve_sr(const void *src, int src_stride, void *dst, int dst_stride, int w, int h, int filter_x, int filter_y,
+                     int subpel_x_qn, int subpel_y_qn, int elem16, int bd) {
+  const int tbd = elem16 ? bd : 8;
+  int round_0 = 3, round_1 = 11;
+  if (elem16 && bd + 7 - round_0 + 2 > 16) { /* intbufrange > 16 (12-bit) */
+    const int extra = bd + 7 - round_0 + 2 - 16;
+    round_0 += extra;
+    round_1 -= extra;
+  }
+  const int16_t *fx = kernel_of(filter_x, w, subpel_x_qn), *fy = kernel_of(filter_y, h, subpel_y_qn);
+  if (!subpel_x_qn && !subpel_y_qn) { /* aom_convolve_copy */
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) put(dst, elem16, (ptrdiff_t)y * dst_stride + x, px(src, elem16, (ptrdiff_t)y * src_stride + x), tbd);
+  } else if (subpel_x_qn && !subpel_y_qn) { /* av1_[highbd_]convolve_x_sr_c (convolve.c:149-174,569-595) */
+    const int bits = 7 - round_0;
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        int res = 0;
+        for (int k = 0; k < 8; ++k) res += fx[k] * px(src, elem16, (ptrdiff_t)y * src_stride + x - 3 + k);
+        res = RPOT(res, round_0);
+        put(dst, elem16, (ptrdiff_t)y * dst_stride + x, RPOT(res, bits), tbd);
+      }
+  } else if (!subpel_x_qn) { /* av1_[highbd_]convolve_y_sr_c (convolve.c:128-147,597-615) */
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        int res = 0;
+        for (int k = 0; k < 8; ++k) res += fy[k] * px(src, elem16, (ptrdiff_t)(y - 3 + k) * src_stride + x);
+        put(dst, elem16, (ptrdiff_t)y * dst_stride + x, RPOT(res, 7), tbd);
+      }
+  } else { /* av1_[highbd_]convolve_2d_sr_c (convolve.c:76-126,617-668) */
+    const int im_h = h + 7, bits = 14 - round_0 - round_1, offset_bits = tbd + 14 - round_0;
+    int16_t *im = (int16_t *)malloc(sizeof(int16_t) * (size_t)im_h * w);
+    for (int y = 0; y < im_h; ++y)
+      for (int x = 0; x < w; ++x) {
+        int sum = 1 << (tbd + 6);
+        for (int k = 0; k < 8; ++k) sum += fx[k] * px(src, elem16, (ptrdiff_t)(y - 3) * src_stride + x - 3 + k);
+        im[y * w + x] = (int16_t)RPOT(sum, round_0);
+      }
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        int sum = 1 << offset_bits;
+        for (int k = 0; k < 8; ++k) sum += fy[k] * im[(y + k) * w + x];
+        int res = RPOT(sum, round_1) - ((1 << (offset_bits - round_1)) + (1 << (offset_bits - round_1 - 1)));
+        if (!elem16) res = (int16_t)res; /* the 8-bit function keeps it in an int16_t (convolve.c:119) */
+        put(dst, elem16, (ptrdiff_t)y * dst_stride + x, RPOT(res, bits), tbd);
+      }
+    free(im);
+  }
+}
+
+/* One luma block of av1_enc_build_inter_predictor for an unscaled reference: mv in 1/8 pel (row, col) ->
+ * position in 1/16 pel (init_subpel_params, av1/common/reconinter.h:130-165, is_scaled == 0, ss = 0), integer part
+ * selects the source block, the fraction the kernel phase.  ref_origin: pixel (0, 0) of the reference plane. */
+void orc_build_inter_pred_block(const void *ref_origin, int ref_stride, void *dst, int dst_stride, int bx, int by, int bw, int bh,
+                                int mv_row, int mv_col, int filter_x, int filter_y, int elem16, int bd) {
+  const int pos_x = (bx << 4) + mv_col * 2, pos_y = (by << 4) + mv_row * 2;
+  const int esz = elem16 ? 2 : 1;
+  const char *src = (const char *)ref_origin + ((ptrdiff_t)(pos_y >> 4) * ref_stride + (pos_x >> 4)) * esz;
+  orc_convolve_sr(src, ref_stride, dst, dst_stride, bw, bh, filter_x, filter_y, pos_x & 15, pos_y & 15, elem16, bd);
+}

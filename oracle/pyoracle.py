@@ -142,6 +142,20 @@ def compound_batch(src_b, ref_b, border, w, h, cands, kind, subpel, bd=8, preds=
     return var, sse, sad
 
 
+def build_inter_pred(ref_b, border, width, height, w, h, blocks, mvs, filter_x=0, filter_y=0, bd=8):
+    """oracle/aomref_convolve.c over a block list: returns the visible height x width prediction plane (zeros where no
+    block wrote).  ref_b: border-extended reference plane; mvs: (row, col) per block in 1/8 pel."""
+    lib.orc_build_inter_pred_block.restype = None
+    e16 = int(ref_b.dtype != np.uint8)
+    out = np.zeros((height, width), ref_b.dtype)
+    origin = C.c_void_p(_addr(ref_b, border, border))
+    for b, mv in zip(blocks, mvs):
+        x, y = int(b["bx"]), int(b["by"])
+        lib.orc_build_inter_pred_block(origin, ref_b.shape[1], C.c_void_p(_addr(out, y, x)), width, x, y, w, h, int(mv[0]), int(mv[1]),
+                                       filter_x, filter_y, e16, bd)
+    return out
+
+
 def extend_plane(pixels, border, stride=None):
     """Host model of an HBM plane: replicate edges into `border` px on every side
     (aom_scale/generic/yv12extend.c:22-221); returns (bordered array, origin (y, x))."""

@@ -295,8 +295,51 @@ def gen_compound():
         k += 1
     save("ref_eval_compound.npz", arrays, cases)
 
+
+def gen_convolve():
+    """av1_[highbd_]convolve_2d_facade (single reference, unscaled): the copy / x_sr / y_sr / 2d_sr choice, the 8-tap and (for a
+    dimension <= 4) 4-tap kernel sets, round_0 / round_1 from get_conv_params."""
+    ev = evaluator(["av1/common/filter.h", "av1/common/convolve.h", "aom_dsp/aom_convolve.c", "av1/common/convolve.c"])
+    rng = np.random.default_rng(20261015)
+    arrays, cases = {}, []
+    S, ROWS = 112, 100
+    k = 0
+    for bd in (8, 10, 12):
+        mx = (1 << bd) - 1
+        base = rng.integers(0, mx + 1, (ROWS, S))
+        base[:20] = np.where(rng.integers(0, 2, (20, S)) > 0, mx, 0)       # a band of extreme pixels: the clips and the offsets must hold
+        arrays["p%d" % bd] = base.astype(np.uint16)
+        ct = "uint8_t" if bd == 8 else "uint16_t"
+        P = ev.array(base.ravel(), ct)
+        cpv = ev.call("get_conv_params", 0, 0, bd)                        # a struct by value; give it storage to point at
+        cp = R.Ptr([cpv], 0, cpv.st)
+        sizes = {8: [(4, 4), (8, 8), (16, 16), (4, 16), (16, 4), (32, 16), (8, 32), (64, 32)],
+                 10: [(4, 8), (8, 4), (16, 16), (16, 8), (32, 32), (64, 16)],
+                 12: [(4, 4), (8, 16), (16, 16), (16, 32)]}[bd]
+        for (w, h) in sizes:
+            x0, y0 = int(rng.integers(4, S - w - 5)), int(rng.integers(4, ROWS - h - 5))
+            if k % 3 == 0:
+                y0 = int(rng.integers(4, 14))                               # inside the extreme band
+            for (fxi, fyi) in ((0, 0), (1, 2), (2, 1), (3, 3)):
+                fp = [ev.call("av1_get_interp_filter_params_with_block_size", fxi, w), ev.call("av1_get_interp_filter_params_with_block_size", fyi, h)]
+                filt = R.Ptr(fp, 0, ("ptr", ev.structs["InterpFilterParams"]))
+                subs = [(int(rng.integers(1, 16)), 0), (0, int(rng.integers(1, 16))), (int(rng.integers(1, 16)), int(rng.integers(1, 16)))]
+                if (fxi, fyi) == (0, 0):
+                    subs.append((0, 0))
+                for (sx, sy) in subs:
+                    dst = ev.array([0] * (w * h), ct)
+                    fn = "av1_convolve_2d_facade" if bd == 8 else "av1_highbd_convolve_2d_facade"
+                    args = [P.add(y0 * S + x0), S, dst, w, w, h, filt, sx, 16, sy, 16, 0, cp]
+                    if bd > 8:
+                        args.append(bd)
+                    ev.call(fn, *args)
+                    arrays["d%d" % k] = np.asarray(dst.buf, np.uint16)
+                    cases.append({"k": k, "bd": bd, "w": w, "h": h, "x0": x0, "y0": y0, "fx": fxi, "fy": fyi, "sx": sx, "sy": sy})
+                    k += 1
+    save("ref_eval_convolve.npz", arrays, cases)
+
 if __name__ == "__main__":
-    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound"]:
+    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound", "convolve"]:
         t = time.time()
         globals()["gen_" + w]()
         print("  (%s: %.1f s)" % (w, time.time() - t))

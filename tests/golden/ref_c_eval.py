@@ -49,6 +49,8 @@ BASE_TYPEDEFS = {
     "int8_t": I8, "uint8_t": U8, "int16_t": I16, "uint16_t": U16, "int32_t": I32, "uint32_t": U32,
     "int64_t": I64, "uint64_t": U64, "intptr_t": I64, "uintptr_t": U64, "size_t": U64, "ptrdiff_t": I64,
     "ssize_t": I64,
+    # <stdbool.h>: the interpreted paths only ever store comparison results (already 0 / 1) in a bool
+    "bool": U8,
 }
 TYPE_WORDS = {"void", "char", "short", "int", "long", "signed", "unsigned", "_Bool", "double", "float"}
 QUALIFIERS = {"const", "static", "inline", "__inline", "__inline__", "volatile", "register", "extern", "restrict",

@@ -395,3 +395,26 @@ def test_compound_masked_obmc_match_reference_evaluation(oracle):
             assert (got, q.value) == (v, sse), ("osvf", c)
             checked += 1
     assert checked > 300
+
+
+def test_convolve_sr_matches_reference_evaluation(oracle):
+    """orc_convolve_sr (the single-reference sub-pel interpolation of av1_enc_build_inter_predictor) against the interpreted
+    av1_[highbd_]convolve_2d_facade: copy / x_sr / y_sr / 2d_sr, the four interpolation filters, the 4-tap sets for a
+    dimension <= 4, round_0 / round_1 of 8 / 10 / 12-bit (av1/common/convolve.c, convolve.h:63-100, filter.h)."""
+    z, cases = load("ref_eval_convolve.npz")
+    assert len(cases) >= 200
+    f = oracle.lib.orc_convolve_sr
+    f.restype = None
+    kinds = set()
+    for c in cases:
+        bd, w, h = c["bd"], c["w"], c["h"]
+        e16 = int(bd > 8)
+        dt = np.uint16 if e16 else np.uint8
+        p = np.ascontiguousarray(z["p%d" % bd], dt)
+        S = p.shape[1]
+        dst = np.zeros((h, w), dt)
+        f(C.c_void_p(p.ctypes.data + (c["y0"] * S + c["x0"]) * p.itemsize), S, C.c_void_p(dst.ctypes.data), w, w, h, c["fx"], c["fy"],
+          c["sx"], c["sy"], e16, bd)
+        assert np.array_equal(dst.ravel(), z["d%d" % c["k"]]), c
+        kinds.add((bool(c["sx"]), bool(c["sy"])))
+    assert len(kinds) == 4

@@ -1,0 +1,113 @@
+"""Sub-pel motion-compensated prediction (aomhip_build_inter_pred_batch: av1_enc_build_inter_predictor for a single,
+unscaled reference -> av1_[highbd_]convolve_2d_facade) through the C ABI: against the interpreted reference's vectors
+(tests/golden/ref_eval_convolve.npz), against the oracle for all 22 block sizes x 8/10/12-bit x the four interpolation
+filters with MVs covering every 1/8-pel phase pair (copy / x-only / y-only / 2-D cases), extreme content, MVs that
+reach into the border, and the integer-MV case against the full-pel gather."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BLOCK_SIZES = [(4, 4), (4, 8), (8, 4), (8, 8), (8, 16), (16, 8), (16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 32),
+               (64, 64), (64, 128), (128, 64), (128, 128), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
+
+
+def test_inter_pred_goldens(hip, ctx):
+    """The fixture's phases are in 1/16 pel (subpel_x_qn); an MV in 1/8 pel reaches the even ones -- the odd phases belong to
+    chroma / scaled references, outside this call -- so every fixture case with even phases is replayed as an MV."""
+    z = np.load(os.path.join(GOLD, "ref_eval_convolve.npz"))
+    cases = json.loads(bytes(z["cases"]).decode())
+    planes = {}
+    border = 16
+    for bd in (8, 10, 12):
+        p = z["p%d" % bd]
+        dt = np.uint8 if bd == 8 else np.uint16
+        H, W = p.shape
+        pr, pp = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+        ctx.planes_upload(pr, 0, np.ascontiguousarray(p, dt))
+        planes[bd] = (pr, pp, W, H)
+    used = 0
+    for c in cases:
+        if c["sx"] % 2 or c["sy"] % 2:
+            continue
+        pr, pp, W, H = planes[c["bd"]]
+        w, h = c["w"], c["h"]
+        blk = np.zeros(1, hip.capi.search_block_dtype)
+        blk["bx"], blk["by"] = c["x0"], c["y0"]
+        mv = np.array([[c["sy"] // 2, c["sx"] // 2]], np.int16)
+        d_b, d_mv = ctx.to_device(blk), ctx.to_device(mv)
+        ctx.build_inter_pred_batch(pr, 0, pp, 0, w, h, d_b, d_mv, 1, c["fx"], c["fy"])
+        got = ctx.planes_download(pp, 0)[border + c["y0"]:border + c["y0"] + h, border + c["x0"]:border + c["x0"] + w]
+        assert np.array_equal(got.ravel().astype(np.uint16), z["d%d" % c["k"]]), c
+        ctx.free(d_b); ctx.free(d_mv)
+        used += 1
+    assert used >= 40
+    for pr, pp, _, _ in planes.values():
+        ctx.planes_free(pr); ctx.planes_free(pp)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_inter_pred_vs_oracle(hip, oracle, ctx, bd):
+    rng = np.random.default_rng(40 + bd)
+    W, H, border = 256, 256, 64
+    ref = hip.synth.lcg_frame(W, H, 5, 0, bd)
+    mx = (1 << bd) - 1
+    ref[40:72, 100:180] = np.where(rng.integers(0, 2, (32, 80)) > 0, mx, 0).astype(ref.dtype)   # saturating checkerboard noise
+    pr, pp = ctx.planes_alloc(W, H, border, bd, 2), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(pr, 1, ref)
+    rb = oracle.extend_plane(ref, border, pr.stride)
+    for si, (bw, bh) in enumerate(BLOCK_SIZES):
+        xs, ys = np.meshgrid(np.arange(0, W - bw + 1, bw), np.arange(0, H - bh + 1, bh))
+        n = xs.size
+        blocks = np.zeros(n, hip.capi.search_block_dtype)
+        blocks["bx"], blocks["by"] = xs.ravel(), ys.ravel()
+        # MVs in 1/8 pel: up to +-(border - 8) pixels, all 64 phase pairs, with the integer / x-only / y-only cases forced in
+        lim = (border - 8) * 8
+        mv = rng.integers(-lim, lim + 1, (n, 2)).astype(np.int16)
+        mv[0::7] &= ~7
+        mv[1::7, 0] &= ~7
+        mv[2::7, 1] &= ~7
+        d_b, d_mv = ctx.to_device(blocks), ctx.to_device(mv)
+        for fx, fy in (((0, 0), (1, 2), (2, 1), (3, 3), (2, 0), (0, 1)) if (bw, bh) in ((16, 16), (4, 8), (64, 64)) else ((si % 4, (si + 1) % 3),)):
+            ctx.planes_upload(pp, 0, np.zeros_like(ref))
+            ctx.build_inter_pred_batch(pr, 1, pp, 0, bw, bh, d_b, d_mv, n, fx, fy)
+            got = ctx.planes_download(pp, 0)[border:border + H, border:border + W]
+            want = oracle.build_inter_pred(rb, border, W, H, bw, bh, blocks, mv, fx, fy, bd)
+            assert np.array_equal(got, want), (bw, bh, bd, fx, fy)
+        if (bw, bh) == (16, 16):
+            # integer MVs: the interpolating path equals the full-pel gather
+            mvi = (mv >> 3).astype(np.int16)
+            d_i, d_i8 = ctx.to_device(mvi), ctx.to_device((mvi * 8).astype(np.int16))
+            ctx.build_pred_fullpel(pr, 1, pp, 0, bw, bh, d_b, d_i, n)
+            a = ctx.planes_download(pp, 0).copy()
+            ctx.build_inter_pred_batch(pr, 1, pp, 0, bw, bh, d_b, d_i8, n, 2, 1)
+            assert np.array_equal(a, ctx.planes_download(pp, 0))
+            ctx.free(d_i); ctx.free(d_i8)
+        ctx.free(d_b); ctx.free(d_mv)
+    ctx.planes_free(pr); ctx.planes_free(pp)
+
+
+def test_inter_pred_rejects_bad_arguments(hip, ctx):
+    K = hip.capi
+    pr, pp = ctx.planes_alloc(64, 64, 32, 8, 1), ctx.planes_alloc(64, 64, 32, 8, 1)
+    small = ctx.planes_alloc(64, 64, 4, 8, 1)
+    p10 = ctx.planes_alloc(64, 64, 32, 10, 1)
+    d = ctx.malloc(64)
+    with pytest.raises(K.AomHipError):
+        ctx.build_inter_pred_batch(pr, 0, pp, 0, 16, 16, d, d, 1, 4, 0)      # MULTITAP_SHARP2 is not served
+    with pytest.raises(K.AomHipError):
+        ctx.build_inter_pred_batch(pr, 0, pp, 0, 16, 12, d, d, 1, 0, 0)      # not a block size
+    with pytest.raises(K.AomHipError):
+        ctx.build_inter_pred_batch(small, 0, pp, 0, 16, 16, d, d, 1, 0, 0)   # border too small for 8 taps
+    with pytest.raises(K.AomHipError):
+        ctx.build_inter_pred_batch(pr, 0, p10, 0, 16, 16, d, d, 1, 0, 0)     # bit depths differ
+    with pytest.raises(K.AomHipError):
+        ctx.build_inter_pred_batch(pr, 1, pp, 0, 16, 16, d, d, 1, 0, 0)      # no such frame
+    ctx.build_inter_pred_batch(pr, 0, pp, 0, 16, 16, None, None, 0, 0, 0)    # empty list
+    ctx.free(d)
+    for p in (pr, pp, small, p10):
+        ctx.planes_free(p)
