@@ -19,23 +19,44 @@ __device__ const int16_t kInterp[6][16][8] __attribute__((aligned(16))) = {
 struct __attribute__((packed, aligned(1))) PU128 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(1))) PU64 { uint32_t v[2]; };
 
-// 8 consecutive pixels from an arbitrarily aligned address with one wide load
-template <typename T> __device__ __forceinline__ void load8(const T *p, int (&out)[8]) {
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// acc + a.lo * b.lo + a.hi * b.hi on packed signed 16-bit pairs (v_dot2c_i32_i16)
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), acc, false);
+}
+
+struct __attribute__((aligned(4))) PA128 { uint32_t v[4]; };
+struct __attribute__((aligned(4))) PA64 { uint32_t v[2]; };
+
+// 8 consecutive pixels from an arbitrarily aligned address as four (even, odd) 16-bit pairs.  The loads themselves are
+// DWORD-ALIGNED (the enclosing dwords, one more than the pixels need) and the sub-dword offset is taken out with
+// v_alignbit: a 16-byte load from a 2-byte-aligned address runs at half rate on gfx950 (measured: 26.7 us -> 13.6 us per 4K
+// frame for this kernel with the address rounded down, profiles/r01_inter_pred.md), dword alignment is enough for full rate.
+template <typename T> __device__ __forceinline__ void load8_pairs(const T *p, uint32_t (&out)[4]) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  const uint32_t sh = (uint32_t)(a & 3) * 8;
   if constexpr (sizeof(T) == 1) {
-    const PU64 raw = *reinterpret_cast<const PU64 *>(p);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = (raw.v[i / 4] >> (8 * (i % 4))) & 0xFF;
+    const PA64 lo = *reinterpret_cast<const PA64 *>(a & ~(uintptr_t)3);
+    const uint32_t hi = *reinterpret_cast<const uint32_t *>((a & ~(uintptr_t)3) + 8);
+    const uint32_t r0 = __builtin_amdgcn_alignbit(lo.v[1], lo.v[0], sh), r1 = __builtin_amdgcn_alignbit(hi, lo.v[1], sh);
+    out[0] = __builtin_amdgcn_perm(0, r0, 0x0c010c00);
+    out[1] = __builtin_amdgcn_perm(0, r0, 0x0c030c02);
+    out[2] = __builtin_amdgcn_perm(0, r1, 0x0c010c00);
+    out[3] = __builtin_amdgcn_perm(0, r1, 0x0c030c02);
   } else {
-    const PU128 raw = *reinterpret_cast<const PU128 *>(p);
+    const PA128 lo = *reinterpret_cast<const PA128 *>(a & ~(uintptr_t)3);
+    const uint32_t hi = *reinterpret_cast<const uint32_t *>((a & ~(uintptr_t)3) + 16);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = (raw.v[i / 2] >> (16 * (i % 2))) & 0xFFFF;
+    for (int i = 0; i < 3; ++i) out[i] = __builtin_amdgcn_alignbit(lo.v[i + 1], lo.v[i], sh);
+    out[3] = __builtin_amdgcn_alignbit(hi, lo.v[3], sh);
   }
 }
 
-// One LANE owns one column of one block and walks down its H + 7 input rows: per row one unaligned 8-pixel load and
+// One LANE owns one column of one block and walks down its H + 7 input rows: per row one 8-pixel load (load8_pairs) and
 // the horizontal 8-tap (av1_convolve_2d_sr_c's first loop, convolve.c:92-106), the last 8 intermediates stay in
 // registers, and from row 7 on the vertical 8-tap + the two rounding stages + clip produce one output pixel per row
-// (:108-125).  A wavefront therefore holds 64 / W blocks side by side (W <= 64; two column passes for W = 128), every
+// (:108-125).  Pixels, intermediates and taps travel as packed 16-bit pairs, so each 8-tap is four v_dot2c_i32_i16.
+// A wavefront therefore holds 64 / W blocks side by side (W <= 64; two column passes for W = 128), every
 // global access is a run of W adjacent pixels, and nothing goes through LDS or scratch.
 // The facade's other three cases need no code of their own: with round_0 + round_1 == 14 (non-compound,
 // convolve.h:72-81) the 2-D pipeline with an identity kernel (phase 0 = {0,0,0,128,0,0,0,0}) in one direction is
@@ -66,40 +87,32 @@ __global__ __launch_bounds__(256) void inter_pred_kernel(PlaneView<T> ref, int r
   const int voff = (1 << ob) + ((1 << r1) >> 1);
   const int vsub = (1 << (ob - r1)) + (1 << (ob - r1 - 1));
   const int pmax = (1 << tbd) - 1;
-  int fx[8], fy[8];
-  {
-    const PU128 a = *reinterpret_cast<const PU128 *>(&kInterp[set_x][pos_x & 15][0]);
-    const PU128 b = *reinterpret_cast<const PU128 *>(&kInterp[set_y][pos_y & 15][0]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      fx[i] = (int16_t)(a.v[i / 2] >> (16 * (i % 2)));
-      fy[i] = (int16_t)(b.v[i / 2] >> (16 * (i % 2)));
-    }
-  }
+  // the kernels as four (tap 2k, tap 2k + 1) pairs each: exactly the table's memory layout
+  const PU128 fx = *reinterpret_cast<const PU128 *>(&kInterp[set_x][pos_x & 15][0]);
+  const PU128 fy = *reinterpret_cast<const PU128 *>(&kInterp[set_y][pos_y & 15][0]);
   const T *base = ref.origin + (int64_t)ref_frame * ref.frame_stride + (int64_t)((pos_y >> 4) - 3) * ref.stride + (pos_x >> 4) - 3;
   T *dbase = dst_origin + (int64_t)by * dst_stride + bx;
 #pragma unroll 1
   for (int col = col0; col < W; col += 64) {
     const T *p = base + col;
     T *d = dbase + col;
-    int win[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) win[i] = 0;
+    // the last 8 intermediates as four 16-bit pairs (they fit 15 bits: convolve.h:76-81 sizes round_0 for that)
+    uint32_t win[4] = { 0, 0, 0, 0 };
 #pragma unroll 8
     for (int r = 0; r < H + 7; ++r) {
-      int px[8];
-      load8<T>(p, px);
+      uint32_t px[4];
+      load8_pairs<T>(p, px);
       p += ref.stride;
       int hs = hoff;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) hs += fx[k] * px[k];
+      for (int k = 0; k < 4; ++k) hs = dot2(px[k], fx.v[k], hs);
 #pragma unroll
-      for (int k = 0; k < 7; ++k) win[k] = win[k + 1];
-      win[7] = hs >> r0;
+      for (int k = 0; k < 3; ++k) win[k] = __builtin_amdgcn_alignbit(win[k + 1], win[k], 16);
+      win[3] = __builtin_amdgcn_alignbit((uint32_t)(hs >> r0), win[3], 16);
       if (r >= 7) {
         int vs = voff;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) vs += fy[k] * win[k];
+        for (int k = 0; k < 4; ++k) vs = dot2(win[k], fy.v[k], vs);
         int res = (vs >> r1) - vsub;
         if constexpr (sizeof(T) == 1) res = (int16_t)res;  // convolve.c:119 keeps it in an int16_t
         // bits = 14 - round_0 - round_1 == 0: ROUND_POWER_OF_TWO(res, 0) is res

@@ -484,7 +484,7 @@ def run_search(pkg, ctx, dist, dev, rank, world, orc, steps, warmup):
 def run_inner_loop(pkg, ctx, orc, steps, warmup):
     """BASELINE.json configs[4] on one GPU: the whole 4K 10-bit encode inner loop per frame, every stage on the
     device and chained through HBM: full-pel diamond search + bilinear sub-pel refinement (16x16 blocks) ->
-    full-pel motion-compensated prediction -> subtract + fwd_txfm2d 16x16 + quantize_b (qindex 100) ->
+    motion-compensated prediction at the sub-pel MV (8-tap interpolation) -> subtract + fwd_txfm2d 16x16 + quantize_b (qindex 100) ->
     inverse transform + reconstruction -> deblocking (every 8x8 edge, level 32) -> CDEF (pri 4, sec 2, damping 6)."""
     sp = SearchPipeline(pkg, ctx, None, 0, 1, frames=2)
     W, H, bd, border, F = sp.W, sp.H, sp.BD, sp.BORDER, sp.F
@@ -511,7 +511,7 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
         ctx.fullpel_diamond_batch(sp.src, sp.ref, f, 16, 16, 0, 4, capi.MV_COST_L1_HDRES, sp.d_blocks, n, sp.d_mv, sp.d_cost)
         ctx.subpel_bilinear_batch(sp.src, sp.ref, f, 16, 16, capi.MV_COST_L1_HDRES, 2, 1, 0, sp.d_sub_blocks(f), n,
                                   sp.d_smv, sp.d_err, sp.d_dist, sp.d_sse)
-        ctx.build_pred_fullpel(sp.ref, f, pred, f, 16, 16, sp.d_blocks, sp.d_mv, n)
+        ctx.build_inter_pred_batch(sp.ref, f, pred, f, 16, 16, sp.d_blocks, sp.d_smv, n, 0, 0)   # EIGHTTAP_REGULAR both ways
         # grid mode: block i of the plane == block i of the raster list used above
         ctx.subtract_xform_quant_batch(sp.src, pred, f, 2, None, n, W // 16, 0, qp, None, d_q, d_dq, d_e)
         ctx.inv_txfm_add_batch(d_dq, 2, None, n, W // 16, 0, d_e, pred, f)
@@ -539,13 +539,13 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
     stage_fns = {
         "fullpel_diamond": lambda: ctx.fullpel_diamond_batch(sp.src, sp.ref, f0, 16, 16, 0, 4, capi.MV_COST_L1_HDRES, sp.d_blocks, n, sp.d_mv, sp.d_cost),
         "subpel_bilinear": lambda: ctx.subpel_bilinear_batch(sp.src, sp.ref, f0, 16, 16, capi.MV_COST_L1_HDRES, 2, 1, 0, sp.d_sub_blocks(f0), n, sp.d_smv, sp.d_err, sp.d_dist, sp.d_sse),
-        "pred_fullpel": lambda: ctx.build_pred_fullpel(sp.ref, f0, pred, f0, 16, 16, sp.d_blocks, sp.d_mv, n),
+        "inter_pred_8tap": lambda: ctx.build_inter_pred_batch(sp.ref, f0, pred, f0, 16, 16, sp.d_blocks, sp.d_smv, n, 0, 0),
         "subtract_xform_quant_16x16": lambda: ctx.subtract_xform_quant_batch(sp.src, pred, f0, 2, None, n, W // 16, 0, qp, None, d_q, d_dq, d_e),
         "inv_txfm_add_16x16": lambda: ctx.inv_txfm_add_batch(d_dq, 2, None, n, W // 16, 0, d_e, pred, f0),
         "deblock_vert+horz": lambda: ctx.deblock_plane(pred, f0, d_params, W // 4, 0, 3),
         "cdef_luma": lambda: ctx.cdef_luma_plane(pred, f0, out, 0, d_pri, d_sec, fbw, d_skip, 6),
     }
-    stage_bytes = {"pred_fullpel": 2 * px_bytes, "subtract_xform_quant_16x16": 2 * px_bytes + n * (256 * 8 + 2),
+    stage_bytes = {"inter_pred_8tap": 2 * px_bytes, "subtract_xform_quant_16x16": 2 * px_bytes + n * (256 * 8 + 2),
                    "inv_txfm_add_16x16": n * 256 * 4 + 2 * px_bytes, "deblock_vert+horz": 2 * 2 * px_bytes, "cdef_luma": 2 * px_bytes}
     stages = {}
     for name, fn in stage_fns.items():
@@ -557,8 +557,8 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
     return {"workload": "encode_inner_loop_4k_10bit", "value": steps / wall, "unit": "frames/s",
             "ms_per_frame": wall / steps * 1e3, "event_ms_per_frame": ev_ms / steps, "blocks_per_frame": n,
             "recon_psnr_db_last_frame": float(psnr), "stages": stages,
-            "config": {"frame": "3840x2160 10-bit luma", "stages": "fullpel diamond + subpel bilinear (16x16) -> fullpel pred "
-                       "-> subtract+fwd_txfm2d_16x16+quantize_b q100 -> inv_txfm_add -> deblock (8x8 edges, level 32) -> "
+            "config": {"frame": "3840x2160 10-bit luma", "stages": "fullpel diamond + subpel bilinear (16x16) -> inter prediction at the "
+                       "sub-pel MV (8-tap regular, av1_highbd_convolve_2d_sr) -> subtract+fwd_txfm2d_16x16+quantize_b q100 -> inv_txfm_add -> deblock (8x8 edges, level 32) -> "
                        "CDEF (pri 4, sec 2, damping 6)", "gpus": 1}}
 
 
