@@ -36,6 +36,40 @@ struct CostCtx {
   }
 };
 
+#ifndef AOMHIP_SEARCH_ALIGNED_LOADS
+#define AOMHIP_SEARCH_ALIGNED_LOADS 0
+#endif
+struct __attribute__((aligned(4))) AU128 { uint32_t v[4]; };
+struct __attribute__((aligned(4))) AU64 { uint32_t v[2]; };
+// One row unit from an arbitrarily aligned address through DWORD-ALIGNED loads of the enclosing dwords + v_alignbit
+// (a 16-byte global load from an address that is not dword-aligned runs at half rate, profiles/r01_inter_pred.md).
+template <typename L> __device__ __forceinline__ L load_unit(const void *p) {
+#if AOMHIP_SEARCH_ALIGNED_LOADS
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  const uintptr_t a4 = a & ~(uintptr_t)3;
+  const uint32_t sh = (uint32_t)(a & 3) * 8;
+  L out;
+  if constexpr (sizeof(L) == 16) {
+    const AU128 lo = *reinterpret_cast<const AU128 *>(a4);
+    const uint32_t hi = *reinterpret_cast<const uint32_t *>(a4 + 16);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out.v[i] = __builtin_amdgcn_alignbit(lo.v[i + 1], lo.v[i], sh);
+    out.v[3] = __builtin_amdgcn_alignbit(hi, lo.v[3], sh);
+  } else if constexpr (sizeof(L) == 8) {
+    const AU64 lo = *reinterpret_cast<const AU64 *>(a4);
+    const uint32_t hi = *reinterpret_cast<const uint32_t *>(a4 + 8);
+    out.v[0] = __builtin_amdgcn_alignbit(lo.v[1], lo.v[0], sh);
+    out.v[1] = __builtin_amdgcn_alignbit(hi, lo.v[1], sh);
+  } else {
+    const AU64 lo = *reinterpret_cast<const AU64 *>(a4);
+    out.v[0] = __builtin_amdgcn_alignbit(lo.v[1], lo.v[0], sh);
+  }
+  return out;
+#else
+  return *reinterpret_cast<const L *>(p);
+#endif
+}
+
 template <typename T> __device__ __forceinline__ uint32_t sadw(uint32_t a, uint32_t b, uint32_t acc) {
   if constexpr (sizeof(T) == 1) return __builtin_amdgcn_sad_u8(a, b, acc);
   else return __builtin_amdgcn_sad_u16(a, b, acc);
@@ -81,7 +115,7 @@ __device__ __forceinline__ uint32_t group8_sad(const T *sp, int sstride, const T
         const int u = l + 8 * k;
         if (u < G::U) {
           const int row = u / G::UPR, col = (u % G::UPR) * G::UE;
-          const L b = *reinterpret_cast<const L *>(rp + (int64_t)row * rstride + col);
+          const L b = load_unit<L>(rp + (int64_t)row * rstride + col);
 #pragma unroll
           for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(s[k].v[i], b.v[i], acc);
         }
