@@ -156,6 +156,9 @@ _protos = {
     "aomhip_subpel_tree_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_bind_variance_vtable": (C.c_int, [_vp, _i]),
     "aomhip_build_inter_pred_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i, _i, _i]),
+    "aomhip_sse_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp]),
+    "aomhip_hadamard_batch": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "aomhip_txb_init_levels_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
@@ -366,6 +369,15 @@ class Context:
     def build_inter_pred_batch(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, filter_x=0, filter_y=0):
         check(lib.aomhip_build_inter_pred_batch(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks, d_mv, n_blocks,
                                                 filter_x, filter_y), "aomhip_build_inter_pred_batch")
+
+    def sse_batch(self, a, b, frame, w, h, d_cands, n, d_out):
+        check(lib.aomhip_sse_batch(self.h, C.byref(a), C.byref(b), frame, w, h, d_cands, n, d_out), "aomhip_sse_batch")
+
+    def hadamard_batch(self, d_res, stride, n, flavour, d_blocks, n_blocks, d_coeff=None, d_satd=None):
+        check(lib.aomhip_hadamard_batch(self.h, d_res, stride, n, flavour, d_blocks, n_blocks, d_coeff, d_satd), "aomhip_hadamard_batch")
+
+    def txb_init_levels_batch(self, d_coeff, w, h, d_off, n_blocks, d_levels, pitch):
+        check(lib.aomhip_txb_init_levels_batch(self.h, d_coeff, w, h, d_off, n_blocks, d_levels, pitch), "aomhip_txb_init_levels_batch")
 
     def build_pred_fullpel(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n):
         check(lib.aomhip_build_pred_fullpel(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks,

@@ -581,6 +581,33 @@ int aomhip_build_inter_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int
                                   int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv,
                                   int n_blocks, int interp_filter_x, int interp_filter_y);
 
+/* ------------------------------------------------------------------ RD helpers, batched */
+
+/* aom_sse / aom_highbd_sse (aom_dsp/sse.c:19-53): sum of squared differences of the width x height block (any size up
+ * to 128 x 128, not only BLOCK_SIZEs) of plane ring `a` at (sx, sy) against `b` at (rx, ry), 64-bit, no rounding. */
+int aomhip_sse_batch(aomhip_ctx *ctx, const aomhip_planes *a, const aomhip_planes *b, int frame, int width, int height,
+                     const aomhip_sad_cand *d_cands, int n_cands, int64_t *d_out);
+
+/* The Hadamard family + SATD (aom_dsp/avg.c:110-533) over a list of n x n blocks of an int16 residual plane:
+ *   AOMHIP_HADAMARD         aom_hadamard_{4x4,8x8,16x16,32x32}       -> tran_low_t (int32) coefficients, aom_satd
+ *   AOMHIP_HADAMARD_LP      aom_hadamard_lp_{8x8,16x16}              -> int16 coefficients, aom_satd_lp
+ *   AOMHIP_HADAMARD_HIGHBD  aom_highbd_hadamard_{8x8,16x16,32x32}    -> tran_low_t, aom_satd
+ * with the reference's coefficient order (the SSE2 transpose of the 8x8 forms, the AVX2 column swap of the 16x16 form)
+ * and its int16 wrap-around.  Block i is at (x, y) of aomhip_txb, its n * n coefficients go to d_coeff + out_offset
+ * (elements; d_coeff may be NULL), its SATD to d_satd[i] (may be NULL); tx_type is ignored. */
+#define AOMHIP_HADAMARD 0
+#define AOMHIP_HADAMARD_LP 1
+#define AOMHIP_HADAMARD_HIGHBD 2
+int aomhip_hadamard_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int n, int flavour, const aomhip_txb *d_blocks,
+                          int n_blocks, void *d_coeff, int32_t *d_satd);
+
+/* av1_txb_init_levels (av1/encoder/encodetxb.c:238-254): levels[i * (height + TX_PAD_HOR) + j] = min(|coeff[i * height + j]|, 127),
+ * zero padding columns, TX_PAD_BOTTOM rows and TX_PAD_END bytes (av1/common/enums.h:191-199).  Block i reads width * height
+ * coefficients at d_coeff + d_coeff_offset[i] (NULL: i * width * height) and writes (height + 4) * (width + 4) + 16 bytes at
+ * d_levels + i * levels_pitch. */
+int aomhip_txb_init_levels_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int width, int height, const uint32_t *d_coeff_offset, int n_blocks,
+                                 uint8_t *d_levels, int64_t levels_pitch);
+
 /* ------------------------------------------------------------------ rtcd-signature conformance entry points */
 
 /* aom_dsp_rtcd_defs.pl:762-763 aom_sad{W}x{H} / aom_sad_skip_{W}x{H}; host pointers. */

@@ -1,0 +1,118 @@
+/*
+ * oracle/aomref_rdhelp.c -- the RD helpers of SURVEY 8(f)-3: aom_sse / aom_highbd_sse (aom_dsp/sse.c:19-53), the
+ * Hadamard family aom_hadamard_{4x4,8x8,16x16,32x32}, aom_hadamard_lp_{8x8,16x16}, aom_highbd_hadamard_{8x8,16x16,32x32}
+ * (aom_dsp/avg.c:110-514), aom_satd / aom_satd_lp (:517-533) and av1_txb_init_levels (av1/encoder/encodetxb.c:238-254).
+ *
+ * TEST INFRASTRUCTURE ONLY (see aomref.h).  Pinned by tests/golden/ref_eval_rdhelp.npz (the reference's own functions,
+ * interpreted where they lie).  The restatement is recursive over the block size instead of the reference's three
+ * hand-unrolled levels; every intermediate keeps the reference's storage width (int16_t wrap-around where the
+ * reference computes in int16_t).
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "aomref.h"
+
+int64_t orc_sse(const void *a, int a_stride, const void *b, int b_stride, int w, int h, int elem16) {
+  int64_t sse = 0;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const int d = elem16 ? (int)((const uint16_t *)a)[(ptrdiff_t)y * a_stride + x] - (int)((const uint16_t *)b)[(ptrdiff_t)y * b_stride + x]
+                           : (int)((const uint8_t *)a)[(ptrdiff_t)y * a_stride + x] - (int)((const uint8_t *)b)[(ptrdiff_t)y * b_stride + x];
+      sse += d * d;
+    }
+  return sse;
+}
+
+/* hadamard_col8 (avg.c:155-183) on 8 values; WIDE keeps 32 bits (hadamard_highbd_col8_second_pass, :391-422) */
+static void col8(const int32_t in[8], int32_t out[8], int wide) {
+#define W16(v) (wide ? (int32_t)(v) : (int32_t)(int16_t)(v))
+  const int32_t b0 = W16(in[0] + in[1]), b1 = W16(in[0] - in[1]), b2 = W16(in[2] + in[3]), b3 = W16(in[2] - in[3]);
+  const int32_t b4 = W16(in[4] + in[5]), b5 = W16(in[4] - in[5]), b6 = W16(in[6] + in[7]), b7 = W16(in[6] - in[7]);
+  const int32_t c0 = W16(b0 + b2), c1 = W16(b1 + b3), c2 = W16(b0 - b2), c3 = W16(b1 - b3);
+  const int32_t c4 = W16(b4 + b6), c5 = W16(b5 + b7), c6 = W16(b4 - b6), c7 = W16(b5 - b7);
+  out[0] = W16(c0 + c4); out[7] = W16(c1 + c5); out[3] = W16(c2 + c6); out[4] = W16(c3 + c7);
+  out[2] = W16(c0 - c4); out[6] = W16(c1 - c5); out[1] = W16(c2 - c6); out[5] = W16(c3 - c7);
+#undef W16
+}
+
+/* flavour 0: aom_hadamard_NxN (tran_low_t out), 1: aom_hadamard_lp_NxN (int16 out), 2: aom_highbd_hadamard_NxN */
+static void had8(const int16_t *src, ptrdiff_t stride, int32_t *coeff, int flavour) {
+  int32_t buf[64], buf2[64], in[8];
+  for (int c = 0; c < 8; ++c) {
+    for (int r = 0; r < 8; ++r) in[r] = src[r * stride + c];
+    col8(in, buf + c * 8, 0);
+  }
+  for (int c = 0; c < 8; ++c) {
+    for (int r = 0; r < 8; ++r) in[r] = buf[r * 8 + c];
+    col8(in, buf2 + c * 8, flavour == 2);
+  }
+  if (flavour == 2) {
+    memcpy(coeff, buf2, sizeof(buf2));
+  } else { /* the transpose that matches the SSE2 output order (avg.c:207-212,237-243) */
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 8; ++j) coeff[i * 8 + j] = buf2[j * 8 + i];
+  }
+}
+
+static void had_rec(const int16_t *src, ptrdiff_t stride, int32_t *coeff, int n, int flavour) {
+  if (n == 8) {
+    had8(src, stride, coeff, flavour);
+    return;
+  }
+  const int half = n / 2, q = half * half, sh = n == 16 ? 1 : 2;
+  for (int idx = 0; idx < 4; ++idx) had_rec(src + (idx >> 1) * half * stride + (idx & 1) * half, stride, coeff + idx * q, half, flavour);
+  for (int i = 0; i < q; ++i) {
+    const int32_t a0 = coeff[i], a1 = coeff[i + q], a2 = coeff[i + 2 * q], a3 = coeff[i + 3 * q];
+    int32_t b0 = (a0 + a1) >> sh, b1 = (a0 - a1) >> sh, b2 = (a2 + a3) >> sh, b3 = (a2 - a3) >> sh;
+    if (flavour == 1) { b0 = (int16_t)b0; b1 = (int16_t)b1; b2 = (int16_t)b2; b3 = (int16_t)b3; }
+    coeff[i] = b0 + b2; coeff[i + q] = b1 + b3; coeff[i + 2 * q] = b0 - b2; coeff[i + 3 * q] = b1 - b3;
+    if (flavour == 1) for (int k = 0; k < 4; ++k) coeff[i + k * q] = (int16_t)coeff[i + k * q];
+  }
+  if (n == 16 && flavour == 0) /* "extra shift to match AVX2 output" (avg.c:285-294) */
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const int32_t t = coeff[i * 16 + 4 + j];
+        coeff[i * 16 + 4 + j] = coeff[i * 16 + 8 + j];
+        coeff[i * 16 + 8 + j] = t;
+      }
+}
+
+/* n = 4 (flavour 0 only), 8, 16, 32 (flavours 0 and 2; lp: 8 and 16).  coeff: n * n int32 (lp values are int16-ranged).
+ * Returns aom_satd / aom_satd_lp of the result. */
+int orc_hadamard(const int16_t *src, ptrdiff_t stride, int n, int flavour, int32_t *coeff) {
+  if (n == 4) { /* aom_hadamard_4x4_c (avg.c:110-153): both passes halve after the first butterfly */
+    int32_t buf[16], buf2[16];
+    for (int pass = 0; pass < 2; ++pass)
+      for (int c = 0; c < 4; ++c) {
+        int32_t v[4];
+        for (int r = 0; r < 4; ++r) v[r] = pass ? buf[r * 4 + c] : src[r * stride + c];
+        const int32_t b0 = (int16_t)((v[0] + v[1]) >> 1), b1 = (int16_t)((v[0] - v[1]) >> 1);
+        const int32_t b2 = (int16_t)((v[2] + v[3]) >> 1), b3 = (int16_t)((v[2] - v[3]) >> 1);
+        int32_t *o = (pass ? buf2 : buf) + c * 4;
+        o[0] = (int16_t)(b0 + b2); o[1] = (int16_t)(b1 + b3); o[2] = (int16_t)(b0 - b2); o[3] = (int16_t)(b1 - b3);
+      }
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) coeff[i * 4 + j] = buf2[j * 4 + i];
+  } else {
+    had_rec(src, stride, coeff, n, flavour);
+  }
+  int satd = 0;
+  for (int i = 0; i < n * n; ++i) satd += abs(coeff[i]);
+  return satd;
+}
+
+/* av1_txb_init_levels_c (encodetxb.c:238-254): TX_PAD_HOR 4, TX_PAD_BOTTOM 4, TX_PAD_END 16 (av1/common/enums.h:191-199).
+ * levels: (height + 4) * (width + 4) + 16 bytes. */
+void orc_txb_init_levels(const int32_t *coeff, int width, int height, uint8_t *levels) {
+  const int stride = height + 4;
+  uint8_t *ls = levels;
+  memset(levels + stride * width, 0, (size_t)(4 * stride + 16));
+  for (int i = 0; i < width; ++i) {
+    for (int j = 0; j < height; ++j) {
+      const int a = abs(coeff[i * height + j]);
+      *ls++ = (uint8_t)(a > 127 ? 127 : a);
+    }
+    for (int j = 0; j < 4; ++j) *ls++ = 0;
+  }
+}

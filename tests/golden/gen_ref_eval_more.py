@@ -338,8 +338,59 @@ def gen_convolve():
                     k += 1
     save("ref_eval_convolve.npz", arrays, cases)
 
+
+def gen_rdhelp():
+    """aom_[highbd_]sse_c, the Hadamard family + aom_satd[_lp]_c (aom_dsp/avg.c), av1_txb_init_levels_c (av1/encoder/encodetxb.c)."""
+    ev = evaluator(["aom_dsp/sse.c", "aom_dsp/avg.c", "av1/common/txb_common.h", "av1/encoder/encodetxb.c"])
+    rng = np.random.default_rng(20261017)
+    arrays, cases = {}, []
+    k = 0
+    # sse: odd sizes too (the function takes any width x height)
+    for bd in (8, 12):
+        mx = (1 << bd) - 1
+        S = 80
+        a, b = rng.integers(0, mx + 1, (70, S)), rng.integers(0, mx + 1, (70, S))
+        arrays["sa%d" % bd], arrays["sb%d" % bd] = a.astype(np.uint16), b.astype(np.uint16)
+        ct = "uint8_t" if bd == 8 else "uint16_t"
+        pa, pb = ev.array(a.ravel(), ct), ev.array(b.ravel(), ct)
+        for (w, h) in ((4, 4), (8, 8), (16, 16), (64, 64), (5, 7), (12, 3), (33, 17), (64, 1)):
+            ox, oy = int(rng.integers(0, S - w)), int(rng.integers(0, 70 - h))
+            v = ev.call("aom_sse_c" if bd == 8 else "aom_highbd_sse_c", pa.add(oy * S + ox), S, pb.add(3 * S + 2), S, w, h)
+            cases.append({"kind": "sse", "bd": bd, "w": w, "h": h, "ox": ox, "oy": oy, "value": int(v)})
+    # hadamard: residuals of 8-bit range for the plain / lp forms (their int16 arithmetic is sized for that), 12-bit range for highbd,
+    # plus one full-range int16 input per flavour so that the wrap-around of the 16-bit intermediates is pinned too
+    S = 40
+    for flavour, name, sizes, rngbits in ((0, "aom_hadamard_%dx%d_c", (4, 8, 16, 32), 8), (1, "aom_hadamard_lp_%dx%d_c", (8, 16), 8),
+                                          (2, "aom_highbd_hadamard_%dx%d_c", (8, 16, 32), 12)):
+        for n in sizes:
+            for trial in range(3):
+                lim = (1 << rngbits) - 1 if trial < 2 else 32767
+                res = rng.integers(-lim, lim + 1, (n + 3, S))
+                if trial == 1:
+                    res[:] = np.where(rng.integers(0, 2, res.shape) > 0, lim, -lim)
+                arrays["r%d" % k] = res.astype(np.int16)
+                R_ = ev.array(res.ravel(), "int16_t")
+                out = ev.array([0] * (n * n), "int16_t" if flavour == 1 else "tran_low_t")
+                ev.call(name % (n, n), R_.add(2 * S + 3), S, out)
+                satd = ev.call("aom_satd_lp_c" if flavour == 1 else "aom_satd_c", out, n * n)
+                arrays["c%d" % k] = np.asarray(out.buf, np.int32)
+                cases.append({"kind": "hadamard", "k": k, "n": n, "flavour": flavour, "x": 3, "y": 2, "satd": int(satd), "wide_input": int(trial == 2)})
+                k += 1
+    # txb_init_levels
+    for (w, h) in ((4, 4), (8, 8), (16, 16), (32, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 32)):
+        coeff = rng.integers(-300, 301, w * h)
+        coeff[rng.integers(0, w * h, 5)] = (-70000, 127, -128, 128, 0)
+        Cf = ev.array(coeff, "tran_low_t")
+        size = (h + 4) * (w + 4) + 16
+        lv = ev.array([0xAA] * size, "uint8_t")
+        ev.call("av1_txb_init_levels_c", Cf, w, h, lv)
+        arrays["tc%d" % k], arrays["tl%d" % k] = coeff.astype(np.int32), np.asarray(lv.buf, np.uint8)
+        cases.append({"kind": "levels", "k": k, "w": w, "h": h})
+        k += 1
+    save("ref_eval_rdhelp.npz", arrays, cases)
+
 if __name__ == "__main__":
-    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound", "convolve"]:
+    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound", "convolve", "rdhelp"]:
         t = time.time()
         globals()["gen_" + w]()
         print("  (%s: %.1f s)" % (w, time.time() - t))

@@ -418,3 +418,40 @@ def test_convolve_sr_matches_reference_evaluation(oracle):
         assert np.array_equal(dst.ravel(), z["d%d" % c["k"]]), c
         kinds.add((bool(c["sx"]), bool(c["sy"])))
     assert len(kinds) == 4
+
+
+def test_rd_helpers_match_reference_evaluation(oracle):
+    """orc_sse, orc_hadamard (+ satd) and orc_txb_init_levels against the interpreted aom_[highbd_]sse_c, aom_hadamard_*_c /
+    aom_hadamard_lp_*_c / aom_highbd_hadamard_*_c + aom_satd[_lp]_c (aom_dsp/sse.c, aom_dsp/avg.c) and av1_txb_init_levels_c
+    (av1/encoder/encodetxb.c), including full-range int16 residuals that wrap the 16-bit intermediates."""
+    z, cases = load("ref_eval_rdhelp.npz")
+    lib = oracle.lib
+    lib.orc_sse.restype = C.c_int64
+    lib.orc_hadamard.restype = C.c_int
+    lib.orc_txb_init_levels.restype = None
+    seen = set()
+    for c in cases:
+        seen.add(c["kind"])
+        if c["kind"] == "sse":
+            e16 = int(c["bd"] > 8)
+            dt = np.uint16 if e16 else np.uint8
+            a, b = np.ascontiguousarray(z["sa%d" % c["bd"]], dt), np.ascontiguousarray(z["sb%d" % c["bd"]], dt)
+            S = a.shape[1]
+            got = lib.orc_sse(C.c_void_p(a.ctypes.data + (c["oy"] * S + c["ox"]) * a.itemsize), S, C.c_void_p(b.ctypes.data + (3 * S + 2) * b.itemsize), S,
+                              c["w"], c["h"], e16)
+            assert got == c["value"], c
+        elif c["kind"] == "hadamard":
+            r = np.ascontiguousarray(z["r%d" % c["k"]])
+            n = c["n"]
+            out = np.zeros(n * n, np.int32)
+            satd = lib.orc_hadamard(C.c_void_p(r.ctypes.data + (c["y"] * r.shape[1] + c["x"]) * 2), C.c_ssize_t(r.shape[1]), n, c["flavour"],
+                                    C.c_void_p(out.ctypes.data))
+            assert np.array_equal(out, z["c%d" % c["k"]]), c
+            assert satd == c["satd"], c
+        else:
+            coeff = np.ascontiguousarray(z["tc%d" % c["k"]])
+            want = z["tl%d" % c["k"]]
+            lv = np.full(want.size, 0xAA, np.uint8)
+            lib.orc_txb_init_levels(C.c_void_p(coeff.ctypes.data), c["w"], c["h"], C.c_void_p(lv.ctypes.data))
+            assert np.array_equal(lv, want), c
+    assert seen == {"sse", "hadamard", "levels"}
