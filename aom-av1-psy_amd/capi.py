@@ -159,6 +159,7 @@ _protos = {
     "aomhip_sse_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_hadamard_batch": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_txb_init_levels_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64]),
+    "aomhip_cdef_search_sse_luma": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
@@ -378,6 +379,11 @@ class Context:
 
     def txb_init_levels_batch(self, d_coeff, w, h, d_off, n_blocks, d_levels, pitch):
         check(lib.aomhip_txb_init_levels_batch(self.h, d_coeff, w, h, d_off, n_blocks, d_levels, pitch), "aomhip_txb_init_levels_batch")
+
+    def cdef_search_sse_luma(self, recon, recon_frame, source, source_frame, d_strengths, n, d_skip, damping, fb_stride, d_sse,
+                             d_dir=None, d_var=None):
+        check(lib.aomhip_cdef_search_sse_luma(self.h, C.byref(recon), recon_frame, C.byref(source), source_frame, d_strengths, n, d_skip,
+                                              damping, fb_stride, d_sse, d_dir, d_var), "aomhip_cdef_search_sse_luma")
 
     def build_pred_fullpel(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n):
         check(lib.aomhip_build_pred_fullpel(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks,

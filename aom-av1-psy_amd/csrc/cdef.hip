@@ -109,16 +109,31 @@ __device__ __forceinline__ int constrain_s(int diff, int threshold, int shift) {
   return diff < 0 ? -m : m;
 }
 
-template <typename PIX>
+// SEARCH = false: the filtering pass (dst = CDEF(src) with each filter block's strengths).
+// SEARCH = true : the distortion table of av1_cdef_search (av1/encoder/pickcdef.c:401-615 get_filt_error /
+//   av1_cdef_mse_calc_block): the footprint is staged and the directions searched ONCE, then every (pri, sec) of the
+//   strength list is applied to the filter block and the squared error against the source frame `orig` is summed over
+//   the non-skip 8x8 blocks -- nothing is written but n_strengths sums per filter block (fb_pri = the strength pairs,
+//   fb_sec unused, dst unused).
+struct CdefSearchArgs {
+  const void *orig;   // the source frame the reconstruction is compared with, pixel (0, 0), same pixel type
+  int orig_stride;
+  int n_strengths;
+  uint64_t *sse;      // [n_strengths][grid.y * fb_stride + grid.x ...] = [gi][fby * fb_stride + fbx]
+};
+
+template <typename PIX, bool SEARCH>
 __global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ src, PIX *__restrict__ dst, int stride,
                                                         int width, int height, const uint8_t *__restrict__ fb_pri,
                                                         const uint8_t *__restrict__ fb_sec, int fb_stride,
                                                         const uint8_t *__restrict__ skip, int damping, int coeff_shift,
-                                                        uint8_t *__restrict__ dir_out, int32_t *__restrict__ var_out) {
+                                                        uint8_t *__restrict__ dir_out, int32_t *__restrict__ var_out,
+                                                        CdefSearchArgs sa_) {
   __shared__ __attribute__((aligned(16))) uint16_t tile[kTH * kTW];
   __shared__ int32_t scost[8][64];
   __shared__ int8_t sdir[64];
   __shared__ int32_t svar[64];
+  __shared__ unsigned long long swave[4];
   const int fbx = blockIdx.x, fby = blockIdx.y;
   const int x0 = fbx * 64, y0 = fby * 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -155,7 +170,11 @@ __global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ 
       *reinterpret_cast<uint2 *>(&tile[gi * 4]) = make_uint2(lo, hi);
     }
   }
-  const int level = fb_pri[fby * fb_stride + fbx], sec = fb_sec[fby * fb_stride + fbx];
+  int level = 0, sec = 0;
+  if constexpr (!SEARCH) {
+    level = fb_pri[fby * fb_stride + fbx];
+    sec = fb_sec[fby * fb_stride + fbx];
+  }
   __syncthreads();
 
   // 2. direction search: lane = 8x8 block, wave w evaluates directions 2w and 2w + 1 of all 64 blocks
@@ -188,7 +207,7 @@ __global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ 
     int d = -1, var = 0;
     // (a zero-strength filter block is still searched when the caller wants the directions: its chroma strengths
     //  may be non-zero, cdef.c:334-345; filtering with zero strengths below is the identity)
-    if (gy < height && gx < width && ((level | sec) != 0 || dir_out || var_out) && !skip[(gy >> 3) * b8w + (gx >> 3)]) {
+    if (gy < height && gx < width && (SEARCH || (level | sec) != 0 || dir_out || var_out) && !skip[(gy >> 3) * b8w + (gx >> 3)]) {
       int cost[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) cost[k] = scost[k][tid];
@@ -221,7 +240,27 @@ __global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ 
   //    reference computes in.  Disabled taps contribute nothing by themselves (constrain with strength 0 is 0), so the
   //    per-block enables only select whether the final clamp applies: no divergent tap code.
   const int gx = x0 + lane;
-  if (gx >= width) return;
+  if constexpr (!SEARCH) {
+    if (gx >= width) return;
+  }
+  // SEARCH: this lane's 16 source pixels (rows 16 wave .. 16 wave + 15 of column gx) stay in registers for all strengths
+  [[maybe_unused]] int og[16];
+  if constexpr (SEARCH) {
+    const PIX *op = static_cast<const PIX *>(sa_.orig);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gy = y0 + wave * 16 + r;
+      og[r] = (gx < width && gy < height) ? (int)op[(int64_t)gy * sa_.orig_stride + gx] : 0;
+    }
+  }
+  const int n_iter = SEARCH ? sa_.n_strengths : 1;
+#pragma unroll 1
+  for (int gi = 0; gi < n_iter; ++gi) {
+  if constexpr (SEARCH) {
+    level = fb_pri[2 * gi];
+    sec = fb_pri[2 * gi + 1];
+  }
+  [[maybe_unused]] uint32_t err = 0;
   const int pri_strength = level << coeff_shift, sec_strength = sec << coeff_shift;
   const int dmp = damping + coeff_shift;
   const int sec_shift = sec_strength ? max(0, dmp - msb_u((unsigned)sec_strength)) : 0;
@@ -229,7 +268,7 @@ __global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ 
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     const int by = wave * 2 + half, bx = lane >> 3, blk = by * 8 + bx;
-    if (y0 + by * 8 >= height) break;
+    if (y0 + by * 8 >= height || gx >= width) break;
     const int d = sdir[blk];
     int t = 0;
     if (d >= 0) {  // adjust_strength (cdef_block.c:289-293)
@@ -275,11 +314,29 @@ __global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ 
           y = pmin(pmax(y, mn), mx);
         }
       }
-      PIX *o = dst + (int64_t)(y0 + ly) * stride + gx;
-      o[0] = (PIX)(uint16_t)y.x;
-      o[stride] = (PIX)(uint16_t)y.y;
+      if constexpr (SEARCH) {
+        if (d >= 0) {  // only the blocks of the filter list count (compute_cdef_dist*, pickcdef.c:237-315)
+          const int e0 = og[half * 8 + rr] - (int)y.x, e1 = og[half * 8 + rr + 1] - (int)y.y;
+          err += (uint32_t)(e0 * e0) + (uint32_t)(e1 * e1);
+        }
+      } else {
+        PIX *o = dst + (int64_t)(y0 + ly) * stride + gx;
+        o[0] = (PIX)(uint16_t)y.x;
+        o[stride] = (PIX)(uint16_t)y.y;
+      }
     }
   }
+  if constexpr (SEARCH) {
+    unsigned long long tot = err;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) tot += __shfl_xor(tot, m, 64);
+    __syncthreads();  // the previous strength's swave has been consumed
+    if (lane == 0) swave[wave] = tot;
+    __syncthreads();
+    if (tid == 0)
+      sa_.sse[(int64_t)gi * gridDim.y * fb_stride + fby * fb_stride + fbx] = swave[0] + swave[1] + swave[2] + swave[3];
+  }
+  }  // strengths
 }
 
 // Chroma planes: av1_cdef_filter_fb with pli > 0 (cdef_block.c:323-426).  A luma 8x8 block maps to a
@@ -421,14 +478,43 @@ int aomhip_cdef_luma_plane(aomhip_ctx *ctx, const aomhip_planes *src, int src_fr
             ((size_t)dst_frame * dst->frame_stride + (size_t)dst->border * dst->stride + dst->border) * esz;
   const dim3 grid((src->width + 63) / 64, (src->height + 63) / 64);
   if (esz == 1)
-    hipLaunchKernelGGL(cdef_luma_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, reinterpret_cast<const uint8_t *>(s),
+    hipLaunchKernelGGL((cdef_luma_kernel<uint8_t, false>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const uint8_t *>(s),
                        reinterpret_cast<uint8_t *>(d), src->stride, src->width, src->height, d_fb_pri, d_fb_sec,
-                       fb_stride, d_skip8x8, damping, 0, d_dir_out, d_var_out);
+                       fb_stride, d_skip8x8, damping, 0, d_dir_out, d_var_out, CdefSearchArgs{});
   else
-    hipLaunchKernelGGL(cdef_luma_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL((cdef_luma_kernel<uint16_t, false>), grid, dim3(256), 0, ctx->stream,
                        reinterpret_cast<const uint16_t *>(s), reinterpret_cast<uint16_t *>(d), src->stride, src->width,
                        src->height, d_fb_pri, d_fb_sec, fb_stride, d_skip8x8, damping, src->bit_depth - 8, d_dir_out,
-                       d_var_out);
+                       d_var_out, CdefSearchArgs{});
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+int aomhip_cdef_search_sse_luma(aomhip_ctx *ctx, const aomhip_planes *recon, int recon_frame, const aomhip_planes *source,
+                                int source_frame, const uint8_t *d_strengths, int n_strengths, const uint8_t *d_skip8x8, int damping,
+                                int fb_stride, uint64_t *d_sse, uint8_t *d_dir_out, int32_t *d_var_out) {
+  if (!ctx || !recon || !source || !recon->base || !source->base || !d_strengths || n_strengths <= 0 || n_strengths > 64 || !d_skip8x8 ||
+      !d_sse || recon_frame < 0 || recon_frame >= recon->n_frames || source_frame < 0 || source_frame >= source->n_frames ||
+      recon->width != source->width || recon->height != source->height || recon->bit_depth != source->bit_depth || (recon->width & 7) ||
+      (recon->height & 7) || damping < 3 || damping > 6 || fb_stride < (recon->width + 63) / 64) {
+    set_error("aomhip_cdef_search_sse_luma: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  const size_t esz = recon->bit_depth == 8 ? 1 : 2;
+  const char *s = static_cast<const char *>(recon->base) +
+                  ((size_t)recon_frame * recon->frame_stride + (size_t)recon->border * recon->stride + recon->border) * esz;
+  const char *o = static_cast<const char *>(source->base) +
+                  ((size_t)source_frame * source->frame_stride + (size_t)source->border * source->stride + source->border) * esz;
+  const dim3 grid((recon->width + 63) / 64, (recon->height + 63) / 64);
+  const CdefSearchArgs sa{ o, source->stride, n_strengths, d_sse };
+  if (esz == 1)
+    hipLaunchKernelGGL((cdef_luma_kernel<uint8_t, true>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const uint8_t *>(s),
+                       static_cast<uint8_t *>(nullptr), recon->stride, recon->width, recon->height, d_strengths, d_strengths, fb_stride,
+                       d_skip8x8, damping, 0, d_dir_out, d_var_out, sa);
+  else
+    hipLaunchKernelGGL((cdef_luma_kernel<uint16_t, true>), grid, dim3(256), 0, ctx->stream, reinterpret_cast<const uint16_t *>(s),
+                       static_cast<uint16_t *>(nullptr), recon->stride, recon->width, recon->height, d_strengths, d_strengths, fb_stride,
+                       d_skip8x8, damping, recon->bit_depth - 8, d_dir_out, d_var_out, sa);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

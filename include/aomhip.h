@@ -375,6 +375,23 @@ int aomhip_cdef_luma_plane(aomhip_ctx *ctx, const aomhip_planes *src, int src_fr
                            int dst_frame, const uint8_t *d_fb_pri, const uint8_t *d_fb_sec, int fb_stride,
                            const uint8_t *d_skip8x8, int damping, uint8_t *d_dir_out, int32_t *d_var_out);
 
+/* The distortion table of the encoder's CDEF strength search for the luma plane: av1_cdef_mse_calc_block ->
+ * get_filt_error (av1/encoder/pickcdef.c:401-615), i.e. for every 64x64 filter block and every strength pair of the
+ * list, av1_cdef_filter_fb on the deblocked reconstruction and the squared error against the source frame summed over
+ * the block's non-skip 8x8 units (aom_sse / compute_cdef_dist[_highbd], :237-315) -- in ONE launch: the footprint is
+ * staged and the directions searched once per filter block, then all strengths run from LDS and nothing is written
+ * but the sums.
+ *   d_strengths   n_strengths (<= 64) byte pairs { pri, sec } with sec already mapped 3 -> 4 (`sec_strength +
+ *                 (sec_strength == 3)`, :439); get_cdef_filter_strengths (:29-84) gives the list for a pick method
+ *   d_sse         [n_strengths][n_fb_rows * fb_stride] RAW sums.  The reference stores `sum >> 2 * coeff_shift` for
+ *                 high-bit-depth frames (:260) and merges the filter blocks of a 128-wide superblock into one entry
+ *                 (:541-556) before shifting, so both steps are the caller's: mse[0][sb][gi] = (sum of its blocks) >>
+ *                 2 * (bit_depth - 8).
+ *   d_dir_out / d_var_out  as aomhip_cdef_luma_plane (the chroma search reuses the directions). */
+int aomhip_cdef_search_sse_luma(aomhip_ctx *ctx, const aomhip_planes *recon, int recon_frame, const aomhip_planes *source,
+                                int source_frame, const uint8_t *d_strengths, int n_strengths, const uint8_t *d_skip8x8, int damping,
+                                int fb_stride, uint64_t *d_sse, uint8_t *d_dir_out, int32_t *d_var_out);
+
 /* The same for a CHROMA plane (pli > 0 in av1_cdef_filter_fb, cdef_block.c:323-426): `src` / `dst` are rings of that
  * chroma plane, xdec / ydec its subsampling (4:2:0 = 1,1; 4:4:4 = 0,0; 4:2:2 = 1,0; 4:4:0 = 0,1), so one luma 8x8
  * block is a (8 >> xdec) x (8 >> ydec) chroma block and a filter block is (64 >> xdec) x (64 >> ydec).

@@ -449,6 +449,23 @@ def cdef_plane_luma(pixels, fb_pri, fb_sec, skip, damping, bd=8):
     return dst, d, v
 
 
+def cdef_search_sse_luma(recon, source, strengths, skip, damping, bd=8):
+    """The luma distortion table of av1_cdef_search (pickcdef.c:401-615) restated on top of cdef_plane_luma: for each
+    (pri, sec) the whole plane is filtered with that strength in every filter block and the squared error against
+    `source` is summed per 64x64 filter block over the non-skip 8x8 units.  -> uint64 [n_strengths, fb_rows, fb_cols] raw sums."""
+    h, w = recon.shape
+    fbh, fbw = (h + 63) // 64, (w + 63) // 64
+    out = np.zeros((len(strengths), fbh, fbw), np.uint64)
+    keep = np.kron((np.asarray(skip) == 0).astype(np.int64), np.ones((8, 8), np.int64))[:h, :w]
+    for gi, (pri, sec) in enumerate(strengths):
+        filt, _, _ = cdef_plane_luma(recon, np.full((fbh, fbw), pri, np.uint8), np.full((fbh, fbw), sec, np.uint8), skip, damping, bd)
+        e = (filt.astype(np.int64) - source.astype(np.int64)) ** 2 * keep
+        for r in range(fbh):
+            for c in range(fbw):
+                out[gi, r, c] = e[r * 64:(r + 1) * 64, c * 64:(c + 1) * 64].sum()
+    return out
+
+
 def cdef_plane_chroma(pixels, xdec, ydec, luma_dir, fb_pri, fb_sec, skip, damping, bd=8):
     """pixels: chroma plane; luma_dir: [h_blocks, w_blocks] uint8 from cdef_plane_luma; fb_pri / fb_sec: uv strengths."""
     src = np.ascontiguousarray(pixels)

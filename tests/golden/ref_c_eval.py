@@ -1252,6 +1252,11 @@ class Interp:
                     return Ptr(v.buf, v.off, ty[1] if ty[1] is not v.t else v.t), PTR
                 if (v.__class__ is Ptr and ty[0] == "ptr" and ty[1].__class__ is T and v.t.__class__ is T and ty[1] is not v.t
                         and not v.dims):
+                    if ty[1] is U8 and v.t is U16:
+                        # libaom's byte-pointer encoding of a high-bit-depth buffer (`(uint8_t *)p16`, aom_ports/mem.h:79-80):
+                        # such a pointer is only ever handed to CONVERT_TO_SHORTPTR, which is the identity in this
+                        # (buffer, element) pointer model, so it keeps its real element type
+                        return v, PTR
                     if ty[1].size != v.t.size:
                         raise CError("pointer cast changes the element size (%s -> %s)" % (v.t, ty[1]))
                     return Ptr(v.buf, v.off, ty[1]), PTR

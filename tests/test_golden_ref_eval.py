@@ -455,3 +455,20 @@ def test_rd_helpers_match_reference_evaluation(oracle):
             lib.orc_txb_init_levels(C.c_void_p(coeff.ctypes.data), c["w"], c["h"], C.c_void_p(lv.ctypes.data))
             assert np.array_equal(lv, want), c
     assert seen == {"sse", "hadamard", "levels"}
+
+
+def test_cdef_search_distortion_matches_reference_evaluation(oracle):
+    """oracle.cdef_search_sse_luma (orc_cdef_plane_luma per strength + the squared error over the non-skip 8x8 units)
+    against the interpreted get_filt_error (av1/encoder/pickcdef.c:401-501): 8-bit build path (aom_sse on whole or
+    partial filter blocks) and high-bit-depth path (compute_cdef_dist_highbd, >> 2 * coeff_shift)."""
+    from cdef_search_fixture import load_cases, mapped_strengths, planes_of
+    z, cases = load_cases()
+    assert len(cases) == 4
+    for c in cases:
+        recon, source, skip, fb = planes_of(z, c)
+        got = oracle.cdef_search_sse_luma(recon, source, mapped_strengths(c), skip, c["damping"], c["bd"])
+        shift = 2 * (c["bd"] - 8)
+        assert [int(v) >> shift for v in got[:, fb[0], fb[1]]] == c["errors"], c["variant"]
+        others = got.copy()
+        others[:, fb[0], fb[1]] = 0
+        assert not others.any()
