@@ -596,6 +596,41 @@ def run_mesh(pkg, ctx, orc, steps, warmup):
     return out
 
 
+def run_cdef_search(pkg, ctx, orc, steps, warmup):
+    """The distortion table of av1_cdef_search (pickcdef.c:401-615) for a 4K 10-bit luma plane, CDEF_FULL_SEARCH (64 strength
+    pairs per 64x64 filter block), one launch; also the 16-pair list of CDEF_FAST_SEARCH_LVL1-sized searches.  Informational."""
+    W, H, bd, border = 3840, 2160, 10, 64
+    recon = pkg.synth.lcg_frame(W, H, 2, 0, bd)
+    rng = np.random.default_rng(9)
+    source = np.clip(recon.astype(np.int64) + rng.integers(-20, 21, recon.shape), 0, 1023).astype(recon.dtype)
+    pr, ps = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(pr, 0, recon); ctx.planes_upload(ps, 0, source)
+    fbh, fbw = (H + 63) // 64, (W + 63) // 64
+    skip = np.zeros((H // 8, W // 8), np.uint8)
+    d_skip = ctx.to_device(skip)
+    full = np.array([(gi // 4, (gi % 4) + (gi % 4 == 3)) for gi in range(64)], np.uint8)
+    d_st, d_sse = ctx.to_device(full), ctx.malloc(8 * 64 * fbh * fbw)
+    out = {"workload": "cdef_search_luma_4k_10bit", "filter_blocks": fbh * fbw}
+    for name, n in (("full_search_64", 64), ("fast_search_16", 16)):
+        ms = kernel_avg_ms(ctx, lambda n=n: ctx.cdef_search_sse_luma(pr, 0, ps, 0, d_st, n, d_skip, 5, fbw, d_sse), max(steps, 4))
+        out[name] = {"ms_per_frame": ms, "strength_evaluations_per_s": fbh * fbw * n / ms * 1e3,
+                     "filtered_pixels_per_s": float(W) * H * n / ms * 1e3}
+    # exact check of one filter-block row against the oracle (4 strengths)
+    sub = slice(0, 64)
+    want = orc.cdef_search_sse_luma(recon[sub, :256], source[sub, :256], [tuple(int(v) for v in full[i]) for i in (0, 5, 30, 63)], skip[:8, :32], 5, bd)
+    p2, s2 = ctx.planes_alloc(256, 64, border, bd, 1), ctx.planes_alloc(256, 64, border, bd, 1)
+    ctx.planes_upload(p2, 0, np.ascontiguousarray(recon[sub, :256])); ctx.planes_upload(s2, 0, np.ascontiguousarray(source[sub, :256]))
+    d_s4, d_o4, d_k4 = ctx.to_device(np.ascontiguousarray(full[[0, 5, 30, 63]])), ctx.malloc(8 * 4 * 4), ctx.to_device(np.zeros((8, 32), np.uint8))
+    ctx.cdef_search_sse_luma(p2, 0, s2, 0, d_s4, 4, d_k4, 5, 4, d_o4)
+    out["parity_sample"] = bool(np.array_equal(ctx.from_device(d_o4, (4, 1, 4), np.uint64), want))
+    out["value"], out["unit"] = out["full_search_64"]["strength_evaluations_per_s"], "filter-block strength evaluations/s"
+    for d in (d_skip, d_st, d_sse, d_s4, d_o4, d_k4):
+        ctx.free(d)
+    for p in (pr, ps, p2, s2):
+        ctx.planes_free(p)
+    return out
+
+
 def time_steps(wl, ctx, dist, dev, steps, warmup):
     for _ in range(warmup):
         wl.step()
@@ -769,6 +804,7 @@ def main():
             others.append(run_inner_loop(pkg, ctx, orc, max(4, args.steps // 2), 1))
             others.append(run_mesh(pkg, ctx, orc, max(4, args.steps // 4), 1))
             others.append(run_search_default(pkg, ctx, orc, max(4, args.steps // 2), 1))
+            others.append(run_cdef_search(pkg, ctx, orc, max(4, args.steps // 4), 1))
     ctx.close()
 
     if rank == 0:
