@@ -347,17 +347,19 @@ __device__ constexpr int8_t kDirDyDx[8][2][2] = { { { -1, 1 }, { -2, 2 } }, { { 
                                                   { { 0, 1 }, { 1, 2 } },   { { 1, 1 }, { 2, 2 } },  { { 1, 0 }, { 2, 1 } },
                                                   { { 1, 0 }, { 2, 0 } },   { { 1, 0 }, { 2, -1 } } };
 
-template <typename PIX, int XDEC, int YDEC>
+// SEARCH as in cdef_luma_kernel: fb_pri = the (pri, sec) list, only the per-strength squared-error sums are written.
+template <typename PIX, int XDEC, int YDEC, bool SEARCH>
 __global__ __launch_bounds__(256) void cdef_chroma_kernel(const PIX *__restrict__ src, PIX *__restrict__ dst, int stride,
                                                           int width, int height, const uint8_t *__restrict__ luma_dir,
                                                           const uint8_t *__restrict__ fb_pri,
                                                           const uint8_t *__restrict__ fb_sec, int fb_stride,
                                                           const uint8_t *__restrict__ skip, int damping,
-                                                          int coeff_shift) {
+                                                          int coeff_shift, CdefSearchArgs sa_) {
   constexpr int BW = 8 >> XDEC, BH = 8 >> YDEC;    // chroma block of one luma 8x8
   constexpr int FW = 64 >> XDEC, FH = 64 >> YDEC;  // chroma filter block
   constexpr int TW = FW + 8, TH = FH + 4;          // LDS tile: rows -2..FH+1, cols -4..FW+3
   __shared__ uint16_t tile[TH * TW];
+  __shared__ unsigned long long swave[4];
   const int fbx = blockIdx.x, fby = blockIdx.y;
   const int x0 = fbx * FW, y0 = fby * FH;
   const int tid = threadIdx.x;
@@ -369,7 +371,11 @@ __global__ __launch_bounds__(256) void cdef_chroma_kernel(const PIX *__restrict_
     if (y >= 0 && y < height && x >= 0 && x < width) v = src[(int64_t)y * stride + x];
     tile[i] = (uint16_t)v;
   }
-  const int level = fb_pri[fby * fb_stride + fbx], sec = fb_sec[fby * fb_stride + fbx];
+  int level = 0, sec = 0;
+  if constexpr (!SEARCH) {
+    level = fb_pri[fby * fb_stride + fbx];
+    sec = fb_sec[fby * fb_stride + fbx];
+  }
   __syncthreads();
 
   // filter: lane = pixel column (two rows of lanes per wavefront when the filter block is 32 wide), two vertically
@@ -380,7 +386,17 @@ __global__ __launch_bounds__(256) void cdef_chroma_kernel(const PIX *__restrict_
   const int wave = tid >> 6, lane = tid & 63;
   const int col = lane % kLanesPerRow, rsub = lane / kLanesPerRow;
   const int gx = x0 + col;
-  if (gx >= width) return;
+  if constexpr (!SEARCH) {
+    if (gx >= width) return;
+  }
+  const int n_iter = SEARCH ? sa_.n_strengths : 1;
+#pragma unroll 1
+  for (int gi = 0; gi < n_iter; ++gi) {
+  if constexpr (SEARCH) {
+    level = fb_pri[2 * gi];
+    sec = fb_pri[2 * gi + 1];
+  }
+  [[maybe_unused]] uint32_t err = 0;
   const int pri_strength = level << coeff_shift, sec_strength = sec << coeff_shift;
   const int dmp = damping + coeff_shift - 1;
   const int t = pri_strength;
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(256) void cdef_chroma_kernel(const PIX *__restrict_
   for (int step = 0; step < kRowsPerWave / (2 * kSub); ++step) {
     const int ly = wave * kRowsPerWave + (step * kSub + rsub) * 2;   // rows ly, ly + 1 (same chroma block: BH is 4 or 8)
     const int gy = y0 + ly;
-    if (gy >= height) continue;
+    if (gy >= height || gx >= width) continue;
     const int bidx = (gy / BH) * nbx + gx / BW;
     const bool filt = (level | sec) != 0 && !skip[bidx];
     int dir = luma_dir[bidx] & 7;
@@ -434,23 +450,42 @@ __global__ __launch_bounds__(256) void cdef_chroma_kernel(const PIX *__restrict_
         y = pmin(pmax(y, mn), mx);
       }
     }
-    PIX *o = dst + (int64_t)gy * stride + gx;
-    o[0] = (PIX)(uint16_t)y.x;
-    o[stride] = (PIX)(uint16_t)y.y;
+    if constexpr (SEARCH) {
+      if (!skip[bidx]) {  // only the units of the filter list count (compute_cdef_dist*, pickcdef.c:237-315)
+        const PIX *op = static_cast<const PIX *>(sa_.orig) + (int64_t)gy * sa_.orig_stride + gx;
+        const int e0 = (int)op[0] - (int)y.x, e1 = (int)op[sa_.orig_stride] - (int)y.y;
+        err += (uint32_t)(e0 * e0) + (uint32_t)(e1 * e1);
+      }
+    } else {
+      PIX *o = dst + (int64_t)gy * stride + gx;
+      o[0] = (PIX)(uint16_t)y.x;
+      o[stride] = (PIX)(uint16_t)y.y;
+    }
   }
+  if constexpr (SEARCH) {
+    unsigned long long tot = err;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) tot += __shfl_xor(tot, m, 64);
+    __syncthreads();
+    if (lane == 0) swave[wave] = tot;
+    __syncthreads();
+    if (tid == 0)
+      sa_.sse[(int64_t)gi * gridDim.y * fb_stride + fby * fb_stride + fbx] = swave[0] + swave[1] + swave[2] + swave[3];
+  }
+  }  // strengths
 }
 
 }  // namespace aomhip
 
 using namespace aomhip;
 
-template <typename PIX>
+template <typename PIX, bool SEARCH>
 static void launch_chroma(hipStream_t st, dim3 grid, int xdec, int ydec, const void *s, void *d, int stride, int w, int h,
                           const uint8_t *dir, const uint8_t *pri, const uint8_t *sec, int fbs, const uint8_t *skip,
-                          int damping, int cs) {
+                          int damping, int cs, const CdefSearchArgs &sa = CdefSearchArgs{}) {
 #define AOMHIP_CDEF_C(X, Y)                                                                                          \
-  hipLaunchKernelGGL((cdef_chroma_kernel<PIX, X, Y>), grid, dim3(256), 0, st, static_cast<const PIX *>(s),           \
-                     static_cast<PIX *>(d), stride, w, h, dir, pri, sec, fbs, skip, damping, cs)
+  hipLaunchKernelGGL((cdef_chroma_kernel<PIX, X, Y, SEARCH>), grid, dim3(256), 0, st, static_cast<const PIX *>(s),   \
+                     static_cast<PIX *>(d), stride, w, h, dir, pri, sec, fbs, skip, damping, cs, sa)
   if (xdec == 1 && ydec == 1) AOMHIP_CDEF_C(1, 1);
   else if (xdec == 0 && ydec == 0) AOMHIP_CDEF_C(0, 0);
   else if (xdec == 1 && ydec == 0) AOMHIP_CDEF_C(1, 0);
@@ -538,11 +573,39 @@ int aomhip_cdef_chroma_plane(aomhip_ctx *ctx, const aomhip_planes *src, int src_
             ((size_t)dst_frame * dst->frame_stride + (size_t)dst->border * dst->stride + dst->border) * esz;
   const dim3 grid((src->width + (64 >> xdec) - 1) / (64 >> xdec), (src->height + (64 >> ydec) - 1) / (64 >> ydec));
   if (esz == 1)
-    launch_chroma<uint8_t>(ctx->stream, grid, xdec, ydec, s, d, src->stride, src->width, src->height, d_luma_dir,
+    launch_chroma<uint8_t, false>(ctx->stream, grid, xdec, ydec, s, d, src->stride, src->width, src->height, d_luma_dir,
                            d_fb_uv_pri, d_fb_uv_sec, fb_stride, d_skip8x8, damping, 0);
   else
-    launch_chroma<uint16_t>(ctx->stream, grid, xdec, ydec, s, d, src->stride, src->width, src->height, d_luma_dir,
+    launch_chroma<uint16_t, false>(ctx->stream, grid, xdec, ydec, s, d, src->stride, src->width, src->height, d_luma_dir,
                             d_fb_uv_pri, d_fb_uv_sec, fb_stride, d_skip8x8, damping, src->bit_depth - 8);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+int aomhip_cdef_search_sse_chroma(aomhip_ctx *ctx, const aomhip_planes *recon, int recon_frame, const aomhip_planes *source,
+                                  int source_frame, int xdec, int ydec, const uint8_t *d_luma_dir, const uint8_t *d_strengths,
+                                  int n_strengths, const uint8_t *d_skip8x8, int damping, int fb_stride, uint64_t *d_sse) {
+  if (!ctx || !recon || !source || !recon->base || !source->base || !d_luma_dir || !d_strengths || n_strengths <= 0 || n_strengths > 64 ||
+      !d_skip8x8 || !d_sse || recon_frame < 0 || recon_frame >= recon->n_frames || source_frame < 0 || source_frame >= source->n_frames ||
+      recon->width != source->width || recon->height != source->height || recon->bit_depth != source->bit_depth || xdec < 0 || xdec > 1 ||
+      ydec < 0 || ydec > 1 || (recon->width % (8 >> xdec)) || (recon->height % (8 >> ydec)) || damping < 3 || damping > 6 ||
+      fb_stride < (recon->width + (64 >> xdec) - 1) / (64 >> xdec)) {
+    set_error("aomhip_cdef_search_sse_chroma: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  const size_t esz = recon->bit_depth == 8 ? 1 : 2;
+  const char *s = static_cast<const char *>(recon->base) +
+                  ((size_t)recon_frame * recon->frame_stride + (size_t)recon->border * recon->stride + recon->border) * esz;
+  const char *o = static_cast<const char *>(source->base) +
+                  ((size_t)source_frame * source->frame_stride + (size_t)source->border * source->stride + source->border) * esz;
+  const dim3 grid((recon->width + (64 >> xdec) - 1) / (64 >> xdec), (recon->height + (64 >> ydec) - 1) / (64 >> ydec));
+  const CdefSearchArgs sa{ o, source->stride, n_strengths, d_sse };
+  if (esz == 1)
+    launch_chroma<uint8_t, true>(ctx->stream, grid, xdec, ydec, s, nullptr, recon->stride, recon->width, recon->height, d_luma_dir, d_strengths,
+                                 d_strengths, fb_stride, d_skip8x8, damping, 0, sa);
+  else
+    launch_chroma<uint16_t, true>(ctx->stream, grid, xdec, ydec, s, nullptr, recon->stride, recon->width, recon->height, d_luma_dir,
+                                  d_strengths, d_strengths, fb_stride, d_skip8x8, damping, recon->bit_depth - 8, sa);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

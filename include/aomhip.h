@@ -392,6 +392,14 @@ int aomhip_cdef_search_sse_luma(aomhip_ctx *ctx, const aomhip_planes *recon, int
                                 int source_frame, const uint8_t *d_strengths, int n_strengths, const uint8_t *d_skip8x8, int damping,
                                 int fb_stride, uint64_t *d_sse, uint8_t *d_dir_out, int32_t *d_var_out);
 
+/* The same table for a CHROMA plane (pli > 0: no variance adjustment, damping - 1, the luma directions; get_filt_error with
+ * xdec / ydec, pickcdef.c:401-501).  d_luma_dir = the d_dir_out of the luma call; a filter block is (64 >> xdec) x
+ * (64 >> ydec) and a unit (8 >> xdec) x (8 >> ydec).  The reference's mse[1][sb][gi] is (U sums >> 2 * coeff_shift) +
+ * (V sums >> 2 * coeff_shift) (:603-606): call once per plane and combine on the host. */
+int aomhip_cdef_search_sse_chroma(aomhip_ctx *ctx, const aomhip_planes *recon, int recon_frame, const aomhip_planes *source,
+                                  int source_frame, int xdec, int ydec, const uint8_t *d_luma_dir, const uint8_t *d_strengths,
+                                  int n_strengths, const uint8_t *d_skip8x8, int damping, int fb_stride, uint64_t *d_sse);
+
 /* The same for a CHROMA plane (pli > 0 in av1_cdef_filter_fb, cdef_block.c:323-426): `src` / `dst` are rings of that
  * chroma plane, xdec / ydec its subsampling (4:2:0 = 1,1; 4:4:4 = 0,0; 4:2:2 = 1,0; 4:4:0 = 0,1), so one luma 8x8
  * block is a (8 >> xdec) x (8 >> ydec) chroma block and a filter block is (64 >> xdec) x (64 >> ydec).

@@ -466,6 +466,22 @@ def cdef_search_sse_luma(recon, source, strengths, skip, damping, bd=8):
     return out
 
 
+def cdef_search_sse_chroma(recon, source, xdec, ydec, luma_dir, strengths, skip, damping, bd=8):
+    """cdef_search_sse_luma for a chroma plane (built on cdef_plane_chroma): raw sums [n_strengths, fb_rows, fb_cols]."""
+    h, w = recon.shape
+    fh, fw = 64 >> ydec, 64 >> xdec
+    fbh, fbw = (h + fh - 1) // fh, (w + fw - 1) // fw
+    out = np.zeros((len(strengths), fbh, fbw), np.uint64)
+    keep = np.kron((np.asarray(skip) == 0).astype(np.int64), np.ones((8 >> ydec, 8 >> xdec), np.int64))[:h, :w]
+    for gi, (pri, sec) in enumerate(strengths):
+        filt = cdef_plane_chroma(recon, xdec, ydec, luma_dir, np.full((fbh, fbw), pri, np.uint8), np.full((fbh, fbw), sec, np.uint8), skip, damping, bd)
+        e = (filt.astype(np.int64) - source.astype(np.int64)) ** 2 * keep
+        for r in range(fbh):
+            for c in range(fbw):
+                out[gi, r, c] = e[r * fh:(r + 1) * fh, c * fw:(c + 1) * fw].sum()
+    return out
+
+
 def cdef_plane_chroma(pixels, xdec, ydec, luma_dir, fb_pri, fb_sec, skip, damping, bd=8):
     """pixels: chroma plane; luma_dir: [h_blocks, w_blocks] uint8 from cdef_plane_luma; fb_pri / fb_sec: uv strengths."""
     src = np.ascontiguousarray(pixels)

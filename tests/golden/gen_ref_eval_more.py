@@ -411,54 +411,65 @@ def gen_cdef_search():
     BS, VB, HB = 144, 2, 8                       # CDEF_BSTRIDE, CDEF_VBORDER, CDEF_HBORDER (cdef_block.h:24-31)
     BLOCK_8X8, BLOCK_64X64 = 3, 12
     k = 0
-    for bd in (8, 10):
+    BLOCK_4X4 = 0
+    for bd, variant, pli in ((8, "full", 0), (8, "partial", 0), (10, "full", 0), (10, "partial", 0), (8, "partial", 1), (10, "partial", 1)):
         hbd = int(bd > 8)
         cs = bd - 8
-        for variant in ("full", "partial"):
-            mx = (1 << bd) - 1
-            smooth = np.add.outer(np.arange(64 + 2 * VB) * (3 << cs), np.arange(64 + 2 * HB) * (2 << cs)) % (mx + 1)
-            img = np.clip(smooth + rng.integers(-(12 << cs), (12 << cs) + 1, smooth.shape), 0, mx)
-            src = np.clip(img[VB:VB + 64, HB:HB + 64] + rng.integers(-(6 << cs), (6 << cs) + 1, (64, 64)), 0, mx)
-            inbuf = np.full(((64 + 2 * VB) * BS + 64,), 0x4000, np.int64)     # CDEF_VERY_LARGE
-            for r in range(64 + 2 * VB):
-                inbuf[r * BS:r * BS + 64 + 2 * HB] = img[r]
-            if variant == "partial":            # a filter block at the frame's top-left corner: outside = CDEF_VERY_LARGE
-                for r in range(64 + 2 * VB):
-                    inbuf[r * BS:r * BS + HB] = 0x4000
-                inbuf[:VB * BS] = 0x4000
-            IN = ev.array(inbuf, "uint16_t")
-            ct = "uint16_t" if hbd else "uint8_t"
-            # the reconstruction plane (pd->dst) = the footprint's pixels, the source plane (ref_buffer) = src; both 64 wide at (0, 0)
-            rec_plane = ev.array(img[VB:VB + 64, HB:HB + 64].ravel(), ct)
-            src_plane = ev.array(src.ravel(), ct)
-            skip = np.zeros((8, 8), np.uint8)
-            if variant == "partial":
-                skip = (rng.integers(0, 3, (8, 8)) == 0).astype(np.uint8)
-                skip[0, :4] = 0                  # a run of four unskipped neighbours: the 4-unit error path (pickcdef.c:383-389)
-            ys, xs = np.nonzero(skip == 0)
-            count = len(ys)
-            dl_t = ev.typedefs["cdef_list"]
-            dlist = ev.interp.alloc(("arr", dl_t, 64), True)
-            for i, (by, bx) in enumerate(zip(ys, xs)):
-                ev.set(dlist, "[%d].by" % i, int(by)); ev.set(dlist, "[%d].bx" % i, int(bx))
-            cctx = ev.interp.alloc(ctx_t, True)
-            ev.set(cctx, "damping", 5); ev.set(cctx, "use_highbitdepth", hbd)
-            ev.set(cctx, "bsize[0]", BLOCK_8X8)
-            ev.set(cctx, "compute_cdef_dist_fn", R.FuncRef("compute_cdef_dist_highbd" if hbd else "compute_cdef_dist"))
-            pd = ev.interp.alloc(pd_t, True)
-            ev.set(pd, "dst.buf", rec_plane); ev.set(pd, "dst.stride", 64)
-            dirs = ev.interp.alloc(("arr", ("arr", R.I32, 16), 16), True)
-            var = ev.interp.alloc(("arr", ("arr", R.I32, 16), 16), True)
-            dirinit = ev.array([0], "int")
-            errs = []
-            strengths = [(0, 0), (1, 0), (0, 2), (3, 1), (7, 3), (15, 2), (4, 3), (9, 0)]
-            for (pri, sec) in strengths:
-                e = ev.call("get_filt_error", cctx, pd, dlist.deref()[0], dirs.deref()[0], dirinit, var.deref()[0], IN.add(VB * BS + HB), src_plane, 64, 0, 0, pri, sec, count, 0,
-                            cs, BLOCK_64X64)
-                errs.append(int(e))
-            arrays["in%d" % k], arrays["src%d" % k], arrays["skip%d" % k] = inbuf.astype(np.uint16), src.astype(np.uint16), skip
-            cases.append({"k": k, "bd": bd, "variant": variant, "count": count, "damping": 5, "strengths": strengths, "errors": errs})
-            k += 1
+        dec = 1 if pli else 0                   # 4:2:0 chroma: 32 x 32 filter block of 4 x 4 units
+        N = 64 >> dec
+        mx = (1 << bd) - 1
+        smooth = np.add.outer(np.arange(N + 2 * VB) * (3 << cs), np.arange(N + 2 * HB) * (2 << cs)) % (mx + 1)
+        img = np.clip(smooth + rng.integers(-(12 << cs), (12 << cs) + 1, smooth.shape), 0, mx)
+        src = np.clip(img[VB:VB + N, HB:HB + N] + rng.integers(-(6 << cs), (6 << cs) + 1, (N, N)), 0, mx)
+        inbuf = np.full(((N + 2 * VB) * BS + 64,), 0x4000, np.int64)     # CDEF_VERY_LARGE
+        for r in range(N + 2 * VB):
+            inbuf[r * BS:r * BS + N + 2 * HB] = img[r]
+        if variant == "partial":            # a filter block at the frame's top-left corner: outside = CDEF_VERY_LARGE
+            for r in range(N + 2 * VB):
+                inbuf[r * BS:r * BS + HB] = 0x4000
+            inbuf[:VB * BS] = 0x4000
+        IN = ev.array(inbuf, "uint16_t")
+        ct = "uint16_t" if hbd else "uint8_t"
+        # the reconstruction plane (pd->dst) = the footprint's pixels, the source plane (ref_buffer) = src; both N wide at (0, 0)
+        rec_plane = ev.array(img[VB:VB + N, HB:HB + N].ravel(), ct)
+        src_plane = ev.array(src.ravel(), ct)
+        skip = np.zeros((8, 8), np.uint8)
+        if variant == "partial":
+            skip = (rng.integers(0, 3, (8, 8)) == 0).astype(np.uint8)
+            skip[0, :4] = 0                  # a run of four unskipped neighbours: the 4-unit error path (pickcdef.c:383-389)
+        ys, xs = np.nonzero(skip == 0)
+        count = len(ys)
+        dl_t = ev.typedefs["cdef_list"]
+        dlist = ev.interp.alloc(("arr", dl_t, 64), True)
+        for i, (by, bx) in enumerate(zip(ys, xs)):
+            ev.set(dlist, "[%d].by" % i, int(by)); ev.set(dlist, "[%d].bx" % i, int(bx))
+        cctx = ev.interp.alloc(ctx_t, True)
+        ev.set(cctx, "damping", 5); ev.set(cctx, "use_highbitdepth", hbd)
+        ev.set(cctx, "bsize[0]", BLOCK_8X8); ev.set(cctx, "bsize[1]", BLOCK_4X4); ev.set(cctx, "bsize[2]", BLOCK_4X4)
+        for i in (1, 2):
+            ev.set(cctx, "xdec[%d]" % i, 1); ev.set(cctx, "ydec[%d]" % i, 1)
+        ev.set(cctx, "compute_cdef_dist_fn", R.FuncRef("compute_cdef_dist_highbd" if hbd else "compute_cdef_dist"))
+        pd = ev.interp.alloc(pd_t, True)
+        ev.set(pd, "dst.buf", rec_plane); ev.set(pd, "dst.stride", N)
+        ev.set(pd, "subsampling_x", dec); ev.set(pd, "subsampling_y", dec)
+        dirs = ev.interp.alloc(("arr", ("arr", R.I32, 16), 16), True)
+        var = ev.interp.alloc(("arr", ("arr", R.I32, 16), 16), True)
+        dirinit = ev.array([0], "int")
+        if pli:                              # chroma reuses the directions the luma pass left in dir[][] (dirinit = 1)
+            ldir = rng.integers(0, 8, (16, 16))
+            for i, v in enumerate(ldir.ravel()):
+                dirs.buf[i] = int(v)
+            dirinit = ev.array([1], "int")
+            arrays["ld%d" % k] = ldir[:8, :8].astype(np.uint8)
+        errs = []
+        strengths = [(0, 0), (1, 0), (0, 2), (3, 1), (7, 3), (15, 2), (4, 3), (9, 0)]
+        for (pri, sec) in strengths:
+            e = ev.call("get_filt_error", cctx, pd, dlist.deref()[0], dirs.deref()[0], dirinit, var.deref()[0], IN.add(VB * BS + HB), src_plane, N, 0, 0,
+                        pri, sec, count, pli, cs, BLOCK_64X64)
+            errs.append(int(e))
+        arrays["in%d" % k], arrays["src%d" % k], arrays["skip%d" % k] = inbuf.astype(np.uint16), src.astype(np.uint16), skip
+        cases.append({"k": k, "bd": bd, "variant": variant, "pli": pli, "count": count, "damping": 5, "strengths": strengths, "errors": errs})
+        k += 1
     save("ref_eval_cdef_search.npz", arrays, cases)
 
 if __name__ == "__main__":

@@ -463,12 +463,15 @@ def test_cdef_search_distortion_matches_reference_evaluation(oracle):
     partial filter blocks) and high-bit-depth path (compute_cdef_dist_highbd, >> 2 * coeff_shift)."""
     from cdef_search_fixture import load_cases, mapped_strengths, planes_of
     z, cases = load_cases()
-    assert len(cases) == 4
+    assert len(cases) == 6 and sum(c["pli"] for c in cases) == 2
     for c in cases:
-        recon, source, skip, fb = planes_of(z, c)
-        got = oracle.cdef_search_sse_luma(recon, source, mapped_strengths(c), skip, c["damping"], c["bd"])
+        recon, source, skip, fb, ldir = planes_of(z, c)
+        if c["pli"]:
+            got = oracle.cdef_search_sse_chroma(recon, source, 1, 1, ldir, mapped_strengths(c), skip, c["damping"], c["bd"])
+        else:
+            got = oracle.cdef_search_sse_luma(recon, source, mapped_strengths(c), skip, c["damping"], c["bd"])
         shift = 2 * (c["bd"] - 8)
-        assert [int(v) >> shift for v in got[:, fb[0], fb[1]]] == c["errors"], c["variant"]
+        assert [int(v) >> shift for v in got[:, fb[0], fb[1]]] == c["errors"], (c["variant"], c["pli"])
         others = got.copy()
         others[:, fb[0], fb[1]] = 0
         assert not others.any()

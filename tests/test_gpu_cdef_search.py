@@ -26,15 +26,52 @@ def _table(hip, ctx, recon, source, skip, strengths, damping, bd):
     return got, dirs
 
 
+def _table_chroma(hip, ctx, recon, source, skip, ldir, strengths, damping, bd, xdec, ydec):
+    H, W = recon.shape
+    pr, ps = ctx.planes_alloc(W, H, 16, bd, 1), ctx.planes_alloc(W, H, 16, bd, 1)
+    ctx.planes_upload(pr, 0, recon); ctx.planes_upload(ps, 0, source)
+    fh, fw = 64 >> ydec, 64 >> xdec
+    fbh, fbw = (H + fh - 1) // fh, (W + fw - 1) // fw
+    st = np.asarray(strengths, np.uint8).reshape(-1, 2)
+    d_st, d_skip, d_dir = ctx.to_device(st), ctx.to_device(np.ascontiguousarray(skip, np.uint8)), ctx.to_device(np.ascontiguousarray(ldir, np.uint8))
+    d_sse = ctx.malloc(8 * len(st) * fbh * fbw)
+    ctx.cdef_search_sse_chroma(pr, 0, ps, 0, xdec, ydec, d_dir, d_st, len(st), d_skip, damping, fbw, d_sse)
+    got = ctx.from_device(d_sse, (len(st), fbh, fbw), np.uint64)
+    for d in (d_st, d_skip, d_dir, d_sse):
+        ctx.free(d)
+    ctx.planes_free(pr); ctx.planes_free(ps)
+    return got
+
+
 def test_cdef_search_goldens(hip, ctx):
     z, cases = load_cases()
+    assert len(cases) == 6
     for c in cases:
-        recon, source, skip, fb = planes_of(z, c)
-        got, _ = _table(hip, ctx, recon, source, skip, mapped_strengths(c), c["damping"], c["bd"])
+        recon, source, skip, fb, ldir = planes_of(z, c)
+        if c["pli"]:
+            got = _table_chroma(hip, ctx, recon, source, skip, ldir, mapped_strengths(c), c["damping"], c["bd"], 1, 1)
+        else:
+            got, _ = _table(hip, ctx, recon, source, skip, mapped_strengths(c), c["damping"], c["bd"])
         shift = 2 * (c["bd"] - 8)
-        assert [int(v) >> shift for v in got[:, fb[0], fb[1]]] == c["errors"], c["variant"]
+        assert [int(v) >> shift for v in got[:, fb[0], fb[1]]] == c["errors"], (c["variant"], c["pli"])
         got[:, fb[0], fb[1]] = 0
         assert not got.any()          # all-skip filter blocks contribute nothing
+
+
+@pytest.mark.parametrize("bd,xdec,ydec", [(8, 1, 1), (10, 1, 1), (10, 0, 0), (8, 1, 0), (12, 0, 1)])
+def test_cdef_search_chroma_vs_oracle(hip, oracle, ctx, bd, xdec, ydec):
+    rng = np.random.default_rng(10 * bd + 2 * xdec + ydec)
+    LW, LH = 256, 192                           # luma size; the chroma plane is subsampled from it
+    W, H = LW >> xdec, LH >> ydec
+    recon = hip.synth.lcg_frame(W, H, 3, 0, bd)
+    source = np.clip(recon.astype(np.int64) + rng.integers(-(6 << (bd - 8)), (6 << (bd - 8)) + 1, (H, W)), 0, (1 << bd) - 1).astype(recon.dtype)
+    skip = (rng.integers(0, 4, (LH // 8, LW // 8)) == 0).astype(np.uint8)
+    ldir = rng.integers(0, 8, (LH // 8, LW // 8)).astype(np.uint8)
+    full = [(gi // 4, (gi % 4) + (gi % 4 == 3)) for gi in range(64)]
+    strengths = full if (bd, xdec, ydec) == (10, 1, 1) else [full[i] for i in (0, 2, 5, 11, 23, 36, 47, 63)]
+    got = _table_chroma(hip, ctx, recon, source, skip, ldir, strengths, 4, bd, xdec, ydec)
+    want = oracle.cdef_search_sse_chroma(recon, source, xdec, ydec, ldir, strengths, skip, 4, bd)
+    assert np.array_equal(got, want), (bd, xdec, ydec)
 
 
 @pytest.mark.parametrize("bd,W,H,n_strengths", [(8, 256, 192, 64), (10, 320, 200, 64), (12, 136, 72, 12)])
