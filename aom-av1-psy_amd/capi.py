@@ -161,6 +161,7 @@ _protos = {
     "aomhip_txb_init_levels_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64]),
     "aomhip_cdef_search_sse_luma": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "aomhip_cdef_search_sse_chroma": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "aomhip_lpf_search_sse": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _vp, _i64, _i, _i, _i, _i, _vp]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
@@ -390,6 +391,11 @@ class Context:
                                fb_stride, d_sse):
         check(lib.aomhip_cdef_search_sse_chroma(self.h, C.byref(recon), recon_frame, C.byref(source), source_frame, xdec, ydec, d_luma_dir,
                                                 d_strengths, n, d_skip, damping, fb_stride, d_sse), "aomhip_cdef_search_sse_chroma")
+
+    def lpf_search_sse(self, recon, recon_frame, scratch, scratch_frame, source, source_frame, d_params, trial_stride, n_trials, units_stride,
+                       sharpness, passes, d_sse):
+        check(lib.aomhip_lpf_search_sse(self.h, C.byref(recon), recon_frame, C.byref(scratch), scratch_frame, C.byref(source), source_frame,
+                                        d_params, trial_stride, n_trials, units_stride, sharpness, passes, d_sse), "aomhip_lpf_search_sse")
 
     def build_pred_fullpel(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n):
         check(lib.aomhip_build_pred_fullpel(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks,

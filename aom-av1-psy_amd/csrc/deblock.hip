@@ -17,6 +17,8 @@
 //   horizontal pass: one lane per (pixel column, edge unit): lanes of a wavefront cover 64 adjacent
 //                    columns, so each of the up-to-14 row accesses is one coalesced 64-pixel segment
 // Algorithmic bytes: each pixel is read and written once per pass.
+#include <algorithm>
+
 #include "common.h"
 
 namespace aomhip {
@@ -188,6 +190,28 @@ __global__ __launch_bounds__(kDbThreads) void deblock_horz_kernel(PIX *origin, i
   }
 }
 
+// aom_get_sse_plane -> get_sse / highbd_get_sse (aom_dsp/psnr.c:84-198): the sum of squared differences of two whole planes, one
+// atomic per workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void plane_sse_kernel(const T *__restrict__ a, int a_stride, const T *__restrict__ b, int b_stride, int width,
+                                                        int height, unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long part[4];
+  const int y = blockIdx.y;
+  unsigned long long acc = 0;
+  for (int x = blockIdx.x * 256 + threadIdx.x; x < width; x += gridDim.x * 256) {
+    const int d = (int)a[(int64_t)y * a_stride + x] - (int)b[(int64_t)y * b_stride + x];
+    acc += (unsigned)(d * d);
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+    if (t) atomicAdd(out, t);
+  }
+}
+
 }  // namespace aomhip
 
 using namespace aomhip;
@@ -228,6 +252,51 @@ int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, con
       hipLaunchKernelGGL(deblock_horz_kernel<uint16_t>, gh, dim3(kDbThreads), 0, ctx->stream,
                          reinterpret_cast<uint16_t *>(origin), p->stride, p->width, p->height, d_edge_params,
                          units_stride, sharpness, p->bit_depth);
+    AOMHIP_LAUNCH_CHECK();
+  }
+  return AOMHIP_OK;
+}
+
+int aomhip_lpf_search_sse(aomhip_ctx *ctx, const aomhip_planes *recon, int recon_frame, const aomhip_planes *scratch, int scratch_frame,
+                          const aomhip_planes *source, int source_frame, const uint8_t *d_edge_params, int64_t trial_stride, int n_trials,
+                          int units_stride, int sharpness, int passes, uint64_t *d_sse) {
+  if (!ctx || !recon || !scratch || !source || !recon->base || !scratch->base || !source->base || !d_edge_params || n_trials <= 0 || !d_sse ||
+      recon_frame < 0 || recon_frame >= recon->n_frames || scratch_frame < 0 || scratch_frame >= scratch->n_frames || source_frame < 0 ||
+      source_frame >= source->n_frames || recon->width != scratch->width || recon->height != scratch->height ||
+      recon->stride != scratch->stride || recon->border != scratch->border || recon->frame_stride != scratch->frame_stride ||
+      recon->bit_depth != scratch->bit_depth || recon->width != source->width || recon->height != source->height ||
+      recon->bit_depth != source->bit_depth || (recon->base == scratch->base && recon_frame == scratch_frame) ||
+      trial_stride < (int64_t)units_stride * ((recon->height + 3) / 4) * 4) {
+    set_error("aomhip_lpf_search_sse: invalid argument (scratch must have the reconstruction's geometry and be another frame)");
+    return AOMHIP_ERR_INVALID;
+  }
+  const size_t esz = recon->bit_depth == 8 ? 1 : 2;
+  const char *rframe = static_cast<const char *>(recon->base) + (size_t)recon_frame * recon->frame_stride * esz;
+  char *sframe = static_cast<char *>(scratch->base) + (size_t)scratch_frame * scratch->frame_stride * esz;
+  const char *sorigin = sframe + ((size_t)scratch->border * scratch->stride + scratch->border) * esz;
+  const char *oorigin = static_cast<const char *>(source->base) +
+                        ((size_t)source_frame * source->frame_stride + (size_t)source->border * source->stride + source->border) * esz;
+  if (hipMemsetAsync(d_sse, 0, sizeof(uint64_t) * (size_t)n_trials, ctx->stream) != hipSuccess) {
+    set_error("aomhip_lpf_search_sse: memset failed");
+    return AOMHIP_ERR_HIP;
+  }
+  const dim3 grid(std::min((recon->width + 255) / 256, 16), recon->height);
+  for (int t = 0; t < n_trials; ++t) {
+    // try_filter_frame (av1/encoder/picklpf.c:49-86): filter a copy, measure, and leave the unfiltered frame as it was
+    if (hipMemcpyAsync(sframe, rframe, (size_t)recon->frame_stride * esz, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+      set_error("aomhip_lpf_search_sse: frame copy failed");
+      return AOMHIP_ERR_HIP;
+    }
+    const int rc = aomhip_deblock_plane(ctx, scratch, scratch_frame, d_edge_params + (size_t)t * trial_stride, units_stride, sharpness, passes);
+    if (rc != AOMHIP_OK) return rc;
+    if (esz == 1)
+      hipLaunchKernelGGL(plane_sse_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, reinterpret_cast<const uint8_t *>(sorigin), scratch->stride,
+                         reinterpret_cast<const uint8_t *>(oorigin), source->stride, recon->width, recon->height,
+                         reinterpret_cast<unsigned long long *>(d_sse + t));
+    else
+      hipLaunchKernelGGL(plane_sse_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream, reinterpret_cast<const uint16_t *>(sorigin), scratch->stride,
+                         reinterpret_cast<const uint16_t *>(oorigin), source->stride, recon->width, recon->height,
+                         reinterpret_cast<unsigned long long *>(d_sse + t));
     AOMHIP_LAUNCH_CHECK();
   }
   return AOMHIP_OK;

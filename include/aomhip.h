@@ -356,6 +356,18 @@ int aomhip_inv_txfm_add_batch(aomhip_ctx *ctx, const int32_t *d_dqcoeff, int tx_
 int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, const uint8_t *d_edge_params,
                          int units_stride, int sharpness, int passes);
 
+/* The trial loop of the encoder's loop-filter level search: search_filter_level -> try_filter_frame
+ * (av1/encoder/picklpf.c:49-86,88-193) = av1_loop_filter_frame on a copy of the unfiltered reconstruction, then
+ * aom_get_sse_plane against the source (aom_dsp/psnr.c:84-143,208-330).  One call evaluates n_trials candidate settings:
+ * trial t deblocks a copy of frame recon_frame (made in frame scratch_frame of `scratch`, same geometry) with the edge
+ * records at d_edge_params + t * trial_stride -- the caller's set_lpf_parameters output for that trial's filter_level
+ * (records outside the rows of a partial-frame trial, av1_loopfilter.c av1_loop_filter_frame start / end rows, simply carry level 0) -- and writes the plane's
+ * sum of squared differences to d_sse[t].  The reconstruction itself is never modified.  search_filter_level's
+ * bias / direction logic consumes d_sse unchanged. */
+int aomhip_lpf_search_sse(aomhip_ctx *ctx, const aomhip_planes *recon, int recon_frame, const aomhip_planes *scratch, int scratch_frame,
+                          const aomhip_planes *source, int source_frame, const uint8_t *d_edge_params, int64_t trial_stride, int n_trials,
+                          int units_stride, int sharpness, int passes, uint64_t *d_sse);
+
 /* ------------------------------------------------------------------ CDEF */
 
 /* av1_cdef_frame (av1/common/cdef.c:440) for the LUMA plane, out of place: frame `src_frame` of `src` is the
