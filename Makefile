@@ -29,4 +29,9 @@ $(LIBDIR)/libaomhip.so: $(OBJS)
 clean:
 	rm -rf build $(LIBDIR)/libaomhip.so
 	$(MAKE) -C oracle clean
-.PHONY: all lib oracle clean
+# a plain-C99 host program against the C ABI (the reference is a C code base): compiles with gcc, links only libaomhip.so
+demo: build/c_host_demo
+build/c_host_demo: examples/c_host_demo.c include/aomhip.h $(LIBDIR)/libaomhip.so
+	gcc -std=c99 -pedantic -Wall -Wextra -Werror -O2 -Iinclude $< -L$(LIBDIR) -laomhip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -o $@
+
+.PHONY: all lib oracle clean demo
