@@ -80,6 +80,7 @@ search_block_dtype = np.dtype([(n, "<i2") for n in ("bx", "by", "start_row", "st
                                                     "row_max", "col_min", "col_max")])
 MV_COST_L1_LOWRES, MV_COST_L1_MIDRES, MV_COST_L1_HDRES, MV_COST_NONE = 1, 2, 3, 4
 COMP_AVG, COMP_DIST_WTD, COMP_MASK, COMP_OBMC = 0, 1, 2, 3
+rect_dtype = np.dtype([("h_start", "<i4"), ("h_end", "<i4"), ("v_start", "<i4"), ("v_end", "<i4")])
 
 
 class CompoundParams(C.Structure):
@@ -162,6 +163,7 @@ _protos = {
     "aomhip_cdef_search_sse_luma": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "aomhip_cdef_search_sse_chroma": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "aomhip_lpf_search_sse": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "aomhip_compute_stats_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
@@ -396,6 +398,11 @@ class Context:
                        sharpness, passes, d_sse):
         check(lib.aomhip_lpf_search_sse(self.h, C.byref(recon), recon_frame, C.byref(scratch), scratch_frame, C.byref(source), source_frame,
                                         d_params, trial_stride, n_trials, units_stride, sharpness, passes, d_sse), "aomhip_lpf_search_sse")
+
+    def compute_stats_batch(self, dgd, dgd_frame, src, src_frame, win, d_units, h_units, n, downsample, d_M, d_H):
+        hp = h_units.ctypes.data if h_units is not None else None
+        check(lib.aomhip_compute_stats_batch(self.h, C.byref(dgd), dgd_frame, C.byref(src), src_frame, win, d_units, hp, n, downsample, d_M, d_H),
+              "aomhip_compute_stats_batch")
 
     def build_pred_fullpel(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n):
         check(lib.aomhip_build_pred_fullpel(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks,

@@ -645,6 +645,22 @@ int aomhip_hadamard_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residu
 int aomhip_txb_init_levels_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int width, int height, const uint32_t *d_coeff_offset, int n_blocks,
                                  uint8_t *d_levels, int64_t levels_pitch);
 
+/* ------------------------------------------------------------------ loop-restoration search statistics */
+
+/* av1_compute_stats / av1_compute_stats_highbd (av1/encoder/pickrst.c:948-1083; av1_rtcd_defs.pl:452-458): the Wiener
+ * normal-equation statistics M[wiener_win^2] and H[wiener_win^2][wiener_win^2] of every restoration unit of a list, one
+ * launch.  `dgd` = the degraded (deblocked + CDEF) plane ring, border >= 3 and extended like av1_extend_frame leaves
+ * it; `src` = the source.  Unit i covers columns [h_start, h_end) and rows [v_start, v_end) (<= 256 wide); its M goes to
+ * d_M + i * wiener_win^2, its H (both triangles) to d_H + i * wiener_win^4.  wiener_win 7 (luma) or 5 (chroma);
+ * use_downsampled_wiener_stats: the 8-bit function's every-4th-row mode (WIENER_STATS_DOWNSAMPLE_FACTOR).
+ * h_units: the same list in host memory for argument checking, or NULL to skip the check. */
+typedef struct {
+  int32_t h_start, h_end, v_start, v_end;
+} aomhip_rect;
+int aomhip_compute_stats_batch(aomhip_ctx *ctx, const aomhip_planes *dgd, int dgd_frame, const aomhip_planes *src, int src_frame,
+                               int wiener_win, const aomhip_rect *d_units, const aomhip_rect *h_units, int n_units,
+                               int use_downsampled_wiener_stats, int64_t *d_M, int64_t *d_H);
+
 /* ------------------------------------------------------------------ rtcd-signature conformance entry points */
 
 /* aom_dsp_rtcd_defs.pl:762-763 aom_sad{W}x{H} / aom_sad_skip_{W}x{H}; host pointers. */

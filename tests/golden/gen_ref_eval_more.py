@@ -472,8 +472,41 @@ def gen_cdef_search():
         k += 1
     save("ref_eval_cdef_search.npz", arrays, cases)
 
+
+def gen_lrstats():
+    """av1_compute_stats_c (with and without the down-sampled rows) and av1_compute_stats_highbd_c (av1/encoder/pickrst.c)."""
+    ev = evaluator([])
+    for f in ["aom/aom_codec.h", "av1/common/restoration.h", "av1/encoder/pickrst.h", "av1/encoder/pickrst.c"]:
+        ev.load("/root/reference/" + f)
+    rng = np.random.default_rng(20261021)
+    arrays, cases = {}, []
+    S, ROWS = 40, 32
+    k = 0
+    for bd in (8, 10, 12):
+        mx = (1 << bd) - 1
+        dgd = rng.integers(0, mx + 1, (ROWS, S))
+        dgd[:8] = np.where(rng.integers(0, 2, (8, S)) > 0, mx, 0)
+        src = np.clip(dgd + rng.integers(-(9 << (bd - 8)), (9 << (bd - 8)) + 1, dgd.shape), 0, mx)
+        arrays["dgd%d" % bd], arrays["src%d" % bd] = dgd.astype(np.uint16), src.astype(np.uint16)
+        ct = "uint8_t" if bd == 8 else "uint16_t"
+        D, Sx = ev.array(dgd.ravel(), ct), ev.array(src.ravel(), ct)
+        for (win, rect, ds) in ((7, (4, 17, 3, 13), 0), (5, (5, 14, 4, 15), 0), (7, (4, 15, 3, 14), 1), (5, (8, 13, 10, 12), 1)):
+            if bd > 8 and ds:
+                continue
+            hs, he, vs, ve = rect
+            win2 = win * win
+            M, Hm = ev.array([0] * win2, "int64_t"), ev.array([0] * (win2 * win2), "int64_t")
+            if bd == 8:
+                ev.call("av1_compute_stats_c", win, D, Sx, hs, he, vs, ve, S, S, M, Hm, ds)
+            else:
+                ev.call("av1_compute_stats_highbd_c", win, D, Sx, hs, he, vs, ve, S, S, M, Hm, bd)
+            arrays["M%d" % k], arrays["H%d" % k] = np.asarray(M.buf, np.int64), np.asarray(Hm.buf, np.int64)
+            cases.append({"k": k, "bd": bd, "win": win, "rect": list(rect), "downsample": ds})
+            k += 1
+    save("ref_eval_lrstats.npz", arrays, cases)
+
 if __name__ == "__main__":
-    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound", "convolve", "rdhelp", "cdef_search"]:
+    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound", "convolve", "rdhelp", "cdef_search", "lrstats"]:
         t = time.time()
         globals()["gen_" + w]()
         print("  (%s: %.1f s)" % (w, time.time() - t))

@@ -475,3 +475,22 @@ def test_cdef_search_distortion_matches_reference_evaluation(oracle):
         others = got.copy()
         others[:, fb[0], fb[1]] = 0
         assert not others.any()
+
+
+def test_wiener_stats_match_reference_evaluation(oracle):
+    """orc_compute_stats against the interpreted av1_compute_stats_c (full and down-sampled rows) and
+    av1_compute_stats_highbd_c (10 / 12-bit dividers) of av1/encoder/pickrst.c, 7x7 and 5x5 windows."""
+    z, cases = load("ref_eval_lrstats.npz")
+    assert len(cases) == 8
+    f = oracle.lib.orc_compute_stats
+    f.restype = None
+    for c in cases:
+        bd, win = c["bd"], c["win"]
+        e16 = int(bd > 8)
+        dt = np.uint16 if e16 else np.uint8
+        dgd, src = np.ascontiguousarray(z["dgd%d" % bd], dt), np.ascontiguousarray(z["src%d" % bd], dt)
+        hs, he, vs, ve = c["rect"]
+        M, H = np.zeros(win * win, np.int64), np.zeros(win ** 4, np.int64)
+        f(win, C.c_void_p(dgd.ctypes.data), C.c_void_p(src.ctypes.data), hs, he, vs, ve, dgd.shape[1], src.shape[1], e16, bd, c["downsample"],
+          C.c_void_p(M.ctypes.data), C.c_void_p(H.ctypes.data))
+        assert np.array_equal(M, z["M%d" % c["k"]]) and np.array_equal(H, z["H%d" % c["k"]]), c
