@@ -4,11 +4,17 @@
 //
 // Per unit: avg = floor(mean of the degraded pixels), then over the unit's pixels M[k] = sum Y[k] X and
 // H[k][l] = sum Y[k] Y[l] with Y = the win x win window of (degraded - avg) (k = column offset major, row offset
-// minor) and X = source - avg.  These are exact integer sums, so the order of summation is free: one workgroup owns
-// one unit, every thread owns up to five (k, l) entries of the upper triangle (1225 + 49 M entries for win 7) and
-// keeps their 64-bit sums in registers, and the unit streams through LDS in bands of 16 rows as (pixel - avg) int16
-// tiles -- each staged pixel is reused by ~1274 multiply-adds.  Inner loop: two LDS reads + one v_mad_i32_i24 per
-// term, 32-bit partial sums over 64-pixel runs (4095^2 * 64 < 2^31) folded into the 64-bit totals.
+// minor) and X = source - avg.  These are exact integer sums, so the order of summation is free.
+//
+// Mapping (second version; the first one -- a thread per (k, l) entry reading both factors from LDS for every term --
+// ran at 2 % of the integer rate, profiles/r01_wiener_stats.md): a WAVEFRONT owns one pair of window COLUMNS (dxa <= dxb;
+// 28 pairs for win 7, plus win tasks that pair a column with X for M), i.e. a win x win block of H, and keeps its
+// win^2 sums in registers.  Its LANES are 64 adjacent pixel columns; each lane walks down the rows of a 16-row band
+// with the two columns' last `win` values in registers (one LDS read per column per pixel, conflict-free because
+// adjacent lanes read adjacent elements) and issues win^2 v_mad_i32_i24 per pixel.  32-bit band sums (4095^2 x 16
+// rows x 4 column chunks < 2^31) are folded into 64-bit totals per band, and the 64 lanes are reduced once per unit.
+// A workgroup = 4 wavefronts = 4 tasks of one unit; ceil(tasks / 4) workgroups share a unit and each stages the
+// band's (pixel - avg) tile for itself.
 // The 8-bit function's down-sampled mode (every 4th row weighted by 4, the last one by what is left,
 // pickrst.c:988-1013) is a per-row weight here.
 #include "common.h"
@@ -18,20 +24,23 @@ namespace aomhip {
 constexpr int kBandRows = 16;
 constexpr int kMaxUnit = 256;                      // restoration units are at most 256 pixels wide (RESTORATION_UNITSIZE_MAX)
 constexpr int kTileW = kMaxUnit + 6 + 2;           // + the window margin, padded to an even count
-constexpr int kMaxTerms = 5;                       // ceil((1225 + 49) / 256)
 
-template <typename T>
+template <typename T, int WIN>
 __global__ __launch_bounds__(256) void wiener_stats_kernel(const T *__restrict__ dgd, int dgd_stride, const T *__restrict__ src, int src_stride,
-                                                           const aomhip_rect *__restrict__ units, int win, int downsample, int divider,
+                                                           const aomhip_rect *__restrict__ units, int downsample, int divider,
                                                            int64_t *__restrict__ M_out, int64_t *__restrict__ H_out) {
-  __shared__ int16_t ytile[(kBandRows + 6) * kTileW];
+  constexpr int HALF = WIN / 2, WIN2 = WIN * WIN;
+  constexpr int NP = WIN * (WIN + 1) / 2;          // column pairs dxa <= dxb
+  constexpr int NT = NP + WIN;                     // + the M tasks (column dxa against X)
+  constexpr int TG = (NT + 3) / 4;                 // workgroups per unit
+  __shared__ int16_t ytile[(kBandRows + 2 * HALF) * kTileW];
   __shared__ int16_t xtile[kBandRows * kTileW];
   __shared__ unsigned long long red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const aomhip_rect u = units[blockIdx.x];
+  const int unit = blockIdx.x / TG, task = (blockIdx.x % TG) * 4 + wave;
+  const aomhip_rect u = units[unit];
   const int uw = u.h_end - u.h_start, uh = u.v_end - u.v_start;
   if (uw <= 0 || uh <= 0 || uw > kMaxUnit) return;  // (checked on the host when the caller passes the list there too)
-  const int half = win >> 1, win2 = win * win, nH = win2 * (win2 + 1) / 2;
 
   // find_average: floor(sum / count)
   unsigned long long s = 0;
@@ -45,80 +54,110 @@ __global__ __launch_bounds__(256) void wiener_stats_kernel(const T *__restrict__
   __syncthreads();
   const int avg = (int)((red[0] + red[1] + red[2] + red[3]) / (unsigned long long)(uw * uh));
 
-  // this thread's terms: entry p of [upper triangle of H, row-major | M]
-  int oa[kMaxTerms], ob[kMaxTerms], kk[kMaxTerms], ll[kMaxTerms];
-  int64_t acc[kMaxTerms];
-  int n_terms = 0;
-  for (int p = tid; p < nH + win2; p += 256) {
-    int k, l;
-    if (p < nH) {
-      k = 0;
-      int rem = p;
-      while (rem >= win2 - k) {
-        rem -= win2 - k;
-        ++k;
-      }
-      l = k + rem;
-    } else {
-      k = p - nH;
-      l = -1;  // M entry: the second factor is X
+  // this wavefront's task: columns (dxa, dxb) of the window, or (dxa, X)
+  const bool live = task < NT, is_m = task >= NP;
+  int dxa = 0, dxb = 0;
+  if (live && !is_m) {
+    int rem = task;
+    while (rem >= WIN - dxa) {
+      rem -= WIN - dxa;
+      ++dxa;
     }
-    kk[n_terms] = k;
-    ll[n_terms] = l;
-    // window index -> (column offset, row offset): idx = (dx + half) * win + (dy + half) (pickrst.c:957-963)
-    oa[n_terms] = (k % win) * kTileW + k / win;
-    ob[n_terms] = l < 0 ? half : (l % win) * kTileW + l / win;   // X tile: same column origin as the window centre
-    acc[n_terms] = 0;
-    ++n_terms;
+    dxb = dxa + rem;
+  } else if (live) {
+    dxa = task - NP;
   }
+  int64_t tot[WIN2];
+#pragma unroll
+  for (int i = 0; i < WIN2; ++i) tot[i] = 0;
 
   for (int band = 0; band < uh; band += kBandRows) {
     const int rows = min(kBandRows, uh - band);
     __syncthreads();
-    // stage (pixel - avg): window rows band - half .. band + rows - 1 + half, columns -half .. uw - 1 + half
-    for (int i = tid; i < (rows + 2 * half) * (uw + 2 * half); i += 256) {
-      const int r = i / (uw + 2 * half), c = i - r * (uw + 2 * half);
-      ytile[r * kTileW + c] = (int16_t)((int)dgd[(int64_t)(u.v_start + band + r - half) * dgd_stride + u.h_start + c - half] - avg);
+    // stage (pixel - avg): rows band - HALF .. band + rows - 1 + HALF, columns -HALF .. uw - 1 + HALF
+    for (int i = tid; i < (rows + 2 * HALF) * (uw + 2 * HALF); i += 256) {
+      const int r = i / (uw + 2 * HALF), c = i - r * (uw + 2 * HALF);
+      ytile[r * kTileW + c] = (int16_t)((int)dgd[(int64_t)(u.v_start + band + r - HALF) * dgd_stride + u.h_start + c - HALF] - avg);
     }
     for (int i = tid; i < rows * uw; i += 256) {
       const int r = i / uw, c = i - r * uw;
-      xtile[r * kTileW + c + half] = (int16_t)((int)src[(int64_t)(u.v_start + band + r) * src_stride + u.h_start + c] - avg);
+      xtile[r * kTileW + c] = (int16_t)((int)src[(int64_t)(u.v_start + band + r) * src_stride + u.h_start + c] - avg);
     }
     __syncthreads();
-    for (int t = 0; t < n_terms; ++t) {
-      const bool is_m = ll[t] < 0;
+    if (!live) continue;
+    int part[WIN2];
+#pragma unroll
+    for (int i = 0; i < WIN2; ++i) part[i] = 0;
+    for (int j = lane; j < uw; j += 64) {
+      // window entry (dx, dy) of pixel (r, j) is tile element (r + dy, j + dx)
+      const int16_t *ca = ytile + j + dxa, *cb = ytile + j + dxb;
+      int wa[WIN], wb[WIN];
+#pragma unroll
+      for (int i = 1; i < WIN; ++i) {
+        wa[i] = ca[(i - 1) * kTileW];
+        wb[i] = cb[(i - 1) * kTileW];
+      }
       for (int r = 0; r < rows; ++r) {
-        const int row = band + r;
+#pragma unroll
+        for (int i = 0; i < WIN - 1; ++i) {
+          wa[i] = wa[i + 1];
+          wb[i] = wb[i + 1];
+        }
+        wa[WIN - 1] = ca[(r + WIN - 1) * kTileW];
+        wb[WIN - 1] = cb[(r + WIN - 1) * kTileW];
         int weight = 1;
         if (downsample) {
+          const int row = band + r;
           if (row & 3) continue;
           weight = min(4, uh - row);
         }
-        const int16_t *pa = ytile + r * kTileW + oa[t];
-        const int16_t *pb = is_m ? xtile + r * kTileW + ob[t] - half : ytile + r * kTileW + ob[t];
-        // (M: X of pixel j sits at column j + half of its tile row, the window entry k of pixel j at column j + k / win)
-        int64_t rowsum = 0;
-        for (int j0 = 0; j0 < uw; j0 += 64) {
-          const int je = min(uw, j0 + 64);
-          int part = 0;
-          for (int j = j0; j < je; ++j) part += __mul24((int)pa[j], (int)(is_m ? pb[j + half] : pb[j]));
-          rowsum += part;
+        if (is_m) {
+          const int xw = (int)xtile[r * kTileW + j] * weight;
+#pragma unroll
+          for (int ya = 0; ya < WIN; ++ya) part[ya] += __mul24(wa[ya], xw);
+        } else {
+#pragma unroll
+          for (int ya = 0; ya < WIN; ++ya) {
+            const int aw = wa[ya] * weight;  // <= 4095 * 4: still 24 bits
+#pragma unroll
+            for (int yb = 0; yb < WIN; ++yb) part[ya * WIN + yb] += __mul24(aw, wb[yb]);
+          }
         }
-        acc[t] += rowsum * weight;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WIN2; ++i) tot[i] += part[i];
+  }
+  if (!live) return;
+  int64_t *M = M_out + (int64_t)unit * WIN2;
+  int64_t *H = H_out + (int64_t)unit * WIN2 * WIN2;
+#pragma unroll
+  for (int i = 0; i < WIN2; ++i) {
+    int64_t v = tot[i];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor((long long)v, m, 64);
+    if (lane == 0 && !(is_m && i >= WIN)) {
+      v /= divider;  // bit_depth_divider, C division (pickrst.c:1041-1045,1073-1081)
+      if (is_m) {
+        M[dxa * WIN + i] = v;
+      } else {
+        const int k = dxa * WIN + i / WIN, l = dxb * WIN + i % WIN;   // window index = column offset major (pickrst.c:957-963)
+        H[k * WIN2 + l] = v;
+        H[l * WIN2 + k] = v;
       }
     }
   }
-  int64_t *M = M_out + (int64_t)blockIdx.x * win2;
-  int64_t *H = H_out + (int64_t)blockIdx.x * win2 * win2;
-  for (int t = 0; t < n_terms; ++t) {
-    const int64_t v = acc[t] / divider;  // bit_depth_divider, C division (pickrst.c:1041-1045,1073-1081)
-    if (ll[t] < 0) {
-      M[kk[t]] = v;
-    } else {
-      H[kk[t] * win2 + ll[t]] = v;
-      H[ll[t] * win2 + kk[t]] = v;
-    }
-  }
+}
+
+template <typename T>
+static void launch_stats(hipStream_t st, int win, int n_units, const void *d, int dstride, const void *s, int sstride, const aomhip_rect *units,
+                         int downsample, int divider, int64_t *M, int64_t *H) {
+  if (win == 7)
+    hipLaunchKernelGGL((wiener_stats_kernel<T, 7>), dim3(n_units * 9), dim3(256), 0, st, static_cast<const T *>(d), dstride,
+                       static_cast<const T *>(s), sstride, units, downsample, divider, M, H);
+  else
+    hipLaunchKernelGGL((wiener_stats_kernel<T, 5>), dim3(n_units * 5), dim3(256), 0, st, static_cast<const T *>(d), dstride,
+                       static_cast<const T *>(s), sstride, units, downsample, divider, M, H);
 }
 
 }  // namespace aomhip
@@ -151,12 +190,9 @@ extern "C" int aomhip_compute_stats_batch(aomhip_ctx *ctx, const aomhip_planes *
                   ((size_t)src_frame * src->frame_stride + (size_t)src->border * src->stride + src->border) * esz;
   const int divider = dgd->bit_depth == 12 ? 16 : dgd->bit_depth == 10 ? 4 : 1;
   if (esz == 1)
-    hipLaunchKernelGGL(wiener_stats_kernel<uint8_t>, dim3(n_units), dim3(256), 0, ctx->stream, reinterpret_cast<const uint8_t *>(d), dgd->stride,
-                       reinterpret_cast<const uint8_t *>(s), src->stride, d_units, wiener_win, use_downsampled_wiener_stats != 0, divider, d_M,
-                       d_H);
+    launch_stats<uint8_t>(ctx->stream, wiener_win, n_units, d, dgd->stride, s, src->stride, d_units, use_downsampled_wiener_stats != 0, divider, d_M, d_H);
   else
-    hipLaunchKernelGGL(wiener_stats_kernel<uint16_t>, dim3(n_units), dim3(256), 0, ctx->stream, reinterpret_cast<const uint16_t *>(d), dgd->stride,
-                       reinterpret_cast<const uint16_t *>(s), src->stride, d_units, wiener_win, 0, divider, d_M, d_H);
+    launch_stats<uint16_t>(ctx->stream, wiener_win, n_units, d, dgd->stride, s, src->stride, d_units, 0, divider, d_M, d_H);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

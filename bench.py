@@ -631,6 +631,44 @@ def run_cdef_search(pkg, ctx, orc, steps, warmup):
     return out
 
 
+def run_wiener_stats(pkg, ctx, orc, steps, warmup):
+    """av1_compute_stats for every restoration unit of a 4K luma plane (7x7 window): 8-bit with 64x64 and 256x256 units, and
+    10-bit 64x64.  Informational; 1274 multiply-adds per pixel (1225 H entries + 49 M entries)."""
+    import ctypes as C
+    W, H, border = 3840, 2160, 16
+    out = {"workload": "wiener_stats_luma_4k"}
+    for name, bd, unit in (("8bit_units64", 8, 64), ("8bit_units256", 8, 256), ("10bit_units64", 10, 64)):
+        dgd = pkg.synth.lcg_frame(W, H, 3, 0, bd)
+        src = pkg.synth.lcg_frame(W, H, 3, 1, bd)
+        pd, ps = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+        ctx.planes_upload(pd, 0, dgd); ctx.planes_upload(ps, 0, src)
+        rects = [(x, min(x + unit, W), y, min(y + unit, H)) for y in range(0, H, unit) for x in range(0, W, unit)]
+        units = np.zeros(len(rects), pkg.capi.rect_dtype)
+        for i, r in enumerate(rects):
+            units[i] = r
+        d_u, d_M, d_H = ctx.to_device(units), ctx.malloc(8 * 49 * len(rects)), ctx.malloc(8 * 2401 * len(rects))
+        ms = kernel_avg_ms(ctx, lambda: ctx.compute_stats_batch(pd, 0, ps, 0, 7, d_u, None, len(rects), 0, d_M, d_H), max(steps, 3))
+        out[name] = {"ms_per_frame": ms, "units": len(rects), "mac_per_s": float(W) * H * 1274 / ms * 1e3}
+        if name == "8bit_units64":          # exact check of two units against the oracle
+            Hm = ctx.from_device(d_H, (len(rects), 2401), np.int64)
+            db, sb = orc.extend_plane(dgd, border), orc.extend_plane(src, border)
+            ok = True
+            f = orc.lib.orc_compute_stats
+            f.restype = None
+            for i in (0, len(rects) - 1):
+                wm, wh = np.zeros(49, np.int64), np.zeros(2401, np.int64)
+                hs, he, vs, ve = rects[i]
+                f(7, C.c_void_p(orc._addr(db, border, border)), C.c_void_p(orc._addr(sb, border, border)), hs, he, vs, ve, db.shape[1], sb.shape[1], 0, 8, 0,
+                  C.c_void_p(wm.ctypes.data), C.c_void_p(wh.ctypes.data))
+                ok = ok and bool(np.array_equal(Hm[i], wh))
+            out["parity_sample"] = ok
+        for d in (d_u, d_M, d_H):
+            ctx.free(d)
+        ctx.planes_free(pd); ctx.planes_free(ps)
+    out["value"], out["unit"] = out["8bit_units64"]["mac_per_s"], "window multiply-adds/s"
+    return out
+
+
 def time_steps(wl, ctx, dist, dev, steps, warmup):
     for _ in range(warmup):
         wl.step()
@@ -805,6 +843,7 @@ def main():
             others.append(run_mesh(pkg, ctx, orc, max(4, args.steps // 4), 1))
             others.append(run_search_default(pkg, ctx, orc, max(4, args.steps // 2), 1))
             others.append(run_cdef_search(pkg, ctx, orc, max(4, args.steps // 4), 1))
+            others.append(run_wiener_stats(pkg, ctx, orc, max(3, args.steps // 6), 1))
     ctx.close()
 
     if rank == 0:
