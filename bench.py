@@ -763,7 +763,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sad16x16_modeA_1080p_8bit",
-                    choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "search_4k_10bit", "inner_loop_4k_10bit", "default_search_4k_10bit"])
+                    choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "search_4k_10bit", "inner_loop_4k_10bit", "default_search_4k_10bit", "cdef_search_4k_10bit",
+                                                "wiener_stats_4k"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -818,6 +819,14 @@ def main():
         print(json.dumps(dict(r, metric="search blocks/s", n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True,
                               scaling="weak", vs_baseline=None, dtype="u16", data="synthetic",
                               ms_per_step=r["full_pixel_search_NSTEP_ms_per_frame"] + r["subpel_tree_8tap_ms_per_frame"])))
+        return
+    if args.workload in ("cdef_search_4k_10bit", "wiener_stats_4k"):  # informational encoder-side searches (single GPU)
+        r = (run_cdef_search if args.workload == "cdef_search_4k_10bit" else run_wiener_stats)(pkg, ctx, orc, args.steps, args.warmup)
+        ctx.close()
+        first = r["full_search_64"] if "full_search_64" in r else r["8bit_units64"]
+        print(json.dumps(dict(r, metric=r["unit"], n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
+                              vs_baseline=None, dtype="u16" if "cdef" in args.workload else "u8", data="synthetic",
+                              ms_per_step=first["ms_per_frame"], config={"workload": r["workload"]})))
         return
     if args.workload == "txq_1080p_8bit":  # profiling convenience: transform+quantise only (single GPU)
         r = run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline)
