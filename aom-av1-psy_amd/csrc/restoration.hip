@@ -91,36 +91,42 @@ __global__ __launch_bounds__(256) void wiener_stats_kernel(const T *__restrict__
     for (int j = lane; j < uw; j += 64) {
       // window entry (dx, dy) of pixel (r, j) is tile element (r + dy, j + dx)
       const int16_t *ca = ytile + j + dxa, *cb = ytile + j + dxb;
+      // the two columns' last WIN values live in ROTATING slots: tile row t sits in slot t % WIN, so the row loop is
+      // unrolled by WIN and every register index below is static (no per-row shifting of the windows)
       int wa[WIN], wb[WIN];
 #pragma unroll
-      for (int i = 1; i < WIN; ++i) {
-        wa[i] = ca[(i - 1) * kTileW];
-        wb[i] = cb[(i - 1) * kTileW];
+      for (int i = 0; i < WIN - 1; ++i) {
+        wa[i] = ca[i * kTileW];
+        wb[i] = cb[i * kTileW];
       }
-      for (int r = 0; r < rows; ++r) {
+      for (int r0 = 0; r0 < rows; r0 += WIN) {
 #pragma unroll
-        for (int i = 0; i < WIN - 1; ++i) {
-          wa[i] = wa[i + 1];
-          wb[i] = wb[i + 1];
-        }
-        wa[WIN - 1] = ca[(r + WIN - 1) * kTileW];
-        wb[WIN - 1] = cb[(r + WIN - 1) * kTileW];
-        int weight = 1;
-        if (downsample) {
-          const int row = band + r;
-          if (row & 3) continue;
-          weight = min(4, uh - row);
-        }
-        if (is_m) {
-          const int xw = (int)xtile[r * kTileW + j] * weight;
+        for (int q = 0; q < WIN; ++q) {
+          const int r = r0 + q;
+          if (r < rows) {
+            wa[(q + WIN - 1) % WIN] = ca[(r + WIN - 1) * kTileW];
+            wb[(q + WIN - 1) % WIN] = cb[(r + WIN - 1) * kTileW];
+            int weight = 1;
+            bool use = true;
+            if (downsample) {
+              const int row = band + r;
+              use = (row & 3) == 0;
+              weight = min(4, uh - row);
+            }
+            if (use) {
+              if (is_m) {
+                const int xw = (int)xtile[r * kTileW + j] * weight;
 #pragma unroll
-          for (int ya = 0; ya < WIN; ++ya) part[ya] += __mul24(wa[ya], xw);
-        } else {
+                for (int ya = 0; ya < WIN; ++ya) part[ya] += __mul24(wa[(q + ya) % WIN], xw);
+              } else {
 #pragma unroll
-          for (int ya = 0; ya < WIN; ++ya) {
-            const int aw = wa[ya] * weight;  // <= 4095 * 4: still 24 bits
+                for (int ya = 0; ya < WIN; ++ya) {
+                  const int aw = downsample ? wa[(q + ya) % WIN] * weight : wa[(q + ya) % WIN];  // <= 255 * 4
 #pragma unroll
-            for (int yb = 0; yb < WIN; ++yb) part[ya * WIN + yb] += __mul24(aw, wb[yb]);
+                  for (int yb = 0; yb < WIN; ++yb) part[ya * WIN + yb] += __mul24(aw, wb[(q + yb) % WIN]);
+                }
+              }
+            }
           }
         }
       }
