@@ -164,6 +164,7 @@ _protos = {
     "aomhip_cdef_search_sse_chroma": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "aomhip_lpf_search_sse": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _vp, _i64, _i, _i, _i, _i, _vp]),
     "aomhip_compute_stats_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "aomhip_plane_sse": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
@@ -403,6 +404,9 @@ class Context:
         hp = h_units.ctypes.data if h_units is not None else None
         check(lib.aomhip_compute_stats_batch(self.h, C.byref(dgd), dgd_frame, C.byref(src), src_frame, win, d_units, hp, n, downsample, d_M, d_H),
               "aomhip_compute_stats_batch")
+
+    def plane_sse(self, a, a_frame, b, b_frame, d_sse):
+        check(lib.aomhip_plane_sse(self.h, C.byref(a), a_frame, C.byref(b), b_frame, d_sse), "aomhip_plane_sse")
 
     def build_pred_fullpel(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n):
         check(lib.aomhip_build_pred_fullpel(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks,

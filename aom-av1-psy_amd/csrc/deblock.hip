@@ -257,6 +257,30 @@ int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, con
   return AOMHIP_OK;
 }
 
+int aomhip_plane_sse(aomhip_ctx *ctx, const aomhip_planes *a, int a_frame, const aomhip_planes *b, int b_frame, uint64_t *d_sse) {
+  if (!ctx || !a || !b || !a->base || !b->base || !d_sse || a_frame < 0 || a_frame >= a->n_frames || b_frame < 0 || b_frame >= b->n_frames ||
+      a->width != b->width || a->height != b->height || a->bit_depth != b->bit_depth) {
+    set_error("aomhip_plane_sse: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  const size_t esz = a->bit_depth == 8 ? 1 : 2;
+  const char *pa = static_cast<const char *>(a->base) + ((size_t)a_frame * a->frame_stride + (size_t)a->border * a->stride + a->border) * esz;
+  const char *pb = static_cast<const char *>(b->base) + ((size_t)b_frame * b->frame_stride + (size_t)b->border * b->stride + b->border) * esz;
+  if (hipMemsetAsync(d_sse, 0, sizeof(uint64_t), ctx->stream) != hipSuccess) {
+    set_error("aomhip_plane_sse: memset failed");
+    return AOMHIP_ERR_HIP;
+  }
+  const dim3 grid(std::min((a->width + 255) / 256, 16), a->height);
+  if (esz == 1)
+    hipLaunchKernelGGL(plane_sse_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, reinterpret_cast<const uint8_t *>(pa), a->stride,
+                       reinterpret_cast<const uint8_t *>(pb), b->stride, a->width, a->height, reinterpret_cast<unsigned long long *>(d_sse));
+  else
+    hipLaunchKernelGGL(plane_sse_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream, reinterpret_cast<const uint16_t *>(pa), a->stride,
+                       reinterpret_cast<const uint16_t *>(pb), b->stride, a->width, a->height, reinterpret_cast<unsigned long long *>(d_sse));
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
 int aomhip_lpf_search_sse(aomhip_ctx *ctx, const aomhip_planes *recon, int recon_frame, const aomhip_planes *scratch, int scratch_frame,
                           const aomhip_planes *source, int source_frame, const uint8_t *d_edge_params, int64_t trial_stride, int n_trials,
                           int units_stride, int sharpness, int passes, uint64_t *d_sse) {

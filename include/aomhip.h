@@ -356,6 +356,10 @@ int aomhip_inv_txfm_add_batch(aomhip_ctx *ctx, const int32_t *d_dqcoeff, int tx_
 int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, const uint8_t *d_edge_params,
                          int units_stride, int sharpness, int passes);
 
+/* aom_get_sse_plane / aom_get_y_sse / aom_highbd_get_y_sse (aom_dsp/psnr.c:84-330): the sum of squared differences of two
+ * whole planes (the PSNR numerator of aom_calc_psnr, and try_filter_frame's error measure); *d_sse is overwritten. */
+int aomhip_plane_sse(aomhip_ctx *ctx, const aomhip_planes *a, int a_frame, const aomhip_planes *b, int b_frame, uint64_t *d_sse);
+
 /* The trial loop of the encoder's loop-filter level search: search_filter_level -> try_filter_frame
  * (av1/encoder/picklpf.c:49-86,88-193) = av1_loop_filter_frame on a copy of the unfiltered reconstruction, then
  * aom_get_sse_plane against the source (aom_dsp/psnr.c:84-143,208-330).  One call evaluates n_trials candidate settings:

@@ -44,3 +44,23 @@ def test_lpf_trials_vs_oracle(hip, oracle, ctx, bd):
         ctx.lpf_search_sse(pr, 0, pr, 1, ps, 0, d_p, 16, 2, stack.shape[2], 2, 3, d_sse)                  # trials overlap
     ctx.free(d_p); ctx.free(d_sse)
     ctx.planes_free(pr); ctx.planes_free(ps)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_plane_sse(hip, ctx, bd):
+    """aom_get_y_sse on whole planes (odd width: the visible area only, never the border)."""
+    rng = np.random.default_rng(bd)
+    W, H, border = 333, 77, 16
+    a = rng.integers(0, 1 << bd, (H, W)).astype(np.uint8 if bd == 8 else np.uint16)
+    b = rng.integers(0, 1 << bd, (H, W)).astype(a.dtype)
+    a[:5], b[:5] = (1 << bd) - 1, 0
+    pa, pb = ctx.planes_alloc(W, H, border, bd, 2), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(pa, 1, a); ctx.planes_upload(pb, 0, b)
+    d = ctx.malloc(8)
+    ctx.plane_sse(pa, 1, pb, 0, d)
+    assert int(ctx.from_device(d, (1,), np.uint64)[0]) == int(((a.astype(np.int64) - b.astype(np.int64)) ** 2).sum())
+    ctx.plane_sse(pb, 0, pb, 0, d)
+    assert int(ctx.from_device(d, (1,), np.uint64)[0]) == 0
+    with pytest.raises(hip.capi.AomHipError):
+        ctx.plane_sse(pa, 2, pb, 0, d)
+    ctx.free(d); ctx.planes_free(pa); ctx.planes_free(pb)
