@@ -165,6 +165,7 @@ _protos = {
     "aomhip_lpf_search_sse": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _vp, _i64, _i, _i, _i, _i, _vp]),
     "aomhip_compute_stats_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "aomhip_plane_sse": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp]),
+    "aomhip_build_inter_pred_ex_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
@@ -372,7 +373,11 @@ class Context:
                                            d_mvcost_row, d_mvcost_col, d_blocks, d_cost_list, n, d_mv, d_err, d_dist, d_sse),
               "aomhip_subpel_tree_batch")
 
-    def build_inter_pred_batch(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, filter_x=0, filter_y=0):
+    def build_inter_pred_batch(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, filter_x=0, filter_y=0, ss_x=0, ss_y=0):
+        if ss_x or ss_y:
+            check(lib.aomhip_build_inter_pred_ex_batch(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks, d_mv,
+                                                       n_blocks, filter_x, filter_y, ss_x, ss_y), "aomhip_build_inter_pred_ex_batch")
+            return
         check(lib.aomhip_build_inter_pred_batch(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks, d_mv, n_blocks,
                                                 filter_x, filter_y), "aomhip_build_inter_pred_batch")
 

@@ -67,7 +67,7 @@ template <typename T, int W, int H>
 __global__ __launch_bounds__(256) void inter_pred_kernel(PlaneView<T> ref, int ref_frame, T *dst_origin, int dst_stride,
                                                          const aomhip_search_block *__restrict__ blocks,
                                                          const int16_t *__restrict__ mv, int n_blocks, int set_x, int set_y, int bit_depth,
-                                                         int x_lo, int x_hi, int y_lo, int y_hi) {
+                                                         int x_lo, int x_hi, int y_lo, int y_hi, int mvx_mul, int mvy_mul) {
   constexpr int LPB = W < 64 ? W : 64;  // lanes per block
   constexpr int BPW = 64 / LPB;         // blocks per wavefront
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void inter_pred_kernel(PlaneView<T> ref, int r
   if (bi >= n_blocks) return;
   const int col0 = lane % LPB;
   const int bx = blocks[bi].bx, by = blocks[bi].by;
-  // init_subpel_params (reconinter.h:130-165), unscaled luma: position in 1/16 pel
-  int pos_x = (bx << 4) + mv[2 * bi + 1] * 2, pos_y = (by << 4) + mv[2 * bi] * 2;
+  // init_subpel_params (reconinter.h:130-165), unscaled: position in 1/16 pel, mv * (1 << (1 - subsampling))
+  int pos_x = (bx << 4) + mv[2 * bi + 1] * mvx_mul, pos_y = (by << 4) + mv[2 * bi] * mvy_mul;
   // keeps every access inside the allocation; the identity for MVs within av1_set_mv_limits (mcomp.h:216-247)
   pos_x = min(max(pos_x, x_lo), x_hi);
   pos_y = min(max(pos_y, y_lo), y_hi);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void pred_copy_kernel(PlaneView<T> ref, int re
 
 template <typename T>
 static int launch_inter_pred(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred, int pred_frame, int bw,
-                             int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv, int n_blocks, int fx, int fy) {
+                             int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv, int n_blocks, int fx, int fy, int ss_x, int ss_y) {
   // av1_get_interp_filter_params_with_block_size (filter.h:247-253): a dimension <= 4 takes the 4-tap sets
   auto set_of = [](int f, int dim) { return dim <= 4 ? (f == 1 ? 5 : f == 3 ? 3 : 4) : f; };
   T *d = reinterpret_cast<T *>(pred->base) + (size_t)pred_frame * pred->frame_stride + (size_t)pred->border * pred->stride + pred->border;
@@ -161,7 +161,8 @@ static int launch_inter_pred(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_
 #define X(W, H)                                                                                                                    \
   if (bw == W && bh == H) {                                                                                                        \
     hipLaunchKernelGGL((inter_pred_kernel<T, W, H>), grid, block, 0, ctx->stream, view_of<T>(*ref), ref_frame, d, pred->stride,   \
-                       d_blocks, d_mv, n_blocks, set_of(fx, W), set_of(fy, H), ref->bit_depth, x_lo, x_hi, y_lo, y_hi);            \
+                       d_blocks, d_mv, n_blocks, set_of(fx, W), set_of(fy, H), ref->bit_depth, x_lo, x_hi, y_lo, y_hi, 2 >> ss_x,  \
+                       2 >> ss_y);                                                                                                 \
     AOMHIP_LAUNCH_CHECK();                                                                                                         \
     return AOMHIP_OK;                                                                                                              \
   }
@@ -175,12 +176,13 @@ static int launch_inter_pred(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_
 
 using namespace aomhip;
 
-extern "C" int aomhip_build_inter_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred,
-                                             int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv,
-                                             int n_blocks, int interp_filter_x, int interp_filter_y) {
+extern "C" int aomhip_build_inter_pred_ex_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred,
+                                                int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv,
+                                                int n_blocks, int interp_filter_x, int interp_filter_y, int subsampling_x, int subsampling_y) {
   if (!ctx || !ref || !pred || !ref->base || !pred->base || (n_blocks > 0 && (!d_blocks || !d_mv)) || n_blocks < 0 || ref_frame < 0 ||
       ref_frame >= ref->n_frames || pred_frame < 0 || pred_frame >= pred->n_frames || !valid_block(bw, bh) ||
-      ref->bit_depth != pred->bit_depth || interp_filter_x < 0 || interp_filter_x > 3 || interp_filter_y < 0 || interp_filter_y > 3) {
+      ref->bit_depth != pred->bit_depth || interp_filter_x < 0 || interp_filter_x > 3 || interp_filter_y < 0 || interp_filter_y > 3 ||
+      subsampling_x < 0 || subsampling_x > 1 || subsampling_y < 0 || subsampling_y > 1) {
     set_error("aomhip_build_inter_pred_batch: invalid argument");
     return AOMHIP_ERR_INVALID;
   }
@@ -190,8 +192,17 @@ extern "C" int aomhip_build_inter_pred_batch(aomhip_ctx *ctx, const aomhip_plane
   }
   if (n_blocks == 0) return AOMHIP_OK;
   if (ref->bit_depth == 8)
-    return launch_inter_pred<uint8_t>(ctx, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, interp_filter_x, interp_filter_y);
-  return launch_inter_pred<uint16_t>(ctx, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, interp_filter_x, interp_filter_y);
+    return launch_inter_pred<uint8_t>(ctx, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, interp_filter_x, interp_filter_y,
+                                      subsampling_x, subsampling_y);
+  return launch_inter_pred<uint16_t>(ctx, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, interp_filter_x, interp_filter_y,
+                                     subsampling_x, subsampling_y);
+}
+
+extern "C" int aomhip_build_inter_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred,
+                                             int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv,
+                                             int n_blocks, int interp_filter_x, int interp_filter_y) {
+  return aomhip_build_inter_pred_ex_batch(ctx, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, interp_filter_x,
+                                          interp_filter_y, 0, 0);
 }
 
 extern "C" int aomhip_build_pred_fullpel(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame,

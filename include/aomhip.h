@@ -612,7 +612,7 @@ int aomhip_build_pred_fullpel(aomhip_ctx *ctx, const aomhip_planes *ref, int ref
  *                   reconinter.h:153-156, is the identity; out-of-range MVs are clamped to the allocation instead)
  *   interp_filter_* InterpFilter (filter.h:30-36): 0 EIGHTTAP_REGULAR, 1 EIGHTTAP_SMOOTH, 2 MULTITAP_SHARP, 3 BILINEAR;
  *                   x = InterpFilters::x_filter applies horizontally.  MULTITAP_SHARP2 (12 taps, temporal filter only),
- *                   scaled references, compound, warped and OBMC prediction are outside this call.
+ *                   scaled references, compound, warped and OBMC prediction are outside this call (chroma: the _ex form).
  * Writes block i of frame pred_frame of `pred` at (bx, by).  The reference planes need a border >= 8. */
 #define AOMHIP_INTERP_REGULAR 0
 #define AOMHIP_INTERP_SMOOTH 1
@@ -621,6 +621,12 @@ int aomhip_build_pred_fullpel(aomhip_ctx *ctx, const aomhip_planes *ref, int ref
 int aomhip_build_inter_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred,
                                   int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv,
                                   int n_blocks, int interp_filter_x, int interp_filter_y);
+/* The same for a plane with chroma subsampling: `ref` / `pred` are rings of that plane, bx / by / bw / bh are in ITS pixels,
+ * and the luma MV becomes mv * (1 << (1 - subsampling)) sixteenths (init_subpel_params, reconinter.h:133-137), so all 16
+ * kernel phases occur; subsampling 0 / 0 is aomhip_build_inter_pred_batch. */
+int aomhip_build_inter_pred_ex_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred,
+                                     int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv,
+                                     int n_blocks, int interp_filter_x, int interp_filter_y, int subsampling_x, int subsampling_y);
 
 /* ------------------------------------------------------------------ RD helpers, batched */
 

@@ -88,10 +88,15 @@ void orc_convolve_sr(const void *src, int src_stride, void *dst, int dst_stride,
 /* One luma block of av1_enc_build_inter_predictor for an unscaled reference: mv in 1/8 pel (row, col) ->
  * position in 1/16 pel (init_subpel_params, av1/common/reconinter.h:130-165, is_scaled == 0, ss = 0), integer part
  * selects the source block, the fraction the kernel phase.  ref_origin: pixel (0, 0) of the reference plane. */
-void orc_build_inter_pred_block(const void *ref_origin, int ref_stride, void *dst, int dst_stride, int bx, int by, int bw, int bh,
-                                int mv_row, int mv_col, int filter_x, int filter_y, int elem16, int bd) {
-  const int pos_x = (bx << 4) + mv_col * 2, pos_y = (by << 4) + mv_row * 2;
+void orc_build_inter_pred_block_ss(const void *ref_origin, int ref_stride, void *dst, int dst_stride, int bx, int by, int bw, int bh,
+                                   int mv_row, int mv_col, int filter_x, int filter_y, int elem16, int bd, int ss_x, int ss_y) {
+  const int pos_x = (bx << 4) + mv_col * (1 << (1 - ss_x)), pos_y = (by << 4) + mv_row * (1 << (1 - ss_y));
   const int esz = elem16 ? 2 : 1;
   const char *src = (const char *)ref_origin + ((ptrdiff_t)(pos_y >> 4) * ref_stride + (pos_x >> 4)) * esz;
   orc_convolve_sr(src, ref_stride, dst, dst_stride, bw, bh, filter_x, filter_y, pos_x & 15, pos_y & 15, elem16, bd);
+}
+
+void orc_build_inter_pred_block(const void *ref_origin, int ref_stride, void *dst, int dst_stride, int bx, int by, int bw, int bh,
+                                int mv_row, int mv_col, int filter_x, int filter_y, int elem16, int bd) {
+  orc_build_inter_pred_block_ss(ref_origin, ref_stride, dst, dst_stride, bx, by, bw, bh, mv_row, mv_col, filter_x, filter_y, elem16, bd, 0, 0);
 }

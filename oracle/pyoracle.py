@@ -142,17 +142,17 @@ def compound_batch(src_b, ref_b, border, w, h, cands, kind, subpel, bd=8, preds=
     return var, sse, sad
 
 
-def build_inter_pred(ref_b, border, width, height, w, h, blocks, mvs, filter_x=0, filter_y=0, bd=8):
+def build_inter_pred(ref_b, border, width, height, w, h, blocks, mvs, filter_x=0, filter_y=0, bd=8, ss_x=0, ss_y=0):
     """oracle/aomref_convolve.c over a block list: returns the visible height x width prediction plane (zeros where no
     block wrote).  ref_b: border-extended reference plane; mvs: (row, col) per block in 1/8 pel."""
-    lib.orc_build_inter_pred_block.restype = None
+    lib.orc_build_inter_pred_block_ss.restype = None
     e16 = int(ref_b.dtype != np.uint8)
     out = np.zeros((height, width), ref_b.dtype)
     origin = C.c_void_p(_addr(ref_b, border, border))
     for b, mv in zip(blocks, mvs):
         x, y = int(b["bx"]), int(b["by"])
-        lib.orc_build_inter_pred_block(origin, ref_b.shape[1], C.c_void_p(_addr(out, y, x)), width, x, y, w, h, int(mv[0]), int(mv[1]),
-                                       filter_x, filter_y, e16, bd)
+        lib.orc_build_inter_pred_block_ss(origin, ref_b.shape[1], C.c_void_p(_addr(out, y, x)), width, x, y, w, h, int(mv[0]), int(mv[1]),
+                                          filter_x, filter_y, e16, bd, ss_x, ss_y)
     return out
 
 

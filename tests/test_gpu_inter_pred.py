@@ -17,8 +17,8 @@ BLOCK_SIZES = [(4, 4), (4, 8), (8, 4), (8, 8), (8, 16), (16, 8), (16, 16), (16, 
 
 
 def test_inter_pred_goldens(hip, ctx):
-    """The fixture's phases are in 1/16 pel (subpel_x_qn); an MV in 1/8 pel reaches the even ones -- the odd phases belong to
-    chroma / scaled references, outside this call -- so every fixture case with even phases is replayed as an MV."""
+    """The fixture's phases are in 1/16 pel (subpel_x_qn).  A luma MV (1/8 pel) reaches the even ones; with chroma subsampling
+    the MV itself is in sixteenths, so the 4:2:0 form of the call replays EVERY fixture case, and the luma form the even ones."""
     z = np.load(os.path.join(GOLD, "ref_eval_convolve.npz"))
     cases = json.loads(bytes(z["cases"]).decode())
     planes = {}
@@ -30,24 +30,54 @@ def test_inter_pred_goldens(hip, ctx):
         pr, pp = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
         ctx.planes_upload(pr, 0, np.ascontiguousarray(p, dt))
         planes[bd] = (pr, pp, W, H)
-    used = 0
+    luma = 0
     for c in cases:
-        if c["sx"] % 2 or c["sy"] % 2:
-            continue
         pr, pp, W, H = planes[c["bd"]]
         w, h = c["w"], c["h"]
         blk = np.zeros(1, hip.capi.search_block_dtype)
         blk["bx"], blk["by"] = c["x0"], c["y0"]
-        mv = np.array([[c["sy"] // 2, c["sx"] // 2]], np.int16)
-        d_b, d_mv = ctx.to_device(blk), ctx.to_device(mv)
-        ctx.build_inter_pred_batch(pr, 0, pp, 0, w, h, d_b, d_mv, 1, c["fx"], c["fy"])
-        got = ctx.planes_download(pp, 0)[border + c["y0"]:border + c["y0"] + h, border + c["x0"]:border + c["x0"] + w]
-        assert np.array_equal(got.ravel().astype(np.uint16), z["d%d" % c["k"]]), c
-        ctx.free(d_b); ctx.free(d_mv)
-        used += 1
-    assert used >= 40
+        d_b = ctx.to_device(blk)
+        forms = [(1, np.array([[c["sy"], c["sx"]]], np.int16))]
+        if c["sx"] % 2 == 0 and c["sy"] % 2 == 0:
+            forms.append((0, np.array([[c["sy"] // 2, c["sx"] // 2]], np.int16)))
+            luma += 1
+        for ss, mv in forms:
+            d_mv = ctx.to_device(mv)
+            ctx.build_inter_pred_batch(pr, 0, pp, 0, w, h, d_b, d_mv, 1, c["fx"], c["fy"], ss, ss)
+            got = ctx.planes_download(pp, 0)[border + c["y0"]:border + c["y0"] + h, border + c["x0"]:border + c["x0"] + w]
+            assert np.array_equal(got.ravel().astype(np.uint16), z["d%d" % c["k"]]), (ss, c)
+            ctx.free(d_mv)
+        ctx.free(d_b)
+    assert len(cases) >= 200 and luma >= 40
     for pr, pp, _, _ in planes.values():
         ctx.planes_free(pr); ctx.planes_free(pp)
+
+
+@pytest.mark.parametrize("bd,ss_x,ss_y", [(8, 1, 1), (10, 1, 1), (10, 1, 0), (12, 0, 1)])
+def test_chroma_inter_pred_vs_oracle(hip, oracle, ctx, bd, ss_x, ss_y):
+    """Chroma planes: luma MV x (1 << (1 - subsampling)) sixteenths -- all 16 phases, 4-tap sets for the small chroma blocks."""
+    rng = np.random.default_rng(60 + bd + ss_x)
+    W, H, border = 192, 128, 32
+    ref = hip.synth.lcg_frame(W, H, 7, 0, bd)
+    pr, pp = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(pr, 0, ref)
+    rb = oracle.extend_plane(ref, border, pr.stride)
+    for (bw, bh) in ((4, 4), (8, 8), (4, 8), (16, 16), (8, 4), (32, 32), (16, 8)):
+        xs, ys = np.meshgrid(np.arange(0, W - bw + 1, bw), np.arange(0, H - bh + 1, bh))
+        n = xs.size
+        blocks = np.zeros(n, hip.capi.search_block_dtype)
+        blocks["bx"], blocks["by"] = xs.ravel(), ys.ravel()
+        lim_x, lim_y = (border - 8) * (16 >> (1 - ss_x)), (border - 8) * (16 >> (1 - ss_y))
+        mv = np.stack([rng.integers(-lim_y, lim_y + 1, n), rng.integers(-lim_x, lim_x + 1, n)], axis=1).astype(np.int16)
+        d_b, d_mv = ctx.to_device(blocks), ctx.to_device(mv)
+        for fx, fy in ((0, 0), (2, 1), (1, 3)):
+            ctx.planes_upload(pp, 0, np.zeros_like(ref))
+            ctx.build_inter_pred_batch(pr, 0, pp, 0, bw, bh, d_b, d_mv, n, fx, fy, ss_x, ss_y)
+            got = ctx.planes_download(pp, 0)[border:border + H, border:border + W]
+            want = oracle.build_inter_pred(rb, border, W, H, bw, bh, blocks, mv, fx, fy, bd, ss_x, ss_y)
+            assert np.array_equal(got, want), (bw, bh, bd, fx, fy)
+        ctx.free(d_b); ctx.free(d_mv)
+    ctx.planes_free(pr); ctx.planes_free(pp)
 
 
 @pytest.mark.parametrize("bd", [8, 10, 12])
