@@ -166,6 +166,7 @@ _protos = {
     "aomhip_compute_stats_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "aomhip_plane_sse": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp]),
     "aomhip_build_inter_pred_ex_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i]),
+    "aomhip_build_compound_pred_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
@@ -412,6 +413,11 @@ class Context:
 
     def plane_sse(self, a, a_frame, b, b_frame, d_sse):
         check(lib.aomhip_plane_sse(self.h, C.byref(a), a_frame, C.byref(b), b_frame, d_sse), "aomhip_plane_sse")
+
+    def build_compound_pred_batch(self, ref0, f0, ref1, f1, pred, pred_frame, bw, bh, d_blocks, d_mv0, d_mv1, n, filter_x=0, filter_y=0, fwd=0,
+                                  bck=0, ss_x=0, ss_y=0):
+        check(lib.aomhip_build_compound_pred_batch(self.h, C.byref(ref0), f0, C.byref(ref1), f1, C.byref(pred), pred_frame, bw, bh, d_blocks,
+                                                   d_mv0, d_mv1, n, filter_x, filter_y, fwd, bck, ss_x, ss_y), "aomhip_build_compound_pred_batch")
 
     def build_pred_fullpel(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n):
         check(lib.aomhip_build_pred_fullpel(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks,

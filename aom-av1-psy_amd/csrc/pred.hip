@@ -123,6 +123,88 @@ __global__ __launch_bounds__(256) void inter_pred_kernel(PlaneView<T> ref, int r
   }
 }
 
+// Compound prediction (two references): convolve_2d_facade_compound (convolve.c:471-493) -> av1_[highbd_]dist_wtd_convolve_*
+// with get_conv_params_no_round's compound rounding (round_1 = COMPOUND_ROUND1_BITS 7).  Same lane-per-column walk as
+// inter_pred_kernel, with both references' windows side by side in registers; the CONV_BUF intermediate of the first
+// reference never exists in memory.  As in the single-reference case the copy / x / y kernels are the 2-D pipeline with an
+// identity kernel: with round_1 = 7 every one of them produces exactly round_offset + the scaled value the 2-D formula
+// gives (the offsets 2^offset_bits + 2^(offset_bits - 1) are multiples of 2^7 and the identity tap is 2^7).
+template <typename T, int W, int H>
+__global__ __launch_bounds__(256) void compound_pred_kernel(PlaneView<T> ref0, int frame0, PlaneView<T> ref1, int frame1, T *dst_origin,
+                                                            int dst_stride, const aomhip_search_block *__restrict__ blocks,
+                                                            const int16_t *__restrict__ mv0, const int16_t *__restrict__ mv1, int n_blocks,
+                                                            int set_x, int set_y, int bit_depth, int x_lo, int x_hi, int y_lo, int y_hi,
+                                                            int mvx_mul, int mvy_mul, int fwd, int bck) {
+  constexpr int LPB = W < 64 ? W : 64;
+  constexpr int BPW = 64 / LPB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bi = (blockIdx.x * 4 + wave) * BPW + lane / LPB;
+  if (bi >= n_blocks) return;
+  const int col0 = lane % LPB;
+  const int bx = blocks[bi].bx, by = blocks[bi].by;
+  int px0 = (bx << 4) + mv0[2 * bi + 1] * mvx_mul, py0 = (by << 4) + mv0[2 * bi] * mvy_mul;
+  int px1 = (bx << 4) + mv1[2 * bi + 1] * mvx_mul, py1 = (by << 4) + mv1[2 * bi] * mvy_mul;
+  px0 = min(max(px0, x_lo), x_hi); py0 = min(max(py0, y_lo), y_hi);
+  px1 = min(max(px1, x_lo), x_hi); py1 = min(max(py1, y_lo), y_hi);
+  const int tbd = sizeof(T) == 1 ? 8 : bit_depth;
+  const int r0 = tbd == 12 ? 5 : 3, r1 = 7;           // get_conv_params_no_round, is_compound (convolve.h:72-81)
+  const int ob = tbd + 14 - r0;
+  const int hoff = (1 << (tbd + 6)) + ((1 << r0) >> 1);
+  const int voff = (1 << ob) + ((1 << r1) >> 1);
+  const int round_offset = (1 << (ob - r1)) + (1 << (ob - r1 - 1));
+  const int rb = 14 - r0 - r1;                         // round_bits: 4, or 2 for 12-bit
+  const int pmax = (1 << tbd) - 1;
+  const PU128 fx0 = *reinterpret_cast<const PU128 *>(&kInterp[set_x][px0 & 15][0]);
+  const PU128 fy0 = *reinterpret_cast<const PU128 *>(&kInterp[set_y][py0 & 15][0]);
+  const PU128 fx1 = *reinterpret_cast<const PU128 *>(&kInterp[set_x][px1 & 15][0]);
+  const PU128 fy1 = *reinterpret_cast<const PU128 *>(&kInterp[set_y][py1 & 15][0]);
+  const T *b0 = ref0.origin + (int64_t)frame0 * ref0.frame_stride + (int64_t)((py0 >> 4) - 3) * ref0.stride + (px0 >> 4) - 3;
+  const T *b1 = ref1.origin + (int64_t)frame1 * ref1.frame_stride + (int64_t)((py1 >> 4) - 3) * ref1.stride + (px1 >> 4) - 3;
+  T *dbase = dst_origin + (int64_t)by * dst_stride + bx;
+#pragma unroll 1
+  for (int col = col0; col < W; col += 64) {
+    const T *p0 = b0 + col, *p1 = b1 + col;
+    T *d = dbase + col;
+    uint32_t w0[4] = { 0, 0, 0, 0 }, w1[4] = { 0, 0, 0, 0 };
+#pragma unroll 4
+    for (int r = 0; r < H + 7; ++r) {
+      uint32_t a[4], b[4];
+      load8_pairs<T>(p0, a);
+      load8_pairs<T>(p1, b);
+      p0 += ref0.stride;
+      p1 += ref1.stride;
+      int h0 = hoff, h1 = hoff;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        h0 = dot2(a[k], fx0.v[k], h0);
+        h1 = dot2(b[k], fx1.v[k], h1);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        w0[k] = __builtin_amdgcn_alignbit(w0[k + 1], w0[k], 16);
+        w1[k] = __builtin_amdgcn_alignbit(w1[k + 1], w1[k], 16);
+      }
+      w0[3] = __builtin_amdgcn_alignbit((uint32_t)(h0 >> r0), w0[3], 16);
+      w1[3] = __builtin_amdgcn_alignbit((uint32_t)(h1 >> r0), w1[3], 16);
+      if (r >= 7) {
+        int v0 = voff, v1 = voff;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v0 = dot2(w0[k], fy0.v[k], v0);
+          v1 = dot2(w1[k], fy1.v[k], v1);
+        }
+        const int res0 = v0 >> r1, res1 = v1 >> r1;   // the two CONV_BUF values (fit 16 bits)
+        // convolve.c:222-233: distance weights (sum 16) or the plain average, then the offset comes out and the result is rounded
+        int tmp = fwd | bck ? (res0 * fwd + res1 * bck) >> 4 : (res0 + res1) >> 1;
+        tmp -= round_offset;
+        tmp = (tmp + ((1 << rb) >> 1)) >> rb;
+        *d = (T)min(max(tmp, 0), pmax);
+        d += dst_stride;
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pred_copy_kernel(PlaneView<T> ref, int ref_frame, T *dst_origin, int dst_stride,
                                                         const aomhip_search_block *__restrict__ blocks,
@@ -203,6 +285,53 @@ extern "C" int aomhip_build_inter_pred_batch(aomhip_ctx *ctx, const aomhip_plane
                                              int n_blocks, int interp_filter_x, int interp_filter_y) {
   return aomhip_build_inter_pred_ex_batch(ctx, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, interp_filter_x,
                                           interp_filter_y, 0, 0);
+}
+
+template <typename T>
+static int launch_compound_pred(aomhip_ctx *ctx, const aomhip_planes *r0, int f0, const aomhip_planes *r1, int f1, const aomhip_planes *pred,
+                                int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *mv0, const int16_t *mv1,
+                                int n_blocks, int fx, int fy, int fwd, int bck, int ss_x, int ss_y) {
+  auto set_of = [](int f, int dim) { return dim <= 4 ? (f == 1 ? 5 : f == 3 ? 3 : 4) : f; };
+  T *d = reinterpret_cast<T *>(pred->base) + (size_t)pred_frame * pred->frame_stride + (size_t)pred->border * pred->stride + pred->border;
+  const int border = r0->border < r1->border ? r0->border : r1->border;
+  const int x_lo = (-border + 3) << 4, x_hi = ((r0->width + border - bw - 5) << 4) | 15;
+  const int y_lo = (-border + 3) << 4, y_hi = ((r0->height + border - bh - 5) << 4) | 15;
+  const int lpb = bw < 64 ? bw : 64, bpw = 64 / lpb;
+  const dim3 grid((n_blocks + 4 * bpw - 1) / (4 * bpw)), block(256);
+#define X(W, H)                                                                                                                        \
+  if (bw == W && bh == H) {                                                                                                            \
+    hipLaunchKernelGGL((compound_pred_kernel<T, W, H>), grid, block, 0, ctx->stream, view_of<T>(*r0), f0, view_of<T>(*r1), f1, d,      \
+                       pred->stride, d_blocks, mv0, mv1, n_blocks, set_of(fx, W), set_of(fy, H), r0->bit_depth, x_lo, x_hi, y_lo, y_hi, \
+                       2 >> ss_x, 2 >> ss_y, fwd, bck);                                                                                 \
+    AOMHIP_LAUNCH_CHECK();                                                                                                             \
+    return AOMHIP_OK;                                                                                                                  \
+  }
+  AOMHIP_PRED_SIZES(X)
+#undef X
+  set_error("unsupported block size %dx%d", bw, bh);
+  return AOMHIP_ERR_INVALID;
+}
+
+extern "C" int aomhip_build_compound_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref0, int ref0_frame, const aomhip_planes *ref1,
+                                                int ref1_frame, const aomhip_planes *pred, int pred_frame, int bw, int bh,
+                                                const aomhip_search_block *d_blocks, const int16_t *d_mv0, const int16_t *d_mv1, int n_blocks,
+                                                int interp_filter_x, int interp_filter_y, int fwd_offset, int bck_offset, int subsampling_x,
+                                                int subsampling_y) {
+  if (!ctx || !ref0 || !ref1 || !pred || !ref0->base || !ref1->base || !pred->base || (n_blocks > 0 && (!d_blocks || !d_mv0 || !d_mv1)) ||
+      n_blocks < 0 || ref0_frame < 0 || ref0_frame >= ref0->n_frames || ref1_frame < 0 || ref1_frame >= ref1->n_frames || pred_frame < 0 ||
+      pred_frame >= pred->n_frames || !valid_block(bw, bh) || ref0->bit_depth != pred->bit_depth || ref1->bit_depth != pred->bit_depth ||
+      ref0->width != ref1->width || ref0->height != ref1->height || interp_filter_x < 0 || interp_filter_x > 3 || interp_filter_y < 0 ||
+      interp_filter_y > 3 || subsampling_x < 0 || subsampling_x > 1 || subsampling_y < 0 || subsampling_y > 1 || fwd_offset < 0 ||
+      bck_offset < 0 || ((fwd_offset | bck_offset) && fwd_offset + bck_offset != 16) || ref0->border < 8 || ref1->border < 8) {
+    set_error("aomhip_build_compound_pred_batch: invalid argument (weights 0 / 0 or summing to 16; reference borders >= 8)");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  if (pred->bit_depth == 8)
+    return launch_compound_pred<uint8_t>(ctx, ref0, ref0_frame, ref1, ref1_frame, pred, pred_frame, bw, bh, d_blocks, d_mv0, d_mv1, n_blocks,
+                                         interp_filter_x, interp_filter_y, fwd_offset, bck_offset, subsampling_x, subsampling_y);
+  return launch_compound_pred<uint16_t>(ctx, ref0, ref0_frame, ref1, ref1_frame, pred, pred_frame, bw, bh, d_blocks, d_mv0, d_mv1, n_blocks,
+                                        interp_filter_x, interp_filter_y, fwd_offset, bck_offset, subsampling_x, subsampling_y);
 }
 
 extern "C" int aomhip_build_pred_fullpel(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame,

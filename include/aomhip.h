@@ -627,6 +627,16 @@ int aomhip_build_inter_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int
 int aomhip_build_inter_pred_ex_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred,
                                      int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv,
                                      int n_blocks, int interp_filter_x, int interp_filter_y, int subsampling_x, int subsampling_y);
+/* Compound prediction from two references (COMPOUND_AVERAGE and COMPOUND_DISTWTD): av1_[highbd_]convolve_2d_facade with
+ * is_compound = 1, first reference into the CONV_BUF, second averaged in -- convolve_2d_facade_compound
+ * (av1/common/convolve.c:471-493) -> av1_[highbd_]dist_wtd_convolve_{2d_copy,x,y,2d} (:176-370,670-868), rounding of
+ * get_conv_params_no_round (convolve.h:63-95).  d_mv0 / d_mv1: the two MVs per block (1/8 pel); fwd_offset / bck_offset:
+ * 0 / 0 = (p0 + p1) >> 1, otherwise the DIST_WTD_COMP_PARAMS weights (sum 16): (p0 * fwd + p1 * bck) >> 4 in the 16-bit
+ * intermediate domain.  The masked (wedge / diff-weighted) compound modes and OBMC are outside this call. */
+int aomhip_build_compound_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref0, int ref0_frame, const aomhip_planes *ref1, int ref1_frame,
+                                     const aomhip_planes *pred, int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks,
+                                     const int16_t *d_mv0, const int16_t *d_mv1, int n_blocks, int interp_filter_x, int interp_filter_y,
+                                     int fwd_offset, int bck_offset, int subsampling_x, int subsampling_y);
 
 /* ------------------------------------------------------------------ RD helpers, batched */
 

@@ -100,3 +100,70 @@ void orc_build_inter_pred_block(const void *ref_origin, int ref_stride, void *ds
                                 int mv_row, int mv_col, int filter_x, int filter_y, int elem16, int bd) {
   orc_build_inter_pred_block_ss(ref_origin, ref_stride, dst, dst_stride, bx, by, bw, bh, mv_row, mv_col, filter_x, filter_y, elem16, bd, 0, 0);
 }
+
+/* Compound prediction of one block from two references: av1_[highbd_]convolve_2d_facade with is_compound = 1, first
+ * reference into the CONV_BUF (do_average 0), second averaged in (do_average 1) -- convolve_2d_facade_compound
+ * (av1/common/convolve.c:471-493) -> av1_[highbd_]dist_wtd_convolve_{2d_copy,x,y,2d}_c (:176-370,670-868), with
+ * get_conv_params_no_round's compound rounding (convolve.h:63-95: round_1 = COMPOUND_ROUND1_BITS 7, round_0 3, or 5 for
+ * 12-bit).  The four kernels are restated separately, as the reference has them.  fwd = bck = 0: plain average. */
+static void compound_one(const void *src, int src_stride, uint16_t *buf, int w, int h, const int16_t *fx, const int16_t *fy, int sx, int sy,
+                         int elem16, int tbd, int round_0) {
+  const int round_1 = 7, bits = 14 - round_1 - round_0, offset_bits = tbd + 14 - round_0;
+  const int round_offset = (1 << (offset_bits - round_1)) + (1 << (offset_bits - round_1 - 1));
+  if (!sx && !sy) { /* _2d_copy */
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) buf[y * w + x] = (uint16_t)((px(src, elem16, (ptrdiff_t)y * src_stride + x) << bits) + round_offset);
+  } else if (sx && !sy) { /* _x: bits = FILTER_BITS - round_1 = 0 */
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        int res = 0;
+        for (int k = 0; k < 8; ++k) res += fx[k] * px(src, elem16, (ptrdiff_t)y * src_stride + x - 3 + k);
+        buf[y * w + x] = (uint16_t)((1 << (7 - round_1)) * RPOT(res, round_0) + round_offset);
+      }
+  } else if (!sx) { /* _y: bits = FILTER_BITS - round_0 */
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        int res = 0;
+        for (int k = 0; k < 8; ++k) res += fy[k] * px(src, elem16, (ptrdiff_t)(y - 3 + k) * src_stride + x);
+        res *= 1 << (7 - round_0);
+        buf[y * w + x] = (uint16_t)(RPOT(res, round_1) + round_offset);
+      }
+  } else { /* _2d */
+    int16_t *im = (int16_t *)malloc(sizeof(int16_t) * (size_t)(h + 7) * w);
+    for (int y = 0; y < h + 7; ++y)
+      for (int x = 0; x < w; ++x) {
+        int sum = 1 << (tbd + 6);
+        for (int k = 0; k < 8; ++k) sum += fx[k] * px(src, elem16, (ptrdiff_t)(y - 3) * src_stride + x - 3 + k);
+        im[y * w + x] = (int16_t)RPOT(sum, round_0);
+      }
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        int sum = 1 << offset_bits;
+        for (int k = 0; k < 8; ++k) sum += fy[k] * im[(y + k) * w + x];
+        buf[y * w + x] = (uint16_t)RPOT(sum, round_1);
+      }
+    free(im);
+  }
+}
+
+void orc_convolve_compound(const void *src0, int stride0, int sx0, int sy0, const void *src1, int stride1, int sx1, int sy1, void *dst,
+                           int dst_stride, int w, int h, int filter_x, int filter_y, int fwd_offset, int bck_offset, int elem16, int bd) {
+  const int tbd = elem16 ? bd : 8;
+  const int round_0 = (elem16 && bd == 12) ? 5 : 3, round_1 = 7;
+  const int round_bits = 14 - round_0 - round_1, offset_bits = tbd + 14 - round_0;
+  const int round_offset = (1 << (offset_bits - round_1)) + (1 << (offset_bits - round_1 - 1));
+  uint16_t *b0 = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)w * h), *b1 = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)w * h);
+  compound_one(src0, stride0, b0, w, h, kernel_of(filter_x, w, sx0), kernel_of(filter_y, h, sy0), sx0, sy0, elem16, tbd, round_0);
+  compound_one(src1, stride1, b1, w, h, kernel_of(filter_x, w, sx1), kernel_of(filter_y, h, sy1), sx1, sy1, elem16, tbd, round_0);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      int tmp = b0[y * w + x];
+      const int res = b1[y * w + x];
+      if (fwd_offset || bck_offset) tmp = (tmp * fwd_offset + res * bck_offset) >> 4;
+      else tmp = (tmp + res) >> 1;
+      tmp -= round_offset;
+      put(dst, elem16, (ptrdiff_t)y * dst_stride + x, RPOT(tmp, round_bits), tbd);
+    }
+  free(b0);
+  free(b1);
+}

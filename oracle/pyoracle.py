@@ -156,6 +156,22 @@ def build_inter_pred(ref_b, border, width, height, w, h, blocks, mvs, filter_x=0
     return out
 
 
+def build_compound_pred(ref0_b, ref1_b, border, width, height, w, h, blocks, mv0, mv1, filter_x=0, filter_y=0, fwd=0, bck=0, bd=8, ss_x=0, ss_y=0):
+    """orc_convolve_compound over a block list (two border-extended references, two MV lists in 1/8 pel)."""
+    lib.orc_convolve_compound.restype = None
+    e16 = int(ref0_b.dtype != np.uint8)
+    out = np.zeros((height, width), ref0_b.dtype)
+    for b, a, c in zip(blocks, mv0, mv1):
+        x, y = int(b["bx"]), int(b["by"])
+        p = []
+        for ref, mv in ((ref0_b, a), (ref1_b, c)):
+            px, py = (x << 4) + int(mv[1]) * (1 << (1 - ss_x)), (y << 4) + int(mv[0]) * (1 << (1 - ss_y))
+            p.append((C.c_void_p(_addr(ref, border + (py >> 4), border + (px >> 4))), ref.shape[1], px & 15, py & 15))
+        lib.orc_convolve_compound(p[0][0], p[0][1], p[0][2], p[0][3], p[1][0], p[1][1], p[1][2], p[1][3], C.c_void_p(_addr(out, y, x)), width, w, h,
+                                  filter_x, filter_y, fwd, bck, e16, bd)
+    return out
+
+
 def extend_plane(pixels, border, stride=None):
     """Host model of an HBM plane: replicate edges into `border` px on every side
     (aom_scale/generic/yv12extend.c:22-221); returns (bordered array, origin (y, x))."""

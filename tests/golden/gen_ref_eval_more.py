@@ -505,8 +505,53 @@ def gen_lrstats():
             k += 1
     save("ref_eval_lrstats.npz", arrays, cases)
 
+
+def gen_convolve_compound():
+    """Compound prediction through av1_[highbd_]convolve_2d_facade with is_compound = 1: first reference into the CONV_BUF
+    (do_average 0), second reference averaged in (do_average 1), plain average and the distance weights; the copy / x / y / 2-D
+    compound kernels av1_[highbd_]dist_wtd_convolve_{2d_copy,x,y,2d}_c (av1/common/convolve.c:176-370,670-868)."""
+    ev = evaluator(["av1/common/filter.h", "av1/common/convolve.h", "aom_dsp/aom_convolve.c", "av1/common/convolve.c"])
+    rng = np.random.default_rng(20261023)
+    arrays, cases = {}, []
+    S, ROWS = 96, 80
+    k = 0
+    for bd in (8, 10, 12):
+        mx = (1 << bd) - 1
+        planes = []
+        for r in range(2):
+            base = rng.integers(0, mx + 1, (ROWS, S))
+            base[:16] = np.where(rng.integers(0, 2, (16, S)) > 0, mx, 0)
+            planes.append(base)
+            arrays["p%d_%d" % (bd, r)] = base.astype(np.uint16)
+        ct = "uint8_t" if bd == 8 else "uint16_t"
+        P = [ev.array(pl.ravel(), ct) for pl in planes]
+        sizes = {8: [(4, 4), (8, 8), (16, 16), (4, 16), (32, 8)], 10: [(8, 4), (16, 16), (16, 32)], 12: [(4, 8), (8, 8), (16, 16)]}[bd]
+        for (w, h) in sizes:
+            for (fxi, fyi, wts) in ((0, 0, None), (2, 1, (9, 7)), (1, 3, (4, 12)), (0, 2, None)):
+                pos = [(int(rng.integers(4, S - w - 5)), int(rng.integers(4, ROWS - h - 5))) for _ in range(2)]
+                if k % 2 == 0:
+                    pos[0] = (pos[0][0], int(rng.integers(4, 10)))            # extreme band
+                subs = [(int(rng.integers(0, 16)) * int(rng.integers(0, 2)), int(rng.integers(0, 16)) * int(rng.integers(0, 2))) for _ in range(2)]
+                fp = [ev.call("av1_get_interp_filter_params_with_block_size", fxi, w), ev.call("av1_get_interp_filter_params_with_block_size", fyi, h)]
+                filt = R.Ptr(fp, 0, ("ptr", ev.structs["InterpFilterParams"]))
+                buf16 = ev.array([0] * (w * h), "uint16_t")
+                dst = ev.array([0] * (w * h), ct)
+                for r in range(2):
+                    cpv = ev.call("get_conv_params_no_round", r, 0, buf16, w, 1, bd)
+                    cp = R.Ptr([cpv], 0, cpv.st)
+                    if wts:
+                        ev.set(cp, "use_dist_wtd_comp_avg", 1); ev.set(cp, "fwd_offset", wts[0]); ev.set(cp, "bck_offset", wts[1])
+                    args = [P[r].add(pos[r][1] * S + pos[r][0]), S, dst, w, w, h, filt, subs[r][0], 16, subs[r][1], 16, 0, cp]
+                    if bd > 8:
+                        args.append(bd)
+                    ev.call("av1_convolve_2d_facade" if bd == 8 else "av1_highbd_convolve_2d_facade", *args)
+                arrays["d%d" % k] = np.asarray(dst.buf, np.uint16)
+                cases.append({"k": k, "bd": bd, "w": w, "h": h, "pos": pos, "subs": subs, "fx": fxi, "fy": fyi, "weights": wts})
+                k += 1
+    save("ref_eval_convolve_compound.npz", arrays, cases)
+
 if __name__ == "__main__":
-    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound", "convolve", "rdhelp", "cdef_search", "lrstats"]:
+    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound", "convolve", "rdhelp", "cdef_search", "lrstats", "convolve_compound"]:
         t = time.time()
         globals()["gen_" + w]()
         print("  (%s: %.1f s)" % (w, time.time() - t))

@@ -494,3 +494,28 @@ def test_wiener_stats_match_reference_evaluation(oracle):
         f(win, C.c_void_p(dgd.ctypes.data), C.c_void_p(src.ctypes.data), hs, he, vs, ve, dgd.shape[1], src.shape[1], e16, bd, c["downsample"],
           C.c_void_p(M.ctypes.data), C.c_void_p(H.ctypes.data))
         assert np.array_equal(M, z["M%d" % c["k"]]) and np.array_equal(H, z["H%d" % c["k"]]), c
+
+
+def test_compound_convolve_matches_reference_evaluation(oracle):
+    """orc_convolve_compound against the interpreted compound path of av1_[highbd_]convolve_2d_facade (first reference into
+    the CONV_BUF, second averaged in; plain and distance-weighted; copy / x / y / 2-D kernels of both references mixed)."""
+    z, cases = load("ref_eval_convolve_compound.npz")
+    assert len(cases) >= 40
+    f = oracle.lib.orc_convolve_compound
+    f.restype = None
+    kinds = set()
+    for c in cases:
+        bd, w, h = c["bd"], c["w"], c["h"]
+        e16 = int(bd > 8)
+        dt = np.uint16 if e16 else np.uint8
+        p0, p1 = np.ascontiguousarray(z["p%d_0" % bd], dt), np.ascontiguousarray(z["p%d_1" % bd], dt)
+        S = p0.shape[1]
+        (x0, y0), (x1, y1) = c["pos"]
+        (sx0, sy0), (sx1, sy1) = c["subs"]
+        wts = c["weights"] or (0, 0)
+        dst = np.zeros((h, w), dt)
+        f(C.c_void_p(p0.ctypes.data + (y0 * S + x0) * p0.itemsize), S, sx0, sy0, C.c_void_p(p1.ctypes.data + (y1 * S + x1) * p1.itemsize), S, sx1, sy1,
+          C.c_void_p(dst.ctypes.data), w, w, h, c["fx"], c["fy"], wts[0], wts[1], e16, bd)
+        assert np.array_equal(dst.ravel(), z["d%d" % c["k"]]), c
+        kinds.add((bool(sx0), bool(sy0)))
+    assert len(kinds) == 4

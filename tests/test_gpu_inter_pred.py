@@ -141,3 +141,73 @@ def test_inter_pred_rejects_bad_arguments(hip, ctx):
     ctx.free(d)
     for p in (pr, pp, small, p10):
         ctx.planes_free(p)
+
+
+def test_compound_pred_goldens(hip, ctx):
+    """Every case of ref_eval_convolve_compound.npz through aomhip_build_compound_pred_batch (4:2:0 form: MVs in sixteenths)."""
+    z = np.load(os.path.join(GOLD, "ref_eval_convolve_compound.npz"))
+    cases = json.loads(bytes(z["cases"]).decode())
+    border = 16
+    planes = {}
+    for bd in (8, 10, 12):
+        dt = np.uint8 if bd == 8 else np.uint16
+        p0, p1 = np.ascontiguousarray(z["p%d_0" % bd], dt), np.ascontiguousarray(z["p%d_1" % bd], dt)
+        H, W = p0.shape
+        r0, r1, pp = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+        ctx.planes_upload(r0, 0, p0); ctx.planes_upload(r1, 0, p1)
+        planes[bd] = (r0, r1, pp)
+    for c in cases:
+        r0, r1, pp = planes[c["bd"]]
+        w, h = c["w"], c["h"]
+        (x0, y0), (x1, y1) = c["pos"]
+        (sx0, sy0), (sx1, sy1) = c["subs"]
+        # the block is placed at reference 0's position; reference 1's displacement goes into its MV (sixteenths)
+        blk = np.zeros(1, hip.capi.search_block_dtype)
+        blk["bx"], blk["by"] = x0, y0
+        mv0 = np.array([[sy0, sx0]], np.int16)
+        mv1 = np.array([[(y1 - y0) * 16 + sy1, (x1 - x0) * 16 + sx1]], np.int16)
+        wts = c["weights"] or (0, 0)
+        d_b, d_0, d_1 = ctx.to_device(blk), ctx.to_device(mv0), ctx.to_device(mv1)
+        ctx.build_compound_pred_batch(r0, 0, r1, 0, pp, 0, w, h, d_b, d_0, d_1, 1, c["fx"], c["fy"], wts[0], wts[1], 1, 1)
+        got = ctx.planes_download(pp, 0)[border + y0:border + y0 + h, border + x0:border + x0 + w]
+        assert np.array_equal(got.ravel().astype(np.uint16), z["d%d" % c["k"]]), c
+        for d in (d_b, d_0, d_1):
+            ctx.free(d)
+    assert len(cases) >= 40
+    for t in planes.values():
+        for p in t:
+            ctx.planes_free(p)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_compound_pred_vs_oracle(hip, oracle, ctx, bd):
+    rng = np.random.default_rng(80 + bd)
+    W, H, border = 256, 128, 64
+    ref0, ref1 = hip.synth.lcg_frame(W, H, 8, 0, bd), hip.synth.lcg_frame(W, H, 9, 1, bd)
+    ref0[:24, :48] = (1 << bd) - 1
+    ref1[:24, :48] = np.where(rng.integers(0, 2, (24, 48)) > 0, (1 << bd) - 1, 0).astype(ref1.dtype)
+    r0, r1, pp = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 2), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(r0, 0, ref0); ctx.planes_upload(r1, 1, ref1)
+    b0, b1 = oracle.extend_plane(ref0, border, r0.stride), oracle.extend_plane(ref1, border, r1.stride)
+    for si, (bw, bh) in enumerate(BLOCK_SIZES):
+        xs, ys = np.meshgrid(np.arange(0, W - bw + 1, bw), np.arange(0, H - bh + 1, bh))
+        n = xs.size
+        blocks = np.zeros(n, hip.capi.search_block_dtype)
+        blocks["bx"], blocks["by"] = xs.ravel(), ys.ravel()
+        lim = (border - 8) * 8
+        mv0, mv1 = rng.integers(-lim, lim + 1, (n, 2)).astype(np.int16), rng.integers(-lim, lim + 1, (n, 2)).astype(np.int16)
+        mv0[0::5] &= ~7
+        mv1[1::5, 0] &= ~7
+        mv0[2::5, 1] &= ~7
+        d_b, d_0, d_1 = ctx.to_device(blocks), ctx.to_device(mv0), ctx.to_device(mv1)
+        for fx, fy, fwd, bck in ((si % 4, (si + 2) % 4, 0, 0), ((si + 1) % 3, si % 3, (9, 11, 12, 13)[si % 4], (7, 5, 4, 3)[si % 4])):
+            ctx.build_compound_pred_batch(r0, 0, r1, 1, pp, 0, bw, bh, d_b, d_0, d_1, n, fx, fy, fwd, bck)
+            got = ctx.planes_download(pp, 0)[border:border + H, border:border + W][:(H // bh) * bh, :(W // bw) * bw]
+            want = oracle.build_compound_pred(b0, b1, border, W, H, bw, bh, blocks, mv0, mv1, fx, fy, fwd, bck, bd)[:(H // bh) * bh, :(W // bw) * bw]
+            assert np.array_equal(got, want), (bw, bh, bd, fx, fy, fwd)
+        for d in (d_b, d_0, d_1):
+            ctx.free(d)
+    with pytest.raises(hip.capi.AomHipError):
+        ctx.build_compound_pred_batch(r0, 0, r1, 1, pp, 0, 16, 16, 1, 1, 1, 1, 0, 0, 9, 9)      # weights must sum to 16
+    for p in (r0, r1, pp):
+        ctx.planes_free(p)
