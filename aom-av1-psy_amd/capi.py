@@ -167,6 +167,8 @@ _protos = {
     "aomhip_plane_sse": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp]),
     "aomhip_build_inter_pred_ex_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "aomhip_build_compound_pred_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    "aomhip_highbd_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, _i]),
+    "aomhip_highbd_sad_x4d": (None, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),

@@ -498,4 +498,23 @@ unsigned int aomhip_highbd_sad(const uint8_t *src8, int src_stride, const uint8_
   return v;
 }
 
+// aom_highbd_sad_skip_{W}x{H} and the x4d forms (aom_dsp/sad.c:276-332) with the _bits wrappers of
+// av1/encoder/encoder_utils.h:413-470 (skip) / :155-208 (x4d) folded in through bd.
+unsigned int aomhip_highbd_sad_skip(const uint8_t *src8, int src_stride, const uint8_t *ref8, int ref_stride, int bw, int bh, int bd) {
+  const uint16_t *s = reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(src8) << 1);
+  const uint16_t *r = reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(ref8) << 1);
+  uint32_t v = 0;
+  const uint16_t *refs[1] = { r };
+  host_sad_multi<uint16_t>(s, src_stride, refs, 1, ref_stride, bw, bh, AOMHIP_SAD_SKIP_ROWS, wrapper_shift(bd), &v);
+  return v;
+}
+
+void aomhip_highbd_sad_x4d(const uint8_t *src8, int src_stride, const uint8_t *const ref8[4], int ref_stride, uint32_t sad_array[4], int bw,
+                           int bh, int bd, int skip_rows) {
+  const uint16_t *s = reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(src8) << 1);
+  const uint16_t *refs[4];
+  for (int k = 0; k < 4; ++k) refs[k] = reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(ref8[k]) << 1);
+  host_sad_multi<uint16_t>(s, src_stride, refs, 4, ref_stride, bw, bh, skip_rows ? AOMHIP_SAD_SKIP_ROWS : 0, wrapper_shift(bd), sad_array);
+}
+
 }  // extern "C"

@@ -40,7 +40,13 @@ template <int W, int H> struct Fixed {
     return aomhip_highbd_sub_pixel_variance(a, as, xo, yo, b, bs, W, H, BD, sse);
   }
   template <int BD> static void hsdx4df(const uint8_t *a, int as, const uint8_t *const b[], int bs, unsigned int *out) {
-    for (int k = 0; k < 4; ++k) out[k] = aomhip_highbd_sad(a, as, b[k], bs, W, H, BD);
+    aomhip_highbd_sad_x4d(a, as, b, bs, out, W, H, BD, 0);
+  }
+  template <int BD> static unsigned int hsdsf(const uint8_t *a, int as, const uint8_t *b, int bs) {
+    return aomhip_highbd_sad_skip(a, as, b, bs, W, H, BD);
+  }
+  template <int BD> static void hsdsx4df(const uint8_t *a, int as, const uint8_t *const b[], int bs, unsigned int *out) {
+    aomhip_highbd_sad_x4d(a, as, b, bs, out, W, H, BD, 1);
   }
   // The compound / masked / OBMC members (BD 0 = the 8-bit table; 8 / 10 / 12 = the highbd tables).  Operand roles as
   // in aom_dsp/variance.h:29-82: for the SAD forms `a` is the source and `b` the reference, for the sub-pixel forms `a`
@@ -115,10 +121,12 @@ template <int W, int H> void fill(aomhip_variance_vtable *t, int bd) {
   } else if (bd == 10) {
     t->sdf = F::template hsdf<10>; t->vf = F::template hvf<10>; t->svf = F::template hsvf<10>;
     t->sdx4df = F::template hsdx4df<10>; t->sdx3df = F::template hsdx4df<10>;
+    t->sdsf = F::template hsdsf<10>; t->sdsx4df = F::template hsdsx4df<10>;
     fill_compound<W, H, 10>(t);
   } else {
     t->sdf = F::template hsdf<12>; t->vf = F::template hvf<12>; t->svf = F::template hsvf<12>;
     t->sdx4df = F::template hsdx4df<12>; t->sdx3df = F::template hsdx4df<12>;
+    t->sdsf = F::template hsdsf<12>; t->sdsx4df = F::template hsdsx4df<12>;
     fill_compound<W, H, 12>(t);
   }
 }

@@ -587,7 +587,7 @@ typedef struct aomhip_variance_vtable {
                         const uint8_t *second_pred, const void *jcp_param);
 } aomhip_variance_vtable;
 
-/* Overwrites all 16 members (sdsf / sdsx4df: 8-bit tables only) of the 22 entries (BLOCK_SIZE order,
+/* Overwrites all 16 members of the 22 entries (BLOCK_SIZE order,
  * av1/common/enums.h:99-124) with GPU-backed functions of the reference's exact signatures -- what a
  * maintainer calls right after av1_create_primary_compressor fills ppi->fn_ptr (av1/encoder/encoder.c:986-1226;
  * highbd: encoder_utils.h:130-139,572-, the _bits10 / _bits12 SAD wrappers are folded in).  Every other
@@ -703,6 +703,11 @@ void aomhip_sad16x16x4d(const uint8_t *src_ptr, int src_stride, const uint8_t *c
  * bd = 8/10/12 applies the encoder's vtable wrapper; 0 = raw kernel value. */
 unsigned int aomhip_highbd_sad(const uint8_t *src8, int src_stride, const uint8_t *ref8, int ref_stride, int bw,
                                int bh, int bd);
+/* aom_highbd_sad_skip_{W}x{H} (aom_dsp_rtcd_defs.pl, aom_dsp/sad.c:276-332) and the highbd x4d / skip-x4d forms in one
+ * launch (skip_rows selects aom_highbd_sad_skip_{W}x{H}x4d); bd as above. */
+unsigned int aomhip_highbd_sad_skip(const uint8_t *src8, int src_stride, const uint8_t *ref8, int ref_stride, int bw, int bh, int bd);
+void aomhip_highbd_sad_x4d(const uint8_t *src8, int src_stride, const uint8_t *const ref8[4], int ref_stride, uint32_t sad_array[4], int bw,
+                           int bh, int bd, int skip_rows);
 
 /* aom_dsp_rtcd_defs.pl:1367-1370 aom_variance{W}x{H}(a, a_stride, b, b_stride, sse) and
  * aom_sub_pixel_variance{W}x{H}(a, a_stride, xoffset, yoffset, b, b_stride, sse); host pointers. */

@@ -225,3 +225,29 @@ def test_vtable_compound_members(hip, oracle, bd):
         assert (got, sse.value) == (orc.orc_obmc_variance(vp(A), S, 0, 0, 0, vp(WS), vp(OM), w, h, e16, bd, C.byref(q)), q.value)
         got = fn["osvf"](enc(A), S, xo, yo, WS, OM, C.addressof(sse))
         assert (got, sse.value) == (orc.orc_obmc_variance(vp(A), S, 1, xo, yo, vp(WS), vp(OM), w, h, e16, bd, C.byref(q)), q.value)
+
+
+@pytest.mark.parametrize("bd", [10, 12])
+def test_vtable_highbd_skip_members(hip, oracle, bd):
+    """sdsf / sdsx4df of the 10 / 12-bit tables: aom_highbd_sad_skip_{W}x{H}[x4d] with the _bits wrappers
+    (av1/encoder/encoder_utils.h:413-470), called through the table on CONVERT_TO_BYTEPTR pointers."""
+    lib = hip.capi.lib
+    table = (C.c_void_p * (16 * 22))()
+    assert lib.aomhip_bind_variance_vtable(table, bd) == 0
+    rng = np.random.default_rng(bd)
+    S = 160
+    a, b = rng.integers(0, 1 << bd, (140, S)).astype(np.uint16), rng.integers(0, 1 << bd, (140, S)).astype(np.uint16)
+    SAD = C.CFUNCTYPE(C.c_uint, C.c_void_p, C.c_int, C.c_void_p, C.c_int)
+    X4D = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_void_p)
+    for bi, (w, h) in enumerate(BLOCK_SIZES):
+        if h < 8:
+            continue                # the reference installs the down-sampled pair for heights >= 8 only (encoder.c:1193-1221)
+        A = a.ctypes.data + (3 * S + 5) * 2
+        offs = [(int(rng.integers(0, 8)), int(rng.integers(0, 8))) for _ in range(4)]
+        Bs = [b.ctypes.data + (y * S + x) * 2 for (x, y) in offs]
+        want = [oracle.sad(a, 3, 5, b, y, x, w, h, skip=True, bd=bd) for (x, y) in offs]
+        assert SAD(table[bi * 16 + 1])(A >> 1, S, Bs[0] >> 1, S) == want[0], (w, h, bd)
+        ptrs = (C.c_void_p * 4)(*[p >> 1 for p in Bs])
+        out = (C.c_uint * 4)()
+        X4D(table[bi * 16 + 8])(A >> 1, S, ptrs, S, out)
+        assert list(out) == want, (w, h, bd)
