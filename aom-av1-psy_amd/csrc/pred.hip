@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void compound_pred_kernel(PlaneView<T> ref0, i
                                                             int dst_stride, const aomhip_search_block *__restrict__ blocks,
                                                             const int16_t *__restrict__ mv0, const int16_t *__restrict__ mv1, int n_blocks,
                                                             int set_x, int set_y, int bit_depth, int x_lo, int x_hi, int y_lo, int y_hi,
-                                                            int mvx_mul, int mvy_mul, int fwd, int bck) {
+                                                            int mvx_mul, int mvy_mul, int fwd, int bck, const uint8_t *__restrict__ mask,
+                                                            const uint32_t *__restrict__ mask_offset, int mask_stride, int subw, int subh) {
   constexpr int LPB = W < 64 ? W : 64;
   constexpr int BPW = 64 / LPB;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void compound_pred_kernel(PlaneView<T> ref0, i
   if (bi >= n_blocks) return;
   const int col0 = lane % LPB;
   const int bx = blocks[bi].bx, by = blocks[bi].by;
+  const uint8_t *mk = mask ? mask + (mask_offset ? mask_offset[bi] : 0) : nullptr;
   int px0 = (bx << 4) + mv0[2 * bi + 1] * mvx_mul, py0 = (by << 4) + mv0[2 * bi] * mvy_mul;
   int px1 = (bx << 4) + mv1[2 * bi + 1] * mvx_mul, py1 = (by << 4) + mv1[2 * bi] * mvy_mul;
   px0 = min(max(px0, x_lo), x_hi); py0 = min(max(py0, y_lo), y_hi);
@@ -195,7 +197,18 @@ __global__ __launch_bounds__(256) void compound_pred_kernel(PlaneView<T> ref0, i
         }
         const int res0 = v0 >> r1, res1 = v1 >> r1;   // the two CONV_BUF values (fit 16 bits)
         // convolve.c:222-233: distance weights (sum 16) or the plain average, then the offset comes out and the result is rounded
-        int tmp = fwd | bck ? (res0 * fwd + res1 * bck) >> 4 : (res0 + res1) >> 1;
+        int tmp;
+        if (mk) {  // aom_[lowbd|highbd]_blend_a64_d16_mask (aom_dsp/blend_a64_mask.c): the mask weighs reference 0
+          const int y = r - 7;
+          const uint8_t *mr = mk + (y << subh) * mask_stride + (col << subw);
+          int m = mr[0];
+          if (subw & subh) m = (m + mr[1] + mr[mask_stride] + mr[mask_stride + 1] + 2) >> 2;
+          else if (subw) m = (m + mr[1] + 1) >> 1;
+          else if (subh) m = (m + mr[mask_stride] + 1) >> 1;
+          tmp = (m * res0 + (64 - m) * res1) >> 6;
+        } else {
+          tmp = fwd | bck ? (res0 * fwd + res1 * bck) >> 4 : (res0 + res1) >> 1;
+        }
         tmp -= round_offset;
         tmp = (tmp + ((1 << rb) >> 1)) >> rb;
         *d = (T)min(max(tmp, 0), pmax);
@@ -290,7 +303,8 @@ extern "C" int aomhip_build_inter_pred_batch(aomhip_ctx *ctx, const aomhip_plane
 template <typename T>
 static int launch_compound_pred(aomhip_ctx *ctx, const aomhip_planes *r0, int f0, const aomhip_planes *r1, int f1, const aomhip_planes *pred,
                                 int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *mv0, const int16_t *mv1,
-                                int n_blocks, int fx, int fy, int fwd, int bck, int ss_x, int ss_y) {
+                                int n_blocks, int fx, int fy, int fwd, int bck, int ss_x, int ss_y, const uint8_t *mask = nullptr,
+                                const uint32_t *mask_offset = nullptr, int mask_stride = 0, int subw = 0, int subh = 0) {
   auto set_of = [](int f, int dim) { return dim <= 4 ? (f == 1 ? 5 : f == 3 ? 3 : 4) : f; };
   T *d = reinterpret_cast<T *>(pred->base) + (size_t)pred_frame * pred->frame_stride + (size_t)pred->border * pred->stride + pred->border;
   const int border = r0->border < r1->border ? r0->border : r1->border;
@@ -302,7 +316,7 @@ static int launch_compound_pred(aomhip_ctx *ctx, const aomhip_planes *r0, int f0
   if (bw == W && bh == H) {                                                                                                            \
     hipLaunchKernelGGL((compound_pred_kernel<T, W, H>), grid, block, 0, ctx->stream, view_of<T>(*r0), f0, view_of<T>(*r1), f1, d,      \
                        pred->stride, d_blocks, mv0, mv1, n_blocks, set_of(fx, W), set_of(fy, H), r0->bit_depth, x_lo, x_hi, y_lo, y_hi, \
-                       2 >> ss_x, 2 >> ss_y, fwd, bck);                                                                                 \
+                       2 >> ss_x, 2 >> ss_y, fwd, bck, mask, mask_offset, mask_stride, subw, subh);                                     \
     AOMHIP_LAUNCH_CHECK();                                                                                                             \
     return AOMHIP_OK;                                                                                                                  \
   }
@@ -332,6 +346,31 @@ extern "C" int aomhip_build_compound_pred_batch(aomhip_ctx *ctx, const aomhip_pl
                                          interp_filter_x, interp_filter_y, fwd_offset, bck_offset, subsampling_x, subsampling_y);
   return launch_compound_pred<uint16_t>(ctx, ref0, ref0_frame, ref1, ref1_frame, pred, pred_frame, bw, bh, d_blocks, d_mv0, d_mv1, n_blocks,
                                         interp_filter_x, interp_filter_y, fwd_offset, bck_offset, subsampling_x, subsampling_y);
+}
+
+extern "C" int aomhip_build_masked_compound_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref0, int ref0_frame, const aomhip_planes *ref1,
+                                                       int ref1_frame, const aomhip_planes *pred, int pred_frame, int bw, int bh,
+                                                       const aomhip_search_block *d_blocks, const int16_t *d_mv0, const int16_t *d_mv1,
+                                                       int n_blocks, int interp_filter_x, int interp_filter_y, const uint8_t *d_mask,
+                                                       const uint32_t *d_mask_offset, int mask_stride, int mask_subw, int mask_subh,
+                                                       int subsampling_x, int subsampling_y) {
+  if (!ctx || !ref0 || !ref1 || !pred || !ref0->base || !ref1->base || !pred->base || (n_blocks > 0 && (!d_blocks || !d_mv0 || !d_mv1)) ||
+      n_blocks < 0 || ref0_frame < 0 || ref0_frame >= ref0->n_frames || ref1_frame < 0 || ref1_frame >= ref1->n_frames || pred_frame < 0 ||
+      pred_frame >= pred->n_frames || !valid_block(bw, bh) || ref0->bit_depth != pred->bit_depth || ref1->bit_depth != pred->bit_depth ||
+      ref0->width != ref1->width || ref0->height != ref1->height || interp_filter_x < 0 || interp_filter_x > 3 || interp_filter_y < 0 ||
+      interp_filter_y > 3 || subsampling_x < 0 || subsampling_x > 1 || subsampling_y < 0 || subsampling_y > 1 || !d_mask || mask_stride <= 0 ||
+      mask_subw < 0 || mask_subw > 1 || mask_subh < 0 || mask_subh > 1 || ref0->border < 8 || ref1->border < 8) {
+    set_error("aomhip_build_masked_compound_pred_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  if (pred->bit_depth == 8)
+    return launch_compound_pred<uint8_t>(ctx, ref0, ref0_frame, ref1, ref1_frame, pred, pred_frame, bw, bh, d_blocks, d_mv0, d_mv1, n_blocks,
+                                         interp_filter_x, interp_filter_y, 0, 0, subsampling_x, subsampling_y, d_mask, d_mask_offset, mask_stride,
+                                         mask_subw, mask_subh);
+  return launch_compound_pred<uint16_t>(ctx, ref0, ref0_frame, ref1, ref1_frame, pred, pred_frame, bw, bh, d_blocks, d_mv0, d_mv1, n_blocks,
+                                        interp_filter_x, interp_filter_y, 0, 0, subsampling_x, subsampling_y, d_mask, d_mask_offset, mask_stride,
+                                        mask_subw, mask_subh);
 }
 
 extern "C" int aomhip_build_pred_fullpel(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame,

@@ -637,6 +637,19 @@ int aomhip_build_compound_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref0,
                                      const aomhip_planes *pred, int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks,
                                      const int16_t *d_mv0, const int16_t *d_mv1, int n_blocks, int interp_filter_x, int interp_filter_y,
                                      int fwd_offset, int bck_offset, int subsampling_x, int subsampling_y);
+/* Masked compound prediction (COMPOUND_WEDGE, COMPOUND_DIFFWTD once the mask exists): av1_make_masked_inter_predictor ->
+ * build_masked_compound_no_round (av1/common/reconinter.c) = both references through the compound convolve, then
+ * aom_lowbd_blend_a64_d16_mask / aom_highbd_blend_a64_d16_mask (aom_dsp/blend_a64_mask.c): (m * p0 + (64 - m) * p1) >> 6
+ * in the 16-bit intermediate domain, offset out, round, clip.  d_mask: 0..64 weights for reference 0, row stride
+ * mask_stride, block i's mask at d_mask + d_mask_offset[i] (NULL: 0; e.g. into the wedge master table); mask_subw /
+ * mask_subh: the mask is at twice the block's resolution in that direction (the chroma planes reuse the luma mask: 2x2
+ * rounded mean, or AOM_BLEND_AVG of two).  The diff-weighted mask itself (av1_build_compound_diffwtd_mask_d16) is not built
+ * here. */
+int aomhip_build_masked_compound_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref0, int ref0_frame, const aomhip_planes *ref1,
+                                            int ref1_frame, const aomhip_planes *pred, int pred_frame, int bw, int bh,
+                                            const aomhip_search_block *d_blocks, const int16_t *d_mv0, const int16_t *d_mv1, int n_blocks,
+                                            int interp_filter_x, int interp_filter_y, const uint8_t *d_mask, const uint32_t *d_mask_offset,
+                                            int mask_stride, int mask_subw, int mask_subh, int subsampling_x, int subsampling_y);
 
 /* ------------------------------------------------------------------ RD helpers, batched */
 

@@ -146,8 +146,12 @@ static void compound_one(const void *src, int src_stride, uint16_t *buf, int w, 
   }
 }
 
-void orc_convolve_compound(const void *src0, int stride0, int sx0, int sy0, const void *src1, int stride1, int sx1, int sy1, void *dst,
-                           int dst_stride, int w, int h, int filter_x, int filter_y, int fwd_offset, int bck_offset, int elem16, int bd) {
+/* mask != NULL: aom_lowbd_blend_a64_d16_mask_c / aom_highbd_blend_a64_d16_mask_c (aom_dsp/blend_a64_mask.c) of the two
+ * CONV_BUFs -- the masked compound predictor (av1/common/reconinter.c build_masked_compound_no_round); the mask weighs
+ * reference 0 and lies at (1 << subw) x (1 << subh) times the block's resolution. */
+void orc_convolve_compound_mask(const void *src0, int stride0, int sx0, int sy0, const void *src1, int stride1, int sx1, int sy1, void *dst,
+                                int dst_stride, int w, int h, int filter_x, int filter_y, int fwd_offset, int bck_offset, int elem16, int bd,
+                                const uint8_t *mask, int mask_stride, int subw, int subh) {
   const int tbd = elem16 ? bd : 8;
   const int round_0 = (elem16 && bd == 12) ? 5 : 3, round_1 = 7;
   const int round_bits = 14 - round_0 - round_1, offset_bits = tbd + 14 - round_0;
@@ -159,11 +163,29 @@ void orc_convolve_compound(const void *src0, int stride0, int sx0, int sy0, cons
     for (int x = 0; x < w; ++x) {
       int tmp = b0[y * w + x];
       const int res = b1[y * w + x];
-      if (fwd_offset || bck_offset) tmp = (tmp * fwd_offset + res * bck_offset) >> 4;
-      else tmp = (tmp + res) >> 1;
+      if (mask) {
+        int m;
+        if (!subw && !subh) m = mask[y * mask_stride + x];
+        else if (subw && subh)
+          m = RPOT(mask[2 * y * mask_stride + 2 * x] + mask[(2 * y + 1) * mask_stride + 2 * x] + mask[2 * y * mask_stride + 2 * x + 1] +
+                       mask[(2 * y + 1) * mask_stride + 2 * x + 1], 2);
+        else if (subw) m = RPOT(mask[y * mask_stride + 2 * x] + mask[y * mask_stride + 2 * x + 1], 1);
+        else m = RPOT(mask[2 * y * mask_stride + x] + mask[(2 * y + 1) * mask_stride + x], 1);
+        tmp = (m * tmp + (64 - m) * res) >> 6;
+      } else if (fwd_offset || bck_offset) {
+        tmp = (tmp * fwd_offset + res * bck_offset) >> 4;
+      } else {
+        tmp = (tmp + res) >> 1;
+      }
       tmp -= round_offset;
       put(dst, elem16, (ptrdiff_t)y * dst_stride + x, RPOT(tmp, round_bits), tbd);
     }
   free(b0);
   free(b1);
+}
+
+void orc_convolve_compound(const void *src0, int stride0, int sx0, int sy0, const void *src1, int stride1, int sx1, int sy1, void *dst,
+                           int dst_stride, int w, int h, int filter_x, int filter_y, int fwd_offset, int bck_offset, int elem16, int bd) {
+  orc_convolve_compound_mask(src0, stride0, sx0, sy0, src1, stride1, sx1, sy1, dst, dst_stride, w, h, filter_x, filter_y, fwd_offset, bck_offset,
+                             elem16, bd, NULL, 0, 0, 0);
 }

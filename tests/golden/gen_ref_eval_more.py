@@ -550,8 +550,66 @@ def gen_convolve_compound():
                 k += 1
     save("ref_eval_convolve_compound.npz", arrays, cases)
 
+
+def gen_convolve_masked():
+    """Masked compound prediction (COMPOUND_WEDGE / COMPOUND_DIFFWTD given the mask): both references through the compound
+    convolve into 16-bit CONV_BUFs (do_average 0), then aom_lowbd_blend_a64_d16_mask_c / aom_highbd_blend_a64_d16_mask_c
+    (aom_dsp/blend_a64_mask.c) -- what av1_make_masked_inter_predictor -> build_masked_compound_no_round do
+    (av1/common/reconinter.c) -- with the mask at plane resolution and at 2x resolution (4:2:0 / 4:2:2 / 4:4:0 chroma)."""
+    ev = evaluator(["av1/common/filter.h", "av1/common/convolve.h", "aom_dsp/aom_convolve.c", "av1/common/convolve.c", "aom_dsp/blend.h",
+                    "aom_dsp/blend_a64_mask.c"])
+    rng = np.random.default_rng(20261025)
+    arrays, cases = {}, []
+    S, ROWS = 96, 80
+    k = 0
+    for bd in (8, 10, 12):
+        mx = (1 << bd) - 1
+        planes = []
+        for r in range(2):
+            base = rng.integers(0, mx + 1, (ROWS, S))
+            base[:16] = np.where(rng.integers(0, 2, (16, S)) > 0, mx, 0)
+            planes.append(base)
+            arrays["p%d_%d" % (bd, r)] = base.astype(np.uint16)
+        ct = "uint8_t" if bd == 8 else "uint16_t"
+        P = [ev.array(pl.ravel(), ct) for pl in planes]
+        for (w, h, subw, subh) in ((8, 8, 0, 0), (16, 16, 0, 0), (4, 8, 0, 0), (8, 8, 1, 1), (16, 8, 1, 0), (8, 16, 0, 1), (32, 16, 0, 0), (4, 4, 1, 1)):
+            if bd == 12 and w * h > 128:
+                continue
+            fxi, fyi = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            pos = [(int(rng.integers(4, S - w - 5)), int(rng.integers(4, ROWS - h - 5))) for _ in range(2)]
+            if k % 2 == 0:
+                pos[1] = (pos[1][0], int(rng.integers(4, 10)))
+            subs = [(int(rng.integers(0, 16)) * int(rng.integers(0, 2)), int(rng.integers(0, 16)) * int(rng.integers(0, 2))) for _ in range(2)]
+            fp = [ev.call("av1_get_interp_filter_params_with_block_size", fxi, w), ev.call("av1_get_interp_filter_params_with_block_size", fyi, h)]
+            filt = R.Ptr(fp, 0, ("ptr", ev.structs["InterpFilterParams"]))
+            bufs = [ev.array([0] * (w * h), "uint16_t") for _ in range(2)]
+            dst = ev.array([0] * (w * h), ct)
+            cps = []
+            for r in range(2):
+                cpv = ev.call("get_conv_params_no_round", 0, 0, bufs[r], w, 1, bd)
+                cp = R.Ptr([cpv], 0, cpv.st)
+                cps.append(cp)
+                args = [P[r].add(pos[r][1] * S + pos[r][0]), S, dst, w, w, h, filt, subs[r][0], 16, subs[r][1], 16, 0, cp]
+                if bd > 8:
+                    args.append(bd)
+                ev.call("av1_convolve_2d_facade" if bd == 8 else "av1_highbd_convolve_2d_facade", *args)
+            mw, mh = w << subw, h << subh
+            ms = mw + 4
+            mask = rng.integers(0, 65, (mh, ms))
+            mask[0, :mw // 2] = 64
+            mask[-1, :mw // 2] = 0
+            M = ev.array(mask.ravel(), "uint8_t")
+            args = [dst, w, bufs[0], w, bufs[1], w, M, ms, w, h, subw, subh, cps[0]]
+            if bd > 8:
+                args.append(bd)
+            ev.call("aom_lowbd_blend_a64_d16_mask_c" if bd == 8 else "aom_highbd_blend_a64_d16_mask_c", *args)
+            arrays["d%d" % k], arrays["m%d" % k] = np.asarray(dst.buf, np.uint16), mask.astype(np.uint8)
+            cases.append({"k": k, "bd": bd, "w": w, "h": h, "subw": subw, "subh": subh, "pos": pos, "subs": subs, "fx": fxi, "fy": fyi, "mask_stride": ms})
+            k += 1
+    save("ref_eval_convolve_masked.npz", arrays, cases)
+
 if __name__ == "__main__":
-    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound", "convolve", "rdhelp", "cdef_search", "lrstats", "convolve_compound"]:
+    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound", "convolve", "rdhelp", "cdef_search", "lrstats", "convolve_compound", "convolve_masked"]:
         t = time.time()
         globals()["gen_" + w]()
         print("  (%s: %.1f s)" % (w, time.time() - t))

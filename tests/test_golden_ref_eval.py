@@ -519,3 +519,28 @@ def test_compound_convolve_matches_reference_evaluation(oracle):
         assert np.array_equal(dst.ravel(), z["d%d" % c["k"]]), c
         kinds.add((bool(sx0), bool(sy0)))
     assert len(kinds) == 4
+
+
+def test_masked_compound_matches_reference_evaluation(oracle):
+    """orc_convolve_compound_mask against the interpreted compound convolves + aom_[lowbd|highbd]_blend_a64_d16_mask_c
+    (aom_dsp/blend_a64_mask.c), mask at plane resolution and at 2x (2x2 mean / pair average)."""
+    z, cases = load("ref_eval_convolve_masked.npz")
+    assert len(cases) >= 20
+    f = oracle.lib.orc_convolve_compound_mask
+    f.restype = None
+    subs = set()
+    for c in cases:
+        bd, w, h = c["bd"], c["w"], c["h"]
+        e16 = int(bd > 8)
+        dt = np.uint16 if e16 else np.uint8
+        p0, p1 = np.ascontiguousarray(z["p%d_0" % bd], dt), np.ascontiguousarray(z["p%d_1" % bd], dt)
+        S = p0.shape[1]
+        (x0, y0), (x1, y1) = c["pos"]
+        (sx0, sy0), (sx1, sy1) = c["subs"]
+        mask = np.ascontiguousarray(z["m%d" % c["k"]])
+        dst = np.zeros((h, w), dt)
+        f(C.c_void_p(p0.ctypes.data + (y0 * S + x0) * p0.itemsize), S, sx0, sy0, C.c_void_p(p1.ctypes.data + (y1 * S + x1) * p1.itemsize), S, sx1, sy1,
+          C.c_void_p(dst.ctypes.data), w, w, h, c["fx"], c["fy"], 0, 0, e16, bd, C.c_void_p(mask.ctypes.data), c["mask_stride"], c["subw"], c["subh"])
+        assert np.array_equal(dst.ravel(), z["d%d" % c["k"]]), c
+        subs.add((c["subw"], c["subh"]))
+    assert len(subs) == 4

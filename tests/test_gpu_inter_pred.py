@@ -211,3 +211,86 @@ def test_compound_pred_vs_oracle(hip, oracle, ctx, bd):
         ctx.build_compound_pred_batch(r0, 0, r1, 1, pp, 0, 16, 16, 1, 1, 1, 1, 0, 0, 9, 9)      # weights must sum to 16
     for p in (r0, r1, pp):
         ctx.planes_free(p)
+
+
+def test_masked_compound_pred_goldens(hip, ctx):
+    """Every case of ref_eval_convolve_masked.npz through aomhip_build_masked_compound_pred_batch."""
+    z = np.load(os.path.join(GOLD, "ref_eval_convolve_masked.npz"))
+    cases = json.loads(bytes(z["cases"]).decode())
+    border = 16
+    planes = {}
+    for bd in (8, 10, 12):
+        dt = np.uint8 if bd == 8 else np.uint16
+        p0, p1 = np.ascontiguousarray(z["p%d_0" % bd], dt), np.ascontiguousarray(z["p%d_1" % bd], dt)
+        H, W = p0.shape
+        r0, r1, pp = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+        ctx.planes_upload(r0, 0, p0); ctx.planes_upload(r1, 0, p1)
+        planes[bd] = (r0, r1, pp)
+    for c in cases:
+        r0, r1, pp = planes[c["bd"]]
+        w, h = c["w"], c["h"]
+        (x0, y0), (x1, y1) = c["pos"]
+        (sx0, sy0), (sx1, sy1) = c["subs"]
+        blk = np.zeros(1, hip.capi.search_block_dtype)
+        blk["bx"], blk["by"] = x0, y0
+        mv0 = np.array([[sy0, sx0]], np.int16)
+        mv1 = np.array([[(y1 - y0) * 16 + sy1, (x1 - x0) * 16 + sx1]], np.int16)
+        pad = np.zeros(7, np.uint8)
+        mask = np.concatenate([pad, np.ascontiguousarray(z["m%d" % c["k"]]).ravel()])          # the block's mask at a byte offset
+        d_b, d_0, d_1, d_m, d_o = ctx.to_device(blk), ctx.to_device(mv0), ctx.to_device(mv1), ctx.to_device(mask), ctx.to_device(np.array([7], np.uint32))
+        ctx.build_masked_compound_pred_batch(r0, 0, r1, 0, pp, 0, w, h, d_b, d_0, d_1, 1, c["fx"], c["fy"], d_m, d_o, c["mask_stride"], c["subw"],
+                                             c["subh"], 1, 1)
+        got = ctx.planes_download(pp, 0)[border + y0:border + y0 + h, border + x0:border + x0 + w]
+        assert np.array_equal(got.ravel().astype(np.uint16), z["d%d" % c["k"]]), c
+        for d in (d_b, d_0, d_1, d_m, d_o):
+            ctx.free(d)
+    assert len(cases) >= 20
+    for t in planes.values():
+        for p in t:
+            ctx.planes_free(p)
+
+
+@pytest.mark.parametrize("bd,subw,subh", [(8, 0, 0), (10, 0, 0), (10, 1, 1), (8, 1, 0), (12, 0, 1)])
+def test_masked_compound_pred_vs_oracle(hip, oracle, ctx, bd, subw, subh):
+    import ctypes as C
+    rng = np.random.default_rng(90 + bd + subw)
+    W, H, border = 192, 128, 48
+    ref0, ref1 = hip.synth.lcg_frame(W, H, 10, 0, bd), hip.synth.lcg_frame(W, H, 11, 1, bd)
+    r0, r1, pp = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(r0, 0, ref0); ctx.planes_upload(r1, 0, ref1)
+    b0, b1 = oracle.extend_plane(ref0, border, r0.stride), oracle.extend_plane(ref1, border, r1.stride)
+    f = oracle.lib.orc_convolve_compound_mask
+    f.restype = None
+    for (bw, bh) in ((4, 4), (8, 8), (16, 16), (8, 16), (32, 32), (64, 64), (16, 4)):
+        xs, ys = np.meshgrid(np.arange(0, W - bw + 1, bw), np.arange(0, H - bh + 1, bh))
+        n = xs.size
+        blocks = np.zeros(n, hip.capi.search_block_dtype)
+        blocks["bx"], blocks["by"] = xs.ravel(), ys.ravel()
+        lim = (border - 8) * 8
+        mv0, mv1 = rng.integers(-lim, lim + 1, (n, 2)).astype(np.int16), rng.integers(-lim, lim + 1, (n, 2)).astype(np.int16)
+        mw, mh = bw << subw, bh << subh
+        nmask, ms = 5, mw + 3
+        masks = rng.integers(0, 65, (nmask, mh, ms)).astype(np.uint8)
+        masks[0], masks[1] = 64, 0
+        moff = (rng.integers(0, nmask, n) * (mh * ms)).astype(np.uint32)
+        d_b, d_0, d_1, d_m, d_o = ctx.to_device(blocks), ctx.to_device(mv0), ctx.to_device(mv1), ctx.to_device(masks), ctx.to_device(moff)
+        fx, fy = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        ctx.build_masked_compound_pred_batch(r0, 0, r1, 0, pp, 0, bw, bh, d_b, d_0, d_1, n, fx, fy, d_m, d_o, ms, subw, subh)
+        got = ctx.planes_download(pp, 0)[border:border + H, border:border + W]
+        e16 = int(bd > 8)
+        want = np.zeros((H, W), ref0.dtype)
+        flat = masks.reshape(-1)
+        for i in range(n):
+            x, y = int(blocks["bx"][i]), int(blocks["by"][i])
+            p = []
+            for ref, mv in ((b0, mv0[i]), (b1, mv1[i])):
+                px, py = (x << 4) + int(mv[1]) * 2, (y << 4) + int(mv[0]) * 2
+                p.append((C.c_void_p(oracle._addr(ref, border + (py >> 4), border + (px >> 4))), ref.shape[1], px & 15, py & 15))
+            f(p[0][0], p[0][1], p[0][2], p[0][3], p[1][0], p[1][1], p[1][2], p[1][3], C.c_void_p(oracle._addr(want, y, x)), W, bw, bh, fx, fy, 0, 0, e16, bd,
+              C.c_void_p(flat.ctypes.data + int(moff[i])), ms, subw, subh)
+        hh, ww = (H // bh) * bh, (W // bw) * bw
+        assert np.array_equal(got[:hh, :ww], want[:hh, :ww]), (bw, bh, bd, subw, subh)
+        for d in (d_b, d_0, d_1, d_m, d_o):
+            ctx.free(d)
+    for p in (r0, r1, pp):
+        ctx.planes_free(p)
