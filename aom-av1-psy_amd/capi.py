@@ -170,6 +170,7 @@ _protos = {
     "aomhip_highbd_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, _i]),
     "aomhip_highbd_sad_x4d": (None, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i]),
     "aomhip_build_masked_compound_pred_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i]),
+    "aomhip_build_diffwtd_compound_pred_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
@@ -427,6 +428,12 @@ class Context:
         check(lib.aomhip_build_masked_compound_pred_batch(self.h, C.byref(ref0), f0, C.byref(ref1), f1, C.byref(pred), pred_frame, bw, bh, d_blocks,
                                                           d_mv0, d_mv1, n, filter_x, filter_y, d_mask, d_mask_offset, mask_stride, subw, subh,
                                                           ss_x, ss_y), "aomhip_build_masked_compound_pred_batch")
+
+    def build_diffwtd_compound_pred_batch(self, ref0, f0, ref1, f1, pred, pred_frame, bw, bh, d_blocks, d_mv0, d_mv1, n, filter_x, filter_y,
+                                          mask_type, d_mask_out=None):
+        check(lib.aomhip_build_diffwtd_compound_pred_batch(self.h, C.byref(ref0), f0, C.byref(ref1), f1, C.byref(pred), pred_frame, bw, bh, d_blocks,
+                                                           d_mv0, d_mv1, n, filter_x, filter_y, mask_type, d_mask_out),
+              "aomhip_build_diffwtd_compound_pred_batch")
 
     def build_pred_fullpel(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n):
         check(lib.aomhip_build_pred_fullpel(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks,

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void compound_pred_kernel(PlaneView<T> ref0, i
                                                             const int16_t *__restrict__ mv0, const int16_t *__restrict__ mv1, int n_blocks,
                                                             int set_x, int set_y, int bit_depth, int x_lo, int x_hi, int y_lo, int y_hi,
                                                             int mvx_mul, int mvy_mul, int fwd, int bck, const uint8_t *__restrict__ mask,
-                                                            const uint32_t *__restrict__ mask_offset, int mask_stride, int subw, int subh) {
+                                                            const uint32_t *__restrict__ mask_offset, int mask_stride, int subw, int subh, int diffwtd,
+                                                            uint8_t *__restrict__ mask_out) {
   constexpr int LPB = W < 64 ? W : 64;
   constexpr int BPW = 64 / LPB;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -198,7 +199,15 @@ __global__ __launch_bounds__(256) void compound_pred_kernel(PlaneView<T> ref0, i
         const int res0 = v0 >> r1, res1 = v1 >> r1;   // the two CONV_BUF values (fit 16 bits)
         // convolve.c:222-233: distance weights (sum 16) or the plain average, then the offset comes out and the result is rounded
         int tmp;
-        if (mk) {  // aom_[lowbd|highbd]_blend_a64_d16_mask (aom_dsp/blend_a64_mask.c): the mask weighs reference 0
+        if (diffwtd) {  // av1_build_compound_diffwtd_mask_d16 (reconinter.c:296-328): the mask comes from the two predictors
+          const int rnd = rb + tbd - 8;
+          int diff = res0 > res1 ? res0 - res1 : res1 - res0;
+          diff = (diff + ((1 << rnd) >> 1)) >> rnd;
+          int m = min(38 + (diff >> 4), 64);   // DIFF_FACTOR 16; never below 38
+          m = diffwtd == 2 ? 64 - m : m;
+          if (mask_out) mask_out[((int64_t)bi * H + (r - 7)) * W + col] = (uint8_t)m;
+          tmp = (m * res0 + (64 - m) * res1) >> 6;
+        } else if (mk) {  // aom_[lowbd|highbd]_blend_a64_d16_mask (aom_dsp/blend_a64_mask.c): the mask weighs reference 0
           const int y = r - 7;
           const uint8_t *mr = mk + (y << subh) * mask_stride + (col << subw);
           int m = mr[0];
@@ -304,7 +313,8 @@ template <typename T>
 static int launch_compound_pred(aomhip_ctx *ctx, const aomhip_planes *r0, int f0, const aomhip_planes *r1, int f1, const aomhip_planes *pred,
                                 int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *mv0, const int16_t *mv1,
                                 int n_blocks, int fx, int fy, int fwd, int bck, int ss_x, int ss_y, const uint8_t *mask = nullptr,
-                                const uint32_t *mask_offset = nullptr, int mask_stride = 0, int subw = 0, int subh = 0) {
+                                const uint32_t *mask_offset = nullptr, int mask_stride = 0, int subw = 0, int subh = 0, int diffwtd = 0,
+                                uint8_t *mask_out = nullptr) {
   auto set_of = [](int f, int dim) { return dim <= 4 ? (f == 1 ? 5 : f == 3 ? 3 : 4) : f; };
   T *d = reinterpret_cast<T *>(pred->base) + (size_t)pred_frame * pred->frame_stride + (size_t)pred->border * pred->stride + pred->border;
   const int border = r0->border < r1->border ? r0->border : r1->border;
@@ -316,7 +326,7 @@ static int launch_compound_pred(aomhip_ctx *ctx, const aomhip_planes *r0, int f0
   if (bw == W && bh == H) {                                                                                                            \
     hipLaunchKernelGGL((compound_pred_kernel<T, W, H>), grid, block, 0, ctx->stream, view_of<T>(*r0), f0, view_of<T>(*r1), f1, d,      \
                        pred->stride, d_blocks, mv0, mv1, n_blocks, set_of(fx, W), set_of(fy, H), r0->bit_depth, x_lo, x_hi, y_lo, y_hi, \
-                       2 >> ss_x, 2 >> ss_y, fwd, bck, mask, mask_offset, mask_stride, subw, subh);                                     \
+                       2 >> ss_x, 2 >> ss_y, fwd, bck, mask, mask_offset, mask_stride, subw, subh, diffwtd, mask_out);                  \
     AOMHIP_LAUNCH_CHECK();                                                                                                             \
     return AOMHIP_OK;                                                                                                                  \
   }
@@ -371,6 +381,27 @@ extern "C" int aomhip_build_masked_compound_pred_batch(aomhip_ctx *ctx, const ao
   return launch_compound_pred<uint16_t>(ctx, ref0, ref0_frame, ref1, ref1_frame, pred, pred_frame, bw, bh, d_blocks, d_mv0, d_mv1, n_blocks,
                                         interp_filter_x, interp_filter_y, 0, 0, subsampling_x, subsampling_y, d_mask, d_mask_offset, mask_stride,
                                         mask_subw, mask_subh);
+}
+
+extern "C" int aomhip_build_diffwtd_compound_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref0, int ref0_frame, const aomhip_planes *ref1,
+                                                        int ref1_frame, const aomhip_planes *pred, int pred_frame, int bw, int bh,
+                                                        const aomhip_search_block *d_blocks, const int16_t *d_mv0, const int16_t *d_mv1,
+                                                        int n_blocks, int interp_filter_x, int interp_filter_y, int mask_type,
+                                                        uint8_t *d_mask_out) {
+  if (!ctx || !ref0 || !ref1 || !pred || !ref0->base || !ref1->base || !pred->base || (n_blocks > 0 && (!d_blocks || !d_mv0 || !d_mv1)) ||
+      n_blocks < 0 || ref0_frame < 0 || ref0_frame >= ref0->n_frames || ref1_frame < 0 || ref1_frame >= ref1->n_frames || pred_frame < 0 ||
+      pred_frame >= pred->n_frames || !valid_block(bw, bh) || ref0->bit_depth != pred->bit_depth || ref1->bit_depth != pred->bit_depth ||
+      ref0->width != ref1->width || ref0->height != ref1->height || interp_filter_x < 0 || interp_filter_x > 3 || interp_filter_y < 0 ||
+      interp_filter_y > 3 || mask_type < 0 || mask_type > 1 || ref0->border < 8 || ref1->border < 8) {
+    set_error("aomhip_build_diffwtd_compound_pred_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  if (pred->bit_depth == 8)
+    return launch_compound_pred<uint8_t>(ctx, ref0, ref0_frame, ref1, ref1_frame, pred, pred_frame, bw, bh, d_blocks, d_mv0, d_mv1, n_blocks,
+                                         interp_filter_x, interp_filter_y, 0, 0, 0, 0, nullptr, nullptr, 0, 0, 0, mask_type + 1, d_mask_out);
+  return launch_compound_pred<uint16_t>(ctx, ref0, ref0_frame, ref1, ref1_frame, pred, pred_frame, bw, bh, d_blocks, d_mv0, d_mv1, n_blocks,
+                                        interp_filter_x, interp_filter_y, 0, 0, 0, 0, nullptr, nullptr, 0, 0, 0, mask_type + 1, d_mask_out);
 }
 
 extern "C" int aomhip_build_pred_fullpel(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame,

@@ -643,13 +643,21 @@ int aomhip_build_compound_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref0,
  * in the 16-bit intermediate domain, offset out, round, clip.  d_mask: 0..64 weights for reference 0, row stride
  * mask_stride, block i's mask at d_mask + d_mask_offset[i] (NULL: 0; e.g. into the wedge master table); mask_subw /
  * mask_subh: the mask is at twice the block's resolution in that direction (the chroma planes reuse the luma mask: 2x2
- * rounded mean, or AOM_BLEND_AVG of two).  The diff-weighted mask itself (av1_build_compound_diffwtd_mask_d16) is not built
- * here. */
+ * rounded mean, or AOM_BLEND_AVG of two). */
 int aomhip_build_masked_compound_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref0, int ref0_frame, const aomhip_planes *ref1,
                                             int ref1_frame, const aomhip_planes *pred, int pred_frame, int bw, int bh,
                                             const aomhip_search_block *d_blocks, const int16_t *d_mv0, const int16_t *d_mv1, int n_blocks,
                                             int interp_filter_x, int interp_filter_y, const uint8_t *d_mask, const uint32_t *d_mask_offset,
                                             int mask_stride, int mask_subw, int mask_subh, int subsampling_x, int subsampling_y);
+/* COMPOUND_DIFFWTD on the luma plane: the mask is derived from the two predictors themselves --
+ * av1_build_compound_diffwtd_mask_d16 (av1/common/reconinter.c:296-328; mask_type 0 = DIFFWTD_38, 1 = DIFFWTD_38_INV) -- and
+ * applied with the same d16 blend, in one launch.  d_mask_out (may be NULL): block i's bw x bh mask at d_mask_out +
+ * i * bw * bh, row stride bw -- what the chroma planes then pass to aomhip_build_masked_compound_pred_batch
+ * (mask_stride bw, mask_subw / mask_subh = the chroma subsampling). */
+int aomhip_build_diffwtd_compound_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref0, int ref0_frame, const aomhip_planes *ref1,
+                                             int ref1_frame, const aomhip_planes *pred, int pred_frame, int bw, int bh,
+                                             const aomhip_search_block *d_blocks, const int16_t *d_mv0, const int16_t *d_mv1, int n_blocks,
+                                             int interp_filter_x, int interp_filter_y, int mask_type, uint8_t *d_mask_out);
 
 /* ------------------------------------------------------------------ RD helpers, batched */
 

@@ -189,3 +189,28 @@ void orc_convolve_compound(const void *src0, int stride0, int sx0, int sy0, cons
   orc_convolve_compound_mask(src0, stride0, sx0, sy0, src1, stride1, sx1, sy1, dst, dst_stride, w, h, filter_x, filter_y, fwd_offset, bck_offset,
                              elem16, bd, NULL, 0, 0, 0);
 }
+
+/* COMPOUND_DIFFWTD: av1_build_compound_diffwtd_mask_d16_c (av1/common/reconinter.c:296-328) on the two CONV_BUFs --
+ * m = clamp(38 + ROUND_POWER_OF_TWO(|p0 - p1|, round_bits + bd - 8) / 16, 0, 64), inverted for DIFFWTD_38_INV --
+ * followed by the d16 blend.  mask_type 0 / 1 = DIFFWTD_38 / DIFFWTD_38_INV; mask_out: w * h bytes, stride w. */
+void orc_convolve_compound_diffwtd(const void *src0, int stride0, int sx0, int sy0, const void *src1, int stride1, int sx1, int sy1, void *dst,
+                                   int dst_stride, int w, int h, int filter_x, int filter_y, int elem16, int bd, int mask_type,
+                                   uint8_t *mask_out) {
+  const int tbd = elem16 ? bd : 8;
+  const int round_0 = (elem16 && bd == 12) ? 5 : 3, round_1 = 7;
+  const int round = 14 - round_0 - round_1 + (tbd - 8);
+  uint16_t *b0 = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)w * h), *b1 = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)w * h);
+  compound_one(src0, stride0, b0, w, h, kernel_of(filter_x, w, sx0), kernel_of(filter_y, h, sy0), sx0, sy0, elem16, tbd, round_0);
+  compound_one(src1, stride1, b1, w, h, kernel_of(filter_x, w, sx1), kernel_of(filter_y, h, sy1), sx1, sy1, elem16, tbd, round_0);
+  for (int i = 0; i < w * h; ++i) {
+    int diff = abs((int)b0[i] - (int)b1[i]);
+    diff = RPOT(diff, round);
+    int m = 38 + diff / 16;
+    m = m < 0 ? 0 : m > 64 ? 64 : m;
+    mask_out[i] = (uint8_t)(mask_type ? 64 - m : m);
+  }
+  free(b0);
+  free(b1);
+  orc_convolve_compound_mask(src0, stride0, sx0, sy0, src1, stride1, sx1, sy1, dst, dst_stride, w, h, filter_x, filter_y, 0, 0, elem16, bd,
+                             mask_out, w, 0, 0);
+}

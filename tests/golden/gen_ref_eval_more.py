@@ -606,6 +606,46 @@ def gen_convolve_masked():
             arrays["d%d" % k], arrays["m%d" % k] = np.asarray(dst.buf, np.uint16), mask.astype(np.uint8)
             cases.append({"k": k, "bd": bd, "w": w, "h": h, "subw": subw, "subh": subh, "pos": pos, "subs": subs, "fx": fxi, "fy": fyi, "mask_stride": ms})
             k += 1
+    # COMPOUND_DIFFWTD: the mask comes from the two CONV_BUFs themselves (av1_build_compound_diffwtd_mask_d16_c,
+    # av1/common/reconinter.c:296-328), then the same blend
+    ev2 = evaluator([])
+    for f in ["av1/common/filter.h", "av1/common/convolve.h", "aom_dsp/aom_convolve.c", "av1/common/convolve.c", "aom_dsp/blend.h",
+              "aom_dsp/blend_a64_mask.c", "av1/common/mv.h", "aom_scale/yv12config.h", "av1/common/blockd.h", "av1/common/reconinter.h",
+              "av1/common/reconinter.c"]:
+        ev2.load("/root/reference/" + f)
+    for bd in (8, 10, 12):
+        mx = (1 << bd) - 1
+        ct = "uint8_t" if bd == 8 else "uint16_t"
+        P = [ev2.array(arrays["p%d_%d" % (bd, r)].astype(np.int64).ravel(), ct) for r in range(2)]
+        for (w, h, mtype) in ((8, 8, 0), (16, 16, 1), (4, 16, 0), (32, 8, 1)):
+            fxi, fyi = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            pos = [(int(rng.integers(4, S - w - 5)), int(rng.integers(4, ROWS - h - 5))) for _ in range(2)]
+            if k % 2 == 0:
+                pos[0] = (pos[0][0], int(rng.integers(4, 10)))
+            subs = [(int(rng.integers(0, 16)) * int(rng.integers(0, 2)), int(rng.integers(0, 16)) * int(rng.integers(0, 2))) for _ in range(2)]
+            fp = [ev2.call("av1_get_interp_filter_params_with_block_size", fxi, w), ev2.call("av1_get_interp_filter_params_with_block_size", fyi, h)]
+            filt = R.Ptr(fp, 0, ("ptr", ev2.structs["InterpFilterParams"]))
+            bufs = [ev2.array([0] * (w * h), "uint16_t") for _ in range(2)]
+            dst = ev2.array([0] * (w * h), ct)
+            cps = []
+            for r in range(2):
+                cpv = ev2.call("get_conv_params_no_round", 0, 0, bufs[r], w, 1, bd)
+                cp = R.Ptr([cpv], 0, cpv.st)
+                cps.append(cp)
+                args = [P[r].add(pos[r][1] * S + pos[r][0]), S, dst, w, w, h, filt, subs[r][0], 16, subs[r][1], 16, 0, cp]
+                if bd > 8:
+                    args.append(bd)
+                ev2.call("av1_convolve_2d_facade" if bd == 8 else "av1_highbd_convolve_2d_facade", *args)
+            M = ev2.array([0] * (w * h), "uint8_t")
+            ev2.call("av1_build_compound_diffwtd_mask_d16_c", M, mtype, bufs[0], w, bufs[1], w, h, w, cps[0], bd)
+            args = [dst, w, bufs[0], w, bufs[1], w, M, w, w, h, 0, 0, cps[0]]
+            if bd > 8:
+                args.append(bd)
+            ev2.call("aom_lowbd_blend_a64_d16_mask_c" if bd == 8 else "aom_highbd_blend_a64_d16_mask_c", *args)
+            arrays["d%d" % k], arrays["m%d" % k] = np.asarray(dst.buf, np.uint16), np.asarray(M.buf, np.uint8).reshape(h, w)
+            cases.append({"k": k, "bd": bd, "w": w, "h": h, "subw": 0, "subh": 0, "pos": pos, "subs": subs, "fx": fxi, "fy": fyi, "mask_stride": w,
+                          "diffwtd": mtype + 1})
+            k += 1
     save("ref_eval_convolve_masked.npz", arrays, cases)
 
 if __name__ == "__main__":

@@ -529,6 +529,7 @@ def test_masked_compound_matches_reference_evaluation(oracle):
     f = oracle.lib.orc_convolve_compound_mask
     f.restype = None
     subs = set()
+    n_diff = 0
     for c in cases:
         bd, w, h = c["bd"], c["w"], c["h"]
         e16 = int(bd > 8)
@@ -539,8 +540,17 @@ def test_masked_compound_matches_reference_evaluation(oracle):
         (sx0, sy0), (sx1, sy1) = c["subs"]
         mask = np.ascontiguousarray(z["m%d" % c["k"]])
         dst = np.zeros((h, w), dt)
-        f(C.c_void_p(p0.ctypes.data + (y0 * S + x0) * p0.itemsize), S, sx0, sy0, C.c_void_p(p1.ctypes.data + (y1 * S + x1) * p1.itemsize), S, sx1, sy1,
-          C.c_void_p(dst.ctypes.data), w, w, h, c["fx"], c["fy"], 0, 0, e16, bd, C.c_void_p(mask.ctypes.data), c["mask_stride"], c["subw"], c["subh"])
+        A0, A1 = C.c_void_p(p0.ctypes.data + (y0 * S + x0) * p0.itemsize), C.c_void_p(p1.ctypes.data + (y1 * S + x1) * p1.itemsize)
+        if c.get("diffwtd"):     # the mask is an OUTPUT here: av1_build_compound_diffwtd_mask_d16_c (reconinter.c:296-328)
+            g = oracle.lib.orc_convolve_compound_diffwtd
+            g.restype = None
+            mout = np.zeros((h, w), np.uint8)
+            g(A0, S, sx0, sy0, A1, S, sx1, sy1, C.c_void_p(dst.ctypes.data), w, w, h, c["fx"], c["fy"], e16, bd, c["diffwtd"] - 1, C.c_void_p(mout.ctypes.data))
+            assert np.array_equal(mout, mask), c
+            n_diff += 1
+        else:
+            f(A0, S, sx0, sy0, A1, S, sx1, sy1, C.c_void_p(dst.ctypes.data), w, w, h, c["fx"], c["fy"], 0, 0, e16, bd, C.c_void_p(mask.ctypes.data),
+              c["mask_stride"], c["subw"], c["subh"])
         assert np.array_equal(dst.ravel(), z["d%d" % c["k"]]), c
         subs.add((c["subw"], c["subh"]))
-    assert len(subs) == 4
+    assert len(subs) == 4 and n_diff >= 12

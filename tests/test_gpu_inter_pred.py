@@ -226,6 +226,7 @@ def test_masked_compound_pred_goldens(hip, ctx):
         r0, r1, pp = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
         ctx.planes_upload(r0, 0, p0); ctx.planes_upload(r1, 0, p1)
         planes[bd] = (r0, r1, pp)
+    n_diffwtd = 0
     for c in cases:
         r0, r1, pp = planes[c["bd"]]
         w, h = c["w"], c["h"]
@@ -238,16 +239,74 @@ def test_masked_compound_pred_goldens(hip, ctx):
         pad = np.zeros(7, np.uint8)
         mask = np.concatenate([pad, np.ascontiguousarray(z["m%d" % c["k"]]).ravel()])          # the block's mask at a byte offset
         d_b, d_0, d_1, d_m, d_o = ctx.to_device(blk), ctx.to_device(mv0), ctx.to_device(mv1), ctx.to_device(mask), ctx.to_device(np.array([7], np.uint32))
-        ctx.build_masked_compound_pred_batch(r0, 0, r1, 0, pp, 0, w, h, d_b, d_0, d_1, 1, c["fx"], c["fy"], d_m, d_o, c["mask_stride"], c["subw"],
-                                             c["subh"], 1, 1)
+        if c.get("diffwtd"):
+            # the luma form takes MVs in 1/8 pel; the fixture's phases are sixteenths, so only even-phase cases replay exactly
+            if any(v % 2 for pair in c["subs"] for v in pair):
+                for d in (d_b, d_0, d_1, d_m, d_o):
+                    ctx.free(d)
+                continue
+            mv0l = np.array([[sy0 // 2, sx0 // 2]], np.int16)
+            mv1l = np.array([[(y1 - y0) * 8 + sy1 // 2, (x1 - x0) * 8 + sx1 // 2]], np.int16)
+            d_0l, d_1l, d_mo = ctx.to_device(mv0l), ctx.to_device(mv1l), ctx.malloc(w * h + 16)
+            ctx.build_diffwtd_compound_pred_batch(r0, 0, r1, 0, pp, 0, w, h, d_b, d_0l, d_1l, 1, c["fx"], c["fy"], c["diffwtd"] - 1, d_mo)
+            assert np.array_equal(ctx.from_device(d_mo, (h, w), np.uint8), z["m%d" % c["k"]]), c
+            n_diffwtd += 1
+            for d in (d_0l, d_1l, d_mo):
+                ctx.free(d)
+        else:
+            ctx.build_masked_compound_pred_batch(r0, 0, r1, 0, pp, 0, w, h, d_b, d_0, d_1, 1, c["fx"], c["fy"], d_m, d_o, c["mask_stride"], c["subw"],
+                                                 c["subh"], 1, 1)
         got = ctx.planes_download(pp, 0)[border + y0:border + y0 + h, border + x0:border + x0 + w]
         assert np.array_equal(got.ravel().astype(np.uint16), z["d%d" % c["k"]]), c
         for d in (d_b, d_0, d_1, d_m, d_o):
             ctx.free(d)
-    assert len(cases) >= 20
+    assert len(cases) >= 30 and n_diffwtd >= 2
     for t in planes.values():
         for p in t:
             ctx.planes_free(p)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_diffwtd_compound_pred_vs_oracle(hip, oracle, ctx, bd):
+    import ctypes as C
+    rng = np.random.default_rng(95 + bd)
+    W, H, border = 192, 128, 48
+    ref0 = hip.synth.lcg_frame(W, H, 12, 0, bd)
+    ref1 = np.clip(ref0.astype(np.int64) + rng.integers(-(40 << (bd - 8)), (40 << (bd - 8)) + 1, (H, W)), 0, (1 << bd) - 1).astype(ref0.dtype)
+    ref1[:, 96:] = hip.synth.lcg_frame(W, H, 13, 1, bd)[:, 96:]          # half the frame: unrelated content -> the mask saturates at 64
+    r0, r1, pp = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(r0, 0, ref0); ctx.planes_upload(r1, 0, ref1)
+    b0, b1 = oracle.extend_plane(ref0, border, r0.stride), oracle.extend_plane(ref1, border, r1.stride)
+    g = oracle.lib.orc_convolve_compound_diffwtd
+    g.restype = None
+    for (bw, bh), mtype in (((8, 8), 0), ((16, 16), 1), ((32, 16), 0), ((8, 32), 1), ((64, 64), 0)):
+        xs, ys = np.meshgrid(np.arange(0, W - bw + 1, bw), np.arange(0, H - bh + 1, bh))
+        n = xs.size
+        blocks = np.zeros(n, hip.capi.search_block_dtype)
+        blocks["bx"], blocks["by"] = xs.ravel(), ys.ravel()
+        mv0, mv1 = rng.integers(-64, 65, (n, 2)).astype(np.int16), rng.integers(-64, 65, (n, 2)).astype(np.int16)
+        d_b, d_0, d_1, d_mo = ctx.to_device(blocks), ctx.to_device(mv0), ctx.to_device(mv1), ctx.malloc(n * bw * bh)
+        fx, fy = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        ctx.build_diffwtd_compound_pred_batch(r0, 0, r1, 0, pp, 0, bw, bh, d_b, d_0, d_1, n, fx, fy, mtype, d_mo)
+        got = ctx.planes_download(pp, 0)[border:border + H, border:border + W]
+        gmask = ctx.from_device(d_mo, (n, bh, bw), np.uint8)
+        want, wm = np.zeros((H, W), ref0.dtype), np.zeros((bh, bw), np.uint8)
+        for i in range(n):
+            x, y = int(blocks["bx"][i]), int(blocks["by"][i])
+            p = []
+            for ref, mv in ((b0, mv0[i]), (b1, mv1[i])):
+                px, py = (x << 4) + int(mv[1]) * 2, (y << 4) + int(mv[0]) * 2
+                p.append((C.c_void_p(oracle._addr(ref, border + (py >> 4), border + (px >> 4))), ref.shape[1], px & 15, py & 15))
+            g(p[0][0], p[0][1], p[0][2], p[0][3], p[1][0], p[1][1], p[1][2], p[1][3], C.c_void_p(oracle._addr(want, y, x)), W, bw, bh, fx, fy, int(bd > 8), bd,
+              mtype, C.c_void_p(wm.ctypes.data))
+            assert np.array_equal(gmask[i], wm), (bw, bh, bd, i)
+        hh, ww = (H // bh) * bh, (W // bw) * bw
+        assert np.array_equal(got[:hh, :ww], want[:hh, :ww]), (bw, bh, bd)
+        assert gmask.min() >= (0 if mtype else 38) and gmask.max() <= (26 if mtype else 64)
+        for d in (d_b, d_0, d_1, d_mo):
+            ctx.free(d)
+    for p in (r0, r1, pp):
+        ctx.planes_free(p)
 
 
 @pytest.mark.parametrize("bd,subw,subh", [(8, 0, 0), (10, 0, 0), (10, 1, 1), (8, 1, 0), (12, 0, 1)])
