@@ -80,6 +80,7 @@ search_block_dtype = np.dtype([(n, "<i2") for n in ("bx", "by", "start_row", "st
                                                     "row_max", "col_min", "col_max")])
 MV_COST_L1_LOWRES, MV_COST_L1_MIDRES, MV_COST_L1_HDRES, MV_COST_NONE = 1, 2, 3, 4
 COMP_AVG, COMP_DIST_WTD, COMP_MASK, COMP_OBMC = 0, 1, 2, 3
+blend_item_dtype = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("mask_offset", "<u2"), ("vertical", "u1"), ("reserved", "u1")])
 rect_dtype = np.dtype([("h_start", "<i4"), ("h_end", "<i4"), ("v_start", "<i4"), ("v_end", "<i4")])
 
 
@@ -171,6 +172,7 @@ _protos = {
     "aomhip_highbd_sad_x4d": (None, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i]),
     "aomhip_build_masked_compound_pred_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i]),
     "aomhip_build_diffwtd_compound_pred_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "aomhip_blend_a64_1d_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _i, _vp]),
     "aomhip_build_pred_fullpel": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i]),
     "aomhip_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
     "aomhip_sad_skip": (C.c_uint, [_vp, _i, _vp, _i, _i, _i]),
@@ -434,6 +436,10 @@ class Context:
         check(lib.aomhip_build_diffwtd_compound_pred_batch(self.h, C.byref(ref0), f0, C.byref(ref1), f1, C.byref(pred), pred_frame, bw, bh, d_blocks,
                                                            d_mv0, d_mv1, n, filter_x, filter_y, mask_type, d_mask_out),
               "aomhip_build_diffwtd_compound_pred_batch")
+
+    def blend_a64_1d_batch(self, pred, pred_frame, adjacent, adjacent_frame, d_items, n, d_masks):
+        check(lib.aomhip_blend_a64_1d_batch(self.h, C.byref(pred), pred_frame, C.byref(adjacent), adjacent_frame, d_items, n, d_masks),
+              "aomhip_blend_a64_1d_batch")
 
     def build_pred_fullpel(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n):
         check(lib.aomhip_build_pred_fullpel(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks,

@@ -227,6 +227,26 @@ __global__ __launch_bounds__(256) void compound_pred_kernel(PlaneView<T> ref0, i
   }
 }
 
+// aom_[highbd_]blend_a64_vmask / _hmask in place (aom_dsp/blend_a64_vmask.c, blend_a64_hmask.c): the OBMC blends of
+// build_obmc_inter_pred_above / _left (av1/common/reconinter.c:844-920).  One wavefront per rectangle.
+template <typename T>
+__global__ __launch_bounds__(256) void blend_1d_kernel(T *dst, int dst_stride, const T *__restrict__ src1, int src1_stride,
+                                                       const aomhip_blend_item *__restrict__ items, int n, const uint8_t *__restrict__ masks) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ii = blockIdx.x * 4 + wave;
+  if (ii >= n) return;
+  const aomhip_blend_item it = items[ii];
+  const uint8_t *mask = masks + it.mask_offset;
+  T *d = dst + (int64_t)it.y * dst_stride + it.x;
+  const T *s = src1 + (int64_t)it.y * src1_stride + it.x;
+  for (int i = lane; i < it.w * it.h; i += 64) {
+    const int r = i / it.w, c = i - r * it.w;
+    const int m = mask[it.vertical ? r : c];
+    const int a = d[(int64_t)r * dst_stride + c], b = s[(int64_t)r * src1_stride + c];
+    d[(int64_t)r * dst_stride + c] = (T)((m * a + (64 - m) * b + 32) >> 6);   // AOM_BLEND_A64 (aom_dsp/blend.h:24-28)
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pred_copy_kernel(PlaneView<T> ref, int ref_frame, T *dst_origin, int dst_stride,
                                                         const aomhip_search_block *__restrict__ blocks,
@@ -402,6 +422,30 @@ extern "C" int aomhip_build_diffwtd_compound_pred_batch(aomhip_ctx *ctx, const a
                                          interp_filter_x, interp_filter_y, 0, 0, 0, 0, nullptr, nullptr, 0, 0, 0, mask_type + 1, d_mask_out);
   return launch_compound_pred<uint16_t>(ctx, ref0, ref0_frame, ref1, ref1_frame, pred, pred_frame, bw, bh, d_blocks, d_mv0, d_mv1, n_blocks,
                                         interp_filter_x, interp_filter_y, 0, 0, 0, 0, nullptr, nullptr, 0, 0, 0, mask_type + 1, d_mask_out);
+}
+
+extern "C" int aomhip_blend_a64_1d_batch(aomhip_ctx *ctx, const aomhip_planes *pred, int pred_frame, const aomhip_planes *adjacent,
+                                         int adjacent_frame, const aomhip_blend_item *d_items, int n_items, const uint8_t *d_masks) {
+  if (!ctx || !pred || !adjacent || !pred->base || !adjacent->base || (n_items > 0 && (!d_items || !d_masks)) || n_items < 0 || pred_frame < 0 ||
+      pred_frame >= pred->n_frames || adjacent_frame < 0 || adjacent_frame >= adjacent->n_frames || pred->bit_depth != adjacent->bit_depth ||
+      pred->width != adjacent->width || pred->height != adjacent->height) {
+    set_error("aomhip_blend_a64_1d_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_items == 0) return AOMHIP_OK;
+  const size_t esz = pred->bit_depth == 8 ? 1 : 2;
+  char *d = static_cast<char *>(pred->base) + ((size_t)pred_frame * pred->frame_stride + (size_t)pred->border * pred->stride + pred->border) * esz;
+  const char *s = static_cast<const char *>(adjacent->base) +
+                  ((size_t)adjacent_frame * adjacent->frame_stride + (size_t)adjacent->border * adjacent->stride + adjacent->border) * esz;
+  const dim3 grid((n_items + 3) / 4), block(256);
+  if (esz == 1)
+    hipLaunchKernelGGL(blend_1d_kernel<uint8_t>, grid, block, 0, ctx->stream, reinterpret_cast<uint8_t *>(d), pred->stride,
+                       reinterpret_cast<const uint8_t *>(s), adjacent->stride, d_items, n_items, d_masks);
+  else
+    hipLaunchKernelGGL(blend_1d_kernel<uint16_t>, grid, block, 0, ctx->stream, reinterpret_cast<uint16_t *>(d), pred->stride,
+                       reinterpret_cast<const uint16_t *>(s), adjacent->stride, d_items, n_items, d_masks);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
 }
 
 extern "C" int aomhip_build_pred_fullpel(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame,

@@ -658,6 +658,21 @@ int aomhip_build_diffwtd_compound_pred_batch(aomhip_ctx *ctx, const aomhip_plane
                                              int ref1_frame, const aomhip_planes *pred, int pred_frame, int bw, int bh,
                                              const aomhip_search_block *d_blocks, const int16_t *d_mv0, const int16_t *d_mv1, int n_blocks,
                                              int interp_filter_x, int interp_filter_y, int mask_type, uint8_t *d_mask_out);
+/* The OBMC blends: aom_[highbd_]blend_a64_vmask / _hmask applied in place to the prediction (aom_dsp/blend_a64_vmask.c,
+ * blend_a64_hmask.c), as build_obmc_inter_pred_above / _left do (av1/common/reconinter.c:844-920) with the neighbours'
+ * predictions in `adjacent` (same coordinates; built with aomhip_build_inter_pred_batch from the neighbours' MVs).
+ * Each item is one overlap rectangle: pred = AOM_BLEND_A64(m, pred, adjacent) with m = d_masks[mask_offset + row]
+ * (vertical = 1: the "above" blend) or d_masks[mask_offset + column] (0: "left"); d_masks holds the caller's
+ * av1_get_obmc_mask tables (reconinter.c:744-777).  Items must not overlap each other within one call (the reference
+ * runs all "above" blends, then all "left" ones: two calls). */
+typedef struct {
+  int16_t x, y, w, h;     /* rectangle in plane pixels */
+  uint16_t mask_offset;   /* first mask entry in d_masks */
+  uint8_t vertical;       /* 1: mask per row (vmask), 0: mask per column (hmask) */
+  uint8_t reserved;
+} aomhip_blend_item;
+int aomhip_blend_a64_1d_batch(aomhip_ctx *ctx, const aomhip_planes *pred, int pred_frame, const aomhip_planes *adjacent, int adjacent_frame,
+                              const aomhip_blend_item *d_items, int n_items, const uint8_t *d_masks);
 
 /* ------------------------------------------------------------------ RD helpers, batched */
 

@@ -214,3 +214,15 @@ void orc_convolve_compound_diffwtd(const void *src0, int stride0, int sx0, int s
   orc_convolve_compound_mask(src0, stride0, sx0, sy0, src1, stride1, sx1, sy1, dst, dst_stride, w, h, filter_x, filter_y, 0, 0, elem16, bd,
                              mask_out, w, 0, 0);
 }
+
+/* aom_[highbd_]blend_a64_vmask_c / _hmask_c (aom_dsp/blend_a64_vmask.c, blend_a64_hmask.c) in place: dst = AOM_BLEND_A64(m, dst,
+ * src1) with m = mask[row] (vertical) or mask[column] -- the OBMC blends of build_obmc_inter_pred_above / _left
+ * (av1/common/reconinter.c:844-920).  Pinned by tests/golden/ref_eval_obmc_blend.npz. */
+void orc_blend_a64_1d(void *dst, int dst_stride, const void *src1, int src1_stride, const uint8_t *mask, int w, int h, int vertical, int elem16) {
+  for (int i = 0; i < h; ++i)
+    for (int j = 0; j < w; ++j) {
+      const int m = mask[vertical ? i : j];
+      const int v = RPOT(m * px(dst, elem16, (ptrdiff_t)i * dst_stride + j) + (64 - m) * px(src1, elem16, (ptrdiff_t)i * src1_stride + j), 6);
+      if (elem16) ((uint16_t *)dst)[(ptrdiff_t)i * dst_stride + j] = (uint16_t)v; else ((uint8_t *)dst)[(ptrdiff_t)i * dst_stride + j] = (uint8_t)v;
+    }
+}

@@ -648,8 +648,44 @@ def gen_convolve_masked():
             k += 1
     save("ref_eval_convolve_masked.npz", arrays, cases)
 
+
+def gen_obmc_blend():
+    """The OBMC blends: aom_[highbd_]blend_a64_vmask_c / _hmask_c (aom_dsp/blend_a64_vmask.c, blend_a64_hmask.c) in place on the
+    prediction, with av1_get_obmc_mask's tables (av1/common/reconinter.c:744-777) -- build_obmc_inter_pred_above / _left (:844-920)."""
+    ev = evaluator([])
+    for f in ["aom_dsp/blend.h", "aom_dsp/blend_a64_vmask.c", "aom_dsp/blend_a64_hmask.c", "av1/common/mv.h", "aom_scale/yv12config.h",
+              "av1/common/blockd.h", "av1/common/reconinter.h", "av1/common/reconinter.c"]:
+        ev.load("/root/reference/" + f)
+    rng = np.random.default_rng(20261027)
+    arrays, cases = {}, []
+    for n in (1, 2, 4, 8, 16, 32, 64):
+        m = ev.call("av1_get_obmc_mask", n)
+        arrays["obmc_mask_%d" % n] = np.asarray([m.buf[m.off + i] for i in range(n)], np.uint8)
+    S, ROWS = 80, 72
+    k = 0
+    for bd in (8, 10, 12):
+        mx = (1 << bd) - 1
+        pred, adj = rng.integers(0, mx + 1, (ROWS, S)), rng.integers(0, mx + 1, (ROWS, S))
+        pred[:8], adj[:8] = mx, 0
+        arrays["pred%d" % bd], arrays["adj%d" % bd] = pred.astype(np.uint16), adj.astype(np.uint16)
+        ct = "uint8_t" if bd == 8 else "uint16_t"
+        for (w, h, vertical) in ((16, 8, 1), (8, 4, 1), (32, 32, 1), (4, 2, 1), (8, 16, 0), (4, 8, 0), (32, 64, 0), (2, 4, 0), (64, 1, 1), (16, 16, 0)):
+            x, y = int(rng.integers(0, S - w)), int(rng.integers(0, ROWS - h))
+            D = ev.array(pred.ravel(), ct)
+            A = ev.array(adj.ravel(), ct)
+            mask = ev.call("av1_get_obmc_mask", h if vertical else w)
+            fn = "aom_%sblend_a64_%smask_c" % ("highbd_" if bd > 8 else "", "v" if vertical else "h")
+            args = [D.add(y * S + x), S, D.add(y * S + x), S, A.add(y * S + x), S, mask, w, h]
+            if bd > 8:
+                args.append(bd)
+            ev.call(fn, *args)
+            arrays["o%d" % k] = np.asarray(D.buf, np.uint16).reshape(ROWS, S)[y:y + h, x:x + w].copy()
+            cases.append({"k": k, "bd": bd, "x": x, "y": y, "w": w, "h": h, "vertical": vertical})
+            k += 1
+    save("ref_eval_obmc_blend.npz", arrays, cases)
+
 if __name__ == "__main__":
-    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound", "convolve", "rdhelp", "cdef_search", "lrstats", "convolve_compound", "convolve_masked"]:
+    for w in sys.argv[1:] or ["txfm2d", "tables", "cdef_fb", "compound", "convolve", "rdhelp", "cdef_search", "lrstats", "convolve_compound", "convolve_masked", "obmc_blend"]:
         t = time.time()
         globals()["gen_" + w]()
         print("  (%s: %.1f s)" % (w, time.time() - t))

@@ -554,3 +554,21 @@ def test_masked_compound_matches_reference_evaluation(oracle):
         assert np.array_equal(dst.ravel(), z["d%d" % c["k"]]), c
         subs.add((c["subw"], c["subh"]))
     assert len(subs) == 4 and n_diff >= 12
+
+
+def test_obmc_blend_matches_reference_evaluation(oracle):
+    """orc_blend_a64_1d against the interpreted aom_[highbd_]blend_a64_vmask_c / _hmask_c with av1_get_obmc_mask's tables."""
+    z, cases = load("ref_eval_obmc_blend.npz")
+    assert len(cases) == 30
+    f = oracle.lib.orc_blend_a64_1d
+    f.restype = None
+    assert z["obmc_mask_64"][0] == 33 and z["obmc_mask_2"].tolist() == [45, 64]
+    for c in cases:
+        bd = c["bd"]
+        dt = np.uint8 if bd == 8 else np.uint16
+        pred, adj = np.ascontiguousarray(z["pred%d" % bd], dt).copy(), np.ascontiguousarray(z["adj%d" % bd], dt)
+        S = pred.shape[1]
+        mask = np.ascontiguousarray(z["obmc_mask_%d" % (c["h"] if c["vertical"] else c["w"])])
+        off = (c["y"] * S + c["x"]) * pred.itemsize
+        f(C.c_void_p(pred.ctypes.data + off), S, C.c_void_p(adj.ctypes.data + off), S, C.c_void_p(mask.ctypes.data), c["w"], c["h"], c["vertical"], int(bd > 8))
+        assert np.array_equal(pred[c["y"]:c["y"] + c["h"], c["x"]:c["x"] + c["w"]], z["o%d" % c["k"]]), c

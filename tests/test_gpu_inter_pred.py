@@ -353,3 +353,38 @@ def test_masked_compound_pred_vs_oracle(hip, oracle, ctx, bd, subw, subh):
             ctx.free(d)
     for p in (r0, r1, pp):
         ctx.planes_free(p)
+
+
+def test_obmc_blend_goldens_and_batch(hip, ctx):
+    """aomhip_blend_a64_1d_batch: every interpreted-reference case (one item per call, then all non-overlapping ones of a
+    bit depth together), masks = av1_get_obmc_mask's tables from the fixture."""
+    z = np.load(os.path.join(GOLD, "ref_eval_obmc_blend.npz"))
+    cases = json.loads(bytes(z["cases"]).decode())
+    K = hip.capi
+    sizes = (1, 2, 4, 8, 16, 32, 64)
+    table = np.concatenate([z["obmc_mask_%d" % n] for n in sizes])
+    offs = {n: int(sum(s for s in sizes if s < n)) for n in sizes}
+    d_masks = ctx.to_device(table)
+    border = 8
+    for bd in (8, 10, 12):
+        dt = np.uint8 if bd == 8 else np.uint16
+        pred, adj = np.ascontiguousarray(z["pred%d" % bd], dt), np.ascontiguousarray(z["adj%d" % bd], dt)
+        H, W = pred.shape
+        pp, pa = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+        ctx.planes_upload(pa, 0, adj)
+        mine = [c for c in cases if c["bd"] == bd]
+        for c in mine:
+            ctx.planes_upload(pp, 0, pred)
+            it = np.zeros(1, K.blend_item_dtype)
+            it[0] = (c["x"], c["y"], c["w"], c["h"], offs[c["h"] if c["vertical"] else c["w"]], c["vertical"], 0)
+            d_it = ctx.to_device(it)
+            ctx.blend_a64_1d_batch(pp, 0, pa, 0, d_it, 1, d_masks)
+            got = ctx.planes_download(pp, 0)[border:border + H, border:border + W]
+            assert np.array_equal(got[c["y"]:c["y"] + c["h"], c["x"]:c["x"] + c["w"]].astype(np.uint16), z["o%d" % c["k"]]), c
+            keep = got.copy(); keep[c["y"]:c["y"] + c["h"], c["x"]:c["x"] + c["w"]] = pred[c["y"]:c["y"] + c["h"], c["x"]:c["x"] + c["w"]]
+            assert np.array_equal(keep, pred)          # nothing outside the rectangle moved
+            ctx.free(d_it)
+        ctx.planes_free(pp); ctx.planes_free(pa)
+    with pytest.raises(K.AomHipError):
+        ctx.blend_a64_1d_batch(pp, 0, pa, 0, None, 1, d_masks)
+    ctx.free(d_masks)
