@@ -22,7 +22,9 @@
  * initialisers parsed out of the reference sources, and (e) for EVERY family --
  * SAD, variance, subtract, the 2-D transforms, the quantisers and their tables,
  * the loop filters and their thresholds, CDEF (block and filter-block level) and
- * the whole of the motion search -- golden vectors obtained by interpreting the
+ * the whole of the motion search, the compound / masked / OBMC table members, the
+ * sub-pel / compound / masked / OBMC prediction, the RD helpers, the CDEF and loop-
+ * restoration search statistics -- golden vectors obtained by interpreting the
  * reference's own C functions where they lie (tests/golden/ref_c_eval.py, a
  * C-subset interpreter; fixtures tests/golden/ref_eval_*.npz, checked by
  * tests/test_golden_ref_eval.py).  No family is left "parity unpinned".
@@ -171,6 +173,36 @@ void orc_cdef_plane_luma(const void *src, void *dst, int stride, int width, int 
 void orc_cdef_plane_chroma(const void *src, void *dst, int stride, int width, int height, int elem16, int bd, int xdec,
                            int ydec, const uint8_t *dir, const uint8_t *fb_pri, const uint8_t *fb_sec, int fb_stride,
                            const uint8_t *skip, int damping);
+
+/* ---- compound / masked / OBMC table members (aomref_compound.c) ----------- */
+uint32_t orc_compound_sub_pixel_variance(const void *a, int a_stride, int xoff, int yoff, const void *b, int b_stride, int w, int h,
+                                         int elem16, int bd, int kind, const void *second_pred, int fwd_offset, int bck_offset,
+                                         const uint8_t *mask, int mask_stride, int invert_mask, uint32_t *sse);
+unsigned orc_masked_sad(const void *src, int src_stride, const void *ref, int ref_stride, const void *second_pred, const uint8_t *mask,
+                        int mask_stride, int invert_mask, int w, int h, int elem16, int bd);
+unsigned orc_obmc_sad(const void *pre, int pre_stride, const int32_t *wsrc, const int32_t *mask, int w, int h, int elem16, int bd);
+uint32_t orc_obmc_variance(const void *pre, int pre_stride, int subpel, int xoff, int yoff, const int32_t *wsrc, const int32_t *mask, int w,
+                           int h, int elem16, int bd, uint32_t *sse);
+
+/* ---- inter prediction (aomref_convolve.c) --------------------------------- */
+void orc_convolve_sr(const void *src, int src_stride, void *dst, int dst_stride, int w, int h, int filter_x, int filter_y,
+                     int subpel_x_qn, int subpel_y_qn, int elem16, int bd);
+void orc_build_inter_pred_block_ss(const void *ref_origin, int ref_stride, void *dst, int dst_stride, int bx, int by, int bw, int bh,
+                                   int mv_row, int mv_col, int filter_x, int filter_y, int elem16, int bd, int ss_x, int ss_y);
+void orc_convolve_compound_mask(const void *src0, int stride0, int sx0, int sy0, const void *src1, int stride1, int sx1, int sy1, void *dst,
+                                int dst_stride, int w, int h, int filter_x, int filter_y, int fwd_offset, int bck_offset, int elem16, int bd,
+                                const uint8_t *mask, int mask_stride, int subw, int subh);
+void orc_convolve_compound_diffwtd(const void *src0, int stride0, int sx0, int sy0, const void *src1, int stride1, int sx1, int sy1, void *dst,
+                                   int dst_stride, int w, int h, int filter_x, int filter_y, int elem16, int bd, int mask_type,
+                                   uint8_t *mask_out);
+void orc_blend_a64_1d(void *dst, int dst_stride, const void *src1, int src1_stride, const uint8_t *mask, int w, int h, int vertical, int elem16);
+
+/* ---- RD helpers (aomref_rdhelp.c) and restoration statistics (aomref_lrstats.c) */
+int64_t orc_sse(const void *a, int a_stride, const void *b, int b_stride, int w, int h, int elem16);
+int orc_hadamard(const int16_t *src, ptrdiff_t stride, int n, int flavour, int32_t *coeff);
+void orc_txb_init_levels(const int32_t *coeff, int width, int height, uint8_t *levels);
+void orc_compute_stats(int wiener_win, const void *dgd, const void *src, int h_start, int h_end, int v_start, int v_end, int dgd_stride,
+                       int src_stride, int elem16, int bit_depth, int use_downsampled_wiener_stats, int64_t *M, int64_t *H);
 
 #ifdef __cplusplus
 }
