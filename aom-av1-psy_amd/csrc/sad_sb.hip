@@ -3,16 +3,26 @@
 // it -- superblock by superblock with every motion vector inside the superblock's search range
 // (av1/encoder/encodeframe.c:1069 encode_sb_row; mv limits av1/encoder/mcomp.c:101 av1_set_mv_search_range).
 //
-// Why a second kernel.  In the direct kernels (sad.hip) every lane pulls its own 16-byte row out of a
-// different 128-byte cache line, so a 16x16 candidate costs 16 full-line L2->L1 fills for 256 useful bytes;
-// the measured bound is that fill path, not HBM (profiles/r01_sad_variants.md).  Here a workgroup takes one
-// bucket (an sb_w x sb_h cell of source blocks) at a time, pulls the (sb_w + 2*range) x (sb_h + 2*range) reference
-// window into LDS once with full-line coalesced loads (each byte crosses L2->L1 once per bucket), and evaluates
-// every candidate of the bucket from LDS: aligned dword reads + v_alignbyte per 16 reference bytes, v_sad_u8 / v_sad_u16,
-// DPP group reduction.  A candidate whose reference block is not wholly inside the window (the caller exceeded
-// `range`) is still evaluated, straight from global memory -- slower, never wrong.
-// Measured on one MI355X, Mode A 16x16, ring of 64 4K frame pairs (profiles/r01_sad_sb.md): 2.29e10 candidates/s
-// for 8-bit (direct kernels 1.10e10), 1.14e10 for 10-bit (7.2e9).
+// Structure (round 2; the round-1 form staged one (sb_w + 2 range) x (sb_h + 2 range) window per cell and so
+// pulled every reference byte through L2 -> LDS 2.7 times and through the fabric 1.4-1.9 times):
+//   * A persistent workgroup owns one STRIP -- a column of cells of one frame -- and walks it top to bottom.
+//     The reference window lives in an LDS ring of R = 2 sb_h + 2 range rows indexed by (y - ymin) mod R, so
+//     going from one cell to the next brings in only the sb_h NEW rows: every reference byte of the strip
+//     crosses L2 -> LDS once; what is left of the halo is the 2 range columns shared with the neighbour strips.
+//   * Wave specialisation: 8 EVALUATING wavefronts + 8 LOADER wavefronts per workgroup.  The loaders bring in
+//     everything a step needs -- the new ring rows, the step's SOURCE cell (double buffered) and its slice of the
+//     two work lists -- through registers: the loads for step cy + 2 are in flight (in the loaders' VGPRs, so
+//     they need no LDS space yet) while step cy is evaluated and step cy + 1's data is written to LDS.  The
+//     evaluating wavefronts never issue a vector-memory load -- gfx9 returns those in order (one vmcnt), a
+//     single demand load would wait for everything older -- only ds_read, VALU and the result stores; one
+//     workgroup barrier per step.  (LDS-DMA was tried first and dropped: a global_load_lds holds its wavefront
+//     in the issue stage ~260 cycles, and data in flight must already own LDS space, which forces the memory
+//     pipeline to drain at every step -- profiles/r02_sad_strip.md.)
+//   * Strips of one frame go to workgroups of one XCD at the same time (workgroup b runs on XCD b % 8; speed
+//     only), so the halo columns two neighbour strips both read are served by that XCD's L2.
+//   * Any entry whose blocks are not inside the staged source cell / reference window (the caller exceeded
+//     `range`, or put an entry in the wrong bucket) is still evaluated, straight from global memory -- slower,
+//     never wrong.  Lists of any shape go through the same rounds (no "first round only" fast path).
 #include <type_traits>
 
 #include "common.h"
@@ -24,9 +34,9 @@ struct __attribute__((packed, aligned(1))) U128 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(1))) U64 { uint32_t v[2]; };
 struct __attribute__((packed, aligned(1))) U32 { uint32_t v[1]; };
 template <int BYTES> struct UnitLoad;
-template <> struct UnitLoad<16> { using type = U128; };
-template <> struct UnitLoad<8> { using type = U64; };
-template <> struct UnitLoad<4> { using type = U32; };
+template <> struct UnitLoad<16> { using type = U128; using aligned_type = uint4; };
+template <> struct UnitLoad<8> { using type = U64; using aligned_type = uint2; };
+template <> struct UnitLoad<4> { using type = U32; using aligned_type = uint32_t; };
 
 template <typename T> __device__ __forceinline__ uint32_t sad_dword(uint32_t a, uint32_t b, uint32_t acc);
 template <> __device__ __forceinline__ uint32_t sad_dword<uint8_t>(uint32_t a, uint32_t b, uint32_t acc) {
@@ -46,27 +56,27 @@ template <int TPC> __device__ __forceinline__ uint32_t group_sum(uint32_t v) {
   return v;
 }
 
-template <typename T, int W, int H, bool SKIP> struct Geom {
+// UPL = target number of 16-byte row units a lane owns (2: 8 lanes per 16x16 8-bit block; 1: 16 lanes); 0: 16 lanes per
+// block whatever its size (fewer for blocks of fewer than 16 units).
+template <typename T, int W, int H, bool SKIP, int UPL> struct Geom {
   static constexpr int kRowBytes = W * (int)sizeof(T);
   static constexpr int kUnitBytes = kRowBytes < 16 ? kRowBytes : 16;
   static constexpr int kUnitElems = kUnitBytes / (int)sizeof(T);
   static constexpr int kUnitsPerRow = kRowBytes / kUnitBytes;
   static constexpr int kRows = SKIP ? H / 2 : H;
   static constexpr int kUnits = kUnitsPerRow * kRows;
-  static constexpr int kTpcRaw = kUnits >= 2 ? kUnits / 2 : 1;
+  static constexpr int kTpcRaw = UPL > 0 ? (kUnits >= UPL ? kUnits / UPL : 1) : (kUnits < 16 ? kUnits : 16);
   static constexpr int kTpc = kTpcRaw > 64 ? 64 : kTpcRaw;
   static constexpr int kUnitsPerLane = kUnits / kTpc;
   static constexpr int kRowStep = SKIP ? 2 : 1;
 };
 
-constexpr int kLdsPadBytes = 16;  // row pitch = window bytes + 16: 16 consecutive rows start in 16 distinct bank quads
-
-// BYTES at an arbitrary byte offset of the LDS window: BYTES/4 + 1 aligned dword reads, realigned in registers with
-// v_alignbyte.  (gfx950 does execute a ds_read_b128 at any byte address, but a misaligned one runs at 1/12 of the
-// aligned rate -- tools/lds_unaligned_probe.hip: 0.61 vs 7.4 T lane-reads/s -- which made the LDS the bottleneck.)
+// BYTES at an arbitrary byte offset of LDS: BYTES/4 + 1 aligned dword reads, realigned in registers with v_alignbyte.
+// (A ds_read_b64 / _b128 off its natural alignment is replayed at 64 cycles per wave-instruction on gfx950 --
+// tools/lds_unaligned_probe.hip: 0.61 vs 7.4 T lane-reads/s -- 32-bit reads are unaffected.)
 template <int BYTES>
-__device__ __forceinline__ typename UnitLoad<BYTES>::type lds_unit(const uint32_t *lds, unsigned byte_off) {
-  const uint32_t *p = lds + (byte_off >> 2);
+__device__ __forceinline__ typename UnitLoad<BYTES>::type lds_unit(const char *lds, unsigned byte_off) {
+  const uint32_t *p = reinterpret_cast<const uint32_t *>(lds) + (byte_off >> 2);
   const unsigned sh = byte_off & 3;
   uint32_t d[BYTES / 4 + 1];
 #pragma unroll
@@ -76,365 +86,676 @@ __device__ __forceinline__ typename UnitLoad<BYTES>::type lds_unit(const uint32_
   for (int i = 0; i < BYTES / 4; ++i) out.v[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
   return out;
 }
+template <int BYTES>
+__device__ __forceinline__ typename UnitLoad<BYTES>::type lds_unit_aligned(const char *lds, unsigned byte_off) {
+  using A = typename UnitLoad<BYTES>::aligned_type;
+  const A t = *reinterpret_cast<const A *>(lds + byte_off);
+  typename UnitLoad<BYTES>::type out;
+  memcpy(&out, &t, BYTES);
+  return out;
+}
 
-struct SbArgs {
-  int first_frame;
-  int sb_w, sb_h, range, cells_per_row;
-  int xmin, xmax, ymin, ymax;  // readable pixel range of a plane, relative to the visible origin
-  int buckets8;                // buckets per frame rounded up to a multiple of 8
-  int n_buckets;
-  int n_items;                 // buckets8 * n_frames
-  int pitch;                   // LDS row pitch in bytes
-  int dummy_off;               // 16 spare bytes behind the window
+struct StripArgs {
+  int first_frame, n_frames;
+  int sb_w, sb_h, range, cells_per_row, cell_rows;
+  // reference plane: readable pixel range relative to the visible origin, allocated row end, border
+  int xmin, xmax, ymin, ymax, row_end, border;
+  // source plane
+  int s_xmax, s_ymax, s_row_end, s_border;
+  int cpr, pitch, R;           // ring: 16-byte chunks per row, row pitch in bytes, rows
+  int scpr, spitch;            // source cell: chunks per row, pitch
+  unsigned magic_cpr, magic_scpr, magic_R;
+  int ring_off, src_off[2], gdesc_off[2], cdesc_off[2], misc_off, seg_off;  // LDS byte offsets
+  int gcap, ccap;              // list entries per descriptor buffer
   int shift;
+  int dbg;  // AOMHIP_SB_DBG (timing ablations only, results invalid): 1 = no evaluation, 2 = no steady-state DMA
 };
 
-// What a workgroup needs to know about one (frame, bucket) work item.
-struct Item {
-  int next;  // item index to continue the walk from
-  int f_rel, g0, g1, c0, c1;
-  int wx0, wx1, wy0, wy1, cpr;  // window in pixels (x1 / y1 exclusive); 16-byte chunks per window row
-  int valid;
-};
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// Persistent workgroups: the launch has as many workgroups as the chip holds at once (two 68 KB windows per CU)
-// and each walks the (frame, bucket) items blockIdx + k * gridDim.  While the candidates of item i are evaluated
-// out of LDS, the window of item i+1 is already in flight into registers (8 x 16 bytes per lane) and so are the
-// descriptors and source rows of its first round of candidates; after a barrier the registers are dropped into
-// LDS.  HBM / L2 latency and workgroup turnover overlap with the SAD arithmetic instead of adding to it
-// (measured: the one-shot form of this kernel spent 0.19 of its 0.45 ms per launch in turnover + source latency).
-//
-// gfx9 returns vector-memory loads in order (one vmcnt counter), so the overlap only exists if the evaluation of
-// item i waits on NO load younger than the prefetch of item i+1.  Hence two evaluation paths, chosen per wavefront:
-//   fast    -- first round, every reference block inside the window, single candidates that re-use the source rows
-//              of their lane's x4d group (Mode-A style lists): LDS reads and ALU only;
-//   generic -- anything else (later rounds of a crowded bucket, blocks outside the window, unrelated single
-//              candidates, large blocks): loads what it needs, waits for it, still exact.
-template <typename T, int W, int H, bool SKIP, int kThreads>
-__global__ __launch_bounds__(kThreads, 4) void sad_sb_kernel(PlaneView<T> src, PlaneView<T> ref, SbArgs a,
-                                                             const aomhip_sad_x4d_cand *__restrict__ groups,
-                                                             const int32_t *__restrict__ group_off, int n_groups,
-                                                             int64_t group_frame_stride, uint32_t *__restrict__ out4,
-                                                             const aomhip_sad_cand *__restrict__ cands,
-                                                             const int32_t *__restrict__ cand_off, int n_cands,
-                                                             int64_t cand_frame_stride, uint32_t *__restrict__ out1) {
-  using G = Geom<T, W, H, SKIP>;
+#ifdef AOMHIP_SB_PROF  // phase timing of wave 0 of every workgroup (tools/gpu_sb_prof.sh builds a library with it)
+__device__ unsigned long long g_sb_prof[8];
+#define SB_T(v) const long long v = (long long)__builtin_readcyclecounter()
+#define SB_ACC(i, t1, t0) prof_acc[i] += (unsigned long long)((t1) - (t0))
+#define SB_DECL unsigned long long prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
+#define SB_FLUSH if (tid == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_sb_prof[i_], prof_acc[i_]); }
+#else
+#define SB_DECL
+#define SB_FLUSH
+#define SB_T(v)
+#define SB_ACC(i, t1, t0)
+#endif
+
+// Ring rows that are stored twice: a block of height <= kMirrorMax + 1 starting in any ring slot then reads consecutive
+// LDS rows (slots R .. R + H - 2 repeat slots 0 .. H - 2), so the evaluation needs no per-row wrap arithmetic.
+constexpr int kMirrorMax = 15;
+__host__ __device__ constexpr int mirror_rows(int h) { return h - 1 <= kMirrorMax ? h - 1 : 0; }
+
+// kThreads evaluating lanes + kLT loader lanes (the last kLoaders wavefronts of the workgroup).
+constexpr int kEvalThreads = 512;
+constexpr int kLoaders = 8;               // loader wavefronts per workgroup, in two groups that take alternate steps
+constexpr int kRingN = 5, kSrcN = 4, kGN = 2, kCN = 1;  // 16-byte chunks / dwords one loader lane has in flight for its step
+constexpr int kLT = 64 * kLoaders / 2;    // loader lanes per group
+template <typename T, int W, int H, bool SKIP, int kThreads, int UPL>
+__global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(PlaneView<T> src, PlaneView<T> ref, StripArgs a,
+                                                                  const aomhip_sad_x4d_cand *__restrict__ groups,
+                                                                  const int32_t *__restrict__ group_off, int n_groups,
+                                                                  int64_t group_frame_stride, uint32_t *__restrict__ out4,
+                                                                  const aomhip_sad_cand *__restrict__ cands,
+                                                                  const int32_t *__restrict__ cand_off, int n_cands,
+                                                                  int64_t cand_frame_stride, uint32_t *__restrict__ out1) {
+  using G = Geom<T, W, H, SKIP, UPL>;
   using L = typename UnitLoad<G::kUnitBytes>::type;
-  extern __shared__ uint32_t lds[];
-  constexpr int kRegChunks = 8;                      // window chunks a lane keeps in flight in registers
-  constexpr int kPerWg = kThreads / G::kTpc;         // candidates (or groups) evaluated side by side
-  constexpr bool kPrefetch = G::kUnitsPerLane <= 4;  // source rows of the first round ride along with the window
+  extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int kES = (int)sizeof(T);
-  const int lane_in_cand = threadIdx.x % G::kTpc;
-  const int slot = (int)threadIdx.x / G::kTpc;
+  constexpr int kEpc = 16 / kES;  // elements per 16-byte chunk
+  constexpr int kPerWg = kThreads / G::kTpc;
+  constexpr int kWaves = kThreads / 64;       // evaluating wavefronts; wavefront kWaves is the loader
+  constexpr int kAll = kThreads + 64 * kLoaders;
+  constexpr int kGenUnroll = G::kUnitsPerLane <= 4 ? G::kUnitsPerLane : 4;
+  constexpr int kMirror = mirror_rows(H);
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const bool is_loader = wave >= kWaves;
+  const int grp = uni((tid - kThreads) / kLT);  // loader group (0 / 1)
+  const int lt = tid - kThreads - grp * kLT;    // lane index inside the group
+  const int lane_in_cand = tid % G::kTpc;
+  const int slot = tid / G::kTpc;
 
-  auto decode = [&](int item) {
-    Item it;
-    it.valid = 0;
-    it.f_rel = it.g0 = it.g1 = it.c0 = it.c1 = it.wx0 = it.wx1 = it.wy0 = it.wy1 = 0;
-    it.cpr = 1;
-    for (; item < a.n_items; item += (int)gridDim.x) {
-      const int bucket = (int)xcd_chunked_index((unsigned)(item % a.buckets8), (unsigned)a.buckets8);
-      if (bucket >= a.n_buckets) continue;
-      it.g0 = groups ? group_off[bucket] : 0;
-      it.g1 = groups ? group_off[bucket + 1] : 0;
-      it.c0 = cands ? cand_off[bucket] : 0;
-      it.c1 = cands ? cand_off[bucket + 1] : 0;
-      if (it.g0 == it.g1 && it.c0 == it.c1) continue;
-      it.f_rel = item / a.buckets8;
-      const int cell_x = bucket % a.cells_per_row, cell_y = bucket / a.cells_per_row;
-      it.wx0 = max(cell_x * a.sb_w - a.range, a.xmin);
-      // whole 16-byte chunks only: a ragged tail (clamped window) is served by the generic path instead
-      it.cpr = ((min(cell_x * a.sb_w + a.sb_w + a.range, a.xmax) - it.wx0) * kES) >> 4;
-      it.wx1 = it.wx0 + it.cpr * (16 / kES);
-      it.wy0 = max(cell_y * a.sb_h - a.range, a.ymin);
-      it.wy1 = min(cell_y * a.sb_h + a.sb_h + a.range, a.ymax);
-      it.valid = 1;
-      break;
-    }
-    it.next = item + (int)gridDim.x;
-    return it;
-  };
-
-  auto unit_pos = [&](int k, int &row, int &col) {
-    const int u = lane_in_cand + k * G::kTpc;
-    row = (u / G::kUnitsPerRow) * G::kRowStep;
-    col = (u % G::kUnitsPerRow) * G::kUnitElems;
-  };
-  auto src_unit = [&](int f_rel, int sx, int sy, int k) {
-    int row, col;
-    unit_pos(k, row, col);
-    return *reinterpret_cast<const L *>(src.origin + (int64_t)(a.first_frame + f_rel) * src.frame_stride +
-                                        (int64_t)(sy + row) * src.stride + sx + col);
-  };
-
-  // Everything of an item that is requested ahead of time.
-  struct Ahead {
-    U128 win[kRegChunks];
-    L gsrc[kPrefetch ? G::kUnitsPerLane : 1];
-  };
-  // First-round descriptors of an item.  They are requested TWO items ahead: the source-row addresses depend on
-  // them, and a dependent load issued after the window loads would have to wait for all of those (in-order vmcnt).
-  // (kept as plain dwords: halfword h of a descriptor is word h / 2, shifted by 16 * (h & 1))
-  struct Desc {
-    uint32_t g[5];  // aomhip_sad_x4d_cand: sx, sy, rx[4], ry[4]
-    uint32_t c[2];  // aomhip_sad_cand: sx, sy, rx, ry
-  };
-  struct __attribute__((packed, aligned(4))) W5 { uint32_t v[5]; };
-  struct __attribute__((packed, aligned(4))) W2 { uint32_t v[2]; };
-  auto load_desc = [&](const Item &it, Desc &d) {
-    // (no data-dependent branch: an index past the bucket is clamped into the list and the entry ignored later)
-    if constexpr (kPrefetch) {
-      if (groups) {
-        const W5 w = *reinterpret_cast<const W5 *>(groups + (int64_t)it.f_rel * group_frame_stride +
-                                                   max(min(it.g0 + slot, n_groups - 1), 0));
-#pragma unroll
-        for (int i = 0; i < 5; ++i) d.g[i] = w.v[i];
+  // ---- which strips have work at all (the bucket offsets are shared by all frames): a rank of a tile-column
+  // partition, or a caller with a partial list, only walks its own strips.
+  int *misc = reinterpret_cast<int *>(lds + a.misc_off);  // [0] = n_active, [8 .. 15] = flag words, then uint8 active[256]
+  uint8_t *active = reinterpret_cast<uint8_t *>(misc + 72);
+  for (int i = tid; i < 72; i += kAll) misc[i] = 0;
+  __syncthreads();
+  {
+    const int n_buckets = a.cells_per_row * a.cell_rows;
+    for (int b = tid; b < n_buckets; b += kAll) {
+      int n = 0;
+      if (groups) n += group_off[b + 1] - group_off[b];
+      if (cands) n += cand_off[b + 1] - cand_off[b];
+      if (n > 0) {
+        const int cx = b % a.cells_per_row;
+        atomicOr(reinterpret_cast<unsigned *>(&misc[8 + (cx >> 5)]), 1u << (cx & 31));
       }
-      if (cands) {
-        const W2 w = *reinterpret_cast<const W2 *>(cands + (int64_t)it.f_rel * cand_frame_stride +
-                                                   max(min(it.c0 + slot, n_cands - 1), 0));
-        d.c[0] = w.v[0];
-        d.c[1] = w.v[1];
-      }
-    }
-  };
-  auto half = [](const uint32_t *w, int h) { return (int)(int16_t)(w[h >> 1] >> (16 * (h & 1))); };
-  // Chunk q = threadIdx + k * kThreads of a window sits at (row, chunk-in-row) = (q / cpr, q % cpr); the pair is
-  // advanced incrementally (one division per item per lane).  Every load is unconditional (indices clamped to the
-  // last chunk / last list entry) so that the code stays straight-line and the compiler's vmcnt bookkeeping exact.
-  auto request = [&](const Item &it, const Desc &d, Ahead &h) {
-    const char *g = reinterpret_cast<const char *>(ref.origin + (int64_t)(a.first_frame + it.f_rel) * ref.frame_stride +
-                                                   (int64_t)it.wy0 * ref.stride + it.wx0);
-    const int gpitch = ref.stride * kES;
-    const int rows = it.wy1 - it.wy0;
-    const int dr = kThreads / it.cpr, dc = kThreads - dr * it.cpr;
-    int r = (int)threadIdx.x / it.cpr, c = (int)threadIdx.x - r * it.cpr;
-#pragma unroll
-    for (int k = 0; k < kRegChunks; ++k) {
-      const int rr = min(r, rows - 1);
-      h.win[k] = *reinterpret_cast<const U128 *>(g + (int64_t)rr * gpitch + c * 16);
-      r += dr; c += dc;
-      if (c >= it.cpr) { c -= it.cpr; ++r; }
-    }
-    if constexpr (kPrefetch) {
-      if (groups) {
-#pragma unroll
-        for (int k = 0; k < G::kUnitsPerLane; ++k) h.gsrc[k] = src_unit(it.f_rel, half(d.g, 0), half(d.g, 1), k);
-      }
-    }
-  };
-  // Registers -> LDS; chunks beyond kRegChunks per lane (windows larger than 64 KB) are copied synchronously.
-  // Straight-line on purpose: a lane without a chunk stores to a dummy slot behind the window instead of branching,
-  // so that the compiler's wait-count bookkeeping sees every prefetched register consumed on every path (a skipped
-  // conditional store leaves "maybe pending" state behind and turns later waits into vmcnt(0)).
-  auto commit = [&](const Item &it, const Ahead &h) {
-    const int total = (it.wy1 - it.wy0) * it.cpr;
-    const int dr = kThreads / it.cpr, dc = kThreads - dr * it.cpr;
-    int r = (int)threadIdx.x / it.cpr, c = (int)threadIdx.x - r * it.cpr;
-#pragma unroll
-    for (int k = 0; k < kRegChunks; ++k) {
-      const int off = (int)threadIdx.x + k * kThreads < total ? r * a.pitch + c * 16 : a.dummy_off;
-      *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lds) + off) =
-          make_uint4(h.win[k].v[0], h.win[k].v[1], h.win[k].v[2], h.win[k].v[3]);
-      r += dr; c += dc;
-      if (c >= it.cpr) { c -= it.cpr; ++r; }
-    }
-    if (total > kRegChunks * kThreads) {
-      const char *g = reinterpret_cast<const char *>(ref.origin + (int64_t)(a.first_frame + it.f_rel) * ref.frame_stride +
-                                                     (int64_t)it.wy0 * ref.stride + it.wx0);
-      const int gpitch = ref.stride * kES;
-      const int rows = it.wy1 - it.wy0;
-      for (int q0 = (int)threadIdx.x + kRegChunks * kThreads; q0 - (int)threadIdx.x < total; q0 += 4 * kThreads) {
-        U128 t[4];
-        int lo[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          t[k] = *reinterpret_cast<const U128 *>(g + (int64_t)min(r, rows - 1) * gpitch + c * 16);
-          lo[k] = q0 + k * kThreads < total ? r * a.pitch + c * 16 : a.dummy_off;
-          r += dr; c += dc;
-          if (c >= it.cpr) { c -= it.cpr; ++r; }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lds) + lo[k]) = make_uint4(t[k].v[0], t[k].v[1], t[k].v[2], t[k].v[3]);
-      }
-    }
-  };
-
-  auto inside = [&](const Item &it, int rx, int ry) {
-    return rx >= it.wx0 && rx + W <= it.wx1 && ry >= it.wy0 && ry + H <= it.wy1;
-  };
-  auto lds_off = [&](const Item &it, int rx, int ry) {
-    return (unsigned)((ry - it.wy0) * a.pitch + (rx - it.wx0) * kES);
-  };
-  auto store4 = [&](const Item &it, int gi, uint32_t (&acc)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = group_sum<G::kTpc>(acc[j]);
-    if (lane_in_cand == 0) {
-      uint4 o;
-      o.x = (SKIP ? 2u * acc[0] : acc[0]) >> a.shift;
-      o.y = (SKIP ? 2u * acc[1] : acc[1]) >> a.shift;
-      o.z = (SKIP ? 2u * acc[2] : acc[2]) >> a.shift;
-      o.w = (SKIP ? 2u * acc[3] : acc[3]) >> a.shift;
-      reinterpret_cast<uint4 *>(out4)[(int64_t)it.f_rel * n_groups + gi] = o;
-    }
-  };
-  auto store1 = [&](const Item &it, int ci, uint32_t acc) {
-    acc = group_sum<G::kTpc>(acc);
-    if (lane_in_cand == 0) out1[(int64_t)it.f_rel * n_cands + ci] = (SKIP ? 2u * acc : acc) >> a.shift;
-  };
-  // generic evaluation of one reference block against source rows fetched here
-  auto generic_ref = [&](const Item &it, int sx, int sy, int rx, int ry) {
-    const T *rbase = ref.origin + (int64_t)(a.first_frame + it.f_rel) * ref.frame_stride;
-    const bool in = inside(it, rx, ry);
-    const unsigned loff = lds_off(it, rx, ry);
-    uint32_t acc = 0;
-#pragma unroll(kPrefetch ? G::kUnitsPerLane : 4)
-    for (int k = 0; k < G::kUnitsPerLane; ++k) {
-      int row, col;
-      unit_pos(k, row, col);
-      const L sv = src_unit(it.f_rel, sx, sy, k);
-      L r;
-      if (in)
-        r = lds_unit<G::kUnitBytes>(lds, loff + (unsigned)(row * a.pitch + col * kES));
-      else
-        r = *reinterpret_cast<const L *>(rbase + (int64_t)(ry + row) * ref.stride + rx + col);
-#pragma unroll
-      for (int i = 0; i < G::kUnitBytes / 4; ++i) acc = sad_dword<T>(sv.v[i], r.v[i], acc);
-    }
-    return acc;
-  };
-  auto generic_group = [&](const Item &it, int gi, const aomhip_sad_x4d_cand &d) {
-    // one copy of generic_ref in the code, no dynamically indexed arrays (they would live in scratch)
-    uint64_t rx4, ry4;
-    memcpy(&rx4, d.rx, 8);
-    memcpy(&ry4, d.ry, 8);
-    uint32_t acc[4] = { 0, 0, 0, 0 };
-#pragma unroll 1
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t v = generic_ref(it, d.sx, d.sy, (int16_t)(rx4 >> (16 * j)), (int16_t)(ry4 >> (16 * j)));
-      acc[0] = j == 0 ? v : acc[0];
-      acc[1] = j == 1 ? v : acc[1];
-      acc[2] = j == 2 ? v : acc[2];
-      acc[3] = j == 3 ? v : acc[3];
-    }
-    store4(it, gi, acc);
-  };
-
-  Ahead cur;
-  Desc d_it, d_n1, d_n2;
-#pragma unroll
-  for (int i = 0; i < 5; ++i) d_it.g[i] = d_n1.g[i] = d_n2.g[i] = 0;
-  d_it.c[0] = d_it.c[1] = d_n1.c[0] = d_n1.c[1] = d_n2.c[0] = d_n2.c[1] = 0;
-  Item it = decode((int)blockIdx.x);
-  Item n1 = it;
-  n1.valid = 0;
-  if (it.valid) {
-    load_desc(it, d_it);
-    n1 = decode(it.next);
-    load_desc(n1.valid ? n1 : it, d_n1);
-    request(it, d_it, cur);
-  }
-  while (it.valid) {
-    commit(it, cur);
-    // source rows of this item move out of the way of the next request
-    aomhip_sad_x4d_cand gdesc;
-    aomhip_sad_cand cdesc;
-    gdesc.sx = (int16_t)half(d_it.g, 0); gdesc.sy = (int16_t)half(d_it.g, 1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { gdesc.rx[j] = (int16_t)half(d_it.g, 2 + j); gdesc.ry[j] = (int16_t)half(d_it.g, 6 + j); }
-    cdesc.sx = (int16_t)half(d_it.c, 0); cdesc.sy = (int16_t)half(d_it.c, 1);
-    cdesc.rx = (int16_t)half(d_it.c, 2); cdesc.ry = (int16_t)half(d_it.c, 3);
-    L gsrc[kPrefetch ? G::kUnitsPerLane : 1];
-    if constexpr (kPrefetch) {
-#pragma unroll
-      for (int k = 0; k < G::kUnitsPerLane; ++k) gsrc[k] = cur.gsrc[k];
     }
     __syncthreads();
-    // Requests are unconditional (past the end of the walk they re-fetch the current item): a conditional request
-    // would merge "old" and "new" register values at the join and make the compiler wait for the loads right there.
-    const Item rq = n1.valid ? n1 : it;
-    Desc d_rq;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) d_rq.g[i] = n1.valid ? d_n1.g[i] : d_it.g[i];
-    request(rq, d_rq, cur);  // first, so that the window is in flight while the scalar loads of decode() return
-    const Item n2 = decode(n1.next);  // (an invalid n1 carries next >= n_items, so n2 is invalid too)
-    load_desc(n2.valid ? n2 : rq, d_n2);  // consumed at the end of this iteration, after the window has landed anyway
+    if (tid < 64) {
+      int count = 0;
+      for (int base = 0; base < a.cells_per_row; base += 64) {
+        const int cx = base + tid;
+        const bool f = cx < a.cells_per_row && ((misc[8 + (cx >> 5)] >> (cx & 31)) & 1);
+        const unsigned long long m = __ballot(f);
+        if (f) active[count + __popcll(m & ((1ull << tid) - 1))] = (uint8_t)cx;
+        count += __popcll(m);
+      }
+      if (tid == 0) misc[0] = count;
+    }
+    __syncthreads();
+  }
+  const int n_active = uni(misc[0]);
+  if (n_active == 0) return;
 
-    int gi = it.g0 + slot, ci = it.c0 + slot;
-    if constexpr (kPrefetch) {
-      // ---- first round, x4d groups
-      const bool g_act = gi < it.g1;
-      bool g_in = true;
+  // The two roles run two separate instantiations of everything below: values only one role needs (the evaluation's
+  // unit tables, the loaders' staging registers and chunk offsets) then never share a live range with the other role's
+  // -- with one copy of the code the loaders' loop spilled, and a scratch reload behind a batch of staged loads waits
+  // for all of them (vector-memory operations return in order).
+  auto run = [&](auto role) {
+    constexpr bool kLoader = decltype(role)::value;
+    // per-lane constants of the block-unit mapping: row of the lane's k-th unit, its byte offset in a ring row walk and
+    // in a source-cell walk
+    int unit_row[G::kUnitsPerLane], unit_colb[G::kUnitsPerLane];
+    unsigned unit_roff[G::kUnitsPerLane], unit_soff[G::kUnitsPerLane];
+  #pragma unroll
+    for (int k = 0; k < G::kUnitsPerLane; ++k) {
+      const int u = lane_in_cand + k * G::kTpc;
+      unit_row[k] = (u / G::kUnitsPerRow) * G::kRowStep;
+      unit_colb[k] = (u % G::kUnitsPerRow) * G::kUnitBytes;
+      unit_roff[k] = (unsigned)(unit_row[k] * a.pitch + unit_colb[k]);
+      unit_soff[k] = (unsigned)(unit_row[k] * a.spitch + unit_colb[k]);
+    }
+
+    // ---- the walk over (frame, strip) items
+    const bool affine = a.n_frames >= 8;  // strips of one frame side by side on one XCD
+    const int xcd = affine ? (int)(blockIdx.x & 7) : 0;
+    const int wg_j = affine ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int wg_n = affine ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int frames_here = affine ? (a.n_frames - xcd + 7) >> 3 : a.n_frames;
+    const int n_items = frames_here * n_active;
+
+    SB_DECL;
+    for (int item = wg_j; item < n_items; item += wg_n) {
+      const int fi = item / n_active;
+      const int f_rel = affine ? xcd + 8 * fi : fi;
+      const int cx = uni((int)active[item - fi * n_active]);
+      const int cell_x0 = cx * a.sb_w;
+      // window / source-cell columns: start rounded down to a 16-byte boundary of the plane row
+      const int wx0 = max(((cell_x0 - a.range + a.border) & ~(kEpc - 1)) - a.border, a.xmin);
+      const int colmax = min(a.cpr - 1, (a.row_end - wx0) / kEpc - 1);  // last chunk that stays inside the row's allocation
+      const int wx1 = min(wx0 + (colmax + 1) * kEpc, a.xmax);
+      const int sx0 = ((cell_x0 + a.s_border) & ~(kEpc - 1)) - a.s_border;
+      const int scolmax = min(a.scpr - 1, (a.s_row_end - sx0) / kEpc - 1);
+      const int sx1 = min(sx0 + (scolmax + 1) * kEpc, a.s_xmax);
+      const char *ref_frame = reinterpret_cast<const char *>(ref.origin + (int64_t)(a.first_frame + f_rel) * ref.frame_stride);
+      const char *src_frame = reinterpret_cast<const char *>(src.origin + (int64_t)(a.first_frame + f_rel) * src.frame_stride);
+      const int gpitch = ref.stride * kES, sgpitch = src.stride * kES;
+      const aomhip_sad_x4d_cand *glist = groups ? groups + (int64_t)f_rel * group_frame_stride : nullptr;
+      const aomhip_sad_cand *clist = cands ? cands + (int64_t)f_rel * cand_frame_stride : nullptr;
+
+      // ---- transport (loader lanes): one BATCH = what step `cy` adds to LDS: new ring rows [ya, yb), source cell cy,
+      // the list slices of cell cy.  request() starts the loads into registers, commit() writes them to LDS a step later.
+      struct Batch { int ya, yb, sy0, ns, g0, ng, c0, nc, buf; };
+      struct Stage { U128 ring[kRingN]; U128 srcv[kSrcN]; uint32_t g[kGN]; uint32_t c[kCN]; };
+      // Every load is unconditional and straight-line (lanes past the end of a batch re-read its last chunk; an unused
+      // register slot re-reads chunk 0): a conditional load would leave "maybe pending" registers behind at the join
+      // and the compiler's wait-count pass would then drain vmcnt(0) at every later use.  `me` of `n` lanes take part.
+      const uint32_t *gwords = groups ? reinterpret_cast<const uint32_t *>(glist) : reinterpret_cast<const uint32_t *>(ref_frame);
+      const uint32_t *cwords = cands ? reinterpret_cast<const uint32_t *>(clist) : reinterpret_cast<const uint32_t *>(ref_frame);
+      const int gwords_n = groups ? n_groups * 5 : 1, cwords_n = cands ? n_cands * 2 : 1;
+      auto request_gen = [&](const Batch &b, Stage &st, int me, int n) {
+        const int total_r = (b.yb - b.ya) * a.cpr, total_s = b.ns * a.scpr;
+        const char *rb = ref_frame + (int64_t)b.ya * gpitch + (int64_t)wx0 * kES;
+        const char *sb_ = src_frame + (int64_t)b.sy0 * sgpitch + (int64_t)sx0 * kES;
+  #pragma unroll
+        for (int i = 0; i < kRingN; ++i) {
+          const unsigned q = (unsigned)max(min(me + i * n, total_r - 1), 0);
+          const unsigned row = __umulhi(q, a.magic_cpr), col = q - row * (unsigned)a.cpr;
+          st.ring[i] = *reinterpret_cast<const U128 *>(rb + (row * (unsigned)gpitch + (unsigned)min((int)col, colmax) * 16u));
+        }
+  #pragma unroll
+        for (int i = 0; i < kSrcN; ++i) {
+          const unsigned q = (unsigned)max(min(me + i * n, total_s - 1), 0);
+          const unsigned row = __umulhi(q, a.magic_scpr), col = q - row * (unsigned)a.scpr;
+          st.srcv[i] = *reinterpret_cast<const U128 *>(sb_ + (row * (unsigned)sgpitch + (unsigned)min((int)col, scolmax) * 16u));
+        }
+  #pragma unroll
+        for (int i = 0; i < kGN; ++i) st.g[i] = gwords[(unsigned)max(min(b.g0 * 5 + min(me + i * n, b.ng * 5 - 1), gwords_n - 1), 0)];
+  #pragma unroll
+        for (int i = 0; i < kCN; ++i) st.c[i] = cwords[(unsigned)max(min(b.c0 * 2 + min(me + i * n, b.nc * 2 - 1), cwords_n - 1), 0)];
+      };
+      auto commit_gen = [&](const Batch &b, const Stage &st, int me, int n) {
+        const int total_r = (b.yb - b.ya) * a.cpr, total_s = b.ns * a.scpr;
+        const unsigned s_first = (unsigned)((b.ya - a.ymin) % a.R);
+  #pragma unroll
+        for (int i = 0; i < kRingN; ++i) {
+          const unsigned q = (unsigned)(me + i * n);
+          if ((int)q < total_r) {
+            const unsigned row = __umulhi(q, a.magic_cpr), col = q - row * (unsigned)a.cpr;
+            unsigned sl = s_first + row;
+            sl = min(sl, sl - (unsigned)a.R);
+            const uint4 v = make_uint4(st.ring[i].v[0], st.ring[i].v[1], st.ring[i].v[2], st.ring[i].v[3]);
+            *reinterpret_cast<uint4 *>(lds + a.ring_off + sl * a.pitch + col * 16) = v;
+            if (kMirror > 0 && sl < (unsigned)kMirror)
+              *reinterpret_cast<uint4 *>(lds + a.ring_off + (sl + a.R) * a.pitch + col * 16) = v;
+          }
+        }
+  #pragma unroll
+        for (int i = 0; i < kSrcN; ++i) {
+          const unsigned q = (unsigned)(me + i * n);
+          if ((int)q < total_s) {
+            const unsigned row = __umulhi(q, a.magic_scpr), col = q - row * (unsigned)a.scpr;
+            *reinterpret_cast<uint4 *>(lds + a.src_off[b.buf] + row * a.spitch + col * 16) =
+                make_uint4(st.srcv[i].v[0], st.srcv[i].v[1], st.srcv[i].v[2], st.srcv[i].v[3]);
+          }
+        }
+  #pragma unroll
+        for (int i = 0; i < kGN; ++i)
+          if (me + i * n < b.ng * 5) *reinterpret_cast<uint32_t *>(lds + a.gdesc_off[b.buf] + (me + i * n) * 4) = st.g[i];
+  #pragma unroll
+        for (int i = 0; i < kCN; ++i)
+          if (me + i * n < b.nc * 2) *reinterpret_cast<uint32_t *>(lds + a.cdesc_off[b.buf] + (me + i * n) * 4) = st.c[i];
+      };
+      auto win_y0 = [&](int cy) { return max(cy * a.sb_h - a.range, a.ymin); };
+      auto win_y1 = [&](int cy) { return min(cy * a.sb_h + a.sb_h + a.range, a.ymax); };
+      struct Seg { int g0, g1, c0, c1; };
+      // The strip's bucket bounds come out of LDS (filled in the prologue): a scalar load from global memory at the top of
+      // a step took 1000-3000 cycles while the loaders keep the memory system saturated.
+      const int4 *segs = reinterpret_cast<const int4 *>(lds + a.seg_off);
+      auto seg_of = [&](int cy) {
+        const int4 v = segs[cy];
+        Seg s;
+        s.g0 = uni(v.x); s.g1 = uni(v.y); s.c0 = uni(v.z); s.c1 = uni(v.w);
+        return s;
+      };
+      // ---- evaluation of list entries out of LDS.  Per step: window rows [wy0, wy0 + wh), ring slot of row wy0, source
+      // cell rows [sy0, sy0 + sh); per strip: window columns [wx0, wx0 + ww), source columns [sx0, sx0 + sw).
+      struct Win { int wy0, s0; unsigned wh_ok, sy0, sh_ok; };  // *_ok: largest admissible block offset (unsigned compare)
+      const unsigned ww_ok = (unsigned)(wx1 - wx0 - W), sw_ok = (unsigned)(sx1 - sx0 - W);
+      const bool strip_ok = wx1 - wx0 >= W && sx1 - sx0 >= W;
+      auto global_unit = [&](const char *frame, int pitch_b, int x, int y, int k) {
+        return *reinterpret_cast<const L *>(frame + (int64_t)(y + unit_row[k]) * pitch_b + (int64_t)x * kES + unit_colb[k]);
+      };
+      auto sad_unit = [&](const L &s, const L &r, uint32_t acc) {
+  #pragma unroll
+        for (int i = 0; i < G::kUnitBytes / 4; ++i) acc = sad_dword<T>(s.v[i], r.v[i], acc);
+        return acc;
+      };
+      auto finish = [&](uint32_t acc) { return ((SKIP ? 2u * acc : acc) >> a.shift); };
+      auto generic_ref = [&](int sx, int sy, int rx, int ry) {  // both blocks straight from global memory
+        uint32_t acc = 0;
+  #pragma unroll kGenUnroll
+        for (int k = 0; k < G::kUnitsPerLane; ++k)
+          acc = sad_unit(global_unit(src_frame, sgpitch, sx, sy, k), global_unit(ref_frame, gpitch, rx, ry, k), acc);
+        return acc;
+      };
+      // LDS byte offset of the reference block's first row / first byte; false when the block is not wholly in the window
+      auto ring_pos = [&](const Win &w, int rx, int ry, unsigned &base, int &slot0) {
+        const unsigned dx = (unsigned)(rx - wx0), dy = (unsigned)(ry - w.wy0);
+        unsigned t = (unsigned)w.s0 + dy;
+        t = min(t, t - (unsigned)a.R);  // one wrap at most: t - R underflows to a huge value unless t >= R
+        slot0 = (int)t;
+        base = (unsigned)a.ring_off + t * (unsigned)a.pitch + dx * kES;
+        return dx <= ww_ok && dy <= w.wh_ok;
+      };
+      auto ring_unit = [&](unsigned base, int slot0, int k) {
+        if constexpr (kMirror > 0) {
+          return lds_unit<G::kUnitBytes>(lds, base + unit_roff[k]);
+        } else {
+          unsigned s = (unsigned)(slot0 + unit_row[k]);
+          const unsigned wrap = s >= (unsigned)a.R ? (unsigned)(a.R * a.pitch) : 0u;
+          return lds_unit<G::kUnitBytes>(lds, base + unit_roff[k] - wrap);
+        }
+      };
+      auto src_pos = [&](const Win &w, int sx, int sy, unsigned &soff) {
+        const unsigned dx = (unsigned)(sx - sx0), dy = (unsigned)sy - w.sy0;
+        soff = dy * (unsigned)a.spitch + dx * kES;
+        return dx <= sw_ok && dy <= w.sh_ok;
+      };
+
+      // One loop over the two list slices: iteration i handles group i and single candidate i of the slice (in a Mode-A
+      // style list they belong to the same source block, whose rows are then read once for all five references).
+      // The 4 reference positions of a group are decoded and located by 4 different lanes of the block's lane group
+      // (lane & 3 = reference index) and then shared with quad broadcasts, instead of every lane redoing all of it:
+      // the kernel is bound by the number of wave-instructions issued (PMC: 56 % of wave time waiting with two
+      // wavefronts per SIMD, the rest issuing), so per-entry bookkeeping counts as much as the SAD arithmetic.
+      constexpr bool kCoop = G::kTpc >= 4;
+      const int my_j = lane & 3;                      // the reference this lane decodes (kCoop)
+      const int my_w = my_j >> 1, my_sh = 16 * (my_j & 1);
+      auto quad_bcast = [](unsigned v, int jj) {
+        switch (jj) {
+          case 0: return (unsigned)__builtin_amdgcn_update_dpp(0u, v, 0x00, 0xf, 0xf, false);
+          case 1: return (unsigned)__builtin_amdgcn_update_dpp(0u, v, 0x55, 0xf, 0xf, false);
+          case 2: return (unsigned)__builtin_amdgcn_update_dpp(0u, v, 0xAA, 0xf, 0xf, false);
+          default: return (unsigned)__builtin_amdgcn_update_dpp(0u, v, 0xFF, 0xf, 0xf, false);
+        }
+      };
+      auto eval = [&](const Win &w, int buf, int g0, int ng, int c0, int nc) {
+        const uint32_t *gd = reinterpret_cast<const uint32_t *>(lds + a.gdesc_off[buf]);
+        const uint32_t *cd = reinterpret_cast<const uint32_t *>(lds + a.cdesc_off[buf]);
+        const char *sbuf = lds + a.src_off[buf];
+        const int n_it = max(ng, nc);
+        for (int i = slot; i < n_it; i += kPerWg) {
+          const bool has_g = i < ng && !(a.dbg & 8), has_c = i < nc && !(a.dbg & 4);
+          if constexpr (kCoop && G::kUnitsPerLane <= 4 && kMirror > 0) {
+            // The common case as ONE basic block: a group and a single candidate of the same source block, everything
+            // inside the staged cell / window, source rows unit aligned (a Mode-A style list, a diamond step ...).
+            // With no branch between the five references the compiler overlaps their LDS reads, realignments and
+            // SADs; the general code below is a chain of small dependent blocks, and with two evaluating wavefronts
+            // per SIMD that chain's latency -- not LDS or VALU throughput -- set the step time.
+            const bool both = has_g && has_c;
+            const uint32_t d0 = gd[both ? i * 5 : 0], c0w = cd[both ? i * 2 : 0], c1w = cd[both ? i * 2 + 1 : 1];
+            const int mrx = __builtin_amdgcn_sbfe((int)gd[both ? i * 5 + 1 + my_w : 1 + my_w], my_sh, 16);
+            const int mry = __builtin_amdgcn_sbfe((int)gd[both ? i * 5 + 3 + my_w : 3 + my_w], my_sh, 16);
+            const int fsx = (int16_t)d0, fsy = (int16_t)(d0 >> 16);
+            unsigned soff, mbase, cbase, base[5];
+            int unused;
+            bool ok = src_pos(w, fsx, fsy, soff);
+            ok = ring_pos(w, mrx, mry, mbase, unused) && ok;
+            ok = ring_pos(w, (int16_t)c1w, (int16_t)(c1w >> 16), cbase, unused) && ok;
+            ok = ok && c0w == d0 && (soff & (G::kUnitBytes - 1)) == 0;
+            unsigned okv = ok ? 1u : 0u;
+            okv &= (unsigned)__builtin_amdgcn_update_dpp(0u, okv, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+            okv &= (unsigned)__builtin_amdgcn_update_dpp(0u, okv, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+            if (__all((both && okv != 0) || (!has_g && !has_c))) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g_in = g_in && inside(it, gdesc.rx[j], gdesc.ry[j]);
-      if (__all(!g_act || g_in)) {
-        if (g_act) {
-          uint32_t acc[4] = { 0, 0, 0, 0 };
-          unsigned loff[4];
+              for (int j = 0; j < 4; ++j) base[j] = both ? quad_bcast(mbase, j) : (unsigned)a.ring_off;
+              base[4] = both ? cbase : (unsigned)a.ring_off;
+              if (!both) soff = 0;
+              uint32_t acc[5] = { 0, 0, 0, 0, 0 };
 #pragma unroll
-          for (int j = 0; j < 4; ++j) loff[j] = lds_off(it, gdesc.rx[j], gdesc.ry[j]);
+              for (int k = 0; k < G::kUnitsPerLane; ++k) {
+                const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
 #pragma unroll
-          for (int k = 0; k < G::kUnitsPerLane; ++k) {
-            int row, col;
-            unit_pos(k, row, col);
+                for (int j = 0; j < 5; ++j) acc[j] = sad_unit(sv, lds_unit<G::kUnitBytes>(lds, base[j] + unit_roff[k]), acc[j]);
+              }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const L r = lds_unit<G::kUnitBytes>(lds, loff[j] + (unsigned)(row * a.pitch + col * kES));
-#pragma unroll
-              for (int i = 0; i < G::kUnitBytes / 4; ++i) acc[j] = sad_dword<T>(gsrc[k].v[i], r.v[i], acc[j]);
+              for (int j = 0; j < 5; ++j) acc[j] = group_sum<G::kTpc>(acc[j]);
+              if (lane_in_cand == 0 && both) {
+                reinterpret_cast<uint4 *>(out4)[(int64_t)f_rel * n_groups + g0 + i] =
+                    make_uint4(finish(acc[0]), finish(acc[1]), finish(acc[2]), finish(acc[3]));
+                out1[(int64_t)f_rel * n_cands + c0 + i] = finish(acc[4]);
+              }
+              continue;
             }
           }
-          store4(it, gi, acc);
-        }
-      } else if (g_act) {
-        generic_group(it, gi, gdesc);
-      }
-      gi += kPerWg;
-      // ---- first round, single candidates
-      const bool c_act = ci < it.c1;
-      const bool c_fast = g_act && cdesc.sx == gdesc.sx && cdesc.sy == gdesc.sy && inside(it, cdesc.rx, cdesc.ry);
-      if (__all(!c_act || c_fast)) {
-        if (c_act) {
-          const unsigned loff = lds_off(it, cdesc.rx, cdesc.ry);
-          uint32_t acc = 0;
-#pragma unroll
-          for (int k = 0; k < G::kUnitsPerLane; ++k) {
-            int row, col;
-            unit_pos(k, row, col);
-            const L r = lds_unit<G::kUnitBytes>(lds, loff + (unsigned)(row * a.pitch + col * kES));
-#pragma unroll
-            for (int i = 0; i < G::kUnitBytes / 4; ++i) acc = sad_dword<T>(gsrc[k].v[i], r.v[i], acc);
+          int gsx = 0, gsy = 0;
+          constexpr bool kKeepSrc = G::kUnitsPerLane <= 4;  // larger blocks do not keep their source rows in registers
+          L gsrc[kKeepSrc ? G::kUnitsPerLane : 1];
+          bool gsrc_ok = false;  // gsrc holds the rows of block (gsx, gsy)
+          if (has_g) {
+            const uint32_t d0 = gd[i * 5];
+            gsx = (int16_t)d0; gsy = (int16_t)(d0 >> 16);
+            unsigned soff, base[4];
+            int slot0[4];
+            bool in = src_pos(w, gsx, gsy, soff);
+            int rx[4], ry[4];  // all four only on the non-cooperative / fallback paths
+            if constexpr (kCoop) {
+              const int mrx = __builtin_amdgcn_sbfe((int)gd[i * 5 + 1 + my_w], my_sh, 16);
+              const int mry = __builtin_amdgcn_sbfe((int)gd[i * 5 + 3 + my_w], my_sh, 16);
+              unsigned mbase;
+              int mslot;
+              unsigned ok = ring_pos(w, mrx, mry, mbase, mslot) ? 1u : 0u;
+              ok &= (unsigned)__builtin_amdgcn_update_dpp(0u, ok, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+              ok &= (unsigned)__builtin_amdgcn_update_dpp(0u, ok, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+              in = in && ok != 0;
+  #pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                base[j] = quad_bcast(mbase, j);
+                slot0[j] = kMirror > 0 ? 0 : (int)quad_bcast((unsigned)mslot, j);
+                rx[j] = mrx; ry[j] = mry;  // (own reference only; the fallback below re-broadcasts)
+              }
+            } else {
+              uint32_t d[5];
+              d[0] = d0;
+  #pragma unroll
+              for (int q = 1; q < 5; ++q) d[q] = gd[i * 5 + q];
+  #pragma unroll
+              for (int j = 0; j < 4; ++j) {  // halfword h of the record: word h / 2, shifted by 16 (h & 1); rx = halves 2..5, ry = 6..9
+                rx[j] = (int16_t)(d[(2 + j) >> 1] >> (16 * ((2 + j) & 1)));
+                ry[j] = (int16_t)(d[(6 + j) >> 1] >> (16 * ((6 + j) & 1)));
+                in = ring_pos(w, rx[j], ry[j], base[j], slot0[j]) && in;
+              }
+            }
+            uint32_t acc[4] = { 0, 0, 0, 0 };
+            if (in && !(a.dbg & 16)) {
+              const bool s_al = (soff & (G::kUnitBytes - 1)) == 0;
+              if (__all(s_al)) {
+  #pragma unroll
+                for (int k = 0; k < G::kUnitsPerLane; ++k) {
+                  const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
+                  if constexpr (kKeepSrc) gsrc[k] = sv;
+  #pragma unroll
+                  for (int j = 0; j < 4; ++j) acc[j] = sad_unit(sv, ring_unit(base[j], slot0[j], k), acc[j]);
+                }
+              } else {
+  #pragma unroll kGenUnroll
+                for (int k = 0; k < G::kUnitsPerLane; ++k) {
+                  const L sv = lds_unit<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
+                  if constexpr (kKeepSrc) gsrc[k] = sv;
+  #pragma unroll
+                  for (int j = 0; j < 4; ++j) acc[j] = sad_unit(sv, ring_unit(base[j], slot0[j], k), acc[j]);
+                }
+              }
+              gsrc_ok = kKeepSrc;
+            } else {
+  #pragma unroll 1
+              for (int j = 0; j < 4; ++j) {
+                int jrx = rx[j], jry = ry[j];
+                if constexpr (kCoop) {  // every lane of the block's lane group is in this branch together
+                  jrx = (int)quad_bcast((unsigned)rx[0], j);
+                  jry = (int)quad_bcast((unsigned)ry[0], j);
+                }
+                const uint32_t v = generic_ref(gsx, gsy, jrx, jry);
+                acc[0] = j == 0 ? v : acc[0]; acc[1] = j == 1 ? v : acc[1];
+                acc[2] = j == 2 ? v : acc[2]; acc[3] = j == 3 ? v : acc[3];
+              }
+            }
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = group_sum<G::kTpc>(acc[j]);
+            if (lane_in_cand == 0)
+              reinterpret_cast<uint4 *>(out4)[(int64_t)f_rel * n_groups + g0 + i] =
+                  make_uint4(finish(acc[0]), finish(acc[1]), finish(acc[2]), finish(acc[3]));
           }
-          store1(it, ci, acc);
+          if (has_c) {
+            const uint32_t d0 = cd[i * 2], d1 = cd[i * 2 + 1];
+            const int sx = (int16_t)d0, sy = (int16_t)(d0 >> 16), rx = (int16_t)d1, ry = (int16_t)(d1 >> 16);
+            uint32_t acc = 0;
+            unsigned soff, base;
+            int slot0;
+            bool in = src_pos(w, sx, sy, soff);
+            in = ring_pos(w, rx, ry, base, slot0) && in;
+            if (in) {
+              const bool reuse = gsrc_ok && sx == gsx && sy == gsy;
+              if (__all(reuse)) {
+                if constexpr (kKeepSrc) {
+  #pragma unroll
+                  for (int k = 0; k < G::kUnitsPerLane; ++k) acc = sad_unit(gsrc[k], ring_unit(base, slot0, k), acc);
+                }
+              } else {
+  #pragma unroll kGenUnroll
+                for (int k = 0; k < G::kUnitsPerLane; ++k)
+                  acc = sad_unit(lds_unit<G::kUnitBytes>(sbuf, soff + unit_soff[k]), ring_unit(base, slot0, k), acc);
+              }
+            } else {
+              acc = generic_ref(sx, sy, rx, ry);
+            }
+            acc = group_sum<G::kTpc>(acc);
+            if (lane_in_cand == 0) out1[(int64_t)f_rel * n_cands + c0 + i] = finish(acc);
+          }
         }
-      } else if (c_act) {
-        store1(it, ci, generic_ref(it, cdesc.sx, cdesc.sy, cdesc.rx, cdesc.ry));
+      };
+
+      auto batch_of = [&](int cy) {  // what step cy adds on top of step cy - 1 (nothing past the last cell)
+        const bool real = cy < a.cell_rows;
+        const int cyc = real ? cy : a.cell_rows - 1;  // (addresses of an empty batch stay inside the planes)
+        const Seg sg = seg_of(cyc);
+        Batch b;
+        b.ya = cyc > 0 ? win_y1(cyc - 1) : win_y0(0);
+        b.yb = real ? win_y1(cyc) : b.ya;
+        b.sy0 = cyc * a.sb_h; b.ns = real ? min(b.sy0 + a.sb_h, a.s_ymax) - b.sy0 : 0;
+        b.g0 = sg.g0; b.ng = real ? min(sg.g1 - sg.g0, a.gcap) : 0;
+        b.c0 = sg.c0; b.nc = real ? min(sg.c1 - sg.c0, a.ccap) : 0;
+        b.buf = cy & 1;
+        if ((a.dbg & 2) && cy > 0) { b.yb = b.ya; b.ns = 0; }  // (timing ablation: list slices only)
+        return b;
+      };
+      for (int cy = tid; cy < a.cell_rows; cy += kAll) {
+        const int b = cy * a.cells_per_row + cx;
+        reinterpret_cast<int4 *>(lds + a.seg_off)[cy] = make_int4(groups ? group_off[b] : 0, groups ? group_off[b + 1] : 0,
+                                                                    cands ? cand_off[b] : 0, cands ? cand_off[b + 1] : 0);
       }
-      ci += kPerWg;
+      __syncthreads();
+      // ---- prologue of the strip: the whole first window in passes of what the staging registers hold, the first source
+      // cell and list slices (every wavefront of the workgroup takes part: nothing to evaluate yet)
+      SB_T(p0);
+      {
+        Stage st0;
+        const int rows_per_pass = (kRingN * kAll) / a.cpr;
+        const Batch b = batch_of(0);
+        for (int ya = win_y0(0); ya < win_y1(0); ya += rows_per_pass) {
+          Batch p = b;
+          p.ya = ya; p.yb = min(ya + rows_per_pass, win_y1(0));
+          if (ya != win_y0(0)) { p.ns = 0; p.ng = 0; p.nc = 0; }
+          request_gen(p, st0, tid, kAll);
+          commit_gen(p, st0, tid, kAll);
+        }
+      }
+      // The two roles run their own step loops with the same sequence of workgroup barriers.  The loader's loop body is
+      // straight-line around the registers that are in flight across the barrier (commit, then request): any join
+      // with a live staged register makes the compiler copy it -- and wait for it -- on the spot.
+      // Steady-state transport of the loader lanes: a batch always has the same shape (sb_h rows below the previous one),
+      // so each lane's chunk offsets are computed once per strip and a staged load costs a compare, a select and the load
+      // (scalar base + 32-bit lane offset).  The general forms above cost ~25 instructions per chunk, and with ~14 chunks
+      // per lane that made the loaders, not the memory system or the evaluation, the longest thing in a step.
+      unsigned r_goff[kRingN], r_loff[kRingN], s_goff[kSrcN], s_loff[kSrcN];
+#pragma unroll
+      for (int i = 0; i < kRingN; ++i) {
+        const unsigned q = (unsigned)(lt + i * kLT), row = __umulhi(q, a.magic_cpr), col = q - row * (unsigned)a.cpr;
+        r_goff[i] = row * (unsigned)gpitch + (unsigned)min((int)col, colmax) * 16u;
+        r_loff[i] = row * (unsigned)a.pitch + col * 16u;
+      }
+  #pragma unroll
+      for (int i = 0; i < kSrcN; ++i) {
+        const unsigned q = (unsigned)(lt + i * kLT), row = __umulhi(q, a.magic_scpr), col = q - row * (unsigned)a.scpr;
+        s_goff[i] = row * (unsigned)sgpitch + (unsigned)min((int)col, scolmax) * 16u;
+        s_loff[i] = row * (unsigned)a.spitch + col * 16u;
+      }
+      const unsigned ring_bytes = (unsigned)(a.R * a.pitch);
+      auto request = [&](const Batch &b, Stage &st) {
+        // (an empty batch still issues its loads -- at row ymax - 1 / the last source row, inside the planes)
+        const char *rb = ref_frame + (int64_t)min(b.ya, a.ymax - 1) * gpitch + (int64_t)wx0 * kES;
+        const char *sb_ = src_frame + (int64_t)min(b.sy0, a.s_ymax - 1) * sgpitch + (int64_t)sx0 * kES;
+        const unsigned rlim = (unsigned)((b.yb - b.ya) * gpitch), slim = (unsigned)(b.ns * sgpitch);
+  #pragma unroll
+        for (int i = 0; i < kRingN; ++i) st.ring[i] = *reinterpret_cast<const U128 *>(rb + (r_goff[i] < rlim ? r_goff[i] : 0u));
+  #pragma unroll
+        for (int i = 0; i < kSrcN; ++i) st.srcv[i] = *reinterpret_cast<const U128 *>(sb_ + (s_goff[i] < slim ? s_goff[i] : 0u));
+  #pragma unroll
+        for (int i = 0; i < kGN; ++i) st.g[i] = gwords[(unsigned)max(min(b.g0 * 5 + min(lt + i * kLT, b.ng * 5 - 1), gwords_n - 1), 0)];
+  #pragma unroll
+        for (int i = 0; i < kCN; ++i) st.c[i] = cwords[(unsigned)max(min(b.c0 * 2 + min(lt + i * kLT, b.nc * 2 - 1), cwords_n - 1), 0)];
+      };
+      auto commit = [&](const Batch &b, const Stage &st) {
+        const unsigned rlim = (unsigned)((b.yb - b.ya) * gpitch), slim = (unsigned)(b.ns * sgpitch);
+        const unsigned first = (unsigned)(((b.ya - a.ymin) % a.R) * a.pitch);
+  #pragma unroll
+        for (int i = 0; i < kRingN; ++i)
+          if (r_goff[i] < rlim) {
+            unsigned t = first + r_loff[i];
+            t = min(t, t - ring_bytes);  // wrap: t - ring_bytes underflows to a huge value unless t >= ring_bytes
+            const uint4 v = make_uint4(st.ring[i].v[0], st.ring[i].v[1], st.ring[i].v[2], st.ring[i].v[3]);
+            *reinterpret_cast<uint4 *>(lds + a.ring_off + t) = v;
+            if (kMirror > 0 && t < (unsigned)(kMirror * a.pitch)) *reinterpret_cast<uint4 *>(lds + a.ring_off + t + ring_bytes) = v;
+          }
+  #pragma unroll
+        for (int i = 0; i < kSrcN; ++i)
+          if (s_goff[i] < slim)
+            *reinterpret_cast<uint4 *>(lds + a.src_off[b.buf] + s_loff[i]) =
+                make_uint4(st.srcv[i].v[0], st.srcv[i].v[1], st.srcv[i].v[2], st.srcv[i].v[3]);
+  #pragma unroll
+        for (int i = 0; i < kGN; ++i)
+          if (lt + i * kLT < b.ng * 5) *reinterpret_cast<uint32_t *>(lds + a.gdesc_off[b.buf] + (lt + i * kLT) * 4) = st.g[i];
+  #pragma unroll
+        for (int i = 0; i < kCN; ++i)
+          if (lt + i * kLT < b.nc * 2) *reinterpret_cast<uint32_t *>(lds + a.cdesc_off[b.buf] + (lt + i * kLT) * 4) = st.c[i];
+      };
+      const int steps = (a.cell_rows + 1) & ~1;  // both roles run an even number of steps (the odd one out only meets the barriers)
+      if constexpr (kLoader) {
+        // Two loader groups take alternate steps: during step cy the group of that parity writes batch cy + 1 (requested
+        // two steps earlier) to LDS and requests batch cy + 3, so two batches -- about 2 x 36 KB per CU, what it takes
+        // to keep HBM busy at its loaded latency -- are in flight at any time, and each wavefront only ever waits for
+        // its own loads (with both batches in one wavefront the compiler's vmcnt bookkeeping drained the younger batch
+        // too).  Each group's loop is straight-line around the staged registers.
+        Stage st;
+        auto overflow = [&](int cy, bool mine) {  // a crowded bucket: further slices through the same buffers
+          if (cy >= a.cell_rows) return;
+          const Seg cur = seg_of(cy);
+          int g = cur.g0 + min(cur.g1 - cur.g0, a.gcap), c = cur.c0 + min(cur.c1 - cur.c0, a.ccap);
+          while (g < cur.g1 || c < cur.c1) {
+            Batch o;
+            o.ya = o.yb = win_y0(0); o.sy0 = 0; o.ns = 0; o.buf = cy & 1;
+            o.g0 = g; o.ng = min(cur.g1 - g, a.gcap); o.c0 = c; o.nc = min(cur.c1 - c, a.ccap);
+            __syncthreads();  // the evaluating wavefronts are done with the previous slice
+            if (mine) {
+              Stage so;
+              request_gen(o, so, lt, kLT);
+              commit_gen(o, so, lt, kLT);
+            }
+            __syncthreads();
+            g += o.ng; c += o.nc;
+          }
+        };
+        auto active = [&](int cy) {
+          if (a.dbg & 64) { __syncthreads(); return; }  // (timing ablation: barriers only)
+          commit(batch_of(cy + 1), st);  // requested two steps ago
+          overflow(cy, true);
+          request(batch_of(cy + 3), st);  // in flight across the next two barriers
+          __syncthreads();  // step cy + 1 is in LDS; nobody reads step cy's rows / cell / slices any more
+        };
+        auto passive = [&](int cy) {
+          if (a.dbg & 64) { __syncthreads(); return; }
+          overflow(cy, false);
+          __syncthreads();
+        };
+        if (grp == 0) {
+          request(batch_of(1), st);
+          __syncthreads();
+          for (int cy = 0; cy < steps; cy += 2) {
+            active(cy);
+            passive(cy + 1);
+          }
+        } else {
+          request(batch_of(2), st);
+          __syncthreads();
+          for (int cy = 0; cy < steps; cy += 2) {
+            passive(cy);
+            active(cy + 1);
+          }
+        }
+      } else {
+        __syncthreads();
+        SB_T(p1);
+        SB_ACC(5, p1, p0); SB_ACC(6, 1, 0);
+        for (int cy = 0; cy < steps; ++cy) {
+          if (cy >= a.cell_rows) {  // (the padding step of an odd walk)
+            __syncthreads();
+            break;
+          }
+          if (a.dbg & 64) { __syncthreads(); continue; }
+          const int buf = cy & 1;
+          SB_T(t1);
+          const Seg cur = seg_of(cy);
+          Win w;
+          w.wy0 = win_y0(cy);
+          w.s0 = (w.wy0 - a.ymin) % a.R;
+          w.wh_ok = strip_ok && win_y1(cy) - w.wy0 >= H ? (unsigned)(win_y1(cy) - w.wy0 - H) : 0u;
+          w.sy0 = (unsigned)(cy * a.sb_h);
+          w.sh_ok = (unsigned)(min(cy * a.sb_h + a.sb_h, a.s_ymax) - cy * a.sb_h - H);
+          const bool step_ok = strip_ok && win_y1(cy) - w.wy0 >= H && min(cy * a.sb_h + a.sb_h, a.s_ymax) - cy * a.sb_h >= H;
+          int g = cur.g0, c = cur.c0;
+          bool first = true;
+          do {
+            const int ng = min(cur.g1 - g, a.gcap), nc = min(cur.c1 - c, a.ccap);
+            if (!first) {
+              __syncthreads();
+              __syncthreads();  // the loaders have put the next slices in place
+            }
+            if (!(a.dbg & 1)) {
+              if (step_ok) {
+                eval(w, buf, g, ng, c, nc);
+              } else {  // a window / cell lower or narrower than the block: nothing can be served from LDS
+                for (int gi = slot; gi < ng; gi += kPerWg) {
+                  const uint32_t *e = reinterpret_cast<const uint32_t *>(glist + g + gi);
+                  const uint32_t e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
+                  const int sx = (int16_t)e0, sy = (int16_t)(e0 >> 16);
+                  uint32_t acc[4];
+                  acc[0] = group_sum<G::kTpc>(generic_ref(sx, sy, (int16_t)e1, (int16_t)e3));
+                  acc[1] = group_sum<G::kTpc>(generic_ref(sx, sy, (int16_t)(e1 >> 16), (int16_t)(e3 >> 16)));
+                  acc[2] = group_sum<G::kTpc>(generic_ref(sx, sy, (int16_t)e2, (int16_t)e4));
+                  acc[3] = group_sum<G::kTpc>(generic_ref(sx, sy, (int16_t)(e2 >> 16), (int16_t)(e4 >> 16)));
+                  if (lane_in_cand == 0)
+                    reinterpret_cast<uint4 *>(out4)[(int64_t)f_rel * n_groups + g + gi] =
+                        make_uint4(finish(acc[0]), finish(acc[1]), finish(acc[2]), finish(acc[3]));
+                }
+                for (int ci = slot; ci < nc; ci += kPerWg) {
+                  const uint32_t *e = reinterpret_cast<const uint32_t *>(clist + c + ci);
+                  const uint32_t e0 = e[0], e1 = e[1];
+                  const uint32_t v = group_sum<G::kTpc>(generic_ref((int16_t)e0, (int16_t)(e0 >> 16), (int16_t)e1, (int16_t)(e1 >> 16)));
+                  if (lane_in_cand == 0) out1[(int64_t)f_rel * n_cands + c + ci] = finish(v);
+                }
+              }
+            }
+            g += ng; c += nc;
+            first = false;
+          } while (g < cur.g1 || c < cur.c1);
+          SB_T(t2);
+          __syncthreads();
+          SB_T(t4);
+          SB_ACC(1, t2, t1); SB_ACC(3, t4, t2); SB_ACC(4, 1, 0);
+        }
+      }
     }
-    // ---- remaining rounds (crowded buckets; every round for large blocks)
-    for (; gi < it.g1; gi += kPerWg) generic_group(it, gi, groups[(int64_t)it.f_rel * group_frame_stride + gi]);
-    for (; ci < it.c1; ci += kPerWg) {
-      const aomhip_sad_cand d = cands[(int64_t)it.f_rel * cand_frame_stride + ci];
-      store1(it, ci, generic_ref(it, d.sx, d.sy, d.rx, d.ry));
-    }
-    __syncthreads();  // every lane is done reading this window
-    it = n1;
-    d_it = d_n1;
-    n1 = n2;
-    d_n1 = d_n2;
-  }
+  };
+  if (is_loader) run(std::true_type{}); else run(std::false_type{});
+  SB_FLUSH;
 }
 
 struct SbLaunch {
   hipStream_t stream;
-  int n_frames;
-  int grid;
-  int threads;
+  int grid, threads, upl;
   size_t lds_bytes;
-  SbArgs a;
+  StripArgs a;
   const aomhip_sad_x4d_cand *groups;
   const int32_t *group_off;
   int n_groups;
@@ -447,27 +768,25 @@ struct SbLaunch {
   uint32_t *out1;
 };
 
-template <typename T, int W, int H, bool SKIP, int kThreads>
+template <typename T, int W, int H, bool SKIP, int kThreads, int UPL>
 static int launch_nt(const SbLaunch &l, const PlaneView<T> &s, const PlaneView<T> &r) {
-  auto k = sad_sb_kernel<T, W, H, SKIP, kThreads>;
+  auto k = sad_strip_kernel<T, W, H, SKIP, kThreads, UPL>;
   static thread_local size_t granted = 0;  // per instantiation
   if (l.lds_bytes > granted) {
     AOMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)l.lds_bytes));
     granted = l.lds_bytes;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)l.grid), dim3(kThreads), l.lds_bytes, l.stream, s, r, l.a,
+  hipLaunchKernelGGL(k, dim3((unsigned)l.grid), dim3(kThreads + 64 * sb::kLoaders), l.lds_bytes, l.stream, s, r, l.a,
                      l.groups, l.group_off, l.n_groups, l.gfs, l.out4, l.cands, l.cand_off, l.n_cands, l.cfs, l.out1);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
 
-// 512-lane workgroups when two windows fit a CU (they overlap each other), 1024-lane ones when only one does.
+// 512 evaluating lanes (2 row units per lane: 8 lanes per 16x16 8-bit block) + the loader wavefront.
 template <typename T, int W, int H, bool SKIP>
 static int launch(const SbLaunch &l, const PlaneView<T> &s, const PlaneView<T> &r) {
-  // blocks with 64 lanes per candidate keep 512 lanes: 1024 would only add idle slots for the few blocks of a cell
-  if (l.threads == 1024 && Geom<T, W, H, SKIP>::kTpc < 64) return launch_nt<T, W, H, SKIP, 1024>(l, s, r);
-  return launch_nt<T, W, H, SKIP, 512>(l, s, r);
+  return launch_nt<T, W, H, SKIP, sb::kEvalThreads, 2>(l, s, r);
 }
 
 #define AOMHIP_FOR_BLOCK_SIZES(X)                                                                                \
@@ -484,10 +803,20 @@ static int dispatch(const SbLaunch &l, bool skip, const PlaneView<T> &s, const P
   return AOMHIP_ERR_INVALID;
 }
 
+static unsigned magic_of(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+
 }  // namespace sb
 }  // namespace aomhip
 
 using namespace aomhip;
+
+#ifdef AOMHIP_SB_PROF
+extern "C" int aomhip_debug_sb_prof(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sb::g_sb_prof), 64) != hipSuccess) return AOMHIP_ERR_HIP;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sb::g_sb_prof), z, 64) != hipSuccess) return AOMHIP_ERR_HIP; }
+  return AOMHIP_OK;
+}
+#endif
 
 extern "C" int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame,
                                    int n_frames, int bw, int bh, int flags, int sb_w, int sb_h, int range,
@@ -529,44 +858,80 @@ extern "C" int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
               src->width, src->height);
     return AOMHIP_ERR_INVALID;
   }
-  if (n_buckets == 0 || n_frames == 0) return AOMHIP_OK;
-  const int es = ref->bit_depth > 8 ? 2 : 1;
-  const int pitch = (((sb_w + 2 * range) * es + 15) & ~15) + sb::kLdsPadBytes;
-  const size_t lds_bytes = (size_t)pitch * (sb_h + 2 * range) + 48;
-  if (lds_bytes > 160 * 1024) {
-    set_error("reference window %d x %d (%zu bytes) exceeds the 160 KB LDS of a CU", sb_w + 2 * range, sb_h + 2 * range,
-              lds_bytes);
+  if (cells_per_row > 256) {
+    set_error("at most 256 cells per row (%d of width %d)", cells_per_row, sb_w);
     return AOMHIP_ERR_INVALID;
   }
+  if (n_buckets == 0 || n_frames == 0) return AOMHIP_OK;
+  const int es = ref->bit_depth > 8 ? 2 : 1, epc = 16 / es;
   sb::SbLaunch l;
+  sb::StripArgs &a = l.a;
+  memset(&a, 0, sizeof(a));
+  // Rows travel as 16-byte chunks (one spare chunk when the window start is not chunk aligned by construction).  The LDS
+  // row pitches are odd multiples of 16 bytes (ring) / not multiples of 64 (source cell), so that the rows a block's
+  // lanes read at the same column fall into distinct LDS banks.
+  const bool aligned = (sb_w % epc) == 0 && (range % epc) == 0 && (ref->border % epc) == 0;
+  a.cpr = ((sb_w + 2 * range) * es + 15) / 16 + (aligned ? 0 : 1);
+  a.pitch = (a.cpr | 1) * 16;
+  a.R = 2 * sb_h + 2 * range;
+  a.scpr = (sb_w * es + 15) / 16 + (((sb_w % epc) == 0 && (src->border % epc) == 0) ? 0 : 1);
+  a.spitch = ((a.scpr & 3) == 0 ? a.scpr + 1 : a.scpr) * 16;
+  if (sb_h * a.cpr > sb::kRingN * sb::kLT || sb_h * a.scpr > sb::kSrcN * sb::kLT) {
+    set_error("a step of %d rows x (%d + %d) bytes exceeds what the loader wavefronts keep in flight (%d + %d KB): use a lower cell",
+              sb_h, a.cpr * 16, a.scpr * 16, sb::kRingN * sb::kLT / 64, sb::kSrcN * sb::kLT / 64);
+    return AOMHIP_ERR_INVALID;
+  }
+  const size_t ring_bytes = (size_t)(a.R + sb::mirror_rows(bh)) * a.pitch, cell_bytes = (size_t)sb_h * a.spitch;
+  const size_t kLds = 160 * 1024, misc_bytes = 72 * 4 + 256 + (size_t)cell_rows * 16 + 16;
+  if (ring_bytes + 2 * cell_bytes + misc_bytes + 4 * 256 > kLds) {
+    set_error("LDS ring of %d rows x %d bytes + two %d x %d source cells (%zu bytes) exceed the 160 KB LDS of a CU: "
+              "use a lower cell (sb_h) or a narrower one", a.R, a.pitch, sb_w, sb_h, ring_bytes + 2 * cell_bytes);
+    return AOMHIP_ERR_INVALID;
+  }
+  {  // the rest of the LDS holds the list slices: two buffers, groups (20 B) and candidates (8 B) in equal numbers
+    size_t per_buf = (kLds - ring_bytes - 2 * cell_bytes - misc_bytes) / 2;
+    if (per_buf > 16 * 1024) per_buf = 16 * 1024;
+    int cap = (int)((per_buf - 32) / 28);
+    if (cap > sb::kGN * sb::kLT / 5) cap = sb::kGN * sb::kLT / 5;  // what the loader lanes hold per step
+    if (cap > sb::kCN * sb::kLT / 2) cap = sb::kCN * sb::kLT / 2;
+    if (const char *e = getenv("AOMHIP_SB_DESC_CAP")) cap = atoi(e) < cap && atoi(e) > 0 ? atoi(e) : cap;  // tests: force the crowded-bucket path
+    a.gcap = a.ccap = cap;
+    size_t off = 0;
+    a.ring_off = 0; off += ring_bytes;
+    for (int i = 0; i < 2; ++i) { a.src_off[i] = (int)off; off += cell_bytes; }
+    for (int i = 0; i < 2; ++i) {
+      a.gdesc_off[i] = (int)off; off += ((size_t)cap * 20 + 15) & ~(size_t)15;
+      a.cdesc_off[i] = (int)off; off += ((size_t)cap * 8 + 15) & ~(size_t)15;
+    }
+    a.misc_off = (int)off; a.seg_off = (int)((off + 72 * 4 + 256 + 15) & ~(size_t)15); off += misc_bytes;
+    l.lds_bytes = (off + 15) & ~(size_t)15;
+  }
+  a.magic_cpr = sb::magic_of(a.cpr); a.magic_scpr = sb::magic_of(a.scpr); a.magic_R = sb::magic_of(a.R);
+  a.first_frame = first_frame; a.n_frames = n_frames;
+  a.sb_w = sb_w; a.sb_h = sb_h; a.range = range; a.cells_per_row = cells_per_row; a.cell_rows = cell_rows;
+  a.xmin = -ref->border; a.xmax = ref->width + ref->border; a.ymin = -ref->border; a.ymax = ref->height + ref->border;
+  a.row_end = ref->stride - ref->border; a.border = ref->border;
+  a.s_xmax = src->width + src->border; a.s_ymax = src->height + src->border; a.s_row_end = src->stride - src->border;
+  a.s_border = src->border;
+  a.shift = src->bit_depth == 10 ? 2 : src->bit_depth == 12 ? 4 : 0;
+  if (const char *e = getenv("AOMHIP_SB_DBG")) a.dbg = atoi(e);
   l.stream = ctx->stream;
-  l.n_frames = n_frames;
-  l.lds_bytes = lds_bytes;
-  l.a.first_frame = first_frame;
-  l.a.sb_w = sb_w; l.a.sb_h = sb_h; l.a.range = range; l.a.cells_per_row = cells_per_row;
-  l.a.xmin = -ref->border; l.a.xmax = ref->width + ref->border;
-  l.a.ymin = -ref->border; l.a.ymax = ref->height + ref->border;
-  l.a.n_buckets = n_buckets;
-  l.a.buckets8 = (n_buckets + 7) & ~7;
-  l.a.pitch = pitch;
-  l.a.dummy_off = pitch * (sb_h + 2 * range) + 32;  // (the 32 bytes before it absorb the 5th dword of edge reads)
-  l.a.shift = src->bit_depth == 10 ? 2 : src->bit_depth == 12 ? 4 : 0;
-  l.a.n_items = l.a.buckets8 * n_frames;
-  {  // persistent grid: what the chip holds at once, a multiple of 8 so that item % 8 keeps naming one XCD
+  {  // persistent grid: what the chip holds at once, a multiple of 8 so that blockIdx % 8 keeps naming one XCD
     static thread_local int cus = 0;
     if (!cus) {
       hipDeviceProp_t prop;
       AOMHIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
       cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int per_cu = (int)((160 * 1024) / lds_bytes) < 1 ? 1 : (int)((160 * 1024) / lds_bytes);
-    int grid = cus * (per_cu > 2 ? 2 : per_cu);
+    const int per_cu = (int)(kLds / l.lds_bytes) < 1 ? 1 : (int)(kLds / l.lds_bytes);
     l.threads = per_cu >= 2 ? 512 : 1024;
+    int grid = cus * (per_cu > 2 ? 2 : per_cu);
     if (const char *e = getenv("AOMHIP_SB_THREADS")) l.threads = atoi(e);
     if (const char *e = getenv("AOMHIP_SB_GRID")) grid = atoi(e);
     grid &= ~7;
     if (grid < 8) grid = 8;
-    if (grid > l.a.n_items) grid = l.a.n_items;
+    const int items = n_frames * cells_per_row;
+    if (n_frames < 8 && grid > items) grid = items;
     l.grid = grid;
   }
   l.groups = n_groups > 0 ? d_groups : nullptr; l.group_off = d_group_bucket_offsets; l.n_groups = n_groups; l.gfs = group_frame_stride;

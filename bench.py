@@ -111,17 +111,18 @@ class SadModeA:
         self.h_cands, self.h_groups0 = base_c, allg[0].copy()
         self.d_cands = ctx.to_device(base_c) if n else None
         self.d_groups = ctx.to_device(allg) if n else None
-        # Superblock-bucketed copy of the same lists (aomhip_sad_sb_batch), range 64: cells of 384x128 pixels for
-        # 8-bit planes (512 x 256-byte window + row padding = 136 KB of LDS), 128x128 for 10/12-bit (256 x 512 bytes).
-        # It is the path the step uses (2.1x / 1.6x the direct kernels); AOMHIP_SAD_PATH=direct|sb overrides.
+        # Superblock-bucketed copy of the same lists (aomhip_sad_sb_batch), range 64.  The kernel walks STRIPS (columns of
+        # cells) with the reference window in an LDS ring, so a cell is one step of that walk: 32 rows high, and as wide
+        # as the LDS ring of 2*32 + 128 rows allows (profiles/r02_sad_strip.md: 480 / 384 px for 8-bit 1080p / 4K,
+        # 160 px for 10-bit).  It is the path the step uses; AOMHIP_SAD_PATH=direct|sb overrides.
         self.path = os.environ.get("AOMHIP_SAD_PATH", "sb")
         # Cells are anchored at x = 0, tile columns start at multiples of their width: a cell width that divides the
-        # column width keeps every cell inside one rank's column (a straddling cell would stage its whole window for
-        # a fraction of its blocks).  Tuned width when it divides, else the largest divisor that fits LDS.
-        tuned, widest = (384, 384) if bd == 8 else (128, 176)
+        # column width keeps every strip inside one rank's column.  Tuned width when it divides, else the largest
+        # divisor below it.
+        tuned = (480 if W <= 1920 else 384) if bd == 8 else 160
         col_w = pkg.partition.column_of_rank(W, world, 0)[1] - pkg.partition.column_of_rank(W, world, 0)[0]
-        cw = tuned if col_w % tuned == 0 else max([d for d in range(16, widest + 1, 16) if col_w % d == 0] or [tuned])
-        self.cell = (cw, 128)
+        cw = tuned if col_w % tuned == 0 else max([d for d in range(16, tuned + 1, 16) if col_w % d == 0] or [tuned])
+        self.cell = (cw, 32)
         self.d_sb = None
         if n and self.path == "sb":
             perm, off = synth.bucket_order(base_c["sx"], base_c["sy"], W, H, *self.cell)
@@ -728,29 +729,41 @@ def run_workload(pkg, ctx, dist, dev, rank, world, name, steps, warmup, want_cpu
     if wl.path == "sb":  # dominant (only) kernel of the step: all five candidates of every block in one launch
         k_ms = kernel_avg_ms(ctx, wl.launch_sb, max(steps, 10))
         x4d_bytes = 5 * wl.blocks_per_frame * wl.ring * wl.bytes_per_cand()
-        kname, traffic = "sad_sb_kernel<16x16>", load_traffic(name + ":sb")
+        kname, traffic = "sad_strip_kernel<16x16>", load_traffic(name + ":sb")
     else:
         k_ms = kx_ms
         x4d_bytes = 4 * wl.blocks_per_frame * wl.ring * wl.bytes_per_cand()
         kname, traffic = "sad_x4d_kernel<16x16>", load_traffic(name)
-    ach = x4d_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    # Roofline of the dominant kernel, as an HBM figure: COMPULSORY bytes = every visible source and reference byte of
+    # the ring once + the work-list entries read + the results written (a launch cannot move less), over the launch
+    # time, against the 8 TB/s spec peak.  The SURVEY 8(d) per-candidate figure (516 / 1028 B) counts overlapping
+    # reference bytes once per candidate -- they are served by LDS, so that rate (`achieved_algorithmic`) is not an
+    # HBM rate and is never divided by the HBM peak.  `traffic` = fabric bytes per launch from the PMC passes.
+    cfg = wl.cfg
+    es = 1 if cfg["bit_depth"] == 8 else 2
+    col_px = wl.tile[1] - wl.tile[0]
+    n_blk = wl.blocks_per_frame
+    compulsory = wl.ring * (2 * col_px * cfg["height"] * es + n_blk * (5 * 4 + 20 + 8)) if wl.path == "sb" else x4d_bytes
+    ach = compulsory / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    alg = x4d_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     res = {
         "workload": name, "value": total * steps / wall, "unit": "candidates/s", "ms_per_step": wall / steps * 1e3,
         "event_ms_per_step": ev_ms / steps, "candidates_per_step": total, "parity_frame0": ok,
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                     "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": x4d_bytes,
-                     "note": "achieved = ALGORITHMIC bytes (516 B per 8-bit 16x16 candidate, 1028 B 10-bit) / launch time; "
-                             "overlapping candidates are served by L2/Infinity Cache, so compare with `traffic`"},
-        "kernels": {"path": wl.path, "sad_sb_kernel_avg_ms": k_ms if wl.path == "sb" else None,
+                     "avg_launch_ms": k_ms, "compulsory_bytes_per_launch": compulsory,
+                     "achieved_algorithmic": alg, "algorithmic_bytes_per_launch": x4d_bytes,
+                     "note": "achieved / frac = COMPULSORY bytes (each visible src + ref byte of this rank's tile column once, "
+                             "+ lists + results) / launch time; achieved_algorithmic = 516 B (1028 B 10-bit) per candidate / "
+                             "launch time, an LDS-side rate that is NOT an HBM rate"},
+        "kernels": {"path": wl.path, "cell": list(wl.cell), "sad_strip_kernel_avg_ms": k_ms if wl.path == "sb" else None,
                     "sad_x4d_kernel_avg_ms": kx_ms, "sad_cand_kernel_avg_ms": k1_ms},
         "ring_frames": wl.ring, "blocks_per_frame_this_rank": wl.blocks_per_frame, "tile_column_px": list(wl.tile),
     }
-    if traffic and k_ms > 0:  # the mandatory companion figure and the cache-bound rule
+    if traffic and k_ms > 0:  # the mandatory companion figure
         res["roofline"]["traffic_GBs"] = traffic / (k_ms * 1e-3) / 1e9
         res["roofline"]["traffic_frac_of_peak"] = res["roofline"]["traffic_GBs"] / HBM_PEAK_GBS
-        res["roofline"]["regime"] = ("cache-bound: algorithmic bytes exceed measured fabric traffic by %.2fx"
-                                     % (x4d_bytes / traffic)) if x4d_bytes > 1.5 * traffic else "hbm-bound"
+        res["roofline"]["traffic_over_compulsory"] = traffic / compulsory
     if want_cpu and rank == 0 and orc is not None:
         res["cpu_baseline"] = wl.cpu_baseline(orc)
     wl.free()

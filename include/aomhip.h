@@ -159,17 +159,23 @@ int aomhip_sad_avg_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip
  * laid out the way the encoder's per-superblock call sites issue them (av1/encoder/encodeframe.c:1069
  * encode_sb_row; motion vectors confined by av1_set_mv_search_range, av1/encoder/mcomp.c:101).
  *   The visible plane is cut into cells of sb_w x sb_h pixels, raster order, cells_per_row =
- *   ceil(width / sb_w); n_buckets must equal the number of cells.  Bucket b holds the entries whose SOURCE
+ *   ceil(width / sb_w) (<= 256); n_buckets must equal the number of cells.  Bucket b holds the entries whose SOURCE
  *   block starts inside cell b: entries [d_*_bucket_offsets[b], d_*_bucket_offsets[b + 1]) of the list.  The
- *   offsets are shared by all frames (frame f uses list + f_rel * *_frame_stride, 0 = one shared list).
+ *   offsets are shared by all frames (frame f uses list + f_rel * *_frame_stride, 0 = one shared list).  Lists are
+ *   4-byte aligned.
  *   Every reference block is expected to lie within `range` pixels of its cell
- *   ([cell_x0 - range, cell_x0 + sb_w + range) x likewise in y): persistent workgroups stage that window in LDS
- *   (the next cell's window is in flight while the current one is evaluated) and serve all the bucket's
- *   candidates from it.  An entry outside the window is still evaluated exactly, from global memory -- the
- *   contract is about speed, not validity.
- *   Either list may be NULL (then its offsets / output are ignored).  The window
- *   (sb_w + 2 range) x (sb_h + 2 range) x bytes-per-pixel (+ 16 B per row) must fit the 160 KB LDS of a CU.
- *   Measured best on MI355X at range 64: 384 x 128 cells for 8-bit planes, 128 x 128 for 10/12-bit.
+ *   ([cell_x0 - range, cell_x0 + sb_w + range) x likewise in y) and every source block inside its cell: a persistent
+ *   workgroup walks one column of cells of one frame top to bottom with the reference window in an LDS ring of
+ *   2 sb_h + 2 range rows (each step brings in the sb_h new rows, the step's source cell and its list slices), and
+ *   serves the entries from LDS.  An entry that breaks the expectation is still evaluated exactly, from global memory --
+ *   the contract is about speed, not validity.  Lists of any shape are served (several entries per block, groups
+ *   without single candidates, ...); a group and a single candidate at the same list position that share their source
+ *   block (Mode-A style) read it once.
+ *   Either list may be NULL (then its offsets / output are ignored).  LDS budget (160 KB per CU):
+ *   (2 sb_h + 2 range [+ block height - 1 when <= 16]) x (sb_w + 2 range) x bytes-per-pixel for the ring + two source
+ *   cells + two list-slice buffers; one step may carry at most 20 KB of ring rows and 16 KB of source rows.
+ *   Measured best on MI355X at range 64 (profiles/r02_sad_strip.md): 480 x 32 / 384 x 32 cells for 8-bit 1080p / 4K
+ *   planes, 160 x 32 for 10/12-bit.
  *   Outputs: d_out_groups[(f_rel * n_groups + i) * 4 + k], d_out_cands[f_rel * n_cands + i]. */
 int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame,
                         int n_frames, int bw, int bh, int flags, int sb_w, int sb_h, int range, int n_buckets,

@@ -60,7 +60,7 @@ def test_all_block_sizes(hip, oracle, ctx, w, h, bd):
     cands, groups = _lists(hip, rng, W, H, w, h, 24, n_extra_far=5)
     if len(groups) > 600:
         keep = np.sort(rng.choice(len(groups), 600, replace=False)); cands, groups = cands[keep], groups[keep]
-    sbw, sbh = (128, 64) if bd > 8 else (128, 128)
+    sbw, sbh = (128, 32) if bd > 8 else (128, 64)
     for flags in (0, 1):
         gs, cs, out4, out1 = _run(hip, ctx, ps, pr, 1, 1, w, h, flags, sbw, sbh, 32, cands, groups, W, H)
         assert np.array_equal(out4[0], oracle.sad_x4d_batch(sb, rb, border, w, h, gs, skip=bool(flags), bd=bd)), (w, h, bd, flags)
@@ -68,7 +68,7 @@ def test_all_block_sizes(hip, oracle, ctx, w, h, bd):
     ctx.planes_free(ps); ctx.planes_free(pr)
 
 
-@pytest.mark.parametrize("sbw,sbh,search", [(128, 128, 64), (384, 128, 64), (64, 64, 16), (128, 64, 64), (256, 32, 8), (48, 80, 20), (128, 128, 0)])
+@pytest.mark.parametrize("sbw,sbh,search", [(96, 48, 64), (384, 32, 64), (480, 32, 64), (64, 64, 16), (128, 64, 64), (256, 32, 8), (48, 80, 20), (128, 128, 0), (640, 16, 64)])
 def test_geometries_and_partial_lists(hip, oracle, ctx, sbw, sbh, search):
     rng = np.random.default_rng(sbw + sbh + search)
     W, H, border, bd = 704, 416, 160, 8
@@ -112,7 +112,7 @@ def test_per_frame_lists_and_frame_ring(hip, oracle, ctx):
         frames.append((oracle.extend_plane(s, border, ps.stride), oracle.extend_plane(r, border, pr.stride)))
     per = [_lists(hip, rng, W, H, 16, 16, 64) for _ in range(F)]
     cands = np.concatenate([p[0] for p in per]); groups = np.concatenate([p[1] for p in per])
-    gs, cs, out4, out1 = _run(hip, ctx, ps, pr, 1, F, 16, 16, 0, 128, 128, 64, cands, groups, W, H, cfs=1, gfs=1)
+    gs, cs, out4, out1 = _run(hip, ctx, ps, pr, 1, F, 16, 16, 0, 128, 64, 64, cands, groups, W, H, cfs=1, gfs=1)
     n = len(per[0][0])
     for f in range(F):
         sb, rb = frames[f]
@@ -129,7 +129,7 @@ def test_full_size_4k_mode_a(hip, oracle, ctx, bd):
     ps, pr = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
     ctx.planes_upload(ps, 0, src); ctx.planes_upload(pr, 0, ref)
     cands, groups = hip.synth.mode_a_worklist(W, H, 16, seed=5, search=64)
-    sbw, sbh = (384, 128) if bd == 8 else (128, 128)  # the bench's cells
+    sbw, sbh = (384, 32) if bd == 8 else (160, 32)  # the bench's cells
     gs, cs, out4, out1 = _run(hip, ctx, ps, pr, 0, 1, 16, 16, 0, sbw, sbh, 64, cands, groups, W, H)
     n = len(gs)
     d_g, d_c, d_o4, d_o1 = ctx.to_device(gs), ctx.to_device(cs), ctx.malloc(n * 16), ctx.malloc(n * 4)
@@ -141,5 +141,30 @@ def test_full_size_4k_mode_a(hip, oracle, ctx, bd):
     assert np.array_equal(out4[0], oracle.sad_x4d_batch(sb, rb, border, 16, 16, gs, bd=bd, threads=8))
     assert np.array_equal(out1[0], oracle.sad_batch(sb, rb, border, 16, 16, cs, bd=bd, threads=8))
     for d in (d_g, d_c, d_o4, d_o1):
+        ctx.free(d)
+    ctx.planes_free(ps); ctx.planes_free(pr)
+
+
+def test_crowded_buckets_overflow_the_descriptor_buffers(hip, oracle, ctx, monkeypatch):
+    """More entries in a cell than one LDS descriptor buffer holds: the cell is evaluated in several slices."""
+    monkeypatch.setenv("AOMHIP_SB_DESC_CAP", "24")
+    rng = np.random.default_rng(77)
+    W, H, border, bd = 320, 192, 160, 8
+    src = hip.synth.lcg_frame(W, H, 5, 0, bd); ref = hip.synth.lcg_frame(W, H, 6, 1, bd)
+    ps, pr = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(ps, 0, src); ctx.planes_upload(pr, 0, ref)
+    sb, rb = oracle.extend_plane(src, border, ps.stride), oracle.extend_plane(ref, border, pr.stride)
+    cands, groups = _lists(hip, rng, W, H, 8, 8, 16)   # 8x8 blocks: 128 entries per 128x64 cell
+    cands = np.concatenate([cands, cands[::3]])        # unequal list lengths: 171 candidates vs 128 groups per cell
+    cands["rx"] += rng.integers(-8, 9, len(cands)).astype(np.int16)
+    pg, og = hip.synth.bucket_order(groups["sx"], groups["sy"], W, H, 128, 64)
+    pc, oc = hip.synth.bucket_order(cands["sx"], cands["sy"], W, H, 128, 64)
+    gs, cs = groups[pg], cands[pc]
+    d_g, d_c, d_og, d_oc = ctx.to_device(gs), ctx.to_device(cs), ctx.to_device(og), ctx.to_device(oc)
+    d_o4, d_o1 = ctx.malloc(len(gs) * 16), ctx.malloc(len(cs) * 4)
+    ctx.sad_sb_batch(ps, pr, 0, 1, 8, 8, 0, 128, 64, 16, len(og) - 1, d_g, d_og, len(gs), 0, d_o4, d_c, d_oc, len(cs), 0, d_o1)
+    assert np.array_equal(ctx.from_device(d_o4, (len(gs), 4), np.uint32), oracle.sad_x4d_batch(sb, rb, border, 8, 8, gs))
+    assert np.array_equal(ctx.from_device(d_o1, (len(cs),), np.uint32), oracle.sad_batch(sb, rb, border, 8, 8, cs))
+    for d in (d_g, d_c, d_og, d_oc, d_o4, d_o1):
         ctx.free(d)
     ctx.planes_free(ps); ctx.planes_free(pr)

@@ -19,7 +19,7 @@ def main(tag, wl):
     for f in glob.glob(os.path.join(base, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            short = "sad_sb" if "sad_sb_kernel" in k else "sad_x4d" if "sad_x4d_kernel" in k else "sad_cand" if "sad_cand_kernel" in k else None
+            short = "sad_sb" if ("sad_sb_kernel" in k or "sad_strip_kernel" in k) else "sad_x4d" if "sad_x4d_kernel" in k else "sad_cand" if "sad_cand_kernel" in k else None
             if short:
                 acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
     m = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
