@@ -26,6 +26,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The CPU-baseline leg pins its OpenMP threads, one per physical core (set before liboracle / libgomp load).
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 FRAMES_OVERRIDE = 0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -89,11 +92,14 @@ class SadModeA:
         self.src = ctx.planes_alloc(W, H, self.border, bd, self.ring)
         self.ref = ctx.planes_alloc(W, H, self.border, bd, self.ring)
         self.host_pair0 = None
+        self.host_frames = []  # every base frame pair (the CPU baseline walks the same ring as the GPU)
         for f in range(self.F):  # ring slots beyond F re-use the F base frames' pixels
             s = synth.lcg_frame(W, H, 2 * f, 0, bd)
             r = synth.lcg_frame(W, H, 2 * f + 1, 0, bd)
             if f == 0:
                 self.host_pair0 = (s, r)
+            if rank == 0:
+                self.host_frames.append((s, r))
             for k in range(world):
                 ctx.planes_upload(self.src, f + k * self.F, s)
                 ctx.planes_upload(self.ref, f + k * self.F, r)
@@ -109,6 +115,7 @@ class SadModeA:
         allg["rx"] = allg["sx"][..., None] + rng.integers(-64, 65, (self.ring, n, 4), dtype=np.int16)
         allg["ry"] = allg["sy"][..., None] + rng.integers(-64, 65, (self.ring, n, 4), dtype=np.int16)
         self.h_cands, self.h_groups0 = base_c, allg[0].copy()
+        self.h_groups_all = allg[:self.F] if rank == 0 else None
         self.d_cands = ctx.to_device(base_c) if n else None
         self.d_groups = ctx.to_device(allg) if n else None
         # Superblock-bucketed copy of the same lists (aomhip_sad_sb_batch), range 64.  The kernel walks STRIPS (columns of
@@ -182,30 +189,28 @@ class SadModeA:
         ok &= np.array_equal(got4, orc.sad_x4d_batch(sb, rb, self.border, 16, 16, self.h_groups0, bd=bd, threads=4))
         return bool(ok)
 
-    def cpu_baseline(self, orc, target_s=12.0):
-        """Oracle ("port") on the host cores over a bounded sample of the same work list."""
-        s, r = self.host_pair0
-        sb = orc.extend_plane(s, self.border, self.src.stride)
-        rb = orc.extend_plane(r, self.border, self.ref.stride)
+    def cpu_baseline(self, orc, seconds=5.0):
+        """The same Mode-A ring on the host cores (oracle/aomref_bench.c, kind "port"): static partition of the candidate
+        list over the threads, thread-private results, every base frame pair of the ring; scalar C and AVX2-intrinsics
+        kernels, one thread and all physical cores (pinned: OMP_PROC_BIND=close OMP_PLACES=cores)."""
         bd = self.cfg["bit_depth"]
-        threads = min(orc.lib.orc_max_threads(), os.cpu_count() or 1)
-        full_c, full_g = self.pkg.synth.mode_a_worklist(self.cfg["width"], self.cfg["height"], 16, seed=1)
-
-        def passes(reps):
-            orc.sad_batch(sb, rb, self.border, 16, 16, full_c, bd=bd, threads=threads, reps=reps)
-            orc.sad_x4d_batch(sb, rb, self.border, 16, 16, full_g, bd=bd, threads=threads, reps=reps)
-        passes(4)
-        t0 = time.perf_counter()
-        passes(16)
-        dt = max(time.perf_counter() - t0, 1e-6) / 16
-        reps = int(min(max(target_s / dt, 16), 200000))
-        t0 = time.perf_counter()
-        passes(reps)
-        dt = time.perf_counter() - t0
-        n = 5 * len(full_c) * reps
-        return {"value": n / dt, "unit": "candidates/s", "cores": threads, "kind": "port",
-                "sample": "%d passes over the full-frame Mode-A list of frame pair 0 (%d candidates per pass), "
-                          "oracle C (gcc -O3 -mavx2), one OpenMP static loop over candidates" % (reps, 5 * len(full_c))}
+        sp = [orc.extend_plane(s, self.border, self.src.stride) for s, _ in self.host_frames]
+        rp = [orc.extend_plane(r, self.border, self.ref.stride) for _, r in self.host_frames]
+        groups = np.ascontiguousarray(self.h_groups_all).reshape(-1)
+        phys, logical, model = orc.physical_cores()
+        phys = min(phys, orc.lib.orc_max_threads())
+        legs = {}
+        for name, threads, avx2, secs in (("scalar_1_thread", 1, 0, seconds * 0.6), ("avx2_1_thread", 1, 1, seconds * 0.6),
+                                          ("scalar_all_physical_cores", phys, 0, seconds), ("avx2_all_physical_cores", phys, 1, seconds)):
+            rate, done, el = orc.bench_sad_mode_a(sp, rp, self.border, self.h_cands, groups, bd, threads, avx2, secs)
+            legs[name] = {"candidates_per_s": rate, "threads": threads, "seconds": el, "candidates": done}
+        best = legs["avx2_all_physical_cores"]
+        return {"value": best["candidates_per_s"], "unit": "candidates/s", "cores": phys, "kind": "port",
+                "cpu_model": model, "logical_cpus": logical, "legs": legs,
+                "sample": "%d candidates = whole passes over the Mode-A lists of all %d base frame pairs of the ring (%.1f s), "
+                          "oracle/aomref_bench.c AVX2-intrinsics 16x16 SAD (gcc -O3 -mavx2), static partition over %d pinned "
+                          "threads (one per physical core); `legs` has the scalar-C and 1-thread figures"
+                          % (best["candidates"], len(sp), best["seconds"], phys)}
 
     def free(self):
         c = self.ctx
@@ -232,8 +237,11 @@ class TxqGrid:
         rng = np.random.default_rng(seed)
         self.h_res0 = ((rng.integers(0, 1 << 16, (self.H, self.W)) & 511) - 256).astype(np.int16)
         self.d_res = ctx.malloc(frames * self.H * self.W * 2)
+        self.h_planes = []
         for f in range(frames):
             plane = self.h_res0 if f == 0 else ((rng.integers(0, 1 << 16, (self.H, self.W)) & 511) - 256).astype(np.int16)
+            if f < 8:
+                self.h_planes.append(plane)  # the CPU baseline walks 8 planes (34 MB: past any core's private caches)
             pkg.capi.check(pkg.capi.lib.aomhip_memcpy_h2d(ctx.h, self.d_res + f * self.H * self.W * 2,
                                                           plane.ctypes.data, plane.nbytes), "h2d")
         self.samples = frames * self.H * self.W
@@ -262,22 +270,24 @@ class TxqGrid:
                                                   False, threads=8)
         return bool(np.array_equal(gq, wq) and np.array_equal(ge, we))
 
-    def cpu_baseline(self, target_s=8.0):
-        threads = min(self.orc.lib.orc_max_threads(), os.cpu_count() or 1)
-
-        def passes(reps):
-            for ts, n in TXQ_SIZES:
-                nb = (self.W // n) * (self.H // n)
-                self.orc.xform_quant_batch(self.h_res0, ts, None, nb, self.W // n, 0, self.qt, False, nb * n * n, False,
-                                           threads=threads, reps=reps)
-        passes(1)
-        t0 = time.perf_counter(); passes(2); dt = max(time.perf_counter() - t0, 1e-6) / 2
-        reps = int(min(max(target_s / dt, 2), 5000))
-        t0 = time.perf_counter(); passes(reps); dt = time.perf_counter() - t0
-        per_pass = sum((self.W // n) * (self.H // n) for _, n in TXQ_SIZES)
-        return {"value": per_pass * reps / dt, "unit": "blocks/s", "cores": threads, "kind": "port",
-                "sample": "%d passes over all 4x4/8x8/16x16/32x32 blocks of residual plane 0 (%d blocks per pass), "
-                          "oracle C (gcc -O3 -mavx2), OpenMP static over blocks" % (reps, per_pass)}
+    def cpu_baseline(self, seconds=4.0):
+        """fwd_txfm2d + quantize_b over every 4x4 / 8x8 / 16x16 / 32x32 block of the residual planes on the host cores
+        (oracle/aomref_bench.c): blocks partitioned statically over pinned threads, thread-private outputs; scalar C, and
+        scalar transform + AVX2 quantiser; one thread and all physical cores."""
+        phys, logical, model = self.orc.physical_cores()
+        phys = min(phys, self.orc.lib.orc_max_threads())
+        planes = self.h_planes
+        legs = {}
+        for name, threads, avx2, secs in (("scalar_1_thread", 1, 0, seconds * 0.6), ("scalar_all_physical_cores", phys, 0, seconds),
+                                          ("scalar_txfm+avx2_quant_all_physical_cores", phys, 1, seconds)):
+            rate, done, el = self.orc.bench_txq(planes, self.qt, threads, avx2, secs)
+            legs[name] = {"blocks_per_s": rate, "threads": threads, "seconds": el, "blocks": done}
+        best = legs["scalar_txfm+avx2_quant_all_physical_cores"]
+        return {"value": best["blocks_per_s"], "unit": "blocks/s", "cores": phys, "kind": "port", "cpu_model": model,
+                "logical_cpus": logical, "legs": legs,
+                "sample": "%d blocks = whole passes over all 4x4/8x8/16x16/32x32 blocks of %d residual planes (%.1f s), oracle C "
+                          "forward transform (scalar, gcc -O3 -mavx2 auto-vectorised) + AVX2-intrinsics quantize_b, static "
+                          "partition over %d pinned threads" % (best["blocks"], len(planes), best["seconds"], phys)}
 
     def free(self):
         for d in (self.d_res, self.d_q, self.d_dq, self.d_eob):

@@ -18,10 +18,10 @@ void orc_sad_batch(const void *src_origin, int src_stride, const void *ref_origi
                    int bd, int w, int h, int skip, const orc_cand *c, int n, uint32_t *out, int threads, int reps) {
   if (threads < 1) threads = 1;
   if (reps < 1) reps = 1;
-  /* reps > 1: the CPU-baseline leg walks the same list `reps` times inside one parallel loop */
+  /* static partition of the list over the threads; reps > 1 repeats each thread's own slice (no shared output lines) */
 #pragma omp parallel for num_threads(threads) schedule(static)
-  for (long long it = 0; it < (long long)n * reps; ++it) {
-    const int i = (int)(it % n);
+  for (int i = 0; i < n; ++i)
+   for (int rep = 0; rep < reps; ++rep) {
     if (!elem16) {
       const uint8_t *s = (const uint8_t *)src_origin + (ptrdiff_t)c[i].sy * src_stride + c[i].sx;
       const uint8_t *r = (const uint8_t *)ref_origin + (ptrdiff_t)c[i].ry * ref_stride + c[i].rx;
@@ -40,8 +40,8 @@ void orc_sad_x4d_batch(const void *src_origin, int src_stride, const void *ref_o
   if (threads < 1) threads = 1;
   if (reps < 1) reps = 1;
 #pragma omp parallel for num_threads(threads) schedule(static)
-  for (long long it = 0; it < (long long)n * reps; ++it) {
-    const int i = (int)(it % n);
+  for (int i = 0; i < n; ++i)
+   for (int rep = 0; rep < reps; ++rep) {
     for (int k = 0; k < 4; ++k) {
       if (!elem16) {
         const uint8_t *s = (const uint8_t *)src_origin + (ptrdiff_t)g[i].sy * src_stride + g[i].sx;
@@ -82,8 +82,8 @@ void orc_xform_quant_batch(const int16_t *residual, int stride, int tx_size, con
   if (threads < 1) threads = 1;
   if (reps < 1) reps = 1;
 #pragma omp parallel for num_threads(threads) schedule(static)
-  for (long long it = 0; it < (long long)n * reps; ++it) {
-    const int i = (int)(it % n);
+  for (int i = 0; i < n; ++i)
+   for (int rep = 0; rep < reps; ++rep) {
     int32_t full[64 * 64];
     const int bx = blocks ? blocks[i].x : (i % grid_cols) * w, by = blocks ? blocks[i].y : (i / grid_cols) * h;
     const int tt = blocks ? blocks[i].tx_type : uniform_type;

@@ -195,6 +195,66 @@ def sad_batch(src_b, ref_b, border, w, h, cands, skip=False, bd=8, threads=1, re
     return out
 
 
+def physical_cores():
+    """(physical cores, logical CPUs, model name) of this host (Linux /proc/cpuinfo; SMT siblings counted once)."""
+    cores, model, logical = set(), "unknown", 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                logical += 1
+            elif k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+                cores.add((phys, core))
+    except OSError:
+        pass
+    import os
+    logical = logical or (os.cpu_count() or 1)
+    return (len(cores) or logical), logical, model
+
+
+def bench_sad_mode_a(src_planes, ref_planes, border, cands, groups, bd, threads, avx2, seconds):
+    """bench.py's CPU baseline for the Mode-A SAD workload (oracle/aomref_bench.c): F bordered frame pairs, the shared
+    single-candidate list and F per-frame x4d lists; -> (candidates/s, candidates, elapsed s)."""
+    F = len(src_planes)
+    cands, groups = np.ascontiguousarray(cands), np.ascontiguousarray(groups)
+    n = len(cands)
+    assert groups.shape[0] == F * n
+    so = (C.c_void_p * F)(*[_addr(p, border, border) for p in src_planes])
+    ro = (C.c_void_p * F)(*[_addr(p, border, border) for p in ref_planes])
+    el, ck = C.c_double(), C.c_ulonglong()
+    f = lib.orc_bench_sad_mode_a
+    f.restype = C.c_longlong
+    f.argtypes = None
+    done = f(so, ro, C.c_int(F), C.c_int(src_planes[0].shape[1]), C.c_int(ref_planes[0].shape[1]),
+             C.c_int(int(src_planes[0].dtype != np.uint8)), C.c_int(bd), C.c_void_p(cands.ctypes.data),
+             C.c_void_p(groups.ctypes.data), C.c_int(n), C.c_int(threads), C.c_int(int(avx2)), C.c_double(seconds),
+             C.byref(el), C.byref(ck))
+    return done / el.value, done, el.value
+
+
+def bench_txq(planes, q, threads, avx2_quant, seconds):
+    """bench.py's CPU baseline for fwd_txfm2d + quantize_b over all 4x4..32x32 blocks of int16 residual planes;
+    -> (blocks/s, blocks, elapsed s)."""
+    P = len(planes)
+    H, W = planes[0].shape
+    ptrs = (C.c_void_p * P)(*[p.ctypes.data for p in planes])
+    qa = np.ascontiguousarray([q[k] for k in ("zbin", "round", "quant", "quant_shift", "dequant")], np.int16)
+    el, ck = C.c_double(), C.c_ulonglong()
+    f = lib.orc_bench_txq
+    f.restype = C.c_longlong
+    f.argtypes = None
+    done = f(ptrs, C.c_int(P), C.c_int(W), C.c_int(H), C.c_void_p(qa.ctypes.data), C.c_int(threads), C.c_int(int(avx2_quant)),
+             C.c_double(seconds), C.byref(el), C.byref(ck))
+    return done / el.value, done, el.value
+
+
 def sad_x4d_batch(src_b, ref_b, border, w, h, groups, skip=False, bd=8, threads=1, reps=1):
     groups = np.ascontiguousarray(groups)
     out = np.empty((len(groups), 4), np.uint32)
