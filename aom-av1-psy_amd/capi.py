@@ -187,6 +187,22 @@ for _name, (_res, _args) in _protos.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
+# The rtcd-signature conformance surface (host pointers; the tests call these with explicit ctypes arguments).
+RTCD_TX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16), (32, 64), (64, 32),
+                 (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]  # TX_SIZE order (av1/common/enums.h)
+RTCD_STAMPED = (["aomhip_%squantize_b%s%s" % (h, sz, a) for h in ("", "highbd_") for sz in ("", "_32x32", "_64x64") for a in ("", "_adaptive")] +
+                ["aomhip_%s_%dx%d" % (k, w, hh) for k in ("fwd_txfm2d", "inv_txfm2d_add") for w, hh in RTCD_TX_SIZES] +
+                ["aomhip_%slpf_%s_%d%s" % (h, d, n, k) for h in ("", "highbd_") for d in ("horizontal", "vertical") for n in (4, 6, 8, 14)
+                 for k in (("", "_dual", "_quad") if not h else ("", "_dual"))] +
+                ["aomhip_cdef_filter_%d_%d" % (b, v) for b in (8, 16) for v in range(4)])
+for _name in RTCD_STAMPED + ["aomhip_fwd_txfm2d", "aomhip_inv_txfm2d_add", "aomhip_subtract_block", "aomhip_highbd_subtract_block",
+                             "aomhip_cdef_find_dir_dual", "aomhip_status_clear"]:
+    getattr(lib, _name).restype = None  # raises AttributeError if the library lacks the symbol
+    _protos[_name] = (None, None)
+for _name, _res in (("aomhip_cdef_find_dir", C.c_int), ("aomhip_rtcd", C.c_int), ("aomhip_status", C.c_int), ("aomhip_failure_count", C.c_long)):
+    getattr(lib, _name).restype = _res
+    _protos[_name] = (_res, None)
+
 EXPORTED = sorted(_protos)
 
 

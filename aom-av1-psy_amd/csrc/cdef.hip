@@ -479,6 +479,75 @@ __global__ __launch_bounds__(256) void cdef_chroma_kernel(const PIX *__restrict_
 
 using namespace aomhip;
 
+
+// ---- the reference's block-level primitives on staged blocks (rtcd-signature entry points) ----
+// cdef_find_dir_c (cdef_block.c:57-126) for `n` 8x8 blocks (n = 2: cdef_find_dir_dual_c), lane = block.
+__global__ __launch_bounds__(64) void cdef_find_dir_kernel(const uint16_t *__restrict__ img, int n, int coeff_shift, int32_t *__restrict__ out) {
+  const int b = threadIdx.x;
+  if (b >= n) return;
+  int x[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) x[i] = (int)(img[b * 64 + i] >> coeff_shift) - 128;
+  int cost[8];
+  cost[0] = dir_cost<0>(x); cost[1] = dir_cost<1>(x); cost[2] = dir_cost<2>(x); cost[3] = dir_cost<3>(x);
+  cost[4] = dir_cost<4>(x); cost[5] = dir_cost<5>(x); cost[6] = dir_cost<6>(x); cost[7] = dir_cost<7>(x);
+  int best = 0, best_cost = 0;
+#pragma unroll
+  for (int d = 0; d < 8; ++d)
+    if (cost[d] > best_cost) { best_cost = cost[d]; best = d; }
+  int orth = 0;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) orth = d == ((best + 4) & 7) ? cost[d] : orth;
+  out[2 * b] = best;
+  out[2 * b + 1] = (best_cost - orth) >> 10;
+}
+
+// cdef_filter_block_internal (cdef_block.c:139-281) = cdef_filter_{8,16}_{0..3}_c: `in` is the staged (bh + 4) x (bw + 4)
+// neighbourhood (2 pixels on every side, row pitch bw + 4) of the uint16 input whose stride was CDEF_BSTRIDE; lane = pixel.
+__global__ __launch_bounds__(64) void cdef_filter_block_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, int bw, int bh,
+                                                               int pri_strength, int sec_strength, int dir, int pri_damping,
+                                                               int sec_damping, int coeff_shift, int enable_primary, int enable_secondary) {
+  const int t = threadIdx.x;
+  if (t >= bw * bh) return;
+  const int i = t / bw, j = t % bw, s = bw + 4;
+  const uint16_t *c = in + (i + 2) * s + (j + 2);
+  constexpr int pri_taps[2][2] = { { 4, 2 }, { 3, 3 } };
+  constexpr int sec_taps[2] = { 2, 1 };
+  const int ps = (pri_strength >> coeff_shift) & 1;
+  const bool clip = enable_primary && enable_secondary;
+  const int x = c[0];
+  int sum = 0, mx = x, mn = x;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (enable_primary) {
+      const int o = kDirDyDx[dir][k][0] * s + kDirDyDx[dir][k][1];
+      const int p0 = c[o], p1 = c[-o];
+      sum += pri_taps[ps][k] * (constrain_d(p0 - x, pri_strength, pri_damping) + constrain_d(p1 - x, pri_strength, pri_damping));
+      if (clip) {
+        if (p0 != kVeryLarge) mx = max(mx, p0);
+        if (p1 != kVeryLarge) mx = max(mx, p1);
+        mn = min(mn, min(p0, p1));
+      }
+    }
+    if (enable_secondary) {
+      const int o1 = kDirDyDx[(dir + 2) & 7][k][0] * s + kDirDyDx[(dir + 2) & 7][k][1];
+      const int o2 = kDirDyDx[(dir + 6) & 7][k][0] * s + kDirDyDx[(dir + 6) & 7][k][1];
+      const int q[4] = { c[o1], c[-o1], c[o2], c[-o2] };
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (clip) {
+          if (q[m] != kVeryLarge) mx = max(mx, q[m]);
+          mn = min(mn, q[m]);
+        }
+        sum += sec_taps[k] * constrain_d(q[m] - x, sec_strength, sec_damping);
+      }
+    }
+  }
+  int y = (int)(int16_t)x + ((8 + (int)(int16_t)sum - ((int16_t)sum < 0)) >> 4);
+  if (clip) y = y < mn ? mn : (y > mx ? mx : y);
+  out[t] = (uint16_t)y;
+}
+
 template <typename PIX, bool SEARCH>
 static void launch_chroma(hipStream_t st, dim3 grid, int xdec, int ydec, const void *s, void *d, int stride, int w, int h,
                           const uint8_t *dir, const uint8_t *pri, const uint8_t *sec, int fbs, const uint8_t *skip,
@@ -608,6 +677,63 @@ int aomhip_cdef_search_sse_chroma(aomhip_ctx *ctx, const aomhip_planes *recon, i
                                   d_strengths, d_strengths, fb_stride, d_skip8x8, damping, recon->bit_depth - 8, sa);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
+}
+
+
+// cdef_find_dir / cdef_find_dir_dual (av1/common/av1_rtcd_defs.pl:504-506) on host pointers.
+int aomhip_cdef_find_dir(const uint16_t *img, int stride, int32_t *var, int coeff_shift) {
+  *var = 0;
+  aomhip_ctx *ctx = default_ctx();
+  if (!ctx) return 0;
+  const size_t total = 128 + 16;
+  char *h = static_cast<char *>(pinned(ctx, total)), *d = static_cast<char *>(scratch(ctx, total));
+  if (!h || !d) { note_failure("aomhip_cdef_find_dir scratch", AOMHIP_ERR_NOMEM); return 0; }
+  for (int r = 0; r < 8; ++r) memcpy(h + r * 16, img + (ptrdiff_t)r * stride, 16);
+  if (hipMemcpyAsync(d, h, 128, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { note_failure("aomhip_cdef_find_dir H2D"); return 0; }
+  hipLaunchKernelGGL(cdef_find_dir_kernel, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<const uint16_t *>(d), 1, coeff_shift,
+                     reinterpret_cast<int32_t *>(d + 128));
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h + 128, d + 128, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) { note_failure("aomhip_cdef_find_dir"); return 0; }
+  const int32_t *o = reinterpret_cast<const int32_t *>(h + 128);
+  *var = o[1];
+  return o[0];
+}
+void aomhip_cdef_find_dir_dual(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1, int32_t *var2, int coeff_shift,
+                               int *out1, int *out2) {
+  *out1 = aomhip_cdef_find_dir(img1, stride, var1, coeff_shift);
+  *out2 = aomhip_cdef_find_dir(img2, stride, var2, coeff_shift);
+}
+
+// cdef_filter_{8,16}_{0..3} (av1_rtcd_defs.pl:508-519): dst8 is a uint8_t (is_16 = 0) or uint16_t (is_16 = 1) block, `in` points
+// into the 16-bit CDEF_BSTRIDE (144) buffer with its 2-pixel borders; variant _0 = primary + secondary, _1 primary only,
+// _2 secondary only, _3 neither (cdef_block.c:232-281).
+void aomhip_cdef_filter_any(void *dst8, int dstride, const uint16_t *in, int pri_strength, int sec_strength, int dir, int pri_damping,
+                            int sec_damping, int coeff_shift, int block_width, int block_height, int is_16, int variant) {
+  aomhip_ctx *ctx = default_ctx();
+  if (!ctx) return;
+  if (block_width < 1 || block_height < 1 || block_width * block_height > 64 || variant < 0 || variant > 3 || dir < 0 || dir > 7) {
+    set_error("aomhip_cdef_filter: unsupported block %dx%d / variant %d", block_width, block_height, variant);
+    return note_failure("aomhip_cdef_filter", AOMHIP_ERR_INVALID);
+  }
+  const int enable_primary = variant == 0 || variant == 1, enable_secondary = variant == 0 || variant == 2;
+  const int s = block_width + 4, rows = block_height + 4;
+  const size_t in_bytes = (size_t)s * rows * 2, out_off = (in_bytes + 15) & ~(size_t)15, total = out_off + 128;
+  char *h = static_cast<char *>(pinned(ctx, total)), *d = static_cast<char *>(scratch(ctx, total));
+  if (!h || !d) return note_failure("aomhip_cdef_filter scratch", AOMHIP_ERR_NOMEM);
+  for (int r = 0; r < rows; ++r) memcpy(h + (size_t)r * s * 2, in + (ptrdiff_t)(r - 2) * 144 - 2, (size_t)s * 2);
+  if (hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return note_failure("aomhip_cdef_filter H2D");
+  hipLaunchKernelGGL(cdef_filter_block_kernel, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<const uint16_t *>(d),
+                     reinterpret_cast<uint16_t *>(d + out_off), block_width, block_height, pri_strength, sec_strength, dir, pri_damping,
+                     sec_damping, coeff_shift, enable_primary, enable_secondary);
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h + out_off, d + out_off, 128, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return note_failure("aomhip_cdef_filter");
+  const uint16_t *o = reinterpret_cast<const uint16_t *>(h + out_off);
+  for (int i = 0; i < block_height; ++i)
+    for (int j = 0; j < block_width; ++j) {
+      if (is_16) static_cast<uint16_t *>(dst8)[(ptrdiff_t)i * dstride + j] = o[i * block_width + j];
+      else static_cast<uint8_t *>(dst8)[(ptrdiff_t)i * dstride + j] = (uint8_t)o[i * block_width + j];
+    }
 }
 
 }  // extern "C"

@@ -26,8 +26,13 @@ struct aomhip_ctx {
 namespace aomhip {
 
 void set_error(const char *fmt, ...);
-[[noreturn]] void fatal(const char *what);  // rtcd-signature paths: report and abort (no fallback)
-aomhip_ctx *default_ctx();                  // lazily created per-thread context for the rtcd-signature paths
+// rtcd-signature paths (the reference's signatures have no error return): record the failure in the process-wide
+// sticky status (aomhip_status()) and let the caller return its defined "failed" value (0 / outputs zeroed).  Never
+// aborts, never longjmps (the encoder's only error path is its own, av1/encoder/encoder.c:947-952) -- unless
+// AOMHIP_ABORT_ON_ERROR=1 asks for the old fail-stop behaviour.  There is still no CPU fallback: a failed call
+// computes nothing.
+void note_failure(const char *what, int status = AOMHIP_ERR_HIP);
+aomhip_ctx *default_ctx();                  // lazily created per-thread context for the rtcd-signature paths; nullptr on failure
 void *scratch(aomhip_ctx *ctx, size_t bytes);
 void *pinned(aomhip_ctx *ctx, size_t bytes);
 

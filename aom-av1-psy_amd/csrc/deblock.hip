@@ -28,14 +28,11 @@ struct __attribute__((packed, aligned(1))) DU128 { uint32_t v[4]; };
 __device__ __forceinline__ int iabsd(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int clampd(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// x[7 + i] holds tap i (i = -7 .. 6: p6 .. p0, q0 .. q6); filters in place.
-__device__ __forceinline__ void lpf_window(int (&x)[14], int len, int level, int sharpness, int bd) {
-  // update_sharpness / av1_loop_filter_frame_init (av1_loopfilter.c:47-66,118-120)
-  int inside = level >> ((sharpness > 0) + (sharpness > 4));
-  if (sharpness > 0 && inside > 9 - sharpness) inside = 9 - sharpness;
-  if (inside < 1) inside = 1;
+// x[7 + i] holds tap i (i = -7 .. 6: p6 .. p0, q0 .. q6); filters in place.  lim8 / blim8 / thr8: the 8-bit thresholds
+// the reference's functions take as *limit / *blimit / *thresh (scaled by bd - 8 inside, loopfilter.c:521-522,568,596).
+__device__ __forceinline__ void lpf_window_thr(int (&x)[14], int len, int lim8, int blim8, int thr8, int bd) {
   const int sh = bd - 8;
-  const int lim = inside << sh, blim = (2 * (level + 2) + inside) << sh, thr = (level >> 4) << sh, one = 1 << sh;
+  const int lim = lim8 << sh, blim = blim8 << sh, thr = thr8 << sh, one = 1 << sh;
   const int p3 = x[3], p2 = x[4], p1 = x[5], p0 = x[6], q0 = x[7], q1 = x[8], q2 = x[9], q3 = x[10];
 
   bool mask = !(iabsd(p1 - p0) > lim || iabsd(q1 - q0) > lim || iabsd(p0 - q0) * 2 + iabsd(p1 - q1) / 2 > blim);
@@ -115,6 +112,42 @@ __device__ __forceinline__ void lpf_window(int (&x)[14], int len, int level, int
     x[6] = clampd(ps0 + f2, lo, hi) + off;
     x[8] = clampd(qs1 - f3, lo, hi) + off;
     x[5] = clampd(ps1 + f3, lo, hi) + off;
+  }
+}
+
+__device__ __forceinline__ void lpf_window(int (&x)[14], int len, int level, int sharpness, int bd) {
+  // update_sharpness / av1_loop_filter_frame_init (av1_loopfilter.c:47-66,118-120)
+  int inside = level >> ((sharpness > 0) + (sharpness > 4));
+  if (sharpness > 0 && inside > 9 - sharpness) inside = 9 - sharpness;
+  if (inside < 1) inside = 1;
+  lpf_window_thr(x, len, inside, 2 * (level + 2) + inside, level >> 4, bd);
+}
+
+// One call of aom_[highbd_]lpf_{horizontal,vertical}_{4,6,8,14}[_dual,_quad] (loopfilter.c:136-511,602-997) on a staged
+// patch: `count` pixels along the edge (4 / 8 / 16), thresholds set 0 for pixels below `second_at`, set 1 from there.
+// patch layout: horizontal edge: rows -reach .. reach - 1 of `count` columns (row pitch = count); vertical edge: `count`
+// rows of 2 * reach columns.  q0 is row / column `reach`.
+template <typename PIX>
+__global__ __launch_bounds__(64) void lpf_edge_kernel(PIX *patch, int horizontal, int len, int count, int second_at, int lim0,
+                                                      int blim0, int thr0, int lim1, int blim1, int thr1, int bd) {
+  const int i = threadIdx.x;
+  if (i >= count) return;
+  const int reach = len == 14 ? 7 : (len == 8 ? 4 : (len == 6 ? 3 : 2));
+  int x[14];
+#pragma unroll
+  for (int k = 0; k < 14; ++k) {
+    const int t = k - 7;
+    x[k] = (t >= -reach && t < reach) ? (int)(horizontal ? patch[(t + reach) * count + i] : patch[i * 2 * reach + t + reach]) : 0;
+  }
+  const bool g1 = i >= second_at;
+  lpf_window_thr(x, len, g1 ? lim1 : lim0, g1 ? blim1 : blim0, g1 ? thr1 : thr0, bd);
+#pragma unroll
+  for (int k = 0; k < 14; ++k) {
+    const int t = k - 7;
+    if (t >= -reach && t < reach) {
+      if (horizontal) patch[(t + reach) * count + i] = (PIX)x[k];
+      else patch[i * 2 * reach + t + reach] = (PIX)x[k];
+    }
   }
 }
 
@@ -225,6 +258,10 @@ int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, con
     set_error("aomhip_deblock_plane: invalid argument");
     return AOMHIP_ERR_INVALID;
   }
+  if ((passes & 1) && p->border < 4) {  // the vertical pass loads the 16-pixel window x - 8 .. x + 7 of every edge (x = 4: from -4)
+    set_error("aomhip_deblock_plane: the vertical pass needs a border of >= 4 pixels (plane has %d)", p->border);
+    return AOMHIP_ERR_INVALID;
+  }
   const size_t esz = p->bit_depth == 8 ? 1 : 2;
   char *origin = static_cast<char *>(p->base) +
                  ((size_t)frame * p->frame_stride + (size_t)p->border * p->stride + p->border) * esz;
@@ -324,6 +361,44 @@ int aomhip_lpf_search_sse(aomhip_ctx *ctx, const aomhip_planes *recon, int recon
     AOMHIP_LAUNCH_CHECK();
   }
   return AOMHIP_OK;
+}
+
+
+// aom_lpf_* / aom_highbd_lpf_* (aom_dsp/aom_dsp_rtcd_defs.pl:474-594) on host pointers: the pixels the reference function
+// touches (reach = 2 / 3 / 4 / 7 each side of the edge, `count` pixels along it) are staged, filtered by the plane
+// kernels' own tap code (lpf_window_thr) and copied back.  is_hbd: `s` is a uint16_t plane.  count 4 (single), 8 (dual:
+// the second four pixels use blimit1 / limit1 / thresh1) or 16 (quad: one threshold set).
+void aomhip_lpf_any(void *s, int pitch, int horizontal, int len, int count, const uint8_t *blimit0, const uint8_t *limit0,
+                    const uint8_t *thresh0, const uint8_t *blimit1, const uint8_t *limit1, const uint8_t *thresh1, int bd,
+                    int is_hbd) {
+  aomhip_ctx *ctx = default_ctx();
+  if (!ctx) return;
+  if ((len != 4 && len != 6 && len != 8 && len != 14) || (count != 4 && count != 8 && count != 16) || (bd != 8 && bd != 10 && bd != 12)) {
+    set_error("aomhip_lpf: unsupported length %d / count %d / bit depth %d", len, count, bd);
+    return note_failure("aomhip_lpf", AOMHIP_ERR_INVALID);
+  }
+  const int reach = len == 14 ? 7 : (len == 8 ? 4 : (len == 6 ? 3 : 2));
+  const size_t esz = is_hbd ? 2 : 1, bytes = (size_t)2 * reach * count * esz;
+  char *h = static_cast<char *>(pinned(ctx, bytes)), *d = static_cast<char *>(scratch(ctx, bytes));
+  if (!h || !d) return note_failure("aomhip_lpf scratch", AOMHIP_ERR_NOMEM);
+  char *base = static_cast<char *>(s);
+  // horizontal edge: 2*reach rows of `count` pixels starting at row -reach; vertical: `count` rows of 2*reach pixels from column -reach
+  const int rows = horizontal ? 2 * reach : count, cols = horizontal ? count : 2 * reach;
+  char *origin = base + (horizontal ? -(ptrdiff_t)reach * pitch : -(ptrdiff_t)reach) * (ptrdiff_t)esz;
+  for (int r = 0; r < rows; ++r) memcpy(h + (size_t)r * cols * esz, origin + (ptrdiff_t)r * pitch * (ptrdiff_t)esz, (size_t)cols * esz);
+  if (hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return note_failure("aomhip_lpf H2D");
+  const int l1 = limit1 ? *limit1 : *limit0, b1 = blimit1 ? *blimit1 : *blimit0, t1 = thresh1 ? *thresh1 : *thresh0;
+  const int second_at = blimit1 ? 4 : count;
+  if (is_hbd)
+    hipLaunchKernelGGL(lpf_edge_kernel<uint16_t>, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<uint16_t *>(d), horizontal, len, count,
+                       second_at, (int)*limit0, (int)*blimit0, (int)*thresh0, l1, b1, t1, bd);
+  else
+    hipLaunchKernelGGL(lpf_edge_kernel<uint8_t>, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<uint8_t *>(d), horizontal, len, count,
+                       second_at, (int)*limit0, (int)*blimit0, (int)*thresh0, l1, b1, t1, 8);
+  if (hipGetLastError() != hipSuccess) return note_failure("aomhip_lpf launch");
+  if (hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return note_failure("aomhip_lpf D2H");
+  for (int r = 0; r < rows; ++r) memcpy(origin + (ptrdiff_t)r * pitch * (ptrdiff_t)esz, h + (size_t)r * cols * esz, (size_t)cols * esz);
 }
 
 }  // extern "C"

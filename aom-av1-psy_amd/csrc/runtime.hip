@@ -1,5 +1,6 @@
 // libaomhip runtime: contexts, streams, device memory, HBM-resident YV12 plane rings.
 // Host side of include/aomhip.h "context" and "planes in HBM".
+#include <atomic>
 #include <cstdarg>
 
 #include "common.h"
@@ -15,10 +16,18 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-void fatal(const char *what) {
-  fprintf(stderr, "libaomhip: fatal in %s: %s\n", what, g_err);
-  fflush(stderr);
-  abort();
+static std::atomic<int> g_sticky{ AOMHIP_OK };
+static std::atomic<long> g_failures{ 0 };
+
+void note_failure(const char *what, int status) {
+  int expected = AOMHIP_OK;
+  g_sticky.compare_exchange_strong(expected, status);  // the first failure wins
+  if (g_failures.fetch_add(1) == 0) {
+    fprintf(stderr, "libaomhip: %s failed: %s (sticky status %d; later failures are counted, not printed)\n", what, g_err, status);
+    fflush(stderr);
+  }
+  static const bool abort_on_error = [] { const char *e = getenv("AOMHIP_ABORT_ON_ERROR"); return e && atoi(e) != 0; }();
+  if (abort_on_error) abort();
 }
 
 static thread_local aomhip_ctx *g_default_ctx = nullptr;
@@ -26,7 +35,10 @@ static thread_local aomhip_ctx *g_default_ctx = nullptr;
 aomhip_ctx *default_ctx() {
   if (!g_default_ctx) {
     const char *dev = getenv("AOMHIP_DEVICE");
-    if (aomhip_ctx_create(dev ? atoi(dev) : 0, nullptr, &g_default_ctx) != AOMHIP_OK) fatal("default context");
+    if (aomhip_ctx_create(dev ? atoi(dev) : 0, nullptr, &g_default_ctx) != AOMHIP_OK) {
+      note_failure("default context", AOMHIP_ERR_NO_DEVICE);
+      g_default_ctx = nullptr;
+    }
   }
   return g_default_ctx;
 }
@@ -90,6 +102,13 @@ using namespace aomhip;
 extern "C" {
 
 int aomhip_abi_version(void) { return AOMHIP_ABI_VERSION; }
+
+int aomhip_status(void) { return g_sticky.load(); }
+long aomhip_failure_count(void) { return g_failures.load(); }
+void aomhip_status_clear(void) {
+  g_sticky.store(AOMHIP_OK);
+  g_failures.store(0);
+}
 
 const char *aomhip_last_error(void) { return g_err; }
 

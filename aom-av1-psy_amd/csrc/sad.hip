@@ -340,10 +340,12 @@ static int wrapper_shift(int bit_depth) { return bit_depth == 10 ? 2 : bit_depth
 template <typename T>
 static void host_sad_multi(const T *src, int src_stride, const T *const refs[], int n_refs, int ref_stride, int bw,
                            int bh, int flags, int shift, uint32_t *result) {
+  for (int k = 0; k < n_refs; ++k) result[k] = 0;  // the defined result of a failed call
   aomhip_ctx *ctx = default_ctx();
+  if (!ctx) return;
   if (!valid_block(bw, bh)) {
     set_error("unsupported block size %dx%d", bw, bh);
-    fatal("aomhip_sad");
+    return note_failure("aomhip_sad", AOMHIP_ERR_INVALID);
   }
   const size_t blk = (size_t)bw * bh * sizeof(T);
   const size_t in_bytes = blk * (1 + n_refs);
@@ -352,7 +354,7 @@ static void host_sad_multi(const T *src, int src_stride, const T *const refs[], 
   const size_t total = out_off + sizeof(uint32_t) * 4;
   char *h = static_cast<char *>(pinned(ctx, total));
   char *d = static_cast<char *>(scratch(ctx, total));
-  if (!h || !d) fatal("aomhip_sad scratch");
+  if (!h || !d) return note_failure("aomhip_sad scratch", AOMHIP_ERR_NOMEM);
   T *hs = reinterpret_cast<T *>(h);
   for (int r = 0; r < bh; ++r) memcpy(hs + (size_t)r * bw, src + (size_t)r * src_stride, (size_t)bw * sizeof(T));
   for (int k = 0; k < n_refs; ++k) {
@@ -363,19 +365,19 @@ static void host_sad_multi(const T *src, int src_stride, const T *const refs[], 
   for (int k = 0; k < n_refs; ++k) hc[k] = aomhip_sad_cand{ 0, 0, 0, (int16_t)(k * bh) };
   if (hipMemcpyAsync(d, h, out_off, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
     set_error("H2D failed");
-    fatal("aomhip_sad");
+    return note_failure("aomhip_sad");
   }
   PlaneView<T> sv{ reinterpret_cast<const T *>(d), 0, bw };
   PlaneView<T> rv{ reinterpret_cast<const T *>(d + blk), 0, bw };
   SadLaunch l{ ctx->stream, 0, 1, flags, shift };
   if (dispatch<T, aomhip_sad_cand>(false, l, sv, rv, bw, bh, reinterpret_cast<const aomhip_sad_cand *>(d + cand_off),
                                    n_refs, 0, reinterpret_cast<uint32_t *>(d + out_off)) != AOMHIP_OK)
-    fatal("aomhip_sad launch");
+    return note_failure("aomhip_sad launch");
   if (hipMemcpyAsync(h + out_off, d + out_off, sizeof(uint32_t) * n_refs, hipMemcpyDeviceToHost, ctx->stream) !=
           hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess) {
     set_error("D2H / sync failed: %s", hipGetErrorString(hipGetLastError()));
-    fatal("aomhip_sad");
+    return note_failure("aomhip_sad");
   }
   memcpy(result, h + out_off, sizeof(uint32_t) * n_refs);
 }

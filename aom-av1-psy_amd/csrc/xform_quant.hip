@@ -682,6 +682,65 @@ __global__ __launch_bounds__(256) void quant_adaptive_kernel(const int32_t *__re
   if (lane == 0) eob[bi] = (uint16_t)last;
 }
 
+// aom_quantize_b* / aom_highbd_quantize_b* with the caller's own scan tables: what the rtcd-signature entry points
+// (aomhip_quantize_b ...) run -- those signatures carry `scan` / `iscan` pointers and a coefficient count instead of a
+// transform size and type.  The same quantize_one as the fused kernels; eob = 1 + max iscan[rc] over non-zero levels
+// (SURVEY 8a': the reference's backward pre-scan only skips coefficients the dead-zone test zeroes anyway).  ADAPT: the
+// adaptive form (quant_adaptive_kernel's three reductions) with positions from the table.  One wavefront per call.
+template <bool HBD, int LS, bool ADAPT>
+__global__ __launch_bounds__(64) void quant_table_kernel(const int32_t *__restrict__ coeff, int n, QuantArgs qa,
+                                                         const int16_t *__restrict__ iscan, int32_t *__restrict__ qcoeff,
+                                                         int32_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob) {
+  const int lane = threadIdx.x;
+  const int zb[2] = { (qa.zbin[0] + ((1 << LS) >> 1)) >> LS, (qa.zbin[1] + ((1 << LS) >> 1)) >> LS };
+  const int rd[2] = { (qa.round[0] + ((1 << LS) >> 1)) >> LS, (qa.round[1] + ((1 << LS) >> 1)) >> LS };
+  const int add1[2] = { (qa.dequant[0] * 325 + 64) >> 7, (qa.dequant[1] * 325 + 64) >> 7 };
+  const int add2[2] = { (qa.dequant[0] * 525 + 64) >> 7, (qa.dequant[1] * 525 + 64) >> 7 };
+  int nzc = n;
+  if constexpr (ADAPT) {
+    nzc = 0;
+    for (int rc = lane; rc < n; rc += 64) {
+      const int ac = rc != 0;
+      const int64_t cw = (int64_t)coeff[rc] * 32;
+      const bool inside = cw < (int64_t)zb[ac] * 32 + add1[ac] && cw > -(int64_t)zb[ac] * 32 - add1[ac];
+      if (!inside) nzc = max(nzc, (int)iscan[rc] + 1);
+    }
+    nzc = group_max<64>(nzc);
+  }
+  int last = 0, first = n;
+  for (int rc = lane; rc < n; rc += 64) {
+    const int ac = rc != 0, pos = iscan[rc];
+    int32_t qv = 0, dv = 0;
+    if (pos < nzc)
+      quantize_one<HBD, LS>(coeff[rc], zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.qs_log2[ac], qa.dequant[ac], &qv, &dv);
+    qcoeff[rc] = qv;
+    dqcoeff[rc] = dv;
+    if (qv) {
+      last = max(last, pos + 1);
+      first = min(first, pos);
+    }
+  }
+  last = group_max<64>(last);
+  if constexpr (ADAPT) {
+    first = -group_max<64>(-first);
+    if (last > 0 && first == last - 1) {  // exactly one non-zero level: drop a lone +-1 inside the wider zone
+      int dropped = 0;
+      for (int rc = lane; rc < n; rc += 64) {
+        if (iscan[rc] == first && (qcoeff[rc] == 1 || qcoeff[rc] == -1)) {
+          const int ac = rc != 0;
+          const int64_t cw = (int64_t)coeff[rc] * 32;
+          if (cw < (int64_t)zb[ac] * 32 + add2[ac] && cw > -(int64_t)zb[ac] * 32 - add2[ac]) {
+            qcoeff[rc] = dqcoeff[rc] = 0;
+            dropped = 1;
+          }
+        }
+      }
+      if (group_max<64>(dropped)) last = 0;
+    }
+  }
+  if (lane == 0) *eob = (uint16_t)last;
+}
+
 struct XqLaunch {
   hipStream_t stream;
   const void *in0, *in1;
@@ -913,6 +972,59 @@ int aomhip_quantize_b_adaptive_batch(aomhip_ctx *ctx, const int32_t *d_coeff, in
 #undef AOMHIP_QA
   set_error("aomhip_quantize_b_adaptive_batch: no kernel for tx_size %d", tx_size);
   return AOMHIP_ERR_INVALID;
+}
+
+
+// The rtcd-signature quantisers (aom_dsp/aom_dsp_rtcd_defs.pl:653-693): host pointers, one launch, synchronous.
+// log_scale 0 / 1 / 2 = aom_quantize_b / _32x32 / _64x64; is_hbd: the aom_highbd_ family; adaptive: the _adaptive family.
+// A failed call records the sticky status (aomhip_status()), zeroes the outputs and returns.
+void aomhip_quantize_b_any(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr,
+                           const int16_t *quant_ptr, const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr,
+                           const int16_t *dequant_ptr, uint16_t *eob_ptr, const int16_t *scan, const int16_t *iscan, int log_scale,
+                           int is_hbd, int adaptive) {
+  (void)scan;
+  const size_t n = (size_t)n_coeffs;
+  memset(qcoeff_ptr, 0, n * 4);
+  memset(dqcoeff_ptr, 0, n * 4);
+  *eob_ptr = 0;
+  aomhip_ctx *ctx = default_ctx();
+  if (!ctx) return;
+  if (n_coeffs <= 0 || n_coeffs > 4096 || log_scale < 0 || log_scale > 2) {
+    set_error("aomhip_quantize_b: n_coeffs %ld / log_scale %d unsupported", (long)n_coeffs, log_scale);
+    return note_failure("aomhip_quantize_b", AOMHIP_ERR_INVALID);
+  }
+  const size_t isc_off = n * 4, q_off = (isc_off + n * 2 + 15) & ~(size_t)15, dq_off = q_off + n * 4, e_off = dq_off + n * 4;
+  const size_t total = e_off + 16;
+  char *h = static_cast<char *>(pinned(ctx, total)), *d = static_cast<char *>(scratch(ctx, total));
+  if (!h || !d) return note_failure("aomhip_quantize_b scratch", AOMHIP_ERR_NOMEM);
+  memcpy(h, coeff_ptr, n * 4);
+  memcpy(h + isc_off, iscan, n * 2);
+  if (hipMemcpyAsync(d, h, q_off, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return note_failure("aomhip_quantize_b H2D");
+  aomhip_quant_params qp;
+  for (int i = 0; i < 2; ++i) {
+    qp.zbin[i] = zbin_ptr[i]; qp.round[i] = round_ptr[i]; qp.quant[i] = quant_ptr[i];
+    qp.quant_shift[i] = quant_shift_ptr[i]; qp.dequant[i] = dequant_ptr[i];
+  }
+  const QuantArgs qa = to_args(&qp);
+  const int32_t *dc = reinterpret_cast<const int32_t *>(d);
+  const int16_t *di = reinterpret_cast<const int16_t *>(d + isc_off);
+  int32_t *dq = reinterpret_cast<int32_t *>(d + q_off), *ddq = reinterpret_cast<int32_t *>(d + dq_off);
+  uint16_t *de = reinterpret_cast<uint16_t *>(d + e_off);
+#define AOMHIP_QT(HBD, LS, AD) \
+  hipLaunchKernelGGL((quant_table_kernel<HBD, LS, AD>), dim3(1), dim3(64), 0, ctx->stream, dc, (int)n, qa, di, dq, ddq, de)
+#define AOMHIP_QT_LS(HBD, AD) \
+  do { if (log_scale == 0) AOMHIP_QT(HBD, 0, AD); else if (log_scale == 1) AOMHIP_QT(HBD, 1, AD); else AOMHIP_QT(HBD, 2, AD); } while (0)
+  if (is_hbd) { if (adaptive) AOMHIP_QT_LS(true, true); else AOMHIP_QT_LS(true, false); }
+  else { if (adaptive) AOMHIP_QT_LS(false, true); else AOMHIP_QT_LS(false, false); }
+#undef AOMHIP_QT_LS
+#undef AOMHIP_QT
+  if (hipGetLastError() != hipSuccess) return note_failure("aomhip_quantize_b launch");
+  if (hipMemcpyAsync(h + q_off, d + q_off, total - q_off, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return note_failure("aomhip_quantize_b D2H");
+  memcpy(qcoeff_ptr, h + q_off, n * 4);
+  memcpy(dqcoeff_ptr, h + dq_off, n * 4);
+  *eob_ptr = *reinterpret_cast<const uint16_t *>(h + e_off);
 }
 
 }  // extern "C"

@@ -23,9 +23,15 @@
  *
  * Error model: the reference's DSP functions have no error return
  * (aom_dsp_rtcd_defs.pl protos are value/void).  Batched calls return an
- * aomhip_status_t; rtcd-signature calls cannot, so any HIP failure there is
- * reported on stderr and the process aborts (there is NO CPU fallback anywhere in
- * this library: a result is either computed on the GPU or not at all).
+ * aomhip_status_t.  rtcd-signature calls cannot: a failure there (no device, a HIP
+ * error, an unsupported size) is recorded in a process-wide STICKY status --
+ * aomhip_status(), first failure wins, reported once on stderr -- and the call
+ * returns its defined "failed" result (0 / outputs zeroed or left untouched).  It
+ * never aborts and never longjmps: the encoder's only error path stays its own
+ * (av1/encoder/encoder.c:947-952), which a caller can take after checking
+ * aomhip_status() at a frame boundary.  AOMHIP_ABORT_ON_ERROR=1 restores fail-stop
+ * for debugging.  There is NO CPU fallback anywhere in this library: a result is
+ * either computed on the GPU or not at all.
  */
 #ifndef AOMHIP_H_
 #define AOMHIP_H_
@@ -62,6 +68,10 @@ void *aomhip_ctx_stream(aomhip_ctx *ctx);        /* the hipStream_t in use */
 int aomhip_device_count(void);                   /* 0 when no GPU is visible */
 const char *aomhip_last_error(void);             /* thread-local text of the last failure */
 int aomhip_abi_version(void);
+/* Sticky status of the rtcd-signature entry points: AOMHIP_OK until the first failure, then that failure's code. */
+int aomhip_status(void);
+long aomhip_failure_count(void);
+void aomhip_status_clear(void);
 
 /* HIP-event timing on the context's stream (bench.py's per-launch durations). */
 int aomhip_timer_begin(aomhip_ctx *ctx);
@@ -776,6 +786,111 @@ unsigned int aomhip_highbd_variance(const uint8_t *a8, int a_stride, const uint8
 unsigned int aomhip_highbd_sub_pixel_variance(const uint8_t *a8, int a_stride, int xoffset, int yoffset,
                                               const uint8_t *b8, int b_stride, int bw, int bh, int bd,
                                               unsigned int *sse);
+
+
+/* ---- the rest of the rtcd surface: host pointers, the reference's exact signatures (tran_low_t = int32_t) ---- */
+
+/* aom_quantize_b / _32x32 / _64x64, aom_highbd_quantize_b*, and the _adaptive forms (aom_dsp/aom_dsp_rtcd_defs.pl:653-693).
+ * `scan` / `iscan` are the caller's tables (av1_scan_orders[tx_size][tx_type]); results equal aom_*_c bit for bit. */
+#define AOMHIP_DECL_QUANTIZE_B(name)                                                                                         \
+  void name(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr,                  \
+            const int16_t *quant_ptr, const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr,             \
+            const int16_t *dequant_ptr, uint16_t *eob_ptr, const int16_t *scan, const int16_t *iscan)
+AOMHIP_DECL_QUANTIZE_B(aomhip_quantize_b);
+AOMHIP_DECL_QUANTIZE_B(aomhip_quantize_b_32x32);
+AOMHIP_DECL_QUANTIZE_B(aomhip_quantize_b_64x64);
+AOMHIP_DECL_QUANTIZE_B(aomhip_highbd_quantize_b);
+AOMHIP_DECL_QUANTIZE_B(aomhip_highbd_quantize_b_32x32);
+AOMHIP_DECL_QUANTIZE_B(aomhip_highbd_quantize_b_64x64);
+AOMHIP_DECL_QUANTIZE_B(aomhip_quantize_b_adaptive);
+AOMHIP_DECL_QUANTIZE_B(aomhip_quantize_b_32x32_adaptive);
+AOMHIP_DECL_QUANTIZE_B(aomhip_quantize_b_64x64_adaptive);
+AOMHIP_DECL_QUANTIZE_B(aomhip_highbd_quantize_b_adaptive);
+AOMHIP_DECL_QUANTIZE_B(aomhip_highbd_quantize_b_32x32_adaptive);
+AOMHIP_DECL_QUANTIZE_B(aomhip_highbd_quantize_b_64x64_adaptive);
+typedef AOMHIP_DECL_QUANTIZE_B((*aomhip_quantize_b_fn));
+
+/* av1_fwd_txfm2d_WxH / av1_inv_txfm2d_add_WxH (av1/common/av1_rtcd_defs.pl:355-399,137-243), the 19 sizes in TX_SIZE order
+ * (av1/common/enums.h).  The forward form writes aomhip_tx_max_eob(tx_size) coefficients (reference layout). */
+#define AOMHIP_RTCD_TX_SIZES(X)                                                                                       \
+  X(4, 4) X(8, 8) X(16, 16) X(32, 32) X(64, 64) X(4, 8) X(8, 4) X(8, 16) X(16, 8) X(16, 32) X(32, 16) X(32, 64) X(64, 32) \
+  X(4, 16) X(16, 4) X(8, 32) X(32, 8) X(16, 64) X(64, 16)
+#define AOMHIP_DECL_TX(W, H)                                                                                  \
+  void aomhip_fwd_txfm2d_##W##x##H(const int16_t *input, int32_t *output, int stride, int tx_type, int bd);   \
+  void aomhip_inv_txfm2d_add_##W##x##H(const int32_t *input, uint16_t *output, int stride, int tx_type, int bd);
+AOMHIP_RTCD_TX_SIZES(AOMHIP_DECL_TX)
+#undef AOMHIP_DECL_TX
+void aomhip_fwd_txfm2d(const int16_t *input, int32_t *output, int stride, int tx_type, int bd, int w, int h);
+void aomhip_inv_txfm2d_add(const int32_t *input, uint16_t *output, int stride, int tx_type, int bd, int w, int h);
+typedef void (*aomhip_fwd_txfm2d_fn)(const int16_t *input, int32_t *output, int stride, int tx_type, int bd);
+typedef void (*aomhip_inv_txfm2d_add_fn)(const int32_t *input, uint16_t *output, int stride, int tx_type, int bd);
+
+/* aom_subtract_block / aom_highbd_subtract_block (aom_dsp_rtcd_defs.pl:723,733; the highbd pointers are CONVERT_TO_BYTEPTR-encoded) */
+void aomhip_subtract_block(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride,
+                           const uint8_t *pred_ptr, ptrdiff_t pred_stride);
+void aomhip_highbd_subtract_block(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src8, ptrdiff_t src_stride,
+                                  const uint8_t *pred8, ptrdiff_t pred_stride);
+
+/* aom_lpf_{horizontal,vertical}_{4,6,8,14}[_dual,_quad] and aom_highbd_lpf_*[_dual] (aom_dsp_rtcd_defs.pl:474-594) */
+#define AOMHIP_DECL_LPF(DIR, LEN)                                                                                                  \
+  void aomhip_lpf_##DIR##_##LEN(uint8_t *s, int pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh);        \
+  void aomhip_lpf_##DIR##_##LEN##_dual(uint8_t *s, int pitch, const uint8_t *blimit0, const uint8_t *limit0, const uint8_t *thresh0, \
+                                       const uint8_t *blimit1, const uint8_t *limit1, const uint8_t *thresh1);                     \
+  void aomhip_lpf_##DIR##_##LEN##_quad(uint8_t *s, int pitch, const uint8_t *blimit0, const uint8_t *limit0, const uint8_t *thresh0); \
+  void aomhip_highbd_lpf_##DIR##_##LEN(uint16_t *s, int pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh, int bd); \
+  void aomhip_highbd_lpf_##DIR##_##LEN##_dual(uint16_t *s, int pitch, const uint8_t *blimit0, const uint8_t *limit0, const uint8_t *thresh0, \
+                                              const uint8_t *blimit1, const uint8_t *limit1, const uint8_t *thresh1, int bd);
+AOMHIP_DECL_LPF(horizontal, 4) AOMHIP_DECL_LPF(horizontal, 6) AOMHIP_DECL_LPF(horizontal, 8) AOMHIP_DECL_LPF(horizontal, 14)
+AOMHIP_DECL_LPF(vertical, 4) AOMHIP_DECL_LPF(vertical, 6) AOMHIP_DECL_LPF(vertical, 8) AOMHIP_DECL_LPF(vertical, 14)
+#undef AOMHIP_DECL_LPF
+typedef void (*aomhip_lpf_fn)(uint8_t *s, int pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh);
+typedef void (*aomhip_lpf_dual_fn)(uint8_t *s, int pitch, const uint8_t *blimit0, const uint8_t *limit0, const uint8_t *thresh0,
+                                   const uint8_t *blimit1, const uint8_t *limit1, const uint8_t *thresh1);
+typedef void (*aomhip_highbd_lpf_fn)(uint16_t *s, int pitch, const uint8_t *blimit, const uint8_t *limit, const uint8_t *thresh, int bd);
+typedef void (*aomhip_highbd_lpf_dual_fn)(uint16_t *s, int pitch, const uint8_t *blimit0, const uint8_t *limit0, const uint8_t *thresh0,
+                                          const uint8_t *blimit1, const uint8_t *limit1, const uint8_t *thresh1, int bd);
+
+/* cdef_find_dir, cdef_find_dir_dual, cdef_filter_{8,16}_{0..3} (av1/common/av1_rtcd_defs.pl:504-519) */
+int aomhip_cdef_find_dir(const uint16_t *img, int stride, int32_t *var, int coeff_shift);
+void aomhip_cdef_find_dir_dual(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1, int32_t *var2, int coeff_shift,
+                               int *out1, int *out2);
+#define AOMHIP_DECL_CDEF(BITS, V)                                                                                               \
+  void aomhip_cdef_filter_##BITS##_##V(void *dst, int dstride, const uint16_t *in, int pri_strength, int sec_strength, int dir, \
+                                       int pri_damping, int sec_damping, int coeff_shift, int block_width, int block_height);
+AOMHIP_DECL_CDEF(8, 0) AOMHIP_DECL_CDEF(8, 1) AOMHIP_DECL_CDEF(8, 2) AOMHIP_DECL_CDEF(8, 3)
+AOMHIP_DECL_CDEF(16, 0) AOMHIP_DECL_CDEF(16, 1) AOMHIP_DECL_CDEF(16, 2) AOMHIP_DECL_CDEF(16, 3)
+#undef AOMHIP_DECL_CDEF
+typedef void (*aomhip_cdef_filter_fn)(void *dst, int dstride, const uint16_t *in, int pri_strength, int sec_strength, int dir, int pri_damping,
+                                      int sec_damping, int coeff_shift, int block_width, int block_height);
+
+/* The installer.  Mirrors setup_rtcd_internal (build/cmake/rtcd.pl:189-209,262-290): a maintainer who adds the pseudo-ISA `hip`
+ * assigns these pointers to the generated globals when the capability probe says HAS_HIP.  Returns
+ * AOMHIP_ERR_NO_DEVICE and an all-NULL table when no GPU is visible, so the caller keeps its C / SIMD pointers.
+ * Index conventions: fwd_txfm2d / inv_txfm2d_add by TX_SIZE; lpf*[0 = horizontal, 1 = vertical][0..3 = length 4, 6, 8, 14];
+ * cdef_filter_8 / _16 by the _0.._3 suffix. */
+typedef struct aomhip_rtcd_table {
+  unsigned int (*sad16x16)(const uint8_t *src_ptr, int src_stride, const uint8_t *ref_ptr, int ref_stride);
+  void (*sad16x16x4d)(const uint8_t *src_ptr, int src_stride, const uint8_t *const ref_ptr[4], int ref_stride, uint32_t sad_array[4]);
+  unsigned int (*variance16x16)(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, unsigned int *sse);
+  void (*subtract_block)(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src_ptr, ptrdiff_t src_stride,
+                         const uint8_t *pred_ptr, ptrdiff_t pred_stride);
+  void (*highbd_subtract_block)(int rows, int cols, int16_t *diff_ptr, ptrdiff_t diff_stride, const uint8_t *src8, ptrdiff_t src_stride,
+                                const uint8_t *pred8, ptrdiff_t pred_stride);
+  aomhip_quantize_b_fn quantize_b, quantize_b_32x32, quantize_b_64x64, highbd_quantize_b, highbd_quantize_b_32x32, highbd_quantize_b_64x64,
+      quantize_b_adaptive, quantize_b_32x32_adaptive, quantize_b_64x64_adaptive, highbd_quantize_b_adaptive, highbd_quantize_b_32x32_adaptive,
+      highbd_quantize_b_64x64_adaptive;
+  aomhip_fwd_txfm2d_fn fwd_txfm2d[19];
+  aomhip_inv_txfm2d_add_fn inv_txfm2d_add[19];
+  aomhip_lpf_fn lpf[2][4], lpf_quad[2][4];
+  aomhip_lpf_dual_fn lpf_dual[2][4];
+  aomhip_highbd_lpf_fn highbd_lpf[2][4];
+  aomhip_highbd_lpf_dual_fn highbd_lpf_dual[2][4];
+  int (*cdef_find_dir)(const uint16_t *img, int stride, int32_t *var, int coeff_shift);
+  void (*cdef_find_dir_dual)(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1, int32_t *var2, int coeff_shift, int *out1,
+                             int *out2);
+  aomhip_cdef_filter_fn cdef_filter_8[4], cdef_filter_16[4];
+} aomhip_rtcd_table;
+int aomhip_rtcd(aomhip_rtcd_table *table);
 
 #ifdef __cplusplus
 }

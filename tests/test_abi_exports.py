@@ -26,6 +26,13 @@ def test_library_exports_every_declared_symbol(hip):
     assert not missing, missing
     # the Python binding declares a prototype for each of them too
     assert sorted(set(names) - set(hip.capi.EXPORTED)) == []
+    # the macro-stamped rtcd names of the header (AOMHIP_DECL_QUANTIZE_B / _TX / _LPF / _CDEF): 12 + 38 + 40 + 8
+    stamped = hip.capi.RTCD_STAMPED
+    assert len(stamped) == 98 and not [n for n in stamped if not hasattr(lib, n)]
+    src = open(os.path.join(ROOT, "include", "aomhip.h")).read()
+    for frag in ("AOMHIP_DECL_QUANTIZE_B(aomhip_highbd_quantize_b_64x64_adaptive)", "AOMHIP_RTCD_TX_SIZES(AOMHIP_DECL_TX)",
+                 "AOMHIP_DECL_LPF(vertical, 14)", "AOMHIP_DECL_CDEF(16, 3)"):
+        assert frag in src
 
 
 def test_abi_version_and_stride_rule(hip):
