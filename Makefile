@@ -7,7 +7,8 @@ LIBDIR := $(PKG)/lib
 HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 SRCS := $(wildcard $(CSRC)/*.hip)
 CPPS := $(wildcard $(CSRC)/*.cpp)
-OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS)) $(patsubst $(CSRC)/%.cpp,build/%.o,$(CPPS))
+HOSTC := $(wildcard $(PKG)/host/*.c)
+OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS)) $(patsubst $(CSRC)/%.cpp,build/%.o,$(CPPS)) $(patsubst $(PKG)/host/%.c,build/host_%.o,$(HOSTC))
 
 all: lib oracle
 lib: $(LIBDIR)/libaomhip.so
@@ -21,6 +22,11 @@ build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) inclu
 build/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/aomhip.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+# the host-side modules are plain C99 (the reference is a C code base): compiled with gcc, no HIP in them
+build/host_%.o: $(PKG)/host/%.c include/aomhip.h
+	@mkdir -p build
+	gcc -std=c99 -pedantic -Wall -Wextra -Werror -O2 -fPIC -Iinclude -c $< -o $@
 
 $(LIBDIR)/libaomhip.so: $(OBJS)
 	@mkdir -p $(LIBDIR)

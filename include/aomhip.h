@@ -788,6 +788,46 @@ unsigned int aomhip_highbd_sub_pixel_variance(const uint8_t *a8, int a_stride, i
                                               unsigned int *sse);
 
 
+/* ------------------------------------------------------------------ producers of the in-loop filter parameter planes (host only) */
+
+/* What the integrator copies out of the encoder's mode-info grid, once per frame and plane, for every 4x4 unit of THAT
+ * plane (for a subsampled chroma plane: the mode info at the odd luma mi row / column, av1_loopfilter.c:240-247):
+ *   tx_size      get_transform_size() for this plane (:197-217: inter_tx_size for inter non-skip luma, the max uv size for
+ *                chroma, TX_4X4 when lossless); 255 = mode info not set up (TX_INVALID, no filtering)
+ *   skip_inter   mbmi->skip_txfm && is_inter_block(mbmi)
+ *   pb_*_log2    log2 of block_size_wide / _high[get_plane_block_size(mbmi->bsize, ss_x, ss_y)] (prediction-unit edges)
+ *   level_v/_h   av1_get_filter_level(cm, &cm->lf_info, VERT_EDGE / HORZ_EDGE, plane, mbmi) (:68-111) -- from
+ *                aomhip_lf_level_table when delta_lf is off */
+typedef struct {
+  uint8_t tx_size, skip_inter, pb_w_log2, pb_h_log2, level_v, level_h;
+} aomhip_lf_unit;
+
+/* set_lpf_parameters (av1/common/av1_loopfilter.c:223-328) at every 4x4 unit of a plane, both edge directions ->
+ * the edge-parameter plane aomhip_deblock_plane takes (4 bytes per unit: len_v, lvl_v, len_h, lvl_h).  is_chroma selects the
+ * 4 / 6 lengths of the chroma planes.  units_stride / edge_stride in units (>= ceil(plane_width / 4)). */
+int aomhip_lf_build_edge_params(const aomhip_lf_unit *units, int units_stride, int plane_width, int plane_height, int is_chroma,
+                                uint8_t *edge_params, int edge_stride);
+
+/* av1_loop_filter_frame_init (av1_loopfilter.c:126-195) for one plane: lvl[segment][dir][ref_frame][mode_lf_lut[mode]], what
+ * av1_get_filter_level returns when cm->delta_q_info.delta_lf_present_flag is 0. */
+typedef struct {
+  int filter_level[2], filter_level_u, filter_level_v; /* cm->lf */
+  int mode_ref_delta_enabled;
+  int8_t ref_deltas[8], mode_deltas[2];
+  int seg_enabled;
+  uint8_t seg_feature_mask[8];      /* bit f = segfeature_active(seg, f) */
+  int16_t seg_feature_data[8][8];   /* get_segdata(seg, f) */
+} aomhip_lf_frame_params;
+void aomhip_lf_level_table(const aomhip_lf_frame_params *fp, int plane, uint8_t lvl[8][2][8][2]);
+
+/* is_8x8_block_skip over the frame (av1/common/cdef.c:24-35; av1_cdef_compute_sb_list :36-68 lists the blocks where this
+ * is 0): mi_skip_txfm holds mbmi->skip_txfm per 4x4 mode-info unit; skip8x8 gets one byte per 8x8 luma block. */
+int aomhip_cdef_build_skip8x8(const uint8_t *mi_skip_txfm, int mi_stride, int mi_rows, int mi_cols, uint8_t *skip8x8, int skip_stride);
+/* cdef.c:296-322: per 64x64 filter block the index its top-left mode info carries (mbmi->cdef_strength, -1 = skipped) ->
+ * primary level and secondary strength (3 -> 4) from cdef_strengths[] / cdef_uv_strengths[] (the uv outputs may be NULL). */
+int aomhip_cdef_build_strengths(const int8_t *fb_strength_index, int n_fb, const int *cdef_strengths, const int *cdef_uv_strengths,
+                                uint8_t *fb_pri, uint8_t *fb_sec, uint8_t *fb_uv_pri, uint8_t *fb_uv_sec);
+
 /* ---- the rest of the rtcd surface: host pointers, the reference's exact signatures (tran_low_t = int32_t) ---- */
 
 /* aom_quantize_b / _32x32 / _64x64, aom_highbd_quantize_b*, and the _adaptive forms (aom_dsp/aom_dsp_rtcd_defs.pl:653-693).

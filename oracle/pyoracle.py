@@ -715,3 +715,82 @@ def mv_limits_for_block(bx, by, w, h, width, height, border, ref_row=0, ref_col=
     col_min, col_max = max(col_min, fc - 1023), min(col_max, fc + 1023)
     row_min, row_max = max(row_min, fr - 1023), min(row_max, fr + 1023)
     return row_min, row_max, col_min, col_max
+
+
+# ---- in-loop filter parameter planes from a mode-info grid (oracle/aomref_filtermaps.c) ----
+mbmi_dtype = np.dtype([("bsize", "u1"), ("tx_size", "u1"), ("inter_tx_size", "u1", (16,)), ("skip_txfm", "u1"), ("mode", "u1"), ("segment_id", "u1"),
+                       ("ref_frame0", "i1"), ("delta_lf_from_base", "i1"), ("delta_lf", "i1", (4,)), ("cdef_strength", "i1")])
+
+
+class LfFrame(C.Structure):
+    _fields_ = [("filter_level", C.c_int * 2), ("filter_level_u", C.c_int), ("filter_level_v", C.c_int), ("mode_ref_delta_enabled", C.c_int),
+                ("ref_deltas", C.c_int8 * 8), ("mode_deltas", C.c_int8 * 2), ("delta_lf_present_flag", C.c_int), ("delta_lf_multi", C.c_int),
+                ("seg_enabled", C.c_int), ("seg_feature_mask", C.c_uint8 * 8), ("seg_feature_data", (C.c_int16 * 8) * 8)]
+
+
+class MiGrid:
+    """blocks: structured array (mbmi_dtype); owner[mi_rows, mi_cols]: index of the block covering each 4x4 mode-info unit (-1: none)."""
+
+    def __init__(self, blocks, owner):
+        self.blocks = np.ascontiguousarray(blocks)
+        self.owner = np.asarray(owner)
+        self.mi_rows, self.mi_cols = self.owner.shape
+        base = self.blocks.ctypes.data
+        ptrs = np.where(self.owner >= 0, base + self.owner.astype(np.int64) * self.blocks.itemsize, 0).astype(np.uint64)
+        # two spare rows / columns of NULL around the grid's far side (the reference's grid is allocated larger than mi_rows x mi_cols)
+        self.ptrs = np.zeros((self.mi_rows + 2, self.mi_cols + 2), np.uint64)
+        self.ptrs[:self.mi_rows, :self.mi_cols] = ptrs
+        self.mi_stride = self.mi_cols + 2
+
+
+def lf_frame_init(frame):
+    lvl = np.zeros((3, 8, 2, 8, 2), np.uint8)
+    lib.orc_lf_frame_init.restype = None
+    lib.orc_lf_frame_init.argtypes = None
+    lib.orc_lf_frame_init(C.byref(frame), C.c_void_p(lvl.ctypes.data))
+    return lvl
+
+
+def lf_edge_plane(grid, frame, lvl, plane, ssx, ssy):
+    """set_lpf_parameters at every 4x4 unit of the plane -> int16 [rows, cols, 5]: len_v, lvl_v, len_h, lvl_h, ts."""
+    w, h = (grid.mi_cols * 4) >> ssx, (grid.mi_rows * 4) >> ssy
+    out = np.zeros((h // 4, w // 4, 5), np.int16)
+    f = lib.orc_set_lpf_parameters
+    f.restype = C.c_int
+    f.argtypes = None
+    fl, lv = C.c_int(), C.c_int()
+    for uy in range(h // 4):
+        for ux in range(w // 4):
+            for d in range(2):
+                ts = f(C.c_void_p(grid.ptrs.ctypes.data), C.c_int(grid.mi_stride), C.byref(frame), C.c_void_p(lvl.ctypes.data), C.c_int(d),
+                       C.c_uint(4 * ux), C.c_uint(4 * uy), C.c_int(plane), C.c_int(ssx), C.c_int(ssy), C.c_uint(w), C.c_uint(h), C.byref(fl), C.byref(lv))
+                out[uy, ux, 2 * d], out[uy, ux, 2 * d + 1] = fl.value, lv.value
+                out[uy, ux, 4] = ts
+    return out
+
+
+def lf_units(grid, frame, lvl, plane, ssx, ssy):
+    """The compact description aomhip_lf_build_edge_params takes: uint8 [rows, cols, 6] = aomhip_lf_unit."""
+    w, h = (grid.mi_cols * 4) >> ssx, (grid.mi_rows * 4) >> ssy
+    u = np.zeros((h // 4, w // 4, 6), np.uint8)
+    lib.orc_lf_units.restype = None
+    lib.orc_lf_units.argtypes = None
+    lib.orc_lf_units(C.c_void_p(grid.ptrs.ctypes.data), C.c_int(grid.mi_stride), C.byref(frame), C.c_void_p(lvl.ctypes.data), C.c_int(plane),
+                     C.c_int(ssx), C.c_int(ssy), C.c_int(w), C.c_int(h), C.c_void_p(u.ctypes.data))
+    return u
+
+
+def cdef_skip_map(grid):
+    """1 where av1_cdef_compute_sb_list leaves an 8x8 block out (all four mode infos skip_txfm), over the whole grid."""
+    skip = np.ones((grid.mi_rows // 2, grid.mi_cols // 2), np.uint8)
+    f = lib.orc_cdef_compute_sb_list
+    f.restype = C.c_int
+    f.argtypes = None
+    buf = np.zeros(512, np.uint8)
+    for fr in range((grid.mi_rows + 15) // 16):
+        for fc in range((grid.mi_cols + 15) // 16):
+            n = f(C.c_void_p(grid.ptrs.ctypes.data), C.c_int(grid.mi_stride), C.c_int(grid.mi_rows), C.c_int(grid.mi_cols), C.c_int(fr * 16),
+                  C.c_int(fc * 16), C.c_void_p(buf.ctypes.data))
+            for i in range(n):
+                skip[fr * 8 + buf[2 * i], fc * 8 + buf[2 * i + 1]] = 0
+    return skip

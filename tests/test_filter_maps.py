@@ -1,0 +1,191 @@
+"""Producers of the in-loop filter parameter planes (aom-av1-psy_amd/host/filter_maps.c, plain C, no GPU):
+  * the oracle's mode-info walk (oracle/aomref_filtermaps.c) reproduces the interpreted reference -- set_lpf_parameters,
+    av1_get_filter_level, av1_loop_filter_frame_init, av1_cdef_compute_sb_list on random mode-info grids
+    (tests/golden/ref_eval_filtermaps.npz) -- bit for bit;
+  * the product's producers, fed the compact per-unit description, give the same edge-parameter / skip / strength planes,
+    on the fixture grids and on fresh random grids against the oracle."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+BW = [4, 4, 8, 8, 8, 16, 16, 16, 32, 32, 32, 64, 64, 64, 128, 128, 4, 16, 8, 32, 16, 64]
+BH = [4, 8, 4, 8, 16, 8, 16, 32, 16, 32, 64, 32, 64, 128, 64, 128, 16, 4, 32, 8, 64, 16]
+TXW = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
+TXH = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
+
+
+class LfFrameParams(C.Structure):  # aomhip_lf_frame_params
+    _fields_ = [("filter_level", C.c_int * 2), ("filter_level_u", C.c_int), ("filter_level_v", C.c_int), ("mode_ref_delta_enabled", C.c_int),
+                ("ref_deltas", C.c_int8 * 8), ("mode_deltas", C.c_int8 * 2), ("seg_enabled", C.c_int), ("seg_feature_mask", C.c_uint8 * 8),
+                ("seg_feature_data", (C.c_int16 * 8) * 8)]
+
+
+def _fixture():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_eval_filtermaps.npz"))
+    return z, json.loads(bytes(z["cases"]).decode())
+
+
+def _grid_from_case(oracle, z, case):
+    blocks = np.zeros(len(case["blocks"]), oracle.mbmi_dtype)
+    for i, b in enumerate(case["blocks"]):
+        blocks[i]["bsize"], blocks[i]["tx_size"], blocks[i]["inter_tx_size"] = b["bsize"], b["tx_size"], b["inter_tx"]
+        blocks[i]["skip_txfm"], blocks[i]["mode"], blocks[i]["segment_id"], blocks[i]["ref_frame0"] = b["skip"], b["mode"], b["seg"], b["ref"]
+        blocks[i]["delta_lf_from_base"], blocks[i]["delta_lf"], blocks[i]["cdef_strength"] = b["dlf_base"], b["dlf"], b["cdef"]
+    grid = oracle.MiGrid(blocks, z["owner%d" % case["k"]])
+    f = oracle.LfFrame()
+    f.filter_level[0], f.filter_level[1], f.filter_level_u, f.filter_level_v = case["filter_level"]
+    f.mode_ref_delta_enabled, f.delta_lf_present_flag, f.delta_lf_multi, f.seg_enabled = case["mode_ref"], case["delta_lf"], case["delta_lf_multi"], case["seg_on"]
+    for i in range(8):
+        f.ref_deltas[i] = case["ref_deltas"][i]
+        f.seg_feature_mask[i] = int(z["segmask%d" % case["k"]][i])
+        for j in range(8):
+            f.seg_feature_data[i][j] = int(z["segdata%d" % case["k"]][i, j])
+    for i in range(2):
+        f.mode_deltas[i] = case["mode_deltas"][i]
+    return grid, f
+
+
+def _product_params(f):
+    p = LfFrameParams()
+    p.filter_level[0], p.filter_level[1], p.filter_level_u, p.filter_level_v = f.filter_level[0], f.filter_level[1], f.filter_level_u, f.filter_level_v
+    p.mode_ref_delta_enabled, p.seg_enabled = f.mode_ref_delta_enabled, f.seg_enabled
+    for i in range(8):
+        p.ref_deltas[i] = f.ref_deltas[i]
+        p.seg_feature_mask[i] = f.seg_feature_mask[i]
+        for j in range(8):
+            p.seg_feature_data[i][j] = f.seg_feature_data[i][j]
+    for i in range(2):
+        p.mode_deltas[i] = f.mode_deltas[i]
+    return p
+
+
+def _product_edges(lib, units, w, h, is_chroma):
+    units = np.ascontiguousarray(units)
+    rows, cols = units.shape[:2]
+    edge = np.full((rows, cols + 3, 4), 0xEE, np.uint8)
+    f = lib.aomhip_lf_build_edge_params
+    f.restype, f.argtypes = C.c_int, None
+    assert f(C.c_void_p(units.ctypes.data), C.c_int(cols), C.c_int(w), C.c_int(h), C.c_int(is_chroma), C.c_void_p(edge.ctypes.data), C.c_int(cols + 3)) == 0
+    assert np.all(edge[:, cols:] == 0xEE)
+    return edge[:, :cols]
+
+
+def test_oracle_walk_reproduces_the_interpreted_reference(oracle):
+    z, cases = _fixture()
+    for case in cases:
+        k = case["k"]
+        grid, f = _grid_from_case(oracle, z, case)
+        lvl = oracle.lf_frame_init(f)
+        assert np.array_equal(lvl, z["lvl%d" % k]), k
+        for plane, (ssx, ssy) in ((0, (0, 0)), (1, (1, 1)), (2, (1, 1))):
+            got = oracle.lf_edge_plane(grid, f, lvl, plane, ssx, ssy)
+            assert np.array_equal(got, z["edge%d_p%d" % (k, plane)]), (k, plane)
+        assert np.array_equal(oracle.cdef_skip_map(grid), z["cdefskip%d" % k]), k
+
+
+def test_product_producers_on_the_fixture_grids(hip, oracle):
+    lib = hip.capi.lib
+    z, cases = _fixture()
+    for case in cases:
+        k = case["k"]
+        grid, f = _grid_from_case(oracle, z, case)
+        lvl = oracle.lf_frame_init(f)
+        if not case["delta_lf"]:  # the level table the integrator reads when delta_lf is off
+            for plane in range(3):
+                tab = np.zeros((8, 2, 8, 2), np.uint8)
+                lib.aomhip_lf_level_table.restype, lib.aomhip_lf_level_table.argtypes = None, None
+                lib.aomhip_lf_level_table(C.byref(_product_params(f)), C.c_int(plane), C.c_void_p(tab.ctypes.data))
+                want = z["lvl%d" % k][plane].copy()
+                # (the reference leaves the INTRA_FRAME row's second mode slot at its previous contents; only [0][0] is read)
+                if case["mode_ref"]:
+                    tab[:, :, 0, 1] = want[:, :, 0, 1]
+                base = [case["filter_level"][0] or case["filter_level"][1], case["filter_level"][2], case["filter_level"][3]][plane]
+                if base:
+                    assert np.array_equal(tab, want), (k, plane)
+        for plane, (ssx, ssy) in ((0, (0, 0)), (1, (1, 1)), (2, (1, 1))):
+            units = oracle.lf_units(grid, f, lvl, plane, ssx, ssy)
+            w, h = (grid.mi_cols * 4) >> ssx, (grid.mi_rows * 4) >> ssy
+            got = _product_edges(lib, units, w, h, int(plane > 0))
+            want = z["edge%d_p%d" % (k, plane)]
+            assert np.array_equal(got[..., 0], want[..., 0]) and np.array_equal(got[..., 2], want[..., 2]), (k, plane, "lengths")
+            assert np.array_equal(got[..., 1][want[..., 0] > 0], want[..., 1][want[..., 0] > 0]), (k, plane, "levels v")
+            assert np.array_equal(got[..., 3][want[..., 2] > 0], want[..., 3][want[..., 2] > 0]), (k, plane, "levels h")
+        # CDEF skip map from the per-mi skip flags
+        mi_skip = np.ascontiguousarray(grid.blocks["skip_txfm"][grid.owner]).astype(np.uint8)
+        skip = np.full((grid.mi_rows // 2, grid.mi_cols // 2 + 1), 7, np.uint8)
+        fsk = lib.aomhip_cdef_build_skip8x8
+        fsk.restype, fsk.argtypes = C.c_int, None
+        assert fsk(C.c_void_p(mi_skip.ctypes.data), C.c_int(grid.mi_cols), C.c_int(grid.mi_rows), C.c_int(grid.mi_cols), C.c_void_p(skip.ctypes.data),
+                   C.c_int(skip.shape[1])) == 0
+        assert np.array_equal(skip[:, :-1], z["cdefskip%d" % k]) and np.all(skip[:, -1] == 7)
+
+
+def _random_grid(oracle, rng, mi_rows, mi_cols):
+    owner = -np.ones((mi_rows, mi_cols), np.int32)
+    recs = []
+    sizes = [b for b in range(22) if BW[b] <= 64 and BH[b] <= 64]
+    for r in range(mi_rows):
+        for c in range(mi_cols):
+            if owner[r, c] >= 0:
+                continue
+            cand = [b for b in sizes if r % (BH[b] // 4) == 0 and c % (BW[b] // 4) == 0 and r + BH[b] // 4 <= mi_rows and c + BW[b] // 4 <= mi_cols
+                    and np.all(owner[r:r + BH[b] // 4, c:c + BW[b] // 4] < 0)]
+            b = int(rng.choice(cand))
+            owner[r:r + BH[b] // 4, c:c + BW[b] // 4] = len(recs)
+            fits = [t for t in range(19) if BW[b] % TXW[t] == 0 and BH[b] % TXH[t] == 0]
+            inter = int(rng.integers(0, 2))
+            rec = np.zeros((), oracle.mbmi_dtype)
+            rec["bsize"], rec["tx_size"] = b, int(rng.choice(fits))
+            rec["inter_tx_size"] = rng.choice(fits, 16)
+            rec["skip_txfm"], rec["ref_frame0"] = int(rng.integers(0, 3) == 0), int(rng.integers(1, 8)) if inter else 0
+            rec["mode"], rec["segment_id"] = (int(rng.integers(13, 25)) if inter else int(rng.integers(0, 13))), int(rng.integers(0, 8))
+            rec["delta_lf_from_base"], rec["delta_lf"] = int(rng.integers(-20, 21)), rng.integers(-20, 21, 4)
+            recs.append(rec)
+    return oracle.MiGrid(np.array(recs, oracle.mbmi_dtype), owner)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_product_producers_equal_the_oracle_on_random_grids(hip, oracle, seed):
+    lib = hip.capi.lib
+    rng = np.random.default_rng(100 + seed)
+    grid = _random_grid(oracle, rng, int(rng.choice([16, 18, 34])), int(rng.choice([16, 22, 40])))
+    f = oracle.LfFrame()
+    f.filter_level[0], f.filter_level[1], f.filter_level_u, f.filter_level_v = [int(v) for v in rng.integers(0, 64, 4)]
+    f.filter_level[0] = max(f.filter_level[0], 1)
+    f.mode_ref_delta_enabled, f.delta_lf_present_flag, f.delta_lf_multi, f.seg_enabled = seed & 1, (seed >> 1) & 1, seed % 3 == 0, seed % 2 == 0
+    for i in range(8):
+        f.ref_deltas[i] = int(rng.integers(-8, 9))
+        f.seg_feature_mask[i] = int(rng.integers(0, 32)) & ~1
+        for j in range(8):
+            f.seg_feature_data[i][j] = int(rng.integers(-40, 41))
+    f.mode_deltas[0], f.mode_deltas[1] = int(rng.integers(-4, 5)), int(rng.integers(-4, 5))
+    lvl = oracle.lf_frame_init(f)
+    for plane, (ssx, ssy) in ((0, (0, 0)), (1, (1, 1)), (2, (0, 0))):   # (4:2:2 forbids some block shapes; random grids contain them)
+        if (grid.mi_rows * 4 >> ssy) % 4 or (grid.mi_cols * 4 >> ssx) % 4:
+            continue
+        want = oracle.lf_edge_plane(grid, f, lvl, plane, ssx, ssy)
+        units = oracle.lf_units(grid, f, lvl, plane, ssx, ssy)
+        w, h = (grid.mi_cols * 4) >> ssx, (grid.mi_rows * 4) >> ssy
+        got = _product_edges(lib, units, w, h, int(plane > 0))
+        assert np.array_equal(got[..., 0], want[..., 0]) and np.array_equal(got[..., 2], want[..., 2])
+        assert np.array_equal(got[..., 1][want[..., 0] > 0], want[..., 1][want[..., 0] > 0])
+        assert np.array_equal(got[..., 3][want[..., 2] > 0], want[..., 3][want[..., 2] > 0])
+
+
+def test_cdef_strength_planes(hip):
+    lib = hip.capi.lib
+    idx = np.array([0, 3, -1, 7, 2], np.int8)
+    ys = np.array([0, 5, 63, 22, 17, 9, 30, 11], np.int32); uv = np.array([3, 0, 7, 60, 12, 1, 2, 35], np.int32)
+    out = [np.zeros(5, np.uint8) for _ in range(4)]
+    f = lib.aomhip_cdef_build_strengths
+    f.restype, f.argtypes = C.c_int, None
+    assert f(C.c_void_p(idx.ctypes.data), C.c_int(5), C.c_void_p(ys.ctypes.data), C.c_void_p(uv.ctypes.data), *[C.c_void_p(o.ctypes.data) for o in out]) == 0
+    for i, k in enumerate(idx):
+        y, c = (int(ys[k]), int(uv[k])) if k >= 0 else (0, 0)
+        sec = lambda s: (s % 4) + ((s % 4) == 3)   # cdef.c:309-313
+        assert (out[0][i], out[1][i], out[2][i], out[3][i]) == (y // 4, sec(y), c // 4, sec(c))
