@@ -6,7 +6,7 @@
  *   is_8x8_block_skip / av1_cdef_compute_sb_list         av1/common/cdef.c:24-68
  * PINNED by tests/golden/ref_eval_filtermaps.npz: those functions interpreted where they lie on random mode-info grids
  * (luma + 4:2:0 chroma, delta_lf on / off, segment features, reference / mode deltas), checked bit for bit in
- * tests/test_golden_ref_eval.py.  The product's producers (aom-av1-psy_amd/host/filter_maps.c) take the compact per-unit
+ * tests/test_filter_maps.py.  The product's producers (aom-av1-psy_amd/host/filter_maps.c) take the compact per-unit
  * description this file derives from the grid (orc_lf_units) and must give the same planes.
  */
 #include <string.h>

@@ -82,3 +82,60 @@ def test_full_size_4k_10bit_all_8x8_edges(hip, oracle, ctx):
     cx, cy = np.arange(W) % 8, np.arange(H) % 8
     assert not changed[np.ix_((cy == 3) | (cy == 4), (cx == 3) | (cx == 4))].any()
     assert not changed[:5, :5].any()  # the frame edges themselves are never filtered
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_mode_info_grid_to_filtered_planes(hip, oracle, ctx, bd):
+    """The whole chain of row E3: a random mode-info grid -> the host producers (aomhip_lf_build_edge_params,
+    aomhip_cdef_build_skip8x8 / _strengths) -> the deblocking and CDEF kernels, luma and 4:2:0 chroma deblocking, against the
+    oracle fed the planes its own mode-info walk derives (which tests/test_filter_maps.py pins to the interpreted reference)."""
+    import ctypes as C
+    from test_filter_maps import _random_grid, _product_edges
+    lib = hip.capi.lib
+    rng = np.random.default_rng(60 + bd)
+    grid = _random_grid(oracle, rng, 32, 48)   # 192 x 128 luma
+    f = oracle.LfFrame()
+    f.filter_level[0], f.filter_level[1], f.filter_level_u, f.filter_level_v = 30, 26, 22, 18
+    f.mode_ref_delta_enabled = 1
+    for i, v in enumerate([1, 0, 0, 0, -1, 0, -1, -1]):
+        f.ref_deltas[i] = v
+    lvl = oracle.lf_frame_init(f)
+    for plane, (ssx, ssy) in ((0, (0, 0)), (1, (1, 1))):
+        W, H = (grid.mi_cols * 4) >> ssx, (grid.mi_rows * 4) >> ssy
+        pix = _content(rng, W, H, bd)
+        units = oracle.lf_units(grid, f, lvl, plane, ssx, ssy)
+        params = np.ascontiguousarray(_product_edges(lib, units, W, H, int(plane > 0)))
+        want_params = np.ascontiguousarray(oracle.lf_edge_plane(grid, f, lvl, plane, ssx, ssy)[..., :4].astype(np.uint8))
+        got = _run(hip, ctx, pix, params, bd, 0, 3)
+        want = oracle.deblock_plane(pix, want_params, 0, bd)
+        assert np.array_equal(got, want), (plane, bd)
+        assert not np.array_equal(got, pix)
+    # CDEF luma with producer-made skip / strength planes
+    W, H = grid.mi_cols * 4, grid.mi_rows * 4
+    pix = _content(rng, W, H, bd)
+    mi_skip = np.ascontiguousarray(grid.blocks["skip_txfm"][grid.owner]).astype(np.uint8)
+    skip = np.zeros((H // 8, W // 8), np.uint8)
+    fsk = lib.aomhip_cdef_build_skip8x8
+    fsk.restype, fsk.argtypes = C.c_int, None
+    assert fsk(C.c_void_p(mi_skip.ctypes.data), C.c_int(grid.mi_cols), C.c_int(grid.mi_rows), C.c_int(grid.mi_cols), C.c_void_p(skip.ctypes.data),
+               C.c_int(W // 8)) == 0
+    assert np.array_equal(skip, oracle.cdef_skip_map(grid))
+    fbw, fbh = (W + 63) // 64, (H + 63) // 64
+    idx = rng.integers(-1, 4, fbw * fbh).astype(np.int8)
+    strengths = np.array([0, 9, 22, 63], np.int32)
+    pri, sec = np.zeros(fbw * fbh, np.uint8), np.zeros(fbw * fbh, np.uint8)
+    fst = lib.aomhip_cdef_build_strengths
+    fst.restype, fst.argtypes = C.c_int, None
+    assert fst(C.c_void_p(idx.ctypes.data), C.c_int(fbw * fbh), C.c_void_p(strengths.ctypes.data), None, C.c_void_p(pri.ctypes.data),
+               C.c_void_p(sec.ctypes.data), None, None) == 0
+    ps, pd = ctx.planes_alloc(W, H, 32, bd, 1), ctx.planes_alloc(W, H, 32, bd, 1)
+    ctx.planes_upload(ps, 0, pix)
+    d_pri, d_sec, d_skip = ctx.to_device(pri), ctx.to_device(sec), ctx.to_device(skip)
+    ctx.cdef_luma_plane(ps, 0, pd, 0, d_pri, d_sec, fbw, d_skip, 5)
+    got = ctx.planes_download(pd, 0)[32:32 + H, 32:32 + W]
+    want = oracle.cdef_plane_luma(pix, pri.reshape(fbh, fbw), sec.reshape(fbh, fbw), skip, 5, bd)
+    want = want[0] if isinstance(want, tuple) else want
+    assert np.array_equal(got, want)
+    for d in (d_pri, d_sec, d_skip):
+        ctx.free(d)
+    ctx.planes_free(ps); ctx.planes_free(pd)
