@@ -30,7 +30,7 @@ build/host_%.o: $(PKG)/host/%.c include/aomhip.h
 
 $(LIBDIR)/libaomhip.so: $(OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 
 clean:
 	rm -rf build $(LIBDIR)/libaomhip.so

@@ -14,7 +14,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
-OK = 0
+OK, ERR_INVALID = 0, 2
 SAD_SKIP_ROWS = 1
 
 
@@ -181,6 +181,13 @@ _protos = {
     "aomhip_sad16x16": (C.c_uint, [_vp, _i, _vp, _i]),
     "aomhip_sad16x16x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp]),
     "aomhip_highbd_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, _i]),
+    "aomhip_tile_column_bounds": (C.c_int, [_i, _i, _i, _vp]),
+    "aomhip_recon_exchange_plan": (C.c_int, [_i, _i, _vp, _i, _i, _vp, _vp]),
+    "aomhip_comm_unique_id": (C.c_int, [_vp]),
+    "aomhip_comm_init": (C.c_int, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "aomhip_comm_destroy": (None, [_vp]),
+    "aomhip_allgather_recon": (C.c_int, [_vp, _vp, _PP, _i, _vp, _i]),
+    "aomhip_exchange_loopback": (C.c_int, [_vp, _vp, _PP, _i, _i, _i, _i]),
 }
 for _name, (_res, _args) in _protos.items():
     _fn = getattr(lib, _name)  # AttributeError here = header/library mismatch: fail loudly
@@ -199,7 +206,8 @@ for _name in RTCD_STAMPED + ["aomhip_fwd_txfm2d", "aomhip_inv_txfm2d_add", "aomh
                              "aomhip_cdef_find_dir_dual", "aomhip_status_clear"]:
     getattr(lib, _name).restype = None  # raises AttributeError if the library lacks the symbol
     _protos[_name] = (None, None)
-for _name, _res in (("aomhip_cdef_find_dir", C.c_int), ("aomhip_rtcd", C.c_int), ("aomhip_status", C.c_int), ("aomhip_failure_count", C.c_long)):
+for _name, _res in (("aomhip_lf_build_edge_params", C.c_int), ("aomhip_lf_level_table", None), ("aomhip_cdef_build_skip8x8", C.c_int),
+                    ("aomhip_cdef_build_strengths", C.c_int), ("aomhip_cdef_find_dir", C.c_int), ("aomhip_rtcd", C.c_int), ("aomhip_status", C.c_int), ("aomhip_failure_count", C.c_long)):
     getattr(lib, _name).restype = _res
     _protos[_name] = (_res, None)
 
@@ -284,6 +292,22 @@ class Context:
         out = np.empty((p.height + 2 * p.border, p.stride), dt)
         check(lib.aomhip_planes_download(self.h, C.byref(p), frame, out.ctypes.data), "download")
         return out
+
+    # ---- multi-GPU: the per-frame exchange of the reconstruction (RCCL inside the library)
+    def comm_init(self, unique_id, rank, n_ranks):
+        """unique_id: the 128 bytes rank 0 got from comm_unique_id(), handed to every rank by the launcher."""
+        uid = np.frombuffer(bytes(unique_id), np.uint8).copy()
+        assert uid.size == 128
+        h = _vp()
+        check(lib.aomhip_comm_init(self.h, uid.ctypes.data, rank, n_ranks, C.byref(h)), "aomhip_comm_init")
+        return h
+
+    def comm_destroy(self, comm):
+        lib.aomhip_comm_destroy(comm)
+
+    def allgather_recon(self, comm, p, frame, col_bounds, halo=-1):
+        b = np.ascontiguousarray(col_bounds, np.int32).reshape(-1, 2)
+        check(lib.aomhip_allgather_recon(self.h, comm, C.byref(p), frame, b.ctypes.data, halo), "aomhip_allgather_recon")
 
     # ---- SAD
     def sad_batch(self, src, ref, first_frame, n_frames, bw, bh, flags, d_cands, n_cands, cand_frame_stride, d_out):
@@ -460,6 +484,27 @@ class Context:
     def build_pred_fullpel(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n):
         check(lib.aomhip_build_pred_fullpel(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, d_blocks,
                                             d_mv, n), "aomhip_build_pred_fullpel")
+
+
+def comm_unique_id():
+    uid = np.zeros(128, np.uint8)
+    check(lib.aomhip_comm_unique_id(uid.ctypes.data), "aomhip_comm_unique_id")
+    return uid
+
+
+def tile_column_bounds(width, n_cols, sb_size=64):
+    """[n_cols, 2] int32 pixel bounds of the uniform tile columns; (0, 0) for ranks beyond the last column."""
+    b = np.zeros((n_cols, 2), np.int32)
+    n = lib.aomhip_tile_column_bounds(width, n_cols, sb_size, b.ctypes.data)
+    return b, n
+
+
+def recon_exchange_plan(n_ranks, rank, col_bounds, width, halo=-1):
+    """(send, recv): [n_ranks, 2] int32 pixel column ranges per peer (aomhip_recon_exchange_plan; host only)."""
+    b = np.ascontiguousarray(col_bounds, np.int32).reshape(-1, 2)
+    send, recv = np.zeros((n_ranks, 2), np.int32), np.zeros((n_ranks, 2), np.int32)
+    check(lib.aomhip_recon_exchange_plan(n_ranks, rank, b.ctypes.data, width, halo, send.ctypes.data, recv.ctypes.data), "aomhip_recon_exchange_plan")
+    return send, recv
 
 
 def planes_from_tensor(t, width, height, border, bit_depth, n_frames=1):

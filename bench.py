@@ -331,38 +331,41 @@ def run_txq(pkg, ctx, orc, steps, warmup, want_cpu):
 
 class SearchPipeline:
     """BASELINE.json configs[3]: full-pel diamond search (DIAMOND, step_param 4, MV_COST_L1_HDRES) + bilinear sub-pel
-    tree (1/2, 1/4, 1/8) for every 16x16 block of 3840x2160 10-bit frame pairs, tile columns across the GPUs.
-    With N > 1 the reference plane lives in a torch tensor and each step first exchanges the tile-column strips
-    (partition.exchange_strips: one RCCL broadcast per strip) -- the per-frame exchange of the real encoder."""
+    tree (1/2, 1/4, 1/8) for every 16x16 block of 3840x2160 10-bit frame pairs, tile columns across the GPUs (STRONG
+    scaling: the frame is fixed, every rank searches the blocks of its own column).  With N > 1 every step first runs the
+    per-frame exchange of the real encoder, aomhip_allgather_recon (csrc/exchange.hip: pack -> one group of RCCL
+    sends / receives -> unpack -> borders, on the context's stream like the kernels behind it): each rank contributes
+    its column of the reference ("the reconstruction of frame t") and receives what its search can touch --
+    exchange="halo": own column +- (search reach 127 + 1 + AOM_INTERP_EXTEND 4), "allgather": the whole plane."""
 
     W, H, BD, BORDER, BS = 3840, 2160, 10, 160, 16
+    HALO = 127 + 1 + 4  # DIAMOND step_param 4: steps 64 + 32 + ... + 1 = 127; sub-pel moves < 1 more; AOM_INTERP_EXTEND
 
-    def __init__(self, pkg, ctx, dist, rank, world, frames=4):
-        import ctypes as C
+    def __init__(self, pkg, ctx, dist, rank, world, frames=4, exchange="halo"):
         self.pkg, self.ctx, self.dist, self.rank, self.world, self.F = pkg, ctx, dist, rank, world, frames
-        capi, synth, part = pkg.capi, pkg.synth, pkg.partition
+        capi, synth = pkg.capi, pkg.synth
         W, H, bd, border = self.W, self.H, self.BD, self.BORDER
         self.src = ctx.planes_alloc(W, H, border, bd, frames)
-        self.ref_t = None
+        self.ref = ctx.planes_alloc(W, H, border, bd, frames)
+        self.bounds, self.n_cols = capi.tile_column_bounds(W, world)  # idle ranks (fewer columns than ranks): (0, 0)
+        x0, x1 = (int(v) for v in self.bounds[rank])
+        self.halo = -1 if exchange == "allgather" else self.HALO
+        self.comm = None
         if world > 1:
             import torch
-            stride = capi.lib.aomhip_calc_stride(W, border)
-            rows = ((H + 7) & ~7) + 2 * border
-            fe = (rows * stride + 255) & ~255
-            # raw bytes: RCCL has no 16-bit integer type, the strips are exchanged as uint8
-            self.ref_t = torch.zeros((fe * frames + stride + 64) * 2, dtype=torch.uint8, device="cuda")
-            self.ref, self.fe, self.rows = capi.planes_from_tensor(self.ref_t.view(torch.int16), W, H, border, bd, frames)
-        else:
-            self.ref = ctx.planes_alloc(W, H, border, bd, frames)
+            uid = torch.zeros(128, dtype=torch.uint8, device=_red_device())
+            if rank == 0:
+                uid = torch.from_numpy(capi.comm_unique_id()).to(uid.device)
+            dist.broadcast(uid, src=0)
+            self.comm = ctx.comm_init(uid.cpu().numpy(), rank, world)
         for f in range(frames):
             s_, r_ = synth.shifted_smooth_pair(W, H, f, bd, shift=(3 + f % 3, -2 + f % 2), frac8=(f % 8, (3 * f) % 8))
             ctx.planes_upload(self.src, f, s_)
+            if world > 1:  # a rank owns only its column of the reconstruction: the rest arrives through the exchange
+                m = np.zeros_like(r_)
+                m[:, x0:x1] = r_[:, x0:x1]
+                r_ = m
             ctx.planes_upload(self.ref, f, r_)
-        x0, x1 = part.column_of_rank(W, world, rank)
-        self.bounds = []
-        for r in range(world):
-            a, b = part.column_of_rank(W, world, r)
-            self.bounds.append((0 if r == 0 else 2 * (a + border), 2 * (self.ref.stride if r == world - 1 else b + border)))
         xs, ys = np.meshgrid(np.arange(x0, x1 - self.BS + 1, self.BS), np.arange(0, H - self.BS + 1, self.BS))
         n = xs.size
         b = np.zeros(n, capi.search_block_dtype)
@@ -377,12 +380,27 @@ class SearchPipeline:
         self.d_mv, self.d_cost = ctx.malloc(max(16, n * 4)), ctx.malloc(max(16, n * 4))
         self.d_smv, self.d_err, self.d_dist, self.d_sse = (ctx.malloc(max(16, n * 4)) for _ in range(4))
         self.frame = 0
+        if world > 1:  # make every slot's reference valid before anything reads it
+            for f in range(frames):
+                self.exchange(f)
+            ctx.sync()
+
+    def exchange(self, f, halo=None):
+        self.ctx.allgather_recon(self.comm, self.ref, f, self.bounds, self.halo if halo is None else halo)
+
+    def exchange_ms(self, halo, reps=10):
+        """the exchange alone (HIP events on the context's stream, max over ranks is taken by the caller)."""
+        k = [0]
+        def once():
+            self.exchange(k[0] % self.F, halo); k[0] += 1
+        return kernel_avg_ms(self.ctx, once, reps)
 
     def free(self):
         c = self.ctx
         c.planes_free(self.src)
-        if self.ref_t is None:
-            c.planes_free(self.ref)
+        c.planes_free(self.ref)
+        if self.comm is not None:
+            c.comm_destroy(self.comm)
         for d in (self.d_blocks, self.d_sub, self.d_mv, self.d_cost, self.d_smv, self.d_err, self.d_dist, self.d_sse):
             if d:
                 c.free(d)
@@ -393,11 +411,7 @@ class SearchPipeline:
         f = self.frame % self.F
         self.frame += 1
         if self.world > 1:
-            import torch
-            rb = 2 * self.ref.stride  # bytes per row
-            plane = self.ref_t[2 * f * self.fe: 2 * f * self.fe + self.rows * rb].view(self.rows, rb)
-            self.pkg.partition.exchange_strips(self.dist, plane, self.bounds, self.rank)
-            torch.cuda.current_stream().synchronize()
+            self.exchange(f)  # same stream as the searches behind it: ordered without a host synchronisation
         if not self.n:
             return
         c, capi = self.ctx, self.pkg.capi
@@ -471,25 +485,39 @@ def run_search_default(pkg, ctx, orc, steps, warmup):
     return out
 
 
-def run_search(pkg, ctx, dist, dev, rank, world, orc, steps, warmup):
-    wl = SearchPipeline(pkg, ctx, dist, rank, world)
-    ok = wl.check(orc) if orc is not None else None
+def run_search(pkg, ctx, dist, dev, rank, world, orc, steps, warmup, exchange="halo"):
+    wl = SearchPipeline(pkg, ctx, dist, rank, world, exchange=exchange)
+    ok = wl.check(orc) if orc is not None else None   # N > 1: on the EXCHANGED reference against the oracle's whole-frame search
     for f in range(wl.F):
         if wl.n:
             wl.d_sub_blocks(f)
     wall, ev_ms = time_steps(wl, ctx, dist, dev, steps, warmup)
-    total = wl.n
+    total, extra = wl.n, {}
     if dist is not None:
         import torch
-        t = torch.tensor([float(total)], dtype=torch.float64, device=_red_device())
-        dist.all_reduce(t)
-        total = int(t.item())
-    return {"workload": "fullpel_diamond+subpel_bilinear_4k_10bit", "value": total * steps / wall, "unit": "blocks/s",
-            "frames_per_s": steps / wall, "ms_per_step": wall / steps * 1e3, "blocks_per_step": total,
-            "parity_sample_slot0": ok,
-            "config": {"frame": "3840x2160 10-bit", "block": "16x16", "search": "DIAMOND step_param 4, MV_COST_L1_HDRES; "
-                       "sub-pel tree pruned_more, bilinear, 1/8 pel, iters 2", "exchange": "one RCCL broadcast per "
-                       "tile-column strip per frame" if world > 1 else "none (1 GPU)"}}
+        red = lambda v, op: pkg.partition.reduce_scalar(dist, float(v), op, _red_device())
+        total = int(red(total, "SUM"))
+        ok = bool(red(1.0 if ok in (True, None) else 0.0, "MIN")) if orc is not None else None
+        barrier(dist, dev)
+        ex_halo = red(wl.exchange_ms(wl.HALO), "MAX")
+        barrier(dist, dev)
+        ex_all = red(wl.exchange_ms(-1), "MAX")
+        es = 2 * wl.H
+        widths = [int(b - a) for a, b in wl.bounds]
+        recv_all = max((wl.W - w) * es for w in widths if w) if any(widths) else 0
+        extra = {"exchange": {"mode": exchange, "halo_px": wl.HALO, "halo_ms_per_frame": ex_halo, "allgather_ms_per_frame": ex_all,
+                              "allgather_bytes_received_max_rank": recv_all,
+                              "allgather_GBs_per_rank": recv_all / (ex_all * 1e-3) / 1e9 if ex_all > 0 else None,
+                              "transport": "aomhip_allgather_recon: pack kernels -> one ncclGroup of per-peer ncclSend / ncclRecv (uint8) -> "
+                                           "unpack kernels -> border extension, all on the context's stream"},
+                 "tile_columns_px": widths, "blocks_max_rank_over_mean": max(widths) / (sum(widths) / world) if sum(widths) else None}
+    return dict({"workload": "fullpel_diamond+subpel_bilinear_4k_10bit", "value": total * steps / wall, "unit": "blocks/s",
+                 "frames_per_s": steps / wall, "ms_per_step": wall / steps * 1e3, "blocks_per_step": total,
+                 "parity_sample_slot0": ok,
+                 "config": {"frame": "3840x2160 10-bit", "block": "16x16", "search": "DIAMOND step_param 4, MV_COST_L1_HDRES; "
+                            "sub-pel tree pruned_more, bilinear, 1/8 pel, iters 2",
+                            "partition": "uniform tile columns (tile_common.c:76-110), one per GPU",
+                            "exchange": ("per frame, aomhip_allgather_recon (RCCL), " + exchange) if world > 1 else "none (1 GPU)"}}, **extra)
 
 
 def run_inner_loop(pkg, ctx, orc, steps, warmup):
@@ -780,12 +808,32 @@ def run_workload(pkg, ctx, dist, dev, rank, world, name, steps, warmup, want_cpu
     return res
 
 
+def spawn_ranks(n):
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p_ in procs:
+        rc = max(rc, abs(p_.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="sad16x16_modeA_1080p_8bit",
+    ap.add_argument("--workload", default=None,
+                    help="default: sad16x16_modeA_1080p_8bit on one GPU; with N > 1 the strong-scaling search pipeline with the "
+                         "per-frame RCCL exchange (search_4k_10bit) + the SAD workload as a second, weak-scaling entry",
                     choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "search_4k_10bit", "inner_loop_4k_10bit", "default_search_4k_10bit", "cdef_search_4k_10bit",
                                                 "wiener_stats_4k"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
@@ -793,7 +841,17 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path); gloo only to dry-run the N > 1 code on one GPU")
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="override the ring size per GPU (0 = workload default)")
+    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
+                    help="N > 1 search pipeline: what aomhip_allgather_recon moves per frame (both are timed; this one is in `value`)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes, BEFORE this process touches the
+        # GPU (it never does: it only waits).  Under torch.distributed.run WORLD_SIZE is set and this branch is not taken.
+        sys.exit(spawn_ranks(args.gpus))
+    default_multi = args.workload is None and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if args.workload is None:
+        args.workload = "search_4k_10bit" if default_multi else "sad16x16_modeA_1080p_8bit"
 
     global FRAMES_OVERRIDE
     FRAMES_OVERRIDE = args.frames_per_gpu
@@ -816,14 +874,32 @@ def main():
         print("warning: oracle unavailable (%s): no parity spot check / cpu_baseline" % e, file=sys.stderr)
 
     if args.workload == "search_4k_10bit":  # configs[3]: search pipeline with the per-frame strip exchange (any N)
-        r = run_search(pkg, ctx, dist, dev, rank, world, orc, args.steps, args.warmup)
+        r = run_search(pkg, ctx, dist, dev, rank, world, orc, args.steps, args.warmup, args.exchange)
+        line = {"metric": "search blocks/s", "value": r["value"], "unit": "blocks/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16",
+                "data": "synthetic", "config": dict(r["config"], workload=r["workload"]),
+                "frames_per_s": r["frames_per_s"], "parity_sample_slot0": r["parity_sample_slot0"]}
+        for k in ("exchange", "tile_columns_px", "blocks_max_rank_over_mean"):
+            if k in r:
+                line[k] = r[k]
+        if default_multi:
+            # the same box's 1-GPU figure of THIS metric (rank 0 alone, whole frame, no exchange), so the strong-scaling speed-up can
+            # be read off one line; then BASELINE.json's SAD metric as the second, weak-scaling entry (no data-path collective)
+            if rank == 0:
+                one = run_search(pkg, ctx, None, dev, 0, 1, None, args.steps, args.warmup)
+                line["single_gpu_same_box"] = {"value": one["value"], "ms_per_step": one["ms_per_step"]}
+                line["speedup_over_single_gpu"] = r["value"] / one["value"]
+            barrier(dist, dev)
+            sad = run_workload(pkg, ctx, dist, dev, rank, world, "sad16x16_modeA_1080p_8bit", args.steps, args.warmup, False, orc)
+            line["weak_scaling_sad"] = {"metric": "SAD-candidates/s", "value": sad["value"], "unit": "candidates/s", "scaling": "weak",
+                                        "ms_per_step": sad["ms_per_step"], "candidates_per_step": sad["candidates_per_step"],
+                                        "parity_frame0_rank0": sad["parity_frame0"], "roofline_rank0": sad["roofline"],
+                                        "note": "BASELINE.json's headline metric: tile columns are independent, so no collective; "
+                                                "each GPU keeps its own ring of frame pairs (per-GPU work fixed)"}
         ctx.close()
         if rank == 0:
-            print(json.dumps({"metric": "search blocks/s", "value": r["value"], "unit": "blocks/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
-                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16",
-                              "data": "synthetic", "config": dict(r["config"], workload=r["workload"]),
-                              "frames_per_s": r["frames_per_s"], "parity_sample_slot0": r["parity_sample_slot0"]}))
+            print(json.dumps(line))
         if dist is not None:
             dist.destroy_process_group()
         return

@@ -788,6 +788,40 @@ unsigned int aomhip_highbd_sub_pixel_variance(const uint8_t *a8, int a_stride, i
                                               unsigned int *sse);
 
 
+/* ------------------------------------------------------------------ multi-GPU: tile columns + the per-frame exchange (RCCL) */
+
+/* Uniform tile columns in superblock units (av1/common/tile_common.c:76-110: size_sb = ceil(sb_cols / n_cols)): bounds[i] =
+ * [x0, x1) in pixels of column i; returns the number of columns that exist (ranks beyond it get (0, 0): with 1080p and
+ * 8 ranks the columns are 4,4,4,4,4,4,4,2 superblocks wide -- the imbalance is the reference's rule). */
+int aomhip_tile_column_bounds(int width, int n_cols, int sb_size, int (*bounds)[2]);
+
+/* Which pixel columns this rank sends to / receives from every peer when the reconstruction is exchanged (host only, no
+ * GPU call): send[r] = the part of MY column rank r needs, recv[r] = the part of r's column I need; halo < 0: whole columns
+ * (all-gather), halo >= 0: only what lies within `halo` pixels of the receiver's column.  By construction
+ * plan(a).send[b] == plan(b).recv[a]. */
+typedef struct { int32_t x0, x1; } aomhip_exchange_item;
+int aomhip_recon_exchange_plan(int n_ranks, int rank, const int (*col_bounds)[2], int width, int halo, aomhip_exchange_item *send,
+                               aomhip_exchange_item *recv);
+
+/* One RCCL communicator over the ranks of the encode (one process per GPU).  Rank 0 makes the 128-byte id and hands it to the
+ * others by whatever the host application uses to start its ranks (the reference's threads become processes here). */
+typedef struct aomhip_comm aomhip_comm;
+int aomhip_comm_unique_id(uint8_t id[128]);
+int aomhip_comm_init(aomhip_ctx *ctx, const uint8_t id[128], int rank, int n_ranks, aomhip_comm **out);
+void aomhip_comm_destroy(aomhip_comm *comm);
+
+/* After frame `frame` of `p` (the reconstruction) is valid in this rank's tile column: exchange the column strips so that every
+ * rank holds what it can reference in the next frame (MV limits are frame-relative, av1/encoder/mcomp.h:216-247), then
+ * re-extend the borders.  One ncclGroup of per-peer sends / receives on the context's stream (asynchronous like every batched
+ * call).  halo as in aomhip_recon_exchange_plan: -1 = every rank ends with the whole plane; search_range + AOM_INTERP_EXTEND
+ * = only the pixels a search confined to that range can touch.  Results are bit-identical to a 1-GPU run by construction
+ * (pure data movement; test/ethread_test.cc:139-201 is the reference's analogous invariance test). */
+int aomhip_allgather_recon(aomhip_ctx *ctx, aomhip_comm *comm, const aomhip_planes *p, int frame, const int (*col_bounds)[2], int halo);
+
+/* Transport self-test for a machine with one GPU: pixel columns [x0, x1) of `frame` take the same road as an exchanged strip
+ * (pack kernel -> ncclSend / ncclRecv, here to this rank itself -> unpack kernel -> border extension) and land at dst_x0. */
+int aomhip_exchange_loopback(aomhip_ctx *ctx, aomhip_comm *comm, const aomhip_planes *p, int frame, int x0, int x1, int dst_x0);
+
 /* ------------------------------------------------------------------ producers of the in-loop filter parameter planes (host only) */
 
 /* What the integrator copies out of the encoder's mode-info grid, once per frame and plane, for every 4x4 unit of THAT

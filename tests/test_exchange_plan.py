@@ -1,0 +1,106 @@
+"""The per-frame reconstruction exchange of the tile-column encoder: the host-side protocol of aomhip_allgather_recon
+(csrc/exchange.hip), checked without a GPU and without torch.distributed: tile-column bounds against the
+reference's rule (av1/common/tile_common.c:76-110) and the plan's pairwise consistency and coverage, then a
+numpy simulation of pack -> send/recv -> unpack driven by the plan (what rank a sends to b is what b unpacks)."""
+import numpy as np
+import pytest
+
+import aom_av1_psy_amd as pkg
+
+capi = pkg.capi
+
+
+def ref_bounds(width, n_cols, sb=64):
+    # av1_get_uniform_tile_size: tile width in superblocks = ceil(sb_cols / n_cols); columns until the frame ends
+    sb_cols = -(-width // sb)
+    size = -(-sb_cols // n_cols)
+    out = []
+    s = 0
+    while s < sb_cols and len(out) < n_cols:
+        out.append((s * sb, min((s + size) * sb, width)))
+        s += size
+    return out
+
+
+@pytest.mark.parametrize("width,n", [(1920, 1), (1920, 2), (1920, 4), (1920, 8), (3840, 4), (3840, 8), (352, 8), (64, 4), (4096, 7), (1000, 3)])
+def test_tile_column_bounds_follow_the_uniform_tile_rule(width, n):
+    b, cols = capi.tile_column_bounds(width, n)
+    want = ref_bounds(width, n)
+    assert cols == len(want)
+    assert [tuple(x) for x in b[:cols]] == want
+    assert (b[cols:] == 0).all()
+    assert b[0, 0] == 0 and b[cols - 1, 1] == width
+    assert np.array_equal(np.asarray(pkg.synth.tile_column_bounds(width, n)), b[:cols])
+
+
+def test_4k_on_8_ranks_is_seven_512_columns_and_one_256():
+    b, cols = capi.tile_column_bounds(3840, 8)
+    assert cols == 8 and [int(x1 - x0) for x0, x1 in b] == [512] * 7 + [256]
+
+
+@pytest.mark.parametrize("width,n,halo", [(3840, 8, -1), (3840, 8, 132), (3840, 8, 600), (1920, 4, 68), (352, 8, -1), (352, 8, 40), (1920, 2, 0),
+                                          (704, 3, 1000)])
+def test_plan_is_pairwise_consistent_and_covers_what_a_rank_may_reference(width, n, halo):
+    b, cols = capi.tile_column_bounds(width, n)
+    plans = [capi.recon_exchange_plan(n, r, b, width, halo) for r in range(n)]
+    for a in range(n):
+        sa, ra = plans[a]
+        assert (sa[a] == 0).all() and (ra[a] == 0).all()
+        for c in range(n):
+            assert tuple(sa[c]) == tuple(plans[c][1][a])          # a's send to c is c's receive from a
+            x0, x1 = sa[c]
+            if x1 > x0:                                           # only own pixels are sent
+                assert b[a, 0] <= x0 and x1 <= b[a, 1]
+    # a rank ends up with its own column + everything within the halo (the whole frame for -1); idle ranks with nothing
+    for r in range(n):
+        have = np.zeros(width, bool)
+        have[b[r, 0]:b[r, 1]] = True
+        for c in range(n):
+            x0, x1 = plans[r][1][c]
+            assert not have[x0:x1].any()                          # nothing arrives twice
+            have[x0:x1] = True
+        if b[r, 1] > b[r, 0]:
+            lo, hi = (0, width) if halo < 0 else (max(0, b[r, 0] - halo), min(width, b[r, 1] + halo))
+            assert have[lo:hi].all() and have.sum() == hi - lo
+        else:
+            assert not have.any()
+
+
+@pytest.mark.parametrize("halo", [-1, 24])
+def test_simulated_exchange_reassembles_the_plane(halo):
+    rng = np.random.default_rng(5)
+    W, H, n = 352, 40, 4
+    full = rng.integers(0, 1 << 10, (H, W), dtype=np.uint16)
+    b, _ = capi.tile_column_bounds(W, n)
+    planes = []
+    for r in range(n):
+        p = np.full_like(full, 0xFFFF)
+        p[:, b[r, 0]:b[r, 1]] = full[:, b[r, 0]:b[r, 1]]
+        planes.append(p)
+    wire = {}
+    for r in range(n):                                            # pack (bytes, as the library sends them)
+        send, _ = capi.recon_exchange_plan(n, r, b, W, halo)
+        for c in range(n):
+            x0, x1 = send[c]
+            if x1 > x0:
+                wire[(r, c)] = np.ascontiguousarray(planes[r][:, x0:x1]).view(np.uint8).copy()
+    for r in range(n):                                            # unpack
+        _, recv = capi.recon_exchange_plan(n, r, b, W, halo)
+        for c in range(n):
+            x0, x1 = recv[c]
+            if x1 > x0:
+                planes[r][:, x0:x1] = wire.pop((c, r)).view(np.uint16).reshape(H, x1 - x0)
+    assert not wire                                               # every message had a receiver
+    for r in range(n):
+        lo, hi = (0, W) if halo < 0 else (max(0, b[r, 0] - halo), min(W, b[r, 1] + halo))
+        if b[r, 1] == b[r, 0]:                                    # 352 px = 6 superblocks = 3 columns: rank 3 is idle
+            lo = hi = 0
+        assert np.array_equal(planes[r][:, lo:hi], full[:, lo:hi])
+        assert (planes[r][:, :lo] == 0xFFFF).all() and (planes[r][:, hi:] == 0xFFFF).all()
+
+
+def test_plan_rejects_bad_arguments():
+    b, _ = capi.tile_column_bounds(640, 2)
+    s = np.zeros((2, 2), np.int32)
+    assert capi.lib.aomhip_recon_exchange_plan(2, 2, b.ctypes.data, 640, -1, s.ctypes.data, s.ctypes.data) == capi.ERR_INVALID
+    assert capi.lib.aomhip_recon_exchange_plan(0, 0, b.ctypes.data, 640, -1, s.ctypes.data, s.ctypes.data) == capi.ERR_INVALID

@@ -125,7 +125,9 @@ def test_product_producers_on_the_fixture_grids(hip, oracle):
         assert np.array_equal(skip[:, :-1], z["cdefskip%d" % k]) and np.all(skip[:, -1] == 7)
 
 
-def _random_grid(oracle, rng, mi_rows, mi_cols):
+def _random_grid(oracle, rng, mi_rows, mi_cols, consistent_tx=False):
+    """consistent_tx: one transform size per block (a partition a bitstream can carry, which the filtering KERNELS need: the edges
+    of one row then never overlap).  Otherwise inter_tx_size is random per entry: still well defined for the parameter walk."""
     owner = -np.ones((mi_rows, mi_cols), np.int32)
     recs = []
     sizes = [b for b in range(22) if BW[b] <= 64 and BH[b] <= 64]
@@ -141,7 +143,7 @@ def _random_grid(oracle, rng, mi_rows, mi_cols):
             inter = int(rng.integers(0, 2))
             rec = np.zeros((), oracle.mbmi_dtype)
             rec["bsize"], rec["tx_size"] = b, int(rng.choice(fits))
-            rec["inter_tx_size"] = rng.choice(fits, 16)
+            rec["inter_tx_size"] = rec["tx_size"] if consistent_tx else rng.choice(fits, 16)
             rec["skip_txfm"], rec["ref_frame0"] = int(rng.integers(0, 3) == 0), int(rng.integers(1, 8)) if inter else 0
             rec["mode"], rec["segment_id"] = (int(rng.integers(13, 25)) if inter else int(rng.integers(0, 13))), int(rng.integers(0, 8))
             rec["delta_lf_from_base"], rec["delta_lf"] = int(rng.integers(-20, 21)), rng.integers(-20, 21, 4)

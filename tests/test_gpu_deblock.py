@@ -93,7 +93,7 @@ def test_mode_info_grid_to_filtered_planes(hip, oracle, ctx, bd):
     from test_filter_maps import _random_grid, _product_edges
     lib = hip.capi.lib
     rng = np.random.default_rng(60 + bd)
-    grid = _random_grid(oracle, rng, 32, 48)   # 192 x 128 luma
+    grid = _random_grid(oracle, rng, 32, 48, consistent_tx=True)   # 192 x 128 luma
     f = oracle.LfFrame()
     f.filter_level[0], f.filter_level[1], f.filter_level_u, f.filter_level_v = 30, 26, 22, 18
     f.mode_ref_delta_enabled = 1
