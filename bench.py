@@ -49,11 +49,17 @@ _BACKEND = "nccl"  # RCCL; "gloo" only for the single-GPU dry run of the N > 1 c
 def dist_setup(n_gpus, backend):
     global _BACKEND
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    forced = world <= 1 and os.environ.get("AOMHIP_BENCH_FORCE_DIST") == "1"
+    if world <= 1 and not forced:
         return None, 0, 1
     import torch
     import torch.distributed as dist
     _BACKEND = backend
+    if forced:  # tools/gpu_dist_dryrun.sh: the whole N > 1 code path (process group, RCCL communicator, exchange, reductions) with ONE rank
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % (29400 + os.getpid() % 500), rank=0, world_size=1,
+                                **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
+        return dist, 0, 1
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
@@ -351,7 +357,7 @@ class SearchPipeline:
         x0, x1 = (int(v) for v in self.bounds[rank])
         self.halo = -1 if exchange == "allgather" else self.HALO
         self.comm = None
-        if world > 1:
+        if dist is not None:
             import torch
             uid = torch.zeros(128, dtype=torch.uint8, device=_red_device())
             if rank == 0:
@@ -361,7 +367,7 @@ class SearchPipeline:
         for f in range(frames):
             s_, r_ = synth.shifted_smooth_pair(W, H, f, bd, shift=(3 + f % 3, -2 + f % 2), frac8=(f % 8, (3 * f) % 8))
             ctx.planes_upload(self.src, f, s_)
-            if world > 1:  # a rank owns only its column of the reconstruction: the rest arrives through the exchange
+            if dist is not None:  # a rank owns only its column of the reconstruction: the rest arrives through the exchange
                 m = np.zeros_like(r_)
                 m[:, x0:x1] = r_[:, x0:x1]
                 r_ = m
@@ -380,7 +386,7 @@ class SearchPipeline:
         self.d_mv, self.d_cost = ctx.malloc(max(16, n * 4)), ctx.malloc(max(16, n * 4))
         self.d_smv, self.d_err, self.d_dist, self.d_sse = (ctx.malloc(max(16, n * 4)) for _ in range(4))
         self.frame = 0
-        if world > 1:  # make every slot's reference valid before anything reads it
+        if self.comm is not None:  # make every slot's reference valid before anything reads it
             for f in range(frames):
                 self.exchange(f)
             ctx.sync()
@@ -410,7 +416,7 @@ class SearchPipeline:
         full-pel result of the PREVIOUS visit of this ring slot; the kernels' work is what is timed)."""
         f = self.frame % self.F
         self.frame += 1
-        if self.world > 1:
+        if self.comm is not None:
             self.exchange(f)  # same stream as the searches behind it: ordered without a host synchronisation
         if not self.n:
             return
@@ -517,7 +523,7 @@ def run_search(pkg, ctx, dist, dev, rank, world, orc, steps, warmup, exchange="h
                  "config": {"frame": "3840x2160 10-bit", "block": "16x16", "search": "DIAMOND step_param 4, MV_COST_L1_HDRES; "
                             "sub-pel tree pruned_more, bilinear, 1/8 pel, iters 2",
                             "partition": "uniform tile columns (tile_common.c:76-110), one per GPU",
-                            "exchange": ("per frame, aomhip_allgather_recon (RCCL), " + exchange) if world > 1 else "none (1 GPU)"}}, **extra)
+                            "exchange": ("per frame, aomhip_allgather_recon (RCCL), " + exchange) if dist is not None else "none (1 GPU)"}}, **extra)
 
 
 def run_inner_loop(pkg, ctx, orc, steps, warmup):
@@ -849,23 +855,21 @@ def main():
         # Plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes, BEFORE this process touches the
         # GPU (it never does: it only waits).  Under torch.distributed.run WORLD_SIZE is set and this branch is not taken.
         sys.exit(spawn_ranks(args.gpus))
-    default_multi = args.workload is None and int(os.environ.get("WORLD_SIZE", "1")) > 1
-    if args.workload is None:
-        args.workload = "search_4k_10bit" if default_multi else "sad16x16_modeA_1080p_8bit"
 
     global FRAMES_OVERRIDE
     FRAMES_OVERRIDE = args.frames_per_gpu
     dist, rank, world = dist_setup(args.gpus, args.dist_backend)
+    default_multi = args.workload is None and dist is not None
+    if args.workload is None:
+        args.workload = "search_4k_10bit" if default_multi else "sad16x16_modeA_1080p_8bit"
     dev = 0
     if world > 1:
         import torch
         dev = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     import aom_av1_psy_amd as pkg  # raises if libaomhip.so is missing: no fallback
-    stream = None
-    if world > 1:
-        import torch
-        stream = torch.cuda.current_stream().cuda_stream or None
-    ctx = pkg.capi.Context(dev, stream)
+    # one stream, the context's own: the kernels AND the RCCL exchange (aomhip_allgather_recon) are enqueued on it, so a step is
+    # ordered without host synchronisation; torch.distributed only carries the barrier / reductions around the timed region
+    ctx = pkg.capi.Context(dev, None)
     orc = None
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -1,14 +1,14 @@
 #!/bin/bash
-# Dry run of bench.py's N > 1 code path on a ONE-GPU box: 2 and 4 ranks share device 0, gloo carries the
-# barrier / reductions (RCCL cannot put two ranks on one GPU).  Checks sharding, ring growth, timing reduction.
+# Dry run of bench.py's N > 1 code path on a ONE-GPU box.  RCCL refuses two ranks on one device, so the path runs with a
+# process group and an RCCL communicator of ONE rank: torch.distributed set-up, the id broadcast, aomhip_comm_init,
+# aomhip_allgather_recon in front of every search step, the reductions, the single-GPU comparison leg and the weak SAD entry.
+# (Peer traffic itself: the loop-back case of tests/test_gpu_exchange.py on one GPU, the multi-process case with >= 2.)
 mkdir -p gpurun_out/dryrun
-for N in 2 4 8; do
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29500 + N)) \
-      bench.py --gpus $N --steps 5 --warmup 1 --dist-backend gloo --frames-per-gpu 8 "$@" 2> gpurun_out/dryrun/n$N.err | grep '^{' > gpurun_out/dryrun/n$N.json
-  python - gpurun_out/dryrun/n$N.json <<'PY'
+AOMHIP_BENCH_FORCE_DIST=1 python bench.py --steps 5 --warmup 1 "$@" 2> gpurun_out/dryrun/forced.err | grep '^{' > gpurun_out/dryrun/forced.json
+python - gpurun_out/dryrun/forced.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read())
-print("world", d["n_gpus"], "value %.4g" % d["value"], d["unit"], "parity", d.get("parity_frame0", d.get("parity_sample_slot0")),
-      "kernels", d.get("kernels"), "cfg", {k: d["config"].get(k) for k in ("workload", "candidates_per_step")})
+print({k: d.get(k) for k in ("metric", "value", "n_gpus", "scaling", "parity_sample_slot0", "exchange", "tile_columns_px", "speedup_over_single_gpu")})
+print("weak entry:", {k: d["weak_scaling_sad"].get(k) for k in ("value", "ms_per_step", "parity_frame0_rank0")})
 PY
-done
+tail -5 gpurun_out/dryrun/forced.err
