@@ -53,6 +53,29 @@ class SubpelParams(C.Structure):
                                          "subpel_search_type")]
 
 
+class TfParams(C.Structure):
+    """aomhip_tf_params."""
+    _fields_ = [("full", SearchParams), ("sub", SubpelParams), ("use_cost_list", C.c_int32), ("force_integer_mv", C.c_int32),
+                ("mse_thresh", C.c_int32)]
+
+    @classmethod
+    def default(cls, width, height, bit_depth, q, prune_mesh_level, mesh, subpel_tree=2, iters_per_step=2, allow_hp=1, use_cost_list=0,
+                use_downsampled_sad=0, force_integer_mv=0):
+        """aomhip_tf_default_params (host/aomhip_tf.c)."""
+        out = cls()
+        pat = (C.c_int * 8)(*[int(v) for v in np.asarray(mesh).reshape(-1)])
+        lib.aomhip_tf_default_params(width, height, bit_depth, q, prune_mesh_level, pat, SUBPEL_TREES.get(subpel_tree, subpel_tree), iters_per_step,
+                                     allow_hp, use_cost_list, use_downsampled_sad, force_integer_mv, C.byref(out))
+        return out
+
+
+def tf_block_list(width, height, border):
+    n = lib.aomhip_tf_block_list(width, height, border, None)
+    b = np.zeros(n, search_block_dtype)
+    assert lib.aomhip_tf_block_list(width, height, border, b.ctypes.data) == n
+    return b
+
+
 def search_sites(method):
     """aomhip_search_sites -> (num_search_steps, searches_per_step[22], radius[22], mv[22, 17, 2])."""
     ns = C.c_int()
@@ -181,6 +204,9 @@ _protos = {
     "aomhip_sad16x16": (C.c_uint, [_vp, _i, _vp, _i]),
     "aomhip_sad16x16x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp]),
     "aomhip_highbd_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, _i]),
+    "aomhip_tf_default_params": (None, [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "aomhip_tf_block_list": (C.c_int, [_i, _i, _i, _vp]),
+    "aomhip_tf_motion_search_frames": (C.c_int, [_vp, _PP, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "aomhip_tile_column_bounds": (C.c_int, [_i, _i, _i, _vp]),
     "aomhip_recon_exchange_plan": (C.c_int, [_i, _i, _vp, _i, _i, _vp, _vp]),
     "aomhip_comm_unique_id": (C.c_int, [_vp]),
@@ -292,6 +318,11 @@ class Context:
         out = np.empty((p.height + 2 * p.border, p.stride), dt)
         check(lib.aomhip_planes_download(self.h, C.byref(p), frame, out.ctypes.data), "download")
         return out
+
+    def tf_motion_search_frames(self, frames, filter_frame, params, d_blocks, n_blocks, d_mvs, d_mses, d_ref_mv=None, frame_present=None):
+        fp = None if frame_present is None else np.ascontiguousarray(frame_present, np.uint8)
+        check(lib.aomhip_tf_motion_search_frames(self.h, C.byref(frames), filter_frame, None if fp is None else fp.ctypes.data, C.byref(params),
+                                                 d_blocks, n_blocks, d_mvs, d_mses, d_ref_mv), "aomhip_tf_motion_search_frames")
 
     # ---- multi-GPU: the per-frame exchange of the reconstruction (RCCL inside the library)
     def comm_init(self, unique_id, rank, n_ranks):

@@ -21,6 +21,12 @@ struct aomhip_ctx {
   size_t d_scratch_bytes;
   void *h_pinned;
   size_t h_pinned_bytes;
+  // work memory of the device-side composites (aomhip_tf_motion_search_frames): intermediate lists between batched kernels
+  void *d_work;
+  size_t d_work_bytes;
+  // device-side status word: kernels that find a work-list entry they cannot process (e.g. an aomhip_txb whose tx_type does not
+  // exist for the transform size) OR a code into it; aomhip_ctx_sync reports and clears it
+  int *d_status;
 };
 
 namespace aomhip {
@@ -35,6 +41,11 @@ void note_failure(const char *what, int status = AOMHIP_ERR_HIP);
 aomhip_ctx *default_ctx();                  // lazily created per-thread context for the rtcd-signature paths; nullptr on failure
 void *scratch(aomhip_ctx *ctx, size_t bytes);
 void *pinned(aomhip_ctx *ctx, size_t bytes);
+void *work(aomhip_ctx *ctx, size_t bytes);
+// enqueue the check of a per-block transform list (tx_type valid for tx_size; `wht_ok`: AOMHIP_TX_WHT allowed) on the context's stream
+int validate_txb_list(aomhip_ctx *ctx, const aomhip_txb *d_blocks, int n_blocks, int tx_size, bool wht_ok, bool any_type_0_15);
+constexpr int kStatusBadTxType = 1;
+bool tx_type_ok(int tx_size, int tx_type);  // (size, type) pairs av1_get_fwd_txfm_cfg serves, + AOMHIP_TX_WHT for TX_4X4
 
 #define AOMHIP_TRY(expr)                                                                       \
   do {                                                                                         \

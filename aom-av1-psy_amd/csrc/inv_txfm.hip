@@ -213,11 +213,12 @@ int aomhip_inv_txfm_add_batch(aomhip_ctx *ctx, const int32_t *d_dqcoeff, int tx_
                               int n_blocks, int grid_cols, int uniform_tx_type, const uint16_t *d_eob,
                               const aomhip_planes *dst, int frame) {
   if (!ctx || !d_dqcoeff || !dst || !dst->base || tx_size < 0 || tx_size >= 19 || n_blocks < 0 || frame < 0 ||
-      frame >= dst->n_frames || (!d_blocks && grid_cols <= 0)) {
+      frame >= dst->n_frames || (!d_blocks && (grid_cols <= 0 || !tx_type_ok(tx_size, uniform_tx_type)))) {
     set_error("aomhip_inv_txfm_add_batch: invalid argument");
     return AOMHIP_ERR_INVALID;
   }
   if (n_blocks == 0) return AOMHIP_OK;
+  if (int rc = validate_txb_list(ctx, d_blocks, n_blocks, tx_size, true, false)) return rc;
   const size_t esz = dst->bit_depth == 8 ? 1 : 2;
   void *origin = static_cast<char *>(dst->base) +
                  ((size_t)frame * dst->frame_stride + (size_t)dst->border * dst->stride + dst->border) * esz;

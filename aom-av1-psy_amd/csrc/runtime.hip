@@ -58,6 +58,25 @@ void *scratch(aomhip_ctx *ctx, size_t bytes) {
   return ctx->d_scratch;
 }
 
+void *work(aomhip_ctx *ctx, size_t bytes) {
+  if (ctx->d_work_bytes < bytes) {
+    if (ctx->d_work) {
+      (void)hipStreamSynchronize(ctx->stream);  // kernels of an earlier call may still use it
+      (void)hipFree(ctx->d_work);
+    }
+    ctx->d_work = nullptr;
+    ctx->d_work_bytes = 0;
+    const size_t cap = bytes + bytes / 4;
+    if (hipMalloc(&ctx->d_work, cap) != hipSuccess) {
+      ctx->d_work = nullptr;
+      set_error("hipMalloc(%zu) for work memory failed", cap);
+      return nullptr;
+    }
+    ctx->d_work_bytes = cap;
+  }
+  return ctx->d_work;
+}
+
 void *pinned(aomhip_ctx *ctx, size_t bytes) {
   if (ctx->h_pinned_bytes < bytes) {
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -151,6 +170,11 @@ int aomhip_ctx_create(int device, void *stream, aomhip_ctx **out) {
     free(c);
     return AOMHIP_ERR_HIP;
   }
+  if (hipMalloc(reinterpret_cast<void **>(&c->d_status), sizeof(int)) != hipSuccess || hipMemset(c->d_status, 0, sizeof(int)) != hipSuccess) {
+    set_error("hipMalloc for the device status word failed");
+    free(c);
+    return AOMHIP_ERR_NOMEM;
+  }
   *out = c;
   return AOMHIP_OK;
 }
@@ -160,6 +184,8 @@ void aomhip_ctx_destroy(aomhip_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  if (ctx->d_work) (void)hipFree(ctx->d_work);
+  if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
@@ -171,6 +197,14 @@ void aomhip_ctx_destroy(aomhip_ctx *ctx) {
 int aomhip_ctx_sync(aomhip_ctx *ctx) {
   if (!ctx) return AOMHIP_ERR_INVALID;
   AOMHIP_TRY(hipStreamSynchronize(ctx->stream));
+  int st = 0;
+  AOMHIP_TRY(hipMemcpy(&st, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost));
+  if (st) {
+    AOMHIP_TRY(hipMemset(ctx->d_status, 0, sizeof(int)));
+    set_error("a batched call since the last synchronisation was given work-list entries it cannot process (device status 0x%x:%s); "
+              "its outputs are undefined", st, (st & kStatusBadTxType) ? " an aomhip_txb tx_type that does not exist for the transform size" : "");
+    return AOMHIP_ERR_INVALID;
+  }
   return AOMHIP_OK;
 }
 

@@ -1,0 +1,254 @@
+// tf_motion_search (av1/encoder/temporal_filter.c:87-253) for every 32x32 block of a frame, one filter window per call:
+// aomhip_tf_motion_search_frames.  The searches themselves are the library's batched av1_full_pixel_search and sub-pel
+// tree kernels; this file is the frame loop of av1_tf_do_filtering_row (:849-867) turned inside out (per frame, all blocks)
+// and the small element-wise kernels between the searches -- start MVs, limits, the block / sub-block bookkeeping, the partition
+// decision and the ref_mv hand-over -- so that the whole chain stays in device memory with no host round trip.
+#include <climits>
+
+#include "common.h"
+
+namespace aomhip {
+namespace {
+
+constexpr int kTfBlock = 32, kTfSub = 16;
+constexpr int kMaxFullPel = 1023;          // MAX_FULL_PEL_VAL (mcomp_structs.h:22)
+constexpr int kMvLow = -(1 << 14), kMvUpp = 1 << 14;  // MV_LOW / MV_UPP (entropymv.h:75-76)
+
+__device__ __forceinline__ int rawpel(int x) { return (x + 3 + (x >= 0)) >> 3; }  // GET_MV_RAWPEL (mv.h:28)
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// FullMvLimits of a search around the zero baseline MV: av1_set_mv_search_range(&mv_limits, &kZeroMv) (mcomp.c:196-215)
+__device__ __forceinline__ void full_limits(const aomhip_search_block &in, aomhip_search_block *out) {
+  const int lo = -kMaxFullPel > rawpel(kMvLow) + 1 ? -kMaxFullPel : rawpel(kMvLow) + 1;
+  const int hi = kMaxFullPel < rawpel(kMvUpp) - 1 ? kMaxFullPel : rawpel(kMvUpp) - 1;
+  out->row_min = (int16_t)(in.row_min < lo ? lo : in.row_min);
+  out->row_max = (int16_t)(in.row_max > hi ? hi : in.row_max);
+  out->col_min = (int16_t)(in.col_min < lo ? lo : in.col_min);
+  out->col_max = (int16_t)(in.col_max > hi ? hi : in.col_max);
+}
+// SubpelMvLimits: av1_set_subpel_mv_search_range(.., &x->mv_limits, &kZeroMv) (mcomp.h:344-361)
+__device__ __forceinline__ void subpel_limits(const aomhip_search_block &in, aomhip_search_block *out) {
+  const int max_mv = kMaxFullPel * 8;
+  auto lo = [&](int v) { int m = v * 8 > -max_mv ? v * 8 : -max_mv; return m > kMvLow + 1 ? m : kMvLow + 1; };
+  auto hi = [&](int v) { int m = v * 8 < max_mv ? v * 8 : max_mv; return m < kMvUpp - 1 ? m : kMvUpp - 1; };
+  out->row_min = (int16_t)lo(in.row_min); out->row_max = (int16_t)hi(in.row_max);
+  out->col_min = (int16_t)lo(in.col_min); out->col_max = (int16_t)hi(in.col_max);
+}
+
+// full-pel list of the 32x32 blocks: start = get_fullmv_from_mv(ref_mv) (:131), baseline MV 0
+__global__ void tf_full32_list_kernel(const aomhip_search_block *blocks, const int16_t *ref_mv, int n, aomhip_search_block *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  aomhip_search_block b = blocks[i], o;
+  o.bx = b.bx; o.by = b.by; o.ref_row = 0; o.ref_col = 0;
+  o.start_row = (int16_t)rawpel(ref_mv[2 * i]); o.start_col = (int16_t)rawpel(ref_mv[2 * i + 1]);
+  full_limits(b, &o);
+  out[i] = o;
+}
+
+// sub-pel list from a full-pel result: subpel_start_mv = get_mv_from_fullmv(best) (:187, :232); `per` entries of `mv` per block of
+// `blocks` (1 for the block itself, 4 for its sub-blocks, whose origin is the block's + (i, j) * 16 while the limits stay the block's)
+__global__ void tf_subpel_list_kernel(const aomhip_search_block *blocks, const int16_t *full_mv, int n, int per, aomhip_search_block *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * per) return;
+  const aomhip_search_block b = blocks[i / per];
+  const int k = i % per;
+  aomhip_search_block o;
+  o.bx = (int16_t)(b.bx + (per == 4 ? (k & 1) * kTfSub : 0));
+  o.by = (int16_t)(b.by + (per == 4 ? (k >> 1) * kTfSub : 0));
+  o.ref_row = 0; o.ref_col = 0;
+  o.start_row = (int16_t)(full_mv[2 * i] * 8); o.start_col = (int16_t)(full_mv[2 * i + 1] * 8);
+  subpel_limits(b, &o);
+  out[i] = o;
+}
+
+// after the block's sub-pel search: block_mse (:190), *ref_mv = block MV (:192), and the full-pel list of the four sub-blocks started
+// at get_fullmv_from_mv(ref_mv) (:198)
+__global__ void tf_after_block_kernel(const aomhip_search_block *blocks, const int16_t *block_mv, const uint32_t *block_err, int n,
+                                      int16_t *ref_mv, int32_t *block_mse, aomhip_search_block *sub_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const aomhip_search_block b = blocks[i];
+  const int row = block_mv[2 * i], col = block_mv[2 * i + 1];
+  block_mse[i] = (int32_t)((block_err[i] + (unsigned)(kTfBlock * kTfBlock / 2)) / (unsigned)(kTfBlock * kTfBlock));  // DIVIDE_AND_ROUND, unsigned
+  ref_mv[2 * i] = (int16_t)row; ref_mv[2 * i + 1] = (int16_t)col;
+  aomhip_search_block o;
+  o.ref_row = 0; o.ref_col = 0;
+  o.start_row = (int16_t)rawpel(row); o.start_col = (int16_t)rawpel(col);
+  full_limits(b, &o);
+  for (int k = 0; k < 4; ++k) {
+    o.bx = (int16_t)(b.bx + (k & 1) * kTfSub); o.by = (int16_t)(b.by + (k >> 1) * kTfSub);
+    sub_out[4 * i + k] = o;
+  }
+}
+
+// tf_determine_block_partition (:270-293) + the ref_mv rule (:249-252); writes the frame's outputs
+__global__ void tf_finish_kernel(const int16_t *block_mv, const int32_t *block_mse, const int16_t *sub_mv, const uint32_t *sub_err, int n,
+                                 int have_sub, int mse_thresh, int16_t *ref_mv, int16_t *out_mvs, int32_t *out_mses) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int mses[4], mvs[4][2];
+  for (int k = 0; k < 4; ++k) {
+    if (have_sub) {
+      mses[k] = (int32_t)((sub_err[4 * i + k] + (unsigned)(kTfSub * kTfSub / 2)) / (unsigned)(kTfSub * kTfSub));
+      mvs[k][0] = sub_mv[8 * i + 2 * k]; mvs[k][1] = sub_mv[8 * i + 2 * k + 1];
+    } else {  // force_integer_mv: the caller's initial values (:861-862)
+      mses[k] = INT_MAX; mvs[k][0] = mvs[k][1] = 0;
+    }
+  }
+  const int bmse = block_mse[i];
+  int mn = INT_MAX, mx = INT_MIN;
+  int64_t sum = 0;
+  for (int k = 0; k < 4; ++k) {
+    sum += mses[k];
+    mn = mses[k] < mn ? mses[k] : mn;
+    mx = mses[k] > mx ? mses[k] : mx;
+  }
+  const int spread = (int)((unsigned)mx - (unsigned)mn);
+  if (((int64_t)(bmse * 15) < sum * 4 && spread < 48) || ((int64_t)(bmse * 14) < sum * 4 && spread < 24)) {  // no split
+    for (int k = 0; k < 4; ++k) {
+      mvs[k][0] = block_mv[2 * i]; mvs[k][1] = block_mv[2 * i + 1];
+      mses[k] = bmse;
+    }
+  }
+  for (int k = 0; k < 4; ++k) {
+    out_mvs[8 * i + 2 * k] = (int16_t)mvs[k][0]; out_mvs[8 * i + 2 * k + 1] = (int16_t)mvs[k][1];
+    out_mses[4 * i + k] = mses[k];
+  }
+  if (bmse > mse_thresh) ref_mv[2 * i] = ref_mv[2 * i + 1] = 0;
+}
+
+// force_integer_mv (:158-168): error = vf(ref + mv, src) is one aomhip_variance_batch evaluation per block ...
+__global__ void tf_integer_cands_kernel(const aomhip_search_block *blocks, const int16_t *full_mv, int n, aomhip_var_cand *cands) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const aomhip_search_block b = blocks[i];
+  aomhip_var_cand c;
+  c.sx = b.bx; c.sy = b.by;
+  c.rx = (int16_t)(b.bx + full_mv[2 * i + 1]); c.ry = (int16_t)(b.by + full_mv[2 * i]);
+  c.xoff = c.yoff = 0; c.reserved[0] = c.reserved[1] = 0;
+  cands[i] = c;
+}
+// ... and then block_mv = the full-pel MV in 1/8 pel, block_mse = DIVIDE_AND_ROUND(error, 1024); *ref_mv is NOT updated on this path
+__global__ void tf_integer_finish_kernel(const int16_t *full_mv, const uint32_t *var, int n, int16_t *block_mv, int32_t *block_mse) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  block_mv[2 * i] = (int16_t)(full_mv[2 * i] * 8); block_mv[2 * i + 1] = (int16_t)(full_mv[2 * i + 1] * 8);
+  block_mse[i] = (int32_t)((var[i] + (unsigned)(kTfBlock * kTfBlock / 2)) / (unsigned)(kTfBlock * kTfBlock));
+}
+
+__global__ void tf_negate_kernel(int16_t *ref_mv, int n2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n2) ref_mv[i] = (int16_t)-ref_mv[i];
+}
+__global__ void tf_fill_kernel(int16_t *mvs, int32_t *mses, int n4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  mvs[2 * i] = mvs[2 * i + 1] = 0;
+  mses[i] = INT_MAX;
+}
+
+}  // namespace
+}  // namespace aomhip
+
+using namespace aomhip;
+
+extern "C" int aomhip_tf_motion_search_frames(aomhip_ctx *ctx, const aomhip_planes *frames, int filter_frame, const uint8_t *frame_present,
+                                              const aomhip_tf_params *tp, const aomhip_search_block *d_blocks, int n, int16_t *d_subblock_mvs,
+                                              int32_t *d_subblock_mses, int16_t *d_ref_mv_out) {
+  if (!ctx || !frames || !frames->base || !tp || n < 0 || (n > 0 && (!d_blocks || !d_subblock_mvs || !d_subblock_mses)) || filter_frame < 0 ||
+      filter_frame >= frames->n_frames) {
+    set_error("aomhip_tf_motion_search_frames: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (tp->full.search_method != AOMHIP_SEARCH_NSTEP || !tp->full.run_mesh_search || tp->sub.subpel_search_type != 3 || tp->sub.forced_stop != 0 ||
+      tp->sub.mv_cost_type != AOMHIP_MV_COST_NONE || tp->full.mv_cost_type < AOMHIP_MV_COST_L1_LOWRES || tp->full.mv_cost_type > AOMHIP_MV_COST_L1_HDRES ||
+      tp->sub.tree < 0 || tp->sub.tree > 2) {
+    set_error("aomhip_tf_motion_search_frames: parameters are not tf_motion_search's (NSTEP + mesh, L1 cost; USE_8_TAPS, EIGHTH_PEL, MV_COST_NONE)");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n == 0) return AOMHIP_OK;
+  AOMHIP_TRY(hipSetDevice(ctx->device));
+  // work memory of the chain (stream-ordered re-use from call to call; growing it synchronises)
+  const size_t n1 = (size_t)n, n4 = 4 * n1;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_ref = take(n1 * 4), o_l32 = take(n1 * sizeof(aomhip_search_block)), o_fmv32 = take(n1 * 4), o_fcost32 = take(n1 * 4),
+               o_cl32 = take(n1 * 20), o_s32 = take(n1 * sizeof(aomhip_search_block)), o_mv32 = take(n1 * 4), o_err32 = take(n1 * 4),
+               o_dist32 = take(n1 * 4), o_sse32 = take(n1 * 4), o_mse32 = take(n1 * 4), o_l16 = take(n4 * sizeof(aomhip_search_block)),
+               o_fmv16 = take(n4 * 4), o_fcost16 = take(n4 * 4), o_cl16 = take(n4 * 20), o_s16 = take(n4 * sizeof(aomhip_search_block)),
+               o_mv16 = take(n4 * 4), o_err16 = take(n4 * 4), o_dist16 = take(n4 * 4), o_sse16 = take(n4 * 4),
+               o_cand = take(n1 * sizeof(aomhip_var_cand));
+  char *w = static_cast<char *>(work(ctx, off));
+  if (!w) return AOMHIP_ERR_NOMEM;
+  auto at = [&](size_t o) { return w + o; };
+  int16_t *ref_mv = reinterpret_cast<int16_t *>(at(o_ref));
+  aomhip_search_block *l32 = reinterpret_cast<aomhip_search_block *>(at(o_l32)), *s32 = reinterpret_cast<aomhip_search_block *>(at(o_s32));
+  aomhip_search_block *l16 = reinterpret_cast<aomhip_search_block *>(at(o_l16)), *s16 = reinterpret_cast<aomhip_search_block *>(at(o_s16));
+  int16_t *fmv32 = reinterpret_cast<int16_t *>(at(o_fmv32)), *mv32 = reinterpret_cast<int16_t *>(at(o_mv32));
+  int16_t *fmv16 = reinterpret_cast<int16_t *>(at(o_fmv16)), *mv16 = reinterpret_cast<int16_t *>(at(o_mv16));
+  int32_t *cl32 = tp->use_cost_list ? reinterpret_cast<int32_t *>(at(o_cl32)) : nullptr;
+  int32_t *cl16 = tp->use_cost_list ? reinterpret_cast<int32_t *>(at(o_cl16)) : nullptr;
+  int32_t *mse32 = reinterpret_cast<int32_t *>(at(o_mse32));
+  uint32_t *err32 = reinterpret_cast<uint32_t *>(at(o_err32)), *err16 = reinterpret_cast<uint32_t *>(at(o_err16));
+
+  const size_t esz = frames->bit_depth == 8 ? 1 : 2;
+  auto frame_view = [&](int f) {  // one frame of the ring as a ring of one (the batched searches pair src / ref by frame index)
+    aomhip_planes v = *frames;
+    v.base = static_cast<char *>(frames->base) + (size_t)f * frames->frame_stride * esz;
+    v.n_frames = 1;
+    return v;
+  };
+  const aomhip_planes src = frame_view(filter_frame);
+  const unsigned g1 = (unsigned)((n1 + 255) / 256), g4 = (unsigned)((n4 + 255) / 256);
+  hipStream_t st = ctx->stream;
+  AOMHIP_TRY(hipMemsetAsync(ref_mv, 0, n1 * 4, st));  // MV ref_mv = kZeroMv (:855)
+  for (int f = 0; f < frames->n_frames; ++f) {
+    int16_t *out_mvs = d_subblock_mvs + (size_t)f * n4 * 2;
+    int32_t *out_mses = d_subblock_mses + (size_t)f * n4;
+    if (f == filter_frame || (frame_present && !frame_present[f])) {
+      hipLaunchKernelGGL(tf_fill_kernel, dim3(g4), dim3(256), 0, st, out_mvs, out_mses, (int)n4);
+      if (f == filter_frame) hipLaunchKernelGGL(tf_negate_kernel, dim3((unsigned)((2 * n1 + 255) / 256)), dim3(256), 0, st, ref_mv, (int)(2 * n1));  // :864-867
+      AOMHIP_LAUNCH_CHECK();
+      continue;
+    }
+    const aomhip_planes ref = frame_view(f);
+    int rc;
+    hipLaunchKernelGGL(tf_full32_list_kernel, dim3(g1), dim3(256), 0, st, d_blocks, ref_mv, n, l32);
+    AOMHIP_LAUNCH_CHECK();
+    rc = aomhip_full_pixel_search_batch(ctx, &src, &ref, 0, kTfBlock, kTfBlock, &tp->full, nullptr, nullptr, nullptr, l32, n, fmv32,
+                                        reinterpret_cast<int32_t *>(at(o_fcost32)), cl32, nullptr);
+    if (rc != AOMHIP_OK) return rc;
+    if (tp->force_integer_mv) {
+      aomhip_var_cand *cands = reinterpret_cast<aomhip_var_cand *>(at(o_cand));
+      hipLaunchKernelGGL(tf_integer_cands_kernel, dim3(g1), dim3(256), 0, st, d_blocks, fmv32, n, cands);
+      AOMHIP_LAUNCH_CHECK();
+      rc = aomhip_variance_batch(ctx, &src, &ref, 0, 1, kTfBlock, kTfBlock, cands, n, 0, err32, reinterpret_cast<uint32_t *>(at(o_sse32)));
+      if (rc != AOMHIP_OK) return rc;
+      hipLaunchKernelGGL(tf_integer_finish_kernel, dim3(g1), dim3(256), 0, st, fmv32, err32, n, mv32, mse32);
+      hipLaunchKernelGGL(tf_finish_kernel, dim3(g1), dim3(256), 0, st, mv32, mse32, (const int16_t *)nullptr, (const uint32_t *)nullptr, n, 0,
+                         tp->mse_thresh, ref_mv, out_mvs, out_mses);
+      AOMHIP_LAUNCH_CHECK();
+      continue;
+    }
+    hipLaunchKernelGGL(tf_subpel_list_kernel, dim3(g1), dim3(256), 0, st, d_blocks, fmv32, n, 1, s32);
+    AOMHIP_LAUNCH_CHECK();
+    rc = aomhip_subpel_tree_batch(ctx, &src, &ref, 0, kTfBlock, kTfBlock, &tp->sub, nullptr, nullptr, nullptr, s32, cl32, n, mv32, err32,
+                                  reinterpret_cast<int32_t *>(at(o_dist32)), reinterpret_cast<uint32_t *>(at(o_sse32)));
+    if (rc != AOMHIP_OK) return rc;
+    hipLaunchKernelGGL(tf_after_block_kernel, dim3(g1), dim3(256), 0, st, d_blocks, mv32, err32, n, ref_mv, mse32, l16);
+    AOMHIP_LAUNCH_CHECK();
+    rc = aomhip_full_pixel_search_batch(ctx, &src, &ref, 0, kTfSub, kTfSub, &tp->full, nullptr, nullptr, nullptr, l16, (int)n4, fmv16,
+                                        reinterpret_cast<int32_t *>(at(o_fcost16)), cl16, nullptr);
+    if (rc != AOMHIP_OK) return rc;
+    hipLaunchKernelGGL(tf_subpel_list_kernel, dim3(g4), dim3(256), 0, st, d_blocks, fmv16, n, 4, s16);
+    AOMHIP_LAUNCH_CHECK();
+    rc = aomhip_subpel_tree_batch(ctx, &src, &ref, 0, kTfSub, kTfSub, &tp->sub, nullptr, nullptr, nullptr, s16, cl16, (int)n4, mv16, err16,
+                                  reinterpret_cast<int32_t *>(at(o_dist16)), reinterpret_cast<uint32_t *>(at(o_sse16)));
+    if (rc != AOMHIP_OK) return rc;
+    hipLaunchKernelGGL(tf_finish_kernel, dim3(g1), dim3(256), 0, st, mv32, mse32, mv16, err16, n, 1, tp->mse_thresh, ref_mv, out_mvs, out_mses);
+    AOMHIP_LAUNCH_CHECK();
+  }
+  if (d_ref_mv_out) AOMHIP_TRY(hipMemcpyAsync(d_ref_mv_out, ref_mv, n1 * 4, hipMemcpyDeviceToDevice, st));
+  return AOMHIP_OK;
+}

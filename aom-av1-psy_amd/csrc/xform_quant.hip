@@ -837,6 +837,32 @@ static bool type_ok(int tx_size, int tx_type) {
   return kTxH[tx_size] <= vmax && kTxW[tx_size] <= hmax;
 }
 
+__global__ void validate_txb_kernel(const aomhip_txb *blocks, int n, int tw, int th, int wht_ok, int any_type, int *status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = blocks[i].tx_type;
+  bool ok;
+  if (t == AOMHIP_TX_WHT) ok = wht_ok != 0;
+  else if (t > 15) ok = false;
+  else if (any_type) ok = true;
+  else {  // av1_get_fwd_txfm_cfg (av1_txfm.c:89-96): ADST <= 16 points, identity <= 32, 64-point DCT only
+    const uint8_t vkind[16] = { 0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3 }, hkind[16] = { 0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2 };
+    const int vmax = vkind[t] == 0 ? 64 : vkind[t] == 3 ? 32 : 16, hmax = hkind[t] == 0 ? 64 : hkind[t] == 3 ? 32 : 16;
+    ok = th <= vmax && tw <= hmax;
+  }
+  if (!ok) atomicOr(status, kStatusBadTxType);
+}
+int validate_txb_list(aomhip_ctx *ctx, const aomhip_txb *d_blocks, int n_blocks, int tx_size, bool wht_ok, bool any_type_0_15) {
+  if (!d_blocks || n_blocks <= 0) return AOMHIP_OK;
+  static const int tw[19] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64 };
+  static const int th[19] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16 };
+  hipLaunchKernelGGL(validate_txb_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, ctx->stream, d_blocks, n_blocks, tw[tx_size],
+                     th[tx_size], (int)(wht_ok && tx_size == 0), (int)any_type_0_15, ctx->d_status);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+bool tx_type_ok(int tx_size, int tx_type) { return tx_size >= 0 && tx_size < 19 && type_ok(tx_size, tx_type); }
+
 static QuantArgs to_args(const aomhip_quant_params *q, int quant_kind = 0) {
   QuantArgs a;
   for (int i = 0; i < 2; ++i) {
@@ -882,6 +908,7 @@ int aomhip_xform_quant_batch(aomhip_ctx *ctx, const int16_t *d_residual, int res
     return AOMHIP_ERR_INVALID;
   }
   if (n_blocks == 0) return AOMHIP_OK;
+  if (int rc = validate_txb_list(ctx, d_blocks, n_blocks, tx_size, true, false)) return rc;
   XqLaunch l{ ctx->stream, d_residual, nullptr, residual_stride, 0, d_blocks, n_blocks, grid_cols, uniform_tx_type,
               to_args(qparams), d_coeff, d_qcoeff, d_dqcoeff, d_eob };
   return is_hbd ? dispatch_xq<true, 0>(tx_size, l) : dispatch_xq<false, 0>(tx_size, l);
@@ -899,6 +926,7 @@ int aomhip_xform_quant_ex_batch(aomhip_ctx *ctx, const int16_t *d_residual, int 
     return AOMHIP_ERR_INVALID;
   }
   if (n_blocks == 0) return AOMHIP_OK;
+  if (int rc = validate_txb_list(ctx, d_blocks, n_blocks, tx_size, true, false)) return rc;
   XqLaunch l{ ctx->stream, d_residual, nullptr, residual_stride, 0, d_blocks, n_blocks, grid_cols, uniform_tx_type,
               to_args(qparams, quant_kind), d_coeff, d_qcoeff, d_dqcoeff, d_eob };
   l.err_out = d_block_error;
@@ -920,6 +948,7 @@ int aomhip_subtract_xform_quant_ex_batch(aomhip_ctx *ctx, const aomhip_planes *s
     return AOMHIP_ERR_INVALID;
   }
   if (n_blocks == 0) return AOMHIP_OK;
+  if (int rc = validate_txb_list(ctx, d_blocks, n_blocks, tx_size, true, false)) return rc;
   const size_t esz = src->bit_depth == 8 ? 1 : 2;
   const char *s = static_cast<const char *>(src->base) +
                   ((size_t)frame * src->frame_stride + (size_t)src->border * src->stride + src->border) * esz;
@@ -950,6 +979,7 @@ int aomhip_quantize_b_adaptive_batch(aomhip_ctx *ctx, const int32_t *d_coeff, in
     return AOMHIP_ERR_INVALID;
   }
   if (n_blocks == 0) return AOMHIP_OK;
+  if (int rc = validate_txb_list(ctx, d_blocks, n_blocks, tx_size, false, true)) return rc;
   const QuantArgs qa = to_args(qparams);
   const int w = kTxW[tx_size], h = kTxH[tx_size];
   const int kw = w > 32 ? 32 : w, kh = h > 32 ? 32 : h;

@@ -300,7 +300,23 @@ class TxqGrid:
             self.ctx.free(d)
 
 
+def pmc_calibration_ops(ctx):
+    """tools/gpu_pmc_txq.sh (AOMHIP_PMC_CALIB=1): two launches with KNOWN HBM byte counts inside the profiled process, so that the
+    FETCH_SIZE / WRITE_SIZE counters of the kernels of interest can be scaled by factors measured in the same run: a 256 MiB fill
+    (writes only) and aomhip_plane_sse over two 3840x2160 16-bit planes (reads every visible byte of both once, writes 8 bytes)."""
+    d = ctx.malloc(256 << 20)
+    a, b = ctx.planes_alloc(3840, 2160, 32, 10, 1), ctx.planes_alloc(3840, 2160, 32, 10, 1)
+    d_sse = ctx.malloc(8)
+    for _ in range(3):
+        ctx.memset(d, 1, 256 << 20)
+        ctx.plane_sse(a, 0, b, 0, d_sse)
+    ctx.sync()
+    ctx.free(d); ctx.free(d_sse); ctx.planes_free(a); ctx.planes_free(b)
+
+
 def run_txq(pkg, ctx, orc, steps, warmup, want_cpu):
+    if os.environ.get("AOMHIP_PMC_CALIB") == "1":
+        pmc_calibration_ops(ctx)
     wl = TxqGrid(pkg, ctx, orc)
     ok = wl.check()
     for _ in range(warmup):
@@ -329,6 +345,10 @@ def run_txq(pkg, ctx, orc, steps, warmup, want_cpu):
                         "avg_launch_ms": per[dom]["avg_launch_ms"],
                         "note": "algorithmic bytes = (10*N + 2) per block of N samples (int16 in, qcoeff + dqcoeff out, eob)"},
            "per_size": per}
+    if res["roofline"]["traffic"]:   # profiles/traffic.json, tools/gpu_pmc_txq.sh: FETCH_SIZE x 2 (guide) + WRITE_SIZE calibrated on a fill
+        t, ms = res["roofline"]["traffic"], per[dom]["avg_launch_ms"]
+        res["roofline"]["traffic_GBs"] = t / (ms * 1e-3) / 1e9
+        res["roofline"]["traffic_over_algorithmic"] = t / (wl.blocks[int(dom.split("x")[0])] * (10 * int(dom.split("x")[0]) ** 2 + 2))
     if want_cpu and orc is not None:
         res["cpu_baseline"] = wl.cpu_baseline()
     wl.free()
@@ -714,6 +734,53 @@ def run_wiener_stats(pkg, ctx, orc, steps, warmup):
     return out
 
 
+def run_tf(pkg, ctx, orc, steps, warmup, width=3840, height=2160, bd=10, n_frames=5):
+    """the temporal filter's motion search (tf_motion_search, temporal_filter.c:87-253) for every 32x32 block of a
+    4K 10-bit frame against the 4 other frames of a 5-frame window, one aomhip_tf_motion_search_frames call per filtered frame: per
+    reference frame the 32x32 NSTEP + mesh full-pel search, the 8-tap sub-pel tree, the same pair for the four 16x16 sub-blocks, the
+    partition decision and the ref_mv hand-over, all in device memory."""
+    capi, synth = pkg.capi, pkg.synth
+    border, filt = 160, n_frames // 2
+    mesh = [(64, 8), (28, 4), (15, 1), (7, 1)]   # good_quality_mesh_patterns[0] (speed_features.c:25-33)
+    planes = ctx.planes_alloc(width, height, border, bd, n_frames)
+    base, _ = synth.shifted_smooth_pair(width + 64, height + 64, 0, bd)
+    rng = np.random.default_rng(11)
+    host = []
+    for f in range(n_frames):
+        d = f - filt
+        img = base[32 + d:32 + d + height, 32 - 2 * d:32 - 2 * d + width].astype(np.int32) + rng.integers(-3, 4, (height, width))
+        host.append(np.clip(img, 0, (1 << bd) - 1).astype(np.uint16 if bd > 8 else np.uint8))
+        ctx.planes_upload(planes, f, host[-1])
+    blocks = capi.tf_block_list(width, height, border)
+    n = len(blocks)
+    d_b = ctx.to_device(blocks)
+    d_mv, d_mse, d_ref = ctx.malloc(n_frames * n * 16), ctx.malloc(n_frames * n * 16), ctx.malloc(n * 4)
+    out = {}
+    for name, q in (("q30_mesh_pruned_when_close", 30), ("q12_mesh_always", 12)):
+        tp = capi.TfParams.default(width, height, bd, q, 1, mesh)
+        once = lambda: ctx.tf_motion_search_frames(planes, filt, tp, d_b, n, d_mv, d_mse, d_ref)
+        for _ in range(warmup):
+            once()
+        out[name] = {"ms_per_filtered_frame": kernel_avg_ms(ctx, once, max(3, steps // 4))}
+    ok = None
+    if orc is not None:   # the last call (q 12) against the oracle on every 97th block (blocks are independent)
+        mvs = ctx.from_device(d_mv, (n_frames, n, 4, 2), np.int16)
+        mses = ctx.from_device(d_mse, (n_frames, n, 4), np.int32)
+        idx = np.arange(0, n, 97)
+        fb = [orc.extend_plane(h, border, planes.stride) for h in host]
+        wmv, wmse, _ = orc.tf_motion_search_frames(fb, filt, border, orc.tf_block_list(width, height, border)[idx], orc.tf_params(width, height, bd, 12, 1, mesh),
+                                                   threads=8)
+        ok = bool(np.array_equal(mvs[:, idx], wmv) and np.array_equal(mses[:, idx], wmse))
+    for d in (d_b, d_mv, d_mse, d_ref):
+        ctx.free(d)
+    ctx.planes_free(planes)
+    ms = out["q30_mesh_pruned_when_close"]["ms_per_filtered_frame"]
+    return dict(out, workload="tf_motion_search_4k_10bit", value=n * (n_frames - 1) / (ms * 1e-3), unit="block searches/s (32x32 block x reference frame)",
+                blocks_per_frame=n, reference_frames=n_frames - 1, parity_sample=ok,
+                config={"frame": "%dx%d %d-bit" % (width, height, bd), "window": n_frames, "search": "NSTEP + mesh (run_mesh_search 1, prune LVL_1), L1_HDRES; "
+                        "av1_find_best_sub_pixel_tree USE_8_TAPS; 32x32 + four 16x16 per block and frame"})
+
+
 def time_steps(wl, ctx, dist, dev, steps, warmup):
     for _ in range(warmup):
         wl.step()
@@ -841,7 +908,7 @@ def main():
                     help="default: sad16x16_modeA_1080p_8bit on one GPU; with N > 1 the strong-scaling search pipeline with the "
                          "per-frame RCCL exchange (search_4k_10bit) + the SAD workload as a second, weak-scaling entry",
                     choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "search_4k_10bit", "inner_loop_4k_10bit", "default_search_4k_10bit", "cdef_search_4k_10bit",
-                                                "wiener_stats_4k"])
+                                                "wiener_stats_4k", "tf_motion_search_4k_10bit"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -923,6 +990,12 @@ def main():
                               scaling="weak", vs_baseline=None, dtype="u16", data="synthetic",
                               ms_per_step=r["full_pixel_search_NSTEP_ms_per_frame"] + r["subpel_tree_8tap_ms_per_frame"])))
         return
+    if args.workload == "tf_motion_search_4k_10bit":  # SURVEY 8(f) row 1 (single GPU)
+        r = run_tf(pkg, ctx, orc, args.steps, args.warmup)
+        ctx.close()
+        print(json.dumps(dict(r, metric="tf block searches/s", n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
+                              vs_baseline=None, dtype="u16", data="synthetic", ms_per_step=r["q30_mesh_pruned_when_close"]["ms_per_filtered_frame"])))
+        return
     if args.workload in ("cdef_search_4k_10bit", "wiener_stats_4k"):  # informational encoder-side searches (single GPU)
         r = (run_cdef_search if args.workload == "cdef_search_4k_10bit" else run_wiener_stats)(pkg, ctx, orc, args.steps, args.warmup)
         ctx.close()
@@ -956,6 +1029,7 @@ def main():
             others.append(run_search_default(pkg, ctx, orc, max(4, args.steps // 2), 1))
             others.append(run_cdef_search(pkg, ctx, orc, max(4, args.steps // 4), 1))
             others.append(run_wiener_stats(pkg, ctx, orc, max(3, args.steps // 6), 1))
+            others.append(run_tf(pkg, ctx, orc, max(4, args.steps // 4), 1))
     ctx.close()
 
     if rank == 0:

@@ -571,6 +571,53 @@ int aomhip_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
 int aomhip_search_sites(int search_method, int *num_search_steps, int searches_per_step[22], int radius[22],
                         int16_t sites[22][17][2]);
 
+/* ------------------------------------------------------------------ temporal filter: the motion search of one filtered frame */
+
+/* tf_motion_search (av1/encoder/temporal_filter.c:87-253) for EVERY 32x32 block of the frame to filter against every other
+ * frame of the filter window, in one call.  The reference walks block by block and, per block, frame by frame
+ * (av1_tf_do_filtering_row, :849-867), handing ref_mv from one frame's search to the next; blocks never depend on each
+ * other, so here each frame is one pass over all blocks with the ref_mv of every block kept in device memory between the passes.
+ * Per block and reference frame, exactly as the reference:
+ *   av1_full_pixel_search (NSTEP, start = full-pel ref_mv, run_mesh_search = 1, baseline MV 0, L1 MV cost) on the 32x32 block,
+ *   the sub-pel search from there (find_fractional_mv_step: `sub.tree`; USE_8_TAPS; EIGHTH_PEL; MV_COST_NONE) -> block MV, block_mse,
+ *   the same two searches for the four 16x16 sub-blocks, started at the block's MV, inside the BLOCK's mv_limits,
+ *   tf_determine_block_partition (:270-293), and ref_mv = block MV, or 0 when block_mse > mse_thresh.
+ * With force_integer_mv only the 32x32 full-pel search runs and the block variance at that MV gives block_mse (:158-168). */
+typedef struct {
+  aomhip_search_params full;   /* what av1_make_default_fullpel_ms_params + tf_motion_search set: search_method NSTEP, step_param =
+                                * av1_init_search_range(max(width, height)), mv_cost_type by min(width, height), run_mesh_search 1,
+                                * prune_mesh_search / mesh_search_mv_diff_threshold (from sf.mv_sf.prune_mesh_search and q, :139-143),
+                                * mesh_patterns = sf.mv_sf.mesh_patterns, use_downsampled_sad = sf.mv_sf.use_downsampled_sad */
+  aomhip_subpel_params sub;    /* tree = sf.mv_sf.subpel_search_method, mv_cost_type NONE, forced_stop 0 (EIGHTH_PEL),
+                                * subpel_search_type 3 (USE_8_TAPS), iters_per_step = sf.mv_sf.subpel_iters_per_step,
+                                * allow_hp = cm->features.allow_high_precision_mv */
+  int32_t use_cost_list;       /* cond_cost_list(cpi, cost_list) != NULL (encoder.h: subpel_search_method != SUBPEL_TREE &&
+                                * use_fullpel_costlist): the full-pel search fills the list, the pruned sub-pel trees read it */
+  int32_t force_integer_mv;    /* cm->features.cur_frame_force_integer_mv */
+  int32_t mse_thresh;          /* (min(width, height) >= 720 ? 12 : 3) << (bit_depth - 8)   (:249-252) */
+} aomhip_tf_params;
+
+/* Host helpers (aom-av1-psy_amd/host/aomhip_tf.c, plain C, no GPU call): the values above for a frame size, bit depth and q the way
+ * tf_motion_search derives them (prune_mesh_level = sf.mv_sf.prune_mesh_search: 0 disabled, 1 LVL_1, 2 LVL_2; mesh_patterns as
+ * given); and the block list of a frame: one entry per 32x32 block in raster order (mb_rows x mb_cols = ceil(height / 32) x
+ * ceil(width / 32): get_num_blocks, encoder.h:3850, temporal_filter.c:1236-1237), bx / by, and row/col min/max = mb->mv_limits of that block
+ * (av1_set_mv_row_limits / av1_set_mv_col_limits, mcomp.h:216-240, with mi_rows / mi_cols of the 8-aligned frame and `border` =
+ * oxcf.border_in_pixels); start_* / ref_* are unused.  aomhip_tf_block_list returns the number of blocks (blocks may be NULL). */
+void aomhip_tf_default_params(int width, int height, int bit_depth, int q, int prune_mesh_level, const int mesh_patterns[8],
+                              int subpel_tree, int subpel_iters_per_step, int allow_hp, int use_cost_list, int use_downsampled_sad,
+                              int force_integer_mv, aomhip_tf_params *out);
+int aomhip_tf_block_list(int width, int height, int border, aomhip_search_block *blocks);
+
+/* frames: ring of the filter window's luma planes (frames->n_frames of them, border >= the one given to aomhip_tf_block_list);
+ * filter_frame: index of the frame to filter; frame_present: n_frames flags or NULL (frames[frame] == NULL is skipped, :858).
+ * d_blocks: the list of aomhip_tf_block_list in device memory.  Outputs, for frame f and block i at [(f * n_blocks + i) * 4 + k],
+ * k = the sub-block in raster order: d_subblock_mvs (row, col in 1/8 pel) and d_subblock_mses after the partition decision;
+ * the entries of the filter frame itself and of absent frames are 0 / INT32_MAX (what the caller's initialisation leaves, :861-862).
+ * d_ref_mv (2 * n_blocks int16, or NULL): the ref_mv each block ends with.  Asynchronous on the context's stream. */
+int aomhip_tf_motion_search_frames(aomhip_ctx *ctx, const aomhip_planes *frames, int filter_frame, const uint8_t *frame_present,
+                                   const aomhip_tf_params *params, const aomhip_search_block *d_blocks, int n_blocks,
+                                   int16_t *d_subblock_mvs, int32_t *d_subblock_mses, int16_t *d_ref_mv);
+
 /* ------------------------------------------------------------------ the encoder's kernel vtable */
 
 /* Mirror of aom_variance_fn_ptr_t (aom_dsp/variance.h:84-103): same field order, same pointer types

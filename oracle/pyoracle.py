@@ -794,3 +794,117 @@ def cdef_skip_map(grid):
             for i in range(n):
                 skip[fr * 8 + buf[2 * i], fc * 8 + buf[2 * i + 1]] = 0
     return skip
+
+
+# ---- temporal filter: tf_motion_search over a filter window (av1/encoder/temporal_filter.c:87-293, 849-867) ----
+# A composition of the search restatements above (orc_full_pixel_search_batch = av1_full_pixel_search, orc_subpel_tree_batch
+# = av1_find_best_sub_pixel_tree*) with the reference's bookkeeping between them in numpy integer arithmetic.
+TF_BLOCK = 32
+
+
+def tf_init_search_range(size):
+    """av1_init_search_range (mcomp.c:217-226)"""
+    sr, size = 0, max(16, size)
+    while (size << sr) < 1023:
+        sr += 1
+    return min(sr, 11 - 2)
+
+
+def tf_block_list(width, height, border):
+    """One record per 32x32 block, raster order (get_num_blocks, encoder.h:3850); limits = mb->mv_limits from av1_set_mv_row_limits /
+    av1_set_mv_col_limits (mcomp.h:216-240) with mi_rows / mi_cols = size_in_mi (encoder_utils.h:55-69)."""
+    mb_rows, mb_cols = -(-height // TF_BLOCK), -(-width // TF_BLOCK)
+    mi_rows, mi_cols = ((height + 7) & ~7) // 4, ((width + 7) & ~7) // 4
+    b = np.zeros(mb_rows * mb_cols, np.dtype([(n, "<i2") for n in ("bx", "by", "start_row", "start_col", "ref_row", "ref_col", "row_min", "row_max",
+                                                                    "col_min", "col_max")]))
+    r, c = np.divmod(np.arange(b.size), mb_cols)
+    b["bx"], b["by"] = c * TF_BLOCK, r * TF_BLOCK
+    for pos, mi_n, lo, hi in ((r * 8, mi_rows, "row_min", "row_max"), (c * 8, mi_cols, "col_min", "col_max")):
+        b[lo] = np.maximum(-(pos * 4 + border - 8), -((pos + 8) * 4 + 8))
+        b[hi] = np.minimum((mi_n - pos - 8) * 4 + border - 8, (mi_n - pos) * 4 + 8)
+    return b
+
+
+def tf_params(width, height, bit_depth, q, prune_mesh_level, mesh, subpel_tree="tree", iters_per_step=2, allow_hp=1, use_cost_list=0,
+              use_downsampled_sad=0, force_integer_mv=0):
+    """What tf_motion_search sets up (:118-128, :153-167, :176-185, :249-252)."""
+    m = min(width, height)
+    prune, thr = int(prune_mesh_level == 2), 4                                   # mcomp.c:138-140
+    if prune_mesh_level == 1:
+        prune, thr = int(q > 20), 2                                              # :163-167
+    return dict(step_param=tf_init_search_range(max(width, height)), cost_type=3 if m >= 720 else (2 if m >= 480 else 1), prune=prune, thr=thr,
+                mesh=mesh, tree=subpel_tree, iters=iters_per_step, allow_hp=allow_hp, use_cost_list=use_cost_list, skip_sad=use_downsampled_sad,
+                force_integer_mv=force_integer_mv, mse_thresh=(12 if m >= 720 else 3) << (bit_depth - 8), bd=bit_depth)
+
+
+def _rawpel(v):
+    v = np.asarray(v, np.int32)
+    return (v + 3 + (v >= 0)) >> 3                                               # GET_MV_RAWPEL (mv.h:28)
+
+
+def _tf_lists(blocks, per, start, subpel):
+    """search records for the block (per = 1) or its four sub-blocks (per = 4): origin, start MV, limits derived from the BLOCK's
+    mb->mv_limits for the zero baseline MV (av1_set_mv_search_range, mcomp.c:196-215 / av1_set_subpel_mv_search_range, mcomp.h:344-361)."""
+    out = np.repeat(blocks, per)
+    if per == 4:
+        k = np.tile(np.arange(4), len(blocks))
+        out["bx"] += (k & 1) * 16
+        out["by"] += (k >> 1) * 16
+    out["ref_row"] = out["ref_col"] = 0
+    out["start_row"], out["start_col"] = start[:, 0], start[:, 1]
+    for lo, hi in (("row_min", "row_max"), ("col_min", "col_max")):
+        if subpel:
+            out[lo] = np.maximum(np.maximum(out[lo].astype(np.int32) * 8, -1023 * 8), -(1 << 14) + 1)
+            out[hi] = np.minimum(np.minimum(out[hi].astype(np.int32) * 8, 1023 * 8), (1 << 14) - 1)
+        else:
+            out[lo] = np.maximum(out[lo], max(-1023, int(_rawpel(-(1 << 14))) + 1))
+            out[hi] = np.minimum(out[hi], min(1023, int(_rawpel(1 << 14)) - 1))
+    return out
+
+
+def tf_motion_search_frames(frames_b, filter_frame, border, blocks, p, frame_present=None, threads=4):
+    """frames_b: border-extended luma planes of the window.  -> (mvs [F, n, 4, 2] int16, mses [F, n, 4] int32, ref_mv [n, 2])."""
+    F, n = len(frames_b), len(blocks)
+    mvs = np.zeros((F, n, 4, 2), np.int16)
+    mses = np.full((F, n, 4), 2147483647, np.int32)
+    ref_mv = np.zeros((n, 2), np.int32)                                          # :855
+    src = frames_b[filter_frame]
+    q = search_params("NSTEP", p["step_param"], p["cost_type"], skip_sad=p["skip_sad"], run_mesh=1, prune_mesh=p["prune"], mesh_diff_thr=p["thr"],
+                      mesh=p["mesh"], no_cost_list=int(not p["use_cost_list"]))
+    sub = dict(tree=p["tree"], cost_type=4, iters=p["iters"], allow_hp=p["allow_hp"], forced_stop=0, bd=p["bd"], threads=threads, subpel_search_type=3)
+    for f in range(F):
+        if f == filter_frame:
+            ref_mv = -ref_mv                                                     # :864-867
+            continue
+        if frame_present is not None and not frame_present[f]:
+            continue
+        ref = frames_b[f]
+        full32, _, cl32, _ = full_pixel_search_batch(src, ref, border, 32, 32, _tf_lists(blocks, 1, _rawpel(ref_mv), False), q, bd=p["bd"], threads=threads)
+        if p["force_integer_mv"]:                                                # :158-168
+            block_mv = full32.astype(np.int32) * 8
+            err = np.array([variance(ref, border + int(b["by"]) + int(m[0]), border + int(b["bx"]) + int(m[1]), src, border + int(b["by"]),
+                                     border + int(b["bx"]), 32, 32, p["bd"] if p["bd"] > 8 else None)[0] for b, m in zip(blocks, full32)], np.uint32)
+            block_mse = ((err.astype(np.uint64) + 512) // 1024).astype(np.int32)
+            sub_mv = np.zeros((n, 4, 2), np.int32)
+            sub_mse = np.full((n, 4), 2147483647, np.int64)
+        else:
+            mv32, err32, _, _ = subpel_tree_batch(src, ref, border, 32, 32, _tf_lists(blocks, 1, full32.astype(np.int32) * 8, True),
+                                                  cost_lists=cl32 if p["use_cost_list"] else None, **sub)
+            block_mv = mv32.astype(np.int32)
+            block_mse = ((err32.astype(np.uint64) + 512) // 1024).astype(np.int32)  # DIVIDE_AND_ROUND on unsigned error (:190)
+            ref_mv = block_mv.copy()                                             # :192
+            full16, _, cl16, _ = full_pixel_search_batch(src, ref, border, 16, 16, _tf_lists(blocks, 4, np.repeat(_rawpel(ref_mv), 4, axis=0), False), q,
+                                                         bd=p["bd"], threads=threads)
+            mv16, err16, _, _ = subpel_tree_batch(src, ref, border, 16, 16, _tf_lists(blocks, 4, full16.astype(np.int32) * 8, True),
+                                                  cost_lists=cl16 if p["use_cost_list"] else None, **sub)
+            sub_mv = mv16.astype(np.int32).reshape(n, 4, 2)
+            sub_mse = ((err16.astype(np.uint64) + 128) // 256).astype(np.int64).reshape(n, 4)
+        # tf_determine_block_partition (:270-293)
+        total, spread = sub_mse.sum(1), sub_mse.max(1) - sub_mse.min(1)
+        bm = block_mse.astype(np.int64)
+        keep = ((bm * 15 < total * 4) & (spread < 48)) | ((bm * 14 < total * 4) & (spread < 24))
+        sub_mv[keep] = block_mv[keep][:, None, :]
+        sub_mse[keep] = bm[keep][:, None]
+        mvs[f], mses[f] = sub_mv, sub_mse
+        ref_mv = np.where((block_mse > p["mse_thresh"])[:, None], 0, ref_mv)     # :249-252
+    return mvs, mses, ref_mv.astype(np.int16)

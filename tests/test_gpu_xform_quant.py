@@ -321,3 +321,31 @@ def test_quantize_fp_flavour(hip, oracle, ctx, tx_size, is_hbd):
                 assert np.array_equal(g[used], wv[used]), (tx_size, is_hbd, qindex, name)
         for d in (d_res, d_blk, d_c, d_q, d_dq, d_e):
             ctx.free(d)
+
+
+def test_per_block_tx_type_that_does_not_exist_for_the_size_is_reported(hip, oracle, ctx):
+    """a per-block list is in device memory, so the host cannot validate it when the call is made; a check kernel in
+    front of the transform ORs a code into the context's device status word and the next aomhip_ctx_sync fails (then clears it)."""
+    rng = np.random.default_rng(5)
+    W = H = 64
+    residual = rng.integers(-255, 256, (H, W)).astype(np.int16)
+    d_res = ctx.to_device(residual)
+    q = hip.capi.QuantParams.from_tables(oracle.build_quantizer_y(8, 100))
+    for tx_size, bad_type, good_type in ((3, 1, 0), (4, 9, 0), (2, 16, 1), (1, 200, 3)):     # ADST on 32 points, IDTX on 64, WHT beyond 4x4, junk
+        w = hip.capi.lib.aomhip_tx_size_wide(tx_size)
+        nc = hip.capi.lib.aomhip_tx_max_eob(tx_size)
+        blocks = np.zeros(2, hip.capi.txb_dtype)
+        blocks["x"] = [0, 0]; blocks["y"] = [0, 0]; blocks["out_offset"] = [0, nc]
+        d_c, d_q, d_dq, d_e = ctx.malloc(2 * nc * 4), ctx.malloc(2 * nc * 4), ctx.malloc(2 * nc * 4), ctx.malloc(16)
+        for types, fails in (([good_type, bad_type], True), ([good_type, good_type], False)):
+            blocks["tx_type"] = types
+            d_b = ctx.to_device(blocks)
+            ctx.xform_quant_batch(d_res, W, tx_size, d_b, 2, 0, 0, q, False, d_c, d_q, d_dq, d_e)
+            if fails:
+                with pytest.raises(hip.capi.AomHipError, match="tx_type"):
+                    ctx.sync()
+            ctx.sync()                                           # reported once, then clear
+            ctx.free(d_b)
+        for d in (d_c, d_q, d_dq, d_e):
+            ctx.free(d)
+    ctx.free(d_res)
