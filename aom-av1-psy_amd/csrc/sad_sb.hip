@@ -408,6 +408,7 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
             okv &= (unsigned)__builtin_amdgcn_update_dpp(0u, okv, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
             okv &= (unsigned)__builtin_amdgcn_update_dpp(0u, okv, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
             if (__all((both && okv != 0) || (!has_g && !has_c))) {
+              if (a.dbg & 32) continue;  // (timing ablation: decode and tests only)
 #pragma unroll
               for (int j = 0; j < 4; ++j) base[j] = both ? quad_bcast(mbase, j) : (unsigned)a.ring_off;
               base[4] = both ? cbase : (unsigned)a.ring_off;
@@ -418,6 +419,10 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
                 const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
 #pragma unroll
                 for (int j = 0; j < 5; ++j) acc[j] = sad_unit(sv, lds_unit<G::kUnitBytes>(lds, base[j] + unit_roff[k]), acc[j]);
+              }
+              if (a.dbg & 128) {  // (timing ablation: no reduction, no stores)
+                if ((acc[0] & acc[1] & acc[2] & acc[3] & acc[4]) == 0xFFFFFFFFu) out1[0] = 0;
+                continue;
               }
 #pragma unroll
               for (int j = 0; j < 5; ++j) acc[j] = group_sum<G::kTpc>(acc[j]);
