@@ -451,8 +451,13 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
   constexpr int NC = W * H;
   constexpr int LS = 0;  // <= 64 samples: av1_get_tx_scale == 0
   const unsigned wg = xcd_chunked_index(blockIdx.x, nblk8);
-  const int bi = wg * kXqThreads + threadIdx.x;
-  if (bi >= n_blocks) return;
+  // 4x4: the stores below exchange data between the four lanes of a quad, so lanes past the end of the list stay alive
+  // (they redo the last block and store nothing)
+  constexpr bool kQuadStores = W == 4 && H == 4;
+  const int bi_raw = wg * kXqThreads + threadIdx.x;
+  const bool valid = bi_raw < n_blocks;
+  if (!kQuadStores && !valid) return;
+  const int bi = valid ? bi_raw : n_blocks - 1;
   int bx, by, tx_type = uniform_type;
   int64_t out_off = (int64_t)bi * NC;
   if (blocks) {
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
   int64_t berr = 0, bssz = 0;
   int32_t qv[H][W], dv[H][W];
   auto emit = [&](int r, int c, int32_t v) {  // coefficient (r, c) = index c * H + r of the reference's output
-    if (coeff) coeff[out_off + c * H + r] = v;
+    if (coeff && valid) coeff[out_off + c * H + r] = v;
     const int ac = (r | c) != 0;
     quantize_one<HBD, LS>(v, zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.qs_log2[ac], qa.dequant[ac], &qv[r][c],
                           &dv[r][c]);
@@ -577,8 +582,62 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
       }
     }
   }
-  eob[bi] = (uint16_t)my_eob;
-  if (AOMHIP_XQ_EXTRAS && err_out) block_err_store(err_out, bi, berr, bssz, err_shift);
+  if (valid) eob[bi] = (uint16_t)my_eob;
+  if (AOMHIP_XQ_EXTRAS && err_out && valid) block_err_store(err_out, bi, berr, bssz, err_shift);
+  if constexpr (kQuadStores) {
+    // A lane's block is 64 contiguous output bytes per array, but written as four 16-byte stores the wavefront's store
+    // instruction touches 64 different 64-byte chunks with a quarter of each (4x the L2 write requests of a full-chunk
+    // store: PMC put this kernel at 3.4 TB/s against 4.5-4.7 for the sizes that store whole runs).  So the quad transposes
+    // first: with M[k][c] = column c of the block of quad lane k, two exchange stages (lane ^ 1, lane ^ 2) leave lane j
+    // with M[0..3][j], and store k then has the four lanes of a quad writing the four columns of ONE block = one 64-byte run.
+    const int qj = (int)(threadIdx.x & 3);
+    auto dpp_x1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); };  // quad_perm [1,0,3,2]
+    auto dpp_x2 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); };  // quad_perm [2,3,0,1]
+    auto transpose = [&](uint32_t (&m)[4][4]) {  // m[c][r]: column c (4 dwords) of this lane's block -> m[k][r]: this lane's column of lane k's block
+#pragma unroll
+      for (int c = 0; c < 4; c += 2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t send = (qj & 1) ? m[c][r] : m[c + 1][r];
+          const uint32_t recv = dpp_x1(send);
+          if (qj & 1) m[c][r] = recv; else m[c + 1][r] = recv;
+        }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t send = (qj & 2) ? m[c][r] : m[c + 2][r];
+          const uint32_t recv = dpp_x2(send);
+          if (qj & 2) m[c][r] = recv; else m[c + 2][r] = recv;
+        }
+    };
+    uint32_t mq[4][4], md[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { mq[c][r] = (uint32_t)qv[r][c]; md[c][r] = (uint32_t)dv[r][c]; }
+    transpose(mq);
+    transpose(md);
+    const uint32_t off_lo = (uint32_t)out_off, off_hi = (uint32_t)((uint64_t)out_off >> 32), vflag = valid ? 1u : 0u;
+    auto quad_bcast = [](uint32_t v, int k) {  // quad_perm [k,k,k,k]
+      switch (k) {
+        case 0: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xf, 0xf, false);
+        case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xf, 0xf, false);
+        case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xf, 0xf, false);
+        default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xf, 0xf, false);
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t lo = quad_bcast(off_lo, k), hi = quad_bcast(off_hi, k), ok = quad_bcast(vflag, k);
+      const int64_t o = (int64_t)(((uint64_t)hi << 32) | lo) + qj * 4;
+      if (ok) {
+        *reinterpret_cast<uint4 *>(qcoeff + o) = make_uint4(mq[k][0], mq[k][1], mq[k][2], mq[k][3]);
+        *reinterpret_cast<uint4 *>(dqcoeff + o) = make_uint4(md[k][0], md[k][1], md[k][2], md[k][3]);
+      }
+    }
+    return;
+  }
   // ---- store in the reference's transposed order (index c*H + r): column c is H contiguous values
 #pragma unroll
   for (int c = 0; c < W; ++c) {
