@@ -196,6 +196,14 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
   }
   const int n_active = uni(misc[0]);
   if (n_active == 0) return;
+  // The double-buffer offsets as selects over values read ONCE: indexing the by-value argument struct with the step's parity
+  // compiles to scalar loads from the kernel-argument segment in every step, and a scalar-cache miss costs 1000-3000 cycles while
+  // the loaders keep the memory system saturated (ISA of the first version: three s_load_dword + s_waitcnt at the top of every step).
+  const int src_off0 = a.src_off[0], src_off1 = a.src_off[1], gdesc_off0 = a.gdesc_off[0], gdesc_off1 = a.gdesc_off[1];
+  const int cdesc_off0 = a.cdesc_off[0], cdesc_off1 = a.cdesc_off[1];
+  auto src_off_of = [&](int buf) { return buf ? src_off1 : src_off0; };
+  auto gdesc_off_of = [&](int buf) { return buf ? gdesc_off1 : gdesc_off0; };
+  auto cdesc_off_of = [&](int buf) { return buf ? cdesc_off1 : cdesc_off0; };
 
   // The two roles run two separate instantiations of everything below: values only one role needs (the evaluation's
   // unit tables, the loaders' staging registers and chunk offsets) then never share a live range with the other role's
@@ -295,16 +303,16 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
           const unsigned q = (unsigned)(me + i * n);
           if ((int)q < total_s) {
             const unsigned row = __umulhi(q, a.magic_scpr), col = q - row * (unsigned)a.scpr;
-            *reinterpret_cast<uint4 *>(lds + a.src_off[b.buf] + row * a.spitch + col * 16) =
+            *reinterpret_cast<uint4 *>(lds + src_off_of(b.buf) + row * a.spitch + col * 16) =
                 make_uint4(st.srcv[i].v[0], st.srcv[i].v[1], st.srcv[i].v[2], st.srcv[i].v[3]);
           }
         }
   #pragma unroll
         for (int i = 0; i < kGN; ++i)
-          if (me + i * n < b.ng * 5) *reinterpret_cast<uint32_t *>(lds + a.gdesc_off[b.buf] + (me + i * n) * 4) = st.g[i];
+          if (me + i * n < b.ng * 5) *reinterpret_cast<uint32_t *>(lds + gdesc_off_of(b.buf) + (me + i * n) * 4) = st.g[i];
   #pragma unroll
         for (int i = 0; i < kCN; ++i)
-          if (me + i * n < b.nc * 2) *reinterpret_cast<uint32_t *>(lds + a.cdesc_off[b.buf] + (me + i * n) * 4) = st.c[i];
+          if (me + i * n < b.nc * 2) *reinterpret_cast<uint32_t *>(lds + cdesc_off_of(b.buf) + (me + i * n) * 4) = st.c[i];
       };
       auto win_y0 = [&](int cy) { return max(cy * a.sb_h - a.range, a.ymin); };
       auto win_y1 = [&](int cy) { return min(cy * a.sb_h + a.sb_h + a.range, a.ymax); };
@@ -381,9 +389,9 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
         }
       };
       auto eval = [&](const Win &w, int buf, int g0, int ng, int c0, int nc) {
-        const uint32_t *gd = reinterpret_cast<const uint32_t *>(lds + a.gdesc_off[buf]);
-        const uint32_t *cd = reinterpret_cast<const uint32_t *>(lds + a.cdesc_off[buf]);
-        const char *sbuf = lds + a.src_off[buf];
+        const uint32_t *gd = reinterpret_cast<const uint32_t *>(lds + gdesc_off_of(buf));
+        const uint32_t *cd = reinterpret_cast<const uint32_t *>(lds + cdesc_off_of(buf));
+        const char *sbuf = lds + src_off_of(buf);
         const int n_it = max(ng, nc);
         for (int i = slot; i < n_it; i += kPerWg) {
           const bool has_g = i < ng && !(a.dbg & 8), has_c = i < nc && !(a.dbg & 4);
@@ -626,16 +634,16 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
   #pragma unroll
         for (int i = 0; i < kSrcN; ++i)
           if (s_goff[i] < slim)
-            *reinterpret_cast<uint4 *>(lds + a.src_off[b.buf] + s_loff[i]) =
+            *reinterpret_cast<uint4 *>(lds + src_off_of(b.buf) + s_loff[i]) =
                 make_uint4(st.srcv[i].v[0], st.srcv[i].v[1], st.srcv[i].v[2], st.srcv[i].v[3]);
   #pragma unroll
         for (int i = 0; i < kGN; ++i)
-          if (lt + i * kLT < b.ng * 5) *reinterpret_cast<uint32_t *>(lds + a.gdesc_off[b.buf] + (lt + i * kLT) * 4) = st.g[i];
+          if (lt + i * kLT < b.ng * 5) *reinterpret_cast<uint32_t *>(lds + gdesc_off_of(b.buf) + (lt + i * kLT) * 4) = st.g[i];
   #pragma unroll
         for (int i = 0; i < kCN; ++i)
-          if (lt + i * kLT < b.nc * 2) *reinterpret_cast<uint32_t *>(lds + a.cdesc_off[b.buf] + (lt + i * kLT) * 4) = st.c[i];
+          if (lt + i * kLT < b.nc * 2) *reinterpret_cast<uint32_t *>(lds + cdesc_off_of(b.buf) + (lt + i * kLT) * 4) = st.c[i];
       };
-      const int steps = (a.cell_rows + 1) & ~1;  // both roles run an even number of steps (the odd one out only meets the barriers)
+      const int steps = (a.dbg & 256) ? 0 : (a.cell_rows + 1) & ~1;  // both roles run an even number of steps (the odd one out only meets the barriers); (dbg 256: timing ablation, prologue only)
       if constexpr (kLoader) {
         // Two loader groups take alternate steps: during step cy the group of that parity writes batch cy + 1 (requested
         // two steps earlier) to LDS and requests batch cy + 3, so two batches -- about 2 x 36 KB per CU, what it takes
@@ -751,9 +759,9 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
         }
       }
     }
+    SB_FLUSH;
   };
   if (is_loader) run(std::true_type{}); else run(std::false_type{});
-  SB_FLUSH;
 }
 
 struct SbLaunch {
