@@ -203,20 +203,23 @@ class SadModeA:
         sp = [orc.extend_plane(s, self.border, self.src.stride) for s, _ in self.host_frames]
         rp = [orc.extend_plane(r, self.border, self.ref.stride) for _, r in self.host_frames]
         groups = np.ascontiguousarray(self.h_groups_all).reshape(-1)
-        phys, logical, model = orc.physical_cores()
-        phys = min(phys, orc.lib.orc_max_threads())
+        host_phys, logical, model = orc.physical_cores()
+        usable, quota = orc.usable_cpus()
+        phys = max(1, min(host_phys, usable))  # one thread per core this process may really use
         legs = {}
         for name, threads, avx2, secs in (("scalar_1_thread", 1, 0, seconds * 0.6), ("avx2_1_thread", 1, 1, seconds * 0.6),
-                                          ("scalar_all_physical_cores", phys, 0, seconds), ("avx2_all_physical_cores", phys, 1, seconds)):
+                                          ("scalar_all_usable_cores", phys, 0, seconds), ("avx2_all_usable_cores", phys, 1, seconds)):
             rate, done, el = orc.bench_sad_mode_a(sp, rp, self.border, self.h_cands, groups, bd, threads, avx2, secs)
             legs[name] = {"candidates_per_s": rate, "threads": threads, "seconds": el, "candidates": done}
-        best = legs["avx2_all_physical_cores"]
+        best = legs["avx2_all_usable_cores"]
         return {"value": best["candidates_per_s"], "unit": "candidates/s", "cores": phys, "kind": "port",
-                "cpu_model": model, "logical_cpus": logical, "legs": legs,
+                "cpu_model": model, "logical_cpus": logical, "host_physical_cores": host_phys, "cgroup_cpu_quota": quota, "legs": legs,
+                "per_core": best["candidates_per_s"] / phys,
                 "sample": "%d candidates = whole passes over the Mode-A lists of all %d base frame pairs of the ring (%.1f s), "
                           "oracle/aomref_bench.c AVX2-intrinsics 16x16 SAD (gcc -O3 -mavx2), static partition over %d pinned "
-                          "threads (one per physical core); `legs` has the scalar-C and 1-thread figures"
-                          % (best["candidates"], len(sp), best["seconds"], phys)}
+                          "threads = the cores this process may use (host: %d physical cores, cgroup CPU quota %s); `legs` has the "
+                          "scalar-C and 1-thread figures"
+                          % (best["candidates"], len(sp), best["seconds"], phys, host_phys, quota)}
 
     def free(self):
         c = self.ctx
@@ -280,17 +283,18 @@ class TxqGrid:
         """fwd_txfm2d + quantize_b over every 4x4 / 8x8 / 16x16 / 32x32 block of the residual planes on the host cores
         (oracle/aomref_bench.c): blocks partitioned statically over pinned threads, thread-private outputs; scalar C, and
         scalar transform + AVX2 quantiser; one thread and all physical cores."""
-        phys, logical, model = self.orc.physical_cores()
-        phys = min(phys, self.orc.lib.orc_max_threads())
+        host_phys, logical, model = self.orc.physical_cores()
+        usable, quota = self.orc.usable_cpus()
+        phys = max(1, min(host_phys, usable))
         planes = self.h_planes
         legs = {}
-        for name, threads, avx2, secs in (("scalar_1_thread", 1, 0, seconds * 0.6), ("scalar_all_physical_cores", phys, 0, seconds),
-                                          ("scalar_txfm+avx2_quant_all_physical_cores", phys, 1, seconds)):
+        for name, threads, avx2, secs in (("scalar_1_thread", 1, 0, seconds * 0.6), ("scalar_all_usable_cores", phys, 0, seconds),
+                                          ("scalar_txfm+avx2_quant_all_usable_cores", phys, 1, seconds)):
             rate, done, el = self.orc.bench_txq(planes, self.qt, threads, avx2, secs)
             legs[name] = {"blocks_per_s": rate, "threads": threads, "seconds": el, "blocks": done}
-        best = legs["scalar_txfm+avx2_quant_all_physical_cores"]
+        best = legs["scalar_txfm+avx2_quant_all_usable_cores"]
         return {"value": best["blocks_per_s"], "unit": "blocks/s", "cores": phys, "kind": "port", "cpu_model": model,
-                "logical_cpus": logical, "legs": legs,
+                "logical_cpus": logical, "host_physical_cores": host_phys, "cgroup_cpu_quota": quota, "legs": legs,
                 "sample": "%d blocks = whole passes over all 4x4/8x8/16x16/32x32 blocks of %d residual planes (%.1f s), oracle C "
                           "forward transform (scalar, gcc -O3 -mavx2 auto-vectorised) + AVX2-intrinsics quantize_b, static "
                           "partition over %d pinned threads" % (best["blocks"], len(planes), best["seconds"], phys)}

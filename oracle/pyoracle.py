@@ -18,6 +18,9 @@ def build():
 
 if not os.path.exists(_SO):
     build()
+# before libgomp loads: with OMP_PROC_BIND set its constructor binds THIS thread to the first place, after which the affinity mask
+# no longer says how many CPUs the process may use
+_CPUS_AT_IMPORT = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 lib = C.CDLL(_SO)
 
 _u8 = np.ctypeslib.ndpointer(np.uint8, flags="C")
@@ -216,7 +219,35 @@ def physical_cores():
         pass
     import os
     logical = logical or (os.cpu_count() or 1)
-    return (len(cores) or logical), logical, model
+    n = len(cores) or logical
+    if n * 4 < logical:  # a virtualised /proc/cpuinfo that repeats core ids: assume 2-way SMT rather than report 2 cores
+        n = max(1, logical // 2)
+    return n, logical, model
+
+
+def usable_cpus():
+    """CPUs this process may actually use at once: min(scheduler affinity, cgroup CPU quota -- cpu.max of cgroup v2 or
+    cfs_quota_us / cfs_period_us of v1).  A container on a shared host sees every core in /proc/cpuinfo but is throttled to its
+    quota: more threads than that only time-share it.  -> (usable, quota or None)"""
+    import math
+    import os
+    n = _CPUS_AT_IMPORT
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(math.floor(quota + 1e-9))))
+    return n, quota
 
 
 def bench_sad_mode_a(src_planes, ref_planes, border, cands, groups, bd, threads, avx2, seconds):
