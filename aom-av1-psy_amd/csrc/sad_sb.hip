@@ -422,11 +422,37 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
               base[4] = both ? cbase : (unsigned)a.ring_off;
               if (!both) soff = 0;
               uint32_t acc[5] = { 0, 0, 0, 0, 0 };
+              if constexpr (sizeof(T) == 1) {
+                // 8-bit planes: all LDS reads of a row unit's five references are issued before the first realignment (left to
+                // itself the compiler reads one reference, waits, computes, reads the next: ten LDS round trips in the one
+                // iteration a wavefront runs per step).  1080p -4.6 %, 4K -2 %; on 16-bit planes the same form was 5 % slower.
+                constexpr int kDw = G::kUnitBytes / 4;
 #pragma unroll
-              for (int k = 0; k < G::kUnitsPerLane; ++k) {
-                const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
+                for (int k = 0; k < G::kUnitsPerLane; ++k) {
+                  const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
+                  uint32_t raw[5][kDw + 1];
+                  unsigned sh[5];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) acc[j] = sad_unit(sv, lds_unit<G::kUnitBytes>(lds, base[j] + unit_roff[k]), acc[j]);
+                  for (int j = 0; j < 5; ++j) {
+                    const unsigned o = base[j] + unit_roff[k];
+                    const uint32_t *p = reinterpret_cast<const uint32_t *>(lds) + (o >> 2);
+                    sh[j] = o & 3;
+#pragma unroll
+                    for (int i = 0; i <= kDw; ++i) raw[j][i] = p[i];
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                  for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int i = 0; i < kDw; ++i) acc[j] = sad_dword<T>(sv.v[i], __builtin_amdgcn_alignbyte(raw[j][i + 1], raw[j][i], sh[j]), acc[j]);
+                }
+              } else {
+#pragma unroll
+                for (int k = 0; k < G::kUnitsPerLane; ++k) {
+                  const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
+#pragma unroll
+                  for (int j = 0; j < 5; ++j) acc[j] = sad_unit(sv, lds_unit<G::kUnitBytes>(lds, base[j] + unit_roff[k]), acc[j]);
+                }
               }
               if (a.dbg & 128) {  // (timing ablation: no reduction, no stores)
                 if ((acc[0] & acc[1] & acc[2] & acc[3] & acc[4]) == 0xFFFFFFFFu) out1[0] = 0;
