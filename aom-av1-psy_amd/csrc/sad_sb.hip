@@ -254,7 +254,11 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
       // ---- transport (loader lanes): one BATCH = what step `cy` adds to LDS: new ring rows [ya, yb), source cell cy,
       // the list slices of cell cy.  request() starts the loads into registers, commit() writes them to LDS a step later.
       struct Batch { int ya, yb, sy0, ns, g0, ng, c0, nc, buf; };
-      struct Stage { U128 ring[kRingN]; U128 srcv[kSrcN]; uint32_t g[kGN]; uint32_t c[kCN]; };
+      // The staged 16-byte chunks are NATIVE 4 x 32-bit vectors, moved as a whole from the load to the ds_write: as a struct of four
+      // scalars the register allocator was free to park single components elsewhere (it did: `v_mov v68, v23` behind an
+      // `s_waitcnt vmcnt(6)` at the end of request(), i.e. the loader waited for half of the loads it had just issued, every step).
+      typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+      struct Stage { V4 ring[kRingN]; V4 srcv[kSrcN]; uint32_t g[kGN]; uint32_t c[kCN]; };
       // Every load is unconditional and straight-line (lanes past the end of a batch re-read its last chunk; an unused
       // register slot re-reads chunk 0): a conditional load would leave "maybe pending" registers behind at the join
       // and the compiler's wait-count pass would then drain vmcnt(0) at every later use.  `me` of `n` lanes take part.
@@ -269,13 +273,13 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
         for (int i = 0; i < kRingN; ++i) {
           const unsigned q = (unsigned)max(min(me + i * n, total_r - 1), 0);
           const unsigned row = __umulhi(q, a.magic_cpr), col = q - row * (unsigned)a.cpr;
-          st.ring[i] = *reinterpret_cast<const U128 *>(rb + (row * (unsigned)gpitch + (unsigned)min((int)col, colmax) * 16u));
+          st.ring[i] = *reinterpret_cast<const V4 *>(rb + (row * (unsigned)gpitch + (unsigned)min((int)col, colmax) * 16u));
         }
   #pragma unroll
         for (int i = 0; i < kSrcN; ++i) {
           const unsigned q = (unsigned)max(min(me + i * n, total_s - 1), 0);
           const unsigned row = __umulhi(q, a.magic_scpr), col = q - row * (unsigned)a.scpr;
-          st.srcv[i] = *reinterpret_cast<const U128 *>(sb_ + (row * (unsigned)sgpitch + (unsigned)min((int)col, scolmax) * 16u));
+          st.srcv[i] = *reinterpret_cast<const V4 *>(sb_ + (row * (unsigned)sgpitch + (unsigned)min((int)col, scolmax) * 16u));
         }
   #pragma unroll
         for (int i = 0; i < kGN; ++i) st.g[i] = gwords[(unsigned)max(min(b.g0 * 5 + min(me + i * n, b.ng * 5 - 1), gwords_n - 1), 0)];
@@ -292,10 +296,10 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
             const unsigned row = __umulhi(q, a.magic_cpr), col = q - row * (unsigned)a.cpr;
             unsigned sl = s_first + row;
             sl = min(sl, sl - (unsigned)a.R);
-            const uint4 v = make_uint4(st.ring[i].v[0], st.ring[i].v[1], st.ring[i].v[2], st.ring[i].v[3]);
-            *reinterpret_cast<uint4 *>(lds + a.ring_off + sl * a.pitch + col * 16) = v;
+            const V4 v = st.ring[i];
+            *reinterpret_cast<V4 *>(lds + a.ring_off + sl * a.pitch + col * 16) = v;
             if (kMirror > 0 && sl < (unsigned)kMirror)
-              *reinterpret_cast<uint4 *>(lds + a.ring_off + (sl + a.R) * a.pitch + col * 16) = v;
+              *reinterpret_cast<V4 *>(lds + a.ring_off + (sl + a.R) * a.pitch + col * 16) = v;
           }
         }
   #pragma unroll
@@ -303,8 +307,7 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
           const unsigned q = (unsigned)(me + i * n);
           if ((int)q < total_s) {
             const unsigned row = __umulhi(q, a.magic_scpr), col = q - row * (unsigned)a.scpr;
-            *reinterpret_cast<uint4 *>(lds + src_off_of(b.buf) + row * a.spitch + col * 16) =
-                make_uint4(st.srcv[i].v[0], st.srcv[i].v[1], st.srcv[i].v[2], st.srcv[i].v[3]);
+            *reinterpret_cast<V4 *>(lds + src_off_of(b.buf) + row * a.spitch + col * 16) = st.srcv[i];
           }
         }
   #pragma unroll
@@ -637,9 +640,9 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
         const char *sb_ = src_frame + (int64_t)min(b.sy0, a.s_ymax - 1) * sgpitch + (int64_t)sx0 * kES;
         const unsigned rlim = (unsigned)((b.yb - b.ya) * gpitch), slim = (unsigned)(b.ns * sgpitch);
   #pragma unroll
-        for (int i = 0; i < kRingN; ++i) st.ring[i] = *reinterpret_cast<const U128 *>(rb + (r_goff[i] < rlim ? r_goff[i] : 0u));
+        for (int i = 0; i < kRingN; ++i) st.ring[i] = *reinterpret_cast<const V4 *>(rb + (r_goff[i] < rlim ? r_goff[i] : 0u));
   #pragma unroll
-        for (int i = 0; i < kSrcN; ++i) st.srcv[i] = *reinterpret_cast<const U128 *>(sb_ + (s_goff[i] < slim ? s_goff[i] : 0u));
+        for (int i = 0; i < kSrcN; ++i) st.srcv[i] = *reinterpret_cast<const V4 *>(sb_ + (s_goff[i] < slim ? s_goff[i] : 0u));
   #pragma unroll
         for (int i = 0; i < kGN; ++i) st.g[i] = gwords[(unsigned)max(min(b.g0 * 5 + min(lt + i * kLT, b.ng * 5 - 1), gwords_n - 1), 0)];
   #pragma unroll
@@ -653,15 +656,14 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
           if (r_goff[i] < rlim) {
             unsigned t = first + r_loff[i];
             t = min(t, t - ring_bytes);  // wrap: t - ring_bytes underflows to a huge value unless t >= ring_bytes
-            const uint4 v = make_uint4(st.ring[i].v[0], st.ring[i].v[1], st.ring[i].v[2], st.ring[i].v[3]);
-            *reinterpret_cast<uint4 *>(lds + a.ring_off + t) = v;
-            if (kMirror > 0 && t < (unsigned)(kMirror * a.pitch)) *reinterpret_cast<uint4 *>(lds + a.ring_off + t + ring_bytes) = v;
+            const V4 v = st.ring[i];
+            *reinterpret_cast<V4 *>(lds + a.ring_off + t) = v;
+            if (kMirror > 0 && t < (unsigned)(kMirror * a.pitch)) *reinterpret_cast<V4 *>(lds + a.ring_off + t + ring_bytes) = v;
           }
   #pragma unroll
         for (int i = 0; i < kSrcN; ++i)
           if (s_goff[i] < slim)
-            *reinterpret_cast<uint4 *>(lds + src_off_of(b.buf) + s_loff[i]) =
-                make_uint4(st.srcv[i].v[0], st.srcv[i].v[1], st.srcv[i].v[2], st.srcv[i].v[3]);
+            *reinterpret_cast<V4 *>(lds + src_off_of(b.buf) + s_loff[i]) = st.srcv[i];
   #pragma unroll
         for (int i = 0; i < kGN; ++i)
           if (lt + i * kLT < b.ng * 5) *reinterpret_cast<uint32_t *>(lds + gdesc_off_of(b.buf) + (lt + i * kLT) * 4) = st.g[i];
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
             __syncthreads();
             break;
           }
-          if (a.dbg & 64) { __syncthreads(); continue; }
+          if (a.dbg & (64 | 2048)) { __syncthreads(); continue; }  // (2048: timing ablation, the evaluators skip their bookkeeping too)
           const int buf = cy & 1;
           SB_T(t1);
           const Seg cur = seg_of(cy);

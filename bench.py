@@ -543,7 +543,7 @@ def run_search(pkg, ctx, dist, dev, rank, world, orc, steps, warmup, exchange="h
                  "tile_columns_px": widths, "blocks_max_rank_over_mean": max(widths) / (sum(widths) / world) if sum(widths) else None}
     return dict({"workload": "fullpel_diamond+subpel_bilinear_4k_10bit", "value": total * steps / wall, "unit": "blocks/s",
                  "frames_per_s": steps / wall, "ms_per_step": wall / steps * 1e3, "blocks_per_step": total,
-                 "parity_sample_slot0": ok,
+                 "parity_sample_slot0": ok, "bound": search_bound(),
                  "config": {"frame": "3840x2160 10-bit", "block": "16x16", "search": "DIAMOND step_param 4, MV_COST_L1_HDRES; "
                             "sub-pel tree pruned_more, bilinear, 1/8 pel, iters 2",
                             "partition": "uniform tile columns (tile_common.c:76-110), one per GPU",
@@ -813,6 +813,19 @@ def kernel_avg_ms(ctx, fn, reps):
     for _ in range(reps):
         fn()
     return ctx.timer_end() / reps
+
+
+def search_bound():
+    """The measured bound of the search kernels (profiles/r02_search_l1_bound.json, PMC): L1 cache-line accesses per CU per clock."""
+    p = os.path.join(ROOT, "profiles", "r02_search_l1_bound.json")
+    try:
+        d = json.load(open(p))
+        return {"bound": "L1 (TCP) cache-line access rate, 1 per CU per clock: a 16x16 candidate row is one 32-byte piece of its own line",
+                "fullpel_diamond_kernel_frac": d["fullpel_diamond"]["l1_accesses_per_cu_cycle"],
+                "subpel_bilinear_kernel_frac": d["subpel_bilinear"]["l1_accesses_per_cu_cycle"],
+                "source": "profiles/r02_search_bound.md (rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum / (256 CUs x launch cycles))"}
+    except Exception:
+        return None
 
 
 def load_traffic(name):
