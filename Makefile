@@ -10,21 +10,29 @@ CPPS := $(wildcard $(CSRC)/*.cpp)
 HOSTC := $(wildcard $(PKG)/host/*.c)
 OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS)) $(patsubst $(CSRC)/%.cpp,build/%.o,$(CPPS)) $(patsubst $(PKG)/host/%.c,build/host_%.o,$(HOSTC))
 
+# Objects also depend on a stamp named after the compiler version + flags: a build/ directory left behind by another toolchain or another
+# flag set is rebuilt, not reused (timestamps alone would accept it).
+STAMP := build/.toolchain_$(shell (echo '$(HIPCC) $(HIPFLAGS)'; $(HIPCC) --version 2>/dev/null | head -2; gcc --version | head -1) | md5sum | cut -c1-16)
+$(STAMP):
+	@mkdir -p build
+	@rm -f build/.toolchain_*
+	@touch $@
+
 all: lib oracle
 lib: $(LIBDIR)/libaomhip.so
 oracle:
 	$(MAKE) -C oracle
 
-build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) include/aomhip.h
+build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) include/aomhip.h $(STAMP)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-build/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/aomhip.h
+build/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/aomhip.h $(STAMP)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 # the host-side modules are plain C99 (the reference is a C code base): compiled with gcc, no HIP in them
-build/host_%.o: $(PKG)/host/%.c include/aomhip.h
+build/host_%.o: $(PKG)/host/%.c include/aomhip.h $(STAMP)
 	@mkdir -p build
 	gcc -std=c99 -pedantic -Wall -Wextra -Werror -O2 -fPIC -Iinclude -c $< -o $@
 

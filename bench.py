@@ -785,6 +785,60 @@ def run_tf(pkg, ctx, orc, steps, warmup, width=3840, height=2160, bd=10, n_frame
                         "av1_find_best_sub_pixel_tree USE_8_TAPS; 32x32 + four 16x16 per block and frame"})
 
 
+def run_sad_diamond_lists(pkg, ctx, orc, steps, warmup, width=3840, height=2160, bd=8, frames=16):
+    """lists that are NOT Mode-A shaped through aomhip_sad_sb_batch -- one diamond step per 16x16 block as the
+    encoder issues it (mcomp.c:1299-1416): 8 sites = two x4d groups at (+-r, 0), (0, +-r), (+-r, +-r) around a per-block centre within
+    +-40 of the block, r in {1, 2, 4, 8, 16}, no single candidates.  These take the kernel's general per-entry path (source rows re-read
+    per group, no fused group + candidate block), still out of the LDS ring; compared with the direct x4d kernel on the same lists."""
+    capi, synth = pkg.capi, pkg.synth
+    border = 160
+    src, ref = ctx.planes_alloc(width, height, border, bd, frames), ctx.planes_alloc(width, height, border, bd, frames)
+    for f in range(frames):
+        ctx.planes_upload(src, f, synth.lcg_frame(width, height, 2 * f, 0, bd))
+        ctx.planes_upload(ref, f, synth.lcg_frame(width, height, 2 * f + 1, 0, bd))
+    _, g0 = synth.mode_a_worklist(width, height, 16, seed=3)
+    nb = len(g0)
+    rng = np.random.default_rng(9)
+    cx = g0["sx"].astype(np.int32) + rng.integers(-40, 41, nb)
+    cy = g0["sy"].astype(np.int32) + rng.integers(-40, 41, nb)
+    r = (1 << rng.integers(0, 5, nb)).astype(np.int32)
+    groups = np.zeros(2 * nb, capi.sad_x4d_dtype)
+    groups["sx"] = np.repeat(g0["sx"], 2); groups["sy"] = np.repeat(g0["sy"], 2)
+    dr = np.array([[-1, 1, 0, 0], [-1, 1, -1, 1]]); dc = np.array([[0, 0, -1, 1], [-1, 1, 1, -1]])   # site order of mcomp.c:366-370
+    for k in range(2):
+        groups["ry"][k::2] = cy[:, None] + dr[k][None, :] * r[:, None]
+        groups["rx"][k::2] = cx[:, None] + dc[k][None, :] * r[:, None]
+    cell = (384, 32) if bd == 8 else (160, 32)
+    perm, off = synth.bucket_order(groups["sx"], groups["sy"], width, height, *cell)
+    gs = np.ascontiguousarray(groups[perm])
+    d_gs, d_off, d_g = ctx.to_device(gs), ctx.to_device(off), ctx.to_device(groups)
+    n = len(groups)
+    d_o_sb, d_o_dir = ctx.malloc(frames * n * 16), ctx.malloc(frames * n * 16)
+    sb = lambda: ctx.sad_sb_batch(src, ref, 0, frames, 16, 16, 0, cell[0], cell[1], 64, len(off) - 1, d_gs, d_off, n, 0, d_o_sb)
+    direct = lambda: ctx.sad_x4d_batch(src, ref, 0, frames, 16, 16, 0, d_g, n, 0, d_o_dir)
+    for _ in range(warmup):
+        sb(); direct()
+    ms_sb, ms_dir = kernel_avg_ms(ctx, sb, max(5, steps // 2)), kernel_avg_ms(ctx, direct, max(5, steps // 2))
+    a = ctx.from_device(d_o_sb, (frames, n, 4), np.uint32)
+    b = ctx.from_device(d_o_dir, (frames, n, 4), np.uint32)
+    same = bool(np.array_equal(a, b[:, perm]))
+    ok = None
+    if orc is not None:
+        s0, r0 = synth.lcg_frame(width, height, 0, 0, bd), synth.lcg_frame(width, height, 1, 0, bd)
+        idx = np.arange(0, n, 53)
+        want = orc.sad_x4d_batch(orc.extend_plane(s0, border, src.stride), orc.extend_plane(r0, border, ref.stride), border, 16, 16, groups[idx], bd=bd, threads=8)
+        ok = bool(np.array_equal(b[0][idx], want))
+    for d in (d_gs, d_off, d_g, d_o_sb, d_o_dir):
+        ctx.free(d)
+    ctx.planes_free(src); ctx.planes_free(ref)
+    cands = 4 * n * frames
+    return {"workload": "sad16x16_diamond_step_lists_4k_%dbit" % bd, "value": cands / (ms_sb * 1e-3), "unit": "candidates/s",
+            "sad_strip_kernel_ms": ms_sb, "sad_x4d_kernel_ms": ms_dir, "direct_candidates_per_s": cands / (ms_dir * 1e-3),
+            "strip_equals_direct": same, "parity_sample_frame0": ok, "candidates_per_launch": cands,
+            "config": {"frame": "%dx%d %d-bit x %d pairs" % (width, height, bd, frames), "list": "8 diamond sites (2 x4d groups) per 16x16 block, "
+                       "centre within +-40, radius 1..16; no single candidates (not Mode-A shaped)", "cell": list(cell)}}
+
+
 def time_steps(wl, ctx, dist, dev, steps, warmup):
     for _ in range(warmup):
         wl.step()
@@ -925,7 +979,7 @@ def main():
                     help="default: sad16x16_modeA_1080p_8bit on one GPU; with N > 1 the strong-scaling search pipeline with the "
                          "per-frame RCCL exchange (search_4k_10bit) + the SAD workload as a second, weak-scaling entry",
                     choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "search_4k_10bit", "inner_loop_4k_10bit", "default_search_4k_10bit", "cdef_search_4k_10bit",
-                                                "wiener_stats_4k", "tf_motion_search_4k_10bit"])
+                                                "wiener_stats_4k", "tf_motion_search_4k_10bit", "sad_diamond_lists_4k_8bit"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -1007,6 +1061,12 @@ def main():
                               scaling="weak", vs_baseline=None, dtype="u16", data="synthetic",
                               ms_per_step=r["full_pixel_search_NSTEP_ms_per_frame"] + r["subpel_tree_8tap_ms_per_frame"])))
         return
+    if args.workload == "sad_diamond_lists_4k_8bit":  # non-Mode-A lists through the bucketed kernel (single GPU)
+        r = run_sad_diamond_lists(pkg, ctx, orc, args.steps, args.warmup)
+        ctx.close()
+        print(json.dumps(dict(r, metric="SAD-candidates/s", n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
+                              vs_baseline=None, dtype="u8", data="synthetic", ms_per_step=r["sad_strip_kernel_ms"])))
+        return
     if args.workload == "tf_motion_search_4k_10bit":  # SURVEY 8(f) row 1 (single GPU)
         r = run_tf(pkg, ctx, orc, args.steps, args.warmup)
         ctx.close()
@@ -1047,6 +1107,7 @@ def main():
             others.append(run_cdef_search(pkg, ctx, orc, max(4, args.steps // 4), 1))
             others.append(run_wiener_stats(pkg, ctx, orc, max(3, args.steps // 6), 1))
             others.append(run_tf(pkg, ctx, orc, max(4, args.steps // 4), 1))
+            others.append(run_sad_diamond_lists(pkg, ctx, orc, max(6, args.steps // 2), 1))
     ctx.close()
 
     if rank == 0:
