@@ -22,6 +22,26 @@
 #include "txfm_device.h"
 
 namespace aomhip {
+#ifndef AOMHIP_XQ_NT_STORES
+#define AOMHIP_XQ_NT_STORES 1
+#endif
+typedef uint32_t XqV4 __attribute__((ext_vector_type(4)));
+// the coefficient outputs are written once and read by a later kernel: streaming (non-temporal) stores
+__device__ __forceinline__ void xq_store4(int32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  XqV4 v = { a, b, c, d };
+#if AOMHIP_XQ_NT_STORES
+  __builtin_nontemporal_store(v, reinterpret_cast<XqV4 *>(p));
+#else
+  *reinterpret_cast<XqV4 *>(p) = v;
+#endif
+}
+__device__ __forceinline__ void xq_store1(int32_t *p, int32_t v) {
+#if AOMHIP_XQ_NT_STORES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 
 using namespace txfm;
 
@@ -237,8 +257,8 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
       quantize_one<HBD, LS>(v, zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.qs_log2[ac], qa.dequant[ac], &qv,
                             &dqv);
       last_c = qv ? c : last_c;
-      qcoeff[out_off + rc] = qv;
-      dqcoeff[out_off + rc] = dqv;
+      xq_store1(qcoeff + out_off + rc, qv);
+      xq_store1(dqcoeff + out_off + rc, dqv);
       if (AOMHIP_XQ_EXTRAS && err_out) block_err_acc(v, dqv, err_shift, berr, bssz);
     }
     if (last_c >= 0) my_eob = iscan_pos<KW, KH>(r, last_c, scan_class) + 1;
@@ -426,8 +446,11 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
     for (int k = 0; k < (NC / 4 + LPB - 1) / LPB; ++k) {
       const int i = lane + k * LPB;
       if (i < NC / 4) {
-        *reinterpret_cast<uint4 *>(qcoeff + out_off + 4 * i) = *reinterpret_cast<const uint4 *>(A + 4 * i);
-        *reinterpret_cast<uint4 *>(dqcoeff + out_off + 4 * i) = *reinterpret_cast<const uint4 *>(B + 4 * i);
+        {
+          const uint4 va = *reinterpret_cast<const uint4 *>(A + 4 * i), vb = *reinterpret_cast<const uint4 *>(B + 4 * i);
+          xq_store4(qcoeff + out_off + 4 * i, va.x, va.y, va.z, va.w);
+          xq_store4(dqcoeff + out_off + 4 * i, vb.x, vb.y, vb.z, vb.w);
+        }
       }
     }
   }
@@ -632,8 +655,8 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
       const uint32_t lo = quad_bcast(off_lo, k), hi = quad_bcast(off_hi, k), ok = quad_bcast(vflag, k);
       const int64_t o = (int64_t)(((uint64_t)hi << 32) | lo) + qj * 4;
       if (ok) {
-        *reinterpret_cast<uint4 *>(qcoeff + o) = make_uint4(mq[k][0], mq[k][1], mq[k][2], mq[k][3]);
-        *reinterpret_cast<uint4 *>(dqcoeff + o) = make_uint4(md[k][0], md[k][1], md[k][2], md[k][3]);
+        xq_store4(qcoeff + o, mq[k][0], mq[k][1], mq[k][2], mq[k][3]);
+        xq_store4(dqcoeff + o, md[k][0], md[k][1], md[k][2], md[k][3]);
       }
     }
     return;
