@@ -477,7 +477,13 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
   // 4x4: the stores below exchange data between the four lanes of a quad, so lanes past the end of the list stay alive
   // (they redo the last block and store nothing)
   constexpr bool kQuadStores = W == 4 && H == 4;
-  const int bi_raw = wg * kXqThreads + threadIdx.x;
+  // 4x4: lane l of a wavefront takes block (l & 3) * 16 + (l >> 2) of the wavefront's 64, so that a quad holds blocks q, q + 16,
+  // q + 32, q + 48 and store k of the transposed quads (below) writes blocks 16 k .. 16 k + 15 = ONE contiguous KB per store
+  // instruction.  (With lane = block, store k wrote every fourth block: isolated 64-byte runs, which the non-temporal path turned
+  // into 1.4 x the write traffic -- PMC, profiles/r02_txq.md.)  The row loads then read 16 blocks' 8 bytes = one whole 128-byte line
+  // per group of 16 lanes.
+  const int t_in_wg = kQuadStores ? (int)((threadIdx.x & ~63u) + ((threadIdx.x & 3u) << 4) + ((threadIdx.x & 63u) >> 2)) : (int)threadIdx.x;
+  const int bi_raw = wg * kXqThreads + t_in_wg;
   const bool valid = bi_raw < n_blocks;
   if (!kQuadStores && !valid) return;
   const int bi = valid ? bi_raw : n_blocks - 1;
