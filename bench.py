@@ -874,10 +874,13 @@ def search_bound():
     p = os.path.join(ROOT, "profiles", "r02_search_l1_bound.json")
     try:
         d = json.load(open(p))
-        return {"bound": "L1 (TCP) cache-line access rate, 1 per CU per clock: a 16x16 candidate row is one 32-byte piece of its own line",
-                "fullpel_diamond_kernel_frac": d["fullpel_diamond"]["l1_accesses_per_cu_cycle"],
-                "subpel_bilinear_kernel_frac": d["subpel_bilinear"]["l1_accesses_per_cu_cycle"],
-                "source": "profiles/r02_search_bound.md (rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum / (256 CUs x launch cycles))"}
+        return {"fullpel_diamond_kernel": {"bound": "L1 (TCP) cache-line access rate, 1 per CU per clock: a 16x16 candidate row is one 32-byte "
+                                                    "piece of its own line", "frac": d["fullpel_diamond"]["l1_accesses_per_cu_cycle"]},
+                "subpel_bilinear_kernel": {"bound": "VALU issue (1 wave-instruction per SIMD per 2 clocks), after the reference footprint moved "
+                                                    "to LDS (round 1 form: 0.88 of the L1 look-up rate)",
+                                           "frac": d["subpel_bilinear_lds_footprint"]["valu_issue_frac"],
+                                           "issue_wait_frac": d["subpel_bilinear_lds_footprint"]["SQ_WAIT_INST_ANY_over_WAVE_CYCLES"]},
+                "source": "profiles/r02_search_bound.md, profiles/r02_search_l1_bound.json (rocprofv3 --pmc)"}
     except Exception:
         return None
 
