@@ -1126,6 +1126,12 @@ def main():
                        "ring_frame_pairs_per_gpu": FRAMES_OVERRIDE or cfg["frames"], "candidates_per_step": main_res["candidates_per_step"],
                        "partition": "tile columns (tile_common.c:76-97), one per GPU; no data-path collective"},
             "roofline": main_res["roofline"],
+            # the three SAD sizes side by side (the bench contract's configuration is the 1080p one above; 4K 10-bit is the north-star size)
+            "sad_sizes": {r_["workload"]: {"value": r_["value"], "unit": "candidates/s", "avg_launch_ms": r_["roofline"]["avg_launch_ms"],
+                                           "frac_compulsory_of_8TBs": r_["roofline"]["frac"],
+                                           "traffic_over_compulsory": r_["roofline"].get("traffic_over_compulsory"),
+                                           "traffic_frac_of_peak": r_["roofline"].get("traffic_frac_of_peak")}
+                          for r_ in [main_res] + [o for o in others if str(o.get("workload", "")).startswith("sad16x16_modeA")]},
             "cpu_baseline": main_res.get("cpu_baseline"),
             "parity_frame0": main_res["parity_frame0"],
             "kernels": main_res["kernels"],
