@@ -101,7 +101,7 @@ txb_dtype = np.dtype([("x", "<i4"), ("y", "<i4"), ("out_offset", "<u4"), ("tx_ty
 sad_cand_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2"), ("ry", "<i2")])
 search_block_dtype = np.dtype([(n, "<i2") for n in ("bx", "by", "start_row", "start_col", "ref_row", "ref_col", "row_min",
                                                     "row_max", "col_min", "col_max")])
-MV_COST_L1_LOWRES, MV_COST_L1_MIDRES, MV_COST_L1_HDRES, MV_COST_NONE = 1, 2, 3, 4
+MV_COST_ENTROPY, MV_COST_L1_LOWRES, MV_COST_L1_MIDRES, MV_COST_L1_HDRES, MV_COST_NONE = 0, 1, 2, 3, 4
 COMP_AVG, COMP_DIST_WTD, COMP_MASK, COMP_OBMC = 0, 1, 2, 3
 blend_item_dtype = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("mask_offset", "<u2"), ("vertical", "u1"), ("reserved", "u1")])
 rect_dtype = np.dtype([("h_start", "<i4"), ("h_end", "<i4"), ("v_start", "<i4"), ("v_end", "<i4")])
@@ -204,6 +204,7 @@ _protos = {
     "aomhip_sad16x16": (C.c_uint, [_vp, _i, _vp, _i]),
     "aomhip_sad16x16x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp]),
     "aomhip_highbd_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, _i]),
+    "aomhip_first_pass_motion_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "aomhip_tf_default_params": (None, [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aomhip_tf_block_list": (C.c_int, [_i, _i, _i, _vp]),
     "aomhip_tf_motion_search_frames": (C.c_int, [_vp, _PP, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -318,6 +319,11 @@ class Context:
         out = np.empty((p.height + 2 * p.border, p.stride), dt)
         check(lib.aomhip_planes_download(self.h, C.byref(p), frame, out.ctypes.data), "download")
         return out
+
+    def first_pass_motion_search_batch(self, src, ref, frame, bw, bh, params, d_blocks, n, d_mv, d_err, d_mvjcost=None, d_mvcost_row=None,
+                                       d_mvcost_col=None):
+        check(lib.aomhip_first_pass_motion_search_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(params), d_mvjcost, d_mvcost_row,
+                                                        d_mvcost_col, d_blocks, n, d_mv, d_err), "aomhip_first_pass_motion_search_batch")
 
     def tf_motion_search_frames(self, frames, filter_frame, params, d_blocks, n_blocks, d_mvs, d_mses, d_ref_mv=None, frame_present=None):
         fp = None if frame_present is None else np.ascontiguousarray(frame_present, np.uint8)

@@ -6,6 +6,7 @@
 #include <climits>
 
 #include "common.h"
+#include "search_device.h"
 
 namespace aomhip {
 namespace {
@@ -250,5 +251,74 @@ extern "C" int aomhip_tf_motion_search_frames(aomhip_ctx *ctx, const aomhip_plan
     AOMHIP_LAUNCH_CHECK();
   }
   if (d_ref_mv_out) AOMHIP_TRY(hipMemcpyAsync(d_ref_mv_out, ref_mv, n1 * 4, hipMemcpyDeviceToDevice, st));
+  return AOMHIP_OK;
+}
+
+
+// ---- first pass: first_pass_motion_search (av1/encoder/firstpass.c:261-299) for a list of blocks ------------------------------
+namespace aomhip {
+namespace {
+__global__ void fp_cands_kernel(const aomhip_search_block *blocks, const int16_t *mv, int n, aomhip_var_cand *cands) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const aomhip_search_block b = blocks[i];
+  aomhip_var_cand c;
+  c.sx = b.bx; c.sy = b.by;
+  c.rx = (int16_t)(b.bx + mv[2 * i + 1]); c.ry = (int16_t)(b.by + mv[2 * i]);
+  c.xoff = c.yoff = 0; c.reserved[0] = c.reserved[1] = 0;
+  cands[i] = c;
+}
+// tmp_err = sse + mv_err_cost_(get_mv_from_fullmv(best), params) + NEW_MV_MODE_PENALTY   (mcomp.c:271-308, 3637-3649)
+__global__ void fp_finish_kernel(const aomhip_search_block *blocks, const int16_t *mv, const int32_t *search_cost, const uint32_t *sse, int n,
+                                 int cost_type, int error_per_bit, const int32_t *mvjcost, const int32_t *mvcost0, const int32_t *mvcost1,
+                                 int32_t *err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (search_cost[i] == INT_MAX) { err[i] = INT_MAX; return; }
+  const aomhip_search_block b = blocks[i];
+  const int mrow = mv[2 * i] * 8, mcol = mv[2 * i + 1] * 8;
+  int cost;
+  if (cost_type == kCostEntropy) {
+    const int dr = mrow - b.ref_row, dc = mcol - b.ref_col;
+    const int64_t bits = mvjcost[(dc != 0) | ((dr != 0) << 1)] + mvcost0[dr] + mvcost1[dc];
+    cost = (int)((bits * error_per_bit + (1 << 13)) >> 14);
+  } else {
+    const CostCtx cc{ cost_type, b.ref_row, b.ref_col };
+    cost = cc.var_cost(mrow, mcol);
+  }
+  err[i] = (int32_t)(sse[i] + (uint32_t)cost + 32u);
+}
+}  // namespace
+}  // namespace aomhip
+
+extern "C" int aomhip_first_pass_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                                     const aomhip_search_params *p, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                                                     const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, int n, int16_t *d_best_mv,
+                                                     int32_t *d_err) {
+  if (!ctx || !p || !d_best_mv || !d_err || n < 0) {
+    set_error("aomhip_first_pass_motion_search_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n == 0) return AOMHIP_OK;
+  AOMHIP_TRY(hipSetDevice(ctx->device));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t n1 = (size_t)n, o_cost = take(n1 * 4), o_cand = take(n1 * sizeof(aomhip_var_cand)), o_var = take(n1 * 4), o_sse = take(n1 * 4);
+  char *w = static_cast<char *>(work(ctx, off));
+  if (!w) return AOMHIP_ERR_NOMEM;
+  int32_t *cost = reinterpret_cast<int32_t *>(w + o_cost);
+  aomhip_var_cand *cands = reinterpret_cast<aomhip_var_cand *>(w + o_cand);
+  uint32_t *var = reinterpret_cast<uint32_t *>(w + o_var), *sse = reinterpret_cast<uint32_t *>(w + o_sse);
+  int rc = aomhip_full_pixel_search_batch(ctx, src, ref, frame, bw, bh, p, d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, n, d_best_mv, cost, nullptr,
+                                          nullptr);
+  if (rc != AOMHIP_OK) return rc;
+  const unsigned g = (unsigned)((n1 + 255) / 256);
+  hipLaunchKernelGGL(fp_cands_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_best_mv, n, cands);
+  AOMHIP_LAUNCH_CHECK();
+  rc = aomhip_variance_batch(ctx, src, ref, frame, 1, bw, bh, cands, n, 0, var, sse);
+  if (rc != AOMHIP_OK) return rc;
+  hipLaunchKernelGGL(fp_finish_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_best_mv, cost, sse, n, p->mv_cost_type, p->error_per_bit, d_mvjcost,
+                     d_mvcost_row, d_mvcost_col, d_err);
+  AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

@@ -618,6 +618,24 @@ int aomhip_tf_motion_search_frames(aomhip_ctx *ctx, const aomhip_planes *frames,
                                    const aomhip_tf_params *params, const aomhip_search_block *d_blocks, int n_blocks,
                                    int16_t *d_subblock_mvs, int32_t *d_subblock_mses, int16_t *d_ref_mv);
 
+/* ------------------------------------------------------------------ first pass: one motion-search leg for a list of blocks */
+
+/* first_pass_motion_search (av1/encoder/firstpass.c:261-299) for every block of a list against one reference frame (the last frame or
+ * the golden frame): av1_full_pixel_search on `params` -- the first pass sets search_method AOMHIP_SEARCH_NSTEP_FPF (NSTEP on the
+ * av1_init_motion_fpf site table), step_param = sf.fp_sf.reduce_mv_step_param + get_search_range(initial dimensions), the default
+ * MV_COST_ENTROPY with x->mv_costs and x->errorperbit / sadperbit (init_mv_cost_params, mcomp.c:35-52) -- started at
+ * get_fullmv_from_mv(ref_mv) (block.start_* in full-pel, block.ref_* = ref_mv in 1/8 pel), and then
+ *   tmp_err = av1_get_mvpred_sse(mv_cost_params, best_mv, vfp, src, ref) + NEW_MV_MODE_PENALTY (32)     (mcomp.c:3637-3649)
+ * when the search returned less than INT_MAX.  Outputs per block: d_best_mv (row, col, full-pel) and d_err (tmp_err).  The
+ * comparison with *best_motion_err and the choice between the ref_mv, zero-MV and golden legs (firstpass.c:720-760) stay with the
+ * caller: the two zero-MV legs of every block of a frame are independent and go through in one call each; the leg started at the
+ * previous block's MV is a raster chain per row (one call per block column, rows in parallel).  Cost tables as for
+ * aomhip_full_pixel_search_batch (component pointers at the table centres); ignored for the L1 / NONE cost types. */
+int aomhip_first_pass_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                          const aomhip_search_params *params, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                                          const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, int n_blocks,
+                                          int16_t *d_best_mv, int32_t *d_err);
+
 /* ------------------------------------------------------------------ the encoder's kernel vtable */
 
 /* Mirror of aom_variance_fn_ptr_t (aom_dsp/variance.h:84-103): same field order, same pointer types

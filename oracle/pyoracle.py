@@ -939,3 +939,29 @@ def tf_motion_search_frames(frames_b, filter_frame, border, blocks, p, frame_pre
         mvs[f], mses[f] = sub_mv, sub_mse
         ref_mv = np.where((block_mse > p["mse_thresh"])[:, None], 0, ref_mv)     # :249-252
     return mvs, mses, ref_mv.astype(np.int16)
+
+
+# ---- first pass: first_pass_motion_search for a list of blocks (av1/encoder/firstpass.c:261-299) ----
+def mv_err_cost(mrow, mcol, ref_row, ref_col, cost_type, error_per_bit=0, mvjcost=None, mvcost0=None, mvcost1=None):
+    """mv_err_cost_ (mcomp.c:271-308) for an MV in 1/8 pel; entropy tables are full arrays addressed from their centres."""
+    dr, dc = int(mrow) - int(ref_row), int(mcol) - int(ref_col)
+    if cost_type == 0:
+        bits = int(mvjcost[(dc != 0) | ((dr != 0) << 1)]) + int(mvcost0[len(mvcost0) // 2 + dr]) + int(mvcost1[len(mvcost1) // 2 + dc])
+        return (bits * int(error_per_bit) + (1 << 13)) >> 14
+    lam = {1: 2, 2: 0, 3: 1}.get(cost_type, 0)
+    return (lam * (abs(dr) + abs(dc))) >> 3
+
+
+def first_pass_motion_search_batch(src_b, ref_b, border, w, h, blocks, q, mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4):
+    """av1_full_pixel_search (q: search_params, normally NSTEP_FPF + entropy costs) then av1_get_mvpred_sse + NEW_MV_MODE_PENALTY (32)
+    when the search returned < INT_MAX (mcomp.c:3637-3649).  -> (mv [n, 2] full-pel, err [n] int32)"""
+    mv, cost, _, _ = full_pixel_search_batch(src_b, ref_b, border, w, h, blocks, q, mvjcost, mvcost0, mvcost1, bd=bd, threads=threads)
+    err = np.full(len(blocks), 2147483647, np.int32)
+    for i, b in enumerate(blocks):
+        if cost[i] == 2147483647:
+            continue
+        y, x = border + int(b["by"]), border + int(b["bx"])
+        sse = variance(src_b, y, x, ref_b, y + int(mv[i, 0]), x + int(mv[i, 1]), w, h, bd if bd > 8 else None)[1]
+        err[i] = sse + mv_err_cost(int(mv[i, 0]) * 8, int(mv[i, 1]) * 8, b["ref_row"], b["ref_col"], q.cost_type, q.error_per_bit, mvjcost, mvcost0,
+                                   mvcost1) + 32
+    return mv, err
