@@ -205,6 +205,7 @@ _protos = {
     "aomhip_sad16x16x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp]),
     "aomhip_highbd_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, _i]),
     "aomhip_first_pass_motion_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "aomhip_motion_estimation_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_tf_default_params": (None, [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aomhip_tf_block_list": (C.c_int, [_i, _i, _i, _vp]),
     "aomhip_tf_motion_search_frames": (C.c_int, [_vp, _PP, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -324,6 +325,12 @@ class Context:
                                        d_mvcost_col=None):
         check(lib.aomhip_first_pass_motion_search_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(params), d_mvjcost, d_mvcost_row,
                                                         d_mvcost_col, d_blocks, n, d_mv, d_err), "aomhip_first_pass_motion_search_batch")
+
+    def motion_estimation_batch(self, src, ref, frame, bw, bh, full, sub, use_cost_list, d_blocks, n, d_mv, d_err, d_dist, d_sse, d_full_mv=None,
+                                d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):
+        check(lib.aomhip_motion_estimation_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(full), C.byref(sub), use_cost_list, d_mvjcost,
+                                                 d_mvcost_row, d_mvcost_col, d_blocks, n, d_mv, d_err, d_dist, d_sse, d_full_mv),
+              "aomhip_motion_estimation_batch")
 
     def tf_motion_search_frames(self, frames, filter_frame, params, d_blocks, n_blocks, d_mvs, d_mses, d_ref_mv=None, frame_present=None):
         fp = None if frame_present is None else np.ascontiguousarray(frame_present, np.uint8)

@@ -322,3 +322,84 @@ extern "C" int aomhip_first_pass_motion_search_batch(aomhip_ctx *ctx, const aomh
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
+
+
+// ---- full-pel + sub-pel search of a block list (tpl_model.c motion_estimation, :248-301) --------------------------------------
+namespace aomhip {
+namespace {
+// av1_set_mv_search_range(&limits, &ref_mv) (mcomp.c:196-215) on raw x->mv_limits
+__device__ __forceinline__ void full_limits_ref(const aomhip_search_block &in, aomhip_search_block *out) {
+  const int rr = in.ref_row, rc = in.ref_col;
+  int col_min = rawpel(rc) - kMaxFullPel + ((rc & 7) ? 1 : 0), row_min = rawpel(rr) - kMaxFullPel + ((rr & 7) ? 1 : 0);
+  int col_max = rawpel(rc) + kMaxFullPel, row_max = rawpel(rr) + kMaxFullPel;
+  const int lo = rawpel(kMvLow) + 1, hi = rawpel(kMvUpp) - 1;
+  col_min = col_min > lo ? col_min : lo; row_min = row_min > lo ? row_min : lo;
+  col_max = col_max < hi ? col_max : hi; row_max = row_max < hi ? row_max : hi;
+  out->col_min = (int16_t)(in.col_min < col_min ? col_min : in.col_min);
+  out->col_max = (int16_t)(in.col_max > col_max ? col_max : in.col_max);
+  out->row_min = (int16_t)(in.row_min < row_min ? row_min : in.row_min);
+  out->row_max = (int16_t)(in.row_max > row_max ? row_max : in.row_max);
+}
+// av1_set_subpel_mv_search_range(.., &x->mv_limits, &ref_mv) (mcomp.h:344-361)
+__device__ __forceinline__ void subpel_limits_ref(const aomhip_search_block &in, aomhip_search_block *out) {
+  const int max_mv = kMaxFullPel * 8;
+  auto mx = [](int a, int b) { return a > b ? a : b; };
+  auto mn = [](int a, int b) { return a < b ? a : b; };
+  out->col_min = (int16_t)mx(kMvLow + 1, mx(in.col_min * 8, in.ref_col - max_mv));
+  out->col_max = (int16_t)mn(kMvUpp - 1, mn(in.col_max * 8, in.ref_col + max_mv));
+  out->row_min = (int16_t)mx(kMvLow + 1, mx(in.row_min * 8, in.ref_row - max_mv));
+  out->row_max = (int16_t)mn(kMvUpp - 1, mn(in.row_max * 8, in.ref_row + max_mv));
+}
+__global__ void me_full_list_kernel(const aomhip_search_block *blocks, int n, aomhip_search_block *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const aomhip_search_block b = blocks[i];
+  aomhip_search_block o = b;
+  o.start_row = (int16_t)rawpel(b.ref_row); o.start_col = (int16_t)rawpel(b.ref_col);  // get_fullmv_from_mv(&center_mv)
+  full_limits_ref(b, &o);
+  out[i] = o;
+}
+__global__ void me_subpel_list_kernel(const aomhip_search_block *blocks, const int16_t *full_mv, int n, aomhip_search_block *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const aomhip_search_block b = blocks[i];
+  aomhip_search_block o = b;
+  o.start_row = (int16_t)(full_mv[2 * i] * 8); o.start_col = (int16_t)(full_mv[2 * i + 1] * 8);  // get_mv_from_fullmv
+  subpel_limits_ref(b, &o);
+  out[i] = o;
+}
+}  // namespace
+}  // namespace aomhip
+
+extern "C" int aomhip_motion_estimation_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                              const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list,
+                                              const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                              const aomhip_search_block *d_blocks, int n, int16_t *d_best_mv, uint32_t *d_best_err,
+                                              int32_t *d_distortion, uint32_t *d_sse, int16_t *d_fullpel_mv) {
+  if (!ctx || !full || !sub || n < 0 || (n > 0 && (!d_blocks || !d_best_mv || !d_best_err || !d_distortion || !d_sse))) {
+    set_error("aomhip_motion_estimation_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n == 0) return AOMHIP_OK;
+  AOMHIP_TRY(hipSetDevice(ctx->device));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t n1 = (size_t)n;
+  const size_t o_fl = take(n1 * sizeof(aomhip_search_block)), o_sl = take(n1 * sizeof(aomhip_search_block)), o_fmv = take(n1 * 4), o_cost = take(n1 * 4),
+               o_cl = take(n1 * 20);
+  char *w = static_cast<char *>(work(ctx, off));
+  if (!w) return AOMHIP_ERR_NOMEM;
+  aomhip_search_block *fl = reinterpret_cast<aomhip_search_block *>(w + o_fl), *sl = reinterpret_cast<aomhip_search_block *>(w + o_sl);
+  int16_t *fmv = d_fullpel_mv ? d_fullpel_mv : reinterpret_cast<int16_t *>(w + o_fmv);
+  int32_t *cl = use_cost_list ? reinterpret_cast<int32_t *>(w + o_cl) : nullptr;
+  const unsigned g = (unsigned)((n1 + 255) / 256);
+  hipLaunchKernelGGL(me_full_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, n, fl);
+  AOMHIP_LAUNCH_CHECK();
+  int rc = aomhip_full_pixel_search_batch(ctx, src, ref, frame, bw, bh, full, d_mvjcost, d_mvcost_row, d_mvcost_col, fl, n, fmv,
+                                          reinterpret_cast<int32_t *>(w + o_cost), cl, nullptr);
+  if (rc != AOMHIP_OK) return rc;
+  hipLaunchKernelGGL(me_subpel_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, fmv, n, sl);
+  AOMHIP_LAUNCH_CHECK();
+  return aomhip_subpel_tree_batch(ctx, src, ref, frame, bw, bh, sub, d_mvjcost, d_mvcost_row, d_mvcost_col, sl, cl, n, d_best_mv, d_best_err, d_distortion,
+                                  d_sse);
+}

@@ -636,6 +636,24 @@ int aomhip_first_pass_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *
                                           const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, int n_blocks,
                                           int16_t *d_best_mv, int32_t *d_err);
 
+/* ------------------------------------------------------------------ full-pel + sub-pel search of a block list in one call (TPL, single motion search) */
+
+/* The two-call shape of tpl_model.c's motion_estimation (av1/encoder/tpl_model.c:248-301) and of av1_single_motion_search's core
+ * (motion_search_facade.c:120-): av1_full_pixel_search from get_fullmv_from_mv(center_mv) with the limits
+ * av1_set_mv_search_range(&x->mv_limits, &center_mv) (mcomp.c:196-215), then find_fractional_mv_step from get_mv_from_fullmv(best) with
+ * av1_set_subpel_mv_search_range(.., &x->mv_limits, &center_mv) (mcomp.h:344-361), both with ref_mv = center_mv for the MV cost.
+ * Blocks: bx / by; ref_row / ref_col = center_mv in 1/8 pel; row/col min/max = x->mv_limits (the RAW limits of av1_set_mv_limits: both derived
+ * sets are computed on the device); start_* is ignored.  `full` / `sub` as for the two batched calls; use_cost_list: the full-pel search
+ * fills the 5-entry list and the pruned sub-pel trees read it (cond_cost_list).  Outputs as aomhip_subpel_tree_batch (best MV in 1/8
+ * pel, error, distortion, sse) + optionally the full-pel MV.  TPL: full->search_method = sf.tpl_sf.search_method, step_param =
+ * min(sf.tpl_sf.reduce_first_step_size, MAX_MVSEARCH_STEPS - 2), entropy costs; sub: subpel_search_type USE_2_TAPS (1 -> pass 0 here:
+ * the bilinear estimate), mv_cost_type NONE, forced_stop = sf.tpl_sf.subpel_force_stop.  One entry per (block, centre-MV candidate). */
+int aomhip_motion_estimation_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                   const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list,
+                                   const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                   const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv, uint32_t *d_best_err,
+                                   int32_t *d_distortion, uint32_t *d_sse, int16_t *d_fullpel_mv);
+
 /* ------------------------------------------------------------------ the encoder's kernel vtable */
 
 /* Mirror of aom_variance_fn_ptr_t (aom_dsp/variance.h:84-103): same field order, same pointer types

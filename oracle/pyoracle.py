@@ -965,3 +965,39 @@ def first_pass_motion_search_batch(src_b, ref_b, border, w, h, blocks, q, mvjcos
         err[i] = sse + mv_err_cost(int(mv[i, 0]) * 8, int(mv[i, 1]) * 8, b["ref_row"], b["ref_col"], q.cost_type, q.error_per_bit, mvjcost, mvcost0,
                                    mvcost1) + 32
     return mv, err
+
+
+# ---- full-pel + sub-pel search of a block list: tpl_model.c motion_estimation (av1/encoder/tpl_model.c:248-301) ----
+def set_mv_search_range(limits, ref_row, ref_col):
+    """av1_set_mv_search_range (mcomp.c:196-215): limits = (row_min, row_max, col_min, col_max) of x->mv_limits -> FullMvLimits around ref_mv."""
+    out = []
+    for (lo, hi), r in (((limits[0], limits[1]), int(ref_row)), ((limits[2], limits[3]), int(ref_col))):
+        mn = int(_rawpel(r)) - 1023 + (1 if r & 7 else 0)
+        mx = int(_rawpel(r)) + 1023
+        mn, mx = max(mn, int(_rawpel(-(1 << 14))) + 1), min(mx, int(_rawpel(1 << 14)) - 1)
+        out += [max(int(lo), mn), min(int(hi), mx)]
+    return out
+
+
+def set_subpel_mv_search_range(limits, ref_row, ref_col):
+    """av1_set_subpel_mv_search_range (mcomp.h:344-361) -> (row_min, row_max, col_min, col_max) in 1/8 pel."""
+    out = []
+    for (lo, hi), r in (((limits[0], limits[1]), int(ref_row)), ((limits[2], limits[3]), int(ref_col))):
+        out += [max(-(1 << 14) + 1, max(int(lo) * 8, r - 8184)), min((1 << 14) - 1, min(int(hi) * 8, r + 8184))]
+    return out
+
+
+def motion_estimation_batch(src_b, ref_b, border, w, h, blocks, q, sub, use_cost_list=0, mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4):
+    """blocks: ref_* = center_mv (1/8 pel), limits = raw x->mv_limits.  sub: kwargs of subpel_tree_batch (tree, cost_type, iters, ...).
+    -> (mv [n, 2] 1/8 pel, err, dist, sse, full_mv [n, 2])"""
+    fl, sl = np.array(blocks, copy=True), np.array(blocks, copy=True)
+    for i, b in enumerate(blocks):
+        raw = (b["row_min"], b["row_max"], b["col_min"], b["col_max"])
+        fl["row_min"][i], fl["row_max"][i], fl["col_min"][i], fl["col_max"][i] = set_mv_search_range(raw, b["ref_row"], b["ref_col"])
+        sl["row_min"][i], sl["row_max"][i], sl["col_min"][i], sl["col_max"][i] = set_subpel_mv_search_range(raw, b["ref_row"], b["ref_col"])
+    fl["start_row"], fl["start_col"] = _rawpel(blocks["ref_row"]), _rawpel(blocks["ref_col"])
+    full_mv, _, cl, _ = full_pixel_search_batch(src_b, ref_b, border, w, h, fl, q, mvjcost, mvcost0, mvcost1, bd=bd, threads=threads)
+    sl["start_row"], sl["start_col"] = full_mv[:, 0].astype(np.int32) * 8, full_mv[:, 1].astype(np.int32) * 8
+    mv, err, dist, sse = subpel_tree_batch(src_b, ref_b, border, w, h, sl, mvjcost=mvjcost, mvcost0=mvcost0, mvcost1=mvcost1,
+                                           cost_lists=cl if use_cost_list else None, bd=bd, threads=threads, **sub)
+    return mv, err, dist, sse, full_mv
