@@ -880,6 +880,8 @@ def search_bound():
                                                     "to LDS (round 1 form: 0.88 of the L1 look-up rate)",
                                            "frac": d["subpel_bilinear_lds_footprint"]["valu_issue_frac"],
                                            "issue_wait_frac": d["subpel_bilinear_lds_footprint"]["SQ_WAIT_INST_ANY_over_WAVE_CYCLES"]},
+                "full_pixel_search_kernel_NSTEP": {"bound": "L1 (TCP) cache-line access rate, as the diamond kernel",
+                                                   "frac": d.get("full_pixel_search_nstep", {}).get("l1_accesses_per_cu_cycle")},
                 "source": "profiles/r02_search_bound.md, profiles/r02_search_l1_bound.json (rocprofv3 --pmc)"}
     except Exception:
         return None
