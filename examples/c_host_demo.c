@@ -31,7 +31,36 @@ static unsigned sad16(const uint8_t *a, const uint8_t *b, int stride) {
   return s;
 }
 
+/* The host-only helpers (no GPU call): tile columns + exchange plan of a 4K frame on 8 ranks, the temporal filter's block list and
+ * parameters.  Returns 0 when they say what the reference's rules say. */
+static int host_helpers(void) {
+  int bounds[8][2];
+  if (aomhip_tile_column_bounds(3840, 8, 64, bounds) != 8 || bounds[0][1] != 512 || bounds[7][0] != 3584 || bounds[7][1] != 3840) return 1;
+  aomhip_exchange_item send[8], recv[8];
+  if (aomhip_recon_exchange_plan(8, 3, (const int(*)[2])bounds, 3840, 132, send, recv) != AOMHIP_OK) return 2;
+  /* rank 3 owns [1536, 2048): with a 132-pixel halo it sends its two edge bands to its neighbours only */
+  if (send[2].x0 != 1536 || send[2].x1 != 1536 + 132 || send[4].x0 != 2048 - 132 || send[4].x1 != 2048 || send[0].x1 != send[0].x0) return 3;
+  if (recv[2].x0 != 1536 - 132 || recv[2].x1 != 1536 || recv[4].x0 != 2048 || recv[4].x1 != 2048 + 132) return 4;
+  const int n = aomhip_tf_block_list(1920, 1080, 160, NULL);
+  if (n != 60 * 34) return 5;
+  static aomhip_search_block blocks[60 * 34];
+  if (aomhip_tf_block_list(1920, 1080, 160, blocks) != n || blocks[61].bx != 32 || blocks[61].by != 32) return 6;
+  const int mesh[8] = { 64, 8, 28, 4, 15, 1, 7, 1 };
+  aomhip_tf_params tp;
+  aomhip_tf_default_params(1920, 1080, 10, 30, 1, mesh, 2, 2, 1, 0, 0, 0, &tp);
+  if (tp.full.search_method != AOMHIP_SEARCH_NSTEP || !tp.full.run_mesh_search || !tp.full.prune_mesh_search ||
+      tp.full.mv_cost_type != AOMHIP_MV_COST_L1_HDRES || tp.sub.subpel_search_type != 3 || tp.mse_thresh != (12 << 2)) return 7;
+  return 0;
+}
+
 int main(void) {
+  {
+    const int rc = host_helpers();
+    if (rc) {
+      fprintf(stderr, "host helper check %d failed\n", rc);
+      return 3;
+    }
+  }
   if (aomhip_device_count() <= 0) {
     fprintf(stderr, "no GPU visible: %s\n", aomhip_last_error());
     return 2;

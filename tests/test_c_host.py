@@ -39,3 +39,16 @@ def test_c_host_program_runs(tmp_path):
     r = subprocess.run([str(out)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "0 SAD mismatches" in r.stdout
+
+
+def test_c_host_helpers_run_without_a_gpu(tmp_path):
+    """The plain-C host helpers the demo checks first (tile columns, exchange plan, temporal-filter block list and parameters) need no
+    device: the program gets past them (exit code 3 = a helper check failed) and then stops at the device probe (2) or runs (0)."""
+    out = tmp_path / "c_host_demo"
+    lib = os.path.join(ROOT, "aom-av1-psy_amd", "lib")
+    r = subprocess.run(["gcc", "-std=c99", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_host_demo.c"), "-L" + lib,
+                        "-laomhip", "-Wl,-rpath," + lib, "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[:2000]
+    r = subprocess.run([str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode in (0, 2), (r.returncode, r.stdout, r.stderr)
+    assert "host helper check" not in r.stderr
