@@ -132,10 +132,12 @@ class SadModeA:
         # Cells are anchored at x = 0, tile columns start at multiples of their width: a cell width that divides the
         # column width keeps every strip inside one rank's column.  Tuned width when it divides, else the largest
         # divisor below it.
-        tuned = (480 if W <= 1920 else 384) if bd == 8 else 160
+        # r02 sweep (tools/gpu_ab_sb_dbg.sh, profiles/r02_sad_strip.md): 8-bit 240 x 48 (16 / 8 strips per 4K / 1080p frame = a whole
+        # number of items per CU with 64 frames, 45 blocks and fewer, taller steps), 16-bit 160 x 32 (what the loaders' staging holds)
+        tuned, cell_h = (240, 48) if bd == 8 else (160, 32)
         col_w = pkg.partition.column_of_rank(W, world, 0)[1] - pkg.partition.column_of_rank(W, world, 0)[0]
         cw = tuned if col_w % tuned == 0 else max([d for d in range(16, tuned + 1, 16) if col_w % d == 0] or [tuned])
-        self.cell = (cw, 32)
+        self.cell = (cw, cell_h)
         self.d_sb = None
         if n and self.path == "sb":
             perm, off = synth.bucket_order(base_c["sx"], base_c["sy"], W, H, *self.cell)
