@@ -48,4 +48,23 @@ demo: build/c_host_demo
 build/c_host_demo: examples/c_host_demo.c include/aomhip.h $(LIBDIR)/libaomhip.so
 	gcc -std=c99 -pedantic -Wall -Wextra -Werror -O2 -Iinclude $< -L$(LIBDIR) -laomhip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -o $@
 
-.PHONY: all lib oracle clean demo
+.PHONY: all lib oracle clean demo prof exp
+
+# phase timing build of the strip-walking SAD kernel (tools/gpu_sb_prof.py): the product library with sad_sb.hip compiled -DAOMHIP_SB_PROF
+prof: build/prof/libaomhip_prof.so
+build/prof/libaomhip_prof.so: $(OBJS) $(CSRC)/sad_sb.hip
+	@mkdir -p build/prof
+	$(HIPCC) $(HIPFLAGS) -DAOMHIP_SB_PROF -c $(CSRC)/sad_sb.hip -o build/prof/sad_sb.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out build/sad_sb.o,$(OBJS)) build/prof/sad_sb.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+
+# kernel experiments on sad_sb.hip without the 3-minute rebuild: only the 16x16 instantiations (AOMHIP_LIB=build/exp/libaomhip_exp.so
+# python tools/gpu_ab_sadsb.py ...; the _prof one for tools/gpu_sb_prof.py).  Not the product library.
+exp: build/exp/libaomhip_exp.so build/exp/libaomhip_exp_prof.so
+build/exp/libaomhip_exp.so: $(CSRC)/sad_sb.hip $(filter-out build/sad_sb.o,$(OBJS))
+	@mkdir -p build/exp
+	$(HIPCC) $(HIPFLAGS) -DAOMHIP_SB_ONLY_16 $(EXPFLAGS) -c $(CSRC)/sad_sb.hip -o build/exp/sad_sb.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out build/sad_sb.o,$(OBJS)) build/exp/sad_sb.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+build/exp/libaomhip_exp_prof.so: $(CSRC)/sad_sb.hip $(filter-out build/sad_sb.o,$(OBJS))
+	@mkdir -p build/exp
+	$(HIPCC) $(HIPFLAGS) -DAOMHIP_SB_ONLY_16 $(EXPFLAGS) -DAOMHIP_SB_PROF -c $(CSRC)/sad_sb.hip -o build/exp/sad_sb_prof.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out build/sad_sb.o,$(OBJS)) build/exp/sad_sb_prof.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib

@@ -114,16 +114,19 @@ struct StripArgs {
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 #ifdef AOMHIP_SB_PROF  // phase timing of wave 0 of every workgroup (tools/gpu_sb_prof.sh builds a library with it)
-__device__ unsigned long long g_sb_prof[8];
+__device__ unsigned long long g_sb_prof[32];  // [0..7] first evaluating wavefront, [8..15] first loader wavefront, [16..31] barrier wait of wavefront w
 #define SB_T(v) const long long v = (long long)__builtin_readcyclecounter()
 #define SB_ACC(i, t1, t0) prof_acc[i] += (unsigned long long)((t1) - (t0))
-#define SB_DECL unsigned long long prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
-#define SB_FLUSH if (tid == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_sb_prof[i_], prof_acc[i_]); }
+#define SB_DECL unsigned long long prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, prof_wait = 0
+#define SB_WAIT(t1, t0) prof_wait += (unsigned long long)((t1) - (t0))
+#define SB_FLUSH if (tid == 0 || tid == kThreads) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_sb_prof[(tid ? 8 : 0) + i_], prof_acc[i_]); } \
+  if (lane == 0) atomicAdd(&g_sb_prof[16 + wave], prof_wait);
 #else
 #define SB_DECL
 #define SB_FLUSH
 #define SB_T(v)
 #define SB_ACC(i, t1, t0)
+#define SB_WAIT(t1, t0)
 #endif
 
 // Ring rows that are stored twice: a block of height <= kMirrorMax + 1 starting in any ring slot then reads consecutive
@@ -131,19 +134,29 @@ __device__ unsigned long long g_sb_prof[8];
 constexpr int kMirrorMax = 15;
 __host__ __device__ constexpr int mirror_rows(int h) { return h - 1 <= kMirrorMax ? h - 1 : 0; }
 
-// kThreads evaluating lanes + kLT loader lanes (the last kLoaders wavefronts of the workgroup).
-constexpr int kEvalThreads = 512;
-constexpr int kLoaders = 8;               // loader wavefronts per workgroup, in two groups that take alternate steps
-constexpr int kRingN = 5, kSrcN = 4, kGN = 2, kCN = 1;  // 16-byte chunks / dwords one loader lane has in flight for its step
-constexpr int kLT = 64 * kLoaders / 2;    // loader lanes per group
-template <typename T, int W, int H, bool SKIP, int kThreads, int UPL>
-__global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(PlaneView<T> src, PlaneView<T> ref, StripArgs a,
+// A workgroup = C::kThreads evaluating lanes + C::kLoaders loader wavefronts (the last ones), 1024 lanes in all (the 128-VGPR budget).
+// kRingN / kSrcN / kGN / kCN: 16-byte chunks / dwords one loader lane has in flight for its step; the loader wavefronts work in two
+// groups of kLT lanes that take alternate steps.
+template <int EVAL, int UPL_, int LOADERS, int RING_N, int SRC_N, int G_N, int C_N> struct Cfg {
+  static constexpr int kThreads = EVAL, kUPL = UPL_, kLoaders = LOADERS, kRingN = RING_N, kSrcN = SRC_N, kGN = G_N, kCN = C_N;
+  static constexpr int kLT = 64 * LOADERS / 2;
+  static constexpr int kAll = EVAL + 64 * LOADERS;
+};
+// 8 evaluating wavefronts with two row units per lane + 8 loader wavefronts.
+using CfgWide = Cfg<512, 2, 8, 6, 4, 2, 1>;
+// 12 evaluating wavefronts with ONE row unit per lane + 4 loader wavefronts that keep twice the chunks in flight each (experiment,
+// see use_deep()).
+using CfgDeep = Cfg<768, 1, 4, 9, 6, 4, 2>;
+template <typename T, int W, int H, bool SKIP, typename C>
+__global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, PlaneView<T> ref, StripArgs a,
                                                                   const aomhip_sad_x4d_cand *__restrict__ groups,
                                                                   const int32_t *__restrict__ group_off, int n_groups,
                                                                   int64_t group_frame_stride, uint32_t *__restrict__ out4,
                                                                   const aomhip_sad_cand *__restrict__ cands,
                                                                   const int32_t *__restrict__ cand_off, int n_cands,
                                                                   int64_t cand_frame_stride, uint32_t *__restrict__ out1) {
+  constexpr int kThreads = C::kThreads, UPL = C::kUPL, kRingN = C::kRingN, kSrcN = C::kSrcN, kGN = C::kGN,
+                kCN = C::kCN, kLT = C::kLT;
   using G = Geom<T, W, H, SKIP, UPL>;
   using L = typename UnitLoad<G::kUnitBytes>::type;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
   constexpr int kEpc = 16 / kES;  // elements per 16-byte chunk
   constexpr int kPerWg = kThreads / G::kTpc;
   constexpr int kWaves = kThreads / 64;       // evaluating wavefronts; wavefront kWaves is the loader
-  constexpr int kAll = kThreads + 64 * kLoaders;
+  constexpr int kAll = C::kAll;
   constexpr int kGenUnroll = G::kUnitsPerLane <= 4 ? G::kUnitsPerLane : 4;
   constexpr int kMirror = mirror_rows(H);
   const int tid = (int)threadIdx.x;
@@ -430,16 +443,18 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
                 // itself the compiler reads one reference, waits, computes, reads the next: ten LDS round trips in the one
                 // iteration a wavefront runs per step).  1080p -4.6 %, 4K -2 %; on 16-bit planes the same form was 5 % slower.
                 constexpr int kDw = G::kUnitBytes / 4;
+                // (row pitches and unit offsets are multiples of 16 bytes: a reference's dword base and byte shift are the same
+                // for all of its rows)
+                unsigned sh[5], bdw[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { sh[j] = base[j] & 3u; bdw[j] = base[j] & ~3u; }
 #pragma unroll
                 for (int k = 0; k < G::kUnitsPerLane; ++k) {
                   const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
                   uint32_t raw[5][kDw + 1];
-                  unsigned sh[5];
 #pragma unroll
                   for (int j = 0; j < 5; ++j) {
-                    const unsigned o = base[j] + unit_roff[k];
-                    const uint32_t *p = reinterpret_cast<const uint32_t *>(lds) + (o >> 2);
-                    sh[j] = o & 3;
+                    const uint32_t *p = reinterpret_cast<const uint32_t *>(lds + (bdw[j] + unit_roff[k]));
 #pragma unroll
                     for (int i = 0; i <= kDw; ++i) raw[j][i] = p[i];
                   }
@@ -609,8 +624,10 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
           Batch p = b;
           p.ya = ya; p.yb = min(ya + rows_per_pass, win_y1(0));
           if (ya != win_y0(0)) { p.ns = 0; p.ng = 0; p.nc = 0; }
-          request_gen(p, st0, tid, kAll);
-          commit_gen(p, st0, tid, kAll);
+          int me = tid;
+          asm volatile("" : "+v"(me));  // (as in overflow() below: nothing of this loop is worth keeping across the strip)
+          request_gen(p, st0, me, kAll);
+          commit_gen(p, st0, me, kAll);
         }
       }
       // The two roles run their own step loops with the same sequence of workgroup barriers.  The loader's loop body is
@@ -621,15 +638,17 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
       // (scalar base + 32-bit lane offset).  The general forms above cost ~25 instructions per chunk, and with ~14 chunks
       // per lane that made the loaders, not the memory system or the evaluation, the longest thing in a step.
       unsigned r_goff[kRingN], r_loff[kRingN], s_goff[kSrcN], s_loff[kSrcN];
+      int lt_s = lt;  // (opaque: the tables below must not be computed -- and kept alive -- across the prologue above)
+      asm volatile("" : "+v"(lt_s));
 #pragma unroll
       for (int i = 0; i < kRingN; ++i) {
-        const unsigned q = (unsigned)(lt + i * kLT), row = __umulhi(q, a.magic_cpr), col = q - row * (unsigned)a.cpr;
+        const unsigned q = (unsigned)(lt_s + i * kLT), row = __umulhi(q, a.magic_cpr), col = q - row * (unsigned)a.cpr;
         r_goff[i] = row * (unsigned)gpitch + (unsigned)min((int)col, colmax) * 16u;
         r_loff[i] = row * (unsigned)a.pitch + col * 16u;
       }
   #pragma unroll
       for (int i = 0; i < kSrcN; ++i) {
-        const unsigned q = (unsigned)(lt + i * kLT), row = __umulhi(q, a.magic_scpr), col = q - row * (unsigned)a.scpr;
+        const unsigned q = (unsigned)(lt_s + i * kLT), row = __umulhi(q, a.magic_scpr), col = q - row * (unsigned)a.scpr;
         s_goff[i] = row * (unsigned)sgpitch + (unsigned)min((int)col, scolmax) * 16u;
         s_loff[i] = row * (unsigned)a.spitch + col * 16u;
       }
@@ -673,11 +692,10 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
       };
       const int steps = (a.dbg & 256) ? 0 : (a.cell_rows + 1) & ~1;  // both roles run an even number of steps (the odd one out only meets the barriers); (dbg 256: timing ablation, prologue only)
       if constexpr (kLoader) {
-        // Two loader groups take alternate steps: during step cy the group of that parity writes batch cy + 1 (requested
-        // two steps earlier) to LDS and requests batch cy + 3, so two batches -- about 2 x 36 KB per CU, what it takes
-        // to keep HBM busy at its loaded latency -- are in flight at any time, and each wavefront only ever waits for
-        // its own loads (with both batches in one wavefront the compiler's vmcnt bookkeeping drained the younger batch
-        // too).  Each group's loop is straight-line around the staged registers.
+        // Two loader groups take alternate steps: during step cy the group of that parity writes batch cy + 1 (which it requested
+        // during step cy - 1) to LDS while the other group requests batch cy + 2, so a batch -- ~30 KB per CU -- has a whole step to
+        // arrive and each wavefront only ever waits for its own loads (with two batches in one wavefront the compiler's vmcnt
+        // bookkeeping drained the younger batch too).  Each group's loop is straight-line around the staged registers.
         Stage st;
         auto overflow = [&](int cy, bool mine) {  // a crowded bucket: further slices through the same buffers
           if (cy >= a.cell_rows) return;
@@ -689,25 +707,49 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
             o.g0 = g; o.ng = min(cur.g1 - g, a.gcap); o.c0 = c; o.nc = min(cur.c1 - c, a.ccap);
             __syncthreads();  // the evaluating wavefronts are done with the previous slice
             if (mine) {
+              // (the lane index goes through an opaque statement: otherwise every per-lane quantity of this rarely taken path is
+              // hoisted out of the step loop and stays in registers -- or in scratch -- for the whole strip)
+              int me = lt;
+              asm volatile("" : "+v"(me));
               Stage so;
-              request_gen(o, so, lt, kLT);
-              commit_gen(o, so, lt, kLT);
+              request_gen(o, so, me, kLT);
+              commit_gen(o, so, me, kLT);
             }
             __syncthreads();
             g += o.ng; c += o.nc;
           }
         };
+        // A group's two steps: in its ACTIVE step it writes the batch it holds (batch cy + 1) to LDS; in its PASSIVE step -- while the other
+        // group writes -- it works out and requests the batch it will write next (cy + 2 seen from the passive step).  Doing both in the
+        // active step (the first form) made one wavefront's commit -> bookkeeping -> request sequence, ~4400 clock ticks, the longest
+        // thing in a step, with the other group idle and the evaluating wavefronts (~3700) waiting at the barrier for it.
         auto active = [&](int cy) {
           if (a.dbg & 64) { __syncthreads(); return; }  // (timing ablation: barriers only)
-          commit(batch_of(cy + 1), st);  // requested two steps ago
+          SB_T(l0);
+          const Batch bc = batch_of(cy + 1);
+          SB_T(l1);
+#ifdef AOMHIP_SB_PROF
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          SB_T(l1w);
+          SB_ACC(7, l1w, l1);
+#endif
+          commit(bc, st);  // requested in the previous step
+          SB_T(l2);
           overflow(cy, true);
-          request(batch_of(cy + 3), st);  // in flight across the next two barriers
+          SB_T(l3);
           __syncthreads();  // step cy + 1 is in LDS; nobody reads step cy's rows / cell / slices any more
+          SB_T(l5);
+          SB_ACC(0, l1, l0); SB_ACC(1, l2, l1); SB_ACC(2, l3, l2); SB_ACC(4, l5, l3); SB_ACC(5, 1, 0); SB_WAIT(l5, l3);
         };
         auto passive = [&](int cy) {
           if (a.dbg & 64) { __syncthreads(); return; }
+          SB_T(q0);
+          request(batch_of(cy + 2), st);  // in flight across this step's barrier
+          SB_T(q1);
           overflow(cy, false);
           __syncthreads();
+          SB_T(q2);
+          SB_ACC(3, q1, q0); SB_ACC(6, q2, q1); SB_WAIT(q2, q1);
         };
         if (grp == 0) {
           request(batch_of(1), st);
@@ -717,7 +759,6 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
             passive(cy + 1);
           }
         } else {
-          request(batch_of(2), st);
           __syncthreads();
           for (int cy = 0; cy < steps; cy += 2) {
             passive(cy);
@@ -746,6 +787,8 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
           const bool step_ok = strip_ok && win_y1(cy) - w.wy0 >= H && min(cy * a.sb_h + a.sb_h, a.s_ymax) - cy * a.sb_h >= H;
           int g = cur.g0, c = cur.c0;
           bool first = true;
+          SB_T(t1b);
+          SB_ACC(0, t1b, t1);
           do {
             const int ng = min(cur.g1 - g, a.gcap), nc = min(cur.c1 - c, a.ccap);
             if (!first) {
@@ -783,7 +826,7 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
           SB_T(t2);
           __syncthreads();
           SB_T(t4);
-          SB_ACC(1, t2, t1); SB_ACC(3, t4, t2); SB_ACC(4, 1, 0);
+          SB_ACC(1, t2, t1); SB_ACC(3, t4, t2); SB_ACC(4, 1, 0); SB_WAIT(t4, t2);
         }
       }
     }
@@ -795,6 +838,7 @@ __global__ __launch_bounds__(kThreads + 64 * kLoaders) void sad_strip_kernel(Pla
 struct SbLaunch {
   hipStream_t stream;
   int grid, threads, upl;
+  bool deep;  // CfgDeep
   size_t lds_bytes;
   StripArgs a;
   const aomhip_sad_x4d_cand *groups;
@@ -809,30 +853,44 @@ struct SbLaunch {
   uint32_t *out1;
 };
 
-template <typename T, int W, int H, bool SKIP, int kThreads, int UPL>
+template <typename T, int W, int H, bool SKIP, typename C>
 static int launch_nt(const SbLaunch &l, const PlaneView<T> &s, const PlaneView<T> &r) {
-  auto k = sad_strip_kernel<T, W, H, SKIP, kThreads, UPL>;
+  auto k = sad_strip_kernel<T, W, H, SKIP, C>;
   static thread_local size_t granted = 0;  // per instantiation
   if (l.lds_bytes > granted) {
     AOMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)l.lds_bytes));
     granted = l.lds_bytes;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)l.grid), dim3(kThreads + 64 * sb::kLoaders), l.lds_bytes, l.stream, s, r, l.a,
+  hipLaunchKernelGGL(k, dim3((unsigned)l.grid), dim3(C::kAll), l.lds_bytes, l.stream, s, r, l.a,
                      l.groups, l.group_off, l.n_groups, l.gfs, l.out4, l.cands, l.cand_off, l.n_cands, l.cfs, l.out1);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
 
-// 512 evaluating lanes (2 row units per lane: 8 lanes per 16x16 8-bit block) + the loader wavefront.
+// The deep configuration is an experiment (AOMHIP_SB_CFG=deep, 16x16 on 8-bit planes only): its evaluation is ~25 % shorter per step,
+// but four loader wavefronts cannot carry a step's transport (15 chunks per lane: the commit sequence alone outlasts the evaluation).
+constexpr bool deep_size(int es, int w, int h) { return es == 1 && w == 16 && h == 16; }
+inline bool use_deep(int es, int w, int h, bool skip) {
+  if (!deep_size(es, w, h) || skip) return false;
+  const char *e = getenv("AOMHIP_SB_CFG");
+  return e && e[0] == 'd';
+}
 template <typename T, int W, int H, bool SKIP>
 static int launch(const SbLaunch &l, const PlaneView<T> &s, const PlaneView<T> &r) {
-  return launch_nt<T, W, H, SKIP, sb::kEvalThreads, 2>(l, s, r);
+  if constexpr (deep_size((int)sizeof(T), W, H) && !SKIP) {
+    if (l.deep) return launch_nt<T, W, H, SKIP, CfgDeep>(l, s, r);
+  }
+  return launch_nt<T, W, H, SKIP, CfgWide>(l, s, r);
 }
 
+#ifdef AOMHIP_SB_ONLY_16  // (codegen experiments: one block size compiles in seconds)
+#define AOMHIP_FOR_BLOCK_SIZES(X) X(16, 16)
+#else
 #define AOMHIP_FOR_BLOCK_SIZES(X)                                                                                \
   X(4, 4) X(4, 8) X(8, 4) X(8, 8) X(8, 16) X(16, 8) X(16, 16) X(16, 32) X(32, 16) X(32, 32) X(32, 64) X(64, 32) \
   X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(4, 16) X(16, 4) X(8, 32) X(32, 8) X(16, 64) X(64, 16)
+#endif
 
 template <typename T>
 static int dispatch(const SbLaunch &l, bool skip, const PlaneView<T> &s, const PlaneView<T> &r, int bw, int bh) {
@@ -852,9 +910,9 @@ static unsigned magic_of(int d) { return (unsigned)((0x100000000ull + (unsigned)
 using namespace aomhip;
 
 #ifdef AOMHIP_SB_PROF
-extern "C" int aomhip_debug_sb_prof(unsigned long long out[8], int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sb::g_sb_prof), 64) != hipSuccess) return AOMHIP_ERR_HIP;
-  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sb::g_sb_prof), z, 64) != hipSuccess) return AOMHIP_ERR_HIP; }
+extern "C" int aomhip_debug_sb_prof(unsigned long long out[32], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sb::g_sb_prof), 256) != hipSuccess) return AOMHIP_ERR_HIP;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sb::g_sb_prof), z, 256) != hipSuccess) return AOMHIP_ERR_HIP; }
   return AOMHIP_OK;
 }
 #endif
@@ -917,9 +975,14 @@ extern "C" int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
   a.R = 2 * sb_h + 2 * range;
   a.scpr = (sb_w * es + 15) / 16 + (((sb_w % epc) == 0 && (src->border % epc) == 0) ? 0 : 1);
   a.spitch = ((a.scpr & 3) == 0 ? a.scpr + 1 : a.scpr) * 16;
-  if (sb_h * a.cpr > sb::kRingN * sb::kLT || sb_h * a.scpr > sb::kSrcN * sb::kLT) {
+  l.deep = sb::use_deep(es, bw, bh, (flags & AOMHIP_SAD_SKIP_ROWS) != 0);
+  const int ring_chunks = l.deep ? sb::CfgDeep::kRingN * sb::CfgDeep::kLT : sb::CfgWide::kRingN * sb::CfgWide::kLT;
+  const int src_chunks = l.deep ? sb::CfgDeep::kSrcN * sb::CfgDeep::kLT : sb::CfgWide::kSrcN * sb::CfgWide::kLT;
+  const int g_words = l.deep ? sb::CfgDeep::kGN * sb::CfgDeep::kLT : sb::CfgWide::kGN * sb::CfgWide::kLT;
+  const int c_words = l.deep ? sb::CfgDeep::kCN * sb::CfgDeep::kLT : sb::CfgWide::kCN * sb::CfgWide::kLT;
+  if (sb_h * a.cpr > ring_chunks || sb_h * a.scpr > src_chunks) {
     set_error("a step of %d rows x (%d + %d) bytes exceeds what the loader wavefronts keep in flight (%d + %d KB): use a lower cell",
-              sb_h, a.cpr * 16, a.scpr * 16, sb::kRingN * sb::kLT / 64, sb::kSrcN * sb::kLT / 64);
+              sb_h, a.cpr * 16, a.scpr * 16, ring_chunks / 64, src_chunks / 64);
     return AOMHIP_ERR_INVALID;
   }
   const size_t ring_bytes = (size_t)(a.R + sb::mirror_rows(bh)) * a.pitch, cell_bytes = (size_t)sb_h * a.spitch;
@@ -933,8 +996,8 @@ extern "C" int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
     size_t per_buf = (kLds - ring_bytes - 2 * cell_bytes - misc_bytes) / 2;
     if (per_buf > 16 * 1024) per_buf = 16 * 1024;
     int cap = (int)((per_buf - 32) / 28);
-    if (cap > sb::kGN * sb::kLT / 5) cap = sb::kGN * sb::kLT / 5;  // what the loader lanes hold per step
-    if (cap > sb::kCN * sb::kLT / 2) cap = sb::kCN * sb::kLT / 2;
+    if (cap > g_words / 5) cap = g_words / 5;  // what the loader lanes hold per step
+    if (cap > c_words / 2) cap = c_words / 2;
     if (const char *e = getenv("AOMHIP_SB_DESC_CAP")) cap = atoi(e) < cap && atoi(e) > 0 ? atoi(e) : cap;  // tests: force the crowded-bucket path
     a.gcap = a.ccap = cap;
     size_t off = 0;

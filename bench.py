@@ -125,16 +125,15 @@ class SadModeA:
         self.d_cands = ctx.to_device(base_c) if n else None
         self.d_groups = ctx.to_device(allg) if n else None
         # Superblock-bucketed copy of the same lists (aomhip_sad_sb_batch), range 64.  The kernel walks STRIPS (columns of
-        # cells) with the reference window in an LDS ring, so a cell is one step of that walk: 32 rows high, and as wide
-        # as the LDS ring of 2*32 + 128 rows allows (profiles/r02_sad_strip.md: 480 / 384 px for 8-bit 1080p / 4K,
-        # 160 px for 10-bit).  It is the path the step uses; AOMHIP_SAD_PATH=direct|sb overrides.
+        # cells) with the reference window in an LDS ring, so a cell is one step of that walk.  It is the path the step uses;
+        # AOMHIP_SAD_PATH=direct|sb overrides.
         self.path = os.environ.get("AOMHIP_SAD_PATH", "sb")
         # Cells are anchored at x = 0, tile columns start at multiples of their width: a cell width that divides the
         # column width keeps every strip inside one rank's column.  Tuned width when it divides, else the largest
         # divisor below it.
-        # r02 sweep (tools/gpu_ab_sb_dbg.sh, profiles/r02_sad_strip.md): 8-bit 240 x 48 (16 / 8 strips per 4K / 1080p frame = a whole
-        # number of items per CU with 64 frames, 45 blocks and fewer, taller steps), 16-bit 160 x 32 (what the loaders' staging holds)
-        tuned, cell_h = (240, 48) if bd == 8 else (160, 32)
+        # r02 sweeps (profiles/r02_sad_strip.md): 8-bit 240 x 64 (16 / 8 strips per 4K / 1080p frame = a whole number of items per CU
+        # with 64 frames; 60 blocks per step keep all eight evaluating wavefronts busy, two per SIMD), 16-bit 160 x 32
+        tuned, cell_h = (240, 64) if bd == 8 else (160, 32)
         col_w = pkg.partition.column_of_rank(W, world, 0)[1] - pkg.partition.column_of_rank(W, world, 0)[0]
         cw = tuned if col_w % tuned == 0 else max([d for d in range(16, tuned + 1, 16) if col_w % d == 0] or [tuned])
         self.cell = (cw, cell_h)

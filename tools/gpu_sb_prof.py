@@ -27,14 +27,18 @@ def main():
         def go():
             ctx.sad_sb_batch(ps, pr, 0, F, 16, 16, 0, sbw, sbh, 64, len(off) - 1, d_gs, d_off, n, 0, d_p4, d_cs, d_off, n, 0, d_p1)
         go(); ctx.sync()
-        buf = (C.c_ulonglong * 8)()
+        buf = (C.c_ulonglong * 32)()
         lib.aomhip_debug_sb_prof(buf, 1)
         ctx.timer_begin(); go(); ms = ctx.timer_end()
         lib.aomhip_debug_sb_prof(buf, 1)
         p = list(buf)
         steps, items = max(p[4], 1), max(p[6], 1)
+        lsteps = max(p[8 + 5], 1)
         print(json.dumps({"cell": spec, "ms": ms, "steps": steps, "items": items,
-                          "per_step_cycles": {"issue_next": p[0] / steps, "evaluate": p[1] / steps, "dma_wait": p[2] / steps, "barrier": p[3] / steps},
-                          "prologue_cycles_per_item": p[5] / items}), flush=True)
+                          "evaluator_per_step_cycles": {"bookkeeping": p[0] / steps, "bookkeeping+evaluate": p[1] / steps, "barrier": p[3] / steps},
+                          "loader_per_active_step_cycles": {"batch_of(cy+1)": p[8] / lsteps, "commit(incl. wait)": p[9] / lsteps, "wait_for_loads": p[15] / lsteps, "overflow+batch_of(cy+3)": p[10] / lsteps,
+                                                            "request(+batch_of)": p[11] / lsteps, "barrier": p[12] / lsteps, "passive_overflow+barrier": p[14] / lsteps},
+                          "prologue_cycles_per_item": p[5] / items,
+                          "barrier_wait_per_step_by_wavefront": [round(x / steps) for x in p[16:32]]}), flush=True)
         for d in (d_gs, d_cs, d_off): ctx.free(d)
 main()
