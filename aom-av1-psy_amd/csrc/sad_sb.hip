@@ -418,9 +418,10 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
             // SADs; the general code below is a chain of small dependent blocks, and with two evaluating wavefronts
             // per SIMD that chain's latency -- not LDS or VALU throughput -- set the step time.
             const bool both = has_g && has_c;
-            const uint32_t d0 = gd[both ? i * 5 : 0], c0w = cd[both ? i * 2 : 0], c1w = cd[both ? i * 2 + 1 : 1];
-            const int mrx = __builtin_amdgcn_sbfe((int)gd[both ? i * 5 + 1 + my_w : 1 + my_w], my_sh, 16);
-            const int mry = __builtin_amdgcn_sbfe((int)gd[both ? i * 5 + 3 + my_w : 3 + my_w], my_sh, 16);
+            const int ii = both ? i : 0;  // (lanes without a pair read entry 0: no out-of-range LDS address, no per-word select)
+            const uint32_t d0 = gd[ii * 5], c0w = cd[ii * 2], c1w = cd[ii * 2 + 1];
+            const int mrx = __builtin_amdgcn_sbfe((int)gd[ii * 5 + 1 + my_w], my_sh, 16);
+            const int mry = __builtin_amdgcn_sbfe((int)gd[ii * 5 + 3 + my_w], my_sh, 16);
             const int fsx = (int16_t)d0, fsy = (int16_t)(d0 >> 16);
             unsigned soff, mbase, cbase, base[5];
             int unused;
@@ -433,8 +434,11 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
             okv &= (unsigned)__builtin_amdgcn_update_dpp(0u, okv, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
             if (__all((both && okv != 0) || (!has_g && !has_c))) {
               if (a.dbg & 32) continue;  // (timing ablation: decode and tests only)
+              // (`both` is uniform over a block's lanes: the select goes BEFORE the quad broadcasts, which then run unconditionally --
+              // selecting after them compiled to four exec-masked DPP moves, each inside its own branch)
+              mbase = both ? mbase : (unsigned)a.ring_off;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) base[j] = both ? quad_bcast(mbase, j) : (unsigned)a.ring_off;
+              for (int j = 0; j < 4; ++j) base[j] = quad_bcast(mbase, j);
               base[4] = both ? cbase : (unsigned)a.ring_off;
               if (!both) soff = 0;
               uint32_t acc[5] = { 0, 0, 0, 0, 0 };
