@@ -354,6 +354,11 @@ def run_txq(pkg, ctx, orc, steps, warmup, want_cpu):
         t, ms = res["roofline"]["traffic"], per[dom]["avg_launch_ms"]
         res["roofline"]["traffic_GBs"] = t / (ms * 1e-3) / 1e9
         res["roofline"]["traffic_over_algorithmic"] = t / (wl.blocks[int(dom.split("x")[0])] * (10 * int(dom.split("x")[0]) ** 2 + 2))
+    try:  # the 16x16 kernel's other limit, measured once with PMC (profiles/r02_txq.md): it is VALU-issue bound, HBM follows
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02v_pmc_txq16.json")))
+        per["16x16"]["valu_issue_occupancy_pmc"] = round(pmc["_valu_issue_occupancy"], 3)
+    except Exception:
+        pass
     if want_cpu and orc is not None:
         res["cpu_baseline"] = wl.cpu_baseline()
     wl.free()
