@@ -266,7 +266,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
 
       // ---- transport (loader lanes): one BATCH = what step `cy` adds to LDS: new ring rows [ya, yb), source cell cy,
       // the list slices of cell cy.  request() starts the loads into registers, commit() writes them to LDS a step later.
-      struct Batch { int ya, yb, sy0, ns, g0, ng, c0, nc, buf; };
+      struct Batch { int ya, yb, sy0, ns, g0, ng, c0, nc, buf; unsigned first; };  // first: ring byte offset of row ya
       // The staged 16-byte chunks are NATIVE 4 x 32-bit vectors, moved as a whole from the load to the ds_write: as a struct of four
       // scalars the register allocator was free to park single components elsewhere (it did: `v_mov v68, v23` behind an
       // `s_waitcnt vmcnt(6)` at the end of request(), i.e. the loader waited for half of the loads it had just issued, every step).
@@ -336,6 +336,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
       // The strip's bucket bounds come out of LDS (filled in the prologue): a scalar load from global memory at the top of
       // a step took 1000-3000 cycles while the loaders keep the memory system saturated.
       const int4 *segs = reinterpret_cast<const int4 *>(lds + a.seg_off);
+      int4 *wins = reinterpret_cast<int4 *>(lds + a.seg_off) + a.cell_rows, *bats = wins + a.cell_rows;
       auto seg_of = [&](int cy) {
         const int4 v = segs[cy];
         Seg s;
@@ -601,20 +602,32 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
         const bool real = cy < a.cell_rows;
         const int cyc = real ? cy : a.cell_rows - 1;  // (addresses of an empty batch stay inside the planes)
         const Seg sg = seg_of(cyc);
+        const int4 bv = bats[cyc];  // {first new row, new rows, source cell rows, ring byte offset of the first new row}
         Batch b;
-        b.ya = cyc > 0 ? win_y1(cyc - 1) : win_y0(0);
-        b.yb = real ? win_y1(cyc) : b.ya;
-        b.sy0 = cyc * a.sb_h; b.ns = real ? min(b.sy0 + a.sb_h, a.s_ymax) - b.sy0 : 0;
+        b.ya = uni(bv.x);
+        b.yb = real ? b.ya + uni(bv.y) : b.ya;
+        b.sy0 = cyc * a.sb_h; b.ns = real ? uni(bv.z) : 0;
+        b.first = (unsigned)uni(bv.w);
         b.g0 = sg.g0; b.ng = real ? min(sg.g1 - sg.g0, a.gcap) : 0;
         b.c0 = sg.c0; b.nc = real ? min(sg.c1 - sg.c0, a.ccap) : 0;
         b.buf = cy & 1;
         if ((a.dbg & 2) && cy > 0) { b.yb = b.ya; b.ns = 0; }  // (timing ablation: list slices only)
         return b;
       };
+      // Per-step records, worked out once per strip (one lane per step) instead of by every wavefront in every step: the scalar
+      // arithmetic of a step -- window rows, ring slot (a modulo), bucket bounds -- was ~330 clock ticks on every evaluating wavefront's
+      // chain and more on the loaders', much of it reloads of spilled scalars.
       for (int cy = tid; cy < a.cell_rows; cy += kAll) {
         const int b = cy * a.cells_per_row + cx;
         reinterpret_cast<int4 *>(lds + a.seg_off)[cy] = make_int4(groups ? group_off[b] : 0, groups ? group_off[b + 1] : 0,
                                                                     cands ? cand_off[b] : 0, cands ? cand_off[b + 1] : 0);
+        const int wy0 = win_y0(cy), wy1 = win_y1(cy);
+        const int sh = min(cy * a.sb_h + a.sb_h, a.s_ymax) - cy * a.sb_h;
+        const bool ok = strip_ok && wy1 - wy0 >= H && sh >= H;
+        const unsigned wh_ok = strip_ok && wy1 - wy0 >= H ? (unsigned)(wy1 - wy0 - H) : 0u;
+        wins[cy] = make_int4(wy0, (wy0 - a.ymin) % a.R, (int)wh_ok, (int)(((unsigned)(sh - H) & 0x7fffffffu) | (ok ? 0x80000000u : 0u)));
+        const int ya = cy > 0 ? win_y1(cy - 1) : win_y0(0);
+        bats[cy] = make_int4(ya, wy1 - ya, sh, ((ya - a.ymin) % a.R) * a.pitch);
       }
       __syncthreads();
       // ---- prologue of the strip: the whole first window in passes of what the staging registers hold, the first source
@@ -673,7 +686,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
       };
       auto commit = [&](const Batch &b, const Stage &st) {
         const unsigned rlim = (unsigned)((b.yb - b.ya) * gpitch), slim = (unsigned)(b.ns * sgpitch);
-        const unsigned first = (unsigned)(((b.ya - a.ymin) % a.R) * a.pitch);
+        const unsigned first = b.first;
   #pragma unroll
         for (int i = 0; i < kRingN; ++i)
           if (r_goff[i] < rlim) {
@@ -782,13 +795,14 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
           const int buf = cy & 1;
           SB_T(t1);
           const Seg cur = seg_of(cy);
+          const int4 wv = wins[cy];
           Win w;
-          w.wy0 = win_y0(cy);
-          w.s0 = (w.wy0 - a.ymin) % a.R;
-          w.wh_ok = strip_ok && win_y1(cy) - w.wy0 >= H ? (unsigned)(win_y1(cy) - w.wy0 - H) : 0u;
+          w.wy0 = uni(wv.x);
+          w.s0 = uni(wv.y);
+          w.wh_ok = (unsigned)uni(wv.z);
           w.sy0 = (unsigned)(cy * a.sb_h);
-          w.sh_ok = (unsigned)(min(cy * a.sb_h + a.sb_h, a.s_ymax) - cy * a.sb_h - H);
-          const bool step_ok = strip_ok && win_y1(cy) - w.wy0 >= H && min(cy * a.sb_h + a.sb_h, a.s_ymax) - cy * a.sb_h >= H;
+          w.sh_ok = (unsigned)uni(wv.w) & 0x7fffffffu;
+          const bool step_ok = (unsigned)uni(wv.w) >> 31;
           int g = cur.g0, c = cur.c0;
           bool first = true;
           SB_T(t1b);
@@ -990,7 +1004,7 @@ extern "C" int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
     return AOMHIP_ERR_INVALID;
   }
   const size_t ring_bytes = (size_t)(a.R + sb::mirror_rows(bh)) * a.pitch, cell_bytes = (size_t)sb_h * a.spitch;
-  const size_t kLds = 160 * 1024, misc_bytes = 72 * 4 + 256 + (size_t)cell_rows * 16 + 16;
+  const size_t kLds = 160 * 1024, misc_bytes = 72 * 4 + 256 + (size_t)cell_rows * 48 + 16;  // flags, active strips, 3 records per step
   if (ring_bytes + 2 * cell_bytes + misc_bytes + 4 * 256 > kLds) {
     set_error("LDS ring of %d rows x %d bytes + two %d x %d source cells (%zu bytes) exceed the 160 KB LDS of a CU: "
               "use a lower cell (sb_h) or a narrower one", a.R, a.pitch, sb_w, sb_h, ring_bytes + 2 * cell_bytes);
