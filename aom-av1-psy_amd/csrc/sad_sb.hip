@@ -443,40 +443,53 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
               base[4] = both ? cbase : (unsigned)a.ring_off;
               if (!both) soff = 0;
               uint32_t acc[5] = { 0, 0, 0, 0, 0 };
-              if constexpr (sizeof(T) == 1) {
-                // 8-bit planes: all LDS reads of a row unit's five references are issued before the first realignment (left to
-                // itself the compiler reads one reference, waits, computes, reads the next: ten LDS round trips in the one
-                // iteration a wavefront runs per step).  1080p -4.6 %, 4K -2 %; on 16-bit planes the same form was 5 % slower.
-                constexpr int kDw = G::kUnitBytes / 4;
-                // (row pitches and unit offsets are multiples of 16 bytes: a reference's dword base and byte shift are the same
-                // for all of its rows)
-                unsigned sh[5], bdw[5];
+              // The single candidate of a Mode-A style pair is the zero-MV one: 16-byte aligned in the ring whenever the cell grid is.  When
+              // that holds for the whole wavefront its rows are read like the source's, with one aligned 16-byte load and no
+              // realignment (and without the 4-way bank conflict of eight aligned rows x four aligned blocks read dword by dword).
+              const bool cand_aligned = __all((base[4] & 15u) == 0);
+              auto body = [&](auto al) {
+                constexpr bool kAl = decltype(al)::value && G::kUnitBytes == 16;
+                constexpr int kNr = kAl ? 4 : 5;  // references read through the realigning path
+                if constexpr (sizeof(T) == 1) {
+                  // 8-bit planes: all LDS reads of a row unit's references are issued before the first realignment (left to
+                  // itself the compiler reads one reference, waits, computes, reads the next: ten LDS round trips in the one
+                  // iteration a wavefront runs per step).  1080p -4.6 %, 4K -2 %; on 16-bit planes the same form was 5 % slower.
+                  constexpr int kDw = G::kUnitBytes / 4;
+                  // (row pitches and unit offsets are multiples of 16 bytes: a reference's dword base and byte shift are the same
+                  // for all of its rows)
+                  unsigned sh[5], bdw[5];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) { sh[j] = base[j] & 3u; bdw[j] = base[j] & ~3u; }
+                  for (int j = 0; j < 5; ++j) { sh[j] = base[j] & 3u; bdw[j] = base[j] & ~3u; }
 #pragma unroll
-                for (int k = 0; k < G::kUnitsPerLane; ++k) {
-                  const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
-                  uint32_t raw[5][kDw + 1];
+                  for (int k = 0; k < G::kUnitsPerLane; ++k) {
+                    const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
+                    uint32_t raw[5][kDw + 1];
+                    L c4 = sv;
 #pragma unroll
-                  for (int j = 0; j < 5; ++j) {
-                    const uint32_t *p = reinterpret_cast<const uint32_t *>(lds + (bdw[j] + unit_roff[k]));
+                    for (int j = 0; j < kNr; ++j) {
+                      const uint32_t *p = reinterpret_cast<const uint32_t *>(lds + (bdw[j] + unit_roff[k]));
 #pragma unroll
-                    for (int i = 0; i <= kDw; ++i) raw[j][i] = p[i];
+                      for (int i = 0; i <= kDw; ++i) raw[j][i] = p[i];
+                    }
+                    if constexpr (kAl) c4 = lds_unit_aligned<G::kUnitBytes>(lds, base[4] + unit_roff[k]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < kNr; ++j)
+#pragma unroll
+                      for (int i = 0; i < kDw; ++i) acc[j] = sad_dword<T>(sv.v[i], __builtin_amdgcn_alignbyte(raw[j][i + 1], raw[j][i], sh[j]), acc[j]);
+                    if constexpr (kAl) acc[4] = sad_unit(sv, c4, acc[4]);
                   }
-                  __builtin_amdgcn_sched_barrier(0);
+                } else {
 #pragma unroll
-                  for (int j = 0; j < 5; ++j)
+                  for (int k = 0; k < G::kUnitsPerLane; ++k) {
+                    const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
 #pragma unroll
-                    for (int i = 0; i < kDw; ++i) acc[j] = sad_dword<T>(sv.v[i], __builtin_amdgcn_alignbyte(raw[j][i + 1], raw[j][i], sh[j]), acc[j]);
+                    for (int j = 0; j < kNr; ++j) acc[j] = sad_unit(sv, lds_unit<G::kUnitBytes>(lds, base[j] + unit_roff[k]), acc[j]);
+                    if constexpr (kAl) acc[4] = sad_unit(sv, lds_unit_aligned<G::kUnitBytes>(lds, base[4] + unit_roff[k]), acc[4]);
+                  }
                 }
-              } else {
-#pragma unroll
-                for (int k = 0; k < G::kUnitsPerLane; ++k) {
-                  const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
-#pragma unroll
-                  for (int j = 0; j < 5; ++j) acc[j] = sad_unit(sv, lds_unit<G::kUnitBytes>(lds, base[j] + unit_roff[k]), acc[j]);
-                }
-              }
+              };
+              if (cand_aligned) body(std::true_type{}); else body(std::false_type{});
               if (a.dbg & 128) {  // (timing ablation: no reduction, no stores)
                 if ((acc[0] & acc[1] & acc[2] & acc[3] & acc[4]) == 0xFFFFFFFFu) out1[0] = 0;
                 continue;
@@ -687,15 +700,24 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
       auto commit = [&](const Batch &b, const Stage &st) {
         const unsigned rlim = (unsigned)((b.yb - b.ya) * gpitch), slim = (unsigned)(b.ns * sgpitch);
         const unsigned first = b.first;
+        // Only a batch that starts inside the mirrored slots or wraps around the end of the ring has rows to store twice (a uniform
+        // test per step; with R a multiple of the step height it is one step in R / sb_h): the others skip the per-chunk mirror test.
+        const bool mirrored = kMirror > 0 && (first < (unsigned)(kMirror * a.pitch) || first + (unsigned)(b.yb - b.ya) * (unsigned)a.pitch > ring_bytes);
+        if (mirrored) {
   #pragma unroll
-        for (int i = 0; i < kRingN; ++i)
-          if (r_goff[i] < rlim) {
-            unsigned t = first + r_loff[i];
-            t = min(t, t - ring_bytes);  // wrap: t - ring_bytes underflows to a huge value unless t >= ring_bytes
-            const V4 v = st.ring[i];
-            *reinterpret_cast<V4 *>(lds + a.ring_off + t) = v;
-            if (kMirror > 0 && t < (unsigned)(kMirror * a.pitch)) *reinterpret_cast<V4 *>(lds + a.ring_off + t + ring_bytes) = v;
-          }
+          for (int i = 0; i < kRingN; ++i)
+            if (r_goff[i] < rlim) {
+              unsigned t = first + r_loff[i];
+              t = min(t, t - ring_bytes);  // wrap: t - ring_bytes underflows to a huge value unless t >= ring_bytes
+              const V4 v = st.ring[i];
+              *reinterpret_cast<V4 *>(lds + a.ring_off + t) = v;
+              if (t < (unsigned)(kMirror * a.pitch)) *reinterpret_cast<V4 *>(lds + a.ring_off + t + ring_bytes) = v;
+            }
+        } else {
+  #pragma unroll
+          for (int i = 0; i < kRingN; ++i)
+            if (r_goff[i] < rlim) *reinterpret_cast<V4 *>(lds + a.ring_off + first + r_loff[i]) = st.ring[i];
+        }
   #pragma unroll
         for (int i = 0; i < kSrcN; ++i)
           if (s_goff[i] < slim)
