@@ -450,10 +450,10 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
               auto body = [&](auto al) {
                 constexpr bool kAl = decltype(al)::value && G::kUnitBytes == 16;
                 constexpr int kNr = kAl ? 4 : 5;  // references read through the realigning path
-                if constexpr (sizeof(T) == 1) {
-                  // 8-bit planes: all LDS reads of a row unit's references are issued before the first realignment (left to
-                  // itself the compiler reads one reference, waits, computes, reads the next: ten LDS round trips in the one
-                  // iteration a wavefront runs per step).  1080p -4.6 %, 4K -2 %; on 16-bit planes the same form was 5 % slower.
+                {
+                  // All LDS reads of a row unit's references are issued before the first realignment (left to itself the compiler
+                  // reads one reference, waits, computes, reads the next: ten LDS round trips in the one iteration a wavefront runs
+                  // per step).  8-bit: 1080p -4.6 %, 4K -2 %; 16-bit planes: -4 % (it was +5 % while the kernel sat at the 128-VGPR cap).
                   constexpr int kDw = G::kUnitBytes / 4;
                   // (row pitches and unit offsets are multiples of 16 bytes: a reference's dword base and byte shift are the same
                   // for all of its rows)
@@ -478,14 +478,6 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
 #pragma unroll
                       for (int i = 0; i < kDw; ++i) acc[j] = sad_dword<T>(sv.v[i], __builtin_amdgcn_alignbyte(raw[j][i + 1], raw[j][i], sh[j]), acc[j]);
                     if constexpr (kAl) acc[4] = sad_unit(sv, c4, acc[4]);
-                  }
-                } else {
-#pragma unroll
-                  for (int k = 0; k < G::kUnitsPerLane; ++k) {
-                    const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
-#pragma unroll
-                    for (int j = 0; j < kNr; ++j) acc[j] = sad_unit(sv, lds_unit<G::kUnitBytes>(lds, base[j] + unit_roff[k]), acc[j]);
-                    if constexpr (kAl) acc[4] = sad_unit(sv, lds_unit_aligned<G::kUnitBytes>(lds, base[4] + unit_roff[k]), acc[4]);
                   }
                 }
               };
