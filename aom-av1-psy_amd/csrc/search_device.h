@@ -76,6 +76,9 @@ template <typename T> __device__ __forceinline__ uint32_t sadw(uint32_t a, uint3
 }
 
 // Geometry of the 8-lanes-per-site SAD: row units of <= 16 bytes, lane l of a group owns units l, l + 8, ...
+#ifndef AOMHIP_G8_KEEP_MAX
+#define AOMHIP_G8_KEEP_MAX 4
+#endif
 template <typename T, int W, int H> struct G8 {
   static constexpr int RB = W * (int)sizeof(T);
   static constexpr int UB = RB < 16 ? RB : 16;
@@ -83,8 +86,10 @@ template <typename T, int W, int H> struct G8 {
   static constexpr int UPR = RB / UB;
   static constexpr int U = UPR * H;
   static constexpr int PER_LANE = (U + 7) / 8;
-  // the lane's source units stay in registers across all the sites of a search when they fit (<= 32 VGPRs)
-  static constexpr bool KEEP = PER_LANE <= 8;
+  // The lane's source units stay in registers across all the sites of a search when they are few: up to 4 (16 VGPRs).  With up to 8
+  // (32 VGPRs: 32x32 / 64x16 / 16x64 on 8-bit planes, 32x16 / 16x32 on 16-bit ones) full_pixel_search_kernel went to 157 VGPRs + 560
+  // bytes of scratch and the temporal filter's 8-bit search ran 11.1 instead of 8.4 ms per 4K frame.
+  static constexpr bool KEEP = PER_LANE <= AOMHIP_G8_KEEP_MAX;
   using L = typename MLoad<UB>::type;
 };
 

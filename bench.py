@@ -1080,6 +1080,8 @@ def main():
         return
     if args.workload == "tf_motion_search_4k_10bit":  # SURVEY 8(f) row 1 (single GPU)
         r = run_tf(pkg, ctx, orc, args.steps, args.warmup)
+        r8 = run_tf(pkg, ctx, None, args.steps, args.warmup, bd=8)   # the same pass on an 8-bit window (timing only)
+        r["same_pass_8bit"] = {k: r8[k] for k in ("q30_mesh_pruned_when_close", "q12_mesh_always", "value")}
         ctx.close()
         print(json.dumps(dict(r, metric="tf block searches/s", n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
                               vs_baseline=None, dtype="u16", data="synthetic", ms_per_step=r["q30_mesh_pruned_when_close"]["ms_per_filtered_frame"])))
