@@ -226,16 +226,35 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
     constexpr bool kLoader = decltype(role)::value;
     // per-lane constants of the block-unit mapping: row of the lane's k-th unit, its byte offset in a ring row walk and
     // in a source-cell walk
-    int unit_row[G::kUnitsPerLane], unit_colb[G::kUnitsPerLane];
-    unsigned unit_roff[G::kUnitsPerLane], unit_soff[G::kUnitsPerLane];
+    // Tables (registers) while a lane owns few units; a lane with many units walks them in partly unrolled loops, where a table would
+    // be indexed dynamically and therefore live in scratch (272-720 bytes per lane for the 64x128 ... 128x128 instantiations): those
+    // work the unit's row / column out of its index instead (the units-per-row count is a power of two).
+    constexpr bool kTab = G::kUnitsPerLane <= 4;
+    constexpr int kTabN = kTab ? G::kUnitsPerLane : 1;
+    int unit_row_t[kTabN], unit_colb_t[kTabN];
+    unsigned unit_roff_t[kTabN], unit_soff_t[kTabN];
+    if constexpr (kTab) {
   #pragma unroll
-    for (int k = 0; k < G::kUnitsPerLane; ++k) {
-      const int u = lane_in_cand + k * G::kTpc;
-      unit_row[k] = (u / G::kUnitsPerRow) * G::kRowStep;
-      unit_colb[k] = (u % G::kUnitsPerRow) * G::kUnitBytes;
-      unit_roff[k] = (unsigned)(unit_row[k] * a.pitch + unit_colb[k]);
-      unit_soff[k] = (unsigned)(unit_row[k] * a.spitch + unit_colb[k]);
+      for (int k = 0; k < G::kUnitsPerLane; ++k) {
+        const int u = lane_in_cand + k * G::kTpc;
+        unit_row_t[k] = (u / G::kUnitsPerRow) * G::kRowStep;
+        unit_colb_t[k] = (u % G::kUnitsPerRow) * G::kUnitBytes;
+        unit_roff_t[k] = (unsigned)(unit_row_t[k] * a.pitch + unit_colb_t[k]);
+        unit_soff_t[k] = (unsigned)(unit_row_t[k] * a.spitch + unit_colb_t[k]);
+      }
     }
+    auto unit_row = [&](int k) -> int {
+      if constexpr (kTab) return unit_row_t[k]; else return ((lane_in_cand + k * G::kTpc) / G::kUnitsPerRow) * G::kRowStep;
+    };
+    auto unit_colb = [&](int k) -> int {
+      if constexpr (kTab) return unit_colb_t[k]; else return ((lane_in_cand + k * G::kTpc) % G::kUnitsPerRow) * G::kUnitBytes;
+    };
+    auto unit_roff = [&](int k) -> unsigned {
+      if constexpr (kTab) return unit_roff_t[k]; else return (unsigned)(unit_row(k) * a.pitch + unit_colb(k));
+    };
+    auto unit_soff = [&](int k) -> unsigned {
+      if constexpr (kTab) return unit_soff_t[k]; else return (unsigned)(unit_row(k) * a.spitch + unit_colb(k));
+    };
 
     // ---- the walk over (frame, strip) items
     const bool affine = a.n_frames >= 8;  // strips of one frame side by side on one XCD
@@ -349,7 +368,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
       const unsigned ww_ok = (unsigned)(wx1 - wx0 - W), sw_ok = (unsigned)(sx1 - sx0 - W);
       const bool strip_ok = wx1 - wx0 >= W && sx1 - sx0 >= W;
       auto global_unit = [&](const char *frame, int pitch_b, int x, int y, int k) {
-        return *reinterpret_cast<const L *>(frame + (int64_t)(y + unit_row[k]) * pitch_b + (int64_t)x * kES + unit_colb[k]);
+        return *reinterpret_cast<const L *>(frame + (int64_t)(y + unit_row(k)) * pitch_b + (int64_t)x * kES + unit_colb(k));
       };
       auto sad_unit = [&](const L &s, const L &r, uint32_t acc) {
   #pragma unroll
@@ -375,11 +394,11 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
       };
       auto ring_unit = [&](unsigned base, int slot0, int k) {
         if constexpr (kMirror > 0) {
-          return lds_unit<G::kUnitBytes>(lds, base + unit_roff[k]);
+          return lds_unit<G::kUnitBytes>(lds, base + unit_roff(k));
         } else {
-          unsigned s = (unsigned)(slot0 + unit_row[k]);
+          unsigned s = (unsigned)(slot0 + unit_row(k));
           const unsigned wrap = s >= (unsigned)a.R ? (unsigned)(a.R * a.pitch) : 0u;
-          return lds_unit<G::kUnitBytes>(lds, base + unit_roff[k] - wrap);
+          return lds_unit<G::kUnitBytes>(lds, base + unit_roff(k) - wrap);
         }
       };
       auto src_pos = [&](const Win &w, int sx, int sy, unsigned &soff) {
@@ -462,16 +481,16 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
                   for (int j = 0; j < 5; ++j) { sh[j] = base[j] & 3u; bdw[j] = base[j] & ~3u; }
 #pragma unroll
                   for (int k = 0; k < G::kUnitsPerLane; ++k) {
-                    const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
+                    const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff(k));
                     uint32_t raw[5][kDw + 1];
                     L c4 = sv;
 #pragma unroll
                     for (int j = 0; j < kNr; ++j) {
-                      const uint32_t *p = reinterpret_cast<const uint32_t *>(lds + (bdw[j] + unit_roff[k]));
+                      const uint32_t *p = reinterpret_cast<const uint32_t *>(lds + (bdw[j] + unit_roff(k)));
 #pragma unroll
                       for (int i = 0; i <= kDw; ++i) raw[j][i] = p[i];
                     }
-                    if constexpr (kAl) c4 = lds_unit_aligned<G::kUnitBytes>(lds, base[4] + unit_roff[k]);
+                    if constexpr (kAl) c4 = lds_unit_aligned<G::kUnitBytes>(lds, base[4] + unit_roff(k));
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < kNr; ++j)
@@ -540,7 +559,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
               if (__all(s_al)) {
   #pragma unroll
                 for (int k = 0; k < G::kUnitsPerLane; ++k) {
-                  const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
+                  const L sv = lds_unit_aligned<G::kUnitBytes>(sbuf, soff + unit_soff(k));
                   if constexpr (kKeepSrc) gsrc[k] = sv;
   #pragma unroll
                   for (int j = 0; j < 4; ++j) acc[j] = sad_unit(sv, ring_unit(base[j], slot0[j], k), acc[j]);
@@ -548,7 +567,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
               } else {
   #pragma unroll kGenUnroll
                 for (int k = 0; k < G::kUnitsPerLane; ++k) {
-                  const L sv = lds_unit<G::kUnitBytes>(sbuf, soff + unit_soff[k]);
+                  const L sv = lds_unit<G::kUnitBytes>(sbuf, soff + unit_soff(k));
                   if constexpr (kKeepSrc) gsrc[k] = sv;
   #pragma unroll
                   for (int j = 0; j < 4; ++j) acc[j] = sad_unit(sv, ring_unit(base[j], slot0[j], k), acc[j]);
@@ -592,7 +611,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
               } else {
   #pragma unroll kGenUnroll
                 for (int k = 0; k < G::kUnitsPerLane; ++k)
-                  acc = sad_unit(lds_unit<G::kUnitBytes>(sbuf, soff + unit_soff[k]), ring_unit(base, slot0, k), acc);
+                  acc = sad_unit(lds_unit<G::kUnitBytes>(sbuf, soff + unit_soff(k)), ring_unit(base, slot0, k), acc);
               }
             } else {
               acc = generic_ref(sx, sy, rx, ry);
