@@ -54,7 +54,7 @@ build/c_host_demo: examples/c_host_demo.c include/aomhip.h $(LIBDIR)/libaomhip.s
 prof: build/prof/libaomhip_prof.so
 build/prof/libaomhip_prof.so: $(OBJS) $(CSRC)/sad_sb.hip
 	@mkdir -p build/prof
-	$(HIPCC) $(HIPFLAGS) -DAOMHIP_SB_PROF -c $(CSRC)/sad_sb.hip -o build/prof/sad_sb.o
+	$(HIPCC) $(HIPFLAGS) -DAOMHIP_SB_PROF -DAOMHIP_SB_DBG_KNOBS=1 -c $(CSRC)/sad_sb.hip -o build/prof/sad_sb.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out build/sad_sb.o,$(OBJS)) build/prof/sad_sb.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 
 # kernel experiments on sad_sb.hip without the 3-minute rebuild: only the 16x16 instantiations (AOMHIP_LIB=build/exp/libaomhip_exp.so
@@ -62,9 +62,9 @@ build/prof/libaomhip_prof.so: $(OBJS) $(CSRC)/sad_sb.hip
 exp: build/exp/libaomhip_exp.so build/exp/libaomhip_exp_prof.so
 build/exp/libaomhip_exp.so: $(CSRC)/sad_sb.hip $(filter-out build/sad_sb.o,$(OBJS))
 	@mkdir -p build/exp
-	$(HIPCC) $(HIPFLAGS) -DAOMHIP_SB_ONLY_16 $(EXPFLAGS) -c $(CSRC)/sad_sb.hip -o build/exp/sad_sb.o
+	$(HIPCC) $(HIPFLAGS) -DAOMHIP_SB_ONLY_16 -DAOMHIP_SB_DBG_KNOBS=1 $(EXPFLAGS) -c $(CSRC)/sad_sb.hip -o build/exp/sad_sb.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out build/sad_sb.o,$(OBJS)) build/exp/sad_sb.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 build/exp/libaomhip_exp_prof.so: $(CSRC)/sad_sb.hip $(filter-out build/sad_sb.o,$(OBJS))
 	@mkdir -p build/exp
-	$(HIPCC) $(HIPFLAGS) -DAOMHIP_SB_ONLY_16 $(EXPFLAGS) -DAOMHIP_SB_PROF -c $(CSRC)/sad_sb.hip -o build/exp/sad_sb_prof.o
+	$(HIPCC) $(HIPFLAGS) -DAOMHIP_SB_ONLY_16 -DAOMHIP_SB_DBG_KNOBS=1 $(EXPFLAGS) -DAOMHIP_SB_PROF -c $(CSRC)/sad_sb.hip -o build/exp/sad_sb_prof.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(filter-out build/sad_sb.o,$(OBJS)) build/exp/sad_sb_prof.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib

@@ -113,6 +113,9 @@ struct StripArgs {
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+#ifndef AOMHIP_SB_DBG_KNOBS
+#define AOMHIP_SB_DBG_KNOBS 0
+#endif
 #ifdef AOMHIP_SB_PROF  // phase timing of wave 0 of every workgroup (tools/gpu_sb_prof.sh builds a library with it)
 __device__ unsigned long long g_sb_prof[32];  // [0..7] first evaluating wavefront, [8..15] first loader wavefront, [16..31] barrier wait of wavefront w
 #define SB_T(v) const long long v = (long long)__builtin_readcyclecounter()
@@ -168,6 +171,13 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
   constexpr int kGenUnroll = G::kUnitsPerLane <= 4 ? G::kUnitsPerLane : 4;
   constexpr int kMirror = mirror_rows(H);
   const int tid = (int)threadIdx.x;
+  // AOMHIP_SB_DBG (timing ablations, results invalid) is honoured only by the experiment / profiling builds (make exp, make prof): the
+  // product kernel carries none of those tests in its loops.
+#if AOMHIP_SB_DBG_KNOBS
+  const int dbg = a.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
   const int lane = tid & 63;
   const int wave = uni(tid >> 6);
   const bool is_loader = wave >= kWaves;
@@ -430,7 +440,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
         const char *sbuf = lds + src_off_of(buf);
         const int n_it = max(ng, nc);
         for (int i = slot; i < n_it; i += kPerWg) {
-          const bool has_g = i < ng && !(a.dbg & 8), has_c = i < nc && !(a.dbg & 4);
+          const bool has_g = i < ng && !(dbg & 8), has_c = i < nc && !(dbg & 4);
           if constexpr (kCoop && G::kUnitsPerLane <= 4 && kMirror > 0) {
             // The common case as ONE basic block: a group and a single candidate of the same source block, everything
             // inside the staged cell / window, source rows unit aligned (a Mode-A style list, a diamond step ...).
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
             okv &= (unsigned)__builtin_amdgcn_update_dpp(0u, okv, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
             okv &= (unsigned)__builtin_amdgcn_update_dpp(0u, okv, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
             if (__all((both && okv != 0) || (!has_g && !has_c))) {
-              if (a.dbg & 32) continue;  // (timing ablation: decode and tests only)
+              if (dbg & 32) continue;  // (timing ablation: decode and tests only)
               // (`both` is uniform over a block's lanes: the select goes BEFORE the quad broadcasts, which then run unconditionally --
               // selecting after them compiled to four exec-masked DPP moves, each inside its own branch)
               mbase = both ? mbase : (unsigned)a.ring_off;
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
                 }
               };
               if (cand_aligned) body(std::true_type{}); else body(std::false_type{});
-              if (a.dbg & 128) {  // (timing ablation: no reduction, no stores)
+              if (dbg & 128) {  // (timing ablation: no reduction, no stores)
                 if ((acc[0] & acc[1] & acc[2] & acc[3] & acc[4]) == 0xFFFFFFFFu) out1[0] = 0;
                 continue;
               }
@@ -554,7 +564,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
               }
             }
             uint32_t acc[4] = { 0, 0, 0, 0 };
-            if (in && !(a.dbg & 16)) {
+            if (in && !(dbg & 16)) {
               const bool s_al = (soff & (G::kUnitBytes - 1)) == 0;
               if (__all(s_al)) {
   #pragma unroll
@@ -635,7 +645,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
         b.g0 = sg.g0; b.ng = real ? min(sg.g1 - sg.g0, a.gcap) : 0;
         b.c0 = sg.c0; b.nc = real ? min(sg.c1 - sg.c0, a.ccap) : 0;
         b.buf = cy & 1;
-        if ((a.dbg & 2) && cy > 0) { b.yb = b.ya; b.ns = 0; }  // (timing ablation: list slices only)
+        if ((dbg & 2) && cy > 0) { b.yb = b.ya; b.ns = 0; }  // (timing ablation: list slices only)
         return b;
       };
       // Per-step records, worked out once per strip (one lane per step) instead of by every wavefront in every step: the scalar
@@ -740,7 +750,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
         for (int i = 0; i < kCN; ++i)
           if (lt + i * kLT < b.nc * 2) *reinterpret_cast<uint32_t *>(lds + cdesc_off_of(b.buf) + (lt + i * kLT) * 4) = st.c[i];
       };
-      const int steps = (a.dbg & 256) ? 0 : (a.cell_rows + 1) & ~1;  // both roles run an even number of steps (the odd one out only meets the barriers); (dbg 256: timing ablation, prologue only)
+      const int steps = (dbg & 256) ? 0 : (a.cell_rows + 1) & ~1;  // both roles run an even number of steps (the odd one out only meets the barriers); (dbg 256: timing ablation, prologue only)
       if constexpr (kLoader) {
         // Two loader groups take alternate steps: during step cy the group of that parity writes batch cy + 1 (which it requested
         // during step cy - 1) to LDS while the other group requests batch cy + 2, so a batch -- ~30 KB per CU -- has a whole step to
@@ -774,7 +784,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
         // active step (the first form) made one wavefront's commit -> bookkeeping -> request sequence, ~4400 clock ticks, the longest
         // thing in a step, with the other group idle and the evaluating wavefronts (~3700) waiting at the barrier for it.
         auto active = [&](int cy) {
-          if (a.dbg & 64) { __syncthreads(); return; }  // (timing ablation: barriers only)
+          if (dbg & 64) { __syncthreads(); return; }  // (timing ablation: barriers only)
           SB_T(l0);
           const Batch bc = batch_of(cy + 1);
           SB_T(l1);
@@ -792,7 +802,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
           SB_ACC(0, l1, l0); SB_ACC(1, l2, l1); SB_ACC(2, l3, l2); SB_ACC(4, l5, l3); SB_ACC(5, 1, 0); SB_WAIT(l5, l3);
         };
         auto passive = [&](int cy) {
-          if (a.dbg & 64) { __syncthreads(); return; }
+          if (dbg & 64) { __syncthreads(); return; }
           SB_T(q0);
           request(batch_of(cy + 2), st);  // in flight across this step's barrier
           SB_T(q1);
@@ -824,7 +834,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
             __syncthreads();
             break;
           }
-          if (a.dbg & (64 | 2048)) { __syncthreads(); continue; }  // (2048: timing ablation, the evaluators skip their bookkeeping too)
+          if (dbg & (64 | 2048)) { __syncthreads(); continue; }  // (2048: timing ablation, the evaluators skip their bookkeeping too)
           const int buf = cy & 1;
           SB_T(t1);
           const Seg cur = seg_of(cy);
@@ -846,7 +856,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
               __syncthreads();
               __syncthreads();  // the loaders have put the next slices in place
             }
-            if (!(a.dbg & 1)) {
+            if (!(dbg & 1)) {
               if (step_ok) {
                 eval(w, buf, g, ng, c, nc);
               } else {  // a window / cell lower or narrower than the block: nothing can be served from LDS
