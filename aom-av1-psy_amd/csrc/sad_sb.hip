@@ -651,10 +651,12 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
       // Per-step records, worked out once per strip (one lane per step) instead of by every wavefront in every step: the scalar
       // arithmetic of a step -- window rows, ring slot (a modulo), bucket bounds -- was ~330 clock ticks on every evaluating wavefront's
       // chain and more on the loaders', much of it reloads of spilled scalars.
+      int crowded = 0;  // does any cell of this strip hold more entries than a slice buffer (the loaders' overflow() path)?
       for (int cy = tid; cy < a.cell_rows; cy += kAll) {
         const int b = cy * a.cells_per_row + cx;
-        reinterpret_cast<int4 *>(lds + a.seg_off)[cy] = make_int4(groups ? group_off[b] : 0, groups ? group_off[b + 1] : 0,
-                                                                    cands ? cand_off[b] : 0, cands ? cand_off[b + 1] : 0);
+        const int4 sg = make_int4(groups ? group_off[b] : 0, groups ? group_off[b + 1] : 0, cands ? cand_off[b] : 0, cands ? cand_off[b + 1] : 0);
+        reinterpret_cast<int4 *>(lds + a.seg_off)[cy] = sg;
+        crowded |= (sg.y - sg.x > a.gcap) | (sg.w - sg.z > a.ccap);
         const int wy0 = win_y0(cy), wy1 = win_y1(cy);
         const int sh = min(cy * a.sb_h + a.sb_h, a.s_ymax) - cy * a.sb_h;
         const bool ok = strip_ok && wy1 - wy0 >= H && sh >= H;
@@ -663,7 +665,16 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
         const int ya = cy > 0 ? win_y1(cy - 1) : win_y0(0);
         bats[cy] = make_int4(ya, wy1 - ya, sh, ((ya - a.ymin) % a.R) * a.pitch);
       }
+      // (an OR over the workgroup through 16 words of the flag area: __syncthreads_or() brings its own static LDS, and the widest cells
+      // leave none)
+      if (lane == 0) misc[16 + wave] = __ballot(crowded != 0) != 0 ? 1 : 0;
       __syncthreads();
+      bool any_crowded;  // (uniform: the loaders skip overflow()'s per-step look-up otherwise)
+      {
+        const int4 *f = reinterpret_cast<const int4 *>(misc + 16);
+        const int4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
+        any_crowded = uni((f0.x | f0.y | f0.z | f0.w | f1.x | f1.y | f1.z | f1.w | f2.x | f2.y | f2.z | f2.w | f3.x | f3.y | f3.z | f3.w)) != 0;
+      }
       // ---- prologue of the strip: the whole first window in passes of what the staging registers hold, the first source
       // cell and list slices (every wavefront of the workgroup takes part: nothing to evaluate yet)
       SB_T(p0);
@@ -783,10 +794,11 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
         // group writes -- it works out and requests the batch it will write next (cy + 2 seen from the passive step).  Doing both in the
         // active step (the first form) made one wavefront's commit -> bookkeeping -> request sequence, ~4400 clock ticks, the longest
         // thing in a step, with the other group idle and the evaluating wavefronts (~3700) waiting at the barrier for it.
+        Batch held = batch_of(0);
         auto active = [&](int cy) {
           if (dbg & 64) { __syncthreads(); return; }  // (timing ablation: barriers only)
           SB_T(l0);
-          const Batch bc = batch_of(cy + 1);
+          const Batch bc = held;  // the batch this group requested in its passive step (its description rides along in scalars)
           SB_T(l1);
 #ifdef AOMHIP_SB_PROF
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -795,7 +807,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
 #endif
           commit(bc, st);  // requested in the previous step
           SB_T(l2);
-          overflow(cy, true);
+          if (any_crowded) overflow(cy, true);
           SB_T(l3);
           __syncthreads();  // step cy + 1 is in LDS; nobody reads step cy's rows / cell / slices any more
           SB_T(l5);
@@ -804,15 +816,17 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
         auto passive = [&](int cy) {
           if (dbg & 64) { __syncthreads(); return; }
           SB_T(q0);
-          request(batch_of(cy + 2), st);  // in flight across this step's barrier
+          held = batch_of(cy + 2);
+          request(held, st);  // in flight across this step's barrier
           SB_T(q1);
-          overflow(cy, false);
+          if (any_crowded) overflow(cy, false);
           __syncthreads();
           SB_T(q2);
           SB_ACC(3, q1, q0); SB_ACC(6, q2, q1); SB_WAIT(q2, q1);
         };
         if (grp == 0) {
-          request(batch_of(1), st);
+          held = batch_of(1);
+          request(held, st);
           __syncthreads();
           for (int cy = 0; cy < steps; cy += 2) {
             active(cy);
