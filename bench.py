@@ -131,9 +131,10 @@ class SadModeA:
         # Cells are anchored at x = 0, tile columns start at multiples of their width: a cell width that divides the
         # column width keeps every strip inside one rank's column.  Tuned width when it divides, else the largest
         # divisor below it.
-        # r02 sweeps (profiles/r02_sad_strip.md): 8-bit 240 x 64 (16 / 8 strips per 4K / 1080p frame = a whole number of items per CU
-        # with 64 frames; 60 blocks per step keep all eight evaluating wavefronts busy, two per SIMD), 16-bit 160 x 32
-        tuned, cell_h = (240, 64) if bd == 8 else (160, 32)
+        # r02 sweeps (profiles/r02_sad_strip.md): 60 blocks per step keep all eight evaluating wavefronts busy, two per SIMD, and the strips
+        # per frame x 64 frames must be a whole number of items per CU: 8-bit 240 x 64 at 1080p (8 strips), 320 x 48 at 4K (12 strips, ~2 %
+        # ahead of 240 x 64 there); 16-bit 160 x 32 (LDS)
+        tuned, cell_h = ((320, 48) if W >= 3840 else (240, 64)) if bd == 8 else (160, 32)
         col_w = pkg.partition.column_of_rank(W, world, 0)[1] - pkg.partition.column_of_rank(W, world, 0)[0]
         cw = tuned if col_w % tuned == 0 else max([d for d in range(16, tuned + 1, 16) if col_w % d == 0] or [tuned])
         self.cell = (cw, cell_h)

@@ -129,7 +129,7 @@ def test_full_size_4k_mode_a(hip, oracle, ctx, bd):
     ps, pr = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
     ctx.planes_upload(ps, 0, src); ctx.planes_upload(pr, 0, ref)
     cands, groups = hip.synth.mode_a_worklist(W, H, 16, seed=5, search=64)
-    sbw, sbh = (240, 64) if bd == 8 else (160, 32)  # the bench's cells
+    sbw, sbh = (320, 48) if bd == 8 else (160, 32)  # the bench's cells at 4K
     gs, cs, out4, out1 = _run(hip, ctx, ps, pr, 0, 1, 16, 16, 0, sbw, sbh, 64, cands, groups, W, H)
     n = len(gs)
     d_g, d_c, d_o4, d_o1 = ctx.to_device(gs), ctx.to_device(cs), ctx.malloc(n * 16), ctx.malloc(n * 4)
