@@ -134,8 +134,13 @@ class SadModeA:
         # r02 sweeps (profiles/r02_sad_strip.md): 60 blocks per step keep all eight evaluating wavefronts busy, two per SIMD, and the strips
         # per frame x 64 frames must be a whole number of items per CU: 8-bit 240 x 64 at 1080p (8 strips), 320 x 48 at 4K (12 strips, ~2 %
         # ahead of 240 x 64 there); 16-bit 160 x 32 (LDS)
-        tuned, cell_h = ((320, 48) if W >= 3840 else (240, 64)) if bd == 8 else (160, 32)
         col_w = pkg.partition.column_of_rank(W, world, 0)[1] - pkg.partition.column_of_rank(W, world, 0)[0]
+        # (a rank's items = strips of its column x ring frames; the kernel's persistent grid is 256 workgroups: prefer the cell whose
+        # item count is a multiple of that -- 320 x 48 on a whole 4K frame, 240 x 64 on a 1080p frame or a 1920 / 960-wide tile column)
+        options = [(320, 48), (240, 64)] if bd == 8 else [(160, 32)]
+        fits = [c for c in options if col_w % c[0] == 0]
+        whole = [c for c in fits if ((col_w // c[0]) * self.ring) % 256 == 0]
+        tuned, cell_h = (whole or fits or options[-1:])[0]
         cw = tuned if col_w % tuned == 0 else max([d for d in range(16, tuned + 1, 16) if col_w % d == 0] or [tuned])
         self.cell = (cw, cell_h)
         self.d_sb = None
