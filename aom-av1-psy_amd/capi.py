@@ -214,6 +214,7 @@ _protos = {
     "aomhip_comm_unique_id": (C.c_int, [_vp]),
     "aomhip_comm_init": (C.c_int, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "aomhip_comm_destroy": (None, [_vp]),
+    "aomhip_comm_info": (C.c_int, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "aomhip_allgather_recon": (C.c_int, [_vp, _vp, _PP, _i, _vp, _i]),
     "aomhip_exchange_loopback": (C.c_int, [_vp, _vp, _PP, _i, _i, _i, _i]),
 }
@@ -348,6 +349,12 @@ class Context:
 
     def comm_destroy(self, comm):
         lib.aomhip_comm_destroy(comm)
+
+    def comm_info(self, comm):
+        """(rank, n_ranks) as RCCL reports them for this communicator."""
+        r, n = _i(), _i()
+        check(lib.aomhip_comm_info(comm, C.byref(r), C.byref(n)), "aomhip_comm_info")
+        return r.value, n.value
 
     def allgather_recon(self, comm, p, frame, col_bounds, halo=-1):
         b = np.ascontiguousarray(col_bounds, np.int32).reshape(-1, 2)

@@ -14,6 +14,8 @@
 
 #include "common.h"
 
+constexpr int kMaxRanks = 64;
+
 struct aomhip_comm {
   ncclComm_t comm;
   int rank, n_ranks;
@@ -99,6 +101,10 @@ int aomhip_comm_unique_id(uint8_t id[128]) {
 int aomhip_comm_init(aomhip_ctx *ctx, const uint8_t id[128], int rank, int n_ranks, aomhip_comm **out) {
   if (!ctx || !id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return AOMHIP_ERR_INVALID;
   *out = nullptr;
+  if (n_ranks > kMaxRanks) {  // (the exchange plans live in fixed arrays; one node has 8 GPUs)
+    set_error("aomhip_comm_init: at most %d ranks (%d asked for)", kMaxRanks, n_ranks);
+    return AOMHIP_ERR_INVALID;
+  }
   AOMHIP_TRY(hipSetDevice(ctx->device));
   aomhip_comm *c = static_cast<aomhip_comm *>(calloc(1, sizeof(aomhip_comm)));
   if (!c) return AOMHIP_ERR_NOMEM;
@@ -116,6 +122,15 @@ int aomhip_comm_init(aomhip_ctx *ctx, const uint8_t id[128], int rank, int n_ran
   return AOMHIP_OK;
 }
 
+int aomhip_comm_info(aomhip_comm *c, int *rank, int *n_ranks) {
+  if (!c || !rank || !n_ranks) return AOMHIP_ERR_INVALID;
+  if (ncclCommUserRank(c->comm, rank) != ncclSuccess || ncclCommCount(c->comm, n_ranks) != ncclSuccess) {
+    set_error("aomhip_comm_info: RCCL query failed");
+    return AOMHIP_ERR_HIP;
+  }
+  return AOMHIP_OK;
+}
+
 void aomhip_comm_destroy(aomhip_comm *c) {
   if (!c) return;
   if (c->d_stage) (void)hipFree(c->d_stage);
@@ -128,7 +143,11 @@ static int exchange(aomhip_ctx *ctx, aomhip_comm *c, const aomhip_planes *p, int
                     const aomhip_exchange_item *recv) {
   const size_t esz = p->bit_depth == 8 ? 1 : 2;
   const int rows = p->height;
-  size_t off[2][64], total = 0;
+  if (n > kMaxRanks) {
+    set_error("exchange: at most %d ranks", kMaxRanks);
+    return AOMHIP_ERR_INVALID;
+  }
+  size_t off[2][kMaxRanks], total = 0;
   for (int dir = 0; dir < 2; ++dir)
     for (int r = 0; r < n; ++r) {
       const aomhip_exchange_item &it = dir == 0 ? send[r] : recv[r];
@@ -170,6 +189,9 @@ static int exchange(aomhip_ctx *ctx, aomhip_comm *c, const aomhip_planes *p, int
   }
   const ncclResult_t ne = ncclGroupEnd();
   if (nr != ncclSuccess || ne != ncclSuccess) {
+    // (the pack kernels are already queued and the staging buffer's receive half is undefined: drain the stream so that nothing of this
+    // exchange is still running when the caller sees the error; the plane itself has not been written)
+    (void)hipStreamSynchronize(ctx->stream);
     set_error("aomhip_allgather_recon: RCCL send / recv failed: %s", ncclGetErrorString(nr != ncclSuccess ? nr : ne));
     return AOMHIP_ERR_HIP;
   }

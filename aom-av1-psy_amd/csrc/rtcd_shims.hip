@@ -98,12 +98,15 @@ void aomhip_inv_txfm2d_add(const int32_t *input, uint16_t *output, int stride, i
 
 static void subtract_any(int rows, int cols, int16_t *diff, ptrdiff_t diff_stride, const void *src, ptrdiff_t src_stride, const void *pred,
                          ptrdiff_t pred_stride, int is_hbd) {
-  aomhip_ctx *ctx = default_ctx();
-  if (!ctx) return;
+  // (one failure convention for the shims, common.h: costs UINT32_MAX, coefficient-like outputs -- this residual -- zeroed, pixels untouched;
+  // the size is checked before anything is written through it)
   if (rows < 1 || cols < 1 || rows > 128 || cols > 128) {
     set_error("aomhip_subtract_block: %dx%d unsupported", cols, rows);
     return note_failure("aomhip_subtract_block", AOMHIP_ERR_INVALID);
   }
+  for (int r = 0; r < rows; ++r) memset(diff + r * diff_stride, 0, (size_t)cols * 2);
+  aomhip_ctx *ctx = default_ctx();
+  if (!ctx) return;
   const size_t esz = is_hbd ? 2 : 1, n = (size_t)rows * cols, pb = (n * esz + 15) & ~(size_t)15, total = 2 * pb + n * 2;
   char *hb = static_cast<char *>(pinned(ctx, total)), *d = static_cast<char *>(scratch(ctx, total));
   if (!hb || !d) return note_failure("aomhip_subtract_block scratch", AOMHIP_ERR_NOMEM);
@@ -201,6 +204,9 @@ int aomhip_rtcd(aomhip_rtcd_table *t) {
     return AOMHIP_ERR_NO_DEVICE;  // the caller keeps its C / SIMD pointers, exactly like a missing ISA in setup_rtcd_internal
   }
   t->sad16x16 = aomhip_sad16x16; t->sad16x16x4d = aomhip_sad16x16x4d; t->variance16x16 = aomhip_variance16x16;
+  // all 22 block sizes x {8-bit, highbd 10, highbd 12}: the same fixed-size functions the vtable binder installs
+  for (int d = 0; d < 3; ++d)
+    if (aomhip_bind_variance_vtable(t->block_fns[d], 8 + 2 * d) != AOMHIP_OK) return AOMHIP_ERR_INVALID;
   t->subtract_block = aomhip_subtract_block; t->highbd_subtract_block = aomhip_highbd_subtract_block;
   t->quantize_b = aomhip_quantize_b; t->quantize_b_32x32 = aomhip_quantize_b_32x32; t->quantize_b_64x64 = aomhip_quantize_b_64x64;
   t->highbd_quantize_b = aomhip_highbd_quantize_b; t->highbd_quantize_b_32x32 = aomhip_highbd_quantize_b_32x32;

@@ -31,13 +31,15 @@ void note_failure(const char *what, int status) {
 }
 
 static thread_local aomhip_ctx *g_default_ctx = nullptr;
+static thread_local bool g_default_ctx_failed = false;  // a failed creation is remembered: not retried (and re-reported) by every later call
 
 aomhip_ctx *default_ctx() {
-  if (!g_default_ctx) {
+  if (!g_default_ctx && !g_default_ctx_failed) {
     const char *dev = getenv("AOMHIP_DEVICE");
     if (aomhip_ctx_create(dev ? atoi(dev) : 0, nullptr, &g_default_ctx) != AOMHIP_OK) {
       note_failure("default context", AOMHIP_ERR_NO_DEVICE);
       g_default_ctx = nullptr;
+      g_default_ctx_failed = true;
     }
   }
   return g_default_ctx;
@@ -127,6 +129,7 @@ long aomhip_failure_count(void) { return g_failures.load(); }
 void aomhip_status_clear(void) {
   g_sticky.store(AOMHIP_OK);
   g_failures.store(0);
+  g_default_ctx_failed = false;  // (the calling thread may try to create its default context again)
 }
 
 const char *aomhip_last_error(void) { return g_err; }
@@ -165,16 +168,26 @@ int aomhip_ctx_create(int device, void *stream, aomhip_ctx **out) {
     }
     c->own_stream = true;
   }
+  // (every resource taken so far is released on a failed creation: the stream it owns, the events, the status words)
+  auto fail = [&](int rc) {
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    free(c);
+    return rc;
+  };
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     set_error("hipEventCreate failed");
-    free(c);
-    return AOMHIP_ERR_HIP;
+    return fail(AOMHIP_ERR_HIP);
   }
-  if (hipMalloc(reinterpret_cast<void **>(&c->d_status), sizeof(int)) != hipSuccess || hipMemset(c->d_status, 0, sizeof(int)) != hipSuccess) {
-    set_error("hipMalloc for the device status word failed");
-    free(c);
-    return AOMHIP_ERR_NOMEM;
+  if (hipMalloc(reinterpret_cast<void **>(&c->d_status), sizeof(int)) != hipSuccess || hipMemset(c->d_status, 0, sizeof(int)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void **>(&c->h_status), sizeof(int), hipHostMallocDefault) != hipSuccess) {
+    set_error("allocating the device status word / its pinned mirror failed");
+    return fail(AOMHIP_ERR_NOMEM);
   }
+  *c->h_status = 0;
   *out = c;
   return AOMHIP_OK;
 }
@@ -186,6 +199,7 @@ void aomhip_ctx_destroy(aomhip_ctx *ctx) {
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_work) (void)hipFree(ctx->d_work);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
+  if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
@@ -196,9 +210,10 @@ void aomhip_ctx_destroy(aomhip_ctx *ctx) {
 
 int aomhip_ctx_sync(aomhip_ctx *ctx) {
   if (!ctx) return AOMHIP_ERR_INVALID;
+  // the status word travels behind the queued work on the same stream: one synchronise, no second blocking copy
+  AOMHIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   AOMHIP_TRY(hipStreamSynchronize(ctx->stream));
-  int st = 0;
-  AOMHIP_TRY(hipMemcpy(&st, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost));
+  const int st = *ctx->h_status;
   if (st) {
     AOMHIP_TRY(hipMemset(ctx->d_status, 0, sizeof(int)));
     set_error("a batched call since the last synchronisation was given work-list entries it cannot process (device status 0x%x:%s); "

@@ -340,7 +340,7 @@ static int wrapper_shift(int bit_depth) { return bit_depth == 10 ? 2 : bit_depth
 template <typename T>
 static void host_sad_multi(const T *src, int src_stride, const T *const refs[], int n_refs, int ref_stride, int bw,
                            int bh, int flags, int shift, uint32_t *result) {
-  for (int k = 0; k < n_refs; ++k) result[k] = 0;  // the defined result of a failed call
+  for (int k = 0; k < n_refs; ++k) result[k] = kFailedCost;  // the defined result of a failed call: a LOSING score (0 would win every search)
   aomhip_ctx *ctx = default_ctx();
   if (!ctx) return;
   if (!valid_block(bw, bh)) {

@@ -72,8 +72,10 @@ template <typename T, int W, int H, bool SKIP, int UPL> struct Geom {
 };
 
 // BYTES at an arbitrary byte offset of LDS: BYTES/4 + 1 aligned dword reads, realigned in registers with v_alignbyte.
-// (A ds_read_b64 / _b128 off its natural alignment is replayed at 64 cycles per wave-instruction on gfx950 --
-// tools/lds_unaligned_probe.hip: 0.61 vs 7.4 T lane-reads/s -- 32-bit reads are unaffected.)
+// (Any LDS read off its natural alignment -- ds_read_b32 / _b64 / _b96 / _b128 alike -- returns the right bytes but is replayed at ~64
+// cycles per wave-instruction on gfx950: tools/r03_ubench.hip, profiles/r03_ubench.log: a 20-byte row at a random byte offset costs
+// 134 ns as five misaligned b32, 54 ns as b128 + b32, against 17 ns for five aligned dwords; v_qsad_pk_u16_u8 / v_mqsad_* issue at
+// 1/3.6 of v_sad_u8's rate, so the quad-SAD forms lose to v_alignbyte + v_sad_u8 as well.)
 template <int BYTES>
 __device__ __forceinline__ typename UnitLoad<BYTES>::type lds_unit(const char *lds, unsigned byte_off) {
   const uint32_t *p = reinterpret_cast<const uint32_t *>(lds) + (byte_off >> 2);
@@ -497,11 +499,28 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
 #pragma unroll
                     for (int j = 0; j < kNr; ++j) {
                       const uint32_t *p = reinterpret_cast<const uint32_t *>(lds + (bdw[j] + unit_roff(k)));
+#if AOMHIP_SB_DBG_KNOBS
+                      if (dbg & 1024) {  // (timing ablation: the arithmetic without the references' LDS reads)
+#pragma unroll
+                        for (int i = 0; i <= kDw; ++i) raw[j][i] = bdw[j] + i + k;
+                        continue;
+                      }
+#endif
 #pragma unroll
                       for (int i = 0; i <= kDw; ++i) raw[j][i] = p[i];
                     }
                     if constexpr (kAl) c4 = lds_unit_aligned<G::kUnitBytes>(lds, base[4] + unit_roff(k));
                     __builtin_amdgcn_sched_barrier(0);
+#if AOMHIP_SB_DBG_KNOBS
+                    if (dbg & 512) {  // (timing ablation: the LDS reads without the realign + SAD arithmetic)
+#pragma unroll
+                      for (int j = 0; j < kNr; ++j)
+#pragma unroll
+                        for (int i = 0; i <= kDw; ++i) acc[j] ^= raw[j][i];
+                      acc[4] ^= c4.v[0] ^ c4.v[3] ^ sv.v[1];
+                      continue;
+                    }
+#endif
 #pragma unroll
                     for (int j = 0; j < kNr; ++j)
 #pragma unroll

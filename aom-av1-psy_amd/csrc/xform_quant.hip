@@ -1101,16 +1101,17 @@ void aomhip_quantize_b_any(const int32_t *coeff_ptr, intptr_t n_coeffs, const in
                            const int16_t *dequant_ptr, uint16_t *eob_ptr, const int16_t *scan, const int16_t *iscan, int log_scale,
                            int is_hbd, int adaptive) {
   (void)scan;
-  const size_t n = (size_t)n_coeffs;
-  memset(qcoeff_ptr, 0, n * 4);
-  memset(dqcoeff_ptr, 0, n * 4);
   *eob_ptr = 0;
-  aomhip_ctx *ctx = default_ctx();
-  if (!ctx) return;
+  // (range check BEFORE anything is sized by n_coeffs: an invalid count zeroes *eob_ptr only and touches no block memory)
   if (n_coeffs <= 0 || n_coeffs > 4096 || log_scale < 0 || log_scale > 2) {
     set_error("aomhip_quantize_b: n_coeffs %ld / log_scale %d unsupported", (long)n_coeffs, log_scale);
     return note_failure("aomhip_quantize_b", AOMHIP_ERR_INVALID);
   }
+  const size_t n = (size_t)n_coeffs;
+  memset(qcoeff_ptr, 0, n * 4);
+  memset(dqcoeff_ptr, 0, n * 4);
+  aomhip_ctx *ctx = default_ctx();
+  if (!ctx) return;
   const size_t isc_off = n * 4, q_off = (isc_off + n * 2 + 15) & ~(size_t)15, dq_off = q_off + n * 4, e_off = dq_off + n * 4;
   const size_t total = e_off + 16;
   char *h = static_cast<char *>(pinned(ctx, total)), *d = static_cast<char *>(scratch(ctx, total));

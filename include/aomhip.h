@@ -26,7 +26,9 @@
  * aomhip_status_t.  rtcd-signature calls cannot: a failure there (no device, a HIP
  * error, an unsupported size) is recorded in a process-wide STICKY status --
  * aomhip_status(), first failure wins, reported once on stderr -- and the call
- * returns its defined "failed" result (0 / outputs zeroed or left untouched).  It
+ * returns its defined "failed" result: UINT32_MAX for every cost (SAD, variance, sse:
+ * a failed candidate loses the search, it never wins it), zeroed coefficients / eob,
+ * pixels untouched.  It
  * never aborts and never longjmps: the encoder's only error path stays its own
  * (av1/encoder/encoder.c:947-952), which a caller can take after checking
  * aomhip_status() at a frame boundary.  AOMHIP_ABORT_ON_ERROR=1 restores fail-stop
@@ -892,6 +894,8 @@ typedef struct aomhip_comm aomhip_comm;
 int aomhip_comm_unique_id(uint8_t id[128]);
 int aomhip_comm_init(aomhip_ctx *ctx, const uint8_t id[128], int rank, int n_ranks, aomhip_comm **out);
 void aomhip_comm_destroy(aomhip_comm *comm);
+/* What RCCL itself says about the communicator (ncclCommUserRank / ncclCommCount): a launcher can assert that every rank joined. */
+int aomhip_comm_info(aomhip_comm *comm, int *rank, int *n_ranks);
 
 /* After frame `frame` of `p` (the reconstruction) is valid in this rank's tile column: exchange the column strips so that every
  * rank holds what it can reference in the next frame (MV limits are frame-relative, av1/encoder/mcomp.h:216-247), then
@@ -1024,7 +1028,7 @@ typedef void (*aomhip_cdef_filter_fn)(void *dst, int dstride, const uint16_t *in
  * assigns these pointers to the generated globals when the capability probe says HAS_HIP.  Returns
  * AOMHIP_ERR_NO_DEVICE and an all-NULL table when no GPU is visible, so the caller keeps its C / SIMD pointers.
  * Index conventions: fwd_txfm2d / inv_txfm2d_add by TX_SIZE; lpf*[0 = horizontal, 1 = vertical][0..3 = length 4, 6, 8, 14];
- * cdef_filter_8 / _16 by the _0.._3 suffix. */
+ * cdef_filter_8 / _16 by the _0.._3 suffix; block_fns[depth][BLOCK_SIZE] = every SAD / variance member of every block size. */
 typedef struct aomhip_rtcd_table {
   unsigned int (*sad16x16)(const uint8_t *src_ptr, int src_stride, const uint8_t *ref_ptr, int ref_stride);
   void (*sad16x16x4d)(const uint8_t *src_ptr, int src_stride, const uint8_t *const ref_ptr[4], int ref_stride, uint32_t sad_array[4]);
@@ -1046,6 +1050,10 @@ typedef struct aomhip_rtcd_table {
   void (*cdef_find_dir_dual)(const uint16_t *img1, const uint16_t *img2, int stride, int32_t *var1, int32_t *var2, int coeff_shift, int *out1,
                              int *out2);
   aomhip_cdef_filter_fn cdef_filter_8[4], cdef_filter_16[4];
+  /* aom_sadWxH / aom_sad_skip_WxH / aom_sadWxHx4d / aom_sad_skip_WxHx4d / aom_varianceWxH / aom_sub_pixel_varianceWxH for ALL 22 block
+   * sizes (aom_dsp_rtcd_defs.pl:798-905,1001-1005,1367-1415), indexed by BLOCK_SIZE (av1/common/enums.h:99-124), and the three
+   * highbd depths of each: [0] = 8-bit entry points, [1] / [2] = the aom_highbd_*_bits10 / _bits12 forms (CONVERT_TO_BYTEPTR pointers). */
+  aomhip_variance_vtable block_fns[3][22];
 } aomhip_rtcd_table;
 int aomhip_rtcd(aomhip_rtcd_table *table);
 

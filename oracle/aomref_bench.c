@@ -177,8 +177,16 @@ uint32_t orc_sad16x16_avx2(const void *s, int ss, const void *r, int rs, int ele
  * blocks of each (plane, size) pass are partitioned statically over the threads, outputs are thread-private scratch.
  * Returns blocks processed.
  */
+long long orc_bench_txq_bd(const int16_t *const *planes, int n_planes, int width, int height, const int16_t q[5][2], int threads,
+                           int avx2_quant, int bd, double seconds, double *elapsed, unsigned long long *checksum);
 long long orc_bench_txq(const int16_t *const *planes, int n_planes, int width, int height, const int16_t q[5][2], int threads,
                         int avx2_quant, double seconds, double *elapsed, unsigned long long *checksum) {
+  return orc_bench_txq_bd(planes, n_planes, width, height, q, threads, avx2_quant, 8, seconds, elapsed, checksum);
+}
+/* bd > 8: the high-bit-depth leg -- the forward transform with bd's stage ranges and aom_highbd_quantize_b (64-bit products; the port has
+ * no AVX2 form of it, avx2_quant is ignored there). */
+long long orc_bench_txq_bd(const int16_t *const *planes, int n_planes, int width, int height, const int16_t q[5][2], int threads,
+                           int avx2_quant, int bd, double seconds, double *elapsed, unsigned long long *checksum) {
   if (threads < 1) threads = 1;
   static const int kTx[4] = { 0, 1, 2, 3 }; /* TX_4X4 .. TX_32X32 */
   int16_t scans[4][1024], iscans[4][1024];
@@ -203,8 +211,10 @@ long long orc_bench_txq(const int16_t *const *planes, int n_planes, int width, i
           const int lo = (int)((long long)nb * t / nt), hi = (int)((long long)nb * (t + 1) / nt);
           for (int i = lo; i < hi; ++i) {
             uint16_t eob;
-            orc_fwd_txfm2d(planes[p] + (ptrdiff_t)(i / cols) * nside * width + (i % cols) * nside, full, width, kTx[s], 0, 8);
-            if (avx2_quant && nc >= 8)
+            orc_fwd_txfm2d(planes[p] + (ptrdiff_t)(i / cols) * nside * width + (i % cols) * nside, full, width, kTx[s], 0, bd);
+            if (bd > 8)
+              orc_highbd_quantize_b(full, nc, q[0], q[1], q[2], q[3], qc, dq, q[4], &eob, scans[s], iscans[s], log_scale);
+            else if (avx2_quant && nc >= 8)
               quantize_b_avx2(full, nc, q[0], q[1], q[2], q[3], qc, dq, q[4], &eob, iscans[s], log_scale);
             else
               orc_quantize_b(full, nc, q[0], q[1], q[2], q[3], qc, dq, q[4], &eob, scans[s], iscans[s], log_scale);

@@ -270,19 +270,19 @@ def bench_sad_mode_a(src_planes, ref_planes, border, cands, groups, bd, threads,
     return done / el.value, done, el.value
 
 
-def bench_txq(planes, q, threads, avx2_quant, seconds):
-    """bench.py's CPU baseline for fwd_txfm2d + quantize_b over all 4x4..32x32 blocks of int16 residual planes;
-    -> (blocks/s, blocks, elapsed s)."""
+def bench_txq(planes, q, threads, avx2_quant, seconds, bd=8):
+    """bench.py's CPU baseline for fwd_txfm2d + quantize_b over all 4x4..32x32 blocks of int16 residual planes
+    (bd > 8: aom_highbd_quantize_b and the transform's bd stage ranges); -> (blocks/s, blocks, elapsed s)."""
     P = len(planes)
     H, W = planes[0].shape
     ptrs = (C.c_void_p * P)(*[p.ctypes.data for p in planes])
     qa = np.ascontiguousarray([q[k] for k in ("zbin", "round", "quant", "quant_shift", "dequant")], np.int16)
     el, ck = C.c_double(), C.c_ulonglong()
-    f = lib.orc_bench_txq
+    f = lib.orc_bench_txq_bd
     f.restype = C.c_longlong
     f.argtypes = None
     done = f(ptrs, C.c_int(P), C.c_int(W), C.c_int(H), C.c_void_p(qa.ctypes.data), C.c_int(threads), C.c_int(int(avx2_quant)),
-             C.c_double(seconds), C.byref(el), C.byref(ck))
+             C.c_int(int(bd)), C.c_double(seconds), C.byref(el), C.byref(ck))
     return done / el.value, done, el.value
 
 

@@ -188,12 +188,25 @@ def test_installer_table_and_sticky_status(hip):
     lib.aomhip_status_clear.restype = None
     lib.aomhip_status_clear()
     assert lib.aomhip_status() == 0
-    n_ptrs = 3 + 2 + 12 + 19 + 19 + 8 * 5 + 2 + 8
+    n_fixed = 3 + 2 + 12 + 19 + 19 + 8 * 5 + 2 + 8
+    n_ptrs = n_fixed + 3 * 22 * 16  # + block_fns[3 depths][22 BLOCK_SIZEs] x the 16 members of aom_variance_fn_ptr_t
     table = (C.c_void_p * n_ptrs)()
     assert lib.aomhip_rtcd(table) == 0
     assert all(table[i] for i in range(n_ptrs)), "every pointer of aomhip_rtcd_table is filled"
     # pointers are the exported symbols
     assert table[5] == C.cast(lib.aomhip_quantize_b, C.c_void_p).value
+    # block_fns = what the vtable binder installs: the sdf of BLOCK_64X32 (index 11) at 8 bits computes aom_sad64x32
+    vt = (C.c_void_p * (22 * 16))()
+    assert lib.aomhip_bind_variance_vtable(vt, 8) == 0
+    assert [table[n_fixed + i] for i in range(22 * 16)] == list(vt)
+    sdf = C.CFUNCTYPE(C.c_uint, C.c_void_p, C.c_int, C.c_void_p, C.c_int)(table[n_fixed + 11 * 16 + 0])
+    rng = np.random.default_rng(9)
+    a, b = rng.integers(0, 256, (32, 80), dtype=np.uint8), rng.integers(0, 256, (32, 72), dtype=np.uint8)
+    assert sdf(a.ctypes.data, 80, b.ctypes.data, 72) == int(np.abs(a[:, :64].astype(np.int32) - b[:, :64].astype(np.int32)).sum())
+    hsdf = C.CFUNCTYPE(C.c_uint, C.c_void_p, C.c_int, C.c_void_p, C.c_int)(table[n_fixed + (1 * 22 + 6) * 16 + 0])  # highbd 10-bit, BLOCK_16X16
+    a16, b16 = rng.integers(0, 1024, (16, 24), dtype=np.uint16), rng.integers(0, 1024, (16, 16), dtype=np.uint16)
+    # (the encoder's _bits10 wrapper: aom_highbd_sad16x16 >> 2, av1/encoder/encoder_utils.h:130-139)
+    assert hsdf(a16.ctypes.data >> 1, 24, b16.ctypes.data >> 1, 16) == int(np.abs(a16[:, :16].astype(np.int32) - b16.astype(np.int32)).sum()) >> 2
     # an unsupported call records the sticky status, returns its defined result and does not take the process down
     f = _fn(lib, "aomhip_fwd_txfm2d")
     out = np.full(16, 5, np.int32); res = np.zeros((4, 4), np.int16)

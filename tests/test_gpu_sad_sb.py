@@ -168,3 +168,41 @@ def test_crowded_buckets_overflow_the_descriptor_buffers(hip, oracle, ctx, monke
     for d in (d_g, d_c, d_og, d_oc, d_o4, d_o1):
         ctx.free(d)
     ctx.planes_free(ps); ctx.planes_free(pr)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_bench_geometry_1080p_ring_of_frames_last_slot(hip, oracle, ctx, bd):
+    """bench.py's own launch at 1080p: 240 x 64 cells (160 x 32 for 16-bit planes), a ring of 9 frame pairs in ONE launch, per-frame group
+    lists (group_frame_stride = n) with a shared single-candidate list -- and the slots checked against the oracle are the first, a middle
+    one and the LAST one (the far end of every per-frame stride the kernel uses: plane, list, output)."""
+    W, H, border, F = 1920, 1080, 160, 9
+    rng = np.random.default_rng(1080 + bd)
+    ps, pr = ctx.planes_alloc(W, H, border, bd, F), ctx.planes_alloc(W, H, border, bd, F)
+    frames = []
+    for f in range(F):
+        s, r = hip.synth.lcg_frame(W, H, 2 * f, 0, bd), hip.synth.lcg_frame(W, H, 2 * f + 1, 0, bd)
+        ctx.planes_upload(ps, f, s); ctx.planes_upload(pr, f, r)
+        frames.append((s, r))
+    cands, groups = hip.synth.mode_a_worklist(W, H, 16, seed=3, search=64)
+    n = len(groups)
+    allg = np.tile(groups, (F, 1))
+    allg["rx"] = allg["sx"][..., None] + rng.integers(-64, 65, (F, n, 4), dtype=np.int16)   # distinct positions per ring slot
+    allg["ry"] = allg["sy"][..., None] + rng.integers(-64, 65, (F, n, 4), dtype=np.int16)
+    sbw, sbh = (240, 64) if bd == 8 else (160, 32)
+    perm, off = hip.synth.bucket_order(groups["sx"], groups["sy"], W, H, sbw, sbh)
+    gs, cs = np.ascontiguousarray(allg[:, perm]), cands[perm]
+    d_g, d_c, d_o = ctx.to_device(gs), ctx.to_device(cs), ctx.to_device(off)
+    d_out4, d_out1 = ctx.malloc(F * n * 16), ctx.malloc(F * n * 4)
+    ctx.memset(d_out4, 0xff, F * n * 16); ctx.memset(d_out1, 0xff, F * n * 4)
+    ctx.sad_sb_batch(ps, pr, 0, F, 16, 16, 0, sbw, sbh, 64, len(off) - 1, d_g, d_o, n, n, d_out4, d_c, d_o, n, 0, d_out1)
+    out4, out1 = ctx.from_device(d_out4, (F, n, 4), np.uint32), ctx.from_device(d_out1, (F, n), np.uint32)
+    for f in (0, F // 2, F - 1):
+        sb, rb = oracle.extend_plane(frames[f][0], border, ps.stride), oracle.extend_plane(frames[f][1], border, pr.stride)
+        assert np.array_equal(out4[f], oracle.sad_x4d_batch(sb, rb, border, 16, 16, gs[f], bd=bd, threads=8)), f
+        assert np.array_equal(out1[f], oracle.sad_batch(sb, rb, border, 16, 16, cs, bd=bd, threads=8)), f
+    # every slot was written (none left at the 0xff fill) and the slots differ from each other
+    assert not (out4 == 0xFFFFFFFF).any() and not (out1 == 0xFFFFFFFF).any()
+    assert not np.array_equal(out4[0], out4[F - 1])
+    for d in (d_g, d_c, d_o, d_out4, d_out1):
+        ctx.free(d)
+    ctx.planes_free(ps); ctx.planes_free(pr)

@@ -11,14 +11,21 @@ def main():
     ctx = pkg.capi.Context(0)
     border = 160
     ps, pr = ctx.planes_alloc(W, H, border, bd, F), ctx.planes_alloc(W, H, border, bd, F)
+    data = os.environ.get("AB_DATA", "lcg")  # lcg: the bench's frames; zero / smooth: the same launch on low-toggle data (is the chip power limited?)
+    def frame(f, plane):
+        if data == "zero": return np.zeros((H, W), np.uint16 if bd > 8 else np.uint8)
+        if data == "smooth":
+            g = (np.add.outer(np.arange(H), np.arange(W)) // 8 + 3 * f + plane) % (1 << bd)
+            return g.astype(np.uint16 if bd > 8 else np.uint8)
+        return pkg.synth.lcg_frame(W, H, f, plane, bd)
     for f in range(F):
-        ctx.planes_upload(ps, f, pkg.synth.lcg_frame(W, H, f, 0, bd)); ctx.planes_upload(pr, f, pkg.synth.lcg_frame(W, H, f, 1, bd))
+        ctx.planes_upload(ps, f, frame(f, 0)); ctx.planes_upload(pr, f, frame(f, 1))
     cands, groups = pkg.synth.mode_a_worklist(W, H, 16, seed=1, search=64)
     n = len(groups)
     d_g, d_c = ctx.to_device(groups), ctx.to_device(cands)
     d_o4, d_o1 = ctx.malloc(F * n * 16), ctx.malloc(F * n * 4)
     d_p4, d_p1 = ctx.malloc(F * n * 16), ctx.malloc(F * n * 4)
-    def timed(fn, reps=10):
+    def timed(fn, reps=int(os.environ.get("AB_REPS", "10"))):
         for _ in range(3): fn()
         ctx.sync(); ctx.timer_begin()
         for _ in range(reps): fn()
