@@ -189,6 +189,22 @@ void orc_convolve_sr(const void *src, int src_stride, void *dst, int dst_stride,
                      int subpel_x_qn, int subpel_y_qn, int elem16, int bd);
 void orc_build_inter_pred_block_ss(const void *ref_origin, int ref_stride, void *dst, int dst_stride, int bx, int by, int bw, int bh,
                                    int mv_row, int mv_col, int filter_x, int filter_y, int elem16, int bd, int ss_x, int ss_y);
+/* aomref_tf.c: the temporal filter after its motion search (temporal_filter.c:331-392,407-442,460-512,557-712,740-775,849-905) */
+void orc_convolve_sr12(const void *src, int src_stride, void *dst, int dst_stride, int w, int h, int subpel_x_qn, int subpel_y_qn,
+                       int elem16, int bd);
+void orc_tf_build_predictor_plane(const void *ref_origin, int ref_stride, void *pred, int mb_row, int mb_col, int ss_x, int ss_y,
+                                  const int16_t *subblock_mvs, int elem16, int bd);
+void orc_tf_apply_block(const void *const *frame_planes, const int *strides, int frame_w, int frame_h, int num_planes, int ss_x, int ss_y,
+                        int mb_row, int mb_col, const double *noise_levels, const int16_t *subblock_mvs, const int32_t *subblock_mses,
+                        int q_factor, int filter_strength, const void *pred, uint32_t *accum, uint16_t *count, int elem16, int bd);
+void orc_tf_apply_self_block(const void *const *frame_planes, const int *strides, int num_planes, int ss_x, int ss_y, int mb_row, int mb_col,
+                             uint32_t *accum, uint16_t *count, int elem16);
+void orc_tf_normalize_block(void *const *out_planes, const int *strides, int num_planes, int ss_x, int ss_y, int mb_row, int mb_col,
+                            const uint32_t *accum, const uint16_t *count, int elem16);
+void orc_tf_apply_frames(const void *const *frame_origins, const int *strides, int n_frames, int filter_frame, int frame_w, int frame_h,
+                         int num_planes, int ss_x, int ss_y, const double *noise_levels, const int16_t *subblock_mvs,
+                         const int32_t *subblock_mses, int q_factor, int filter_strength, void *const *out_planes, const int *out_strides,
+                         int elem16, int bd, int threads);
 void orc_convolve_compound_mask(const void *src0, int stride0, int sx0, int sy0, const void *src1, int stride1, int sx1, int sy1, void *dst,
                                 int dst_stride, int w, int h, int filter_x, int filter_y, int fwd_offset, int bck_offset, int elem16, int bd,
                                 const uint8_t *mask, int mask_stride, int subw, int subh);
