@@ -69,6 +69,19 @@ class TfParams(C.Structure):
         return out
 
 
+class TfApplyParams(C.Structure):
+    _fields_ = [("noise_levels", C.c_double * 3), ("q_factor", C.c_int32), ("filter_strength", C.c_int32), ("num_planes", C.c_int32),
+                ("ss_x", C.c_int32), ("ss_y", C.c_int32)]
+
+    @classmethod
+    def make(cls, noise_levels, q_factor, filter_strength, num_planes=1, ss_x=0, ss_y=0):
+        o = cls()
+        for i, v in enumerate(list(noise_levels)[:3]):
+            o.noise_levels[i] = float(v)
+        o.q_factor, o.filter_strength, o.num_planes, o.ss_x, o.ss_y = q_factor, filter_strength, num_planes, ss_x, ss_y
+        return o
+
+
 def tf_block_list(width, height, border):
     n = lib.aomhip_tf_block_list(width, height, border, None)
     b = np.zeros(n, search_block_dtype)
@@ -212,6 +225,7 @@ _protos = {
     "aomhip_tile_column_bounds": (C.c_int, [_i, _i, _i, _vp]),
     "aomhip_recon_exchange_plan": (C.c_int, [_i, _i, _vp, _i, _i, _vp, _vp]),
     "aomhip_comm_unique_id": (C.c_int, [_vp]),
+    "aomhip_tf_apply_frames": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "aomhip_comm_init": (C.c_int, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "aomhip_comm_destroy": (None, [_vp]),
     "aomhip_comm_info": (C.c_int, [_vp, C.POINTER(_i), C.POINTER(_i)]),
@@ -337,6 +351,14 @@ class Context:
         fp = None if frame_present is None else np.ascontiguousarray(frame_present, np.uint8)
         check(lib.aomhip_tf_motion_search_frames(self.h, C.byref(frames), filter_frame, None if fp is None else fp.ctypes.data, C.byref(params),
                                                  d_blocks, n_blocks, d_mvs, d_mses, d_ref_mv), "aomhip_tf_motion_search_frames")
+
+    def tf_apply_frames(self, frames, filter_frame, params, n_blocks, d_mvs, d_mses, outs, out_frame, frame_present=None, d_diff=None):
+        """frames / outs: (y,) or (y, u, v) plane rings; params: TfApplyParams."""
+        fp = None if frame_present is None else np.ascontiguousarray(frame_present, np.uint8)
+        fr = [C.byref(x) for x in frames] + [None] * (3 - len(frames))
+        ou = [C.byref(x) for x in outs] + [None] * (3 - len(outs))
+        check(lib.aomhip_tf_apply_frames(self.h, fr[0], fr[1], fr[2], filter_frame, None if fp is None else fp.ctypes.data, C.byref(params), n_blocks,
+                                         d_mvs, d_mses, ou[0], ou[1], ou[2], out_frame, d_diff), "aomhip_tf_apply_frames")
 
     # ---- multi-GPU: the per-frame exchange of the reconstruction (RCCL inside the library)
     def comm_init(self, unique_id, rank, n_ranks):

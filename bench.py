@@ -812,6 +812,42 @@ def run_tf(pkg, ctx, orc, steps, warmup, width=3840, height=2160, bd=10, n_frame
         for _ in range(warmup):
             once()
         out[name] = {"ms_per_filtered_frame": kernel_avg_ms(ctx, once, max(3, steps // 4))}
+    # what follows the search in av1_tf_do_filtering_row, on the MVs / errors still in HBM: predictors (12-tap), pixel weights, accumulation and
+    # normalisation of the whole frame in one launch (aomhip_tf_apply_frames) -- luma + 4:2:0 chroma planes of the same window
+    cw, ch = (width + 1) >> 1, (height + 1) >> 1
+    chroma = [ctx.planes_alloc(cw, ch, border, bd, n_frames) for _ in range(2)]
+    for f in range(n_frames):
+        for c in chroma:
+            ctx.planes_upload(c, f, host[f][::2, ::2][:ch, :cw])
+    outs = [ctx.planes_alloc(width, height, border, bd, 1)] + [ctx.planes_alloc(cw, ch, border, bd, 1) for _ in range(2)]
+    ap3 = capi.TfApplyParams.make([2.0, 1.5, 1.5], 30, 5, 3, 1, 1)
+    ap1 = capi.TfApplyParams.make([2.0, 0, 0], 30, 5, 1, 0, 0)
+    d_diff = ctx.malloc(16)
+    apply3 = lambda: ctx.tf_apply_frames([planes] + chroma, filt, ap3, n, d_mv, d_mse, outs, 0, d_diff=d_diff)
+    apply1 = lambda: ctx.tf_apply_frames([planes], filt, ap1, n, d_mv, d_mse, outs[:1], 0)
+    vis = width * height * (2 if bd > 8 else 1)
+    for nm, fn, planes_n in (("apply_yuv420", apply3, 1.5), ("apply_luma", apply1, 1.0)):
+        ms_a = kernel_avg_ms(ctx, fn, max(3, steps // 4))
+        moved = vis * planes_n * (n_frames + 1)   # every window frame read once + the filtered frame written
+        out[nm] = {"ms_per_filtered_frame": ms_a, "GBs_window_plus_output": moved / (ms_a * 1e-3) / 1e9, "frac_of_8TBs": moved / (ms_a * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    apply_ok = None
+    if orc is not None:   # the luma launch against the oracle on every 61st block (blocks are independent)
+        apply1(); ctx.sync()
+        mvs_a = ctx.from_device(d_mv, (n_frames, n, 4, 2), np.int16)
+        mses_a = ctx.from_device(d_mse, (n_frames, n, 4), np.int32)
+        mb_cols = (width + 31) // 32
+        fb = [orc.extend_plane(h, border, planes.stride) for h in host]
+        want = orc.tf_apply_frames([fb], border, width, height, filt, mvs_a, mses_a, [2.0, 0, 0], 30, 5, bd=bd, block_first=0, block_step=61)[0]
+        got = ctx.planes_download(outs[0], 0)
+        okb = []
+        for bi in range(0, n, 61):
+            r0, c0 = border + 32 * (bi // mb_cols), border + 32 * (bi % mb_cols)
+            okb.append(np.array_equal(got[r0:r0 + 32, c0:c0 + 32], want[r0:r0 + 32, c0:c0 + 32]))
+        apply_ok = {"blocks_checked": len(okb), "identical": bool(all(okb))}
+    out["apply_parity_sample"] = apply_ok
+    for pl in chroma + outs:
+        ctx.planes_free(pl)
+    ctx.free(d_diff)
     ok = None
     if orc is not None:   # the last call (q 12) against the oracle on every 97th block (blocks are independent)
         mvs = ctx.from_device(d_mv, (n_frames, n, 4, 2), np.int16)

@@ -620,6 +620,33 @@ int aomhip_tf_motion_search_frames(aomhip_ctx *ctx, const aomhip_planes *frames,
                                    const aomhip_tf_params *params, const aomhip_search_block *d_blocks, int n_blocks,
                                    int16_t *d_subblock_mvs, int32_t *d_subblock_mses, int16_t *d_ref_mv);
 
+/* ------------------------------------------------------------------ temporal filter: predictor, weights, accumulation, normalisation */
+
+/* What follows tf_motion_search in av1_tf_do_filtering_row (av1/encoder/temporal_filter.c:849-905), for every 32x32 block of the frame to
+ * filter and every frame of the window, in one launch -- so that the MVs / errors of aomhip_tf_motion_search_frames never leave the device:
+ *   tf_build_predictor (:331-392; MULTITAP_SHARP2, the 12-tap kernels, per sub-block MV), tf_apply_temporal_filter_self (:407-442),
+ *   av1_apply_temporal_filter_c (:557-712; av1/common/av1_rtcd_defs.pl:405-406) -- luma, and U / V with the luma error term --,
+ *   tf_normalize_filtered_frame (:740-775) into `out`, and optionally FRAME_DIFF { sum, sse } of the luma plane (:892-904).
+ * noise_levels: av1_estimate_noise_from_single_plane per plane (the caller's, as tf_ctx->noise_levels); q_factor: tf_ctx->q_factor;
+ * filter_strength: oxcf.algo_cfg.arnr_strength after the adjustments of av1_tf_do_filtering_row (:806-833).
+ * Integer results are bit-exact; the pixel weights are (int)(exp(-x) * 1000) in double precision with the reference's operation order, the
+ * device's exp() being within 1 ulp of libm's. */
+typedef struct {
+  double noise_levels[3];
+  int32_t q_factor, filter_strength;
+  int32_t num_planes;      /* 1 (luma only, monochrome) or 3 */
+  int32_t ss_x, ss_y;      /* chroma subsampling of planes 1, 2 */
+} aomhip_tf_apply_params;
+/* frames_y / _u / _v: the window's rings (same n_frames; _u / _v NULL when num_planes == 1; chroma planes (width + ss_x) >> ss_x wide);
+ * every plane's border must cover the 32-aligned frame (blocks of the last row / column reach beyond the visible area exactly as in the
+ * reference) and the predictors' reach (MV limits + 6 pixels).  n_blocks = ceil(height / 32) * ceil(width / 32), the count
+ * aomhip_tf_block_list returns; d_subblock_mvs / d_subblock_mses: as aomhip_tf_motion_search_frames writes them.
+ * out_*: frame out_frame of these rings receives the filtered frame; d_frame_diff: two int64 { sum, sse } or NULL. */
+int aomhip_tf_apply_frames(aomhip_ctx *ctx, const aomhip_planes *frames_y, const aomhip_planes *frames_u, const aomhip_planes *frames_v,
+                           int filter_frame, const uint8_t *frame_present, const aomhip_tf_apply_params *params, int n_blocks,
+                           const int16_t *d_subblock_mvs, const int32_t *d_subblock_mses, const aomhip_planes *out_y,
+                           const aomhip_planes *out_u, const aomhip_planes *out_v, int out_frame, int64_t *d_frame_diff);
+
 /* ------------------------------------------------------------------ first pass: one motion-search leg for a list of blocks */
 
 /* first_pass_motion_search (av1/encoder/firstpass.c:261-299) for every block of a list against one reference frame (the last frame or

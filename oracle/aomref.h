@@ -204,7 +204,7 @@ void orc_tf_normalize_block(void *const *out_planes, const int *strides, int num
 void orc_tf_apply_frames(const void *const *frame_origins, const int *strides, int n_frames, int filter_frame, int frame_w, int frame_h,
                          int num_planes, int ss_x, int ss_y, const double *noise_levels, const int16_t *subblock_mvs,
                          const int32_t *subblock_mses, int q_factor, int filter_strength, void *const *out_planes, const int *out_strides,
-                         int elem16, int bd, int threads);
+                         int elem16, int bd, int threads, int block_first, int block_step);
 void orc_convolve_compound_mask(const void *src0, int stride0, int sx0, int sy0, const void *src1, int stride1, int sx1, int sy1, void *dst,
                                 int dst_stride, int w, int h, int filter_x, int filter_y, int fwd_offset, int bck_offset, int elem16, int bd,
                                 const uint8_t *mask, int mask_stride, int subw, int subh);

@@ -218,11 +218,13 @@ void orc_tf_normalize_block(void *const *out_planes, const int *strides, int num
 void orc_tf_apply_frames(const void *const *frame_origins, const int *strides, int n_frames, int filter_frame, int frame_w, int frame_h,
                          int num_planes, int ss_x, int ss_y, const double *noise_levels, const int16_t *subblock_mvs,
                          const int32_t *subblock_mses, int q_factor, int filter_strength, void *const *out_planes, const int *out_strides,
-                         int elem16, int bd, int threads) {
+                         int elem16, int bd, int threads, int block_first, int block_step) {
   const int mb_rows = (frame_h + 31) / 32, mb_cols = (frame_w + 31) / 32, n_blocks = mb_rows * mb_cols;
   (void)threads;
+  if (block_step < 1) block_step = 1;
+  /* (block_first, block_step: a test may ask for every k-th block only -- blocks are independent) */
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4)
-  for (int b = 0; b < n_blocks; ++b) {
+  for (int b = block_first; b < n_blocks; b += block_step) {
     const int mb_row = b / mb_cols, mb_col = b % mb_cols;
     uint32_t accum[3 * 1024];
     uint16_t count[3 * 1024];

@@ -160,9 +160,9 @@ def build_inter_pred(ref_b, border, width, height, w, h, blocks, mvs, filter_x=0
 
 
 def tf_apply_frames(planes_b, border, width, height, filter_frame, mvs, mses, noise_levels, q_factor, filter_strength, bd=8, ss_x=0, ss_y=0,
-                    present=None, threads=8):
+                    present=None, threads=8, block_first=0, block_step=1):
     """oracle/aomref_tf.c orc_tf_apply_frames.  planes_b: per component (1 or 3) a list of border-extended frames of the window
-    (chroma borders = border >> ss); mvs (F, n_blocks, 4, 2) int16, mses (F, n_blocks, 4) int32 as aomhip_tf_motion_search_frames
+    (every plane with the same `border`); mvs (F, n_blocks, 4, 2) int16, mses (F, n_blocks, 4) int32 as aomhip_tf_motion_search_frames
     writes them.  Returns the filtered planes (border-extended arrays of the same shapes; only the block-covered area is written)."""
     P, F = len(planes_b), len(planes_b[0])
     e16 = int(planes_b[0][0].dtype != np.uint8)
@@ -173,9 +173,9 @@ def tf_apply_frames(planes_b, border, width, height, filter_frame, mvs, mses, no
         for f in range(F):
             assert planes_b[p][f].shape == planes_b[p][0].shape
             if present is None or present[f]:
-                origins[f * 3 + p] = _addr(planes_b[p][f], border >> (ss_y if p else 0), border >> (ss_x if p else 0))
+                origins[f * 3 + p] = _addr(planes_b[p][f], border, border)
     outs = [np.zeros_like(planes_b[p][0]) for p in range(P)]
-    out_ptrs = (C.c_void_p * 3)(*[_addr(outs[p], border >> (ss_y if p else 0), border >> (ss_x if p else 0)) for p in range(P)] + [None] * (3 - P))
+    out_ptrs = (C.c_void_p * 3)(*[_addr(outs[p], border, border) for p in range(P)] + [None] * (3 - P))
     ostr = (C.c_int * 3)(*[outs[p].shape[1] for p in range(P)] + [0] * (3 - P))
     nl = (C.c_double * 3)(*([float(v) for v in noise_levels] + [0.0] * 3)[:3])
     mv = np.ascontiguousarray(mvs, np.int16)
@@ -185,7 +185,7 @@ def tf_apply_frames(planes_b, border, width, height, filter_frame, mvs, mses, no
     f.argtypes = None
     f(origins, strides, C.c_int(F), C.c_int(filter_frame), C.c_int(width), C.c_int(height), C.c_int(P), C.c_int(ss_x), C.c_int(ss_y), nl,
       C.c_void_p(mv.ctypes.data), C.c_void_p(ms.ctypes.data), C.c_int(q_factor), C.c_int(filter_strength), out_ptrs, ostr, C.c_int(e16),
-      C.c_int(bd), C.c_int(threads))
+      C.c_int(bd), C.c_int(threads), C.c_int(block_first), C.c_int(block_step))
     return outs
 
 
