@@ -403,3 +403,125 @@ extern "C" int aomhip_motion_estimation_batch(aomhip_ctx *ctx, const aomhip_plan
   return aomhip_subpel_tree_batch(ctx, src, ref, frame, bw, bh, sub, d_mvjcost, d_mvcost_row, d_mvcost_col, sl, cl, n, d_best_mv, d_best_err, d_distortion,
                                   d_sse);
 }
+
+// ---- av1_simple_motion_search / av1_simple_motion_sse_var (av1/encoder/motion_search_facade.c:925-1060): the partition-pruning search.
+// Per block: av1_full_pixel_search from the caller's start_mv around ref_mv = 0 (limits av1_set_mv_search_range(&x->mv_limits, &kZeroMv)),
+// the sub-pel search from get_mv_from_fullmv(best) when use_subpixel and the full-pel search returned less than INT_MAX (:1003-1024),
+// the EIGHTTAP_REGULAR luma predictor at the result (:1029-1031) and the block's vf(src, pred) -> sse, var (:1052-1057).
+namespace aomhip {
+namespace {
+__global__ void sms_full_list_kernel(const aomhip_search_block *blocks, int n, aomhip_search_block *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const aomhip_search_block b = blocks[i];
+  aomhip_search_block o = b;
+  o.ref_row = 0; o.ref_col = 0;   // const MV ref_mv = kZeroMv (:948); start_row / start_col: the caller's FULLPEL start_mv
+  full_limits(b, &o);
+  out[i] = o;
+}
+__global__ void sms_subpel_list_kernel(const aomhip_search_block *blocks, const int16_t *full_mv, int n, aomhip_search_block *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const aomhip_search_block b = blocks[i];
+  aomhip_search_block o = b;
+  o.ref_row = 0; o.ref_col = 0;
+  o.start_row = (int16_t)(full_mv[2 * i] * 8); o.start_col = (int16_t)(full_mv[2 * i + 1] * 8);  // get_mv_from_fullmv
+  subpel_limits(b, &o);
+  out[i] = o;
+}
+// blocks whose full-pel search returned INT_MAX (or every block when there is no sub-pel stage): convert_fullmv_to_mv (:1025-1029)
+__global__ void sms_fullmv_result_kernel(const int16_t *full_mv, const int32_t *full_cost, int n, int all, int16_t *best_mv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (all || full_cost[i] == INT_MAX) {
+    best_mv[2 * i] = (int16_t)(full_mv[2 * i] * 8);
+    best_mv[2 * i + 1] = (int16_t)(full_mv[2 * i + 1] * 8);
+  }
+}
+// fn_ptr[bsize].vf(src, pred) (aom_dsp/variance.c:141-148 VAR, :383-420 HIGHBD_VAR): one wavefront per block
+template <typename T>
+__global__ __launch_bounds__(256) void sms_var_kernel(PlaneView<T> src, int src_frame, PlaneView<T> pred, int pred_frame, int bw, int bh, int bit_depth,
+                                                       const aomhip_search_block *blocks, int n, uint32_t *out_sse, uint32_t *out_var) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const aomhip_search_block b = blocks[i];
+  const T *s = src.origin + (int64_t)src_frame * src.frame_stride + (int64_t)b.by * src.stride + b.bx;
+  const T *p = pred.origin + (int64_t)pred_frame * pred.frame_stride + (int64_t)b.by * pred.stride + b.bx;
+  long long sum = 0;
+  unsigned long long sse = 0;
+  for (int q = lane; q < bw * bh; q += 64) {
+    const int y = q / bw, x = q - y * bw;
+    const int d = (int)s[(int64_t)y * src.stride + x] - (int)p[(int64_t)y * pred.stride + x];
+    sum += d; sse += (unsigned)(d * d);
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { sum += __shfl_xor(sum, m, 64); sse += __shfl_xor(sse, m, 64); }
+  if (lane == 0) {
+    int32_t sm; uint32_t q;
+    if (bit_depth == 10) { q = (uint32_t)((sse + 8) >> 4); sm = (int32_t)((sum + 2) >> 2); }
+    else if (bit_depth == 12) { q = (uint32_t)((sse + 128) >> 8); sm = (int32_t)((sum + 8) >> 4); }
+    else { q = (uint32_t)sse; sm = (int32_t)sum; }
+    const int64_t sq = ((int64_t)sm * sm) / (bw * bh);
+    out_sse[i] = q;
+    if (bit_depth == 8) out_var[i] = q - (uint32_t)sq;
+    else { const int64_t v = (int64_t)q - sq; out_var[i] = v >= 0 ? (uint32_t)v : 0u; }
+  }
+}
+}  // namespace
+}  // namespace aomhip
+
+extern "C" int aomhip_simple_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                                 const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list,
+                                                 const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                                 const aomhip_search_block *d_blocks, int n, const aomhip_planes *pred, int pred_frame,
+                                                 int16_t *d_best_mv, uint32_t *d_sse, uint32_t *d_var) {
+  if (!ctx || !src || !ref || !full || n < 0 || (n > 0 && (!d_blocks || !d_best_mv)) || (pred && (!pred->base || pred_frame < 0 || pred_frame >= pred->n_frames)) ||
+      ((d_sse || d_var) && (!pred || !d_sse || !d_var))) {
+    set_error("aomhip_simple_motion_search_batch: invalid argument (sse / var need the predictor plane and each other)");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (pred && (pred->width != src->width || pred->height != src->height || pred->bit_depth != src->bit_depth)) {
+    set_error("aomhip_simple_motion_search_batch: the predictor plane must have the source's geometry");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n == 0) return AOMHIP_OK;
+  AOMHIP_TRY(hipSetDevice(ctx->device));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t n1 = (size_t)n;
+  const size_t o_fl = take(n1 * sizeof(aomhip_search_block)), o_sl = take(n1 * sizeof(aomhip_search_block)), o_fmv = take(n1 * 4), o_cost = take(n1 * 4),
+               o_cl = take(n1 * 20), o_err = take(n1 * 4), o_dist = take(n1 * 4), o_s2 = take(n1 * 4);
+  char *w = static_cast<char *>(work(ctx, off));
+  if (!w) return AOMHIP_ERR_NOMEM;
+  aomhip_search_block *fl = reinterpret_cast<aomhip_search_block *>(w + o_fl), *sl = reinterpret_cast<aomhip_search_block *>(w + o_sl);
+  int16_t *fmv = reinterpret_cast<int16_t *>(w + o_fmv);
+  int32_t *fcost = reinterpret_cast<int32_t *>(w + o_cost);
+  int32_t *cl = use_cost_list ? reinterpret_cast<int32_t *>(w + o_cl) : nullptr;
+  const unsigned g = (unsigned)((n1 + 255) / 256);
+  hipLaunchKernelGGL(sms_full_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, n, fl);
+  AOMHIP_LAUNCH_CHECK();
+  int rc = aomhip_full_pixel_search_batch(ctx, src, ref, frame, bw, bh, full, d_mvjcost, d_mvcost_row, d_mvcost_col, fl, n, fmv, fcost, cl, nullptr);
+  if (rc != AOMHIP_OK) return rc;
+  if (sub) {
+    hipLaunchKernelGGL(sms_subpel_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, fmv, n, sl);
+    AOMHIP_LAUNCH_CHECK();
+    rc = aomhip_subpel_tree_batch(ctx, src, ref, frame, bw, bh, sub, d_mvjcost, d_mvcost_row, d_mvcost_col, sl, cl, n, d_best_mv,
+                                  reinterpret_cast<uint32_t *>(w + o_err), reinterpret_cast<int32_t *>(w + o_dist), reinterpret_cast<uint32_t *>(w + o_s2));
+    if (rc != AOMHIP_OK) return rc;
+  }
+  hipLaunchKernelGGL(sms_fullmv_result_kernel, dim3(g), dim3(256), 0, ctx->stream, fmv, fcost, n, sub ? 0 : 1, d_best_mv);
+  AOMHIP_LAUNCH_CHECK();
+  if (!pred) return AOMHIP_OK;
+  // av1_enc_build_inter_predictor(.., AOM_PLANE_Y, AOM_PLANE_Y) with interp_filters = EIGHTTAP_REGULAR (:944, :1029-1031)
+  rc = aomhip_build_inter_pred_batch(ctx, ref, frame, pred, pred_frame, bw, bh, d_blocks, d_best_mv, n, AOMHIP_INTERP_REGULAR, AOMHIP_INTERP_REGULAR);
+  if (rc != AOMHIP_OK || !d_sse) return rc;
+  const unsigned gv = (unsigned)((n1 + 3) / 4);
+  if (src->bit_depth == 8)
+    hipLaunchKernelGGL(sms_var_kernel<uint8_t>, dim3(gv), dim3(256), 0, ctx->stream, view_of<uint8_t>(*src), frame, view_of<uint8_t>(*pred), pred_frame, bw, bh,
+                       src->bit_depth, d_blocks, n, d_sse, d_var);
+  else
+    hipLaunchKernelGGL(sms_var_kernel<uint16_t>, dim3(gv), dim3(256), 0, ctx->stream, view_of<uint16_t>(*src), frame, view_of<uint16_t>(*pred), pred_frame, bw,
+                       bh, src->bit_depth, d_blocks, n, d_sse, d_var);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}

@@ -722,6 +722,28 @@ typedef struct aomhip_variance_vtable {
  * entry keeps the reference's value.  These are the one-launch-per-call conformance functions. */
 int aomhip_bind_variance_vtable(aomhip_variance_vtable *table, int bit_depth);
 
+/* ------------------------------------------------------------------ the partition-pruning search: av1_simple_motion_search / _sse_var */
+
+/* av1_simple_motion_search (av1/encoder/motion_search_facade.c:925-1037) for a list of blocks of ONE size against one reference frame --
+ * what simple_motion_search_get_best_ref / av1_simple_motion_search_sse_var (av1/encoder/partition_strategy.c) issue per square block of
+ * a superblock's tree; the blocks of one tree level are independent (a level's start MVs are the parent level's results), so a level
+ * of every superblock of the frame is one call:
+ *   av1_full_pixel_search from the block's start_row / start_col (FULLPEL start_mv) with ref_mv = 0 and the limits
+ *   av1_set_mv_search_range(&x->mv_limits, &kZeroMv); `full`: what av1_make_default_fullpel_ms_params sets (search_method =
+ *   sf.mv_sf.search_method, step_param = min(mv_step_param + sf.part_sf.simple_motion_search_reduce_search_steps, MAX_MVSEARCH_STEPS - 2));
+ *   `sub` != NULL (use_subpixel and !cur_frame_force_integer_mv): the sub-pel search from get_mv_from_fullmv(best) for every block whose
+ *   full-pel search returned less than INT_MAX (forced_stop = sf.mv_sf.simple_motion_subpel_force_stop), else convert_fullmv_to_mv;
+ *   pred != NULL: the EIGHTTAP_REGULAR luma predictor of every block at its result, written to frame pred_frame of `pred` at the
+ *   block's position (av1_enc_build_inter_predictor, :1029-1031);
+ *   d_sse / d_var != NULL: fn_ptr[bsize].vf(src, pred) per block -- av1_simple_motion_sse_var (:1039-1060).
+ * Blocks: bx / by, start_row / start_col in full pels, row/col min/max = x->mv_limits (raw); ref_* ignored (ref_mv is kZeroMv).
+ * d_best_mv: (row, col) in 1/8 pel. */
+int aomhip_simple_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                      const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list,
+                                      const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                      const aomhip_search_block *d_blocks, int n_blocks, const aomhip_planes *pred, int pred_frame,
+                                      int16_t *d_best_mv, uint32_t *d_sse, uint32_t *d_var);
+
 /* Full-pel motion-compensated prediction for the frame-level pipeline: pred block i = reference block at
  * (bx + mv.col, by + mv.row) with mv = d_fullpel_mv[2i], [2i+1] (row, col), i.e. av1_build_inter_predictor
  * (av1/common/reconinter.c) for an integer MV, where the convolve is aom_convolve_copy. */

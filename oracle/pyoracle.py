@@ -1031,3 +1031,32 @@ def motion_estimation_batch(src_b, ref_b, border, w, h, blocks, q, sub, use_cost
     mv, err, dist, sse = subpel_tree_batch(src_b, ref_b, border, w, h, sl, mvjcost=mvjcost, mvcost0=mvcost0, mvcost1=mvcost1,
                                            cost_lists=cl if use_cost_list else None, bd=bd, threads=threads, **sub)
     return mv, err, dist, sse, full_mv
+
+
+def simple_motion_search_batch(src_b, ref_b, border, width, height, w, h, blocks, q, sub=None, use_cost_list=0, mvjcost=None, mvcost0=None, mvcost1=None, bd=8,
+                               threads=4):
+    """av1_simple_motion_search + av1_simple_motion_sse_var (motion_search_facade.c:925-1060) as a composition of the pinned pieces:
+    blocks: start_* = FULLPEL start_mv, limits = raw x->mv_limits, ref_mv = 0.  sub: kwargs of subpel_tree_batch or None (no sub-pel
+    stage).  -> (mv [n, 2] 1/8 pel, sse, var, pred plane)"""
+    fl, sl = np.array(blocks, copy=True), np.array(blocks, copy=True)
+    fl["ref_row"] = fl["ref_col"] = sl["ref_row"] = sl["ref_col"] = 0
+    for i, b in enumerate(blocks):
+        raw = (b["row_min"], b["row_max"], b["col_min"], b["col_max"])
+        fl["row_min"][i], fl["row_max"][i], fl["col_min"][i], fl["col_max"][i] = set_mv_search_range(raw, 0, 0)
+        sl["row_min"][i], sl["row_max"][i], sl["col_min"][i], sl["col_max"][i] = set_subpel_mv_search_range(raw, 0, 0)
+    full_mv, cost, cl, _ = full_pixel_search_batch(src_b, ref_b, border, w, h, fl, q, mvjcost, mvcost0, mvcost1, bd=bd, threads=threads)
+    mv = full_mv.astype(np.int32) * 8
+    if sub is not None:
+        sl["start_row"], sl["start_col"] = mv[:, 0], mv[:, 1]
+        smv, _, _, _ = subpel_tree_batch(src_b, ref_b, border, w, h, sl, mvjcost=mvjcost, mvcost0=mvcost0, mvcost1=mvcost1,
+                                         cost_lists=cl if use_cost_list else None, bd=bd, threads=threads, **sub)
+        ok = np.asarray(cost) != 2147483647
+        mv[ok] = smv[ok]
+    mv = mv.astype(np.int16)
+    pred = build_inter_pred(ref_b, border, width, height, w, h, blocks, mv, 0, 0, bd=bd)
+    sse, var = np.zeros(len(blocks), np.uint32), np.zeros(len(blocks), np.uint32)
+    src_vis = src_b[border:border + height, border:border + width]
+    for i, b in enumerate(blocks):
+        x, y = int(b["bx"]), int(b["by"])
+        var[i], sse[i], _ = variance(np.ascontiguousarray(src_vis), y, x, pred, y, x, w, h, bd=bd)
+    return mv, sse, var, pred
