@@ -225,6 +225,7 @@ _protos = {
     "aomhip_tile_column_bounds": (C.c_int, [_i, _i, _i, _vp]),
     "aomhip_recon_exchange_plan": (C.c_int, [_i, _i, _vp, _i, _i, _vp, _vp]),
     "aomhip_comm_unique_id": (C.c_int, [_vp]),
+    "aomhip_deblock_plane_fused": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _i, _i]),
     "aomhip_simple_motion_search_batch": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "aomhip_tf_apply_frames": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "aomhip_comm_init": (C.c_int, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
@@ -352,6 +353,10 @@ class Context:
         fp = None if frame_present is None else np.ascontiguousarray(frame_present, np.uint8)
         check(lib.aomhip_tf_motion_search_frames(self.h, C.byref(frames), filter_frame, None if fp is None else fp.ctypes.data, C.byref(params),
                                                  d_blocks, n_blocks, d_mvs, d_mses, d_ref_mv), "aomhip_tf_motion_search_frames")
+
+    def deblock_plane_fused(self, src, src_frame, dst, dst_frame, d_params, units_stride, sharpness=0):
+        check(lib.aomhip_deblock_plane_fused(self.h, C.byref(src), src_frame, C.byref(dst), dst_frame, d_params, units_stride, sharpness),
+              "aomhip_deblock_plane_fused")
 
     def simple_motion_search_batch(self, src, ref, frame, bw, bh, full, sub, use_cost_list, d_blocks, n, pred, pred_frame, d_mv, d_sse=None, d_var=None,
                                    d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):

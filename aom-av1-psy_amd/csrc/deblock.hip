@@ -223,6 +223,151 @@ __global__ __launch_bounds__(kDbThreads) void deblock_horz_kernel(PIX *origin, i
   }
 }
 
+// ---- Both passes in ONE launch, out of place (aomhip_deblock_plane_fused).  A workgroup produces a kFW x kFH tile of the output:
+// it stages the tile + an 8-pixel halo on every side in LDS (as 16-bit pixels), filters every vertical edge that touches the staged
+// region's tile columns -- for the halo ROWS too: the horizontal edges at the tile's top and bottom read vertically filtered pixels
+// 7 rows outside it -- then every horizontal edge of the tile (inclusive of both boundary rows), and stores the tile.  The plane is
+// read 1.4 x (the halos come out of L2: neighbouring tiles run at the same time) and written once, instead of read twice and
+// written twice; the halo's vertical edges are filtered twice (1.25 x the vertical-edge arithmetic).  In place this would race with
+// the neighbours' stores -- hence source and destination planes.  Edge zones are disjoint (see the header of this file), so the
+// order of the edges inside a pass is free and every intermediate equals the two-launch form's.
+constexpr int kFW = 128, kFH = 64, kFHalo = 8;
+constexpr int kFRows = kFH + 2 * kFHalo, kFCols = kFW + 2 * kFHalo;   // 80 x 144 staged pixels
+constexpr int kFPitch = 148;                                            // LDS row pitch in pixels: 74 dwords = 2 * (5 r mod 32) banks over 32 rows
+constexpr int kFUCols = kFW / 4 + 1, kFURows = kFRows / 4;              // 33 x 20 edge-parameter records
+
+template <typename PIX>
+__global__ __launch_bounds__(kDbThreads) void deblock_fused_kernel(const PIX *__restrict__ src_origin, int src_stride, PIX *__restrict__ dst_origin,
+                                                                   int dst_stride, int width, int height, int border,
+                                                                   const uint8_t *__restrict__ params, int units_stride, int sharpness, int bd) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[kFRows * kFPitch];
+  __shared__ uint32_t sp[kFURows * kFUCols];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * kFW, y0 = blockIdx.y * kFH;
+  const int ucols = (width + 3) >> 2, urows = (height + 3) >> 2;
+  // 1. stage pixels (8 per step; coordinates clamped into the bordered plane: what lies outside the frame is never used by an edge
+  //    that is filtered) and the edge-parameter records of the region
+  for (int q = tid; q < kFRows * (kFCols / 8); q += kDbThreads) {
+    const int r = q / (kFCols / 8), c8 = q - r * (kFCols / 8);
+    const int y = min(max(y0 - kFHalo + r, -border), height + border - 1);
+    const int x = x0 - kFHalo + c8 * 8;
+    uint16_t v[8];
+    if (x >= -border && x + 8 <= width + border) {
+      const PIX *p = src_origin + (int64_t)y * src_stride + x;
+      if constexpr (sizeof(PIX) == 2) {
+        const DU128 w = *reinterpret_cast<const DU128 *>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (uint16_t)(w.v[i / 2] >> (16 * (i % 2)));
+      } else {
+        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(p)), w1 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(p) + 4);
+        // (byte loads would do as well: 8-bit planes are not the measured path; the two dword loads need p 4-byte aligned, else scalar)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (uint16_t)(((i < 4 ? w0 : w1) >> (8 * (i % 4))) & 0xFF);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int xc = min(max(x + i, -border), width + border - 1);
+        v[i] = (uint16_t)src_origin[(int64_t)y * src_stride + xc];
+      }
+    }
+    uint32_t *t = reinterpret_cast<uint32_t *>(&tile[r * kFPitch + c8 * 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = (uint32_t)v[2 * i] | ((uint32_t)v[2 * i + 1] << 16);
+  }
+  for (int q = tid; q < kFURows * kFUCols; q += kDbThreads) {
+    const int ur = q / kFUCols, uc = q - ur * kFUCols;
+    const int uy = (y0 - kFHalo) / 4 + ur, ux = x0 / 4 + uc;   // (y0 - 8 is a multiple of 4: the division is exact, also at y0 = 0)
+    uint32_t rec = 0;
+    if (uy >= 0 && uy < urows && ux >= 0 && ux < ucols) rec = *reinterpret_cast<const uint32_t *>(params + ((size_t)uy * units_stride + ux) * 4);
+    sp[q] = rec;
+  }
+  __syncthreads();
+  // 2. vertical edges: item = (edge column e, staged row r); consecutive lanes take consecutive rows (conflict-free at this pitch)
+  for (int q = tid; q < kFUCols * kFRows; q += kDbThreads) {
+    const int e = q / kFRows, r = q - e * kFRows;
+    const int y = y0 - kFHalo + r, ux = x0 / 4 + e;
+    if (ux <= 0 || ux >= ucols || y < 0 || y >= height) continue;
+    const uint32_t rec = sp[(r >> 2) * kFUCols + e];
+    const int len = rec & 0xFF, level = (rec >> 8) & 0xFF;
+    if (len == 0 || level == 0) continue;
+    uint16_t *row = &tile[r * kFPitch + 4 * e];   // pixels x - 8 .. x + 7 of the edge at x = x0 + 4 e (q0 = row[8])
+    uint32_t w[8];
+    {
+      const uint2 a = *reinterpret_cast<const uint2 *>(row), b = *reinterpret_cast<const uint2 *>(row + 4), c = *reinterpret_cast<const uint2 *>(row + 8),
+                  d = *reinterpret_cast<const uint2 *>(row + 12);
+      w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y; w[4] = c.x; w[5] = c.y; w[6] = d.x; w[7] = d.y;
+    }
+    int x[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) x[i] = (w[(i + 1) / 2] >> (16 * ((i + 1) % 2))) & 0xFFFF;
+    lpf_window(x, len, level, sharpness, bd);
+    // the edge's own zone: p5 .. q5 (len 14), p2 .. q2 (8), p1 .. q1 (4, 6) -- pairs of pixels at dword-aligned positions
+    if (len == 14) {
+#pragma unroll
+      for (int i = 1; i <= 11; i += 2) *reinterpret_cast<uint32_t *>(row + i + 1) = (uint32_t)x[i] | ((uint32_t)x[i + 1] << 16);
+    } else if (len == 8) {
+      row[5] = (uint16_t)x[4];
+      *reinterpret_cast<uint32_t *>(row + 6) = (uint32_t)x[5] | ((uint32_t)x[6] << 16);
+      *reinterpret_cast<uint32_t *>(row + 8) = (uint32_t)x[7] | ((uint32_t)x[8] << 16);
+      row[10] = (uint16_t)x[9];
+    } else {
+      *reinterpret_cast<uint32_t *>(row + 6) = (uint32_t)x[5] | ((uint32_t)x[6] << 16);
+      *reinterpret_cast<uint32_t *>(row + 8) = (uint32_t)x[7] | ((uint32_t)x[8] << 16);
+    }
+  }
+  __syncthreads();
+  // 3. horizontal edges of the tile: item = (edge row k, pixel column pair); the two columns of a pair share their 4x4 unit's record
+  for (int q = tid; q < (kFH / 4 + 1) * (kFW / 2); q += kDbThreads) {
+    const int k = q / (kFW / 2), c2 = q - k * (kFW / 2);
+    const int uy = y0 / 4 + k, xg = x0 + 2 * c2;
+    if (uy <= 0 || uy >= urows || xg >= width) continue;
+    const uint32_t rec = sp[(k + kFHalo / 4) * kFUCols + (c2 >> 1)];
+    const int len = (rec >> 16) & 0xFF, level = rec >> 24;
+    if (len == 0 || level == 0) continue;
+    const int reach = len == 14 ? 7 : (len == 8 ? 4 : (len == 6 ? 3 : 2));
+    uint32_t *col = reinterpret_cast<uint32_t *>(&tile[(kFHalo + 4 * k) * kFPitch + kFHalo + 2 * c2]);   // q0 of both columns
+    constexpr int kPd = kFPitch / 2;
+    int xa[14], xb[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      const int t = i - 7;
+      const uint32_t v = (t >= -reach && t < reach) ? col[t * kPd] : 0u;
+      xa[i] = v & 0xFFFF; xb[i] = v >> 16;
+    }
+    lpf_window(xa, len, level, sharpness, bd);
+    if (xg + 1 < width) lpf_window(xb, len, level, sharpness, bd);
+    const int wr = len == 14 ? 6 : (len == 8 ? 3 : 2);
+#pragma unroll
+    for (int i = 1; i <= 12; ++i) {
+      const int t = i - 7;
+      if (t >= -wr && t < wr) col[t * kPd] = (uint32_t)xa[i] | ((uint32_t)xb[i] << 16);
+    }
+  }
+  __syncthreads();
+  // 4. store the tile
+  for (int q = tid; q < kFH * (kFW / 8); q += kDbThreads) {
+    const int r = q / (kFW / 8), c8 = q - r * (kFW / 8);
+    const int y = y0 + r, x = x0 + c8 * 8;
+    if (y >= height || x >= width) continue;
+    const uint32_t *t = reinterpret_cast<const uint32_t *>(&tile[(r + kFHalo) * kFPitch + kFHalo + c8 * 8]);
+    PIX *o = dst_origin + (int64_t)y * dst_stride + x;
+    if (x + 8 <= width) {
+      if constexpr (sizeof(PIX) == 2) {
+        DU128 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w.v[i] = t[i];
+        *reinterpret_cast<DU128 *>(o) = w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[2 * i] = (PIX)(t[i] & 0xFF); o[2 * i + 1] = (PIX)((t[i] >> 16) & 0xFF); }
+      }
+    } else {
+      for (int i = 0; i < 8 && x + i < width; ++i) o[i] = (PIX)((t[i / 2] >> (16 * (i % 2))) & 0xFFFF);
+    }
+  }
+}
+
 // aom_get_sse_plane -> get_sse / highbd_get_sse (aom_dsp/psnr.c:84-198): the sum of squared differences of two whole planes, one
 // atomic per workgroup.
 template <typename T>
@@ -291,6 +436,38 @@ int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, con
                          units_stride, sharpness, p->bit_depth);
     AOMHIP_LAUNCH_CHECK();
   }
+  return AOMHIP_OK;
+}
+
+int aomhip_deblock_plane_fused(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dst, int dst_frame,
+                               const uint8_t *d_edge_params, int units_stride, int sharpness) {
+  if (!ctx || !src || !dst || !src->base || !dst->base || !d_edge_params || src_frame < 0 || src_frame >= src->n_frames || dst_frame < 0 ||
+      dst_frame >= dst->n_frames || sharpness < 0 || sharpness > 7 || units_stride < (src->width + 3) / 4 || src->width != dst->width ||
+      src->height != dst->height || src->bit_depth != dst->bit_depth) {
+    set_error("aomhip_deblock_plane_fused: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (src->base == dst->base && src_frame == dst_frame) {
+    set_error("aomhip_deblock_plane_fused: source and destination must be different frames (tiles read their neighbours' unfiltered halo)");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (src->border < 8) {
+    set_error("aomhip_deblock_plane_fused: the source plane needs a border of >= 8 pixels (has %d)", src->border);
+    return AOMHIP_ERR_INVALID;
+  }
+  const size_t esz = src->bit_depth == 8 ? 1 : 2;
+  const char *so = static_cast<const char *>(src->base) + ((size_t)src_frame * src->frame_stride + (size_t)src->border * src->stride + src->border) * esz;
+  char *dor = static_cast<char *>(dst->base) + ((size_t)dst_frame * dst->frame_stride + (size_t)dst->border * dst->stride + dst->border) * esz;
+  const dim3 grid((src->width + kFW - 1) / kFW, (src->height + kFH - 1) / kFH);
+  if (esz == 1)
+    hipLaunchKernelGGL(deblock_fused_kernel<uint8_t>, grid, dim3(kDbThreads), 0, ctx->stream, reinterpret_cast<const uint8_t *>(so), src->stride,
+                       reinterpret_cast<uint8_t *>(dor), dst->stride, src->width, src->height, src->border, d_edge_params, units_stride, sharpness,
+                       src->bit_depth);
+  else
+    hipLaunchKernelGGL(deblock_fused_kernel<uint16_t>, grid, dim3(kDbThreads), 0, ctx->stream, reinterpret_cast<const uint16_t *>(so), src->stride,
+                       reinterpret_cast<uint16_t *>(dor), dst->stride, src->width, src->height, src->border, d_edge_params, units_stride, sharpness,
+                       src->bit_depth);
+  AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
 

@@ -606,6 +606,8 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
     capi = pkg.capi
     pred = ctx.planes_alloc(W, H, border, bd, F)  # slot f: prediction, then reconstruction, of ring frame f
     out = ctx.planes_alloc(W, H, border, bd, 1)
+    dbk = ctx.planes_alloc(W, H, border, bd, 1)
+    fused_deblock = os.environ.get("AOMHIP_BENCH_DEBLOCK", "fused") != "two_pass"
     n = sp.n
     nc = 256
     d_q, d_dq, d_e = ctx.malloc(n * nc * 4), ctx.malloc(n * nc * 4), ctx.malloc(2 * n)
@@ -630,8 +632,14 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
         # grid mode: block i of the plane == block i of the raster list used above
         ctx.subtract_xform_quant_batch(sp.src, pred, f, 2, None, n, W // 16, 0, qp, None, d_q, d_dq, d_e)
         ctx.inv_txfm_add_batch(d_dq, 2, None, n, W // 16, 0, d_e, pred, f)
-        ctx.deblock_plane(pred, f, d_params, W // 4, 0, 3)
-        ctx.cdef_luma_plane(pred, f, out, 0, d_pri, d_sec, fbw, d_skip, 6)
+        # both deblocking passes in one launch, out of place into `dbk` (CDEF reads a second buffer anyway); AOMHIP_BENCH_DEBLOCK=two_pass
+        # keeps the in-place vertical + horizontal launches
+        if fused_deblock:
+            ctx.deblock_plane_fused(pred, f, dbk, 0, d_params, W // 4, 0)
+            ctx.cdef_luma_plane(dbk, 0, out, 0, d_pri, d_sec, fbw, d_skip, 6)
+        else:
+            ctx.deblock_plane(pred, f, d_params, W // 4, 0, 3)
+            ctx.cdef_luma_plane(pred, f, out, 0, d_pri, d_sec, fbw, d_skip, 6)
 
     for _ in range(warmup):
         frame()
@@ -658,10 +666,11 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
         "subtract_xform_quant_16x16": lambda: ctx.subtract_xform_quant_batch(sp.src, pred, f0, 2, None, n, W // 16, 0, qp, None, d_q, d_dq, d_e),
         "inv_txfm_add_16x16": lambda: ctx.inv_txfm_add_batch(d_dq, 2, None, n, W // 16, 0, d_e, pred, f0),
         "deblock_vert+horz": lambda: ctx.deblock_plane(pred, f0, d_params, W // 4, 0, 3),
+        "deblock_fused": lambda: ctx.deblock_plane_fused(pred, f0, dbk, 0, d_params, W // 4, 0),
         "cdef_luma": lambda: ctx.cdef_luma_plane(pred, f0, out, 0, d_pri, d_sec, fbw, d_skip, 6),
     }
     stage_bytes = {"inter_pred_8tap": 2 * px_bytes, "subtract_xform_quant_16x16": 2 * px_bytes + n * (256 * 8 + 2),
-                   "inv_txfm_add_16x16": n * 256 * 4 + 2 * px_bytes, "deblock_vert+horz": 2 * 2 * px_bytes, "cdef_luma": 2 * px_bytes}
+                   "inv_txfm_add_16x16": n * 256 * 4 + 2 * px_bytes, "deblock_vert+horz": 2 * 2 * px_bytes, "deblock_fused": 2 * px_bytes, "cdef_luma": 2 * px_bytes}
     stages = {}
     for name, fn in stage_fns.items():
         ms = kernel_avg_ms(ctx, fn, max(steps, 8))
@@ -671,7 +680,7 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
             stages[name]["frac_of_8TBs"] = stages[name]["algorithmic_GBs"] / HBM_PEAK_GBS
     return {"workload": "encode_inner_loop_4k_10bit", "value": steps / wall, "unit": "frames/s",
             "ms_per_frame": wall / steps * 1e3, "event_ms_per_frame": ev_ms / steps, "blocks_per_frame": n,
-            "recon_psnr_db_last_frame": float(psnr), "stages": stages,
+            "recon_psnr_db_last_frame": float(psnr), "stages": stages, "deblock_in_frame": "fused" if fused_deblock else "two_pass",
             "config": {"frame": "3840x2160 10-bit luma", "stages": "fullpel diamond + subpel bilinear (16x16) -> inter prediction at the "
                        "sub-pel MV (8-tap regular, av1_highbd_convolve_2d_sr) -> subtract+fwd_txfm2d_16x16+quantize_b q100 -> inv_txfm_add -> deblock (8x8 edges, level 32) -> "
                        "CDEF (pri 4, sec 2, damping 6)", "gpus": 1}}
@@ -1189,7 +1198,7 @@ def main():
         print(json.dumps({"metric": "encode inner loop frames/s", "value": r["value"], "unit": "frames/s", "n_gpus": 1,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_frame"], "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-                          "config": dict(r["config"], workload=r["workload"]), "stages": r["stages"],
+                          "config": dict(r["config"], workload=r["workload"]), "stages": r["stages"], "deblock_in_frame": r["deblock_in_frame"],
                           "recon_psnr_db_last_frame": r["recon_psnr_db_last_frame"]}))
         return
     if args.workload == "default_search_4k_10bit":  # informational: NSTEP full-pel + 8-tap sub-pel tree (single GPU)

@@ -373,6 +373,13 @@ int aomhip_inv_txfm_add_batch(aomhip_ctx *ctx, const int32_t *d_dqcoeff, int tx_
  * horizontal edges; 3 runs both in the reference's order (all vertical, then all horizontal). */
 int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, const uint8_t *d_edge_params,
                          int units_stride, int sharpness, int passes);
+/* The same two passes in ONE launch, out of place: frame src_frame of `src` is read, frame dst_frame of `dst` (same geometry; a
+ * different frame) receives the deblocked plane -- every pixel, filtered or not.  Each pixel is read ~1.4 times (tile halos, served
+ * by L2) and written once instead of read and written twice; the results are identical to aomhip_deblock_plane with passes = 3.
+ * What the in-loop chain uses when the next stage (CDEF) reads from a second buffer anyway.  `src` needs a border of >= 8 pixels. */
+int aomhip_deblock_plane_fused(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dst, int dst_frame,
+                               const uint8_t *d_edge_params, int units_stride, int sharpness);
+
 
 /* aom_get_sse_plane / aom_get_y_sse / aom_highbd_get_y_sse (aom_dsp/psnr.c:84-330): the sum of squared differences of two
  * whole planes (the PSNR numerator of aom_calc_psnr, and try_filter_frame's error measure); *d_sse is overwritten. */

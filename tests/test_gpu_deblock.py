@@ -139,3 +139,49 @@ def test_mode_info_grid_to_filtered_planes(hip, oracle, ctx, bd):
     for d in (d_pri, d_sec, d_skip):
         ctx.free(d)
     ctx.planes_free(ps); ctx.planes_free(pd)
+
+
+def _run_fused(hip, ctx, pix, params, bd, sharp, border=32):
+    H, W = pix.shape
+    p, q = ctx.planes_alloc(W, H, border, bd, 2), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(p, 1, pix)
+    d = ctx.to_device(params)
+    ctx.deblock_plane_fused(p, 1, q, 0, d, params.shape[1], sharp)
+    out = ctx.planes_download(q, 0)[border:border + H, border:border + W]
+    src_after = ctx.planes_download(p, 1)[border:border + H, border:border + W]
+    ctx.planes_free(p); ctx.planes_free(q); ctx.free(d)
+    assert np.array_equal(src_after, pix)  # out of place: the source is untouched
+    return out
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("chroma", [False, True])
+def test_fused_single_launch_equals_the_two_passes(hip, oracle, ctx, bd, chroma):
+    """aomhip_deblock_plane_fused (one launch, LDS tiles with halos, out of place) == the oracle's vertical-then-horizontal result on random
+    transform partitions: sizes that are not multiples of the 128 x 64 tile, every length, all sharpness values."""
+    rng = np.random.default_rng(100 + bd * 2 + chroma)
+    changed = False
+    for trial in range(5):
+        W, H = int(rng.choice([64, 136, 200, 384, 520])), int(rng.choice([64, 72, 136, 192]))
+        pix = _content(rng, W, H, bd)
+        params = oracle.random_edge_params(rng, W, H, chroma=chroma)
+        sharp = int(rng.integers(0, 8))
+        want = oracle.deblock_plane(pix, params, sharp, bd, order=0)
+        got = _run_fused(hip, ctx, pix, params, bd, sharp, border=int(rng.choice([8, 32, 160])))
+        assert np.array_equal(got, want), (bd, chroma, trial, W, H)
+        changed |= not np.array_equal(want, pix)
+    assert changed
+
+
+def test_fused_full_size_4k_10bit(hip, oracle, ctx):
+    rng = np.random.default_rng(4)
+    W, H, bd = 3840, 2160, 10
+    pix = _content(rng, W, H, bd)
+    params = np.zeros((H // 4, W // 4, 4), np.uint8)
+    # left half: 8x8 transforms (8-tap edges every 8 pixels); right half: 16x16 transforms (14-tap edges every 16) -- edge zones never overlap
+    hw = (W // 8) // 4 * 4   # unit column where the 16x16 region starts (a multiple of 16 pixels)
+    params[:, 2:hw:2, 0] = 8; params[:, 2:hw:2, 1] = 32; params[2::2, :hw, 2] = 8; params[2::2, :hw, 3] = 32
+    params[:, hw::4, 0] = 14; params[:, hw::4, 1] = 40; params[4::4, hw:, 2] = 14; params[4::4, hw:, 3] = 40
+    params[:, hw, 0] = 8   # (the seam: an 8x8 transform on its left side limits the edge to 8 taps, as get_filter_length does)
+    want = oracle.deblock_plane(pix, params, 0, bd, order=0)
+    assert np.array_equal(_run_fused(hip, ctx, pix, params, bd, 0, border=160), want)
