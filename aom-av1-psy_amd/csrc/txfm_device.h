@@ -49,19 +49,26 @@ __device__ __forceinline__ int32_t rshift(int32_t x, int bit) { return (x >> bit
 __device__ __forceinline__ int32_t rshift64(int64_t v, int bit) { return (int32_t)((v + ((int64_t)1 << (bit - 1))) >> bit); }
 
 // half_btf (av1_txfm.h:80-102): 32-bit wrapping products, 64-bit sum + rounding, shift.
-#ifndef AOMHIP_EXPERIMENT_FAST_BTF
-#define AOMHIP_EXPERIMENT_FAST_BTF 0
-#endif
+// The template argument of every network below carries one extra flag on top of the cos bit: BIT = cos_bit + kFastBtf selects the FAST
+// butterfly -- two 24-bit multiply-adds into a 32-bit wrapping sum, one arithmetic shift: 3 instructions instead of 9 -- which equals
+// half_btf whenever both operands lie inside (-2^23, 2^23) (the 32-bit result of v_mad_i32_i24 is then the low half of the exact product,
+// i.e. the reference's wrapped product) and the exact sum w0 a + w1 b + 2^(bit-1) fits int32.  Callers may only set the flag for blocks
+// whose residual magnitude is at most kSafeMax[tx_size][tx_type] (txfm_safe_max.inc): oracle/aomref_txfm.c's interval analysis proves
+// both conditions for every butterfly of both passes under that bound (oracle/gen_txfm_bounds.py; tests/test_oracle_txfm_bounds.py).
+// Every 8- and 10-bit video residual qualifies at every size; other inputs take the exact form.  The forward transform + quantise
+// kernels were VALU-issue bound on exactly these butterflies (profiles/r02_txq.md, r03_txq.md).
+constexpr int kFastBtf = 32;
 template <int BIT> __device__ __forceinline__ int32_t hbtf(int32_t w0, int32_t a, int32_t w1, int32_t b) {
-#if AOMHIP_EXPERIMENT_FAST_BTF
-  // 24-bit multiply-adds, 32-bit wrapping sum (valid when |a|,|b| < 2^23 and the rounded sum fits 32 bits)
-  return (int32_t)((uint32_t)__mul24(w0, a) + (uint32_t)__mul24(w1, b) + (1u << (BIT - 1))) >> BIT;
-#else
-  const int32_t p0 = (int32_t)((uint32_t)w0 * (uint32_t)a);
-  const int32_t p1 = (int32_t)((uint32_t)w1 * (uint32_t)b);
-  const int64_t s = (int64_t)p0 + (int64_t)p1 + ((int64_t)1 << (BIT - 1));
-  return (int32_t)(s >> BIT);
-#endif
+  constexpr int B = BIT & 31;
+  if constexpr (BIT >= kFastBtf) {
+    // (unsigned adds: the partial sums may wrap, only the total is known to fit; the compiler fuses them into v_mad_i32_i24)
+    return (int32_t)((uint32_t)__mul24(w0, a) + (uint32_t)__mul24(w1, b) + (1u << (B - 1))) >> B;
+  } else {
+    const int32_t p0 = (int32_t)((uint32_t)w0 * (uint32_t)a);
+    const int32_t p1 = (int32_t)((uint32_t)w1 * (uint32_t)b);
+    const int64_t s = (int64_t)p0 + (int64_t)p1 + ((int64_t)1 << (B - 1));
+    return (int32_t)(s >> B);
+  }
 }
 __device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
@@ -86,7 +93,7 @@ template <int M, int J, int BIT, int OFF, int NN> __device__ __forceinline__ voi
     const int run = (l - g / 2) / (2 * g);
     const int a = (J == 1) ? 32 : base * (1 + 4 * bitrevc(run, J - 2));
     const int h = M - 1 - l;
-    const int32_t ca = kCospi[BIT - 10][a], cb = kCospi[BIT - 10][64 - a];
+    const int32_t ca = kCospi[(BIT & 31) - 10][a], cb = kCospi[(BIT & 31) - 10][64 - a];
     const int32_t lo = x[OFF + l], hi = x[OFF + h];
     if (pos < g / 2 || J == 1) {
       x[OFF + l] = hbtf<BIT>(-ca, lo, cb, hi);
@@ -121,7 +128,7 @@ template <int M, bool INV, int BIT, int OFF, int NN> __device__ __forceinline__ 
   for (int l = 0; l < M / 2; ++l) {
     const int h = M - 1 - l;
     const int th = bitrevc(M + l, LN) * 64 / N;
-    const int32_t c = kCospi[BIT - 10][64 - th], s = kCospi[BIT - 10][th];
+    const int32_t c = kCospi[(BIT & 31) - 10][64 - th], s = kCospi[(BIT & 31) - 10][th];
     const int32_t lo = x[OFF + l], hi = x[OFF + h];
     if (!INV) {
       x[OFF + l] = hbtf<BIT>(c, lo, s, hi);
@@ -150,7 +157,7 @@ template <int M, int J, bool INV, int BIT, int CB, int OFF, int NN> struct DctOd
 // in-place on x[0..N), natural (pre bit-reversal) order
 template <int N, int BIT, int NN> __device__ __forceinline__ void fdct_rec(int32_t (&x)[NN]) {
   if constexpr (N == 2) {
-    const int32_t c = kCospi[BIT - 10][32];
+    const int32_t c = kCospi[(BIT & 31) - 10][32];
     const int32_t a = x[0], b = x[1];
     x[0] = hbtf<BIT>(c, a, c, b);
     x[1] = hbtf<BIT>(-c, b, c, a);
@@ -168,7 +175,7 @@ template <int N, int BIT, int NN> __device__ __forceinline__ void fdct_rec(int32
 }
 template <int N, int BIT, int CB, int NN> __device__ __forceinline__ void idct_rec(int32_t (&x)[NN]) {
   if constexpr (N == 2) {
-    const int32_t c = kCospi[BIT - 10][32];
+    const int32_t c = kCospi[(BIT & 31) - 10][32];
     const int32_t a = x[0], b = x[1];
     x[0] = hbtf<BIT>(c, a, c, b);
     x[1] = hbtf<BIT>(c, a, -c, b);
@@ -200,7 +207,7 @@ template <int N, int S, int BIT> __device__ __forceinline__ void adst_level_rot(
     for (int q = 0; q < pairs; ++q) {
       const int p = gb + half + 2 * q;
       const int a = base * (1 + 4 * bitrevc(q % nP, ilog2c(nP)));
-      const int32_t ca = kCospi[BIT - 10][a], cb = kCospi[BIT - 10][64 - a];
+      const int32_t ca = kCospi[(BIT & 31) - 10][a], cb = kCospi[(BIT & 31) - 10][64 - a];
       const int32_t x = v[p], y = v[p + 1];
       if (q < nP) {
         v[p] = hbtf<BIT>(ca, x, cb, y);
@@ -228,7 +235,7 @@ template <int N, int BIT> __device__ __forceinline__ void adst_final_rot(int32_t
 #pragma unroll
   for (int q = 0; q < N / 2; ++q) {
     const int a = (1 + 4 * q) * 32 / N;
-    const int32_t ca = kCospi[BIT - 10][a], cb = kCospi[BIT - 10][64 - a];
+    const int32_t ca = kCospi[(BIT & 31) - 10][a], cb = kCospi[(BIT & 31) - 10][64 - a];
     const int32_t x = v[2 * q], y = v[2 * q + 1];
     v[2 * q] = hbtf<BIT>(ca, x, cb, y);
     v[2 * q + 1] = hbtf<BIT>(cb, x, -ca, y);
@@ -253,31 +260,31 @@ template <int N, int S, bool INV, int BIT, int CB> struct AdstLevels {
 // av1_fadst4 (av1_fwd_txfm1d.c:676-733): all products / sums wrap at 32 bits
 template <int BIT> __device__ __forceinline__ void fadst4(int32_t (&x)[4]) {
   const uint32_t x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
-  constexpr uint32_t s1 = kSinpi[BIT - 10][1], s2 = kSinpi[BIT - 10][2], s3 = kSinpi[BIT - 10][3],
-                     s4 = kSinpi[BIT - 10][4];
+  constexpr uint32_t s1 = kSinpi[(BIT & 31) - 10][1], s2 = kSinpi[(BIT & 31) - 10][2], s3 = kSinpi[(BIT & 31) - 10][3],
+                     s4 = kSinpi[(BIT & 31) - 10][4];
   const uint32_t a = s1 * x0 + s2 * x1 + s4 * x3;
   const uint32_t b = s3 * (x0 + x1 - x3);
   const uint32_t c = s4 * x0 - s1 * x1 + s2 * x3;
   const uint32_t d = s3 * x2;
   // an all-zero input gives all-zero output through the same formula (the reference's early-out)
-  x[0] = rshift((int32_t)(a + d), BIT);
-  x[1] = rshift((int32_t)b, BIT);
-  x[2] = rshift((int32_t)(c - d), BIT);
-  x[3] = rshift((int32_t)(c - a + d), BIT);
+  x[0] = rshift((int32_t)(a + d), BIT & 31);
+  x[1] = rshift((int32_t)b, BIT & 31);
+  x[2] = rshift((int32_t)(c - d), BIT & 31);
+  x[3] = rshift((int32_t)(c - a + d), BIT & 31);
 }
 // av1_iadst4 (av1_inv_txfm1d.c:656-711)
 template <int BIT> __device__ __forceinline__ void iadst4(int32_t (&x)[4]) {
   const uint32_t x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
-  constexpr uint32_t s1 = kSinpi[BIT - 10][1], s2 = kSinpi[BIT - 10][2], s3 = kSinpi[BIT - 10][3],
-                     s4 = kSinpi[BIT - 10][4];
+  constexpr uint32_t s1 = kSinpi[(BIT & 31) - 10][1], s2 = kSinpi[(BIT & 31) - 10][2], s3 = kSinpi[(BIT & 31) - 10][3],
+                     s4 = kSinpi[(BIT & 31) - 10][4];
   const uint32_t a = s1 * x0 + s4 * x2 + s2 * x3;
   const uint32_t b = s2 * x0 - s1 * x2 - s4 * x3;
   const uint32_t c = s3 * x1;
   const uint32_t d = s3 * (x0 - x2 + x3);
-  x[0] = rshift((int32_t)(a + c), BIT);
-  x[1] = rshift((int32_t)(b + c), BIT);
-  x[2] = rshift((int32_t)d, BIT);
-  x[3] = rshift((int32_t)(a + b - c), BIT);
+  x[0] = rshift((int32_t)(a + c), BIT & 31);
+  x[1] = rshift((int32_t)(b + c), BIT & 31);
+  x[2] = rshift((int32_t)d, BIT & 31);
+  x[3] = rshift((int32_t)(a + b - c), BIT & 31);
 }
 
 // ------------------------------------------------------------------ 1-D entry points (in place)

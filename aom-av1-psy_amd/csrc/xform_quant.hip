@@ -122,6 +122,26 @@ template <int KW, int KH> __device__ __forceinline__ int iscan_pos(int r, int c,
 __device__ constexpr uint8_t kVKind[16] = { 0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3 };
 __device__ constexpr uint8_t kHKind[16] = { 0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2 };
 
+// Largest residual magnitude per [TX_SIZE][TX_TYPE] under which the fast butterfly is exact (txfm_device.h: kFastBtf)
+__device__ constexpr int16_t kSafeMax[19][16] = {
+#include "txfm_safe_max.inc"
+};
+constexpr int tx_index_of(int w, int h) {  // TX_SIZE (av1/common/enums.h:174-197) of a w x h transform
+  constexpr int tw[19] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64 };
+  constexpr int th[19] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16 };
+  for (int i = 0; i < 19; ++i)
+    if (tw[i] == w && th[i] == h) return i;
+  return 0;
+}
+#ifndef AOMHIP_XQ_FAST_BTF
+#define AOMHIP_XQ_FAST_BTF 1   // 0: every block takes the exact butterfly (A/B, tools/r03_ab_txq.sh)
+#endif
+// the 1-D pass of a block whose residual magnitude allows (fast) / does not allow the fast butterfly
+template <int N, int BIT> __device__ __forceinline__ void fwd_1d_sel(int32_t (&x)[N], int kind, bool fast) {
+  if (AOMHIP_XQ_FAST_BTF && fast) fwd_1d<N, BIT + txfm::kFastBtf>(x, kind);
+  else fwd_1d<N, BIT>(x, kind);
+}
+
 template <int LPB> __device__ __forceinline__ int group_max(int v) {
   if constexpr (LPB >= 2) v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
   if constexpr (LPB >= 4) v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
@@ -203,8 +223,9 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
   int32_t(&t)[KH * LSTRIDE] = tile[slot];
 
   // ---- columns
+  int32_t x[H];
+  int amax = 0;  // largest residual magnitude of this lane's column; the block's decides between the fast and the exact butterfly
   if (live && lane < W) {
-    int32_t x[H];
     const bool ud = (vk == 2);
 #pragma unroll
     for (int r = 0; r < H; ++r) {
@@ -219,9 +240,13 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
         v = (int)static_cast<const uint16_t *>(in0)[(int64_t)(by + rr) * stride0 + bx + lane] -
             (int)static_cast<const uint16_t *>(in1)[(int64_t)(by + rr) * stride1 + bx + lane];
       }
+      amax = max(amax, max(v, -v));
       x[r] = v * (1 << C::fs0);  // round_shift_array with a negative bit = exact left shift of an int16
     }
-    fwd_1d<H, C::cos_bit_col>(x, vk == 2 ? 1 : vk);
+  }
+  const bool fast = group_max<LPB>(amax) <= kSafeMax[tx_index_of(W, H)][tx_type & 15];
+  if (live && lane < W) {
+    fwd_1d_sel<H, C::cos_bit_col>(x, vk == 2 ? 1 : vk, fast);
     const int dc = (hk == 2) ? W - 1 - lane : lane;
 #pragma unroll
     for (int r = 0; r < KH; ++r) {
@@ -240,7 +265,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
     int32_t y[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) y[c] = t[r * LSTRIDE + c];
-    fwd_1d<W, C::cos_bit_row>(y, hk == 2 ? 1 : hk);
+    fwd_1d_sel<W, C::cos_bit_row>(y, hk == 2 ? 1 : hk, fast);
     const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
     const int zb[2] = { (qa.zbin[0] + ((1 << LS) >> 1)) >> LS, (qa.zbin[1] + ((1 << LS) >> 1)) >> LS };
     const int rd[2] = { (qa.round[0] + ((1 << LS) >> 1)) >> LS, (qa.round[1] + ((1 << LS) >> 1)) >> LS };
@@ -324,6 +349,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
   constexpr int CS = W < 8 ? W : 8;             // samples per chunk
   constexpr int CPR = W / CS;                   // chunks per row
   constexpr int CHUNKS = H * CPR;
+  int amax = 0;  // largest residual magnitude this lane staged (see xform_quant_kernel)
   if (live) {
 #pragma unroll
     for (int k = 0; k < (CHUNKS + LPB - 1) / LPB; ++k) {
@@ -373,11 +399,14 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
             v[j] = (int16_t)((int)((a[j / 2] >> (16 * (j % 2))) & 0xFFFF) - (int)((b[j / 2] >> (16 * (j % 2))) & 0xFFFF));
         }
 #pragma unroll
+        for (int j = 0; j < CS; ++j) amax = max(amax, max((int)v[j], -(int)v[j]));
+#pragma unroll
         for (int j = 0; j < CS; j += 2)
           *reinterpret_cast<uint32_t *>(&A16[row * W + col + j]) = (uint16_t)v[j] | ((uint32_t)(uint16_t)v[j + 1] << 16);
       }
     }
   }
+  const bool fast = group_max<LPB>(amax) <= kSafeMax[tx_index_of(W, H)][tx_type & 15];
   __syncthreads();
 
   // ---- 2. columns
@@ -386,7 +415,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
     const bool ud = (vk == 2);
 #pragma unroll
     for (int r = 0; r < H; ++r) x[r] = (int)A16[(ud ? H - 1 - r : r) * W + lane] * (1 << C::fs0);
-    fwd_1d<H, C::cos_bit_col>(x, vk == 2 ? 1 : vk);
+    fwd_1d_sel<H, C::cos_bit_col>(x, vk == 2 ? 1 : vk, fast);
     const int dc = (hk == 2) ? W - 1 - lane : lane;
 #pragma unroll
     for (int r = 0; r < KH; ++r) {
@@ -408,7 +437,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
   }
   __syncthreads();  // A (input) and B (tile) are dead from here: they become the output staging areas
   if (live && lane < KH) {
-    fwd_1d<W, C::cos_bit_row>(y, hk == 2 ? 1 : hk);
+    fwd_1d_sel<W, C::cos_bit_row>(y, hk == 2 ? 1 : hk, fast);
     const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
     const int zb[2] = { (qa.zbin[0] + ((1 << LS) >> 1)) >> LS, (qa.zbin[1] + ((1 << LS) >> 1)) >> LS };
     const int rd[2] = { (qa.round[0] + ((1 << LS) >> 1)) >> LS, (qa.round[1] + ((1 << LS) >> 1)) >> LS };
@@ -502,6 +531,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
   // ---- load rows (one wide access per row), apply the up/down flip while loading
   int32_t x[H][W];
   int32_t x0[H][W];  // the raw residual (the lossless WHT takes it unshifted)
+  int amax = 0;
 #pragma unroll
   for (int r = 0; r < H; ++r) {
     const int rr = ud ? H - 1 - r : r;
@@ -532,8 +562,10 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
     for (int j = 0; j < W; ++j) {
       x0[r][j] = v[j];
       x[r][j] = v[j] * (1 << C::fs0);
+      amax = max(amax, max(v[j], -v[j]));
     }
   }
+  const bool fast = amax <= kSafeMax[tx_index_of(W, H)][tx_type & 15];  // (a lane owns its whole block here)
 
   // ---- columns
 #pragma unroll
@@ -541,7 +573,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
     int32_t col[H];
 #pragma unroll
     for (int r = 0; r < H; ++r) col[r] = x[r][c];
-    fwd_1d<H, C::cos_bit_col>(col, vk == 2 ? 1 : vk);
+    fwd_1d_sel<H, C::cos_bit_col>(col, vk == 2 ? 1 : vk, fast);
 #pragma unroll
     for (int r = 0; r < H; ++r) x[r][c] = (C::fs1 < 0) ? rshift(col[r], C::fs1 < 0 ? -C::fs1 : 1) : col[r];
   }
@@ -601,7 +633,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
       int32_t y[W];
 #pragma unroll
       for (int c = 0; c < W; ++c) y[c] = x[r][lr ? W - 1 - c : c];  // left/right flip of the column-pass output
-      fwd_1d<W, C::cos_bit_row>(y, hk == 2 ? 1 : hk);
+      fwd_1d_sel<W, C::cos_bit_row>(y, hk == 2 ? 1 : hk, fast);
 #pragma unroll
       for (int c = 0; c < W; ++c) {
         int32_t v = y[c];

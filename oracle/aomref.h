@@ -119,6 +119,8 @@ int orc_txfm_valid(int tx_size, int tx_type);
  * including the 64-point zero-out / re-pack.  Output length = min(w,32)*min(h,32) packed
  * for 64-wide sizes exactly as the reference leaves it (full w*h array is written). */
 void orc_fwd_txfm2d(const int16_t *input, int32_t *output, int stride, int tx_size, int tx_type, int bd);
+/* interval analysis of the same transform (bound mode, aomref_txfm.c) */
+void orc_fwd_txfm2d_bounds(int tx_size, int tx_type, int input_max, int64_t *max_operand, int64_t *max_sum);
 /* av1_inv_txfm2d.c:234-309 inv_txfm2d_add_c via av1_inv_txfm2d_add_WxH_c; dst is uint16 (highbd) */
 void orc_inv_txfm2d_add(const int32_t *input, uint16_t *dst, int stride, int tx_size, int tx_type, int bd);
 #define ORC_TX_WHT 16 /* lossless 4x4 Walsh-Hadamard in the batch drivers' tx_type field */

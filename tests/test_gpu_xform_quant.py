@@ -349,3 +349,49 @@ def test_per_block_tx_type_that_does_not_exist_for_the_size_is_reported(hip, ora
         for d in (d_c, d_q, d_dq, d_e):
             ctx.free(d)
     ctx.free(d_res)
+
+
+@pytest.mark.parametrize("tx_size", range(19))
+def test_fast_butterfly_boundary(hip, oracle, ctx, tx_size):
+    """The kernels evaluate half_btf with 24-bit products and a 32-bit sum for blocks whose residual magnitude is at most
+    kSafeMax[tx_size][tx_type] (csrc/txfm_safe_max.inc, from the oracle's interval analysis) and with the exact 64-bit form otherwise.
+    Blocks AT the bound -- all +M, all -M, checkerboards, the sign patterns of the DCT's basis functions (the worst cases of a
+    butterfly network), random signs -- and blocks one above it (exact path), interleaved in one launch so that wavefronts mix both
+    paths, must equal the oracle bit for bit."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import gen_txfm_bounds as gb
+    w, h = oracle.TX_W[tx_size], oracle.TX_H[tx_size]
+    nc = hip.capi.lib.aomhip_tx_max_eob(tx_size)
+    rng = np.random.default_rng(900 + tx_size)
+    types = [t for t in range(16) if oracle.lib.orc_txfm_valid(tx_size, t)]
+    yy, xx = np.mgrid[0:h, 0:w]
+    tiles, btypes = [], []
+    for t in types:
+        M = gb.safe_max(tx_size, t)
+        assert M > 0
+        pats = [np.ones((h, w)), -np.ones((h, w)), np.where((yy + xx) & 1, -1, 1), np.where(yy & 1, -1, 1), np.where(xx & 1, -1, 1)]
+        for k in (1, 2, 3, w - 1):   # sign of cos((2x + 1) k pi / 2w) x the same in y: rows / columns of the DCT matrix
+            cx = np.sign(np.cos((2 * xx + 1) * k * np.pi / (2 * w)) + 1e-9)
+            cy = np.sign(np.cos((2 * yy + 1) * min(k, h - 1) * np.pi / (2 * h)) + 1e-9)
+            pats += [cx, cy, cx * cy]
+        pats += [rng.choice([-1, 1], (h, w)) for _ in range(3)]
+        for p in pats:
+            for mag in ((M, min(M + 1, 32767)) if M < 32767 else (M,)):
+                tiles.append((p * mag).astype(np.int16)); btypes.append(t)
+            if M >= 32767:
+                tiles.append(np.full((h, w), -32768, np.int16)); btypes.append(t)   # |x| = 32768 > every bound: the exact path
+    n = len(tiles)
+    cols = max(1, 1024 // w)
+    rows = (n + cols - 1) // cols
+    residual = np.zeros((rows * h, cols * w), np.int16)
+    blocks = np.zeros(n, hip.capi.txb_dtype)
+    for i, tl in enumerate(tiles):
+        r, c = divmod(i, cols)
+        residual[r * h:(r + 1) * h, c * w:(c + 1) * w] = tl
+        blocks[i] = (c * w, r * h, i * nc, btypes[i], (0, 0, 0))
+    q = oracle.build_quantizer_y(10, 40)
+    got, want = _run_list(hip, oracle, ctx, residual, tx_size, blocks, q, True)
+    for g, wv, name in zip(got, want, ("coeff", "qcoeff", "dqcoeff", "eob")):
+        bad = np.nonzero(g != wv)[0]
+        assert bad.size == 0, (tx_size, name, bad[:5], [btypes[i // nc] for i in bad[:5]] if name != "eob" else [btypes[i] for i in bad[:5]])
