@@ -4,12 +4,14 @@
 # profiles/traffic.json["txq_<size>"].   Usage: gpurun -- 'bash tools/gpu_pmc_txq.sh <tag>'
 set -u
 TAG=${1:-r02}
+WL=${2:-txq_1080p_8bit}
 export TMPDIR=/tmp
 export AOMHIP_PMC_CALIB=1
 OUT=gpurun_out/$TAG/pmctxq
+[ "$WL" != "txq_1080p_8bit" ] && OUT=gpurun_out/$TAG/pmc$WL
 mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- \
-      python3 bench.py --steps 3 --warmup 1 --workload txq_1080p_8bit --no-cpu-baseline > $OUT/$C.json 2> $OUT/$C.err
+      python3 bench.py --steps 3 --warmup 1 --workload $WL --no-cpu-baseline > $OUT/$C.json 2> $OUT/$C.err
 done
-python3 tools/pmc_traffic_txq.py $TAG
+python3 tools/pmc_traffic_txq.py $TAG $WL

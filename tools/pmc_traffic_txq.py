@@ -12,8 +12,9 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 
-def main(tag):
-    base = os.path.join("gpurun_out", tag, "pmctxq")
+def main(tag, workload="txq_1080p_8bit"):
+    prefix = "txq_" if workload == "txq_1080p_8bit" else workload + "_"     # profiles/traffic.json keys, as bench.py's load_traffic() reads them
+    base = os.path.join("gpurun_out", tag, "pmctxq" if workload == "txq_1080p_8bit" else "pmc" + workload)
     acc = defaultdict(lambda: defaultdict(list))
     names = set()
     for f in glob.glob(os.path.join(base, "*", "*counter_collection.csv")):
@@ -26,7 +27,7 @@ def main(tag):
                 key = "calib_write"
             elif "xform_quant" in k:
                 m = re.search(r"xform_quant\w*<\s*(\d+)\w*,\s*(\d+)", k)
-                key = "txq_%sx%s" % (m.group(1), m.group(2)) if m else "txq_other"
+                key = prefix + "%sx%s" % (m.group(1), m.group(2)) if m else prefix + "other"
             else:
                 continue
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -41,14 +42,15 @@ def main(tag):
     fw = None
     if "calib_write" in acc and acc["calib_write"].get("WRITE_SIZE"):
         fw = 3.0 * wr_known / (sum(acc["calib_write"]["WRITE_SIZE"]) * 1024.0)
-    residual_ring = 32 * 1920 * 1088 * 2   # bench.py TxqGrid: 32 planes of 1920x1088 int16, each sample read once per launch
+    # bench.py TxqGrid: every sample of the residual ring read once per launch (32 planes of 1920x1088 / 12 planes of 3840x2176 int16)
+    residual_ring = 32 * 1920 * 1088 * 2 if workload == "txq_1080p_8bit" else 12 * 3840 * 2176 * 2
     out["calibration"] = {"read_factor": fr, "write_factor": fw, "write_known_bytes": wr_known, "narrow_read_factor_plane_sse": narrow,
                           "residual_ring_bytes": residual_ring}
     tj = os.path.join("profiles", "traffic.json")
     t = json.load(open(tj)) if os.path.exists(tj) else {}
     per = {}
     for k in sorted(mean):
-        if not k.startswith("txq_") or fr is None or fw is None:
+        if not k.startswith(prefix) or k.startswith("calib") or fr is None or fw is None:
             continue
         rd = mean[k].get("FETCH_SIZE", 0.0) * 1024.0 * fr
         wr = mean[k].get("WRITE_SIZE", 0.0) * 1024.0 * fw
@@ -56,9 +58,9 @@ def main(tag):
         t[k] = rd + wr
     out["hbm_bytes_per_launch"] = per
     json.dump(t, open(tj, "w"), indent=1, sort_keys=True)
-    json.dump(out, open(os.path.join("profiles", "%s_pmc_txq.json" % tag), "w"), indent=1, sort_keys=True)
+    json.dump(out, open(os.path.join("profiles", "%s_pmc_%s.json" % (tag, "txq" if workload == "txq_1080p_8bit" else workload)), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: out[k] for k in out if k not in ("notes",)}, sort_keys=True)[:3000])
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], *(sys.argv[2:3]))
