@@ -69,6 +69,10 @@ class TfParams(C.Structure):
         return out
 
 
+class FirstPassParams(C.Structure):
+    _fields_ = [("unit_rows", C.c_int32), ("unit_cols", C.c_int32), ("skip_motion_search_threshold", C.c_int32), ("skip_zeromv_motion_search", C.c_int32)]
+
+
 class TfApplyParams(C.Structure):
     _fields_ = [("noise_levels", C.c_double * 3), ("q_factor", C.c_int32), ("filter_strength", C.c_int32), ("num_planes", C.c_int32),
                 ("ss_x", C.c_int32), ("ss_y", C.c_int32)]
@@ -218,6 +222,7 @@ _protos = {
     "aomhip_sad16x16x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp]),
     "aomhip_highbd_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, _i]),
     "aomhip_first_pass_motion_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "aomhip_first_pass_inter_frame": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_motion_estimation_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_tf_default_params": (None, [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aomhip_tf_block_list": (C.c_int, [_i, _i, _i, _vp]),
@@ -342,6 +347,14 @@ class Context:
                                        d_mvcost_col=None):
         check(lib.aomhip_first_pass_motion_search_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(params), d_mvjcost, d_mvcost_row,
                                                         d_mvcost_col, d_blocks, n, d_mv, d_err), "aomhip_first_pass_motion_search_batch")
+
+    def first_pass_inter_frame(self, src, src_frame, last, last_frame, golden, golden_frame, last_source, last_source_frame, bw, bh, params, fp,
+                               d_blocks, d_intra_error, d_best_mv, d_motion_error, d_full_mv=None, d_gf_motion_error=None, d_raw_motion_error=None,
+                               d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):
+        check(lib.aomhip_first_pass_inter_frame(self.h, C.byref(src), src_frame, C.byref(last), last_frame, C.byref(golden) if golden is not None else None,
+                                                golden_frame, C.byref(last_source), last_source_frame, bw, bh, C.byref(params), d_mvjcost, d_mvcost_row,
+                                                d_mvcost_col, C.byref(fp), d_blocks, d_intra_error, d_best_mv, d_full_mv, d_motion_error, d_gf_motion_error,
+                                                d_raw_motion_error), "aomhip_first_pass_inter_frame")
 
     def motion_estimation_batch(self, src, ref, frame, bw, bh, full, sub, use_cost_list, d_blocks, n, d_mv, d_err, d_dist, d_sse, d_full_mv=None,
                                 d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):

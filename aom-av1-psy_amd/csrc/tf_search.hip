@@ -525,3 +525,171 @@ extern "C" int aomhip_simple_motion_search_batch(aomhip_ctx *ctx, const aomhip_p
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
+
+// ---- first pass: the inter half of one frame (av1/encoder/firstpass.c firstpass_inter_prediction :690-815 under the raster loop :1148-1193)
+// best_ref_mv of block (r, c) is block (r, c-1)'s *best_mv and kZeroMv at c == 0 (:1165, :1190): rows are independent, columns a chain.
+// Everything independent of the chain -- the three 0,0 errors and the two zero-MV legs -- goes through once for the whole frame; the
+// leg started at best_ref_mv runs one block column at a time with every row in flight, list -> search -> decision, all on the stream.
+namespace aomhip {
+namespace {
+__global__ void fpf_zero_list_kernel(const aomhip_search_block *blocks, int n, aomhip_search_block *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const aomhip_search_block b = blocks[i];
+  aomhip_search_block o = b;
+  o.ref_row = o.ref_col = 0; o.start_row = o.start_col = 0;
+  full_limits(b, &o);
+  out[i] = o;
+}
+__global__ void fpf_chain_list_kernel(const aomhip_search_block *blocks, const int16_t *chain, int col, int rows, int cols, aomhip_search_block *out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  aomhip_search_block b = blocks[(size_t)r * cols + col];
+  b.ref_row = chain[2 * r]; b.ref_col = chain[2 * r + 1];
+  aomhip_search_block o = b;
+  o.start_row = (int16_t)rawpel(b.ref_row); o.start_col = (int16_t)rawpel(b.ref_col);   // get_fullmv_from_mv(ref_mv)
+  full_limits_ref(b, &o);
+  out[r] = o;
+}
+struct FpfLegs {
+  const int16_t *zmv; const int32_t *zerr;   // zero-MV leg on the last frame, per block
+  const int16_t *gmv; const int32_t *gerr;   // zero-MV leg on the golden frame, per block (null without one)
+  const int16_t *cmv; const int32_t *cerr;   // chained leg of this column, per row
+  const uint32_t *err0, *raw, *gf0;           // get_prediction_error_bitdepth at 0,0: last frame, last source, golden
+};
+__global__ void fpf_decide_kernel(FpfLegs L, const int32_t *intra, int col, int rows, int cols, int thr, int skip_zeromv, int16_t *chain,
+                                  int16_t *best_mv, int16_t *full_mv, int32_t *motion_error, int32_t *gf_motion_error, int32_t *raw_motion_error) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const size_t i = (size_t)r * cols + col;
+  const int ref_row = chain[2 * r], ref_col = chain[2 * r + 1];
+  int err = (int)L.err0[i], mrow = 0, mcol = 0;                // FULLPEL_MV mv = kZeroFullMv; motion_error at 0,0 (:698-708)
+  const int raw = (int)L.raw[i];
+  int gf = err;
+  if (raw > thr) {                                             // :722
+    const bool moved = (ref_row | ref_col) != 0;
+    const int e1 = moved ? L.cerr[r] : L.zerr[i];              // first_pass_motion_search(ref_mv): tmp_err < *best_motion_err (:294)
+    if (e1 < err) { err = e1; mrow = moved ? L.cmv[2 * r] : L.zmv[2 * i]; mcol = moved ? L.cmv[2 * r + 1] : L.zmv[2 * i + 1]; }
+    if (!skip_zeromv && moved) {                               // :729-738: tmp_err starts at INT_MAX, so it becomes the leg's own error
+      const int e0 = L.zerr[i];
+      if (e0 < err) { err = e0; mrow = L.zmv[2 * i]; mcol = L.zmv[2 * i + 1]; }
+    }
+    gf = err;                                                  // :741
+    if (L.gerr) { gf = (int)L.gf0[i]; if (L.gerr[i] < gf) gf = L.gerr[i]; }   // :742-752
+  }
+  int brow = 0, bcol = 0;                                      // *best_mv = kZeroMv (:777)
+  if (err <= intra[i]) { brow = mrow * 8; bcol = mcol * 8; }  // get_mv_from_fullmv(&mv) (:794)
+  chain[2 * r] = (int16_t)brow; chain[2 * r + 1] = (int16_t)bcol;
+  best_mv[2 * i] = (int16_t)brow; best_mv[2 * i + 1] = (int16_t)bcol;
+  if (full_mv) { full_mv[2 * i] = (int16_t)mrow; full_mv[2 * i + 1] = (int16_t)mcol; }
+  motion_error[i] = err;
+  if (gf_motion_error) gf_motion_error[i] = gf;
+  if (raw_motion_error) raw_motion_error[i] = raw;
+}
+}  // namespace
+}  // namespace aomhip
+
+extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *last, int last_frame,
+                                             const aomhip_planes *golden, int golden_frame, const aomhip_planes *last_source, int last_source_frame,
+                                             int bw, int bh, const aomhip_search_params *p, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                                             const int32_t *d_mvcost_col, const aomhip_first_pass_params *fp, const aomhip_search_block *d_blocks,
+                                             const int32_t *d_intra_error, int16_t *d_best_mv, int16_t *d_full_mv, int32_t *d_motion_error,
+                                             int32_t *d_gf_motion_error, int32_t *d_raw_motion_error) {
+  auto ring_ok = [&](const aomhip_planes *q, int f) {
+    return q && q->base && f >= 0 && f < q->n_frames && q->width == src->width && q->height == src->height && q->stride == src->stride &&
+           q->border == src->border && q->bit_depth == src->bit_depth;
+  };
+  if (!ctx || !src || !p || !fp || fp->unit_rows < 0 || fp->unit_cols < 0 || !ring_ok(src, src_frame) || !ring_ok(last, last_frame) ||
+      !ring_ok(last_source, last_source_frame) || (golden && !ring_ok(golden, golden_frame))) {
+    set_error("aomhip_first_pass_inter_frame: invalid argument (the source, last, golden and last-source planes must share one geometry)");
+    return AOMHIP_ERR_INVALID;
+  }
+  const int rows = fp->unit_rows, cols = fp->unit_cols;
+  const size_t n1 = (size_t)rows * cols;
+  if (n1 == 0) return AOMHIP_OK;
+  if (n1 > (size_t)INT_MAX / 64 || !d_blocks || !d_intra_error || !d_best_mv || !d_motion_error) {
+    set_error("aomhip_first_pass_inter_frame: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  const int n = (int)n1;
+  AOMHIP_TRY(hipSetDevice(ctx->device));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t r1 = (size_t)rows;
+  const size_t o_zl = take(n1 * sizeof(aomhip_search_block)), o_zmv = take(n1 * 4), o_zerr = take(n1 * 4), o_gmv = take(n1 * 4), o_gerr = take(n1 * 4),
+               o_e0 = take(n1 * 4), o_raw = take(n1 * 4), o_gf0 = take(n1 * 4), o_var = take(n1 * 4), o_cost = take(n1 * 4), o_sse = take(n1 * 4),
+               o_cand = take(n1 * sizeof(aomhip_var_cand)), o_cl = take(r1 * sizeof(aomhip_search_block)), o_cmv = take(r1 * 4), o_cerr = take(r1 * 4),
+               o_chain = take(r1 * 4);
+  char *w = static_cast<char *>(work(ctx, off));
+  if (!w) return AOMHIP_ERR_NOMEM;
+  auto i32 = [&](size_t o) { return reinterpret_cast<int32_t *>(w + o); };
+  auto u32 = [&](size_t o) { return reinterpret_cast<uint32_t *>(w + o); };
+  auto i16 = [&](size_t o) { return reinterpret_cast<int16_t *>(w + o); };
+  aomhip_search_block *zl = reinterpret_cast<aomhip_search_block *>(w + o_zl), *cl = reinterpret_cast<aomhip_search_block *>(w + o_cl);
+  aomhip_var_cand *cands = reinterpret_cast<aomhip_var_cand *>(w + o_cand);
+  const size_t esz = src->bit_depth == 8 ? 1 : 2;
+  auto one = [&](const aomhip_planes *q, int f) {   // one frame of a ring as a ring of one: the batched searches pair src / ref by frame index
+    aomhip_planes v = *q;
+    v.base = static_cast<char *>(q->base) + (size_t)f * q->frame_stride * esz;
+    v.n_frames = 1;
+    return v;
+  };
+  const aomhip_planes s1 = one(src, src_frame), l1 = one(last, last_frame), ls1 = one(last_source, last_source_frame);
+  const aomhip_planes g1 = golden ? one(golden, golden_frame) : s1;
+  const unsigned g = (unsigned)((n1 + 255) / 256), gr = (unsigned)((r1 + 63) / 64);
+  auto sse0 = [&](const aomhip_planes &ref, uint32_t *out) {   // get_prediction_error_bitdepth: the mse function's sse at 0,0 (:113-160)
+    const unsigned gv = (unsigned)((n1 + 3) / 4);
+    if (src->bit_depth == 8)
+      hipLaunchKernelGGL(sms_var_kernel<uint8_t>, dim3(gv), dim3(256), 0, ctx->stream, view_of<uint8_t>(s1), 0, view_of<uint8_t>(ref), 0, bw, bh, 8, d_blocks,
+                         n, out, u32(o_var));
+    else
+      hipLaunchKernelGGL(sms_var_kernel<uint16_t>, dim3(gv), dim3(256), 0, ctx->stream, view_of<uint16_t>(s1), 0, view_of<uint16_t>(ref), 0, bw, bh,
+                         src->bit_depth, d_blocks, n, out, u32(o_var));
+  };
+  // one first_pass_motion_search leg of `m` listed blocks (the body of aomhip_first_pass_motion_search_batch on this call's work memory)
+  auto leg = [&](const aomhip_planes &ref, const aomhip_search_block *list, int m, int16_t *mv, int32_t *err) -> int {
+    int rc = aomhip_full_pixel_search_batch(ctx, &s1, &ref, 0, bw, bh, p, d_mvjcost, d_mvcost_row, d_mvcost_col, list, m, mv, i32(o_cost), nullptr, nullptr);
+    if (rc != AOMHIP_OK) return rc;
+    const unsigned gm = (unsigned)((m + 255) / 256);
+    hipLaunchKernelGGL(fp_cands_kernel, dim3(gm), dim3(256), 0, ctx->stream, list, mv, m, cands);
+    AOMHIP_LAUNCH_CHECK();
+    rc = aomhip_variance_batch(ctx, &s1, &ref, 0, 1, bw, bh, cands, m, 0, u32(o_var), u32(o_sse));
+    if (rc != AOMHIP_OK) return rc;
+    hipLaunchKernelGGL(fp_finish_kernel, dim3(gm), dim3(256), 0, ctx->stream, list, mv, i32(o_cost), u32(o_sse), m, p->mv_cost_type, p->error_per_bit, d_mvjcost,
+                       d_mvcost_row, d_mvcost_col, err);
+    AOMHIP_LAUNCH_CHECK();
+    return AOMHIP_OK;
+  };
+  sse0(l1, u32(o_e0));
+  AOMHIP_LAUNCH_CHECK();
+  sse0(ls1, u32(o_raw));
+  AOMHIP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(fpf_zero_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, n, zl);
+  AOMHIP_LAUNCH_CHECK();
+  int rc = leg(l1, zl, n, i16(o_zmv), i32(o_zerr));
+  if (rc != AOMHIP_OK) return rc;
+  if (golden) {
+    sse0(g1, u32(o_gf0));
+    AOMHIP_LAUNCH_CHECK();
+    rc = leg(g1, zl, n, i16(o_gmv), i32(o_gerr));
+    if (rc != AOMHIP_OK) return rc;
+  }
+  AOMHIP_TRY(hipMemsetAsync(w + o_chain, 0, r1 * 4, ctx->stream));   // MV best_ref_mv = kZeroMv at the start of every row (:1165)
+  aomhip::FpfLegs L;
+  L.zmv = i16(o_zmv); L.zerr = i32(o_zerr);
+  L.gmv = golden ? i16(o_gmv) : nullptr; L.gerr = golden ? i32(o_gerr) : nullptr;
+  L.cmv = i16(o_cmv); L.cerr = i32(o_cerr);
+  L.err0 = u32(o_e0); L.raw = u32(o_raw); L.gf0 = u32(o_gf0);
+  for (int c = 0; c < cols; ++c) {
+    if (c > 0) {   // column 0 starts from kZeroMv: its ref_mv leg IS the zero-MV leg
+      hipLaunchKernelGGL(fpf_chain_list_kernel, dim3(gr), dim3(64), 0, ctx->stream, d_blocks, i16(o_chain), c, rows, cols, cl);
+      AOMHIP_LAUNCH_CHECK();
+      rc = leg(l1, cl, rows, i16(o_cmv), i32(o_cerr));
+      if (rc != AOMHIP_OK) return rc;
+    }
+    hipLaunchKernelGGL(fpf_decide_kernel, dim3(gr), dim3(64), 0, ctx->stream, L, d_intra_error, c, rows, cols, fp->skip_motion_search_threshold,
+                       fp->skip_zeromv_motion_search, i16(o_chain), d_best_mv, d_full_mv, d_motion_error, d_gf_motion_error, d_raw_motion_error);
+    AOMHIP_LAUNCH_CHECK();
+  }
+  return AOMHIP_OK;
+}

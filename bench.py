@@ -720,6 +720,73 @@ def run_mesh(pkg, ctx, orc, steps, warmup):
     return out
 
 
+def run_first_pass(pkg, ctx, orc, steps, warmup):
+    """The inter half of the first pass for whole 4K 10-bit frames in one call each (aomhip_first_pass_inter_frame): 240 x 135 blocks of
+    16x16, NSTEP on the first-pass site table with entropy MV costs, last + golden reference, the best_ref_mv chain of every block row kept
+    on the device (one column of 135 searches at a time).  Beside it: the chain-free part alone (both zero-MV legs of every block through
+    aomhip_first_pass_motion_search_batch), i.e. what the frame would cost if the raster dependency did not exist."""
+    capi = pkg.capi
+    sp = SearchPipeline(pkg, ctx, None, 0, 1, frames=3)
+    cols, rows = sp.W // sp.BS, sp.H // sp.BS
+    n = sp.n
+    assert n == rows * cols
+    mv_max = (1 << 14) - 1
+    v = np.abs(np.arange(-mv_max, mv_max + 1))
+    bits = np.where(v == 0, 0, np.floor(np.log2(np.maximum(v, 1))) + 1).astype(np.int64)
+    tj, t0, t1 = np.array([200, 650, 640, 1050], np.int32), (150 + bits * 310).astype(np.int32), (170 + bits * 290 + (v & 7) * 3).astype(np.int32)
+    d_j, d_c0, d_c1 = ctx.to_device(tj), ctx.to_device(t0), ctx.to_device(t1)
+    q = capi.SearchParams.make("NSTEP_FPF", 1, capi.MV_COST_ENTROPY, sad_per_bit=24, error_per_bit=70)
+    rng = np.random.default_rng(3)
+    intra = rng.integers(0, 1 << 16, n).astype(np.int32)       # around the inter errors of this content: the chain is both carried and reset
+    d_i = ctx.to_device(intra)
+    fp = capi.FirstPassParams(rows, cols, 0, 0)
+    outs = [ctx.malloc(n * 4) for _ in range(5)]
+    def frame(f=0):   # source f; last = ref f, golden = ref f+1, last source = ref f+2 (slots of one ring)
+        ctx.first_pass_inter_frame(sp.src, f, sp.ref, f, sp.ref, (f + 1) % sp.F, sp.ref, (f + 2) % sp.F, sp.BS, sp.BS, q, fp, sp.d_blocks, d_i, outs[0], outs[2],
+                                   outs[1], outs[3], outs[4], d_j, d_c0 + mv_max * 4, d_c1 + mv_max * 4)
+    for _ in range(warmup):
+        frame()
+    ctx.sync()
+    ctx.timer_begin()
+    for k in range(steps):
+        frame(k % sp.F)
+    ms = ctx.timer_end() / steps
+    t0w = time.perf_counter()
+    frame(); ctx.sync()
+    wall_ms = (time.perf_counter() - t0w) * 1e3
+    def legs(f=0):
+        ctx.first_pass_motion_search_batch(sp.src, sp.ref, f, sp.BS, sp.BS, q, sp.d_blocks, n, sp.d_mv, sp.d_cost, d_j, d_c0 + mv_max * 4, d_c1 + mv_max * 4)
+    legs(); ctx.sync()
+    ctx.timer_begin()
+    for k in range(steps):
+        legs(k % sp.F); legs(k % sp.F)
+    ms_legs = ctx.timer_end() / steps
+    # parity of the last launch on a sample of block rows (rows are independent chains)
+    f = (steps - 1) % sp.F
+    frame(f); ctx.sync()
+    got = [ctx.from_device(outs[0], (n, 2), np.int16), ctx.from_device(outs[1], (n, 2), np.int16), ctx.from_device(outs[2], (n,), np.int32),
+           ctx.from_device(outs[3], (n,), np.int32), ctx.from_device(outs[4], (n,), np.int32)]
+    parity, moved = None, None
+    if orc is not None:
+        def plane(ring, slot):
+            return ctx.planes_download(ring, slot)
+        sb, lb, gb, lsb = plane(sp.src, f), plane(sp.ref, f), plane(sp.ref, (f + 1) % sp.F), plane(sp.ref, (f + 2) % sp.F)
+        oq = orc.search_params("NSTEP_FPF", 1, 0, sad_per_bit=24, error_per_bit=70, no_cost_list=1)
+        pick = np.array([0, rows // 2, rows - 1])
+        idx = (pick[:, None] * cols + np.arange(cols)[None, :]).ravel()
+        want = orc.first_pass_inter_frame(sb, lb, gb, lsb, sp.BORDER, sp.BS, sp.h_blocks[idx], len(pick), cols, oq, intra[idx], 0, 0, tj, t0, t1, bd=sp.BD)
+        parity = bool(all(np.array_equal(g[idx], w) for g, w in zip(got, want)))
+    best = got[0].reshape(rows, cols, 2)
+    moved = float((best[:, :-1] != 0).any(2).mean())
+    out = {"workload": "first_pass_4k_10bit", "blocks_per_frame": n, "ms_per_frame": ms, "frames_per_s": 1e3 / ms, "wall_ms_one_frame": wall_ms,
+           "block_columns": cols, "ms_zero_mv_legs_only": ms_legs, "share_of_blocks_with_nonzero_best_ref_mv": moved, "parity_sample_rows": parity,
+           "value": n / ms * 1e3, "unit": "blocks/s"}
+    for d in [d_j, d_c0, d_c1, d_i] + outs:
+        ctx.free(d)
+    sp.free()
+    return out
+
+
 def run_cdef_search(pkg, ctx, orc, steps, warmup):
     """The distortion table of av1_cdef_search (pickcdef.c:401-615) for a 4K 10-bit luma plane, CDEF_FULL_SEARCH (64 strength
     pairs per 64x64 filter block), one launch; also the 16-pair list of CDEF_FAST_SEARCH_LVL1-sized searches.  Informational."""
@@ -1120,7 +1187,7 @@ def main():
                     help="default: sad16x16_modeA_1080p_8bit (BASELINE.json's metric) at every N; with N > 1 the line also carries the "
                          "strong-scaling search pipeline with its per-frame RCCL exchange as `strong_scaling_search`",
                     choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "txq_4k_10bit", "search_4k_10bit", "inner_loop_4k_10bit", "default_search_4k_10bit", "cdef_search_4k_10bit",
-                                                "wiener_stats_4k", "tf_motion_search_4k_10bit", "sad_diamond_lists_4k_8bit"])
+                                                "wiener_stats_4k", "tf_motion_search_4k_10bit", "sad_diamond_lists_4k_8bit", "first_pass_4k_10bit"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -1214,6 +1281,12 @@ def main():
         print(json.dumps(dict(r, metric="SAD-candidates/s", n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
                               vs_baseline=None, dtype="u8", data="synthetic", ms_per_step=r["sad_strip_kernel_ms"])))
         return
+    if args.workload == "first_pass_4k_10bit":  # the first pass's inter half, one call per frame (single GPU)
+        r = run_first_pass(pkg, ctx, orc, args.steps, args.warmup)
+        ctx.close()
+        print(json.dumps(dict(r, metric="first-pass blocks/s", n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
+                              vs_baseline=None, dtype="u16", data="synthetic", ms_per_step=r["ms_per_frame"], config={"workload": r["workload"]})))
+        return
     if args.workload == "tf_motion_search_4k_10bit":  # SURVEY 8(f) row 1 (single GPU)
         r = run_tf(pkg, ctx, orc, args.steps, args.warmup)
         r8 = run_tf(pkg, ctx, None, args.steps, args.warmup, bd=8)   # the same pass on an 8-bit window (timing only)
@@ -1260,6 +1333,7 @@ def main():
             others.append(run_cdef_search(pkg, ctx, orc, max(4, args.steps // 4), 1))
             others.append(run_wiener_stats(pkg, ctx, orc, max(3, args.steps // 6), 1))
             others.append(run_tf(pkg, ctx, orc, max(4, args.steps // 4), 1))
+            others.append(run_first_pass(pkg, ctx, orc, max(3, args.steps // 6), 1))
             others.append(run_sad_diamond_lists(pkg, ctx, orc, max(6, args.steps // 2), 1))
     if dist is not None and default_multi:
         _, strong = search_block(True)   # mandatory companion of the N > 1 line (the forced one-rank dry run emits the same schema)

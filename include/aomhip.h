@@ -672,6 +672,39 @@ int aomhip_first_pass_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *
                                           const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, int n_blocks,
                                           int16_t *d_best_mv, int32_t *d_err);
 
+/* The inter half of the first pass for one frame in one call (firstpass_inter_prediction, av1/encoder/firstpass.c:690-815, under the
+ * raster loop of first_pass_tile / av1_first_pass_row, :1148-1193).  Block (r, c) of the unit_rows x unit_cols raster is searched
+ * around best_ref_mv = the *best_mv of block (r, c-1), kZeroMv at c == 0 (:1165, :1190) -- a chain along each row, which this call
+ * keeps on the device: the three 0,0 errors (get_prediction_error_bitdepth against the last frame, the last SOURCE frame and the
+ * golden frame) and the two zero-MV legs of every block run once for the frame, the leg started at best_ref_mv runs one block column
+ * at a time with all rows in flight, and a decision kernel per column applies :722-752 and :777-794:
+ *     motion_error = err(0,0); mv = 0
+ *     if raw_motion_error > skip_motion_search_threshold:
+ *         leg(ref_mv); if (!skip_zeromv_motion_search && ref_mv != 0) leg(0); gf_motion_error = min(err_golden(0,0), golden leg(0))
+ *     best_mv = motion_error <= this_intra_error ? mv * 8 : 0           -> the next block's best_ref_mv
+ * Every leg is aomhip_first_pass_motion_search_batch's (same `params` and cost tables).  The statistics the reference accumulates from
+ * these values (coded_error, sr_coded_error, neutral_count, the MV sums, :754-813) are sums over the outputs and stay with the caller,
+ * as do the intra half (this_intra_error is an input: it comes from the intra prediction of the frame being reconstructed) and the
+ * reconstruction (av1_encode_sby_pass1 when fp_sf.disable_recon == 0).
+ *   src / last / golden / last_source   rings of one geometry; golden NULL when frame_number <= 1 or there is no golden frame (:742)
+ *   d_blocks       unit_rows * unit_cols entries in raster order: bx, by and the RAW x->mv_limits of the block (av1_set_mv_row_limits /
+ *                  av1_set_mv_col_limits, full-pel); av1_set_mv_search_range around each leg's ref_mv is applied here.  start_* / ref_* ignored
+ *   d_intra_error  this_intra_error per block
+ * Outputs per block: d_best_mv (*best_mv, 1/8 pel, row then col), d_full_mv (the FULLPEL `mv` that produced motion_error, also when intra
+ * won; may be NULL), d_motion_error, d_gf_motion_error (= motion_error when there is no golden frame or the search was skipped; may be
+ * NULL), d_raw_motion_error (may be NULL). */
+typedef struct {
+  int32_t unit_rows, unit_cols;
+  int32_t skip_motion_search_threshold;  /* fp_sf.skip_motion_search_threshold */
+  int32_t skip_zeromv_motion_search;     /* fp_sf.skip_zeromv_motion_search */
+} aomhip_first_pass_params;
+int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *last, int last_frame,
+                                  const aomhip_planes *golden, int golden_frame, const aomhip_planes *last_source, int last_source_frame,
+                                  int bw, int bh, const aomhip_search_params *params, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                                  const int32_t *d_mvcost_col, const aomhip_first_pass_params *fp, const aomhip_search_block *d_blocks,
+                                  const int32_t *d_intra_error, int16_t *d_best_mv, int16_t *d_full_mv, int32_t *d_motion_error,
+                                  int32_t *d_gf_motion_error, int32_t *d_raw_motion_error);
+
 /* ------------------------------------------------------------------ full-pel + sub-pel search of a block list in one call (TPL, single motion search) */
 
 /* The two-call shape of tpl_model.c's motion_estimation (av1/encoder/tpl_model.c:248-301) and of av1_single_motion_search's core

@@ -997,6 +997,58 @@ def first_pass_motion_search_batch(src_b, ref_b, border, w, h, blocks, q, mvjcos
     return mv, err
 
 
+def first_pass_inter_frame(src_b, last_b, golden_b, last_source_b, border, bs, blocks, rows, cols, q, intra_error, skip_motion_search_threshold=0,
+                           skip_zeromv_motion_search=0, mvjcost=None, mvcost0=None, mvcost1=None, bd=8):
+    """firstpass_inter_prediction (av1/encoder/firstpass.c:690-815) for every block of a frame in the raster order of av1_first_pass_row
+    (:1148-1193): best_ref_mv starts at kZeroMv in every row (:1165) and becomes each block's *best_mv (:1190).  A scalar walk, one block and
+    one search leg at a time, as the reference does it.  blocks: raster list with bx, by and the raw x->mv_limits; golden_b None when the
+    frame has no golden reference (:742).  -> (best_mv [n, 2] 1/8 pel, full_mv [n, 2], motion_error, gf_motion_error, raw_motion_error)"""
+    hb = bd if bd > 8 else None
+    n = rows * cols
+    best_mv, full_mv = np.zeros((n, 2), np.int16), np.zeros((n, 2), np.int16)
+    motion_error, gf_error, raw_error = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+
+    def err00(ref_b, b):                                   # get_prediction_error_bitdepth (:113-160): the mse function's sse
+        y, x = border + int(b["by"]), border + int(b["bx"])
+        return int(variance(src_b, y, x, ref_b, y, x, bs, bs, hb)[1])
+
+    def leg(ref_b, b, ref_row, ref_col, mv, best_err):     # first_pass_motion_search (:261-299)
+        one = np.array([b], dtype=blocks.dtype)
+        one["ref_row"], one["ref_col"] = ref_row, ref_col
+        one["start_row"], one["start_col"] = _rawpel(np.int32(ref_row)), _rawpel(np.int32(ref_col))
+        raw = (b["row_min"], b["row_max"], b["col_min"], b["col_max"])
+        one["row_min"], one["row_max"], one["col_min"], one["col_max"] = set_mv_search_range(raw, ref_row, ref_col)
+        m, e = first_pass_motion_search_batch(src_b, ref_b, border, bs, bs, one, q, mvjcost, mvcost0, mvcost1, bd=bd, threads=1)
+        if int(e[0]) < best_err:
+            return (int(m[0, 0]), int(m[0, 1])), int(e[0])
+        return mv, best_err
+
+    for r in range(rows):
+        ref_row = ref_col = 0
+        for c in range(cols):
+            i = r * cols + c
+            b = blocks[i]
+            mv, err = (0, 0), err00(last_b, b)
+            raw = err00(last_source_b, b)
+            gf = err
+            if raw > skip_motion_search_threshold:
+                mv, err = leg(last_b, b, ref_row, ref_col, mv, err)
+                if not skip_zeromv_motion_search and (ref_row or ref_col):
+                    tmp_mv, tmp_err = leg(last_b, b, 0, 0, (0, 0), 2147483647)
+                    if tmp_err < err:
+                        mv, err = tmp_mv, tmp_err
+                gf = err
+                if golden_b is not None:
+                    _, gf = leg(golden_b, b, 0, 0, (0, 0), err00(golden_b, b))
+            ref_row = ref_col = 0
+            if err <= int(intra_error[i]):
+                ref_row, ref_col = mv[0] * 8, mv[1] * 8
+            best_mv[i] = (ref_row, ref_col)
+            full_mv[i] = mv
+            motion_error[i], gf_error[i], raw_error[i] = err, gf, raw
+    return best_mv, full_mv, motion_error, gf_error, raw_error
+
+
 # ---- full-pel + sub-pel search of a block list: tpl_model.c motion_estimation (av1/encoder/tpl_model.c:248-301) ----
 def set_mv_search_range(limits, ref_row, ref_col):
     """av1_set_mv_search_range (mcomp.c:196-215): limits = (row_min, row_max, col_min, col_max) of x->mv_limits -> FullMvLimits around ref_mv."""
