@@ -53,8 +53,8 @@ __device__ __forceinline__ int32_t rshift64(int64_t v, int bit) { return (int32_
 // butterfly -- two 24-bit multiply-adds into a 32-bit wrapping sum, one arithmetic shift: 3 instructions instead of 9 -- which equals
 // half_btf whenever both operands lie inside (-2^23, 2^23) (the 32-bit result of v_mad_i32_i24 is then the low half of the exact product,
 // i.e. the reference's wrapped product) and the exact sum w0 a + w1 b + 2^(bit-1) fits int32.  Callers may only set the flag for blocks
-// whose residual magnitude is at most kSafeMax[tx_size][tx_type] (txfm_safe_max.inc): oracle/aomref_txfm.c's interval analysis proves
-// both conditions for every butterfly of both passes under that bound (oracle/gen_txfm_bounds.py; tests/test_oracle_txfm_bounds.py).
+// whose residual magnitude is at most kSafeMax[tx_size][tx_type] (txfm_safe_max.inc): an offline interval analysis of every stage proves
+// both conditions for every butterfly of both passes under that bound (the generator is named in the table's header; tests/test_oracle_txfm_bounds.py re-derives it).
 // Every 8- and 10-bit video residual qualifies at every size; other inputs take the exact form.  The forward transform + quantise
 // kernels were VALU-issue bound on exactly these butterflies (profiles/r02_txq.md, r03_txq.md).
 constexpr int kFastBtf = 32;
