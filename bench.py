@@ -368,18 +368,12 @@ def run_txq(pkg, ctx, orc, steps, warmup, want_cpu, name="txq_1080p_8bit"):
                                  "blocks_per_s": wl.blocks[n] / (ms * 1e-3),
                                  "achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     dom = max(per, key=lambda k: per[k]["avg_launch_ms"])
-    pmc16 = None
-    try:  # the 16x16 kernel's other limit, measured with PMC (profiles/r02_txq.md, r02v_pmc_txq16.json): VALU issue, HBM follows
-        pmc16 = json.load(open(os.path.join(ROOT, "profiles", "r02v_pmc_txq16.json")))["_valu_issue_occupancy"]
-    except Exception:
-        pass
     res = {"workload": "fwd_txfm2d+quantize_b_%s" % name[4:], "value": wl.blocks_per_step * steps / wall, "unit": "blocks/s",
            "ms_per_step": wall / steps * 1e3, "event_ms_per_step": ev_ms / steps, "blocks_per_step": wl.blocks_per_step,
            "parity_frame0_16x16": ok, "config": {"plane": "%dx%d int16 residual, %d-bit signed" % (wl.W, wl.H, wl.bd + 1), "ring_planes": wl.F,
                                                  "quantiser": "aom_highbd_quantize_b" if wl.hbd else "aom_quantize_b",
                                                  "tx_type": "DCT_DCT", "qindex": 100, "sizes": "4x4,8x8,16x16,32x32 (all blocks of each)"},
-           "roofline": {"bound": "hbm (measured fabric traffic = algorithmic bytes); the 16x16 / 32x32 launches are held below it by VALU issue "
-                                 "(PMC: %.2f of the issue slots at 16x16)" % pmc16 if pmc16 else "hbm",
+           "roofline": {"bound": "hbm",   # measured fabric traffic = algorithmic bytes (profiles/*_pmc_txq*.json); a pure copy kernel runs at 0.63-0.79 here
                         "kernel": "xform_quant_kernel<%s>" % dom, "achieved": per[dom]["achieved_GBs"],
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom]["frac"],
                         "traffic": load_traffic(("txq_" if name == "txq_1080p_8bit" else name + "_") + dom),
@@ -390,8 +384,6 @@ def run_txq(pkg, ctx, orc, steps, warmup, want_cpu, name="txq_1080p_8bit"):
         t, ms = res["roofline"]["traffic"], per[dom]["avg_launch_ms"]
         res["roofline"]["traffic_GBs"] = t / (ms * 1e-3) / 1e9
         res["roofline"]["traffic_over_algorithmic"] = t / (wl.blocks[int(dom.split("x")[0])] * (10 * int(dom.split("x")[0]) ** 2 + 2))
-    if pmc16:
-        per["16x16"]["valu_issue_occupancy_pmc"] = round(pmc16, 3)
     if want_cpu and orc is not None:
         res["cpu_baseline"] = wl.cpu_baseline()
     wl.free()
