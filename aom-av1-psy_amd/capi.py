@@ -196,6 +196,8 @@ _protos = {
     "aomhip_full_pixel_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_search_sites": (C.c_int, [_i, C.POINTER(C.c_int), _vp, _vp, _vp]),
     "aomhip_subpel_tree_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "aomhip_subpel_tree_list_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "aomhip_single_motion_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_bind_variance_vtable": (C.c_int, [_vp, _i]),
     "aomhip_build_inter_pred_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i, _i, _i]),
     "aomhip_sse_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp]),
@@ -305,6 +307,10 @@ class Context:
         p = self.malloc(max(arr.nbytes, 16))
         check(lib.aomhip_memcpy_h2d(self.h, p, arr.ctypes.data, arr.nbytes), "h2d")
         return p
+
+    def memcpy_h2d(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(lib.aomhip_memcpy_h2d(self.h, ptr, arr.ctypes.data, arr.nbytes), "h2d")
 
     def from_device(self, ptr, shape, dtype):
         out = np.empty(shape, dtype)
@@ -514,10 +520,22 @@ class Context:
               "aomhip_full_pixel_search_batch")
 
     def subpel_tree_batch(self, src, ref, frame, bw, bh, params, d_blocks, n, d_mv, d_err, d_dist, d_sse, d_cost_list=None,
-                          d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):
+                          d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None, d_mv_lists=None):
+        if d_mv_lists is not None:
+            check(lib.aomhip_subpel_tree_list_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(params), d_mvjcost, d_mvcost_row, d_mvcost_col,
+                                                    d_blocks, d_cost_list, n, d_mv, d_err, d_dist, d_sse, d_mv_lists), "aomhip_subpel_tree_list_batch")
+            return
         check(lib.aomhip_subpel_tree_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(params), d_mvjcost,
                                            d_mvcost_row, d_mvcost_col, d_blocks, d_cost_list, n, d_mv, d_err, d_dist, d_sse),
               "aomhip_subpel_tree_batch")
+
+    def single_motion_search_batch(self, src, ref, frame, bw, bh, full, sub, d_blocks, n, d_best_mv, d_bestsme, d_rate_mv, d_mvjcost, d_mvcost_row,
+                                   d_mvcost_col, d_start2=None, use_cost_list=0, try_second_mv=0, force_integer_mv=0, d_pred_sse=None, d_full_mv=None,
+                                   d_second_best=None):
+        check(lib.aomhip_single_motion_search_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(full), None if sub is None else C.byref(sub),
+                                                    use_cost_list, try_second_mv, force_integer_mv, d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, d_start2,
+                                                    n, d_best_mv, d_bestsme, d_rate_mv, d_pred_sse, d_full_mv, d_second_best),
+              "aomhip_single_motion_search_batch")
 
     def build_inter_pred_batch(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, filter_x=0, filter_y=0, ss_x=0, ss_y=0):
         if ss_x or ss_y:

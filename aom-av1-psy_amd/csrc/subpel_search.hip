@@ -11,6 +11,7 @@ struct SubpelCostTables {
   const int *mvjcost, *mvcost0, *mvcost1;
   int error_per_bit;
   int upsampled;  // tree 2 with subpel_search_type USE_8_TAPS: errors from the up-sampled prediction
+  int16_t *mv_lists;  // last_mv_search_list per block (3 x (row, col), read and updated; general instantiation only) or null
 };
 
 #define AOMHIP_DECL_SUBPEL(NAME)                                                                                              \
@@ -48,7 +49,7 @@ int aomhip_subpel_bilinear_batch(aomhip_ctx *ctx, const aomhip_planes *src, cons
     return AOMHIP_ERR_INVALID;
   }
   return launch_subpel(ctx, src, ref, frame, bw, bh, mv_cost_type, iters_per_step, allow_hp, forced_stop, /*tree=*/0, nullptr,
-                       SubpelCostTables{ nullptr, nullptr, nullptr, 0, 0 }, d_blocks, n_blocks, d_best_mv, d_best_err,
+                       SubpelCostTables{ nullptr, nullptr, nullptr, 0, 0, nullptr }, d_blocks, n_blocks, d_best_mv, d_best_err,
                        d_distortion, d_sse);
 }
 
@@ -56,6 +57,15 @@ int aomhip_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *src, const ao
                              const aomhip_subpel_params *p, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
                              const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, const int32_t *d_cost_list,
                              int n_blocks, int16_t *d_best_mv, uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse) {
+  return aomhip_subpel_tree_list_batch(ctx, src, ref, frame, bw, bh, p, d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, d_cost_list, n_blocks, d_best_mv,
+                                       d_best_err, d_distortion, d_sse, nullptr);
+}
+
+int aomhip_subpel_tree_list_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                  const aomhip_subpel_params *p, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                                  const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, const int32_t *d_cost_list,
+                                  int n_blocks, int16_t *d_best_mv, uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse,
+                                  int16_t *d_mv_lists) {
   if (!p) {
     set_error("aomhip_subpel_tree_batch: invalid argument");
     return AOMHIP_ERR_INVALID;
@@ -70,7 +80,7 @@ int aomhip_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *src, const ao
     return AOMHIP_ERR_INVALID;
   }
   return launch_subpel(ctx, src, ref, frame, bw, bh, p->mv_cost_type, p->iters_per_step, p->allow_hp, p->forced_stop, p->tree,
-                       d_cost_list, SubpelCostTables{ d_mvjcost, d_mvcost_row, d_mvcost_col, p->error_per_bit, p->tree == 2 && p->subpel_search_type == 3 }, d_blocks,
+                       d_cost_list, SubpelCostTables{ d_mvjcost, d_mvcost_row, d_mvcost_col, p->error_per_bit, p->tree == 2 && p->subpel_search_type == 3, d_mv_lists }, d_blocks,
                        n_blocks, d_best_mv, d_best_err, d_distortion, d_sse);
 }
 

@@ -693,3 +693,156 @@ extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_plane
   }
   return AOMHIP_OK;
 }
+
+// ---- av1_single_motion_search, SIMPLE_TRANSLATION core (av1/encoder/motion_search_facade.c:120-495) for independent (block, reference) pairs:
+// up to two full-pel searches from the caller's candidate start MVs (:271-290), the sub-pel search from the winner, optionally the second
+// sub-pel search from second_best_mv on the same last_mv_search_list, kept when its error is smaller (:367-430, disable_second_mv == 1), and
+// av1_mv_bit_cost of the result (:485-493).  The decisions that need the mode loop's state (mode_info[], args->single_newmv*, DRL costs:
+// :300-341, :447-483) read only this call's outputs and stay with the caller.
+namespace aomhip {
+namespace {
+constexpr int kInvalidMv = -32768;   // INVALID_MV_ROW_COL
+__global__ void single_full_list_kernel(const aomhip_search_block *blocks, const int16_t *start2, int n, aomhip_search_block *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const aomhip_search_block b = blocks[i];
+  aomhip_search_block o = b;
+  if (start2) { o.start_row = start2[2 * i]; o.start_col = start2[2 * i + 1]; }
+  if (o.start_row == kInvalidMv) o.start_row = o.start_col = 0;   // searched, never looked at (single_select_kernel tests the caller's value)
+  full_limits_ref(b, &o);
+  out[i] = o;
+}
+struct SingleCand { const int16_t *mv, *second; const int32_t *cost, *cl; };
+__global__ void single_select_kernel(const aomhip_search_block *blocks, const int16_t *start2, SingleCand c0, SingleCand c1, int n, int16_t *full_mv,
+                                     int16_t *second, int32_t *bestsme, int32_t *cl, aomhip_search_block *sub_list) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const aomhip_search_block b = blocks[i];
+  int sme = INT_MAX, mr = kInvalidMv, mc = kInvalidMv, sr = kInvalidMv, sc = kInvalidMv;
+  int l0 = INT_MAX, l1 = INT_MAX, l2 = INT_MAX, l3 = INT_MAX, l4 = INT_MAX;
+  auto take = [&](const SingleCand &c) {
+    if (c.cl) { l0 = c.cl[5 * i]; l1 = c.cl[5 * i + 1]; l2 = c.cl[5 * i + 2]; l3 = c.cl[5 * i + 3]; l4 = c.cl[5 * i + 4]; }   // one array for all candidates
+    if (c.cost[i] < sme) { sme = c.cost[i]; mr = c.mv[2 * i]; mc = c.mv[2 * i + 1]; sr = c.second[2 * i]; sc = c.second[2 * i + 1]; }
+  };
+  if (b.start_row != kInvalidMv) take(c0);
+  if (start2 && start2[2 * i] != kInvalidMv) take(c1);
+  full_mv[2 * i] = (int16_t)mr; full_mv[2 * i + 1] = (int16_t)mc;
+  second[2 * i] = (int16_t)sr; second[2 * i + 1] = (int16_t)sc;
+  bestsme[i] = sme;
+  if (cl) { cl[5 * i] = l0; cl[5 * i + 1] = l1; cl[5 * i + 2] = l2; cl[5 * i + 3] = l3; cl[5 * i + 4] = l4; }
+  aomhip_search_block o = b;
+  subpel_limits_ref(b, &o);
+  const bool dead = mr == kInvalidMv;
+  o.start_row = (int16_t)(dead ? max(min(0, (int)o.row_max), (int)o.row_min) : mr * 8);     // get_mv_from_fullmv(best_mv) (:358)
+  o.start_col = (int16_t)(dead ? max(min(0, (int)o.col_max), (int)o.col_min) : mc * 8);
+  sub_list[i] = o;
+}
+// the second sub-pel start (:370-389): second_best_mv when it is valid, differs from the winner and lies inside the sub-pel limits; the other
+// blocks start at the winner again, which the list stops at iteration 0 with INT_MAX -- the value that can never win below
+__global__ void single_second_list_kernel(const aomhip_search_block *sub_list, const int16_t *full_mv, const int16_t *second, int n, aomhip_search_block *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  aomhip_search_block o = sub_list[i];
+  const int sr = second[2 * i], sc = second[2 * i + 1];
+  const bool differs = sr != full_mv[2 * i] || sc != full_mv[2 * i + 1];
+  if (sr != kInvalidMv && differs && sc * 8 >= o.col_min && sc * 8 <= o.col_max && sr * 8 >= o.row_min && sr * 8 <= o.row_max) {
+    o.start_row = (int16_t)(sr * 8); o.start_col = (int16_t)(sc * 8);
+  }
+  out[i] = o;
+}
+__global__ void single_fill_invalid_kernel(int16_t *p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (int16_t)kInvalidMv;
+}
+__global__ void single_finish_kernel(const aomhip_search_block *blocks, const int16_t *full_mv, int force_integer_mv, const int16_t *mv_a, const uint32_t *err_a,
+                                     const uint32_t *sse_a, const int16_t *mv_b, const uint32_t *err_b, const uint32_t *sse_b, int n, const int32_t *mvjcost,
+                                     const int32_t *mvcost0, const int32_t *mvcost1, int16_t *best_mv, int32_t *rate_mv, uint32_t *pred_sse) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int row = kInvalidMv, col = kInvalidMv, rate = 0;
+  uint32_t sse = 0;
+  if (full_mv[2 * i] != kInvalidMv) {
+    if (force_integer_mv) { row = full_mv[2 * i] * 8; col = full_mv[2 * i + 1] * 8; }   // convert_fullmv_to_mv (:343-345)
+    else {
+      row = mv_a[2 * i]; col = mv_a[2 * i + 1]; sse = sse_a[i];
+      if (mv_b && (int)err_b[i] < (int)err_a[i]) { row = mv_b[2 * i]; col = mv_b[2 * i + 1]; sse = sse_b[i]; }   // this_var < best_mv_var (:421-425)
+    }
+    const aomhip_search_block b = blocks[i];
+    const int dr = row - b.ref_row, dc = col - b.ref_col;                               // av1_mv_bit_cost(.., MV_COST_WEIGHT) (mcomp.c:261-266)
+    const int64_t bits = (int64_t)mvjcost[(dc != 0) | ((dr != 0) << 1)] + mvcost0[dr] + mvcost1[dc];
+    rate = (int)((bits * 108 + 64) >> 7);
+  }
+  best_mv[2 * i] = (int16_t)row; best_mv[2 * i + 1] = (int16_t)col;
+  rate_mv[i] = rate;
+  if (pred_sse) pred_sse[i] = sse;
+}
+}  // namespace
+}  // namespace aomhip
+
+extern "C" int aomhip_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                                 const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list, int try_second_mv,
+                                                 int force_integer_mv, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                                 const aomhip_search_block *d_blocks, const int16_t *d_start2, int n, int16_t *d_best_mv, int32_t *d_bestsme,
+                                                 int32_t *d_rate_mv, uint32_t *d_pred_sse, int16_t *d_full_mv, int16_t *d_second_best_mv) {
+  if (!ctx || !src || !ref || !full || (!sub && !force_integer_mv) || n < 0 || !d_mvjcost || !d_mvcost_row || !d_mvcost_col ||
+      (n > 0 && (!d_blocks || !d_best_mv || !d_bestsme || !d_rate_mv))) {
+    set_error("aomhip_single_motion_search_batch: invalid argument (the rate of the result needs the MV cost tables)");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n == 0) return AOMHIP_OK;
+  AOMHIP_TRY(hipSetDevice(ctx->device));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t n1 = (size_t)n, SB = sizeof(aomhip_search_block);
+  const size_t o_fl = take(n1 * SB), o_sl = take(n1 * SB), o_sl2 = take(n1 * SB), o_mv0 = take(n1 * 4), o_mv1 = take(n1 * 4), o_sec0 = take(n1 * 4),
+               o_sec1 = take(n1 * 4), o_c0 = take(n1 * 4), o_c1 = take(n1 * 4), o_cl0 = take(n1 * 20), o_cl1 = take(n1 * 20), o_cl = take(n1 * 20),
+               o_fmv = take(n1 * 4), o_sec = take(n1 * 4), o_lists = take(n1 * 12), o_mva = take(n1 * 4), o_erra = take(n1 * 4), o_dist = take(n1 * 4),
+               o_ssea = take(n1 * 4), o_mvb = take(n1 * 4), o_errb = take(n1 * 4), o_sseb = take(n1 * 4);
+  char *w = static_cast<char *>(work(ctx, off));
+  if (!w) return AOMHIP_ERR_NOMEM;
+  auto blk = [&](size_t o) { return reinterpret_cast<aomhip_search_block *>(w + o); };
+  auto i16 = [&](size_t o) { return reinterpret_cast<int16_t *>(w + o); };
+  auto i32 = [&](size_t o) { return reinterpret_cast<int32_t *>(w + o); };
+  auto u32 = [&](size_t o) { return reinterpret_cast<uint32_t *>(w + o); };
+  int16_t *fmv = d_full_mv ? d_full_mv : i16(o_fmv), *sec = d_second_best_mv ? d_second_best_mv : i16(o_sec);
+  const unsigned g = (unsigned)((n1 + 255) / 256);
+  hipLaunchKernelGGL(single_full_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, (const int16_t *)nullptr, n, blk(o_fl));
+  AOMHIP_LAUNCH_CHECK();
+  int rc = aomhip_full_pixel_search_batch(ctx, src, ref, frame, bw, bh, full, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_fl), n, i16(o_mv0), i32(o_c0),
+                                          use_cost_list ? i32(o_cl0) : nullptr, i16(o_sec0));
+  if (rc != AOMHIP_OK) return rc;
+  aomhip::SingleCand c0{ i16(o_mv0), i16(o_sec0), i32(o_c0), use_cost_list ? i32(o_cl0) : nullptr }, c1 = c0;
+  if (d_start2) {
+    hipLaunchKernelGGL(single_full_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_start2, n, blk(o_fl));
+    AOMHIP_LAUNCH_CHECK();
+    rc = aomhip_full_pixel_search_batch(ctx, src, ref, frame, bw, bh, full, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_fl), n, i16(o_mv1), i32(o_c1),
+                                        use_cost_list ? i32(o_cl1) : nullptr, i16(o_sec1));
+    if (rc != AOMHIP_OK) return rc;
+    c1 = aomhip::SingleCand{ i16(o_mv1), i16(o_sec1), i32(o_c1), use_cost_list ? i32(o_cl1) : nullptr };
+  }
+  int32_t *cl = use_cost_list ? i32(o_cl) : nullptr;
+  hipLaunchKernelGGL(single_select_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_start2, c0, c1, n, fmv, sec, d_bestsme, cl, blk(o_sl));
+  AOMHIP_LAUNCH_CHECK();
+  const bool second = try_second_mv && !force_integer_mv;
+  if (!force_integer_mv) {
+    int16_t *lists = second ? i16(o_lists) : nullptr;
+    if (second) {
+      hipLaunchKernelGGL(single_fill_invalid_kernel, dim3((unsigned)((6 * n1 + 255) / 256)), dim3(256), 0, ctx->stream, lists, 6 * n);   // av1_set_fractional_mv
+      AOMHIP_LAUNCH_CHECK();
+    }
+    rc = aomhip_subpel_tree_list_batch(ctx, src, ref, frame, bw, bh, sub, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_sl), cl, n, i16(o_mva), u32(o_erra),
+                                       i32(o_dist), u32(o_ssea), lists);
+    if (rc != AOMHIP_OK) return rc;
+    if (second) {
+      hipLaunchKernelGGL(single_second_list_kernel, dim3(g), dim3(256), 0, ctx->stream, blk(o_sl), fmv, sec, n, blk(o_sl2));
+      AOMHIP_LAUNCH_CHECK();
+      rc = aomhip_subpel_tree_list_batch(ctx, src, ref, frame, bw, bh, sub, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_sl2), cl, n, i16(o_mvb),
+                                         u32(o_errb), i32(o_dist), u32(o_sseb), lists);
+      if (rc != AOMHIP_OK) return rc;
+    }
+  }
+  hipLaunchKernelGGL(single_finish_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, fmv, force_integer_mv, i16(o_mva), u32(o_erra), u32(o_ssea),
+                     second ? i16(o_mvb) : nullptr, u32(o_errb), u32(o_sseb), n, d_mvjcost, d_mvcost_row, d_mvcost_col, d_best_mv, d_rate_mv, d_pred_sse);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}

@@ -515,6 +515,16 @@ int aomhip_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *src, const ao
                              const aomhip_subpel_params *params, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
                              const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, const int32_t *d_cost_list,
                              int n_blocks, int16_t *d_best_mv, uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse);
+/* The same with last_mv_search_list (check_repeated_mv_and_update, mcomp.c:2816-2828): d_mv_lists holds 3 x (row, col) int16 per block,
+ * INVALID_MV = (-32768, -32768) as av1_set_fractional_mv leaves it, read AND updated: a search whose centre at iteration k equals entry k
+ * stops there and returns INT_MAX in d_best_err, with d_best_mv / d_distortion / d_sse as they stand at that point; otherwise entry k
+ * becomes that centre.  Calling it twice on one list is av1_single_motion_search's second-MV refinement
+ * (motion_search_facade.c:367-430).  NULL = aomhip_subpel_tree_batch. */
+int aomhip_subpel_tree_list_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                  const aomhip_subpel_params *params, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                                  const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, const int32_t *d_cost_list,
+                                  int n_blocks, int16_t *d_best_mv, uint32_t *d_best_err, int32_t *d_distortion, uint32_t *d_sse,
+                                  int16_t *d_mv_lists);
 
 /* full_pixel_exhaustive (av1/encoder/mcomp.c:1547-1617): the mesh search av1_full_pixel_search (:1693-1832) runs as a
  * follow-up / for intra block copy.  mesh_patterns = MAX_MESH_STEP (4) pairs {range, interval} on the HOST (a row of
@@ -704,6 +714,27 @@ int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_planes *src, int
                                   const int32_t *d_mvcost_col, const aomhip_first_pass_params *fp, const aomhip_search_block *d_blocks,
                                   const int32_t *d_intra_error, int16_t *d_best_mv, int16_t *d_full_mv, int32_t *d_motion_error,
                                   int32_t *d_gf_motion_error, int32_t *d_raw_motion_error);
+
+/* The SIMPLE_TRANSLATION core of av1_single_motion_search (av1/encoder/motion_search_facade.c:120-495) for a list of independent
+ * (block, reference frame) pairs -- e.g. one block against all its reference frames and ref_mv_idx values, or the blocks of a frame whose
+ * ref_mvs are already known:
+ *   1. av1_full_pixel_search from cand[0] (block.start_*, FULLPEL) and, where d_start2 holds one, cand[1] (:271-290; the caller applies
+ *      get_mv_candidate_from_tpl, the weight rule and skip_fullpel_search_using_startmv: a start of (-32768, -32768) is not searched), the
+ *      smaller bestsme wins together with its second_best_mv; ONE cost_list serves all candidates (the last search's stays, as in the
+ *      reference); limits = av1_set_mv_search_range(x->mv_limits, ref_mv) from block.ref_* and the raw limits in the block;
+ *   2. unless force_integer_mv: find_fractional_mv_step (params->tree) from get_mv_from_fullmv(best) inside av1_set_subpel_mv_search_range,
+ *      with the cost list when use_cost_list; with try_second_mv (sf.mv_sf.use_accurate_subpel_search && disable_second_mv == 1) a second
+ *      search from second_best_mv on the same last_mv_search_list, kept when its error is smaller (:367-430);
+ *   3. *rate_mv = av1_mv_bit_cost(best_mv, ref_mv, .., MV_COST_WEIGHT) (:485-493).
+ * Not here: OBMC_CAUSAL, scaled references, disable_second_mv == 0 (needs av1_estimate_txfm_yrd), and the early exits that read the mode
+ * loop's state (mode_info[], args->single_newmv*, :300-341, :447-483) -- those compare values this call returns.
+ * Outputs per pair: d_best_mv (1/8 pel; (-32768, -32768) when no candidate was searched or every search returned INT_MAX), d_bestsme (the
+ * full-pel value), d_rate_mv, d_pred_sse (x->pred_sse[ref]; NULL allowed), d_full_mv / d_second_best_mv (FULLPEL; NULL allowed). */
+int aomhip_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                      const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list, int try_second_mv,
+                                      int force_integer_mv, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                      const aomhip_search_block *d_blocks, const int16_t *d_start2, int n_blocks, int16_t *d_best_mv,
+                                      int32_t *d_bestsme, int32_t *d_rate_mv, uint32_t *d_pred_sse, int16_t *d_full_mv, int16_t *d_second_best_mv);
 
 /* ------------------------------------------------------------------ full-pel + sub-pel search of a block list in one call (TPL, single motion search) */
 

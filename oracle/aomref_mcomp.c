@@ -979,11 +979,22 @@ void orc_subpel_bilinear_batch(const void *src_origin, int src_stride, const voi
  * cost_lists: 5 ints per block (what av1_full_pixel_search returned) or NULL. */
 static int divide_and_round(int n, int d) { return ((n < 0) ^ (d < 0)) ? ((n - d / 2) / d) : ((n + d / 2) / d); }
 
-void orc_subpel_tree_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16, int bd,
-                           int w, int h, int tree, int subpel_search_type, int cost_type, int error_per_bit, const int *mvjcost, const int *mvcost0,
-                           const int *mvcost1, int iters_per_step, int allow_hp, int forced_stop,
-                           const orc_subpel_block *blocks, const int32_t *cost_lists, int n, int16_t *out_mv, uint32_t *out_err,
-                           int32_t *out_distortion, uint32_t *out_sse, int threads) {
+/* check_repeated_mv_and_update (mcomp.c:2818-2828) on one block's last_mv_search_list: 3 x (row, col), INVALID_MV = (-32768, -32768) */
+static int repeated_mv(int16_t *list, int row, int col, int iter) {
+  if (!list) return 0;
+  if (list[2 * iter] == row && list[2 * iter + 1] == col) return 1;
+  list[2 * iter] = (int16_t)row;
+  list[2 * iter + 1] = (int16_t)col;
+  return 0;
+}
+
+/* mv_lists: last_mv_search_list per block (n x 3 x 2 int16, read and updated) or NULL.  A search that finds the centre of one of its
+ * iterations equal to the list's entry for that iteration returns INT_MAX there, leaving bestmv / distortion / sse1 as they stand. */
+void orc_subpel_tree_batch_list(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16, int bd,
+                                int w, int h, int tree, int subpel_search_type, int cost_type, int error_per_bit, const int *mvjcost, const int *mvcost0,
+                                const int *mvcost1, int iters_per_step, int allow_hp, int forced_stop,
+                                const orc_subpel_block *blocks, const int32_t *cost_lists, int n, int16_t *out_mv, uint32_t *out_err,
+                                int32_t *out_distortion, uint32_t *out_sse, int threads, int16_t *mv_lists) {
   if (threads < 1) threads = 1;
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 16)
   for (int i = 0; i < n; ++i) {
@@ -1012,16 +1023,20 @@ void orc_subpel_tree_batch(const void *src_origin, int src_stride, const void *r
     }
     int hstep = 4; /* INIT_SUBPEL_STEP_SIZE */
     const int sr = b->start_row, sc = b->start_col;
+    int16_t *ml = mv_lists ? mv_lists + 6 * i : NULL;
     if (tree == 2) {
       int round = 3 - forced_stop; /* FULL_PEL - forced_stop */
       if (round > 3 - !allow_hp) round = 3 - !allow_hp;
       for (int iter = 0; iter < round; ++iter) {
         const int cr = s.best_row, cc = s.best_col;
         int drow, dcol;
+        if (repeated_mv(ml, cr, cc, iter)) { s.besterr = INT_MAX; break; }   /* :3106-3109 */
         first_level_check_fast(&s, cr, cc, hstep, &drow, &dcol);
         if (!(cr == s.best_row && cc == s.best_col) && iters_per_step > 1) second_level_check_v2(&s, cr, cc, drow, dcol);
         hstep >>= 1;
       }
+    } else if (forced_stop != 3 && repeated_mv(ml, s.best_row, s.best_col, 0)) {   /* :2874-2876, :2959-2961 */
+      s.besterr = INT_MAX;
     } else if (forced_stop != 3) {
       const int32_t *cl = cost_lists ? cost_lists + 5 * i : NULL;
       const int usable = cl && cl[0] != INT_MAX && cl[1] != INT_MAX && cl[2] != INT_MAX && cl[3] != INT_MAX && cl[4] != INT_MAX;
@@ -1039,13 +1054,21 @@ void orc_subpel_tree_batch(const void *src_origin, int src_stride, const void *r
       } else {
         two_level_checks_fast(&s, sr, sc, hstep, iters_per_step);
       }
+      int live = 1;
       if (forced_stop < 2) {
-        hstep >>= 1;
-        two_level_checks_fast(&s, s.best_row, s.best_col, hstep, iters_per_step);
+        if (repeated_mv(ml, s.best_row, s.best_col, 1)) { s.besterr = INT_MAX; live = 0; }   /* :2899-2903 */
+        else {
+          hstep >>= 1;
+          two_level_checks_fast(&s, s.best_row, s.best_col, hstep, iters_per_step);
+        }
       }
-      if (allow_hp && forced_stop == 0) {
-        hstep >>= 1;
-        two_level_checks_fast(&s, s.best_row, s.best_col, hstep, iters_per_step);
+      if (live && allow_hp && forced_stop == 0) {
+        /* the third check uses the running `iter`: 2 after a quarter-pel level (the only way here: forced_stop == 0 < HALF_PEL) */
+        if (repeated_mv(ml, s.best_row, s.best_col, 2)) s.besterr = INT_MAX;                  /* :2912-2916 */
+        else {
+          hstep >>= 1;
+          two_level_checks_fast(&s, s.best_row, s.best_col, hstep, iters_per_step);
+        }
       }
     }
     out_mv[2 * i] = (int16_t)s.best_row;
@@ -1054,4 +1077,14 @@ void orc_subpel_tree_batch(const void *src_origin, int src_stride, const void *r
     out_distortion[i] = s.distortion;
     out_sse[i] = s.sse1;
   }
+}
+
+void orc_subpel_tree_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16, int bd,
+                           int w, int h, int tree, int subpel_search_type, int cost_type, int error_per_bit, const int *mvjcost, const int *mvcost0,
+                           const int *mvcost1, int iters_per_step, int allow_hp, int forced_stop,
+                           const orc_subpel_block *blocks, const int32_t *cost_lists, int n, int16_t *out_mv, uint32_t *out_err,
+                           int32_t *out_distortion, uint32_t *out_sse, int threads) {
+  orc_subpel_tree_batch_list(src_origin, src_stride, ref_origin, ref_stride, elem16, bd, w, h, tree, subpel_search_type, cost_type, error_per_bit, mvjcost,
+                             mvcost0, mvcost1, iters_per_step, allow_hp, forced_stop, blocks, cost_lists, n, out_mv, out_err, out_distortion, out_sse,
+                             threads, NULL);
 }

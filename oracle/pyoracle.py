@@ -686,8 +686,9 @@ SUBPEL_TREES = {"pruned_more": 0, "pruned": 1, "tree": 2}
 
 def subpel_tree_batch(src_b, ref_b, border, w, h, blocks, tree="pruned_more", cost_type=3, error_per_bit=0, mvjcost=None,
                       mvcost0=None, mvcost1=None, iters=2, allow_hp=1, forced_stop=0, cost_lists=None, bd=8, threads=4,
-                      subpel_search_type=0):
-    """The three bilinear sub-pel trees (tree: pruned_more / pruned / tree) with an optional per-block cost list."""
+                      subpel_search_type=0, mv_lists=None):
+    """The three bilinear sub-pel trees (tree: pruned_more / pruned / tree) with an optional per-block cost list and an optional
+    last_mv_search_list per block (mv_lists: int16 [n, 3, 2], INVALID_MV = -32768, updated in place; check_repeated_mv_and_update)."""
     blocks = np.ascontiguousarray(blocks)
     n = len(blocks)
     mv = np.zeros((n, 2), np.int16); err = np.zeros(n, np.uint32); dist = np.zeros(n, np.int32); sse = np.zeros(n, np.uint32)
@@ -703,12 +704,16 @@ def subpel_tree_batch(src_b, ref_b, border, w, h, blocks, tree="pruned_more", co
     cl = None
     if cost_lists is not None:
         cla = np.ascontiguousarray(cost_lists, np.int32).reshape(n, 5); keep.append(cla); cl = C.c_void_p(cla.ctypes.data)
-    lib.orc_subpel_tree_batch.restype = None
-    lib.orc_subpel_tree_batch(C.c_void_p(_addr(src_b, border, border)), src_b.shape[1], C.c_void_p(_addr(ref_b, border, border)),
-                              ref_b.shape[1], int(src_b.dtype != np.uint8), bd, w, h, SUBPEL_TREES.get(tree, tree), subpel_search_type,
-                              cost_type, error_per_bit, j, centre(mvcost0), centre(mvcost1), iters, allow_hp, forced_stop,
-                              C.c_void_p(blocks.ctypes.data), cl, n, C.c_void_p(mv.ctypes.data), C.c_void_p(err.ctypes.data),
-                              C.c_void_p(dist.ctypes.data), C.c_void_p(sse.ctypes.data), threads)
+    ml = None
+    if mv_lists is not None:
+        assert mv_lists.dtype == np.int16 and mv_lists.shape == (n, 3, 2) and mv_lists.flags.c_contiguous
+        ml = C.c_void_p(mv_lists.ctypes.data)
+    lib.orc_subpel_tree_batch_list.restype = None
+    lib.orc_subpel_tree_batch_list(C.c_void_p(_addr(src_b, border, border)), src_b.shape[1], C.c_void_p(_addr(ref_b, border, border)),
+                                   ref_b.shape[1], int(src_b.dtype != np.uint8), bd, w, h, SUBPEL_TREES.get(tree, tree), subpel_search_type,
+                                   cost_type, error_per_bit, j, centre(mvcost0), centre(mvcost1), iters, allow_hp, forced_stop,
+                                   C.c_void_p(blocks.ctypes.data), cl, n, C.c_void_p(mv.ctypes.data), C.c_void_p(err.ctypes.data),
+                                   C.c_void_p(dist.ctypes.data), C.c_void_p(sse.ctypes.data), threads, ml)
     return mv, err, dist, sse
 
 
@@ -1083,6 +1088,84 @@ def motion_estimation_batch(src_b, ref_b, border, w, h, blocks, q, sub, use_cost
     mv, err, dist, sse = subpel_tree_batch(src_b, ref_b, border, w, h, sl, mvjcost=mvjcost, mvcost0=mvcost0, mvcost1=mvcost1,
                                            cost_lists=cl if use_cost_list else None, bd=bd, threads=threads, **sub)
     return mv, err, dist, sse, full_mv
+
+
+def mv_bit_cost(mrow, mcol, ref_row, ref_col, mvjcost, mvcost0, mvcost1, weight=108):
+    """av1_mv_bit_cost (mcomp.c:261-266): ROUND_POWER_OF_TWO(mv_cost(diff) * weight, 7); weight MV_COST_WEIGHT = 108 (rd.h:45)."""
+    dr, dc = int(mrow) - int(ref_row), int(mcol) - int(ref_col)
+    bits = int(mvjcost[(dc != 0) | ((dr != 0) << 1)]) + int(mvcost0[len(mvcost0) // 2 + dr]) + int(mvcost1[len(mvcost1) // 2 + dc])
+    return (bits * int(weight) + 64) >> 7
+
+
+INVALID_MV_ROW_COL = -32768
+
+
+def single_motion_search_batch(src_b, ref_b, border, w, h, blocks, q, sub, start2=None, use_cost_list=0, try_second_mv=0, force_integer_mv=0,
+                               mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4):
+    """The SIMPLE_TRANSLATION core of av1_single_motion_search (motion_search_facade.c:120-495) as a composition of the pinned pieces, for a
+    list of independent (block, reference) pairs.  blocks: ref_* = ref_mv (1/8 pel), start_* = cand[0] (FULLPEL, -32768 = skipped by
+    skip_fullpel_search_using_startmv), limits = raw x->mv_limits; start2 [n, 2] = cand[1] or -32768 (:271-290: the caller knows before
+    searching how many candidates the weight rule admits).  try_second_mv: use_accurate_subpel_search with disable_second_mv == 1 (:367-430, the
+    second sub-pel search from second_best_mv, kept when its var is smaller).  -> dict(best_mv [n,2] 1/8 pel or -32768, bestsme, rate_mv,
+    pred_sse, full_mv, second_best)"""
+    n = len(blocks)
+    fl, sl = np.array(blocks, copy=True), np.array(blocks, copy=True)
+    for i, b in enumerate(blocks):
+        raw = (b["row_min"], b["row_max"], b["col_min"], b["col_max"])
+        fl["row_min"][i], fl["row_max"][i], fl["col_min"][i], fl["col_max"][i] = set_mv_search_range(raw, b["ref_row"], b["ref_col"])
+        sl["row_min"][i], sl["row_max"][i], sl["col_min"][i], sl["col_max"][i] = set_subpel_mv_search_range(raw, b["ref_row"], b["ref_col"])
+    bestsme = np.full(n, 2147483647, np.int64)
+    full_mv = np.full((n, 2), INVALID_MV_ROW_COL, np.int16)
+    second = np.full((n, 2), INVALID_MV_ROW_COL, np.int16)
+    cost_list = np.zeros((n, 5), np.int32)
+    starts = [np.stack([blocks["start_row"], blocks["start_col"]], 1).astype(np.int16)]
+    if start2 is not None:
+        starts.append(np.asarray(start2, np.int16))
+    for st in starts:                                      # "Perform a search with the top 2 candidates" (:271-290)
+        idx = np.flatnonzero(st[:, 0] != INVALID_MV_ROW_COL)
+        if not len(idx):
+            continue
+        l = fl[idx].copy()
+        l["start_row"], l["start_col"] = st[idx, 0], st[idx, 1]
+        mv, cost, cl, sec = full_pixel_search_batch(src_b, ref_b, border, w, h, l, q, mvjcost, mvcost0, mvcost1, bd=bd, threads=threads)
+        for k, i in enumerate(idx):
+            cost_list[i] = cl[k]                            # ONE cost_list array for all candidates (:247, :279): the last search's stays
+            if int(cost[k]) < bestsme[i]:
+                bestsme[i], full_mv[i], second[i] = int(cost[k]), mv[k], sec[k]
+    out = dict(best_mv=np.full((n, 2), INVALID_MV_ROW_COL, np.int16), bestsme=bestsme.astype(np.int32), rate_mv=np.zeros(n, np.int32),
+               pred_sse=np.zeros(n, np.uint32), full_mv=full_mv, second_best=second)
+    live = np.flatnonzero(full_mv[:, 0] != INVALID_MV_ROW_COL)     # if (best_mv->as_int == INVALID_MV) return (:298)
+    if not len(live):
+        return out
+    if force_integer_mv:                                    # convert_fullmv_to_mv, no fractional search (:343-349)
+        out["best_mv"][live] = full_mv[live] * 8
+    else:
+        l = sl[live].copy()
+        l["start_row"], l["start_col"] = full_mv[live, 0].astype(np.int32) * 8, full_mv[live, 1].astype(np.int32) * 8
+        lists = np.full((len(live), 3, 2), INVALID_MV_ROW_COL, np.int16) if try_second_mv else None     # av1_set_fractional_mv
+        cls = cost_list[live] if use_cost_list else None
+        mv, err, dist, sse = subpel_tree_batch(src_b, ref_b, border, w, h, l, mvjcost=mvjcost, mvcost0=mvcost0, mvcost1=mvcost1, cost_lists=cls, bd=bd,
+                                               threads=threads, mv_lists=lists, **sub)
+        out["best_mv"][live], out["pred_sse"][live] = mv, sse
+        if try_second_mv:
+            for k, i in enumerate(live):
+                s2 = second[i]
+                if s2[0] == INVALID_MV_ROW_COL or (s2 == full_mv[i]).all():                  # try_second (:370-372)
+                    continue
+                st = (int(s2[0]) * 8, int(s2[1]) * 8)
+                if not (l["row_min"][k] <= st[0] <= l["row_max"][k] and l["col_min"][k] <= st[1] <= l["col_max"][k]):   # av1_is_subpelmv_in_range
+                    continue
+                one = l[k:k + 1].copy()
+                one["start_row"], one["start_col"] = st
+                mv2, err2, _, sse2 = subpel_tree_batch(src_b, ref_b, border, w, h, one, mvjcost=mvjcost, mvcost0=mvcost0, mvcost1=mvcost1,
+                                                       cost_lists=cls[k:k + 1] if cls is not None else None, bd=bd, threads=1,
+                                                       mv_lists=lists[k:k + 1], **sub)
+                if int(np.int32(err2[0])) < int(np.int32(err[k])):                              # this_var < best_mv_var (int compare, :421)
+                    out["best_mv"][i], out["pred_sse"][i] = mv2[0], sse2[0]
+    for i in live:
+        b = blocks[i]
+        out["rate_mv"][i] = mv_bit_cost(out["best_mv"][i, 0], out["best_mv"][i, 1], b["ref_row"], b["ref_col"], mvjcost, mvcost0, mvcost1)
+    return out
 
 
 def simple_motion_search_batch(src_b, ref_b, border, width, height, w, h, blocks, q, sub=None, use_cost_list=0, mvjcost=None, mvcost0=None, mvcost1=None, bd=8,
