@@ -4,7 +4,9 @@ for R in $(seq 1 ${REPS:-2}); do
 IFS=';' read -ra WORKS <<< "${WORK:-4k 8 64 320,48;1080p 8 64 240,64;4k 10 32 160,32}"
 for W in "${WORKS[@]}"; do
   for LIBP in ${LIBS:-build/exp_base/libaomhip_exp.so build/exp/libaomhip_exp.so}; do
-  for D in ${DBGS:-0}; do echo "args=$W lib=$LIBP dbg=$D"; AOMHIP_LIB=$LIBP AOMHIP_SB_DBG=$D timeout 300 python tools/gpu_ab_sadsb.py $W 2>&1 | grep -E '^\{"cell|rror' | cut -c1-400; done
+  for CFG in ${CFGS:-wide}; do
+  for D in ${DBGS:-0}; do echo "args=$W lib=$LIBP cfg=$CFG dbg=$D"; AOMHIP_SB_CFG=$CFG AOMHIP_LIB=$LIBP AOMHIP_SB_DBG=$D timeout 300 python tools/gpu_ab_sadsb.py $W 2>&1 | grep -E '^\{"cell|rror' | cut -c1-400; done
+  done
 done; done; done > gpurun_out/${OUT:-r03d}/ab.log 2>&1
 python3 - <<'PY'
 import re,os
