@@ -541,50 +541,89 @@ __global__ void fpf_zero_list_kernel(const aomhip_search_block *blocks, int n, a
   full_limits(b, &o);
   out[i] = o;
 }
-__global__ void fpf_chain_list_kernel(const aomhip_search_block *blocks, const int16_t *chain, int col, int rows, int cols, aomhip_search_block *out) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  aomhip_search_block b = blocks[(size_t)r * cols + col];
-  b.ref_row = chain[2 * r]; b.ref_col = chain[2 * r + 1];
-  aomhip_search_block o = b;
-  o.start_row = (int16_t)rawpel(b.ref_row); o.start_col = (int16_t)rawpel(b.ref_col);   // get_fullmv_from_mv(ref_mv)
-  full_limits_ref(b, &o);
-  out[r] = o;
-}
 struct FpfLegs {
   const int16_t *zmv; const int32_t *zerr;   // zero-MV leg on the last frame, per block
   const int16_t *gmv; const int32_t *gerr;   // zero-MV leg on the golden frame, per block (null without one)
   const int16_t *cmv; const int32_t *cerr;   // chained leg of this column, per row
   const uint32_t *err0, *raw, *gf0;           // get_prediction_error_bitdepth at 0,0: last frame, last source, golden
 };
-__global__ void fpf_decide_kernel(FpfLegs L, const int32_t *intra, int col, int rows, int cols, int thr, int skip_zeromv, int16_t *chain,
-                                  int16_t *best_mv, int16_t *full_mv, int32_t *motion_error, int32_t *gf_motion_error, int32_t *raw_motion_error) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+// One block column of the chain in ONE launch behind its search (a wavefront per block row): the leg's av1_get_mvpred_sse + MV cost +
+// NEW_MV_MODE_PENALTY (what fp_cands / variance / fp_finish do for a list), the decision (firstpass.c:722-752, :777-794), and the next column's list
+// entry (get_fullmv_from_mv(best_ref_mv), av1_set_mv_search_range).  Six launches per column were 110 us of a 4K frame's 240 columns.
+struct FpfCost { int type, error_per_bit; const int32_t *mvjcost, *mvcost0, *mvcost1; };
+template <typename T>
+__global__ __launch_bounds__(256) void fpf_column_kernel(PlaneView<T> src, PlaneView<T> last, int bw, int bh, int bit_depth, const aomhip_search_block *blocks,
+                                                         const aomhip_search_block *cur_list, const int32_t *search_cost, FpfLegs L, FpfCost C,
+                                                         const int32_t *intra, int col, int rows, int cols, int thr, int skip_zeromv, int16_t *chain,
+                                                         aomhip_search_block *next_list, int16_t *best_mv, int16_t *full_mv, int32_t *motion_error,
+                                                         int32_t *gf_motion_error, int32_t *raw_motion_error) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= rows) return;
   const size_t i = (size_t)r * cols + col;
   const int ref_row = chain[2 * r], ref_col = chain[2 * r + 1];
-  int err = (int)L.err0[i], mrow = 0, mcol = 0;                // FULLPEL_MV mv = kZeroFullMv; motion_error at 0,0 (:698-708)
+  const bool moved = (ref_row | ref_col) != 0;
   const int raw = (int)L.raw[i];
-  int gf = err;
-  if (raw > thr) {                                             // :722
-    const bool moved = (ref_row | ref_col) != 0;
-    const int e1 = moved ? L.cerr[r] : L.zerr[i];              // first_pass_motion_search(ref_mv): tmp_err < *best_motion_err (:294)
-    if (e1 < err) { err = e1; mrow = moved ? L.cmv[2 * r] : L.zmv[2 * i]; mcol = moved ? L.cmv[2 * r + 1] : L.zmv[2 * i + 1]; }
-    if (!skip_zeromv && moved) {                               // :729-738: tmp_err starts at INT_MAX, so it becomes the leg's own error
+  int e1 = INT_MAX, m1r = 0, m1c = 0;
+  if (raw > thr) {
+    if (moved) {   // (col > 0: the chained leg was searched from cur_list[r])
+      m1r = L.cmv[2 * r]; m1c = L.cmv[2 * r + 1];
+      if (search_cost[r] != INT_MAX) {
+        const aomhip_search_block b = cur_list[r];
+        const T *sp = src.origin + (int64_t)b.by * src.stride + b.bx;
+        const T *rp = last.origin + (int64_t)(b.by + m1r) * last.stride + b.bx + m1c;
+        unsigned long long sse = 0;
+        for (int q = lane; q < bw * bh; q += 64) {
+          const int y = q / bw, x = q - y * bw;
+          const int d = (int)sp[(int64_t)y * src.stride + x] - (int)rp[(int64_t)y * last.stride + x];
+          sse += (unsigned)(d * d);
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) sse += __shfl_xor(sse, m, 64);
+        const uint32_t q = bit_depth == 10 ? (uint32_t)((sse + 8) >> 4) : bit_depth == 12 ? (uint32_t)((sse + 128) >> 8) : (uint32_t)sse;
+        const int mrow = m1r * 8, mcol = m1c * 8;
+        int cost;
+        if (C.type == kCostEntropy) {
+          const int dr = mrow - b.ref_row, dc = mcol - b.ref_col;
+          const int64_t bits = (int64_t)C.mvjcost[(dc != 0) | ((dr != 0) << 1)] + C.mvcost0[dr] + C.mvcost1[dc];
+          cost = (int)((bits * C.error_per_bit + (1 << 13)) >> 14);
+        } else {
+          const CostCtx cc{ C.type, b.ref_row, b.ref_col };
+          cost = cc.var_cost(mrow, mcol);
+        }
+        e1 = (int32_t)(q + (uint32_t)cost + 32u);
+      }
+    } else {
+      e1 = L.zerr[i]; m1r = L.zmv[2 * i]; m1c = L.zmv[2 * i + 1];
+    }
+  }
+  if (lane != 0) return;
+  int err = (int)L.err0[i], mrow = 0, mcol = 0, gf;
+  gf = err;
+  if (raw > thr) {
+    if (e1 < err) { err = e1; mrow = m1r; mcol = m1c; }
+    if (!skip_zeromv && moved) {
       const int e0 = L.zerr[i];
       if (e0 < err) { err = e0; mrow = L.zmv[2 * i]; mcol = L.zmv[2 * i + 1]; }
     }
-    gf = err;                                                  // :741
-    if (L.gerr) { gf = (int)L.gf0[i]; if (L.gerr[i] < gf) gf = L.gerr[i]; }   // :742-752
+    gf = err;
+    if (L.gerr) { gf = (int)L.gf0[i]; if (L.gerr[i] < gf) gf = L.gerr[i]; }
   }
-  int brow = 0, bcol = 0;                                      // *best_mv = kZeroMv (:777)
-  if (err <= intra[i]) { brow = mrow * 8; bcol = mcol * 8; }  // get_mv_from_fullmv(&mv) (:794)
+  int brow = 0, bcol = 0;
+  if (err <= intra[i]) { brow = mrow * 8; bcol = mcol * 8; }
   chain[2 * r] = (int16_t)brow; chain[2 * r + 1] = (int16_t)bcol;
   best_mv[2 * i] = (int16_t)brow; best_mv[2 * i + 1] = (int16_t)bcol;
   if (full_mv) { full_mv[2 * i] = (int16_t)mrow; full_mv[2 * i + 1] = (int16_t)mcol; }
   motion_error[i] = err;
   if (gf_motion_error) gf_motion_error[i] = gf;
   if (raw_motion_error) raw_motion_error[i] = raw;
+  if (col + 1 < cols) {
+    aomhip_search_block b = blocks[i + 1];
+    b.ref_row = (int16_t)brow; b.ref_col = (int16_t)bcol;
+    aomhip_search_block o = b;
+    o.start_row = (int16_t)rawpel(brow); o.start_col = (int16_t)rawpel(bcol);
+    full_limits_ref(b, &o);
+    next_list[r] = o;
+  }
 }
 }  // namespace
 }  // namespace aomhip
@@ -618,8 +657,8 @@ extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_plane
   const size_t r1 = (size_t)rows;
   const size_t o_zl = take(n1 * sizeof(aomhip_search_block)), o_zmv = take(n1 * 4), o_zerr = take(n1 * 4), o_gmv = take(n1 * 4), o_gerr = take(n1 * 4),
                o_e0 = take(n1 * 4), o_raw = take(n1 * 4), o_gf0 = take(n1 * 4), o_var = take(n1 * 4), o_cost = take(n1 * 4), o_sse = take(n1 * 4),
-               o_cand = take(n1 * sizeof(aomhip_var_cand)), o_cl = take(r1 * sizeof(aomhip_search_block)), o_cmv = take(r1 * 4), o_cerr = take(r1 * 4),
-               o_chain = take(r1 * 4);
+               o_cand = take(n1 * sizeof(aomhip_var_cand)), o_cl = take(r1 * sizeof(aomhip_search_block)), o_cl2 = take(r1 * sizeof(aomhip_search_block)),
+               o_cmv = take(r1 * 4), o_cerr = take(r1 * 4), o_chain = take(r1 * 4);
   char *w = static_cast<char *>(work(ctx, off));
   if (!w) return AOMHIP_ERR_NOMEM;
   auto i32 = [&](size_t o) { return reinterpret_cast<int32_t *>(w + o); };
@@ -636,7 +675,7 @@ extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_plane
   };
   const aomhip_planes s1 = one(src, src_frame), l1 = one(last, last_frame), ls1 = one(last_source, last_source_frame);
   const aomhip_planes g1 = golden ? one(golden, golden_frame) : s1;
-  const unsigned g = (unsigned)((n1 + 255) / 256), gr = (unsigned)((r1 + 63) / 64);
+  const unsigned g = (unsigned)((n1 + 255) / 256);
   auto sse0 = [&](const aomhip_planes &ref, uint32_t *out) {   // get_prediction_error_bitdepth: the mse function's sse at 0,0 (:113-160)
     const unsigned gv = (unsigned)((n1 + 3) / 4);
     if (src->bit_depth == 8)
@@ -680,15 +719,24 @@ extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_plane
   L.gmv = golden ? i16(o_gmv) : nullptr; L.gerr = golden ? i32(o_gerr) : nullptr;
   L.cmv = i16(o_cmv); L.cerr = i32(o_cerr);
   L.err0 = u32(o_e0); L.raw = u32(o_raw); L.gf0 = u32(o_gf0);
+  aomhip::FpfCost C{ p->mv_cost_type, p->error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col };
+  aomhip_search_block *cl2 = reinterpret_cast<aomhip_search_block *>(w + o_cl2);
+  const unsigned gw = (unsigned)((r1 + 3) / 4);
   for (int c = 0; c < cols; ++c) {
+    aomhip_search_block *cur = (c & 1) ? cl2 : cl, *nxt = (c & 1) ? cl : cl2;
     if (c > 0) {   // column 0 starts from kZeroMv: its ref_mv leg IS the zero-MV leg
-      hipLaunchKernelGGL(fpf_chain_list_kernel, dim3(gr), dim3(64), 0, ctx->stream, d_blocks, i16(o_chain), c, rows, cols, cl);
-      AOMHIP_LAUNCH_CHECK();
-      rc = leg(l1, cl, rows, i16(o_cmv), i32(o_cerr));
+      rc = aomhip_full_pixel_search_batch(ctx, &s1, &l1, 0, bw, bh, p, d_mvjcost, d_mvcost_row, d_mvcost_col, cur, rows, i16(o_cmv), i32(o_cost), nullptr,
+                                          nullptr);
       if (rc != AOMHIP_OK) return rc;
     }
-    hipLaunchKernelGGL(fpf_decide_kernel, dim3(gr), dim3(64), 0, ctx->stream, L, d_intra_error, c, rows, cols, fp->skip_motion_search_threshold,
-                       fp->skip_zeromv_motion_search, i16(o_chain), d_best_mv, d_full_mv, d_motion_error, d_gf_motion_error, d_raw_motion_error);
+    if (src->bit_depth == 8)
+      hipLaunchKernelGGL(fpf_column_kernel<uint8_t>, dim3(gw), dim3(256), 0, ctx->stream, view_of<uint8_t>(s1), view_of<uint8_t>(l1), bw, bh, 8, d_blocks, cur,
+                         i32(o_cost), L, C, d_intra_error, c, rows, cols, fp->skip_motion_search_threshold, fp->skip_zeromv_motion_search, i16(o_chain), nxt,
+                         d_best_mv, d_full_mv, d_motion_error, d_gf_motion_error, d_raw_motion_error);
+    else
+      hipLaunchKernelGGL(fpf_column_kernel<uint16_t>, dim3(gw), dim3(256), 0, ctx->stream, view_of<uint16_t>(s1), view_of<uint16_t>(l1), bw, bh,
+                         src->bit_depth, d_blocks, cur, i32(o_cost), L, C, d_intra_error, c, rows, cols, fp->skip_motion_search_threshold,
+                         fp->skip_zeromv_motion_search, i16(o_chain), nxt, d_best_mv, d_full_mv, d_motion_error, d_gf_motion_error, d_raw_motion_error);
     AOMHIP_LAUNCH_CHECK();
   }
   return AOMHIP_OK;
