@@ -1034,19 +1034,22 @@ def kernel_avg_ms(ctx, fn, reps):
 
 
 def search_bound():
-    """The measured bound of the search kernels (profiles/r02_search_l1_bound.json, PMC): L1 cache-line accesses per CU per clock."""
+    """What bounds the search kernels.  Round 2 read the PMC figures (L1 busy 95 %, 0.81 line accesses per CU per clock) as an L1 line-rate
+    bound; round 3 tested that directly -- a reference layout with 4-8 x fewer lines per candidate left the diamond kernel's time unchanged
+    (profiles/r03_search.md, section 4) -- so the bound is the latency of a search's ~20 dependent rounds, and the L1 counters measure requests
+    waiting for data."""
     p = os.path.join(ROOT, "profiles", "r02_search_l1_bound.json")
     try:
         d = json.load(open(p))
-        return {"fullpel_diamond_kernel": {"bound": "L1 (TCP) cache-line access rate, 1 per CU per clock: a 16x16 candidate row is one 32-byte "
-                                                    "piece of its own line", "frac": d["fullpel_diamond"]["l1_accesses_per_cu_cycle"]},
-                "subpel_bilinear_kernel": {"bound": "VALU issue (1 wave-instruction per SIMD per 2 clocks), after the reference footprint moved "
-                                                    "to LDS (round 1 form: 0.88 of the L1 look-up rate)",
+        return {"fullpel_diamond_kernel": {"bound": "latency: ~20 dependent rounds (8 sites -> SAD -> compare -> next centre) per block, 5 blocks per SIMD "
+                                                    "in flight; NOT the L1 line rate (a layout with 4-8x fewer line look-ups per candidate: same time)",
+                                           "l1_accesses_per_cu_cycle_pmc": d["fullpel_diamond"]["l1_accesses_per_cu_cycle"]},
+                "subpel_bilinear_kernel": {"bound": "VALU issue (1 wave-instruction per SIMD per 2 clocks), reference footprint in LDS",
                                            "frac": d["subpel_bilinear_lds_footprint"]["valu_issue_frac"],
                                            "issue_wait_frac": d["subpel_bilinear_lds_footprint"]["SQ_WAIT_INST_ANY_over_WAVE_CYCLES"]},
-                "full_pixel_search_kernel_NSTEP": {"bound": "L1 (TCP) cache-line access rate, as the diamond kernel",
-                                                   "frac": d.get("full_pixel_search_nstep", {}).get("l1_accesses_per_cu_cycle")},
-                "source": "profiles/r02_search_bound.md, profiles/r02_search_l1_bound.json (rocprofv3 --pmc)"}
+                "full_pixel_search_kernel_NSTEP": {"bound": "latency, as the diamond kernel (3 blocks per SIMD at 145 VGPRs)",
+                                                   "l1_accesses_per_cu_cycle_pmc": d.get("full_pixel_search_nstep", {}).get("l1_accesses_per_cu_cycle")},
+                "source": "profiles/r03_search.md, profiles/r02_search_bound.md, profiles/r02_search_l1_bound.json (rocprofv3 --pmc)"}
     except Exception:
         return None
 
