@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kSearchThreads, AOMHIP_DIAMOND_WAVES) void fullpel_
     PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
     int level, int step_param, int cost_type, int bit_depth, int16_t *__restrict__ out_mv,
     int32_t *__restrict__ out_cost) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (uniform: the block record and everything derived from it -- centre, limits, step state -- then lives in SGPRs and the search loops branch on the scalar unit)
   const int bi = blockIdx.x * (kSearchThreads / 64) + wave;
   if (bi >= n_blocks) return;
   const aomhip_search_block b = blocks[bi];
@@ -116,20 +116,22 @@ __global__ __launch_bounds__(kSearchThreads, AOMHIP_DIAMOND_WAVES) void fullpel_
       } else {
         mine = group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)srow * ref.stride + scol, ref.stride, l, inr, srcu) >> shift;
       }
+      // The reference walks the 8 sites in order with `if (sad < best) { sad += cost; if (sad < best) take it }` (mcomp.c:1350-1395): since
+      // the L1 costs of this kernel are never negative that is "the FIRST site that attains the smallest sad + cost, if that is below the
+      // best so far".  Every group adds its own site's cost, the 8 keys (sad + cost) << 4 | site are min-reduced -- one DPP step inside
+      // the 16-lane rows, four v_readlane, three s_min -- instead of 16 v_readlane and eight dependent scalar compare / branch sequences.
       int best_site = 0;
-#pragma unroll
-      for (int idx = 1; idx <= 8; ++idx) {
-        // (v_readlane to an SGPR: every lane needs the same value; a ds_bpermute-based __shfl costs an LDS round trip)
-        const uint32_t sad = (uint32_t)__builtin_amdgcn_readlane((int)mine, (idx - 1) * 8);
-        const int ok = __builtin_amdgcn_readlane((int)inr, (idx - 1) * 8);
-        const int ddr = (idx == 1 || idx == 5 || idx == 7) ? -1 : (idx == 2 || idx == 6 || idx == 8) ? 1 : 0;
-        const int ddc = (idx == 3 || idx == 5 || idx == 8) ? -1 : (idx == 4 || idx == 6 || idx == 7) ? 1 : 0;
-        if (ok && sad < bestsad) {
-          const uint32_t thissad = sad + (uint32_t)cc.sad_cost(row + ddr * r, col + ddc * r);
-          if (thissad < bestsad) {
-            bestsad = thissad;
-            best_site = idx;
-          }
+      {
+        const uint32_t my_this = mine + (uint32_t)cc.sad_cost(srow, scol);
+        uint32_t key = inr ? ((my_this << 4) | (uint32_t)(g + 1)) : 0xFFFFFFFFu;
+        const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x128, 0xf, 0xf, false);  // row_ror:8: the row's other group
+        key = min(key, other);
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, 0), k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, 16);
+        const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)key, 32), k3 = (uint32_t)__builtin_amdgcn_readlane((int)key, 48);
+        const uint32_t kb = min(min(k0, k1), min(k2, k3));
+        if (kb != 0xFFFFFFFFu && (kb >> 4) < bestsad) {
+          bestsad = kb >> 4;
+          best_site = (int)(kb & 15u);
         }
       }
       if (best_site != 0) {
