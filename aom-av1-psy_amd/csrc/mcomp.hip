@@ -48,6 +48,16 @@ __global__ __launch_bounds__(kSearchThreads, AOMHIP_DIAMOND_WAVES) void fullpel_
 
   typename G8<T, W, H>::L srcu[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1];
   group8_load_src<T, W, H>(sp, src.stride, l, srcu);
+  // candidates as uniform base + 32-bit lane offset (search_device.h group8_sad_u); the base sits at the smallest legal MV
+  [[maybe_unused]] uint32_t uoff[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1];
+  group8_unit_offsets<T, W, H>(ref.stride, l, uoff);
+  [[maybe_unused]] const char *ubase = reinterpret_cast<const char *>(rbase + (int64_t)b.row_min * ref.stride + b.col_min);
+  auto site_sad = [&](int row, int col, bool active) -> uint32_t {
+    if constexpr (G8<T, W, H>::KEEP)
+      return group8_sad_u<T, W, H>(ubase, (uint32_t)(((row - b.row_min) * ref.stride + (col - b.col_min)) * (int)sizeof(T)), l, active, uoff, srcu);
+    else
+      return group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)row * ref.stride + col, ref.stride, l, active, srcu);
+  };
 
   // LDS window for the fine steps of a search (radius <= 8): the (2*15 + H) x (2*15 + W) pixels around the current
   // centre are staged once (about the traffic of ONE diamond step) and the remaining steps of the run -- whose
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(kSearchThreads, AOMHIP_DIAMOND_WAVES) void fullpel_
     const int tot_steps = 11 - search_step;
     *num00 = 0;
     // (the centre is one position: group 0 evaluates it, the other seven groups would only repeat its loads)
-    uint32_t s0 = group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)row * ref.stride + col, ref.stride, l, g == 0, srcu) >> shift;
+    uint32_t s0 = site_sad(row, col, g == 0) >> shift;
     s0 = (uint32_t)__builtin_amdgcn_readlane((int)s0, 0);
     uint32_t bestsad = s0 + (uint32_t)cc.sad_cost(row, col);
     int is_off_center = 0;
@@ -112,9 +122,9 @@ __global__ __launch_bounds__(kSearchThreads, AOMHIP_DIAMOND_WAVES) void fullpel_
           mine = group8_sad_lds<T, W, H>(win, (unsigned)((srow - wr0) * kWinPitch + (scol - wc0) * (int)sizeof(T)), kWinPitch, l,
                                          inr, srcu) >> shift;
         else
-          mine = group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)srow * ref.stride + scol, ref.stride, l, inr, srcu) >> shift;
+          mine = site_sad(srow, scol, inr) >> shift;
       } else {
-        mine = group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)srow * ref.stride + scol, ref.stride, l, inr, srcu) >> shift;
+        mine = site_sad(srow, scol, inr) >> shift;
       }
       // The reference walks the 8 sites in order with `if (sad < best) { sad += cost; if (sad < best) take it }` (mcomp.c:1350-1395): since
       // the L1 costs of this kernel are never negative that is "the FIRST site that attains the smallest sad + cost, if that is below the

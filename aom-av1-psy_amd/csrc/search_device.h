@@ -141,6 +141,46 @@ __device__ __forceinline__ uint32_t group8_sad(const T *sp, int sstride, const T
   return acc;
 }
 
+// The same SAD with the candidate addressed as a UNIFORM base (SGPR pair: the wavefront's block) + a 32-bit byte offset per lane: the
+// loads take the `global_load v, v_off, s[base]` form and the per-unit address is one v_add_u32 -- the pointer form above costs three
+// 64-bit VALU operations per load (v_mad_i64_i32 + v_lshl_add_u64), a fifth of a search step's vector instructions.
+// site_off = ((row - row0) * rstride + (col - col0)) * sizeof(T) >= 0 relative to `base` (the caller anchors base at the block's
+// smallest legal MV); unit_off[k] = this lane's k-th unit inside a block (group8_unit_offsets).
+template <typename T, int W, int H>
+__device__ __forceinline__ void group8_unit_offsets(int rstride, int l, uint32_t (&uo)[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1]) {
+  using G = G8<T, W, H>;
+  if constexpr (G::KEEP) {
+#pragma unroll
+    for (int k = 0; k < G::PER_LANE; ++k) {
+      const int u = min(l + 8 * k, G::U - 1);
+      uo[k] = (uint32_t)(((u / G::UPR) * rstride + (u % G::UPR) * G::UE) * (int)sizeof(T));
+    }
+  }
+}
+template <typename T, int W, int H>
+__device__ __forceinline__ uint32_t group8_sad_u(const char *base, uint32_t site_off, int l, bool active,
+                                                 const uint32_t (&uo)[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1],
+                                                 const typename G8<T, W, H>::L (&s)[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1]) {
+  using G = G8<T, W, H>;
+  using L = typename G::L;
+  static_assert(G::KEEP, "uniform-base path: blocks whose source units stay in registers");
+  uint32_t acc = 0;
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < G::PER_LANE; ++k) {
+      if (l + 8 * k < G::U) {
+        const L b = *reinterpret_cast<const L *>(base + (size_t)(uint32_t)(site_off + uo[k]));
+#pragma unroll
+        for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(s[k].v[i], b.v[i], acc);
+      }
+    }
+  }
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0xB1, 0xf, 0xf, false);
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0x4E, 0xf, 0xf, false);
+  acc += __builtin_amdgcn_update_dpp(0u, acc, 0x141, 0xf, 0xf, false);
+  return acc;
+}
+
 // The same SAD with the reference block taken from an LDS window (byte offset `off` of the block's top-left pixel,
 // row pitch `pitch` bytes, both multiples of sizeof(T)): aligned dword reads + v_alignbyte, because a misaligned
 // ds_read_b128 runs at 1/12 of the aligned rate (tools/lds_unaligned_probe.hip).  Source units from registers.
