@@ -1041,13 +1041,13 @@ def search_bound():
     p = os.path.join(ROOT, "profiles", "r02_search_l1_bound.json")
     try:
         d = json.load(open(p))
-        return {"fullpel_diamond_kernel": {"bound": "latency: ~20 dependent rounds (8 sites -> SAD -> compare -> next centre) per block, 5 blocks per SIMD "
-                                                    "in flight; NOT the L1 line rate (a layout with 4-8x fewer line look-ups per candidate: same time)",
+        return {"fullpel_diamond_kernel": {"bound": "latency of the L1 -> L2 round trip of a step's loads: ~30 dependent steps per block, 7 blocks per SIMD in flight; NOT the "
+                                                    "L1 line rate and NOT VALU issue (4-8x fewer line look-ups per candidate, or 20 % fewer vector instructions: same time)",
                                            "l1_accesses_per_cu_cycle_pmc": d["fullpel_diamond"]["l1_accesses_per_cu_cycle"]},
                 "subpel_bilinear_kernel": {"bound": "VALU issue (1 wave-instruction per SIMD per 2 clocks), reference footprint in LDS",
                                            "frac": d["subpel_bilinear_lds_footprint"]["valu_issue_frac"],
                                            "issue_wait_frac": d["subpel_bilinear_lds_footprint"]["SQ_WAIT_INST_ANY_over_WAVE_CYCLES"]},
-                "full_pixel_search_kernel_NSTEP": {"bound": "latency, as the diamond kernel (3 blocks per SIMD at 145 VGPRs)",
+                "full_pixel_search_kernel_NSTEP": {"bound": "latency, as the diamond kernel (5 blocks per SIMD at 95 VGPRs)",
                                                    "l1_accesses_per_cu_cycle_pmc": d.get("full_pixel_search_nstep", {}).get("l1_accesses_per_cu_cycle")},
                 "source": "profiles/r03_search.md, profiles/r02_search_bound.md, profiles/r02_search_l1_bound.json (rocprofv3 --pmc)"}
     except Exception:
