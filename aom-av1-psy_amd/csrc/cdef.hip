@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void cdef_luma_kernel(const PIX *__restrict__ 
   __shared__ unsigned long long swave[4];
   const int fbx = blockIdx.x, fby = blockIdx.y;
   const int x0 = fbx * 64, y0 = fby * 64;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = tid & 63;
   const int b8w = width >> 3;
 
   // 1. stage the 68 x 72 footprint, four pixels per lane and step.  The frame width is a multiple of 8 and a group
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void cdef_chroma_kernel(const PIX *__restrict_
   constexpr int kLanesPerRow = FW;                       // 64 or 32
   constexpr int kSub = 64 / kLanesPerRow;                // row pairs a wavefront handles per step
   constexpr int kRowsPerWave = FH / 4;                   // 16 or 8
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = tid & 63;
   const int col = lane % kLanesPerRow, rsub = lane / kLanesPerRow;
   const int gx = x0 + col;
   if constexpr (!SEARCH) {

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kDbThreads) void deblock_vert_kernel(PIX *origin, i
                                                                   const uint8_t *__restrict__ params, int units_stride,
                                                                   int sharpness, int bd) {
   const int ux = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * (kDbThreads / 64) + (threadIdx.x >> 6);
+  const int y = blockIdx.y * (kDbThreads / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int ucols = (width + 3) >> 2;
   if (ux <= 0 || ux >= ucols || y >= height) return;
   const uint8_t *e = params + ((size_t)(y >> 2) * units_stride + ux) * 4;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kDbThreads) void deblock_horz_kernel(PIX *origin, i
                                                                   const uint8_t *__restrict__ params, int units_stride,
                                                                   int sharpness, int bd) {
   const int xcol = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int uy = blockIdx.y * (kDbThreads / 64) + (threadIdx.x >> 6);
+  const int uy = blockIdx.y * (kDbThreads / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int urows = (height + 3) >> 2;
   if (xcol >= width || uy <= 0 || uy >= urows) return;
   const uint8_t *e = params + ((size_t)uy * units_stride + (xcol >> 2)) * 4;

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kMeshThreads) void mesh_search_kernel(
   __shared__ unsigned long long wg_key[kMeshThreads / 64];
   uint32_t *lds_src = mesh_lds;
   char *lds_win = reinterpret_cast<char *>(mesh_lds) + ((kSrcBytes + 15) & ~15);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int bi = blockIdx.x;
   if (bi >= n_blocks) return;
   const aomhip_search_block b = blocks[bi];

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void inter_pred_kernel(PlaneView<T> ref, int r
                                                          int x_lo, int x_hi, int y_lo, int y_hi, int mvx_mul, int mvy_mul) {
   constexpr int LPB = W < 64 ? W : 64;  // lanes per block
   constexpr int BPW = 64 / LPB;         // blocks per wavefront
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int bi = (blockIdx.x * 4 + wave) * BPW + lane / LPB;
   if (bi >= n_blocks) return;
   const int col0 = lane % LPB;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void compound_pred_kernel(PlaneView<T> ref0, i
                                                             uint8_t *__restrict__ mask_out) {
   constexpr int LPB = W < 64 ? W : 64;
   constexpr int BPW = 64 / LPB;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int bi = (blockIdx.x * 4 + wave) * BPW + lane / LPB;
   if (bi >= n_blocks) return;
   const int col0 = lane % LPB;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void compound_pred_kernel(PlaneView<T> ref0, i
 template <typename T>
 __global__ __launch_bounds__(256) void blend_1d_kernel(T *dst, int dst_stride, const T *__restrict__ src1, int src1_stride,
                                                        const aomhip_blend_item *__restrict__ items, int n, const uint8_t *__restrict__ masks) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int ii = blockIdx.x * 4 + wave;
   if (ii >= n) return;
   const aomhip_blend_item it = items[ii];
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void pred_copy_kernel(PlaneView<T> ref, int re
                                                         const aomhip_search_block *__restrict__ blocks,
                                                         const int16_t *__restrict__ mv, int n_blocks, int bw, int bh) {
   // one wavefront per block; lanes sweep the block in 16-byte pieces
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int bi = blockIdx.x * 4 + wave;
   if (bi >= n_blocks) return;
   const int bx = blocks[bi].bx, by = blocks[bi].by;

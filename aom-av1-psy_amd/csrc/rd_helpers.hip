@@ -20,7 +20,7 @@ __device__ __forceinline__ int64_t wave_sum64(int64_t v) {
 template <typename T>
 __global__ __launch_bounds__(256) void sse_kernel(PlaneView<T> a, PlaneView<T> b, int frame, int w, int h,
                                                   const aomhip_sad_cand *__restrict__ cands, int n, int64_t *__restrict__ out) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int ci = blockIdx.x * 4 + wave;
   if (ci >= n) return;
   const aomhip_sad_cand c = cands[ci];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void hadamard_kernel(const int16_t *__restrict
                                                        int32_t *__restrict__ satd_out) {
   constexpr int NSUB = (N / 8) * (N / 8);
   __shared__ int lds[4][2][N * N];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int bi = blockIdx.x * 4 + wave;
   const bool live = bi < n_blocks;
   const aomhip_txb blk = blocks[live ? bi : n_blocks - 1];
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void hadamard4_kernel(const int16_t *__restric
 __global__ __launch_bounds__(256) void txb_levels_kernel(const int32_t *__restrict__ coeff, int width, int height,
                                                          const uint32_t *__restrict__ coeff_offset, int n_blocks, uint8_t *__restrict__ levels,
                                                          int64_t levels_pitch) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int bi = blockIdx.x * 4 + wave;
   if (bi >= n_blocks) return;
   const int32_t *cf = coeff + (coeff_offset ? (int64_t)coeff_offset[bi] : (int64_t)bi * width * height);

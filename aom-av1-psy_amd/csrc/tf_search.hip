@@ -442,7 +442,7 @@ __global__ void sms_fullmv_result_kernel(const int16_t *full_mv, const int32_t *
 template <typename T>
 __global__ __launch_bounds__(256) void sms_var_kernel(PlaneView<T> src, int src_frame, PlaneView<T> pred, int pred_frame, int bw, int bh, int bit_depth,
                                                        const aomhip_search_block *blocks, int n, uint32_t *out_sse, uint32_t *out_var) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   if (i >= n) return;
   const aomhip_search_block b = blocks[i];
   const T *s = src.origin + (int64_t)src_frame * src.frame_stride + (int64_t)b.by * src.stride + b.bx;
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void fpf_column_kernel(PlaneView<T> src, Plane
                                                          const int32_t *intra, int col, int rows, int cols, int thr, int skip_zeromv, int16_t *chain,
                                                          aomhip_search_block *next_list, int16_t *best_mv, int16_t *full_mv, int32_t *motion_error,
                                                          int32_t *gf_motion_error, int32_t *raw_motion_error) {
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   if (r >= rows) return;
   const size_t i = (size_t)r * cols + col;
   const int ref_row = chain[2 * r], ref_col = chain[2 * r + 1];

@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void quant_adaptive_kernel(const int32_t *__re
   constexpr int NC = KW * KH;
   constexpr int PER = (NC + 63) / 64;
   const int lane = threadIdx.x & 63;
-  const int bi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int bi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (bi >= n_blocks) return;
   const int tx_type = blocks ? blocks[bi].tx_type : uniform_type;
   const int64_t off = blocks ? (int64_t)blocks[bi].out_offset : (int64_t)bi * NC;
