@@ -1331,7 +1331,13 @@ def main():
             others.append(run_first_pass(pkg, ctx, orc, max(3, args.steps // 6), 1))
             others.append(run_sad_diamond_lists(pkg, ctx, orc, max(6, args.steps // 2), 1))
     if dist is not None and default_multi:
-        _, strong = search_block(True)   # mandatory companion of the N > 1 line (the forced one-rank dry run emits the same schema)
+        # mandatory companion of the N > 1 line (the forced one-rank dry run emits the same schema).  The headline (SAD, no collective)
+        # has been measured by now: a failure that every rank sees alike (communicator set-up, allocation) is reported inside the block
+        # instead of taking the line with it.  (A rank that dies alone is the launcher's business: spawn_ranks / torchrun end the others.)
+        try:
+            _, strong = search_block(True)
+        except Exception as e:  # noqa: BLE001
+            strong = {"metric": "search blocks/s", "error": "%s: %s" % (type(e).__name__, e)}
     ctx.close()
 
     if rank == 0:
