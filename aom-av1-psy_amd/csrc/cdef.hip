@@ -92,12 +92,13 @@ __device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_eleme
 __device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 // constrain() (av1/common/cdef.h:59-67) on a pair, with shift = max(0, damping - msb(threshold)) hoisted out of it;
 // threshold 0 yields 0 by itself (m = -(a >> shift) <= 0)
+// sign(d) min(|d|, max(0, thr - (|d| >> shift))) written as a clamp of d to [-lim, lim] with lim = thr -sat (|d| >> shift) (unsigned saturating
+// subtract: one v_pk_sub_u16 clamp): 7 packed operations instead of 10 -- the kernel is VALU-bound and runs this 12 times per pixel pair.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 constrain_pk(s16x2 diff, s16x2 thr, s16x2 shift) {
   const s16x2 a = pmax(diff, -diff);
-  s16x2 m = thr - (a >> shift);
-  m = pmin(pmax(m, splat2(0)), a);
-  const s16x2 sg = diff >> splat2(15);
-  return (m ^ sg) - sg;
+  const s16x2 lim = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, thr), __builtin_bit_cast(u16x2, a >> shift)));
+  return pmax(pmin(diff, lim), -lim);
 }
 
 // constrain() with the shift (damping - msb(threshold), floored at 0) hoisted out; threshold 0 gives 0 by itself
