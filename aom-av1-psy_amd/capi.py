@@ -224,6 +224,10 @@ _protos = {
     "aomhip_sad16x16x4d": (None, [_vp, _i, C.POINTER(_vp), _i, _vp]),
     "aomhip_highbd_sad": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, _i]),
     "aomhip_first_pass_motion_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "aomhip_graph_capture_begin": (C.c_int, [_vp]),
+    "aomhip_graph_capture_end": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "aomhip_graph_launch": (C.c_int, [_vp, _vp]),
+    "aomhip_graph_destroy": (C.c_int, [_vp]),
     "aomhip_first_pass_inter_frame": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_motion_estimation_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_tf_default_params": (None, [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -307,6 +311,23 @@ class Context:
         p = self.malloc(max(arr.nbytes, 16))
         check(lib.aomhip_memcpy_h2d(self.h, p, arr.ctypes.data, arr.nbytes), "h2d")
         return p
+
+    def capture(self, fn):
+        """Record the batched calls fn() makes on this context into a graph (fn must have run once before); -> handle for graph_launch."""
+        check(lib.aomhip_graph_capture_begin(self.h), "aomhip_graph_capture_begin")
+        try:
+            fn()
+        finally:
+            g = _vp()
+            rc = lib.aomhip_graph_capture_end(self.h, C.byref(g))
+        check(rc, "aomhip_graph_capture_end")
+        return g.value
+
+    def graph_launch(self, g):
+        check(lib.aomhip_graph_launch(self.h, g), "aomhip_graph_launch")
+
+    def graph_destroy(self, g):
+        check(lib.aomhip_graph_destroy(g), "aomhip_graph_destroy")
 
     def memcpy_h2d(self, ptr, arr):
         arr = np.ascontiguousarray(arr)

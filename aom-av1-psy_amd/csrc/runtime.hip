@@ -225,6 +225,72 @@ int aomhip_ctx_sync(aomhip_ctx *ctx) {
 
 void *aomhip_ctx_stream(aomhip_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
 
+// ---- replaying a sequence of batched calls as one hipGraph ----------------------------------------------------------------------
+// The per-frame chain of an encoder (search -> predict -> transform -> filters) is a dozen dependent launches, some of them 7-20 us long:
+// enqueued one by one, each pays the queue's dispatch latency behind its predecessor.  Between capture_begin and capture_end the batched
+// entry points are RECORDED instead of run (everything they enqueue goes to the context's stream); the graph replays them in one launch.
+// The sequence must have run once un-captured before (work buffers grow on first use, and an allocation cannot be captured), and its
+// arguments -- device pointers, frame indices, list lengths -- are frozen into the graph.
+struct aomhip_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+int aomhip_graph_capture_begin(aomhip_ctx *ctx) {
+  if (!ctx) return AOMHIP_ERR_INVALID;
+  AOMHIP_TRY(hipSetDevice(ctx->device));
+  AOMHIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  return AOMHIP_OK;
+}
+
+int aomhip_graph_capture_end(aomhip_ctx *ctx, aomhip_graph **out) {
+  if (!ctx || !out) return AOMHIP_ERR_INVALID;
+  *out = nullptr;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+  if (e != hipSuccess || !g) {
+    set_error("aomhip_graph_capture_end: %s (a call inside the capture allocated, synchronised or failed: run the sequence once before capturing it)",
+              hipGetErrorString(e));
+    // leave the stream usable: an invalidated capture keeps failing every later call until it has been ended and the error state read
+    for (int k = 0; k < 4; ++k) {
+      (void)hipGetLastError();
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(ctx->stream, &st) == hipSuccess && st == hipStreamCaptureStatusNone) break;
+      hipGraph_t g2 = nullptr;
+      (void)hipStreamEndCapture(ctx->stream, &g2);
+      if (g2) (void)hipGraphDestroy(g2);
+    }
+    (void)hipGetLastError();
+    return AOMHIP_ERR_HIP;
+  }
+  hipGraphExec_t x = nullptr;
+  e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+    return AOMHIP_ERR_HIP;
+  }
+  aomhip_graph *gr = static_cast<aomhip_graph *>(malloc(sizeof(aomhip_graph)));
+  if (!gr) { (void)hipGraphExecDestroy(x); (void)hipGraphDestroy(g); return AOMHIP_ERR_NOMEM; }
+  gr->graph = g; gr->exec = x;
+  *out = gr;
+  return AOMHIP_OK;
+}
+
+int aomhip_graph_launch(aomhip_ctx *ctx, aomhip_graph *g) {
+  if (!ctx || !g) return AOMHIP_ERR_INVALID;
+  AOMHIP_TRY(hipGraphLaunch(g->exec, ctx->stream));
+  return AOMHIP_OK;
+}
+
+int aomhip_graph_destroy(aomhip_graph *g) {
+  if (!g) return AOMHIP_OK;
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  free(g);
+  return AOMHIP_OK;
+}
+
 int aomhip_timer_begin(aomhip_ctx *ctx) {
   if (!ctx) return AOMHIP_ERR_INVALID;
   AOMHIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));

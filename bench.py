@@ -614,9 +614,10 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
         sp.d_sub_blocks(f)
     state = {"f": 0}
 
-    def frame():
-        f = state["f"] % F
-        state["f"] += 1
+    def frame(f=None):
+        if f is None:
+            f = state["f"] % F
+            state["f"] += 1
         ctx.fullpel_diamond_batch(sp.src, sp.ref, f, 16, 16, 0, 4, capi.MV_COST_L1_HDRES, sp.d_blocks, n, sp.d_mv, sp.d_cost)
         ctx.subpel_bilinear_batch(sp.src, sp.ref, f, 16, 16, capi.MV_COST_L1_HDRES, 2, 1, 0, sp.d_sub_blocks(f), n,
                                   sp.d_smv, sp.d_err, sp.d_dist, sp.d_sse)
@@ -633,15 +634,33 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
             ctx.deblock_plane(pred, f, d_params, W // 4, 0, 3)
             ctx.cdef_luma_plane(pred, f, out, 0, d_pri, d_sec, fbw, d_skip, 6)
 
-    for _ in range(warmup):
+    for _ in range(max(warmup, F)):
         frame()
     ctx.sync()
-    t0 = time.perf_counter()
-    ctx.timer_begin()
-    for _ in range(steps):
-        frame()
-    ev_ms = ctx.timer_end()
-    wall = time.perf_counter() - t0
+    # The frame's chain replayed as one hipGraph per ring slot (aomhip_graph_*): the eight launches then follow each other without the
+    # queue's per-launch dispatch latency (AOMHIP_BENCH_GRAPH=0: enqueue them one by one; both figures are reported)
+    use_graph = os.environ.get("AOMHIP_BENCH_GRAPH", "1") != "0"
+    def timed(step_fn):
+        step_fn(); ctx.sync()
+        t0 = time.perf_counter()
+        ctx.timer_begin()
+        for _ in range(steps):
+            step_fn()
+        ev = ctx.timer_end()
+        return time.perf_counter() - t0, ev
+    wall_plain, ev_plain = timed(frame)
+    wall, ev_ms, graph_note = wall_plain, ev_plain, None
+    if use_graph:
+        graphs = [ctx.capture(lambda f=f: frame(f)) for f in range(F)]
+        def replay():
+            f = state["f"] % F
+            state["f"] += 1
+            ctx.graph_launch(graphs[f])
+        wall, ev_ms = timed(replay)
+        graph_note = {"frames_per_s_launches_one_by_one": steps / wall_plain, "ms_per_frame_launches_one_by_one": wall_plain / steps * 1e3}
+        ctx.sync()
+        for g in graphs:
+            ctx.graph_destroy(g)
     # sanity: the reconstruction of the last frame is close to its source (fine quantiser, converged search)
     f_last = (state["f"] - 1) % F
     rec = ctx.planes_download(out, 0)[border:border + H, border:border + W].astype(np.int32)
@@ -673,6 +692,7 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
     return {"workload": "encode_inner_loop_4k_10bit", "value": steps / wall, "unit": "frames/s",
             "ms_per_frame": wall / steps * 1e3, "event_ms_per_frame": ev_ms / steps, "blocks_per_frame": n,
             "recon_psnr_db_last_frame": float(psnr), "stages": stages, "deblock_in_frame": "fused" if fused_deblock else "two_pass",
+            "launch": "one hipGraph per frame (aomhip_graph_launch)" if graph_note else "eight launches per frame", "without_graph": graph_note,
             "config": {"frame": "3840x2160 10-bit luma", "stages": "fullpel diamond + subpel bilinear (16x16) -> inter prediction at the "
                        "sub-pel MV (8-tap regular, av1_highbd_convolve_2d_sr) -> subtract+fwd_txfm2d_16x16+quantize_b q100 -> inv_txfm_add -> deblock (8x8 edges, level 32) -> "
                        "CDEF (pri 4, sec 2, damping 6)", "gpus": 1}}
@@ -1261,7 +1281,7 @@ def main():
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_frame"], "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
                           "config": dict(r["config"], workload=r["workload"]), "stages": r["stages"], "deblock_in_frame": r["deblock_in_frame"],
-                          "recon_psnr_db_last_frame": r["recon_psnr_db_last_frame"]}))
+                          "launch": r["launch"], "without_graph": r["without_graph"], "recon_psnr_db_last_frame": r["recon_psnr_db_last_frame"]}))
         return
     if args.workload == "default_search_4k_10bit":  # informational: NSTEP full-pel + 8-tap sub-pel tree (single GPU)
         r = run_search_default(pkg, ctx, orc, args.steps, args.warmup)

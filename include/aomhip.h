@@ -75,6 +75,21 @@ int aomhip_status(void);
 long aomhip_failure_count(void);
 void aomhip_status_clear(void);
 
+/* A sequence of batched calls recorded once and replayed as ONE hipGraph launch (the per-frame chain of an encoder -- search, prediction,
+ * transform, in-loop filters -- is a dozen dependent launches of 7-300 us; replayed from a graph they follow each other without the
+ * queue's per-launch dispatch latency).  Between capture_begin and capture_end every batched entry point called on `ctx` is recorded,
+ * not run.  Rules: run the same sequence once BEFORE capturing it (work buffers grow on first use and an allocation cannot be captured);
+ * no aomhip_ctx_sync / memcpy_d2h / rtcd-signature call inside a capture; the arguments (device pointers, frame indices, list lengths)
+ * are frozen into the graph -- data may change between launches, addresses may not.  A graph is replayed on the context it was
+ * captured on, stream-ordered with the calls around it.  A capture that fails (capture_end returns an error) leaves that context's
+ * stream in HIP's 'capture invalidated' state: destroy the context and create a new one.  Measured (bench.py inner loop, 4K 10-bit,
+ * eight launches of 7-250 us per frame): 1 773 vs 1 762 frames/s -- the gaps between dependent kernels are the GPU's, not the host's. */
+typedef struct aomhip_graph aomhip_graph;
+int aomhip_graph_capture_begin(aomhip_ctx *ctx);
+int aomhip_graph_capture_end(aomhip_ctx *ctx, aomhip_graph **graph);
+int aomhip_graph_launch(aomhip_ctx *ctx, aomhip_graph *graph);
+int aomhip_graph_destroy(aomhip_graph *graph);
+
 /* HIP-event timing on the context's stream (bench.py's per-launch durations). */
 int aomhip_timer_begin(aomhip_ctx *ctx);
 int aomhip_timer_end(aomhip_ctx *ctx, float *elapsed_ms); /* records, syncs, returns ms */

@@ -1,0 +1,73 @@
+"""aomhip_graph_*: a recorded sequence of batched calls replays with the same results, picks up new DATA at frozen addresses, and a capture
+that would allocate is refused with an error instead of a crash."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_replayed_chain_equals_the_direct_calls(hip, oracle, ctx):
+    capi = hip.capi
+    W, H, B, bs, bd = 256, 128, 64, 16, 10
+    src, ref = hip.synth.shifted_smooth_pair(W, H, 2, bd, shift=(3, -2), frac8=(2, 6))
+    ps, pr = ctx.planes_alloc(W, H, B, bd, 1), ctx.planes_alloc(W, H, B, bd, 1)
+    ctx.planes_upload(ps, 0, src); ctx.planes_upload(pr, 0, ref)
+    gc, gr = W // bs, H // bs
+    n = gc * gr
+    blocks = np.zeros(n, capi.search_block_dtype)
+    blocks["bx"], blocks["by"] = (np.arange(n) % gc) * bs, (np.arange(n) // gc) * bs
+    ext = B - 8
+    blocks["col_min"] = np.maximum(-(blocks["bx"] + ext), -1023); blocks["col_max"] = np.minimum(W - blocks["bx"] - bs + ext, 1023)
+    blocks["row_min"] = np.maximum(-(blocks["by"] + ext), -1023); blocks["row_max"] = np.minimum(H - blocks["by"] - bs + ext, 1023)
+    d_b = ctx.to_device(blocks)
+    d_mv, d_cost = ctx.malloc(n * 4), ctx.malloc(n * 4)
+    d_sb = ctx.malloc(n * blocks.itemsize)
+    d_smv, d_err, d_dist, d_sse = (ctx.malloc(n * 4) for _ in range(4))
+
+    def seq():   # full-pel search, then an element-wise fill behind it: two stream-ordered operations whose order the graph must keep
+        ctx.fullpel_diamond_batch(ps, pr, 0, bs, bs, 0, 4, capi.MV_COST_L1_HDRES, d_b, n, d_mv, d_cost)
+        ctx.memset(d_dist, 0x5A, n * 4)
+
+    seq(); ctx.sync()
+    want_mv, want_cost = ctx.from_device(d_mv, (n, 2), np.int16), ctx.from_device(d_cost, (n,), np.int32)
+    sb, rb = oracle.extend_plane(src, B, ps.stride), oracle.extend_plane(ref, B, pr.stride)
+    omv, ocost = oracle.fullpel_diamond_batch(sb, rb, B, bs, bs, blocks, 0, 4, 3, bd)
+    assert np.array_equal(want_mv, omv) and np.array_equal(want_cost, ocost)
+    g = ctx.capture(seq)
+    ctx.memset(d_mv, 0, n * 4); ctx.memset(d_cost, 0, n * 4); ctx.memset(d_dist, 0, n * 4)
+    ctx.graph_launch(g); ctx.sync()
+    assert np.array_equal(ctx.from_device(d_mv, (n, 2), np.int16), want_mv) and np.array_equal(ctx.from_device(d_cost, (n,), np.int32), want_cost)
+    assert (ctx.from_device(d_dist, (n,), np.uint32) == 0x5A5A5A5A).all()
+    # new data at the same addresses: the replay searches the new frame
+    src2, ref2 = hip.synth.shifted_smooth_pair(W, H, 9, bd, shift=(-4, 5), frac8=(0, 0))
+    ctx.planes_upload(ps, 0, src2); ctx.planes_upload(pr, 0, ref2)
+    ctx.graph_launch(g); ctx.sync()
+    sb2, rb2 = oracle.extend_plane(src2, B, ps.stride), oracle.extend_plane(ref2, B, pr.stride)
+    omv2, ocost2 = oracle.fullpel_diamond_batch(sb2, rb2, B, bs, bs, blocks, 0, 4, 3, bd)
+    assert np.array_equal(ctx.from_device(d_mv, (n, 2), np.int16), omv2) and np.array_equal(ctx.from_device(d_cost, (n,), np.int32), ocost2)
+    assert not np.array_equal(omv2, omv)
+    ctx.graph_destroy(g)
+    for d in (d_b, d_mv, d_cost, d_sb, d_smv, d_err, d_dist, d_sse):
+        ctx.free(d)
+    ctx.planes_free(ps); ctx.planes_free(pr)
+
+
+def test_a_capture_that_synchronises_is_refused(hip):
+    """A blocking call inside a capture is an error, not a crash; HIP leaves that stream in its 'capture invalidated' state, so the documented
+    way on is a new context (include/aomhip.h)."""
+    capi = hip.capi
+    bad_ctx = capi.Context(0)
+    d = bad_ctx.malloc(64)
+
+    def bad():
+        bad_ctx.memset(d, 1, 64)
+        bad_ctx.from_device(d, (16,), np.int32)   # a blocking copy: not capturable
+
+    with pytest.raises(capi.AomHipError):
+        bad_ctx.capture(bad)
+    ctx2 = capi.Context(0)                        # other contexts (other streams) are unaffected
+    e = ctx2.malloc(64)
+    ctx2.memset(e, 2, 64); ctx2.sync()
+    assert (ctx2.from_device(e, (16,), np.int32) == 0x02020202).all()
+    ctx2.free(e)
+    ctx2.close()
