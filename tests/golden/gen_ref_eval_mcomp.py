@@ -276,8 +276,7 @@ def main():
         else:
             cost = ev.call("av1_full_pixel_search", start.buf[0], ms, step_param, cl, best, second)
         rec = dict(kind=kind, bd=bd, w=w, h=h, block=list(blk), method=method, step_param=step_param, cost_type=COST_TYPES[cost_type],
-                   mv=[ev.get(best, "row"), ev.get(best, "col")], cost=cost, cost_list=list(cl.buf),
-                   sec_s=round(time.time() - t0, 2))
+                   mv=[ev.get(best, "row"), ev.get(best, "col")], cost=cost, cost_list=list(cl.buf))
         if kind != "mesh":
             try:
                 rec["second_best"] = [ev.get(second, "row"), ev.get(second, "col")]
@@ -368,8 +367,7 @@ def main():
                     lim = [ev.get(sp, "mv_limits." + k) for k in ("row_min", "row_max", "col_min", "col_max")]
                     cases.append(dict(kind="subpel", fn=fn, bd=bd, w=w, h=h, block=list(blk), fullpel_mv=fp["mv"], cost_type=COST_TYPES[cost_type],
                                       allow_hp=allow_hp, forced_stop=forced_stop, iters=iters, subpel_limits=lim, error_per_bit=60,
-                                      mv=[ev.get(best, "row"), ev.get(best, "col")], err=err, distortion=dist.buf[0], sse=sse.buf[0],
-                                      sec_s=round(time.time() - t1, 2)))
+                                      mv=[ev.get(best, "row"), ev.get(best, "col")], err=err, distortion=dist.buf[0], sse=sse.buf[0]))
     print("subpel: %d cases, %.0f s" % (len(cases) - n0, time.time() - t0))
     # 5. the sub-pel trees driven by a cost list, as the encoder does: cost_list = what av1_full_pixel_search returned
     #    (appended after the sections above with its own generator so that the earlier cases keep their values)
@@ -446,7 +444,7 @@ def main():
                 cases.append(dict(kind="subpel", fn="av1_find_best_sub_pixel_tree", subpel_search_type=3, bd=bd, w=w, h=h, block=list(blk),
                                   fullpel_mv=fp["mv"], cost_type=COST_TYPES[cost_type], allow_hp=allow_hp, forced_stop=forced_stop, iters=iters,
                                   subpel_limits=lim, error_per_bit=70, mv=[ev.get(best, "row"), ev.get(best, "col")], err=err,
-                                  distortion=dist.buf[0], sse=sse.buf[0], sec_s=round(time.time() - t1, 1)))
+                                  distortion=dist.buf[0], sse=sse.buf[0]))
     print("subpel tree, 8-tap up-sampled error: %d cases, %.0f s" % (len(cases) - n0, time.time() - t0))
     # 7. NSTEP on the first-pass site table av1_init_motion_fpf (own generator)
     n0 = len(cases)

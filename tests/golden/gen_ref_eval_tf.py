@@ -217,7 +217,7 @@ def main():
                     continue
                 t1 = time.time()
                 mvs, mses, ref_mv, info = tf.motion_search(s["filter_frame"], f, mb_row, mb_col, ref_mv, p)
-                per_frame.append(dict(mvs=mvs, mses=mses, ref_mv_after=list(ref_mv), sec_s=round(time.time() - t1, 1), **info))
+                per_frame.append(dict(mvs=mvs, mses=mses, ref_mv_after=list(ref_mv), **info))
                 print(s["name"], (mb_row, mb_col), f, per_frame[-1], flush=True)
             out.append(dict(mb_row=mb_row, mb_col=mb_col, frames=per_frame, ref_mv_final=list(ref_mv)))
         cases.append(dict(spec={k: v for k, v in s.items() if k != "blocks"}, params={k: (v if k != "mesh" else [list(x) for x in v]) for k, v in p.items()},
