@@ -58,22 +58,25 @@ template <int D> __device__ __forceinline__ int dir_cost(const int (&x)[64]) {
     for (int j = 0; j < 8; ++j) partial[dir_line<D>(i, j)] += x[i * 8 + j];
   // weights 840 / (pixels on the line): div_table (cdef_block.c:67)
   constexpr int div_table[9] = { 0, 840, 420, 280, 210, 168, 140, 120, 105 };
+  // |partial| <= 8 * 128, so partial^2 < 2^21 and every product below fits the 24-bit multiplier (v_mul_i32_i24 / v_mad_i32_i24 run at
+  // full rate; the 32-bit v_mul_lo_u32 the plain `*` compiled to is a quarter-rate instruction, 69 of them per wavefront)
+  auto sq = [](int v) { return __mul24(v, v); };
   int cost = 0;
   if constexpr (D == 2 || D == 6) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) cost += partial[k] * partial[k];
-    cost *= div_table[8];
+    for (int k = 0; k < 8; ++k) cost += sq(partial[k]);
+    cost = (int)__umul24((unsigned)cost, div_table[8]);   // cost <= 8 * 2^20 = 2^23: inside the UNSIGNED 24-bit range (all-zero pixels reach it)
   } else if constexpr (D == 0 || D == 4) {
 #pragma unroll
-    for (int k = 0; k < 7; ++k) cost += (partial[k] * partial[k] + partial[14 - k] * partial[14 - k]) * div_table[k + 1];
-    cost += partial[7] * partial[7] * div_table[8];
+    for (int k = 0; k < 7; ++k) cost += (int)__umul24((unsigned)(sq(partial[k]) + sq(partial[14 - k])), div_table[k + 1]);
+    cost += (int)__umul24((unsigned)sq(partial[7]), div_table[8]);
   } else {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) cost += partial[3 + k] * partial[3 + k];
-    cost *= div_table[8];
+    for (int k = 0; k < 5; ++k) cost += sq(partial[3 + k]);
+    cost = (int)__umul24((unsigned)cost, div_table[8]);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-      cost += (partial[k] * partial[k] + partial[10 - k] * partial[10 - k]) * div_table[2 * k + 2];
+      cost += (int)__umul24((unsigned)(sq(partial[k]) + sq(partial[10 - k])), div_table[2 * k + 2]);
   }
   return cost;
 }

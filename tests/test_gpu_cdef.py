@@ -52,6 +52,29 @@ def test_random_strength_maps(hip, oracle, ctx, bd):
         assert not np.array_equal(got, pix)
 
 
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_extreme_direction_costs(hip, oracle, ctx, bd):
+    """Blocks whose line sums reach +-8 * 128 (all-zero / all-maximum pixels), and the sharpest lines of each direction between them: the
+    direction cost's products sit at the top of the 24-bit multiplier's range (cdef_find_dir, cdef_block.c:103-197)."""
+    rng = np.random.default_rng(40 + bd)
+    mx = (1 << bd) - 1
+    W, H = 192, 128
+    pix = np.zeros((H, W), np.int64)
+    pix[:, 64:128] = mx
+    i, j = np.indices((H, 64))
+    stripes = [i, j, i + j, i - j, i + j // 2, i - j // 2, i // 2 + j, j - i // 2]       # lines of the eight directions, 0 / max alternating
+    for k, line in enumerate(stripes):
+        blk = np.where(line[k * 16:k * 16 + 16] % 2 == 0, 0, mx)
+        pix[k * 16:k * 16 + 16, 128:192] = blk
+    pix = pix.astype(np.uint8 if bd == 8 else np.uint16)
+    pri = np.full((2, 3), 7, np.uint8); sec = np.full((2, 3), 2, np.uint8)
+    skip = np.zeros((H // 8, W // 8), np.uint8)
+    got, gdir, gvar = _run(hip, ctx, pix, pri, sec, skip, 6, bd)
+    want, wdir, wvar = oracle.cdef_plane_luma(pix, pri, sec, skip, 6, bd)
+    assert np.array_equal(gdir, wdir) and np.array_equal(gvar, wvar) and np.array_equal(got, want)
+    assert wvar.max() > (1 << 17) and len(np.unique(wdir[:, 16:])) >= 4     # huge variances, several directions present
+
+
 def test_each_enable_combination(hip, oracle, ctx):
     """strength_index 0..3 of av1_cdef_filter_fb: {pri, sec} x {on, off}, odd / even primary strengths
     (the two cdef_pri_taps rows) and every damping."""
