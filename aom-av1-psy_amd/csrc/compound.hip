@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kVarThreads) void compound_kernel(PlaneView<T> src,
       for (int i = 0; i < E; ++i) {
         const int h0 = (r0[i] * fx0 + r0n[i] * fx1 + 64) >> 7;
         const int h1 = (r1[i] * fx0 + r1n[i] * fx1 + 64) >> 7;
-        a[i] = ((h0 * fy0 + h1 * fy1 + 64) >> 7) & (sizeof(T) == 1 ? 0xFF : 0xFFFF);
+        a[i] = ((__mul24(h0, fy0) + __mul24(h1, fy1) + 64) >> 7) & (sizeof(T) == 1 ? 0xFF : 0xFFFF);
       }
     }
     int32_t us = 0;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kVarThreads) void compound_kernel(PlaneView<T> src,
         const int mag = (abs(v) + 2048) >> 12;  // ROUND_POWER_OF_TWO(abs(v), 12); _SIGNED puts the sign back
         const int d = v < 0 ? -mag : mag;
         us += d;
-        uq += (uint32_t)(d * d);
+        uq += (uint32_t)__mul24(d, d);
         ua += (uint32_t)mag;
       }
     } else {
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kVarThreads) void compound_kernel(PlaneView<T> src,
         }
         const int d = comp - s[i];
         us += d;
-        uq += (uint32_t)(d * d);
+        uq += (uint32_t)__mul24(d, d);
         ua += (uint32_t)abs(d);
       }
     }

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void plane_sse_kernel(const T *__restrict__ a,
   unsigned long long acc = 0;
   for (int x = blockIdx.x * 256 + threadIdx.x; x < width; x += gridDim.x * 256) {
     const int d = (int)a[(int64_t)y * a_stride + x] - (int)b[(int64_t)y * b_stride + x];
-    acc += (unsigned)(d * d);
+    acc += (unsigned)__mul24(d, d);
   }
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);

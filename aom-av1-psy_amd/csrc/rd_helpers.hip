@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void sse_kernel(PlaneView<T> a, PlaneView<T> b
   for (int i = lane; i < w * h; i += 64) {
     const int r = i / w, x = i - r * w;
     const int d = (int)ap[(int64_t)r * a.stride + x] - (int)bp[(int64_t)r * b.stride + x];
-    acc += d * d;
+    acc += __mul24(d, d);
   }
   acc = wave_sum64(acc);
   if (lane == 0) out[ci] = acc;

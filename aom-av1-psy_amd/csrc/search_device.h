@@ -243,14 +243,14 @@ __device__ __forceinline__ uint32_t wave_variance(const T *ap, int astride, int 
       if constexpr (SUBPEL) {
         const int h0 = ((int)a0[i] * fx0 + (int)a0[i + 1] * fx1 + 64) >> 7;
         const int h1 = ((int)a0[astride + i] * fx0 + (int)a0[astride + i + 1] * fx1 + 64) >> 7;
-        av = (h0 * fy0 + h1 * fy1 + 64) >> 7;
+        av = (__mul24(h0, fy0) + __mul24(h1, fy1) + 64) >> 7;   // h <= 4095: 24-bit multiplies (v_mul_lo_u32 is quarter rate)
         av &= (sizeof(T) == 1) ? 0xFF : 0xFFFF;
       } else {
         av = a0[i];
       }
       const int d = a_minus_b ? av - (int)b0[i] : (int)b0[i] - av;
       us += d;
-      uq += (uint32_t)(d * d);
+      uq += (uint32_t)__mul24(d, d);   // |d| < 2^12: the 24-bit multiplier is exact and full rate (v_mul_lo_u32 is quarter rate)
     }
     sum += us;
     sse += uq;
@@ -335,14 +335,14 @@ __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, i
         for (int i = 0; i < UE; ++i) {
           const int p00 = px_of<T>(r0.v, i), p01 = i + 1 < UE ? px_of<T>(r0.v, i + 1 < UE ? i + 1 : i) : e0;
           const int p10 = px_of<T>(r1.v, i), p11 = i + 1 < UE ? px_of<T>(r1.v, i + 1 < UE ? i + 1 : i) : e1;
-          const int h0 = (p00 * fx0 + p01 * fx1 + 64) >> 7;
-          const int h1 = (p10 * fx0 + p11 * fx1 + 64) >> 7;
-          int av = (h0 * fy0 + h1 * fy1 + 64) >> 7;
+          const int h0 = (__mul24(p00, fx0) + __mul24(p01, fx1) + 64) >> 7;
+          const int h1 = (__mul24(p10, fx0) + __mul24(p11, fx1) + 64) >> 7;
+          int av = (__mul24(h0, fy0) + __mul24(h1, fy1) + 64) >> 7;   // h <= 4095: 24-bit multiplies (v_mul_lo_u32 is quarter rate)
           av &= (sizeof(T) == 1) ? 0xFF : 0xFFFF;
           const int bvp = px_of<T>(bv.v, i);
           const int d = a_minus_b ? av - bvp : bvp - av;
           us += d;
-          uq += (uint32_t)(d * d);
+          uq += (uint32_t)__mul24(d, d);   // |d| < 2^12: the 24-bit multiplier is exact and full rate (v_mul_lo_u32 is quarter rate)
         }
       } else {
 #pragma unroll
@@ -350,7 +350,7 @@ __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, i
           const int av = px_of<T>(r0.v, i), bvp = px_of<T>(bv.v, i);
           const int d = a_minus_b ? av - bvp : bvp - av;
           us += d;
-          uq += (uint32_t)(d * d);
+          uq += (uint32_t)__mul24(d, d);   // |d| < 2^12: the 24-bit multiplier is exact and full rate (v_mul_lo_u32 is quarter rate)
         }
       }
       sum += us;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void tf_apply_kernel(TfApplyArgs a) {
       }
       for (int q = tid; q < npix; q += kThreads) {
         const int d = (int)s_self[q] - (int)s_pred[q];
-        s_sq[q] = (uint32_t)(d * d);
+        s_sq[q] = (uint32_t)__mul24(d, d);
       }
       __syncthreads();
       const double inv_num_ref_pixels = __ddiv_rn(1.0, (double)(25 + (p ? (1 << (sx + sy)) : 0)));
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void tf_apply_kernel(TfApplyArgs a) {
         out_org[o] = (T)v;
         if (p == 0 && a.diff) {
           const int d = (int)self_org[(int64_t)(plane_y + q / w) * a.stride[p] + plane_x + q % w] - (int)v;
-          sse += (unsigned)(d * d);
+          sse += (unsigned)__mul24(d, d);
         }
       }
     }

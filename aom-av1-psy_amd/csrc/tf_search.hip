@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void sms_var_kernel(PlaneView<T> src, int src_
   for (int q = lane; q < bw * bh; q += 64) {
     const int y = q / bw, x = q - y * bw;
     const int d = (int)s[(int64_t)y * src.stride + x] - (int)p[(int64_t)y * pred.stride + x];
-    sum += d; sse += (unsigned)(d * d);
+    sum += d; sse += (unsigned)__mul24(d, d);
   }
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) { sum += __shfl_xor(sum, m, 64); sse += __shfl_xor(sse, m, 64); }
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void fpf_column_kernel(PlaneView<T> src, Plane
         for (int q = lane; q < bw * bh; q += 64) {
           const int y = q / bw, x = q - y * bw;
           const int d = (int)sp[(int64_t)y * src.stride + x] - (int)rp[(int64_t)y * last.stride + x];
-          sse += (unsigned)(d * d);
+          sse += (unsigned)__mul24(d, d);
         }
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) sse += __shfl_xor(sse, m, 64);

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kVarThreads) void variance_kernel(PlaneView<T> src,
       for (int i = 0; i < E; ++i) {
         const int h0 = (r0[i] * fx0 + r0n[i] * fx1 + 64) >> 7;  // first pass, uint16 range
         const int h1 = (r1[i] * fx0 + r1n[i] * fx1 + 64) >> 7;
-        apx[i] = (h0 * fy0 + h1 * fy1 + 64) >> 7;               // second pass
+        apx[i] = (__mul24(h0, fy0) + __mul24(h1, fy1) + 64) >> 7;               // second pass
         if constexpr (sizeof(T) == 1) apx[i] &= 0xFF;           // stored to uint8_t temp2 (variance.c:155)
         else apx[i] &= 0xFFFF;
       }
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kVarThreads) void variance_kernel(PlaneView<T> src,
       // matters for the 10/12-bit rounding of the (possibly negative) sum.
       const int d = SUBPEL ? apx[i] - bpx[i] : bpx[i] - apx[i];
       us += d;
-      uq += (uint32_t)(d * d);
+      uq += (uint32_t)__mul24(d, d);
     }
     sum += us;
     sse += uq;  // <= 8 * 4095^2 per unit: no 32-bit overflow inside a unit
