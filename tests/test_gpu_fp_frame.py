@@ -13,11 +13,12 @@ def _tables():
     return mv_max, np.array([200, 650, 640, 1050], np.int32), (150 + bits * 310).astype(np.int32), (170 + bits * 290 + (v & 7) * 3).astype(np.int32)
 
 
-@pytest.mark.parametrize("bd,golden,thr,skip_zero,cost", [(8, True, 0, 0, "ENTROPY"), (10, True, 300, 0, "ENTROPY"), (8, False, 0, 1, "L1_HDRES"),
-                                                         (10, False, 0, 0, "NONE")])
-def test_frame_call_equals_the_scalar_raster_walk(hip, oracle, ctx, bd, golden, thr, skip_zero, cost):
+@pytest.mark.parametrize("bd,golden,thr,skip_zero,cost,bs", [(8, True, 0, 0, "ENTROPY", 16), (10, True, 300, 0, "ENTROPY", 16), (8, False, 0, 1, "L1_HDRES", 16),
+                                                            (10, False, 0, 0, "NONE", 16),
+                                                            (8, True, 0, 0, "ENTROPY", 8)])   # fp_block_size BLOCK_8X8: frames of at most 352x288 (firstpass.c get_fp_block_size)
+def test_frame_call_equals_the_scalar_raster_walk(hip, oracle, ctx, bd, golden, thr, skip_zero, cost, bs):
     capi = hip.capi
-    W, H, B, bs = 352, 288, 64, 16
+    W, H, B = (352, 288, 64) if bs == 16 else (176, 144, 64)
     rng = np.random.default_rng(7 * bd + thr + skip_zero)
     # the frame moved by (5, -7) against the last reconstruction and by (-2, 3) against the golden frame; noise so that errors differ per block
     src, last = hip.synth.shifted_smooth_pair(W, H, 11, bd, shift=(5, -7), frac8=(0, 0))
@@ -25,7 +26,7 @@ def test_frame_call_equals_the_scalar_raster_walk(hip, oracle, ctx, bd, golden, 
     hi = (1 << bd) - 1
     noisy = lambda a, k: np.clip(a.astype(np.int32) + rng.integers(-k, k + 1, a.shape), 0, hi).astype(a.dtype)
     last, gold, lsrc = noisy(last, 3), noisy(gold, 5), noisy(last, 6)
-    lsrc[:64, :] = src[:64, :]                              # rows of blocks whose raw_motion_error is 0: the search is skipped at any threshold
+    lsrc[:4 * bs, :] = src[:4 * bs, :]                      # four rows of blocks whose raw_motion_error is 0: the search is skipped at any threshold
     rings = [ctx.planes_alloc(W, H, B, bd, 2) for _ in range(4)]
     ps, pl, pg, pls = rings
     frames = {0: (ps, 1, src), 1: (pl, 0, last), 2: (pg, 1, gold), 3: (pls, 1, lsrc)}

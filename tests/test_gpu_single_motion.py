@@ -52,12 +52,13 @@ def test_device_trees_on_a_search_list_equal_the_interpreted_reference(hip, ctx)
         ctx.planes_free(ps); ctx.planes_free(pr)
 
 
-@pytest.mark.parametrize("bd,tree,method,use_cl,second,force_int", [(8, "pruned_more", "NSTEP", 1, 1, 0), (10, "tree", "DIAMOND", 0, 1, 0),
-                                                                   (8, "pruned", "BIGDIA", 1, 0, 0), (10, "pruned_more", "NSTEP", 0, 0, 1),
-                                                                   (8, "tree", "HEX", 0, 1, 0)])
-def test_single_motion_search_core_equals_the_oracle_composition(hip, oracle, ctx, bd, tree, method, use_cl, second, force_int):
+@pytest.mark.parametrize("bd,tree,method,use_cl,second,force_int,bs", [(8, "pruned_more", "NSTEP", 1, 1, 0, 16), (10, "tree", "DIAMOND", 0, 1, 0, 16),
+                                                                      (8, "pruned", "BIGDIA", 1, 0, 0, 16), (10, "pruned_more", "NSTEP", 0, 0, 1, 16),
+                                                                      (8, "tree", "HEX", 0, 1, 0, 16), (10, "pruned_more", "NSTEP", 1, 1, 0, 32),
+                                                                      (8, "pruned", "NSTEP", 0, 1, 0, 8)])
+def test_single_motion_search_core_equals_the_oracle_composition(hip, oracle, ctx, bd, tree, method, use_cl, second, force_int, bs):
     capi = hip.capi
-    W, H, B, bs = 352, 288, 64, 16
+    W, H, B = 352, 288, 64
     rng = np.random.default_rng(bd * 31 + len(tree) + second)
     src, ref = hip.synth.shifted_smooth_pair(W, H, 5, bd, shift=(4, -6), frac8=(3, 5))
     k = 60 << (bd - 8)   # heavy noise on both frames: the full-pel winner and its runner-up are close, so the second sub-pel search wins sometimes
@@ -104,7 +105,7 @@ def test_single_motion_search_core_equals_the_oracle_composition(hip, oracle, ct
         assert np.array_equal(got[k], want[k]), (k, np.flatnonzero((got[k] != want[k]).reshape(n, -1).any(1))[:8])
     dead = (want["best_mv"][:, 0] == -32768)
     assert 0 < dead.sum() < n // 4 and (want["rate_mv"][~dead] > 0).any()
-    if second and method in ("NSTEP", "DIAMOND"):   # (the pattern searches leave second_best_mv invalid) the second start won somewhere: exercised, not just executed
+    if second and method in ("NSTEP", "DIAMOND") and bs == 16:   # (the pattern searches leave second_best_mv invalid) the second start won somewhere: exercised, not just executed
         first = oracle.single_motion_search_batch(sb, rb, B, bs, bs, blocks, oq, dict(tree=tree, cost_type=0, error_per_bit=70, iters=2, allow_hp=1, forced_stop=0),
                                                   start2=start2, use_cost_list=use_cl, try_second_mv=0, mvjcost=tj, mvcost0=t0, mvcost1=t1, bd=bd, threads=8)
         assert (first["best_mv"] != want["best_mv"]).any()
