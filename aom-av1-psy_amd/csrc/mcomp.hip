@@ -16,141 +16,214 @@
 
 #include "common.h"
 #include "search_device.h"
-
-// LDS window for the fine diamond steps: bit-exact, but measured 5 % SLOWER than the L1/L2 path on 4K 10-bit 16x16
-// (0.59 vs 0.56 ms per frame, tools/gpu_ab_search.sh) -- the staging costs more than the few r <= 8 steps save.  Off.
-#ifndef AOMHIP_DIAMOND_LDS_WINDOW
-#define AOMHIP_DIAMOND_LDS_WINDOW 0
-#endif
+#include "search_window.h"
 
 namespace aomhip {
 
-#ifndef AOMHIP_DIAMOND_WAVES
-#define AOMHIP_DIAMOND_WAVES 5   // waves per SIMD the register allocation aims at (A/B: profiles/r01_search_variants.md)
+// Phase timing of the cell kernel (kernel experiments only: -DAOMHIP_CELL_PROF; tools/r04_cell_prof.py): shader cycles per wavefront
+// summed over the launch -- [0] waves, [1] prologue + staging, [2] LDS rounds, [3] their count, [4] global rounds, [5] their count,
+// [6] variances, [7] their count, [8] whole wavefront
+#ifdef AOMHIP_CELL_PROF
+__device__ unsigned int g_cell_prof[40960 * 16];   // one record of plain stores per block (atomics distort the memory phases)
+#define CELL_T() __builtin_readcyclecounter()
+#define CELL_ADD(i, v) do { if (lane == 0 && bi < 40960) g_cell_prof[bi * 16 + (i)] = (unsigned int)(v); } while (0)
+#else
+#define CELL_T() 0ull
+#define CELL_ADD(i, v) do { } while (0)
 #endif
 
-template <typename T, int W, int H>
-__global__ __launch_bounds__(kSearchThreads, AOMHIP_DIAMOND_WAVES) void fullpel_diamond_kernel(
-    PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
-    int level, int step_param, int cost_type, int bit_depth, int16_t *__restrict__ out_mv,
-    int32_t *__restrict__ out_cost) {
+// WAVES blocks (wavefronts) per workgroup.  CELL: the workgroup's blocks share a reference window staged once in LDS
+// (search_window.h); a round whose 8 sites lie inside it reads LDS, any other round reads the plane.
+//
+// A round of the search is a dependent chain -- addresses, 8 site SADs, reduction, costs, arg-min, new centre -- and the kernel is
+// bound by the ISSUE of that chain's instructions (profiles/r04_search_cell.md: a round costs the same 1 300 - 1 500 cycles per wavefront
+// from LDS as from L2, at 4 wavefronts per SIMD), so the round is written for instruction count: radius products on the 24-bit
+// multiplier, the limits tested once per round on the scalar unit when the whole diamond lies inside them, |d| through v_sad_u32 on
+// biased coordinates, two SAD accumulators, the winning site decoded from two packed tables instead of compare chains, the start
+// position's SAD kept across the restarts (every run of full_pixel_diamond starts at the same clamped MV) and the final variance
+// kept while consecutive runs end on the same MV.
+template <typename T, int W, int H, int WAVES, bool CELL>
+__global__ __launch_bounds__(WAVES * 64, CELL ? 8 : 5) void fullpel_diamond_kernel(
+    PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks, CellMap cm,
+    int level, int step_param, int cost_type, int bit_depth, int16_t *__restrict__ out_mv, int32_t *__restrict__ out_cost) {
+  extern __shared__ uint32_t cell_lds[];
+  using G = G8<T, W, H>;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int NU = G::KEEP ? G::PER_LANE : 1;
+  [[maybe_unused]] const unsigned long long t_begin = CELL_T();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (uniform: the block record and everything derived from it -- centre, limits, step state -- then lives in SGPRs and the search loops branch on the scalar unit)
-  const int bi = blockIdx.x * (kSearchThreads / 64) + wave;
-  if (bi >= n_blocks) return;
-  const aomhip_search_block b = blocks[bi];
+  int bi;
+  if constexpr (CELL) bi = cell_block_index<WAVES>((int)xcd_chunked_index(blockIdx.x, (unsigned)cm.n_cells), wave, n_blocks);
+  else bi = (int)blockIdx.x * WAVES + wave < n_blocks ? (int)blockIdx.x * WAVES + wave : -1;
+  const bool have = bi >= 0;
+  if constexpr (!CELL) {
+    if (!have) return;
+  }
+  const aomhip_search_block b = blocks[have ? bi : 0];
+  const int row_min = __builtin_amdgcn_readfirstlane((int)b.row_min), row_max = __builtin_amdgcn_readfirstlane((int)b.row_max);
+  const int col_min = __builtin_amdgcn_readfirstlane((int)b.col_min), col_max = __builtin_amdgcn_readfirstlane((int)b.col_max);
+  // clamp_fullmv (readfirstlane: the compiler packs the two 16-bit clamps into v_pk_min / max_i16 -- VALU only -- and everything derived
+  // from a VGPR, the whole search state, then follows it into the vector unit and under exec masks)
+  const int start_row = __builtin_amdgcn_readfirstlane(min(max((int)b.start_row, row_min), row_max));
+  const int start_col = __builtin_amdgcn_readfirstlane(min(max((int)b.start_col, col_min), col_max));
+  const T *rframe = ref.origin + (int64_t)frame * ref.frame_stride;
   const T *sp = src.origin + (int64_t)frame * src.frame_stride + (int64_t)b.by * src.stride + b.bx;
-  const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)b.by * ref.stride + b.bx;
+  const T *rbase = rframe + (int64_t)b.by * ref.stride + b.bx;
+  [[maybe_unused]] CellWin cw{ 0, 0, 0, 0, 0 };
+  if constexpr (CELL) {
+    if (cm.win_r >= 0) cw = stage_cell_window<T, W, H, WAVES>(cm, rframe, ref.stride, have, b.bx + start_col, b.by + start_row, wave, cell_lds, t_begin, bi);
+    if (!have) return;   // (behind the window's barriers)
+  }
+  [[maybe_unused]] unsigned long long t_lds = 0, t_glob = 0, t_var = 0, n_lds = 0, n_glob = 0, n_var = 0;
+  CELL_ADD(0, 1);
+  CELL_ADD(1, CELL_T() - t_begin);
   const CostCtx cc{ cost_type, b.ref_row, b.ref_col };
   const int shift = bit_depth == 10 ? 2 : bit_depth == 12 ? 4 : 0;  // vtable wrappers for highbd SAD
+  const int lambda = cost_type == kCostL1Low ? 32 : cost_type == kCostL1Mid ? 15 : cost_type == kCostL1Hd ? 8 : 0;  // mvsad_err_cost_: (lambda * 8 d) >> 3
+  const int frr = __builtin_amdgcn_readfirstlane((b.ref_row + 3 + (b.ref_row >= 0)) >> 3);  // GET_MV_RAWPEL (readfirstlane: as for the start MV)
+  const int frc = __builtin_amdgcn_readfirstlane((b.ref_col + 3 + (b.ref_col >= 0)) >> 3);
   const int g = lane >> 3, l = lane & 7;
   const int dr = (g == 0 || g == 4 || g == 6) ? -1 : (g == 1 || g == 5 || g == 7) ? 1 : 0;   // site order of
   const int dc = (g == 2 || g == 4 || g == 7) ? -1 : (g == 3 || g == 5 || g == 6) ? 1 : 0;   // mcomp.c:366-370
+  // site g + 1 -> (dr + 1, dc + 1), two bits each: the centre's move when that site wins
+  constexpr uint32_t kSiteDr = (0u << 2) | (2u << 4) | (1u << 6) | (1u << 8) | (0u << 10) | (2u << 12) | (0u << 14) | (2u << 16);
+  constexpr uint32_t kSiteDc = (1u << 2) | (1u << 4) | (0u << 6) | (2u << 8) | (0u << 10) | (2u << 12) | (2u << 14) | (0u << 16);
 
-  typename G8<T, W, H>::L srcu[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1];
+  typename G::L srcu[NU];
   group8_load_src<T, W, H>(sp, src.stride, l, srcu);
-  // candidates as uniform base + 32-bit lane offset (search_device.h group8_sad_u); the base sits at the smallest legal MV
-  [[maybe_unused]] uint32_t uoff[G8<T, W, H>::KEEP ? G8<T, W, H>::PER_LANE : 1];
-  group8_unit_offsets<T, W, H>(ref.stride, l, uoff);
-  [[maybe_unused]] const char *ubase = reinterpret_cast<const char *>(rbase + (int64_t)b.row_min * ref.stride + b.col_min);
-  auto site_sad = [&](int row, int col, bool active) -> uint32_t {
-    if constexpr (G8<T, W, H>::KEEP)
-      return group8_sad_u<T, W, H>(ubase, (uint32_t)(((row - b.row_min) * ref.stride + (col - b.col_min)) * (int)sizeof(T)), l, active, uoff, srcu);
-    else
-      return group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)row * ref.stride + col, ref.stride, l, active, srcu);
-  };
+  // candidates as uniform base + 32-bit lane offset; the base sits at the smallest legal MV.  The lane's unit k is unit 0 moved down by
+  // k * (8 / UPR) rows (u = l + 8 k): one offset register per address space and a uniform step, not one register per unit
+  static_assert(!G::KEEP || 8 % G::UPR == 0 || G::PER_LANE == 1, "unit k = unit 0 + k * step");
+  constexpr int kRowStep = G::UPR <= 8 ? 8 / G::UPR : 0;
+  [[maybe_unused]] const uint32_t uoff0 = (uint32_t)(((min(l, G::U - 1) / G::UPR) * ref.stride + (min(l, G::U - 1) % G::UPR) * G::UE) * ES);
+  [[maybe_unused]] const uint32_t ustep = (uint32_t)(kRowStep * ref.stride * ES);
+  [[maybe_unused]] uint32_t loff0 = 0, lstep = 0;   // the same inside the window
+  if constexpr (CELL && G::KEEP) {
+    loff0 = (uint32_t)((min(l, G::U - 1) / G::UPR) * cw.pitch + (min(l, G::U - 1) % G::UPR) * G::UB);
+    lstep = (uint32_t)(kRowStep * cw.pitch);
+  }
+  [[maybe_unused]] const int site_goff = (dr * ref.stride + dc) * ES;                       // this lane's site per unit of radius: plane ...
+  [[maybe_unused]] const int site_loff = CELL ? dr * cw.pitch + dc * ES : 0;               // ... and window
+  [[maybe_unused]] const char *ubase = reinterpret_cast<const char *>(rbase + (int64_t)row_min * ref.stride + col_min);
 
-  // LDS window for the fine steps of a search (radius <= 8): the (2*15 + H) x (2*15 + W) pixels around the current
-  // centre are staged once (about the traffic of ONE diamond step) and the remaining steps of the run -- whose
-  // sites stay within 8 + 4 + 2 + 1 = 15 pixels of that centre -- read LDS instead of the L1/L2 path.  Only for
-  // blocks up to 32 x 32 (LDS per wavefront: 4.4 KB for 16x16 16-bit, 15 KB for 32x32); a window is only ever
-  // placed over legal MV positions, so it never reaches outside the bordered plane.
-  constexpr bool kUseLds = AOMHIP_DIAMOND_LDS_WINDOW && G8<T, W, H>::KEEP && W * H <= 1024 && W >= 8;
-  constexpr int kRW = 15;
-  constexpr int kWinRows = 2 * kRW + H, kWinPitch = ((2 * kRW + W) * (int)sizeof(T) + 15) & ~15;
-  __shared__ uint32_t win_all[kUseLds ? (kSearchThreads / 64) * (kWinRows * kWinPitch / 4 + 8) : 1];
-  uint32_t *win = win_all + (kUseLds ? wave * (kWinRows * kWinPitch / 4 + 8) : 0);
-  int wr0 = INT_MIN / 2, wc0 = INT_MIN / 2;  // window origin in MV space; far away = nothing staged
-  auto stage_window = [&](int row, int col) {
-    if constexpr (kUseLds) {
-      if (b.row_max - b.row_min < 2 * kRW || b.col_max - b.col_min < 2 * kRW) return;
-      wr0 = min(max(row - kRW, (int)b.row_min), (int)b.row_max - 2 * kRW);
-      wc0 = min(max(col - kRW, (int)b.col_min), (int)b.col_max - 2 * kRW);
-      const char *g0 = reinterpret_cast<const char *>(rbase + (int64_t)wr0 * ref.stride + wc0);
-      constexpr int kCpr = kWinPitch / 16;
-      for (int q = lane; q < kWinRows * kCpr; q += 64) {
-        const int r = q / kCpr, c = q - r * kCpr;
-        const MU128 v = *reinterpret_cast<const MU128 *>(g0 + (int64_t)r * ref.stride * (int)sizeof(T) + c * 16);
-        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(win) + r * kWinPitch + c * 16) = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+  // SAD of this lane's group's site (dr, dc) * r around (row, col) -- or of (row, col) itself with r = 0 -- by the group's 8 lanes
+  auto round_sad = [&](int row, int col, int r, bool active, bool in_win) -> uint32_t {
+    uint32_t a0 = 0, a1 = 0;
+    if constexpr (G::KEEP) {
+      if (in_win) {
+        if constexpr (CELL) {
+          const int base = (b.by + row - cw.y0) * cw.pitch + (b.bx + col - cw.x0) * ES;   // (scalar)
+          const uint32_t so = (uint32_t)(__mul24(site_loff, r) + base);
+          if (active) {
+            uint32_t d[NU][G::UB / 4 + 1];
+            unsigned sh[NU];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+              const uint32_t o = so + loff0 + (uint32_t)k * lstep;
+              const uint32_t *p = cell_lds + (o >> 2);
+              sh[k] = o & 3;
+#pragma unroll
+              for (int i = 0; i <= G::UB / 4; ++i) d[k][i] = p[i];
+            }
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+              if (l + 8 * k < G::U) {
+#pragma unroll
+                for (int i = 0; i < G::UB / 4; ++i) {
+                  const uint32_t v = __builtin_amdgcn_alignbyte(d[k][i + 1], d[k][i], sh[k]);
+                  if ((k * (G::UB / 4) + i) & 1) a1 = sadw<T>(srcu[k].v[i], v, a1); else a0 = sadw<T>(srcu[k].v[i], v, a0);
+                }
+              }
+            }
+          }
+        }
+      } else {
+        const int base = ((row - row_min) * ref.stride + (col - col_min)) * ES;   // (scalar)
+        const uint32_t so = (uint32_t)(__mul24(site_goff, r) + base);
+        if (active) {
+          typename G::L v[NU];
+#pragma unroll
+          for (int k = 0; k < NU; ++k) v[k] = *reinterpret_cast<const typename G::L *>(ubase + (size_t)(uint32_t)(so + uoff0 + (uint32_t)k * ustep));
+#pragma unroll
+          for (int k = 0; k < NU; ++k) {
+            if (l + 8 * k < G::U) {
+#pragma unroll
+              for (int i = 0; i < G::UB / 4; ++i) {
+                if ((k * (G::UB / 4) + i) & 1) a1 = sadw<T>(srcu[k].v[i], v[k].v[i], a1); else a0 = sadw<T>(srcu[k].v[i], v[k].v[i], a0);
+              }
+            }
+          }
+        }
       }
-      // one wavefront owns the window: its own LDS writes are visible to its later reads once they have retired
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+      uint32_t acc = a0 + a1;
+      acc += __builtin_amdgcn_update_dpp(0u, acc, 0xB1, 0xf, 0xf, false);
+      acc += __builtin_amdgcn_update_dpp(0u, acc, 0x4E, 0xf, 0xf, false);
+      acc += __builtin_amdgcn_update_dpp(0u, acc, 0x141, 0xf, 0xf, false);
+      return acc;
+    } else {
+      return group8_sad<T, W, H>(sp, src.stride, rbase + (int64_t)(row + dr * r) * ref.stride + (col + dc * r), ref.stride, l, active, srcu);
     }
   };
-  auto covered = [&](int row, int col, int r) {
-    return row - r >= wr0 && row + r <= wr0 + 2 * kRW && col - r >= wc0 && col + r <= wc0 + 2 * kRW;
+  // does the window hold every pixel of the blocks at (row +- r, col +- r)?  (scalar)
+  auto win_covers = [&](int row, int col, int r) -> bool {
+    if constexpr (CELL && G::KEEP) return cw.covers(b.bx + col - r, b.by + row - r, b.bx + col + r + W, b.by + row + r + H);
+    else return false;
   };
 
   // radius of stage k (av1_init_dsmotion_compensation): DIAMOND 2^k, CLAMPED_DIAMOND min(2^k, 256); 11 stages
   auto radius = [level](int k) { const int r = 1 << k; return (level > 0 && r > 256) ? 256 : r; };
 
+  // every run starts at the clamped start MV: its SAD once (group 0 evaluates it, the other seven would only repeat its loads)
+  uint32_t start_sad;
+  {
+    const uint32_t s0 = round_sad(start_row, start_col, 0, g == 0, win_covers(start_row, start_col, 0)) >> shift;
+    start_sad = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)__builtin_amdgcn_readlane((int)s0, 0) + (uint32_t)(lambda * (iabsm(start_row - frr) + iabsm(start_col - frc)))));
+  }
+
   auto run_diamond = [&](int search_step, int *num00, int *orow, int *ocol) -> int {
-    int row = min(max((int)b.start_row, (int)b.row_min), (int)b.row_max);  // clamp_fullmv
-    int col = min(max((int)b.start_col, (int)b.col_min), (int)b.col_max);
+    int row = start_row, col = start_col;
     const int tot_steps = 11 - search_step;
     *num00 = 0;
-    // (the centre is one position: group 0 evaluates it, the other seven groups would only repeat its loads)
-    uint32_t s0 = site_sad(row, col, g == 0) >> shift;
-    s0 = (uint32_t)__builtin_amdgcn_readlane((int)s0, 0);
-    uint32_t bestsad = s0 + (uint32_t)cc.sad_cost(row, col);
+    uint32_t bestsad = start_sad;
     int is_off_center = 0;
     int next_step_size = tot_steps > 2 ? radius(tot_steps - 2) : 1;
     for (int step = tot_steps - 1; step >= 0; --step) {
       const int r = radius(step);
       if (step > 0) next_step_size = radius(step - 1);
-      const int srow = row + dr * r, scol = col + dc * r;
-      const bool inr = scol >= b.col_min && scol <= b.col_max && srow >= b.row_min && srow <= b.row_max;
-      uint32_t mine;
-      bool from_lds = false;
-      if constexpr (kUseLds) {
-        if (r <= 8) {
-          if (!covered(row, col, r) && step >= 2) stage_window(row, col);
-          from_lds = covered(row, col, r);
-        }
+      [[maybe_unused]] const unsigned long long t_r0 = CELL_T();
+      // the whole diamond inside the limits (the usual case): no per-site test
+      const bool all_in = row - r >= row_min && row + r <= row_max && col - r >= col_min && col + r <= col_max;   // (scalar)
+      bool inr = true;
+      if (!all_in) {
+        const int srow = row + dr * r, scol = col + dc * r;
+        inr = scol >= col_min && scol <= col_max && srow >= row_min && srow <= row_max;
       }
-      if constexpr (kUseLds) {
-        if (from_lds)
-          mine = group8_sad_lds<T, W, H>(win, (unsigned)((srow - wr0) * kWinPitch + (scol - wc0) * (int)sizeof(T)), kWinPitch, l,
-                                         inr, srcu) >> shift;
-        else
-          mine = site_sad(srow, scol, inr) >> shift;
-      } else {
-        mine = site_sad(srow, scol, inr) >> shift;
-      }
+      const bool in_win = win_covers(row, col, r);
+      const uint32_t mine = round_sad(row, col, r, inr, in_win) >> shift;
       // The reference walks the 8 sites in order with `if (sad < best) { sad += cost; if (sad < best) take it }` (mcomp.c:1350-1395): since
       // the L1 costs of this kernel are never negative that is "the FIRST site that attains the smallest sad + cost, if that is below the
       // best so far".  Every group adds its own site's cost, the 8 keys (sad + cost) << 4 | site are min-reduced -- one DPP step inside
       // the 16-lane rows, four v_readlane, three s_min -- instead of 16 v_readlane and eight dependent scalar compare / branch sequences.
-      int best_site = 0;
-      {
-        const uint32_t my_this = mine + (uint32_t)cc.sad_cost(srow, scol);
-        uint32_t key = inr ? ((my_this << 4) | (uint32_t)(g + 1)) : 0xFFFFFFFFu;
-        const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x128, 0xf, 0xf, false);  // row_ror:8: the row's other group
-        key = min(key, other);
-        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, 0), k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, 16);
-        const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)key, 32), k3 = (uint32_t)__builtin_amdgcn_readlane((int)key, 48);
-        const uint32_t kb = min(min(k0, k1), min(k2, k3));
-        if (kb != 0xFFFFFFFFu && (kb >> 4) < bestsad) {
-          bestsad = kb >> 4;
-          best_site = (int)(kb & 15u);
-        }
+      // cost = lambda * (|srow - frr| + |scol - frc|) (mvsad_err_cost_ of an L1 type: (lambda * 8 d) >> 3); |x| as v_sad_u32 against a bias
+      uint32_t my_this = mine;
+      if (lambda) {   // (scalar)
+        constexpr int kBias = 1 << 16;
+        const uint32_t tr = (uint32_t)(__mul24(dr, r) + (row - frr + kBias)), tc = (uint32_t)(__mul24(dc, r) + (col - frc + kBias));
+        uint32_t d;   // (no builtin for v_sad_u32)
+        asm("v_sad_u32 %0, %1, %2, 0\n\tv_sad_u32 %0, %3, %2, %0" : "=&v"(d) : "v"(tc), "s"(kBias), "v"(tr));
+        my_this += (uint32_t)__mul24((int)d, lambda);
       }
-      if (best_site != 0) {
-        const int ddr = (best_site == 1 || best_site == 5 || best_site == 7) ? -1
-                        : (best_site == 2 || best_site == 6 || best_site == 8) ? 1 : 0;
-        const int ddc = (best_site == 3 || best_site == 5 || best_site == 8) ? -1
-                        : (best_site == 4 || best_site == 6 || best_site == 7) ? 1 : 0;
-        row += ddr * r;
-        col += ddc * r;
+      uint32_t key = inr ? ((my_this << 4) | (uint32_t)(g + 1)) : 0xFFFFFFFFu;
+      key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x128, 0xf, 0xf, false));  // row_ror:8: the row's other group
+      const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, 0), k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, 16);
+      const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)key, 32), k3 = (uint32_t)__builtin_amdgcn_readlane((int)key, 48);
+      const uint32_t kb = min(min(k0, k1), min(k2, k3));
+      int best_site = 0;
+      if (kb != 0xFFFFFFFFu && (kb >> 4) < bestsad) {
+        bestsad = kb >> 4;
+        best_site = (int)(kb & 15u);
+        row += ((int)((kSiteDr >> (2 * best_site)) & 3u) - 1) * r;
+        col += ((int)((kSiteDc >> (2 * best_site)) & 3u) - 1) * r;
         is_off_center = 1;
       }
       if (is_off_center == 0) (*num00)++;
@@ -161,6 +234,9 @@ __global__ __launch_bounds__(kSearchThreads, AOMHIP_DIAMOND_WAVES) void fullpel_
           next_step_size = radius(step - 1);
         }
       }
+#ifdef AOMHIP_CELL_PROF
+      if (in_win) { t_lds += CELL_T() - t_r0; ++n_lds; } else { t_glob += CELL_T() - t_r0; ++n_glob; }
+#endif
     }
     *orow = row;
     *ocol = col;
@@ -168,12 +244,27 @@ __global__ __launch_bounds__(kSearchThreads, AOMHIP_DIAMOND_WAVES) void fullpel_
   };
 
   auto var_cost_at = [&](int row, int col) -> int {  // get_mvpred_var_cost: vf(src, ref) + mv_err_cost_
-    // lanes 0..15 (one DPP row) evaluate it: the sums reduce with four DPP steps instead of twelve 64-bit shuffles,
-    // which made one variance as expensive as five diamond steps
-    uint32_t sse;
-    uint32_t v = group16_variance<T, W, H, false>(rbase + (int64_t)row * ref.stride + col, ref.stride, 0, 0, sp, src.stride,
-                                                  /*a_minus_b=*/false, bit_depth, lane & 15, lane < 16, &sse);
+    [[maybe_unused]] const unsigned long long t_v0 = CELL_T();
+    uint32_t v = 0;
+    bool done = false;
+    if constexpr (CELL && G::KEEP) {
+      if (win_covers(row, col, 0)) {  // group 0 out of the window: no global-memory round trip at the end of every run
+        v = group8_variance_lds<T, W, H>(cell_lds, (unsigned)((b.by + row - cw.y0) * cw.pitch + (b.bx + col - cw.x0) * ES), cw.pitch, l,
+                                         g == 0, bit_depth, srcu);
+        done = true;
+      }
+    }
+    if (!done) {
+      // lanes 0..15 (one DPP row) evaluate it: the sums reduce with four DPP steps instead of twelve 64-bit shuffles,
+      // which made one variance as expensive as five diamond steps
+      uint32_t sse;
+      v = group16_variance<T, W, H, false>(rbase + (int64_t)row * ref.stride + col, ref.stride, 0, 0, sp, src.stride,
+                                           /*a_minus_b=*/false, bit_depth, lane & 15, lane < 16, &sse);
+    }
     v = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+#ifdef AOMHIP_CELL_PROF
+    t_var += CELL_T() - t_v0; ++n_var;
+#endif
     return (int)v + cc.var_cost(row * 8, col * 8);
   };
 
@@ -181,6 +272,7 @@ __global__ __launch_bounds__(kSearchThreads, AOMHIP_DIAMOND_WAVES) void fullpel_
   // skipped while the previous search reported it would have stayed on the centre (num00).  One loop, one inlined
   // copy of the search body (two copies cost 30 VGPRs = one wave per SIMD of occupancy).
   int n = 0, num00 = 0, br = 0, bc = 0, bestsme = INT_MAX;
+  int last_r = INT_MIN, last_c = INT_MIN, last_var = 0;   // the variance at the MV the previous run ended on
   const int further_steps = 11 - 1 - step_param;
   bool first = true;
   for (;;) {
@@ -199,7 +291,14 @@ __global__ __launch_bounds__(kSearchThreads, AOMHIP_DIAMOND_WAVES) void fullpel_
     if (run_it) {
       int t00, tr, tc;
       int sme = run_diamond(sstep, &t00, &tr, &tc);
-      if (sme < INT_MAX) sme = var_cost_at(tr, tc);
+      if (sme < INT_MAX) {
+        if (tr != last_r || tc != last_c) {
+          last_var = var_cost_at(tr, tc);
+          last_r = tr;
+          last_c = tc;
+        }
+        sme = last_var;
+      }
       if (first) {
         bestsme = sme;
         br = tr;
@@ -221,6 +320,8 @@ __global__ __launch_bounds__(kSearchThreads, AOMHIP_DIAMOND_WAVES) void fullpel_
     out_mv[2 * bi + 1] = (int16_t)bc;
     out_cost[bi] = bestsme;
   }
+  CELL_ADD(2, t_lds); CELL_ADD(3, n_lds); CELL_ADD(4, t_glob); CELL_ADD(5, n_glob); CELL_ADD(6, t_var); CELL_ADD(7, n_var);
+  CELL_ADD(8, CELL_T() - t_begin);
 }
 
 // ---- exhaustive mesh search: full_pixel_exhaustive (mcomp.c:1547-1617) over exhaustive_mesh_search (:1474-1543) ----
@@ -247,7 +348,7 @@ __device__ __forceinline__ uint32_t mesh_sad(const uint32_t *lds_src, const char
   constexpr int UPR = RB / UB;
   using L = typename MLoad<UB>::type;
   uint32_t acc = 0;
-#pragma unroll(H <= 16 ? H : 4)
+#pragma unroll H <= 16 ? H : 4
   for (int r = 0; r < H; ++r) {
 #pragma unroll
     for (int u = 0; u < UPR; ++u) {
@@ -425,6 +526,13 @@ using namespace aomhip;
 
 extern "C" {
 
+#ifdef AOMHIP_CELL_PROF
+int aomhip_debug_cell_prof(unsigned int *out, int n_blocks) {   // out[n_blocks][16]
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cell_prof), (size_t)n_blocks * 16 * sizeof(unsigned int)) != hipSuccess) return AOMHIP_ERR_HIP;
+  return AOMHIP_OK;
+}
+#endif
+
 int aomhip_fullpel_diamond_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw,
                                  int bh, int clamped, int step_param, int mv_cost_type,
                                  const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
@@ -436,22 +544,34 @@ int aomhip_fullpel_diamond_batch(aomhip_ctx *ctx, const aomhip_planes *src, cons
     return AOMHIP_ERR_INVALID;
   }
   if (n_blocks == 0) return AOMHIP_OK;
-  const dim3 grid((n_blocks + 3) / 4), block(kSearchThreads);
+  // the cell window: reach of the search's first steps around the start MVs (the whole search reaches 2 * first - 1)
+  const int first_r = 1 << (10 - step_param);
+  const CellPlan cp = plan_cells(ref, bw, bh, n_blocks, 2 * first_r);
+#define LAUNCH(T, W, H, WAVES, CELL)                                                                                            \
+  {                                                                                                                             \
+    auto k = fullpel_diamond_kernel<T, W, H, WAVES, CELL>;                                                                      \
+    if (cp.lds > 64 * 1024) AOMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, cp.lds)); \
+    hipLaunchKernelGGL(k, dim3(CELL ? cp.map.n_cells : (n_blocks + WAVES - 1) / WAVES), dim3(WAVES * 64), CELL ? cp.lds : 0, ctx->stream, \
+                       view_of<T>(*src), view_of<T>(*ref), frame, d_blocks, n_blocks, cp.map, clamped, step_param, mv_cost_type,  \
+                       src->bit_depth, d_best_mv, d_best_cost);                                                                  \
+  }
 #define X(W, H)                                                                                                      \
   if (bw == W && bh == H) {                                                                                          \
-    if (src->bit_depth == 8)                                                                                         \
-      hipLaunchKernelGGL((fullpel_diamond_kernel<uint8_t, W, H>), grid, block, 0, ctx->stream, view_of<uint8_t>(*src), \
-                         view_of<uint8_t>(*ref), frame, d_blocks, n_blocks, clamped, step_param, mv_cost_type, 8,    \
-                         d_best_mv, d_best_cost);                                                                    \
-    else                                                                                                             \
-      hipLaunchKernelGGL((fullpel_diamond_kernel<uint16_t, W, H>), grid, block, 0, ctx->stream,                       \
-                         view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame, d_blocks, n_blocks, clamped,       \
-                         step_param, mv_cost_type, src->bit_depth, d_best_mv, d_best_cost);                          \
+    if (src->bit_depth == 8) {                                                                                       \
+      if constexpr (G8<uint8_t, W, H>::KEEP) {                                                                       \
+        if (cp.waves) LAUNCH(uint8_t, W, H, kCellWaves, true) else LAUNCH(uint8_t, W, H, 4, false)                    \
+      } else LAUNCH(uint8_t, W, H, 4, false)                                                                         \
+    } else {                                                                                                         \
+      if constexpr (G8<uint16_t, W, H>::KEEP) {                                                                      \
+        if (cp.waves) LAUNCH(uint16_t, W, H, kCellWaves, true) else LAUNCH(uint16_t, W, H, 4, false)                  \
+      } else LAUNCH(uint16_t, W, H, 4, false)                                                                        \
+    }                                                                                                                \
     AOMHIP_LAUNCH_CHECK();                                                                                           \
     return AOMHIP_OK;                                                                                                \
   }
   AOMHIP_FOR_BLOCK_SIZES(X)
 #undef X
+#undef LAUNCH
   return AOMHIP_ERR_INVALID;
 }
 

@@ -191,19 +191,24 @@ __device__ __forceinline__ uint32_t group8_sad_lds(const uint32_t *win, unsigned
   static_assert(G::KEEP, "LDS path is only instantiated for blocks whose source units stay in registers");
   uint32_t acc = 0;
   if (active) {
+    // every read of the site first, then the arithmetic: one LDS round trip per site instead of one per unit
+    uint32_t d[G::PER_LANE][G::UB / 4 + 1];
+    unsigned sh[G::PER_LANE];
 #pragma unroll
     for (int k = 0; k < G::PER_LANE; ++k) {
-      const int u = l + 8 * k;
-      if (u < G::U) {
-        const int row = u / G::UPR, colb = (u % G::UPR) * G::UB;
-        const unsigned o = off + (unsigned)(row * pitch + colb);
-        const uint32_t *p = win + (o >> 2);
-        const unsigned sh = o & 3;
-        uint32_t d[G::UB / 4 + 1];
+      const int u = min(l + 8 * k, G::U - 1);
+      const int row = u / G::UPR, colb = (u % G::UPR) * G::UB;
+      const unsigned o = off + (unsigned)(row * pitch + colb);
+      const uint32_t *p = win + (o >> 2);
+      sh[k] = o & 3;
 #pragma unroll
-        for (int i = 0; i <= G::UB / 4; ++i) d[i] = p[i];
+      for (int i = 0; i <= G::UB / 4; ++i) d[k][i] = p[i];
+    }
 #pragma unroll
-        for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(s[k].v[i], __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh), acc);
+    for (int k = 0; k < G::PER_LANE; ++k) {
+      if (l + 8 * k < G::U) {
+#pragma unroll
+        for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(s[k].v[i], __builtin_amdgcn_alignbyte(d[k][i + 1], d[k][i], sh[k]), acc);
       }
     }
   }
