@@ -27,7 +27,8 @@ struct SearchArgs {
 
 #define AOMHIP_DECL_FPS(NAME)                                                                                                 \
   int NAME(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,                   \
-           const aomhip_search_block *d_blocks, int n_blocks, const SiteTable *d_sites, SearchArgs q, int16_t *d_best_mv,     \
+           const aomhip_search_block *d_blocks, int n_blocks, const SiteTable *d_sites, SearchArgs q, int reach,          \
+           int16_t *d_best_mv,                                                                                                  \
            int32_t *d_best_cost, int32_t *d_cost_list, int16_t *d_second_best_mv);
 AOMHIP_DECL_FPS(launch_fps_u8)
 AOMHIP_DECL_FPS(launch_fps_u16)

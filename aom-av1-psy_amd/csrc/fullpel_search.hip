@@ -166,6 +166,7 @@ int aomhip_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
     set_error("aomhip_full_pixel_search_batch: could not place the site table on device %d", ctx->device);
     return AOMHIP_ERR_HIP;
   }
+  int reach;   // of the whole search around its start MV: the sum of the radii from step_param down (the LDS window takes what it can)
   {
     SiteTable h;
     build_sites(p->search_method, &h);
@@ -173,6 +174,8 @@ int aomhip_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
       set_error("aomhip_full_pixel_search_batch: step_param %d >= %d search steps", p->step_param, h.num_search_steps);
       return AOMHIP_ERR_INVALID;
     }
+    reach = 0;
+    for (int st = h.num_search_steps - 1 - p->step_param; st >= 0; --st) reach += h.radius[st];
   }
   SearchArgs q;
   q.method = p->search_method; q.step_param = p->step_param; q.cost_type = p->mv_cost_type;
@@ -182,7 +185,7 @@ int aomhip_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
   for (int i = 0; i < 8; ++i) q.mesh[i] = p->mesh_patterns[i];
   q.mvjcost = d_mvjcost; q.mvcost0 = d_mvcost_row; q.mvcost1 = d_mvcost_col;
   q.bit_depth = src->bit_depth; q.want_cl = d_cost_list != nullptr;
-  return (src->bit_depth == 8 ? launch_fps_u8 : launch_fps_u16)(ctx, src, ref, frame, bw, bh, d_blocks, n_blocks, d_sites, q, d_best_mv,
+  return (src->bit_depth == 8 ? launch_fps_u8 : launch_fps_u16)(ctx, src, ref, frame, bw, bh, d_blocks, n_blocks, d_sites, q, reach, d_best_mv,
                                                                d_best_cost, d_cost_list, d_second_best_mv);
 }
 
