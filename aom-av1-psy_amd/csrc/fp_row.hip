@@ -1,0 +1,148 @@
+// The first pass's chained motion search as ONE launch per frame: a wavefront per block row walks its blocks left to right.
+//
+// firstpass_inter_prediction (av1/encoder/firstpass.c:690-815) under the raster loop (:1148-1193): best_ref_mv of block (r, c) is block
+// (r, c - 1)'s *best_mv and kZeroMv at c == 0 (:1165, :1190) -- rows are independent, columns a chain.  aomhip_first_pass_inter_frame
+// computes everything that does not depend on the chain (the three 0,0 errors, the two zero-MV legs) for the whole frame first; the leg
+// started at best_ref_mv used to run one block COLUMN at a time, a search launch + a decision launch per column: 2 x 240 dependent
+// launches of a 4K frame with 135 wavefronts each (profiles/r03z_first_pass_4k_10bit_kernel_stats.csv: 6 066 search launches of 95.7 us,
+// 24 ms per frame).  Here the chain lives in the registers of the row's wavefront: list entry (get_fullmv_from_mv(best_ref_mv),
+// av1_set_mv_search_range) -> av1_full_pixel_search (the same device function the batched kernel runs, fullpel_search.inc fps_block) ->
+// av1_get_mvpred_sse + MV cost + NEW_MV_MODE_PENALTY -> the decision (:722-752, :777-794) -> next block, with no launch and no global
+// round trip between the links, and only for the blocks that need it (raw_motion_error above the threshold, best_ref_mv != 0).
+#include <climits>
+
+#define AOMHIP_FPS_DEVICE_ONLY
+#include "fullpel_search.inc"
+
+namespace aomhip {
+namespace {
+
+constexpr int kMaxFullPel = 1023;          // MAX_FULL_PEL_VAL (mcomp_structs.h:22)
+constexpr int kMvLow = -(1 << 14), kMvUpp = 1 << 14;  // MV_LOW / MV_UPP (entropymv.h:75-76)
+__device__ __forceinline__ int rawpel(int x) { return (x + 3 + (x >= 0)) >> 3; }  // GET_MV_RAWPEL (mv.h:28)
+
+template <typename T, int W, int H>
+__global__ __launch_bounds__(64) void fp_row_kernel(PlaneView<T> src, PlaneView<T> last, const aomhip_search_block *__restrict__ blocks,
+                                                    const SiteTable *__restrict__ sites, SearchArgs q, FpfLegs L, FpfCost C,
+                                                    const int32_t *__restrict__ intra, int rows, int cols, int thr, int skip_zeromv, FpfOut out) {
+  __shared__ SiteTable sS;
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(sites);
+    uint32_t *d = reinterpret_cast<uint32_t *>(&sS);
+    for (int i = threadIdx.x; i < (int)(sizeof(SiteTable) / 4); i += 64) d[i] = g[i];
+  }
+  __syncthreads();
+  const int r = blockIdx.x, lane = threadIdx.x;
+  if (r >= rows) return;
+  const CellWin no_win{ 0, 0, 0, 0, 0 };
+  int brow = 0, bcol = 0;   // MV best_ref_mv = kZeroMv at the start of every row (:1165), in 1/8 pel
+  for (int c = 0; c < cols; ++c) {
+    const size_t i = (size_t)r * cols + c;
+    const aomhip_search_block b = blocks[i];
+    const int bx = __builtin_amdgcn_readfirstlane((int)b.bx), by = __builtin_amdgcn_readfirstlane((int)b.by);
+    const bool moved = (brow | bcol) != 0;
+    const int raw = (int)L.raw[i];
+    int e1 = INT_MAX, m1r = 0, m1c = 0;
+    if (raw > thr) {
+      if (moved) {
+        // the list entry of first_pass_motion_search (:261-299): ref_mv = best_ref_mv, start = get_fullmv_from_mv(ref_mv), limits =
+        // av1_set_mv_search_range(&x->mv_limits, &ref_mv) (mcomp.c:196-215) on the block's raw limits
+        BlockScalars bs = BlockScalars::of(b);
+        bs.ref_row = brow; bs.ref_col = bcol;
+        bs.start_row = rawpel(brow); bs.start_col = rawpel(bcol);
+        {
+          int col_min = rawpel(bcol) - kMaxFullPel + ((bcol & 7) ? 1 : 0), row_min = rawpel(brow) - kMaxFullPel + ((brow & 7) ? 1 : 0);
+          int col_max = rawpel(bcol) + kMaxFullPel, row_max = rawpel(brow) + kMaxFullPel;
+          const int lo = rawpel(kMvLow) + 1, hi = rawpel(kMvUpp) - 1;
+          col_min = max(col_min, lo); row_min = max(row_min, lo);
+          col_max = min(col_max, hi); row_max = min(row_max, hi);
+          bs.col_min = max(bs.col_min, col_min); bs.col_max = min(bs.col_max, col_max);
+          bs.row_min = max(bs.row_min, row_min); bs.row_max = min(bs.row_max, row_max);
+        }
+        const T *sp = src.origin + (int64_t)by * src.stride + bx;
+        const T *rbase = last.origin + (int64_t)by * last.stride + bx;
+        FpsResult fr;
+        fps_block<T, W, H, false>(sp, src.stride, rbase, last.stride, bx, by, bs, sS, q, no_win, nullptr, lane, &fr);
+        m1r = fr.br; m1c = fr.bc;
+        if (fr.var != INT_MAX) {
+          // av1_get_mvpred_sse (mcomp.c:3661-3677): the sse of the mse function at the full-pel MV + mv_err_cost, + NEW_MV_MODE_PENALTY (:292-296)
+          const T *rp = rbase + (int64_t)m1r * last.stride + m1c;
+          unsigned long long sse = 0;
+          for (int t = lane; t < W * H; t += 64) {
+            const int y = t / W, x = t - y * W;
+            const int d = (int)sp[(int64_t)y * src.stride + x] - (int)rp[(int64_t)y * last.stride + x];
+            sse += (unsigned)__mul24(d, d);
+          }
+#pragma unroll
+          for (int m = 1; m < 64; m <<= 1) sse += __shfl_xor(sse, m, 64);
+          const uint32_t qq = q.bit_depth == 10 ? (uint32_t)((sse + 8) >> 4) : q.bit_depth == 12 ? (uint32_t)((sse + 128) >> 8) : (uint32_t)sse;
+          const int mrow = m1r * 8, mcol = m1c * 8;
+          int cost;
+          if (C.type == kCostEntropy) {
+            const int dr = mrow - brow, dc = mcol - bcol;
+            const int64_t bits = (int64_t)C.mvjcost[(dc != 0) | ((dr != 0) << 1)] + C.mvcost0[dr] + C.mvcost1[dc];
+            cost = (int)((bits * C.error_per_bit + (1 << 13)) >> 14);
+          } else {
+            const CostCtx cc{ C.type, brow, bcol };
+            cost = cc.var_cost(mrow, mcol);
+          }
+          e1 = (int32_t)(qq + (uint32_t)cost + 32u);
+        }
+      } else {
+        e1 = L.zerr[i]; m1r = L.zmv[2 * i]; m1c = L.zmv[2 * i + 1];
+      }
+    }
+    // the decision (:722-752, :777-794), every lane the same values
+    int err = (int)L.err0[i], mrow = 0, mcol = 0, gf;
+    gf = err;
+    if (raw > thr) {
+      if (e1 < err) { err = e1; mrow = m1r; mcol = m1c; }
+      if (!skip_zeromv && moved) {
+        const int e0 = L.zerr[i];
+        if (e0 < err) { err = e0; mrow = L.zmv[2 * i]; mcol = L.zmv[2 * i + 1]; }
+      }
+      gf = err;
+      if (L.gerr) { gf = (int)L.gf0[i]; if (L.gerr[i] < gf) gf = L.gerr[i]; }
+    }
+    int nrow = 0, ncol = 0;
+    if (err <= intra[i]) { nrow = mrow * 8; ncol = mcol * 8; }
+    brow = __builtin_amdgcn_readfirstlane(nrow); bcol = __builtin_amdgcn_readfirstlane(ncol);
+    if (lane == 0) {
+      out.best_mv[2 * i] = (int16_t)brow; out.best_mv[2 * i + 1] = (int16_t)bcol;
+      if (out.full_mv) { out.full_mv[2 * i] = (int16_t)mrow; out.full_mv[2 * i + 1] = (int16_t)mcol; }
+      out.motion_error[i] = err;
+      if (out.gf_motion_error) out.gf_motion_error[i] = gf;
+      if (out.raw_motion_error) out.raw_motion_error[i] = raw;
+    }
+  }
+}
+
+}  // namespace
+
+bool fp_rows_supported(int bw, int bh) { return (bw == 16 && bh == 16) || (bw == 8 && bh == 8); }
+
+int launch_fp_rows(aomhip_ctx *ctx, const aomhip_planes *src1, const aomhip_planes *last1, int bw, int bh, const aomhip_search_params *p,
+                   const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks,
+                   const FpfLegs &L, const int32_t *d_intra, int rows, int cols, int thr, int skip_zeromv, const FpfOut &out) {
+  if (!fp_rows_supported(bw, bh)) return AOMHIP_ERR_INVALID;
+  const SiteTable *d_sites = fps_device_sites(ctx->device, p->search_method);
+  if (!d_sites) {
+    set_error("first pass: could not place the site table on device %d", ctx->device);
+    return AOMHIP_ERR_HIP;
+  }
+  const SearchArgs q = fps_search_args(p, d_mvjcost, d_mvcost_row, d_mvcost_col, src1->bit_depth, false);
+  const FpfCost C{ p->mv_cost_type, p->error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col };
+#define X(T, W, H)                                                                                                                      \
+  hipLaunchKernelGGL((fp_row_kernel<T, W, H>), dim3(rows), dim3(64), 0, ctx->stream, view_of<T>(*src1), view_of<T>(*last1), d_blocks,  \
+                     d_sites, q, L, C, d_intra, rows, cols, thr, skip_zeromv, out)
+  if (src1->bit_depth == 8) {
+    if (bw == 16) X(uint8_t, 16, 16); else X(uint8_t, 8, 8);
+  } else {
+    if (bw == 16) X(uint16_t, 16, 16); else X(uint16_t, 8, 8);
+  }
+#undef X
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+}  // namespace aomhip

@@ -34,6 +34,24 @@ AOMHIP_DECL_FPS(launch_fps_u8)
 AOMHIP_DECL_FPS(launch_fps_u16)
 #undef AOMHIP_DECL_FPS
 
+// shared by the first-pass composite (tf_search.hip) and its row-persistent kernel (fp_row.hip)
+const SiteTable *fps_device_sites(int device, int method);   // the per-(device, method) table in device memory; nullptr on failure
+SearchArgs fps_search_args(const aomhip_search_params *p, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                           int bit_depth, bool want_cost_list);
+struct FpfLegs {
+  const int16_t *zmv; const int32_t *zerr;   // zero-MV leg on the last frame, per block
+  const int16_t *gmv; const int32_t *gerr;   // zero-MV leg on the golden frame, per block (null without one)
+  const int16_t *cmv; const int32_t *cerr;   // chained leg of this column, per row (the column-at-a-time form only)
+  const uint32_t *err0, *raw, *gf0;           // get_prediction_error_bitdepth at 0,0: last frame, last source, golden
+};
+struct FpfCost { int type, error_per_bit; const int32_t *mvjcost, *mvcost0, *mvcost1; };
+struct FpfOut { int16_t *best_mv, *full_mv; int32_t *motion_error, *gf_motion_error, *raw_motion_error; };
+// the chained leg of a whole frame in one launch (fp_row.hip); AOMHIP_ERR_INVALID for block sizes it is not built for
+int launch_fp_rows(aomhip_ctx *ctx, const aomhip_planes *src1, const aomhip_planes *last1, int bw, int bh, const aomhip_search_params *p,
+                   const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks,
+                   const FpfLegs &L, const int32_t *d_intra, int rows, int cols, int thr, int skip_zeromv, const FpfOut &out);
+bool fp_rows_supported(int bw, int bh);
+
 }  // namespace aomhip
 
 #endif  // AOMHIP_CSRC_FULLPEL_SEARCH_H_

@@ -119,6 +119,20 @@ static const SiteTable *device_sites(int device, int method) {
   return tab[device][method];
 }
 
+const SiteTable *fps_device_sites(int device, int method) { return device_sites(device, method); }
+SearchArgs fps_search_args(const aomhip_search_params *p, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                           int bit_depth, bool want_cost_list) {
+  SearchArgs q;
+  q.method = p->search_method; q.step_param = p->step_param; q.cost_type = p->mv_cost_type;
+  q.sad_per_bit = p->sad_per_bit; q.error_per_bit = p->error_per_bit; q.skip_sad = p->use_downsampled_sad != 0;
+  q.run_mesh = p->run_mesh_search; q.prune_mesh = p->prune_mesh_search; q.mesh_diff_thr = p->mesh_search_mv_diff_threshold;
+  q.force_mesh_thresh = p->force_mesh_thresh; q.fine_interval = p->fine_search_interval;
+  for (int i = 0; i < 8; ++i) q.mesh[i] = p->mesh_patterns[i];
+  q.mvjcost = d_mvjcost; q.mvcost0 = d_mvcost_row; q.mvcost1 = d_mvcost_col;
+  q.bit_depth = bit_depth; q.want_cl = want_cost_list;
+  return q;
+}
+
 }  // namespace aomhip
 
 using namespace aomhip;
@@ -177,14 +191,7 @@ int aomhip_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
     reach = 0;
     for (int st = h.num_search_steps - 1 - p->step_param; st >= 0; --st) reach += h.radius[st];
   }
-  SearchArgs q;
-  q.method = p->search_method; q.step_param = p->step_param; q.cost_type = p->mv_cost_type;
-  q.sad_per_bit = p->sad_per_bit; q.error_per_bit = p->error_per_bit; q.skip_sad = p->use_downsampled_sad != 0;
-  q.run_mesh = p->run_mesh_search; q.prune_mesh = p->prune_mesh_search; q.mesh_diff_thr = p->mesh_search_mv_diff_threshold;
-  q.force_mesh_thresh = p->force_mesh_thresh; q.fine_interval = p->fine_search_interval;
-  for (int i = 0; i < 8; ++i) q.mesh[i] = p->mesh_patterns[i];
-  q.mvjcost = d_mvjcost; q.mvcost0 = d_mvcost_row; q.mvcost1 = d_mvcost_col;
-  q.bit_depth = src->bit_depth; q.want_cl = d_cost_list != nullptr;
+  const SearchArgs q = fps_search_args(p, d_mvjcost, d_mvcost_row, d_mvcost_col, src->bit_depth, d_cost_list != nullptr);
   return (src->bit_depth == 8 ? launch_fps_u8 : launch_fps_u16)(ctx, src, ref, frame, bw, bh, d_blocks, n_blocks, d_sites, q, reach, d_best_mv,
                                                                d_best_cost, d_cost_list, d_second_best_mv);
 }

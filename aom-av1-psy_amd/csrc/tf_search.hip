@@ -6,6 +6,7 @@
 #include <climits>
 
 #include "common.h"
+#include "fullpel_search.h"
 #include "search_device.h"
 
 namespace aomhip {
@@ -541,16 +542,9 @@ __global__ void fpf_zero_list_kernel(const aomhip_search_block *blocks, int n, a
   full_limits(b, &o);
   out[i] = o;
 }
-struct FpfLegs {
-  const int16_t *zmv; const int32_t *zerr;   // zero-MV leg on the last frame, per block
-  const int16_t *gmv; const int32_t *gerr;   // zero-MV leg on the golden frame, per block (null without one)
-  const int16_t *cmv; const int32_t *cerr;   // chained leg of this column, per row
-  const uint32_t *err0, *raw, *gf0;           // get_prediction_error_bitdepth at 0,0: last frame, last source, golden
-};
 // One block column of the chain in ONE launch behind its search (a wavefront per block row): the leg's av1_get_mvpred_sse + MV cost +
 // NEW_MV_MODE_PENALTY (what fp_cands / variance / fp_finish do for a list), the decision (firstpass.c:722-752, :777-794), and the next column's list
 // entry (get_fullmv_from_mv(best_ref_mv), av1_set_mv_search_range).  Six launches per column were 110 us of a 4K frame's 240 columns.
-struct FpfCost { int type, error_per_bit; const int32_t *mvjcost, *mvcost0, *mvcost1; };
 template <typename T>
 __global__ __launch_bounds__(256) void fpf_column_kernel(PlaneView<T> src, PlaneView<T> last, int bw, int bh, int bit_depth, const aomhip_search_block *blocks,
                                                          const aomhip_search_block *cur_list, const int32_t *search_cost, FpfLegs L, FpfCost C,
@@ -720,6 +714,13 @@ extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_plane
   L.cmv = i16(o_cmv); L.cerr = i32(o_cerr);
   L.err0 = u32(o_e0); L.raw = u32(o_raw); L.gf0 = u32(o_gf0);
   aomhip::FpfCost C{ p->mv_cost_type, p->error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col };
+  // the chain: one launch, a wavefront per row (fp_row.hip) -- or, for block sizes that kernel is not built for, column by column
+  const char *force_cols = getenv("AOMHIP_FP_COLUMNS");   // (tests: the column-at-a-time form on the sizes the row kernel serves)
+  if (aomhip::fp_rows_supported(bw, bh) && !(force_cols && atoi(force_cols))) {
+    const aomhip::FpfOut out{ d_best_mv, d_full_mv, d_motion_error, d_gf_motion_error, d_raw_motion_error };
+    return aomhip::launch_fp_rows(ctx, &s1, &l1, bw, bh, p, d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, L, d_intra_error, rows, cols,
+                                  fp->skip_motion_search_threshold, fp->skip_zeromv_motion_search, out);
+  }
   aomhip_search_block *cl2 = reinterpret_cast<aomhip_search_block *>(w + o_cl2);
   const unsigned gw = (unsigned)((r1 + 3) / 4);
   for (int c = 0; c < cols; ++c) {
