@@ -27,6 +27,9 @@ struct aomhip_ctx {
   // device-side status word: kernels that find a work-list entry they cannot process (e.g. an aomhip_txb whose tx_type does not
   // exist for the transform size) OR a code into it; aomhip_ctx_sync reports and clears it
   int *d_status;
+  // bumped whenever scratch / work / pinned memory is reallocated: an aomhip_graph captured on this context froze the old addresses and
+  // must not be replayed after that (aomhip_graph_launch compares)
+  unsigned buf_generation;
   int *h_status;  // pinned mirror: aomhip_ctx_sync reads the word with an async copy ordered before its one stream synchronise
 };
 
@@ -34,14 +37,18 @@ namespace aomhip {
 
 void set_error(const char *fmt, ...);
 // rtcd-signature paths (the reference's signatures have no error return): record the failure in the process-wide
-// sticky status (aomhip_status()) and let the caller return its defined "failed" value: kFailedCost (UINT32_MAX) for every
-// cost-type result -- SAD, variance, sse: a failed candidate must LOSE the encoder's search, 0 would win it -- and
+// sticky status (aomhip_status()) and let the caller return its defined "failed" value -- a failed candidate must LOSE the encoder's
+// search, 0 would win it: kFailedCost (UINT32_MAX) for SAD, whose consumers compare unsigned (mcomp.c:1350-1395), and kFailedVarCost
+// (0x3FFFFFFF) for variance / sub-pixel variance / sse and their *sse, whose consumers convert to int and add an MV cost in 32 bits
+// (check_better_fast `int thismse = svf(..); cost += thismse`, mcomp.c:2441-2448; get_mvpred_var_cost :645-664; av1_get_mvpred_sse
+// :3661-3677): UINT32_MAX would read as -1 there and WIN, 0x3FFFFFFF stays positive and cannot wrap when a cost is added -- and
 // zeroed outputs for everything else (coefficients, eob, filtered pixels untouched).  Never
 // aborts, never longjmps (the encoder's only error path is its own, av1/encoder/encoder.c:947-952) -- unless
 // AOMHIP_ABORT_ON_ERROR=1 asks for the old fail-stop behaviour.  There is still no CPU fallback: a failed call
 // computes nothing.
 void note_failure(const char *what, int status = AOMHIP_ERR_HIP);
 constexpr uint32_t kFailedCost = 0xFFFFFFFFu;
+constexpr uint32_t kFailedVarCost = 0x3FFFFFFFu;
 aomhip_ctx *default_ctx();                  // lazily created per-thread context for the rtcd-signature paths; nullptr on failure
 void *scratch(aomhip_ctx *ctx, size_t bytes);
 void *pinned(aomhip_ctx *ctx, size_t bytes);

@@ -234,13 +234,13 @@ template <typename T>
 static uint32_t host_compound(const aomhip_compound_params *p, const T *a, int a_stride, int xoff, int yoff, const T *b, int b_stride,
                               const T *second_pred, const uint8_t *mask, const int32_t *wsrc, const int32_t *omask, int bw, int bh,
                               int bit_depth, bool want_sad, uint32_t *sse_out) {
-  if (sse_out) *sse_out = kFailedCost;  // the defined results of a failed call: LOSING scores (0 would win every search)
+  if (sse_out) *sse_out = kFailedVarCost;  // the defined results of a failed call: LOSING scores (0 would win every search)
   aomhip_ctx *ctx = default_ctx();
-  if (!ctx) return kFailedCost;
+  if (!ctx) return kFailedVarCost;
   if (!valid_block(bw, bh) || !params_ok(p)) {
     set_error("aomhip_compound: unsupported block size %dx%d or parameters", bw, bh);
     note_failure("aomhip_compound", AOMHIP_ERR_INVALID);
-    return kFailedCost;
+    return kFailedVarCost;
   }
   const bool subpel = p->subpel != 0, obmc = p->kind == AOMHIP_COMP_OBMC;
   const int aw = bw + (subpel ? 1 : 0), ah = bh + (subpel ? 1 : 0);
@@ -253,7 +253,7 @@ static uint32_t host_compound(const aomhip_compound_params *p, const T *a, int a
   const size_t r_off = c_off + 16, total = r_off + 16;
   char *h = static_cast<char *>(pinned(ctx, total));
   char *d = static_cast<char *>(scratch(ctx, total));
-  if (!h || !d) { note_failure("aomhip_compound scratch", AOMHIP_ERR_NOMEM); return kFailedCost; }
+  if (!h || !d) { note_failure("aomhip_compound scratch", AOMHIP_ERR_NOMEM); return kFailedVarCost; }
   memset(h, 0, total);
   for (int r = 0; r < ah; ++r) memcpy(reinterpret_cast<T *>(h) + (size_t)r * astr, a + (size_t)r * a_stride, (size_t)aw * sizeof(T));
   if (!obmc) {
@@ -266,7 +266,7 @@ static uint32_t host_compound(const aomhip_compound_params *p, const T *a, int a
     memcpy(h + o_off, omask, n * 4);
   }
   *reinterpret_cast<aomhip_var_cand *>(h + c_off) = aomhip_var_cand{ 0, 0, 0, 0, (uint8_t)xoff, (uint8_t)yoff, { 0, 0 } };
-  if (hipMemcpyAsync(d, h, r_off, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { note_failure("aomhip_compound H2D"); return kFailedCost; }
+  if (hipMemcpyAsync(d, h, r_off, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { note_failure("aomhip_compound H2D"); return kFailedVarCost; }
   PlaneView<T> pa{ reinterpret_cast<const T *>(d), 0, astr };
   PlaneView<T> pb{ reinterpret_cast<const T *>(d + b_off), 0, bw };
   uint32_t *res = reinterpret_cast<uint32_t *>(d + r_off);
@@ -276,11 +276,11 @@ static uint32_t host_compound(const aomhip_compound_params *p, const T *a, int a
   fill_args(p, &l.g);
   l.g.mask_stride = bw;  // the staged mask is packed
   const int kind = p->kind == AOMHIP_COMP_MASK ? kCompMask : obmc ? kCompObmc : kCompWeights;
-  if (dispatch_compound<T>(kind, subpel, l, pb, pa, bw, bh) != AOMHIP_OK) { note_failure("aomhip_compound launch"); return kFailedCost; }
+  if (dispatch_compound<T>(kind, subpel, l, pb, pa, bw, bh) != AOMHIP_OK) { note_failure("aomhip_compound launch"); return kFailedVarCost; }
   if (hipMemcpyAsync(h + r_off, d + r_off, 12, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess) {
     note_failure("aomhip_compound D2H");
-    return kFailedCost;
+    return kFailedVarCost;
   }
   const uint32_t *out = reinterpret_cast<const uint32_t *>(h + r_off);
   if (sse_out) *sse_out = out[1];

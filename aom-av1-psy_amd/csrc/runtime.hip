@@ -47,6 +47,7 @@ aomhip_ctx *default_ctx() {
 
 void *scratch(aomhip_ctx *ctx, size_t bytes) {
   if (ctx->d_scratch_bytes < bytes) {
+    ++ctx->buf_generation;
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
     if (hipMalloc(&ctx->d_scratch, cap) != hipSuccess) {
@@ -62,6 +63,7 @@ void *scratch(aomhip_ctx *ctx, size_t bytes) {
 
 void *work(aomhip_ctx *ctx, size_t bytes) {
   if (ctx->d_work_bytes < bytes) {
+    ++ctx->buf_generation;
     if (ctx->d_work) {
       (void)hipStreamSynchronize(ctx->stream);  // kernels of an earlier call may still use it
       (void)hipFree(ctx->d_work);
@@ -81,6 +83,7 @@ void *work(aomhip_ctx *ctx, size_t bytes) {
 
 void *pinned(aomhip_ctx *ctx, size_t bytes) {
   if (ctx->h_pinned_bytes < bytes) {
+    ++ctx->buf_generation;
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
     if (hipHostMalloc(&ctx->h_pinned, cap, hipHostMallocDefault) != hipSuccess) {
@@ -234,6 +237,8 @@ void *aomhip_ctx_stream(aomhip_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
 struct aomhip_graph {
   hipGraph_t graph;
   hipGraphExec_t exec;
+  const aomhip_ctx *ctx;     // the context it was captured on ...
+  unsigned buf_generation;   // ... and the state of that context's internal buffers, whose addresses the graph froze
 };
 
 int aomhip_graph_capture_begin(aomhip_ctx *ctx) {
@@ -272,13 +277,20 @@ int aomhip_graph_capture_end(aomhip_ctx *ctx, aomhip_graph **out) {
   }
   aomhip_graph *gr = static_cast<aomhip_graph *>(malloc(sizeof(aomhip_graph)));
   if (!gr) { (void)hipGraphExecDestroy(x); (void)hipGraphDestroy(g); return AOMHIP_ERR_NOMEM; }
-  gr->graph = g; gr->exec = x;
+  gr->graph = g; gr->exec = x; gr->ctx = ctx; gr->buf_generation = ctx->buf_generation;
   *out = gr;
   return AOMHIP_OK;
 }
 
 int aomhip_graph_launch(aomhip_ctx *ctx, aomhip_graph *g) {
   if (!ctx || !g) return AOMHIP_ERR_INVALID;
+  if (g->ctx != ctx || g->buf_generation != ctx->buf_generation) {
+    // the composite entry points keep their intermediates in the context's work / scratch memory, which grows (free + malloc) when a
+    // later call needs more: the graph would read and write freed memory
+    set_error(g->ctx != ctx ? "aomhip_graph_launch: the graph was captured on another context"
+                            : "aomhip_graph_launch: a larger call on this context reallocated its work buffers after the capture: capture again");
+    return AOMHIP_ERR_INVALID;
+  }
   AOMHIP_TRY(hipGraphLaunch(g->exec, ctx->stream));
   return AOMHIP_OK;
 }

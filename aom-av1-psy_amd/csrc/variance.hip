@@ -151,14 +151,14 @@ static int var_batch(bool subpel, aomhip_ctx *ctx, const aomhip_planes *src, con
 template <typename T>
 static uint32_t host_variance(bool subpel, const T *a, int a_stride, int xoff, int yoff, const T *b, int b_stride, int bw,
                               int bh, int bit_depth, uint32_t *sse_out, int *sum_out = nullptr) {
-  if (sse_out) *sse_out = kFailedCost;  // the defined results of a failed call: LOSING scores (0 would win every search)
+  if (sse_out) *sse_out = kFailedVarCost;  // the defined results of a failed call: LOSING scores (0 would win every search)
   if (sum_out) *sum_out = 0;
   aomhip_ctx *ctx = default_ctx();
-  if (!ctx) return kFailedCost;
+  if (!ctx) return kFailedVarCost;
   if (!valid_block(bw, bh)) {
     set_error("unsupported block size %dx%d", bw, bh);
     note_failure("aomhip_variance", AOMHIP_ERR_INVALID);
-    return kFailedCost;
+    return kFailedVarCost;
   }
   const int aw = bw + (subpel ? 1 : 0), ah = bh + (subpel ? 1 : 0);
   const int astr = (aw + 15) & ~15;  // padded so the kernel's trailing wide load stays inside the staging area
@@ -167,7 +167,7 @@ static uint32_t host_variance(bool subpel, const T *a, int a_stride, int xoff, i
   const size_t o_off = c_off + 16, total = o_off + 16;
   char *h = static_cast<char *>(pinned(ctx, total));
   char *d = static_cast<char *>(scratch(ctx, total));
-  if (!h || !d) { note_failure("aomhip_variance scratch", AOMHIP_ERR_NOMEM); return kFailedCost; }
+  if (!h || !d) { note_failure("aomhip_variance scratch", AOMHIP_ERR_NOMEM); return kFailedVarCost; }
   memset(h, 0, total);
   for (int r = 0; r < ah; ++r)
     memcpy(reinterpret_cast<T *>(h) + (size_t)r * astr, a + (size_t)r * a_stride, (size_t)aw * sizeof(T));
@@ -175,7 +175,7 @@ static uint32_t host_variance(bool subpel, const T *a, int a_stride, int xoff, i
     memcpy(reinterpret_cast<T *>(h + b_off) + (size_t)r * bw, b + (size_t)r * b_stride, (size_t)bw * sizeof(T));
   aomhip_var_cand *hc = reinterpret_cast<aomhip_var_cand *>(h + c_off);
   *hc = aomhip_var_cand{ 0, 0, 0, 0, (uint8_t)xoff, (uint8_t)yoff, { 0, 0 } };
-  if (hipMemcpyAsync(d, h, o_off, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { note_failure("aomhip_variance H2D"); return kFailedCost; }
+  if (hipMemcpyAsync(d, h, o_off, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { note_failure("aomhip_variance H2D"); return kFailedVarCost; }
   // sub-pixel: a is the (interpolated) "ref" operand, b the "src" operand; plain: variance(a, b) = a - b, so a
   // takes the src slot.
   PlaneView<T> pa{ reinterpret_cast<const T *>(d), 0, astr };
@@ -188,12 +188,12 @@ static uint32_t host_variance(bool subpel, const T *a, int a_stride, int xoff, i
   if (dispatch_var<T>(subpel, l, sv, rv, bw, bh, reinterpret_cast<const aomhip_var_cand *>(d + c_off), 1, 0, dv,
                       dv + 1) != AOMHIP_OK) {
     note_failure("aomhip_variance launch");
-    return kFailedCost;
+    return kFailedVarCost;
   }
   if (hipMemcpyAsync(h + o_off, d + o_off, 12, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess) {
     note_failure("aomhip_variance D2H");
-    return kFailedCost;
+    return kFailedVarCost;
   }
   const uint32_t *res = reinterpret_cast<const uint32_t *>(h + o_off);
   if (sse_out) *sse_out = res[1];

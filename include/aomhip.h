@@ -26,9 +26,11 @@
  * aomhip_status_t.  rtcd-signature calls cannot: a failure there (no device, a HIP
  * error, an unsupported size) is recorded in a process-wide STICKY status --
  * aomhip_status(), first failure wins, reported once on stderr -- and the call
- * returns its defined "failed" result: UINT32_MAX for every cost (SAD, variance, sse:
- * a failed candidate loses the search, it never wins it), zeroed coefficients / eob,
- * pixels untouched.  It
+ * returns its defined "failed" result: a LOSING score for every cost -- UINT32_MAX for
+ * SAD (compared unsigned by its callers), 0x3FFFFFFF for variance / sub-pixel variance /
+ * sse and their *sse (their callers convert to int and add an MV cost in 32 bits,
+ * av1/encoder/mcomp.c:2441-2448: UINT32_MAX would read as -1 and win) --, zeroed
+ * coefficients / eob, pixels untouched.  It
  * never aborts and never longjmps: the encoder's only error path stays its own
  * (av1/encoder/encoder.c:947-952), which a caller can take after checking
  * aomhip_status() at a frame boundary.  AOMHIP_ABORT_ON_ERROR=1 restores fail-stop
@@ -80,7 +82,9 @@ void aomhip_status_clear(void);
  * queue's per-launch dispatch latency).  Between capture_begin and capture_end every batched entry point called on `ctx` is recorded,
  * not run.  Rules: run the same sequence once BEFORE capturing it (work buffers grow on first use and an allocation cannot be captured);
  * no aomhip_ctx_sync / memcpy_d2h / rtcd-signature call inside a capture; the arguments (device pointers, frame indices, list lengths)
- * are frozen into the graph -- data may change between launches, addresses may not.  A graph is replayed on the context it was
+ * are frozen into the graph -- data may change between launches, addresses may not: that includes the context's internal work buffers,
+ * so a LATER call on the same context that needs more work memory than any before it (a bigger frame, a longer list) invalidates the
+ * context's graphs -- aomhip_graph_launch then returns AOMHIP_ERR_INVALID and the sequence must be captured again.  A graph is replayed on the context it was
  * captured on, stream-ordered with the calls around it.  A capture that fails (capture_end returns an error) leaves that context's
  * stream in HIP's 'capture invalidated' state: destroy the context and create a new one.  Measured (bench.py inner loop, 4K 10-bit,
  * eight launches of 7-250 us per frame): 1 773 vs 1 762 frames/s -- the gaps between dependent kernels are the GPU's, not the host's. */

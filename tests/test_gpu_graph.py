@@ -71,3 +71,44 @@ def test_a_capture_that_synchronises_is_refused(hip):
     assert (ctx2.from_device(e, (16,), np.int32) == 0x02020202).all()
     ctx2.free(e)
     ctx2.close()
+
+
+def test_a_graph_is_refused_after_the_contexts_work_memory_moved(hip):
+    """The composite entry points keep intermediates in the context's work memory, which is freed and reallocated when a later call needs
+    more: a graph captured before that froze the old address.  aomhip_graph_launch must refuse it (include/aomhip.h) instead of replaying
+    into freed memory; a graph captured afterwards works."""
+    capi = hip.capi
+    ctx = capi.Context(0)
+    W, H, B, bs, bd = 256, 128, 64, 16, 8
+    src, ref = hip.synth.shifted_smooth_pair(W, H, 4, bd, shift=(2, -3), frac8=(0, 0))
+    ps, pr = ctx.planes_alloc(W, H, B, bd, 1), ctx.planes_alloc(W, H, B, bd, 1)
+    ctx.planes_upload(ps, 0, src); ctx.planes_upload(pr, 0, ref)
+    gc, gr = W // bs, H // bs
+    n = gc * gr
+    blocks = np.zeros(n, capi.search_block_dtype)
+    blocks["bx"], blocks["by"] = (np.arange(n) % gc) * bs, (np.arange(n) // gc) * bs
+    ext = B - 8
+    blocks["col_min"], blocks["col_max"] = -(blocks["bx"] + ext), W - blocks["bx"] - bs + ext
+    blocks["row_min"], blocks["row_max"] = -(blocks["by"] + ext), H - blocks["by"] - bs + ext
+    big = np.tile(blocks, 16)                      # the same blocks 16 times over: 16 x the work memory
+    d_small, d_big = ctx.to_device(blocks), ctx.to_device(big)
+    outs = [ctx.malloc(big.size * 4) for _ in range(5)]
+    full = capi.SearchParams.make("NSTEP", 2, capi.MV_COST_L1_HDRES)
+    sub = capi.SubpelParams(capi.SUBPEL_TREES["pruned"], capi.MV_COST_NONE, 64, 2, 1, 0, 0)
+    me = lambda d, m: ctx.motion_estimation_batch(ps, pr, 0, bs, bs, full, sub, 0, d, m, *outs)
+    me(d_small, n); ctx.sync()
+    want = ctx.from_device(outs[0], (n, 2), np.int16).copy()
+    g = ctx.capture(lambda: me(d_small, n))
+    ctx.graph_launch(g); ctx.sync()                # valid: nothing moved yet
+    assert np.array_equal(ctx.from_device(outs[0], (n, 2), np.int16), want)
+    me(d_big, big.size); ctx.sync()                # grows the work memory: free + malloc
+    with pytest.raises(capi.AomHipError, match="capture again"):
+        ctx.graph_launch(g)
+    g2 = ctx.capture(lambda: me(d_small, n))       # captured on the grown buffers
+    ctx.memset(outs[0], 0, n * 4)
+    ctx.graph_launch(g2); ctx.sync()
+    assert np.array_equal(ctx.from_device(outs[0], (n, 2), np.int16), want)
+    other = capi.Context(0)
+    with pytest.raises(capi.AomHipError, match="another context"):
+        other.graph_launch(g2)
+    ctx.graph_destroy(g); ctx.graph_destroy(g2)
