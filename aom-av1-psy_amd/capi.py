@@ -190,6 +190,7 @@ _protos = {
     "aomhip_deblock_plane": (C.c_int, [_vp, _PP, _i, _vp, _i, _i, _i]),
     "aomhip_cdef_luma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "aomhip_cdef_chroma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i]),
+    "aomhip_strip_read_probe": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int64)]),
     "aomhip_fullpel_diamond_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_subpel_bilinear_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_mesh_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, C.POINTER(C.c_int), _i, _vp, _i, _vp, _vp]),
@@ -523,6 +524,12 @@ class Context:
                                          fb_stride, d_skip, damping, d_dir, d_var), "aomhip_cdef_luma_plane")
 
     # ---- motion search
+    def strip_read_probe(self, src, ref, first_frame, n_frames, x0, x1, sb_w, sb_h, rng):
+        """-> bytes requested (measurement support: the transport of sad_sb_batch alone)."""
+        b = C.c_int64(0)
+        check(lib.aomhip_strip_read_probe(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, x0, x1, sb_w, sb_h, rng, C.byref(b)), "aomhip_strip_read_probe")
+        return b.value
+
     def fullpel_diamond_batch(self, src, ref, frame, bw, bh, clamped, step_param, cost_type, d_blocks, n, d_mv, d_cost):
         check(lib.aomhip_fullpel_diamond_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, clamped, step_param,
                                                cost_type, d_blocks, n, d_mv, d_cost), "aomhip_fullpel_diamond_batch")

@@ -215,6 +215,13 @@ int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_
                         const int32_t *d_cand_bucket_offsets, int n_cands, int64_t cand_frame_stride,
                         uint32_t *d_out_cands);
 
+/* Measurement support (bench.py's roofline.ceiling_GBs): the memory walk of aomhip_sad_sb_batch with everything else removed -- 256
+ * persistent workgroups read the windows (sb_w + 2 * range reference pixels, sb_w source pixels per row, sb_h rows per step) of the
+ * strips of columns [x0, x1) of n_frames frame pairs into registers and discard them.  Computes nothing; *bytes_requested (may be NULL)
+ * = the bytes its loads ask for.  Its launch time is what the transport alone costs on this box. */
+int aomhip_strip_read_probe(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame, int n_frames,
+                            int x0, int x1, int sb_w, int sb_h, int range, int64_t *bytes_requested);
+
 /* ------------------------------------------------------------------ batched variance / sub-pixel variance */
 
 /* One evaluation: source block at (sx, sy), reference block at (rx, ry) [+ (xoff, yoff)/8 pel for the
