@@ -190,6 +190,8 @@ _protos = {
     "aomhip_deblock_plane": (C.c_int, [_vp, _PP, _i, _vp, _i, _i, _i]),
     "aomhip_cdef_luma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "aomhip_cdef_chroma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i]),
+    "aomhip_refining_search_8p_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "aomhip_obmc_full_pixel_search_batch": (C.c_int, [_vp, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_strip_read_probe": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int64)]),
     "aomhip_fullpel_diamond_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_subpel_bilinear_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
@@ -524,6 +526,18 @@ class Context:
                                          fb_stride, d_skip, damping, d_dir, d_var), "aomhip_cdef_luma_plane")
 
     # ---- motion search
+    def refining_search_8p_batch(self, src, ref, frame, bw, bh, cost_type, sad_per_bit, error_per_bit, d_blocks, n, d_second_pred, d_mask, invert_mask,
+                                 d_mv, d_sad, d_var, d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):
+        check(lib.aomhip_refining_search_8p_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, cost_type, sad_per_bit, error_per_bit, d_mvjcost,
+                                                  d_mvcost_row, d_mvcost_col, d_blocks, n, d_second_pred, d_mask, int(invert_mask), d_mv, d_sad, d_var),
+              "aomhip_refining_search_8p_batch")
+
+    def obmc_full_pixel_search_batch(self, ref, frame, bw, bh, method, step_param, fast, cost_type, sad_per_bit, error_per_bit, d_blocks, n, d_wsrc, d_mask,
+                                     d_mv, d_cost, d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):
+        check(lib.aomhip_obmc_full_pixel_search_batch(self.h, C.byref(ref), frame, bw, bh, method if isinstance(method, int) else SEARCH_METHODS.index(method),
+                                                      step_param, int(fast), cost_type, sad_per_bit, error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col,
+                                                      d_blocks, n, d_wsrc, d_mask, d_mv, d_cost), "aomhip_obmc_full_pixel_search_batch")
+
     def strip_read_probe(self, src, ref, first_frame, n_frames, x0, x1, sb_w, sb_h, rng):
         """-> bytes requested (measurement support: the transport of sad_sb_batch alone)."""
         b = C.c_int64(0)

@@ -34,6 +34,18 @@ AOMHIP_DECL_FPS(launch_fps_u8)
 AOMHIP_DECL_FPS(launch_fps_u16)
 #undef AOMHIP_DECL_FPS
 
+// The per-block record as scalars (every member wave-uniform; BlockScalars::of applies v_readfirstlane: the compiler packs pairs of the
+// record's 16-bit fields into v_pk_min / max_i16 -- VALU only -- and everything derived from a VGPR, the whole search state, then
+// follows it into the vector unit and under exec masks; mcomp.hip).
+struct BlockScalars {
+  int row_min, row_max, col_min, col_max, ref_row, ref_col, start_row, start_col;
+  static __device__ __forceinline__ BlockScalars of(const aomhip_search_block &b) {
+    return BlockScalars{ __builtin_amdgcn_readfirstlane((int)b.row_min), __builtin_amdgcn_readfirstlane((int)b.row_max),
+                         __builtin_amdgcn_readfirstlane((int)b.col_min), __builtin_amdgcn_readfirstlane((int)b.col_max),
+                         __builtin_amdgcn_readfirstlane((int)b.ref_row), __builtin_amdgcn_readfirstlane((int)b.ref_col),
+                         __builtin_amdgcn_readfirstlane((int)b.start_row), __builtin_amdgcn_readfirstlane((int)b.start_col) };
+  }
+};
 // shared by the first-pass composite (tf_search.hip) and its row-persistent kernel (fp_row.hip)
 const SiteTable *fps_device_sites(int device, int method);   // the per-(device, method) table in device memory; nullptr on failure
 SearchArgs fps_search_args(const aomhip_search_params *p, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,

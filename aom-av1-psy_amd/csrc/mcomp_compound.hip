@@ -1,0 +1,359 @@
+// The compound-reference and OBMC full-pel searches of the RD path (av1/encoder/mcomp.c), batched: one wavefront per block.
+//
+//   aomhip_refining_search_8p_batch      av1_refining_search_8p_c (:1621-1691) -- the 8-neighbour refinement of one MV of a compound against the
+//       predictor of the OTHER reference (get_mvpred_compound_sad, :710-731: vfp->sdaf, or vfp->msdf with a wedge / diff-weighted mask),
+//       with its 7 x 7 "already visited" grid -- then av1_get_mvpred_compound_var (:3679-3693: vfp->svaf / msvf at the full-pel MV + MV cost)
+//       at the result: the full-pel half of av1_joint_motion_search / av1_compound_single_motion_search
+//       (av1/encoder/motion_search_facade.c:496-870).
+//   aomhip_obmc_full_pixel_search_batch  av1_obmc_full_pixel_search (:2272-2285): obmc_full_pixel_diamond (:2236-2270) over
+//       obmc_diamond_search_sad (:2173-2234) with get_obmc_mvpred_var (:2110-2125), or -- fast_obmc_search -- obmc_refining_search_sad
+//       (:2127-2171); vfp->osdf / ovf on the weighted source and mask of calc_target_weighted_pred.
+//
+// These searches are short (<= 25 evaluations; an OBMC diamond ~100) and every evaluation needs a per-pixel blend before the difference, so
+// an evaluation is done by all 64 lanes pixel by pixel (no packed SAD applies) and the candidates of a round are taken in the reference's
+// order; comparisons are the reference's, literally (the OBMC diamond compares as `int`, the others as `unsigned`).
+#include <climits>
+
+#include "fullpel_search.h"
+
+namespace aomhip {
+namespace {
+
+struct CompoundArgs {
+  int bw, bh, bit_depth, cost_type, sad_per_bit, error_per_bit, invert_mask;
+  const int32_t *mvjcost, *mvcost0, *mvcost1;
+};
+
+__device__ __forceinline__ int64_t wsum(int64_t v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor((long long)v, m, 64);
+  return v;
+}
+__device__ __forceinline__ int mv_bits(const CompoundArgs &a, int dr, int dc) {
+  return a.mvjcost[(dc != 0) | ((dr != 0) << 1)] + a.mvcost0[dr] + a.mvcost1[dc];
+}
+__device__ __forceinline__ int sad_cost(const CompoundArgs &a, int frr, int frc, int row, int col) {   // mvsad_err_cost_ (:310-339)
+  const int dr = (row - frr) * 8, dc = (col - frc) * 8;
+  if (a.cost_type == kCostEntropy) return (int)(((unsigned)mv_bits(a, dr, dc) * (unsigned)a.sad_per_bit + 256u) >> 9);
+  const int lambda = a.cost_type == kCostL1Low ? 32 : a.cost_type == kCostL1Mid ? 15 : a.cost_type == kCostL1Hd ? 8 : 0;
+  return (lambda * (iabsm(dr) + iabsm(dc))) >> 3;
+}
+__device__ __forceinline__ int var_cost(const CompoundArgs &a, int ref_row, int ref_col, int mrow, int mcol) {   // mv_err_cost_ (:271-308)
+  const int dr = mrow - ref_row, dc = mcol - ref_col;
+  if (a.cost_type == kCostEntropy) return (int)(((int64_t)mv_bits(a, dr, dc) * a.error_per_bit + (1 << 13)) >> 14);
+  const int lambda = a.cost_type == kCostL1Low ? 2 : a.cost_type == kCostL1Hd ? 1 : 0;
+  return (lambda * (iabsm(dr) + iabsm(dc))) >> 3;
+}
+__device__ __forceinline__ uint32_t finish_var(int64_t s64, uint64_t q64, int n_px, int bit_depth) {   // variance.c:141-148 / :383-420
+  int32_t s;
+  uint32_t q;
+  if (bit_depth == 10) { q = (uint32_t)((q64 + 8) >> 4); s = (int32_t)((s64 + 2) >> 2); }
+  else if (bit_depth == 12) { q = (uint32_t)((q64 + 128) >> 8); s = (int32_t)((s64 + 8) >> 4); }
+  else { q = (uint32_t)q64; s = (int32_t)s64; }
+  const int64_t sq = ((int64_t)s * s) / n_px;
+  if (bit_depth == 8) return q - (uint32_t)sq;
+  const int64_t v = (int64_t)q - sq;
+  return v >= 0 ? (uint32_t)v : 0u;
+}
+
+// the compound predictor of one pixel: aom_comp_avg_pred (variance.c:306-319) / aom_comp_mask_pred (:773-791, AOM_BLEND_A64)
+__device__ __forceinline__ int blend_px(int f, int p, const uint8_t *mask, int t, int invert) {
+  if (!mask) return (p + f + 1) >> 1;
+  const int m = mask[t];
+  return invert ? (m * p + (64 - m) * f + 32) >> 6 : (m * f + (64 - m) * p + 32) >> 6;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks,
+                                                                 int n_blocks, CompoundArgs a, const T *__restrict__ second_pred,
+                                                                 const uint8_t *__restrict__ masks, int16_t *__restrict__ out_mv,
+                                                                 int32_t *__restrict__ out_sad, int32_t *__restrict__ out_var) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * 4 + wave;
+  if (bi >= n_blocks) return;
+  const BlockScalars bs = BlockScalars::of(blocks[bi]);
+  const int bx = __builtin_amdgcn_readfirstlane((int)blocks[bi].bx), by = __builtin_amdgcn_readfirstlane((int)blocks[bi].by);
+  const int W = a.bw, H = a.bh, n_px = W * H;
+  const T *sp = src.origin + (int64_t)frame * src.frame_stride + (int64_t)by * src.stride + bx;
+  const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)by * ref.stride + bx;
+  const T *pred = second_pred + (size_t)bi * n_px;
+  const uint8_t *mask = masks ? masks + (size_t)bi * n_px : nullptr;
+  const int shift = a.bit_depth == 10 ? 2 : a.bit_depth == 12 ? 4 : 0;   // the _bits10 / _bits12 vtable wrappers (encoder_utils.h)
+  const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
+  auto sad_at = [&](int row, int col) -> uint32_t {   // get_mvpred_compound_sad
+    const T *rp = rbase + (int64_t)row * ref.stride + col;
+    int64_t acc = 0;
+    for (int t = lane; t < n_px; t += 64) {
+      const int y = t / W, x = t - y * W;
+      const int v = blend_px((int)rp[(int64_t)y * ref.stride + x], (int)pred[t], mask, t, a.invert_mask);
+      acc += iabsm(v - (int)sp[(int64_t)y * src.stride + x]);
+    }
+    return (uint32_t)wsum(acc) >> shift;
+  };
+  constexpr int kRange = 3, kStride = 2 * kRange + 1;   // SEARCH_RANGE_8P, SEARCH_GRID_STRIDE_8P (mcomp_structs.h:26-29)
+  unsigned long long visited = 0;                       // the 49 cells of do_refine_search_grid
+  int grid_center = kRange * kStride + kRange;
+  int row = min(max(bs.start_row, bs.row_min), bs.row_max), col = min(max(bs.start_col, bs.col_min), bs.col_max);   // clamp_fullmv
+  uint32_t best_sad = sad_at(row, col) + (uint32_t)sad_cost(a, frr, frc, row, col);
+  visited |= 1ull << grid_center;
+  for (int i = 0; i < kRange; ++i) {
+    int best_site = -1;
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j) {
+      // neighbors[] (:1623-1632): (-1,0) (0,-1) (0,1) (1,0) (-1,-1) (1,-1) (-1,1) (1,1)
+      const int drow = j == 0 || j == 4 || j == 6 ? -1 : (j == 3 || j == 5 || j == 7 ? 1 : 0);
+      const int dcol = j == 1 || j == 4 || j == 5 ? -1 : (j == 2 || j == 6 || j == 7 ? 1 : 0);
+      const int gc = grid_center + drow * kStride + dcol;
+      if ((visited >> gc) & 1) continue;
+      visited |= 1ull << gc;
+      const int r = row + drow, c = col + dcol;
+      if (c < bs.col_min || c > bs.col_max || r < bs.row_min || r > bs.row_max) continue;
+      uint32_t sad = sad_at(r, c);
+      if (sad < best_sad) {
+        sad += (uint32_t)sad_cost(a, frr, frc, r, c);
+        if (sad < best_sad) {
+          best_sad = sad;
+          best_site = j;
+        }
+      }
+    }
+    if (best_site == -1) break;
+    const int j = best_site;
+    const int drow = j == 0 || j == 4 || j == 6 ? -1 : (j == 3 || j == 5 || j == 7 ? 1 : 0);
+    const int dcol = j == 1 || j == 4 || j == 5 ? -1 : (j == 2 || j == 6 || j == 7 ? 1 : 0);
+    row += drow; col += dcol;
+    grid_center += drow * kStride + dcol;
+  }
+  // av1_get_mvpred_compound_var: svaf / msvf at sub-pel offset (0, 0) -- the bilinear passes with offset 0 are the identity -- + mv_err_cost_
+  int var;
+  {
+    const T *rp = rbase + (int64_t)row * ref.stride + col;
+    int64_t s = 0, q = 0;
+    for (int t = lane; t < n_px; t += 64) {
+      const int y = t / W, x = t - y * W;
+      const int v = blend_px((int)rp[(int64_t)y * ref.stride + x], (int)pred[t], mask, t, a.invert_mask);
+      const int d = v - (int)sp[(int64_t)y * src.stride + x];
+      s += d;
+      q += (uint32_t)(d * d);
+    }
+    var = (int)finish_var(wsum(s), (uint64_t)wsum(q), n_px, a.bit_depth) + var_cost(a, bs.ref_row, bs.ref_col, row * 8, col * 8);
+  }
+  if (lane == 0) {
+    out_mv[2 * bi] = (int16_t)row; out_mv[2 * bi + 1] = (int16_t)col;
+    out_sad[bi] = (int32_t)best_sad;
+    out_var[bi] = var;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
+                                                                     CompoundArgs a, const SiteTable *__restrict__ sites, int step_param, int fast,
+                                                                     const int32_t *__restrict__ wsrc_all, const int32_t *__restrict__ omask_all,
+                                                                     int16_t *__restrict__ out_mv, int32_t *__restrict__ out_cost) {
+  __shared__ SiteTable S;
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(sites);
+    uint32_t *d = reinterpret_cast<uint32_t *>(&S);
+    for (int i = threadIdx.x; i < (int)(sizeof(SiteTable) / 4); i += 256) d[i] = g[i];
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * 4 + wave;
+  if (bi >= n_blocks) return;
+  const BlockScalars bs = BlockScalars::of(blocks[bi]);
+  const int bx = __builtin_amdgcn_readfirstlane((int)blocks[bi].bx), by = __builtin_amdgcn_readfirstlane((int)blocks[bi].by);
+  const int W = a.bw, H = a.bh, n_px = W * H;
+  const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)by * ref.stride + bx;
+  const int32_t *wsrc = wsrc_all + (size_t)bi * n_px, *omask = omask_all + (size_t)bi * n_px;
+  const int shift = a.bit_depth == 10 ? 2 : a.bit_depth == 12 ? 4 : 0;
+  const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
+  auto osad_at = [&](int row, int col) -> uint32_t {   // vfp->osdf: obmc_sad (sad_av1.c:163-180) + the bit-depth wrapper
+    const T *rp = rbase + (int64_t)row * ref.stride + col;
+    int64_t acc = 0;
+    for (int t = lane; t < n_px; t += 64) {
+      const int y = t / W, x = t - y * W;
+      const int v = wsrc[t] - (int)rp[(int64_t)y * ref.stride + x] * omask[t];
+      acc += (iabsm(v) + 2048) >> 12;   // ROUND_POWER_OF_TWO(abs(..), 12)
+    }
+    return (uint32_t)wsum(acc) >> shift;
+  };
+  auto ovar_at = [&](int row, int col) -> int {   // get_obmc_mvpred_var: vfp->ovf (variance.c:957-1000 / :1064-1192) + mv_err_cost_
+    const T *rp = rbase + (int64_t)row * ref.stride + col;
+    int64_t s = 0, q = 0;
+    for (int t = lane; t < n_px; t += 64) {
+      const int y = t / W, x = t - y * W;
+      const int v = wsrc[t] - (int)rp[(int64_t)y * ref.stride + x] * omask[t];
+      const int d = v < 0 ? -((-v + 2048) >> 12) : (v + 2048) >> 12;   // ROUND_POWER_OF_TWO_SIGNED(v, 12)
+      s += d;
+      q += (uint32_t)(d * d);
+    }
+    return (int)finish_var(wsum(s), (uint64_t)wsum(q), n_px, a.bit_depth) + var_cost(a, bs.ref_row, bs.ref_col, row * 8, col * 8);
+  };
+  auto in_range = [&](int r, int c) { return c >= bs.col_min && c <= bs.col_max && r >= bs.row_min && r <= bs.row_max; };
+  const int start_row = min(max(bs.start_row, bs.row_min), bs.row_max), start_col = min(max(bs.start_col, bs.col_min), bs.col_max);
+  int best_row, best_col, result;
+  if (!fast) {
+    auto diamond = [&](int search_step, int *num00, int *orow, int *ocol) -> int {   // obmc_diamond_search_sad
+      const int tot_steps = S.num_search_steps - search_step;
+      int row = start_row, col = start_col;
+      *num00 = 0;
+      int best_sad = (int)(osad_at(row, col) + (uint32_t)sad_cost(a, frr, frc, row, col));
+      for (int step = tot_steps - 1; step >= 0; --step) {
+        int best_site = 0;
+        const int nper = S.searches_per_step[step];
+        for (int idx = 1; idx <= nper; ++idx) {
+          const int r = row + S.mv[step][idx][0], c = col + S.mv[step][idx][1];
+          if (!in_range(r, c)) continue;
+          int sad = (int)osad_at(r, c);   // (`int sad < int best_sad`: this function compares signed, mcomp.c:2206-2215)
+          if (sad < best_sad) {
+            sad += sad_cost(a, frr, frc, r, c);
+            if (sad < best_sad) {
+              best_sad = sad;
+              best_site = idx;
+            }
+          }
+        }
+        if (best_site != 0) {
+          row += S.mv[step][best_site][0];
+          col += S.mv[step][best_site][1];
+        } else if (row == start_row && col == start_col) {   // best_address == init_ref
+          (*num00)++;
+        }
+      }
+      *orow = row; *ocol = col;
+      return best_sad;
+    };
+    int n, num00 = 0, tr, tc;   // obmc_full_pixel_diamond
+    int bestsme = diamond(step_param, &n, &tr, &tc);
+    if (bestsme < INT_MAX) bestsme = ovar_at(tr, tc);
+    best_row = tr; best_col = tc;
+    const int further_steps = S.num_search_steps - 1 - step_param;
+    while (n < further_steps) {
+      ++n;
+      if (num00) {
+        num00--;
+      } else {
+        int thissme = diamond(step_param + n, &num00, &tr, &tc);
+        if (thissme < INT_MAX) thissme = ovar_at(tr, tc);
+        if (thissme < bestsme) {
+          bestsme = thissme;
+          best_row = tr; best_col = tc;
+        }
+      }
+    }
+    result = bestsme;
+  } else {   // obmc_refining_search_sad from the clamped start MV
+    int row = start_row, col = start_col;
+    uint32_t best_sad = osad_at(row, col) + (uint32_t)sad_cost(a, frr, frc, row, col);
+    for (int i = 0; i < 8; ++i) {
+      int best_site = -1;
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) {   // neighbors[4] = (-1,0) (0,-1) (0,1) (1,0)
+        const int r = row + (j == 0 ? -1 : j == 3 ? 1 : 0), c = col + (j == 1 ? -1 : j == 2 ? 1 : 0);
+        if (!in_range(r, c)) continue;
+        uint32_t sad = osad_at(r, c);
+        if (sad < best_sad) {
+          sad += (uint32_t)sad_cost(a, frr, frc, r, c);
+          if (sad < best_sad) {
+            best_sad = sad;
+            best_site = j;
+          }
+        }
+      }
+      if (best_site == -1) break;
+      row += best_site == 0 ? -1 : best_site == 3 ? 1 : 0;
+      col += best_site == 1 ? -1 : best_site == 2 ? 1 : 0;
+    }
+    best_row = row; best_col = col;
+    result = (int)best_sad;
+    if (result < INT_MAX) result = ovar_at(row, col);
+  }
+  if (lane == 0) {
+    out_mv[2 * bi] = (int16_t)best_row; out_mv[2 * bi + 1] = (int16_t)best_col;
+    out_cost[bi] = result;
+  }
+}
+
+int check_compound(aomhip_ctx *ctx, const aomhip_planes *ref, int frame, int bw, int bh, const void *blocks, int n, int cost_type, const int32_t *j,
+                   const int32_t *c0, const int32_t *c1, const char *who) {
+  if (!ctx || !ref || !ref->base || n < 0 || (n > 0 && !blocks) || frame < 0 || frame >= ref->n_frames || !valid_block(bw, bh) || cost_type < 0 ||
+      cost_type > kCostNone) {
+    set_error("%s: invalid argument", who);
+    return AOMHIP_ERR_INVALID;
+  }
+  if (cost_type == kCostEntropy && (!j || !c0 || !c1)) {
+    set_error("%s: MV_COST_ENTROPY needs the three cost tables", who);
+    return AOMHIP_ERR_INVALID;
+  }
+  return AOMHIP_OK;
+}
+
+}  // namespace
+}  // namespace aomhip
+
+using namespace aomhip;
+
+extern "C" {
+
+int aomhip_refining_search_8p_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh, int mv_cost_type,
+                                    int sad_per_bit, int error_per_bit, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                    const aomhip_search_block *d_blocks, int n_blocks, const void *d_second_pred, const uint8_t *d_mask, int invert_mask,
+                                    int16_t *d_best_mv, int32_t *d_best_sad, int32_t *d_best_var) {
+  int rc = check_compound(ctx, ref, frame, bw, bh, d_blocks, n_blocks, mv_cost_type, d_mvjcost, d_mvcost_row, d_mvcost_col, "aomhip_refining_search_8p_batch");
+  if (rc != AOMHIP_OK) return rc;
+  if (!src || !src->base || frame >= src->n_frames || (src->bit_depth == 8) != (ref->bit_depth == 8) || !d_second_pred || !d_best_mv || !d_best_sad ||
+      !d_best_var) {
+    set_error("aomhip_refining_search_8p_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  const CompoundArgs a{ bw, bh, src->bit_depth, mv_cost_type, sad_per_bit, error_per_bit, invert_mask != 0, d_mvjcost, d_mvcost_row, d_mvcost_col };
+  const dim3 grid((n_blocks + 3) / 4), block(256);
+  if (src->bit_depth == 8)
+    hipLaunchKernelGGL(refining_search_8p_kernel<uint8_t>, grid, block, 0, ctx->stream, view_of<uint8_t>(*src), view_of<uint8_t>(*ref), frame, d_blocks, n_blocks,
+                       a, static_cast<const uint8_t *>(d_second_pred), d_mask, d_best_mv, d_best_sad, d_best_var);
+  else
+    hipLaunchKernelGGL(refining_search_8p_kernel<uint16_t>, grid, block, 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame, d_blocks,
+                       n_blocks, a, static_cast<const uint16_t *>(d_second_pred), d_mask, d_best_mv, d_best_sad, d_best_var);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+int aomhip_obmc_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int frame, int bw, int bh, int search_method, int step_param,
+                                        int fast_obmc_search, int mv_cost_type, int sad_per_bit, int error_per_bit, const int32_t *d_mvjcost,
+                                        const int32_t *d_mvcost_row, const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, int n_blocks,
+                                        const int32_t *d_wsrc, const int32_t *d_obmc_mask, int16_t *d_best_mv, int32_t *d_best_cost) {
+  int rc = check_compound(ctx, ref, frame, bw, bh, d_blocks, n_blocks, mv_cost_type, d_mvjcost, d_mvcost_row, d_mvcost_col, "aomhip_obmc_full_pixel_search_batch");
+  if (rc != AOMHIP_OK) return rc;
+  if (search_method < 0 || search_method >= kMethods || step_param < 0 || !d_wsrc || !d_obmc_mask || !d_best_mv || !d_best_cost) {
+    set_error("aomhip_obmc_full_pixel_search_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  const SiteTable *d_sites = fps_device_sites(ctx->device, search_method);
+  if (!d_sites) {
+    set_error("aomhip_obmc_full_pixel_search_batch: could not place the site table on device %d", ctx->device);
+    return AOMHIP_ERR_HIP;
+  }
+  {
+    int ns = 0, per[22], rad[22];
+    int16_t mv[22][17][2];
+    (void)aomhip_search_sites(search_method, &ns, per, rad, mv);
+    if (!fast_obmc_search && step_param >= ns) {
+      set_error("aomhip_obmc_full_pixel_search_batch: step_param %d >= %d search steps", step_param, ns);
+      return AOMHIP_ERR_INVALID;
+    }
+  }
+  const CompoundArgs a{ bw, bh, ref->bit_depth, mv_cost_type, sad_per_bit, error_per_bit, 0, d_mvjcost, d_mvcost_row, d_mvcost_col };
+  const dim3 grid((n_blocks + 3) / 4), block(256);
+  if (ref->bit_depth == 8)
+    hipLaunchKernelGGL(obmc_full_pixel_search_kernel<uint8_t>, grid, block, 0, ctx->stream, view_of<uint8_t>(*ref), frame, d_blocks, n_blocks, a, d_sites,
+                       step_param, fast_obmc_search != 0, d_wsrc, d_obmc_mask, d_best_mv, d_best_cost);
+  else
+    hipLaunchKernelGGL(obmc_full_pixel_search_kernel<uint16_t>, grid, block, 0, ctx->stream, view_of<uint16_t>(*ref), frame, d_blocks, n_blocks, a, d_sites,
+                       step_param, fast_obmc_search != 0, d_wsrc, d_obmc_mask, d_best_mv, d_best_cost);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+}  // extern "C"

@@ -610,6 +610,32 @@ int aomhip_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
                                    const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv,
                                    int32_t *d_best_cost, int32_t *d_cost_list, int16_t *d_second_best_mv);
 
+/* ---- the compound-reference and OBMC full-pel searches of the RD path (csrc/mcomp_compound.hip)
+ *
+ * av1_refining_search_8p_c (av1/encoder/mcomp.c:1621-1691) for every block, then av1_get_mvpred_compound_var (:3679-3693) at the MV it
+ * returns: the full-pel half of one iteration of av1_joint_motion_search / of av1_compound_single_motion_search
+ * (av1/encoder/motion_search_facade.c:496-870) -- the 8-neighbour refinement of ONE MV of a compound against the predictor of the other
+ * reference.  Per block i:
+ *   d_second_pred   bw x bh pixels (the planes' pixel type), contiguous, block i at element i * bw * bh: what av1_enc_build_one_inter_predictor
+ *                   produced for the other reference (aomhip_build_inter_pred_batch writes exactly this layout when given a bw-wide plane)
+ *   d_mask          bw x bh blend weights 0..64 (stride bw), block i at i * bw * bh, or NULL: with a mask the SAD is vfp->msdf and the variance
+ *                   vfp->msvf (invert_mask as av1_set_ms_compound_refs passes it: the searched reference is the mask's second operand),
+ *                   without one vfp->sdaf / svaf (get_mvpred_compound_sad, mcomp.c:710-731)
+ *   blocks          start_* = the start MV (full-pel), ref_* = ref_mv (1/8 pel), limits = FullMvLimits
+ * Outputs: d_best_mv (row, col), d_best_sad (the function's return value: sad + MV cost), d_best_var (av1_get_mvpred_compound_var). */
+int aomhip_refining_search_8p_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh, int mv_cost_type,
+                                    int sad_per_bit, int error_per_bit, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                    const aomhip_search_block *d_blocks, int n_blocks, const void *d_second_pred, const uint8_t *d_mask, int invert_mask,
+                                    int16_t *d_best_mv, int32_t *d_best_sad, int32_t *d_best_var);
+/* av1_obmc_full_pixel_search (mcomp.c:2272-2285) for every block: obmc_full_pixel_diamond (:2236-2270; the site table of search_method from
+ * step_param, restarts, get_obmc_mvpred_var) or, with fast_obmc_search, obmc_refining_search_sad (:2127-2171) from the clamped start MV.
+ *   d_wsrc / d_obmc_mask   bw x bh int32 each, block i at i * bw * bh: calc_target_weighted_pred's weighted source and mask (x->obmc_buffer)
+ * Outputs: d_best_mv (row, col), d_best_cost (the returned variance + MV cost). */
+int aomhip_obmc_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int frame, int bw, int bh, int search_method, int step_param,
+                                        int fast_obmc_search, int mv_cost_type, int sad_per_bit, int error_per_bit, const int32_t *d_mvjcost,
+                                        const int32_t *d_mvcost_row, const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, int n_blocks,
+                                        const int32_t *d_wsrc, const int32_t *d_obmc_mask, int16_t *d_best_mv, int32_t *d_best_cost);
+
 /* The site table av1_init_motion_compensation[search_method_lookup[method]] builds (mcomp.c:350-634), without the
  * stride-dependent offsets: sites[stage][index] = {row, col}; index 0 is the centre for the diamond / n-step tables,
  * a candidate for the pattern tables.  Host only (for tests and for callers that want the table). */

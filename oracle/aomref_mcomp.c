@@ -1088,3 +1088,226 @@ void orc_subpel_tree_batch(const void *src_origin, int src_stride, const void *r
                              mvcost0, mvcost1, iters_per_step, allow_hp, forced_stop, blocks, cost_lists, n, out_mv, out_err, out_distortion, out_sse,
                              threads, NULL);
 }
+
+/* =====================================================================================================================
+ * Compound-reference and OBMC full-pel searches (the last search call sites of the RD path).
+ *   av1_refining_search_8p_c        av1/encoder/mcomp.c:1621-1691  (+ get_mvpred_compound_sad :710-731)
+ *   av1_get_mvpred_compound_var     :3679-3693 (get_mvpred_av_var :3650-3663, get_mvpred_mask_var :3665-3677)
+ *   obmc_refining_search_sad        :2127-2171     obmc_diamond_search_sad :2173-2234     obmc_full_pixel_diamond :2236-2270
+ *   av1_obmc_full_pixel_search      :2272-2285     get_obmc_mvpred_var :2110-2125
+ * PINNED by interpreting those functions themselves: tests/golden/ref_eval_compound_search.npz
+ * (generator tests/golden/gen_ref_eval_compound_search.py), checked in tests/test_golden_compound_search.py.
+ * second_pred: the W x H predictor of the OTHER reference, contiguous (stride W); mask: W x H blend weights 0..64 (stride W) or NULL.
+ * ===================================================================================================================== */
+typedef struct {
+  search_ctx c;
+  const void *second_pred;
+  const uint8_t *mask;
+  int invert_mask;
+} compound_ctx;
+
+static unsigned compound_sad_at(const compound_ctx *cc, int row, int col) { /* get_mvpred_compound_sad: msdf / sdaf */
+  const search_ctx *c = &cc->c;
+  const size_t es = c->elem16 ? 2 : 1;
+  const void *rp = (const char *)c->ref + ((ptrdiff_t)row * c->ref_stride + col) * (ptrdiff_t)es;
+  if (cc->mask)
+    return orc_masked_sad(c->src, c->src_stride, rp, c->ref_stride, cc->second_pred, cc->mask, c->w, cc->invert_mask, c->w, c->h, c->elem16, c->bd);
+  return orc_sad_avg_any(c->src, c->src_stride, rp, c->ref_stride, cc->second_pred, c->w, c->h, c->elem16, c->bd, 0, 0);
+}
+static int compound_var_at(const compound_ctx *cc, int row, int col) { /* av1_get_mvpred_compound_var: msvf / svaf at offset 0, + mv_err_cost_ */
+  const search_ctx *c = &cc->c;
+  const size_t es = c->elem16 ? 2 : 1;
+  const void *rp = (const char *)c->ref + ((ptrdiff_t)row * c->ref_stride + col) * (ptrdiff_t)es;
+  uint32_t sse;
+  const uint32_t v = orc_compound_sub_pixel_variance(rp, c->ref_stride, 0, 0, c->src, c->src_stride, c->w, c->h, c->elem16, c->bd, cc->mask ? 2 : 0,
+                                                     cc->second_pred, 0, 0, cc->mask, c->w, cc->invert_mask, &sse);
+  return (int)v + mv_cost_var(c, row * 8, col * 8);
+}
+
+static int refining_search_8p(const compound_ctx *cc, const orc_search_block *b, int *best_row, int *best_col) {
+  static const int8_t nb[8][2] = { { -1, 0 }, { 0, -1 }, { 0, 1 }, { 1, 0 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
+  enum { RANGE = 3, STRIDE = 2 * RANGE + 1 }; /* SEARCH_RANGE_8P, SEARCH_GRID_STRIDE_8P (mcomp_structs.h:26-29) */
+  uint8_t visited[STRIDE * STRIDE] = { 0 };
+  int grid_center = RANGE * STRIDE + RANGE;
+  int row = b->start_row, col = b->start_col;
+  row = row < b->row_min ? b->row_min : row > b->row_max ? b->row_max : row; /* clamp_fullmv */
+  col = col < b->col_min ? b->col_min : col > b->col_max ? b->col_max : col;
+  unsigned best_sad = compound_sad_at(cc, row, col) + (unsigned)mvsad_cost(&cc->c, row, col);
+  visited[grid_center] = 1;
+  for (int i = 0; i < RANGE; ++i) {
+    int best_site = -1;
+    for (int j = 0; j < 8; ++j) {
+      const int gc = grid_center + nb[j][0] * STRIDE + nb[j][1];
+      if (visited[gc]) continue;
+      const int r = row + nb[j][0], c = col + nb[j][1];
+      visited[gc] = 1;
+      if (c < b->col_min || c > b->col_max || r < b->row_min || r > b->row_max) continue;
+      unsigned sad = compound_sad_at(cc, r, c);
+      if (sad < best_sad) {
+        sad += (unsigned)mvsad_cost(&cc->c, r, c);
+        if (sad < best_sad) {
+          best_sad = sad;
+          best_site = j;
+        }
+      }
+    }
+    if (best_site == -1) break;
+    row += nb[best_site][0];
+    col += nb[best_site][1];
+    grid_center += nb[best_site][0] * STRIDE + nb[best_site][1];
+  }
+  *best_row = row;
+  *best_col = col;
+  return (int)best_sad;
+}
+
+/* blocks[n]; second_pred: n x (w*h) pixels; mask: n x (w*h) bytes or NULL.  Outputs: best_mv[n][2], best_sad[n] (the return value of
+ * av1_refining_search_8p_c), best_var[n] (av1_get_mvpred_compound_var at best_mv). */
+void orc_refining_search_8p_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16, int bd, int w, int h,
+                                  const void *blocks_v, int n, int cost_type, int sad_per_bit, int error_per_bit, const int *mvjcost,
+                                  const int *mvcost0, const int *mvcost1, const void *second_pred, const uint8_t *mask, int invert_mask,
+                                  int16_t *best_mv, int32_t *best_sad, int32_t *best_var, int threads) {
+  const orc_search_block *blocks = (const orc_search_block *)blocks_v;
+  const size_t es = elem16 ? 2 : 1;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 8)
+  for (int i = 0; i < n; ++i) {
+    const orc_search_block *b = &blocks[i];
+    compound_ctx cc;
+    memset(&cc, 0, sizeof(cc));
+    cc.c.src = (const char *)src_origin + ((ptrdiff_t)b->by * src_stride + b->bx) * (ptrdiff_t)es;
+    cc.c.ref = (const char *)ref_origin + ((ptrdiff_t)b->by * ref_stride + b->bx) * (ptrdiff_t)es;
+    cc.c.src_stride = src_stride; cc.c.ref_stride = ref_stride; cc.c.elem16 = elem16; cc.c.bd = bd; cc.c.w = w; cc.c.h = h;
+    cc.c.cost_type = cost_type; cc.c.ref_row = b->ref_row; cc.c.ref_col = b->ref_col;
+    cc.c.mvjcost = mvjcost; cc.c.mvcost[0] = mvcost0; cc.c.mvcost[1] = mvcost1; cc.c.sad_per_bit = sad_per_bit; cc.c.error_per_bit = error_per_bit;
+    cc.second_pred = (const char *)second_pred + (size_t)i * w * h * es;
+    cc.mask = mask ? mask + (size_t)i * w * h : NULL;
+    cc.invert_mask = invert_mask;
+    int r, c;
+    best_sad[i] = refining_search_8p(&cc, b, &r, &c);
+    best_mv[2 * i] = (int16_t)r; best_mv[2 * i + 1] = (int16_t)c;
+    best_var[i] = compound_var_at(&cc, r, c);
+  }
+}
+
+typedef struct {
+  search_ctx c; /* (src unused) */
+  const int32_t *wsrc, *omask;
+} obmc_ctx;
+static unsigned obmc_sad_at(const obmc_ctx *oc, int row, int col) { /* vfp->osdf */
+  const search_ctx *c = &oc->c;
+  const void *rp = (const char *)c->ref + ((ptrdiff_t)row * c->ref_stride + col) * (ptrdiff_t)(c->elem16 ? 2 : 1);
+  return orc_obmc_sad(rp, c->ref_stride, oc->wsrc, oc->omask, c->w, c->h, c->elem16, c->bd);
+}
+static int obmc_var_at(const obmc_ctx *oc, int row, int col) { /* get_obmc_mvpred_var */
+  const search_ctx *c = &oc->c;
+  const void *rp = (const char *)c->ref + ((ptrdiff_t)row * c->ref_stride + col) * (ptrdiff_t)(c->elem16 ? 2 : 1);
+  uint32_t sse;
+  return (int)orc_obmc_variance(rp, c->ref_stride, 0, 0, 0, oc->wsrc, oc->omask, c->w, c->h, c->elem16, c->bd, &sse) + mv_cost_var(c, row * 8, col * 8);
+}
+static int obmc_diamond(const obmc_ctx *oc, const orc_search_block *b, const orc_sites *s, int search_step, int *num00, int *best_row, int *best_col) {
+  const int tot_steps = s->num_search_steps - search_step;
+  int row = b->start_row, col = b->start_col;
+  row = row < b->row_min ? b->row_min : row > b->row_max ? b->row_max : row;
+  col = col < b->col_min ? b->col_min : col > b->col_max ? b->col_max : col;
+  const int init_row = row, init_col = col;
+  *num00 = 0;
+  int best_sad = (int)(obmc_sad_at(oc, row, col) + (unsigned)mvsad_cost(&oc->c, row, col));
+  for (int step = tot_steps - 1; step >= 0; --step) {
+    int best_site = 0;
+    for (int idx = 1; idx <= s->searches_per_step[step]; ++idx) {
+      const int r = row + s->mv[step][idx][0], c = col + s->mv[step][idx][1];
+      if (c < b->col_min || c > b->col_max || r < b->row_min || r > b->row_max) continue;
+      int sad = (int)obmc_sad_at(oc, r, c); /* `int sad`, `int best_sad`: signed comparisons in this function (mcomp.c:2206-2215) */
+      if (sad < best_sad) {
+        sad += mvsad_cost(&oc->c, r, c);
+        if (sad < best_sad) {
+          best_sad = sad;
+          best_site = idx;
+        }
+      }
+    }
+    if (best_site != 0) {
+      row += s->mv[step][best_site][0];
+      col += s->mv[step][best_site][1];
+    } else if (row == init_row && col == init_col) { /* best_address == init_ref */
+      (*num00)++;
+    }
+  }
+  *best_row = row;
+  *best_col = col;
+  return best_sad;
+}
+static int obmc_full_pixel_search(const obmc_ctx *oc, const orc_search_block *b, const orc_sites *s, int step_param, int fast, int *best_row, int *best_col) {
+  if (!fast) { /* obmc_full_pixel_diamond */
+    int n, num00 = 0, tr, tc;
+    int bestsme = obmc_diamond(oc, b, s, step_param, &n, &tr, &tc);
+    if (bestsme < INT_MAX) bestsme = obmc_var_at(oc, tr, tc);
+    *best_row = tr; *best_col = tc;
+    const int further_steps = s->num_search_steps - 1 - step_param;
+    while (n < further_steps) {
+      ++n;
+      if (num00) {
+        num00--;
+      } else {
+        int thissme = obmc_diamond(oc, b, s, step_param + n, &num00, &tr, &tc);
+        if (thissme < INT_MAX) thissme = obmc_var_at(oc, tr, tc);
+        if (thissme < bestsme) {
+          bestsme = thissme;
+          *best_row = tr; *best_col = tc;
+        }
+      }
+    }
+    return bestsme;
+  }
+  /* obmc_refining_search_sad from the clamped start */
+  static const int8_t nb[4][2] = { { -1, 0 }, { 0, -1 }, { 0, 1 }, { 1, 0 } };
+  int row = b->start_row, col = b->start_col;
+  row = row < b->row_min ? b->row_min : row > b->row_max ? b->row_max : row;
+  col = col < b->col_min ? b->col_min : col > b->col_max ? b->col_max : col;
+  unsigned best_sad = obmc_sad_at(oc, row, col) + (unsigned)mvsad_cost(&oc->c, row, col);
+  for (int i = 0; i < 8; ++i) {
+    int best_site = -1;
+    for (int j = 0; j < 4; ++j) {
+      const int r = row + nb[j][0], c = col + nb[j][1];
+      if (c < b->col_min || c > b->col_max || r < b->row_min || r > b->row_max) continue;
+      unsigned sad = obmc_sad_at(oc, r, c);
+      if (sad < best_sad) {
+        sad += (unsigned)mvsad_cost(&oc->c, r, c);
+        if (sad < best_sad) {
+          best_sad = sad;
+          best_site = j;
+        }
+      }
+    }
+    if (best_site == -1) break;
+    row += nb[best_site][0];
+    col += nb[best_site][1];
+  }
+  *best_row = row; *best_col = col;
+  int thissme = (int)best_sad;
+  if (thissme < INT_MAX) thissme = obmc_var_at(oc, row, col);
+  return thissme;
+}
+/* wsrc / obmc_mask: n x (w*h) int32 (calc_target_weighted_pred's outputs).  Outputs: best_mv[n][2], best_cost[n] (the return value). */
+void orc_obmc_full_pixel_search_batch(const void *ref_origin, int ref_stride, int elem16, int bd, int w, int h, const void *blocks_v, int n, int method,
+                                      int step_param, int fast_obmc_search, int cost_type, int sad_per_bit, int error_per_bit, const int *mvjcost,
+                                      const int *mvcost0, const int *mvcost1, const int32_t *wsrc, const int32_t *omask, int16_t *best_mv,
+                                      int32_t *best_cost, int threads) {
+  const orc_search_block *blocks = (const orc_search_block *)blocks_v;
+  orc_sites sites;
+  orc_init_search_sites(method, &sites);
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 8)
+  for (int i = 0; i < n; ++i) {
+    const orc_search_block *b = &blocks[i];
+    obmc_ctx oc;
+    memset(&oc, 0, sizeof(oc));
+    oc.c.ref = (const char *)ref_origin + ((ptrdiff_t)b->by * ref_stride + b->bx) * (ptrdiff_t)(elem16 ? 2 : 1);
+    oc.c.ref_stride = ref_stride; oc.c.elem16 = elem16; oc.c.bd = bd; oc.c.w = w; oc.c.h = h;
+    oc.c.cost_type = cost_type; oc.c.ref_row = b->ref_row; oc.c.ref_col = b->ref_col;
+    oc.c.mvjcost = mvjcost; oc.c.mvcost[0] = mvcost0; oc.c.mvcost[1] = mvcost1; oc.c.sad_per_bit = sad_per_bit; oc.c.error_per_bit = error_per_bit;
+    oc.wsrc = wsrc + (size_t)i * w * h; oc.omask = omask + (size_t)i * w * h;
+    int r, c;
+    best_cost[i] = obmc_full_pixel_search(&oc, b, &sites, step_param, fast_obmc_search, &r, &c);
+    best_mv[2 * i] = (int16_t)r; best_mv[2 * i + 1] = (int16_t)c;
+  }
+}

@@ -1195,3 +1195,51 @@ def simple_motion_search_batch(src_b, ref_b, border, width, height, w, h, blocks
         x, y = int(b["bx"]), int(b["by"])
         var[i], sse[i], _ = variance(np.ascontiguousarray(src_vis), y, x, pred, y, x, w, h, bd=bd)
     return mv, sse, var, pred
+
+
+def _cost_tables(mvjcost, mvcost0, mvcost1, keep):
+    def centre(t):
+        if t is None:
+            return None
+        t = np.ascontiguousarray(t, np.int32); keep.append(t)
+        return C.c_void_p(t.ctypes.data + (t.size // 2) * 4)
+    j = None
+    if mvjcost is not None:
+        jj = np.ascontiguousarray(mvjcost, np.int32); keep.append(jj); j = C.c_void_p(jj.ctypes.data)
+    return j, centre(mvcost0), centre(mvcost1)
+
+
+def refining_search_8p_batch(src_b, ref_b, border, w, h, blocks, second_pred, mask=None, invert_mask=0, cost_type=3, sad_per_bit=0, error_per_bit=0,
+                             mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4):
+    """av1_refining_search_8p_c + av1_get_mvpred_compound_var per block (oracle/aomref_mcomp.c).  second_pred [n, h, w] (plane dtype), mask
+    [n, h, w] uint8 or None.  -> mv [n, 2], sad [n], var [n]"""
+    blocks = np.ascontiguousarray(blocks)
+    n = len(blocks)
+    sp = np.ascontiguousarray(second_pred, src_b.dtype).reshape(n, h * w)
+    mk = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(n, h * w)
+    mv = np.zeros((n, 2), np.int16); sad = np.zeros(n, np.int32); var = np.zeros(n, np.int32)
+    keep = []
+    j, c0, c1 = _cost_tables(mvjcost, mvcost0, mvcost1, keep)
+    lib.orc_refining_search_8p_batch.restype = None
+    lib.orc_refining_search_8p_batch(C.c_void_p(_addr(src_b, border, border)), src_b.shape[1], C.c_void_p(_addr(ref_b, border, border)), ref_b.shape[1],
+                                     int(src_b.dtype != np.uint8), bd, w, h, C.c_void_p(blocks.ctypes.data), n, cost_type, sad_per_bit, error_per_bit, j, c0, c1,
+                                     C.c_void_p(sp.ctypes.data), None if mk is None else C.c_void_p(mk.ctypes.data), int(invert_mask),
+                                     C.c_void_p(mv.ctypes.data), C.c_void_p(sad.ctypes.data), C.c_void_p(var.ctypes.data), threads)
+    return mv, sad, var
+
+
+def obmc_full_pixel_search_batch(ref_b, border, w, h, blocks, wsrc, obmc_mask, method="NSTEP", step_param=0, fast_obmc_search=0, cost_type=3, sad_per_bit=0,
+                                 error_per_bit=0, mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4):
+    """av1_obmc_full_pixel_search per block.  wsrc / obmc_mask [n, h, w] int32.  -> mv [n, 2], cost [n]"""
+    blocks = np.ascontiguousarray(blocks)
+    n = len(blocks)
+    ws = np.ascontiguousarray(wsrc, np.int32).reshape(n, h * w); om = np.ascontiguousarray(obmc_mask, np.int32).reshape(n, h * w)
+    mv = np.zeros((n, 2), np.int16); cost = np.zeros(n, np.int32)
+    keep = []
+    j, c0, c1 = _cost_tables(mvjcost, mvcost0, mvcost1, keep)
+    lib.orc_obmc_full_pixel_search_batch.restype = None
+    lib.orc_obmc_full_pixel_search_batch(C.c_void_p(_addr(ref_b, border, border)), ref_b.shape[1], int(ref_b.dtype != np.uint8), bd, w, h,
+                                         C.c_void_p(blocks.ctypes.data), n, method if isinstance(method, int) else SEARCH_METHODS.index(method), step_param,
+                                         int(fast_obmc_search), cost_type, sad_per_bit, error_per_bit, j, c0, c1, C.c_void_p(ws.ctypes.data),
+                                         C.c_void_p(om.ctypes.data), C.c_void_p(mv.ctypes.data), C.c_void_p(cost.ctypes.data), threads)
+    return mv, cost

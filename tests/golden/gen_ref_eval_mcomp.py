@@ -37,7 +37,9 @@ BSIZE = {(4, 4): "BLOCK_4X4", (8, 8): "BLOCK_8X8", (16, 16): "BLOCK_16X16", (32,
          (32, 32): "BLOCK_32X32", (8, 16): "BLOCK_8X16"}
 
 
-def make_evaluator():
+def make_evaluator(with_compound=False):
+    """with_compound: also aom_dsp/blend.h (before the files that use AOM_BLEND_A64) and aom_dsp/sad_av1.c -- the masked / OBMC vtable
+    members of gen_ref_eval_compound_search.py; the default is what produced ref_eval_mcomp.npz."""
     ev = R.CEval({"CONFIG_AV1_HIGHBITDEPTH": 1, "CONFIG_REALTIME_ONLY": 0})
     for f in ["aom_ports/mem.h", "aom_ports/bitops.h", "aom_dsp/aom_dsp_common.h", "av1/common/enums.h", "aom_dsp/aom_filter.h",
               "av1/common/filter.h", "aom_dsp/variance.h", "av1/common/common_data.h"]:
@@ -47,9 +49,13 @@ def make_evaluator():
     for f in ["av1/common/mv.h"]:
         ev.load(REF + f)
     ev.define("MARK_MV_INVALID", "do { (mv)->row = INVALID_MV_ROW_COL; (mv)->col = INVALID_MV_ROW_COL; } while (0)", ["mv"])
-    for f in ["av1/common/entropymv.h", "aom_scale/yv12config.h", "av1/common/blockd.h", "av1/encoder/speed_features.h", "av1/encoder/cost.h", "av1/encoder/rd.h", "av1/encoder/encodemv.h", "av1/encoder/mcomp_structs.h", "av1/encoder/mcomp.h",
-              "av1/common/scale.h", "aom_dsp/sad.c", "aom_dsp/variance.c", "av1/encoder/encoder_utils.h", "aom_dsp/aom_convolve.c",
-              "av1/encoder/reconinter_enc.c", "av1/encoder/mcomp.c"]:
+    files = ["av1/common/entropymv.h", "aom_scale/yv12config.h", "av1/common/blockd.h", "av1/encoder/speed_features.h", "av1/encoder/cost.h", "av1/encoder/rd.h", "av1/encoder/encodemv.h", "av1/encoder/mcomp_structs.h", "av1/encoder/mcomp.h",
+             "av1/common/scale.h", "aom_dsp/sad.c", "aom_dsp/variance.c", "av1/encoder/encoder_utils.h", "aom_dsp/aom_convolve.c",
+             "av1/encoder/reconinter_enc.c", "av1/encoder/mcomp.c"]
+    if with_compound:
+        files.insert(files.index("aom_dsp/sad.c"), "aom_dsp/blend.h")
+        files.insert(files.index("aom_dsp/variance.c"), "aom_dsp/sad_av1.c")
+    for f in files:
         ev.load(REF + f)
     # aom_convolve8_* recover the kernel table and the phase from the kernel POINTER (get_filter_base masks the address
     # with ~0xFF, relying on the table's 256-byte alignment; get_filter_offset is a pointer difference in kernels).  In
