@@ -237,6 +237,8 @@ _protos = {
     "aomhip_tf_block_list": (C.c_int, [_i, _i, _i, _vp]),
     "aomhip_tf_motion_search_frames": (C.c_int, [_vp, _PP, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "aomhip_tile_column_bounds": (C.c_int, [_i, _i, _i, _vp]),
+    "aomhip_tile_column_bounds_balanced": (C.c_int, [_i, _i, _i, _i, _vp]),
+    "aomhip_tile_column_bounds_widths": (C.c_int, [_i, _i, _vp, _i, _i, _i, _vp]),
     "aomhip_recon_exchange_plan": (C.c_int, [_i, _i, _vp, _i, _i, _vp, _vp]),
     "aomhip_comm_unique_id": (C.c_int, [_vp]),
     "aomhip_deblock_plane_fused": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _i, _i]),
@@ -655,6 +657,22 @@ def tile_column_bounds(width, n_cols, sb_size=64):
     """[n_cols, 2] int32 pixel bounds of the uniform tile columns; (0, 0) for ranks beyond the last column."""
     b = np.zeros((n_cols, 2), np.int32)
     n = lib.aomhip_tile_column_bounds(width, n_cols, sb_size, b.ctypes.data)
+    return b, n
+
+
+def tile_column_bounds_balanced(width, n_cols, sb_size=64, max_width_sb=0):
+    """auto_tile_size_balancing's columns for n_cols = 2^k ranks: ([n_cols, 2] int32 pixel bounds, number of columns that exist)."""
+    k = int(n_cols).bit_length() - 1
+    assert 1 << k == n_cols, "auto_tile_size_balancing takes a power-of-two column count"
+    b = np.zeros((n_cols, 2), np.int32)
+    n = lib.aomhip_tile_column_bounds_balanced(width, k, sb_size, max_width_sb, b.ctypes.data)
+    return b, n
+
+
+def tile_column_bounds_widths(width, widths_sb, n_cols, sb_size=64, max_width_sb=0):
+    w = np.ascontiguousarray(widths_sb, np.int32)
+    b = np.zeros((n_cols, 2), np.int32)
+    n = lib.aomhip_tile_column_bounds_widths(width, sb_size, w.ctypes.data, len(w), max_width_sb, n_cols, b.ctypes.data)
     return b, n
 
 

@@ -61,6 +61,46 @@ int aomhip_tile_column_bounds(int width, int n_cols, int sb_size, int (*bounds)[
   return n;
 }
 
+int aomhip_tile_column_bounds_widths(int width, int sb_size, const int *tile_widths_sb, int n_widths, int max_width_sb, int n_cols, int (*bounds)[2]) {
+  // set_tile_info's explicit form (av1/encoder/encoder.c:303-312): the width list is walked cyclically, every width clipped to max_width_sb
+  if (width <= 0 || sb_size <= 0 || !tile_widths_sb || n_widths <= 0 || n_cols <= 0 || !bounds) return 0;
+  const int sb_cols = (width + sb_size - 1) / sb_size;
+  int n = 0, j = 0;
+  for (int s = 0; s < sb_cols && n < n_cols;) {
+    int size_sb = tile_widths_sb[j++];
+    if (j >= n_widths) j = 0;
+    if (max_width_sb > 0 && size_sb > max_width_sb) size_sb = max_width_sb;
+    if (size_sb <= 0) return 0;
+    bounds[n][0] = s * sb_size;
+    bounds[n][1] = (s + size_sb) * sb_size < width ? (s + size_sb) * sb_size : width;
+    s += size_sb;
+    ++n;
+    if (n == n_cols && s < sb_cols) bounds[n - 1][1] = width;   // (the reference closes the last tile at the frame edge: col_start_sb[cols] = sb_cols)
+  }
+  for (int i = n; i < n_cols; ++i) bounds[i][0] = bounds[i][1] = 0;
+  return n;
+}
+
+int aomhip_tile_column_bounds_balanced(int width, int log2_cols, int sb_size, int max_width_sb, int (*bounds)[2]) {
+  // auto_tile_size_balancing (av1/encoder/encoder.c:247-275; tile_widths[0] < 0): floor(sb_cols / 2^k) superblocks per column, the LAST
+  // (sb_cols mod 2^k) columns one wider -- every rank gets a column even where the uniform rule leaves the last one short or empty
+  if (width <= 0 || log2_cols < 0 || log2_cols > 6 || sb_size <= 0 || !bounds) return 0;
+  const int sb_cols = (width + sb_size - 1) / sb_size, n_cols = 1 << log2_cols;
+  int size_sb = sb_cols >> log2_cols;
+  const int res = sb_cols - (size_sb << log2_cols), inc_index = n_cols - res;
+  int n = 0;
+  for (int s = 0; s < sb_cols && n < n_cols; ++n) {
+    if (n == inc_index) ++size_sb;
+    const int w = max_width_sb > 0 && size_sb > max_width_sb ? max_width_sb : size_sb;
+    if (w <= 0) break;   // (fewer superblocks than columns: the leading zero-width columns do not exist in the reference either)
+    bounds[n][0] = s * sb_size;
+    bounds[n][1] = (s + w) * sb_size < width ? (s + w) * sb_size : width;
+    s += w;
+  }
+  for (int i = n; i < n_cols; ++i) bounds[i][0] = bounds[i][1] = 0;
+  return n;
+}
+
 int aomhip_recon_exchange_plan(int n_ranks, int rank, const int (*col_bounds)[2], int width, int halo, aomhip_exchange_item *send,
                                aomhip_exchange_item *recv) {
   if (n_ranks < 1 || rank < 0 || rank >= n_ranks || !col_bounds || !send || !recv) return AOMHIP_ERR_INVALID;

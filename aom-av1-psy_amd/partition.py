@@ -9,8 +9,25 @@ import numpy as np
 from .synth import tile_column_bounds
 
 
-def column_of_rank(width, world, rank, sb=64):
-    cols = tile_column_bounds(width, world, sb)
+def column_of_rank(width, world, rank, sb=64, mode="uniform"):
+    """Pixel bounds [x0, x1) of rank's tile column.  mode "uniform": av1_calculate_tile_cols' uniform spacing (tile_common.c:76-97);
+    "balanced": auto_tile_size_balancing (av1/encoder/encoder.c:247-275; world must be a power of two)."""
+    if mode == "balanced" and world & (world - 1) == 0:
+        sb_cols = (width + sb - 1) // sb
+        k = world.bit_length() - 1
+        size = sb_cols >> k
+        inc = world - (sb_cols - (size << k))
+        cols, s = [], 0
+        for i in range(world):
+            if s >= sb_cols:
+                break
+            if i == inc:
+                size += 1
+            if size > 0:
+                cols.append((s * sb, min((s + size) * sb, width)))
+            s += size
+    else:
+        cols = tile_column_bounds(width, world, sb)
     return cols[rank] if rank < len(cols) else (0, 0)
 
 

@@ -31,6 +31,7 @@ os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
 
 FRAMES_OVERRIDE = 0
+TILE_COLUMNS = "uniform"   # --tile-columns
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SAD16_BYTES_8BIT = 516  # src block + ref block + 4 B result
 
@@ -111,7 +112,7 @@ class SadModeA:
             for k in range(world):
                 ctx.planes_upload(self.src, f + k * self.F, s)
                 ctx.planes_upload(self.ref, f + k * self.F, r)
-        x0, x1 = pkg.partition.column_of_rank(W, world, rank)
+        x0, x1 = pkg.partition.column_of_rank(W, world, rank, mode=TILE_COLUMNS)
         cands, groups = synth.mode_a_worklist(W, H, 16, seed=seed)
         keep = (cands["sx"] >= x0) & (cands["sx"] < x1)
         self.blocks_per_frame = int(keep.sum())
@@ -137,7 +138,7 @@ class SadModeA:
         # r02 sweeps (profiles/r02_sad_strip.md): 60 blocks per step keep all eight evaluating wavefronts busy, two per SIMD, and the strips
         # per frame x 64 frames must be a whole number of items per CU: 8-bit 240 x 64 at 1080p (8 strips), 320 x 48 at 4K (12 strips, ~2 %
         # ahead of 240 x 64 there); 16-bit 160 x 32 (LDS)
-        col_w = pkg.partition.column_of_rank(W, world, 0)[1] - pkg.partition.column_of_rank(W, world, 0)[0]
+        col_w = pkg.partition.column_of_rank(W, world, 0, mode=TILE_COLUMNS)[1] - pkg.partition.column_of_rank(W, world, 0, mode=TILE_COLUMNS)[0]
         # (a rank's items = strips of its column x ring frames; the kernel's persistent grid is 256 workgroups: prefer the cell whose
         # item count is a multiple of that -- 320 x 48 on a whole 4K frame, 240 x 64 on a 1080p frame or a 1920 / 960-wide tile column)
         options = [(320, 48), (240, 64)] if bd == 8 else [(160, 32)]
@@ -413,7 +414,7 @@ class SearchPipeline:
         W, H, bd, border = self.W, self.H, self.BD, self.BORDER
         self.src = ctx.planes_alloc(W, H, border, bd, frames)
         self.ref = ctx.planes_alloc(W, H, border, bd, frames)
-        self.bounds, self.n_cols = capi.tile_column_bounds(W, world)  # idle ranks (fewer columns than ranks): (0, 0)
+        self.bounds, self.n_cols = (capi.tile_column_bounds_balanced if TILE_COLUMNS == "balanced" and world & (world - 1) == 0 else capi.tile_column_bounds)(W, world)  # idle ranks (fewer columns than ranks): (0, 0)
         x0, x1 = (int(v) for v in self.bounds[rank])
         self.halo = -1 if exchange == "allgather" else self.HALO
         self.comm = None
@@ -583,13 +584,18 @@ def run_search(pkg, ctx, dist, dev, rank, world, orc, steps, warmup, exchange="h
                               "halo_GBs_per_link": recv_halo / (ex_halo * 1e-3) / 1e9 / max(min(2, world - 1), 1) if ex_halo > 0 else None,
                               "transport": "aomhip_allgather_recon: pack kernels -> one ncclGroup of per-peer ncclSend / ncclRecv (uint8) -> "
                                            "unpack kernels -> border extension, all on the context's stream"},
-                 "tile_columns_px": widths, "blocks_max_rank_over_mean": max(widths) / (sum(widths) / world) if sum(widths) else None}
+                 "tile_columns_px": widths, "blocks_max_rank_over_mean": max(widths) / (sum(widths) / world) if sum(widths) else None,
+                 # the same frame under the other rule (the widest column is what the slowest rank searches)
+                 "tile_columns_px_uniform": [int(b_ - a_) for a_, b_ in pkg.capi.tile_column_bounds(wl.W, world)[0]],
+                 "tile_columns_px_balanced": ([int(b_ - a_) for a_, b_ in pkg.capi.tile_column_bounds_balanced(wl.W, world)[0]]
+                                              if world & (world - 1) == 0 else None)}
     return dict({"workload": "fullpel_diamond+subpel_bilinear_4k_10bit", "value": total * steps / wall, "unit": "blocks/s",
                  "frames_per_s": steps / wall, "ms_per_step": wall / steps * 1e3, "blocks_per_step": total,
                  "parity_sample_slot0": ok, "bound": search_bound(),
                  "config": {"frame": "3840x2160 10-bit", "block": "16x16", "search": "DIAMOND step_param 4, MV_COST_L1_HDRES; "
                             "sub-pel tree pruned_more, bilinear, 1/8 pel, iters 2",
-                            "partition": "uniform tile columns (tile_common.c:76-110), one per GPU",
+                            "partition": ("balanced tile columns (auto_tile_size_balancing, encoder.c:247-275)" if TILE_COLUMNS == "balanced" else
+                                          "uniform tile columns (tile_common.c:76-110)") + ", one per GPU",
                             "exchange": ("per frame, aomhip_allgather_recon (RCCL), " + exchange) if dist is not None else "none (1 GPU)"}}, **extra)
 
 
@@ -1230,6 +1236,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path); gloo only to dry-run the N > 1 code on one GPU")
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="override the ring size per GPU (0 = workload default)")
+    ap.add_argument("--tile-columns", default="uniform", choices=["uniform", "balanced"],
+                    help="N > 1: how the frame is cut into one tile column per GPU -- the reference's uniform spacing (tile_common.c:76-97) or its "
+                         "auto_tile_size_balancing (encoder.c:247-275: widths within one superblock of each other)")
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
                     help="N > 1 search pipeline: what aomhip_allgather_recon moves per frame (both are timed; this one is in `value`)")
     args = ap.parse_args()
@@ -1239,8 +1248,9 @@ def main():
         # GPU (it never does: it only waits).  Under torch.distributed.run WORLD_SIZE is set and this branch is not taken.
         sys.exit(spawn_ranks(args.gpus))
 
-    global FRAMES_OVERRIDE
+    global FRAMES_OVERRIDE, TILE_COLUMNS
     FRAMES_OVERRIDE = args.frames_per_gpu
+    TILE_COLUMNS = args.tile_columns
     dist, rank, world = dist_setup(args.gpus, args.dist_backend)
     default_multi = args.workload is None and dist is not None
     if args.workload is None:
@@ -1269,7 +1279,7 @@ def main():
         blk = {"metric": "search blocks/s", "value": r["value"], "unit": "blocks/s", "scaling": "strong", "ms_per_step": r["ms_per_step"],
                "frames_per_s": r["frames_per_s"], "parity_sample_slot0": r["parity_sample_slot0"], "config": dict(r["config"], workload=r["workload"]),
                "rccl_ranks_in_communicator": r.get("rccl_ranks_in_communicator")}
-        for k in ("exchange", "tile_columns_px", "blocks_max_rank_over_mean"):
+        for k in ("exchange", "tile_columns_px", "blocks_max_rank_over_mean", "tile_columns_px_uniform", "tile_columns_px_balanced"):
             blk[k] = r.get(k)
         if with_single:
             # the same box's 1-GPU figure of THIS metric (rank 0 alone, whole frame, no exchange), so the speed-up can be read off one line
@@ -1287,7 +1297,7 @@ def main():
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16",
                 "data": "synthetic", "config": dict(r["config"], workload=r["workload"]),
                 "frames_per_s": r["frames_per_s"], "parity_sample_slot0": r["parity_sample_slot0"]}
-        for k in ("exchange", "tile_columns_px", "blocks_max_rank_over_mean", "rccl_ranks_in_communicator"):
+        for k in ("exchange", "tile_columns_px", "blocks_max_rank_over_mean", "rccl_ranks_in_communicator", "tile_columns_px_uniform", "tile_columns_px_balanced"):
             if k in r:
                 line[k] = r[k]
         ctx.close()
@@ -1408,7 +1418,8 @@ def main():
                        "bit_depth": cfg["bit_depth"], "block": "16x16",
                        "mode": "A: 1 sad16x16 @mv(0,0) + 1 sad16x16x4d (uniform in [-64,64]^2) per block",
                        "ring_frame_pairs_per_gpu": FRAMES_OVERRIDE or cfg["frames"], "candidates_per_step": main_res["candidates_per_step"],
-                       "partition": "tile columns (tile_common.c:76-97), one per GPU; no data-path collective",
+                       "partition": ("balanced tile columns (encoder.c:247-275)" if TILE_COLUMNS == "balanced" else "uniform tile columns (tile_common.c:76-97)") +
+                                    ", one per GPU; no data-path collective",
                        "clock_ramp_s": float(os.environ.get("AOMHIP_BENCH_RAMP_S", "0.25"))},
             "roofline": main_res["roofline"],
             "cpu_baseline": main_res.get("cpu_baseline"),

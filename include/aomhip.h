@@ -1051,6 +1051,13 @@ unsigned int aomhip_highbd_sub_pixel_variance(const uint8_t *a8, int a_stride, i
  * [x0, x1) in pixels of column i; returns the number of columns that exist (ranks beyond it get (0, 0): with 1080p and
  * 8 ranks the columns are 4,4,4,4,4,4,4,2 superblocks wide -- the imbalance is the reference's rule). */
 int aomhip_tile_column_bounds(int width, int n_cols, int sb_size, int (*bounds)[2]);
+/* The two non-uniform forms of set_tile_info (av1/encoder/encoder.c:277-313).  _balanced = auto_tile_size_balancing (:247-275, chosen with
+ * tile_widths[0] < 0): floor(sb_cols / 2^log2_cols) superblocks per column, the last (sb_cols mod 2^log2_cols) columns one wider -- e.g. 4K
+ * on 8 ranks 7,7,7,7,8,8,8,8 superblocks instead of the uniform rule's 8 x 7 + 4: the widest column (what the slowest rank gets) is the
+ * same, no rank is short-changed.  _widths = an explicit list of widths in superblocks, walked cyclically, each clipped to max_width_sb (0:
+ * no clip), at most n_cols columns.  Both return the number of columns that exist and zero the rest. */
+int aomhip_tile_column_bounds_balanced(int width, int log2_cols, int sb_size, int max_width_sb, int (*bounds)[2]);
+int aomhip_tile_column_bounds_widths(int width, int sb_size, const int *tile_widths_sb, int n_widths, int max_width_sb, int n_cols, int (*bounds)[2]);
 
 /* Which pixel columns this rank sends to / receives from every peer when the reconstruction is exchanged (host only, no
  * GPU call): send[r] = the part of MY column rank r needs, recv[r] = the part of r's column I need; halo < 0: whole columns

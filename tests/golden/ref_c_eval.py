@@ -144,6 +144,13 @@ class Ptr:
             return v, t
         if t.__class__ is StructType:
             if vt is not t:
+                # the two arms of a union the evaluator models as ONE member (ALIASED_STRUCTS, set by the generator that needs it: int_mv's
+                # as_mv / as_fullmv, both { int16_t row; int16_t col }): the value is stored re-tagged, field for field
+                if vt.__class__ is StructType and frozenset((t.name, vt.name)) in ALIASED_STRUCTS and [f[0] for f in t.fields] == [f[0] for f in vt.fields]:
+                    c = copy_struct(v)
+                    c.st = t
+                    self.buf[self.off] = c
+                    return c, t
                 raise CError("struct type mismatch: %s <- %s" % (t, vt))
             self.buf[self.off] = copy_struct(v)
             return v, t
@@ -168,6 +175,9 @@ class StructType:
 
     def __repr__(self):
         return "struct " + self.name
+
+
+ALIASED_STRUCTS = set()   # frozenset({name_a, name_b}) of layout-identical struct types that stand for the arms of one union
 
 
 class StructVal:
@@ -1512,6 +1522,10 @@ class Interp:
                 return None, VOID
             if rt.__class__ is StructType:
                 return copy_struct(v), rt
+            if t.__class__ is T:   # `return cond ? ptr : NULL;` taking the NULL arm: an integer 0 converted to the pointer return type
+                if v != 0:
+                    raise CError("%s returns a non-zero integer as a pointer" % name)
+                v = None
             return v, PTR
         return None, VOID
 

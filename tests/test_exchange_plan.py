@@ -104,3 +104,53 @@ def test_plan_rejects_bad_arguments():
     s = np.zeros((2, 2), np.int32)
     assert capi.lib.aomhip_recon_exchange_plan(2, 2, b.ctypes.data, 640, -1, s.ctypes.data, s.ctypes.data) == capi.ERR_INVALID
     assert capi.lib.aomhip_recon_exchange_plan(0, 0, b.ctypes.data, 640, -1, s.ctypes.data, s.ctypes.data) == capi.ERR_INVALID
+
+
+def ref_balanced(width, log2_cols, sb=64, max_width_sb=1 << 30):
+    # auto_tile_size_balancing (av1/encoder/encoder.c:247-275), restated from the text: col_start_sb[] in superblocks
+    num_sbs = -(-width // sb)
+    size_sb = num_sbs >> log2_cols
+    res = num_sbs - (size_sb << log2_cols)
+    inc_index = (1 << log2_cols) - res
+    starts, s, i = [], 0, 0
+    while s < num_sbs and i < 64:
+        if i == inc_index:
+            size_sb += 1
+        starts.append(s)
+        s += min(size_sb, max_width_sb)
+        i += 1
+    starts.append(num_sbs)
+    return [(a * sb, min(b_ * sb, width)) for a, b_ in zip(starts[:-1], starts[1:])]
+
+
+@pytest.mark.parametrize("width,n", [(3840, 8), (3840, 4), (1920, 8), (1920, 4), (1920, 2), (4096, 8), (1280, 8), (3840, 1)])
+def test_balanced_tile_columns_follow_auto_tile_size_balancing(width, n):
+    b, cols = capi.tile_column_bounds_balanced(width, n)
+    want = ref_balanced(width, n.bit_length() - 1)
+    want = [w for w in want if w[1] > w[0]][:n]
+    assert cols == len(want) and [tuple(x) for x in b[:cols]] == want
+    assert b[0, 0] == 0 and b[cols - 1, 1] == width
+    widths = [int(x1 - x0) for x0, x1 in b[:cols]]
+    uni, ucols = capi.tile_column_bounds(width, n)
+    assert max(widths) <= max(int(x1 - x0) for x0, x1 in uni[:ucols])          # never a wider widest column than the uniform rule
+    assert max(widths) - min(widths) <= 64                                      # within one superblock of each other
+
+
+def test_4k_on_8_ranks_balanced_is_four_448_and_four_512_columns():
+    b, cols = capi.tile_column_bounds_balanced(3840, 8)
+    assert cols == 8 and [int(x1 - x0) for x0, x1 in b] == [448] * 4 + [512] * 4
+
+
+def test_explicit_tile_widths_cycle_and_clip_like_set_tile_info():
+    # encoder.c:303-312: widths walked cyclically, clipped to max_width_sb, the last column closed at the frame edge
+    b, cols = capi.tile_column_bounds_widths(3840, [20, 10], 8)                  # 60 superblocks: 20, 10, 20, 10
+    assert cols == 4 and [tuple(x) for x in b[:4]] == [(0, 1280), (1280, 1920), (1920, 3200), (3200, 3840)]
+    b, cols = capi.tile_column_bounds_widths(3840, [40], 8, max_width_sb=16)     # clipped to 16: 16, 16, 16, 12
+    assert cols == 4 and [int(x1 - x0) for x0, x1 in b[:4]] == [1024, 1024, 1024, 768]
+    b, cols = capi.tile_column_bounds_widths(1920, [4], 4)                       # 30 superblocks in 4 columns of 4: the 4th runs to the edge
+    assert cols == 4 and tuple(b[3]) == (768, 1920)
+    # the exchange plan works on any bounds
+    bal, n = capi.tile_column_bounds_balanced(3840, 8)
+    for r in range(8):
+        send, recv = capi.recon_exchange_plan(8, r, bal, 3840, 132)
+        assert (send[r] == 0).all()
