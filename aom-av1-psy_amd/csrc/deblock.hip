@@ -456,6 +456,19 @@ int aomhip_deblock_plane_fused(aomhip_ctx *ctx, const aomhip_planes *src, int sr
     return AOMHIP_ERR_INVALID;
   }
   const size_t esz = src->bit_depth == 8 ? 1 : 2;
+  // the kernel moves tile rows as 16-byte (16-bit planes) / 4-byte (8-bit) vectors: origins, strides and frame strides of both planes must
+  // keep that alignment (aomhip_planes_alloc does; a caller-built aomhip_planes may not)
+  {
+    const size_t al = esz == 2 ? 16 : 4;
+    auto aligned = [&](const aomhip_planes *q, int f) {
+      const uintptr_t o = reinterpret_cast<uintptr_t>(q->base) + ((size_t)f * q->frame_stride + (size_t)q->border * q->stride + q->border) * esz;
+      return o % al == 0 && ((size_t)q->stride * esz) % al == 0;
+    };
+    if (!aligned(src, src_frame) || !aligned(dst, dst_frame)) {
+      set_error("aomhip_deblock_plane_fused: plane origin / stride not %zu-byte aligned (use aomhip_deblock_plane for such planes)", al);
+      return AOMHIP_ERR_INVALID;
+    }
+  }
   const char *so = static_cast<const char *>(src->base) + ((size_t)src_frame * src->frame_stride + (size_t)src->border * src->stride + src->border) * esz;
   char *dor = static_cast<char *>(dst->base) + ((size_t)dst_frame * dst->frame_stride + (size_t)dst->border * dst->stride + dst->border) * esz;
   const dim3 grid((src->width + kFW - 1) / kFW, (src->height + kFH - 1) / kFH);

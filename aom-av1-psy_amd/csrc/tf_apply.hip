@@ -2,7 +2,9 @@
 // Reference (av1/encoder/temporal_filter.c), per 32x32 block and window frame in av1_tf_do_filtering_row's order (:849-905):
 //   tf_build_predictor (:331-392): the plane's four sub-blocks through av1_enc_build_one_inter_predictor with MULTITAP_SHARP2 --
 //       av1_[highbd_]convolve_2d_facade -> copy / x_sr / y_sr / 2d_sr with the 12-tap set (av1/common/convolve.c:76-174,495-515,
-//       569-668; get_conv_params rounding, convolve.h:63-100; position arithmetic init_subpel_params, reconinter.h:130-165),
+//       569-668; get_conv_params rounding, convolve.h:63-100; position arithmetic init_subpel_params, reconinter.h:130-165 -- WITHOUT its
+//       clamp of the block position into the frame (:155-158): the planes' borders are replicated, so a read outside the frame returns
+//       the pixel the clamp would have selected; the precondition is stated at aomhip_tf_apply_frames),
 //   tf_apply_temporal_filter_self (:407-442) for the frame to filter itself,
 //   av1_apply_temporal_filter_c (:557-712; rtcd proto av1/common/av1_rtcd_defs.pl:405-406): compute_square_diff, the 5x5 window sums
 //       with coordinates clamped to the block, compute_luma_sq_error_sum for the chroma planes, the weight

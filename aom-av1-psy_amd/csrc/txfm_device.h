@@ -55,7 +55,10 @@ __device__ __forceinline__ int32_t rshift64(int64_t v, int bit) { return (int32_
 // i.e. the reference's wrapped product) and the exact sum w0 a + w1 b + 2^(bit-1) fits int32.  Callers may only set the flag for blocks
 // whose residual magnitude is at most kSafeMax[tx_size][tx_type] (txfm_safe_max.inc): an offline interval analysis of every stage proves
 // both conditions for every butterfly of both passes under that bound (the generator is named in the table's header; tests/test_oracle_txfm_bounds.py re-derives it).
-// Every 8- and 10-bit video residual qualifies at every size; other inputs take the exact form.  The forward transform + quantise
+// Every 8-bit video residual (|r| <= 255) qualifies at every size and type; a 10-bit one (|r| <= 1023) qualifies everywhere except where
+// txfm_safe_max.inc is below 1023 -- the ADST / FLIPADST rows of TX_8X4 (915 / 781) and TX_16X4 (390 / 329): blocks of those sizes and types
+// whose residual exceeds the bound silently take the exact form (same result, 3 x the butterfly instructions), as do 12-bit residuals above
+// the bound of their size.  tests/test_gpu_xform_quant.py runs blocks AT the bound and one above it.  The forward transform + quantise
 // kernels were VALU-issue bound on exactly these butterflies (profiles/r02_txq.md, r03_txq.md).
 constexpr int kFastBtf = 32;
 template <int BIT> __device__ __forceinline__ int32_t hbtf(int32_t w0, int32_t a, int32_t w1, int32_t b) {

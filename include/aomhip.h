@@ -402,7 +402,15 @@ int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, con
 /* The same two passes in ONE launch, out of place: frame src_frame of `src` is read, frame dst_frame of `dst` (same geometry; a
  * different frame) receives the deblocked plane -- every pixel, filtered or not.  Each pixel is read ~1.4 times (tile halos, served
  * by L2) and written once instead of read and written twice; the results are identical to aomhip_deblock_plane with passes = 3.
- * What the in-loop chain uses when the next stage (CDEF) reads from a second buffer anyway.  `src` needs a border of >= 8 pixels. */
+ * What the in-loop chain uses when the next stage (CDEF) reads from a second buffer anyway.  Preconditions (checked where the call can see
+ * them, AOMHIP_ERR_INVALID otherwise -- fall back to aomhip_deblock_plane): `src` has a border of >= 8 pixels; the pixel (0, 0) of both
+ * frames and both row strides are 16-byte aligned for 16-bit planes, 4-byte aligned for 8-bit ones (aomhip_planes_alloc with a border
+ * that is a multiple of 8 gives that).  Preconditions on the EDGE RECORDS, which live in device memory and are not checked: they are what
+ * set_lpf_parameters produces for an AV1 stream (aomhip_lf_build_edge_params) -- edges only on the 4-pixel grid, a length-8 / 14 edge
+ * only at a column / row that is a multiple of 8 / 16 of its transform block, neighbouring edges >= 4 pixels apart so that their filter
+ * zones (up to 7 pixels each side at length 14, 4 at 8, 2-3 at 4 / 6) never overlap.  Records that violate this (hand-built ones) are
+ * undefined in this entry point (a zone reaching outside its tile is dropped, overlapping zones race); aomhip_deblock_plane has no such
+ * restriction. */
 int aomhip_deblock_plane_fused(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dst, int dst_frame,
                                const uint8_t *d_edge_params, int units_stride, int sharpness);
 
@@ -708,7 +716,9 @@ typedef struct {
 } aomhip_tf_apply_params;
 /* frames_y / _u / _v: the window's rings (same n_frames; _u / _v NULL when num_planes == 1; chroma planes (width + ss_x) >> ss_x wide);
  * every plane's border must cover the 32-aligned frame (blocks of the last row / column reach beyond the visible area exactly as in the
- * reference) and the predictors' reach (MV limits + 6 pixels).  n_blocks = ceil(height / 32) * ceil(width / 32), the count
+ * reference) and the predictors' reach (MV limits + 6 pixels), and it must be REPLICATED (aomhip_planes_upload / _extend_borders do it): the
+ * device predictor does not clamp the block position into the frame as init_subpel_params does (av1/common/reconinter.h:155-158) -- it
+ * reads the border pixels, which equal the clamped ones only when the border repeats the edge.  n_blocks = ceil(height / 32) * ceil(width / 32), the count
  * aomhip_tf_block_list returns; d_subblock_mvs / d_subblock_mses: as aomhip_tf_motion_search_frames writes them.
  * out_*: frame out_frame of these rings receives the filtered frame; d_frame_diff: two int64 { sum, sse } or NULL. */
 int aomhip_tf_apply_frames(aomhip_ctx *ctx, const aomhip_planes *frames_y, const aomhip_planes *frames_u, const aomhip_planes *frames_v,
