@@ -436,6 +436,9 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
           default: return (unsigned)__builtin_amdgcn_update_dpp(0u, v, 0xFF, 0xf, 0xf, false);
         }
       };
+#if AOMHIP_SB_DBG_KNOBS
+      const unsigned grid_magic = (unsigned)((0x100000000ull + (unsigned)(a.sb_w / W) - 1) / (unsigned)(a.sb_w / W));
+#endif
       auto eval = [&](const Win &w, int buf, int g0, int ng, int c0, int nc) {
         const uint32_t *gd = reinterpret_cast<const uint32_t *>(lds + gdesc_off_of(buf));
         const uint32_t *cd = reinterpret_cast<const uint32_t *>(lds + cdesc_off_of(buf));
@@ -451,9 +454,22 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
             // per SIMD that chain's latency -- not LDS or VALU throughput -- set the step time.
             const bool both = has_g && has_c;
             const int ii = both ? i : 0;  // (lanes without a pair read entry 0: no out-of-range LDS address, no per-word select)
+#if AOMHIP_SB_DBG_KNOBS
+            uint32_t d0 = gd[ii * 5], c0w = cd[ii * 2], c1w = cd[ii * 2 + 1];
+            int mrx = __builtin_amdgcn_sbfe((int)gd[ii * 5 + 1 + my_w], my_sh, 16);
+            int mry = __builtin_amdgcn_sbfe((int)gd[ii * 5 + 3 + my_w], my_sh, 16);
+            if (dbg & 8192) {  // (timing ablation = upper bound of a grid-mode entry point: no list travels, the entry is a function of its index)
+              const unsigned bpr = (unsigned)a.sb_w / W, row = __umulhi((unsigned)ii, grid_magic), col = (unsigned)ii - row * bpr;
+              const int gx = cell_x0 + (int)col * W, gy = (int)w.sy0 + (int)row * H;
+              d0 = c0w = c1w = ((uint32_t)gx & 0xffffu) | ((uint32_t)gy << 16);
+              mrx = gx + (int)((ii * 29u + my_j * 13u) & 31u) - 16;
+              mry = gy + (int)((ii * 11u + my_j * 7u) & 31u) - 16;
+            }
+#else
             const uint32_t d0 = gd[ii * 5], c0w = cd[ii * 2], c1w = cd[ii * 2 + 1];
             const int mrx = __builtin_amdgcn_sbfe((int)gd[ii * 5 + 1 + my_w], my_sh, 16);
             const int mry = __builtin_amdgcn_sbfe((int)gd[ii * 5 + 3 + my_w], my_sh, 16);
+#endif
             const int fsx = (int16_t)d0, fsy = (int16_t)(d0 >> 16);
             unsigned soff, mbase, cbase, base[5];
             int unused;
@@ -665,6 +681,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
         b.c0 = sg.c0; b.nc = real ? min(sg.c1 - sg.c0, a.ccap) : 0;
         b.buf = cy & 1;
         if ((dbg & 2) && cy > 0) { b.yb = b.ya; b.ns = 0; }  // (timing ablation: list slices only)
+        if (dbg & 8192) { b.ng = 0; b.nc = 0; }              // (timing ablation: no list slices, profiles/r04_sad_strip.md)
         return b;
       };
       // Per-step records, worked out once per strip (one lane per step) instead of by every wavefront in every step: the scalar

@@ -42,6 +42,11 @@ WORKLOADS = {
     "sad16x16_modeA_4k_8bit": dict(width=3840, height=2160, bit_depth=8, frames=64),
     "sad16x16_modeA_4k_10bit": dict(width=3840, height=2160, bit_depth=10, frames=32),
 }
+# The same three rings under a +-32 search-range contract (lists uniform in [-32, 32]^2, aomhip_sad_sb_batch's `range` = 32): the LDS window's
+# halo halves, so a step of the strip walk holds 30 blocks instead of 20 on 16-bit planes and the 8-bit cells get wider (profiles/r04_sad_strip.md).
+# Reported NEXT TO the +-64 figures (roofline.*_range32), never instead of them.
+for _k in list(WORKLOADS):
+    WORKLOADS[_k + "_range32"] = dict(WORKLOADS[_k], search_range=32)
 
 
 _BACKEND = "nccl"  # RCCL; "gloo" only for the single-GPU dry run of the N > 1 code path (tools/gpu_dist_dryrun.sh)
@@ -113,7 +118,8 @@ class SadModeA:
                 ctx.planes_upload(self.src, f + k * self.F, s)
                 ctx.planes_upload(self.ref, f + k * self.F, r)
         x0, x1 = pkg.partition.column_of_rank(W, world, rank, mode=TILE_COLUMNS)
-        cands, groups = synth.mode_a_worklist(W, H, 16, seed=seed)
+        self.range = SR = int(cfg.get("search_range", 64))
+        cands, groups = synth.mode_a_worklist(W, H, 16, seed=seed, search=SR)
         keep = (cands["sx"] >= x0) & (cands["sx"] < x1)
         self.blocks_per_frame = int(keep.sum())
         base_c, base_g = cands[keep], groups[keep]
@@ -121,8 +127,8 @@ class SadModeA:
         # distinct random positions per frame (same block grid)
         rng = np.random.default_rng(seed + 977 * rank)
         allg = np.tile(base_g, (self.ring, 1))
-        allg["rx"] = allg["sx"][..., None] + rng.integers(-64, 65, (self.ring, n, 4), dtype=np.int16)
-        allg["ry"] = allg["sy"][..., None] + rng.integers(-64, 65, (self.ring, n, 4), dtype=np.int16)
+        allg["rx"] = allg["sx"][..., None] + rng.integers(-SR, SR + 1, (self.ring, n, 4), dtype=np.int16)
+        allg["ry"] = allg["sy"][..., None] + rng.integers(-SR, SR + 1, (self.ring, n, 4), dtype=np.int16)
         self.h_cands, self.h_groups0 = base_c, allg[0].copy()
         self.h_groups_last = allg[self.ring - 1].copy()
         self.h_groups_all = allg[:self.F] if rank == 0 else None
@@ -142,6 +148,8 @@ class SadModeA:
         # (a rank's items = strips of its column x ring frames; the kernel's persistent grid is 256 workgroups: prefer the cell whose
         # item count is a multiple of that -- 320 x 48 on a whole 4K frame, 240 x 64 on a 1080p frame or a 1920 / 960-wide tile column)
         options = [(320, 48), (240, 64)] if bd == 8 else [(160, 32)]
+        if SR <= 32:  # r04 sweep (profiles/r04_sad_strip.md): 480 x 32 (8-bit), 160 x 48 (16-bit: 24 strips x 32 frames = 3 items per workgroup)
+            options = [(480, 32), (320, 48), (240, 64)] if bd == 8 else [(160, 48), (256, 32), (160, 32)]
         fits = [c for c in options if col_w % c[0] == 0]
         whole = [c for c in fits if ((col_w // c[0]) * self.ring) % 256 == 0]
         tuned, cell_h = (whole or fits or options[-1:])[0]
@@ -172,14 +180,14 @@ class SadModeA:
     def launch_sb(self):
         if self.d_sb:
             n = self.blocks_per_frame
-            self.ctx.sad_sb_batch(self.src, self.ref, 0, self.ring, 16, 16, 0, self.cell[0], self.cell[1], 64, self.n_buckets,
+            self.ctx.sad_sb_batch(self.src, self.ref, 0, self.ring, 16, 16, 0, self.cell[0], self.cell[1], self.range, self.n_buckets,
                                   self.d_sb[0], self.d_sb[2], n, n, self.d_sb_out4, self.d_sb[1], self.d_sb[2], n, 0,
                                   self.d_sb_out1)
 
     def launch_probe(self):
         """the transport of launch_sb alone (aomhip_strip_read_probe): same ring, same cells, same range, nothing evaluated."""
         if self.d_sb:
-            self.probe_bytes = self.ctx.strip_read_probe(self.src, self.ref, 0, self.ring, self.tile[0], self.tile[1], self.cell[0], self.cell[1], 64)
+            self.probe_bytes = self.ctx.strip_read_probe(self.src, self.ref, 0, self.ring, self.tile[0], self.tile[1], self.cell[0], self.cell[1], self.range)
 
     def step(self):
         if self.path == "sb":
@@ -1363,7 +1371,8 @@ def main():
                             not args.no_cpu_baseline and world == 1, orc)
     others, strong = [], None
     if world == 1:
-        names = ([n for n in ("sad16x16_modeA_4k_8bit", "sad16x16_modeA_4k_10bit") if n != args.workload]
+        names = ([n for n in ("sad16x16_modeA_4k_8bit", "sad16x16_modeA_4k_10bit", "sad16x16_modeA_1080p_8bit_range32",
+                               "sad16x16_modeA_4k_8bit_range32", "sad16x16_modeA_4k_10bit_range32") if n != args.workload]
                  if args.others == "auto" else [n for n in args.others.split(",") if n])
         for n in names:
             if n in TXQ_WORKLOADS:
@@ -1416,7 +1425,7 @@ def main():
             "dtype": "u8" if cfg["bit_depth"] == 8 else "u16", "data": "synthetic",
             "config": {"workload": args.workload, "frame": "%dx%d" % (cfg["width"], cfg["height"]),
                        "bit_depth": cfg["bit_depth"], "block": "16x16",
-                       "mode": "A: 1 sad16x16 @mv(0,0) + 1 sad16x16x4d (uniform in [-64,64]^2) per block",
+                       "mode": "A: 1 sad16x16 @mv(0,0) + 1 sad16x16x4d (uniform in [-%d,%d]^2) per block" % (cfg.get("search_range", 64), cfg.get("search_range", 64)),
                        "ring_frame_pairs_per_gpu": FRAMES_OVERRIDE or cfg["frames"], "candidates_per_step": main_res["candidates_per_step"],
                        "partition": ("balanced tile columns (encoder.c:247-275)" if TILE_COLUMNS == "balanced" else "uniform tile columns (tile_common.c:76-97)") +
                                     ", one per GPU; no data-path collective",

@@ -59,16 +59,27 @@ def test_apply_frames_equals_oracle(hip, oracle, ctx, W, H, bd, planes, ssx, ssy
         d = np.abs(g - wv)
         assert d.max() <= 1, (p, d.max())
         off += int((d != 0).sum()); total += d.size
+        if p == 0: luma_dev, luma_off = g, int((d != 0).sum())
     assert off <= max(1, total // 20000), (off, total)
     # FRAME_DIFF: sse of every luma block (source vs filtered), highbd forms rounded to the 8-bit scale
     diff = ctx.from_device(d_diff, (2,), np.int64)
     src = host[0][filt][border:border + mb_rows * 32, border:border + mb_cols * 32].astype(np.int64)
-    flt = want[0][border:border + mb_rows * 32, border:border + mb_cols * 32].astype(np.int64)
-    sse = ((src - flt) ** 2).reshape(mb_rows, 32, mb_cols, 32).sum(axis=(1, 3))
-    if bd == 10: sse = (sse + 8) >> 4
-    if bd == 12: sse = (sse + 128) >> 8
-    if off == 0:
-        assert diff[0] == sse.sum() and diff[1] == (sse * sse).sum()
+
+    def frame_diff(flt):
+        sse = ((src - flt) ** 2).reshape(mb_rows, 32, mb_cols, 32).sum(axis=(1, 3))
+        if bd == 10: sse = (sse + 8) >> 4
+        if bd == 12: sse = (sse + 128) >> 8
+        return int(sse.sum()), int((sse * sse).sum())
+    # unconditionally: the sums are those of the plane the device wrote (the fp64 weights may move a pixel by one against this host's libm,
+    # the sums must follow the device's own pixels exactly) ...
+    assert (int(diff[0]), int(diff[1])) == frame_diff(luma_dev)
+    # ... and the oracle's sums whenever no luma pixel differs; otherwise within what the counted +-1 pixels can move them
+    want_sum, want_sq = frame_diff(want[0][border:border + mb_rows * 32, border:border + mb_cols * 32].astype(np.int64))
+    if luma_off == 0:
+        assert (int(diff[0]), int(diff[1])) == (want_sum, want_sq)
+    else:
+        peak = (1 << bd) - 1
+        assert abs(int(diff[0]) - want_sum) <= luma_off * (2 * peak + 1) + mb_rows * mb_cols
     for d_ in (d_mvs, d_mses, d_diff):
         ctx.free(d_)
     for r in rings + outs:

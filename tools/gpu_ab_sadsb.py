@@ -1,5 +1,6 @@
 """A/B on one MI355X: direct sad_x4d + sad_cand launches vs the strip-walking bucketed launch, Mode A lists.
-    python tools/gpu_ab_sadsb.py <4k|1080p> <bit depth> <frames> <sbw,sbh[,threads]> [<sbw,sbh[,threads]> ...]"""
+    python tools/gpu_ab_sadsb.py <4k|1080p> <bit depth> <frames> <sbw,sbh[,threads]> [<sbw,sbh[,threads]> ...]
+AB_RANGE=<px> (default 64): the search range of the lists AND the kernel's range contract (the LDS window's halo)."""
 import os, sys, json
 import numpy as np
 sys.path.insert(0, os.getcwd())
@@ -20,7 +21,8 @@ def main():
         return pkg.synth.lcg_frame(W, H, f, plane, bd)
     for f in range(F):
         ctx.planes_upload(ps, f, frame(f, 0)); ctx.planes_upload(pr, f, frame(f, 1))
-    cands, groups = pkg.synth.mode_a_worklist(W, H, 16, seed=1, search=64)
+    RANGE = int(os.environ.get("AB_RANGE", "64"))
+    cands, groups = pkg.synth.mode_a_worklist(W, H, 16, seed=1, search=RANGE)
     n = len(groups)
     d_g, d_c = ctx.to_device(groups), ctx.to_device(cands)
     d_o4, d_o1 = ctx.malloc(F * n * 16), ctx.malloc(F * n * 4)
@@ -46,7 +48,7 @@ def main():
         d_gs, d_cs, d_off = ctx.to_device(groups[perm]), ctx.to_device(cands[perm]), ctx.to_device(off)
         ctx.memset(d_p4, 0xff, F * n * 16); ctx.memset(d_p1, 0xff, F * n * 4)
         def sb_both():
-            ctx.sad_sb_batch(ps, pr, 0, F, 16, 16, 0, sbw, sbh, 64, len(off) - 1, d_gs, d_off, n, 0, d_p4, d_cs, d_off, n, 0, d_p1)
+            ctx.sad_sb_batch(ps, pr, 0, F, 16, 16, 0, sbw, sbh, RANGE, len(off) - 1, d_gs, d_off, n, 0, d_p4, d_cs, d_off, n, 0, d_p1)
         try:
             ms = timed(sb_both)
         except Exception as e:
@@ -54,7 +56,7 @@ def main():
             continue
         b4 = ctx.from_device(d_p4, (F, n, 4), np.uint32); b1 = ctx.from_device(d_p1, (F, n), np.uint32)
         ok = bool(np.array_equal(a4[:, perm], b4) and np.array_equal(a1[:, perm], b1))
-        print(json.dumps({"cell": spec, "ms": ms, "cand_per_s": 5 * n * F / ms * 1e3, "compulsory_GBs": compulsory / ms / 1e6,
+        print(json.dumps({"cell": spec, "range": RANGE, "ms": ms, "cand_per_s": 5 * n * F / ms * 1e3, "compulsory_GBs": compulsory / ms / 1e6,
                           "frac_of_8TBs": compulsory / ms / 1e6 / 8000, "identical": ok}), flush=True)
         for d in (d_gs, d_cs, d_off): ctx.free(d)
 

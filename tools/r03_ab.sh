@@ -15,7 +15,8 @@ for l in open('gpurun_out/%s/ab.log' % os.environ.get('OUT','r03d')):
     if l.startswith('args='): cur=l.strip()
     elif l.startswith('{'):
         m=re.search(r'"ms": ([0-9.]+)',l); i=re.search(r'"identical": (\w+)',l); f=re.search(r'"frac_of_8TBs": ([0-9.]+)',l)
-        print(cur, 'ms', round(float(m.group(1)),4) if m else l[:100], 'frac', round(float(f.group(1)),3) if f else None, 'identical', i.group(1) if i else None)
+        c=re.search(r'"cell": "([0-9,]+)"',l); rg=re.search(r'"range": (\d+)',l)
+        print(cur, 'cell', c.group(1) if c else None, 'range', rg.group(1) if rg else None, 'ms', round(float(m.group(1)),4) if m else l[:100], 'frac', round(float(f.group(1)),3) if f else None, 'identical', i.group(1) if i else None)
     else: print(l.strip()[:200])
 PY
 if [ -n "$PROF" ]; then for D in $PROF; do AOMHIP_SB_DBG=$D AOMHIP_LIB=build/exp/libaomhip_exp_prof.so python tools/gpu_sb_prof.py ${PROFARGS:-4k 8 64 320,48} 2>&1 | tail -1 | tee -a gpurun_out/${OUT:-r03d}/prof.log; done; fi
