@@ -31,6 +31,10 @@ struct aomhip_ctx {
   // must not be replayed after that (aomhip_graph_launch compares)
   unsigned buf_generation;
   int *h_status;  // pinned mirror: aomhip_ctx_sync reads the word with an async copy ordered before its one stream synchronise
+  // a second stream for the independent halves of a composite call (the first pass's golden-frame leg beside its chain kernel): forked from
+  // and joined back into `stream` with the two events inside the call, so callers -- and a graph capture of `stream` -- see one stream
+  hipStream_t side_stream;
+  hipEvent_t ev_fork, ev_join;
 };
 
 namespace aomhip {
@@ -51,6 +55,7 @@ constexpr uint32_t kFailedCost = 0xFFFFFFFFu;
 constexpr uint32_t kFailedVarCost = 0x3FFFFFFFu;
 aomhip_ctx *default_ctx();                  // lazily created per-thread context for the rtcd-signature paths; nullptr on failure
 void *scratch(aomhip_ctx *ctx, size_t bytes);
+hipStream_t side_stream(aomhip_ctx *ctx);   // created on first use; nullptr on failure (the caller then stays on ctx->stream)
 void *pinned(aomhip_ctx *ctx, size_t bytes);
 void *work(aomhip_ctx *ctx, size_t bytes);
 // enqueue the check of a per-block transform list (tx_type valid for tx_size; `wht_ok`: AOMHIP_TX_WHT allowed) on the context's stream

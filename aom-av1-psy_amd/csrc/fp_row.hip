@@ -1,14 +1,16 @@
-// The first pass's chained motion search as ONE launch per frame: a wavefront per block row walks its blocks left to right.
+// The first pass's chained motion search as ONE launch per frame: a workgroup per block row walks its blocks left to right.
 //
 // firstpass_inter_prediction (av1/encoder/firstpass.c:690-815) under the raster loop (:1148-1193): best_ref_mv of block (r, c) is block
 // (r, c - 1)'s *best_mv and kZeroMv at c == 0 (:1165, :1190) -- rows are independent, columns a chain.  aomhip_first_pass_inter_frame
-// computes everything that does not depend on the chain (the three 0,0 errors, the two zero-MV legs) for the whole frame first; the leg
+// computes everything that does not depend on the chain (the three 0,0 errors, the two zero-MV legs) for the whole frame; the leg
 // started at best_ref_mv used to run one block COLUMN at a time, a search launch + a decision launch per column: 2 x 240 dependent
-// launches of a 4K frame with 135 wavefronts each (profiles/r03z_first_pass_4k_10bit_kernel_stats.csv: 6 066 search launches of 95.7 us,
-// 24 ms per frame).  Here the chain lives in the registers of the row's wavefront: list entry (get_fullmv_from_mv(best_ref_mv),
-// av1_set_mv_search_range) -> av1_full_pixel_search (the same device function the batched kernel runs, fullpel_search.inc fps_block) ->
-// av1_get_mvpred_sse + MV cost + NEW_MV_MODE_PENALTY -> the decision (:722-752, :777-794) -> next block, with no launch and no global
-// round trip between the links, and only for the blocks that need it (raw_motion_error above the threshold, best_ref_mv != 0).
+// launches of a 4K frame with 135 wavefronts each (profiles/r03z_first_pass_4k_10bit_kernel_stats.csv: 24 ms per frame).  Here the chain
+// lives in the registers of the row's wavefronts: list entry (get_fullmv_from_mv(best_ref_mv), av1_set_mv_search_range) ->
+// av1_full_pixel_search (the same device function the batched kernel runs, fullpel_search.inc fps_block) -> av1_get_mvpred_sse + MV cost +
+// NEW_MV_MODE_PENALTY -> the decision (:722-752, :777-794) -> next block, with no launch and no global round trip between the links, and
+// only for the blocks that need it (raw_motion_error above the threshold, best_ref_mv != 0).  A link of the chain is ~45 000 clocks of pure
+// latency (8 dependent search rounds with two memory round trips each, profiles/r04_first_pass.md), so the row's wavefronts SPECULATE
+// along it (below): 7.6 -> 4.9 ms per 4K 10-bit frame; the golden-frame leg runs beside the kernel on a second stream (tf_search.hip): 3.7 ms.
 #include <climits>
 
 #define AOMHIP_FPS_DEVICE_ONLY
@@ -21,22 +23,34 @@ constexpr int kMaxFullPel = 1023;          // MAX_FULL_PEL_VAL (mcomp_structs.h:
 constexpr int kMvLow = -(1 << 14), kMvUpp = 1 << 14;  // MV_LOW / MV_UPP (entropymv.h:75-76)
 __device__ __forceinline__ int rawpel(int x) { return (x + 3 + (x >= 0)) >> 3; }  // GET_MV_RAWPEL (mv.h:28)
 
-template <typename T, int W, int H>
-__global__ __launch_bounds__(64) void fp_row_kernel(PlaneView<T> src, PlaneView<T> last, const aomhip_search_block *__restrict__ blocks,
-                                                    const SiteTable *__restrict__ sites, SearchArgs q, FpfLegs L, FpfCost C,
-                                                    const int32_t *__restrict__ intra, int rows, int cols, int thr, int skip_zeromv, FpfOut out) {
+// SPEC wavefronts per row, speculating on the chain.  best_ref_mv of block c + 1 is block c's *best_mv, and over most of a frame that is
+// the SAME vector block after block (camera motion, static background).  So the row's wavefronts search blocks c .. c + width - 1 side by
+// side, ALL started from the last known best_ref_mv; then every wavefront reads the results in order: block c is always right; block c + 1
+// is right if block c's *best_mv equals the best_ref_mv it was started from, and so on -- the first block whose result changes the vector
+// ends the batch, the blocks behind it are searched again from the new vector in the next one.  Exactly the reference's values (a block's
+// result is only kept when its input was the true one), at up to `width` links of the chain per search latency; `width` halves after a
+// batch that was cut short and doubles after one that went through (1 .. SPEC), so incoherent content costs what one wavefront per row costs.
+struct FpBlockOut { int nrow, ncol, err, mrow, mcol, gf, raw; };
+
+template <typename T, int W, int H, int SPEC>
+__global__ __launch_bounds__(SPEC * 64) void fp_row_kernel(PlaneView<T> src, PlaneView<T> last, const aomhip_search_block *__restrict__ blocks,
+                                                          const SiteTable *__restrict__ sites, SearchArgs q, FpfLegs L, FpfCost C,
+                                                          const int32_t *__restrict__ intra, int rows, int cols, int thr, int skip_zeromv, FpfOut out) {
   __shared__ SiteTable sS;
+  __shared__ int next_mv[SPEC][2];
   {
     const uint32_t *g = reinterpret_cast<const uint32_t *>(sites);
     uint32_t *d = reinterpret_cast<uint32_t *>(&sS);
-    for (int i = threadIdx.x; i < (int)(sizeof(SiteTable) / 4); i += 64) d[i] = g[i];
+    for (int i = threadIdx.x; i < (int)(sizeof(SiteTable) / 4); i += SPEC * 64) d[i] = g[i];
   }
   __syncthreads();
-  const int r = blockIdx.x, lane = threadIdx.x;
+  const int r = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (r >= rows) return;
+  __builtin_amdgcn_s_setprio(3);   // a chain of latencies: its instructions go first when a throughput kernel shares the SIMD (the golden leg)
   const CellWin no_win{ 0, 0, 0, 0, 0 };
-  int brow = 0, bcol = 0;   // MV best_ref_mv = kZeroMv at the start of every row (:1165), in 1/8 pel
-  for (int c = 0; c < cols; ++c) {
+
+  // one block of firstpass_inter_prediction with best_ref_mv = (brow, bcol) (1/8 pel)
+  auto one_block = [&](int c, int brow, int bcol) -> FpBlockOut {
     const size_t i = (size_t)r * cols + c;
     const aomhip_search_block b = blocks[i];
     const int bx = __builtin_amdgcn_readfirstlane((int)b.bx), by = __builtin_amdgcn_readfirstlane((int)b.by);
@@ -93,6 +107,7 @@ __global__ __launch_bounds__(64) void fp_row_kernel(PlaneView<T> src, PlaneView<
       }
     }
     // the decision (:722-752, :777-794), every lane the same values
+    FpBlockOut o;
     int err = (int)L.err0[i], mrow = 0, mcol = 0, gf;
     gf = err;
     if (raw > thr) {
@@ -106,13 +121,50 @@ __global__ __launch_bounds__(64) void fp_row_kernel(PlaneView<T> src, PlaneView<
     }
     int nrow = 0, ncol = 0;
     if (err <= intra[i]) { nrow = mrow * 8; ncol = mcol * 8; }
-    brow = __builtin_amdgcn_readfirstlane(nrow); bcol = __builtin_amdgcn_readfirstlane(ncol);
-    if (lane == 0) {
-      out.best_mv[2 * i] = (int16_t)brow; out.best_mv[2 * i + 1] = (int16_t)bcol;
-      if (out.full_mv) { out.full_mv[2 * i] = (int16_t)mrow; out.full_mv[2 * i + 1] = (int16_t)mcol; }
-      out.motion_error[i] = err;
-      if (out.gf_motion_error) out.gf_motion_error[i] = gf;
-      if (out.raw_motion_error) out.raw_motion_error[i] = raw;
+    o.nrow = __builtin_amdgcn_readfirstlane(nrow); o.ncol = __builtin_amdgcn_readfirstlane(ncol);
+    o.err = err; o.mrow = mrow; o.mcol = mcol; o.gf = gf; o.raw = raw;
+    return o;
+  };
+  auto store = [&](int c, const FpBlockOut &o) {
+    const size_t i = (size_t)r * cols + c;
+    out.best_mv[2 * i] = (int16_t)o.nrow; out.best_mv[2 * i + 1] = (int16_t)o.ncol;
+    if (out.full_mv) { out.full_mv[2 * i] = (int16_t)o.mrow; out.full_mv[2 * i + 1] = (int16_t)o.mcol; }
+    out.motion_error[i] = o.err;
+    if (out.gf_motion_error) out.gf_motion_error[i] = o.gf;
+    if (out.raw_motion_error) out.raw_motion_error[i] = o.raw;
+  };
+
+  int brow = 0, bcol = 0;   // MV best_ref_mv = kZeroMv at the start of every row (:1165), in 1/8 pel
+  if constexpr (SPEC == 1) {
+    for (int c = 0; c < cols; ++c) {
+      const FpBlockOut o = one_block(c, brow, bcol);
+      brow = o.nrow; bcol = o.ncol;
+      if (lane == 0) store(c, o);
+    }
+  } else {
+    int width = SPEC;
+    for (int c = 0; c < cols;) {
+      const int lim = min(width, cols - c);
+      const bool mine = wave < lim;
+      FpBlockOut o{};
+      if (mine) {
+        o = one_block(c + wave, brow, bcol);
+        if (lane == 0) { next_mv[wave][0] = o.nrow; next_mv[wave][1] = o.ncol; }
+      }
+      __syncthreads();
+      int valid = 0, nr = brow, nc = bcol;
+      bool same = true;
+      while (valid < lim && same) {   // block c + valid was searched from the true best_ref_mv
+        nr = __builtin_amdgcn_readfirstlane(next_mv[valid][0]);
+        nc = __builtin_amdgcn_readfirstlane(next_mv[valid][1]);
+        same = nr == brow && nc == bcol;
+        ++valid;
+      }
+      if (mine && wave < valid && lane == 0) store(c + wave, o);
+      width = valid == lim ? min(2 * width, SPEC) : max(width >> 1, 1);
+      brow = nr; bcol = nc;
+      c += valid;
+      __syncthreads();   // (next_mv is rewritten by the next batch)
     }
   }
 }
@@ -132,14 +184,20 @@ int launch_fp_rows(aomhip_ctx *ctx, const aomhip_planes *src1, const aomhip_plan
   }
   const SearchArgs q = fps_search_args(p, d_mvjcost, d_mvcost_row, d_mvcost_col, src1->bit_depth, false);
   const FpfCost C{ p->mv_cost_type, p->error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col };
+  static const int spec = [] { const char *e = getenv("AOMHIP_FP_ROW_WAVES"); const int v = e ? atoi(e) : 8; return v == 1 || v == 4 || v == 16 ? v : 8; }();   // (A/B)
+#define XP(T, W, H, P)                                                                                                                   \
+  hipLaunchKernelGGL((fp_row_kernel<T, W, H, P>), dim3(rows), dim3(P * 64), 0, ctx->stream, view_of<T>(*src1), view_of<T>(*last1),       \
+                     d_blocks, d_sites, q, L, C, d_intra, rows, cols, thr, skip_zeromv, out);
 #define X(T, W, H)                                                                                                                      \
-  hipLaunchKernelGGL((fp_row_kernel<T, W, H>), dim3(rows), dim3(64), 0, ctx->stream, view_of<T>(*src1), view_of<T>(*last1), d_blocks,  \
-                     d_sites, q, L, C, d_intra, rows, cols, thr, skip_zeromv, out)
-  if (src1->bit_depth == 8) {
-    if (bw == 16) X(uint8_t, 16, 16); else X(uint8_t, 8, 8);
-  } else {
-    if (bw == 16) X(uint16_t, 16, 16); else X(uint16_t, 8, 8);
+  {                                                                                                                                     \
+    if (spec == 1) XP(T, W, H, 1) else if (spec == 4) XP(T, W, H, 4) else if (spec == 16) XP(T, W, H, 16) else XP(T, W, H, 8)            \
   }
+  if (src1->bit_depth == 8) {
+    if (bw == 16) X(uint8_t, 16, 16) else X(uint8_t, 8, 8)
+  } else {
+    if (bw == 16) X(uint16_t, 16, 16) else X(uint16_t, 8, 8)
+  }
+#undef XP
 #undef X
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;

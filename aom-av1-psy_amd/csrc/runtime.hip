@@ -45,6 +45,22 @@ aomhip_ctx *default_ctx() {
   return g_default_ctx;
 }
 
+hipStream_t side_stream(aomhip_ctx *ctx) {
+  if (ctx->side_stream) return ctx->side_stream;
+  hipStream_t st = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+    if (b) (void)hipEventDestroy(b);
+    if (a) (void)hipEventDestroy(a);
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  ctx->side_stream = st; ctx->ev_fork = a; ctx->ev_join = b;
+  return st;
+}
+
 void *scratch(aomhip_ctx *ctx, size_t bytes) {
   if (ctx->d_scratch_bytes < bytes) {
     ++ctx->buf_generation;
@@ -206,6 +222,12 @@ void aomhip_ctx_destroy(aomhip_ctx *ctx) {
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
+  if (ctx->side_stream) {
+    (void)hipStreamSynchronize(ctx->side_stream);
+    (void)hipStreamDestroy(ctx->side_stream);
+    (void)hipEventDestroy(ctx->ev_fork);
+    (void)hipEventDestroy(ctx->ev_join);
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   if (g_default_ctx == ctx) g_default_ctx = nullptr;
   free(ctx);

@@ -269,6 +269,15 @@ __global__ void fp_cands_kernel(const aomhip_search_block *blocks, const int16_t
   c.xoff = c.yoff = 0; c.reserved[0] = c.reserved[1] = 0;
   cands[i] = c;
 }
+// gf_motion_error of a frame with a golden reference (firstpass.c:777-794 under :722): the smaller of the 0,0 error and the golden search's
+// for a block that is searched at all, the last frame's 0,0 error otherwise -- nothing of the best_ref_mv chain enters it
+__global__ void fp_gf_kernel(const uint32_t *raw, const uint32_t *err0, const uint32_t *gf0, const int32_t *gerr, int thr, int n, int32_t *gf_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int gf = (int)err0[i];
+  if ((int)raw[i] > thr) { gf = (int)gf0[i]; if (gerr[i] < gf) gf = gerr[i]; }
+  gf_out[i] = gf;
+}
 // tmp_err = sse + mv_err_cost_(get_mv_from_fullmv(best), params) + NEW_MV_MODE_PENALTY   (mcomp.c:271-308, 3637-3649)
 __global__ void fp_finish_kernel(const aomhip_search_block *blocks, const int16_t *mv, const int32_t *search_cost, const uint32_t *sse, int n,
                                  int cost_type, int error_per_bit, const int32_t *mvjcost, const int32_t *mvcost0, const int32_t *mvcost1,
@@ -652,14 +661,15 @@ extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_plane
   const size_t o_zl = take(n1 * sizeof(aomhip_search_block)), o_zmv = take(n1 * 4), o_zerr = take(n1 * 4), o_gmv = take(n1 * 4), o_gerr = take(n1 * 4),
                o_e0 = take(n1 * 4), o_raw = take(n1 * 4), o_gf0 = take(n1 * 4), o_var = take(n1 * 4), o_cost = take(n1 * 4), o_sse = take(n1 * 4),
                o_cand = take(n1 * sizeof(aomhip_var_cand)), o_cl = take(r1 * sizeof(aomhip_search_block)), o_cl2 = take(r1 * sizeof(aomhip_search_block)),
-               o_cmv = take(r1 * 4), o_cerr = take(r1 * 4), o_chain = take(r1 * 4);
+               o_cmv = take(r1 * 4), o_cerr = take(r1 * 4), o_chain = take(r1 * 4),
+               // the golden leg's own intermediates: it runs beside the last-frame leg and the chain (side stream)
+               o_var_g = take(n1 * 4), o_cost_g = take(n1 * 4), o_sse_g = take(n1 * 4), o_cand_g = take(n1 * sizeof(aomhip_var_cand));
   char *w = static_cast<char *>(work(ctx, off));
   if (!w) return AOMHIP_ERR_NOMEM;
   auto i32 = [&](size_t o) { return reinterpret_cast<int32_t *>(w + o); };
   auto u32 = [&](size_t o) { return reinterpret_cast<uint32_t *>(w + o); };
   auto i16 = [&](size_t o) { return reinterpret_cast<int16_t *>(w + o); };
   aomhip_search_block *zl = reinterpret_cast<aomhip_search_block *>(w + o_zl), *cl = reinterpret_cast<aomhip_search_block *>(w + o_cl);
-  aomhip_var_cand *cands = reinterpret_cast<aomhip_var_cand *>(w + o_cand);
   const size_t esz = src->bit_depth == 8 ? 1 : 2;
   auto one = [&](const aomhip_planes *q, int f) {   // one frame of a ring as a ring of one: the batched searches pair src / ref by frame index
     aomhip_planes v = *q;
@@ -670,42 +680,67 @@ extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_plane
   const aomhip_planes s1 = one(src, src_frame), l1 = one(last, last_frame), ls1 = one(last_source, last_source_frame);
   const aomhip_planes g1 = golden ? one(golden, golden_frame) : s1;
   const unsigned g = (unsigned)((n1 + 255) / 256);
-  auto sse0 = [&](const aomhip_planes &ref, uint32_t *out) {   // get_prediction_error_bitdepth: the mse function's sse at 0,0 (:113-160)
+  struct LegMem { size_t var, cost, sse, cand; };
+  const LegMem mem_main{ o_var, o_cost, o_sse, o_cand }, mem_side{ o_var_g, o_cost_g, o_sse_g, o_cand_g };
+  auto sse0 = [&](aomhip_ctx *cx, const LegMem &m, const aomhip_planes &ref, uint32_t *out) {   // get_prediction_error_bitdepth: the mse function's sse at 0,0 (:113-160)
     const unsigned gv = (unsigned)((n1 + 3) / 4);
     if (src->bit_depth == 8)
-      hipLaunchKernelGGL(sms_var_kernel<uint8_t>, dim3(gv), dim3(256), 0, ctx->stream, view_of<uint8_t>(s1), 0, view_of<uint8_t>(ref), 0, bw, bh, 8, d_blocks,
-                         n, out, u32(o_var));
+      hipLaunchKernelGGL(sms_var_kernel<uint8_t>, dim3(gv), dim3(256), 0, cx->stream, view_of<uint8_t>(s1), 0, view_of<uint8_t>(ref), 0, bw, bh, 8, d_blocks,
+                         n, out, u32(m.var));
     else
-      hipLaunchKernelGGL(sms_var_kernel<uint16_t>, dim3(gv), dim3(256), 0, ctx->stream, view_of<uint16_t>(s1), 0, view_of<uint16_t>(ref), 0, bw, bh,
-                         src->bit_depth, d_blocks, n, out, u32(o_var));
+      hipLaunchKernelGGL(sms_var_kernel<uint16_t>, dim3(gv), dim3(256), 0, cx->stream, view_of<uint16_t>(s1), 0, view_of<uint16_t>(ref), 0, bw, bh,
+                         src->bit_depth, d_blocks, n, out, u32(m.var));
   };
   // one first_pass_motion_search leg of `m` listed blocks (the body of aomhip_first_pass_motion_search_batch on this call's work memory)
-  auto leg = [&](const aomhip_planes &ref, const aomhip_search_block *list, int m, int16_t *mv, int32_t *err) -> int {
-    int rc = aomhip_full_pixel_search_batch(ctx, &s1, &ref, 0, bw, bh, p, d_mvjcost, d_mvcost_row, d_mvcost_col, list, m, mv, i32(o_cost), nullptr, nullptr);
+  auto leg = [&](aomhip_ctx *cx, const LegMem &mm, const aomhip_planes &ref, const aomhip_search_block *list, int m, int16_t *mv, int32_t *err) -> int {
+    aomhip_var_cand *cd = reinterpret_cast<aomhip_var_cand *>(w + mm.cand);
+    int rc = aomhip_full_pixel_search_batch(cx, &s1, &ref, 0, bw, bh, p, d_mvjcost, d_mvcost_row, d_mvcost_col, list, m, mv, i32(mm.cost), nullptr, nullptr);
     if (rc != AOMHIP_OK) return rc;
     const unsigned gm = (unsigned)((m + 255) / 256);
-    hipLaunchKernelGGL(fp_cands_kernel, dim3(gm), dim3(256), 0, ctx->stream, list, mv, m, cands);
+    hipLaunchKernelGGL(fp_cands_kernel, dim3(gm), dim3(256), 0, cx->stream, list, mv, m, cd);
     AOMHIP_LAUNCH_CHECK();
-    rc = aomhip_variance_batch(ctx, &s1, &ref, 0, 1, bw, bh, cands, m, 0, u32(o_var), u32(o_sse));
+    rc = aomhip_variance_batch(cx, &s1, &ref, 0, 1, bw, bh, cd, m, 0, u32(mm.var), u32(mm.sse));
     if (rc != AOMHIP_OK) return rc;
-    hipLaunchKernelGGL(fp_finish_kernel, dim3(gm), dim3(256), 0, ctx->stream, list, mv, i32(o_cost), u32(o_sse), m, p->mv_cost_type, p->error_per_bit, d_mvjcost,
+    hipLaunchKernelGGL(fp_finish_kernel, dim3(gm), dim3(256), 0, cx->stream, list, mv, i32(mm.cost), u32(mm.sse), m, p->mv_cost_type, p->error_per_bit, d_mvjcost,
                        d_mvcost_row, d_mvcost_col, err);
     AOMHIP_LAUNCH_CHECK();
     return AOMHIP_OK;
   };
-  sse0(l1, u32(o_e0));
-  AOMHIP_LAUNCH_CHECK();
-  sse0(ls1, u32(o_raw));
-  AOMHIP_LAUNCH_CHECK();
   hipLaunchKernelGGL(fpf_zero_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, n, zl);
   AOMHIP_LAUNCH_CHECK();
-  int rc = leg(l1, zl, n, i16(o_zmv), i32(o_zerr));
+  sse0(ctx, mem_main, l1, u32(o_e0));
+  AOMHIP_LAUNCH_CHECK();
+  sse0(ctx, mem_main, ls1, u32(o_raw));
+  AOMHIP_LAUNCH_CHECK();
+  int rc = leg(ctx, mem_main, l1, zl, n, i16(o_zmv), i32(o_zerr));
   if (rc != AOMHIP_OK) return rc;
-  if (golden) {
-    sse0(g1, u32(o_gf0));
+  const char *force_cols = getenv("AOMHIP_FP_COLUMNS");   // (tests: the column-at-a-time form on the sizes the row kernel serves)
+  const bool by_rows = aomhip::fp_rows_supported(bw, bh) && !(force_cols && atoi(force_cols));
+  // The golden-frame leg depends on nothing the chain produces, and gf_motion_error (:777-794) on nothing of the chain: with the row kernel
+  // -- one workgroup per block row, a chip mostly idle -- it runs on the context's side stream BESIDE the chain, forked here and joined behind
+  // the chain kernel (whose wavefronts raise their priority: the chain is latency, the leg throughput).  AOMHIP_FP_SERIAL=1: one stream (A/B).
+  aomhip_ctx side = *ctx;
+  bool forked = false;
+  hipStream_t ss = nullptr;
+  auto golden_leg = [&]() -> int {
+    aomhip_ctx *cx = forked ? &side : ctx;
+    const LegMem &mm = forked ? mem_side : mem_main;
+    sse0(cx, mm, g1, u32(o_gf0));
     AOMHIP_LAUNCH_CHECK();
-    rc = leg(g1, zl, n, i16(o_gmv), i32(o_gerr));
-    if (rc != AOMHIP_OK) return rc;
+    return leg(cx, mm, g1, zl, n, i16(o_gmv), i32(o_gerr));
+  };
+  if (golden) {
+    static const bool serial = [] { const char *e = getenv("AOMHIP_FP_SERIAL"); return e && atoi(e) != 0; }();
+    ss = (serial || !by_rows) ? nullptr : aomhip::side_stream(ctx);
+    if (ss) {
+      side.stream = ss;
+      AOMHIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+      AOMHIP_TRY(hipStreamWaitEvent(ss, ctx->ev_fork, 0));
+      forked = true;
+    } else {
+      rc = golden_leg();
+      if (rc != AOMHIP_OK) return rc;
+    }
   }
   AOMHIP_TRY(hipMemsetAsync(w + o_chain, 0, r1 * 4, ctx->stream));   // MV best_ref_mv = kZeroMv at the start of every row (:1165)
   aomhip::FpfLegs L;
@@ -714,12 +749,27 @@ extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_plane
   L.cmv = i16(o_cmv); L.cerr = i32(o_cerr);
   L.err0 = u32(o_e0); L.raw = u32(o_raw); L.gf0 = u32(o_gf0);
   aomhip::FpfCost C{ p->mv_cost_type, p->error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col };
-  // the chain: one launch, a wavefront per row (fp_row.hip) -- or, for block sizes that kernel is not built for, column by column
-  const char *force_cols = getenv("AOMHIP_FP_COLUMNS");   // (tests: the column-at-a-time form on the sizes the row kernel serves)
-  if (aomhip::fp_rows_supported(bw, bh) && !(force_cols && atoi(force_cols))) {
-    const aomhip::FpfOut out{ d_best_mv, d_full_mv, d_motion_error, d_gf_motion_error, d_raw_motion_error };
-    return aomhip::launch_fp_rows(ctx, &s1, &l1, bw, bh, p, d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, L, d_intra_error, rows, cols,
-                                  fp->skip_motion_search_threshold, fp->skip_zeromv_motion_search, out);
+  // the chain: one launch, a workgroup per row (fp_row.hip) -- or, for block sizes that kernel is not built for, column by column
+  if (by_rows) {
+    aomhip::FpfOut out{ d_best_mv, d_full_mv, d_motion_error, d_gf_motion_error, d_raw_motion_error };
+    if (forked) {   // the golden leg is still running beside this: gf_motion_error does not depend on the chain, it follows the join
+      L.gerr = nullptr;
+      out.gf_motion_error = nullptr;
+    }
+    rc = aomhip::launch_fp_rows(ctx, &s1, &l1, bw, bh, p, d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, L, d_intra_error, rows, cols,
+                                fp->skip_motion_search_threshold, fp->skip_zeromv_motion_search, out);
+    if (forked) {
+      const int rcg = golden_leg();   // (queued behind the chain kernel's launch: the chain's workgroups are placed first)
+      AOMHIP_TRY(hipEventRecord(ctx->ev_join, ss));   // joined on every path: a capture of ctx->stream must not end forked
+      AOMHIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+      if (rc == AOMHIP_OK) rc = rcg;
+      if (rc == AOMHIP_OK && d_gf_motion_error) {
+        hipLaunchKernelGGL(fp_gf_kernel, dim3(g), dim3(256), 0, ctx->stream, u32(o_raw), u32(o_e0), u32(o_gf0), i32(o_gerr), fp->skip_motion_search_threshold, n,
+                           d_gf_motion_error);
+        AOMHIP_LAUNCH_CHECK();
+      }
+    }
+    return rc;
   }
   aomhip_search_block *cl2 = reinterpret_cast<aomhip_search_block *>(w + o_cl2);
   const unsigned gw = (unsigned)((r1 + 3) / 4);
