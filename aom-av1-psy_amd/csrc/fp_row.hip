@@ -184,7 +184,7 @@ int launch_fp_rows(aomhip_ctx *ctx, const aomhip_planes *src1, const aomhip_plan
   }
   const SearchArgs q = fps_search_args(p, d_mvjcost, d_mvcost_row, d_mvcost_col, src1->bit_depth, false);
   const FpfCost C{ p->mv_cost_type, p->error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col };
-  static const int spec = [] { const char *e = getenv("AOMHIP_FP_ROW_WAVES"); const int v = e ? atoi(e) : 8; return v == 1 || v == 4 || v == 16 ? v : 8; }();   // (A/B)
+  const int spec = [] { const char *e = getenv("AOMHIP_FP_ROW_WAVES"); const int v = e ? atoi(e) : 8; return v == 1 || v == 4 || v == 16 ? v : 8; }();   // (A/B, tests)
 #define XP(T, W, H, P)                                                                                                                   \
   hipLaunchKernelGGL((fp_row_kernel<T, W, H, P>), dim3(rows), dim3(P * 64), 0, ctx->stream, view_of<T>(*src1), view_of<T>(*last1),       \
                      d_blocks, d_sites, q, L, C, d_intra, rows, cols, thr, skip_zeromv, out);

@@ -730,7 +730,7 @@ extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_plane
     return leg(cx, mm, g1, zl, n, i16(o_gmv), i32(o_gerr));
   };
   if (golden) {
-    static const bool serial = [] { const char *e = getenv("AOMHIP_FP_SERIAL"); return e && atoi(e) != 0; }();
+    const bool serial = [] { const char *e = getenv("AOMHIP_FP_SERIAL"); return e && atoi(e) != 0; }();
     ss = (serial || !by_rows) ? nullptr : aomhip::side_stream(ctx);
     if (ss) {
       side.stream = ss;
