@@ -274,6 +274,135 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
   }
 }
 
+// ---- av1_find_best_obmc_sub_pixel_tree_up (mcomp.c:3588-3633): the sub-pel half of the OBMC motion search.  One wavefront per block, the
+// candidates of obmc_first_level_check / obmc_second_level_check_v2 one after the other in the reference's order (they are few -- at most 8
+// per precision -- and each needs a filtered prediction before the weighted difference), every evaluation by all 64 lanes pixel by pixel:
+//   USE_2_TAPS_ORIG  vfp->osvf = aom_[highbd_]obmc_sub_pixel_variance (variance.c:1002-1062 / :1194-1330: the two bilinear passes, each rounded
+//                    by FILTER_BITS, then obmc_variance) + estimate_obmc_mvcost (:3390-3412); the centre by setup_obmc_center_error (:3359-3374),
+//                    which measures ms_buffers->ref->buf -- MV 0 -- whatever the start MV is (the reference's own TODO; reproduced)
+//   USE_8_TAPS       upsampled_obmc_pref_error (:3314-3357): aom_[highbd_]upsampled_pred = the 8-tap regular kernel of phase 2 * (mv & 7),
+//                    horizontal then vertical pass, each rounded and clipped (taps 0 and 7 are zero in every phase: six taps), then vfp->ovf,
+//                    + mv_err_cost_
+__device__ constexpr int16_t kObmcSubPel8[16][6] = {   // av1_sub_pel_filters_8 (av1/common/filter.h:124-141), taps 1 .. 6
+  { 0, 0, 128, 0, 0, 0 },      { 2, -6, 126, 8, -2, 0 },    { 2, -10, 122, 18, -4, 0 },  { 2, -12, 116, 28, -8, 2 },
+  { 2, -14, 110, 38, -10, 2 }, { 2, -14, 102, 48, -12, 2 }, { 2, -16, 94, 58, -12, 2 },  { 2, -14, 84, 66, -12, 2 },
+  { 2, -14, 76, 76, -14, 2 },  { 2, -12, 66, 84, -14, 2 },  { 2, -12, 58, 94, -16, 2 },  { 2, -12, 48, 102, -14, 2 },
+  { 2, -10, 38, 110, -14, 2 }, { 2, -8, 28, 116, -12, 2 },  { 0, -4, 18, 122, -10, 2 },  { 0, -2, 8, 126, -6, 2 }
+};
+struct ObmcSubpelArgs { int iters_per_step, allow_hp, forced_stop, upsampled; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
+                                                               CompoundArgs a, ObmcSubpelArgs sa, const int32_t *__restrict__ wsrc_all,
+                                                               const int32_t *__restrict__ omask_all, int16_t *__restrict__ out_mv,
+                                                               uint32_t *__restrict__ out_err, int32_t *__restrict__ out_dist, uint32_t *__restrict__ out_sse) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * 4 + wave;
+  if (bi >= n_blocks) return;
+  const BlockScalars bs = BlockScalars::of(blocks[bi]);   // start_* in 1/8 pel, limits = SubpelMvLimits
+  const int bx = __builtin_amdgcn_readfirstlane((int)blocks[bi].bx), by = __builtin_amdgcn_readfirstlane((int)blocks[bi].by);
+  const int W = a.bw, H = a.bh, n_px = W * H;
+  const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)by * ref.stride + bx;
+  const int32_t *wsrc = wsrc_all + (size_t)bi * n_px, *omask = omask_all + (size_t)bi * n_px;
+  const int pmax = sizeof(T) == 1 ? 255 : (1 << a.bit_depth) - 1;
+  constexpr uint8_t kBil[8][2] = { { 128, 0 }, { 112, 16 }, { 96, 32 }, { 80, 48 }, { 64, 64 }, { 48, 80 }, { 32, 96 }, { 16, 112 } };  // aom_filter.h:43-50
+  // obmc_variance of the prediction at (mrow, mcol): form 0 = the plain block at the full-pel part (ovf), 1 = bilinear (osvf), 2 = up-sampled
+  auto obmc_err = [&](int mrow, int mcol, int form, uint32_t *sse_out) -> uint32_t {
+    const T *rp = rbase + (int64_t)(mrow >> 3) * ref.stride + (mcol >> 3);
+    const int sx = mcol & 7, sy = mrow & 7;
+    const int fx0 = kBil[sx][0], fx1 = kBil[sx][1], fy0 = kBil[sy][0], fy1 = kBil[sy][1];
+    int64_t s = 0, q = 0;
+    for (int t = lane; t < n_px; t += 64) {
+      const int y = t / W, x = t - y * W;
+      const T *p = rp + (int64_t)y * ref.stride + x;
+      int pv;
+      if (form == 0) {
+        pv = (int)p[0];
+      } else if (form == 1) {   // aom_var_filter_block2d_bil_first_pass / _second_pass
+        const int h0 = ((int)p[0] * fx0 + (int)p[1] * fx1 + 64) >> 7;
+        const int h1 = ((int)p[ref.stride] * fx0 + (int)p[ref.stride + 1] * fx1 + 64) >> 7;
+        pv = (h0 * fy0 + h1 * fy1 + 64) >> 7;
+      } else {
+        auto hrow = [&](int dy) -> int {   // the horizontal pass at row y + dy
+          const T *r = p + (int64_t)dy * ref.stride;
+          if (!sx) return (int)r[0];
+          int sum = 0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) sum += (int)r[k - 2] * kObmcSubPel8[2 * sx][k];
+          return min(max((sum + 64) >> 7, 0), pmax);
+        };
+        if (!sy) {
+          pv = hrow(0);
+        } else {
+          int sum = 0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) sum += hrow(k - 2) * kObmcSubPel8[2 * sy][k];
+          pv = min(max((sum + 64) >> 7, 0), pmax);
+        }
+      }
+      const int v = wsrc[t] - pv * omask[t];
+      const int d = v < 0 ? -((-v + 2048) >> 12) : (v + 2048) >> 12;   // ROUND_POWER_OF_TWO_SIGNED(v, 12)
+      s += d;
+      q += (uint32_t)(d * d);
+    }
+    const int64_t s64 = wsum(s);
+    const uint64_t q64 = (uint64_t)wsum(q);
+    *sse_out = a.bit_depth == 10 ? (uint32_t)((q64 + 8) >> 4) : a.bit_depth == 12 ? (uint32_t)((q64 + 128) >> 8) : (uint32_t)q64;
+    return finish_var(s64, q64, n_px, a.bit_depth);
+  };
+  auto est_cost = [&](int mrow, int mcol) -> uint32_t {   // estimate_obmc_mvcost: the difference x 8 (GET_MV_SUBPEL), 13-bit rounding; 0 but for ENTROPY
+    if (a.cost_type != kCostEntropy) return 0u;
+    const int dr = (mrow - bs.ref_row) * 8, dc = (mcol - bs.ref_col) * 8;
+    return ((unsigned)mv_bits(a, dr, dc) * (unsigned)a.error_per_bit + 4096u) >> 13;
+  };
+  uint32_t besterr, sse1;
+  int distortion, best_row = bs.start_row, best_col = bs.start_col;
+  {
+    uint32_t q;
+    const uint32_t v = sa.upsampled ? obmc_err(best_row, best_col, 2, &q) : obmc_err(0, 0, 0, &q);
+    distortion = (int)v; sse1 = q;
+    besterr = v + (uint32_t)var_cost(a, bs.ref_row, bs.ref_col, best_row, best_col);
+  }
+  auto check = [&](int mrow, int mcol, int *has_better) -> uint32_t {   // obmc_check_better / obmc_check_better_fast
+    if (mcol < bs.col_min || mcol > bs.col_max || mrow < bs.row_min || mrow > bs.row_max) return (uint32_t)INT_MAX;
+    uint32_t q;
+    const int thismse = (int)obmc_err(mrow, mcol, sa.upsampled ? 2 : 1, &q);
+    uint32_t cost = sa.upsampled ? (uint32_t)var_cost(a, bs.ref_row, bs.ref_col, mrow, mcol) : est_cost(mrow, mcol);
+    cost += (uint32_t)thismse;
+    if (cost < besterr) {
+      besterr = cost; best_row = mrow; best_col = mcol; distortion = thismse; sse1 = q;
+      *has_better |= 1;
+    }
+    return cost;
+  };
+  int hstep = 4;   // INIT_SUBPEL_STEP_SIZE
+  const int round = min(3 - sa.forced_stop, 3 - (sa.allow_hp ? 0 : 1));
+  for (int iter = 0; iter < round; ++iter) {
+    const int tr = best_row, tc = best_col;
+    int dummy = 0;
+    const uint32_t left = check(tr, tc - hstep, &dummy), right = check(tr, tc + hstep, &dummy);
+    const uint32_t up = check(tr - hstep, tc, &dummy), down = check(tr + hstep, tc, &dummy);
+    int drow = up <= down ? -hstep : hstep, dcol = left <= right ? -hstep : hstep;   // get_best_diag_step (:2490-2498)
+    check(tr + drow, tc + dcol, &dummy);
+    if ((tr != best_row || tc != best_col) && sa.iters_per_step > 1) {   // obmc_second_level_check_v2 (:3535-3586)
+      if (tr == best_row) drow = -drow;
+      else if (tc == best_col) dcol = -dcol;
+      const int br = best_row, bc = best_col;
+      int has_better = 0;
+      check(br + drow, bc, &has_better);
+      check(br, bc + dcol, &has_better);
+      if (has_better) check(br + drow, bc + dcol, &has_better);
+    }
+    hstep >>= 1;
+  }
+  if (lane == 0) {
+    out_mv[2 * bi] = (int16_t)best_row; out_mv[2 * bi + 1] = (int16_t)best_col;
+    out_err[bi] = besterr;
+    if (out_dist) out_dist[bi] = distortion;
+    if (out_sse) out_sse[bi] = sse1;
+  }
+}
+
 int check_compound(aomhip_ctx *ctx, const aomhip_planes *ref, int frame, int bw, int bh, const void *blocks, int n, int cost_type, const int32_t *j,
                    const int32_t *c0, const int32_t *c1, const char *who) {
   if (!ctx || !ref || !ref->base || n < 0 || (n > 0 && !blocks) || frame < 0 || frame >= ref->n_frames || !valid_block(bw, bh) || cost_type < 0 ||
@@ -352,6 +481,35 @@ int aomhip_obmc_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *re
   else
     hipLaunchKernelGGL(obmc_full_pixel_search_kernel<uint16_t>, grid, block, 0, ctx->stream, view_of<uint16_t>(*ref), frame, d_blocks, n_blocks, a, d_sites,
                        step_param, fast_obmc_search != 0, d_wsrc, d_obmc_mask, d_best_mv, d_best_cost);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+int aomhip_obmc_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int frame, int bw, int bh, const aomhip_subpel_params *params,
+                                  const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks,
+                                  int n_blocks, const int32_t *d_wsrc, const int32_t *d_obmc_mask, int16_t *d_best_mv, uint32_t *d_best_err,
+                                  int32_t *d_distortion, uint32_t *d_sse) {
+  if (!params) {
+    set_error("aomhip_obmc_subpel_tree_batch: null params");
+    return AOMHIP_ERR_INVALID;
+  }
+  int rc = check_compound(ctx, ref, frame, bw, bh, d_blocks, n_blocks, params->mv_cost_type, d_mvjcost, d_mvcost_row, d_mvcost_col, "aomhip_obmc_subpel_tree_batch");
+  if (rc != AOMHIP_OK) return rc;
+  if ((params->subpel_search_type != 0 && params->subpel_search_type != 3) || params->forced_stop < 0 || params->forced_stop > 3 || !d_wsrc || !d_obmc_mask ||
+      !d_best_mv || !d_best_err) {
+    set_error("aomhip_obmc_subpel_tree_batch: invalid argument (subpel_search_type USE_2_TAPS_ORIG 0 or USE_8_TAPS 3)");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  const CompoundArgs a{ bw, bh, ref->bit_depth, params->mv_cost_type, 0, params->error_per_bit, 0, d_mvjcost, d_mvcost_row, d_mvcost_col };
+  const ObmcSubpelArgs sa{ params->iters_per_step, params->allow_hp, params->forced_stop, params->subpel_search_type == 3 };
+  const dim3 grid((n_blocks + 3) / 4), block(256);
+  if (ref->bit_depth == 8)
+    hipLaunchKernelGGL(obmc_subpel_tree_kernel<uint8_t>, grid, block, 0, ctx->stream, view_of<uint8_t>(*ref), frame, d_blocks, n_blocks, a, sa, d_wsrc,
+                       d_obmc_mask, d_best_mv, d_best_err, d_distortion, d_sse);
+  else
+    hipLaunchKernelGGL(obmc_subpel_tree_kernel<uint16_t>, grid, block, 0, ctx->stream, view_of<uint16_t>(*ref), frame, d_blocks, n_blocks, a, sa, d_wsrc,
+                       d_obmc_mask, d_best_mv, d_best_err, d_distortion, d_sse);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

@@ -643,6 +643,17 @@ int aomhip_obmc_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *re
                                         int fast_obmc_search, int mv_cost_type, int sad_per_bit, int error_per_bit, const int32_t *d_mvjcost,
                                         const int32_t *d_mvcost_row, const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, int n_blocks,
                                         const int32_t *d_wsrc, const int32_t *d_obmc_mask, int16_t *d_best_mv, int32_t *d_best_cost);
+/* av1_find_best_obmc_sub_pixel_tree_up (mcomp.c:3588-3633) for every block: the sub-pel half of the OBMC search (the branch of
+ * av1_single_motion_search for OBMC_CAUSAL, motion_search_facade.c:432-445).  params: iters_per_step, allow_hp, forced_stop, mv_cost_type,
+ * error_per_bit and subpel_search_type -- 0 USE_2_TAPS_ORIG: vfp->osvf + estimate_obmc_mvcost (:3390-3412; ENTROPY or NONE, the L1 types
+ * cost 0 as in a release build of the reference), the centre measured by setup_obmc_center_error at MV 0 as the reference does; 3 USE_8_TAPS:
+ * upsampled_obmc_pref_error (aom_[highbd_]upsampled_pred + vfp->ovf) + mv_err_cost_ -- `tree` is ignored.  Blocks as aomhip_subpel_tree_batch
+ * (start MV and limits in 1/8 pel), d_wsrc / d_obmc_mask as aomhip_obmc_full_pixel_search_batch.  Outputs: best MV (1/8 pel), besterr (the
+ * return value), *distortion, *sse1 (the last two may be NULL). */
+int aomhip_obmc_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int frame, int bw, int bh, const aomhip_subpel_params *params,
+                                  const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks,
+                                  int n_blocks, const int32_t *d_wsrc, const int32_t *d_obmc_mask, int16_t *d_best_mv, uint32_t *d_best_err,
+                                  int32_t *d_distortion, uint32_t *d_sse);
 
 /* The site table av1_init_motion_compensation[search_method_lookup[method]] builds (mcomp.c:350-634), without the
  * stride-dependent offsets: sites[stage][index] = {row, col}; index 0 is the centre for the diamond / n-step tables,

@@ -1311,3 +1311,114 @@ void orc_obmc_full_pixel_search_batch(const void *ref_origin, int ref_stride, in
     best_mv[2 * i] = (int16_t)r; best_mv[2 * i + 1] = (int16_t)c;
   }
 }
+
+/* ---- av1_find_best_obmc_sub_pixel_tree_up (mcomp.c:3588-3633) ----
+ * subpel_search_type USE_2_TAPS_ORIG: the centre by setup_obmc_center_error (:3359-3374 -- vfp->ovf at ms_buffers->ref->buf, i.e. at MV 0
+ * whatever the start MV is: the reference's own TODO) and candidates by obmc_check_better_fast (:3416-3442: vfp->osvf + estimate_obmc_mvcost,
+ * :3390-3412, whose difference MV is multiplied by 8 and whose ENTROPY form rounds by 13 bits); USE_8_TAPS: centre and candidates by
+ * upsampled_obmc_pref_error (:3314-3357: aom_[highbd_]upsampled_pred, then vfp->ovf on the w-pitch prediction) + mv_err_cost_. */
+typedef struct {
+  const obmc_ctx *oc;
+  int upsampled;
+  int row_min, row_max, col_min, col_max;
+  unsigned besterr;
+  int best_row, best_col, distortion;
+  uint32_t sse1;
+} obmc_subpel_state;
+static unsigned obmc_upsampled_err(const obmc_ctx *oc, int mrow, int mcol, uint32_t *sse) {
+  const search_ctx *c = &oc->c;
+  const int n = c->w * c->h;
+  uint16_t *pred = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)n);
+  upsampled_pred8(c, mrow, mcol, pred);
+  unsigned v;
+  if (c->elem16) {
+    v = orc_obmc_variance(pred, c->w, 0, 0, 0, oc->wsrc, oc->omask, c->w, c->h, 1, c->bd, sse);
+  } else {
+    uint8_t *p8 = (uint8_t *)malloc((size_t)n);
+    for (int i = 0; i < n; ++i) p8[i] = (uint8_t)pred[i];
+    v = orc_obmc_variance(p8, c->w, 0, 0, 0, oc->wsrc, oc->omask, c->w, c->h, 0, c->bd, sse);
+    free(p8);
+  }
+  free(pred);
+  return v;
+}
+static int estimate_obmc_mvcost(const search_ctx *c, int mrow, int mcol) {
+  if (c->cost_type != 0) return 0; /* MV_COST_NONE: 0; the L1 types: assert(0) in the reference, 0 in a release build */
+  const int dr = (mrow - c->ref_row) * 8, dc = (mcol - c->ref_col) * 8; /* GET_MV_SUBPEL of a 1/8-pel difference */
+  const int bits = c->mvjcost[(dc != 0) | ((dr != 0) << 1)] + c->mvcost[0][dr] + c->mvcost[1][dc];
+  return (int)(((unsigned)bits * (unsigned)c->error_per_bit + 4096u) >> 13);
+}
+static unsigned obmc_check_better(obmc_subpel_state *s, int mrow, int mcol, int *has_better) {
+  if (mcol < s->col_min || mcol > s->col_max || mrow < s->row_min || mrow > s->row_max) return INT_MAX;
+  const search_ctx *c = &s->oc->c;
+  uint32_t sse;
+  int thismse;
+  unsigned cost;
+  if (s->upsampled) {
+    thismse = (int)obmc_upsampled_err(s->oc, mrow, mcol, &sse);
+    cost = (unsigned)mv_cost_var(c, mrow, mcol);
+  } else {
+    const void *rp = (const char *)c->ref + ((ptrdiff_t)(mrow >> 3) * c->ref_stride + (mcol >> 3)) * (ptrdiff_t)(c->elem16 ? 2 : 1);
+    thismse = (int)orc_obmc_variance(rp, c->ref_stride, 1, mcol & 7, mrow & 7, s->oc->wsrc, s->oc->omask, c->w, c->h, c->elem16, c->bd, &sse);
+    cost = (unsigned)estimate_obmc_mvcost(c, mrow, mcol);
+  }
+  cost += (unsigned)thismse;
+  if (cost < s->besterr) {
+    s->besterr = cost; s->best_row = mrow; s->best_col = mcol; s->distortion = thismse; s->sse1 = sse;
+    *has_better |= 1;
+  }
+  return cost;
+}
+void orc_obmc_subpel_tree_batch(const void *ref_origin, int ref_stride, int elem16, int bd, int w, int h, const void *blocks_v, int n, int cost_type,
+                                int error_per_bit, const int *mvjcost, const int *mvcost0, const int *mvcost1, int iters_per_step, int allow_hp,
+                                int forced_stop, int upsampled, const int32_t *wsrc, const int32_t *omask, int16_t *best_mv, uint32_t *best_err,
+                                int32_t *distortion, uint32_t *sse1, int threads) {
+  const orc_subpel_block *blocks = (const orc_subpel_block *)blocks_v;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4)
+  for (int i = 0; i < n; ++i) {
+    const orc_subpel_block *b = &blocks[i];
+    obmc_ctx oc;
+    memset(&oc, 0, sizeof(oc));
+    oc.c.ref = (const char *)ref_origin + ((ptrdiff_t)b->by * ref_stride + b->bx) * (ptrdiff_t)(elem16 ? 2 : 1);
+    oc.c.ref_stride = ref_stride; oc.c.elem16 = elem16; oc.c.bd = bd; oc.c.w = w; oc.c.h = h;
+    oc.c.cost_type = cost_type; oc.c.ref_row = b->ref_row; oc.c.ref_col = b->ref_col;
+    oc.c.mvjcost = mvjcost; oc.c.mvcost[0] = mvcost0; oc.c.mvcost[1] = mvcost1; oc.c.error_per_bit = error_per_bit;
+    oc.wsrc = wsrc + (size_t)i * w * h; oc.omask = omask + (size_t)i * w * h;
+    obmc_subpel_state s;
+    memset(&s, 0, sizeof(s));
+    s.oc = &oc; s.upsampled = upsampled;
+    s.row_min = b->row_min; s.row_max = b->row_max; s.col_min = b->col_min; s.col_max = b->col_max;
+    s.best_row = b->start_row; s.best_col = b->start_col;
+    if (upsampled) {
+      s.distortion = (int)obmc_upsampled_err(&oc, s.best_row, s.best_col, &s.sse1);
+    } else { /* setup_obmc_center_error: ovf at ref->buf, NOT at the start MV */
+      s.distortion = (int)orc_obmc_variance(oc.c.ref, ref_stride, 0, 0, 0, oc.wsrc, oc.omask, w, h, elem16, bd, &s.sse1);
+    }
+    s.besterr = (unsigned)s.distortion + (unsigned)mv_cost_var(&oc.c, s.best_row, s.best_col);
+    int hstep = 4; /* INIT_SUBPEL_STEP_SIZE */
+    const int round = (3 - forced_stop) < (3 - !allow_hp) ? (3 - forced_stop) : (3 - !allow_hp);
+    for (int iter = 0; iter < round; ++iter) {
+      const int tr = s.best_row, tc = s.best_col;
+      int dummy = 0;
+      /* obmc_first_level_check (:3471-3533) */
+      const unsigned left = obmc_check_better(&s, tr, tc - hstep, &dummy);
+      const unsigned right = obmc_check_better(&s, tr, tc + hstep, &dummy);
+      const unsigned up = obmc_check_better(&s, tr - hstep, tc, &dummy);
+      const unsigned down = obmc_check_better(&s, tr + hstep, tc, &dummy);
+      int drow = up <= down ? -hstep : hstep, dcol = left <= right ? -hstep : hstep;
+      obmc_check_better(&s, tr + drow, tc + dcol, &dummy);
+      if ((tr != s.best_row || tc != s.best_col) && iters_per_step > 1) { /* obmc_second_level_check_v2 (:3535-3586) */
+        if (tr == s.best_row) drow = -drow;
+        else if (tc == s.best_col) dcol = -dcol;
+        const int br = s.best_row, bc = s.best_col;
+        int has_better = 0;
+        obmc_check_better(&s, br + drow, bc, &has_better);
+        obmc_check_better(&s, br, bc + dcol, &has_better);
+        if (has_better) obmc_check_better(&s, br + drow, bc + dcol, &has_better);
+      }
+      hstep >>= 1;
+    }
+    best_mv[2 * i] = (int16_t)s.best_row; best_mv[2 * i + 1] = (int16_t)s.best_col;
+    best_err[i] = s.besterr; distortion[i] = s.distortion; sse1[i] = s.sse1;
+  }
+}

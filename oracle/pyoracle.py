@@ -1243,3 +1243,21 @@ def obmc_full_pixel_search_batch(ref_b, border, w, h, blocks, wsrc, obmc_mask, m
                                          int(fast_obmc_search), cost_type, sad_per_bit, error_per_bit, j, c0, c1, C.c_void_p(ws.ctypes.data),
                                          C.c_void_p(om.ctypes.data), C.c_void_p(mv.ctypes.data), C.c_void_p(cost.ctypes.data), threads)
     return mv, cost
+
+
+def obmc_subpel_tree_batch(ref_b, border, w, h, blocks, wsrc, obmc_mask, cost_type=4, error_per_bit=0, mvjcost=None, mvcost0=None, mvcost1=None,
+                           iters_per_step=2, allow_hp=1, forced_stop=0, subpel_search_type=0, bd=8, threads=4):
+    """av1_find_best_obmc_sub_pixel_tree_up per block (blocks: subpel_block_dtype, start / limits in 1/8 pel; subpel_search_type 0 =
+    USE_2_TAPS_ORIG, 3 = USE_8_TAPS).  wsrc / obmc_mask [n, h, w] int32.  -> mv [n, 2], err [n], distortion [n], sse [n]"""
+    blocks = np.ascontiguousarray(blocks)
+    n = len(blocks)
+    ws = np.ascontiguousarray(wsrc, np.int32).reshape(n, h * w); om = np.ascontiguousarray(obmc_mask, np.int32).reshape(n, h * w)
+    mv = np.zeros((n, 2), np.int16); err = np.zeros(n, np.uint32); dist = np.zeros(n, np.int32); sse = np.zeros(n, np.uint32)
+    keep = []
+    j, c0, c1 = _cost_tables(mvjcost, mvcost0, mvcost1, keep)
+    lib.orc_obmc_subpel_tree_batch.restype = None
+    lib.orc_obmc_subpel_tree_batch(C.c_void_p(_addr(ref_b, border, border)), ref_b.shape[1], int(ref_b.dtype != np.uint8), bd, w, h,
+                                   C.c_void_p(blocks.ctypes.data), n, cost_type, error_per_bit, j, c0, c1, iters_per_step, allow_hp, forced_stop,
+                                   int(subpel_search_type != 0), C.c_void_p(ws.ctypes.data), C.c_void_p(om.ctypes.data), C.c_void_p(mv.ctypes.data),
+                                   C.c_void_p(err.ctypes.data), C.c_void_p(dist.ctypes.data), C.c_void_p(sse.ctypes.data), threads)
+    return mv, err, dist, sse
