@@ -116,12 +116,14 @@ __global__ __launch_bounds__(WAVES * 64, CELL ? 8 : 5) void fullpel_diamond_kern
           const uint32_t so = (uint32_t)(__mul24(site_loff, r) + base);
           if (active) {
             uint32_t d[NU][G::UB / 4 + 1];
-            unsigned sh[NU];
+            // (the window's pitch is a multiple of 4 bytes: every unit of the lane has the byte phase of its first one, and its dword address
+            // is the first one's + k * lstep -- one mask and NU - 1 adds instead of a shift, a mask and a base add per unit)
+            const uint32_t o0 = so + loff0;
+            const unsigned sh = o0 & 3;
+            const uint32_t *p0 = cell_lds + (o0 >> 2);
 #pragma unroll
             for (int k = 0; k < NU; ++k) {
-              const uint32_t o = so + loff0 + (uint32_t)k * lstep;
-              const uint32_t *p = cell_lds + (o >> 2);
-              sh[k] = o & 3;
+              const uint32_t *p = p0 + k * (int)(lstep >> 2);
 #pragma unroll
               for (int i = 0; i <= G::UB / 4; ++i) d[k][i] = p[i];
             }
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(WAVES * 64, CELL ? 8 : 5) void fullpel_diamond_kern
               if (l + 8 * k < G::U) {
 #pragma unroll
                 for (int i = 0; i < G::UB / 4; ++i) {
-                  const uint32_t v = __builtin_amdgcn_alignbyte(d[k][i + 1], d[k][i], sh[k]);
+                  const uint32_t v = __builtin_amdgcn_alignbyte(d[k][i + 1], d[k][i], sh);
                   if ((k * (G::UB / 4) + i) & 1) a1 = sadw<T>(srcu[k].v[i], v, a1); else a0 = sadw<T>(srcu[k].v[i], v, a0);
                 }
               }
@@ -180,25 +182,35 @@ __global__ __launch_bounds__(WAVES * 64, CELL ? 8 : 5) void fullpel_diamond_kern
     start_sad = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)__builtin_amdgcn_readlane((int)s0, 0) + (uint32_t)(lambda * (iabsm(start_row - frr) + iabsm(start_col - frc)))));
   }
 
+  // How far the centre is from the nearest MV limit / from the nearest edge of the window (scalars): a round of radius r lies inside the
+  // limits iff r <= lim_margin and inside the window iff r <= win_margin -- one compare each per round instead of eight; the margins change
+  // only when the centre moves (a round in four), and every run starts at the same centre.
+  auto lim_margin_of = [&](int row, int col) { return min(min(row - row_min, row_max - row), min(col - col_min, col_max - col)); };
+  auto win_margin_of = [&](int row, int col) -> int {
+    if constexpr (CELL && G::KEEP)
+      return min(min(b.bx + col - cw.x0, cw.x1 - (b.bx + col + W)), min(b.by + row - cw.y0, cw.y1 - (b.by + row + H)));
+    else return -1;
+  };
+  const int lim_margin0 = lim_margin_of(start_row, start_col), win_margin0 = win_margin_of(start_row, start_col);
+
   auto run_diamond = [&](int search_step, int *num00, int *orow, int *ocol) -> int {
     int row = start_row, col = start_col;
+    int lim_margin = lim_margin0, win_margin = win_margin0;
     const int tot_steps = 11 - search_step;
     *num00 = 0;
     uint32_t bestsad = start_sad;
     int is_off_center = 0;
-    int next_step_size = tot_steps > 2 ? radius(tot_steps - 2) : 1;
     for (int step = tot_steps - 1; step >= 0; --step) {
       const int r = radius(step);
-      if (step > 0) next_step_size = radius(step - 1);
       [[maybe_unused]] const unsigned long long t_r0 = CELL_T();
       // the whole diamond inside the limits (the usual case): no per-site test
-      const bool all_in = row - r >= row_min && row + r <= row_max && col - r >= col_min && col + r <= col_max;   // (scalar)
+      const bool all_in = r <= lim_margin;   // (scalar)
       bool inr = true;
       if (!all_in) {
         const int srow = row + dr * r, scol = col + dc * r;
         inr = scol >= col_min && scol <= col_max && srow >= row_min && srow <= row_max;
       }
-      const bool in_win = win_covers(row, col, r);
+      const bool in_win = r <= win_margin;
       const uint32_t mine = round_sad(row, col, r, inr, in_win) >> shift;
       // The reference walks the 8 sites in order with `if (sad < best) { sad += cost; if (sad < best) take it }` (mcomp.c:1350-1395): since
       // the L1 costs of this kernel are never negative that is "the FIRST site that attains the smallest sad + cost, if that is below the
@@ -225,13 +237,14 @@ __global__ __launch_bounds__(WAVES * 64, CELL ? 8 : 5) void fullpel_diamond_kern
         row += ((int)((kSiteDr >> (2 * best_site)) & 3u) - 1) * r;
         col += ((int)((kSiteDc >> (2 * best_site)) & 3u) - 1) * r;
         is_off_center = 1;
+        lim_margin = lim_margin_of(row, col);
+        win_margin = win_margin_of(row, col);
       }
       if (is_off_center == 0) (*num00)++;
-      if (best_site == 0) {
-        while (next_step_size == radius(step) && step > 2) {
+      if (level > 0 && best_site == 0) {   // (equal consecutive radii exist only in the clamped table: radius(k) = 2^k otherwise)
+        while (step > 2 && radius(step - 1) == radius(step)) {
           ++(*num00);
           --step;
-          next_step_size = radius(step - 1);
         }
       }
 #ifdef AOMHIP_CELL_PROF
