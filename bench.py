@@ -710,6 +710,31 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
             # dependent stages, so this is the rate at which the stage moves its algorithmic bytes through the cache hierarchy
             stages[name]["cache_resident_GBs"] = stage_bytes[name] / (ms * 1e-3) / 1e9
             stages[name]["cache_resident_rate_over_8TBs"] = stages[name]["cache_resident_GBs"] / HBM_PEAK_GBS
+    # Each stage's own roofline: these kernels are bound by instruction issue, not by bytes.  VALU wave-instructions per launch come from the
+    # committed PMC passes (profiles/r04_inner_loop_pmc.json, tools/r04_pmc_stages.sh: SQ_INSTS_VALU / SQ_WAVES of the same kernel x the launch's
+    # wavefronts); a SIMD retires one wave64 VALU instruction per 4 clocks, so the floor of a launch is insts x 4 / (CUs x 4 SIMDs x clock).
+    # valu_frac = that floor / the launch time measured HERE; salu / lds / vmem instructions per wavefront ride along.
+    pmc_map = {"fullpel_diamond": "fullpel_diamond_kernel", "subpel_bilinear": "subpel_bilinear_kernel", "inter_pred_8tap": "inter_pred_kernel",
+               "subtract_xform_quant_16x16": "xform_quant_staged_kernel", "inv_txfm_add_16x16": "inv_txfm_add_kernel",
+               "deblock_vert+horz": ("deblock_vert_kernel", "deblock_horz_kernel"), "deblock_fused": "deblock_fused_kernel", "cdef_luma": "cdef_luma_kernel"}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_inner_loop_pmc.json")))
+    except Exception:  # noqa: BLE001
+        pmc = {}
+    simd_valu_per_s = 256 * 4 * 2.4e9 / 4.0
+    for name, kn in pmc_map.items():
+        kns = kn if isinstance(kn, tuple) else (kn,)
+        ents = [next((e for k_, e in pmc.items() if k_.startswith(x)), None) for x in kns]
+        if name not in stages or any(e is None for e in ents):
+            continue
+        insts = sum(e["SQ_INSTS_VALU_per_wavefront"] * e["wavefronts_per_launch"] for e in ents)
+        st = stages[name]
+        st["valu_wave_insts_per_launch"] = insts
+        st["valu_floor_ms"] = insts / simd_valu_per_s * 1e3
+        st["valu_frac"] = st["valu_floor_ms"] / st["ms"] if st["ms"] > 0 else None
+        st["insts_per_wavefront"] = {k_.replace("SQ_INSTS_", "").replace("_per_wavefront", "").lower(): round(sum(e.get(k_, 0.0) for e in ents), 1)
+                                     for k_ in ("SQ_INSTS_VALU_per_wavefront", "SQ_INSTS_SALU_per_wavefront", "SQ_INSTS_LDS_per_wavefront",
+                                                "SQ_INSTS_VMEM_RD_per_wavefront", "SQ_INSTS_VMEM_WR_per_wavefront")}
     # blocks whose quantised coefficients are all zero skip the inverse transform (and cost the forward stage its coefficient writes only)
     eob = ctx.from_device(d_e, (n,), np.uint16)
     for nm in ("inv_txfm_add_16x16", "subtract_xform_quant_16x16"):
