@@ -22,7 +22,8 @@ for f in glob.glob(out + "/g*/*counter_collection.csv"):
 res = {}
 for k, c in acc.items():
     short = k.split("(")[0].replace("void ", "").replace("aomhip::", "")
-    if not any(s in short for s in ("fullpel_diamond", "subpel_bilinear", "inter_pred", "xform_quant", "inv_txfm", "deblock", "cdef_luma", "subtract")):
+    if not any(s in short for s in ("fullpel_diamond", "subpel_bilinear", "inter_pred", "xform_quant", "inv_txfm", "deblock", "cdef_luma", "subtract",
+                                    "full_pixel_search", "fp_row", "tf_apply", "sad_strip", "mesh")):
         continue
     e = {"wavefronts_per_launch": waves[k]}
     for n, v in c.items():
