@@ -192,6 +192,7 @@ _protos = {
     "aomhip_cdef_chroma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i]),
     "aomhip_refining_search_8p_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "aomhip_obmc_full_pixel_search_batch": (C.c_int, [_vp, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "aomhip_compound_subpel_tree_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_obmc_subpel_tree_batch": (C.c_int, [_vp, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_strip_read_probe": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int64)]),
     "aomhip_fullpel_diamond_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
@@ -540,6 +541,13 @@ class Context:
         check(lib.aomhip_obmc_full_pixel_search_batch(self.h, C.byref(ref), frame, bw, bh, method if isinstance(method, int) else SEARCH_METHODS.index(method),
                                                       step_param, int(fast), cost_type, sad_per_bit, error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col,
                                                       d_blocks, n, d_wsrc, d_mask, d_mv, d_cost), "aomhip_obmc_full_pixel_search_batch")
+
+    def compound_subpel_tree_batch(self, src, ref, frame, bw, bh, params, d_blocks, n, d_second_pred, d_mask, invert_mask, d_mv, d_err, d_dist, d_sse,
+                                   d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):
+        """the sub-pel trees on a compound prediction (second_pred [/ mask]); params: SubpelParams."""
+        check(lib.aomhip_compound_subpel_tree_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(params), d_mvjcost, d_mvcost_row, d_mvcost_col,
+                                                    d_blocks, n, d_second_pred, d_mask, int(invert_mask), d_mv, d_err, d_dist, d_sse),
+              "aomhip_compound_subpel_tree_batch")
 
     def obmc_subpel_tree_batch(self, ref, frame, bw, bh, params, d_blocks, n, d_wsrc, d_mask, d_mv, d_err, d_dist=None, d_sse=None, d_mvjcost=None,
                                d_mvcost_row=None, d_mvcost_col=None):

@@ -311,10 +311,25 @@ __device__ __forceinline__ uint64_t row16_sum_u64(uint64_t v) {
   return v;
 }
 
+// The other reference's predictor of a compound search (ms_buffers.second_pred / mask / inv_mask): `second` W x H pixels, `mask` W x H blend
+// weights 0..64 or null.  blend(): aom_comp_avg_pred (variance.c:306-319) / aom_comp_mask_pred (:773-791, AOM_BLEND_A64) on one pixel, `f` the
+// (filtered) pixel of the searched reference.
+template <typename T> struct CompoundRef {
+  const T *second;
+  const uint8_t *mask;
+  int invert;
+  __device__ __forceinline__ int blend(int f, int idx) const {
+    const int p = (int)second[idx];
+    if (!mask) return (p + f + 1) >> 1;
+    const int m = mask[idx];
+    return invert ? (m * p + (64 - m) * f + 32) >> 6 : (m * f + (64 - m) * p + 32) >> 6;
+  }
+};
+
 template <typename T, int W, int H, bool SUBPEL>
 __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, int xoff, int yoff, const T *bp, int bstride,
                                                      bool a_minus_b, int bit_depth, int j, bool active,
-                                                     uint32_t *sse_out) {
+                                                     uint32_t *sse_out, const CompoundRef<T> *comp = nullptr) {
   constexpr int UE = W >= 8 ? 8 : 4;
   constexpr int UPR = W / UE;
   constexpr int U = UPR * H;
@@ -344,6 +359,7 @@ __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, i
           const int h1 = (__mul24(p10, fx0) + __mul24(p11, fx1) + 64) >> 7;
           int av = (__mul24(h0, fy0) + __mul24(h1, fy1) + 64) >> 7;   // h <= 4095: 24-bit multiplies (v_mul_lo_u32 is quarter rate)
           av &= (sizeof(T) == 1) ? 0xFF : 0xFFFF;
+          if (comp) av = comp->blend(av, row * W + col + i);
           const int bvp = px_of<T>(bv.v, i);
           const int d = a_minus_b ? av - bvp : bvp - av;
           us += d;
@@ -352,7 +368,9 @@ __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, i
       } else {
 #pragma unroll
         for (int i = 0; i < UE; ++i) {
-          const int av = px_of<T>(r0.v, i), bvp = px_of<T>(bv.v, i);
+          int av = px_of<T>(r0.v, i);
+          const int bvp = px_of<T>(bv.v, i);
+          if (comp) av = comp->blend(av, row * W + col + i);
           const int d = a_minus_b ? av - bvp : bvp - av;
           us += d;
           uq += (uint32_t)__mul24(d, d);   // |d| < 2^12: the 24-bit multiplier is exact and full rate (v_mul_lo_u32 is quarter rate)

@@ -643,6 +643,17 @@ int aomhip_obmc_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *re
                                         int fast_obmc_search, int mv_cost_type, int sad_per_bit, int error_per_bit, const int32_t *d_mvjcost,
                                         const int32_t *d_mvcost_row, const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, int n_blocks,
                                         const int32_t *d_wsrc, const int32_t *d_obmc_mask, int16_t *d_best_mv, int32_t *d_best_cost);
+/* The sub-pel trees on a COMPOUND prediction: aomhip_subpel_tree_batch with ms_buffers.second_pred [/ mask / inv_mask] set (av1_set_ms_compound_refs,
+ * mcomp.h:152-166) -- the find_fractional_mv_step call of av1_joint_motion_search / av1_compound_single_motion_search
+ * (motion_search_facade.c:496-870).  Every error is vfp->svaf, or vfp->msvf with a mask (estimated_pref_error, mcomp.c:2311-2337), or -- tree 2 with
+ * USE_8_TAPS -- aom_[highbd_]comp_avg_upsampled_pred / comp_mask_upsampled_pred + vf (upsampled_pref_error, :2339-2428); cost_list and
+ * last_mv_search_list are NULL as in those callers.  d_second_pred / d_mask / invert_mask as aomhip_refining_search_8p_batch; blocks and outputs
+ * as aomhip_subpel_tree_batch. */
+int aomhip_compound_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                      const aomhip_subpel_params *params, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                                      const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, int n_blocks, const void *d_second_pred,
+                                      const uint8_t *d_mask, int invert_mask, int16_t *d_best_mv, uint32_t *d_best_err, int32_t *d_distortion,
+                                      uint32_t *d_sse);
 /* av1_find_best_obmc_sub_pixel_tree_up (mcomp.c:3588-3633) for every block: the sub-pel half of the OBMC search (the branch of
  * av1_single_motion_search for OBMC_CAUSAL, motion_search_facade.c:432-445).  params: iters_per_step, allow_hp, forced_stop, mv_cost_type,
  * error_per_bit and subpel_search_type -- 0 USE_2_TAPS_ORIG: vfp->osvf + estimate_obmc_mvcost (:3390-3412; ENTROPY or NONE, the L1 types

@@ -33,6 +33,11 @@ typedef struct {
   const int *mvjcost, *mvcost[2];
   int sad_per_bit, error_per_bit;
   int skip_sad; /* ms_params->sdf is the vtable's sdsf (rows skipped): av1_make_default_fullpel_ms_params, mcomp.c:122-133 */
+  /* compound sub-pel search (ms_buffers.second_pred / mask / inv_mask, av1_set_ms_compound_refs): the W x H predictor of the other
+   * reference (contiguous) and, for a masked compound, W x H blend weights 0..64; NULL = single reference */
+  const void *second_pred;
+  const uint8_t *cmask;
+  int invert_mask;
 } search_ctx;
 
 static unsigned sad_at(const search_ctx *c, int row, int col) { /* ms_params->sdf */
@@ -165,6 +170,7 @@ static void make_ctx(search_ctx *c, const void *src_origin, int src_stride, cons
   c->src_stride = src_stride; c->ref_stride = ref_stride; c->elem16 = elem16; c->bd = bd; c->w = w; c->h = h;
   c->cost_type = cost_type; c->ref_row = ref_row; c->ref_col = ref_col;
   c->mvjcost = NULL; c->mvcost[0] = c->mvcost[1] = NULL; c->sad_per_bit = c->error_per_bit = 0; c->skip_sad = 0;
+  c->second_pred = NULL; c->cmask = NULL; c->invert_mask = 0;
 }
 
 void orc_fullpel_diamond_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride,
@@ -777,6 +783,11 @@ typedef struct {
 
 static unsigned svf_at(const search_ctx *c, int mrow, int mcol, uint32_t *sse) { /* estimated_pref_error */
   const int fr = mrow >> 3, fc = mcol >> 3; /* get_buf_from_mv: floor */
+  if (c->second_pred) { /* vfp->svaf / msvf (:2311-2337) */
+    const void *rp = (const char *)c->ref + ((ptrdiff_t)fr * c->ref_stride + fc) * (ptrdiff_t)(c->elem16 ? 2 : 1);
+    return orc_compound_sub_pixel_variance(rp, c->ref_stride, mcol & 7, mrow & 7, c->src, c->src_stride, c->w, c->h, c->elem16, c->bd, c->cmask ? 2 : 0,
+                                           c->second_pred, 0, 0, c->cmask, c->w, c->invert_mask, sse);
+  }
   if (c->elem16)
     return orc_highbd_sub_pixel_variance((const uint16_t *)c->ref + (ptrdiff_t)fr * c->ref_stride + fc, c->ref_stride,
                                          mcol & 7, mrow & 7, (const uint16_t *)c->src, c->src_stride, c->w, c->h,
@@ -847,6 +858,19 @@ static void upsampled_pred8(const search_ctx *c, int mrow, int mcol, uint16_t *p
 static unsigned upsampled_err(const search_ctx *c, int mrow, int mcol, uint32_t *sse) { /* upsampled_pref_error */
   uint16_t *pred = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)c->w * c->h);
   upsampled_pred8(c, mrow, mcol, pred);
+  if (c->second_pred) { /* aom_[highbd_]comp_avg_upsampled_pred / comp_mask_upsampled_pred (reconinter_enc.c:507-560, 642-...): the up-sampled
+                         * block blended with second_pred as aom_comp_avg_pred / aom_comp_mask_pred do */
+    for (int i = 0; i < c->w * c->h; ++i) {
+      const int r = pred[i], p = c->elem16 ? ((const uint16_t *)c->second_pred)[i] : ((const uint8_t *)c->second_pred)[i];
+      int v;
+      if (!c->cmask) v = (p + r + 1) >> 1;
+      else {
+        const int m = c->cmask[i];
+        v = c->invert_mask ? (m * p + (64 - m) * r + 32) >> 6 : (m * r + (64 - m) * p + 32) >> 6;
+      }
+      pred[i] = (uint16_t)v;
+    }
+  }
   unsigned v;
   if (c->elem16) {
     v = orc_highbd_variance(pred, c->w, (const uint16_t *)c->src, c->src_stride, c->w, c->h, c->bd, sse, NULL);
@@ -990,11 +1014,12 @@ static int repeated_mv(int16_t *list, int row, int col, int iter) {
 
 /* mv_lists: last_mv_search_list per block (n x 3 x 2 int16, read and updated) or NULL.  A search that finds the centre of one of its
  * iterations equal to the list's entry for that iteration returns INT_MAX there, leaving bestmv / distortion / sse1 as they stand. */
-void orc_subpel_tree_batch_list(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16, int bd,
-                                int w, int h, int tree, int subpel_search_type, int cost_type, int error_per_bit, const int *mvjcost, const int *mvcost0,
-                                const int *mvcost1, int iters_per_step, int allow_hp, int forced_stop,
-                                const orc_subpel_block *blocks, const int32_t *cost_lists, int n, int16_t *out_mv, uint32_t *out_err,
-                                int32_t *out_distortion, uint32_t *out_sse, int threads, int16_t *mv_lists) {
+static void subpel_tree_core(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16, int bd,
+                             int w, int h, int tree, int subpel_search_type, int cost_type, int error_per_bit, const int *mvjcost, const int *mvcost0,
+                             const int *mvcost1, int iters_per_step, int allow_hp, int forced_stop,
+                             const orc_subpel_block *blocks, const int32_t *cost_lists, int n, int16_t *out_mv, uint32_t *out_err,
+                             int32_t *out_distortion, uint32_t *out_sse, int threads, int16_t *mv_lists, const void *second_pred,
+                             const uint8_t *cmask, int invert_mask) {
   if (threads < 1) threads = 1;
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 16)
   for (int i = 0; i < n; ++i) {
@@ -1003,6 +1028,11 @@ void orc_subpel_tree_batch_list(const void *src_origin, int src_stride, const vo
     make_ctx(&c, src_origin, src_stride, ref_origin, ref_stride, elem16, bd, w, h, cost_type, b->bx, b->by, b->ref_row,
              b->ref_col);
     c.mvjcost = mvjcost; c.mvcost[0] = mvcost0; c.mvcost[1] = mvcost1; c.error_per_bit = error_per_bit;
+    if (second_pred) {
+      c.second_pred = (const char *)second_pred + (size_t)i * w * h * (elem16 ? 2 : 1);
+      c.cmask = cmask ? cmask + (size_t)i * w * h : NULL;
+      c.invert_mask = invert_mask;
+    }
     /* only av1_find_best_sub_pixel_tree measures with the up-sampled prediction (check_better / first_level_check,
      * :2465-2663); the pruned trees always use the bilinear estimate on an unscaled reference (check_better_fast) */
     const int upsampled = tree == 2 && subpel_search_type == 3; /* USE_8_TAPS */
@@ -1011,7 +1041,9 @@ void orc_subpel_tree_batch_list(const void *src_origin, int src_stride, const vo
       uint32_t sse;
       unsigned v;
       const int fr = b->start_row >> 3, fc = b->start_col >> 3;
-      if (elem16)
+      if (c.second_pred) /* svaf / msvf at offset 0, or the up-sampled form, at the start MV (:2746-2777, :2780-2795) */
+        v = upsampled ? upsampled_err(&c, b->start_row, b->start_col, &sse) : svf_at(&c, b->start_row, b->start_col, &sse);
+      else if (elem16)
         v = orc_highbd_variance((const uint16_t *)c.ref + (ptrdiff_t)fr * ref_stride + fc, ref_stride,
                                 (const uint16_t *)c.src, src_stride, w, h, bd, &sse, NULL);
       else
@@ -1077,6 +1109,29 @@ void orc_subpel_tree_batch_list(const void *src_origin, int src_stride, const vo
     out_distortion[i] = s.distortion;
     out_sse[i] = s.sse1;
   }
+}
+
+void orc_subpel_tree_batch_list(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16, int bd,
+                                int w, int h, int tree, int subpel_search_type, int cost_type, int error_per_bit, const int *mvjcost, const int *mvcost0,
+                                const int *mvcost1, int iters_per_step, int allow_hp, int forced_stop,
+                                const orc_subpel_block *blocks, const int32_t *cost_lists, int n, int16_t *out_mv, uint32_t *out_err,
+                                int32_t *out_distortion, uint32_t *out_sse, int threads, int16_t *mv_lists) {
+  subpel_tree_core(src_origin, src_stride, ref_origin, ref_stride, elem16, bd, w, h, tree, subpel_search_type, cost_type, error_per_bit, mvjcost, mvcost0,
+                   mvcost1, iters_per_step, allow_hp, forced_stop, blocks, cost_lists, n, out_mv, out_err, out_distortion, out_sse, threads, mv_lists, NULL,
+                   NULL, 0);
+}
+
+/* The sub-pel trees of a COMPOUND search (av1_joint_motion_search / av1_compound_single_motion_search, motion_search_facade.c:496-870: the
+ * find_fractional_mv_step call with ms_buffers.second_pred [/ mask / inv_mask]): every error is vfp->svaf or msvf (bilinear form) or the
+ * comp_avg / comp_mask up-sampled prediction + vf (tree 2 with USE_8_TAPS).  second_pred: n x (w*h) pixels; cmask: n x (w*h) bytes or NULL. */
+void orc_compound_subpel_tree_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16, int bd, int w, int h,
+                                    int tree, int subpel_search_type, int cost_type, int error_per_bit, const int *mvjcost, const int *mvcost0,
+                                    const int *mvcost1, int iters_per_step, int allow_hp, int forced_stop, const orc_subpel_block *blocks, int n,
+                                    const void *second_pred, const uint8_t *cmask, int invert_mask, int16_t *out_mv, uint32_t *out_err,
+                                    int32_t *out_distortion, uint32_t *out_sse, int threads) {
+  subpel_tree_core(src_origin, src_stride, ref_origin, ref_stride, elem16, bd, w, h, tree, subpel_search_type, cost_type, error_per_bit, mvjcost, mvcost0,
+                   mvcost1, iters_per_step, allow_hp, forced_stop, blocks, NULL, n, out_mv, out_err, out_distortion, out_sse, threads, NULL, second_pred,
+                   cmask, invert_mask);
 }
 
 void orc_subpel_tree_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16, int bd,

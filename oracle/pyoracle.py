@@ -1261,3 +1261,23 @@ def obmc_subpel_tree_batch(ref_b, border, w, h, blocks, wsrc, obmc_mask, cost_ty
                                    int(subpel_search_type != 0), C.c_void_p(ws.ctypes.data), C.c_void_p(om.ctypes.data), C.c_void_p(mv.ctypes.data),
                                    C.c_void_p(err.ctypes.data), C.c_void_p(dist.ctypes.data), C.c_void_p(sse.ctypes.data), threads)
     return mv, err, dist, sse
+
+
+def compound_subpel_tree_batch(src_b, ref_b, border, w, h, blocks, second_pred, mask=None, invert_mask=0, tree=2, subpel_search_type=0, cost_type=4, error_per_bit=0,
+                               mvjcost=None, mvcost0=None, mvcost1=None, iters_per_step=2, allow_hp=1, forced_stop=0, bd=8, threads=4):
+    """The sub-pel trees on a compound prediction (ms_buffers.second_pred [/ mask]): second_pred [n, h, w] pixels, mask [n, h, w] uint8 or None.
+    -> mv [n, 2], err [n], distortion [n], sse [n]"""
+    blocks = np.ascontiguousarray(blocks)
+    n = len(blocks)
+    sp = np.ascontiguousarray(second_pred, src_b.dtype).reshape(n, h * w)
+    mk = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(n, h * w)
+    mv = np.zeros((n, 2), np.int16); err = np.zeros(n, np.uint32); dist = np.zeros(n, np.int32); sse = np.zeros(n, np.uint32)
+    keep = []
+    j, c0, c1 = _cost_tables(mvjcost, mvcost0, mvcost1, keep)
+    lib.orc_compound_subpel_tree_batch.restype = None
+    lib.orc_compound_subpel_tree_batch(C.c_void_p(_addr(src_b, border, border)), src_b.shape[1], C.c_void_p(_addr(ref_b, border, border)), ref_b.shape[1],
+                                       int(src_b.dtype != np.uint8), bd, w, h, tree, subpel_search_type, cost_type, error_per_bit, j, c0, c1, iters_per_step,
+                                       allow_hp, forced_stop, C.c_void_p(blocks.ctypes.data), n, C.c_void_p(sp.ctypes.data),
+                                       None if mk is None else C.c_void_p(mk.ctypes.data), int(invert_mask), C.c_void_p(mv.ctypes.data),
+                                       C.c_void_p(err.ctypes.data), C.c_void_p(dist.ctypes.data), C.c_void_p(sse.ctypes.data), threads)
+    return mv, err, dist, sse
