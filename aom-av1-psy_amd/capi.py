@@ -192,6 +192,8 @@ _protos = {
     "aomhip_cdef_chroma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i]),
     "aomhip_refining_search_8p_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "aomhip_obmc_full_pixel_search_batch": (C.c_int, [_vp, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "aomhip_build_inter_pred_contiguous_batch": (C.c_int, [_vp, _PP, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i]),
+    "aomhip_joint_motion_search_batch": (C.c_int, [_vp, _PP, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "aomhip_compound_subpel_tree_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_obmc_subpel_tree_batch": (C.c_int, [_vp, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_strip_read_probe": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int64)]),
@@ -541,6 +543,17 @@ class Context:
         check(lib.aomhip_obmc_full_pixel_search_batch(self.h, C.byref(ref), frame, bw, bh, method if isinstance(method, int) else SEARCH_METHODS.index(method),
                                                       step_param, int(fast), cost_type, sad_per_bit, error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col,
                                                       d_blocks, n, d_wsrc, d_mask, d_mv, d_cost), "aomhip_obmc_full_pixel_search_batch")
+
+    def build_inter_pred_contiguous_batch(self, ref, frame, d_pred, bw, bh, d_blocks, d_mv, n, fx=0, fy=0):
+        check(lib.aomhip_build_inter_pred_contiguous_batch(self.h, C.byref(ref), frame, d_pred, bw, bh, d_blocks, d_mv, n, fx, fy),
+              "aomhip_build_inter_pred_contiguous_batch")
+
+    def joint_motion_search_batch(self, src, ref0, ref1, frame, bw, bh, cost_type, sad_per_bit, sub, force_integer_mv, d_blocks, d_ref_mv, d_cur_mv, d_mask, n,
+                                  d_rate_mv, d_best_err, d_mvjcost, d_mvcost_row, d_mvcost_col):
+        """av1_joint_motion_search per block (refining-search branch); sub: SubpelParams."""
+        check(lib.aomhip_joint_motion_search_batch(self.h, C.byref(src), C.byref(ref0), C.byref(ref1), frame, bw, bh, cost_type, sad_per_bit, C.byref(sub),
+                                                   int(force_integer_mv), d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, d_ref_mv, d_cur_mv, d_mask, n,
+                                                   d_rate_mv, d_best_err), "aomhip_joint_motion_search_batch")
 
     def compound_subpel_tree_batch(self, src, ref, frame, bw, bh, params, d_blocks, n, d_second_pred, d_mask, invert_mask, d_mv, d_err, d_dist, d_sse,
                                    d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):

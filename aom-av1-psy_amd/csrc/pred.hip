@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void inter_pred_kernel(PlaneView<T> ref, int r
   const PU128 fx = *reinterpret_cast<const PU128 *>(&kInterp[set_x][pos_x & 15][0]);
   const PU128 fy = *reinterpret_cast<const PU128 *>(&kInterp[set_y][pos_y & 15][0]);
   const T *base = ref.origin + (int64_t)ref_frame * ref.frame_stride + (int64_t)((pos_y >> 4) - 3) * ref.stride + (pos_x >> 4) - 3;
-  T *dbase = dst_origin + (int64_t)by * dst_stride + bx;
+  // dst_stride 0: block i contiguous at dst_origin + i * W * H (the second_pred layout of the compound searches)
+  T *dbase = dst_stride ? dst_origin + (int64_t)by * dst_stride + bx : dst_origin + (int64_t)bi * (W * H);
+  if (!dst_stride) dst_stride = W;
 #pragma unroll 1
   for (int col = col0; col < W; col += 64) {
     const T *p = base + col;
@@ -273,10 +275,13 @@ __global__ __launch_bounds__(256) void pred_copy_kernel(PlaneView<T> ref, int re
 
 template <typename T>
 static int launch_inter_pred(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred, int pred_frame, int bw,
-                             int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv, int n_blocks, int fx, int fy, int ss_x, int ss_y) {
+                             int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv, int n_blocks, int fx, int fy, int ss_x, int ss_y,
+                             void *d_contiguous = nullptr) {
   // av1_get_interp_filter_params_with_block_size (filter.h:247-253): a dimension <= 4 takes the 4-tap sets
   auto set_of = [](int f, int dim) { return dim <= 4 ? (f == 1 ? 5 : f == 3 ? 3 : 4) : f; };
-  T *d = reinterpret_cast<T *>(pred->base) + (size_t)pred_frame * pred->frame_stride + (size_t)pred->border * pred->stride + pred->border;
+  T *d = d_contiguous ? static_cast<T *>(d_contiguous)
+                      : reinterpret_cast<T *>(pred->base) + (size_t)pred_frame * pred->frame_stride + (size_t)pred->border * pred->stride + pred->border;
+  const int dst_stride = d_contiguous ? 0 : pred->stride;
   // the 8-pixel row load starts 3 left of the integer position and the walk covers rows -3 .. bh + 3
   const int x_lo = (-ref->border + 3) << 4, x_hi = ((ref->width + ref->border - bw - 5) << 4) | 15;
   const int y_lo = (-ref->border + 3) << 4, y_hi = ((ref->height + ref->border - bh - 5) << 4) | 15;
@@ -284,7 +289,7 @@ static int launch_inter_pred(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_
   const dim3 grid((n_blocks + 4 * bpw - 1) / (4 * bpw)), block(256);
 #define X(W, H)                                                                                                                    \
   if (bw == W && bh == H) {                                                                                                        \
-    hipLaunchKernelGGL((inter_pred_kernel<T, W, H>), grid, block, 0, ctx->stream, view_of<T>(*ref), ref_frame, d, pred->stride,   \
+    hipLaunchKernelGGL((inter_pred_kernel<T, W, H>), grid, block, 0, ctx->stream, view_of<T>(*ref), ref_frame, d, dst_stride,     \
                        d_blocks, d_mv, n_blocks, set_of(fx, W), set_of(fy, H), ref->bit_depth, x_lo, x_hi, y_lo, y_hi, 2 >> ss_x,  \
                        2 >> ss_y);                                                                                                 \
     AOMHIP_LAUNCH_CHECK();                                                                                                         \
@@ -320,6 +325,24 @@ extern "C" int aomhip_build_inter_pred_ex_batch(aomhip_ctx *ctx, const aomhip_pl
                                       subsampling_x, subsampling_y);
   return launch_inter_pred<uint16_t>(ctx, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, interp_filter_x, interp_filter_y,
                                      subsampling_x, subsampling_y);
+}
+
+extern "C" int aomhip_build_inter_pred_contiguous_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, void *d_pred, int bw, int bh,
+                                                        const aomhip_search_block *d_blocks, const int16_t *d_mv, int n_blocks, int interp_filter_x,
+                                                        int interp_filter_y) {
+  if (!ctx || !ref || !ref->base || !d_pred || (n_blocks > 0 && (!d_blocks || !d_mv)) || n_blocks < 0 || ref_frame < 0 || ref_frame >= ref->n_frames ||
+      !valid_block(bw, bh) || interp_filter_x < 0 || interp_filter_x > 3 || interp_filter_y < 0 || interp_filter_y > 3) {
+    set_error("aomhip_build_inter_pred_contiguous_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (ref->border < 8) {
+    set_error("aomhip_build_inter_pred_contiguous_batch: the reference planes need a border of at least 8 pixels for the 8-tap kernels");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  if (ref->bit_depth == 8)
+    return launch_inter_pred<uint8_t>(ctx, ref, ref_frame, nullptr, 0, bw, bh, d_blocks, d_mv, n_blocks, interp_filter_x, interp_filter_y, 0, 0, d_pred);
+  return launch_inter_pred<uint16_t>(ctx, ref, ref_frame, nullptr, 0, bw, bh, d_blocks, d_mv, n_blocks, interp_filter_x, interp_filter_y, 0, 0, d_pred);
 }
 
 extern "C" int aomhip_build_inter_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred,

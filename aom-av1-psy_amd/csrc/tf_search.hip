@@ -945,3 +945,136 @@ extern "C" int aomhip_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_p
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
+
+// ---- av1_joint_motion_search (av1/encoder/motion_search_facade.c:496-702) for independent compound blocks, the branch every speed preset takes
+// (disable_extensive_joint_motion_search, or COMPOUND_WEDGE): up to four alternating iterations -- the other reference's predictor at cur_mv[!id]
+// (av1_enc_build_one_inter_predictor, EIGHTTAP_REGULAR), av1_refining_search_8p_c from get_fullmv_from_mv(cur_mv[id]) against it, the compound
+// sub-pel tree from the result (forced_stop EIGHTH_PEL) -- a block stops at the first iteration that does not lower its reference's error
+// (:689-696) or whose MVs are back at the initial ones (:544-562); then *rate_mv and min(last_besterr).  All four iterations are launched for
+// the whole batch; a block that has stopped is carried along and its later results are dropped.
+namespace aomhip {
+namespace {
+__global__ void joint_prepare_kernel(const aomhip_search_block *blocks, const int16_t *ref_mv, const int16_t *cur_mv, const int16_t *init_mv, int ite,
+                                     int n, uint8_t *live, aomhip_search_block *full_list, int16_t *other_mv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int id = ite & 1;
+  const int16_t *cm = cur_mv + 4 * i, *im = init_mv + 4 * i;
+  if (live[i] && ite >= 2 && cm[2 * !id] == im[2 * !id] && cm[2 * !id + 1] == im[2 * !id + 1]) {   // (:544-562)
+    if (cm[2 * id] == im[2 * id] && cm[2 * id + 1] == im[2 * id + 1]) live[i] = 0;
+    else if ((cm[2 * id] >> 3) == (im[2 * id] >> 3) && (cm[2 * id + 1] >> 3) == (im[2 * id + 1] >> 3)) live[i] = 0;
+  }
+  aomhip_search_block b = blocks[i];
+  b.ref_row = ref_mv[4 * i + 2 * id]; b.ref_col = ref_mv[4 * i + 2 * id + 1];
+  aomhip_search_block o = b;
+  o.start_row = (int16_t)rawpel(cm[2 * id]); o.start_col = (int16_t)rawpel(cm[2 * id + 1]);   // get_fullmv_from_mv(&cur_mv[id])
+  full_limits_ref(b, &o);   // av1_make_default_fullpel_ms_params: av1_set_mv_search_range(&mv_limits, ref_mv) on x->mv_limits
+  full_list[i] = o;
+  other_mv[2 * i] = cm[2 * !id]; other_mv[2 * i + 1] = cm[2 * !id + 1];
+}
+__global__ void joint_subpel_list_kernel(const aomhip_search_block *blocks, const int16_t *ref_mv, const int16_t *full_mv, int id, int n,
+                                         aomhip_search_block *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  aomhip_search_block b = blocks[i];
+  b.ref_row = ref_mv[4 * i + 2 * id]; b.ref_col = ref_mv[4 * i + 2 * id + 1];
+  aomhip_search_block o = b;
+  o.start_row = (int16_t)(full_mv[2 * i] * 8); o.start_col = (int16_t)(full_mv[2 * i + 1] * 8);   // get_mv_from_fullmv
+  subpel_limits_ref(b, &o);   // av1_set_subpel_mv_search_range(.., &x->mv_limits, ref_mv)
+  out[i] = o;
+}
+__global__ void joint_update_kernel(int id, int n, int force_integer_mv, const int16_t *full_mv, const int32_t *full_sad, const int16_t *sub_mv,
+                                    const uint32_t *sub_err, uint8_t *live, int32_t *last_besterr, int16_t *cur_mv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !live[i]) return;
+  int bestsme = full_sad[i], row = full_mv[2 * i] * 8, col = full_mv[2 * i + 1] * 8;   // convert_fullmv_to_mv (:630-632)
+  if (bestsme < INT_MAX && !force_integer_mv) { bestsme = (int)sub_err[i]; row = sub_mv[2 * i]; col = sub_mv[2 * i + 1]; }
+  if (bestsme < last_besterr[2 * i + id]) {
+    cur_mv[4 * i + 2 * id] = (int16_t)row; cur_mv[4 * i + 2 * id + 1] = (int16_t)col;
+    last_besterr[2 * i + id] = bestsme;
+  } else {
+    live[i] = 0;
+  }
+}
+__global__ void joint_finish_kernel(int n, const int16_t *cur_mv, const int16_t *ref_mv, const int32_t *last_besterr, const int32_t *mvjcost,
+                                    const int32_t *mvcost0, const int32_t *mvcost1, int32_t *rate_mv, int32_t *best_err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int rate = 0;
+  for (int r = 0; r < 2; ++r) {   // av1_mv_bit_cost(.., MV_COST_WEIGHT) (mcomp.c:261-266)
+    const int dr = cur_mv[4 * i + 2 * r] - ref_mv[4 * i + 2 * r], dc = cur_mv[4 * i + 2 * r + 1] - ref_mv[4 * i + 2 * r + 1];
+    const int64_t bits = (int64_t)mvjcost[(dc != 0) | ((dr != 0) << 1)] + mvcost0[dr] + mvcost1[dc];
+    rate += (int)((bits * 108 + 64) >> 7);
+  }
+  rate_mv[i] = rate;
+  best_err[i] = last_besterr[2 * i] < last_besterr[2 * i + 1] ? last_besterr[2 * i] : last_besterr[2 * i + 1];
+}
+__global__ void joint_init_kernel(int n, const int16_t *cur_mv, int16_t *init_mv, uint8_t *live, int32_t *last_besterr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < 4; ++k) init_mv[4 * i + k] = cur_mv[4 * i + k];
+  live[i] = 1;
+  last_besterr[2 * i] = last_besterr[2 * i + 1] = INT_MAX;
+}
+}  // namespace
+}  // namespace aomhip
+
+extern "C" int aomhip_joint_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref0, const aomhip_planes *ref1, int frame,
+                                                int bw, int bh, int mv_cost_type, int sad_per_bit, const aomhip_subpel_params *sub, int force_integer_mv,
+                                                const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                                const aomhip_search_block *d_blocks, const int16_t *d_ref_mv, int16_t *d_cur_mv, const uint8_t *d_mask, int n,
+                                                int32_t *d_rate_mv, int32_t *d_best_err) {
+  if (!ctx || !src || !ref0 || !ref1 || !sub || n < 0 || !d_mvjcost || !d_mvcost_row || !d_mvcost_col ||
+      (n > 0 && (!d_blocks || !d_ref_mv || !d_cur_mv || !d_rate_mv || !d_best_err))) {
+    set_error("aomhip_joint_motion_search_batch: invalid argument (the rate of the result needs the MV cost tables)");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n == 0) return AOMHIP_OK;
+  AOMHIP_TRY(hipSetDevice(ctx->device));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t n1 = (size_t)n, SB = sizeof(aomhip_search_block), px = (size_t)bw * bh * (src->bit_depth == 8 ? 1 : 2);
+  const size_t o_fl = take(n1 * SB), o_sl = take(n1 * SB), o_init = take(n1 * 8), o_live = take(n1), o_last = take(n1 * 8), o_other = take(n1 * 4),
+               o_fmv = take(n1 * 4), o_fsad = take(n1 * 4), o_fvar = take(n1 * 4), o_smv = take(n1 * 4), o_serr = take(n1 * 4), o_dist = take(n1 * 4),
+               o_sse = take(n1 * 4), o_pred = take(n1 * px);
+  char *w = static_cast<char *>(work(ctx, off));
+  if (!w) return AOMHIP_ERR_NOMEM;
+  auto blk = [&](size_t o) { return reinterpret_cast<aomhip_search_block *>(w + o); };
+  auto i16 = [&](size_t o) { return reinterpret_cast<int16_t *>(w + o); };
+  auto i32 = [&](size_t o) { return reinterpret_cast<int32_t *>(w + o); };
+  auto u32 = [&](size_t o) { return reinterpret_cast<uint32_t *>(w + o); };
+  uint8_t *live = reinterpret_cast<uint8_t *>(w + o_live);
+  const unsigned g = (unsigned)((n1 + 255) / 256);
+  hipLaunchKernelGGL(joint_init_kernel, dim3(g), dim3(256), 0, ctx->stream, n, d_cur_mv, i16(o_init), live, i32(o_last));
+  AOMHIP_LAUNCH_CHECK();
+  aomhip_subpel_params sp = *sub;
+  sp.forced_stop = 0;   // ms_params.forced_stop = EIGHTH_PEL (:645)
+  sp.mv_cost_type = mv_cost_type;
+  for (int ite = 0; ite < 4; ++ite) {
+    const int id = ite & 1;
+    const aomhip_planes *rid = id ? ref1 : ref0, *roth = id ? ref0 : ref1;
+    hipLaunchKernelGGL(joint_prepare_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_ref_mv, d_cur_mv, i16(o_init), ite, n, live, blk(o_fl),
+                       i16(o_other));
+    AOMHIP_LAUNCH_CHECK();
+    int rc = aomhip_build_inter_pred_contiguous_batch(ctx, roth, frame, w + o_pred, bw, bh, d_blocks, i16(o_other), n, AOMHIP_INTERP_REGULAR,
+                                                      AOMHIP_INTERP_REGULAR);
+    if (rc != AOMHIP_OK) return rc;
+    rc = aomhip_refining_search_8p_batch(ctx, src, rid, frame, bw, bh, mv_cost_type, sad_per_bit, sub->error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col,
+                                         blk(o_fl), n, w + o_pred, d_mask, id, i16(o_fmv), i32(o_fsad), i32(o_fvar));
+    if (rc != AOMHIP_OK) return rc;
+    if (!force_integer_mv) {
+      hipLaunchKernelGGL(joint_subpel_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_ref_mv, i16(o_fmv), id, n, blk(o_sl));
+      AOMHIP_LAUNCH_CHECK();
+      rc = aomhip_compound_subpel_tree_batch(ctx, src, rid, frame, bw, bh, &sp, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_sl), n, w + o_pred, d_mask, id,
+                                             i16(o_smv), u32(o_serr), i32(o_dist), u32(o_sse));
+      if (rc != AOMHIP_OK) return rc;
+    }
+    hipLaunchKernelGGL(joint_update_kernel, dim3(g), dim3(256), 0, ctx->stream, id, n, force_integer_mv, i16(o_fmv), i32(o_fsad), i16(o_smv), u32(o_serr),
+                       live, i32(o_last), d_cur_mv);
+    AOMHIP_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(joint_finish_kernel, dim3(g), dim3(256), 0, ctx->stream, n, d_cur_mv, d_ref_mv, i32(o_last), d_mvjcost, d_mvcost_row, d_mvcost_col,
+                     d_rate_mv, d_best_err);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}

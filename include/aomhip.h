@@ -654,6 +654,22 @@ int aomhip_compound_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *src,
                                       const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, int n_blocks, const void *d_second_pred,
                                       const uint8_t *d_mask, int invert_mask, int16_t *d_best_mv, uint32_t *d_best_err, int32_t *d_distortion,
                                       uint32_t *d_sse);
+/* av1_joint_motion_search (motion_search_facade.c:496-702) for n independent compound blocks, on the branch with the 8-neighbour refinement
+ * (disable_extensive_joint_motion_search, or COMPOUND_WEDGE -- every speed preset): up to four alternating iterations of {predictor of the
+ * other reference at cur_mv[!id] (EIGHTTAP_REGULAR), av1_refining_search_8p_c from get_fullmv_from_mv(cur_mv[id]), the compound sub-pel tree of
+ * `sub` with forced_stop EIGHTH_PEL}, a block stopping at the first iteration that does not lower its reference's error (:689-696) or that finds
+ * its MVs back at the initial ones (:544-562); second_best_mv == best_mv on this branch, so allow_second_mv has no effect.
+ *   d_blocks   bx, by and the RAW x->mv_limits of every block (the other members are ignored): av1_set_mv_search_range /
+ *              av1_set_subpel_mv_search_range with ref_mv[id] are applied per iteration as the reference's ms-params builders do
+ *   d_ref_mv   n x 2 references x (row, col), 1/8 pel: av1_get_ref_mv(x, ref)
+ *   d_cur_mv   n x 2 x (row, col), 1/8 pel: in = the single-reference results, out = the refined pair
+ *   d_mask     n x (bw * bh) blend weights or NULL (inv_mask = id, av1_set_ms_compound_refs)
+ * Outputs: d_rate_mv (the two av1_mv_bit_cost terms), d_best_err (the return value: min of the two last_besterr). */
+int aomhip_joint_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref0, const aomhip_planes *ref1, int frame, int bw,
+                                     int bh, int mv_cost_type, int sad_per_bit, const aomhip_subpel_params *sub, int force_integer_mv,
+                                     const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                     const aomhip_search_block *d_blocks, const int16_t *d_ref_mv, int16_t *d_cur_mv, const uint8_t *d_mask, int n,
+                                     int32_t *d_rate_mv, int32_t *d_best_err);
 /* av1_find_best_obmc_sub_pixel_tree_up (mcomp.c:3588-3633) for every block: the sub-pel half of the OBMC search (the branch of
  * av1_single_motion_search for OBMC_CAUSAL, motion_search_facade.c:432-445).  params: iters_per_step, allow_hp, forced_stop, mv_cost_type,
  * error_per_bit and subpel_search_type -- 0 USE_2_TAPS_ORIG: vfp->osvf + estimate_obmc_mvcost (:3390-3412; ENTROPY or NONE, the L1 types
@@ -926,6 +942,12 @@ int aomhip_build_pred_fullpel(aomhip_ctx *ctx, const aomhip_planes *ref, int ref
 int aomhip_build_inter_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred,
                                   int pred_frame, int bw, int bh, const aomhip_search_block *d_blocks, const int16_t *d_mv,
                                   int n_blocks, int interp_filter_x, int interp_filter_y);
+/* The same, written as n contiguous bw x bh blocks (block i at element i * bw * bh of d_pred, row pitch bw): the `second_pred` operand of the
+ * compound searches (aomhip_refining_search_8p_batch, aomhip_compound_subpel_tree_batch) -- what av1_enc_build_one_inter_predictor(second_pred, pw,
+ * &cur_mv[!id].as_mv, ..) leaves in av1_joint_motion_search's buffer (motion_search_facade.c:586-595). */
+int aomhip_build_inter_pred_contiguous_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, void *d_pred, int bw, int bh,
+                                             const aomhip_search_block *d_blocks, const int16_t *d_mv, int n_blocks, int interp_filter_x,
+                                             int interp_filter_y);
 /* The same for a plane with chroma subsampling: `ref` / `pred` are rings of that plane, bx / by / bw / bh are in ITS pixels,
  * and the luma MV becomes mv * (1 << (1 - subsampling)) sixteenths (init_subpel_params, reconinter.h:133-137), so all 16
  * kernel phases occur; subsampling 0 / 0 is aomhip_build_inter_pred_batch. */

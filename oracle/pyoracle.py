@@ -1281,3 +1281,58 @@ def compound_subpel_tree_batch(src_b, ref_b, border, w, h, blocks, second_pred, 
                                        None if mk is None else C.c_void_p(mk.ctypes.data), int(invert_mask), C.c_void_p(mv.ctypes.data),
                                        C.c_void_p(err.ctypes.data), C.c_void_p(dist.ctypes.data), C.c_void_p(sse.ctypes.data), threads)
     return mv, err, dist, sse
+
+
+def joint_motion_search_batch(src_b, ref0_b, ref1_b, border, width, height, w, h, blocks, ref_mv, cur_mv, mask=None, cost_type=0, sad_per_bit=0, sub=None,
+                              force_integer_mv=0, mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4):
+    """av1_joint_motion_search (motion_search_facade.c:496-702) on the refining-search branch, composed of the pinned pieces (the sequencing itself
+    is read from the reference, not interpreted): blocks = bx, by + raw x->mv_limits; ref_mv / cur_mv [n, 2, 2] in 1/8 pel; sub = kwargs of
+    compound_subpel_tree_batch (tree, subpel_search_type, error_per_bit, iters_per_step, allow_hp).  -> (cur_mv [n, 2, 2], rate_mv [n], best_err [n], iterations [n])"""
+    blocks = np.ascontiguousarray(blocks)
+    n = len(blocks)
+    cur = np.array(cur_mv, np.int32).reshape(n, 2, 2).copy()
+    init = cur.copy()
+    refmv = np.asarray(ref_mv, np.int32).reshape(n, 2, 2)
+    last = np.full((n, 2), 2**31 - 1, np.int64)
+    live = np.ones(n, bool)
+    iters = np.zeros(n, np.int32)
+    refs = (ref0_b, ref1_b)
+    sub = dict(sub or {})
+    epb = sub.get("error_per_bit", 0)
+    for ite in range(4):
+        i_d = ite & 1
+        for i in range(n):
+            if live[i] and ite >= 2 and (cur[i, 1 - i_d] == init[i, 1 - i_d]).all():
+                if (cur[i, i_d] == init[i, i_d]).all() or ((cur[i, i_d] >> 3) == (init[i, i_d] >> 3)).all():
+                    live[i] = False
+        plane = build_inter_pred(refs[1 - i_d], border, width, height, w, h, blocks, cur[:, 1 - i_d], 0, 0, bd=bd)
+        sp = np.stack([plane[b["by"]:b["by"] + h, b["bx"]:b["bx"] + w] for b in blocks])
+        fl, sl = np.array(blocks, copy=True), np.array(blocks, copy=True)
+        for i, b in enumerate(blocks):
+            raw = (b["row_min"], b["row_max"], b["col_min"], b["col_max"])
+            rr, rc = int(refmv[i, i_d, 0]), int(refmv[i, i_d, 1])
+            fl["row_min"][i], fl["row_max"][i], fl["col_min"][i], fl["col_max"][i] = set_mv_search_range(raw, rr, rc)
+            sl["row_min"][i], sl["row_max"][i], sl["col_min"][i], sl["col_max"][i] = set_subpel_mv_search_range(raw, rr, rc)
+            for l_ in (fl, sl):
+                l_["ref_row"][i], l_["ref_col"][i] = rr, rc
+        fl["start_row"], fl["start_col"] = _rawpel(cur[:, i_d, 0]), _rawpel(cur[:, i_d, 1])
+        fmv, fsad, _ = refining_search_8p_batch(src_b, refs[i_d], border, w, h, fl, sp, mask, i_d, cost_type=cost_type, sad_per_bit=sad_per_bit,
+                                                error_per_bit=epb, mvjcost=mvjcost, mvcost0=mvcost0, mvcost1=mvcost1, bd=bd, threads=threads)
+        best = fmv.astype(np.int32) * 8
+        sme = fsad.astype(np.int64)
+        if not force_integer_mv:
+            sl["start_row"], sl["start_col"] = best[:, 0], best[:, 1]
+            smv, serr, _, _ = compound_subpel_tree_batch(src_b, refs[i_d], border, w, h, sl, sp, mask, i_d, cost_type=cost_type, mvjcost=mvjcost, mvcost0=mvcost0,
+                                                         mvcost1=mvcost1, forced_stop=0, bd=bd, threads=threads, **sub)
+            ok = sme < 2**31 - 1
+            best = np.where(ok[:, None], smv.astype(np.int32), best)
+            sme = np.where(ok, serr.astype(np.int64).astype(np.int32).astype(np.int64), sme)   # (int)besterr
+        for i in range(n):
+            if not live[i]:
+                continue
+            if sme[i] < last[i, i_d]:
+                cur[i, i_d] = best[i]; last[i, i_d] = sme[i]; iters[i] = ite + 1
+            else:
+                live[i] = False
+    rate = np.array([sum(mv_bit_cost(cur[i, r, 0], cur[i, r, 1], refmv[i, r, 0], refmv[i, r, 1], mvjcost, mvcost0, mvcost1) for r in range(2)) for i in range(n)], np.int32)
+    return cur.astype(np.int16), rate, last.min(1).astype(np.int32), iters

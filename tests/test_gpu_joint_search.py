@@ -1,0 +1,89 @@
+"""aomhip_joint_motion_search_batch: av1_joint_motion_search (av1/encoder/motion_search_facade.c:496-702) on the refining-search branch, as one call
+per batch of compound blocks, against the composition of the pinned pieces (oracle.joint_motion_search_batch: predictor of the other reference ->
+av1_refining_search_8p_c -> compound sub-pel tree -> the update / early-out rules, four alternating iterations) -- 8 / 10-bit, averaged and masked
+compounds, entropy and L1 MV costs, force_integer_mv; and aomhip_build_inter_pred_contiguous_batch against the plane form."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables():
+    mv_max = (1 << 14) - 1
+    v = np.abs(np.arange(-mv_max, mv_max + 1))
+    bits = np.where(v == 0, 0, np.floor(np.log2(np.maximum(v, 1))) + 1).astype(np.int64)
+    return mv_max, np.array([190, 660, 655, 1040], np.int32), (140 + bits * 305).astype(np.int32), (165 + bits * 285 + (v & 7) * 5).astype(np.int32)
+
+
+@pytest.mark.parametrize("bd,bw,bh,masked,ct,tree,sst,force_int", [(8, 16, 16, 0, 0, 2, 0, 0), (10, 16, 16, 1, 3, 0, 0, 0), (8, 32, 16, 1, 0, 1, 0, 0),
+                                                                   (10, 8, 8, 0, 0, 2, 3, 0), (8, 16, 16, 0, 3, 2, 0, 1)])
+def test_joint_search_equals_the_composition(hip, oracle, ctx, bd, bw, bh, masked, ct, tree, sst, force_int):
+    capi = hip.capi
+    W, H, B = 256, 160, 96
+    rng = np.random.default_rng(5 * bd + bw + 7 * masked + tree)
+    # the source lies between two references that moved in opposite directions: the compound of both predicts it, each alone does not
+    src, ref0 = hip.synth.shifted_smooth_pair(W, H, 21, bd, shift=(2, -3), frac8=(3, 0))
+    _, ref1 = hip.synth.shifted_smooth_pair(W, H, 21, bd, shift=(-3, 2), frac8=(0, 5))
+    mx = (1 << bd) - 1
+    noisy = lambda a, k: np.clip(a.astype(np.int32) + rng.integers(-k, k + 1, a.shape), 0, mx).astype(a.dtype)
+    ref0, ref1 = noisy(ref0, 2 << (bd - 8)), noisy(ref1, 2 << (bd - 8))
+    ps, p0, p1 = (ctx.planes_alloc(W, H, B, bd, 1) for _ in range(3))
+    for p_, a in ((ps, src), (p0, ref0), (p1, ref1)):
+        ctx.planes_upload(p_, 0, a)
+    gc, gr = W // bw, H // bh
+    n = gc * gr
+    blocks = np.zeros(n, capi.search_block_dtype)
+    blocks["bx"], blocks["by"] = (np.arange(n) % gc) * bw, (np.arange(n) // gc) * bh
+    ext = B - 8 - 16
+    blocks["col_min"], blocks["col_max"] = -(blocks["bx"] + ext), W - blocks["bx"] - bw + ext
+    blocks["row_min"], blocks["row_max"] = -(blocks["by"] + ext), H - blocks["by"] - bh + ext
+    ref_mv = rng.integers(-40, 41, (n, 2, 2)).astype(np.int16)
+    cur = np.zeros((n, 2, 2), np.int16)
+    cur[:, 0] = np.array([-3 * 8 + 1, 2 * 8 - 3]) + rng.integers(-10, 11, (n, 2))      # near the true motion of each reference, a few eighths off
+    cur[:, 1] = np.array([2 * 8 - 2, -3 * 8 + 4]) + rng.integers(-10, 11, (n, 2))
+    cur[::5] = 0                                                                             # some start from zero
+    mask = np.clip((np.arange(bw)[None, None, :] * 64 // bw + rng.integers(-6, 7, (n, bh, bw))), 0, 64).astype(np.uint8) if masked else None
+    mv_max, tj, t0, t1 = _tables()
+    sb, r0b, r1b = (oracle.extend_plane(a, B, ps.stride) for a in (src, ref0, ref1))
+    sub_kw = dict(tree=tree, subpel_search_type=sst, error_per_bit=61, iters_per_step=2, allow_hp=1)
+    want_mv, want_rate, want_err, iters = oracle.joint_motion_search_batch(sb, r0b, r1b, B, W, H, bw, bh, blocks, ref_mv, cur, mask, cost_type=ct, sad_per_bit=22,
+                                                                           sub=sub_kw, force_integer_mv=force_int, mvjcost=tj, mvcost0=t0, mvcost1=t1, bd=bd, threads=8)
+    d_j, d_c0, d_c1 = ctx.to_device(tj), ctx.to_device(t0), ctx.to_device(t1)
+    d_b, d_r, d_cur = ctx.to_device(blocks), ctx.to_device(ref_mv), ctx.to_device(cur)
+    d_m = ctx.to_device(mask) if masked else None
+    d_rate, d_err = ctx.malloc(n * 4), ctx.malloc(n * 4)
+    sub = capi.SubpelParams(tree, ct, 61, 2, 1, 3, sst)        # forced_stop is overridden (EIGHTH_PEL) as the reference does
+    ctx.joint_motion_search_batch(ps, p0, p1, 0, bw, bh, ct, 22, sub, force_int, d_b, d_r, d_cur, d_m, n, d_rate, d_err, d_j, d_c0 + mv_max * 4, d_c1 + mv_max * 4)
+    got_mv = ctx.from_device(d_cur, (n, 2, 2), np.int16)
+    assert np.array_equal(got_mv, want_mv), np.flatnonzero((got_mv != want_mv).reshape(n, -1).any(1))[:8]
+    assert np.array_equal(ctx.from_device(d_rate, (n,), np.int32), want_rate)
+    assert np.array_equal(ctx.from_device(d_err, (n,), np.int32), want_err)
+    # the loop is exercised: blocks that stop after 1, 2, 3 and 4 iterations all occur across the cases; most MVs move
+    assert (want_mv != cur).any(axis=(1, 2)).mean() > 0.5 and len(set(iters.tolist())) >= 2
+    for d in [d_j, d_c0, d_c1, d_b, d_r, d_cur, d_rate, d_err] + ([d_m] if masked else []):
+        ctx.free(d)
+    for p_ in (ps, p0, p1):
+        ctx.planes_free(p_)
+
+
+def test_contiguous_predictor_equals_the_plane_form(hip, ctx):
+    capi = hip.capi
+    W, H, B, bw, bh, bd = 128, 96, 64, 16, 8, 10
+    rng = np.random.default_rng(3)
+    _, ref = hip.synth.shifted_smooth_pair(W, H, 2, bd, shift=(1, 1), frac8=(0, 0))
+    pr, pp = ctx.planes_alloc(W, H, B, bd, 1), ctx.planes_alloc(W, H, B, bd, 1)
+    ctx.planes_upload(pr, 0, ref)
+    n = (W // bw) * (H // bh)
+    blocks = np.zeros(n, capi.search_block_dtype)
+    blocks["bx"], blocks["by"] = (np.arange(n) % (W // bw)) * bw, (np.arange(n) // (W // bw)) * bh
+    mv = rng.integers(-60, 61, (n, 2)).astype(np.int16)
+    d_b, d_mv, d_out = ctx.to_device(blocks), ctx.to_device(mv), ctx.malloc(n * bw * bh * 2)
+    ctx.build_inter_pred_batch(pr, 0, pp, 0, bw, bh, d_b, d_mv, n, 0, 0)
+    ctx.build_inter_pred_contiguous_batch(pr, 0, d_out, bw, bh, d_b, d_mv, n, 0, 0)
+    plane = ctx.planes_download(pp, 0)[B:B + H, B:B + W]
+    got = ctx.from_device(d_out, (n, bh, bw), np.uint16)
+    want = np.stack([plane[b["by"]:b["by"] + bh, b["bx"]:b["bx"] + bw] for b in blocks])
+    assert np.array_equal(got, want)
+    for d in (d_b, d_mv, d_out):
+        ctx.free(d)
+    ctx.planes_free(pr); ctx.planes_free(pp)
