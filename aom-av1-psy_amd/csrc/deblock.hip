@@ -24,6 +24,7 @@
 namespace aomhip {
 
 struct __attribute__((packed, aligned(1))) DU128 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) DU64 { uint32_t v[2]; };
 
 __device__ __forceinline__ int iabsd(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int clampd(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -223,6 +224,87 @@ __global__ __launch_bounds__(kDbThreads) void deblock_horz_kernel(PIX *origin, i
   }
 }
 
+// ---- Four lines of an edge per lane (16-bit planes, width and height multiples of 4, 8-byte aligned rows).  The one-line kernels above are
+// 32 400 wavefronts of ~330 instructions on a 4K plane: a wavefront lives for one memory round trip and little else (PMC: VALU floor 12.0 +
+// 5.6 us against 30 us for the pair of launches, profiles/r04_inner_loop_pmc.json).  Here a lane owns the four pixel rows (vertical edges) /
+// four pixel columns (horizontal edges) of ONE 4x4 unit's edge -- one parameter record, four independent lines whose loads are all in
+// flight before the first filter runs: a quarter of the wavefronts, the same latency each.  The arithmetic per line is lpf_window's, unchanged.
+__global__ __launch_bounds__(kDbThreads) void deblock_vert4_kernel(uint16_t *origin, int stride, int width, int height, const uint8_t *__restrict__ params,
+                                                                   int units_stride, int sharpness, int bd) {
+  const int ux = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int uy = blockIdx.y * (kDbThreads / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ucols = width >> 2;
+  if (ux <= 0 || ux >= ucols || 4 * uy >= height) return;
+  const uint8_t *e = params + ((size_t)uy * units_stride + ux) * 4;
+  const int len = e[0], level = e[1];
+  if (len == 0 || level == 0) return;
+  uint16_t *s = origin + (int64_t)(4 * uy) * stride + 4 * ux;  // q0 of the unit's first row
+  DU128 w0[4], w1[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    w0[r] = *reinterpret_cast<const DU128 *>(s + (int64_t)r * stride - 8);
+    w1[r] = *reinterpret_cast<const DU128 *>(s + (int64_t)r * stride);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int x[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      const int px = i + 1;  // index within the 16-pixel window
+      const uint32_t d = px < 8 ? w0[r].v[px / 2] : w1[r].v[(px - 8) / 2];
+      x[i] = (d >> (16 * (px % 2))) & 0xFFFF;
+    }
+    lpf_window(x, len, level, sharpness, bd);
+    // this edge's own zone only (the neighbours' zones are theirs to write), as few stores as its 4-byte alignment allows: the edge sits at
+    // a multiple of 4 pixels, so x - 6 and x - 2 are dword boundaries (the one-line kernel issues a 2-byte store per pixel)
+    uint16_t *sr = s + (int64_t)r * stride;
+    auto pk = [&](int i) { return (uint32_t)x[i] | ((uint32_t)x[i + 1] << 16); };   // pixels (i - 7, i - 6) relative to q0
+    if (len == 14) {
+      *reinterpret_cast<DU128 *>(sr - 6) = DU128{ { pk(1), pk(3), pk(5), pk(7) } };
+      *reinterpret_cast<DU64 *>(sr + 2) = DU64{ { pk(9), pk(11) } };
+    } else if (len == 8) {
+      sr[-3] = (uint16_t)x[4];
+      *reinterpret_cast<DU64 *>(sr - 2) = DU64{ { pk(5), pk(7) } };
+      sr[2] = (uint16_t)x[9];
+    } else {
+      *reinterpret_cast<DU64 *>(sr - 2) = DU64{ { pk(5), pk(7) } };
+    }
+  }
+}
+
+__global__ __launch_bounds__(kDbThreads) void deblock_horz4_kernel(uint16_t *origin, int stride, int width, int height, const uint8_t *__restrict__ params,
+                                                                   int units_stride, int sharpness, int bd) {
+  const int ux = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int uy = blockIdx.y * (kDbThreads / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (4 * ux >= width || uy <= 0 || 4 * uy >= height) return;
+  const uint8_t *e = params + ((size_t)uy * units_stride + ux) * 4;
+  const int len = e[2], level = e[3];
+  if (len == 0 || level == 0) return;
+  uint16_t *s = origin + (int64_t)(4 * uy) * stride + 4 * ux;  // q0 of the unit's first column
+  const int reach = len == 14 ? 7 : (len == 8 ? 4 : (len == 6 ? 3 : 2));
+  uint2 rows[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    const int k = i - 7;
+    rows[i] = (k >= -reach && k < reach) ? *reinterpret_cast<const uint2 *>(s + (int64_t)k * stride) : make_uint2(0, 0);
+  }
+  int out[4][14];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int i = 0; i < 14; ++i) out[c][i] = (int)(((c < 2 ? rows[i].x : rows[i].y) >> (16 * (c & 1))) & 0xFFFF);
+    lpf_window(out[c], len, level, sharpness, bd);
+  }
+  const int wr = len == 14 ? 6 : (len == 8 ? 3 : 2);
+#pragma unroll
+  for (int i = 1; i <= 12; ++i) {
+    const int k = i - 7;
+    if (k >= -wr && k < wr)
+      *reinterpret_cast<uint2 *>(s + (int64_t)k * stride) =
+          make_uint2((uint32_t)out[0][i] | ((uint32_t)out[1][i] << 16), (uint32_t)out[2][i] | ((uint32_t)out[3][i] << 16));
+  }
+}
+
 // ---- Both passes in ONE launch, out of place (aomhip_deblock_plane_fused).  A workgroup produces a kFW x kFH tile of the output:
 // it stages the tile + an 8-pixel halo on every side in LDS (as 16-bit pixels), filters every vertical edge that touches the staged
 // region's tile columns -- for the halo ROWS too: the horizontal edges at the tile's top and bottom read vertically filtered pixels
@@ -414,6 +496,24 @@ int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, con
   const int rows_per_wg = kDbThreads / 64;
   const dim3 gv((ucols + 63) / 64, (p->height + rows_per_wg - 1) / rows_per_wg);
   const dim3 gh((p->width + 63) / 64, (urows + rows_per_wg - 1) / rows_per_wg);
+  // 16-bit planes whose rows keep 4-pixel groups 8-byte aligned: four lines of an edge per lane (AOMHIP_DEBLOCK_LINES=1: the one-line kernels, A/B)
+  const char *one = getenv("AOMHIP_DEBLOCK_LINES");
+  const bool four = esz == 2 && (p->width & 3) == 0 && (p->height & 3) == 0 && (p->stride & 3) == 0 && (p->border & 3) == 0 && p->border >= 8 &&
+                    (reinterpret_cast<uintptr_t>(origin) & 7) == 0 && !(one && atoi(one) == 1);
+  if (four) {
+    const dim3 g4((ucols + 63) / 64, (urows + rows_per_wg - 1) / rows_per_wg);
+    if (passes & 1) {
+      hipLaunchKernelGGL(deblock_vert4_kernel, g4, dim3(kDbThreads), 0, ctx->stream, reinterpret_cast<uint16_t *>(origin), p->stride, p->width, p->height,
+                         d_edge_params, units_stride, sharpness, p->bit_depth);
+      AOMHIP_LAUNCH_CHECK();
+    }
+    if (passes & 2) {
+      hipLaunchKernelGGL(deblock_horz4_kernel, g4, dim3(kDbThreads), 0, ctx->stream, reinterpret_cast<uint16_t *>(origin), p->stride, p->width, p->height,
+                         d_edge_params, units_stride, sharpness, p->bit_depth);
+      AOMHIP_LAUNCH_CHECK();
+    }
+    return AOMHIP_OK;
+  }
   if (passes & 1) {
     if (esz == 1)
       hipLaunchKernelGGL(deblock_vert_kernel<uint8_t>, gv, dim3(kDbThreads), 0, ctx->stream,

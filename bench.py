@@ -618,7 +618,7 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
     pred = ctx.planes_alloc(W, H, border, bd, F)  # slot f: prediction, then reconstruction, of ring frame f
     out = ctx.planes_alloc(W, H, border, bd, 1)
     dbk = ctx.planes_alloc(W, H, border, bd, 1)
-    fused_deblock = os.environ.get("AOMHIP_BENCH_DEBLOCK", "fused") != "two_pass"
+    fused_deblock = os.environ.get("AOMHIP_BENCH_DEBLOCK", "two_pass") == "fused"   # (round 4: the two in-place passes with four lines per lane are the faster form)
     n = sp.n
     nc = 256
     d_q, d_dq, d_e = ctx.malloc(n * nc * 4), ctx.malloc(n * nc * 4), ctx.malloc(2 * n)
