@@ -716,7 +716,7 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
     # valu_frac = that floor / the launch time measured HERE; salu / lds / vmem instructions per wavefront ride along.
     pmc_map = {"fullpel_diamond": "fullpel_diamond_kernel", "subpel_bilinear": "subpel_bilinear_kernel", "inter_pred_8tap": "inter_pred_kernel",
                "subtract_xform_quant_16x16": "xform_quant_staged_kernel", "inv_txfm_add_16x16": "inv_txfm_add_kernel",
-               "deblock_vert+horz": ("deblock_vert_kernel", "deblock_horz_kernel"), "deblock_fused": "deblock_fused_kernel", "cdef_luma": "cdef_luma_kernel"}
+               "deblock_vert+horz": ("deblock_vert", "deblock_horz"), "deblock_fused": "deblock_fused_kernel", "cdef_luma": "cdef_luma_kernel"}
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_inner_loop_pmc.json")))
     except Exception:  # noqa: BLE001
