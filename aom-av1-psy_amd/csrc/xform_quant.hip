@@ -60,6 +60,11 @@ struct QuantArgs {
 // coefficient, qm == NULL (wt = iwt = 32), branch-free.  Exact re-associations used for the low-bd form:
 //   ((32t * quant) >> 16)            == (t * quant) >> 11         (same rational, same floor; fits int32)
 //   (t2 * 2^k) >> m                  == t2 >> (m - k)             (quant_shift is a power of two)
+__device__ __forceinline__ int __mulhi24(int a, int b) {   // v_mul_hi_i32_i24: bits 32..47 of the signed 24 x 24-bit product, sign-extended
+  int r;
+  asm("v_mul_hi_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 template <bool HBD, int LS>
 __device__ __forceinline__ void quantize_one(int32_t v, int zb, int rd, int quant, int qshift, int qs_log2, int dequant,
                                              int32_t *qout, int32_t *dqout) {
@@ -82,18 +87,36 @@ __device__ __forceinline__ void quantize_one(int32_t v, int zb, int rd, int quan
   if constexpr (!HBD) {
     int t = a + rd;
     t = t > 32767 ? 32767 : t;  // clamp(.., INT16_MIN, INT16_MAX); a + rd >= 0
-    const int t2 = ((t * quant) >> 11) + (t << 5);
+    // 0 <= t < 2^15 and quant is an int16: the product is exact on the 24-bit multiplier (v_mul_i32_i24, full rate; the plain `*` compiles to
+    // v_mul_lo_u32, a quarter-rate instruction, because the compiler cannot see t's lower bound) -- the kernels run at 0.82-0.96 of their VALU
+    // floor (profiles/r04_txq_pmc.json), so issue cycles are launch time
+    const int t2 = (__mul24(t, quant) >> 11) + (t << 5);
     if (qs_log2 >= 0)
       q = t2 >> (21 - LS - qs_log2);
     else
       q = (int)(((int64_t)t2 * qshift) >> (21 - LS));
   } else {
-    const int64_t tw = ((int64_t)a + rd) * 32;
-    const int64_t t2 = ((tw * quant) >> 16) + tw;
-    q = (int)((t2 * qshift) >> (21 - LS));
+    // aom_highbd_quantize_b_helper_c computes in int64: tmp2 = ((32 T quant) >> 16) + 32 T, abs_q = (tmp2 quant_shift) >> (21 - log_scale), T = |c| +
+    // round.  (32 T quant) >> 16 == (T quant) >> 11 (same rational, same floor).  A transform coefficient of AV1 has at most bd + 8 <= 20
+    // bits, so T < 2^23 and the 48-bit product T x quant comes out of the 24-bit multiplier pair (v_mul_i32_i24 + v_mul_hi_i32_i24, full rate)
+    // instead of a 64-bit multiply-add sequence; tmp2 < 2^25 then fits 32 bits and the power-of-two quant_shift is a shift.  Anything
+    // outside those ranges takes the literal int64 form.
+    const int T = a + rd;
+    if (qs_log2 >= 0 && (unsigned)a < (1u << 22) && (unsigned)rd < (1u << 22)) {
+      const uint32_t lo = (uint32_t)__mul24(T, quant);
+      const int hi = __mulhi24(T, quant);
+      const int t2 = (int)__builtin_amdgcn_alignbit((uint32_t)hi, lo, 11) + (T << 5);   // (hi:lo) >> 11: |T quant| < 2^38, so it fits 32 bits
+      q = t2 >> (21 - LS - qs_log2);
+    } else {
+      const int64_t tw = ((int64_t)a + rd) * 32;
+      const int64_t t2 = ((tw * quant) >> 16) + tw;
+      q = (int)((t2 * qshift) >> (21 - LS));
+    }
   }
   q = (a >= zb) ? q : 0;
-  const int dq = (int)((uint32_t)q * (uint32_t)dequant) >> LS;
+  int dq;
+  if constexpr (!HBD) dq = (int)__umul24((unsigned)q, (unsigned)dequant) >> LS;   // 0 <= q < 2^17, 0 < dequant < 2^15: exact in 24 x 24 bits
+  else dq = (int)((uint32_t)q * (uint32_t)dequant) >> LS;
   *qout = (q ^ sign) - sign;
   *dqout = (dq ^ sign) - sign;
 }
@@ -105,13 +128,13 @@ template <int KW, int KH> __device__ __forceinline__ int iscan_pos(int r, int c,
   if (scan_class == 1) return r * KW + c;
   constexpr int m = KW < KH ? KW : KH, M = KW < KH ? KH : KW;
   const int d = r + c;
-  int before;  // coefficients on earlier anti-diagonals
+  int before;  // coefficients on earlier anti-diagonals (all factors < 128: 24-bit multiplies, v_mul_lo_u32 is quarter rate)
   if (d <= m)
-    before = d * (d + 1) / 2;
+    before = __mul24(d, d + 1) / 2;
   else if (d <= M)
-    before = m * (m + 1) / 2 + (d - m) * m;
+    before = m * (m + 1) / 2 + __mul24(d - m, m);
   else
-    before = KW * KH - (KW + KH - 1 - d) * (KW + KH - d) / 2;
+    before = KW * KH - __mul24(KW + KH - 1 - d, KW + KH - d) / 2;
   const bool up = (KW > KH) || (KW == KH && (d & 1) == 0);
   const int cmin = d - (KH - 1) > 0 ? d - (KH - 1) : 0;
   const int rmin = d - (KW - 1) > 0 ? d - (KW - 1) : 0;
