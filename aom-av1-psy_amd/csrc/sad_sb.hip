@@ -401,7 +401,9 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
         unsigned t = (unsigned)w.s0 + dy;
         t = min(t, t - (unsigned)a.R);  // one wrap at most: t - R underflows to a huge value unless t >= R
         slot0 = (int)t;
-        base = (unsigned)a.ring_off + t * (unsigned)a.pitch + dx * kES;
+        // (t < R <= 2^9 and the pitch < 2^12 bytes: v_mul_u32_u24, full rate -- the plain product is v_mul_lo_u32, a quarter-rate instruction on
+        // the evaluating wavefronts' critical chain; an entry outside the window yields a garbage base that `ok` discards)
+        base = (unsigned)a.ring_off + __umul24(t, (unsigned)a.pitch) + dx * kES;
         return dx <= ww_ok && dy <= w.wh_ok;
       };
       auto ring_unit = [&](unsigned base, int slot0, int k) {
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
       };
       auto src_pos = [&](const Win &w, int sx, int sy, unsigned &soff) {
         const unsigned dx = (unsigned)(sx - sx0), dy = (unsigned)sy - w.sy0;
-        soff = dy * (unsigned)a.spitch + dx * kES;
+        soff = __umul24(dy, (unsigned)a.spitch) + dx * kES;
         return dx <= sw_ok && dy <= w.sh_ok;
       };
 
