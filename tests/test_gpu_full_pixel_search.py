@@ -133,6 +133,35 @@ def test_full_pixel_search_matches_oracle(hip, oracle, ctx, bw, bh, bd):
     ctx.planes_free(ps); ctx.planes_free(pr)
 
 
+@pytest.mark.parametrize("bd,bw,bh", [(8, 16, 16), (10, 16, 16), (10, 32, 32), (8, 8, 8)])
+def test_entropy_tables_with_negative_entries_take_the_literal_comparison(hip, oracle, ctx, bd, bw, bh):
+    """libaom's MV cost tables are bit counts (>= 0) and a step of the diamond / n-step searches then ends in one key reduction; the API takes
+    any int32 tables, and with a negative sad cost `sad < best` no longer follows from `sad + cost < best`: those steps replay the reference's
+    in-order double comparison.  Tables whose small differences cost LESS than nothing pull both forms into every search."""
+    rng = np.random.default_rng(17 * bd + bw)
+    W, H, border = 320, 192, 160
+    src, ref = hip.synth.shifted_smooth_pair(W, H, 3 + bd, bd, shift=(4, -5))
+    ref = np.clip(ref.astype(np.int32) + rng.integers(-3 << (bd - 8), (3 << (bd - 8)) + 1, ref.shape), 0, (1 << bd) - 1).astype(ref.dtype)
+    ps, pr = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(ps, 0, src); ctx.planes_upload(pr, 0, ref)
+    sb, rb = oracle.extend_plane(src, border, ps.stride), oracle.extend_plane(ref, border, pr.stride)
+    blocks = _mk_blocks(hip, oracle, rng, W, H, bw, bh, border, 150, start_range=6, ref_range=40)
+    tj, c0, c1 = _cost_tables(rng)
+    mid = c0.size // 2
+    c0 = c0.copy(); c1 = c1.copy()
+    c0[mid - 40:mid + 40] -= 2600      # differences below 5 pixels: a large negative row cost (sad cost = bits * sad_per_bit >> 9 < 0)
+    c1[mid - 24:mid + 24:3] -= 1900    # and every third small column difference
+    tables = (tj, c0, c1)
+    for method, step_param in (("NSTEP", 2), ("DIAMOND", 4), ("NSTEP_8PT", 1)):
+        qd = hip.capi.SearchParams.make(method, step_param, 0, 210, 71)
+        qo = oracle.search_params(method, step_param, 0, 210, 71)
+        got = _run(hip, ctx, ps, pr, 0, bw, bh, qd, blocks, tables)
+        want = oracle.full_pixel_search_batch(sb, rb, border, bw, bh, blocks, qo, *tables, bd=bd)
+        for gname, a, w in zip(("mv", "cost", "cost_list", "second"), got, want):
+            assert np.array_equal(a, w), (method, gname, np.flatnonzero((np.asarray(a) != np.asarray(w)).reshape(len(blocks), -1).any(1))[:5])
+    ctx.planes_free(ps); ctx.planes_free(pr)
+
+
 def test_full_pixel_search_without_cost_list_and_noise(hip, oracle, ctx):
     """cost_list == NULL changes pattern_search's last scale for the 4-candidate tables (mcomp.c:1077); pure noise makes
     every descent data-dependent."""
