@@ -47,6 +47,13 @@ aomhip_ctx *default_ctx() {
 
 hipStream_t side_stream(aomhip_ctx *ctx) {
   if (ctx->side_stream) return ctx->side_stream;
+  {  // not while ctx->stream is being captured into a graph: creating a stream there is not a capturable operation -- the caller stays serial
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+  }
   hipStream_t st = nullptr;
   hipEvent_t a = nullptr, b = nullptr;
   if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||

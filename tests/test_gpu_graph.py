@@ -112,3 +112,80 @@ def test_a_graph_is_refused_after_the_contexts_work_memory_moved(hip):
     with pytest.raises(capi.AomHipError, match="another context"):
         other.graph_launch(g2)
     ctx.graph_destroy(g); ctx.graph_destroy(g2)
+
+
+def test_first_pass_frame_call_replays_from_a_graph_with_and_without_its_side_stream(hip):
+    """aomhip_first_pass_inter_frame forks its golden-frame leg onto the context's second stream and joins it again inside the call: a capture of
+    ctx->stream must record the fork and the join (cross-stream events are capturable), and a capture taken before the second stream exists must
+    not try to create it (stream creation is not capturable) -- that replay runs everything on one stream.  Both graphs and the direct call give
+    the same five outputs."""
+    capi = hip.capi
+    ctx = capi.Context(0)   # a fresh context: no side stream yet
+    W, H, B, bs, bd = 352, 288, 64, 16, 8
+    rng = np.random.default_rng(5)
+    src, last = hip.synth.shifted_smooth_pair(W, H, 11, bd, shift=(5, -7), frac8=(0, 0))
+    _, gold = hip.synth.shifted_smooth_pair(W, H, 11, bd, shift=(-2, 3), frac8=(0, 0))
+    noisy = lambda a, k: np.clip(a.astype(np.int32) + rng.integers(-k, k + 1, a.shape), 0, 255).astype(a.dtype)
+    last, gold, lsrc = noisy(last, 3), noisy(gold, 5), noisy(last, 6)
+    rings = [ctx.planes_alloc(W, H, B, bd, 1) for _ in range(4)]
+    for ring, img in zip(rings, (src, last, gold, lsrc)):
+        ctx.planes_upload(ring, 0, img)
+    ps, pl, pg, pls = rings
+    rows, cols = H // bs, W // bs
+    n = rows * cols
+    blocks = np.zeros(n, capi.search_block_dtype)
+    blocks["bx"], blocks["by"] = (np.arange(n) % cols) * bs, (np.arange(n) // cols) * bs
+    ext = B - 8
+    blocks["col_min"] = np.maximum(-(blocks["bx"] + ext), -1023); blocks["col_max"] = np.minimum(W - blocks["bx"] - bs + ext, 1023)
+    blocks["row_min"] = np.maximum(-(blocks["by"] + ext), -1023); blocks["row_max"] = np.minimum(H - blocks["by"] - bs + ext, 1023)
+    mv_max = (1 << 14) - 1
+    v = np.abs(np.arange(-mv_max, mv_max + 1))
+    bits = np.where(v == 0, 0, np.floor(np.log2(np.maximum(v, 1))) + 1).astype(np.int64)
+    tj, t0, t1 = np.array([200, 650, 640, 1050], np.int32), (150 + bits * 310).astype(np.int32), (170 + bits * 290 + (v & 7) * 3).astype(np.int32)
+    q = capi.SearchParams.make("NSTEP_FPF", 2, 0, sad_per_bit=24, error_per_bit=70)
+    fp = capi.FirstPassParams(rows, cols, 0, 0)
+    intra = rng.integers(2000, 60000, n).astype(np.int32)
+    d_b, d_i, d_j, d_c0, d_c1 = ctx.to_device(blocks), ctx.to_device(intra), ctx.to_device(tj), ctx.to_device(t0), ctx.to_device(t1)
+    outs = [ctx.malloc(n * 4) for _ in range(5)]
+
+    def call():
+        ctx.first_pass_inter_frame(ps, 0, pl, 0, pg, 0, pls, 0, bs, bs, q, fp, d_b, d_i, outs[0], outs[2], outs[1], outs[3], outs[4], d_j, d_c0 + mv_max * 4,
+                                   d_c1 + mv_max * 4)
+
+    def read():
+        ctx.sync()
+        return [ctx.from_device(o, (n,), np.int32).copy() for o in outs]
+
+    def clear():
+        for o in outs:
+            ctx.memset(o, 0xEE, n * 4)
+
+    # the work memory must exist before a capture (a capture that would allocate is refused): size it with the side stream still absent
+    import os
+    os.environ["AOMHIP_FP_SERIAL"] = "1"
+    try:
+        call()
+    finally:
+        os.environ["AOMHIP_FP_SERIAL"] = "0"
+    want = read()
+    g_serial = ctx.capture(call)          # no side stream yet: captured on one stream
+    clear(); ctx.graph_launch(g_serial)
+    got = read()
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    clear(); call()                       # outside a capture: creates the side stream, forks and joins
+    got = read()
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    g_forked = ctx.capture(call)          # now the fork / join is part of the graph
+    clear(); ctx.graph_launch(g_forked)
+    got = read()
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    clear(); ctx.graph_launch(g_serial)   # and the first graph still replays
+    got = read()
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert (want[0] != 0).any()
+    ctx.graph_destroy(g_serial); ctx.graph_destroy(g_forked)
+    for d in [d_b, d_i, d_j, d_c0, d_c1] + outs:
+        ctx.free(d)
+    for r in rings:
+        ctx.planes_free(r)
+    ctx.close()
