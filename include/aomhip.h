@@ -802,7 +802,10 @@ int aomhip_first_pass_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *
  *   d_intra_error  this_intra_error per block
  * Outputs per block: d_best_mv (*best_mv, 1/8 pel, row then col), d_full_mv (the FULLPEL `mv` that produced motion_error, also when intra
  * won; may be NULL), d_motion_error, d_gf_motion_error (= motion_error when there is no golden frame or the search was skipped; may be
- * NULL), d_raw_motion_error (may be NULL). */
+ * NULL), d_raw_motion_error (may be NULL).
+ * Streams: with a golden frame the call forks its golden-frame leg onto a second stream the context owns and joins it again before it returns
+ * (cross-stream events: the fork and the join are part of a graph captured from the context's stream); to every caller it is one stream-ordered
+ * operation on the context's stream.  A capture taken before that second stream exists runs the call on one stream. */
 typedef struct {
   int32_t unit_rows, unit_cols;
   int32_t skip_motion_search_threshold;  /* fp_sf.skip_motion_search_threshold */
