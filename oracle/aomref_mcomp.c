@@ -162,6 +162,25 @@ static int var_cost_at(const search_ctx *c, int row, int col) { /* get_mvpred_va
   return (int)v + mv_cost_var(c, row * 8, col * 8);
 }
 
+/* get_mvpred_compound_sad (mcomp.c:710-731) / get_mvpred_compound_var_cost (:676-708): what diamond_search_sad and full_pixel_diamond call --
+ * vfp->msdf / msvf with a mask, vfp->sdaf / svaf with a second predictor only, the plain sdf / vf of a single reference otherwise.  (The mesh
+ * passes, the pattern searches and the cost list keep get_mvpred_sad / get_mvpred_var_cost, i.e. the plain forms, even on a compound.) */
+static unsigned diamond_sad_at(const search_ctx *c, int row, int col) {
+  if (!c->second_pred) return sad_at(c, row, col);
+  const void *rp = (const char *)c->ref + ((ptrdiff_t)row * c->ref_stride + col) * (ptrdiff_t)(c->elem16 ? 2 : 1);
+  if (c->cmask)
+    return orc_masked_sad(c->src, c->src_stride, rp, c->ref_stride, c->second_pred, c->cmask, c->w, c->invert_mask, c->w, c->h, c->elem16, c->bd);
+  return orc_sad_avg_any(c->src, c->src_stride, rp, c->ref_stride, c->second_pred, c->w, c->h, c->elem16, c->bd, 0, 0);
+}
+static int diamond_var_cost_at(const search_ctx *c, int row, int col) {
+  if (!c->second_pred) return var_cost_at(c, row, col);
+  const void *rp = (const char *)c->ref + ((ptrdiff_t)row * c->ref_stride + col) * (ptrdiff_t)(c->elem16 ? 2 : 1);
+  uint32_t sse;
+  const uint32_t v = orc_compound_sub_pixel_variance(rp, c->ref_stride, 0, 0, c->src, c->src_stride, c->w, c->h, c->elem16, c->bd, c->cmask ? 2 : 0,
+                                                     c->second_pred, 0, 0, c->cmask, c->w, c->invert_mask, &sse);
+  return (int)v + mv_cost_var(c, row * 8, col * 8);
+}
+
 static void make_ctx(search_ctx *c, const void *src_origin, int src_stride, const void *ref_origin, int ref_stride,
                      int elem16, int bd, int w, int h, int cost_type, int bx, int by, int ref_row, int ref_col) {
   const size_t e = elem16 ? 2 : 1;
@@ -430,7 +449,7 @@ static int diamond_search_sites(const search_ctx *c, const orc_search_block *b, 
   col = col < b->col_min ? b->col_min : col > b->col_max ? b->col_max : col;
   const int tot_steps = s->num_search_steps - search_step;
   *num00 = 0;
-  unsigned bestsad = sad_at(c, row, col) + (unsigned)mvsad_cost(c, row, col);
+  unsigned bestsad = diamond_sad_at(c, row, col) + (unsigned)mvsad_cost(c, row, col);
   int is_off_center = 0;
   int next_step_size = tot_steps > 2 ? s->radius[tot_steps - 2] : 1;
   for (int step = tot_steps - 1; step >= 0; --step) {
@@ -440,7 +459,7 @@ static int diamond_search_sites(const search_ctx *c, const orc_search_block *b, 
     for (int idx = 1; idx <= s->searches_per_step[step]; ++idx) {
       const int r = row + s->mv[step][idx][0], cc = col + s->mv[step][idx][1];
       if (!mv_in_range(b, r, cc)) continue;
-      unsigned thissad = sad_at(c, r, cc);
+      unsigned thissad = diamond_sad_at(c, r, cc);
       if (thissad < bestsad) {
         thissad += (unsigned)mvsad_cost(c, r, cc);
         if (thissad < bestsad) {
@@ -492,7 +511,7 @@ static int full_pixel_diamond_sites(const search_ctx *c, const orc_search_block 
                                     int *cost_list, int *best_row, int *best_col, int *second) {
   int n, num00 = 0, br, bc;
   int bestsme = diamond_search_sites(c, b, s, step_param, &n, &br, &bc, second);
-  if (bestsme < INT_MAX) bestsme = var_cost_at(c, br, bc);
+  if (bestsme < INT_MAX) bestsme = diamond_var_cost_at(c, br, bc);
   const int further_steps = s->num_search_steps - 1 - step_param;
   while (n < further_steps) {
     ++n;
@@ -501,7 +520,7 @@ static int full_pixel_diamond_sites(const search_ctx *c, const orc_search_block 
     } else {
       int tr, tc;
       int thissme = diamond_search_sites(c, b, s, step_param + n, &num00, &tr, &tc, second);
-      if (thissme < INT_MAX) thissme = var_cost_at(c, tr, tc);
+      if (thissme < INT_MAX) thissme = diamond_var_cost_at(c, tr, tc);
       if (thissme < bestsme) {
         bestsme = thissme;
         br = tr;
@@ -756,6 +775,33 @@ void orc_full_pixel_search_batch(const void *src_origin, int src_stride, const v
     out_mv[2 * i] = (int16_t)br; out_mv[2 * i + 1] = (int16_t)bc;
     out_cost[i] = var;
     for (int k = 0; k < 5; ++k) out_cost_list[5 * i + k] = cl[k];
+    out_second[2 * i] = (int16_t)second[0]; out_second[2 * i + 1] = (int16_t)second[1];
+  }
+}
+
+/* av1_full_pixel_search with ms_buffers.second_pred [/ mask / inv_mask] set (av1_set_ms_compound_refs): the full-pel step of
+ * av1_joint_motion_search when disable_extensive_joint_motion_search is 0 (motion_search_facade.c:613-619; speed 0).  second_pred: n x (w*h)
+ * pixels; cmask: n x (w*h) bytes or NULL.  cost_list is NULL there; skip_sad is not a compound form (the diamond ignores ms_params->sdf). */
+void orc_compound_full_pixel_search_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride, int elem16, int bd, int w,
+                                          int h, const orc_search_params *q, const int *mvjcost, const int *mvcost0, const int *mvcost1,
+                                          const orc_search_block *blocks, int n, const void *second_pred, const uint8_t *cmask, int invert_mask,
+                                          int16_t *out_mv, int32_t *out_cost, int16_t *out_second, int threads) {
+  orc_sites sites;
+  orc_init_search_sites(q->search_method, &sites);
+  if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 8)
+  for (int i = 0; i < n; ++i) {
+    const orc_search_block *b = &blocks[i];
+    search_ctx c;
+    make_ctx(&c, src_origin, src_stride, ref_origin, ref_stride, elem16, bd, w, h, q->cost_type, b->bx, b->by, b->ref_row, b->ref_col);
+    c.mvjcost = mvjcost; c.mvcost[0] = mvcost0; c.mvcost[1] = mvcost1;
+    c.sad_per_bit = q->sad_per_bit; c.error_per_bit = q->error_per_bit;
+    c.second_pred = (const char *)second_pred + (size_t)i * w * h * (elem16 ? 2 : 1);
+    c.cmask = cmask ? cmask + (size_t)i * w * h : NULL;
+    c.invert_mask = invert_mask;
+    int br, bc, second[2];
+    out_cost[i] = full_pixel_search(&c, b, q, &sites, NULL, &br, &bc, second);
+    out_mv[2 * i] = (int16_t)br; out_mv[2 * i + 1] = (int16_t)bc;
     out_second[2 * i] = (int16_t)second[0]; out_second[2 * i + 1] = (int16_t)second[1];
   }
 }

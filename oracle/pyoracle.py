@@ -1228,6 +1228,27 @@ def refining_search_8p_batch(src_b, ref_b, border, w, h, blocks, second_pred, ma
     return mv, sad, var
 
 
+def compound_full_pixel_search_batch(src_b, ref_b, border, w, h, blocks, q, second_pred, mask=None, invert_mask=0, mvjcost=None, mvcost0=None,
+                                     mvcost1=None, bd=8, threads=4):
+    """av1_full_pixel_search with ms_buffers.second_pred [/ mask] set (the extensive full-pel step of av1_joint_motion_search): the diamond
+    runs on sdaf / msdf and svaf / msvf, the mesh passes on the plain SAD as in the reference.  q: search params (cost_list NULL).
+    -> mv [n, 2], cost [n], second_best [n, 2]"""
+    blocks = np.ascontiguousarray(blocks)
+    n = len(blocks)
+    sp = np.ascontiguousarray(second_pred, src_b.dtype).reshape(n, h * w)
+    mk = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(n, h * w)
+    mv = np.zeros((n, 2), np.int16); cost = np.zeros(n, np.int32); sec = np.zeros((n, 2), np.int16)
+    keep = []
+    j, c0, c1 = _cost_tables(mvjcost, mvcost0, mvcost1, keep)
+    lib.orc_compound_full_pixel_search_batch.restype = None
+    lib.orc_compound_full_pixel_search_batch(C.c_void_p(_addr(src_b, border, border)), src_b.shape[1], C.c_void_p(_addr(ref_b, border, border)),
+                                             ref_b.shape[1], int(src_b.dtype != np.uint8), bd, w, h, C.byref(q), j, c0, c1,
+                                             C.c_void_p(blocks.ctypes.data), n, C.c_void_p(sp.ctypes.data),
+                                             None if mk is None else C.c_void_p(mk.ctypes.data), int(invert_mask), C.c_void_p(mv.ctypes.data),
+                                             C.c_void_p(cost.ctypes.data), C.c_void_p(sec.ctypes.data), threads)
+    return mv, cost, sec
+
+
 def obmc_full_pixel_search_batch(ref_b, border, w, h, blocks, wsrc, obmc_mask, method="NSTEP", step_param=0, fast_obmc_search=0, cost_type=3, sad_per_bit=0,
                                  error_per_bit=0, mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4):
     """av1_obmc_full_pixel_search per block.  wsrc / obmc_mask [n, h, w] int32.  -> mv [n, 2], cost [n]"""
