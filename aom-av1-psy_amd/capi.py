@@ -191,6 +191,7 @@ _protos = {
     "aomhip_cdef_luma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "aomhip_cdef_chroma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i]),
     "aomhip_refining_search_8p_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "aomhip_compound_full_pixel_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "aomhip_obmc_full_pixel_search_batch": (C.c_int, [_vp, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_build_inter_pred_contiguous_batch": (C.c_int, [_vp, _PP, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i]),
     "aomhip_joint_motion_search_batch": (C.c_int, [_vp, _PP, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -537,6 +538,13 @@ class Context:
         check(lib.aomhip_refining_search_8p_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, cost_type, sad_per_bit, error_per_bit, d_mvjcost,
                                                   d_mvcost_row, d_mvcost_col, d_blocks, n, d_second_pred, d_mask, int(invert_mask), d_mv, d_sad, d_var),
               "aomhip_refining_search_8p_batch")
+
+    def compound_full_pixel_search_batch(self, src, ref, frame, bw, bh, params, d_blocks, n, d_second_pred, d_mask, invert_mask, d_mv, d_cost, d_second,
+                                         d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):
+        """av1_full_pixel_search with a second predictor [and mask] (the extensive joint-search step); params: SearchParams."""
+        check(lib.aomhip_compound_full_pixel_search_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(params), d_mvjcost, d_mvcost_row,
+                                                          d_mvcost_col, d_blocks, n, d_second_pred, d_mask, int(invert_mask), d_mv, d_cost, d_second),
+              "aomhip_compound_full_pixel_search_batch")
 
     def obmc_full_pixel_search_batch(self, ref, frame, bw, bh, method, step_param, fast, cost_type, sad_per_bit, error_per_bit, d_blocks, n, d_wsrc, d_mask,
                                      d_mv, d_cost, d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):

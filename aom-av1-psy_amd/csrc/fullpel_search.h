@@ -23,6 +23,8 @@ struct SearchArgs {
   int mesh[8];
   const int *mvjcost, *mvcost0, *mvcost1;
   int bit_depth, want_cl;  // want_cl: the caller keeps a cost_list (changes pattern_search's last scale, :1077)
+  int resume;  // the method's own search ran elsewhere (the compound diamond, mcomp_compound.hip): out_mv / out_cost / out_second hold its result,
+               // only the follow-up of av1_full_pixel_search (:1756-1830: mesh rules, full_pixel_exhaustive) runs here
 };
 
 #define AOMHIP_DECL_FPS(NAME)                                                                                                 \

@@ -130,6 +130,7 @@ SearchArgs fps_search_args(const aomhip_search_params *p, const int32_t *d_mvjco
   for (int i = 0; i < 8; ++i) q.mesh[i] = p->mesh_patterns[i];
   q.mvjcost = d_mvjcost; q.mvcost0 = d_mvcost_row; q.mvcost1 = d_mvcost_col;
   q.bit_depth = bit_depth; q.want_cl = want_cost_list;
+  q.resume = 0;
   return q;
 }
 

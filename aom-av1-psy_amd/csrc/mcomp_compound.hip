@@ -145,6 +145,127 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
   }
 }
 
+// full_pixel_diamond (mcomp.c:1421-1470) on a COMPOUND prediction: diamond_search_sad (:1299-1416) takes its per-site branch with
+// get_mvpred_compound_sad whenever ms_buffers.second_pred is set (:1347), every run ends on get_mvpred_compound_var_cost (:676-708) and
+// *second_best_mv follows every move of every run.  What av1_full_pixel_search does after it (:1756-1830) -- on the PLAIN sdf / vf even on a
+// compound -- is the general kernel's (fullpel_search.inc, SearchArgs::resume).
+template <typename T>
+__global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneView<T> src, PlaneView<T> ref, int frame,
+                                                                          const aomhip_search_block *__restrict__ blocks, int n_blocks, CompoundArgs a,
+                                                                          const SiteTable *__restrict__ sites, int step_param,
+                                                                          const T *__restrict__ second_pred, const uint8_t *__restrict__ masks,
+                                                                          int16_t *__restrict__ out_mv, int32_t *__restrict__ out_cost,
+                                                                          int16_t *__restrict__ out_second) {
+  __shared__ SiteTable S;
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(sites);
+    uint32_t *d = reinterpret_cast<uint32_t *>(&S);
+    for (int i = threadIdx.x; i < (int)(sizeof(SiteTable) / 4); i += 256) d[i] = g[i];
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * 4 + wave;
+  if (bi >= n_blocks) return;
+  const BlockScalars bs = BlockScalars::of(blocks[bi]);
+  const int bx = __builtin_amdgcn_readfirstlane((int)blocks[bi].bx), by = __builtin_amdgcn_readfirstlane((int)blocks[bi].by);
+  const int W = a.bw, H = a.bh, n_px = W * H;
+  const T *sp = src.origin + (int64_t)frame * src.frame_stride + (int64_t)by * src.stride + bx;
+  const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)by * ref.stride + bx;
+  const T *pred = second_pred + (size_t)bi * n_px;
+  const uint8_t *mask = masks ? masks + (size_t)bi * n_px : nullptr;
+  const int shift = a.bit_depth == 10 ? 2 : a.bit_depth == 12 ? 4 : 0;
+  const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
+  auto sad_at = [&](int row, int col) -> uint32_t {   // get_mvpred_compound_sad: sdaf / msdf
+    const T *rp = rbase + (int64_t)row * ref.stride + col;
+    int64_t acc = 0;
+    for (int t = lane; t < n_px; t += 64) {
+      const int y = t / W, x = t - y * W;
+      const int v = blend_px((int)rp[(int64_t)y * ref.stride + x], (int)pred[t], mask, t, a.invert_mask);
+      acc += iabsm(v - (int)sp[(int64_t)y * src.stride + x]);
+    }
+    return (uint32_t)wsum(acc) >> shift;
+  };
+  auto var_at = [&](int row, int col) -> int {   // get_mvpred_compound_var_cost: svaf / msvf at offset (0, 0) + mv_err_cost_
+    const T *rp = rbase + (int64_t)row * ref.stride + col;
+    int64_t s = 0, q = 0;
+    for (int t = lane; t < n_px; t += 64) {
+      const int y = t / W, x = t - y * W;
+      const int v = blend_px((int)rp[(int64_t)y * ref.stride + x], (int)pred[t], mask, t, a.invert_mask);
+      const int d = v - (int)sp[(int64_t)y * src.stride + x];
+      s += d;
+      q += (uint32_t)(d * d);
+    }
+    return (int)finish_var(wsum(s), (uint64_t)wsum(q), n_px, a.bit_depth) + var_cost(a, bs.ref_row, bs.ref_col, row * 8, col * 8);
+  };
+  const int start_row = min(max(bs.start_row, bs.row_min), bs.row_max), start_col = min(max(bs.start_col, bs.col_min), bs.col_max);   // clamp_fullmv
+  const uint32_t start_sad = sad_at(start_row, start_col) + (uint32_t)sad_cost(a, frr, frc, start_row, start_col);   // (the same in every run)
+  int second_row = -32768, second_col = -32768;   // MARK_MV_INVALID (av1_full_pixel_search, :1704-1707)
+  auto diamond = [&](int search_step, int *num00, int *orow, int *ocol) -> int {
+    const int tot_steps = S.num_search_steps - search_step;
+    int row = start_row, col = start_col;
+    *num00 = 0;
+    uint32_t bestsad = start_sad;
+    int is_off_center = 0;
+    int next_step_size = tot_steps > 2 ? S.radius[tot_steps - 2] : 1;
+    for (int step = tot_steps - 1; step >= 0; --step) {
+      int best_site = 0;
+      if (step > 0) next_step_size = S.radius[step - 1];
+      const int nper = S.searches_per_step[step];
+      for (int idx = 1; idx <= nper; ++idx) {
+        const int r = row + S.mv[step][idx][0], c = col + S.mv[step][idx][1];
+        if (c < bs.col_min || c > bs.col_max || r < bs.row_min || r > bs.row_max) continue;   // av1_is_fullmv_in_range
+        uint32_t sad = sad_at(r, c);
+        if (sad < bestsad) {
+          sad += (uint32_t)sad_cost(a, frr, frc, r, c);
+          if (sad < bestsad) {
+            bestsad = sad;
+            best_site = idx;
+          }
+        }
+      }
+      if (best_site != 0) {
+        second_row = row; second_col = col;
+        row += S.mv[step][best_site][0];
+        col += S.mv[step][best_site][1];
+        is_off_center = 1;
+      }
+      if (is_off_center == 0) (*num00)++;
+      if (best_site == 0) {
+        while (next_step_size == S.radius[step] && step > 2) {
+          ++(*num00);
+          --step;
+          next_step_size = S.radius[step - 1];
+        }
+      }
+    }
+    *orow = row; *ocol = col;
+    return (int)bestsad;
+  };
+  int n, num00 = 0, tr, tc;
+  int bestsme = diamond(step_param, &n, &tr, &tc);
+  if (bestsme < INT_MAX) bestsme = var_at(tr, tc);
+  int best_row = tr, best_col = tc;
+  const int further_steps = S.num_search_steps - 1 - step_param;
+  while (n < further_steps) {
+    ++n;
+    if (num00) {
+      num00--;
+    } else {
+      int thissme = diamond(step_param + n, &num00, &tr, &tc);
+      if (thissme < INT_MAX) thissme = var_at(tr, tc);
+      if (thissme < bestsme) {
+        bestsme = thissme;
+        best_row = tr; best_col = tc;
+      }
+    }
+  }
+  if (lane == 0) {
+    out_mv[2 * bi] = (int16_t)best_row; out_mv[2 * bi + 1] = (int16_t)best_col;
+    out_cost[bi] = bestsme;
+    out_second[2 * bi] = (int16_t)second_row; out_second[2 * bi + 1] = (int16_t)second_col;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
                                                                      CompoundArgs a, const SiteTable *__restrict__ sites, int step_param, int fast,
@@ -446,6 +567,68 @@ int aomhip_refining_search_8p_batch(aomhip_ctx *ctx, const aomhip_planes *src, c
                        n_blocks, a, static_cast<const uint16_t *>(d_second_pred), d_mask, d_best_mv, d_best_sad, d_best_var);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
+}
+
+int aomhip_compound_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                            const aomhip_search_params *p, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                                            const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, int n_blocks, const void *d_second_pred,
+                                            const uint8_t *d_mask, int invert_mask, int16_t *d_best_mv, int32_t *d_best_cost, int16_t *d_second_best_mv) {
+  if (!p) {
+    set_error("aomhip_compound_full_pixel_search_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  int rc = check_compound(ctx, ref, frame, bw, bh, d_blocks, n_blocks, p->mv_cost_type, d_mvjcost, d_mvcost_row, d_mvcost_col,
+                          "aomhip_compound_full_pixel_search_batch");
+  if (rc != AOMHIP_OK) return rc;
+  if (!src || !src->base || frame >= src->n_frames || (src->bit_depth == 8) != (ref->bit_depth == 8) || !d_second_pred || !d_best_mv || !d_best_cost ||
+      !d_second_best_mv || p->step_param < 0) {
+    set_error("aomhip_compound_full_pixel_search_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  // the compound operand enters diamond_search_sad / full_pixel_diamond only (mcomp.c:1347, :1431): the methods that run them
+  if (p->search_method != kDiamond && p->search_method != kNstep && p->search_method != kNstep8 && p->search_method != kClamped) {
+    set_error("aomhip_compound_full_pixel_search_batch: search method %d is a pattern search (it ignores second_pred in the reference: use "
+              "aomhip_full_pixel_search_batch)", p->search_method);
+    return AOMHIP_ERR_INVALID;
+  }
+  if (p->use_downsampled_sad) {
+    set_error("aomhip_compound_full_pixel_search_batch: use_downsampled_sad does not apply to a compound search (sdaf / msdf have no row-skipping form)");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  const SiteTable *d_sites = fps_device_sites(ctx->device, p->search_method);
+  if (!d_sites) {
+    set_error("aomhip_compound_full_pixel_search_batch: could not place the site table on device %d", ctx->device);
+    return AOMHIP_ERR_HIP;
+  }
+  {
+    int ns, per[22], rad[22];
+    int16_t mv[22][17][2];
+    rc = aomhip_search_sites(p->search_method, &ns, per, rad, mv);
+    if (rc != AOMHIP_OK) return rc;
+    if (p->step_param >= ns) {
+      set_error("aomhip_compound_full_pixel_search_batch: step_param %d >= %d search steps", p->step_param, ns);
+      return AOMHIP_ERR_INVALID;
+    }
+  }
+  const CompoundArgs a{ bw, bh, src->bit_depth, p->mv_cost_type, p->sad_per_bit, p->error_per_bit, invert_mask != 0, d_mvjcost, d_mvcost_row, d_mvcost_col };
+  const dim3 grid((n_blocks + 3) / 4), block(256);
+  if (src->bit_depth == 8)
+    hipLaunchKernelGGL(compound_full_pixel_diamond_kernel<uint8_t>, grid, block, 0, ctx->stream, view_of<uint8_t>(*src), view_of<uint8_t>(*ref), frame,
+                       d_blocks, n_blocks, a, d_sites, p->step_param, static_cast<const uint8_t *>(d_second_pred), d_mask, d_best_mv, d_best_cost,
+                       d_second_best_mv);
+  else
+    hipLaunchKernelGGL(compound_full_pixel_diamond_kernel<uint16_t>, grid, block, 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame,
+                       d_blocks, n_blocks, a, d_sites, p->step_param, static_cast<const uint16_t *>(d_second_pred), d_mask, d_best_mv, d_best_cost,
+                       d_second_best_mv);
+  AOMHIP_LAUNCH_CHECK();
+  // the follow-up of av1_full_pixel_search: needed only where a mesh search can follow (NSTEP's variance threshold, or run_mesh_search)
+  const bool nstep = p->search_method == kNstep || p->search_method == kNstep8;
+  if (!p->run_mesh_search && !nstep) return AOMHIP_OK;
+  SearchArgs q = fps_search_args(p, d_mvjcost, d_mvcost_row, d_mvcost_col, src->bit_depth, false);
+  q.resume = 1;
+  return (src->bit_depth == 8 ? launch_fps_u8 : launch_fps_u16)(ctx, src, ref, frame, bw, bh, d_blocks, n_blocks, d_sites, q, /*reach=*/-1, d_best_mv,
+                                                               d_best_cost, nullptr, d_second_best_mv);
 }
 
 int aomhip_obmc_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int frame, int bw, int bh, int search_method, int step_param,

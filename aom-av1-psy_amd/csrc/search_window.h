@@ -50,7 +50,7 @@ inline CellPlan plan_cells(const aomhip_planes *ref, int bw, int bh, int n_block
   static const int env_on = [] { const char *e = getenv("AOMHIP_SEARCH_CELL"); return e ? atoi(e) : 1; }();
   static const int env_r = [] { const char *e = getenv("AOMHIP_SEARCH_CELL_R"); return e ? atoi(e) : -1; }();
   CellPlan p{};
-  if (!env_on) return p;
+  if (!env_on || reach < 0) return p;   // (reach < 0: the caller wants the form without a window)
   const int es = ref->bit_depth == 8 ? 1 : 2;
   const int r = env_r >= 0 ? env_r : (reach < kCellReach ? reach : kCellReach);
   // the window of a cell whose blocks are horizontal neighbours and start at the same MV; rounded up so that the workgroups of a CU

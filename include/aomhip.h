@@ -635,6 +635,17 @@ int aomhip_refining_search_8p_batch(aomhip_ctx *ctx, const aomhip_planes *src, c
                                     int sad_per_bit, int error_per_bit, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
                                     const aomhip_search_block *d_blocks, int n_blocks, const void *d_second_pred, const uint8_t *d_mask, int invert_mask,
                                     int16_t *d_best_mv, int32_t *d_best_sad, int32_t *d_best_var);
+/* av1_full_pixel_search (mcomp.c:1693-1832) with ms_buffers.second_pred [/ mask / inv_mask] set: the full-pel step of av1_joint_motion_search when
+ * disable_extensive_joint_motion_search is 0 (motion_search_facade.c:613-619: speed 0, step_param 5, cost_list NULL).  As in the reference the
+ * compound operand enters diamond_search_sad (get_mvpred_compound_sad, its per-site branch, :1347-1390) and the variance at the end of every run of
+ * full_pixel_diamond (get_mvpred_compound_var_cost, :1431-1451) -- search_method must be DIAMOND / CLAMPED_DIAMOND / NSTEP / NSTEP_8PT, the pattern
+ * searches ignore second_pred there -- while the mesh passes that may follow (NSTEP's variance threshold, run_mesh_search, prune_mesh_search) and
+ * the variance after them stay on the plain sdf / vf (:1474-1616).  use_downsampled_sad must be 0.  d_second_pred / d_mask / invert_mask and blocks
+ * as aomhip_refining_search_8p_batch.  Outputs: d_best_mv, d_best_cost (the return value), d_second_best_mv (INVALID_MV_ROW_COL where none). */
+int aomhip_compound_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                            const aomhip_search_params *params, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                                            const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, int n_blocks, const void *d_second_pred,
+                                            const uint8_t *d_mask, int invert_mask, int16_t *d_best_mv, int32_t *d_best_cost, int16_t *d_second_best_mv);
 /* av1_obmc_full_pixel_search (mcomp.c:2272-2285) for every block: obmc_full_pixel_diamond (:2236-2270; the site table of search_method from
  * step_param, restarts, get_obmc_mvpred_var) or, with fast_obmc_search, obmc_refining_search_sad (:2127-2171) from the clamped start MV.
  *   d_wsrc / d_obmc_mask   bw x bh int32 each, block i at i * bw * bh: calc_target_weighted_pred's weighted source and mask (x->obmc_buffer)
