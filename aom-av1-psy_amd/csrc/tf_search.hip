@@ -946,7 +946,7 @@ extern "C" int aomhip_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_p
   return AOMHIP_OK;
 }
 
-// ---- av1_joint_motion_search (av1/encoder/motion_search_facade.c:496-702) for independent compound blocks, the branch every speed preset takes
+// ---- av1_joint_motion_search (av1/encoder/motion_search_facade.c:496-702) for independent compound blocks.  The branch of speed >= 1
 // (disable_extensive_joint_motion_search, or COMPOUND_WEDGE): up to four alternating iterations -- the other reference's predictor at cur_mv[!id]
 // (av1_enc_build_one_inter_predictor, EIGHTTAP_REGULAR), av1_refining_search_8p_c from get_fullmv_from_mv(cur_mv[id]) against it, the compound
 // sub-pel tree from the result (forced_stop EIGHTH_PEL) -- a block stops at the first iteration that does not lower its reference's error
@@ -983,12 +983,30 @@ __global__ void joint_subpel_list_kernel(const aomhip_search_block *blocks, cons
   subpel_limits_ref(b, &o);   // av1_set_subpel_mv_search_range(.., &x->mv_limits, ref_mv)
   out[i] = o;
 }
+// try_second (:621-623, :664-676): the sub-pel search is repeated from second_best_mv when that is valid, differs from best_mv and lies inside the
+// sub-pel limits; the other blocks are carried along from best_mv and their second result is dropped (use_second 0)
+__global__ void joint_second_list_kernel(const aomhip_search_block *sub_list, const int16_t *full_mv, const int16_t *second, int n, aomhip_search_block *out,
+                                         uint8_t *use_second) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  aomhip_search_block o = sub_list[i];
+  const int sr = second[2 * i], sc = second[2 * i + 1];
+  const bool differs = sr != full_mv[2 * i] || sc != full_mv[2 * i + 1];
+  const bool use = !(sr == kInvalidMv && sc == kInvalidMv) && differs && sc * 8 >= o.col_min && sc * 8 <= o.col_max && sr * 8 >= o.row_min && sr * 8 <= o.row_max;
+  if (use) { o.start_row = (int16_t)(sr * 8); o.start_col = (int16_t)(sc * 8); }
+  use_second[i] = use;
+  out[i] = o;
+}
 __global__ void joint_update_kernel(int id, int n, int force_integer_mv, const int16_t *full_mv, const int32_t *full_sad, const int16_t *sub_mv,
-                                    const uint32_t *sub_err, uint8_t *live, int32_t *last_besterr, int16_t *cur_mv) {
+                                    const uint32_t *sub_err, const uint8_t *use_second, const int16_t *sub_mv2, const uint32_t *sub_err2, uint8_t *live,
+                                    int32_t *last_besterr, int16_t *cur_mv) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !live[i]) return;
   int bestsme = full_sad[i], row = full_mv[2 * i] * 8, col = full_mv[2 * i + 1] * 8;   // convert_fullmv_to_mv (:630-632)
-  if (bestsme < INT_MAX && !force_integer_mv) { bestsme = (int)sub_err[i]; row = sub_mv[2 * i]; col = sub_mv[2 * i + 1]; }
+  if (bestsme < INT_MAX && !force_integer_mv) {
+    bestsme = (int)sub_err[i]; row = sub_mv[2 * i]; col = sub_mv[2 * i + 1];
+    if (use_second && use_second[i] && (int)sub_err2[i] < bestsme) { bestsme = (int)sub_err2[i]; row = sub_mv2[2 * i]; col = sub_mv2[2 * i + 1]; }
+  }
   if (bestsme < last_besterr[2 * i + id]) {
     cur_mv[4 * i + 2 * id] = (int16_t)row; cur_mv[4 * i + 2 * id + 1] = (int16_t)col;
     last_besterr[2 * i + id] = bestsme;
@@ -1019,11 +1037,13 @@ __global__ void joint_init_kernel(int n, const int16_t *cur_mv, int16_t *init_mv
 }  // namespace
 }  // namespace aomhip
 
-extern "C" int aomhip_joint_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref0, const aomhip_planes *ref1, int frame,
-                                                int bw, int bh, int mv_cost_type, int sad_per_bit, const aomhip_subpel_params *sub, int force_integer_mv,
-                                                const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
-                                                const aomhip_search_block *d_blocks, const int16_t *d_ref_mv, int16_t *d_cur_mv, const uint8_t *d_mask, int n,
-                                                int32_t *d_rate_mv, int32_t *d_best_err) {
+// `full` null: the 8-neighbour refinement (disable_extensive_joint_motion_search, or COMPOUND_WEDGE); non-null: av1_full_pixel_search on the
+// compound prediction with these parameters (:613-617) and, with allow_second_mv, the second sub-pel start
+static int joint_motion_search(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref0, const aomhip_planes *ref1, int frame, int bw, int bh,
+                               const aomhip_search_params *full, int allow_second_mv, int mv_cost_type, int sad_per_bit, const aomhip_subpel_params *sub,
+                               int force_integer_mv, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                               const aomhip_search_block *d_blocks, const int16_t *d_ref_mv, int16_t *d_cur_mv, const uint8_t *d_mask, int n,
+                               int32_t *d_rate_mv, int32_t *d_best_err) {
   if (!ctx || !src || !ref0 || !ref1 || !sub || n < 0 || !d_mvjcost || !d_mvcost_row || !d_mvcost_col ||
       (n > 0 && (!d_blocks || !d_ref_mv || !d_cur_mv || !d_rate_mv || !d_best_err))) {
     set_error("aomhip_joint_motion_search_batch: invalid argument (the rate of the result needs the MV cost tables)");
@@ -1036,7 +1056,8 @@ extern "C" int aomhip_joint_motion_search_batch(aomhip_ctx *ctx, const aomhip_pl
   const size_t n1 = (size_t)n, SB = sizeof(aomhip_search_block), px = (size_t)bw * bh * (src->bit_depth == 8 ? 1 : 2);
   const size_t o_fl = take(n1 * SB), o_sl = take(n1 * SB), o_init = take(n1 * 8), o_live = take(n1), o_last = take(n1 * 8), o_other = take(n1 * 4),
                o_fmv = take(n1 * 4), o_fsad = take(n1 * 4), o_fvar = take(n1 * 4), o_smv = take(n1 * 4), o_serr = take(n1 * 4), o_dist = take(n1 * 4),
-               o_sse = take(n1 * 4), o_pred = take(n1 * px);
+               o_sse = take(n1 * 4), o_sec = take(n1 * 4), o_sl2 = take(n1 * SB), o_use2 = take(n1), o_smv2 = take(n1 * 4), o_serr2 = take(n1 * 4),
+               o_pred = take(n1 * px);
   char *w = static_cast<char *>(work(ctx, off));
   if (!w) return AOMHIP_ERR_NOMEM;
   auto blk = [&](size_t o) { return reinterpret_cast<aomhip_search_block *>(w + o); };
@@ -1059,22 +1080,57 @@ extern "C" int aomhip_joint_motion_search_batch(aomhip_ctx *ctx, const aomhip_pl
     int rc = aomhip_build_inter_pred_contiguous_batch(ctx, roth, frame, w + o_pred, bw, bh, d_blocks, i16(o_other), n, AOMHIP_INTERP_REGULAR,
                                                       AOMHIP_INTERP_REGULAR);
     if (rc != AOMHIP_OK) return rc;
-    rc = aomhip_refining_search_8p_batch(ctx, src, rid, frame, bw, bh, mv_cost_type, sad_per_bit, sub->error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col,
-                                         blk(o_fl), n, w + o_pred, d_mask, id, i16(o_fmv), i32(o_fsad), i32(o_fvar));
+    if (full)   // bestsme = av1_full_pixel_search(start_fullmv, &full_ms_params, 5, NULL, &best_mv, &second_best_mv)
+      rc = aomhip_compound_full_pixel_search_batch(ctx, src, rid, frame, bw, bh, full, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_fl), n, w + o_pred, d_mask,
+                                                   id, i16(o_fmv), i32(o_fsad), i16(o_sec));
+    else
+      rc = aomhip_refining_search_8p_batch(ctx, src, rid, frame, bw, bh, mv_cost_type, sad_per_bit, sub->error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col,
+                                           blk(o_fl), n, w + o_pred, d_mask, id, i16(o_fmv), i32(o_fsad), i32(o_fvar));
     if (rc != AOMHIP_OK) return rc;
+    const bool second = full && allow_second_mv && !force_integer_mv;
     if (!force_integer_mv) {
       hipLaunchKernelGGL(joint_subpel_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_ref_mv, i16(o_fmv), id, n, blk(o_sl));
       AOMHIP_LAUNCH_CHECK();
       rc = aomhip_compound_subpel_tree_batch(ctx, src, rid, frame, bw, bh, &sp, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_sl), n, w + o_pred, d_mask, id,
                                              i16(o_smv), u32(o_serr), i32(o_dist), u32(o_sse));
       if (rc != AOMHIP_OK) return rc;
+      if (second) {
+        hipLaunchKernelGGL(joint_second_list_kernel, dim3(g), dim3(256), 0, ctx->stream, blk(o_sl), i16(o_fmv), i16(o_sec), n, blk(o_sl2),
+                           reinterpret_cast<uint8_t *>(w + o_use2));
+        AOMHIP_LAUNCH_CHECK();
+        rc = aomhip_compound_subpel_tree_batch(ctx, src, rid, frame, bw, bh, &sp, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_sl2), n, w + o_pred, d_mask, id,
+                                               i16(o_smv2), u32(o_serr2), i32(o_dist), u32(o_sse));
+        if (rc != AOMHIP_OK) return rc;
+      }
     }
     hipLaunchKernelGGL(joint_update_kernel, dim3(g), dim3(256), 0, ctx->stream, id, n, force_integer_mv, i16(o_fmv), i32(o_fsad), i16(o_smv), u32(o_serr),
-                       live, i32(o_last), d_cur_mv);
+                       second ? reinterpret_cast<const uint8_t *>(w + o_use2) : nullptr, i16(o_smv2), u32(o_serr2), live, i32(o_last), d_cur_mv);
     AOMHIP_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(joint_finish_kernel, dim3(g), dim3(256), 0, ctx->stream, n, d_cur_mv, d_ref_mv, i32(o_last), d_mvjcost, d_mvcost_row, d_mvcost_col,
                      d_rate_mv, d_best_err);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
+}
+
+extern "C" int aomhip_joint_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref0, const aomhip_planes *ref1, int frame,
+                                                int bw, int bh, int mv_cost_type, int sad_per_bit, const aomhip_subpel_params *sub, int force_integer_mv,
+                                                const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                                const aomhip_search_block *d_blocks, const int16_t *d_ref_mv, int16_t *d_cur_mv, const uint8_t *d_mask, int n,
+                                                int32_t *d_rate_mv, int32_t *d_best_err) {
+  return joint_motion_search(ctx, src, ref0, ref1, frame, bw, bh, nullptr, 0, mv_cost_type, sad_per_bit, sub, force_integer_mv, d_mvjcost, d_mvcost_row,
+                             d_mvcost_col, d_blocks, d_ref_mv, d_cur_mv, d_mask, n, d_rate_mv, d_best_err);
+}
+
+extern "C" int aomhip_joint_motion_search_extensive_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref0, const aomhip_planes *ref1,
+                                                          int frame, int bw, int bh, const aomhip_search_params *full, const aomhip_subpel_params *sub,
+                                                          int allow_second_mv, int force_integer_mv, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                                                          const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, const int16_t *d_ref_mv,
+                                                          int16_t *d_cur_mv, const uint8_t *d_mask, int n, int32_t *d_rate_mv, int32_t *d_best_err) {
+  if (!full) {
+    set_error("aomhip_joint_motion_search_extensive_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  return joint_motion_search(ctx, src, ref0, ref1, frame, bw, bh, full, allow_second_mv, full->mv_cost_type, full->sad_per_bit, sub, force_integer_mv,
+                             d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, d_ref_mv, d_cur_mv, d_mask, n, d_rate_mv, d_best_err);
 }

@@ -666,7 +666,7 @@ int aomhip_compound_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *src,
                                       const uint8_t *d_mask, int invert_mask, int16_t *d_best_mv, uint32_t *d_best_err, int32_t *d_distortion,
                                       uint32_t *d_sse);
 /* av1_joint_motion_search (motion_search_facade.c:496-702) for n independent compound blocks, on the branch with the 8-neighbour refinement
- * (disable_extensive_joint_motion_search, or COMPOUND_WEDGE -- every speed preset): up to four alternating iterations of {predictor of the
+ * (disable_extensive_joint_motion_search -- speed >= 1, speed_features.c:958 -- or COMPOUND_WEDGE): up to four alternating iterations of {predictor of the
  * other reference at cur_mv[!id] (EIGHTTAP_REGULAR), av1_refining_search_8p_c from get_fullmv_from_mv(cur_mv[id]), the compound sub-pel tree of
  * `sub` with forced_stop EIGHTH_PEL}, a block stopping at the first iteration that does not lower its reference's error (:689-696) or that finds
  * its MVs back at the initial ones (:544-562); second_best_mv == best_mv on this branch, so allow_second_mv has no effect.
@@ -681,6 +681,17 @@ int aomhip_joint_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, 
                                      const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
                                      const aomhip_search_block *d_blocks, const int16_t *d_ref_mv, int16_t *d_cur_mv, const uint8_t *d_mask, int n,
                                      int32_t *d_rate_mv, int32_t *d_best_err);
+/* The same function on its OTHER branch (disable_extensive_joint_motion_search == 0: speed 0; not COMPOUND_WEDGE): the full-pel step of an iteration is
+ * av1_full_pixel_search(start_fullmv, &full_ms_params, 5, NULL, &best_mv, &second_best_mv) on the compound prediction (:613-617;
+ * aomhip_compound_full_pixel_search_batch with `full` -- what av1_make_default_fullpel_ms_params fills: search method, mesh rules, MV cost type,
+ * sad_per_bit; step_param 5 is the reference's), and with allow_second_mv (!sf.mv_sf.disable_second_mv) the compound sub-pel tree is run a second
+ * time from second_best_mv where that is valid, differs from best_mv and lies inside the sub-pel limits, the lower error winning (:621-623,
+ * :664-676).  Everything else as aomhip_joint_motion_search_batch. */
+int aomhip_joint_motion_search_extensive_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref0, const aomhip_planes *ref1, int frame,
+                                               int bw, int bh, const aomhip_search_params *full, const aomhip_subpel_params *sub, int allow_second_mv,
+                                               int force_integer_mv, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                               const aomhip_search_block *d_blocks, const int16_t *d_ref_mv, int16_t *d_cur_mv, const uint8_t *d_mask,
+                                               int n, int32_t *d_rate_mv, int32_t *d_best_err);
 /* av1_find_best_obmc_sub_pixel_tree_up (mcomp.c:3588-3633) for every block: the sub-pel half of the OBMC search (the branch of
  * av1_single_motion_search for OBMC_CAUSAL, motion_search_facade.c:432-445).  params: iters_per_step, allow_hp, forced_stop, mv_cost_type,
  * error_per_bit and subpel_search_type -- 0 USE_2_TAPS_ORIG: vfp->osvf + estimate_obmc_mvcost (:3390-3412; ENTROPY or NONE, the L1 types

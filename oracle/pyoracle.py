@@ -1305,9 +1305,10 @@ def compound_subpel_tree_batch(src_b, ref_b, border, w, h, blocks, second_pred, 
 
 
 def joint_motion_search_batch(src_b, ref0_b, ref1_b, border, width, height, w, h, blocks, ref_mv, cur_mv, mask=None, cost_type=0, sad_per_bit=0, sub=None,
-                              force_integer_mv=0, mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4):
-    """av1_joint_motion_search (motion_search_facade.c:496-702) on the refining-search branch, composed of the pinned pieces (the sequencing itself
-    is read from the reference, not interpreted): blocks = bx, by + raw x->mv_limits; ref_mv / cur_mv [n, 2, 2] in 1/8 pel; sub = kwargs of
+                              force_integer_mv=0, mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4, full=None, allow_second_mv=0):
+    """av1_joint_motion_search (motion_search_facade.c:496-702), composed of the pinned pieces (the sequencing itself is read from the reference,
+    not interpreted).  full None: the refining-search branch; full = search params (search_params(..)): the extensive branch -- av1_full_pixel_search
+    on the compound prediction, and with allow_second_mv the second sub-pel start (:621-623, :664-676).  blocks = bx, by + raw x->mv_limits; ref_mv / cur_mv [n, 2, 2] in 1/8 pel; sub = kwargs of
     compound_subpel_tree_batch (tree, subpel_search_type, error_per_bit, iters_per_step, allow_hp).  -> (cur_mv [n, 2, 2], rate_mv [n], best_err [n], iterations [n])"""
     blocks = np.ascontiguousarray(blocks)
     n = len(blocks)
@@ -1337,8 +1338,13 @@ def joint_motion_search_batch(src_b, ref0_b, ref1_b, border, width, height, w, h
             for l_ in (fl, sl):
                 l_["ref_row"][i], l_["ref_col"][i] = rr, rc
         fl["start_row"], fl["start_col"] = _rawpel(cur[:, i_d, 0]), _rawpel(cur[:, i_d, 1])
-        fmv, fsad, _ = refining_search_8p_batch(src_b, refs[i_d], border, w, h, fl, sp, mask, i_d, cost_type=cost_type, sad_per_bit=sad_per_bit,
-                                                error_per_bit=epb, mvjcost=mvjcost, mvcost0=mvcost0, mvcost1=mvcost1, bd=bd, threads=threads)
+        sec = None
+        if full is not None:
+            fmv, fsad, sec = compound_full_pixel_search_batch(src_b, refs[i_d], border, w, h, fl, full, sp, mask, i_d, mvjcost=mvjcost, mvcost0=mvcost0,
+                                                              mvcost1=mvcost1, bd=bd, threads=threads)
+        else:
+            fmv, fsad, _ = refining_search_8p_batch(src_b, refs[i_d], border, w, h, fl, sp, mask, i_d, cost_type=cost_type, sad_per_bit=sad_per_bit,
+                                                    error_per_bit=epb, mvjcost=mvjcost, mvcost0=mvcost0, mvcost1=mvcost1, bd=bd, threads=threads)
         best = fmv.astype(np.int32) * 8
         sme = fsad.astype(np.int64)
         if not force_integer_mv:
@@ -1348,6 +1354,21 @@ def joint_motion_search_batch(src_b, ref0_b, ref1_b, border, width, height, w, h
             ok = sme < 2**31 - 1
             best = np.where(ok[:, None], smv.astype(np.int32), best)
             sme = np.where(ok, serr.astype(np.int64).astype(np.int32).astype(np.int64), sme)   # (int)besterr
+            if sec is not None and allow_second_mv:   # try_second: valid, != best_mv, inside the sub-pel limits
+                s8 = sec.astype(np.int32) * 8
+                use = ok & ~((sec[:, 0] == -32768) & (sec[:, 1] == -32768)) & (sec != fmv).any(1) & (s8[:, 0] >= sl["row_min"]) & (s8[:, 0] <= sl["row_max"]) & \
+                    (s8[:, 1] >= sl["col_min"]) & (s8[:, 1] <= sl["col_max"])
+                if use.any():
+                    idx = np.flatnonzero(use)
+                    sl2 = np.array(sl[idx], copy=True)
+                    sl2["start_row"], sl2["start_col"] = s8[idx, 0], s8[idx, 1]
+                    smv2, serr2, _, _ = compound_subpel_tree_batch(src_b, refs[i_d], border, w, h, sl2, sp[idx], None if mask is None else np.asarray(mask)[idx],
+                                                                   i_d, cost_type=cost_type, mvjcost=mvjcost, mvcost0=mvcost0, mvcost1=mvcost1, forced_stop=0,
+                                                                   bd=bd, threads=threads, **sub)
+                    e2 = serr2.astype(np.int64).astype(np.int32).astype(np.int64)
+                    for j, i in enumerate(idx):
+                        if e2[j] < sme[i]:
+                            sme[i] = e2[j]; best[i] = smv2[j]
         for i in range(n):
             if not live[i]:
                 continue

@@ -1,5 +1,5 @@
-"""aomhip_joint_motion_search_batch: av1_joint_motion_search (av1/encoder/motion_search_facade.c:496-702) on the refining-search branch, as one call
-per batch of compound blocks, against the composition of the pinned pieces (oracle.joint_motion_search_batch: predictor of the other reference ->
+"""aomhip_joint_motion_search_batch / _extensive_batch: av1_joint_motion_search (av1/encoder/motion_search_facade.c:496-702) on the refining-search
+branch and on the extensive one (av1_full_pixel_search on the compound prediction, second sub-pel start), as one call per batch of compound blocks, against the composition of the pinned pieces (oracle.joint_motion_search_batch: predictor of the other reference ->
 av1_refining_search_8p_c -> compound sub-pel tree -> the update / early-out rules, four alternating iterations) -- 8 / 10-bit, averaged and masked
 compounds, entropy and L1 MV costs, force_integer_mv; and aomhip_build_inter_pred_contiguous_batch against the plane form."""
 import numpy as np
@@ -64,6 +64,77 @@ def test_joint_search_equals_the_composition(hip, oracle, ctx, bd, bw, bh, maske
         ctx.free(d)
     for p_ in (ps, p0, p1):
         ctx.planes_free(p_)
+
+
+@pytest.mark.parametrize("bd,bw,bh,masked,ct,tree,sst,second,mesh_thr", [(8, 16, 16, 0, 0, 2, 0, 1, None), (10, 16, 16, 1, 3, 2, 3, 1, 0), (8, 32, 16, 0, 0, 1, 0, 0, None),
+                                                                         (10, 8, 8, 1, 0, 2, 0, 1, 3000)])
+def test_extensive_joint_search_equals_the_composition(hip, oracle, ctx, bd, bw, bh, masked, ct, tree, sst, second, mesh_thr):
+    """disable_extensive_joint_motion_search == 0 (speed 0): av1_full_pixel_search(.., 5, ..) on the compound prediction per iteration, the second
+    sub-pel start from second_best_mv (allow_second_mv), NSTEP's mesh follow-up on the plain SAD."""
+    capi = hip.capi
+    W, H, B = 256, 160, 96
+    rng = np.random.default_rng(11 * bd + bw + 7 * masked + tree)
+    src, ref0 = hip.synth.shifted_smooth_pair(W, H, 33, bd, shift=(3, -4), frac8=(2, 0))
+    _, ref1 = hip.synth.shifted_smooth_pair(W, H, 33, bd, shift=(-4, 3), frac8=(0, 6))
+    mx = (1 << bd) - 1
+    noisy = lambda a, k: np.clip(a.astype(np.int32) + rng.integers(-k, k + 1, a.shape), 0, mx).astype(a.dtype)
+    ref0, ref1 = noisy(ref0, 2 << (bd - 8)), noisy(ref1, 2 << (bd - 8))
+    ps, p0, p1 = (ctx.planes_alloc(W, H, B, bd, 1) for _ in range(3))
+    for p_, a in ((ps, src), (p0, ref0), (p1, ref1)):
+        ctx.planes_upload(p_, 0, a)
+    gc, gr = W // bw, H // bh
+    n = min(gc * gr, 120)
+    pick = rng.permutation(gc * gr)[:n]
+    blocks = np.zeros(n, capi.search_block_dtype)
+    blocks["bx"], blocks["by"] = (pick % gc) * bw, (pick // gc) * bh
+    ext = B - 8 - 16
+    blocks["col_min"], blocks["col_max"] = -(blocks["bx"] + ext), W - blocks["bx"] - bw + ext
+    blocks["row_min"], blocks["row_max"] = -(blocks["by"] + ext), H - blocks["by"] - bh + ext
+    ref_mv = rng.integers(-40, 41, (n, 2, 2)).astype(np.int16)
+    cur = np.zeros((n, 2, 2), np.int16)
+    cur[:, 0] = np.array([-4 * 8, 3 * 8]) + rng.integers(-60, 61, (n, 2))        # up to 7 PIXELS off the true motion: out of the 8-neighbour refinement's reach
+    cur[:, 1] = np.array([3 * 8, -4 * 8]) + rng.integers(-60, 61, (n, 2))
+    cur[::5] = 0
+    mask = np.clip((np.arange(bw)[None, None, :] * 64 // bw + rng.integers(-6, 7, (n, bh, bw))), 0, 64).astype(np.uint8) if masked else None
+    mv_max, tj, t0, t1 = _tables()
+    sb, r0b, r1b = (oracle.extend_plane(a, B, ps.stride) for a in (src, ref0, ref1))
+    sub_kw = dict(tree=tree, subpel_search_type=sst, error_per_bit=61, iters_per_step=2, allow_hp=1)
+    mesh = [(12, 4), (6, 2), (4, 1), (3, 1)]
+    kw = {} if mesh_thr is None else dict(force_mesh_thresh=mesh_thr, mesh=mesh)
+    oq = oracle.search_params("NSTEP", 5, ct, 22, 61, no_cost_list=1, **kw)
+    want_mv, want_rate, want_err, iters = oracle.joint_motion_search_batch(sb, r0b, r1b, B, W, H, bw, bh, blocks, ref_mv, cur, mask, cost_type=ct, sad_per_bit=22,
+                                                                           sub=sub_kw, mvjcost=tj, mvcost0=t0, mvcost1=t1, bd=bd, threads=8, full=oq,
+                                                                           allow_second_mv=second)
+    d_j, d_c0, d_c1 = ctx.to_device(tj), ctx.to_device(t0), ctx.to_device(t1)
+    d_b, d_r, d_cur = ctx.to_device(blocks), ctx.to_device(ref_mv), ctx.to_device(cur)
+    d_m = ctx.to_device(mask) if masked else None
+    d_rate, d_err = ctx.malloc(n * 4), ctx.malloc(n * 4)
+    sub = capi.SubpelParams(tree, ct, 61, 2, 1, 3, sst)
+    full = capi.SearchParams.make("NSTEP", 5, ct, 22, 61, **kw)
+    ctx.joint_motion_search_extensive_batch(ps, p0, p1, 0, bw, bh, full, sub, second, 0, d_b, d_r, d_cur, d_m, n, d_rate, d_err, d_j, d_c0 + mv_max * 4,
+                                            d_c1 + mv_max * 4)
+    got_mv = ctx.from_device(d_cur, (n, 2, 2), np.int16)
+    assert np.array_equal(got_mv, want_mv), np.flatnonzero((got_mv != want_mv).reshape(n, -1).any(1))[:8]
+    assert np.array_equal(ctx.from_device(d_rate, (n,), np.int32), want_rate)
+    assert np.array_equal(ctx.from_device(d_err, (n,), np.int32), want_err)
+    assert (want_mv != cur).any(axis=(1, 2)).mean() > 0.5 and len(set(iters.tolist())) >= 2
+    # ... and it is a different search from the refining branch on these inputs
+    ref_mv_, _, ref_err, _ = oracle.joint_motion_search_batch(sb, r0b, r1b, B, W, H, bw, bh, blocks, ref_mv, cur, mask, cost_type=ct, sad_per_bit=22, sub=sub_kw,
+                                                              mvjcost=tj, mvcost0=t0, mvcost1=t1, bd=bd, threads=8)
+    assert (ref_mv_ != want_mv).any()
+    if second:   # the second start does win somewhere (else the branch is not exercised)
+        no2, _, _, _ = oracle.joint_motion_search_batch(sb, r0b, r1b, B, W, H, bw, bh, blocks, ref_mv, cur, mask, cost_type=ct, sad_per_bit=22, sub=sub_kw,
+                                                        mvjcost=tj, mvcost0=t0, mvcost1=t1, bd=bd, threads=8, full=oq, allow_second_mv=0)
+        test_extensive_joint_search_equals_the_composition.second_won = getattr(test_extensive_joint_search_equals_the_composition, "second_won", 0) + \
+            int((no2 != want_mv).any())
+    for d in [d_j, d_c0, d_c1, d_b, d_r, d_cur, d_rate, d_err] + ([d_m] if masked else []):
+        ctx.free(d)
+    for p_ in (ps, p0, p1):
+        ctx.planes_free(p_)
+
+
+def test_the_second_subpel_start_won_somewhere():
+    assert getattr(test_extensive_joint_search_equals_the_composition, "second_won", 0) >= 1
 
 
 def test_contiguous_predictor_equals_the_plane_form(hip, ctx):
