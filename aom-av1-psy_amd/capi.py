@@ -195,6 +195,7 @@ _protos = {
     "aomhip_obmc_full_pixel_search_batch": (C.c_int, [_vp, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_build_inter_pred_contiguous_batch": (C.c_int, [_vp, _PP, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i]),
     "aomhip_joint_motion_search_batch": (C.c_int, [_vp, _PP, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "aomhip_compound_single_motion_search_batch": (C.c_int, [_vp, _PP, _PP, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "aomhip_joint_motion_search_extensive_batch": (C.c_int, [_vp, _PP, _PP, _PP, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "aomhip_compound_subpel_tree_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_obmc_subpel_tree_batch": (C.c_int, [_vp, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -556,6 +557,14 @@ class Context:
     def build_inter_pred_contiguous_batch(self, ref, frame, d_pred, bw, bh, d_blocks, d_mv, n, fx=0, fy=0):
         check(lib.aomhip_build_inter_pred_contiguous_batch(self.h, C.byref(ref), frame, d_pred, bw, bh, d_blocks, d_mv, n, fx, fy),
               "aomhip_build_inter_pred_contiguous_batch")
+
+    def compound_single_motion_search_batch(self, src, ref, ref_other, frame, bw, bh, full, sub, force_integer_mv, d_blocks, d_ref_mv, d_this_mv, d_other_mv,
+                                            fx, fy, d_second_pred, d_mask, ref_idx, n, d_rate_mv, d_bestsme, d_mvjcost, d_mvcost_row, d_mvcost_col):
+        """av1_compound_single_motion_search[_interinter] per block; ref_other None with d_second_pred given, or the other way round."""
+        check(lib.aomhip_compound_single_motion_search_batch(self.h, C.byref(src), C.byref(ref), None if ref_other is None else C.addressof(ref_other), frame, bw,
+                                                             bh, C.byref(full), C.byref(sub), int(force_integer_mv), d_mvjcost, d_mvcost_row, d_mvcost_col,
+                                                             d_blocks, d_ref_mv, d_this_mv, d_other_mv, fx, fy, d_second_pred, d_mask, ref_idx, n, d_rate_mv,
+                                                             d_bestsme), "aomhip_compound_single_motion_search_batch")
 
     def joint_motion_search_extensive_batch(self, src, ref0, ref1, frame, bw, bh, full, sub, allow_second_mv, force_integer_mv, d_blocks, d_ref_mv, d_cur_mv,
                                             d_mask, n, d_rate_mv, d_best_err, d_mvjcost, d_mvcost_row, d_mvcost_col):

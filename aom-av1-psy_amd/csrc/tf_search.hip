@@ -1134,3 +1134,99 @@ extern "C" int aomhip_joint_motion_search_extensive_batch(aomhip_ctx *ctx, const
   return joint_motion_search(ctx, src, ref0, ref1, frame, bw, bh, full, allow_second_mv, full->mv_cost_type, full->sad_per_bit, sub, force_integer_mv,
                              d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, d_ref_mv, d_cur_mv, d_mask, n, d_rate_mv, d_best_err);
 }
+
+// ---- av1_compound_single_motion_search[_interinter] (av1/encoder/motion_search_facade.c:703-853): ONE component of a compound refined against the
+// fixed predictor of the other -- do_masked_motion_search_indexed / the interintra search.  Always the full search: av1_full_pixel_search(start, .., 5,
+// NULL, &best, NULL) on the compound prediction (:758-764), then the compound sub-pel tree with forced_stop EIGHTH_PEL (:779-793).
+namespace aomhip {
+namespace {
+__global__ void csingle_prepare_kernel(const aomhip_search_block *blocks, const int16_t *ref_mv, const int16_t *this_mv, int n, aomhip_search_block *full_list) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  aomhip_search_block b = blocks[i];
+  b.ref_row = ref_mv[2 * i]; b.ref_col = ref_mv[2 * i + 1];
+  aomhip_search_block o = b;
+  o.start_row = (int16_t)rawpel(this_mv[2 * i]); o.start_col = (int16_t)rawpel(this_mv[2 * i + 1]);   // get_fullmv_from_mv(this_mv)
+  full_limits_ref(b, &o);
+  full_list[i] = o;
+}
+__global__ void csingle_subpel_list_kernel(const aomhip_search_block *blocks, const int16_t *ref_mv, const int16_t *full_mv, int n, aomhip_search_block *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  aomhip_search_block b = blocks[i];
+  b.ref_row = ref_mv[2 * i]; b.ref_col = ref_mv[2 * i + 1];
+  aomhip_search_block o = b;
+  o.start_row = (int16_t)(full_mv[2 * i] * 8); o.start_col = (int16_t)(full_mv[2 * i + 1] * 8);
+  subpel_limits_ref(b, &o);
+  out[i] = o;
+}
+__global__ void csingle_finish_kernel(int n, int force_integer_mv, const int16_t *full_mv, const int32_t *full_var, const int16_t *sub_mv, const uint32_t *sub_err,
+                                      const int16_t *ref_mv, const int32_t *mvjcost, const int32_t *mvcost0, const int32_t *mvcost1, int16_t *this_mv,
+                                      int32_t *rate_mv, int32_t *bestsme_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int bestsme = full_var[i], row = full_mv[2 * i] * 8, col = full_mv[2 * i + 1] * 8;   // convert_fullmv_to_mv (:773-775)
+  if (bestsme < INT_MAX && !force_integer_mv) { bestsme = (int)sub_err[i]; row = sub_mv[2 * i]; col = sub_mv[2 * i + 1]; }
+  if (bestsme < INT_MAX) { this_mv[2 * i] = (int16_t)row; this_mv[2 * i + 1] = (int16_t)col; }   // (:798)
+  const int dr = this_mv[2 * i] - ref_mv[2 * i], dc = this_mv[2 * i + 1] - ref_mv[2 * i + 1];   // av1_mv_bit_cost(.., MV_COST_WEIGHT)
+  const int64_t bits = (int64_t)mvjcost[(dc != 0) | ((dr != 0) << 1)] + mvcost0[dr] + mvcost1[dc];
+  rate_mv[i] = (int)((bits * 108 + 64) >> 7);
+  bestsme_out[i] = bestsme;
+}
+}  // namespace
+}  // namespace aomhip
+
+extern "C" int aomhip_compound_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, const aomhip_planes *ref_other,
+                                                          int frame, int bw, int bh, const aomhip_search_params *full, const aomhip_subpel_params *sub,
+                                                          int force_integer_mv, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                                                          const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks, const int16_t *d_ref_mv,
+                                                          int16_t *d_this_mv, const int16_t *d_other_mv, int interp_filter_x, int interp_filter_y,
+                                                          const void *d_second_pred, const uint8_t *d_mask, int ref_idx, int n, int32_t *d_rate_mv,
+                                                          int32_t *d_bestsme) {
+  if (!ctx || !src || !ref || !full || (!sub && !force_integer_mv) || n < 0 || !d_mvjcost || !d_mvcost_row || !d_mvcost_col ||
+      (n > 0 && (!d_blocks || !d_ref_mv || !d_this_mv || !d_rate_mv || !d_bestsme)) || (!d_second_pred && (!ref_other || !d_other_mv)) ||
+      (ref_idx != 0 && ref_idx != 1)) {
+    set_error("aomhip_compound_single_motion_search_batch: invalid argument (second_pred, or the other reference and its MVs; the MV cost tables)");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n == 0) return AOMHIP_OK;
+  AOMHIP_TRY(hipSetDevice(ctx->device));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t n1 = (size_t)n, SB = sizeof(aomhip_search_block), px = (size_t)bw * bh * (src->bit_depth == 8 ? 1 : 2);
+  const size_t o_fl = take(n1 * SB), o_sl = take(n1 * SB), o_fmv = take(n1 * 4), o_fvar = take(n1 * 4), o_sec = take(n1 * 4), o_smv = take(n1 * 4),
+               o_serr = take(n1 * 4), o_dist = take(n1 * 4), o_sse = take(n1 * 4), o_pred = take(d_second_pred ? 0 : n1 * px);
+  char *w = static_cast<char *>(work(ctx, off));
+  if (!w) return AOMHIP_ERR_NOMEM;
+  auto blk = [&](size_t o) { return reinterpret_cast<aomhip_search_block *>(w + o); };
+  auto i16 = [&](size_t o) { return reinterpret_cast<int16_t *>(w + o); };
+  auto i32 = [&](size_t o) { return reinterpret_cast<int32_t *>(w + o); };
+  auto u32 = [&](size_t o) { return reinterpret_cast<uint32_t *>(w + o); };
+  const unsigned g = (unsigned)((n1 + 255) / 256);
+  int rc;
+  const void *pred = d_second_pred;
+  if (!pred) {   // build_second_inter_pred (:803-834): the other reference at other_mv with the block's own interpolation filters
+    rc = aomhip_build_inter_pred_contiguous_batch(ctx, ref_other, frame, w + o_pred, bw, bh, d_blocks, d_other_mv, n, interp_filter_x, interp_filter_y);
+    if (rc != AOMHIP_OK) return rc;
+    pred = w + o_pred;
+  }
+  hipLaunchKernelGGL(csingle_prepare_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_ref_mv, d_this_mv, n, blk(o_fl));
+  AOMHIP_LAUNCH_CHECK();
+  rc = aomhip_compound_full_pixel_search_batch(ctx, src, ref, frame, bw, bh, full, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_fl), n, pred, d_mask, ref_idx,
+                                               i16(o_fmv), i32(o_fvar), i16(o_sec));
+  if (rc != AOMHIP_OK) return rc;
+  if (!force_integer_mv) {
+    aomhip_subpel_params sp = *sub;
+    sp.forced_stop = 0;   // EIGHTH_PEL (:787)
+    sp.mv_cost_type = full->mv_cost_type;
+    hipLaunchKernelGGL(csingle_subpel_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_ref_mv, i16(o_fmv), n, blk(o_sl));
+    AOMHIP_LAUNCH_CHECK();
+    rc = aomhip_compound_subpel_tree_batch(ctx, src, ref, frame, bw, bh, &sp, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_sl), n, pred, d_mask, ref_idx,
+                                           i16(o_smv), u32(o_serr), i32(o_dist), u32(o_sse));
+    if (rc != AOMHIP_OK) return rc;
+  }
+  hipLaunchKernelGGL(csingle_finish_kernel, dim3(g), dim3(256), 0, ctx->stream, n, force_integer_mv, i16(o_fmv), i32(o_fvar), i16(o_smv), u32(o_serr), d_ref_mv,
+                     d_mvjcost, d_mvcost_row, d_mvcost_col, d_this_mv, d_rate_mv, d_bestsme);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}

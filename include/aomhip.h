@@ -621,9 +621,9 @@ int aomhip_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
 /* ---- the compound-reference and OBMC full-pel searches of the RD path (csrc/mcomp_compound.hip)
  *
  * av1_refining_search_8p_c (av1/encoder/mcomp.c:1621-1691) for every block, then av1_get_mvpred_compound_var (:3679-3693) at the MV it
- * returns: the full-pel half of one iteration of av1_joint_motion_search / of av1_compound_single_motion_search
- * (av1/encoder/motion_search_facade.c:496-870) -- the 8-neighbour refinement of ONE MV of a compound against the predictor of the other
- * reference.  Per block i:
+ * returns: the full-pel half of one iteration of av1_joint_motion_search on its refinement branch (av1/encoder/motion_search_facade.c:617-620;
+ * av1_compound_single_motion_search always runs av1_full_pixel_search instead: aomhip_compound_full_pixel_search_batch) -- the 8-neighbour
+ * refinement of ONE MV of a compound against the predictor of the other reference.  Per block i:
  *   d_second_pred   bw x bh pixels (the planes' pixel type), contiguous, block i at element i * bw * bh: what av1_enc_build_one_inter_predictor
  *                   produced for the other reference (aomhip_build_inter_pred_batch writes exactly this layout when given a bw-wide plane)
  *   d_mask          bw x bh blend weights 0..64 (stride bw), block i at i * bw * bh, or NULL: with a mask the SAD is vfp->msdf and the variance
@@ -692,6 +692,23 @@ int aomhip_joint_motion_search_extensive_batch(aomhip_ctx *ctx, const aomhip_pla
                                                int force_integer_mv, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
                                                const aomhip_search_block *d_blocks, const int16_t *d_ref_mv, int16_t *d_cur_mv, const uint8_t *d_mask,
                                                int n, int32_t *d_rate_mv, int32_t *d_best_err);
+/* av1_compound_single_motion_search / _interinter (motion_search_facade.c:703-853; do_masked_motion_search_indexed, the interintra search): ONE MV of a
+ * compound refined against the fixed predictor of the other side, for n independent blocks -- av1_full_pixel_search(get_fullmv_from_mv(this_mv),
+ * &full_ms_params, 5, NULL, &best, NULL) on the compound prediction (every speed: aomhip_compound_full_pixel_search_batch with `full`), the compound
+ * sub-pel tree of `sub` with forced_stop EIGHTH_PEL unless force_integer_mv, *this_mv = the result where bestsme < INT_MAX, *rate_mv =
+ * av1_mv_bit_cost(this_mv, ref_mv, MV_COST_WEIGHT).
+ *   d_blocks   bx, by and the RAW x->mv_limits (the limits are derived with ref_mv as the ms-params builders do)
+ *   d_ref_mv / d_this_mv   n x (row, col), 1/8 pel; d_this_mv is in/out
+ *   d_second_pred          n contiguous bw x bh predictors (the interintra caller's), or NULL: build_second_inter_pred -- the predictor of ref_other at
+ *                          d_other_mv (n x (row, col)) with the block's interpolation filters (interp_filter_x / _y)
+ *   d_mask, ref_idx        the blend weights (n x bw x bh, or NULL) and which side is searched (inv_mask = ref_idx, av1_set_ms_compound_refs)
+ * Outputs: d_this_mv, d_rate_mv, d_bestsme (the return value). */
+int aomhip_compound_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, const aomhip_planes *ref_other, int frame,
+                                               int bw, int bh, const aomhip_search_params *full, const aomhip_subpel_params *sub, int force_integer_mv,
+                                               const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                               const aomhip_search_block *d_blocks, const int16_t *d_ref_mv, int16_t *d_this_mv, const int16_t *d_other_mv,
+                                               int interp_filter_x, int interp_filter_y, const void *d_second_pred, const uint8_t *d_mask, int ref_idx, int n,
+                                               int32_t *d_rate_mv, int32_t *d_bestsme);
 /* av1_find_best_obmc_sub_pixel_tree_up (mcomp.c:3588-3633) for every block: the sub-pel half of the OBMC search (the branch of
  * av1_single_motion_search for OBMC_CAUSAL, motion_search_facade.c:432-445).  params: iters_per_step, allow_hp, forced_stop, mv_cost_type,
  * error_per_bit and subpel_search_type -- 0 USE_2_TAPS_ORIG: vfp->osvf + estimate_obmc_mvcost (:3390-3412; ENTROPY or NONE, the L1 types

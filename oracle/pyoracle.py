@@ -1378,3 +1378,42 @@ def joint_motion_search_batch(src_b, ref0_b, ref1_b, border, width, height, w, h
                 live[i] = False
     rate = np.array([sum(mv_bit_cost(cur[i, r, 0], cur[i, r, 1], refmv[i, r, 0], refmv[i, r, 1], mvjcost, mvcost0, mvcost1) for r in range(2)) for i in range(n)], np.int32)
     return cur.astype(np.int16), rate, last.min(1).astype(np.int32), iters
+
+
+def compound_single_motion_search_batch(src_b, ref_b, border, width, height, w, h, blocks, ref_mv, this_mv, full, sub=None, other_b=None, other_mv=None,
+                                        filter_x=0, filter_y=0, second_pred=None, mask=None, ref_idx=0, force_integer_mv=0, mvjcost=None, mvcost0=None,
+                                        mvcost1=None, bd=8, threads=4):
+    """av1_compound_single_motion_search[_interinter] (motion_search_facade.c:703-853), composed of the pinned pieces: [build_second_inter_pred ->]
+    av1_full_pixel_search on the compound prediction (full = search_params(..), step_param 5 in the reference) -> the compound sub-pel tree
+    (forced_stop EIGHTH_PEL) -> *this_mv, *rate_mv.  blocks = bx, by + raw x->mv_limits; ref_mv / this_mv / other_mv [n, 2] in 1/8 pel.
+    -> (this_mv [n, 2], rate_mv [n], bestsme [n])"""
+    blocks = np.ascontiguousarray(blocks)
+    n = len(blocks)
+    this = np.array(this_mv, np.int32).reshape(n, 2).copy()
+    refmv = np.asarray(ref_mv, np.int32).reshape(n, 2)
+    if second_pred is None:
+        plane = build_inter_pred(other_b, border, width, height, w, h, blocks, np.asarray(other_mv).reshape(n, 2), filter_x, filter_y, bd=bd)
+        second_pred = np.stack([plane[b["by"]:b["by"] + h, b["bx"]:b["bx"] + w] for b in blocks])
+    fl, sl = np.array(blocks, copy=True), np.array(blocks, copy=True)
+    for i, b in enumerate(blocks):
+        raw = (b["row_min"], b["row_max"], b["col_min"], b["col_max"])
+        rr, rc = int(refmv[i, 0]), int(refmv[i, 1])
+        fl["row_min"][i], fl["row_max"][i], fl["col_min"][i], fl["col_max"][i] = set_mv_search_range(raw, rr, rc)
+        sl["row_min"][i], sl["row_max"][i], sl["col_min"][i], sl["col_max"][i] = set_subpel_mv_search_range(raw, rr, rc)
+        for l_ in (fl, sl):
+            l_["ref_row"][i], l_["ref_col"][i] = rr, rc
+    fl["start_row"], fl["start_col"] = _rawpel(this[:, 0]), _rawpel(this[:, 1])
+    fmv, fvar, _ = compound_full_pixel_search_batch(src_b, ref_b, border, w, h, fl, full, second_pred, mask, ref_idx, mvjcost=mvjcost, mvcost0=mvcost0,
+                                                    mvcost1=mvcost1, bd=bd, threads=threads)
+    best = fmv.astype(np.int32) * 8
+    sme = fvar.astype(np.int64)
+    if not force_integer_mv:
+        sl["start_row"], sl["start_col"] = best[:, 0], best[:, 1]
+        smv, serr, _, _ = compound_subpel_tree_batch(src_b, ref_b, border, w, h, sl, second_pred, mask, ref_idx, cost_type=full.cost_type, mvjcost=mvjcost,
+                                                     mvcost0=mvcost0, mvcost1=mvcost1, forced_stop=0, bd=bd, threads=threads, **dict(sub or {}))
+        ok = sme < 2**31 - 1
+        best = np.where(ok[:, None], smv.astype(np.int32), best)
+        sme = np.where(ok, serr.astype(np.int64).astype(np.int32).astype(np.int64), sme)
+    this = np.where((sme < 2**31 - 1)[:, None], best, this)
+    rate = np.array([mv_bit_cost(this[i, 0], this[i, 1], refmv[i, 0], refmv[i, 1], mvjcost, mvcost0, mvcost1) for i in range(n)], np.int32)
+    return this.astype(np.int16), rate, sme.astype(np.int32)

@@ -137,6 +137,73 @@ def test_the_second_subpel_start_won_somewhere():
     assert getattr(test_extensive_joint_search_equals_the_composition, "second_won", 0) >= 1
 
 
+@pytest.mark.parametrize("bd,bw,bh,masked,ref_idx,ct,tree,sst,given_pred,force_int", [(8, 16, 16, 1, 0, 0, 2, 0, 0, 0), (10, 16, 16, 1, 1, 3, 2, 3, 0, 0),
+                                                                                     (8, 32, 32, 0, 1, 0, 1, 0, 1, 0), (10, 8, 16, 1, 0, 0, 0, 0, 1, 0),
+                                                                                     (8, 16, 8, 1, 1, 3, 2, 0, 0, 1)])
+def test_compound_single_search_equals_the_composition(hip, oracle, ctx, bd, bw, bh, masked, ref_idx, ct, tree, sst, given_pred, force_int):
+    """av1_compound_single_motion_search[_interinter] (motion_search_facade.c:703-853): one side of a (masked) compound against the fixed predictor
+    of the other -- the interinter form builds that predictor from the other reference with the block's own filters, the plain form is handed it."""
+    capi = hip.capi
+    W, H, B = 256, 160, 96
+    rng = np.random.default_rng(13 * bd + bw + 5 * bh + ref_idx)
+    src, ref0 = hip.synth.shifted_smooth_pair(W, H, 41, bd, shift=(3, -4), frac8=(2, 0))
+    _, ref1 = hip.synth.shifted_smooth_pair(W, H, 41, bd, shift=(-4, 3), frac8=(0, 6))
+    mx = (1 << bd) - 1
+    noisy = lambda a, k: np.clip(a.astype(np.int32) + rng.integers(-k, k + 1, a.shape), 0, mx).astype(a.dtype)
+    ref0, ref1 = noisy(ref0, 2 << (bd - 8)), noisy(ref1, 2 << (bd - 8))
+    refs = (ref0, ref1)
+    ps, p0, p1 = (ctx.planes_alloc(W, H, B, bd, 1) for _ in range(3))
+    for p_, a in ((ps, src), (p0, ref0), (p1, ref1)):
+        ctx.planes_upload(p_, 0, a)
+    planes = (p0, p1)
+    gc, gr = W // bw, H // bh
+    n = min(gc * gr, 100)
+    pick = rng.permutation(gc * gr)[:n]
+    blocks = np.zeros(n, capi.search_block_dtype)
+    blocks["bx"], blocks["by"] = (pick % gc) * bw, (pick // gc) * bh
+    ext = B - 8 - 16
+    blocks["col_min"], blocks["col_max"] = -(blocks["bx"] + ext), W - blocks["bx"] - bw + ext
+    blocks["row_min"], blocks["row_max"] = -(blocks["by"] + ext), H - blocks["by"] - bh + ext
+    true_mv = (np.array([-4 * 8, 3 * 8]), np.array([3 * 8, -4 * 8]))
+    ref_mv = rng.integers(-40, 41, (n, 2)).astype(np.int16)
+    this = (true_mv[ref_idx] + rng.integers(-44, 45, (n, 2))).astype(np.int16)
+    this[::6] = 0
+    other = (true_mv[1 - ref_idx] + rng.integers(-6, 7, (n, 2))).astype(np.int16)
+    mask = np.clip((np.arange(bw)[None, None, :] * 64 // bw + rng.integers(-6, 7, (n, bh, bw))), 0, 64).astype(np.uint8) if masked else None
+    mv_max, tj, t0, t1 = _tables()
+    sb = oracle.extend_plane(src, B, ps.stride)
+    rb = [oracle.extend_plane(a, B, ps.stride) for a in refs]
+    sub_kw = dict(tree=tree, subpel_search_type=sst, error_per_bit=61, iters_per_step=2, allow_hp=1)
+    mesh = [(12, 4), (6, 2), (4, 1), (3, 1)]
+    kw = dict(force_mesh_thresh=6000 if bw * bh >= 256 else 1500, mesh=mesh)
+    oq = oracle.search_params("NSTEP", 5, ct, 22, 61, no_cost_list=1, **kw)
+    fx, fy = 2, 1   # AOMHIP_INTERP_SHARP horizontally, _SMOOTH vertically (mbmi->interp_filters)
+    sp = None
+    if given_pred:   # the interintra caller's form: any predictor
+        sp = np.stack([np.clip(rb[1 - ref_idx][B + b["by"] + 1:B + b["by"] + 1 + bh, B + b["bx"] - 2:B + b["bx"] - 2 + bw].astype(np.int32) +
+                               rng.integers(-5, 6, (bh, bw)), 0, mx) for b in blocks]).astype(src.dtype)
+    want_mv, want_rate, want_sme = oracle.compound_single_motion_search_batch(sb, rb[ref_idx], B, W, H, bw, bh, blocks, ref_mv, this, oq, sub_kw, rb[1 - ref_idx],
+                                                                              other, fx, fy, sp, mask, ref_idx, force_int, tj, t0, t1, bd=bd, threads=8)
+    d_j, d_c0, d_c1 = ctx.to_device(tj), ctx.to_device(t0), ctx.to_device(t1)
+    d_b, d_r, d_this, d_o = ctx.to_device(blocks), ctx.to_device(ref_mv), ctx.to_device(this), ctx.to_device(other)
+    d_m = ctx.to_device(mask) if masked else None
+    d_sp = ctx.to_device(sp) if given_pred else None
+    d_rate, d_sme = ctx.malloc(n * 4), ctx.malloc(n * 4)
+    sub = capi.SubpelParams(tree, ct, 61, 2, 1, 3, sst)
+    full = capi.SearchParams.make("NSTEP", 5, ct, 22, 61, **kw)
+    ctx.compound_single_motion_search_batch(ps, planes[ref_idx], None if given_pred else planes[1 - ref_idx], 0, bw, bh, full, sub, force_int, d_b, d_r, d_this,
+                                            None if given_pred else d_o, fx, fy, d_sp, d_m, ref_idx, n, d_rate, d_sme, d_j, d_c0 + mv_max * 4, d_c1 + mv_max * 4)
+    got_mv = ctx.from_device(d_this, (n, 2), np.int16)
+    assert np.array_equal(got_mv, want_mv), np.flatnonzero((got_mv != want_mv).any(1))[:8]
+    assert np.array_equal(ctx.from_device(d_rate, (n,), np.int32), want_rate)
+    assert np.array_equal(ctx.from_device(d_sme, (n,), np.int32), want_sme)
+    assert (want_mv != this).any(1).mean() > 0.5
+    for d in [d_j, d_c0, d_c1, d_b, d_r, d_this, d_o, d_rate, d_sme] + ([d_m] if masked else []) + ([d_sp] if given_pred else []):
+        ctx.free(d)
+    for p_ in (ps, p0, p1):
+        ctx.planes_free(p_)
+
+
 def test_contiguous_predictor_equals_the_plane_form(hip, ctx):
     capi = hip.capi
     W, H, B, bw, bh, bd = 128, 96, 64, 16, 8, 10
