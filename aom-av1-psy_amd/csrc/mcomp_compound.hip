@@ -410,7 +410,18 @@ __device__ constexpr int16_t kObmcSubPel8[16][6] = {   // av1_sub_pel_filters_8 
   { 2, -14, 76, 76, -14, 2 },  { 2, -12, 66, 84, -14, 2 },  { 2, -12, 58, 94, -16, 2 },  { 2, -12, 48, 102, -14, 2 },
   { 2, -10, 38, 110, -14, 2 }, { 2, -8, 28, 116, -12, 2 },  { 0, -4, 18, 122, -10, 2 },  { 0, -2, 8, 126, -6, 2 }
 };
-struct ObmcSubpelArgs { int iters_per_step, allow_hp, forced_stop, upsampled; };
+__device__ constexpr int16_t kObmcSubPel4[16][6] = {   // av1_sub_pel_filters_4 (filter.h:205-215; USE_4_TAPS, av1_get_filter :270-279), taps 1 .. 6
+  { 0, 0, 128, 0, 0, 0 },     { 0, -4, 126, 8, -2, 0 },   { 0, -8, 122, 18, -4, 0 },  { 0, -10, 116, 28, -6, 0 },
+  { 0, -12, 110, 38, -8, 0 }, { 0, -12, 102, 48, -10, 0 }, { 0, -14, 94, 58, -10, 0 }, { 0, -12, 84, 66, -10, 0 },
+  { 0, -12, 76, 76, -12, 0 }, { 0, -10, 66, 84, -12, 0 }, { 0, -10, 58, 94, -14, 0 }, { 0, -10, 48, 102, -12, 0 },
+  { 0, -8, 38, 110, -12, 0 }, { 0, -6, 28, 116, -10, 0 }, { 0, -4, 18, 122, -8, 0 },  { 0, -2, 8, 126, -4, 0 }
+};
+// tap k + 1 of the kernel of phase ph (0 .. 15) under SUBPEL_SEARCH_TYPE type: 1 USE_2_TAPS = av1_bilinear_filters, 2 USE_4_TAPS, 3 USE_8_TAPS
+__device__ __forceinline__ int obmc_up_tap(int type, int ph, int k) {
+  if (type == 1) return k == 2 ? 128 - 8 * ph : (k == 3 ? 8 * ph : 0);
+  return type == 2 ? kObmcSubPel4[ph][k] : kObmcSubPel8[ph][k];
+}
+struct ObmcSubpelArgs { int iters_per_step, allow_hp, forced_stop, upsampled; };   // upsampled: 0, or the SUBPEL_SEARCH_TYPE (1 / 2 / 3)
 
 template <typename T>
 __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
@@ -449,7 +460,7 @@ __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref,
           if (!sx) return (int)r[0];
           int sum = 0;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) sum += (int)r[k - 2] * kObmcSubPel8[2 * sx][k];
+          for (int k = 0; k < 6; ++k) sum += (int)r[k - 2] * obmc_up_tap(sa.upsampled, 2 * sx, k);
           return min(max((sum + 64) >> 7, 0), pmax);
         };
         if (!sy) {
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref,
         } else {
           int sum = 0;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) sum += hrow(k - 2) * kObmcSubPel8[2 * sy][k];
+          for (int k = 0; k < 6; ++k) sum += hrow(k - 2) * obmc_up_tap(sa.upsampled, 2 * sy, k);
           pv = min(max((sum + 64) >> 7, 0), pmax);
         }
       }
@@ -678,14 +689,14 @@ int aomhip_obmc_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int
   }
   int rc = check_compound(ctx, ref, frame, bw, bh, d_blocks, n_blocks, params->mv_cost_type, d_mvjcost, d_mvcost_row, d_mvcost_col, "aomhip_obmc_subpel_tree_batch");
   if (rc != AOMHIP_OK) return rc;
-  if ((params->subpel_search_type != 0 && params->subpel_search_type != 3) || params->forced_stop < 0 || params->forced_stop > 3 || !d_wsrc || !d_obmc_mask ||
+  if ((params->subpel_search_type < 0 || params->subpel_search_type > 3) || params->forced_stop < 0 || params->forced_stop > 3 || !d_wsrc || !d_obmc_mask ||
       !d_best_mv || !d_best_err) {
-    set_error("aomhip_obmc_subpel_tree_batch: invalid argument (subpel_search_type USE_2_TAPS_ORIG 0 or USE_8_TAPS 3)");
+    set_error("aomhip_obmc_subpel_tree_batch: invalid argument (subpel_search_type 0 .. 3)");
     return AOMHIP_ERR_INVALID;
   }
   if (n_blocks == 0) return AOMHIP_OK;
   const CompoundArgs a{ bw, bh, ref->bit_depth, params->mv_cost_type, 0, params->error_per_bit, 0, d_mvjcost, d_mvcost_row, d_mvcost_col };
-  const ObmcSubpelArgs sa{ params->iters_per_step, params->allow_hp, params->forced_stop, params->subpel_search_type == 3 };
+  const ObmcSubpelArgs sa{ params->iters_per_step, params->allow_hp, params->forced_stop, params->subpel_search_type };
   const dim3 grid((n_blocks + 3) / 4), block(256);
   if (ref->bit_depth == 8)
     hipLaunchKernelGGL(obmc_subpel_tree_kernel<uint8_t>, grid, block, 0, ctx->stream, view_of<uint8_t>(*ref), frame, d_blocks, n_blocks, a, sa, d_wsrc,

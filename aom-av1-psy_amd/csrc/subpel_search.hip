@@ -10,7 +10,7 @@ namespace aomhip {
 struct SubpelCostTables {
   const int *mvjcost, *mvcost0, *mvcost1;
   int error_per_bit;
-  int upsampled;  // tree 2 with subpel_search_type USE_8_TAPS: errors from the up-sampled prediction
+  int upsampled;  // tree 2 with subpel_search_type != USE_2_TAPS_ORIG: errors from the up-sampled prediction; the value is the type (1 / 2 / 3 = 2 / 4 / 8 taps)
   int16_t *mv_lists;  // last_mv_search_list per block (3 x (row, col), read and updated; general instantiation only) or null
   const void *second_pred;  // compound search: n x (W * H) pixels of the other reference's predictor, or null (general instantiation only)
   const uint8_t *cmask;     // ... and n x (W * H) blend weights for a masked compound, or null
@@ -77,13 +77,13 @@ int aomhip_subpel_tree_list_batch(aomhip_ctx *ctx, const aomhip_planes *src, con
   int rc = check_common(ctx, src, ref, frame, bw, bh, d_blocks, n_blocks, entropy ? kCostNone : p->mv_cost_type);
   if (rc != AOMHIP_OK) return rc;
   if (!d_best_mv || !d_best_err || !d_distortion || !d_sse || p->forced_stop < 0 || p->forced_stop > 3 || p->tree < 0 ||
-      p->tree > 2 || (p->subpel_search_type != 0 && p->subpel_search_type != 3) ||
+      p->tree > 2 || (p->subpel_search_type < 0 || p->subpel_search_type > 3) ||
       (entropy && (!d_mvjcost || !d_mvcost_row || !d_mvcost_col))) {
     set_error("aomhip_subpel_tree_batch: invalid argument (tree 0..2, forced_stop 0..3, MV_COST_ENTROPY needs its tables)");
     return AOMHIP_ERR_INVALID;
   }
   return launch_subpel(ctx, src, ref, frame, bw, bh, p->mv_cost_type, p->iters_per_step, p->allow_hp, p->forced_stop, p->tree,
-                       d_cost_list, SubpelCostTables{ d_mvjcost, d_mvcost_row, d_mvcost_col, p->error_per_bit, p->tree == 2 && p->subpel_search_type == 3, d_mv_lists, nullptr, nullptr, 0 }, d_blocks,
+                       d_cost_list, SubpelCostTables{ d_mvjcost, d_mvcost_row, d_mvcost_col, p->error_per_bit, p->tree == 2 ? p->subpel_search_type : 0, d_mv_lists, nullptr, nullptr, 0 }, d_blocks,
                        n_blocks, d_best_mv, d_best_err, d_distortion, d_sse);
 }
 
@@ -99,12 +99,12 @@ int aomhip_compound_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *src,
   int rc = check_common(ctx, src, ref, frame, bw, bh, d_blocks, n_blocks, entropy ? kCostNone : p->mv_cost_type);
   if (rc != AOMHIP_OK) return rc;
   if (!d_best_mv || !d_best_err || !d_distortion || !d_sse || p->forced_stop < 0 || p->forced_stop > 3 || p->tree < 0 || p->tree > 2 ||
-      (p->subpel_search_type != 0 && p->subpel_search_type != 3) || (entropy && (!d_mvjcost || !d_mvcost_row || !d_mvcost_col))) {
+      (p->subpel_search_type < 0 || p->subpel_search_type > 3) || (entropy && (!d_mvjcost || !d_mvcost_row || !d_mvcost_col))) {
     set_error("aomhip_compound_subpel_tree_batch: invalid argument (tree 0..2, forced_stop 0..3, MV_COST_ENTROPY needs its tables)");
     return AOMHIP_ERR_INVALID;
   }
   return launch_subpel(ctx, src, ref, frame, bw, bh, p->mv_cost_type, p->iters_per_step, p->allow_hp, p->forced_stop, p->tree, nullptr,
-                       SubpelCostTables{ d_mvjcost, d_mvcost_row, d_mvcost_col, p->error_per_bit, p->tree == 2 && p->subpel_search_type == 3, nullptr,
+                       SubpelCostTables{ d_mvjcost, d_mvcost_row, d_mvcost_col, p->error_per_bit, p->tree == 2 ? p->subpel_search_type : 0, nullptr,
                                          d_second_pred, d_mask, invert_mask != 0 },
                        d_blocks, n_blocks, d_best_mv, d_best_err, d_distortion, d_sse);
 }

@@ -526,8 +526,7 @@ int aomhip_subpel_bilinear_batch(aomhip_ctx *ctx, const aomhip_planes *src, cons
 
 /* The three bilinear sub-pel searches with everything the scalar calls take: `tree` 0 =
  * av1_find_best_sub_pixel_tree_pruned_more (mcomp.c:2844-2929), 1 = _pruned (:2931-3067), 2 = av1_find_best_sub_pixel_tree
- * (:3069-3133: first_level_check[_fast] + second_level_check_v2 per precision); subpel_search_type USE_2_TAPS_ORIG or
- * USE_8_TAPS, unscaled reference, last_mv_search_list == NULL.
+ * (:3069-3133: first_level_check[_fast] + second_level_check_v2 per precision); every subpel_search_type, unscaled reference, last_mv_search_list == NULL.
  *   d_cost_list    5 ints per block as aomhip_full_pixel_search_batch wrote them (ms_params->cost_list), or NULL: a
  *                  usable list replaces the first two-level check (pruned_more: minimum of the fitted cost surface,
  *                  get_cost_surf_min; pruned: the three candidates of the cheaper quadrant)
@@ -539,9 +538,11 @@ typedef struct {
   int32_t mv_cost_type;         /* AOMHIP_MV_COST_* */
   int32_t error_per_bit;
   int32_t iters_per_step, allow_hp, forced_stop;
-  int32_t subpel_search_type;   /* SUBPEL_SEARCH_TYPE (av1/common/filter.h:45-50): 0 USE_2_TAPS_ORIG, or 3 USE_8_TAPS -- the
-                                 * tree then measures every candidate with the up-sampled prediction (aom_upsampled_pred:
-                                 * 8-tap regular filter, two rounded passes) as upsampled_pref_error does; the pruned
+  int32_t subpel_search_type;   /* SUBPEL_SEARCH_TYPE (av1/common/filter.h:45-50): 0 USE_2_TAPS_ORIG; 1 USE_2_TAPS, 2 USE_4_TAPS (speed 1 - 2
+                                 * of the good-quality presets) or 3 USE_8_TAPS (speed 0) -- with any of the last three the
+                                 * tree measures every candidate with the up-sampled prediction (aom_upsampled_pred with
+                                 * av1_get_filter(type): bilinear / 4-tap regular / 8-tap regular kernel, two rounded passes)
+                                 * as upsampled_pref_error does; the pruned
                                  * trees use the bilinear estimate for every value (check_better_fast, unscaled ref).
                                  * The block + MV + 3 pixels must stay inside the bordered plane. */
 } aomhip_subpel_params;
@@ -712,8 +713,8 @@ int aomhip_compound_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_pla
 /* av1_find_best_obmc_sub_pixel_tree_up (mcomp.c:3588-3633) for every block: the sub-pel half of the OBMC search (the branch of
  * av1_single_motion_search for OBMC_CAUSAL, motion_search_facade.c:432-445).  params: iters_per_step, allow_hp, forced_stop, mv_cost_type,
  * error_per_bit and subpel_search_type -- 0 USE_2_TAPS_ORIG: vfp->osvf + estimate_obmc_mvcost (:3390-3412; ENTROPY or NONE, the L1 types
- * cost 0 as in a release build of the reference), the centre measured by setup_obmc_center_error at MV 0 as the reference does; 3 USE_8_TAPS:
- * upsampled_obmc_pref_error (aom_[highbd_]upsampled_pred + vfp->ovf) + mv_err_cost_ -- `tree` is ignored.  Blocks as aomhip_subpel_tree_batch
+ * cost 0 as in a release build of the reference), the centre measured by setup_obmc_center_error at MV 0 as the reference does; 1 / 2 / 3 USE_2_TAPS /
+ * USE_4_TAPS / USE_8_TAPS: upsampled_obmc_pref_error (aom_[highbd_]upsampled_pred with that kernel + vfp->ovf) + mv_err_cost_ -- `tree` is ignored.  Blocks as aomhip_subpel_tree_batch
  * (start MV and limits in 1/8 pel), d_wsrc / d_obmc_mask as aomhip_obmc_full_pixel_search_batch.  Outputs: best MV (1/8 pel), besterr (the
  * return value), *distortion, *sse1 (the last two may be NULL). */
 int aomhip_obmc_subpel_tree_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int frame, int bw, int bh, const aomhip_subpel_params *params,
@@ -888,8 +889,8 @@ int aomhip_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src,
  * sets are computed on the device); start_* is ignored.  `full` / `sub` as for the two batched calls; use_cost_list: the full-pel search
  * fills the 5-entry list and the pruned sub-pel trees read it (cond_cost_list).  Outputs as aomhip_subpel_tree_batch (best MV in 1/8
  * pel, error, distortion, sse) + optionally the full-pel MV.  TPL: full->search_method = sf.tpl_sf.search_method, step_param =
- * min(sf.tpl_sf.reduce_first_step_size, MAX_MVSEARCH_STEPS - 2), entropy costs; sub: subpel_search_type USE_2_TAPS (1 -> pass 0 here:
- * the bilinear estimate), mv_cost_type NONE, forced_stop = sf.tpl_sf.subpel_force_stop.  One entry per (block, centre-MV candidate). */
+ * min(sf.tpl_sf.reduce_first_step_size, MAX_MVSEARCH_STEPS - 2), entropy costs; sub: subpel_search_type USE_2_TAPS (1: the tree then measures the
+ * up-sampled bilinear prediction, the pruned trees their bilinear estimate either way), mv_cost_type NONE, forced_stop = sf.tpl_sf.subpel_force_stop.  One entry per (block, centre-MV candidate). */
 int aomhip_motion_estimation_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
                                    const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list,
                                    const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,

@@ -38,6 +38,7 @@ typedef struct {
   const void *second_pred;
   const uint8_t *cmask;
   int invert_mask;
+  int up_taps; /* SUBPEL_SEARCH_TYPE of the up-sampled prediction error: 1 USE_2_TAPS, 2 USE_4_TAPS, 3 (and 0: default) USE_8_TAPS */
 } search_ctx;
 
 static unsigned sad_at(const search_ctx *c, int row, int col) { /* ms_params->sdf */
@@ -189,7 +190,7 @@ static void make_ctx(search_ctx *c, const void *src_origin, int src_stride, cons
   c->src_stride = src_stride; c->ref_stride = ref_stride; c->elem16 = elem16; c->bd = bd; c->w = w; c->h = h;
   c->cost_type = cost_type; c->ref_row = ref_row; c->ref_col = ref_col;
   c->mvjcost = NULL; c->mvcost[0] = c->mvcost[1] = NULL; c->sad_per_bit = c->error_per_bit = 0; c->skip_sad = 0;
-  c->second_pred = NULL; c->cmask = NULL; c->invert_mask = 0;
+  c->second_pred = NULL; c->cmask = NULL; c->invert_mask = 0; c->up_taps = 3;
 }
 
 void orc_fullpel_diamond_batch(const void *src_origin, int src_stride, const void *ref_origin, int ref_stride,
@@ -852,6 +853,20 @@ static const int16_t k_sub_pel_8[16][8] = {
   { 0, 0, -2, 8, 126, -6, 2, 0 }
 };
 const int16_t *orc_sub_pel_filters_8(void) { return &k_sub_pel_8[0][0]; }
+/* av1_get_filter(subpel_search_type) (av1/common/filter.h:270-279): USE_2_TAPS -> av1_interp_4tap[BILINEAR] = av1_bilinear_filters (:111-121),
+ * USE_4_TAPS -> av1_interp_4tap[EIGHTTAP_REGULAR] = av1_sub_pel_filters_4 (:205-215), USE_8_TAPS -> av1_sub_pel_filters_8; all stored as 8 taps */
+static const int16_t k_sub_pel_4[16][8] = {
+  { 0, 0, 0, 128, 0, 0, 0, 0 },     { 0, 0, -4, 126, 8, -2, 0, 0 },   { 0, 0, -8, 122, 18, -4, 0, 0 },  { 0, 0, -10, 116, 28, -6, 0, 0 },
+  { 0, 0, -12, 110, 38, -8, 0, 0 }, { 0, 0, -12, 102, 48, -10, 0, 0 }, { 0, 0, -14, 94, 58, -10, 0, 0 }, { 0, 0, -12, 84, 66, -10, 0, 0 },
+  { 0, 0, -12, 76, 76, -12, 0, 0 }, { 0, 0, -10, 66, 84, -12, 0, 0 }, { 0, 0, -10, 58, 94, -14, 0, 0 }, { 0, 0, -10, 48, 102, -12, 0, 0 },
+  { 0, 0, -8, 38, 110, -12, 0, 0 }, { 0, 0, -6, 28, 116, -10, 0, 0 }, { 0, 0, -4, 18, 122, -8, 0, 0 },  { 0, 0, -2, 8, 126, -4, 0, 0 }
+};
+static const int16_t k_bilinear_8[16][8] = { /* av1_bilinear_filters (:111-121) */
+  { 0, 0, 0, 128, 0, 0, 0, 0 }, { 0, 0, 0, 120, 8, 0, 0, 0 }, { 0, 0, 0, 112, 16, 0, 0, 0 }, { 0, 0, 0, 104, 24, 0, 0, 0 }, { 0, 0, 0, 96, 32, 0, 0, 0 }, { 0, 0, 0, 88, 40, 0, 0, 0 }, { 0, 0, 0, 80, 48, 0, 0, 0 }, { 0, 0, 0, 72, 56, 0, 0, 0 }, { 0, 0, 0, 64, 64, 0, 0, 0 }, { 0, 0, 0, 56, 72, 0, 0, 0 }, { 0, 0, 0, 48, 80, 0, 0, 0 }, { 0, 0, 0, 40, 88, 0, 0, 0 }, { 0, 0, 0, 32, 96, 0, 0, 0 }, { 0, 0, 0, 24, 104, 0, 0, 0 }, { 0, 0, 0, 16, 112, 0, 0, 0 }, { 0, 0, 0, 8, 120, 0, 0, 0 }
+};
+static const int16_t *up_kernel(const search_ctx *c, int phase8) { /* the kernel of a 1/8-pel offset: row 2 * offset of the 16-phase table */
+  return c->up_taps == 1 ? k_bilinear_8[2 * phase8] : c->up_taps == 2 ? k_sub_pel_4[2 * phase8] : k_sub_pel_8[2 * phase8];
+}
 
 static int ref_px(const search_ctx *c, int row, int col) {
   return c->elem16 ? ((const uint16_t *)c->ref)[(ptrdiff_t)row * c->ref_stride + col]
@@ -863,7 +878,7 @@ static int ref_px(const search_ctx *c, int row, int col) {
  * clipped to the pixel range; a zero offset in one direction skips that pass.  pred: w * h, row pitch w. */
 static void upsampled_pred8(const search_ctx *c, int mrow, int mcol, uint16_t *pred) {
   const int fr = mrow >> 3, fc = mcol >> 3, sx = mcol & 7, sy = mrow & 7;
-  const int16_t *kx = k_sub_pel_8[2 * sx], *ky = k_sub_pel_8[2 * sy];
+  const int16_t *kx = up_kernel(c, sx), *ky = up_kernel(c, sy);
   const int mx = c->elem16 ? (1 << c->bd) - 1 : 255;
   const int w = c->w, h = c->h;
   if (!sx && !sy) {
@@ -1081,7 +1096,8 @@ static void subpel_tree_core(const void *src_origin, int src_stride, const void 
     }
     /* only av1_find_best_sub_pixel_tree measures with the up-sampled prediction (check_better / first_level_check,
      * :2465-2663); the pruned trees always use the bilinear estimate on an unscaled reference (check_better_fast) */
-    const int upsampled = tree == 2 && subpel_search_type == 3; /* USE_8_TAPS */
+    const int upsampled = tree == 2 && subpel_search_type != 0; /* != USE_2_TAPS_ORIG (mcomp.c:2689, :3093, :3112) */
+    c.up_taps = subpel_search_type;
     subpel_state s = { &c, b->row_min, b->row_max, b->col_min, b->col_max, INT_MAX, 0, 0, b->start_row, b->start_col, upsampled };
     { /* setup_center_error (:2718-2778) / upsampled_setup_center_error: vf(ref at the full-pel part, src) */
       uint32_t sse;
@@ -1487,7 +1503,7 @@ void orc_obmc_subpel_tree_batch(const void *ref_origin, int ref_stride, int elem
     oc.wsrc = wsrc + (size_t)i * w * h; oc.omask = omask + (size_t)i * w * h;
     obmc_subpel_state s;
     memset(&s, 0, sizeof(s));
-    s.oc = &oc; s.upsampled = upsampled;
+    s.oc = &oc; s.upsampled = upsampled; oc.c.up_taps = upsampled; /* `upsampled` = the SUBPEL_SEARCH_TYPE, 0 = USE_2_TAPS_ORIG */
     s.row_min = b->row_min; s.row_max = b->row_max; s.col_min = b->col_min; s.col_max = b->col_max;
     s.best_row = b->start_row; s.best_col = b->start_col;
     if (upsampled) {

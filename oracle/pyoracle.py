@@ -1279,7 +1279,7 @@ def obmc_subpel_tree_batch(ref_b, border, w, h, blocks, wsrc, obmc_mask, cost_ty
     lib.orc_obmc_subpel_tree_batch.restype = None
     lib.orc_obmc_subpel_tree_batch(C.c_void_p(_addr(ref_b, border, border)), ref_b.shape[1], int(ref_b.dtype != np.uint8), bd, w, h,
                                    C.c_void_p(blocks.ctypes.data), n, cost_type, error_per_bit, j, c0, c1, iters_per_step, allow_hp, forced_stop,
-                                   int(subpel_search_type != 0), C.c_void_p(ws.ctypes.data), C.c_void_p(om.ctypes.data), C.c_void_p(mv.ctypes.data),
+                                   int(subpel_search_type), C.c_void_p(ws.ctypes.data), C.c_void_p(om.ctypes.data), C.c_void_p(mv.ctypes.data),
                                    C.c_void_p(err.ctypes.data), C.c_void_p(dist.ctypes.data), C.c_void_p(sse.ctypes.data), threads)
     return mv, err, dist, sse
 

@@ -26,10 +26,12 @@ import gen_ref_eval_mcomp as M  # noqa: E402
 TREES = ["av1_find_best_sub_pixel_tree_pruned_more", "av1_find_best_sub_pixel_tree_pruned", "av1_find_best_sub_pixel_tree"]
 
 
-def main():
+def main(plan=None, out="ref_eval_compound_subpel.npz", seed=20261301):
+    """plan: (bd, w, h, tree, subpel_search_type, masked[, compound = 1]) per case; the default is what produced ref_eval_compound_subpel.npz
+    (gen_ref_eval_subpel_taps.py passes its own: the USE_2_TAPS / USE_4_TAPS forms, single-reference and compound)."""
     ev = M.make_evaluator(with_compound=True)
     arrays, cases = {}, []
-    rng = np.random.default_rng(20261301)
+    rng = np.random.default_rng(seed)
     mvc = M.synth_mv_costs(17)
     arrays["mvjcost"], arrays["mvcost0"], arrays["mvcost1"] = mvc
     harness = {}
@@ -40,15 +42,18 @@ def main():
     W, H, B = M.W, M.H, M.BORDER
     t0 = time.time()
     k = 0
+    given = plan
     plan = []
-    for bd in (8, 10):
+    for bd in (8, 10) if given is None else ():
         for (w, h) in ((8, 8), (16, 16), (16, 8), (32, 16)):
             for tree in range(3):
                 for masked in (0, 1):
                     plan.append((bd, w, h, tree, 0, masked))
             for masked in (0, 1):
                 plan.append((bd, w, h, 2, 3, masked))        # the tree with the up-sampled error
-    for (bd, w, h, tree, sst, masked) in plan:
+    for entry in (plan if given is None else given):
+        bd, w, h, tree, sst, masked = entry[:6]
+        compound = entry[6] if len(entry) > 6 else 1
         hs = harness[bd]
         mx = (1 << bd) - 1
         ct = "uint8_t" if bd == 8 else "uint16_t"
@@ -77,16 +82,17 @@ def main():
             assert fn in ev.funcs, fn
             ev.set(vfp, kk, R.FuncRef(fn))
         ev.set(sp, "var_params.vfp", vfp)
-        ev.set(sp, "var_params.subpel_search_type", hs.const("USE_8_TAPS" if sst == 3 else "USE_2_TAPS_ORIG"))
+        ev.set(sp, "var_params.subpel_search_type", hs.const(("USE_2_TAPS_ORIG", "USE_2_TAPS", "USE_4_TAPS", "USE_8_TAPS")[sst]))
         ev.set(sp, "var_params.ms_buffers.ref", hs.buf2d(hs.refp, by, bx)); ev.set(sp, "var_params.ms_buffers.src", hs.buf2d(hs.srcp, by, bx))
         ev.set(sp, "var_params.w", w); ev.set(sp, "var_params.h", h)
         # the other reference's predictor: the reference block near the full-pel MV plus noise (an input here)
         refpl = arrays["ref%d" % bd]
         oy, ox = by + full[0] + int(rng.integers(-2, 3)), bx + full[1] + int(rng.integers(-2, 3))
         spred = np.clip(refpl[B + oy:B + oy + h, B + ox:B + ox + w].astype(np.int32) + rng.integers(-(6 << (bd - 8)), (6 << (bd - 8)) + 1, (h, w)), 0, mx).astype(np.uint16)
-        ev.set(sp, "var_params.ms_buffers.second_pred", ev.array(spred.ravel(), ct))
+        if compound:
+            ev.set(sp, "var_params.ms_buffers.second_pred", ev.array(spred.ravel(), ct))
         mask = None
-        if masked:
+        if masked and compound:
             ramp = np.clip((np.arange(w)[None, :] * 2 + np.arange(h)[:, None] - (w + h) // 2) * 4 + 32 + rng.integers(-3, 4, (h, w)), 0, 64)
             mask = ramp.astype(np.uint8)
             ev.set(sp, "var_params.ms_buffers.mask", ev.array(mask.ravel(), "uint8_t"))
@@ -99,17 +105,17 @@ def main():
         err = ev.call(TREES[tree], M.make_xd(ev, bd), None, sp, start.buf[0], best, dist, sse, None)
         sl = [ev.get(sp, "mv_limits." + kk) for kk in ("row_min", "row_max", "col_min", "col_max")]
         arrays["sp%d" % k] = spred
-        if masked:
+        if mask is not None:
             arrays["mask%d" % k] = mask
-        cases.append(dict(k=k, bd=bd, w=w, h=h, block=list(blk), tree=tree, subpel_search_type=sst, masked=masked, inv=inv, cost_type=M.COST_TYPES[cost_type],
+        cases.append(dict(k=k, bd=bd, w=w, h=h, block=list(blk), tree=tree, subpel_search_type=sst, masked=int(mask is not None), inv=inv, compound=compound, cost_type=M.COST_TYPES[cost_type],
                           error_per_bit=epb, allow_hp=allow_hp, forced_stop=forced_stop, iters=iters, subpel_limits=sl,
                           mv=[ev.get(best, "row"), ev.get(best, "col")], err=err, distortion=dist.buf[0], sse=sse.buf[0]))
         print(k, bd, w, h, TREES[tree][25:], sst, "masked" if masked else "avg", inv, cost_type, cases[-1]["mv"], err, "%.0f s" % (time.time() - t1), flush=True)
         k += 1
-    meta = dict(border=B, width=W, height=H, generated_by="tests/golden/gen_ref_eval_compound_subpel.py", cases=cases)
+    meta = dict(border=B, width=W, height=H, generated_by="tests/golden/gen_ref_eval_compound_subpel.py" if given is None else "tests/golden/gen_ref_eval_subpel_taps.py", cases=cases)
     arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
-    np.savez_compressed(os.path.join(HERE, "ref_eval_compound_subpel.npz"), **arrays)
-    print("wrote ref_eval_compound_subpel.npz: %d cases, %.0f s" % (len(cases), time.time() - t0))
+    np.savez_compressed(os.path.join(HERE, out), **arrays)
+    print("wrote %s: %d cases, %.0f s" % (out, len(cases), time.time() - t0))
 
 
 if __name__ == "__main__":

@@ -39,12 +39,13 @@ def pred_buffer_adaptation(ev):
     return {8: fn, 10: fn.replace(decl, "DECLARE_ALIGNED(16, uint16_t, pred[MAX_SB_SQUARE]);")}
 
 
-def main():
+def main(plan=None, out="ref_eval_obmc_subpel.npz", seed=20261201):
+    """plan: (bd, w, h, SUBPEL_SEARCH_TYPE name, trial) per case; the default is what produced ref_eval_obmc_subpel.npz."""
     ev = M.make_evaluator(with_compound=True)
     pred_text = pred_buffer_adaptation(ev)
     loaded_for = None
     arrays, cases = {}, []
-    rng = np.random.default_rng(20261201)
+    rng = np.random.default_rng(seed)
     mvc = M.synth_mv_costs(13)
     arrays["mvjcost"], arrays["mvcost0"], arrays["mvcost1"] = mvc
     harness = {}
@@ -55,13 +56,13 @@ def main():
     W, H, B = M.W, M.H, M.BORDER
     t0 = time.time()
     k = 0
-    plan = []
-    for bd in (8, 10):
+    given, plan = plan, []
+    for bd in (8, 10) if given is None else ():
         for (w, h) in ((8, 8), (16, 16), (16, 8), (8, 16), (32, 16)):
             for stype in ("USE_2_TAPS_ORIG", "USE_8_TAPS"):
                 for trial in range(3):
                     plan.append((bd, w, h, stype, trial))
-    for (bd, w, h, stype, trial) in plan:
+    for (bd, w, h, stype, trial) in (plan if given is None else given):
         hs = harness[bd]
         if loaded_for != bd:
             ev.load_text(pred_text[bd], "mcomp.c:upsampled_obmc_pref_error")
@@ -112,15 +113,15 @@ def main():
         err = ev.call("av1_find_best_obmc_sub_pixel_tree_up", M.make_xd(ev, bd), None, sp, start.buf[0], best, dist, sse, None)
         sl = [ev.get(sp, "mv_limits." + kk) for kk in ("row_min", "row_max", "col_min", "col_max")]
         arrays["ws%d" % k], arrays["om%d" % k] = ws.astype(np.int32), om.astype(np.int32)
-        cases.append(dict(k=k, bd=bd, w=w, h=h, block=list(blk), subpel_search_type=0 if stype == "USE_2_TAPS_ORIG" else 3, cost_type=M.COST_TYPES[cost_type],
+        cases.append(dict(k=k, bd=bd, w=w, h=h, block=list(blk), subpel_search_type=("USE_2_TAPS_ORIG", "USE_2_TAPS", "USE_4_TAPS", "USE_8_TAPS").index(stype), cost_type=M.COST_TYPES[cost_type],
                           error_per_bit=epb, allow_hp=allow_hp, forced_stop=forced_stop, iters=iters, subpel_limits=sl,
                           mv=[ev.get(best, "row"), ev.get(best, "col")], err=err, distortion=dist.buf[0], sse=sse.buf[0]))
         print(k, bd, w, h, stype, cost_type, cases[-1]["mv"], err, "%.0f s" % (time.time() - t1), flush=True)
         k += 1
     meta = dict(border=B, width=W, height=H, generated_by="tests/golden/gen_ref_eval_obmc_subpel.py", cases=cases)
     arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
-    np.savez_compressed(os.path.join(HERE, "ref_eval_obmc_subpel.npz"), **arrays)
-    print("wrote ref_eval_obmc_subpel.npz: %d cases, %.0f s" % (len(cases), time.time() - t0))
+    np.savez_compressed(os.path.join(HERE, out), **arrays)
+    print("wrote %s: %d cases, %.0f s" % (out, len(cases), time.time() - t0))
 
 
 if __name__ == "__main__":

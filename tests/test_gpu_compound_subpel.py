@@ -16,9 +16,11 @@ def _tables(ctx, j, c0, c1):
     return ctx.to_device(j.astype(np.int32)), ctx.to_device(c0.astype(np.int32)), ctx.to_device(c1.astype(np.int32)), mv_max
 
 
-def test_matches_the_interpreted_reference(hip, ctx):
+@pytest.mark.parametrize("fixture,least", [("ref_eval_compound_subpel.npz", 60), ("ref_eval_subpel_taps.npz", 32)])
+def test_matches_the_interpreted_reference(hip, ctx, fixture, least):
+    """(ref_eval_subpel_taps.npz: the tree with USE_4_TAPS / USE_2_TAPS, single-reference cases through aomhip_subpel_tree_batch)"""
     capi = hip.capi
-    z = np.load(os.path.join(HERE, "golden", "ref_eval_compound_subpel.npz"))
+    z = np.load(os.path.join(HERE, "golden", fixture))
     meta = json.loads(bytes(z["meta"]).decode())
     B, W, H = meta["border"], meta["width"], meta["height"]
     d_j, d_c0, d_c1, mv_max = _tables(ctx, z["mvjcost"], z["mvcost0"], z["mvcost1"])
@@ -40,15 +42,18 @@ def test_matches_the_interpreted_reference(hip, ctx):
         d_m = ctx.to_device(np.ascontiguousarray(z["mask%d" % k])) if c["masked"] else None
         outs = [ctx.malloc(16) for _ in range(4)]
         ps, pr = planes[c["bd"]]
-        ctx.compound_subpel_tree_batch(ps, pr, 0, c["w"], c["h"], p, d_b, 1, d_sp, d_m, c["inv"], outs[0], outs[1], outs[2], outs[3], d_j, d_c0 + mv_max * 4,
-                                       d_c1 + mv_max * 4)
+        if c.get("compound", 1):
+            ctx.compound_subpel_tree_batch(ps, pr, 0, c["w"], c["h"], p, d_b, 1, d_sp, d_m, c["inv"], outs[0], outs[1], outs[2], outs[3], d_j, d_c0 + mv_max * 4,
+                                           d_c1 + mv_max * 4)
+        else:
+            ctx.subpel_tree_batch(ps, pr, 0, c["w"], c["h"], p, d_b, 1, outs[0], outs[1], outs[2], outs[3], None, d_j, d_c0 + mv_max * 4, d_c1 + mv_max * 4)
         got = (ctx.from_device(outs[0], (2,), np.int16).tolist(), int(ctx.from_device(outs[1], (1,), np.uint32)[0]), int(ctx.from_device(outs[2], (1,), np.int32)[0]),
                int(ctx.from_device(outs[3], (1,), np.uint32)[0]))
         assert got == (c["mv"], c["err"], c["distortion"], c["sse"]), c
         n += 1
         for d in [d_b, d_sp] + ([d_m] if d_m is not None else []) + outs:
             ctx.free(d)
-    assert n >= 60
+    assert n >= least
     for d in (d_j, d_c0, d_c1):
         ctx.free(d)
     for ps, pr in planes.values():
@@ -89,7 +94,8 @@ def test_batches_match_the_oracle(hip, oracle, ctx, bd, bw, bh):
     outs = [ctx.malloc(n * 4) for _ in range(4)]
     for (tree, sst, m, inv, ct, iters, hp, fs) in ((0, 0, None, 0, capi.MV_COST_ENTROPY, 2, 1, 0), (1, 0, mask, 1, capi.MV_COST_L1_HDRES, 2, 0, 0),
                                                    (2, 0, mask, 0, capi.MV_COST_NONE, 2, 1, 1), (2, 3, None, 0, capi.MV_COST_ENTROPY, 2, 1, 0),
-                                                   (2, 3, mask, 1, capi.MV_COST_L1_HDRES, 1, 0, 0)):
+                                                   (2, 3, mask, 1, capi.MV_COST_L1_HDRES, 1, 0, 0), (2, 2, None, 0, capi.MV_COST_ENTROPY, 2, 1, 0),
+                                                   (2, 2, mask, 1, capi.MV_COST_L1_HDRES, 2, 0, 0), (2, 1, mask, 0, capi.MV_COST_NONE, 1, 1, 0)):
         p = capi.SubpelParams(tree, ct, 63, iters, hp, fs, sst)
         ctx.compound_subpel_tree_batch(ps, pr, 0, bw, bh, p, d_b, n, d_sp, None if m is None else d_m, inv, outs[0], outs[1], outs[2], outs[3], d_j,
                                        d_c0 + mv_max * 4, d_c1 + mv_max * 4)

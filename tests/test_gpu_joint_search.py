@@ -204,6 +204,70 @@ def test_compound_single_search_equals_the_composition(hip, oracle, ctx, bd, bw,
         ctx.planes_free(p_)
 
 
+def test_device_matches_the_interpreted_callers(hip, ctx):
+    """The three entry points straight against av1_joint_motion_search (both branches) / av1_compound_single_motion_search interpreted as they are
+    written (tests/golden/ref_eval_joint.npz): no oracle in between."""
+    import json
+    import os
+    from test_golden_joint import TAPS, TREES
+    capi = hip.capi
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_eval_joint.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    B, W, H = meta["border"], meta["width"], meta["height"]
+    j, c0, c1 = z["mvjcost"].astype(np.int32), z["mvcost0"].astype(np.int32), z["mvcost1"].astype(np.int32)
+    mv_max = c0.size // 2
+    d_j, d_c0, d_c1 = ctx.to_device(j), ctx.to_device(c0), ctx.to_device(c1)
+    planes = {}
+    for bd in (8, 10):
+        planes[bd] = [ctx.planes_alloc(W, H, B, bd, 1) for _ in range(3)]
+        for p_, name in zip(planes[bd], ("src%d", "ref0_%d", "ref1_%d")):
+            ctx.planes_upload(p_, 0, np.ascontiguousarray(z[name % bd][B:B + H, B:B + W]))
+    n = 0
+    for c in meta["cases"]:
+        bd, w, h, k = c["bd"], c["w"], c["h"], c["k"]
+        ps, p0, p1 = planes[bd]
+        b = np.zeros(1, capi.search_block_dtype)
+        b["bx"], b["by"] = c["bx"], c["by"]
+        b["row_min"], b["row_max"], b["col_min"], b["col_max"] = c["limits"]
+        kw = {} if "mesh_thr" not in c else dict(force_mesh_thresh=c["mesh_thr"])
+        full = capi.SearchParams.make("NSTEP", 5, 0, c["sadperbit"], c["errorperbit"], mesh_diff_thr=4, mesh=meta["mesh"], **kw)
+        sub = capi.SubpelParams(TREES[c["tree"]], 0, c["errorperbit"], 2, 1, 3, TAPS[c["taps"]])
+        d_b = ctx.to_device(b)
+        d_m = ctx.to_device(np.ascontiguousarray(z["mask%d" % k])) if c["masked"] else None
+        d_rate, d_err = ctx.malloc(16), ctx.malloc(16)
+        fi = c.get("force_int", 0)
+        extra = []
+        if c["fn"] == "joint":
+            d_r, d_cur = ctx.to_device(np.array(c["ref_mv"], np.int16)), ctx.to_device(np.array(c["cur_in"], np.int16))
+            if c["ext"]:
+                ctx.joint_motion_search_extensive_batch(ps, p0, p1, 0, w, h, full, sub, c["second"], fi, d_b, d_r, d_cur, d_m, 1, d_rate, d_err, d_j,
+                                                        d_c0 + mv_max * 4, d_c1 + mv_max * 4)
+            else:
+                ctx.joint_motion_search_batch(ps, p0, p1, 0, w, h, 0, c["sadperbit"], sub, fi, d_b, d_r, d_cur, d_m, 1, d_rate, d_err, d_j, d_c0 + mv_max * 4,
+                                              d_c1 + mv_max * 4)
+            got = (ctx.from_device(d_cur, (2, 2), np.int16).tolist(), int(ctx.from_device(d_rate, (1,), np.int32)[0]), int(ctx.from_device(d_err, (1,), np.int32)[0]))
+            assert got == (c["cur_out"], c["rate_mv"], c["err"]), (c, got)
+        else:
+            ri = c["ref_idx"]
+            dt = np.uint8 if bd == 8 else np.uint16
+            d_r, d_cur = ctx.to_device(np.array(c["ref_mv"][ri], np.int16)), ctx.to_device(np.array(c["cur_in"][ri], np.int16))
+            d_sp = ctx.to_device(np.ascontiguousarray(z["sp%d" % k].astype(dt)))
+            extra.append(d_sp)
+            ctx.compound_single_motion_search_batch(ps, (p0, p1)[ri], None, 0, w, h, full, sub, fi, d_b, d_r, d_cur, None, 0, 0, d_sp, d_m, ri, 1, d_rate, d_err, d_j,
+                                                    d_c0 + mv_max * 4, d_c1 + mv_max * 4)
+            got = (ctx.from_device(d_cur, (2,), np.int16).tolist(), int(ctx.from_device(d_rate, (1,), np.int32)[0]), int(ctx.from_device(d_err, (1,), np.int32)[0]))
+            assert got == (c["this_out"], c["rate_mv"], c["err"]), (c, got)
+        n += 1
+        for d in [d_b, d_rate, d_err, d_r, d_cur] + extra + ([d_m] if d_m is not None else []):
+            ctx.free(d)
+    assert n >= 22
+    for d in (d_j, d_c0, d_c1):
+        ctx.free(d)
+    for ps_ in planes.values():
+        for p_ in ps_:
+            ctx.planes_free(p_)
+
+
 def test_contiguous_predictor_equals_the_plane_form(hip, ctx):
     capi = hip.capi
     W, H, B, bw, bh, bd = 128, 96, 64, 16, 8, 10

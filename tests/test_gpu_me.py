@@ -34,7 +34,7 @@ def test_device_matches_the_oracle(hip, oracle, ctx, bd, bs, method, cost, tree,
     t0, t1 = (140 + bits * 305).astype(np.int32), (165 + bits * 285 + (v & 7) * 5).astype(np.int32)
     tj = np.array([190, 660, 655, 1040], np.int32)
     full = capi.SearchParams.make(method, 2, ct, sad_per_bit=20, error_per_bit=64)
-    sub = capi.SubpelParams(capi.SUBPEL_TREES[tree], capi.MV_COST_NONE, 64, 2, 1, 0, 0)          # USE_2_TAPS, MV_COST_NONE (tpl_model.c:293-294)
+    sub = capi.SubpelParams(capi.SUBPEL_TREES[tree], capi.MV_COST_NONE, 64, 2, 1, 0, 1)          # USE_2_TAPS (1), MV_COST_NONE (tpl_model.c:293-294)
     d_b = ctx.to_device(blocks)
     d_mv, d_err, d_dist, d_sse, d_fmv = (ctx.malloc(n * 4) for _ in range(5))
     d_j, d_c0, d_c1 = ctx.to_device(tj), ctx.to_device(t0), ctx.to_device(t1)
@@ -43,7 +43,7 @@ def test_device_matches_the_oracle(hip, oracle, ctx, bd, bs, method, cost, tree,
            ctx.from_device(d_sse, (n,), np.uint32), ctx.from_device(d_fmv, (n, 2), np.int16))
     sb, rb = oracle.extend_plane(src, B, ps.stride), oracle.extend_plane(ref, B, pr.stride)
     oq = oracle.search_params(method, 2, ct, sad_per_bit=20, error_per_bit=64, no_cost_list=int(not ucl))
-    want = oracle.motion_estimation_batch(sb, rb, B, bs, bs, blocks, oq, dict(tree=tree, cost_type=4, error_per_bit=64, iters=2, allow_hp=1, forced_stop=0),
+    want = oracle.motion_estimation_batch(sb, rb, B, bs, bs, blocks, oq, dict(tree=tree, cost_type=4, error_per_bit=64, iters=2, allow_hp=1, forced_stop=0, subpel_search_type=1),
                                           ucl, tj, t0, t1, bd=bd, threads=8)
     for g, w_, name in zip(got, want, ("mv", "err", "distortion", "sse", "full_mv")):
         assert np.array_equal(g, w_), name

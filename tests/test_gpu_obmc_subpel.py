@@ -17,9 +17,11 @@ def _tables(ctx, j, c0, c1):
     return d_j, d_c0, d_c1, mv_max
 
 
-def test_matches_the_interpreted_reference(hip, ctx):
+@pytest.mark.parametrize("fixture,least", [("ref_eval_obmc_subpel.npz", 50), ("ref_eval_obmc_subpel_taps.npz", 24)])
+def test_matches_the_interpreted_reference(hip, ctx, fixture, least):
+    """(ref_eval_obmc_subpel_taps.npz: USE_4_TAPS / USE_2_TAPS)"""
     capi = hip.capi
-    z = np.load(os.path.join(HERE, "golden", "ref_eval_obmc_subpel.npz"))
+    z = np.load(os.path.join(HERE, "golden", fixture))
     meta = json.loads(bytes(z["meta"]).decode())
     B, W, H = meta["border"], meta["width"], meta["height"]
     d_j, d_c0, d_c1, mv_max = _tables(ctx, z["mvjcost"], z["mvcost0"], z["mvcost1"])
@@ -45,7 +47,7 @@ def test_matches_the_interpreted_reference(hip, ctx):
         n += 1
         for d in [d_b, d_ws, d_om] + outs:
             ctx.free(d)
-    assert n >= 50
+    assert n >= least
     for d in (d_j, d_c0, d_c1):
         ctx.free(d)
     for p_ in planes.values():
@@ -89,7 +91,7 @@ def test_batches_match_the_oracle(hip, oracle, ctx, bd, bw, bh):
     outs = [ctx.malloc(n * 4) for _ in range(4)]
     moved = 0
     for (sst, ct, iters, hp, fs) in ((0, capi.MV_COST_ENTROPY, 2, 1, 0), (0, capi.MV_COST_NONE, 1, 0, 0), (3, capi.MV_COST_ENTROPY, 2, 1, 0),
-                                     (3, capi.MV_COST_L1_HDRES, 2, 0, 1)):
+                                     (3, capi.MV_COST_L1_HDRES, 2, 0, 1), (2, capi.MV_COST_ENTROPY, 2, 1, 0), (1, capi.MV_COST_L1_HDRES, 1, 1, 0)):
         p = capi.SubpelParams(2, ct, 63, iters, hp, fs, sst)
         ctx.obmc_subpel_tree_batch(pr, 0, bw, bh, p, d_b, n, d_ws, d_om, outs[0], outs[1], outs[2], outs[3], d_j, d_c0 + mv_max * 4, d_c1 + mv_max * 4)
         got = (ctx.from_device(outs[0], (n, 2), np.int16), ctx.from_device(outs[1], (n,), np.uint32), ctx.from_device(outs[2], (n,), np.int32),
@@ -103,7 +105,7 @@ def test_batches_match_the_oracle(hip, oracle, ctx, bd, bw, bh):
     # optional outputs, bad arguments
     ctx.obmc_subpel_tree_batch(pr, 0, bw, bh, capi.SubpelParams(2, capi.MV_COST_NONE, 0, 2, 1, 0, 0), d_b, n, d_ws, d_om, outs[0], outs[1])
     with pytest.raises(capi.AomHipError):
-        ctx.obmc_subpel_tree_batch(pr, 0, bw, bh, capi.SubpelParams(2, capi.MV_COST_NONE, 0, 2, 1, 0, 2), d_b, n, d_ws, d_om, outs[0], outs[1])   # USE_4_TAPS: not built
+        ctx.obmc_subpel_tree_batch(pr, 0, bw, bh, capi.SubpelParams(2, capi.MV_COST_NONE, 0, 2, 1, 0, 4), d_b, n, d_ws, d_om, outs[0], outs[1])   # not a SUBPEL_SEARCH_TYPE
     with pytest.raises(capi.AomHipError):
         ctx.obmc_subpel_tree_batch(pr, 0, bw, bh, capi.SubpelParams(2, capi.MV_COST_ENTROPY, 1, 2, 1, 0, 0), d_b, n, d_ws, d_om, outs[0], outs[1])   # no tables
     for d in [d_j, d_c0, d_c1, d_b, d_ws, d_om] + outs:
