@@ -185,7 +185,10 @@ int aomhip_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
   {
     SiteTable h;
     build_sites(p->search_method, &h);
-    if (p->step_param >= h.num_search_steps) {
+    // (step_param == num_search_steps is what av1_single_motion_search passes for search_range < 1, motion_search_facade.c:234-236: the diamond
+    // family then measures the start position only; pattern_search asserts search_step < num_search_steps)
+    const bool diamond_family = p->search_method < kHex || p->search_method == kNstepFpf;
+    if (p->step_param > h.num_search_steps || (p->step_param == h.num_search_steps && !diamond_family)) {
       set_error("aomhip_full_pixel_search_batch: step_param %d >= %d search steps", p->step_param, h.num_search_steps);
       return AOMHIP_ERR_INVALID;
     }

@@ -617,8 +617,8 @@ int aomhip_compound_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes
     int16_t mv[22][17][2];
     rc = aomhip_search_sites(p->search_method, &ns, per, rad, mv);
     if (rc != AOMHIP_OK) return rc;
-    if (p->step_param >= ns) {
-      set_error("aomhip_compound_full_pixel_search_batch: step_param %d >= %d search steps", p->step_param, ns);
+    if (p->step_param > ns) {   // (== ns: the start position only, as av1_single_motion_search's search_range < 1 asks for)
+      set_error("aomhip_compound_full_pixel_search_batch: step_param %d > %d search steps", p->step_param, ns);
       return AOMHIP_ERR_INVALID;
     }
   }
@@ -662,8 +662,8 @@ int aomhip_obmc_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *re
     int ns = 0, per[22], rad[22];
     int16_t mv[22][17][2];
     (void)aomhip_search_sites(search_method, &ns, per, rad, mv);
-    if (!fast_obmc_search && step_param >= ns) {
-      set_error("aomhip_obmc_full_pixel_search_batch: step_param %d >= %d search steps", step_param, ns);
+    if (!fast_obmc_search && step_param > ns) {
+      set_error("aomhip_obmc_full_pixel_search_batch: step_param %d > %d search steps", step_param, ns);
       return AOMHIP_ERR_INVALID;
     }
   }

@@ -188,8 +188,10 @@ def test_full_pixel_search_rejects_bad_arguments(hip, ctx):
     d_b, d_mv, d_c = ctx.to_device(blk), ctx.malloc(16), ctx.malloc(16)
     with pytest.raises(Exception):      # entropy cost without tables
         ctx.full_pixel_search_batch(ps, pr, 0, 16, 16, hip.capi.SearchParams.make("NSTEP", 0, 0), d_b, 1, d_mv, d_c)
-    with pytest.raises(Exception):      # step_param beyond the table
-        ctx.full_pixel_search_batch(ps, pr, 0, 16, 16, hip.capi.SearchParams.make("DIAMOND", 11, 3), d_b, 1, d_mv, d_c)
+    with pytest.raises(Exception):      # step_param beyond the table (== num_search_steps is the diamonds' "start position only")
+        ctx.full_pixel_search_batch(ps, pr, 0, 16, 16, hip.capi.SearchParams.make("DIAMOND", 12, 3), d_b, 1, d_mv, d_c)
+    with pytest.raises(Exception):      # ... which the pattern searches do not have
+        ctx.full_pixel_search_batch(ps, pr, 0, 16, 16, hip.capi.SearchParams.make("HEX", 11, 3), d_b, 1, d_mv, d_c)
     with pytest.raises(Exception):      # unknown method
         ctx.full_pixel_search_batch(ps, pr, 0, 16, 16, hip.capi.SearchParams.make(12, 0, 3), d_b, 1, d_mv, d_c)
     for d in (d_b, d_mv, d_c):
