@@ -56,12 +56,117 @@ __device__ __forceinline__ uint32_t finish_var(int64_t s64, uint64_t q64, int n_
   return v >= 0 ? (uint32_t)v : 0u;
 }
 
-// the compound predictor of one pixel: aom_comp_avg_pred (variance.c:306-319) / aom_comp_mask_pred (:773-791, AOM_BLEND_A64)
-__device__ __forceinline__ int blend_px(int f, int p, const uint8_t *mask, int t, int invert) {
-  if (!mask) return (p + f + 1) >> 1;
-  const int m = mask[t];
-  return invert ? (m * p + (64 - m) * f + 32) >> 6 : (m * f + (64 - m) * p + 32) >> 6;
+// 32-bit sum over the wavefront, wave-uniform result: four DPP steps to the sums of the four 16-lane rows, four v_readlane, scalar adds
+__device__ __forceinline__ uint32_t row_sum32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);    // quad_perm [1, 0, 3, 2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);    // quad_perm [2, 3, 0, 1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);   // row_mirror
+  return v;
 }
+__device__ __forceinline__ uint32_t wsum32(uint32_t v) {
+  v = row_sum32(v);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32) +
+         (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ uint64_t wsum32_wide(uint32_t v) {   // the same when only the row sums fit 32 bits
+  v = row_sum32(v);
+  return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32) +
+         (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ uint64_t wsum32_split(uint32_t v) {   // exact for any per-lane value: the two 16-bit halves summed separately
+  return ((uint64_t)wsum32(v >> 16) << 16) + wsum32(v & 0xffffu);
+}
+
+// One block's compound error functions evaluated by the 64 lanes pixel by pixel (pixel t of the block -> lane t & 63): get_mvpred_compound_sad
+// (vfp->sdaf / msdf) and the variance of get_mvpred_compound_var[_cost] (svaf / msvf at offset 0).  What does not depend on the candidate --
+// the source block, the other reference's predictor, the blend weights -- stays in registers for blocks of up to 64 x kKeep pixels (a search
+// evaluates ~25 .. ~180 candidates); the candidate's reference pixels are then kKeep independent loads per lane, issued together.  Block
+// widths are powers of two: row / column of pixel t by shift and mask.  SADs are summed in 32 bits (<= 128 x 128 x 4095).
+template <typename T> struct CompoundEval {
+  static constexpr int kKeep = 8;
+  const T *sp, *rbase, *pred;
+  const uint8_t *mask;
+  int sstride, rstride, lw, wm, n_px, shift, invert, bit_depth, lane;
+  bool keep;
+  int s_[kKeep], p_[kKeep], m_[kKeep];
+  __device__ __forceinline__ void init(const T *sp_, int sstride_, const T *rbase_, int rstride_, const T *pred_, const uint8_t *mask_, int W, int H, int invert_,
+                                       int bit_depth_, int lane_) {
+    sp = sp_; rbase = rbase_; pred = pred_; mask = mask_; sstride = sstride_; rstride = rstride_;
+    lw = __builtin_ctz((unsigned)W); wm = W - 1; n_px = W * H; invert = invert_; bit_depth = bit_depth_; lane = lane_;
+    shift = bit_depth == 10 ? 2 : bit_depth == 12 ? 4 : 0;   // the _bits10 / _bits12 vtable wrappers (encoder_utils.h)
+    keep = n_px <= 64 * kKeep;
+    if (keep) {
+#pragma unroll
+      for (int k = 0; k < kKeep; ++k) {
+        const int t = k * 64 + lane;
+        const bool on = t < n_px;
+        s_[k] = on ? (int)sp[(int64_t)(t >> lw) * sstride + (t & wm)] : 0;
+        p_[k] = on ? (int)pred[t] : 0;
+        m_[k] = on && mask ? (int)mask[t] : 0;
+      }
+    }
+  }
+  __device__ __forceinline__ int blend(int f, int p, int m) const {   // aom_comp_avg_pred (variance.c:306-319) / aom_comp_mask_pred (:773-791)
+    if (!mask) return (p + f + 1) >> 1;
+    return invert ? (m * p + (64 - m) * f + 32) >> 6 : (m * f + (64 - m) * p + 32) >> 6;
+  }
+  __device__ __forceinline__ uint32_t sad(int row, int col) const {
+    const T *rp = rbase + (int64_t)row * rstride + col;
+    uint32_t acc = 0;
+    if (keep) {
+      int f[kKeep];
+#pragma unroll
+      for (int k = 0; k < kKeep; ++k) {
+        const int t = k * 64 + lane;
+        f[k] = t < n_px ? (int)rp[(t >> lw) * rstride + (t & wm)] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < kKeep; ++k)
+        if (k * 64 < n_px) acc += (uint32_t)iabsm(blend(f[k], p_[k], m_[k]) - s_[k]);   // (lanes beyond the block: 0 - 0)
+    } else {
+      for (int t = lane; t < n_px; t += 64) {
+        const int y = t >> lw, x = t & wm;
+        const int v = blend((int)rp[(int64_t)y * rstride + x], (int)pred[t], mask ? (int)mask[t] : 0);
+        acc += (uint32_t)iabsm(v - (int)sp[(int64_t)y * sstride + x]);
+      }
+    }
+    return wsum32(acc) >> shift;
+  }
+  __device__ __forceinline__ uint32_t var(int row, int col) const {   // (without the MV cost)
+    const T *rp = rbase + (int64_t)row * rstride + col;
+    int32_t s = 0;
+    uint64_t q64;
+    if (keep) {
+      uint32_t q = 0;   // <= 8 x 4095^2 per lane, <= 16 lanes of that per row
+      int f[kKeep];
+#pragma unroll
+      for (int k = 0; k < kKeep; ++k) {
+        const int t = k * 64 + lane;
+        f[k] = t < n_px ? (int)rp[(t >> lw) * rstride + (t & wm)] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < kKeep; ++k) {
+        if (k * 64 < n_px) {
+          const int d = blend(f[k], p_[k], m_[k]) - s_[k];
+          s += d;
+          q += (uint32_t)(d * d);
+        }
+      }
+      q64 = wsum32_wide(q);
+    } else {
+      uint64_t q = 0;
+      for (int t = lane; t < n_px; t += 64) {
+        const int y = t >> lw, x = t & wm;
+        const int d = blend((int)rp[(int64_t)y * rstride + x], (int)pred[t], mask ? (int)mask[t] : 0) - (int)sp[(int64_t)y * sstride + x];
+        s += d;
+        q += (uint32_t)(d * d);
+      }
+      q64 = (uint64_t)wsum((int64_t)q);
+    }
+    return finish_var((int64_t)(int32_t)wsum32((uint32_t)s), q64, n_px, bit_depth);
+  }
+};
 
 template <typename T>
 __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks,
@@ -78,18 +183,10 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
   const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)by * ref.stride + bx;
   const T *pred = second_pred + (size_t)bi * n_px;
   const uint8_t *mask = masks ? masks + (size_t)bi * n_px : nullptr;
-  const int shift = a.bit_depth == 10 ? 2 : a.bit_depth == 12 ? 4 : 0;   // the _bits10 / _bits12 vtable wrappers (encoder_utils.h)
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
-  auto sad_at = [&](int row, int col) -> uint32_t {   // get_mvpred_compound_sad
-    const T *rp = rbase + (int64_t)row * ref.stride + col;
-    int64_t acc = 0;
-    for (int t = lane; t < n_px; t += 64) {
-      const int y = t / W, x = t - y * W;
-      const int v = blend_px((int)rp[(int64_t)y * ref.stride + x], (int)pred[t], mask, t, a.invert_mask);
-      acc += iabsm(v - (int)sp[(int64_t)y * src.stride + x]);
-    }
-    return (uint32_t)wsum(acc) >> shift;
-  };
+  CompoundEval<T> ce;
+  ce.init(sp, src.stride, rbase, ref.stride, pred, mask, W, H, a.invert_mask, a.bit_depth, lane);
+  auto sad_at = [&](int row, int col) -> uint32_t { return ce.sad(row, col); };   // get_mvpred_compound_sad
   constexpr int kRange = 3, kStride = 2 * kRange + 1;   // SEARCH_RANGE_8P, SEARCH_GRID_STRIDE_8P (mcomp_structs.h:26-29)
   unsigned long long visited = 0;                       // the 49 cells of do_refine_search_grid
   int grid_center = kRange * kStride + kRange;
@@ -125,19 +222,7 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
     grid_center += drow * kStride + dcol;
   }
   // av1_get_mvpred_compound_var: svaf / msvf at sub-pel offset (0, 0) -- the bilinear passes with offset 0 are the identity -- + mv_err_cost_
-  int var;
-  {
-    const T *rp = rbase + (int64_t)row * ref.stride + col;
-    int64_t s = 0, q = 0;
-    for (int t = lane; t < n_px; t += 64) {
-      const int y = t / W, x = t - y * W;
-      const int v = blend_px((int)rp[(int64_t)y * ref.stride + x], (int)pred[t], mask, t, a.invert_mask);
-      const int d = v - (int)sp[(int64_t)y * src.stride + x];
-      s += d;
-      q += (uint32_t)(d * d);
-    }
-    var = (int)finish_var(wsum(s), (uint64_t)wsum(q), n_px, a.bit_depth) + var_cost(a, bs.ref_row, bs.ref_col, row * 8, col * 8);
-  }
+  const int var = (int)ce.var(row, col) + var_cost(a, bs.ref_row, bs.ref_col, row * 8, col * 8);
   if (lane == 0) {
     out_mv[2 * bi] = (int16_t)row; out_mv[2 * bi + 1] = (int16_t)col;
     out_sad[bi] = (int32_t)best_sad;
@@ -173,29 +258,12 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
   const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)by * ref.stride + bx;
   const T *pred = second_pred + (size_t)bi * n_px;
   const uint8_t *mask = masks ? masks + (size_t)bi * n_px : nullptr;
-  const int shift = a.bit_depth == 10 ? 2 : a.bit_depth == 12 ? 4 : 0;
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
-  auto sad_at = [&](int row, int col) -> uint32_t {   // get_mvpred_compound_sad: sdaf / msdf
-    const T *rp = rbase + (int64_t)row * ref.stride + col;
-    int64_t acc = 0;
-    for (int t = lane; t < n_px; t += 64) {
-      const int y = t / W, x = t - y * W;
-      const int v = blend_px((int)rp[(int64_t)y * ref.stride + x], (int)pred[t], mask, t, a.invert_mask);
-      acc += iabsm(v - (int)sp[(int64_t)y * src.stride + x]);
-    }
-    return (uint32_t)wsum(acc) >> shift;
-  };
+  CompoundEval<T> ce;
+  ce.init(sp, src.stride, rbase, ref.stride, pred, mask, W, H, a.invert_mask, a.bit_depth, lane);
+  auto sad_at = [&](int row, int col) -> uint32_t { return ce.sad(row, col); };   // get_mvpred_compound_sad: sdaf / msdf
   auto var_at = [&](int row, int col) -> int {   // get_mvpred_compound_var_cost: svaf / msvf at offset (0, 0) + mv_err_cost_
-    const T *rp = rbase + (int64_t)row * ref.stride + col;
-    int64_t s = 0, q = 0;
-    for (int t = lane; t < n_px; t += 64) {
-      const int y = t / W, x = t - y * W;
-      const int v = blend_px((int)rp[(int64_t)y * ref.stride + x], (int)pred[t], mask, t, a.invert_mask);
-      const int d = v - (int)sp[(int64_t)y * src.stride + x];
-      s += d;
-      q += (uint32_t)(d * d);
-    }
-    return (int)finish_var(wsum(s), (uint64_t)wsum(q), n_px, a.bit_depth) + var_cost(a, bs.ref_row, bs.ref_col, row * 8, col * 8);
+    return (int)ce.var(row, col) + var_cost(a, bs.ref_row, bs.ref_col, row * 8, col * 8);
   };
   const int start_row = min(max(bs.start_row, bs.row_min), bs.row_max), start_col = min(max(bs.start_col, bs.col_min), bs.col_max);   // clamp_fullmv
   const uint32_t start_sad = sad_at(start_row, start_col) + (uint32_t)sad_cost(a, frr, frc, start_row, start_col);   // (the same in every run)
@@ -288,13 +356,39 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
   const int32_t *wsrc = wsrc_all + (size_t)bi * n_px, *omask = omask_all + (size_t)bi * n_px;
   const int shift = a.bit_depth == 10 ? 2 : a.bit_depth == 12 ? 4 : 0;
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
+  // As CompoundEval: the weighted source and the mask of the block stay in registers for blocks of up to 512 pixels, a candidate is then eight
+  // independent reference loads per lane; widths are powers of two (row / column of pixel t by shift and mask).
+  constexpr int kKeep = 8;
+  const int lw = __builtin_ctz((unsigned)W), wm = W - 1;
+  const bool keep = n_px <= 64 * kKeep;
+  int ws_[kKeep], om_[kKeep];
+  if (keep) {
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k) {
+      const int t = k * 64 + lane;
+      ws_[k] = t < n_px ? wsrc[t] : 0;
+      om_[k] = t < n_px ? omask[t] : 0;
+    }
+  }
   auto osad_at = [&](int row, int col) -> uint32_t {   // vfp->osdf: obmc_sad (sad_av1.c:163-180) + the bit-depth wrapper
     const T *rp = rbase + (int64_t)row * ref.stride + col;
+    if (keep) {
+      uint32_t acc = 0;
+      int f[kKeep];
+#pragma unroll
+      for (int k = 0; k < kKeep; ++k) {
+        const int t = k * 64 + lane;
+        f[k] = t < n_px ? (int)rp[(t >> lw) * ref.stride + (t & wm)] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < kKeep; ++k)
+        if (k * 64 < n_px) acc += (uint32_t)((iabsm(ws_[k] - f[k] * om_[k]) + 2048) >> 12);   // ROUND_POWER_OF_TWO(abs(..), 12); beyond the block: 0
+      return (uint32_t)wsum32_split(acc) >> shift;
+    }
     int64_t acc = 0;
     for (int t = lane; t < n_px; t += 64) {
-      const int y = t / W, x = t - y * W;
-      const int v = wsrc[t] - (int)rp[(int64_t)y * ref.stride + x] * omask[t];
-      acc += (iabsm(v) + 2048) >> 12;   // ROUND_POWER_OF_TWO(abs(..), 12)
+      const int v = wsrc[t] - (int)rp[(int64_t)(t >> lw) * ref.stride + (t & wm)] * omask[t];
+      acc += (iabsm(v) + 2048) >> 12;
     }
     return (uint32_t)wsum(acc) >> shift;
   };
@@ -302,8 +396,7 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
     const T *rp = rbase + (int64_t)row * ref.stride + col;
     int64_t s = 0, q = 0;
     for (int t = lane; t < n_px; t += 64) {
-      const int y = t / W, x = t - y * W;
-      const int v = wsrc[t] - (int)rp[(int64_t)y * ref.stride + x] * omask[t];
+      const int v = wsrc[t] - (int)rp[(int64_t)(t >> lw) * ref.stride + (t & wm)] * omask[t];
       const int d = v < 0 ? -((-v + 2048) >> 12) : (v + 2048) >> 12;   // ROUND_POWER_OF_TWO_SIGNED(v, 12)
       s += d;
       q += (uint32_t)(d * d);
@@ -437,6 +530,7 @@ __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref,
   const T *rbase = ref.origin + (int64_t)frame * ref.frame_stride + (int64_t)by * ref.stride + bx;
   const int32_t *wsrc = wsrc_all + (size_t)bi * n_px, *omask = omask_all + (size_t)bi * n_px;
   const int pmax = sizeof(T) == 1 ? 255 : (1 << a.bit_depth) - 1;
+  const int lw_ = __builtin_ctz((unsigned)W);
   constexpr uint8_t kBil[8][2] = { { 128, 0 }, { 112, 16 }, { 96, 32 }, { 80, 48 }, { 64, 64 }, { 48, 80 }, { 32, 96 }, { 16, 112 } };  // aom_filter.h:43-50
   // obmc_variance of the prediction at (mrow, mcol): form 0 = the plain block at the full-pel part (ovf), 1 = bilinear (osvf), 2 = up-sampled
   auto obmc_err = [&](int mrow, int mcol, int form, uint32_t *sse_out) -> uint32_t {
@@ -445,7 +539,7 @@ __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref,
     const int fx0 = kBil[sx][0], fx1 = kBil[sx][1], fy0 = kBil[sy][0], fy1 = kBil[sy][1];
     int64_t s = 0, q = 0;
     for (int t = lane; t < n_px; t += 64) {
-      const int y = t / W, x = t - y * W;
+      const int y = t >> lw_, x = t & (W - 1);   // (block widths are powers of two)
       const T *p = rp + (int64_t)y * ref.stride + x;
       int pv;
       if (form == 0) {

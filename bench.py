@@ -1005,6 +1005,110 @@ def run_tf(pkg, ctx, orc, steps, warmup, width=3840, height=2160, bd=10, n_frame
                         "av1_find_best_sub_pixel_tree USE_8_TAPS; 32x32 + four 16x16 per block and frame"})
 
 
+def run_compound_search(pkg, ctx, orc, steps, warmup, width=3840, height=2160, bd=10, bs=16):
+    """SURVEY 8(f) row 1, the RD path's compound searches of handle_newmv on every 16x16 block of a 4K 10-bit frame against two references:
+    av1_joint_motion_search on both branches (8-neighbour refinement: speed >= 1; av1_full_pixel_search on the compound prediction with the second
+    sub-pel start: speed 0), av1_compound_single_motion_search_interinter (masked), and the OBMC pair (av1_obmc_full_pixel_search +
+    av1_find_best_obmc_sub_pixel_tree_up).  One call per frame each; ms per frame.  A sample of blocks is checked against the oracle."""
+    capi, synth = pkg.capi, pkg.synth
+    border = 160
+    src, ref0 = synth.shifted_smooth_pair(width, height, 61, bd, shift=(2, -3), frac8=(3, 0))
+    _, ref1 = synth.shifted_smooth_pair(width, height, 61, bd, shift=(-3, 2), frac8=(0, 5))
+    ps, p0, p1 = (ctx.planes_alloc(width, height, border, bd, 1) for _ in range(3))
+    for p_, a in ((ps, src), (p0, ref0), (p1, ref1)):
+        ctx.planes_upload(p_, 0, a)
+    gc, gr = width // bs, height // bs
+    n = gc * gr
+    rng = np.random.default_rng(5)
+    blocks = np.zeros(n, capi.search_block_dtype)
+    blocks["bx"], blocks["by"] = (np.arange(n) % gc) * bs, (np.arange(n) // gc) * bs
+    ext = border - 8 - 16
+    blocks["col_min"], blocks["col_max"] = np.maximum(-(blocks["bx"] + ext), -1000), np.minimum(width - blocks["bx"] - bs + ext, 1000)
+    blocks["row_min"], blocks["row_max"] = np.maximum(-(blocks["by"] + ext), -1000), np.minimum(height - blocks["by"] - bs + ext, 1000)
+    ref_mv = rng.integers(-24, 25, (n, 2, 2)).astype(np.int16)
+    cur = np.zeros((n, 2, 2), np.int16)
+    cur[:, 0] = np.array([-3 * 8, 2 * 8]) + rng.integers(-20, 21, (n, 2))      # the single-reference results: a few pixels off the true motion
+    cur[:, 1] = np.array([2 * 8, -3 * 8]) + rng.integers(-20, 21, (n, 2))
+    mask = np.clip((np.arange(bs)[None, None, :] * 64 // bs + rng.integers(-6, 7, (n, bs, bs))), 0, 64).astype(np.uint8)
+    mv_max = (1 << 14) - 1
+    v = np.abs(np.arange(-mv_max, mv_max + 1))
+    bits = np.where(v == 0, 0, np.floor(np.log2(np.maximum(v, 1))) + 1).astype(np.int64)
+    t0, t1 = (140 + bits * 305).astype(np.int32), (165 + bits * 285 + (v & 7) * 5).astype(np.int32)
+    tj = np.array([190, 660, 655, 1040], np.int32)
+    d_j, d_c0, d_c1 = ctx.to_device(tj), ctx.to_device(t0), ctx.to_device(t1)
+    tabs = (d_j, d_c0 + mv_max * 4, d_c1 + mv_max * 4)
+    d_b, d_r, d_m = ctx.to_device(blocks), ctx.to_device(ref_mv), ctx.to_device(mask)
+    d_cur = ctx.malloc(n * 8)
+    d_rate, d_err = ctx.malloc(n * 4), ctx.malloc(n * 4)
+    sub8 = capi.SubpelParams(2, 0, 61, 2, 1, 0, 3)      # SUBPEL_TREE, USE_8_TAPS (speed 0)
+    sub4 = capi.SubpelParams(2, 0, 61, 2, 1, 0, 2)      # SUBPEL_TREE, USE_4_TAPS (speed 1 - 2)
+    full = capi.SearchParams.make("NSTEP", 5, 0, 22, 61, mesh_diff_thr=4, mesh=[(64, 8), (28, 4), (15, 1), (7, 1)])
+    # every call starts from the single-reference results again: a 261 KB host copy on the stream, inside the timed region (~1 % of the shortest call)
+    reset = lambda: ctx.memcpy_h2d(d_cur, cur)
+    out = {}
+
+    def timed(name, fn, note):
+        def once():
+            reset()
+            fn()
+        for _ in range(max(1, warmup)):
+            once()
+        ms = kernel_avg_ms(ctx, once, max(3, steps // 2))
+        out[name] = {"ms_per_frame": ms, "blocks_per_s": n / (ms * 1e-3), "what": note}
+    timed("joint_refining_4tap", lambda: ctx.joint_motion_search_batch(ps, p0, p1, 0, bs, bs, 0, 22, sub4, 0, d_b, d_r, d_cur, None, n, d_rate, d_err, *tabs),
+          "av1_joint_motion_search, disable_extensive_joint_motion_search (speed >= 1): 4 iterations of {predictor, av1_refining_search_8p_c, compound sub-pel tree USE_4_TAPS}")
+    timed("joint_extensive_8tap", lambda: ctx.joint_motion_search_extensive_batch(ps, p0, p1, 0, bs, bs, full, sub8, 1, 0, d_b, d_r, d_cur, None, n, d_rate, d_err, *tabs),
+          "av1_joint_motion_search, speed 0: 4 iterations of {predictor, av1_full_pixel_search(.., 5, ..) on the compound, compound sub-pel tree USE_8_TAPS twice (second MV)}")
+    want = None
+    if orc is not None:   # the extensive call against the oracle's composition on every 211th block
+        got_mv = ctx.from_device(d_cur, (n, 2, 2), np.int16)
+        got_rate, got_err = ctx.from_device(d_rate, (n,), np.int32), ctx.from_device(d_err, (n,), np.int32)
+        idx = np.arange(0, n, 211)
+        sb, r0b, r1b = (orc.extend_plane(a, border, ps.stride) for a in (src, ref0, ref1))
+        oq = orc.search_params("NSTEP", 5, 0, 22, 61, 0, 0, 0, 4, 2147483647, 0, [(64, 8), (28, 4), (15, 1), (7, 1)], no_cost_list=1)
+        w_mv, w_rate, w_err, _ = orc.joint_motion_search_batch(sb, r0b, r1b, border, width, height, bs, bs, blocks[idx], ref_mv[idx], cur[idx], None, cost_type=0,
+                                                               sad_per_bit=22, sub=dict(tree=2, subpel_search_type=3, error_per_bit=61, iters_per_step=2, allow_hp=1),
+                                                               mvjcost=tj, mvcost0=t0, mvcost1=t1, bd=bd, threads=8, full=oq, allow_second_mv=1)
+        want = bool(np.array_equal(got_mv[idx], w_mv) and np.array_equal(got_rate[idx], w_rate) and np.array_equal(got_err[idx], w_err))
+    d_this, d_other = ctx.to_device(np.ascontiguousarray(cur[:, 0])), ctx.to_device(np.ascontiguousarray(cur[:, 1]))
+    d_this_w, d_ref0 = ctx.malloc(n * 4), ctx.to_device(np.ascontiguousarray(ref_mv[:, 0]))
+    this0 = np.ascontiguousarray(cur[:, 0])
+    reset = lambda: ctx.memcpy_h2d(d_this_w, this0)
+    timed("compound_single_masked_4tap", lambda: ctx.compound_single_motion_search_batch(ps, p0, p1, 0, bs, bs, full, sub4, 0, d_b, d_ref0, d_this_w, d_other, 0, 0, None, d_m, 0,
+                                                                                         n, d_rate, d_err, *tabs),
+          "av1_compound_single_motion_search_interinter with a mask: predictor of the other side, av1_full_pixel_search(.., 5, ..) on the masked compound, sub-pel tree USE_4_TAPS")
+    # OBMC: weighted source / mask of calc_target_weighted_pred (synthetic: top / left neighbours overlap half a block)
+    om = np.full((bs, bs), 4096, np.int64)
+    om[:bs // 2, :] = (np.linspace(36, 64, bs // 2).astype(np.int64)[:, None]) * 64
+    om[:, :bs // 2] = np.minimum(om[:, :bs // 2], (np.linspace(34, 64, bs // 2).astype(np.int64)[None, :]) * 64)
+    sblk = src[:gr * bs, :gc * bs].reshape(gr, bs, gc, bs).transpose(0, 2, 1, 3).reshape(n, bs, bs).astype(np.int64)
+    nb = np.clip(sblk + rng.integers(-(10 << (bd - 8)), (10 << (bd - 8)) + 1, sblk.shape), 0, (1 << bd) - 1)
+    ws = (sblk * 4096 - nb * (4096 - om[None])).astype(np.int32)
+    d_ws, d_om = ctx.to_device(ws), ctx.to_device(np.broadcast_to(om.astype(np.int32), (n, bs, bs)).copy())
+    ob = blocks.copy()
+    ob["ref_row"], ob["ref_col"] = ref_mv[:, 0, 0], ref_mv[:, 0, 1]
+    ob["start_row"], ob["start_col"] = cur[:, 0, 0] >> 3, cur[:, 0, 1] >> 3
+    ob["row_min"], ob["row_max"] = np.maximum(ob["row_min"], -64), np.minimum(ob["row_max"], 64)
+    ob["col_min"], ob["col_max"] = np.maximum(ob["col_min"], -64), np.minimum(ob["col_max"], 64)
+    sbl = ob.copy()
+    for k_ in ("start_row", "start_col", "row_min", "row_max", "col_min", "col_max"):
+        sbl[k_] = ob[k_] * 8
+    d_ob, d_sbl = ctx.to_device(ob), ctx.to_device(sbl)
+    d_mv, d_dist, d_sse = ctx.malloc(n * 4), ctx.malloc(n * 4), ctx.malloc(n * 4)
+    reset = lambda: None
+    timed("obmc_full_pixel_nstep", lambda: ctx.obmc_full_pixel_search_batch(p0, 0, bs, bs, "NSTEP", 4, 0, 0, 22, 61, d_ob, n, d_ws, d_om, d_mv, d_err, *tabs),
+          "av1_obmc_full_pixel_search: obmc_full_pixel_diamond, NSTEP from step_param 4")
+    timed("obmc_subpel_tree_4tap", lambda: ctx.obmc_subpel_tree_batch(p0, 0, bs, bs, sub4, d_sbl, n, d_ws, d_om, d_mv, d_err, d_dist, d_sse, *tabs),
+          "av1_find_best_obmc_sub_pixel_tree_up, USE_4_TAPS, from the full-pel start")
+    for d in (d_j, d_c0, d_c1, d_b, d_r, d_m, d_cur, d_rate, d_err, d_this, d_other, d_this_w, d_ref0, d_ws, d_om, d_ob, d_sbl, d_mv, d_dist, d_sse):
+        ctx.free(d)
+    for p_ in (ps, p0, p1):
+        ctx.planes_free(p_)
+    ms = out["joint_refining_4tap"]["ms_per_frame"]
+    return dict(out, workload="compound_search_4k_10bit", value=n / (ms * 1e-3), unit="compound blocks/s (av1_joint_motion_search, refining branch)", ms_per_frame=ms,
+                blocks_per_frame=n, parity_sample_extensive=want)
+
+
 def run_sad_diamond_lists(pkg, ctx, orc, steps, warmup, width=3840, height=2160, bd=8, frames=16):
     """lists that are NOT Mode-A shaped through aomhip_sad_sb_batch -- one diamond step per 16x16 block as the
     encoder issues it (mcomp.c:1299-1416): 8 sites = two x4d groups at (+-r, 0), (0, +-r), (+-r, +-r) around a per-block centre within
@@ -1263,7 +1367,7 @@ def main():
                     help="default: sad16x16_modeA_1080p_8bit (BASELINE.json's metric) at every N; with N > 1 the line also carries the "
                          "strong-scaling search pipeline with its per-frame RCCL exchange as `strong_scaling_search`",
                     choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "txq_4k_10bit", "search_4k_10bit", "inner_loop_4k_10bit", "default_search_4k_10bit", "cdef_search_4k_10bit",
-                                                "wiener_stats_4k", "tf_motion_search_4k_10bit", "sad_diamond_lists_4k_8bit", "first_pass_4k_10bit"])
+                                                "wiener_stats_4k", "tf_motion_search_4k_10bit", "sad_diamond_lists_4k_8bit", "first_pass_4k_10bit", "compound_search_4k_10bit"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -1365,6 +1469,12 @@ def main():
         r = run_first_pass(pkg, ctx, orc, args.steps, args.warmup)
         ctx.close()
         print(json.dumps(dict(r, metric="first-pass blocks/s", n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
+                              vs_baseline=None, dtype="u16", data="synthetic", ms_per_step=r["ms_per_frame"], config={"workload": r["workload"]})))
+        return
+    if args.workload == "compound_search_4k_10bit":  # the RD path's compound / OBMC searches (single GPU)
+        r = run_compound_search(pkg, ctx, orc, args.steps, args.warmup)
+        ctx.close()
+        print(json.dumps(dict(r, metric="compound blocks/s", n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
                               vs_baseline=None, dtype="u16", data="synthetic", ms_per_step=r["ms_per_frame"], config={"workload": r["workload"]})))
         return
     if args.workload == "tf_motion_search_4k_10bit":  # SURVEY 8(f) row 1 (single GPU)
