@@ -56,7 +56,12 @@ hipStream_t side_stream(aomhip_ctx *ctx) {
   }
   hipStream_t st = nullptr;
   hipEvent_t a = nullptr, b = nullptr;
-  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+  // the side stream carries throughput work beside a latency chain on ctx->stream (first pass: the golden leg beside the row chain; temporal
+  // filter: a frame's sub-block searches beside the next frame's block search): the lowest priority the device offers
+  int prio_lo = 0, prio_hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { prio_lo = 0; (void)hipGetLastError(); }
+  static const int env_prio = [] { const char *e = getenv("AOMHIP_SIDE_PRIORITY"); return e ? atoi(e) : 1; }();
+  if ((env_prio ? hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess || hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
     if (b) (void)hipEventDestroy(b);
     if (a) (void)hipEventDestroy(a);

@@ -66,14 +66,19 @@ __global__ void tf_subpel_list_kernel(const aomhip_search_block *blocks, const i
 
 // after the block's sub-pel search: block_mse (:190), *ref_mv = block MV (:192), and the full-pel list of the four sub-blocks started
 // at get_fullmv_from_mv(ref_mv) (:198)
-__global__ void tf_after_block_kernel(const aomhip_search_block *blocks, const int16_t *block_mv, const uint32_t *block_err, int n,
-                                      int16_t *ref_mv, int32_t *block_mse, aomhip_search_block *sub_out) {
+__global__ void tf_after_block_kernel(const aomhip_search_block *blocks, const int16_t *block_mv, const uint32_t *block_err, int n, int mse_thresh,
+                                      int16_t *ref_mv, int32_t *block_mse, int16_t *block_mv_keep, aomhip_search_block *sub_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const aomhip_search_block b = blocks[i];
   const int row = block_mv[2 * i], col = block_mv[2 * i + 1];
-  block_mse[i] = (int32_t)((block_err[i] + (unsigned)(kTfBlock * kTfBlock / 2)) / (unsigned)(kTfBlock * kTfBlock));  // DIVIDE_AND_ROUND, unsigned
-  ref_mv[2 * i] = (int16_t)row; ref_mv[2 * i + 1] = (int16_t)col;
+  const int bmse = (int32_t)((block_err[i] + (unsigned)(kTfBlock * kTfBlock / 2)) / (unsigned)(kTfBlock * kTfBlock));  // DIVIDE_AND_ROUND, unsigned
+  block_mse[i] = bmse;
+  block_mv_keep[2 * i] = (int16_t)row; block_mv_keep[2 * i + 1] = (int16_t)col;   // (this frame's own copy: the sub-block chain reads it while the next frame's block search runs)
+  // *ref_mv = block MV (:192), then the caller's rule (:249-252) -- which reads block_mse only, so the NEXT frame's 32x32 search does not wait
+  // for this frame's sub-block searches
+  const bool zero = bmse > mse_thresh;
+  ref_mv[2 * i] = zero ? (int16_t)0 : (int16_t)row; ref_mv[2 * i + 1] = zero ? (int16_t)0 : (int16_t)col;
   aomhip_search_block o;
   o.ref_row = 0; o.ref_col = 0;
   o.start_row = (int16_t)rawpel(row); o.start_col = (int16_t)rawpel(col);
@@ -86,7 +91,8 @@ __global__ void tf_after_block_kernel(const aomhip_search_block *blocks, const i
 
 // tf_determine_block_partition (:270-293) + the ref_mv rule (:249-252); writes the frame's outputs
 __global__ void tf_finish_kernel(const int16_t *block_mv, const int32_t *block_mse, const int16_t *sub_mv, const uint32_t *sub_err, int n,
-                                 int have_sub, int mse_thresh, int16_t *ref_mv, int16_t *out_mvs, int32_t *out_mses) {
+                                 int have_sub, int mse_thresh, int16_t *ref_mv /* null: tf_after_block_kernel applied the rule */, int16_t *out_mvs,
+                                 int32_t *out_mses) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int mses[4], mvs[4][2];
@@ -117,7 +123,7 @@ __global__ void tf_finish_kernel(const int16_t *block_mv, const int32_t *block_m
     out_mvs[8 * i + 2 * k] = (int16_t)mvs[k][0]; out_mvs[8 * i + 2 * k + 1] = (int16_t)mvs[k][1];
     out_mses[4 * i + k] = mses[k];
   }
-  if (bmse > mse_thresh) ref_mv[2 * i] = ref_mv[2 * i + 1] = 0;
+  if (ref_mv && bmse > mse_thresh) ref_mv[2 * i] = ref_mv[2 * i + 1] = 0;
 }
 
 // force_integer_mv (:158-168): error = vf(ref + mv, src) is one aomhip_variance_batch evaluation per block ...
@@ -177,16 +183,19 @@ extern "C" int aomhip_tf_motion_search_frames(aomhip_ctx *ctx, const aomhip_plan
   auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t o_ref = take(n1 * 4), o_l32 = take(n1 * sizeof(aomhip_search_block)), o_fmv32 = take(n1 * 4), o_fcost32 = take(n1 * 4),
                o_cl32 = take(n1 * 20), o_s32 = take(n1 * sizeof(aomhip_search_block)), o_mv32 = take(n1 * 4), o_err32 = take(n1 * 4),
-               o_dist32 = take(n1 * 4), o_sse32 = take(n1 * 4), o_mse32 = take(n1 * 4), o_l16 = take(n4 * sizeof(aomhip_search_block)),
+               o_dist32 = take(n1 * 4), o_sse32 = take(n1 * 4), o_mse32 = take(n1 * 4),
                o_fmv16 = take(n4 * 4), o_fcost16 = take(n4 * 4), o_cl16 = take(n4 * 20), o_s16 = take(n4 * sizeof(aomhip_search_block)),
                o_mv16 = take(n4 * 4), o_err16 = take(n4 * 4), o_dist16 = take(n4 * 4), o_sse16 = take(n4 * 4),
                o_cand = take(n1 * sizeof(aomhip_var_cand));
+  // per reference frame: what the sub-block chain of frame f reads after the block chain of frame f + 1 has started
+  const size_t nf = (size_t)frames->n_frames;
+  const size_t o_fmv32k = take(nf * n1 * 4), o_fmse32 = take(nf * n1 * 4), o_fl16 = take(nf * n4 * sizeof(aomhip_search_block));
   char *w = static_cast<char *>(work(ctx, off));
   if (!w) return AOMHIP_ERR_NOMEM;
   auto at = [&](size_t o) { return w + o; };
   int16_t *ref_mv = reinterpret_cast<int16_t *>(at(o_ref));
   aomhip_search_block *l32 = reinterpret_cast<aomhip_search_block *>(at(o_l32)), *s32 = reinterpret_cast<aomhip_search_block *>(at(o_s32));
-  aomhip_search_block *l16 = reinterpret_cast<aomhip_search_block *>(at(o_l16)), *s16 = reinterpret_cast<aomhip_search_block *>(at(o_s16));
+  aomhip_search_block *s16 = reinterpret_cast<aomhip_search_block *>(at(o_s16));
   int16_t *fmv32 = reinterpret_cast<int16_t *>(at(o_fmv32)), *mv32 = reinterpret_cast<int16_t *>(at(o_mv32));
   int16_t *fmv16 = reinterpret_cast<int16_t *>(at(o_fmv16)), *mv16 = reinterpret_cast<int16_t *>(at(o_mv16));
   int32_t *cl32 = tp->use_cost_list ? reinterpret_cast<int32_t *>(at(o_cl32)) : nullptr;
@@ -205,6 +214,15 @@ extern "C" int aomhip_tf_motion_search_frames(aomhip_ctx *ctx, const aomhip_plan
   const unsigned g1 = (unsigned)((n1 + 255) / 256), g4 = (unsigned)((n4 + 255) / 256);
   hipStream_t st = ctx->stream;
   AOMHIP_TRY(hipMemsetAsync(ref_mv, 0, n1 * 4, st));  // MV ref_mv = kZeroMv (:855)
+  // ref_mv chains the frames through their 32x32 searches only: the four 16x16 searches of frame f (60 % of a frame's work) run on the
+  // context's side stream beside the 32x32 search of frame f + 1, whose 8 160 wavefronts leave the chip half empty in their last round.
+  // AOMHIP_TF_SERIAL=1: one stream (A/B); also while ctx->stream is being captured (no side stream then).
+  aomhip_ctx side = *ctx;
+  hipStream_t ss = nullptr;
+  if (!tp->force_integer_mv && !([] { const char *e = getenv("AOMHIP_TF_SERIAL"); return e && atoi(e) != 0; }())) ss = aomhip::side_stream(ctx);
+  if (ss) side.stream = ss;
+  aomhip_ctx *cb = ss ? &side : ctx;   // where the sub-block chain is enqueued
+  bool forked = false;
   for (int f = 0; f < frames->n_frames; ++f) {
     int16_t *out_mvs = d_subblock_mvs + (size_t)f * n4 * 2;
     int32_t *out_mses = d_subblock_mses + (size_t)f * n4;
@@ -238,18 +256,38 @@ extern "C" int aomhip_tf_motion_search_frames(aomhip_ctx *ctx, const aomhip_plan
     rc = aomhip_subpel_tree_batch(ctx, &src, &ref, 0, kTfBlock, kTfBlock, &tp->sub, nullptr, nullptr, nullptr, s32, cl32, n, mv32, err32,
                                   reinterpret_cast<int32_t *>(at(o_dist32)), reinterpret_cast<uint32_t *>(at(o_sse32)));
     if (rc != AOMHIP_OK) return rc;
-    hipLaunchKernelGGL(tf_after_block_kernel, dim3(g1), dim3(256), 0, st, d_blocks, mv32, err32, n, ref_mv, mse32, l16);
+    int16_t *mv32f = reinterpret_cast<int16_t *>(at(o_fmv32k)) + (size_t)f * n1 * 2;
+    int32_t *mse32f = reinterpret_cast<int32_t *>(at(o_fmse32)) + (size_t)f * n1;
+    aomhip_search_block *l16f = reinterpret_cast<aomhip_search_block *>(at(o_fl16)) + (size_t)f * n4;
+    hipLaunchKernelGGL(tf_after_block_kernel, dim3(g1), dim3(256), 0, st, d_blocks, mv32, err32, n, tp->mse_thresh, ref_mv, mse32f, mv32f, l16f);
     AOMHIP_LAUNCH_CHECK();
-    rc = aomhip_full_pixel_search_batch(ctx, &src, &ref, 0, kTfSub, kTfSub, &tp->full, nullptr, nullptr, nullptr, l16, (int)n4, fmv16,
+    if (ss) {   // the sub-block chain of this frame starts when its block chain is done; the next frame's block chain does not wait for it
+      AOMHIP_TRY(hipEventRecord(ctx->ev_fork, st));
+      AOMHIP_TRY(hipStreamWaitEvent(ss, ctx->ev_fork, 0));
+      forked = true;
+    }
+    rc = aomhip_full_pixel_search_batch(cb, &src, &ref, 0, kTfSub, kTfSub, &tp->full, nullptr, nullptr, nullptr, l16f, (int)n4, fmv16,
                                         reinterpret_cast<int32_t *>(at(o_fcost16)), cl16, nullptr);
-    if (rc != AOMHIP_OK) return rc;
-    hipLaunchKernelGGL(tf_subpel_list_kernel, dim3(g4), dim3(256), 0, st, d_blocks, fmv16, n, 4, s16);
-    AOMHIP_LAUNCH_CHECK();
-    rc = aomhip_subpel_tree_batch(ctx, &src, &ref, 0, kTfSub, kTfSub, &tp->sub, nullptr, nullptr, nullptr, s16, cl16, (int)n4, mv16, err16,
-                                  reinterpret_cast<int32_t *>(at(o_dist16)), reinterpret_cast<uint32_t *>(at(o_sse16)));
-    if (rc != AOMHIP_OK) return rc;
-    hipLaunchKernelGGL(tf_finish_kernel, dim3(g1), dim3(256), 0, st, mv32, mse32, mv16, err16, n, 1, tp->mse_thresh, ref_mv, out_mvs, out_mses);
-    AOMHIP_LAUNCH_CHECK();
+    if (rc == AOMHIP_OK) {
+      hipLaunchKernelGGL(tf_subpel_list_kernel, dim3(g4), dim3(256), 0, cb->stream, d_blocks, fmv16, n, 4, s16);
+      rc = aomhip_subpel_tree_batch(cb, &src, &ref, 0, kTfSub, kTfSub, &tp->sub, nullptr, nullptr, nullptr, s16, cl16, (int)n4, mv16, err16,
+                                    reinterpret_cast<int32_t *>(at(o_dist16)), reinterpret_cast<uint32_t *>(at(o_sse16)));
+    }
+    if (rc == AOMHIP_OK)
+      hipLaunchKernelGGL(tf_finish_kernel, dim3(g1), dim3(256), 0, cb->stream, mv32f, mse32f, mv16, err16, n, 1, tp->mse_thresh, (int16_t *)nullptr, out_mvs,
+                         out_mses);
+    if (rc != AOMHIP_OK || hipGetLastError() != hipSuccess) {
+      if (forked) {   // never leave the streams forked
+        (void)hipEventRecord(ctx->ev_join, ss);
+        (void)hipStreamWaitEvent(st, ctx->ev_join, 0);
+      }
+      if (rc == AOMHIP_OK) { set_error("aomhip_tf_motion_search_frames: kernel launch failed"); rc = AOMHIP_ERR_HIP; }
+      return rc;
+    }
+  }
+  if (forked) {
+    AOMHIP_TRY(hipEventRecord(ctx->ev_join, ss));
+    AOMHIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
   }
   if (d_ref_mv_out) AOMHIP_TRY(hipMemcpyAsync(d_ref_mv_out, ref_mv, n1 * 4, hipMemcpyDeviceToDevice, st));
   return AOMHIP_OK;

@@ -770,7 +770,11 @@ int aomhip_tf_block_list(int width, int height, int border, aomhip_search_block 
  * d_blocks: the list of aomhip_tf_block_list in device memory.  Outputs, for frame f and block i at [(f * n_blocks + i) * 4 + k],
  * k = the sub-block in raster order: d_subblock_mvs (row, col in 1/8 pel) and d_subblock_mses after the partition decision;
  * the entries of the filter frame itself and of absent frames are 0 / INT32_MAX (what the caller's initialisation leaves, :861-862).
- * d_ref_mv (2 * n_blocks int16, or NULL): the ref_mv each block ends with.  Asynchronous on the context's stream. */
+ * d_ref_mv (2 * n_blocks int16, or NULL): the ref_mv each block ends with.  Asynchronous on the context's stream.
+ * Streams: the ref_mv chain runs through the frames' 32x32 searches only (temporal_filter.c:192, :249-252), so unless force_integer_mv the
+ * 16x16 searches of a frame are forked onto a second stream the context owns, beside the 32x32 search of the next frame, and joined again
+ * before the call returns: to the caller it stays ONE ordered operation on the context's stream (a graph capture taken before that second
+ * stream exists runs it on one stream; AOMHIP_TF_SERIAL=1 forces that). */
 int aomhip_tf_motion_search_frames(aomhip_ctx *ctx, const aomhip_planes *frames, int filter_frame, const uint8_t *frame_present,
                                    const aomhip_tf_params *params, const aomhip_search_block *d_blocks, int n_blocks,
                                    int16_t *d_subblock_mvs, int32_t *d_subblock_mses, int16_t *d_ref_mv);
