@@ -1525,6 +1525,7 @@ def main():
             others.append(run_wiener_stats(pkg, ctx, orc, max(3, args.steps // 6), 1))
             others.append(run_tf(pkg, ctx, orc, max(4, args.steps // 4), 1))
             others.append(run_first_pass(pkg, ctx, orc, max(3, args.steps // 6), 1))
+            others.append(run_compound_search(pkg, ctx, orc, max(4, args.steps // 3), 1))
             others.append(run_sad_diamond_lists(pkg, ctx, orc, max(6, args.steps // 2), 1))
     if dist is not None and default_multi:
         # mandatory companion of the N > 1 line (the forced one-rank dry run emits the same schema).  The headline (SAD, no collective)
