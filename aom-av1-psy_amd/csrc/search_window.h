@@ -37,6 +37,7 @@ struct CellMap {
 // windows share all their rows (2 x 2 cells from a grid hint measured 3 % slower and were dropped).
 constexpr int kCellWaves = 2;
 constexpr int kCellReach = 16;
+constexpr int kCellReachBig = 8;   // blocks of >= 1024 pixels
 
 // Host side: how a search call cuts its list into cells.  waves = 0: no window (the kernels' plain form).
 // AOMHIP_SEARCH_CELL=0 switches the window off, AOMHIP_SEARCH_CELL_R=<pixels> overrides the reach (kernel A/B only; results never depend
@@ -52,7 +53,12 @@ inline CellPlan plan_cells(const aomhip_planes *ref, int bw, int bh, int n_block
   CellPlan p{};
   if (!env_on || reach < 0) return p;   // (reach < 0: the caller wants the form without a window)
   const int es = ref->bit_depth == 8 ? 1 : 2;
-  const int r = env_r >= 0 ? env_r : (reach < kCellReach ? reach : kCellReach);
+  static const int env_rb = [] { const char *e = getenv("AOMHIP_SEARCH_CELL_RB"); return e ? atoi(e) : -1; }();   // (blocks of >= 1024 pixels)
+  // Blocks of 32x32 and larger take a reach of 8: their window is 13 KB per two-block cell at 16 (16-bit planes) and the workgroups per CU
+  // it costs outweigh the radius 9 .. 16 rounds it serves -- temporal filter, 4K 10-bit: 7.04 -> 6.55 ms (R x RB sweep in profiles/r04_search_cell.md)
+  const bool big = bw * bh >= 1024;
+  const int cap = big ? (env_rb >= 0 ? env_rb : (env_r >= 0 ? env_r : kCellReachBig)) : (env_r >= 0 ? env_r : kCellReach);
+  const int r = (env_r >= 0 || (big && env_rb >= 0)) ? cap : (reach < cap ? reach : cap);
   // the window of a cell whose blocks are horizontal neighbours and start at the same MV; rounded up so that the workgroups of a CU
   // fill its 160 KB without a remainder (the slack serves cells whose start MVs differ; a window that still does not fit shrinks its
   // reach, stage_cell_window)
