@@ -189,3 +189,59 @@ def test_first_pass_frame_call_replays_from_a_graph_with_and_without_its_side_st
     for r in rings:
         ctx.planes_free(r)
     ctx.close()
+
+
+def test_tf_frames_call_gives_the_same_outputs_on_one_stream_on_two_and_from_graphs(hip):
+    """aomhip_tf_motion_search_frames runs a frame's 16x16 searches on the context's second stream beside the next frame's 32x32 search
+    (csrc/tf_search.hip): AOMHIP_TF_SERIAL=1, the forked form, a capture taken before the second stream exists (one stream) and a capture with
+    the fork / joins recorded all write the same MVs, errors and ref_mvs."""
+    import os
+    capi = hip.capi
+    ctx = capi.Context(0)   # a fresh context: no side stream yet
+    W, H, B, bd, F = 352, 288, 64, 10, 5
+    rng = np.random.default_rng(9)
+    base, _ = hip.synth.shifted_smooth_pair(W + 64, H + 64, 17, bd)
+    planes = ctx.planes_alloc(W, H, B, bd, F)
+    for f in range(F):
+        img = base[32 + f:32 + f + H, 32 - 2 * f:32 - 2 * f + W].astype(np.int32) + rng.integers(-3, 4, (H, W))
+        ctx.planes_upload(planes, f, np.clip(img, 0, (1 << bd) - 1).astype(np.uint16))
+    blocks = capi.tf_block_list(W, H, B)
+    n = len(blocks)
+    tp = capi.TfParams.default(W, H, bd, 30, 1, [(64, 8), (28, 4), (15, 1), (7, 1)])
+    d_b = ctx.to_device(blocks)
+    outs = [ctx.malloc(F * n * 16), ctx.malloc(F * n * 16), ctx.malloc(n * 4)]
+    sizes = [F * n * 16, F * n * 16, n * 4]
+
+    def call():
+        ctx.tf_motion_search_frames(planes, F // 2, tp, d_b, n, outs[0], outs[1], outs[2])
+
+    def read():
+        ctx.sync()
+        return [ctx.from_device(o, (s // 2,), np.int16).copy() for o, s in zip(outs, sizes)]
+
+    def clear():
+        for o, s in zip(outs, sizes):
+            ctx.memset(o, 0xEE, s)
+
+    os.environ["AOMHIP_TF_SERIAL"] = "1"
+    try:
+        call()                            # (sizes the work memory; one stream)
+        want = read()
+        g_serial = ctx.capture(call)      # no side stream yet
+    finally:
+        os.environ["AOMHIP_TF_SERIAL"] = "0"
+    clear(); ctx.graph_launch(g_serial)
+    assert all(np.array_equal(a, b) for a, b in zip(read(), want))
+    clear(); call()                       # outside a capture: creates the side stream, forks per frame, joins once
+    assert all(np.array_equal(a, b) for a, b in zip(read(), want))
+    g_forked = ctx.capture(call)
+    clear(); ctx.graph_launch(g_forked)
+    assert all(np.array_equal(a, b) for a, b in zip(read(), want))
+    clear(); ctx.graph_launch(g_serial)
+    assert all(np.array_equal(a, b) for a, b in zip(read(), want))
+    assert (want[0] != 0).any()
+    ctx.graph_destroy(g_serial); ctx.graph_destroy(g_forked)
+    for d in [d_b] + outs:
+        ctx.free(d)
+    ctx.planes_free(planes)
+    ctx.close()
