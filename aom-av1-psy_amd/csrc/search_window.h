@@ -36,6 +36,12 @@ struct CellMap {
 // no window = 0.231.  Cells are consecutive list entries: for raster-ordered lists that is a strip of horizontal neighbours, whose
 // windows share all their rows (2 x 2 cells from a grid hint measured 3 % slower and were dropped).
 constexpr int kCellWaves = 2;
+#ifndef AOMHIP_BIG_CELL_WAVES
+#define AOMHIP_BIG_CELL_WAVES 2
+#endif
+#ifndef AOMHIP_BIG_CELL_PIXELS
+#define AOMHIP_BIG_CELL_PIXELS 1024
+#endif
 constexpr int kCellReach = 16;
 constexpr int kCellReachBig = 8;   // blocks of >= 1024 pixels
 
@@ -47,7 +53,9 @@ struct CellPlan {
   int lds;       // dynamic LDS bytes of the launch
   CellMap map;
 };
-inline CellPlan plan_cells(const aomhip_planes *ref, int bw, int bh, int n_blocks, int reach) {
+// blocks per cell (= wavefronts per workgroup) of the general search kernel, by block size
+constexpr int cell_waves_for(int bw, int bh) { return bw * bh >= AOMHIP_BIG_CELL_PIXELS ? AOMHIP_BIG_CELL_WAVES : kCellWaves; }
+inline CellPlan plan_cells(const aomhip_planes *ref, int bw, int bh, int n_blocks, int reach, int waves = kCellWaves) {
   static const int env_on = [] { const char *e = getenv("AOMHIP_SEARCH_CELL"); return e ? atoi(e) : 1; }();
   static const int env_r = [] { const char *e = getenv("AOMHIP_SEARCH_CELL_R"); return e ? atoi(e) : -1; }();
   CellPlan p{};
@@ -62,17 +70,17 @@ inline CellPlan plan_cells(const aomhip_planes *ref, int bw, int bh, int n_block
   // the window of a cell whose blocks are horizontal neighbours and start at the same MV; rounded up so that the workgroups of a CU
   // fill its 160 KB without a remainder (the slack serves cells whose start MVs differ; a window that still does not fit shrinks its
   // reach, stage_cell_window)
-  int64_t pitch = ((int64_t)kCellWaves * bw + 2 * r) * es + 16;
+  int64_t pitch = ((int64_t)waves * bw + 2 * r) * es + 16;
   pitch += ((7 - (pitch >> 2)) & 31) << 2;
   int64_t want = pitch * (bh + 2 * r);
-  for (int k = 16; k >= 1; --k) {   // (16 two-wavefront workgroups = the CU's 32 wavefronts)
+  for (int k = 32 / waves; k >= 1; --k) {   // (16 two-wavefront workgroups = the CU's 32 wavefronts)
     const int64_t budget = (160 * 1024 - 512 * k) / k - 256;
     if (want <= budget) { want = budget; break; }
   }
   if (want > 156 * 1024) want = 156 * 1024;
-  p.waves = kCellWaves;
+  p.waves = waves;
   p.lds = (int)want;
-  p.map = CellMap{ (n_blocks + kCellWaves - 1) / kCellWaves, r, (int)want, -ref->border, -ref->border, ref->stride - ref->border,
+  p.map = CellMap{ (n_blocks + waves - 1) / waves, r, (int)want, -ref->border, -ref->border, ref->stride - ref->border,
                    ((ref->height + 7) & ~7) + ref->border };
   return p;
 }
