@@ -78,32 +78,46 @@ __device__ __forceinline__ uint64_t wsum32_split(uint32_t v) {   // exact for an
   return ((uint64_t)wsum32(v >> 16) << 16) + wsum32(v & 0xffffu);
 }
 
+// four adjacent pixels at p (any alignment: the planes' rows start anywhere) as ints
+template <typename T> __device__ __forceinline__ void load_px4(const T *p, int out[4]) {
+  if constexpr (sizeof(T) == 1) {
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(p);
+    out[0] = (int)(w & 0xffu); out[1] = (int)((w >> 8) & 0xffu); out[2] = (int)((w >> 16) & 0xffu); out[3] = (int)(w >> 24);
+  } else {
+    const uint2 w = *reinterpret_cast<const uint2 *>(p);
+    out[0] = (int)(w.x & 0xffffu); out[1] = (int)(w.x >> 16); out[2] = (int)(w.y & 0xffffu); out[3] = (int)(w.y >> 16);
+  }
+}
 // One block's compound error functions evaluated by the 64 lanes pixel by pixel (pixel t of the block -> lane t & 63): get_mvpred_compound_sad
 // (vfp->sdaf / msdf) and the variance of get_mvpred_compound_var[_cost] (svaf / msvf at offset 0).  What does not depend on the candidate --
-// the source block, the other reference's predictor, the blend weights -- stays in registers for blocks of up to 64 x kKeep pixels (a search
-// evaluates ~25 .. ~180 candidates); the candidate's reference pixels are then kKeep independent loads per lane, issued together.  Block
+// the source block, the other reference's predictor, the blend weights -- stays in registers for blocks of up to 512 pixels (a search
+// evaluates ~25 .. ~180 candidates); a lane owns units of four adjacent pixels, so the candidate's reference pixels are one or two 4-pixel loads per
+// lane, issued together.  Block
 // widths are powers of two: row / column of pixel t by shift and mask.  SADs are summed in 32 bits (<= 128 x 128 x 4095).
 template <typename T> struct CompoundEval {
-  static constexpr int kKeep = 8;
+  static constexpr int kUnits = 2;   // 4-pixel units per lane kept in registers: blocks of up to 64 x 2 x 4 = 512 pixels
   const T *sp, *rbase, *pred;
   const uint8_t *mask;
   int sstride, rstride, lw, wm, n_px, shift, invert, bit_depth, lane;
   bool keep;
-  int s_[kKeep], p_[kKeep], m_[kKeep];
+  int s_[kUnits][4], p_[kUnits][4], m_[kUnits][4];
   __device__ __forceinline__ void init(const T *sp_, int sstride_, const T *rbase_, int rstride_, const T *pred_, const uint8_t *mask_, int W, int H, int invert_,
                                        int bit_depth_, int lane_) {
     sp = sp_; rbase = rbase_; pred = pred_; mask = mask_; sstride = sstride_; rstride = rstride_;
     lw = __builtin_ctz((unsigned)W); wm = W - 1; n_px = W * H; invert = invert_; bit_depth = bit_depth_; lane = lane_;
     shift = bit_depth == 10 ? 2 : bit_depth == 12 ? 4 : 0;   // the _bits10 / _bits12 vtable wrappers (encoder_utils.h)
-    keep = n_px <= 64 * kKeep;
+    keep = n_px <= 256 * kUnits;
     if (keep) {
 #pragma unroll
-      for (int k = 0; k < kKeep; ++k) {
-        const int t = k * 64 + lane;
-        const bool on = t < n_px;
-        s_[k] = on ? (int)sp[(int64_t)(t >> lw) * sstride + (t & wm)] : 0;
-        p_[k] = on ? (int)pred[t] : 0;
-        m_[k] = on && mask ? (int)mask[t] : 0;
+      for (int k = 0; k < kUnits; ++k) {
+        const int t = 4 * (k * 64 + lane);   // (widths are multiples of 4: a unit lies in one row)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_[k][i] = p_[k][i] = m_[k][i] = 0;
+        if (t < n_px) {
+          load_px4<T>(sp + (t >> lw) * sstride + (t & wm), s_[k]);
+          load_px4<T>(pred + t, p_[k]);
+          if (mask) load_px4<uint8_t>(mask + t, m_[k]);
+        }
       }
     }
   }
@@ -111,19 +125,27 @@ template <typename T> struct CompoundEval {
     if (!mask) return (p + f + 1) >> 1;
     return invert ? (m * p + (64 - m) * f + 32) >> 6 : (m * f + (64 - m) * p + 32) >> 6;
   }
+  __device__ __forceinline__ void load_ref(const T *rp, int f[kUnits][4]) const {
+#pragma unroll
+    for (int k = 0; k < kUnits; ++k) {
+      const int t = 4 * (k * 64 + lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[k][i] = 0;
+      if (t < n_px) load_px4<T>(rp + (t >> lw) * rstride + (t & wm), f[k]);
+    }
+  }
   __device__ __forceinline__ uint32_t sad(int row, int col) const {
     const T *rp = rbase + (int64_t)row * rstride + col;
     uint32_t acc = 0;
     if (keep) {
-      int f[kKeep];
+      int f[kUnits][4];
+      load_ref(rp, f);
 #pragma unroll
-      for (int k = 0; k < kKeep; ++k) {
-        const int t = k * 64 + lane;
-        f[k] = t < n_px ? (int)rp[(t >> lw) * rstride + (t & wm)] : 0;
-      }
+      for (int k = 0; k < kUnits; ++k)
+        if (k * 256 < n_px) {
 #pragma unroll
-      for (int k = 0; k < kKeep; ++k)
-        if (k * 64 < n_px) acc += (uint32_t)iabsm(blend(f[k], p_[k], m_[k]) - s_[k]);   // (lanes beyond the block: 0 - 0)
+          for (int i = 0; i < 4; ++i) acc += (uint32_t)iabsm(blend(f[k][i], p_[k][i], m_[k][i]) - s_[k][i]);   // (lanes beyond the block: 0 - 0)
+        }
     } else {
       for (int t = lane; t < n_px; t += 64) {
         const int y = t >> lw, x = t & wm;
@@ -139,18 +161,17 @@ template <typename T> struct CompoundEval {
     uint64_t q64;
     if (keep) {
       uint32_t q = 0;   // <= 8 x 4095^2 per lane, <= 16 lanes of that per row
-      int f[kKeep];
+      int f[kUnits][4];
+      load_ref(rp, f);
 #pragma unroll
-      for (int k = 0; k < kKeep; ++k) {
-        const int t = k * 64 + lane;
-        f[k] = t < n_px ? (int)rp[(t >> lw) * rstride + (t & wm)] : 0;
-      }
+      for (int k = 0; k < kUnits; ++k) {
+        if (k * 256 < n_px) {
 #pragma unroll
-      for (int k = 0; k < kKeep; ++k) {
-        if (k * 64 < n_px) {
-          const int d = blend(f[k], p_[k], m_[k]) - s_[k];
-          s += d;
-          q += (uint32_t)(d * d);
+          for (int i = 0; i < 4; ++i) {
+            const int d = blend(f[k][i], p_[k][i], m_[k][i]) - s_[k][i];
+            s += d;
+            q += (uint32_t)(d * d);
+          }
         }
       }
       q64 = wsum32_wide(q);
@@ -284,7 +305,7 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
         if (c < bs.col_min || c > bs.col_max || r < bs.row_min || r > bs.row_max) continue;   // av1_is_fullmv_in_range
         uint32_t sad = sad_at(r, c);
         if (sad < bestsad) {
-          sad += (uint32_t)sad_cost(a, frr, frc, r, c);
+          sad += (uint32_t)sad_cost(a, frr, frc, r, c);   // (looked up only for a site that can win: issuing it for every site beside the pixel reads was SLOWER, 7.7 -> 8.9 ms)
           if (sad < bestsad) {
             bestsad = sad;
             best_site = idx;
@@ -358,31 +379,38 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
   // As CompoundEval: the weighted source and the mask of the block stay in registers for blocks of up to 512 pixels, a candidate is then eight
   // independent reference loads per lane; widths are powers of two (row / column of pixel t by shift and mask).
-  constexpr int kKeep = 8;
+  constexpr int kUnits = 2;   // 4-pixel units per lane
   const int lw = __builtin_ctz((unsigned)W), wm = W - 1;
-  const bool keep = n_px <= 64 * kKeep;
-  int ws_[kKeep], om_[kKeep];
+  const bool keep = n_px <= 256 * kUnits;
+  int ws_[kUnits][4], om_[kUnits][4];
   if (keep) {
 #pragma unroll
-    for (int k = 0; k < kKeep; ++k) {
-      const int t = k * 64 + lane;
-      ws_[k] = t < n_px ? wsrc[t] : 0;
-      om_[k] = t < n_px ? omask[t] : 0;
+    for (int k = 0; k < kUnits; ++k) {
+      const int t = 4 * (k * 64 + lane);
+      int4 a = make_int4(0, 0, 0, 0), b = a;
+      if (t < n_px) { a = *reinterpret_cast<const int4 *>(wsrc + t); b = *reinterpret_cast<const int4 *>(omask + t); }
+      ws_[k][0] = a.x; ws_[k][1] = a.y; ws_[k][2] = a.z; ws_[k][3] = a.w;
+      om_[k][0] = b.x; om_[k][1] = b.y; om_[k][2] = b.z; om_[k][3] = b.w;
     }
   }
   auto osad_at = [&](int row, int col) -> uint32_t {   // vfp->osdf: obmc_sad (sad_av1.c:163-180) + the bit-depth wrapper
     const T *rp = rbase + (int64_t)row * ref.stride + col;
     if (keep) {
       uint32_t acc = 0;
-      int f[kKeep];
+      int f[kUnits][4];
 #pragma unroll
-      for (int k = 0; k < kKeep; ++k) {
-        const int t = k * 64 + lane;
-        f[k] = t < n_px ? (int)rp[(t >> lw) * ref.stride + (t & wm)] : 0;
+      for (int k = 0; k < kUnits; ++k) {
+        const int t = 4 * (k * 64 + lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[k][i] = 0;
+        if (t < n_px) load_px4<T>(rp + (t >> lw) * ref.stride + (t & wm), f[k]);
       }
 #pragma unroll
-      for (int k = 0; k < kKeep; ++k)
-        if (k * 64 < n_px) acc += (uint32_t)((iabsm(ws_[k] - f[k] * om_[k]) + 2048) >> 12);   // ROUND_POWER_OF_TWO(abs(..), 12); beyond the block: 0
+      for (int k = 0; k < kUnits; ++k)
+        if (k * 256 < n_px) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc += (uint32_t)((iabsm(ws_[k][i] - f[k][i] * om_[k][i]) + 2048) >> 12);   // ROUND_POWER_OF_TWO(abs(..), 12); beyond the block: 0
+        }
       return (uint32_t)wsum32_split(acc) >> shift;
     }
     int64_t acc = 0;
