@@ -566,6 +566,55 @@ __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref,
     const int sx = mcol & 7, sy = mrow & 7;
     const int fx0 = kBil[sx][0], fx1 = kBil[sx][1], fy0 = kBil[sy][0], fy1 = kBil[sy][1];
     int64_t s = 0, q = 0;
+    if (form == 2) {
+      // The up-sampled form by units of four adjacent pixels per lane: a row of the horizontal pass is three 4-pixel loads for four outputs
+      // (9 of the 12 pixels are taps), six rows feed the vertical pass -- 4.5 loads per pixel instead of the 36 of the pixel-by-pixel form.
+      // (The right-most load reaches 6 pixels beyond the block, 3 more than the taps: inside the 8 pixels the MV limits keep clear.)
+      int tx[6], ty[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { tx[k] = obmc_up_tap(sa.upsampled, 2 * sx, k); ty[k] = obmc_up_tap(sa.upsampled, 2 * sy, k); }
+      for (int t = 4 * lane; t < n_px; t += 256) {
+        const int y = t >> lw_, x = t & (W - 1);
+        const T *p = rp + (int64_t)y * ref.stride + x;
+        int pv[4];
+        auto hrow4 = [&](int dy, int out[4]) {   // the horizontal pass of outputs x .. x + 3 at row y + dy
+          const T *r = p + (int64_t)dy * ref.stride;
+          if (!sx) { load_px4<T>(r, out); return; }
+          int in[12];
+          load_px4<T>(r - 2, in); load_px4<T>(r + 2, in + 4); load_px4<T>(r + 6, in + 8);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sum += in[i + k] * tx[k];
+            out[i] = min(max((sum + 64) >> 7, 0), pmax);
+          }
+        };
+        if (!sy) {
+          hrow4(0, pv);
+        } else {
+          int acc[4] = { 0, 0, 0, 0 };
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            int h[4];
+            hrow4(k - 2, h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += h[i] * ty[k];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pv[i] = min(max((acc[i] + 64) >> 7, 0), pmax);
+        }
+        const int4 wv = *reinterpret_cast<const int4 *>(wsrc + t), mv4 = *reinterpret_cast<const int4 *>(omask + t);
+        const int w4[4] = { wv.x, wv.y, wv.z, wv.w }, m4[4] = { mv4.x, mv4.y, mv4.z, mv4.w };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int v = w4[i] - pv[i] * m4[i];
+          const int d = v < 0 ? -((-v + 2048) >> 12) : (v + 2048) >> 12;   // ROUND_POWER_OF_TWO_SIGNED(v, 12)
+          s += d;
+          q += (uint32_t)(d * d);
+        }
+      }
+    } else
     for (int t = lane; t < n_px; t += 64) {
       const int y = t >> lw_, x = t & (W - 1);   // (block widths are powers of two)
       const T *p = rp + (int64_t)y * ref.stride + x;
