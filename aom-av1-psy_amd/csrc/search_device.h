@@ -324,6 +324,42 @@ template <typename T> struct CompoundRef {
     const int m = mask[idx];
     return invert ? (m * p + (64 - m) * f + 32) >> 6 : (m * f + (64 - m) * p + 32) >> 6;
   }
+  // N (4 or 8) adjacent pixels of the predictor starting at idx (a multiple of N): one vector load of the predictor and one of the weights
+  // instead of 2 N element loads
+  template <int N> __device__ __forceinline__ void blend_run(int *f, int idx) const {
+    int p[N], m[N];
+    if constexpr (sizeof(T) == 2) {
+      if constexpr (N == 8) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(second + idx);
+        const uint32_t w4[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { p[2 * i] = (int)(w4[i] & 0xffffu); p[2 * i + 1] = (int)(w4[i] >> 16); }
+      } else {
+        const uint2 w = *reinterpret_cast<const uint2 *>(second + idx);
+        p[0] = (int)(w.x & 0xffffu); p[1] = (int)(w.x >> 16); p[2] = (int)(w.y & 0xffffu); p[3] = (int)(w.y >> 16);
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < N / 4; ++h) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(second + idx + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[4 * h + i] = (int)((w >> (8 * i)) & 0xffu);
+      }
+    }
+    if (!mask) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) f[i] = (p[i] + f[i] + 1) >> 1;
+      return;
+    }
+#pragma unroll
+    for (int h = 0; h < N / 4; ++h) {
+      const uint32_t w = *reinterpret_cast<const uint32_t *>(mask + idx + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) m[4 * h + i] = (int)((w >> (8 * i)) & 0xffu);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = invert ? (m[i] * p[i] + (64 - m[i]) * f[i] + 32) >> 6 : (m[i] * f[i] + (64 - m[i]) * p[i] + 32) >> 6;
+  }
 };
 
 template <typename T, int W, int H, bool SUBPEL>
@@ -348,6 +384,7 @@ __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, i
       const L r0 = *reinterpret_cast<const L *>(a0);
       int us = 0;
       uint32_t uq = 0;  // 8 * 4095^2 < 2^32
+      int avv[UE];
       if constexpr (SUBPEL) {
         const L r1 = *reinterpret_cast<const L *>(a0 + astride);
         const int e0 = a0[UE], e1 = a0[astride + UE];
@@ -359,22 +396,19 @@ __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, i
           const int h1 = (__mul24(p10, fx0) + __mul24(p11, fx1) + 64) >> 7;
           int av = (__mul24(h0, fy0) + __mul24(h1, fy1) + 64) >> 7;   // h <= 4095: 24-bit multiplies (v_mul_lo_u32 is quarter rate)
           av &= (sizeof(T) == 1) ? 0xFF : 0xFFFF;
-          if (comp) av = comp->blend(av, row * W + col + i);
-          const int bvp = px_of<T>(bv.v, i);
-          const int d = a_minus_b ? av - bvp : bvp - av;
-          us += d;
-          uq += (uint32_t)__mul24(d, d);   // |d| < 2^12: the 24-bit multiplier is exact and full rate (v_mul_lo_u32 is quarter rate)
+          avv[i] = av;
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < UE; ++i) {
-          int av = px_of<T>(r0.v, i);
-          const int bvp = px_of<T>(bv.v, i);
-          if (comp) av = comp->blend(av, row * W + col + i);
-          const int d = a_minus_b ? av - bvp : bvp - av;
-          us += d;
-          uq += (uint32_t)__mul24(d, d);   // |d| < 2^12: the 24-bit multiplier is exact and full rate (v_mul_lo_u32 is quarter rate)
-        }
+        for (int i = 0; i < UE; ++i) avv[i] = px_of<T>(r0.v, i);
+      }
+      if (comp) comp->template blend_run<UE>(avv, row * W + col);   // (the unit's predictor pixels and weights: one vector load each)
+#pragma unroll
+      for (int i = 0; i < UE; ++i) {
+        const int bvp = px_of<T>(bv.v, i);
+        const int d = a_minus_b ? avv[i] - bvp : bvp - avv[i];
+        us += d;
+        uq += (uint32_t)__mul24(d, d);   // |d| < 2^12: the 24-bit multiplier is exact and full rate (v_mul_lo_u32 is quarter rate)
       }
       sum += us;
       sse += uq;
