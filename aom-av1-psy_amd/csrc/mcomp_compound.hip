@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc += (uint32_t)((iabsm(ws_[k][i] - f[k][i] * om_[k][i]) + 2048) >> 12);   // ROUND_POWER_OF_TWO(abs(..), 12); beyond the block: 0
         }
-      return (uint32_t)wsum32_split(acc) >> shift;
+      return wsum32(acc) >> shift;   // (<= 8 x 2^19 per lane whatever wsrc holds: the 32-bit sum is exact)
     }
     int64_t acc = 0;
     for (int t = lane; t < n_px; t += 64) {
