@@ -612,7 +612,9 @@ typedef struct {
  *                         (index = mv difference in 1/8 pel).  Ignored (may be NULL) for the other cost types.
  * Outputs per block: d_best_mv (row, col), d_best_cost (the returned variance + MV cost),
  * d_cost_list (5 ints: centre, left, bottom, right, top -- calc_int_sad_list, :768-821; may be NULL),
- * d_second_best_mv (row, col; INVALID_MV_ROW_COL -32768 where the reference leaves it invalid; may be NULL). */
+ * d_second_best_mv (row, col; INVALID_MV_ROW_COL -32768 where the reference leaves it invalid; may be NULL).
+ * step_param may equal the table's num_search_steps for the diamond / n-step methods (what av1_single_motion_search passes for search_range < 1,
+ * motion_search_facade.c:234-236): the search then measures its clamped start position only. */
 int aomhip_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw,
                                    int bh, const aomhip_search_params *params, const int32_t *d_mvjcost,
                                    const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
