@@ -88,15 +88,22 @@ int aomhip_tile_column_bounds_balanced(int width, int log2_cols, int sb_size, in
   const int sb_cols = (width + sb_size - 1) / sb_size, n_cols = 1 << log2_cols;
   int size_sb = sb_cols >> log2_cols;
   const int res = sb_cols - (size_sb << log2_cols), inc_index = n_cols - res;
-  int n = 0;
-  for (int s = 0; s < sb_cols && n < n_cols; ++n) {
-    if (n == inc_index) ++size_sb;
+  // The reference's loop runs over tile indices i < MAX_TILE_COLS and records every index, zero-width ones too (fewer superblocks than
+  // columns: the leading `inc_index` tiles have size_sb == 0).  A rank cannot own an empty column, so the output keeps the columns that
+  // have pixels, in order: i walks the reference's tile indices, n counts the columns written.
+  int n = 0, s = 0;
+  for (int i = 0; s < sb_cols && i < n_cols; ++i) {
+    if (i == inc_index) ++size_sb;
     const int w = max_width_sb > 0 && size_sb > max_width_sb ? max_width_sb : size_sb;
-    if (w <= 0) break;   // (fewer superblocks than columns: the leading zero-width columns do not exist in the reference either)
+    if (w <= 0) continue;
     bounds[n][0] = s * sb_size;
     bounds[n][1] = (s + w) * sb_size < width ? (s + w) * sb_size : width;
     s += w;
+    ++n;
   }
+  // max_width_sb clipped the columns short of the frame edge: the reference keeps opening tiles up to MAX_TILE_COLS; with one column per
+  // rank and 2^log2_cols ranks the last column is closed at the frame edge instead (as col_start_sb[cols] = num_sbs closes the last tile)
+  if (n > 0 && s < sb_cols) bounds[n - 1][1] = width;
   for (int i = n; i < n_cols; ++i) bounds[i][0] = bounds[i][1] = 0;
   return n;
 }

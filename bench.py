@@ -221,10 +221,11 @@ class SadModeA:
             ok &= np.array_equal(got4, orc.sad_x4d_batch(sb, rb, self.border, 16, 16, groups, bd=bd, threads=4))
         return bool(ok)
 
-    def cpu_baseline(self, orc, seconds=5.0):
+    def cpu_baseline(self, orc, seconds=None):
         """The same Mode-A ring on the host cores (oracle/aomref_bench.c, kind "port"): static partition of the candidate
         list over the threads, thread-private results, every base frame pair of the ring; scalar C and AVX2-intrinsics
         kernels, one thread and all physical cores (pinned: OMP_PROC_BIND=close OMP_PLACES=cores)."""
+        seconds = float(os.environ.get("AOMHIP_BENCH_CPU_SECONDS", "5.0")) if seconds is None else seconds
         bd = self.cfg["bit_depth"]
         sp = [orc.extend_plane(s, self.border, self.src.stride) for s, _ in self.host_frames]
         rp = [orc.extend_plane(r, self.border, self.ref.stride) for _, r in self.host_frames]
@@ -245,7 +246,8 @@ class SadModeA:
                           "oracle/aomref_bench.c AVX2-intrinsics 16x16 SAD (gcc -O3 -mavx2), static partition over %d pinned "
                           "threads = the cores this process may use (host: %d physical cores, cgroup CPU quota %s); `legs` has the "
                           "scalar-C and 1-thread figures"
-                          % (best["candidates"], len(sp), best["seconds"], phys, host_phys, quota)}
+                          % (best["candidates"], len(sp), best["seconds"], phys, host_phys, quota),
+                "sample_short": "%.1f s of AVX2 16x16 SAD over the ring's Mode-A lists (%d candidates), %d pinned threads" % (best["seconds"], best["candidates"], phys)}
 
     def free(self):
         c = self.ctx
@@ -318,10 +320,11 @@ class TxqGrid:
                                                   False, threads=8)
         return bool(np.array_equal(gq, wq) and np.array_equal(ge, we))
 
-    def cpu_baseline(self, seconds=4.0):
+    def cpu_baseline(self, seconds=None):
         """fwd_txfm2d + quantize_b over every 4x4 / 8x8 / 16x16 / 32x32 block of the residual planes on the host cores
         (oracle/aomref_bench.c): blocks partitioned statically over pinned threads, thread-private outputs; scalar C, and
         scalar transform + AVX2 quantiser; one thread and all physical cores."""
+        seconds = float(os.environ.get("AOMHIP_BENCH_CPU_SECONDS", "4.0")) if seconds is None else seconds
         host_phys, logical, model = self.orc.physical_cores()
         usable, quota = self.orc.usable_cpus()
         phys = max(1, min(host_phys, usable))
@@ -1228,16 +1231,35 @@ def search_bound():
         return None
 
 
+TRAFFIC_SOURCES = {"sb": ("sad_sb.hip",), "sad": ("sad.hip",), "txq": ("xform_quant.hip", "txfm_device.h")}
+
+
+def traffic_kind(name):
+    return "sb" if name.endswith(":sb") else "txq" if name.startswith("txq") else "sad"
+
+
+def kernel_source_sha(kind):
+    """sha256[:16] of the kernel source a traffic figure describes (tools/pmc_traffic*.py store it beside the figure)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in TRAFFIC_SOURCES[kind]:
+        with open(os.path.join(ROOT, "aom-av1-psy_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(name):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json,
-    produced by tools/pmc_traffic.py from separate rocprofv3 --pmc runs); None when not measured."""
+    produced by tools/pmc_traffic*.py from separate rocprofv3 --pmc runs); None when not measured OR when the
+    figure was measured on another version of the kernel source than the one in this tree (a stale counter is not evidence)."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get(name)
-        except Exception:
+    try:
+        t = json.load(open(p))
+        if (t.get("_measured_on") or {}).get(name) != kernel_source_sha(traffic_kind(name)):
             return None
-    return None
+        return t.get(name)
+    except Exception:
+        return None
 
 
 def run_workload(pkg, ctx, dist, dev, rank, world, name, steps, warmup, want_cpu, orc):
@@ -1312,6 +1334,121 @@ def run_workload(pkg, ctx, dist, dev, rank, world, name, steps, warmup, want_cpu
         res["cpu_baseline"] = wl.cpu_baseline(orc)
     wl.free()
     return res
+
+
+def _sig(x, n=5):
+    """Floats to n significant digits, recursively (the printed line is read by a parser with a size limit; the side file keeps full precision)."""
+    if isinstance(x, float):
+        return float("%.*g" % (n, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "compulsory_bytes_per_launch",
+                 "algorithmic_bytes_per_launch", "ceiling_GBs", "frac_of_ceiling", "traffic_over_compulsory", "traffic_measured_on")
+LINE_LIMIT = 6000  # bytes of the final stdout line; the driver's record keeps an 8 KB tail (round 4's 31 KB line was not parsed)
+
+
+def _other_summary(o):
+    """One or two scalars per informational workload for the printed line; the whole entry goes to the side file / stderr."""
+    out = {}
+    for k in ("value", "unit", "ms_per_frame", "ms_per_step", "frames_per_s"):
+        if isinstance(o.get(k), (int, float, str)):
+            out[k] = o[k]
+    for k, v in o.items():  # nested legs that carry a per-frame time (TF q30 / q12, joint search branches, NSTEP / 8-tap ...)
+        if isinstance(v, dict) and isinstance(v.get("ms_per_frame", v.get("ms_per_filtered_frame")), (int, float)):
+            out[k + "_ms"] = v.get("ms_per_frame", v.get("ms_per_filtered_frame"))
+        elif k.endswith("_ms_per_frame") and isinstance(v, (int, float)):
+            out[k] = v
+    for k in o:
+        if k.startswith("parity") and o[k] is not None:
+            out["parity"] = bool(out.get("parity", True)) and bool(o[k])
+    return out
+
+
+def build_lines(args, world, main_res, others, strong):
+    """(full record, printed line).  The printed line carries the contract's keys, the roofline as flat scalars (the three north-star sizes
+    side by side), the cpu baseline, the transform half of the metric and one summary scalar set per informational workload -- and stays
+    under LINE_LIMIT bytes.  Everything else (per-size tables, stage timings, notes, cpu legs) is in the full record."""
+    cfg = WORKLOADS[args.workload]
+    sad_all = [main_res] + [o for o in others if str(o.get("workload", "")).startswith("sad16x16_modeA")]
+    roof_full = dict(main_res["roofline"])
+    roof_full["sizes"] = {r_["workload"]: dict(r_["roofline"], candidates_per_s=r_["value"]) for r_ in sad_all}
+    roof = {k: main_res["roofline"][k] for k in ROOFLINE_KEYS if main_res["roofline"].get(k) is not None}
+    roof.setdefault("traffic", None)
+    for r_ in sad_all[1:]:
+        tag = r_["workload"].replace("sad16x16_modeA_", "")   # 4k_8bit / 4k_10bit / *_range32
+        for k_ in ("frac", "avg_launch_ms", "frac_of_ceiling", "traffic_over_compulsory"):
+            if r_["roofline"].get(k_) is not None:
+                roof["%s_%s" % (k_, tag)] = r_["roofline"][k_]
+        roof["candidates_per_s_%s" % tag] = r_["value"]
+    txqs = [o for o in others if str(o.get("workload", "")).startswith("fwd_txfm2d+quantize_b")]
+    rest = [o for o in others if o not in txqs and o not in sad_all]
+    cpu = main_res.get("cpu_baseline")
+    head = {
+        "metric": "SAD-candidates/s", "value": main_res["value"], "unit": "candidates/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8" if cfg["bit_depth"] == 8 else "u16", "data": "synthetic",
+        "config": {"workload": args.workload, "frame": "%dx%d" % (cfg["width"], cfg["height"]),
+                   "bit_depth": cfg["bit_depth"], "block": "16x16",
+                   "mode": "A: 1 sad16x16 @mv(0,0) + 1 sad16x16x4d (uniform in [-%d,%d]^2) per block" % (cfg.get("search_range", 64), cfg.get("search_range", 64)),
+                   "ring_frame_pairs_per_gpu": FRAMES_OVERRIDE or cfg["frames"], "candidates_per_step": main_res["candidates_per_step"],
+                   "partition": ("balanced tile columns (encoder.c:247-275)" if TILE_COLUMNS == "balanced" else "uniform tile columns (tile_common.c:76-97)") +
+                                ", one per GPU; no data-path collective",
+                   "clock_ramp_s": float(os.environ.get("AOMHIP_BENCH_RAMP_S", "0.25"))},
+    }
+    full = dict(head, roofline=roof_full, cpu_baseline=cpu,
+                txq={t["workload"]: t for t in txqs} or None, strong_scaling_search=strong,
+                parity_frame0_and_last_slot=main_res["parity_frame0"], kernels=main_res["kernels"], others=others)
+    line = dict(head, roofline=roof,
+                cpu_baseline=None if cpu is None else dict({k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "cpu_model")},
+                                                           sample=cpu.get("sample_short", "")),
+                # the other half of BASELINE.json's metric: fwd_txfm+quant blocks/s at 1080p (8-bit) and 4K (10-bit)
+                txq={t["workload"]: {"value": t["value"], "unit": "blocks/s",
+                                     "roofline": {k: t["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms")},
+                                     "cpu_baseline": {k: (t.get("cpu_baseline") or {}).get(k) for k in ("value", "cores", "kind")},
+                                     "per_size_frac": {k: v["frac"] for k, v in t["per_size"].items()}} for t in txqs} or None,
+                strong_scaling_search=strong,
+                parity_frame0_and_last_slot=main_res["parity_frame0"],
+                parity_all=all(bool(v) for o in [main_res] + others for k, v in o.items() if k.startswith("parity") and v is not None),
+                others={str(o.get("workload")): _other_summary(o) for o in rest} or None)
+    line = _sig(line)
+    # never let the line outgrow the record that reads it: shed the least important keys first (they stay in the full record)
+    for drop in ("others", "strong_scaling_search.tile_columns_px_balanced", "strong_scaling_search.tile_columns_px_uniform", "txq"):
+        if len(json.dumps(line, separators=(",", ":"))) <= LINE_LIMIT:
+            break
+        if "." in drop:
+            a, b = drop.split(".")
+            if isinstance(line.get(a), dict):
+                line[a].pop(b, None)
+        else:
+            line[drop] = None
+    return full, line
+
+
+def emit_lines(full, line):
+    """Full record -> bench_full.json (gpurun_out/ when it exists, else beside this script; AOMHIP_BENCH_FULL overrides) and, one JSON object
+    per workload, to stderr; then the ONE stdout line."""
+    path = os.environ.get("AOMHIP_BENCH_FULL")
+    if not path:
+        d = os.path.join(ROOT, "gpurun_out")
+        path = os.path.join(d if os.path.isdir(d) else ROOT, "bench_full.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f)
+        line["full_record"] = os.path.relpath(path, ROOT)
+    except OSError as e:
+        print("bench.py: could not write %s (%s)" % (path, e), file=sys.stderr)
+    for o in full.get("others") or []:
+        print(json.dumps(_sig(o, 6)), file=sys.stderr)
+    sys.stderr.flush()
+    out = json.dumps(line, separators=(",", ":"))
+    assert len(out) <= LINE_LIMIT + 200, "bench line grew to %d bytes" % len(out)
+    print(out, flush=True)
 
 
 def spawn_ranks(n):
@@ -1538,47 +1675,8 @@ def main():
     ctx.close()
 
     if rank == 0:
-        cfg = WORKLOADS[args.workload]
-        sad_all = [main_res] + [o for o in others if str(o.get("workload", "")).startswith("sad16x16_modeA")]
-        # the north-star sizes INSIDE the roofline object (4K 8-bit: the size the 0.70 target is quoted on; 4K 10-bit: the fork's default depth)
-        main_res["roofline"]["sizes"] = {
-            r_["workload"]: {"frac": r_["roofline"]["frac"], "avg_launch_ms": r_["roofline"]["avg_launch_ms"],
-                             "achieved": r_["roofline"]["achieved"], "traffic": r_["roofline"].get("traffic"),
-                             "traffic_over_compulsory": r_["roofline"].get("traffic_over_compulsory"),
-                             "candidates_per_s": r_["value"], "bound": r_["roofline"]["bound"]} for r_ in sad_all}
-        # ... and flat, as scalar keys of the roofline object (a record that keeps scalars only keeps these)
-        for r_ in sad_all:
-            tag = r_["workload"].replace("sad16x16_modeA_", "")   # 1080p_8bit / 4k_8bit / 4k_10bit
-            for k_ in ("frac", "avg_launch_ms", "achieved", "ceiling_GBs", "frac_of_ceiling", "traffic_over_compulsory"):
-                if r_["roofline"].get(k_) is not None:
-                    main_res["roofline"]["%s_%s" % (k_, tag)] = r_["roofline"][k_]
-            main_res["roofline"]["candidates_per_s_%s" % tag] = r_["value"]
-        txqs = [o for o in others if str(o.get("workload", "")).startswith("fwd_txfm2d+quantize_b")]
-        line = {
-            "metric": "SAD-candidates/s", "value": main_res["value"], "unit": "candidates/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8" if cfg["bit_depth"] == 8 else "u16", "data": "synthetic",
-            "config": {"workload": args.workload, "frame": "%dx%d" % (cfg["width"], cfg["height"]),
-                       "bit_depth": cfg["bit_depth"], "block": "16x16",
-                       "mode": "A: 1 sad16x16 @mv(0,0) + 1 sad16x16x4d (uniform in [-%d,%d]^2) per block" % (cfg.get("search_range", 64), cfg.get("search_range", 64)),
-                       "ring_frame_pairs_per_gpu": FRAMES_OVERRIDE or cfg["frames"], "candidates_per_step": main_res["candidates_per_step"],
-                       "partition": ("balanced tile columns (encoder.c:247-275)" if TILE_COLUMNS == "balanced" else "uniform tile columns (tile_common.c:76-97)") +
-                                    ", one per GPU; no data-path collective",
-                       "clock_ramp_s": float(os.environ.get("AOMHIP_BENCH_RAMP_S", "0.25"))},
-            "roofline": main_res["roofline"],
-            "cpu_baseline": main_res.get("cpu_baseline"),
-            # the other half of BASELINE.json's metric: fwd_txfm+quant blocks/s at 1080p (8-bit) and 4K (10-bit), each with its own
-            # roofline / cpu_baseline (full entries under `others`)
-            "txq": {t["workload"]: {"value": t["value"], "unit": "blocks/s", "roofline": t["roofline"],
-                                    "cpu_baseline": {k: (t.get("cpu_baseline") or {}).get(k) for k in ("value", "unit", "cores", "kind")},
-                                    "per_size_frac": {k: v["frac"] for k, v in t["per_size"].items()}} for t in txqs} or None,
-            "strong_scaling_search": strong,
-            "parity_frame0_and_last_slot": main_res["parity_frame0"],
-            "kernels": main_res["kernels"],
-            "others": others,
-        }
-        print(json.dumps(line))
+        full, line = build_lines(args, world, main_res, others, strong)
+        emit_lines(full, line)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1158,7 +1158,10 @@ int aomhip_tile_column_bounds(int width, int n_cols, int sb_size, int (*bounds)[
  * tile_widths[0] < 0): floor(sb_cols / 2^log2_cols) superblocks per column, the last (sb_cols mod 2^log2_cols) columns one wider -- e.g. 4K
  * on 8 ranks 7,7,7,7,8,8,8,8 superblocks instead of the uniform rule's 8 x 7 + 4: the widest column (what the slowest rank gets) is the
  * same, no rank is short-changed.  _widths = an explicit list of widths in superblocks, walked cyclically, each clipped to max_width_sb (0:
- * no clip), at most n_cols columns.  Both return the number of columns that exist and zero the rest. */
+ * no clip), at most n_cols columns.  Both return the number of columns that exist and zero the rest.  _balanced with fewer superblocks than
+ * columns: the reference's leading zero-width tiles are skipped (352 px on 8 ranks: 6 columns of 64, 64, 64, 64, 64, 32 px, two idle ranks);
+ * when max_width_sb clips the columns short of the frame, the last of the 2^log2_cols columns runs to the frame edge (the reference would
+ * open further tiles; there is one column per rank here). */
 int aomhip_tile_column_bounds_balanced(int width, int log2_cols, int sb_size, int max_width_sb, int (*bounds)[2]);
 int aomhip_tile_column_bounds_widths(int width, int sb_size, const int *tile_widths_sb, int n_widths, int max_width_sb, int n_cols, int (*bounds)[2]);
 

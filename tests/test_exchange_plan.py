@@ -7,7 +7,7 @@ import pytest
 
 import aom_av1_psy_amd as pkg
 
-capi = pkg.capi
+capi, partition = pkg.capi, pkg.partition
 
 
 def ref_bounds(width, n_cols, sb=64):
@@ -123,7 +123,7 @@ def ref_balanced(width, log2_cols, sb=64, max_width_sb=1 << 30):
     return [(a * sb, min(b_ * sb, width)) for a, b_ in zip(starts[:-1], starts[1:])]
 
 
-@pytest.mark.parametrize("width,n", [(3840, 8), (3840, 4), (1920, 8), (1920, 4), (1920, 2), (4096, 8), (1280, 8), (3840, 1)])
+@pytest.mark.parametrize("width,n", [(3840, 8), (3840, 4), (1920, 8), (1920, 4), (1920, 2), (4096, 8), (1280, 8), (3840, 1), (352, 8), (64, 4), (100, 8), (65, 2)])
 def test_balanced_tile_columns_follow_auto_tile_size_balancing(width, n):
     b, cols = capi.tile_column_bounds_balanced(width, n)
     want = ref_balanced(width, n.bit_length() - 1)
@@ -134,6 +134,24 @@ def test_balanced_tile_columns_follow_auto_tile_size_balancing(width, n):
     uni, ucols = capi.tile_column_bounds(width, n)
     assert max(widths) <= max(int(x1 - x0) for x0, x1 in uni[:ucols])          # never a wider widest column than the uniform rule
     assert max(widths) - min(widths) <= 64                                      # within one superblock of each other
+
+
+def test_balanced_with_fewer_superblocks_than_ranks_keeps_the_columns_that_have_pixels():
+    # 352 px = 6 superblocks on 8 ranks: the reference's tiles 0-1 are zero-width (size_sb 0 until inc_index = 2); six ranks get a column
+    b, cols = capi.tile_column_bounds_balanced(352, 8)
+    assert cols == 6 and [tuple(x) for x in b] == [(0, 64), (64, 128), (128, 192), (192, 256), (256, 320), (320, 352), (0, 0), (0, 0)]
+    b, cols = capi.tile_column_bounds_balanced(64, 4)
+    assert cols == 1 and [tuple(x) for x in b] == [(0, 64), (0, 0), (0, 0), (0, 0)]
+    assert partition.column_of_rank(352, 8, 5, mode="balanced") == (320, 352) and partition.column_of_rank(352, 8, 6, mode="balanced") == (0, 0)
+
+
+@pytest.mark.parametrize("width,n,max_sb", [(8192, 1, 64), (8192, 2, 32), (3840, 4, 10), (3840, 8, 7), (3840, 8, 8)])
+def test_balanced_with_clipped_widths_covers_the_frame(width, n, max_sb):
+    b, cols = capi.tile_column_bounds_balanced(width, n, max_width_sb=max_sb)
+    want = ref_balanced(width, n.bit_length() - 1, max_width_sb=max_sb)[:n]     # the reference's first 2^k tiles ...
+    want[-1] = (want[-1][0], width) if len(want) == n else want[-1]             # ... the last one closed at the frame edge
+    assert cols == len(want) and [tuple(x) for x in b[:cols]] == want
+    assert b[0, 0] == 0 and b[cols - 1, 1] == width and all(b[i, 1] == b[i + 1, 0] for i in range(cols - 1))
 
 
 def test_4k_on_8_ranks_balanced_is_four_448_and_four_512_columns():

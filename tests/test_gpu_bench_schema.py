@@ -41,3 +41,36 @@ def test_forced_one_rank_run_emits_the_multi_gpu_schema(tile_columns):
     assert s["tile_columns_px"] == [3840] and s["tile_columns_px_uniform"] == [3840] and s["tile_columns_px_balanced"] == [3840]
     assert s["single_gpu_same_box"]["value"] > 0 and s["speedup_over_single_gpu"] > 0
     assert s["parity_sample_slot0"] in (True, None)
+
+
+def test_default_single_gpu_line_is_small_enough_for_the_driver_record(tmp_path):
+    """The driver keeps an 8 KB tail of the output: round 4's 31 KB default line was not parsed.  The default N = 1 run must end in ONE JSON
+    line under 8000 bytes that still carries the headline, the roofline (flat scalars) and the cpu baseline; everything else is in the side file."""
+    full = tmp_path / "bench_full.json"
+    env = dict(os.environ, AOMHIP_BENCH_RAMP_S="0.02", AOMHIP_BENCH_FULL=str(full), AOMHIP_BENCH_CPU_SECONDS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out_lines = p.stdout.splitlines()
+    assert len([ln for ln in out_lines if ln.startswith("{")]) == 1, "exactly ONE JSON line on stdout"
+    last = out_lines[-1]
+    assert len(last) < 8000, len(last)
+    d = json.loads(last)
+    assert d["metric"] == "SAD-candidates/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0
+    assert d["config"]["workload"] == "sad16x16_modeA_1080p_8bit"
+    r = d["roofline"]
+    assert all(not isinstance(v, (dict, list)) for v in r.values()), "roofline: flat scalars only"
+    assert 0 < r["frac"] < 1 and r["peak"] == 8000.0 and r["bound"] and r["achieved"] > 0 and "traffic" in r
+    assert 0 < r["frac_4k_8bit"] < 1 and 0 < r["frac_4k_10bit"] < 1 and r["avg_launch_ms_4k_8bit"] > 0
+    c = d["cpu_baseline"]
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] in ("port", "reference") and c["sample"]
+    assert set(d["txq"]) == {"fwd_txfm2d+quantize_b_1080p_8bit", "fwd_txfm2d+quantize_b_4k_10bit"}
+    for t in d["txq"].values():
+        assert t["value"] > 0 and 0 < t["roofline"]["frac"] < 1 and set(t["per_size_frac"]) == {"4x4", "8x8", "16x16", "32x32"}
+    assert d["parity_all"] is True and d["parity_frame0_and_last_slot"] is True
+    assert "encode_inner_loop_4k_10bit" in d["others"]
+    # the full record: every informational workload entire, the per-size roofline table, the cpu legs
+    f = json.loads(full.read_text())
+    assert len(f["others"]) >= 15 and "sizes" in f["roofline"] and "legs" in f["cpu_baseline"]
+    # ... and each of them as one JSON line on stderr
+    assert sum(1 for ln in p.stderr.splitlines() if ln.startswith("{")) == len(f["others"])

@@ -11,6 +11,9 @@ factor 1.6 -- which is why the read factor is not taken from it.)  Per-launch av
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
+sys.path.insert(0, os.getcwd())
+import bench  # kernel_source_sha (no GPU work at import)
+
 
 def main(tag, workload="txq_1080p_8bit"):
     prefix = "txq_" if workload == "txq_1080p_8bit" else workload + "_"     # profiles/traffic.json keys, as bench.py's load_traffic() reads them
@@ -56,6 +59,7 @@ def main(tag, workload="txq_1080p_8bit"):
         wr = mean[k].get("WRITE_SIZE", 0.0) * 1024.0 * fw
         per[k] = {"read": rd, "write": wr, "total": rd + wr, "read_over_known": rd / residual_ring}
         t[k] = rd + wr
+        t.setdefault("_measured_on", {})[k] = bench.kernel_source_sha("txq")
     out["hbm_bytes_per_launch"] = per
     json.dump(t, open(tj, "w"), indent=1, sort_keys=True)
     json.dump(out, open(os.path.join("profiles", "%s_pmc_%s.json" % (tag, "txq" if workload == "txq_1080p_8bit" else workload)), "w"), indent=1, sort_keys=True)
