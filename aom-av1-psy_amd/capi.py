@@ -200,6 +200,8 @@ _protos = {
     "aomhip_compound_subpel_tree_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_obmc_subpel_tree_batch": (C.c_int, [_vp, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_strip_read_probe": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_int64)]),
+    "aomhip_valu_issue_probe": (C.c_int, [_vp, _i, _i, _i, _vp]),
+    "aomhip_valu_issue_probe_name": (C.c_char_p, [_i]),
     "aomhip_fullpel_diamond_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_subpel_bilinear_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_mesh_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, C.POINTER(C.c_int), _i, _vp, _i, _vp, _vp]),
@@ -600,6 +602,14 @@ class Context:
         check(lib.aomhip_strip_read_probe(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, x0, x1, sb_w, sb_h, rng, C.byref(b)), "aomhip_strip_read_probe")
         return b.value
 
+    def valu_issue_probe(self, op_class, waves_per_simd=8, iters=3000):
+        """-> dict (measurement support: the issue rate of one VALU opcode class on this box, aomhip.h)."""
+        r = ValuProbeResult()
+        check(lib.aomhip_valu_issue_probe(self.h, op_class, waves_per_simd, iters, C.byref(r)), "aomhip_valu_issue_probe")
+        return {"op": valu_issue_probe_names()[op_class], "wave_insts_per_s_per_simd": r.wave_insts_per_s_per_simd, "launch_ms": r.launch_ms,
+                "memtime_ticks_per_wave_inst": r.memtime_ticks_per_wave_inst, "memtime_hz": r.memtime_hz, "waves_per_simd": r.waves_per_simd,
+                "compute_units": r.compute_units}
+
     def fullpel_diamond_batch(self, src, ref, frame, bw, bh, clamped, step_param, cost_type, d_blocks, n, d_mv, d_cost):
         check(lib.aomhip_fullpel_diamond_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, clamped, step_param,
                                                cost_type, d_blocks, n, d_mv, d_cost), "aomhip_fullpel_diamond_batch")
@@ -705,6 +715,21 @@ def comm_unique_id():
     uid = np.zeros(128, np.uint8)
     check(lib.aomhip_comm_unique_id(uid.ctypes.data), "aomhip_comm_unique_id")
     return uid
+
+
+class ValuProbeResult(C.Structure):
+    _fields_ = [("wave_insts_per_s_per_simd", C.c_double), ("launch_ms", C.c_double), ("memtime_ticks_per_wave_inst", C.c_double),
+                ("memtime_hz", C.c_double), ("waves_per_simd", C.c_int32), ("compute_units", C.c_int32)]
+
+
+def valu_issue_probe_names():
+    out, i = [], 0
+    while True:
+        n = lib.aomhip_valu_issue_probe_name(i)
+        if n is None:
+            return out
+        out.append(n.decode())
+        i += 1
 
 
 def tile_column_bounds(width, n_cols, sb_size=64):

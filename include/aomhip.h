@@ -222,6 +222,21 @@ int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_
 int aomhip_strip_read_probe(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame, int n_frames,
                             int x0, int x1, int sb_w, int sb_h, int range, int64_t *bytes_requested);
 
+/* Measurement support (the denominator of bench.py's `valu_frac` figures): the issue rate of ONE VALU opcode class on this box, in this run.
+ * waves_per_simd (1 / 2 / 4 / 8) wavefronts on every SIMD of the chip, each with 8 independent dependency chains of the instruction,
+ * `iters` loop trips of 128 instructions (choose iters so that the launch lasts milliseconds: the first ~0.3 ms after idle run at a lower
+ * clock; a shorter untimed launch of the same kernel precedes the timed one).  aomhip_valu_issue_probe_name(op_class) names the classes
+ * 0 .. n-1 (NULL beyond the last).  Computes nothing.
+ *   wave_insts_per_s_per_simd   = wavefront-instructions retired per second per SIMD (HIP-event time of the launch)
+ *   memtime_ticks_per_wave_inst = s_memtime ticks between two instructions of the SIMD (median over the wavefronts)
+ *   memtime_hz                  = s_memtime ticks per second, measured against s_memrealtime (100 MHz) inside the kernel */
+typedef struct {
+  double wave_insts_per_s_per_simd, launch_ms, memtime_ticks_per_wave_inst, memtime_hz;
+  int32_t waves_per_simd, compute_units;
+} aomhip_valu_probe_result;
+int aomhip_valu_issue_probe(aomhip_ctx *ctx, int op_class, int waves_per_simd, int iters, aomhip_valu_probe_result *out);
+const char *aomhip_valu_issue_probe_name(int op_class);
+
 /* ------------------------------------------------------------------ batched variance / sub-pixel variance */
 
 /* One evaluation: source block at (sx, sy), reference block at (rx, ry) [+ (xoff, yoff)/8 pel for the
