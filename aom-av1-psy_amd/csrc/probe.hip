@@ -129,56 +129,107 @@ extern "C" int aomhip_strip_read_probe(aomhip_ctx *ctx, const aomhip_planes *src
 namespace aomhip {
 namespace {
 
+// X(enum tag, printed name, instructions per chain step, 64-bit chain?, asm)   -- [c] = the chain register, [a] / [b] = loop-invariant VGPRs,
+// [t] = a 32-bit scratch VGPR of the 64-bit forms
+#define AOMHIP_VALU_OPS(X)                                                                                              \
+  X(ADD_U32, "v_add_u32", 1, 0, "v_add_u32 %[c], %[c], %[a]")                                                                  \
+  X(ADD_U32_E64, "v_add_u32_e64", 1, 0, "v_add_u32_e64 %[c], %[c], %[a]")                                                  \
+  X(SUB_U32, "v_sub_u32", 1, 0, "v_sub_u32 %[c], %[c], %[a]")                                                                  \
+  X(MOV_B32, "v_mov_b32", 1, 0, "v_mov_b32 %[c], %[a]")                                                                      \
+  X(AND_B32, "v_and_b32", 1, 0, "v_and_b32 %[c], %[c], %[a]")                                                                  \
+  X(OR_B32, "v_or_b32", 1, 0, "v_or_b32 %[c], %[c], %[a]")                                                                     \
+  X(XOR_B32, "v_xor_b32", 1, 0, "v_xor_b32 %[c], %[c], %[a]")                                                                  \
+  X(LSHLREV_B32, "v_lshlrev_b32", 1, 0, "v_lshlrev_b32 %[c], 1, %[c]")                                                       \
+  X(LSHRREV_B32, "v_lshrrev_b32", 1, 0, "v_lshrrev_b32 %[c], 1, %[c]")                                                       \
+  X(ASHRREV_I32, "v_ashrrev_i32", 1, 0, "v_ashrrev_i32 %[c], 1, %[c]")                                                       \
+  X(MAX_I32, "v_max_i32", 1, 0, "v_max_i32 %[c], %[c], %[a]")                                                                  \
+  X(MIN_I32, "v_min_i32", 1, 0, "v_min_i32 %[c], %[c], %[a]")                                                                  \
+  X(MUL_U32_U24, "v_mul_u32_u24", 1, 0, "v_mul_u32_u24 %[c], %[c], %[a]")                                                      \
+  X(MUL_I32_I24, "v_mul_i32_i24", 1, 0, "v_mul_i32_i24 %[c], %[c], %[a]")                                                      \
+  X(MAD_I32_I24, "v_mad_i32_i24", 1, 0, "v_mad_i32_i24 %[c], %[c], %[a], %[b]")                                                  \
+  X(MUL_LO_U32, "v_mul_lo_u32", 1, 0, "v_mul_lo_u32 %[c], %[c], %[a]")                                                         \
+  X(MUL_HI_U32, "v_mul_hi_u32", 1, 0, "v_mul_hi_u32 %[c], %[c], %[a]")                                                         \
+  X(LSHL_ADD_U32, "v_lshl_add_u32", 1, 0, "v_lshl_add_u32 %[c], %[c], 1, %[a]")                                                \
+  X(ADD3_U32, "v_add3_u32", 1, 0, "v_add3_u32 %[c], %[c], %[a], %[b]")                                                           \
+  X(BFE_U32, "v_bfe_u32", 1, 0, "v_bfe_u32 %[c], %[c], %[a], 16")                                                              \
+  X(BFE_I32, "v_bfe_i32", 1, 0, "v_bfe_i32 %[c], %[c], %[a], 16")                                                              \
+  X(MED3_I32, "v_med3_i32", 1, 0, "v_med3_i32 %[c], %[c], %[a], %[b]")                                                           \
+  X(ALIGNBIT, "v_alignbit_b32", 1, 0, "v_alignbit_b32 %[c], %[c], %[a], %[b]")                                                   \
+  X(ALIGNBYTE, "v_alignbyte_b32", 1, 0, "v_alignbyte_b32 %[c], %[c], %[a], %[b]")                                                \
+  X(PERM_B32, "v_perm_b32", 1, 0, "v_perm_b32 %[c], %[c], %[a], %[b]")                                                           \
+  X(CMP_CNDMASK, "v_cmp_gt_i32+v_cndmask_b32", 2, 0, "v_cmp_gt_i32 vcc, %[c], %[a]\n\tv_cndmask_b32 %[c], %[c], %[b], vcc")        \
+  X(SAD_U8, "v_sad_u8", 1, 0, "v_sad_u8 %[c], %[a], %[b], %[c]")                                                                 \
+  X(SAD_U16, "v_sad_u16", 1, 0, "v_sad_u16 %[c], %[a], %[b], %[c]")                                                              \
+  X(ADD_U16, "v_add_u16", 1, 0, "v_add_u16 %[c], %[c], %[a]")                                                                  \
+  X(PK_ADD_I16, "v_pk_add_i16", 1, 0, "v_pk_add_i16 %[c], %[c], %[a]")                                                         \
+  X(PK_SUB_I16, "v_pk_sub_i16", 1, 0, "v_pk_sub_i16 %[c], %[c], %[a]")                                                         \
+  X(PK_MAD_I16, "v_pk_mad_i16", 1, 0, "v_pk_mad_i16 %[c], %[c], %[a], %[b]")                                                     \
+  X(PK_MAX_I16, "v_pk_max_i16", 1, 0, "v_pk_max_i16 %[c], %[c], %[a]")                                                         \
+  X(DOT2_I32_I16, "v_dot2_i32_i16", 1, 0, "v_dot2_i32_i16 %[c], %[a], %[b], %[c]")                                               \
+  X(DOT2C_I32_I16, "v_dot2c_i32_i16", 1, 0, "v_dot2c_i32_i16 %[c], %[a], %[b]")                                                \
+  X(DOT2_U32_U16, "v_dot2_u32_u16", 1, 0, "v_dot2_u32_u16 %[c], %[a], %[b], %[c]")                                               \
+  X(ADD_DPP_ROW_SHR, "v_add_u32_dpp(row_shr:1)", 1, 0, "v_add_u32_dpp %[c], %[c], %[a] row_shr:1 row_mask:0xf bank_mask:0xf")  \
+  X(MOV_DPP_ROW_MIRROR, "v_mov_b32_dpp(row_mirror)", 1, 0, "v_mov_b32_dpp %[c], %[c] row_mirror row_mask:0xf bank_mask:0xf") \
+  X(READLANE, "v_readlane_b32", 1, 0, "v_readlane_b32 s20, %[c], 3")                                                       \
+  X(ADD_F32, "v_add_f32", 1, 0, "v_add_f32 %[c], %[c], %[a]")                                                                  \
+  X(MUL_F32, "v_mul_f32", 1, 0, "v_mul_f32 %[c], %[c], %[a]")                                                                  \
+  X(FMA_F32, "v_fma_f32", 1, 0, "v_fma_f32 %[c], %[c], %[a], %[b]")                                                              \
+  X(EXP_F32, "v_exp_f32", 1, 0, "v_exp_f32 %[c], %[c]")                                                                      \
+  X(CVT_F32_I32, "v_cvt_f32_i32", 1, 0, "v_cvt_f32_i32 %[c], %[c]")                                                          \
+  X(LSHL_ADD_U64, "v_lshl_add_u64", 1, 1, "v_lshl_add_u64 %[c], %[c], 1, %[a]")                                                \
+  X(LSHRREV_B64, "v_lshrrev_b64", 1, 1, "v_lshrrev_b64 %[c], 1, %[c]")                                                       \
+  X(MOV_B64, "v_mov_b64", 1, 1, "v_mov_b64 %[c], %[a]")                                                                      \
+  X(MAD_U64_U32, "v_mad_u64_u32", 1, 1, "v_mad_u64_u32 %[c], vcc, %[t], %[t], %[c]")                                             \
+  X(MAD_I64_I32, "v_mad_i64_i32", 1, 1, "v_mad_i64_i32 %[c], vcc, %[t], %[t], %[c]")                                             \
+  X(FMA_F64, "v_fma_f64", 1, 1, "v_fma_f64 %[c], %[c], %[a], %[b]")                                                              \
+  X(MUL_F64, "v_mul_f64", 1, 1, "v_mul_f64 %[c], %[c], %[a]")                                                                  \
+  X(ADD_F64, "v_add_f64", 1, 1, "v_add_f64 %[c], %[c], %[a]")                                                                  \
+  X(RCP_F64, "v_rcp_f64", 1, 1, "v_rcp_f64 %[c], %[c]")                                                                      \
+  X(CVT_F64_I32, "v_cvt_f64_i32", 1, 1, "v_cvt_f64_i32 %[c], %[t]")                                                          \
+  X(EXP_F32_VIA_F64, "v_cvt_f32_f64+v_exp_f32+v_cvt_f64_f32", 3, 1, "v_cvt_f32_f64 %[t], %[c]\n\tv_exp_f32 %[t], %[t]\n\tv_cvt_f64_f32 %[c], %[t]")
+
 enum ValuOp {
-  OP_ADD_U32 = 0, OP_MAD_I32_I24, OP_MUL_U32_U24, OP_MUL_LO_U32, OP_MUL_HI_U32, OP_MAD_U64_U32, OP_LSHL_ADD_U32, OP_ADD3_U32, OP_BFE_I32,
-  OP_MAX_I32, OP_MED3_I32, OP_CNDMASK, OP_SAD_U8, OP_SAD_U16, OP_ALIGNBYTE, OP_PERM_B32, OP_PK_ADD_I16, OP_PK_MAD_I16, OP_PK_MAX_I16,
-  OP_DOT2_I32_I16, OP_DOT2_U32_U16, OP_ADD_DPP_ROW_SHR, OP_MOV_DPP_ROW_MIRROR, OP_ADD_F32, OP_FMA_F32, OP_EXP_F32, OP_FMA_F64, OP_MUL_F64,
-  OP_ADD_F64, OP_RCP_F64, OP_CVT_F64_I32, OP_COUNT
+#define X(tag, name, n, wide, text) OP_##tag,
+  AOMHIP_VALU_OPS(X)
+#undef X
+  OP_COUNT
 };
 const char *const kValuOpNames[OP_COUNT] = {
-  "v_add_u32", "v_mad_i32_i24", "v_mul_u32_u24", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_lshl_add_u32", "v_add3_u32", "v_bfe_i32",
-  "v_max_i32", "v_med3_i32", "v_cndmask_b32", "v_sad_u8", "v_sad_u16", "v_alignbyte_b32", "v_perm_b32", "v_pk_add_i16", "v_pk_mad_i16", "v_pk_max_i16",
-  "v_dot2_i32_i16", "v_dot2_u32_u16", "v_add_u32_dpp(row_shr:1)", "v_mov_b32_dpp(row_mirror)", "v_add_f32", "v_fma_f32", "v_exp_f32", "v_fma_f64", "v_mul_f64",
-  "v_add_f64", "v_rcp_f64", "v_cvt_f64_i32"
+#define X(tag, name, n, wide, text) name,
+  AOMHIP_VALU_OPS(X)
+#undef X
+};
+const int kValuOpInsts[OP_COUNT] = {
+#define X(tag, name, n, wide, text) n,
+  AOMHIP_VALU_OPS(X)
+#undef X
+};
+constexpr bool kValuOpWide[OP_COUNT] = {
+#define X(tag, name, n, wide, text) wide != 0,
+  AOMHIP_VALU_OPS(X)
+#undef X
 };
 
-// one instruction on chain register c (32-bit chains) / d (64-bit chains); a, b: loop-invariant VGPR operands
-template <int OP> __device__ __forceinline__ void one32(uint32_t &c, uint32_t a, uint32_t b) {
-  if constexpr (OP == OP_ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(c) : "v"(a));
-  else if constexpr (OP == OP_MAD_I32_I24) asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
-  else if constexpr (OP == OP_MUL_U32_U24) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(c) : "v"(a));
-  else if constexpr (OP == OP_MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(c) : "v"(a));
-  else if constexpr (OP == OP_MUL_HI_U32) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(c) : "v"(a));
-  else if constexpr (OP == OP_LSHL_ADD_U32) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(c) : "v"(a));
-  else if constexpr (OP == OP_ADD3_U32) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
-  else if constexpr (OP == OP_BFE_I32) asm volatile("v_bfe_i32 %0, %0, %1, 16" : "+v"(c) : "v"(a));
-  else if constexpr (OP == OP_MAX_I32) asm volatile("v_max_i32 %0, %0, %1" : "+v"(c) : "v"(a));
-  else if constexpr (OP == OP_MED3_I32) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
-  else if constexpr (OP == OP_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(c) : "v"(a));
-  else if constexpr (OP == OP_SAD_U8) asm volatile("v_sad_u8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-  else if constexpr (OP == OP_SAD_U16) asm volatile("v_sad_u16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-  else if constexpr (OP == OP_ALIGNBYTE) asm volatile("v_alignbyte_b32 %0, %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
-  else if constexpr (OP == OP_PERM_B32) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
-  else if constexpr (OP == OP_PK_ADD_I16) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(c) : "v"(a));
-  else if constexpr (OP == OP_PK_MAD_I16) asm volatile("v_pk_mad_i16 %0, %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
-  else if constexpr (OP == OP_PK_MAX_I16) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(c) : "v"(a));
-  else if constexpr (OP == OP_DOT2_I32_I16) asm volatile("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-  else if constexpr (OP == OP_DOT2_U32_U16) asm volatile("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-  else if constexpr (OP == OP_ADD_DPP_ROW_SHR) asm volatile("v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(c) : "v"(a));
-  else if constexpr (OP == OP_MOV_DPP_ROW_MIRROR) asm volatile("v_mov_b32_dpp %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(c));
-  else if constexpr (OP == OP_ADD_F32) asm volatile("v_add_f32 %0, %0, %1" : "+v"(c) : "v"(a));
-  else if constexpr (OP == OP_FMA_F32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
-  else if constexpr (OP == OP_EXP_F32) asm volatile("v_exp_f32 %0, %0" : "+v"(c));
+// one chain step on chain register c (32-bit chains) / d (64-bit chains); a, b / da, db: loop-invariant VGPR operands; t: a 32-bit temporary
+template <int OP> __device__ __forceinline__ void step32(uint32_t &c, uint32_t a, uint32_t b) {
+#define X(tag, name, n, wide, text) \
+  if constexpr (OP == OP_##tag && !wide) {                                                                                          \
+    if constexpr (OP == OP_CMP_CNDMASK || OP == OP_READLANE) asm volatile(text : [c] "+v"(c) : [a] "v"(a), [b] "v"(b), [t] "v"(b) : "vcc", "s20"); \
+    else asm volatile(text : [c] "+v"(c) : [a] "v"(a), [b] "v"(b), [t] "v"(b));                                                       \
+  }
+  AOMHIP_VALU_OPS(X)
+#undef X
 }
-template <int OP> __device__ __forceinline__ void one64(double &d, double a, double b, uint32_t ia) {
-  if constexpr (OP == OP_FMA_F64) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d) : "v"(a), "v"(b));
-  else if constexpr (OP == OP_MUL_F64) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d) : "v"(a));
-  else if constexpr (OP == OP_ADD_F64) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d) : "v"(a));
-  else if constexpr (OP == OP_RCP_F64) asm volatile("v_rcp_f64 %0, %0" : "+v"(d));
-  else if constexpr (OP == OP_CVT_F64_I32) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(d) : "v"(ia));
-  else if constexpr (OP == OP_MAD_U64_U32) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d) : "v"(ia), "v"(ia) : "vcc");
+template <int OP> __device__ __forceinline__ void step64(double &d, double da, double db, uint32_t &t) {
+#define X(tag, name, n, wide, text) \
+  if constexpr (OP == OP_##tag && wide) {                                                                                          \
+    if constexpr (OP == OP_MAD_U64_U32 || OP == OP_MAD_I64_I32) asm volatile(text : [c] "+v"(d), [t] "+v"(t) : [a] "v"(da), [b] "v"(db) : "vcc"); \
+    else asm volatile(text : [c] "+v"(d), [t] "+v"(t) : [a] "v"(da), [b] "v"(db));                                                    \
+  }
+  AOMHIP_VALU_OPS(X)
+#undef X
 }
-template <int OP> constexpr bool is64() { return OP == OP_FMA_F64 || OP == OP_MUL_F64 || OP == OP_ADD_F64 || OP == OP_RCP_F64 || OP == OP_CVT_F64_I32 || OP == OP_MAD_U64_U32; }
+template <int OP> constexpr bool is64() { return kValuOpWide[OP]; }
 
 constexpr int kProbeChains = 8, kProbeReps = 16;   // 128 instructions per loop trip
 
@@ -199,7 +250,7 @@ __global__ __launch_bounds__(1024) void valu_issue_probe_kernel(int iters, uint3
     for (int r = 0; r < kProbeReps; ++r) {
 #pragma unroll
       for (int k = 0; k < kProbeChains; ++k) {
-        if constexpr (is64<OP>()) one64<OP>(d[k], da, db, a); else one32<OP>(c[k], a, b);
+        if constexpr (is64<OP>()) step64<OP>(d[k], da, db, a); else step32<OP>(c[k], a, b);
       }
     }
   }
@@ -209,9 +260,8 @@ __global__ __launch_bounds__(1024) void valu_issue_probe_kernel(int iters, uint3
   for (int k = 0; k < kProbeChains; ++k) x ^= is64<OP>() ? (uint32_t)__double2loint(d[k]) ^ (uint32_t)__double2hiint(d[k]) : c[k];
   if (x == 0x12345678u && sink) sink[0] = x + probe_lds_pad[0];
   if ((tid & 63) == 0 && stamps) {
-    unsigned long long *s = stamps + ((size_t)blockIdx.x * (blockDim.x >> 6) + (tid >> 6)) * 2;
-    s[0] = t1 - t0;
-    s[1] = r1 - r0;
+    unsigned long long *s = stamps + ((size_t)blockIdx.x * (blockDim.x >> 6) + (tid >> 6)) * 4;
+    s[0] = t0; s[1] = t1; s[2] = r0; s[3] = r1;
   }
 }
 
@@ -240,7 +290,7 @@ extern "C" int aomhip_valu_issue_probe(aomhip_ctx *ctx, int op_class, int waves_
   const size_t lds = wgs_per_cu == 1 ? 96 * 1024 : 1024;
   const size_t n_waves = (size_t)grid.x * (block.x / 64);
   unsigned long long *d_stamps = nullptr;
-  AOMHIP_TRY(hipMalloc(&d_stamps, n_waves * 2 * sizeof(unsigned long long)));
+  AOMHIP_TRY(hipMalloc(&d_stamps, n_waves * 4 * sizeof(unsigned long long)));
   ProbeFn fn = table[op_class];
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e == hipSuccess) {
@@ -255,25 +305,40 @@ extern "C" int aomhip_valu_issue_probe(aomhip_ctx *ctx, int op_class, int waves_
   if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
   float ms = 0.f;
   if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-  std::vector<unsigned long long> h(n_waves * 2);
+  std::vector<unsigned long long> h(n_waves * 4);
   if (e == hipSuccess) e = hipMemcpy(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   (void)hipFree(d_stamps);
   if (e != hipSuccess) {
     set_error("aomhip_valu_issue_probe: %s", hipGetErrorString(e));
     return AOMHIP_ERR_HIP;
   }
-  const double insts_per_wave = (double)iters * kProbeChains * kProbeReps;
-  std::vector<double> ticks(n_waves), hz(n_waves);
-  for (size_t i = 0; i < n_waves; ++i) {
-    ticks[i] = (double)h[2 * i] / insts_per_wave;
-    hz[i] = h[2 * i + 1] ? (double)h[2 * i] / (double)h[2 * i + 1] * 1e8 : 0.0;
+  const double insts_per_wave = (double)iters * kProbeChains * kProbeReps * kValuOpInsts[op_class];
+  // Ticks: the SIMD arbitrates by age (the oldest wavefront that can issue does), so the wavefronts of a SIMD finish one after another and
+  // a single wavefront's interval says little; the span from the first start to the last end over the wavefronts of ONE workgroup (one CU,
+  // one counter) covers W * insts_per_wave instructions on every SIMD when that workgroup has the CU to itself (W <= 4).  With two
+  // workgroups per CU (W = 8) which two share a CU is not known: the figure is then the launch's event time at the measured tick rate.
+  const int wpb = (int)block.x / 64;
+  std::vector<double> span(grid.x), hzv;
+  hzv.reserve(n_waves);
+  for (unsigned g = 0; g < grid.x; ++g) {
+    unsigned long long t_lo = ~0ull, t_hi = 0;
+    for (int w = 0; w < wpb; ++w) {
+      const unsigned long long *q = &h[((size_t)g * wpb + w) * 4];
+      t_lo = std::min(t_lo, q[0]); t_hi = std::max(t_hi, q[1]);
+      if (q[3] > q[2]) hzv.push_back((double)(q[1] - q[0]) / (double)(q[3] - q[2]) * 1e8);
+    }
+    span[g] = (double)(t_hi - t_lo);
   }
-  std::nth_element(ticks.begin(), ticks.begin() + n_waves / 2, ticks.end());
-  std::nth_element(hz.begin(), hz.begin() + n_waves / 2, hz.end());
+  std::nth_element(span.begin(), span.begin() + span.size() / 2, span.end());
+  if (hzv.empty()) hzv.push_back(0.0);
+  std::nth_element(hzv.begin(), hzv.begin() + hzv.size() / 2, hzv.end());
+  const double hz_med = hzv[hzv.size() / 2];
+  const double ticks_per_inst = wgs_per_cu == 1 ? span[span.size() / 2] / (insts_per_wave * (double)waves_per_simd)
+                                                : hz_med * (double)ms * 1e-3 / (insts_per_wave * (double)waves_per_simd);
   out->launch_ms = ms;
   out->wave_insts_per_s_per_simd = insts_per_wave * (double)n_waves / ((double)cus * 4.0) / ((double)ms * 1e-3);
-  out->memtime_ticks_per_wave_inst = ticks[n_waves / 2] / (double)waves_per_simd;   // issue interval of the SIMD (a wave sees W times that)
-  out->memtime_hz = hz[n_waves / 2];
+  out->memtime_ticks_per_wave_inst = ticks_per_inst;
+  out->memtime_hz = hz_med;
   out->waves_per_simd = waves_per_simd;
   out->compute_units = cus;
   return AOMHIP_OK;

@@ -690,65 +690,142 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
     psnr = 10 * np.log10(1023.0 ** 2 / max(np.mean((rec - srcf) ** 2), 1e-9))
     # per-stage launch times (each stage alone, same inputs) and the algorithmic rate of the memory-bound ones
     # (deblock / CDEF read + write each pixel once per pass; transform stages as the txq workload)
-    f0 = 0
     px_bytes = W * H * 2
-    stage_fns = {
-        "fullpel_diamond": lambda: ctx.fullpel_diamond_batch(sp.src, sp.ref, f0, 16, 16, 0, 4, capi.MV_COST_L1_HDRES, sp.d_blocks, n, sp.d_mv, sp.d_cost),
-        "subpel_bilinear": lambda: ctx.subpel_bilinear_batch(sp.src, sp.ref, f0, 16, 16, capi.MV_COST_L1_HDRES, 2, 1, 0, sp.d_sub_blocks(f0), n, sp.d_smv, sp.d_err, sp.d_dist, sp.d_sse),
-        "inter_pred_8tap": lambda: ctx.build_inter_pred_batch(sp.ref, f0, pred, f0, 16, 16, sp.d_blocks, sp.d_smv, n, 0, 0),
-        "subtract_xform_quant_16x16": lambda: ctx.subtract_xform_quant_batch(sp.src, pred, f0, 2, None, n, W // 16, 0, qp, None, d_q, d_dq, d_e),
-        "inv_txfm_add_16x16": lambda: ctx.inv_txfm_add_batch(d_dq, 2, None, n, W // 16, 0, d_e, pred, f0),
-        "deblock_vert+horz": lambda: ctx.deblock_plane(pred, f0, d_params, W // 4, 0, 3),
-        "deblock_fused": lambda: ctx.deblock_plane_fused(pred, f0, dbk, 0, d_params, W // 4, 0),
-        "cdef_luma": lambda: ctx.cdef_luma_plane(pred, f0, out, 0, d_pri, d_sec, fbw, d_skip, 6),
-    }
+
+    def stage_fns_of(f0):
+        return {
+            "fullpel_diamond": lambda: ctx.fullpel_diamond_batch(sp.src, sp.ref, f0, 16, 16, 0, 4, capi.MV_COST_L1_HDRES, sp.d_blocks, n, sp.d_mv, sp.d_cost),
+            "subpel_bilinear": lambda: ctx.subpel_bilinear_batch(sp.src, sp.ref, f0, 16, 16, capi.MV_COST_L1_HDRES, 2, 1, 0, sp.d_sub_blocks(f0), n, sp.d_smv, sp.d_err, sp.d_dist, sp.d_sse),
+            "inter_pred_8tap": lambda: ctx.build_inter_pred_batch(sp.ref, f0, pred, f0, 16, 16, sp.d_blocks, sp.d_smv, n, 0, 0),
+            "subtract_xform_quant_16x16": lambda: ctx.subtract_xform_quant_batch(sp.src, pred, f0, 2, None, n, W // 16, 0, qp, None, d_q, d_dq, d_e),
+            "inv_txfm_add_16x16": lambda: ctx.inv_txfm_add_batch(d_dq, 2, None, n, W // 16, 0, d_e, pred, f0),
+            "deblock_vert+horz": lambda: ctx.deblock_plane(pred, f0, d_params, W // 4, 0, 3),
+            "deblock_fused": lambda: ctx.deblock_plane_fused(pred, f0, dbk, 0, d_params, W // 4, 0),
+            "cdef_luma": lambda: ctx.cdef_luma_plane(pred, f0, out, 0, d_pri, d_sec, fbw, d_skip, 6),
+        }
     stage_bytes = {"inter_pred_8tap": 2 * px_bytes, "subtract_xform_quant_16x16": 2 * px_bytes + n * (256 * 8 + 2),
                    "inv_txfm_add_16x16": n * 256 * 4 + 2 * px_bytes, "deblock_vert+horz": 2 * 2 * px_bytes, "deblock_fused": 2 * px_bytes, "cdef_luma": 2 * px_bytes}
+    # The stages are data dependent (the search by the motion, the inverse transform by the share of blocks with coefficients) and the ring's
+    # frames differ (profiles/r05_inner_loop_timeline.md: 408 vs 323 us per frame): every stage is timed on every ring slot, each slot prepared
+    # by running the chain up to that stage on it, and the mean over the slots is reported (`ms_by_slot` has them all).
     stages = {}
-    for name, fn in stage_fns.items():
-        ms = kernel_avg_ms(ctx, fn, max(steps, 8))
-        stages[name] = {"ms": ms}
+    order = ["fullpel_diamond", "subpel_bilinear", "inter_pred_8tap", "subtract_xform_quant_16x16", "inv_txfm_add_16x16", "deblock_vert+horz", "deblock_fused", "cdef_luma"]
+    for f0 in range(F):
+        fns = stage_fns_of(f0)
+        for name in order:
+            if name == "deblock_fused":
+                ms = kernel_avg_ms(ctx, fns[name], max(steps, 8))
+            else:
+                fns[name](); ctx.sync()     # (the chain's state for the next stage; deblock is in place: its re-runs filter an already filtered plane, same work)
+                ms = kernel_avg_ms(ctx, fns[name], max(steps, 8))
+                if name in ("inv_txfm_add_16x16", "deblock_vert+horz"):   # in-place stages: restore the chain before the next stage is timed
+                    for nm in order[2:order.index(name) + 1]:
+                        fns[nm]()
+                    ctx.sync()
+            stages.setdefault(name, {"ms_by_slot": []})["ms_by_slot"].append(ms)
+    for name in order:
+        stages[name]["ms"] = sum(stages[name]["ms_by_slot"]) / F
+    eob_share = []
+    for f0 in range(F):
+        fns = stage_fns_of(f0)
+        for nm in order[:4]:
+            fns[nm]()
+        ctx.sync()
+        eob_share.append(float((ctx.from_device(d_e, (n,), np.uint16) > 0).mean()))
+    for name in order:
+        ms = stages[name]["ms"]
         if name in stage_bytes:
             # NOT an HBM figure: the whole luma chain of a 4K frame (~100 MB) lives in the 256 MiB Infinity Cache between the
             # dependent stages, so this is the rate at which the stage moves its algorithmic bytes through the cache hierarchy
             stages[name]["cache_resident_GBs"] = stage_bytes[name] / (ms * 1e-3) / 1e9
             stages[name]["cache_resident_rate_over_8TBs"] = stages[name]["cache_resident_GBs"] / HBM_PEAK_GBS
     # Each stage's own roofline: these kernels are bound by instruction issue, not by bytes.  VALU wave-instructions per launch come from the
-    # committed PMC passes (profiles/r04_inner_loop_pmc.json, tools/r04_pmc_stages.sh: SQ_INSTS_VALU / SQ_WAVES of the same kernel x the launch's
-    # wavefronts); a SIMD retires one wave64 VALU instruction per 4 clocks, so the floor of a launch is insts x 4 / (CUs x 4 SIMDs x clock).
-    # valu_frac = that floor / the launch time measured HERE; salu / lds / vmem instructions per wavefront ride along.
+    # committed PMC passes (profiles/r0N_inner_loop_pmc.json, tools/r04_pmc_stages.sh: SQ_INSTS_VALU / SQ_WAVES of the same kernel x the
+    # launch's wavefronts).  The issue rate is MEASURED in this run (aomhip_valu_issue_probe, csrc/probe.hip; profiles/r05_valu_issue.md):
+    # a SIMD of gfx950 retires one wave64 instruction per ~2 clocks for a small "fast" class (v_add/sub_u32, v_mov, v_and/or/xor,
+    # v_lshrrev, v_ashrrev, fp32 add / mul / fma) and one per ~4 clocks for every other integer / packed / dot / SAD / DPP / 64-bit opcode
+    # the kernels issue; the kernel's class shares are its static opcode mix (profiles/r05_isa_mix.json, tools/isa_mix.py).
+    # floor = insts x sum(share_c / rate_c) / (CUs x 4 SIMDs); valu_frac = floor / the launch time measured HERE.
     pmc_map = {"fullpel_diamond": "fullpel_diamond_kernel", "subpel_bilinear": "subpel_bilinear_kernel", "inter_pred_8tap": "inter_pred_kernel",
                "subtract_xform_quant_16x16": "xform_quant_staged_kernel", "inv_txfm_add_16x16": "inv_txfm_add_kernel",
                "deblock_vert+horz": ("deblock_vert", "deblock_horz"), "deblock_fused": "deblock_fused_kernel", "cdef_luma": "cdef_luma_kernel"}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_inner_loop_pmc.json")))
-    except Exception:  # noqa: BLE001
-        pmc = {}
-    simd_valu_per_s = 256 * 4 * 2.4e9 / 4.0
+    pmc = latest_profile_json("_inner_loop_pmc.json")
+    rates = valu_class_rates(ctx)
+    mix = (latest_profile_json("_isa_mix.json") or {}).get("kernels", {})
     for name, kn in pmc_map.items():
         kns = kn if isinstance(kn, tuple) else (kn,)
-        ents = [next((e for k_, e in pmc.items() if k_.startswith(x)), None) for x in kns]
+        ents = [next(((k_, e) for k_, e in pmc.items() if k_.startswith(x)), None) for x in kns]
         if name not in stages or any(e is None for e in ents):
             continue
-        insts = sum(e["SQ_INSTS_VALU_per_wavefront"] * e["wavefronts_per_launch"] for e in ents)
+        insts = sum(e["SQ_INSTS_VALU_per_wavefront"] * e["wavefronts_per_launch"] for _, e in ents)
+        floor_s = sum(e["SQ_INSTS_VALU_per_wavefront"] * e["wavefronts_per_launch"] * valu_seconds_per_inst(mix.get(k_), rates) for k_, e in ents)
         st = stages[name]
         st["valu_wave_insts_per_launch"] = insts
-        st["valu_floor_ms"] = insts / simd_valu_per_s * 1e3
+        st["valu_floor_ms"] = floor_s / (rates["compute_units"] * 4) * 1e3
         st["valu_frac"] = st["valu_floor_ms"] / st["ms"] if st["ms"] > 0 else None
-        st["insts_per_wavefront"] = {k_.replace("SQ_INSTS_", "").replace("_per_wavefront", "").lower(): round(sum(e.get(k_, 0.0) for e in ents), 1)
+        st["valu_fast_share_static"] = [round((mix.get(k_) or {}).get("share", {}).get("fast", 0.0), 3) for k_, _ in ents]
+        st["insts_per_wavefront"] = {k_.replace("SQ_INSTS_", "").replace("_per_wavefront", "").lower(): round(sum(e.get(k_, 0.0) for _, e in ents), 1)
                                      for k_ in ("SQ_INSTS_VALU_per_wavefront", "SQ_INSTS_SALU_per_wavefront", "SQ_INSTS_LDS_per_wavefront",
                                                 "SQ_INSTS_VMEM_RD_per_wavefront", "SQ_INSTS_VMEM_WR_per_wavefront")}
     # blocks whose quantised coefficients are all zero skip the inverse transform (and cost the forward stage its coefficient writes only)
-    eob = ctx.from_device(d_e, (n,), np.uint16)
     for nm in ("inv_txfm_add_16x16", "subtract_xform_quant_16x16"):
-        stages[nm]["eob_nonzero_share"] = float((eob > 0).mean())
+        stages[nm]["eob_nonzero_share_by_slot"] = eob_share
     return {"workload": "encode_inner_loop_4k_10bit", "value": steps / wall, "unit": "frames/s",
             "ms_per_frame": wall / steps * 1e3, "event_ms_per_frame": ev_ms / steps, "blocks_per_frame": n,
-            "recon_psnr_db_last_frame": float(psnr), "stages": stages, "deblock_in_frame": "fused" if fused_deblock else "two_pass",
+            "recon_psnr_db_last_frame": float(psnr), "stages": stages, "valu_issue_rates": rates, "deblock_in_frame": "fused" if fused_deblock else "two_pass",
             "launch": "one hipGraph per frame (aomhip_graph_launch)" if graph_note else "eight launches per frame", "without_graph": graph_note,
             "config": {"frame": "3840x2160 10-bit luma", "stages": "fullpel diamond + subpel bilinear (16x16) -> inter prediction at the "
                        "sub-pel MV (8-tap regular, av1_highbd_convolve_2d_sr) -> subtract+fwd_txfm2d_16x16+quantize_b q100 -> inv_txfm_add -> deblock (8x8 edges, level 32) -> "
                        "CDEF (pri 4, sec 2, damping 6)", "gpus": 1}}
+
+
+def latest_profile_json(suffix):
+    """The newest profiles/r0N*<suffix> (rounds sort by name); {} when there is none."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*" + suffix)))
+    try:
+        return json.load(open(fs[-1])) if fs else {}
+    except Exception:  # noqa: BLE001
+        return {}
+
+
+VALU_CLASS_OPS = {"fast": ("v_add_u32", "v_mov_b32", "v_and_b32", "v_ashrrev_i32"),
+                  "slow": ("v_mad_i32_i24", "v_add3_u32", "v_sad_u16", "v_dot2_i32_i16", "v_perm_b32", "v_lshl_add_u64", "v_lshlrev_b32"),
+                  "trans": ("v_exp_f32",), "trans64": ("v_rcp_f64",)}
+_VALU_RATES = {}
+
+
+def valu_class_rates(ctx):
+    """Wave-instructions per second per SIMD of each issue class, measured on this box in this run (8 wavefronts per SIMD, 8 independent
+    chains each, ~4 ms per opcode after a ramp launch of the same kernel): the harmonic mean over the class's probe opcodes."""
+    if _VALU_RATES:
+        return _VALU_RATES
+    import aom_av1_psy_amd as pkg
+    names = pkg.capi.valu_issue_probe_names()
+    per_op, cus, hz = {}, 256, []
+    for cls, ops in VALU_CLASS_OPS.items():
+        inv = []
+        for op in ops:
+            r = ctx.valu_issue_probe(names.index(op), 8, 300)
+            iters = max(200, int(4e-3 * r["wave_insts_per_s_per_simd"] / 8 / 128))
+            r = ctx.valu_issue_probe(names.index(op), 8, iters)
+            per_op[op] = r["wave_insts_per_s_per_simd"]
+            inv.append(1.0 / r["wave_insts_per_s_per_simd"])
+            cus = r["compute_units"]
+            hz.append(r["memtime_hz"])
+        _VALU_RATES[cls] = len(inv) / sum(inv)
+    _VALU_RATES["per_op"] = per_op
+    _VALU_RATES["compute_units"] = cus
+    _VALU_RATES["clock_hz_median"] = sorted(hz)[len(hz) // 2]
+    _VALU_RATES["clocks_per_wave_inst"] = {c: _VALU_RATES["clock_hz_median"] / _VALU_RATES[c] for c in VALU_CLASS_OPS}
+    return _VALU_RATES
+
+
+def valu_seconds_per_inst(mix_entry, rates):
+    """Seconds of one SIMD per wave-instruction of a kernel with this static class mix (no mix known: everything at the 4-clock rate)."""
+    share = (mix_entry or {}).get("share") or {"slow": 1.0}
+    return sum(v / rates[c] for c, v in share.items())
+
 
 
 def run_mesh(pkg, ctx, orc, steps, warmup):
@@ -1416,9 +1493,17 @@ def build_lines(args, world, main_res, others, strong):
                 parity_frame0_and_last_slot=main_res["parity_frame0"],
                 parity_all=all(bool(v) for o in [main_res] + others for k, v in o.items() if k.startswith("parity") and v is not None),
                 others={str(o.get("workload")): _other_summary(o) for o in rest} or None)
+    il = next((o for o in rest if o.get("workload") == "encode_inner_loop_4k_10bit"), None)
+    if il and il.get("valu_issue_rates"):
+        vr = il["valu_issue_rates"]
+        # the measured denominator of every valu_frac (aomhip_valu_issue_probe, this run) and the stage fractions re-based on it
+        line["valu_issue"] = {"unit": "G wave-instr/s/SIMD", "fast": vr["fast"] / 1e9, "slow": vr["slow"] / 1e9, "trans": vr["trans"] / 1e9,
+                              "clocks_per_wave_inst": vr["clocks_per_wave_inst"], "clock_GHz": vr["clock_hz_median"] / 1e9,
+                              "stage_valu_frac": {k: v.get("valu_frac") for k, v in il["stages"].items() if v.get("valu_frac") is not None},
+                              "stage_ms": {k: v["ms"] for k, v in il["stages"].items()}}
     line = _sig(line)
     # never let the line outgrow the record that reads it: shed the least important keys first (they stay in the full record)
-    for drop in ("others", "strong_scaling_search.tile_columns_px_balanced", "strong_scaling_search.tile_columns_px_uniform", "txq"):
+    for drop in ("valu_issue.stage_ms", "others", "strong_scaling_search.tile_columns_px_balanced", "strong_scaling_search.tile_columns_px_uniform", "txq"):
         if len(json.dumps(line, separators=(",", ":"))) <= LINE_LIMIT:
             break
         if "." in drop:
@@ -1586,7 +1671,7 @@ def main():
         print(json.dumps({"metric": "encode inner loop frames/s", "value": r["value"], "unit": "frames/s", "n_gpus": 1,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_frame"], "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-                          "config": dict(r["config"], workload=r["workload"]), "stages": r["stages"], "deblock_in_frame": r["deblock_in_frame"],
+                          "config": dict(r["config"], workload=r["workload"]), "stages": r["stages"], "valu_issue_rates": r.get("valu_issue_rates"), "deblock_in_frame": r["deblock_in_frame"],
                           "launch": r["launch"], "without_graph": r["without_graph"], "recon_psnr_db_last_frame": r["recon_psnr_db_last_frame"]}))
         return
     if args.workload == "default_search_4k_10bit":  # informational: NSTEP full-pel + 8-tap sub-pel tree (single GPU)

@@ -228,7 +228,9 @@ int aomhip_strip_read_probe(aomhip_ctx *ctx, const aomhip_planes *src, const aom
  * clock; a shorter untimed launch of the same kernel precedes the timed one).  aomhip_valu_issue_probe_name(op_class) names the classes
  * 0 .. n-1 (NULL beyond the last).  Computes nothing.
  *   wave_insts_per_s_per_simd   = wavefront-instructions retired per second per SIMD (HIP-event time of the launch)
- *   memtime_ticks_per_wave_inst = s_memtime ticks between two instructions of the SIMD (median over the wavefronts)
+ *   memtime_ticks_per_wave_inst = s_memtime ticks per instruction of a SIMD: waves_per_simd <= 4 (one workgroup per CU): the span from the
+ *                                 first start to the last end over the wavefronts of a workgroup / (waves_per_simd x instructions per
+ *                                 wavefront), median over the workgroups; 8: the event time of the launch at memtime_hz
  *   memtime_hz                  = s_memtime ticks per second, measured against s_memrealtime (100 MHz) inside the kernel */
 typedef struct {
   double wave_insts_per_s_per_simd, launch_ms, memtime_ticks_per_wave_inst, memtime_hz;

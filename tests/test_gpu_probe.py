@@ -18,10 +18,11 @@ def test_valu_issue_probe_reports_every_opcode_class():
         assert 1e7 < r["wave_insts_per_s_per_simd"] < 3e9, (nm, r)     # between 1/60 and 1.25 instructions per clock at ~2.4 GHz
         assert r["memtime_ticks_per_wave_inst"] > 0 and 2e7 < r["memtime_hz"] < 4e9
         rates[nm] = r["wave_insts_per_s_per_simd"]
-    # the relations the kernels' instruction choices rest on (profiles/r04_valu_floors.md): the 24-bit multiplier is faster than v_mul_lo_u32,
-    # fp64 fused multiply-add is slower than 32-bit integer add
-    assert rates["v_mul_u32_u24"] > 1.5 * rates["v_mul_lo_u32"]
-    assert rates["v_add_u32"] > rates["v_fma_f64"]
+    # relations measured on MI355X (profiles/r05_valu_issue.md): most integer / packed / dot / SAD opcodes retire one wave64 instruction per
+    # ~4 clocks per SIMD, v_add_u32 and the fp32 add / fma one per ~2; transcendentals and fp64 reciprocal are slower
+    assert rates["v_add_u32"] > 1.3 * rates["v_sad_u8"] and rates["v_fma_f32"] > 1.3 * rates["v_sad_u8"]
+    assert rates["v_exp_f32"] < 0.7 * rates["v_sad_u8"] and rates["v_rcp_f64"] < 0.5 * rates["v_sad_u8"]
+    assert 0.8 < rates["v_mul_u32_u24"] / rates["v_mad_i32_i24"] < 1.25
     # one wavefront per SIMD cannot issue faster than eight
     one = ctx.valu_issue_probe(0, 1, 300)
     assert one["wave_insts_per_s_per_simd"] <= 1.05 * ctx.valu_issue_probe(0, 8, 300)["wave_insts_per_s_per_simd"]

@@ -19,7 +19,7 @@ for op, nm in enumerate(names):
     rows.append(row)
     print("| `%s` | %s | %.3f | %.2f | %.2f GHz | %.1f ms |" % (
         nm, " / ".join("%.3f" % (row["w%d" % w]["wave_insts_per_s_per_simd"] / 1e9) for w in (1, 2, 4, 8)),
-        row["w8"]["wave_insts_per_s_per_simd"] / 1e9, row["w8"]["memtime_ticks_per_wave_inst"], row["w8"]["memtime_hz"] / 1e9, row["w8"]["launch_ms"]), flush=True)
+        row["w8"]["wave_insts_per_s_per_simd"] / 1e9, row["w4"]["memtime_ticks_per_wave_inst"], row["w8"]["memtime_hz"] / 1e9, row["w8"]["launch_ms"]), flush=True)
 os.makedirs("gpurun_out/" + tag, exist_ok=True)
 json.dump(rows, open("gpurun_out/%s/valu_issue.json" % tag, "w"), indent=1)
 ctx.close()
