@@ -187,6 +187,7 @@ _protos = {
                                                     _vp, _vp, _vp, _vp]),
     "aomhip_quantize_b_adaptive_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, C.POINTER(QuantParams), _i, _vp, _vp, _vp]),
     "aomhip_inv_txfm_add_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _PP, _i]),
+    "aomhip_encode_inter_blocks_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "aomhip_deblock_plane": (C.c_int, [_vp, _PP, _i, _vp, _i, _i, _i]),
     "aomhip_cdef_luma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "aomhip_cdef_chroma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i]),
@@ -516,6 +517,13 @@ class Context:
     def inv_txfm_add_batch(self, d_dqcoeff, tx_size, d_blocks, n_blocks, grid_cols, tx_type, d_eob, dst, frame):
         check(lib.aomhip_inv_txfm_add_batch(self.h, d_dqcoeff, tx_size, d_blocks, n_blocks, grid_cols, tx_type, d_eob,
                                             C.byref(dst), frame), "aomhip_inv_txfm_add_batch")
+
+    def encode_inter_blocks_batch(self, src, src_frame, ref, ref_frame, recon, recon_frame, bw, d_blocks, d_mv, n_blocks, qparams, d_qcoeff, d_dqcoeff,
+                                  d_eob, filter_x=0, filter_y=0, tx_type=0):
+        """prediction -> residual -> fwd_txfm2d + quantize_b -> inverse + add for square inter blocks, one kernel (csrc/encode_block.hip)."""
+        check(lib.aomhip_encode_inter_blocks_batch(self.h, C.byref(src), src_frame, C.byref(ref), ref_frame, C.byref(recon), recon_frame, bw, d_blocks,
+                                                   d_mv, n_blocks, filter_x, filter_y, tx_type, C.byref(qparams), d_qcoeff, d_dqcoeff, d_eob),
+              "aomhip_encode_inter_blocks_batch")
 
     def mesh_search_batch(self, src, ref, frame, bw, bh, cost_type, patterns, fine, d_blocks, n_blocks, d_mv, d_cost):
         pat = (C.c_int * 8)(*[int(v) for pair in patterns for v in pair])

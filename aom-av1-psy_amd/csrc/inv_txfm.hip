@@ -12,13 +12,12 @@
 // low-frequency coefficients; all-zero rows are not transformed (every network maps 0 -> 0).
 #include "common.h"
 #include "txfm_device.h"
+#include "quant_device.h"
 
 namespace aomhip {
 
 using namespace txfm;
 
-__device__ constexpr uint8_t kIVKind[16] = { 0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3 };
-__device__ constexpr uint8_t kIHKind[16] = { 0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2 };
 
 constexpr int kInvThreads = 256;
 

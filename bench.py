@@ -621,6 +621,7 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
     pred = ctx.planes_alloc(W, H, border, bd, F)  # slot f: prediction, then reconstruction, of ring frame f
     out = ctx.planes_alloc(W, H, border, bd, 1)
     dbk = ctx.planes_alloc(W, H, border, bd, 1)
+    fused_middle = os.environ.get("AOMHIP_BENCH_MIDDLE", "fused") != "three_calls"   # (three_calls: the separate predictor / transform / inverse launches)
     fused_deblock = os.environ.get("AOMHIP_BENCH_DEBLOCK", "two_pass") == "fused"   # (round 4: the two in-place passes with four lines per lane are the faster form)
     n = sp.n
     nc = 256
@@ -643,10 +644,14 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
         ctx.fullpel_diamond_batch(sp.src, sp.ref, f, 16, 16, 0, 4, capi.MV_COST_L1_HDRES, sp.d_blocks, n, sp.d_mv, sp.d_cost)
         ctx.subpel_bilinear_batch(sp.src, sp.ref, f, 16, 16, capi.MV_COST_L1_HDRES, 2, 1, 0, sp.d_sub_blocks(f), n,
                                   sp.d_smv, sp.d_err, sp.d_dist, sp.d_sse)
-        ctx.build_inter_pred_batch(sp.ref, f, pred, f, 16, 16, sp.d_blocks, sp.d_smv, n, 0, 0)   # EIGHTTAP_REGULAR both ways
-        # grid mode: block i of the plane == block i of the raster list used above
-        ctx.subtract_xform_quant_batch(sp.src, pred, f, 2, None, n, W // 16, 0, qp, None, d_q, d_dq, d_e)
-        ctx.inv_txfm_add_batch(d_dq, 2, None, n, W // 16, 0, d_e, pred, f)
+        if fused_middle:
+            # prediction -> residual -> transform + quantise -> inverse + add in one kernel (csrc/encode_block.hip); EIGHTTAP_REGULAR both ways
+            ctx.encode_inter_blocks_batch(sp.src, f, sp.ref, f, pred, f, 16, sp.d_blocks, sp.d_smv, n, qp, d_q, d_dq, d_e, 0, 0, 0)
+        else:
+            ctx.build_inter_pred_batch(sp.ref, f, pred, f, 16, 16, sp.d_blocks, sp.d_smv, n, 0, 0)
+            # grid mode: block i of the plane == block i of the raster list used above
+            ctx.subtract_xform_quant_batch(sp.src, pred, f, 2, None, n, W // 16, 0, qp, None, d_q, d_dq, d_e)
+            ctx.inv_txfm_add_batch(d_dq, 2, None, n, W // 16, 0, d_e, pred, f)
         # both deblocking passes in one launch, out of place into `dbk` (CDEF reads a second buffer anyway); AOMHIP_BENCH_DEBLOCK=two_pass
         # keeps the in-place vertical + horizontal launches
         if fused_deblock:
@@ -699,21 +704,23 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
             "inter_pred_8tap": lambda: ctx.build_inter_pred_batch(sp.ref, f0, pred, f0, 16, 16, sp.d_blocks, sp.d_smv, n, 0, 0),
             "subtract_xform_quant_16x16": lambda: ctx.subtract_xform_quant_batch(sp.src, pred, f0, 2, None, n, W // 16, 0, qp, None, d_q, d_dq, d_e),
             "inv_txfm_add_16x16": lambda: ctx.inv_txfm_add_batch(d_dq, 2, None, n, W // 16, 0, d_e, pred, f0),
+            "encode_inter_blocks_16x16": lambda: ctx.encode_inter_blocks_batch(sp.src, f0, sp.ref, f0, pred, f0, 16, sp.d_blocks, sp.d_smv, n, qp, d_q, d_dq, d_e, 0, 0, 0),
             "deblock_vert+horz": lambda: ctx.deblock_plane(pred, f0, d_params, W // 4, 0, 3),
             "deblock_fused": lambda: ctx.deblock_plane_fused(pred, f0, dbk, 0, d_params, W // 4, 0),
             "cdef_luma": lambda: ctx.cdef_luma_plane(pred, f0, out, 0, d_pri, d_sec, fbw, d_skip, 6),
         }
-    stage_bytes = {"inter_pred_8tap": 2 * px_bytes, "subtract_xform_quant_16x16": 2 * px_bytes + n * (256 * 8 + 2),
+    stage_bytes = {"encode_inter_blocks_16x16": 3 * px_bytes + n * (256 * 8 + 2), "inter_pred_8tap": 2 * px_bytes, "subtract_xform_quant_16x16": 2 * px_bytes + n * (256 * 8 + 2),
                    "inv_txfm_add_16x16": n * 256 * 4 + 2 * px_bytes, "deblock_vert+horz": 2 * 2 * px_bytes, "deblock_fused": 2 * px_bytes, "cdef_luma": 2 * px_bytes}
     # The stages are data dependent (the search by the motion, the inverse transform by the share of blocks with coefficients) and the ring's
     # frames differ (profiles/r05_inner_loop_timeline.md: 408 vs 323 us per frame): every stage is timed on every ring slot, each slot prepared
     # by running the chain up to that stage on it, and the mean over the slots is reported (`ms_by_slot` has them all).
     stages = {}
-    order = ["fullpel_diamond", "subpel_bilinear", "inter_pred_8tap", "subtract_xform_quant_16x16", "inv_txfm_add_16x16", "deblock_vert+horz", "deblock_fused", "cdef_luma"]
+    order = ["fullpel_diamond", "subpel_bilinear", "inter_pred_8tap", "subtract_xform_quant_16x16", "inv_txfm_add_16x16", "encode_inter_blocks_16x16",
+             "deblock_vert+horz", "deblock_fused", "cdef_luma"]
     for f0 in range(F):
         fns = stage_fns_of(f0)
         for name in order:
-            if name == "deblock_fused":
+            if name in ("deblock_fused", "encode_inter_blocks_16x16"):   # out of place / idempotent: re-running them leaves the chain's state as it is
                 ms = kernel_avg_ms(ctx, fns[name], max(steps, 8))
             else:
                 fns[name](); ctx.sync()     # (the chain's state for the next stage; deblock is in place: its re-runs filter an already filtered plane, same work)
@@ -774,6 +781,7 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
             "ms_per_frame": wall / steps * 1e3, "event_ms_per_frame": ev_ms / steps, "blocks_per_frame": n,
             "recon_psnr_db_last_frame": float(psnr), "stages": stages, "valu_issue_rates": rates, "deblock_in_frame": "fused" if fused_deblock else "two_pass",
             "launch": "one hipGraph per frame (aomhip_graph_launch)" if graph_note else "eight launches per frame", "without_graph": graph_note,
+            "middle_of_frame": "one kernel (aomhip_encode_inter_blocks_batch)" if fused_middle else "three launches",
             "config": {"frame": "3840x2160 10-bit luma", "stages": "fullpel diamond + subpel bilinear (16x16) -> inter prediction at the "
                        "sub-pel MV (8-tap regular, av1_highbd_convolve_2d_sr) -> subtract+fwd_txfm2d_16x16+quantize_b q100 -> inv_txfm_add -> deblock (8x8 edges, level 32) -> "
                        "CDEF (pri 4, sec 2, damping 6)", "gpus": 1}}

@@ -981,6 +981,25 @@ int aomhip_simple_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src,
                                       const aomhip_search_block *d_blocks, int n_blocks, const aomhip_planes *pred, int pred_frame,
                                       int16_t *d_best_mv, uint32_t *d_sse, uint32_t *d_var);
 
+/* ------------------------------------------------------------------ the block-local middle of the encode loop in one kernel */
+
+/* encode_block (av1/encoder/encodemb.c:343-470) behind its predictor, for inter blocks whose prediction block is ONE square transform block
+ * (bw = 8, 16 or 32: TX_8X8 / TX_16X16 / TX_32X32): av1_enc_build_inter_predictor (av1/encoder/reconinter_enc.c:47-51; the 8-tap convolve of
+ * aomhip_build_inter_pred_batch, same filters and MV contract) -> aom_[highbd_]subtract_block (encodemb.c:53-77) -> av1_xform_quant
+ * (:288-341: av1_fwd_txfm2d + aom_[highbd_]quantize_b, as aomhip_subtract_xform_quant_batch) -> av1_inverse_transform_block + the clipped add
+ * (:454-459, as aomhip_inv_txfm_add_batch; blocks with eob == 0 keep the prediction).  One launch instead of three: the prediction, the
+ * residual and the dequantised coefficients never leave the lanes that own the block (csrc/encode_block.hip).
+ *   d_blocks / d_mv   block positions and (row, col) MVs in 1/8 pel, as aomhip_build_inter_pred_batch takes them
+ *   tx_type           one TX_TYPE for the batch (0 = DCT_DCT; must exist at that size)
+ *   recon             frame recon_frame receives the reconstruction at (bx, by); must not be the reference frame being read
+ *   d_qcoeff, d_dqcoeff  block i at element i * bw * bw in the reference's coefficient order; either may be NULL (not stored)
+ *   d_eob             one per block
+ * Results are bit-identical to the three calls in sequence. */
+int aomhip_encode_inter_blocks_batch(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *ref, int ref_frame,
+                                     const aomhip_planes *recon, int recon_frame, int bw, const aomhip_search_block *d_blocks,
+                                     const int16_t *d_mv, int n_blocks, int interp_filter_x, int interp_filter_y, int tx_type,
+                                     const aomhip_quant_params *qparams, int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);
+
 /* Full-pel motion-compensated prediction for the frame-level pipeline: pred block i = reference block at
  * (bx + mv.col, by + mv.row) with mv = d_fullpel_mv[2i], [2i+1] (row, col), i.e. av1_build_inter_predictor
  * (av1/common/reconinter.c) for an integer MV, where the convolve is aom_convolve_copy. */
