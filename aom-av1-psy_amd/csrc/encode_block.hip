@@ -32,15 +32,6 @@ struct EbArgs {
   int src_stride, rec_stride, tx_type;
 };
 
-// The W <= 32 lanes of a block sit in ONE wavefront and a wavefront's LDS instructions execute in program order: what one lane wrote is
-// there for the block's other lanes as soon as the compiler keeps the accesses in order -- no s_barrier, the workgroup's wavefronts (other
-// blocks) never wait for each other.
-__device__ __forceinline__ void block_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <int W> constexpr int eb_threads() { return W >= 32 ? 128 : kEbThreads; }   // (a 32x32 block needs 12.4 KB of LDS: four per workgroup)
 
 template <typename T, int W, int BD>

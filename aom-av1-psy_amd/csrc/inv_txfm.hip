@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kInvThreads) void inv_txfm_add_kernel(const int32_t
       t[r * LSTRIDE + c] = v;
     }
   }
-  __syncthreads();
+  block_sync();
 
   // ---- columns + add
   if (live && lane < W) {

@@ -98,77 +98,149 @@ template <typename T> struct CompoundEval {
   static constexpr int kUnits = 2;   // 4-pixel units per lane kept in registers: blocks of up to 64 x 2 x 4 = 512 pixels
   const T *sp, *rbase, *pred;
   const uint8_t *mask;
-  int sstride, rstride, lw, wm, n_px, shift, invert, bit_depth, lane;
-  bool keep;
-  int s_[kUnits][4], p_[kUnits][4], m_[kUnits][4];
+  int sstride, rstride, lw, wm, n_px, shift, invert, bit_depth, lane, sh;
+  bool keep, packed;
+  // A candidate's pixels are addressed as base0 + 32-bit byte offset (scalar base, one vector add per unit): base0 is the reference block at
+  // the search window's top-left MV (row_min, col_min), so every offset a search can ask for is non-negative; lo_ = the lane's own offset
+  const char *base0;
+  int rmin, cmin;
+  unsigned lo_[kUnits];
+  // The blend of aom_comp_avg_pred (variance.c:306-319) / aom_comp_mask_pred (:773-791) is (A * f + C) >> sh per pixel with A, C fixed for
+  // the search: comp_avg A = 1, C = p + 1, sh = 1; comp_mask A = m (inverted: 64 - m), C = (64 - A) * p + 32, sh = 6.  One branch-free form
+  // for the three cases: with `if (!mask) .. else if (invert) ..` inside the per-pixel blend the compiler emitted two or three scalar
+  // branches PER PIXEL (7 700 scalar instructions per block, PMC r05).
+  int s_[kUnits][4], A_[kUnits][4], C_[kUnits][4];
+  // The SAD's operands as packed 16-bit pairs (two dwords per 4-pixel unit): A * f + C fits 16 bits for every depth without a mask
+  // (<= 2 * 4095 + 1) and up to 10 bits with one (<= 64 * 1023 + 32): v_pk_mad_u16, v_pk_lshrrev_b16, v_sad_u16 -- 3 instructions per pixel
+  // pair.  12-bit masked blocks keep the 32-bit form.  (These searches are issue bound, not latency bound: evaluating a stage's 8 sites
+  // together was 17-32 % SLOWER, profiles/r05_compound_batch8.patch.)
+  uint32_t sA_[kUnits][2], sC_[kUnits][2], sS_[kUnits][2], sh2;
+  __device__ __forceinline__ void coeffs(int p, int m, int &A, int &Cc) const {
+    A = !mask ? 1 : (invert ? 64 - m : m);
+    Cc = !mask ? p + 1 : (64 - A) * p + 32;
+  }
   __device__ __forceinline__ void init(const T *sp_, int sstride_, const T *rbase_, int rstride_, const T *pred_, const uint8_t *mask_, int W, int H, int invert_,
-                                       int bit_depth_, int lane_) {
+                                       int bit_depth_, int lane_, int row_min, int col_min) {
     sp = sp_; rbase = rbase_; pred = pred_; mask = mask_; sstride = sstride_; rstride = rstride_;
+    rmin = row_min; cmin = col_min;
+    base0 = reinterpret_cast<const char *>(rbase_ + (int64_t)row_min * rstride_ + col_min);
     lw = __builtin_ctz((unsigned)W); wm = W - 1; n_px = W * H; invert = invert_; bit_depth = bit_depth_; lane = lane_;
     shift = bit_depth == 10 ? 2 : bit_depth == 12 ? 4 : 0;   // the _bits10 / _bits12 vtable wrappers (encoder_utils.h)
+    sh = mask ? 6 : 1;
+    sh2 = (uint32_t)sh | ((uint32_t)sh << 16);
     keep = n_px <= 256 * kUnits;
+    packed = keep && (!mask || bit_depth <= 10);
     if (keep) {
 #pragma unroll
       for (int k = 0; k < kUnits; ++k) {
         const int t = 4 * (k * 64 + lane);   // (widths are multiples of 4: a unit lies in one row)
+        lo_[k] = t < n_px ? (unsigned)(((t >> lw) * rstride + (t & wm)) * (int)sizeof(T)) : 0u;
+        int p4[4] = { 0, 0, 0, 0 }, m4[4] = { 0, 0, 0, 0 };
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s_[k][i] = p_[k][i] = m_[k][i] = 0;
+        for (int i = 0; i < 4; ++i) s_[k][i] = 0;
         if (t < n_px) {
           load_px4<T>(sp + (t >> lw) * sstride + (t & wm), s_[k]);
-          load_px4<T>(pred + t, p_[k]);
-          if (mask) load_px4<uint8_t>(mask + t, m_[k]);
+          load_px4<T>(pred + t, p4);
+          if (mask) load_px4<uint8_t>(mask + t, m4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          coeffs(p4[i], m4[i], A_[k][i], C_[k][i]);
+          if (t >= n_px) { A_[k][i] = 0; C_[k][i] = 0; }   // lanes beyond the block: blend 0 against source 0
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          sA_[k][h] = (uint32_t)A_[k][2 * h] | ((uint32_t)A_[k][2 * h + 1] << 16);
+          sC_[k][h] = (uint32_t)C_[k][2 * h] | ((uint32_t)C_[k][2 * h + 1] << 16);
+          sS_[k][h] = (uint32_t)s_[k][2 * h] | ((uint32_t)s_[k][2 * h + 1] << 16);
         }
       }
     }
   }
-  __device__ __forceinline__ int blend(int f, int p, int m) const {   // aom_comp_avg_pred (variance.c:306-319) / aom_comp_mask_pred (:773-791)
-    if (!mask) return (p + f + 1) >> 1;
-    return invert ? (m * p + (64 - m) * f + 32) >> 6 : (m * f + (64 - m) * p + 32) >> 6;
+  __device__ __forceinline__ int blend_at(int f, int k, int i) const { return (A_[k][i] * f + C_[k][i]) >> sh; }
+  __device__ __forceinline__ int blend_mem(int f, int t) const {   // blocks too large for the registers: the operands from memory
+    int A, Cc;
+    coeffs((int)pred[t], mask ? (int)mask[t] : 0, A, Cc);
+    return (A * f + Cc) >> sh;
   }
-  __device__ __forceinline__ void load_ref(const T *rp, int f[kUnits][4]) const {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  // SAD of one pixel pair: blend = (A * f + C) >> sh on both halves, then |blend - s| summed into acc
+  __device__ __forceinline__ uint32_t pair_sad(uint32_t f, uint32_t A, uint32_t Cc, uint32_t S, uint32_t acc) const {
+    const u16x2 b = (u16x2)(__builtin_bit_cast(u16x2, A) * __builtin_bit_cast(u16x2, f) + __builtin_bit_cast(u16x2, Cc)) >> __builtin_bit_cast(u16x2, sh2);
+    return __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, b), S, acc);
+  }
+  __device__ __forceinline__ unsigned cand_off(int row, int col) const {   // (row, col) inside the search window: >= 0
+    return (unsigned)(((row - rmin) * rstride + (col - cmin)) * (int)sizeof(T));
+  }
+  __device__ __forceinline__ void load_ref(unsigned off, int f[kUnits][4]) const {
 #pragma unroll
     for (int k = 0; k < kUnits; ++k) {
       const int t = 4 * (k * 64 + lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i) f[k][i] = 0;
-      if (t < n_px) load_px4<T>(rp + (t >> lw) * rstride + (t & wm), f[k]);
+      if (t < n_px) load_px4<T>(reinterpret_cast<const T *>(base0 + (lo_[k] + off)), f[k]);
     }
   }
   __device__ __forceinline__ uint32_t sad(int row, int col) const {
-    const T *rp = rbase + (int64_t)row * rstride + col;
+    const unsigned off = cand_off(row, col);
+    const T *rp = reinterpret_cast<const T *>(base0 + off);
     uint32_t acc = 0;
-    if (keep) {
+    if (packed) {
+      uint32_t f2[kUnits][2];
+#pragma unroll
+      for (int k = 0; k < kUnits; ++k) {
+        const int t = 4 * (k * 64 + lane);
+        f2[k][0] = f2[k][1] = 0;
+        if (t < n_px) {
+          const char *q = base0 + (lo_[k] + off);
+          if constexpr (sizeof(T) == 1) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(q);
+            f2[k][0] = __builtin_amdgcn_perm(0, w, 0x0c010c00);   // (px0, px1) as 16-bit halves
+            f2[k][1] = __builtin_amdgcn_perm(0, w, 0x0c030c02);   // (px2, px3)
+          } else {
+            const uint2 w = *reinterpret_cast<const uint2 *>(q);
+            f2[k][0] = w.x; f2[k][1] = w.y;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kUnits; ++k)
+        if (k * 256 < n_px) {
+          acc = pair_sad(f2[k][0], sA_[k][0], sC_[k][0], sS_[k][0], acc);   // (lanes beyond the block: (0 * f + 0) >> sh == 0 == s)
+          acc = pair_sad(f2[k][1], sA_[k][1], sC_[k][1], sS_[k][1], acc);
+        }
+    } else if (keep) {
       int f[kUnits][4];
-      load_ref(rp, f);
+      load_ref(off, f);
 #pragma unroll
       for (int k = 0; k < kUnits; ++k)
         if (k * 256 < n_px) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc += (uint32_t)iabsm(blend(f[k][i], p_[k][i], m_[k][i]) - s_[k][i]);   // (lanes beyond the block: 0 - 0)
+          for (int i = 0; i < 4; ++i) acc += (uint32_t)iabsm(blend_at(f[k][i], k, i) - s_[k][i]);
         }
     } else {
       for (int t = lane; t < n_px; t += 64) {
         const int y = t >> lw, x = t & wm;
-        const int v = blend((int)rp[(int64_t)y * rstride + x], (int)pred[t], mask ? (int)mask[t] : 0);
-        acc += (uint32_t)iabsm(v - (int)sp[(int64_t)y * sstride + x]);
+        acc += (uint32_t)iabsm(blend_mem((int)rp[(int64_t)y * rstride + x], t) - (int)sp[(int64_t)y * sstride + x]);
       }
     }
     return wsum32(acc) >> shift;
   }
   __device__ __forceinline__ uint32_t var(int row, int col) const {   // (without the MV cost)
-    const T *rp = rbase + (int64_t)row * rstride + col;
+    const unsigned off = cand_off(row, col);
+    const T *rp = reinterpret_cast<const T *>(base0 + off);
     int32_t s = 0;
     uint64_t q64;
     if (keep) {
       uint32_t q = 0;   // <= 8 x 4095^2 per lane, <= 16 lanes of that per row
       int f[kUnits][4];
-      load_ref(rp, f);
+      load_ref(off, f);
 #pragma unroll
       for (int k = 0; k < kUnits; ++k) {
         if (k * 256 < n_px) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int d = blend(f[k][i], p_[k][i], m_[k][i]) - s_[k][i];
+            const int d = blend_at(f[k][i], k, i) - s_[k][i];
             s += d;
             q += (uint32_t)(d * d);
           }
@@ -179,7 +251,7 @@ template <typename T> struct CompoundEval {
       uint64_t q = 0;
       for (int t = lane; t < n_px; t += 64) {
         const int y = t >> lw, x = t & wm;
-        const int d = blend((int)rp[(int64_t)y * rstride + x], (int)pred[t], mask ? (int)mask[t] : 0) - (int)sp[(int64_t)y * sstride + x];
+        const int d = blend_mem((int)rp[(int64_t)y * rstride + x], t) - (int)sp[(int64_t)y * sstride + x];
         s += d;
         q += (uint32_t)(d * d);
       }
@@ -198,6 +270,7 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
   const int bi = blockIdx.x * 4 + wave;
   if (bi >= n_blocks) return;
   const BlockScalars bs = BlockScalars::of(blocks[bi]);
+  if (bs.row_min > bs.row_max) return;   // an EMPTY window marks a block the caller wants skipped (fullpel_search.inc): outputs stay as they are
   const int bx = __builtin_amdgcn_readfirstlane((int)blocks[bi].bx), by = __builtin_amdgcn_readfirstlane((int)blocks[bi].by);
   const int W = a.bw, H = a.bh, n_px = W * H;
   const T *sp = src.origin + (int64_t)frame * src.frame_stride + (int64_t)by * src.stride + bx;
@@ -206,7 +279,7 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
   const uint8_t *mask = masks ? masks + (size_t)bi * n_px : nullptr;
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
   CompoundEval<T> ce;
-  ce.init(sp, src.stride, rbase, ref.stride, pred, mask, W, H, a.invert_mask, a.bit_depth, lane);
+  ce.init(sp, src.stride, rbase, ref.stride, pred, mask, W, H, a.invert_mask, a.bit_depth, lane, bs.row_min, bs.col_min);
   auto sad_at = [&](int row, int col) -> uint32_t { return ce.sad(row, col); };   // get_mvpred_compound_sad
   constexpr int kRange = 3, kStride = 2 * kRange + 1;   // SEARCH_RANGE_8P, SEARCH_GRID_STRIDE_8P (mcomp_structs.h:26-29)
   unsigned long long visited = 0;                       // the 49 cells of do_refine_search_grid
@@ -273,6 +346,7 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
   const int bi = blockIdx.x * 4 + wave;
   if (bi >= n_blocks) return;
   const BlockScalars bs = BlockScalars::of(blocks[bi]);
+  if (bs.row_min > bs.row_max) return;   // an EMPTY window marks a block the caller wants skipped (fullpel_search.inc): outputs stay as they are
   const int bx = __builtin_amdgcn_readfirstlane((int)blocks[bi].bx), by = __builtin_amdgcn_readfirstlane((int)blocks[bi].by);
   const int W = a.bw, H = a.bh, n_px = W * H;
   const T *sp = src.origin + (int64_t)frame * src.frame_stride + (int64_t)by * src.stride + bx;
@@ -281,7 +355,7 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
   const uint8_t *mask = masks ? masks + (size_t)bi * n_px : nullptr;
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
   CompoundEval<T> ce;
-  ce.init(sp, src.stride, rbase, ref.stride, pred, mask, W, H, a.invert_mask, a.bit_depth, lane);
+  ce.init(sp, src.stride, rbase, ref.stride, pred, mask, W, H, a.invert_mask, a.bit_depth, lane, bs.row_min, bs.col_min);
   auto sad_at = [&](int row, int col) -> uint32_t { return ce.sad(row, col); };   // get_mvpred_compound_sad: sdaf / msdf
   auto var_at = [&](int row, int col) -> int {   // get_mvpred_compound_var_cost: svaf / msvf at offset (0, 0) + mv_err_cost_
     return (int)ce.var(row, col) + var_cost(a, bs.ref_row, bs.ref_col, row * 8, col * 8);
@@ -289,19 +363,26 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
   const int start_row = min(max(bs.start_row, bs.row_min), bs.row_max), start_col = min(max(bs.start_col, bs.col_min), bs.col_max);   // clamp_fullmv
   const uint32_t start_sad = sad_at(start_row, start_col) + (uint32_t)sad_cost(a, frr, frc, start_row, start_col);   // (the same in every run)
   int second_row = -32768, second_col = -32768;   // MARK_MV_INVALID (av1_full_pixel_search, :1704-1707)
+  const int nsteps = __builtin_amdgcn_readfirstlane(S.num_search_steps);
   auto diamond = [&](int search_step, int *num00, int *orow, int *ocol) -> int {
-    const int tot_steps = S.num_search_steps - search_step;
+    // (the table lives in LDS: what is read from it arrives in a VGPR, and a search state derived from a VGPR is kept in the vector unit and
+    // walked under exec masks -- 7 700 scalar + 4 000 vector instructions per block, PMC.  v_readfirstlane / v_readlane keep row, col, the
+    // limits tests and the loop on the scalar unit; a stage's sites are one LDS read per lane, fetched by lane index)
+    const int tot_steps = nsteps - search_step;
     int row = start_row, col = start_col;
     *num00 = 0;
     uint32_t bestsad = start_sad;
     int is_off_center = 0;
-    int next_step_size = tot_steps > 2 ? S.radius[tot_steps - 2] : 1;
+    int next_step_size = tot_steps > 2 ? __builtin_amdgcn_readfirstlane(S.radius[tot_steps - 2]) : 1;
     for (int step = tot_steps - 1; step >= 0; --step) {
       int best_site = 0;
-      if (step > 0) next_step_size = S.radius[step - 1];
-      const int nper = S.searches_per_step[step];
+      if (step > 0) next_step_size = __builtin_amdgcn_readfirstlane(S.radius[step - 1]);
+      const int this_radius = __builtin_amdgcn_readfirstlane(S.radius[step]);
+      const int nper = __builtin_amdgcn_readfirstlane(S.searches_per_step[step]);
+      const int my_site = *reinterpret_cast<const int *>(&S.mv[step][lane < 17 ? lane : 0][0]);   // (row, col) of site `lane` as one dword
       for (int idx = 1; idx <= nper; ++idx) {
-        const int r = row + S.mv[step][idx][0], c = col + S.mv[step][idx][1];
+        const int site = __builtin_amdgcn_readlane(my_site, idx);
+        const int r = row + (int)(int16_t)(site & 0xffff), c = col + (site >> 16);
         if (c < bs.col_min || c > bs.col_max || r < bs.row_min || r > bs.row_max) continue;   // av1_is_fullmv_in_range
         uint32_t sad = sad_at(r, c);
         if (sad < bestsad) {
@@ -314,16 +395,19 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
       }
       if (best_site != 0) {
         second_row = row; second_col = col;
-        row += S.mv[step][best_site][0];
-        col += S.mv[step][best_site][1];
+        const int site = __builtin_amdgcn_readlane(my_site, best_site);
+        row += (int)(int16_t)(site & 0xffff);
+        col += site >> 16;
         is_off_center = 1;
       }
       if (is_off_center == 0) (*num00)++;
       if (best_site == 0) {
-        while (next_step_size == S.radius[step] && step > 2) {
+        int rad = this_radius;
+        while (next_step_size == rad && step > 2) {
           ++(*num00);
           --step;
-          next_step_size = S.radius[step - 1];
+          rad = __builtin_amdgcn_readfirstlane(S.radius[step]);
+          next_step_size = __builtin_amdgcn_readfirstlane(S.radius[step - 1]);
         }
       }
     }
@@ -334,7 +418,7 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
   int bestsme = diamond(step_param, &n, &tr, &tc);
   if (bestsme < INT_MAX) bestsme = var_at(tr, tc);
   int best_row = tr, best_col = tc;
-  const int further_steps = S.num_search_steps - 1 - step_param;
+  const int further_steps = nsteps - 1 - step_param;
   while (n < further_steps) {
     ++n;
     if (num00) {
@@ -383,10 +467,14 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
   const int lw = __builtin_ctz((unsigned)W), wm = W - 1;
   const bool keep = n_px <= 256 * kUnits;
   int ws_[kUnits][4], om_[kUnits][4];
+  // candidate pixels by 32-bit byte offset from the block at the window's top-left MV (see CompoundEval)
+  const char *base0 = reinterpret_cast<const char *>(rbase + (int64_t)bs.row_min * ref.stride + bs.col_min);
+  unsigned lo_[kUnits];
   if (keep) {
 #pragma unroll
     for (int k = 0; k < kUnits; ++k) {
       const int t = 4 * (k * 64 + lane);
+      lo_[k] = t < n_px ? (unsigned)(((t >> lw) * ref.stride + (t & wm)) * (int)sizeof(T)) : 0u;
       int4 a = make_int4(0, 0, 0, 0), b = a;
       if (t < n_px) { a = *reinterpret_cast<const int4 *>(wsrc + t); b = *reinterpret_cast<const int4 *>(omask + t); }
       ws_[k][0] = a.x; ws_[k][1] = a.y; ws_[k][2] = a.z; ws_[k][3] = a.w;
@@ -394,7 +482,8 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
     }
   }
   auto osad_at = [&](int row, int col) -> uint32_t {   // vfp->osdf: obmc_sad (sad_av1.c:163-180) + the bit-depth wrapper
-    const T *rp = rbase + (int64_t)row * ref.stride + col;
+    const unsigned off = (unsigned)(((row - bs.row_min) * ref.stride + (col - bs.col_min)) * (int)sizeof(T));
+    const T *rp = reinterpret_cast<const T *>(base0 + off);
     if (keep) {
       uint32_t acc = 0;
       int f[kUnits][4];
@@ -403,7 +492,7 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
         const int t = 4 * (k * 64 + lane);
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[k][i] = 0;
-        if (t < n_px) load_px4<T>(rp + (t >> lw) * ref.stride + (t & wm), f[k]);
+        if (k * 256 < n_px && t < n_px) load_px4<T>(reinterpret_cast<const T *>(base0 + (lo_[k] + off)), f[k]);
       }
 #pragma unroll
       for (int k = 0; k < kUnits; ++k)
@@ -434,17 +523,20 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
   auto in_range = [&](int r, int c) { return c >= bs.col_min && c <= bs.col_max && r >= bs.row_min && r <= bs.row_max; };
   const int start_row = min(max(bs.start_row, bs.row_min), bs.row_max), start_col = min(max(bs.start_col, bs.col_min), bs.col_max);
   int best_row, best_col, result;
+  const int nsteps = __builtin_amdgcn_readfirstlane(S.num_search_steps);
   if (!fast) {
     auto diamond = [&](int search_step, int *num00, int *orow, int *ocol) -> int {   // obmc_diamond_search_sad
-      const int tot_steps = S.num_search_steps - search_step;
+      const int tot_steps = nsteps - search_step;   // (table reads through v_readfirstlane / v_readlane: see compound_full_pixel_diamond_kernel)
       int row = start_row, col = start_col;
       *num00 = 0;
       int best_sad = (int)(osad_at(row, col) + (uint32_t)sad_cost(a, frr, frc, row, col));
       for (int step = tot_steps - 1; step >= 0; --step) {
         int best_site = 0;
-        const int nper = S.searches_per_step[step];
+        const int nper = __builtin_amdgcn_readfirstlane(S.searches_per_step[step]);
+        const int my_site = *reinterpret_cast<const int *>(&S.mv[step][lane < 17 ? lane : 0][0]);
         for (int idx = 1; idx <= nper; ++idx) {
-          const int r = row + S.mv[step][idx][0], c = col + S.mv[step][idx][1];
+          const int site = __builtin_amdgcn_readlane(my_site, idx);
+          const int r = row + (int)(int16_t)(site & 0xffff), c = col + (site >> 16);
           if (!in_range(r, c)) continue;
           int sad = (int)osad_at(r, c);   // (`int sad < int best_sad`: this function compares signed, mcomp.c:2206-2215)
           if (sad < best_sad) {
@@ -456,8 +548,9 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
           }
         }
         if (best_site != 0) {
-          row += S.mv[step][best_site][0];
-          col += S.mv[step][best_site][1];
+          const int site = __builtin_amdgcn_readlane(my_site, best_site);
+          row += (int)(int16_t)(site & 0xffff);
+          col += site >> 16;
         } else if (row == start_row && col == start_col) {   // best_address == init_ref
           (*num00)++;
         }
@@ -469,7 +562,7 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
     int bestsme = diamond(step_param, &n, &tr, &tc);
     if (bestsme < INT_MAX) bestsme = ovar_at(tr, tc);
     best_row = tr; best_col = tc;
-    const int further_steps = S.num_search_steps - 1 - step_param;
+    const int further_steps = nsteps - 1 - step_param;
     while (n < further_steps) {
       ++n;
       if (num00) {

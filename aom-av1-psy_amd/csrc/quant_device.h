@@ -163,6 +163,22 @@ template <int LPB> __device__ __forceinline__ int group_max(int v) {
 }
 
 
+// The lanes of a transform block (max(W, H) <= 64 adjacent lanes, a power of two) sit in ONE wavefront and a wavefront's LDS instructions
+// execute in program order: what one lane wrote is there for the block's other lanes as soon as the compiler keeps the accesses in order --
+// no s_barrier, the workgroup's other wavefronts (other blocks, private LDS regions) never wait for each other.
+#ifndef AOMHIP_TX_WAVE_SYNC
+#define AOMHIP_TX_WAVE_SYNC 1   // 0: workgroup barriers (A/B)
+#endif
+__device__ __forceinline__ void block_sync() {
+#if AOMHIP_TX_WAVE_SYNC
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+  __syncthreads();
+#endif
+}
+
 // QuantArgs of a parameter block (quant_kind 1: the av1_quantize_fp family)
 inline QuantArgs to_quant_args(const aomhip_quant_params *q, int quant_kind = 0) {
   QuantArgs a;

@@ -1007,11 +1007,12 @@ __global__ void joint_prepare_kernel(const aomhip_search_block *blocks, const in
   aomhip_search_block o = b;
   o.start_row = (int16_t)rawpel(cm[2 * id]); o.start_col = (int16_t)rawpel(cm[2 * id + 1]);   // get_fullmv_from_mv(&cur_mv[id])
   full_limits_ref(b, &o);   // av1_make_default_fullpel_ms_params: av1_set_mv_search_range(&mv_limits, ref_mv) on x->mv_limits
+  if (!live[i]) { o.row_min = 1; o.row_max = 0; }   // the block has left the loop: an empty window, the search kernels skip it
   full_list[i] = o;
   other_mv[2 * i] = cm[2 * !id]; other_mv[2 * i + 1] = cm[2 * !id + 1];
 }
 __global__ void joint_subpel_list_kernel(const aomhip_search_block *blocks, const int16_t *ref_mv, const int16_t *full_mv, int id, int n,
-                                         aomhip_search_block *out) {
+                                         const uint8_t *live, aomhip_search_block *out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   aomhip_search_block b = blocks[i];
@@ -1019,6 +1020,7 @@ __global__ void joint_subpel_list_kernel(const aomhip_search_block *blocks, cons
   aomhip_search_block o = b;
   o.start_row = (int16_t)(full_mv[2 * i] * 8); o.start_col = (int16_t)(full_mv[2 * i + 1] * 8);   // get_mv_from_fullmv
   subpel_limits_ref(b, &o);   // av1_set_subpel_mv_search_range(.., &x->mv_limits, ref_mv)
+  if (live && !live[i]) { o.row_min = 1; o.row_max = 0; }   // (skipped by the sub-pel kernel)
   out[i] = o;
 }
 // try_second (:621-623, :664-676): the sub-pel search is repeated from second_best_mv when that is valid, differs from best_mv and lies inside the
@@ -1032,6 +1034,7 @@ __global__ void joint_second_list_kernel(const aomhip_search_block *sub_list, co
   const bool differs = sr != full_mv[2 * i] || sc != full_mv[2 * i + 1];
   const bool use = !(sr == kInvalidMv && sc == kInvalidMv) && differs && sc * 8 >= o.col_min && sc * 8 <= o.col_max && sr * 8 >= o.row_min && sr * 8 <= o.row_max;
   if (use) { o.start_row = (int16_t)(sr * 8); o.start_col = (int16_t)(sc * 8); }
+  else { o.row_min = 1; o.row_max = 0; }   // no second start for this block (or it has left the loop: sub_list carries the mark): skipped
   use_second[i] = use;
   out[i] = o;
 }
@@ -1127,7 +1130,7 @@ static int joint_motion_search(aomhip_ctx *ctx, const aomhip_planes *src, const 
     if (rc != AOMHIP_OK) return rc;
     const bool second = full && allow_second_mv && !force_integer_mv;
     if (!force_integer_mv) {
-      hipLaunchKernelGGL(joint_subpel_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_ref_mv, i16(o_fmv), id, n, blk(o_sl));
+      hipLaunchKernelGGL(joint_subpel_list_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_ref_mv, i16(o_fmv), id, n, live, blk(o_sl));
       AOMHIP_LAUNCH_CHECK();
       rc = aomhip_compound_subpel_tree_batch(ctx, src, rid, frame, bw, bh, &sp, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_sl), n, w + o_pred, d_mask, id,
                                              i16(o_smv), u32(o_serr), i32(o_dist), u32(o_sse));

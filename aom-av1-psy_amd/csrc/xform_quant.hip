@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
       t[r * LSTRIDE + dc] = v;
     }
   }
-  __syncthreads();
+  block_sync();
 
   // ---- rows + quantise
   int my_eob = 0;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
     }
   }
   const bool fast = group_max<LPB>(amax) <= kSafeMax[tx_index_of(W, H)][tx_type & 15];
-  __syncthreads();
+  block_sync();
 
   // ---- 2. columns
   if (live && lane < W) {
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
       B[r * LSTRIDE + dc] = v;
     }
   }
-  __syncthreads();
+  block_sync();
 
   // ---- 3. rows + quantise
   int my_eob = 0;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
 #pragma unroll
     for (int c = 0; c < W; ++c) y[c] = B[r * LSTRIDE + c];
   }
-  __syncthreads();  // A (input) and B (tile) are dead from here: they become the output staging areas
+  block_sync();  // A (input) and B (tile) are dead from here: they become the output staging areas
   if (live && lane < KH) {
     fwd_1d_sel<W, C::cos_bit_row>(y, hk == 2 ? 1 : hk, fast);
     const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
     bssz = group_sum64<LPB>(bssz);
     if (live && lane == 0) block_err_store(err_out, bi, berr, bssz, err_shift);
   }
-  __syncthreads();
+  block_sync();
 
   // ---- 4. copy out, 16 bytes per lane per store
   if (live) {
