@@ -187,6 +187,9 @@ _protos = {
                                                     _vp, _vp, _vp, _vp]),
     "aomhip_quantize_b_adaptive_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, C.POINTER(QuantParams), _i, _vp, _vp, _vp]),
     "aomhip_inv_txfm_add_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _PP, _i]),
+    "aomhip_quantize_b_qm_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "aomhip_xform_quant_qm_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aomhip_subtract_xform_quant_qm_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_encode_inter_blocks_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "aomhip_deblock_plane": (C.c_int, [_vp, _PP, _i, _vp, _i, _i, _i]),
     "aomhip_cdef_luma_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
@@ -517,6 +520,21 @@ class Context:
     def inv_txfm_add_batch(self, d_dqcoeff, tx_size, d_blocks, n_blocks, grid_cols, tx_type, d_eob, dst, frame):
         check(lib.aomhip_inv_txfm_add_batch(self.h, d_dqcoeff, tx_size, d_blocks, n_blocks, grid_cols, tx_type, d_eob,
                                             C.byref(dst), frame), "aomhip_inv_txfm_add_batch")
+
+    def quantize_b_qm_batch(self, d_coeff, tx_size, d_blocks, n_blocks, tx_type, qparams, is_hbd, d_qm, d_iqm, d_qcoeff, d_dqcoeff, d_eob):
+        check(lib.aomhip_quantize_b_qm_batch(self.h, d_coeff, tx_size, d_blocks, n_blocks, tx_type, C.byref(qparams), int(is_hbd), d_qm, d_iqm,
+                                             d_qcoeff, d_dqcoeff, d_eob), "aomhip_quantize_b_qm_batch")
+
+    def xform_quant_qm_batch(self, d_residual, stride, tx_size, d_blocks, n_blocks, grid_cols, tx_type, qparams, is_hbd, d_qm, d_iqm, d_coeff, d_qcoeff,
+                             d_dqcoeff, d_eob):
+        check(lib.aomhip_xform_quant_qm_batch(self.h, d_residual, stride, tx_size, d_blocks, n_blocks, grid_cols, tx_type, C.byref(qparams), int(is_hbd),
+                                              d_qm, d_iqm, d_coeff, d_qcoeff, d_dqcoeff, d_eob), "aomhip_xform_quant_qm_batch")
+
+    def subtract_xform_quant_qm_batch(self, src, pred, frame, tx_size, d_blocks, n_blocks, grid_cols, tx_type, qparams, d_qm, d_iqm, d_coeff, d_qcoeff,
+                                      d_dqcoeff, d_eob):
+        check(lib.aomhip_subtract_xform_quant_qm_batch(self.h, C.byref(src), C.byref(pred), frame, tx_size, d_blocks, n_blocks, grid_cols, tx_type,
+                                                       C.byref(qparams), d_qm, d_iqm, d_coeff, d_qcoeff, d_dqcoeff, d_eob),
+              "aomhip_subtract_xform_quant_qm_batch")
 
     def encode_inter_blocks_batch(self, src, src_frame, ref, ref_frame, recon, recon_frame, bw, d_blocks, d_mv, n_blocks, qparams, d_qcoeff, d_dqcoeff,
                                   d_eob, filter_x=0, filter_y=0, tx_type=0):

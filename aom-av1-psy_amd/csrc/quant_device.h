@@ -105,6 +105,37 @@ __device__ __forceinline__ void quantize_one(int32_t v, int zb, int rd, int quan
   *dqout = (dq ^ sign) - sign;
 }
 
+// The same two helpers with quantisation matrices (qm_ptr / iqm_ptr non-NULL: aom_dsp/quantize.c:39,61-77 and :283,299-312), for one
+// coefficient: wt scales the dead-zone test and the level, iwt the dequantiser.  Literal 64-bit arithmetic (this is not the hot path:
+// enable_qm defaults to 0, av1/av1_cx_iface.c:246).  zb / rd arrive log-scaled like quantize_one's.
+template <bool HBD, int LS>
+__device__ __forceinline__ void quantize_one_qm(int32_t v, int zb, int rd, int quant, int qshift, int dequant, int wt, int iwt,
+                                                int32_t *qout, int32_t *dqout) {
+  constexpr int QM = 5;   // AOM_QM_BITS
+  const int sign = v >> 31;
+  const int a = (v ^ sign) - sign;
+  int q = 0;
+  if constexpr (!HBD) {
+    if (a * wt >= (zb << QM)) {
+      int64_t t = (int64_t)a + rd;
+      t = t > 32767 ? 32767 : t;   // clamp(.., INT16_MIN, INT16_MAX); a + rd >= 0
+      t *= wt;
+      q = (int)(((((t * quant) >> 16) + t) * qshift) >> (16 - LS + QM));
+    }
+  } else {
+    const int cw = (int)((uint32_t)v * (uint32_t)wt);   // `coeff_ptr[rc] * wt` in int
+    if (cw >= zb * (1 << QM) || cw <= -zb * (1 << QM)) {
+      const int64_t tw = ((int64_t)a + rd) * wt;
+      const int64_t t2 = ((tw * quant) >> 16) + tw;
+      q = (int)((t2 * qshift) >> (16 - LS + QM));
+    }
+  }
+  const int dqv = (dequant * iwt + (1 << (QM - 1))) >> QM;
+  const int adq = (int)((uint32_t)q * (uint32_t)dqv) >> LS;
+  *qout = (q ^ sign) - sign;
+  *dqout = (adq ^ sign) - sign;
+}
+
 // av1_scan_orders (scan.c:1666-): class 0 = zig-zag (all 2-D types), 1 = "mrow" (V_* types),
 // 2 = "mcol" (H_* types).  Position of coefficient (r, c) in a KW x KH scan.
 template <int KW, int KH> __device__ __forceinline__ int iscan_pos(int r, int c, int scan_class) {

@@ -673,6 +673,37 @@ __global__ __launch_bounds__(256) void quant_adaptive_kernel(const int32_t *__re
   if (lane == 0) eob[bi] = (uint16_t)last;
 }
 
+// Quantisation with matrices (qm_ptr / iqm_ptr non-NULL: aom_[highbd_]quantize_b_helper_c, aom_dsp/quantize.c:108-169,261-316) on already
+// materialised transform coefficients, like the adaptive form above: one wavefront per block, lane l owns coefficients l, l + 64, ... of the
+// (transposed) coefficient array, the matrices are indexed by the same position.  eob = 1 + the last scan position with a non-zero level.
+template <int KW, int KH, bool HBD, int LS>
+__global__ __launch_bounds__(256) void quant_qm_kernel(const int32_t *__restrict__ coeff, const aomhip_txb *__restrict__ blocks, int n_blocks,
+                                                       int uniform_type, QuantArgs qa, const uint8_t *__restrict__ qm,
+                                                       const uint8_t *__restrict__ iqm, int32_t *__restrict__ qcoeff,
+                                                       int32_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob) {
+  constexpr int NC = KW * KH;
+  const int lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (bi >= n_blocks) return;
+  const int tx_type = blocks ? blocks[bi].tx_type : uniform_type;
+  const int64_t off = blocks ? (int64_t)blocks[bi].out_offset : (int64_t)bi * NC;
+  const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
+  const int zb[2] = { (qa.zbin[0] + ((1 << LS) >> 1)) >> LS, (qa.zbin[1] + ((1 << LS) >> 1)) >> LS };
+  const int rd[2] = { (qa.round[0] + ((1 << LS) >> 1)) >> LS, (qa.round[1] + ((1 << LS) >> 1)) >> LS };
+  int last = 0;
+  for (int rc = lane; rc < NC; rc += 64) {
+    const int ac = rc != 0;
+    int32_t qv, dv;
+    quantize_one_qm<HBD, LS>(coeff[off + rc], zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.dequant[ac], qm ? (int)qm[rc] : 32,
+                             iqm ? (int)iqm[rc] : 32, &qv, &dv);
+    qcoeff[off + rc] = qv;
+    dqcoeff[off + rc] = dv;
+    if (qv) last = max(last, iscan_pos<KW, KH>(rc % KH, rc / KH, scan_class) + 1);   // transposed layout: rc = c * KH + r
+  }
+  last = group_max<64>(last);
+  if (lane == 0) eob[bi] = (uint16_t)last;
+}
+
 // aom_quantize_b* / aom_highbd_quantize_b* with the caller's own scan tables: what the rtcd-signature entry points
 // (aomhip_quantize_b ...) run -- those signatures carry `scan` / `iscan` pointers and a coefficient count instead of a
 // transform size and type.  The same quantize_one as the fused kernels; eob = 1 + max iscan[rc] over non-zero levels
@@ -975,6 +1006,72 @@ int aomhip_quantize_b_adaptive_batch(aomhip_ctx *ctx, const int32_t *d_coeff, in
 #undef AOMHIP_QA
   set_error("aomhip_quantize_b_adaptive_batch: no kernel for tx_size %d", tx_size);
   return AOMHIP_ERR_INVALID;
+}
+
+
+int aomhip_quantize_b_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
+                               int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd, const uint8_t *d_qm, const uint8_t *d_iqm,
+                               int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
+  if (!ctx || !d_coeff || !qparams || !d_qcoeff || !d_dqcoeff || !d_eob || tx_size < 0 || tx_size >= 19 || n_blocks < 0 ||
+      (!d_blocks && (uniform_tx_type < 0 || uniform_tx_type > 15))) {
+    set_error("aomhip_quantize_b_qm_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  if (int rc = validate_txb_list(ctx, d_blocks, n_blocks, tx_size, false, true)) return rc;
+  const QuantArgs qa = to_args(qparams);
+  const int w = kTxW[tx_size], h = kTxH[tx_size];
+  const int kw = w > 32 ? 32 : w, kh = h > 32 ? 32 : h;
+  const int ls = (w * h > 256) + (w * h > 1024);  // av1_get_tx_scale (av1/common/idct.c:24-28)
+  const dim3 grid((n_blocks + 3) / 4), block(256);
+#define AOMHIP_QM(KW_, KH_, LS_)                                                                                                   \
+  if (kw == KW_ && kh == KH_ && ls == LS_) {                                                                                       \
+    if (is_hbd)                                                                                                                    \
+      hipLaunchKernelGGL((quant_qm_kernel<KW_, KH_, true, LS_>), grid, block, 0, ctx->stream, d_coeff, d_blocks, n_blocks,          \
+                         uniform_tx_type, qa, d_qm, d_iqm, d_qcoeff, d_dqcoeff, d_eob);                                            \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((quant_qm_kernel<KW_, KH_, false, LS_>), grid, block, 0, ctx->stream, d_coeff, d_blocks, n_blocks,         \
+                         uniform_tx_type, qa, d_qm, d_iqm, d_qcoeff, d_dqcoeff, d_eob);                                            \
+    AOMHIP_LAUNCH_CHECK();                                                                                                         \
+    return AOMHIP_OK;                                                                                                              \
+  }
+  AOMHIP_QM(4, 4, 0) AOMHIP_QM(8, 8, 0) AOMHIP_QM(16, 16, 0) AOMHIP_QM(32, 32, 1) AOMHIP_QM(32, 32, 2)
+  AOMHIP_QM(4, 8, 0) AOMHIP_QM(8, 4, 0) AOMHIP_QM(8, 16, 0) AOMHIP_QM(16, 8, 0) AOMHIP_QM(16, 32, 1) AOMHIP_QM(32, 16, 1)
+  AOMHIP_QM(4, 16, 0) AOMHIP_QM(16, 4, 0) AOMHIP_QM(8, 32, 0) AOMHIP_QM(32, 8, 0)
+#undef AOMHIP_QM
+  set_error("aomhip_quantize_b_qm_batch: no kernel for tx_size %d", tx_size);
+  return AOMHIP_ERR_INVALID;
+}
+
+// av1_xform_quant with quantisation matrices: the forward transform by the fused kernel (its own flat-matrix levels are overwritten), then
+// the matrix quantiser on the coefficients it stored
+int aomhip_xform_quant_qm_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int tx_size, const aomhip_txb *d_blocks,
+                                int n_blocks, int grid_cols, int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd,
+                                const uint8_t *d_qm, const uint8_t *d_iqm, int32_t *d_coeff, int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
+  if (!d_coeff) {
+    set_error("aomhip_xform_quant_qm_batch: d_coeff is required (the matrix quantiser reads the transform coefficients from it)");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (int rc = aomhip_xform_quant_batch(ctx, d_residual, residual_stride, tx_size, d_blocks, n_blocks, grid_cols, uniform_tx_type, qparams, is_hbd, d_coeff,
+                                        d_qcoeff, d_dqcoeff, d_eob))
+    return rc;
+  // (grid mode: block i's coefficients are at i * NC, which is what the quantiser assumes without a list)
+  return aomhip_quantize_b_qm_batch(ctx, d_coeff, tx_size, d_blocks, n_blocks, uniform_tx_type, qparams, is_hbd, d_qm, d_iqm, d_qcoeff, d_dqcoeff, d_eob);
+}
+
+int aomhip_subtract_xform_quant_qm_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *pred, int frame, int tx_size,
+                                         const aomhip_txb *d_blocks, int n_blocks, int grid_cols, int uniform_tx_type, const aomhip_quant_params *qparams,
+                                         const uint8_t *d_qm, const uint8_t *d_iqm, int32_t *d_coeff, int32_t *d_qcoeff, int32_t *d_dqcoeff,
+                                         uint16_t *d_eob) {
+  if (!d_coeff || !src) {
+    set_error("aomhip_subtract_xform_quant_qm_batch: d_coeff is required (the matrix quantiser reads the transform coefficients from it)");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (int rc = aomhip_subtract_xform_quant_batch(ctx, src, pred, frame, tx_size, d_blocks, n_blocks, grid_cols, uniform_tx_type, qparams, d_coeff, d_qcoeff,
+                                                 d_dqcoeff, d_eob))
+    return rc;
+  return aomhip_quantize_b_qm_batch(ctx, d_coeff, tx_size, d_blocks, n_blocks, uniform_tx_type, qparams, src->bit_depth != 8, d_qm, d_iqm, d_qcoeff, d_dqcoeff,
+                                    d_eob);
 }
 
 

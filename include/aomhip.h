@@ -336,7 +336,7 @@ int aomhip_tx_max_eob(int tx_size);   /* av1_get_max_eob (av1/common/blockd.h:16
 /* av1_xform_quant (av1/encoder/encodemb.c:288-341) over a list of transform blocks of one TX_SIZE:
  * av1_fwd_txfm2d_WxH (av1_rtcd_defs.pl:355-399) on the int16 residual, then aom_quantize_b /
  * _32x32 / _64x64 (or aom_highbd_quantize_b* when is_hbd) chosen by av1_get_tx_scale exactly like
- * av1_quantize_b_facade (av1_quantize.c:302-372), quant matrices off (NULL qm pointers).
+ * av1_quantize_b_facade (av1_quantize.c:302-372), quant matrices off (NULL qm pointers; with matrices: the _qm_ entry points below).
  *   d_residual     device int16 samples, residual_stride elements per row
  *   d_blocks       device list, or NULL for "grid mode": block i is at
  *                  ((i % grid_cols) * W, (i / grid_cols) * H), all of type uniform_tx_type,
@@ -379,6 +379,28 @@ int aomhip_subtract_xform_quant_ex_batch(aomhip_ctx *ctx, const aomhip_planes *s
                                          int uniform_tx_type, const aomhip_quant_params *qparams, int quant_kind,
                                          int32_t *d_coeff, int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob,
                                          int64_t *d_block_error);
+
+/* Quantisation MATRICES (--enable-qm=1: qparam->qmatrix / iqmatrix non-NULL, av1/encoder/av1_quantize.c:302-372 -> aom_quantize_b_helper_c /
+ * aom_highbd_quantize_b_helper_c with qm_ptr / iqm_ptr, aom_dsp/quantize.c:108-169,261-316).  d_qm / d_iqm: the two matrices of this transform
+ * size in device memory, uint8, indexed by the coefficient's position in the reference layout like the coefficients -- what
+ * av1_qmatrix(&cm->quant_params, qmlevel, plane, tx_size) / av1_iqmatrix(..) return (av1/common/quant_common.c:230-275; the level tables stay with
+ * the host: they are bitstream-format data); either may be NULL (that matrix flat, 32).  One (d_qm, d_iqm) pair per call: the caller buckets its
+ * blocks by (plane, qmlevel) like it buckets them by transform size.
+ *   aomhip_quantize_b_qm_batch            on transform coefficients already in device memory (d_coeff of aomhip_xform_quant_batch), list or grid mode
+ *   aomhip_xform_quant_qm_batch           av1_xform_quant with matrices: the forward transform kernel, then the matrix quantiser (d_coeff REQUIRED:
+ *                                         it carries the coefficients between the two launches)
+ *   aomhip_subtract_xform_quant_qm_batch  the same from source and prediction planes
+ * The adaptive and fp quantiser families with matrices (av1_quantize.c:70-142) are not covered. */
+int aomhip_quantize_b_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
+                               int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd, const uint8_t *d_qm, const uint8_t *d_iqm,
+                               int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);
+int aomhip_xform_quant_qm_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int tx_size, const aomhip_txb *d_blocks,
+                                int n_blocks, int grid_cols, int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd,
+                                const uint8_t *d_qm, const uint8_t *d_iqm, int32_t *d_coeff, int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);
+int aomhip_subtract_xform_quant_qm_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *pred, int frame, int tx_size,
+                                         const aomhip_txb *d_blocks, int n_blocks, int grid_cols, int uniform_tx_type, const aomhip_quant_params *qparams,
+                                         const uint8_t *d_qm, const uint8_t *d_iqm, int32_t *d_coeff, int32_t *d_qcoeff, int32_t *d_dqcoeff,
+                                         uint16_t *d_eob);
 
 /* The adaptive quantiser (qparam->use_quant_b_adapt, av1/encoder/av1_quantize.c:309-341,453-):
  * aom_quantize_b_adaptive_helper_c / aom_highbd_quantize_b_adaptive_helper_c (aom_dsp/quantize.c:16-105,173-258;

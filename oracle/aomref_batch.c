@@ -67,6 +67,10 @@ void orc_quantize_fp(const int32_t *coeff, intptr_t n, const int16_t *round_fp, 
 static int g_quant_kind = 0; /* 0 quantize_b, 1 quantize_fp: set by orc_xform_quant_set_kind (tests only, single-threaded setup) */
 void orc_xform_quant_set_kind(int kind) { g_quant_kind = kind; }
 
+/* quantisation matrices of the following orc_xform_quant_batch calls (NULL, NULL: none): one (qm, iqm) pair for the batch's transform size */
+static const uint8_t *g_qm, *g_iqm;
+void orc_set_qm(const uint8_t *qm, const uint8_t *iqm) { g_qm = qm; g_iqm = iqm; }
+
 void orc_xform_quant_batch(const int16_t *residual, int stride, int tx_size, const orc_txb *blocks, int n,
                            int grid_cols, int uniform_type, const int16_t q[5][2], int is_hbd, int32_t *coeff,
                            int32_t *qcoeff, int32_t *dqcoeff, uint16_t *eob, int threads, int reps) {
@@ -91,7 +95,10 @@ void orc_xform_quant_batch(const int16_t *residual, int stride, int tx_size, con
     if (tt == ORC_TX_WHT) orc_fwht4x4(residual + (ptrdiff_t)by * stride + bx, full, stride);
     else orc_fwd_txfm2d(residual + (ptrdiff_t)by * stride + bx, full, stride, tx_size, tt, is_hbd ? 10 : 8);
     if (coeff) for (int k = 0; k < nc; ++k) coeff[off + k] = full[k];
-    if (g_quant_kind == 1)
+    if (g_qm && g_quant_kind != 1) {
+      if (is_hbd) orc_highbd_quantize_b_qm(full, nc, q[0], q[1], q[2], q[3], qcoeff + off, dqcoeff + off, q[4], &eob[i], scans[tt], log_scale, g_qm, g_iqm);
+      else orc_quantize_b_qm(full, nc, q[0], q[1], q[2], q[3], qcoeff + off, dqcoeff + off, q[4], &eob[i], scans[tt], log_scale, g_qm, g_iqm);
+    } else if (g_quant_kind == 1)
       orc_quantize_fp(full, nc, q[1], q[2], qcoeff + off, dqcoeff + off, q[4], &eob[i], scans[tt], log_scale, is_hbd);
     else if (is_hbd)
       orc_highbd_quantize_b(full, nc, q[0], q[1], q[2], q[3], qcoeff + off, dqcoeff + off, q[4], &eob[i], scans[tt],

@@ -14,9 +14,71 @@
 
 #include <string.h>
 
-#define QM_BITS 5 /* aom_dsp/quantize.h AOM_QM_BITS; qmatrix pointers are NULL on this path => wt = iwt = 32 */
+#define QM_BITS 5 /* aom_dsp/quantize.h AOM_QM_BITS; qmatrix pointers NULL => wt = iwt = 32 (the _qm forms take them) */
 
 static int rpot(int v, int n) { return (v + ((1 << n) >> 1)) >> n; } /* ROUND_POWER_OF_TWO */
+
+/* aom_quantize_b_helper_c (quantize.c:108-169) with its qm_ptr / iqm_ptr arguments (NULL: wt = iwt = 32).  The quantisation matrices are
+ * indexed by the coefficient's buffer position rc like the coefficients themselves.  PINNED with matrices by
+ * tests/golden/ref_eval_qm.npz (the helpers interpreted with the level 0 / 8 / 14 matrices of av1/common/quant_common.c). */
+void orc_quantize_b_qm(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
+                       const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
+                       const int16_t *dequant, uint16_t *eob, const int16_t *scan, int log_scale, const uint8_t *qm,
+                       const uint8_t *iqm) {
+  const int zb[2] = { rpot(zbin[0], log_scale), rpot(zbin[1], log_scale) };
+  int last = -1;
+  memset(qcoeff, 0, (size_t)n * sizeof(*qcoeff));
+  memset(dqcoeff, 0, (size_t)n * sizeof(*dqcoeff));
+  for (int i = 0; i < (int)n; ++i) {
+    const int rc = scan[i], ac = (rc != 0);
+    const int wt = qm ? qm[rc] : 1 << QM_BITS, iwt = iqm ? iqm[rc] : 1 << QM_BITS;
+    const int c = coeff[rc];
+    const int sign = c >> 31;
+    const int a = (c ^ sign) - sign;
+    if (a * wt < (zb[ac] << QM_BITS)) continue; /* pre-scan (:127-137) and :62 are the same test */
+    int64_t t = a + rpot(round[ac], log_scale);
+    if (t > INT16_MAX) t = INT16_MAX;
+    if (t < INT16_MIN) t = INT16_MIN;
+    t *= wt;
+    const int q = (int)(((((t * quant[ac]) >> 16) + t) * quant_shift[ac]) >> (16 - log_scale + QM_BITS));
+    qcoeff[rc] = (q ^ sign) - sign;
+    const int dq = (dequant[ac] * iwt + (1 << (QM_BITS - 1))) >> QM_BITS;
+    const int adq = (q * dq) >> log_scale;
+    dqcoeff[rc] = (adq ^ sign) - sign;
+    if (q) last = i;
+  }
+  *eob = (uint16_t)(last + 1);
+}
+
+/* aom_highbd_quantize_b_helper_c (quantize.c:261-316) with qm_ptr / iqm_ptr */
+void orc_highbd_quantize_b_qm(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
+                              const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
+                              const int16_t *dequant, uint16_t *eob, const int16_t *scan, int log_scale,
+                              const uint8_t *qm, const uint8_t *iqm) {
+  const int zb[2] = { rpot(zbin[0], log_scale), rpot(zbin[1], log_scale) };
+  int last = -1;
+  memset(qcoeff, 0, (size_t)n * sizeof(*qcoeff));
+  memset(dqcoeff, 0, (size_t)n * sizeof(*dqcoeff));
+  for (int i = 0; i < (int)n; ++i) {
+    const int rc = scan[i], ac = (rc != 0);
+    const int wt = qm ? qm[rc] : 1 << QM_BITS, iwt = iqm ? iqm[rc] : 1 << QM_BITS;
+    const int c = coeff[rc];
+    const int cw = (int)((uint32_t)c * (uint32_t)wt);
+    if (!(cw >= zb[ac] * (1 << QM_BITS) || cw <= -zb[ac] * (1 << QM_BITS))) continue;
+    const int sign = c >> 31;
+    const int a = (c ^ sign) - sign;
+    const int64_t t1 = a + rpot(round[ac], log_scale);
+    const int64_t tw = t1 * wt;
+    const int64_t t2 = ((tw * quant[ac]) >> 16) + tw;
+    const int q = (int)((t2 * quant_shift[ac]) >> (16 - log_scale + QM_BITS));
+    qcoeff[rc] = (q ^ sign) - sign;
+    const int dq = (dequant[ac] * iwt + (1 << (QM_BITS - 1))) >> QM_BITS;
+    const int adq = (int)((uint32_t)q * (uint32_t)dq) >> log_scale;
+    dqcoeff[rc] = (adq ^ sign) - sign;
+    if (q) last = i;
+  }
+  *eob = (uint16_t)(last + 1);
+}
 
 void orc_quantize_b(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
                     const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,

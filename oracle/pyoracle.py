@@ -414,10 +414,21 @@ def build_quantizer_y(bit_depth, qindex):
     return dict(zip(("zbin", "round", "quant", "quant_shift", "dequant"), t))
 
 
-def quantize_b(coeff, q, scan, iscan, log_scale, highbd=False):
+def quantize_b(coeff, q, scan, iscan, log_scale, highbd=False, qm=None, iqm=None):
+    """aom_[highbd_]quantize_b_helper_c; qm / iqm: uint8 quantisation matrices indexed like the coefficients (None: flat)."""
     coeff = np.ascontiguousarray(coeff, np.int32)
     qc, dq = np.zeros_like(coeff), np.zeros_like(coeff)
     eob = C.c_uint16()
+    if qm is not None or iqm is not None:
+        qm_ = np.ascontiguousarray(qm, np.uint8) if qm is not None else None
+        iqm_ = np.ascontiguousarray(iqm, np.uint8) if iqm is not None else None
+        f = lib.orc_highbd_quantize_b_qm if highbd else lib.orc_quantize_b_qm
+        f.restype = None
+        f(C.c_void_p(coeff.ctypes.data), C.c_ssize_t(coeff.size), *[C.c_void_p(np.ascontiguousarray(q[k], np.int16).ctypes.data) for k in ("zbin", "round", "quant", "quant_shift")],
+          C.c_void_p(qc.ctypes.data), C.c_void_p(dq.ctypes.data), C.c_void_p(np.ascontiguousarray(q["dequant"], np.int16).ctypes.data), C.byref(eob),
+          C.c_void_p(np.ascontiguousarray(scan, np.int16).ctypes.data), C.c_int(log_scale), C.c_void_p(qm_.ctypes.data if qm_ is not None else None),
+          C.c_void_p(iqm_.ctypes.data if iqm_ is not None else None))
+        return qc, dq, eob.value
     f = lib.orc_highbd_quantize_b if highbd else lib.orc_quantize_b
     f(coeff, coeff.size, q["zbin"], q["round"], q["quant"], q["quant_shift"], qc, dq, q["dequant"], C.byref(eob),
       np.ascontiguousarray(scan, np.int16), np.ascontiguousarray(iscan, np.int16), log_scale)
@@ -443,10 +454,19 @@ lib.orc_xform_quant_batch.argtypes = [_vp, _i, _i, _vp, _i, _i, _i, _i16, _i, _v
 
 
 def xform_quant_batch(residual, tx_size, blocks, n, grid_cols, tx_type, q, is_hbd, total_coeffs, want_coeff=True,
-                      threads=1, reps=1):
+                      threads=1, reps=1, qm=None, iqm=None):
     """residual: int16 2-D array; blocks: structured array (x,y,out_offset,tx_type) or None (grid mode);
-    q: dict from build_quantizer_y.  -> (coeff|None, qcoeff, dqcoeff, eob)"""
+    q: dict from build_quantizer_y; qm / iqm: the quantisation matrices of this transform size (uint8, coefficient order) or None.
+    -> (coeff|None, qcoeff, dqcoeff, eob)"""
     residual = np.ascontiguousarray(residual, np.int16)
+    if qm is not None:
+        qm, iqm = np.ascontiguousarray(qm, np.uint8), np.ascontiguousarray(iqm, np.uint8)
+        lib.orc_set_qm.restype = None
+        lib.orc_set_qm(C.c_void_p(qm.ctypes.data), C.c_void_p(iqm.ctypes.data))
+        try:
+            return xform_quant_batch(residual, tx_size, blocks, n, grid_cols, tx_type, q, is_hbd, total_coeffs, want_coeff, threads, reps)
+        finally:
+            lib.orc_set_qm(None, None)
     qt = np.ascontiguousarray(np.stack([q[k] for k in ("zbin", "round", "quant", "quant_shift", "dequant")]), np.int16)
     coeff = np.zeros(total_coeffs, np.int32) if want_coeff else None
     qc, dq = np.zeros(total_coeffs, np.int32), np.zeros(total_coeffs, np.int32)
