@@ -54,7 +54,8 @@ __global__ __launch_bounds__(kThreads) void tf_apply_kernel(TfApplyArgs a) {
   __shared__ uint16_t s_pred[kMb * kMb];
   __shared__ uint32_t s_sq[kMb * kMb];          // square_diff of the current plane
   __shared__ uint32_t s_lsum[kMb * kMb];        // luma_sse_sum (chroma planes)
-  __shared__ uint16_t s_self[kMb * kMb];        // the frame-to-filter's own block of the current plane
+  __shared__ uint32_t s_hs[kMb * kMb];          // the window sum's row pass
+  __shared__ uint16_t s_self3[kMb * kMb + 2 * (kMb * kMb)];   // the frame-to-filter's own block of every plane (chroma at most 32 x 32 each)
   __shared__ unsigned long long s_red[kThreads / 64];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
@@ -76,6 +77,20 @@ __global__ __launch_bounds__(kThreads) void tf_apply_kernel(TfApplyArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) accum[p][j] = count[p][j] = 0;
 
+  // the frame-to-filter's own pixels of every plane's block: the same for every window frame, staged once
+  for (int p = 0; p < a.num_planes; ++p) {
+    const int sx = p ? a.ss_x : 0, sy = p ? a.ss_y : 0;
+    const int lw = 5 - sx, w = 1 << lw, npix = (kMb >> sy) << lw;
+    const int plane_y = (kMb * mb_row) >> sy, plane_x = (kMb * mb_col) >> sx;
+    const T *self_org = static_cast<const T *>(a.frames[p]) + (int64_t)a.filter_frame * a.frame_stride[p] + (int64_t)a.border[p] * a.stride[p] + a.border[p];
+    for (int i = tid; i < npix; i += kThreads)
+      s_self3[p * (kMb * kMb) + i] = (uint16_t)self_org[(int64_t)(plane_y + (i >> lw)) * a.stride[p] + plane_x + (i & (w - 1))];
+  }
+  __syncthreads();
+
+  // Barriers per (frame, plane): after the staging, after the horizontal stage (only when some sub-block needs it), after predictor +
+  // squared difference, after the window sum's row pass.  Nothing an early phase writes is read by the previous iteration's last phase
+  // (that one reads s_pred, s_hs, s_lsum: rewritten two or more barriers later), so no barrier separates two iterations.
   for (int f = 0; f < a.n_frames; ++f) {
     if (!((a.present_mask >> f) & 1u)) continue;
     const bool self = f == a.filter_frame;
@@ -94,18 +109,19 @@ __global__ __launch_bounds__(kThreads) void tf_apply_kernel(TfApplyArgs a) {
       d_factor[s] = df > 1.0 ? df : 1.0;
       block_error[s] = self ? 0.0 : (double)msep[s];
     }
+    // (block constants of the weight: the same operation on the same operands as the reference's per-pixel expression, done once)
+    double be_inv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) be_inv[s] = __dmul_rn(block_error[s], a.inv_factor);
     for (int p = 0; p < a.num_planes; ++p) {
       const int sx = p ? a.ss_x : 0, sy = p ? a.ss_y : 0;
-      const int h = kMb >> sy, w = kMb >> sx, npix = h * w;
-      const int sub_h = h >> 1, sub_w = w >> 1;
+      // every extent is a power of two: rows / columns by shift and mask (h, w runtime values made every `/ w`, `% reg_w` ... a 20-30
+      // instruction division sequence -- most of this kernel's instructions, profiles/r05_tf_apply.md)
+      const int lw = 5 - sx, lh = 5 - sy, h = 1 << lh, w = 1 << lw, npix = h * w;
+      const int sub_h = h >> 1, sub_w = w >> 1, lsw = lw - 1;
       const int plane_y = (kMb * mb_row) >> sy, plane_x = (kMb * mb_col) >> sx;
-      const T *self_org = static_cast<const T *>(a.frames[p]) + (int64_t)a.filter_frame * a.frame_stride[p] + (int64_t)a.border[p] * a.stride[p] + a.border[p];
-      __syncthreads();  // (the previous plane / frame is done with the shared arrays)
-      // the frame-to-filter's own pixels of this plane's block
-      for (int i = tid; i < npix; i += kThreads)
-        s_self[i] = (uint16_t)self_org[(int64_t)(plane_y + i / w) * a.stride[p] + plane_x + i % w];
+      const uint16_t *s_self = s_self3 + p * (kMb * kMb);
       if (self) {  // tf_apply_temporal_filter_self: weight TF_WEIGHT_SCALE everywhere
-        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int i = tid + kThreads * j;
@@ -123,28 +139,55 @@ __global__ __launch_bounds__(kThreads) void tf_apply_kernel(TfApplyArgs a) {
       }
       const int reg_h = sub_h + kTaps - 1, reg_w = sub_w + kTaps - 1;
       const int ymin = -a.border[p], ymax = a.rows_alloc[p] - a.border[p] - 1, xmin = -a.border[p], xmax = a.stride[p] - a.border[p] - 1;
-      for (int q = tid; q < 4 * reg_h * reg_w; q += kThreads) {
-        const int s = q / (reg_h * reg_w), r = (q / reg_w) % reg_h, c = q % reg_w;
-        int y = (pos_y[s] >> 4) - kFo + r, x = (pos_x[s] >> 4) - kFo + c;
-        y = min(max(y, ymin), ymax); x = min(max(x, xmin), xmax);  // (memory safety only: MVs inside the mv limits never get here)
-        s_src[s][r][c] = (uint16_t)ref_org[(int64_t)y * a.stride[p] + x];
-      }
-      __syncthreads();
-      // horizontal stage of the 2-D case (sx != 0 && sy != 0): im rows -5 .. sub_h + 5
-      for (int q = tid; q < 4 * reg_h * sub_w; q += kThreads) {
-        const int s = q / (reg_h * sub_w), r = (q / sub_w) % reg_h, c = q % sub_w;
-        const int fxq = pos_x[s] & 15, fyq = pos_y[s] & 15;
-        if (fxq && fyq) {
-          int sum = 1 << (tbd + 6);
+      {  // a pass = 8 rows x 32 columns of one sub-block's region (reg_w <= 27)
+        const int c = tid & 31, r0 = tid >> 5;
 #pragma unroll
-          for (int k = 0; k < kTaps; ++k) sum += k_interp12[fxq][k] * (int)s_src[s][r][c + k];
-          s_im[s][r][c] = (int16_t)rpot(sum, round_0);
+        for (int s = 0; s < 4; ++s) {
+          const int by0 = (pos_y[s] >> 4) - kFo, bx0 = (pos_x[s] >> 4) - kFo;
+          const int x = min(max(bx0 + c, xmin), xmax);   // (memory safety only: MVs inside the mv limits never get here)
+          for (int r = r0; r < reg_h; r += 8) {
+            const int y = min(max(by0 + r, ymin), ymax);
+            if (c < reg_w) s_src[s][r][c] = (uint16_t)ref_org[(int64_t)y * a.stride[p] + x];
+          }
         }
       }
       __syncthreads();
+      // horizontal stage of the 2-D case (both fractions non-zero): im rows -5 .. sub_h + 5
+      bool any_2d = false;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) any_2d = any_2d || ((pos_x[s] & 15) && (pos_y[s] & 15));
+      if (any_2d) {   // (uniform over the workgroup: the barrier below is taken by all or by none)
+        const int c = tid & (sub_w - 1), r0 = tid >> lsw, rpp = kThreads >> lsw;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int fxq = pos_x[s] & 15, fyq = pos_y[s] & 15;
+          if (fxq && fyq) {   // (uniform over the workgroup)
+            int tap[kTaps];
+#pragma unroll
+            for (int k = 0; k < kTaps; ++k) tap[k] = k_interp12[fxq][k];
+            for (int r = r0; r < reg_h; r += rpp) {
+              int sum = 1 << (tbd + 6);
+#pragma unroll
+              for (int k = 0; k < kTaps; ++k) sum += tap[k] * (int)s_src[s][r][c + k];
+              s_im[s][r][c] = (int16_t)rpot(sum, round_0);
+            }
+          }
+        }
+        __syncthreads();
+      }
+      if (p == 1) {  // compute_luma_sq_error_sum: from the LUMA plane's square_diff (still in s_sq), once for both chroma planes
+        for (int q = tid; q < npix; q += kThreads) {
+          const int i = q >> lw, j = q & (w - 1);
+          uint32_t t = 0;
+          for (int ii = 0; ii < (1 << sy); ++ii)
+            for (int jj = 0; jj < (1 << sx); ++jj) t += s_sq[(((i << sy) + ii) << (lw + sx)) + (j << sx) + jj];
+          s_lsum[q] = t;
+        }
+        __syncthreads();   // (s_sq is overwritten below)
+      }
       for (int q = tid; q < npix; q += kThreads) {
-        const int i = q / w, j = q % w;
-        const int s = (i >= sub_h) * 2 + (j >= sub_w), r = i - (s >> 1) * sub_h, c = j - (s & 1) * sub_w;
+        const int i = q >> lw, j = q & (w - 1);
+        const int s = (i >= sub_h) * 2 + (j >= sub_w), r = i & (sub_h - 1), c = j & (sub_w - 1);
         const int fxq = pos_x[s] & 15, fyq = pos_y[s] & 15;
         int v;
         if (!fxq && !fyq) {
@@ -171,42 +214,33 @@ __global__ __launch_bounds__(kThreads) void tf_apply_kernel(TfApplyArgs a) {
         }
         v = min(max(v, 0), pix_max);
         s_pred[q] = (uint16_t)v;
-      }
-      __syncthreads();
-      // ---- av1_apply_temporal_filter_c for this plane
-      if (p == 1) {  // compute_luma_sq_error_sum: from the LUMA plane's square_diff (still in s_sq), once for both chroma planes
-        for (int q = tid; q < npix; q += kThreads) {
-          const int i = q / w, j = q % w;
-          uint32_t t = 0;
-          for (int ii = 0; ii < (1 << sy); ++ii)
-            for (int jj = 0; jj < (1 << sx); ++jj) t += s_sq[((i << sy) + ii) * (w << sx) + (j << sx) + jj];
-          s_lsum[q] = t;
-        }
-        __syncthreads();
-      }
-      for (int q = tid; q < npix; q += kThreads) {
-        const int d = (int)s_self[q] - (int)s_pred[q];
+        // ---- av1_apply_temporal_filter_c for this plane: compute_square_diff of the pixel this lane just predicted
+        const int d = (int)s_self[q] - v;
         s_sq[q] = (uint32_t)__mul24(d, d);
       }
       __syncthreads();
+      // the 5 x 5 window sum (coordinates clamped to the block) as a row pass and a column pass: sum over rows of (sum over columns), the
+      // same 25 terms; a term is < 2^24 (12-bit difference squared), 25 of them + the 4 luma terms of a chroma pixel < 2^29: 32-bit sums
+      for (int q = tid; q < npix; q += kThreads) {
+        const int i = q >> lw, j = q & (w - 1);
+        const uint32_t *row = s_sq + (i << lw);
+        s_hs[q] = row[max(j - 2, 0)] + row[max(j - 1, 0)] + row[j] + row[min(j + 1, w - 1)] + row[min(j + 2, w - 1)];
+      }
+      __syncthreads();
       const double inv_num_ref_pixels = __ddiv_rn(1.0, (double)(25 + (p ? (1 << (sx + sy)) : 0)));
+      const int err_shift = a.bd > 8 ? (a.bd - 8) * 2 : 0;
 #pragma unroll
       for (int jq = 0; jq < 4; ++jq) {
         const int q = tid + kThreads * jq;
         if (q < npix) {
-          const int i = q / w, j = q % w;
-          unsigned long long sum = 0;
-#pragma unroll
-          for (int wi = -2; wi <= 2; ++wi) {
-            const int y = min(max(i + wi, 0), h - 1);
-#pragma unroll
-            for (int wj = -2; wj <= 2; ++wj) sum += s_sq[y * w + min(max(j + wj, 0), w - 1)];
-          }
+          const int i = q >> lw, j = q & (w - 1);
+          uint32_t sum = s_hs[(max(i - 2, 0) << lw) + j] + s_hs[(max(i - 1, 0) << lw) + j] + s_hs[q] + s_hs[(min(i + 1, h - 1) << lw) + j] +
+                         s_hs[(min(i + 2, h - 1) << lw) + j];
           if (p) sum += s_lsum[q];
-          if (a.bd > 8) sum >>= ((a.bd - 8) * 2);
+          sum >>= err_shift;
           const double window_error = __dmul_rn((double)sum, inv_num_ref_pixels);
-          const int sidx = (i >= h / 2) * 2 + (j >= w / 2);
-          const double combined = __dadd_rn(__dmul_rn(a.weight_factor, window_error), __dmul_rn(block_error[sidx], a.inv_factor));
+          const int sidx = (i >= sub_h) * 2 + (j >= sub_w);
+          const double combined = __dadd_rn(__dmul_rn(a.weight_factor, window_error), be_inv[sidx]);
           double scaled = __dmul_rn(__dmul_rn(combined, d_factor[sidx]), a.decay_factor[p]);
           scaled = scaled < 7.0 ? scaled : 7.0;
           const int weight = (int)__dmul_rn(exp(-scaled), 1000.0);
@@ -220,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void tf_apply_kernel(TfApplyArgs a) {
   unsigned long long sse = 0;
   for (int p = 0; p < a.num_planes; ++p) {
     const int sx = p ? a.ss_x : 0, sy = p ? a.ss_y : 0;
-    const int h = kMb >> sy, w = kMb >> sx, npix = h * w;
+    const int lw = 5 - sx, h = kMb >> sy, w = kMb >> sx, npix = h * w;
     const int plane_y = (kMb * mb_row) >> sy, plane_x = (kMb * mb_col) >> sx;
     T *out_org = static_cast<T *>(a.out[p]) + (int64_t)a.out_frame * a.out_frame_stride[p] + (int64_t)a.out_border[p] * a.out_stride[p] + a.out_border[p];
     const T *self_org = static_cast<const T *>(a.frames[p]) + (int64_t)a.filter_frame * a.frame_stride[p] + (int64_t)a.border[p] * a.stride[p] + a.border[p];
@@ -230,10 +264,10 @@ __global__ __launch_bounds__(kThreads) void tf_apply_kernel(TfApplyArgs a) {
       if (q < npix) {
         const uint32_t c = count[p][j];
         const uint32_t v = c ? (accum[p][j] + (c >> 1)) / c : 0u;
-        const int64_t o = (int64_t)(plane_y + q / w) * a.out_stride[p] + plane_x + q % w;
+        const int64_t o = (int64_t)(plane_y + (q >> lw)) * a.out_stride[p] + plane_x + (q & (w - 1));
         out_org[o] = (T)v;
         if (p == 0 && a.diff) {
-          const int d = (int)self_org[(int64_t)(plane_y + q / w) * a.stride[p] + plane_x + q % w] - (int)v;
+          const int d = (int)self_org[(int64_t)(plane_y + (q >> lw)) * a.stride[p] + plane_x + (q & (w - 1))] - (int)v;
           sse += (unsigned)__mul24(d, d);
         }
       }
