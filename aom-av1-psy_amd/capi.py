@@ -245,6 +245,7 @@ _protos = {
     "aomhip_graph_launch": (C.c_int, [_vp, _vp]),
     "aomhip_graph_destroy": (C.c_int, [_vp]),
     "aomhip_first_pass_inter_frame": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aomhip_tpl_inter_estimation_batch": (C.c_int, [_vp, _PP, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_motion_estimation_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_tf_default_params": (None, [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aomhip_tf_block_list": (C.c_int, [_i, _i, _i, _vp]),
@@ -406,6 +407,14 @@ class Context:
         check(lib.aomhip_motion_estimation_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(full), C.byref(sub), use_cost_list, d_mvjcost,
                                                  d_mvcost_row, d_mvcost_col, d_blocks, n, d_mv, d_err, d_dist, d_sse, d_full_mv),
               "aomhip_motion_estimation_batch")
+
+    def tpl_inter_estimation_batch(self, src, refs, frame, bw, full, sub, use_cost_list, prune_starting_mv, d_blocks, d_center_mvs, d_center_counts, n,
+                                   d_best_mv, d_pred_error, d_best_rf, d_best_cost, d_mvjcost=None, d_mvcost_row=None, d_mvcost_col=None):
+        """The inter leg of tpl_model.c's mode_estimation for independent blocks (aomhip.h); refs: list of plane rings."""
+        arr = (C.POINTER(Planes) * len(refs))(*[C.pointer(r) for r in refs])
+        check(lib.aomhip_tpl_inter_estimation_batch(self.h, C.byref(src), arr, len(refs), frame, bw, C.byref(full), C.byref(sub), use_cost_list,
+                                                    prune_starting_mv, d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, d_center_mvs, d_center_counts, n,
+                                                    d_best_mv, d_pred_error, d_best_rf, d_best_cost), "aomhip_tpl_inter_estimation_batch")
 
     def tf_motion_search_frames(self, frames, filter_frame, params, d_blocks, n_blocks, d_mvs, d_mses, d_ref_mv=None, frame_present=None):
         fp = None if frame_present is None else np.ascontiguousarray(frame_present, np.uint8)

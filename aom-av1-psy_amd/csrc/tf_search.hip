@@ -405,6 +405,7 @@ __global__ void me_full_list_kernel(const aomhip_search_block *blocks, int n, ao
   aomhip_search_block o = b;
   o.start_row = (int16_t)rawpel(b.ref_row); o.start_col = (int16_t)rawpel(b.ref_col);  // get_fullmv_from_mv(&center_mv)
   full_limits_ref(b, &o);
+  if (b.row_min > b.row_max) { o.row_min = 1; o.row_max = 0; }   // an entry the caller wants skipped stays skipped (fullpel_search.inc)
   out[i] = o;
 }
 __global__ void me_subpel_list_kernel(const aomhip_search_block *blocks, const int16_t *full_mv, int n, aomhip_search_block *out) {
@@ -414,6 +415,7 @@ __global__ void me_subpel_list_kernel(const aomhip_search_block *blocks, const i
   aomhip_search_block o = b;
   o.start_row = (int16_t)(full_mv[2 * i] * 8); o.start_col = (int16_t)(full_mv[2 * i + 1] * 8);  // get_mv_from_fullmv
   subpel_limits_ref(b, &o);
+  if (b.row_min > b.row_max) { o.row_min = 1; o.row_max = 0; }
   out[i] = o;
 }
 }  // namespace
@@ -1268,6 +1270,208 @@ extern "C" int aomhip_compound_single_motion_search_batch(aomhip_ctx *ctx, const
   }
   hipLaunchKernelGGL(csingle_finish_kernel, dim3(g), dim3(256), 0, ctx->stream, n, force_integer_mv, i16(o_fmv), i32(o_fvar), i16(o_smv), u32(o_serr), d_ref_mv,
                      d_mvjcost, d_mvcost_row, d_mvcost_col, d_this_mv, d_rate_mv, d_bestsme);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+
+// ---- The inter leg of tpl_model.c's mode_estimation (av1/encoder/tpl_model.c:620-770) for blocks whose centre-MV candidates the caller has
+// gathered (the candidates come from the TPL stats of the blocks above / left / above-right, :652-683: a raster dependency the host walks,
+// anti-diagonal by anti-diagonal; a batch = blocks that do not depend on each other).  Per block and reference frame:
+//   prune_starting_mv (:706-731): the SAD of every candidate at its clamped full-pel position, the candidates ranked by it (qsort with
+//       compare_sad, :308-315; ties keep their order: glibc's qsort is a merge sort), the count cut to 4 - prune_starting_mv and once more
+//       when the last SAD is more than 20 % above the one before it,
+//   motion_estimation (:248-301) from every remaining candidate, the first smallest error wins (:733-743),
+//   av1_enc_build_one_inter_predictor at the winner with EIGHTTAP_REGULAR (:748-757), tpl_get_satd_cost (:199-212): residual, DCT_DCT of the
+//       block's size (av1_quick_txfm with use_hadamard 0), aom_satd = the sum of the coefficients' magnitudes; pred_error = max(1, cost),
+// then the reference with the smallest cost (first one on ties, :759-765).
+namespace aomhip {
+namespace {
+constexpr int kTplCands = 4;
+__global__ void tpl_center_cand_kernel(const aomhip_search_block *blocks, const int16_t *centers, const uint8_t *counts, int n, int ref, int n_refs,
+                                       aomhip_sad_cand *out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * kTplCands) return;
+  const int i = t / kTplCands, k = t % kTplCands;
+  const aomhip_search_block b = blocks[i];
+  const int cnt = counts[i * n_refs + ref];
+  const int16_t *c = centers + ((size_t)(i * n_refs + ref) * kTplCands + (k < cnt ? k : 0)) * 2;
+  int row = rawpel(c[0]), col = rawpel(c[1]);                       // get_fullmv_from_mv
+  row = min(max(row, (int)b.row_min), (int)b.row_max);              // clamp_fullmv(&mv, &x->mv_limits)
+  col = min(max(col, (int)b.col_min), (int)b.col_max);
+  out[t] = aomhip_sad_cand{ b.bx, b.by, (int16_t)(b.bx + col), (int16_t)(b.by + row) };
+}
+// the ranking and the two cuts; writes one motion_estimation entry per (block, slot): ref_mv = the centre MV, raw limits, or the skip mark
+__global__ void tpl_prune_kernel(const aomhip_search_block *blocks, const int16_t *centers, const uint8_t *counts, const uint32_t *sads, int n, int ref,
+                                 int n_refs, int prune, aomhip_search_block *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const aomhip_search_block b = blocks[i];
+  int cnt = counts[i * n_refs + ref];   // 0: this reference does not exist for the block (:633-637): nothing is searched
+  cnt = cnt > kTplCands ? kTplCands : cnt;
+  int order[kTplCands] = { 0, 1, 2, 3 };
+  if (prune) {
+    int sad[kTplCands];
+    for (int k = 0; k < kTplCands; ++k) sad[k] = k < cnt ? (int)sads[i * kTplCands + k] : INT_MAX;
+    if (cnt > 1) {   // insertion sort: stable, like the merge sort behind qsort
+      for (int a = 1; a < cnt; ++a) {
+        const int o = order[a], v = sad[o];
+        int j = a - 1;
+        while (j >= 0 && sad[order[j]] > v) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = o;
+      }
+    }
+    cnt = min(4 - prune, cnt);   // (refmv_count = AOMMIN(4 - prune_starting_mv, refmv_count))
+    if (cnt > 1) {
+      const int last = sad[order[cnt - 1]], prev = sad[order[cnt - 2]];
+      if ((last - prev) * 5 > prev) --cnt;
+    }
+  }
+  for (int k = 0; k < kTplCands; ++k) {
+    aomhip_search_block o = b;
+    if (k < cnt) {
+      const int16_t *c = centers + ((size_t)(i * n_refs + ref) * kTplCands + order[k]) * 2;
+      o.ref_row = c[0]; o.ref_col = c[1];
+    } else {
+      o.row_min = 1; o.row_max = 0;   // not searched
+    }
+    out[i * kTplCands + k] = o;
+  }
+}
+__global__ void tpl_best_cand_kernel(const aomhip_search_block *entries, const int16_t *mvs, const uint32_t *errs, int n, int16_t *best_mv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t best = 0xFFFFFFFFu;   // bestsme = UINT32_MAX; best_rfidx_mv = { 0 }
+  int r = 0, c = 0, any = 0;
+  for (int k = 0; k < kTplCands; ++k) {
+    const int e = i * kTplCands + k;
+    if (entries[e].row_min > entries[e].row_max) continue;
+    any = 1;
+    if (errs[e] < best) { best = errs[e]; r = mvs[2 * e]; c = mvs[2 * e + 1]; }
+  }
+  if (!any) r = c = -32768;   // INVALID_MV: the reference does not exist for this block
+  best_mv[2 * i] = (int16_t)r; best_mv[2 * i + 1] = (int16_t)c;
+}
+template <typename T>
+__global__ void tpl_residual_kernel(PlaneView<T> src, int frame, const aomhip_search_block *blocks, const T *pred, int n, int bw, int bh, int16_t *res) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int px = bw * bh;
+  if (t >= (int64_t)n * px) return;
+  const int i = (int)(t / px), q = (int)(t % px), y = q / bw, x = q % bw;
+  const T *sp = src.origin + (int64_t)frame * src.frame_stride + (int64_t)(blocks[i].by + y) * src.stride + blocks[i].bx + x;
+  res[t] = (int16_t)((int)*sp - (int)pred[t]);   // av1_subtract_block; block i = rows i * bh .. of a bw-wide residual plane
+}
+__global__ void tpl_satd_kernel(const int32_t *coeff, const uint8_t *counts, int n, int nc, int ref, int n_refs, int32_t *raw_cost, int32_t *pred_error) {
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (wave >= n) return;
+  int acc = 0;   // aom_satd_c / aom_highbd_satd_c: int satd += abs(coeff[i])
+  for (int k = lane; k < nc; k += 64) { const int v = coeff[(size_t)wave * nc + k]; acc += v < 0 ? -v : v; }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
+  if (lane == 0) {
+    const bool have = counts[wave * n_refs + ref] != 0;
+    raw_cost[wave * n_refs + ref] = have ? acc : INT_MAX;                    // inter_cost: what the references are compared by
+    pred_error[wave * n_refs + ref] = have ? (acc > 1 ? acc : 1) : INT_MAX;   // tpl_stats->pred_error = AOMMAX(1, inter_cost)
+  }
+}
+__global__ void tpl_best_ref_kernel(const int32_t *raw_cost, const uint8_t *counts, int n, int n_refs, int8_t *best_rf, int32_t *best_cost) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int best = INT_MAX, rf = -1;   // best_inter_cost = INT32_MAX, best_rf_idx = -1
+  for (int r = 0; r < n_refs; ++r) {
+    if (!counts[i * n_refs + r]) continue;
+    const int c = raw_cost[i * n_refs + r];
+    if (c < best) { best = c; rf = r; }   // (inter_cost < best_inter_cost: the first smallest)
+  }
+  best_rf[i] = (int8_t)rf;
+  best_cost[i] = best;
+}
+}  // namespace
+}  // namespace aomhip
+
+extern "C" int aomhip_tpl_inter_estimation_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *const *refs, int n_refs, int frame, int bw,
+                                                 const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list,
+                                                 int prune_starting_mv, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                                 const aomhip_search_block *d_blocks, const int16_t *d_center_mvs, const uint8_t *d_center_counts, int n,
+                                                 int16_t *d_best_mv, int32_t *d_pred_error, int8_t *d_best_rf_idx, int32_t *d_best_inter_cost) {
+  const int tx_size = bw == 8 ? 1 : bw == 16 ? 2 : bw == 32 ? 3 : -1;
+  if (!ctx || !src || !refs || n_refs < 1 || n_refs > 7 || !full || !sub || n < 0 || tx_size < 0 || prune_starting_mv < 0 || prune_starting_mv > 3 ||
+      (n > 0 && (!d_blocks || !d_center_mvs || !d_center_counts || !d_best_mv || !d_pred_error || !d_best_rf_idx || !d_best_inter_cost))) {
+    set_error("aomhip_tpl_inter_estimation_batch: invalid argument (square blocks of 8, 16 or 32; 1 .. 7 references)");
+    return AOMHIP_ERR_INVALID;
+  }
+  for (int r = 0; r < n_refs; ++r)
+    if (!refs[r] || !refs[r]->base || refs[r]->bit_depth != src->bit_depth) {
+      set_error("aomhip_tpl_inter_estimation_batch: reference %d missing or of another bit depth", r);
+      return AOMHIP_ERR_INVALID;
+    }
+  if (n == 0) return AOMHIP_OK;
+  AOMHIP_TRY(hipSetDevice(ctx->device));
+  const int bh = bw, px = bw * bh, K = kTplCands;
+  const size_t n1 = (size_t)n, SB = sizeof(aomhip_search_block), es = src->bit_depth == 8 ? 1 : 2;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_cand = take(n1 * K * sizeof(aomhip_sad_cand)), o_sad = take(n1 * K * 4), o_ent = take(n1 * K * SB), o_fl = take(n1 * K * SB),
+               o_sl = take(n1 * K * SB), o_fmv = take(n1 * K * 4), o_fcost = take(n1 * K * 4), o_cl = take(n1 * K * 20), o_mv = take(n1 * K * 4),
+               o_err = take(n1 * K * 4), o_dist = take(n1 * K * 4), o_sse = take(n1 * K * 4), o_bmv = take(n1 * 4), o_pred = take(n1 * px * es),
+               o_res = take(n1 * px * 2), o_coeff = take(n1 * px * 4), o_q = take(n1 * px * 4), o_dq = take(n1 * px * 4), o_eob = take(n1 * 2),
+               o_raw = take(n1 * n_refs * 4);
+  char *w = static_cast<char *>(work(ctx, off));
+  if (!w) return AOMHIP_ERR_NOMEM;
+  auto blk = [&](size_t o) { return reinterpret_cast<aomhip_search_block *>(w + o); };
+  auto i16 = [&](size_t o) { return reinterpret_cast<int16_t *>(w + o); };
+  auto i32 = [&](size_t o) { return reinterpret_cast<int32_t *>(w + o); };
+  auto u32 = [&](size_t o) { return reinterpret_cast<uint32_t *>(w + o); };
+  const unsigned g = (unsigned)((n1 + 255) / 256), gk = (unsigned)((n1 * K + 255) / 256);
+  aomhip_quant_params qp;   // (the transform kernel quantises as well: any valid parameters, its levels are not used)
+  for (int k = 0; k < 2; ++k) { qp.zbin[k] = 64; qp.round[k] = 32; qp.quant[k] = 1; qp.quant_shift[k] = 1 << 14; qp.dequant[k] = 64; }
+  for (int r = 0; r < n_refs; ++r) {
+    const aomhip_planes *ref = refs[r];
+    int rc;
+    if (prune_starting_mv) {
+      hipLaunchKernelGGL(tpl_center_cand_kernel, dim3(gk), dim3(256), 0, ctx->stream, d_blocks, d_center_mvs, d_center_counts, n, r, n_refs,
+                         reinterpret_cast<aomhip_sad_cand *>(w + o_cand));
+      AOMHIP_LAUNCH_CHECK();
+      rc = aomhip_sad_batch(ctx, src, ref, frame, 1, bw, bh, 0, reinterpret_cast<const aomhip_sad_cand *>(w + o_cand), n * K, 0, u32(o_sad));
+      if (rc != AOMHIP_OK) return rc;
+    }
+    hipLaunchKernelGGL(tpl_prune_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_center_mvs, d_center_counts, u32(o_sad), n, r, n_refs,
+                       prune_starting_mv, blk(o_ent));
+    AOMHIP_LAUNCH_CHECK();
+    // motion_estimation for every (block, slot) entry (aomhip_motion_estimation_batch's steps on this call's own work memory)
+    int32_t *cl = use_cost_list ? i32(o_cl) : nullptr;
+    hipLaunchKernelGGL(me_full_list_kernel, dim3(gk), dim3(256), 0, ctx->stream, blk(o_ent), n * K, blk(o_fl));
+    AOMHIP_LAUNCH_CHECK();
+    rc = aomhip_full_pixel_search_batch(ctx, src, ref, frame, bw, bh, full, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_fl), n * K, i16(o_fmv), i32(o_fcost),
+                                        cl, nullptr);
+    if (rc != AOMHIP_OK) return rc;
+    hipLaunchKernelGGL(me_subpel_list_kernel, dim3(gk), dim3(256), 0, ctx->stream, blk(o_ent), i16(o_fmv), n * K, blk(o_sl));
+    AOMHIP_LAUNCH_CHECK();
+    rc = aomhip_subpel_tree_batch(ctx, src, ref, frame, bw, bh, sub, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_sl), cl, n * K, i16(o_mv), u32(o_err),
+                                  i32(o_dist), u32(o_sse));
+    if (rc != AOMHIP_OK) return rc;
+    hipLaunchKernelGGL(tpl_best_cand_kernel, dim3(g), dim3(256), 0, ctx->stream, blk(o_ent), i16(o_mv), u32(o_err), n, i16(o_bmv));
+    AOMHIP_LAUNCH_CHECK();
+    AOMHIP_TRY(hipMemcpy2DAsync(d_best_mv + 2 * r, (size_t)n_refs * 4, w + o_bmv, 4, 4, n1, hipMemcpyDeviceToDevice, ctx->stream));
+    // predictor at the winner, residual, DCT_DCT, satd
+    rc = aomhip_build_inter_pred_contiguous_batch(ctx, ref, frame, w + o_pred, bw, bh, d_blocks, i16(o_bmv), n, AOMHIP_INTERP_REGULAR, AOMHIP_INTERP_REGULAR);
+    if (rc != AOMHIP_OK) return rc;
+    const unsigned gp = (unsigned)((n1 * px + 255) / 256);
+    if (es == 1)
+      hipLaunchKernelGGL(tpl_residual_kernel<uint8_t>, dim3(gp), dim3(256), 0, ctx->stream, view_of<uint8_t>(*src), frame, d_blocks,
+                         reinterpret_cast<const uint8_t *>(w + o_pred), n, bw, bh, i16(o_res));
+    else
+      hipLaunchKernelGGL(tpl_residual_kernel<uint16_t>, dim3(gp), dim3(256), 0, ctx->stream, view_of<uint16_t>(*src), frame, d_blocks,
+                         reinterpret_cast<const uint16_t *>(w + o_pred), n, bw, bh, i16(o_res));
+    AOMHIP_LAUNCH_CHECK();
+    rc = aomhip_xform_quant_batch(ctx, i16(o_res), bw, tx_size, nullptr, n, 1, 0, &qp, src->bit_depth != 8, i32(o_coeff), i32(o_q), i32(o_dq),
+                                  reinterpret_cast<uint16_t *>(w + o_eob));
+    if (rc != AOMHIP_OK) return rc;
+    hipLaunchKernelGGL(tpl_satd_kernel, dim3((unsigned)((n1 * 64 + 255) / 256)), dim3(256), 0, ctx->stream, i32(o_coeff), d_center_counts, n, px, r, n_refs,
+                       i32(o_raw), d_pred_error);
+    AOMHIP_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(tpl_best_ref_kernel, dim3(g), dim3(256), 0, ctx->stream, i32(o_raw), d_center_counts, n, n_refs, d_best_rf_idx, d_best_inter_cost);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

@@ -942,6 +942,30 @@ int aomhip_motion_estimation_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
                                    const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv, uint32_t *d_best_err,
                                    int32_t *d_distortion, uint32_t *d_sse, int16_t *d_fullpel_mv);
 
+/* The INTER leg of tpl_model.c's mode_estimation (av1/encoder/tpl_model.c:620-770) for a batch of blocks that do not depend on each other.
+ * The candidates' derivation -- the MVs the TPL stats hold for the blocks above, left and above-right, de-duplicated by is_alike_mv (:317-331,
+ * :652-683) -- is a raster dependency between blocks and stays with the host, which walks the frame anti-diagonal by anti-diagonal and hands
+ * every block its candidates; everything from there is one call:
+ *   per reference r < n_refs (refs[r]: a ring whose frame `frame` is the reference picture for the source's frame `frame`):
+ *     prune_starting_mv 1 .. 3 (sf.tpl_sf.prune_starting_mv; 0 = off): sdf of every candidate at its clamped full-pel position, the candidates
+ *         ranked by it (qsort + compare_sad, ties in their given order), the count cut to 4 - prune_starting_mv and by one more when the
+ *         last SAD exceeds the one before it by more than 20 % (:706-731);
+ *     motion_estimation (:248-301 = aomhip_motion_estimation_batch: `full`, `sub`, use_cost_list as there) from every remaining candidate;
+ *         the first smallest error wins (:733-743; no candidate: MV 0) -> d_best_mv[(i * n_refs + r) * 2] (row, col, 1/8 pel);
+ *     av1_enc_build_one_inter_predictor (EIGHTTAP_REGULAR) at it, tpl_get_satd_cost (:199-212: residual, DCT_DCT of the block's size,
+ *         aom_[highbd_]satd) -> d_pred_error[i * n_refs + r] = max(1, cost) (:757);
+ *   the reference with the smallest cost, the first one on ties (:759-765) -> d_best_rf_idx[i] (-1: none), d_best_inter_cost[i].
+ *   d_blocks          bx, by and the RAW x->mv_limits (row/col min/max); the other fields are ignored
+ *   d_center_mvs      [(i * n_refs + r) * 4 + k] (row, col) in 1/8 pel, k < d_center_counts[i * n_refs + r] (1 .. 4; candidate 0 is the zero
+ *                     MV in the reference, :646-649).  A count of 0 = the reference does not exist for the block: MV (-32768, -32768), error INT32_MAX
+ * Square blocks of 8, 16 or 32 pixels (tpl_bsize_1d).  The caller compares d_best_inter_cost with its intra cost (:767-771) and runs the
+ * compound leg (:773-880) with aomhip_joint_motion_search_batch / the compound predictor calls. */
+int aomhip_tpl_inter_estimation_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *const *refs, int n_refs, int frame, int bw,
+                                      const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list, int prune_starting_mv,
+                                      const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                      const aomhip_search_block *d_blocks, const int16_t *d_center_mvs, const uint8_t *d_center_counts, int n_blocks,
+                                      int16_t *d_best_mv, int32_t *d_pred_error, int8_t *d_best_rf_idx, int32_t *d_best_inter_cost);
+
 /* ------------------------------------------------------------------ the encoder's kernel vtable */
 
 /* Mirror of aom_variance_fn_ptr_t (aom_dsp/variance.h:84-103): same field order, same pointer types

@@ -1110,6 +1110,78 @@ def motion_estimation_batch(src_b, ref_b, border, w, h, blocks, q, sub, use_cost
     return mv, err, dist, sse, full_mv
 
 
+def tpl_inter_estimation_batch(src_b, ref_bs, border, width, height, bw, blocks, centers, counts, q, sub, use_cost_list=0, prune_starting_mv=0,
+                               mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4):
+    """The inter leg of mode_estimation (av1/encoder/tpl_model.c:620-770) for independent blocks, as a composition of the pinned pieces:
+    per reference the candidates' SADs, the ranking and the two cuts of prune_starting_mv (:706-731; qsort with compare_sad, stable on ties:
+    glibc's qsort is a merge sort), motion_estimation (:248-301) from every remaining candidate with the first smallest error winning
+    (:733-743), the EIGHTTAP_REGULAR predictor and tpl_get_satd_cost (:199-212: residual, DCT_DCT, aom_satd), pred_error = max(1, cost); then
+    the reference with the smallest cost (:759-765).  The selection glue is restated from the text (parity of the glue: unpinned; every piece
+    it strings together is pinned by interpreted fixtures).
+    blocks: bx, by, raw mv limits; centers [n, n_refs, 4, 2] 1/8 pel; counts [n, n_refs].
+    -> (best_mv [n, n_refs, 2], pred_error [n, n_refs], best_rf [n], best_cost [n])"""
+    n, n_refs = len(blocks), len(ref_bs)
+    tx = {8: 1, 16: 2, 32: 3}[bw]
+    px = bw * bw
+    best_mv = np.zeros((n, n_refs, 2), np.int16)
+    pred_error = np.zeros((n, n_refs), np.int32)
+    raw = np.full((n, n_refs), 2147483647, np.int64)
+    qd = build_quantizer_y(bd, 100)
+    for r, ref_b in enumerate(ref_bs):
+        entries, owner = [], []
+        for i, b in enumerate(blocks):
+            cnt = int(counts[i, r])
+            if cnt == 0:
+                best_mv[i, r] = -32768
+                pred_error[i, r] = 2147483647
+                continue
+            order = list(range(cnt))
+            if prune_starting_mv:
+                cands = np.zeros(cnt, np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2"), ("ry", "<i2")]))
+                for k in range(cnt):
+                    row = min(max(int(_rawpel(int(centers[i, r, k, 0]))), int(b["row_min"])), int(b["row_max"]))     # get_fullmv_from_mv + clamp_fullmv
+                    col = min(max(int(_rawpel(int(centers[i, r, k, 1]))), int(b["col_min"])), int(b["col_max"]))
+                    cands[k] = (b["bx"], b["by"], b["bx"] + col, b["by"] + row)
+                sads = [int(v) for v in sad_batch(src_b, ref_b, border, bw, bw, cands, bd=bd)]
+                order = sorted(order, key=lambda k: sads[k])                                                          # stable
+                cnt = min(4 - prune_starting_mv, cnt)
+                if cnt > 1 and (sads[order[cnt - 1]] - sads[order[cnt - 2]]) * 5 > sads[order[cnt - 2]]:
+                    cnt -= 1
+            for k in order[:cnt]:
+                entries.append(k)
+                owner.append(i)
+        if not entries:
+            continue
+        ent = blocks[owner].copy()   # (one entry per (block, surviving candidate): ref_mv = the candidate, raw limits)
+        ent["ref_row"], ent["ref_col"] = centers[owner, r, entries, 0], centers[owner, r, entries, 1]
+        mv, err, _, _, _ = motion_estimation_batch(src_b, ref_b, border, bw, bw, ent, q, sub, use_cost_list, mvjcost, mvcost0, mvcost1, bd=bd, threads=threads)
+        best = {}
+        for e, i in enumerate(owner):
+            if i not in best or int(err[e]) < best[i][0]:
+                best[i] = (int(err[e]), mv[e])
+        idx = sorted(best)
+        for i in idx:
+            best_mv[i, r] = best[i][1]
+        sub_blocks = blocks[idx]
+        pred = build_inter_pred(ref_b, border, width, height, bw, bw, sub_blocks, np.array([best[i][1] for i in idx], np.int16), 0, 0, bd)
+        src_vis = src_b[border:border + height, border:border + width]
+        residual = np.zeros((len(idx) * bw, bw), np.int16)
+        for j, i in enumerate(idx):
+            bx, by = int(blocks["bx"][i]), int(blocks["by"][i])
+            residual[j * bw:(j + 1) * bw] = src_vis[by:by + bw, bx:bx + bw].astype(np.int32) - pred[by:by + bw, bx:bx + bw].astype(np.int32)
+        coeff, _, _, _ = xform_quant_batch(residual, tx, None, len(idx), 1, 0, qd, bd > 8, len(idx) * px, True, threads)
+        satd = np.abs(coeff.astype(np.int64)).reshape(len(idx), px).sum(1)
+        for j, i in enumerate(idx):
+            raw[i, r] = int(satd[j])
+            pred_error[i, r] = max(1, int(satd[j]))
+    best_rf, best_cost = np.full(n, -1, np.int8), np.full(n, 2147483647, np.int32)
+    for i in range(n):
+        for r in range(n_refs):
+            if counts[i, r] and raw[i, r] < best_cost[i]:
+                best_cost[i], best_rf[i] = raw[i, r], r
+    return best_mv, pred_error, best_rf, best_cost
+
+
 def mv_bit_cost(mrow, mcol, ref_row, ref_col, mvjcost, mvcost0, mvcost1, weight=108):
     """av1_mv_bit_cost (mcomp.c:261-266): ROUND_POWER_OF_TWO(mv_cost(diff) * weight, 7); weight MV_COST_WEIGHT = 108 (rd.h:45)."""
     dr, dc = int(mrow) - int(ref_row), int(mcol) - int(ref_col)
