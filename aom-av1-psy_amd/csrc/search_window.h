@@ -55,7 +55,9 @@ struct CellPlan {
 };
 // blocks per cell (= wavefronts per workgroup) of the general search kernel, by block size
 constexpr int cell_waves_for(int bw, int bh) { return bw * bh >= AOMHIP_BIG_CELL_PIXELS ? AOMHIP_BIG_CELL_WAVES : kCellWaves; }
-inline CellPlan plan_cells(const aomhip_planes *ref, int bw, int bh, int n_blocks, int reach, int waves = kCellWaves) {
+// static_lds: the LDS the kernel declares by itself (site table, per-wavefront source slices): it comes off every budget below, so the
+// workgroups-per-CU figure the window is rounded to is the one the launch really gets and the cap never exceeds the CU's 160 KB
+inline CellPlan plan_cells(const aomhip_planes *ref, int bw, int bh, int n_blocks, int reach, int waves = kCellWaves, int static_lds = 2048) {
   static const int env_on = [] { const char *e = getenv("AOMHIP_SEARCH_CELL"); return e ? atoi(e) : 1; }();
   static const int env_r = [] { const char *e = getenv("AOMHIP_SEARCH_CELL_R"); return e ? atoi(e) : -1; }();
   CellPlan p{};
@@ -74,14 +76,16 @@ inline CellPlan plan_cells(const aomhip_planes *ref, int bw, int bh, int n_block
   pitch += ((7 - (pitch >> 2)) & 31) << 2;
   int64_t want = pitch * (bh + 2 * r);
   for (int k = 32 / waves; k >= 1; --k) {   // (16 two-wavefront workgroups = the CU's 32 wavefronts)
-    const int64_t budget = (160 * 1024 - 512 * k) / k - 256;
+    const int64_t budget = (160 * 1024 - 512 * k) / k - 256 - static_lds;
     if (want <= budget) { want = budget; break; }
   }
-  if (want > 156 * 1024) want = 156 * 1024;
+  if (want > 156 * 1024 - static_lds) want = 156 * 1024 - static_lds;
   p.waves = waves;
   p.lds = (int)want;
+  // readable rows end at height + border: true of every valid plane (aomhip_planes_alloc rounds the height up to 8 first, a caller-built
+  // plane need not), so the window's copy never reads past the allocation
   p.map = CellMap{ (n_blocks + waves - 1) / waves, r, (int)want, -ref->border, -ref->border, ref->stride - ref->border,
-                   ((ref->height + 7) & ~7) + ref->border };
+                   ref->height + ref->border };
   return p;
 }
 

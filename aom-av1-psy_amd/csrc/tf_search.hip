@@ -161,6 +161,20 @@ __global__ void tf_fill_kernel(int16_t *mvs, int32_t *mses, int n4) {
 
 using namespace aomhip;
 
+// Joins the context's side stream back into its main stream on EVERY way out of a composite that forked them -- an error return between the
+// fork and the regular join must not leave the caller's stream unordered behind side-stream work (or a capture of it forked).
+struct StreamJoinGuard {
+  aomhip_ctx *ctx;
+  hipStream_t *side;
+  const bool *forked;
+  ~StreamJoinGuard() {
+    if (*forked && *side) {
+      (void)hipEventRecord(ctx->ev_join, *side);
+      (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+    }
+  }
+};
+
 extern "C" int aomhip_tf_motion_search_frames(aomhip_ctx *ctx, const aomhip_planes *frames, int filter_frame, const uint8_t *frame_present,
                                               const aomhip_tf_params *tp, const aomhip_search_block *d_blocks, int n, int16_t *d_subblock_mvs,
                                               int32_t *d_subblock_mses, int16_t *d_ref_mv_out) {
@@ -223,6 +237,7 @@ extern "C" int aomhip_tf_motion_search_frames(aomhip_ctx *ctx, const aomhip_plan
   if (ss) side.stream = ss;
   aomhip_ctx *cb = ss ? &side : ctx;   // where the sub-block chain is enqueued
   bool forked = false;
+  StreamJoinGuard join_on_exit{ ctx, &ss, &forked };   // (the regular end of the function included)
   for (int f = 0; f < frames->n_frames; ++f) {
     int16_t *out_mvs = d_subblock_mvs + (size_t)f * n4 * 2;
     int32_t *out_mses = d_subblock_mses + (size_t)f * n4;
@@ -277,17 +292,14 @@ extern "C" int aomhip_tf_motion_search_frames(aomhip_ctx *ctx, const aomhip_plan
       hipLaunchKernelGGL(tf_finish_kernel, dim3(g1), dim3(256), 0, cb->stream, mv32f, mse32f, mv16, err16, n, 1, tp->mse_thresh, (int16_t *)nullptr, out_mvs,
                          out_mses);
     if (rc != AOMHIP_OK || hipGetLastError() != hipSuccess) {
-      if (forked) {   // never leave the streams forked
-        (void)hipEventRecord(ctx->ev_join, ss);
-        (void)hipStreamWaitEvent(st, ctx->ev_join, 0);
-      }
       if (rc == AOMHIP_OK) { set_error("aomhip_tf_motion_search_frames: kernel launch failed"); rc = AOMHIP_ERR_HIP; }
-      return rc;
+      return rc;   // (joined by join_on_exit)
     }
   }
-  if (forked) {
+  if (forked) {   // the regular join, with its errors reported; the guard then has nothing left to do
     AOMHIP_TRY(hipEventRecord(ctx->ev_join, ss));
     AOMHIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    forked = false;
   }
   if (d_ref_mv_out) AOMHIP_TRY(hipMemcpyAsync(d_ref_mv_out, ref_mv, n1 * 4, hipMemcpyDeviceToDevice, st));
   return AOMHIP_OK;
@@ -762,6 +774,7 @@ extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_plane
   aomhip_ctx side = *ctx;
   bool forked = false;
   hipStream_t ss = nullptr;
+  StreamJoinGuard join_on_exit{ ctx, &ss, &forked };   // an error return between the fork and the regular join still joins
   auto golden_leg = [&]() -> int {
     aomhip_ctx *cx = forked ? &side : ctx;
     const LegMem &mm = forked ? mem_side : mem_main;
@@ -802,6 +815,7 @@ extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_plane
       const int rcg = golden_leg();   // (queued behind the chain kernel's launch: the chain's workgroups are placed first)
       AOMHIP_TRY(hipEventRecord(ctx->ev_join, ss));   // joined on every path: a capture of ctx->stream must not end forked
       AOMHIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+      forked = false;   // (the guard has nothing left to do)
       if (rc == AOMHIP_OK) rc = rcg;
       if (rc == AOMHIP_OK && d_gf_motion_error) {
         hipLaunchKernelGGL(fp_gf_kernel, dim3(g), dim3(256), 0, ctx->stream, u32(o_raw), u32(o_e0), u32(o_gf0), i32(o_gerr), fp->skip_motion_search_threshold, n,

@@ -1748,7 +1748,7 @@ def main():
             others.append(run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline))
             others.append(run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline, "txq_4k_10bit"))
             others.append(run_search(pkg, ctx, None, dev, 0, 1, orc, max(4, args.steps // 2), 1))
-            others.append(run_inner_loop(pkg, ctx, orc, max(4, args.steps // 2), 1))
+            others.append(run_inner_loop(pkg, ctx, orc, max(40, 2 * args.steps), 2))   # (two ring slots of different cost: enough frames for a stable mean)
             others.append(run_mesh(pkg, ctx, orc, max(4, args.steps // 4), 1))
             others.append(run_search_default(pkg, ctx, orc, max(4, args.steps // 2), 1))
             others.append(run_cdef_search(pkg, ctx, orc, max(4, args.steps // 4), 1))
