@@ -76,7 +76,7 @@ __global__ __launch_bounds__(SPEC * 64) void fp_row_kernel(PlaneView<T> src, Pla
         const T *sp = src.origin + (int64_t)by * src.stride + bx;
         const T *rbase = last.origin + (int64_t)by * last.stride + bx;
         FpsResult fr;
-        fps_block<T, W, H, false>(sp, src.stride, rbase, last.stride, bx, by, bs, sS, q, no_win, nullptr, lane, &fr);
+        fps_block<T, W, H, false, true>(sp, src.stride, rbase, last.stride, bx, by, bs, sS, q, no_win, nullptr, lane, &fr);
         m1r = fr.br; m1c = fr.bc;
         if (fr.var != INT_MAX) {
           // av1_get_mvpred_sse (mcomp.c:3661-3677): the sse of the mse function at the full-pel MV + mv_err_cost, + NEW_MV_MODE_PENALTY (:292-296)
@@ -172,11 +172,14 @@ __global__ __launch_bounds__(SPEC * 64) void fp_row_kernel(PlaneView<T> src, Pla
 }  // namespace
 
 bool fp_rows_supported(int bw, int bh) { return (bw == 16 && bh == 16) || (bw == 8 && bh == 8); }
+// the row kernel carries the lean search body (fullpel_search.inc): the diamond / n-step family -- what the first pass uses (NSTEP on the
+// first-pass site table); any other method takes the column-by-column form with the general kernel
+bool fp_rows_supported(int bw, int bh, int method) { return fp_rows_supported(bw, bh) && (method < kHex || method == kNstepFpf); }
 
 int launch_fp_rows(aomhip_ctx *ctx, const aomhip_planes *src1, const aomhip_planes *last1, int bw, int bh, const aomhip_search_params *p,
                    const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks,
                    const FpfLegs &L, const int32_t *d_intra, int rows, int cols, int thr, int skip_zeromv, const FpfOut &out) {
-  if (!fp_rows_supported(bw, bh)) return AOMHIP_ERR_INVALID;
+  if (!fp_rows_supported(bw, bh, p->search_method)) return AOMHIP_ERR_INVALID;
   const SiteTable *d_sites = fps_device_sites(ctx->device, p->search_method);
   if (!d_sites) {
     set_error("first pass: could not place the site table on device %d", ctx->device);

@@ -65,6 +65,7 @@ int launch_fp_rows(aomhip_ctx *ctx, const aomhip_planes *src1, const aomhip_plan
                    const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col, const aomhip_search_block *d_blocks,
                    const FpfLegs &L, const int32_t *d_intra, int rows, int cols, int thr, int skip_zeromv, const FpfOut &out);
 bool fp_rows_supported(int bw, int bh);
+bool fp_rows_supported(int bw, int bh, int method);   // ... and the search method (the row kernel has the diamond / n-step body only)
 
 }  // namespace aomhip
 

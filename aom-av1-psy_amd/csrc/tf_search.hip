@@ -767,7 +767,7 @@ extern "C" int aomhip_first_pass_inter_frame(aomhip_ctx *ctx, const aomhip_plane
   int rc = leg(ctx, mem_main, l1, zl, n, i16(o_zmv), i32(o_zerr));
   if (rc != AOMHIP_OK) return rc;
   const char *force_cols = getenv("AOMHIP_FP_COLUMNS");   // (tests: the column-at-a-time form on the sizes the row kernel serves)
-  const bool by_rows = aomhip::fp_rows_supported(bw, bh) && !(force_cols && atoi(force_cols));
+  const bool by_rows = aomhip::fp_rows_supported(bw, bh, p->search_method) && !(force_cols && atoi(force_cols));
   // The golden-frame leg depends on nothing the chain produces, and gf_motion_error (:777-794) on nothing of the chain: with the row kernel
   // -- one workgroup per block row, a chip mostly idle -- it runs on the context's side stream BESIDE the chain, forked here and joined behind
   // the chain kernel (whose wavefronts raise their priority: the chain is latency, the leg throughput).  AOMHIP_FP_SERIAL=1: one stream (A/B).
