@@ -754,7 +754,7 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
     # the kernels issue; the kernel's class shares are its static opcode mix (profiles/r05_isa_mix.json, tools/isa_mix.py).
     # floor = insts x sum(share_c / rate_c) / (CUs x 4 SIMDs); valu_frac = floor / the launch time measured HERE.
     pmc_map = {"fullpel_diamond": "fullpel_diamond_kernel", "subpel_bilinear": "subpel_bilinear_kernel", "inter_pred_8tap": "inter_pred_kernel",
-               "subtract_xform_quant_16x16": "xform_quant_staged_kernel", "inv_txfm_add_16x16": "inv_txfm_add_kernel",
+               "subtract_xform_quant_16x16": "xform_quant_staged_kernel", "inv_txfm_add_16x16": "inv_txfm_add_kernel", "encode_inter_blocks_16x16": "encode_inter_block_kernel",
                "deblock_vert+horz": ("deblock_vert", "deblock_horz"), "deblock_fused": "deblock_fused_kernel", "cdef_luma": "cdef_luma_kernel"}
     pmc = latest_profile_json("_inner_loop_pmc.json")
     rates = valu_class_rates(ctx)

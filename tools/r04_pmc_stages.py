@@ -21,9 +21,9 @@ for f in glob.glob(out + "/g*/*counter_collection.csv"):
         waves[k] = c["_waves"]
 res = {}
 for k, c in acc.items():
-    short = k.split("(")[0].replace("void ", "").replace("aomhip::", "")
+    short = k.replace("void ", "").replace("aomhip::", "").replace("(anonymous namespace)::", "").split("(")[0]
     if not any(s in short for s in ("fullpel_diamond", "subpel_bilinear", "inter_pred", "xform_quant", "inv_txfm", "deblock", "cdef_luma", "subtract",
-                                    "full_pixel_search", "fp_row", "tf_apply", "sad_strip", "mesh")):
+                                    "full_pixel_search", "fp_row", "tf_apply", "sad_strip", "mesh", "encode_inter_block", "compound", "obmc", "refining")):
         continue
     e = {"wavefronts_per_launch": waves[k]}
     for n, v in c.items():
