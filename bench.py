@@ -1316,7 +1316,7 @@ def search_bound():
         return None
 
 
-TRAFFIC_SOURCES = {"sb": ("sad_sb.hip",), "sad": ("sad.hip",), "txq": ("xform_quant.hip", "txfm_device.h")}
+TRAFFIC_SOURCES = {"sb": ("sad_sb.hip",), "sad": ("sad.hip",), "txq": ("xform_quant.hip", "txfm_device.h", "quant_device.h")}
 
 
 def traffic_kind(name):
