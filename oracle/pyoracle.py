@@ -1110,14 +1110,50 @@ def motion_estimation_batch(src_b, ref_b, border, w, h, blocks, q, sub, use_cost
     return mv, err, dist, sse, full_mv
 
 
+def tpl_prune(sads, prune_starting_mv):
+    """The `if (cpi->sf.tpl_sf.prune_starting_mv)` block of mode_estimation (av1/encoder/tpl_model.c:706-731) on the candidates' SADs: the order qsort +
+    compare_sad leave them in (ties keep their order: glibc's qsort is a merge sort), cut to 4 - prune_starting_mv and once more when the last SAD
+    exceeds the one before it by more than 20 %.  -> the surviving candidate indices, best first.  PINNED by tests/golden/ref_eval_tpl.npz (the
+    block's own statements interpreted)."""
+    order = sorted(range(len(sads)), key=lambda k: int(sads[k]))
+    cnt = min(4 - int(prune_starting_mv), len(order))
+    if cnt > 1 and (int(sads[order[cnt - 1]]) - int(sads[order[cnt - 2]])) * 5 > int(sads[order[cnt - 2]]):
+        cnt -= 1
+    return order[:cnt]
+
+
+def tpl_best_of(errs):
+    """The loop over a reference's remaining candidates (:733-743): index of the first candidate whose motion_estimation error is below every earlier one
+    and below UINT32_MAX, or None (best_rfidx_mv then stays { 0 })."""
+    best, which = 0xFFFFFFFF, None
+    for k, e in enumerate(errs):
+        if int(e) < best:
+            best, which = int(e), k
+    return which
+
+
+def tpl_best_ref(costs, have):
+    """The per-reference tail (:755-765): pred_error[r] = max(1, cost) for the references that exist, best_rf = the first smallest cost (-1: none).
+    -> (best_rf, best_cost, pred_error list with None for missing references)"""
+    best_rf, best_cost, pe = -1, 2147483647, []
+    for r, c in enumerate(costs):
+        if not have[r]:
+            pe.append(None)
+            continue
+        pe.append(max(1, int(c)))
+        if int(c) < best_cost:
+            best_rf, best_cost = r, int(c)
+    return best_rf, best_cost, pe
+
+
 def tpl_inter_estimation_batch(src_b, ref_bs, border, width, height, bw, blocks, centers, counts, q, sub, use_cost_list=0, prune_starting_mv=0,
                                mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4):
     """The inter leg of mode_estimation (av1/encoder/tpl_model.c:620-770) for independent blocks, as a composition of the pinned pieces:
     per reference the candidates' SADs, the ranking and the two cuts of prune_starting_mv (:706-731; qsort with compare_sad, stable on ties:
     glibc's qsort is a merge sort), motion_estimation (:248-301) from every remaining candidate with the first smallest error winning
     (:733-743), the EIGHTTAP_REGULAR predictor and tpl_get_satd_cost (:199-212: residual, DCT_DCT, aom_satd), pred_error = max(1, cost); then
-    the reference with the smallest cost (:759-765).  The selection glue is restated from the text (parity of the glue: unpinned; every piece
-    it strings together is pinned by interpreted fixtures).
+    the reference with the smallest cost (:759-765).  The selection glue is tpl_prune / tpl_best_of / tpl_best_ref above, each pinned by the
+    reference's own statements interpreted (tests/golden/ref_eval_tpl.npz); the pieces it strings together are pinned by their own fixtures.
     blocks: bx, by, raw mv limits; centers [n, n_refs, 4, 2] 1/8 pel; counts [n, n_refs].
     -> (best_mv [n, n_refs, 2], pred_error [n, n_refs], best_rf [n], best_cost [n])"""
     n, n_refs = len(blocks), len(ref_bs)
@@ -1142,11 +1178,8 @@ def tpl_inter_estimation_batch(src_b, ref_bs, border, width, height, bw, blocks,
                     row = min(max(int(_rawpel(int(centers[i, r, k, 0]))), int(b["row_min"])), int(b["row_max"]))     # get_fullmv_from_mv + clamp_fullmv
                     col = min(max(int(_rawpel(int(centers[i, r, k, 1]))), int(b["col_min"])), int(b["col_max"]))
                     cands[k] = (b["bx"], b["by"], b["bx"] + col, b["by"] + row)
-                sads = [int(v) for v in sad_batch(src_b, ref_b, border, bw, bw, cands, bd=bd)]
-                order = sorted(order, key=lambda k: sads[k])                                                          # stable
-                cnt = min(4 - prune_starting_mv, cnt)
-                if cnt > 1 and (sads[order[cnt - 1]] - sads[order[cnt - 2]]) * 5 > sads[order[cnt - 2]]:
-                    cnt -= 1
+                order = tpl_prune([int(v) for v in sad_batch(src_b, ref_b, border, bw, bw, cands, bd=bd)], prune_starting_mv)
+                cnt = len(order)
             for k in order[:cnt]:
                 entries.append(k)
                 owner.append(i)
@@ -1156,9 +1189,11 @@ def tpl_inter_estimation_batch(src_b, ref_bs, border, width, height, bw, blocks,
         ent["ref_row"], ent["ref_col"] = centers[owner, r, entries, 0], centers[owner, r, entries, 1]
         mv, err, _, _, _ = motion_estimation_batch(src_b, ref_b, border, bw, bw, ent, q, sub, use_cost_list, mvjcost, mvcost0, mvcost1, bd=bd, threads=threads)
         best = {}
-        for e, i in enumerate(owner):
-            if i not in best or int(err[e]) < best[i][0]:
-                best[i] = (int(err[e]), mv[e])
+        owner_a = np.array(owner)
+        for i in sorted(set(owner)):
+            es = np.nonzero(owner_a == i)[0]
+            k = tpl_best_of(err[es])
+            best[i] = (int(err[es[k]]), mv[es[k]]) if k is not None else (0xFFFFFFFF, np.zeros(2, np.int16))
         idx = sorted(best)
         for i in idx:
             best_mv[i, r] = best[i][1]
@@ -1176,9 +1211,7 @@ def tpl_inter_estimation_batch(src_b, ref_bs, border, width, height, bw, blocks,
             pred_error[i, r] = max(1, int(satd[j]))
     best_rf, best_cost = np.full(n, -1, np.int8), np.full(n, 2147483647, np.int32)
     for i in range(n):
-        for r in range(n_refs):
-            if counts[i, r] and raw[i, r] < best_cost[i]:
-                best_cost[i], best_rf[i] = raw[i, r], r
+        best_rf[i], best_cost[i], _ = tpl_best_ref(raw[i], counts[i])
     return best_mv, pred_error, best_rf, best_cost
 
 
