@@ -1703,6 +1703,12 @@ def main():
         return
     if args.workload == "compound_search_4k_10bit":  # the RD path's compound / OBMC searches (single GPU)
         r = run_compound_search(pkg, ctx, orc, args.steps, args.warmup)
+        # the same five calls over the frame cut into 8x8, 32x32 and 64x64 blocks (timing only; the tests cover the sizes' parity)
+        r["by_block_size"] = {"16x16": {k: v["ms_per_frame"] for k, v in r.items() if isinstance(v, dict) and "ms_per_frame" in v}}
+        for bs_ in (8, 32, 64):
+            r2 = run_compound_search(pkg, ctx, None, max(3, args.steps // 2), 1, bs=bs_)
+            r["by_block_size"]["%dx%d" % (bs_, bs_)] = dict({k: v["ms_per_frame"] for k, v in r2.items() if isinstance(v, dict) and "ms_per_frame" in v},
+                                                            blocks_per_frame=r2["blocks_per_frame"])
         ctx.close()
         print(json.dumps(dict(r, metric="compound blocks/s", n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
                               vs_baseline=None, dtype="u16", data="synthetic", ms_per_step=r["ms_per_frame"], config={"workload": r["workload"]})))
