@@ -88,15 +88,24 @@ template <typename T> __device__ __forceinline__ void load_px4(const T *p, int o
     out[0] = (int)(w.x & 0xffffu); out[1] = (int)(w.x >> 16); out[2] = (int)(w.y & 0xffffu); out[3] = (int)(w.y >> 16);
   }
 }
-// One block's compound error functions evaluated by the 64 lanes pixel by pixel (pixel t of the block -> lane t & 63): get_mvpred_compound_sad
+// One block's compound error functions evaluated by the 64 lanes (a lane owns units of four adjacent pixels): get_mvpred_compound_sad
 // (vfp->sdaf / msdf) and the variance of get_mvpred_compound_var[_cost] (svaf / msvf at offset 0).  What does not depend on the candidate --
-// the source block, the other reference's predictor, the blend weights -- stays in registers for blocks of up to 512 pixels (a search
-// evaluates ~25 .. ~180 candidates); a lane owns units of four adjacent pixels, so the candidate's reference pixels are one or two 4-pixel loads per
-// lane, issued together.  Block
-// widths are powers of two: row / column of pixel t by shift and mask.  SADs are summed in 32 bits (<= 128 x 128 x 4095).
-template <typename T> struct CompoundEval {
-  static constexpr int kUnits = 2;   // 4-pixel units per lane kept in registers: blocks of up to 64 x 2 x 4 = 512 pixels
-  const T *sp, *rbase, *pred;
+// the source block, the other reference's predictor, the blend weights -- stays in registers, as packed 16-bit pairs, for blocks of up to
+// 256 * UNITS pixels (a search evaluates ~25 .. ~180 candidates): UNITS = 2 for blocks of up to 512 pixels, 4 for those of up to 1024
+// (32 x 32, 16 x 64, 64 x 16).  Larger blocks stream the same operands unit by unit from memory (they sit in L1 / L2 after the first candidate).
+// The candidate's reference pixels are one 4-pixel load per unit, issued together.  Block widths are powers of two: row / column of pixel t
+// by shift and mask.  SADs are summed in 32 bits (<= 128 x 128 x 4095).
+// Small blocks leave most of the wavefront idle (an 8 x 8 block is 16 units): with G = 2 / 4 the wavefront is G groups of 64 / G lanes, every
+// group holds the whole block (<= 128 / <= 64 pixels) and evaluates a DIFFERENT candidate -- sad_partial() takes the candidate's offset per
+// lane, group_total() reads one group's sum -- so a search stage's sites are evaluated G at a time and then judged one after the other in the
+// reference's order (the comparisons are the same: which sites are read does not depend on the running best).
+template <typename T, int UNITS, int G = 1> struct CompoundEval {
+  static constexpr int kUnits = UNITS;   // 4-pixel units per lane kept in registers
+  static constexpr int kGroups = G, kLanes = 64 / G;   // lanes per group
+  static_assert(G == 1 || (UNITS == 1 && (G == 2 || G == 4)), "groups hold one unit per lane");
+  int u, grp;   // the lane's unit within its group, its group
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const T *sp, *pred;
   const uint8_t *mask;
   int sstride, rstride, lw, wm, n_px, shift, invert, bit_depth, lane, sh;
   bool keep, packed;
@@ -109,159 +118,170 @@ template <typename T> struct CompoundEval {
   // the search: comp_avg A = 1, C = p + 1, sh = 1; comp_mask A = m (inverted: 64 - m), C = (64 - A) * p + 32, sh = 6.  One branch-free form
   // for the three cases: with `if (!mask) .. else if (invert) ..` inside the per-pixel blend the compiler emitted two or three scalar
   // branches PER PIXEL (7 700 scalar instructions per block, PMC r05).
-  int s_[kUnits][4], A_[kUnits][4], C_[kUnits][4];
-  // The SAD's operands as packed 16-bit pairs (two dwords per 4-pixel unit): A * f + C fits 16 bits for every depth without a mask
+  // The operands are packed 16-bit pairs (two dwords per 4-pixel unit): A * f + C fits 16 bits for every depth without a mask
   // (<= 2 * 4095 + 1) and up to 10 bits with one (<= 64 * 1023 + 32): v_pk_mad_u16, v_pk_lshrrev_b16, v_sad_u16 -- 3 instructions per pixel
-  // pair.  12-bit masked blocks keep the 32-bit form.  (These searches are issue bound, not latency bound: evaluating a stage's 8 sites
-  // together was 17-32 % SLOWER, profiles/r05_compound_batch8.patch.)
+  // pair (`packed`).  12-bit masked blocks hold p in place of C and blend in 32 bits.  (These searches are issue bound, not latency bound:
+  // evaluating a stage's 8 sites together was 17-32 % SLOWER, profiles/r05_compound_batch8.patch.)
   uint32_t sA_[kUnits][2], sC_[kUnits][2], sS_[kUnits][2], sh2;
-  __device__ __forceinline__ void coeffs(int p, int m, int &A, int &Cc) const {
-    A = !mask ? 1 : (invert ? 64 - m : m);
-    Cc = !mask ? p + 1 : (64 - A) * p + 32;
+  template <typename U> static __device__ __forceinline__ void load_pairs(const U *p, uint32_t o[2]) {   // four adjacent pixels (any alignment) as two 16-bit pairs
+    if constexpr (sizeof(U) == 1) {
+      const uint32_t w = *reinterpret_cast<const uint32_t *>(p);
+      o[0] = __builtin_amdgcn_perm(0, w, 0x0c010c00);   // (px0, px1) as 16-bit halves
+      o[1] = __builtin_amdgcn_perm(0, w, 0x0c030c02);   // (px2, px3)
+    } else {
+      const uint2 w = *reinterpret_cast<const uint2 *>(p);
+      o[0] = w.x; o[1] = w.y;
+    }
+  }
+  // the candidate-independent operands of the unit at pixel t (t < n_px)
+  __device__ __forceinline__ void operands(int t, uint32_t A2[2], uint32_t C2[2], uint32_t S2[2]) const {
+    uint32_t p2[2], m2[2] = { 0, 0 };
+    load_pairs<T>(sp + (t >> lw) * sstride + (t & wm), S2);   // (widths are multiples of 4: a unit lies in one row)
+    load_pairs<T>(pred + t, p2);
+    if (mask) load_pairs<uint8_t>(mask + t, m2);
+    const u16x2 one = { 1, 1 }, c64 = { 64, 64 }, c32 = { 32, 32 };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u16x2 p = __builtin_bit_cast(u16x2, p2[h]), m = __builtin_bit_cast(u16x2, m2[h]);
+      const u16x2 A = !mask ? one : (invert ? c64 - m : m);
+      const u16x2 Cc = !mask ? p + one : (packed ? (c64 - A) * p + c32 : p);
+      A2[h] = __builtin_bit_cast(uint32_t, A);
+      C2[h] = __builtin_bit_cast(uint32_t, Cc);
+    }
   }
   __device__ __forceinline__ void init(const T *sp_, int sstride_, const T *rbase_, int rstride_, const T *pred_, const uint8_t *mask_, int W, int H, int invert_,
                                        int bit_depth_, int lane_, int row_min, int col_min) {
-    sp = sp_; rbase = rbase_; pred = pred_; mask = mask_; sstride = sstride_; rstride = rstride_;
+    sp = sp_; pred = pred_; mask = mask_; sstride = sstride_; rstride = rstride_;
     rmin = row_min; cmin = col_min;
     base0 = reinterpret_cast<const char *>(rbase_ + (int64_t)row_min * rstride_ + col_min);
     lw = __builtin_ctz((unsigned)W); wm = W - 1; n_px = W * H; invert = invert_; bit_depth = bit_depth_; lane = lane_;
+    u = lane & (kLanes - 1); grp = lane / kLanes;
     shift = bit_depth == 10 ? 2 : bit_depth == 12 ? 4 : 0;   // the _bits10 / _bits12 vtable wrappers (encoder_utils.h)
     sh = mask ? 6 : 1;
     sh2 = (uint32_t)sh | ((uint32_t)sh << 16);
-    keep = n_px <= 256 * kUnits;
-    packed = keep && (!mask || bit_depth <= 10);
+    keep = n_px <= 4 * kLanes * kUnits;
+    packed = !mask || bit_depth <= 10;
     if (keep) {
 #pragma unroll
       for (int k = 0; k < kUnits; ++k) {
-        const int t = 4 * (k * 64 + lane);   // (widths are multiples of 4: a unit lies in one row)
-        lo_[k] = t < n_px ? (unsigned)(((t >> lw) * rstride + (t & wm)) * (int)sizeof(T)) : 0u;
-        int p4[4] = { 0, 0, 0, 0 }, m4[4] = { 0, 0, 0, 0 };
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s_[k][i] = 0;
-        if (t < n_px) {
-          load_px4<T>(sp + (t >> lw) * sstride + (t & wm), s_[k]);
-          load_px4<T>(pred + t, p4);
-          if (mask) load_px4<uint8_t>(mask + t, m4);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          coeffs(p4[i], m4[i], A_[k][i], C_[k][i]);
-          if (t >= n_px) { A_[k][i] = 0; C_[k][i] = 0; }   // lanes beyond the block: blend 0 against source 0
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          sA_[k][h] = (uint32_t)A_[k][2 * h] | ((uint32_t)A_[k][2 * h + 1] << 16);
-          sC_[k][h] = (uint32_t)C_[k][2 * h] | ((uint32_t)C_[k][2 * h + 1] << 16);
-          sS_[k][h] = (uint32_t)s_[k][2 * h] | ((uint32_t)s_[k][2 * h + 1] << 16);
-        }
+        const int t = 4 * (k * kLanes + u);
+        lo_[k] = t < n_px ? ref_off(t) : 0u;
+        sA_[k][0] = sA_[k][1] = sC_[k][0] = sC_[k][1] = sS_[k][0] = sS_[k][1] = 0;   // lanes beyond the block: blend 0 against source 0
+        if (t < n_px) operands(t, sA_[k], sC_[k], sS_[k]);
       }
     }
   }
-  __device__ __forceinline__ int blend_at(int f, int k, int i) const { return (A_[k][i] * f + C_[k][i]) >> sh; }
-  __device__ __forceinline__ int blend_mem(int f, int t) const {   // blocks too large for the registers: the operands from memory
-    int A, Cc;
-    coeffs((int)pred[t], mask ? (int)mask[t] : 0, A, Cc);
-    return (A * f + Cc) >> sh;
-  }
-  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  __device__ __forceinline__ unsigned ref_off(int t) const { return (unsigned)(((t >> lw) * rstride + (t & wm)) * (int)sizeof(T)); }
+  // the blend of one pixel in 32 bits (12-bit masked blocks: Cc holds p)
+  __device__ __forceinline__ int blend32(int f, int A, int p) const { return (A * f + (64 - A) * p + 32) >> 6; }
   // SAD of one pixel pair: blend = (A * f + C) >> sh on both halves, then |blend - s| summed into acc
   __device__ __forceinline__ uint32_t pair_sad(uint32_t f, uint32_t A, uint32_t Cc, uint32_t S, uint32_t acc) const {
     const u16x2 b = (u16x2)(__builtin_bit_cast(u16x2, A) * __builtin_bit_cast(u16x2, f) + __builtin_bit_cast(u16x2, Cc)) >> __builtin_bit_cast(u16x2, sh2);
     return __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, b), S, acc);
   }
+  __device__ __forceinline__ uint32_t unit_sad(const uint32_t f2[2], const uint32_t A2[2], const uint32_t C2[2], const uint32_t S2[2], uint32_t acc) const {
+    if (packed) {
+      acc = pair_sad(f2[0], A2[0], C2[0], S2[0], acc);   // (lanes beyond the block: (0 * f + 0) >> sh == 0 == s)
+      acc = pair_sad(f2[1], A2[1], C2[1], S2[1], acc);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        acc += (uint32_t)iabsm(blend32((int)(f2[h] & 0xffffu), (int)(A2[h] & 0xffffu), (int)(C2[h] & 0xffffu)) - (int)(S2[h] & 0xffffu));
+        acc += (uint32_t)iabsm(blend32((int)(f2[h] >> 16), (int)(A2[h] >> 16), (int)(C2[h] >> 16)) - (int)(S2[h] >> 16));
+      }
+    }
+    return acc;
+  }
+  // sum and sum of squares of blend - source over one unit
+  __device__ __forceinline__ void unit_var(const uint32_t f2[2], const uint32_t A2[2], const uint32_t C2[2], const uint32_t S2[2], int32_t &s, uint32_t &q) const {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int b0, b1;
+      if (packed) {
+        const u16x2 b = (u16x2)(__builtin_bit_cast(u16x2, A2[h]) * __builtin_bit_cast(u16x2, f2[h]) + __builtin_bit_cast(u16x2, C2[h])) >> __builtin_bit_cast(u16x2, sh2);
+        b0 = (int)b.x; b1 = (int)b.y;
+      } else {
+        b0 = blend32((int)(f2[h] & 0xffffu), (int)(A2[h] & 0xffffu), (int)(C2[h] & 0xffffu));
+        b1 = blend32((int)(f2[h] >> 16), (int)(A2[h] >> 16), (int)(C2[h] >> 16));
+      }
+      const int d0 = b0 - (int)(S2[h] & 0xffffu), d1 = b1 - (int)(S2[h] >> 16);
+      s += d0 + d1;
+      q += (uint32_t)(d0 * d0) + (uint32_t)(d1 * d1);
+    }
+  }
   __device__ __forceinline__ unsigned cand_off(int row, int col) const {   // (row, col) inside the search window: >= 0
     return (unsigned)(((row - rmin) * rstride + (col - cmin)) * (int)sizeof(T));
   }
-  __device__ __forceinline__ void load_ref(unsigned off, int f[kUnits][4]) const {
+  __device__ __forceinline__ void load_ref(unsigned off, uint32_t f2[kUnits][2]) const {
 #pragma unroll
     for (int k = 0; k < kUnits; ++k) {
-      const int t = 4 * (k * 64 + lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) f[k][i] = 0;
-      if (t < n_px) load_px4<T>(reinterpret_cast<const T *>(base0 + (lo_[k] + off)), f[k]);
+      const int t = 4 * (k * kLanes + u);
+      f2[k][0] = f2[k][1] = 0;
+      if (k * 4 * kLanes < n_px && t < n_px) load_pairs<T>(reinterpret_cast<const T *>(base0 + (lo_[k] + off)), f2[k]);
     }
   }
-  __device__ __forceinline__ uint32_t sad(int row, int col) const {
-    const unsigned off = cand_off(row, col);
-    const T *rp = reinterpret_cast<const T *>(base0 + off);
+  // the sum of one group's lanes out of the 16-lane sums row_sum32 leaves in every lane (g is uniform)
+  static __device__ __forceinline__ uint32_t group_total(uint32_t rows, int g) {
+    if constexpr (G == 4) return (uint32_t)__builtin_amdgcn_readlane((int)rows, 16 * g);
+    if constexpr (G == 2) return (uint32_t)__builtin_amdgcn_readlane((int)rows, 32 * g) + (uint32_t)__builtin_amdgcn_readlane((int)rows, 32 * g + 16);
+    return (uint32_t)__builtin_amdgcn_readlane((int)rows, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rows, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)rows, 32) + (uint32_t)__builtin_amdgcn_readlane((int)rows, 48);
+  }
+  // the lane's share of the SAD of the candidate at byte offset `off` (cand_off; with G > 1 a value per group)
+  __device__ __forceinline__ uint32_t sad_partial(unsigned off) const {
     uint32_t acc = 0;
-    if (packed) {
+    if (keep) {
       uint32_t f2[kUnits][2];
-#pragma unroll
-      for (int k = 0; k < kUnits; ++k) {
-        const int t = 4 * (k * 64 + lane);
-        f2[k][0] = f2[k][1] = 0;
-        if (t < n_px) {
-          const char *q = base0 + (lo_[k] + off);
-          if constexpr (sizeof(T) == 1) {
-            const uint32_t w = *reinterpret_cast<const uint32_t *>(q);
-            f2[k][0] = __builtin_amdgcn_perm(0, w, 0x0c010c00);   // (px0, px1) as 16-bit halves
-            f2[k][1] = __builtin_amdgcn_perm(0, w, 0x0c030c02);   // (px2, px3)
-          } else {
-            const uint2 w = *reinterpret_cast<const uint2 *>(q);
-            f2[k][0] = w.x; f2[k][1] = w.y;
-          }
-        }
-      }
+      load_ref(off, f2);
 #pragma unroll
       for (int k = 0; k < kUnits; ++k)
-        if (k * 256 < n_px) {
-          acc = pair_sad(f2[k][0], sA_[k][0], sC_[k][0], sS_[k][0], acc);   // (lanes beyond the block: (0 * f + 0) >> sh == 0 == s)
-          acc = pair_sad(f2[k][1], sA_[k][1], sC_[k][1], sS_[k][1], acc);
-        }
-    } else if (keep) {
-      int f[kUnits][4];
-      load_ref(off, f);
-#pragma unroll
-      for (int k = 0; k < kUnits; ++k)
-        if (k * 256 < n_px) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc += (uint32_t)iabsm(blend_at(f[k][i], k, i) - s_[k][i]);
-        }
-    } else {
-      for (int t = lane; t < n_px; t += 64) {
-        const int y = t >> lw, x = t & wm;
-        acc += (uint32_t)iabsm(blend_mem((int)rp[(int64_t)y * rstride + x], t) - (int)sp[(int64_t)y * sstride + x]);
+        if (k * 4 * kLanes < n_px) acc = unit_sad(f2[k], sA_[k], sC_[k], sS_[k], acc);
+    } else if constexpr (G == 1) {
+#pragma unroll 2
+      for (int t = 4 * lane; t < n_px; t += 256) {
+        uint32_t A2[2], C2[2], S2[2], f2[2];
+        load_pairs<T>(reinterpret_cast<const T *>(base0 + (ref_off(t) + off)), f2);
+        operands(t, A2, C2, S2);
+        acc = unit_sad(f2, A2, C2, S2, acc);
       }
     }
-    return wsum32(acc) >> shift;
+    return acc;
   }
+  // G candidates at once: rows = sad_rows(offset per group), then sad_of(rows, g) for each
+  __device__ __forceinline__ uint32_t sad_rows(unsigned off) const { return row_sum32(sad_partial(off)); }
+  __device__ __forceinline__ uint32_t sad_of(uint32_t rows, int g) const { return group_total(rows, g) >> shift; }
+  __device__ __forceinline__ uint32_t sad(int row, int col) const { return sad_of(sad_rows(cand_off(row, col)), 0); }
   __device__ __forceinline__ uint32_t var(int row, int col) const {   // (without the MV cost)
     const unsigned off = cand_off(row, col);
-    const T *rp = reinterpret_cast<const T *>(base0 + off);
     int32_t s = 0;
     uint64_t q64;
     if (keep) {
-      uint32_t q = 0;   // <= 8 x 4095^2 per lane, <= 16 lanes of that per row
-      int f[kUnits][4];
-      load_ref(off, f);
+      uint32_t q = 0;   // <= 4 x kUnits x 4095^2 per lane, 16 lanes of that per row: 256 x 4095^2 < 2^32
+      uint32_t f2[kUnits][2];
+      load_ref(off, f2);
 #pragma unroll
-      for (int k = 0; k < kUnits; ++k) {
-        if (k * 256 < n_px) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int d = blend_at(f[k][i], k, i) - s_[k][i];
-            s += d;
-            q += (uint32_t)(d * d);
-          }
-        }
-      }
-      q64 = wsum32_wide(q);
+      for (int k = 0; k < kUnits; ++k)
+        if (k * 4 * kLanes < n_px) unit_var(f2[k], sA_[k], sC_[k], sS_[k], s, q);
+      if constexpr (G == 1) q64 = wsum32_wide(q);
+      else q64 = group_total(row_sum32(q), 0);   // (every group evaluated the same candidate; <= 128 pixels: 32 bits)
+    } else if constexpr (G > 1) {
+      q64 = 0;
     } else {
       uint64_t q = 0;
-      for (int t = lane; t < n_px; t += 64) {
-        const int y = t >> lw, x = t & wm;
-        const int d = blend_mem((int)rp[(int64_t)y * rstride + x], t) - (int)sp[(int64_t)y * sstride + x];
-        s += d;
-        q += (uint32_t)(d * d);
+      for (int t = 4 * lane; t < n_px; t += 256) {
+        uint32_t A2[2], C2[2], S2[2], f2[2], qu = 0;
+        load_pairs<T>(reinterpret_cast<const T *>(base0 + (ref_off(t) + off)), f2);
+        operands(t, A2, C2, S2);
+        unit_var(f2, A2, C2, S2, s, qu);
+        q += qu;
       }
       q64 = (uint64_t)wsum((int64_t)q);
     }
-    return finish_var((int64_t)(int32_t)wsum32((uint32_t)s), q64, n_px, bit_depth);
+    return finish_var((int64_t)(int32_t)group_total(row_sum32((uint32_t)s), 0), q64, n_px, bit_depth);
   }
 };
 
-template <typename T>
+template <typename T, int UNITS, int G>
 __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks,
                                                                  int n_blocks, CompoundArgs a, const T *__restrict__ second_pred,
                                                                  const uint8_t *__restrict__ masks, int16_t *__restrict__ out_mv,
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
   const T *pred = second_pred + (size_t)bi * n_px;
   const uint8_t *mask = masks ? masks + (size_t)bi * n_px : nullptr;
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
-  CompoundEval<T> ce;
+  CompoundEval<T, UNITS, G> ce;
   ce.init(sp, src.stride, rbase, ref.stride, pred, mask, W, H, a.invert_mask, a.bit_depth, lane, bs.row_min, bs.col_min);
   auto sad_at = [&](int row, int col) -> uint32_t { return ce.sad(row, col); };   // get_mvpred_compound_sad
   constexpr int kRange = 3, kStride = 2 * kRange + 1;   // SEARCH_RANGE_8P, SEARCH_GRID_STRIDE_8P (mcomp_structs.h:26-29)
@@ -287,24 +307,35 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
   int row = min(max(bs.start_row, bs.row_min), bs.row_max), col = min(max(bs.start_col, bs.col_min), bs.col_max);   // clamp_fullmv
   uint32_t best_sad = sad_at(row, col) + (uint32_t)sad_cost(a, frr, frc, row, col);
   visited |= 1ull << grid_center;
+  // neighbors[] (:1623-1632): (-1,0) (0,-1) (0,1) (1,0) (-1,-1) (1,-1) (-1,1) (1,1)
+  auto drow_of = [](int j) { return j == 0 || j == 4 || j == 6 ? -1 : (j == 3 || j == 5 || j == 7 ? 1 : 0); };
+  auto dcol_of = [](int j) { return j == 1 || j == 4 || j == 5 ? -1 : (j == 2 || j == 6 || j == 7 ? 1 : 0); };
   for (int i = 0; i < kRange; ++i) {
     int best_site = -1;
 #pragma unroll 1
-    for (int j = 0; j < 8; ++j) {
-      // neighbors[] (:1623-1632): (-1,0) (0,-1) (0,1) (1,0) (-1,-1) (1,-1) (-1,1) (1,1)
-      const int drow = j == 0 || j == 4 || j == 6 ? -1 : (j == 3 || j == 5 || j == 7 ? 1 : 0);
-      const int dcol = j == 1 || j == 4 || j == 5 ? -1 : (j == 2 || j == 6 || j == 7 ? 1 : 0);
-      const int gc = grid_center + drow * kStride + dcol;
-      if ((visited >> gc) & 1) continue;
-      visited |= 1ull << gc;
-      const int r = row + drow, c = col + dcol;
-      if (c < bs.col_min || c > bs.col_max || r < bs.row_min || r > bs.row_max) continue;
-      uint32_t sad = sad_at(r, c);
-      if (sad < best_sad) {
-        sad += (uint32_t)sad_cost(a, frr, frc, r, c);
+    for (int j0 = 0; j0 < 8; j0 += G) {
+      uint32_t rows = 0;
+      if constexpr (G > 1) {   // the G neighbours j0 .. j0 + G - 1, one per group of lanes; judged in order below
+        const int jl = j0 + ce.grp, r = row + drow_of(jl), c = col + dcol_of(jl), gc = grid_center + drow_of(jl) * kStride + dcol_of(jl);
+        const bool ok = !((visited >> gc) & 1) && c >= bs.col_min && c <= bs.col_max && r >= bs.row_min && r <= bs.row_max;
+        rows = ce.sad_rows(ok ? ce.cand_off(r, c) : 0u);
+      }
+#pragma unroll 1
+      for (int g = 0; g < G; ++g) {
+        const int j = j0 + g;
+        const int drow = drow_of(j), dcol = dcol_of(j);
+        const int gc = grid_center + drow * kStride + dcol;
+        if ((visited >> gc) & 1) continue;
+        visited |= 1ull << gc;
+        const int r = row + drow, c = col + dcol;
+        if (c < bs.col_min || c > bs.col_max || r < bs.row_min || r > bs.row_max) continue;
+        uint32_t sad = G > 1 ? ce.sad_of(rows, g) : sad_at(r, c);
         if (sad < best_sad) {
-          best_sad = sad;
-          best_site = j;
+          sad += (uint32_t)sad_cost(a, frr, frc, r, c);
+          if (sad < best_sad) {
+            best_sad = sad;
+            best_site = j;
+          }
         }
       }
     }
@@ -328,7 +359,7 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
 // get_mvpred_compound_sad whenever ms_buffers.second_pred is set (:1347), every run ends on get_mvpred_compound_var_cost (:676-708) and
 // *second_best_mv follows every move of every run.  What av1_full_pixel_search does after it (:1756-1830) -- on the PLAIN sdf / vf even on a
 // compound -- is the general kernel's (fullpel_search.inc, SearchArgs::resume).
-template <typename T>
+template <typename T, int UNITS, int G>
 __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneView<T> src, PlaneView<T> ref, int frame,
                                                                           const aomhip_search_block *__restrict__ blocks, int n_blocks, CompoundArgs a,
                                                                           const SiteTable *__restrict__ sites, int step_param,
@@ -354,7 +385,7 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
   const T *pred = second_pred + (size_t)bi * n_px;
   const uint8_t *mask = masks ? masks + (size_t)bi * n_px : nullptr;
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
-  CompoundEval<T> ce;
+  CompoundEval<T, UNITS, G> ce;
   ce.init(sp, src.stride, rbase, ref.stride, pred, mask, W, H, a.invert_mask, a.bit_depth, lane, bs.row_min, bs.col_min);
   auto sad_at = [&](int row, int col) -> uint32_t { return ce.sad(row, col); };   // get_mvpred_compound_sad: sdaf / msdf
   auto var_at = [&](int row, int col) -> int {   // get_mvpred_compound_var_cost: svaf / msvf at offset (0, 0) + mv_err_cost_
@@ -380,16 +411,28 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
       const int this_radius = __builtin_amdgcn_readfirstlane(S.radius[step]);
       const int nper = __builtin_amdgcn_readfirstlane(S.searches_per_step[step]);
       const int my_site = *reinterpret_cast<const int *>(&S.mv[step][lane < 17 ? lane : 0][0]);   // (row, col) of site `lane` as one dword
-      for (int idx = 1; idx <= nper; ++idx) {
-        const int site = __builtin_amdgcn_readlane(my_site, idx);
-        const int r = row + (int)(int16_t)(site & 0xffff), c = col + (site >> 16);
-        if (c < bs.col_min || c > bs.col_max || r < bs.row_min || r > bs.row_max) continue;   // av1_is_fullmv_in_range
-        uint32_t sad = sad_at(r, c);
-        if (sad < bestsad) {
-          sad += (uint32_t)sad_cost(a, frr, frc, r, c);   // (looked up only for a site that can win: issuing it for every site beside the pixel reads was SLOWER, 7.7 -> 8.9 ms)
+      for (int idx0 = 1; idx0 <= nper; idx0 += G) {
+        uint32_t rows = 0;
+        if constexpr (G > 1) {   // sites idx0 .. idx0 + G - 1, one per group of lanes; judged in order below
+          const int il = idx0 + ce.grp, site = __builtin_amdgcn_ds_bpermute(il << 2, my_site);   // (il <= 19: lanes past 16 hold site 0, never `ok`)
+          const int r = row + (int)(int16_t)(site & 0xffff), c = col + (site >> 16);
+          const bool ok = il <= nper && c >= bs.col_min && c <= bs.col_max && r >= bs.row_min && r <= bs.row_max;
+          rows = ce.sad_rows(ok ? ce.cand_off(r, c) : 0u);
+        }
+#pragma unroll 1
+        for (int g = 0; g < G; ++g) {
+          const int idx = idx0 + g;
+          if (idx > nper) break;
+          const int site = __builtin_amdgcn_readlane(my_site, idx);
+          const int r = row + (int)(int16_t)(site & 0xffff), c = col + (site >> 16);
+          if (c < bs.col_min || c > bs.col_max || r < bs.row_min || r > bs.row_max) continue;   // av1_is_fullmv_in_range
+          uint32_t sad = G > 1 ? ce.sad_of(rows, g) : sad_at(r, c);
           if (sad < bestsad) {
-            bestsad = sad;
-            best_site = idx;
+            sad += (uint32_t)sad_cost(a, frr, frc, r, c);   // (looked up only for a site that can win: issuing it for every site beside the pixel reads was SLOWER, 7.7 -> 8.9 ms)
+            if (sad < bestsad) {
+              bestsad = sad;
+              best_site = idx;
+            }
           }
         }
       }
@@ -439,7 +482,7 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
   }
 }
 
-template <typename T>
+template <typename T, int UNITS, int G>
 __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks,
                                                                      CompoundArgs a, const SiteTable *__restrict__ sites, int step_param, int fast,
                                                                      const int32_t *__restrict__ wsrc_all, const int32_t *__restrict__ omask_all,
@@ -461,62 +504,82 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
   const int32_t *wsrc = wsrc_all + (size_t)bi * n_px, *omask = omask_all + (size_t)bi * n_px;
   const int shift = a.bit_depth == 10 ? 2 : a.bit_depth == 12 ? 4 : 0;
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
-  // As CompoundEval: the weighted source and the mask of the block stay in registers for blocks of up to 512 pixels, a candidate is then eight
-  // independent reference loads per lane; widths are powers of two (row / column of pixel t by shift and mask).
-  constexpr int kUnits = 2;   // 4-pixel units per lane
+  // As CompoundEval: the weighted source and the mask of the block stay in registers for blocks of up to 256 * UNITS pixels, a candidate is then
+  // 2 * UNITS independent reference loads per lane; larger blocks stream them four pixels at a time.  Widths are powers of two (row / column
+  // of pixel t by shift and mask).
+  // G > 1: the wavefront as G groups of lanes, each holding the whole (small) block and evaluating its own candidate (see CompoundEval).
+  constexpr int kUnits = UNITS, kLanes = 64 / G;   // 4-pixel units per lane, lanes per group
+  static_assert(G == 1 || UNITS == 1, "groups hold one unit per lane");
+  const int u = lane & (kLanes - 1), grp = lane / kLanes;
   const int lw = __builtin_ctz((unsigned)W), wm = W - 1;
-  const bool keep = n_px <= 256 * kUnits;
+  const bool keep = n_px <= 4 * kLanes * kUnits;
   int ws_[kUnits][4], om_[kUnits][4];
   // candidate pixels by 32-bit byte offset from the block at the window's top-left MV (see CompoundEval)
   const char *base0 = reinterpret_cast<const char *>(rbase + (int64_t)bs.row_min * ref.stride + bs.col_min);
+  auto ref_off = [&](int t) -> unsigned { return (unsigned)(((t >> lw) * ref.stride + (t & wm)) * (int)sizeof(T)); };
   unsigned lo_[kUnits];
   if (keep) {
 #pragma unroll
     for (int k = 0; k < kUnits; ++k) {
-      const int t = 4 * (k * 64 + lane);
-      lo_[k] = t < n_px ? (unsigned)(((t >> lw) * ref.stride + (t & wm)) * (int)sizeof(T)) : 0u;
+      const int t = 4 * (k * kLanes + u);
+      lo_[k] = t < n_px ? ref_off(t) : 0u;
       int4 a = make_int4(0, 0, 0, 0), b = a;
       if (t < n_px) { a = *reinterpret_cast<const int4 *>(wsrc + t); b = *reinterpret_cast<const int4 *>(omask + t); }
       ws_[k][0] = a.x; ws_[k][1] = a.y; ws_[k][2] = a.z; ws_[k][3] = a.w;
       om_[k][0] = b.x; om_[k][1] = b.y; om_[k][2] = b.z; om_[k][3] = b.w;
     }
   }
-  auto osad_at = [&](int row, int col) -> uint32_t {   // vfp->osdf: obmc_sad (sad_av1.c:163-180) + the bit-depth wrapper
-    const unsigned off = (unsigned)(((row - bs.row_min) * ref.stride + (col - bs.col_min)) * (int)sizeof(T));
-    const T *rp = reinterpret_cast<const T *>(base0 + off);
+  auto cand_off = [&](int row, int col) -> unsigned { return (unsigned)(((row - bs.row_min) * ref.stride + (col - bs.col_min)) * (int)sizeof(T)); };
+  // vfp->osdf: obmc_sad (sad_av1.c:163-180), the lane's share for the candidate at byte offset `off` (with G > 1 a value per group); obmc_sad
+  // sums in an unsigned int, so do the lanes and the reductions (modulo 2^32 like the reference)
+  auto osad_partial = [&](unsigned off) -> uint32_t {
+    uint32_t acc = 0;
     if (keep) {
-      uint32_t acc = 0;
       int f[kUnits][4];
 #pragma unroll
       for (int k = 0; k < kUnits; ++k) {
-        const int t = 4 * (k * 64 + lane);
+        const int t = 4 * (k * kLanes + u);
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[k][i] = 0;
-        if (k * 256 < n_px && t < n_px) load_px4<T>(reinterpret_cast<const T *>(base0 + (lo_[k] + off)), f[k]);
+        if (k * 4 * kLanes < n_px && t < n_px) load_px4<T>(reinterpret_cast<const T *>(base0 + (lo_[k] + off)), f[k]);
       }
 #pragma unroll
       for (int k = 0; k < kUnits; ++k)
-        if (k * 256 < n_px) {
+        if (k * 4 * kLanes < n_px) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc += (uint32_t)((iabsm(ws_[k][i] - f[k][i] * om_[k][i]) + 2048) >> 12);   // ROUND_POWER_OF_TWO(abs(..), 12); beyond the block: 0
         }
-      return wsum32(acc) >> shift;   // (<= 8 x 2^19 per lane whatever wsrc holds: the 32-bit sum is exact)
+    } else if constexpr (G == 1) {
+#pragma unroll 1   // (unrolled by two the int4 loads took the kernel to ~300 VGPRs)
+      for (int t = 4 * lane; t < n_px; t += 256) {
+        int f[4];
+        load_px4<T>(reinterpret_cast<const T *>(base0 + (ref_off(t) + off)), f);
+        const int4 w = *reinterpret_cast<const int4 *>(wsrc + t), m = *reinterpret_cast<const int4 *>(omask + t);
+        acc += (uint32_t)((iabsm(w.x - f[0] * m.x) + 2048) >> 12) + (uint32_t)((iabsm(w.y - f[1] * m.y) + 2048) >> 12) +
+               (uint32_t)((iabsm(w.z - f[2] * m.z) + 2048) >> 12) + (uint32_t)((iabsm(w.w - f[3] * m.w) + 2048) >> 12);
+      }
     }
-    int64_t acc = 0;
-    for (int t = lane; t < n_px; t += 64) {
-      const int v = wsrc[t] - (int)rp[(int64_t)(t >> lw) * ref.stride + (t & wm)] * omask[t];
-      acc += (iabsm(v) + 2048) >> 12;
-    }
-    return (uint32_t)wsum(acc) >> shift;
+    return acc;
   };
+  auto osad_rows = [&](unsigned off) -> uint32_t { return row_sum32(osad_partial(off)); };
+  auto osad_of = [&](uint32_t rows, int g) -> uint32_t { return CompoundEval<T, UNITS, G>::group_total(rows, g) >> shift; };   // + the bit-depth wrapper
+  auto osad_at = [&](int row, int col) -> uint32_t { return osad_of(osad_rows(cand_off(row, col)), 0); };
   auto ovar_at = [&](int row, int col) -> int {   // get_obmc_mvpred_var: vfp->ovf (variance.c:957-1000 / :1064-1192) + mv_err_cost_
-    const T *rp = rbase + (int64_t)row * ref.stride + col;
+    const unsigned off = cand_off(row, col);
     int64_t s = 0, q = 0;
-    for (int t = lane; t < n_px; t += 64) {
-      const int v = wsrc[t] - (int)rp[(int64_t)(t >> lw) * ref.stride + (t & wm)] * omask[t];
-      const int d = v < 0 ? -((-v + 2048) >> 12) : (v + 2048) >> 12;   // ROUND_POWER_OF_TWO_SIGNED(v, 12)
-      s += d;
-      q += (uint32_t)(d * d);
+#pragma unroll 1
+    for (int t = 4 * lane; t < n_px; t += 256) {   // (once per run: every lane of the wavefront, whatever G)
+      int f[4];
+      load_px4<T>(reinterpret_cast<const T *>(base0 + (ref_off(t) + off)), f);
+      const int4 w4 = *reinterpret_cast<const int4 *>(wsrc + t), m4 = *reinterpret_cast<const int4 *>(omask + t);
+      const int w[4] = { w4.x, w4.y, w4.z, w4.w }, m[4] = { m4.x, m4.y, m4.z, m4.w };
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int v = w[i] - f[i] * m[i];
+        const int d = v < 0 ? -((-v + 2048) >> 12) : (v + 2048) >> 12;   // ROUND_POWER_OF_TWO_SIGNED(v, 12)
+        s += d;
+        q += (uint32_t)(d * d);
+      }
     }
     return (int)finish_var(wsum(s), (uint64_t)wsum(q), n_px, a.bit_depth) + var_cost(a, bs.ref_row, bs.ref_col, row * 8, col * 8);
   };
@@ -534,16 +597,28 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
         int best_site = 0;
         const int nper = __builtin_amdgcn_readfirstlane(S.searches_per_step[step]);
         const int my_site = *reinterpret_cast<const int *>(&S.mv[step][lane < 17 ? lane : 0][0]);
-        for (int idx = 1; idx <= nper; ++idx) {
-          const int site = __builtin_amdgcn_readlane(my_site, idx);
-          const int r = row + (int)(int16_t)(site & 0xffff), c = col + (site >> 16);
-          if (!in_range(r, c)) continue;
-          int sad = (int)osad_at(r, c);   // (`int sad < int best_sad`: this function compares signed, mcomp.c:2206-2215)
-          if (sad < best_sad) {
-            sad += sad_cost(a, frr, frc, r, c);
+        for (int idx0 = 1; idx0 <= nper; idx0 += G) {
+          uint32_t rows = 0;
+          if constexpr (G > 1) {   // sites idx0 .. idx0 + G - 1, one per group of lanes; judged in order below
+            const int il = idx0 + grp, site = __builtin_amdgcn_ds_bpermute(il << 2, my_site);
+            const int r = row + (int)(int16_t)(site & 0xffff), c = col + (site >> 16);
+            const bool ok = il <= nper && c >= bs.col_min && c <= bs.col_max && r >= bs.row_min && r <= bs.row_max;
+            rows = osad_rows(ok ? cand_off(r, c) : 0u);
+          }
+#pragma unroll 1
+          for (int g = 0; g < G; ++g) {
+            const int idx = idx0 + g;
+            if (idx > nper) break;
+            const int site = __builtin_amdgcn_readlane(my_site, idx);
+            const int r = row + (int)(int16_t)(site & 0xffff), c = col + (site >> 16);
+            if (!in_range(r, c)) continue;
+            int sad = (int)(G > 1 ? osad_of(rows, g) : osad_at(r, c));   // (`int sad < int best_sad`: this function compares signed, mcomp.c:2206-2215)
             if (sad < best_sad) {
-              best_sad = sad;
-              best_site = idx;
+              sad += sad_cost(a, frr, frc, r, c);
+              if (sad < best_sad) {
+                best_sad = sad;
+                best_site = idx;
+              }
             }
           }
         }
@@ -583,15 +658,24 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
     for (int i = 0; i < 8; ++i) {
       int best_site = -1;
 #pragma unroll 1
-      for (int j = 0; j < 4; ++j) {   // neighbors[4] = (-1,0) (0,-1) (0,1) (1,0)
-        const int r = row + (j == 0 ? -1 : j == 3 ? 1 : 0), c = col + (j == 1 ? -1 : j == 2 ? 1 : 0);
-        if (!in_range(r, c)) continue;
-        uint32_t sad = osad_at(r, c);
-        if (sad < best_sad) {
-          sad += (uint32_t)sad_cost(a, frr, frc, r, c);
+      for (int j0 = 0; j0 < 4; j0 += G) {   // neighbors[4] = (-1,0) (0,-1) (0,1) (1,0)
+        uint32_t rows = 0;
+        if constexpr (G > 1) {
+          const int jl = j0 + grp, r = row + (jl == 0 ? -1 : jl == 3 ? 1 : 0), c = col + (jl == 1 ? -1 : jl == 2 ? 1 : 0);
+          rows = osad_rows(in_range(r, c) ? cand_off(r, c) : 0u);
+        }
+#pragma unroll 1
+        for (int g = 0; g < G; ++g) {
+          const int j = j0 + g;
+          const int r = row + (j == 0 ? -1 : j == 3 ? 1 : 0), c = col + (j == 1 ? -1 : j == 2 ? 1 : 0);
+          if (!in_range(r, c)) continue;
+          uint32_t sad = G > 1 ? osad_of(rows, g) : osad_at(r, c);
           if (sad < best_sad) {
-            best_sad = sad;
-            best_site = j;
+            sad += (uint32_t)sad_cost(a, frr, frc, r, c);
+            if (sad < best_sad) {
+              best_sad = sad;
+              best_site = j;
+            }
           }
         }
       }
@@ -818,6 +902,15 @@ int check_compound(aomhip_ctx *ctx, const aomhip_planes *ref, int frame, int bw,
 
 using namespace aomhip;
 
+// the full-pel kernels of this file by block size (CompoundEval's UNITS and G)
+#define LAUNCH_BY_UNITS(kernel, T, n_px, ...)                                                     \
+  do {                                                                                            \
+    if ((n_px) <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 1, 4>), __VA_ARGS__);          \
+    else if ((n_px) <= 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 1, 2>), __VA_ARGS__);    \
+    else if ((n_px) <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 2, 1>), __VA_ARGS__);    \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 4, 1>), __VA_ARGS__);                       \
+  } while (0)
+
 extern "C" {
 
 int aomhip_refining_search_8p_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh, int mv_cost_type,
@@ -834,12 +927,16 @@ int aomhip_refining_search_8p_batch(aomhip_ctx *ctx, const aomhip_planes *src, c
   if (n_blocks == 0) return AOMHIP_OK;
   const CompoundArgs a{ bw, bh, src->bit_depth, mv_cost_type, sad_per_bit, error_per_bit, invert_mask != 0, d_mvjcost, d_mvcost_row, d_mvcost_col };
   const dim3 grid((n_blocks + 3) / 4), block(256);
-  if (src->bit_depth == 8)
-    hipLaunchKernelGGL(refining_search_8p_kernel<uint8_t>, grid, block, 0, ctx->stream, view_of<uint8_t>(*src), view_of<uint8_t>(*ref), frame, d_blocks, n_blocks,
-                       a, static_cast<const uint8_t *>(d_second_pred), d_mask, d_best_mv, d_best_sad, d_best_var);
-  else
-    hipLaunchKernelGGL(refining_search_8p_kernel<uint16_t>, grid, block, 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame, d_blocks,
-                       n_blocks, a, static_cast<const uint16_t *>(d_second_pred), d_mask, d_best_mv, d_best_sad, d_best_var);
+  // by block size: G = 4 / 2 candidates per wavefront for blocks of up to 64 / 128 pixels, 2 units per lane in registers up to 512 pixels,
+  // 4 up to 1024; beyond that the operands stream
+  const int wide = bw * bh;
+  if (src->bit_depth == 8) {
+    LAUNCH_BY_UNITS(refining_search_8p_kernel, uint8_t, wide, grid, block, 0, ctx->stream, view_of<uint8_t>(*src), view_of<uint8_t>(*ref), frame,
+                    d_blocks, n_blocks, a, static_cast<const uint8_t *>(d_second_pred), d_mask, d_best_mv, d_best_sad, d_best_var);
+  } else {
+    LAUNCH_BY_UNITS(refining_search_8p_kernel, uint16_t, wide, grid, block, 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame,
+                    d_blocks, n_blocks, a, static_cast<const uint16_t *>(d_second_pred), d_mask, d_best_mv, d_best_sad, d_best_var);
+  }
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
@@ -888,14 +985,18 @@ int aomhip_compound_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes
   }
   const CompoundArgs a{ bw, bh, src->bit_depth, p->mv_cost_type, p->sad_per_bit, p->error_per_bit, invert_mask != 0, d_mvjcost, d_mvcost_row, d_mvcost_col };
   const dim3 grid((n_blocks + 3) / 4), block(256);
-  if (src->bit_depth == 8)
-    hipLaunchKernelGGL(compound_full_pixel_diamond_kernel<uint8_t>, grid, block, 0, ctx->stream, view_of<uint8_t>(*src), view_of<uint8_t>(*ref), frame,
-                       d_blocks, n_blocks, a, d_sites, p->step_param, static_cast<const uint8_t *>(d_second_pred), d_mask, d_best_mv, d_best_cost,
-                       d_second_best_mv);
-  else
-    hipLaunchKernelGGL(compound_full_pixel_diamond_kernel<uint16_t>, grid, block, 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame,
-                       d_blocks, n_blocks, a, d_sites, p->step_param, static_cast<const uint16_t *>(d_second_pred), d_mask, d_best_mv, d_best_cost,
-                       d_second_best_mv);
+  // by block size: G = 4 / 2 candidates per wavefront for blocks of up to 64 / 128 pixels, 2 units per lane in registers up to 512 pixels,
+  // 4 up to 1024; beyond that the operands stream
+  const int wide = bw * bh;
+  if (src->bit_depth == 8) {
+    LAUNCH_BY_UNITS(compound_full_pixel_diamond_kernel, uint8_t, wide, grid, block, 0, ctx->stream, view_of<uint8_t>(*src), view_of<uint8_t>(*ref),
+                    frame, d_blocks, n_blocks, a, d_sites, p->step_param, static_cast<const uint8_t *>(d_second_pred), d_mask, d_best_mv, d_best_cost,
+                    d_second_best_mv);
+  } else {
+    LAUNCH_BY_UNITS(compound_full_pixel_diamond_kernel, uint16_t, wide, grid, block, 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref),
+                    frame, d_blocks, n_blocks, a, d_sites, p->step_param, static_cast<const uint16_t *>(d_second_pred), d_mask, d_best_mv,
+                    d_best_cost, d_second_best_mv);
+  }
   AOMHIP_LAUNCH_CHECK();
   // the follow-up of av1_full_pixel_search: needed only where a mesh search can follow (NSTEP's variance threshold, or run_mesh_search)
   const bool nstep = p->search_method == kNstep || p->search_method == kNstep8;
@@ -933,12 +1034,16 @@ int aomhip_obmc_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *re
   }
   const CompoundArgs a{ bw, bh, ref->bit_depth, mv_cost_type, sad_per_bit, error_per_bit, 0, d_mvjcost, d_mvcost_row, d_mvcost_col };
   const dim3 grid((n_blocks + 3) / 4), block(256);
-  if (ref->bit_depth == 8)
-    hipLaunchKernelGGL(obmc_full_pixel_search_kernel<uint8_t>, grid, block, 0, ctx->stream, view_of<uint8_t>(*ref), frame, d_blocks, n_blocks, a, d_sites,
-                       step_param, fast_obmc_search != 0, d_wsrc, d_obmc_mask, d_best_mv, d_best_cost);
-  else
-    hipLaunchKernelGGL(obmc_full_pixel_search_kernel<uint16_t>, grid, block, 0, ctx->stream, view_of<uint16_t>(*ref), frame, d_blocks, n_blocks, a, d_sites,
-                       step_param, fast_obmc_search != 0, d_wsrc, d_obmc_mask, d_best_mv, d_best_cost);
+  // by block size: G = 4 / 2 candidates per wavefront for blocks of up to 64 / 128 pixels, 2 units per lane in registers up to 512 pixels,
+  // 4 up to 1024; beyond that the operands stream
+  const int wide = bw * bh;
+  if (ref->bit_depth == 8) {
+    LAUNCH_BY_UNITS(obmc_full_pixel_search_kernel, uint8_t, wide, grid, block, 0, ctx->stream, view_of<uint8_t>(*ref), frame, d_blocks, n_blocks, a,
+                    d_sites, step_param, fast_obmc_search != 0, d_wsrc, d_obmc_mask, d_best_mv, d_best_cost);
+  } else {
+    LAUNCH_BY_UNITS(obmc_full_pixel_search_kernel, uint16_t, wide, grid, block, 0, ctx->stream, view_of<uint16_t>(*ref), frame, d_blocks, n_blocks, a,
+                    d_sites, step_param, fast_obmc_search != 0, d_wsrc, d_obmc_mask, d_best_mv, d_best_cost);
+  }
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

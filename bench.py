@@ -1702,10 +1702,11 @@ def main():
                               vs_baseline=None, dtype="u16", data="synthetic", ms_per_step=r["ms_per_frame"], config={"workload": r["workload"]})))
         return
     if args.workload == "compound_search_4k_10bit":  # the RD path's compound / OBMC searches (single GPU)
-        r = run_compound_search(pkg, ctx, orc, args.steps, args.warmup)
+        only = int(os.environ.get("AOMHIP_BENCH_COMPOUND_BS", "0"))   # profiling aid: this block size alone (tools/r05_e.sh)
+        r = run_compound_search(pkg, ctx, orc if not only else None, args.steps, args.warmup, bs=only or 16)
         # the same five calls over the frame cut into 8x8, 32x32 and 64x64 blocks (timing only; the tests cover the sizes' parity)
-        r["by_block_size"] = {"16x16": {k: v["ms_per_frame"] for k, v in r.items() if isinstance(v, dict) and "ms_per_frame" in v}}
-        for bs_ in (8, 32, 64):
+        r["by_block_size"] = {"%dx%d" % (only or 16, only or 16): {k: v["ms_per_frame"] for k, v in r.items() if isinstance(v, dict) and "ms_per_frame" in v}}
+        for bs_ in () if only else (8, 32, 64):
             r2 = run_compound_search(pkg, ctx, None, max(3, args.steps // 2), 1, bs=bs_)
             r["by_block_size"]["%dx%d" % (bs_, bs_)] = dict({k: v["ms_per_frame"] for k, v in r2.items() if isinstance(v, dict) and "ms_per_frame" in v},
                                                             blocks_per_frame=r2["blocks_per_frame"])

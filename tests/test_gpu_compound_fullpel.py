@@ -49,8 +49,8 @@ def test_matches_the_interpreted_reference(hip, ctx):
     assert n >= 30
 
 
-@pytest.mark.parametrize("bd", [8, 10])
-@pytest.mark.parametrize("bw,bh", [(16, 16), (8, 8), (32, 16), (32, 32), (64, 64), (4, 8)])
+@pytest.mark.parametrize("bd", [8, 10, 12])   # (12 bits with a mask: the 32-bit blend)
+@pytest.mark.parametrize("bw,bh", [(16, 16), (8, 8), (8, 16), (32, 16), (32, 32), (64, 16), (64, 64), (128, 64), (4, 8)])   # 4 / 2 candidates per wavefront, <= 512 px, <= 1024 px, streamed
 def test_batches_match_the_oracle(hip, oracle, ctx, bd, bw, bh):
     capi = hip.capi
     W, H, B = 320, 192, 96

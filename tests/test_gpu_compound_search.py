@@ -76,8 +76,8 @@ def test_both_searches_match_the_interpreted_reference(hip, ctx):
     assert n8 >= 40 and nob >= 32
 
 
-@pytest.mark.parametrize("bd", [8, 10])
-@pytest.mark.parametrize("bw,bh", [(16, 16), (8, 8), (32, 16), (16, 32), (64, 64)])
+@pytest.mark.parametrize("bd", [8, 10, 12])   # (12 bits with a mask: the 32-bit blend)
+@pytest.mark.parametrize("bw,bh", [(16, 16), (8, 8), (4, 4), (16, 8), (32, 16), (16, 32), (32, 32), (16, 64), (64, 64), (128, 128)])   # 4 / 2 candidates per wavefront, <= 512 px, <= 1024 px, streamed
 def test_batches_match_the_oracle(hip, oracle, ctx, bd, bw, bh):
     capi = hip.capi
     W, H, B = 320, 192, 96
