@@ -38,6 +38,22 @@ __device__ __forceinline__ int sad_cost(const CompoundArgs &a, int frr, int frc,
   const int lambda = a.cost_type == kCostL1Low ? 32 : a.cost_type == kCostL1Mid ? 15 : a.cost_type == kCostL1Hd ? 8 : 0;
   return (lambda * (iabsm(dr) + iabsm(dc))) >> 3;
 }
+// the same with what does not depend on the candidate worked out once per block (left inline the compiler re-derived lambda from cost_type
+// through a chain of scalar branches at every call)
+struct SadCost {
+  const CompoundArgs &a;
+  int frr, frc, lambda;
+  bool entropy;
+  __device__ __forceinline__ SadCost(const CompoundArgs &a_, int frr_, int frc_) : a(a_), frr(frr_), frc(frc_) {
+    entropy = a.cost_type == kCostEntropy;
+    lambda = a.cost_type == kCostL1Low ? 32 : a.cost_type == kCostL1Mid ? 15 : a.cost_type == kCostL1Hd ? 8 : 0;
+  }
+  __device__ __forceinline__ int operator()(int row, int col) const {
+    const int dr = (row - frr) * 8, dc = (col - frc) * 8;
+    if (entropy) return (int)(((unsigned)mv_bits(a, dr, dc) * (unsigned)a.sad_per_bit + 256u) >> 9);
+    return (lambda * (iabsm(dr) + iabsm(dc))) >> 3;
+  }
+};
 __device__ __forceinline__ int var_cost(const CompoundArgs &a, int ref_row, int ref_col, int mrow, int mcol) {   // mv_err_cost_ (:271-308)
   const int dr = mrow - ref_row, dc = mcol - ref_col;
   if (a.cost_type == kCostEntropy) return (int)(((int64_t)mv_bits(a, dr, dc) * a.error_per_bit + (1 << 13)) >> 14);
@@ -64,11 +80,14 @@ __device__ __forceinline__ uint32_t row_sum32(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);   // row_mirror
   return v;
 }
-__device__ __forceinline__ uint32_t wsum32(uint32_t v) {
-  v = row_sum32(v);
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32) +
-         (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+// the four 16-lane sums of row_sum32 added up: row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3, the total in lane 63 -- two DPP
+// adds and one v_readlane instead of four v_readlane and three s_add (these kernels are bound by the CU's one scalar unit, PMC r05e)
+__device__ __forceinline__ uint32_t rows_total32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast31
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ uint32_t wsum32(uint32_t v) { return rows_total32(row_sum32(v)); }
 __device__ __forceinline__ uint64_t wsum32_wide(uint32_t v) {   // the same when only the row sums fit 32 bits
   v = row_sum32(v);
   return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32) +
@@ -224,8 +243,7 @@ template <typename T, int UNITS, int G = 1> struct CompoundEval {
   static __device__ __forceinline__ uint32_t group_total(uint32_t rows, int g) {
     if constexpr (G == 4) return (uint32_t)__builtin_amdgcn_readlane((int)rows, 16 * g);
     if constexpr (G == 2) return (uint32_t)__builtin_amdgcn_readlane((int)rows, 32 * g) + (uint32_t)__builtin_amdgcn_readlane((int)rows, 32 * g + 16);
-    return (uint32_t)__builtin_amdgcn_readlane((int)rows, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rows, 16) +
-           (uint32_t)__builtin_amdgcn_readlane((int)rows, 32) + (uint32_t)__builtin_amdgcn_readlane((int)rows, 48);
+    return rows_total32(rows);
   }
   // the lane's share of the SAD of the candidate at byte offset `off` (cand_off; with G > 1 a value per group)
   __device__ __forceinline__ uint32_t sad_partial(unsigned off) const {
@@ -298,6 +316,7 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
   const T *pred = second_pred + (size_t)bi * n_px;
   const uint8_t *mask = masks ? masks + (size_t)bi * n_px : nullptr;
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
+  const SadCost cost_of(a, frr, frc);   // mvsad_err_cost_
   CompoundEval<T, UNITS, G> ce;
   ce.init(sp, src.stride, rbase, ref.stride, pred, mask, W, H, a.invert_mask, a.bit_depth, lane, bs.row_min, bs.col_min);
   auto sad_at = [&](int row, int col) -> uint32_t { return ce.sad(row, col); };   // get_mvpred_compound_sad
@@ -305,36 +324,50 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
   unsigned long long visited = 0;                       // the 49 cells of do_refine_search_grid
   int grid_center = kRange * kStride + kRange;
   int row = min(max(bs.start_row, bs.row_min), bs.row_max), col = min(max(bs.start_col, bs.col_min), bs.col_max);   // clamp_fullmv
-  uint32_t best_sad = sad_at(row, col) + (uint32_t)sad_cost(a, frr, frc, row, col);
+  uint32_t best_sad = sad_at(row, col) + (uint32_t)cost_of(row, col);
   visited |= 1ull << grid_center;
   // neighbors[] (:1623-1632): (-1,0) (0,-1) (0,1) (1,0) (-1,-1) (1,-1) (-1,1) (1,1)
   auto drow_of = [](int j) { return j == 0 || j == 4 || j == 6 ? -1 : (j == 3 || j == 5 || j == 7 ? 1 : 0); };
   auto dcol_of = [](int j) { return j == 1 || j == 4 || j == 5 ? -1 : (j == 2 || j == 6 || j == 7 ? 1 : 0); };
+  // (the eight neighbours by lane, the scalar unit walks the bits of `valid` in neighbour order: see compound_full_pixel_diamond_kernel)
+  const int dr_l = drow_of(lane & 7), dc_l = dcol_of(lane & 7);
+  constexpr unsigned long long kNeighbours = 0x1C287ull;   // the cells (-1..1, -1..1) \ (0, 0) around cell 8 of the 7-wide grid
   for (int i = 0; i < kRange; ++i) {
     int best_site = -1;
-#pragma unroll 1
-    for (int j0 = 0; j0 < 8; j0 += G) {
-      uint32_t rows = 0;
-      if constexpr (G > 1) {   // the G neighbours j0 .. j0 + G - 1, one per group of lanes; judged in order below
-        const int jl = j0 + ce.grp, r = row + drow_of(jl), c = col + dcol_of(jl), gc = grid_center + drow_of(jl) * kStride + dcol_of(jl);
-        const bool ok = !((visited >> gc) & 1) && c >= bs.col_min && c <= bs.col_max && r >= bs.row_min && r <= bs.row_max;
-        rows = ce.sad_rows(ok ? ce.cand_off(r, c) : 0u);
-      }
-#pragma unroll 1
+    const int r_l = row + dr_l, c_l = col + dc_l, gc_l = grid_center + dr_l * kStride + dc_l;
+    const bool ok_l = lane < 8 && !((visited >> gc_l) & 1) && (unsigned)(r_l - bs.row_min) <= (unsigned)(bs.row_max - bs.row_min) &&
+                      (unsigned)(c_l - bs.col_min) <= (unsigned)(bs.col_max - bs.col_min);
+    visited |= kNeighbours << (grid_center - 8);   // every neighbour is marked before its range test; the centre stays >= 8: two moves at most so far
+    const unsigned off_l = ok_l ? ce.cand_off(r_l, c_l) : 0u;
+    uint32_t valid = (uint32_t)__ballot(ok_l);
+    const unsigned off_c = ce.cand_off(row, col);   // (what an idle group reads)
+    while (valid) {
+      int idx[G], cnt = 0;
+#pragma unroll
       for (int g = 0; g < G; ++g) {
-        const int j = j0 + g;
-        const int drow = drow_of(j), dcol = dcol_of(j);
-        const int gc = grid_center + drow * kStride + dcol;
-        if ((visited >> gc) & 1) continue;
-        visited |= 1ull << gc;
-        const int r = row + drow, c = col + dcol;
-        if (c < bs.col_min || c > bs.col_max || r < bs.row_min || r > bs.row_max) continue;
-        uint32_t sad = G > 1 ? ce.sad_of(rows, g) : sad_at(r, c);
+        idx[g] = valid ? __builtin_ctz(valid) : -1;
+        cnt += valid != 0;
+        valid &= valid - 1;
+      }
+      unsigned off;
+      if constexpr (G == 1) {
+        off = (unsigned)__builtin_amdgcn_readlane((int)off_l, idx[0]);
+      } else {
+        int sel = idx[0];
+#pragma unroll
+        for (int g = 1; g < G; ++g) sel = ce.grp == g ? idx[g] : sel;
+        off = sel < 0 ? off_c : (unsigned)__builtin_amdgcn_ds_bpermute(sel << 2, (int)off_l);
+      }
+      const uint32_t rows = ce.sad_rows(off);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (g >= cnt) break;
+        uint32_t sad = ce.sad_of(rows, g);
         if (sad < best_sad) {
-          sad += (uint32_t)sad_cost(a, frr, frc, r, c);
+          sad += (uint32_t)cost_of(row + drow_of(idx[g]), col + dcol_of(idx[g]));
           if (sad < best_sad) {
             best_sad = sad;
-            best_site = j;
+            best_site = idx[g];
           }
         }
       }
@@ -385,6 +418,7 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
   const T *pred = second_pred + (size_t)bi * n_px;
   const uint8_t *mask = masks ? masks + (size_t)bi * n_px : nullptr;
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
+  const SadCost cost_of(a, frr, frc);   // mvsad_err_cost_
   CompoundEval<T, UNITS, G> ce;
   ce.init(sp, src.stride, rbase, ref.stride, pred, mask, W, H, a.invert_mask, a.bit_depth, lane, bs.row_min, bs.col_min);
   auto sad_at = [&](int row, int col) -> uint32_t { return ce.sad(row, col); };   // get_mvpred_compound_sad: sdaf / msdf
@@ -392,7 +426,7 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
     return (int)ce.var(row, col) + var_cost(a, bs.ref_row, bs.ref_col, row * 8, col * 8);
   };
   const int start_row = min(max(bs.start_row, bs.row_min), bs.row_max), start_col = min(max(bs.start_col, bs.col_min), bs.col_max);   // clamp_fullmv
-  const uint32_t start_sad = sad_at(start_row, start_col) + (uint32_t)sad_cost(a, frr, frc, start_row, start_col);   // (the same in every run)
+  const uint32_t start_sad = sad_at(start_row, start_col) + (uint32_t)cost_of(start_row, start_col);   // (the same in every run)
   int second_row = -32768, second_col = -32768;   // MARK_MV_INVALID (av1_full_pixel_search, :1704-1707)
   const int nsteps = __builtin_amdgcn_readfirstlane(S.num_search_steps);
   auto diamond = [&](int search_step, int *num00, int *orow, int *ocol) -> int {
@@ -411,27 +445,41 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
       const int this_radius = __builtin_amdgcn_readfirstlane(S.radius[step]);
       const int nper = __builtin_amdgcn_readfirstlane(S.searches_per_step[step]);
       const int my_site = *reinterpret_cast<const int *>(&S.mv[step][lane < 17 ? lane : 0][0]);   // (row, col) of site `lane` as one dword
-      for (int idx0 = 1; idx0 <= nper; idx0 += G) {
-        uint32_t rows = 0;
-        if constexpr (G > 1) {   // sites idx0 .. idx0 + G - 1, one per group of lanes; judged in order below
-          const int il = idx0 + ce.grp, site = __builtin_amdgcn_ds_bpermute(il << 2, my_site);   // (il <= 19: lanes past 16 hold site 0, never `ok`)
-          const int r = row + (int)(int16_t)(site & 0xffff), c = col + (site >> 16);
-          const bool ok = il <= nper && c >= bs.col_min && c <= bs.col_max && r >= bs.row_min && r <= bs.row_max;
-          rows = ce.sad_rows(ok ? ce.cand_off(r, c) : 0u);
-        }
-#pragma unroll 1
+      // The stage's sites by lane: position, av1_is_fullmv_in_range and the candidate's offset are worked out for all of them at once in the
+      // vector unit; the scalar unit then only walks the bits of `valid` in site order (per site: ~10 scalar instructions instead of ~40).
+      const int r_l = row + (int)(int16_t)(my_site & 0xffff), c_l = col + (my_site >> 16);
+      const bool ok_l = lane >= 1 && lane <= nper && (unsigned)(r_l - bs.row_min) <= (unsigned)(bs.row_max - bs.row_min) &&
+                        (unsigned)(c_l - bs.col_min) <= (unsigned)(bs.col_max - bs.col_min);
+      const unsigned off_l = ok_l ? ce.cand_off(r_l, c_l) : 0u;
+      uint32_t valid = (uint32_t)__ballot(ok_l);
+      while (valid) {
+        int idx[G], cnt = 0;   // the next G sites in range, one per group of lanes; judged in order below
+#pragma unroll
         for (int g = 0; g < G; ++g) {
-          const int idx = idx0 + g;
-          if (idx > nper) break;
-          const int site = __builtin_amdgcn_readlane(my_site, idx);
-          const int r = row + (int)(int16_t)(site & 0xffff), c = col + (site >> 16);
-          if (c < bs.col_min || c > bs.col_max || r < bs.row_min || r > bs.row_max) continue;   // av1_is_fullmv_in_range
-          uint32_t sad = G > 1 ? ce.sad_of(rows, g) : sad_at(r, c);
+          idx[g] = valid ? __builtin_ctz(valid) : 0;
+          cnt += valid != 0;
+          valid &= valid - 1;
+        }
+        unsigned off;
+        if constexpr (G == 1) {
+          off = (unsigned)__builtin_amdgcn_readlane((int)off_l, idx[0]);
+        } else {
+          int sel = idx[0];
+#pragma unroll
+          for (int g = 1; g < G; ++g) sel = ce.grp == g ? idx[g] : sel;
+          off = (unsigned)__builtin_amdgcn_ds_bpermute(sel << 2, (int)off_l);
+        }
+        const uint32_t rows = ce.sad_rows(off);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (g >= cnt) break;
+          uint32_t sad = ce.sad_of(rows, g);
           if (sad < bestsad) {
-            sad += (uint32_t)sad_cost(a, frr, frc, r, c);   // (looked up only for a site that can win: issuing it for every site beside the pixel reads was SLOWER, 7.7 -> 8.9 ms)
+            const int site = __builtin_amdgcn_readlane(my_site, idx[g]);
+            sad += (uint32_t)cost_of(row + (int)(int16_t)(site & 0xffff), col + (site >> 16));   // (looked up only for a site that can win: issuing it for every site beside the pixel reads was SLOWER, 7.7 -> 8.9 ms)
             if (sad < bestsad) {
               bestsad = sad;
-              best_site = idx;
+              best_site = idx[g];
             }
           }
         }
@@ -504,6 +552,7 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
   const int32_t *wsrc = wsrc_all + (size_t)bi * n_px, *omask = omask_all + (size_t)bi * n_px;
   const int shift = a.bit_depth == 10 ? 2 : a.bit_depth == 12 ? 4 : 0;
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
+  const SadCost cost_of(a, frr, frc);   // mvsad_err_cost_
   // As CompoundEval: the weighted source and the mask of the block stay in registers for blocks of up to 256 * UNITS pixels, a candidate is then
   // 2 * UNITS independent reference loads per lane; larger blocks stream them four pixels at a time.  Widths are powers of two (row / column
   // of pixel t by shift and mask).
@@ -513,6 +562,16 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
   const int u = lane & (kLanes - 1), grp = lane / kLanes;
   const int lw = __builtin_ctz((unsigned)W), wm = W - 1;
   const bool keep = n_px <= 4 * kLanes * kUnits;
+  // |wsrc - pre * mask| + 2048 as ONE v_sad_u32 on operands biased by 2^31 (the unsigned difference of the biased values is the signed one's
+  // magnitude), pre * mask + 2^31 as one v_mad_u32_u24 (pre < 2^12; mask <= 4096 = 64 x 64 as calc_target_weighted_pred builds it, any
+  // value below 2^24 works): 4 instructions per pixel with the shift and the sum instead of 7
+  constexpr int kBias = (int)0x80000000u;
+  auto round_abs12 = [](int ws_biased, int f, int m) -> uint32_t {
+    uint32_t pm, r;   // (no builtin for v_sad_u32, and the compiler splits the biased product into v_mul_u32_u24 + v_xor: the constants ride in SGPRs)
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pm) : "v"((uint32_t)f), "v"((uint32_t)m), "s"(0x80000000u));
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"((uint32_t)ws_biased), "v"(pm), "s"(2048u));
+    return r >> 12;   // ROUND_POWER_OF_TWO(abs(..), 12)
+  };
   int ws_[kUnits][4], om_[kUnits][4];
   // candidate pixels by 32-bit byte offset from the block at the window's top-left MV (see CompoundEval)
   const char *base0 = reinterpret_cast<const char *>(rbase + (int64_t)bs.row_min * ref.stride + bs.col_min);
@@ -525,7 +584,7 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
       lo_[k] = t < n_px ? ref_off(t) : 0u;
       int4 a = make_int4(0, 0, 0, 0), b = a;
       if (t < n_px) { a = *reinterpret_cast<const int4 *>(wsrc + t); b = *reinterpret_cast<const int4 *>(omask + t); }
-      ws_[k][0] = a.x; ws_[k][1] = a.y; ws_[k][2] = a.z; ws_[k][3] = a.w;
+      ws_[k][0] = a.x ^ kBias; ws_[k][1] = a.y ^ kBias; ws_[k][2] = a.z ^ kBias; ws_[k][3] = a.w ^ kBias;
       om_[k][0] = b.x; om_[k][1] = b.y; om_[k][2] = b.z; om_[k][3] = b.w;
     }
   }
@@ -547,7 +606,7 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
       for (int k = 0; k < kUnits; ++k)
         if (k * 4 * kLanes < n_px) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc += (uint32_t)((iabsm(ws_[k][i] - f[k][i] * om_[k][i]) + 2048) >> 12);   // ROUND_POWER_OF_TWO(abs(..), 12); beyond the block: 0
+          for (int i = 0; i < 4; ++i) acc += round_abs12(ws_[k][i], f[k][i], om_[k][i]);   // (beyond the block: |0 - 0| + 2048 >> 12 = 0)
         }
     } else if constexpr (G == 1) {
 #pragma unroll 1   // (unrolled by two the int4 loads took the kernel to ~300 VGPRs)
@@ -555,8 +614,8 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
         int f[4];
         load_px4<T>(reinterpret_cast<const T *>(base0 + (ref_off(t) + off)), f);
         const int4 w = *reinterpret_cast<const int4 *>(wsrc + t), m = *reinterpret_cast<const int4 *>(omask + t);
-        acc += (uint32_t)((iabsm(w.x - f[0] * m.x) + 2048) >> 12) + (uint32_t)((iabsm(w.y - f[1] * m.y) + 2048) >> 12) +
-               (uint32_t)((iabsm(w.z - f[2] * m.z) + 2048) >> 12) + (uint32_t)((iabsm(w.w - f[3] * m.w) + 2048) >> 12);
+        acc += round_abs12(w.x ^ kBias, f[0], m.x) + round_abs12(w.y ^ kBias, f[1], m.y) + round_abs12(w.z ^ kBias, f[2], m.z) +
+               round_abs12(w.w ^ kBias, f[3], m.w);
       }
     }
     return acc;
@@ -592,32 +651,45 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
       const int tot_steps = nsteps - search_step;   // (table reads through v_readfirstlane / v_readlane: see compound_full_pixel_diamond_kernel)
       int row = start_row, col = start_col;
       *num00 = 0;
-      int best_sad = (int)(osad_at(row, col) + (uint32_t)sad_cost(a, frr, frc, row, col));
+      int best_sad = (int)(osad_at(row, col) + (uint32_t)cost_of(row, col));
       for (int step = tot_steps - 1; step >= 0; --step) {
         int best_site = 0;
         const int nper = __builtin_amdgcn_readfirstlane(S.searches_per_step[step]);
         const int my_site = *reinterpret_cast<const int *>(&S.mv[step][lane < 17 ? lane : 0][0]);
-        for (int idx0 = 1; idx0 <= nper; idx0 += G) {
-          uint32_t rows = 0;
-          if constexpr (G > 1) {   // sites idx0 .. idx0 + G - 1, one per group of lanes; judged in order below
-            const int il = idx0 + grp, site = __builtin_amdgcn_ds_bpermute(il << 2, my_site);
-            const int r = row + (int)(int16_t)(site & 0xffff), c = col + (site >> 16);
-            const bool ok = il <= nper && c >= bs.col_min && c <= bs.col_max && r >= bs.row_min && r <= bs.row_max;
-            rows = osad_rows(ok ? cand_off(r, c) : 0u);
-          }
-#pragma unroll 1
+        // (the stage's sites by lane, the scalar unit walks the bits of `valid`: see compound_full_pixel_diamond_kernel)
+        const int r_l = row + (int)(int16_t)(my_site & 0xffff), c_l = col + (my_site >> 16);
+        const bool ok_l = lane >= 1 && lane <= nper && (unsigned)(r_l - bs.row_min) <= (unsigned)(bs.row_max - bs.row_min) &&
+                          (unsigned)(c_l - bs.col_min) <= (unsigned)(bs.col_max - bs.col_min);
+        const unsigned off_l = ok_l ? cand_off(r_l, c_l) : 0u;
+        uint32_t valid = (uint32_t)__ballot(ok_l);
+        while (valid) {
+          int idx[G], cnt = 0;
+#pragma unroll
           for (int g = 0; g < G; ++g) {
-            const int idx = idx0 + g;
-            if (idx > nper) break;
-            const int site = __builtin_amdgcn_readlane(my_site, idx);
-            const int r = row + (int)(int16_t)(site & 0xffff), c = col + (site >> 16);
-            if (!in_range(r, c)) continue;
-            int sad = (int)(G > 1 ? osad_of(rows, g) : osad_at(r, c));   // (`int sad < int best_sad`: this function compares signed, mcomp.c:2206-2215)
+            idx[g] = valid ? __builtin_ctz(valid) : 0;
+            cnt += valid != 0;
+            valid &= valid - 1;
+          }
+          unsigned off;
+          if constexpr (G == 1) {
+            off = (unsigned)__builtin_amdgcn_readlane((int)off_l, idx[0]);
+          } else {
+            int sel = idx[0];
+#pragma unroll
+            for (int g = 1; g < G; ++g) sel = grp == g ? idx[g] : sel;
+            off = (unsigned)__builtin_amdgcn_ds_bpermute(sel << 2, (int)off_l);
+          }
+          const uint32_t rows = osad_rows(off);
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            if (g >= cnt) break;
+            int sad = (int)osad_of(rows, g);   // (`int sad < int best_sad`: this function compares signed, mcomp.c:2206-2215)
             if (sad < best_sad) {
-              sad += sad_cost(a, frr, frc, r, c);
+              const int site = __builtin_amdgcn_readlane(my_site, idx[g]);
+              sad += cost_of(row + (int)(int16_t)(site & 0xffff), col + (site >> 16));
               if (sad < best_sad) {
                 best_sad = sad;
-                best_site = idx;
+                best_site = idx[g];
               }
             }
           }
@@ -654,7 +726,7 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
     result = bestsme;
   } else {   // obmc_refining_search_sad from the clamped start MV
     int row = start_row, col = start_col;
-    uint32_t best_sad = osad_at(row, col) + (uint32_t)sad_cost(a, frr, frc, row, col);
+    uint32_t best_sad = osad_at(row, col) + (uint32_t)cost_of(row, col);
     for (int i = 0; i < 8; ++i) {
       int best_site = -1;
 #pragma unroll 1
@@ -671,7 +743,7 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
           if (!in_range(r, c)) continue;
           uint32_t sad = G > 1 ? osad_of(rows, g) : osad_at(r, c);
           if (sad < best_sad) {
-            sad += (uint32_t)sad_cost(a, frr, frc, r, c);
+            sad += (uint32_t)cost_of(r, c);
             if (sad < best_sad) {
               best_sad = sad;
               best_site = j;

@@ -360,12 +360,89 @@ template <typename T> struct CompoundRef {
 #pragma unroll
     for (int i = 0; i < N; ++i) f[i] = invert ? (m[i] * p[i] + (64 - m[i]) * f[i] + 32) >> 6 : (m[i] * f[i] + (64 - m[i]) * p[i] + 32) >> 6;
   }
+  // The same on N pixels held as N / 2 packed 16-bit pairs: (A * f + C) >> sh with A = 1, C = p + 1, sh = 1 without a mask and A = m (inverted:
+  // 64 - m), C = (64 - A) * p + 32, sh = 6 with one -- v_pk_* on pixel pairs, 3 / 6 instructions per pair instead of 6 / 14.  A * f + C fits 16
+  // bits for every depth without a mask and up to 10 bits with one; 12-bit masked pixels go through blend_run.
+  template <int N> __device__ __forceinline__ void blend_pairs(uint32_t *f2, int idx, int bit_depth) const {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    if (mask && bit_depth > 10) {
+      int f[N];
+#pragma unroll
+      for (int i = 0; i < N / 2; ++i) { f[2 * i] = (int)(f2[i] & 0xffffu); f[2 * i + 1] = (int)(f2[i] >> 16); }
+      blend_run<N>(f, idx);
+#pragma unroll
+      for (int i = 0; i < N / 2; ++i) f2[i] = (uint32_t)f[2 * i] | ((uint32_t)f[2 * i + 1] << 16);
+      return;
+    }
+    uint32_t p2[N / 2], m2[N / 2];
+    if constexpr (sizeof(T) == 2) {
+      if constexpr (N == 8) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(second + idx);
+        p2[0] = w.x; p2[1] = w.y; p2[2] = w.z; p2[3] = w.w;
+      } else {
+        const uint2 w = *reinterpret_cast<const uint2 *>(second + idx);
+        p2[0] = w.x; p2[1] = w.y;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < N / 4; ++h) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(second + idx + 4 * h);
+        p2[2 * h] = __builtin_amdgcn_perm(0, w, 0x0c010c00);
+        p2[2 * h + 1] = __builtin_amdgcn_perm(0, w, 0x0c030c02);
+      }
+    }
+    const u16x2 one = { 1, 1 }, c64 = { 64, 64 }, c32 = { 32, 32 }, s6 = { 6, 6 };
+    if (!mask) {
+#pragma unroll
+      for (int i = 0; i < N / 2; ++i)
+        f2[i] = __builtin_bit_cast(uint32_t, (u16x2)((__builtin_bit_cast(u16x2, f2[i]) + __builtin_bit_cast(u16x2, p2[i]) + one) >> one));
+      return;
+    }
+#pragma unroll
+    for (int h = 0; h < N / 4; ++h) {
+      const uint32_t w = *reinterpret_cast<const uint32_t *>(mask + idx + 4 * h);
+      m2[2 * h] = __builtin_amdgcn_perm(0, w, 0x0c010c00);
+      m2[2 * h + 1] = __builtin_amdgcn_perm(0, w, 0x0c030c02);
+    }
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+      const u16x2 m = __builtin_bit_cast(u16x2, m2[i]), A = invert ? c64 - m : m;
+      const u16x2 Cc = (c64 - A) * __builtin_bit_cast(u16x2, p2[i]) + c32;
+      f2[i] = __builtin_bit_cast(uint32_t, (u16x2)((A * __builtin_bit_cast(u16x2, f2[i]) + Cc) >> s6));
+    }
+  }
 };
+
+// How many 16-lane groups share one candidate in a round of n candidates (general sub-pel instantiation): the block's rows are cut into
+// that many parts (>= 4 rows each), the parts' sums added at the end (parts_sum).
+// (a lone candidate over FOUR groups: at 16 x 16 the horizontal pass of a 4-row part is 9 rows x 2 units = 18 units, two passes of the 16 lanes
+// like the 26 units of an 8-row part -- the same latency for twice the instructions; two groups is the default)
+#ifndef AOMHIP_SUBPEL_SPLIT1
+#define AOMHIP_SUBPEL_SPLIT1 2
+#endif
+template <int H> __device__ __forceinline__ constexpr int parts_of(int n) {
+  constexpr int kMax = H >= 16 ? 4 : (H >= 8 ? 2 : 1);
+  return n == 1 ? (kMax < AOMHIP_SUBPEL_SPLIT1 ? kMax : AOMHIP_SUBPEL_SPLIT1) : (n == 2 ? (kMax < 2 ? kMax : 2) : 1);
+}
+// the sums of the nparts (2 or 4) adjacent groups that shared a candidate, in every lane of them
+__device__ __forceinline__ void parts_sum(int64_t &tsum, uint64_t &tsse, int nparts) {
+  int32_t s32 = (int32_t)tsum;   // |sum| <= 4095 * 128 * 128 < 2^31
+  uint32_t lo = (uint32_t)tsse, hi = (uint32_t)(tsse >> 32);
+  s32 += __shfl_xor(s32, 16, 64);
+  uint64_t q = tsse + (((uint64_t)(uint32_t)__shfl_xor((int)hi, 16, 64) << 32) | (uint32_t)__shfl_xor((int)lo, 16, 64));
+  if (nparts == 4) {
+    s32 += __shfl_xor(s32, 32, 64);
+    lo = (uint32_t)q; hi = (uint32_t)(q >> 32);
+    q += ((uint64_t)(uint32_t)__shfl_xor((int)hi, 32, 64) << 32) | (uint32_t)__shfl_xor((int)lo, 32, 64);
+  }
+  tsum = s32;
+  tsse = q;
+}
 
 template <typename T, int W, int H, bool SUBPEL>
 __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, int xoff, int yoff, const T *bp, int bstride,
                                                      bool a_minus_b, int bit_depth, int j, bool active,
-                                                     uint32_t *sse_out, const CompoundRef<T> *comp = nullptr) {
+                                                     uint32_t *sse_out, const CompoundRef<T> *comp = nullptr, int part = 0, int nparts = 1) {
   constexpr int UE = W >= 8 ? 8 : 4;
   constexpr int UPR = W / UE;
   constexpr int U = UPR * H;
@@ -377,7 +454,7 @@ __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, i
   int32_t sum = 0;   // |Σd| <= 4095 * W * H < 2^31 for every block size
   uint64_t sse = 0;
   if (active) {
-    for (int u = j; u < U; u += 16) {
+    for (int u = part * (U / nparts) + j; u < (part + 1) * (U / nparts); u += 16) {   // (nparts groups share the candidate: rows part * H / nparts ..)
       const int row = u / UPR, col = (u % UPR) * UE;
       const T *a0 = ap + (int64_t)row * astride + col;
       const L bv = *reinterpret_cast<const L *>(bp + (int64_t)row * bstride + col);
@@ -414,8 +491,9 @@ __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, i
       sse += uq;
     }
   }
-  const int64_t tsum = (int64_t)(int32_t)row16_sum_u32((uint32_t)sum);
-  const uint64_t tsse = row16_sum_u64(sse);
+  int64_t tsum = (int64_t)(int32_t)row16_sum_u32((uint32_t)sum);
+  uint64_t tsse = row16_sum_u64(sse);
+  if (nparts > 1) parts_sum(tsum, tsse, nparts);
   int32_t sfin;
   uint32_t q;
   if (bit_depth == 10) {
