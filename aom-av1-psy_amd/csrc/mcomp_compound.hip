@@ -107,6 +107,49 @@ template <typename T> __device__ __forceinline__ void load_px4(const T *p, int o
     out[0] = (int)(w.x & 0xffffu); out[1] = (int)(w.x >> 16); out[2] = (int)(w.y & 0xffffu); out[3] = (int)(w.y >> 16);
   }
 }
+// The candidates of one search stage, judged in site order.  The stage's sites live one per lane: `valid` has a bit per site that is to be
+// evaluated (in range, not yet visited), `off_l` is the lane's site's candidate offset.  The scalar unit walks the bits G at a time (G groups
+// of lanes evaluate G candidates at once, `idle_off` is what a group without a candidate reads).  fetch(off, px) requests the pixels,
+// rows_of(off, px) -> the 16-lane sums; judge(site, rows, g).
+// (Requesting the NEXT batch's pixels before the current one is reduced and judged -- within a stage which sites are read does not depend
+// on the outcomes -- was measured and is not taken: the rotation of the fetched registers and the second copy of the control flow cost
+// more issue slots than the overlap hides, compound diamond 475 -> 520 us, OBMC 0.67 -> 0.75 ms per 4K 10-bit frame; PMC: 4038 -> 5326
+// scalar and 3621 -> 4550 vector instructions per block.  These kernels are bound by instruction issue, not by latency.)
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f) {   // f(0) .. f(N - 1), unrolled by construction
+  if constexpr (I < N) {
+    f(I);
+    static_for<I + 1, N>(f);
+  }
+}
+template <int G, typename PX, typename FetchFn, typename RowsFn, typename JudgeFn>
+__device__ __forceinline__ void walk_sites(uint32_t valid, unsigned off_l, unsigned idle_off, int grp, FetchFn fetch, RowsFn rows_of, JudgeFn judge) {
+  auto pop = [&](int (&idx)[G], int &cnt) -> unsigned {
+    cnt = 0;
+    static_for<0, G>([&](int g) {
+      idx[g] = valid ? __builtin_ctz(valid) : -1;
+      cnt += valid != 0;
+      valid &= valid - 1;
+    });
+    if constexpr (G == 1) {
+      return (unsigned)__builtin_amdgcn_readlane((int)off_l, idx[0]);
+    } else {
+      int sel = idx[0];
+      static_for<1, G>([&](int g) { sel = grp == g ? idx[g] : sel; });
+      return sel < 0 ? idle_off : (unsigned)__builtin_amdgcn_ds_bpermute(sel << 2, (int)off_l);
+    }
+  };
+  while (valid) {
+    int idx[G], cnt;
+    PX px;
+    const unsigned off = pop(idx, cnt);
+    fetch(off, px);
+    const uint32_t rows = rows_of(off, px);
+    static_for<0, G>([&](int g) {
+      if (g < cnt) judge(idx[g], rows, g);
+    });
+  }
+}
+
 // One block's compound error functions evaluated by the 64 lanes (a lane owns units of four adjacent pixels): get_mvpred_compound_sad
 // (vfp->sdaf / msdf) and the variance of get_mvpred_compound_var[_cost] (svaf / msvf at offset 0).  What does not depend on the candidate --
 // the source block, the other reference's predictor, the blend weights -- stays in registers, as packed 16-bit pairs, for blocks of up to
@@ -118,7 +161,7 @@ template <typename T> __device__ __forceinline__ void load_px4(const T *p, int o
 // group holds the whole block (<= 128 / <= 64 pixels) and evaluates a DIFFERENT candidate -- sad_partial() takes the candidate's offset per
 // lane, group_total() reads one group's sum -- so a search stage's sites are evaluated G at a time and then judged one after the other in the
 // reference's order (the comparisons are the same: which sites are read does not depend on the running best).
-template <typename T, int UNITS, int G = 1> struct CompoundEval {
+template <typename T, int UNITS, int G = 1, bool PACKED = true> struct CompoundEval {
   static constexpr int kUnits = UNITS;   // 4-pixel units per lane kept in registers
   static constexpr int kGroups = G, kLanes = 64 / G;   // lanes per group
   static_assert(G == 1 || (UNITS == 1 && (G == 2 || G == 4)), "groups hold one unit per lane");
@@ -127,7 +170,11 @@ template <typename T, int UNITS, int G = 1> struct CompoundEval {
   const T *sp, *pred;
   const uint8_t *mask;
   int sstride, rstride, lw, wm, n_px, shift, invert, bit_depth, lane, sh;
-  bool keep, packed;
+  bool keep;
+  static constexpr bool packed = PACKED;   // (the launcher's choice: !mask || bit_depth <= 10)
+  // G == 1: the launcher gives blocks of exactly 256 * UNITS pixels to this instantiation (256, 512, 1024; larger ones stream), so a kept block
+  // fills every unit of every lane -- no per-lane or per-unit tests inside a candidate; G > 1: blocks of 16 .. 128 pixels, tested
+  static constexpr bool kFull = G == 1;
   // A candidate's pixels are addressed as base0 + 32-bit byte offset (scalar base, one vector add per unit): base0 is the reference block at
   // the search window's top-left MV (row_min, col_min), so every offset a search can ask for is non-negative; lo_ = the lane's own offset
   const char *base0;
@@ -178,15 +225,14 @@ template <typename T, int UNITS, int G = 1> struct CompoundEval {
     shift = bit_depth == 10 ? 2 : bit_depth == 12 ? 4 : 0;   // the _bits10 / _bits12 vtable wrappers (encoder_utils.h)
     sh = mask ? 6 : 1;
     sh2 = (uint32_t)sh | ((uint32_t)sh << 16);
-    keep = n_px <= 4 * kLanes * kUnits;
-    packed = !mask || bit_depth <= 10;
+    keep = kFull ? n_px == 4 * kLanes * kUnits : n_px <= 4 * kLanes * kUnits;
     if (keep) {
 #pragma unroll
       for (int k = 0; k < kUnits; ++k) {
         const int t = 4 * (k * kLanes + u);
-        lo_[k] = t < n_px ? ref_off(t) : 0u;
+        lo_[k] = kFull || t < n_px ? ref_off(t) : 0u;
         sA_[k][0] = sA_[k][1] = sC_[k][0] = sC_[k][1] = sS_[k][0] = sS_[k][1] = 0;   // lanes beyond the block: blend 0 against source 0
-        if (t < n_px) operands(t, sA_[k], sC_[k], sS_[k]);
+        if (kFull || t < n_px) operands(t, sA_[k], sC_[k], sS_[k]);
       }
     }
   }
@@ -236,7 +282,7 @@ template <typename T, int UNITS, int G = 1> struct CompoundEval {
     for (int k = 0; k < kUnits; ++k) {
       const int t = 4 * (k * kLanes + u);
       f2[k][0] = f2[k][1] = 0;
-      if (k * 4 * kLanes < n_px && t < n_px) load_pairs<T>(reinterpret_cast<const T *>(base0 + (lo_[k] + off)), f2[k]);
+      if (kFull || (k * 4 * kLanes < n_px && t < n_px)) load_pairs<T>(reinterpret_cast<const T *>(base0 + (lo_[k] + off)), f2[k]);
     }
   }
   // the sum of one group's lanes out of the 16-lane sums row_sum32 leaves in every lane (g is uniform)
@@ -245,17 +291,20 @@ template <typename T, int UNITS, int G = 1> struct CompoundEval {
     if constexpr (G == 2) return (uint32_t)__builtin_amdgcn_readlane((int)rows, 32 * g) + (uint32_t)__builtin_amdgcn_readlane((int)rows, 32 * g + 16);
     return rows_total32(rows);
   }
-  // the lane's share of the SAD of the candidate at byte offset `off` (cand_off; with G > 1 a value per group)
-  __device__ __forceinline__ uint32_t sad_partial(unsigned off) const {
+  // the lane's share of the SAD of the candidate at byte offset `off` (cand_off; with G > 1 a value per group): fetch() requests the
+  // candidate's pixels (blocks kept in registers; a streamed block reads them as it goes), sad_partial() does the arithmetic
+  struct Px { uint32_t f2[kUnits][2]; };
+  __device__ __forceinline__ void fetch(unsigned off, Px &px) const {
+    if (keep) load_ref(off, px.f2);
+  }
+  __device__ __forceinline__ uint32_t sad_partial(unsigned off, const Px &px) const {
     uint32_t acc = 0;
     if (keep) {
-      uint32_t f2[kUnits][2];
-      load_ref(off, f2);
 #pragma unroll
       for (int k = 0; k < kUnits; ++k)
-        if (k * 4 * kLanes < n_px) acc = unit_sad(f2[k], sA_[k], sC_[k], sS_[k], acc);
+        if (kFull || k * 4 * kLanes < n_px) acc = unit_sad(px.f2[k], sA_[k], sC_[k], sS_[k], acc);
     } else if constexpr (G == 1) {
-#pragma unroll 2
+#pragma unroll 1
       for (int t = 4 * lane; t < n_px; t += 256) {
         uint32_t A2[2], C2[2], S2[2], f2[2];
         load_pairs<T>(reinterpret_cast<const T *>(base0 + (ref_off(t) + off)), f2);
@@ -266,7 +315,12 @@ template <typename T, int UNITS, int G = 1> struct CompoundEval {
     return acc;
   }
   // G candidates at once: rows = sad_rows(offset per group), then sad_of(rows, g) for each
-  __device__ __forceinline__ uint32_t sad_rows(unsigned off) const { return row_sum32(sad_partial(off)); }
+  __device__ __forceinline__ uint32_t sad_rows(unsigned off, const Px &px) const { return row_sum32(sad_partial(off, px)); }
+  __device__ __forceinline__ uint32_t sad_rows(unsigned off) const {
+    Px px;
+    fetch(off, px);
+    return sad_rows(off, px);
+  }
   __device__ __forceinline__ uint32_t sad_of(uint32_t rows, int g) const { return group_total(rows, g) >> shift; }
   __device__ __forceinline__ uint32_t sad(int row, int col) const { return sad_of(sad_rows(cand_off(row, col)), 0); }
   __device__ __forceinline__ uint32_t var(int row, int col) const {   // (without the MV cost)
@@ -279,7 +333,7 @@ template <typename T, int UNITS, int G = 1> struct CompoundEval {
       load_ref(off, f2);
 #pragma unroll
       for (int k = 0; k < kUnits; ++k)
-        if (k * 4 * kLanes < n_px) unit_var(f2[k], sA_[k], sC_[k], sS_[k], s, q);
+        if (kFull || k * 4 * kLanes < n_px) unit_var(f2[k], sA_[k], sC_[k], sS_[k], s, q);
       if constexpr (G == 1) q64 = wsum32_wide(q);
       else q64 = group_total(row_sum32(q), 0);   // (every group evaluated the same candidate; <= 128 pixels: 32 bits)
     } else if constexpr (G > 1) {
@@ -299,7 +353,7 @@ template <typename T, int UNITS, int G = 1> struct CompoundEval {
   }
 };
 
-template <typename T, int UNITS, int G>
+template <typename T, int UNITS, int G, bool PACKED>
 __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks,
                                                                  int n_blocks, CompoundArgs a, const T *__restrict__ second_pred,
                                                                  const uint8_t *__restrict__ masks, int16_t *__restrict__ out_mv,
@@ -317,7 +371,7 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
   const uint8_t *mask = masks ? masks + (size_t)bi * n_px : nullptr;
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
   const SadCost cost_of(a, frr, frc);   // mvsad_err_cost_
-  CompoundEval<T, UNITS, G> ce;
+  CompoundEval<T, UNITS, G, PACKED> ce;
   ce.init(sp, src.stride, rbase, ref.stride, pred, mask, W, H, a.invert_mask, a.bit_depth, lane, bs.row_min, bs.col_min);
   auto sad_at = [&](int row, int col) -> uint32_t { return ce.sad(row, col); };   // get_mvpred_compound_sad
   constexpr int kRange = 3, kStride = 2 * kRange + 1;   // SEARCH_RANGE_8P, SEARCH_GRID_STRIDE_8P (mcomp_structs.h:26-29)
@@ -340,38 +394,19 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
     visited |= kNeighbours << (grid_center - 8);   // every neighbour is marked before its range test; the centre stays >= 8: two moves at most so far
     const unsigned off_l = ok_l ? ce.cand_off(r_l, c_l) : 0u;
     uint32_t valid = (uint32_t)__ballot(ok_l);
-    const unsigned off_c = ce.cand_off(row, col);   // (what an idle group reads)
-    while (valid) {
-      int idx[G], cnt = 0;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        idx[g] = valid ? __builtin_ctz(valid) : -1;
-        cnt += valid != 0;
-        valid &= valid - 1;
-      }
-      unsigned off;
-      if constexpr (G == 1) {
-        off = (unsigned)__builtin_amdgcn_readlane((int)off_l, idx[0]);
-      } else {
-        int sel = idx[0];
-#pragma unroll
-        for (int g = 1; g < G; ++g) sel = ce.grp == g ? idx[g] : sel;
-        off = sel < 0 ? off_c : (unsigned)__builtin_amdgcn_ds_bpermute(sel << 2, (int)off_l);
-      }
-      const uint32_t rows = ce.sad_rows(off);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if (g >= cnt) break;
-        uint32_t sad = ce.sad_of(rows, g);
-        if (sad < best_sad) {
-          sad += (uint32_t)cost_of(row + drow_of(idx[g]), col + dcol_of(idx[g]));
+    walk_sites<G, typename CompoundEval<T, UNITS, G, PACKED>::Px>(
+        valid, off_l, ce.cand_off(row, col), ce.grp, [&](unsigned off, auto &px) { ce.fetch(off, px); },
+        [&](unsigned off, const auto &px) { return ce.sad_rows(off, px); },
+        [&](int j, uint32_t rows, int g) {
+          uint32_t sad = ce.sad_of(rows, g);
           if (sad < best_sad) {
-            best_sad = sad;
-            best_site = idx[g];
+            sad += (uint32_t)cost_of(row + drow_of(j), col + dcol_of(j));
+            if (sad < best_sad) {
+              best_sad = sad;
+              best_site = j;
+            }
           }
-        }
-      }
-    }
+        });
     if (best_site == -1) break;
     const int j = best_site;
     const int drow = j == 0 || j == 4 || j == 6 ? -1 : (j == 3 || j == 5 || j == 7 ? 1 : 0);
@@ -392,7 +427,7 @@ __global__ __launch_bounds__(256) void refining_search_8p_kernel(PlaneView<T> sr
 // get_mvpred_compound_sad whenever ms_buffers.second_pred is set (:1347), every run ends on get_mvpred_compound_var_cost (:676-708) and
 // *second_best_mv follows every move of every run.  What av1_full_pixel_search does after it (:1756-1830) -- on the PLAIN sdf / vf even on a
 // compound -- is the general kernel's (fullpel_search.inc, SearchArgs::resume).
-template <typename T, int UNITS, int G>
+template <typename T, int UNITS, int G, bool PACKED>
 __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneView<T> src, PlaneView<T> ref, int frame,
                                                                           const aomhip_search_block *__restrict__ blocks, int n_blocks, CompoundArgs a,
                                                                           const SiteTable *__restrict__ sites, int step_param,
@@ -419,7 +454,7 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
   const uint8_t *mask = masks ? masks + (size_t)bi * n_px : nullptr;
   const int frr = (bs.ref_row + 3 + (bs.ref_row >= 0)) >> 3, frc = (bs.ref_col + 3 + (bs.ref_col >= 0)) >> 3;
   const SadCost cost_of(a, frr, frc);   // mvsad_err_cost_
-  CompoundEval<T, UNITS, G> ce;
+  CompoundEval<T, UNITS, G, PACKED> ce;
   ce.init(sp, src.stride, rbase, ref.stride, pred, mask, W, H, a.invert_mask, a.bit_depth, lane, bs.row_min, bs.col_min);
   auto sad_at = [&](int row, int col) -> uint32_t { return ce.sad(row, col); };   // get_mvpred_compound_sad: sdaf / msdf
   auto var_at = [&](int row, int col) -> int {   // get_mvpred_compound_var_cost: svaf / msvf at offset (0, 0) + mv_err_cost_
@@ -451,39 +486,21 @@ __global__ __launch_bounds__(256) void compound_full_pixel_diamond_kernel(PlaneV
       const bool ok_l = lane >= 1 && lane <= nper && (unsigned)(r_l - bs.row_min) <= (unsigned)(bs.row_max - bs.row_min) &&
                         (unsigned)(c_l - bs.col_min) <= (unsigned)(bs.col_max - bs.col_min);
       const unsigned off_l = ok_l ? ce.cand_off(r_l, c_l) : 0u;
-      uint32_t valid = (uint32_t)__ballot(ok_l);
-      while (valid) {
-        int idx[G], cnt = 0;   // the next G sites in range, one per group of lanes; judged in order below
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          idx[g] = valid ? __builtin_ctz(valid) : 0;
-          cnt += valid != 0;
-          valid &= valid - 1;
-        }
-        unsigned off;
-        if constexpr (G == 1) {
-          off = (unsigned)__builtin_amdgcn_readlane((int)off_l, idx[0]);
-        } else {
-          int sel = idx[0];
-#pragma unroll
-          for (int g = 1; g < G; ++g) sel = ce.grp == g ? idx[g] : sel;
-          off = (unsigned)__builtin_amdgcn_ds_bpermute(sel << 2, (int)off_l);
-        }
-        const uint32_t rows = ce.sad_rows(off);
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          if (g >= cnt) break;
-          uint32_t sad = ce.sad_of(rows, g);
-          if (sad < bestsad) {
-            const int site = __builtin_amdgcn_readlane(my_site, idx[g]);
-            sad += (uint32_t)cost_of(row + (int)(int16_t)(site & 0xffff), col + (site >> 16));   // (looked up only for a site that can win: issuing it for every site beside the pixel reads was SLOWER, 7.7 -> 8.9 ms)
+      walk_sites<G, typename CompoundEval<T, UNITS, G, PACKED>::Px>(
+          (uint32_t)__ballot(ok_l), off_l, 0u, ce.grp, [&](unsigned off, auto &px) { ce.fetch(off, px); },
+          [&](unsigned off, const auto &px) { return ce.sad_rows(off, px); },
+          [&](int idx, uint32_t rows, int g) {
+            uint32_t sad = ce.sad_of(rows, g);
             if (sad < bestsad) {
-              bestsad = sad;
-              best_site = idx[g];
+              const int site = __builtin_amdgcn_readlane(my_site, idx);
+              // (the cost is looked up only for a site that can win: issuing it for every site beside the pixel reads was SLOWER, 7.7 -> 8.9 ms)
+              sad += (uint32_t)cost_of(row + (int)(int16_t)(site & 0xffff), col + (site >> 16));
+              if (sad < bestsad) {
+                bestsad = sad;
+                best_site = idx;
+              }
             }
-          }
-        }
-      }
+          });
       if (best_site != 0) {
         second_row = row; second_col = col;
         const int site = __builtin_amdgcn_readlane(my_site, best_site);
@@ -561,7 +578,8 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
   static_assert(G == 1 || UNITS == 1, "groups hold one unit per lane");
   const int u = lane & (kLanes - 1), grp = lane / kLanes;
   const int lw = __builtin_ctz((unsigned)W), wm = W - 1;
-  const bool keep = n_px <= 4 * kLanes * kUnits;
+  constexpr bool kFull = G == 1;   // (G == 1: a kept block has exactly 256 * UNITS pixels -- see CompoundEval)
+  const bool keep = kFull ? n_px == 4 * kLanes * kUnits : n_px <= 4 * kLanes * kUnits;
   // |wsrc - pre * mask| + 2048 as ONE v_sad_u32 on operands biased by 2^31 (the unsigned difference of the biased values is the signed one's
   // magnitude), pre * mask + 2^31 as one v_mad_u32_u24 (pre < 2^12; mask <= 4096 = 64 x 64 as calc_target_weighted_pred builds it, any
   // value below 2^24 works): 4 instructions per pixel with the shift and the sum instead of 7
@@ -581,9 +599,9 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
 #pragma unroll
     for (int k = 0; k < kUnits; ++k) {
       const int t = 4 * (k * kLanes + u);
-      lo_[k] = t < n_px ? ref_off(t) : 0u;
+      lo_[k] = kFull || t < n_px ? ref_off(t) : 0u;
       int4 a = make_int4(0, 0, 0, 0), b = a;
-      if (t < n_px) { a = *reinterpret_cast<const int4 *>(wsrc + t); b = *reinterpret_cast<const int4 *>(omask + t); }
+      if (kFull || t < n_px) { a = *reinterpret_cast<const int4 *>(wsrc + t); b = *reinterpret_cast<const int4 *>(omask + t); }
       ws_[k][0] = a.x ^ kBias; ws_[k][1] = a.y ^ kBias; ws_[k][2] = a.z ^ kBias; ws_[k][3] = a.w ^ kBias;
       om_[k][0] = b.x; om_[k][1] = b.y; om_[k][2] = b.z; om_[k][3] = b.w;
     }
@@ -591,22 +609,26 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
   auto cand_off = [&](int row, int col) -> unsigned { return (unsigned)(((row - bs.row_min) * ref.stride + (col - bs.col_min)) * (int)sizeof(T)); };
   // vfp->osdf: obmc_sad (sad_av1.c:163-180), the lane's share for the candidate at byte offset `off` (with G > 1 a value per group); obmc_sad
   // sums in an unsigned int, so do the lanes and the reductions (modulo 2^32 like the reference)
-  auto osad_partial = [&](unsigned off) -> uint32_t {
-    uint32_t acc = 0;
+  struct Px { int f[kUnits][4]; };
+  auto ofetch = [&](unsigned off, Px &px) {   // the candidate's pixels requested (blocks kept in registers; a streamed block reads them as it goes)
     if (keep) {
-      int f[kUnits][4];
 #pragma unroll
       for (int k = 0; k < kUnits; ++k) {
         const int t = 4 * (k * kLanes + u);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f[k][i] = 0;
-        if (k * 4 * kLanes < n_px && t < n_px) load_px4<T>(reinterpret_cast<const T *>(base0 + (lo_[k] + off)), f[k]);
+        for (int i = 0; i < 4; ++i) px.f[k][i] = 0;
+        if (kFull || (k * 4 * kLanes < n_px && t < n_px)) load_px4<T>(reinterpret_cast<const T *>(base0 + (lo_[k] + off)), px.f[k]);
       }
+    }
+  };
+  auto osad_partial = [&](unsigned off, const Px &px) -> uint32_t {
+    uint32_t acc = 0;
+    if (keep) {
 #pragma unroll
       for (int k = 0; k < kUnits; ++k)
-        if (k * 4 * kLanes < n_px) {
+        if (kFull || k * 4 * kLanes < n_px) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc += round_abs12(ws_[k][i], f[k][i], om_[k][i]);   // (beyond the block: |0 - 0| + 2048 >> 12 = 0)
+          for (int i = 0; i < 4; ++i) acc += round_abs12(ws_[k][i], px.f[k][i], om_[k][i]);   // (beyond the block: |0 - 0| + 2048 >> 12 = 0)
         }
     } else if constexpr (G == 1) {
 #pragma unroll 1   // (unrolled by two the int4 loads took the kernel to ~300 VGPRs)
@@ -620,9 +642,13 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
     }
     return acc;
   };
-  auto osad_rows = [&](unsigned off) -> uint32_t { return row_sum32(osad_partial(off)); };
+  auto osad_rows = [&](unsigned off, const Px &px) -> uint32_t { return row_sum32(osad_partial(off, px)); };
   auto osad_of = [&](uint32_t rows, int g) -> uint32_t { return CompoundEval<T, UNITS, G>::group_total(rows, g) >> shift; };   // + the bit-depth wrapper
-  auto osad_at = [&](int row, int col) -> uint32_t { return osad_of(osad_rows(cand_off(row, col)), 0); };
+  auto osad_at = [&](int row, int col) -> uint32_t {
+    Px px;
+    ofetch(cand_off(row, col), px);
+    return osad_of(osad_rows(cand_off(row, col), px), 0);
+  };
   auto ovar_at = [&](int row, int col) -> int {   // get_obmc_mvpred_var: vfp->ovf (variance.c:957-1000 / :1064-1192) + mv_err_cost_
     const unsigned off = cand_off(row, col);
     int64_t s = 0, q = 0;
@@ -661,39 +687,17 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
         const bool ok_l = lane >= 1 && lane <= nper && (unsigned)(r_l - bs.row_min) <= (unsigned)(bs.row_max - bs.row_min) &&
                           (unsigned)(c_l - bs.col_min) <= (unsigned)(bs.col_max - bs.col_min);
         const unsigned off_l = ok_l ? cand_off(r_l, c_l) : 0u;
-        uint32_t valid = (uint32_t)__ballot(ok_l);
-        while (valid) {
-          int idx[G], cnt = 0;
-#pragma unroll
-          for (int g = 0; g < G; ++g) {
-            idx[g] = valid ? __builtin_ctz(valid) : 0;
-            cnt += valid != 0;
-            valid &= valid - 1;
-          }
-          unsigned off;
-          if constexpr (G == 1) {
-            off = (unsigned)__builtin_amdgcn_readlane((int)off_l, idx[0]);
-          } else {
-            int sel = idx[0];
-#pragma unroll
-            for (int g = 1; g < G; ++g) sel = grp == g ? idx[g] : sel;
-            off = (unsigned)__builtin_amdgcn_ds_bpermute(sel << 2, (int)off_l);
-          }
-          const uint32_t rows = osad_rows(off);
-#pragma unroll
-          for (int g = 0; g < G; ++g) {
-            if (g >= cnt) break;
-            int sad = (int)osad_of(rows, g);   // (`int sad < int best_sad`: this function compares signed, mcomp.c:2206-2215)
+        walk_sites<G, Px>((uint32_t)__ballot(ok_l), off_l, 0u, grp, ofetch, osad_rows, [&](int idx, uint32_t rows, int g) {
+          int sad = (int)osad_of(rows, g);   // (`int sad < int best_sad`: this function compares signed, mcomp.c:2206-2215)
+          if (sad < best_sad) {
+            const int site = __builtin_amdgcn_readlane(my_site, idx);
+            sad += cost_of(row + (int)(int16_t)(site & 0xffff), col + (site >> 16));
             if (sad < best_sad) {
-              const int site = __builtin_amdgcn_readlane(my_site, idx[g]);
-              sad += cost_of(row + (int)(int16_t)(site & 0xffff), col + (site >> 16));
-              if (sad < best_sad) {
-                best_sad = sad;
-                best_site = idx[g];
-              }
+              best_sad = sad;
+              best_site = idx;
             }
           }
-        }
+        });
         if (best_site != 0) {
           const int site = __builtin_amdgcn_readlane(my_site, best_site);
           row += (int)(int16_t)(site & 0xffff);
@@ -729,28 +733,19 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
     uint32_t best_sad = osad_at(row, col) + (uint32_t)cost_of(row, col);
     for (int i = 0; i < 8; ++i) {
       int best_site = -1;
-#pragma unroll 1
-      for (int j0 = 0; j0 < 4; j0 += G) {   // neighbors[4] = (-1,0) (0,-1) (0,1) (1,0)
-        uint32_t rows = 0;
-        if constexpr (G > 1) {
-          const int jl = j0 + grp, r = row + (jl == 0 ? -1 : jl == 3 ? 1 : 0), c = col + (jl == 1 ? -1 : jl == 2 ? 1 : 0);
-          rows = osad_rows(in_range(r, c) ? cand_off(r, c) : 0u);
-        }
-#pragma unroll 1
-        for (int g = 0; g < G; ++g) {
-          const int j = j0 + g;
-          const int r = row + (j == 0 ? -1 : j == 3 ? 1 : 0), c = col + (j == 1 ? -1 : j == 2 ? 1 : 0);
-          if (!in_range(r, c)) continue;
-          uint32_t sad = G > 1 ? osad_of(rows, g) : osad_at(r, c);
+      // neighbors[4] = (-1,0) (0,-1) (0,1) (1,0), one per lane
+      const int jl = lane & 3, r_l = row + (jl == 0 ? -1 : jl == 3 ? 1 : 0), c_l = col + (jl == 1 ? -1 : jl == 2 ? 1 : 0);
+      const bool ok_l = lane < 4 && in_range(r_l, c_l);
+      walk_sites<G, Px>((uint32_t)__ballot(ok_l), ok_l ? cand_off(r_l, c_l) : 0u, 0u, grp, ofetch, osad_rows, [&](int j, uint32_t rows, int g) {
+        uint32_t sad = osad_of(rows, g);
+        if (sad < best_sad) {
+          sad += (uint32_t)cost_of(row + (j == 0 ? -1 : j == 3 ? 1 : 0), col + (j == 1 ? -1 : j == 2 ? 1 : 0));
           if (sad < best_sad) {
-            sad += (uint32_t)cost_of(r, c);
-            if (sad < best_sad) {
-              best_sad = sad;
-              best_site = j;
-            }
+            best_sad = sad;
+            best_site = j;
           }
         }
-      }
+      });
       if (best_site == -1) break;
       row += best_site == 0 ? -1 : best_site == 3 ? 1 : 0;
       col += best_site == 1 ? -1 : best_site == 2 ? 1 : 0;
@@ -975,12 +970,15 @@ int check_compound(aomhip_ctx *ctx, const aomhip_planes *ref, int frame, int bw,
 using namespace aomhip;
 
 // the full-pel kernels of this file by block size (CompoundEval's UNITS and G)
-#define LAUNCH_BY_UNITS(kernel, T, n_px, ...)                                                     \
-  do {                                                                                            \
-    if ((n_px) <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 1, 4>), __VA_ARGS__);          \
-    else if ((n_px) <= 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 1, 2>), __VA_ARGS__);    \
-    else if ((n_px) <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 2, 1>), __VA_ARGS__);    \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 4, 1>), __VA_ARGS__);                       \
+// (EXTRA: further template arguments, with their leading comma, or nothing)
+#define AOMHIP_COMMA ,
+#define LAUNCH_BY_UNITS(kernel, T, EXTRA, n_px, ...)                                                    \
+  do {                                                                                                  \
+    if ((n_px) <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 1, 4 EXTRA>), __VA_ARGS__);          \
+    else if ((n_px) <= 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 1, 2 EXTRA>), __VA_ARGS__);    \
+    else if ((n_px) <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 1, 1 EXTRA>), __VA_ARGS__);    \
+    else if ((n_px) <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 2, 1 EXTRA>), __VA_ARGS__);    \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(kernel<T, 4, 1 EXTRA>), __VA_ARGS__);                       \
   } while (0)
 
 extern "C" {
@@ -999,15 +997,20 @@ int aomhip_refining_search_8p_batch(aomhip_ctx *ctx, const aomhip_planes *src, c
   if (n_blocks == 0) return AOMHIP_OK;
   const CompoundArgs a{ bw, bh, src->bit_depth, mv_cost_type, sad_per_bit, error_per_bit, invert_mask != 0, d_mvjcost, d_mvcost_row, d_mvcost_col };
   const dim3 grid((n_blocks + 3) / 4), block(256);
-  // by block size: G = 4 / 2 candidates per wavefront for blocks of up to 64 / 128 pixels, 2 units per lane in registers up to 512 pixels,
-  // 4 up to 1024; beyond that the operands stream
+  // by block size: G = 4 / 2 candidates per wavefront for blocks of up to 64 / 128 pixels; 1 / 2 / 4 units per lane in registers for blocks of
+  // 256 / 512 / 1024 pixels; beyond that the operands stream
   const int wide = bw * bh;
   if (src->bit_depth == 8) {
-    LAUNCH_BY_UNITS(refining_search_8p_kernel, uint8_t, wide, grid, block, 0, ctx->stream, view_of<uint8_t>(*src), view_of<uint8_t>(*ref), frame,
+    LAUNCH_BY_UNITS(refining_search_8p_kernel, uint8_t, AOMHIP_COMMA true, wide, grid, block, 0, ctx->stream, view_of<uint8_t>(*src), view_of<uint8_t>(*ref), frame,
                     d_blocks, n_blocks, a, static_cast<const uint8_t *>(d_second_pred), d_mask, d_best_mv, d_best_sad, d_best_var);
   } else {
-    LAUNCH_BY_UNITS(refining_search_8p_kernel, uint16_t, wide, grid, block, 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame,
+    if (!d_mask || src->bit_depth <= 10) {   // the 16-bit blend (CompoundEval::packed)
+      LAUNCH_BY_UNITS(refining_search_8p_kernel, uint16_t, AOMHIP_COMMA true, wide, grid, block, 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame,
                     d_blocks, n_blocks, a, static_cast<const uint16_t *>(d_second_pred), d_mask, d_best_mv, d_best_sad, d_best_var);
+    } else {
+      LAUNCH_BY_UNITS(refining_search_8p_kernel, uint16_t, AOMHIP_COMMA false, wide, grid, block, 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref), frame,
+                    d_blocks, n_blocks, a, static_cast<const uint16_t *>(d_second_pred), d_mask, d_best_mv, d_best_sad, d_best_var);
+    }
   }
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
@@ -1057,17 +1060,23 @@ int aomhip_compound_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes
   }
   const CompoundArgs a{ bw, bh, src->bit_depth, p->mv_cost_type, p->sad_per_bit, p->error_per_bit, invert_mask != 0, d_mvjcost, d_mvcost_row, d_mvcost_col };
   const dim3 grid((n_blocks + 3) / 4), block(256);
-  // by block size: G = 4 / 2 candidates per wavefront for blocks of up to 64 / 128 pixels, 2 units per lane in registers up to 512 pixels,
-  // 4 up to 1024; beyond that the operands stream
+  // by block size: G = 4 / 2 candidates per wavefront for blocks of up to 64 / 128 pixels; 1 / 2 / 4 units per lane in registers for blocks of
+  // 256 / 512 / 1024 pixels; beyond that the operands stream
   const int wide = bw * bh;
   if (src->bit_depth == 8) {
-    LAUNCH_BY_UNITS(compound_full_pixel_diamond_kernel, uint8_t, wide, grid, block, 0, ctx->stream, view_of<uint8_t>(*src), view_of<uint8_t>(*ref),
+    LAUNCH_BY_UNITS(compound_full_pixel_diamond_kernel, uint8_t, AOMHIP_COMMA true, wide, grid, block, 0, ctx->stream, view_of<uint8_t>(*src), view_of<uint8_t>(*ref),
                     frame, d_blocks, n_blocks, a, d_sites, p->step_param, static_cast<const uint8_t *>(d_second_pred), d_mask, d_best_mv, d_best_cost,
                     d_second_best_mv);
   } else {
-    LAUNCH_BY_UNITS(compound_full_pixel_diamond_kernel, uint16_t, wide, grid, block, 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref),
+    if (!d_mask || src->bit_depth <= 10) {   // the 16-bit blend (CompoundEval::packed)
+      LAUNCH_BY_UNITS(compound_full_pixel_diamond_kernel, uint16_t, AOMHIP_COMMA true, wide, grid, block, 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref),
                     frame, d_blocks, n_blocks, a, d_sites, p->step_param, static_cast<const uint16_t *>(d_second_pred), d_mask, d_best_mv,
                     d_best_cost, d_second_best_mv);
+    } else {
+      LAUNCH_BY_UNITS(compound_full_pixel_diamond_kernel, uint16_t, AOMHIP_COMMA false, wide, grid, block, 0, ctx->stream, view_of<uint16_t>(*src), view_of<uint16_t>(*ref),
+                    frame, d_blocks, n_blocks, a, d_sites, p->step_param, static_cast<const uint16_t *>(d_second_pred), d_mask, d_best_mv,
+                    d_best_cost, d_second_best_mv);
+    }
   }
   AOMHIP_LAUNCH_CHECK();
   // the follow-up of av1_full_pixel_search: needed only where a mesh search can follow (NSTEP's variance threshold, or run_mesh_search)
@@ -1106,14 +1115,14 @@ int aomhip_obmc_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *re
   }
   const CompoundArgs a{ bw, bh, ref->bit_depth, mv_cost_type, sad_per_bit, error_per_bit, 0, d_mvjcost, d_mvcost_row, d_mvcost_col };
   const dim3 grid((n_blocks + 3) / 4), block(256);
-  // by block size: G = 4 / 2 candidates per wavefront for blocks of up to 64 / 128 pixels, 2 units per lane in registers up to 512 pixels,
-  // 4 up to 1024; beyond that the operands stream
+  // by block size: G = 4 / 2 candidates per wavefront for blocks of up to 64 / 128 pixels; 1 / 2 / 4 units per lane in registers for blocks of
+  // 256 / 512 / 1024 pixels; beyond that the operands stream
   const int wide = bw * bh;
   if (ref->bit_depth == 8) {
-    LAUNCH_BY_UNITS(obmc_full_pixel_search_kernel, uint8_t, wide, grid, block, 0, ctx->stream, view_of<uint8_t>(*ref), frame, d_blocks, n_blocks, a,
+    LAUNCH_BY_UNITS(obmc_full_pixel_search_kernel, uint8_t, , wide, grid, block, 0, ctx->stream, view_of<uint8_t>(*ref), frame, d_blocks, n_blocks, a,
                     d_sites, step_param, fast_obmc_search != 0, d_wsrc, d_obmc_mask, d_best_mv, d_best_cost);
   } else {
-    LAUNCH_BY_UNITS(obmc_full_pixel_search_kernel, uint16_t, wide, grid, block, 0, ctx->stream, view_of<uint16_t>(*ref), frame, d_blocks, n_blocks, a,
+    LAUNCH_BY_UNITS(obmc_full_pixel_search_kernel, uint16_t, , wide, grid, block, 0, ctx->stream, view_of<uint16_t>(*ref), frame, d_blocks, n_blocks, a,
                     d_sites, step_param, fast_obmc_search != 0, d_wsrc, d_obmc_mask, d_best_mv, d_best_cost);
   }
   AOMHIP_LAUNCH_CHECK();
