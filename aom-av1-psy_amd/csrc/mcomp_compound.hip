@@ -793,7 +793,10 @@ __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref,
                                                                CompoundArgs a, ObmcSubpelArgs sa, const int32_t *__restrict__ wsrc_all,
                                                                const int32_t *__restrict__ omask_all, int16_t *__restrict__ out_mv,
                                                                uint32_t *__restrict__ out_err, int32_t *__restrict__ out_dist, uint32_t *__restrict__ out_sse) {
+  constexpr int kObmcTileDw = 1024;   // 4 KB of LDS per wavefront: the horizontally filtered rows of a strip (form 2 below)
+  __shared__ uint32_t tiles[4][kObmcTileDw];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  uint32_t *tile = tiles[wave];
   const int bi = blockIdx.x * 4 + wave;
   if (bi >= n_blocks) return;
   const BlockScalars bs = BlockScalars::of(blocks[bi]);   // start_* in 1/8 pel, limits = SubpelMvLimits
@@ -811,52 +814,107 @@ __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref,
     const int fx0 = kBil[sx][0], fx1 = kBil[sx][1], fy0 = kBil[sy][0], fy1 = kBil[sy][1];
     int64_t s = 0, q = 0;
     if (form == 2) {
-      // The up-sampled form by units of four adjacent pixels per lane: a row of the horizontal pass is three 4-pixel loads for four outputs
-      // (9 of the 12 pixels are taps), six rows feed the vertical pass -- 4.5 loads per pixel instead of the 36 of the pixel-by-pixel form.
+      // The up-sampled form in two passes through the wavefront's LDS tile, a lane taking units of four adjacent pixels: the horizontal pass
+      // filters every row of a strip ONCE (rows -2 .. +3 around it: three 4-pixel loads, 9 of the 12 pixels are taps) and stores it as
+      // uint16 pairs; the vertical pass reads six rows of a pixel pair as dwords -- three v_perm + three v_dot2 per pixel, as in the
+      // compound search's kernel (subpel_search.inc) -- and takes the weighted difference.  (Row by row per lane, the form before, every lane
+      // filtered six rows for one row of output: 9 846 vector instructions per 16 x 16 block, PMC r05e.)
       // (The right-most load reaches 6 pixels beyond the block, 3 more than the taps: inside the 8 pixels the MV limits keep clear.)
-      int tx[6], ty[6];
+      typedef short s16x2_t __attribute__((ext_vector_type(2)));
+      s16x2_t kxp[3], kyp[3];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { tx[k] = obmc_up_tap(sa.upsampled, 2 * sx, k); ty[k] = obmc_up_tap(sa.upsampled, 2 * sy, k); }
-      for (int t = 4 * lane; t < n_px; t += 256) {
-        const int y = t >> lw_, x = t & (W - 1);
-        const T *p = rp + (int64_t)y * ref.stride + x;
-        int pv[4];
-        auto hrow4 = [&](int dy, int out[4]) {   // the horizontal pass of outputs x .. x + 3 at row y + dy
-          const T *r = p + (int64_t)dy * ref.stride;
-          if (!sx) { load_px4<T>(r, out); return; }
-          int in[12];
-          load_px4<T>(r - 2, in); load_px4<T>(r + 2, in + 4); load_px4<T>(r + 6, in + 8);
+      for (int k = 0; k < 3; ++k) {
+        kxp[k] = s16x2_t{ (short)obmc_up_tap(sa.upsampled, 2 * sx, 2 * k), (short)obmc_up_tap(sa.upsampled, 2 * sx, 2 * k + 1) };
+        kyp[k] = s16x2_t{ (short)obmc_up_tap(sa.upsampled, 2 * sy, 2 * k), (short)obmc_up_tap(sa.upsampled, 2 * sy, 2 * k + 1) };
+      }
+      const int lupr = lw_ - 2, upr = 1 << lupr;                   // 4-pixel units per row
+      const int S = min(H, (kObmcTileDw * 2 >> lw_) - 5);          // output rows per strip: (S + 5) rows of W uint16 fill the tile
+      for (int r0 = 0; r0 < H; r0 += S) {
+        const int sh = min(S, H - r0);
+        for (int uu = lane; uu < ((sh + 5) << lupr); uu += 64) {   // horizontal pass: rows r0 - 2 .. r0 + sh + 2 -> tile rows 0 .. sh + 4
+          const int tr = uu >> lupr, c = (uu & (upr - 1)) << 2;
+          const T *r = rp + (int64_t)(r0 + tr - 2) * ref.stride + c - 2;
+          uint32_t wv[6];   // pixels c - 2 .. c + 9 as pairs
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const uint2 w = *reinterpret_cast<const uint2 *>(r + 4 * k);
+              wv[2 * k] = w.x; wv[2 * k + 1] = w.y;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const uint32_t w = *reinterpret_cast<const uint32_t *>(r + 4 * k);
+              wv[2 * k] = __builtin_amdgcn_perm(0, w, 0x0c010c00);
+              wv[2 * k + 1] = __builtin_amdgcn_perm(0, w, 0x0c030c02);
+            }
+          }
+          uint32_t o2[2];
+          if (!sx) {
+            o2[0] = wv[1]; o2[1] = wv[2];
+          } else {
+            uint32_t ov[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) ov[k] = __builtin_amdgcn_alignbit(wv[k + 1], wv[k], 16);
+            int o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t *sw = (i & 1) ? ov : wv;
+              int acc = 64;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, sw[(i >> 1) + k]), kxp[k], acc, false);
+              o[i] = min(max(acc >> 7, 0), pmax);
+            }
+            o2[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16); o2[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+          }
+          uint32_t *dst = tile + ((tr << lw_) + c) / 2;
+          dst[0] = o2[0]; dst[1] = o2[1];
+        }
+        // the wavefront's own LDS writes must be visible to its reads below: one wavefront, so a wave-level fence suffices
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int uu = lane; uu < (sh << lupr); uu += 64) {   // vertical pass + the weighted difference
+          const int orow = uu >> lupr, c = (uu & (upr - 1)) << 2;
+          uint32_t pp[2];
+          if (!sy) {
+            const uint32_t *src = tile + (((orow + 2) << lw_) + c) / 2;
+            pp[0] = src[0]; pp[1] = src[1];
+          } else {
+            uint32_t rows6[6][2];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              const uint32_t *src = tile + (((orow + k) << lw_) + c) / 2;
+              rows6[k][0] = src[0]; rows6[k][1] = src[1];
+            }
+#pragma unroll
+            for (int qd = 0; qd < 2; ++qd) {
+              int a0 = 64, a1 = 64;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                const uint32_t lo = __builtin_amdgcn_perm(rows6[2 * k + 1][qd], rows6[2 * k][qd], 0x05040100u);
+                const uint32_t hi = __builtin_amdgcn_perm(rows6[2 * k + 1][qd], rows6[2 * k][qd], 0x07060302u);
+                a0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, lo), kyp[k], a0, false);
+                a1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, hi), kyp[k], a1, false);
+              }
+              pp[qd] = (uint32_t)min(max(a0 >> 7, 0), pmax) | ((uint32_t)min(max(a1 >> 7, 0), pmax) << 16);
+            }
+          }
+          const int t = ((r0 + orow) << lw_) + c;
+          const int4 wv4 = *reinterpret_cast<const int4 *>(wsrc + t), mv4 = *reinterpret_cast<const int4 *>(omask + t);
+          const int w4[4] = { wv4.x, wv4.y, wv4.z, wv4.w }, m4[4] = { mv4.x, mv4.y, mv4.z, mv4.w };
+          const int pv[4] = { (int)(pp[0] & 0xffffu), (int)(pp[0] >> 16), (int)(pp[1] & 0xffffu), (int)(pp[1] >> 16) };
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            int sum = 0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) sum += in[i + k] * tx[k];
-            out[i] = min(max((sum + 64) >> 7, 0), pmax);
+            const int v = w4[i] - pv[i] * m4[i];
+            const int d = v < 0 ? -((-v + 2048) >> 12) : (v + 2048) >> 12;   // ROUND_POWER_OF_TWO_SIGNED(v, 12)
+            s += d;
+            q += (uint32_t)(d * d);
           }
-        };
-        if (!sy) {
-          hrow4(0, pv);
-        } else {
-          int acc[4] = { 0, 0, 0, 0 };
-#pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            int h[4];
-            hrow4(k - 2, h);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] += h[i] * ty[k];
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) pv[i] = min(max((acc[i] + 64) >> 7, 0), pmax);
         }
-        const int4 wv = *reinterpret_cast<const int4 *>(wsrc + t), mv4 = *reinterpret_cast<const int4 *>(omask + t);
-        const int w4[4] = { wv.x, wv.y, wv.z, wv.w }, m4[4] = { mv4.x, mv4.y, mv4.z, mv4.w };
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int v = w4[i] - pv[i] * m4[i];
-          const int d = v < 0 ? -((-v + 2048) >> 12) : (v + 2048) >> 12;   // ROUND_POWER_OF_TWO_SIGNED(v, 12)
-          s += d;
-          q += (uint32_t)(d * d);
-        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     } else
     for (int t = lane; t < n_px; t += 64) {
