@@ -93,6 +93,11 @@ __device__ __forceinline__ uint64_t wsum32_wide(uint32_t v) {   // the same when
   return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32) +
          (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
+// The sums of the variance's two accumulators over the wavefront without the six dependent 64-bit shuffle steps of wsum(): the sum of
+// differences fits 32 bits (|d| <= 8191, <= 128 x 128 pixels), the sum of squares is summed as its low 16 bits and the rest (a lane's
+// share is < 2^42: <= 256 pixels of d^2 < 2^26) -- DPP adds only.
+__device__ __forceinline__ int64_t wsum_s(int64_t s) { return (int64_t)(int32_t)wsum32((uint32_t)(int32_t)s); }
+__device__ __forceinline__ uint64_t wsum_q(uint64_t q) { return ((uint64_t)wsum32((uint32_t)(q >> 16)) << 16) + wsum32((uint32_t)q & 0xffffu); }
 __device__ __forceinline__ uint64_t wsum32_split(uint32_t v) {   // exact for any per-lane value: the two 16-bit halves summed separately
   return ((uint64_t)wsum32(v >> 16) << 16) + wsum32(v & 0xffffu);
 }
@@ -347,7 +352,7 @@ template <typename T, int UNITS, int G = 1, bool PACKED = true> struct CompoundE
         unit_var(f2, A2, C2, S2, s, qu);
         q += qu;
       }
-      q64 = (uint64_t)wsum((int64_t)q);
+      q64 = wsum_q(q);
     }
     return finish_var((int64_t)(int32_t)group_total(row_sum32((uint32_t)s), 0), q64, n_px, bit_depth);
   }
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(256) void obmc_full_pixel_search_kernel(PlaneView<T
         q += (uint32_t)(d * d);
       }
     }
-    return (int)finish_var(wsum(s), (uint64_t)wsum(q), n_px, a.bit_depth) + var_cost(a, bs.ref_row, bs.ref_col, row * 8, col * 8);
+    return (int)finish_var(wsum_s(s), wsum_q((uint64_t)q), n_px, a.bit_depth) + var_cost(a, bs.ref_row, bs.ref_col, row * 8, col * 8);
   };
   auto in_range = [&](int r, int c) { return c >= bs.col_min && c <= bs.col_max && r >= bs.row_min && r <= bs.row_max; };
   const int start_row = min(max(bs.start_row, bs.row_min), bs.row_max), start_col = min(max(bs.start_col, bs.col_min), bs.col_max);
@@ -950,8 +955,8 @@ __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref,
       s += d;
       q += (uint32_t)(d * d);
     }
-    const int64_t s64 = wsum(s);
-    const uint64_t q64 = (uint64_t)wsum(q);
+    const int64_t s64 = wsum_s(s);
+    const uint64_t q64 = wsum_q((uint64_t)q);
     *sse_out = a.bit_depth == 10 ? (uint32_t)((q64 + 8) >> 4) : a.bit_depth == 12 ? (uint32_t)((q64 + 128) >> 8) : (uint32_t)q64;
     return finish_var(s64, q64, n_px, a.bit_depth);
   };
