@@ -66,7 +66,7 @@ __device__ __forceinline__ uint32_t finish_var(int64_t s64, uint64_t q64, int n_
   if (bit_depth == 10) { q = (uint32_t)((q64 + 8) >> 4); s = (int32_t)((s64 + 2) >> 2); }
   else if (bit_depth == 12) { q = (uint32_t)((q64 + 128) >> 8); s = (int32_t)((s64 + 8) >> 4); }
   else { q = (uint32_t)q64; s = (int32_t)s64; }
-  const int64_t sq = ((int64_t)s * s) / n_px;
+  const int64_t sq = ((int64_t)s * s) >> __builtin_ctz((unsigned)n_px);   // (/ (w * h): block areas are powers of two -- a 64-bit division is ~100 instructions)
   if (bit_depth == 8) return q - (uint32_t)sq;
   const int64_t v = (int64_t)q - sq;
   return v >= 0 ? (uint32_t)v : 0u;
@@ -812,6 +812,13 @@ __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref,
   const int pmax = sizeof(T) == 1 ? 255 : (1 << a.bit_depth) - 1;
   const int lw_ = __builtin_ctz((unsigned)W);
   constexpr uint8_t kBil[8][2] = { { 128, 0 }, { 112, 16 }, { 96, 32 }, { 80, 48 }, { 64, 64 }, { 48, 80 }, { 32, 96 }, { 16, 112 } };  // aom_filter.h:43-50
+  // the up-sampling kernel's tap pairs (taps 2 k, 2 k + 1 of the six) of the eight 1/8-pel phases, one per lane: lane = 3 * phase + k.  (Looked
+  // up per candidate through obmc_up_tap they were twelve table reads on the scalar unit, which bounds this kernel: PMC r05e.)
+  int tap_l = 0;
+  if (sa.upsampled && lane < 24) {
+    const int ph = 2 * (lane / 3), k = lane % 3;
+    tap_l = (int)(((uint32_t)(uint16_t)(int16_t)obmc_up_tap(sa.upsampled, ph, 2 * k)) | ((uint32_t)(uint16_t)(int16_t)obmc_up_tap(sa.upsampled, ph, 2 * k + 1) << 16));
+  }
   // obmc_variance of the prediction at (mrow, mcol): form 0 = the plain block at the full-pel part (ovf), 1 = bilinear (osvf), 2 = up-sampled
   auto obmc_err = [&](int mrow, int mcol, int form, uint32_t *sse_out) -> uint32_t {
     const T *rp = rbase + (int64_t)(mrow >> 3) * ref.stride + (mcol >> 3);
@@ -826,11 +833,11 @@ __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref,
       // filtered six rows for one row of output: 9 846 vector instructions per 16 x 16 block, PMC r05e.)
       // (The right-most load reaches 6 pixels beyond the block, 3 more than the taps: inside the 8 pixels the MV limits keep clear.)
       typedef short s16x2_t __attribute__((ext_vector_type(2)));
-      s16x2_t kxp[3], kyp[3];
+      s16x2_t kxp[3], kyp[3];   // (the tap pairs of the two phases out of the per-lane table: six v_readlane)
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        kxp[k] = s16x2_t{ (short)obmc_up_tap(sa.upsampled, 2 * sx, 2 * k), (short)obmc_up_tap(sa.upsampled, 2 * sx, 2 * k + 1) };
-        kyp[k] = s16x2_t{ (short)obmc_up_tap(sa.upsampled, 2 * sy, 2 * k), (short)obmc_up_tap(sa.upsampled, 2 * sy, 2 * k + 1) };
+        kxp[k] = __builtin_bit_cast(s16x2_t, __builtin_amdgcn_readlane(tap_l, sx * 3 + k));
+        kyp[k] = __builtin_bit_cast(s16x2_t, __builtin_amdgcn_readlane(tap_l, sy * 3 + k));
       }
       const int lupr = lw_ - 2, upr = 1 << lupr;                   // 4-pixel units per row
       const int S = min(H, (kObmcTileDw * 2 >> lw_) - 5);          // output rows per strip: (S + 5) rows of W uint16 fill the tile
@@ -988,20 +995,35 @@ __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref,
   int hstep = 4;   // INIT_SUBPEL_STEP_SIZE
   const int round = min(3 - sa.forced_stop, 3 - (sa.allow_hp ? 0 : 1));
   for (int iter = 0; iter < round; ++iter) {
+    // The up to eight candidates of an iteration through ONE call site of check() (inlined eight times the kernel was 44 KB of code):
+    // steps 0 .. 3 left, right, up, down; 4 the diagonal get_best_diag_step picks (:2490-2498); 5 .. 7 obmc_second_level_check_v2
+    // (:3535-3586): row, column, and both if either improved.
     const int tr = best_row, tc = best_col;
-    int dummy = 0;
-    const uint32_t left = check(tr, tc - hstep, &dummy), right = check(tr, tc + hstep, &dummy);
-    const uint32_t up = check(tr - hstep, tc, &dummy), down = check(tr + hstep, tc, &dummy);
-    int drow = up <= down ? -hstep : hstep, dcol = left <= right ? -hstep : hstep;   // get_best_diag_step (:2490-2498)
-    check(tr + drow, tc + dcol, &dummy);
-    if ((tr != best_row || tc != best_col) && sa.iters_per_step > 1) {   // obmc_second_level_check_v2 (:3535-3586)
-      if (tr == best_row) drow = -drow;
-      else if (tc == best_col) dcol = -dcol;
-      const int br = best_row, bc = best_col;
-      int has_better = 0;
-      check(br + drow, bc, &has_better);
-      check(br, bc + dcol, &has_better);
-      if (has_better) check(br + drow, bc + dcol, &has_better);
+    uint32_t left = 0, right = 0, up = 0, down = 0;
+    int drow = 0, dcol = 0, br = 0, bc = 0, has_better = 0, dummy = 0;
+#pragma unroll 1
+    for (int step = 0; step < 8; ++step) {
+      int mrow, mcol;
+      if (step < 4) {
+        mrow = tr + (step == 2 ? -hstep : step == 3 ? hstep : 0);
+        mcol = tc + (step == 0 ? -hstep : step == 1 ? hstep : 0);
+      } else if (step == 4) {
+        drow = up <= down ? -hstep : hstep; dcol = left <= right ? -hstep : hstep;
+        mrow = tr + drow; mcol = tc + dcol;
+      } else {
+        if (step == 5) {
+          if (!((tr != best_row || tc != best_col) && sa.iters_per_step > 1)) break;
+          if (tr == best_row) drow = -drow;
+          else if (tc == best_col) dcol = -dcol;
+          br = best_row; bc = best_col;
+        }
+        if (step == 7 && !has_better) break;
+        mrow = step == 6 ? br : br + drow;
+        mcol = step == 5 ? bc : bc + dcol;
+      }
+      const uint32_t cost = check(mrow, mcol, step >= 5 ? &has_better : &dummy);
+      left = step == 0 ? cost : left; right = step == 1 ? cost : right;
+      up = step == 2 ? cost : up; down = step == 3 ? cost : down;
     }
     hstep >>= 1;
   }
