@@ -442,7 +442,7 @@ __device__ __forceinline__ void parts_sum(int64_t &tsum, uint64_t &tsse, int npa
 template <typename T, int W, int H, bool SUBPEL>
 __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, int xoff, int yoff, const T *bp, int bstride,
                                                      bool a_minus_b, int bit_depth, int j, bool active,
-                                                     uint32_t *sse_out, const CompoundRef<T> *comp = nullptr, int part = 0, int nparts = 1) {
+                                                     uint32_t *sse_out, const CompoundRef<T> comp = CompoundRef<T>{ nullptr, nullptr, 0 }, int part = 0, int nparts = 1) {
   constexpr int UE = W >= 8 ? 8 : 4;
   constexpr int UPR = W / UE;
   constexpr int U = UPR * H;
@@ -479,7 +479,7 @@ __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, i
 #pragma unroll
         for (int i = 0; i < UE; ++i) avv[i] = px_of<T>(r0.v, i);
       }
-      if (comp) comp->template blend_run<UE>(avv, row * W + col);   // (the unit's predictor pixels and weights: one vector load each)
+      if (comp.second) comp.template blend_run<UE>(avv, row * W + col);   // (the unit's predictor pixels and weights: one vector load each)
 #pragma unroll
       for (int i = 0; i < UE; ++i) {
         const int bvp = px_of<T>(bv.v, i);

@@ -20,3 +20,9 @@ unset AOMHIP_BENCH_COMPOUND_BS
 timeout 600 python bench.py --workload compound_search_4k_10bit --steps 10 --warmup 3 > gpurun_out/r05e/bench_compound.json 2> gpurun_out/r05e/bench_compound.err
 python3 -c "
 import json; d=json.load(open('gpurun_out/r05e/bench_compound.json')); print(json.dumps(d['by_block_size'], indent=0))"
+timeout 600 python bench.py --workload inner_loop_4k_10bit --steps 60 --warmup 5 > gpurun_out/r05e/bench_inner.json 2> gpurun_out/r05e/bench_inner.err
+python3 -c "
+import json; d=json.load(open('gpurun_out/r05e/bench_inner.json')); print('inner loop', d.get('value'), d.get('ms_per_step')); print(json.dumps(d.get('stages_ms', d.get('stages', {})))[:1500])"
+timeout 600 python bench.py --workload tf_motion_search_4k_10bit --steps 10 --warmup 3 > gpurun_out/r05e/bench_tf.json 2> gpurun_out/r05e/bench_tf.err
+python3 -c "
+import json; d=json.load(open('gpurun_out/r05e/bench_tf.json')); print('tf', d.get('value'), d.get('ms_per_step'))"
