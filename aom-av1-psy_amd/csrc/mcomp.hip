@@ -227,9 +227,16 @@ __global__ __launch_bounds__(WAVES * 64, CELL ? 8 : 5) void fullpel_diamond_kern
       }
       uint32_t key = inr ? ((my_this << 4) | (uint32_t)(g + 1)) : 0xFFFFFFFFu;
       key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x128, 0xf, 0xf, false));  // row_ror:8: the row's other group
+#ifdef AOMHIP_DIAMOND_MIN_READLANES   // (the form before: four v_readlane and three s_min)
       const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, 0), k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, 16);
       const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)key, 32), k3 = (uint32_t)__builtin_amdgcn_readlane((int)key, 48);
       const uint32_t kb = min(min(k0, k1), min(k2, k3));
+#else
+      // the four rows' minima: row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3, the wavefront's minimum in lane 63
+      key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x142, 0xa, 0xf, false));
+      key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x143, 0xc, 0xf, false));
+      const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)key, 63);
+#endif
       int best_site = 0;
       if (kb != 0xFFFFFFFFu && (kb >> 4) < bestsad) {
         bestsad = kb >> 4;

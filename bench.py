@@ -685,6 +685,29 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
             ctx.graph_launch(graphs[f])
         wall, ev_ms = timed(replay)
         graph_note = {"frames_per_s_launches_one_by_one": steps / wall_plain, "ms_per_frame_launches_one_by_one": wall_plain / steps * 1e3}
+        # Between two graph launches the queue idles ~9 us (profiles/r05_inner_loop_timeline.md): the ring's F frames as ONE graph halve that
+        # share per frame (an encoder submits its frames back to back; AOMHIP_BENCH_GRAPH=frame keeps one graph per frame).  Exactly `steps`
+        # frames are run: steps // F ring graphs, then the remainder frame by frame.
+        if os.environ.get("AOMHIP_BENCH_GRAPH", "ring") != "frame" and F > 1 and steps >= F:
+            state["f"] = 0
+            ring = ctx.capture(lambda: [frame(f) for f in range(F)])
+            def timed_ring():
+                ctx.graph_launch(ring); ctx.sync()
+                t0 = time.perf_counter()
+                ctx.timer_begin()
+                for _ in range(steps // F):
+                    ctx.graph_launch(ring)
+                for f in range(steps % F):
+                    ctx.graph_launch(graphs[f])
+                ev = ctx.timer_end()
+                return time.perf_counter() - t0, ev
+            wall_frame, ev_frame = wall, ev_ms
+            wall, ev_ms = timed_ring()
+            state["f"] = steps % F if steps % F else F
+            graph_note.update({"frames_per_s_one_graph_per_frame": steps / wall_frame, "ms_per_frame_one_graph_per_frame": wall_frame / steps * 1e3,
+                               "frames_per_graph": F})
+            ctx.sync()
+            ctx.graph_destroy(ring)
         ctx.sync()
         for g in graphs:
             ctx.graph_destroy(g)
@@ -780,7 +803,8 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
     return {"workload": "encode_inner_loop_4k_10bit", "value": steps / wall, "unit": "frames/s",
             "ms_per_frame": wall / steps * 1e3, "event_ms_per_frame": ev_ms / steps, "blocks_per_frame": n,
             "recon_psnr_db_last_frame": float(psnr), "stages": stages, "valu_issue_rates": rates, "deblock_in_frame": "fused" if fused_deblock else "two_pass",
-            "launch": "one hipGraph per frame (aomhip_graph_launch)" if graph_note else "eight launches per frame", "without_graph": graph_note,
+            "launch": ("one hipGraph per ring of %d frames (aomhip_graph_launch)" % graph_note["frames_per_graph"] if graph_note and "frames_per_graph" in graph_note
+                       else "one hipGraph per frame (aomhip_graph_launch)" if graph_note else "eight launches per frame"), "without_graph": graph_note,
             "middle_of_frame": "one kernel (aomhip_encode_inter_blocks_batch)" if fused_middle else "three launches",
             "config": {"frame": "3840x2160 10-bit luma", "stages": "fullpel diamond + subpel bilinear (16x16) -> inter prediction at the "
                        "sub-pel MV (8-tap regular, av1_highbd_convolve_2d_sr) -> subtract+fwd_txfm2d_16x16+quantize_b q100 -> inv_txfm_add -> deblock (8x8 edges, level 32) -> "
