@@ -690,7 +690,9 @@ int aomhip_compound_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes
                                             const uint8_t *d_mask, int invert_mask, int16_t *d_best_mv, int32_t *d_best_cost, int16_t *d_second_best_mv);
 /* av1_obmc_full_pixel_search (mcomp.c:2272-2285) for every block: obmc_full_pixel_diamond (:2236-2270; the site table of search_method from
  * step_param, restarts, get_obmc_mvpred_var) or, with fast_obmc_search, obmc_refining_search_sad (:2127-2171) from the clamped start MV.
- *   d_wsrc / d_obmc_mask   bw x bh int32 each, block i at i * bw * bh: calc_target_weighted_pred's weighted source and mask (x->obmc_buffer)
+ *   d_wsrc / d_obmc_mask   bw x bh int32 each, block i at i * bw * bh: calc_target_weighted_pred's weighted source and mask (x->obmc_buffer);
+ *                          mask values are 0 .. 4096 (64 x 64) as that function builds them -- the full-pel kernel multiplies pixel x mask with
+ *                          the 24-bit multiplier, any mask below 2^24 is exact
  * Outputs: d_best_mv (row, col), d_best_cost (the returned variance + MV cost). */
 int aomhip_obmc_full_pixel_search_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int frame, int bw, int bh, int search_method, int step_param,
                                         int fast_obmc_search, int mv_cost_type, int sad_per_bit, int error_per_bit, const int32_t *d_mvjcost,
