@@ -42,7 +42,10 @@ __device__ unsigned int g_cell_prof[40960 * 16];   // one record of plain stores
 // biased coordinates, two SAD accumulators, the winning site decoded from two packed tables instead of compare chains, the start
 // position's SAD kept across the restarts (every run of full_pixel_diamond starts at the same clamped MV) and the final variance
 // kept while consecutive runs end on the same MV.
-template <typename T, int W, int H, int WAVES, bool CELL>
+// CLAMPED: the CLAMPED_DIAMOND table (radii capped at 256, equal consecutive radii skipped) -- a template argument: as a run-time `level` its
+// tests sat in every round of the plain diamond (about 10 of the round's ~65 scalar instructions; the kernel's scalar and vector counts are
+// about even, profiles/r05_inner_loop_pmc.json)
+template <typename T, int W, int H, int WAVES, bool CELL, bool CLAMPED>
 __global__ __launch_bounds__(WAVES * 64, CELL ? 8 : 5) void fullpel_diamond_kernel(
     PlaneView<T> src, PlaneView<T> ref, int frame, const aomhip_search_block *__restrict__ blocks, int n_blocks, CellMap cm,
     int level, int step_param, int cost_type, int bit_depth, int16_t *__restrict__ out_mv, int32_t *__restrict__ out_cost) {
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(WAVES * 64, CELL ? 8 : 5) void fullpel_diamond_kern
   };
 
   // radius of stage k (av1_init_dsmotion_compensation): DIAMOND 2^k, CLAMPED_DIAMOND min(2^k, 256); 11 stages
-  auto radius = [level](int k) { const int r = 1 << k; return (level > 0 && r > 256) ? 256 : r; };
+  auto radius = [](int k) { const int r = 1 << k; return (CLAMPED && r > 256) ? 256 : r; };
 
   // every run starts at the clamped start MV: its SAD once (group 0 evaluates it, the other seven would only repeat its loads)
   uint32_t start_sad;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(WAVES * 64, CELL ? 8 : 5) void fullpel_diamond_kern
         win_margin = win_margin_of(row, col);
       }
       if (is_off_center == 0) (*num00)++;
-      if (level > 0 && best_site == 0) {   // (equal consecutive radii exist only in the clamped table: radius(k) = 2^k otherwise)
+      if (CLAMPED && best_site == 0) {   // (equal consecutive radii exist only in the clamped table: radius(k) = 2^k otherwise)
         while (step > 2 && radius(step - 1) == radius(step)) {
           ++(*num00);
           --step;
@@ -569,7 +572,7 @@ int aomhip_fullpel_diamond_batch(aomhip_ctx *ctx, const aomhip_planes *src, cons
   const CellPlan cp = plan_cells(ref, bw, bh, n_blocks, 2 * first_r);
 #define LAUNCH(T, W, H, WAVES, CELL)                                                                                            \
   {                                                                                                                             \
-    auto k = fullpel_diamond_kernel<T, W, H, WAVES, CELL>;                                                                      \
+    auto k = clamped ? fullpel_diamond_kernel<T, W, H, WAVES, CELL, true> : fullpel_diamond_kernel<T, W, H, WAVES, CELL, false>;  \
     if (cp.lds > 64 * 1024) AOMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, cp.lds)); \
     hipLaunchKernelGGL(k, dim3(CELL ? cp.map.n_cells : (n_blocks + WAVES - 1) / WAVES), dim3(WAVES * 64), CELL ? cp.lds : 0, ctx->stream, \
                        view_of<T>(*src), view_of<T>(*ref), frame, d_blocks, n_blocks, cp.map, clamped, step_param, mv_cost_type,  \
