@@ -54,8 +54,8 @@ def test_matches_the_interpreted_reference(hip, ctx, fixture, least):
         ctx.planes_free(p_)
 
 
-@pytest.mark.parametrize("bd", [8, 10])
-@pytest.mark.parametrize("bw,bh", [(16, 16), (8, 8), (32, 16), (64, 64)])
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bw,bh", [(16, 16), (8, 8), (4, 8), (32, 16), (8, 32), (64, 16), (32, 64), (64, 64), (128, 128)])   # (the up-sampled form's LDS strips: one, two, twelve per block)
 def test_batches_match_the_oracle(hip, oracle, ctx, bd, bw, bh):
     capi = hip.capi
     W, H, B = 320, 192, 96
