@@ -229,21 +229,7 @@ __global__ __launch_bounds__(WAVES * 64, CELL ? 8 : 5) void fullpel_diamond_kern
         my_this += (uint32_t)__mul24((int)d, lambda);
       }
       uint32_t key = inr ? ((my_this << 4) | (uint32_t)(g + 1)) : 0xFFFFFFFFu;
-#ifdef AOMHIP_DIAMOND_MIN_READLANES   // (the form before: one DPP step, four v_readlane and three s_min)
-      key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x128, 0xf, 0xf, false));  // row_ror:8: the row's other group
-      const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, 0), k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, 16);
-      const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)key, 32), k3 = (uint32_t)__builtin_amdgcn_readlane((int)key, 48);
-      const uint32_t kb = min(min(k0, k1), min(k2, k3));
-#else
-      // the minimum of the eight keys in lane 63: the row's other group (row_ror:8), then row_bcast15 into rows 1 and 3 and row_bcast31 into
-      // rows 2 and 3 -- v_min_u32 with the DPP operand directly (through update_dpp the compiler emits v_mov + v_mov_dpp + v_min per step);
-      // s_nop 1: the two wait states between a VALU write and a DPP read of the same register
-      asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-                   "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                   "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
-                   : "+v"(key));
-      const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)key, 63);
-#endif
+      const uint32_t kb = groups8_min_u32(key);   // (search_device.h: three v_min_u32_dpp + one v_readlane; four v_readlane + three s_min before)
       int best_site = 0;
       if (kb != 0xFFFFFFFFu && (kb >> 4) < bestsad) {
         bestsad = kb >> 4;

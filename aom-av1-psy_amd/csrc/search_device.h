@@ -299,6 +299,17 @@ __device__ __forceinline__ uint32_t row16_sum_u32(uint32_t v) {
   v += __builtin_amdgcn_update_dpp(0u, v, 0x140, 0xf, 0xf, false);
   return v;
 }
+// The minimum of a key over the wavefront when the 8 lanes of each group already hold their group's key: the row's other group (row_ror:8),
+// then row_bcast15 into rows 1 and 3 and row_bcast31 into rows 2 and 3, the result read from lane 63 -- three v_min_u32 with the DPP operand
+// and one v_readlane instead of one DPP step, four v_readlane and three s_min (through update_dpp the compiler emits v_mov + v_mov_dpp +
+// v_min per step).  s_nop 1: the two wait states between a VALU write and a DPP read of the same register.
+__device__ __forceinline__ uint32_t groups8_min_u32(uint32_t key) {
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+               : "+v"(key));
+  return (uint32_t)__builtin_amdgcn_readlane((int)key, 63);
+}
 __device__ __forceinline__ uint64_t row16_sum_u64(uint64_t v) {
 #define AOMHIP_STEP64(CTRL)                                                                      \
   {                                                                                              \
