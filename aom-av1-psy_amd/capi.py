@@ -219,6 +219,9 @@ _protos = {
     "aomhip_sse_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_hadamard_batch": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_txb_init_levels_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64]),
+    "aomhip_wedge_sse_from_residuals_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "aomhip_wedge_sign_from_residuals_batch": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aomhip_wedge_compute_delta_squares_batch": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
     "aomhip_cdef_search_sse_luma": (C.c_int, [_vp, _PP, _i, _PP, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "aomhip_cdef_search_sse_chroma": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "aomhip_lpf_search_sse": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _vp, _i64, _i, _i, _i, _i, _vp]),
@@ -696,6 +699,17 @@ class Context:
 
     def txb_init_levels_batch(self, d_coeff, w, h, d_off, n_blocks, d_levels, pitch):
         check(lib.aomhip_txb_init_levels_batch(self.h, d_coeff, w, h, d_off, n_blocks, d_levels, pitch), "aomhip_txb_init_levels_batch")
+
+    def wedge_sse_from_residuals_batch(self, d_r1, d_d, d_masks, n, n_blocks, n_masks, d_sse):
+        """av1_wedge_sse_from_residuals for every (block, mask): d_sse[i * n_masks + k] (uint64)."""
+        check(lib.aomhip_wedge_sse_from_residuals_batch(self.h, d_r1, d_d, d_masks, n, n_blocks, n_masks, d_sse), "aomhip_wedge_sse_from_residuals_batch")
+
+    def wedge_sign_from_residuals_batch(self, d_ds, d_masks, n, n_blocks, n_masks, d_limits, d_sign):
+        """av1_wedge_sign_from_residuals for every (block, mask): d_sign[i * n_masks + k] (int8), limits per block (int64)."""
+        check(lib.aomhip_wedge_sign_from_residuals_batch(self.h, d_ds, d_masks, n, n_blocks, n_masks, d_limits, d_sign), "aomhip_wedge_sign_from_residuals_batch")
+
+    def wedge_compute_delta_squares_batch(self, d_a, d_b, n, n_blocks, d_d):
+        check(lib.aomhip_wedge_compute_delta_squares_batch(self.h, d_a, d_b, n, n_blocks, d_d), "aomhip_wedge_compute_delta_squares_batch")
 
     def cdef_search_sse_luma(self, recon, recon_frame, source, source_frame, d_strengths, n, d_skip, damping, fb_stride, d_sse,
                              d_dir=None, d_var=None):

@@ -193,6 +193,87 @@ __global__ __launch_bounds__(256) void txb_levels_kernel(const int32_t *__restri
   }
 }
 
+
+// ---- the wedge-mask helpers of pick_wedge (av1/encoder/compound_type.c): av1_wedge_sse_from_residuals / _sign_from_residuals /
+// _compute_delta_squares (av1/encoder/wedge_utils.c:52-125).  One wavefront per (block, mask): the block's residual arrays are N int16
+// (N = bw * bh, a multiple of 64), the masks N uint8 each -- 8 elements per lane and step (one 16-byte load of each int16 array, one 8-byte
+// load of the mask), the wavefront's sums by shuffles.  HBM-bound streaming: 5 N bytes per (block, mask) for the SSE, 3 N for the sign.
+__global__ __launch_bounds__(256) void wedge_sse_kernel(const int16_t *__restrict__ r1, const int16_t *__restrict__ d, const uint8_t *__restrict__ masks, int n,
+                                                         int n_blocks, int n_masks, uint64_t *__restrict__ out) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int64_t job = (int64_t)blockIdx.x * 4 + wave;
+  if (job >= (int64_t)n_blocks * n_masks) return;
+  const int bi = (int)(job / n_masks), mi = (int)(job - (int64_t)bi * n_masks);
+  const int16_t *pr = r1 + (int64_t)bi * n, *pd = d + (int64_t)bi * n;
+  const uint8_t *pm = masks + (int64_t)mi * n;
+  unsigned long long csse = 0;
+  for (int i = lane * 8; i < n; i += 512) {
+    const uint4 vr = *reinterpret_cast<const uint4 *>(pr + i), vd = *reinterpret_cast<const uint4 *>(pd + i);
+    const uint2 vm = *reinterpret_cast<const uint2 *>(pm + i);
+    const uint32_t wr[4] = { vr.x, vr.y, vr.z, vr.w }, wd[4] = { vd.x, vd.y, vd.z, vd.w };
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      uint32_t pair = 0;   // t^2 <= 2^30 (t = -32768): two of them fit 32 bits, more do not
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = k + h;
+        const int r = (int)(int16_t)(wr[e >> 1] >> (16 * (e & 1))), dd = (int)(int16_t)(wd[e >> 1] >> (16 * (e & 1)));
+        const int m = (int)(((e < 4 ? vm.x : vm.y) >> (8 * (e & 3))) & 0xffu);
+        int t = 64 * r + m * dd;   // MAX_MASK_VALUE * r1 + m * d
+        t = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
+        pair += (uint32_t)(t * t);
+      }
+      csse += pair;
+    }
+  }
+  for (int msk = 1; msk < 64; msk <<= 1) csse += __shfl_xor(csse, msk, 64);
+  if (lane == 0) out[job] = (csse + 2048) >> 12;   // ROUND_POWER_OF_TWO(csse, 2 * WEDGE_WEIGHT_BITS)
+}
+
+__global__ __launch_bounds__(256) void wedge_sign_kernel(const int16_t *__restrict__ ds, const uint8_t *__restrict__ masks, int n, int n_blocks, int n_masks,
+                                                          const int64_t *__restrict__ limits, int8_t *__restrict__ out) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int64_t job = (int64_t)blockIdx.x * 4 + wave;
+  if (job >= (int64_t)n_blocks * n_masks) return;
+  const int bi = (int)(job / n_masks), mi = (int)(job - (int64_t)bi * n_masks);
+  const int16_t *pd = ds + (int64_t)bi * n;
+  const uint8_t *pm = masks + (int64_t)mi * n;
+  long long acc = 0;
+  for (int i = lane * 8; i < n; i += 512) {
+    const uint4 vd = *reinterpret_cast<const uint4 *>(pd + i);
+    const uint2 vm = *reinterpret_cast<const uint2 *>(pm + i);
+    const uint32_t wd[4] = { vd.x, vd.y, vd.z, vd.w };
+    int a = 0;   // 8 x 2^15 x 2^6
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      a += (int)(int16_t)(wd[k >> 1] >> (16 * (k & 1))) * (int)(((k < 4 ? vm.x : vm.y) >> (8 * (k & 3))) & 0xffu);
+    acc += a;
+  }
+  for (int msk = 1; msk < 64; msk <<= 1) acc += __shfl_xor(acc, msk, 64);
+  if (lane == 0) out[job] = (int8_t)(acc > limits[bi]);
+}
+
+__global__ __launch_bounds__(256) void wedge_delta_squares_kernel(const int16_t *__restrict__ a, const int16_t *__restrict__ b, int64_t n_total,
+                                                                   int16_t *__restrict__ d) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= n_total) return;
+  const uint4 va = *reinterpret_cast<const uint4 *>(a + i), vb = *reinterpret_cast<const uint4 *>(b + i);
+  const uint32_t wa[4] = { va.x, va.y, va.z, va.w }, wb[4] = { vb.x, vb.y, vb.z, vb.w };
+  uint32_t o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int x = (int)(int16_t)(wa[k] >> (16 * h)), y = (int)(int16_t)(wb[k] >> (16 * h));
+      const int t = x * x - y * y;
+      v[h] = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
+    }
+    o[k] = (uint32_t)(uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16);
+  }
+  *reinterpret_cast<uint4 *>(d + i) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 }  // namespace aomhip
 
 using namespace aomhip;
@@ -259,6 +340,44 @@ int aomhip_txb_init_levels_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int wi
   if (n_blocks == 0) return AOMHIP_OK;
   hipLaunchKernelGGL(txb_levels_kernel, dim3((n_blocks + 3) / 4), dim3(256), 0, ctx->stream, d_coeff, width, height, d_coeff_offset, n_blocks,
                      d_levels, levels_pitch);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+int aomhip_wedge_sse_from_residuals_batch(aomhip_ctx *ctx, const int16_t *d_r1, const int16_t *d_d, const uint8_t *d_masks, int n, int n_blocks, int n_masks,
+                                          uint64_t *d_sse) {
+  if (!ctx || n_blocks < 0 || n_masks < 0 || n <= 0 || (n & 63) || ((n_blocks > 0 && n_masks > 0) && (!d_r1 || !d_d || !d_masks || !d_sse))) {
+    set_error("aomhip_wedge_sse_from_residuals_batch: invalid argument (N is a positive multiple of 64)");
+    return AOMHIP_ERR_INVALID;
+  }
+  const int64_t jobs = (int64_t)n_blocks * n_masks;
+  if (jobs == 0) return AOMHIP_OK;
+  hipLaunchKernelGGL(wedge_sse_kernel, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, ctx->stream, d_r1, d_d, d_masks, n, n_blocks, n_masks, d_sse);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+int aomhip_wedge_sign_from_residuals_batch(aomhip_ctx *ctx, const int16_t *d_ds, const uint8_t *d_masks, int n, int n_blocks, int n_masks,
+                                           const int64_t *d_limits, int8_t *d_sign) {
+  if (!ctx || n_blocks < 0 || n_masks < 0 || n <= 0 || (n & 63) || ((n_blocks > 0 && n_masks > 0) && (!d_ds || !d_masks || !d_limits || !d_sign))) {
+    set_error("aomhip_wedge_sign_from_residuals_batch: invalid argument (N is a positive multiple of 64)");
+    return AOMHIP_ERR_INVALID;
+  }
+  const int64_t jobs = (int64_t)n_blocks * n_masks;
+  if (jobs == 0) return AOMHIP_OK;
+  hipLaunchKernelGGL(wedge_sign_kernel, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, ctx->stream, d_ds, d_masks, n, n_blocks, n_masks, d_limits, d_sign);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+int aomhip_wedge_compute_delta_squares_batch(aomhip_ctx *ctx, const int16_t *d_a, const int16_t *d_b, int n, int n_blocks, int16_t *d_d) {
+  if (!ctx || n_blocks < 0 || n <= 0 || (n & 63) || (n_blocks > 0 && (!d_a || !d_b || !d_d))) {
+    set_error("aomhip_wedge_compute_delta_squares_batch: invalid argument (N is a positive multiple of 64)");
+    return AOMHIP_ERR_INVALID;
+  }
+  const int64_t total = (int64_t)n * n_blocks;
+  if (total == 0) return AOMHIP_OK;
+  hipLaunchKernelGGL(wedge_delta_squares_kernel, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, ctx->stream, d_a, d_b, total, d_d);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

@@ -1161,6 +1161,21 @@ int aomhip_hadamard_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residu
 int aomhip_txb_init_levels_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int width, int height, const uint32_t *d_coeff_offset, int n_blocks,
                                  uint8_t *d_levels, int64_t levels_pitch);
 
+/* The wedge-mask helpers of pick_wedge / pick_interinter_wedge (av1/encoder/compound_type.c), which choose the wedge index and sign of the
+ * masked compound whose motion search is aomhip_compound_single_motion_search_batch: av1_wedge_sse_from_residuals,
+ * av1_wedge_sign_from_residuals, av1_wedge_compute_delta_squares (av1/encoder/wedge_utils.c:52-125; av1/common/av1_rtcd_defs.pl:440-445).
+ * N = bw * bh elements per block, a positive multiple of 64 (the reference's SIMD forms assume it, wedge blocks are >= 8 x 8); block i's
+ * int16 arrays at i * N; d_masks holds n_masks contiguous masks of N weights 0 .. 64 (the wedge codebook of the block size,
+ * av1_get_contiguous_soft_mask), shared by all blocks.
+ *   _sse_:   d_sse[i * n_masks + k] = ROUND_POWER_OF_TWO(sum clamp(64 * r1 + mask_k * d, int16)^2, 12)
+ *   _sign_:  d_sign[i * n_masks + k] = sum(ds * mask_k) > d_limits[i]
+ *   _delta_squares_: d = clamp(a^2 - b^2, int16), element-wise over n_blocks * N */
+int aomhip_wedge_sse_from_residuals_batch(aomhip_ctx *ctx, const int16_t *d_r1, const int16_t *d_d, const uint8_t *d_masks, int n, int n_blocks, int n_masks,
+                                          uint64_t *d_sse);
+int aomhip_wedge_sign_from_residuals_batch(aomhip_ctx *ctx, const int16_t *d_ds, const uint8_t *d_masks, int n, int n_blocks, int n_masks,
+                                           const int64_t *d_limits, int8_t *d_sign);
+int aomhip_wedge_compute_delta_squares_batch(aomhip_ctx *ctx, const int16_t *d_a, const int16_t *d_b, int n, int n_blocks, int16_t *d_d);
+
 /* ------------------------------------------------------------------ loop-restoration search statistics */
 
 /* av1_compute_stats / av1_compute_stats_highbd (av1/encoder/pickrst.c:948-1083; av1_rtcd_defs.pl:452-458): the Wiener

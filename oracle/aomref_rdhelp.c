@@ -1,7 +1,9 @@
 /*
  * oracle/aomref_rdhelp.c -- the RD helpers of SURVEY 8(f)-3: aom_sse / aom_highbd_sse (aom_dsp/sse.c:19-53), the
  * Hadamard family aom_hadamard_{4x4,8x8,16x16,32x32}, aom_hadamard_lp_{8x8,16x16}, aom_highbd_hadamard_{8x8,16x16,32x32}
- * (aom_dsp/avg.c:110-514), aom_satd / aom_satd_lp (:517-533) and av1_txb_init_levels (av1/encoder/encodetxb.c:238-254).
+ * (aom_dsp/avg.c:110-514), aom_satd / aom_satd_lp (:517-533), av1_txb_init_levels (av1/encoder/encodetxb.c:238-254) and the wedge-mask helpers
+ * av1_wedge_sse_from_residuals / av1_wedge_sign_from_residuals / av1_wedge_compute_delta_squares (av1/encoder/wedge_utils.c:52-125; pinned by
+ * tests/golden/ref_eval_wedge.npz).
  *
  * TEST INFRASTRUCTURE ONLY (see aomref.h).  Pinned by tests/golden/ref_eval_rdhelp.npz (the reference's own functions,
  * interpreted where they lie).  The restatement is recursive over the block size instead of the reference's three
@@ -114,5 +116,29 @@ void orc_txb_init_levels(const int32_t *coeff, int width, int height, uint8_t *l
       *ls++ = (uint8_t)(a > 127 ? 127 : a);
     }
     for (int j = 0; j < 4; ++j) *ls++ = 0;
+  }
+}
+
+/* av1_wedge_sse_from_residuals_c (av1/encoder/wedge_utils.c:52-63): sum of clamp(64 r1 + m d, int16)^2, rounded by 2 * WEDGE_WEIGHT_BITS = 12 */
+uint64_t orc_wedge_sse_from_residuals(const int16_t *r1, const int16_t *d, const uint8_t *m, int n) {
+  uint64_t csse = 0;
+  for (int i = 0; i < n; ++i) {
+    int32_t t = 64 * (int32_t)r1[i] + (int32_t)m[i] * d[i];
+    t = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
+    csse += (uint64_t)((int64_t)t * t);
+  }
+  return (csse + 2048) >> 12;
+}
+/* av1_wedge_sign_from_residuals_c (:96-105): sum(ds * m) > limit */
+int orc_wedge_sign_from_residuals(const int16_t *ds, const uint8_t *m, int n, int64_t limit) {
+  int64_t acc = 0;
+  for (int i = 0; i < n; ++i) acc += (int64_t)ds[i] * m[i];
+  return acc > limit;
+}
+/* av1_wedge_compute_delta_squares_c (:119-125): d = clamp(a^2 - b^2, int16) */
+void orc_wedge_compute_delta_squares(int16_t *d, const int16_t *a, const int16_t *b, int n) {
+  for (int i = 0; i < n; ++i) {
+    const int32_t v = (int32_t)a[i] * a[i] - (int32_t)b[i] * b[i];
+    d[i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
   }
 }
