@@ -122,6 +122,8 @@ MV_COST_ENTROPY, MV_COST_L1_LOWRES, MV_COST_L1_MIDRES, MV_COST_L1_HDRES, MV_COST
 COMP_AVG, COMP_DIST_WTD, COMP_MASK, COMP_OBMC = 0, 1, 2, 3
 blend_item_dtype = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("mask_offset", "<u2"), ("vertical", "u1"), ("reserved", "u1")])
 rect_dtype = np.dtype([("h_start", "<i4"), ("h_end", "<i4"), ("v_start", "<i4"), ("v_end", "<i4")])
+warp_block_dtype = np.dtype([("mat", "<i4", (6,)), ("alpha", "<i2"), ("beta", "<i2"), ("gamma", "<i2"), ("delta", "<i2"), ("p_col", "<i4"), ("p_row", "<i4"),
+                             ("p_width", "<i4"), ("p_height", "<i4")])   # aomhip_warp_block (48 bytes)
 
 
 class CompoundParams(C.Structure):
@@ -219,6 +221,7 @@ _protos = {
     "aomhip_sse_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_hadamard_batch": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_txb_init_levels_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64]),
+    "aomhip_warp_affine_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i]),
     "aomhip_wedge_sse_from_residuals_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "aomhip_wedge_sign_from_residuals_batch": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "aomhip_wedge_compute_delta_squares_batch": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -699,6 +702,11 @@ class Context:
 
     def txb_init_levels_batch(self, d_coeff, w, h, d_off, n_blocks, d_levels, pitch):
         check(lib.aomhip_txb_init_levels_batch(self.h, d_coeff, w, h, d_off, n_blocks, d_levels, pitch), "aomhip_txb_init_levels_batch")
+
+    def warp_affine_batch(self, ref, ref_frame, pred, pred_frame, ssx, ssy, d_blocks, n_blocks, max_w, max_h):
+        """av1_[highbd_]warp_affine for a batch of blocks (warp_block_dtype records), single reference, not compound."""
+        check(lib.aomhip_warp_affine_batch(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, ssx, ssy, d_blocks, n_blocks, max_w, max_h),
+              "aomhip_warp_affine_batch")
 
     def wedge_sse_from_residuals_batch(self, d_r1, d_d, d_masks, n, n_blocks, n_masks, d_sse):
         """av1_wedge_sse_from_residuals for every (block, mask): d_sse[i * n_masks + k] (uint64)."""

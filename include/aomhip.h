@@ -1176,6 +1176,24 @@ int aomhip_wedge_sign_from_residuals_batch(aomhip_ctx *ctx, const int16_t *d_ds,
                                            const int64_t *d_limits, int8_t *d_sign);
 int aomhip_wedge_compute_delta_squares_batch(aomhip_ctx *ctx, const int16_t *d_a, const int16_t *d_b, int n, int n_blocks, int16_t *d_d);
 
+/* ------------------------------------------------------------------ warped-motion prediction */
+
+/* av1_warp_affine / av1_highbd_warp_affine (av1/common/warped_motion.c:264-393,538-675; av1_rtcd_defs.pl:454-459 "WARPED_MOTION" group), the
+ * predictor av1_warp_plane runs for a block with motion_mode WARPED_CAUSAL or a global-motion reference, single reference, not compound
+ * (conv_params->is_compound == 0; round_0 as get_conv_params_no_round gives it: 3, 5 at 12 bits).  Block i is the p_width x p_height block
+ * at (p_col, p_row) of the plane -- multiples of 8 or, for the last tile, the remainder as the reference clips it -- predicted from
+ * `ref` (frame ref_frame; the function clamps every sample to the visible width x height of that plane: no border is read) with the affine
+ * model mat[6] (WarpedMotionParams::wmmat, WARPEDMODEL_PREC_BITS = 16) and its shear parameters alpha .. delta (av1_get_shear_params), into
+ * `pred` (frame pred_frame) at the same position.  subsampling_x / _y: the plane's (the chroma planes of 4:2:0 pass 1, 1 and their own
+ * p_col / p_row).  max_block_width / _height bound the blocks of the batch (<= 128). */
+typedef struct {
+  int32_t mat[6];
+  int16_t alpha, beta, gamma, delta;
+  int32_t p_col, p_row, p_width, p_height;
+} aomhip_warp_block;
+int aomhip_warp_affine_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred, int pred_frame, int subsampling_x,
+                             int subsampling_y, const aomhip_warp_block *d_blocks, int n_blocks, int max_block_width, int max_block_height);
+
 /* ------------------------------------------------------------------ loop-restoration search statistics */
 
 /* av1_compute_stats / av1_compute_stats_highbd (av1/encoder/pickrst.c:948-1083; av1_rtcd_defs.pl:452-458): the Wiener

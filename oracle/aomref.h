@@ -226,6 +226,9 @@ void orc_blend_a64_1d(void *dst, int dst_stride, const void *src1, int src1_stri
 int64_t orc_sse(const void *a, int a_stride, const void *b, int b_stride, int w, int h, int elem16);
 int orc_hadamard(const int16_t *src, ptrdiff_t stride, int n, int flavour, int32_t *coeff);
 void orc_txb_init_levels(const int32_t *coeff, int width, int height, uint8_t *levels);
+/* the warped-motion predictor of one reference, not compound (aomref_warp.c) */
+void orc_warp_affine(const int32_t *mat, const void *ref, int elem16, int width, int height, int stride, void *pred, int p_col, int p_row, int p_width,
+                     int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int round_0, int alpha, int beta, int gamma, int delta);
 uint64_t orc_wedge_sse_from_residuals(const int16_t *r1, const int16_t *d, const uint8_t *m, int n);
 int orc_wedge_sign_from_residuals(const int16_t *ds, const uint8_t *m, int n, int64_t limit);
 void orc_wedge_compute_delta_squares(int16_t *d, const int16_t *a, const int16_t *b, int n);

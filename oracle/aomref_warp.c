@@ -1,0 +1,81 @@
+/*
+ * oracle/aomref_warp.c -- the warped-motion predictor of a single reference: av1_warp_affine / av1_highbd_warp_affine
+ * (av1/common/warped_motion.c:264-393,538-675; AV1 spec 7.11.3.5 block warp process), the form av1_warp_plane runs for a WARPED_CAUSAL block or a
+ * global-motion reference when the prediction is not a compound (conv_params->is_compound == 0).
+ *
+ * TEST INFRASTRUCTURE ONLY (see aomref.h).  Pinned by tests/golden/ref_eval_warp.npz (the reference's own two functions, interpreted where
+ * they lie).  One loop nest for both pixel types; every intermediate keeps the reference's width (the horizontal sums are int32, the
+ * 15 x 8 intermediate block is per 8 x 8 output tile as in the reference).
+ */
+#include <stdint.h>
+#include <stddef.h>
+
+#include "aomref.h"
+
+static const int16_t k_warped_filter[193][8] = {
+#include "aomref_warp.inc"
+};
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static int rpot(int v, int n) { return (v + ((1 << n) >> 1)) >> n; }   /* ROUND_POWER_OF_TWO on a signed int as the reference applies it */
+
+/* mat[6] = wmmat, (alpha, beta, gamma, delta) = the shear parameters (av1_get_shear_params); round_0 = conv_params->round_0 (3, or 5 at 12 bits:
+ * get_conv_params_no_round); elem16: uint16 planes with bit depth bd, else uint8 (bd = 8) */
+void orc_warp_affine(const int32_t *mat, const void *ref, int elem16, int width, int height, int stride, void *pred, int p_col, int p_row, int p_width,
+                     int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int round_0, int alpha, int beta, int gamma, int delta) {
+  int32_t tmp[15 * 8];
+  if (!elem16) bd = 8;
+  const int extra = elem16 ? (bd + 7 - round_0 - 14 > 0 ? bd + 7 - round_0 - 14 : 0) : 0;   /* (highbd only: AOMMAX(bd + FILTER_BITS - round_0 - 14, 0)) */
+  const int reduce_bits_horiz = round_0 + extra;
+  const int reduce_bits_vert = 2 * 7 - reduce_bits_horiz;
+  const int offset_bits_horiz = bd + 7 - 1;
+  const int offset_bits_vert = bd + 2 * 7 - reduce_bits_horiz;
+  const int pmax = (1 << bd) - 1;
+  for (int i = p_row; i < p_row + p_height; i += 8) {
+    for (int j = p_col; j < p_col + p_width; j += 8) {
+      const int32_t src_x = (j + 4) << subsampling_x, src_y = (i + 4) << subsampling_y;
+      const int64_t dst_x = (int64_t)mat[2] * src_x + (int64_t)mat[3] * src_y + (int64_t)mat[0];
+      const int64_t dst_y = (int64_t)mat[4] * src_x + (int64_t)mat[5] * src_y + (int64_t)mat[1];
+      const int64_t x4 = dst_x >> subsampling_x, y4 = dst_y >> subsampling_y;
+      const int32_t ix4 = (int32_t)(x4 >> 16), iy4 = (int32_t)(y4 >> 16);
+      int32_t sx4 = (int32_t)(x4 & 0xffff), sy4 = (int32_t)(y4 & 0xffff);
+      sx4 += alpha * (-4) + beta * (-4);
+      sy4 += gamma * (-4) + delta * (-4);
+      sx4 &= ~63;   /* WARP_PARAM_REDUCE_BITS */
+      sy4 &= ~63;
+      for (int k = -7; k < 8; ++k) {   /* horizontal filter */
+        const int iy = clampi(iy4 + k, 0, height - 1);
+        int sx = sx4 + beta * (k + 4);
+        for (int l = -4; l < 4; ++l) {
+          const int ix = ix4 + l - 3;
+          const int offs = rpot(sx, 10) + 64;   /* WARPEDDIFF_PREC_BITS, WARPEDPIXEL_PREC_SHIFTS */
+          const int16_t *c = k_warped_filter[offs];
+          int32_t sum = 1 << offset_bits_horiz;
+          for (int m = 0; m < 8; ++m) {
+            const int sample_x = clampi(ix + m, 0, width - 1);
+            const int px = elem16 ? ((const uint16_t *)ref)[(ptrdiff_t)iy * stride + sample_x] : ((const uint8_t *)ref)[(ptrdiff_t)iy * stride + sample_x];
+            sum += px * c[m];
+          }
+          tmp[(k + 7) * 8 + (l + 4)] = rpot(sum, reduce_bits_horiz);
+          sx += alpha;
+        }
+      }
+      const int kmax = 4 < p_row + p_height - i - 4 ? 4 : p_row + p_height - i - 4, lmax = 4 < p_col + p_width - j - 4 ? 4 : p_col + p_width - j - 4;
+      for (int k = -4; k < kmax; ++k) {   /* vertical filter */
+        int sy = sy4 + delta * (k + 4);
+        for (int l = -4; l < lmax; ++l) {
+          const int offs = rpot(sy, 10) + 64;
+          const int16_t *c = k_warped_filter[offs];
+          int32_t sum = 1 << offset_bits_vert;
+          for (int m = 0; m < 8; ++m) sum += tmp[(k + m + 4) * 8 + (l + 4)] * c[m];
+          sum = rpot(sum, reduce_bits_vert);
+          const int v = clampi(sum - (1 << (bd - 1)) - (1 << bd), 0, pmax);
+          const ptrdiff_t o = (ptrdiff_t)(i - p_row + k + 4) * p_stride + (j - p_col + l + 4);
+          if (elem16) ((uint16_t *)pred)[o] = (uint16_t)v;
+          else ((uint8_t *)pred)[o] = (uint8_t)v;
+          sy += gamma;
+        }
+      }
+    }
+  }
+}
