@@ -222,6 +222,8 @@ _protos = {
     "aomhip_hadamard_batch": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_txb_init_levels_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64]),
     "aomhip_warp_affine_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i]),
+    "aomhip_calc_proj_params_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    "aomhip_pixel_proj_error_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _i, _vp]),
     "aomhip_wedge_sse_from_residuals_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "aomhip_wedge_sign_from_residuals_batch": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "aomhip_wedge_compute_delta_squares_batch": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -702,6 +704,16 @@ class Context:
 
     def txb_init_levels_batch(self, d_coeff, w, h, d_off, n_blocks, d_levels, pitch):
         check(lib.aomhip_txb_init_levels_batch(self.h, d_coeff, w, h, d_off, n_blocks, d_levels, pitch), "aomhip_txb_init_levels_batch")
+
+    def calc_proj_params_batch(self, src, src_frame, dat, dat_frame, d_units, n_units, d_flt0, d_flt1, flt_stride, flt_pitch, d_radii, d_H, d_C):
+        """av1_calc_proj_params[_high_bd] per restoration unit: H (4 int64) and C (2 int64) each."""
+        check(lib.aomhip_calc_proj_params_batch(self.h, C.byref(src), src_frame, C.byref(dat), dat_frame, d_units, n_units, d_flt0, d_flt1, flt_stride, flt_pitch,
+                                                d_radii, d_H, d_C), "aomhip_calc_proj_params_batch")
+
+    def pixel_proj_error_batch(self, src, src_frame, dat, dat_frame, d_units, n_units, d_flt0, d_flt1, flt_stride, flt_pitch, d_radii, d_xq, n_xq, d_err):
+        """av1_[lowbd|highbd]_pixel_proj_error per (unit, xq): int64 each."""
+        check(lib.aomhip_pixel_proj_error_batch(self.h, C.byref(src), src_frame, C.byref(dat), dat_frame, d_units, n_units, d_flt0, d_flt1, flt_stride, flt_pitch,
+                                                d_radii, d_xq, n_xq, d_err), "aomhip_pixel_proj_error_batch")
 
     def warp_affine_batch(self, ref, ref_frame, pred, pred_frame, ssx, ssy, d_blocks, n_blocks, max_w, max_h):
         """av1_[highbd_]warp_affine for a batch of blocks (warp_block_dtype records), single reference, not compound."""

@@ -166,6 +166,79 @@ static void launch_stats(hipStream_t st, int win, int n_units, const void *d, in
                        static_cast<const T *>(s), sstride, units, downsample, divider, M, H);
 }
 
+
+// ---- the self-guided filter's projection statistics: av1_calc_proj_params[_high_bd] (av1/encoder/pickrst.c:470-657: H[2][2], C[2] of
+// get_proj_subspace) and av1_[lowbd|highbd]_pixel_proj_error (:226-370: get_pixel_proj_error, evaluated once per xq that finer_search tries).
+// One 256-lane workgroup per (unit [, xq]): lanes stride the unit's pixels row-major, the sums are exact 64-bit integers (products of
+// two ~17-bit values, up to 2^16 pixels), reduced by shuffles and one LDS step.  Streaming: 2 pixels + 2 int32 per pixel.
+__device__ __forceinline__ long long wg_sum_i64(long long v, long long *scratch /* 4 */) {
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+  __syncthreads();
+  return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void proj_params_kernel(const T *__restrict__ src, int src_stride, const T *__restrict__ dat, int dat_stride,
+                                                           const aomhip_rect *__restrict__ units, const int32_t *__restrict__ flt0, const int32_t *__restrict__ flt1,
+                                                           int flt_stride, int64_t flt_pitch, const int32_t *__restrict__ radii, int64_t *__restrict__ H,
+                                                           int64_t *__restrict__ C) {
+  __shared__ long long scratch[4];
+  const int ui = blockIdx.x;
+  const aomhip_rect u = units[ui];
+  const int w = u.h_end - u.h_start, h = u.v_end - u.v_start, n = w * h;
+  const int r0 = radii[2 * ui], r1 = radii[2 * ui + 1];
+  const int32_t *f0 = flt0 + (int64_t)ui * flt_pitch, *f1 = flt1 + (int64_t)ui * flt_pitch;
+  long long h00 = 0, h01 = 0, h11 = 0, c0 = 0, c1 = 0;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    const int i = t / w, j = t - i * w;
+    const int64_t po = (int64_t)(u.v_start + i) * dat_stride + u.h_start + j, so = (int64_t)(u.v_start + i) * src_stride + u.h_start + j;
+    const int uu = (int)dat[po] << 4;                    // SGRPROJ_RST_BITS
+    const int sv = ((int)src[so] << 4) - uu;
+    const int a = r0 > 0 ? f0[(int64_t)i * flt_stride + j] - uu : 0, b = r1 > 0 ? f1[(int64_t)i * flt_stride + j] - uu : 0;
+    h00 += (long long)a * a; h11 += (long long)b * b; h01 += (long long)a * b;
+    c0 += (long long)a * sv; c1 += (long long)b * sv;
+  }
+  h00 = wg_sum_i64(h00, scratch); h01 = wg_sum_i64(h01, scratch); h11 = wg_sum_i64(h11, scratch);
+  c0 = wg_sum_i64(c0, scratch); c1 = wg_sum_i64(c1, scratch);
+  if (threadIdx.x == 0) {
+    const long long size = n;   // (C's integer division: towards zero, as `H[0][0] /= size` in the reference)
+    int64_t *Ho = H + 4 * (int64_t)ui, *Co = C + 2 * (int64_t)ui;
+    Ho[0] = r0 > 0 ? h00 / size : 0; Ho[3] = r1 > 0 ? h11 / size : 0;
+    Ho[1] = Ho[2] = (r0 > 0 && r1 > 0) ? h01 / size : 0;
+    Co[0] = r0 > 0 ? c0 / size : 0; Co[1] = r1 > 0 ? c1 / size : 0;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void proj_error_kernel(const T *__restrict__ src, int src_stride, const T *__restrict__ dat, int dat_stride,
+                                                          const aomhip_rect *__restrict__ units, const int32_t *__restrict__ flt0, const int32_t *__restrict__ flt1,
+                                                          int flt_stride, int64_t flt_pitch, const int32_t *__restrict__ radii, const int32_t *__restrict__ xq,
+                                                          int n_xq, int64_t *__restrict__ err_out) {
+  __shared__ long long scratch[4];
+  const int ui = blockIdx.x, qi = blockIdx.y;
+  const aomhip_rect u = units[ui];
+  const int w = u.h_end - u.h_start, h = u.v_end - u.v_start, n = w * h;
+  const int r0 = radii[2 * ui], r1 = radii[2 * ui + 1];
+  const int xq0 = xq[2 * ((int64_t)ui * n_xq + qi)], xq1 = xq[2 * ((int64_t)ui * n_xq + qi) + 1];
+  const int32_t *f0 = flt0 + (int64_t)ui * flt_pitch, *f1 = flt1 + (int64_t)ui * flt_pitch;
+  long long err = 0;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    const int i = t / w, j = t - i * w;
+    const int d = (int)dat[(int64_t)(u.v_start + i) * dat_stride + u.h_start + j], sv = (int)src[(int64_t)(u.v_start + i) * src_stride + u.h_start + j];
+    const int uu = d << 4;
+    int v = 1 << 10;                                     // half of 1 << (SGRPROJ_RST_BITS + SGRPROJ_PRJ_BITS)
+    if (r0 > 0) v += xq0 * (f0[(int64_t)i * flt_stride + j] - uu);
+    if (r1 > 0) v += xq1 * (f1[(int64_t)i * flt_stride + j] - uu);
+    const int e = ((r0 > 0 || r1 > 0) ? (v >> 11) : 0) + d - sv;
+    err += (long long)e * e;
+  }
+  err = wg_sum_i64(err, scratch);
+  if (threadIdx.x == 0) err_out[(int64_t)ui * n_xq + qi] = err;
+}
+
 }  // namespace aomhip
 
 using namespace aomhip;
@@ -199,6 +272,54 @@ extern "C" int aomhip_compute_stats_batch(aomhip_ctx *ctx, const aomhip_planes *
     launch_stats<uint8_t>(ctx->stream, wiener_win, n_units, d, dgd->stride, s, src->stride, d_units, use_downsampled_wiener_stats != 0, divider, d_M, d_H);
   else
     launch_stats<uint16_t>(ctx->stream, wiener_win, n_units, d, dgd->stride, s, src->stride, d_units, 0, divider, d_M, d_H);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+static int check_proj(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dat, int dat_frame, const aomhip_rect *d_units, int n_units,
+                      const int32_t *d_flt0, const int32_t *d_flt1, int flt_stride, int64_t flt_pitch, const int32_t *d_radii, const char *who) {
+  if (!ctx || !src || !dat || !src->base || !dat->base || n_units < 0 || (n_units > 0 && (!d_units || !d_flt0 || !d_flt1 || !d_radii)) || src_frame < 0 ||
+      src_frame >= src->n_frames || dat_frame < 0 || dat_frame >= dat->n_frames || src->bit_depth != dat->bit_depth || flt_stride <= 0 || flt_pitch <= 0) {
+    set_error("%s: invalid argument", who);
+    return AOMHIP_ERR_INVALID;
+  }
+  return AOMHIP_OK;
+}
+
+extern "C" int aomhip_calc_proj_params_batch(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dat, int dat_frame,
+                                             const aomhip_rect *d_units, int n_units, const int32_t *d_flt0, const int32_t *d_flt1, int flt_stride, int64_t flt_pitch,
+                                             const int32_t *d_radii, int64_t *d_H, int64_t *d_C) {
+  int rc = check_proj(ctx, src, src_frame, dat, dat_frame, d_units, n_units, d_flt0, d_flt1, flt_stride, flt_pitch, d_radii, "aomhip_calc_proj_params_batch");
+  if (rc != AOMHIP_OK) return rc;
+  if (n_units > 0 && (!d_H || !d_C)) { set_error("aomhip_calc_proj_params_batch: invalid argument"); return AOMHIP_ERR_INVALID; }
+  if (n_units == 0) return AOMHIP_OK;
+  const int64_t so = (int64_t)src_frame * src->frame_stride + (int64_t)src->border * src->stride + src->border;
+  const int64_t po = (int64_t)dat_frame * dat->frame_stride + (int64_t)dat->border * dat->stride + dat->border;
+  if (src->bit_depth == 8)
+    hipLaunchKernelGGL(proj_params_kernel<uint8_t>, dim3(n_units), dim3(256), 0, ctx->stream, static_cast<const uint8_t *>(src->base) + so, src->stride,
+                       static_cast<const uint8_t *>(dat->base) + po, dat->stride, d_units, d_flt0, d_flt1, flt_stride, flt_pitch, d_radii, d_H, d_C);
+  else
+    hipLaunchKernelGGL(proj_params_kernel<uint16_t>, dim3(n_units), dim3(256), 0, ctx->stream, static_cast<const uint16_t *>(src->base) + so, src->stride,
+                       static_cast<const uint16_t *>(dat->base) + po, dat->stride, d_units, d_flt0, d_flt1, flt_stride, flt_pitch, d_radii, d_H, d_C);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+extern "C" int aomhip_pixel_proj_error_batch(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dat, int dat_frame,
+                                             const aomhip_rect *d_units, int n_units, const int32_t *d_flt0, const int32_t *d_flt1, int flt_stride, int64_t flt_pitch,
+                                             const int32_t *d_radii, const int32_t *d_xq, int n_xq, int64_t *d_err) {
+  int rc = check_proj(ctx, src, src_frame, dat, dat_frame, d_units, n_units, d_flt0, d_flt1, flt_stride, flt_pitch, d_radii, "aomhip_pixel_proj_error_batch");
+  if (rc != AOMHIP_OK) return rc;
+  if (n_xq < 0 || n_xq > 65535 || (n_units > 0 && n_xq > 0 && (!d_xq || !d_err))) { set_error("aomhip_pixel_proj_error_batch: invalid argument"); return AOMHIP_ERR_INVALID; }
+  if (n_units == 0 || n_xq == 0) return AOMHIP_OK;
+  const int64_t so = (int64_t)src_frame * src->frame_stride + (int64_t)src->border * src->stride + src->border;
+  const int64_t po = (int64_t)dat_frame * dat->frame_stride + (int64_t)dat->border * dat->stride + dat->border;
+  if (src->bit_depth == 8)
+    hipLaunchKernelGGL(proj_error_kernel<uint8_t>, dim3(n_units, n_xq), dim3(256), 0, ctx->stream, static_cast<const uint8_t *>(src->base) + so, src->stride,
+                       static_cast<const uint8_t *>(dat->base) + po, dat->stride, d_units, d_flt0, d_flt1, flt_stride, flt_pitch, d_radii, d_xq, n_xq, d_err);
+  else
+    hipLaunchKernelGGL(proj_error_kernel<uint16_t>, dim3(n_units, n_xq), dim3(256), 0, ctx->stream, static_cast<const uint16_t *>(src->base) + so, src->stride,
+                       static_cast<const uint16_t *>(dat->base) + po, dat->stride, d_units, d_flt0, d_flt1, flt_stride, flt_pitch, d_radii, d_xq, n_xq, d_err);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

@@ -1210,6 +1210,20 @@ int aomhip_compute_stats_batch(aomhip_ctx *ctx, const aomhip_planes *dgd, int dg
                                int wiener_win, const aomhip_rect *d_units, const aomhip_rect *h_units, int n_units,
                                int use_downsampled_wiener_stats, int64_t *d_M, int64_t *d_H);
 
+/* The self-guided filter's projection statistics (search_sgrproj -> search_selfguided_restoration, av1/encoder/pickrst.c:
+ * av1_calc_proj_params[_high_bd] :470-657 = get_proj_subspace's normal equations, av1_[lowbd|highbd]_pixel_proj_error :226-370 = the error of
+ * one (xq0, xq1) that finer_search tries; av1_rtcd_defs.pl:454-463).  Unit i is a rectangle of `src` (the source) and `dat` (the degraded plane);
+ * its two self-guided filter outputs are int32 arrays at d_flt0 / d_flt1 + i * flt_pitch with rows flt_stride apart (row 0 = the unit's first
+ * row); d_radii[2 i], [2 i + 1] = params->r[0], r[1] of the unit's sgr_params entry (a radius 0 switches that filter off: the reference's three
+ * branches).  _params_: d_H[4 i ..] = H[0][0], H[0][1], H[1][0], H[1][1] and d_C[2 i ..] (each sum / (w * h), integer division towards zero,
+ * unused entries 0).  _error_: n_xq pairs per unit at d_xq[2 (i * n_xq + k)], d_err[i * n_xq + k] = the summed squared error. */
+int aomhip_calc_proj_params_batch(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dat, int dat_frame,
+                                  const aomhip_rect *d_units, int n_units, const int32_t *d_flt0, const int32_t *d_flt1, int flt_stride, int64_t flt_pitch,
+                                  const int32_t *d_radii, int64_t *d_H, int64_t *d_C);
+int aomhip_pixel_proj_error_batch(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *dat, int dat_frame,
+                                  const aomhip_rect *d_units, int n_units, const int32_t *d_flt0, const int32_t *d_flt1, int flt_stride, int64_t flt_pitch,
+                                  const int32_t *d_radii, const int32_t *d_xq, int n_xq, int64_t *d_err);
+
 /* ------------------------------------------------------------------ rtcd-signature conformance entry points */
 
 /* aom_dsp_rtcd_defs.pl:762-763 aom_sad{W}x{H} / aom_sad_skip_{W}x{H}; host pointers. */
