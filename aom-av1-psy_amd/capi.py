@@ -222,6 +222,7 @@ _protos = {
     "aomhip_hadamard_batch": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_txb_init_levels_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64]),
     "aomhip_warp_affine_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i]),
+    "aomhip_selfguided_restoration_batch": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i64]),
     "aomhip_calc_proj_params_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     "aomhip_pixel_proj_error_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _i, _vp]),
     "aomhip_wedge_sse_from_residuals_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -704,6 +705,12 @@ class Context:
 
     def txb_init_levels_batch(self, d_coeff, w, h, d_off, n_blocks, d_levels, pitch):
         check(lib.aomhip_txb_init_levels_batch(self.h, d_coeff, w, h, d_off, n_blocks, d_levels, pitch), "aomhip_txb_init_levels_batch")
+
+    def selfguided_restoration_batch(self, dgd, dgd_frame, d_units, h_units, n_units, d_idx, max_w, max_h, d_flt0, d_flt1, flt_stride, flt_pitch):
+        """av1_selfguided_restoration per restoration unit (rect_dtype records, sgr_params index per unit): two int32 outputs each."""
+        hu = None if h_units is None else np.ascontiguousarray(h_units).ctypes.data
+        check(lib.aomhip_selfguided_restoration_batch(self.h, C.byref(dgd), dgd_frame, d_units, hu, n_units, d_idx, max_w, max_h, d_flt0, d_flt1, flt_stride, flt_pitch),
+              "aomhip_selfguided_restoration_batch")
 
     def calc_proj_params_batch(self, src, src_frame, dat, dat_frame, d_units, n_units, d_flt0, d_flt1, flt_stride, flt_pitch, d_radii, d_H, d_C):
         """av1_calc_proj_params[_high_bd] per restoration unit: H (4 int64) and C (2 int64) each."""

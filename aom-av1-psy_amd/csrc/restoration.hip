@@ -167,6 +167,94 @@ static void launch_stats(hipStream_t st, int win, int n_units, const void *d, in
 }
 
 
+// ---- the self-guided restoration filter: av1_selfguided_restoration (av1/common/restoration.c:871-915; calculate_intermediate_result :672-764,
+// selfguided_restoration_fast_internal :766-823 for r[0] = 2 on every other row, selfguided_restoration_internal :825-869 for r[1] = 1; AV1 spec
+// 7.17.3) -- apply_sgr of the encoder's search_sgrproj runs it per restoration unit and parameter set.  The reference's running box sums are
+// truncated only where they are never used (tests/test_golden_sgr.py checks that property), so a unit's output does not depend on how it is cut: one 256-lane workgroup
+// per 32 x 32 tile of a unit (tile rows start on even rows of the unit: the r[0] filter's row parity), the tile's 38 x 38 footprint staged in LDS
+// once for both filters, A[] / B[] of the 34 x 34 positions the tile's outputs read in LDS, then the weighted 3 x 3 sums.
+#include "sgr_table.inc"
+__device__ const int kSgrParams[16][4] = AOMHIP_SGR_PARAMS;
+__device__ const int32_t kXByXplus1[256] = AOMHIP_X_BY_XPLUS1;
+__device__ const int32_t kOneByX[25] = AOMHIP_ONE_BY_X;
+
+constexpr int kSgrTile = 32, kSgrFoot = kSgrTile + 6, kSgrAB = kSgrTile + 2;
+
+template <typename T>
+__global__ __launch_bounds__(256) void selfguided_kernel(const T *__restrict__ dgd, int dgd_stride, const aomhip_rect *__restrict__ units,
+                                                          const int32_t *__restrict__ sgr_idx, int bit_depth, int32_t *__restrict__ flt0,
+                                                          int32_t *__restrict__ flt1, int flt_stride, int64_t flt_pitch, int tiles_x) {
+  __shared__ int32_t s_d[kSgrFoot * kSgrFoot];
+  __shared__ int32_t s_A[kSgrAB * kSgrAB], s_B[kSgrAB * kSgrAB];
+  const int ui = blockIdx.x;
+  const aomhip_rect u = units[ui];
+  const int w = u.h_end - u.h_start, h = u.v_end - u.v_start;
+  const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
+  const int ox = tx * kSgrTile, oy = ty * kSgrTile;   // the tile inside the unit
+  if (ox >= w || oy >= h) return;
+  const int idx = sgr_idx[ui];
+  // footprint: unit coordinates ox - 3 .. ox + 34, clamped to the unit's own 3-pixel surround (what lies beyond cannot reach an output)
+  for (int t = threadIdx.x; t < kSgrFoot * kSgrFoot; t += 256) {
+    const int fy = t / kSgrFoot, fx = t - fy * kSgrFoot;
+    const int y = min(max(oy + fy - 3, -3), h + 2), x = min(max(ox + fx - 3, -3), w + 2);
+    s_d[t] = (int32_t)dgd[(int64_t)(u.v_start + y) * dgd_stride + u.h_start + x];
+  }
+  __syncthreads();
+  const int sh = bit_depth - 8;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = kSgrParams[idx][pass], sv = kSgrParams[idx][2 + pass];
+    if (r <= 0) continue;   // (uniform)
+    int32_t *dst = (pass ? flt1 : flt0) + (int64_t)ui * flt_pitch;
+    const int n = (2 * r + 1) * (2 * r + 1);
+    // A, B at tile positions (i, j) in [-1, 32]: s_A[(i + 1) * 34 + j + 1]; the r[0] filter needs the odd rows only
+    for (int t = threadIdx.x; t < kSgrAB * kSgrAB; t += 256) {
+      const int ai = t / kSgrAB, aj = t - ai * kSgrAB;   // position (ai - 1, aj - 1)
+      if (pass == 0 && (ai & 1)) continue;                // (ai - 1 even: not computed, not read)
+      uint32_t sum = 0, sq = 0;
+      for (int y = -r; y <= r; ++y)
+        for (int x = -r; x <= r; ++x) {
+          const uint32_t v = (uint32_t)s_d[(ai + 2 + y) * kSgrFoot + (aj + 2 + x)];   // footprint row of position i is i + 3 = ai + 2
+          sum += v; sq += v * v;
+        }
+      const uint32_t a = (sq + ((1u << (2 * sh)) >> 1)) >> (2 * sh), b = (sum + ((1u << sh) >> 1)) >> sh;
+      const uint32_t p = (a * n < b * b) ? 0u : a * n - b * b;
+      const uint32_t z = (p * (uint32_t)sv + (1u << 19)) >> 20;                        // SGRPROJ_MTABLE_BITS
+      const int32_t A = kXByXplus1[z < 255u ? z : 255u];
+      s_A[t] = A;
+      s_B[t] = (int32_t)(((uint32_t)(256 - A) * sum * (uint32_t)kOneByX[n - 1] + (1u << 11)) >> 12);   // SGRPROJ_SGR, SGRPROJ_RECIP_BITS
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < kSgrTile * kSgrTile; t += 256) {
+      const int i = t >> 5, j = t & 31;
+      if (oy + i >= h || ox + j >= w) continue;
+      const int k = (i + 1) * kSgrAB + (j + 1);
+      int32_t a, b;
+      int nb;
+      if (pass == 0) {
+        if (!(i & 1)) {   // (the tile starts on an even row of the unit)
+          nb = 5;
+          a = (s_A[k - kSgrAB] + s_A[k + kSgrAB]) * 6 + (s_A[k - 1 - kSgrAB] + s_A[k - 1 + kSgrAB] + s_A[k + 1 - kSgrAB] + s_A[k + 1 + kSgrAB]) * 5;
+          b = (s_B[k - kSgrAB] + s_B[k + kSgrAB]) * 6 + (s_B[k - 1 - kSgrAB] + s_B[k - 1 + kSgrAB] + s_B[k + 1 - kSgrAB] + s_B[k + 1 + kSgrAB]) * 5;
+        } else {
+          nb = 4;
+          a = s_A[k] * 6 + (s_A[k - 1] + s_A[k + 1]) * 5;
+          b = s_B[k] * 6 + (s_B[k - 1] + s_B[k + 1]) * 5;
+        }
+      } else {
+        nb = 5;
+        a = (s_A[k] + s_A[k - 1] + s_A[k + 1] + s_A[k - kSgrAB] + s_A[k + kSgrAB]) * 4 +
+            (s_A[k - 1 - kSgrAB] + s_A[k - 1 + kSgrAB] + s_A[k + 1 - kSgrAB] + s_A[k + 1 + kSgrAB]) * 3;
+        b = (s_B[k] + s_B[k - 1] + s_B[k + 1] + s_B[k - kSgrAB] + s_B[k + kSgrAB]) * 4 +
+            (s_B[k - 1 - kSgrAB] + s_B[k - 1 + kSgrAB] + s_B[k + 1 - kSgrAB] + s_B[k + 1 + kSgrAB]) * 3;
+      }
+      const int32_t v = a * s_d[(i + 3) * kSgrFoot + (j + 3)] + b;
+      const int rs = 8 + nb - 4;   // SGRPROJ_SGR_BITS + nb - SGRPROJ_RST_BITS
+      dst[(int64_t)(oy + i) * flt_stride + ox + j] = (v + ((1 << rs) >> 1)) >> rs;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- the self-guided filter's projection statistics: av1_calc_proj_params[_high_bd] (av1/encoder/pickrst.c:470-657: H[2][2], C[2] of
 // get_proj_subspace) and av1_[lowbd|highbd]_pixel_proj_error (:226-370: get_pixel_proj_error, evaluated once per xq that finer_search tries).
 // One 256-lane workgroup per (unit [, xq]): lanes stride the unit's pixels row-major, the sums are exact 64-bit integers (products of
@@ -320,6 +408,37 @@ extern "C" int aomhip_pixel_proj_error_batch(aomhip_ctx *ctx, const aomhip_plane
   else
     hipLaunchKernelGGL(proj_error_kernel<uint16_t>, dim3(n_units, n_xq), dim3(256), 0, ctx->stream, static_cast<const uint16_t *>(src->base) + so, src->stride,
                        static_cast<const uint16_t *>(dat->base) + po, dat->stride, d_units, d_flt0, d_flt1, flt_stride, flt_pitch, d_radii, d_xq, n_xq, d_err);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+extern "C" int aomhip_selfguided_restoration_batch(aomhip_ctx *ctx, const aomhip_planes *dgd, int dgd_frame, const aomhip_rect *d_units, const aomhip_rect *h_units,
+                                                   int n_units, const int32_t *d_sgr_params_idx, int max_unit_width, int max_unit_height, int32_t *d_flt0,
+                                                   int32_t *d_flt1, int flt_stride, int64_t flt_pitch) {
+  if (!ctx || !dgd || !dgd->base || n_units < 0 || (n_units > 0 && (!d_units || !d_sgr_params_idx || !d_flt0 || !d_flt1)) || dgd_frame < 0 ||
+      dgd_frame >= dgd->n_frames || dgd->border < 3 || max_unit_width < 1 || max_unit_height < 1 || flt_stride < max_unit_width ||
+      flt_pitch < (int64_t)flt_stride * max_unit_height) {
+    set_error("aomhip_selfguided_restoration_batch: invalid argument (border >= 3; flt_stride / flt_pitch hold the largest unit)");
+    return AOMHIP_ERR_INVALID;
+  }
+  for (int i = 0; h_units && i < n_units; ++i) {
+    const aomhip_rect &r = h_units[i];
+    if (r.h_start < 0 || r.v_start < 0 || r.h_end > dgd->width || r.v_end > dgd->height || r.h_end <= r.h_start || r.v_end <= r.v_start ||
+        r.h_end - r.h_start > max_unit_width || r.v_end - r.v_start > max_unit_height) {
+      set_error("aomhip_selfguided_restoration_batch: unit %d is empty, outside the plane or larger than the stated maximum", i);
+      return AOMHIP_ERR_INVALID;
+    }
+  }
+  if (n_units == 0) return AOMHIP_OK;
+  const int tiles_x = (max_unit_width + kSgrTile - 1) / kSgrTile, tiles_y = (max_unit_height + kSgrTile - 1) / kSgrTile;
+  const int64_t po = (int64_t)dgd_frame * dgd->frame_stride + (int64_t)dgd->border * dgd->stride + dgd->border;
+  const dim3 grid((unsigned)n_units, (unsigned)(tiles_x * tiles_y));
+  if (dgd->bit_depth == 8)
+    hipLaunchKernelGGL(selfguided_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint8_t *>(dgd->base) + po, dgd->stride, d_units,
+                       d_sgr_params_idx, 8, d_flt0, d_flt1, flt_stride, flt_pitch, tiles_x);
+  else
+    hipLaunchKernelGGL(selfguided_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint16_t *>(dgd->base) + po, dgd->stride, d_units,
+                       d_sgr_params_idx, dgd->bit_depth, d_flt0, d_flt1, flt_stride, flt_pitch, tiles_x);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

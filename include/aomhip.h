@@ -1210,6 +1210,17 @@ int aomhip_compute_stats_batch(aomhip_ctx *ctx, const aomhip_planes *dgd, int dg
                                int wiener_win, const aomhip_rect *d_units, const aomhip_rect *h_units, int n_units,
                                int use_downsampled_wiener_stats, int64_t *d_M, int64_t *d_H);
 
+/* av1_selfguided_restoration (av1/common/restoration.c:871-915; av1_rtcd_defs.pl:449-450; AV1 spec 7.17.3): the two self-guided filter outputs of
+ * every restoration unit of a list -- apply_sgr of search_sgrproj (av1/encoder/pickrst.c) runs it per unit and parameter set.  `dgd` = the
+ * degraded plane ring, border >= 3 and extended like av1_extend_frame leaves it (the filter reads 3 pixels around a unit).  Unit i = the
+ * rectangle d_units[i] with parameter set d_sgr_params_idx[i] (0 .. 15: av1_sgr_params); its outputs go to d_flt0 / d_flt1 + i * flt_pitch, rows
+ * flt_stride apart; a filter whose radius is 0 in that set leaves its output untouched, like the reference.  Units of any size up to
+ * max_unit_width x max_unit_height: the reference calls the function on 64 x 64 processing units, and a unit's output does not depend on that
+ * cut (tests/test_golden_sgr.py).  h_units: the same list in host memory for argument checking, or NULL. */
+int aomhip_selfguided_restoration_batch(aomhip_ctx *ctx, const aomhip_planes *dgd, int dgd_frame, const aomhip_rect *d_units, const aomhip_rect *h_units,
+                                        int n_units, const int32_t *d_sgr_params_idx, int max_unit_width, int max_unit_height, int32_t *d_flt0,
+                                        int32_t *d_flt1, int flt_stride, int64_t flt_pitch);
+
 /* The self-guided filter's projection statistics (search_sgrproj -> search_selfguided_restoration, av1/encoder/pickrst.c:
  * av1_calc_proj_params[_high_bd] :470-657 = get_proj_subspace's normal equations, av1_[lowbd|highbd]_pixel_proj_error :226-370 = the error of
  * one (xq0, xq1) that finer_search tries; av1_rtcd_defs.pl:454-463).  Unit i is a rectangle of `src` (the source) and `dat` (the degraded plane);
