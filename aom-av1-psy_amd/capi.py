@@ -222,6 +222,7 @@ _protos = {
     "aomhip_hadamard_batch": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_txb_init_levels_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64]),
     "aomhip_warp_affine_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i]),
+    "aomhip_warp_affine_compound_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i]),
     "aomhip_selfguided_restoration_batch": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i64]),
     "aomhip_calc_proj_params_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     "aomhip_pixel_proj_error_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _i, _vp]),
@@ -726,6 +727,13 @@ class Context:
         """av1_[highbd_]warp_affine for a batch of blocks (warp_block_dtype records), single reference, not compound."""
         check(lib.aomhip_warp_affine_batch(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, ssx, ssy, d_blocks, n_blocks, max_w, max_h),
               "aomhip_warp_affine_batch")
+
+    def warp_affine_compound_batch(self, ref, ref_frame, pred, pred_frame, ssx, ssy, d_blocks, n_blocks, max_w, max_h, d_conv, conv_stride, do_average,
+                                   weights=None):
+        """av1_[highbd_]warp_affine with is_compound: do_average 0 fills the CONV_BUF, 1 blends the second reference in (weights = (fwd, bck) or None)."""
+        check(lib.aomhip_warp_affine_compound_batch(self.h, C.byref(ref), ref_frame, None if pred is None else C.byref(pred), pred_frame, ssx, ssy, d_blocks, n_blocks,
+                                                    max_w, max_h, d_conv, conv_stride, do_average, int(weights is not None), weights[0] if weights else 0,
+                                                    weights[1] if weights else 0), "aomhip_warp_affine_compound_batch")
 
     def wedge_sse_from_residuals_batch(self, d_r1, d_d, d_masks, n, n_blocks, n_masks, d_sse):
         """av1_wedge_sse_from_residuals for every (block, mask): d_sse[i * n_masks + k] (uint64)."""

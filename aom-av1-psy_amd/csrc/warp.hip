@@ -9,6 +9,9 @@
 //                    rounded, offsets removed, clipped.
 // The tile's centre, its integer / fractional source position and the two phases' starting values are scalars (64-bit affine products
 // included).  Bytes per tile: ~15 x 15 reference pixels in, 64 out -- a latency-bound gather; nothing is staged twice.
+// Compound (conv_params->is_compound): MODE 1 = the first reference, its vertical sums rounded by round_1 = COMPOUND_ROUND1_BITS into the
+// CONV_BUF (uint16, addressed like the plane); MODE 2 = the second reference blended with it -- (a + b) >> 1 or the distance weights
+// (a fwd + b bck) >> DIST_PRECISION_BITS -- offsets removed, rounded by round_bits, clipped into the prediction.
 #include "common.h"
 
 namespace aomhip {
@@ -18,9 +21,16 @@ __device__ const int16_t kWarpedFilter[193][8] __attribute__((aligned(16))) = {
 #include "warp_table.inc"
 };
 
-template <typename T>
+struct WarpCompound {
+  uint16_t *conv;      // CONV_BUF: element (row, col) of the plane at conv[row * conv_stride + col]
+  int conv_stride;
+  int use_dist_wtd, fwd_offset, bck_offset;
+};
+
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void warp_affine_kernel(PlaneView<T> ref, int ref_frame, int width, int height, T *__restrict__ pred_origin, int64_t pred_frame_off,
-                                                          int pred_stride, int ssx, int ssy, int bd, const aomhip_warp_block *__restrict__ blocks, int n_blocks) {
+                                                          int pred_stride, int ssx, int ssy, int bd, const aomhip_warp_block *__restrict__ blocks, int n_blocks,
+                                                          WarpCompound cm) {
   __shared__ int32_t tmp_all[4][15 * 8];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int bi = blockIdx.x;
@@ -40,7 +50,9 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(PlaneView<T> ref, int 
   const bool hbd = sizeof(T) == 2;
   const int round_0 = bd == 12 ? 5 : 3;   // ROUND0_BITS (+ 2 at 12 bits): get_conv_params_no_round (av1/common/convolve.h)
   const int extra = hbd ? max(bd + 7 - round_0 - 14, 0) : 0;
-  const int reduce_bits_horiz = round_0 + extra, reduce_bits_vert = 14 - reduce_bits_horiz;
+  const int round_1 = MODE ? 7 : 14 - round_0;   // COMPOUND_ROUND1_BITS
+  const int reduce_bits_horiz = round_0 + extra, reduce_bits_vert = MODE ? round_1 : 14 - reduce_bits_horiz;
+  [[maybe_unused]] const int round_bits = 14 - round_0 - round_1, offset_bits = bd + 14 - round_0;
   const int offset_bits_horiz = bd + 6, offset_bits_vert = bd + 14 - reduce_bits_horiz;
   // the centre of the tile in luma coordinates, through the model, back to this plane's coordinates
   const int32_t src_x = (j + 4) << ssx, src_y = (i + 4) << ssy;
@@ -86,8 +98,20 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(PlaneView<T> ref, int 
 #pragma unroll
       for (int m = 0; m < 8; ++m) sum += tmp[(k + m + 4) * 8 + (l + 4)] * c[m];
       sum = (sum + ((1 << reduce_bits_vert) >> 1)) >> reduce_bits_vert;
-      const int v = min(max(sum - (1 << (bd - 1)) - (1 << bd), 0), (1 << bd) - 1);
-      pred_origin[pred_frame_off + (int64_t)(i + k + 4) * pred_stride + (j + l + 4)] = (T)v;
+      if constexpr (MODE == 1) {
+        cm.conv[(int64_t)(i + k + 4) * cm.conv_stride + (j + l + 4)] = (uint16_t)sum;   // CONV_BUF_TYPE
+      } else {
+        int v;
+        if constexpr (MODE == 2) {
+          int t32 = (int)cm.conv[(int64_t)(i + k + 4) * cm.conv_stride + (j + l + 4)];
+          t32 = cm.use_dist_wtd ? (t32 * cm.fwd_offset + sum * cm.bck_offset) >> 4 : (t32 + sum) >> 1;   // DIST_PRECISION_BITS
+          t32 = t32 - (1 << (offset_bits - round_1)) - (1 << (offset_bits - round_1 - 1));
+          v = (t32 + ((1 << round_bits) >> 1)) >> round_bits;
+        } else {
+          v = sum - (1 << (bd - 1)) - (1 << bd);
+        }
+        pred_origin[pred_frame_off + (int64_t)(i + k + 4) * pred_stride + (j + l + 4)] = (T)min(max(v, 0), (1 << bd) - 1);
+      }
     }
   }
 }
@@ -97,25 +121,46 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(PlaneView<T> ref, int 
 
 using namespace aomhip;
 
-extern "C" int aomhip_warp_affine_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred, int pred_frame, int subsampling_x,
-                                        int subsampling_y, const aomhip_warp_block *d_blocks, int n_blocks, int max_block_width, int max_block_height) {
-  if (!ctx || !ref || !ref->base || !pred || !pred->base || n_blocks < 0 || (n_blocks > 0 && !d_blocks) || ref_frame < 0 || ref_frame >= ref->n_frames ||
-      pred_frame < 0 || pred_frame >= pred->n_frames || (ref->bit_depth == 8) != (pred->bit_depth == 8) || (subsampling_x | subsampling_y) < 0 ||
-      subsampling_x > 1 || subsampling_y > 1 || max_block_width < 1 || max_block_height < 1 || max_block_width > 128 || max_block_height > 128) {
-    set_error("aomhip_warp_affine_batch: invalid argument");
+static int warp_launch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred, int pred_frame, int subsampling_x, int subsampling_y,
+                       const aomhip_warp_block *d_blocks, int n_blocks, int max_block_width, int max_block_height, int mode, WarpCompound cm, const char *who) {
+  if (!ctx || !ref || !ref->base || n_blocks < 0 || (n_blocks > 0 && !d_blocks) || ref_frame < 0 || ref_frame >= ref->n_frames ||
+      (mode != 1 && (!pred || !pred->base || pred_frame < 0 || pred_frame >= pred->n_frames || (ref->bit_depth == 8) != (pred->bit_depth == 8))) ||
+      (subsampling_x | subsampling_y) < 0 || subsampling_x > 1 || subsampling_y > 1 || max_block_width < 1 || max_block_height < 1 || max_block_width > 128 ||
+      max_block_height > 128 || (mode != 0 && (!cm.conv || cm.conv_stride <= 0))) {
+    set_error("%s: invalid argument", who);
     return AOMHIP_ERR_INVALID;
   }
   if (n_blocks == 0) return AOMHIP_OK;
   AOMHIP_TRY(hipSetDevice(ctx->device));
   const int tiles = ((max_block_width + 7) / 8) * ((max_block_height + 7) / 8);
   const dim3 grid((unsigned)n_blocks, (unsigned)((tiles + 3) / 4)), block(256);
-  const int64_t poff = (int64_t)pred_frame * pred->frame_stride + (int64_t)pred->border * pred->stride + pred->border;
-  if (ref->bit_depth == 8)
-    hipLaunchKernelGGL(warp_affine_kernel<uint8_t>, grid, block, 0, ctx->stream, view_of<uint8_t>(*ref), ref_frame, ref->width, ref->height,
-                       static_cast<uint8_t *>(pred->base), poff, pred->stride, subsampling_x, subsampling_y, 8, d_blocks, n_blocks);
-  else
-    hipLaunchKernelGGL(warp_affine_kernel<uint16_t>, grid, block, 0, ctx->stream, view_of<uint16_t>(*ref), ref_frame, ref->width, ref->height,
-                       static_cast<uint16_t *>(pred->base), poff, pred->stride, subsampling_x, subsampling_y, ref->bit_depth, d_blocks, n_blocks);
+  const int64_t poff = pred ? (int64_t)pred_frame * pred->frame_stride + (int64_t)pred->border * pred->stride + pred->border : 0;
+  void *pbase = pred ? pred->base : nullptr;
+  const int pstride = pred ? pred->stride : 0;
+#define LAUNCH(T, M)                                                                                                                                   \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(warp_affine_kernel<T, M>), grid, block, 0, ctx->stream, view_of<T>(*ref), ref_frame, ref->width, ref->height,    \
+                     static_cast<T *>(pbase), poff, pstride, subsampling_x, subsampling_y, ref->bit_depth == 8 ? 8 : ref->bit_depth, d_blocks, n_blocks, cm)
+  if (ref->bit_depth == 8) {
+    if (mode == 0) LAUNCH(uint8_t, 0); else if (mode == 1) LAUNCH(uint8_t, 1); else LAUNCH(uint8_t, 2);
+  } else {
+    if (mode == 0) LAUNCH(uint16_t, 0); else if (mode == 1) LAUNCH(uint16_t, 1); else LAUNCH(uint16_t, 2);
+  }
+#undef LAUNCH
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
+}
+
+extern "C" int aomhip_warp_affine_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred, int pred_frame, int subsampling_x,
+                                        int subsampling_y, const aomhip_warp_block *d_blocks, int n_blocks, int max_block_width, int max_block_height) {
+  return warp_launch(ctx, ref, ref_frame, pred, pred_frame, subsampling_x, subsampling_y, d_blocks, n_blocks, max_block_width, max_block_height, 0,
+                     WarpCompound{ nullptr, 0, 0, 0, 0 }, "aomhip_warp_affine_batch");
+}
+
+extern "C" int aomhip_warp_affine_compound_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred, int pred_frame,
+                                                 int subsampling_x, int subsampling_y, const aomhip_warp_block *d_blocks, int n_blocks, int max_block_width,
+                                                 int max_block_height, uint16_t *d_conv, int conv_stride, int do_average, int use_dist_wtd_comp_avg,
+                                                 int fwd_offset, int bck_offset) {
+  return warp_launch(ctx, ref, ref_frame, do_average ? pred : nullptr, pred_frame, subsampling_x, subsampling_y, d_blocks, n_blocks, max_block_width,
+                     max_block_height, do_average ? 2 : 1, WarpCompound{ d_conv, conv_stride, use_dist_wtd_comp_avg, fwd_offset, bck_offset },
+                     "aomhip_warp_affine_compound_batch");
 }

@@ -1193,6 +1193,13 @@ typedef struct {
 } aomhip_warp_block;
 int aomhip_warp_affine_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred, int pred_frame, int subsampling_x,
                              int subsampling_y, const aomhip_warp_block *d_blocks, int n_blocks, int max_block_width, int max_block_height);
+/* The same with conv_params->is_compound = 1 (the two calls av1_make_inter_predictor makes for a compound whose references are warped):
+ * do_average 0 = the first reference, its sums rounded by COMPOUND_ROUND1_BITS into the CONV_BUF d_conv (uint16; element (row, col) of the plane at
+ * d_conv[row * conv_stride + col]; `pred` unused, may be NULL); do_average 1 = the second reference blended with what d_conv holds -- plain
+ * average, or with use_dist_wtd_comp_avg (tmp * fwd_offset + sum * bck_offset) >> DIST_PRECISION_BITS -- into `pred`. */
+int aomhip_warp_affine_compound_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred, int pred_frame, int subsampling_x,
+                                      int subsampling_y, const aomhip_warp_block *d_blocks, int n_blocks, int max_block_width, int max_block_height,
+                                      uint16_t *d_conv, int conv_stride, int do_average, int use_dist_wtd_comp_avg, int fwd_offset, int bck_offset);
 
 /* ------------------------------------------------------------------ loop-restoration search statistics */
 

@@ -236,6 +236,9 @@ int64_t orc_pixel_proj_error(const void *src, int width, int height, int src_str
 /* the warped-motion predictor of one reference, not compound (aomref_warp.c) */
 void orc_warp_affine(const int32_t *mat, const void *ref, int elem16, int width, int height, int stride, void *pred, int p_col, int p_row, int p_width,
                      int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int round_0, int alpha, int beta, int gamma, int delta);
+void orc_warp_affine_compound(const int32_t *mat, const void *ref, int elem16, int width, int height, int stride, void *pred, int p_col, int p_row, int p_width,
+                              int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int round_0, int alpha, int beta, int gamma, int delta,
+                              int do_average, int use_dist_wtd, int fwd_offset, int bck_offset, uint16_t *conv, int conv_stride);
 uint64_t orc_wedge_sse_from_residuals(const int16_t *r1, const int16_t *d, const uint8_t *m, int n);
 int orc_wedge_sign_from_residuals(const int16_t *ds, const uint8_t *m, int n, int64_t limit);
 void orc_wedge_compute_delta_squares(int16_t *d, const int16_t *a, const int16_t *b, int n);

@@ -21,13 +21,16 @@ static int rpot(int v, int n) { return (v + ((1 << n) >> 1)) >> n; }   /* ROUND_
 
 /* mat[6] = wmmat, (alpha, beta, gamma, delta) = the shear parameters (av1_get_shear_params); round_0 = conv_params->round_0 (3, or 5 at 12 bits:
  * get_conv_params_no_round); elem16: uint16 planes with bit depth bd, else uint8 (bd = 8) */
-void orc_warp_affine(const int32_t *mat, const void *ref, int elem16, int width, int height, int stride, void *pred, int p_col, int p_row, int p_width,
-                     int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int round_0, int alpha, int beta, int gamma, int delta) {
+static void warp_affine(const int32_t *mat, const void *ref, int elem16, int width, int height, int stride, void *pred, int p_col, int p_row, int p_width,
+                        int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int round_0, int alpha, int beta, int gamma, int delta,
+                        int is_compound, int do_average, int use_dist_wtd, int fwd_offset, int bck_offset, uint16_t *conv, int conv_stride) {
   int32_t tmp[15 * 8];
   if (!elem16) bd = 8;
   const int extra = elem16 ? (bd + 7 - round_0 - 14 > 0 ? bd + 7 - round_0 - 14 : 0) : 0;   /* (highbd only: AOMMAX(bd + FILTER_BITS - round_0 - 14, 0)) */
   const int reduce_bits_horiz = round_0 + extra;
-  const int reduce_bits_vert = 2 * 7 - reduce_bits_horiz;
+  const int round_1 = is_compound ? 7 : 2 * 7 - round_0;   /* COMPOUND_ROUND1_BITS (get_conv_params_no_round) */
+  const int reduce_bits_vert = is_compound ? round_1 : 2 * 7 - reduce_bits_horiz;
+  const int round_bits = 2 * 7 - round_0 - round_1, offset_bits = bd + 2 * 7 - round_0;
   const int offset_bits_horiz = bd + 7 - 1;
   const int offset_bits_vert = bd + 2 * 7 - reduce_bits_horiz;
   const int pmax = (1 << bd) - 1;
@@ -69,8 +72,19 @@ void orc_warp_affine(const int32_t *mat, const void *ref, int elem16, int width,
           int32_t sum = 1 << offset_bits_vert;
           for (int m = 0; m < 8; ++m) sum += tmp[(k + m + 4) * 8 + (l + 4)] * c[m];
           sum = rpot(sum, reduce_bits_vert);
-          const int v = clampi(sum - (1 << (bd - 1)) - (1 << bd), 0, pmax);
           const ptrdiff_t o = (ptrdiff_t)(i - p_row + k + 4) * p_stride + (j - p_col + l + 4);
+          int v;
+          if (is_compound) {
+            uint16_t *cp = &conv[(ptrdiff_t)(i - p_row + k + 4) * conv_stride + (j - p_col + l + 4)];
+            if (!do_average) { *cp = (uint16_t)sum; sy += gamma; continue; }   /* CONV_BUF_TYPE is uint16_t */
+            int32_t t32 = *cp;
+            if (use_dist_wtd) t32 = (t32 * fwd_offset + sum * bck_offset) >> 4;   /* DIST_PRECISION_BITS */
+            else t32 = (t32 + sum) >> 1;
+            t32 = t32 - (1 << (offset_bits - round_1)) - (1 << (offset_bits - round_1 - 1));
+            v = clampi(rpot(t32, round_bits), 0, pmax);
+          } else {
+            v = clampi(sum - (1 << (bd - 1)) - (1 << bd), 0, pmax);
+          }
           if (elem16) ((uint16_t *)pred)[o] = (uint16_t)v;
           else ((uint8_t *)pred)[o] = (uint8_t)v;
           sy += gamma;
@@ -78,4 +92,18 @@ void orc_warp_affine(const int32_t *mat, const void *ref, int elem16, int width,
       }
     }
   }
+}
+
+void orc_warp_affine(const int32_t *mat, const void *ref, int elem16, int width, int height, int stride, void *pred, int p_col, int p_row, int p_width,
+                     int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int round_0, int alpha, int beta, int gamma, int delta) {
+  warp_affine(mat, ref, elem16, width, height, stride, pred, p_col, p_row, p_width, p_height, p_stride, subsampling_x, subsampling_y, bd, round_0, alpha, beta,
+              gamma, delta, 0, 0, 0, 0, 0, NULL, 0);
+}
+/* conv_params->is_compound = 1: do_average 0 writes the block's CONV_BUF (conv, conv_stride: the block's own buffer, element (0, 0) = its first pixel),
+ * do_average 1 blends with it -- plain average or the distance weights -- into pred */
+void orc_warp_affine_compound(const int32_t *mat, const void *ref, int elem16, int width, int height, int stride, void *pred, int p_col, int p_row, int p_width,
+                              int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int round_0, int alpha, int beta, int gamma, int delta,
+                              int do_average, int use_dist_wtd, int fwd_offset, int bck_offset, uint16_t *conv, int conv_stride) {
+  warp_affine(mat, ref, elem16, width, height, stride, pred, p_col, p_row, p_width, p_height, p_stride, subsampling_x, subsampling_y, bd, round_0, alpha, beta,
+              gamma, delta, 1, do_average, use_dist_wtd, fwd_offset, bck_offset, conv, conv_stride);
 }

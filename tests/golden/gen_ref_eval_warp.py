@@ -76,6 +76,50 @@ def main():
                           "round_0": 5 if bd == 12 else 3})
             k += 1
     save("ref_eval_warp.npz", arrays, cases)
+    # ---- compound: the first reference into the CONV_BUF (do_average 0), the second blended in (do_average 1): plain average and distance weights
+    arrays2, cases2 = {}, []
+    k = 0
+    for bd in (8, 10, 12):
+        mx = (1 << bd) - 1
+        ct = "uint8_t" if bd == 8 else "uint16_t"
+        planes = [rng.integers(0, mx + 1, (H, W)) for _ in range(2)]
+        planes[0][:6] = np.where(rng.integers(0, 2, (6, W)) > 0, mx, 0)
+        for r in range(2):
+            arrays2["ref%d_%d" % (bd, r)] = planes[r].astype(np.uint16)
+        P = [ev.array(pl.ravel(), ct) for pl in planes]
+        for trial in range(8):
+            pw, ph = [(8, 8), (16, 8), (8, 16), (16, 16)][trial % 4]
+            p_col, p_row = int(rng.integers(0, (W - pw) // 8 + 1)) * 8, int(rng.integers(0, (H - ph) // 8 + 1)) * 8
+            if trial == 5:
+                p_col, p_row = 0, 0
+            ssx = ssy = 1 if trial % 3 == 2 else 0
+            wts = None if trial % 2 == 0 else [(9, 7), (4, 12), (13, 3), (2, 14)][trial // 2]
+            mats, shears = [], []
+            for r in range(2):
+                mat = [int(rng.integers(-6 << 16, 6 << 16)), int(rng.integers(-6 << 16, 6 << 16)), (1 << 16) + int(rng.integers(-(1 << 12), 1 << 12)),
+                       int(rng.integers(-(1 << 12), 1 << 12)), int(rng.integers(-(1 << 12), 1 << 12)), (1 << 16) + int(rng.integers(-(1 << 12), 1 << 12))]
+                if trial == 6 and r == 1:
+                    mat[0] += 70 << 16
+                mats.append(mat); shears.append(list(shear_of(mat)))
+            buf16 = ev.array([0] * (pw * ph), "uint16_t")
+            dst = ev.array([0] * (pw * ph), ct)
+            for r in range(2):
+                cpv = ev.call("get_conv_params_no_round", r, 0, buf16, pw, 1, bd)
+                cp = R.Ptr([cpv], 0, cpv.st)
+                if wts:
+                    ev.set(cp, "use_dist_wtd_comp_avg", 1); ev.set(cp, "fwd_offset", wts[0]); ev.set(cp, "bck_offset", wts[1])
+                args = [ev.array(mats[r], "int32_t"), P[r], W, H, W, dst, p_col, p_row, pw, ph, pw, ssx, ssy]
+                if bd > 8:
+                    args.append(bd)
+                args += [cp] + shears[r]
+                ev.call("av1_warp_affine_c" if bd == 8 else "av1_highbd_warp_affine_c", *args)
+                if r == 0:
+                    arrays2["c%d" % k] = np.asarray(buf16.buf, np.uint16).copy()
+            arrays2["d%d" % k] = np.asarray(dst.buf, np.uint16)
+            cases2.append({"k": k, "bd": bd, "mat": mats, "shear": shears, "p_col": p_col, "p_row": p_row, "pw": pw, "ph": ph, "ss": ssx, "weights": wts,
+                           "round_0": 5 if bd == 12 else 3})
+            k += 1
+    save("ref_eval_warp_compound.npz", arrays2, cases2)
 
 
 if __name__ == "__main__":

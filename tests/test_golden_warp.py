@@ -45,3 +45,39 @@ def test_oracle_warp_reproduces_the_interpreted_reference(oracle):
             assert np.abs(want.astype(np.int32) - blk).max() <= max(4, (1 << c["bd"]) // 64)
             identity += 1
     assert clamped >= 6 and identity >= 2
+
+
+def orc_warp_compound(oracle, planes, bd, c):
+    """Both calls of a compound: reference 0 into the block's CONV_BUF, reference 1 blended in -> (conv buffer, prediction)."""
+    lib = oracle.lib
+    lib.orc_warp_affine_compound.restype = None
+    lib.orc_warp_affine_compound.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] + [C.c_int] * 17 + [C.c_void_p, C.c_int]
+    dt = np.uint8 if bd == 8 else np.uint16
+    out = np.zeros((c["ph"], c["pw"]), dt)
+    conv = np.zeros((c["ph"], c["pw"]), np.uint16)
+    wts = c["weights"]
+    for r in range(2):
+        ref = np.ascontiguousarray(planes[r], dt)
+        h, w = ref.shape
+        mat = np.array(c["mat"][r], np.int32)
+        a, b, g, d = c["shear"][r]
+        lib.orc_warp_affine_compound(mat.ctypes.data, ref.ctypes.data, int(bd > 8), w, h, w, out.ctypes.data, c["p_col"], c["p_row"], c["pw"], c["ph"], c["pw"],
+                                     c["ss"], c["ss"], bd, c["round_0"], a, b, g, d, r, int(wts is not None), wts[0] if wts else 0, wts[1] if wts else 0,
+                                     conv.ctypes.data, c["pw"])
+        if r == 0:
+            first = conv.copy()
+    return first, out
+
+
+def test_oracle_compound_warp_reproduces_the_interpreted_reference(oracle):
+    z = np.load(os.path.join(HERE, "golden", "ref_eval_warp_compound.npz"))
+    cases = json.loads(bytes(z["cases"]).decode())
+    assert len(cases) == 24
+    weighted = 0
+    for c in cases:
+        planes = [z["ref%d_%d" % (c["bd"], r)] for r in range(2)]
+        conv, pred = orc_warp_compound(oracle, planes, c["bd"], c)
+        assert np.array_equal(conv.ravel(), z["c%d" % c["k"]]), c
+        assert np.array_equal(pred.ravel().astype(np.uint16), z["d%d" % c["k"]]), c
+        weighted += c["weights"] is not None
+    assert weighted == 12
