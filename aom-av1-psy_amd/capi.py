@@ -122,6 +122,7 @@ MV_COST_ENTROPY, MV_COST_L1_LOWRES, MV_COST_L1_MIDRES, MV_COST_L1_HDRES, MV_COST
 COMP_AVG, COMP_DIST_WTD, COMP_MASK, COMP_OBMC = 0, 1, 2, 3
 blend_item_dtype = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("mask_offset", "<u2"), ("vertical", "u1"), ("reserved", "u1")])
 rect_dtype = np.dtype([("h_start", "<i4"), ("h_end", "<i4"), ("v_start", "<i4"), ("v_end", "<i4")])
+scaled_block_dtype = np.dtype([(n, "<i4") for n in ("src_x", "src_y", "subpel_x_qn", "subpel_y_qn", "dst_x", "dst_y")])   # aomhip_scaled_block
 warp_block_dtype = np.dtype([("mat", "<i4", (6,)), ("alpha", "<i2"), ("beta", "<i2"), ("gamma", "<i2"), ("delta", "<i2"), ("p_col", "<i4"), ("p_row", "<i4"),
                              ("p_width", "<i4"), ("p_height", "<i4")])   # aomhip_warp_block (48 bytes)
 
@@ -221,6 +222,8 @@ _protos = {
     "aomhip_sse_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_hadamard_batch": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_txb_init_levels_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64]),
+    "aomhip_scaled_pred_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),
+    "aomhip_scaled_pred_compound_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i]),
     "aomhip_warp_affine_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i]),
     "aomhip_warp_affine_compound_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i]),
     "aomhip_selfguided_restoration_batch": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i64]),
@@ -722,6 +725,17 @@ class Context:
         """av1_[lowbd|highbd]_pixel_proj_error per (unit, xq): int64 each."""
         check(lib.aomhip_pixel_proj_error_batch(self.h, C.byref(src), src_frame, C.byref(dat), dat_frame, d_units, n_units, d_flt0, d_flt1, flt_stride, flt_pitch,
                                                 d_radii, d_xq, n_xq, d_err), "aomhip_pixel_proj_error_batch")
+
+    def scaled_pred_batch(self, ref, ref_frame, pred, pred_frame, bw, bh, fx, fy, x_step_qn, y_step_qn, d_blocks, n_blocks):
+        """av1_[highbd_]convolve_2d_scale for a batch of blocks (scaled_block_dtype records), single reference."""
+        check(lib.aomhip_scaled_pred_batch(self.h, C.byref(ref), ref_frame, C.byref(pred), pred_frame, bw, bh, fx, fy, x_step_qn, y_step_qn, d_blocks, n_blocks),
+              "aomhip_scaled_pred_batch")
+
+    def scaled_pred_compound_batch(self, ref, ref_frame, pred, pred_frame, bw, bh, fx, fy, x_step_qn, y_step_qn, d_blocks, n_blocks, d_conv, conv_stride, do_average,
+                                   weights=None):
+        check(lib.aomhip_scaled_pred_compound_batch(self.h, C.byref(ref), ref_frame, None if pred is None else C.byref(pred), pred_frame, bw, bh, fx, fy, x_step_qn,
+                                                    y_step_qn, d_blocks, n_blocks, d_conv, conv_stride, do_average, int(weights is not None),
+                                                    weights[0] if weights else 0, weights[1] if weights else 0), "aomhip_scaled_pred_compound_batch")
 
     def warp_affine_batch(self, ref, ref_frame, pred, pred_frame, ssx, ssy, d_blocks, n_blocks, max_w, max_h):
         """av1_[highbd_]warp_affine for a batch of blocks (warp_block_dtype records), single reference, not compound."""

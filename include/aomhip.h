@@ -1201,6 +1201,27 @@ int aomhip_warp_affine_compound_batch(aomhip_ctx *ctx, const aomhip_planes *ref,
                                       int subsampling_y, const aomhip_warp_block *d_blocks, int n_blocks, int max_block_width, int max_block_height,
                                       uint16_t *d_conv, int conv_stride, int do_average, int use_dist_wtd_comp_avg, int fwd_offset, int bck_offset);
 
+/* ------------------------------------------------------------------ prediction from a scaled reference */
+
+/* av1_convolve_2d_scale / av1_highbd_convolve_2d_scale (av1/common/convolve.c; av1_rtcd_defs.pl:616-617,599-600): the predictor
+ * av1_make_inter_predictor runs when the reference has another resolution than the frame (scale factors x_step_qn / y_step_qn in 1/1024 pel
+ * per output sample: av1_setup_scale_factors_for_frame; 1024 = unscaled, 2048 = 2:1 down, 64 = 1:16 up).  Block i: bw x bh outputs written at
+ * (dst_x, dst_y) of `pred`, read from `ref` starting at the integer sample (src_x, src_y) -- pos >> SCALE_SUBPEL_BITS of
+ * calc_subpel_params, may lie in the border; the caller keeps the block's reads ((bw - 1) * x_step_qn >> 10) + 8 wide, likewise down) inside
+ * the plane's allocation as the reference's clamping does -- with sub-sample offsets subpel_x_qn / subpel_y_qn in [0, 1024).  filter_x / _y:
+ * 0 EIGHTTAP_REGULAR, 1 EIGHTTAP_SMOOTH, 2 MULTITAP_SHARP, 3 BILINEAR (a dimension <= 4 takes the 4-tap sets).  conv_params as
+ * get_conv_params_no_round.  _compound_: the two calls of a compound, as aomhip_warp_affine_compound_batch. */
+typedef struct {
+  int32_t src_x, src_y;
+  int32_t subpel_x_qn, subpel_y_qn;
+  int32_t dst_x, dst_y;
+} aomhip_scaled_block;
+int aomhip_scaled_pred_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred, int pred_frame, int bw, int bh, int filter_x,
+                             int filter_y, int x_step_qn, int y_step_qn, const aomhip_scaled_block *d_blocks, int n_blocks);
+int aomhip_scaled_pred_compound_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *pred, int pred_frame, int bw, int bh,
+                                      int filter_x, int filter_y, int x_step_qn, int y_step_qn, const aomhip_scaled_block *d_blocks, int n_blocks,
+                                      uint16_t *d_conv, int conv_stride, int do_average, int use_dist_wtd_comp_avg, int fwd_offset, int bck_offset);
+
 /* ------------------------------------------------------------------ loop-restoration search statistics */
 
 /* av1_compute_stats / av1_compute_stats_highbd (av1/encoder/pickrst.c:948-1083; av1_rtcd_defs.pl:452-458): the Wiener

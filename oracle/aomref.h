@@ -226,6 +226,9 @@ void orc_blend_a64_1d(void *dst, int dst_stride, const void *src1, int src1_stri
 int64_t orc_sse(const void *a, int a_stride, const void *b, int b_stride, int w, int h, int elem16);
 int orc_hadamard(const int16_t *src, ptrdiff_t stride, int n, int flavour, int32_t *coeff);
 void orc_txb_init_levels(const int32_t *coeff, int width, int height, uint8_t *levels);
+void orc_convolve_2d_scale(const void *src, int src_stride, void *dst, int dst_stride, int w, int h, int filter_x, int filter_y, int subpel_x_qn,
+                           int x_step_qn, int subpel_y_qn, int y_step_qn, int elem16, int bd, int is_compound, int do_average, int use_dist_wtd,
+                           int fwd_offset, int bck_offset, uint16_t *conv, int conv_stride);
 /* the self-guided restoration filter (aomref_sgr.c): dgd points at the unit's first pixel and is read 3 pixels beyond it on every side */
 void orc_selfguided_restoration(const void *dgd, int elem16, int width, int height, int stride, int32_t *flt0, int32_t *flt1, int flt_stride,
                                 int sgr_params_idx, int bit_depth);

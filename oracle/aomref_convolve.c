@@ -226,3 +226,49 @@ void orc_blend_a64_1d(void *dst, int dst_stride, const void *src1, int src1_stri
       if (elem16) ((uint16_t *)dst)[(ptrdiff_t)i * dst_stride + j] = (uint16_t)v; else ((uint8_t *)dst)[(ptrdiff_t)i * dst_stride + j] = (uint8_t)v;
     }
 }
+
+/* av1_convolve_2d_scale_c / av1_highbd_convolve_2d_scale_c (av1/common/convolve.c:560-668,1090-1200): the predictor of a SCALED reference
+ * (reference scaling / frame resizing; av1_make_inter_predictor's `is_scaled` branch).  src points at the block's integer source position
+ * (pos >> SCALE_SUBPEL_BITS), subpel_*_qn / *_step_qn in 1/1024 pel; the kernel phase of a sample is (qn & 1023) >> 6.  conv_params as
+ * get_conv_params_no_round gives them: round_0 = 3 (5 at 12 bits), round_1 = 7 for a compound, else 14 - round_0.  is_compound with
+ * do_average 0 writes conv (the block's CONV_BUF), do_average 1 blends with it into dst.  Pinned by tests/golden/ref_eval_scale.npz. */
+void orc_convolve_2d_scale(const void *src, int src_stride, void *dst, int dst_stride, int w, int h, int filter_x, int filter_y, int subpel_x_qn,
+                           int x_step_qn, int subpel_y_qn, int y_step_qn, int elem16, int bd, int is_compound, int do_average, int use_dist_wtd,
+                           int fwd_offset, int bck_offset, uint16_t *conv, int conv_stride) {
+  if (!elem16) bd = 8;
+  const int round_0 = bd == 12 ? 5 : 3, round_1 = is_compound ? 7 : 14 - round_0, bits = 14 - round_0 - round_1;
+  const int im_h = (((h - 1) * y_step_qn + subpel_y_qn) >> 10) + 8;
+  int16_t *im = (int16_t *)malloc(sizeof(int16_t) * (size_t)im_h * w);
+  for (int y = 0; y < im_h; ++y) {
+    int x_qn = subpel_x_qn;
+    for (int x = 0; x < w; ++x, x_qn += x_step_qn) {
+      const ptrdiff_t at = (ptrdiff_t)(y - 3) * src_stride + (x_qn >> 10);
+      const int16_t *f = kernel_of(filter_x, w, (x_qn & 1023) >> 6);
+      int32_t sum = 1 << (bd + 7 - 1);
+      for (int k = 0; k < 8; ++k) sum += f[k] * px(src, elem16, at + k - 3);
+      im[y * w + x] = (int16_t)RPOT(sum, round_0);
+    }
+  }
+  const int offset_bits = bd + 14 - round_0;
+  for (int x = 0; x < w; ++x) {
+    int y_qn = subpel_y_qn;
+    for (int y = 0; y < h; ++y, y_qn += y_step_qn) {
+      const int16_t *col = im + ((y_qn >> 10) + 3) * w + x;
+      const int16_t *f = kernel_of(filter_y, h, (y_qn & 1023) >> 6);
+      int32_t sum = 1 << offset_bits;
+      for (int k = 0; k < 8; ++k) sum += f[k] * col[(k - 3) * w];
+      const int res = RPOT(sum, round_1);
+      const int off = (1 << (offset_bits - round_1)) + (1 << (offset_bits - round_1 - 1));
+      if (is_compound && !do_average) {
+        conv[(ptrdiff_t)y * conv_stride + x] = (uint16_t)res;
+      } else if (is_compound) {
+        int32_t t = conv[(ptrdiff_t)y * conv_stride + x];
+        t = use_dist_wtd ? (t * fwd_offset + res * bck_offset) >> 4 : (t + res) >> 1;
+        put(dst, elem16, (ptrdiff_t)y * dst_stride + x, RPOT(t - off, bits), bd);
+      } else {
+        put(dst, elem16, (ptrdiff_t)y * dst_stride + x, RPOT(res - off, bits), bd);
+      }
+    }
+  }
+  free(im);
+}
