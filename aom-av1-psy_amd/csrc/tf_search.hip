@@ -1008,10 +1008,8 @@ extern "C" int aomhip_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_p
 // the whole batch; a block that has stopped is carried along and its later results are dropped.
 namespace aomhip {
 namespace {
-__global__ void joint_prepare_kernel(const aomhip_search_block *blocks, const int16_t *ref_mv, const int16_t *cur_mv, const int16_t *init_mv, int ite,
-                                     int n, uint8_t *live, aomhip_search_block *full_list, int16_t *other_mv) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void joint_prepare_one(int i, const aomhip_search_block *blocks, const int16_t *ref_mv, const int16_t *cur_mv, const int16_t *init_mv,
+                                                  int ite, uint8_t *live, aomhip_search_block *full_list, int16_t *other_mv) {
   const int id = ite & 1;
   const int16_t *cm = cur_mv + 4 * i, *im = init_mv + 4 * i;
   if (live[i] && ite >= 2 && cm[2 * !id] == im[2 * !id] && cm[2 * !id + 1] == im[2 * !id + 1]) {   // (:544-562)
@@ -1026,6 +1024,12 @@ __global__ void joint_prepare_kernel(const aomhip_search_block *blocks, const in
   if (!live[i]) { o.row_min = 1; o.row_max = 0; }   // the block has left the loop: an empty window, the search kernels skip it
   full_list[i] = o;
   other_mv[2 * i] = cm[2 * !id]; other_mv[2 * i + 1] = cm[2 * !id + 1];
+}
+__global__ void joint_prepare_kernel(const aomhip_search_block *blocks, const int16_t *ref_mv, const int16_t *cur_mv, const int16_t *init_mv, int ite,
+                                     int n, uint8_t *live, aomhip_search_block *full_list, int16_t *other_mv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  joint_prepare_one(i, blocks, ref_mv, cur_mv, init_mv, ite, live, full_list, other_mv);
 }
 __global__ void joint_subpel_list_kernel(const aomhip_search_block *blocks, const int16_t *ref_mv, const int16_t *full_mv, int id, int n,
                                          const uint8_t *live, aomhip_search_block *out) {
@@ -1054,11 +1058,10 @@ __global__ void joint_second_list_kernel(const aomhip_search_block *sub_list, co
   use_second[i] = use;
   out[i] = o;
 }
-__global__ void joint_update_kernel(int id, int n, int force_integer_mv, const int16_t *full_mv, const int32_t *full_sad, const int16_t *sub_mv,
-                                    const uint32_t *sub_err, const uint8_t *use_second, const int16_t *sub_mv2, const uint32_t *sub_err2, uint8_t *live,
-                                    int32_t *last_besterr, int16_t *cur_mv) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !live[i]) return;
+__device__ __forceinline__ void joint_update_one(int i, int id, int force_integer_mv, const int16_t *full_mv, const int32_t *full_sad, const int16_t *sub_mv,
+                                                 const uint32_t *sub_err, const uint8_t *use_second, const int16_t *sub_mv2, const uint32_t *sub_err2, uint8_t *live,
+                                                 int32_t *last_besterr, int16_t *cur_mv) {
+  if (!live[i]) return;
   int bestsme = full_sad[i], row = full_mv[2 * i] * 8, col = full_mv[2 * i + 1] * 8;   // convert_fullmv_to_mv (:630-632)
   if (bestsme < INT_MAX && !force_integer_mv) {
     bestsme = (int)sub_err[i]; row = sub_mv[2 * i]; col = sub_mv[2 * i + 1];
@@ -1070,6 +1073,16 @@ __global__ void joint_update_kernel(int id, int n, int force_integer_mv, const i
   } else {
     live[i] = 0;
   }
+}
+// the end of iteration `ite` and the head of the next one in ONE launch (both are per-block; the iteration's last launch is update alone)
+__global__ void joint_update_prepare_kernel(int ite, int n, int force_integer_mv, const int16_t *full_mv, const int32_t *full_sad, const int16_t *sub_mv,
+                                            const uint32_t *sub_err, const uint8_t *use_second, const int16_t *sub_mv2, const uint32_t *sub_err2, uint8_t *live,
+                                            int32_t *last_besterr, int16_t *cur_mv, const aomhip_search_block *blocks, const int16_t *ref_mv, const int16_t *init_mv,
+                                            aomhip_search_block *full_list, int16_t *other_mv, int prepare_next) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  joint_update_one(i, ite & 1, force_integer_mv, full_mv, full_sad, sub_mv, sub_err, use_second, sub_mv2, sub_err2, live, last_besterr, cur_mv);
+  if (prepare_next) joint_prepare_one(i, blocks, ref_mv, cur_mv, init_mv, ite + 1, live, full_list, other_mv);
 }
 __global__ void joint_finish_kernel(int n, const int16_t *cur_mv, const int16_t *ref_mv, const int32_t *last_besterr, const int32_t *mvjcost,
                                     const int32_t *mvcost0, const int32_t *mvcost1, int32_t *rate_mv, int32_t *best_err) {
@@ -1131,9 +1144,11 @@ static int joint_motion_search(aomhip_ctx *ctx, const aomhip_planes *src, const 
   for (int ite = 0; ite < 4; ++ite) {
     const int id = ite & 1;
     const aomhip_planes *rid = id ? ref1 : ref0, *roth = id ? ref0 : ref1;
-    hipLaunchKernelGGL(joint_prepare_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_ref_mv, d_cur_mv, i16(o_init), ite, n, live, blk(o_fl),
-                       i16(o_other));
-    AOMHIP_LAUNCH_CHECK();
+    if (ite == 0) {   // (later iterations' lists come from the previous iteration's joint_update_prepare_kernel)
+      hipLaunchKernelGGL(joint_prepare_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, d_ref_mv, d_cur_mv, i16(o_init), ite, n, live, blk(o_fl),
+                         i16(o_other));
+      AOMHIP_LAUNCH_CHECK();
+    }
     int rc = aomhip_build_inter_pred_contiguous_batch(ctx, roth, frame, w + o_pred, bw, bh, d_blocks, i16(o_other), n, AOMHIP_INTERP_REGULAR,
                                                       AOMHIP_INTERP_REGULAR);
     if (rc != AOMHIP_OK) return rc;
@@ -1160,8 +1175,9 @@ static int joint_motion_search(aomhip_ctx *ctx, const aomhip_planes *src, const 
         if (rc != AOMHIP_OK) return rc;
       }
     }
-    hipLaunchKernelGGL(joint_update_kernel, dim3(g), dim3(256), 0, ctx->stream, id, n, force_integer_mv, i16(o_fmv), i32(o_fsad), i16(o_smv), u32(o_serr),
-                       second ? reinterpret_cast<const uint8_t *>(w + o_use2) : nullptr, i16(o_smv2), u32(o_serr2), live, i32(o_last), d_cur_mv);
+    hipLaunchKernelGGL(joint_update_prepare_kernel, dim3(g), dim3(256), 0, ctx->stream, ite, n, force_integer_mv, i16(o_fmv), i32(o_fsad), i16(o_smv), u32(o_serr),
+                       second ? reinterpret_cast<const uint8_t *>(w + o_use2) : nullptr, i16(o_smv2), u32(o_serr2), live, i32(o_last), d_cur_mv, d_blocks, d_ref_mv,
+                       i16(o_init), blk(o_fl), i16(o_other), ite < 3 ? 1 : 0);
     AOMHIP_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(joint_finish_kernel, dim3(g), dim3(256), 0, ctx->stream, n, d_cur_mv, d_ref_mv, i32(o_last), d_mvjcost, d_mvcost_row, d_mvcost_col,

@@ -1412,7 +1412,8 @@ def run_workload(pkg, ctx, dist, dev, rank, world, name, steps, warmup, want_cpu
         # 1.05-1.09 x the compulsory bytes and the transport alone runs at 0.70 of the peak, but no unit is saturated (VALU 47 %, LDS
         # 50 % busy) -- the launch time is the evaluating wavefronts' serial instruction chain, one iteration per step at two
         # wavefronts per SIMD.  `frac` stays what the north star asks for: compulsory HBM bytes / time / HBM peak.
-        "roofline": {"bound": "issue/latency" if wl.path == "sb" else "L1 fill path (TA)", "frac_is": "compulsory HBM bytes / launch time / 8 TB/s",
+        # (`bound` names the ROOFLINE the fraction is priced against -- the contract's "hbm" | "mfma" --; `limited_by` what actually limits the kernel)
+        "roofline": {"bound": "hbm", "limited_by": "issue/latency" if wl.path == "sb" else "L1 fill path (TA)", "frac_is": "compulsory HBM bytes / launch time / 8 TB/s",
                      "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_launch_ms": k_ms, "compulsory_bytes_per_launch": compulsory,
@@ -1456,7 +1457,7 @@ def _sig(x, n=5):
     return x
 
 
-ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "compulsory_bytes_per_launch",
+ROOFLINE_KEYS = ("bound", "limited_by", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "compulsory_bytes_per_launch",
                  "algorithmic_bytes_per_launch", "ceiling_GBs", "frac_of_ceiling", "traffic_over_compulsory", "traffic_measured_on")
 LINE_LIMIT = 6000  # bytes of the final stdout line; the driver's record keeps an 8 KB tail (round 4's 31 KB line was not parsed)
 

@@ -60,7 +60,7 @@ def test_default_single_gpu_line_is_small_enough_for_the_driver_record(tmp_path)
     assert d["config"]["workload"] == "sad16x16_modeA_1080p_8bit"
     r = d["roofline"]
     assert all(not isinstance(v, (dict, list)) for v in r.values()), "roofline: flat scalars only"
-    assert 0 < r["frac"] < 1 and r["peak"] == 8000.0 and r["bound"] and r["achieved"] > 0 and "traffic" in r
+    assert 0 < r["frac"] < 1 and r["peak"] == 8000.0 and r["bound"] in ("hbm", "mfma") and r["achieved"] > 0 and "traffic" in r
     assert 0 < r["frac_4k_8bit"] < 1 and 0 < r["frac_4k_10bit"] < 1 and r["avg_launch_ms_4k_8bit"] > 0
     c = d["cpu_baseline"]
     assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] in ("port", "reference") and c["sample"]
