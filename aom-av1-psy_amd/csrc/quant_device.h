@@ -136,6 +136,26 @@ __device__ __forceinline__ void quantize_one_qm(int32_t v, int zb, int rd, int q
   *dqout = (adq ^ sign) - sign;
 }
 
+// The `fp` quantiser with matrices (quantize_fp_helper_c / highbd_quantize_fp_helper_c, av1/encoder/av1_quantize.c:92-121,141-169): dead zone
+// a * wt >= dequant << (AOM_QM_BITS - (1 + log_scale)), level (a + round) * wt * quant >> (16 - log_scale + AOM_QM_BITS) with the
+// low-bit-depth form's int16 clamp of a + round.  rd arrives log-scaled; quant / rd are the caller's quant_fp / round_fp.
+template <bool HBD, int LS>
+__device__ __forceinline__ void quantize_one_qm_fp(int32_t v, int rd, int quant, int dequant, int wt, int iwt, int32_t *qout, int32_t *dqout) {
+  constexpr int QM = 5;   // AOM_QM_BITS
+  const int sign = v >> 31;
+  int64_t a = (int64_t)((v ^ sign) - sign);
+  int q = 0;
+  if (a * wt >= (dequant << (QM - (1 + LS)))) {
+    a += rd;
+    if (!HBD && a > 32767) a = 32767;   // clamp64(.., INT16_MIN, INT16_MAX); a >= 0
+    q = (int)((a * wt * quant) >> (16 - LS + QM));
+  }
+  const int dqv = (dequant * iwt + (1 << (QM - 1))) >> QM;
+  const int adq = (int)((uint32_t)q * (uint32_t)dqv) >> LS;
+  *qout = (q ^ sign) - sign;
+  *dqout = (adq ^ sign) - sign;
+}
+
 // av1_scan_orders (scan.c:1666-): class 0 = zig-zag (all 2-D types), 1 = "mrow" (V_* types),
 // 2 = "mcol" (H_* types).  Position of coefficient (r, c) in a KW x KH scan.
 template <int KW, int KH> __device__ __forceinline__ int iscan_pos(int r, int c, int scan_class) {

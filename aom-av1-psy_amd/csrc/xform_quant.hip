@@ -676,7 +676,8 @@ __global__ __launch_bounds__(256) void quant_adaptive_kernel(const int32_t *__re
 // Quantisation with matrices (qm_ptr / iqm_ptr non-NULL: aom_[highbd_]quantize_b_helper_c, aom_dsp/quantize.c:108-169,261-316) on already
 // materialised transform coefficients, like the adaptive form above: one wavefront per block, lane l owns coefficients l, l + 64, ... of the
 // (transposed) coefficient array, the matrices are indexed by the same position.  eob = 1 + the last scan position with a non-zero level.
-template <int KW, int KH, bool HBD, int LS>
+// FP: the `fp` flavour (quantize_one_qm_fp; qa.round / qa.quant carry round_fp / quant_fp, zbin and quant_shift are not read).
+template <int KW, int KH, bool HBD, int LS, bool FP = false>
 __global__ __launch_bounds__(256) void quant_qm_kernel(const int32_t *__restrict__ coeff, const aomhip_txb *__restrict__ blocks, int n_blocks,
                                                        int uniform_type, QuantArgs qa, const uint8_t *__restrict__ qm,
                                                        const uint8_t *__restrict__ iqm, int32_t *__restrict__ qcoeff,
@@ -694,8 +695,11 @@ __global__ __launch_bounds__(256) void quant_qm_kernel(const int32_t *__restrict
   for (int rc = lane; rc < NC; rc += 64) {
     const int ac = rc != 0;
     int32_t qv, dv;
-    quantize_one_qm<HBD, LS>(coeff[off + rc], zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.dequant[ac], qm ? (int)qm[rc] : 32,
-                             iqm ? (int)iqm[rc] : 32, &qv, &dv);
+    if constexpr (FP)
+      quantize_one_qm_fp<HBD, LS>(coeff[off + rc], rd[ac], qa.quant[ac], qa.dequant[ac], qm ? (int)qm[rc] : 32, iqm ? (int)iqm[rc] : 32, &qv, &dv);
+    else
+      quantize_one_qm<HBD, LS>(coeff[off + rc], zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.dequant[ac], qm ? (int)qm[rc] : 32,
+                               iqm ? (int)iqm[rc] : 32, &qv, &dv);
     qcoeff[off + rc] = qv;
     dqcoeff[off + rc] = dv;
     if (qv) last = max(last, iscan_pos<KW, KH>(rc % KH, rc / KH, scan_class) + 1);   // transposed layout: rc = c * KH + r
@@ -1009,12 +1013,12 @@ int aomhip_quantize_b_adaptive_batch(aomhip_ctx *ctx, const int32_t *d_coeff, in
 }
 
 
-int aomhip_quantize_b_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
-                               int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd, const uint8_t *d_qm, const uint8_t *d_iqm,
-                               int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
+static int quantize_qm_launch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
+                              const aomhip_quant_params *qparams, int is_hbd, const uint8_t *d_qm, const uint8_t *d_iqm, int32_t *d_qcoeff,
+                              int32_t *d_dqcoeff, uint16_t *d_eob, bool fp) {
   if (!ctx || !d_coeff || !qparams || !d_qcoeff || !d_dqcoeff || !d_eob || tx_size < 0 || tx_size >= 19 || n_blocks < 0 ||
       (!d_blocks && (uniform_tx_type < 0 || uniform_tx_type > 15))) {
-    set_error("aomhip_quantize_b_qm_batch: invalid argument");
+    set_error("aomhip_quantize_%s_qm_batch: invalid argument", fp ? "fp" : "b");
     return AOMHIP_ERR_INVALID;
   }
   if (n_blocks == 0) return AOMHIP_OK;
@@ -1024,14 +1028,13 @@ int aomhip_quantize_b_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_s
   const int kw = w > 32 ? 32 : w, kh = h > 32 ? 32 : h;
   const int ls = (w * h > 256) + (w * h > 1024);  // av1_get_tx_scale (av1/common/idct.c:24-28)
   const dim3 grid((n_blocks + 3) / 4), block(256);
+#define AOMHIP_QM_K(KW_, KH_, HBD_, LS_, FP_)                                                                                      \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(quant_qm_kernel<KW_, KH_, HBD_, LS_, FP_>), grid, block, 0, ctx->stream, d_coeff, d_blocks, n_blocks, \
+                     uniform_tx_type, qa, d_qm, d_iqm, d_qcoeff, d_dqcoeff, d_eob)
 #define AOMHIP_QM(KW_, KH_, LS_)                                                                                                   \
   if (kw == KW_ && kh == KH_ && ls == LS_) {                                                                                       \
-    if (is_hbd)                                                                                                                    \
-      hipLaunchKernelGGL((quant_qm_kernel<KW_, KH_, true, LS_>), grid, block, 0, ctx->stream, d_coeff, d_blocks, n_blocks,          \
-                         uniform_tx_type, qa, d_qm, d_iqm, d_qcoeff, d_dqcoeff, d_eob);                                            \
-    else                                                                                                                           \
-      hipLaunchKernelGGL((quant_qm_kernel<KW_, KH_, false, LS_>), grid, block, 0, ctx->stream, d_coeff, d_blocks, n_blocks,         \
-                         uniform_tx_type, qa, d_qm, d_iqm, d_qcoeff, d_dqcoeff, d_eob);                                            \
+    if (is_hbd) { if (fp) AOMHIP_QM_K(KW_, KH_, true, LS_, true); else AOMHIP_QM_K(KW_, KH_, true, LS_, false); }                  \
+    else { if (fp) AOMHIP_QM_K(KW_, KH_, false, LS_, true); else AOMHIP_QM_K(KW_, KH_, false, LS_, false); }                       \
     AOMHIP_LAUNCH_CHECK();                                                                                                         \
     return AOMHIP_OK;                                                                                                              \
   }
@@ -1039,8 +1042,22 @@ int aomhip_quantize_b_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_s
   AOMHIP_QM(4, 8, 0) AOMHIP_QM(8, 4, 0) AOMHIP_QM(8, 16, 0) AOMHIP_QM(16, 8, 0) AOMHIP_QM(16, 32, 1) AOMHIP_QM(32, 16, 1)
   AOMHIP_QM(4, 16, 0) AOMHIP_QM(16, 4, 0) AOMHIP_QM(8, 32, 0) AOMHIP_QM(32, 8, 0)
 #undef AOMHIP_QM
-  set_error("aomhip_quantize_b_qm_batch: no kernel for tx_size %d", tx_size);
+#undef AOMHIP_QM_K
+  set_error("aomhip_quantize_%s_qm_batch: no kernel for tx_size %d", fp ? "fp" : "b", tx_size);
   return AOMHIP_ERR_INVALID;
+}
+
+int aomhip_quantize_b_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
+                               int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd, const uint8_t *d_qm, const uint8_t *d_iqm,
+                               int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
+  return quantize_qm_launch(ctx, d_coeff, tx_size, d_blocks, n_blocks, uniform_tx_type, qparams, is_hbd, d_qm, d_iqm, d_qcoeff, d_dqcoeff, d_eob, false);
+}
+
+// av1_[highbd_]quantize_fp* with matrices (AV1_XFORM_QUANT_FP when enable_qm is on): qparams carries round_fp / quant_fp in its round / quant fields
+int aomhip_quantize_fp_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
+                                int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd, const uint8_t *d_qm, const uint8_t *d_iqm,
+                                int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
+  return quantize_qm_launch(ctx, d_coeff, tx_size, d_blocks, n_blocks, uniform_tx_type, qparams, is_hbd, d_qm, d_iqm, d_qcoeff, d_dqcoeff, d_eob, true);
 }
 
 // av1_xform_quant with quantisation matrices: the forward transform by the fused kernel (its own flat-matrix levels are overwritten), then

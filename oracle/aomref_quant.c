@@ -330,3 +330,34 @@ void orc_quantize_fp(const int32_t *coeff, intptr_t n, const int16_t *round_fp, 
   }
   *eob_out = (uint16_t)eob;
 }
+
+/* quantize_fp_helper_c / highbd_quantize_fp_helper_c WITH matrices (av1/encoder/av1_quantize.c:92-121,141-169: qm_ptr / iqm_ptr non-NULL): the
+ * dead zone is dequant scaled by the weight -- a * wt >= dequant << (AOM_QM_BITS - (1 + log_scale)) --, the level (a + round) * wt * quant
+ * >> (16 - log_scale + AOM_QM_BITS), the low-bit-depth form clamps a + round to int16 first; dqcoeff through the weighted dequantiser.
+ * Pinned by tests/golden/ref_eval_qm_fp.npz. */
+void orc_quantize_fp_qm(const int32_t *coeff, intptr_t n, const int16_t *round_fp, const int16_t *quant_fp, int32_t *qcoeff, int32_t *dqcoeff,
+                        const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale, int highbd, const uint8_t *qm,
+                        const uint8_t *iqm) {
+  const int rounding[2] = { (round_fp[0] + ((1 << log_scale) >> 1)) >> log_scale, (round_fp[1] + ((1 << log_scale) >> 1)) >> log_scale };
+  int eob = -1;
+  memset(qcoeff, 0, (size_t)n * sizeof(*qcoeff));
+  memset(dqcoeff, 0, (size_t)n * sizeof(*dqcoeff));
+  for (intptr_t i = 0; i < n; ++i) {
+    const int rc = scan[i], ac = rc != 0;
+    const int wt = qm ? qm[rc] : 32, iwt = iqm ? iqm[rc] : 32;
+    const int dq = (dequant[ac] * iwt + 16) >> 5;
+    const int c = coeff[rc], sign = c < 0 ? -1 : 0;
+    int64_t a = (int64_t)((c ^ sign) - sign);
+    int q = 0;
+    if (a * wt >= (dequant[ac] << (5 - (1 + log_scale)))) {
+      a += rounding[ac];
+      if (!highbd && a > INT16_MAX) a = INT16_MAX;
+      q = (int)((a * wt * quant_fp[ac]) >> (16 - log_scale + 5));
+      qcoeff[rc] = (q ^ sign) - sign;
+      const int32_t adq = (int32_t)((uint32_t)q * (uint32_t)dq) >> log_scale;
+      dqcoeff[rc] = (adq ^ sign) - sign;
+    }
+    if (q) eob = (int)i;
+  }
+  *eob_out = (uint16_t)(eob + 1);
+}
