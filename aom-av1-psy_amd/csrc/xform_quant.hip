@@ -593,11 +593,14 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
 //   if first == eob and that level is +-1 and the coefficient lies inside the zone widened by
 //                    dequant * (325 + SKIP_EOB_FACTOR_ADJUST(200)) / 128: drop it, eob = 0   (:84-102)
 // One wavefront per block; lane l owns coefficients l, l + 64, ... of the (transposed) coefficient array.
-template <int KW, int KH, bool HBD, int LS>
+// QMX: with quantisation matrices (qm / iqm per coefficient position, either may be NULL = flat): the helper's matrix branches -- the weight
+// enters the pre-scan's test, the dead zone, the level and the single-coefficient rule, the inverse weight the dequantiser.
+template <int KW, int KH, bool HBD, int LS, bool QMX = false>
 __global__ __launch_bounds__(256) void quant_adaptive_kernel(const int32_t *__restrict__ coeff,
                                                              const aomhip_txb *__restrict__ blocks, int n_blocks,
                                                              int uniform_type, QuantArgs qa, int32_t *__restrict__ qcoeff,
-                                                             int32_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob) {
+                                                             int32_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob,
+                                                             const uint8_t *__restrict__ qm = nullptr, const uint8_t *__restrict__ iqm = nullptr) {
   constexpr int NC = KW * KH;
   constexpr int PER = (NC + 63) / 64;
   const int lane = threadIdx.x & 63;
@@ -612,18 +615,21 @@ __global__ __launch_bounds__(256) void quant_adaptive_kernel(const int32_t *__re
   const int add2[2] = { (qa.dequant[0] * 525 + 64) >> 7, (qa.dequant[1] * 525 + 64) >> 7 };
   int32_t v[PER];
   int pos[PER];
+  [[maybe_unused]] int wt[PER];
   int nzc = 0;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int rc = lane + 64 * k;
     v[k] = 0;
     pos[k] = -1;
+    if constexpr (QMX) wt[k] = 32;
     if (rc < NC) {
       v[k] = coeff[off + rc];
       const int c = rc / KH, r = rc % KH;  // transposed layout: rc = c * KH + r
       pos[k] = iscan_pos<KW, KH>(r, c, scan_class);
       const int ac = rc != 0;
-      const int64_t cw = (int64_t)v[k] * 32;  // coeff * wt (the reference forms it in int; |coeff| < 2^26 here)
+      if constexpr (QMX) wt[k] = qm ? (int)qm[rc] : 32;
+      const int64_t cw = (int64_t)v[k] * (QMX ? wt[k] : 32);  // coeff * wt (the reference forms it in int; |coeff| < 2^26 here)
       const bool inside = cw < (int64_t)zb[ac] * 32 + add1[ac] && cw > -(int64_t)zb[ac] * 32 - add1[ac];
       if (!inside) nzc = max(nzc, pos[k] + 1);
     }
@@ -636,8 +642,11 @@ __global__ __launch_bounds__(256) void quant_adaptive_kernel(const int32_t *__re
     qv[k] = dv[k] = 0;
     if (pos[k] >= 0 && pos[k] < nzc) {
       const int ac = (lane + 64 * k) != 0;
-      quantize_one<HBD, LS>(v[k], zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.qs_log2[ac], qa.dequant[ac], &qv[k],
-                            &dv[k]);
+      if constexpr (QMX)
+        quantize_one_qm<HBD, LS>(v[k], zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.dequant[ac], wt[k], iqm ? (int)iqm[lane + 64 * k] : 32, &qv[k], &dv[k]);
+      else
+        quantize_one<HBD, LS>(v[k], zb[ac], rd[ac], qa.quant[ac], qa.quant_shift[ac], qa.qs_log2[ac], qa.dequant[ac], &qv[k],
+                              &dv[k]);
       if (qv[k]) {
         last = max(last, pos[k] + 1);
         first = min(first, pos[k]);
@@ -651,7 +660,7 @@ __global__ __launch_bounds__(256) void quant_adaptive_kernel(const int32_t *__re
     for (int k = 0; k < PER; ++k) {
       if (pos[k] == first && (qv[k] == 1 || qv[k] == -1)) {
         const int ac = (lane + 64 * k) != 0;
-        const int64_t cw = (int64_t)v[k] * 32;
+        const int64_t cw = (int64_t)v[k] * (QMX ? wt[k] : 32);
         if (cw < (int64_t)zb[ac] * 32 + add2[ac] && cw > -(int64_t)zb[ac] * 32 - add2[ac]) qv[k] = dv[k] = 0;
       }
     }
@@ -978,12 +987,12 @@ int aomhip_subtract_xform_quant_batch(aomhip_ctx *ctx, const aomhip_planes *src,
                                               qparams, 0, d_coeff, d_qcoeff, d_dqcoeff, d_eob, nullptr);
 }
 
-int aomhip_quantize_b_adaptive_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks,
-                                     int n_blocks, int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd,
-                                     int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
+static int quantize_adaptive_launch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
+                                    const aomhip_quant_params *qparams, int is_hbd, int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob, bool with_qm,
+                                    const uint8_t *d_qm, const uint8_t *d_iqm, const char *who) {
   if (!ctx || !d_coeff || !qparams || !d_qcoeff || !d_dqcoeff || !d_eob || tx_size < 0 || tx_size >= 19 || n_blocks < 0 ||
       (!d_blocks && (uniform_tx_type < 0 || uniform_tx_type > 15))) {
-    set_error("aomhip_quantize_b_adaptive_batch: invalid argument");
+    set_error("%s: invalid argument", who);
     return AOMHIP_ERR_INVALID;
   }
   if (n_blocks == 0) return AOMHIP_OK;
@@ -993,23 +1002,38 @@ int aomhip_quantize_b_adaptive_batch(aomhip_ctx *ctx, const int32_t *d_coeff, in
   const int kw = w > 32 ? 32 : w, kh = h > 32 ? 32 : h;
   const int ls = (w * h > 256) + (w * h > 1024);  // av1_get_tx_scale (av1/common/idct.c:24-28)
   const dim3 grid((n_blocks + 3) / 4), block(256);
-#define AOMHIP_QA(KW_, KH_, LS_)                                                                                       \
-  if (kw == KW_ && kh == KH_ && ls == LS_) {                                                                           \
-    if (is_hbd)                                                                                                        \
-      hipLaunchKernelGGL((quant_adaptive_kernel<KW_, KH_, true, LS_>), grid, block, 0, ctx->stream, d_coeff, d_blocks,  \
-                         n_blocks, uniform_tx_type, qa, d_qcoeff, d_dqcoeff, d_eob);                                   \
-    else                                                                                                               \
-      hipLaunchKernelGGL((quant_adaptive_kernel<KW_, KH_, false, LS_>), grid, block, 0, ctx->stream, d_coeff, d_blocks, \
-                         n_blocks, uniform_tx_type, qa, d_qcoeff, d_dqcoeff, d_eob);                                   \
-    AOMHIP_LAUNCH_CHECK();                                                                                             \
-    return AOMHIP_OK;                                                                                                  \
+#define AOMHIP_QA_K(KW_, KH_, HBD_, LS_, QMX_)                                                                                            \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(quant_adaptive_kernel<KW_, KH_, HBD_, LS_, QMX_>), grid, block, 0, ctx->stream, d_coeff, d_blocks,   \
+                     n_blocks, uniform_tx_type, qa, d_qcoeff, d_dqcoeff, d_eob, d_qm, d_iqm)
+#define AOMHIP_QA(KW_, KH_, LS_)                                                                                                          \
+  if (kw == KW_ && kh == KH_ && ls == LS_) {                                                                                              \
+    if (is_hbd) { if (with_qm) AOMHIP_QA_K(KW_, KH_, true, LS_, true); else AOMHIP_QA_K(KW_, KH_, true, LS_, false); }                    \
+    else { if (with_qm) AOMHIP_QA_K(KW_, KH_, false, LS_, true); else AOMHIP_QA_K(KW_, KH_, false, LS_, false); }                         \
+    AOMHIP_LAUNCH_CHECK();                                                                                                                \
+    return AOMHIP_OK;                                                                                                                     \
   }
   AOMHIP_QA(4, 4, 0) AOMHIP_QA(8, 8, 0) AOMHIP_QA(16, 16, 0) AOMHIP_QA(32, 32, 1) AOMHIP_QA(32, 32, 2)
   AOMHIP_QA(4, 8, 0) AOMHIP_QA(8, 4, 0) AOMHIP_QA(8, 16, 0) AOMHIP_QA(16, 8, 0) AOMHIP_QA(16, 32, 1) AOMHIP_QA(32, 16, 1)
   AOMHIP_QA(4, 16, 0) AOMHIP_QA(16, 4, 0) AOMHIP_QA(8, 32, 0) AOMHIP_QA(32, 8, 0)
 #undef AOMHIP_QA
-  set_error("aomhip_quantize_b_adaptive_batch: no kernel for tx_size %d", tx_size);
+#undef AOMHIP_QA_K
+  set_error("%s: no kernel for tx_size %d", who, tx_size);
   return AOMHIP_ERR_INVALID;
+}
+
+int aomhip_quantize_b_adaptive_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks,
+                                     int n_blocks, int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd,
+                                     int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
+  return quantize_adaptive_launch(ctx, d_coeff, tx_size, d_blocks, n_blocks, uniform_tx_type, qparams, is_hbd, d_qcoeff, d_dqcoeff, d_eob, false, nullptr,
+                                  nullptr, "aomhip_quantize_b_adaptive_batch");
+}
+
+// aom_[highbd_]quantize_b_adaptive_helper_c with qm_ptr / iqm_ptr (use_quant_b_adapt under enable_qm); either matrix may be NULL (flat)
+int aomhip_quantize_b_adaptive_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
+                                        int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd, const uint8_t *d_qm, const uint8_t *d_iqm,
+                                        int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
+  return quantize_adaptive_launch(ctx, d_coeff, tx_size, d_blocks, n_blocks, uniform_tx_type, qparams, is_hbd, d_qcoeff, d_dqcoeff, d_eob, true, d_qm, d_iqm,
+                                  "aomhip_quantize_b_adaptive_qm_batch");
 }
 
 

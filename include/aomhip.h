@@ -393,10 +393,13 @@ int aomhip_subtract_xform_quant_ex_batch(aomhip_ctx *ctx, const aomhip_planes *s
  *   aomhip_quantize_fp_qm_batch           the `fp` flavour with matrices (quantize_fp_helper_c / highbd_quantize_fp_helper_c, av1_quantize.c:71-199;
  *                                         AV1_XFORM_QUANT_FP with enable_qm): as aomhip_quantize_b_qm_batch, qparams carrying round_fp / quant_fp in
  *                                         its round / quant fields (zbin and quant_shift are not read)
- * The adaptive quantiser with matrices (aom_quantize_b_adaptive_helper_c's qm branch) is not covered. */
+ *   aomhip_quantize_b_adaptive_qm_batch   the adaptive quantiser (below) with matrices: aom_[highbd_]quantize_b_adaptive_helper_c's qm branches */
 int aomhip_quantize_b_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
                                int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd, const uint8_t *d_qm, const uint8_t *d_iqm,
                                int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);
+int aomhip_quantize_b_adaptive_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
+                                        int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd, const uint8_t *d_qm, const uint8_t *d_iqm,
+                                        int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);
 int aomhip_quantize_fp_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
                                 int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd, const uint8_t *d_qm, const uint8_t *d_iqm,
                                 int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);

@@ -150,6 +150,9 @@ void orc_highbd_quantize_b(const int32_t *coeff, intptr_t n, const int16_t *zbin
                            int32_t *dqcoeff, const int16_t *dequant, uint16_t *eob, const int16_t *scan,
                            const int16_t *iscan, int log_scale);
 /* quantize.c:16-105,173-258 adaptive variants (use_quant_b_adapt, av1_quantize.c:309-341,453-) */
+void orc_quantize_b_adaptive_qm(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round, const int16_t *quant,
+                                const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff, const int16_t *dequant, uint16_t *eob_out,
+                                const int16_t *scan, int log_scale, int highbd, const uint8_t *qm, const uint8_t *iqm);
 void orc_quantize_b_adaptive(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
                              const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
                              const int16_t *dequant, uint16_t *eob, const int16_t *scan, int log_scale, int highbd);

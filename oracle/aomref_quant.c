@@ -214,12 +214,14 @@ int orc_get_scan(int tx_size, int tx_type, int16_t *scan, int16_t *iscan) {
  * qm_ptr == iqm_ptr == NULL; EOB_FACTOR 325, SKIP_EOB_FACTOR_ADJUST 200 (aom_dsp/quantize.h:23-24).  Literal:
  * backward pre-scan over a dead zone widened by dequant * 325 / 128, forward quantisation of what is left, and the
  * "single +-1 coefficient" kill with the zone widened by dequant * 525 / 128.  Pinned like quantize_b (file header). */
-void orc_quantize_b_adaptive(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
-                             const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
-                             const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale, int highbd) {
+/* (with qm / iqm non-NULL: the same functions' matrix branches -- every `wt` / `iwt` below per coefficient; pinned by ref_eval_qm_adaptive.npz) */
+void orc_quantize_b_adaptive_qm(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
+                                const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
+                                const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale, int highbd, const uint8_t *qm,
+                                const uint8_t *iqm) {
   const int zb[2] = { rpot(zbin[0], log_scale), rpot(zbin[1], log_scale) };
   const int nzb[2] = { -zb[0], -zb[1] };
-  const int wt = 1 << QM_BITS;
+#define wt (qm ? (int)qm[rc] : (1 << QM_BITS))
   int non_zero_count = (int)n, eob = -1, first = -1;
   memset(qcoeff, 0, (size_t)n * sizeof(*qcoeff));
   memset(dqcoeff, 0, (size_t)n * sizeof(*dqcoeff));
@@ -253,8 +255,8 @@ void orc_quantize_b_adaptive(const int32_t *coeff, intptr_t n, const int16_t *zb
       q = (int)((t2 * quant_shift[ac]) >> (16 - log_scale + QM_BITS));
     }
     qcoeff[rc] = (q ^ sign) - sign;
-    const int dq = (dequant[ac] * wt + (1 << (QM_BITS - 1))) >> QM_BITS;
-    const int adq = (q * dq) >> log_scale;
+    const int dq = (dequant[ac] * (iqm ? (int)iqm[rc] : (1 << QM_BITS)) + (1 << (QM_BITS - 1))) >> QM_BITS;
+    const int adq = (int)((uint32_t)q * (uint32_t)dq) >> log_scale;
     dqcoeff[rc] = (adq ^ sign) - sign;
     if (q) {
       eob = i;
@@ -274,6 +276,12 @@ void orc_quantize_b_adaptive(const int32_t *coeff, intptr_t n, const int16_t *zb
     }
   }
   *eob_out = (uint16_t)(eob + 1);
+}
+#undef wt
+void orc_quantize_b_adaptive(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round,
+                             const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff, int32_t *dqcoeff,
+                             const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale, int highbd) {
+  orc_quantize_b_adaptive_qm(coeff, n, zbin, round, quant, quant_shift, qcoeff, dqcoeff, dequant, eob_out, scan, log_scale, highbd, NULL, NULL);
 }
 
 /* av1_block_error_c / av1_highbd_block_error_c (av1/encoder/rdopt.c:635-682): transform-domain distortion and the energy
