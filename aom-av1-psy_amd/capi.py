@@ -229,6 +229,8 @@ _protos = {
     "aomhip_warp_affine_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i]),
     "aomhip_warp_affine_compound_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i]),
     "aomhip_selfguided_restoration_batch": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _i64]),
+    "aomhip_apply_selfguided_restoration_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i64]),
+    "aomhip_wiener_convolve_add_src_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i]),
     "aomhip_calc_proj_params_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     "aomhip_pixel_proj_error_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _i, _vp]),
     "aomhip_wedge_sse_from_residuals_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -726,6 +728,17 @@ class Context:
         hu = None if h_units is None else np.ascontiguousarray(h_units).ctypes.data
         check(lib.aomhip_selfguided_restoration_batch(self.h, C.byref(dgd), dgd_frame, d_units, hu, n_units, d_idx, max_w, max_h, d_flt0, d_flt1, flt_stride, flt_pitch),
               "aomhip_selfguided_restoration_batch")
+
+    def apply_selfguided_restoration_batch(self, dat, dat_frame, dst, dst_frame, d_units, h_units, n_units, d_idx, d_xqd, max_w, max_h, d_flt0, d_flt1, flt_stride,
+                                           flt_pitch):
+        hu = None if h_units is None else np.ascontiguousarray(h_units).ctypes.data
+        check(lib.aomhip_apply_selfguided_restoration_batch(self.h, C.byref(dat), dat_frame, C.byref(dst), dst_frame, d_units, hu, n_units, d_idx, d_xqd, max_w, max_h,
+                                                            d_flt0, d_flt1, flt_stride, flt_pitch), "aomhip_apply_selfguided_restoration_batch")
+
+    def wiener_convolve_add_src_batch(self, dat, dat_frame, dst, dst_frame, d_units, h_units, n_units, d_filters, max_w, max_h):
+        hu = None if h_units is None else np.ascontiguousarray(h_units).ctypes.data
+        check(lib.aomhip_wiener_convolve_add_src_batch(self.h, C.byref(dat), dat_frame, C.byref(dst), dst_frame, d_units, hu, n_units, d_filters, max_w, max_h),
+              "aomhip_wiener_convolve_add_src_batch")
 
     def calc_proj_params_batch(self, src, src_frame, dat, dat_frame, d_units, n_units, d_flt0, d_flt1, flt_stride, flt_pitch, d_radii, d_H, d_C):
         """av1_calc_proj_params[_high_bd] per restoration unit: H (4 int64) and C (2 int64) each."""

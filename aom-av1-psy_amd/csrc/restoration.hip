@@ -255,6 +255,83 @@ __global__ __launch_bounds__(256) void selfguided_kernel(const T *__restrict__ d
   }
 }
 
+// av1_apply_selfguided_restoration (restoration.c:917-956) after selfguided_kernel: per pixel u = dat << 4, v = (u << 7) + xq0 (flt0 - u) + xq1 (flt1 - u)
+// over the radii in use, (xq0, xq1) = av1_decode_xq(xqd) (:631-643), w = (int16_t)ROUND_POWER_OF_TWO(v, 11), clipped.  One lane per pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void selfguided_apply_kernel(const T *__restrict__ dat, int dat_stride, T *__restrict__ dst, int dst_stride,
+                                                                const aomhip_rect *__restrict__ units, const int32_t *__restrict__ sgr_idx,
+                                                                const int32_t *__restrict__ xqd, int bit_depth, const int32_t *__restrict__ flt0,
+                                                                const int32_t *__restrict__ flt1, int flt_stride, int64_t flt_pitch) {
+  const int ui = blockIdx.x;
+  const aomhip_rect u = units[ui];
+  const int w = u.h_end - u.h_start, h = u.v_end - u.v_start;
+  const int idx = sgr_idx[ui];
+  const int r0 = kSgrParams[idx][0], r1 = kSgrParams[idx][1];
+  int xq0, xq1;
+  if (r0 == 0) { xq0 = 0; xq1 = 128 - xqd[2 * ui + 1]; }
+  else if (r1 == 0) { xq0 = xqd[2 * ui]; xq1 = 0; }
+  else { xq0 = xqd[2 * ui]; xq1 = 128 - xq0 - xqd[2 * ui + 1]; }
+  const int32_t *f0 = flt0 + (int64_t)ui * flt_pitch, *f1 = flt1 + (int64_t)ui * flt_pitch;
+  const int mx = (1 << bit_depth) - 1;
+  for (int t = blockIdx.y * 256 + threadIdx.x; t < w * h; t += gridDim.y * 256) {
+    const int i = t / w, j = t - i * w;
+    const int uu = (int)dat[(int64_t)(u.v_start + i) * dat_stride + u.h_start + j] << 4;
+    int v = uu << 7;
+    if (r0 > 0) v += xq0 * (f0[(int64_t)i * flt_stride + j] - uu);
+    if (r1 > 0) v += xq1 * (f1[(int64_t)i * flt_stride + j] - uu);
+    const int wv = (int)(int16_t)((v + (1 << 10)) >> 11);
+    dst[(int64_t)(u.v_start + i) * dst_stride + u.h_start + j] = (T)min(max(wv, 0), mx);
+  }
+}
+
+// av1_[highbd_]wiener_convolve_add_src (av1/common/convolve.c:1093-1257) as wiener_filter_stripe calls it (steps of 16): the unit's two 7-tap
+// filters (8 stored taps, centre reduced by 128: the passes add the source back).  One workgroup per 32 x 32 tile: footprint rows -3 .. +4 and
+// columns -3 .. +4 staged in LDS, horizontal pass (+ src << 7 + offset, rounded by round_0, clamped to WIENER_CLAMP_LIMIT) into 40 x 32 uint16,
+// vertical pass (offset removed, rounded by round_1, clipped).  round_0 / round_1 = get_conv_params_wiener(bd): 3 / 11, at 12 bits 5 / 9.
+constexpr int kWienerTile = 32, kWienerFoot = kWienerTile + 8;
+template <typename T>
+__global__ __launch_bounds__(256) void wiener_kernel(const T *__restrict__ dat, int dat_stride, T *__restrict__ dst, int dst_stride,
+                                                      const aomhip_rect *__restrict__ units, const int16_t *__restrict__ filters, int bd, int tiles_x) {
+  __shared__ uint16_t s_src[kWienerFoot * kWienerFoot];
+  __shared__ uint16_t s_tmp[kWienerFoot * kWienerTile];
+  const int ui = blockIdx.x;
+  const aomhip_rect u = units[ui];
+  const int w = u.h_end - u.h_start, h = u.v_end - u.v_start;
+  const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
+  const int ox = tx * kWienerTile, oy = ty * kWienerTile;
+  if (ox >= w || oy >= h) return;
+  int fx[8], fy[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { fx[k] = filters[16 * ui + k]; fy[k] = filters[16 * ui + 8 + k]; }
+  for (int t = threadIdx.x; t < kWienerFoot * kWienerFoot; t += 256) {   // unit coordinates ox - 3 .. ox + 36, clamped to the unit's 3 (4) pixel surround
+    const int sy = t / kWienerFoot, sx = t - sy * kWienerFoot;
+    const int y = min(max(oy + sy - 3, -3), h + 2), x = min(max(ox + sx - 3, -3), w + 2);   // (what tap 7 reads is multiplied by 0: any staged value will do)
+    s_src[t] = (uint16_t)dat[(int64_t)(u.v_start + y) * dat_stride + u.h_start + x];
+  }
+  __syncthreads();
+  const int round_0 = bd == 12 ? 5 : 3, round_1 = 14 - round_0;
+  const int limit = (1 << (bd + 8 - round_0)) - 1;
+  for (int t = threadIdx.x; t < kWienerFoot * kWienerTile; t += 256) {   // temp row r = footprint row r, columns of the tile
+    const int r = t >> 5, x = t & 31;
+    const uint16_t *p = s_src + r * kWienerFoot + x;   // footprint column x = source column x - 3
+    int sum = ((int)p[3] << 7) + (1 << (bd + 6));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += (int)p[k] * fx[k];
+    s_tmp[t] = (uint16_t)min(max((sum + ((1 << round_0) >> 1)) >> round_0, 0), limit);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < kWienerTile * kWienerTile; t += 256) {
+    const int y = t >> 5, x = t & 31;
+    if (oy + y >= h || ox + x >= w) continue;
+    const uint16_t *p = s_tmp + y * kWienerTile + x;   // temp row y = source row y - 3
+    int sum = ((int)p[3 * kWienerTile] << 7) - (1 << (bd + round_1 - 1));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += (int)p[k * kWienerTile] * fy[k];
+    const int v = (sum + ((1 << round_1) >> 1)) >> round_1;
+    dst[(int64_t)(u.v_start + oy + y) * dst_stride + u.h_start + ox + x] = (T)min(max(v, 0), (1 << bd) - 1);
+  }
+}
+
 // ---- the self-guided filter's projection statistics: av1_calc_proj_params[_high_bd] (av1/encoder/pickrst.c:470-657: H[2][2], C[2] of
 // get_proj_subspace) and av1_[lowbd|highbd]_pixel_proj_error (:226-370: get_pixel_proj_error, evaluated once per xq that finer_search tries).
 // One 256-lane workgroup per (unit [, xq]): lanes stride the unit's pixels row-major, the sums are exact 64-bit integers (products of
@@ -439,6 +516,70 @@ extern "C" int aomhip_selfguided_restoration_batch(aomhip_ctx *ctx, const aomhip
   else
     hipLaunchKernelGGL(selfguided_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint16_t *>(dgd->base) + po, dgd->stride, d_units,
                        d_sgr_params_idx, dgd->bit_depth, d_flt0, d_flt1, flt_stride, flt_pitch, tiles_x);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+static int check_lr_units(const aomhip_planes *dat, const aomhip_rect *h_units, int n_units, int max_w, int max_h, const char *who) {
+  for (int i = 0; h_units && i < n_units; ++i) {
+    const aomhip_rect &r = h_units[i];
+    if (r.h_start < 0 || r.v_start < 0 || r.h_end > dat->width || r.v_end > dat->height || r.h_end <= r.h_start || r.v_end <= r.v_start ||
+        r.h_end - r.h_start > max_w || r.v_end - r.v_start > max_h) {
+      set_error("%s: unit %d is empty, outside the plane or larger than the stated maximum", who, i);
+      return AOMHIP_ERR_INVALID;
+    }
+  }
+  return AOMHIP_OK;
+}
+
+extern "C" int aomhip_apply_selfguided_restoration_batch(aomhip_ctx *ctx, const aomhip_planes *dat, int dat_frame, const aomhip_planes *dst, int dst_frame,
+                                                         const aomhip_rect *d_units, const aomhip_rect *h_units, int n_units, const int32_t *d_sgr_params_idx,
+                                                         const int32_t *d_xqd, int max_unit_width, int max_unit_height, int32_t *d_flt0, int32_t *d_flt1,
+                                                         int flt_stride, int64_t flt_pitch) {
+  if (!dst || !dst->base || !dat || dst_frame < 0 || dst_frame >= dst->n_frames || dst->bit_depth != dat->bit_depth || dst->width != dat->width ||
+      dst->height != dat->height || (n_units > 0 && !d_xqd)) {
+    set_error("aomhip_apply_selfguided_restoration_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  int rc = aomhip_selfguided_restoration_batch(ctx, dat, dat_frame, d_units, h_units, n_units, d_sgr_params_idx, max_unit_width, max_unit_height, d_flt0, d_flt1,
+                                               flt_stride, flt_pitch);
+  if (rc != AOMHIP_OK || n_units == 0) return rc;
+  const int64_t po = (int64_t)dat_frame * dat->frame_stride + (int64_t)dat->border * dat->stride + dat->border;
+  const int64_t qo = (int64_t)dst_frame * dst->frame_stride + (int64_t)dst->border * dst->stride + dst->border;
+  const int chunks = (max_unit_width * max_unit_height + 256 * 16 - 1) / (256 * 16);
+  const dim3 grid((unsigned)n_units, (unsigned)(chunks < 1 ? 1 : chunks));
+  if (dat->bit_depth == 8)
+    hipLaunchKernelGGL(selfguided_apply_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint8_t *>(dat->base) + po, dat->stride,
+                       static_cast<uint8_t *>(dst->base) + qo, dst->stride, d_units, d_sgr_params_idx, d_xqd, 8, d_flt0, d_flt1, flt_stride, flt_pitch);
+  else
+    hipLaunchKernelGGL(selfguided_apply_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint16_t *>(dat->base) + po, dat->stride,
+                       static_cast<uint16_t *>(dst->base) + qo, dst->stride, d_units, d_sgr_params_idx, d_xqd, dat->bit_depth, d_flt0, d_flt1, flt_stride,
+                       flt_pitch);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
+
+extern "C" int aomhip_wiener_convolve_add_src_batch(aomhip_ctx *ctx, const aomhip_planes *dat, int dat_frame, const aomhip_planes *dst, int dst_frame,
+                                                    const aomhip_rect *d_units, const aomhip_rect *h_units, int n_units, const int16_t *d_filters,
+                                                    int max_unit_width, int max_unit_height) {
+  if (!ctx || !dat || !dat->base || !dst || !dst->base || n_units < 0 || (n_units > 0 && (!d_units || !d_filters)) || dat_frame < 0 ||
+      dat_frame >= dat->n_frames || dst_frame < 0 || dst_frame >= dst->n_frames || dst->bit_depth != dat->bit_depth || dst->width != dat->width ||
+      dst->height != dat->height || dat->border < 3 || max_unit_width < 1 || max_unit_height < 1) {
+    set_error("aomhip_wiener_convolve_add_src_batch: invalid argument (border >= 3)");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (int rc = check_lr_units(dat, h_units, n_units, max_unit_width, max_unit_height, "aomhip_wiener_convolve_add_src_batch")) return rc;
+  if (n_units == 0) return AOMHIP_OK;
+  const int tiles_x = (max_unit_width + kWienerTile - 1) / kWienerTile, tiles_y = (max_unit_height + kWienerTile - 1) / kWienerTile;
+  const int64_t po = (int64_t)dat_frame * dat->frame_stride + (int64_t)dat->border * dat->stride + dat->border;
+  const int64_t qo = (int64_t)dst_frame * dst->frame_stride + (int64_t)dst->border * dst->stride + dst->border;
+  const dim3 grid((unsigned)n_units, (unsigned)(tiles_x * tiles_y));
+  if (dat->bit_depth == 8)
+    hipLaunchKernelGGL(wiener_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint8_t *>(dat->base) + po, dat->stride,
+                       static_cast<uint8_t *>(dst->base) + qo, dst->stride, d_units, d_filters, 8, tiles_x);
+  else
+    hipLaunchKernelGGL(wiener_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint16_t *>(dat->base) + po, dat->stride,
+                       static_cast<uint16_t *>(dst->base) + qo, dst->stride, d_units, d_filters, dat->bit_depth, tiles_x);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

@@ -1258,6 +1258,21 @@ int aomhip_selfguided_restoration_batch(aomhip_ctx *ctx, const aomhip_planes *dg
                                         int n_units, const int32_t *d_sgr_params_idx, int max_unit_width, int max_unit_height, int32_t *d_flt0,
                                         int32_t *d_flt1, int flt_stride, int64_t flt_pitch);
 
+/* The two restoration filters as the search APPLIES them to a unit (try_restoration_unit -> av1_loop_restoration_filter_unit, av1/encoder/pickrst.c,
+ * av1/common/restoration.c: sgrproj_filter_stripe / wiener_filter_stripe), into `dst` (same geometry as `dat`) at the unit's place; the SSE of
+ * the result against the source is aomhip_sse_batch's.
+ *   _apply_selfguided_:  av1_apply_selfguided_restoration (restoration.c:917-956): aomhip_selfguided_restoration_batch, then the projection
+ *                        with d_xqd[2 i], [2 i + 1] (av1_decode_xq) -- d_flt0 / d_flt1 are its scratch, sized as for that call
+ *   _wiener_:            av1_[highbd_]wiener_convolve_add_src (av1/common/convolve.c:1093-1257, steps 16): d_filters[16 i ..] = the unit's hfilter[8]
+ *                        then vfilter[8] (WienerInfo: 7 taps + 0, centre tap stored minus 128); `dat` border >= 3, extended */
+int aomhip_apply_selfguided_restoration_batch(aomhip_ctx *ctx, const aomhip_planes *dat, int dat_frame, const aomhip_planes *dst, int dst_frame,
+                                              const aomhip_rect *d_units, const aomhip_rect *h_units, int n_units, const int32_t *d_sgr_params_idx,
+                                              const int32_t *d_xqd, int max_unit_width, int max_unit_height, int32_t *d_flt0, int32_t *d_flt1,
+                                              int flt_stride, int64_t flt_pitch);
+int aomhip_wiener_convolve_add_src_batch(aomhip_ctx *ctx, const aomhip_planes *dat, int dat_frame, const aomhip_planes *dst, int dst_frame,
+                                         const aomhip_rect *d_units, const aomhip_rect *h_units, int n_units, const int16_t *d_filters,
+                                         int max_unit_width, int max_unit_height);
+
 /* The self-guided filter's projection statistics (search_sgrproj -> search_selfguided_restoration, av1/encoder/pickrst.c:
  * av1_calc_proj_params[_high_bd] :470-657 = get_proj_subspace's normal equations, av1_[lowbd|highbd]_pixel_proj_error :226-370 = the error of
  * one (xq0, xq1) that finer_search tries; av1_rtcd_defs.pl:454-463).  Unit i is a rectangle of `src` (the source) and `dat` (the degraded plane);

@@ -239,6 +239,10 @@ void orc_convolve_2d_scale(const void *src, int src_stride, void *dst, int dst_s
 /* the self-guided restoration filter (aomref_sgr.c): dgd points at the unit's first pixel and is read 3 pixels beyond it on every side */
 void orc_selfguided_restoration(const void *dgd, int elem16, int width, int height, int stride, int32_t *flt0, int32_t *flt1, int flt_stride,
                                 int sgr_params_idx, int bit_depth);
+void orc_apply_selfguided_restoration(const void *dat, int elem16, int width, int height, int stride, int eps, const int *xqd, void *dst, int dst_stride,
+                                      int bit_depth);
+void orc_wiener_convolve_add_src(const void *src, int elem16, int src_stride, void *dst, int dst_stride, const int16_t *filter_x, const int16_t *filter_y, int w,
+                                 int h, int bd);
 void orc_calc_proj_params(const void *src, int width, int height, int src_stride, const void *dat, int dat_stride, const int32_t *flt0, int flt0_stride,
                           const int32_t *flt1, int flt1_stride, int elem16, int r0, int r1, int64_t H[4], int64_t C[2]);
 int64_t orc_pixel_proj_error(const void *src, int width, int height, int src_stride, const void *dat, int dat_stride, const int32_t *flt0, int flt0_stride,

@@ -80,3 +80,63 @@ void orc_selfguided_restoration(const void *dgd, int elem16, int width, int heig
   }
   free(A);
 }
+
+/* av1_apply_selfguided_restoration_c (av1/common/restoration.c:917-956): the filter, then per pixel u = dat << SGRPROJ_RST_BITS,
+ * v = (u << SGRPROJ_PRJ_BITS) + xq0 (flt0 - u) + xq1 (flt1 - u) over the radii in use with (xq0, xq1) = av1_decode_xq(xqd) (:631-643),
+ * w = (int16_t)ROUND_POWER_OF_TWO(v, 11), clipped to the bit depth.  Pinned by tests/golden/ref_eval_sgr_apply.npz. */
+void orc_apply_selfguided_restoration(const void *dat, int elem16, int width, int height, int stride, int eps, const int *xqd, void *dst, int dst_stride,
+                                      int bit_depth) {
+  int32_t *flt0 = (int32_t *)malloc(sizeof(int32_t) * (size_t)width * height * 2), *flt1 = flt0 + (size_t)width * height;
+  orc_selfguided_restoration(dat, elem16, width, height, stride, flt0, flt1, width, eps, bit_depth);
+  const int r0 = k_sgr[eps][0], r1 = k_sgr[eps][1];
+  int xq[2];
+  if (r0 == 0) { xq[0] = 0; xq[1] = 128 - xqd[1]; }
+  else if (r1 == 0) { xq[0] = xqd[0]; xq[1] = 0; }
+  else { xq[0] = xqd[0]; xq[1] = 128 - xq[0] - xqd[1]; }
+  const int mx = (1 << bit_depth) - 1;
+  for (int i = 0; i < height; ++i)
+    for (int j = 0; j < width; ++j) {
+      const int k = i * width + j;
+      const int32_t u = (int32_t)PXS(dat, (ptrdiff_t)i * stride + j) << 4;
+      int32_t v = u << 7;
+      if (r0 > 0) v += xq[0] * (flt0[k] - u);
+      if (r1 > 0) v += xq[1] * (flt1[k] - u);
+      const int16_t w = (int16_t)((v + (1 << 10)) >> 11);
+      const int o = w < 0 ? 0 : (w > mx ? mx : w);
+      if (elem16) ((uint16_t *)dst)[(ptrdiff_t)i * dst_stride + j] = (uint16_t)o;
+      else ((uint8_t *)dst)[(ptrdiff_t)i * dst_stride + j] = (uint8_t)o;
+    }
+  free(flt0);
+}
+
+/* av1_wiener_convolve_add_src_c / av1_highbd_wiener_convolve_add_src_c (av1/common/convolve.c:1093-1257) as wiener_filter_stripe calls them: steps
+ * 16 (no scaling), the unit's 7-tap filters stored as 8 taps with the centre tap reduced by 128 -- the functions add the source back
+ * ("add_src": + src << FILTER_BITS).  round_0 / round_1 as get_conv_params_wiener(bd) (convolve.h:102-117): 3 / 11, at 12 bits 5 / 9.  The
+ * horizontal pass clamps to [0, WIENER_CLAMP_LIMIT), the vertical one removes the offset the horizontal one added and clips to the pixel range.
+ * src points at the block's first pixel and is read 3 pixels beyond it on every side (4 to the right / below: tap 7, which is 0).
+ * Pinned by tests/golden/ref_eval_lr_apply.npz (the two static passes interpreted where they lie). */
+void orc_wiener_convolve_add_src(const void *src, int elem16, int src_stride, void *dst, int dst_stride, const int16_t *filter_x, const int16_t *filter_y, int w,
+                                 int h, int bd) {
+  if (!elem16) bd = 8;
+  const int round_0 = bd == 12 ? 5 : 3, round_1 = 14 - round_0;
+  const int limit = 1 << (bd + 1 + 7 - round_0);
+  const int mx = (1 << bd) - 1;
+  uint16_t *temp = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)w * (h + 8));
+  for (int y = 0; y < h + 8; ++y)       /* temp row y = source row y - 3 */
+    for (int x = 0; x < w; ++x) {
+      int sum = (PXS(src, (ptrdiff_t)(y - 3) * src_stride + x) << 7) + (1 << (bd + 7 - 1));
+      for (int k = 0; k < 8; ++k) sum += PXS(src, (ptrdiff_t)(y - 3) * src_stride + x - 3 + k) * filter_x[k];
+      int v = (sum + ((1 << round_0) >> 1)) >> round_0;
+      temp[y * w + x] = (uint16_t)(v < 0 ? 0 : (v > limit - 1 ? limit - 1 : v));
+    }
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      int sum = ((int)temp[(y + 3) * w + x] << 7) - (1 << (bd + round_1 - 1));
+      for (int k = 0; k < 8; ++k) sum += (int)temp[(y + k) * w + x] * filter_y[k];
+      const int v = (sum + ((1 << round_1) >> 1)) >> round_1;
+      const int o = v < 0 ? 0 : (v > mx ? mx : v);
+      if (elem16) ((uint16_t *)dst)[(ptrdiff_t)y * dst_stride + x] = (uint16_t)o;
+      else ((uint8_t *)dst)[(ptrdiff_t)y * dst_stride + x] = (uint8_t)o;
+    }
+  free(temp);
+}
