@@ -193,6 +193,7 @@ _protos = {
     "aomhip_quantize_b_qm_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_quantize_fp_qm_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_quantize_b_adaptive_qm_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "aomhip_quantize_lp_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_xform_quant_qm_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_subtract_xform_quant_qm_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_encode_inter_blocks_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _PP, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -559,6 +560,11 @@ class Context:
         """the `fp` quantiser with matrices: qparams carries round_fp / quant_fp in its round / quant fields"""
         check(lib.aomhip_quantize_fp_qm_batch(self.h, d_coeff, tx_size, d_blocks, n_blocks, tx_type, C.byref(qparams), int(is_hbd), d_qm, d_iqm,
                                               d_qcoeff, d_dqcoeff, d_eob), "aomhip_quantize_fp_qm_batch")
+
+    def quantize_lp_batch(self, d_coeff, tx_size, d_blocks, n_blocks, tx_type, qparams, d_qcoeff, d_dqcoeff, d_eob, d_err=None):
+        """av1_quantize_lp on int16 coefficients (+ av1_block_error_lp into d_err): qparams carries round_fp / quant_fp in its round / quant fields"""
+        check(lib.aomhip_quantize_lp_batch(self.h, d_coeff, tx_size, d_blocks, n_blocks, tx_type, C.byref(qparams), d_qcoeff, d_dqcoeff, d_eob, d_err),
+              "aomhip_quantize_lp_batch")
 
     def xform_quant_qm_batch(self, d_residual, stride, tx_size, d_blocks, n_blocks, grid_cols, tx_type, qparams, is_hbd, d_qm, d_iqm, d_coeff, d_qcoeff,
                              d_dqcoeff, d_eob):

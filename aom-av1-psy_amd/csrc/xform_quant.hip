@@ -717,6 +717,44 @@ __global__ __launch_bounds__(256) void quant_qm_kernel(const int32_t *__restrict
   if (lane == 0) eob[bi] = (uint16_t)last;
 }
 
+// The low-precision quantiser of the non-RD mode search (av1_quantize_lp_c, av1/encoder/av1_quantize.c:212-240) with the transform-domain
+// distortion the same caller takes next (av1_block_error_lp_c, av1/encoder/rdopt.c:650-660) on int16 coefficients: one wavefront per block as
+// above.  |c| + round saturates at INT16_MAX, the level is (that * quant) >> 16, and dqcoeff is the product's low 16 bits (the reference
+// stores it through an int16_t).  err (optional): sum (coeff - dqcoeff)^2, each square in 32-bit wrap-around arithmetic like the compiled `int`.
+template <int KW, int KH>
+__global__ __launch_bounds__(256) void quant_lp_kernel(const int16_t *__restrict__ coeff, const aomhip_txb *__restrict__ blocks, int n_blocks,
+                                                       int uniform_type, QuantArgs qa, int16_t *__restrict__ qcoeff, int16_t *__restrict__ dqcoeff,
+                                                       uint16_t *__restrict__ eob, int64_t *__restrict__ err) {
+  constexpr int NC = KW * KH;
+  const int lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (bi >= n_blocks) return;
+  const int tx_type = blocks ? blocks[bi].tx_type : uniform_type;
+  const int64_t off = blocks ? (int64_t)blocks[bi].out_offset : (int64_t)bi * NC;
+  const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
+  int last = 0;
+  int64_t e = 0;
+  for (int rc = lane; rc < NC; rc += 64) {
+    const int ac = rc != 0;
+    const int c = coeff[off + rc], sign = c >> 31;
+    int t = min((c ^ sign) - sign + (int)(int16_t)qa.round[ac], 32767);
+    t = (t * (int)(int16_t)qa.quant[ac]) >> 16;
+    const int16_t qv = (int16_t)((t ^ sign) - sign);
+    const int16_t dv = (int16_t)(qv * (int)(int16_t)qa.dequant[ac]);
+    qcoeff[off + rc] = qv;
+    dqcoeff[off + rc] = dv;
+    if (t) last = max(last, iscan_pos<KW, KH>(rc % KH, rc / KH, scan_class) + 1);
+    const uint32_t d = (uint32_t)(c - dv);
+    e += (int32_t)(d * d);
+  }
+  last = group_max<64>(last);
+  if (lane == 0) eob[bi] = (uint16_t)last;
+  if (err) {
+    e = group_sum64<64>(e);
+    if (lane == 0) err[bi] = e;
+  }
+}
+
 // aom_quantize_b* / aom_highbd_quantize_b* with the caller's own scan tables: what the rtcd-signature entry points
 // (aomhip_quantize_b ...) run -- those signatures carry `scan` / `iscan` pointers and a coefficient count instead of a
 // transform size and type.  The same quantize_one as the fused kernels; eob = 1 + max iscan[rc] over non-zero levels
@@ -1082,6 +1120,34 @@ int aomhip_quantize_fp_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_
                                 int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd, const uint8_t *d_qm, const uint8_t *d_iqm,
                                 int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob) {
   return quantize_qm_launch(ctx, d_coeff, tx_size, d_blocks, n_blocks, uniform_tx_type, qparams, is_hbd, d_qm, d_iqm, d_qcoeff, d_dqcoeff, d_eob, true);
+}
+
+// av1_quantize_lp (+ av1_block_error_lp when d_err is given): qparams carries round_fp / quant_fp in its round / quant fields
+int aomhip_quantize_lp_batch(aomhip_ctx *ctx, const int16_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
+                             const aomhip_quant_params *qparams, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob, int64_t *d_err) {
+  if (!ctx || !d_coeff || !qparams || !d_qcoeff || !d_dqcoeff || !d_eob || tx_size < 0 || tx_size >= 19 || n_blocks < 0 ||
+      (!d_blocks && (uniform_tx_type < 0 || uniform_tx_type > 15))) {
+    set_error("aomhip_quantize_lp_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  if (int rc = validate_txb_list(ctx, d_blocks, n_blocks, tx_size, false, true)) return rc;
+  const QuantArgs qa = to_args(qparams);
+  const int w = kTxW[tx_size], h = kTxH[tx_size];
+  const int kw = w, kh = h;   // (no 64-point sizes: the non-RD search's transforms stop at 32 x 32, and av1_quantize_lp has no log-scale form)
+  const dim3 grid((n_blocks + 3) / 4), block(256);
+#define AOMHIP_LP(KW_, KH_)                                                                                                        \
+  if (kw == KW_ && kh == KH_) {                                                                                                    \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(quant_lp_kernel<KW_, KH_>), grid, block, 0, ctx->stream, d_coeff, d_blocks, n_blocks,       \
+                       uniform_tx_type, qa, d_qcoeff, d_dqcoeff, d_eob, d_err);                                                    \
+    AOMHIP_LAUNCH_CHECK();                                                                                                         \
+    return AOMHIP_OK;                                                                                                              \
+  }
+  AOMHIP_LP(4, 4) AOMHIP_LP(8, 8) AOMHIP_LP(16, 16) AOMHIP_LP(32, 32) AOMHIP_LP(4, 8) AOMHIP_LP(8, 4) AOMHIP_LP(8, 16) AOMHIP_LP(16, 8)
+  AOMHIP_LP(16, 32) AOMHIP_LP(32, 16) AOMHIP_LP(4, 16) AOMHIP_LP(16, 4) AOMHIP_LP(8, 32) AOMHIP_LP(32, 8)
+#undef AOMHIP_LP
+  set_error("aomhip_quantize_lp_batch: no kernel for tx_size %d", tx_size);
+  return AOMHIP_ERR_INVALID;
 }
 
 // av1_xform_quant with quantisation matrices: the forward transform by the fused kernel (its own flat-matrix levels are overwritten), then

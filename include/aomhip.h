@@ -403,6 +403,13 @@ int aomhip_quantize_b_adaptive_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff,
 int aomhip_quantize_fp_qm_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
                                 int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd, const uint8_t *d_qm, const uint8_t *d_iqm,
                                 int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);
+/* The low-precision quantiser of the non-RD mode search: av1_quantize_lp_c (av1/encoder/av1_quantize.c:212-240; rtcd av1_quantize_lp) on int16
+ * transform coefficients (aom_hadamard_lp_* / the lowbd transform's int16 output), list or grid mode like the quantisers above (a block's
+ * coefficients at out_offset, or block i at i * n_coeffs), qparams carrying round_fp / quant_fp in its round / quant fields, scan order from
+ * (tx_size, tx_type).  d_qcoeff / d_dqcoeff are int16 like the reference's (dqcoeff = the product's low 16 bits).  d_err (may be NULL): per block
+ * av1_block_error_lp_c (av1/encoder/rdopt.c:650-660) of (coeff, dqcoeff), what block_yrd takes next (nonrd_pickmode.c). */
+int aomhip_quantize_lp_batch(aomhip_ctx *ctx, const int16_t *d_coeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
+                             const aomhip_quant_params *qparams, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob, int64_t *d_err);
 int aomhip_xform_quant_qm_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int tx_size, const aomhip_txb *d_blocks,
                                 int n_blocks, int grid_cols, int uniform_tx_type, const aomhip_quant_params *qparams, int is_hbd,
                                 const uint8_t *d_qm, const uint8_t *d_iqm, int32_t *d_coeff, int32_t *d_qcoeff, int32_t *d_dqcoeff, uint16_t *d_eob);

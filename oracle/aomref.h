@@ -129,6 +129,9 @@ void orc_iwht4x4_add(const int32_t *input, uint16_t *dst, int stride, int eob, i
 
 /* ---- quantize (aom_dsp/quantize.c, av1/encoder/av1_quantize.c) -------------------- */
 /* quantize.c:108-169 aom_quantize_b_helper_c with qm_ptr == iqm_ptr == NULL */
+void orc_quantize_lp(const int16_t *coeff, intptr_t n, const int16_t *round_fp, const int16_t *quant_fp, int16_t *qcoeff, int16_t *dqcoeff,
+                     const int16_t *dequant, uint16_t *eob_out, const int16_t *scan);
+int64_t orc_block_error_lp(const int16_t *coeff, const int16_t *dqcoeff, intptr_t n);
 /* the fp quantiser with matrices (aomref_quant.c; quantize_fp_helper_c / highbd_quantize_fp_helper_c, qm_ptr / iqm_ptr non-NULL) */
 void orc_quantize_fp_qm(const int32_t *coeff, intptr_t n, const int16_t *round_fp, const int16_t *quant_fp, int32_t *qcoeff, int32_t *dqcoeff,
                         const int16_t *dequant, uint16_t *eob_out, const int16_t *scan, int log_scale, int highbd, const uint8_t *qm,

@@ -369,3 +369,33 @@ void orc_quantize_fp_qm(const int32_t *coeff, intptr_t n, const int16_t *round_f
   }
   *eob_out = (uint16_t)(eob + 1);
 }
+
+/* av1_quantize_lp_c (av1/encoder/av1_quantize.c:212-240): the low-precision (int16 coefficients) quantiser of the non-RD mode search --
+ * clamp(|c| + round) * quant >> 16, dqcoeff = qcoeff * dequant stored in int16 -- and av1_block_error_lp_c (av1/encoder/rdopt.c:650-660; the
+ * products in `int`, as the compiled reference).  Pinned by tests/golden/ref_eval_quant_lp.npz. */
+void orc_quantize_lp(const int16_t *coeff, intptr_t n, const int16_t *round_fp, const int16_t *quant_fp, int16_t *qcoeff, int16_t *dqcoeff,
+                     const int16_t *dequant, uint16_t *eob_out, const int16_t *scan) {
+  int eob = -1;
+  memset(qcoeff, 0, (size_t)n * sizeof(*qcoeff));
+  memset(dqcoeff, 0, (size_t)n * sizeof(*dqcoeff));
+  for (intptr_t i = 0; i < n; ++i) {
+    const int rc = scan[i], ac = rc != 0;
+    const int c = coeff[rc], sign = c < 0 ? -1 : 0;
+    const int a = (c ^ sign) - sign;
+    int t = a + round_fp[ac];
+    t = t > INT16_MAX ? INT16_MAX : (t < INT16_MIN ? INT16_MIN : t);
+    t = (t * quant_fp[ac]) >> 16;
+    qcoeff[rc] = (int16_t)((t ^ sign) - sign);
+    dqcoeff[rc] = (int16_t)(qcoeff[rc] * dequant[ac]);
+    if (t) eob = (int)i;
+  }
+  *eob_out = (uint16_t)(eob + 1);
+}
+int64_t orc_block_error_lp(const int16_t *coeff, const int16_t *dqcoeff, intptr_t n) {
+  int64_t error = 0;
+  for (intptr_t i = 0; i < n; ++i) {
+    const int diff = coeff[i] - dqcoeff[i];
+    error += (int32_t)((uint32_t)diff * (uint32_t)diff);
+  }
+  return error;
+}
