@@ -123,6 +123,7 @@ COMP_AVG, COMP_DIST_WTD, COMP_MASK, COMP_OBMC = 0, 1, 2, 3
 blend_item_dtype = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("mask_offset", "<u2"), ("vertical", "u1"), ("reserved", "u1")])
 rect_dtype = np.dtype([("h_start", "<i4"), ("h_end", "<i4"), ("v_start", "<i4"), ("v_end", "<i4")])
 scaled_block_dtype = np.dtype([(n, "<i4") for n in ("src_x", "src_y", "subpel_x_qn", "subpel_y_qn", "dst_x", "dst_y")])   # aomhip_scaled_block
+warp_model_dtype = np.dtype([("mat", "<i4", (6,)), ("alpha", "<i2"), ("beta", "<i2"), ("gamma", "<i2"), ("delta", "<i2")])
 warp_block_dtype = np.dtype([("mat", "<i4", (6,)), ("alpha", "<i2"), ("beta", "<i2"), ("gamma", "<i2"), ("delta", "<i2"), ("p_col", "<i4"), ("p_row", "<i4"),
                              ("p_width", "<i4"), ("p_height", "<i4")])   # aomhip_warp_block (48 bytes)
 
@@ -193,6 +194,9 @@ _protos = {
     "aomhip_quantize_b_qm_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_quantize_fp_qm_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_quantize_b_adaptive_qm_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "aomhip_get_shear_params": (C.c_int, [_vp]),
+    "aomhip_warp_error_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "aomhip_segmented_frame_error": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_quantize_lp_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_xform_quant_qm_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_subtract_xform_quant_qm_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -305,6 +309,11 @@ for _name, _res in (("aomhip_lf_build_edge_params", C.c_int), ("aomhip_lf_level_
     _protos[_name] = (_res, None)
 
 EXPORTED = sorted(_protos)
+
+
+def get_shear_params(models):
+    """av1_get_shear_params on a warp_model_dtype array in place (host, no GPU); returns the per-model verdicts"""
+    return [int(lib.aomhip_get_shear_params(C.c_void_p(models[i:i + 1].ctypes.data))) for i in range(len(models))]
 
 
 class AomHipError(RuntimeError):
@@ -560,6 +569,15 @@ class Context:
         """the `fp` quantiser with matrices: qparams carries round_fp / quant_fp in its round / quant fields"""
         check(lib.aomhip_quantize_fp_qm_batch(self.h, d_coeff, tx_size, d_blocks, n_blocks, tx_type, C.byref(qparams), int(is_hbd), d_qm, d_iqm,
                                               d_qcoeff, d_dqcoeff, d_eob), "aomhip_quantize_fp_qm_batch")
+
+    def warp_error_batch(self, ref, ref_frame, cur, cur_frame, ssx, ssy, d_models, n_models, p_col, p_row, p_width, p_height, d_seg, seg_stride, d_error):
+        """av1_warp_error for n_models candidate models (shear values already in them: get_shear_params)"""
+        check(lib.aomhip_warp_error_batch(self.h, C.byref(ref), ref_frame, C.byref(cur), cur_frame, ssx, ssy, d_models, n_models, p_col, p_row, p_width,
+                                          p_height, d_seg, seg_stride, d_error), "aomhip_warp_error_batch")
+
+    def segmented_frame_error(self, ref, ref_frame, cur, cur_frame, p_width, p_height, d_seg, seg_stride, d_error):
+        check(lib.aomhip_segmented_frame_error(self.h, C.byref(ref), ref_frame, C.byref(cur), cur_frame, p_width, p_height, d_seg, seg_stride, d_error),
+              "aomhip_segmented_frame_error")
 
     def quantize_lp_batch(self, d_coeff, tx_size, d_blocks, n_blocks, tx_type, qparams, d_qcoeff, d_dqcoeff, d_eob, d_err=None):
         """av1_quantize_lp on int16 coefficients (+ av1_block_error_lp into d_err): qparams carries round_fp / quant_fp in its round / quant fields"""

@@ -1034,6 +1034,59 @@ def run_wiener_stats(pkg, ctx, orc, steps, warmup):
     return out
 
 
+def run_warp_error(pkg, ctx, orc, steps, warmup):
+    """The global-motion search's inner loop (av1_warp_error, av1/encoder/global_motion.c:128-224) on a 4K luma plane: 14 candidate models per call
+    (the +step / -step pair of one parameter for 7 references' worth of candidates), every 32 x 32 tile active, 10 and 8 bits; and the baseline
+    av1_segmented_frame_error.  Informational.  Algorithmic bytes per model: the reference and the current frame once each."""
+    import ctypes as C
+    capi = pkg.capi
+    W, H, border, n_models = 3840, 2160, 32, 14
+    out = {"workload": "global_motion_warp_error_luma_4k", "models_per_call": n_models}
+    rng = np.random.default_rng(5)
+    for name, bd in (("10bit", 10), ("8bit", 8)):
+        ref = pkg.synth.lcg_frame(W, H, 3, 0, bd)
+        cur = pkg.synth.lcg_frame(W, H, 3, 1, bd)
+        pr, pc = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+        ctx.planes_upload(pr, 0, ref); ctx.planes_upload(pc, 0, cur)
+        models = np.zeros(n_models, capi.warp_model_dtype)
+        for i in range(n_models):
+            while True:
+                models["mat"][i] = [rng.integers(-8 << 16, 8 << 16), rng.integers(-8 << 16, 8 << 16), (1 << 16) + rng.integers(-(1 << 10), 1 << 10),
+                                    rng.integers(-(1 << 10), 1 << 10), rng.integers(-(1 << 10), 1 << 10), (1 << 16) + rng.integers(-(1 << 10), 1 << 10)]
+                if capi.get_shear_params(models[i:i + 1])[0]:
+                    break
+        sw, sh = (W + 31) // 32, (H + 31) // 32
+        seg = np.ones((sh, sw), np.uint8)
+        d_m, d_s, d_e = ctx.to_device(models), ctx.to_device(seg), ctx.malloc(8 * n_models)
+        once = lambda: ctx.warp_error_batch(pr, 0, pc, 0, 0, 0, d_m, n_models, 0, 0, W, H, d_s, sw, d_e)
+        for _ in range(warmup):
+            once()
+        ms = kernel_avg_ms(ctx, once, max(steps, 3))
+        es = 2 if bd > 8 else 1
+        out[name] = {"ms_per_call": ms, "ms_per_model": ms / n_models, "model_pixels_per_s": float(W) * H * n_models / ms * 1e3,
+                     "algorithmic_GBps": 2.0 * W * H * es * n_models / ms / 1e6}
+        ms_f = kernel_avg_ms(ctx, lambda: ctx.segmented_frame_error(pr, 0, pc, 0, W, H, d_s, sw, d_e), max(steps, 3))
+        out[name]["segmented_frame_error_ms"] = ms_f
+        if name == "10bit":   # exact check of one model over the whole frame against the oracle
+            once()
+            got = ctx.from_device(d_e, (n_models,), np.int64)
+            f = orc.lib.orc_warp_error
+            f.restype = C.c_int64
+            m = np.ascontiguousarray(models["mat"][3], np.int32)
+            sh4 = np.array([models[k][3] for k in ("alpha", "beta", "gamma", "delta")], np.int16)
+            rc, cc = np.ascontiguousarray(ref), np.ascontiguousarray(cur)
+            t0 = time.perf_counter()
+            want = f(C.c_void_p(m.ctypes.data), C.c_void_p(sh4.ctypes.data), C.c_void_p(rc.ctypes.data), 1, W, H, W, C.c_void_p(cc.ctypes.data), 0, 0, W, H, W, 0, 0, bd,
+                     C.c_int64((1 << 63) - 1), C.c_void_p(seg.ctypes.data), sw)
+            out["cpu_port_ms_per_model"] = (time.perf_counter() - t0) * 1e3     # the C restatement, one host core, the same frame
+            out["parity_sample"] = bool(int(got[3]) == int(want))
+        for d in (d_m, d_s, d_e):
+            ctx.free(d)
+        ctx.planes_free(pr); ctx.planes_free(pc)
+    out["value"], out["unit"] = out["10bit"]["model_pixels_per_s"], "model pixels/s"
+    return out
+
+
 def run_tf(pkg, ctx, orc, steps, warmup, width=3840, height=2160, bd=10, n_frames=5):
     """the temporal filter's motion search (tf_motion_search, temporal_filter.c:87-253) for every 32x32 block of a
     4K 10-bit frame against the 4 other frames of a 5-frame window, one aomhip_tf_motion_search_frames call per filtered frame: per
@@ -1622,7 +1675,7 @@ def main():
                     help="default: sad16x16_modeA_1080p_8bit (BASELINE.json's metric) at every N; with N > 1 the line also carries the "
                          "strong-scaling search pipeline with its per-frame RCCL exchange as `strong_scaling_search`",
                     choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "txq_4k_10bit", "search_4k_10bit", "inner_loop_4k_10bit", "default_search_4k_10bit", "cdef_search_4k_10bit",
-                                                "wiener_stats_4k", "tf_motion_search_4k_10bit", "sad_diamond_lists_4k_8bit", "first_pass_4k_10bit", "compound_search_4k_10bit"])
+                                                "wiener_stats_4k", "warp_error_4k", "tf_motion_search_4k_10bit", "sad_diamond_lists_4k_8bit", "first_pass_4k_10bit", "compound_search_4k_10bit"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -1747,10 +1800,11 @@ def main():
         print(json.dumps(dict(r, metric="tf block searches/s", n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
                               vs_baseline=None, dtype="u16", data="synthetic", ms_per_step=r["q30_mesh_pruned_when_close"]["ms_per_filtered_frame"])))
         return
-    if args.workload in ("cdef_search_4k_10bit", "wiener_stats_4k"):  # informational encoder-side searches (single GPU)
-        r = (run_cdef_search if args.workload == "cdef_search_4k_10bit" else run_wiener_stats)(pkg, ctx, orc, args.steps, args.warmup)
+    if args.workload in ("cdef_search_4k_10bit", "wiener_stats_4k", "warp_error_4k"):  # informational encoder-side searches (single GPU)
+        r = {"cdef_search_4k_10bit": run_cdef_search, "wiener_stats_4k": run_wiener_stats, "warp_error_4k": run_warp_error}[args.workload](
+            pkg, ctx, orc, args.steps, args.warmup)
         ctx.close()
-        first = r["full_search_64"] if "full_search_64" in r else r["8bit_units64"]
+        first = r["full_search_64"] if "full_search_64" in r else (r["8bit_units64"] if "8bit_units64" in r else {"ms_per_frame": r["10bit"]["ms_per_call"]})
         print(json.dumps(dict(r, metric=r["unit"], n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
                               vs_baseline=None, dtype="u16" if "cdef" in args.workload else "u8", data="synthetic",
                               ms_per_step=first["ms_per_frame"], config={"workload": r["workload"]})))

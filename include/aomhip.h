@@ -1217,6 +1217,28 @@ int aomhip_warp_affine_compound_batch(aomhip_ctx *ctx, const aomhip_planes *ref,
                                       int subsampling_y, const aomhip_warp_block *d_blocks, int n_blocks, int max_block_width, int max_block_height,
                                       uint16_t *d_conv, int conv_stride, int do_average, int use_dist_wtd_comp_avg, int fwd_offset, int bck_offset);
 
+/* The global-motion search's model error: av1_warp_error (av1/encoder/global_motion.c:128-224), what av1_refine_integerized_param (:237-322) calls for
+ * every step of its coordinate descent, for n_models candidate models at once (the +step / -step pair of a parameter, the candidates of several
+ * references).  `cur` is the frame being coded, `ref` the reference the models warp; for model m, every 32 x 32 tile (WARP_ERROR_BLOCK) of the region
+ * (p_col, p_row, p_width, p_height) whose d_segment_map[(row >> 5) * segment_map_stride + (col >> 5)] is non-zero is predicted through the model
+ * (av1_[highbd_]warp_affine with get_conv_params(0, 0, bd)) and compared with `cur` pixel by pixel through error_measure_lut
+ * (av1/common/warped_motion.h:42-146, warped_motion.c:248-259); d_error[m] = the total.  The reference's `best_error` early exit returns INT64_MAX as
+ * soon as the running sum passes the bound -- every term is >= 0, so that is `total > best_error ? INT64_MAX : total` on what this returns.  The
+ * models carry the four shear values of av1_get_shear_params: aomhip_get_shear_params below (host, no GPU) derives them and tells an invalid model,
+ * for which av1_warp_error returns INT64_MAX without warping -- such a model must not be sent.
+ *   aomhip_segmented_frame_error   av1_segmented_frame_error (av1/common/warped_motion.c:400-460,687-760): the same metric between `ref` as it is and
+ *                                  `cur` over (0, 0, p_width, p_height) -- the search's baseline (ref_frame_error, av1/encoder/global_motion_facade.c) */
+typedef struct {
+  int32_t mat[6];                      /* WarpedMotionParams.wmmat */
+  int16_t alpha, beta, gamma, delta;
+} aomhip_warp_model;
+int aomhip_get_shear_params(aomhip_warp_model *model);   /* av1_get_shear_params (av1/common/warped_motion.c:186-245): fills alpha .. delta; 1 valid, 0 not */
+int aomhip_warp_error_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *cur, int cur_frame, int subsampling_x,
+                            int subsampling_y, const aomhip_warp_model *d_models, int n_models, int p_col, int p_row, int p_width, int p_height,
+                            const uint8_t *d_segment_map, int segment_map_stride, int64_t *d_error);
+int aomhip_segmented_frame_error(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *cur, int cur_frame, int p_width, int p_height,
+                                 const uint8_t *d_segment_map, int segment_map_stride, int64_t *d_error);
+
 /* ------------------------------------------------------------------ prediction from a scaled reference */
 
 /* av1_convolve_2d_scale / av1_highbd_convolve_2d_scale (av1/common/convolve.c; av1_rtcd_defs.pl:616-617,599-600): the predictor

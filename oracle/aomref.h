@@ -256,6 +256,12 @@ void orc_warp_affine(const int32_t *mat, const void *ref, int elem16, int width,
 void orc_warp_affine_compound(const int32_t *mat, const void *ref, int elem16, int width, int height, int stride, void *pred, int p_col, int p_row, int p_width,
                               int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int round_0, int alpha, int beta, int gamma, int delta,
                               int do_average, int use_dist_wtd, int fwd_offset, int bck_offset, uint16_t *conv, int conv_stride);
+int orc_get_shear_params(const int32_t *mat, int16_t *abgd);
+int64_t orc_warp_error(const int32_t *mat, const int16_t *abgd, const void *ref, int elem16, int width, int height, int stride, const void *dst, int p_col,
+                       int p_row, int p_width, int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int64_t best_error,
+                       const uint8_t *segment_map, int segment_map_stride);
+int64_t orc_segmented_frame_error(const void *ref, int elem16, int stride, const void *dst, int p_width, int p_height, int p_stride, int bd,
+                                  const uint8_t *segment_map, int segment_map_stride);
 uint64_t orc_wedge_sse_from_residuals(const int16_t *r1, const int16_t *d, const uint8_t *m, int n);
 int orc_wedge_sign_from_residuals(const int16_t *ds, const uint8_t *m, int n, int64_t limit);
 void orc_wedge_compute_delta_squares(int16_t *d, const int16_t *a, const int16_t *b, int n);

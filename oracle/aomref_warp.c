@@ -9,6 +9,7 @@
  */
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 #include "aomref.h"
 
@@ -107,3 +108,90 @@ void orc_warp_affine_compound(const int32_t *mat, const void *ref, int elem16, i
   warp_affine(mat, ref, elem16, width, height, stride, pred, p_col, p_row, p_width, p_height, p_stride, subsampling_x, subsampling_y, bd, round_0, alpha, beta,
               gamma, delta, 1, do_average, use_dist_wtd, fwd_offset, bck_offset, conv, conv_stride);
 }
+
+/* ---- the global-motion search's use of the warp: av1_get_shear_params (av1/common/warped_motion.c:186-245), av1_warp_error (av1/encoder/global_motion.c:
+ * 128-224: 32 x 32 tiles of the model's prediction against the frame, only where the segment map holds inliers, every pixel's difference through
+ * error_measure_lut -- interpolated between neighbouring entries above 8 bits, warped_motion.c:248-259) and av1_segmented_frame_error (warped_motion.c:
+ * 400-460,687-760: the same metric without a warp).  Pinned by tests/golden/ref_eval_warp_error.npz. */
+#include "aomref_warp_error.inc"
+static const int k_error_measure_lut[512] = AOMHIP_ERROR_MEASURE_LUT;
+static const uint16_t k_div_lut[257] = AOMHIP_DIV_LUT;
+
+static int64_t rpot_s64(int64_t v, int n) { return v < 0 ? -((-v + ((int64_t)1 << n >> 1)) >> n) : (v + ((int64_t)1 << n >> 1)) >> n; }
+static int rpot_s(int v, int n) { return v < 0 ? -((-v + ((1 << n) >> 1)) >> n) : (v + ((1 << n) >> 1)) >> n; }
+
+int orc_get_shear_params(const int32_t *mat, int16_t *abgd) {
+  if (mat[2] <= 0) return 0;   /* is_affine_valid */
+  int alpha = clampi(mat[2] - (1 << 16), INT16_MIN, INT16_MAX), beta = clampi(mat[3], INT16_MIN, INT16_MAX);
+  const uint32_t D = (uint32_t)mat[2];
+  int shift = 31;
+  while (!(D >> shift)) --shift;   /* get_msb */
+  const int32_t e = (int32_t)(D - ((uint32_t)1 << shift));
+  const int32_t f = shift > 8 ? (e + ((1 << (shift - 8)) >> 1)) >> (shift - 8) : e << (8 - shift);
+  shift += 14;
+  const int16_t y = (int16_t)k_div_lut[f];
+  int64_t v = ((int64_t)mat[4] * (1 << 16)) * y;
+  int gamma = clampi((int)rpot_s64(v, shift), INT16_MIN, INT16_MAX);
+  v = ((int64_t)mat[3] * mat[4]) * y;
+  int delta = clampi(mat[5] - (int)rpot_s64(v, shift) - (1 << 16), INT16_MIN, INT16_MAX);
+  alpha = rpot_s(alpha, 6) * 64;   /* WARP_PARAM_REDUCE_BITS */
+  beta = rpot_s(beta, 6) * 64;
+  gamma = rpot_s(gamma, 6) * 64;
+  delta = rpot_s(delta, 6) * 64;
+  abgd[0] = (int16_t)alpha; abgd[1] = (int16_t)beta; abgd[2] = (int16_t)gamma; abgd[3] = (int16_t)delta;
+  if (4 * abs(alpha) + 7 * abs(beta) >= (1 << 16) || 4 * abs(gamma) + 4 * abs(delta) >= (1 << 16)) return 0;   /* is_affine_shear_allowed */
+  return 1;
+}
+
+static int64_t frame_error(const void *ref, int stride, const void *dst, int w, int h, int p_stride, int elem16, int bd) {
+  int64_t sum = 0;
+  const int b = bd - 8, bmask = (1 << b) - 1, v = 1 << b;
+  for (int i = 0; i < h; ++i)
+    for (int j = 0; j < w; ++j) {
+      if (elem16) {
+        const int err = abs((int)((const uint16_t *)dst)[j + (ptrdiff_t)i * p_stride] - (int)((const uint16_t *)ref)[j + (ptrdiff_t)i * stride]);
+        const int e1 = err >> b, e2 = err & bmask;
+        sum += k_error_measure_lut[255 + e1] * (v - e2) + k_error_measure_lut[256 + e1] * e2;
+      } else {
+        sum += k_error_measure_lut[255 + (int)((const uint8_t *)dst)[j + (ptrdiff_t)i * p_stride] - (int)((const uint8_t *)ref)[j + (ptrdiff_t)i * stride]];
+      }
+    }
+  return sum;
+}
+
+/* mat + the four shear values as av1_get_shear_params left them in the model; ref / dst point at pixel (0, 0) of their planes */
+int64_t orc_warp_error(const int32_t *mat, const int16_t *abgd, const void *ref, int elem16, int width, int height, int stride, const void *dst, int p_col,
+                       int p_row, int p_width, int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int64_t best_error,
+                       const uint8_t *segment_map, int segment_map_stride) {
+  int64_t sumerr = 0;
+  const int bw = p_width < 32 ? p_width : 32, bh = p_height < 32 ? p_height : 32;   /* WARP_ERROR_BLOCK */
+  uint16_t tmp16[32 * 32];
+  uint8_t tmp8[32 * 32];
+  const int es = elem16 ? 2 : 1;
+  for (int i = p_row; i < p_row + p_height; i += 32)
+    for (int j = p_col; j < p_col + p_width; j += 32) {
+      if (!segment_map[(i >> 5) * segment_map_stride + (j >> 5)]) continue;
+      const int ww = bw < p_col + p_width - j ? bw : p_col + p_width - j, wh = bh < p_row + p_height - i ? bh : p_row + p_height - i;
+      void *tmp = elem16 ? (void *)tmp16 : (void *)tmp8;
+      orc_warp_affine(mat, ref, elem16, width, height, stride, tmp, j, i, ww, wh, 32, subsampling_x, subsampling_y, bd, bd == 12 ? 5 : 3, abgd[0], abgd[1],
+                      abgd[2], abgd[3]);
+      sumerr += frame_error(tmp, 32, (const char *)dst + ((ptrdiff_t)i * p_stride + j) * es, ww, wh, p_stride, elem16, bd);
+      if (sumerr > best_error) return INT64_MAX;
+    }
+  return sumerr;
+}
+
+int64_t orc_segmented_frame_error(const void *ref, int elem16, int stride, const void *dst, int p_width, int p_height, int p_stride, int bd,
+                                  const uint8_t *segment_map, int segment_map_stride) {
+  int64_t sum = 0;
+  const int bw = p_width < 32 ? p_width : 32, bh = p_height < 32 ? p_height : 32, es = elem16 ? 2 : 1;
+  for (int i = 0; i < p_height; i += 32)
+    for (int j = 0; j < p_width; j += 32) {
+      if (!segment_map[(i >> 5) * segment_map_stride + (j >> 5)]) continue;
+      const int pw = bw < p_width - j ? bw : p_width - j, ph = bh < p_height - i ? bh : p_height - i;
+      sum += frame_error((const char *)ref + ((ptrdiff_t)i * stride + j) * es, stride, (const char *)dst + ((ptrdiff_t)i * p_stride + j) * es, pw, ph,
+                         p_stride, elem16, bd);
+    }
+  return sum;
+}
+
