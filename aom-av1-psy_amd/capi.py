@@ -194,6 +194,7 @@ _protos = {
     "aomhip_quantize_b_qm_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_quantize_fp_qm_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_quantize_b_adaptive_qm_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "aomhip_int_pro_motion_estimation_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_get_shear_params": (C.c_int, [_vp]),
     "aomhip_warp_error_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_segmented_frame_error": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _vp]),
@@ -569,6 +570,11 @@ class Context:
         """the `fp` quantiser with matrices: qparams carries round_fp / quant_fp in its round / quant fields"""
         check(lib.aomhip_quantize_fp_qm_batch(self.h, d_coeff, tx_size, d_blocks, n_blocks, tx_type, C.byref(qparams), int(is_hbd), d_qm, d_iqm,
                                               d_qcoeff, d_dqcoeff, d_eob), "aomhip_quantize_fp_qm_batch")
+
+    def int_pro_motion_estimation_batch(self, src, src_frame, ref, ref_frame, bw, bh, d_blocks, n_blocks, d_best_mv, d_best_sad):
+        """av1_int_pro_motion_estimation for a batch of blocks: (row, col) in 1/8 pel and the SAD"""
+        check(lib.aomhip_int_pro_motion_estimation_batch(self.h, C.byref(src), src_frame, C.byref(ref), ref_frame, bw, bh, d_blocks, n_blocks, d_best_mv,
+                                                         d_best_sad), "aomhip_int_pro_motion_estimation_batch")
 
     def warp_error_batch(self, ref, ref_frame, cur, cur_frame, ssx, ssy, d_models, n_models, p_col, p_row, p_width, p_height, d_seg, seg_stride, d_error):
         """av1_warp_error for n_models candidate models (shear values already in them: get_shear_params)"""

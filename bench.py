@@ -1087,6 +1087,53 @@ def run_warp_error(pkg, ctx, orc, steps, warmup):
     return out
 
 
+def run_int_pro(pkg, ctx, orc, steps, warmup):
+    """av1_int_pro_motion_estimation (av1/encoder/mcomp.c:1897-2105) for every block of a 4K 8-bit luma plane: the 64 x 64 superblocks (the vector
+    variance partitioning starts from) and all 16 x 16 / 32 x 32 blocks.  Informational."""
+    import ctypes as C
+    capi = pkg.capi
+    W, H, border = 3840, 2160, 160
+    base, _ = pkg.synth.shifted_smooth_pair(W + 64, H + 64, 0, 8)
+    rng = np.random.default_rng(3)
+    src = np.clip(base[32:32 + H, 32:32 + W].astype(np.int32) + rng.integers(-3, 4, (H, W)), 0, 255).astype(np.uint8)
+    ref = np.clip(base[29:29 + H, 37:37 + W].astype(np.int32) + rng.integers(-3, 4, (H, W)), 0, 255).astype(np.uint8)
+    ps, pr = ctx.planes_alloc(W, H, border, 8, 1), ctx.planes_alloc(W, H, border, 8, 1)
+    ctx.planes_upload(ps, 0, src); ctx.planes_upload(pr, 0, ref)
+    out = {"workload": "int_pro_motion_estimation_luma_4k_8bit"}
+    for bs in (64, 32, 16):
+        pos = [(x, y) for y in range(0, H - bs + 1, bs) for x in range(0, W - bs + 1, bs)]
+        blocks = np.zeros(len(pos), capi.search_block_dtype)
+        blocks["bx"], blocks["by"] = [p[0] for p in pos], [p[1] for p in pos]
+        blocks["row_min"], blocks["row_max"], blocks["col_min"], blocks["col_max"] = -1023, 1023, -1023, 1023
+        n = len(pos)
+        d_b, d_mv, d_sad = ctx.to_device(blocks), ctx.malloc(4 * n), ctx.malloc(4 * n)
+        once = lambda: ctx.int_pro_motion_estimation_batch(ps, 0, pr, 0, bs, bs, d_b, n, d_mv, d_sad)
+        for _ in range(warmup):
+            once()
+        ms = kernel_avg_ms(ctx, once, max(steps, 3))
+        out["%dx%d" % (bs, bs)] = {"ms_per_frame": ms, "blocks": n, "blocks_per_s": n / ms * 1e3}
+        if bs == 64:   # a sample of blocks against the oracle, and the CPU restatement's rate on them
+            mv, sad = ctx.from_device(d_mv, (n, 2), np.int16), ctx.from_device(d_sad, (n,), np.uint32)
+            sb, rb = np.pad(src, border, mode="edge"), np.pad(ref, border, mode="edge")
+            f = orc.lib.orc_int_pro_motion_estimation
+            f.restype = C.c_uint
+            lim, rm, o = np.array([-1023, 1023, -1023, 1023], np.int32), np.zeros(2, np.int16), np.zeros(2, np.int16)
+            ok, t0, sample = True, time.perf_counter(), range(0, n, 17)
+            for i in sample:
+                off = (border + pos[i][1]) * sb.shape[1] + border + pos[i][0]
+                w = f(C.c_void_p(sb.ctypes.data + off), sb.shape[1], C.c_void_p(rb.ctypes.data + off), rb.shape[1], bs, bs, 8, C.c_void_p(lim.ctypes.data),
+                      C.c_void_p(rm.ctypes.data), C.c_void_p(o.ctypes.data))
+                ok = ok and int(w) == int(sad[i]) and o.tolist() == mv[i].tolist()
+            out["cpu_port_blocks_per_s_64x64"] = len(sample) / (time.perf_counter() - t0)
+            out["parity_sample"] = bool(ok)
+            out["vectors_found"] = int(len({tuple(v) for v in mv.tolist()}))
+        for d in (d_b, d_mv, d_sad):
+            ctx.free(d)
+    ctx.planes_free(ps); ctx.planes_free(pr)
+    out["value"], out["unit"] = out["64x64"]["blocks_per_s"], "64x64 blocks/s"
+    return out
+
+
 def run_tf(pkg, ctx, orc, steps, warmup, width=3840, height=2160, bd=10, n_frames=5):
     """the temporal filter's motion search (tf_motion_search, temporal_filter.c:87-253) for every 32x32 block of a
     4K 10-bit frame against the 4 other frames of a 5-frame window, one aomhip_tf_motion_search_frames call per filtered frame: per
@@ -1675,7 +1722,7 @@ def main():
                     help="default: sad16x16_modeA_1080p_8bit (BASELINE.json's metric) at every N; with N > 1 the line also carries the "
                          "strong-scaling search pipeline with its per-frame RCCL exchange as `strong_scaling_search`",
                     choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "txq_4k_10bit", "search_4k_10bit", "inner_loop_4k_10bit", "default_search_4k_10bit", "cdef_search_4k_10bit",
-                                                "wiener_stats_4k", "warp_error_4k", "tf_motion_search_4k_10bit", "sad_diamond_lists_4k_8bit", "first_pass_4k_10bit", "compound_search_4k_10bit"])
+                                                "wiener_stats_4k", "warp_error_4k", "int_pro_4k_8bit", "tf_motion_search_4k_10bit", "sad_diamond_lists_4k_8bit", "first_pass_4k_10bit", "compound_search_4k_10bit"])
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -1800,11 +1847,12 @@ def main():
         print(json.dumps(dict(r, metric="tf block searches/s", n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
                               vs_baseline=None, dtype="u16", data="synthetic", ms_per_step=r["q30_mesh_pruned_when_close"]["ms_per_filtered_frame"])))
         return
-    if args.workload in ("cdef_search_4k_10bit", "wiener_stats_4k", "warp_error_4k"):  # informational encoder-side searches (single GPU)
-        r = {"cdef_search_4k_10bit": run_cdef_search, "wiener_stats_4k": run_wiener_stats, "warp_error_4k": run_warp_error}[args.workload](
+    if args.workload in ("cdef_search_4k_10bit", "wiener_stats_4k", "warp_error_4k", "int_pro_4k_8bit"):  # informational encoder-side searches (single GPU)
+        r = {"cdef_search_4k_10bit": run_cdef_search, "wiener_stats_4k": run_wiener_stats, "warp_error_4k": run_warp_error,
+             "int_pro_4k_8bit": run_int_pro}[args.workload](
             pkg, ctx, orc, args.steps, args.warmup)
         ctx.close()
-        first = r["full_search_64"] if "full_search_64" in r else (r["8bit_units64"] if "8bit_units64" in r else {"ms_per_frame": r["10bit"]["ms_per_call"]})
+        first = r["full_search_64"] if "full_search_64" in r else (r["8bit_units64"] if "8bit_units64" in r else (r["64x64"] if "64x64" in r else {"ms_per_frame": r["10bit"]["ms_per_call"]}))
         print(json.dumps(dict(r, metric=r["unit"], n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
                               vs_baseline=None, dtype="u16" if "cdef" in args.workload else "u8", data="synthetic",
                               ms_per_step=first["ms_per_frame"], config={"workload": r["workload"]})))

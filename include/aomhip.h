@@ -1239,6 +1239,17 @@ int aomhip_warp_error_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_f
 int aomhip_segmented_frame_error(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *cur, int cur_frame, int p_width, int p_height,
                                  const uint8_t *d_segment_map, int segment_map_stride, int64_t *d_error);
 
+/* The projection-based motion estimation of the real-time path: av1_int_pro_motion_estimation (av1/encoder/mcomp.c:1897-2105; the superblock's vector
+ * before variance partitioning, av1/encoder/var_based_part.c, and the non-RD mode search's estimate) for a batch of bw x bh blocks (16 .. 128 a side):
+ * aom_int_pro_row / aom_int_pro_col projections of the block and of the reference window of twice its size, vector_match on aom_vector_var per
+ * direction, then the SAD of the vector, the zero vector, the four neighbours and one diagonal.  Block i: bx / by its origin, ref_row / ref_col =
+ * ref_mv (1/8 pel), row_min .. col_max = x->mv_limits (full pel) -- both only feed the final clamp_mv; start_* unused.  d_best_mv[2 i], [2 i + 1] =
+ * xd->mi[0]->mv[0] (row, col in 1/8 pel), d_best_sad[i] = the return value.  Above 8 bits the reference measures the zero vector only (its vtable
+ * SAD, >> (bd - 8)); so does this.  The reference plane's border must hold what a block on the frame's edge reads -- half a block for the window, one more pixel for the last SADs: border >= max(bw, bh) / 2 + 1 --
+ * and the blocks lie inside the frame. */
+int aomhip_int_pro_motion_estimation_batch(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *ref, int ref_frame, int bw, int bh,
+                                           const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv, uint32_t *d_best_sad);
+
 /* ------------------------------------------------------------------ prediction from a scaled reference */
 
 /* av1_convolve_2d_scale / av1_highbd_convolve_2d_scale (av1/common/convolve.c; av1_rtcd_defs.pl:616-617,599-600): the predictor

@@ -256,6 +256,8 @@ void orc_warp_affine(const int32_t *mat, const void *ref, int elem16, int width,
 void orc_warp_affine_compound(const int32_t *mat, const void *ref, int elem16, int width, int height, int stride, void *pred, int p_col, int p_row, int p_width,
                               int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int round_0, int alpha, int beta, int gamma, int delta,
                               int do_average, int use_dist_wtd, int fwd_offset, int bck_offset, uint16_t *conv, int conv_stride);
+unsigned orc_int_pro_motion_estimation(const void *src, int src_stride, const void *ref, int ref_stride, int bw, int bh, int bd, const int *limits,
+                                       const int16_t *ref_mv, int16_t *out_mv);
 int orc_get_shear_params(const int32_t *mat, int16_t *abgd);
 int64_t orc_warp_error(const int32_t *mat, const int16_t *abgd, const void *ref, int elem16, int width, int height, int stride, const void *dst, int p_col,
                        int p_row, int p_width, int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int64_t best_error,
