@@ -195,6 +195,8 @@ _protos = {
     "aomhip_quantize_fp_qm_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_quantize_b_adaptive_qm_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_int_pro_motion_estimation_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "aomhip_vbp_8x8_stats_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _vp, _i]),
+    "aomhip_vbp_4x4_avg_plane": (C.c_int, [_vp, _PP, _i, _i, _i, _i, _vp, _i]),
     "aomhip_get_shear_params": (C.c_int, [_vp]),
     "aomhip_warp_error_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_segmented_frame_error": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _vp]),
@@ -575,6 +577,13 @@ class Context:
         """av1_int_pro_motion_estimation for a batch of blocks: (row, col) in 1/8 pel and the SAD"""
         check(lib.aomhip_int_pro_motion_estimation_batch(self.h, C.byref(src), src_frame, C.byref(ref), ref_frame, bw, bh, d_blocks, n_blocks, d_best_mv,
                                                          d_best_sad), "aomhip_int_pro_motion_estimation_batch")
+
+    def vbp_8x8_stats_plane(self, src, src_frame, ref, ref_frame, vis_w, vis_h, d_sum8, sum_stride, d_minmax16=None, minmax_stride=0):
+        check(lib.aomhip_vbp_8x8_stats_plane(self.h, C.byref(src), src_frame, C.byref(ref), ref_frame, vis_w, vis_h, d_sum8, sum_stride, d_minmax16,
+                                             minmax_stride), "aomhip_vbp_8x8_stats_plane")
+
+    def vbp_4x4_avg_plane(self, src, src_frame, vis_w, vis_h, border_offset_4x4, d_sum4, sum_stride):
+        check(lib.aomhip_vbp_4x4_avg_plane(self.h, C.byref(src), src_frame, vis_w, vis_h, border_offset_4x4, d_sum4, sum_stride), "aomhip_vbp_4x4_avg_plane")
 
     def warp_error_batch(self, ref, ref_frame, cur, cur_frame, ssx, ssy, d_models, n_models, p_col, p_row, p_width, p_height, d_seg, seg_stride, d_error):
         """av1_warp_error for n_models candidate models (shear values already in them: get_shear_params)"""

@@ -1129,6 +1129,14 @@ def run_int_pro(pkg, ctx, orc, steps, warmup):
             out["vectors_found"] = int(len({tuple(v) for v in mv.tolist()}))
         for d in (d_b, d_mv, d_sad):
             ctx.free(d)
+    # the variance tree's leaves on the same pair of planes (what follows the vector in av1_choose_var_based_partitioning)
+    n8x, n8y = W // 8, (H + 7) // 8
+    d_s8, d_mm, d_s4 = ctx.malloc(2 * n8x * n8y), ctx.malloc(4 * (W // 16) * ((H + 15) // 16)), ctx.malloc(2 * (W // 4) * (H // 4))
+    ms8 = kernel_avg_ms(ctx, lambda: ctx.vbp_8x8_stats_plane(ps, 0, pr, 0, W, H, d_s8, n8x, d_mm, W // 16), max(steps, 3))
+    ms4 = kernel_avg_ms(ctx, lambda: ctx.vbp_4x4_avg_plane(ps, 0, W, H, 0, d_s4, W // 4), max(steps, 3))
+    out["vbp_leaves"] = {"ms_8x8_stats": ms8, "GBps_8x8_stats": 2.0 * W * H / ms8 / 1e6, "ms_4x4_avg": ms4, "GBps_4x4_avg": 1.0 * W * H / ms4 / 1e6}
+    for d in (d_s8, d_mm, d_s4):
+        ctx.free(d)
     ctx.planes_free(ps); ctx.planes_free(pr)
     out["value"], out["unit"] = out["64x64"]["blocks_per_s"], "64x64 blocks/s"
     return out

@@ -1250,6 +1250,21 @@ int aomhip_segmented_frame_error(aomhip_ctx *ctx, const aomhip_planes *ref, int 
 int aomhip_int_pro_motion_estimation_batch(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *ref, int ref_frame, int bw, int bh,
                                            const aomhip_search_block *d_blocks, int n_blocks, int16_t *d_best_mv, uint32_t *d_best_sad);
 
+/* The leaves of the variance-based partitioning's tree (av1_choose_var_based_partitioning, av1/encoder/var_based_part.c) for a whole plane: `src` the
+ * frame being coded, `ref` the prediction the partitioning compares it with (the reference frame at the vector of aomhip_int_pro_motion_estimation_batch,
+ * or at zero); visible_width / _height = the frame's visible size (what pixels_wide / pixels_high measure from a superblock's origin).
+ *   aomhip_vbp_8x8_stats_plane   d_sum8x8[(y / 8) * sum_stride + x / 8] = aom_[highbd_]avg_8x8(src) - aom_[highbd_]avg_8x8(ref) of the 8 x 8 block at
+ *                                (x, y) -- fill_variance_8x8avg's sum_error (:266-344; sum_square_error is its square), 0 for a block that starts
+ *                                outside the visible part; d_minmax16x16 (may be NULL)[(y / 16) * minmax_stride + x / 16] = compute_minmax_8x8
+ *                                (:346-384) of the 16 x 16 block: the spread of its visible 8 x 8 blocks' (max - min) of |src - ref|
+ *   aomhip_vbp_4x4_avg_plane     key frames: d_sum4x4[(y / 4) * sum_stride + x / 4] = aom_[highbd_]avg_4x4(src) - 128, fill_variance_4x4avg's
+ *                                sum_error (:386-423), 0 from border_offset_4x4 before the visible edge on
+ * Blocks that start inside the visible part read up to 7 (3) pixels past it: the planes' borders (>= 8, >= 4) hold them, as the reference's do. */
+int aomhip_vbp_8x8_stats_plane(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, const aomhip_planes *ref, int ref_frame, int visible_width,
+                               int visible_height, int16_t *d_sum8x8, int sum_stride, int32_t *d_minmax16x16, int minmax_stride);
+int aomhip_vbp_4x4_avg_plane(aomhip_ctx *ctx, const aomhip_planes *src, int src_frame, int visible_width, int visible_height, int border_offset_4x4,
+                             int16_t *d_sum4x4, int sum_stride);
+
 /* ------------------------------------------------------------------ prediction from a scaled reference */
 
 /* av1_convolve_2d_scale / av1_highbd_convolve_2d_scale (av1/common/convolve.c; av1_rtcd_defs.pl:616-617,599-600): the predictor

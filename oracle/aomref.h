@@ -258,6 +258,11 @@ void orc_warp_affine_compound(const int32_t *mat, const void *ref, int elem16, i
                               int do_average, int use_dist_wtd, int fwd_offset, int bck_offset, uint16_t *conv, int conv_stride);
 unsigned orc_int_pro_motion_estimation(const void *src, int src_stride, const void *ref, int ref_stride, int bw, int bh, int bd, const int *limits,
                                        const int16_t *ref_mv, int16_t *out_mv);
+void orc_vbp_fill_8x8avg(const void *src, int src_stride, const void *dst, int dst_stride, int x16, int y16, int hbd, int pixels_wide, int pixels_high,
+                         int32_t *sum, uint32_t *sse);
+int orc_vbp_minmax_8x8(const void *src, int src_stride, const void *dst, int dst_stride, int x16, int y16, int hbd, int pixels_wide, int pixels_high);
+void orc_vbp_fill_4x4avg(const void *src, int src_stride, int x8, int y8, int hbd, int pixels_wide, int pixels_high, int border_offset_4x4, int32_t *sum,
+                         uint32_t *sse);
 int orc_get_shear_params(const int32_t *mat, int16_t *abgd);
 int64_t orc_warp_error(const int32_t *mat, const int16_t *abgd, const void *ref, int elem16, int width, int height, int stride, const void *dst, int p_col,
                        int p_row, int p_width, int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int64_t best_error,
