@@ -232,6 +232,7 @@ _protos = {
     "aomhip_sse_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_hadamard_batch": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_txb_init_levels_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64]),
+    "aomhip_get_nz_map_contexts_batch": (C.c_int, [_vp, _vp, _i64, _i, _vp, _i, _i, _vp, _vp, _i64]),
     "aomhip_scaled_pred_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "aomhip_scaled_pred_compound_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i]),
     "aomhip_warp_affine_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i]),
@@ -758,6 +759,10 @@ class Context:
 
     def hadamard_batch(self, d_res, stride, n, flavour, d_blocks, n_blocks, d_coeff=None, d_satd=None):
         check(lib.aomhip_hadamard_batch(self.h, d_res, stride, n, flavour, d_blocks, n_blocks, d_coeff, d_satd), "aomhip_hadamard_batch")
+
+    def get_nz_map_contexts_batch(self, d_levels, levels_pitch, tx_size, d_blocks, n_blocks, tx_type, d_eob, d_contexts, contexts_pitch):
+        check(lib.aomhip_get_nz_map_contexts_batch(self.h, d_levels, levels_pitch, tx_size, d_blocks, n_blocks, tx_type, d_eob, d_contexts, contexts_pitch),
+              "aomhip_get_nz_map_contexts_batch")
 
     def txb_init_levels_batch(self, d_coeff, w, h, d_off, n_blocks, d_levels, pitch):
         check(lib.aomhip_txb_init_levels_batch(self.h, d_coeff, w, h, d_off, n_blocks, d_levels, pitch), "aomhip_txb_init_levels_batch")

@@ -755,6 +755,55 @@ __global__ __launch_bounds__(256) void quant_lp_kernel(const int16_t *__restrict
   }
 }
 
+// av1_get_nz_map_contexts_c (av1/encoder/encodetxb.c:222-267): the context of every coefficient before the end of block, from the magnitudes of its
+// causal neighbours in the padded level map (av1_txb_init_levels' output: aomhip_txb_init_levels_batch) -- get_nz_mag / get_nz_map_ctx_from_stats
+// (av1/common/txb_common.h:150-224).  One wavefront per block, a lane per coefficient position: the scan index comes from iscan_pos, positions at
+// or past the end of block are not written (the reference's loop never reaches them); the 2-D position offsets by Nz_Map's rule
+// (av1_nz_map_ctx_offset; `rel` = sign(tx_w - tx_h) of the transform's own size: TX_64X32 / TX_32X64 code 32 x 32 coefficients with the
+// rectangular offsets).
+template <int KW, int KH>
+__global__ __launch_bounds__(256) void nz_map_contexts_kernel(const uint8_t *__restrict__ levels, int64_t levels_pitch, const aomhip_txb *__restrict__ blocks,
+                                                              int n_blocks, int uniform_type, int rel, const uint16_t *__restrict__ eobs,
+                                                              int8_t *__restrict__ contexts, int64_t contexts_pitch) {
+  constexpr int NC = KW * KH, BHL = KH == 4 ? 2 : (KH == 8 ? 3 : (KH == 16 ? 4 : 5));
+  const int lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (bi >= n_blocks) return;
+  const int tx_type = blocks ? blocks[bi].tx_type : uniform_type;
+  const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
+  const int tx_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 1 : 2);   // tx_type_to_class: H_* -> TX_CLASS_HORIZ (1), V_* -> TX_CLASS_VERT (2)
+  const int eob = eobs[bi];
+  const uint8_t *lv0 = levels + (int64_t)bi * levels_pitch;
+  int8_t *out = contexts + (int64_t)bi * contexts_pitch;
+  for (int pos = lane; pos < NC; pos += 64) {
+    const int col = pos >> BHL, row = pos & (KH - 1);
+    const int i = iscan_pos<KW, KH>(row, col, scan_class);
+    if (i >= eob) continue;
+    int ctx;
+    if (i == eob - 1) {
+      ctx = i == 0 ? 0 : (i <= NC / 8 ? 1 : (i <= NC / 4 ? 2 : 3));
+    } else {
+      const uint8_t *lv = lv0 + pos + (col << 2);   // get_padded_idx: TX_PAD_HOR = 4 entries after every column
+      auto c3 = [](uint8_t v) { return min((int)v, 3); };
+      int mag = c3(lv[KH + 4]) + c3(lv[1]);
+      if (tx_class == 0) mag += c3(lv[KH + 4 + 1]) + c3(lv[2 * KH + 8]) + c3(lv[2]);
+      else if (tx_class == 2) mag += c3(lv[2]) + c3(lv[3]) + c3(lv[4]);
+      else mag += c3(lv[2 * KH + 8]) + c3(lv[3 * KH + 12]) + c3(lv[4 * KH + 16]);
+      if ((tx_class | pos) == 0) {
+        ctx = 0;
+      } else {
+        ctx = min((mag + 1) >> 1, 4);
+        if (tx_class == 0) ctx += (rel < 0 && row < 2) ? 11 : ((rel > 0 && col < 2) ? 16 : (row + col < 2 ? 1 : (row + col < 4 ? 6 : 21)));
+        else {
+          const int k = tx_class == 1 ? col : row;
+          ctx += 26 + (k == 0 ? 0 : (k == 1 ? 5 : 10));   // SIG_COEF_CONTEXTS_2D + nz_map_ctx_offset_1d
+        }
+      }
+    }
+    out[pos] = (int8_t)ctx;
+  }
+}
+
 // aom_quantize_b* / aom_highbd_quantize_b* with the caller's own scan tables: what the rtcd-signature entry points
 // (aomhip_quantize_b ...) run -- those signatures carry `scan` / `iscan` pointers and a coefficient count instead of a
 // transform size and type.  The same quantize_one as the fused kernels; eob = 1 + max iscan[rc] over non-zero levels
@@ -1147,6 +1196,37 @@ int aomhip_quantize_lp_batch(aomhip_ctx *ctx, const int16_t *d_coeff, int tx_siz
   AOMHIP_LP(16, 32) AOMHIP_LP(32, 16) AOMHIP_LP(4, 16) AOMHIP_LP(16, 4) AOMHIP_LP(8, 32) AOMHIP_LP(32, 8)
 #undef AOMHIP_LP
   set_error("aomhip_quantize_lp_batch: no kernel for tx_size %d", tx_size);
+  return AOMHIP_ERR_INVALID;
+}
+
+int aomhip_get_nz_map_contexts_batch(aomhip_ctx *ctx, const uint8_t *d_levels, int64_t levels_pitch, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
+                                     int uniform_tx_type, const uint16_t *d_eob, int8_t *d_coeff_contexts, int64_t contexts_pitch) {
+  if (!ctx || tx_size < 0 || tx_size >= 19 || n_blocks < 0 || (n_blocks > 0 && (!d_levels || !d_eob || !d_coeff_contexts)) ||
+      (!d_blocks && (uniform_tx_type < 0 || uniform_tx_type > 15))) {
+    set_error("aomhip_get_nz_map_contexts_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  const int w = kTxW[tx_size], h = kTxH[tx_size];
+  const int kw = w > 32 ? 32 : w, kh = h > 32 ? 32 : h;   // av1_get_adjusted_tx_size
+  if (levels_pitch < (int64_t)(kh + 4) * (kw + 4) + 16 || contexts_pitch < (int64_t)kw * kh) {
+    set_error("aomhip_get_nz_map_contexts_batch: pitch too small for a %d x %d level map", kw, kh);
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  if (int rc = validate_txb_list(ctx, d_blocks, n_blocks, tx_size, false, true)) return rc;
+  const int rel = (w > h) - (w < h);
+  const dim3 grid((n_blocks + 3) / 4), block(256);
+#define AOMHIP_NZ(KW_, KH_)                                                                                                         \
+  if (kw == KW_ && kh == KH_) {                                                                                                     \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(nz_map_contexts_kernel<KW_, KH_>), grid, block, 0, ctx->stream, d_levels, levels_pitch, d_blocks, n_blocks, \
+                       uniform_tx_type, rel, d_eob, d_coeff_contexts, contexts_pitch);                                              \
+    AOMHIP_LAUNCH_CHECK();                                                                                                          \
+    return AOMHIP_OK;                                                                                                               \
+  }
+  AOMHIP_NZ(4, 4) AOMHIP_NZ(8, 8) AOMHIP_NZ(16, 16) AOMHIP_NZ(32, 32) AOMHIP_NZ(4, 8) AOMHIP_NZ(8, 4) AOMHIP_NZ(8, 16) AOMHIP_NZ(16, 8)
+  AOMHIP_NZ(16, 32) AOMHIP_NZ(32, 16) AOMHIP_NZ(4, 16) AOMHIP_NZ(16, 4) AOMHIP_NZ(8, 32) AOMHIP_NZ(32, 8)
+#undef AOMHIP_NZ
+  set_error("aomhip_get_nz_map_contexts_batch: no kernel for tx_size %d", tx_size);
   return AOMHIP_ERR_INVALID;
 }
 

@@ -1176,6 +1176,13 @@ int aomhip_hadamard_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residu
  * d_levels + i * levels_pitch. */
 int aomhip_txb_init_levels_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int width, int height, const uint32_t *d_coeff_offset, int n_blocks,
                                  uint8_t *d_levels, int64_t levels_pitch);
+/* av1_get_nz_map_contexts (av1/encoder/encodetxb.c:222-267; av1_rtcd_defs.pl) on those level maps: block i's map at d_levels + i * levels_pitch,
+ * its end of block d_eob[i], its transform type d_blocks[i].tx_type (or uniform_tx_type with d_blocks NULL: the type picks the scan order and the
+ * transform class); d_coeff_contexts + i * contexts_pitch receives coeff_contexts[pos] for the eob positions the scan visits, the rest is left
+ * as it was (the reference's loop does not reach it).  tx_size: the transform's own size (the 64-point sizes code 32 x 32 / 32 x 16 / 16 x 32
+ * coefficients: levels_pitch / contexts_pitch are sized for those). */
+int aomhip_get_nz_map_contexts_batch(aomhip_ctx *ctx, const uint8_t *d_levels, int64_t levels_pitch, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
+                                     int uniform_tx_type, const uint16_t *d_eob, int8_t *d_coeff_contexts, int64_t contexts_pitch);
 
 /* The wedge-mask helpers of pick_wedge / pick_interinter_wedge (av1/encoder/compound_type.c), which choose the wedge index and sign of the
  * masked compound whose motion search is aomhip_compound_single_motion_search_batch: av1_wedge_sse_from_residuals,

@@ -142,3 +142,48 @@ void orc_wedge_compute_delta_squares(int16_t *d, const int16_t *a, const int16_t
     d[i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
   }
 }
+
+/* av1_get_nz_map_contexts_c (av1/encoder/encodetxb.c:222-267) with get_nz_mag / get_nz_map_ctx_from_stats (av1/common/txb_common.h:150-224): the
+ * context of every coefficient before the end of block from the magnitudes of its causal neighbours in the padded level map.  The 2-D position
+ * offsets are Nz_Map's rule (av1_nz_map_ctx_offset, txb_common.c:18-360; oracle/gen_tables.py checks the rule against all 19 tables).
+ * tx_w / tx_h: the transform's own size (64 included); tx_class 0 2D, 1 HORIZ, 2 VERT.  Pinned by tests/golden/ref_eval_nzmap.npz. */
+static int clip3(int v) { return v > 3 ? 3 : v; }
+void orc_get_nz_map_contexts(const uint8_t *levels, const int16_t *scan, int eob, int tx_w, int tx_h, int tx_class, int8_t *coeff_contexts) {
+  const int w = tx_w > 32 ? 32 : tx_w, h = tx_h > 32 ? 32 : tx_h;   /* av1_get_adjusted_tx_size */
+  int bhl = 0;
+  while ((1 << bhl) < h) ++bhl;
+  for (int i = 0; i < eob; ++i) {
+    const int pos = scan[i];
+    int ctx;
+    if (i == eob - 1) {
+      ctx = i == 0 ? 0 : (i <= (w << bhl) / 8 ? 1 : (i <= (w << bhl) / 4 ? 2 : 3));
+    } else {
+      const uint8_t *lv = levels + pos + ((pos >> bhl) << 2);   /* get_padded_idx, TX_PAD_HOR_LOG2 */
+      int mag = clip3(lv[(1 << bhl) + 4]) + clip3(lv[1]);
+      if (tx_class == 0) mag += clip3(lv[(1 << bhl) + 4 + 1]) + clip3(lv[(2 << bhl) + (2 << 2)]) + clip3(lv[2]);
+      else if (tx_class == 2) mag += clip3(lv[2]) + clip3(lv[3]) + clip3(lv[4]);
+      else mag += clip3(lv[(2 << bhl) + (2 << 2)]) + clip3(lv[(3 << bhl) + (3 << 2)]) + clip3(lv[(4 << bhl) + (4 << 2)]);
+      const int col = pos >> bhl, row = pos - (col << bhl);
+      if ((tx_class | pos) == 0) {
+        ctx = 0;
+      } else {
+        ctx = (mag + 1) >> 1;
+        ctx = ctx > 4 ? 4 : ctx;
+        if (tx_class == 0) {
+          int off;
+          if (tx_w < tx_h && row < 2) off = 11;
+          else if (tx_w > tx_h && col < 2) off = 16;
+          else if (row + col < 2) off = 1;
+          else if (row + col < 4) off = 6;
+          else off = 21;
+          ctx += off;
+        } else {
+          const int k = tx_class == 1 ? col : row;   /* nz_map_ctx_offset_1d: SIG_COEF_CONTEXTS_2D (26) + 0, 5, 10, 10, .. */
+          ctx += 26 + (k == 0 ? 0 : (k == 1 ? 5 : 10));
+        }
+      }
+    }
+    coeff_contexts[pos] = (int8_t)ctx;
+  }
+}
+
