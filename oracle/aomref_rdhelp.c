@@ -187,3 +187,99 @@ void orc_get_nz_map_contexts(const uint8_t *levels, const int16_t *scan, int eob
   }
 }
 
+/* av1_cost_coeffs_txb (av1/encoder/txb_rdopt.c:450-544,603-622): the rate of a transform block's quantised coefficients under the level-map coder's
+ * cost tables -- everything the function adds except get_tx_type_cost (a table look-up on the block's mode, added by the caller).  `costs`: the
+ * LV_MAP_COEFF_COST of (transform-size context, plane type) as its 944 ints in declaration order (av1/encoder/block.h:173-195: txb_skip_cost[13][2],
+ * base_eob_cost[4][3], base_cost[42][8], eob_extra_cost[9][2], dc_sign_cost[3][2], lps_cost[21][26]) followed by LV_MAP_EOB_COST.eob_cost[2][11] of
+ * (eob_multi_size, plane type).  Pinned by tests/golden/ref_eval_txb_cost.npz. */
+enum { OFF_SKIP = 0, OFF_BASE_EOB = 26, OFF_BASE = 38, OFF_EOB_EXTRA = 374, OFF_DC_SIGN = 392, OFF_LPS = 398, OFF_EOB = 944 };
+static int golomb_cost(int abs_qc) {
+  if (abs_qc >= 1 + 2 + 12) {   /* NUM_BASE_LEVELS, COEFF_BASE_RANGE */
+    const int r = abs_qc - 12 - 2;
+    int length = 0;
+    while ((r >> length) > 0) ++length;   /* get_msb(r) + 1 */
+    return (2 * length - 1) * 512;        /* av1_cost_literal: 1 << AV1_PROB_COST_SHIFT */
+  }
+  return 0;
+}
+static int br_cost(int level, const int *lps) {
+  const int base_range = level - 1 - 2 < 12 ? level - 1 - 2 : 12;
+  return lps[base_range] + golomb_cost(level);
+}
+static int br_ctx(const uint8_t *levels, int c, int bhl, int tx_class) {
+  const int col = c >> bhl, row = c - (col << bhl), stride = (1 << bhl) + 4, pos = col * stride + row;
+  int mag = levels[pos + 1] + levels[pos + stride];
+  if (tx_class == 0) {
+    mag += levels[pos + stride + 1];
+    mag = (mag + 1) >> 1 < 6 ? (mag + 1) >> 1 : 6;
+    if (c == 0) return mag;
+    if (row < 2 && col < 2) return mag + 7;
+  } else if (tx_class == 1) {
+    mag += levels[pos + (stride << 1)];
+    mag = (mag + 1) >> 1 < 6 ? (mag + 1) >> 1 : 6;
+    if (c == 0) return mag;
+    if (col == 0) return mag + 7;
+  } else {
+    mag += levels[pos + 2];
+    mag = (mag + 1) >> 1 < 6 ? (mag + 1) >> 1 : 6;
+    if (c == 0) return mag;
+    if (row == 0) return mag + 7;
+  }
+  return mag + 14;
+}
+int orc_cost_coeffs_txb(const int32_t *qcoeff, int eob, int tx_w, int tx_h, int tx_class, const int16_t *scan, int txb_skip_ctx, int dc_sign_ctx,
+                        const int32_t *costs) {
+  if (eob == 0) return costs[OFF_SKIP + txb_skip_ctx * 2 + 1];
+  const int w = tx_w > 32 ? 32 : tx_w, h = tx_h > 32 ? 32 : tx_h;
+  int bhl = 0;
+  while ((1 << bhl) < h) ++bhl;
+  uint8_t levels[(32 + 4) * (32 + 4) + 16];
+  int8_t ctxs[1024];
+  orc_txb_init_levels(qcoeff, w, h, levels);
+  orc_get_nz_map_contexts(levels, scan, eob, tx_w, tx_h, tx_class, ctxs);
+  int cost = costs[OFF_SKIP + txb_skip_ctx * 2 + 0];
+  {   /* get_eob_cost (txb_rdopt_utils.h:66-83) with av1_get_eob_pos_token (encodetxb.c:100-130) */
+    static const int group_start[12] = { 0, 1, 2, 3, 5, 9, 17, 33, 65, 129, 257, 513 }, offset_bits[12] = { 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9 };
+    int t = 0;
+    while (t < 11 && eob >= group_start[t + 1]) ++t;   /* eob_to_pos_small / _large: the group whose start is the last one <= eob */
+    const int extra = eob - group_start[t];
+    cost += costs[OFF_EOB + (tx_class == 0 ? 0 : 1) * 11 + t - 1];
+    if (offset_bits[t] > 0) {
+      const int bit = (extra >> (offset_bits[t] - 1)) & 1;
+      cost += costs[OFF_EOB_EXTRA + (t - 3) * 2 + bit];
+      if (offset_bits[t] > 1) cost += (offset_bits[t] - 1) * 512;
+    }
+  }
+  int c = eob - 1;
+  {
+    const int pos = scan[c], v = qcoeff[pos], level = abs(v), coeff_ctx = ctxs[pos];
+    cost += costs[OFF_BASE_EOB + coeff_ctx * 3 + (level < 3 ? level : 3) - 1];
+    if (v) {
+      if (level > 2) {
+        const int col = pos >> bhl, row = pos - (col << bhl);
+        const int ctx = pos == 0 ? 0 : (((tx_class == 0 && row < 2 && col < 2) || (tx_class == 1 && col == 0) || (tx_class == 2 && row == 0)) ? 7 : 14);
+        cost += br_cost(level, costs + OFF_LPS + ctx * 26);
+      }
+      if (c) cost += 512;
+      else return cost + costs[OFF_DC_SIGN + dc_sign_ctx * 2 + (v < 0)];
+    }
+  }
+  for (c = eob - 2; c >= 1; --c) {
+    const int pos = scan[c], v = qcoeff[pos], level = abs(v);
+    cost += costs[OFF_BASE + ctxs[pos] * 8 + (level < 3 ? level : 3)];
+    if (v) {
+      cost += 512;
+      if (level > 2) cost += br_cost(level, costs + OFF_LPS + br_ctx(levels, pos, bhl, tx_class) * 26);
+    }
+  }
+  {
+    const int pos = scan[0], v = qcoeff[pos], level = abs(v);
+    cost += costs[OFF_BASE + ctxs[pos] * 8 + (level < 3 ? level : 3)];
+    if (v) {
+      cost += costs[OFF_DC_SIGN + dc_sign_ctx * 2 + (v < 0)];
+      if (level > 2) cost += br_cost(level, costs + OFF_LPS + br_ctx(levels, pos, bhl, tx_class) * 26);
+    }
+  }
+  return cost;
+}
+
