@@ -804,6 +804,107 @@ __global__ __launch_bounds__(256) void nz_map_contexts_kernel(const uint8_t *__r
   }
 }
 
+// av1_cost_coeffs_txb (av1/encoder/txb_rdopt.c:450-544,603-622): the rate of a block's quantised coefficients under the level-map coder's cost tables,
+// everything but get_tx_type_cost.  One wavefront per block, a lane per coefficient position: its scan index from iscan_pos, its level and its
+// neighbours' (min(|q|, 127), 0 outside the block: what the padded level map holds) straight from the coefficients, the three kinds of term of the
+// reference's loop -- last coefficient (base_eob_cost, get_br_ctx_eob), middle (base_cost on the nz-map context, the sign bit, get_br_ctx), first
+// (base_cost, dc_sign_cost) -- chosen by the index, a wavefront sum, and the block's two scalar terms (txb_skip_cost, get_eob_cost) on lane 0.
+// `costs`: LV_MAP_COEFF_COST's 944 ints in declaration order, then LV_MAP_EOB_COST.eob_cost[2][11].
+template <int KW, int KH>
+__global__ __launch_bounds__(256) void cost_coeffs_txb_kernel(const int32_t *__restrict__ qcoeff, const aomhip_txb *__restrict__ blocks, int n_blocks,
+                                                              int uniform_type, int rel, const uint16_t *__restrict__ eobs, const uint8_t *__restrict__ txb_ctx,
+                                                              const int32_t *__restrict__ costs, int32_t *__restrict__ out) {
+  constexpr int NC = KW * KH, BHL = KH == 4 ? 2 : (KH == 8 ? 3 : (KH == 16 ? 4 : 5));
+  constexpr int kSkip = 0, kBaseEob = 26, kBase = 38, kEobExtra = 374, kDcSign = 392, kLps = 398, kEob = 944;
+  const int lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (bi >= n_blocks) return;
+  const int tx_type = blocks ? blocks[bi].tx_type : uniform_type;
+  const int64_t off = blocks ? (int64_t)blocks[bi].out_offset : (int64_t)bi * NC;
+  const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
+  const int tx_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 1 : 2);
+  const int eob = eobs[bi], skip_ctx = txb_ctx[2 * bi], dc_ctx = txb_ctx[2 * bi + 1];
+  if (eob == 0) {
+    if (lane == 0) out[bi] = costs[kSkip + skip_ctx * 2 + 1];
+    return;
+  }
+  const int32_t *q = qcoeff + off;
+  auto L = [&](int r, int c) { return (r < KH && c < KW) ? min(abs(q[c * KH + r]), 127) : 0; };   // av1_txb_init_levels' entry (row r of column c)
+  auto br_cost = [&](int level, int ctx) {   // get_br_cost + get_golomb_cost (txb_rdopt_utils.h:85-97)
+    int c = costs[kLps + ctx * 26 + min(level - 3, 12)];
+    if (level >= 15) c += (2 * (32 - __builtin_clz(level - 14)) - 1) * 512;
+    return c;
+  };
+  int acc = 0;
+  for (int pos = lane; pos < NC; pos += 64) {
+    const int col = pos >> BHL, row = pos & (KH - 1);
+    const int i = iscan_pos<KW, KH>(row, col, scan_class);
+    if (i >= eob) continue;
+    const int v = q[pos], level = abs(v);
+    if (i == eob - 1) {
+      const int ctx = i == 0 ? 0 : (i <= NC / 8 ? 1 : (i <= NC / 4 ? 2 : 3));
+      acc += costs[kBaseEob + ctx * 3 + min(level, 3) - 1];
+      if (v) {
+        if (level > 2) {
+          const bool near = (tx_class == 0 && row < 2 && col < 2) || (tx_class == 1 && col == 0) || (tx_class == 2 && row == 0);
+          acc += br_cost(level, pos == 0 ? 0 : (near ? 7 : 14));   // get_br_ctx_eob
+        }
+        acc += i ? 512 : costs[kDcSign + dc_ctx * 2 + (v < 0)];
+      }
+      continue;
+    }
+    // the nz-map context (get_nz_mag / get_nz_map_ctx_from_stats, clipped at 3) and, for levels above NUM_BASE_LEVELS, get_br_ctx (unclipped)
+    const int l10 = L(row + 1, col), l01 = L(row, col + 1);
+    int mag = min(l10, 3) + min(l01, 3), bmag = l10 + l01;
+    if (tx_class == 0) {
+      const int l11 = L(row + 1, col + 1);
+      mag += min(l11, 3) + min(L(row, col + 2), 3) + min(L(row + 2, col), 3);
+      bmag += l11;
+    } else if (tx_class == 2) {
+      const int l20 = L(row + 2, col);
+      mag += min(l20, 3) + min(L(row + 3, col), 3) + min(L(row + 4, col), 3);
+      bmag += l20;
+    } else {
+      const int l02 = L(row, col + 2);
+      mag += min(l02, 3) + min(L(row, col + 3), 3) + min(L(row, col + 4), 3);
+      bmag += l02;
+    }
+    int ctx = 0;
+    if ((tx_class | pos) != 0) {
+      ctx = min((mag + 1) >> 1, 4);
+      if (tx_class == 0) ctx += (rel < 0 && row < 2) ? 11 : ((rel > 0 && col < 2) ? 16 : (row + col < 2 ? 1 : (row + col < 4 ? 6 : 21)));
+      else {
+        const int k = tx_class == 1 ? col : row;
+        ctx += 26 + (k == 0 ? 0 : (k == 1 ? 5 : 10));
+      }
+    }
+    acc += costs[kBase + ctx * 8 + min(level, 3)];
+    if (v) {
+      acc += i ? 512 : costs[kDcSign + dc_ctx * 2 + (v < 0)];
+      if (level > 2) {
+        int b = min((bmag + 1) >> 1, 6);
+        if (pos != 0) {
+          const bool near = (tx_class == 0 && row < 2 && col < 2) || (tx_class == 1 && col == 0) || (tx_class == 2 && row == 0);
+          b += near ? 7 : 14;
+        }
+        acc += br_cost(level, b);
+      }
+    }
+  }
+  for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
+  if (lane == 0) {
+    // get_eob_cost (txb_rdopt_utils.h:66-83) with av1_get_eob_pos_token: group t = the last one whose start (1, 2, 3, 5, 9, 17, ..) is <= eob
+    const int t = eob < 3 ? eob : 33 - __builtin_clz(eob - 1);
+    const int bits = t < 3 ? 0 : t - 2;   // av1_eob_offset_bits
+    int c = costs[kSkip + skip_ctx * 2] + costs[kEob + (tx_class == 0 ? 0 : 11) + t - 1];
+    if (bits > 0) {
+      const int extra = eob - ((1 << (t - 2)) + 1);   // av1_eob_group_start[t] for t >= 3
+      c += costs[kEobExtra + (t - 3) * 2 + ((extra >> (bits - 1)) & 1)] + (bits - 1) * 512;
+    }
+    out[bi] = acc + c;
+  }
+}
+
 // aom_quantize_b* / aom_highbd_quantize_b* with the caller's own scan tables: what the rtcd-signature entry points
 // (aomhip_quantize_b ...) run -- those signatures carry `scan` / `iscan` pointers and a coefficient count instead of a
 // transform size and type.  The same quantize_one as the fused kernels; eob = 1 + max iscan[rc] over non-zero levels
@@ -1227,6 +1328,33 @@ int aomhip_get_nz_map_contexts_batch(aomhip_ctx *ctx, const uint8_t *d_levels, i
   AOMHIP_NZ(16, 32) AOMHIP_NZ(32, 16) AOMHIP_NZ(4, 16) AOMHIP_NZ(16, 4) AOMHIP_NZ(8, 32) AOMHIP_NZ(32, 8)
 #undef AOMHIP_NZ
   set_error("aomhip_get_nz_map_contexts_batch: no kernel for tx_size %d", tx_size);
+  return AOMHIP_ERR_INVALID;
+}
+
+int aomhip_cost_coeffs_txb_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
+                                 const uint16_t *d_eob, const uint8_t *d_txb_ctx, const int32_t *d_costs, int32_t *d_cost) {
+  if (!ctx || tx_size < 0 || tx_size >= 19 || n_blocks < 0 || (n_blocks > 0 && (!d_qcoeff || !d_eob || !d_txb_ctx || !d_costs || !d_cost)) ||
+      (!d_blocks && (uniform_tx_type < 0 || uniform_tx_type > 15))) {
+    set_error("aomhip_cost_coeffs_txb_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  if (int rc = validate_txb_list(ctx, d_blocks, n_blocks, tx_size, false, true)) return rc;
+  const int w = kTxW[tx_size], h = kTxH[tx_size];
+  const int kw = w > 32 ? 32 : w, kh = h > 32 ? 32 : h;   // av1_get_adjusted_tx_size
+  const int rel = (w > h) - (w < h);
+  const dim3 grid((n_blocks + 3) / 4), block(256);
+#define AOMHIP_CC(KW_, KH_)                                                                                                         \
+  if (kw == KW_ && kh == KH_) {                                                                                                     \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(cost_coeffs_txb_kernel<KW_, KH_>), grid, block, 0, ctx->stream, d_qcoeff, d_blocks, n_blocks, uniform_tx_type, \
+                       rel, d_eob, d_txb_ctx, d_costs, d_cost);                                                                     \
+    AOMHIP_LAUNCH_CHECK();                                                                                                          \
+    return AOMHIP_OK;                                                                                                               \
+  }
+  AOMHIP_CC(4, 4) AOMHIP_CC(8, 8) AOMHIP_CC(16, 16) AOMHIP_CC(32, 32) AOMHIP_CC(4, 8) AOMHIP_CC(8, 4) AOMHIP_CC(8, 16) AOMHIP_CC(16, 8)
+  AOMHIP_CC(16, 32) AOMHIP_CC(32, 16) AOMHIP_CC(4, 16) AOMHIP_CC(16, 4) AOMHIP_CC(8, 32) AOMHIP_CC(32, 8)
+#undef AOMHIP_CC
+  set_error("aomhip_cost_coeffs_txb_batch: no kernel for tx_size %d", tx_size);
   return AOMHIP_ERR_INVALID;
 }
 

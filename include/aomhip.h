@@ -1183,6 +1183,17 @@ int aomhip_txb_init_levels_batch(aomhip_ctx *ctx, const int32_t *d_coeff, int wi
  * coefficients: levels_pitch / contexts_pitch are sized for those). */
 int aomhip_get_nz_map_contexts_batch(aomhip_ctx *ctx, const uint8_t *d_levels, int64_t levels_pitch, int tx_size, const aomhip_txb *d_blocks, int n_blocks,
                                      int uniform_tx_type, const uint16_t *d_eob, int8_t *d_coeff_contexts, int64_t contexts_pitch);
+/* av1_cost_coeffs_txb (av1/encoder/txb_rdopt.c:450-544,603-622): the rate of each block's quantised coefficients under the level-map coder's cost
+ * tables -- everything the function adds except get_tx_type_cost (a table look-up on the block's mode: the caller's addend).  d_qcoeff: the levels
+ * the quantisers above wrote (block i at d_blocks[i].out_offset, or i * n_coeffs), d_eob their ends of block, d_txb_ctx[2 i], [2 i + 1] =
+ * TXB_CTX.txb_skip_ctx / .dc_sign_ctx of block i (get_txb_ctx on the above / left entropy contexts: the host's state), d_costs = 966 ints:
+ * x->coeff_costs.coeff_costs[txs_ctx][plane_type] as its members in declaration order (LV_MAP_COEFF_COST, av1/encoder/block.h:173-195: txb_skip_cost
+ * [13][2], base_eob_cost[4][3], base_cost[42][8], eob_extra_cost[9][2], dc_sign_cost[3][2], lps_cost[21][26] -- a memcpy of the struct) followed by
+ * x->coeff_costs.eob_costs[txsize_log2_minus4[tx_size]][plane_type].eob_cost[2][11]; the tables follow the frame's CDFs, so they are uploaded when
+ * av1_fill_coeff_costs rebuilds them, one (transform-size context, plane type) pair per call like the transform size.  d_cost[i] = the rate;
+ * eob 0: txb_skip_cost[txb_skip_ctx][1]. */
+int aomhip_cost_coeffs_txb_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
+                                 const uint16_t *d_eob, const uint8_t *d_txb_ctx, const int32_t *d_costs, int32_t *d_cost);
 
 /* The wedge-mask helpers of pick_wedge / pick_interinter_wedge (av1/encoder/compound_type.c), which choose the wedge index and sign of the
  * masked compound whose motion search is aomhip_compound_single_motion_search_batch: av1_wedge_sse_from_residuals,
