@@ -21,6 +21,7 @@
 #include "common.h"
 #include "txfm_device.h"
 #include "quant_device.h"
+#include "txb_cost_table.inc"
 
 namespace aomhip {
 template <int LPB> __device__ __forceinline__ int64_t group_sum64(int64_t v) {
@@ -810,7 +811,11 @@ __global__ __launch_bounds__(256) void nz_map_contexts_kernel(const uint8_t *__r
 // reference's loop -- last coefficient (base_eob_cost, get_br_ctx_eob), middle (base_cost on the nz-map context, the sign bit, get_br_ctx), first
 // (base_cost, dc_sign_cost) -- chosen by the index, a wavefront sum, and the block's two scalar terms (txb_skip_cost, get_eob_cost) on lane 0.
 // `costs`: LV_MAP_COEFF_COST's 944 ints in declaration order, then LV_MAP_EOB_COST.eob_cost[2][11].
-template <int KW, int KH>
+// LAPLACIAN: av1_cost_coeffs_txb_laplacian with adjust_eob == 0 (:546-601,624-668) -- the same two scalar terms, per coefficient costLUT[min(|q|, 14)]
+// (the last one (|q| - 1) << 11) and const_term + loge_par per position.
+__device__ const int kTxbCostLut[15] = AOMHIP_TXB_COST_LUT;
+
+template <int KW, int KH, bool LAPLACIAN = false>
 __global__ __launch_bounds__(256) void cost_coeffs_txb_kernel(const int32_t *__restrict__ qcoeff, const aomhip_txb *__restrict__ blocks, int n_blocks,
                                                               int uniform_type, int rel, const uint16_t *__restrict__ eobs, const uint8_t *__restrict__ txb_ctx,
                                                               const int32_t *__restrict__ costs, int32_t *__restrict__ out) {
@@ -841,6 +846,10 @@ __global__ __launch_bounds__(256) void cost_coeffs_txb_kernel(const int32_t *__r
     const int i = iscan_pos<KW, KH>(row, col, scan_class);
     if (i >= eob) continue;
     const int v = q[pos], level = abs(v);
+    if constexpr (LAPLACIAN) {
+      acc += i == eob - 1 ? (level - 1) * 2048 : kTxbCostLut[min(level, 14)];
+      continue;
+    }
     if (i == eob - 1) {
       const int ctx = i == 0 ? 0 : (i <= NC / 8 ? 1 : (i <= NC / 4 ? 2 : 3));
       acc += costs[kBaseEob + ctx * 3 + min(level, 3) - 1];
@@ -901,7 +910,7 @@ __global__ __launch_bounds__(256) void cost_coeffs_txb_kernel(const int32_t *__r
       const int extra = eob - ((1 << (t - 2)) + 1);   // av1_eob_group_start[t] for t >= 3
       c += costs[kEobExtra + (t - 3) * 2 + ((extra >> (bits - 1)) & 1)] + (bits - 1) * 512;
     }
-    out[bi] = acc + c;
+    out[bi] = acc + c + (LAPLACIAN ? (512 + 739) * (eob - 1) : 0);   // const_term + loge_par
   }
 }
 
@@ -1331,8 +1340,8 @@ int aomhip_get_nz_map_contexts_batch(aomhip_ctx *ctx, const uint8_t *d_levels, i
   return AOMHIP_ERR_INVALID;
 }
 
-int aomhip_cost_coeffs_txb_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
-                                 const uint16_t *d_eob, const uint8_t *d_txb_ctx, const int32_t *d_costs, int32_t *d_cost) {
+static int cost_coeffs_launch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
+                              const uint16_t *d_eob, const uint8_t *d_txb_ctx, const int32_t *d_costs, int32_t *d_cost, bool laplacian) {
   if (!ctx || tx_size < 0 || tx_size >= 19 || n_blocks < 0 || (n_blocks > 0 && (!d_qcoeff || !d_eob || !d_txb_ctx || !d_costs || !d_cost)) ||
       (!d_blocks && (uniform_tx_type < 0 || uniform_tx_type > 15))) {
     set_error("aomhip_cost_coeffs_txb_batch: invalid argument");
@@ -1346,8 +1355,12 @@ int aomhip_cost_coeffs_txb_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int t
   const dim3 grid((n_blocks + 3) / 4), block(256);
 #define AOMHIP_CC(KW_, KH_)                                                                                                         \
   if (kw == KW_ && kh == KH_) {                                                                                                     \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(cost_coeffs_txb_kernel<KW_, KH_>), grid, block, 0, ctx->stream, d_qcoeff, d_blocks, n_blocks, uniform_tx_type, \
-                       rel, d_eob, d_txb_ctx, d_costs, d_cost);                                                                     \
+    if (laplacian)                                                                                                                  \
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(cost_coeffs_txb_kernel<KW_, KH_, true>), grid, block, 0, ctx->stream, d_qcoeff, d_blocks, n_blocks,        \
+                         uniform_tx_type, rel, d_eob, d_txb_ctx, d_costs, d_cost);                                                  \
+    else                                                                                                                            \
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(cost_coeffs_txb_kernel<KW_, KH_, false>), grid, block, 0, ctx->stream, d_qcoeff, d_blocks, n_blocks,       \
+                         uniform_tx_type, rel, d_eob, d_txb_ctx, d_costs, d_cost);                                                  \
     AOMHIP_LAUNCH_CHECK();                                                                                                          \
     return AOMHIP_OK;                                                                                                               \
   }
@@ -1356,6 +1369,17 @@ int aomhip_cost_coeffs_txb_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int t
 #undef AOMHIP_CC
   set_error("aomhip_cost_coeffs_txb_batch: no kernel for tx_size %d", tx_size);
   return AOMHIP_ERR_INVALID;
+}
+
+int aomhip_cost_coeffs_txb_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
+                                 const uint16_t *d_eob, const uint8_t *d_txb_ctx, const int32_t *d_costs, int32_t *d_cost) {
+  return cost_coeffs_launch(ctx, d_qcoeff, tx_size, d_blocks, n_blocks, uniform_tx_type, d_eob, d_txb_ctx, d_costs, d_cost, false);
+}
+
+// av1_cost_coeffs_txb_laplacian (adjust_eob == 0): the transform-type search's estimate
+int aomhip_cost_coeffs_txb_laplacian_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
+                                           const uint16_t *d_eob, const uint8_t *d_txb_ctx, const int32_t *d_costs, int32_t *d_cost) {
+  return cost_coeffs_launch(ctx, d_qcoeff, tx_size, d_blocks, n_blocks, uniform_tx_type, d_eob, d_txb_ctx, d_costs, d_cost, true);
 }
 
 // av1_xform_quant with quantisation matrices: the forward transform by the fused kernel (its own flat-matrix levels are overwritten), then

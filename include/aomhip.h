@@ -1194,6 +1194,11 @@ int aomhip_get_nz_map_contexts_batch(aomhip_ctx *ctx, const uint8_t *d_levels, i
  * eob 0: txb_skip_cost[txb_skip_ctx][1]. */
 int aomhip_cost_coeffs_txb_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
                                  const uint16_t *d_eob, const uint8_t *d_txb_ctx, const int32_t *d_costs, int32_t *d_cost);
+/* av1_cost_coeffs_txb_laplacian with adjust_eob == 0 (av1/encoder/txb_rdopt.c:546-601,624-668; the transform-type search's rate, tx_search.c:1176-1299):
+ * the same arguments and the same two scalar terms; per coefficient costLUT[min(|q|, 14)] (the last one (|q| - 1) << 11) and const_term + loge_par
+ * per position (txb_rdopt_utils.h:31-37).  d_txb_ctx's dc_sign_ctx is not read. */
+int aomhip_cost_coeffs_txb_laplacian_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
+                                           const uint16_t *d_eob, const uint8_t *d_txb_ctx, const int32_t *d_costs, int32_t *d_cost);
 
 /* The wedge-mask helpers of pick_wedge / pick_interinter_wedge (av1/encoder/compound_type.c), which choose the wedge index and sign of the
  * masked compound whose motion search is aomhip_compound_single_motion_search_batch: av1_wedge_sse_from_residuals,

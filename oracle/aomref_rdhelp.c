@@ -283,3 +283,30 @@ int orc_cost_coeffs_txb(const int32_t *qcoeff, int eob, int tx_w, int tx_h, int 
   return cost;
 }
 
+/* av1_cost_coeffs_txb_laplacian with adjust_eob == 0 (av1/encoder/txb_rdopt.c:546-601,624-668): the transform-type search's cheap rate -- the skip and
+ * end-of-block terms of the exact form, then per coefficient a table entry by its level (the last one: (|q| - 1) << 11) and a constant per position.
+ * Without get_tx_type_cost, like orc_cost_coeffs_txb; the same `costs` layout. */
+#include "aomref_txb_cost.inc"
+int orc_cost_coeffs_txb_laplacian(const int32_t *qcoeff, int eob, int tx_class, const int16_t *scan, int txb_skip_ctx, const int32_t *costs) {
+  static const int lut[15] = AOMHIP_TXB_COST_LUT;
+  if (eob == 0) return costs[OFF_SKIP + txb_skip_ctx * 2 + 1];
+  int cost = costs[OFF_SKIP + txb_skip_ctx * 2 + 0];
+  {
+    static const int group_start[12] = { 0, 1, 2, 3, 5, 9, 17, 33, 65, 129, 257, 513 }, offset_bits[12] = { 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9 };
+    int t = 0;
+    while (t < 11 && eob >= group_start[t + 1]) ++t;
+    const int extra = eob - group_start[t];
+    cost += costs[OFF_EOB + (tx_class == 0 ? 0 : 1) * 11 + t - 1];
+    if (offset_bits[t] > 0) {
+      cost += costs[OFF_EOB_EXTRA + (t - 3) * 2 + ((extra >> (offset_bits[t] - 1)) & 1)];
+      if (offset_bits[t] > 1) cost += (offset_bits[t] - 1) * 512;
+    }
+  }
+  cost += (abs(qcoeff[scan[eob - 1]]) - 1) * 2048;   /* << (AV1_PROB_COST_SHIFT + 2) */
+  for (int c = eob - 2; c >= 0; --c) {
+    const int v = abs(qcoeff[scan[c]]);
+    cost += lut[v < 14 ? v : 14];
+  }
+  return cost + (512 + 739) * (eob - 1);   /* const_term + loge_par */
+}
+

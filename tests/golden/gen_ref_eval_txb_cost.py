@@ -3,7 +3,8 @@
 
   ref_eval_txb_cost.npz   warehouse_efficients_txb (av1/encoder/txb_rdopt.c:450-544: what av1_cost_coeffs_txb returns for eob > 0) with get_eob_cost /
                           get_br_cost / get_golomb_cost (txb_rdopt_utils.h:66-97), av1_get_eob_pos_token, av1_txb_init_levels_c, av1_get_nz_map_contexts_c
-                          (encodetxb.c:100-130,222-267) and get_br_ctx[_eob] (av1/common/txb_common.h:90-135) under it, on random cost tables.
+                          (encodetxb.c:100-130,222-267) and get_br_ctx[_eob] (av1/common/txb_common.h:90-135) under it, on random cost tables;
+                          and warehouse_efficients_txb_laplacian + av1_cost_coeffs_txb_estimate (:546-601) on the same blocks and tables (costLUT, txb_rdopt_utils.h:31-37).
 
 Supplied as inputs / adaptations:
   * get_tx_type_cost returns 0 (a table look-up on the block's mode: the caller's addend); get_scan returns the scan order of (tx_size, tx_type) built
@@ -53,7 +54,7 @@ def main():
     blk = open(REF + "av1/encoder/block.h").read()
     ev.load_text(re.search(r"typedef struct \{\s*//! Cost to skip txfm for the current txfm block\..*?\} LV_MAP_EOB_COST;", blk, re.S).group(0), "block.h:LV_MAP_*")
     ev.load_text("typedef struct { LV_MAP_COEFF_COST coeff_costs[TX_SIZES][PLANE_TYPES]; LV_MAP_EOB_COST eob_costs[7][2]; } CoeffCosts;\n"
-                 "typedef struct macroblock { CoeffCosts coeff_costs; } MACROBLOCK;\nstruct macroblock_plane { tran_low_t *qcoeff; };\n"
+                 "struct macroblock_plane { tran_low_t *qcoeff; uint16_t *eobs; };\ntypedef struct macroblock { CoeffCosts coeff_costs; struct macroblock_plane plane[3]; } MACROBLOCK;\n"
                  "typedef struct macroblockd { int unused; } MACROBLOCKD;\n", "block.h:views")
     text = open(REF + "av1/encoder/encodetxb.c").read()
     for pat in (r"static const int8_t eob_to_pos_small\[33\] = \{.*?\};", r"static const int8_t eob_to_pos_large\[17\] = \{.*?\};",
@@ -62,6 +63,8 @@ def main():
         ev.load_text(re.search(pat, text, re.S).group(0), "encodetxb.c:" + pat[:30])
     ev.define("av1_txb_init_levels", "av1_txb_init_levels_c"); ev.define("av1_get_nz_map_contexts", "av1_get_nz_map_contexts_c")
     utl = open(REF + "av1/encoder/txb_rdopt_utils.h").read()
+    ev.load_text(re.search(r"static const int costLUT\[15\] = \{.*?\};", utl, re.S).group(0) + "\n" + re.search(r"static const int const_term = [^;]*;", utl).group(0) + "\n"
+                 + re.search(r"static const int loge_par = [^;]*;", utl).group(0) + "\n", "txb_rdopt_utils.h:costLUT")
     for pat in (r"static int get_eob_cost\([^;{]*\)\s*\{.*?\n}\n", r"static INLINE int get_golomb_cost\([^;{]*\)\s*\{.*?\n}\n", r"static INLINE int get_br_cost\([^;{]*\)\s*\{.*?\n}\n"):
         ev.load_text(re.search(pat, utl, re.S).group(0), "txb_rdopt_utils.h:" + pat[:30])
     state = {}
@@ -69,6 +72,8 @@ def main():
     ev.interp.pycalls["get_scan"] = lambda it, a: (state["scan_order"], R.PTR)
     rd = open(REF + "av1/encoder/txb_rdopt.c").read()
     ev.load_text(re.search(r"static AOM_FORCE_INLINE int warehouse_efficients_txb\([^;{]*\)\s*\{.*?\n}\n", rd, re.S).group(0), "txb_rdopt.c:warehouse_efficients_txb")
+    for pat in (r"int av1_cost_coeffs_txb_estimate\([^;{]*\)\s*\{.*?\n}\n", r"static AOM_FORCE_INLINE int warehouse_efficients_txb_laplacian\([^;{]*\)\s*\{.*?\n}\n"):
+        ev.load_text(re.search(pat, rd, re.S).group(0), "txb_rdopt.c:" + pat[:40])
     bad = [s for s in ev.skipped if s[0].startswith(("txb_rdopt", "encodetxb.c", "block.h"))]
     assert not bad, bad
     rng = np.random.default_rng(20261114)
@@ -114,9 +119,15 @@ def main():
                 ev.set(tc, "txb_skip_ctx", skip_ctx); ev.set(tc, "dc_sign_ctx", dc_ctx)
                 xd = ev.new("MACROBLOCKD")
                 cost = ev.call("warehouse_efficients_txb", x, plane_type, 0, tx_size, tc, p, eob, plane_type, cc, xd, tx_type, tx_class, 0)
+                # the Laplacian form on the same block (plane 0: av1_cost_coeffs_txb_estimate asserts it): x->plane[0] carries the coefficients and the eob
+                ev.set(x, "plane[0].qcoeff", ev.array(coeff, "int32_t")); ev.set(x, "plane[0].eobs", ev.array([eob], "uint16_t"))
+                for i in range(2):
+                    for j in range(11):
+                        ev.set(x, "coeff_costs.eob_costs[%d][0].eob_cost[%d][%d]" % (ems, i, j), int(costs[N_COSTS + i * 11 + j]))
+                lap = ev.call("warehouse_efficients_txb_laplacian", x, 0, 0, tx_size, tc, eob, 0, cc, xd, tx_type, tx_class, 0)
                 arrays["c%d" % k], arrays["t%d" % k] = coeff.astype(np.int32), costs.astype(np.int32)
                 cases.append({"k": k, "tx_size": tx_size, "tx_type": tx_type, "tx_class": tx_class, "eob": eob, "txb_skip_ctx": skip_ctx, "dc_sign_ctx": dc_ctx,
-                              "cost": int(cost)})
+                              "cost": int(cost), "cost_laplacian": int(lap)})
                 k += 1
         print(tx_size, k, flush=True)
     save("ref_eval_txb_cost.npz", arrays, cases)

@@ -26,6 +26,22 @@ def oracle_cost(coeff, eob, tx_size, tx_type, skip_ctx, dc_ctx, costs):
                                            C.c_void_p(cs.ctypes.data)))
 
 
+def oracle_cost_laplacian(coeff, eob, tx_size, tx_type, skip_ctx, costs):
+    scan, _ = orc.get_scan(tx_size, tx_type)
+    sc = np.ascontiguousarray(scan, np.int16)
+    tx_class = 0 if tx_type < 10 else (2 if tx_type % 2 == 0 else 1)
+    co, cs = np.ascontiguousarray(coeff, np.int32), np.ascontiguousarray(costs, np.int32)
+    return int(orc.lib.orc_cost_coeffs_txb_laplacian(C.c_void_p(co.ctypes.data), eob, tx_class, C.c_void_p(sc.ctypes.data), skip_ctx, C.c_void_p(cs.ctypes.data)))
+
+
+def test_laplacian_rate_matches_the_reference():
+    z, cases = load()
+    for c in cases:
+        got = oracle_cost_laplacian(z["c%d" % c["k"]], c["eob"], c["tx_size"], c["tx_type"], c["txb_skip_ctx"], z["t%d" % c["k"]])
+        assert got == c["cost_laplacian"], c
+    assert len({c["cost_laplacian"] for c in cases}) > 90
+
+
 def test_rate_matches_the_reference():
     z, cases = load()
     assert len(cases) >= 99

@@ -1,10 +1,10 @@
-"""aomhip_cost_coeffs_txb_batch (csrc/xform_quant.hip) against (a) warehouse_efficients_txb interpreted on random cost tables
+"""aomhip_cost_coeffs_txb_batch / _laplacian_batch (csrc/xform_quant.hip) against (a) warehouse_efficients_txb interpreted on random cost tables
 (tests/golden/ref_eval_txb_cost.npz, directly) and (b) the oracle on lists of blocks with mixed transform types."""
 import numpy as np
 import pytest
 
 from test_golden_nzmap import TXH, TXW
-from test_golden_txb_cost import load, oracle_cost
+from test_golden_txb_cost import load, oracle_cost, oracle_cost_laplacian
 
 pytestmark = pytest.mark.gpu
 
@@ -17,6 +17,8 @@ def test_device_matches_the_interpreted_function(hip, ctx):
         d_e, d_x, d_o = ctx.to_device(np.array([c["eob"]], np.uint16)), ctx.to_device(np.array([c["txb_skip_ctx"], c["dc_sign_ctx"]], np.uint8)), ctx.malloc(4)
         ctx.cost_coeffs_txb_batch(d_q, c["tx_size"], None, 1, c["tx_type"], d_e, d_x, d_t, d_o)
         assert int(ctx.from_device(d_o, (1,), np.int32)[0]) == c["cost"], c
+        ctx.cost_coeffs_txb_batch(d_q, c["tx_size"], None, 1, c["tx_type"], d_e, d_x, d_t, d_o, laplacian=True)
+        assert int(ctx.from_device(d_o, (1,), np.int32)[0]) == c["cost_laplacian"], c
         for d in (d_q, d_t, d_e, d_x, d_o):
             ctx.free(d)
 
@@ -57,6 +59,10 @@ def test_lists_of_blocks_equal_the_oracle(hip, oracle, ctx, tx_size):
     for i in range(nb):
         want = oracle_cost(coeff[i], int(eobs[i]), tx_size, int(types[i]), int(ctxs[i, 0]), int(ctxs[i, 1]), costs)
         assert int(got[i]) == want, (i, types[i], eobs[i])
+    ctx.cost_coeffs_txb_batch(d_q, tx_size, d_b, nb, 0, d_e, d_x, d_t, d_o, laplacian=True)
+    got = ctx.from_device(d_o, (nb,), np.int32)
+    for i in range(nb):
+        assert int(got[i]) == oracle_cost_laplacian(coeff[i], int(eobs[i]), tx_size, int(types[i]), int(ctxs[i, 0]), costs), (i, types[i], eobs[i])
     for d in (d_q, d_b, d_t, d_e, d_x, d_o):
         ctx.free(d)
 
