@@ -233,6 +233,7 @@ _protos = {
     "aomhip_hadamard_batch": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_txb_init_levels_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64]),
     "aomhip_cost_coeffs_txb_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "aomhip_txb_entropy_context_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "aomhip_cost_coeffs_txb_laplacian_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "aomhip_get_nz_map_contexts_batch": (C.c_int, [_vp, _vp, _i64, _i, _vp, _i, _i, _vp, _vp, _i64]),
     "aomhip_scaled_pred_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),
@@ -766,6 +767,9 @@ class Context:
         """av1_cost_coeffs_txb[_laplacian] minus get_tx_type_cost: d_costs = LV_MAP_COEFF_COST (944 ints) + eob_cost[2][11]"""
         f = lib.aomhip_cost_coeffs_txb_laplacian_batch if laplacian else lib.aomhip_cost_coeffs_txb_batch
         check(f(self.h, d_qcoeff, tx_size, d_blocks, n_blocks, tx_type, d_eob, d_txb_ctx, d_costs, d_cost), "aomhip_cost_coeffs_txb_batch")
+
+    def txb_entropy_context_batch(self, d_qcoeff, tx_size, d_blocks, n_blocks, tx_type, d_eob, d_out):
+        check(lib.aomhip_txb_entropy_context_batch(self.h, d_qcoeff, tx_size, d_blocks, n_blocks, tx_type, d_eob, d_out), "aomhip_txb_entropy_context_batch")
 
     def get_nz_map_contexts_batch(self, d_levels, levels_pitch, tx_size, d_blocks, n_blocks, tx_type, d_eob, d_contexts, contexts_pitch):
         check(lib.aomhip_get_nz_map_contexts_batch(self.h, d_levels, levels_pitch, tx_size, d_blocks, n_blocks, tx_type, d_eob, d_contexts, contexts_pitch),

@@ -914,6 +914,37 @@ __global__ __launch_bounds__(256) void cost_coeffs_txb_kernel(const int32_t *__r
   }
 }
 
+// av1_get_txb_entropy_context (av1/encoder/encodetxb.c:451-467): what a coded block leaves in the above / left entropy contexts -- min(sum of the levels
+// before the end of block, COEFF_CONTEXT_MASK) with the DC coefficient's sign above it (set_dc_sign).  The reference's early exit only bounds its sum:
+// a lane per position adds min(|q|, 8).
+template <int KW, int KH>
+__global__ __launch_bounds__(256) void txb_entropy_context_kernel(const int32_t *__restrict__ qcoeff, const aomhip_txb *__restrict__ blocks, int n_blocks,
+                                                                  int uniform_type, const uint16_t *__restrict__ eobs, uint8_t *__restrict__ out) {
+  constexpr int NC = KW * KH;
+  const int lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (bi >= n_blocks) return;
+  const int tx_type = blocks ? blocks[bi].tx_type : uniform_type;
+  const int64_t off = blocks ? (int64_t)blocks[bi].out_offset : (int64_t)bi * NC;
+  const int scan_class = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
+  const int eob = eobs[bi];
+  const int32_t *q = qcoeff + off;
+  int acc = 0;
+  for (int pos = lane; pos < NC && eob; pos += 64)
+    if (iscan_pos<KW, KH>(pos % KH, pos / KH, scan_class) < eob) acc += min(abs(q[pos]), 8);
+  for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
+  if (lane == 0) {
+    int cul = 0;
+    if (eob) {
+      cul = min(acc, 7);
+      const int dc = q[0];
+      if (dc < 0) cul |= 1 << 3;          // COEFF_CONTEXT_BITS
+      else if (dc > 0) cul += 2 << 3;
+    }
+    out[bi] = (uint8_t)cul;
+  }
+}
+
 // aom_quantize_b* / aom_highbd_quantize_b* with the caller's own scan tables: what the rtcd-signature entry points
 // (aomhip_quantize_b ...) run -- those signatures carry `scan` / `iscan` pointers and a coefficient count instead of a
 // transform size and type.  The same quantize_one as the fused kernels; eob = 1 + max iscan[rc] over non-zero levels
@@ -1380,6 +1411,32 @@ int aomhip_cost_coeffs_txb_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int t
 int aomhip_cost_coeffs_txb_laplacian_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
                                            const uint16_t *d_eob, const uint8_t *d_txb_ctx, const int32_t *d_costs, int32_t *d_cost) {
   return cost_coeffs_launch(ctx, d_qcoeff, tx_size, d_blocks, n_blocks, uniform_tx_type, d_eob, d_txb_ctx, d_costs, d_cost, true);
+}
+
+int aomhip_txb_entropy_context_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
+                                     const uint16_t *d_eob, uint8_t *d_entropy_ctx) {
+  if (!ctx || tx_size < 0 || tx_size >= 19 || n_blocks < 0 || (n_blocks > 0 && (!d_qcoeff || !d_eob || !d_entropy_ctx)) ||
+      (!d_blocks && (uniform_tx_type < 0 || uniform_tx_type > 15))) {
+    set_error("aomhip_txb_entropy_context_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  if (int rc = validate_txb_list(ctx, d_blocks, n_blocks, tx_size, false, true)) return rc;
+  const int w = kTxW[tx_size], h = kTxH[tx_size];
+  const int kw = w > 32 ? 32 : w, kh = h > 32 ? 32 : h;
+  const dim3 grid((n_blocks + 3) / 4), block(256);
+#define AOMHIP_EC(KW_, KH_)                                                                                                         \
+  if (kw == KW_ && kh == KH_) {                                                                                                     \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(txb_entropy_context_kernel<KW_, KH_>), grid, block, 0, ctx->stream, d_qcoeff, d_blocks, n_blocks, uniform_tx_type, \
+                       d_eob, d_entropy_ctx);                                                                                       \
+    AOMHIP_LAUNCH_CHECK();                                                                                                          \
+    return AOMHIP_OK;                                                                                                               \
+  }
+  AOMHIP_EC(4, 4) AOMHIP_EC(8, 8) AOMHIP_EC(16, 16) AOMHIP_EC(32, 32) AOMHIP_EC(4, 8) AOMHIP_EC(8, 4) AOMHIP_EC(8, 16) AOMHIP_EC(16, 8)
+  AOMHIP_EC(16, 32) AOMHIP_EC(32, 16) AOMHIP_EC(4, 16) AOMHIP_EC(16, 4) AOMHIP_EC(8, 32) AOMHIP_EC(32, 8)
+#undef AOMHIP_EC
+  set_error("aomhip_txb_entropy_context_batch: no kernel for tx_size %d", tx_size);
+  return AOMHIP_ERR_INVALID;
 }
 
 // av1_xform_quant with quantisation matrices: the forward transform by the fused kernel (its own flat-matrix levels are overwritten), then

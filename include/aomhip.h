@@ -1199,6 +1199,10 @@ int aomhip_cost_coeffs_txb_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int t
  * per position (txb_rdopt_utils.h:31-37).  d_txb_ctx's dc_sign_ctx is not read. */
 int aomhip_cost_coeffs_txb_laplacian_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
                                            const uint16_t *d_eob, const uint8_t *d_txb_ctx, const int32_t *d_costs, int32_t *d_cost);
+/* av1_get_txb_entropy_context (av1/encoder/encodetxb.c:451-467) of the same blocks: d_entropy_ctx[i] = the value av1_set_entropy_contexts then writes
+ * into the above / left context arrays -- min(sum of the levels, 7) | the DC sign bits; the arrays and their update order stay with the host. */
+int aomhip_txb_entropy_context_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
+                                     const uint16_t *d_eob, uint8_t *d_entropy_ctx);
 
 /* The wedge-mask helpers of pick_wedge / pick_interinter_wedge (av1/encoder/compound_type.c), which choose the wedge index and sign of the
  * masked compound whose motion search is aomhip_compound_single_motion_search_batch: av1_wedge_sse_from_residuals,

@@ -310,3 +310,18 @@ int orc_cost_coeffs_txb_laplacian(const int32_t *qcoeff, int eob, int tx_class, 
   return cost + (512 + 739) * (eob - 1);   /* const_term + loge_par */
 }
 
+/* av1_get_txb_entropy_context (av1/encoder/encodetxb.c:451-467): what a coded transform block leaves in the above / left entropy contexts -- the sum of
+ * its levels saturated at COEFF_CONTEXT_MASK (7), the DC coefficient's sign in the bits above (set_dc_sign, txb_common.h:274-279). */
+int orc_get_txb_entropy_context(const int32_t *qcoeff, const int16_t *scan, int eob) {
+  if (eob == 0) return 0;
+  int cul = 0;
+  for (int c = 0; c < eob; ++c) {
+    cul += abs(qcoeff[scan[c]]);
+    if (cul > 7) break;
+  }
+  cul = cul < 7 ? cul : 7;
+  if (qcoeff[0] < 0) cul |= 1 << 3;
+  else if (qcoeff[0] > 0) cul += 2 << 3;
+  return cul & 255;
+}
+

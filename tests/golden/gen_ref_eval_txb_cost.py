@@ -4,7 +4,8 @@
   ref_eval_txb_cost.npz   warehouse_efficients_txb (av1/encoder/txb_rdopt.c:450-544: what av1_cost_coeffs_txb returns for eob > 0) with get_eob_cost /
                           get_br_cost / get_golomb_cost (txb_rdopt_utils.h:66-97), av1_get_eob_pos_token, av1_txb_init_levels_c, av1_get_nz_map_contexts_c
                           (encodetxb.c:100-130,222-267) and get_br_ctx[_eob] (av1/common/txb_common.h:90-135) under it, on random cost tables;
-                          and warehouse_efficients_txb_laplacian + av1_cost_coeffs_txb_estimate (:546-601) on the same blocks and tables (costLUT, txb_rdopt_utils.h:31-37).
+                          and warehouse_efficients_txb_laplacian + av1_cost_coeffs_txb_estimate (:546-601) on the same blocks and tables (costLUT, txb_rdopt_utils.h:31-37);
+                          and av1_get_txb_entropy_context (encodetxb.c:451-467) of every block.
 
 Supplied as inputs / adaptations:
   * get_tx_type_cost returns 0 (a table look-up on the block's mode: the caller's addend); get_scan returns the scan order of (tx_size, tx_type) built
@@ -12,6 +13,7 @@ Supplied as inputs / adaptations:
   * MACROBLOCK / macroblock_plane as views with the members the function reads (coeff_costs.eob_costs, qcoeff); MACROBLOCKD opaque (only passed on);
   * TX_SIZE / TX_CLASS / TX_TYPE / PLANE_TYPE are UENUM1BYTE enums the evaluator skips: int, with the enumerators' declaration-order values.
 """
+import json
 import os
 import re
 import sys
@@ -46,7 +48,7 @@ def main():
     ev.load_text("#define BLOCK_OFFSET(i) ((i) << 4)\ntypedef int8_t ENTROPY_CONTEXT; typedef struct { int txb_skip_ctx; int dc_sign_ctx; } TXB_CTX;\n"
                  "typedef struct { const int16_t *scan; const int16_t *iscan; } SCAN_ORDER;\n", "blockd.h / entropymode.h: types")
     ent = open(REF + "av1/common/entropy.h").read()
-    ev.load_text("\n".join(re.findall(r"#define (?:SIG_COEF_CONTEXTS\w*|TXB_SKIP_CONTEXTS|EOB_COEF_CONTEXTS|DC_SIGN_CONTEXTS|LEVEL_CONTEXTS|BR_CDF_SIZE|COEFF_BASE_RANGE|NUM_BASE_LEVELS) [^\n]*",
+    ev.load_text("\n".join(re.findall(r"#define (?:SIG_COEF_CONTEXTS\w*|COEFF_CONTEXT_\w+|TXB_SKIP_CONTEXTS|EOB_COEF_CONTEXTS|DC_SIGN_CONTEXTS|LEVEL_CONTEXTS|BR_CDF_SIZE|COEFF_BASE_RANGE|NUM_BASE_LEVELS) [^\n]*",
                                       ent)) + "\n", "entropy.h:context counts")
     ev.load(REF + "av1/common/txb_common.h")
     ev.load(REF + "av1/common/txb_common.c")
@@ -62,6 +64,7 @@ def main():
                 r"void av1_txb_init_levels_c\([^;{]*\)\s*\{.*?\n}\n", r"void av1_get_nz_map_contexts_c\([^;{]*\)\s*\{.*?\n}\n"):
         ev.load_text(re.search(pat, text, re.S).group(0), "encodetxb.c:" + pat[:30])
     ev.define("av1_txb_init_levels", "av1_txb_init_levels_c"); ev.define("av1_get_nz_map_contexts", "av1_get_nz_map_contexts_c")
+    ev.load_text(re.search(r"uint8_t av1_get_txb_entropy_context\([^;{]*\)\s*\{.*?\n}\n", text, re.S).group(0), "encodetxb.c:av1_get_txb_entropy_context")
     utl = open(REF + "av1/encoder/txb_rdopt_utils.h").read()
     ev.load_text(re.search(r"static const int costLUT\[15\] = \{.*?\};", utl, re.S).group(0) + "\n" + re.search(r"static const int const_term = [^;]*;", utl).group(0) + "\n"
                  + re.search(r"static const int loge_par = [^;]*;", utl).group(0) + "\n", "txb_rdopt_utils.h:costLUT")
@@ -127,9 +130,21 @@ def main():
                 lap = ev.call("warehouse_efficients_txb_laplacian", x, 0, 0, tx_size, tc, eob, 0, cc, xd, tx_type, tx_class, 0)
                 arrays["c%d" % k], arrays["t%d" % k] = coeff.astype(np.int32), costs.astype(np.int32)
                 cases.append({"k": k, "tx_size": tx_size, "tx_type": tx_type, "tx_class": tx_class, "eob": eob, "txb_skip_ctx": skip_ctx, "dc_sign_ctx": dc_ctx,
-                              "cost": int(cost), "cost_laplacian": int(lap)})
+                              "cost": int(cost), "cost_laplacian": int(lap),
+                              "entropy_ctx": int(ev.call("av1_get_txb_entropy_context", ev.array(coeff, "int32_t"), so, eob))})
                 k += 1
         print(tx_size, k, flush=True)
+    # av1_get_txb_entropy_context below its saturation: small sums, the three DC signs (TX_4X4, default scan)
+    scan, iscan = orc.get_scan(0, 0)
+    so = ev.new("SCAN_ORDER")
+    ev.set(so, "scan", ev.array(scan, "int16_t")); ev.set(so, "iscan", ev.array(iscan, "int16_t"))
+    small = []
+    for vals, eob in (([1], 1), ([-1], 1), ([0, 1], 2), ([2, -1, 1], 3), ([-3, 0, 2, 1], 4), ([0, 0, 0, 5], 4), ([1, 1, 1, 1, 1, 1, 1], 7), ([-1, 0, 0, 0, 0, 0, 0, 7], 8),
+                      ([6, 2], 1)):
+        coeff = np.zeros(16, np.int64)
+        coeff[scan[:len(vals)]] = vals
+        small.append({"coeff": coeff.tolist(), "eob": eob, "entropy_ctx": int(ev.call("av1_get_txb_entropy_context", ev.array(coeff, "int32_t"), so, eob))})
+    arrays["small_ctx"] = np.frombuffer(json.dumps(small).encode(), np.uint8)
     save("ref_eval_txb_cost.npz", arrays, cases)
 
 

@@ -34,6 +34,26 @@ def oracle_cost_laplacian(coeff, eob, tx_size, tx_type, skip_ctx, costs):
     return int(orc.lib.orc_cost_coeffs_txb_laplacian(C.c_void_p(co.ctypes.data), eob, tx_class, C.c_void_p(sc.ctypes.data), skip_ctx, C.c_void_p(cs.ctypes.data)))
 
 
+def oracle_entropy_ctx(coeff, eob, tx_size, tx_type):
+    scan, _ = orc.get_scan(tx_size, tx_type)
+    sc, co = np.ascontiguousarray(scan, np.int16), np.ascontiguousarray(coeff, np.int32)
+    return int(orc.lib.orc_get_txb_entropy_context(C.c_void_p(co.ctypes.data), C.c_void_p(sc.ctypes.data), eob))
+
+
+def test_entropy_context_matches_the_reference():
+    z, cases = load()
+    seen = set()
+    for c in cases:
+        got = oracle_entropy_ctx(z["c%d" % c["k"]], c["eob"], c["tx_size"], c["tx_type"])
+        assert got == c["entropy_ctx"], c
+        seen.add(got)
+    for c in json.loads(bytes(z["small_ctx"])):          # below the saturation: small sums, the three DC signs
+        got = oracle_entropy_ctx(np.array(c["coeff"], np.int32), c["eob"], 0, 0)
+        assert got == c["entropy_ctx"], c
+        seen.add(got)
+    assert len(seen) >= 9 and oracle_entropy_ctx(np.zeros(16, np.int32), 0, 0, 0) == 0
+
+
 def test_laplacian_rate_matches_the_reference():
     z, cases = load()
     for c in cases:

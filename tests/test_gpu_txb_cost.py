@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from test_golden_nzmap import TXH, TXW
-from test_golden_txb_cost import load, oracle_cost, oracle_cost_laplacian
+from test_golden_txb_cost import load, oracle_cost, oracle_cost_laplacian, oracle_entropy_ctx
 
 pytestmark = pytest.mark.gpu
 
@@ -19,6 +19,8 @@ def test_device_matches_the_interpreted_function(hip, ctx):
         assert int(ctx.from_device(d_o, (1,), np.int32)[0]) == c["cost"], c
         ctx.cost_coeffs_txb_batch(d_q, c["tx_size"], None, 1, c["tx_type"], d_e, d_x, d_t, d_o, laplacian=True)
         assert int(ctx.from_device(d_o, (1,), np.int32)[0]) == c["cost_laplacian"], c
+        ctx.txb_entropy_context_batch(d_q, c["tx_size"], None, 1, c["tx_type"], d_e, d_o)
+        assert int(ctx.from_device(d_o, (1,), np.uint8)[0]) == c["entropy_ctx"], c
         for d in (d_q, d_t, d_e, d_x, d_o):
             ctx.free(d)
 
@@ -63,8 +65,23 @@ def test_lists_of_blocks_equal_the_oracle(hip, oracle, ctx, tx_size):
     got = ctx.from_device(d_o, (nb,), np.int32)
     for i in range(nb):
         assert int(got[i]) == oracle_cost_laplacian(coeff[i], int(eobs[i]), tx_size, int(types[i]), int(ctxs[i, 0]), costs), (i, types[i], eobs[i])
+    ctx.txb_entropy_context_batch(d_q, tx_size, d_b, nb, 0, d_e, d_o)
+    got8 = ctx.from_device(d_o, (nb,), np.uint8)
+    for i in range(nb):
+        assert int(got8[i]) == oracle_entropy_ctx(coeff[i], int(eobs[i]), tx_size, int(types[i])), (i, types[i], eobs[i])
     for d in (d_q, d_b, d_t, d_e, d_x, d_o):
         ctx.free(d)
+
+
+def test_small_entropy_contexts_match_the_interpreted_function(hip, ctx):
+    import json
+    z, _ = load()
+    for c in json.loads(bytes(z["small_ctx"])):
+        d_q, d_e, d_o = ctx.to_device(np.array(c["coeff"], np.int32)), ctx.to_device(np.array([c["eob"]], np.uint16)), ctx.malloc(4)
+        ctx.txb_entropy_context_batch(d_q, 0, None, 1, 0, d_e, d_o)
+        assert int(ctx.from_device(d_o, (1,), np.uint8)[0]) == c["entropy_ctx"], c
+        for d in (d_q, d_e, d_o):
+            ctx.free(d)
 
 
 def test_invalid_arguments_are_refused(hip, ctx):
