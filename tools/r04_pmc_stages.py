@@ -23,7 +23,7 @@ res = {}
 for k, c in acc.items():
     short = k.replace("void ", "").replace("aomhip::", "").replace("(anonymous namespace)::", "").split("(")[0]
     if not any(s in short for s in ("fullpel_diamond", "subpel_bilinear", "inter_pred", "xform_quant", "inv_txfm", "deblock", "cdef_luma", "subtract",
-                                    "full_pixel_search", "fp_row", "tf_apply", "sad_strip", "mesh", "encode_inter_block", "compound", "obmc", "refining")):
+                                    "full_pixel_search", "fp_row", "tf_apply", "sad_strip", "mesh", "encode_inter_block", "compound", "obmc", "refining", "warp_error", "int_pro", "vbp_")):
         continue
     e = {"wavefronts_per_launch": waves[k]}
     for n, v in c.items():
