@@ -1,4 +1,4 @@
-/* The shear decomposition of an affine motion model (av1_get_shear_params, av1/common/warped_motion.c:186-245; AV1 specification 7.11.3.6): host-side scalar
+/* The shear decomposition of an affine motion model (av1_get_shear_params, av1/common/warped_motion.c:186-247; AV1 specification 7.11.3.6): host-side scalar
  * arithmetic the global-motion search runs on every candidate before it measures it (aomhip_warp_error_batch).  Plain C, no GPU. */
 #include <stdint.h>
 #include <stdlib.h>

@@ -1259,7 +1259,7 @@ typedef struct {
   int32_t mat[6];                      /* WarpedMotionParams.wmmat */
   int16_t alpha, beta, gamma, delta;
 } aomhip_warp_model;
-int aomhip_get_shear_params(aomhip_warp_model *model);   /* av1_get_shear_params (av1/common/warped_motion.c:186-245): fills alpha .. delta; 1 valid, 0 not */
+int aomhip_get_shear_params(aomhip_warp_model *model);   /* av1_get_shear_params (av1/common/warped_motion.c:186-247): fills alpha .. delta; 1 valid, 0 not */
 int aomhip_warp_error_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *cur, int cur_frame, int subsampling_x,
                             int subsampling_y, const aomhip_warp_model *d_models, int n_models, int p_col, int p_row, int p_width, int p_height,
                             const uint8_t *d_segment_map, int segment_map_stride, int64_t *d_error);

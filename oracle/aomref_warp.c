@@ -109,7 +109,7 @@ void orc_warp_affine_compound(const int32_t *mat, const void *ref, int elem16, i
               gamma, delta, 1, do_average, use_dist_wtd, fwd_offset, bck_offset, conv, conv_stride);
 }
 
-/* ---- the global-motion search's use of the warp: av1_get_shear_params (av1/common/warped_motion.c:186-245), av1_warp_error (av1/encoder/global_motion.c:
+/* ---- the global-motion search's use of the warp: av1_get_shear_params (av1/common/warped_motion.c:186-247), av1_warp_error (av1/encoder/global_motion.c:
  * 128-224: 32 x 32 tiles of the model's prediction against the frame, only where the segment map holds inliers, every pixel's difference through
  * error_measure_lut -- interpolated between neighbouring entries above 8 bits, warped_motion.c:248-259) and av1_segmented_frame_error (warped_motion.c:
  * 400-460,687-760: the same metric without a warp).  Pinned by tests/golden/ref_eval_warp_error.npz. */
