@@ -231,6 +231,7 @@ _protos = {
     "aomhip_build_inter_pred_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i, _i, _i]),
     "aomhip_sse_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_hadamard_batch": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "aomhip_sum_sse_2d_i16_batch": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "aomhip_txb_init_levels_batch": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp, _i64]),
     "aomhip_cost_coeffs_txb_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "aomhip_txb_entropy_context_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
@@ -774,6 +775,9 @@ class Context:
     def get_nz_map_contexts_batch(self, d_levels, levels_pitch, tx_size, d_blocks, n_blocks, tx_type, d_eob, d_contexts, contexts_pitch):
         check(lib.aomhip_get_nz_map_contexts_batch(self.h, d_levels, levels_pitch, tx_size, d_blocks, n_blocks, tx_type, d_eob, d_contexts, contexts_pitch),
               "aomhip_get_nz_map_contexts_batch")
+
+    def sum_sse_2d_i16_batch(self, d_residual, stride, width, height, d_blocks, n_blocks, d_sse, d_sum=None):
+        check(lib.aomhip_sum_sse_2d_i16_batch(self.h, d_residual, stride, width, height, d_blocks, n_blocks, d_sse, d_sum), "aomhip_sum_sse_2d_i16_batch")
 
     def txb_init_levels_batch(self, d_coeff, w, h, d_off, n_blocks, d_levels, pitch):
         check(lib.aomhip_txb_init_levels_batch(self.h, d_coeff, w, h, d_off, n_blocks, d_levels, pitch), "aomhip_txb_init_levels_batch")

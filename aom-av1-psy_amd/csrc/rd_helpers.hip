@@ -274,11 +274,52 @@ __global__ __launch_bounds__(256) void wedge_delta_squares_kernel(const int16_t 
   *reinterpret_cast<uint4 *>(d + i) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// aom_sum_squares_2d_i16 / aom_sum_sse_2d_i16 (aom_dsp/sum_squares.c:16-30,75-90) over a list of width x height blocks of an int16 residual plane: one
+// wavefront per block, 64 pixels per step; the squares fit 31 bits, the sums are 64-bit (32-bit for `sum`, as the reference's int).
+__global__ __launch_bounds__(256) void sum_sse_i16_kernel(const int16_t *__restrict__ residual, int stride, int width, int height,
+                                                          const aomhip_txb *__restrict__ blocks, int n_blocks, int64_t *__restrict__ sse,
+                                                          int32_t *__restrict__ sum) {
+  const int lane = threadIdx.x & 63;
+  const int bi = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (bi >= n_blocks) return;
+  const int16_t *p = residual + (int64_t)blocks[bi].y * stride + blocks[bi].x;
+  int64_t ss = 0;
+  int s = 0;
+  for (int i = lane; i < width * height; i += 64) {
+    const int r = i / width, c = i - r * width;
+    const int v = p[(int64_t)r * stride + c];
+    ss += v * v;
+    s += v;
+  }
+  for (int m = 1; m < 64; m <<= 1) {
+    ss += __shfl_xor((unsigned long long)ss, m, 64);
+    s += __shfl_xor(s, m, 64);
+  }
+  if (lane == 0) {
+    sse[bi] = ss;
+    if (sum) sum[bi] = s;
+  }
+}
+
 }  // namespace aomhip
 
 using namespace aomhip;
 
 extern "C" {
+
+int aomhip_sum_sse_2d_i16_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int width, int height, const aomhip_txb *d_blocks,
+                                int n_blocks, int64_t *d_sse, int32_t *d_sum) {
+  if (!ctx || !d_residual || residual_stride <= 0 || width <= 0 || height <= 0 || width > 128 || height > 128 || n_blocks < 0 ||
+      (n_blocks > 0 && (!d_blocks || !d_sse))) {
+    set_error("aomhip_sum_sse_2d_i16_batch: invalid argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  if (n_blocks == 0) return AOMHIP_OK;
+  hipLaunchKernelGGL(sum_sse_i16_kernel, dim3((n_blocks + 3) / 4), dim3(256), 0, ctx->stream, d_residual, residual_stride, width, height, d_blocks, n_blocks,
+                     d_sse, d_sum);
+  AOMHIP_LAUNCH_CHECK();
+  return AOMHIP_OK;
+}
 
 int aomhip_sse_batch(aomhip_ctx *ctx, const aomhip_planes *a, const aomhip_planes *b, int frame, int width, int height,
                      const aomhip_sad_cand *d_cands, int n_cands, int64_t *d_out) {

@@ -1156,6 +1156,11 @@ int aomhip_blend_a64_1d_batch(aomhip_ctx *ctx, const aomhip_planes *pred, int pr
  * to 128 x 128, not only BLOCK_SIZEs) of plane ring `a` at (sx, sy) against `b` at (rx, ry), 64-bit, no rounding. */
 int aomhip_sse_batch(aomhip_ctx *ctx, const aomhip_planes *a, const aomhip_planes *b, int frame, int width, int height,
                      const aomhip_sad_cand *d_cands, int n_cands, int64_t *d_out);
+/* aom_sum_squares_2d_i16 / aom_sum_sse_2d_i16 (aom_dsp/sum_squares.c:16-30,75-90; the transform search's skip prediction and residual statistics,
+ * av1/encoder/tx_search.c): d_sse[i] = the sum of squares of the width x height block of the int16 residual plane at (d_blocks[i].x, .y) (tx_type /
+ * out_offset unused), d_sum[i] (may be NULL) = its sum. */
+int aomhip_sum_sse_2d_i16_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int width, int height, const aomhip_txb *d_blocks,
+                                int n_blocks, int64_t *d_sse, int32_t *d_sum);
 
 /* The Hadamard family + SATD (aom_dsp/avg.c:110-533) over a list of n x n blocks of an int16 residual plane:
  *   AOMHIP_HADAMARD         aom_hadamard_{4x4,8x8,16x16,32x32}       -> tran_low_t (int32) coefficients, aom_satd

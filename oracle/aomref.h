@@ -239,6 +239,7 @@ int orc_cost_coeffs_txb(const int32_t *qcoeff, int eob, int tx_w, int tx_h, int 
                         const int32_t *costs);
 int orc_cost_coeffs_txb_laplacian(const int32_t *qcoeff, int eob, int tx_class, const int16_t *scan, int txb_skip_ctx, const int32_t *costs);
 int orc_get_txb_entropy_context(const int32_t *qcoeff, const int16_t *scan, int eob);
+uint64_t orc_sum_sse_2d_i16(const int16_t *src, int src_stride, int width, int height, int *sum);
 void orc_get_nz_map_contexts(const uint8_t *levels, const int16_t *scan, int eob, int tx_w, int tx_h, int tx_class, int8_t *coeff_contexts);
 void orc_txb_init_levels(const int32_t *coeff, int width, int height, uint8_t *levels);
 void orc_convolve_2d_scale(const void *src, int src_stride, void *dst, int dst_stride, int w, int h, int filter_x, int filter_y, int subpel_x_qn,

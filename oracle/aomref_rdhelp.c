@@ -325,3 +325,16 @@ int orc_get_txb_entropy_context(const int32_t *qcoeff, const int16_t *scan, int 
   return cul & 255;
 }
 
+/* aom_sum_squares_2d_i16_c / aom_sum_sse_2d_i16_c (aom_dsp/sum_squares.c:16-30,75-90): a residual block's sum of squares (and sum) -- the transform
+ * search's skip prediction and per-pixel statistics.  *sum is ADDED to, like the reference's. */
+uint64_t orc_sum_sse_2d_i16(const int16_t *src, int src_stride, int width, int height, int *sum) {
+  uint64_t ss = 0;
+  for (int r = 0; r < height; ++r)
+    for (int c = 0; c < width; ++c) {
+      const int v = src[(ptrdiff_t)r * src_stride + c];
+      ss += (uint64_t)(int64_t)(v * v);
+      if (sum) *sum += v;
+    }
+  return ss;
+}
+
