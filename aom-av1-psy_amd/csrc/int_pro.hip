@@ -62,7 +62,7 @@ __device__ __forceinline__ unsigned block_sad(const T *__restrict__ s, int s_str
   int acc = 0;
   for (int i = lane; i < n_px; i += 64) {
     const int y = i >> (bwl + 2), x = i & (bw - 1);
-    acc += abs((int)s[(int64_t)y * s_stride + x] - (int)r[(int64_t)y * r_stride + x]);
+    acc += abs((int)s[y * s_stride + x] - (int)r[y * r_stride + x]);   // (offsets inside a plane fit 32 bits)
   }
   return (unsigned)wave_sum(acc);
 }
@@ -95,12 +95,12 @@ __global__ __launch_bounds__(256) void int_pro_kernel(PlaneView<T> src, int src_
     for (int idx = lane; idx < 2 * bw; idx += 64) {
       const T *p = r - (bw >> 1) + idx;
       int acc = 0;
-      for (int i = 0; i < bh; ++i) acc += (int)p[(int64_t)i * ref.stride];
+      for (int i = 0; i < bh; ++i) acc += (int)p[i * ref.stride];
       hbuf[idx] = (int16_t)(acc >> row_norm);
     }
     for (int idx = lane; idx < bw; idx += 64) {
       int acc = 0;
-      for (int i = 0; i < bh; ++i) acc += (int)s[(int64_t)i * src.stride + idx];
+      for (int i = 0; i < bh; ++i) acc += (int)s[i * src.stride + idx];
       src_h[idx] = (int16_t)(acc >> row_norm);
     }
     // aom_int_pro_col: row sums over the block's columns -- the reference window from bh / 2 above
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void int_pro_kernel(PlaneView<T> src, int src_
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     int col = vector_match(hbuf, src_h, bw, bwl, lane), row = vector_match(vbuf, src_v, bh, bhl, lane);
     int trow = row, tcol = col;   // this_mv
-    auto sad_at = [&](int rr, int cc) { return block_sad<T>(s, src.stride, r + (int64_t)rr * ref.stride + cc, ref.stride, bw, bwl, n_px, lane); };
+    auto sad_at = [&](int rr, int cc) { return block_sad<T>(s, src.stride, r + (rr * ref.stride + cc), ref.stride, bw, bwl, n_px, lane); };
     unsigned best = sad_at(trow, tcol);
     if (row != 0 || col != 0) {   // the zero vector
       const unsigned t = sad_at(0, 0);
