@@ -174,6 +174,12 @@ _protos = {
     "aomhip_variance": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint)]),
     "aomhip_mse": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint)]),
     "aomhip_get_var": (None, [_vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint), C.POINTER(C.c_int)]),
+    "aomhip_get_mb_ss": (C.c_uint, [_vp]),
+    "aomhip_mse_wxh_16bit": (C.c_uint64, [_vp, _i, _vp, _i, _i, _i]),
+    "aomhip_mse_16xh_16bit": (C.c_uint64, [_vp, _i, _vp, _i, _i]),
+    "aomhip_mse_wxh_16bit_highbd": (C.c_uint64, [_vp, _i, _vp, _i, _i, _i]),
+    "aomhip_comp_mask_pred": (None, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _i]),
+    "aomhip_highbd_comp_mask_pred": (None, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _i]),
     "aomhip_get_var_sse_sum_8x8_quad": (None, [_vp, _i, _vp, _i, _vp, _vp, C.POINTER(C.c_uint), C.POINTER(C.c_int), _vp]),
     "aomhip_get_var_sse_sum_16x16_dual": (None, [_vp, _i, _vp, _i, _vp, C.POINTER(C.c_uint), C.POINTER(C.c_int), _vp]),
     "aomhip_sub_pixel_variance": (C.c_uint, [_vp, _i, _i, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint)]),

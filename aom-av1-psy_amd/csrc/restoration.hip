@@ -180,14 +180,24 @@ __device__ const int32_t kOneByX[25] = AOMHIP_ONE_BY_X;
 
 constexpr int kSgrTile = 32, kSgrFoot = kSgrTile + 6, kSgrAB = kSgrTile + 2;
 
+// A unit as the kernels use it: clipped to the plane and to the stated maximum size.  Identity for every unit the entry points accept -- they can
+// only check the optional HOST copy of the list -- and what keeps a bad device-side rectangle from writing past the caller's flt0 / flt1 rows or
+// outside the destination plane (it then filters the clipped rectangle).
+__device__ __forceinline__ aomhip_rect clip_unit(aomhip_rect u, int plane_w, int plane_h, int max_w, int max_h) {
+  u.h_start = min(max(u.h_start, 0), plane_w); u.v_start = min(max(u.v_start, 0), plane_h);
+  u.h_end = min(min(u.h_end, plane_w), u.h_start + max_w); u.v_end = min(min(u.v_end, plane_h), u.v_start + max_h);
+  return u;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void selfguided_kernel(const T *__restrict__ dgd, int dgd_stride, const aomhip_rect *__restrict__ units,
                                                           const int32_t *__restrict__ sgr_idx, int bit_depth, int32_t *__restrict__ flt0,
-                                                          int32_t *__restrict__ flt1, int flt_stride, int64_t flt_pitch, int tiles_x) {
+                                                          int32_t *__restrict__ flt1, int flt_stride, int64_t flt_pitch, int tiles_x, int plane_w,
+                                                          int plane_h, int max_w, int max_h) {
   __shared__ int32_t s_d[kSgrFoot * kSgrFoot];
   __shared__ int32_t s_A[kSgrAB * kSgrAB], s_B[kSgrAB * kSgrAB];
   const int ui = blockIdx.x;
-  const aomhip_rect u = units[ui];
+  const aomhip_rect u = clip_unit(units[ui], plane_w, plane_h, max_w, max_h);
   const int w = u.h_end - u.h_start, h = u.v_end - u.v_start;
   const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
   const int ox = tx * kSgrTile, oy = ty * kSgrTile;   // the tile inside the unit
@@ -261,9 +271,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void selfguided_apply_kernel(const T *__restrict__ dat, int dat_stride, T *__restrict__ dst, int dst_stride,
                                                                 const aomhip_rect *__restrict__ units, const int32_t *__restrict__ sgr_idx,
                                                                 const int32_t *__restrict__ xqd, int bit_depth, const int32_t *__restrict__ flt0,
-                                                                const int32_t *__restrict__ flt1, int flt_stride, int64_t flt_pitch) {
+                                                                const int32_t *__restrict__ flt1, int flt_stride, int64_t flt_pitch, int plane_w, int plane_h,
+                                                                int max_w, int max_h) {
   const int ui = blockIdx.x;
-  const aomhip_rect u = units[ui];
+  const aomhip_rect u = clip_unit(units[ui], plane_w, plane_h, max_w, max_h);
   const int w = u.h_end - u.h_start, h = u.v_end - u.v_start;
   const int idx = sgr_idx[ui];
   const int r0 = kSgrParams[idx][0], r1 = kSgrParams[idx][1];
@@ -291,11 +302,12 @@ __global__ __launch_bounds__(256) void selfguided_apply_kernel(const T *__restri
 constexpr int kWienerTile = 32, kWienerFoot = kWienerTile + 8;
 template <typename T>
 __global__ __launch_bounds__(256) void wiener_kernel(const T *__restrict__ dat, int dat_stride, T *__restrict__ dst, int dst_stride,
-                                                      const aomhip_rect *__restrict__ units, const int16_t *__restrict__ filters, int bd, int tiles_x) {
+                                                      const aomhip_rect *__restrict__ units, const int16_t *__restrict__ filters, int bd, int tiles_x, int plane_w,
+                                                      int plane_h, int max_w, int max_h) {
   __shared__ uint16_t s_src[kWienerFoot * kWienerFoot];
   __shared__ uint16_t s_tmp[kWienerFoot * kWienerTile];
   const int ui = blockIdx.x;
-  const aomhip_rect u = units[ui];
+  const aomhip_rect u = clip_unit(units[ui], plane_w, plane_h, max_w, max_h);
   const int w = u.h_end - u.h_start, h = u.v_end - u.v_start;
   const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
   const int ox = tx * kWienerTile, oy = ty * kWienerTile;
@@ -512,10 +524,10 @@ extern "C" int aomhip_selfguided_restoration_batch(aomhip_ctx *ctx, const aomhip
   const dim3 grid((unsigned)n_units, (unsigned)(tiles_x * tiles_y));
   if (dgd->bit_depth == 8)
     hipLaunchKernelGGL(selfguided_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint8_t *>(dgd->base) + po, dgd->stride, d_units,
-                       d_sgr_params_idx, 8, d_flt0, d_flt1, flt_stride, flt_pitch, tiles_x);
+                       d_sgr_params_idx, 8, d_flt0, d_flt1, flt_stride, flt_pitch, tiles_x, dgd->width, dgd->height, max_unit_width, max_unit_height);
   else
     hipLaunchKernelGGL(selfguided_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint16_t *>(dgd->base) + po, dgd->stride, d_units,
-                       d_sgr_params_idx, dgd->bit_depth, d_flt0, d_flt1, flt_stride, flt_pitch, tiles_x);
+                       d_sgr_params_idx, dgd->bit_depth, d_flt0, d_flt1, flt_stride, flt_pitch, tiles_x, dgd->width, dgd->height, max_unit_width, max_unit_height);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
@@ -550,11 +562,11 @@ extern "C" int aomhip_apply_selfguided_restoration_batch(aomhip_ctx *ctx, const 
   const dim3 grid((unsigned)n_units, (unsigned)(chunks < 1 ? 1 : chunks));
   if (dat->bit_depth == 8)
     hipLaunchKernelGGL(selfguided_apply_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint8_t *>(dat->base) + po, dat->stride,
-                       static_cast<uint8_t *>(dst->base) + qo, dst->stride, d_units, d_sgr_params_idx, d_xqd, 8, d_flt0, d_flt1, flt_stride, flt_pitch);
+                       static_cast<uint8_t *>(dst->base) + qo, dst->stride, d_units, d_sgr_params_idx, d_xqd, 8, d_flt0, d_flt1, flt_stride, flt_pitch, dat->width, dat->height, max_unit_width, max_unit_height);
   else
     hipLaunchKernelGGL(selfguided_apply_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint16_t *>(dat->base) + po, dat->stride,
                        static_cast<uint16_t *>(dst->base) + qo, dst->stride, d_units, d_sgr_params_idx, d_xqd, dat->bit_depth, d_flt0, d_flt1, flt_stride,
-                       flt_pitch);
+                       flt_pitch, dat->width, dat->height, max_unit_width, max_unit_height);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
@@ -576,10 +588,10 @@ extern "C" int aomhip_wiener_convolve_add_src_batch(aomhip_ctx *ctx, const aomhi
   const dim3 grid((unsigned)n_units, (unsigned)(tiles_x * tiles_y));
   if (dat->bit_depth == 8)
     hipLaunchKernelGGL(wiener_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint8_t *>(dat->base) + po, dat->stride,
-                       static_cast<uint8_t *>(dst->base) + qo, dst->stride, d_units, d_filters, 8, tiles_x);
+                       static_cast<uint8_t *>(dst->base) + qo, dst->stride, d_units, d_filters, 8, tiles_x, dat->width, dat->height, max_unit_width, max_unit_height);
   else
     hipLaunchKernelGGL(wiener_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint16_t *>(dat->base) + po, dat->stride,
-                       static_cast<uint16_t *>(dst->base) + qo, dst->stride, d_units, d_filters, dat->bit_depth, tiles_x);
+                       static_cast<uint16_t *>(dst->base) + qo, dst->stride, d_units, d_filters, dat->bit_depth, tiles_x, dat->width, dat->height, max_unit_width, max_unit_height);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }

@@ -35,6 +35,25 @@ static int launch_subpel(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip
                                                                      n_blocks, d_best_mv, d_best_err, d_distortion, d_sse);
 }
 
+// av1_return_max_sub_pixel_mv / av1_return_min_sub_pixel_mv (mcomp.c:3139-3190): the extreme MV the block's SubpelMvLimits allow, with
+// lower_mv_precision (av1/common/mvref_common.h:88-97: an odd component moves one step towards zero when high precision is off); besterr 0.
+// A block with an empty window (row_min > row_max) is skipped like everywhere else.
+__global__ __launch_bounds__(256) void extreme_mv_kernel(const aomhip_search_block *__restrict__ blocks, int n_blocks, int allow_hp, int want_max,
+                                                         int16_t *__restrict__ best_mv, uint32_t *__restrict__ best_err) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_blocks) return;
+  const aomhip_search_block b = blocks[i];
+  if (b.row_min > b.row_max) return;
+  int row = want_max ? b.row_max : b.row_min, col = want_max ? b.col_max : b.col_min;
+  if (!allow_hp) {
+    if (row & 1) row += row > 0 ? -1 : 1;
+    if (col & 1) col += col > 0 ? -1 : 1;
+  }
+  best_mv[2 * i] = (int16_t)row;
+  best_mv[2 * i + 1] = (int16_t)col;
+  best_err[i] = 0;
+}
+
 }  // namespace aomhip
 
 using namespace aomhip;
@@ -76,10 +95,22 @@ int aomhip_subpel_tree_list_batch(aomhip_ctx *ctx, const aomhip_planes *src, con
   const bool entropy = p->mv_cost_type == kCostEntropy;
   int rc = check_common(ctx, src, ref, frame, bw, bh, d_blocks, n_blocks, entropy ? kCostNone : p->mv_cost_type);
   if (rc != AOMHIP_OK) return rc;
+  if (p->tree == 3 || p->tree == 4) {   // av1_return_max_sub_pixel_mv / av1_return_min_sub_pixel_mv (mcomp.c:3139-3190)
+    if (!d_best_mv || !d_best_err) {
+      set_error("aomhip_subpel_tree_batch: invalid argument");
+      return AOMHIP_ERR_INVALID;
+    }
+    if (n_blocks == 0) return AOMHIP_OK;
+    AOMHIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(extreme_mv_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, ctx->stream, d_blocks, n_blocks, p->allow_hp,
+                       p->tree == 3 ? 1 : 0, d_best_mv, d_best_err);
+    AOMHIP_LAUNCH_CHECK();
+    return AOMHIP_OK;
+  }
   if (!d_best_mv || !d_best_err || !d_distortion || !d_sse || p->forced_stop < 0 || p->forced_stop > 3 || p->tree < 0 ||
       p->tree > 2 || (p->subpel_search_type < 0 || p->subpel_search_type > 3) ||
       (entropy && (!d_mvjcost || !d_mvcost_row || !d_mvcost_col))) {
-    set_error("aomhip_subpel_tree_batch: invalid argument (tree 0..2, forced_stop 0..3, MV_COST_ENTROPY needs its tables)");
+    set_error("aomhip_subpel_tree_batch: invalid argument (tree 0..4, forced_stop 0..3, MV_COST_ENTROPY needs its tables)");
     return AOMHIP_ERR_INVALID;
   }
   return launch_subpel(ctx, src, ref, frame, bw, bh, p->mv_cost_type, p->iters_per_step, p->allow_hp, p->forced_stop, p->tree,

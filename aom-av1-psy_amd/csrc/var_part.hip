@@ -39,7 +39,9 @@ __global__ __launch_bounds__(256) void vbp_8x8_kernel(PlaneView<T> src, int src_
     mn = min(mn, __shfl_xor(mn, m, 64));
     mx = max(mx, __shfl_xor(mx, m, 64));
   }
-  if (row == 0 && b16 < n16 && x8 < ((vis_w + 7) & ~7) && y8 < ((vis_h + 7) & ~7))
+  // (every leaf of every launched 16 x 16 block is written -- fill_variance_8x8avg gives a leaf outside the visible area sum = sse = 0 --, so a host
+  // tree builder may walk all four leaves of an edge block without a pre-zeroed array)
+  if (row == 0 && b16 < n16)
     sum8[(int64_t)(y8 >> 3) * sum_stride + (x8 >> 3)] = valid ? (int16_t)(((ssum + 32) >> 6) - ((dsum + 32) >> 6)) : (int16_t)0;
   if (minmax16) {
     int hi = valid ? mx - mn : 0, lo = valid ? min(mx - mn, 255) : 255;   // minmax_max starts at 0, minmax_min at 255 (also above 8 bits, where a block's spread can pass it)
@@ -80,7 +82,7 @@ extern "C" int aomhip_vbp_8x8_stats_plane(aomhip_ctx *ctx, const aomhip_planes *
                                           int visible_height, int16_t *d_sum8x8, int sum_stride, int32_t *d_minmax16x16, int minmax_stride) {
   if (!ctx || !src || !ref || !src->base || !ref->base || src_frame < 0 || src_frame >= src->n_frames || ref_frame < 0 || ref_frame >= ref->n_frames ||
       src->bit_depth != ref->bit_depth || visible_width < 1 || visible_height < 1 || visible_width > src->width || visible_height > src->height ||
-      visible_width > ref->width || visible_height > ref->height || src->border < 8 || ref->border < 8 || !d_sum8x8 || sum_stride < (visible_width + 7) / 8 ||
+      visible_width > ref->width || visible_height > ref->height || src->border < 8 || ref->border < 8 || !d_sum8x8 || sum_stride < 2 * ((visible_width + 15) / 16) ||
       (d_minmax16x16 && minmax_stride < (visible_width + 15) / 16)) {
     set_error("aomhip_vbp_8x8_stats_plane: invalid argument");
     return AOMHIP_ERR_INVALID;

@@ -26,7 +26,7 @@ int aomhip_get_shear_params(aomhip_warp_model *model) {
   shift += 14;
   const int16_t y = (int16_t)k_div_lut[f];
   int64_t v = ((int64_t)mat[4] * (1 << 16)) * y;
-  int gamma = clamp16(round_signed(v, shift));
+  int gamma = clamp16((int)round_signed(v, shift));   /* (the reference truncates the rounded quotient to int before it clamps: degenerate models wrap) */
   v = ((int64_t)mat[3] * mat[4]) * y;
   int delta = clamp16((int64_t)mat[5] - (int)round_signed(v, shift) - (1 << 16));
   alpha = reduce(alpha);

@@ -589,7 +589,10 @@ int aomhip_subpel_bilinear_batch(aomhip_ctx *ctx, const aomhip_planes *src, cons
  *                  error_per_bit; ignored for the other cost types
  * Blocks and outputs as aomhip_subpel_bilinear_batch. */
 typedef struct {
-  int32_t tree;                 /* 0 pruned_more, 1 pruned, 2 tree */
+  int32_t tree;                 /* 0 pruned_more, 1 pruned, 2 tree; 3 / 4 = av1_return_max_sub_pixel_mv / av1_return_min_sub_pixel_mv
+                                 * (mcomp.c:3139-3190, the motion-vector unit test's find_fractional_mv_step members): best MV = the block's
+                                 * (row_max, col_max) / (row_min, col_min) with lower_mv_precision(allow_hp), best_err = 0, distortion and sse
+                                 * left as they are; nothing is measured */
   int32_t mv_cost_type;         /* AOMHIP_MV_COST_* */
   int32_t error_per_bit;
   int32_t iters_per_step, allow_hp, forced_stop;
@@ -1158,7 +1161,8 @@ int aomhip_sse_batch(aomhip_ctx *ctx, const aomhip_planes *a, const aomhip_plane
                      const aomhip_sad_cand *d_cands, int n_cands, int64_t *d_out);
 /* aom_sum_squares_2d_i16 / aom_sum_sse_2d_i16 (aom_dsp/sum_squares.c:16-30,75-90; the transform search's skip prediction and residual statistics,
  * av1/encoder/tx_search.c): d_sse[i] = the sum of squares of the width x height block of the int16 residual plane at (d_blocks[i].x, .y) (tx_type /
- * out_offset unused), d_sum[i] (may be NULL) = its sum. */
+ * out_offset unused), d_sum[i] (may be NULL) = its sum.  Both are OVERWRITTEN: aom_sum_sse_2d_i16_c accumulates into the caller's *sum
+ * (`*sum += v`), so a caller that chains calls over sub-blocks adds the entries itself. */
 int aomhip_sum_sse_2d_i16_batch(aomhip_ctx *ctx, const int16_t *d_residual, int residual_stride, int width, int height, const aomhip_txb *d_blocks,
                                 int n_blocks, int64_t *d_sse, int32_t *d_sum);
 
@@ -1287,7 +1291,9 @@ int aomhip_int_pro_motion_estimation_batch(aomhip_ctx *ctx, const aomhip_planes 
  * or at zero); visible_width / _height = the frame's visible size (what pixels_wide / pixels_high measure from a superblock's origin).
  *   aomhip_vbp_8x8_stats_plane   d_sum8x8[(y / 8) * sum_stride + x / 8] = aom_[highbd_]avg_8x8(src) - aom_[highbd_]avg_8x8(ref) of the 8 x 8 block at
  *                                (x, y) -- fill_variance_8x8avg's sum_error (:266-344; sum_square_error is its square), 0 for a block that starts
- *                                outside the visible part; d_minmax16x16 (may be NULL)[(y / 16) * minmax_stride + x / 16] = compute_minmax_8x8
+ *                                outside the visible part: ALL FOUR leaves of every 16 x 16 block that starts inside it are written, so the
+ *                                array holds 2 ceil(visible_height / 16) rows of sum_stride >= 2 ceil(visible_width / 16) entries and needs
+ *                                no pre-zeroing; d_minmax16x16 (may be NULL)[(y / 16) * minmax_stride + x / 16] = compute_minmax_8x8
  *                                (:346-384) of the 16 x 16 block: the spread of its visible 8 x 8 blocks' (max - min) of |src - ref|
  *   aomhip_vbp_4x4_avg_plane     key frames: d_sum4x4[(y / 4) * sum_stride + x / 4] = aom_[highbd_]avg_4x4(src) - 128, fill_variance_4x4avg's
  *                                sum_error (:386-423), 0 from border_offset_4x4 before the visible edge on
@@ -1427,6 +1433,21 @@ unsigned int aomhip_highbd_variance(const uint8_t *a8, int a_stride, const uint8
 unsigned int aomhip_highbd_sub_pixel_variance(const uint8_t *a8, int a_stride, int xoffset, int yoffset,
                                               const uint8_t *b8, int b_stride, int bw, int bh, int bd,
                                               unsigned int *sse);
+/* The small members of aom_dsp/variance.c (csrc/dsp_misc.hip), exact signatures, host pointers:
+ *   aom_get_mb_ss (aom_dsp_rtcd_defs.pl:1344; variance.c:46-54)   sum of squares of 256 int16, modulo 2^32
+ *   aom_mse_wxh_16bit / aom_mse_16xh_16bit / aom_mse_wxh_16bit_highbd (:1359,1362,1780; variance.c:1258-1297)   sum of (dst - src)^2 of a
+ *       w x h block of an 8-bit (16-bit) plane against a 16-bit block -- the CDEF search's distortion (pickcdef.c); _16xh_: 16 / w blocks side
+ *       by side in dst, one after the other (w * h entries, pitch w) in src.  A failed call returns UINT64_MAX (the sticky status says why).
+ *   aom_comp_mask_pred / aom_highbd_comp_mask_pred (:2032,2036; variance.c:773-791,841-862)   comp_pred (pitch width) =
+ *       AOM_BLEND_A64(mask, invert_mask ? pred : ref, invert_mask ? ref : pred); highbd pointers CONVERT_TO_BYTEPTR-encoded. */
+unsigned int aomhip_get_mb_ss(const int16_t *a);
+uint64_t aomhip_mse_wxh_16bit(uint8_t *dst, int dstride, uint16_t *src, int sstride, int w, int h);
+uint64_t aomhip_mse_16xh_16bit(uint8_t *dst, int dstride, uint16_t *src, int w, int h);
+uint64_t aomhip_mse_wxh_16bit_highbd(uint16_t *dst, int dstride, uint16_t *src, int sstride, int w, int h);
+void aomhip_comp_mask_pred(uint8_t *comp_pred, const uint8_t *pred, int width, int height, const uint8_t *ref, int ref_stride,
+                           const uint8_t *mask, int mask_stride, int invert_mask);
+void aomhip_highbd_comp_mask_pred(uint8_t *comp_pred, const uint8_t *pred8, int width, int height, const uint8_t *ref8, int ref_stride,
+                                  const uint8_t *mask, int mask_stride, int invert_mask);
 
 
 /* ------------------------------------------------------------------ multi-GPU: tile columns + the per-frame exchange (RCCL) */

@@ -281,6 +281,14 @@ void orc_wedge_compute_delta_squares(int16_t *d, const int16_t *a, const int16_t
 void orc_compute_stats(int wiener_win, const void *dgd, const void *src, int h_start, int h_end, int v_start, int v_end, int dgd_stride,
                        int src_stride, int elem16, int bit_depth, int use_downsampled_wiener_stats, int64_t *M, int64_t *H);
 
+/* the small members of the named files (aomref_misc.c) */
+uint32_t orc_get_mb_ss(const int16_t *a);
+uint64_t orc_mse_wxh_16bit(const void *dst, int dstride, int dst16, const uint16_t *src, int sstride, int w, int h);
+uint64_t orc_mse_16xh_16bit(const uint8_t *dst, int dstride, const uint16_t *src, int w, int h);
+void orc_comp_mask_pred(void *comp_pred, const void *pred, int width, int height, const void *ref, int ref_stride, const uint8_t *mask, int mask_stride,
+                        int invert_mask, int elem16);
+int orc_return_extreme_sub_pixel_mv(const int *limits, int allow_hp, int want_max, int16_t *bestmv);
+
 #ifdef __cplusplus
 }
 #endif

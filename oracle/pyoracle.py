@@ -1542,3 +1542,51 @@ def compound_single_motion_search_batch(src_b, ref_b, border, width, height, w, 
     this = np.where((sme < 2**31 - 1)[:, None], best, this)
     rate = np.array([mv_bit_cost(this[i, 0], this[i, 1], refmv[i, 0], refmv[i, 1], mvjcost, mvcost0, mvcost1) for i in range(n)], np.int32)
     return this.astype(np.int16), rate, sme.astype(np.int32)
+
+
+# ---- the small members of the named files (aomref_misc.c)
+lib.orc_get_mb_ss.restype = C.c_uint32
+lib.orc_get_mb_ss.argtypes = [_vp]
+lib.orc_mse_wxh_16bit.restype = C.c_uint64
+lib.orc_mse_wxh_16bit.argtypes = [_vp, _i, _i, _vp, _i, _i, _i]
+lib.orc_mse_16xh_16bit.restype = C.c_uint64
+lib.orc_mse_16xh_16bit.argtypes = [_vp, _i, _vp, _i, _i]
+lib.orc_comp_mask_pred.restype = None
+lib.orc_comp_mask_pred.argtypes = [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i]
+lib.orc_return_extreme_sub_pixel_mv.restype = _i
+lib.orc_return_extreme_sub_pixel_mv.argtypes = [_vp, _i, _i, _vp]
+
+
+def get_mb_ss(a):
+    a = np.ascontiguousarray(a, np.int16)
+    assert a.size == 256
+    return int(lib.orc_get_mb_ss(a.ctypes.data))
+
+
+def mse_wxh_16bit(dst, src, w, h):
+    """dst: 2-D uint8 / uint16 view (its row pitch is used), src: 2-D uint16 view."""
+    assert dst.strides[1] == dst.itemsize and src.strides[1] == 2
+    return int(lib.orc_mse_wxh_16bit(dst.ctypes.data, dst.strides[0] // dst.itemsize, int(dst.itemsize == 2), src.ctypes.data, src.strides[0] // 2, w, h))
+
+
+def mse_16xh_16bit(dst, src, w, h):
+    src = np.ascontiguousarray(src, np.uint16)
+    return int(lib.orc_mse_16xh_16bit(dst.ctypes.data, dst.strides[0], src.ctypes.data, w, h))
+
+
+def comp_mask_pred(pred, ref, mask, invert_mask):
+    """pred: (h, w) contiguous; ref / mask: 2-D views; -> (h, w) of pred's dtype."""
+    pred = np.ascontiguousarray(pred)
+    h, w = pred.shape
+    out = np.empty_like(pred)
+    lib.orc_comp_mask_pred(out.ctypes.data, pred.ctypes.data, w, h, ref.ctypes.data, ref.strides[0] // ref.itemsize, mask.ctypes.data, mask.strides[0],
+                           int(invert_mask), int(pred.itemsize == 2))
+    return out
+
+
+def return_extreme_sub_pixel_mv(limits, allow_hp, want_max):
+    """limits = (col_min, col_max, row_min, row_max) -> (besterr, (row, col))."""
+    lim = np.asarray(limits, np.int32)
+    mv = np.zeros(2, np.int16)
+    e = lib.orc_return_extreme_sub_pixel_mv(lim.ctypes.data, int(allow_hp), int(want_max), mv.ctypes.data)
+    return int(e), (int(mv[0]), int(mv[1]))

@@ -42,6 +42,8 @@ def test_device_matches_the_interpreted_functions(hip, ctx):
                     n8 += 1
                 else:
                     assert c["sum"][k] == 0 and c["sse"][k] == 0
+                    if c["x16"] < c["pw"] and c["y16"] < c["ph"]:   # a leaf of a launched block beyond the visible part: written, 0
+                        assert int(cache[0][y8 // 8, x8 // 8]) == 0, (c, k)
             if c["x16"] < c["pw"] and c["y16"] < c["ph"]:
                 assert int(cache[1][c["y16"] // 16, c["x16"] // 16]) == c["minmax"], c
         else:
@@ -68,9 +70,13 @@ def test_whole_planes_equal_the_oracle(hip, oracle, ctx, bd, W, H, vw, vh):
     ctx.planes_upload(ps, 0, src); ctx.planes_upload(pd, 0, dst)
     sb, db = np.pad(src, B, mode="edge"), np.pad(dst, B, mode="edge")
     n8x, n8y, n16x, n16y = (vw + 7) // 8, (vh + 7) // 8, (vw + 15) // 16, (vh + 15) // 16
-    d_s, d_m = ctx.malloc(2 * (n8x + 3) * n8y), ctx.malloc(4 * (n16x + 1) * n16y)
-    ctx.vbp_8x8_stats_plane(ps, 0, pd, 0, vw, vh, d_s, n8x + 3, d_m, n16x + 1)
-    s8, m16 = ctx.from_device(d_s, (n8y, n8x + 3), np.int16), ctx.from_device(d_m, (n16y, n16x + 1), np.int32)
+    # (all four leaves of every 16 x 16 block are written: 2 n16y rows of >= 2 n16x entries, no pre-zeroing needed)
+    d_s, d_m = ctx.malloc(2 * (2 * n16x + 3) * 2 * n16y), ctx.malloc(4 * (n16x + 1) * n16y)
+    ctx.memset(d_s, 0x7f, 2 * (2 * n16x + 3) * 2 * n16y)
+    ctx.vbp_8x8_stats_plane(ps, 0, pd, 0, vw, vh, d_s, 2 * n16x + 3, d_m, n16x + 1)
+    s8, m16 = ctx.from_device(d_s, (2 * n16y, 2 * n16x + 3), np.int16), ctx.from_device(d_m, (n16y, n16x + 1), np.int32)
+    assert np.all(s8[n8y:, :2 * n16x] == 0) and np.all(s8[:, n8x:2 * n16x] == 0)   # the leaves beyond the visible part
+    assert np.all(s8[:, 2 * n16x:] == 0x7f7f)                                          # nothing past the 2 n16x columns
     for y16 in range(0, vh, 16):
         for x16 in range(0, vw, 16):
             s, q, mm = oracle_8x8(sb, db, 0, 0, int(bd > 8), vw - x16, vh - y16, x0=B + x16, y0=B + y16)
@@ -106,6 +112,8 @@ def test_invalid_arguments_are_refused(hip, ctx):
         ctx.vbp_8x8_stats_plane(p8, 0, p8, 0, 72, 64, d, 9)
     with pytest.raises(capi.AomHipError):
         ctx.vbp_8x8_stats_plane(p8, 0, p8, 0, 64, 64, d, 7)
+    with pytest.raises(capi.AomHipError):
+        ctx.vbp_8x8_stats_plane(p8, 0, p8, 0, 40, 40, d, 5)   # 2 * ceil(40 / 16) = 6 entries per row
     with pytest.raises(capi.AomHipError):
         ctx.vbp_8x8_stats_plane(p8, 0, pn, 0, 64, 64, d, 8)
     with pytest.raises(capi.AomHipError):

@@ -30,3 +30,16 @@ def test_host_shear_decomposition():
             assert [int(rec[f][0]) for f in ("alpha", "beta", "gamma", "delta")] == want.tolist(), mat
         verdicts += ok
     assert 800 < verdicts < 3600
+    # degenerate models (tiny mat[2], huge mat[4]): the rounded quotient does not fit an int and the reference truncates it BEFORE clamping
+    # (av1/common/warped_motion.c:227-228) -- gamma wraps instead of saturating
+    wrapped = 0
+    for m2, m4 in ((1, 1 << 20), (1, (1 << 20) + 12345), (3, -(1 << 22) - 7), (2, (1 << 30) - 1), (5, -(1 << 31) + 1), (1, 1 << 15)):
+        mat = [0, 0, m2, 17, m4, 1 << 16]
+        rec = np.zeros(1, capi.warp_model_dtype)
+        rec["mat"][0] = mat
+        ok = capi.get_shear_params(rec)[0]
+        want_ok, want = oracle_shear(mat)
+        assert ok == want_ok
+        assert [int(rec[f][0]) for f in ("alpha", "beta", "gamma", "delta")] == want.tolist(), mat
+        wrapped += abs(int(want[2])) < 32704
+    assert wrapped >= 1   # (at least one case where a saturating gamma would have been +-32704)

@@ -5,6 +5,9 @@ import os, sys, json
 import numpy as np
 sys.path.insert(0, os.getcwd())
 import aom_av1_psy_amd as pkg
+sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import sb_override
+sb_override.apply(pkg)
 
 def main():
     W, H = (1920, 1080) if sys.argv[1] == "1080p" else (3840, 2160)

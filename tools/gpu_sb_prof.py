@@ -4,6 +4,9 @@ import os, sys, json, ctypes as C
 import numpy as np
 sys.path.insert(0, os.getcwd())
 import aom_av1_psy_amd as pkg
+sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import sb_override
+sb_override.apply(pkg)
 
 def main():
     W, H = (1920, 1080) if sys.argv[1] == "1080p" else (3840, 2160)
@@ -38,6 +41,7 @@ def main():
                           "evaluator_per_step_cycles": {"bookkeeping": p[0] / steps, "bookkeeping+evaluate": p[1] / steps, "barrier": p[3] / steps},
                           "loader_per_active_step_cycles": {"batch_of(cy+1)": p[8] / lsteps, "commit(incl. wait)": p[9] / lsteps, "wait_for_loads": p[15] / lsteps, "overflow+batch_of(cy+3)": p[10] / lsteps,
                                                             "request(+batch_of)": p[11] / lsteps, "barrier": p[12] / lsteps, "passive_overflow+barrier": p[14] / lsteps},
+                          "raw_first_wavefront_per_step": [round(p[i] / steps) for i in range(4)],
                           "prologue_cycles_per_item": p[5] / items,
                           "barrier_wait_per_step_by_wavefront": [round(x / steps) for x in p[16:32]]}), flush=True)
         for d in (d_gs, d_cs, d_off): ctx.free(d)
