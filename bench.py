@@ -30,9 +30,12 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
 
+from benchlib.common import HBM_PEAK_GBS, kernel_avg_ms, ramp  # noqa: E402
+from benchlib.filters import run_filters_ring  # noqa: E402
+from benchlib.variance import VAR_WORKLOADS, run_variance  # noqa: E402
+
 FRAMES_OVERRIDE = 0
 TILE_COLUMNS = "uniform"   # --tile-columns
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SAD16_BYTES_8BIT = 516  # src block + ref block + 4 B result
 
 WORKLOADS = {
@@ -302,8 +305,8 @@ class TxqGrid:
         self.blocks = {n: (self.W // n) * (self.H // n) * frames for _, n in TXQ_SIZES}
         self.blocks_per_step = sum(self.blocks.values())
 
-    def launch(self, tx_size, n):
-        self.ctx.xform_quant_batch(self.d_res, self.W, tx_size, None, self.blocks[n], self.W // n, 0, self.qp, self.hbd, None,
+    def launch(self, tx_size, n, tx_type=0):
+        self.ctx.xform_quant_batch(self.d_res, self.W, tx_size, None, self.blocks[n], self.W // n, tx_type, self.qp, self.hbd, None,
                                    self.d_q, self.d_dq, self.d_eob)
 
     def step(self):
@@ -401,6 +404,19 @@ def run_txq(pkg, ctx, orc, steps, warmup, want_cpu, name="txq_1080p_8bit"):
         t, ms = res["roofline"]["traffic"], per[dom]["avg_launch_ms"]
         res["roofline"]["traffic_GBs"] = t / (ms * 1e-3) / 1e9
         res["roofline"]["traffic_over_algorithmic"] = t / (wl.blocks[int(dom.split("x")[0])] * (10 * int(dom.split("x")[0]) ** 2 + 2))
+    if orc is not None and os.environ.get("AOMHIP_BENCH_TXQ_SWEEPS", "1") != "0":
+        # the quantiser at qindex 20 / 200 next to the default 100 (the quantiser's dead zone decides how many
+        # coefficients survive, the bytes moved do not change) and the 16 transform types of the <= 16x16 sizes, timed on the 16x16 launch
+        b16 = wl.blocks[16] * (10 * 256 + 2)
+        frac16 = lambda fn: b16 / (kernel_avg_ms(ctx, fn, max(steps, 10)) * 1e-3) / 1e9 / HBM_PEAK_GBS
+        qp100 = wl.qp
+        res["qindex_sweep_16x16_frac"] = {"100": per["16x16"]["frac"]}
+        for qi in (20, 200):
+            wl.qp = pkg.capi.QuantParams.from_tables(orc.build_quantizer_y(wl.bd, qi))
+            res["qindex_sweep_16x16_frac"][str(qi)] = frac16(lambda: wl.launch(2, 16))
+        wl.qp = qp100
+        by_type = [frac16(lambda t=t: wl.launch(2, 16, t)) for t in range(16)]
+        res["tx_type_sweep_16x16_frac"] = {"min": min(by_type), "max": max(by_type), "by_tx_type": by_type}
     if want_cpu and orc is not None:
         res["cpu_baseline"] = wl.cpu_baseline()
     wl.free()
@@ -711,6 +727,63 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
         ctx.sync()
         for g in graphs:
             ctx.graph_destroy(g)
+    # ---- the same frame with its two 4:2:0 chroma planes (8x8 chroma blocks at the luma block's MV, TX_8X8, deblock at level 32 on the 8x8
+    # chroma grid's 4-sample units, CDEF chroma with the luma directions): luma chain + two chroma chains as ONE graph per ring slot
+    # (tests/test_gpu_full_size.py::test_config4... checks this chain bit for bit against the oracle)
+    yuv = None
+    if use_graph and os.environ.get("AOMHIP_BENCH_420", "1") != "0":
+        CW, CH, cbd = W // 2, H // 2, border // 2
+        cs = [ctx.planes_alloc(CW, CH, cbd, bd, F) for _ in range(2)]
+        cr = [ctx.planes_alloc(CW, CH, cbd, bd, F) for _ in range(2)]
+        cp = [ctx.planes_alloc(CW, CH, cbd, bd, F) for _ in range(2)]
+        co = ctx.planes_alloc(CW, CH, cbd, bd, 1)
+        for f in range(F):
+            ys, yr = ctx.planes_download(sp.src, f)[border:border + H, border:border + W], ctx.planes_download(sp.ref, f)[border:border + H, border:border + W]
+            for pl, off in enumerate((200, 330)):
+                ctx.planes_upload(cs[pl], f, np.clip(ys[::2, ::2].astype(np.int32) // 2 + off, 0, 1023).astype(np.uint16))
+                ctx.planes_upload(cr[pl], f, np.clip(yr[::2, ::2].astype(np.int32) // 2 + off, 0, 1023).astype(np.uint16))
+        cblocks = sp.h_blocks.copy()
+        cblocks["bx"] //= 2; cblocks["by"] //= 2
+        d_cb = ctx.to_device(cblocks)
+        cparams = np.zeros((CH // 4, CW // 4, 4), np.uint8)
+        cparams[:, 2::2, 0] = 6; cparams[:, 2::2, 1] = 32; cparams[2::2, :, 2] = 6; cparams[2::2, :, 3] = 32
+        d_cparams = ctx.to_device(cparams)
+        d_cq, d_cdq, d_ce = ctx.malloc(n * 64 * 4), ctx.malloc(n * 64 * 4), ctx.malloc(2 * n)
+        d_dir, d_var = ctx.malloc((H // 8) * (W // 8)), ctx.malloc((H // 8) * (W // 8) * 4)
+
+        def frame_420(f):
+            ctx.fullpel_diamond_batch(sp.src, sp.ref, f, 16, 16, 0, 4, capi.MV_COST_L1_HDRES, sp.d_blocks, n, sp.d_mv, sp.d_cost)
+            ctx.subpel_bilinear_batch(sp.src, sp.ref, f, 16, 16, capi.MV_COST_L1_HDRES, 2, 1, 0, sp.d_sub_blocks(f), n, sp.d_smv, sp.d_err, sp.d_dist, sp.d_sse)
+            ctx.encode_inter_blocks_batch(sp.src, f, sp.ref, f, pred, f, 16, sp.d_blocks, sp.d_smv, n, qp, d_q, d_dq, d_e, 0, 0, 0)
+            ctx.deblock_plane(pred, f, d_params, W // 4, 0, 3)
+            ctx.cdef_luma_plane(pred, f, out, 0, d_pri, d_sec, fbw, d_skip, 6, d_dir, d_var)
+            for pl in range(2):
+                ctx.build_inter_pred_batch(cr[pl], f, cp[pl], f, 8, 8, d_cb, sp.d_smv, n, 0, 0, 1, 1)
+                ctx.subtract_xform_quant_batch(cs[pl], cp[pl], f, 1, None, n, CW // 8, 0, qp, None, d_cq, d_cdq, d_ce)
+                ctx.inv_txfm_add_batch(d_cdq, 1, None, n, CW // 8, 0, d_ce, cp[pl], f)
+                ctx.deblock_plane(cp[pl], f, d_cparams, CW // 4, 0, 3)
+                ctx.cdef_chroma_plane(cp[pl], f, co, 0, 1, 1, d_dir, d_pri, d_sec, fbw, d_skip, 6)
+        for f in range(F):
+            frame_420(f)
+        ctx.sync()
+        ring420 = ctx.capture(lambda: [frame_420(f) for f in range(F)])
+        reps = max(2, steps // F)
+        ctx.graph_launch(ring420); ctx.sync()
+        t0 = time.perf_counter()
+        ctx.timer_begin()
+        for _ in range(reps):
+            ctx.graph_launch(ring420)
+        ev420 = ctx.timer_end()
+        wall420 = time.perf_counter() - t0
+        ctx.graph_destroy(ring420)
+        yuv = {"ms_per_frame": wall420 / (reps * F) * 1e3, "event_ms_per_frame": ev420 / (reps * F), "frames_per_s": reps * F / wall420,
+               "chain": "the luma chain + per chroma plane: 8x8 prediction at the luma MV (ss 1, 1), subtract + fwd_txfm2d_8x8 + quantize_b, inverse + add, deblock, CDEF chroma"}
+        for pl in range(2):
+            for x in (cs[pl], cr[pl], cp[pl]):
+                ctx.planes_free(x)
+        ctx.planes_free(co)
+        for d in (d_cb, d_cparams, d_cq, d_cdq, d_ce, d_dir, d_var):
+            ctx.free(d)
     # sanity: the reconstruction of the last frame is close to its source (fine quantiser, converged search)
     f_last = (state["f"] - 1) % F
     rec = ctx.planes_download(out, 0)[border:border + H, border:border + W].astype(np.int32)
@@ -800,7 +873,17 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
     # blocks whose quantised coefficients are all zero skip the inverse transform (and cost the forward stage its coefficient writes only)
     for nm in ("inv_txfm_add_16x16", "subtract_xform_quant_16x16"):
         stages[nm]["eob_nonzero_share_by_slot"] = eob_share
-    return {"workload": "encode_inner_loop_4k_10bit", "value": steps / wall, "unit": "frames/s",
+    # BASELINE.json configs[4] asks "fps + HBM-roofline fraction": the frame's algorithmic bytes by SURVEY 8(d)'s units -- 16x16 transform blocks at
+    # 10 N + 2 B, one deblocked and one CDEF-filtered pixel at 4 B each (the search has no byte unit there) -- over the frame time.  The chain is
+    # bound by the search kernels' instruction issue, not by bytes: the fraction says how far from an HBM limit the frame is, nothing more.
+    algo_luma = n * (10 * 256 + 2) + 2 * (4 * W * H)
+    algo_420 = algo_luma + 2 * (n * (10 * 64 + 2) + 2 * (4 * (W // 2) * (H // 2)))
+    roof = {"bound": "issue/latency (search kernels 2/3 of the frame)", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_frame": algo_luma,
+            "achieved": algo_luma / (wall / steps) / 1e9, "frac": algo_luma / (wall / steps) / 1e9 / HBM_PEAK_GBS}
+    if yuv:
+        yuv["algorithmic_bytes_per_frame"] = algo_420
+        yuv["roofline_frac"] = algo_420 / (yuv["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return {"workload": "encode_inner_loop_4k_10bit", "value": steps / wall, "unit": "frames/s", "roofline": roof, "roofline_frac": roof["frac"], "yuv420": yuv,
             "ms_per_frame": wall / steps * 1e3, "event_ms_per_frame": ev_ms / steps, "blocks_per_frame": n,
             "recon_psnr_db_last_frame": float(psnr), "stages": stages, "valu_issue_rates": rates, "deblock_in_frame": "fused" if fused_deblock else "two_pass",
             "launch": ("one hipGraph per ring of %d frames (aomhip_graph_launch)" % graph_note["frames_per_graph"] if graph_note and "frames_per_graph" in graph_note
@@ -1383,18 +1466,6 @@ def run_sad_diamond_lists(pkg, ctx, orc, steps, warmup, width=3840, height=2160,
                        "centre within +-40, radius 1..16; no single candidates (not Mode-A shaped)", "cell": list(cell)}}
 
 
-def ramp(ctx, fn, seconds=None):
-    """Untimed: keep the chip busy with the workload itself before anything is measured.  The first milliseconds after an idle period run
-    at a lower clock (profiles/r03_sad_strip.md section 4: the same launch 0.310 ms right after 3 warm-up launches, 0.273 ms sustained);
-    the W warm-up steps of the contract (a few hundred microseconds here) do not cover that."""
-    seconds = float(os.environ.get("AOMHIP_BENCH_RAMP_S", "0.25")) if seconds is None else seconds
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(8):
-            fn()
-        ctx.sync()
-
-
 def time_steps(wl, ctx, dist, dev, steps, warmup):
     ramp(ctx, wl.step)
     for _ in range(warmup):
@@ -1415,16 +1486,6 @@ def time_steps(wl, ctx, dist, dev, steps, warmup):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     return wall, ev_ms
-
-
-def kernel_avg_ms(ctx, fn, reps):
-    ramp(ctx, fn, 0.1)
-    fn()
-    ctx.sync()
-    ctx.timer_begin()
-    for _ in range(reps):
-        fn()
-    return ctx.timer_end() / reps
 
 
 def search_bound():
@@ -1573,9 +1634,11 @@ LINE_LIMIT = 6000  # bytes of the final stdout line; the driver's record keeps a
 def _other_summary(o):
     """One or two scalars per informational workload for the printed line; the whole entry goes to the side file / stderr."""
     out = {}
-    for k in ("value", "unit", "ms_per_frame", "ms_per_step", "frames_per_s"):
+    for k in ("value", "ms_per_frame", "ms_per_step", "frames_per_s", "roofline_frac"):   # (units: the full record)
         if isinstance(o.get(k), (int, float, str)):
             out[k] = o[k]
+    if isinstance(o.get("yuv420"), dict):   # the inner loop's 4:2:0 leg
+        out["yuv420_ms_per_frame"], out["yuv420_roofline_frac"] = o["yuv420"]["ms_per_frame"], o["yuv420"].get("roofline_frac")
     for k, v in o.items():  # nested legs that carry a per-frame time (TF q30 / q12, joint search branches, NSTEP / 8-tap ...)
         if isinstance(v, dict) and isinstance(v.get("ms_per_frame", v.get("ms_per_filtered_frame")), (int, float)):
             out[k + "_ms"] = v.get("ms_per_frame", v.get("ms_per_filtered_frame"))
@@ -1604,7 +1667,9 @@ def build_lines(args, world, main_res, others, strong):
                 roof["%s_%s" % (k_, tag)] = r_["roofline"][k_]
         roof["candidates_per_s_%s" % tag] = r_["value"]
     txqs = [o for o in others if str(o.get("workload", "")).startswith("fwd_txfm2d+quantize_b")]
-    rest = [o for o in others if o not in txqs and o not in sad_all]
+    vars_ = [o for o in others if o.get("workload") in VAR_WORKLOADS]
+    filt = next((o for o in others if o.get("workload") == "filters_ring_4k_10bit"), None)
+    rest = [o for o in others if o not in txqs and o not in sad_all and o not in vars_ and o is not filt]
     cpu = main_res.get("cpu_baseline")
     head = {
         "metric": "SAD-candidates/s", "value": main_res["value"], "unit": "candidates/s", "n_gpus": world,
@@ -1629,7 +1694,18 @@ def build_lines(args, world, main_res, others, strong):
                 txq={t["workload"]: {"value": t["value"], "unit": "blocks/s",
                                      "roofline": {k: t["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms")},
                                      "cpu_baseline": {k: (t.get("cpu_baseline") or {}).get(k) for k in ("value", "cores", "kind")},
-                                     "per_size_frac": {k: v["frac"] for k, v in t["per_size"].items()}} for t in txqs} or None,
+                                     "per_size_frac": {k: v["frac"] for k, v in t["per_size"].items()},
+                                     "qindex_frac_16x16": t.get("qindex_sweep_16x16_frac"),
+                                     "tx_type_frac_16x16": None if not t.get("tx_type_sweep_16x16_frac") else
+                                     {k: t["tx_type_sweep_16x16_frac"][k] for k in ("min", "max")}} for t in txqs} or None,
+                # SURVEY 8(d) rows A6-A8 / E / F on HBM-resident rings: frac = algorithmic bytes, c = compulsory bytes (every ring byte once),
+                # t = counter traffic (null until measured on this kernel source), all / launch time / 8 TB/s
+                variance={o["workload"].replace("variance16x16_modeA_", "var_").replace("sub_pixel_var_", "subpel_var_"):
+                          {"frac": o["roofline"]["frac"], "c": o["roofline"]["frac_compulsory"], "t": o["roofline"]["frac_traffic"],
+                           "ms": o["roofline"]["avg_launch_ms"], "parity": o["parity_sample_slot0_and_last"]} for o in vars_} or None,
+                filters_ring=None if filt is None else dict(
+                    {k: {"us": filt[k]["ms_per_plane"] * 1e3, "frac": filt[k]["frac"], "c": filt[k]["frac_compulsory"], "t": filt[k]["frac_traffic"]}
+                     for k in ("deblock_vert+horz", "cdef_luma")}, parity=filt["parity_slot0_and_last"], ring_GB=1.32),
                 strong_scaling_search=strong,
                 parity_frame0_and_last_slot=main_res["parity_frame0"],
                 parity_all=all(bool(v) for o in [main_res] + others for k, v in o.items() if k.startswith("parity") and v is not None),
@@ -1644,7 +1720,8 @@ def build_lines(args, world, main_res, others, strong):
                               "stage_ms": {k: v["ms"] for k, v in il["stages"].items()}}
     line = _sig(line)
     # never let the line outgrow the record that reads it: shed the least important keys first (they stay in the full record)
-    for drop in ("valu_issue.stage_ms", "others", "strong_scaling_search.tile_columns_px_balanced", "strong_scaling_search.tile_columns_px_uniform", "txq"):
+    for drop in ("valu_issue.stage_ms", "valu_issue.stage_valu_frac", "strong_scaling_search.tile_columns_px_balanced", "strong_scaling_search.tile_columns_px_uniform",
+                 "others.wiener_stats_luma_4k", "others.cdef_search_luma_4k_10bit", "others.mesh_search_4k_10bit", "others", "txq"):
         if len(json.dumps(line, separators=(",", ":"))) <= LINE_LIMIT:
             break
         if "." in drop:
@@ -1730,7 +1807,8 @@ def main():
                     help="default: sad16x16_modeA_1080p_8bit (BASELINE.json's metric) at every N; with N > 1 the line also carries the "
                          "strong-scaling search pipeline with its per-frame RCCL exchange as `strong_scaling_search`",
                     choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "txq_4k_10bit", "search_4k_10bit", "inner_loop_4k_10bit", "default_search_4k_10bit", "cdef_search_4k_10bit",
-                                                "wiener_stats_4k", "warp_error_4k", "int_pro_4k_8bit", "tf_motion_search_4k_10bit", "sad_diamond_lists_4k_8bit", "first_pass_4k_10bit", "compound_search_4k_10bit"])
+                                                "wiener_stats_4k", "warp_error_4k", "int_pro_4k_8bit", "tf_motion_search_4k_10bit", "sad_diamond_lists_4k_8bit", "first_pass_4k_10bit", "compound_search_4k_10bit",
+                                                "filters_ring_4k_10bit"] + sorted(VAR_WORKLOADS))
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -1865,6 +1943,12 @@ def main():
                               vs_baseline=None, dtype="u16" if "cdef" in args.workload else "u8", data="synthetic",
                               ms_per_step=first["ms_per_frame"], config={"workload": r["workload"]})))
         return
+    if args.workload in VAR_WORKLOADS or args.workload == "filters_ring_4k_10bit":  # profiling convenience: one HBM-ring workload (single GPU)
+        r = run_variance(pkg, ctx, orc, args.steps, args.warmup, args.workload) if args.workload in VAR_WORKLOADS else run_filters_ring(pkg, ctx, orc, args.steps, args.warmup)
+        ctx.close()
+        print(json.dumps(dict(r, metric=r["unit"], n_gpus=1, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak", vs_baseline=None,
+                              dtype="u8" if "8bit" in args.workload else "u16", data="synthetic", config=dict(r["config"], workload=r["workload"]))))
+        return
     if args.workload in TXQ_WORKLOADS:  # profiling convenience: transform+quantise only (single GPU)
         r = run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline, args.workload)
         ctx.close()
@@ -1889,6 +1973,9 @@ def main():
         if args.others == "auto" and orc is not None:
             others.append(run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline))
             others.append(run_txq(pkg, ctx, orc, args.steps, args.warmup, not args.no_cpu_baseline, "txq_4k_10bit"))
+            for vn in VAR_WORKLOADS:   # the variance half of "SAD / variance"
+                others.append(run_variance(pkg, ctx, orc, max(5, args.steps // 2), 1, vn))
+            others.append(run_filters_ring(pkg, ctx, orc, max(3, args.steps // 5), 1))   # deblock / CDEF on a 1.3 GB ring
             others.append(run_search(pkg, ctx, None, dev, 0, 1, orc, max(4, args.steps // 2), 1))
             others.append(run_inner_loop(pkg, ctx, orc, max(40, 2 * args.steps), 2))   # (two ring slots of different cost: enough frames for a stable mean)
             others.append(run_mesh(pkg, ctx, orc, max(4, args.steps // 4), 1))

@@ -1,0 +1,50 @@
+"""Helpers every workload module shares: the clock ramp, the per-launch HIP-event timing and the roofline constants."""
+import os
+import time
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def ramp(ctx, fn, seconds=None):
+    """Untimed: keep the chip busy with the workload itself before anything is measured.  The first milliseconds after an idle period run
+    at a lower clock (profiles/r03_sad_strip.md section 4: the same launch 0.310 ms right after 3 warm-up launches, 0.273 ms sustained);
+    the W warm-up steps of the contract (a few hundred microseconds here) do not cover that."""
+    seconds = float(os.environ.get("AOMHIP_BENCH_RAMP_S", "0.25")) if seconds is None else seconds
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            fn()
+        ctx.sync()
+
+
+def kernel_avg_ms(ctx, fn, reps):
+    """Average duration of `fn`'s launches: HIP events on the context's own stream (the stream the kernels are launched on)."""
+    ramp(ctx, fn, 0.1)
+    fn()
+    ctx.sync()
+    ctx.timer_begin()
+    for _ in range(reps):
+        fn()
+    return ctx.timer_end() / reps
+
+
+def load_traffic_entry(root, name, sha):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json); None when not measured or measured on another version
+    of the kernel source (`sha` = sha256[:16] of the sources the figure describes)."""
+    import json
+    try:
+        t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+        if (t.get("_measured_on") or {}).get(name) != sha:
+            return None
+        return t.get(name)
+    except Exception:
+        return None
+
+
+def source_sha(root, files):
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(root, "aom-av1-psy_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

@@ -69,8 +69,23 @@ def test_default_single_gpu_line_is_small_enough_for_the_driver_record(tmp_path)
         assert t["value"] > 0 and 0 < t["roofline"]["frac"] < 1 and set(t["per_size_frac"]) == {"4x4", "8x8", "16x16", "32x32"}
     assert d["parity_all"] is True and d["parity_frame0_and_last_slot"] is True
     assert "encode_inner_loop_4k_10bit" in d["others"]
+    # round 6: the measurement gaps of SURVEY 8(d) closed IN THE LINE, which still stays under 6 KB
+    assert len(last) < 6200, len(last)
+    v = d["variance"]
+    assert set(v) == {"var_1080p_8bit", "subpel_var_1080p_8bit", "var_4k_10bit", "subpel_var_4k_10bit"}
+    for e in v.values():   # frac: algorithmic bytes (520 / 553 / 1 032 / 1 098 B per evaluation), c: compulsory bytes, t: counter traffic
+        assert e["frac"] > 0 and 0 < e["c"] < 1 and e["ms"] > 0 and e["parity"] is True and "t" in e
+    fr = d["filters_ring"]
+    for k in ("deblock_vert+horz", "cdef_luma"):   # on a 1.3 GB ring of 4K 10-bit planes: an HBM figure
+        assert 0 < fr[k]["frac"] < 1 and 0 < fr[k]["c"] < 1 and fr[k]["us"] > 0 and "t" in fr[k]
+    assert fr["parity"] is True and fr["ring_GB"] >= 1.0
+    il = d["others"]["encode_inner_loop_4k_10bit"]
+    assert 0 < il["roofline_frac"] < 1 and 0 < il["yuv420_roofline_frac"] < 1 and il["yuv420_ms_per_frame"] > il["ms_per_frame"]
+    for t in d["txq"].values():
+        assert set(t["qindex_frac_16x16"]) == {"20", "100", "200"} and all(0 < x < 1 for x in t["qindex_frac_16x16"].values())
+        assert 0 < t["tx_type_frac_16x16"]["min"] <= t["tx_type_frac_16x16"]["max"] < 1 and "traffic" in t["roofline"]
     # the full record: every informational workload entire, the per-size roofline table, the cpu legs
     f = json.loads(full.read_text())
-    assert len(f["others"]) >= 15 and "sizes" in f["roofline"] and "legs" in f["cpu_baseline"]
+    assert len(f["others"]) >= 20 and "sizes" in f["roofline"] and "legs" in f["cpu_baseline"]
     # ... and each of them as one JSON line on stderr
     assert sum(1 for ln in p.stderr.splitlines() if ln.startswith("{")) == len(f["others"])
