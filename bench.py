@@ -71,10 +71,12 @@ def dist_setup(n_gpus, backend):
         return dist, 0, 1
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
     if backend == "nccl":
+        torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
+    else:   # gloo: CPU tensors only (the launcher dry run of tests/test_bench_launcher_gloo.py runs where there is no GPU)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
         dist.init_process_group(backend)
     return dist, rank, world
 
@@ -88,9 +90,11 @@ def barrier(dist, dev):
         import torch
         if _BACKEND == "nccl":
             dist.barrier(device_ids=[dev])
+            torch.cuda.synchronize()
         else:
             dist.barrier()
-        torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
 
 class SadModeA:
@@ -579,6 +583,53 @@ def run_search_default(pkg, ctx, orc, steps, warmup):
     return out
 
 
+def exchange_bytes_plan(pkg, width, height, elem_bytes, world, bounds, halo):
+    """What aomhip_allgather_recon moves per frame, from the plan alone (aomhip_recon_exchange_plan, host only): per rank the bytes it sends
+    and receives (pixel columns x visible rows x element size), for the halo exchange and for the whole-column all-gather.  The driver's
+    SCALE record can be checked against these: received bytes / exchange time = the per-rank xGMI rate."""
+    out = {"halo": {"send": [], "recv": []}, "allgather": {"send": [], "recv": []}}
+    for mode, h in (("halo", halo), ("allgather", -1)):
+        for r in range(world):
+            send, recv = pkg.capi.recon_exchange_plan(world, r, bounds, width, h)
+            out[mode]["send"].append(int(sum(int(b - a) for a, b in send)) * height * elem_bytes)
+            out[mode]["recv"].append(int(sum(int(b - a) for a, b in recv)) * height * elem_bytes)
+    return out
+
+
+def run_launcher_dry_run(args, dist, rank, world):
+    """--workload launcher_dry_run: everything bench.py does AROUND a measurement at N > 1 -- fresh child processes, the process group, the tile-column
+    partition, the exchange plan, the reductions, the supervising parent, ONE JSON line from rank 0 -- with no device call, no oracle and nothing
+    measured (value 0).  tests/test_bench_launcher_gloo.py runs it at 4 and 8 gloo ranks on the CPU and injects the two failures the real run
+    must survive with a non-zero exit: a rank that dies (AOMHIP_BENCH_FAIL_RANK) and a communicator that holds fewer ranks than the job
+    (AOMHIP_BENCH_FAKE_COMM_RANKS: stands for aomhip_comm_info's answer)."""
+    import aom_av1_psy_amd as pkg
+    W, H = SearchPipeline.W, SearchPipeline.H
+    bounds, _ = (pkg.capi.tile_column_bounds_balanced if TILE_COLUMNS == "balanced" and world & (world - 1) == 0 else pkg.capi.tile_column_bounds)(W, world)
+    x0, x1 = (int(v) for v in bounds[rank])
+    blocks = ((x1 - x0) // 16) * (H // 16)
+    if os.environ.get("AOMHIP_BENCH_FAIL_RANK") == str(rank):
+        print("bench.py: rank %d fails on purpose (AOMHIP_BENCH_FAIL_RANK)" % rank, file=sys.stderr)
+        os._exit(3)   # (the others are on their way into the barrier below: only the supervising parent can end them)
+    barrier(dist, 0)
+    n_comm = int(os.environ.get("AOMHIP_BENCH_FAKE_COMM_RANKS", world))
+    assert n_comm == world, "RCCL communicator holds %s ranks, the job has %d" % (n_comm, world)
+    red = lambda v, op: pkg.partition.reduce_scalar(dist, float(v), op, _red_device())
+    total = int(red(blocks, "SUM"))
+    t_max = red(1.0 + rank, "MAX")
+    barrier(dist, 0)
+    if rank == 0:
+        widths = [int(b - a) for a, b in bounds]
+        print(json.dumps({"metric": "launcher dry run (nothing measured)", "value": 0.0, "unit": "none", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                          "config": {"workload": "launcher_dry_run", "dist_backend": args.dist_backend},
+                          "strong_scaling_search": {"blocks_per_step": total, "max_over_ranks_check": t_max, "rccl_ranks_in_communicator": n_comm,
+                                                    "tile_columns_px": widths,
+                                                    "exchange": {"halo_px": SearchPipeline.HALO,
+                                                                 "expected_bytes_per_rank_per_frame": exchange_bytes_plan(pkg, W, H, 2, world, bounds, SearchPipeline.HALO)}}}),
+              flush=True)
+    dist.destroy_process_group()
+
+
 def run_search(pkg, ctx, dist, dev, rank, world, orc, steps, warmup, exchange="halo"):
     wl = SearchPipeline(pkg, ctx, dist, rank, world, exchange=exchange)
     ok = wl.check(orc) if orc is not None else None   # N > 1: on the EXCHANGED reference against the oracle's whole-frame search
@@ -606,6 +657,7 @@ def run_search(pkg, ctx, dist, dev, rank, world, orc, steps, warmup, exchange="h
         extra = {"rccl_ranks_in_communicator": n_comm,
                  "exchange": {"mode": exchange, "halo_px": wl.HALO, "halo_ms_per_frame": ex_halo, "allgather_ms_per_frame": ex_all,
                               "allgather_bytes_received_max_rank": recv_all, "halo_bytes_received_max_rank": recv_halo,
+                              "expected_bytes_per_rank_per_frame": exchange_bytes_plan(pkg, wl.W, wl.H, 2, world, wl.bounds, wl.HALO),
                               "allgather_GBs_per_rank": recv_all / (ex_all * 1e-3) / 1e9 if ex_all > 0 else None,
                               "allgather_GBs_per_link": recv_all / (ex_all * 1e-3) / 1e9 / max(world - 1, 1) if ex_all > 0 else None,
                               "halo_GBs_per_link": recv_halo / (ex_halo * 1e-3) / 1e9 / max(min(2, world - 1), 1) if ex_halo > 0 else None,
@@ -1808,7 +1860,7 @@ def main():
                          "strong-scaling search pipeline with its per-frame RCCL exchange as `strong_scaling_search`",
                     choices=sorted(WORKLOADS) + ["txq_1080p_8bit", "txq_4k_10bit", "search_4k_10bit", "inner_loop_4k_10bit", "default_search_4k_10bit", "cdef_search_4k_10bit",
                                                 "wiener_stats_4k", "warp_error_4k", "int_pro_4k_8bit", "tf_motion_search_4k_10bit", "sad_diamond_lists_4k_8bit", "first_pass_4k_10bit", "compound_search_4k_10bit",
-                                                "filters_ring_4k_10bit"] + sorted(VAR_WORKLOADS))
+                                                "filters_ring_4k_10bit", "launcher_dry_run"] + sorted(VAR_WORKLOADS))
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -1830,6 +1882,10 @@ def main():
     FRAMES_OVERRIDE = args.frames_per_gpu
     TILE_COLUMNS = args.tile_columns
     dist, rank, world = dist_setup(args.gpus, args.dist_backend)
+    if args.workload == "launcher_dry_run":   # (no device, no oracle: the launcher / process group / line around a measurement)
+        assert dist is not None, "launcher_dry_run is an N > 1 check: --gpus N"
+        run_launcher_dry_run(args, dist, rank, world)
+        return
     default_multi = args.workload is None and dist is not None
     if args.workload is None:
         # ONE metric at every N: BASELINE.json's SAD-candidates/s on the 1080p 8-bit configuration, whole-job aggregate (tile columns are
