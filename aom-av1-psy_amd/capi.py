@@ -170,6 +170,7 @@ _protos = {
     "aomhip_sad_sb_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp,
                                       _i, _i64, _vp]),
     "aomhip_variance_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp]),
+    "aomhip_variance_sb_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "aomhip_sub_pixel_variance_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp]),
     "aomhip_variance": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint)]),
     "aomhip_mse": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint)]),
@@ -562,6 +563,13 @@ class Context:
                                                    int(is_hbd), d_qcoeff, d_dqcoeff, d_eob), "aomhip_quantize_b_adaptive_batch")
 
     # ---- variance
+    def variance_sb_batch(self, src, ref, first_frame, n_frames, bw, bh, sb_w, sb_h, rng, n_buckets, d_groups=None, d_group_off=None, n_groups=0,
+                          group_frame_stride=0, d_var_groups=None, d_sse_groups=None, d_cands=None, d_cand_off=None, n_cands=0, cand_frame_stride=0,
+                          d_var_cands=None, d_sse_cands=None):
+        check(lib.aomhip_variance_sb_batch(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, bw, bh, sb_w, sb_h, rng, n_buckets, d_groups,
+                                           d_group_off, n_groups, group_frame_stride, d_var_groups, d_sse_groups, d_cands, d_cand_off, n_cands,
+                                           cand_frame_stride, d_var_cands, d_sse_cands), "aomhip_variance_sb_batch")
+
     def variance_batch(self, src, ref, first_frame, n_frames, bw, bh, d_cands, n, stride, d_var, d_sse, subpel=False):
         f = lib.aomhip_sub_pixel_variance_batch if subpel else lib.aomhip_variance_batch
         check(f(self.h, C.byref(src), C.byref(ref), first_frame, n_frames, bw, bh, d_cands, n, stride, d_var, d_sse),

@@ -20,7 +20,7 @@
 
 namespace aomhip {
 
-// Phase timing of the cell kernel (kernel experiments only: -DAOMHIP_CELL_PROF; tools/r04_cell_prof.py): shader cycles per wavefront
+// Phase timing of the cell kernel (kernel experiments only: -DAOMHIP_CELL_PROF; profiles/r04_search_cell.md): shader cycles per wavefront
 // summed over the launch -- [0] waves, [1] prologue + staging, [2] LDS rounds, [3] their count, [4] global rounds, [5] their count,
 // [6] variances, [7] their count, [8] whole wavefront
 #ifdef AOMHIP_CELL_PROF

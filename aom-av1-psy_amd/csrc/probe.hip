@@ -125,7 +125,7 @@ extern "C" int aomhip_strip_read_probe(aomhip_ctx *ctx, const aomhip_planes *src
 // one scalar add / compare / branch beside them), long enough to run at the sustained clock.  Reported: wave-instructions per second per
 // SIMD from the HIP-event time of the launch, and the same interval in s_memtime ticks per wave-instruction together with the tick rate
 // (against s_memrealtime, 100 MHz), so "how many clocks does a wave64 instruction take" does not rest on an assumed frequency.
-// Measurement support, not part of the encoder path: it computes nothing.  (Origin: tools/r03_ubench.hip, profiles/r03_ubench.log.)
+// Measurement support, not part of the encoder path: it computes nothing.  (Origin: tools/lds_ubench.hip, profiles/r03_ubench.log.)
 namespace aomhip {
 namespace {
 

@@ -195,7 +195,7 @@ constexpr int tx_index_of(int w, int h) {  // TX_SIZE (av1/common/enums.h:174-19
   return 0;
 }
 #ifndef AOMHIP_XQ_FAST_BTF
-#define AOMHIP_XQ_FAST_BTF 1   // 0: every block takes the exact butterfly (A/B, tools/r03_ab_txq.sh)
+#define AOMHIP_XQ_FAST_BTF 1   // 0: every block takes the exact butterfly (A/B: profiles/history_r02_r04.md)
 #endif
 // the 1-D pass of a block whose residual magnitude allows (fast) / does not allow the fast butterfly
 template <int N, int BIT> __device__ __forceinline__ void fwd_1d_sel(int32_t (&x)[N], int kind, bool fast) {

@@ -26,9 +26,27 @@
 #include <type_traits>
 
 #include "common.h"
+#include "variance_device.h"
+#undef AOMHIP_FOR_BLOCK_SIZES   // (variance_device.h's list; this file has its own below)
 
 namespace aomhip {
 namespace sb {
+
+// What a candidate accumulates.  SAD: one sum.  VARIANCE (round 6: aom_varianceWxH through the same strip walk, aom_dsp/variance.c:56-163,
+// 383-420): S(r), S(r^2), S(s r) per reference and S(s), S(s^2) of the source block -- sum = S(s) - S(r), sse = S(s^2) + S(r^2) - 2 S(s r)
+// in 32-bit modular arithmetic, exact because the true sse of a block of <= 256 pixels is < 2^32 at every bit depth (256 x 4095^2); the
+// packed dot products take 4 (8-bit) or 2 (16-bit) pixels per instruction.
+template <bool VAR> struct Ac;
+template <> struct Ac<false> { uint32_t a = 0; };
+template <> struct Ac<true> { uint32_t a = 0, rr = 0, xr = 0, ssum = 0, ss = 0; };   // a = S(r)
+template <bool VAR> struct Res;
+template <> struct Res<false> { uint32_t v; };
+template <> struct Res<true> { uint32_t v, sse; };
+template <typename T> __device__ __forceinline__ uint32_t dot_dword(uint32_t a, uint32_t b, uint32_t acc) {
+  if constexpr (sizeof(T) == 1) return __builtin_amdgcn_udot4(a, b, acc, false);
+  else return __builtin_amdgcn_udot2(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned short)))) unsigned short, a),
+                                     __builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned short)))) unsigned short, b), acc, false);
+}
 
 struct __attribute__((packed, aligned(1))) U128 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(1))) U64 { uint32_t v[2]; };
@@ -73,7 +91,7 @@ template <typename T, int W, int H, bool SKIP, int UPL> struct Geom {
 
 // BYTES at an arbitrary byte offset of LDS: BYTES/4 + 1 aligned dword reads, realigned in registers with v_alignbyte.
 // (Any LDS read off its natural alignment -- ds_read_b32 / _b64 / _b96 / _b128 alike -- returns the right bytes but is replayed at ~64
-// cycles per wave-instruction on gfx950: tools/r03_ubench.hip, profiles/r03_ubench.log: a 20-byte row at a random byte offset costs
+// cycles per wave-instruction on gfx950: tools/lds_ubench.hip, profiles/r03_ubench.log: a 20-byte row at a random byte offset costs
 // 134 ns as five misaligned b32, 54 ns as b128 + b32, against 17 ns for five aligned dwords; v_qsad_pk_u16_u8 / v_mqsad_* issue at
 // 1/3.6 of v_sad_u8's rate, so the quad-SAD forms lose to v_alignbyte + v_sad_u8 as well.)
 template <int BYTES>
@@ -152,14 +170,16 @@ using CfgWide = Cfg<512, 2, 8, 6, 4, 2, 1>;
 // 12 evaluating wavefronts with ONE row unit per lane + 4 loader wavefronts that keep twice the chunks in flight each (experiment,
 // see use_deep()).
 using CfgDeep = Cfg<768, 1, 4, 9, 6, 4, 2>;
-template <typename T, int W, int H, bool SKIP, typename C>
+template <typename T, int W, int H, bool SKIP, typename C, bool VAR = false>
 __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, PlaneView<T> ref, StripArgs a,
                                                                   const aomhip_sad_x4d_cand *__restrict__ groups,
                                                                   const int32_t *__restrict__ group_off, int n_groups,
                                                                   int64_t group_frame_stride, uint32_t *__restrict__ out4,
                                                                   const aomhip_sad_cand *__restrict__ cands,
                                                                   const int32_t *__restrict__ cand_off, int n_cands,
-                                                                  int64_t cand_frame_stride, uint32_t *__restrict__ out1) {
+                                                                  int64_t cand_frame_stride, uint32_t *__restrict__ out1,
+                                                                  uint32_t *__restrict__ out4b = nullptr, uint32_t *__restrict__ out1b = nullptr) {
+  static_assert(!VAR || (!SKIP && W * H <= 256), "the variance form: whole blocks of at most 256 pixels (32-bit sums)");
   constexpr int kThreads = C::kThreads, UPL = C::kUPL, kRingN = C::kRingN, kSrcN = C::kSrcN, kGN = C::kGN,
                 kCN = C::kCN, kLT = C::kLT;
   using G = Geom<T, W, H, SKIP, UPL>;
@@ -382,14 +402,52 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
       auto global_unit = [&](const char *frame, int pitch_b, int x, int y, int k) {
         return *reinterpret_cast<const L *>(frame + (int64_t)(y + unit_row(k)) * pitch_b + (int64_t)x * kES + unit_colb(k));
       };
-      auto sad_unit = [&](const L &s, const L &r, uint32_t acc) {
+      using AcT = Ac<VAR>;
+      using ResT = Res<VAR>;
+      // one reference dword against one source dword (the fast path hoists the source's own sums out of its five references)
+      auto add_ref = [&](uint32_t sd, uint32_t rd, AcT &acc) {
+        if constexpr (VAR) {
+          acc.a = sad_dword<T>(rd, 0u, acc.a);
+          acc.rr = dot_dword<T>(rd, rd, acc.rr);
+          acc.xr = dot_dword<T>(sd, rd, acc.xr);
+        } else {
+          acc.a = sad_dword<T>(sd, rd, acc.a);
+        }
+      };
+      auto add_src = [&](uint32_t sd, uint32_t &ssum, uint32_t &ss) {
+        ssum = sad_dword<T>(sd, 0u, ssum);
+        ss = dot_dword<T>(sd, sd, ss);
+      };
+      auto sad_unit = [&](const L &s, const L &r, AcT acc) {
   #pragma unroll
-        for (int i = 0; i < G::kUnitBytes / 4; ++i) acc = sad_dword<T>(s.v[i], r.v[i], acc);
+        for (int i = 0; i < G::kUnitBytes / 4; ++i) {
+          add_ref(s.v[i], r.v[i], acc);
+          if constexpr (VAR) add_src(s.v[i], acc.ssum, acc.ss);
+        }
         return acc;
       };
-      auto finish = [&](uint32_t acc) { return ((SKIP ? 2u * acc : acc) >> a.shift); };
+      // the lane group's partial sums -> the candidate's result (every lane of the group ends up with it)
+      auto reduce = [&](const AcT &acc) {
+        ResT r;
+        if constexpr (VAR) {
+          const uint32_t dsum = group_sum<G::kTpc>(acc.ssum - acc.a);                  // S(s) - S(r), two's complement
+          const uint32_t q = group_sum<G::kTpc>(acc.ss + acc.rr - 2u * acc.xr);
+          finish<(sizeof(T) > 1), ilog2v(W * H)>((int64_t)(int32_t)dsum, (uint64_t)q, 8 + a.shift, &r.v, &r.sse);   // (a.shift 0 / 2 / 4 <-> 8 / 10 / 12 bits)
+        } else {
+          r.v = ((SKIP ? 2u * group_sum<G::kTpc>(acc.a) : group_sum<G::kTpc>(acc.a)) >> a.shift);
+        }
+        return r;
+      };
+      auto store_group = [&](int64_t idx, const ResT &r0, const ResT &r1, const ResT &r2, const ResT &r3) {
+        reinterpret_cast<uint4 *>(out4)[idx] = make_uint4(r0.v, r1.v, r2.v, r3.v);
+        if constexpr (VAR) reinterpret_cast<uint4 *>(out4b)[idx] = make_uint4(r0.sse, r1.sse, r2.sse, r3.sse);
+      };
+      auto store_cand = [&](int64_t idx, const ResT &r) {
+        out1[idx] = r.v;
+        if constexpr (VAR) out1b[idx] = r.sse;
+      };
       auto generic_ref = [&](int sx, int sy, int rx, int ry) {  // both blocks straight from global memory
-        uint32_t acc = 0;
+        AcT acc;
   #pragma unroll kGenUnroll
         for (int k = 0; k < G::kUnitsPerLane; ++k)
           acc = sad_unit(global_unit(src_frame, sgpitch, sx, sy, k), global_unit(ref_frame, gpitch, rx, ry, k), acc);
@@ -491,7 +549,8 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
               for (int j = 0; j < 4; ++j) base[j] = quad_bcast(mbase, j);
               base[4] = both ? cbase : (unsigned)a.ring_off;
               if (!both) soff = 0;
-              uint32_t acc[5] = { 0, 0, 0, 0, 0 };
+              AcT acc[5];
+              [[maybe_unused]] uint32_t src_sum = 0, src_ss = 0;   // (variance: the source block's own sums, once for its five references)
               // The single candidate of a Mode-A style pair is the zero-MV one: 16-byte aligned in the ring whenever the cell grid is.  When
               // that holds for the whole wavefront its rows are read like the source's, with one aligned 16-byte load and no
               // realignment (and without the 4-way bank conflict of eight aligned rows x four aligned blocks read dword by dword).
@@ -534,30 +593,40 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
 #pragma unroll
                       for (int j = 0; j < kNr; ++j)
 #pragma unroll
-                        for (int i = 0; i <= kDw; ++i) acc[j] ^= raw[j][i];
-                      acc[4] ^= c4.v[0] ^ c4.v[3] ^ sv.v[1];
+                        for (int i = 0; i <= kDw; ++i) acc[j].a ^= raw[j][i];
+                      acc[4].a ^= c4.v[0] ^ c4.v[3] ^ sv.v[1];
                       continue;
                     }
 #endif
 #pragma unroll
                     for (int j = 0; j < kNr; ++j)
 #pragma unroll
-                      for (int i = 0; i < kDw; ++i) acc[j] = sad_dword<T>(sv.v[i], __builtin_amdgcn_alignbyte(raw[j][i + 1], raw[j][i], sh[j]), acc[j]);
-                    if constexpr (kAl) acc[4] = sad_unit(sv, c4, acc[4]);
+                      for (int i = 0; i < kDw; ++i) add_ref(sv.v[i], __builtin_amdgcn_alignbyte(raw[j][i + 1], raw[j][i], sh[j]), acc[j]);
+                    if constexpr (kAl) {
+#pragma unroll
+                      for (int i = 0; i < kDw; ++i) add_ref(sv.v[i], c4.v[i], acc[4]);
+                    }
+                    if constexpr (VAR) {
+#pragma unroll
+                      for (int i = 0; i < kDw; ++i) add_src(sv.v[i], src_sum, src_ss);
+                    }
                   }
                 }
               };
               if (cand_aligned) body(std::true_type{}); else body(std::false_type{});
               if (dbg & 128) {  // (timing ablation: no reduction, no stores)
-                if ((acc[0] & acc[1] & acc[2] & acc[3] & acc[4]) == 0xFFFFFFFFu) out1[0] = 0;
+                if ((acc[0].a & acc[1].a & acc[2].a & acc[3].a & acc[4].a) == 0xFFFFFFFFu) out1[0] = 0;
                 continue;
               }
+              ResT res[5];
 #pragma unroll
-              for (int j = 0; j < 5; ++j) acc[j] = group_sum<G::kTpc>(acc[j]);
+              for (int j = 0; j < 5; ++j) {
+                if constexpr (VAR) { acc[j].ssum = src_sum; acc[j].ss = src_ss; }
+                res[j] = reduce(acc[j]);
+              }
               if (lane_in_cand == 0 && both) {
-                reinterpret_cast<uint4 *>(out4)[(int64_t)f_rel * n_groups + g0 + i] =
-                    make_uint4(finish(acc[0]), finish(acc[1]), finish(acc[2]), finish(acc[3]));
-                out1[(int64_t)f_rel * n_cands + c0 + i] = finish(acc[4]);
+                store_group((int64_t)f_rel * n_groups + g0 + i, res[0], res[1], res[2], res[3]);
+                store_cand((int64_t)f_rel * n_cands + c0 + i, res[4]);
               }
               continue;
             }
@@ -600,7 +669,7 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
                 in = ring_pos(w, rx[j], ry[j], base[j], slot0[j]) && in;
               }
             }
-            uint32_t acc[4] = { 0, 0, 0, 0 };
+            AcT acc[4];
             if (in && !(dbg & 16)) {
               const bool s_al = (soff & (G::kUnitBytes - 1)) == 0;
               if (__all(s_al)) {
@@ -629,21 +698,24 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
                   jrx = (int)quad_bcast((unsigned)rx[0], j);
                   jry = (int)quad_bcast((unsigned)ry[0], j);
                 }
-                const uint32_t v = generic_ref(gsx, gsy, jrx, jry);
-                acc[0] = j == 0 ? v : acc[0]; acc[1] = j == 1 ? v : acc[1];
-                acc[2] = j == 2 ? v : acc[2]; acc[3] = j == 3 ? v : acc[3];
+                const AcT v = generic_ref(gsx, gsy, jrx, jry);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {   // (j is a loop counter here, the accumulators are registers: select, do not index)
+                  acc[q].a = j == q ? v.a : acc[q].a;
+                  if constexpr (VAR) {
+                    acc[q].rr = j == q ? v.rr : acc[q].rr; acc[q].xr = j == q ? v.xr : acc[q].xr;
+                    acc[q].ssum = j == q ? v.ssum : acc[q].ssum; acc[q].ss = j == q ? v.ss : acc[q].ss;
+                  }
+                }
               }
             }
-  #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = group_sum<G::kTpc>(acc[j]);
-            if (lane_in_cand == 0)
-              reinterpret_cast<uint4 *>(out4)[(int64_t)f_rel * n_groups + g0 + i] =
-                  make_uint4(finish(acc[0]), finish(acc[1]), finish(acc[2]), finish(acc[3]));
+            const ResT r0 = reduce(acc[0]), r1 = reduce(acc[1]), r2 = reduce(acc[2]), r3 = reduce(acc[3]);
+            if (lane_in_cand == 0) store_group((int64_t)f_rel * n_groups + g0 + i, r0, r1, r2, r3);
           }
           if (has_c) {
             const uint32_t d0 = cd[i * 2], d1 = cd[i * 2 + 1];
             const int sx = (int16_t)d0, sy = (int16_t)(d0 >> 16), rx = (int16_t)d1, ry = (int16_t)(d1 >> 16);
-            uint32_t acc = 0;
+            AcT acc;
             unsigned soff, base;
             int slot0;
             bool in = src_pos(w, sx, sy, soff);
@@ -663,8 +735,8 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
             } else {
               acc = generic_ref(sx, sy, rx, ry);
             }
-            acc = group_sum<G::kTpc>(acc);
-            if (lane_in_cand == 0) out1[(int64_t)f_rel * n_cands + c0 + i] = finish(acc);
+            const ResT rc = reduce(acc);
+            if (lane_in_cand == 0) store_cand((int64_t)f_rel * n_cands + c0 + i, rc);
           }
         }
       };
@@ -916,20 +988,17 @@ __global__ __launch_bounds__(C::kAll) void sad_strip_kernel(PlaneView<T> src, Pl
                   const uint32_t *e = reinterpret_cast<const uint32_t *>(glist + g + gi);
                   const uint32_t e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
                   const int sx = (int16_t)e0, sy = (int16_t)(e0 >> 16);
-                  uint32_t acc[4];
-                  acc[0] = group_sum<G::kTpc>(generic_ref(sx, sy, (int16_t)e1, (int16_t)e3));
-                  acc[1] = group_sum<G::kTpc>(generic_ref(sx, sy, (int16_t)(e1 >> 16), (int16_t)(e3 >> 16)));
-                  acc[2] = group_sum<G::kTpc>(generic_ref(sx, sy, (int16_t)e2, (int16_t)e4));
-                  acc[3] = group_sum<G::kTpc>(generic_ref(sx, sy, (int16_t)(e2 >> 16), (int16_t)(e4 >> 16)));
-                  if (lane_in_cand == 0)
-                    reinterpret_cast<uint4 *>(out4)[(int64_t)f_rel * n_groups + g + gi] =
-                        make_uint4(finish(acc[0]), finish(acc[1]), finish(acc[2]), finish(acc[3]));
+                  const ResT r0 = reduce(generic_ref(sx, sy, (int16_t)e1, (int16_t)e3));
+                  const ResT r1 = reduce(generic_ref(sx, sy, (int16_t)(e1 >> 16), (int16_t)(e3 >> 16)));
+                  const ResT r2 = reduce(generic_ref(sx, sy, (int16_t)e2, (int16_t)e4));
+                  const ResT r3 = reduce(generic_ref(sx, sy, (int16_t)(e2 >> 16), (int16_t)(e4 >> 16)));
+                  if (lane_in_cand == 0) store_group((int64_t)f_rel * n_groups + g + gi, r0, r1, r2, r3);
                 }
                 for (int ci = slot; ci < nc; ci += kPerWg) {
                   const uint32_t *e = reinterpret_cast<const uint32_t *>(clist + c + ci);
                   const uint32_t e0 = e[0], e1 = e[1];
-                  const uint32_t v = group_sum<G::kTpc>(generic_ref((int16_t)e0, (int16_t)(e0 >> 16), (int16_t)e1, (int16_t)(e1 >> 16)));
-                  if (lane_in_cand == 0) out1[(int64_t)f_rel * n_cands + c + ci] = finish(v);
+                  const ResT v = reduce(generic_ref((int16_t)e0, (int16_t)(e0 >> 16), (int16_t)e1, (int16_t)(e1 >> 16)));
+                  if (lane_in_cand == 0) store_cand((int64_t)f_rel * n_cands + c + ci, v);
                 }
               }
             }
@@ -967,11 +1036,13 @@ struct SbLaunch {
   int n_cands;
   int64_t cfs;
   uint32_t *out1;
+  uint32_t *out4b, *out1b;  // variance form: the sse arrays (out4 / out1 hold the variances)
+  bool var;
 };
 
-template <typename T, int W, int H, bool SKIP, typename C>
+template <typename T, int W, int H, bool SKIP, typename C, bool VAR = false>
 static int launch_nt(const SbLaunch &l, const PlaneView<T> &s, const PlaneView<T> &r) {
-  auto k = sad_strip_kernel<T, W, H, SKIP, C>;
+  auto k = sad_strip_kernel<T, W, H, SKIP, C, VAR>;
   static thread_local size_t granted = 0;  // per instantiation
   if (l.lds_bytes > granted) {
     AOMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -979,7 +1050,7 @@ static int launch_nt(const SbLaunch &l, const PlaneView<T> &s, const PlaneView<T
     granted = l.lds_bytes;
   }
   hipLaunchKernelGGL(k, dim3((unsigned)l.grid), dim3(C::kAll), l.lds_bytes, l.stream, s, r, l.a,
-                     l.groups, l.group_off, l.n_groups, l.gfs, l.out4, l.cands, l.cand_off, l.n_cands, l.cfs, l.out1);
+                     l.groups, l.group_off, l.n_groups, l.gfs, l.out4, l.cands, l.cand_off, l.n_cands, l.cfs, l.out1, l.out4b, l.out1b);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
 }
@@ -1008,8 +1079,22 @@ static int launch(const SbLaunch &l, const PlaneView<T> &s, const PlaneView<T> &
   X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(4, 16) X(16, 4) X(8, 32) X(32, 8) X(16, 64) X(64, 16)
 #endif
 
+#ifdef AOMHIP_SB_ONLY_16
+#define AOMHIP_FOR_VAR_BLOCK_SIZES(X) X(16, 16)
+#else
+#define AOMHIP_FOR_VAR_BLOCK_SIZES(X) X(4, 4) X(4, 8) X(8, 4) X(8, 8) X(8, 16) X(16, 8) X(16, 16) X(4, 16) X(16, 4) X(8, 32) X(32, 8)
+#endif
+
 template <typename T>
 static int dispatch(const SbLaunch &l, bool skip, const PlaneView<T> &s, const PlaneView<T> &r, int bw, int bh) {
+  if (l.var) {   // the variance form: whole blocks of at most 256 pixels
+#define X(W, H) \
+  if (bw == W && bh == H) return launch_nt<T, W, H, false, CfgWide, true>(l, s, r);
+    AOMHIP_FOR_VAR_BLOCK_SIZES(X)
+#undef X
+    set_error("aomhip_variance_sb_batch: blocks of at most 256 pixels (%dx%d): use aomhip_variance_batch", bw, bh);
+    return AOMHIP_ERR_INVALID;
+  }
 #define X(W, H) \
   if (bw == W && bh == H) return skip ? launch<T, W, H, (H >= 2)>(l, s, r) : launch<T, W, H, false>(l, s, r);
   AOMHIP_FOR_BLOCK_SIZES(X)
@@ -1033,19 +1118,19 @@ extern "C" int aomhip_debug_sb_prof(unsigned long long out[32], int reset) {
 }
 #endif
 
-extern "C" int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame,
-                                   int n_frames, int bw, int bh, int flags, int sb_w, int sb_h, int range,
-                                   int n_buckets, const aomhip_sad_x4d_cand *d_groups,
-                                   const int32_t *d_group_bucket_offsets, int n_groups, int64_t group_frame_stride,
-                                   uint32_t *d_out_groups, const aomhip_sad_cand *d_cands,
-                                   const int32_t *d_cand_bucket_offsets, int n_cands, int64_t cand_frame_stride,
-                                   uint32_t *d_out_cands) {
+static int sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame,
+                    int n_frames, int bw, int bh, int flags, int sb_w, int sb_h, int range,
+                    int n_buckets, const aomhip_sad_x4d_cand *d_groups,
+                    const int32_t *d_group_bucket_offsets, int n_groups, int64_t group_frame_stride,
+                    uint32_t *d_out_groups, const aomhip_sad_cand *d_cands,
+                    const int32_t *d_cand_bucket_offsets, int n_cands, int64_t cand_frame_stride,
+                    uint32_t *d_out_cands, bool var, uint32_t *d_out_groups_b, uint32_t *d_out_cands_b) {
   if (!ctx || !src || !ref || !src->base || !ref->base) {
     set_error("null argument");
     return AOMHIP_ERR_INVALID;
   }
-  if ((d_groups && (!d_group_bucket_offsets || !d_out_groups)) || (d_cands && (!d_cand_bucket_offsets || !d_out_cands)) ||
-      (!d_groups && !d_cands)) {
+  if ((d_groups && (!d_group_bucket_offsets || !d_out_groups || (var && !d_out_groups_b))) ||
+      (d_cands && (!d_cand_bucket_offsets || !d_out_cands || (var && !d_out_cands_b))) || (!d_groups && !d_cands) || (var && flags != 0)) {
     set_error("a list needs its bucket offsets and its output array; at least one list is required");
     return AOMHIP_ERR_INVALID;
   }
@@ -1158,7 +1243,29 @@ extern "C" int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
   l.out4 = d_out_groups;
   l.cands = n_cands > 0 ? d_cands : nullptr; l.cand_off = d_cand_bucket_offsets; l.n_cands = n_cands; l.cfs = cand_frame_stride;
   l.out1 = d_out_cands;
+  l.var = var; l.out4b = d_out_groups_b; l.out1b = d_out_cands_b;
   const bool skip = (flags & AOMHIP_SAD_SKIP_ROWS) != 0;
   if (src->bit_depth == 8) return sb::dispatch<uint8_t>(l, skip, view_of<uint8_t>(*src), view_of<uint8_t>(*ref), bw, bh);
   return sb::dispatch<uint16_t>(l, skip, view_of<uint16_t>(*src), view_of<uint16_t>(*ref), bw, bh);
+}
+
+extern "C" int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame,
+                                   int n_frames, int bw, int bh, int flags, int sb_w, int sb_h, int range,
+                                   int n_buckets, const aomhip_sad_x4d_cand *d_groups,
+                                   const int32_t *d_group_bucket_offsets, int n_groups, int64_t group_frame_stride,
+                                   uint32_t *d_out_groups, const aomhip_sad_cand *d_cands,
+                                   const int32_t *d_cand_bucket_offsets, int n_cands, int64_t cand_frame_stride,
+                                   uint32_t *d_out_cands) {
+  return sb_batch(ctx, src, ref, first_frame, n_frames, bw, bh, flags, sb_w, sb_h, range, n_buckets, d_groups, d_group_bucket_offsets, n_groups,
+                  group_frame_stride, d_out_groups, d_cands, d_cand_bucket_offsets, n_cands, cand_frame_stride, d_out_cands, false, nullptr, nullptr);
+}
+
+extern "C" int aomhip_variance_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame, int n_frames, int bw,
+                                        int bh, int sb_w, int sb_h, int range, int n_buckets, const aomhip_sad_x4d_cand *d_groups,
+                                        const int32_t *d_group_bucket_offsets, int n_groups, int64_t group_frame_stride, uint32_t *d_var_groups,
+                                        uint32_t *d_sse_groups, const aomhip_sad_cand *d_cands, const int32_t *d_cand_bucket_offsets, int n_cands,
+                                        int64_t cand_frame_stride, uint32_t *d_var_cands, uint32_t *d_sse_cands) {
+  return sb_batch(ctx, src, ref, first_frame, n_frames, bw, bh, 0, sb_w, sb_h, range, n_buckets, d_groups, d_group_bucket_offsets, n_groups,
+                  group_frame_stride, d_var_groups, d_cands, d_cand_bucket_offsets, n_cands, cand_frame_stride, d_var_cands, true, d_sse_groups,
+                  d_sse_cands);
 }

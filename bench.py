@@ -895,7 +895,7 @@ def run_inner_loop(pkg, ctx, orc, steps, warmup):
             stages[name]["cache_resident_GBs"] = stage_bytes[name] / (ms * 1e-3) / 1e9
             stages[name]["cache_resident_rate_over_8TBs"] = stages[name]["cache_resident_GBs"] / HBM_PEAK_GBS
     # Each stage's own roofline: these kernels are bound by instruction issue, not by bytes.  VALU wave-instructions per launch come from the
-    # committed PMC passes (profiles/r0N_inner_loop_pmc.json, tools/r04_pmc_stages.sh: SQ_INSTS_VALU / SQ_WAVES of the same kernel x the
+    # committed PMC passes (profiles/r0N_inner_loop_pmc.json, tools/gpu_pmc_stages.sh: SQ_INSTS_VALU / SQ_WAVES of the same kernel x the
     # launch's wavefronts).  The issue rate is MEASURED in this run (aomhip_valu_issue_probe, csrc/probe.hip; profiles/r05_valu_issue.md):
     # a SIMD of gfx950 retires one wave64 instruction per ~2 clocks for a small "fast" class (v_add/sub_u32, v_mov, v_and/or/xor,
     # v_lshrrev, v_ashrrev, fp32 add / mul / fma) and one per ~4 clocks for every other integer / packed / dot / SAD / DPP / 64-bit opcode
@@ -1753,8 +1753,11 @@ def build_lines(args, world, main_res, others, strong):
                 # SURVEY 8(d) rows A6-A8 / E / F on HBM-resident rings: frac = algorithmic bytes, c = compulsory bytes (every ring byte once),
                 # t = counter traffic (null until measured on this kernel source), all / launch time / 8 TB/s
                 variance={o["workload"].replace("variance16x16_modeA_", "var_").replace("sub_pixel_var_", "subpel_var_"):
-                          {"frac": o["roofline"]["frac"], "c": o["roofline"]["frac_compulsory"], "t": o["roofline"]["frac_traffic"],
-                           "ms": o["roofline"]["avg_launch_ms"], "parity": o["parity_sample_slot0_and_last"]} for o in vars_} or None,
+                          dict({"frac": o["roofline"]["frac"], "c": o["roofline"]["frac_compulsory"], "t": o["roofline"]["frac_traffic"],
+                                "ms": o["roofline"]["avg_launch_ms"], "parity": o["parity_sample_slot0_and_last"]},
+                               # (full-pel lists through the strip walk, aomhip_variance_sb_batch: the same evaluations, bit-identical)
+                               **({"sb_ms": o["strip_walk"]["avg_launch_ms"], "sb_c": o["strip_walk"]["frac_compulsory"], "sb_t": o["strip_walk"]["frac_traffic"],
+                                   "sb_same": o["strip_walk"]["identical_to_direct_slot0_and_last"]} if o.get("strip_walk") else {})) for o in vars_} or None,
                 filters_ring=None if filt is None else dict(
                     {k: {"us": filt[k]["ms_per_plane"] * 1e3, "frac": filt[k]["frac"], "c": filt[k]["frac_compulsory"], "t": filt[k]["frac_traffic"]}
                      for k in ("deblock_vert+horz", "cdef_luma")}, parity=filt["parity_slot0_and_last"], ring_GB=1.32),
@@ -1969,7 +1972,7 @@ def main():
                               vs_baseline=None, dtype="u16", data="synthetic", ms_per_step=r["ms_per_frame"], config={"workload": r["workload"]})))
         return
     if args.workload == "compound_search_4k_10bit":  # the RD path's compound / OBMC searches (single GPU)
-        only = int(os.environ.get("AOMHIP_BENCH_COMPOUND_BS", "0"))   # profiling aid: this block size alone (tools/r05_e.sh)
+        only = int(os.environ.get("AOMHIP_BENCH_COMPOUND_BS", "0"))   # profiling aid: this block size alone (profiles/r05e_compound_pmc.json)
         r = run_compound_search(pkg, ctx, orc if not only else None, args.steps, args.warmup, bs=only or 16)
         # the same five calls over the frame cut into 8x8, 32x32 and 64x64 blocks (timing only; the tests cover the sizes' parity)
         r["by_block_size"] = {"%dx%d" % (only or 16, only or 16): {k: v["ms_per_frame"] for k, v in r.items() if isinstance(v, dict) and "ms_per_frame" in v}}

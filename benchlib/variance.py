@@ -81,13 +81,48 @@ def run_variance(pkg, ctx, orc, steps, warmup, name):
             got_v = ctx.from_device(d_var + f * n * 4, (n,), np.uint32)[pick]
             got_s = ctx.from_device(d_sse + f * n * 4, (n,), np.uint32)[pick]
             ok &= bool(np.array_equal(got_v, want[:, 0]) and np.array_equal(got_s, want[:, 1]))
+    # ---- the same evaluations through the strip walk (aomhip_variance_sb_batch, full-pel only): lists bucketed by cell as for the SAD kernel
+    strip = None
+    if not subpel:
+        cell = (240, 64) if bd == 8 and W == 1920 else (320, 48) if bd == 8 else (160, 32)
+        perm, off = synth.bucket_order(base_c["sx"], base_c["sy"], W, H, *cell)
+        c5 = cands.reshape(F, nb, 5)
+        g = np.zeros((F, nb), capi.sad_x4d_dtype)
+        g["sx"], g["sy"] = c5["sx"][:, :, 0], c5["sy"][:, :, 0]
+        g["rx"], g["ry"] = c5["rx"][:, :, 1:], c5["ry"][:, :, 1:]
+        d_g, d_c1, d_off = ctx.to_device(np.ascontiguousarray(g[:, perm])), ctx.to_device(base_c[perm]), ctx.to_device(off)
+        d_v4, d_s4, d_v1, d_s1 = ctx.malloc(F * nb * 16), ctx.malloc(F * nb * 16), ctx.malloc(F * nb * 4), ctx.malloc(F * nb * 4)
+
+        def step_sb():
+            ctx.variance_sb_batch(src, ref, 0, F, 16, 16, cell[0], cell[1], 64, len(off) - 1, d_g, d_off, nb, nb, d_v4, d_s4, d_c1, d_off, nb, 0, d_v1, d_s1)
+
+        sb_ms = kernel_avg_ms(ctx, step_sb, max(steps, 10))
+        # parity: every evaluation of ring slot 0 and of the last slot against the direct kernel's results (which the oracle sample above checks)
+        same = True
+        for f in (0, F - 1):
+            dv = ctx.from_device(d_var + f * n * 4, (nb, 5), np.uint32)[perm]
+            dq = ctx.from_device(d_sse + f * n * 4, (nb, 5), np.uint32)[perm]
+            same &= bool(np.array_equal(ctx.from_device(d_v4 + f * nb * 16, (nb, 4), np.uint32), dv[:, 1:]) and
+                         np.array_equal(ctx.from_device(d_s4 + f * nb * 16, (nb, 4), np.uint32), dq[:, 1:]) and
+                         np.array_equal(ctx.from_device(d_v1 + f * nb * 4, (nb,), np.uint32), dv[:, 0]) and
+                         np.array_equal(ctx.from_device(d_s1 + f * nb * 4, (nb,), np.uint32), dq[:, 0]))
+        es_ = 1 if bd == 8 else 2
+        comp_sb = F * (2 * W * H * es_ + nb * (20 + 8 / F + 40))   # planes + one group record, the shared single list, 10 results per block
+        strip = {"kernel": "sad_strip_kernel<VAR>", "cell": list(cell), "avg_launch_ms": sb_ms, "identical_to_direct_slot0_and_last": same,
+                 "frac": F * n * bytes_per_eval(bd, False) / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "frac_compulsory": comp_sb / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "speedup_over_direct": avg_ms / sb_ms,
+                 "traffic": load_traffic_entry(ROOT, name + ":sb", source_sha(ROOT, ("sad_sb.hip",)))}
+        strip["frac_traffic"] = (strip["traffic"] / (sb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if strip["traffic"] else None
+        for d in (d_g, d_c1, d_off, d_v4, d_s4, d_v1, d_s1):
+            ctx.free(d)
     es = 1 if bd == 8 else 2
     algo = F * n * bytes_per_eval(bd, subpel)
     compulsory = F * (2 * W * H * es + n * (12 + 8))
     key = name
     traffic = load_traffic_entry(ROOT, key, source_sha(ROOT, VAR_SOURCES))
     res = {"workload": name, "value": F * n * steps / wall, "unit": "evaluations/s", "ms_per_step": wall / steps * 1e3, "event_ms_per_step": ev_ms / steps,
-           "evaluations_per_step": F * n, "parity_sample_slot0_and_last": ok,
+           "evaluations_per_step": F * n, "parity_sample_slot0_and_last": ok, "strip_walk": strip,
+           "parity_strip_walk": None if strip is None else strip["identical_to_direct_slot0_and_last"],
            "roofline": {"bound": "hbm", "kernel": "variance_kernel", "avg_launch_ms": avg_ms, "achieved": algo / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": algo / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo,
                         "bytes_per_evaluation": bytes_per_eval(bd, subpel), "compulsory_bytes_per_launch": compulsory,

@@ -214,6 +214,17 @@ int aomhip_sad_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_
                         int64_t group_frame_stride, uint32_t *d_out_groups, const aomhip_sad_cand *d_cands,
                         const int32_t *d_cand_bucket_offsets, int n_cands, int64_t cand_frame_stride,
                         uint32_t *d_out_cands);
+/* aom_varianceWxH / aom_highbd_{10,12}_varianceWxH (aom_dsp/variance.c:56-163,383-420) through the SAME strip walk: the lists, the buckets, the
+ * range contract and the fall-backs are aomhip_sad_sb_batch's (a candidate outside its window is still evaluated, from memory), the results
+ * per candidate are the variance (d_var_*) and *sse (d_sse_*): d_var_groups / d_sse_groups hold 4 values per group, d_var_cands / d_sse_cands
+ * one per candidate; diff = src - ref.  Blocks of at most 256 pixels (4x4 .. 16x16, 8x32, 32x8: the sums are 32-bit); larger blocks and
+ * sub-pixel positions: aomhip_variance_batch / aomhip_sub_pixel_variance_batch.  Round 6: on the Mode-A rings the direct kernel is bound by
+ * the L1 fill path (every lane pulls its 16-byte row out of a different line); here every reference row enters LDS once. */
+int aomhip_variance_sb_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int first_frame, int n_frames, int bw, int bh,
+                             int sb_w, int sb_h, int range, int n_buckets, const aomhip_sad_x4d_cand *d_groups,
+                             const int32_t *d_group_bucket_offsets, int n_groups, int64_t group_frame_stride, uint32_t *d_var_groups,
+                             uint32_t *d_sse_groups, const aomhip_sad_cand *d_cands, const int32_t *d_cand_bucket_offsets, int n_cands,
+                             int64_t cand_frame_stride, uint32_t *d_var_cands, uint32_t *d_sse_cands);
 
 /* Measurement support (bench.py's roofline.ceiling_GBs): the memory walk of aomhip_sad_sb_batch with everything else removed -- 256
  * persistent workgroups read the windows (sb_w + 2 * range reference pixels, sb_w source pixels per row, sb_h rows per step) of the

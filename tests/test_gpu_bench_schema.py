@@ -75,6 +75,8 @@ def test_default_single_gpu_line_is_small_enough_for_the_driver_record(tmp_path)
     assert set(v) == {"var_1080p_8bit", "subpel_var_1080p_8bit", "var_4k_10bit", "subpel_var_4k_10bit"}
     for e in v.values():   # frac: algorithmic bytes (520 / 553 / 1 032 / 1 098 B per evaluation), c: compulsory bytes, t: counter traffic
         assert e["frac"] > 0 and 0 < e["c"] < 1 and e["ms"] > 0 and e["parity"] is True and "t" in e
+    for k in ("var_1080p_8bit", "var_4k_10bit"):   # the full-pel lists also through the strip walk (aomhip_variance_sb_batch), bit-identical and faster
+        assert v[k]["sb_same"] is True and 0 < v[k]["sb_ms"] < v[k]["ms"] and v[k]["c"] < v[k]["sb_c"] < 1 and "sb_t" in v[k]
     fr = d["filters_ring"]
     for k in ("deblock_vert+horz", "cdef_luma"):   # on a 1.3 GB ring of 4K 10-bit planes: an HBM figure
         assert 0 < fr[k]["frac"] < 1 and 0 < fr[k]["c"] < 1 and fr[k]["us"] > 0 and "t" in fr[k]

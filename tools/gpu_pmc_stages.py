@@ -1,4 +1,4 @@
-"""Per-kernel instruction counts of the inner loop from the --pmc passes of tools/r04_pmc_stages.sh -> gpurun_out/r04_pmc_stages/summary.json
+"""Per-kernel instruction counts of the inner loop from the --pmc passes of tools/gpu_pmc_stages.sh -> gpurun_out/gpu_pmc_stages/summary.json
 (copied to profiles/r04_inner_loop_pmc.json).  Counters are normalised per wavefront (counter / SQ_WAVES of the same pass and kernel) and scaled
 by the wavefronts the launch really has (grid / 64): the ratio does not depend on how many shader engines a counter is sampled on."""
 import csv, glob, json, sys, collections

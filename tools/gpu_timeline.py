@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of the configs[4] frame from a rocprofv3 --kernel-trace of `bench.py --workload inner_loop_4k_10bit`: the last N frames of the
 timed region, per kernel the in-chain duration and the gap to the previous kernel's end -> markdown on stdout.
-    python3 tools/r05_timeline.py <dir with *_kernel_trace.csv> [frames=20]"""
+    python3 tools/gpu_timeline.py <dir with *_kernel_trace.csv> [frames=20]"""
 import csv, glob, re, sys
 from collections import defaultdict
 

@@ -3,7 +3,7 @@
 //       v_sad_u16, v_perm_b32) against v_add_u32;
 //   (2) LDS read cost and RESULT of ds_read_b32 / ds_read2_b32 / ds_read_b64 / ds_read_b96 / ds_read_b128 by address alignment, with the
 //       strip kernel's lane pattern (8 lanes = 8 rows of one block at a 464-byte pitch, blocks at random columns).
-//   hipcc --offload-arch=gfx950 -O3 tools/r03_ubench.hip -o build/r03_ubench && build/r03_ubench
+//   hipcc --offload-arch=gfx950 -O3 tools/lds_ubench.hip -o build/r03_ubench && build/r03_ubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

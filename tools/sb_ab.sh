@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 6 A/B on one box: experiment builds of sad_strip_kernel (explib/libsadsb_<name>.so, tools/r06_build_exp.sh) x workloads x rounds,
-# then the phase clocks of the _prof builds.   OUT=<dir under gpurun_out> NAMES="base pd1 ..." REPS=3 PROF="base pd1" bash tools/r06_sad_ab.sh
+# round 6 A/B on one box: experiment builds of sad_strip_kernel (explib/libsadsb_<name>.so, tools/sb_build_exp.sh) x workloads x rounds,
+# then the phase clocks of the _prof builds.   OUT=<dir under gpurun_out> NAMES="base pd1 ..." REPS=3 PROF="base pd1" bash tools/sb_ab.sh
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"

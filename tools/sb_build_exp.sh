@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: experiment builds of csrc/sad_sb.hip (16x16 instantiations only) for same-box A/B runs.
-#   bash tools/r06_build_exp.sh name "flags" [name "flags" ...]   ->  explib/libsadsb_<name>.so and explib/libsadsb_<name>_prof.so
+#   bash tools/sb_build_exp.sh name "flags" [name "flags" ...]   ->  explib/libsadsb_<name>.so and explib/libsadsb_<name>_prof.so
 # Each is ONLY aomhip_sad_sb_batch (+ the phase-clock read-out) linked against the product library for the rest; the A/B tools rebind that
 # one entry point to it (tools/sb_override.py, AOMHIP_SB_LIB=...).  explib/ travels to the GPU box; build/ does not.
 set -eu

@@ -1,5 +1,5 @@
 """Kernel A/B support: AOMHIP_SB_LIB=<explib/libsadsb_*.so> rebinds aomhip_sad_sb_batch (and the phase-clock read-out) of the loaded
-binding to an experiment build of csrc/sad_sb.hip (tools/r06_build_exp.sh).  Tools only -- the package never looks at this variable."""
+binding to an experiment build of csrc/sad_sb.hip (tools/sb_build_exp.sh).  Tools only -- the package never looks at this variable."""
 import ctypes as C, os
 
 
