@@ -36,19 +36,25 @@ __device__ __forceinline__ void lpf_window_thr(int (&x)[14], int len, int lim8, 
   const int lim = lim8 << sh, blim = blim8 << sh, thr = thr8 << sh, one = 1 << sh;
   const int p3 = x[3], p2 = x[4], p1 = x[5], p0 = x[6], q0 = x[7], q1 = x[8], q2 = x[9], q3 = x[10];
 
-  bool mask = !(iabsd(p1 - p0) > lim || iabsd(q1 - q0) > lim || iabsd(p0 - q0) * 2 + iabsd(p1 - q1) / 2 > blim);
-  bool flat = false, flat2 = false;
-  if (len >= 6) {
-    mask = mask && !(iabsd(p2 - p1) > lim || iabsd(q2 - q1) > lim);
-    flat = !(iabsd(p1 - p0) > one || iabsd(q1 - q0) > one || iabsd(p2 - p0) > one || iabsd(q2 - q0) > one);
-  }
-  if (len >= 8) {
-    mask = mask && !(iabsd(p3 - p2) > lim || iabsd(q3 - q2) > lim);
-    flat = flat && !(iabsd(p3 - p0) > one || iabsd(q3 - q0) > one);
-  }
+  // filter_mask* / flat_mask* (loopfilter.c:26-102,521-600) as MAXIMA: "no difference of the set exceeds the limit" is one comparison of the
+  // largest one.  Written as a chain of `||` every comparison became a v_cmp into a scalar register pair plus an s_or -- ~25 scalar
+  // instructions per line, four lines per lane: the kernels issued 531 scalar against 898 vector instructions per wavefront and waited on
+  // the CU's one scalar unit (profiles/r05z inner loop PMC).  |a - b| of two pixel values is one v_sad_u32.
+  auto ad = [](int a, int b) {
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return (int)d;
+  };
+  const int d_p1p0 = ad(p1, p0), d_q1q0 = ad(q1, q0);
+  int m = max(d_p1p0, d_q1q0);
+  const int m6 = max(m, max(ad(p2, p1), ad(q2, q1))), m8 = max(m6, max(ad(p3, p2), ad(q3, q2)));
+  const int f6 = max(m, max(ad(p2, p0), ad(q2, q0))), f8 = max(f6, max(ad(p3, p0), ad(q3, q0)));
+  m = len >= 8 ? m8 : (len >= 6 ? m6 : m);
+  const bool mask = m <= lim && ad(p0, q0) * 2 + (ad(p1, q1) >> 1) <= blim;
+  const bool flat = len >= 6 && (len >= 8 ? f8 : f6) <= one;
+  bool flat2 = false;
   if (len == 14) {
-    flat2 = !(iabsd(x[2] - p0) > one || iabsd(x[11] - q0) > one || iabsd(x[1] - p0) > one ||
-              iabsd(x[12] - q0) > one || iabsd(x[0] - p0) > one || iabsd(x[13] - q0) > one);
+    flat2 = max(max(ad(x[2], p0), ad(x[11], q0)), max(max(ad(x[1], p0), ad(x[12], q0)), max(ad(x[0], p0), ad(x[13], q0)))) <= one;
   }
 
   if (len == 14 && flat2 && flat && mask) {
@@ -103,7 +109,7 @@ __device__ __forceinline__ void lpf_window_thr(int (&x)[14], int len, int lim8, 
     // filter4 / highbd_filter4 (loopfilter.c:104-134,602-638) in the signed offset domain
     const int off = 0x80 << sh, lo = -(128 << sh), hi = (128 << sh) - 1;
     const int ps1 = p1 - off, ps0 = p0 - off, qs0 = q0 - off, qs1 = q1 - off;
-    const bool hev = iabsd(p1 - p0) > thr || iabsd(q1 - q0) > thr;
+    const bool hev = max(d_p1p0, d_q1q0) > thr;
     int f = hev ? clampd(ps1 - qs1, lo, hi) : 0;
     f = mask ? clampd(f + 3 * (qs0 - ps0), lo, hi) : 0;
     const int f1 = clampd(f + 4, lo, hi) >> 3;
