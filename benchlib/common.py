@@ -1,4 +1,5 @@
 """Helpers every workload module shares: the clock ramp, the per-launch HIP-event timing and the roofline constants."""
+import json
 import os
 import time
 
@@ -48,3 +49,41 @@ def source_sha(root, files):
         with open(os.path.join(root, "aom-av1-psy_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# run-wide settings (bench.py's arguments), read by the workload modules
+FRAMES_OVERRIDE = 0
+TILE_COLUMNS = "uniform"   # --tile-columns
+BACKEND = "nccl"           # RCCL; "gloo" only for dry runs of the N > 1 code path
+
+
+TRAFFIC_SOURCES = {"sb": ("sad_sb.hip",), "sad": ("sad.hip",), "txq": ("xform_quant.hip", "txfm_device.h", "quant_device.h")}
+
+
+def traffic_kind(name):
+    return "sb" if name.endswith(":sb") else "txq" if name.startswith("txq") else "sad"
+
+
+def kernel_source_sha(kind):
+    """sha256[:16] of the kernel source a traffic figure describes (tools/pmc_traffic*.py store it beside the figure)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in TRAFFIC_SOURCES[kind]:
+        with open(os.path.join(ROOT, "aom-av1-psy_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json,
+    produced by tools/pmc_traffic*.py from separate rocprofv3 --pmc runs); None when not measured OR when the
+    figure was measured on another version of the kernel source than the one in this tree (a stale counter is not evidence)."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(p))
+        if (t.get("_measured_on") or {}).get(name) != kernel_source_sha(traffic_kind(name)):
+            return None
+        return t.get(name)
+    except Exception:
+        return None

@@ -38,6 +38,8 @@ def test_forced_one_rank_run_emits_the_multi_gpu_schema(tile_columns):
     ex = s["exchange"]
     assert ex["halo_ms_per_frame"] > 0 and ex["allgather_ms_per_frame"] > 0   # both exchange modes were run and timed
     assert ex["mode"] == "halo" and ex["halo_px"] == 132
+    eb = ex["expected_bytes_per_frame_max_rank"]   # from the exchange plan alone: what the driver's SCALE record can be checked against
+    assert set(eb) == {"halo_send", "halo_recv", "allgather_send", "allgather_recv"} and all(v == 0 for v in eb.values())   # one rank: nothing to exchange
     assert s["tile_columns_px"] == [3840] and s["tile_columns_px_uniform"] == [3840] and s["tile_columns_px_balanced"] == [3840]
     assert s["single_gpu_same_box"]["value"] > 0 and s["speedup_over_single_gpu"] > 0
     assert s["parity_sample_slot0"] in (True, None)

@@ -3,7 +3,7 @@
 import sys, os
 sys.path.insert(0, os.getcwd())
 import aom_av1_psy_amd as pkg
-import bench
+from benchlib import search as bench
 class P(bench.SearchPipeline):
     BS, BD = int(sys.argv[1]), int(sys.argv[2])
 ctx = pkg.capi.Context(0)

@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np
 import aom_av1_psy_amd as pkg
-import bench
+from benchlib import search as bench
 ctx = pkg.capi.Context(0)
 wl = bench.SearchPipeline(pkg, ctx, None, 0, 1, frames=2)
 q = pkg.capi.SearchParams.make(sys.argv[1], int(sys.argv[2]), pkg.capi.MV_COST_L1_HDRES, run_mesh=int(sys.argv[3]) if len(sys.argv) > 3 else 0,

@@ -10,7 +10,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 sys.path.insert(0, os.getcwd())
-import bench  # WORKLOADS (sizes only; no GPU work at import)
+from benchlib import common as bench_common, sad as bench  # WORKLOADS (sizes only; no GPU work at import)
 
 
 def main(tag, wl):
@@ -38,7 +38,7 @@ def main(tag, wl):
         tj = os.path.join("profiles", "traffic.json")
         t = json.load(open(tj)) if os.path.exists(tj) else {}
         t[wl + ":sb"] = rd + wr
-        t.setdefault("_measured_on", {})[wl + ":sb"] = bench.kernel_source_sha("sb")
+        t.setdefault("_measured_on", {})[wl + ":sb"] = bench_common.kernel_source_sha("sb")
         json.dump(t, open(tj, "w"), indent=1, sort_keys=True)
     json.dump(out, open(os.path.join("profiles", "%s_pmc_sb_%s.json" % (tag, wl)), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: out[k] for k in out if k != "notes"}, sort_keys=True)[:1500])

@@ -12,7 +12,7 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 sys.path.insert(0, os.getcwd())
-import bench  # kernel_source_sha (no GPU work at import)
+from benchlib import common as bench  # kernel_source_sha (no GPU work at import)
 
 
 def main(tag, workload="txq_1080p_8bit"):
