@@ -123,6 +123,9 @@ COMP_AVG, COMP_DIST_WTD, COMP_MASK, COMP_OBMC = 0, 1, 2, 3
 blend_item_dtype = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("mask_offset", "<u2"), ("vertical", "u1"), ("reserved", "u1")])
 rect_dtype = np.dtype([("h_start", "<i4"), ("h_end", "<i4"), ("v_start", "<i4"), ("v_end", "<i4")])
 scaled_block_dtype = np.dtype([(n, "<i4") for n in ("src_x", "src_y", "subpel_x_qn", "subpel_y_qn", "dst_x", "dst_y")])   # aomhip_scaled_block
+txfm_yrd_block_dtype = np.dtype([("bx", "<i2"), ("by", "<i2"), ("tx_size_rate", "<i4"), ("no_skip_txfm_rate", "<i4"), ("skip_txfm_rate", "<i4"),
+                                 ("above_ctx", "u1", (32,)), ("left_ctx", "u1", (32,))])   # aomhip_txfm_yrd_block
+txfm_yrd_stats_dtype = np.dtype([("rd", "<i8"), ("dist", "<i8"), ("sse", "<i8"), ("rate", "<i4"), ("skip_txfm", "<i4")])   # aomhip_txfm_yrd_stats
 warp_model_dtype = np.dtype([("mat", "<i4", (6,)), ("alpha", "<i2"), ("beta", "<i2"), ("gamma", "<i2"), ("delta", "<i2")])
 warp_block_dtype = np.dtype([("mat", "<i4", (6,)), ("alpha", "<i2"), ("beta", "<i2"), ("gamma", "<i2"), ("delta", "<i2"), ("p_col", "<i4"), ("p_row", "<i4"),
                              ("p_width", "<i4"), ("p_height", "<i4")])   # aomhip_warp_block (48 bytes)
@@ -170,6 +173,7 @@ _protos = {
     "aomhip_sad_sb_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp,
                                       _i, _i64, _vp]),
     "aomhip_variance_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp]),
+    "aomhip_estimate_txfm_yrd_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_variance_sb_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "aomhip_sub_pixel_variance_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _i, _vp, _i, _i64, _vp, _vp]),
     "aomhip_variance": (C.c_uint, [_vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_uint)]),
@@ -563,6 +567,10 @@ class Context:
                                                    int(is_hbd), d_qcoeff, d_dqcoeff, d_eob), "aomhip_quantize_b_adaptive_batch")
 
     # ---- variance
+    def estimate_txfm_yrd_batch(self, src, pred, frame, bw, bh, qparams, d_costs, tx_type_rate, rdmult, lossless, d_blocks, n_blocks, d_stats):
+        check(lib.aomhip_estimate_txfm_yrd_batch(self.h, C.byref(src), C.byref(pred), frame, bw, bh, C.byref(qparams), d_costs, tx_type_rate, rdmult, lossless,
+                                                 d_blocks, n_blocks, d_stats), "aomhip_estimate_txfm_yrd_batch")
+
     def variance_sb_batch(self, src, ref, first_frame, n_frames, bw, bh, sb_w, sb_h, rng, n_buckets, d_groups=None, d_group_off=None, n_groups=0,
                           group_frame_stride=0, d_var_groups=None, d_sse_groups=None, d_cands=None, d_cand_off=None, n_cands=0, cand_frame_stride=0,
                           d_var_cands=None, d_sse_cands=None):

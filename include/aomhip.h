@@ -1224,6 +1224,30 @@ int aomhip_cost_coeffs_txb_laplacian_batch(aomhip_ctx *ctx, const int32_t *d_qco
 int aomhip_txb_entropy_context_batch(aomhip_ctx *ctx, const int32_t *d_qcoeff, int tx_size, const aomhip_txb *d_blocks, int n_blocks, int uniform_tx_type,
                                      const uint16_t *d_eob, uint8_t *d_entropy_ctx);
 
+/* av1_estimate_txfm_yrd (av1/encoder/tx_search.c:3016-3139) with ref_best_rd = INT64_MAX for a batch of INTER blocks of bw x bh luma pixels, each
+ * wholly inside the frame: the RD path's estimate of a candidate's luma rate and distortion through ONE transform size (max_txsize_rect_lookup
+ * [bsize]: the block's own size up to 64x64, 2 or 4 transform blocks of 64x64 for the 128-class sizes), DCT_DCT, AV1_XFORM_QUANT_B without
+ * matrices -- what av1_single_motion_search compares its two sub-pel candidates with when sf.mv_sf.disable_second_mv == 0
+ * (av1/encoder/motion_search_facade.c:378-425).  residual = src - pred of frame `frame` at the block; per transform block get_txb_ctx on the
+ * block's running above / left entropy contexts, av1_cost_coeffs_txb under d_costs (the 966 ints of aomhip_cost_coeffs_txb_batch for this
+ * transform size's context, plane type 0) + tx_type_rate when it has coefficients (get_tx_type_cost: mode_costs.inter_tx_type_costs[set]
+ * [square size][DCT_DCT], 0 for the 64-point sizes), dist_block_tx_domain, av1_set_txb_context; then the function's tail with the block's header
+ * rates and the forced-skip check (skipped when `lossless`).  Per block the host supplies what it looks up on its mode contexts. */
+typedef struct {
+  int16_t bx, by;                              /* the block's luma position, pixels relative to the visible origin */
+  int32_t tx_size_rate;                        /* tx_select ? mode_costs.txfm_partition_cost[txfm_partition_context(..)][0] : 0 */
+  int32_t no_skip_txfm_rate, skip_txfm_rate;   /* mode_costs.skip_txfm_cost[av1_get_skip_txfm_context(xd)][0], [1] */
+  uint8_t above_ctx[32], left_ctx[32];         /* xd->plane[0].above / left_entropy_context at the block: bw / 4 and bh / 4 entries are read */
+} aomhip_txfm_yrd_block;
+typedef struct {
+  int64_t rd;                                  /* the function's return value */
+  int64_t dist, sse;                           /* RD_STATS as the function leaves it */
+  int32_t rate, skip_txfm;
+} aomhip_txfm_yrd_stats;
+int aomhip_estimate_txfm_yrd_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *pred, int frame, int bw, int bh,
+                                   const aomhip_quant_params *qparams, const int32_t *d_costs, int tx_type_rate, int rdmult, int lossless,
+                                   const aomhip_txfm_yrd_block *d_blocks, int n_blocks, aomhip_txfm_yrd_stats *d_stats);
+
 /* The wedge-mask helpers of pick_wedge / pick_interinter_wedge (av1/encoder/compound_type.c), which choose the wedge index and sign of the
  * masked compound whose motion search is aomhip_compound_single_motion_search_batch: av1_wedge_sse_from_residuals,
  * av1_wedge_sign_from_residuals, av1_wedge_compute_delta_squares (av1/encoder/wedge_utils.c:52-125; av1/common/av1_rtcd_defs.pl:440-445).

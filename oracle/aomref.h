@@ -289,6 +289,12 @@ void orc_comp_mask_pred(void *comp_pred, const void *pred, int width, int height
                         int invert_mask, int elem16);
 int orc_return_extreme_sub_pixel_mv(const int *limits, int allow_hp, int want_max, int16_t *bestmv);
 
+/* av1_estimate_txfm_yrd and the RD-based second-MV choice (aomref_yrd.c) */
+int64_t orc_estimate_txfm_yrd(const int16_t *residual, int stride, int bw, int bh, int bd, int is_hbd, const int16_t q[5][2], const uint8_t *above,
+                              const uint8_t *left, const int32_t *costs, int tx_type_rate, int tx_size_rate, int no_skip_txfm_rate,
+                              int skip_txfm_rate, int rdmult, int lossless, int64_t *out);
+int orc_second_mv_rd_choice(int rdmult, int mv_rate0, int rate0, int64_t dist0, int mv_rate1, int rate1, int64_t dist1);
+
 #ifdef __cplusplus
 }
 #endif

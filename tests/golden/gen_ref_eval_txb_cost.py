@@ -30,8 +30,8 @@ TXH = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
 N_COSTS = 944
 
 
-def main():
-    import pyoracle as orc   # scan orders as INPUTS (pinned separately)
+def make_txb_evaluator(extra_macroblock_members="", extra_plane_members="", extra_xd_members="int unused;", pre_views=""):
+    """The evaluator of the coefficient coder's rate (shared with gen_ref_eval_yrd.py, which widens the MACROBLOCK views)."""
     ev = evaluator([])
     for n in ("TX_SIZE", "TX_CLASS", "TX_TYPE", "PLANE_TYPE"):
         ev.define(n, "int")
@@ -55,9 +55,11 @@ def main():
     ev.load(REF + "av1/encoder/cost.h")
     blk = open(REF + "av1/encoder/block.h").read()
     ev.load_text(re.search(r"typedef struct \{\s*//! Cost to skip txfm for the current txfm block\..*?\} LV_MAP_EOB_COST;", blk, re.S).group(0), "block.h:LV_MAP_*")
+    if pre_views:
+        ev.load_text(pre_views, "views: types the wider MACROBLOCK views need")
     ev.load_text("typedef struct { LV_MAP_COEFF_COST coeff_costs[TX_SIZES][PLANE_TYPES]; LV_MAP_EOB_COST eob_costs[7][2]; } CoeffCosts;\n"
-                 "struct macroblock_plane { tran_low_t *qcoeff; uint16_t *eobs; };\ntypedef struct macroblock { CoeffCosts coeff_costs; struct macroblock_plane plane[3]; } MACROBLOCK;\n"
-                 "typedef struct macroblockd { int unused; } MACROBLOCKD;\n", "block.h:views")
+                 "struct macroblock_plane { tran_low_t *qcoeff; uint16_t *eobs; " + extra_plane_members + " };\n" + extra_xd_members_decl(extra_xd_members) +
+                 "typedef struct macroblock { CoeffCosts coeff_costs; struct macroblock_plane plane[3]; " + extra_macroblock_members + " } MACROBLOCK;\n", "block.h:views")
     text = open(REF + "av1/encoder/encodetxb.c").read()
     for pat in (r"static const int8_t eob_to_pos_small\[33\] = \{.*?\};", r"static const int8_t eob_to_pos_large\[17\] = \{.*?\};",
                 r"int av1_get_eob_pos_token\([^;{]*\)\s*\{.*?\n}\n", r"static INLINE int get_nz_map_ctx\([^;{]*\)\s*\{.*?\n}\n",
@@ -79,6 +81,16 @@ def main():
         ev.load_text(re.search(pat, rd, re.S).group(0), "txb_rdopt.c:" + pat[:40])
     bad = [s for s in ev.skipped if s[0].startswith(("txb_rdopt", "encodetxb.c", "block.h"))]
     assert not bad, bad
+    return ev, state
+
+
+def extra_xd_members_decl(members):
+    return "typedef struct macroblockd { " + members + " } MACROBLOCKD;\n"
+
+
+def main():
+    import pyoracle as orc   # scan orders as INPUTS (pinned separately)
+    ev, state = make_txb_evaluator()
     rng = np.random.default_rng(20261114)
     arrays, cases = {}, []
     k = 0
