@@ -114,6 +114,13 @@ class QuantParams(C.Structure):
         return q
 
 
+class SingleRdParams(C.Structure):
+    """aomhip_single_rd_params."""
+    _fields_ = [("pred", C.POINTER(Planes)), ("filter_x", C.c_int32), ("filter_y", C.c_int32), ("qparams", C.POINTER(QuantParams)), ("d_costs", C.c_void_p),
+                ("tx_type_rate", C.c_int32), ("rdmult", C.c_int32), ("lossless", C.c_int32), ("d_yrd_blocks", C.c_void_p), ("d_stats_first", C.c_void_p),
+                ("d_stats_second", C.c_void_p), ("d_candidate_mvs", C.c_void_p)]
+
+
 txb_dtype = np.dtype([("x", "<i4"), ("y", "<i4"), ("out_offset", "<u4"), ("tx_type", "u1"), ("reserved", "u1", (3,))])
 sad_cand_dtype = np.dtype([("sx", "<i2"), ("sy", "<i2"), ("rx", "<i2"), ("ry", "<i2")])
 search_block_dtype = np.dtype([(n, "<i2") for n in ("bx", "by", "start_row", "start_col", "ref_row", "ref_col", "row_min",
@@ -237,6 +244,7 @@ _protos = {
     "aomhip_search_sites": (C.c_int, [_i, C.POINTER(C.c_int), _vp, _vp, _vp]),
     "aomhip_subpel_tree_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "aomhip_subpel_tree_list_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "aomhip_single_motion_search_rd_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_single_motion_search_batch": (C.c_int, [_vp, _PP, _PP, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aomhip_bind_variance_vtable": (C.c_int, [_vp, _i]),
     "aomhip_build_inter_pred_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _vp, _i, _i, _i]),
@@ -771,6 +779,14 @@ class Context:
                                                     use_cost_list, try_second_mv, force_integer_mv, d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, d_start2,
                                                     n, d_best_mv, d_bestsme, d_rate_mv, d_pred_sse, d_full_mv, d_second_best),
               "aomhip_single_motion_search_batch")
+
+    def single_motion_search_rd_batch(self, src, ref, frame, bw, bh, full, sub, d_blocks, n, rd, d_best_mv, d_bestsme, d_rate_mv, d_mvjcost, d_mvcost_row,
+                                      d_mvcost_col, d_start2=None, use_cost_list=0, force_integer_mv=0, d_pred_sse=None, d_full_mv=None, d_second_best=None):
+        """rd: SingleRdParams (keep the objects it points at alive for the call)"""
+        check(lib.aomhip_single_motion_search_rd_batch(self.h, C.byref(src), C.byref(ref), frame, bw, bh, C.byref(full), None if sub is None else C.byref(sub),
+                                                       use_cost_list, force_integer_mv, d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, d_start2, n,
+                                                       None if rd is None else C.byref(rd), d_best_mv, d_bestsme, d_rate_mv, d_pred_sse, d_full_mv, d_second_best),
+              "aomhip_single_motion_search_rd_batch")
 
     def build_inter_pred_batch(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, filter_x=0, filter_y=0, ss_x=0, ss_y=0):
         if ss_x or ss_y:

@@ -892,38 +892,60 @@ __global__ void single_select_kernel(const aomhip_search_block *blocks, const in
 }
 // the second sub-pel start (:370-389): second_best_mv when it is valid, differs from the winner and lies inside the sub-pel limits; the other
 // blocks start at the winner again, which the list stops at iteration 0 with INT_MAX -- the value that can never win below
-__global__ void single_second_list_kernel(const aomhip_search_block *sub_list, const int16_t *full_mv, const int16_t *second, int n, aomhip_search_block *out) {
+__global__ void single_second_list_kernel(const aomhip_search_block *sub_list, const int16_t *full_mv, const int16_t *second, int n, aomhip_search_block *out,
+                                          uint8_t *has_second) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   aomhip_search_block o = sub_list[i];
   const int sr = second[2 * i], sc = second[2 * i + 1];
   const bool differs = sr != full_mv[2 * i] || sc != full_mv[2 * i + 1];
-  if (sr != kInvalidMv && differs && sc * 8 >= o.col_min && sc * 8 <= o.col_max && sr * 8 >= o.row_min && sr * 8 <= o.row_max) {
+  // try_second (:370-372) && av1_is_subpelmv_in_range(&ms_params.mv_limits, subpel_start_mv) (:395-396)
+  const bool ok = full_mv[2 * i] != kInvalidMv && sr != kInvalidMv && differs && sc * 8 >= o.col_min && sc * 8 <= o.col_max && sr * 8 >= o.row_min && sr * 8 <= o.row_max;
+  if (ok) {
     o.start_row = (int16_t)(sr * 8); o.start_col = (int16_t)(sc * 8);
   }
   out[i] = o;
+  if (has_second) has_second[i] = ok ? 1 : 0;
 }
 __global__ void single_fill_invalid_kernel(int16_t *p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = (int16_t)kInvalidMv;
 }
+// (the RD form of the second-MV decision, sf.mv_sf.disable_second_mv == 0, motion_search_facade.c:378-425: yrd_a / yrd_b = av1_estimate_txfm_yrd of the
+// predictor at each candidate, has_second = the second search ran; NULL: the variance form)
 __global__ void single_finish_kernel(const aomhip_search_block *blocks, const int16_t *full_mv, int force_integer_mv, const int16_t *mv_a, const uint32_t *err_a,
                                      const uint32_t *sse_a, const int16_t *mv_b, const uint32_t *err_b, const uint32_t *sse_b, int n, const int32_t *mvjcost,
-                                     const int32_t *mvcost0, const int32_t *mvcost1, int16_t *best_mv, int32_t *rate_mv, uint32_t *pred_sse) {
+                                     const int32_t *mvcost0, const int32_t *mvcost1, int16_t *best_mv, int32_t *rate_mv, uint32_t *pred_sse,
+                                     const aomhip_txfm_yrd_stats *yrd_a = nullptr, const aomhip_txfm_yrd_stats *yrd_b = nullptr, const uint8_t *has_second = nullptr,
+                                     int rdmult = 0, int16_t *candidates = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int row = kInvalidMv, col = kInvalidMv, rate = 0;
   uint32_t sse = 0;
+  if (candidates) {
+    const bool live = full_mv[2 * i] != kInvalidMv && !force_integer_mv, two = live && yrd_a && has_second[i];
+    candidates[4 * i] = live ? mv_a[2 * i] : (int16_t)kInvalidMv; candidates[4 * i + 1] = live ? mv_a[2 * i + 1] : (int16_t)kInvalidMv;
+    candidates[4 * i + 2] = two ? mv_b[2 * i] : (int16_t)kInvalidMv; candidates[4 * i + 3] = two ? mv_b[2 * i + 1] : (int16_t)kInvalidMv;
+  }
   if (full_mv[2 * i] != kInvalidMv) {
+    const aomhip_search_block b = blocks[i];
+    auto mv_rate = [&](int r, int c) {                                                  // av1_mv_bit_cost(.., MV_COST_WEIGHT) (mcomp.c:261-266)
+      const int dr = r - b.ref_row, dc = c - b.ref_col;
+      const int64_t bits = (int64_t)mvjcost[(dc != 0) | ((dr != 0) << 1)] + mvcost0[dr] + mvcost1[dc];
+      return (int)((bits * 108 + 64) >> 7);
+    };
     if (force_integer_mv) { row = full_mv[2 * i] * 8; col = full_mv[2 * i + 1] * 8; }   // convert_fullmv_to_mv (:343-345)
     else {
       row = mv_a[2 * i]; col = mv_a[2 * i + 1]; sse = sse_a[i];
-      if (mv_b && (int)err_b[i] < (int)err_a[i]) { row = mv_b[2 * i]; col = mv_b[2 * i + 1]; sse = sse_b[i]; }   // this_var < best_mv_var (:421-425)
+      if (yrd_a) {
+        if (has_second[i]) {   // RDCOST(x->rdmult, mv_rate + stats.rate, stats.dist) of both; the second one replaces the first when SMALLER (:414-418)
+          const int64_t rd = ((((int64_t)mv_rate(row, col) + yrd_a[i].rate) * rdmult + 256) >> 9) + yrd_a[i].dist * 128;
+          const int64_t tmp_rd = ((((int64_t)yrd_b[i].rate + mv_rate(mv_b[2 * i], mv_b[2 * i + 1])) * rdmult + 256) >> 9) + yrd_b[i].dist * 128;
+          if (tmp_rd < rd) { row = mv_b[2 * i]; col = mv_b[2 * i + 1]; sse = sse_b[i]; }
+        }
+      } else if (mv_b && (int)err_b[i] < (int)err_a[i]) { row = mv_b[2 * i]; col = mv_b[2 * i + 1]; sse = sse_b[i]; }   // this_var < best_mv_var (:421-425)
     }
-    const aomhip_search_block b = blocks[i];
-    const int dr = row - b.ref_row, dc = col - b.ref_col;                               // av1_mv_bit_cost(.., MV_COST_WEIGHT) (mcomp.c:261-266)
-    const int64_t bits = (int64_t)mvjcost[(dc != 0) | ((dr != 0) << 1)] + mvcost0[dr] + mvcost1[dc];
-    rate = (int)((bits * 108 + 64) >> 7);
+    rate = mv_rate(row, col);
   }
   best_mv[2 * i] = (int16_t)row; best_mv[2 * i + 1] = (int16_t)col;
   rate_mv[i] = rate;
@@ -932,11 +954,23 @@ __global__ void single_finish_kernel(const aomhip_search_block *blocks, const in
 }  // namespace
 }  // namespace aomhip
 
-extern "C" int aomhip_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
-                                                 const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list, int try_second_mv,
-                                                 int force_integer_mv, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
-                                                 const aomhip_search_block *d_blocks, const int16_t *d_start2, int n, int16_t *d_best_mv, int32_t *d_bestsme,
-                                                 int32_t *d_rate_mv, uint32_t *d_pred_sse, int16_t *d_full_mv, int16_t *d_second_best_mv) {
+namespace aomhip {
+size_t yrd_workspace_bytes(int n_blocks, int bw, int bh);
+int estimate_txfm_yrd_ws(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *pred, int frame, int bw, int bh, const aomhip_quant_params *qparams,
+                         const int32_t *d_costs, int tx_type_rate, int rdmult, int lossless, const aomhip_txfm_yrd_block *d_blocks, int n_blocks,
+                         aomhip_txfm_yrd_stats *d_stats, char *ws);
+}  // namespace aomhip
+
+static int single_motion_search_impl(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                     const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list, int try_second_mv,
+                                     int force_integer_mv, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                     const aomhip_search_block *d_blocks, const int16_t *d_start2, int n, int16_t *d_best_mv, int32_t *d_bestsme,
+                                     int32_t *d_rate_mv, uint32_t *d_pred_sse, int16_t *d_full_mv, int16_t *d_second_best_mv, const aomhip_single_rd_params *rd) {
+  if (rd && (!rd->pred || !rd->pred->base || !rd->qparams || !rd->d_costs || !rd->d_yrd_blocks || frame >= rd->pred->n_frames ||
+             rd->pred->bit_depth != src->bit_depth || rd->pred->width != src->width || rd->pred->height != src->height)) {
+    set_error("aomhip_single_motion_search_rd_batch: the RD form needs a predictor ring of the source's geometry, the quantiser, the cost tables and the blocks' rates");
+    return AOMHIP_ERR_INVALID;
+  }
   if (!ctx || !src || !ref || !full || (!sub && !force_integer_mv) || n < 0 || !d_mvjcost || !d_mvcost_row || !d_mvcost_col ||
       (n > 0 && (!d_blocks || !d_best_mv || !d_bestsme || !d_rate_mv))) {
     set_error("aomhip_single_motion_search_batch: invalid argument (the rate of the result needs the MV cost tables)");
@@ -950,7 +984,9 @@ extern "C" int aomhip_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_p
   const size_t o_fl = take(n1 * SB), o_sl = take(n1 * SB), o_sl2 = take(n1 * SB), o_mv0 = take(n1 * 4), o_mv1 = take(n1 * 4), o_sec0 = take(n1 * 4),
                o_sec1 = take(n1 * 4), o_c0 = take(n1 * 4), o_c1 = take(n1 * 4), o_cl0 = take(n1 * 20), o_cl1 = take(n1 * 20), o_cl = take(n1 * 20),
                o_fmv = take(n1 * 4), o_sec = take(n1 * 4), o_lists = take(n1 * 12), o_mva = take(n1 * 4), o_erra = take(n1 * 4), o_dist = take(n1 * 4),
-               o_ssea = take(n1 * 4), o_mvb = take(n1 * 4), o_errb = take(n1 * 4), o_sseb = take(n1 * 4);
+               o_ssea = take(n1 * 4), o_mvb = take(n1 * 4), o_errb = take(n1 * 4), o_sseb = take(n1 * 4), o_has2 = take(n1),
+               o_yrda = take(n1 * sizeof(aomhip_txfm_yrd_stats)), o_yrdb = take(n1 * sizeof(aomhip_txfm_yrd_stats)),
+               o_yrdws = take(rd ? aomhip::yrd_workspace_bytes(n, bw, bh) : 0);
   char *w = static_cast<char *>(work(ctx, off));
   if (!w) return AOMHIP_ERR_NOMEM;
   auto blk = [&](size_t o) { return reinterpret_cast<aomhip_search_block *>(w + o); };
@@ -987,17 +1023,59 @@ extern "C" int aomhip_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_p
                                        i32(o_dist), u32(o_ssea), lists);
     if (rc != AOMHIP_OK) return rc;
     if (second) {
-      hipLaunchKernelGGL(single_second_list_kernel, dim3(g), dim3(256), 0, ctx->stream, blk(o_sl), fmv, sec, n, blk(o_sl2));
+      hipLaunchKernelGGL(single_second_list_kernel, dim3(g), dim3(256), 0, ctx->stream, blk(o_sl), fmv, sec, n, blk(o_sl2), reinterpret_cast<uint8_t *>(w + o_has2));
       AOMHIP_LAUNCH_CHECK();
       rc = aomhip_subpel_tree_list_batch(ctx, src, ref, frame, bw, bh, sub, d_mvjcost, d_mvcost_row, d_mvcost_col, blk(o_sl2), cl, n, i16(o_mvb),
                                          u32(o_errb), i32(o_dist), u32(o_sseb), lists);
       if (rc != AOMHIP_OK) return rc;
     }
   }
+  const aomhip_txfm_yrd_stats *ya = nullptr, *yb = nullptr;
+  if (rd && second) {
+    // the actual rd cost of each candidate (:378-391, :404-413): the predictor at the MV (av1_enc_build_inter_predictor, luma), its residual through
+    // av1_estimate_txfm_yrd.  Both candidates of every block are measured; blocks without a second search ignore the second figure.
+    aomhip_txfm_yrd_stats *sa = reinterpret_cast<aomhip_txfm_yrd_stats *>(w + o_yrda), *sb = reinterpret_cast<aomhip_txfm_yrd_stats *>(w + o_yrdb);
+    const int16_t *mvs[2] = { i16(o_mva), i16(o_mvb) };
+    aomhip_txfm_yrd_stats *st[2] = { sa, sb };
+    for (int c = 0; c < 2; ++c) {
+      rc = aomhip_build_inter_pred_batch(ctx, ref, frame, rd->pred, frame, bw, bh, d_blocks, mvs[c], n, rd->filter_x, rd->filter_y);
+      if (rc != AOMHIP_OK) return rc;
+      rc = aomhip::estimate_txfm_yrd_ws(ctx, src, rd->pred, frame, bw, bh, rd->qparams, rd->d_costs, rd->tx_type_rate, rd->rdmult, rd->lossless, rd->d_yrd_blocks, n,
+                                        st[c], w + o_yrdws);
+      if (rc != AOMHIP_OK) return rc;
+    }
+    ya = sa; yb = sb;
+    if (rd->d_stats_first) AOMHIP_TRY(hipMemcpyAsync(rd->d_stats_first, sa, n1 * sizeof(aomhip_txfm_yrd_stats), hipMemcpyDeviceToDevice, ctx->stream));
+    if (rd->d_stats_second) AOMHIP_TRY(hipMemcpyAsync(rd->d_stats_second, sb, n1 * sizeof(aomhip_txfm_yrd_stats), hipMemcpyDeviceToDevice, ctx->stream));
+  }
   hipLaunchKernelGGL(single_finish_kernel, dim3(g), dim3(256), 0, ctx->stream, d_blocks, fmv, force_integer_mv, i16(o_mva), u32(o_erra), u32(o_ssea),
-                     second ? i16(o_mvb) : nullptr, u32(o_errb), u32(o_sseb), n, d_mvjcost, d_mvcost_row, d_mvcost_col, d_best_mv, d_rate_mv, d_pred_sse);
+                     second ? i16(o_mvb) : nullptr, u32(o_errb), u32(o_sseb), n, d_mvjcost, d_mvcost_row, d_mvcost_col, d_best_mv, d_rate_mv, d_pred_sse, ya, yb,
+                     reinterpret_cast<const uint8_t *>(w + o_has2), rd ? rd->rdmult : 0, rd ? rd->d_candidate_mvs : nullptr);
   AOMHIP_LAUNCH_CHECK();
   return AOMHIP_OK;
+}
+
+extern "C" int aomhip_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                                 const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list, int try_second_mv,
+                                                 int force_integer_mv, const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                                 const aomhip_search_block *d_blocks, const int16_t *d_start2, int n, int16_t *d_best_mv, int32_t *d_bestsme,
+                                                 int32_t *d_rate_mv, uint32_t *d_pred_sse, int16_t *d_full_mv, int16_t *d_second_best_mv) {
+  return single_motion_search_impl(ctx, src, ref, frame, bw, bh, full, sub, use_cost_list, try_second_mv, force_integer_mv, d_mvjcost, d_mvcost_row, d_mvcost_col,
+                                   d_blocks, d_start2, n, d_best_mv, d_bestsme, d_rate_mv, d_pred_sse, d_full_mv, d_second_best_mv, nullptr);
+}
+
+extern "C" int aomhip_single_motion_search_rd_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                                    const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list, int force_integer_mv,
+                                                    const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                                    const aomhip_search_block *d_blocks, const int16_t *d_start2, int n, const aomhip_single_rd_params *rd,
+                                                    int16_t *d_best_mv, int32_t *d_bestsme, int32_t *d_rate_mv, uint32_t *d_pred_sse, int16_t *d_full_mv,
+                                                    int16_t *d_second_best_mv) {
+  if (!rd) {
+    set_error("aomhip_single_motion_search_rd_batch: null argument");
+    return AOMHIP_ERR_INVALID;
+  }
+  return single_motion_search_impl(ctx, src, ref, frame, bw, bh, full, sub, use_cost_list, /*try_second_mv=*/1, force_integer_mv, d_mvjcost, d_mvcost_row, d_mvcost_col,
+                                   d_blocks, d_start2, n, d_best_mv, d_bestsme, d_rate_mv, d_pred_sse, d_full_mv, d_second_best_mv, rd);
 }
 
 // ---- av1_joint_motion_search (av1/encoder/motion_search_facade.c:496-702) for independent compound blocks.  The branch of speed >= 1

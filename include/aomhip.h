@@ -956,6 +956,7 @@ int aomhip_single_motion_search_batch(aomhip_ctx *ctx, const aomhip_planes *src,
                                       const aomhip_search_block *d_blocks, const int16_t *d_start2, int n_blocks, int16_t *d_best_mv,
                                       int32_t *d_bestsme, int32_t *d_rate_mv, uint32_t *d_pred_sse, int16_t *d_full_mv, int16_t *d_second_best_mv);
 
+
 /* ------------------------------------------------------------------ full-pel + sub-pel search of a block list in one call (TPL, single motion search) */
 
 /* The two-call shape of tpl_model.c's motion_estimation (av1/encoder/tpl_model.c:248-301) and of av1_single_motion_search's core
@@ -1247,6 +1248,32 @@ typedef struct {
 int aomhip_estimate_txfm_yrd_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *pred, int frame, int bw, int bh,
                                    const aomhip_quant_params *qparams, const int32_t *d_costs, int tx_type_rate, int rdmult, int lossless,
                                    const aomhip_txfm_yrd_block *d_blocks, int n_blocks, aomhip_txfm_yrd_stats *d_stats);
+
+/* aomhip_single_motion_search_batch with the RD form of the second-MV decision (sf.mv_sf.use_accurate_subpel_search, disable_second_mv == 0; :378-425): after the sub-pel
+ * search from best_mv and -- where try_second holds and the start is inside the sub-pel limits -- from second_best_mv, each candidate's
+ * predictor is built into rd->pred (frame `frame` of a ring with the source's geometry; av1_enc_build_inter_predictor, luma, filters
+ * rd->filter_x / _y) and measured with aomhip_estimate_txfm_yrd_batch's composite; the second candidate replaces the first when
+ * RDCOST(rdmult, mv rate + rate, dist) is SMALLER, and x->pred_sse follows it.  rd->d_yrd_blocks[i] carries block i's header rates and entropy
+ * contexts (its bx / by are d_blocks[i]'s).  rd->d_stats_first / _second (may be NULL): av1_estimate_txfm_yrd's RD_STATS of the two candidates
+ * (the second one is meaningful where a second search ran); rd->d_candidate_mvs (may be NULL): [n][2][2], the MVs the two sub-pel searches ended on,
+ * -32768 for a search that did not run. */
+typedef struct {
+  const aomhip_planes *pred;
+  int32_t filter_x, filter_y;                /* mbmi->interp_filters as aomhip_build_inter_pred_batch takes them (0 = EIGHTTAP_REGULAR) */
+  const aomhip_quant_params *qparams;
+  const int32_t *d_costs;                    /* aomhip_estimate_txfm_yrd_batch's */
+  int32_t tx_type_rate, rdmult, lossless;
+  const aomhip_txfm_yrd_block *d_yrd_blocks;
+  aomhip_txfm_yrd_stats *d_stats_first, *d_stats_second;
+  int16_t *d_candidate_mvs;
+} aomhip_single_rd_params;
+int aomhip_single_motion_search_rd_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, int bw, int bh,
+                                         const aomhip_search_params *full, const aomhip_subpel_params *sub, int use_cost_list, int force_integer_mv,
+                                         const int32_t *d_mvjcost, const int32_t *d_mvcost_row, const int32_t *d_mvcost_col,
+                                         const aomhip_search_block *d_blocks, const int16_t *d_start2, int n, const aomhip_single_rd_params *rd,
+                                         int16_t *d_best_mv, int32_t *d_bestsme, int32_t *d_rate_mv, uint32_t *d_pred_sse, int16_t *d_full_mv,
+                                         int16_t *d_second_best_mv);
+
 
 /* The wedge-mask helpers of pick_wedge / pick_interinter_wedge (av1/encoder/compound_type.c), which choose the wedge index and sign of the
  * masked compound whose motion search is aomhip_compound_single_motion_search_batch: av1_wedge_sse_from_residuals,

@@ -1225,14 +1225,34 @@ def mv_bit_cost(mrow, mcol, ref_row, ref_col, mvjcost, mvcost0, mvcost1, weight=
 INVALID_MV_ROW_COL = -32768
 
 
+def estimate_txfm_yrd(residual, bw, bh, bd, q, above, left, costs, tx_type_rate, tx_size_rate, no_skip_txfm_rate, skip_txfm_rate, rdmult, lossless=0):
+    """oracle/aomref_yrd.c orc_estimate_txfm_yrd (av1_estimate_txfm_yrd, tx_search.c:3204-3255) of one block's residual (int16 [bh, bw]); q = build_quantizer_y's
+    tables, above / left = the block's entropy contexts (32 bytes each), costs = LV_MAP_COEFF_COST + eob_cost.  -> dict(rd, rate, skip_txfm, dist, sse)"""
+    f = lib.orc_estimate_txfm_yrd
+    f.restype = C.c_int64
+    res = np.ascontiguousarray(residual, np.int16)
+    tabs = np.ascontiguousarray(np.stack([np.asarray(q[k], np.int16)[:2] for k in ("zbin", "round", "quant", "quant_shift", "dequant")]))
+    ab, lf, cs = np.ascontiguousarray(above, np.uint8), np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(costs, np.int32)
+    out = np.zeros(4, np.int64)
+    rd = f(C.c_void_p(res.ctypes.data), res.shape[1], bw, bh, bd, int(bd > 8), C.c_void_p(tabs.ctypes.data), C.c_void_p(ab.ctypes.data), C.c_void_p(lf.ctypes.data),
+           C.c_void_p(cs.ctypes.data), int(tx_type_rate), int(tx_size_rate), int(no_skip_txfm_rate), int(skip_txfm_rate), int(rdmult), int(lossless),
+           C.c_void_p(out.ctypes.data))
+    return dict(rd=int(rd), rate=int(out[0]), skip_txfm=int(out[1]), dist=int(out[2]), sse=int(out[3]))
+
+
 def single_motion_search_batch(src_b, ref_b, border, w, h, blocks, q, sub, start2=None, use_cost_list=0, try_second_mv=0, force_integer_mv=0,
-                               mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4):
+                               mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=4, rd=None):
     """The SIMPLE_TRANSLATION core of av1_single_motion_search (motion_search_facade.c:120-495) as a composition of the pinned pieces, for a
     list of independent (block, reference) pairs.  blocks: ref_* = ref_mv (1/8 pel), start_* = cand[0] (FULLPEL, -32768 = skipped by
     skip_fullpel_search_using_startmv), limits = raw x->mv_limits; start2 [n, 2] = cand[1] or -32768 (:271-290: the caller knows before
     searching how many candidates the weight rule admits).  try_second_mv: use_accurate_subpel_search with disable_second_mv == 1 (:367-430, the
-    second sub-pel search from second_best_mv, kept when its var is smaller).  -> dict(best_mv [n,2] 1/8 pel or -32768, bestsme, rate_mv,
-    pred_sse, full_mv, second_best)"""
+    second sub-pel search from second_best_mv, kept when its var is smaller).  rd (with try_second_mv): the disable_second_mv == 0 form (:378-418) --
+    dict(filter_x, filter_y, q = build_quantizer_y tables, costs, tx_type_rate, rdmult, lossless, yrd_blocks = records with tx_size_rate,
+    no_skip_txfm_rate, skip_txfm_rate, above_ctx, left_ctx per block): each candidate's luma predictor (build_inter_pred) and residual go through
+    estimate_txfm_yrd, and the second candidate is kept when RDCOST(rdmult, mv rate + rate, dist) is smaller (orc_second_mv_rd_choice); the two RD_STATS
+    come back as stats_first / stats_second (lists, None where not computed) and the two candidates as cand_mvs [n, 2, 2] (-32768 where none).
+    rd["yrd_fn"] (tests of the sequencing only): called as yrd_fn(i, (row, col)) -> dict(rate, dist) INSTEAD of predictor + estimate_txfm_yrd.  -> dict(best_mv [n,2] 1/8 pel or -32768, bestsme, rate_mv, pred_sse,
+    full_mv, second_best)"""
     n = len(blocks)
     fl, sl = np.array(blocks, copy=True), np.array(blocks, copy=True)
     for i, b in enumerate(blocks):
@@ -1259,6 +1279,19 @@ def single_motion_search_batch(src_b, ref_b, border, w, h, blocks, q, sub, start
                 bestsme[i], full_mv[i], second[i] = int(cost[k]), mv[k], sec[k]
     out = dict(best_mv=np.full((n, 2), INVALID_MV_ROW_COL, np.int16), bestsme=bestsme.astype(np.int32), rate_mv=np.zeros(n, np.int32),
                pred_sse=np.zeros(n, np.uint32), full_mv=full_mv, second_best=second)
+    if rd is not None:
+        out["stats_first"], out["stats_second"], out["cand_mvs"] = [None] * n, [None] * n, np.full((n, 2, 2), INVALID_MV_ROW_COL, np.int16)
+        height, width = src_b.shape[0] - 2 * border, src_b.shape[1] - 2 * border
+
+        def yrd_at(i, mv):   # av1_enc_build_inter_predictor + av1_subtract_plane + av1_estimate_txfm_yrd (:381-388, :404-411)
+            if rd.get("yrd_fn") is not None:
+                return rd["yrd_fn"](i, (int(mv[0]), int(mv[1])))
+            b, yb = blocks[i], rd["yrd_blocks"][i]
+            pred = build_inter_pred(ref_b, border, width, height, w, h, blocks[i:i + 1], [mv], rd.get("filter_x", 0), rd.get("filter_y", 0), bd=bd)
+            x0, y0 = int(b["bx"]), int(b["by"])
+            res = src_b[border + y0:border + y0 + h, border + x0:border + x0 + w].astype(np.int32) - pred[y0:y0 + h, x0:x0 + w].astype(np.int32)
+            return estimate_txfm_yrd(res, w, h, bd, rd["q"], yb["above_ctx"], yb["left_ctx"], rd["costs"], rd["tx_type_rate"], yb["tx_size_rate"],
+                                     yb["no_skip_txfm_rate"], yb["skip_txfm_rate"], rd["rdmult"], rd.get("lossless", 0))
     live = np.flatnonzero(full_mv[:, 0] != INVALID_MV_ROW_COL)     # if (best_mv->as_int == INVALID_MV) return (:298)
     if not len(live):
         return out
@@ -1285,7 +1318,17 @@ def single_motion_search_batch(src_b, ref_b, border, w, h, blocks, q, sub, start
                 mv2, err2, _, sse2 = subpel_tree_batch(src_b, ref_b, border, w, h, one, mvjcost=mvjcost, mvcost0=mvcost0, mvcost1=mvcost1,
                                                        cost_lists=cls[k:k + 1] if cls is not None else None, bd=bd, threads=1,
                                                        mv_lists=lists[k:k + 1], **sub)
-                if int(np.int32(err2[0])) < int(np.int32(err[k])):                              # this_var < best_mv_var (int compare, :421)
+                if rd is not None:
+                    b = blocks[i]
+                    s0, s1 = yrd_at(i, mv[k]), yrd_at(i, mv2[0])
+                    out["stats_first"][i], out["stats_second"][i] = s0, s1
+                    out["cand_mvs"][i, 0], out["cand_mvs"][i, 1] = mv[k], mv2[0]
+                    r0 = mv_bit_cost(mv[k][0], mv[k][1], b["ref_row"], b["ref_col"], mvjcost, mvcost0, mvcost1)
+                    r1 = mv_bit_cost(mv2[0][0], mv2[0][1], b["ref_row"], b["ref_col"], mvjcost, mvcost0, mvcost1)
+                    lib.orc_second_mv_rd_choice.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64]
+                    if lib.orc_second_mv_rd_choice(int(rd["rdmult"]), r0, s0["rate"], s0["dist"], r1, s1["rate"], s1["dist"]):   # tmp_rd < rd (:414-418)
+                        out["best_mv"][i], out["pred_sse"][i] = mv2[0], sse2[0]
+                elif int(np.int32(err2[0])) < int(np.int32(err[k])):                            # this_var < best_mv_var (int compare, :421)
                     out["best_mv"][i], out["pred_sse"][i] = mv2[0], sse2[0]
     for i in live:
         b = blocks[i]

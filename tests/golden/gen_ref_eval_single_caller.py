@@ -38,7 +38,7 @@ I32, U8, PTR = R.I32, R.U8, R.PTR
 OPER = r"((?:\w+(?:\[[^\]]+\])*(?:\.|->))*\w+(?:\[[^\]]+\])*)(\.|->)as_int"
 
 
-def adapt(text):
+def adapt(text, keep_rd=False):
     t = text.replace("void av1_single_motion_search(", "void single_ms(")
     t = t.replace("struct buf_2d backup_yv12[MAX_MB_PLANE] = { { 0, 0, 0, 0, 0 } };", "struct buf_2d backup_yv12[MAX_MB_PLANE];")
     t, n = re.subn(r"cand_mv_t cand\[MAX_TPL_BLK_IN_SB \* MAX_TPL_BLK_IN_SB \+ 1\];\s*av1_zero\(cand\);",
@@ -47,13 +47,21 @@ def adapt(text):
     inv = lambda a, acc: "(%s%sas_mv.row == INVALID_MV_ROW_COL && %s%sas_mv.col == INVALID_MV_ROW_COL)" % (a, acc, a, acc)
     setinv = lambda a, acc: "%s%sas_mv.row = INVALID_MV_ROW_COL; %s%sas_mv.col = INVALID_MV_ROW_COL" % (a, acc, a, acc)
     t = t.replace("best_mv->as_int = second_best_mv.as_int = INVALID_MV;", setinv("best_mv", "->") + "; " + setinv("second_best_mv", ".") + ";")
-    # the RD branch of the second-MV decision
-    a = t.index("struct macroblockd_plane *p = xd->plane;")
-    b = t.index("MV this_best_mv;", a)
-    t = t[:a] + t[b:]
-    a = t.index("if (!cpi->sf.mv_sf.disable_second_mv) {\n                // If cpi->sf.mv_sf.disable_second_mv is 0")
-    b = t.index("} else {\n                // If cpi->sf.mv_sf.disable_second_mv = 1", a)
-    t = t[:a] + "{" + t[b + len("} else {"):]
+    if keep_rd:
+        # the RD branch stays (gen_ref_eval_single_rd.py): only orig_dst -- the predictor's destination, an argument of a supplied function -- goes
+        a = t.index("struct macroblockd_plane *p = xd->plane;")
+        b = t.index("int64_t rd = INT64_MAX;", a)
+        t = t[:a] + t[b:]
+        assert t.count("&orig_dst") == 2
+        t = t.replace("&orig_dst", "NULL")
+    else:
+        # the RD branch of the second-MV decision
+        a = t.index("struct macroblockd_plane *p = xd->plane;")
+        b = t.index("MV this_best_mv;", a)
+        t = t[:a] + t[b:]
+        a = t.index("if (!cpi->sf.mv_sf.disable_second_mv) {\n                // If cpi->sf.mv_sf.disable_second_mv is 0")
+        b = t.index("} else {\n                // If cpi->sf.mv_sf.disable_second_mv = 1", a)
+        t = t[:a] + "{" + t[b + len("} else {"):]
     eq = lambda a1, c1, a2, c2: "(%s%sas_mv.row == %s%sas_mv.row && %s%sas_mv.col == %s%sas_mv.col)" % (a1, c1, a2, c2, a1, c1, a2, c2)
     t = re.sub(OPER + r" == INVALID_MV", lambda m: inv(m.group(1), m.group(2)), t)
     t = re.sub(OPER + r" != INVALID_MV", lambda m: "!" + inv(m.group(1), m.group(2)), t)
@@ -62,11 +70,12 @@ def adapt(text):
     t = re.sub(OPER + r" = INVALID_MV;", lambda m: "{ " + setinv(m.group(1), m.group(2)) + "; }", t)
     t = re.sub(OPER + r" = " + OPER + ";", lambda m: "%s%sas_mv = %s%sas_mv;" % (m.group(1), m.group(2), m.group(3), m.group(4)), t)
     assert "as_int" not in t, re.findall(r".{40}as_int.{20}", t)
-    assert "BUFFER_SET" not in t and "RD_STATS" not in t
+    assert "BUFFER_SET" not in t and (keep_rd or "RD_STATS" not in t)
     return t
 
 
-def main():
+def setup(keep_rd=False, before_function=None):
+    """-> (ev, enc, state, pred_text): the evaluator with av1_single_motion_search loaded; before_function(ev, enc): declarations the kept text needs"""
     ev = CS.make_evaluator()
     C.view(ev, "int_mv", [("as_mv", ev.structs["mv"])])
     ev.define("as_fullmv", "as_mv")
@@ -118,12 +127,22 @@ def main():
             ev.define(name, "(%d)" % val)
     text = open(REF + "av1/encoder/motion_search_facade.c").read()
     fn = re.search(r"void av1_single_motion_search\([^;{]*\)\s*\{.*?\n}\n", text, re.S).group(0)
-    ev.load_text(adapt(fn), "motion_search_facade.c:av1_single_motion_search")
+    if before_function:
+        before_function(ev, enc)
+    ev.load_text(adapt(fn, keep_rd), "motion_search_facade.c:av1_single_motion_search")
     for f in list(pyc):
         ev.funcs.pop(f, None)
     bad = [s for s in ev.skipped if s[0].startswith("motion_search_facade.c") or s[0].startswith("single:")]
     assert not bad, bad
     pred_text = OS.pred_buffer_adaptation(ev)   # upsampled_obmc_pref_error's pred[] typed per bit depth (see gen_ref_eval_obmc_subpel.py)
+    return ev, enc, state, pred_text
+
+
+MESH = [(12, 4), (6, 2), (4, 1), (3, 1)]
+
+
+def main():
+    ev, enc, state, pred_text = setup()
     arrays, cases = {}, []
     mvc = G.synth_mv_costs(23)
     arrays["mvjcost"], arrays["mvcost0"], arrays["mvcost1"] = mvc
