@@ -1385,7 +1385,7 @@ extern "C" int aomhip_compound_single_motion_search_batch(aomhip_ctx *ctx, const
 
 // ---- The inter leg of tpl_model.c's mode_estimation (av1/encoder/tpl_model.c:620-770) for blocks whose centre-MV candidates the caller has
 // gathered (the candidates come from the TPL stats of the blocks above / left / above-right, :652-683: a raster dependency the host walks,
-// anti-diagonal by anti-diagonal; a batch = blocks that do not depend on each other).  Per block and reference frame:
+// wavefront by wavefront -- blocks (r, c) with 2 r + c equal; a batch = blocks that do not depend on each other).  Per block and reference frame:
 //   prune_starting_mv (:706-731): the SAD of every candidate at its clamped full-pel position, the candidates ranked by it (qsort with
 //       compare_sad, :308-315; ties keep their order: glibc's qsort is a merge sort), the count cut to 4 - prune_starting_mv and once more
 //       when the last SAD is more than 20 % above the one before it,

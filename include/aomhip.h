@@ -977,7 +977,7 @@ int aomhip_motion_estimation_batch(aomhip_ctx *ctx, const aomhip_planes *src, co
 
 /* The INTER leg of tpl_model.c's mode_estimation (av1/encoder/tpl_model.c:620-770) for a batch of blocks that do not depend on each other.
  * The candidates' derivation -- the MVs the TPL stats hold for the blocks above, left and above-right, de-duplicated by is_alike_mv (:317-331,
- * :652-683) -- is a raster dependency between blocks and stays with the host, which walks the frame anti-diagonal by anti-diagonal and hands
+ * :652-683) -- is a raster dependency between blocks and stays with the host, which walks the frame wavefront by wavefront (blocks (r, c) with 2 r + c equal) and hands
  * every block its candidates; everything from there is one call:
  *   per reference r < n_refs (refs[r]: a ring whose frame `frame` is the reference picture for the source's frame `frame`):
  *     prune_starting_mv 1 .. 3 (sf.tpl_sf.prune_starting_mv; 0 = off): sdf of every candidate at its clamped full-pel position, the candidates

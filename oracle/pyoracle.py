@@ -1336,6 +1336,72 @@ def single_motion_search_batch(src_b, ref_b, border, w, h, blocks, q, sub, start
     return out
 
 
+def tpl_is_alike_mv(cand, centers, skip_alike_starting_mv):
+    """is_alike_mv (av1/encoder/tpl_model.c:317-331): both components closer than the threshold (1/8 pel: 1, 8 << 3, 16 << 3) to one of the centres"""
+    thr = (1, 8 << 3, 16 << 3)[int(skip_alike_starting_mv)]
+    return any(abs(int(c[1]) - int(cand[1])) < thr and abs(int(c[0]) - int(cand[0])) < thr for c in centers)
+
+
+def tpl_gather_candidates(above, left, above_right, skip_alike_starting_mv):
+    """The starting MVs of one reference for one TPL block (mode_estimation, tpl_model.c:643-683): the zero MV, then the MVs the TPL stats hold for the
+    block above, the block to the left and the block above-right (None where xd->up_available / left_available / `mi_col + mi_width < tile.mi_col_end`
+    fails), each taken unless is_alike_mv finds it among those already taken.  -> list of (row, col), 1 to 4 entries"""
+    centers = [(0, 0)]
+    for mv in (above, left, above_right):
+        if mv is not None and not tpl_is_alike_mv(mv, centers, skip_alike_starting_mv):
+            centers.append((int(mv[0]), int(mv[1])))
+    return centers
+
+
+def tpl_mode_decision(intra_costs, best_rf, best_inter_cost, best_mv):
+    """mode_estimation's decisions around the inter leg with allow_compound_pred == 0 (tpl_model.c:552-566, :766-770, :912-915, :990-994): the intra mode
+    with the first smallest cost (INT32_MAX start, DC_PRED = 0 first), NEWMV (16) when a reference exists and its cost is SMALLER than the best intra
+    cost; intra_cost = max(best, 1), inter_cost = min(intra_cost, best inter cost); ref_frame_index = (best_rf, -1) for NEWMV, (-1, -1) otherwise.
+    -> dict(best_mode, intra_cost, inter_cost, ref_frame_index)"""
+    best_intra, mode = 2147483647, 0
+    for m, c in enumerate(intra_costs):
+        if int(c) < best_intra:
+            best_intra, mode = int(c), m
+    newmv = int(best_rf) != -1 and int(best_inter_cost) < best_intra
+    intra_cost = max(best_intra, 1)
+    return dict(best_mode=16 if newmv else mode, intra_cost=intra_cost, inter_cost=min(intra_cost, int(best_inter_cost)),
+                ref_frame_index=[int(best_rf), -1] if newmv else [-1, -1])
+
+
+def tpl_mode_estimation_rows(src_b, ref_bs, border, width, height, bw, positions, limits, intra_costs, q, sub, use_cost_list=0, prune_starting_mv=0,
+                             skip_alike_starting_mv=0, mvjcost=None, mvcost0=None, mvcost1=None, bd=8, threads=1):
+    """mode_estimation for the blocks of whole rows of a frame in raster order, as av1_mc_flow_dispenser_row calls it (tpl_model.c:1257-1330) with
+    tpl_model_store between blocks: per block and reference tpl_gather_candidates on the stored stats of the neighbours, tpl_inter_estimation_batch for
+    the block, tpl_mode_decision.  ref_bs: list of border-extended reference planes (every reference exists); positions: (bx, by) in raster order,
+    complete rows from row 0; limits: raw x->mv_limits per block; intra_costs: per block the costs of the intra modes searched.
+    -> list of dict(mv [n_refs, 2], pred_error [n_refs], best_rf, best_inter_cost, candidates [n_refs] lists, **tpl_mode_decision)"""
+    n_refs = len(ref_bs)
+    stored, out = {}, []
+    cols = width // bw
+    for (bx, by), lim, ic in zip(positions, limits, intra_costs):
+        r, c = by // bw, bx // bw
+        blk = np.zeros(1, np.dtype([(k, "<i2") for k in ("bx", "by", "start_row", "start_col", "ref_row", "ref_col", "row_min", "row_max", "col_min", "col_max")]))
+        blk["bx"], blk["by"] = bx, by
+        blk["row_min"], blk["row_max"], blk["col_min"], blk["col_max"] = lim
+        centers = np.zeros((1, n_refs, 4, 2), np.int16)
+        counts = np.zeros((1, n_refs), np.uint8)
+        cands = []
+        for k in range(n_refs):
+            nb = lambda rr, cc: stored[(rr, cc)]["mv"][k] if (rr, cc) in stored else None
+            cl = tpl_gather_candidates(nb(r - 1, c) if r > 0 else None, nb(r, c - 1) if c > 0 else None,
+                                       nb(r - 1, c + 1) if r > 0 and c + 1 < cols else None, skip_alike_starting_mv)
+            cands.append(cl)
+            centers[0, k, :len(cl)] = cl
+            counts[0, k] = len(cl)
+        mv, pe, rf, bc = tpl_inter_estimation_batch(src_b, ref_bs, border, width, height, bw, blk, centers, counts, q, sub, use_cost_list, prune_starting_mv,
+                                                    mvjcost, mvcost0, mvcost1, bd=bd, threads=threads)
+        rec = dict(mv=mv[0].copy(), pred_error=pe[0].copy(), best_rf=int(rf[0]), best_inter_cost=int(bc[0]), candidates=cands)
+        rec.update(tpl_mode_decision(ic, rf[0], bc[0], mv[0, int(rf[0])] if rf[0] >= 0 else None))
+        stored[(r, c)] = rec
+        out.append(rec)
+    return out
+
+
 def simple_motion_search_batch(src_b, ref_b, border, width, height, w, h, blocks, q, sub=None, use_cost_list=0, mvjcost=None, mvcost0=None, mvcost1=None, bd=8,
                                threads=4):
     """av1_simple_motion_search + av1_simple_motion_sse_var (motion_search_facade.c:925-1060) as a composition of the pinned pieces:
