@@ -32,7 +32,7 @@ __device__ __forceinline__ int rawpel(int x) { return (x + 3 + (x >= 0)) >> 3; }
 // batch that was cut short and doubles after one that went through (1 .. SPEC), so incoherent content costs what one wavefront per row costs.
 struct FpBlockOut { int nrow, ncol, err, mrow, mcol, gf, raw; };
 
-template <typename T, int W, int H, int SPEC>
+template <typename T, int W, int H, int SPEC, bool NOSKIP>
 __global__ __launch_bounds__(SPEC * 64) void fp_row_kernel(PlaneView<T> src, PlaneView<T> last, const aomhip_search_block *__restrict__ blocks,
                                                           const SiteTable *__restrict__ sites, SearchArgs q, FpfLegs L, FpfCost C,
                                                           const int32_t *__restrict__ intra, int rows, int cols, int thr, int skip_zeromv, FpfOut out) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(SPEC * 64) void fp_row_kernel(PlaneView<T> src, Pla
         const T *sp = src.origin + (int64_t)by * src.stride + bx;
         const T *rbase = last.origin + (int64_t)by * last.stride + bx;
         FpsResult fr;
-        fps_block<T, W, H, false, true>(sp, src.stride, rbase, last.stride, bx, by, bs, sS, q, no_win, nullptr, lane, &fr);
+        fps_block<T, W, H, false, true, NOSKIP>(sp, src.stride, rbase, last.stride, bx, by, bs, sS, q, no_win, nullptr, lane, &fr);
         m1r = fr.br; m1c = fr.bc;
         if (fr.var != INT_MAX) {
           // av1_get_mvpred_sse (mcomp.c:3661-3677): the sse of the mse function at the full-pel MV + mv_err_cost, + NEW_MV_MODE_PENALTY (:292-296)
@@ -188,9 +188,13 @@ int launch_fp_rows(aomhip_ctx *ctx, const aomhip_planes *src1, const aomhip_plan
   const SearchArgs q = fps_search_args(p, d_mvjcost, d_mvcost_row, d_mvcost_col, src1->bit_depth, false);
   const FpfCost C{ p->mv_cost_type, p->error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col };
   const int spec = [] { const char *e = getenv("AOMHIP_FP_ROW_WAVES"); const int v = e ? atoi(e) : 8; return v == 1 || v == 4 || v == 16 ? v : 8; }();   // (A/B, tests)
+  // (NOSKIP: the full-SAD form -- fps_block without the row-skipping SAD and its re-check, 75 instead of 112 VGPRs in the batched kernel)
 #define XP(T, W, H, P)                                                                                                                   \
-  hipLaunchKernelGGL((fp_row_kernel<T, W, H, P>), dim3(rows), dim3(P * 64), 0, ctx->stream, view_of<T>(*src1), view_of<T>(*last1),       \
-                     d_blocks, d_sites, q, L, C, d_intra, rows, cols, thr, skip_zeromv, out);
+  {                                                                                                                                     \
+    auto k = q.skip_sad ? fp_row_kernel<T, W, H, P, false> : fp_row_kernel<T, W, H, P, true>;                                           \
+    hipLaunchKernelGGL(k, dim3(rows), dim3(P * 64), 0, ctx->stream, view_of<T>(*src1), view_of<T>(*last1),                              \
+                       d_blocks, d_sites, q, L, C, d_intra, rows, cols, thr, skip_zeromv, out);                                         \
+  }
 #define X(T, W, H)                                                                                                                      \
   {                                                                                                                                     \
     if (spec == 1) XP(T, W, H, 1) else if (spec == 4) XP(T, W, H, 4) else if (spec == 16) XP(T, W, H, 16) else XP(T, W, H, 8)            \
