@@ -57,3 +57,19 @@ def test_a_short_communicator_ends_the_job_with_a_non_zero_exit():
     p, el = run(4, {"AOMHIP_BENCH_FAKE_COMM_RANKS": "3"})
     assert p.returncode != 0 and el < 100, (p.returncode, el)
     assert "communicator holds 3 ranks, the job has 4" in p.stderr
+
+
+def test_the_driver_launch_form_under_torch_distributed_run():
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...`: bench.py then finds RANK / WORLD_SIZE in its environment and must NOT start ranks of its own."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29641",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "launcher_dry_run", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["strong_scaling_search"]["rccl_ranks_in_communicator"] == 2 and sum(d["strong_scaling_search"]["tile_columns_px"]) == 3840
