@@ -133,8 +133,8 @@ def build_lines(args, world, main_res, others, strong):
         line["strong_scaling_search"] = st
     line = _sig(line)
     # never let the line outgrow the record that reads it: shed the least important keys first (they stay in the full record)
-    for drop in ("valu_issue.stage_ms", "valu_issue.stage_valu_frac", "strong_scaling_search.tile_columns_px_balanced", "strong_scaling_search.tile_columns_px_uniform",
-                 "others.wiener_stats_luma_4k", "others.cdef_search_luma_4k_10bit", "others.mesh_search_4k_10bit", "others", "txq"):
+    for drop in ("valu_issue.stage_ms", "valu_issue.stage_valu_frac", "others.wiener_stats_luma_4k", "others.cdef_search_luma_4k_10bit", "others.mesh_search_4k_10bit",
+                 "strong_scaling_search.tile_columns_px_balanced", "strong_scaling_search.tile_columns_px_uniform", "others", "txq"):
         if len(json.dumps(line, separators=(",", ":"))) <= LINE_LIMIT:
             break
         if "." in drop:
