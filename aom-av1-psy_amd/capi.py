@@ -216,6 +216,8 @@ _protos = {
     "aomhip_vbp_8x8_stats_plane": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _vp, _i]),
     "aomhip_vbp_4x4_avg_plane": (C.c_int, [_vp, _PP, _i, _i, _i, _i, _vp, _i]),
     "aomhip_get_shear_params": (C.c_int, [_vp]),
+    "aomhip_select_samples": (C.c_int, [_i, _i, _vp, _vp, _i, _i, _i]),
+    "aomhip_find_projection": (C.c_int, [_i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i]),
     "aomhip_warp_error_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_segmented_frame_error": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_quantize_lp_batch": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -341,6 +343,19 @@ EXPORTED = sorted(_protos)
 def get_shear_params(models):
     """av1_get_shear_params on a warp_model_dtype array in place (host, no GPU); returns the per-model verdicts"""
     return [int(lib.aomhip_get_shear_params(C.c_void_p(models[i:i + 1].ctypes.data))) for i in range(len(models))]
+
+
+def select_samples(mv, pts, pts_inref, n, bw, bh):
+    """av1_selectSamples in place on two int32 arrays of (x, y) pairs (host, no GPU); mv = (row, col); returns the number kept"""
+    assert pts.dtype == np.int32 and pts_inref.dtype == np.int32 and pts.flags.c_contiguous and pts_inref.flags.c_contiguous
+    return int(lib.aomhip_select_samples(int(mv[0]), int(mv[1]), C.c_void_p(pts.ctypes.data), C.c_void_p(pts_inref.ctypes.data), n, bw, bh))
+
+
+def find_projection(n, pts, pts_inref, bw, bh, mv, model, mi_row, mi_col):
+    """av1_find_projection into model (a 1-element warp_model_dtype array; host, no GPU); True = a usable model"""
+    assert pts.dtype == np.int32 and pts_inref.dtype == np.int32
+    return bool(lib.aomhip_find_projection(n, C.c_void_p(pts.ctypes.data), C.c_void_p(pts_inref.ctypes.data), bw, bh, int(mv[0]), int(mv[1]),
+                                           C.c_void_p(model.ctypes.data), mi_row, mi_col))
 
 
 class AomHipError(RuntimeError):

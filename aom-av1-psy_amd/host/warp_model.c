@@ -40,3 +40,19 @@ int aomhip_get_shear_params(aomhip_warp_model *model) {
   /* is_affine_shear_allowed */
   return !(4 * abs(alpha) + 7 * abs(beta) >= (1 << 16) || 4 * abs(gamma) + 4 * abs(delta) >= (1 << 16));
 }
+
+/* ---- the LOCAL warp model (WARPED_CAUSAL blocks): av1_selectSamples and av1_find_projection; the arithmetic is csrc/warp_fit.h, shared with the device
+ * composite that refines such a block's MV ---- */
+#include "../csrc/warp_fit.h"
+
+int aomhip_select_samples(int mv_row, int mv_col, int32_t *pts, int32_t *pts_inref, int n_samples, int bw, int bh) {
+  if (!pts || !pts_inref || n_samples < 1 || n_samples > 8) return -1;   /* LEAST_SQUARES_SAMPLES_MAX */
+  return wf_select_samples(mv_row, mv_col, pts, pts_inref, n_samples, bw, bh);
+}
+
+int aomhip_find_projection(int n_samples, const int32_t *pts, const int32_t *pts_inref, int bw, int bh, int mv_row, int mv_col, aomhip_warp_model *model,
+                           int mi_row, int mi_col) {
+  if (!pts || !pts_inref || !model || n_samples < 1) return 0;
+  if (!wf_find_affine(n_samples, pts, pts_inref, bw, bh, mv_row, mv_col, mi_row, mi_col, k_div_lut, model->mat)) return 0;
+  return wf_shear(model->mat, k_div_lut, &model->alpha);
+}

@@ -1331,6 +1331,16 @@ typedef struct {
   int16_t alpha, beta, gamma, delta;
 } aomhip_warp_model;
 int aomhip_get_shear_params(aomhip_warp_model *model);   /* av1_get_shear_params (av1/common/warped_motion.c:186-247): fills alpha .. delta; 1 valid, 0 not */
+/* The LOCAL warp model of a WARPED_CAUSAL block (host, no GPU), as av1_refine_warped_mv and motion_mode_rd derive it from the block's neighbours:
+ *   aomhip_select_samples    av1_selectSamples (av1/common/mvref_common.c:1083-1104): pts / pts_inref [n_samples][2] = (x, y) of the neighbours' centres
+ *                            relative to the block's top-left pixel and their positions in the reference, 1/8 pel (av1_findSamples' output); the samples
+ *                            within clamp(max(bw, bh), 16, 112) of the block's MV move to the front of both arrays; returns how many (>= 1), -1 on a bad call
+ *   aomhip_find_projection   av1_find_projection (av1/common/warped_motion.c:894-1015): the least-squares affine model through the first n_samples
+ *                            samples that keeps the block's centre on its MV, into model->mat, and its shear values; returns 1 for a usable model and
+ *                            0 otherwise (the reference returns the opposite); a singular system leaves model->mat untouched, as the reference does */
+int aomhip_select_samples(int mv_row, int mv_col, int32_t *pts, int32_t *pts_inref, int n_samples, int bw, int bh);
+int aomhip_find_projection(int n_samples, const int32_t *pts, const int32_t *pts_inref, int bw, int bh, int mv_row, int mv_col, aomhip_warp_model *model,
+                           int mi_row, int mi_col);
 int aomhip_warp_error_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *cur, int cur_frame, int subsampling_x,
                             int subsampling_y, const aomhip_warp_model *d_models, int n_models, int p_col, int p_row, int p_width, int p_height,
                             const uint8_t *d_segment_map, int segment_map_stride, int64_t *d_error);

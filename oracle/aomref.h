@@ -270,6 +270,9 @@ int orc_vbp_minmax_8x8(const void *src, int src_stride, const void *dst, int dst
 void orc_vbp_fill_4x4avg(const void *src, int src_stride, int x8, int y8, int hbd, int pixels_wide, int pixels_high, int border_offset_4x4, int32_t *sum,
                          uint32_t *sse);
 int orc_get_shear_params(const int32_t *mat, int16_t *abgd);
+/* aomref_warpfit.c: av1_selectSamples / av1_find_projection (1 = no usable model, as the reference returns it) */
+int orc_select_samples(int mv_row, int mv_col, int *pts, int *pts_inref, int len, int bw, int bh);
+int orc_find_projection(int np, const int *pts1, const int *pts2, int bw, int bh, int mvy, int mvx, int32_t *mat, int16_t *abgd, int mi_row, int mi_col);
 int64_t orc_warp_error(const int32_t *mat, const int16_t *abgd, const void *ref, int elem16, int width, int height, int stride, const void *dst, int p_col,
                        int p_row, int p_width, int p_height, int p_stride, int subsampling_x, int subsampling_y, int bd, int64_t best_error,
                        const uint8_t *segment_map, int segment_map_stride);

@@ -1,6 +1,6 @@
-# round 5, final measurement set of the tree: GPU test suite, per-workload rocprofv3 kernel stats (tools/gpu_profiles.sh), the default bench line
+# final measurement set of the tree (tag = the round, e.g. r06z): GPU test suite, per-workload rocprofv3 kernel stats (tools/gpu_profiles.sh), the default bench line
 set -u; export TMPDIR=/tmp
-T=${1:-r05z}; OUT=gpurun_out/$T; mkdir -p $OUT
+T=${1:-r06z}; OUT=gpurun_out/$T; mkdir -p $OUT
 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/pytest_gpu.log; cat $OUT/pytest_gpu.log
 bash tools/gpu_profiles.sh $T > $OUT/profiles.log 2>&1
 find $OUT/stats -name '*kernel_trace.csv' -delete; find $OUT/stats -name '*agent_info.csv' -delete; find $OUT/stats -name '*domain_stats.csv' -delete
