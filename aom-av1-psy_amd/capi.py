@@ -134,6 +134,10 @@ txfm_yrd_block_dtype = np.dtype([("bx", "<i2"), ("by", "<i2"), ("tx_size_rate", 
                                  ("above_ctx", "u1", (32,)), ("left_ctx", "u1", (32,))])   # aomhip_txfm_yrd_block
 txfm_yrd_stats_dtype = np.dtype([("rd", "<i8"), ("dist", "<i8"), ("sse", "<i8"), ("rate", "<i4"), ("skip_txfm", "<i4")])   # aomhip_txfm_yrd_stats
 warp_model_dtype = np.dtype([("mat", "<i4", (6,)), ("alpha", "<i2"), ("beta", "<i2"), ("gamma", "<i2"), ("delta", "<i2")])
+warp_refine_block_dtype = np.dtype([(n_, "<i2") for n_ in ("bx", "by", "mv_row", "mv_col", "ref_row", "ref_col", "row_min", "row_max", "col_min", "col_max")] +
+                                   [("total_samples", "<i4"), ("num_proj_ref", "<i4"), ("pts", "<i4", (16,)), ("pts_inref", "<i4", (16,)),
+                                    ("model", warp_model_dtype)])   # aomhip_warp_refine_block (188 bytes)
+warp_refine_result_dtype = np.dtype([("mv_row", "<i2"), ("mv_col", "<i2"), ("num_proj_ref", "<i4"), ("bestmse", "<u4"), ("model", warp_model_dtype)])
 warp_block_dtype = np.dtype([("mat", "<i4", (6,)), ("alpha", "<i2"), ("beta", "<i2"), ("gamma", "<i2"), ("delta", "<i2"), ("p_col", "<i4"), ("p_row", "<i4"),
                              ("p_width", "<i4"), ("p_height", "<i4")])   # aomhip_warp_block (48 bytes)
 
@@ -217,6 +221,7 @@ _protos = {
     "aomhip_vbp_4x4_avg_plane": (C.c_int, [_vp, _PP, _i, _i, _i, _i, _vp, _i]),
     "aomhip_get_shear_params": (C.c_int, [_vp]),
     "aomhip_select_samples": (C.c_int, [_i, _i, _vp, _vp, _i, _i, _i]),
+    "aomhip_refine_warped_mv_batch": (C.c_int, [_vp, _PP, _PP, _i, _PP, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "aomhip_find_projection": (C.c_int, [_i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i]),
     "aomhip_warp_error_batch": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "aomhip_segmented_frame_error": (C.c_int, [_vp, _PP, _i, _PP, _i, _i, _i, _vp, _i, _vp]),
@@ -802,6 +807,11 @@ class Context:
                                                        use_cost_list, force_integer_mv, d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, d_start2, n,
                                                        None if rd is None else C.byref(rd), d_best_mv, d_bestsme, d_rate_mv, d_pred_sse, d_full_mv, d_second_best),
               "aomhip_single_motion_search_rd_batch")
+
+    def refine_warped_mv_batch(self, src, ref, frame, pred, bw, bh, allow_hp, mv_cost_type, error_per_bit, d_blocks, n, d_results, d_mvjcost=None,
+                               d_mvcost_row=None, d_mvcost_col=None):
+        check(lib.aomhip_refine_warped_mv_batch(self.h, C.byref(src), C.byref(ref), frame, C.byref(pred), bw, bh, allow_hp, mv_cost_type, error_per_bit,
+                                                d_mvjcost, d_mvcost_row, d_mvcost_col, d_blocks, n, d_results), "aomhip_refine_warped_mv_batch")
 
     def build_inter_pred_batch(self, ref, ref_frame, pred, pred_frame, bw, bh, d_blocks, d_mv, n_blocks, filter_x=0, filter_y=0, ss_x=0, ss_y=0):
         if ss_x or ss_y:

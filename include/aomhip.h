@@ -1341,6 +1341,33 @@ int aomhip_get_shear_params(aomhip_warp_model *model);   /* av1_get_shear_params
 int aomhip_select_samples(int mv_row, int mv_col, int32_t *pts, int32_t *pts_inref, int n_samples, int bw, int bh);
 int aomhip_find_projection(int n_samples, const int32_t *pts, const int32_t *pts_inref, int bw, int bh, int mv_row, int mv_col, aomhip_warp_model *model,
                            int mi_row, int mi_col);
+
+/* av1_refine_warped_mv (av1/encoder/mcomp.c:3224-3293) for a batch of WARPED_CAUSAL blocks of one size (>= 8x8: is_motion_variation_allowed_bsize) and one
+ * reference: two rounds over the four neighbours of the block's MV at 1/8 pel (allow_hp) or 1/4 pel, each candidate with its OWN warp model
+ * (av1_selectSamples on a copy of the block's samples when it has more than one, then av1_find_projection), its warped luma predictor
+ * (av1_warp_plane as av1_enc_build_inter_predictor calls it: the block's rectangle, get_conv_params(0, 0, bd)), vf(pred, src) + mv_err_cost_ of the
+ * candidate; a candidate replaces the best so far when its cost is SMALLER, in neighbour order, and a round without a winner ends the block's search.
+ *   d_blocks[i]: position, the starting MV (mbmi->mv[0], inside the limits) with the model and num_proj_ref the caller derived for it (mbmi->wm_params,
+ *                shear values filled), ref_mv and the SubpelMvLimits of ms_params (all 1/8 pel), the samples av1_findSamples gathered
+ *                (pts / pts_inref [total_samples][2], at most 8)
+ *   pred:        a scratch ring of >= 4 frames with the source's geometry (the four neighbours' predictors of a round)
+ *   mv costs:    ms_params->mv_cost_params -- mv_cost_type AOMHIP_MV_COST_*, error_per_bit, the centre-addressed tables for the entropy type
+ *   d_results[i]: the refined MV, its model and num_proj_ref (what the function leaves in mbmi) and bestmse (its return value) */
+typedef struct {
+  int16_t bx, by, mv_row, mv_col, ref_row, ref_col, row_min, row_max, col_min, col_max;
+  int32_t total_samples, num_proj_ref;
+  int32_t pts[16], pts_inref[16];
+  aomhip_warp_model model;
+} aomhip_warp_refine_block;   /* 188 bytes */
+typedef struct {
+  int16_t mv_row, mv_col;
+  int32_t num_proj_ref;
+  uint32_t bestmse;
+  aomhip_warp_model model;
+} aomhip_warp_refine_result;   /* 44 bytes */
+int aomhip_refine_warped_mv_batch(aomhip_ctx *ctx, const aomhip_planes *src, const aomhip_planes *ref, int frame, const aomhip_planes *pred, int bw, int bh,
+                                  int allow_hp, int mv_cost_type, int error_per_bit, const int32_t *d_mvjcost, const int32_t *d_mvcost_row,
+                                  const int32_t *d_mvcost_col, const aomhip_warp_refine_block *d_blocks, int n_blocks, aomhip_warp_refine_result *d_results);
 int aomhip_warp_error_batch(aomhip_ctx *ctx, const aomhip_planes *ref, int ref_frame, const aomhip_planes *cur, int cur_frame, int subsampling_x,
                             int subsampling_y, const aomhip_warp_model *d_models, int n_models, int p_col, int p_row, int p_width, int p_height,
                             const uint8_t *d_segment_map, int segment_map_stride, int64_t *d_error);

@@ -1402,6 +1402,73 @@ def tpl_mode_estimation_rows(src_b, ref_bs, border, width, height, bw, positions
     return out
 
 
+def warp_block_pred(ref_vis, bd, mat, shear, bx, by, bw, bh):
+    """The luma predictor of a WARPED_CAUSAL block: av1_warp_plane as av1_make_inter_predictor calls it (reconinter.c: the block's rectangle, the frame's
+    visible size, get_conv_params(0, 0, bd)) through oracle/aomref_warp.c.  ref_vis: the visible reference plane.  -> [bh, bw]"""
+    lib.orc_warp_affine.restype = None
+    lib.orc_warp_affine.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] + [C.c_int] * 13
+    ref = np.ascontiguousarray(ref_vis)
+    h, w = ref.shape
+    m = np.ascontiguousarray(mat, np.int32)
+    out = np.zeros((bh, bw), ref.dtype)
+    lib.orc_warp_affine(m.ctypes.data, ref.ctypes.data, int(ref.dtype != np.uint8), w, h, w, out.ctypes.data, int(bx), int(by), bw, bh, bw, 0, 0, bd,
+                        5 if bd == 12 else 3, int(shear[0]), int(shear[1]), int(shear[2]), int(shear[3]))
+    return out
+
+
+def find_projection(n, pts, pts_inref, bw, bh, mv, mi_row, mi_col, mat0=None):
+    """orc_find_projection: -> (ok, mat [6] int32, shear [4] int16); mat0 = the model before the call (left alone by a singular system)"""
+    p, q = np.ascontiguousarray(pts, np.int32), np.ascontiguousarray(pts_inref, np.int32)
+    mat = np.array(mat0 if mat0 is not None else [0, 0, 1 << 16, 0, 0, 1 << 16], np.int32)
+    sh = np.zeros(4, np.int16)
+    bad = lib.orc_find_projection(int(n), p.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), bw, bh, int(mv[0]), int(mv[1]), mat.ctypes.data_as(C.c_void_p),
+                                  sh.ctypes.data_as(C.c_void_p), int(mi_row), int(mi_col))
+    return (not bad), mat, sh
+
+
+def refine_warped_mv(src_vis, ref_vis, bd, bw, bh, b, allow_hp, cost_type, error_per_bit=0, mvjcost=None, mvcost0=None, mvcost1=None, pred_fn=None):
+    """av1_refine_warped_mv (av1/encoder/mcomp.c:3224-3293) for ONE block, statement by statement, over the pinned pieces: orc_select_samples /
+    orc_find_projection, the warped predictor (warp_block_pred; pred_fn(mat, shear) replaces it in tests of the sequencing), vf(pred, src) and
+    mv_err_cost_.  b: a record with bx, by, mv_row / mv_col (the start), ref_row / ref_col, the four SubpelMvLimits, total_samples, num_proj_ref, pts,
+    pts_inref, model (mat + alpha .. delta).  -> dict(mv, mat, shear, num_proj_ref, bestmse, measured = the candidate MVs whose cost was computed)"""
+    bx, by = int(b["bx"]), int(b["by"])
+    src_blk = np.ascontiguousarray(src_vis[by:by + bh, bx:bx + bw])
+
+    def motion_cost(mv, mat, shear):   # compute_motion_cost (:3197-3221)
+        pred = pred_fn(mat, shear) if pred_fn else warp_block_pred(ref_vis, bd, mat, shear, bx, by, bw, bh)
+        v = variance(np.ascontiguousarray(pred), 0, 0, src_blk, 0, 0, bw, bh, bd)[0]      # vf(dst, dst_stride, src, src_stride, &sse)
+        return (int(v) + mv_err_cost(mv[0], mv[1], b["ref_row"], b["ref_col"], cost_type, error_per_bit, mvjcost, mvcost0, mvcost1)) & 0xFFFFFFFF
+    nb = [(0, -1), (1, 0), (0, 1), (-1, 0), (0, -2), (2, 0), (0, 2), (-2, 0)]
+    best_mv = [int(b["mv_row"]), int(b["mv_col"])]
+    model = b["model"]
+    best_mat, best_sh = np.array(model["mat"], np.int32).reshape(6), np.array([model["alpha"], model["beta"], model["gamma"], model["delta"]], np.int16).reshape(4)
+    cur_mat, cur_np = best_mat.copy(), int(b["num_proj_ref"])
+    best_np = cur_np
+    total = int(b["total_samples"])
+    start = 0 if allow_hp else 4
+    measured = [tuple(best_mv)]
+    bestmse = motion_cost(best_mv, best_mat, best_sh)
+    for _ in range(2):
+        best_idx = -1
+        for idx in range(start, start + 4):
+            mv = (best_mv[0] + nb[idx][0], best_mv[1] + nb[idx][1])
+            if not (b["col_min"] <= mv[1] <= b["col_max"] and b["row_min"] <= mv[0] <= b["row_max"]):     # av1_is_subpelmv_in_range
+                continue
+            pts, pin = np.array(b["pts"], np.int32).reshape(-1).copy(), np.array(b["pts_inref"], np.int32).reshape(-1).copy()
+            if total > 1:
+                cur_np = lib.orc_select_samples(mv[0], mv[1], pts.ctypes.data_as(C.c_void_p), pin.ctypes.data_as(C.c_void_p), total, bw, bh)
+            ok, cur_mat, sh = find_projection(cur_np, pts, pin, bw, bh, mv, by >> 2, bx >> 2, cur_mat)
+            if ok:
+                measured.append(mv)
+                mse = motion_cost(mv, cur_mat, sh)
+                if mse < bestmse:
+                    best_idx, best_mat, best_sh, best_np, bestmse = idx, cur_mat.copy(), sh.copy(), cur_np, mse
+        if best_idx == -1:
+            break
+        best_mv = [best_mv[0] + nb[best_idx][0], best_mv[1] + nb[best_idx][1]]
+    return dict(mv=best_mv, mat=best_mat.tolist(), shear=best_sh.tolist(), num_proj_ref=int(best_np), bestmse=int(bestmse), measured=measured)
+
+
 def simple_motion_search_batch(src_b, ref_b, border, width, height, w, h, blocks, q, sub=None, use_cost_list=0, mvjcost=None, mvcost0=None, mvcost1=None, bd=8,
                                threads=4):
     """av1_simple_motion_search + av1_simple_motion_sse_var (motion_search_facade.c:925-1060) as a composition of the pinned pieces:
