@@ -35,7 +35,10 @@ struct CellMap {
 // frame, 4 x 16 = 0.149, 8 x 16 = 0.163, 16 x 64 (the whole first step inside the window, 79 KB, one or two workgroups per CU) = 0.18 - 0.20,
 // no window = 0.231.  Cells are consecutive list entries: for raster-ordered lists that is a strip of horizontal neighbours, whose
 // windows share all their rows (2 x 2 cells from a grid hint measured 3 % slower and were dropped).
-constexpr int kCellWaves = 2;
+#ifndef AOMHIP_CELL_WAVES
+#define AOMHIP_CELL_WAVES 2   // (kernel experiments: tools/fps_build_exp.sh name "-DAOMHIP_CELL_WAVES=4")
+#endif
+constexpr int kCellWaves = AOMHIP_CELL_WAVES;
 #ifndef AOMHIP_BIG_CELL_WAVES
 #define AOMHIP_BIG_CELL_WAVES 2
 #endif
@@ -44,6 +47,15 @@ constexpr int kCellWaves = 2;
 #endif
 constexpr int kCellReach = 16;
 constexpr int kCellReachBig = 8;   // blocks of >= 1024 pixels
+// The general search kernel (fullpel_search.inc) on blocks below 1 024 pixels: FOUR blocks per cell and a reach of 32.  Its n-step searches wander -- the
+// centre moves in half of the steps -- and the steps that leave the window read the plane at 2.2 x the cost of a window step (profiles/r06_fps_nstep.md);
+// a window shared by four neighbours costs (64 + 2 R) x (16 + 2 R) pixels where two cost (32 + 2 R) x (16 + 2 R), so the reach that fits the CU's LDS at
+// six wavefronts per SIMD doubles.  NSTEP step_param 3, 4K 10-bit 16x16, ms per frame (same box): 2 x 16 0.794, 2 x 32 0.806, 3 x 32 0.694, 4 x 24 0.705,
+// **4 x 32 0.638**, 4 x 36 0.724, 5 x 36 0.696, 6 x 48 0.680, 8 x 40 0.647; blocks of 32x32 keep 2 x 8 (0.513; 4 x 16 0.511).
+#ifndef AOMHIP_FPS_CELL_WAVES_SMALL
+#define AOMHIP_FPS_CELL_WAVES_SMALL 4
+#endif
+constexpr int kFpsCellReach = 32;
 
 // Host side: how a search call cuts its list into cells.  waves = 0: no window (the kernels' plain form).
 // AOMHIP_SEARCH_CELL=0 switches the window off, AOMHIP_SEARCH_CELL_R=<pixels> overrides the reach (kernel A/B only; results never depend
@@ -54,10 +66,11 @@ struct CellPlan {
   CellMap map;
 };
 // blocks per cell (= wavefronts per workgroup) of the general search kernel, by block size
-constexpr int cell_waves_for(int bw, int bh) { return bw * bh >= AOMHIP_BIG_CELL_PIXELS ? AOMHIP_BIG_CELL_WAVES : kCellWaves; }
+constexpr int cell_waves_for(int bw, int bh) { return bw * bh >= AOMHIP_BIG_CELL_PIXELS ? AOMHIP_BIG_CELL_WAVES : AOMHIP_FPS_CELL_WAVES_SMALL; }
 // static_lds: the LDS the kernel declares by itself (site table, per-wavefront source slices): it comes off every budget below, so the
 // workgroups-per-CU figure the window is rounded to is the one the launch really gets and the cap never exceeds the CU's 160 KB
-inline CellPlan plan_cells(const aomhip_planes *ref, int bw, int bh, int n_blocks, int reach, int waves = kCellWaves, int static_lds = 2048) {
+inline CellPlan plan_cells(const aomhip_planes *ref, int bw, int bh, int n_blocks, int reach, int waves = kCellWaves, int static_lds = 2048,
+                            int cap_small = kCellReach) {
   static const int env_on = [] { const char *e = getenv("AOMHIP_SEARCH_CELL"); return e ? atoi(e) : 1; }();
   static const int env_r = [] { const char *e = getenv("AOMHIP_SEARCH_CELL_R"); return e ? atoi(e) : -1; }();
   CellPlan p{};
@@ -67,7 +80,7 @@ inline CellPlan plan_cells(const aomhip_planes *ref, int bw, int bh, int n_block
   // Blocks of 32x32 and larger take a reach of 8: their window is 13 KB per two-block cell at 16 (16-bit planes) and the workgroups per CU
   // it costs outweigh the radius 9 .. 16 rounds it serves -- temporal filter, 4K 10-bit: 7.04 -> 6.55 ms (R x RB sweep in profiles/r04_search_cell.md)
   const bool big = bw * bh >= 1024;
-  const int cap = big ? (env_rb >= 0 ? env_rb : (env_r >= 0 ? env_r : kCellReachBig)) : (env_r >= 0 ? env_r : kCellReach);
+  const int cap = big ? (env_rb >= 0 ? env_rb : (env_r >= 0 ? env_r : kCellReachBig)) : (env_r >= 0 ? env_r : cap_small);
   const int r = (env_r >= 0 || (big && env_rb >= 0)) ? cap : (reach < cap ? reach : cap);
   // the window of a cell whose blocks are horizontal neighbours and start at the same MV; rounded up so that the workgroups of a CU
   // fill its 160 KB without a remainder (the slack serves cells whose start MVs differ; a window that still does not fit shrinks its

@@ -20,10 +20,15 @@ def child(name, workloads, reps):
     capi = pkg.capi
     exp = None
     if name != "product":
-        exp = C.CDLL(os.path.join(ROOT, "explib", "libfps_%s.so" % name), mode=C.RTLD_GLOBAL)
-        f = exp.aomhip_full_pixel_search_batch
-        f.restype, f.argtypes = capi.lib.aomhip_full_pixel_search_batch.restype, capi.lib.aomhip_full_pixel_search_batch.argtypes
-        capi.lib.aomhip_full_pixel_search_batch = f
+        if os.path.exists(os.path.join(ROOT, "explib", "libmcomp_%s.so" % name)):
+            exp = C.CDLL(os.path.join(ROOT, "explib", "libmcomp_%s.so" % name), mode=C.RTLD_GLOBAL)
+            entry = "aomhip_fullpel_diamond_batch"
+        else:
+            exp = C.CDLL(os.path.join(ROOT, "explib", "libfps_%s.so" % name), mode=C.RTLD_GLOBAL)
+            entry = "aomhip_full_pixel_search_batch"
+        f = getattr(exp, entry)
+        f.restype, f.argtypes = getattr(capi.lib, entry).restype, getattr(capi.lib, entry).argtypes
+        setattr(capi.lib, entry, f)
     ctx = capi.Context(0)
     out = {"lib": name}
     if "nstep" in workloads:
@@ -49,6 +54,40 @@ def child(name, workloads, reps):
                                      "cost_list": m[8], "two_batch_steps": m[9], "runs": m[10], "glob_steps_rad_le_8": m[11], "glob_steps_rad_le_18": m[12], "moves": m[13],
                                      "per_lds_step": m[2] / max(m[3], 1e-9), "per_glob_step": m[4] / max(m[5], 1e-9), "per_var": m[6] / max(m[7], 1e-9)}
         ctx.free(d_cl); ctx.free(d_sec); wl.free()
+    if "diamond" in workloads:   # the inner loop's search: fullpel_diamond_kernel, DIAMOND step_param 4 (explib/libmcomp_<name>.so rebinds its entry point)
+        wl = search.SearchPipeline(pkg, ctx, None, 0, 1)
+        k = [0]
+        def onced():
+            ctx.fullpel_diamond_batch(wl.src, wl.ref, k[0] % wl.F, 16, 16, 0, 4, capi.MV_COST_L1_HDRES, wl.d_blocks, wl.n, wl.d_mv, wl.d_cost); k[0] += 1
+        common.ramp(ctx, onced)
+        out["diamond_ms"] = [round(common.kernel_avg_ms(ctx, onced, 60), 4) for _ in range(reps)]
+        k[0] = 0; onced(); ctx.sync()
+        import hashlib
+        out["diamond_sha"] = hashlib.sha1(np.concatenate([ctx.from_device(wl.d_mv, (wl.n, 2), np.int16).ravel(), ctx.from_device(wl.d_cost, (wl.n,), np.int32)]).tobytes()).hexdigest()[:12]
+        wl.free()
+    if "nstep32" in workloads:   # 32x32 blocks (the temporal filter's first search): NSTEP step_param 3 over the same 4K 10-bit pair
+        wl = search.SearchPipeline(pkg, ctx, None, 0, 1)
+        W, H = wl.W, wl.H
+        gc, gr = W // 32, H // 32
+        n = gc * gr
+        b = np.zeros(n, capi.search_block_dtype)
+        b["bx"], b["by"] = (np.arange(n) % gc) * 32, (np.arange(n) // gc) * 32
+        ext = wl.BORDER - 8
+        b["col_min"] = np.maximum(-(b["bx"] + ext), -1023); b["col_max"] = np.minimum(W - b["bx"] - 32 + ext, 1023)
+        b["row_min"] = np.maximum(-(b["by"] + ext), -1023); b["row_max"] = np.minimum(H - b["by"] - 32 + ext, 1023)
+        d_b, d_mv, d_cost = ctx.to_device(b), ctx.malloc(n * 4), ctx.malloc(n * 4)
+        q = capi.SearchParams.make("NSTEP", 3, capi.MV_COST_L1_HDRES)
+        k = [0]
+        def once32():
+            ctx.full_pixel_search_batch(wl.src, wl.ref, k[0] % wl.F, 32, 32, q, d_b, n, d_mv, d_cost); k[0] += 1
+        common.ramp(ctx, once32)
+        out["nstep32_ms"] = [round(common.kernel_avg_ms(ctx, once32, 40), 4) for _ in range(reps)]
+        k[0] = 0; once32(); ctx.sync()
+        import hashlib
+        out["nstep32_sha"] = hashlib.sha1(np.concatenate([ctx.from_device(d_mv, (n, 2), np.int16).ravel(), ctx.from_device(d_cost, (n,), np.int32)]).tobytes()).hexdigest()[:12]
+        for d in (d_b, d_mv, d_cost):
+            ctx.free(d)
+        wl.free()
     if "tf" in workloads:
         from benchlib import encoder
         r = encoder.run_tf(pkg, ctx, None, 6, 2)
