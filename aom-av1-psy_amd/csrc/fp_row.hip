@@ -35,7 +35,11 @@ struct FpBlockOut { int nrow, ncol, err, mrow, mcol, gf, raw; };
 template <typename T, int W, int H, int SPEC, bool NOSKIP>
 __global__ __launch_bounds__(SPEC * 64) void fp_row_kernel(PlaneView<T> src, PlaneView<T> last, const aomhip_search_block *__restrict__ blocks,
                                                           const SiteTable *__restrict__ sites, SearchArgs q, FpfLegs L, FpfCost C,
-                                                          const int32_t *__restrict__ intra, int rows, int cols, int thr, int skip_zeromv, FpfOut out) {
+                                                          const int32_t *__restrict__ intra, int rows, int cols, int thr, int skip_zeromv, FpfOut out, CellMap cm) {
+  // A batch's blocks are horizontal neighbours searched from ONE vector: a cell, if ever there was one.  Their window (search_window.h) is staged
+  // once per batch by the whole workgroup -- the row's workgroup has a CU to itself, so its reach is whatever the launch's LDS allows -- and the
+  // steps of a link that stay inside it read LDS: a plane step is 2.2 x a window step on this kernel's body (profiles/r06_fps_nstep.md).
+  extern __shared__ uint32_t cell_lds[];
   __shared__ SiteTable sS;
   __shared__ int next_mv[SPEC][2];
   {
@@ -47,10 +51,34 @@ __global__ __launch_bounds__(SPEC * 64) void fp_row_kernel(PlaneView<T> src, Pla
   const int r = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (r >= rows) return;
   __builtin_amdgcn_s_setprio(3);   // a chain of latencies: its instructions go first when a throughput kernel shares the SIMD (the golden leg)
-  const CellWin no_win{ 0, 0, 0, 0, 0 };
+  // the list entry of first_pass_motion_search (:261-299): ref_mv = best_ref_mv, start = get_fullmv_from_mv(ref_mv), limits =
+  // av1_set_mv_search_range(&x->mv_limits, &ref_mv) (mcomp.c:196-215) on the block's raw limits
+  auto list_entry = [&](const aomhip_search_block &b, int brow, int bcol) -> BlockScalars {
+    BlockScalars bs = BlockScalars::of(b);
+    bs.ref_row = brow; bs.ref_col = bcol;
+    bs.start_row = rawpel(brow); bs.start_col = rawpel(bcol);
+    int col_min = rawpel(bcol) - kMaxFullPel + ((bcol & 7) ? 1 : 0), row_min = rawpel(brow) - kMaxFullPel + ((brow & 7) ? 1 : 0);
+    int col_max = rawpel(bcol) + kMaxFullPel, row_max = rawpel(brow) + kMaxFullPel;
+    const int lo = rawpel(kMvLow) + 1, hi = rawpel(kMvUpp) - 1;
+    col_min = max(col_min, lo); row_min = max(row_min, lo);
+    col_max = min(col_max, hi); row_max = min(row_max, hi);
+    bs.col_min = max(bs.col_min, col_min); bs.col_max = min(bs.col_max, col_max);
+    bs.row_min = max(bs.row_min, row_min); bs.row_max = min(bs.row_max, row_max);
+    return bs;
+  };
+  // does block c run the chained search from (brow, bcol), and where does it start (pixel position of the clamped start MV's block)?
+  auto search_start = [&](int c, int brow, int bcol, int *px, int *py) -> bool {
+    const size_t i = (size_t)r * cols + c;
+    if ((brow | bcol) == 0 || (int)L.raw[i] <= thr) return false;
+    const aomhip_search_block b = blocks[i];
+    const BlockScalars bs = list_entry(b, brow, bcol);
+    *px = __builtin_amdgcn_readfirstlane((int)b.bx) + min(max(bs.start_col, bs.col_min), bs.col_max);
+    *py = __builtin_amdgcn_readfirstlane((int)b.by) + min(max(bs.start_row, bs.row_min), bs.row_max);
+    return true;
+  };
 
-  // one block of firstpass_inter_prediction with best_ref_mv = (brow, bcol) (1/8 pel)
-  auto one_block = [&](int c, int brow, int bcol) -> FpBlockOut {
+  // one block of firstpass_inter_prediction with best_ref_mv = (brow, bcol) (1/8 pel); cw: the batch's window (may be empty)
+  auto one_block = [&](int c, int brow, int bcol, const CellWin &cw) -> FpBlockOut {
     const size_t i = (size_t)r * cols + c;
     const aomhip_search_block b = blocks[i];
     const int bx = __builtin_amdgcn_readfirstlane((int)b.bx), by = __builtin_amdgcn_readfirstlane((int)b.by);
@@ -59,24 +87,11 @@ __global__ __launch_bounds__(SPEC * 64) void fp_row_kernel(PlaneView<T> src, Pla
     int e1 = INT_MAX, m1r = 0, m1c = 0;
     if (raw > thr) {
       if (moved) {
-        // the list entry of first_pass_motion_search (:261-299): ref_mv = best_ref_mv, start = get_fullmv_from_mv(ref_mv), limits =
-        // av1_set_mv_search_range(&x->mv_limits, &ref_mv) (mcomp.c:196-215) on the block's raw limits
-        BlockScalars bs = BlockScalars::of(b);
-        bs.ref_row = brow; bs.ref_col = bcol;
-        bs.start_row = rawpel(brow); bs.start_col = rawpel(bcol);
-        {
-          int col_min = rawpel(bcol) - kMaxFullPel + ((bcol & 7) ? 1 : 0), row_min = rawpel(brow) - kMaxFullPel + ((brow & 7) ? 1 : 0);
-          int col_max = rawpel(bcol) + kMaxFullPel, row_max = rawpel(brow) + kMaxFullPel;
-          const int lo = rawpel(kMvLow) + 1, hi = rawpel(kMvUpp) - 1;
-          col_min = max(col_min, lo); row_min = max(row_min, lo);
-          col_max = min(col_max, hi); row_max = min(row_max, hi);
-          bs.col_min = max(bs.col_min, col_min); bs.col_max = min(bs.col_max, col_max);
-          bs.row_min = max(bs.row_min, row_min); bs.row_max = min(bs.row_max, row_max);
-        }
+        const BlockScalars bs = list_entry(b, brow, bcol);
         const T *sp = src.origin + (int64_t)by * src.stride + bx;
         const T *rbase = last.origin + (int64_t)by * last.stride + bx;
         FpsResult fr;
-        fps_block<T, W, H, false, true, NOSKIP>(sp, src.stride, rbase, last.stride, bx, by, bs, sS, q, no_win, nullptr, lane, &fr);
+        fps_block<T, W, H, true, true, NOSKIP>(sp, src.stride, rbase, last.stride, bx, by, bs, sS, q, cw, cell_lds, lane, &fr);
         m1r = fr.br; m1c = fr.bc;
         if (fr.var != INT_MAX) {
           // av1_get_mvpred_sse (mcomp.c:3661-3677): the sse of the mse function at the full-pel MV + mv_err_cost, + NEW_MV_MODE_PENALTY (:292-296)
@@ -137,7 +152,11 @@ __global__ __launch_bounds__(SPEC * 64) void fp_row_kernel(PlaneView<T> src, Pla
   int brow = 0, bcol = 0;   // MV best_ref_mv = kZeroMv at the start of every row (:1165), in 1/8 pel
   if constexpr (SPEC == 1) {
     for (int c = 0; c < cols; ++c) {
-      const FpBlockOut o = one_block(c, brow, bcol);
+      int px = 0, py = 0;
+      const bool need = search_start(c, brow, bcol, &px, &py);
+      CellWin cw{ 0, 0, 0, 0, 0 };
+      if (cm.win_r >= 0) cw = stage_cell_window<T, W, H, SPEC>(cm, last.origin, last.stride, need, px, py, 0, cell_lds);
+      const FpBlockOut o = one_block(c, brow, bcol, cw);
       brow = o.nrow; bcol = o.ncol;
       if (lane == 0) store(c, o);
     }
@@ -146,9 +165,13 @@ __global__ __launch_bounds__(SPEC * 64) void fp_row_kernel(PlaneView<T> src, Pla
     for (int c = 0; c < cols;) {
       const int lim = min(width, cols - c);
       const bool mine = wave < lim;
+      int px = 0, py = 0;
+      const bool need = mine && search_start(c + wave, brow, bcol, &px, &py);
+      CellWin cw{ 0, 0, 0, 0, 0 };
+      if (cm.win_r >= 0) cw = stage_cell_window<T, W, H, SPEC>(cm, last.origin, last.stride, need, px, py, wave, cell_lds);   // (workgroup barriers inside)
       FpBlockOut o{};
       if (mine) {
-        o = one_block(c + wave, brow, bcol);
+        o = one_block(c + wave, brow, bcol, cw);
         if (lane == 0) { next_mv[wave][0] = o.nrow; next_mv[wave][1] = o.ncol; }
       }
       __syncthreads();
@@ -187,17 +210,31 @@ int launch_fp_rows(aomhip_ctx *ctx, const aomhip_planes *src1, const aomhip_plan
   }
   const SearchArgs q = fps_search_args(p, d_mvjcost, d_mvcost_row, d_mvcost_col, src1->bit_depth, false);
   const FpfCost C{ p->mv_cost_type, p->error_per_bit, d_mvjcost, d_mvcost_row, d_mvcost_col };
-  const int spec = [] { const char *e = getenv("AOMHIP_FP_ROW_WAVES"); const int v = e ? atoi(e) : 8; return v == 1 || v == 4 || v == 16 ? v : 8; }();   // (A/B, tests)
+  const int spec = [] { const char *e = getenv("AOMHIP_FP_ROW_WAVES"); const int v = e ? atoi(e) : 16; return v == 1 || v == 4 || v == 8 ? v : 16; }();   // (A/B, tests)
+  // the batch's window: reach AOMHIP_FP_ROW_R (default 64; < 0: none) around the common start, in whatever LDS one workgroup per CU may take.
+  // 4K 10-bit, ms per frame (same box): 8 wavefronts per row without a window 3.10, with reach 32 / 64 / 96: 2.96 / 2.92 / 2.97; 16 wavefronts: 2.97
+  // without, 2.93 / 2.87 / 2.88 / 2.93 with reach 56 / 64 / 72 / 80
+  const int win_r = [] { const char *e = getenv("AOMHIP_FP_ROW_R"); return e ? atoi(e) : 64; }();   // (read per launch: A/B, tests)
+  const int es = src1->bit_depth == 8 ? 1 : 2;
+  CellMap cm{ rows, win_r, 0, -last1->border, -last1->border, last1->stride - last1->border, last1->height + last1->border };
+  int lds = 0;
+  if (win_r >= 0) {
+    int64_t pitch = ((int64_t)spec * bw + 2 * win_r) * es + 16 + 16;   // (+ 16: the left edge is rounded down to a 16-byte boundary)
+    pitch += ((7 - (pitch >> 2)) & 31) << 2;
+    lds = (int)std::min<int64_t>(pitch * (bh + 2 * win_r), 120 * 1024);
+    cm.lds_bytes = lds;
+  }
   // (NOSKIP: the full-SAD form -- fps_block without the row-skipping SAD and its re-check, 75 instead of 112 VGPRs in the batched kernel)
 #define XP(T, W, H, P)                                                                                                                   \
   {                                                                                                                                     \
     auto k = q.skip_sad ? fp_row_kernel<T, W, H, P, false> : fp_row_kernel<T, W, H, P, true>;                                           \
-    hipLaunchKernelGGL(k, dim3(rows), dim3(P * 64), 0, ctx->stream, view_of<T>(*src1), view_of<T>(*last1),                              \
-                       d_blocks, d_sites, q, L, C, d_intra, rows, cols, thr, skip_zeromv, out);                                         \
+    if (lds > 48 * 1024) AOMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    hipLaunchKernelGGL(k, dim3(rows), dim3(P * 64), (size_t)lds, ctx->stream, view_of<T>(*src1), view_of<T>(*last1),                     \
+                       d_blocks, d_sites, q, L, C, d_intra, rows, cols, thr, skip_zeromv, out, cm);                                     \
   }
 #define X(T, W, H)                                                                                                                      \
   {                                                                                                                                     \
-    if (spec == 1) XP(T, W, H, 1) else if (spec == 4) XP(T, W, H, 4) else if (spec == 16) XP(T, W, H, 16) else XP(T, W, H, 8)            \
+    if (spec == 1) XP(T, W, H, 1) else if (spec == 4) XP(T, W, H, 4) else if (spec == 8) XP(T, W, H, 8) else XP(T, W, H, 16)            \
   }
   if (src1->bit_depth == 8) {
     if (bw == 16) X(uint8_t, 16, 16) else X(uint8_t, 8, 8)

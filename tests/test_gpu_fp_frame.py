@@ -16,13 +16,15 @@ def _tables():
 @pytest.mark.parametrize("bd,golden,thr,skip_zero,cost,bs", [(8, True, 0, 0, "ENTROPY", 16), (10, True, 300, 0, "ENTROPY", 16), (8, False, 0, 1, "L1_HDRES", 16),
                                                             (10, False, 0, 0, "NONE", 16),
                                                             (8, True, 0, 0, "ENTROPY", 8)])   # fp_block_size BLOCK_8X8: frames of at most 352x288 (firstpass.c get_fp_block_size)
-# the row kernel (csrc/fp_row.hip) as shipped -- 8 wavefronts per row speculating along the chain, golden leg on the side stream --, with
-# one wavefront per row on one stream (no speculation), with 16, and the column-at-a-time fallback: the intra errors below reset the chain at
-# a fifth of the blocks and perturb the rest, so batches are cut short at every width
-@pytest.mark.parametrize("form", ["rows", "rows_1_serial", "rows_16", "columns"])
+# the row kernel (csrc/fp_row.hip) as shipped -- 16 wavefronts per row speculating along the chain, a batch's window of reach 64 in LDS, golden leg on
+# the side stream --, with 8 wavefronts, with one wavefront per row on one stream (no speculation), without a window, with a window too small for
+# most steps, and the column-at-a-time fallback: the intra errors below reset the chain at a fifth of the blocks and perturb the rest, so batches
+# are cut short at every width
+@pytest.mark.parametrize("form", ["rows", "rows_1_serial", "rows_16", "rows_16_no_window", "rows_16_reach_8", "columns"])
 def test_frame_call_equals_the_scalar_raster_walk(hip, oracle, ctx, bd, golden, thr, skip_zero, cost, bs, form, monkeypatch):
     monkeypatch.setenv("AOMHIP_FP_COLUMNS", "1" if form == "columns" else "0")
-    monkeypatch.setenv("AOMHIP_FP_ROW_WAVES", {"rows_1_serial": "1", "rows_16": "16"}.get(form, "8"))
+    monkeypatch.setenv("AOMHIP_FP_ROW_WAVES", {"rows_1_serial": "1", "rows": "8"}.get(form, "16"))
+    monkeypatch.setenv("AOMHIP_FP_ROW_R", {"rows_16_no_window": "-1", "rows_16_reach_8": "8"}.get(form, "64"))
     monkeypatch.setenv("AOMHIP_FP_SERIAL", "1" if form == "rows_1_serial" else "0")
     capi = hip.capi
     W, H, B = (352, 288, 64) if bs == 16 else (176, 144, 64)
