@@ -126,12 +126,26 @@ __device__ __forceinline__ uint32_t group8_sad(const T *sp, int sstride, const T
         }
       }
     } else {
-      for (int u = l; u < G::U; u += 8) {
-        const int row = u / G::UPR, col = (u % G::UPR) * G::UE;
-        const L a = *reinterpret_cast<const L *>(sp + (int64_t)row * sstride + col);
-        const L b = *reinterpret_cast<const L *>(rp + (int64_t)row * rstride + col);
+      // four units at a time, their eight reads requested before the first SAD (one read per iteration made a candidate of a large block a chain of
+      // memory round trips: profiles/r06_fps_nstep.md, the 32x32 search)
+      constexpr int kN = (G::U + 7) / 8, kBatch = kN >= 4 ? 4 : kN;
+#pragma unroll 1
+      for (int k0 = 0; k0 < kN; k0 += kBatch) {
+        L a[kBatch], b[kBatch];
 #pragma unroll
-        for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(a.v[i], b.v[i], acc);
+        for (int j = 0; j < kBatch; ++j) {
+          const int u = min(l + 8 * (k0 + j), G::U - 1);
+          const int row = u / G::UPR, col = (u % G::UPR) * G::UE;
+          a[j] = *reinterpret_cast<const L *>(sp + (int64_t)row * sstride + col);
+          b[j] = *reinterpret_cast<const L *>(rp + (int64_t)row * rstride + col);
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+          if (k0 + j < kN && l + 8 * (k0 + j) < G::U) {
+#pragma unroll
+            for (int i = 0; i < G::UB / 4; ++i) acc = sadw<T>(a[j].v[i], b[j].v[i], acc);
+          }
+        }
       }
     }
   }

@@ -84,6 +84,13 @@ def child(name, workloads, reps):
         out["nstep32_ms"] = [round(common.kernel_avg_ms(ctx, once32, 40), 4) for _ in range(reps)]
         k[0] = 0; once32(); ctx.sync()
         import hashlib
+        if name.endswith("_prof"):
+            buf = np.zeros((n, 16), np.uint32)
+            assert exp.aomhip_debug_fps_prof(C.c_void_p(buf.ctypes.data), n) == 0
+            m = buf.astype(np.float64).mean(0)
+            out["prof32_per_block"] = {"total": m[0], "prologue": m[1], "lds_steps": m[2], "n_lds": m[3], "glob_steps": m[4], "n_glob": m[5], "var": m[6], "n_var": m[7],
+                                       "runs": m[10], "glob_rad_le_8": m[11], "glob_rad_le_18": m[12], "moves": m[13],
+                                       "per_lds_step": m[2] / max(m[3], 1e-9), "per_glob_step": m[4] / max(m[5], 1e-9)}
         out["nstep32_sha"] = hashlib.sha1(np.concatenate([ctx.from_device(d_mv, (n, 2), np.int16).ravel(), ctx.from_device(d_cost, (n,), np.int32)]).tobytes()).hexdigest()[:12]
         for d in (d_b, d_mv, d_cost):
             ctx.free(d)
