@@ -95,6 +95,30 @@ def child(name, workloads, reps):
         for d in (d_b, d_mv, d_cost):
             ctx.free(d)
         wl.free()
+    if "nstepmesh" in workloads:   # NSTEP + the four mesh passes on every block (run_mesh_search 1, no pruning): 16x16 and 32x32 over the same pair
+        import hashlib
+        for bs in (16, 32):
+            wl = search.SearchPipeline(pkg, ctx, None, 0, 1)
+            W, H = wl.W, wl.H
+            gc, gr = W // bs, H // bs
+            n = gc * gr
+            b = np.zeros(n, capi.search_block_dtype)
+            b["bx"], b["by"] = (np.arange(n) % gc) * bs, (np.arange(n) // gc) * bs
+            ext = wl.BORDER - 8
+            b["col_min"] = np.maximum(-(b["bx"] + ext), -1023); b["col_max"] = np.minimum(W - b["bx"] - bs + ext, 1023)
+            b["row_min"] = np.maximum(-(b["by"] + ext), -1023); b["row_max"] = np.minimum(H - b["by"] - bs + ext, 1023)
+            d_b, d_mv, d_cost = ctx.to_device(b), ctx.malloc(n * 4), ctx.malloc(n * 4)
+            q = capi.SearchParams.make("NSTEP", 3, capi.MV_COST_L1_HDRES, run_mesh=1, mesh=[(64, 8), (28, 4), (15, 1), (7, 1)])
+            k = [0]
+            def oncem():
+                ctx.full_pixel_search_batch(wl.src, wl.ref, k[0] % wl.F, bs, bs, q, d_b, n, d_mv, d_cost); k[0] += 1
+            common.ramp(ctx, oncem)
+            out["nstepmesh%d_ms" % bs] = [round(common.kernel_avg_ms(ctx, oncem, 20), 4) for _ in range(reps)]
+            k[0] = 0; oncem(); ctx.sync()
+            out["nstepmesh%d_sha" % bs] = hashlib.sha1(np.concatenate([ctx.from_device(d_mv, (n, 2), np.int16).ravel(), ctx.from_device(d_cost, (n,), np.int32)]).tobytes()).hexdigest()[:12]
+            for d in (d_b, d_mv, d_cost):
+                ctx.free(d)
+            wl.free()
     if "tf" in workloads:
         from benchlib import encoder
         r = encoder.run_tf(pkg, ctx, None, 6, 2)
