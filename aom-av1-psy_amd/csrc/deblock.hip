@@ -24,6 +24,7 @@
 namespace aomhip {
 
 struct __attribute__((packed, aligned(1))) DU128 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(4))) DU128A4 { uint32_t v[4]; };   // 16 bytes at a 4-byte boundary
 struct __attribute__((packed, aligned(1))) DU64 { uint32_t v[2]; };
 
 __device__ __forceinline__ int iabsd(int v) { return v < 0 ? -v : v; }
@@ -230,12 +231,13 @@ __global__ __launch_bounds__(kDbThreads) void deblock_horz_kernel(PIX *origin, i
   }
 }
 
-// ---- Four lines of an edge per lane (16-bit planes, width and height multiples of 4, 8-byte aligned rows).  The one-line kernels above are
+// ---- Four lines of an edge per lane (width and height multiples of 4, rows that keep 4-pixel groups naturally aligned).  The one-line kernels above are
 // 32 400 wavefronts of ~330 instructions on a 4K plane: a wavefront lives for one memory round trip and little else (PMC: VALU floor 12.0 +
 // 5.6 us against 30 us for the pair of launches, profiles/r04_inner_loop_pmc.json).  Here a lane owns the four pixel rows (vertical edges) /
 // four pixel columns (horizontal edges) of ONE 4x4 unit's edge -- one parameter record, four independent lines whose loads are all in
 // flight before the first filter runs: a quarter of the wavefronts, the same latency each.  The arithmetic per line is lpf_window's, unchanged.
-__global__ __launch_bounds__(kDbThreads) void deblock_vert4_kernel(uint16_t *origin, int stride, int width, int height, const uint8_t *__restrict__ params,
+template <typename PIX>
+__global__ __launch_bounds__(kDbThreads) void deblock_vert4_kernel(PIX *origin, int stride, int width, int height, const uint8_t *__restrict__ params,
                                                                    int units_stride, int sharpness, int bd) {
   const int ux = blockIdx.x * 64 + (threadIdx.x & 63);
   const int uy = blockIdx.y * (kDbThreads / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -244,7 +246,39 @@ __global__ __launch_bounds__(kDbThreads) void deblock_vert4_kernel(uint16_t *ori
   const uint8_t *e = params + ((size_t)uy * units_stride + ux) * 4;
   const int len = e[0], level = e[1];
   if (len == 0 || level == 0) return;
-  uint16_t *s = origin + (int64_t)(4 * uy) * stride + 4 * ux;  // q0 of the unit's first row
+  PIX *s = origin + (int64_t)(4 * uy) * stride + 4 * ux;  // q0 of the unit's first row
+  if constexpr (sizeof(PIX) == 1) {
+    // 8-bit planes: the 16-pixel window of a line is ONE 16-byte load (4-byte aligned: the edge sits at a multiple of 4 pixels)
+    DU128A4 w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const DU128A4 *>(s + (int64_t)r * stride - 8);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t (&wv)[4] = w[r].v;
+      int x[14];
+#pragma unroll
+      for (int i = 0; i < 14; ++i) x[i] = (int)((wv[(i + 1) / 4] >> (8 * ((i + 1) % 4))) & 0xFF);
+      lpf_window(x, len, level, sharpness, bd);
+      // this edge's own zone only, cut at its natural alignments: q0 is a dword boundary, x - 6 and x - 2 are halfword boundaries
+      uint8_t *sr = s + (int64_t)r * stride;
+      auto p2 = [&](int i) { return (uint16_t)((uint32_t)x[i] | ((uint32_t)x[i + 1] << 8)); };   // pixels (i - 7, i - 6) relative to q0
+      auto p4 = [&](int i) { return (uint32_t)x[i] | ((uint32_t)x[i + 1] << 8) | ((uint32_t)x[i + 2] << 16) | ((uint32_t)x[i + 3] << 24); };
+      if (len == 14) {
+        *reinterpret_cast<uint16_t *>(sr - 6) = p2(1);
+        *reinterpret_cast<uint32_t *>(sr - 4) = p4(3);
+        *reinterpret_cast<uint32_t *>(sr) = p4(7);
+        *reinterpret_cast<uint16_t *>(sr + 4) = p2(11);
+      } else if (len == 8) {
+        sr[-3] = (uint8_t)x[4];
+        *reinterpret_cast<uint16_t *>(sr - 2) = p2(5);
+        *reinterpret_cast<uint16_t *>(sr) = p2(7);
+        sr[2] = (uint8_t)x[9];
+      } else {
+        *reinterpret_cast<uint16_t *>(sr - 2) = p2(5);
+        *reinterpret_cast<uint16_t *>(sr) = p2(7);
+      }
+    }
+  } else {
   DU128 w0[4], w1[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -276,9 +310,11 @@ __global__ __launch_bounds__(kDbThreads) void deblock_vert4_kernel(uint16_t *ori
       *reinterpret_cast<DU64 *>(sr - 2) = DU64{ { pk(5), pk(7) } };
     }
   }
+  }
 }
 
-__global__ __launch_bounds__(kDbThreads) void deblock_horz4_kernel(uint16_t *origin, int stride, int width, int height, const uint8_t *__restrict__ params,
+template <typename PIX>
+__global__ __launch_bounds__(kDbThreads) void deblock_horz4_kernel(PIX *origin, int stride, int width, int height, const uint8_t *__restrict__ params,
                                                                    int units_stride, int sharpness, int bd) {
   const int ux = blockIdx.x * 64 + (threadIdx.x & 63);
   const int uy = blockIdx.y * (kDbThreads / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -286,28 +322,50 @@ __global__ __launch_bounds__(kDbThreads) void deblock_horz4_kernel(uint16_t *ori
   const uint8_t *e = params + ((size_t)uy * units_stride + ux) * 4;
   const int len = e[2], level = e[3];
   if (len == 0 || level == 0) return;
-  uint16_t *s = origin + (int64_t)(4 * uy) * stride + 4 * ux;  // q0 of the unit's first column
+  PIX *s = origin + (int64_t)(4 * uy) * stride + 4 * ux;  // q0 of the unit's first column
   const int reach = len == 14 ? 7 : (len == 8 ? 4 : (len == 6 ? 3 : 2));
+  const int wr = len == 14 ? 6 : (len == 8 ? 3 : 2);
+  int out[4][14];
+  if constexpr (sizeof(PIX) == 1) {   // 8-bit planes: the unit's four columns of a row are one dword
+    uint32_t rows[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      const int k = i - 7;
+      rows[i] = (k >= -reach && k < reach) ? *reinterpret_cast<const uint32_t *>(s + (int64_t)k * stride) : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int i = 0; i < 14; ++i) out[c][i] = (int)((rows[i] >> (8 * c)) & 0xFF);
+      lpf_window(out[c], len, level, sharpness, bd);
+    }
+#pragma unroll
+    for (int i = 1; i <= 12; ++i) {
+      const int k = i - 7;
+      if (k >= -wr && k < wr)
+        *reinterpret_cast<uint32_t *>(s + (int64_t)k * stride) =
+            (uint32_t)out[0][i] | ((uint32_t)out[1][i] << 8) | ((uint32_t)out[2][i] << 16) | ((uint32_t)out[3][i] << 24);
+    }
+  } else {
   uint2 rows[14];
 #pragma unroll
   for (int i = 0; i < 14; ++i) {
     const int k = i - 7;
     rows[i] = (k >= -reach && k < reach) ? *reinterpret_cast<const uint2 *>(s + (int64_t)k * stride) : make_uint2(0, 0);
   }
-  int out[4][14];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
 #pragma unroll
     for (int i = 0; i < 14; ++i) out[c][i] = (int)(((c < 2 ? rows[i].x : rows[i].y) >> (16 * (c & 1))) & 0xFFFF);
     lpf_window(out[c], len, level, sharpness, bd);
   }
-  const int wr = len == 14 ? 6 : (len == 8 ? 3 : 2);
 #pragma unroll
   for (int i = 1; i <= 12; ++i) {
     const int k = i - 7;
     if (k >= -wr && k < wr)
       *reinterpret_cast<uint2 *>(s + (int64_t)k * stride) =
           make_uint2((uint32_t)out[0][i] | ((uint32_t)out[1][i] << 16), (uint32_t)out[2][i] | ((uint32_t)out[3][i] << 16));
+  }
   }
 }
 
@@ -502,20 +560,28 @@ int aomhip_deblock_plane(aomhip_ctx *ctx, const aomhip_planes *p, int frame, con
   const int rows_per_wg = kDbThreads / 64;
   const dim3 gv((ucols + 63) / 64, (p->height + rows_per_wg - 1) / rows_per_wg);
   const dim3 gh((p->width + 63) / 64, (urows + rows_per_wg - 1) / rows_per_wg);
-  // 16-bit planes whose rows keep 4-pixel groups 8-byte aligned: four lines of an edge per lane (AOMHIP_DEBLOCK_LINES=1: the one-line kernels, A/B)
+  // planes whose rows keep 4-pixel groups naturally aligned (8 bytes at 16 bits, 4 at 8): four lines of an edge per lane (AOMHIP_DEBLOCK_LINES=1: the one-line kernels, A/B)
   const char *one = getenv("AOMHIP_DEBLOCK_LINES");
-  const bool four = esz == 2 && (p->width & 3) == 0 && (p->height & 3) == 0 && (p->stride & 3) == 0 && (p->border & 3) == 0 && p->border >= 8 &&
-                    (reinterpret_cast<uintptr_t>(origin) & 7) == 0 && !(one && atoi(one) == 1);
+  const bool four = (p->width & 3) == 0 && (p->height & 3) == 0 && (p->stride & 3) == 0 && (p->border & 3) == 0 && p->border >= 8 &&
+                    (reinterpret_cast<uintptr_t>(origin) & (4 * esz - 1)) == 0 && !(one && atoi(one) == 1);
   if (four) {
     const dim3 g4((ucols + 63) / 64, (urows + rows_per_wg - 1) / rows_per_wg);
     if (passes & 1) {
-      hipLaunchKernelGGL(deblock_vert4_kernel, g4, dim3(kDbThreads), 0, ctx->stream, reinterpret_cast<uint16_t *>(origin), p->stride, p->width, p->height,
-                         d_edge_params, units_stride, sharpness, p->bit_depth);
+      if (esz == 1)
+        hipLaunchKernelGGL(deblock_vert4_kernel<uint8_t>, g4, dim3(kDbThreads), 0, ctx->stream, reinterpret_cast<uint8_t *>(origin), p->stride, p->width,
+                           p->height, d_edge_params, units_stride, sharpness, p->bit_depth);
+      else
+        hipLaunchKernelGGL(deblock_vert4_kernel<uint16_t>, g4, dim3(kDbThreads), 0, ctx->stream, reinterpret_cast<uint16_t *>(origin), p->stride, p->width,
+                           p->height, d_edge_params, units_stride, sharpness, p->bit_depth);
       AOMHIP_LAUNCH_CHECK();
     }
     if (passes & 2) {
-      hipLaunchKernelGGL(deblock_horz4_kernel, g4, dim3(kDbThreads), 0, ctx->stream, reinterpret_cast<uint16_t *>(origin), p->stride, p->width, p->height,
-                         d_edge_params, units_stride, sharpness, p->bit_depth);
+      if (esz == 1)
+        hipLaunchKernelGGL(deblock_horz4_kernel<uint8_t>, g4, dim3(kDbThreads), 0, ctx->stream, reinterpret_cast<uint8_t *>(origin), p->stride, p->width,
+                           p->height, d_edge_params, units_stride, sharpness, p->bit_depth);
+      else
+        hipLaunchKernelGGL(deblock_horz4_kernel<uint16_t>, g4, dim3(kDbThreads), 0, ctx->stream, reinterpret_cast<uint16_t *>(origin), p->stride, p->width,
+                           p->height, d_edge_params, units_stride, sharpness, p->bit_depth);
       AOMHIP_LAUNCH_CHECK();
     }
     return AOMHIP_OK;

@@ -101,6 +101,8 @@ def main():
                                                 "filters_ring_4k_10bit", "launcher_dry_run"] + sorted(VAR_WORKLOADS))
     ap.add_argument("--others", default="auto", help="comma list of extra workloads reported under 'others' (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bit-depth", type=int, default=0, choices=[0, 8, 10],
+                    help="audit aid: run the *_4k_10bit search / filter workloads on planes of this depth instead (0 = the workload's own); the line says so")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path); gloo only to dry-run the N > 1 code on one GPU")
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="override the ring size per GPU (0 = workload default)")
@@ -110,6 +112,10 @@ def main():
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
                     help="N > 1 search pipeline: what aomhip_allgather_recon moves per frame (both are timed; this one is in `value`)")
     args = ap.parse_args()
+    if args.bit_depth:   # (audit aid, tools/bd_audit.sh: the same kernels' other instantiation on the same content)
+        from benchlib import search as _search
+        common.BD_OVERRIDE = _search.SearchPipeline.BD = args.bit_depth
+        print("note: planes of %d bits instead of the workload's own depth (--bit-depth)" % args.bit_depth, file=sys.stderr)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes, BEFORE this process touches the
@@ -207,11 +213,11 @@ def main():
         return
     if args.workload == "compound_search_4k_10bit":  # the RD path's compound / OBMC searches (single GPU)
         only = int(os.environ.get("AOMHIP_BENCH_COMPOUND_BS", "0"))   # profiling aid: this block size alone (profiles/r05e_compound_pmc.json)
-        r = run_compound_search(pkg, ctx, orc if not only else None, args.steps, args.warmup, bs=only or 16)
+        r = run_compound_search(pkg, ctx, orc if not only else None, args.steps, args.warmup, bd=args.bit_depth or 10, bs=only or 16)
         # the same five calls over the frame cut into 8x8, 32x32 and 64x64 blocks (timing only; the tests cover the sizes' parity)
         r["by_block_size"] = {"%dx%d" % (only or 16, only or 16): {k: v["ms_per_frame"] for k, v in r.items() if isinstance(v, dict) and "ms_per_frame" in v}}
         for bs_ in () if only else (8, 32, 64):
-            r2 = run_compound_search(pkg, ctx, None, max(3, args.steps // 2), 1, bs=bs_)
+            r2 = run_compound_search(pkg, ctx, None, max(3, args.steps // 2), 1, bd=args.bit_depth or 10, bs=bs_)
             r["by_block_size"]["%dx%d" % (bs_, bs_)] = dict({k: v["ms_per_frame"] for k, v in r2.items() if isinstance(v, dict) and "ms_per_frame" in v},
                                                             blocks_per_frame=r2["blocks_per_frame"])
         ctx.close()

@@ -6,6 +6,9 @@ import time
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+BD_OVERRIDE = 0   # bench.py --bit-depth: the search / filter workloads on planes of this depth (0 = their own)
+
+
 def ramp(ctx, fn, seconds=None):
     """Untimed: keep the chip busy with the workload itself before anything is measured.  The first milliseconds after an idle period run
     at a lower clock (profiles/r03_sad_strip.md section 4: the same launch 0.310 ms right after 3 warm-up launches, 0.273 ms sustained);

@@ -14,10 +14,10 @@ from .common import HBM_PEAK_GBS, ROOT, kernel_avg_ms, ramp
 def run_cdef_search(pkg, ctx, orc, steps, warmup):
     """The distortion table of av1_cdef_search (pickcdef.c:401-615) for a 4K 10-bit luma plane, CDEF_FULL_SEARCH (64 strength
     pairs per 64x64 filter block), one launch; also the 16-pair list of CDEF_FAST_SEARCH_LVL1-sized searches.  Informational."""
-    W, H, bd, border = 3840, 2160, 10, 64
+    W, H, bd, border = 3840, 2160, common.BD_OVERRIDE or 10, 64
     recon = pkg.synth.lcg_frame(W, H, 2, 0, bd)
     rng = np.random.default_rng(9)
-    source = np.clip(recon.astype(np.int64) + rng.integers(-20, 21, recon.shape), 0, 1023).astype(recon.dtype)
+    source = np.clip(recon.astype(np.int64) + rng.integers(-20, 21, recon.shape), 0, (1 << bd) - 1).astype(recon.dtype)
     pr, ps = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
     ctx.planes_upload(pr, 0, recon); ctx.planes_upload(ps, 0, source)
     fbh, fbw = (H + 63) // 64, (W + 63) // 64
