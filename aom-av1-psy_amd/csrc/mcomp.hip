@@ -460,24 +460,10 @@ __global__ __launch_bounds__(kMeshThreads) void mesh_search_kernel(
       if (fits) {
         const int cpr = wpitch / 16 - 1;  // chunks that carry pixels (the tail chunk may over-read <= 15 bytes: in-row)
         const int total = wrows * cpr;
-        // four chunks per thread requested before the first LDS write (one per iteration made the copy a chain of memory round trips)
-        constexpr int kBatch = 4;
-        for (int q0 = tid; q0 < total; q0 += kBatch * kMeshThreads) {
-          MU128 v[kBatch];
-#pragma unroll
-          for (int t = 0; t < kBatch; ++t) {
-            const int q = min(q0 + t * kMeshThreads, total - 1);
-            const int r = q / cpr, c = q - r * cpr;
-            v[t] = *reinterpret_cast<const MU128 *>(reinterpret_cast<const char *>(worg + (int64_t)r * ref.stride) + c * 16);
-          }
-#pragma unroll
-          for (int t = 0; t < kBatch; ++t) {
-            const int q = q0 + t * kMeshThreads;
-            if (q < total) {
-              const int r = q / cpr, c = q - r * cpr;
-              *reinterpret_cast<uint4 *>(lds_win + r * wpitch + c * 16) = make_uint4(v[t].v[0], v[t].v[1], v[t].v[2], v[t].v[3]);
-            }
-          }
+        for (int q = tid; q < total; q += kMeshThreads) {
+          const int r = q / cpr, c = q - r * cpr;
+          const MU128 v = *reinterpret_cast<const MU128 *>(reinterpret_cast<const char *>(worg + (int64_t)r * ref.stride) + c * 16);
+          *reinterpret_cast<uint4 *>(lds_win + r * wpitch + c * 16) = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
         }
       }
       __syncthreads();

@@ -7,3 +7,4 @@ find $OUT/stats -name '*kernel_trace.csv' -delete; find $OUT/stats -name '*agent
 grep -E "^== |bench:" $OUT/profiles.log
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; wc -c $OUT/bench_default.json; cp gpurun_out/bench_full.json $OUT/bench_full.json
 du -sh $OUT
+bash tools/bd_audit.sh $OUT/bd_audit > $OUT/bd_audit.txt 2>&1; grep -c "8-BIT SLOWER" $OUT/bd_audit.txt
