@@ -328,3 +328,35 @@ def test_edge_cases_empty_ragged_degenerate_limits(hip, oracle, ctx):
                 assert np.array_equal(a, w_), (n, method, name)
             assert got[0][0].tolist() == [2, -3]
     ctx.planes_free(ps); ctx.planes_free(pr)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bs", [16, 32, 64])
+def test_mesh_passes_over_a_grid_of_neighbours(hip, oracle, ctx, bs, bd):
+    """NSTEP + the good-quality mesh pattern on EVERY block of a frame cut into a grid -- the layout the cells are made for: horizontal neighbours
+    share a window, and a mesh batch whose candidates all lie inside it reads the window instead of the plane (round 6).  Ranges 64 / 28 / 15 / 7
+    straddle the window's reach (32 at 16x16, 8 above) in both directions; the frame pair moves by a different vector in each quadrant so that
+    neighbouring blocks end their n-step search on different centres.  Also with the pruning rule on (mesh only where the n-step result is far)."""
+    rng = np.random.default_rng(bs + bd)
+    W, H, border = 256, 192, 160
+    src, ref = hip.synth.shifted_smooth_pair(W, H, bs + bd, bd, shift=(5, -7))
+    _, ref2 = hip.synth.shifted_smooth_pair(W, H, bs + bd, bd, shift=(-11, 3))
+    ref[H // 2:, :] = ref2[H // 2:, :]
+    ref[:, W // 2:] = np.roll(ref[:, W // 2:], 9, axis=1)
+    ref = np.clip(ref.astype(np.int32) + rng.integers(-2 << (bd - 8), (2 << (bd - 8)) + 1, ref.shape), 0, (1 << bd) - 1).astype(ref.dtype)
+    ps, pr = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(ps, 0, src); ctx.planes_upload(pr, 0, ref)
+    sb, rb = oracle.extend_plane(src, border, ps.stride), oracle.extend_plane(ref, border, pr.stride)
+    xs, ys = np.meshgrid(np.arange(0, W - bs + 1, bs), np.arange(0, H - bs + 1, bs))
+    b = np.zeros(xs.size, hip.capi.search_block_dtype)
+    b["bx"], b["by"] = xs.ravel(), ys.ravel()
+    for i in range(b.size):
+        b["row_min"][i], b["row_max"][i], b["col_min"][i], b["col_max"][i] = oracle.mv_limits_for_block(int(b["bx"][i]), int(b["by"][i]), bs, bs, W, H, border, 0, 0)
+    mesh = [(64, 8), (28, 4), (15, 1), (7, 1)]
+    for kw in (dict(run_mesh=1), dict(run_mesh=1, prune_mesh=1, mesh_diff_thr=4), dict(force_mesh_thresh=1 << 10)):
+        got = _run(hip, ctx, ps, pr, 0, bs, bs, hip.capi.SearchParams.make("NSTEP", 3, 3, mesh=mesh, **kw), b)
+        want = oracle.full_pixel_search_batch(sb, rb, border, bs, bs, b, oracle.search_params("NSTEP", 3, 3, mesh=mesh, **kw), bd=bd)
+        for name, a, w_ in zip(("mv", "cost", "cost_list", "second"), got, want):
+            assert np.array_equal(a, w_), (bs, bd, kw, name, int(np.flatnonzero((a != w_).reshape(len(a), -1).any(1))[0]))
+        assert len(np.unique(got[0], axis=0)) > 2   # the quadrants did end on different vectors
+    ctx.planes_free(ps); ctx.planes_free(pr)
