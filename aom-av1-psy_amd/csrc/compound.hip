@@ -52,8 +52,8 @@ __global__ __launch_bounds__(kVarThreads) void compound_kernel(PlaneView<T> src,
   const int64_t blk = (g.pred_index ? (int64_t)g.pred_index[slot] : 0) * (W * H);
   const T *pp = KIND == kCompObmc ? nullptr : static_cast<const T *>(g.second_pred) + blk;
   const uint8_t *mp = KIND == kCompMask ? g.mask + (g.mask_offset ? g.mask_offset[slot] : 0) : nullptr;
-  const int fx0 = kBilinear[c.xoff & 7][0], fx1 = kBilinear[c.xoff & 7][1];
-  const int fy0 = kBilinear[c.yoff & 7][0], fy1 = kBilinear[c.yoff & 7][1];
+  static_assert(kBilinear[3][0] == 128 - 16 * 3 && kBilinear[3][1] == 16 * 3 && kBilinear[7][0] == 16, "bilinear taps are 128 - 16 i, 16 i");
+  const int fx1 = (c.xoff & 7) << 4, fx0 = 128 - fx1, fy1 = (c.yoff & 7) << 4, fy0 = 128 - fy1;   // (by arithmetic: a table index is a memory load)
   int64_t sum = 0;
   uint64_t sse = 0, sad = 0;
 #pragma unroll

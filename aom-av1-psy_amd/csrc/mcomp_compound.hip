@@ -823,7 +823,8 @@ __global__ __launch_bounds__(256) void obmc_subpel_tree_kernel(PlaneView<T> ref,
   auto obmc_err = [&](int mrow, int mcol, int form, uint32_t *sse_out) -> uint32_t {
     const T *rp = rbase + (int64_t)(mrow >> 3) * ref.stride + (mcol >> 3);
     const int sx = mcol & 7, sy = mrow & 7;
-    const int fx0 = kBil[sx][0], fx1 = kBil[sx][1], fy0 = kBil[sy][0], fy1 = kBil[sy][1];
+    static_assert(kBil[3][0] == 128 - 16 * 3 && kBil[3][1] == 16 * 3 && kBil[7][0] == 16, "bilinear taps are 128 - 16 i, 16 i");
+    const int fx1 = (sx & 7) << 4, fx0 = 128 - fx1, fy1 = (sy & 7) << 4, fy0 = 128 - fy1;   // (by arithmetic: a table index is a memory load)
     int64_t s = 0, q = 0;
     if (form == 2) {
       // The up-sampled form in two passes through the wavefront's LDS tile, a lane taking units of four adjacent pixels: the horizontal pass

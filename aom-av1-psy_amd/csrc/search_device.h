@@ -248,7 +248,8 @@ __device__ __forceinline__ uint32_t wave_variance(const T *ap, int astride, int 
   constexpr int U = UPR * H;
   constexpr uint8_t kBil[8][2] = { { 128, 0 }, { 112, 16 }, { 96, 32 }, { 80, 48 },
                                    { 64, 64 }, { 48, 80 },  { 32, 96 }, { 16, 112 } };  // aom_filter.h:43-50
-  const int fx0 = kBil[xoff & 7][0], fx1 = kBil[xoff & 7][1], fy0 = kBil[yoff & 7][0], fy1 = kBil[yoff & 7][1];
+  static_assert(kBil[3][0] == 128 - 16 * 3 && kBil[3][1] == 16 * 3 && kBil[7][0] == 16, "bilinear taps are 128 - 16 i, 16 i");
+  const int fx1 = (xoff & 7) << 4, fx0 = 128 - fx1, fy1 = (yoff & 7) << 4, fy0 = 128 - fy1;   // = kBil[off & 7]: {128 - 16 i, 16 i} (aom_filter.h:43-50) by arithmetic -- indexed as a table the compiler put it in memory: two loads on the chain of every candidate
   int64_t sum = 0, sse = 0;
   for (int u = lane; u < U; u += 64) {
     const int row = u / UPR, col = (u % UPR) * UE;
@@ -475,7 +476,8 @@ __device__ __forceinline__ uint32_t group16_variance(const T *ap, int astride, i
   using L = typename MLoad<UB>::type;
   constexpr uint8_t kBil[8][2] = { { 128, 0 }, { 112, 16 }, { 96, 32 }, { 80, 48 },
                                    { 64, 64 }, { 48, 80 },  { 32, 96 }, { 16, 112 } };  // aom_filter.h:43-50
-  const int fx0 = kBil[xoff & 7][0], fx1 = kBil[xoff & 7][1], fy0 = kBil[yoff & 7][0], fy1 = kBil[yoff & 7][1];
+  static_assert(kBil[3][0] == 128 - 16 * 3 && kBil[3][1] == 16 * 3 && kBil[7][0] == 16, "bilinear taps are 128 - 16 i, 16 i");
+  const int fx1 = (xoff & 7) << 4, fx0 = 128 - fx1, fy1 = (yoff & 7) << 4, fy0 = 128 - fy1;   // = kBil[off & 7]: {128 - 16 i, 16 i} (aom_filter.h:43-50) by arithmetic -- indexed as a table the compiler put it in memory: two loads on the chain of every candidate
   int32_t sum = 0;   // |Σd| <= 4095 * W * H < 2^31 for every block size
   uint64_t sse = 0;
   if (active) {
