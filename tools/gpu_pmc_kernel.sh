@@ -2,7 +2,7 @@
 # PMC diagnostics for the kernels of one bench workload.  Usage: gpurun -- 'bash tools/gpu_pmc_kernel.sh <tag> <workload> <kernel-substring>'
 set -u
 TAG=${1:-r01}; WL=${2:-inner_loop_4k_10bit}; KS=${3:-cdef_luma}
-OUT=gpurun_out/$TAG/pmc_$KS
+OUT=gpurun_out/$TAG/pmc_$(echo "$KS" | tr -c "A-Za-z0-9_" "_")
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o k -- python bench.py --steps 4 --warmup 1 --workload $WL --others "" --no-cpu-baseline > $OUT/trace.json 2> $OUT/trace.err
