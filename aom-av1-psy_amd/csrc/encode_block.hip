@@ -108,7 +108,7 @@ __global__ __launch_bounds__(eb_threads<W>()) void encode_inter_block_kernel(Pla
   }
 
   // ---- 2. residual column (aom_[highbd_]subtract_block) = the forward column pass's input
-  const int vk = kVKind[tx_type & 15], hk = kHKind[tx_type & 15];
+  const int vk = v_kind(tx_type), hk = h_kind(tx_type);
   int32_t x[H];
   int amax = 0;
   if (live) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(eb_threads<W>()) void encode_inter_block_kernel(Pla
 
   // ---- 6. inverse rows (av1_inverse_transform_block: nothing to add when eob == 0) -> transpose tile I (over Q / D)
   if (has_coeffs) {
-    const int ihk = kIHKind[tx_type & 15];
+    const int ihk = ih_kind(tx_type);
 #pragma unroll
     for (int c = 0; c < W; ++c) y[c] = clampv<BD + 8>(y[c]);
     inv_1d<W, 12, RNG_ROW>(y, ihk == 2 ? 1 : ihk);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(eb_threads<W>()) void encode_inter_block_kernel(Pla
   if (live) {
     constexpr int kMax = (1 << BD) - 1;
     if (has_coeffs) {
-      const int ivk = kIVKind[tx_type & 15], ihk = kIHKind[tx_type & 15];
+      const int ivk = iv_kind(tx_type), ihk = ih_kind(tx_type);
       const int sc = (ihk == 2) ? W - 1 - lane : lane;
       int32_t z[H];
 #pragma unroll

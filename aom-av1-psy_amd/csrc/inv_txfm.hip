@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kInvThreads) void inv_txfm_add_kernel(const int32_t
       live = false;
     }
   }
-  const int vk = kIVKind[tx_type & 15], hk = kIHKind[tx_type & 15];
+  const int vk = iv_kind(tx_type), hk = ih_kind(tx_type);
   int32_t(&t)[KH * LSTRIDE] = tile[slot];
 
   // ---- rows (only the KH rows that can be non-zero)

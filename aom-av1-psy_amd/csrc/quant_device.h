@@ -183,6 +183,18 @@ __device__ constexpr uint8_t kHKind[16] = { 0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 
 __device__ constexpr uint8_t kIVKind[16] = { 0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3 };
 __device__ constexpr uint8_t kIHKind[16] = { 0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2 };
 
+// The same four tables as 2-bit fields of one 32-bit constant each: `kVKind[tx_type]` with a block's own type is an index into constant MEMORY (a vector load
+// behind the record's load at the head of every transform kernel); a shift and a mask of an immediate are not.
+constexpr uint32_t pack_kinds(const uint8_t (&t)[16]) {
+  uint32_t v = 0;
+  for (int i = 0; i < 16; ++i) v |= (uint32_t)(t[i] & 3) << (2 * i);
+  return v;
+}
+__device__ __forceinline__ int v_kind(int tx_type) { return (int)((pack_kinds(kVKind) >> (2 * (tx_type & 15))) & 3u); }
+__device__ __forceinline__ int h_kind(int tx_type) { return (int)((pack_kinds(kHKind) >> (2 * (tx_type & 15))) & 3u); }
+__device__ __forceinline__ int iv_kind(int tx_type) { return (int)((pack_kinds(kIVKind) >> (2 * (tx_type & 15))) & 3u); }
+__device__ __forceinline__ int ih_kind(int tx_type) { return (int)((pack_kinds(kIHKind) >> (2 * (tx_type & 15))) & 3u); }
+
 // Largest residual magnitude per [TX_SIZE][TX_TYPE] under which the fast butterfly is exact (txfm_device.h: kFastBtf)
 __device__ constexpr int16_t kSafeMax[19][16] = {
 #include "txfm_safe_max.inc"

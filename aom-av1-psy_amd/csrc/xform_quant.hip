@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_kernel(
       by = (bi / grid_cols) * H;
     }
   }
-  const int vk = kVKind[tx_type & 15], hk = kHKind[tx_type & 15];
+  const int vk = v_kind(tx_type), hk = h_kind(tx_type);
   int32_t(&t)[KH * LSTRIDE] = tile[slot];
 
   // ---- columns
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_staged_kernel(
       by = (bi / grid_cols) * H;
     }
   }
-  const int vk = kVKind[tx_type & 15], hk = kHKind[tx_type & 15];
+  const int vk = v_kind(tx_type), hk = h_kind(tx_type);
   int32_t *A = lds[slot];
   int32_t *B = lds[slot] + A_WORDS;
   int16_t *A16 = reinterpret_cast<int16_t *>(A);
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kXqThreads) void xform_quant_lane_kernel(
     bx = (bi % grid_cols) * W;
     by = (bi / grid_cols) * H;
   }
-  const int vk = kVKind[tx_type & 15], hk = kHKind[tx_type & 15];
+  const int vk = v_kind(tx_type), hk = h_kind(tx_type);
   const bool ud = (vk == 2), lr = (hk == 2);
 
   // ---- load rows (one wide access per row), apply the up/down flip while loading
