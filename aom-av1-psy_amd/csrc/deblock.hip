@@ -519,16 +519,58 @@ __global__ __launch_bounds__(kDbThreads) void deblock_fused_kernel(const PIX *__
 template <typename T>
 __global__ __launch_bounds__(256) void plane_sse_kernel(const T *__restrict__ a, int a_stride, const T *__restrict__ b, int b_stride, int width,
                                                         int height, unsigned long long *__restrict__ out) {
+  // A wavefront per row (four rows per workgroup), 16 bytes per lane and step, four steps of both planes requested together: the planes are read once at
+  // the width of the memory path and a 4K plane ends in 540 atomic adds.  (Round 1's form read ONE pixel per lane and step -- 32 400 workgroups on a 4K plane,
+  // each ending in an atomic add to the ONE result word: 392 us, all of it the serialised atomics, against 11 us now; a filter-level trial of
+  // aomhip_lpf_search_sse -- copy + deblock + this -- went from 420 to 40 us.  tools/plane_sse_time.py)
+  constexpr int VEC = 16 / (int)sizeof(T), kBatch = 4;
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
   __shared__ unsigned long long part[4];
-  const int y = blockIdx.y;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int y = blockIdx.x * 4 + wave;
   unsigned long long acc = 0;
-  for (int x = blockIdx.x * 256 + threadIdx.x; x < width; x += gridDim.x * 256) {
-    const int d = (int)a[(int64_t)y * a_stride + x] - (int)b[(int64_t)y * b_stride + x];
-    acc += (unsigned)__mul24(d, d);
+  if (y < height) {
+    const T *ra = a + (int64_t)y * a_stride, *rb = b + (int64_t)y * b_stride;
+    const int nvec = width / VEC;   // whole 16-byte pieces of the row (any byte alignment: the loads are dword-addressable)
+    for (int v0 = lane; v0 < nvec; v0 += 64 * kBatch) {
+      DU128 va[kBatch], vb[kBatch];
+#pragma unroll
+      for (int t = 0; t < kBatch; ++t) {
+        const int v = min(v0 + 64 * t, nvec - 1);
+        va[t] = *reinterpret_cast<const DU128 *>(ra + (int64_t)v * VEC);
+        vb[t] = *reinterpret_cast<const DU128 *>(rb + (int64_t)v * VEC);
+      }
+      uint32_t q = 0;   // <= kBatch * 16 * 4095^2 < 2^32
+#pragma unroll
+      for (int t = 0; t < kBatch; ++t) {
+        if (v0 + 64 * t < nvec) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if constexpr (sizeof(T) == 2) {
+              const s16x2_t d = __builtin_bit_cast(s16x2_t, va[t].v[i]) - __builtin_bit_cast(s16x2_t, vb[t].v[i]);
+              q = (uint32_t)__builtin_amdgcn_sdot2(d, d, (int)q, false);
+            } else {
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {   // bytes (2 h, 2 h + 1) of the dword as 16-bit halves
+                const uint32_t sel = h ? 0x0c030c02u : 0x0c010c00u;
+                const s16x2_t d = __builtin_bit_cast(s16x2_t, __builtin_amdgcn_perm(0u, va[t].v[i], sel)) -
+                                  __builtin_bit_cast(s16x2_t, __builtin_amdgcn_perm(0u, vb[t].v[i], sel));
+                q = (uint32_t)__builtin_amdgcn_sdot2(d, d, (int)q, false);
+              }
+            }
+          }
+        }
+      }
+      acc += q;
+    }
+    for (int x = nvec * VEC + lane; x < width; x += 64) {   // the row's last width % VEC pixels
+      const int d = (int)ra[x] - (int)rb[x];
+      acc += (unsigned)__mul24(d, d);
+    }
   }
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  if (lane == 0) part[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned long long t = part[0] + part[1] + part[2] + part[3];
@@ -669,7 +711,7 @@ int aomhip_plane_sse(aomhip_ctx *ctx, const aomhip_planes *a, int a_frame, const
     set_error("aomhip_plane_sse: memset failed");
     return AOMHIP_ERR_HIP;
   }
-  const dim3 grid(std::min((a->width + 255) / 256, 16), a->height);
+  const dim3 grid((a->height + 3) / 4);   // a wavefront per row
   if (esz == 1)
     hipLaunchKernelGGL(plane_sse_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, reinterpret_cast<const uint8_t *>(pa), a->stride,
                        reinterpret_cast<const uint8_t *>(pb), b->stride, a->width, a->height, reinterpret_cast<unsigned long long *>(d_sse));
@@ -703,7 +745,7 @@ int aomhip_lpf_search_sse(aomhip_ctx *ctx, const aomhip_planes *recon, int recon
     set_error("aomhip_lpf_search_sse: memset failed");
     return AOMHIP_ERR_HIP;
   }
-  const dim3 grid(std::min((recon->width + 255) / 256, 16), recon->height);
+  const dim3 grid((recon->height + 3) / 4);   // (plane_sse_kernel: a wavefront per row)
   for (int t = 0; t < n_trials; ++t) {
     // try_filter_frame (av1/encoder/picklpf.c:49-86): filter a copy, measure, and leave the unfiltered frame as it was
     if (hipMemcpyAsync(sframe, rframe, (size_t)recon->frame_stride * esz, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
