@@ -91,7 +91,29 @@ def run_filters_ring(pkg, ctx, orc, steps, warmup, width=3840, height=2160, bd=1
                 "frac_compulsory": compulsory_factor * algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "frac_traffic": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None}
 
+    # one trial of the loop-filter level search (search_filter_level -> try_filter_frame, picklpf.c:49-193) = aomhip_lpf_search_sse: copy the frame,
+    # deblock the copy at the trial's levels, SSE against the source -- eight trials over ring slots 0 (reconstruction), 1 (scratch), 2 (source)
+    n_trials = 8
+    tp = np.zeros((n_trials,) + params.shape, np.uint8)
+    for t in range(n_trials):
+        tp[t] = params
+        tp[t, :, 2::2, 1] = 4 * (t + 1); tp[t, 2::2, :, 3] = 4 * (t + 1)
+    d_tp, d_tsse = ctx.to_device(tp), ctx.malloc(8 * n_trials)
+    restore()
+    trial = lambda: ctx.lpf_search_sse(p, 0, p, 1, p, 2, d_tp, params.size, n_trials, W // 4, 0, 3, d_tsse)
+    trial(); ctx.sync()
+    lpf_ok = None
+    if orc is not None:   # the first trial's SSE against the oracle's deblocked plane
+        want_d = orc.deblock_plane(host[0], tp[0], sharpness=0, bd=bd)
+        lpf_ok = int(ctx.from_device(d_tsse, (n_trials,), np.uint64)[0]) == int(((want_d.astype(np.int64) - host[2].astype(np.int64)) ** 2).sum())
+    ctx.timer_begin()
+    for _ in range(max(steps, 3)):
+        trial()
+    lpf_us = ctx.timer_end() / (max(steps, 3) * n_trials) * 1e3
+    ctx.free(d_tp); ctx.free(d_tsse)
     res = {"workload": "filters_ring_4k_10bit", "value": steps * F / ((dbk_ms + cdef_ms) * 1e-3), "unit": "planes/s (deblock + CDEF)",
+           "lpf_search_trial": {"us_per_trial": lpf_us, "trial": "frame copy + deblock at the trial's levels + plane SSE against the source"},
+           "parity_lpf_first_trial": lpf_ok,
            "ms_per_step": (dbk_ms + cdef_ms) / steps, "wall_ms_per_step_incl_restore": wall / steps * 1e3, "parity_slot0_and_last": ok,
            "deblock_vert+horz": leg(dbk_ms, 2, ("deblock_vert", "deblock_horz"), ("deblock.hip",)),
            "cdef_luma": leg(cdef_ms, 1, ("cdef_luma_kernel",), ("cdef.hip",)),

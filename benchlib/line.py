@@ -108,7 +108,8 @@ def build_lines(args, world, main_res, others, strong):
                                    "sb_same": o["strip_walk"]["identical_to_direct_slot0_and_last"]} if o.get("strip_walk") else {})) for o in vars_} or None,
                 filters_ring=None if filt is None else dict(
                     {k: {"us": filt[k]["ms_per_plane"] * 1e3, "frac": filt[k]["frac"], "c": filt[k]["frac_compulsory"], "t": filt[k]["frac_traffic"]}
-                     for k in ("deblock_vert+horz", "cdef_luma")}, parity=filt["parity_slot0_and_last"], ring_GB=1.32),
+                     for k in ("deblock_vert+horz", "cdef_luma")}, parity=filt["parity_slot0_and_last"], ring_GB=1.32,
+                    lpf_trial_us=(filt.get("lpf_search_trial") or {}).get("us_per_trial")),
                 strong_scaling_search=strong,
                 parity_frame0_and_last_slot=main_res["parity_frame0"],
                 parity_all=all(bool(v) for o in [main_res] + others for k, v in o.items() if k.startswith("parity") and v is not None),

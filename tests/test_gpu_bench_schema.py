@@ -83,6 +83,8 @@ def test_default_single_gpu_line_is_small_enough_for_the_driver_record(tmp_path)
     for k in ("deblock_vert+horz", "cdef_luma"):   # on a 1.3 GB ring of 4K 10-bit planes: an HBM figure
         assert 0 < fr[k]["frac"] < 1 and 0 < fr[k]["c"] < 1 and fr[k]["us"] > 0 and "t" in fr[k]
     assert fr["parity"] is True and fr["ring_GB"] >= 1.0
+    # one trial of the loop-filter level search (copy + deblock + plane SSE): tens of microseconds -- round 1's plane SSE alone was 392 us of serialised atomics
+    assert 0 < fr["lpf_trial_us"] < 150
     il = d["others"]["encode_inner_loop_4k_10bit"]
     assert 0 < il["roofline_frac"] < 1 and 0 < il["yuv420_roofline_frac"] < 1 and il["yuv420_ms_per_frame"] > il["ms_per_frame"]
     for t in d["txq"].values():
