@@ -43,3 +43,39 @@ for bs in (8, 16, 32, 64):
     print("sum_sse_2d_i16 %3dx%-3d: %7.1f us per frame, %5.2f TB/s" % (bs, bs, ms * 1e3, 2.0 * n * bs * bs / ms / 1e9))
     for d in (dt, dsse, dsum):
         ctx.free(d)
+# frame-level statistics of the variance-based partition and the global-motion segment error, and the Hadamard / SATD helper
+for bd in (10, 8):
+    a = pkg.synth.lcg_frame(W, H, 2, 0, bd); b = pkg.synth.lcg_frame(W, H, 2, 1, bd)
+    pa, pb = ctx.planes_alloc(W, H, border, bd, 1), ctx.planes_alloc(W, H, border, bd, 1)
+    ctx.planes_upload(pa, 0, a); ctx.planes_upload(pb, 0, b)
+    n16x, n16y = (W + 15) // 16, (H + 15) // 16
+    d_sum8 = ctx.malloc(8 * 4 * (2 * n16x) * (2 * n16y) + 4096)
+    f8 = lambda: ctx.vbp_8x8_stats_plane(pa, 0, pb, 0, W, H, d_sum8, 2 * n16x)
+    common.ramp(ctx, f8, 0.05)
+    m8 = common.kernel_avg_ms(ctx, f8, 20)
+    d_sum4 = ctx.malloc(8 * 4 * (W // 4 + 8) * (H // 4 + 8))
+    f4 = lambda: ctx.vbp_4x4_avg_plane(pa, 0, W, H, 0, d_sum4, W // 4)
+    common.ramp(ctx, f4, 0.05)
+    m4 = common.kernel_avg_ms(ctx, f4, 20)
+    seg = np.ones((H // 32 + 1, W // 32 + 1), np.uint8)
+    d_seg, d_err = ctx.to_device(seg), ctx.malloc(8)
+    fe = lambda: ctx.segmented_frame_error(pa, 0, pb, 0, W, H, d_seg, seg.shape[1], d_err)
+    common.ramp(ctx, fe, 0.05)
+    me = common.kernel_avg_ms(ctx, fe, 20)
+    print("%2d-bit 4K: vbp 8x8 statistics %.1f us, vbp 4x4 averages %.1f us, segmented frame error %.1f us" % (bd, m8 * 1e3, m4 * 1e3, me * 1e3))
+    ctx.planes_free(pa); ctx.planes_free(pb)
+for nn, fl in ((8, 0), (16, 0), (32, 0), (8, 2), (16, 2), (32, 2)):
+    xs, ys = np.meshgrid(np.arange(0, W - nn + 1, nn), np.arange(0, H - nn + 1, nn))
+    n = xs.size
+    t = np.zeros(n, capi.txb_dtype)
+    t["x"], t["y"] = xs.ravel(), ys.ravel()
+    t["out_offset"] = np.arange(n, dtype=np.uint32) * (nn * nn)
+    dt, dsatd = ctx.to_device(t), ctx.malloc(4 * n)
+    fh = lambda: ctx.hadamard_batch(dres, W, nn, fl, dt, n, None, dsatd)
+    try:
+        common.ramp(ctx, fh, 0.05)
+        ms = common.kernel_avg_ms(ctx, fh, 20)
+        print("hadamard + satd %2dx%-2d flavour %d: %7.1f us per frame, %5.2f TB/s" % (nn, nn, fl, ms * 1e3, 2.0 * n * nn * nn / ms / 1e9))
+    except Exception as e:
+        print("hadamard", nn, fl, type(e).__name__, e)
+    ctx.free(dt); ctx.free(dsatd)
